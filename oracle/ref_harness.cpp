@@ -1,0 +1,341 @@
+// oracle/ref_harness.cpp -- TEST INFRASTRUCTURE ONLY. Never linked into, imported by, or called from the product.
+//
+// A thin C ABI (for ctypes) over the REAL reference encoder, compiled from the reference sources where they lie
+// (-I/root/reference, see oracle/Makefile). It lets tests/ drive the reference's own hot-path functions directly and
+// snapshot every intermediate of basisu_frontend so that the HIP path can be diffed stage by stage:
+//   * etc1_optimizer (encoder/basisu_etc.cpp:776-1278) on arbitrary pixel lists
+//   * basisu_frontend stage methods (encoder/basisu_frontend.cpp:733-2715) called one at a time in the same order
+//     as basisu_frontend::compress() (frontend.cpp:159-316), single-threaded job pool (SURVEY hazard H1)
+//   * tree_vector_quant / generate_hierarchical_codebook_threaded (encoder/basisu_enc.h:1546-2354)
+//   * encode_uastc (encoder/basisu_uastc_enc.cpp:3126)
+// All code in this file is ours; the reference is only #included and linked.
+#include <cstdint>
+#include <cstring>
+#include <cstdio>
+#include <cstdlib>
+#include <cmath>
+#include <string>
+#include <vector>
+#include <map>
+#include <unordered_map>
+#include <unordered_set>
+#include <algorithm>
+#include <functional>
+#include <thread>
+#include <mutex>
+#include <atomic>
+#include <condition_variable>
+#include <random>
+#include <memory>
+#include <limits>
+#include <sstream>
+#include <iostream>
+
+// The frontend keeps all stage state private; the harness needs to read it. Access specifiers do not change layout
+// under the Itanium ABI, and the reference objects themselves are compiled untouched.
+#define private public
+#define protected public
+#include "encoder/basisu_frontend.h"
+#include "encoder/basisu_uastc_enc.h"
+#include "encoder/basisu_comp.h"
+#undef private
+#undef protected
+
+using namespace basisu;
+
+#define REF_API extern "C" __attribute__((visibility("default")))
+
+namespace {
+struct frontend_handle {
+	basisu_frontend fe;
+	job_pool jp;
+	std::vector<pixel_block> blocks;
+	basisu_frontend::params p;
+	frontend_handle() : jp(1) {}
+};
+
+template <typename T>
+uint64_t emit(const std::vector<T>& v, void* buf, uint64_t cap) {
+	const uint64_t need = (uint64_t)v.size() * sizeof(T);
+	if (buf && cap >= need && need) memcpy(buf, v.data(), need);
+	return need;
+}
+
+// CSR serialisation of a vector<uint_vec>: [n, off_0..off_n, idx...] as u32
+std::vector<uint32_t> csr(const basisu::vector<uint_vec>& lists) {
+	std::vector<uint32_t> out;
+	out.push_back((uint32_t)lists.size());
+	uint32_t ofs = 0;
+	for (uint32_t i = 0; i < lists.size(); i++) { out.push_back(ofs); ofs += (uint32_t)lists[i].size(); }
+	out.push_back(ofs);
+	for (uint32_t i = 0; i < lists.size(); i++)
+		for (uint32_t j = 0; j < lists[i].size(); j++) out.push_back(lists[i][j]);
+	return out;
+}
+
+basis_etc_quality level_to_block_quality(int level) {
+	// frontend.cpp:783-788 (level 0 fast, 1 medium, 6 uber, else the basis_etc1_pack_params default = slow)
+	if (level == 0) return cETCQualityFast;
+	if (level == 1) return cETCQualityMedium;
+	if (level == (int)BASISU_MAX_ETC1S_COMPRESSION_LEVEL) return cETCQualityUber;
+	return cETCQualitySlow;
+}
+} // namespace
+
+REF_API int ref_init(void) {
+	return basisu_encoder_init(false, false) ? 1 : 0;
+}
+
+// Runs the reference etc1_optimizer over n RGBA pixels exactly as init_etc1_images / generate_endpoint_codebook do.
+// quality: 0 fast, 1 medium, 2 slow, 3 uber (basis_etc_quality). out_selectors may be NULL.
+REF_API int ref_etc1_optimize(const uint8_t* rgba, uint32_t n, int quality, int perceptual,
+	uint8_t* out_color5, uint32_t* out_inten, uint64_t* out_err, uint8_t* out_selectors) {
+	etc1_optimizer opt;
+	etc1_optimizer::params prm;
+	etc1_optimizer::results res;
+	prm.m_quality = (basis_etc_quality)quality;
+	prm.m_num_src_pixels = n;
+	prm.m_pSrc_pixels = reinterpret_cast<const color_rgba*>(rgba);
+	prm.m_use_color4 = false;
+	prm.m_perceptual = perceptual != 0;
+	std::vector<uint8_t> sels(n ? n : 1);
+	res.m_pSelectors = sels.data();
+	res.m_n = n;
+	opt.init(prm, res);
+	if (!opt.compute()) return 0;
+	out_color5[0] = res.m_block_color_unscaled.r;
+	out_color5[1] = res.m_block_color_unscaled.g;
+	out_color5[2] = res.m_block_color_unscaled.b;
+	*out_inten = res.m_block_inten_table;
+	*out_err = res.m_error;
+	if (out_selectors) memcpy(out_selectors, sels.data(), n);
+	return 1;
+}
+
+// init_etc1_images' CPU branch (frontend.cpp:765-818) over a bare array of pixel blocks.
+REF_API void ref_encode_etc1s_blocks(const uint8_t* pixel_blocks, uint32_t n_blocks, int comp_level, int perceptual, uint8_t* out_blocks) {
+	const pixel_block* src = reinterpret_cast<const pixel_block*>(pixel_blocks);
+	etc_block* dst = reinterpret_cast<etc_block*>(out_blocks);
+	for (uint32_t i = 0; i < n_blocks; i++) {
+		etc1_optimizer opt;
+		etc1_optimizer::params prm;
+		etc1_optimizer::results res;
+		prm.m_quality = level_to_block_quality(comp_level);
+		prm.m_num_src_pixels = 16;
+		prm.m_pSrc_pixels = src[i].get_ptr();
+		prm.m_perceptual = perceptual != 0;
+		uint8_t sels[16];
+		res.m_pSelectors = sels;
+		res.m_n = 16;
+		opt.init(prm, res);
+		if (!opt.compute()) abort();
+		etc_block& blk = dst[i];
+		memset(&blk, 0, sizeof(blk));
+		blk.set_block_color5_etc1s(res.m_block_color_unscaled);
+		blk.set_inten_tables_etc1s(res.m_block_inten_table);
+		blk.set_flip_bit(true);
+		for (uint32_t y = 0; y < 4; y++)
+			for (uint32_t x = 0; x < 4; x++)
+				blk.set_selector(x, y, sels[x + y * 4]);
+	}
+}
+
+// etc_block::determine_selectors (etc.h:374-436) for blocks with given colour5+inten, flip=1, delta3=0.
+REF_API void ref_determine_selectors(const uint8_t* pixel_blocks, uint32_t n_blocks, const uint8_t* color5_inten /*4B each*/, int perceptual, uint8_t* out_blocks) {
+	const pixel_block* src = reinterpret_cast<const pixel_block*>(pixel_blocks);
+	etc_block* dst = reinterpret_cast<etc_block*>(out_blocks);
+	for (uint32_t i = 0; i < n_blocks; i++) {
+		etc_block& blk = dst[i];
+		memset(&blk, 0, sizeof(blk));
+		color_rgba c(color5_inten[i * 4 + 0], color5_inten[i * 4 + 1], color5_inten[i * 4 + 2], 255);
+		blk.set_block_color5(c, c);
+		blk.set_flip_bit(true);
+		blk.set_inten_table(0, color5_inten[i * 4 + 3]);
+		blk.set_inten_table(1, color5_inten[i * 4 + 3]);
+		blk.determine_selectors(src[i].get_ptr(), perceptual != 0);
+	}
+}
+
+REF_API uint32_t ref_color_distance(int perceptual, const uint8_t* a, const uint8_t* b) {
+	return color_distance(perceptual != 0, color_rgba(a[0], a[1], a[2], 255), color_rgba(b[0], b[1], b[2], 255), false);
+}
+
+// ---------------------------------------------------------------- frontend, stage by stage
+
+REF_API void* ref_frontend_create(const uint8_t* pixel_blocks, uint32_t n_blocks, uint32_t max_endpoint_clusters,
+	uint32_t max_selector_clusters, int comp_level, int perceptual) {
+	frontend_handle* h = new frontend_handle();
+	h->blocks.resize(n_blocks);
+	memcpy(h->blocks.data(), pixel_blocks, (size_t)n_blocks * sizeof(pixel_block));
+	basisu_frontend::params& p = h->p;
+	p.m_num_source_blocks = n_blocks;
+	p.m_pSource_blocks = h->blocks.data();
+	p.m_max_endpoint_clusters = max_endpoint_clusters;
+	p.m_max_selector_clusters = max_selector_clusters;
+	p.m_perceptual = perceptual != 0;
+	p.m_compression_level = comp_level;
+	p.m_tex_type = basist::cBASISTexType2D;
+	p.m_multithreaded = false;
+	p.m_validate = false;
+	p.m_pJob_pool = &h->jp;
+	p.m_pGlobal_codebooks = nullptr;
+	p.m_pOpenCL_context = nullptr;
+	if (!h->fe.init(p)) { delete h; return nullptr; }
+	h->fe.m_total_blocks = n_blocks;
+	h->fe.m_total_pixels = n_blocks * 16;
+	return h;
+}
+
+REF_API void ref_frontend_destroy(void* hv) { delete static_cast<frontend_handle*>(hv); }
+
+// Calls one private stage method by name. Returns the method's return value (or 1), -1 if unknown.
+REF_API int64_t ref_frontend_call(void* hv, const char* name, uint32_t arg) {
+	basisu_frontend& fe = static_cast<frontend_handle*>(hv)->fe;
+	const std::string n(name);
+	if (n == "compress") return fe.compress() ? 1 : 0;
+	if (n == "init_etc1_images") { fe.init_etc1_images(); return 1; }
+	if (n == "init_endpoint_training_vectors") { fe.init_endpoint_training_vectors(); return 1; }
+	if (n == "generate_endpoint_clusters") { fe.generate_endpoint_clusters(); return 1; }
+	if (n == "introduce_new_endpoint_clusters") { fe.introduce_new_endpoint_clusters(); return 1; }
+	if (n == "generate_endpoint_codebook") { fe.generate_endpoint_codebook(arg); return 1; }
+	if (n == "refine_endpoint_clusterization") return fe.refine_endpoint_clusterization();
+	if (n == "eliminate_redundant_or_empty_endpoint_clusters") { fe.eliminate_redundant_or_empty_endpoint_clusters(); return 1; }
+	if (n == "generate_block_endpoint_clusters") { fe.generate_block_endpoint_clusters(); return 1; }
+	if (n == "create_initial_packed_texture") { fe.create_initial_packed_texture(); return 1; }
+	if (n == "generate_selector_clusters") { fe.generate_selector_clusters(); return 1; }
+	if (n == "compute_selector_clusters_within_each_parent_cluster") { fe.compute_selector_clusters_within_each_parent_cluster(); return 1; }
+	if (n == "create_optimized_selector_codebook") { fe.create_optimized_selector_codebook(arg); return 1; }
+	if (n == "find_optimal_selector_clusters_for_each_block") { fe.find_optimal_selector_clusters_for_each_block(); return 1; }
+	if (n == "introduce_special_selector_clusters") { fe.introduce_special_selector_clusters(); return 1; }
+	if (n == "refine_block_endpoints_given_selectors") return fe.refine_block_endpoints_given_selectors();
+	if (n == "optimize_selector_codebook") { fe.optimize_selector_codebook(); return 1; }
+	if (n == "finalize") { fe.finalize(); return 1; }
+	if (n == "use_hierarchical_endpoint_codebooks") return fe.m_use_hierarchical_endpoint_codebooks;
+	if (n == "use_hierarchical_selector_codebooks") return fe.m_use_hierarchical_selector_codebooks;
+	if (n == "endpoint_refinement") return fe.m_endpoint_refinement;
+	if (n == "num_endpoint_codebook_iterations") return fe.m_num_endpoint_codebook_iterations;
+	if (n == "num_selector_codebook_iterations") return fe.m_num_selector_codebook_iterations;
+	return -1;
+}
+
+// Serialises one piece of frontend state. Returns the number of bytes required; copies only if cap is large enough.
+REF_API uint64_t ref_frontend_get(void* hv, const char* name, void* buf, uint64_t cap) {
+	basisu_frontend& fe = static_cast<frontend_handle*>(hv)->fe;
+	const std::string n(name);
+	auto raw = [&](const void* p, uint64_t bytes) -> uint64_t {
+		if (buf && cap >= bytes && bytes) memcpy(buf, p, bytes);
+		return bytes;
+	};
+	if (n == "etc1_blocks") return raw(fe.m_etc1_blocks_etc1s.data(), fe.m_etc1_blocks_etc1s.size() * 8ull);
+	if (n == "encoded_blocks") return raw(fe.m_encoded_blocks.data(), fe.m_encoded_blocks.size() * 8ull);
+	if (n == "orig_encoded_blocks") return raw(fe.m_orig_encoded_blocks.data(), fe.m_orig_encoded_blocks.size() * 8ull);
+	if (n == "optimized_cluster_selectors") return raw(fe.m_optimized_cluster_selectors.data(), fe.m_optimized_cluster_selectors.size() * 8ull);
+	if (n == "block_selector_cluster_index") return raw(fe.m_block_selector_cluster_index.data(), fe.m_block_selector_cluster_index.size() * 4ull);
+	if (n == "block_parent_endpoint_cluster") return raw(fe.m_block_parent_endpoint_cluster.data(), fe.m_block_parent_endpoint_cluster.size());
+	if (n == "block_parent_selector_cluster") return raw(fe.m_block_parent_selector_cluster.data(), fe.m_block_parent_selector_cluster.size());
+	if (n == "endpoint_clusters") return emit(csr(fe.m_endpoint_clusters), buf, cap);
+	if (n == "endpoint_parent_clusters") return emit(csr(fe.m_endpoint_parent_clusters), buf, cap);
+	if (n == "endpoint_clusters_within_each_parent_cluster") return emit(csr(fe.m_endpoint_clusters_within_each_parent_cluster), buf, cap);
+	if (n == "selector_cluster_block_indices") return emit(csr(fe.m_selector_cluster_block_indices), buf, cap);
+	if (n == "selector_parent_cluster_block_indices") return emit(csr(fe.m_selector_parent_cluster_block_indices), buf, cap);
+	if (n == "selector_clusters_within_each_parent_cluster") return emit(csr(fe.m_selector_clusters_within_each_parent_cluster), buf, cap);
+	if (n == "block_endpoint_clusters_indices") {
+		std::vector<uint32_t> v(fe.m_block_endpoint_clusters_indices.size());
+		for (size_t i = 0; i < v.size(); i++) v[i] = fe.m_block_endpoint_clusters_indices[(uint32_t)i][0];
+		return emit(v, buf, cap);
+	}
+	if (n == "endpoint_cluster_etc_params") {
+		// per cluster: r, g, b, inten (4 bytes), then a u8 valid flag padded to 8 bytes total, then u64 color_error
+		std::vector<uint8_t> v(fe.m_endpoint_cluster_etc_params.size() * 16);
+		for (size_t i = 0; i < fe.m_endpoint_cluster_etc_params.size(); i++) {
+			const auto& e = fe.m_endpoint_cluster_etc_params[(uint32_t)i];
+			v[i * 16 + 0] = e.m_color_unscaled[0].r;
+			v[i * 16 + 1] = e.m_color_unscaled[0].g;
+			v[i * 16 + 2] = e.m_color_unscaled[0].b;
+			v[i * 16 + 3] = (uint8_t)e.m_inten_table[0];
+			v[i * 16 + 4] = e.m_valid ? 1 : 0;
+			memcpy(&v[i * 16 + 8], &e.m_color_error[0], 8);
+		}
+		return emit(v, buf, cap);
+	}
+	if (n == "endpoint_training_vecs") {
+		// per training vec: 6 floats + u64 weight = 32 bytes
+		const auto& tv = fe.m_endpoint_clusterizer.get_training_vecs();
+		std::vector<uint8_t> v(tv.size() * 32);
+		for (size_t i = 0; i < tv.size(); i++) {
+			memcpy(&v[i * 32], tv[(uint32_t)i].first.get_ptr(), 24);
+			memcpy(&v[i * 32 + 24], &tv[(uint32_t)i].second, 8);
+		}
+		return emit(v, buf, cap);
+	}
+	return ~0ull;
+}
+
+// ---------------------------------------------------------------- TSVQ
+
+// generate_hierarchical_codebook_threaded (enc.h:2218) single-threaded over n weighted vectors of dimension dim (6 or 16).
+// Outputs CSR blobs ([n, offsets(n+1), indices]) for the codebook and the parent codebook into caller buffers.
+REF_API int ref_tsvq(uint32_t dim, const float* vecs, const uint64_t* weights, uint32_t n, uint32_t max_codebook_size,
+	uint32_t max_parent_codebook_size, int even_odd_pairs_equal,
+	uint32_t* out_codebook, uint64_t cap_codebook_words, uint32_t* out_parent, uint64_t cap_parent_words) {
+	basisu::vector<uint_vec> codebook, parent;
+	job_pool jp(1);
+	bool ok = false;
+	if (dim == 6) {
+		tree_vector_quant<vec<6, float>> q;
+		for (uint32_t i = 0; i < n; i++) { vec<6, float> v; for (uint32_t k = 0; k < 6; k++) v[k] = vecs[i * 6 + k]; q.add_training_vec(v, weights[i]); }
+		ok = generate_hierarchical_codebook_threaded(q, max_codebook_size, max_parent_codebook_size, codebook, parent, 0, &jp, even_odd_pairs_equal != 0);
+	} else if (dim == 16) {
+		tree_vector_quant<vec16F> q;
+		for (uint32_t i = 0; i < n; i++) { vec16F v; for (uint32_t k = 0; k < 16; k++) v[k] = vecs[i * 16 + k]; q.add_training_vec(v, weights[i]); }
+		ok = generate_hierarchical_codebook_threaded(q, max_codebook_size, max_parent_codebook_size, codebook, parent, 0, &jp, even_odd_pairs_equal != 0);
+	}
+	if (!ok) return 0;
+	std::vector<uint32_t> a = csr(codebook), b = csr(parent);
+	if (a.size() > cap_codebook_words || b.size() > cap_parent_words) return -1;
+	memcpy(out_codebook, a.data(), a.size() * 4);
+	memcpy(out_parent, b.data(), b.size() * 4);
+	return 1;
+}
+
+// ---------------------------------------------------------------- UASTC
+
+REF_API void ref_encode_uastc(const uint8_t* pixel_blocks, uint32_t n_blocks, uint32_t flags, uint8_t* out_blocks16) {
+	for (uint32_t i = 0; i < n_blocks; i++) {
+		basist::uastc_block blk;
+		encode_uastc(pixel_blocks + (size_t)i * 64, blk, flags);
+		memcpy(out_blocks16 + (size_t)i * 16, &blk, 16);
+	}
+}
+
+// ---------------------------------------------------------------- whole-encoder anchors (quality -> cluster counts)
+
+// Mirrors nothing: just runs the real basis_compressor on a raw RGBA image and reports the frontend parameters it chose
+// (comp.cpp:3325-3420) plus the .basis bytes, so tests can pin the quality->codebook-size mapping of the host mirror.
+REF_API int ref_compress_etc1s(const uint8_t* rgba, uint32_t w, uint32_t h, int quality, int comp_level, int perceptual,
+	uint32_t* out_max_endpoint_clusters, uint32_t* out_max_selector_clusters, uint8_t* out_file, uint64_t cap, uint64_t* out_size) {
+	job_pool jp(1);
+	basis_compressor_params params;
+	params.m_source_images.resize(1);
+	params.m_source_images[0].init(rgba, w, h, 4);
+	params.m_quality_level = quality;
+	params.m_etc1s_compression_level = comp_level;
+	params.m_perceptual = perceptual != 0;
+	params.m_multithreading = false;
+	params.m_pJob_pool = &jp;
+	params.m_status_output = false;
+	params.m_compute_stats = false;
+	params.m_mip_gen = false;
+	params.m_check_for_alpha = true;
+	params.m_uastc = false;
+	basis_compressor comp;
+	if (!comp.init(params)) return 0;
+	if (comp.process() != basis_compressor::cECSuccess) return 0;
+	const auto& fp = comp.m_frontend.get_params();
+	*out_max_endpoint_clusters = fp.m_max_endpoint_clusters;
+	*out_max_selector_clusters = fp.m_max_selector_clusters;
+	const uint8_vec& f = comp.get_output_basis_file();
+	*out_size = f.size();
+	if (out_file && cap >= f.size()) memcpy(out_file, f.data(), f.size());
+	return 1;
+}

@@ -1,0 +1,192 @@
+"""Shared test plumbing: ctypes bindings for the CPU checkers and the synthetic inputs.
+
+Nothing here touches the product; see basis_universal_amd/ for that. The two checkers are
+  * oracle/liboracle_etc1s.so   -- our plain-C restatement (travels to the GPU box as source + .so)
+  * oracle/_ref/libref_harness.so -- the REAL reference compiled from /root/reference (prebuilt; travels as a binary)
+"""
+import ctypes as C
+import os
+import pathlib
+import subprocess
+
+import numpy as np
+
+ROOT = pathlib.Path(__file__).resolve().parent.parent
+ORACLE_DIR = ROOT / "oracle"
+REF_DIR = pathlib.Path("/root/reference")
+
+u8p = C.POINTER(C.c_uint8)
+u32p = C.POINTER(C.c_uint32)
+u64p = C.POINTER(C.c_uint64)
+f32p = C.POINTER(C.c_float)
+
+
+def ptr(a, t=u8p):
+    return a.ctypes.data_as(t) if a is not None else None
+
+
+# ----------------------------------------------------------------------------- inputs
+
+def synth(w, h, seed):
+    """SURVEY.md §8(d) synthetic RGBA image: smooth sinusoids + 4x4 tile noise N(0,12) + pixel noise N(0,6)."""
+    rng = np.random.default_rng(seed)
+    y, x = np.mgrid[0:h, 0:w].astype(np.float32)
+    img = np.empty((h, w, 3), np.float32)
+    img[..., 0] = 128 + 100 * np.sin(x / 97) * np.cos(y / 131)
+    img[..., 1] = 128 + 90 * np.sin((x + y) / 211)
+    img[..., 2] = 128 + 110 * np.cos(x / 53 + y / 71)
+    tile = rng.normal(0, 12, (h // 4, w // 4, 3)).astype(np.float32)
+    img += np.repeat(np.repeat(tile, 4, axis=0), 4, axis=1)
+    img += rng.normal(0, 6, (h, w, 3)).astype(np.float32)
+    out = np.empty((h, w, 4), np.uint8)
+    out[..., :3] = np.clip(img, 0, 255).astype(np.uint8)
+    out[..., 3] = 255
+    return out
+
+
+def uniform_random(w, h, seed=42):
+    rng = np.random.default_rng(seed)
+    out = rng.integers(0, 256, (h, w, 4), dtype=np.uint8)
+    out[..., 3] = 255
+    return out
+
+
+def to_pixel_blocks(img):
+    """(H, W, 4) u8 -> (n_blocks, 4, 4, 4) u8 in block-raster order, [y][x] inside the block (comp.cpp:3207-3268).
+    Edges are clamped like image::extract_block_clamped."""
+    h, w, _ = img.shape
+    bh, bw = (h + 3) // 4, (w + 3) // 4
+    if (h % 4) or (w % 4):
+        ys = np.minimum(np.arange(bh * 4), h - 1)
+        xs = np.minimum(np.arange(bw * 4), w - 1)
+        img = img[ys][:, xs]
+    blocks = img.reshape(bh, 4, bw, 4, 4).transpose(0, 2, 1, 3, 4)
+    return np.ascontiguousarray(blocks.reshape(bh * bw, 4, 4, 4))
+
+
+def load_png(path):
+    from PIL import Image
+    return np.ascontiguousarray(np.array(Image.open(path).convert("RGBA"), dtype=np.uint8))
+
+
+def csr_from_lists(lists):
+    offs = np.zeros(len(lists) + 1, np.uint32)
+    offs[1:] = np.cumsum([len(l) for l in lists])
+    idx = np.concatenate([np.asarray(l, np.uint32) for l in lists]) if len(lists) and offs[-1] else np.zeros(0, np.uint32)
+    return offs, np.ascontiguousarray(idx, np.uint32)
+
+
+def csr_blob_split(blob):
+    """[n, off_0..off_n, idx...] u32 blob (oracle/ref_harness.cpp csr()) -> (offsets, indices)."""
+    n = int(blob[0])
+    offs = blob[1:n + 2].copy()
+    idx = blob[n + 2:n + 2 + int(offs[-1])].copy()
+    return offs, idx
+
+
+# ----------------------------------------------------------------------------- C oracle
+
+_oracle = None
+
+
+def oracle():
+    global _oracle
+    if _oracle is None:
+        so = ORACLE_DIR / "liboracle_etc1s.so"
+        src = ORACLE_DIR / "etc1s_oracle.c"
+        if not so.exists() or so.stat().st_mtime < src.stat().st_mtime:
+            subprocess.check_call(["make", "-C", str(ORACLE_DIR), "liboracle_etc1s.so"], stdout=subprocess.DEVNULL)
+        L = C.CDLL(str(so))
+        L.orc_color_distance.restype = C.c_uint32
+        L.orc_color_distance.argtypes = [C.c_int, u8p, u8p]
+        L.orc_hash_hsieh3.restype = C.c_uint32
+        L.orc_hash_hsieh3.argtypes = [C.c_uint8] * 3
+        L.orc_etc1_optimize.restype = C.c_int
+        L.orc_etc1_optimize.argtypes = [u8p, C.c_uint32, C.c_int, C.c_int, u8p, u32p, u64p, u8p]
+        L.orc_encode_etc1s_blocks.argtypes = [u8p, C.c_uint32, C.c_int, C.c_int, u8p]
+        L.orc_determine_selectors.argtypes = [u8p, C.c_uint32, u8p, C.c_int, u8p]
+        L.orc_generate_endpoint_codebook.argtypes = [u8p, C.c_uint32, u32p, u32p, C.c_int, C.c_int, C.c_uint32, u8p, u64p, u8p]
+        L.orc_refine_endpoint_clusterization.argtypes = [u8p, C.c_uint32, u32p, u8p, C.c_uint32, C.c_uint32, u32p, u32p, u8p, C.c_int, u32p]
+        L.orc_create_optimized_selector_codebook.argtypes = [u8p, u8p, C.c_uint32, u32p, u32p, C.c_int, u8p]
+        L.orc_find_optimal_selector_clusters.argtypes = [u8p, u8p, C.c_uint32, u8p, C.c_uint32, C.c_uint32, u32p, u32p, u8p, C.c_int, C.c_uint32, u32p]
+        L.orc_endpoint_training_vectors.argtypes = [u8p, C.c_uint32, f32p]
+        L.orc_selector_training_vectors.argtypes = [u8p, C.c_uint32, C.c_int, f32p, u64p]
+        _oracle = L
+    return _oracle
+
+
+def orc_encode_blocks(blocks, level, perceptual=True):
+    n = blocks.shape[0]
+    out = np.zeros((n, 8), np.uint8)
+    oracle().orc_encode_etc1s_blocks(ptr(blocks), n, level, int(perceptual), ptr(out))
+    return out
+
+
+# ----------------------------------------------------------------------------- the real reference
+
+_ref = None
+
+
+def have_ref():
+    return (ORACLE_DIR / "_ref" / "libref_harness.so").exists()
+
+
+def ref():
+    global _ref
+    if _ref is None:
+        L = C.CDLL(str(ORACLE_DIR / "_ref" / "libref_harness.so"))
+        L.ref_init.restype = C.c_int
+        L.ref_etc1_optimize.restype = C.c_int
+        L.ref_etc1_optimize.argtypes = [u8p, C.c_uint32, C.c_int, C.c_int, u8p, u32p, u64p, u8p]
+        L.ref_encode_etc1s_blocks.argtypes = [u8p, C.c_uint32, C.c_int, C.c_int, u8p]
+        L.ref_determine_selectors.argtypes = [u8p, C.c_uint32, u8p, C.c_int, u8p]
+        L.ref_color_distance.restype = C.c_uint32
+        L.ref_color_distance.argtypes = [C.c_int, u8p, u8p]
+        L.ref_frontend_create.restype = C.c_void_p
+        L.ref_frontend_create.argtypes = [u8p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_int]
+        L.ref_frontend_destroy.argtypes = [C.c_void_p]
+        L.ref_frontend_call.restype = C.c_int64
+        L.ref_frontend_call.argtypes = [C.c_void_p, C.c_char_p, C.c_uint32]
+        L.ref_frontend_get.restype = C.c_uint64
+        L.ref_frontend_get.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_uint64]
+        L.ref_tsvq.restype = C.c_int
+        L.ref_tsvq.argtypes = [C.c_uint32, f32p, u64p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, u32p, C.c_uint64, u32p, C.c_uint64]
+        L.ref_encode_uastc.argtypes = [u8p, C.c_uint32, C.c_uint32, u8p]
+        L.ref_compress_etc1s.restype = C.c_int
+        L.ref_compress_etc1s.argtypes = [u8p, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_int, u32p, u32p, u8p, C.c_uint64, u64p]
+        assert L.ref_init() == 1
+        _ref = L
+    return _ref
+
+
+class RefFrontend:
+    """The reference's basisu_frontend, driven one private stage at a time (oracle/ref_harness.cpp)."""
+
+    def __init__(self, blocks, max_ep, max_sel, level, perceptual=True):
+        self.L = ref()
+        self.blocks = np.ascontiguousarray(blocks)
+        self.h = self.L.ref_frontend_create(ptr(self.blocks), self.blocks.shape[0], max_ep, max_sel, level, int(perceptual))
+        assert self.h
+
+    def call(self, name, arg=0):
+        r = self.L.ref_frontend_call(self.h, name.encode(), arg)
+        assert r != -1, name
+        return r
+
+    def get(self, name, dtype=np.uint8):
+        need = self.L.ref_frontend_get(self.h, name.encode(), None, 0)
+        assert need != 2 ** 64 - 1, name
+        buf = np.zeros(need, np.uint8)
+        self.L.ref_frontend_get(self.h, name.encode(), buf.ctypes.data_as(C.c_void_p), need)
+        return buf.view(dtype)
+
+    def get_csr(self, name):
+        return csr_blob_split(self.get(name, np.uint32))
+
+    def close(self):
+        if self.h:
+            self.L.ref_frontend_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
