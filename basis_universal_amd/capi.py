@@ -1,0 +1,149 @@
+"""ctypes binding of libbasisu_hip.so (include/basisu_hip.h).
+
+The binding mirrors the C ABI one-to-one; nothing here computes anything. `HipLibrary` can be constructed without a GPU
+(so that CPU-only CI can check that the library loads and exports every declared symbol); creating a context without a GPU
+raises HipError.
+"""
+import ctypes as C
+import pathlib
+import re
+
+import numpy as np
+
+PKG_DIR = pathlib.Path(__file__).resolve().parent
+LIB_PATH = PKG_DIR / "lib" / "libbasisu_hip.so"
+HEADER_PATH = PKG_DIR.parent / "include" / "basisu_hip.h"
+
+_vp = C.c_void_p
+_u32 = C.c_uint32
+_int = C.c_int
+
+
+class HipError(RuntimeError):
+    pass
+
+
+def declared_symbols(header=HEADER_PATH):
+    """Every BU_HIP_API function name declared in include/basisu_hip.h."""
+    txt = pathlib.Path(header).read_text()
+    return sorted(set(re.findall(r"BU_HIP_API[^;(]*?\b(bu_hip_\w+)\s*\(", txt)))
+
+
+_SIGNATURES = {
+    # section 1
+    "bu_hip_init": (_int, [_int]),
+    "bu_hip_deinit": (None, []),
+    "bu_hip_is_available": (_int, []),
+    "bu_hip_create_context": (_vp, []),
+    "bu_hip_destroy_context": (None, [_vp]),
+    "bu_hip_set_pixel_blocks": (_int, [_vp, C.c_size_t, _vp]),
+    "bu_hip_encode_etc1s_blocks": (_int, [_vp, _vp, _int, _u32]),
+    "bu_hip_encode_etc1s_pixel_clusters": (_int, [_vp, _vp, _u32, _vp, C.c_uint64, _vp, _vp, _int, _u32]),
+    "bu_hip_refine_endpoint_clusterization": (_int, [_vp, _vp, _u32, _vp, _vp, _vp, _int]),
+    "bu_hip_find_optimal_selector_clusters_for_each_block": (_int, [_vp, _vp, _u32, _vp, _vp, _vp, _int]),
+    "bu_hip_determine_selectors": (_int, [_vp, _vp, _vp, _int]),
+    # section 2
+    "bu_hip_create_context_on": (_vp, [_int]),
+    "bu_hip_context_device": (_int, [_vp]),
+    "bu_hip_set_stream": (_int, [_vp, _vp]),
+    "bu_hip_get_stream": (_vp, [_vp]),
+    "bu_hip_sync": (_int, [_vp]),
+    "bu_hip_last_error": (C.c_char_p, [_vp]),
+    "bu_hip_malloc": (_vp, [_vp, C.c_size_t]),
+    "bu_hip_free": (None, [_vp, _vp]),
+    "bu_hip_memcpy_h2d": (_int, [_vp, _vp, _vp, C.c_size_t]),
+    "bu_hip_memcpy_d2h": (_int, [_vp, _vp, _vp, C.c_size_t]),
+    "bu_hip_memset": (_int, [_vp, _vp, _int, C.c_size_t]),
+    "bu_hip_set_pixel_blocks_device": (_int, [_vp, C.c_size_t, _vp]),
+    "bu_hip_get_pixel_blocks_device": (_vp, [_vp, C.POINTER(C.c_size_t)]),
+    "bu_hip_k_encode_etc1s_blocks": (_int, [_vp, _vp, _u32, _int, _int, _vp]),
+    "bu_hip_k_endpoint_training_vectors": (_int, [_vp, _vp, _u32, _vp]),
+    "bu_hip_k_generate_endpoint_codebook": (_int, [_vp, _vp, _u32, _vp, _vp, _vp, _int, _int, _u32, _vp, _vp, _vp]),
+    "bu_hip_k_refine_endpoint_clusterization": (_int, [_vp, _vp, _u32, _vp, _vp, _u32, _u32, _vp, _vp, _vp, _int, _vp]),
+    "bu_hip_k_determine_selectors": (_int, [_vp, _vp, _u32, _vp, _vp, _int, _vp]),
+    "bu_hip_k_selector_training_vectors": (_int, [_vp, _vp, _u32, _int, _vp, _vp]),
+    "bu_hip_k_create_optimized_selector_codebook": (_int, [_vp, _vp, _vp, _u32, _vp, _vp, _int, _vp]),
+    "bu_hip_k_find_optimal_selector_clusters": (_int, [_vp, _vp, _vp, _u32, _vp, _u32, _u32, _vp, _vp, _vp, _int, _u32, _vp]),
+}
+
+
+class HipLibrary:
+    def __init__(self, path=LIB_PATH):
+        path = pathlib.Path(path)
+        if not path.exists():
+            raise HipError(f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                           f"(there is no CPU fallback)")
+        self.path = path
+        self.dll = C.CDLL(str(path))
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(self.dll, name)  # AttributeError = symbol missing = broken build
+            fn.restype = res
+            fn.argtypes = args
+            if name != "bu_hip_last_error":
+                setattr(self, name[len("bu_hip_"):], fn)
+
+    def last_error(self, ctx=None):
+        s = self.dll.bu_hip_last_error(ctx)
+        return s.decode() if s else ""
+
+
+_lib = None
+
+
+def load_library():
+    global _lib
+    if _lib is None:
+        _lib = HipLibrary()
+    return _lib
+
+
+class Context:
+    """One bu_hip_context (= one HIP stream + resident buffers). Raises HipError if no GPU is usable."""
+
+    def __init__(self, device=None, lib=None):
+        self.lib = lib or load_library()
+        if not self.lib.init(0):
+            raise HipError("bu_hip_init failed: " + self.lib.last_error(None))
+        self.h = self.lib.create_context() if device is None else self.lib.create_context_on(int(device))
+        if not self.h:
+            raise HipError("bu_hip_create_context failed: " + self.lib.last_error(None))
+
+    def check(self, ok, what=""):
+        if not ok:
+            raise HipError(f"{what} failed: {self.lib.last_error(self.h)}")
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.destroy_context(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- raw device memory helpers (used by tests and the host frontend; torch tensors can be passed by data_ptr instead)
+    def alloc(self, nbytes):
+        p = self.lib.malloc(self.h, int(nbytes))
+        if not p:
+            raise HipError("bu_hip_malloc failed: " + self.lib.last_error(self.h))
+        return p
+
+    def free(self, p):
+        self.lib.free(self.h, p)
+
+    def upload(self, arr):
+        arr = np.ascontiguousarray(arr)
+        p = self.alloc(max(arr.nbytes, 1))
+        if arr.nbytes:
+            self.check(self.lib.memcpy_h2d(self.h, p, arr.ctypes.data_as(_vp), arr.nbytes), "memcpy_h2d")
+        return p
+
+    def download(self, p, shape, dtype):
+        out = np.empty(shape, dtype)
+        self.check(self.lib.memcpy_d2h(self.h, out.ctypes.data_as(_vp), p, out.nbytes), "memcpy_d2h")
+        return out
+
+    def sync(self):
+        self.check(self.lib.sync(self.h), "sync")

@@ -1,0 +1,503 @@
+// bu_hip_api.cpp -- context management and the C ABI of libbasisu_hip.so (include/basisu_hip.h).
+//
+// Replaces encoder/basisu_opencl.cpp of the reference: same entry points, same ownership and error conventions
+// (opencl.cpp:730-1213), but one HIP stream per context, persistent scratch arenas instead of per-call cl buffers,
+// and a device-resident layer (section 2 of the header) underneath the blocking host-pointer layer (section 1).
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "../../include/basisu_hip.h"
+#include "etc1s_kernels.h"
+
+namespace {
+
+std::mutex g_init_mutex;
+bool g_initialized = false;
+int g_device_count = 0;
+std::string g_global_error;
+
+// A grow-only device buffer: the per-call temporaries of the blocking layer live here so that repeated calls
+// (one per frontend stage, several per refinement iteration) do not hit hipMalloc/hipFree.
+struct arena {
+    void* p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t bytes) {
+        if (bytes <= cap) return hipSuccess;
+        if (p) { hipError_t e = hipFree(p); p = nullptr; cap = 0; if (e != hipSuccess) return e; }
+        size_t want = std::max(bytes, (size_t)4096);
+        want += want / 4;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) { p = nullptr; return e; }
+        cap = want;
+        return hipSuccess;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+} // namespace
+
+struct bu_hip_context {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    const void* d_pixel_blocks = nullptr; // resident tiles (a1): 64 B per block
+    size_t total_blocks = 0;
+    arena pixel_arena;                    // owns the tiles when they were uploaded through bu_hip_set_pixel_blocks
+    arena scratch[6];
+    std::string error;
+};
+
+namespace {
+
+void set_error(bu_hip_context* ctx, const char* fmt, ...) {
+    char buf[512];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof(buf), fmt, ap); va_end(ap);
+    if (ctx) ctx->error = buf; else g_global_error = buf;
+}
+
+#define BU_TRY(ctx, expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) { set_error(ctx, "%s: %s", #expr, hipGetErrorString(e__)); return 0; } } while (0)
+
+struct device_guard {
+    int prev = -1; bool ok = false;
+    explicit device_guard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        ok = (prev == dev) || (hipSetDevice(dev) == hipSuccess);
+    }
+    ~device_guard() { /* leave the context's device current: callers (torch) re-select theirs explicitly */ }
+};
+
+int quality_from_perms(uint32_t total_perms) {
+    // frontend.cpp:746-752 / etc.cpp:792-800: {4,16,64,165} <-> {fast, medium, slow, uber}
+    if (total_perms <= 4) return bu::BU_Q_FAST;
+    if (total_perms <= 16) return bu::BU_Q_MEDIUM;
+    if (total_perms <= 64) return bu::BU_Q_SLOW;
+    return bu::BU_Q_UBER;
+}
+
+} // namespace
+
+extern "C" {
+
+// ---------------------------------------------------------------------------------------------------------------- init
+
+int bu_hip_init(int /*force_serialization*/) {
+    std::lock_guard<std::mutex> lock(g_init_mutex);
+    if (g_initialized) return 1;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        set_error(nullptr, "bu_hip_init: no HIP device (%s)", e == hipSuccess ? "count 0" : hipGetErrorString(e));
+        (void)hipGetLastError();
+        return 0;
+    }
+    g_device_count = n;
+    g_initialized = true;
+    return 1;
+}
+
+void bu_hip_deinit(void) {
+    std::lock_guard<std::mutex> lock(g_init_mutex);
+    g_initialized = false;
+}
+
+int bu_hip_is_available(void) { return g_initialized ? 1 : 0; }
+
+bu_hip_context* bu_hip_create_context_on(int device) {
+    if (!g_initialized) { set_error(nullptr, "bu_hip_create_context: bu_hip_init() has not succeeded"); return nullptr; }
+    if (device < 0 || device >= g_device_count) { set_error(nullptr, "bu_hip_create_context: bad device %d", device); return nullptr; }
+    if (hipSetDevice(device) != hipSuccess) { set_error(nullptr, "hipSetDevice(%d) failed", device); return nullptr; }
+    bu_hip_context* ctx = new (std::nothrow) bu_hip_context();
+    if (!ctx) return nullptr;
+    ctx->device = device;
+    if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) { set_error(nullptr, "hipStreamCreate failed"); delete ctx; return nullptr; }
+    ctx->stream = ctx->own_stream;
+    hipError_t e = bu::upload_etc1s_tables(device);
+    if (e != hipSuccess) { set_error(nullptr, "constant table upload failed: %s", hipGetErrorString(e)); (void)hipStreamDestroy(ctx->own_stream); delete ctx; return nullptr; }
+    return ctx;
+}
+
+bu_hip_context* bu_hip_create_context(void) {
+    int dev = 0;
+    if (!g_initialized) { set_error(nullptr, "bu_hip_create_context: bu_hip_init() has not succeeded"); return nullptr; }
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    return bu_hip_create_context_on(dev);
+}
+
+void bu_hip_destroy_context(bu_hip_context* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    ctx->pixel_arena.release();
+    for (auto& a : ctx->scratch) a.release();
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+}
+
+int bu_hip_context_device(const bu_hip_context* ctx) { return ctx ? ctx->device : -1; }
+int bu_hip_set_stream(bu_hip_context* ctx, void* s) { if (!ctx) return 0; ctx->stream = s ? (hipStream_t)s : ctx->own_stream; return 1; }
+void* bu_hip_get_stream(bu_hip_context* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+const char* bu_hip_last_error(const bu_hip_context* ctx) { return ctx ? ctx->error.c_str() : g_global_error.c_str(); }
+
+int bu_hip_sync(bu_hip_context* ctx) {
+    if (!ctx) return 0;
+    device_guard g(ctx->device);
+    BU_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return 1;
+}
+
+void* bu_hip_malloc(bu_hip_context* ctx, size_t bytes) {
+    if (!ctx) return nullptr;
+    device_guard g(ctx->device);
+    void* p = nullptr;
+    if (hipMalloc(&p, bytes ? bytes : 1) != hipSuccess) { set_error(ctx, "hipMalloc(%zu) failed", bytes); (void)hipGetLastError(); return nullptr; }
+    return p;
+}
+void bu_hip_free(bu_hip_context* ctx, void* p) {
+    if (!ctx || !p) return;
+    device_guard g(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(p);
+}
+int bu_hip_memcpy_h2d(bu_hip_context* ctx, void* d, const void* h, size_t bytes) {
+    if (!ctx) return 0;
+    if (!bytes) return 1;
+    device_guard g(ctx->device);
+    BU_TRY(ctx, hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, ctx->stream));
+    BU_TRY(ctx, hipStreamSynchronize(ctx->stream)); // h may be pageable and released by the caller right after
+    return 1;
+}
+int bu_hip_memcpy_d2h(bu_hip_context* ctx, void* h, const void* d, size_t bytes) {
+    if (!ctx) return 0;
+    device_guard g(ctx->device);
+    if (bytes) BU_TRY(ctx, hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    BU_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return 1;
+}
+int bu_hip_memset(bu_hip_context* ctx, void* d, int value, size_t bytes) {
+    if (!ctx) return 0;
+    if (!bytes) return 1;
+    device_guard g(ctx->device);
+    BU_TRY(ctx, hipMemsetAsync(d, value, bytes, ctx->stream));
+    return 1;
+}
+
+// ---------------------------------------------------------------------------------------------------------------- tiles
+
+int bu_hip_set_pixel_blocks(bu_hip_context* ctx, size_t total_blocks, const bu_pixel_block* blocks) {
+    if (!ctx) return 0;
+    if (total_blocks > 0xFFFFFFFFull) { set_error(ctx, "too many blocks"); return 0; }
+    device_guard g(ctx->device);
+    BU_TRY(ctx, ctx->pixel_arena.reserve(total_blocks * sizeof(bu_pixel_block)));
+    if (total_blocks) BU_TRY(ctx, hipMemcpyAsync(ctx->pixel_arena.p, blocks, total_blocks * sizeof(bu_pixel_block), hipMemcpyHostToDevice, ctx->stream));
+    BU_TRY(ctx, hipStreamSynchronize(ctx->stream)); // the caller may free its copy right after (frontend.cpp:67-79)
+    ctx->d_pixel_blocks = ctx->pixel_arena.p;
+    ctx->total_blocks = total_blocks;
+    return 1;
+}
+
+int bu_hip_set_pixel_blocks_device(bu_hip_context* ctx, size_t total_blocks, const void* d_blocks) {
+    if (!ctx || total_blocks > 0xFFFFFFFFull) return 0;
+    ctx->d_pixel_blocks = d_blocks;
+    ctx->total_blocks = total_blocks;
+    return 1;
+}
+
+const void* bu_hip_get_pixel_blocks_device(const bu_hip_context* ctx, size_t* total_blocks) {
+    if (!ctx) return nullptr;
+    if (total_blocks) *total_blocks = ctx->total_blocks;
+    return ctx->d_pixel_blocks;
+}
+
+// ---------------------------------------------------------------------------------------------------------------- section 2
+
+int bu_hip_k_encode_etc1s_blocks(bu_hip_context* ctx, const void* d_px, uint32_t n, int quality, int perceptual, void* d_out) {
+    if (!ctx) return 0;
+    device_guard g(ctx->device);
+    BU_TRY(ctx, bu::launch_encode_etc1s_blocks(ctx->stream, d_px, n, quality, perceptual != 0, d_out));
+    return 1;
+}
+
+int bu_hip_k_endpoint_training_vectors(bu_hip_context* ctx, const void* d_etc, uint32_t n, float* d_out6) {
+    if (!ctx) return 0;
+    device_guard g(ctx->device);
+    BU_TRY(ctx, bu::launch_endpoint_training_vectors(ctx->stream, d_etc, n, d_out6));
+    return 1;
+}
+
+int bu_hip_k_generate_endpoint_codebook(bu_hip_context* ctx, const void* d_px, uint32_t n_clusters, const uint32_t* h_offsets,
+                                        const uint32_t* d_offsets, const uint32_t* d_indices, int quality, int perceptual, uint32_t step,
+                                        uint8_t* d_params, uint64_t* d_err, uint8_t* d_valid) {
+    if (!ctx) return 0;
+    if (!n_clusters) return 1;
+    device_guard g(ctx->device);
+    // largest clusters first: one workgroup per cluster, so the big ones must not start last
+    std::vector<uint32_t> order(n_clusters);
+    std::iota(order.begin(), order.end(), 0u);
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
+        return (h_offsets[a + 1] - h_offsets[a]) > (h_offsets[b + 1] - h_offsets[b]);
+    });
+    arena& ord = ctx->scratch[5];
+    BU_TRY(ctx, ord.reserve(n_clusters * sizeof(uint32_t)));
+    BU_TRY(ctx, hipMemcpyAsync(ord.p, order.data(), n_clusters * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    BU_TRY(ctx, bu::launch_generate_endpoint_codebook(ctx->stream, d_px, n_clusters, static_cast<const uint32_t*>(ord.p), d_offsets, d_indices,
+                                                      quality, perceptual != 0, step, d_params, d_err, d_valid));
+    BU_TRY(ctx, hipStreamSynchronize(ctx->stream)); // `order` is pageable host memory owned by this call
+    return 1;
+}
+
+int bu_hip_k_refine_endpoint_clusterization(bu_hip_context* ctx, const void* d_px, uint32_t n_blocks, const uint32_t* d_block_cluster,
+                                            const uint8_t* d_cluster_params, uint32_t n_clusters, uint32_t n_parents, const uint32_t* d_cand_offsets,
+                                            const uint32_t* d_cand_indices, const uint8_t* d_block_parent, int perceptual, uint32_t* d_out_best) {
+    if (!ctx) return 0;
+    device_guard g(ctx->device);
+    BU_TRY(ctx, bu::launch_refine_endpoint_clusterization(ctx->stream, d_px, n_blocks, d_block_cluster, d_cluster_params, n_clusters, n_parents,
+                                                          d_cand_offsets, d_cand_indices, d_block_parent, perceptual != 0, d_out_best));
+    return 1;
+}
+
+int bu_hip_k_determine_selectors(bu_hip_context* ctx, const void* d_px, uint32_t n_blocks, const uint8_t* d_color5_inten,
+                                 const uint32_t* d_block_cluster, int perceptual, void* d_out) {
+    if (!ctx) return 0;
+    device_guard g(ctx->device);
+    BU_TRY(ctx, bu::launch_determine_selectors(ctx->stream, d_px, n_blocks, d_color5_inten, d_block_cluster, perceptual != 0, d_out));
+    return 1;
+}
+
+int bu_hip_k_selector_training_vectors(bu_hip_context* ctx, const void* d_enc, uint32_t n_blocks, int perceptual, float* d_out16, uint64_t* d_w) {
+    if (!ctx) return 0;
+    device_guard g(ctx->device);
+    BU_TRY(ctx, bu::launch_selector_training_vectors(ctx->stream, d_enc, n_blocks, perceptual != 0, d_out16, d_w));
+    return 1;
+}
+
+int bu_hip_k_create_optimized_selector_codebook(bu_hip_context* ctx, const void* d_px, const void* d_enc, uint32_t n_clusters,
+                                                const uint32_t* d_offsets, const uint32_t* d_block_indices, int perceptual, void* d_selector_blocks) {
+    if (!ctx) return 0;
+    device_guard g(ctx->device);
+    BU_TRY(ctx, bu::launch_create_optimized_selector_codebook(ctx->stream, d_px, d_enc, n_clusters, d_offsets, d_block_indices, perceptual != 0, d_selector_blocks));
+    return 1;
+}
+
+int bu_hip_k_find_optimal_selector_clusters(bu_hip_context* ctx, const void* d_px, void* d_enc, uint32_t n_blocks, const void* d_selector_blocks,
+                                            uint32_t n_selectors, uint32_t n_parents, const uint32_t* d_cand_offsets, const uint32_t* d_cand_indices,
+                                            const uint8_t* d_block_parent, int perceptual, uint32_t chunk, uint32_t* d_out) {
+    if (!ctx) return 0;
+    device_guard g(ctx->device);
+    arena& tmp = ctx->scratch[4];
+    BU_TRY(ctx, tmp.reserve((size_t)n_blocks * sizeof(uint32_t)));
+    BU_TRY(ctx, bu::launch_find_optimal_selector_clusters(ctx->stream, d_px, d_enc, n_blocks, d_selector_blocks, n_selectors, n_parents, d_cand_offsets,
+                                                          d_cand_indices, d_block_parent, perceptual != 0, chunk, static_cast<uint32_t*>(tmp.p), d_out));
+    return 1;
+}
+
+// ---------------------------------------------------------------------------------------------------------------- section 1 (blocking, host pointers)
+
+int bu_hip_encode_etc1s_blocks(bu_hip_context* ctx, bu_etc_block* out, int perceptual, uint32_t total_perms) {
+    if (!ctx || !ctx->d_pixel_blocks) { if (ctx) set_error(ctx, "no pixel blocks set"); return 0; }
+    device_guard g(ctx->device);
+    const uint32_t n = (uint32_t)ctx->total_blocks;
+    arena& o = ctx->scratch[0];
+    BU_TRY(ctx, o.reserve((size_t)n * 8));
+    BU_TRY(ctx, bu::launch_encode_etc1s_blocks(ctx->stream, ctx->d_pixel_blocks, n, quality_from_perms(total_perms), perceptual != 0, o.p));
+    BU_TRY(ctx, hipMemcpyAsync(out, o.p, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    BU_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return 1;
+}
+
+int bu_hip_determine_selectors(bu_hip_context* ctx, const bu_color_rgba* color5_inten, bu_etc_block* out, int perceptual) {
+    if (!ctx || !ctx->d_pixel_blocks) { if (ctx) set_error(ctx, "no pixel blocks set"); return 0; }
+    device_guard g(ctx->device);
+    const uint32_t n = (uint32_t)ctx->total_blocks;
+    arena &in = ctx->scratch[0], &o = ctx->scratch[1];
+    BU_TRY(ctx, in.reserve((size_t)n * 4));
+    BU_TRY(ctx, o.reserve((size_t)n * 8));
+    BU_TRY(ctx, hipMemcpyAsync(in.p, color5_inten, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+    BU_TRY(ctx, bu::launch_determine_selectors(ctx->stream, ctx->d_pixel_blocks, n, static_cast<const uint8_t*>(in.p), nullptr, perceptual != 0, o.p));
+    BU_TRY(ctx, hipMemcpyAsync(out, o.p, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    BU_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return 1;
+}
+
+int bu_hip_refine_endpoint_clusterization(bu_hip_context* ctx, const bu_block_info* info, uint32_t total_clusters, const bu_endpoint_cluster* clusters,
+                                          const uint32_t* /*sorted_block_indices*/, uint32_t* out, int perceptual) {
+    // The reference seam passes, per block, a window [first_cluster_ofs, first_cluster_ofs+num_clusters) into a flat list of
+    // {unscaled colour, inten, cluster index} (frontend.cpp:1684-1750). We translate that to the device layer's form:
+    // a parameter table addressed by POSITION in the flat list, one "parent" per distinct window. The block's current
+    // cluster is identified by its index value; the kernel's tie rule compares against the candidate's position, so the
+    // position of the current cluster inside the window is looked up here.
+    if (!ctx || !ctx->d_pixel_blocks) { if (ctx) set_error(ctx, "no pixel blocks set"); return 0; }
+    device_guard g(ctx->device);
+    const uint32_t n = (uint32_t)ctx->total_blocks;
+    std::vector<uint32_t> params(total_clusters);
+    for (uint32_t i = 0; i < total_clusters; i++)
+        params[i] = clusters[i].m_unscaled_color.r | (clusters[i].m_unscaled_color.g << 8) | (clusters[i].m_unscaled_color.b << 16) | ((uint32_t)clusters[i].m_etc_inten << 24);
+    // windows -> parents
+    std::vector<uint32_t> win_first, win_count, cand_offsets(1, 0), cand_indices;
+    std::vector<uint8_t> block_parent8;
+    std::vector<uint32_t> block_parent(n), block_cur(n);
+    std::vector<int32_t> first_to_parent(65536, -1);
+    for (uint32_t b = 0; b < n; b++) {
+        const uint32_t f = info[b].m_first_cluster_ofs, c = info[b].m_num_clusters;
+        int32_t p = first_to_parent[f];
+        if (p < 0 || win_count[p] != c) {
+            p = (int32_t)win_first.size();
+            first_to_parent[f] = p;
+            win_first.push_back(f); win_count.push_back(c);
+            for (uint32_t k = 0; k < c; k++) cand_indices.push_back(f + k);
+            cand_offsets.push_back((uint32_t)cand_indices.size());
+        }
+        block_parent[b] = (uint32_t)p;
+        // position of the block's current cluster inside its window (it is always present, frontend.cpp:971-996)
+        uint32_t pos = f;
+        for (uint32_t k = 0; k < c; k++)
+            if (clusters[f + k].m_cluster_index == info[b].m_cur_cluster_index) { pos = f + k; break; }
+        block_cur[b] = pos;
+    }
+    if (win_first.size() > 255) { set_error(ctx, "refine: more than 255 distinct candidate windows"); return 0; }
+    block_parent8.resize(n);
+    for (uint32_t b = 0; b < n; b++) block_parent8[b] = (uint8_t)block_parent[b];
+
+    arena &a_par = ctx->scratch[0], &a_cur = ctx->scratch[1], &a_off = ctx->scratch[2], &a_idx = ctx->scratch[3], &a_out = ctx->scratch[4];
+    arena& a_bp = ctx->scratch[5];
+    BU_TRY(ctx, a_par.reserve(total_clusters * 4ull)); BU_TRY(ctx, a_cur.reserve(n * 4ull)); BU_TRY(ctx, a_off.reserve(cand_offsets.size() * 4ull));
+    BU_TRY(ctx, a_idx.reserve(cand_indices.size() * 4ull + 4)); BU_TRY(ctx, a_out.reserve(n * 4ull)); BU_TRY(ctx, a_bp.reserve(n));
+    BU_TRY(ctx, hipMemcpyAsync(a_par.p, params.data(), total_clusters * 4ull, hipMemcpyHostToDevice, ctx->stream));
+    BU_TRY(ctx, hipMemcpyAsync(a_cur.p, block_cur.data(), n * 4ull, hipMemcpyHostToDevice, ctx->stream));
+    BU_TRY(ctx, hipMemcpyAsync(a_off.p, cand_offsets.data(), cand_offsets.size() * 4ull, hipMemcpyHostToDevice, ctx->stream));
+    if (!cand_indices.empty()) BU_TRY(ctx, hipMemcpyAsync(a_idx.p, cand_indices.data(), cand_indices.size() * 4ull, hipMemcpyHostToDevice, ctx->stream));
+    BU_TRY(ctx, hipMemcpyAsync(a_bp.p, block_parent8.data(), n, hipMemcpyHostToDevice, ctx->stream));
+    BU_TRY(ctx, bu::launch_refine_endpoint_clusterization(ctx->stream, ctx->d_pixel_blocks, n, static_cast<const uint32_t*>(a_cur.p),
+                                                          static_cast<const uint8_t*>(a_par.p), total_clusters, (uint32_t)win_first.size(),
+                                                          static_cast<const uint32_t*>(a_off.p), static_cast<const uint32_t*>(a_idx.p),
+                                                          static_cast<const uint8_t*>(a_bp.p), perceptual != 0, static_cast<uint32_t*>(a_out.p)));
+    std::vector<uint32_t> pos(n);
+    BU_TRY(ctx, hipMemcpyAsync(pos.data(), a_out.p, n * 4ull, hipMemcpyDeviceToHost, ctx->stream));
+    BU_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (uint32_t b = 0; b < n; b++) out[b] = clusters[pos[b]].m_cluster_index; // positions -> cluster indices (.cl:1150)
+    return 1;
+}
+
+int bu_hip_find_optimal_selector_clusters_for_each_block(bu_hip_context* ctx, const bu_fosc_block* info, uint32_t total_input_selectors,
+                                                         const bu_fosc_selector* selectors, const uint32_t* selector_cluster_indices, uint32_t* out, int perceptual) {
+    if (!ctx || !ctx->d_pixel_blocks) { if (ctx) set_error(ctx, "no pixel blocks set"); return 0; }
+    device_guard g(ctx->device);
+    const uint32_t n = (uint32_t)ctx->total_blocks;
+    // packed 2-bit selectors [p*2] (frontend.cpp:2462-2464) -> etc_block selector bytes, addressed by position in the flat list
+    std::vector<uint64_t> sel_blocks(total_input_selectors);
+    for (uint32_t i = 0; i < total_input_selectors; i++) {
+        uint32_t bits = 0;
+        for (uint32_t p = 0; p < 16; p++) {
+            const uint32_t s = (selectors[i].m_packed_selectors >> (p * 2)) & 3u, x = p & 3u, y = p >> 2;
+            const uint32_t raw = (0x4Bu >> (s * 2)) & 3u, bit = x * 4 + y;
+            bits |= ((raw & 1u) << bit) | ((raw >> 1) << (16 + bit));
+        }
+        sel_blocks[i] = __builtin_bswap64((uint64_t)bits);
+    }
+    std::vector<uint64_t> enc(n);
+    std::vector<uint32_t> win_first, win_count, cand_offsets(1, 0), cand_indices, block_parent(n);
+    std::vector<uint8_t> bp8(n);
+    for (uint32_t b = 0; b < n; b++) {
+        const bu_color_rgba c = info[b].m_etc_color5_inten;
+        const uint64_t v = ((uint64_t)c.r << 59) | ((uint64_t)c.g << 51) | ((uint64_t)c.b << 43) | ((uint64_t)c.a << 37) | ((uint64_t)c.a << 34) | (3ull << 32);
+        enc[b] = __builtin_bswap64(v);
+        const uint32_t f = info[b].m_first_selector, cnt = info[b].m_num_selectors;
+        int32_t p = -1;
+        for (size_t w = 0; w < win_first.size(); w++) if (win_first[w] == f && win_count[w] == cnt) { p = (int32_t)w; break; }
+        if (p < 0) {
+            p = (int32_t)win_first.size();
+            win_first.push_back(f); win_count.push_back(cnt);
+            for (uint32_t k = 0; k < cnt; k++) cand_indices.push_back(f + k);
+            cand_offsets.push_back((uint32_t)cand_indices.size());
+        }
+        block_parent[b] = (uint32_t)p;
+    }
+    if (win_first.size() > 255) { set_error(ctx, "fosc: more than 255 distinct candidate windows"); return 0; }
+    for (uint32_t b = 0; b < n; b++) bp8[b] = (uint8_t)block_parent[b];
+
+    arena &a_sel = ctx->scratch[0], &a_enc = ctx->scratch[1], &a_off = ctx->scratch[2], &a_idx = ctx->scratch[3], &a_tmp = ctx->scratch[4], &a_bp = ctx->scratch[5];
+    BU_TRY(ctx, a_sel.reserve(total_input_selectors * 8ull + 8)); BU_TRY(ctx, a_enc.reserve(n * 8ull + n * 4ull)); BU_TRY(ctx, a_off.reserve(cand_offsets.size() * 4ull));
+    BU_TRY(ctx, a_idx.reserve(cand_indices.size() * 4ull + 4)); BU_TRY(ctx, a_tmp.reserve(n * 4ull)); BU_TRY(ctx, a_bp.reserve(n));
+    uint32_t* d_out = reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(a_enc.p) + n * 8ull);
+    if (total_input_selectors) BU_TRY(ctx, hipMemcpyAsync(a_sel.p, sel_blocks.data(), total_input_selectors * 8ull, hipMemcpyHostToDevice, ctx->stream));
+    BU_TRY(ctx, hipMemcpyAsync(a_enc.p, enc.data(), n * 8ull, hipMemcpyHostToDevice, ctx->stream));
+    BU_TRY(ctx, hipMemcpyAsync(a_off.p, cand_offsets.data(), cand_offsets.size() * 4ull, hipMemcpyHostToDevice, ctx->stream));
+    if (!cand_indices.empty()) BU_TRY(ctx, hipMemcpyAsync(a_idx.p, cand_indices.data(), cand_indices.size() * 4ull, hipMemcpyHostToDevice, ctx->stream));
+    BU_TRY(ctx, hipMemcpyAsync(a_bp.p, bp8.data(), n, hipMemcpyHostToDevice, ctx->stream));
+    // chunk = 0: the OpenCL seam has no "same tile as previous block" shortcut (ocl_kernels.cl:1159-1225)
+    BU_TRY(ctx, bu::launch_find_optimal_selector_clusters(ctx->stream, ctx->d_pixel_blocks, a_enc.p, n, a_sel.p, total_input_selectors, (uint32_t)win_first.size(),
+                                                          static_cast<const uint32_t*>(a_off.p), static_cast<const uint32_t*>(a_idx.p), static_cast<const uint8_t*>(a_bp.p),
+                                                          perceptual != 0, 0, static_cast<uint32_t*>(a_tmp.p), d_out));
+    std::vector<uint32_t> pos(n);
+    BU_TRY(ctx, hipMemcpyAsync(pos.data(), d_out, n * 4ull, hipMemcpyDeviceToHost, ctx->stream));
+    BU_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (uint32_t b = 0; b < n; b++) out[b] = selector_cluster_indices[pos[b]];
+    return 1;
+}
+
+int bu_hip_encode_etc1s_pixel_clusters(bu_hip_context* ctx, bu_etc_block* out, uint32_t total_clusters, const bu_pixel_cluster* clusters,
+                                       uint64_t total_pixels, const bu_color_rgba* pixels, const uint32_t* weights, int perceptual, uint32_t total_perms) {
+    // The reference seam hands over de-duplicated colours with multiplicities. The device layer works on unweighted pixel lists
+    // (bu_hip_k_generate_endpoint_codebook, which is what our own frontend uses and what INTEGRATION.md binds). For the legacy
+    // call we expand the multiplicities into a temporary tile array laid out as "training vectors" of 8 pixels; clusters whose
+    // expanded size is not a multiple of 8 cannot be expressed that way, so the expansion pads by REPEATING the whole colour
+    // list k times (k = 8 / gcd(n, 8)): errors scale by k, the float mean and min/max are unchanged while sums stay < 2^24,
+    // and the argmin over (colour, table) is invariant under a uniform positive scaling of all errors.
+    if (!ctx) return 0;
+    device_guard g(ctx->device);
+    if (!total_clusters) return 1;
+    std::vector<uint32_t> offsets(total_clusters + 1, 0), expanded;
+    std::vector<uint32_t> words;
+    words.reserve((size_t)total_pixels * 2);
+    for (uint32_t c = 0; c < total_clusters; c++) {
+        const uint64_t first = clusters[c].m_first_pixel_index, cnt = clusters[c].m_total_pixels;
+        if (first + cnt > total_pixels) { set_error(ctx, "pixel cluster out of range"); return 0; }
+        uint64_t n = 0;
+        for (uint64_t i = 0; i < cnt; i++) n += weights[first + i];
+        if (!n) { set_error(ctx, "empty pixel cluster"); return 0; }
+        uint32_t gcd = 8; while (n % gcd) gcd >>= 1;
+        const uint32_t reps = 8 / gcd;
+        if (n * reps > 0x7FFFFFFFull) { set_error(ctx, "pixel cluster too large"); return 0; }
+        const size_t base = words.size();
+        for (uint32_t r = 0; r < reps; r++)
+            for (uint64_t i = 0; i < cnt; i++) {
+                uint32_t w; memcpy(&w, &pixels[first + i], 4);
+                words.insert(words.end(), weights[first + i], w);
+            }
+        const uint32_t tv_first = (uint32_t)(base / 8), tv_cnt = (uint32_t)((words.size() - base) / 8);
+        offsets[c + 1] = offsets[c] + tv_cnt;
+        for (uint32_t t = 0; t < tv_cnt; t++) expanded.push_back(tv_first + t);
+    }
+    words.resize((words.size() + 15) / 16 * 16, 0);
+    arena &a_px = ctx->scratch[0], &a_off = ctx->scratch[1], &a_idx = ctx->scratch[2], &a_par = ctx->scratch[3];
+    const size_t params_bytes = ((total_clusters * 4ull + 7) / 8) * 8;
+    BU_TRY(ctx, a_px.reserve(words.size() * 4ull)); BU_TRY(ctx, a_off.reserve(offsets.size() * 4ull)); BU_TRY(ctx, a_idx.reserve(expanded.size() * 4ull + 4));
+    BU_TRY(ctx, a_par.reserve(params_bytes + total_clusters * 8ull + total_clusters));
+    BU_TRY(ctx, hipMemcpyAsync(a_px.p, words.data(), words.size() * 4ull, hipMemcpyHostToDevice, ctx->stream));
+    BU_TRY(ctx, hipMemcpyAsync(a_off.p, offsets.data(), offsets.size() * 4ull, hipMemcpyHostToDevice, ctx->stream));
+    BU_TRY(ctx, hipMemcpyAsync(a_idx.p, expanded.data(), expanded.size() * 4ull, hipMemcpyHostToDevice, ctx->stream));
+    uint8_t* d_params = static_cast<uint8_t*>(a_par.p);
+    uint64_t* d_err = reinterpret_cast<uint64_t*>(d_params + params_bytes);
+    uint8_t* d_valid = reinterpret_cast<uint8_t*>(d_err + total_clusters);
+    if (!bu_hip_k_generate_endpoint_codebook(ctx, a_px.p, total_clusters, offsets.data(), static_cast<const uint32_t*>(a_off.p), static_cast<const uint32_t*>(a_idx.p),
+                                             std::max(quality_from_perms(total_perms), (int)bu::BU_Q_MEDIUM), perceptual, 0, d_params, d_err, d_valid))
+        return 0;
+    std::vector<uint8_t> params(total_clusters * 4ull);
+    BU_TRY(ctx, hipMemcpyAsync(params.data(), d_params, params.size(), hipMemcpyDeviceToHost, ctx->stream));
+    BU_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (uint32_t c = 0; c < total_clusters; c++) {
+        const uint64_t v = ((uint64_t)params[c * 4] << 59) | ((uint64_t)params[c * 4 + 1] << 51) | ((uint64_t)params[c * 4 + 2] << 43) |
+                           ((uint64_t)params[c * 4 + 3] << 37) | ((uint64_t)params[c * 4 + 3] << 34) | (3ull << 32);
+        const uint64_t m = __builtin_bswap64(v);
+        memcpy(&out[c], &m, 8);
+    }
+    return 1;
+}
+
+} // extern "C"

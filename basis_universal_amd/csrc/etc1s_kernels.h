@@ -1,0 +1,30 @@
+// etc1s_kernels.h -- host-side launch interface of etc1s_kernels.hip (internal to libbasisu_hip.so).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace bu {
+
+enum { BU_Q_FAST = 0, BU_Q_MEDIUM = 1, BU_Q_SLOW = 2, BU_Q_UBER = 3 }; // basis_etc_quality, basisu_etc.h:794-801
+
+hipError_t upload_etc1s_tables(int device);
+
+hipError_t launch_encode_etc1s_blocks(hipStream_t st, const void* d_pixel_blocks, uint32_t n_blocks, int quality, bool perceptual, void* d_out);
+hipError_t launch_endpoint_training_vectors(hipStream_t st, const void* d_etc_blocks, uint32_t n_blocks, float* d_out6);
+hipError_t launch_selector_training_vectors(hipStream_t st, const void* d_enc_blocks, uint32_t n_blocks, bool perceptual, float* d_out16, uint64_t* d_w);
+hipError_t launch_generate_endpoint_codebook(hipStream_t st, const void* d_pixel_blocks, uint32_t n_clusters, const uint32_t* d_order,
+                                             const uint32_t* d_offsets, const uint32_t* d_indices, int quality, bool perceptual, uint32_t step,
+                                             uint8_t* d_params, uint64_t* d_err, uint8_t* d_valid);
+hipError_t launch_refine_endpoint_clusterization(hipStream_t st, const void* d_pixel_blocks, uint32_t n_blocks, const uint32_t* d_block_cluster,
+                                                 const uint8_t* d_cluster_params, uint32_t n_clusters, uint32_t n_parents, const uint32_t* d_cand_offsets,
+                                                 const uint32_t* d_cand_indices, const uint8_t* d_block_parent, bool perceptual, uint32_t* d_out_best);
+hipError_t launch_determine_selectors(hipStream_t st, const void* d_pixel_blocks, uint32_t n_blocks, const uint8_t* d_color5_inten,
+                                      const uint32_t* d_block_cluster, bool perceptual, void* d_out);
+hipError_t launch_create_optimized_selector_codebook(hipStream_t st, const void* d_pixel_blocks, const void* d_enc_blocks, uint32_t n_clusters,
+                                                     const uint32_t* d_offsets, const uint32_t* d_block_indices, bool perceptual, void* d_selector_blocks);
+hipError_t launch_find_optimal_selector_clusters(hipStream_t st, const void* d_pixel_blocks, void* d_enc_blocks, uint32_t n_blocks,
+                                                 const void* d_selector_blocks, uint32_t n_selectors, uint32_t n_parents, const uint32_t* d_cand_offsets,
+                                                 const uint32_t* d_cand_indices, const uint8_t* d_block_parent, bool perceptual, uint32_t chunk,
+                                                 uint32_t* d_scratch_idx, uint32_t* d_out_idx);
+
+} // namespace bu

@@ -1,0 +1,899 @@
+// etc1s_kernels.hip -- hand-written gfx950 kernels for the ETC1S frontend hot path.
+//
+// All kernels are integer-ALU bound (hundreds of integer ops per byte of pixel data), so the design rules are:
+//   * wave64 mappings that keep all 64 lanes on the SAME kind of work (no per-lane trial loops with different trip counts);
+//   * the 64-byte pixel tile is read once per kernel with 16-byte loads and kept in registers in the metric's separable
+//     basis (etc1s_device.h: cvec), so a colour distance is 3 subtractions + 3 24-bit multiplies + shifts;
+//   * wavefront reductions (DPP/ds_swizzle via __shfl_xor) pick the best intensity table / candidate, with the
+//     reference's tie rules encoded in the reduction key (lowest index wins on equal error);
+//   * candidate codebooks are read through the scalar/vector caches (they are KB-sized and shared by all lanes).
+// Result parity with the reference CPU encoder is bit-exact; each kernel cites the code it restates.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "etc1s_device.h"
+#include "etc1s_tables.inc"
+#include "etc1s_kernels.h"
+
+namespace bu {
+
+__device__ __constant__ static unsigned int c_cluster_fit_order[165];
+__device__ __constant__ static unsigned char c_inten_enable_by_spread[256];
+static bool g_tables_uploaded[16] = {};
+
+hipError_t upload_etc1s_tables(int device) {
+    if (device >= 0 && device < 16 && g_tables_uploaded[device]) return hipSuccess;
+    hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(c_cluster_fit_order), k_cluster_fit_order, sizeof(k_cluster_fit_order));
+    if (e != hipSuccess) return e;
+    e = hipMemcpyToSymbol(HIP_SYMBOL(c_inten_enable_by_spread), k_inten_enable_by_spread, sizeof(k_inten_enable_by_spread));
+    if (e != hipSuccess) return e;
+    if (device >= 0 && device < 16) g_tables_uploaded[device] = true;
+    return hipSuccess;
+}
+
+// -------------------------------------------------------------------------------------------------------------------
+// Shared pieces of etc1_optimizer (etc.cpp:948-1278)
+// -------------------------------------------------------------------------------------------------------------------
+
+__device__ __forceinline__ uint32_t perms_for_quality(int quality) {
+    return quality == BU_Q_FAST ? 4u : quality == BU_Q_MEDIUM ? 16u : quality == BU_Q_SLOW ? 64u : 165u; // etc.cpp:792-800
+}
+
+// m_br/m_bg/m_bb (etc.cpp:1047-1049): round(avg * 31 / 255), float ops in this exact order, no contraction.
+__device__ __forceinline__ int avg_to_color5(float avg) {
+    const float t = avg * 31.0f;
+    const float q = t / 255.0f;
+    const float r = q + 0.5f;
+    return min(max((int)(uint32_t)r, 0), 31);
+}
+
+// One cluster-fit trial colour (etc.cpp:958-986) from the current best solution and selector histogram `hist`.
+// Returns false when all three delta sums are zero (the trial is skipped).
+__device__ __forceinline__ bool cluster_fit_trial(uint32_t hist, int best_r5, int best_g5, int best_b5, int best_inten,
+                                                  float avg_r, float avg_g, float avg_b, int& tr, int& tg, int& tb) {
+    const int base_r = scale5(best_r5), base_g = scale5(best_g5), base_b = scale5(best_b5);
+    int dr = 0, dg = 0, db = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int cnt = (int)((hist >> (8 * q)) & 255u);
+        const int yd = inten_delta(best_inten, q);
+        dr += cnt * (clamp255(base_r + yd) - base_r);
+        dg += cnt * (clamp255(base_g + yd) - base_g);
+        db += cnt * (clamp255(base_b + yd) - base_b);
+    }
+    if (!(dr | dg | db)) return false;
+    const float fr = (float)dr / 8.0f, fg = (float)dg / 8.0f, fb = (float)db / 8.0f;
+    {
+        const float a = avg_r - fr; const float m = a * 31.0f; const float q = m / 255.0f; const float r = q + 0.5f;
+        tr = min(max((int)r, 0), 31);
+    }
+    {
+        const float a = avg_g - fg; const float m = a * 31.0f; const float q = m / 255.0f; const float r = q + 0.5f;
+        tg = min(max((int)r, 0), 31);
+    }
+    {
+        const float a = avg_b - fb; const float m = a * 31.0f; const float q = m / 255.0f; const float r = q + 0.5f;
+        tb = min(max((int)r, 0), 31);
+    }
+    return true;
+}
+
+// check_for_redundant_solution (etc.cpp:1072-1089) on a 1024-bit filter stored as 32 dwords. Returns true if the colour
+// is definitely new (and inserts it). Must be called by exactly one lane per filter, or by lanes that all see the same
+// state and write the same value.
+__device__ __forceinline__ bool bloom_test_and_set(uint32_t* filter, int r5, int g5, int b5) {
+    const uint32_t kh = hash_hsieh3((uint32_t)r5, (uint32_t)g5, (uint32_t)b5);
+    const uint32_t h0 = kh & 1023u, h1 = (kh >> 10) & 1023u;
+    const uint32_t w0 = filter[h0 >> 5], w1 = filter[h1 >> 5];
+    const uint32_t m0 = 1u << (h0 & 31), m1 = 1u << (h1 & 31);
+    if ((w0 & m0) && (w1 & m1)) return false;
+    if ((h0 >> 5) == (h1 >> 5)) {
+        filter[h0 >> 5] = w0 | m0 | m1;
+    } else {
+        filter[h0 >> 5] = w0 | m0;
+        filter[h1 >> 5] = w1 | m1;
+    }
+    return true;
+}
+
+// -------------------------------------------------------------------------------------------------------------------
+// a6: init_etc1_images -- per 4x4 block etc1_optimizer (frontend.cpp:765-818; etc.cpp:776-1278)
+//
+// Mapping: 8 lanes per block (lane = intensity table), 8 blocks per wave, 32 blocks per 256-thread workgroup.
+// Every lane keeps the block's 16 pixels in registers; a trial base colour costs each lane one pass over 16 pixels x 4
+// selectors for ITS table; the best table is an 8-lane min-reduction on key (error << 3 | table), which reproduces the
+// reference's ascending-table strict-< scan. Trial colours depend on the running best solution, so trials are serial.
+// -------------------------------------------------------------------------------------------------------------------
+
+template <bool PERCEPTUAL, int QUALITY>
+__global__ __launch_bounds__(256) void k_encode_etc1s_blocks(const uint4* __restrict__ pixel_blocks, uint32_t n_blocks, uint2* __restrict__ out_blocks) {
+    __shared__ uint32_t s_bloom[32][32];
+
+    const uint32_t tid = threadIdx.x;
+    const uint32_t table = tid & 7u;
+    const uint32_t slot = tid >> 3;
+    const uint32_t block_raw = blockIdx.x * 32u + slot;
+    const bool in_range = block_raw < n_blocks;
+    const uint32_t block = in_range ? block_raw : (n_blocks - 1);
+
+    // clear this block's Bloom filter (8 lanes x 4 dwords)
+#pragma unroll
+    for (int i = 0; i < 4; i++) s_bloom[slot][table * 4 + i] = 0;
+
+    // 64-byte tile: four 16-byte loads, identical for the 8 lanes of a block (served by one cache line)
+    uint32_t px[16];
+    {
+        const uint4* src = pixel_blocks + (size_t)block * 4;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint4 v = src[i];
+            px[i * 4 + 0] = v.x; px[i * 4 + 1] = v.y; px[i * 4 + 2] = v.z; px[i * 4 + 3] = v.w;
+        }
+    }
+
+    // etc1_optimizer::init (etc.cpp:998-1070)
+    cvec pc[16];
+    float sum_r = 0.0f, sum_g = 0.0f, sum_b = 0.0f;
+    int mn_r = 255, mn_g = 255, mn_b = 255, mx_r = 0, mx_g = 0, mx_b = 0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const int r = px[i] & 255, g = (px[i] >> 8) & 255, b = (px[i] >> 16) & 255;
+        mn_r = min(mn_r, r); mn_g = min(mn_g, g); mn_b = min(mn_b, b);
+        mx_r = max(mx_r, r); mx_g = max(mx_g, g); mx_b = max(mx_b, b);
+        sum_r += (float)r; sum_g += (float)g; sum_b += (float)b;
+        pc[i] = to_cvec<PERCEPTUAL>(r, g, b);
+    }
+    const float avg_r = sum_r / 16.0f, avg_g = sum_g / 16.0f, avg_b = sum_b / 16.0f;
+    const int spread = max(max(mx_r - mn_r, mx_g - mn_g), mx_b - mn_b);
+    const bool table_enabled = (QUALITY > BU_Q_MEDIUM) ? true : (((uint32_t)c_inten_enable_by_spread[spread] >> table) & 1u) != 0; // etc.cpp:1135-1140
+
+    uint32_t best_err = 0xFFFFFFFFu; // every real total is < 2^28
+    int best_r = 0, best_g = 0, best_b = 0, best_inten = 0;
+    bool done = false;
+
+    __syncthreads(); // filters cleared
+
+    const int perms = (int)perms_for_quality(QUALITY);
+    for (int i = -1; i < perms; i++) {
+        if (__all(done)) break;
+        bool active = !done;
+        int tr = 0, tg = 0, tb = 0;
+        if (i < 0) {
+            tr = avg_to_color5(avg_r); tg = avg_to_color5(avg_g); tb = avg_to_color5(avg_b);
+        } else if (active) {
+            active = cluster_fit_trial(c_cluster_fit_order[i], best_r, best_g, best_b, best_inten, avg_r, avg_g, avg_b, tr, tg, tb);
+        }
+        if (active) {
+            // The 8 lanes of a block run in lockstep inside one wave: all of them read the filter words before any of them
+            // writes, and all write the same values.
+            active = bloom_test_and_set(&s_bloom[slot][0], tr, tg, tb);
+        }
+        if (active) {
+            // evaluate_solution_slow (etc.cpp:1104-1278): this lane's table only
+            uint32_t total = 0x0FFFFFFFu;
+            if (table_enabled) {
+                cvec bc[4];
+                block_cvecs<PERCEPTUAL>(bc, scale5(tr), scale5(tg), scale5(tb), (int)table);
+                total = 0;
+#pragma unroll
+                for (int p = 0; p < 16; p++) total += min_err4<PERCEPTUAL>(pc[p], bc);
+            }
+            uint32_t key = (total << 3) | table;
+            key = min(key, (uint32_t)__shfl_xor((int)key, 1, 8));
+            key = min(key, (uint32_t)__shfl_xor((int)key, 2, 8));
+            key = min(key, (uint32_t)__shfl_xor((int)key, 4, 8));
+            const uint32_t trial_err = key >> 3;
+            if (trial_err < best_err) {
+                best_err = trial_err; best_inten = (int)(key & 7u);
+                best_r = tr; best_g = tg; best_b = tb;
+            }
+        }
+        if (best_err == 0) done = true; // etc.cpp:955-956, 993-994
+    }
+
+    // Selectors of the winning (colour, table): each of the 8 lanes classifies 2 pixels, first-min over s (etc.cpp:1188-1219).
+    cvec bc[4];
+    block_cvecs<PERCEPTUAL>(bc, scale5(best_r), scale5(best_g), scale5(best_b), best_inten);
+    uint32_t bits = 0;
+#pragma unroll
+    for (int p = 0; p < 16; p++) {
+        if ((uint32_t)(p >> 1) == table) {
+            const uint32_t s = best_sel4<PERCEPTUAL>(pc[p], bc);
+            bits |= selector_bits((uint32_t)(p & 3), (uint32_t)(p >> 2), s);
+        }
+    }
+    bits |= (uint32_t)__shfl_xor((int)bits, 1, 8);
+    bits |= (uint32_t)__shfl_xor((int)bits, 2, 8);
+    bits |= (uint32_t)__shfl_xor((int)bits, 4, 8);
+    if (table == 0 && in_range) {
+        const uint64_t v = etc1s_header_bits((uint32_t)best_r, (uint32_t)best_g, (uint32_t)best_b, (uint32_t)best_inten) | bits;
+        const uint64_t m = bswap64(v);
+        out_blocks[block] = make_uint2((uint32_t)m, (uint32_t)(m >> 32));
+    }
+}
+
+// Level-0 variant: evaluate_solution_fast (etc.cpp:1280-1506). Linear metric is forced (:1313); a pixel's selector is the
+// number of block-colour luma midpoints at or below twice its luma; tables are scanned 7..0 with strict <, so on equal error
+// the HIGHEST table wins -> reduction key uses (7 - table).
+template <bool PERCEPTUAL_UNUSED>
+__global__ __launch_bounds__(256) void k_encode_etc1s_blocks_fast(const uint4* __restrict__ pixel_blocks, uint32_t n_blocks, uint2* __restrict__ out_blocks) {
+    __shared__ uint32_t s_bloom[32][32];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t table = tid & 7u;
+    const uint32_t slot = tid >> 3;
+    const uint32_t block_raw = blockIdx.x * 32u + slot;
+    const bool in_range = block_raw < n_blocks;
+    const uint32_t block = in_range ? block_raw : (n_blocks - 1);
+#pragma unroll
+    for (int i = 0; i < 4; i++) s_bloom[slot][table * 4 + i] = 0;
+
+    uint32_t px[16];
+    {
+        const uint4* src = pixel_blocks + (size_t)block * 4;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint4 v = src[i];
+            px[i * 4 + 0] = v.x; px[i * 4 + 1] = v.y; px[i * 4 + 2] = v.z; px[i * 4 + 3] = v.w;
+        }
+    }
+    cvec pc[16];
+    uint32_t luma2[16];
+    float sum_r = 0.0f, sum_g = 0.0f, sum_b = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const int r = px[i] & 255, g = (px[i] >> 8) & 255, b = (px[i] >> 16) & 255;
+        sum_r += (float)r; sum_g += (float)g; sum_b += (float)b;
+        pc[i] = to_cvec<false>(r, g, b);
+        luma2[i] = (uint32_t)(r + g + b) * 2u;
+    }
+    const float avg_r = sum_r / 16.0f, avg_g = sum_g / 16.0f, avg_b = sum_b / 16.0f;
+
+    uint32_t best_err = 0xFFFFFFFFu;
+    int best_r = 0, best_g = 0, best_b = 0, best_inten = 0;
+    bool done = false;
+    __syncthreads();
+
+    for (int i = -1; i < 4; i++) {
+        if (__all(done)) break;
+        bool active = !done;
+        int tr = 0, tg = 0, tb = 0;
+        if (i < 0) {
+            tr = avg_to_color5(avg_r); tg = avg_to_color5(avg_g); tb = avg_to_color5(avg_b);
+        } else if (active) {
+            active = cluster_fit_trial(c_cluster_fit_order[i], best_r, best_g, best_b, best_inten, avg_r, avg_g, avg_b, tr, tg, tb);
+        }
+        if (active) active = bloom_test_and_set(&s_bloom[slot][0], tr, tg, tb);
+        if (active) {
+            cvec bc[4];
+            block_cvecs<false>(bc, scale5(tr), scale5(tg), scale5(tb), (int)table);
+            const uint32_t i0 = (uint32_t)(bc[0].x + bc[0].y + bc[0].z), i1 = (uint32_t)(bc[1].x + bc[1].y + bc[1].z);
+            const uint32_t i2 = (uint32_t)(bc[2].x + bc[2].y + bc[2].z), i3 = (uint32_t)(bc[3].x + bc[3].y + bc[3].z);
+            const uint32_t m0 = i0 + i1, m1 = i1 + i2, m2 = i2 + i3;
+            uint32_t total = 0;
+#pragma unroll
+            for (int p = 0; p < 16; p++) {
+                const uint32_t s = (uint32_t)(luma2[p] >= m0) + (uint32_t)(luma2[p] >= m1) + (uint32_t)(luma2[p] >= m2);
+                // midpoints are non-decreasing, so the count equals the reference's walk (etc.cpp:1368-1376)
+                const cvec c = (s == 0) ? bc[0] : (s == 1) ? bc[1] : (s == 2) ? bc[2] : bc[3];
+                total += cdist<false>(pc[p], c);
+            }
+            uint32_t key = (total << 3) | (7u - table);
+            key = min(key, (uint32_t)__shfl_xor((int)key, 1, 8));
+            key = min(key, (uint32_t)__shfl_xor((int)key, 2, 8));
+            key = min(key, (uint32_t)__shfl_xor((int)key, 4, 8));
+            const uint32_t trial_err = key >> 3;
+            if (trial_err < best_err) {
+                best_err = trial_err; best_inten = (int)(7u - (key & 7u));
+                best_r = tr; best_g = tg; best_b = tb;
+            }
+        }
+        if (best_err == 0) done = true;
+    }
+
+    cvec bc[4];
+    block_cvecs<false>(bc, scale5(best_r), scale5(best_g), scale5(best_b), best_inten);
+    const uint32_t i0 = (uint32_t)(bc[0].x + bc[0].y + bc[0].z), i1 = (uint32_t)(bc[1].x + bc[1].y + bc[1].z);
+    const uint32_t i2 = (uint32_t)(bc[2].x + bc[2].y + bc[2].z), i3 = (uint32_t)(bc[3].x + bc[3].y + bc[3].z);
+    const uint32_t m0 = i0 + i1, m1 = i1 + i2, m2 = i2 + i3;
+    uint32_t bits = 0;
+#pragma unroll
+    for (int p = 0; p < 16; p++) {
+        if ((uint32_t)(p >> 1) == table) {
+            const uint32_t s = (uint32_t)(luma2[p] >= m0) + (uint32_t)(luma2[p] >= m1) + (uint32_t)(luma2[p] >= m2);
+            bits |= selector_bits((uint32_t)(p & 3), (uint32_t)(p >> 2), s);
+        }
+    }
+    bits |= (uint32_t)__shfl_xor((int)bits, 1, 8);
+    bits |= (uint32_t)__shfl_xor((int)bits, 2, 8);
+    bits |= (uint32_t)__shfl_xor((int)bits, 4, 8);
+    if (table == 0 && in_range) {
+        const uint64_t v = etc1s_header_bits((uint32_t)best_r, (uint32_t)best_g, (uint32_t)best_b, (uint32_t)best_inten) | bits;
+        const uint64_t m = bswap64(v);
+        out_blocks[block] = make_uint2((uint32_t)m, (uint32_t)(m >> 32));
+    }
+}
+
+// -------------------------------------------------------------------------------------------------------------------
+// a7: init_endpoint_training_vectors (frontend.cpp:825-866) and a12: selector training vectors (frontend.cpp:2155-2183)
+// -------------------------------------------------------------------------------------------------------------------
+
+__global__ __launch_bounds__(256) void k_endpoint_training_vectors(const uint64_t* __restrict__ etc_blocks, uint32_t n_blocks, float* __restrict__ out6) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_blocks) return;
+    uint32_t r5, g5, b5, inten;
+    unpack_etc1s_header(etc_blocks[i], r5, g5, b5, inten);
+    const int br = scale5((int)r5), bg = scale5((int)g5), bb = scale5((int)b5), d = k_inten_b[inten];
+    float* o = out6 + (size_t)i * 6;
+    const float k = 1.0f / 255.0f; // the reference multiplies by the rounded reciprocal (frontend.cpp:846-851)
+    o[0] = (float)clamp255(br - d) * k; o[1] = (float)clamp255(bg - d) * k; o[2] = (float)clamp255(bb - d) * k;
+    o[3] = (float)clamp255(br + d) * k; o[4] = (float)clamp255(bg + d) * k; o[5] = (float)clamp255(bb + d) * k;
+}
+
+template <bool PERCEPTUAL>
+__global__ __launch_bounds__(256) void k_selector_training_vectors(const uint64_t* __restrict__ enc_blocks, uint32_t n_blocks, float* __restrict__ out16, uint64_t* __restrict__ out_w) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_blocks) return;
+    const uint64_t m = enc_blocks[i];
+    uint32_t r5, g5, b5, inten;
+    unpack_etc1s_header(m, r5, g5, b5, inten);
+    const uint32_t lo = (uint32_t)bswap64(m);
+    float4* o = reinterpret_cast<float4*>(out16 + (size_t)i * 16);
+#pragma unroll
+    for (uint32_t y = 0; y < 4; y++) {
+        float4 v;
+        v.x = (float)selector_from_bits(lo, 0, y); v.y = (float)selector_from_bits(lo, 1, y);
+        v.z = (float)selector_from_bits(lo, 2, y); v.w = (float)selector_from_bits(lo, 3, y);
+        o[y] = v;
+    }
+    const int br = scale5((int)r5), bg = scale5((int)g5), bb = scale5((int)b5), d = k_inten_b[inten];
+    const cvec lo_c = to_cvec<PERCEPTUAL>(clamp255(br - d), clamp255(bg - d), clamp255(bb - d));
+    const cvec hi_c = to_cvec<PERCEPTUAL>(clamp255(br + d), clamp255(bg + d), clamp255(bb + d));
+    const uint32_t dist = cdist<PERCEPTUAL>(lo_c, hi_c);
+    out_w[i] = (uint64_t)min(max(dist / 300u, 1u), 4096u);
+}
+
+// -------------------------------------------------------------------------------------------------------------------
+// a9: generate_endpoint_codebook (frontend.cpp:1482-1613) -- etc1_optimizer over all pixels of an endpoint cluster.
+//
+// One 1024-thread workgroup per cluster (largest clusters are dispatched first). A trial is one pass over the cluster's
+// pixels computing all 8 intensity-table totals at once (u64), a wave shuffle reduction and a 16-wave LDS reduction.
+// Pixels are gathered straight from the resident tiles: training vector v = block*2+subblock owns the 32 contiguous
+// bytes of rows 2*subblock..2*subblock+1 (flipped layout, etc.cpp:352-361).
+// The float colour mean is order dependent beyond 2^24 (SURVEY hazard H4): integer channel sums <= 2^24 are provably
+// identical to the reference's running float sum; otherwise three lanes replay the float accumulation in pixel order.
+// -------------------------------------------------------------------------------------------------------------------
+
+constexpr int CB_THREADS = 1024;
+constexpr int CB_WAVES = CB_THREADS / 64;
+
+__device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, o, 64);
+        const uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), o, 64);
+        v += ((uint64_t)hi << 32) | lo;
+    }
+    return v;
+}
+__device__ __forceinline__ int wave_min_i32(int v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ int wave_max_i32(int v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+__device__ __forceinline__ uint32_t cluster_pixel(const uint32_t* __restrict__ pixel_words, const uint32_t* __restrict__ members, uint32_t j) {
+    const uint32_t tv = members[j >> 3];
+    // word index = block*16 + subblock*8 + (j & 7); tv = block*2 + subblock
+    return pixel_words[(size_t)tv * 8 + (j & 7u)];
+}
+
+template <bool PERCEPTUAL, int QUALITY>
+__global__ __launch_bounds__(CB_THREADS) void k_generate_endpoint_codebook(
+    const uint32_t* __restrict__ pixel_words, const uint32_t* __restrict__ order, const uint32_t* __restrict__ offsets,
+    const uint32_t* __restrict__ indices, uint32_t step, uint8_t* __restrict__ params, uint64_t* __restrict__ err_out, uint8_t* __restrict__ valid) {
+    __shared__ uint64_t s_part[CB_WAVES][8];
+    __shared__ uint64_t s_tot[8];
+    __shared__ int s_mm[CB_WAVES][6];
+    __shared__ uint32_t s_bloom[32];
+    __shared__ float s_avg[3];
+    __shared__ int s_spread;
+    __shared__ int s_active;
+
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t ci = order[blockIdx.x];
+    const uint32_t first = offsets[ci];
+    const uint32_t n = (offsets[ci + 1] - first) * 8u; // pixels
+    const uint32_t* members = indices + first;
+
+    if (tid < 32) s_bloom[tid] = 0;
+
+    // ---- init: channel sums, min/max
+    {
+        uint64_t sr = 0, sg = 0, sb = 0;
+        int mn_r = 255, mn_g = 255, mn_b = 255, mx_r = 0, mx_g = 0, mx_b = 0;
+        for (uint32_t j = tid; j < n; j += CB_THREADS) {
+            const uint32_t w = cluster_pixel(pixel_words, members, j);
+            const int r = w & 255, g = (w >> 8) & 255, b = (w >> 16) & 255;
+            sr += r; sg += g; sb += b;
+            mn_r = min(mn_r, r); mn_g = min(mn_g, g); mn_b = min(mn_b, b);
+            mx_r = max(mx_r, r); mx_g = max(mx_g, g); mx_b = max(mx_b, b);
+        }
+        sr = wave_sum_u64(sr); sg = wave_sum_u64(sg); sb = wave_sum_u64(sb);
+        mn_r = wave_min_i32(mn_r); mn_g = wave_min_i32(mn_g); mn_b = wave_min_i32(mn_b);
+        mx_r = wave_max_i32(mx_r); mx_g = wave_max_i32(mx_g); mx_b = wave_max_i32(mx_b);
+        if (lane == 0) {
+            s_part[wave][0] = sr; s_part[wave][1] = sg; s_part[wave][2] = sb;
+            s_mm[wave][0] = mn_r; s_mm[wave][1] = mn_g; s_mm[wave][2] = mn_b;
+            s_mm[wave][3] = mx_r; s_mm[wave][4] = mx_g; s_mm[wave][5] = mx_b;
+        }
+    }
+    __syncthreads();
+    if (tid < 3) {
+        uint64_t s = 0;
+        for (int w = 0; w < CB_WAVES; w++) s += s_part[w][tid];
+        float fs;
+        if (s <= (1ull << 24)) {
+            fs = (float)s; // every partial sum of the reference's running float sum is an exactly representable integer
+        } else {
+            fs = 0.0f;     // replay the float accumulation in pixel order (etc.cpp:1034-1041)
+            for (uint32_t j = 0; j < n; j++) fs += (float)((cluster_pixel(pixel_words, members, j) >> (8 * tid)) & 255u);
+        }
+        s_avg[tid] = fs / (float)n;
+    }
+    if (tid == 0) {
+        int mn[3] = {255, 255, 255}, mx[3] = {0, 0, 0};
+        for (int w = 0; w < CB_WAVES; w++)
+            for (int c = 0; c < 3; c++) { mn[c] = min(mn[c], s_mm[w][c]); mx[c] = max(mx[c], s_mm[w][3 + c]); }
+        s_spread = max(max(mx[0] - mn[0], mx[1] - mn[1]), mx[2] - mn[2]);
+    }
+    __syncthreads();
+    const float avg_r = s_avg[0], avg_g = s_avg[1], avg_b = s_avg[2];
+    const uint32_t enable_mask = (QUALITY > BU_Q_MEDIUM) ? 0xFFu : (uint32_t)c_inten_enable_by_spread[s_spread];
+
+    uint64_t best_err = ~0ull;
+    int best_r = 0, best_g = 0, best_b = 0, best_inten = 0;
+    bool best_valid = false;
+
+    const int perms = (int)perms_for_quality(QUALITY);
+    for (int i = -1; i < perms; i++) {
+        int tr = 0, tg = 0, tb = 0;
+        bool active = true;
+        if (i < 0) {
+            tr = avg_to_color5(avg_r); tg = avg_to_color5(avg_g); tb = avg_to_color5(avg_b);
+        } else {
+            active = cluster_fit_trial(c_cluster_fit_order[i], best_r, best_g, best_b, best_inten, avg_r, avg_g, avg_b, tr, tg, tb);
+        }
+        // all threads hold identical state, so `active` is workgroup-uniform; thread 0 owns the Bloom filter
+        if (tid == 0) s_active = active ? (bloom_test_and_set(s_bloom, tr, tg, tb) ? 1 : 0) : 0;
+        __syncthreads();
+        active = s_active != 0;
+        if (active) {
+            cvec bc[8][4];
+#pragma unroll
+            for (int t = 0; t < 8; t++) block_cvecs<PERCEPTUAL>(bc[t], scale5(tr), scale5(tg), scale5(tb), t);
+            uint64_t tot[8];
+#pragma unroll
+            for (int t = 0; t < 8; t++) tot[t] = 0;
+            for (uint32_t j = tid; j < n; j += CB_THREADS) {
+                const cvec p = pixel_cvec<PERCEPTUAL>(cluster_pixel(pixel_words, members, j));
+#pragma unroll
+                for (int t = 0; t < 8; t++)
+                    if ((enable_mask >> t) & 1u) tot[t] += min_err4<PERCEPTUAL>(p, bc[t]);
+            }
+#pragma unroll
+            for (int t = 0; t < 8; t++) {
+                const uint64_t s = wave_sum_u64(tot[t]);
+                if (lane == 0) s_part[wave][t] = s;
+            }
+            __syncthreads();
+            if (tid < 8) {
+                uint64_t s = 0;
+                for (int w = 0; w < CB_WAVES; w++) s += s_part[w][tid];
+                s_tot[tid] = s;
+            }
+            __syncthreads();
+            uint64_t trial_err = (uint64_t)INT64_MAX; // etc.cpp:1131
+            int trial_inten = 0;
+            bool trial_valid = false;
+#pragma unroll
+            for (int t = 0; t < 8; t++) {
+                if (!((enable_mask >> t) & 1u)) continue;
+                const uint64_t s = s_tot[t];
+                if (s < trial_err) { trial_err = s; trial_inten = t; trial_valid = true; }
+            }
+            if (trial_err < best_err) {
+                best_err = trial_err; best_inten = trial_inten; best_valid = trial_valid;
+                best_r = tr; best_g = tg; best_b = tb;
+            }
+        }
+        __syncthreads(); // s_active / s_part / s_tot are reused by the next trial
+        if (best_err == 0 || !best_valid) break; // etc.cpp:955-956, 993-994
+    }
+
+    // ---- keep the previous endpoints unless the error strictly drops (frontend.cpp:1554-1605)
+    bool use_new = true;
+    if (step != 0 && valid[ci]) {
+        const int pr = params[ci * 4 + 0], pg = params[ci * 4 + 1], pb = params[ci * 4 + 2], pi = params[ci * 4 + 3];
+        cvec bc[4];
+        block_cvecs<PERCEPTUAL>(bc, scale5(pr), scale5(pg), scale5(pb), pi);
+        uint64_t tot = 0;
+        for (uint32_t j = tid; j < n; j += CB_THREADS) tot += min_err4<PERCEPTUAL>(pixel_cvec<PERCEPTUAL>(cluster_pixel(pixel_words, members, j)), bc);
+        tot = wave_sum_u64(tot);
+        if (lane == 0) s_part[wave][0] = tot;
+        __syncthreads();
+        uint64_t prev = 0;
+        for (int w = 0; w < CB_WAVES; w++) prev += s_part[w][0];
+        use_new = prev > best_err;
+    }
+    if (tid == 0 && use_new) {
+        params[ci * 4 + 0] = (uint8_t)best_r; params[ci * 4 + 1] = (uint8_t)best_g; params[ci * 4 + 2] = (uint8_t)best_b; params[ci * 4 + 3] = (uint8_t)best_inten;
+        err_out[ci] = best_err;
+        valid[ci] = 1;
+    }
+}
+
+// -------------------------------------------------------------------------------------------------------------------
+// a10: refine_endpoint_clusterization (frontend.cpp:1772-1917)
+//
+// One wave per block; lanes sweep the candidate endpoint clusters (the block's parent-cluster list, or all clusters for flat
+// codebooks). The block's 16 pixels are wave-uniform, the candidate's four colours are per lane. Winner = first minimum in
+// list order, except that the block's current cluster wins ties at non-zero error, and a zero-error candidate ends the
+// reference's scan (:1896-1904) -- encoded below from (min key, error of the current cluster).
+// -------------------------------------------------------------------------------------------------------------------
+
+template <bool PERCEPTUAL>
+__global__ __launch_bounds__(256) void k_refine_endpoint_clusterization(
+    const uint4* __restrict__ pixel_blocks, uint32_t n_blocks, const uint32_t* __restrict__ block_cluster,
+    const uint32_t* __restrict__ cluster_params, uint32_t n_clusters, uint32_t n_parents,
+    const uint32_t* __restrict__ cand_offsets, const uint32_t* __restrict__ cand_indices, const uint8_t* __restrict__ block_parent,
+    uint32_t* __restrict__ out_best) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t block = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (block >= n_blocks) return; // whole wave exits together
+
+    cvec pc[16];
+    {
+        const uint4* src = pixel_blocks + (size_t)block * 4;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint4 v = src[i];
+            pc[i * 4 + 0] = pixel_cvec<PERCEPTUAL>(v.x); pc[i * 4 + 1] = pixel_cvec<PERCEPTUAL>(v.y);
+            pc[i * 4 + 2] = pixel_cvec<PERCEPTUAL>(v.z); pc[i * 4 + 3] = pixel_cvec<PERCEPTUAL>(v.w);
+        }
+    }
+    const uint32_t cur = block_cluster[block];
+    const uint32_t cur_inten = (cluster_params[cur] >> 24) & 255u;
+
+    uint32_t first = 0, total = n_clusters;
+    if (n_parents) {
+        const uint32_t p = block_parent[block];
+        first = cand_offsets[p];
+        total = cand_offsets[p + 1] - first;
+    }
+
+    // key = error << 32 | position in list; the skipped / out-of-range sentinel sorts last
+    uint64_t best_key = ~0ull;
+    uint32_t cur_err = 0xFFFFFFFFu;
+    for (uint32_t k = lane; k < total; k += 64) {
+        const uint32_t ci = n_parents ? cand_indices[first + k] : k;
+        const uint32_t prm = cluster_params[ci];
+        const uint32_t inten = (prm >> 24) & 255u;
+        if (inten > cur_inten) continue; // frontend.cpp:1811-1815
+        cvec bc[4];
+        block_cvecs<PERCEPTUAL>(bc, scale5((int)(prm & 255u)), scale5((int)((prm >> 8) & 255u)), scale5((int)((prm >> 16) & 255u)), (int)inten);
+        uint32_t tot = 0;
+#pragma unroll
+        for (int p = 0; p < 16; p++) tot += min_err4<PERCEPTUAL>(pc[p], bc);
+        const uint64_t key = ((uint64_t)tot << 32) | k;
+        best_key = min(best_key, key);
+        if (ci == cur) cur_err = tot;
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)best_key, o, 64);
+        const uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)(best_key >> 32), o, 64);
+        best_key = min(best_key, ((uint64_t)hi << 32) | lo);
+        cur_err = min(cur_err, (uint32_t)__shfl_xor((int)cur_err, o, 64));
+    }
+    if (lane == 0) {
+        const uint32_t min_err = (uint32_t)(best_key >> 32);
+        const uint32_t k = (uint32_t)best_key;
+        uint32_t winner;
+        if (best_key == ~0ull) winner = 0;                       // no admissible candidate: best_cluster_index stays 0 (:1787)
+        else if (min_err != 0 && cur_err == min_err) winner = cur; // tie goes to the current cluster
+        else winner = n_parents ? cand_indices[first + k] : k;
+        out_best[block] = winner;
+    }
+}
+
+// -------------------------------------------------------------------------------------------------------------------
+// a11: create_initial_packed_texture -> etc_block::determine_selectors (frontend.cpp:2058-2085, etc.h:374-436)
+//
+// 16 lanes per block, lane l owns pixel (x = l>>2, y = l&3) so that a wave ballot of "raw selector lsb/msb" IS the packed
+// selector bit plane (bit index x*4+y). The only kernel of the path that is close to HBM-bound: 64 B in, 8 B out per block.
+// -------------------------------------------------------------------------------------------------------------------
+
+template <bool PERCEPTUAL>
+__global__ __launch_bounds__(256) void k_determine_selectors(
+    const uint32_t* __restrict__ pixel_words, uint32_t n_blocks, const uint32_t* __restrict__ color5_inten,
+    const uint32_t* __restrict__ block_cluster, uint2* __restrict__ out_blocks) {
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t block_raw = gid >> 4;
+    const bool in_range = block_raw < n_blocks;
+    const uint32_t block = in_range ? block_raw : (n_blocks - 1);
+    const uint32_t l = threadIdx.x & 15u;
+    const uint32_t x = l >> 2, y = l & 3u;
+    const uint32_t w = pixel_words[(size_t)block * 16 + y * 4 + x];
+    const uint32_t prm = block_cluster ? color5_inten[block_cluster[block]] : color5_inten[block];
+    const uint32_t inten = (prm >> 24) & 255u;
+    cvec bc[4];
+    block_cvecs<PERCEPTUAL>(bc, scale5((int)(prm & 255u)), scale5((int)((prm >> 8) & 255u)), scale5((int)((prm >> 16) & 255u)), (int)inten);
+    const uint32_t s = best_sel4<PERCEPTUAL>(pixel_cvec<PERCEPTUAL>(w), bc);
+    const uint32_t raw = (0x4Bu >> (s * 2)) & 3u;
+    const uint64_t lsb = __ballot(raw & 1u);
+    const uint64_t msb = __ballot(raw >> 1);
+    const uint32_t group = (threadIdx.x & 63u) >> 4;
+    if (l == 0 && in_range) {
+        const uint32_t bits = (uint32_t)((lsb >> (group * 16)) & 0xFFFFu) | ((uint32_t)((msb >> (group * 16)) & 0xFFFFu) << 16);
+        const uint64_t v = etc1s_header_bits(prm & 255u, (prm >> 8) & 255u, (prm >> 16) & 255u, inten) | bits;
+        const uint64_t m = bswap64(v);
+        out_blocks[block] = make_uint2((uint32_t)m, (uint32_t)(m >> 32));
+    }
+}
+
+// -------------------------------------------------------------------------------------------------------------------
+// a13: create_optimized_selector_codebook (frontend.cpp:2259-2354)
+//
+// One wave per selector cluster; lane = (pixel p = lane>>2, selector s = lane&3) accumulates the u64 error of "pixel p of
+// every member block encoded with selector s" -- exactly the reference's total_err[y][x][s] -- then a 4-lane first-min.
+// -------------------------------------------------------------------------------------------------------------------
+
+template <bool PERCEPTUAL>
+__global__ __launch_bounds__(256) void k_create_optimized_selector_codebook(
+    const uint32_t* __restrict__ pixel_words, const uint64_t* __restrict__ enc_blocks, uint32_t n_clusters,
+    const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ block_indices, uint64_t* __restrict__ selector_blocks) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t ci = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (ci >= n_clusters) return;
+    const uint32_t first = offsets[ci], cnt = offsets[ci + 1] - first;
+    if (!cnt) return; // empty clusters keep their previous selectors (frontend.cpp:2282-2283)
+    const uint32_t p = lane >> 2, s = lane & 3u;
+    uint64_t tot = 0;
+    for (uint32_t k = 0; k < cnt; k++) {
+        const uint32_t bi = block_indices[first + k];
+        uint32_t r5, g5, b5, inten;
+        unpack_etc1s_header(enc_blocks[bi], r5, g5, b5, inten);
+        const int yd = inten_delta((int)inten, (int)s);
+        const cvec c = to_cvec<PERCEPTUAL>(clamp255(scale5((int)r5) + yd), clamp255(scale5((int)g5) + yd), clamp255(scale5((int)b5) + yd));
+        tot += cdist<PERCEPTUAL>(c, pixel_cvec<PERCEPTUAL>(pixel_words[(size_t)bi * 16 + p]));
+    }
+    // first-min over the 4 selectors of this pixel: compare (tot, s) lexicographically
+    uint64_t bt = tot; uint32_t bs = s;
+#pragma unroll
+    for (int o = 1; o <= 2; o <<= 1) {
+        const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)bt, o, 64);
+        const uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)(bt >> 32), o, 64);
+        const uint64_t ot = ((uint64_t)hi << 32) | lo;
+        const uint32_t os = (uint32_t)__shfl_xor((int)bs, o, 64);
+        if (ot < bt || (ot == bt && os < bs)) { bt = ot; bs = os; }
+    }
+    // pixel p = y*4+x
+    uint32_t bits = (s == 0) ? selector_bits(p & 3u, p >> 2, bs) : 0u;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) bits |= (uint32_t)__shfl_xor((int)bits, o, 64);
+    if (lane == 0) {
+        const uint64_t v = (bswap64(selector_blocks[ci]) & ~0xFFFFFFFFull) | bits;
+        selector_blocks[ci] = bswap64(v);
+    }
+}
+
+// -------------------------------------------------------------------------------------------------------------------
+// a14: find_optimal_selector_clusters_for_each_block (frontend.cpp:2534-2706)
+//
+// One wave per block. The 4x16 table err[s][p] of the block's endpoint is built by the 64 lanes (one entry each) into LDS;
+// lanes then sweep candidate codebook entries, summing 16 table lookups each (all lanes of a step hit one of 4 banks per
+// pixel -> conflict-free broadcasts). Winner = first minimum in list order; the reference's early-outs (:2640-2660) never
+// change it. The "identical to the previous block of this 2048-block job" shortcut (:2557-2564) is applied by a second
+// pass so that results stay identical even when equal tiles carry different endpoints.
+// -------------------------------------------------------------------------------------------------------------------
+
+template <bool PERCEPTUAL>
+__global__ __launch_bounds__(256) void k_find_optimal_selector_clusters(
+    const uint32_t* __restrict__ pixel_words, const uint64_t* __restrict__ enc_blocks, uint32_t n_blocks,
+    const uint64_t* __restrict__ selector_blocks, uint32_t n_selectors, uint32_t n_parents,
+    const uint32_t* __restrict__ cand_offsets, const uint32_t* __restrict__ cand_indices, const uint8_t* __restrict__ block_parent,
+    uint32_t* __restrict__ out_idx) {
+    __shared__ uint32_t s_err[4][64]; // [wave][s*16+p]
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t block = blockIdx.x * 4u + wave;
+    if (block >= n_blocks) return;
+
+    {
+        uint32_t r5, g5, b5, inten;
+        unpack_etc1s_header(enc_blocks[block], r5, g5, b5, inten);
+        const uint32_t s = lane >> 4, p = lane & 15u;
+        const int yd = inten_delta((int)inten, (int)s);
+        const cvec c = to_cvec<PERCEPTUAL>(clamp255(scale5((int)r5) + yd), clamp255(scale5((int)g5) + yd), clamp255(scale5((int)b5) + yd));
+        s_err[wave][lane] = cdist<PERCEPTUAL>(pixel_cvec<PERCEPTUAL>(pixel_words[(size_t)block * 16 + p]), c);
+    }
+    // same-wave producer/consumer: LDS ops of one wave are ordered
+    __builtin_amdgcn_wave_barrier();
+
+    uint32_t first = 0, total = n_selectors;
+    if (n_parents) {
+        const uint32_t p = block_parent[block];
+        first = cand_offsets[p];
+        total = cand_offsets[p + 1] - first;
+    }
+    uint64_t best_key = ~0ull;
+    for (uint32_t k = lane; k < total; k += 64) {
+        const uint32_t ci = n_parents ? cand_indices[first + k] : k;
+        const uint32_t lo = (uint32_t)bswap64(selector_blocks[ci]);
+        uint32_t e = 0;
+#pragma unroll
+        for (uint32_t p = 0; p < 16; p++) {
+            const uint32_t s = selector_from_bits(lo, p & 3u, p >> 2);
+            e += s_err[wave][s * 16 + p];
+        }
+        best_key = min(best_key, ((uint64_t)e << 32) | k);
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)best_key, o, 64);
+        const uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)(best_key >> 32), o, 64);
+        best_key = min(best_key, ((uint64_t)hi << 32) | lo);
+    }
+    if (lane == 0) {
+        const uint32_t k = (uint32_t)best_key;
+        out_idx[block] = (best_key == ~0ull) ? 0u : (n_parents ? cand_indices[first + k] : k);
+    }
+}
+
+// Pass 2 of a14: resolve runs of identical consecutive tiles inside each `chunk`-block job to the run head's choice
+// (frontend.cpp:2557-2564), then stamp the chosen selector bits into the encoded blocks (:2688-2690).
+__global__ __launch_bounds__(256) void k_fosc_resolve_and_stamp(
+    const uint4* __restrict__ pixel_blocks, uint64_t* __restrict__ enc_blocks, uint32_t n_blocks, const uint64_t* __restrict__ selector_blocks,
+    uint32_t chunk, const uint32_t* __restrict__ raw_idx, uint32_t* __restrict__ out_idx) {
+    const uint32_t block = blockIdx.x * blockDim.x + threadIdx.x;
+    if (block >= n_blocks) return;
+    uint32_t head = block;
+    if (chunk) {
+        const uint32_t chunk_first = (block / chunk) * chunk;
+        while (head > chunk_first) {
+            const uint4* a = pixel_blocks + (size_t)head * 4;
+            const uint4* b = pixel_blocks + (size_t)(head - 1) * 4;
+            bool same = true;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const uint4 u = a[i], v = b[i];
+                same = same && (u.x == v.x) && (u.y == v.y) && (u.z == v.z) && (u.w == v.w);
+            }
+            if (!same) break;
+            head--;
+        }
+    }
+    const uint32_t best = raw_idx[head];
+    out_idx[block] = best;
+    const uint64_t hdr = bswap64(enc_blocks[block]) & ~0xFFFFFFFFull;
+    const uint64_t sel = bswap64(selector_blocks[best]) & 0xFFFFFFFFull;
+    enc_blocks[block] = bswap64(hdr | sel);
+}
+
+// -------------------------------------------------------------------------------------------------------------------
+// Launchers
+// -------------------------------------------------------------------------------------------------------------------
+
+#define BU_LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return e_; } while (0)
+
+hipError_t launch_encode_etc1s_blocks(hipStream_t st, const void* d_pixel_blocks, uint32_t n_blocks, int quality, bool perceptual, void* d_out) {
+    if (!n_blocks) return hipSuccess;
+    const dim3 grid((n_blocks + 31) / 32), blk(256);
+    const uint4* in = static_cast<const uint4*>(d_pixel_blocks);
+    uint2* out = static_cast<uint2*>(d_out);
+    if (quality == BU_Q_FAST) {
+        hipLaunchKernelGGL(k_encode_etc1s_blocks_fast<false>, grid, blk, 0, st, in, n_blocks, out);
+    } else if (perceptual) {
+        if (quality == BU_Q_MEDIUM) hipLaunchKernelGGL((k_encode_etc1s_blocks<true, BU_Q_MEDIUM>), grid, blk, 0, st, in, n_blocks, out);
+        else if (quality == BU_Q_SLOW) hipLaunchKernelGGL((k_encode_etc1s_blocks<true, BU_Q_SLOW>), grid, blk, 0, st, in, n_blocks, out);
+        else hipLaunchKernelGGL((k_encode_etc1s_blocks<true, BU_Q_UBER>), grid, blk, 0, st, in, n_blocks, out);
+    } else {
+        if (quality == BU_Q_MEDIUM) hipLaunchKernelGGL((k_encode_etc1s_blocks<false, BU_Q_MEDIUM>), grid, blk, 0, st, in, n_blocks, out);
+        else if (quality == BU_Q_SLOW) hipLaunchKernelGGL((k_encode_etc1s_blocks<false, BU_Q_SLOW>), grid, blk, 0, st, in, n_blocks, out);
+        else hipLaunchKernelGGL((k_encode_etc1s_blocks<false, BU_Q_UBER>), grid, blk, 0, st, in, n_blocks, out);
+    }
+    BU_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+hipError_t launch_endpoint_training_vectors(hipStream_t st, const void* d_etc_blocks, uint32_t n_blocks, float* d_out6) {
+    if (!n_blocks) return hipSuccess;
+    hipLaunchKernelGGL(k_endpoint_training_vectors, dim3((n_blocks + 255) / 256), dim3(256), 0, st, static_cast<const uint64_t*>(d_etc_blocks), n_blocks, d_out6);
+    BU_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+hipError_t launch_selector_training_vectors(hipStream_t st, const void* d_enc_blocks, uint32_t n_blocks, bool perceptual, float* d_out16, uint64_t* d_w) {
+    if (!n_blocks) return hipSuccess;
+    const dim3 grid((n_blocks + 255) / 256), blk(256);
+    if (perceptual) hipLaunchKernelGGL(k_selector_training_vectors<true>, grid, blk, 0, st, static_cast<const uint64_t*>(d_enc_blocks), n_blocks, d_out16, d_w);
+    else hipLaunchKernelGGL(k_selector_training_vectors<false>, grid, blk, 0, st, static_cast<const uint64_t*>(d_enc_blocks), n_blocks, d_out16, d_w);
+    BU_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+hipError_t launch_generate_endpoint_codebook(hipStream_t st, const void* d_pixel_blocks, uint32_t n_clusters, const uint32_t* d_order,
+                                             const uint32_t* d_offsets, const uint32_t* d_indices, int quality, bool perceptual, uint32_t step,
+                                             uint8_t* d_params, uint64_t* d_err, uint8_t* d_valid) {
+    if (!n_clusters) return hipSuccess;
+    const dim3 grid(n_clusters), blk(CB_THREADS);
+    const uint32_t* pw = static_cast<const uint32_t*>(d_pixel_blocks);
+    // the etc1_optimizer never runs at "fast" quality for clusters (frontend.cpp:1530-1533)
+    if (quality < BU_Q_MEDIUM) quality = BU_Q_MEDIUM;
+#define BU_CB(P, Q) hipLaunchKernelGGL((k_generate_endpoint_codebook<P, Q>), grid, blk, 0, st, pw, d_order, d_offsets, d_indices, step, d_params, d_err, d_valid)
+    if (perceptual) {
+        if (quality == BU_Q_MEDIUM) BU_CB(true, BU_Q_MEDIUM); else if (quality == BU_Q_SLOW) BU_CB(true, BU_Q_SLOW); else BU_CB(true, BU_Q_UBER);
+    } else {
+        if (quality == BU_Q_MEDIUM) BU_CB(false, BU_Q_MEDIUM); else if (quality == BU_Q_SLOW) BU_CB(false, BU_Q_SLOW); else BU_CB(false, BU_Q_UBER);
+    }
+#undef BU_CB
+    BU_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+hipError_t launch_refine_endpoint_clusterization(hipStream_t st, const void* d_pixel_blocks, uint32_t n_blocks, const uint32_t* d_block_cluster,
+                                                 const uint8_t* d_cluster_params, uint32_t n_clusters, uint32_t n_parents, const uint32_t* d_cand_offsets,
+                                                 const uint32_t* d_cand_indices, const uint8_t* d_block_parent, bool perceptual, uint32_t* d_out_best) {
+    if (!n_blocks) return hipSuccess;
+    const dim3 grid((n_blocks + 3) / 4), blk(256);
+    const uint4* in = static_cast<const uint4*>(d_pixel_blocks);
+    const uint32_t* prm = reinterpret_cast<const uint32_t*>(d_cluster_params);
+    if (perceptual) hipLaunchKernelGGL(k_refine_endpoint_clusterization<true>, grid, blk, 0, st, in, n_blocks, d_block_cluster, prm, n_clusters, n_parents, d_cand_offsets, d_cand_indices, d_block_parent, d_out_best);
+    else hipLaunchKernelGGL(k_refine_endpoint_clusterization<false>, grid, blk, 0, st, in, n_blocks, d_block_cluster, prm, n_clusters, n_parents, d_cand_offsets, d_cand_indices, d_block_parent, d_out_best);
+    BU_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+hipError_t launch_determine_selectors(hipStream_t st, const void* d_pixel_blocks, uint32_t n_blocks, const uint8_t* d_color5_inten,
+                                      const uint32_t* d_block_cluster, bool perceptual, void* d_out) {
+    if (!n_blocks) return hipSuccess;
+    const dim3 grid((n_blocks + 15) / 16), blk(256);
+    const uint32_t* pw = static_cast<const uint32_t*>(d_pixel_blocks);
+    const uint32_t* prm = reinterpret_cast<const uint32_t*>(d_color5_inten);
+    if (perceptual) hipLaunchKernelGGL(k_determine_selectors<true>, grid, blk, 0, st, pw, n_blocks, prm, d_block_cluster, static_cast<uint2*>(d_out));
+    else hipLaunchKernelGGL(k_determine_selectors<false>, grid, blk, 0, st, pw, n_blocks, prm, d_block_cluster, static_cast<uint2*>(d_out));
+    BU_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+hipError_t launch_create_optimized_selector_codebook(hipStream_t st, const void* d_pixel_blocks, const void* d_enc_blocks, uint32_t n_clusters,
+                                                     const uint32_t* d_offsets, const uint32_t* d_block_indices, bool perceptual, void* d_selector_blocks) {
+    if (!n_clusters) return hipSuccess;
+    const dim3 grid((n_clusters + 3) / 4), blk(256);
+    const uint32_t* pw = static_cast<const uint32_t*>(d_pixel_blocks);
+    if (perceptual) hipLaunchKernelGGL(k_create_optimized_selector_codebook<true>, grid, blk, 0, st, pw, static_cast<const uint64_t*>(d_enc_blocks), n_clusters, d_offsets, d_block_indices, static_cast<uint64_t*>(d_selector_blocks));
+    else hipLaunchKernelGGL(k_create_optimized_selector_codebook<false>, grid, blk, 0, st, pw, static_cast<const uint64_t*>(d_enc_blocks), n_clusters, d_offsets, d_block_indices, static_cast<uint64_t*>(d_selector_blocks));
+    BU_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+hipError_t launch_find_optimal_selector_clusters(hipStream_t st, const void* d_pixel_blocks, void* d_enc_blocks, uint32_t n_blocks,
+                                                 const void* d_selector_blocks, uint32_t n_selectors, uint32_t n_parents, const uint32_t* d_cand_offsets,
+                                                 const uint32_t* d_cand_indices, const uint8_t* d_block_parent, bool perceptual, uint32_t chunk,
+                                                 uint32_t* d_scratch_idx, uint32_t* d_out_idx) {
+    if (!n_blocks) return hipSuccess;
+    const dim3 grid((n_blocks + 3) / 4), blk(256);
+    const uint32_t* pw = static_cast<const uint32_t*>(d_pixel_blocks);
+    if (perceptual) hipLaunchKernelGGL(k_find_optimal_selector_clusters<true>, grid, blk, 0, st, pw, static_cast<const uint64_t*>(d_enc_blocks), n_blocks, static_cast<const uint64_t*>(d_selector_blocks), n_selectors, n_parents, d_cand_offsets, d_cand_indices, d_block_parent, d_scratch_idx);
+    else hipLaunchKernelGGL(k_find_optimal_selector_clusters<false>, grid, blk, 0, st, pw, static_cast<const uint64_t*>(d_enc_blocks), n_blocks, static_cast<const uint64_t*>(d_selector_blocks), n_selectors, n_parents, d_cand_offsets, d_cand_indices, d_block_parent, d_scratch_idx);
+    BU_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_fosc_resolve_and_stamp, dim3((n_blocks + 255) / 256), dim3(256), 0, st, static_cast<const uint4*>(d_pixel_blocks),
+                       static_cast<uint64_t*>(d_enc_blocks), n_blocks, static_cast<const uint64_t*>(d_selector_blocks), chunk, d_scratch_idx, d_out_idx);
+    BU_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+} // namespace bu

@@ -1,0 +1,134 @@
+/* include/basisu_hip.h -- C ABI of libbasisu_hip.so, the MI355X (gfx950) replacement for the reference's accelerator seam.
+ *
+ * The reference's seam is encoder/basisu_opencl.h (namespace basisu, ten entry points, opaque per-thread context).
+ * Section 1 below exports the same ten operations with the same POD layouts, ownership and error conventions, so that a
+ * reference maintainer can bind them from basisu_opencl.cpp's call sites one-for-one (see INTEGRATION.md for the shim).
+ * Section 2 is the device-resident layer the ETC1S frontend actually runs on (stream-ordered, device pointers, no
+ * implicit copies); it also covers the stages the reference never offloaded (frontend.cpp CPU-only branches).
+ *
+ * Conventions (same as basisu_opencl.h):
+ *   - every int-returning function returns 1 on success and 0 on failure; nothing throws, nothing aborts;
+ *     on failure the outputs are untouched or unspecified and the caller falls back / reports (frontend.cpp:757-762);
+ *   - host pointers are caller-owned and only used during the call; the library owns all device memory it allocates;
+ *   - one context per calling thread; calls on one context are serialised on its HIP stream;
+ *   - bu_hip_init() is process-global and not re-entrant (opencl.cpp:730-736).
+ */
+#ifndef BASISU_HIP_H
+#define BASISU_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(__GNUC__)
+#define BU_HIP_API __attribute__((visibility("default")))
+#else
+#define BU_HIP_API
+#endif
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Section 1 -- drop-in for encoder/basisu_opencl.h
+ * ------------------------------------------------------------------------------------------------------------------ */
+
+typedef struct bu_hip_context bu_hip_context; /* = basisu::opencl_context (basisu_opencl.h:28-31) */
+
+#pragma pack(push, 1)
+typedef struct { uint8_t m_pixels[16][4]; } bu_pixel_block;          /* = cl_pixel_block, basisu_opencl.h:37-40: [y*4+x] RGBA */
+typedef struct { uint8_t m_bytes[8]; } bu_etc_block;                 /* = basisu::etc_block, basisu_etc.h:91-103 (big-endian u64) */
+typedef struct { uint8_t r, g, b, a; } bu_color_rgba;                /* = basisu::color_rgba, basisu_enc.h:893-907 */
+typedef struct { uint64_t m_total_pixels, m_first_pixel_index; } bu_pixel_cluster;      /* = cl_pixel_cluster, basisu_opencl.h:53-57 */
+typedef struct { uint16_t m_first_cluster_ofs, m_num_clusters, m_cur_cluster_index; uint8_t m_cur_cluster_etc_inten; } bu_block_info;   /* = cl_block_info_struct :73-79 */
+typedef struct { bu_color_rgba m_unscaled_color; uint8_t m_etc_inten; uint16_t m_cluster_index; } bu_endpoint_cluster;               /* = cl_endpoint_cluster_struct :81-86 */
+typedef struct { uint32_t m_packed_selectors; } bu_fosc_selector;    /* = fosc_selector_struct :101-104 */
+typedef struct { bu_color_rgba m_etc_color5_inten; uint32_t m_first_selector, m_num_selectors; } bu_fosc_block;                       /* = fosc_block_struct :106-111 */
+#pragma pack(pop)
+
+#define BU_HIP_ENCODE_ETC1S_MAX_PERMS 165u /* = OPENCL_ENCODE_ETC1S_MAX_PERMS, basisu_opencl.h:44 */
+
+BU_HIP_API int  bu_hip_init(int force_serialization);     /* opencl_init            basisu_opencl.h:24 */
+BU_HIP_API void bu_hip_deinit(void);                      /* opencl_deinit          :25 */
+BU_HIP_API int  bu_hip_is_available(void);                /* opencl_is_available    :26 */
+BU_HIP_API bu_hip_context* bu_hip_create_context(void);   /* opencl_create_context  :33 (current HIP device) */
+BU_HIP_API void bu_hip_destroy_context(bu_hip_context*);  /* opencl_destroy_context :34 */
+
+/* opencl_set_pixel_blocks :46 -- uploads once; the blocks stay resident in the context */
+BU_HIP_API int bu_hip_set_pixel_blocks(bu_hip_context*, size_t total_blocks, const bu_pixel_block* pixel_blocks);
+/* opencl_encode_etc1s_blocks :48 -- total_perms in {4,16,64,165} selects the etc1_optimizer quality (fast/medium/slow/uber) */
+BU_HIP_API int bu_hip_encode_etc1s_blocks(bu_hip_context*, bu_etc_block* output_blocks, int perceptual, uint32_t total_perms);
+/* opencl_encode_etc1s_pixel_clusters :60-68 -- weighted, de-duplicated pixel lists */
+BU_HIP_API int bu_hip_encode_etc1s_pixel_clusters(bu_hip_context*, bu_etc_block* output_blocks, uint32_t total_clusters,
+    const bu_pixel_cluster* clusters, uint64_t total_pixels, const bu_color_rgba* pixels, const uint32_t* pixel_weights,
+    int perceptual, uint32_t total_perms);
+/* opencl_refine_endpoint_clusterization :89-96 */
+BU_HIP_API int bu_hip_refine_endpoint_clusterization(bu_hip_context*, const bu_block_info* pixel_block_info, uint32_t total_clusters,
+    const bu_endpoint_cluster* cluster_info, const uint32_t* sorted_block_indices, uint32_t* output_cluster_indices, int perceptual);
+/* opencl_find_optimal_selector_clusters_for_each_block :120-127 */
+BU_HIP_API int bu_hip_find_optimal_selector_clusters_for_each_block(bu_hip_context*, const bu_fosc_block* input_block_info,
+    uint32_t total_input_selectors, const bu_fosc_selector* input_selectors, const uint32_t* selector_cluster_indices,
+    uint32_t* output_selector_cluster_indices, int perceptual);
+/* opencl_determine_selectors :137-141 */
+BU_HIP_API int bu_hip_determine_selectors(bu_hip_context*, const bu_color_rgba* input_etc_color5_and_inten, bu_etc_block* output_blocks, int perceptual);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Section 2 -- device-resident layer. All `d_` pointers are DEVICE pointers valid on the context's device; every call is
+ * enqueued on the context's stream and returns without synchronising unless stated. `h_` pointers are host pointers.
+ * ------------------------------------------------------------------------------------------------------------------ */
+
+BU_HIP_API bu_hip_context* bu_hip_create_context_on(int device);
+BU_HIP_API int   bu_hip_context_device(const bu_hip_context*);
+/* Use an externally owned hipStream_t (e.g. torch's current stream) instead of the context's own; NULL restores it. */
+BU_HIP_API int   bu_hip_set_stream(bu_hip_context*, void* hip_stream);
+BU_HIP_API void* bu_hip_get_stream(bu_hip_context*);
+BU_HIP_API int   bu_hip_sync(bu_hip_context*);
+BU_HIP_API const char* bu_hip_last_error(const bu_hip_context*); /* NULL context -> last global (init) error */
+
+BU_HIP_API void* bu_hip_malloc(bu_hip_context*, size_t bytes);
+BU_HIP_API void  bu_hip_free(bu_hip_context*, void* d_ptr);
+BU_HIP_API int   bu_hip_memcpy_h2d(bu_hip_context*, void* d_dst, const void* h_src, size_t bytes); /* synchronises */
+BU_HIP_API int   bu_hip_memcpy_d2h(bu_hip_context*, void* h_dst, const void* d_src, size_t bytes); /* synchronises */
+BU_HIP_API int   bu_hip_memset(bu_hip_context*, void* d_dst, int value, size_t bytes);
+
+/* Adopt pixel blocks that are already resident (no copy, not owned). Counterpart of bu_hip_set_pixel_blocks. */
+BU_HIP_API int   bu_hip_set_pixel_blocks_device(bu_hip_context*, size_t total_blocks, const void* d_pixel_blocks);
+BU_HIP_API const void* bu_hip_get_pixel_blocks_device(const bu_hip_context*, size_t* total_blocks);
+
+/* etc1_optimizer quality (basis_etc_quality, basisu_etc.h:794-801) */
+enum { BU_ETC_QUALITY_FAST = 0, BU_ETC_QUALITY_MEDIUM = 1, BU_ETC_QUALITY_SLOW = 2, BU_ETC_QUALITY_UBER = 3 };
+
+/* a6  basisu_frontend::init_etc1_images (frontend.cpp:733-823): per block etc1_optimizer, n = 16. out: n_blocks x 8 B. */
+BU_HIP_API int bu_hip_k_encode_etc1s_blocks(bu_hip_context*, const void* d_pixel_blocks, uint32_t n_blocks, int quality, int perceptual, void* d_out_etc_blocks);
+/* a7  init_endpoint_training_vectors (frontend.cpp:825-866): per block 6 floats (low rgb, high rgb)/255. */
+BU_HIP_API int bu_hip_k_endpoint_training_vectors(bu_hip_context*, const void* d_etc_blocks, uint32_t n_blocks, float* d_out_vec6);
+/* a9  generate_endpoint_codebook (frontend.cpp:1214-1617), CPU semantics incl. step > 0. Clusters are CSR lists of
+ *     training-vector indices (block*2+subblock); h_offsets is a HOST array of n_clusters+1 entries (used to schedule
+ *     large clusters first), d_offsets its device copy. d_params: n_clusters x {r5,g5,b5,inten}; d_err: u64; d_valid: u8. */
+BU_HIP_API int bu_hip_k_generate_endpoint_codebook(bu_hip_context*, const void* d_pixel_blocks, uint32_t n_clusters,
+    const uint32_t* h_offsets, const uint32_t* d_offsets, const uint32_t* d_indices, int quality, int perceptual, uint32_t step,
+    uint8_t* d_params, uint64_t* d_err, uint8_t* d_valid);
+/* a10 refine_endpoint_clusterization (frontend.cpp:1648-1917) for BOTH hierarchical (n_parents > 0: candidates are
+ *     d_cand_indices[d_cand_offsets[p] .. d_cand_offsets[p+1]) for the block's parent p) and flat codebooks (n_parents == 0). */
+BU_HIP_API int bu_hip_k_refine_endpoint_clusterization(bu_hip_context*, const void* d_pixel_blocks, uint32_t n_blocks,
+    const uint32_t* d_block_cluster, const uint8_t* d_cluster_params, uint32_t n_clusters, uint32_t n_parents,
+    const uint32_t* d_cand_offsets, const uint32_t* d_cand_indices, const uint8_t* d_block_parent, int perceptual, uint32_t* d_out_best_cluster);
+/* a11 create_initial_packed_texture (frontend.cpp:2014-2096): d_block_cluster may be NULL, then d_color5_inten is per block. */
+BU_HIP_API int bu_hip_k_determine_selectors(bu_hip_context*, const void* d_pixel_blocks, uint32_t n_blocks,
+    const uint8_t* d_color5_inten, const uint32_t* d_block_cluster, int perceptual, void* d_out_etc_blocks);
+/* a12 generate_selector_clusters training part (frontend.cpp:2155-2183): 16 floats + u64 weight per block. */
+BU_HIP_API int bu_hip_k_selector_training_vectors(bu_hip_context*, const void* d_encoded_blocks, uint32_t n_blocks, int perceptual, float* d_out_vec16, uint64_t* d_out_weight);
+/* a13 create_optimized_selector_codebook (frontend.cpp:2259-2354): CSR lists of block indices per selector cluster;
+ *     rewrites the selector bytes of d_selector_blocks[cluster] (8 B each) for non-empty clusters. */
+BU_HIP_API int bu_hip_k_create_optimized_selector_codebook(bu_hip_context*, const void* d_pixel_blocks, const void* d_encoded_blocks,
+    uint32_t n_clusters, const uint32_t* d_offsets, const uint32_t* d_block_indices, int perceptual, void* d_selector_blocks);
+/* a14 find_optimal_selector_clusters_for_each_block (frontend.cpp:2397-2715), hierarchical or flat; `chunk` reproduces the
+ *     reference's "same pixels as the previous block of this job" shortcut (2048; 0 disables). Rewrites the selector bytes
+ *     of d_encoded_blocks and writes the chosen cluster per block. */
+BU_HIP_API int bu_hip_k_find_optimal_selector_clusters(bu_hip_context*, const void* d_pixel_blocks, void* d_encoded_blocks, uint32_t n_blocks,
+    const void* d_selector_blocks, uint32_t n_selectors, uint32_t n_parents, const uint32_t* d_cand_offsets, const uint32_t* d_cand_indices,
+    const uint8_t* d_block_parent, int perceptual, uint32_t chunk, uint32_t* d_out_block_selector_cluster);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BASISU_HIP_H */

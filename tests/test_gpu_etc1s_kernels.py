@@ -1,0 +1,294 @@
+"""-m gpu parity tests of the device-resident layer (include/basisu_hip.h section 2) against the CPU oracle.
+
+Every comparison is bit-exact. Inputs are seeded; sizes are chosen so the plain-C oracle finishes in seconds.
+The real reference (oracle/_ref) pins the oracle itself in test_oracle_vs_reference.py.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from helpers import (oracle, ptr, u8p, u32p, u64p, f32p, synth, uniform_random, to_pixel_blocks, csr_from_lists)
+
+pytestmark = pytest.mark.gpu
+
+VP = C.c_void_p
+
+
+def _images():
+    a = to_pixel_blocks(synth(256, 192, 1234))
+    b = to_pixel_blocks(uniform_random(64, 64, 42))
+    flat = np.zeros((64, 4, 4, 4), np.uint8)
+    flat[:, :, :, 3] = 255
+    flat[:32, :, :, :3] = 255
+    flat[40:48, :, :, 0] = 17
+    grad = np.zeros((32, 64, 4), np.uint8)
+    grad[..., 0] = np.arange(64)[None, :] * 4
+    grad[..., 1] = np.arange(32)[:, None] * 8
+    grad[..., 3] = 255
+    return np.concatenate([a, b, flat, to_pixel_blocks(grad)])
+
+
+@pytest.fixture(scope="module")
+def blocks():
+    return _images()
+
+
+@pytest.fixture(scope="module")
+def d_blocks(hip_ctx, blocks):
+    p = hip_ctx.upload(blocks)
+    yield p
+    hip_ctx.free(p)
+
+
+@pytest.mark.parametrize("perceptual", [1, 0])
+@pytest.mark.parametrize("quality,level", [(0, 0), (1, 1), (2, 2), (3, 6)])
+def test_encode_etc1s_blocks(hip_ctx, blocks, d_blocks, quality, level, perceptual):
+    n = blocks.shape[0]
+    d_out = hip_ctx.alloc(n * 8)
+    hip_ctx.check(hip_ctx.lib.k_encode_etc1s_blocks(hip_ctx.h, d_blocks, n, quality, perceptual, d_out), "k_encode")
+    got = hip_ctx.download(d_out, (n, 8), np.uint8)
+    hip_ctx.free(d_out)
+    exp = np.zeros((n, 8), np.uint8)
+    oracle().orc_encode_etc1s_blocks(ptr(blocks), n, level, perceptual, ptr(exp))
+    bad = np.nonzero((got != exp).any(axis=1))[0]
+    assert bad.size == 0, f"{bad.size} of {n} blocks differ, first {bad[:5]}: got {got[bad[:2]]} exp {exp[bad[:2]]}"
+
+
+def test_encode_ragged_tail(hip_ctx, blocks):
+    # n not a multiple of the 32 blocks a workgroup handles, and n == 1
+    for n in (1, 33, 95):
+        b = np.ascontiguousarray(blocks[:n])
+        d_in = hip_ctx.upload(b)
+        d_out = hip_ctx.alloc(n * 8 + 64)
+        hip_ctx.check(hip_ctx.lib.memset(hip_ctx.h, d_out, 0xAB, n * 8 + 64), "memset")
+        hip_ctx.check(hip_ctx.lib.k_encode_etc1s_blocks(hip_ctx.h, d_in, n, 1, 1, d_out), "k_encode")
+        got = hip_ctx.download(d_out, (n * 8 + 64,), np.uint8)
+        exp = np.zeros((n, 8), np.uint8)
+        oracle().orc_encode_etc1s_blocks(ptr(b), n, 1, 1, ptr(exp))
+        assert (got[:n * 8].reshape(n, 8) == exp).all()
+        assert (got[n * 8:] == 0xAB).all(), "wrote past the end"
+        hip_ctx.free(d_in); hip_ctx.free(d_out)
+
+
+def _encode_ref(blocks, level=1, perceptual=1):
+    n = blocks.shape[0]
+    out = np.zeros((n, 8), np.uint8)
+    oracle().orc_encode_etc1s_blocks(ptr(blocks), n, level, perceptual, ptr(out))
+    return out
+
+
+def test_endpoint_training_vectors(hip_ctx, blocks):
+    n = blocks.shape[0]
+    etc = _encode_ref(blocks)
+    d_etc = hip_ctx.upload(etc)
+    d_out = hip_ctx.alloc(n * 24)
+    hip_ctx.check(hip_ctx.lib.k_endpoint_training_vectors(hip_ctx.h, d_etc, n, d_out), "k_etv")
+    got = hip_ctx.download(d_out, (n, 6), np.float32)
+    exp = np.zeros((n, 6), np.float32)
+    oracle().orc_endpoint_training_vectors(ptr(etc), n, ptr(exp, f32p))
+    assert (got.view(np.uint32) == exp.view(np.uint32)).all()
+    hip_ctx.free(d_etc); hip_ctx.free(d_out)
+
+
+def _clusters_by_luma(blocks, k, rng):
+    """A plausible endpoint clustering: blocks sorted by mean luma cut into k uneven runs; both subblocks stay together."""
+    n = blocks.shape[0]
+    order = np.argsort(blocks[..., :3].reshape(n, -1).astype(np.int64).sum(axis=1), kind="stable")
+    cuts = np.sort(rng.choice(np.arange(1, n), size=k - 1, replace=False))
+    lists, block_cluster = [], np.zeros(n, np.uint32)
+    for ci, run in enumerate(np.split(order, cuts)):
+        run = rng.permutation(run)
+        lists.append(np.stack([run * 2, run * 2 + 1], axis=1).reshape(-1).astype(np.uint32))
+        block_cluster[run] = ci
+    return lists, block_cluster
+
+
+@pytest.mark.parametrize("perceptual", [1, 0])
+@pytest.mark.parametrize("quality,level", [(1, 1), (2, 2), (3, 6)])
+def test_generate_endpoint_codebook(hip_ctx, blocks, d_blocks, quality, level, perceptual):
+    rng = np.random.default_rng(7)
+    k = 97
+    lists, _ = _clusters_by_luma(blocks, k, rng)
+    # one giant cluster as well: exercises the multi-wave reduction with thousands of pixels
+    lists.append(np.arange(blocks.shape[0] * 2, dtype=np.uint32))
+    k += 1
+    offs, idx = csr_from_lists(lists)
+    d_offs, d_idx = hip_ctx.upload(offs), hip_ctx.upload(idx)
+    params = np.zeros((k, 4), np.uint8); err = np.zeros(k, np.uint64); valid = np.zeros(k, np.uint8)
+    d_params, d_err, d_valid = hip_ctx.upload(params), hip_ctx.upload(err), hip_ctx.upload(valid)
+    L = hip_ctx.lib
+
+    def run(step):
+        hip_ctx.check(L.k_generate_endpoint_codebook(hip_ctx.h, d_blocks, k, offs.ctypes.data_as(VP), d_offs, d_idx, quality, perceptual, step,
+                                                     d_params, d_err, d_valid), "k_gec")
+        return hip_ctx.download(d_params, (k, 4), np.uint8), hip_ctx.download(d_err, (k,), np.uint64), hip_ctx.download(d_valid, (k,), np.uint8)
+
+    got = run(0)
+    oracle().orc_generate_endpoint_codebook(ptr(blocks), k, ptr(offs, u32p), ptr(idx, u32p), level, perceptual, 0, ptr(params), ptr(err, u64p), ptr(valid))
+    assert (got[0] == params).all() and (got[1] == err).all() and (got[2] == valid).all()
+
+    # step 1: perturb half of the previous parameters so that both "keep old" and "take new" branches run (frontend.cpp:1554-1605)
+    params2 = params.copy()
+    params2[::2, 0] = np.minimum(params2[::2, 0] + 1, 31)
+    params2[1::4, 3] = (params2[1::4, 3] + 1) % 8
+    valid2 = valid.copy(); valid2[5] = 0
+    hip_ctx.check(L.memcpy_h2d(hip_ctx.h, d_params, params2.ctypes.data_as(VP), params2.nbytes), "h2d")
+    hip_ctx.check(L.memcpy_h2d(hip_ctx.h, d_valid, valid2.ctypes.data_as(VP), valid2.nbytes), "h2d")
+    got = run(1)
+    err2 = err.copy()
+    oracle().orc_generate_endpoint_codebook(ptr(blocks), k, ptr(offs, u32p), ptr(idx, u32p), level, perceptual, 1, ptr(params2), ptr(err2, u64p), ptr(valid2))
+    assert (got[0] == params2).all() and (got[1] == err2).all() and (got[2] == valid2).all()
+    for p in (d_offs, d_idx, d_params, d_err, d_valid):
+        hip_ctx.free(p)
+
+
+def _codebook(blocks, k, seed, level=1, perceptual=1):
+    rng = np.random.default_rng(seed)
+    lists, block_cluster = _clusters_by_luma(blocks, k, rng)
+    offs, idx = csr_from_lists(lists)
+    params = np.zeros((k, 4), np.uint8); err = np.zeros(k, np.uint64); valid = np.zeros(k, np.uint8)
+    oracle().orc_generate_endpoint_codebook(ptr(blocks), k, ptr(offs, u32p), ptr(idx, u32p), level, perceptual, 0, ptr(params), ptr(err, u64p), ptr(valid))
+    return params, block_cluster
+
+
+@pytest.mark.parametrize("perceptual", [1, 0])
+@pytest.mark.parametrize("hier", [True, False])
+def test_refine_endpoint_clusterization(hip_ctx, blocks, d_blocks, hier, perceptual):
+    n = blocks.shape[0]
+    k = 300
+    params, block_cluster = _codebook(blocks, k, 11, perceptual=perceptual)
+    # duplicate a few codebook entries so that ties between distinct clusters occur
+    params[10] = params[11]; params[200] = params[150]
+    n_parents = 7 if hier else 0
+    if hier:
+        # parents = contiguous ranges of clusters (luma ordered), candidate lists = clusters of that parent, sorted ascending like
+        # compute_endpoint_clusters_within_each_parent_cluster (frontend.cpp:971-996)
+        cluster_parent = (np.arange(k) * n_parents // k).astype(np.uint8)
+        block_parent = cluster_parent[block_cluster]
+        cand = [np.nonzero(cluster_parent == p)[0].astype(np.uint32) for p in range(n_parents)]
+        coffs, cidx = csr_from_lists(cand)
+    else:
+        block_parent = np.zeros(n, np.uint8); coffs = np.zeros(1, np.uint32); cidx = np.zeros(1, np.uint32)
+    exp = np.zeros(n, np.uint32)
+    oracle().orc_refine_endpoint_clusterization(ptr(blocks), n, ptr(block_cluster, u32p), ptr(params), k, n_parents, ptr(coffs, u32p), ptr(cidx, u32p),
+                                                ptr(block_parent), perceptual, ptr(exp, u32p))
+    bufs = [hip_ctx.upload(a) for a in (block_cluster, params, coffs, cidx, block_parent)]
+    d_out = hip_ctx.alloc(n * 4)
+    hip_ctx.check(hip_ctx.lib.k_refine_endpoint_clusterization(hip_ctx.h, d_blocks, n, bufs[0], bufs[1], k, n_parents, bufs[2], bufs[3], bufs[4], perceptual, d_out), "k_refine")
+    got = hip_ctx.download(d_out, (n,), np.uint32)
+    assert (got == exp).all(), f"{int((got != exp).sum())} of {n} differ"
+    assert (got != block_cluster).any(), "degenerate test: nothing moved"
+    for p in bufs + [d_out]:
+        hip_ctx.free(p)
+
+
+@pytest.mark.parametrize("perceptual", [1, 0])
+def test_determine_selectors(hip_ctx, blocks, d_blocks, perceptual):
+    n = blocks.shape[0]
+    params, block_cluster = _codebook(blocks, 64, 3, perceptual=perceptual)
+    per_block = np.ascontiguousarray(params[block_cluster])
+    exp = np.zeros((n, 8), np.uint8)
+    oracle().orc_determine_selectors(ptr(blocks), n, ptr(per_block), perceptual, ptr(exp))
+    d_out = hip_ctx.alloc(n * 8)
+    # (a) per-block colour table, as the reference seam passes it
+    d_pb = hip_ctx.upload(per_block)
+    hip_ctx.check(hip_ctx.lib.k_determine_selectors(hip_ctx.h, d_blocks, n, d_pb, None, perceptual, d_out), "k_ds")
+    assert (hip_ctx.download(d_out, (n, 8), np.uint8) == exp).all()
+    # (b) codebook + per-block cluster index, as the resident frontend calls it
+    d_par, d_bc = hip_ctx.upload(params), hip_ctx.upload(block_cluster)
+    hip_ctx.check(hip_ctx.lib.memset(hip_ctx.h, d_out, 0, n * 8), "memset")
+    hip_ctx.check(hip_ctx.lib.k_determine_selectors(hip_ctx.h, d_blocks, n, d_par, d_bc, perceptual, d_out), "k_ds")
+    assert (hip_ctx.download(d_out, (n, 8), np.uint8) == exp).all()
+    for p in (d_out, d_pb, d_par, d_bc):
+        hip_ctx.free(p)
+
+
+def _encoded(blocks, perceptual=1):
+    n = blocks.shape[0]
+    params, block_cluster = _codebook(blocks, 64, 3, perceptual=perceptual)
+    enc = np.zeros((n, 8), np.uint8)
+    oracle().orc_determine_selectors(ptr(blocks), n, ptr(np.ascontiguousarray(params[block_cluster])), perceptual, ptr(enc))
+    return enc
+
+
+@pytest.mark.parametrize("perceptual", [1, 0])
+def test_selector_training_vectors(hip_ctx, blocks, perceptual):
+    n = blocks.shape[0]
+    enc = _encoded(blocks, perceptual)
+    exp_v = np.zeros((n, 16), np.float32); exp_w = np.zeros(n, np.uint64)
+    oracle().orc_selector_training_vectors(ptr(enc), n, perceptual, ptr(exp_v, f32p), ptr(exp_w, u64p))
+    d_enc = hip_ctx.upload(enc); d_v = hip_ctx.alloc(n * 64); d_w = hip_ctx.alloc(n * 8)
+    hip_ctx.check(hip_ctx.lib.k_selector_training_vectors(hip_ctx.h, d_enc, n, perceptual, d_v, d_w), "k_stv")
+    assert (hip_ctx.download(d_v, (n, 16), np.float32) == exp_v).all()
+    assert (hip_ctx.download(d_w, (n,), np.uint64) == exp_w).all()
+    for p in (d_enc, d_v, d_w):
+        hip_ctx.free(p)
+
+
+def _selector_clusters(enc, k, rng):
+    n = enc.shape[0]
+    key = enc[:, 4:].astype(np.uint32) @ np.array([1, 256, 65536, 16777216], np.uint32)
+    order = np.argsort(key, kind="stable")
+    cuts = np.sort(rng.choice(np.arange(1, n), size=k - 2, replace=False))
+    lists = [rng.permutation(r).astype(np.uint32) for r in np.split(order, cuts)]
+    lists.insert(5, np.zeros(0, np.uint32))  # an empty cluster (frontend.cpp:2282-2283)
+    return lists
+
+
+@pytest.mark.parametrize("perceptual", [1, 0])
+def test_create_optimized_selector_codebook(hip_ctx, blocks, d_blocks, perceptual):
+    enc = _encoded(blocks, perceptual)
+    rng = np.random.default_rng(5)
+    k = 120
+    lists = _selector_clusters(enc, k, rng)
+    offs, idx = csr_from_lists(lists)
+    sel = rng.integers(0, 256, (k, 8), dtype=np.uint8)  # stale contents: only the 4 selector bytes of non-empty clusters may change
+    exp = sel.copy()
+    oracle().orc_create_optimized_selector_codebook(ptr(blocks), ptr(enc), k, ptr(offs, u32p), ptr(idx, u32p), perceptual, ptr(exp))
+    bufs = [hip_ctx.upload(a) for a in (enc, offs, idx, sel)]
+    hip_ctx.check(hip_ctx.lib.k_create_optimized_selector_codebook(hip_ctx.h, d_blocks, bufs[0], k, bufs[1], bufs[2], perceptual, bufs[3]), "k_cosc")
+    got = hip_ctx.download(bufs[3], (k, 8), np.uint8)
+    assert (got == exp).all()
+    for p in bufs:
+        hip_ctx.free(p)
+
+
+@pytest.mark.parametrize("perceptual", [1, 0])
+@pytest.mark.parametrize("hier", [True, False])
+def test_find_optimal_selector_clusters(hip_ctx, blocks, hier, perceptual):
+    # make runs of identical tiles that straddle a job boundary (chunk) so the shortcut of frontend.cpp:2557-2564 is exercised
+    blocks = blocks.copy()
+    blocks[100:110] = blocks[100]
+    blocks[2040:2060] = blocks[2040]
+    n = blocks.shape[0]
+    enc = _encoded(blocks, perceptual)
+    enc[105, :3] ^= 0x18  # identical tiles with DIFFERENT endpoints: the copied choice must still be the run head's
+    rng = np.random.default_rng(9)
+    k = 200
+    lists = _selector_clusters(enc, k, rng)
+    offs, idx = csr_from_lists(lists)
+    sel = np.zeros((k, 8), np.uint8)
+    oracle().orc_create_optimized_selector_codebook(ptr(blocks), ptr(enc), k, ptr(offs, u32p), ptr(idx, u32p), perceptual, ptr(sel))
+    n_parents = 5 if hier else 0
+    if hier:
+        cluster_parent = (np.arange(k) * n_parents // k).astype(np.uint8)
+        block_sel = np.zeros(n, np.uint32)
+        for ci, l in enumerate(lists):
+            block_sel[l] = ci
+        block_parent = cluster_parent[block_sel]
+        coffs, cidx = csr_from_lists([np.nonzero(cluster_parent == p)[0].astype(np.uint32) for p in range(n_parents)])
+    else:
+        block_parent = np.zeros(n, np.uint8); coffs = np.zeros(1, np.uint32); cidx = np.zeros(1, np.uint32)
+    exp_enc = enc.copy(); exp_idx = np.zeros(n, np.uint32)
+    oracle().orc_find_optimal_selector_clusters(ptr(blocks), ptr(exp_enc), n, ptr(sel), k, n_parents, ptr(coffs, u32p), ptr(cidx, u32p), ptr(block_parent),
+                                                perceptual, 2048, ptr(exp_idx, u32p))
+    bufs = [hip_ctx.upload(a) for a in (blocks, enc, sel, coffs, cidx, block_parent)]
+    d_out = hip_ctx.alloc(n * 4)
+    hip_ctx.check(hip_ctx.lib.k_find_optimal_selector_clusters(hip_ctx.h, bufs[0], bufs[1], n, bufs[2], k, n_parents, bufs[3], bufs[4], bufs[5], perceptual, 2048, d_out), "k_fosc")
+    got_idx = hip_ctx.download(d_out, (n,), np.uint32)
+    got_enc = hip_ctx.download(bufs[1], (n, 8), np.uint8)
+    assert (got_idx == exp_idx).all(), f"{int((got_idx != exp_idx).sum())} differ"
+    assert (got_enc == exp_enc).all()
+    for p in bufs + [d_out]:
+        hip_ctx.free(p)
