@@ -49,6 +49,8 @@ _SIGNATURES = {
     "bu_hip_get_stream": (_vp, [_vp]),
     "bu_hip_sync": (_int, [_vp]),
     "bu_hip_last_error": (C.c_char_p, [_vp]),
+    "bu_hip_profile_enable": (_int, [_vp, _int]),
+    "bu_hip_profile_read": (_u32, [_vp, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(_u32), _u32]),
     "bu_hip_malloc": (_vp, [_vp, C.c_size_t]),
     "bu_hip_free": (None, [_vp, _vp]),
     "bu_hip_memcpy_h2d": (_int, [_vp, _vp, _vp, C.c_size_t]),
@@ -144,6 +146,15 @@ class Context:
         out = np.empty(shape, dtype)
         self.check(self.lib.memcpy_d2h(self.h, out.ctypes.data_as(_vp), p, out.nbytes), "memcpy_d2h")
         return out
+
+    def profile_enable(self, on=True):
+        self.check(self.lib.profile_enable(self.h, int(on)), "profile_enable")
+
+    def profile_read(self):
+        """{kernel name: (total ms, launches)} from HIP events on the launch stream since profile_enable(True)."""
+        names = (C.c_char_p * 32)(); ms = (C.c_double * 32)(); cnt = (_u32 * 32)()
+        n = min(self.lib.profile_read(self.h, names, ms, cnt, 32), 32)
+        return {names[i].decode(): (ms[i], cnt[i]) for i in range(n)}
 
     def sync(self):
         self.check(self.lib.sync(self.h), "sync")

@@ -52,6 +52,12 @@ struct bu_hip_context {
     arena pixel_arena;                    // owns the tiles when they were uploaded through bu_hip_set_pixel_blocks
     arena scratch[6];
     std::string error;
+    // optional per-kernel timing with HIP events on the launch stream (bu_hip_profile_*)
+    bool profiling = false;
+    struct prof_rec { const char* name; hipEvent_t start, stop; };
+    std::vector<prof_rec> prof_pending;
+    struct prof_sum { const char* name; double ms; uint32_t launches; };
+    std::vector<prof_sum> prof_totals;
 };
 
 namespace {
@@ -72,6 +78,34 @@ struct device_guard {
     }
     ~device_guard() { /* leave the context's device current: callers (torch) re-select theirs explicitly */ }
 };
+
+// RAII bracket around one kernel launch sequence: records a start/stop event pair on the launch stream when profiling is on.
+struct prof_scope {
+    bu_hip_context* ctx; const char* name; hipEvent_t start = nullptr, stop = nullptr;
+    prof_scope(bu_hip_context* c, const char* n) : ctx(c), name(n) {
+        if (!ctx->profiling) return;
+        if (hipEventCreate(&start) != hipSuccess || hipEventCreate(&stop) != hipSuccess) { start = stop = nullptr; return; }
+        (void)hipEventRecord(start, ctx->stream);
+    }
+    ~prof_scope() {
+        if (!start) return;
+        (void)hipEventRecord(stop, ctx->stream);
+        ctx->prof_pending.push_back({name, start, stop});
+    }
+};
+
+void prof_drain(bu_hip_context* ctx) {
+    for (auto& r : ctx->prof_pending) {
+        float ms = 0.0f;
+        if (hipEventSynchronize(r.stop) == hipSuccess && hipEventElapsedTime(&ms, r.start, r.stop) == hipSuccess) {
+            bool found = false;
+            for (auto& t : ctx->prof_totals) if (t.name == r.name) { t.ms += ms; t.launches++; found = true; break; }
+            if (!found) ctx->prof_totals.push_back({r.name, (double)ms, 1u});
+        }
+        (void)hipEventDestroy(r.start); (void)hipEventDestroy(r.stop);
+    }
+    ctx->prof_pending.clear();
+}
 
 int quality_from_perms(uint32_t total_perms) {
     // frontend.cpp:746-752 / etc.cpp:792-800: {4,16,64,165} <-> {fast, medium, slow, uber}
@@ -188,6 +222,24 @@ int bu_hip_memset(bu_hip_context* ctx, void* d, int value, size_t bytes) {
     return 1;
 }
 
+int bu_hip_profile_enable(bu_hip_context* ctx, int on) {
+    if (!ctx) return 0;
+    device_guard g(ctx->device);
+    prof_drain(ctx);
+    ctx->prof_totals.clear();
+    ctx->profiling = on != 0;
+    return 1;
+}
+
+uint32_t bu_hip_profile_read(bu_hip_context* ctx, const char** names, double* total_ms, uint32_t* launches, uint32_t cap) {
+    if (!ctx) return 0;
+    device_guard g(ctx->device);
+    prof_drain(ctx);
+    const uint32_t n = (uint32_t)std::min<size_t>(ctx->prof_totals.size(), cap);
+    for (uint32_t i = 0; i < n; i++) { names[i] = ctx->prof_totals[i].name; total_ms[i] = ctx->prof_totals[i].ms; launches[i] = ctx->prof_totals[i].launches; }
+    return (uint32_t)ctx->prof_totals.size();
+}
+
 // ---------------------------------------------------------------------------------------------------------------- tiles
 
 int bu_hip_set_pixel_blocks(bu_hip_context* ctx, size_t total_blocks, const bu_pixel_block* blocks) {
@@ -220,6 +272,7 @@ const void* bu_hip_get_pixel_blocks_device(const bu_hip_context* ctx, size_t* to
 int bu_hip_k_encode_etc1s_blocks(bu_hip_context* ctx, const void* d_px, uint32_t n, int quality, int perceptual, void* d_out) {
     if (!ctx) return 0;
     device_guard g(ctx->device);
+    prof_scope ps(ctx, "encode_etc1s_blocks");
     BU_TRY(ctx, bu::launch_encode_etc1s_blocks(ctx->stream, d_px, n, quality, perceptual != 0, d_out));
     return 1;
 }
@@ -227,6 +280,7 @@ int bu_hip_k_encode_etc1s_blocks(bu_hip_context* ctx, const void* d_px, uint32_t
 int bu_hip_k_endpoint_training_vectors(bu_hip_context* ctx, const void* d_etc, uint32_t n, float* d_out6) {
     if (!ctx) return 0;
     device_guard g(ctx->device);
+    prof_scope ps(ctx, "endpoint_training_vectors");
     BU_TRY(ctx, bu::launch_endpoint_training_vectors(ctx->stream, d_etc, n, d_out6));
     return 1;
 }
@@ -246,8 +300,11 @@ int bu_hip_k_generate_endpoint_codebook(bu_hip_context* ctx, const void* d_px, u
     arena& ord = ctx->scratch[5];
     BU_TRY(ctx, ord.reserve(n_clusters * sizeof(uint32_t)));
     BU_TRY(ctx, hipMemcpyAsync(ord.p, order.data(), n_clusters * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
-    BU_TRY(ctx, bu::launch_generate_endpoint_codebook(ctx->stream, d_px, n_clusters, static_cast<const uint32_t*>(ord.p), d_offsets, d_indices,
-                                                      quality, perceptual != 0, step, d_params, d_err, d_valid));
+    {
+        prof_scope ps(ctx, "generate_endpoint_codebook");
+        BU_TRY(ctx, bu::launch_generate_endpoint_codebook(ctx->stream, d_px, n_clusters, static_cast<const uint32_t*>(ord.p), d_offsets, d_indices,
+                                                          quality, perceptual != 0, step, d_params, d_err, d_valid));
+    }
     BU_TRY(ctx, hipStreamSynchronize(ctx->stream)); // `order` is pageable host memory owned by this call
     return 1;
 }
@@ -257,6 +314,7 @@ int bu_hip_k_refine_endpoint_clusterization(bu_hip_context* ctx, const void* d_p
                                             const uint32_t* d_cand_indices, const uint8_t* d_block_parent, int perceptual, uint32_t* d_out_best) {
     if (!ctx) return 0;
     device_guard g(ctx->device);
+    prof_scope ps(ctx, "refine_endpoint_clusterization");
     BU_TRY(ctx, bu::launch_refine_endpoint_clusterization(ctx->stream, d_px, n_blocks, d_block_cluster, d_cluster_params, n_clusters, n_parents,
                                                           d_cand_offsets, d_cand_indices, d_block_parent, perceptual != 0, d_out_best));
     return 1;
@@ -266,6 +324,7 @@ int bu_hip_k_determine_selectors(bu_hip_context* ctx, const void* d_px, uint32_t
                                  const uint32_t* d_block_cluster, int perceptual, void* d_out) {
     if (!ctx) return 0;
     device_guard g(ctx->device);
+    prof_scope ps(ctx, "determine_selectors");
     BU_TRY(ctx, bu::launch_determine_selectors(ctx->stream, d_px, n_blocks, d_color5_inten, d_block_cluster, perceptual != 0, d_out));
     return 1;
 }
@@ -273,6 +332,7 @@ int bu_hip_k_determine_selectors(bu_hip_context* ctx, const void* d_px, uint32_t
 int bu_hip_k_selector_training_vectors(bu_hip_context* ctx, const void* d_enc, uint32_t n_blocks, int perceptual, float* d_out16, uint64_t* d_w) {
     if (!ctx) return 0;
     device_guard g(ctx->device);
+    prof_scope ps(ctx, "selector_training_vectors");
     BU_TRY(ctx, bu::launch_selector_training_vectors(ctx->stream, d_enc, n_blocks, perceptual != 0, d_out16, d_w));
     return 1;
 }
@@ -281,6 +341,7 @@ int bu_hip_k_create_optimized_selector_codebook(bu_hip_context* ctx, const void*
                                                 const uint32_t* d_offsets, const uint32_t* d_block_indices, int perceptual, void* d_selector_blocks) {
     if (!ctx) return 0;
     device_guard g(ctx->device);
+    prof_scope ps(ctx, "create_optimized_selector_codebook");
     BU_TRY(ctx, bu::launch_create_optimized_selector_codebook(ctx->stream, d_px, d_enc, n_clusters, d_offsets, d_block_indices, perceptual != 0, d_selector_blocks));
     return 1;
 }
@@ -290,6 +351,7 @@ int bu_hip_k_find_optimal_selector_clusters(bu_hip_context* ctx, const void* d_p
                                             const uint8_t* d_block_parent, int perceptual, uint32_t chunk, uint32_t* d_out) {
     if (!ctx) return 0;
     device_guard g(ctx->device);
+    prof_scope ps(ctx, "find_optimal_selector_clusters");
     arena& tmp = ctx->scratch[4];
     BU_TRY(ctx, tmp.reserve((size_t)n_blocks * sizeof(uint32_t)));
     BU_TRY(ctx, bu::launch_find_optimal_selector_clusters(ctx->stream, d_px, d_enc, n_blocks, d_selector_blocks, n_selectors, n_parents, d_cand_offsets,

@@ -336,13 +336,15 @@ __global__ __launch_bounds__(256) void k_selector_training_vectors(const uint64_
     uint32_t r5, g5, b5, inten;
     unpack_etc1s_header(m, r5, g5, b5, inten);
     const uint32_t lo = (uint32_t)bswap64(m);
-    float4* o = reinterpret_cast<float4*>(out16 + (size_t)i * 16);
+    if (out16) { // the resident frontend only needs the weights: it de-duplicates on the packed selector word
+        float4* o = reinterpret_cast<float4*>(out16 + (size_t)i * 16);
 #pragma unroll
-    for (uint32_t y = 0; y < 4; y++) {
-        float4 v;
-        v.x = (float)selector_from_bits(lo, 0, y); v.y = (float)selector_from_bits(lo, 1, y);
-        v.z = (float)selector_from_bits(lo, 2, y); v.w = (float)selector_from_bits(lo, 3, y);
-        o[y] = v;
+        for (uint32_t y = 0; y < 4; y++) {
+            float4 v;
+            v.x = (float)selector_from_bits(lo, 0, y); v.y = (float)selector_from_bits(lo, 1, y);
+            v.z = (float)selector_from_bits(lo, 2, y); v.w = (float)selector_from_bits(lo, 3, y);
+            o[y] = v;
+        }
     }
     const int br = scale5((int)r5), bg = scale5((int)g5), bb = scale5((int)b5), d = k_inten_b[inten];
     const cvec lo_c = to_cvec<PERCEPTUAL>(clamp255(br - d), clamp255(bg - d), clamp255(bb - d));

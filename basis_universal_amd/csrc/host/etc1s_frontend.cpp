@@ -1,0 +1,618 @@
+// etc1s_frontend.cpp -- see etc1s_frontend.h. Stage order and bookkeeping follow basisu_frontend (encoder/basisu_frontend.cpp);
+// each method cites the reference code it mirrors.
+#include "etc1s_frontend.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cstring>
+#include <numeric>
+
+#include "tsvq.h"
+
+namespace bu {
+
+namespace {
+
+const uint32_t kEndpointParentCodebookSize = 16;          // frontend.cpp:40
+const uint32_t kSelectorParentCodebookSizeLevel01 = 32;   // frontend.cpp:41
+const uint32_t kSelectorParentCodebookSizeDefault = 16;   // frontend.cpp:42
+const uint32_t kFoscJobSize = 2048;                        // frontend.cpp:2547
+
+const int kIntenB[8] = {8, 17, 29, 42, 60, 80, 106, 183}; // outer entries of g_etc1_inten_tables (etc.cpp:304-308)
+const int kInten[8][4] = {{-8, -2, 2, 8}, {-17, -5, 5, 17}, {-29, -9, 9, 29}, {-42, -13, 13, 42},
+                          {-60, -18, 18, 60}, {-80, -24, 24, 80}, {-106, -33, 33, 106}, {-183, -47, 47, 183}};
+
+inline int clamp255(int v) { return v < 0 ? 0 : (v > 255 ? 255 : v); }
+inline int scale5(int c) { return (c << 3) | (c >> 2); }
+
+inline uint64_t load_be64(const bu_etc_block& b) { uint64_t v; std::memcpy(&v, b.m_bytes, 8); return __builtin_bswap64(v); }
+inline void store_be64(bu_etc_block& b, uint64_t v) { v = __builtin_bswap64(v); std::memcpy(b.m_bytes, &v, 8); }
+inline uint32_t raw_selector_bits(const bu_etc_block& b) { return (uint32_t)load_be64(b); } // low 32 bits of V; same set of bits as get_raw_selector_bits()
+
+struct etc1s_header { uint32_t r, g, b, inten; };
+inline etc1s_header header_of(const bu_etc_block& blk) {
+    const uint64_t v = load_be64(blk);
+    return etc1s_header{(uint32_t)(v >> 59) & 31, (uint32_t)(v >> 51) & 31, (uint32_t)(v >> 43) & 31, (uint32_t)(v >> 37) & 7};
+}
+// selector (index into the intensity table) of pixel (x, y): etc.h:232-236
+inline uint32_t selector_of(uint32_t lo32, uint32_t x, uint32_t y) {
+    const uint32_t bit = x * 4 + y;
+    const uint32_t raw = ((lo32 >> bit) & 1u) | (((lo32 >> (16 + bit)) & 1u) << 1);
+    static const uint8_t to_sel[4] = {2, 3, 1, 0};
+    return to_sel[raw];
+}
+inline uint32_t flat_selector_bits(uint32_t sel) {
+    static const uint8_t to_raw[4] = {3, 2, 0, 1};
+    const uint32_t raw = to_raw[sel];
+    return ((raw & 1u) ? 0xFFFFu : 0u) | ((raw >> 1) ? 0xFFFF0000u : 0u);
+}
+
+// color_distance (enc.h:1141-1195) -- host copy used only by introduce_special_selector_clusters' error comparison
+inline uint32_t color_distance(bool perceptual, const uint8_t* a, const int* b) {
+    const int dr = (int)a[0] - b[0], dg = (int)a[1] - b[1], db = (int)a[2] - b[2];
+    if (!perceptual) return (uint32_t)(dr * dr + dg * dg + db * db);
+    const int dl = dr * 14 + dg * 45 + db * 5, dcr = dr * 64 - dl, dcb = db * 64 - dl;
+    return ((uint32_t)(dl * dl) >> 5) + ((((uint32_t)(dcr * dcr) >> 5) * 26u) >> 7) + ((((uint32_t)(dcb * dcb) >> 5) * 3u) >> 7);
+}
+
+struct csr {
+    std::vector<uint32_t> offsets, indices;
+    void build(const std::vector<std::vector<uint32_t>>& lists) {
+        offsets.resize(lists.size() + 1);
+        size_t total = 0;
+        for (size_t i = 0; i < lists.size(); i++) { offsets[i] = (uint32_t)total; total += lists[i].size(); }
+        offsets[lists.size()] = (uint32_t)total;
+        indices.resize(total);
+        for (size_t i = 0; i < lists.size(); i++)
+            if (!lists[i].empty()) std::memcpy(&indices[offsets[i]], lists[i].data(), lists[i].size() * sizeof(uint32_t));
+    }
+};
+
+class timer {
+public:
+    timer() : t0_(std::chrono::steady_clock::now()) {}
+    double seconds() const { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0_).count(); }
+private:
+    std::chrono::steady_clock::time_point t0_;
+};
+
+} // namespace
+
+// Grow-only device buffers owned by the frontend (all traffic goes through the C ABI).
+struct etc1s_frontend::device_state {
+    bu_hip_context* ctx = nullptr;
+    struct buf {
+        void* p = nullptr; size_t cap = 0;
+    };
+    const void* d_pixels = nullptr;
+    bool owns_pixels = false;
+    buf etc1, enc, block_cluster, params, err, valid, offsets, indices, cand_offsets, cand_indices, block_parent, out_u32, sel_blocks, weights;
+
+    bool reserve(buf& b, size_t bytes) {
+        if (bytes <= b.cap) return true;
+        if (b.p) bu_hip_free(ctx, b.p);
+        b.cap = bytes + bytes / 4 + 256;
+        b.p = bu_hip_malloc(ctx, b.cap);
+        if (!b.p) { b.cap = 0; return false; }
+        return true;
+    }
+    template <typename T> bool upload(buf& b, const T* src, size_t count) {
+        if (!reserve(b, count * sizeof(T))) return false;
+        return count ? bu_hip_memcpy_h2d(ctx, b.p, src, count * sizeof(T)) != 0 : true;
+    }
+    template <typename T> bool download(T* dst, const buf& b, size_t count) { return bu_hip_memcpy_d2h(ctx, dst, b.p, count * sizeof(T)) != 0; }
+    void release() {
+        for (buf* b : {&etc1, &enc, &block_cluster, &params, &err, &valid, &offsets, &indices, &cand_offsets, &cand_indices, &block_parent, &out_u32, &sel_blocks, &weights})
+            if (b->p) { bu_hip_free(ctx, b->p); b->p = nullptr; b->cap = 0; }
+        if (owns_pixels && d_pixels) bu_hip_free(ctx, const_cast<void*>(d_pixels));
+        d_pixels = nullptr;
+    }
+};
+
+etc1s_frontend::etc1s_frontend() {}
+etc1s_frontend::~etc1s_frontend() {
+    if (m_dev) { m_dev->release(); delete m_dev; }
+}
+
+bool etc1s_frontend::fail(const char* what) {
+    m_error = what;
+    if (m_dev && m_dev->ctx) { const char* e = bu_hip_last_error(m_dev->ctx); if (e && *e) { m_error += ": "; m_error += e; } }
+    return false;
+}
+
+// basisu_frontend::init (frontend.cpp:51-157)
+bool etc1s_frontend::init(const params& p) {
+    if (!p.m_pHIP_context) return fail("etc1s_frontend::init: a bu_hip_context is required (there is no CPU path)");
+    if (p.m_max_endpoint_clusters < 1 || p.m_max_endpoint_clusters > cMaxEndpointClusters) return fail("bad max_endpoint_clusters");
+    if (p.m_max_selector_clusters < 1 || p.m_max_selector_clusters > cMaxSelectorClusters) return fail("bad max_selector_clusters");
+    if (!p.m_num_source_blocks || (!p.m_pSource_blocks && !p.m_pDevice_blocks)) return fail("no source blocks");
+    if (p.m_compression_level > 3) return fail("ETC1S compression levels 4-6 (multi-pass codebook refinement) are not built yet");
+    m_params = p;
+    m_total_blocks = p.m_num_source_blocks;
+
+    if (m_dev) { m_dev->release(); delete m_dev; }
+    m_dev = new device_state();
+    m_dev->ctx = p.m_pHIP_context;
+    if (p.m_pDevice_blocks) {
+        m_dev->d_pixels = p.m_pDevice_blocks;
+    } else {
+        void* d = bu_hip_malloc(m_dev->ctx, (size_t)m_total_blocks * sizeof(bu_pixel_block));
+        if (!d) return fail("device allocation of the source blocks failed");
+        m_dev->d_pixels = d; m_dev->owns_pixels = true;
+        if (!bu_hip_memcpy_h2d(m_dev->ctx, d, p.m_pSource_blocks, (size_t)m_total_blocks * sizeof(bu_pixel_block))) return fail("upload of the source blocks failed");
+    }
+
+    m_encoded_blocks.assign(m_total_blocks, bu_etc_block{});
+    m_num_endpoint_codebook_iterations = 1;
+    m_num_selector_codebook_iterations = 1;
+    switch (p.m_compression_level) {  // frontend.cpp:87-148
+    case 0: m_endpoint_refinement = false; m_use_hierarchical_endpoint_codebooks = true; m_use_hierarchical_selector_codebooks = true; break;
+    case 1: case 2: m_endpoint_refinement = true; m_use_hierarchical_endpoint_codebooks = true; m_use_hierarchical_selector_codebooks = true; break;
+    default: m_endpoint_refinement = true; m_use_hierarchical_endpoint_codebooks = false; m_use_hierarchical_selector_codebooks = false; break;
+    }
+    if (p.m_disable_hierarchical_endpoint_codebooks) m_use_hierarchical_endpoint_codebooks = false;
+    return true;
+}
+
+// basisu_frontend::compress (frontend.cpp:159-316), single endpoint/selector iteration (levels 0-3)
+bool etc1s_frontend::compress() {
+    m_stage_times.clear();
+#define BU_STAGE(name, call) do { timer t__; if (!(call)) return false; m_stage_times.push_back(stage_time{name, t__.seconds()}); } while (0)
+#define BU_STAGE_V(name, call) do { timer t__; call; m_stage_times.push_back(stage_time{name, t__.seconds()}); } while (0)
+    BU_STAGE("init_etc1_images", init_etc1_images());
+    BU_STAGE("init_endpoint_training_vectors", init_endpoint_training_vectors());
+    BU_STAGE("generate_endpoint_clusters", generate_endpoint_clusters());
+    for (uint32_t step = 0; step < m_num_endpoint_codebook_iterations; step++) {
+        BU_STAGE("generate_endpoint_codebook", generate_endpoint_codebook(step));
+        if (m_endpoint_refinement) {
+            uint32_t moved = 0;
+            BU_STAGE("refine_endpoint_clusterization", refine_endpoint_clusterization(&moved));
+        }
+        BU_STAGE_V("eliminate_redundant_or_empty_endpoint_clusters", eliminate_redundant_or_empty_endpoint_clusters());
+    }
+    BU_STAGE_V("generate_block_endpoint_clusters", generate_block_endpoint_clusters());
+    BU_STAGE("create_initial_packed_texture", create_initial_packed_texture());
+    BU_STAGE("generate_selector_clusters", generate_selector_clusters());
+    if (m_use_hierarchical_selector_codebooks) BU_STAGE_V("compute_selector_clusters_within_each_parent_cluster", compute_selector_clusters_within_each_parent_cluster());
+    for (uint32_t it = 0; it < m_num_selector_codebook_iterations; it++) {
+        BU_STAGE("create_optimized_selector_codebook", create_optimized_selector_codebook(it));
+        BU_STAGE("find_optimal_selector_clusters_for_each_block", find_optimal_selector_clusters_for_each_block());
+        BU_STAGE("introduce_special_selector_clusters", introduce_special_selector_clusters());
+    }
+    BU_STAGE_V("optimize_selector_codebook", optimize_selector_codebook());
+    BU_STAGE_V("finalize", finalize());
+#undef BU_STAGE
+#undef BU_STAGE_V
+    return true;
+}
+
+// frontend.cpp:733-823
+bool etc1s_frontend::init_etc1_images() {
+    const uint32_t n = m_total_blocks;
+    const int quality = m_params.m_compression_level == 0 ? BU_ETC_QUALITY_FAST : m_params.m_compression_level == 1 ? BU_ETC_QUALITY_MEDIUM
+                      : m_params.m_compression_level == 6 ? BU_ETC_QUALITY_UBER : BU_ETC_QUALITY_SLOW; // frontend.cpp:783-788
+    device_state& d = *m_dev;
+    if (!d.reserve(d.etc1, (size_t)n * 8)) return fail("alloc");
+    if (!bu_hip_k_encode_etc1s_blocks(d.ctx, d.d_pixels, n, quality, m_params.m_perceptual, d.etc1.p)) return fail("bu_hip_k_encode_etc1s_blocks");
+    m_etc1_blocks_etc1s.resize(n);
+    if (!d.download(m_etc1_blocks_etc1s.data(), d.etc1, n)) return fail("download etc1 blocks");
+    return true;
+}
+
+// frontend.cpp:825-866 + the de-duplication of generate_hierarchical_codebook_threaded (enc.h:2218-2290).
+// A training vector is (low rgb, high rgb)/255 of the block's ETC1S colours, identical for both sub-blocks, weight 1 each. The
+// reference de-duplicates them in a std::map (ascending lexicographic float order); the floats are monotone in the 8-bit colours,
+// so we sort integer keys instead and materialise only the distinct vectors.
+bool etc1s_frontend::init_endpoint_training_vectors() {
+    const uint32_t n = m_total_blocks;
+    // counting sort of the blocks by their 18-bit (colour555, inten) code: stable, so every bucket lists its blocks ascending
+    std::vector<uint32_t> code(n), count((1u << 18) + 1, 0);
+    for (uint32_t b = 0; b < n; b++) {
+        const etc1s_header h = header_of(m_etc1_blocks_etc1s[b]);
+        code[b] = h.r | (h.g << 5) | (h.b << 10) | (h.inten << 15);
+        count[code[b] + 1]++;
+    }
+    for (uint32_t c = 0; c < (1u << 18); c++) count[c + 1] += count[c];
+    std::vector<uint32_t> sorted_blocks(n), cursor(count.begin(), count.end() - 1);
+    for (uint32_t b = 0; b < n; b++) sorted_blocks[cursor[code[b]]++] = b;
+
+    struct distinct { uint64_t key; uint32_t code; };
+    std::vector<distinct> codes;
+    for (uint32_t c = 0; c < (1u << 18); c++) {
+        if (count[c + 1] == count[c]) continue;
+        const int r = scale5(c & 31), g = scale5((c >> 5) & 31), bl = scale5((c >> 10) & 31), d = kIntenB[c >> 15];
+        // etc_block::get_block_low_high_colors (etc.h:543-570): selector 0 and selector 3 colours
+        const uint64_t key = ((uint64_t)clamp255(r - d) << 40) | ((uint64_t)clamp255(g - d) << 32) | ((uint64_t)clamp255(bl - d) << 24) |
+                             ((uint64_t)clamp255(r + d) << 16) | ((uint64_t)clamp255(g + d) << 8) | (uint64_t)clamp255(bl + d);
+        codes.push_back(distinct{key, c});
+    }
+    std::sort(codes.begin(), codes.end(), [](const distinct& a, const distinct& b) { return a.key < b.key || (a.key == b.key && a.code < b.code); });
+
+    m_endpoint_unique_rows.clear(); m_endpoint_unique_weights.clear(); m_endpoint_unique_groups.clear();
+    for (size_t i = 0; i < codes.size();) {
+        size_t j = i + 1;
+        while (j < codes.size() && codes[j].key == codes[i].key) j++;
+        // blocks of all codes that decode to this vector, ascending block order
+        std::vector<uint32_t> blocks;
+        for (size_t k = i; k < j; k++) {
+            const uint32_t c = codes[k].code;
+            const size_t mid = blocks.size();
+            blocks.insert(blocks.end(), sorted_blocks.begin() + count[c], sorted_blocks.begin() + count[c + 1]);
+            if (mid) std::inplace_merge(blocks.begin(), blocks.begin() + mid, blocks.end());
+        }
+        std::vector<uint32_t> group(blocks.size() * 2);
+        for (size_t k = 0; k < blocks.size(); k++) { group[k * 2] = blocks[k] * 2; group[k * 2 + 1] = blocks[k] * 2 + 1; }
+        const uint64_t key = codes[i].key;
+        for (int k = 5; k >= 0; k--) m_endpoint_unique_rows.push_back((float)(int)((key >> (8 * k)) & 255) * (1.0f / 255.0f)); // frontend.cpp:846-851
+        m_endpoint_unique_weights.push_back((uint64_t)blocks.size() * 2);
+        m_endpoint_unique_groups.push_back(std::move(group));
+        i = j;
+    }
+    return true;
+}
+
+// frontend.cpp:868-944
+bool etc1s_frontend::generate_endpoint_clusters() {
+    const uint32_t parent_size = (m_params.m_max_endpoint_clusters >= 256) ? kEndpointParentCodebookSize : 0;
+    if (!hierarchical_codebook<6>(m_endpoint_unique_rows, m_endpoint_unique_weights, m_endpoint_unique_groups, m_params.m_max_endpoint_clusters,
+                                  m_use_hierarchical_endpoint_codebooks ? parent_size : 0, m_endpoint_clusters, m_endpoint_parent_clusters))
+        return fail("endpoint TSVQ failed");
+    if (m_use_hierarchical_endpoint_codebooks) {
+        if (m_endpoint_parent_clusters.empty()) {
+            m_endpoint_parent_clusters.resize(1);
+            for (uint32_t i = 0; i < m_total_blocks; i++) { m_endpoint_parent_clusters[0].push_back(i * 2); m_endpoint_parent_clusters[0].push_back(i * 2 + 1); }
+        }
+        m_block_parent_endpoint_cluster.assign(m_total_blocks, 0xFF);
+        for (size_t p = 0; p < m_endpoint_parent_clusters.size(); p++)
+            for (uint32_t tv : m_endpoint_parent_clusters[p]) m_block_parent_endpoint_cluster[tv >> 1] = (uint8_t)p;
+    }
+    return true;
+}
+
+// frontend.cpp:947-968
+void etc1s_frontend::generate_block_endpoint_clusters() {
+    m_block_endpoint_cluster.resize(m_total_blocks);
+    for (size_t ci = 0; ci < m_endpoint_clusters.size(); ci++)
+        for (uint32_t tv : m_endpoint_clusters[ci]) m_block_endpoint_cluster[tv >> 1] = (uint32_t)ci;
+}
+
+// frontend.cpp:971-1003. The reference collects one entry per block and then sorts + uniques each parent's list; the result is
+// "the ascending set of clusters that own at least one block of this parent", which a membership table gives in O(blocks).
+void etc1s_frontend::compute_endpoint_clusters_within_each_parent_cluster() {
+    generate_block_endpoint_clusters();
+    const size_t parents = m_endpoint_parent_clusters.size(), clusters = m_endpoint_clusters.size();
+    std::vector<uint8_t> member(parents * clusters, 0);
+    for (uint32_t b = 0; b < m_total_blocks; b++) member[(size_t)m_block_parent_endpoint_cluster[b] * clusters + m_block_endpoint_cluster[b]] = 1;
+    m_endpoint_clusters_within_each_parent_cluster.assign(parents, {});
+    for (size_t p = 0; p < parents; p++)
+        for (size_t c = 0; c < clusters; c++)
+            if (member[p * clusters + c]) m_endpoint_clusters_within_each_parent_cluster[p].push_back((uint32_t)c);
+}
+
+// frontend.cpp:1214-1617 (CPU semantics; the kernel also handles step > 0)
+bool etc1s_frontend::generate_endpoint_codebook(uint32_t step) {
+    const uint32_t k = (uint32_t)m_endpoint_clusters.size();
+    m_endpoint_cluster_etc_params.resize(k);
+    const int quality = m_params.m_compression_level <= 1 ? BU_ETC_QUALITY_MEDIUM : m_params.m_compression_level == 6 ? BU_ETC_QUALITY_UBER : BU_ETC_QUALITY_SLOW; // :1530-1533
+    csr lists; lists.build(m_endpoint_clusters);
+    std::vector<uint8_t> prm(k * 4ull), valid(k);
+    std::vector<uint64_t> err(k);
+    for (uint32_t i = 0; i < k; i++) {
+        const endpoint_params& e = m_endpoint_cluster_etc_params[i];
+        prm[i * 4] = e.r; prm[i * 4 + 1] = e.g; prm[i * 4 + 2] = e.b; prm[i * 4 + 3] = e.inten; valid[i] = e.valid; err[i] = e.color_error;
+    }
+    device_state& d = *m_dev;
+    if (!d.upload(d.offsets, lists.offsets.data(), lists.offsets.size()) || !d.upload(d.indices, lists.indices.data(), lists.indices.size()) ||
+        !d.upload(d.params, prm.data(), prm.size()) || !d.upload(d.err, err.data(), err.size()) || !d.upload(d.valid, valid.data(), valid.size()))
+        return fail("upload endpoint clusters");
+    if (!bu_hip_k_generate_endpoint_codebook(d.ctx, d.d_pixels, k, lists.offsets.data(), (const uint32_t*)d.offsets.p, (const uint32_t*)d.indices.p, quality,
+                                             m_params.m_perceptual, step, (uint8_t*)d.params.p, (uint64_t*)d.err.p, (uint8_t*)d.valid.p))
+        return fail("bu_hip_k_generate_endpoint_codebook");
+    if (!d.download(prm.data(), d.params, prm.size()) || !d.download(err.data(), d.err, err.size()) || !d.download(valid.data(), d.valid, valid.size()))
+        return fail("download endpoint codebook");
+    for (uint32_t i = 0; i < k; i++) {
+        endpoint_params& e = m_endpoint_cluster_etc_params[i];
+        e.r = prm[i * 4]; e.g = prm[i * 4 + 1]; e.b = prm[i * 4 + 2]; e.inten = prm[i * 4 + 3]; e.valid = valid[i] != 0; e.color_error = err[i];
+    }
+    return true;
+}
+
+// frontend.cpp:1648-1945
+bool etc1s_frontend::refine_endpoint_clusterization(uint32_t* total_reassigned) {
+    if (m_use_hierarchical_endpoint_codebooks) compute_endpoint_clusters_within_each_parent_cluster();
+    const uint32_t n = m_total_blocks, k = (uint32_t)m_endpoint_clusters.size();
+    std::vector<uint32_t> block_cluster(n);
+    for (uint32_t ci = 0; ci < k; ci++)
+        for (uint32_t tv : m_endpoint_clusters[ci]) block_cluster[tv >> 1] = ci;
+    std::vector<uint8_t> prm(k * 4ull);
+    for (uint32_t i = 0; i < k; i++) {
+        const endpoint_params& e = m_endpoint_cluster_etc_params[i];
+        prm[i * 4] = e.r; prm[i * 4 + 1] = e.g; prm[i * 4 + 2] = e.b; prm[i * 4 + 3] = e.inten;
+    }
+    device_state& d = *m_dev;
+    uint32_t n_parents = 0;
+    if (m_use_hierarchical_endpoint_codebooks) {
+        csr cand; cand.build(m_endpoint_clusters_within_each_parent_cluster);
+        n_parents = (uint32_t)m_endpoint_clusters_within_each_parent_cluster.size();
+        if (!d.upload(d.cand_offsets, cand.offsets.data(), cand.offsets.size()) || !d.upload(d.cand_indices, cand.indices.data(), cand.indices.size()) ||
+            !d.upload(d.block_parent, m_block_parent_endpoint_cluster.data(), n))
+            return fail("upload parent lists");
+    }
+    if (!d.upload(d.block_cluster, block_cluster.data(), n) || !d.upload(d.params, prm.data(), prm.size()) || !d.reserve(d.out_u32, (size_t)n * 4)) return fail("upload refine inputs");
+    if (!bu_hip_k_refine_endpoint_clusterization(d.ctx, d.d_pixels, n, (const uint32_t*)d.block_cluster.p, (const uint8_t*)d.params.p, k, n_parents,
+                                                 (const uint32_t*)d.cand_offsets.p, (const uint32_t*)d.cand_indices.p, (const uint8_t*)d.block_parent.p,
+                                                 m_params.m_perceptual, (uint32_t*)d.out_u32.p))
+        return fail("bu_hip_k_refine_endpoint_clusterization");
+    std::vector<uint32_t> best(n);
+    if (!d.download(best.data(), d.out_u32, n)) return fail("download refine result");
+
+    // frontend.cpp:1921-1942: rebuild the cluster lists in block order (empty clusters stay, they are removed by eliminate_...)
+    std::vector<uint32_t> sizes(k, 0);
+    uint32_t moved = 0;
+    for (uint32_t b = 0; b < n; b++) { sizes[best[b]] += 2; moved += best[b] != block_cluster[b]; }
+    std::vector<std::vector<uint32_t>> fresh(k);
+    for (uint32_t ci = 0; ci < k; ci++) fresh[ci].reserve(sizes[ci]);
+    for (uint32_t b = 0; b < n; b++) { fresh[best[b]].push_back(b * 2); fresh[best[b]].push_back(b * 2 + 1); }
+    m_endpoint_clusters.swap(fresh);
+    if (total_reassigned) *total_reassigned = moved;
+    return true;
+}
+
+// frontend.cpp:1947-2012. The ordering comes from indirect_sort = std::sort over indices with operator< on the parameters
+// (frontend.h:248-267): (r, g, b, a=255) of the colour, then the (all-zero) second colour, then inten. std::sort is not stable,
+// so we call the very same algorithm with an equivalent comparator to get the same permutation among equal keys.
+void etc1s_frontend::eliminate_redundant_or_empty_endpoint_clusters() {
+    const uint32_t k = (uint32_t)m_endpoint_clusters.size();
+    std::vector<uint32_t> order(k);
+    std::iota(order.begin(), order.end(), 0u);
+    const std::vector<endpoint_params>& P = m_endpoint_cluster_etc_params;
+    auto key = [&](uint32_t i) { return ((uint32_t)P[i].r << 24) | ((uint32_t)P[i].g << 16) | ((uint32_t)P[i].b << 8) | P[i].inten; };
+    std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return key(a) < key(b); });
+
+    std::vector<std::vector<uint32_t>> clusters;
+    std::vector<endpoint_params> params;
+    for (uint32_t i = 0; i < k;) {
+        const uint32_t ci = order[i];
+        if (m_endpoint_clusters[ci].empty()) { i++; continue; }
+        uint32_t j = i + 1;
+        while (j < k && key(order[j]) == key(ci)) j++;
+        clusters.push_back(std::move(m_endpoint_clusters[ci]));
+        params.push_back(P[ci]);
+        for (uint32_t t = i + 1; t < j; t++) {
+            const std::vector<uint32_t>& src = m_endpoint_clusters[order[t]];
+            clusters.back().insert(clusters.back().end(), src.begin(), src.end());
+        }
+        i = j;
+    }
+    m_endpoint_clusters.swap(clusters);
+    m_endpoint_cluster_etc_params.swap(params);
+}
+
+// frontend.cpp:2014-2096
+bool etc1s_frontend::create_initial_packed_texture() {
+    const uint32_t n = m_total_blocks, k = (uint32_t)m_endpoint_cluster_etc_params.size();
+    std::vector<uint8_t> prm(k * 4ull);
+    for (uint32_t i = 0; i < k; i++) {
+        const endpoint_params& e = m_endpoint_cluster_etc_params[i];
+        prm[i * 4] = e.r; prm[i * 4 + 1] = e.g; prm[i * 4 + 2] = e.b; prm[i * 4 + 3] = e.inten;
+    }
+    device_state& d = *m_dev;
+    if (!d.upload(d.params, prm.data(), prm.size()) || !d.upload(d.block_cluster, m_block_endpoint_cluster.data(), n) || !d.reserve(d.enc, (size_t)n * 8)) return fail("upload");
+    if (!bu_hip_k_determine_selectors(d.ctx, d.d_pixels, n, (const uint8_t*)d.params.p, (const uint32_t*)d.block_cluster.p, m_params.m_perceptual, d.enc.p))
+        return fail("bu_hip_k_determine_selectors");
+    m_encoded_blocks.resize(n);
+    if (!d.download(m_encoded_blocks.data(), d.enc, n)) return fail("download encoded blocks");
+    m_orig_encoded_blocks = m_encoded_blocks;
+    return true;
+}
+
+// frontend.cpp:2140-2257: selector training vectors (16 selector values as floats, weight from the endpoint colour spread) +
+// de-duplication + TSVQ. The std::map order of vec16F (enc.h:382) is the numeric order of the 32-bit word holding s(0,0) in
+// its top two bits ... s(3,3) in its bottom two, so the distinct vectors come out of an LSD radix sort of those words.
+bool etc1s_frontend::generate_selector_clusters() {
+    const uint32_t n = m_total_blocks;
+    device_state& d = *m_dev;
+    if (!d.reserve(d.weights, (size_t)n * 8)) return fail("alloc");
+    if (!bu_hip_k_selector_training_vectors(d.ctx, d.enc.p, n, m_params.m_perceptual, nullptr, (uint64_t*)d.weights.p)) return fail("bu_hip_k_selector_training_vectors");
+    std::vector<uint64_t> weights(n);
+    if (!d.download(weights.data(), d.weights, n)) return fail("download selector weights");
+
+    std::vector<uint32_t> keys(n), idx(n), keys2(n), idx2(n);
+    for (uint32_t b = 0; b < n; b++) {
+        const uint32_t lo = raw_selector_bits(m_encoded_blocks[b]);
+        uint32_t key = 0;
+        for (uint32_t i = 0; i < 16; i++) key = (key << 2) | selector_of(lo, i & 3, i >> 2);
+        keys[b] = key; idx[b] = b;
+    }
+    for (int pass = 0; pass < 4; pass++) { // stable LSD radix sort, 8 bits per pass
+        uint32_t hist[257] = {0};
+        const int sh = pass * 8;
+        for (uint32_t i = 0; i < n; i++) hist[((keys[i] >> sh) & 255) + 1]++;
+        for (int i = 0; i < 256; i++) hist[i + 1] += hist[i];
+        for (uint32_t i = 0; i < n; i++) { const uint32_t p = hist[(keys[i] >> sh) & 255]++; keys2[p] = keys[i]; idx2[p] = idx[i]; }
+        keys.swap(keys2); idx.swap(idx2);
+    }
+    std::vector<float> rows; std::vector<uint64_t> uw; std::vector<std::vector<uint32_t>> groups;
+    for (uint32_t i = 0; i < n;) {
+        uint32_t j = i; uint64_t w = 0;
+        while (j < n && keys[j] == keys[i]) { w += weights[idx[j]]; j++; }
+        for (int s = 15; s >= 0; s--) rows.push_back((float)((keys[i] >> (2 * s)) & 3u));
+        uw.push_back(w);
+        groups.emplace_back(idx.begin() + i, idx.begin() + j);
+        i = j;
+    }
+    const uint32_t parent_default = (m_params.m_compression_level <= 1) ? kSelectorParentCodebookSizeLevel01 : kSelectorParentCodebookSizeDefault;
+    const uint32_t parent_size = (m_params.m_max_selector_clusters >= 256) ? parent_default : 0;
+    if (!hierarchical_codebook<16>(rows, uw, groups, m_params.m_max_selector_clusters, m_use_hierarchical_selector_codebooks ? parent_size : 0,
+                                   m_selector_cluster_block_indices, m_selector_parent_cluster_block_indices))
+        return fail("selector TSVQ failed");
+    if (m_use_hierarchical_selector_codebooks) {
+        if (m_selector_parent_cluster_block_indices.empty()) {
+            m_selector_parent_cluster_block_indices.resize(1);
+            for (uint32_t i = 0; i < n; i++) m_selector_parent_cluster_block_indices[0].push_back(i);
+        }
+        m_block_parent_selector_cluster.assign(n, 0xFF);
+        for (size_t p = 0; p < m_selector_parent_cluster_block_indices.size(); p++)
+            for (uint32_t b : m_selector_parent_cluster_block_indices[p]) m_block_parent_selector_cluster[b] = (uint8_t)p;
+    }
+    return true;
+}
+
+// frontend.cpp:2098-2138
+void etc1s_frontend::compute_selector_clusters_within_each_parent_cluster() {
+    const size_t parents = m_selector_parent_cluster_block_indices.size(), clusters = m_selector_cluster_block_indices.size();
+    std::vector<uint32_t> block_cluster(m_total_blocks, 0);
+    for (size_t ci = 0; ci < clusters; ci++)
+        for (uint32_t b : m_selector_cluster_block_indices[ci]) block_cluster[b] = (uint32_t)ci;
+    std::vector<uint8_t> member(parents * clusters, 0);
+    for (uint32_t b = 0; b < m_total_blocks; b++) member[(size_t)m_block_parent_selector_cluster[b] * clusters + block_cluster[b]] = 1;
+    m_selector_clusters_within_each_parent_cluster.assign(parents, {});
+    for (size_t p = 0; p < parents; p++)
+        for (size_t c = 0; c < clusters; c++)
+            if (member[p * clusters + c]) m_selector_clusters_within_each_parent_cluster[p].push_back((uint32_t)c);
+}
+
+// frontend.cpp:2259-2354
+bool etc1s_frontend::create_optimized_selector_codebook(uint32_t /*iter*/) {
+    const uint32_t k = (uint32_t)m_selector_cluster_block_indices.size();
+    m_optimized_cluster_selectors.resize(k, bu_etc_block{});
+    csr lists; lists.build(m_selector_cluster_block_indices);
+    device_state& d = *m_dev;
+    if (!d.upload(d.offsets, lists.offsets.data(), lists.offsets.size()) || !d.upload(d.indices, lists.indices.data(), lists.indices.size()) ||
+        !d.upload(d.sel_blocks, m_optimized_cluster_selectors.data(), k))
+        return fail("upload selector clusters");
+    if (!bu_hip_k_create_optimized_selector_codebook(d.ctx, d.d_pixels, d.enc.p, k, (const uint32_t*)d.offsets.p, (const uint32_t*)d.indices.p, m_params.m_perceptual, d.sel_blocks.p))
+        return fail("bu_hip_k_create_optimized_selector_codebook");
+    if (!d.download(m_optimized_cluster_selectors.data(), d.sel_blocks, k)) return fail("download selector codebook");
+    return true;
+}
+
+// frontend.cpp:2397-2715
+bool etc1s_frontend::find_optimal_selector_clusters_for_each_block() {
+    const uint32_t n = m_total_blocks, k = (uint32_t)m_optimized_cluster_selectors.size();
+    m_block_selector_cluster_index.resize(n);
+    if (m_params.m_compression_level == 0) {
+        // frontend.cpp:2420-2439: blocks stay in their TSVQ cluster and just take its optimised selectors
+        for (uint32_t ci = 0; ci < m_selector_cluster_block_indices.size(); ci++) {
+            const uint32_t bits = raw_selector_bits(m_optimized_cluster_selectors[ci]);
+            for (uint32_t b : m_selector_cluster_block_indices[ci]) {
+                m_block_selector_cluster_index[b] = ci;
+                store_be64(m_encoded_blocks[b], (load_be64(m_encoded_blocks[b]) & ~0xFFFFFFFFull) | bits);
+            }
+        }
+        return true;
+    }
+    device_state& d = *m_dev;
+    uint32_t n_parents = 0;
+    if (m_use_hierarchical_selector_codebooks) {
+        csr cand; cand.build(m_selector_clusters_within_each_parent_cluster);
+        n_parents = (uint32_t)m_selector_clusters_within_each_parent_cluster.size();
+        if (!d.upload(d.cand_offsets, cand.offsets.data(), cand.offsets.size()) || !d.upload(d.cand_indices, cand.indices.data(), cand.indices.size()) ||
+            !d.upload(d.block_parent, m_block_parent_selector_cluster.data(), n))
+            return fail("upload selector parent lists");
+    }
+    if (!d.upload(d.sel_blocks, m_optimized_cluster_selectors.data(), k) || !d.upload(d.enc, m_encoded_blocks.data(), n) || !d.reserve(d.out_u32, (size_t)n * 4)) return fail("upload fosc inputs");
+    if (!bu_hip_k_find_optimal_selector_clusters(d.ctx, d.d_pixels, d.enc.p, n, d.sel_blocks.p, k, n_parents, (const uint32_t*)d.cand_offsets.p,
+                                                 (const uint32_t*)d.cand_indices.p, (const uint8_t*)d.block_parent.p, m_params.m_perceptual, kFoscJobSize, (uint32_t*)d.out_u32.p))
+        return fail("bu_hip_k_find_optimal_selector_clusters");
+    if (!d.download(m_block_selector_cluster_index.data(), d.out_u32, n) || !d.download(m_encoded_blocks.data(), d.enc, n)) return fail("download fosc result");
+    // frontend.cpp:2696-2708
+    std::vector<uint32_t> sizes(m_selector_cluster_block_indices.size(), 0);
+    for (uint32_t b = 0; b < n; b++) sizes[m_block_selector_cluster_index[b]]++;
+    for (size_t ci = 0; ci < m_selector_cluster_block_indices.size(); ci++) { m_selector_cluster_block_indices[ci].clear(); m_selector_cluster_block_indices[ci].reserve(sizes[ci]); }
+    for (uint32_t b = 0; b < n; b++) m_selector_cluster_block_indices[m_block_selector_cluster_index[b]].push_back(b);
+    return true;
+}
+
+// frontend.cpp:554-654: guarantee the four flat selector patterns exist. Pure codebook bookkeeping, except that a block whose
+// pre-quantisation selectors were flat is moved to the new entry only if that lowers its error -- evaluated here on the few
+// candidate tiles (etc_block::evaluate_etc1_error, etc.cpp:640-700).
+bool etc1s_frontend::introduce_special_selector_clusters() {
+    const uint32_t n = m_total_blocks;
+    const uint32_t initial_clusters = (uint32_t)m_selector_cluster_block_indices.size();
+    std::vector<uint8_t> relocated;
+    std::vector<bu_pixel_block> tiles; // fetched lazily, only when a candidate exists and the caller gave us no host copy
+    auto tile = [&](uint32_t b) -> const bu_pixel_block* {
+        if (m_params.m_pSource_blocks) return &m_params.m_pSource_blocks[b];
+        if (tiles.empty()) {
+            tiles.resize(n);
+            if (!bu_hip_memcpy_d2h(m_dev->ctx, tiles.data(), m_dev->d_pixels, (size_t)n * sizeof(bu_pixel_block))) return nullptr;
+        }
+        return &tiles[b];
+    };
+    auto block_error = [&](const bu_pixel_block& px, const endpoint_params& e, uint32_t bits) {
+        int colors[4][3];
+        const int r = scale5(e.r), g = scale5(e.g), bl = scale5(e.b);
+        for (int s = 0; s < 4; s++) { const int yd = kInten[e.inten][s]; colors[s][0] = clamp255(r + yd); colors[s][1] = clamp255(g + yd); colors[s][2] = clamp255(bl + yd); }
+        uint64_t total = 0;
+        for (uint32_t y = 0; y < 4; y++)
+            for (uint32_t x = 0; x < 4; x++) total += color_distance(m_params.m_perceptual, px.m_pixels[y * 4 + x], colors[selector_of(bits, x, y)]);
+        return total;
+    };
+    uint32_t total_relocated = 0;
+    for (uint32_t sel = 0; sel < 4; sel++) {
+        const uint32_t flat = flat_selector_bits(sel);
+        bool present = false;
+        for (const bu_etc_block& s : m_optimized_cluster_selectors) if (raw_selector_bits(s) == flat) { present = true; break; }
+        if (present) continue;
+        const uint32_t new_index = (uint32_t)m_optimized_cluster_selectors.size();
+        bu_etc_block nb{}; store_be64(nb, flat);
+        m_optimized_cluster_selectors.push_back(nb);
+        if (m_selector_cluster_block_indices.size() <= new_index) m_selector_cluster_block_indices.resize(new_index + 1);
+        for (uint32_t b = 0; b < n; b++) {
+            if (raw_selector_bits(m_orig_encoded_blocks[b]) != flat) continue;
+            const bu_pixel_block* px = tile(b);
+            if (!px) return fail("download tiles");
+            const endpoint_params& e = m_endpoint_cluster_etc_params[m_block_endpoint_cluster[b]];
+            const uint32_t cur_bits = raw_selector_bits(m_optimized_cluster_selectors[m_block_selector_cluster_index[b]]);
+            if (block_error(*px, e, flat) >= block_error(*px, e, cur_bits)) continue;
+            m_block_selector_cluster_index[b] = new_index;
+            m_selector_cluster_block_indices[new_index].push_back(b);
+            if (relocated.empty()) relocated.assign(n, 0);
+            relocated[b] = 1;
+            total_relocated++;
+            store_be64(m_encoded_blocks[b], (load_be64(m_encoded_blocks[b]) & ~0xFFFFFFFFull) | flat);
+        }
+    }
+    if (total_relocated)
+        for (uint32_t ci = 0; ci < initial_clusters; ci++) {
+            std::vector<uint32_t>& v = m_selector_cluster_block_indices[ci];
+            v.erase(std::remove_if(v.begin(), v.end(), [&](uint32_t b) { return relocated[b] != 0; }), v.end());
+        }
+    return true;
+}
+
+// frontend.cpp:657-731: drop unused entries and merge entries with identical selector bits (first occurrence keeps its place)
+void etc1s_frontend::optimize_selector_codebook() {
+    const uint32_t k = (uint32_t)m_optimized_cluster_selectors.size();
+    std::vector<uint8_t> used(k, 0);
+    for (uint32_t b = 0; b < m_total_blocks; b++) used[m_block_selector_cluster_index[b]] = 1;
+    std::vector<int32_t> old_to_new(k, -1);
+    std::vector<uint32_t> new_to_old;
+    std::vector<std::pair<uint32_t, uint32_t>> seen; // (bits, new index), kept sorted
+    for (uint32_t i = 0; i < k; i++) {
+        if (!used[i]) continue;
+        const uint32_t bits = raw_selector_bits(m_optimized_cluster_selectors[i]);
+        auto it = std::lower_bound(seen.begin(), seen.end(), std::make_pair(bits, 0u));
+        if (it != seen.end() && it->first == bits) { old_to_new[i] = (int32_t)it->second; continue; }
+        old_to_new[i] = (int32_t)new_to_old.size();
+        seen.insert(it, std::make_pair(bits, (uint32_t)new_to_old.size()));
+        new_to_old.push_back(i);
+    }
+    for (uint32_t b = 0; b < m_total_blocks; b++) m_block_selector_cluster_index[b] = (uint32_t)old_to_new[m_block_selector_cluster_index[b]];
+    std::vector<bu_etc_block> sels(new_to_old.size());
+    for (size_t i = 0; i < new_to_old.size(); i++) sels[i] = m_optimized_cluster_selectors[new_to_old[i]];
+    std::vector<std::vector<uint32_t>> lists(new_to_old.size());
+    for (uint32_t b = 0; b < m_total_blocks; b++) lists[m_block_selector_cluster_index[b]].push_back(b);
+    m_optimized_cluster_selectors.swap(sels);
+    m_selector_cluster_block_indices.swap(lists);
+    for (auto& l : m_selector_clusters_within_each_parent_cluster)
+        for (uint32_t& c : l) c = (uint32_t)old_to_new[c];
+}
+
+// frontend.cpp:2980-2992
+void etc1s_frontend::finalize() {
+    for (uint32_t b = 0; b < m_total_blocks; b++) m_endpoint_cluster_etc_params[m_block_endpoint_cluster[b]].color_used = true;
+}
+
+} // namespace bu

@@ -1,0 +1,135 @@
+// etc1s_frontend.h -- host-side mirror of the reference's basisu_frontend (encoder/basisu_frontend.h:44-381) on top of the
+// device-resident C ABI (include/basisu_hip.h, section 2).
+//
+// Same public surface (params, init, compress, the getters the backend uses) and the same stage methods in the same order as
+// basisu_frontend::compress() (frontend.cpp:159-316). Every stage that touches pixels runs as a HIP kernel on the resident
+// 4x4 tiles; what stays on the host is what the reference keeps serial and order-dependent: the TSVQ tree builds (tsvq.h) and
+// the cluster-list bookkeeping between stages. There is no CPU implementation of any kernel stage in here: a failing device
+// call fails the frontend.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../../include/basisu_hip.h"
+
+namespace bu {
+
+struct endpoint_params {   // = basisu_frontend::endpoint_cluster_etc_params reduced to what ETC1S uses (frontend.h:202-268)
+    uint8_t r = 0, g = 0, b = 0, inten = 0;
+    uint64_t color_error = 0;
+    bool valid = false;
+    bool color_used = false;
+};
+
+class etc1s_frontend {
+public:
+    enum { cMaxEndpointClusters = 16128, cMaxSelectorClusters = 16128 }; // frontend.h:66-71
+
+    struct params {                       // = basisu_frontend::params (frontend.h:73-115)
+        uint32_t m_num_source_blocks = 0;
+        const bu_pixel_block* m_pSource_blocks = nullptr; // host tiles; uploaded once unless m_pDevice_blocks is given
+        const void* m_pDevice_blocks = nullptr;           // optional: tiles already resident in HBM (not owned)
+        uint32_t m_max_endpoint_clusters = 256;
+        uint32_t m_max_selector_clusters = 256;
+        uint32_t m_compression_level = 2;                 // BASISU_DEFAULT_ETC1S_COMPRESSION_LEVEL
+        bool m_perceptual = true;
+        bool m_validate = false;
+        bool m_disable_hierarchical_endpoint_codebooks = false;
+        bu_hip_context* m_pHIP_context = nullptr;         // = m_pOpenCL_context; REQUIRED
+    };
+
+    etc1s_frontend();
+    ~etc1s_frontend();
+    etc1s_frontend(const etc1s_frontend&) = delete;
+    etc1s_frontend& operator=(const etc1s_frontend&) = delete;
+
+    bool init(const params& p);
+    bool compress();
+    const std::string& error() const { return m_error; }
+
+    // ---- getters with the reference's names (frontend.h:119-156)
+    const params& get_params() const { return m_params; }
+    uint32_t get_total_output_blocks() const { return (uint32_t)m_encoded_blocks.size(); }
+    const bu_etc_block& get_output_block(uint32_t i) const { return m_encoded_blocks[i]; }
+    const std::vector<bu_etc_block>& get_output_blocks() const { return m_encoded_blocks; }
+    const bu_etc_block& get_etc1s_block(uint32_t i) const { return m_etc1_blocks_etc1s[i]; }
+    uint32_t get_total_endpoint_clusters() const { return (uint32_t)m_endpoint_clusters.size(); }
+    uint32_t get_subblock_endpoint_cluster_index(uint32_t block, uint32_t) const { return m_block_endpoint_cluster[block]; }
+    const endpoint_params& get_endpoint_cluster_params(uint32_t ci) const { return m_endpoint_cluster_etc_params[ci]; }
+    uint32_t get_total_selector_clusters() const { return (uint32_t)m_selector_cluster_block_indices.size(); }
+    uint32_t get_block_selector_cluster_index(uint32_t block) const { return m_block_selector_cluster_index[block]; }
+    const bu_etc_block& get_selector_cluster_selector_bits(uint32_t ci) const { return m_optimized_cluster_selectors[ci]; }
+    const std::vector<uint32_t>& get_selector_cluster_block_indices(uint32_t ci) const { return m_selector_cluster_block_indices[ci]; }
+
+    // ---- stage state, exposed for stage-by-stage parity tests
+    const std::vector<bu_etc_block>& etc1_blocks() const { return m_etc1_blocks_etc1s; }
+    const std::vector<bu_etc_block>& orig_encoded_blocks() const { return m_orig_encoded_blocks; }
+    const std::vector<std::vector<uint32_t>>& endpoint_clusters() const { return m_endpoint_clusters; }
+    const std::vector<std::vector<uint32_t>>& endpoint_parent_clusters() const { return m_endpoint_parent_clusters; }
+    const std::vector<endpoint_params>& endpoint_cluster_params() const { return m_endpoint_cluster_etc_params; }
+    const std::vector<uint32_t>& block_endpoint_clusters() const { return m_block_endpoint_cluster; }
+    const std::vector<std::vector<uint32_t>>& selector_cluster_block_indices() const { return m_selector_cluster_block_indices; }
+    const std::vector<bu_etc_block>& optimized_cluster_selectors() const { return m_optimized_cluster_selectors; }
+    const std::vector<uint32_t>& block_selector_cluster_index() const { return m_block_selector_cluster_index; }
+
+    // wall time of each stage of the last compress(), in call order (name, seconds)
+    struct stage_time { const char* name; double seconds; };
+    const std::vector<stage_time>& stage_times() const { return m_stage_times; }
+
+    // ---- stage methods, same names and order as the reference (frontend.h:346-372); public so tests can single-step
+    bool init_etc1_images();
+    bool init_endpoint_training_vectors();
+    bool generate_endpoint_clusters();
+    bool generate_endpoint_codebook(uint32_t step);
+    bool refine_endpoint_clusterization(uint32_t* total_reassigned);
+    void eliminate_redundant_or_empty_endpoint_clusters();
+    void generate_block_endpoint_clusters();
+    void compute_endpoint_clusters_within_each_parent_cluster();
+    bool create_initial_packed_texture();
+    bool generate_selector_clusters();
+    void compute_selector_clusters_within_each_parent_cluster();
+    bool create_optimized_selector_codebook(uint32_t iter);
+    bool find_optimal_selector_clusters_for_each_block();
+    bool introduce_special_selector_clusters();
+    void optimize_selector_codebook();
+    void finalize();
+
+private:
+    struct device_state;
+    bool fail(const char* what);
+
+    params m_params;
+    std::string m_error;
+    device_state* m_dev = nullptr;
+
+    uint32_t m_total_blocks = 0;
+    bool m_endpoint_refinement = false;
+    bool m_use_hierarchical_endpoint_codebooks = false;
+    bool m_use_hierarchical_selector_codebooks = false;
+    uint32_t m_num_endpoint_codebook_iterations = 1;
+    uint32_t m_num_selector_codebook_iterations = 1;
+
+    std::vector<bu_etc_block> m_encoded_blocks, m_orig_encoded_blocks, m_etc1_blocks_etc1s;
+
+    // endpoint side
+    std::vector<float> m_endpoint_unique_rows;            // distinct (low rgb, high rgb)/255 vectors, ascending
+    std::vector<uint64_t> m_endpoint_unique_weights;
+    std::vector<std::vector<uint32_t>> m_endpoint_unique_groups; // training-vector indices (block*2+s) per distinct vector
+    std::vector<std::vector<uint32_t>> m_endpoint_clusters, m_endpoint_parent_clusters;
+    std::vector<uint8_t> m_block_parent_endpoint_cluster;
+    std::vector<std::vector<uint32_t>> m_endpoint_clusters_within_each_parent_cluster;
+    std::vector<endpoint_params> m_endpoint_cluster_etc_params;
+    std::vector<uint32_t> m_block_endpoint_cluster;
+
+    // selector side
+    std::vector<std::vector<uint32_t>> m_selector_cluster_block_indices, m_selector_parent_cluster_block_indices;
+    std::vector<bu_etc_block> m_optimized_cluster_selectors;
+    std::vector<uint8_t> m_block_parent_selector_cluster;
+    std::vector<std::vector<uint32_t>> m_selector_clusters_within_each_parent_cluster;
+    std::vector<uint32_t> m_block_selector_cluster_index;
+
+    std::vector<stage_time> m_stage_times;
+};
+
+} // namespace bu

@@ -1,0 +1,167 @@
+// frontend_capi.cpp -- extern "C" wrapper of bu::etc1s_frontend (include/basisu_hip_frontend.h).
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../../include/basisu_hip_frontend.h"
+#include "etc1s_frontend.h"
+#include "tsvq.h"
+
+struct bu_frontend {
+    bu::etc1s_frontend fe;
+    std::string error;
+};
+
+namespace {
+
+template <typename T> uint64_t emit(const std::vector<T>& v, void* buf, uint64_t cap) {
+    const uint64_t need = (uint64_t)v.size() * sizeof(T);
+    if (buf && cap >= need && need) std::memcpy(buf, v.data(), need);
+    return need;
+}
+std::vector<uint32_t> csr_blob(const std::vector<std::vector<uint32_t>>& lists) {
+    std::vector<uint32_t> out;
+    out.push_back((uint32_t)lists.size());
+    uint32_t ofs = 0;
+    for (const auto& l : lists) { out.push_back(ofs); ofs += (uint32_t)l.size(); }
+    out.push_back(ofs);
+    for (const auto& l : lists) out.insert(out.end(), l.begin(), l.end());
+    return out;
+}
+float clampf(float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); }
+template <typename T> T clampt(T v, T lo, T hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+} // namespace
+
+extern "C" {
+
+bu_frontend* bu_frontend_create(void) { return new (std::nothrow) bu_frontend(); }
+void bu_frontend_destroy(bu_frontend* f) { delete f; }
+const char* bu_frontend_error(const bu_frontend* f) { return f ? f->fe.error().c_str() : "null frontend"; }
+
+int bu_frontend_init(bu_frontend* f, bu_hip_context* ctx, const bu_pixel_block* h_blocks, const void* d_blocks, uint32_t n_blocks,
+                     uint32_t max_ep, uint32_t max_sel, uint32_t level, int perceptual) {
+    if (!f) return 0;
+    bu::etc1s_frontend::params p;
+    p.m_num_source_blocks = n_blocks;
+    p.m_pSource_blocks = h_blocks;
+    p.m_pDevice_blocks = d_blocks;
+    p.m_max_endpoint_clusters = max_ep;
+    p.m_max_selector_clusters = max_sel;
+    p.m_compression_level = level;
+    p.m_perceptual = perceptual != 0;
+    p.m_pHIP_context = ctx;
+    return f->fe.init(p) ? 1 : 0;
+}
+
+int bu_frontend_compress(bu_frontend* f) { return (f && f->fe.compress()) ? 1 : 0; }
+
+int bu_frontend_call(bu_frontend* f, const char* stage, uint32_t arg) {
+    if (!f) return 0;
+    const std::string n(stage);
+    bu::etc1s_frontend& fe = f->fe;
+    if (n == "compress") return fe.compress();
+    if (n == "init_etc1_images") return fe.init_etc1_images();
+    if (n == "init_endpoint_training_vectors") return fe.init_endpoint_training_vectors();
+    if (n == "generate_endpoint_clusters") return fe.generate_endpoint_clusters();
+    if (n == "generate_endpoint_codebook") return fe.generate_endpoint_codebook(arg);
+    if (n == "refine_endpoint_clusterization") { uint32_t moved = 0; return fe.refine_endpoint_clusterization(&moved); }
+    if (n == "eliminate_redundant_or_empty_endpoint_clusters") { fe.eliminate_redundant_or_empty_endpoint_clusters(); return 1; }
+    if (n == "generate_block_endpoint_clusters") { fe.generate_block_endpoint_clusters(); return 1; }
+    if (n == "create_initial_packed_texture") return fe.create_initial_packed_texture();
+    if (n == "generate_selector_clusters") return fe.generate_selector_clusters();
+    if (n == "compute_selector_clusters_within_each_parent_cluster") { fe.compute_selector_clusters_within_each_parent_cluster(); return 1; }
+    if (n == "create_optimized_selector_codebook") return fe.create_optimized_selector_codebook(arg);
+    if (n == "find_optimal_selector_clusters_for_each_block") return fe.find_optimal_selector_clusters_for_each_block();
+    if (n == "introduce_special_selector_clusters") return fe.introduce_special_selector_clusters();
+    if (n == "optimize_selector_codebook") { fe.optimize_selector_codebook(); return 1; }
+    if (n == "finalize") { fe.finalize(); return 1; }
+    return 0;
+}
+
+uint64_t bu_frontend_get(bu_frontend* f, const char* name, void* buf, uint64_t cap) {
+    if (!f) return ~0ull;
+    const std::string n(name);
+    const bu::etc1s_frontend& fe = f->fe;
+    if (n == "etc1_blocks") return emit(fe.etc1_blocks(), buf, cap);
+    if (n == "encoded_blocks") return emit(fe.get_output_blocks(), buf, cap);
+    if (n == "orig_encoded_blocks") return emit(fe.orig_encoded_blocks(), buf, cap);
+    if (n == "optimized_cluster_selectors") return emit(fe.optimized_cluster_selectors(), buf, cap);
+    if (n == "block_selector_cluster_index") return emit(fe.block_selector_cluster_index(), buf, cap);
+    if (n == "block_endpoint_clusters_indices") return emit(fe.block_endpoint_clusters(), buf, cap);
+    if (n == "endpoint_clusters") return emit(csr_blob(fe.endpoint_clusters()), buf, cap);
+    if (n == "endpoint_parent_clusters") return emit(csr_blob(fe.endpoint_parent_clusters()), buf, cap);
+    if (n == "selector_cluster_block_indices") return emit(csr_blob(fe.selector_cluster_block_indices()), buf, cap);
+    if (n == "endpoint_cluster_etc_params") {
+        const auto& P = fe.endpoint_cluster_params();
+        std::vector<uint8_t> v(P.size() * 16, 0);
+        for (size_t i = 0; i < P.size(); i++) {
+            v[i * 16] = P[i].r; v[i * 16 + 1] = P[i].g; v[i * 16 + 2] = P[i].b; v[i * 16 + 3] = P[i].inten; v[i * 16 + 4] = P[i].valid ? 1 : 0;
+            std::memcpy(&v[i * 16 + 8], &P[i].color_error, 8);
+        }
+        return emit(v, buf, cap);
+    }
+    return ~0ull;
+}
+
+uint32_t bu_frontend_stage_times(const bu_frontend* f, const char** names, double* seconds, uint32_t cap) {
+    if (!f) return 0;
+    const auto& t = f->fe.stage_times();
+    const uint32_t n = (uint32_t)std::min<size_t>(t.size(), cap);
+    for (uint32_t i = 0; i < n; i++) { names[i] = t[i].name; seconds[i] = t[i].seconds; }
+    return (uint32_t)t.size();
+}
+
+// Test hook for the host TSVQ (tsvq.h): rows must be DISTINCT and ascending (the order the reference's std::map yields).
+// Blobs are [n, off_0..off_n, idx...] u32, like bu_frontend_get's cluster lists. Returns 1, 0 on failure, -1 if a blob does not fit.
+int bu_host_tsvq(uint32_t dim, const float* rows, const uint64_t* weights, uint32_t n, uint32_t max_codebook_size, uint32_t max_parent_codebook_size,
+                 uint32_t* out_codebook, uint64_t cap_codebook_words, uint32_t* out_parent, uint64_t cap_parent_words) {
+    std::vector<float> r(rows, rows + (size_t)n * dim);
+    std::vector<uint64_t> w(weights, weights + n);
+    std::vector<std::vector<uint32_t>> groups(n), codebook, parents;
+    for (uint32_t i = 0; i < n; i++) groups[i].push_back(i);
+    bool ok = false;
+    if (dim == 6) ok = bu::hierarchical_codebook<6>(r, w, groups, max_codebook_size, max_parent_codebook_size, codebook, parents);
+    else if (dim == 16) ok = bu::hierarchical_codebook<16>(r, w, groups, max_codebook_size, max_parent_codebook_size, codebook, parents);
+    if (!ok) return 0;
+    const std::vector<uint32_t> a = csr_blob(codebook), b = csr_blob(parents);
+    if (a.size() > cap_codebook_words || b.size() > cap_parent_words) return -1;
+    std::memcpy(out_codebook, a.data(), a.size() * 4);
+    std::memcpy(out_parent, b.data(), b.size() * 4);
+    return 1;
+}
+
+// comp.cpp:3310-3379, float arithmetic in the reference's order
+void bu_etc1s_quality_to_clusters(int quality_level, uint32_t total_blocks, uint32_t* out_ep, uint32_t* out_sel) {
+    const double total_texels = total_blocks * 16.0f;
+    const float quality = clampf(quality_level / 255.0f, 0.0f, 1.0f);
+    const float bits_per_cluster = 14.0f;
+    int max_endpoints = static_cast<int>((1.0f * total_texels) / bits_per_cluster);
+    const float mid = 128.0f / 255.0f;
+    float q = quality;
+    uint32_t endpoint_clusters;
+    if (q <= mid) {
+        q = 0.0f + (0.5f - 0.0f) * powf(q / mid, .65f);
+        max_endpoints = clampt<int>(max_endpoints, 256, 4800);
+        max_endpoints = (int)std::min<uint32_t>((uint32_t)max_endpoints, total_blocks);
+        if (max_endpoints < 64) max_endpoints = 64;
+        endpoint_clusters = clampt<uint32_t>((uint32_t)(.5f + (32.0f + (static_cast<float>(max_endpoints) - 32.0f) * q)), 32, 16128);
+    } else {
+        q = powf((q - mid) / (1.0f - mid), 1.6f);
+        max_endpoints = clampt<int>(max_endpoints, 256, 8192);
+        max_endpoints = (int)std::min<uint32_t>((uint32_t)max_endpoints, total_blocks);
+        if (max_endpoints < 4800) max_endpoints = 4800;
+        endpoint_clusters = clampt<uint32_t>((uint32_t)(.5f + (4800.0f + (static_cast<float>(max_endpoints) - 4800.0f) * q)), 32, 16128);
+    }
+    int max_selectors = static_cast<int>((1.0f * total_texels) / bits_per_cluster);
+    max_selectors = clampt<int>(max_selectors, 256, 16128);
+    max_selectors = (int)std::min<uint32_t>((uint32_t)max_selectors, total_blocks);
+    const float sq = powf(quality, 2.62f);
+    if (max_selectors < 96) max_selectors = 96;
+    const uint32_t selector_clusters = clampt<uint32_t>((uint32_t)(.5f + (96.0f + (static_cast<float>(max_selectors) - 96.0f) * sq)), 8, 16128);
+    *out_ep = endpoint_clusters;
+    *out_sel = selector_clusters;
+}
+
+} // extern "C"

@@ -1,0 +1,117 @@
+"""ctypes binding of libbasisu_frontend.so: the host-side mirror of the reference's basisu_frontend
+(include/basisu_hip_frontend.h -> basis_universal_amd/csrc/host/etc1s_frontend.{h,cpp}).
+
+    ctx = capi.Context()
+    fe = Etc1sFrontend(ctx)
+    fe.init(blocks, max_endpoint_clusters, max_selector_clusters, compression_level=1, perceptual=True)   # basisu_frontend::init
+    fe.compress()                                                                                           # basisu_frontend::compress
+    fe.get("encoded_blocks"), fe.get_csr("endpoint_clusters"), ...
+
+`blocks` is either an (n, 4, 4, 4) uint8 numpy array of 4x4 RGBA tiles (uploaded once) or an int device pointer together with
+n_blocks= (tiles already resident in HBM, e.g. a torch tensor's data_ptr()).
+"""
+import ctypes as C
+import pathlib
+
+import numpy as np
+
+from . import capi
+
+FRONTEND_LIB_PATH = capi.PKG_DIR / "lib" / "libbasisu_frontend.so"
+_vp = C.c_void_p
+_lib = None
+
+
+def load_frontend_library():
+    global _lib
+    if _lib is None:
+        if not FRONTEND_LIB_PATH.exists():
+            raise capi.HipError(f"{FRONTEND_LIB_PATH} is missing: run __graft_entry__.build()")
+        capi.load_library()  # libbasisu_hip.so first (the frontend links against it via $ORIGIN rpath)
+        L = C.CDLL(str(FRONTEND_LIB_PATH))
+        L.bu_frontend_create.restype = _vp
+        L.bu_frontend_destroy.argtypes = [_vp]
+        L.bu_frontend_init.restype = C.c_int
+        L.bu_frontend_init.argtypes = [_vp, _vp, _vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int]
+        L.bu_frontend_compress.restype = C.c_int
+        L.bu_frontend_compress.argtypes = [_vp]
+        L.bu_frontend_call.restype = C.c_int
+        L.bu_frontend_call.argtypes = [_vp, C.c_char_p, C.c_uint32]
+        L.bu_frontend_get.restype = C.c_uint64
+        L.bu_frontend_get.argtypes = [_vp, C.c_char_p, _vp, C.c_uint64]
+        L.bu_frontend_error.restype = C.c_char_p
+        L.bu_frontend_error.argtypes = [_vp]
+        L.bu_frontend_stage_times.restype = C.c_uint32
+        L.bu_frontend_stage_times.argtypes = [_vp, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.c_uint32]
+        L.bu_etc1s_quality_to_clusters.argtypes = [C.c_int, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+        L.bu_host_tsvq.restype = C.c_int
+        L.bu_host_tsvq.argtypes = [C.c_uint32, _vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32, _vp, C.c_uint64, _vp, C.c_uint64]
+        _lib = L
+    return _lib
+
+
+def quality_to_clusters(quality_level, total_blocks):
+    """comp.cpp:3325-3379: ETC1S quality (1..255) -> (max endpoint clusters, max selector clusters)."""
+    ep, sel = C.c_uint32(), C.c_uint32()
+    load_frontend_library().bu_etc1s_quality_to_clusters(int(quality_level), int(total_blocks), C.byref(ep), C.byref(sel))
+    return ep.value, sel.value
+
+
+class Etc1sFrontend:
+    def __init__(self, ctx):
+        self.ctx = ctx
+        self.L = load_frontend_library()
+        self.h = self.L.bu_frontend_create()
+        self._keep = None
+
+    def _check(self, ok, what):
+        if not ok:
+            raise capi.HipError(f"{what} failed: {self.L.bu_frontend_error(self.h).decode()}")
+
+    def init(self, blocks, max_endpoint_clusters, max_selector_clusters, compression_level=1, perceptual=True, n_blocks=None):
+        if isinstance(blocks, np.ndarray):
+            blocks = np.ascontiguousarray(blocks, np.uint8)
+            self._keep = blocks
+            n = blocks.size // 64
+            self._check(self.L.bu_frontend_init(self.h, self.ctx.h, blocks.ctypes.data_as(_vp), None, n, max_endpoint_clusters, max_selector_clusters,
+                                                compression_level, int(perceptual)), "bu_frontend_init")
+        else:
+            self._check(self.L.bu_frontend_init(self.h, self.ctx.h, None, _vp(int(blocks)), int(n_blocks), max_endpoint_clusters, max_selector_clusters,
+                                                compression_level, int(perceptual)), "bu_frontend_init")
+
+    def compress(self):
+        self._check(self.L.bu_frontend_compress(self.h), "bu_frontend_compress")
+
+    def call(self, stage, arg=0):
+        self._check(self.L.bu_frontend_call(self.h, stage.encode(), arg), stage)
+
+    def get(self, name, dtype=np.uint8):
+        need = self.L.bu_frontend_get(self.h, name.encode(), None, 0)
+        if need == 2 ** 64 - 1:
+            raise KeyError(name)
+        buf = np.zeros(need, np.uint8)
+        self.L.bu_frontend_get(self.h, name.encode(), buf.ctypes.data_as(_vp), need)
+        return buf.view(dtype)
+
+    def get_csr(self, name):
+        blob = self.get(name, np.uint32)
+        n = int(blob[0])
+        offs = blob[1:n + 2].copy()
+        return offs, blob[n + 2:n + 2 + int(offs[-1])].copy()
+
+    def stage_times(self):
+        names = (C.c_char_p * 64)()
+        secs = (C.c_double * 64)()
+        n = min(self.L.bu_frontend_stage_times(self.h, names, secs, 64), 64)
+        return [(names[i].decode(), secs[i]) for i in range(n)]
+
+    def close(self):
+        if self.h:
+            self.L.bu_frontend_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

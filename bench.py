@@ -1,0 +1,180 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json metric: ETC1S encoder hot path, Mpixels/s, 4096x4096 synthetic RGBA, -q128 (CLI comp level 1).
+
+A "step" is one full pass of the hot path over one image whose 4x4 tiles are already resident in HBM:
+basisu_frontend::init + compress() (per-block ETC1S fit, endpoint TSVQ + codebook + refinement, selector
+TSVQ + codebook + assignment) -- nothing is skipped or cached between steps. With --gpus N every rank encodes its own image
+(independent objects, like the reference's basis_parallel_compress): weak scaling, no data-path collective.
+
+Prints ONE JSON line (rank 0). Extra objects: "roofline" for the dominant kernel (HIP events on the launch stream, live),
+"cpu_baseline" (the real reference frontend from oracle/_ref when present, else the C oracle, on a bounded sample),
+"stages" (host wall seconds per frontend stage) and "kernels" (device ms per kernel).
+"""
+import argparse
+import json
+import os
+import pathlib
+import sys
+import time
+
+import numpy as np
+
+ROOT = pathlib.Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
+
+HBM_PEAK_GBS = 8000.0  # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
+
+# Algorithmic bytes per 4x4 block of each kernel (one 64 B tile read + the stage's side traffic)
+KERNEL_BYTES_PER_BLOCK = {
+    "encode_etc1s_blocks": 64 + 8,
+    "generate_endpoint_codebook": 64 + 2 * 4,          # tile + two training-vector indices
+    "refine_endpoint_clusterization": 64 + 7 + 4,
+    "determine_selectors": 64 + 4 + 8,
+    "create_optimized_selector_codebook": 64 + 8 + 4,
+    "find_optimal_selector_clusters": 64 + 12 + 4 + 8,
+    "selector_training_vectors": 8 + 8,
+    "endpoint_training_vectors": 8 + 24,
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--size", type=int, default=4096)
+    ap.add_argument("--quality", type=int, default=128)
+    ap.add_argument("--level", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import helpers
+    from basis_universal_amd import capi
+    from basis_universal_amd.etc1s import Etc1sFrontend, quality_to_clusters
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    # ---- synthetic input (SURVEY 8d recipe), tiled on the host once, resident in HBM before the timed region
+    w = h = args.size
+    img = helpers.synth(w, h, 1234 + rank)
+    blocks = helpers.to_pixel_blocks(img)
+    n_blocks = blocks.shape[0]
+    d_blocks = torch.from_numpy(blocks.reshape(n_blocks, 64)).to(dev)
+    max_ep, max_sel = quality_to_clusters(args.quality, n_blocks)
+
+    ctx = capi.Context(local_rank)
+    # run on torch's current stream so that torch.cuda.synchronize()/Events bracket our kernels
+    ctx.check(ctx.lib.set_stream(ctx.h, torch.cuda.current_stream().cuda_stream), "set_stream")
+
+    def step():
+        fe = Etc1sFrontend(ctx)
+        fe.init(d_blocks.data_ptr(), max_ep, max_sel, args.level, True, n_blocks=n_blocks)
+        fe.compress()
+        return fe
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step().close()
+    ctx.profile_enable(True)
+    barrier()
+    t0 = time.perf_counter()
+    stage_acc = {}
+    last = None
+    for _ in range(args.steps):
+        if last is not None:
+            last.close()
+        last = step()
+        for name, s in last.stage_times():
+            stage_acc[name] = stage_acc.get(name, 0.0) + s
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kernels = ctx.profile_read()
+    ctx.profile_enable(False)
+
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        mpix = world * args.steps * (w * h) / 1e6
+        value = mpix / elapsed
+        # ---- roofline of the dominant kernel
+        dom = max(kernels.items(), key=lambda kv: kv[1][0]) if kernels else None
+        roofline = None
+        if dom:
+            name, (ms, launches) = dom
+            avg_s = ms / 1e3 / launches
+            alg_bytes = KERNEL_BYTES_PER_BLOCK.get(name, 64) * n_blocks
+            achieved = alg_bytes / avg_s / 1e9
+            roofline = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                        "avg_launch_ms": round(avg_s * 1e3, 4), "algorithmic_bytes_per_launch": alg_bytes,
+                        "note": "integer-ALU bound kernel: see DESIGN.md for the VALU-side analysis"}
+        final_ep = int(last.get("endpoint_clusters", np.uint32)[0])
+        final_sel = int(last.get("selector_cluster_block_indices", np.uint32)[0])
+        out = {
+            "metric": "encoder Mpixels/s (ETC1S frontend hot path)", "value": round(value, 3), "unit": "Mpixels/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "u8/int32", "data": "synthetic",
+            "config": {"workload": f"{w}x{h} synthetic RGBA (SURVEY 8d recipe, seed 1234), ETC1S -q{args.quality} comp_level {args.level}, "
+                                   f"basisu_frontend init+compress with tiles resident in HBM",
+                       "blocks": n_blocks, "max_endpoint_clusters": max_ep, "max_selector_clusters": max_sel,
+                       "final_endpoint_clusters": final_ep, "final_selector_clusters": final_sel,
+                       "parallelism": f"{world} x one image per GPU (no collective)"},
+            "roofline": roofline,
+            "stages_s_per_step": {k: round(v / args.steps, 4) for k, v in stage_acc.items()},
+            "kernels_ms_per_step": {k: round(v[0] / args.steps, 3) for k, v in kernels.items()},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(helpers, args)
+        print(json.dumps(out))
+    if last is not None:
+        last.close()
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(helpers, args):
+    """The same stage set (frontend init + compress) on the host, single thread = the parity-pinned configuration, on a bounded
+    sample: a 1536x1536 crop of the same synthetic image with the codebook sizes -q128 gives for that size."""
+    from basis_universal_amd.etc1s import quality_to_clusters
+    side = min(1536, args.size)
+    sample = helpers.to_pixel_blocks(helpers.synth(args.size, args.size, 1234)[:side, :side])
+    n = sample.shape[0]
+    max_ep, max_sel = quality_to_clusters(args.quality, n)
+    if helpers.have_ref():
+        t0 = time.perf_counter()
+        fe = helpers.RefFrontend(sample, max_ep, max_sel, args.level, True)
+        fe.call("compress")
+        dt = time.perf_counter() - t0
+        fe.close()
+        kind, what = "reference", "reference basisu_frontend::init+compress (oracle/_ref, built from /root/reference, -O3, no SSE)"
+    else:
+        # the oracle only restates the per-block/per-cluster stages; time those (lower bound of the reference frontend)
+        t0 = time.perf_counter()
+        helpers.orc_encode_blocks(sample, args.level, True)
+        dt = time.perf_counter() - t0
+        kind, what = "port", "oracle per-block ETC1S fit only (reference build not present)"
+    return {"value": round(side * side / 1e6 / dt, 4), "unit": "Mpixels/s", "cores": 1, "kind": kind,
+            "sample": f"{side}x{side} crop of the bench image, {n} blocks, {max_ep}/{max_sel} clusters, {what}, {dt:.2f} s",
+            "host": f"{os.cpu_count()} logical CPUs on the GPU box"}
+
+
+if __name__ == "__main__":
+    main()

@@ -84,6 +84,11 @@ BU_HIP_API void* bu_hip_get_stream(bu_hip_context*);
 BU_HIP_API int   bu_hip_sync(bu_hip_context*);
 BU_HIP_API const char* bu_hip_last_error(const bu_hip_context*); /* NULL context -> last global (init) error */
 
+/* Per-kernel timing with HIP events recorded on the launch stream around every section-2 kernel. enable(1) resets the totals;
+ * read() synchronises the pending events and returns the number of distinct kernels (names are static strings). */
+BU_HIP_API int      bu_hip_profile_enable(bu_hip_context*, int on);
+BU_HIP_API uint32_t bu_hip_profile_read(bu_hip_context*, const char** names, double* total_ms, uint32_t* launches, uint32_t cap);
+
 BU_HIP_API void* bu_hip_malloc(bu_hip_context*, size_t bytes);
 BU_HIP_API void  bu_hip_free(bu_hip_context*, void* d_ptr);
 BU_HIP_API int   bu_hip_memcpy_h2d(bu_hip_context*, void* d_dst, const void* h_src, size_t bytes); /* synchronises */
@@ -115,7 +120,7 @@ BU_HIP_API int bu_hip_k_refine_endpoint_clusterization(bu_hip_context*, const vo
 /* a11 create_initial_packed_texture (frontend.cpp:2014-2096): d_block_cluster may be NULL, then d_color5_inten is per block. */
 BU_HIP_API int bu_hip_k_determine_selectors(bu_hip_context*, const void* d_pixel_blocks, uint32_t n_blocks,
     const uint8_t* d_color5_inten, const uint32_t* d_block_cluster, int perceptual, void* d_out_etc_blocks);
-/* a12 generate_selector_clusters training part (frontend.cpp:2155-2183): 16 floats + u64 weight per block. */
+/* a12 generate_selector_clusters training part (frontend.cpp:2155-2183): 16 floats + u64 weight per block (d_out_vec16 may be NULL). */
 BU_HIP_API int bu_hip_k_selector_training_vectors(bu_hip_context*, const void* d_encoded_blocks, uint32_t n_blocks, int perceptual, float* d_out_vec16, uint64_t* d_out_weight);
 /* a13 create_optimized_selector_codebook (frontend.cpp:2259-2354): CSR lists of block indices per selector cluster;
  *     rewrites the selector bytes of d_selector_blocks[cluster] (8 B each) for non-empty clusters. */

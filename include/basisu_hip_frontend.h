@@ -1,0 +1,42 @@
+/* include/basisu_hip_frontend.h -- flat C view of bu::etc1s_frontend (basis_universal_amd/csrc/host/etc1s_frontend.h), the
+ * host-side mirror of the reference's basisu_frontend (encoder/basisu_frontend.h:44-381). Lives in libbasisu_frontend.so, which
+ * calls the kernels only through include/basisu_hip.h. Used by the Python binding, bench.py and the parity tests.
+ * All int-returning functions: 1 = success, 0 = failure (see bu_frontend_error).
+ */
+#ifndef BASISU_HIP_FRONTEND_H
+#define BASISU_HIP_FRONTEND_H
+#include "basisu_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct bu_frontend bu_frontend;
+
+BU_HIP_API bu_frontend* bu_frontend_create(void);
+BU_HIP_API void bu_frontend_destroy(bu_frontend*);
+/* basisu_frontend::init (frontend.cpp:51). Exactly one of h_blocks (host tiles, uploaded once) / d_blocks (tiles already in HBM). */
+BU_HIP_API int bu_frontend_init(bu_frontend*, bu_hip_context* ctx, const bu_pixel_block* h_blocks, const void* d_blocks, uint32_t n_blocks,
+                                uint32_t max_endpoint_clusters, uint32_t max_selector_clusters, uint32_t compression_level, int perceptual);
+/* basisu_frontend::compress (frontend.cpp:159) */
+BU_HIP_API int bu_frontend_compress(bu_frontend*);
+/* Single-step one stage method by its reference name (tests); arg = step / iteration where the method takes one. */
+BU_HIP_API int bu_frontend_call(bu_frontend*, const char* stage, uint32_t arg);
+/* Serialise one piece of state into buf (returns bytes needed; copies only if cap suffices; ~0 = unknown name).
+ * Names and formats match oracle/ref_harness.cpp::ref_frontend_get so both sides can be diffed directly. */
+BU_HIP_API uint64_t bu_frontend_get(bu_frontend*, const char* name, void* buf, uint64_t cap);
+BU_HIP_API const char* bu_frontend_error(const bu_frontend*);
+/* Wall seconds of each stage of the last compress(): writes up to cap entries, returns the count; names are static strings. */
+BU_HIP_API uint32_t bu_frontend_stage_times(const bu_frontend*, const char** names, double* seconds, uint32_t cap);
+
+/* basis_compressor::process_frontend's quality -> codebook size mapping (comp.cpp:3325-3379). */
+BU_HIP_API void bu_etc1s_quality_to_clusters(int quality_level, uint32_t total_blocks, uint32_t* max_endpoint_clusters, uint32_t* max_selector_clusters);
+
+/* Test hook: the host TSVQ (row a8) on n DISTINCT, ascending rows of `dim` (6 or 16) floats; CSR blobs out. */
+BU_HIP_API int bu_host_tsvq(uint32_t dim, const float* rows, const uint64_t* weights, uint32_t n, uint32_t max_codebook_size, uint32_t max_parent_codebook_size,
+                            uint32_t* out_codebook, uint64_t cap_codebook_words, uint32_t* out_parent, uint64_t cap_parent_words);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

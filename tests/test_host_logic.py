@@ -1,0 +1,95 @@
+"""CPU (-m "not gpu"): the C-ABI library loads and exports every declared symbol, fails loudly without a GPU, and the host-side
+logic above the C ABI (TSVQ, quality mapping) matches the real reference where oracle/_ref is available."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from helpers import have_ref, ref, ptr, u32p, u64p, f32p, synth, to_pixel_blocks
+
+
+def test_library_exports_every_declared_symbol():
+    from basis_universal_amd import capi
+    lib = capi.load_library()
+    declared = capi.declared_symbols()
+    assert len(declared) >= 30
+    for sym in declared:
+        assert hasattr(lib.dll, sym), sym
+    assert sorted(capi._SIGNATURES) == declared, "ctypes signature table out of sync with include/basisu_hip.h"
+
+
+def test_frontend_library_loads():
+    from basis_universal_amd import etc1s
+    L = etc1s.load_frontend_library()
+    for sym in ("bu_frontend_create", "bu_frontend_init", "bu_frontend_compress", "bu_frontend_get", "bu_etc1s_quality_to_clusters", "bu_host_tsvq"):
+        assert hasattr(L, sym)
+
+
+def test_no_silent_cpu_fallback():
+    """Without a GPU, creating a context must raise -- never fall back to a host implementation."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from basis_universal_amd import capi
+    with pytest.raises(capi.HipError):
+        capi.Context()
+    lib = capi.load_library()
+    assert lib.is_available() == 0
+    assert not lib.create_context()
+    # section-1/2 calls with a null context fail (return 0) instead of crashing
+    assert lib.encode_etc1s_blocks(None, None, 1, 16) == 0
+    assert lib.k_encode_etc1s_blocks(None, None, 0, 1, 1, None) == 0
+
+
+def test_product_does_not_import_the_oracle():
+    import pathlib, re
+    root = pathlib.Path(__file__).resolve().parent.parent / "basis_universal_amd"
+    for f in list(root.rglob("*.py")) + list(root.rglob("*.cpp")) + list(root.rglob("*.h")) + list(root.rglob("*.hip")):
+        txt = f.read_text()
+        assert not re.search(r"oracle[/_]|liboracle|ref_harness", txt), f"{f} references the oracle"
+
+
+@pytest.mark.skipif(not have_ref(), reason="oracle/_ref not present")
+@pytest.mark.parametrize("dim,n,k,p,kind", [(6, 3000, 256, 16, "ep"), (6, 20000, 1200, 16, "ep"), (16, 20000, 500, 32, "sel"),
+                                            (16, 60000, 900, 16, "sel"), (16, 4000, 300, 0, "gauss"), (6, 10, 64, 16, "ep"), (16, 2, 8, 0, "sel"),
+                                            (16, 300, 300, 32, "dup")])
+def test_host_tsvq_matches_reference(dim, n, k, p, kind):
+    from basis_universal_amd import etc1s
+    F = etc1s.load_frontend_library()
+    rng = np.random.default_rng(n + k)
+    if kind == "sel":
+        v = rng.integers(0, 4, (n, dim)).astype(np.float32)
+    elif kind == "ep":
+        v = rng.integers(0, 256, (n, dim)).astype(np.float32) * np.float32(1.0 / 255.0)
+    elif kind == "dup":
+        v = np.repeat(rng.integers(0, 4, (n // 3, dim)), 3, axis=0).astype(np.float32)  # heavy duplication -> few distinct rows
+    else:
+        v = rng.normal(0, 1, (n, dim)).astype(np.float32)
+    v = np.ascontiguousarray(np.unique(v, axis=0))
+    n = v.shape[0]
+    w = rng.integers(1, 50, n).astype(np.uint64)
+    cap = 4 * n + 4 * k + 100
+    a1 = np.zeros(cap, np.uint32); b1 = np.zeros(cap, np.uint32); a2 = np.zeros(cap, np.uint32); b2 = np.zeros(cap, np.uint32)
+    assert ref().ref_tsvq(dim, ptr(v, f32p), ptr(w, u64p), n, k, p, 0, ptr(a1, u32p), cap, ptr(b1, u32p), cap) == 1
+    assert F.bu_host_tsvq(dim, v.ctypes.data_as(C.c_void_p), w.ctypes.data_as(C.c_void_p), n, k, p, a2.ctypes.data_as(C.c_void_p), cap,
+                          b2.ctypes.data_as(C.c_void_p), cap) == 1
+    assert (a1 == a2).all() and (b1 == b2).all()
+
+
+@pytest.mark.skipif(not have_ref(), reason="oracle/_ref not present")
+@pytest.mark.parametrize("w,h,quality", [(64, 64, 128), (256, 192, 128), (512, 512, 128), (256, 256, 255), (256, 256, 1), (128, 128, 64), (768, 512, 192)])
+def test_quality_to_clusters_matches_reference(w, h, quality):
+    """comp.cpp:3325-3379 through the real basis_compressor (which also runs the whole encode)."""
+    from basis_universal_amd.etc1s import quality_to_clusters
+    img = synth(w, h, 5)
+    ep = np.zeros(1, np.uint32); sel = np.zeros(1, np.uint32); size = np.zeros(1, np.uint64)
+    assert ref().ref_compress_etc1s(ptr(img), w, h, quality, 1, 1, ptr(ep, u32p), ptr(sel, u32p), None, 0, ptr(size, u64p)) == 1
+    assert quality_to_clusters(quality, (w // 4) * (h // 4)) == (int(ep[0]), int(sel[0]))
+
+
+def test_bench_contract_fields():
+    import pathlib, re
+    txt = (pathlib.Path(__file__).resolve().parent.parent / "bench.py").read_text()
+    for field in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+                  "config", "roofline", "cpu_baseline"):
+        assert f'"{field}"' in txt, field
