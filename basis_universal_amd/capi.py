@@ -5,13 +5,15 @@ The binding mirrors the C ABI one-to-one; nothing here computes anything. `HipLi
 raises HipError.
 """
 import ctypes as C
+import os
 import pathlib
 import re
 
 import numpy as np
 
 PKG_DIR = pathlib.Path(__file__).resolve().parent
-LIB_PATH = PKG_DIR / "lib" / "libbasisu_hip.so"
+LIB_DIR = pathlib.Path(os.environ.get("BU_HIP_LIB_DIR", PKG_DIR / "lib"))  # override: developer experiments with variant builds
+LIB_PATH = LIB_DIR / "libbasisu_hip.so"
 HEADER_PATH = PKG_DIR.parent / "include" / "basisu_hip.h"
 
 _vp = C.c_void_p
@@ -66,6 +68,11 @@ _SIGNATURES = {
     "bu_hip_k_selector_training_vectors": (_int, [_vp, _vp, _u32, _int, _vp, _vp]),
     "bu_hip_k_create_optimized_selector_codebook": (_int, [_vp, _vp, _vp, _u32, _vp, _vp, _int, _vp]),
     "bu_hip_k_find_optimal_selector_clusters": (_int, [_vp, _vp, _vp, _u32, _vp, _u32, _u32, _vp, _vp, _vp, _int, _u32, _vp]),
+    "bu_hip_tsvq_create": (_vp, [_vp, _u32, _vp, _vp, _u32, _vp]),
+    "bu_hip_tsvq_create_packed16": (_vp, [_vp, _vp, _vp, _u32, _vp]),
+    "bu_hip_tsvq_split": (_int, [_vp, _vp, _vp, _u32, _vp]),
+    "bu_hip_tsvq_read_members": (_int, [_vp, _vp, _u32, _u32, _u32, _vp]),
+    "bu_hip_tsvq_destroy": (None, [_vp, _vp]),
 }
 
 

@@ -15,6 +15,7 @@
 
 #include "../../include/basisu_hip.h"
 #include "etc1s_kernels.h"
+#include "tsvq_kernels.h"
 
 namespace {
 
@@ -356,6 +357,93 @@ int bu_hip_k_find_optimal_selector_clusters(bu_hip_context* ctx, const void* d_p
     BU_TRY(ctx, tmp.reserve((size_t)n_blocks * sizeof(uint32_t)));
     BU_TRY(ctx, bu::launch_find_optimal_selector_clusters(ctx->stream, d_px, d_enc, n_blocks, d_selector_blocks, n_selectors, n_parents, d_cand_offsets,
                                                           d_cand_indices, d_block_parent, perceptual != 0, chunk, static_cast<uint32_t*>(tmp.p), d_out));
+    return 1;
+}
+
+// ---------------------------------------------------------------------------------------------------------------- a8: TSVQ
+
+} // extern "C" (reopened below)
+
+struct bu_tsvq {
+    uint32_t dim = 0, n = 0;
+    bool packed = false;
+    void* rows = nullptr;       // float[n][dim], or uint32[n] when packed
+    uint64_t* w64 = nullptr;
+    uint32_t* perm[2] = {nullptr, nullptr};
+    uint8_t* side = nullptr;
+    arena nodes, outs;
+};
+
+static_assert(sizeof(bu_tsvq_root) == sizeof(bu::tsvq_root_out), "layout");
+static_assert(sizeof(bu_tsvq_node) == sizeof(bu::tsvq_node_in), "layout");
+static_assert(sizeof(bu_tsvq_split) == sizeof(bu::tsvq_split_out), "layout");
+
+extern "C" {
+
+void bu_hip_tsvq_destroy(bu_hip_context* ctx, bu_tsvq* q) {
+    if (!ctx || !q) return;
+    device_guard g(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (void* p : {q->rows, (void*)q->w64, (void*)q->perm[0], (void*)q->perm[1], (void*)q->side}) if (p) (void)hipFree(p);
+    q->nodes.release(); q->outs.release();
+    delete q;
+}
+
+static bu_tsvq* tsvq_create_common(bu_hip_context* ctx, uint32_t dim, bool packed, const void* h_rows, const uint64_t* h_weights, uint32_t n, bu_tsvq_root* out_root) {
+    if (!ctx || !n || !out_root || (dim != 6 && dim != 16) || (packed && dim != 16)) { if (ctx) set_error(ctx, "tsvq_create: bad arguments"); return nullptr; }
+    device_guard g(ctx->device);
+    bu_tsvq* q = new (std::nothrow) bu_tsvq();
+    if (!q) return nullptr;
+    q->dim = dim; q->n = n; q->packed = packed;
+    const size_t row_bytes = packed ? 4 : (size_t)dim * 4;
+    auto fail = [&](const char* what) -> bu_tsvq* { set_error(ctx, "tsvq_create: %s", what); bu_hip_tsvq_destroy(ctx, q); return nullptr; };
+    if (hipMalloc(&q->rows, (size_t)n * row_bytes) != hipSuccess || hipMalloc((void**)&q->w64, (size_t)n * 8) != hipSuccess ||
+        hipMalloc((void**)&q->perm[0], (size_t)n * 4) != hipSuccess || hipMalloc((void**)&q->perm[1], (size_t)n * 4) != hipSuccess ||
+        hipMalloc((void**)&q->side, (size_t)n) != hipSuccess)
+        return fail("allocation");
+    if (q->outs.reserve(sizeof(bu::tsvq_root_out)) != hipSuccess) return fail("allocation");
+    if (hipMemcpyAsync(q->rows, h_rows, (size_t)n * row_bytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+        hipMemcpyAsync(q->w64, h_weights, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+        return fail("upload");
+    {
+        prof_scope ps(ctx, "tsvq_root");
+        if (bu::launch_tsvq_root(ctx->stream, (int)dim, packed, q->rows, q->w64, n, q->perm[0], static_cast<bu::tsvq_root_out*>(q->outs.p)) != hipSuccess) return fail("root launch");
+    }
+    if (hipMemcpyAsync(out_root, q->outs.p, sizeof(bu_tsvq_root), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess)
+        return fail("root download");
+    return q;
+}
+
+bu_tsvq* bu_hip_tsvq_create(bu_hip_context* ctx, uint32_t dim, const float* h_rows, const uint64_t* h_weights, uint32_t n, bu_tsvq_root* out_root) {
+    return tsvq_create_common(ctx, dim, false, h_rows, h_weights, n, out_root);
+}
+
+bu_tsvq* bu_hip_tsvq_create_packed16(bu_hip_context* ctx, const uint32_t* h_keys, const uint64_t* h_weights, uint32_t n, bu_tsvq_root* out_root) {
+    return tsvq_create_common(ctx, 16, true, h_keys, h_weights, n, out_root);
+}
+
+int bu_hip_tsvq_split(bu_hip_context* ctx, bu_tsvq* q, const bu_tsvq_node* h_nodes, uint32_t n_nodes, bu_tsvq_split* h_out) {
+    if (!ctx || !q) return 0;
+    if (!n_nodes) return 1;
+    device_guard g(ctx->device);
+    BU_TRY(ctx, q->nodes.reserve((size_t)n_nodes * sizeof(bu_tsvq_node)));
+    BU_TRY(ctx, q->outs.reserve((size_t)n_nodes * sizeof(bu_tsvq_split)));
+    BU_TRY(ctx, hipMemcpyAsync(q->nodes.p, h_nodes, (size_t)n_nodes * sizeof(bu_tsvq_node), hipMemcpyHostToDevice, ctx->stream));
+    {
+        prof_scope ps(ctx, "tsvq_split");
+        BU_TRY(ctx, bu::launch_tsvq_split(ctx->stream, (int)q->dim, q->packed, q->rows, q->w64, q->perm[0], q->perm[1], q->side,
+                                          static_cast<const bu::tsvq_node_in*>(q->nodes.p), n_nodes, static_cast<bu::tsvq_split_out*>(q->outs.p)));
+    }
+    BU_TRY(ctx, hipMemcpyAsync(h_out, q->outs.p, (size_t)n_nodes * sizeof(bu_tsvq_split), hipMemcpyDeviceToHost, ctx->stream));
+    BU_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return 1;
+}
+
+int bu_hip_tsvq_read_members(bu_hip_context* ctx, bu_tsvq* q, uint32_t buf, uint32_t start, uint32_t count, uint32_t* h_out) {
+    if (!ctx || !q || buf > 1 || (uint64_t)start + count > q->n) return 0;
+    device_guard g(ctx->device);
+    if (count) BU_TRY(ctx, hipMemcpyAsync(h_out, q->perm[buf] + start, (size_t)count * 4, hipMemcpyDeviceToHost, ctx->stream));
+    BU_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return 1;
 }
 

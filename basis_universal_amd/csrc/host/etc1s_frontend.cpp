@@ -8,6 +8,7 @@
 #include <numeric>
 
 #include "tsvq.h"
+#include "tsvq_device.h"
 
 namespace bu {
 
@@ -254,8 +255,8 @@ bool etc1s_frontend::init_endpoint_training_vectors() {
 // frontend.cpp:868-944
 bool etc1s_frontend::generate_endpoint_clusters() {
     const uint32_t parent_size = (m_params.m_max_endpoint_clusters >= 256) ? kEndpointParentCodebookSize : 0;
-    if (!hierarchical_codebook<6>(m_endpoint_unique_rows, m_endpoint_unique_weights, m_endpoint_unique_groups, m_params.m_max_endpoint_clusters,
-                                  m_use_hierarchical_endpoint_codebooks ? parent_size : 0, m_endpoint_clusters, m_endpoint_parent_clusters))
+    if (!device_tsvq::hierarchical_codebook(m_dev->ctx, 6, m_endpoint_unique_rows, m_endpoint_unique_weights, m_endpoint_unique_groups, m_params.m_max_endpoint_clusters,
+                                            m_use_hierarchical_endpoint_codebooks ? parent_size : 0, m_endpoint_clusters, m_endpoint_parent_clusters))
         return fail("endpoint TSVQ failed");
     if (m_use_hierarchical_endpoint_codebooks) {
         if (m_endpoint_parent_clusters.empty()) {
@@ -432,19 +433,19 @@ bool etc1s_frontend::generate_selector_clusters() {
         for (uint32_t i = 0; i < n; i++) { const uint32_t p = hist[(keys[i] >> sh) & 255]++; keys2[p] = keys[i]; idx2[p] = idx[i]; }
         keys.swap(keys2); idx.swap(idx2);
     }
-    std::vector<float> rows; std::vector<uint64_t> uw; std::vector<std::vector<uint32_t>> groups;
+    std::vector<uint32_t> ukeys; std::vector<uint64_t> uw; std::vector<std::vector<uint32_t>> groups;
     for (uint32_t i = 0; i < n;) {
         uint32_t j = i; uint64_t w = 0;
         while (j < n && keys[j] == keys[i]) { w += weights[idx[j]]; j++; }
-        for (int s = 15; s >= 0; s--) rows.push_back((float)((keys[i] >> (2 * s)) & 3u));
+        ukeys.push_back(keys[i]);
         uw.push_back(w);
         groups.emplace_back(idx.begin() + i, idx.begin() + j);
         i = j;
     }
     const uint32_t parent_default = (m_params.m_compression_level <= 1) ? kSelectorParentCodebookSizeLevel01 : kSelectorParentCodebookSizeDefault;
     const uint32_t parent_size = (m_params.m_max_selector_clusters >= 256) ? parent_default : 0;
-    if (!hierarchical_codebook<16>(rows, uw, groups, m_params.m_max_selector_clusters, m_use_hierarchical_selector_codebooks ? parent_size : 0,
-                                   m_selector_cluster_block_indices, m_selector_parent_cluster_block_indices))
+    if (!device_tsvq::hierarchical_codebook_packed16(d.ctx, ukeys, uw, groups, m_params.m_max_selector_clusters, m_use_hierarchical_selector_codebooks ? parent_size : 0,
+                                                     m_selector_cluster_block_indices, m_selector_parent_cluster_block_indices))
         return fail("selector TSVQ failed");
     if (m_use_hierarchical_selector_codebooks) {
         if (m_selector_parent_cluster_block_indices.empty()) {

@@ -7,6 +7,7 @@
 #include "../../../include/basisu_hip_frontend.h"
 #include "etc1s_frontend.h"
 #include "tsvq.h"
+#include "tsvq_device.h"
 
 struct bu_frontend {
     bu::etc1s_frontend fe;
@@ -125,6 +126,29 @@ int bu_host_tsvq(uint32_t dim, const float* rows, const uint64_t* weights, uint3
     if (dim == 6) ok = bu::hierarchical_codebook<6>(r, w, groups, max_codebook_size, max_parent_codebook_size, codebook, parents);
     else if (dim == 16) ok = bu::hierarchical_codebook<16>(r, w, groups, max_codebook_size, max_parent_codebook_size, codebook, parents);
     if (!ok) return 0;
+    const std::vector<uint32_t> a = csr_blob(codebook), b = csr_blob(parents);
+    if (a.size() > cap_codebook_words || b.size() > cap_parent_words) return -1;
+    std::memcpy(out_codebook, a.data(), a.size() * 4);
+    std::memcpy(out_parent, b.data(), b.size() * 4);
+    return 1;
+}
+
+// The same through the device TSVQ (tsvq_device.h + bu_hip_tsvq_*): what the frontend actually uses. stats3 = {rounds, splits computed, splits used}.
+int bu_device_tsvq(bu_hip_context* ctx, uint32_t dim, const float* rows, const uint64_t* weights, uint32_t n, uint32_t max_codebook_size, uint32_t max_parent_codebook_size,
+                   uint32_t* out_codebook, uint64_t cap_codebook_words, uint32_t* out_parent, uint64_t cap_parent_words, uint32_t* stats3) {
+    std::vector<float> r(rows, rows + (size_t)n * dim);
+    std::vector<uint64_t> w(weights, weights + n);
+    std::vector<std::vector<uint32_t>> groups(n), codebook, parents;
+    for (uint32_t i = 0; i < n; i++) groups[i].push_back(i);
+    bu::device_tsvq::stats st;
+    bool packable = dim == 16;
+    for (size_t i = 0; packable && i < r.size(); i++) packable = r[i] == 0.0f || r[i] == 1.0f || r[i] == 2.0f || r[i] == 3.0f;
+    if (packable && (stats3 && stats3[0] == 0xBACCED)) { // caller asked for the packed selector path
+        std::vector<uint32_t> keys(n, 0);
+        for (uint32_t i = 0; i < n; i++) for (uint32_t k = 0; k < 16; k++) keys[i] = (keys[i] << 2) | (uint32_t)r[(size_t)i * 16 + k];
+        if (!bu::device_tsvq::hierarchical_codebook_packed16(ctx, keys, w, groups, max_codebook_size, max_parent_codebook_size, codebook, parents, &st)) return 0;
+    } else if (!bu::device_tsvq::hierarchical_codebook(ctx, dim, r, w, groups, max_codebook_size, max_parent_codebook_size, codebook, parents, &st)) return 0;
+    if (stats3) { stats3[0] = st.rounds; stats3[1] = st.splits_computed; stats3[2] = st.splits_used; }
     const std::vector<uint32_t> a = csr_blob(codebook), b = csr_blob(parents);
     if (a.size() > cap_codebook_words || b.size() > cap_parent_words) return -1;
     std::memcpy(out_codebook, a.data(), a.size() * 4);

@@ -51,6 +51,9 @@ public:
         }
         h_[k] = entry{index, priority};
     }
+    // raw view of the live entries (1..size), for batch scheduling of speculative splits
+    uint32_t entry_index(uint32_t i) const { return h_[i].index; }
+    float entry_priority(uint32_t i) const { return h_[i].priority; }
 private:
     struct entry { uint32_t index; float priority; };
     std::vector<entry> h_;

@@ -1,0 +1,189 @@
+// tsvq_device.h -- host driver of the device TSVQ (row a8): the tree, the variance priority queue and the order in which nodes
+// are split stay exactly as in tree_vector_quant<>::generate (encoder/basisu_enc.h:1616-1660); the splits themselves
+// (split_node, enc.h:1737-1800) run on the GPU through bu_hip_tsvq_split, many nodes per launch.
+//
+// A node's split depends only on the node, so the driver may compute splits AHEAD of the reference's schedule: it replays the
+// priority queue until it reaches a node whose split is not known yet, then asks the device to split every such candidate in
+// the queue at once (bounded by the number of splits still needed), and resumes the replay. Speculative results that the
+// replay never reaches are simply dropped, so the final tree is the reference's tree.
+#pragma once
+#include <algorithm>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../../../include/basisu_hip.h"
+#include "tsvq.h"
+
+namespace bu {
+
+class device_tsvq {
+public:
+    struct stats { uint32_t rounds = 0, splits_computed = 0, splits_used = 0; };
+
+    // rows: n distinct vectors of `dim` floats, ascending; groups[u]: original training-vector indices of unique vector u.
+    static bool hierarchical_codebook(bu_hip_context* ctx, uint32_t dim, const std::vector<float>& rows, const std::vector<uint64_t>& weights,
+                                      const std::vector<std::vector<uint32_t>>& groups, uint32_t max_codebook_size, uint32_t max_parent_codebook_size,
+                                      std::vector<std::vector<uint32_t>>& codebook, std::vector<std::vector<uint32_t>>& parent_codebook, stats* st = nullptr) {
+        bu_tsvq_root root;
+        bu_tsvq* q = weights.empty() ? nullptr : bu_hip_tsvq_create(ctx, dim, rows.data(), weights.data(), (uint32_t)weights.size(), &root);
+        return q && build(ctx, q, root, (uint32_t)weights.size(), groups, max_codebook_size, max_parent_codebook_size, codebook, parent_codebook, st);
+    }
+
+    // Selector vectors: keys[u] packs the 16 selector values of distinct vector u (value 0 in the top two bits), ascending.
+    static bool hierarchical_codebook_packed16(bu_hip_context* ctx, const std::vector<uint32_t>& keys, const std::vector<uint64_t>& weights,
+                                               const std::vector<std::vector<uint32_t>>& groups, uint32_t max_codebook_size, uint32_t max_parent_codebook_size,
+                                               std::vector<std::vector<uint32_t>>& codebook, std::vector<std::vector<uint32_t>>& parent_codebook, stats* st = nullptr) {
+        bu_tsvq_root root;
+        bu_tsvq* q = weights.empty() ? nullptr : bu_hip_tsvq_create_packed16(ctx, keys.data(), weights.data(), (uint32_t)weights.size(), &root);
+        return q && build(ctx, q, root, (uint32_t)weights.size(), groups, max_codebook_size, max_parent_codebook_size, codebook, parent_codebook, st);
+    }
+
+private:
+    static bool build(bu_hip_context* ctx, bu_tsvq* q, const bu_tsvq_root& root, uint32_t n, const std::vector<std::vector<uint32_t>>& groups,
+                      uint32_t max_codebook_size, uint32_t max_parent_codebook_size, std::vector<std::vector<uint32_t>>& codebook,
+                      std::vector<std::vector<uint32_t>>& parent_codebook, stats* st) {
+        struct guard { bu_hip_context* c; bu_tsvq* q; ~guard() { bu_hip_tsvq_destroy(c, q); } } g{ctx, q};
+
+        struct node {
+            float var; uint64_t weight; float origin[16];
+            int32_t left = -1, right = -1; int codebook_index = -1;
+            uint32_t buf, start, count;
+            int32_t cached = -1; // index into `cache`
+        };
+        std::vector<node> nodes;
+        std::vector<bu_tsvq_split> cache;
+        nodes.reserve((size_t)max_codebook_size * 2 + 1);
+        {
+            node r; r.var = root.var; r.weight = root.weight; std::memcpy(r.origin, root.origin, sizeof(r.origin));
+            r.buf = 0; r.start = 0; r.count = n;
+            nodes.push_back(r);
+        }
+        variance_heap heap;
+        heap.reset(0, nodes[0].var);
+        uint32_t leaves = 1, next_codebook_index = 0;
+        stats local;
+        std::vector<bu_tsvq_node> batch;
+        std::vector<uint32_t> batch_nodes;
+        std::vector<std::pair<float, uint32_t>> pending;
+
+        while (heap.size() && leaves < max_codebook_size) {
+            // ---- replay generate()'s loop (enc.h:1636-1655) while the splits it needs are known
+            bool stalled = false;
+            while (heap.size() && leaves < max_codebook_size) {
+                const uint32_t ni = heap.top_index();
+                if (nodes[ni].count > 1 && nodes[ni].cached < 0) { stalled = true; break; }
+                heap.pop();
+                if (nodes[ni].count <= 1) continue;
+                const bu_tsvq_split& s = cache[(size_t)nodes[ni].cached];
+                if (!s.ok) continue; // prep_split / refine_split returned false: the node stays a leaf
+                local.splits_used++;
+                const uint32_t li = (uint32_t)nodes.size(), ri = li + 1;
+                nodes[ni].left = (int32_t)li; nodes[ni].right = (int32_t)ri;
+                nodes[ni].codebook_index = (int)next_codebook_index++;
+                node l, r;
+                l.var = s.l_var; l.weight = s.l_weight; std::memcpy(l.origin, s.l_centroid, sizeof(l.origin));
+                l.buf = nodes[ni].buf ^ 1u; l.start = nodes[ni].start; l.count = s.l_count;
+                r.var = s.r_var; r.weight = s.r_weight; std::memcpy(r.origin, s.r_centroid, sizeof(r.origin));
+                r.buf = nodes[ni].buf ^ 1u; r.start = nodes[ni].start + s.l_count; r.count = s.r_count;
+                // enc.h:1766-1792: a child with var <= 0 but differing members gets a tiny variance; rows are distinct, so any
+                // child with more than one member qualifies
+                if (l.var <= 0.0f && l.count > 1) l.var = 1e-4f;
+                if (r.var <= 0.0f && r.count > 1) r.var = 1e-4f;
+                nodes.push_back(l); nodes.push_back(r);
+                if (l.var > 0.0f && l.count > 1) heap.push(li, l.var);
+                if (r.var > 0.0f && r.count > 1) heap.push(ri, r.var);
+                leaves++;
+            }
+            if (!stalled) break;
+            // ---- one device round: every queued node whose split is unknown, largest variance first, at most as many as
+            //      there are splits left to do
+            pending.clear();
+            for (uint32_t i = 1; i <= heap.size(); i++) {
+                const uint32_t ni = heap.entry_index(i);
+                if (nodes[ni].count > 1 && nodes[ni].cached < 0) pending.emplace_back(heap.entry_priority(i), ni);
+            }
+            const size_t want = std::min<size_t>(pending.size(), (size_t)(max_codebook_size - leaves));
+            if (want < pending.size()) {
+                std::nth_element(pending.begin(), pending.begin() + want, pending.end(), [](const std::pair<float, uint32_t>& a, const std::pair<float, uint32_t>& b) { return a.first > b.first || (a.first == b.first && a.second < b.second); });
+                pending.resize(want);
+            }
+            // the queue's top must be among them (it is the maximum) -- otherwise the replay could not advance
+            batch.clear(); batch_nodes.clear();
+            for (const auto& p : pending) {
+                const node& nd = nodes[p.second];
+                bu_tsvq_node b; std::memset(&b, 0, sizeof(b));
+                b.buf = nd.buf; b.start = nd.start; b.count = nd.count; b.weight = nd.weight; std::memcpy(b.origin, nd.origin, sizeof(b.origin));
+                batch.push_back(b); batch_nodes.push_back(p.second);
+            }
+            const size_t base = cache.size();
+            cache.resize(base + batch.size());
+            if (std::getenv("BU_TSVQ_SERIAL")) { // debug: one node per launch
+                for (size_t i = 0; i < batch.size(); i++)
+                    if (!bu_hip_tsvq_split(ctx, q, &batch[i], 1, cache.data() + base + i)) return false;
+            } else if (!bu_hip_tsvq_split(ctx, q, batch.data(), (uint32_t)batch.size(), cache.data() + base)) return false;
+            for (size_t i = 0; i < batch.size(); i++) nodes[batch_nodes[i]].cached = (int32_t)(base + i);
+            local.rounds++; local.splits_computed += (uint32_t)batch.size();
+        }
+        if (st) *st = local;
+
+        // ---- leaves in node order (enc.h:1573-1584). Leaf segments are intact in their buffers and ascending.
+        std::vector<uint32_t> perm[2];
+        perm[0].resize(n); perm[1].resize(n);
+        if (!bu_hip_tsvq_read_members(ctx, q, 0, 0, n, perm[0].data()) || !bu_hip_tsvq_read_members(ctx, q, 1, 0, n, perm[1].data())) return false;
+        std::vector<int32_t> leaf_of_node(nodes.size(), -1);
+        std::vector<std::vector<uint32_t>> leaf_members;
+        for (size_t ni = 0; ni < nodes.size(); ni++) {
+            if (nodes[ni].left >= 0) continue;
+            leaf_of_node[ni] = (int32_t)leaf_members.size();
+            const uint32_t* src = perm[nodes[ni].buf].data() + nodes[ni].start;
+            leaf_members.emplace_back(src, src + nodes[ni].count);
+        }
+        auto expand = [&](const std::vector<std::vector<uint32_t>>& in, std::vector<std::vector<uint32_t>>& out) {
+            out.clear(); out.resize(in.size());
+            for (size_t i = 0; i < in.size(); i++) {
+                size_t total = 0;
+                for (uint32_t u : in[i]) total += groups[u].size();
+                out[i].reserve(total);
+                for (uint32_t u : in[i]) out[i].insert(out[i].end(), groups[u].begin(), groups[u].end());
+            }
+        };
+        expand(leaf_members, codebook);
+
+        parent_codebook.clear();
+        if (max_parent_codebook_size) {
+            // retrieve(max_clusters) (enc.h:1598-1628): cut the tree after its first max_clusters-1 splits, depth first, left before right.
+            // Every node's member list is the ascending union of its leaves, so assign each leaf to its cut node and sweep the vectors in order.
+            std::vector<uint32_t> cut_of_leaf(leaf_members.size(), 0);
+            uint32_t cuts = 0;
+            std::vector<uint32_t> stack, sub;
+            uint32_t ni = 0;
+            for (;;) {
+                const node& cur = nodes[ni];
+                if (cur.left < 0 || (2 + cur.codebook_index) > (int)max_parent_codebook_size) {
+                    sub.assign(1, ni);
+                    while (!sub.empty()) { // all leaves below this cut node
+                        const uint32_t x = sub.back(); sub.pop_back();
+                        if (nodes[x].left < 0) cut_of_leaf[(size_t)leaf_of_node[x]] = cuts;
+                        else { sub.push_back((uint32_t)nodes[x].left); sub.push_back((uint32_t)nodes[x].right); }
+                    }
+                    cuts++;
+                    if (stack.empty()) break;
+                    ni = stack.back(); stack.pop_back();
+                    continue;
+                }
+                stack.push_back((uint32_t)cur.right);
+                ni = (uint32_t)cur.left;
+            }
+            std::vector<uint32_t> cut_of_vec(n);
+            for (size_t l = 0; l < leaf_members.size(); l++) for (uint32_t u : leaf_members[l]) cut_of_vec[u] = cut_of_leaf[l];
+            std::vector<std::vector<uint32_t>> cut_members(cuts);
+            for (uint32_t u = 0; u < n; u++) cut_members[cut_of_vec[u]].push_back(u);
+            expand(cut_members, parent_codebook);
+        }
+        return true;
+    }
+};
+
+} // namespace bu

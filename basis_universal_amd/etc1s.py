@@ -17,7 +17,7 @@ import numpy as np
 
 from . import capi
 
-FRONTEND_LIB_PATH = capi.PKG_DIR / "lib" / "libbasisu_frontend.so"
+FRONTEND_LIB_PATH = capi.LIB_DIR / "libbasisu_frontend.so"
 _vp = C.c_void_p
 _lib = None
 
@@ -46,6 +46,8 @@ def load_frontend_library():
         L.bu_etc1s_quality_to_clusters.argtypes = [C.c_int, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         L.bu_host_tsvq.restype = C.c_int
         L.bu_host_tsvq.argtypes = [C.c_uint32, _vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32, _vp, C.c_uint64, _vp, C.c_uint64]
+        L.bu_device_tsvq.restype = C.c_int
+        L.bu_device_tsvq.argtypes = [_vp, C.c_uint32, _vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32, _vp, C.c_uint64, _vp, C.c_uint64, _vp]
         _lib = L
     return _lib
 

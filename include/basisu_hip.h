@@ -133,6 +133,23 @@ BU_HIP_API int bu_hip_k_find_optimal_selector_clusters(bu_hip_context*, const vo
     const void* d_selector_blocks, uint32_t n_selectors, uint32_t n_parents, const uint32_t* d_cand_offsets, const uint32_t* d_cand_indices,
     const uint8_t* d_block_parent, int perceptual, uint32_t chunk, uint32_t* d_out_block_selector_cluster);
 
+/* a8  tree_vector_quant (encoder/basisu_enc.h:1546-2078): the order-dependent TSVQ tree build, split by split, bit-exact.
+ *     The host keeps the tree, the variance priority queue and the split order (enc.h:1616-1660); the device executes batches of
+ *     independent node splits (split_node, enc.h:1737-1800) on the resident training set. Rows must be the DISTINCT training
+ *     vectors in ascending order (what generate_hierarchical_codebook_threaded's std::map yields, enc.h:2233-2290), dim 6 or 16.
+ *     Node member lists live in two device index buffers: the root is {buf 0, start 0, count n}; a split of {buf, start, count}
+ *     leaves its children at {buf^1, start, l_count} and {buf^1, start+l_count, r_count}. Member lists are ascending. */
+typedef struct bu_tsvq bu_tsvq;
+typedef struct { float origin[16]; uint64_t weight; float var; uint32_t pad; } bu_tsvq_root;      /* prepare_root, enc.h:1708-1735 */
+typedef struct { uint32_t buf, start, count, pad; uint64_t weight; float origin[16]; } bu_tsvq_node;
+typedef struct { uint32_t ok, l_count, r_count, pad; uint64_t l_weight, r_weight; float l_var, r_var; float l_centroid[16], r_centroid[16]; } bu_tsvq_split;
+BU_HIP_API bu_tsvq* bu_hip_tsvq_create(bu_hip_context*, uint32_t dim, const float* h_rows, const uint64_t* h_weights, uint32_t n, bu_tsvq_root* h_out_root);
+/* dim 16 with every component in {0,1,2,3} (ETC1S selector vectors): one dword per vector, component 0 in the top two bits. */
+BU_HIP_API bu_tsvq* bu_hip_tsvq_create_packed16(bu_hip_context*, const uint32_t* h_keys, const uint64_t* h_weights, uint32_t n, bu_tsvq_root* h_out_root);
+BU_HIP_API int  bu_hip_tsvq_split(bu_hip_context*, bu_tsvq*, const bu_tsvq_node* h_nodes, uint32_t n_nodes, bu_tsvq_split* h_out); /* synchronises */
+BU_HIP_API int  bu_hip_tsvq_read_members(bu_hip_context*, bu_tsvq*, uint32_t buf, uint32_t start, uint32_t count, uint32_t* h_out);
+BU_HIP_API void bu_hip_tsvq_destroy(bu_hip_context*, bu_tsvq*);
+
 #ifdef __cplusplus
 }
 #endif

@@ -36,6 +36,11 @@ BU_HIP_API void bu_etc1s_quality_to_clusters(int quality_level, uint32_t total_b
 BU_HIP_API int bu_host_tsvq(uint32_t dim, const float* rows, const uint64_t* weights, uint32_t n, uint32_t max_codebook_size, uint32_t max_parent_codebook_size,
                             uint32_t* out_codebook, uint64_t cap_codebook_words, uint32_t* out_parent, uint64_t cap_parent_words);
 
+/* The same input through the DEVICE TSVQ driver the frontend uses (basis_universal_amd/csrc/host/tsvq_device.h). */
+BU_HIP_API int bu_device_tsvq(bu_hip_context* ctx, uint32_t dim, const float* rows, const uint64_t* weights, uint32_t n, uint32_t max_codebook_size,
+                              uint32_t max_parent_codebook_size, uint32_t* out_codebook, uint64_t cap_codebook_words, uint32_t* out_parent,
+                              uint64_t cap_parent_words, uint32_t* stats3);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,65 @@
+"""-m gpu: the device TSVQ (row a8: bu_hip_tsvq_* + host driver tsvq_device.h) must build the identical tree as the
+reference's tree_vector_quant. Checked against the real reference (oracle/_ref, ref_tsvq) where present and against the host
+restatement tsvq.h (itself pinned to the reference in tests/test_host_logic.py) everywhere. Cluster lists compare exactly."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from helpers import have_ref, ref, ptr, u32p, u64p, f32p
+
+pytestmark = pytest.mark.gpu
+VP = C.c_void_p
+
+
+def _data(kind, dim, n, rng):
+    if kind == "sel":
+        v = rng.integers(0, 4, (n, dim)).astype(np.float32)
+    elif kind == "sel_skewed":  # few popular patterns with huge weights + a noisy tail, like real selector statistics
+        base = rng.integers(0, 4, (max(n // 50, 4), dim))
+        v = base[rng.integers(0, base.shape[0], n)] ^ (rng.random((n, dim)) < 0.08)
+        v = np.clip(v, 0, 3).astype(np.float32)
+    elif kind == "ep":
+        v = rng.integers(0, 256, (n, dim)).astype(np.float32) * np.float32(1.0 / 255.0)
+    elif kind == "line":  # all points on a line: degenerate covariance / projection ties
+        t = rng.integers(0, 64, n).astype(np.float32)
+        v = np.tile(t[:, None], (1, dim)) * np.float32(0.25)
+    else:
+        v = rng.normal(0, 1, (n, dim)).astype(np.float32)
+    v = np.ascontiguousarray(np.unique(v, axis=0))
+    return v
+
+
+CASES = [(16, 5000, 300, 32, "sel", 50), (16, 120000, 2731, 32, "sel", 4096), (16, 30000, 900, 16, "sel_skewed", 4096), (6, 3000, 256, 16, "ep", 50),
+         (6, 40000, 2416, 16, "ep", 3), (16, 4000, 300, 0, "gauss", 9), (6, 200, 64, 16, "line", 5), (16, 2, 8, 0, "sel", 3), (16, 3, 3, 2, "sel", 3),
+         (16, 700, 700, 32, "sel", 2), (6, 1, 4, 2, "ep", 1)]
+
+
+@pytest.mark.parametrize("dim,n,k,p,kind,wmax", CASES)
+def test_device_tsvq_matches_host_and_reference(hip_ctx, dim, n, k, p, kind, wmax):
+    from basis_universal_amd import etc1s
+    F = etc1s.load_frontend_library()
+    rng = np.random.default_rng(n * 7 + k)
+    v = _data(kind, dim, n, rng)
+    n = v.shape[0]
+    w = rng.integers(1, wmax + 1, n).astype(np.uint64)
+    if kind == "sel_skewed":
+        w[rng.integers(0, n, 5)] = 3_000_000_000  # weights past 2^24: (float)weight rounds, sums leave the exact range
+    cap = 4 * n + 4 * k + 100
+    a1 = np.zeros(cap, np.uint32); b1 = np.zeros(cap, np.uint32); a2 = np.zeros(cap, np.uint32); b2 = np.zeros(cap, np.uint32)
+    st = np.zeros(3, np.uint32)
+    assert F.bu_host_tsvq(dim, v.ctypes.data_as(VP), w.ctypes.data_as(VP), n, k, p, a1.ctypes.data_as(VP), cap, b1.ctypes.data_as(VP), cap) == 1
+    assert F.bu_device_tsvq(hip_ctx.h, dim, v.ctypes.data_as(VP), w.ctypes.data_as(VP), n, k, p, a2.ctypes.data_as(VP), cap, b2.ctypes.data_as(VP), cap,
+                            st.ctypes.data_as(VP)) == 1
+    assert (a1 == a2).all(), f"codebook differs (leaves host {a1[0]} device {a2[0]}, rounds {st[0]}, splits {st[1]}/{st[2]})"
+    assert (b1 == b2).all(), "parent codebook differs"
+    if kind.startswith("sel"):
+        # the packed (one dword per vector) path the selector codebook uses
+        a4 = np.zeros(cap, np.uint32); b4 = np.zeros(cap, np.uint32); st4 = np.array([0xBACCED, 0, 0], np.uint32)
+        assert F.bu_device_tsvq(hip_ctx.h, dim, v.ctypes.data_as(VP), w.ctypes.data_as(VP), n, k, p, a4.ctypes.data_as(VP), cap, b4.ctypes.data_as(VP), cap,
+                                st4.ctypes.data_as(VP)) == 1
+        assert (a1 == a4).all() and (b1 == b4).all(), "packed16 path differs"
+    if have_ref():
+        a3 = np.zeros(cap, np.uint32); b3 = np.zeros(cap, np.uint32)
+        assert ref().ref_tsvq(dim, ptr(v, f32p), ptr(w, u64p), n, k, p, 0, ptr(a3, u32p), cap, ptr(b3, u32p), cap) == 1
+        assert (a3 == a2).all() and (b3 == b2).all()
