@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <numeric>
@@ -52,6 +53,8 @@ struct bu_hip_context {
     size_t total_blocks = 0;
     arena pixel_arena;                    // owns the tiles when they were uploaded through bu_hip_set_pixel_blocks
     arena scratch[6];
+    // pinned staging ring for host -> device uploads of pageable caller memory (see h2d below)
+    void* stage = nullptr; size_t stage_cap = 0, stage_used = 0;
     std::string error;
     // optional per-kernel timing with HIP events on the launch stream (bu_hip_profile_*)
     bool profiling = false;
@@ -106,6 +109,35 @@ void prof_drain(bu_hip_context* ctx) {
         (void)hipEventDestroy(r.start); (void)hipEventDestroy(r.stop);
     }
     ctx->prof_pending.clear();
+}
+
+// Host -> device upload of caller-owned (pageable) memory, ordered on the context's stream. Pageable memory is never handed to
+// hipMemcpyAsync: on this stack (ROCm 7.2, MI355X) a kernel launched right behind such a copy was observed to read the
+// destination before the data had landed (tools/tsvq_root_repeat.py). Small uploads go through a pinned staging ring (a real
+// stream-ordered DMA; the ring is recycled only after a stream synchronise), large ones through a blocking hipMemcpy.
+hipError_t h2d(bu_hip_context* ctx, void* d, const void* h, size_t bytes) {
+    if (!bytes) return hipSuccess;
+    hipError_t e;
+    if (bytes > ((size_t)8 << 20)) {
+        if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) return e;
+        if ((e = hipMemcpy(d, h, bytes, hipMemcpyHostToDevice)) != hipSuccess) return e;
+        return hipDeviceSynchronize();
+    }
+    const size_t need = (bytes + 255) & ~(size_t)255;
+    if (need > ctx->stage_cap - ctx->stage_used) {
+        if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) return e; // every copy out of the ring has completed
+        ctx->stage_used = 0;
+        if (need > ctx->stage_cap) {
+            if (ctx->stage) { (void)hipHostFree(ctx->stage); ctx->stage = nullptr; ctx->stage_cap = 0; }
+            const size_t want = std::max(need * 2, (size_t)4 << 20);
+            if ((e = hipHostMalloc(&ctx->stage, want, hipHostMallocDefault)) != hipSuccess) { ctx->stage = nullptr; return e; }
+            ctx->stage_cap = want;
+        }
+    }
+    char* slot = static_cast<char*>(ctx->stage) + ctx->stage_used;
+    std::memcpy(slot, h, bytes);
+    ctx->stage_used += need;
+    return hipMemcpyAsync(d, slot, bytes, hipMemcpyHostToDevice, ctx->stream);
 }
 
 int quality_from_perms(uint32_t total_perms) {
@@ -171,12 +203,19 @@ void bu_hip_destroy_context(bu_hip_context* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     ctx->pixel_arena.release();
     for (auto& a : ctx->scratch) a.release();
+    if (ctx->stage) (void)hipHostFree(ctx->stage);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
 
 int bu_hip_context_device(const bu_hip_context* ctx) { return ctx ? ctx->device : -1; }
-int bu_hip_set_stream(bu_hip_context* ctx, void* s) { if (!ctx) return 0; ctx->stream = s ? (hipStream_t)s : ctx->own_stream; return 1; }
+int bu_hip_set_stream(bu_hip_context* ctx, void* s) {
+    if (!ctx) return 0;
+    (void)hipStreamSynchronize(ctx->stream); // staged uploads still in flight belong to the old stream
+    ctx->stage_used = 0;
+    ctx->stream = s ? (hipStream_t)s : ctx->own_stream;
+    return 1;
+}
 void* bu_hip_get_stream(bu_hip_context* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
 const char* bu_hip_last_error(const bu_hip_context* ctx) { return ctx ? ctx->error.c_str() : g_global_error.c_str(); }
 
@@ -204,7 +243,7 @@ int bu_hip_memcpy_h2d(bu_hip_context* ctx, void* d, const void* h, size_t bytes)
     if (!ctx) return 0;
     if (!bytes) return 1;
     device_guard g(ctx->device);
-    BU_TRY(ctx, hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, ctx->stream));
+    BU_TRY(ctx, h2d(ctx, d, h, bytes));
     BU_TRY(ctx, hipStreamSynchronize(ctx->stream)); // h may be pageable and released by the caller right after
     return 1;
 }
@@ -248,7 +287,7 @@ int bu_hip_set_pixel_blocks(bu_hip_context* ctx, size_t total_blocks, const bu_p
     if (total_blocks > 0xFFFFFFFFull) { set_error(ctx, "too many blocks"); return 0; }
     device_guard g(ctx->device);
     BU_TRY(ctx, ctx->pixel_arena.reserve(total_blocks * sizeof(bu_pixel_block)));
-    if (total_blocks) BU_TRY(ctx, hipMemcpyAsync(ctx->pixel_arena.p, blocks, total_blocks * sizeof(bu_pixel_block), hipMemcpyHostToDevice, ctx->stream));
+    if (total_blocks) BU_TRY(ctx, h2d(ctx, ctx->pixel_arena.p, blocks, total_blocks * sizeof(bu_pixel_block)));
     BU_TRY(ctx, hipStreamSynchronize(ctx->stream)); // the caller may free its copy right after (frontend.cpp:67-79)
     ctx->d_pixel_blocks = ctx->pixel_arena.p;
     ctx->total_blocks = total_blocks;
@@ -300,7 +339,7 @@ int bu_hip_k_generate_endpoint_codebook(bu_hip_context* ctx, const void* d_px, u
     });
     arena& ord = ctx->scratch[5];
     BU_TRY(ctx, ord.reserve(n_clusters * sizeof(uint32_t)));
-    BU_TRY(ctx, hipMemcpyAsync(ord.p, order.data(), n_clusters * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    BU_TRY(ctx, h2d(ctx, ord.p, order.data(), n_clusters * sizeof(uint32_t)));
     {
         prof_scope ps(ctx, "generate_endpoint_codebook");
         BU_TRY(ctx, bu::launch_generate_endpoint_codebook(ctx->stream, d_px, n_clusters, static_cast<const uint32_t*>(ord.p), d_offsets, d_indices,
@@ -372,6 +411,19 @@ struct bu_tsvq {
     uint32_t* perm[2] = {nullptr, nullptr};
     uint8_t* side = nullptr;
     arena nodes, outs;
+    // Pinned staging for the per-round node / result records: hipMemcpyAsync on PAGEABLE host memory followed directly by a
+    // kernel on the same stream was observed to let the kernel read the destination before the copy landed (MI355X, ROCm 7.2:
+    // tools/tsvq_root_repeat.py, 2 of 10 runs), so nothing on this path hands pageable memory to an asynchronous copy.
+    void* pinned = nullptr; size_t pinned_cap = 0;
+    hipError_t reserve_pinned(size_t bytes) {
+        if (bytes <= pinned_cap) return hipSuccess;
+        if (pinned) { (void)hipHostFree(pinned); pinned = nullptr; pinned_cap = 0; }
+        const size_t want = bytes + bytes / 4 + 4096;
+        hipError_t e = hipHostMalloc(&pinned, want, hipHostMallocDefault);
+        if (e != hipSuccess) { pinned = nullptr; return e; }
+        pinned_cap = want;
+        return hipSuccess;
+    }
 };
 
 static_assert(sizeof(bu_tsvq_root) == sizeof(bu::tsvq_root_out), "layout");
@@ -386,6 +438,7 @@ void bu_hip_tsvq_destroy(bu_hip_context* ctx, bu_tsvq* q) {
     (void)hipStreamSynchronize(ctx->stream);
     for (void* p : {q->rows, (void*)q->w64, (void*)q->perm[0], (void*)q->perm[1], (void*)q->side}) if (p) (void)hipFree(p);
     q->nodes.release(); q->outs.release();
+    if (q->pinned) (void)hipHostFree(q->pinned);
     delete q;
 }
 
@@ -402,15 +455,34 @@ static bu_tsvq* tsvq_create_common(bu_hip_context* ctx, uint32_t dim, bool packe
         hipMalloc((void**)&q->side, (size_t)n) != hipSuccess)
         return fail("allocation");
     if (q->outs.reserve(sizeof(bu::tsvq_root_out)) != hipSuccess) return fail("allocation");
-    if (hipMemcpyAsync(q->rows, h_rows, (size_t)n * row_bytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
-        hipMemcpyAsync(q->w64, h_weights, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+    // blocking copies (the sources are pageable, see bu_tsvq::pinned); the root kernel below needs both anyway
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess || hipMemcpy(q->rows, h_rows, (size_t)n * row_bytes, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(q->w64, h_weights, (size_t)n * 8, hipMemcpyHostToDevice) != hipSuccess || hipDeviceSynchronize() != hipSuccess)
         return fail("upload");
+    if (q->reserve_pinned(sizeof(bu_tsvq_root)) != hipSuccess) return fail("pinned allocation");
     {
         prof_scope ps(ctx, "tsvq_root");
         if (bu::launch_tsvq_root(ctx->stream, (int)dim, packed, q->rows, q->w64, n, q->perm[0], static_cast<bu::tsvq_root_out*>(q->outs.p)) != hipSuccess) return fail("root launch");
     }
-    if (hipMemcpyAsync(out_root, q->outs.p, sizeof(bu_tsvq_root), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess)
+    if (hipMemcpyAsync(q->pinned, q->outs.p, sizeof(bu_tsvq_root), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess)
         return fail("root download");
+    std::memcpy(out_root, q->pinned, sizeof(bu_tsvq_root));
+    if (std::getenv("BU_TSVQ_ROOT_DEBUG")) { // debugging aid: is a bad root record the kernel's fault or the upload's?
+        std::vector<char> back((size_t)n * row_bytes); std::vector<uint64_t> wback(n);
+        (void)hipMemcpy(back.data(), q->rows, back.size(), hipMemcpyDeviceToHost); (void)hipMemcpy(wback.data(), q->w64, (size_t)n * 8, hipMemcpyDeviceToHost);
+        size_t bad_rows = 0, bad_w = 0, first_w = n;
+        for (size_t i = 0; i < back.size(); i++) bad_rows += back[i] != static_cast<const char*>(h_rows)[i];
+        for (uint32_t i = 0; i < n; i++) if (wback[i] != h_weights[i]) { bad_w++; if (first_w == n) first_w = i; }
+        bu_tsvq_root again[3];
+        for (int r = 0; r < 3; r++) {
+            (void)bu::launch_tsvq_root(ctx->stream, (int)dim, packed, q->rows, q->w64, n, q->perm[0], static_cast<bu::tsvq_root_out*>(q->outs.p));
+            (void)hipStreamSynchronize(ctx->stream);
+            (void)hipMemcpy(&again[r], q->outs.p, sizeof(bu_tsvq_root), hipMemcpyDeviceToHost);
+        }
+        std::fprintf(stderr, "[tsvq root debug] var %.9g weight %llu | reruns var %.9g %.9g %.9g weight %llu %llu %llu | readback bad row bytes %zu bad weights %zu first %zu\n",
+                     out_root->var, (unsigned long long)out_root->weight, again[0].var, again[1].var, again[2].var, (unsigned long long)again[0].weight,
+                     (unsigned long long)again[1].weight, (unsigned long long)again[2].weight, bad_rows, bad_w, first_w);
+    }
     return q;
 }
 
@@ -428,14 +500,18 @@ int bu_hip_tsvq_split(bu_hip_context* ctx, bu_tsvq* q, const bu_tsvq_node* h_nod
     device_guard g(ctx->device);
     BU_TRY(ctx, q->nodes.reserve((size_t)n_nodes * sizeof(bu_tsvq_node)));
     BU_TRY(ctx, q->outs.reserve((size_t)n_nodes * sizeof(bu_tsvq_split)));
-    BU_TRY(ctx, hipMemcpyAsync(q->nodes.p, h_nodes, (size_t)n_nodes * sizeof(bu_tsvq_node), hipMemcpyHostToDevice, ctx->stream));
+    const size_t in_bytes = (size_t)n_nodes * sizeof(bu_tsvq_node), out_bytes = (size_t)n_nodes * sizeof(bu_tsvq_split);
+    BU_TRY(ctx, q->reserve_pinned(std::max(in_bytes, out_bytes)));
+    std::memcpy(q->pinned, h_nodes, in_bytes);
+    BU_TRY(ctx, hipMemcpyAsync(q->nodes.p, q->pinned, in_bytes, hipMemcpyHostToDevice, ctx->stream));
     {
         prof_scope ps(ctx, "tsvq_split");
         BU_TRY(ctx, bu::launch_tsvq_split(ctx->stream, (int)q->dim, q->packed, q->rows, q->w64, q->perm[0], q->perm[1], q->side,
                                           static_cast<const bu::tsvq_node_in*>(q->nodes.p), n_nodes, static_cast<bu::tsvq_split_out*>(q->outs.p)));
     }
-    BU_TRY(ctx, hipMemcpyAsync(h_out, q->outs.p, (size_t)n_nodes * sizeof(bu_tsvq_split), hipMemcpyDeviceToHost, ctx->stream));
+    BU_TRY(ctx, hipMemcpyAsync(q->pinned, q->outs.p, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
     BU_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    std::memcpy(h_out, q->pinned, out_bytes);
     return 1;
 }
 
@@ -468,7 +544,7 @@ int bu_hip_determine_selectors(bu_hip_context* ctx, const bu_color_rgba* color5_
     arena &in = ctx->scratch[0], &o = ctx->scratch[1];
     BU_TRY(ctx, in.reserve((size_t)n * 4));
     BU_TRY(ctx, o.reserve((size_t)n * 8));
-    BU_TRY(ctx, hipMemcpyAsync(in.p, color5_inten, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+    BU_TRY(ctx, h2d(ctx, in.p, color5_inten, (size_t)n * 4));
     BU_TRY(ctx, bu::launch_determine_selectors(ctx->stream, ctx->d_pixel_blocks, n, static_cast<const uint8_t*>(in.p), nullptr, perceptual != 0, o.p));
     BU_TRY(ctx, hipMemcpyAsync(out, o.p, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
     BU_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -518,11 +594,11 @@ int bu_hip_refine_endpoint_clusterization(bu_hip_context* ctx, const bu_block_in
     arena& a_bp = ctx->scratch[5];
     BU_TRY(ctx, a_par.reserve(total_clusters * 4ull)); BU_TRY(ctx, a_cur.reserve(n * 4ull)); BU_TRY(ctx, a_off.reserve(cand_offsets.size() * 4ull));
     BU_TRY(ctx, a_idx.reserve(cand_indices.size() * 4ull + 4)); BU_TRY(ctx, a_out.reserve(n * 4ull)); BU_TRY(ctx, a_bp.reserve(n));
-    BU_TRY(ctx, hipMemcpyAsync(a_par.p, params.data(), total_clusters * 4ull, hipMemcpyHostToDevice, ctx->stream));
-    BU_TRY(ctx, hipMemcpyAsync(a_cur.p, block_cur.data(), n * 4ull, hipMemcpyHostToDevice, ctx->stream));
-    BU_TRY(ctx, hipMemcpyAsync(a_off.p, cand_offsets.data(), cand_offsets.size() * 4ull, hipMemcpyHostToDevice, ctx->stream));
-    if (!cand_indices.empty()) BU_TRY(ctx, hipMemcpyAsync(a_idx.p, cand_indices.data(), cand_indices.size() * 4ull, hipMemcpyHostToDevice, ctx->stream));
-    BU_TRY(ctx, hipMemcpyAsync(a_bp.p, block_parent8.data(), n, hipMemcpyHostToDevice, ctx->stream));
+    BU_TRY(ctx, h2d(ctx, a_par.p, params.data(), total_clusters * 4ull));
+    BU_TRY(ctx, h2d(ctx, a_cur.p, block_cur.data(), n * 4ull));
+    BU_TRY(ctx, h2d(ctx, a_off.p, cand_offsets.data(), cand_offsets.size() * 4ull));
+    if (!cand_indices.empty()) BU_TRY(ctx, h2d(ctx, a_idx.p, cand_indices.data(), cand_indices.size() * 4ull));
+    BU_TRY(ctx, h2d(ctx, a_bp.p, block_parent8.data(), n));
     BU_TRY(ctx, bu::launch_refine_endpoint_clusterization(ctx->stream, ctx->d_pixel_blocks, n, static_cast<const uint32_t*>(a_cur.p),
                                                           static_cast<const uint8_t*>(a_par.p), total_clusters, (uint32_t)win_first.size(),
                                                           static_cast<const uint32_t*>(a_off.p), static_cast<const uint32_t*>(a_idx.p),
@@ -575,11 +651,11 @@ int bu_hip_find_optimal_selector_clusters_for_each_block(bu_hip_context* ctx, co
     BU_TRY(ctx, a_sel.reserve(total_input_selectors * 8ull + 8)); BU_TRY(ctx, a_enc.reserve(n * 8ull + n * 4ull)); BU_TRY(ctx, a_off.reserve(cand_offsets.size() * 4ull));
     BU_TRY(ctx, a_idx.reserve(cand_indices.size() * 4ull + 4)); BU_TRY(ctx, a_tmp.reserve(n * 4ull)); BU_TRY(ctx, a_bp.reserve(n));
     uint32_t* d_out = reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(a_enc.p) + n * 8ull);
-    if (total_input_selectors) BU_TRY(ctx, hipMemcpyAsync(a_sel.p, sel_blocks.data(), total_input_selectors * 8ull, hipMemcpyHostToDevice, ctx->stream));
-    BU_TRY(ctx, hipMemcpyAsync(a_enc.p, enc.data(), n * 8ull, hipMemcpyHostToDevice, ctx->stream));
-    BU_TRY(ctx, hipMemcpyAsync(a_off.p, cand_offsets.data(), cand_offsets.size() * 4ull, hipMemcpyHostToDevice, ctx->stream));
-    if (!cand_indices.empty()) BU_TRY(ctx, hipMemcpyAsync(a_idx.p, cand_indices.data(), cand_indices.size() * 4ull, hipMemcpyHostToDevice, ctx->stream));
-    BU_TRY(ctx, hipMemcpyAsync(a_bp.p, bp8.data(), n, hipMemcpyHostToDevice, ctx->stream));
+    if (total_input_selectors) BU_TRY(ctx, h2d(ctx, a_sel.p, sel_blocks.data(), total_input_selectors * 8ull));
+    BU_TRY(ctx, h2d(ctx, a_enc.p, enc.data(), n * 8ull));
+    BU_TRY(ctx, h2d(ctx, a_off.p, cand_offsets.data(), cand_offsets.size() * 4ull));
+    if (!cand_indices.empty()) BU_TRY(ctx, h2d(ctx, a_idx.p, cand_indices.data(), cand_indices.size() * 4ull));
+    BU_TRY(ctx, h2d(ctx, a_bp.p, bp8.data(), n));
     // chunk = 0: the OpenCL seam has no "same tile as previous block" shortcut (ocl_kernels.cl:1159-1225)
     BU_TRY(ctx, bu::launch_find_optimal_selector_clusters(ctx->stream, ctx->d_pixel_blocks, a_enc.p, n, a_sel.p, total_input_selectors, (uint32_t)win_first.size(),
                                                           static_cast<const uint32_t*>(a_off.p), static_cast<const uint32_t*>(a_idx.p), static_cast<const uint8_t*>(a_bp.p),
@@ -629,9 +705,9 @@ int bu_hip_encode_etc1s_pixel_clusters(bu_hip_context* ctx, bu_etc_block* out, u
     const size_t params_bytes = ((total_clusters * 4ull + 7) / 8) * 8;
     BU_TRY(ctx, a_px.reserve(words.size() * 4ull)); BU_TRY(ctx, a_off.reserve(offsets.size() * 4ull)); BU_TRY(ctx, a_idx.reserve(expanded.size() * 4ull + 4));
     BU_TRY(ctx, a_par.reserve(params_bytes + total_clusters * 8ull + total_clusters));
-    BU_TRY(ctx, hipMemcpyAsync(a_px.p, words.data(), words.size() * 4ull, hipMemcpyHostToDevice, ctx->stream));
-    BU_TRY(ctx, hipMemcpyAsync(a_off.p, offsets.data(), offsets.size() * 4ull, hipMemcpyHostToDevice, ctx->stream));
-    BU_TRY(ctx, hipMemcpyAsync(a_idx.p, expanded.data(), expanded.size() * 4ull, hipMemcpyHostToDevice, ctx->stream));
+    BU_TRY(ctx, h2d(ctx, a_px.p, words.data(), words.size() * 4ull));
+    BU_TRY(ctx, h2d(ctx, a_off.p, offsets.data(), offsets.size() * 4ull));
+    BU_TRY(ctx, h2d(ctx, a_idx.p, expanded.data(), expanded.size() * 4ull));
     uint8_t* d_params = static_cast<uint8_t*>(a_par.p);
     uint64_t* d_err = reinterpret_cast<uint64_t*>(d_params + params_bytes);
     uint8_t* d_valid = reinterpret_cast<uint8_t*>(d_err + total_clusters);

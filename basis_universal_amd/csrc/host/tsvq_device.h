@@ -9,6 +9,7 @@
 #pragma once
 #include <algorithm>
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -41,6 +42,31 @@ public:
     }
 
 private:
+    // Debug aid (BU_TSVQ_VERIFY=1): a split is a pure function of its node, so re-running every node of a batch on its own must
+    // reproduce the batched result bit for bit, including the children's member lists. Reports the first differences to stderr.
+    static void verify_batch(bu_hip_context* ctx, bu_tsvq* q, const std::vector<bu_tsvq_node>& batch, const bu_tsvq_split* batched, uint32_t round) {
+        std::vector<uint32_t> lists0, lists1;
+        for (size_t i = 0; i < batch.size(); i++) {
+            const bu_tsvq_node& b = batch[i];
+            lists0.resize(b.count); lists1.resize(b.count);
+            if (!bu_hip_tsvq_read_members(ctx, q, b.buf ^ 1u, b.start, b.count, lists0.data())) return;
+            for (int rep = 0; rep < 2; rep++) {
+                bu_tsvq_split s; std::memset(&s, 0, sizeof(s));
+                if (!bu_hip_tsvq_split(ctx, q, &b, 1, &s)) return;
+                if (!bu_hip_tsvq_read_members(ctx, q, b.buf ^ 1u, b.start, b.count, lists1.data())) return;
+                bu_tsvq_split ref = batched[i]; ref.pad = 0; s.pad = 0;
+                const bool same_out = s.ok == ref.ok && (!s.ok || std::memcmp(&s, &ref, sizeof(s)) == 0);
+                const bool same_list = !s.ok || lists0 == lists1;
+                if (!same_out || !same_list) {
+                    size_t first = 0; while (first < b.count && lists0[first] == lists1[first]) first++;
+                    std::fprintf(stderr, "[tsvq verify] round %u batch %zu/%zu node{buf %u start %u count %u} rep %d: out %s lists %s | batched ok %u l %u r %u lvar %.9g rvar %.9g | serial ok %u l %u r %u lvar %.9g rvar %.9g | first list diff at %zu\n",
+                                 round, i, batch.size(), b.buf, b.start, b.count, rep, same_out ? "same" : "DIFF", same_list ? "same" : "DIFF", batched[i].ok, batched[i].l_count,
+                                 batched[i].r_count, batched[i].l_var, batched[i].r_var, s.ok, s.l_count, s.r_count, s.l_var, s.r_var, first);
+                }
+            }
+        }
+    }
+
     static bool build(bu_hip_context* ctx, bu_tsvq* q, const bu_tsvq_root& root, uint32_t n, const std::vector<std::vector<uint32_t>>& groups,
                       uint32_t max_codebook_size, uint32_t max_parent_codebook_size, std::vector<std::vector<uint32_t>>& codebook,
                       std::vector<std::vector<uint32_t>>& parent_codebook, stats* st) {
@@ -123,6 +149,7 @@ private:
                 for (size_t i = 0; i < batch.size(); i++)
                     if (!bu_hip_tsvq_split(ctx, q, &batch[i], 1, cache.data() + base + i)) return false;
             } else if (!bu_hip_tsvq_split(ctx, q, batch.data(), (uint32_t)batch.size(), cache.data() + base)) return false;
+            if (std::getenv("BU_TSVQ_VERIFY")) verify_batch(ctx, q, batch, cache.data() + base, local.rounds);
             for (size_t i = 0; i < batch.size(); i++) nodes[batch_nodes[i]].cached = (int32_t)(base + i);
             local.rounds++; local.splits_computed += (uint32_t)batch.size();
         }

@@ -69,8 +69,11 @@ struct float_rows {
 struct packed16_rows { // 16 two-bit values, element 0 in the top two bits (the order the frontend's de-duplication keys use)
     const uint32_t* keys;
     struct payload { uint32_t key; uint64_t w; uint32_t mi; };
+// Depth 8 is NOT safe here: at -O3 the packed root kernel then returns a wrong origin in ~25% of launches on MI355X
+// (tools/tsvq_root_repeat.py; -O1 at depth 8 and -O3 at depths 1/4 are stable) -- treated as a code generation hazard of the
+// 8-way unrolled register queue, so the queue stays at 4 and tests/test_gpu_tsvq.py repeats the root launch to catch a relapse.
 #ifndef BU_TQ_DEPTH_PACKED
-#define BU_TQ_DEPTH_PACKED 8
+#define BU_TQ_DEPTH_PACKED 4
 #endif
     static constexpr int DEPTH = BU_TQ_DEPTH_PACKED;
     __device__ __forceinline__ payload fetch(const uint64_t* __restrict__ w64, uint32_t mi) const {
