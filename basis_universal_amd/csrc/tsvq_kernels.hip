@@ -139,15 +139,24 @@ __device__ __forceinline__ void pipeline_pass(char* lds, const Src& src, const u
     }
 }
 
-// order-preserving running sum of one LDS row (16-byte reads, adds strictly in member order)
+// Order-preserving running sum of one LDS row: the adds happen strictly in member order (one dependent v_add per member is the
+// floor of this algorithm), the 16-byte LDS reads of the NEXT group are issued before the current group is added so that the LDS
+// latency stays off the dependent chain.
 __device__ __forceinline__ void chain_add_f32(float& acc, const float* src, uint32_t m) {
-    uint32_t j = 0;
-    for (; j + 16 <= m; j += 16) {
-        const float4 a = *reinterpret_cast<const float4*>(src + j), b = *reinterpret_cast<const float4*>(src + j + 4);
-        const float4 c = *reinterpret_cast<const float4*>(src + j + 8), d = *reinterpret_cast<const float4*>(src + j + 12);
-        acc += a.x; acc += a.y; acc += a.z; acc += a.w; acc += b.x; acc += b.y; acc += b.z; acc += b.w;
-        acc += c.x; acc += c.y; acc += c.z; acc += c.w; acc += d.x; acc += d.y; acc += d.z; acc += d.w;
+    if (m == (uint32_t)TQ_TILE) {
+        const float4* p = reinterpret_cast<const float4*>(src);
+        float4 c0 = p[0], c1 = p[1], c2 = p[2], c3 = p[3];
+#pragma unroll
+        for (int g = 0; g < TQ_TILE / 16; g++) {
+            float4 n0 = c0, n1 = c1, n2 = c2, n3 = c3;
+            if (g + 1 < TQ_TILE / 16) { n0 = p[g * 4 + 4]; n1 = p[g * 4 + 5]; n2 = p[g * 4 + 6]; n3 = p[g * 4 + 7]; }
+            acc += c0.x; acc += c0.y; acc += c0.z; acc += c0.w; acc += c1.x; acc += c1.y; acc += c1.z; acc += c1.w;
+            acc += c2.x; acc += c2.y; acc += c2.z; acc += c2.w; acc += c3.x; acc += c3.y; acc += c3.z; acc += c3.w;
+            c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        }
+        return;
     }
+    uint32_t j = 0;
     for (; j + 4 <= m; j += 4) {
         const float4 a = *reinterpret_cast<const float4*>(src + j);
         acc += a.x; acc += a.y; acc += a.z; acc += a.w;
@@ -155,12 +164,49 @@ __device__ __forceinline__ void chain_add_f32(float& acc, const float* src, uint
     for (; j < m; j++) acc += src[j];
 }
 __device__ __forceinline__ void chain_add_f64(double& acc, const double* src, uint32_t m) {
+    if (m == (uint32_t)TQ_TILE) {
+        const double2* p = reinterpret_cast<const double2*>(src);
+        double2 c0 = p[0], c1 = p[1], c2 = p[2], c3 = p[3];
+#pragma unroll
+        for (int g = 0; g < TQ_TILE / 8; g++) {
+            double2 n0 = c0, n1 = c1, n2 = c2, n3 = c3;
+            if (g + 1 < TQ_TILE / 8) { n0 = p[g * 4 + 4]; n1 = p[g * 4 + 5]; n2 = p[g * 4 + 6]; n3 = p[g * 4 + 7]; }
+            acc += c0.x; acc += c0.y; acc += c1.x; acc += c1.y; acc += c2.x; acc += c2.y; acc += c3.x; acc += c3.y;
+            c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        }
+        return;
+    }
     uint32_t j = 0;
-    for (; j + 4 <= m; j += 4) {
-        const double2 a = *reinterpret_cast<const double2*>(src + j), b = *reinterpret_cast<const double2*>(src + j + 2);
-        acc += a.x; acc += a.y; acc += b.x; acc += b.y;
+    for (; j + 2 <= m; j += 2) {
+        const double2 a = *reinterpret_cast<const double2*>(src + j);
+        acc += a.x; acc += a.y;
     }
     for (; j < m; j++) acc += src[j];
+}
+// covariance chain: adds dx[j] * wy[j] in member order (product rounded to float first, enc.h:1819)
+__device__ __forceinline__ void chain_add_prod_f32(float& acc, const float* dx, const float* wy, uint32_t m) {
+    if (m == (uint32_t)TQ_TILE) {
+        const float4* pa = reinterpret_cast<const float4*>(dx);
+        const float4* pb = reinterpret_cast<const float4*>(wy);
+        float4 a0 = pa[0], a1 = pa[1], b0 = pb[0], b1 = pb[1];
+#pragma unroll
+        for (int g = 0; g < TQ_TILE / 8; g++) {
+            float4 na0 = a0, na1 = a1, nb0 = b0, nb1 = b1;
+            if (g + 1 < TQ_TILE / 8) { na0 = pa[g * 2 + 2]; na1 = pa[g * 2 + 3]; nb0 = pb[g * 2 + 2]; nb1 = pb[g * 2 + 3]; }
+            const float p0 = a0.x * b0.x, p1 = a0.y * b0.y, p2 = a0.z * b0.z, p3 = a0.w * b0.w;
+            const float p4 = a1.x * b1.x, p5 = a1.y * b1.y, p6 = a1.z * b1.z, p7 = a1.w * b1.w;
+            acc = acc + p0; acc = acc + p1; acc = acc + p2; acc = acc + p3; acc = acc + p4; acc = acc + p5; acc = acc + p6; acc = acc + p7;
+            a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
+        }
+        return;
+    }
+    uint32_t j = 0;
+    for (; j + 4 <= m; j += 4) {
+        const float4 a = *reinterpret_cast<const float4*>(dx + j), b = *reinterpret_cast<const float4*>(wy + j);
+        const float p0 = a.x * b.x, p1 = a.y * b.y, p2 = a.z * b.z, p3 = a.w * b.w;
+        acc = acc + p0; acc = acc + p1; acc = acc + p2; acc = acc + p3;
+    }
+    for (; j < m; j++) { const float pp = dx[j] * wy[j]; acc = acc + pp; }
 }
 
 // compute_pca_from_covar (enc.h:605-648) on one thread: 8 power iterations, double row sums, float early-out.
@@ -229,7 +275,7 @@ __global__ __launch_bounds__(TQ_THREADS) void k_tsvq_root(Src src, const uint64_
     const int tid = threadIdx.x;
     float acc_f = 0.0f; double acc_d = 0.0;
     uint64_t wsum = 0;
-    pipeline_pass<N, 1, 1>(lds, src, w64, nullptr, n,
+    pipeline_pass<N, 1, 2>(lds, src, w64, nullptr, n, // wave 0: the N float chains, wave 1: the double chain
         [&](uint32_t, const typename Src::payload& p, float* f, double* d) {
             float v[N]; Src::decode(p, v);
             const float w = (float)p.w;
@@ -241,11 +287,11 @@ __global__ __launch_bounds__(TQ_THREADS) void k_tsvq_root(Src src, const uint64_
         },
         [&](const float* f, const double* d, uint32_t m) {
             if (tid < N) chain_add_f32(acc_f, f + (size_t)tid * TQ_STRIDE, m);
-            else if (tid == N) chain_add_f64(acc_d, d, m);
+            else if (tid == 64) chain_add_f64(acc_d, d, m);
         });
     wsum = block_sum_u64(wsum, s_red);
     if (tid < N) s_origin[tid] = acc_f;
-    if (tid == N) s_tt = acc_d;
+    if (tid == 64) s_tt = acc_d;
     __syncthreads();
     if (tid == 0) {
         float o[N];
@@ -290,7 +336,7 @@ __global__ __launch_bounds__(TQ_THREADS) void k_tsvq_split(Src src, const uint64
         float acc_f = 0.0f; double acc_d = 0.0;
         uint64_t lw = 0, rw = 0; uint32_t ln = 0;
         const uint32_t first_member = members[0];
-        pipeline_pass<2 * N, 2, 1>(lds, src, w64, members, count,
+        pipeline_pass<2 * N, 2, 2>(lds, src, w64, members, count, // wave 0: 2N float chains, wave 1: the two double chains
             [&](uint32_t pos, const payload& p, float* f, double* d) {
                 float v[N]; Src::decode(p, v);
                 const float w = (float)p.w;
@@ -330,11 +376,11 @@ __global__ __launch_bounds__(TQ_THREADS) void k_tsvq_split(Src src, const uint64
             },
             [&](const float* f, const double* d, uint32_t m) {
                 if (tid < 2 * N) chain_add_f32(acc_f, f + (size_t)tid * TQ_STRIDE, m);
-                else if (tid < 2 * N + 2) chain_add_f64(acc_d, d + (size_t)(tid - 2 * N) * TQ_TILE, m);
+                else if (tid == 64 || tid == 65) chain_add_f64(acc_d, d + (size_t)(tid - 64) * TQ_TILE, m);
             });
         if (tid < 2 * N) s_sum[tid / N][tid % N] = acc_f;
-        if (tid == 2 * N) s_dsum[0] = acc_d;
-        if (tid == 2 * N + 1) s_dsum[1] = acc_d;
+        if (tid == 64) s_dsum[0] = acc_d;
+        if (tid == 65) s_dsum[1] = acc_d;
         const uint64_t LW = block_sum_u64(lw, s_red);
         const uint64_t RW = block_sum_u64(rw, s_red);
         const uint64_t LN = block_sum_u64((uint64_t)ln, s_red);
@@ -369,18 +415,7 @@ __global__ __launch_bounds__(TQ_THREADS) void k_tsvq_split(Src src, const uint64
                 }
             },
             [&](const float* f, const double*, uint32_t m) {
-                if (tid >= C) return;
-                const float* dx = f + (size_t)cx * TQ_STRIDE;
-                const float* wy = f + (size_t)(N + cy) * TQ_STRIDE;
-                uint32_t j = 0;
-                for (; j + 8 <= m; j += 8) {
-                    const float4 a0 = *reinterpret_cast<const float4*>(dx + j), a1 = *reinterpret_cast<const float4*>(dx + j + 4);
-                    const float4 b0 = *reinterpret_cast<const float4*>(wy + j), b1 = *reinterpret_cast<const float4*>(wy + j + 4);
-                    const float p0 = a0.x * b0.x, p1 = a0.y * b0.y, p2 = a0.z * b0.z, p3 = a0.w * b0.w;
-                    const float p4 = a1.x * b1.x, p5 = a1.y * b1.y, p6 = a1.z * b1.z, p7 = a1.w * b1.w;
-                    cv = cv + p0; cv = cv + p1; cv = cv + p2; cv = cv + p3; cv = cv + p4; cv = cv + p5; cv = cv + p6; cv = cv + p7;
-                }
-                for (; j < m; j++) { const float pp = dx[j] * wy[j]; cv = cv + pp; }
+                if (tid < C) chain_add_prod_f32(cv, f + (size_t)cx * TQ_STRIDE, f + (size_t)(N + cy) * TQ_STRIDE, m);
             });
         if (tid < C) c.cov[cx][cy] = cv;
         __syncthreads();
