@@ -411,6 +411,7 @@ struct bu_tsvq {
     uint32_t* perm[2] = {nullptr, nullptr};
     uint8_t* side = nullptr;
     arena nodes, outs;
+    bool force_chained = false; // BU_TSVQ_CHAINED=1: never use the exact (integer-reduced) kernel variants (tests compare both)
     // Pinned staging for the per-round node / result records: hipMemcpyAsync on PAGEABLE host memory followed directly by a
     // kernel on the same stream was observed to let the kernel read the destination before the copy landed (MI355X, ROCm 7.2:
     // tools/tsvq_root_repeat.py, 2 of 10 runs), so nothing on this path hands pageable memory to an asynchronous copy.
@@ -448,6 +449,7 @@ static bu_tsvq* tsvq_create_common(bu_hip_context* ctx, uint32_t dim, bool packe
     bu_tsvq* q = new (std::nothrow) bu_tsvq();
     if (!q) return nullptr;
     q->dim = dim; q->n = n; q->packed = packed;
+    q->force_chained = std::getenv("BU_TSVQ_CHAINED") != nullptr;
     const size_t row_bytes = packed ? 4 : (size_t)dim * 4;
     auto fail = [&](const char* what) -> bu_tsvq* { set_error(ctx, "tsvq_create: %s", what); bu_hip_tsvq_destroy(ctx, q); return nullptr; };
     if (hipMalloc(&q->rows, (size_t)n * row_bytes) != hipSuccess || hipMalloc((void**)&q->w64, (size_t)n * 8) != hipSuccess ||
@@ -460,29 +462,18 @@ static bu_tsvq* tsvq_create_common(bu_hip_context* ctx, uint32_t dim, bool packe
         hipMemcpy(q->w64, h_weights, (size_t)n * 8, hipMemcpyHostToDevice) != hipSuccess || hipDeviceSynchronize() != hipSuccess)
         return fail("upload");
     if (q->reserve_pinned(sizeof(bu_tsvq_root)) != hipSuccess) return fail("pinned allocation");
-    {
-        prof_scope ps(ctx, "tsvq_root");
-        if (bu::launch_tsvq_root(ctx->stream, (int)dim, packed, q->rows, q->w64, n, q->perm[0], static_cast<bu::tsvq_root_out*>(q->outs.p)) != hipSuccess) return fail("root launch");
-    }
-    if (hipMemcpyAsync(q->pinned, q->outs.p, sizeof(bu_tsvq_root), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess)
-        return fail("root download");
-    std::memcpy(out_root, q->pinned, sizeof(bu_tsvq_root));
-    if (std::getenv("BU_TSVQ_ROOT_DEBUG")) { // debugging aid: is a bad root record the kernel's fault or the upload's?
-        std::vector<char> back((size_t)n * row_bytes); std::vector<uint64_t> wback(n);
-        (void)hipMemcpy(back.data(), q->rows, back.size(), hipMemcpyDeviceToHost); (void)hipMemcpy(wback.data(), q->w64, (size_t)n * 8, hipMemcpyDeviceToHost);
-        size_t bad_rows = 0, bad_w = 0, first_w = n;
-        for (size_t i = 0; i < back.size(); i++) bad_rows += back[i] != static_cast<const char*>(h_rows)[i];
-        for (uint32_t i = 0; i < n; i++) if (wback[i] != h_weights[i]) { bad_w++; if (first_w == n) first_w = i; }
-        bu_tsvq_root again[3];
-        for (int r = 0; r < 3; r++) {
-            (void)bu::launch_tsvq_root(ctx->stream, (int)dim, packed, q->rows, q->w64, n, q->perm[0], static_cast<bu::tsvq_root_out*>(q->outs.p));
-            (void)hipStreamSynchronize(ctx->stream);
-            (void)hipMemcpy(&again[r], q->outs.p, sizeof(bu_tsvq_root), hipMemcpyDeviceToHost);
+    // exact (integer-reduced) variant first where it exists; a record flagged pad == 1 left the exact range -> chained variant
+    for (int attempt = 0; attempt < 2; attempt++) {
+        const bool exact = packed && attempt == 0 && !q->force_chained;
+        {
+            prof_scope ps(ctx, "tsvq_root");
+            if (bu::launch_tsvq_root(ctx->stream, (int)dim, packed, exact, q->rows, q->w64, n, q->perm[0], static_cast<bu::tsvq_root_out*>(q->outs.p)) != hipSuccess) return fail("root launch");
         }
-        std::fprintf(stderr, "[tsvq root debug] var %.9g weight %llu | reruns var %.9g %.9g %.9g weight %llu %llu %llu | readback bad row bytes %zu bad weights %zu first %zu\n",
-                     out_root->var, (unsigned long long)out_root->weight, again[0].var, again[1].var, again[2].var, (unsigned long long)again[0].weight,
-                     (unsigned long long)again[1].weight, (unsigned long long)again[2].weight, bad_rows, bad_w, first_w);
+        if (hipMemcpyAsync(q->pinned, q->outs.p, sizeof(bu_tsvq_root), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess)
+            return fail("root download");
+        if (!exact || static_cast<const bu_tsvq_root*>(q->pinned)->pad == 0) break;
     }
+    std::memcpy(out_root, q->pinned, sizeof(bu_tsvq_root));
     return q;
 }
 
@@ -504,14 +495,33 @@ int bu_hip_tsvq_split(bu_hip_context* ctx, bu_tsvq* q, const bu_tsvq_node* h_nod
     BU_TRY(ctx, q->reserve_pinned(std::max(in_bytes, out_bytes)));
     std::memcpy(q->pinned, h_nodes, in_bytes);
     BU_TRY(ctx, hipMemcpyAsync(q->nodes.p, q->pinned, in_bytes, hipMemcpyHostToDevice, ctx->stream));
+    const bool exact = q->packed && !q->force_chained;
     {
         prof_scope ps(ctx, "tsvq_split");
-        BU_TRY(ctx, bu::launch_tsvq_split(ctx->stream, (int)q->dim, q->packed, q->rows, q->w64, q->perm[0], q->perm[1], q->side,
+        BU_TRY(ctx, bu::launch_tsvq_split(ctx->stream, (int)q->dim, q->packed, exact, q->rows, q->w64, q->perm[0], q->perm[1], q->side,
                                           static_cast<const bu::tsvq_node_in*>(q->nodes.p), n_nodes, static_cast<bu::tsvq_split_out*>(q->outs.p)));
     }
     BU_TRY(ctx, hipMemcpyAsync(q->pinned, q->outs.p, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
     BU_TRY(ctx, hipStreamSynchronize(ctx->stream));
     std::memcpy(h_out, q->pinned, out_bytes);
+    if (exact) { // nodes whose data left the exact range (ok == 2) go through the chained variant
+        std::vector<uint32_t> redo;
+        for (uint32_t i = 0; i < n_nodes; i++) if (h_out[i].ok == 2) redo.push_back(i);
+        if (!redo.empty()) {
+            bu_tsvq_node* pn = static_cast<bu_tsvq_node*>(q->pinned);
+            for (size_t j = 0; j < redo.size(); j++) pn[j] = h_nodes[redo[j]];
+            BU_TRY(ctx, hipMemcpyAsync(q->nodes.p, q->pinned, redo.size() * sizeof(bu_tsvq_node), hipMemcpyHostToDevice, ctx->stream));
+            {
+                prof_scope ps(ctx, "tsvq_split");
+                BU_TRY(ctx, bu::launch_tsvq_split(ctx->stream, (int)q->dim, q->packed, false, q->rows, q->w64, q->perm[0], q->perm[1], q->side,
+                                                  static_cast<const bu::tsvq_node_in*>(q->nodes.p), (uint32_t)redo.size(), static_cast<bu::tsvq_split_out*>(q->outs.p)));
+            }
+            BU_TRY(ctx, hipMemcpyAsync(q->pinned, q->outs.p, redo.size() * sizeof(bu_tsvq_split), hipMemcpyDeviceToHost, ctx->stream));
+            BU_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            const bu_tsvq_split* po = static_cast<const bu_tsvq_split*>(q->pinned);
+            for (size_t j = 0; j < redo.size(); j++) h_out[redo[j]] = po[j];
+        }
+    }
     return 1;
 }
 

@@ -297,9 +297,11 @@ private:
                     const float wf = static_cast<float>(w);
                     if (!i || rows_equal(v, first)) {
                         std::memcpy(first, v, sizeof(first));
-                        for (int k = 0; k < N; k++) nr[k] += v[k] * wf; R.weight += w; r_tt += wf * dot(v, v); R.members.push_back(m);
+                        for (int k = 0; k < N; k++) nr[k] += v[k] * wf;
+                        R.weight += w; r_tt += wf * dot(v, v); R.members.push_back(m);
                     } else {
-                        for (int k = 0; k < N; k++) nl[k] += v[k] * wf; L.weight += w; l_tt += wf * dot(v, v); L.members.push_back(m);
+                        for (int k = 0; k < N; k++) nl[k] += v[k] * wf;
+                        L.weight += w; l_tt += wf * dot(v, v); L.members.push_back(m);
                     }
                 }
                 if (!L.weight || !R.weight) return false;

@@ -48,12 +48,9 @@ template <int N> __device__ __forceinline__ float dot_seq(const float* a, const 
 // ---- where a training vector comes from
 template <int N>
 struct float_rows {
+    static constexpr bool PACKED = false;
     const float* rows;
     struct payload { float v[N]; uint64_t w; uint32_t mi; };
-#ifndef BU_TQ_DEPTH_FLOAT
-#define BU_TQ_DEPTH_FLOAT 4
-#endif
-    static constexpr int DEPTH = BU_TQ_DEPTH_FLOAT;
     __device__ __forceinline__ payload fetch(const uint64_t* __restrict__ w64, uint32_t mi) const {
         payload p; p.mi = mi; p.w = w64[mi];
         const float* r = rows + (size_t)mi * N;
@@ -67,15 +64,9 @@ struct float_rows {
     }
 };
 struct packed16_rows { // 16 two-bit values, element 0 in the top two bits (the order the frontend's de-duplication keys use)
+    static constexpr bool PACKED = true;
     const uint32_t* keys;
     struct payload { uint32_t key; uint64_t w; uint32_t mi; };
-// Depth 8 is NOT safe here: at -O3 the packed root kernel then returns a wrong origin in ~25% of launches on MI355X
-// (tools/tsvq_root_repeat.py; -O1 at depth 8 and -O3 at depths 1/4 are stable) -- treated as a code generation hazard of the
-// 8-way unrolled register queue, so the queue stays at 4 and tests/test_gpu_tsvq.py repeats the root launch to catch a relapse.
-#ifndef BU_TQ_DEPTH_PACKED
-#define BU_TQ_DEPTH_PACKED 4
-#endif
-    static constexpr int DEPTH = BU_TQ_DEPTH_PACKED;
     __device__ __forceinline__ payload fetch(const uint64_t* __restrict__ w64, uint32_t mi) const {
         payload p; p.mi = mi; p.w = w64[mi]; p.key = keys[mi];
         return p;
@@ -92,67 +83,86 @@ struct packed16_rows { // 16 two-bit values, element 0 in the top two bits (the 
 template <int FROWS, int DROWS, int CW, typename Src, typename Emit, typename Consume>
 __device__ __forceinline__ void pipeline_pass(char* lds, const Src& src, const uint64_t* __restrict__ w64, const uint32_t* __restrict__ members,
                                               uint32_t count, Emit emit, Consume consume) {
-    constexpr int K = Src::DEPTH;
     constexpr size_t F_BYTES = (size_t)FROWS * TQ_STRIDE * sizeof(float);
     constexpr size_t D_BYTES = (size_t)DROWS * TQ_TILE * sizeof(double);
     constexpr size_t BUF_BYTES = ((F_BYTES + D_BYTES + 15) / 16) * 16;
-    static_assert(TQ_THREADS - CW * 64 >= TQ_TILE, "one producer thread per tile slot");
+    static_assert(TQ_THREADS == 512 && TQ_TILE == 256 && CW >= 1 && CW <= 3, "wave roles below assume 8 waves, 4 of them producing");
     const int tid = threadIdx.x;
     const bool consumer = tid < CW * 64;
-    const uint32_t pid = (uint32_t)(tid - CW * 64);
-    const bool producer = !consumer && pid < (uint32_t)TQ_TILE;
+    // Producer waves are chosen so that they do not share a SIMD with a chain consumer where that is possible (waves are dealt to
+    // the 4 SIMDs round robin): a dependent add chain issues one VALU op per ~4 cycles and every foreign op on its SIMD delays it.
+    const int wave = tid >> 6;
+    int pslot = -1;
+    if (CW == 1) pslot = wave == 1 ? 0 : wave == 2 ? 1 : wave == 3 ? 2 : wave == 5 ? 3 : -1;        // SIMD 0 is the consumer's alone
+    else if (CW == 2) pslot = wave == 2 ? 0 : wave == 3 ? 1 : wave == 6 ? 2 : wave == 7 ? 3 : -1;   // SIMD 0 / 1 reserved
+    else pslot = wave == 3 ? 0 : wave == 7 ? 1 : wave == 4 ? 2 : wave == 5 ? 3 : -1;                // 136 covariance chains need three waves
+    const bool producer = pslot >= 0;
+    const uint32_t pid = (uint32_t)(pslot * 64 + (tid & 63));
     const uint32_t tiles = (count + TQ_TILE - 1) / TQ_TILE;
     auto fptr = [&](uint32_t t) { return reinterpret_cast<float*>(lds + (size_t)(t & 1u) * BUF_BYTES); };
     auto dptr = [&](uint32_t t) { return reinterpret_cast<double*>(lds + (size_t)(t & 1u) * BUF_BYTES + F_BYTES); };
     using payload = typename Src::payload;
-    auto fetch_tile = [&](uint32_t t) -> payload {
-        payload p{};
-        const uint32_t pos = t * TQ_TILE + pid;
-        if (producer && t < tiles && pos < count) p = src.fetch(w64, members ? members[pos] : pos);
-        return p;
+    // Producer schedule. The gather is two dependent loads (member index, then that member's row and weight). Both stages are
+    // issued one tile period ahead of their use, right after the top-of-iteration wait, so a conservative `s_waitcnt vmcnt(0)`
+    // there (which is what the compiler emits around the predicated emit code) only ever waits for loads that have had a whole
+    // tile period (about one HBM latency) to land. Loads are unconditional on a clamped position: a predicated load would be
+    // sunk into the emit branch and waited for on the spot.
+    const uint32_t last = count - 1;
+    auto fetch_index = [&](uint32_t t) -> uint32_t {
+        const uint32_t pos = min(t * TQ_TILE + pid, last);
+        return members ? members[pos] : pos;
     };
     auto emit_tile = [&](uint32_t t, const payload& p) {
         const uint32_t pos = t * TQ_TILE + pid;
-        if (producer && pos < count) emit(pos, p, fptr(t) + pid, dptr(t) + pid);
+        if (pos < count) emit(pos, p, fptr(t) + pid, dptr(t) + pid);
     };
-    payload q[K];
-#pragma unroll
-    for (int i = 0; i < K; i++) q[i] = fetch_tile((uint32_t)i);
-    emit_tile(0, q[0]);
-    q[0] = fetch_tile((uint32_t)K);
-    __syncthreads();
-    for (uint32_t t0 = 0; t0 < tiles; t0 += K) {
-#pragma unroll
-        for (int i = 0; i < K; i++) {
-            const uint32_t t = t0 + (uint32_t)i;
-            if (t >= tiles) break;
-            if (!consumer) {
-                if (t + 1 < tiles) {
-                    emit_tile(t + 1, q[(i + 1) % K]);
-                    q[(i + 1) % K] = fetch_tile(t + 1 + K);
-                }
-            } else {
-                consume(fptr(t), dptr(t), min((uint32_t)TQ_TILE, count - t * TQ_TILE));
-            }
+    if (producer) { // wave-uniform roles: each role runs its own loop, the barriers pair up one to one
+        uint32_t idx = fetch_index(0);
+        payload pay = src.fetch(w64, idx);   // tile 0
+        idx = fetch_index(1);
+        emit_tile(0, pay);
+        pay = src.fetch(w64, idx);           // tile 1
+        idx = fetch_index(2);                // index of tile 2
+        __syncthreads();
+        for (uint32_t t = 0; t < tiles; t++) {
+            if (t + 1 < tiles) emit_tile(t + 1, pay);
+            pay = src.fetch(w64, idx);       // tile t + 2 (clamped past the end)
+            idx = fetch_index(t + 3);
             __syncthreads();
         }
+    } else if (consumer) {
+        __syncthreads();
+        for (uint32_t t = 0; t < tiles; t++) {
+            consume(fptr(t), dptr(t), min((uint32_t)TQ_TILE, count - t * TQ_TILE));
+            __syncthreads();
+        }
+    } else {
+        __syncthreads();
+        for (uint32_t t = 0; t < tiles; t++) __syncthreads();
     }
 }
 
 // Order-preserving running sum of one LDS row: the adds happen strictly in member order (one dependent v_add per member is the
 // floor of this algorithm), the 16-byte LDS reads of the NEXT group are issued before the current group is added so that the LDS
 // latency stays off the dependent chain.
+constexpr int TQ_AHEAD = 3; // LDS read groups in flight ahead of the adds (a ds_read_b128 takes ~2 groups of dependent adds to land)
 __device__ __forceinline__ void chain_add_f32(float& acc, const float* src, uint32_t m) {
     if (m == (uint32_t)TQ_TILE) {
+        constexpr int G = TQ_TILE / 16;
         const float4* p = reinterpret_cast<const float4*>(src);
-        float4 c0 = p[0], c1 = p[1], c2 = p[2], c3 = p[3];
+        float4 r[TQ_AHEAD + 1][4];
 #pragma unroll
-        for (int g = 0; g < TQ_TILE / 16; g++) {
-            float4 n0 = c0, n1 = c1, n2 = c2, n3 = c3;
-            if (g + 1 < TQ_TILE / 16) { n0 = p[g * 4 + 4]; n1 = p[g * 4 + 5]; n2 = p[g * 4 + 6]; n3 = p[g * 4 + 7]; }
-            acc += c0.x; acc += c0.y; acc += c0.z; acc += c0.w; acc += c1.x; acc += c1.y; acc += c1.z; acc += c1.w;
-            acc += c2.x; acc += c2.y; acc += c2.z; acc += c2.w; acc += c3.x; acc += c3.y; acc += c3.z; acc += c3.w;
-            c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        for (int g = 0; g < TQ_AHEAD; g++)
+#pragma unroll
+            for (int k = 0; k < 4; k++) r[g][k] = p[g * 4 + k];
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+            if (g + TQ_AHEAD < G)
+#pragma unroll
+                for (int k = 0; k < 4; k++) r[(g + TQ_AHEAD) % (TQ_AHEAD + 1)][k] = p[(g + TQ_AHEAD) * 4 + k];
+            __builtin_amdgcn_sched_barrier(0); // keep the reads TQ_AHEAD groups ahead: the scheduler otherwise sinks them next to their use
+#pragma unroll
+            for (int k = 0; k < 4; k++) { const float4 c = r[g % (TQ_AHEAD + 1)][k]; acc += c.x; acc += c.y; acc += c.z; acc += c.w; }
         }
         return;
     }
@@ -165,14 +175,21 @@ __device__ __forceinline__ void chain_add_f32(float& acc, const float* src, uint
 }
 __device__ __forceinline__ void chain_add_f64(double& acc, const double* src, uint32_t m) {
     if (m == (uint32_t)TQ_TILE) {
+        constexpr int G = TQ_TILE / 8;
         const double2* p = reinterpret_cast<const double2*>(src);
-        double2 c0 = p[0], c1 = p[1], c2 = p[2], c3 = p[3];
+        double2 r[TQ_AHEAD + 1][4];
 #pragma unroll
-        for (int g = 0; g < TQ_TILE / 8; g++) {
-            double2 n0 = c0, n1 = c1, n2 = c2, n3 = c3;
-            if (g + 1 < TQ_TILE / 8) { n0 = p[g * 4 + 4]; n1 = p[g * 4 + 5]; n2 = p[g * 4 + 6]; n3 = p[g * 4 + 7]; }
-            acc += c0.x; acc += c0.y; acc += c1.x; acc += c1.y; acc += c2.x; acc += c2.y; acc += c3.x; acc += c3.y;
-            c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        for (int g = 0; g < TQ_AHEAD; g++)
+#pragma unroll
+            for (int k = 0; k < 4; k++) r[g][k] = p[g * 4 + k];
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+            if (g + TQ_AHEAD < G)
+#pragma unroll
+                for (int k = 0; k < 4; k++) r[(g + TQ_AHEAD) % (TQ_AHEAD + 1)][k] = p[(g + TQ_AHEAD) * 4 + k];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 0; k < 4; k++) { const double2 c = r[g % (TQ_AHEAD + 1)][k]; acc += c.x; acc += c.y; }
         }
         return;
     }
@@ -186,17 +203,26 @@ __device__ __forceinline__ void chain_add_f64(double& acc, const double* src, ui
 // covariance chain: adds dx[j] * wy[j] in member order (product rounded to float first, enc.h:1819)
 __device__ __forceinline__ void chain_add_prod_f32(float& acc, const float* dx, const float* wy, uint32_t m) {
     if (m == (uint32_t)TQ_TILE) {
+        constexpr int G = TQ_TILE / 8;
         const float4* pa = reinterpret_cast<const float4*>(dx);
         const float4* pb = reinterpret_cast<const float4*>(wy);
-        float4 a0 = pa[0], a1 = pa[1], b0 = pb[0], b1 = pb[1];
+        float4 ra[TQ_AHEAD + 1][2], rb[TQ_AHEAD + 1][2];
 #pragma unroll
-        for (int g = 0; g < TQ_TILE / 8; g++) {
-            float4 na0 = a0, na1 = a1, nb0 = b0, nb1 = b1;
-            if (g + 1 < TQ_TILE / 8) { na0 = pa[g * 2 + 2]; na1 = pa[g * 2 + 3]; nb0 = pb[g * 2 + 2]; nb1 = pb[g * 2 + 3]; }
-            const float p0 = a0.x * b0.x, p1 = a0.y * b0.y, p2 = a0.z * b0.z, p3 = a0.w * b0.w;
-            const float p4 = a1.x * b1.x, p5 = a1.y * b1.y, p6 = a1.z * b1.z, p7 = a1.w * b1.w;
-            acc = acc + p0; acc = acc + p1; acc = acc + p2; acc = acc + p3; acc = acc + p4; acc = acc + p5; acc = acc + p6; acc = acc + p7;
-            a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
+        for (int g = 0; g < TQ_AHEAD; g++)
+#pragma unroll
+            for (int k = 0; k < 2; k++) { ra[g][k] = pa[g * 2 + k]; rb[g][k] = pb[g * 2 + k]; }
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+            if (g + TQ_AHEAD < G)
+#pragma unroll
+                for (int k = 0; k < 2; k++) { ra[(g + TQ_AHEAD) % (TQ_AHEAD + 1)][k] = pa[(g + TQ_AHEAD) * 2 + k]; rb[(g + TQ_AHEAD) % (TQ_AHEAD + 1)][k] = pb[(g + TQ_AHEAD) * 2 + k]; }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                const float4 a = ra[g % (TQ_AHEAD + 1)][k], b = rb[g % (TQ_AHEAD + 1)][k];
+                const float p0 = a.x * b.x, p1 = a.y * b.y, p2 = a.z * b.z, p3 = a.w * b.w;
+                acc = acc + p0; acc = acc + p1; acc = acc + p2; acc = acc + p3;
+            }
         }
         return;
     }
@@ -260,54 +286,108 @@ __device__ __forceinline__ uint64_t block_sum_u64(uint64_t v, uint64_t* scratch 
     return s;
 }
 
+// several u64 block sums behind one pair of barriers; scratch holds TQ_THREADS/64 * K entries
+template <int K>
+__device__ __forceinline__ void block_sum_u64xN(uint64_t (&v)[K], uint64_t* scratch) {
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v[k], o, 64), hi = (uint32_t)__shfl_xor((int)(uint32_t)(v[k] >> 32), o, 64);
+            v[k] += ((uint64_t)hi << 32) | lo;
+        }
+    }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0)
+#pragma unroll
+        for (int k = 0; k < K; k++) scratch[(threadIdx.x >> 6) * K + k] = v[k];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        uint64_t t = 0;
+        for (int w = 0; w < TQ_THREADS / 64; w++) t += scratch[w * K + k];
+        v[k] = t;
+    }
+}
+
+// The reference's double accumulators (ttsum, l_weight / r_weight) only ever add floats. When every addend is a non-negative
+// INTEGER-valued float below 2^53 and the total stays below 2^53 (always the case for selector vectors with real weights), each
+// double add is exact, so the running sum equals the integer sum and its order does not matter: the "exact" kernel variants
+// replace those two chains by an integer reduction (low / high 32-bit halves summed separately so nothing overflows). When the
+// condition fails the kernel reports it and the caller re-runs the node with the chained variant.
+struct exact_acc {
+    uint64_t lo = 0, hi = 0;
+    __device__ __forceinline__ bool add(float t) { // returns false when t is outside the exact range
+        if (!(t < 9007199254740992.0f)) return false;
+        const uint64_t ti = (uint64_t)t;
+        lo += ti & 0xffffffffull; hi += ti >> 32;
+        return true;
+    }
+};
+__device__ __forceinline__ bool exact_total(uint64_t lo, uint64_t hi, double* out) {
+    const uint64_t h = hi + (lo >> 32);
+    if (h >= (1ull << 21)) return false;
+    *out = (double)((h << 32) | (lo & 0xffffffffull));
+    return true;
+}
+
 __global__ __launch_bounds__(256) void k_tsvq_iota(uint32_t n, uint32_t* __restrict__ perm0) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) perm0[i] = i;
 }
 
-// prepare_root (enc.h:1708-1735): origin sums, weight, variance of the whole training set
-template <int N, typename Src>
+// prepare_root (enc.h:1708-1735): origin sums, weight, variance of the whole training set. EX: see exact_acc.
+template <int N, typename Src, bool EX>
 __global__ __launch_bounds__(TQ_THREADS) void k_tsvq_root(Src src, const uint64_t* __restrict__ w64, uint32_t n, tsvq_root_out* __restrict__ out) {
     extern __shared__ __align__(16) char lds[];
     __shared__ float s_origin[16];
     __shared__ double s_tt;
-    __shared__ uint64_t s_red[TQ_THREADS / 64];
+    __shared__ uint64_t s_red[TQ_THREADS / 64 * 3];
     const int tid = threadIdx.x;
     float acc_f = 0.0f; double acc_d = 0.0;
     uint64_t wsum = 0;
-    pipeline_pass<N, 1, 2>(lds, src, w64, nullptr, n, // wave 0: the N float chains, wave 1: the double chain
+    exact_acc tt;
+    bool bad = false;
+    pipeline_pass<N, EX ? 0 : 1, EX ? 1 : 2>(lds, src, w64, nullptr, n, // wave 0: the N float chains, wave 1: the double chain
         [&](uint32_t, const typename Src::payload& p, float* f, double* d) {
             float v[N]; Src::decode(p, v);
             const float w = (float)p.w;
 #pragma unroll
             for (int k = 0; k < N; k++) f[(size_t)k * TQ_STRIDE] = v[k] * w;
             const float t = dot_seq<N>(v, v) * w;
-            d[0] = (double)t;
+            if (EX) bad |= !tt.add(t);
+            else d[0] = (double)t;
             wsum += p.w;
         },
         [&](const float* f, const double* d, uint32_t m) {
             if (tid < N) chain_add_f32(acc_f, f + (size_t)tid * TQ_STRIDE, m);
-            else if (tid == 64) chain_add_f64(acc_d, d, m);
+            else if (!EX && tid == 64) chain_add_f64(acc_d, d, m);
         });
-    wsum = block_sum_u64(wsum, s_red);
+    uint64_t sums[3] = {wsum, tt.lo, tt.hi};
+    block_sum_u64xN<3>(sums, s_red);
+    wsum = sums[0];
+    const bool any_bad = EX && __syncthreads_or(bad ? 1 : 0) != 0;
     if (tid < N) s_origin[tid] = acc_f;
-    if (tid == 64) s_tt = acc_d;
+    if (!EX && tid == 64) s_tt = acc_d;
     __syncthreads();
     if (tid == 0) {
+        double ttsum = EX ? 0.0 : s_tt;
+        const bool ok = !EX || (!any_bad && exact_total(sums[1], sums[2], &ttsum));
         float o[N];
         for (int k = 0; k < N; k++) o[k] = s_origin[k];
         const float wfl = (float)wsum;
         const float q = dot_seq<N>(o, o) / wfl;
-        out->var = (float)(s_tt - (double)q);
+        out->var = (float)(ttsum - (double)q);
         const float inv = 1.0f / wfl;
         for (int k = 0; k < N; k++) out->origin[k] = o[k] * inv;
         for (int k = N; k < 16; k++) out->origin[k] = 0.0f;
         out->weight = wsum;
+        out->pad = ok ? 0u : 1u; // 1: outside the exact range, re-run with the chained variant
     }
 }
 
 // split_node (enc.h:1737-1800) = prep_split (:1848-1960) + refine_split (:1962-2077) for one node per workgroup.
-template <int N, typename Src>
+template <int N, typename Src, bool EX>
 __global__ __launch_bounds__(TQ_THREADS) void k_tsvq_split(Src src, const uint64_t* __restrict__ w64, uint32_t* __restrict__ perm0, uint32_t* __restrict__ perm1,
                                                           uint8_t* __restrict__ side, const tsvq_node_in* __restrict__ nodes, tsvq_split_out* __restrict__ outs) {
     extern __shared__ __align__(16) char lds[];
@@ -315,9 +395,10 @@ __global__ __launch_bounds__(TQ_THREADS) void k_tsvq_split(Src src, const uint64
     __shared__ float s_origin[16];
     __shared__ float s_sum[2][16];
     __shared__ double s_dsum[2];
-    __shared__ uint64_t s_red[TQ_THREADS / 64];
+    __shared__ uint64_t s_red[TQ_THREADS / 64 * 7];
     __shared__ uint32_t s_scan[TQ_THREADS / 64][2];
     __shared__ uint32_t s_base[2];
+    __shared__ double2 s_tab[16][4]; // packed rows: {(l_c[k] - val)^2, (r_c[k] - val)^2} for val = 0..3 (see TQ_MODE_DIST)
     using payload = typename Src::payload;
 
     const int tid = threadIdx.x;
@@ -332,21 +413,39 @@ __global__ __launch_bounds__(TQ_THREADS) void k_tsvq_split(Src src, const uint64
 
     // One classification + accumulation pass. `mode` selects how a member picks its side; float chains 0..N-1 are the left sums,
     // N..2N-1 the right sums; the two double chains are the left/right "ttsum" (in the projection / half passes: the weights).
-    auto side_pass = [&](int mode, bool write_side) {
+    // Returns true (uniformly) when the exact variant met data outside its range: the caller gives the node up with ok = 2.
+    auto side_pass = [&](int mode, bool write_side) -> bool {
         float acc_f = 0.0f; double acc_d = 0.0;
         uint64_t lw = 0, rw = 0; uint32_t ln = 0;
+        exact_acc ex[2];
+        bool bad = false;
         const uint32_t first_member = members[0];
-        pipeline_pass<2 * N, 2, 2>(lds, src, w64, members, count, // wave 0: 2N float chains, wave 1: the two double chains
+        if constexpr (Src::PACKED) {
+            // a selector component takes four values only, so the squared centroid differences of enc.h:483 come from a 16 x 4 table
+            // (same double operations on the same operands as the direct form below, computed once per pass instead of per member)
+            if (mode == TQ_MODE_DIST && tid < 64) {
+                const int k = tid >> 2, val = tid & 3;
+                const double a = (double)c.l_c[k] - (double)(float)val, b = (double)c.r_c[k] - (double)(float)val;
+                s_tab[k][val] = make_double2(a * a, b * b);
+            }
+            __syncthreads();
+        }
+        pipeline_pass<2 * N, EX ? 0 : 2, EX ? 1 : 2>(lds, src, w64, members, count, // wave 0: 2N float chains, wave 1: the two double chains
             [&](uint32_t pos, const payload& p, float* f, double* d) {
                 float v[N]; Src::decode(p, v);
                 const float w = (float)p.w;
                 bool right;
                 if (mode == TQ_MODE_DIST) {
                     double dl = 0, dr = 0;
+                    if constexpr (Src::PACKED) {
 #pragma unroll
-                    for (int k = 0; k < N; k++) {
-                        const double a = (double)c.l_c[k] - (double)v[k]; const double aa = a * a; dl += aa;
-                        const double b = (double)c.r_c[k] - (double)v[k]; const double bb = b * b; dr += bb;
+                        for (int k = 0; k < N; k++) { const double2 t = s_tab[k][(p.key >> (30 - 2 * k)) & 3u]; dl += t.x; dr += t.y; }
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < N; k++) {
+                            const double a = (double)c.l_c[k] - (double)v[k]; const double aa = a * a; dl += aa;
+                            const double b = (double)c.r_c[k] - (double)v[k]; const double bb = b * b; dr += bb;
+                        }
                     }
                     right = dl >= dr;                                 // enc.h:1991
                 } else if (mode == TQ_MODE_PROJ) {
@@ -367,25 +466,36 @@ __global__ __launch_bounds__(TQ_THREADS) void k_tsvq_split(Src src, const uint64
                     f[(size_t)k * TQ_STRIDE] = right ? 0.0f : t;
                     f[(size_t)(N + k) * TQ_STRIDE] = right ? t : 0.0f;
                 }
-                double dv;
-                if (mode == TQ_MODE_PROJ || mode == TQ_MODE_HALF) dv = (double)w; // l_weight / r_weight: doubles of the float weight
-                else { const float tt = w * dot_seq<N>(v, v); dv = (double)tt; }
-                d[0] = right ? 0.0 : dv;
-                d[TQ_TILE] = right ? dv : 0.0;
+                // l_weight / r_weight (projection and half passes) are doubles of the float weight; otherwise ttsum addends
+                const float dvf = (mode == TQ_MODE_PROJ || mode == TQ_MODE_HALF) ? w : w * dot_seq<N>(v, v);
+                if (EX) {
+                    if (right) bad |= !ex[1].add(dvf); else bad |= !ex[0].add(dvf);
+                } else {
+                    const double dv = (double)dvf;
+                    d[0] = right ? 0.0 : dv;
+                    d[TQ_TILE] = right ? dv : 0.0;
+                }
                 if (right) rw += p.w; else { lw += p.w; ln++; }
             },
             [&](const float* f, const double* d, uint32_t m) {
                 if (tid < 2 * N) chain_add_f32(acc_f, f + (size_t)tid * TQ_STRIDE, m);
-                else if (tid == 64 || tid == 65) chain_add_f64(acc_d, d + (size_t)(tid - 64) * TQ_TILE, m);
+                else if (!EX && (tid == 64 || tid == 65)) chain_add_f64(acc_d, d + (size_t)(tid - 64) * TQ_TILE, m);
             });
         if (tid < 2 * N) s_sum[tid / N][tid % N] = acc_f;
-        if (tid == 64) s_dsum[0] = acc_d;
-        if (tid == 65) s_dsum[1] = acc_d;
-        const uint64_t LW = block_sum_u64(lw, s_red);
-        const uint64_t RW = block_sum_u64(rw, s_red);
-        const uint64_t LN = block_sum_u64((uint64_t)ln, s_red);
-        if (tid == 0) { c.l_w = LW; c.r_w = RW; c.l_n = (uint32_t)LN; c.r_n = count - (uint32_t)LN; }
+        if (!EX && tid == 64) s_dsum[0] = acc_d;
+        if (!EX && tid == 65) s_dsum[1] = acc_d;
+        uint64_t sums[7] = {lw, rw, (uint64_t)ln, ex[0].lo, ex[0].hi, ex[1].lo, ex[1].hi};
+        block_sum_u64xN<7>(sums, s_red);
+        bool failed = false;
+        if (EX) {
+            double t0 = 0.0, t1 = 0.0;
+            failed = __syncthreads_or(bad ? 1 : 0) != 0;
+            failed |= !exact_total(sums[3], sums[4], &t0) || !exact_total(sums[5], sums[6], &t1); // same value in every thread
+            if (tid == 0) { s_dsum[0] = t0; s_dsum[1] = t1; }
+        }
+        if (tid == 0) { c.l_w = sums[0]; c.r_w = sums[1]; c.l_n = (uint32_t)sums[2]; c.r_n = count - (uint32_t)sums[2]; }
         __syncthreads();
+        return failed;
     };
 
     // ---------------- prep_split
@@ -426,19 +536,31 @@ __global__ __launch_bounds__(TQ_THREADS) void k_tsvq_split(Src src, const uint64
             principal_axis<N>(c);
         }
         __syncthreads();
-        side_pass(TQ_MODE_PROJ, false);
-        if (tid == 0) {
-            const double lw = s_dsum[0], rw = s_dsum[1];
-            if (lw > 0.0 && rw > 0.0) {
-                const float ls = (float)(1.0 / lw), rs = (float)(1.0 / rw);
-                for (int k = 0; k < N; k++) { c.l_c[k] = s_sum[0][k] * ls; c.r_c[k] = s_sum[1][k] * rs; }
-                c.mode = TQ_MODE_DIST;
-            } else {
-                c.mode = TQ_MODE_HALF; // degenerate projection (enc.h:1893): needs the bounding box first
+    }
+
+    // ---------------- the classification passes of prep_split and refine_split, driven from ONE call site (the pass body is
+    // large; four inlined copies of it would not fit the instruction cache). Every decision below is uniform across the block.
+    enum { PH_PROJ, PH_HALF, PH_REFINE, PH_PEEL };
+    int phase = (count == 2) ? PH_REFINE : PH_PROJ;
+    int iter = 0;
+    if (tid == 0) { c.prev_total = 1e+10f; c.state = 0; }
+    __syncthreads();
+    for (;;) {
+        const int mode = phase == PH_PROJ ? TQ_MODE_PROJ : phase == PH_HALF ? TQ_MODE_HALF : phase == PH_REFINE ? TQ_MODE_DIST : TQ_MODE_PEEL_FIRST;
+        if (side_pass(mode, phase == PH_REFINE || phase == PH_PEEL)) { if (tid == 0) out->ok = 2; return; }
+        if (phase == PH_PROJ) {
+            if (tid == 0) {
+                const double lw = s_dsum[0], rw = s_dsum[1];
+                if (lw > 0.0 && rw > 0.0) {
+                    const float ls = (float)(1.0 / lw), rs = (float)(1.0 / rw);
+                    for (int k = 0; k < N; k++) { c.l_c[k] = s_sum[0][k] * ls; c.r_c[k] = s_sum[1][k] * rs; }
+                    c.mode = TQ_MODE_DIST;
+                } else {
+                    c.mode = TQ_MODE_HALF; // degenerate projection (enc.h:1893): needs the bounding box first
+                }
             }
-        }
-        __syncthreads();
-        if (c.mode == TQ_MODE_HALF) {
+            __syncthreads();
+            if (c.mode != TQ_MODE_HALF) { phase = PH_REFINE; continue; }
             // per-dimension min/max over the members (order independent)
             float lo = 1e+20f, hi = -1e+20f;
             const int k = tid % 16, lane_group = tid / 16;
@@ -456,44 +578,42 @@ __global__ __launch_bounds__(TQ_THREADS) void k_tsvq_split(Src src, const uint64
             if (tid < N) {
                 float l = 1e+20f, h = -1e+20f;
                 for (int g = 0; g < TQ_THREADS / 16; g++) { l = fminf(l, red[g * 16 + tid]); h = fmaxf(h, red[TQ_THREADS + g * 16 + tid]); }
-                s_sum[0][tid] = l; s_sum[1][tid] = h;
+                c.cov[0][tid] = l; c.cov[1][tid] = h; // the covariance is spent: rows 0 / 1 keep the bounding box for the half pass
             }
             __syncthreads();
-            float bb_lo[N], bb_hi[N];
-            for (int kk = 0; kk < N; kk++) { bb_lo[kk] = s_sum[0][kk]; bb_hi[kk] = s_sum[1][kk]; }
-            __syncthreads();
             float widest = 0.0f; int widest_axis = -1;
-            for (int kk = 0; kk < N; kk++) { const float r = bb_hi[kk] - bb_lo[kk]; if (r > widest) { widest = r; widest_axis = kk; } }
+            for (int kk = 0; kk < N; kk++) { const float r = c.cov[1][kk] - c.cov[0][kk]; if (r > widest) { widest = r; widest_axis = kk; } }
             if (widest_axis < 0) {
                 if (tid == 0) out->ok = 0;
                 return;
             }
-            side_pass(TQ_MODE_HALF, false);
+            phase = PH_HALF;
+            continue;
+        }
+        if (phase == PH_HALF) {
             if (tid == 0) {
                 const double lw = s_dsum[0], rw = s_dsum[1];
                 if (lw > 0.0 && rw > 0.0) {
                     const float ls = (float)(1.0 / lw), rs = (float)(1.0 / rw);
                     for (int kk = 0; kk < N; kk++) { c.l_c[kk] = s_sum[0][kk] * ls; c.r_c[kk] = s_sum[1][kk] * rs; }
                 } else {
-                    for (int kk = 0; kk < N; kk++) { c.l_c[kk] = bb_lo[kk]; c.r_c[kk] = bb_hi[kk]; }
+                    for (int kk = 0; kk < N; kk++) { c.l_c[kk] = c.cov[0][kk]; c.r_c[kk] = c.cov[1][kk]; }
                 }
             }
             __syncthreads();
+            phase = PH_REFINE;
+            continue;
         }
-    }
-
-    // ---------------- refine_split: up to 6 two-means iterations
-    if (tid == 0) { c.prev_total = 1e+10f; c.state = 0; }
-    __syncthreads();
-    for (int iter = 0; iter < 6; iter++) {
-        side_pass(TQ_MODE_DIST, true);
+        // refine_split (enc.h:1962-2077): up to 6 two-means iterations
         if (c.l_w == 0 || c.r_w == 0) {
-            side_pass(TQ_MODE_PEEL_FIRST, true);
-            if (c.l_w == 0 || c.r_w == 0) {
+            if (phase == PH_PEEL) { // peeling the first member off did not help either
                 if (tid == 0) out->ok = 0;
                 return;
             }
+            phase = PH_PEEL;
+            continue;
         }
+        phase = PH_REFINE;
         if (tid == 0) {
             float nl[N], nr[N];
             for (int k = 0; k < N; k++) { nl[k] = s_sum[0][k]; nr[k] = s_sum[1][k]; }
@@ -512,7 +632,7 @@ __global__ __launch_bounds__(TQ_THREADS) void k_tsvq_split(Src src, const uint64
             }
         }
         __syncthreads();
-        if (c.state) break;
+        if (c.state || ++iter == 6) break;
     }
 
     // ---------------- children member lists: stable partition of the (ascending) member list by the last classification
@@ -562,45 +682,47 @@ template <typename K> static hipError_t set_lds(K kernel, size_t lds) {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 }
 
-hipError_t launch_tsvq_root(hipStream_t st, int dim, bool packed, const void* d_rows, const uint64_t* d_w64, uint32_t n, uint32_t* d_perm0, tsvq_root_out* d_out) {
+hipError_t launch_tsvq_root(hipStream_t st, int dim, bool packed, bool exact, const void* d_rows, const uint64_t* d_w64, uint32_t n, uint32_t* d_perm0, tsvq_root_out* d_out) {
     if (!n) return hipErrorInvalidValue;
     hipLaunchKernelGGL(k_tsvq_iota, dim3((n + 255) / 256), dim3(256), 0, st, n, d_perm0);
     const size_t lds = tsvq_lds_bytes(dim);
     hipError_t e;
+#define TQ_LAUNCH_ROOT(NN, SRC, EXV, srcval) do { \
+        if ((e = set_lds(k_tsvq_root<NN, SRC, EXV>, lds)) != hipSuccess) return e; \
+        hipLaunchKernelGGL((k_tsvq_root<NN, SRC, EXV>), dim3(1), dim3(TQ_THREADS), lds, st, srcval, d_w64, n, d_out); } while (0)
     if (dim == 16 && packed) {
         packed16_rows src{static_cast<const uint32_t*>(d_rows)};
-        if ((e = set_lds(k_tsvq_root<16, packed16_rows>, lds)) != hipSuccess) return e;
-        hipLaunchKernelGGL((k_tsvq_root<16, packed16_rows>), dim3(1), dim3(TQ_THREADS), lds, st, src, d_w64, n, d_out);
+        if (exact) TQ_LAUNCH_ROOT(16, packed16_rows, true, src); else TQ_LAUNCH_ROOT(16, packed16_rows, false, src);
     } else if (dim == 16) {
         float_rows<16> src{static_cast<const float*>(d_rows)};
-        if ((e = set_lds(k_tsvq_root<16, float_rows<16>>, lds)) != hipSuccess) return e;
-        hipLaunchKernelGGL((k_tsvq_root<16, float_rows<16>>), dim3(1), dim3(TQ_THREADS), lds, st, src, d_w64, n, d_out);
+        TQ_LAUNCH_ROOT(16, float_rows<16>, false, src);
     } else if (dim == 6 && !packed) {
         float_rows<6> src{static_cast<const float*>(d_rows)};
-        if ((e = set_lds(k_tsvq_root<6, float_rows<6>>, lds)) != hipSuccess) return e;
-        hipLaunchKernelGGL((k_tsvq_root<6, float_rows<6>>), dim3(1), dim3(TQ_THREADS), lds, st, src, d_w64, n, d_out);
+        TQ_LAUNCH_ROOT(6, float_rows<6>, false, src);
     } else return hipErrorInvalidValue;
+#undef TQ_LAUNCH_ROOT
     return hipGetLastError();
 }
 
-hipError_t launch_tsvq_split(hipStream_t st, int dim, bool packed, const void* d_rows, const uint64_t* d_w64, uint32_t* d_perm0, uint32_t* d_perm1, uint8_t* d_side,
+hipError_t launch_tsvq_split(hipStream_t st, int dim, bool packed, bool exact, const void* d_rows, const uint64_t* d_w64, uint32_t* d_perm0, uint32_t* d_perm1, uint8_t* d_side,
                              const tsvq_node_in* d_nodes, uint32_t n_nodes, tsvq_split_out* d_outs) {
     if (!n_nodes) return hipSuccess;
     const size_t lds = tsvq_lds_bytes(dim);
     hipError_t e;
+#define TQ_LAUNCH_SPLIT(NN, SRC, EXV, srcval) do { \
+        if ((e = set_lds(k_tsvq_split<NN, SRC, EXV>, lds)) != hipSuccess) return e; \
+        hipLaunchKernelGGL((k_tsvq_split<NN, SRC, EXV>), dim3(n_nodes), dim3(TQ_THREADS), lds, st, srcval, d_w64, d_perm0, d_perm1, d_side, d_nodes, d_outs); } while (0)
     if (dim == 16 && packed) {
         packed16_rows src{static_cast<const uint32_t*>(d_rows)};
-        if ((e = set_lds(k_tsvq_split<16, packed16_rows>, lds)) != hipSuccess) return e;
-        hipLaunchKernelGGL((k_tsvq_split<16, packed16_rows>), dim3(n_nodes), dim3(TQ_THREADS), lds, st, src, d_w64, d_perm0, d_perm1, d_side, d_nodes, d_outs);
+        if (exact) TQ_LAUNCH_SPLIT(16, packed16_rows, true, src); else TQ_LAUNCH_SPLIT(16, packed16_rows, false, src);
     } else if (dim == 16) {
         float_rows<16> src{static_cast<const float*>(d_rows)};
-        if ((e = set_lds(k_tsvq_split<16, float_rows<16>>, lds)) != hipSuccess) return e;
-        hipLaunchKernelGGL((k_tsvq_split<16, float_rows<16>>), dim3(n_nodes), dim3(TQ_THREADS), lds, st, src, d_w64, d_perm0, d_perm1, d_side, d_nodes, d_outs);
+        TQ_LAUNCH_SPLIT(16, float_rows<16>, false, src);
     } else if (dim == 6 && !packed) {
         float_rows<6> src{static_cast<const float*>(d_rows)};
-        if ((e = set_lds(k_tsvq_split<6, float_rows<6>>, lds)) != hipSuccess) return e;
-        hipLaunchKernelGGL((k_tsvq_split<6, float_rows<6>>), dim3(n_nodes), dim3(TQ_THREADS), lds, st, src, d_w64, d_perm0, d_perm1, d_side, d_nodes, d_outs);
+        TQ_LAUNCH_SPLIT(6, float_rows<6>, false, src);
     } else return hipErrorInvalidValue;
+#undef TQ_LAUNCH_SPLIT
     return hipGetLastError();
 }
 

@@ -32,7 +32,10 @@ def _data(kind, dim, n, rng):
 
 CASES = [(16, 5000, 300, 32, "sel", 50), (16, 120000, 2731, 32, "sel", 4096), (16, 30000, 900, 16, "sel_skewed", 4096), (6, 3000, 256, 16, "ep", 50),
          (6, 40000, 2416, 16, "ep", 3), (16, 4000, 300, 0, "gauss", 9), (6, 200, 64, 16, "line", 5), (16, 2, 8, 0, "sel", 3), (16, 3, 3, 2, "sel", 3),
-         (16, 700, 700, 32, "sel", 2), (6, 1, 4, 2, "ep", 1)]
+         (16, 700, 700, 32, "sel", 2), (6, 1, 4, 2, "ep", 1),
+         # weights around 2^50: the double accumulators leave the exactly-representable range, so the packed path must fall back from
+         # its integer-reduced kernels to the chained ones (root and the large nodes), and mix both further down the tree
+         (16, 20000, 600, 16, "sel", 2 ** 50), (16, 3000, 200, 8, "sel", 2 ** 44)]
 
 
 @pytest.mark.parametrize("dim,n,k,p,kind,wmax", CASES)
