@@ -1,0 +1,1714 @@
+// uastc_core.h -- UASTC LDR 4x4 block encoder core, single source for the HIP kernels.
+//
+// What it computes is pinned, bit for bit, by the reference's encode_uastc() (encoder/basisu_uastc_enc.cpp:3126-3645) and the
+// pieces it calls: color_cell_compression (encoder/basisu_bc7enc.cpp:1364-1762), the astc_mode* candidate generators
+// (uastc_enc.cpp:470-2508), unpack_uastc / transcode_uastc_to_bc7 / the BC7 and BC1 decoders (transcoder/basisu_transcoder.cpp),
+// the BC1 / EAC / ETC1 transcode hints (uastc_enc.cpp:2535-3103) and pack_uastc (:110-466). How it is organised is ours:
+//   * one generic colour-cell fitter specialised to the only configuration UASTC uses (ASTC endpoint ranks, unit channel
+//     weights, non-perceptual metric), one generic candidate builder driven by a per-mode descriptor instead of 19 functions,
+//   * candidates live in fixed slots so that independent (block, job) work items can run as separate GPU threads and the
+//     reference's first-wins tie rules still hold (slot order = the reference's result order),
+//   * the BC7 round trip decodes straight from the transcoded endpoints (bit packing and unpacking cancel),
+//   * all tables come from uastc_tables.inc (generated; see tools/gen_uastc_tables.py).
+// Float code keeps the reference's evaluation order; build with -ffp-contract=off (SURVEY hazard H4).
+//
+// The same header compiles with g++ (BU_FN = static inline): tests use that build to diff every stage against the real
+// reference on the CPU; the product only ever runs the hipcc build.
+#pragma once
+#include <stdint.h>
+#include <math.h>
+
+#if defined(__HIPCC__)
+#define BU_FN __device__ inline
+#define BU_FN_BIG __device__ __noinline__
+#define BU_TAB static __device__ const
+#else
+#define BU_FN static inline
+#define BU_FN_BIG static
+#define BU_TAB static const
+#endif
+
+#include "uastc_tables.inc"
+
+namespace bu_uastc {
+
+struct rgba8 { uint8_t c[4]; };
+
+BU_FN int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+BU_FN float saturatef(float v) { return v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v); }
+BU_FN uint32_t astc_levels(uint32_t range) { return (1u + 2u * ku_bise[range * 3 + 1] + 4u * ku_bise[range * 3 + 2]) << ku_bise[range * 3]; }
+// astc_interpolate_linear (bc7enc.cpp:177-183) == basist::astc_interpolate(..., srgb=false) (transcoder_uastc.h:77-93)
+BU_FN uint32_t astc_lerp(uint32_t l, uint32_t h, uint32_t w) {
+    l = (l << 8) | l;
+    h = (h << 8) | h;
+    return ((l * (64 - w) + h * w + 32) >> 6) >> 8;
+}
+BU_FN const uint8_t* weight_set(uint32_t bits) { return ku_weights + ((1u << bits) - 2u); }
+
+// ------------------------------------------------------------------------------------------------------------------
+// Colour-cell fit: color_cell_compression(mode = 255, ASTC range, weights 1/1/1/1, perceptual off)
+// ------------------------------------------------------------------------------------------------------------------
+
+struct cell_cfg {
+    uint8_t wbits;      // 1..5 weight bits -> 2..32 interpolants
+    uint8_t range;      // ASTC endpoint range
+    uint8_t alpha;      // fit 4 channels
+    uint8_t uber;       // bc7enc_compress_block_params::m_uber_level
+    uint8_t ls_passes;  // m_least_squares_passes
+    const uint8_t* force_sel;  // m_pForce_selectors (NULL normally)
+};
+
+struct cell_fit {
+    uint64_t err;
+    uint8_t lo[4], hi[4];            // endpoint RANKS (position in ascending unquantised order)
+    uint8_t astc_lo[4], astc_hi[4];  // the same endpoints as ASTC endpoint indices
+    uint8_t sel[16];
+};
+
+BU_FN uint32_t dist_rgb(const uint8_t* a, const uint8_t* b) {
+    const int dr = (int)a[0] - (int)b[0], dg = (int)a[1] - (int)b[1], db = (int)a[2] - (int)b[2];
+    return (uint32_t)(dr * dr) + (uint32_t)(dg * dg) + (uint32_t)(db * db);
+}
+BU_FN uint32_t dist_rgba(const uint8_t* a, const uint8_t* b) {
+    const int da = (int)a[3] - (int)b[3];
+    return dist_rgb(a, b) + (uint32_t)(da * da);
+}
+
+// evaluate_solution (bc7enc.cpp:822-1049), ASTC branch with the non-perceptual selector search
+BU_FN uint64_t cell_eval(const rgba8* px, uint32_t n, const cell_cfg& cfg, const uint8_t* lo, const uint8_t* hi, cell_fit& best) {
+    const uint32_t N = 1u << cfg.wbits;
+    const uint8_t* W = weight_set(cfg.wbits);
+    const uint8_t* SU = ku_sorted_unquant + cfg.range * 256;
+    const uint32_t nc = cfg.alpha ? 4 : 3;
+    uint8_t wc[32][4];
+    for (uint32_t c = 0; c < 4; c++) {
+        wc[0][c] = SU[lo[c]];
+        wc[N - 1][c] = SU[hi[c]];
+    }
+    for (uint32_t i = 1; i + 1 < N; i++) {
+        for (uint32_t c = 0; c < nc; c++) wc[i][c] = (uint8_t)astc_lerp(wc[0][c], wc[N - 1][c], W[i]);
+        if (nc == 3) wc[i][3] = 0;
+    }
+    const int lr = wc[0][0], lg = wc[0][1], lb = wc[0][2], la = wc[0][3];
+    const int dr = wc[N - 1][0] - lr, dg = wc[N - 1][1] - lg, db = wc[N - 1][2] - lb, da = cfg.alpha ? (wc[N - 1][3] - la) : 0;
+
+    uint64_t total = 0;
+    uint8_t tmp[16];
+    if (cfg.force_sel) {
+        for (uint32_t i = 0; i < n; i++) {
+            const uint8_t s = cfg.force_sel[i];
+            total += cfg.alpha ? dist_rgba(wc[s], px[i].c) : dist_rgb(wc[s], px[i].c);
+            tmp[i] = s;
+        }
+    } else {
+        const float f = (float)N / ((float)(dr * dr + dg * dg + db * db + da * da) + .00000125f);
+        for (uint32_t i = 0; i < n; i++) {
+            const uint8_t* p = px[i].c;
+            int proj = ((int)p[0] - lr) * dr + ((int)p[1] - lg) * dg + ((int)p[2] - lb) * db;
+            if (cfg.alpha) proj += ((int)p[3] - la) * da;
+            int s = (int)((float)proj * f + .5f);
+            s = clampi(s, 1, (int)N - 1);
+            const uint32_t e0 = cfg.alpha ? dist_rgba(wc[s - 1], p) : dist_rgb(wc[s - 1], p);
+            uint32_t e1 = cfg.alpha ? dist_rgba(wc[s], p) : dist_rgb(wc[s], p);
+            if (e0 == e1) {
+                if (s == 1) s = 0;  // prefer the non-interpolated endpoint
+            } else if (e0 < e1) {
+                e1 = e0;
+                --s;
+            }
+            total += e1;
+            tmp[i] = (uint8_t)s;
+        }
+    }
+    if (total < best.err) {
+        best.err = total;
+        for (uint32_t c = 0; c < 4; c++) { best.lo[c] = lo[c]; best.hi[c] = hi[c]; }
+        for (uint32_t i = 0; i < n; i++) best.sel[i] = tmp[i];
+    }
+    return total;
+}
+
+// find_optimal_solution (bc7enc.cpp:1103-1282), ASTC branch, mode 255 degeneracy handling (:1051-1101)
+BU_FN uint64_t cell_try(const rgba8* px, uint32_t n, const cell_cfg& cfg, const float* xl_in, const float* xh_in, cell_fit& best) {
+    float xl[4], xh[4];
+    for (uint32_t c = 0; c < 4; c++) { xl[c] = saturatef(xl_in[c]); xh[c] = saturatef(xh_in[c]); }
+    const int top = (int)astc_levels(cfg.range) - 1;
+    const uint8_t* NEAR = ku_nearest_rank + cfg.range * 256;
+    uint8_t tmin[4], tmax[4];
+    for (uint32_t c = 0; c < 4; c++) {
+        tmin[c] = NEAR[clampi((int)(xl[c] * 255.0f + .5f), 0, 255)];
+        tmax[c] = NEAR[clampi((int)(xh[c] * 255.0f + .5f), 0, 255)];
+    }
+    bool degenerate = false;
+    for (uint32_t c = 0; c < 3; c++)
+        if (tmin[c] == tmax[c] && fabsf(xl[c] - xh[c]) > 0.0f) degenerate = true;
+
+    const uint32_t order[4] = { 1, 0, 2, 3 };
+    const uint32_t trials = degenerate ? 4 : 1;
+    for (uint32_t t = 0; t < trials; t++) {
+        uint8_t a[4], b[4];
+        for (uint32_t c = 0; c < 4; c++) { a[c] = tmin[c]; b[c] = tmax[c]; }
+        if (degenerate) {
+            const uint32_t flags = order[t];
+            for (uint32_t c = 0; c < 3; c++)
+                if (a[c] == b[c] && fabsf(xl[c] - xh[c]) > 0.000125f) {
+                    if ((flags & 1) && a[c] > 0) a[c]--;
+                    if ((flags & 2) && (int)b[c] < top) b[c]++;
+                }
+        }
+        bool differs = best.err == UINT64_MAX;
+        for (uint32_t c = 0; c < 4; c++) differs = differs || a[c] != best.lo[c] || b[c] != best.hi[c];
+        if (differs) cell_eval(px, n, cfg, a, b, best);
+    }
+    const uint8_t* SI = ku_sorted_index + cfg.range * 256;
+    for (uint32_t c = 0; c < 4; c++) { best.astc_lo[c] = SI[best.lo[c]]; best.astc_hi[c] = SI[best.hi[c]]; }
+    return best.err;
+}
+
+// compute_least_squares_endpoints_rgb / _rgba (bc7enc.cpp:394-518). Double accumulators of float products, as there.
+BU_FN void cell_least_squares(const rgba8* px, uint32_t n, const uint8_t* sel, const cell_cfg& cfg, float* xl, float* xh) {
+    const float* WX = ku_weights_ls + ((1u << cfg.wbits) - 2u) * 4;
+    const uint32_t nc = cfg.alpha ? 4 : 3;
+    double z00 = 0.0, z10 = 0.0, z11 = 0.0;
+    double q00[4] = { 0, 0, 0, 0 }, t[4] = { 0, 0, 0, 0 };
+    for (uint32_t i = 0; i < n; i++) {
+        const float* w4 = WX + sel[i] * 4;
+        z00 += w4[0];
+        z10 += w4[1];
+        z11 += w4[2];
+        const float w = w4[3];
+        for (uint32_t c = 0; c < nc; c++) {
+            q00[c] += w * px[i].c[c];
+            t[c] += px[i].c[c];
+        }
+    }
+    const double z01 = z10;
+    double det = z00 * z11 - z01 * z10;
+    if (det != 0.0) det = 1.0 / det;
+    const double iz00 = z11 * det, iz01 = -z01 * det, iz10 = -z10 * det, iz11 = z00 * det;
+    for (uint32_t c = 0; c < nc; c++) {
+        const double q10 = t[c] - q00[c];
+        xl[c] = (float)(iz00 * q00[c] + iz01 * q10);
+        xh[c] = (float)(iz10 * q00[c] + iz11 * q10);
+    }
+    if (nc == 3) { xl[3] = 255.0f; xh[3] = 255.0f; }
+    for (uint32_t c = 0; c < nc; c++)
+        if (xl[c] < 0.0f || xh[c] > 255.0f) {
+            uint32_t lo_v = 255, hi_v = 0;
+            for (uint32_t i = 0; i < n; i++) {
+                const uint32_t v = px[i].c[c];
+                lo_v = v < lo_v ? v : lo_v;
+                hi_v = v > hi_v ? v : hi_v;
+            }
+            if (lo_v == hi_v) { xl[c] = (float)lo_v; xh[c] = (float)hi_v; }
+        }
+}
+
+BU_FN bool cell_refit(const rgba8* px, uint32_t n, const uint8_t* sel, const cell_cfg& cfg, cell_fit& best) {
+    float xl[4], xh[4];
+    cell_least_squares(px, n, sel, cfg, xl, xh);
+    for (uint32_t c = 0; c < 4; c++) { xl[c] = xl[c] * (1.0f / 255.0f); xh[c] = xh[c] * (1.0f / 255.0f); }
+    return cell_try(px, n, cfg, xl, xh, best) != 0;
+}
+
+// The optimal single-colour encodings (bc7enc.cpp:605-820); which one applies is a function of (range, weights, alpha).
+struct one_colour_kind { const uint8_t* table; uint8_t widx; uint8_t alpha_rank; uint8_t rgba; };
+BU_FN bool one_colour_lookup(const cell_cfg& cfg, one_colour_kind& k) {
+    const uint32_t N = 1u << cfg.wbits;
+    if (cfg.range == 8 && N == 8 && !cfg.alpha) { k.table = ku_opt_4bit_3bit; k.widx = 2; k.alpha_rank = 0; k.rgba = 0; return true; }
+    if (cfg.range == 7 && N == 4 && !cfg.alpha) { k.table = ku_opt_r7_2bit; k.widx = 1; k.alpha_rank = 0; k.rgba = 0; return true; }
+    if (cfg.range == 8 && N == 4 && cfg.alpha) { k.table = ku_opt_4bit_2bit; k.widx = 1; k.alpha_rank = 0; k.rgba = 1; return true; }
+    if (cfg.range == 13 && N == 4 && !cfg.alpha) { k.table = ku_opt_r13_2bit; k.widx = 1; k.alpha_rank = 47; k.rgba = 0; return true; }
+    if (cfg.range == 11 && N == 32 && !cfg.alpha) { k.table = ku_opt_r11_5bit; k.widx = 13; k.alpha_rank = 31; k.rgba = 0; return true; }
+    return false;
+}
+BU_FN uint64_t one_colour_fit(const rgba8* px, uint32_t n, const cell_cfg& cfg, const one_colour_kind& k, const uint32_t* col, cell_fit& out) {
+    const uint8_t* SU = ku_sorted_unquant + cfg.range * 256;
+    const uint8_t* SI = ku_sorted_index + cfg.range * 256;
+    const uint32_t w = weight_set(cfg.wbits)[k.widx];
+    uint8_t p[4] = { 0, 0, 0, 255 };
+    for (uint32_t c = 0; c < 4; c++) {
+        if (c < 3 || k.rgba) {
+            out.lo[c] = k.table[col[c] * 2];
+            out.hi[c] = k.table[col[c] * 2 + 1];
+        } else {
+            out.lo[c] = k.alpha_rank;
+            out.hi[c] = k.alpha_rank;
+        }
+        out.astc_lo[c] = SI[out.lo[c]];
+        out.astc_hi[c] = SI[out.hi[c]];
+        if (c < 3 || k.rgba) p[c] = (uint8_t)astc_lerp(SU[out.lo[c]], SU[out.hi[c]], w);
+    }
+    uint64_t total = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        out.sel[i] = k.widx;
+        total += k.rgba ? dist_rgba(p, px[i].c) : dist_rgb(p, px[i].c);
+    }
+    out.err = total;
+    return total;
+}
+
+// color_cell_compression (bc7enc.cpp:1364-1762)
+BU_FN_BIG uint64_t cell_compress(const rgba8* px, uint32_t n, const cell_cfg& cfg, cell_fit& best) {
+    best.err = UINT64_MAX;
+    one_colour_kind kind;
+    const bool has_kind = !cfg.force_sel && one_colour_lookup(cfg, kind);
+
+    if (has_kind) {
+        bool same = true;
+        for (uint32_t i = 1; i < n; i++)
+            for (uint32_t c = 0; c < (kind.rgba ? 4u : 3u); c++) same = same && px[i].c[c] == px[0].c[c];
+        if (same) {
+            const uint32_t col[4] = { px[0].c[0], px[0].c[1], px[0].c[2], px[0].c[3] };
+            return one_colour_fit(px, n, cfg, kind, col, best);
+        }
+    }
+
+    // mean and principal axis
+    float sum[4] = { 0, 0, 0, 0 };
+    for (uint32_t i = 0; i < n; i++)
+        for (uint32_t c = 0; c < 4; c++) sum[c] = sum[c] + (float)px[i].c[c];
+    const float inv_n = 1.0f / (float)n;
+    const float inv_n255 = 1.0f / ((float)n * 255.0f);
+    float mean_s[4], mean[4];
+    for (uint32_t c = 0; c < 4; c++) {
+        mean_s[c] = sum[c] * inv_n;
+        mean[c] = saturatef(sum[c] * inv_n255);
+    }
+
+    float axis[4];
+    if (cfg.alpha) {
+        // incremental 4-D PCA (bc7enc.cpp:1428-1448)
+        axis[0] = axis[1] = axis[2] = axis[3] = 0.0f;
+        for (uint32_t i = 0; i < n; i++) {
+            float col[4];
+            for (uint32_t c = 0; c < 4; c++) col[c] = (float)px[i].c[c] - mean_s[c];
+            float v[4];
+            for (uint32_t c = 0; c < 4; c++) v[c] = i ? axis[c] : col[c];
+            float s = v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+            if (s != 0.0f) {
+                s = 1.0f / sqrtf(s);
+                v[0] *= s; v[1] *= s; v[2] *= s; v[3] *= s;
+            }
+            for (uint32_t c = 0; c < 4; c++) {
+                const float k = col[c];
+                axis[c] += (col[0] * k) * v[0] + (col[1] * k) * v[1] + (col[2] * k) * v[2] + (col[3] * k) * v[3];
+            }
+        }
+        float s = axis[0] * axis[0] + axis[1] * axis[1] + axis[2] * axis[2] + axis[3] * axis[3];
+        if (s != 0.0f) {
+            s = 1.0f / sqrtf(s);
+            axis[0] *= s; axis[1] *= s; axis[2] *= s; axis[3] *= s;
+        }
+    } else {
+        // covariance + 3 power iterations (bc7enc.cpp:1450-1489)
+        float cov[6] = { 0, 0, 0, 0, 0, 0 };
+        for (uint32_t i = 0; i < n; i++) {
+            const float r = (float)px[i].c[0] - mean_s[0];
+            const float g = (float)px[i].c[1] - mean_s[1];
+            const float b = (float)px[i].c[2] - mean_s[2];
+            cov[0] += r * r; cov[1] += r * g; cov[2] += r * b; cov[3] += g * g; cov[4] += g * b; cov[5] += b * b;
+        }
+        float xr = .9f, xg = 1.0f, xb = .7f;
+        for (uint32_t iter = 0; iter < 3; iter++) {
+            float r = xr * cov[0] + xg * cov[1] + xb * cov[2];
+            float g = xr * cov[1] + xg * cov[3] + xb * cov[4];
+            float b = xr * cov[2] + xg * cov[4] + xb * cov[5];
+            float m = fabsf(r) > fabsf(g) ? fabsf(r) : fabsf(g);
+            m = m > fabsf(b) ? m : fabsf(b);
+            if (m > 1e-10f) {
+                m = 1.0f / m;
+                r *= m; g *= m; b *= m;
+            }
+            xr = r; xg = g; xb = b;
+        }
+        float len = xr * xr + xg * xg + xb * xb;
+        if (len < 1e-10f) {
+            axis[0] = axis[1] = axis[2] = axis[3] = 0.0f;
+        } else {
+            len = 1.0f / sqrtf(len);
+            axis[0] = xr * len; axis[1] = xg * len; axis[2] = xb * len; axis[3] = 0.0f;
+        }
+    }
+    if (axis[0] * axis[0] + axis[1] * axis[1] + axis[2] * axis[2] + axis[3] * axis[3] < .5f) {
+        axis[0] = axis[1] = axis[2] = 1.0f;
+        axis[3] = cfg.alpha ? 1.0f : 0.0f;
+        float s = axis[0] * axis[0] + axis[1] * axis[1] + axis[2] * axis[2] + axis[3] * axis[3];
+        s = 1.0f / sqrtf(s);
+        axis[0] *= s; axis[1] *= s; axis[2] *= s; axis[3] *= s;
+    }
+
+    float l = 1e+9f, h = -1e+9f;
+    for (uint32_t i = 0; i < n; i++) {
+        float q[4];
+        for (uint32_t c = 0; c < 4; c++) q[c] = (float)px[i].c[c] - mean_s[c];
+        const float d = q[0] * axis[0] + q[1] * axis[1] + q[2] * axis[2] + q[3] * axis[3];
+        l = l < d ? l : d;
+        h = h > d ? h : d;
+    }
+    l *= (1.0f / 255.0f);
+    h *= (1.0f / 255.0f);
+    float cmin[4], cmax[4];
+    for (uint32_t c = 0; c < 4; c++) {
+        cmin[c] = saturatef(mean[c] + axis[c] * l);
+        cmax[c] = saturatef(mean[c] + axis[c] * h);
+    }
+    if (cmin[0] * 1.0f + cmin[1] * 1.0f + cmin[2] * 1.0f + cmin[3] * 1.0f > cmax[0] * 1.0f + cmax[1] * 1.0f + cmax[2] * 1.0f + cmax[3] * 1.0f)
+        for (uint32_t c = 0; c < 4; c++) { const float t = cmin[c]; cmin[c] = cmax[c]; cmax[c] = t; }
+
+    if (!cell_try(px, n, cfg, cmin, cmax, best)) return 0;
+
+    for (uint32_t pass = 0; pass < cfg.ls_passes; pass++)
+        if (!cell_refit(px, n, best.sel, cfg, best)) return 0;
+
+    if (!cfg.force_sel && cfg.uber > 0) {
+        // selector perturbations (bc7enc.cpp:1567-1677)
+        uint8_t base[16], trial[16];
+        const uint32_t top = (1u << cfg.wbits) - 1;
+        uint32_t smin = 256, smax = 0;
+        for (uint32_t i = 0; i < n; i++) {
+            base[i] = best.sel[i];
+            smin = base[i] < smin ? base[i] : smin;
+            smax = base[i] > smax ? base[i] : smax;
+        }
+        for (uint32_t variant = 0; variant < 3; variant++) {
+            for (uint32_t i = 0; i < n; i++) {
+                uint32_t s = base[i];
+                if (variant != 1 && s == smin && s < top) s++;
+                else if (variant != 0 && s == smax && s > 0) s--;
+                trial[i] = (uint8_t)s;
+            }
+            if (!cell_refit(px, n, trial, cfg, best)) return 0;
+        }
+        const uint32_t thresh = (n * 56) >> 4;
+        if (cfg.uber >= 2 && best.err > thresh) {
+            const int Q = cfg.uber >= 4 ? (int)cfg.uber - 2 : 1;
+            for (int ly = -Q; ly <= 1; ly++)
+                for (int hy = (int)top - 1; hy <= (int)top + Q; hy++) {
+                    if (ly == 0 && hy == (int)top) continue;
+                    for (uint32_t i = 0; i < n; i++) {
+                        float v = floorf((float)top * ((float)base[i] - (float)ly) / ((float)hy - (float)ly) + .5f);
+                        v = v < 0.0f ? 0.0f : (v > (float)top ? (float)top : v);
+                        trial[i] = (uint8_t)v;
+                    }
+                    if (!cell_refit(px, n, trial, cfg, best)) return 0;
+                }
+        }
+    }
+
+    if (has_kind) {
+        // the whole cell as its mean colour (bc7enc.cpp:1679-1755)
+        uint32_t col[4];
+        for (uint32_t c = 0; c < 4; c++) col[c] = (uint32_t)(int)(.5f + mean[c] * 255.0f);
+        cell_fit avg;
+        if (one_colour_fit(px, n, cfg, kind, col, avg) < best.err) best = avg;
+    }
+    return best.err;
+}
+
+// color_cell_compression_est_astc (bc7enc.cpp:1764-1984) with unit channel weights: bounding-box endpoints, threshold selectors
+BU_FN uint64_t cell_estimate(uint32_t wbits, uint32_t comps, const rgba8* px, uint32_t n, uint64_t best_so_far) {
+    const uint32_t N = 1u << wbits;
+    const uint8_t* W = weight_set(wbits);
+    int lo[4] = { 255, 255, 255, 255 }, hi[4] = { 0, 0, 0, 0 };
+    for (uint32_t i = 0; i < n; i++)
+        for (uint32_t c = 0; c < comps; c++) {
+            const int v = px[i].c[c];
+            lo[c] = v < lo[c] ? v : lo[c];
+            hi[c] = v > hi[c] ? v : hi[c];
+        }
+    if (comps == 3) { lo[3] = 255; hi[3] = 255; }
+    uint8_t wc[32][4];
+    int dots[32];
+    const int ar = hi[0] - lo[0], ag = hi[1] - lo[1], ab = hi[2] - lo[2], aa = hi[3] - lo[3];
+    for (uint32_t i = 0; i < N; i++) {
+        for (uint32_t c = 0; c < 4; c++)
+            wc[i][c] = (uint8_t)(i == 0 ? lo[c] : (i == N - 1 ? hi[c] : ((c < 3 || comps == 4) ? (int)astc_lerp(lo[c], hi[c], W[i]) : 255)));
+        dots[i] = wc[i][0] * ar + wc[i][1] * ag + wc[i][2] * ab + (comps == 4 ? wc[i][3] * aa : 0);
+    }
+    uint64_t total = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        const uint8_t* p = px[i].c;
+        const int d = ar * p[0] + ag * p[1] + ab * p[2] + (comps == 4 ? aa * p[3] : 0);
+        uint32_t s = 0;
+        for (int j = (int)N - 2; j >= 0; j--)
+            if (d >= ((dots[j] + dots[j + 1] + 1) >> 1)) { s = (uint32_t)j + 1; break; }
+        total += comps == 4 ? dist_rgba(wc[s], p) : dist_rgb(wc[s], p);
+        if (total > best_so_far) break;
+    }
+    return total;
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------
+// Candidates. One `cand` is one uastc_encode_results (uastc_enc.h:74-81) in a fixed 64-byte slot.
+// ------------------------------------------------------------------------------------------------------------------
+
+struct cand {
+    uint64_t err;           // m_astc_err
+    uint8_t mode, pattern, ccs, valid;
+    uint8_t endpoints[18];  // ASTC endpoint indices: per subset, per channel {low, high}
+    uint8_t weights[32];    // per texel (x2 for dual plane: plane0, plane1)
+    uint8_t pad[2];
+};
+
+struct enc_cfg {            // encode_uastc's per-level settings (uastc_enc.cpp:3187-3263)
+    uint32_t flags, mode_mask, eac_table_mask;
+    uint8_t level, uber, ls_passes, estimate_partition, always_alpha, eac_mul_rad, bc1_hints, la_only_transparent;
+};
+
+enum { FLAG_FAVOR_UASTC = 8, FLAG_FAVOR_BC7 = 16, FLAG_ETC1_FASTER = 64, FLAG_ETC1_FASTEST = 128, FLAG_ETC1_NO_FLIP_INDIVIDUAL = 256, FLAG_FAVOR_SIMPLER = 512 };
+enum { CLS_SOLID = 1, CLS_ALPHA = 2, CLS_LA = 4 };
+
+BU_FN void make_cfg(uint32_t flags, enc_cfg& c) {
+    int level = (int)(flags & 7);
+    level = clampi(level, 0, 4);
+    c.flags = flags;
+    c.level = (uint8_t)level;
+    c.mode_mask = 0xFFFFFFFFu; c.uber = 6; c.estimate_partition = 0; c.always_alpha = 1; c.eac_mul_rad = 3; c.eac_table_mask = 0xFFFFFFFFu;
+    c.ls_passes = 2; c.bc1_hints = 1; c.la_only_transparent = 0;
+    if (level == 0) {
+        c.mode_mask = (1u << 0) | (1u << 8) | (1u << 11) | (1u << 12) | (1u << 15);
+        c.always_alpha = 0; c.eac_mul_rad = 0; c.eac_table_mask = (1u << 2) | (1u << 8) | (1u << 11) | (1u << 13);
+        c.uber = 0; c.ls_passes = 1; c.bc1_hints = 0; c.estimate_partition = 1; c.la_only_transparent = 1;
+    } else if (level == 1) {
+        c.mode_mask = (1u << 0) | (1u << 4) | (1u << 6) | (1u << 8) | (1u << 9) | (1u << 11) | (1u << 12) | (1u << 15) | (1u << 17);
+        c.always_alpha = 0; c.eac_mul_rad = 0; c.eac_table_mask = (1u << 2) | (1u << 8) | (1u << 11) | (1u << 13);
+        c.uber = 0; c.ls_passes = 1; c.estimate_partition = 1;
+    } else if (level == 2) {
+        c.mode_mask = (1u << 0) | (1u << 1) | (1u << 4) | (1u << 5) | (1u << 6) | (1u << 8) | (1u << 9) | (1u << 10) | (1u << 11) | (1u << 12) | (1u << 13) |
+                      (1u << 15) | (1u << 16) | (1u << 17);
+        c.always_alpha = 0; c.eac_mul_rad = 1;
+        c.eac_table_mask = (1u << 0) | (1u << 2) | (1u << 6) | (1u << 7) | (1u << 8) | (1u << 10) | (1u << 11) | (1u << 13);
+        c.uber = 1; c.ls_passes = 1; c.estimate_partition = 1;
+    } else if (level == 3) {
+        c.always_alpha = 0; c.eac_mul_rad = 2; c.uber = 3; c.estimate_partition = 1;
+    }
+}
+
+// solid / alpha / luminance-alpha classification (uastc_enc.cpp:3135-3152, 3275-3279)
+BU_FN uint32_t classify(const rgba8* px, const enc_cfg& cfg) {
+    bool solid = true, alpha = false, la = true;
+    for (uint32_t i = 0; i < 16; i++) {
+        if (px[i].c[3] < 255) alpha = true;
+        for (uint32_t c = 0; c < 4; c++) if (px[i].c[c] != px[0].c[c]) solid = false;
+        if (px[i].c[0] != px[i].c[1] || px[i].c[0] != px[i].c[2]) la = false;
+    }
+    if (solid) return CLS_SOLID | (alpha ? CLS_ALPHA : 0) | (la ? CLS_LA : 0);
+    if (cfg.la_only_transparent && la && !alpha) la = false;
+    return (alpha ? CLS_ALPHA : 0) | (la ? CLS_LA : 0);
+}
+
+BU_FN cell_cfg mode_cell_cfg(uint32_t mode, bool alpha, const enc_cfg& e) {
+    cell_cfg c;
+    c.wbits = ku_mode_weight_bits[mode];
+    c.range = ku_mode_endpoint_ranges[mode];
+    c.alpha = alpha ? 1 : 0;
+    c.uber = e.uber;
+    c.ls_passes = e.ls_passes;
+    c.force_sel = nullptr;
+    return c;
+}
+
+// Order one subset's RGB(A) endpoints so that the low sum comes first (ASTC blue contraction must stay off); returns true
+// when they were swapped, in which case the subset's weights have to be mirrored (e.g. uastc_enc.cpp:519-543).
+BU_FN bool order_endpoints(uint8_t* ep, uint32_t comps, uint32_t range) {
+    const uint8_t* UQ = ku_unquant + range * 256;
+    const int s0 = UQ[ep[0]] + UQ[ep[2]] + UQ[ep[4]];
+    const int s1 = UQ[ep[1]] + UQ[ep[3]] + UQ[ep[5]];
+    if (s1 < s0) {
+        for (uint32_t c = 0; c < comps; c++) { const uint8_t t = ep[c * 2]; ep[c * 2] = ep[c * 2 + 1]; ep[c * 2 + 1] = t; }
+        return true;
+    }
+    return false;
+}
+
+BU_FN void cand_begin(cand& r, uint32_t mode, uint32_t pattern) {
+    r.err = 0; r.mode = (uint8_t)mode; r.pattern = (uint8_t)pattern; r.ccs = 0; r.valid = 1;
+    for (uint32_t i = 0; i < 18; i++) r.endpoints[i] = 0;
+    for (uint32_t i = 0; i < 32; i++) r.weights[i] = 0;
+    r.pad[0] = r.pad[1] = 0;
+}
+
+// luminance/alpha error of a cell fitted on (l,0,0,a) pixels, measured the way the LA modes do (uastc_enc.cpp:1708-1728, 2480-2494)
+BU_FN uint64_t la_cell_error(const rgba8* px, uint32_t n, const cell_fit& f, uint32_t mode) {
+    const uint8_t* UQ = ku_unquant + ku_mode_endpoint_ranges[mode] * 256;
+    const uint8_t* W = weight_set(ku_mode_weight_bits[mode]);
+    const uint32_t ll = UQ[f.astc_lo[0]], lh = UQ[f.astc_hi[0]], al = UQ[f.astc_lo[3]], ah = UQ[f.astc_hi[3]];
+    const uint32_t top = (1u << ku_mode_weight_bits[mode]) - 1;
+    uint64_t total = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        const uint32_t s = f.sel[i];
+        const int l = (int)(s == 0 ? ll : (s == top ? lh : astc_lerp(ll, lh, W[s])));
+        const int a = (int)(s == 0 ? al : (s == top ? ah : astc_lerp(al, ah, W[s])));
+        const int dl = (int)px[i].c[0] - l, da = (int)px[i].c[3] - a;
+        total += (uint32_t)(dl * dl + da * da);
+    }
+    return total;
+}
+
+// modes 0, 1, 5, 18 (RGB), 10, 12, 14 (RGBA), 15 (LA): one subset, one plane
+BU_FN_BIG void build_single(uint32_t mode, const rgba8* px, const enc_cfg& e, cand& r) {
+    cand_begin(r, mode, 0);
+    const uint32_t comps = ku_mode_comps[mode];
+    const uint32_t top = (1u << ku_mode_weight_bits[mode]) - 1;
+    cell_fit f;
+    if (comps == 2) {
+        rgba8 t[16];
+        for (uint32_t i = 0; i < 16; i++) { t[i].c[0] = px[i].c[0]; t[i].c[1] = 0; t[i].c[2] = 0; t[i].c[3] = px[i].c[3]; }
+        const cell_cfg cc = mode_cell_cfg(mode, true, e);
+        cell_compress(t, 16, cc, f);
+        r.endpoints[0] = f.astc_lo[0]; r.endpoints[1] = f.astc_hi[0]; r.endpoints[2] = f.astc_lo[3]; r.endpoints[3] = f.astc_hi[3];
+        for (uint32_t i = 0; i < 16; i++) r.weights[i] = f.sel[i];
+        r.err = la_cell_error(t, 16, f, mode);
+        return;
+    }
+    const cell_cfg cc = mode_cell_cfg(mode, comps == 4, e);
+    r.err = cell_compress(px, 16, cc, f);
+    for (uint32_t c = 0; c < comps; c++) { r.endpoints[c * 2] = f.astc_lo[c]; r.endpoints[c * 2 + 1] = f.astc_hi[c]; }
+    const bool inv = order_endpoints(r.endpoints, comps, cc.range);
+    for (uint32_t i = 0; i < 16; i++) r.weights[i] = (uint8_t)(inv ? top - f.sel[i] : f.sel[i]);
+}
+
+BU_FN uint32_t bc7_3_to_2(uint32_t p, uint32_t k) {  // bc7_convert_partition_index_3_to_2, transcoder.cpp:14303-14328
+    const uint32_t g = k >> 1;
+    uint32_t r = g == 0 ? (p <= 1 ? 0u : 1u) : (g == 1 ? (p == 0 ? 0u : 1u) : ((p == 0 || p == 2) ? 0u : 1u));
+    return (k & 1) ? 1 - r : r;
+}
+
+// The partition a multi-subset mode splits its texels by while fitting: BC7 subsets for modes 2/3/4/9/16, ASTC subsets for 7.
+BU_FN uint32_t fit_partition_bits(uint32_t mode, uint32_t pattern) {
+    if (mode == 3) return ku_bc7_part3[ku_cp3_bc7[pattern]];
+    if (mode == 7) {
+        const uint32_t src = ku_bc7_part3[ku_cp7_bc7[pattern]], k = ku_cp7_k[pattern];
+        uint32_t bits = 0;
+        for (uint32_t i = 0; i < 16; i++) bits |= bc7_3_to_2((src >> (2 * i)) & 3, k) << (2 * i);
+        return bits;
+    }
+    return ku_bc7_part2[ku_cp2_bc7[pattern]];
+}
+
+// modes 2, 4, 7 (RGB, 2 subsets), 3 (RGB, 3 subsets), 9 (RGBA, 2 subsets), 16 (LA, 2 subsets) for one common pattern
+BU_FN_BIG void build_multi(uint32_t mode, uint32_t pattern, const rgba8* px_in, const enc_cfg& e, cand& r) {
+    cand_begin(r, mode, pattern);
+    const uint32_t comps = ku_mode_comps[mode], subsets = ku_mode_subsets[mode];
+    const uint32_t top = (1u << ku_mode_weight_bits[mode]) - 1;
+    rgba8 la[16];
+    const rgba8* px = px_in;
+    if (comps == 2) {
+        for (uint32_t i = 0; i < 16; i++) { la[i].c[0] = px_in[i].c[0]; la[i].c[1] = 0; la[i].c[2] = 0; la[i].c[3] = px_in[i].c[3]; }
+        px = la;
+    }
+    const uint32_t part_bits = fit_partition_bits(mode, pattern);
+    const cell_cfg cc = mode_cell_cfg(mode, comps != 3, e);
+
+    cell_fit fit[3];
+    uint8_t index_in_part[16];
+    uint64_t total = 0;
+    for (uint32_t s = 0; s < subsets; s++) {
+        rgba8 sub[16];
+        uint32_t n = 0;
+        for (uint32_t i = 0; i < 16; i++)
+            if (((part_bits >> (2 * i)) & 3) == s) { index_in_part[i] = (uint8_t)n; sub[n++] = px[i]; }
+        const uint64_t err = cell_compress(sub, n, cc, fit[s]);
+        total += comps == 2 ? la_cell_error(sub, n, fit[s], mode) : err;
+    }
+    r.err = total;
+
+    // which fitted subset feeds ASTC subset a, and the inverse
+    uint32_t src_of_astc[3] = { 0, 1, 2 }, astc_of_src[3] = { 0, 1, 2 };
+    if (mode == 3) {
+        const uint32_t perm = ku_cp3_perm[pattern];
+        for (uint32_t a = 0; a < 3; a++) src_of_astc[a] = ku_astc_to_bc7_perm[perm * 3 + a];
+        for (uint32_t a = 0; a < 3; a++) astc_of_src[src_of_astc[a]] = a;
+    } else if (mode != 7 && ku_cp2_invert[pattern]) {
+        src_of_astc[0] = 1; src_of_astc[1] = 0;
+        astc_of_src[0] = 1; astc_of_src[1] = 0;
+    }
+    bool inv[3] = { false, false, false };
+    for (uint32_t a = 0; a < subsets; a++) {
+        const cell_fit& f = fit[src_of_astc[a]];
+        if (comps == 2) {
+            uint8_t* ep = r.endpoints + a * 4;
+            ep[0] = f.astc_lo[0]; ep[1] = f.astc_hi[0]; ep[2] = f.astc_lo[3]; ep[3] = f.astc_hi[3];
+        } else {
+            uint8_t* ep = r.endpoints + a * comps * 2;
+            for (uint32_t c = 0; c < comps; c++) { ep[c * 2] = f.astc_lo[c]; ep[c * 2 + 1] = f.astc_hi[c]; }
+            inv[a] = order_endpoints(ep, comps, cc.range);
+        }
+    }
+    for (uint32_t i = 0; i < 16; i++) {
+        const uint32_t s = (part_bits >> (2 * i)) & 3;
+        const uint32_t w = fit[s].sel[index_in_part[i]];
+        r.weights[i] = (uint8_t)(inv[astc_of_src[s]] ? top - w : w);
+    }
+}
+
+// modes 6 (RGB), 11, 13 (RGBA), 17 (LA): one subset, two weight planes; `rot` is the channel on the second plane
+BU_FN_BIG void build_dual(uint32_t mode, uint32_t rot, const rgba8* px, const enc_cfg& e, cand& r) {
+    cand_begin(r, mode, 0);
+    const uint32_t top = (1u << ku_mode_weight_bits[mode]) - 1;
+    rgba8 main_px[16], second_px[16];
+    for (uint32_t i = 0; i < 16; i++) {
+        main_px[i] = px[i];
+        if (mode == 17) {
+            const uint8_t l = px[i].c[0], a = px[i].c[3];
+            second_px[i].c[0] = a; second_px[i].c[1] = a; second_px[i].c[2] = a; second_px[i].c[3] = 255;
+            main_px[i].c[1] = l; main_px[i].c[2] = l; main_px[i].c[3] = 255;
+        } else {
+            const uint8_t v = px[i].c[rot];
+            second_px[i].c[0] = v; second_px[i].c[1] = v; second_px[i].c[2] = v; second_px[i].c[3] = 255;
+            if (mode == 6) main_px[i].c[rot] = 255;
+            else { main_px[i].c[rot] = px[i].c[3]; main_px[i].c[3] = 255; }
+        }
+    }
+    const cell_cfg cc = mode_cell_cfg(mode, false, e);
+    cell_fit fm, fs;
+    const uint64_t err_main = cell_compress(main_px, 16, cc, fm);
+    const uint64_t err_second = cell_compress(second_px, 16, cc, fs) / 3;
+    r.err = mode == 17 ? err_main / 3 + err_second : err_main + err_second;
+    bool inv = false;
+    if (mode == 17) {
+        r.ccs = 3;
+        r.endpoints[0] = fm.astc_lo[0]; r.endpoints[1] = fm.astc_hi[0]; r.endpoints[2] = fs.astc_lo[0]; r.endpoints[3] = fs.astc_hi[0];
+    } else {
+        r.ccs = (uint8_t)rot;
+        for (uint32_t c = 0; c < 3; c++) {
+            const cell_fit& f = rot == c ? fs : fm;
+            r.endpoints[c * 2] = f.astc_lo[c]; r.endpoints[c * 2 + 1] = f.astc_hi[c];
+        }
+        if (mode != 6) {
+            if (rot == 3) { r.endpoints[6] = fs.astc_lo[0]; r.endpoints[7] = fs.astc_hi[0]; }
+            else { r.endpoints[6] = fm.astc_lo[rot]; r.endpoints[7] = fm.astc_hi[rot]; }
+        }
+        inv = order_endpoints(r.endpoints, mode == 6 ? 3 : 4, cc.range);
+    }
+    for (uint32_t i = 0; i < 16; i++) {
+        r.weights[i * 2] = (uint8_t)(inv ? top - fm.sel[i] : fm.sel[i]);
+        r.weights[i * 2 + 1] = (uint8_t)(inv ? top - fs.sel[i] : fs.sel[i]);
+    }
+}
+
+// estimate_partition2 / estimate_partition2_list and the inlined variants of modes 3 and 7 (uastc_enc.cpp:638-671, 828-860, 1362-1405,
+// 1542-1594): rank the common patterns by the cheap bounding-box estimate. Writes the `want` best patterns (ascending error).
+BU_FN void estimate_patterns(uint32_t mode, const rgba8* px_in, uint32_t want, uint32_t* out) {
+    const uint32_t comps = ku_mode_comps[mode] == 3 ? 3 : 4, subsets = ku_mode_subsets[mode], wbits = ku_mode_weight_bits[mode];
+    const uint32_t total = mode == 3 ? 11 : (mode == 7 ? 19 : 30);
+    rgba8 la[16];
+    const rgba8* px = px_in;
+    if (ku_mode_comps[mode] == 2) {
+        for (uint32_t i = 0; i < 16; i++) { la[i].c[0] = px_in[i].c[0]; la[i].c[1] = 0; la[i].c[2] = 0; la[i].c[3] = px_in[i].c[3]; }
+        px = la;
+    }
+    uint64_t best_err[8];
+    for (uint32_t i = 0; i < 8; i++) { best_err[i] = UINT64_MAX; if (i < want) out[i] = 0; }
+    const bool list = want > 1;
+    for (uint32_t pat = 0; pat < total; pat++) {
+        const uint32_t bits = mode == 3 ? ku_bc7_part3[ku_cp3_bc7[pat]] : (mode == 7 ? ku_pat7[pat] : ku_bc7_part2[ku_cp2_bc7[pat]]);
+        uint64_t err = 0;
+        for (uint32_t s = 0; s < subsets && (list || err < best_err[0]); s++) {
+            rgba8 sub[16];
+            uint32_t n = 0;
+            for (uint32_t i = 0; i < 16; i++)
+                if (((bits >> (2 * i)) & 3) == s) sub[n++] = px[i];
+            err += cell_estimate(wbits, comps, sub, n, list ? UINT64_MAX : best_err[0]);
+        }
+        for (uint32_t i = 0; i < want; i++)
+            if (err < best_err[i]) {
+                for (uint32_t j = want - 1; j > i; --j) { out[j] = out[j - 1]; best_err[j] = best_err[j - 1]; }
+                out[i] = pat;
+                best_err[i] = err;
+                break;
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Slots: the fixed position of every (mode, variant) in the reference's result order (uastc_enc.cpp:3295-3362).
+// ------------------------------------------------------------------------------------------------------------------
+
+enum { MAX_SLOTS = 176 };
+
+BU_FN uint32_t mode_variants(uint32_t mode, const enc_cfg& e) {
+    if (!((e.mode_mask >> mode) & 1) || mode == 8) return 0;
+    switch (mode) {
+    case 2: case 4: return e.estimate_partition ? 1 : 30;
+    case 3: return e.estimate_partition ? 1 : 11;
+    case 7: return e.estimate_partition ? 1 : 19;
+    case 9: case 16: return e.estimate_partition ? 4 : 30;
+    case 6: return 3;
+    case 11: case 13: return 4;
+    default: return 1;
+    }
+}
+// call order of the mode generators; the first three only for luminance-alpha blocks, 0..18 only for opaque blocks, the rest
+// only when alpha modes are tried
+BU_FN uint32_t mode_order(uint32_t i) {
+    const uint8_t order[18] = { 15, 16, 17, 0, 1, 2, 3, 4, 5, 6, 7, 18, 9, 10, 11, 12, 13, 14 };
+    return order[i];
+}
+BU_FN bool mode_applies(uint32_t mode, uint32_t cls, const enc_cfg& e) {
+    const bool alpha = (cls & CLS_ALPHA) != 0, la = (cls & CLS_LA) != 0;
+    if (mode >= 15 && mode <= 17) return la;
+    if (mode <= 7 || mode == 18) return !alpha;
+    return alpha || e.always_alpha;
+}
+BU_FN uint32_t slot_base(uint32_t mode, const enc_cfg& e) {
+    uint32_t base = 0;
+    for (uint32_t i = 0; i < 18; i++) {
+        const uint32_t m = mode_order(i);
+        if (m == mode) return base;
+        base += mode_variants(m, e);
+    }
+    return base;
+}
+BU_FN uint32_t total_slots(const enc_cfg& e) {
+    uint32_t n = 0;
+    for (uint32_t i = 0; i < 18; i++) n += mode_variants(mode_order(i), e);
+    return n;
+}
+
+// All candidates of one mode for one block -> slots[0 .. mode_variants). The unit of GPU work is (block, mode[, variant range]).
+BU_FN void run_mode(uint32_t mode, const rgba8* px, const enc_cfg& e, cand* slots, uint32_t first_variant, uint32_t n_variants) {
+    const uint32_t subsets = ku_mode_subsets[mode], planes = ku_mode_planes[mode];
+    if (planes == 2) {
+        for (uint32_t v = first_variant; v < first_variant + n_variants; v++) build_dual(mode, v, px, e, slots[v]);
+    } else if (subsets == 1) {
+        build_single(mode, px, e, slots[0]);
+    } else if (e.estimate_partition) {
+        uint32_t pats[8];
+        const uint32_t want = (mode == 9 || mode == 16) ? 4 : 1;
+        estimate_patterns(mode, px, want, pats);
+        for (uint32_t v = first_variant; v < first_variant + n_variants; v++) build_multi(mode, pats[v], px, e, slots[v]);
+    } else {
+        for (uint32_t v = first_variant; v < first_variant + n_variants; v++) build_multi(mode, v, px, e, slots[v]);
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------
+// Decoding a candidate: the UASTC/ASTC view (unpack_uastc, transcoder.cpp:15743-15879) and the BC7 view
+// (transcode_uastc_to_bc7 :16034-16526 followed by encode_bc7_block + unpack_bc7, which cancel except for the decode itself)
+// ------------------------------------------------------------------------------------------------------------------
+
+BU_FN uint32_t astc_pattern_bits(uint32_t mode, uint32_t pattern) {
+    const uint32_t subsets = ku_mode_subsets[mode];
+    if (subsets < 2) return 0;
+    return subsets == 3 ? ku_pat3[pattern] : (mode == 7 ? ku_pat7[pattern] : ku_pat2[pattern]);
+}
+
+BU_FN void decode_uastc(const cand& r, rgba8* out) {
+    const uint32_t mode = r.mode, comps = ku_mode_comps[mode], planes = ku_mode_planes[mode];
+    const uint8_t* UQ = ku_unquant + ku_mode_endpoint_ranges[mode] * 256;
+    const uint8_t* W = weight_set(ku_mode_weight_bits[mode]);
+    const uint32_t pat = astc_pattern_bits(mode, r.pattern);
+    for (uint32_t i = 0; i < 16; i++) {
+        const uint8_t* ep = r.endpoints + ((pat >> (2 * i)) & 3) * comps * 2;
+        for (uint32_t c = 0; c < 4; c++) {
+            const uint32_t w = W[(planes == 2 && c == r.ccs) ? r.weights[i * 2 + 1] : r.weights[i * planes]];
+            if (comps == 2) {
+                const uint32_t k = c == 3 ? 2 : 0;
+                out[i].c[c] = (uint8_t)astc_lerp(UQ[ep[k]], UQ[ep[k + 1]], w);
+            } else if (c < comps) {
+                out[i].c[c] = (uint8_t)astc_lerp(UQ[ep[c * 2]], UQ[ep[c * 2 + 1]], w);
+            } else {
+                out[i].c[c] = 255;
+            }
+        }
+    }
+}
+
+// determine_unique_pbits / determine_shared_pbits (transcoder.cpp:15897-16013): quantise float endpoints to comp_bits + p-bit
+BU_FN void bc7_pbit_quantise(bool shared, uint32_t total_comps, uint32_t comp_bits, const float* xl, const float* xh, uint8_t* lo, uint8_t* hi, uint32_t* pbits) {
+    const uint32_t total_bits = comp_bits + 1;
+    const int iscalep = (1 << total_bits) - 1;
+    const float scalep = (float)iscalep;
+    float best0 = 1e+9f, best1 = 1e+9f;
+    for (int p = 0; p < 2; p++) {
+        uint8_t xmin[4], xmax[4], slo[4], shi[4];
+        for (uint32_t c = 0; c < 4; c++) {
+            xmin[c] = (uint8_t)clampi(((int)((xl[c] * scalep - (float)p) / 2.0f + .5f)) * 2 + p, p, iscalep - 1 + p);
+            xmax[c] = (uint8_t)clampi(((int)((xh[c] * scalep - (float)p) / 2.0f + .5f)) * 2 + p, p, iscalep - 1 + p);
+            slo[c] = (uint8_t)(xmin[c] << (8 - total_bits));
+            slo[c] = (uint8_t)(slo[c] | (slo[c] >> total_bits));
+            shi[c] = (uint8_t)(xmax[c] << (8 - total_bits));
+            shi[c] = (uint8_t)(shi[c] | (shi[c] >> total_bits));
+        }
+        if (shared) {
+            float err = 0;
+            for (uint32_t i = 0; i < total_comps; i++) {
+                const float a = ((float)slo[i] / 255.0f) - xl[i], b = ((float)shi[i] / 255.0f) - xh[i];
+                err += a * a + b * b;
+            }
+            if (err < best0) {
+                best0 = err;
+                pbits[0] = (uint32_t)p; pbits[1] = (uint32_t)p;
+                for (uint32_t c = 0; c < 4; c++) { lo[c] = xmin[c] >> 1; hi[c] = xmax[c] >> 1; }
+            }
+        } else {
+            float err0 = 0, err1 = 0;
+            for (uint32_t i = 0; i < total_comps; i++) {
+                const float a = (float)slo[i] - xl[i] * 255.0f, b = (float)shi[i] - xh[i] * 255.0f;
+                err0 += a * a;
+                err1 += b * b;
+            }
+            if (err0 < best0) { best0 = err0; pbits[0] = (uint32_t)p; for (uint32_t c = 0; c < 4; c++) lo[c] = xmin[c] >> 1; }
+            if (err1 < best1) { best1 = err1; pbits[1] = (uint32_t)p; for (uint32_t c = 0; c < 4; c++) hi[c] = xmax[c] >> 1; }
+        }
+    }
+}
+
+BU_FN uint32_t bc7_dequant_p(uint32_t v, uint32_t pbit, uint32_t bits) {  // bc7u::bc7_dequant with p-bit (transcoder.cpp:29770)
+    const uint32_t total = bits + 1;
+    v = (v << 1) | pbit;
+    v <<= (8 - total);
+    return v | (v >> total);
+}
+BU_FN uint32_t bc7_dequant(uint32_t v, uint32_t bits) { v <<= (8 - bits); return v | (v >> bits); }
+BU_FN uint32_t bc7_lerp(uint32_t l, uint32_t h, uint32_t w) { return (l * (64 - w) + h * w + 32) >> 6; }
+
+BU_FN_BIG void decode_bc7(const cand& r, rgba8* out) {
+    const uint32_t mode = r.mode, comps = ku_mode_comps[mode], range = ku_mode_endpoint_ranges[mode];
+    const uint8_t* UQ = ku_unquant + range * 256;
+    const uint8_t* ep = r.endpoints;
+    switch (mode) {
+    case 0: case 5: case 10: case 12: case 14: case 15: case 18: {  // -> BC7 mode 6
+        float xl[4], xh[4];
+        if (comps == 2) {
+            xl[0] = xl[1] = xl[2] = (float)UQ[ep[0]] / 255.0f; xh[0] = xh[1] = xh[2] = (float)UQ[ep[1]] / 255.0f;
+            xl[3] = (float)UQ[ep[2]] / 255.0f; xh[3] = (float)UQ[ep[3]] / 255.0f;
+        } else {
+            for (uint32_t c = 0; c < 4; c++) {
+                xl[c] = c < comps ? (float)UQ[ep[c * 2]] / 255.0f : 1.0f;
+                xh[c] = c < comps ? (float)UQ[ep[c * 2 + 1]] / 255.0f : 1.0f;
+            }
+        }
+        uint8_t lo[4] = { 0, 0, 0, 0 }, hi[4] = { 0, 0, 0, 0 };
+        uint32_t pb[2] = { 0, 0 };
+        bc7_pbit_quantise(false, comps == 2 ? 4 : comps, 7, xl, xh, lo, hi, pb);
+        if (comps == 3) { lo[3] = 127; hi[3] = 127; }
+        const uint8_t five_to_four[32] = { 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 6, 7, 8, 9, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13, 14, 14, 15, 15 };
+        const uint8_t three_to_four[8] = { 0, 2, 4, 6, 9, 11, 13, 15 };
+        for (uint32_t i = 0; i < 16; i++) {
+            const uint32_t w = r.weights[i];
+            const uint32_t s = mode == 18 ? five_to_four[w] : (mode == 14 ? w * 5 : ((mode == 5 || mode == 12) ? three_to_four[w] : w));
+            for (uint32_t c = 0; c < 4; c++) out[i].c[c] = (uint8_t)bc7_lerp((lo[c] << 1) | pb[0], (hi[c] << 1) | pb[1], ku_bc7_weights4[s]);
+        }
+        break;
+    }
+    case 1: case 4: case 2: case 9: case 16: {  // -> BC7 mode 3 (1, 4), mode 1 (2), mode 7 (9, 16): two subsets with p-bits
+        const uint32_t ncomp = (mode == 9 || mode == 16) ? 4 : 3;
+        const uint32_t bits = mode == 2 ? 6 : (ncomp == 4 ? 5 : 7);
+        const uint32_t part = mode == 1 ? 0 : ku_bc7_part2[ku_cp2_bc7[r.pattern]];
+        const bool invert = mode != 1 && ku_cp2_invert[r.pattern];
+        uint8_t lo[2][4], hi[2][4];
+        uint32_t pb[2][2];
+        for (uint32_t s = 0; s < 2; s++) {
+            float xl[4], xh[4];
+            const uint8_t* e = ep + (mode == 1 ? 0 : s * comps * 2);
+            if (comps == 2) {
+                xl[0] = xl[1] = xl[2] = (float)UQ[e[0]] / 255.0f; xh[0] = xh[1] = xh[2] = (float)UQ[e[1]] / 255.0f;
+                xl[3] = (float)UQ[e[2]] / 255.0f; xh[3] = (float)UQ[e[3]] / 255.0f;
+            } else {
+                for (uint32_t c = 0; c < 4; c++) {
+                    // mode 1 stores 8-bit endpoints directly, mode 2 4-bit ones replicated to 8 bits
+                    xl[c] = c < comps ? (float)UQ[e[c * 2]] / 255.0f : 1.0f;
+                    xh[c] = c < comps ? (float)UQ[e[c * 2 + 1]] / 255.0f : 1.0f;
+                }
+            }
+            const uint32_t d = invert ? 1 - s : s;
+            for (uint32_t c = 0; c < 4; c++) { lo[d][c] = 0; hi[d][c] = 0; }
+            pb[d][0] = pb[d][1] = 0;
+            bc7_pbit_quantise(mode == 2, ncomp, bits, xl, xh, lo[d], hi[d], pb[d]);
+        }
+        const uint8_t* W = weight_set(mode == 2 ? 3 : 2);
+        for (uint32_t i = 0; i < 16; i++) {
+            const uint32_t s = (part >> (2 * i)) & 3;
+            for (uint32_t c = 0; c < 4; c++)
+                out[i].c[c] = c < ncomp ? (uint8_t)bc7_lerp(bc7_dequant_p(lo[s][c], pb[s][0], bits), bc7_dequant_p(hi[s][c], pb[s][mode == 2 ? 0 : 1], bits), W[r.weights[i]]) : 255;
+        }
+        break;
+    }
+    case 3: case 7: {  // -> BC7 mode 2: three subsets, 5-bit endpoints, no p-bits
+        uint8_t lo[3][3], hi[3][3];
+        uint32_t part;
+        if (mode == 3) {
+            part = ku_bc7_part3[ku_cp3_bc7[r.pattern]];
+            const uint32_t perm = ku_cp3_perm[r.pattern];
+            for (uint32_t s = 0; s < 3; s++) {
+                const uint32_t d = ku_astc_to_bc7_perm[perm * 3 + s];
+                for (uint32_t c = 0; c < 3; c++) {
+                    lo[d][c] = (uint8_t)((UQ[ep[c * 2 + s * 6]] * 31 + 127) / 255);
+                    hi[d][c] = (uint8_t)((UQ[ep[c * 2 + 1 + s * 6]] * 31 + 127) / 255);
+                }
+            }
+        } else {
+            part = ku_bc7_part3[ku_cp7_bc7[r.pattern]];
+            for (uint32_t d = 0; d < 3; d++) {
+                const uint32_t s = bc7_3_to_2(d, ku_cp7_k[r.pattern]);
+                for (uint32_t c = 0; c < 3; c++) {
+                    lo[d][c] = (uint8_t)((UQ[ep[c * 2 + s * 6]] * 31 + 127) / 255);
+                    hi[d][c] = (uint8_t)((UQ[ep[c * 2 + 1 + s * 6]] * 31 + 127) / 255);
+                }
+            }
+        }
+        const uint8_t* W = weight_set(2);
+        for (uint32_t i = 0; i < 16; i++) {
+            const uint32_t s = (part >> (2 * i)) & 3;
+            for (uint32_t c = 0; c < 3; c++) out[i].c[c] = (uint8_t)bc7_lerp(bc7_dequant(lo[s][c], 5), bc7_dequant(hi[s][c], 5), W[r.weights[i]]);
+            out[i].c[3] = 255;
+        }
+        break;
+    }
+    default: {  // 6, 11, 13, 17 -> BC7 mode 5: 7-bit colour + 8-bit alpha, separate index planes, channel rotation
+        uint8_t lo[4], hi[4];
+        const uint32_t rot = (r.ccs + 1u) & 3u;
+        if (comps == 2) {
+            lo[0] = lo[1] = lo[2] = (uint8_t)((UQ[ep[0]] * 127 + 127) / 255);
+            hi[0] = hi[1] = hi[2] = (uint8_t)((UQ[ep[1]] * 127 + 127) / 255);
+            lo[3] = UQ[ep[2]]; hi[3] = UQ[ep[3]];
+        } else {
+            for (uint32_t ac = 0; ac < 4; ac++) {
+                const uint32_t bc = ac == r.ccs ? 3 : (ac == 3 ? r.ccs : ac);
+                uint32_t l = 255, h = 255;
+                if (ac < comps) { l = UQ[ep[ac * 2]]; h = UQ[ep[ac * 2 + 1]]; }
+                if (bc < 3) { l = (l * 127 + 127) / 255; h = (h * 127 + 127) / 255; }
+                lo[bc] = (uint8_t)l; hi[bc] = (uint8_t)h;
+            }
+        }
+        const uint8_t* W = weight_set(2);
+        for (uint32_t i = 0; i < 16; i++) {
+            uint32_t cs = r.weights[i * 2], as = r.weights[i * 2 + 1];
+            if (mode == 13) { cs = cs ? 3 : 0; as = as ? 3 : 0; }
+            uint8_t v[4];
+            for (uint32_t c = 0; c < 3; c++) v[c] = (uint8_t)bc7_lerp(bc7_dequant(lo[c], 7), bc7_dequant(hi[c], 7), W[cs]);
+            v[3] = (uint8_t)bc7_lerp(lo[3], hi[3], W[as]);
+            if (rot >= 1) { const uint8_t t = v[3]; v[3] = v[rot - 1]; v[rot - 1] = t; }
+            for (uint32_t c = 0; c < 4; c++) out[i].c[c] = v[c];
+        }
+        break;
+    }
+    }
+}
+
+struct block_err { uint64_t rgb, rgba, la; };
+BU_FN block_err block_error(const rgba8* a, const rgba8* b) {  // compute_block_error, uastc_enc.cpp:2510-2533
+    uint64_t e[4] = { 0, 0, 0, 0 };
+    for (uint32_t i = 0; i < 16; i++)
+        for (uint32_t c = 0; c < 4; c++) { const int d = (int)a[i].c[c] - (int)b[i].c[c]; e[c] += (uint32_t)(d * d); }
+    block_err r;
+    r.la = e[0] + e[3]; r.rgb = e[0] + e[1] + e[2]; r.rgba = r.rgb + e[3];
+    return r;
+}
+
+// Per-candidate scores used by the final choice (uastc_enc.cpp:3403-3488)
+struct cand_score { uint64_t overall; float uastc_rms; };
+BU_FN cand_score score_candidate(const cand& r, const rgba8* px, uint32_t cls, const enc_cfg& e) {
+    rgba8 du[16], db[16];
+    decode_uastc(r, du);
+    decode_bc7(r, db);
+    const block_err eu = block_error(px, du), eb = block_error(px, db);
+    const bool favor_uastc = (e.flags & FLAG_FAVOR_UASTC) != 0, favor_bc7 = !favor_uastc && (e.flags & FLAG_FAVOR_BC7) != 0;
+    const uint32_t bc7_w = favor_bc7 ? 100 : (favor_uastc ? 0 : 50), uastc_w = favor_bc7 ? 0 : 100;
+    const uint64_t u = (cls & CLS_LA) ? eu.la : ((cls & CLS_ALPHA) ? eu.rgba : eu.rgb);
+    const uint64_t b = (cls & CLS_LA) ? eb.la : ((cls & CLS_ALPHA) ? eb.rgba : eb.rgb);
+    cand_score s;
+    s.overall = (b * bc7_w) / 100 + (u * uastc_w) / 100;
+    s.uastc_rms = sqrtf((float)u);
+    return s;
+}
+
+BU_FN float mode_bias(uint32_t mode) { return (mode == 0 || mode == 10) ? .8f : 1.0f; }  // get_uastc_mode_weight, :3110-3124
+
+// Choose among the valid slots, in slot order (uastc_enc.cpp:3391-3548). Returns the slot index.
+BU_FN uint32_t choose_candidate(const cand* slots, const cand_score* score, uint32_t n_slots, const enc_cfg& e) {
+    uint32_t count = 0, first = 0;
+    for (uint32_t i = 0; i < n_slots; i++)
+        if (slots[i].valid) { if (!count) first = i; count++; }
+    if (count <= 1) return first;
+    double best_rms = 1e+20f;
+    for (uint32_t i = 0; i < n_slots; i++) {
+        if (!slots[i].valid) continue;
+        if (!score[i].overall) return i;
+        if ((double)score[i].uastc_rms < best_rms) best_rms = score[i].uastc_rms;
+    }
+    const bool favor_uastc = (e.flags & FLAG_FAVOR_UASTC) != 0, favor_bc7 = !favor_uastc && (e.flags & FLAG_FAVOR_BC7) != 0;
+    const bool window = !(best_rms == 0.0f || favor_bc7);
+    uint64_t best = UINT64_MAX;
+    uint32_t best_i = first;
+    for (uint32_t i = 0; i < n_slots; i++) {
+        if (!slots[i].valid) continue;
+        if (window && !((double)score[i].uastc_rms / best_rms <= (double)1.3f)) continue;
+        const float wgt = (e.flags & FLAG_FAVOR_SIMPLER) ? mode_bias(slots[i].mode) : 1.0f;
+        const uint64_t w = (uint64_t)((float)score[i].overall * wgt);
+        if (w < best) {
+            best = w;
+            best_i = i;
+            if (!best) break;
+        }
+    }
+    return best_i;
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------
+// Transcode hints: BC1 (uastc_enc.cpp:2535-2629), EAC A8 (:3012-3103), ETC1 (:2714-3010)
+// ------------------------------------------------------------------------------------------------------------------
+
+struct bc1_blk { uint16_t c0, c1; uint32_t sel; };  // selectors: 2 bits per texel, texel 0 in the low bits
+
+BU_FN void bc1_decode(const bc1_blk& b, rgba8* out) {  // bcu::unpack_bc1, transcoder/basisu_dds_transcoder.inl:23-80
+    uint8_t col[4][4];
+    const uint32_t c[2] = { b.c0, b.c1 };
+    for (uint32_t k = 0; k < 2; k++) {
+        const uint32_t r = (c[k] >> 11) & 31, g = (c[k] >> 5) & 63, bl = c[k] & 31;
+        col[k][0] = (uint8_t)((r << 3) | (r >> 2)); col[k][1] = (uint8_t)((g << 2) | (g >> 4)); col[k][2] = (uint8_t)((bl << 3) | (bl >> 2)); col[k][3] = 255;
+    }
+    for (uint32_t ch = 0; ch < 3; ch++) {
+        if (b.c0 > b.c1) {
+            col[2][ch] = (uint8_t)((col[0][ch] * 2 + col[1][ch]) / 3);
+            col[3][ch] = (uint8_t)((col[1][ch] * 2 + col[0][ch]) / 3);
+        } else {
+            col[2][ch] = (uint8_t)((col[0][ch] + col[1][ch]) / 2);
+            col[3][ch] = 0;
+        }
+    }
+    col[2][3] = 255;
+    col[3][3] = b.c0 > b.c1 ? 255 : 0;
+    for (uint32_t i = 0; i < 16; i++)
+        for (uint32_t ch = 0; ch < 4; ch++) out[i].c[ch] = col[(b.sel >> (2 * i)) & 3][ch];
+}
+
+// bc1_find_sels (transcoder.cpp:17857-17885): linear selectors 0..3 along low->high for 5:6:5 endpoints
+BU_FN void bc1_pick_selectors(const rgba8* px, const int* l, const int* h, uint8_t* sels) {
+    int br[4], bg[4], bb[4];
+    br[0] = (l[0] << 3) | (l[0] >> 2); bg[0] = (l[1] << 2) | (l[1] >> 4); bb[0] = (l[2] << 3) | (l[2] >> 2);
+    br[3] = (h[0] << 3) | (h[0] >> 2); bg[3] = (h[1] << 2) | (h[1] >> 4); bb[3] = (h[2] << 3) | (h[2] >> 2);
+    br[1] = (br[0] * 2 + br[3]) / 3; bg[1] = (bg[0] * 2 + bg[3]) / 3; bb[1] = (bb[0] * 2 + bb[3]) / 3;
+    br[2] = (br[3] * 2 + br[0]) / 3; bg[2] = (bg[3] * 2 + bg[0]) / 3; bb[2] = (bb[3] * 2 + bb[0]) / 3;
+    int ar = br[3] - br[0], ag = bg[3] - bg[0], ab = bb[3] - bb[0];
+    int dots[4];
+    for (uint32_t i = 0; i < 4; i++) dots[i] = br[i] * ar + bg[i] * ag + bb[i] * ab;
+    const int t0 = dots[0] + dots[1], t1 = dots[1] + dots[2], t2 = dots[2] + dots[3];
+    ar *= 2; ag *= 2; ab *= 2;
+    for (uint32_t i = 0; i < 16; i++) {
+        const int d = px[i].c[0] * ar + px[i].c[1] * ag + px[i].c[2] * ab;
+        sels[i] = (uint8_t)(3 - ((d <= t0) + (d < t1) + (d < t2)));
+    }
+}
+
+BU_FN void bc1_solid(uint32_t r, uint32_t g, uint32_t b, bc1_blk& out) {  // encode_bc1_solid_block, transcoder.cpp:17999-18042
+    uint32_t mask = 0xAA;
+    uint32_t max16 = ((uint32_t)ku_bc1_match5[r * 2] << 11) | ((uint32_t)ku_bc1_match6[g * 2] << 5) | ku_bc1_match5[b * 2];
+    uint32_t min16 = ((uint32_t)ku_bc1_match5[r * 2 + 1] << 11) | ((uint32_t)ku_bc1_match6[g * 2 + 1] << 5) | ku_bc1_match5[b * 2 + 1];
+    if (min16 == max16) {
+        mask = 0;
+        if (min16 > 0) min16--;
+        else { max16 = 1; min16 = 0; mask = 0x55; }
+    }
+    if (max16 < min16) { const uint32_t t = max16; max16 = min16; min16 = t; mask ^= 0x55; }
+    out.c0 = (uint16_t)max16; out.c1 = (uint16_t)min16;
+    out.sel = mask * 0x01010101u;
+}
+
+// basist::encode_bc1 (transcoder.cpp:18047-18283) with flags 0 (given_sels == NULL) or cEncodeBC1UseSelectors
+BU_FN_BIG void bc1_encode(const rgba8* px, const uint8_t* given_sels, bc1_blk& out) {
+    int avg[3] = { -1, 0, 0 };
+    int l[3] = { 0, 0, 0 }, h[3] = { 0, 0, 0 };
+    uint8_t sels[16];
+    if (given_sels) {
+        for (uint32_t i = 0; i < 16; i++) sels[i] = given_sels[i];
+    } else {
+        bool same = true;
+        for (uint32_t i = 1; i < 16; i++) same = same && px[i].c[0] == px[0].c[0] && px[i].c[1] == px[0].c[1] && px[i].c[2] == px[0].c[2];
+        if (same) { bc1_solid(px[0].c[0], px[0].c[1], px[0].c[2], out); return; }
+        int tot[3] = { 0, 0, 0 }, mx[3] = { 0, 0, 0 }, mn[3] = { 255, 255, 255 };
+        for (uint32_t i = 0; i < 16; i++)
+            for (uint32_t c = 0; c < 3; c++) {
+                const int v = px[i].c[c];
+                tot[c] += v; mx[c] = v > mx[c] ? v : mx[c]; mn[c] = v < mn[c] ? v : mn[c];
+            }
+        for (uint32_t c = 0; c < 3; c++) avg[c] = (tot[c] + 8) >> 4;
+        int icov[6] = { 0, 0, 0, 0, 0, 0 };
+        for (uint32_t i = 0; i < 16; i++) {
+            const int r = (int)px[i].c[0] - avg[0], g = (int)px[i].c[1] - avg[1], b = (int)px[i].c[2] - avg[2];
+            icov[0] += r * r; icov[1] += r * g; icov[2] += r * b; icov[3] += g * g; icov[4] += g * b; icov[5] += b * b;
+        }
+        float cov[6];
+        for (uint32_t i = 0; i < 6; i++) cov[i] = (float)icov[i] * (1.0f / 255.0f);
+        float xr = (float)(mx[0] - mn[0]), xg = (float)(mx[1] - mn[1]), xb = (float)(mx[2] - mn[2]);
+        for (uint32_t it = 0; it < 4; it++) {
+            const float r = xr * cov[0] + xg * cov[1] + xb * cov[2];
+            const float g = xr * cov[1] + xg * cov[3] + xb * cov[4];
+            const float b = xr * cov[2] + xg * cov[4] + xb * cov[5];
+            xr = r; xg = g; xb = b;
+        }
+        float k = fabsf(xr) > fabsf(xg) ? fabsf(xr) : fabsf(xg);
+        k = k > fabsf(xb) ? k : fabsf(xb);
+        int sa[3] = { 306, 601, 117 };
+        if (k >= 2) {
+            const float m = 1024.0f / k;
+            sa[0] = (int)(xr * m); sa[1] = (int)(xg * m); sa[2] = (int)(xb * m);
+        }
+        int low_dot = INT32_MAX, high_dot = INT32_MIN;
+        uint32_t low_c = 0, high_c = 0;
+        for (uint32_t i = 0; i < 16; i++) {
+            const int dot = px[i].c[0] * sa[0] + px[i].c[1] * sa[1] + px[i].c[2] * sa[2];
+            if (dot < low_dot) { low_dot = dot; low_c = i; }
+            if (dot > high_dot) { high_dot = dot; high_c = i; }
+        }
+        for (uint32_t c = 0; c < 3; c++) {
+            const uint32_t mul = c == 1 ? 63 : 31;
+            uint32_t v = px[low_c].c[c] * mul + 128;
+            l[c] = (int)((v + (v >> 8)) >> 8);
+            v = px[high_c].c[c] * mul + 128;
+            h[c] = (int)((v + (v >> 8)) >> 8);
+        }
+        bc1_pick_selectors(px, l, h, sels);
+    }
+    {
+        // one least-squares pass (compute_least_squares_endpoints_rgb, transcoder.cpp:17922-17997)
+        uint32_t q00[3] = { 0, 0, 0 }, t[3] = { 0, 0, 0 }, wacc = 0;
+        const uint32_t wvals[4] = { 0x000009, 0x010204, 0x040201, 0x090000 };
+        for (uint32_t i = 0; i < 16; i++) {
+            const uint32_t sel = sels[i];
+            wacc += wvals[sel];
+            for (uint32_t c = 0; c < 3; c++) { t[c] += px[i].c[c]; q00[c] += sel * px[i].c[c]; }
+        }
+        const float z00 = (float)((wacc >> 16) & 0xFF), z10 = (float)((wacc >> 8) & 0xFF), z11 = (float)(wacc & 0xFF), z01 = z10;
+        float det = z00 * z11 - z01 * z10;
+        if (fabsf(det) < 1e-8f) {
+            if (avg[0] < 0) {
+                int tot[3] = { 0, 0, 0 };
+                for (uint32_t i = 0; i < 16; i++) for (uint32_t c = 0; c < 3; c++) tot[c] += px[i].c[c];
+                for (uint32_t c = 0; c < 3; c++) avg[c] = (tot[c] + 8) >> 4;
+            }
+            l[0] = ku_bc1_match5[avg[0] * 2]; l[1] = ku_bc1_match6[avg[1] * 2]; l[2] = ku_bc1_match5[avg[2] * 2];
+            h[0] = ku_bc1_match5[avg[0] * 2 + 1]; h[1] = ku_bc1_match6[avg[1] * 2 + 1]; h[2] = ku_bc1_match5[avg[2] * 2 + 1];
+        } else {
+            det = 3.0f / det;
+            const float iz00 = z11 * det, iz01 = -z01 * det, iz10 = -z10 * det, iz11 = z00 * det;
+            for (uint32_t c = 0; c < 3; c++) {
+                const float fq00 = (float)q00[c], ft = (float)t[c];
+                const float fq10 = ft * 3.0f - fq00;
+                float xl = iz00 * fq00 + iz01 * fq10, xh = iz10 * fq00 + iz11 * fq10;
+                if (xl < 0.0f || xh > 255.0f) {
+                    uint32_t lo_v = 255, hi_v = 0;
+                    for (uint32_t i = 0; i < 16; i++) { const uint32_t v = px[i].c[c]; lo_v = v < lo_v ? v : lo_v; hi_v = v > hi_v ? v : hi_v; }
+                    if (lo_v == hi_v) { xl = (float)lo_v; xh = (float)hi_v; }
+                }
+                const float scale = c == 1 ? (63.0f / 255.0f) : (31.0f / 255.0f);
+                const int top = c == 1 ? 63 : 31;
+                l[c] = clampi((int)(xl * scale + .5f), 0, top);
+                h[c] = clampi((int)(xh * scale + .5f), 0, top);
+            }
+        }
+        bc1_pick_selectors(px, l, h, sels);
+    }
+    uint32_t lc16 = ((uint32_t)l[0] << 11) | ((uint32_t)l[1] << 5) | (uint32_t)l[2];
+    uint32_t hc16 = ((uint32_t)h[0] << 11) | ((uint32_t)h[1] << 5) | (uint32_t)h[2];
+    if (lc16 == hc16) {
+        uint32_t mask = 0;
+        if (hc16 > 0) hc16--;
+        else { hc16 = 0; lc16 = 1; mask = 0x55; }
+        out.c0 = (uint16_t)lc16; out.c1 = (uint16_t)hc16; out.sel = mask * 0x01010101u;
+    } else {
+        uint32_t invert = 0;
+        if (lc16 < hc16) { const uint32_t t = lc16; lc16 = hc16; hc16 = t; invert = 0x55555555u; }
+        const uint8_t tr[4] = { 0, 2, 3, 1 };
+        uint32_t packed = 0;
+        for (uint32_t i = 0; i < 16; i++) packed |= (uint32_t)tr[sels[i]] << (i * 2);
+        out.c0 = (uint16_t)lc16; out.c1 = (uint16_t)hc16; out.sel = packed ^ invert;
+    }
+}
+
+// The candidate as pack_uastc stores it: every subset/plane anchor weight has its top bit clear (weights mirrored and the
+// endpoints of that subset/plane swapped otherwise) -- uastc_enc.cpp:262-338. The BC1 hint transcodes see this form.
+BU_FN void normalise_anchors(cand& r) {
+    const uint32_t mode = r.mode, subsets = ku_mode_subsets[mode], planes = ku_mode_planes[mode], comps = ku_mode_comps[mode];
+    const uint32_t wbits = ku_mode_weight_bits[mode], top = (1u << wbits) - 1;
+    const uint32_t pat = astc_pattern_bits(mode, r.pattern);
+    const uint8_t* anchors = subsets == 3 ? ku_anchor3 + r.pattern * 3 : (mode == 7 ? ku_anchor7 + r.pattern * 3 : ku_anchor2 + r.pattern * 3);
+    for (uint32_t p = 0; p < planes; p++)
+        for (uint32_t s = 0; s < subsets; s++) {
+            const uint32_t anchor = subsets >= 2 ? anchors[s] : 0;
+            if (!(r.weights[anchor * planes + p] & (1u << (wbits - 1)))) continue;
+            for (uint32_t i = 0; i < 16; i++)
+                if (((pat >> (2 * i)) & 3) == s) r.weights[i * planes + p] = (uint8_t)(top - r.weights[i * planes + p]);
+            for (uint32_t c = 0; c < comps; c++) {
+                if (planes == 2) {
+                    const uint32_t comp_plane = comps == 2 ? c : (c == r.ccs ? 1u : 0u);
+                    if (comp_plane != p) continue;
+                }
+                uint8_t* e = r.endpoints + (planes == 2 ? 0 : s * comps * 2) + c * 2;
+                const uint8_t t = e[0]; e[0] = e[1]; e[1] = t;
+            }
+        }
+}
+
+BU_FN uint32_t bc1_weight_translate(uint32_t wbits, uint32_t w) {  // s_uastc{1..5}_to_bc1, transcoder.cpp:17729-17735
+    const uint8_t t5[32] = { 0, 0, 0, 0, 0, 0, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 3, 3, 3, 3, 3, 3, 3, 3, 3, 3, 1, 1, 1, 1, 1, 1 };
+    const uint8_t t4[16] = { 0, 0, 0, 2, 2, 2, 2, 2, 3, 3, 3, 3, 3, 1, 1, 1 };
+    const uint8_t t3[8] = { 0, 0, 2, 2, 3, 3, 1, 1 };
+    const uint8_t t2[4] = { 0, 2, 3, 1 };
+    return wbits == 5 ? t5[w] : (wbits == 4 ? t4[w] : (wbits == 3 ? t3[w] : (wbits == 2 ? t2[w] : w)));
+}
+
+BU_FN uint32_t pack565_scaled(uint32_t r, uint32_t g, uint32_t b) {  // dxt1_block::pack_color(scaled, bias 127), uastc_enc.cpp:69-80
+    r = (r * 31 + 127) / 255; g = (g * 63 + 127) / 255; b = (b * 31 + 127) / 255;
+    return (r << 11) | (g << 5) | b;
+}
+
+// compute_bc1_hints (uastc_enc.cpp:2535-2629); `norm` is the anchor-normalised winner, `decoded` its UASTC decode
+BU_FN_BIG void bc1_hints(const cand& norm, const rgba8* px, const rgba8* decoded, bool& hint0, bool& hint1) {
+    hint0 = hint1 = false;
+    const uint32_t mode = norm.mode;
+    const bool has0 = ku_mode_has_bc1_hint0[mode] != 0, has1 = ku_mode_has_bc1_hint1[mode] != 0;
+    if (!has0 && !has1) return;
+    const uint32_t wbits = ku_mode_weight_bits[mode], planes = ku_mode_planes[mode], comps = ku_mode_comps[mode];
+    rgba8 full[16], h0[16], h1[16];
+    bc1_blk b;
+    bc1_encode(decoded, nullptr, b);
+    bc1_decode(b, full);
+    for (uint32_t i = 0; i < 16; i++) for (uint32_t c = 0; c < 4; c++) { h0[i].c[c] = 0; h1[i].c[c] = 0; }
+    if (has1) {  // transcode_uastc_to_bc1_hint1, transcoder.cpp:18700-18728
+        uint8_t sels[16];
+        const uint8_t back[4] = { 0, 3, 1, 2 };
+        for (uint32_t i = 0; i < 16; i++) sels[i] = back[bc1_weight_translate(wbits, norm.weights[i * planes])];
+        bc1_encode(decoded, sels, b);
+        bc1_decode(b, h1);
+    }
+    if (has0) {  // transcode_uastc_to_bc1_hint0, :18602-18697
+        const uint8_t* UQ = ku_unquant + ku_mode_endpoint_ranges[mode] * 256;
+        const uint8_t* e = norm.endpoints;
+        uint32_t lc, hc;
+        if (comps == 2) { lc = pack565_scaled(UQ[e[0]], UQ[e[0]], UQ[e[0]]); hc = pack565_scaled(UQ[e[1]], UQ[e[1]], UQ[e[1]]); }
+        else { lc = pack565_scaled(UQ[e[0]], UQ[e[2]], UQ[e[4]]); hc = pack565_scaled(UQ[e[1]], UQ[e[3]], UQ[e[5]]); }
+        if (lc == hc) {
+            uint32_t mask = 0;
+            if (hc > 0) hc--;
+            else { hc = 0; lc = 1; mask = 0x55; }
+            b.c0 = (uint16_t)lc; b.c1 = (uint16_t)hc; b.sel = mask * 0x01010101u;
+        } else {
+            bool inv = false;
+            if (lc < hc) { const uint32_t t = lc; lc = hc; hc = t; inv = true; }
+            uint32_t sels = 0;
+            for (int i = 15; i >= 0; --i) {
+                uint32_t s = bc1_weight_translate(wbits, norm.weights[(uint32_t)i * planes]);
+                if (inv) s ^= 1;
+                sels = (sels << 2) | s;
+            }
+            b.c0 = (uint16_t)lc; b.c1 = (uint16_t)hc; b.sel = sels;
+        }
+        bc1_decode(b, h0);
+    }
+    uint64_t et = 0, e0 = 0, e1 = 0;
+    for (uint32_t i = 0; i < 16; i++) { et += dist_rgb(px[i].c, full[i].c); e0 += dist_rgb(px[i].c, h0[i].c); e1 += dist_rgb(px[i].c, h1[i].c); }
+    const float t_err = sqrtf((float)et), t0 = sqrtf((float)e0), t1 = sqrtf((float)e1);
+    if (has0 && t0 <= t_err * 1.075f) hint0 = true;
+    if (has1 && t1 <= t_err * 1.075f) hint1 = true;
+}
+
+// uastc_pack_eac_a8 (uastc_enc.cpp:3019-3103) with base_search_rad 0: only the table and multiplier are kept
+BU_FN void eac_a8_hint(const rgba8* decoded, uint32_t mul_rad, uint32_t table_mask, uint32_t& out_table, uint32_t& out_mul) {
+    uint32_t amin = 255, amax = 0;
+    for (uint32_t i = 0; i < 16; i++) { const uint32_t a = decoded[i].c[3]; amin = a < amin ? a : amin; amax = a > amax ? a : amax; }
+    out_table = 13; out_mul = 1;
+    if (amin == amax) return;
+    out_table = 0; out_mul = 0;
+    const uint32_t arange = amax - amin;
+    uint64_t best = UINT64_MAX;
+    for (uint32_t table = 0; table < 16; table++) {
+        if (!((table_mask >> table) & 1)) continue;
+        const signed char* T = ku_eac_tables + table * 8;
+        const float range = (float)(T[7] - T[3]);
+        const float tpos = (float)(0 - T[3]) / range;
+        const int center = (int)roundf((float)amin + ((float)amax - (float)amin) * tpos);
+        const int base = clampi(center, 0, 255);
+        const int mul = (int)roundf((float)arange / range);
+        const int mlo = clampi(mul - (int)mul_rad, 1, 15), mhi = clampi(mul + (int)mul_rad, 1, 15);
+        for (int m = mlo; m <= mhi; m++) {
+            uint64_t total = 0;
+            for (uint32_t i = 0; i < 16; i++) {
+                const int a = decoded[i].c[3];
+                uint32_t best_s = 0xFFFFFFFFu;
+                for (uint32_t s = 0; s < 8; s++) {
+                    const int v = clampi(m * T[s] + base, 0, 255);
+                    const uint32_t err = (uint32_t)(a > v ? a - v : v - a);
+                    best_s = err < best_s ? err : best_s;
+                }
+                total += best_s * best_s;
+                if (total >= best) break;
+            }
+            if (total < best) {
+                best = total;
+                out_mul = (uint32_t)m; out_table = table;
+                if (!best) return;
+            }
+        }
+    }
+}
+
+struct etc1_hint { uint8_t flip, diff, inten0, inten1, bias; };
+
+BU_FN void ycbcr(const uint8_t* c, int* o) {  // rgb_to_y_cb_cr, uastc_enc.cpp:2638-2644
+    const int y = c[0] * 54 + c[1] * 183 + c[2] * 19;
+    o[0] = y; o[1] = ((int)c[2] << 8) - y; o[2] = ((int)c[0] << 8) - y;
+}
+BU_FN uint64_t ycbcr_diff(const int* a, const int* b) {  // color_diff, :2646-2652
+    const int64_t dy = a[0] - b[0], dcb = a[1] - b[1], dcr = a[2] - b[2];
+    return (uint64_t)(dy * dy * 4 + dcr * dcr + dcb * dcb);
+}
+
+BU_FN uint32_t etc1_bias_apply(uint32_t v_in, uint32_t c, uint32_t bias, uint32_t limit, uint32_t sub) {  // apply_etc1_bias, transcoder.cpp:16547-16612
+    int delta;
+    switch (bias) {
+    case 2: delta = sub ? 0 : (c == 0 ? -1 : 0); break;
+    case 5: delta = sub ? 0 : (c == 1 ? -1 : 0); break;
+    case 6: delta = sub ? 0 : (c == 2 ? -1 : 0); break;
+    case 7: delta = sub ? 0 : (c == 0 ? 1 : 0); break;
+    case 11: delta = sub ? 0 : (c == 1 ? 1 : 0); break;
+    case 15: delta = sub ? 0 : (c == 2 ? 1 : 0); break;
+    case 18: delta = sub ? (c == 0 ? -1 : 0) : 0; break;
+    case 19: delta = sub ? (c == 1 ? -1 : 0) : 0; break;
+    case 20: delta = sub ? (c == 2 ? -1 : 0) : 0; break;
+    case 21: delta = sub ? (c == 0 ? 1 : 0) : 0; break;
+    case 24: delta = sub ? (c == 1 ? 1 : 0) : 0; break;
+    case 8: delta = sub ? (c == 2 ? 1 : 0) : 0; break;
+    case 10: delta = -2; break;
+    case 27: delta = sub ? 0 : -1; break;
+    case 28: delta = sub ? -1 : 1; break;
+    case 29: delta = sub ? 1 : 0; break;
+    case 30: delta = sub ? -1 : 0; break;
+    case 31: delta = sub ? 0 : 1; break;
+    default: { const uint32_t divs[3] = { 1, 3, 9 }; delta = (int)((bias / divs[c]) % 3) - 1; break; }
+    }
+    int v = (int)v_in;
+    if (v == 0) v += delta == -2 ? 3 : delta + 1;
+    else if (v == (int)limit) v += delta - 1;
+    else {
+        v += delta;
+        if (v < 0 || v > (int)limit) v = (v - delta) - delta;
+    }
+    return (uint32_t)v;
+}
+
+BU_FN bool etc1_estimate_flipped(const rgba8* p) {  // pack_etc1_estimate_flipped, uastc_enc.cpp:2654-2712
+    int sums[3][2][2];
+    for (uint32_t c = 0; c < 3; c++)
+        for (uint32_t qx = 0; qx < 2; qx++)
+            for (uint32_t qy = 0; qy < 2; qy++) {
+                int t = 0;
+                for (uint32_t y = 0; y < 2; y++) for (uint32_t x = 0; x < 2; x++) t += p[(qx * 2 + x) + (qy * 2 + y) * 4].c[c];
+                sums[c][qx][qy] = t;
+            }
+    int upper[3], lower[3], left[3], right[3];
+    for (uint32_t c = 0; c < 3; c++) {
+        upper[c] = (sums[c][0][0] + sums[c][1][0] + 4) / 8;
+        lower[c] = (sums[c][0][1] + sums[c][1][1] + 4) / 8;
+        left[c] = (sums[c][0][0] + sums[c][0][1] + 4) / 8;
+        right[c] = (sums[c][1][0] + sums[c][1][1] + 4) / 8;
+    }
+    int ul = 0, lr = 0;
+    for (uint32_t i = 0; i < 4; i++)
+        for (uint32_t j = 0; j < 2; j++) {
+            const struct { uint32_t x, y; const int* avg; } q[4] = { { i, j, upper }, { i, 2 + j, lower }, { j, i, left }, { 2 + j, i, right } };
+            for (uint32_t k = 0; k < 4; k++) {
+                const uint8_t* c = p[q[k].x + q[k].y * 4].c;
+                const int* a = q[k].avg;
+                const int gd = (((int)c[0] - a[0]) + ((int)c[1] - a[1]) + ((int)c[2] - a[2]) + 1) / 3;
+                int d = 0;
+                for (uint32_t ch = 0; ch < 3; ch++) { const int e = (int)c[ch] - clampi(a[ch] + gd, 0, 255); d += e * e; }
+                if (k < 2) ul += d; else lr += d;
+            }
+        }
+    return ul < lr;
+}
+
+// compute_etc1_hints (uastc_enc.cpp:2714-3010) for non-solid blocks
+BU_FN_BIG void etc1_hints(uint32_t mode, const rgba8* px, const rgba8* decoded, const enc_cfg& e, etc1_hint& best) {
+    const bool faster = (e.flags & FLAG_ETC1_FASTER) != 0, fastest = (e.flags & FLAG_ETC1_FASTEST) != 0;
+    const bool has_bias = ku_mode_has_etc1_bias[mode] != 0;
+    const uint8_t sorted_bias[32] = { 13, 0, 22, 29, 27, 12, 26, 9, 30, 31, 8, 10, 25, 2, 23, 5, 15, 7, 3, 11, 6, 17, 28, 18, 1, 19, 20, 21, 24, 4, 14, 16 };
+    uint32_t last_bias = 1;
+    bool sorted_table = false;
+    const bool flip_estimate = e.level <= 1 || faster || fastest;
+    if (has_bias) {
+        sorted_table = e.level <= 3;
+        switch (e.level) {
+        case 0: last_bias = fastest ? 1 : (faster ? 1 : 2); break;
+        case 1: last_bias = fastest ? 1 : (faster ? 3 : 5); break;
+        case 2: last_bias = fastest ? 1 : (faster ? 10 : 20); break;
+        case 3: last_bias = fastest ? 1 : (faster ? 16 : 32); break;
+        default: last_bias = 32; break;
+        }
+    }
+    best.flip = best.diff = best.inten0 = best.inten1 = best.bias = 0;
+    uint64_t best_err = UINT64_MAX;
+    int src_y[16][3], dec_y[16][3];
+    for (uint32_t i = 0; i < 16; i++) { ycbcr(px[i].c, src_y[i]); ycbcr(decoded[i].c, dec_y[i]); }
+    uint32_t first_flip = 0, last_flip = 2, last_individ = 2;
+    if (e.flags & FLAG_ETC1_NO_FLIP_INDIVIDUAL) { last_flip = 1; last_individ = 1; }
+    else if (flip_estimate) { if (etc1_estimate_flipped(decoded)) first_flip = 1; last_flip = first_flip + 1; }
+
+    for (uint32_t flip = first_flip; flip < last_flip; flip++)
+        for (uint32_t individ = 0; individ < last_individ; individ++) {
+            const uint32_t mul = individ ? 15 : 31;
+            uint32_t unbiased[2][3];
+            int mn[2][3], mx[2][3];
+            uint8_t texel[2][8];  // raster index of the 8 texels of each sub-block
+            for (uint32_t sub = 0; sub < 2; sub++) {
+                uint32_t acc[3] = { 0, 0, 0 };
+                for (uint32_t c = 0; c < 3; c++) { mn[sub][c] = 255; mx[sub][c] = 0; }
+                for (uint32_t j = 0; j < 8; j++) {
+                    // g_etc1_pixel_coords (etc.cpp:314-337): unflipped = left/right halves scanned column-major, flipped = top/bottom halves row-major
+                    const uint32_t x = flip ? (j & 3) : (sub * 2 + (j >> 2)), y = flip ? (sub * 2 + (j >> 2)) : (j & 3);
+                    texel[sub][j] = (uint8_t)(x + y * 4);
+                    for (uint32_t c = 0; c < 3; c++) {
+                        const int v = decoded[x + y * 4].c[c];
+                        acc[c] += (uint32_t)v;
+                        mn[sub][c] = v < mn[sub][c] ? v : mn[sub][c];
+                        mx[sub][c] = v > mx[sub][c] ? v : mx[sub][c];
+                    }
+                }
+                for (uint32_t c = 0; c < 3; c++) unbiased[sub][c] = (acc[c] * mul + 1020) / (8 * 255);
+            }
+            for (uint32_t bi = 0; bi < last_bias; bi++) {
+                const uint32_t bias = sorted_table ? sorted_bias[bi] : bi;
+                int base[2][3];
+                {
+                    uint32_t col[2][3];
+                    for (uint32_t sub = 0; sub < 2; sub++)
+                        for (uint32_t c = 0; c < 3; c++) col[sub][c] = has_bias ? etc1_bias_apply(unbiased[sub][c], c, bias, mul, sub) : unbiased[sub][c];
+                    for (uint32_t c = 0; c < 3; c++) {
+                        if (individ) {
+                            base[0][c] = (int)((col[0][c] << 4) | col[0][c]);
+                            base[1][c] = (int)((col[1][c] << 4) | col[1][c]);
+                        } else {
+                            const int d = clampi((int)col[1][c] - (int)col[0][c], -4, 3);
+                            const uint32_t c1 = (uint32_t)((int)col[0][c] + d);
+                            base[0][c] = (int)((col[0][c] << 3) | (col[0][c] >> 2));
+                            base[1][c] = (int)((c1 << 3) | (c1 >> 2));
+                        }
+                    }
+                }
+                uint32_t inten[2] = { 0, 0 };
+                for (uint32_t sub = 0; sub < 2; sub++) {
+                    int range = 0;
+                    for (uint32_t c = 0; c < 3; c++) {
+                        const int pos = mx[sub][c] - base[sub][c], neg = base[sub][c] - mn[sub][c];
+                        const int ap = pos < 0 ? -pos : pos, an = neg < 0 ? -neg : neg;
+                        range = ap > range ? ap : range;
+                        range = an > range ? an : range;
+                    }
+                    const uint32_t limit = e.level == 4 ? 8 : (range > 51 ? 8 : (range >= 7 ? 4 : 2));
+                    uint64_t best_sub = UINT64_MAX;
+                    for (uint32_t table = 0; table < limit; table++) {
+                        int ty[4][3];
+                        for (uint32_t k = 0; k < 4; k++) {
+                            uint8_t col[3];
+                            for (uint32_t c = 0; c < 3; c++) col[c] = (uint8_t)clampi(base[sub][c] + ku_etc1_inten[table * 4 + k], 0, 255);
+                            ycbcr(col, ty[k]);
+                        }
+                        uint64_t total = 0;
+                        // the reference abandons a table after each row of 4 texels (flipped) or after all 8 (unflipped)
+                        for (uint32_t j = 0; j < 8; j++) {
+                            // texel order inside a sub-block does not change the sum; only the early-out granularity matters
+                            const uint32_t t = flip ? (uint32_t)(sub * 8 + j) : (uint32_t)((j >> 1) * 4 + sub * 2 + (j & 1));
+                            const int* c = dec_y[t];
+                            uint64_t m = ycbcr_diff(ty[0], c);
+                            for (uint32_t k = 1; k < 4; k++) { const uint64_t d = ycbcr_diff(ty[k], c); m = d < m ? d : m; }
+                            total += m;
+                            if (flip && (j & 3) == 3 && total >= best_sub) break;
+                        }
+                        if (!flip && total >= best_sub) break;
+                        if (total < best_sub) { best_sub = total; inten[sub] = table; }
+                    }
+                }
+                uint64_t err = 0;
+                for (uint32_t sub = 0; sub < 2; sub++) {
+                    int ty[4][3];
+                    for (uint32_t k = 0; k < 4; k++) {
+                        uint8_t col[3];
+                        for (uint32_t c = 0; c < 3; c++) col[c] = (uint8_t)clampi(base[sub][c] + ku_etc1_inten[inten[sub] * 4 + k], 0, 255);
+                        ycbcr(col, ty[k]);
+                    }
+                    // rows of 4 (flipped) or 2 (unflipped) texels, with the reference's per-row early out
+                    const uint32_t rows = flip ? 2 : 4, per_row = flip ? 4 : 2;
+                    for (uint32_t row = 0; row < rows; row++) {
+                        for (uint32_t k2 = 0; k2 < per_row; k2++) {
+                            const uint32_t t = flip ? ((sub * 2 + row) * 4 + k2) : (row * 4 + sub * 2 + k2);
+                            const int* c = dec_y[t];
+                            uint64_t m = ycbcr_diff(ty[0], c) << 2;
+                            for (uint32_t k = 1; k < 4; k++) { const uint64_t d = (ycbcr_diff(ty[k], c) << 2) + k; m = d < m ? d : m; }
+                            err += ycbcr_diff(src_y[t], ty[m & 3]);
+                        }
+                        if (err >= best_err) break;
+                    }
+                }
+                if (err < best_err) {
+                    best_err = err;
+                    best.flip = (uint8_t)flip; best.diff = (uint8_t)(individ == 0); best.inten0 = (uint8_t)inten[0]; best.inten1 = (uint8_t)inten[1]; best.bias = (uint8_t)bias;
+                }
+            }
+            (void)texel;
+        }
+}
+
+// pack_etc1_block_solid_color (etc.cpp:181-257): diff, intensity table, selector and the packed base colour for a solid block
+struct etc1_solid { uint8_t diff, inten, selector, r, g, b; };
+BU_FN void etc1_solid_fit(const uint8_t* col, etc1_solid& out) {
+    const uint32_t next[4] = { 1, 2, 0, 1 };
+    uint32_t best_err = 0xFFFFFFFFu, best_i = 0, best_x = 0, best_c1 = 0, best_c2 = 0;
+    bool done = false;
+    for (uint32_t i = 0; i < 3 && !done; i++) {
+        const uint32_t c1 = col[next[i]], c2 = col[next[i + 1]];
+        for (int delta = -1; delta <= 1 && !done; delta++) {
+            const int v = clampi((int)col[i] + delta, 0, 255);
+            const unsigned short* t = ku_etc1_solid_cfg + ku_etc1_solid_cfg_ofs[v];
+            do {
+                const uint32_t x = *t++;
+                const unsigned short* inv = ku_etc1_inverse + (x & 0xFF) * 256;
+                const uint32_t p1 = inv[c1], p2 = inv[c2];
+                const int d0 = v - (int)col[i];
+                const uint32_t err = (uint32_t)(d0 * d0) + (p1 >> 8) * (p1 >> 8) + (p2 >> 8) * (p2 >> 8);
+                if (err < best_err) {
+                    best_err = err; best_x = x; best_c1 = p1 & 0xFF; best_c2 = p2 & 0xFF; best_i = i;
+                    if (!best_err) { done = true; break; }
+                }
+            } while (*t != 0xFFFF);
+        }
+    }
+    uint8_t rgb[3];
+    rgb[best_i] = (uint8_t)((best_x >> 8) & 255);
+    rgb[next[best_i]] = (uint8_t)best_c1;
+    rgb[next[best_i + 1]] = (uint8_t)best_c2;
+    out.diff = (uint8_t)(best_x & 1); out.inten = (uint8_t)((best_x >> 1) & 7); out.selector = (uint8_t)((best_x >> 4) & 3);
+    out.r = rgb[0]; out.g = rgb[1]; out.b = rgb[2];
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// pack_uastc (uastc_enc.cpp:110-466)
+// ------------------------------------------------------------------------------------------------------------------
+
+struct bit_writer {
+    uint8_t* buf;
+    uint32_t ofs;
+};
+BU_FN void put_bits(bit_writer& w, uint64_t code, uint32_t n) {
+    while (n) {
+        const uint32_t in_byte = w.ofs & 7;
+        const uint32_t k = n < 8 - in_byte ? n : 8 - in_byte;
+        w.buf[w.ofs >> 3] = (uint8_t)(w.buf[w.ofs >> 3] | (uint8_t)(code << in_byte));
+        code >>= k;
+        n -= k;
+        w.ofs += k;
+    }
+}
+
+BU_FN void pack_solid(const uint8_t* rgba, uint8_t* out16) {
+    uint8_t buf[32];
+    for (uint32_t i = 0; i < 32; i++) buf[i] = 0;
+    bit_writer w = { buf, 0 };
+    put_bits(w, ku_mode_code[8], ku_mode_code_len[8]);
+    for (uint32_t c = 0; c < 4; c++) put_bits(w, rgba[c], 8);
+    etc1_solid s;
+    etc1_solid_fit(rgba, s);
+    put_bits(w, s.diff, 1); put_bits(w, s.inten, 3); put_bits(w, s.selector, 2);
+    put_bits(w, s.r, 5); put_bits(w, s.g, 5); put_bits(w, s.b, 5);
+    for (uint32_t i = 0; i < 16; i++) out16[i] = buf[i];
+}
+
+// `norm` must already be anchor-normalised
+BU_FN void pack_block(const cand& norm, const etc1_hint& etc1, uint32_t eac_table, uint32_t eac_mul, bool hint0, bool hint1, uint8_t* out16) {
+    const uint32_t mode = norm.mode, subsets = ku_mode_subsets[mode], planes = ku_mode_planes[mode], comps = ku_mode_comps[mode];
+    const uint32_t wbits = ku_mode_weight_bits[mode], range = ku_mode_endpoint_ranges[mode];
+    uint8_t buf[32];
+    for (uint32_t i = 0; i < 32; i++) buf[i] = 0;
+    bit_writer w = { buf, 0 };
+    put_bits(w, ku_mode_code[mode], ku_mode_code_len[mode]);
+    if (ku_mode_has_bc1_hint0[mode]) put_bits(w, hint0 ? 1 : 0, 1);
+    if (ku_mode_has_bc1_hint1[mode]) put_bits(w, hint1 ? 1 : 0, 1);
+    put_bits(w, etc1.flip, 1); put_bits(w, etc1.diff, 1); put_bits(w, etc1.inten0, 3); put_bits(w, etc1.inten1, 3);
+    if (ku_mode_has_etc1_bias[mode]) put_bits(w, etc1.bias, 5);
+    if (ku_mode_has_alpha[mode]) put_bits(w, eac_table | (eac_mul << 4), 8);
+    if (subsets == 3) put_bits(w, norm.pattern, 4);
+    else if (subsets == 2) put_bits(w, norm.pattern, 5);
+    if (planes == 2 && mode != 17) put_bits(w, norm.ccs, 2);
+
+    const uint32_t total_values = comps * 2 * subsets;
+    const uint32_t ep_bits = ku_bise[range * 3], ep_trits = ku_bise[range * 3 + 1], ep_quints = ku_bise[range * 3 + 2];
+    uint32_t tq_accum = 0, tq_mul = 1;
+    for (uint32_t i = 0; i < total_values; i++) {
+        const uint32_t tq = norm.endpoints[i] >> ep_bits;
+        if (ep_trits) {
+            tq_accum += tq * tq_mul; tq_mul *= 3;
+            if (tq_mul == 243) { put_bits(w, tq_accum, 8); tq_accum = 0; tq_mul = 1; }
+        } else if (ep_quints) {
+            tq_accum += tq * tq_mul; tq_mul *= 5;
+            if (tq_mul == 125) { put_bits(w, tq_accum, 7); tq_accum = 0; tq_mul = 1; }
+        }
+    }
+    if (tq_mul > 1) {
+        uint32_t nb;
+        if (ep_trits) nb = tq_mul == 3 ? 2 : (tq_mul == 9 ? 4 : (tq_mul == 27 ? 5 : 7));
+        else nb = tq_mul == 5 ? 3 : 5;
+        put_bits(w, tq_accum, nb);
+    }
+    for (uint32_t i = 0; i < total_values; i++) put_bits(w, norm.endpoints[i] & ((1u << ep_bits) - 1), ep_bits);
+
+    const uint8_t* anchors = subsets == 3 ? ku_anchor3 + norm.pattern * 3 : (mode == 7 ? ku_anchor7 + norm.pattern * 3 : ku_anchor2 + norm.pattern * 3);
+    const uint32_t plane_shift = planes == 2 ? 1 : 0;
+    for (uint32_t i = 0; i < 16 * planes; i++) {
+        uint32_t nb = wbits;
+        for (uint32_t s = 0; s < subsets; s++)
+            if ((subsets >= 2 ? anchors[s] : 0u) == (i >> plane_shift)) { nb--; break; }
+        put_bits(w, norm.weights[i], nb);
+    }
+    for (uint32_t i = 0; i < 16; i++) out16[i] = buf[i];
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Whole-block drivers
+// ------------------------------------------------------------------------------------------------------------------
+
+// everything after the candidate search: score, choose, hints, pack (uastc_enc.cpp:3391-3644)
+BU_FN_BIG void finish_block(const rgba8* px, uint32_t cls, const enc_cfg& e, const cand* slots, uint32_t n_slots, uint8_t* out16) {
+    cand_score score[MAX_SLOTS];
+    uint32_t valid = 0;
+    for (uint32_t i = 0; i < n_slots; i++) valid += slots[i].valid ? 1 : 0;
+    for (uint32_t i = 0; i < n_slots; i++) {
+        score[i].overall = 0; score[i].uastc_rms = 0;
+        if (slots[i].valid && valid > 1) score[i] = score_candidate(slots[i], px, cls, e);
+    }
+    const uint32_t pick = choose_candidate(slots, score, n_slots, e);
+    cand best = slots[pick];
+    rgba8 decoded[16];
+    decode_uastc(best, decoded);
+    normalise_anchors(best);
+    bool h0 = false, h1 = false;
+    if (e.bc1_hints) bc1_hints(best, px, decoded, h0, h1);
+    uint32_t eac_table = 0, eac_mul = 0;
+    if (ku_mode_has_alpha[best.mode]) eac_a8_hint(decoded, e.eac_mul_rad, e.eac_table_mask, eac_table, eac_mul);
+    etc1_hint eh;
+    etc1_hints(best.mode, px, decoded, e, eh);
+    pack_block(best, eh, eac_table, eac_mul, h0, h1, out16);
+}
+
+// encode_uastc (uastc_enc.cpp:3126) for one block, everything in one call (host tests; the GPU splits it into jobs)
+BU_FN_BIG void encode_block(const uint8_t* rgba64, uint32_t flags, uint8_t* out16, cand* scratch /* MAX_SLOTS */) {
+    const rgba8* px = (const rgba8*)rgba64;
+    enc_cfg e;
+    make_cfg(flags, e);
+    const uint32_t cls = classify(px, e);
+    if (cls & CLS_SOLID) { pack_solid(rgba64, out16); return; }
+    const uint32_t n_slots = total_slots(e);
+    for (uint32_t i = 0; i < n_slots; i++) scratch[i].valid = 0;
+    for (uint32_t i = 0; i < 18; i++) {
+        const uint32_t m = mode_order(i), nv = mode_variants(m, e);
+        if (nv && mode_applies(m, cls, e)) run_mode(m, px, e, scratch + slot_base(m, e), 0, nv);
+    }
+    finish_block(px, cls, e, scratch, n_slots, out16);
+}
+
+}  // namespace bu_uastc

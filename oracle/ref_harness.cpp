@@ -38,6 +38,8 @@
 #include "encoder/basisu_frontend.h"
 #include "encoder/basisu_uastc_enc.h"
 #include "encoder/basisu_comp.h"
+#include "encoder/basisu_bc7enc.h"
+#include "encoder/basisu_gpu_texture.h"
 #undef private
 #undef protected
 
@@ -306,6 +308,90 @@ REF_API void ref_encode_uastc(const uint8_t* pixel_blocks, uint32_t n_blocks, ui
 		encode_uastc(pixel_blocks + (size_t)i * 64, blk, flags);
 		memcpy(out_blocks16 + (size_t)i * 16, &blk, 16);
 	}
+}
+
+
+// ---------------------------------------------------------------- UASTC: tables and staged hooks
+
+// Raw bytes of the reference's extern data / run-time generated tables (after ref_init), for tools/gen_uastc_tables.py
+// and for table parity tests. Returns the size in bytes (~0 = unknown name); copies when cap suffices.
+REF_API uint64_t ref_table(const char* name, void* buf, uint64_t cap) {
+	using namespace basist;
+	struct ent { const char* n; const void* p; uint64_t sz; };
+	static const ent tabs[] = {
+#define T(x) { #x, (const void*)&x, sizeof(x) }
+		T(g_uastc_mode_weight_bits), T(g_uastc_mode_weight_ranges), T(g_uastc_mode_endpoint_ranges), T(g_uastc_mode_subsets),
+		T(g_uastc_mode_planes), T(g_uastc_mode_comps), T(g_uastc_mode_has_etc1_bias), T(g_uastc_mode_has_bc1_hint0),
+		T(g_uastc_mode_has_bc1_hint1), T(g_uastc_mode_has_alpha), T(g_uastc_mode_is_la), T(g_uastc_mode_huff_codes),
+		T(g_astc_bc7_patterns2), T(g_astc_bc7_patterns3), T(g_bc7_3_astc2_patterns2),
+		T(g_astc_bc7_pattern2_anchors), T(g_astc_bc7_pattern3_anchors), T(g_bc7_3_astc2_patterns2_anchors),
+		T(g_astc_to_bc7_partition_index_perm_tables), T(g_bc7_to_astc_partition_index_perm_tables),
+		T(g_astc_bise_range_table), T(g_astc_unquant), T(g_astc_sorted_order_unquant),
+		T(g_bc7_weights1), T(g_bc7_weights2), T(g_bc7_weights3), T(g_bc7_weights4), T(g_astc_weights4), T(g_astc_weights5),
+		T(g_bc7_weights1x), T(g_bc7_weights2x), T(g_bc7_weights3x), T(g_bc7_weights4x), T(g_astc_weights4x), T(g_astc_weights5x),
+		T(g_bc7_partition2), T(g_bc7_partition3), T(g_bc7_table_anchor_index_second_subset),
+		T(g_bc7_table_anchor_index_third_subset_1), T(g_bc7_table_anchor_index_third_subset_2),
+		T(g_etc2_eac_tables), T(g_etc1_inten_tables),
+#undef T
+	};
+	// struct arrays flattened to plain integers so the consumer does not depend on padding
+	std::vector<uint32_t> flat;
+	if (!strcmp(name, "common_partitions2")) for (auto& d : g_astc_bc7_common_partitions2) { flat.push_back(d.m_bc7); flat.push_back(d.m_astc); flat.push_back(d.m_invert); }
+	else if (!strcmp(name, "common_partitions3")) for (auto& d : g_astc_bc7_common_partitions3) { flat.push_back(d.m_bc7); flat.push_back(d.m_astc); flat.push_back(d.m_astc_to_bc7_perm); }
+	else if (!strcmp(name, "bc73_astc2_partitions")) for (auto& d : g_bc7_3_astc2_common_partitions) { flat.push_back(d.m_bc73); flat.push_back(d.m_astc2); flat.push_back(d.k); }
+	if (!flat.empty()) { const uint64_t need = flat.size() * 4; if (buf && cap >= need) memcpy(buf, flat.data(), need); return need; }
+	for (const ent& e : tabs)
+		if (!strcmp(e.n, name)) { if (buf && cap >= e.sz) memcpy(buf, e.p, e.sz); return e.sz; }
+	return ~0ull;
+}
+
+// color_cell_compression (encoder/basisu_bc7enc.cpp:1364) exactly as basisu_uastc_enc.cpp calls it: mode 255, ASTC endpoint range,
+// unit channel weights, non-perceptual. out: [0..3] low astc endpoint, [4..7] high, [8..23] selectors. Returns the error.
+REF_API uint64_t ref_color_cell_compression(const uint8_t* rgba, uint32_t n, uint32_t weight_bits, uint32_t endpoint_range, int has_alpha,
+	uint32_t uber_level, uint32_t ls_passes, const uint8_t* force_selectors, uint8_t* out24) {
+	static const uint32_t* wt[6] = { nullptr, basist::g_bc7_weights1, basist::g_bc7_weights2, basist::g_bc7_weights3, basist::g_astc_weights4, basist::g_astc_weights5 };
+	static const float* wx[6] = { nullptr, g_bc7_weights1x, g_bc7_weights2x, g_bc7_weights3x, g_astc_weights4x, g_astc_weights5x };
+	color_cell_compressor_params p; memset(&p, 0, sizeof(p));
+	p.m_num_pixels = n; p.m_pPixels = (const basist::color_quad_u8*)rgba;
+	p.m_num_selector_weights = 1u << weight_bits; p.m_pSelector_weights = wt[weight_bits]; p.m_pSelector_weightsx = (const bc7enc_vec4F*)wx[weight_bits];
+	p.m_astc_endpoint_range = endpoint_range; p.m_weights[0] = p.m_weights[1] = p.m_weights[2] = p.m_weights[3] = 1;
+	p.m_has_alpha = has_alpha; p.m_pForce_selectors = force_selectors;
+	bc7enc_compress_block_params cp; memset(&cp, 0, sizeof(cp));
+	cp.m_max_partitions_mode1 = 64; cp.m_least_squares_passes = ls_passes; cp.m_weights[0] = cp.m_weights[1] = cp.m_weights[2] = cp.m_weights[3] = 1; cp.m_uber_level = uber_level;
+	color_cell_compressor_results r; memset(&r, 0, sizeof(r));
+	uint8_t sel[16] = {0}, tmp[16] = {0};
+	r.m_pSelectors = sel; r.m_pSelectors_temp = tmp;
+	const uint64_t err = color_cell_compression(255, &p, &r, &cp);
+	memcpy(out24, r.m_astc_low_endpoint.m_c, 4); memcpy(out24 + 4, r.m_astc_high_endpoint.m_c, 4); memcpy(out24 + 8, sel, 16);
+	return err;
+}
+
+REF_API uint64_t ref_ccell_est(uint32_t weight_bits, uint32_t comps, const uint8_t* rgba, uint32_t n, uint64_t best_so_far) {
+	static const uint32_t* wt[6] = { nullptr, basist::g_bc7_weights1, basist::g_bc7_weights2, basist::g_bc7_weights3, basist::g_astc_weights4, basist::g_astc_weights5 };
+	const uint32_t w[4] = { 1, 1, 1, 1 };
+	return color_cell_compression_est_astc(1u << weight_bits, comps, wt[weight_bits], n, (const basist::color_quad_u8*)rgba, best_so_far, w);
+}
+
+// 16-byte UASTC block -> 16 RGBA pixels via the reference transcoder (basisu_transcoder.cpp:15886)
+REF_API int ref_unpack_uastc(const uint8_t* blk16, uint8_t* out_rgba64) {
+	basist::uastc_block b; memcpy(&b, blk16, 16);
+	return basist::unpack_uastc(b, (basist::color32*)out_rgba64, false) ? 1 : 0;
+}
+// 16-byte UASTC block -> BC7 (transcode_uastc_to_bc7, :16537) -> pixels (unpack_block cBC7)
+REF_API int ref_uastc_to_bc7_pixels(const uint8_t* blk16, uint8_t* out_bc7_16, uint8_t* out_rgba64) {
+	basist::uastc_block b; memcpy(&b, blk16, 16);
+	if (!basist::transcode_uastc_to_bc7(b, out_bc7_16)) return 0;
+	return unpack_block(texture_format::cBC7, out_bc7_16, (color_rgba*)out_rgba64, false) ? 1 : 0;
+}
+// basist::encode_bc1 (:18047) + unpack
+REF_API void ref_encode_bc1(const uint8_t* rgba64, uint32_t flags, uint8_t* out8, uint8_t* out_rgba64) {
+	basist::encode_bc1(out8, rgba64, flags);
+	if (out_rgba64) unpack_block(texture_format::cBC1, out8, (color_rgba*)out_rgba64, false);
+}
+REF_API void ref_pack_etc1_solid(const uint8_t* rgb, uint8_t* out8) {
+	etc_block b; memset(&b, 0, sizeof(b));
+	pack_etc1_block_solid_color(b, rgb);
+	memcpy(out8, &b, 8);
 }
 
 // ---------------------------------------------------------------- whole-encoder anchors (quality -> cluster counts)
