@@ -44,6 +44,7 @@ _SIGNATURES = {
     "bu_hip_refine_endpoint_clusterization": (_int, [_vp, _vp, _u32, _vp, _vp, _vp, _int]),
     "bu_hip_find_optimal_selector_clusters_for_each_block": (_int, [_vp, _vp, _u32, _vp, _vp, _vp, _int]),
     "bu_hip_determine_selectors": (_int, [_vp, _vp, _vp, _int]),
+    "bu_hip_encode_uastc_blocks": (_int, [_vp, _vp, _u32]),
     # section 2
     "bu_hip_create_context_on": (_vp, [_int]),
     "bu_hip_context_device": (_int, [_vp]),
@@ -68,6 +69,8 @@ _SIGNATURES = {
     "bu_hip_k_selector_training_vectors": (_int, [_vp, _vp, _u32, _int, _vp, _vp]),
     "bu_hip_k_create_optimized_selector_codebook": (_int, [_vp, _vp, _vp, _u32, _vp, _vp, _int, _vp]),
     "bu_hip_k_find_optimal_selector_clusters": (_int, [_vp, _vp, _vp, _u32, _vp, _u32, _u32, _vp, _vp, _vp, _int, _u32, _vp]),
+    "bu_hip_k_encode_uastc_blocks": (_int, [_vp, _vp, _u32, _u32, _vp]),
+    "bu_hip_uastc_workspace_bytes": (C.c_size_t, [_u32, _u32]),
     "bu_hip_tsvq_create": (_vp, [_vp, _u32, _vp, _vp, _u32, _vp]),
     "bu_hip_tsvq_create_packed16": (_vp, [_vp, _vp, _vp, _u32, _vp]),
     "bu_hip_tsvq_split": (_int, [_vp, _vp, _vp, _u32, _vp]),

@@ -17,6 +17,7 @@
 #include "../../include/basisu_hip.h"
 #include "etc1s_kernels.h"
 #include "tsvq_kernels.h"
+#include "uastc_kernels.h"
 
 namespace {
 
@@ -534,6 +535,36 @@ int bu_hip_tsvq_read_members(bu_hip_context* ctx, bu_tsvq* q, uint32_t buf, uint
 }
 
 // ---------------------------------------------------------------------------------------------------------------- section 1 (blocking, host pointers)
+
+// ---------------------------------------------------------------- UASTC (rows a16-a19)
+
+size_t bu_hip_uastc_workspace_bytes(uint32_t n_blocks, uint32_t flags) { return bu::uastc_workspace_bytes(n_blocks, flags); }
+
+int bu_hip_k_encode_uastc_blocks(bu_hip_context* ctx, const void* d_px, uint32_t n_blocks, uint32_t flags, void* d_out) {
+    if (!ctx) return 0;
+    if (!d_px || !d_out) { set_error(ctx, "encode_uastc: null device pointer"); return 0; }
+    device_guard g(ctx->device);
+    arena& ws = ctx->scratch[5];
+    BU_TRY(ctx, ws.reserve(bu::uastc_workspace_bytes(n_blocks, flags)));
+    static const char* const names[4] = { "uastc_classify", "uastc_candidates", "uastc_score", "uastc_finish" };
+    for (int phase = 0; phase < 4; phase++) {
+        prof_scope ps(ctx, names[phase]);
+        BU_TRY(ctx, bu::launch_uastc_phase(ctx->stream, phase, d_px, n_blocks, flags, ws.p, d_out));
+    }
+    return 1;
+}
+
+int bu_hip_encode_uastc_blocks(bu_hip_context* ctx, bu_uastc_block* out, uint32_t flags) {
+    if (!ctx || !ctx->d_pixel_blocks) { if (ctx) set_error(ctx, "no pixel blocks set"); return 0; }
+    device_guard g(ctx->device);
+    const uint32_t n = (uint32_t)ctx->total_blocks;
+    arena& o = ctx->scratch[0];
+    BU_TRY(ctx, o.reserve((size_t)n * 16));
+    if (!bu_hip_k_encode_uastc_blocks(ctx, ctx->d_pixel_blocks, n, flags, o.p)) return 0;
+    BU_TRY(ctx, hipMemcpyAsync(out, o.p, (size_t)n * 16, hipMemcpyDeviceToHost, ctx->stream));
+    BU_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return 1;
+}
 
 int bu_hip_encode_etc1s_blocks(bu_hip_context* ctx, bu_etc_block* out, int perceptual, uint32_t total_perms) {
     if (!ctx || !ctx->d_pixel_blocks) { if (ctx) set_error(ctx, "no pixel blocks set"); return 0; }

@@ -20,10 +20,14 @@
 
 #if defined(__HIPCC__)
 #define BU_FN __device__ inline
+#define BU_FN_MEMBER __device__ inline
+#define BU_FN_HD __host__ __device__ inline
 #define BU_FN_BIG __device__ __noinline__
 #define BU_TAB static __device__ const
 #else
 #define BU_FN static inline
+#define BU_FN_MEMBER inline
+#define BU_FN_HD static inline
 #define BU_FN_BIG static
 #define BU_TAB static const
 #endif
@@ -34,7 +38,7 @@ namespace bu_uastc {
 
 struct rgba8 { uint8_t c[4]; };
 
-BU_FN int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+BU_FN_HD int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 BU_FN float saturatef(float v) { return v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v); }
 BU_FN uint32_t astc_levels(uint32_t range) { return (1u + 2u * ku_bise[range * 3 + 1] + 4u * ku_bise[range * 3 + 2]) << ku_bise[range * 3]; }
 // astc_interpolate_linear (bc7enc.cpp:177-183) == basist::astc_interpolate(..., srgb=false) (transcoder_uastc.h:77-93)
@@ -444,7 +448,7 @@ BU_FN uint64_t cell_estimate(uint32_t wbits, uint32_t comps, const rgba8* px, ui
 // Candidates. One `cand` is one uastc_encode_results (uastc_enc.h:74-81) in a fixed 64-byte slot.
 // ------------------------------------------------------------------------------------------------------------------
 
-struct cand {
+struct alignas(16) cand {
     uint64_t err;           // m_astc_err
     uint8_t mode, pattern, ccs, valid;
     uint8_t endpoints[18];  // ASTC endpoint indices: per subset, per channel {low, high}
@@ -460,7 +464,7 @@ struct enc_cfg {            // encode_uastc's per-level settings (uastc_enc.cpp:
 enum { FLAG_FAVOR_UASTC = 8, FLAG_FAVOR_BC7 = 16, FLAG_ETC1_FASTER = 64, FLAG_ETC1_FASTEST = 128, FLAG_ETC1_NO_FLIP_INDIVIDUAL = 256, FLAG_FAVOR_SIMPLER = 512 };
 enum { CLS_SOLID = 1, CLS_ALPHA = 2, CLS_LA = 4 };
 
-BU_FN void make_cfg(uint32_t flags, enc_cfg& c) {
+BU_FN_HD void make_cfg(uint32_t flags, enc_cfg& c) {
     int level = (int)(flags & 7);
     level = clampi(level, 0, 4);
     c.flags = flags;
@@ -729,7 +733,7 @@ BU_FN void estimate_patterns(uint32_t mode, const rgba8* px_in, uint32_t want, u
 
 enum { MAX_SLOTS = 176 };
 
-BU_FN uint32_t mode_variants(uint32_t mode, const enc_cfg& e) {
+BU_FN_HD uint32_t mode_variants(uint32_t mode, const enc_cfg& e) {
     if (!((e.mode_mask >> mode) & 1) || mode == 8) return 0;
     switch (mode) {
     case 2: case 4: return e.estimate_partition ? 1 : 30;
@@ -743,7 +747,7 @@ BU_FN uint32_t mode_variants(uint32_t mode, const enc_cfg& e) {
 }
 // call order of the mode generators; the first three only for luminance-alpha blocks, 0..18 only for opaque blocks, the rest
 // only when alpha modes are tried
-BU_FN uint32_t mode_order(uint32_t i) {
+BU_FN_HD uint32_t mode_order(uint32_t i) {
     const uint8_t order[18] = { 15, 16, 17, 0, 1, 2, 3, 4, 5, 6, 7, 18, 9, 10, 11, 12, 13, 14 };
     return order[i];
 }
@@ -753,7 +757,7 @@ BU_FN bool mode_applies(uint32_t mode, uint32_t cls, const enc_cfg& e) {
     if (mode <= 7 || mode == 18) return !alpha;
     return alpha || e.always_alpha;
 }
-BU_FN uint32_t slot_base(uint32_t mode, const enc_cfg& e) {
+BU_FN_HD uint32_t slot_base(uint32_t mode, const enc_cfg& e) {
     uint32_t base = 0;
     for (uint32_t i = 0; i < 18; i++) {
         const uint32_t m = mode_order(i);
@@ -762,29 +766,29 @@ BU_FN uint32_t slot_base(uint32_t mode, const enc_cfg& e) {
     }
     return base;
 }
-BU_FN uint32_t total_slots(const enc_cfg& e) {
+BU_FN_HD uint32_t total_slots(const enc_cfg& e) {
     uint32_t n = 0;
     for (uint32_t i = 0; i < 18; i++) n += mode_variants(mode_order(i), e);
     return n;
 }
 
-// All candidates of one mode for one block -> slots[0 .. mode_variants). The unit of GPU work is (block, mode[, variant range]).
-BU_FN void run_mode(uint32_t mode, const rgba8* px, const enc_cfg& e, cand* slots, uint32_t first_variant, uint32_t n_variants) {
+// Candidates `first_variant .. first_variant + n_variants` of one mode for one block -> out[0 .. n_variants).
+// The unit of GPU work is (block, mode, variant range).
+BU_FN void run_mode(uint32_t mode, const rgba8* px, const enc_cfg& e, cand* out, uint32_t first_variant, uint32_t n_variants) {
     const uint32_t subsets = ku_mode_subsets[mode], planes = ku_mode_planes[mode];
     if (planes == 2) {
-        for (uint32_t v = first_variant; v < first_variant + n_variants; v++) build_dual(mode, v, px, e, slots[v]);
+        for (uint32_t v = 0; v < n_variants; v++) build_dual(mode, first_variant + v, px, e, out[v]);
     } else if (subsets == 1) {
-        build_single(mode, px, e, slots[0]);
+        build_single(mode, px, e, out[0]);
     } else if (e.estimate_partition) {
         uint32_t pats[8];
         const uint32_t want = (mode == 9 || mode == 16) ? 4 : 1;
         estimate_patterns(mode, px, want, pats);
-        for (uint32_t v = first_variant; v < first_variant + n_variants; v++) build_multi(mode, pats[v], px, e, slots[v]);
+        for (uint32_t v = 0; v < n_variants; v++) build_multi(mode, pats[first_variant + v], px, e, out[v]);
     } else {
-        for (uint32_t v = first_variant; v < first_variant + n_variants; v++) build_multi(mode, v, px, e, slots[v]);
+        for (uint32_t v = 0; v < n_variants; v++) build_multi(mode, first_variant + v, px, e, out[v]);
     }
 }
-
 
 // ------------------------------------------------------------------------------------------------------------------
 // Decoding a candidate: the UASTC/ASTC view (unpack_uastc, transcoder.cpp:15743-15879) and the BC7 view
@@ -1020,27 +1024,29 @@ BU_FN cand_score score_candidate(const cand& r, const rgba8* px, uint32_t cls, c
 
 BU_FN float mode_bias(uint32_t mode) { return (mode == 0 || mode == 10) ? .8f : 1.0f; }  // get_uastc_mode_weight, :3110-3124
 
-// Choose among the valid slots, in slot order (uastc_enc.cpp:3391-3548). Returns the slot index.
-BU_FN uint32_t choose_candidate(const cand* slots, const cand_score* score, uint32_t n_slots, const enc_cfg& e) {
+// Choose among the valid slots, in slot order (uastc_enc.cpp:3391-3548). `V` supplies valid(i), overall(i), rms(i), mode(i).
+template <class V>
+BU_FN uint32_t choose_candidate(const V& v, uint32_t n_slots, const enc_cfg& e) {
     uint32_t count = 0, first = 0;
     for (uint32_t i = 0; i < n_slots; i++)
-        if (slots[i].valid) { if (!count) first = i; count++; }
+        if (v.valid(i)) { if (!count) first = i; count++; }
     if (count <= 1) return first;
     double best_rms = 1e+20f;
     for (uint32_t i = 0; i < n_slots; i++) {
-        if (!slots[i].valid) continue;
-        if (!score[i].overall) return i;
-        if ((double)score[i].uastc_rms < best_rms) best_rms = score[i].uastc_rms;
+        if (!v.valid(i)) continue;
+        if (!v.overall(i)) return i;
+        const float rms = v.rms(i);
+        if ((double)rms < best_rms) best_rms = rms;
     }
     const bool favor_uastc = (e.flags & FLAG_FAVOR_UASTC) != 0, favor_bc7 = !favor_uastc && (e.flags & FLAG_FAVOR_BC7) != 0;
     const bool window = !(best_rms == 0.0f || favor_bc7);
     uint64_t best = UINT64_MAX;
     uint32_t best_i = first;
     for (uint32_t i = 0; i < n_slots; i++) {
-        if (!slots[i].valid) continue;
-        if (window && !((double)score[i].uastc_rms / best_rms <= (double)1.3f)) continue;
-        const float wgt = (e.flags & FLAG_FAVOR_SIMPLER) ? mode_bias(slots[i].mode) : 1.0f;
-        const uint64_t w = (uint64_t)((float)score[i].overall * wgt);
+        if (!v.valid(i)) continue;
+        if (window && !((double)v.rms(i) / best_rms <= (double)1.3f)) continue;
+        const float wgt = (e.flags & FLAG_FAVOR_SIMPLER) ? mode_bias(v.mode(i)) : 1.0f;
+        const uint64_t w = (uint64_t)((float)v.overall(i) * wgt);
         if (w < best) {
             best = w;
             best_i = i;
@@ -1049,7 +1055,6 @@ BU_FN uint32_t choose_candidate(const cand* slots, const cand_score* score, uint
     }
     return best_i;
 }
-
 
 // ------------------------------------------------------------------------------------------------------------------
 // Transcode hints: BC1 (uastc_enc.cpp:2535-2629), EAC A8 (:3012-3103), ETC1 (:2714-3010)
@@ -1672,17 +1677,9 @@ BU_FN void pack_block(const cand& norm, const etc1_hint& etc1, uint32_t eac_tabl
 // Whole-block drivers
 // ------------------------------------------------------------------------------------------------------------------
 
-// everything after the candidate search: score, choose, hints, pack (uastc_enc.cpp:3391-3644)
-BU_FN_BIG void finish_block(const rgba8* px, uint32_t cls, const enc_cfg& e, const cand* slots, uint32_t n_slots, uint8_t* out16) {
-    cand_score score[MAX_SLOTS];
-    uint32_t valid = 0;
-    for (uint32_t i = 0; i < n_slots; i++) valid += slots[i].valid ? 1 : 0;
-    for (uint32_t i = 0; i < n_slots; i++) {
-        score[i].overall = 0; score[i].uastc_rms = 0;
-        if (slots[i].valid && valid > 1) score[i] = score_candidate(slots[i], px, cls, e);
-    }
-    const uint32_t pick = choose_candidate(slots, score, n_slots, e);
-    cand best = slots[pick];
+// hints + packing of the chosen candidate (uastc_enc.cpp:3550-3644)
+BU_FN_BIG void finish_block(const rgba8* px, const enc_cfg& e, const cand& chosen, uint8_t* out16) {
+    cand best = chosen;
     rgba8 decoded[16];
     decode_uastc(best, decoded);
     normalise_anchors(best);
@@ -1694,6 +1691,14 @@ BU_FN_BIG void finish_block(const rgba8* px, uint32_t cls, const enc_cfg& e, con
     etc1_hints(best.mode, px, decoded, e, eh);
     pack_block(best, eh, eac_table, eac_mul, h0, h1, out16);
 }
+
+struct array_view {  // choose_candidate accessor over plain arrays
+    const cand* slots; const cand_score* score;
+    BU_FN_MEMBER bool valid(uint32_t i) const { return slots[i].valid != 0; }
+    BU_FN_MEMBER uint64_t overall(uint32_t i) const { return score[i].overall; }
+    BU_FN_MEMBER float rms(uint32_t i) const { return score[i].uastc_rms; }
+    BU_FN_MEMBER uint32_t mode(uint32_t i) const { return slots[i].mode; }
+};
 
 // encode_uastc (uastc_enc.cpp:3126) for one block, everything in one call (host tests; the GPU splits it into jobs)
 BU_FN_BIG void encode_block(const uint8_t* rgba64, uint32_t flags, uint8_t* out16, cand* scratch /* MAX_SLOTS */) {
@@ -1708,7 +1713,13 @@ BU_FN_BIG void encode_block(const uint8_t* rgba64, uint32_t flags, uint8_t* out1
         const uint32_t m = mode_order(i), nv = mode_variants(m, e);
         if (nv && mode_applies(m, cls, e)) run_mode(m, px, e, scratch + slot_base(m, e), 0, nv);
     }
-    finish_block(px, cls, e, scratch, n_slots, out16);
+    cand_score score[MAX_SLOTS];
+    for (uint32_t i = 0; i < n_slots; i++) {
+        score[i].overall = 0; score[i].uastc_rms = 0;
+        if (scratch[i].valid) score[i] = score_candidate(scratch[i], px, cls, e);
+    }
+    array_view v = { scratch, score };
+    finish_block(px, e, scratch[choose_candidate(v, n_slots, e)], out16);
 }
 
 }  // namespace bu_uastc

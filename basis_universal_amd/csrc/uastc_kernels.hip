@@ -1,0 +1,202 @@
+// uastc_kernels.hip -- UASTC LDR 4x4 block encoding on gfx950 (boundary 8b "encode_uastc batch op").
+//
+// The per-block algorithm is uastc_core.h; this file is the GPU decomposition. The reference encodes a block in one long serial
+// call (19 mode generators, then a choice, then three hint searches). Here the same work is cut along its natural seams so that
+// every wave runs ONE code path over 64 different blocks (no intra-wave mode divergence) and the chip sees
+// n_blocks x n_jobs independent work items instead of n_blocks:
+//   phase 0  classify      1 thread / block : solid / alpha / luminance-alpha class byte; solid blocks are packed right here
+//   phase 1  candidates    1 thread / (block, job), grid.y = job : one mode (or one pattern / rotation of it) -> 64 B slots
+//   phase 2  score         1 thread / (block, slot), grid.y = slot : UASTC decode + BC7 round trip -> {overall error, rms}
+//   phase 3  finish        1 thread / block : first-wins choice over the slots, BC1 / EAC / ETC1 hints, bit packing
+// Slots are stored [slot][block] so a wave's 64 records are contiguous (coalesced 64 B per lane), pixels are read as 4 x 16 B per
+// lane. Between phases everything stays in HBM: at level 2 that is 27 x 64 B per block, i.e. ~1.8 GB for a 4096^2 image.
+#include <hip/hip_runtime.h>
+#include <cstring>
+
+#include "uastc_core.h"
+#include "uastc_kernels.h"
+
+namespace bu {
+using namespace bu_uastc;
+
+namespace {
+
+struct uastc_job { uint8_t mode, first_variant, n_variants, pad; uint32_t slot; };
+struct uastc_plan {
+    enc_cfg e;
+    uint32_t n_slots, n_jobs;
+    uint8_t slot_mode[MAX_SLOTS];
+    uastc_job jobs[MAX_SLOTS];
+};
+
+void build_plan(uint32_t flags, uastc_plan& p) {
+    std::memset(&p, 0, sizeof(p));
+    make_cfg(flags, p.e);
+    p.n_slots = total_slots(p.e);
+    for (uint32_t i = 0; i < 18; i++) {
+        const uint32_t m = mode_order(i), nv = mode_variants(m, p.e);
+        if (!nv) continue;
+        const uint32_t base = slot_base(m, p.e);
+        for (uint32_t v = 0; v < nv; v++) p.slot_mode[base + v] = (uint8_t)m;
+        // modes whose variants share an estimated pattern list stay one job; everything else is one job per variant
+        const bool shared = p.e.estimate_partition && (m == 9 || m == 16);
+        if (shared) p.jobs[p.n_jobs++] = { (uint8_t)m, 0, (uint8_t)nv, 0, base };
+        else for (uint32_t v = 0; v < nv; v++) p.jobs[p.n_jobs++] = { (uint8_t)m, (uint8_t)v, 1, 0, base + v };
+    }
+}
+
+struct workspace {
+    uastc_plan* plan; uint8_t* cls; cand* cands; uint64_t* overall; float* rms;
+};
+size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
+workspace carve(void* base, uint32_t n, uint32_t n_slots, size_t* total) {
+    char* p = static_cast<char*>(base);
+    size_t o = 0;
+    workspace w;
+    w.plan = reinterpret_cast<uastc_plan*>(p + o); o += align_up(sizeof(uastc_plan));
+    w.cls = reinterpret_cast<uint8_t*>(p + o); o += align_up(n);
+    w.cands = reinterpret_cast<cand*>(p + o); o += align_up((size_t)n * n_slots * sizeof(cand));
+    w.overall = reinterpret_cast<uint64_t*>(p + o); o += align_up((size_t)n * n_slots * 8);
+    w.rms = reinterpret_cast<float*>(p + o); o += align_up((size_t)n * n_slots * 4);
+    if (total) *total = o;
+    return w;
+}
+
+__device__ inline void load_tile(const uint4* px, uint32_t b, rgba8* out) {
+    uint4* o = reinterpret_cast<uint4*>(out);
+#pragma unroll
+    for (int k = 0; k < 4; k++) o[k] = px[(size_t)b * 4 + k];
+}
+
+__global__ void __launch_bounds__(64) k_uastc_classify(const uint4* __restrict__ px, uint32_t n, const uastc_plan* __restrict__ plan,
+                                                       uint8_t* __restrict__ cls, uint4* __restrict__ out) {
+    const uint32_t b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= n) return;
+    alignas(16) rgba8 t[16];
+    load_tile(px, b, t);
+    const uint32_t c = classify(t, plan->e);
+    cls[b] = (uint8_t)c;
+    if (c & CLS_SOLID) {
+        alignas(16) uint8_t o[16];
+        pack_solid(t[0].c, o);
+        out[b] = *reinterpret_cast<const uint4*>(o);
+    }
+}
+
+__global__ void __launch_bounds__(64) k_uastc_candidates(const uint4* __restrict__ px, uint32_t n, const uastc_plan* __restrict__ plan,
+                                                         const uint8_t* __restrict__ cls, cand* __restrict__ cands) {
+    const uint32_t b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= n) return;
+    const uastc_job job = plan->jobs[blockIdx.y];
+    const uint32_t c = cls[b];
+    if ((c & CLS_SOLID) || !mode_applies(job.mode, c, plan->e)) return;
+    alignas(16) rgba8 t[16];
+    load_tile(px, b, t);
+    cand local[4];
+    run_mode(job.mode, t, plan->e, local, job.first_variant, job.n_variants);
+    for (uint32_t v = 0; v < job.n_variants; v++) {
+        const uint4* s = reinterpret_cast<const uint4*>(&local[v]);
+        uint4* d = reinterpret_cast<uint4*>(&cands[(size_t)(job.slot + v) * n + b]);
+#pragma unroll
+        for (int k = 0; k < 4; k++) d[k] = s[k];
+    }
+}
+
+__global__ void __launch_bounds__(64) k_uastc_score(const uint4* __restrict__ px, uint32_t n, const uastc_plan* __restrict__ plan,
+                                                    const uint8_t* __restrict__ cls, const cand* __restrict__ cands,
+                                                    uint64_t* __restrict__ overall, float* __restrict__ rms) {
+    const uint32_t b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= n) return;
+    const uint32_t slot = blockIdx.y, c = cls[b];
+    if ((c & CLS_SOLID) || !mode_applies(plan->slot_mode[slot], c, plan->e)) return;
+    alignas(16) rgba8 t[16];
+    load_tile(px, b, t);
+    cand r;
+    {
+        const uint4* s = reinterpret_cast<const uint4*>(&cands[(size_t)slot * n + b]);
+        uint4* d = reinterpret_cast<uint4*>(&r);
+#pragma unroll
+        for (int k = 0; k < 4; k++) d[k] = s[k];
+    }
+    const cand_score sc = score_candidate(r, t, c, plan->e);
+    overall[(size_t)slot * n + b] = sc.overall;
+    rms[(size_t)slot * n + b] = sc.uastc_rms;
+}
+
+struct slot_view {
+    const uastc_plan* plan; const uint64_t* overall_; const float* rms_; uint32_t n, b, cls;
+    __device__ inline bool valid(uint32_t i) const { return mode_applies(plan->slot_mode[i], cls, plan->e); }
+    __device__ inline uint64_t overall(uint32_t i) const { return overall_[(size_t)i * n + b]; }
+    __device__ inline float rms(uint32_t i) const { return rms_[(size_t)i * n + b]; }
+    __device__ inline uint32_t mode(uint32_t i) const { return plan->slot_mode[i]; }
+};
+
+__global__ void __launch_bounds__(64) k_uastc_finish(const uint4* __restrict__ px, uint32_t n, const uastc_plan* __restrict__ plan,
+                                                     const uint8_t* __restrict__ cls, const cand* __restrict__ cands,
+                                                     const uint64_t* __restrict__ overall, const float* __restrict__ rms, uint4* __restrict__ out) {
+    const uint32_t b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= n) return;
+    const uint32_t c = cls[b];
+    if (c & CLS_SOLID) return;
+    const slot_view v = { plan, overall, rms, n, b, c };
+    const uint32_t pick = choose_candidate(v, plan->n_slots, plan->e);
+    alignas(16) rgba8 t[16];
+    load_tile(px, b, t);
+    cand r;
+    {
+        const uint4* s = reinterpret_cast<const uint4*>(&cands[(size_t)pick * n + b]);
+        uint4* d = reinterpret_cast<uint4*>(&r);
+#pragma unroll
+        for (int k = 0; k < 4; k++) d[k] = s[k];
+    }
+    alignas(16) uint8_t o[16];
+    finish_block(t, plan->e, r, o);
+    out[b] = *reinterpret_cast<const uint4*>(o);
+}
+
+} // namespace
+
+size_t uastc_workspace_bytes(uint32_t n_blocks, uint32_t flags) {
+    uastc_plan p;
+    build_plan(flags, p);
+    size_t total = 0;
+    carve(nullptr, n_blocks, p.n_slots, &total);
+    return total;
+}
+
+hipError_t launch_uastc_phase(hipStream_t st, int phase, const void* d_px, uint32_t n, uint32_t flags, void* d_ws, void* d_out) {
+    if (!n) return hipSuccess;
+    uastc_plan p;
+    build_plan(flags, p);
+    const workspace w = carve(d_ws, n, p.n_slots, nullptr);
+    const uint4* px = static_cast<const uint4*>(d_px);
+    const uint32_t gx = (n + 63) / 64;
+    hipError_t e = hipSuccess;
+    switch (phase) {
+    case 0:
+        // the plan is tiny and identical for every call with the same flags; it rides in front of the first kernel
+        if ((e = hipMemcpyAsync(w.plan, &p, sizeof(p), hipMemcpyHostToDevice, st)) != hipSuccess) return e;
+        hipLaunchKernelGGL(k_uastc_classify, dim3(gx), dim3(64), 0, st, px, n, w.plan, w.cls, static_cast<uint4*>(d_out));
+        break;
+    case 1:
+        hipLaunchKernelGGL(k_uastc_candidates, dim3(gx, p.n_jobs), dim3(64), 0, st, px, n, w.plan, w.cls, w.cands);
+        break;
+    case 2:
+        hipLaunchKernelGGL(k_uastc_score, dim3(gx, p.n_slots), dim3(64), 0, st, px, n, w.plan, w.cls, w.cands, w.overall, w.rms);
+        break;
+    default:
+        hipLaunchKernelGGL(k_uastc_finish, dim3(gx), dim3(64), 0, st, px, n, w.plan, w.cls, w.cands, w.overall, w.rms, static_cast<uint4*>(d_out));
+        break;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_encode_uastc(hipStream_t st, const void* d_px, uint32_t n, uint32_t flags, void* d_ws, void* d_out) {
+    for (int phase = 0; phase < 4; phase++) {
+        const hipError_t e = launch_uastc_phase(st, phase, d_px, n, flags, d_ws, d_out);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+} // namespace bu

@@ -71,6 +71,13 @@ BU_HIP_API int bu_hip_find_optimal_selector_clusters_for_each_block(bu_hip_conte
 /* opencl_determine_selectors :137-141 */
 BU_HIP_API int bu_hip_determine_selectors(bu_hip_context*, const bu_color_rgba* input_etc_color5_and_inten, bu_etc_block* output_blocks, int perceptual);
 
+/* NEW seam (the reference has none): basisu::encode_uastc (encoder/basisu_uastc_enc.h:69, uastc_enc.cpp:3126) for every
+ * resident pixel block, replacing the per-block job loop of basis_compressor::encode_slices_to_uastc_4x4_ldr (comp.cpp:2020-2033).
+ * `flags` are the reference's pack flags verbatim: cPackUASTCLevel* in the low bits, cPackUASTCFavor*, cPackUASTCETC1* (uastc_enc.h:24-66).
+ * Output blocks are bit-identical to the reference's for every level and flag. */
+typedef struct { uint8_t m_bytes[16]; } bu_uastc_block;             /* = basist::uastc_block, transcoder/basisu_transcoder_uastc.h:198-205 */
+BU_HIP_API int bu_hip_encode_uastc_blocks(bu_hip_context*, bu_uastc_block* output_blocks, uint32_t flags);
+
 /* ------------------------------------------------------------------------------------------------------------------
  * Section 2 -- device-resident layer. All `d_` pointers are DEVICE pointers valid on the context's device; every call is
  * enqueued on the context's stream and returns without synchronising unless stated. `h_` pointers are host pointers.
@@ -132,6 +139,12 @@ BU_HIP_API int bu_hip_k_create_optimized_selector_codebook(bu_hip_context*, cons
 BU_HIP_API int bu_hip_k_find_optimal_selector_clusters(bu_hip_context*, const void* d_pixel_blocks, void* d_encoded_blocks, uint32_t n_blocks,
     const void* d_selector_blocks, uint32_t n_selectors, uint32_t n_parents, const uint32_t* d_cand_offsets, const uint32_t* d_cand_indices,
     const uint8_t* d_block_parent, int perceptual, uint32_t chunk, uint32_t* d_out_block_selector_cluster);
+
+/* a16-a19 encode_uastc over n_blocks resident tiles -> n_blocks x 16 B (device). Runs four kernels (classify, candidates per
+ *     (block, mode job), score per (block, candidate), finish); the candidate workspace lives in the context and is reused. */
+BU_HIP_API int bu_hip_k_encode_uastc_blocks(bu_hip_context*, const void* d_pixel_blocks, uint32_t n_blocks, uint32_t flags, void* d_out_uastc_blocks);
+/* Bytes of context workspace that call needs (27 candidate slots x 76 B per block at level 2; 170 at level 4). */
+BU_HIP_API size_t bu_hip_uastc_workspace_bytes(uint32_t n_blocks, uint32_t flags);
 
 /* a8  tree_vector_quant (encoder/basisu_enc.h:1546-2078): the order-dependent TSVQ tree build, split by split, bit-exact.
  *     The host keeps the tree, the variance priority queue and the split order (enc.h:1616-1660); the device executes batches of

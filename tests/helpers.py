@@ -152,6 +152,12 @@ def ref():
         L.ref_tsvq.restype = C.c_int
         L.ref_tsvq.argtypes = [C.c_uint32, f32p, u64p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, u32p, C.c_uint64, u32p, C.c_uint64]
         L.ref_encode_uastc.argtypes = [u8p, C.c_uint32, C.c_uint32, u8p]
+        L.ref_color_cell_compression.restype = C.c_uint64
+        L.ref_color_cell_compression.argtypes = [u8p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32, C.c_uint32, u8p, u8p]
+        L.ref_ccell_est.restype = C.c_uint64
+        L.ref_ccell_est.argtypes = [C.c_uint32, C.c_uint32, u8p, C.c_uint32, C.c_uint64]
+        L.ref_table.restype = C.c_uint64
+        L.ref_table.argtypes = [C.c_char_p, C.c_void_p, C.c_uint64]
         L.ref_compress_etc1s.restype = C.c_int
         L.ref_compress_etc1s.argtypes = [u8p, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_int, u32p, u32p, u8p, C.c_uint64, u64p]
         assert L.ref_init() == 1
@@ -190,3 +196,100 @@ class RefFrontend:
 
     def __del__(self):
         self.close()
+
+
+# ----------------------------------------------------------------------------- UASTC
+
+def uastc_test_blocks():
+    """~1.2k source blocks covering every class encode_uastc distinguishes (uastc_enc.cpp:3135-3152) plus degenerate cases."""
+    rng = np.random.default_rng(77)
+    parts = [to_pixel_blocks(synth(64, 64, 1234)), to_pixel_blocks(uniform_random(32, 32, 42))]
+    kod = REF_DIR / "test_files" / "kodim03.png"
+    if kod.exists():
+        parts.append(to_pixel_blocks(load_png(kod)[200:264, 300:364]))
+    else:
+        parts.append(to_pixel_blocks(synth(64, 64, 99)))
+    g = synth(48, 48, 5).copy(); g[..., 1] = g[..., 0]; g[..., 2] = g[..., 0]
+    parts.append(to_pixel_blocks(g))
+    yy, xx = np.mgrid[0:48, 0:48]
+    a = synth(48, 48, 11).copy(); a[..., 3] = np.clip(128 + 100 * np.sin(xx / 9.0) * np.cos(yy / 7.0), 0, 255).astype(np.uint8)
+    parts.append(to_pixel_blocks(a))
+    an = synth(32, 32, 9).copy(); an[..., 3] = rng.integers(0, 256, (32, 32), dtype=np.uint8)
+    parts.append(to_pixel_blocks(an))
+    ga = g.copy(); ga[..., 3] = a[..., 3]
+    parts.append(to_pixel_blocks(ga))
+    parts.append(np.ascontiguousarray(rng.integers(0, 256, (48, 1, 1, 4), dtype=np.uint8).repeat(4, 1).repeat(4, 2)))  # solid, any alpha
+    two = rng.integers(0, 256, (96, 2, 4), dtype=np.uint8)
+    tb = two[np.arange(96)[:, None], rng.integers(0, 2, (96, 16))].reshape(96, 4, 4, 4)
+    tb[:64, :, :, 3] = 255
+    parts.append(np.ascontiguousarray(tb))
+    ramp = np.zeros((32, 4, 4, 4), np.uint8)  # one-channel ramps and near-solid blocks (degenerate endpoint handling)
+    for i in range(32):
+        ramp[i, :, :, :3] = rng.integers(0, 256, 3)
+        ramp[i, :, :, i % 3] = (np.arange(16).reshape(4, 4) * (1 + i % 5) + i) % 256
+        ramp[i, :, :, 3] = 255
+    parts.append(ramp)
+    # piecewise blocks: 2 or 3 regions with unrelated colour (and alpha) ramps, so the multi-subset modes (2, 3, 4, 7, 9, 16) win somewhere
+    yy4, xx4 = np.mgrid[0:4, 0:4]
+    masks = [xx4 >= 2, yy4 >= 2, xx4 + yy4 >= 4, xx4 >= 1, yy4 >= 3, xx4 > yy4, (xx4 >= 1) + (xx4 >= 3), (yy4 >= 1) + (yy4 >= 2) * 1, (xx4 + yy4 >= 2) * 1 + (xx4 + yy4 >= 5)]
+    pw = np.zeros((len(masks) * 24, 4, 4, 4), np.uint8)
+    for i in range(pw.shape[0]):
+        m = masks[i % len(masks)].astype(np.int64)
+        variant = i // len(masks)
+        for region in range(int(m.max()) + 1):
+            base = rng.integers(0, 256, 4)
+            slope = rng.integers(-12, 13, (2, 4))
+            v = base + xx4[..., None] * slope[0] + yy4[..., None] * slope[1] + rng.integers(-2, 3, (4, 4, 4))
+            pw[i][m == region] = np.clip(v, 0, 255).astype(np.uint8)[m == region]
+        if variant % 3 == 0:
+            pw[i, :, :, 3] = 255
+        elif variant % 3 == 1:
+            pw[i, :, :, 1] = pw[i, :, :, 0]; pw[i, :, :, 2] = pw[i, :, :, 0]  # luminance + alpha
+    parts.append(pw)
+    return np.ascontiguousarray(np.concatenate(parts))
+
+
+def uastc_flag_sets():
+    """(name, pack flags): every level plus each option flag (uastc_enc.h:24-66) on top of the default level."""
+    sets = [(f"level{l}", l) for l in range(5)]
+    sets += [("favor_uastc", 2 | 8), ("favor_bc7", 2 | 16), ("etc1_faster", 2 | 64), ("etc1_fastest", 2 | 128),
+             ("etc1_noflip", 2 | 256), ("favor_simpler", 2 | 512), ("level1_faster_simpler", 1 | 64 | 512), ("level3_favor_bc7", 3 | 16)]
+    return sets
+
+
+def ref_encode_uastc(blocks, flags):
+    blocks = np.ascontiguousarray(blocks)
+    n = blocks.shape[0]
+    out = np.zeros((n, 16), np.uint8)
+    ref().ref_encode_uastc(ptr(blocks), n, flags, ptr(out))
+    return out
+
+
+_uastc_host = None
+
+
+def uastc_host():
+    """The UASTC device core compiled for the host (tests/native/uastc_host.cpp): a checker for the CPU-only suite."""
+    global _uastc_host
+    if _uastc_host is None:
+        d = ROOT / "tests" / "native"
+        so, srcs = d / "libuastc_host.so", [d / "uastc_host.cpp", ROOT / "basis_universal_amd" / "csrc" / "uastc_core.h",
+                                            ROOT / "basis_universal_amd" / "csrc" / "uastc_tables.inc"]
+        if not so.exists() or so.stat().st_mtime < max(s.stat().st_mtime for s in srcs):
+            subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-o", str(so), str(srcs[0])])
+        L = C.CDLL(str(so))
+        L.hc_encode_uastc.argtypes = [u8p, C.c_uint32, C.c_uint32, u8p]
+        L.hc_cell_compress.restype = C.c_uint64
+        L.hc_cell_compress.argtypes = [u8p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32, C.c_uint32, u8p, u8p]
+        L.hc_cell_estimate.restype = C.c_uint64
+        L.hc_cell_estimate.argtypes = [C.c_uint32, C.c_uint32, u8p, C.c_uint32, C.c_uint64]
+        _uastc_host = L
+    return _uastc_host
+
+
+def host_encode_uastc(blocks, flags):
+    blocks = np.ascontiguousarray(blocks)
+    n = blocks.shape[0]
+    out = np.zeros((n, 16), np.uint8)
+    uastc_host().hc_encode_uastc(ptr(blocks), n, flags, ptr(out))
+    return out
