@@ -6,6 +6,7 @@
 #include <chrono>
 #include <cstring>
 #include <numeric>
+#include <thread>
 
 #include "tsvq.h"
 #include "tsvq_device.h"
@@ -68,6 +69,20 @@ struct csr {
             if (!lists[i].empty()) std::memcpy(&indices[offsets[i]], lists[i].data(), lists[i].size() * sizeof(uint32_t));
     }
 };
+
+// Plain data-parallel loop over [0, n) on a few host threads (the per-block bookkeeping between device stages).
+template <class F> void parallel_for(uint32_t n, F fn) {
+    unsigned t = std::thread::hardware_concurrency();
+    t = t > 8 ? 8 : (t ? t : 1);
+    if (n < 65536 || t == 1) { fn(0u, n); return; }
+    std::vector<std::thread> th;
+    const uint32_t per = (n + t - 1) / t;
+    for (unsigned i = 0; i < t; i++) {
+        const uint32_t a = i * per, b = a + per < n ? a + per : n;
+        if (a < b) th.emplace_back([=] { fn(a, b); });
+    }
+    for (auto& x : th) x.join();
+}
 
 class timer {
 public:
@@ -413,18 +428,24 @@ bool etc1s_frontend::create_initial_packed_texture() {
 bool etc1s_frontend::generate_selector_clusters() {
     const uint32_t n = m_total_blocks;
     device_state& d = *m_dev;
+    timer sub;
+    auto lap = [&](const char* name) { m_stage_times.push_back(stage_time{name, sub.seconds()}); sub = timer(); };
     if (!d.reserve(d.weights, (size_t)n * 8)) return fail("alloc");
     if (!bu_hip_k_selector_training_vectors(d.ctx, d.enc.p, n, m_params.m_perceptual, nullptr, (uint64_t*)d.weights.p)) return fail("bu_hip_k_selector_training_vectors");
     std::vector<uint64_t> weights(n);
     if (!d.download(weights.data(), d.weights, n)) return fail("download selector weights");
+    lap("~gsc/weights");
 
     std::vector<uint32_t> keys(n), idx(n), keys2(n), idx2(n);
-    for (uint32_t b = 0; b < n; b++) {
-        const uint32_t lo = raw_selector_bits(m_encoded_blocks[b]);
-        uint32_t key = 0;
-        for (uint32_t i = 0; i < 16; i++) key = (key << 2) | selector_of(lo, i & 3, i >> 2);
-        keys[b] = key; idx[b] = b;
-    }
+    parallel_for(n, [&](uint32_t b0, uint32_t b1) {
+        for (uint32_t b = b0; b < b1; b++) {
+            const uint32_t lo = raw_selector_bits(m_encoded_blocks[b]);
+            uint32_t key = 0;
+            for (uint32_t i = 0; i < 16; i++) key = (key << 2) | selector_of(lo, i & 3, i >> 2);
+            keys[b] = key; idx[b] = b;
+        }
+    });
+    lap("~gsc/keys");
     for (int pass = 0; pass < 4; pass++) { // stable LSD radix sort, 8 bits per pass
         uint32_t hist[257] = {0};
         const int sh = pass * 8;
@@ -433,20 +454,33 @@ bool etc1s_frontend::generate_selector_clusters() {
         for (uint32_t i = 0; i < n; i++) { const uint32_t p = hist[(keys[i] >> sh) & 255]++; keys2[p] = keys[i]; idx2[p] = idx[i]; }
         keys.swap(keys2); idx.swap(idx2);
     }
-    std::vector<uint32_t> ukeys; std::vector<uint64_t> uw; std::vector<std::vector<uint32_t>> groups;
+    lap("~gsc/sort");
+    // distinct keys with their summed weights; the members of distinct vector u are idx[goffs[u] .. goffs[u+1]) (ascending block index)
+    std::vector<uint32_t> ukeys, goffs; std::vector<uint64_t> uw;
+    ukeys.reserve(n); goffs.reserve((size_t)n + 1); uw.reserve(n);
     for (uint32_t i = 0; i < n;) {
         uint32_t j = i; uint64_t w = 0;
-        while (j < n && keys[j] == keys[i]) { w += weights[idx[j]]; j++; }
-        ukeys.push_back(keys[i]);
+        const uint32_t key = keys[i];
+        while (j < n && keys[j] == key) { w += weights[idx[j]]; j++; }
+        ukeys.push_back(key);
         uw.push_back(w);
-        groups.emplace_back(idx.begin() + i, idx.begin() + j);
+        goffs.push_back(i);
         i = j;
     }
+    goffs.push_back(n);
+    const csr_groups groups{goffs.data(), idx.data()};
+    lap("~gsc/unique");
     const uint32_t parent_default = (m_params.m_compression_level <= 1) ? kSelectorParentCodebookSizeLevel01 : kSelectorParentCodebookSizeDefault;
     const uint32_t parent_size = (m_params.m_max_selector_clusters >= 256) ? parent_default : 0;
+    device_tsvq::stats ts;
     if (!device_tsvq::hierarchical_codebook_packed16(d.ctx, ukeys, uw, groups, m_params.m_max_selector_clusters, m_use_hierarchical_selector_codebooks ? parent_size : 0,
-                                                     m_selector_cluster_block_indices, m_selector_parent_cluster_block_indices))
+                                                     m_selector_cluster_block_indices, m_selector_parent_cluster_block_indices, &ts))
         return fail("selector TSVQ failed");
+    m_stage_times.push_back(stage_time{"~gsc/tsvq_create", ts.t_create});
+    m_stage_times.push_back(stage_time{"~gsc/tsvq_device", ts.t_device});
+    m_stage_times.push_back(stage_time{"~gsc/tsvq_replay", ts.t_replay});
+    m_stage_times.push_back(stage_time{"~gsc/tsvq_expand", ts.t_expand});
+    sub = timer();
     if (m_use_hierarchical_selector_codebooks) {
         if (m_selector_parent_cluster_block_indices.empty()) {
             m_selector_parent_cluster_block_indices.resize(1);
@@ -456,6 +490,7 @@ bool etc1s_frontend::generate_selector_clusters() {
         for (size_t p = 0; p < m_selector_parent_cluster_block_indices.size(); p++)
             for (uint32_t b : m_selector_parent_cluster_block_indices[p]) m_block_parent_selector_cluster[b] = (uint8_t)p;
     }
+    lap("~gsc/parents");
     return true;
 }
 

@@ -8,6 +8,7 @@
 // replay never reaches are simply dropped, so the final tree is the reference's tree.
 #pragma once
 #include <algorithm>
+#include <chrono>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -19,25 +20,43 @@
 
 namespace bu {
 
+// The original training-vector indices behind every distinct vector: either one std::vector per distinct vector, or CSR
+// (offsets[u] .. offsets[u+1] into one index array), which is what a sort-based de-duplication yields for free.
+struct vec_groups {
+    const std::vector<std::vector<uint32_t>>* g;
+    size_t size(uint32_t u) const { return (*g)[u].size(); }
+    const uint32_t* begin(uint32_t u) const { return (*g)[u].data(); }
+};
+struct csr_groups {
+    const uint32_t* offsets; const uint32_t* items;
+    size_t size(uint32_t u) const { return offsets[u + 1] - offsets[u]; }
+    const uint32_t* begin(uint32_t u) const { return items + offsets[u]; }
+};
+
 class device_tsvq {
 public:
-    struct stats { uint32_t rounds = 0, splits_computed = 0, splits_used = 0; };
+    struct stats { uint32_t rounds = 0, splits_computed = 0, splits_used = 0; double t_create = 0, t_device = 0, t_replay = 0, t_expand = 0; };
 
     // rows: n distinct vectors of `dim` floats, ascending; groups[u]: original training-vector indices of unique vector u.
     static bool hierarchical_codebook(bu_hip_context* ctx, uint32_t dim, const std::vector<float>& rows, const std::vector<uint64_t>& weights,
                                       const std::vector<std::vector<uint32_t>>& groups, uint32_t max_codebook_size, uint32_t max_parent_codebook_size,
                                       std::vector<std::vector<uint32_t>>& codebook, std::vector<std::vector<uint32_t>>& parent_codebook, stats* st = nullptr) {
         bu_tsvq_root root;
+        const auto t0 = std::chrono::steady_clock::now();
         bu_tsvq* q = weights.empty() ? nullptr : bu_hip_tsvq_create(ctx, dim, rows.data(), weights.data(), (uint32_t)weights.size(), &root);
-        return q && build(ctx, q, root, (uint32_t)weights.size(), groups, max_codebook_size, max_parent_codebook_size, codebook, parent_codebook, st);
+        if (st) st->t_create = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        return q && build(ctx, q, root, (uint32_t)weights.size(), vec_groups{&groups}, max_codebook_size, max_parent_codebook_size, codebook, parent_codebook, st);
     }
 
     // Selector vectors: keys[u] packs the 16 selector values of distinct vector u (value 0 in the top two bits), ascending.
+    template <class Groups>
     static bool hierarchical_codebook_packed16(bu_hip_context* ctx, const std::vector<uint32_t>& keys, const std::vector<uint64_t>& weights,
-                                               const std::vector<std::vector<uint32_t>>& groups, uint32_t max_codebook_size, uint32_t max_parent_codebook_size,
+                                               const Groups& groups, uint32_t max_codebook_size, uint32_t max_parent_codebook_size,
                                                std::vector<std::vector<uint32_t>>& codebook, std::vector<std::vector<uint32_t>>& parent_codebook, stats* st = nullptr) {
         bu_tsvq_root root;
+        const auto t0 = std::chrono::steady_clock::now();
         bu_tsvq* q = weights.empty() ? nullptr : bu_hip_tsvq_create_packed16(ctx, keys.data(), weights.data(), (uint32_t)weights.size(), &root);
+        if (st) st->t_create = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         return q && build(ctx, q, root, (uint32_t)weights.size(), groups, max_codebook_size, max_parent_codebook_size, codebook, parent_codebook, st);
     }
 
@@ -67,7 +86,8 @@ private:
         }
     }
 
-    static bool build(bu_hip_context* ctx, bu_tsvq* q, const bu_tsvq_root& root, uint32_t n, const std::vector<std::vector<uint32_t>>& groups,
+    template <class Groups>
+    static bool build(bu_hip_context* ctx, bu_tsvq* q, const bu_tsvq_root& root, uint32_t n, const Groups& groups,
                       uint32_t max_codebook_size, uint32_t max_parent_codebook_size, std::vector<std::vector<uint32_t>>& codebook,
                       std::vector<std::vector<uint32_t>>& parent_codebook, stats* st) {
         struct guard { bu_hip_context* c; bu_tsvq* q; ~guard() { bu_hip_tsvq_destroy(c, q); } } g{ctx, q};
@@ -90,6 +110,10 @@ private:
         heap.reset(0, nodes[0].var);
         uint32_t leaves = 1, next_codebook_index = 0;
         stats local;
+        if (st) local.t_create = st->t_create;
+        auto now = [] { return std::chrono::steady_clock::now(); };
+        auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+        const auto t_loop0 = now();
         std::vector<bu_tsvq_node> batch;
         std::vector<uint32_t> batch_nodes;
         std::vector<std::pair<float, uint32_t>> pending;
@@ -148,35 +172,45 @@ private:
             if (std::getenv("BU_TSVQ_SERIAL")) { // debug: one node per launch
                 for (size_t i = 0; i < batch.size(); i++)
                     if (!bu_hip_tsvq_split(ctx, q, &batch[i], 1, cache.data() + base + i)) return false;
-            } else if (!bu_hip_tsvq_split(ctx, q, batch.data(), (uint32_t)batch.size(), cache.data() + base)) return false;
+            } else {
+                const auto td = now();
+                if (!bu_hip_tsvq_split(ctx, q, batch.data(), (uint32_t)batch.size(), cache.data() + base)) return false;
+                local.t_device += secs(td, now());
+            }
             if (std::getenv("BU_TSVQ_VERIFY")) verify_batch(ctx, q, batch, cache.data() + base, local.rounds);
             for (size_t i = 0; i < batch.size(); i++) nodes[batch_nodes[i]].cached = (int32_t)(base + i);
             local.rounds++; local.splits_computed += (uint32_t)batch.size();
         }
-        if (st) *st = local;
+        const auto t_loop1 = now();
+        local.t_replay = secs(t_loop0, t_loop1) - local.t_device;
+        struct fin { stats* st; stats* local; std::chrono::steady_clock::time_point t; ~fin() { local->t_expand = std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count(); if (st) *st = *local; } } fin_{st, &local, t_loop1};
 
         // ---- leaves in node order (enc.h:1573-1584). Leaf segments are intact in their buffers and ascending.
         std::vector<uint32_t> perm[2];
         perm[0].resize(n); perm[1].resize(n);
         if (!bu_hip_tsvq_read_members(ctx, q, 0, 0, n, perm[0].data()) || !bu_hip_tsvq_read_members(ctx, q, 1, 0, n, perm[1].data())) return false;
         std::vector<int32_t> leaf_of_node(nodes.size(), -1);
-        std::vector<std::vector<uint32_t>> leaf_members;
+        struct span { const uint32_t* p; uint32_t n; };
+        std::vector<span> leaf_members;
         for (size_t ni = 0; ni < nodes.size(); ni++) {
             if (nodes[ni].left >= 0) continue;
             leaf_of_node[ni] = (int32_t)leaf_members.size();
-            const uint32_t* src = perm[nodes[ni].buf].data() + nodes[ni].start;
-            leaf_members.emplace_back(src, src + nodes[ni].count);
+            leaf_members.push_back(span{perm[nodes[ni].buf].data() + nodes[ni].start, nodes[ni].count});
         }
-        auto expand = [&](const std::vector<std::vector<uint32_t>>& in, std::vector<std::vector<uint32_t>>& out) {
-            out.clear(); out.resize(in.size());
-            for (size_t i = 0; i < in.size(); i++) {
-                size_t total = 0;
-                for (uint32_t u : in[i]) total += groups[u].size();
-                out[i].reserve(total);
-                for (uint32_t u : in[i]) out[i].insert(out[i].end(), groups[u].begin(), groups[u].end());
+        // distinct vectors -> the training vectors behind them, list by list
+        auto expand_one = [&](const uint32_t* us, size_t count, std::vector<uint32_t>& out) {
+            size_t total = 0;
+            for (size_t i = 0; i < count; i++) total += groups.size(us[i]);
+            out.resize(total);
+            uint32_t* dst = out.data();
+            for (size_t i = 0; i < count; i++) {
+                const size_t k = groups.size(us[i]);
+                std::memcpy(dst, groups.begin(us[i]), k * sizeof(uint32_t));
+                dst += k;
             }
         };
-        expand(leaf_members, codebook);
+        codebook.clear(); codebook.resize(leaf_members.size());
+        for (size_t i = 0; i < leaf_members.size(); i++) expand_one(leaf_members[i].p, leaf_members[i].n, codebook[i]);
 
         parent_codebook.clear();
         if (max_parent_codebook_size) {
@@ -204,10 +238,15 @@ private:
                 ni = (uint32_t)cur.left;
             }
             std::vector<uint32_t> cut_of_vec(n);
-            for (size_t l = 0; l < leaf_members.size(); l++) for (uint32_t u : leaf_members[l]) cut_of_vec[u] = cut_of_leaf[l];
-            std::vector<std::vector<uint32_t>> cut_members(cuts);
-            for (uint32_t u = 0; u < n; u++) cut_members[cut_of_vec[u]].push_back(u);
-            expand(cut_members, parent_codebook);
+            for (size_t l = 0; l < leaf_members.size(); l++)
+                for (uint32_t i = 0; i < leaf_members[l].n; i++) cut_of_vec[leaf_members[l].p[i]] = cut_of_leaf[l];
+            // counting sort of the distinct vectors by cut, ascending inside a cut
+            std::vector<uint32_t> cut_ofs(cuts + 1, 0), sorted(n);
+            for (uint32_t u = 0; u < n; u++) cut_ofs[cut_of_vec[u] + 1]++;
+            for (uint32_t c = 0; c < cuts; c++) cut_ofs[c + 1] += cut_ofs[c];
+            { std::vector<uint32_t> pos(cut_ofs.begin(), cut_ofs.end() - 1); for (uint32_t u = 0; u < n; u++) sorted[pos[cut_of_vec[u]]++] = u; }
+            parent_codebook.resize(cuts);
+            for (uint32_t c = 0; c < cuts; c++) expand_one(sorted.data() + cut_ofs[c], cut_ofs[c + 1] - cut_ofs[c], parent_codebook[c]);
         }
         return true;
     }

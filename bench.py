@@ -47,6 +47,7 @@ def main():
     ap.add_argument("--quality", type=int, default=128)
     ap.add_argument("--level", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-uastc", action="store_true", help="skip the secondary UASTC level-2 measurement (BASELINE config #3)")
     args = ap.parse_args()
 
     import torch
@@ -140,14 +141,63 @@ def main():
             "stages_s_per_step": {k: round(v / args.steps, 4) for k, v in stage_acc.items()},
             "kernels_ms_per_step": {k: round(v[0] / args.steps, 3) for k, v in kernels.items()},
         }
+        if roofline:
+            roofline["traffic"] = pmc_traffic(roofline["kernel"])
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(helpers, args)
+        if not args.no_uastc:
+            out["uastc"] = uastc_bench(ctx, d_blocks, n_blocks, w, h, helpers, args)
         print(json.dumps(out))
     if last is not None:
         last.close()
     ctx.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC passes of this same command (profiles/pmc_traffic.json, written by
+    tools/rocprof_summary.py traffic from separate --pmc FETCH_SIZE / WRITE_SIZE runs; FETCH_SIZE doubled per the gfx950 note in
+    MI355X_MICROARCH.md). Counters cannot be collected inside a normal run, so this is null when the file has no entry."""
+    f = ROOT / "profiles" / "pmc_traffic.json"
+    if not f.exists():
+        return None
+    rec = json.loads(f.read_text()).get(kernel)
+    return None if not rec else int(rec["fetch_bytes_per_launch"] + rec["write_bytes_per_launch"])
+
+
+def uastc_bench(ctx, d_blocks, n_blocks, w, h, helpers, args):
+    """BASELINE config #3: the same resident tiles through encode_uastc level 2 (rows a16-a19). One step = all four phases."""
+    import torch
+    from basis_universal_amd import uastc
+    d_out = torch.empty((n_blocks, 16), dtype=torch.uint8, device=d_blocks.device)
+    flags = uastc.LEVEL_DEFAULT
+    uastc.encode_uastc_blocks(ctx, d_blocks.data_ptr(), flags, n_blocks=n_blocks, out_device=d_out.data_ptr())
+    torch.cuda.synchronize()
+    ctx.profile_enable(True)
+    steps = max(args.steps, 3)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        uastc.encode_uastc_blocks(ctx, d_blocks.data_ptr(), flags, n_blocks=n_blocks, out_device=d_out.data_ptr())
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    kern = ctx.profile_read()
+    ctx.profile_enable(False)
+    name, (ms, launches) = max(kern.items(), key=lambda kv: kv[1][0])
+    avg_s = ms / 1e3 / launches
+    alg = 80 * n_blocks  # 64 B tile in + 16 B block out
+    res = {"metric": "UASTC LDR 4x4 level 2 encoder Mpixels/s", "value": round(w * h / 1e6 / dt, 2), "unit": "Mpixels/s", "ms_per_step": round(dt * 1e3, 2),
+           "kernels_ms_per_step": {k: round(v[0] / steps, 3) for k, v in kern.items()},
+           "roofline": {"bound": "hbm", "kernel": name, "achieved": round(alg / avg_s / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(alg / avg_s / 1e9 / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(name), "avg_launch_ms": round(avg_s * 1e3, 3)}}
+    if not args.no_cpu_baseline and helpers.have_ref():
+        sample = d_blocks[:: max(1, n_blocks // 65536)][:65536].cpu().numpy().reshape(-1, 4, 4, 4)
+        t0 = time.perf_counter()
+        helpers.ref_encode_uastc(sample, flags)
+        cdt = time.perf_counter() - t0
+        res["cpu_baseline"] = {"value": round(sample.shape[0] * 16 / 1e6 / cdt, 4), "unit": "Mpixels/s", "cores": 1, "kind": "reference",
+                               "sample": f"{sample.shape[0]} blocks strided over the bench image, reference encode_uastc level 2 (oracle/_ref), {cdt:.2f} s"}
+    return res
 
 
 def cpu_baseline(helpers, args):

@@ -37,6 +37,36 @@ def pmc(db):
         print(f"\"{n}\",{cn},{k},{a:.1f},{s:.1f}")
 
 
+def short(name):
+    """bench.py's kernel label for a mangled-demangled kernel name: bu::k_foo<...>(...) -> foo"""
+    import re
+    m = re.search(r"k_(\w+?)(?:<|\()", name)
+    n = m.group(1) if m else name
+    return {"refine_endpoint_clusterization": "refine_endpoint_clusterization", "fosc_resolve_and_stamp": "find_optimal_selector_clusters_stamp",
+            "find_optimal_selector_clusters": "find_optimal_selector_clusters"}.get(n, n)
+
+
+def traffic(fetch_db, write_db):
+    """JSON {kernel: {fetch_bytes_per_launch, write_bytes_per_launch}}: mean per dispatch, FETCH_SIZE/WRITE_SIZE are KiB; FETCH doubled (gfx950)."""
+    import json
+    out = {}
+    for db, key, mul in ((fetch_db, "fetch_bytes_per_launch", 2048.0), (write_db, "write_bytes_per_launch", 1024.0)):
+        d = sqlite3.connect(db)
+        q = ("select kernel_name, avg(v), count(*) from (select kernel_name, dispatch_id, sum(value) as v from counters_collection "
+             "group by kernel_name, dispatch_id) group by kernel_name")
+        acc = {}
+        for n, a, k in d.execute(q):
+            s_ = short(n)
+            tot, cnt = acc.get(s_, (0.0, 0))
+            acc[s_] = (tot + a * k, cnt + k)
+        for s_, (tot, cnt) in acc.items():
+            out.setdefault(s_, {"fetch_bytes_per_launch": 0, "write_bytes_per_launch": 0})[key] = int(tot / cnt * mul)
+    print(json.dumps(out, indent=1, sort_keys=True))
+
+
 if __name__ == "__main__":
+    if sys.argv[1] == "traffic":
+        traffic(sys.argv[2], sys.argv[3])
+        sys.exit(0)
     d = sqlite3.connect(sys.argv[2])
     {"stats": stats, "pmc": pmc}[sys.argv[1]](d)
