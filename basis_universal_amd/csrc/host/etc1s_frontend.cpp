@@ -3,7 +3,9 @@
 #include "etc1s_frontend.h"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 #include <thread>
@@ -11,9 +13,23 @@
 #include "tsvq.h"
 #include "tsvq_device.h"
 
+#include <malloc.h>
+
 namespace bu {
 
 namespace {
+
+// The frontend allocates and frees tens of multi-megabyte index arrays per image. With glibc's default policy each of them is a
+// fresh mmap whose pages fault in one by one (~0.2 ms per MB) and is unmapped again on free; keeping large blocks on the heap makes
+// the second and later images reuse warm pages. Process-wide, so it can be switched off: BU_KEEP_MALLOC_DEFAULTS=1.
+struct allocator_policy {
+    allocator_policy() {
+        if (std::getenv("BU_KEEP_MALLOC_DEFAULTS")) return;
+        mallopt(M_MMAP_THRESHOLD, 1 << 30);
+        mallopt(M_TRIM_THRESHOLD, 1 << 30);
+        mallopt(M_TOP_PAD, 64 << 20);
+    }
+} g_allocator_policy;
 
 const uint32_t kEndpointParentCodebookSize = 16;          // frontend.cpp:40
 const uint32_t kSelectorParentCodebookSizeLevel01 = 32;   // frontend.cpp:41
@@ -82,6 +98,35 @@ template <class F> void parallel_for(uint32_t n, F fn) {
         if (a < b) th.emplace_back([=] { fn(a, b); });
     }
     for (auto& x : th) x.join();
+}
+
+// fn(t) for t in [0, T) on T host threads
+template <class F> void parallel_for_chunks(unsigned T, F fn) {
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < T; t++) th.emplace_back([=] { fn(t); });
+    fn(0u);
+    for (auto& x : th) x.join();
+}
+
+// lists[c] = the items b in [0, n) with cluster_of(b) == c, ascending; every item contributes `emit(b, dst)` -> number of words
+// written (1 = block index, 2 = both training vectors of the block). Counting sort into one flat array, carved in parallel.
+template <int WORDS, class KeyFn>
+void lists_by_cluster(uint32_t n, uint32_t k, KeyFn cluster_of, std::vector<std::vector<uint32_t>>& lists) {
+    std::vector<uint32_t> start(k + 1, 0), flat((size_t)n * WORDS);
+    for (uint32_t b = 0; b < n; b++) start[cluster_of(b) + 1] += WORDS;
+    for (uint32_t c = 0; c < k; c++) start[c + 1] += start[c];
+    std::vector<uint32_t> cur(start.begin(), start.end() - 1);
+    for (uint32_t b = 0; b < n; b++) {
+        uint32_t& c = cur[cluster_of(b)];
+        if (WORDS == 1) flat[c] = b;
+        else { flat[c] = b * 2; flat[c + 1] = b * 2 + 1; }
+        c += WORDS;
+    }
+    lists.clear(); lists.resize(k);
+    std::atomic<uint32_t> next{0};
+    parallel_for_chunks(n > 65536 ? 8 : 1, [&](unsigned) {
+        for (uint32_t c; (c = next.fetch_add(1)) < k;) lists[c].assign(flat.begin() + start[c], flat.begin() + start[c + 1]);
+    });
 }
 
 class timer {
@@ -223,11 +268,13 @@ bool etc1s_frontend::init_endpoint_training_vectors() {
     const uint32_t n = m_total_blocks;
     // counting sort of the blocks by their 18-bit (colour555, inten) code: stable, so every bucket lists its blocks ascending
     std::vector<uint32_t> code(n), count((1u << 18) + 1, 0);
-    for (uint32_t b = 0; b < n; b++) {
-        const etc1s_header h = header_of(m_etc1_blocks_etc1s[b]);
-        code[b] = h.r | (h.g << 5) | (h.b << 10) | (h.inten << 15);
-        count[code[b] + 1]++;
-    }
+    parallel_for(n, [&](uint32_t b0, uint32_t b1) {
+        for (uint32_t b = b0; b < b1; b++) {
+            const etc1s_header h = header_of(m_etc1_blocks_etc1s[b]);
+            code[b] = h.r | (h.g << 5) | (h.b << 10) | (h.inten << 15);
+        }
+    });
+    for (uint32_t b = 0; b < n; b++) count[code[b] + 1]++;
     for (uint32_t c = 0; c < (1u << 18); c++) count[c + 1] += count[c];
     std::vector<uint32_t> sorted_blocks(n), cursor(count.begin(), count.end() - 1);
     for (uint32_t b = 0; b < n; b++) sorted_blocks[cursor[code[b]]++] = b;
@@ -366,9 +413,8 @@ bool etc1s_frontend::refine_endpoint_clusterization(uint32_t* total_reassigned) 
     std::vector<uint32_t> sizes(k, 0);
     uint32_t moved = 0;
     for (uint32_t b = 0; b < n; b++) { sizes[best[b]] += 2; moved += best[b] != block_cluster[b]; }
-    std::vector<std::vector<uint32_t>> fresh(k);
-    for (uint32_t ci = 0; ci < k; ci++) fresh[ci].reserve(sizes[ci]);
-    for (uint32_t b = 0; b < n; b++) { fresh[best[b]].push_back(b * 2); fresh[best[b]].push_back(b * 2 + 1); }
+    std::vector<std::vector<uint32_t>> fresh;
+    lists_by_cluster<2>(n, k, [&](uint32_t b) { return best[b]; }, fresh);
     m_endpoint_clusters.swap(fresh);
     if (total_reassigned) *total_reassigned = moved;
     return true;
@@ -446,28 +492,83 @@ bool etc1s_frontend::generate_selector_clusters() {
         }
     });
     lap("~gsc/keys");
-    for (int pass = 0; pass < 4; pass++) { // stable LSD radix sort, 8 bits per pass
-        uint32_t hist[257] = {0};
-        const int sh = pass * 8;
-        for (uint32_t i = 0; i < n; i++) hist[((keys[i] >> sh) & 255) + 1]++;
-        for (int i = 0; i < 256; i++) hist[i + 1] += hist[i];
-        for (uint32_t i = 0; i < n; i++) { const uint32_t p = hist[(keys[i] >> sh) & 255]++; keys2[p] = keys[i]; idx2[p] = idx[i]; }
+    // Stable sort of (key, block) by key. One MSD pass on the top byte splits the blocks into 256 buckets (per-thread histograms, so
+    // the scatter keeps block order inside a bucket); the buckets are then LSD-sorted on the remaining 24 bits independently.
+    {
+        const unsigned T = 8;
+        const uint32_t per = (n + T - 1) / T;
+        std::vector<uint32_t> hist((size_t)T * 256, 0);
+        parallel_for_chunks(T, [&](unsigned t) {
+            uint32_t* h = &hist[(size_t)t * 256];
+            const uint32_t a = t * per, b = std::min(n, a + per);
+            for (uint32_t i = a; i < b; i++) h[keys[i] >> 24]++;
+        });
+        std::vector<uint32_t> bucket_start(257, 0);
+        {
+            uint32_t run = 0;
+            for (uint32_t v = 0; v < 256; v++) {
+                bucket_start[v] = run;
+                for (unsigned t = 0; t < T; t++) { const uint32_t c = hist[(size_t)t * 256 + v]; hist[(size_t)t * 256 + v] = run; run += c; }
+            }
+            bucket_start[256] = run;
+        }
+        parallel_for_chunks(T, [&](unsigned t) {
+            uint32_t* h = &hist[(size_t)t * 256];
+            const uint32_t a = t * per, b = std::min(n, a + per);
+            for (uint32_t i = a; i < b; i++) { const uint32_t p = h[keys[i] >> 24]++; keys2[p] = keys[i]; idx2[p] = idx[i]; }
+        });
         keys.swap(keys2); idx.swap(idx2);
+        std::atomic<uint32_t> next{0};
+        parallel_for_chunks(T, [&](unsigned) {
+            for (;;) {
+                const uint32_t v = next.fetch_add(1);
+                if (v >= 256) break;
+                const uint32_t a = bucket_start[v], m = bucket_start[v + 1] - a;
+                if (m < 2) continue;
+                uint32_t *k0 = keys.data() + a, *i0 = idx.data() + a, *k1 = keys2.data() + a, *i1 = idx2.data() + a;
+                for (int pass = 0; pass < 3; pass++) {
+                    uint32_t h[257] = {0};
+                    const int sh = pass * 8;
+                    for (uint32_t i = 0; i < m; i++) h[((k0[i] >> sh) & 255) + 1]++;
+                    for (int i = 0; i < 256; i++) h[i + 1] += h[i];
+                    for (uint32_t i = 0; i < m; i++) { const uint32_t p = h[(k0[i] >> sh) & 255]++; k1[p] = k0[i]; i1[p] = i0[i]; }
+                    std::swap(k0, k1); std::swap(i0, i1);
+                }
+                // three passes: the sorted bucket sits in the "2" arrays; bring it home
+                std::memcpy(keys.data() + a, k0, (size_t)m * 4);
+                std::memcpy(idx.data() + a, i0, (size_t)m * 4);
+            }
+        });
     }
     lap("~gsc/sort");
     // distinct keys with their summed weights; the members of distinct vector u are idx[goffs[u] .. goffs[u+1]) (ascending block index)
     std::vector<uint32_t> ukeys, goffs; std::vector<uint64_t> uw;
-    ukeys.reserve(n); goffs.reserve((size_t)n + 1); uw.reserve(n);
-    for (uint32_t i = 0; i < n;) {
-        uint32_t j = i; uint64_t w = 0;
-        const uint32_t key = keys[i];
-        while (j < n && keys[j] == key) { w += weights[idx[j]]; j++; }
-        ukeys.push_back(key);
-        uw.push_back(w);
-        goffs.push_back(i);
-        i = j;
+    {
+        const unsigned T = 8;
+        const uint32_t per = (n + T - 1) / T;
+        uint32_t starts[T + 1] = {0};
+        parallel_for_chunks(T, [&](unsigned t) {  // groups that START inside a chunk belong to it
+            const uint32_t a = t * per, b = std::min(n, a + per);
+            uint32_t c = 0;
+            for (uint32_t i = a; i < b; i++) c += (i == 0 || keys[i] != keys[i - 1]);
+            starts[t + 1] = c;
+        });
+        for (unsigned t = 0; t < T; t++) starts[t + 1] += starts[t];
+        const uint32_t u_total = starts[T];
+        ukeys.resize(u_total); uw.resize(u_total); goffs.resize((size_t)u_total + 1);
+        goffs[u_total] = n;
+        parallel_for_chunks(T, [&](unsigned t) {
+            const uint32_t a = t * per, b = std::min(n, a + per);
+            uint32_t u = starts[t];
+            for (uint32_t i = a; i < b; i++) {
+                if (!(i == 0 || keys[i] != keys[i - 1])) continue;
+                uint32_t j = i; uint64_t w = 0;
+                const uint32_t key = keys[i];
+                while (j < n && keys[j] == key) { w += weights[idx[j]]; j++; }  // may run past b: the group still belongs to this chunk
+                ukeys[u] = key; uw[u] = w; goffs[u] = i; u++;
+            }
+        });
     }
-    goffs.push_back(n);
     const csr_groups groups{goffs.data(), idx.data()};
     lap("~gsc/unique");
     const uint32_t parent_default = (m_params.m_compression_level <= 1) ? kSelectorParentCodebookSizeLevel01 : kSelectorParentCodebookSizeDefault;
@@ -554,9 +655,7 @@ bool etc1s_frontend::find_optimal_selector_clusters_for_each_block() {
     if (!d.download(m_block_selector_cluster_index.data(), d.out_u32, n) || !d.download(m_encoded_blocks.data(), d.enc, n)) return fail("download fosc result");
     // frontend.cpp:2696-2708
     std::vector<uint32_t> sizes(m_selector_cluster_block_indices.size(), 0);
-    for (uint32_t b = 0; b < n; b++) sizes[m_block_selector_cluster_index[b]]++;
-    for (size_t ci = 0; ci < m_selector_cluster_block_indices.size(); ci++) { m_selector_cluster_block_indices[ci].clear(); m_selector_cluster_block_indices[ci].reserve(sizes[ci]); }
-    for (uint32_t b = 0; b < n; b++) m_selector_cluster_block_indices[m_block_selector_cluster_index[b]].push_back(b);
+    lists_by_cluster<1>(n, (uint32_t)m_selector_cluster_block_indices.size(), [&](uint32_t b) { return m_block_selector_cluster_index[b]; }, m_selector_cluster_block_indices);
     return true;
 }
 
@@ -638,8 +737,8 @@ void etc1s_frontend::optimize_selector_codebook() {
     for (uint32_t b = 0; b < m_total_blocks; b++) m_block_selector_cluster_index[b] = (uint32_t)old_to_new[m_block_selector_cluster_index[b]];
     std::vector<bu_etc_block> sels(new_to_old.size());
     for (size_t i = 0; i < new_to_old.size(); i++) sels[i] = m_optimized_cluster_selectors[new_to_old[i]];
-    std::vector<std::vector<uint32_t>> lists(new_to_old.size());
-    for (uint32_t b = 0; b < m_total_blocks; b++) lists[m_block_selector_cluster_index[b]].push_back(b);
+    std::vector<std::vector<uint32_t>> lists;
+    lists_by_cluster<1>(m_total_blocks, (uint32_t)new_to_old.size(), [&](uint32_t b) { return m_block_selector_cluster_index[b]; }, lists);
     m_optimized_cluster_selectors.swap(sels);
     m_selector_cluster_block_indices.swap(lists);
     for (auto& l : m_selector_clusters_within_each_parent_cluster)

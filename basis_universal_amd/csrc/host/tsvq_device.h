@@ -8,7 +8,9 @@
 // replay never reaches are simply dropped, so the final tree is the reference's tree.
 #pragma once
 #include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <thread>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -210,7 +212,15 @@ private:
             }
         };
         codebook.clear(); codebook.resize(leaf_members.size());
-        for (size_t i = 0; i < leaf_members.size(); i++) expand_one(leaf_members[i].p, leaf_members[i].n, codebook[i]);
+        {
+            std::atomic<size_t> next{0};
+            auto work = [&] { for (size_t i; (i = next.fetch_add(1)) < leaf_members.size();) expand_one(leaf_members[i].p, leaf_members[i].n, codebook[i]); };
+            std::vector<std::thread> th;
+            const unsigned T = n > 65536 ? 8 : 1;
+            for (unsigned t = 1; t < T; t++) th.emplace_back(work);
+            work();
+            for (auto& x : th) x.join();
+        }
 
         parent_codebook.clear();
         if (max_parent_codebook_size) {
@@ -246,7 +256,15 @@ private:
             for (uint32_t c = 0; c < cuts; c++) cut_ofs[c + 1] += cut_ofs[c];
             { std::vector<uint32_t> pos(cut_ofs.begin(), cut_ofs.end() - 1); for (uint32_t u = 0; u < n; u++) sorted[pos[cut_of_vec[u]]++] = u; }
             parent_codebook.resize(cuts);
-            for (uint32_t c = 0; c < cuts; c++) expand_one(sorted.data() + cut_ofs[c], cut_ofs[c + 1] - cut_ofs[c], parent_codebook[c]);
+            {
+                std::atomic<uint32_t> next{0};
+                auto work = [&] { for (uint32_t c; (c = next.fetch_add(1)) < cuts;) expand_one(sorted.data() + cut_ofs[c], cut_ofs[c + 1] - cut_ofs[c], parent_codebook[c]); };
+                std::vector<std::thread> th;
+                const unsigned T = n > 65536 ? 8 : 1;
+                for (unsigned t = 1; t < T; t++) th.emplace_back(work);
+                work();
+                for (auto& x : th) x.join();
+            }
         }
         return true;
     }

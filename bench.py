@@ -201,28 +201,32 @@ def uastc_bench(ctx, d_blocks, n_blocks, w, h, helpers, args):
 
 
 def cpu_baseline(helpers, args):
-    """The same stage set (frontend init + compress) on the host, single thread = the parity-pinned configuration, on a bounded
-    sample: a 1536x1536 crop of the same synthetic image with the codebook sizes -q128 gives for that size."""
+    """The same stage set (basisu_frontend init + compress) on one host core = the parity-pinned configuration of the reference.
+    With oracle/_ref present the sample is the bench workload itself (the whole 4096x4096 image, ~20 s of CPU); without it, the C
+    oracle's per-block fit on a crop (a lower bound of the reference's cost)."""
     from basis_universal_amd.etc1s import quality_to_clusters
-    side = min(1536, args.size)
-    sample = helpers.to_pixel_blocks(helpers.synth(args.size, args.size, 1234)[:side, :side])
-    n = sample.shape[0]
-    max_ep, max_sel = quality_to_clusters(args.quality, n)
     if helpers.have_ref():
+        side = args.size
+        sample = helpers.to_pixel_blocks(helpers.synth(args.size, args.size, 1234))
+        n = sample.shape[0]
+        max_ep, max_sel = quality_to_clusters(args.quality, n)
         t0 = time.perf_counter()
         fe = helpers.RefFrontend(sample, max_ep, max_sel, args.level, True)
         fe.call("compress")
         dt = time.perf_counter() - t0
         fe.close()
-        kind, what = "reference", "reference basisu_frontend::init+compress (oracle/_ref, built from /root/reference, -O3, no SSE)"
+        kind, what = "reference", "reference basisu_frontend::init+compress (oracle/_ref, built from /root/reference, -O3, no SSE, single thread)"
     else:
-        # the oracle only restates the per-block/per-cluster stages; time those (lower bound of the reference frontend)
+        side = min(1024, args.size)
+        sample = helpers.to_pixel_blocks(helpers.synth(args.size, args.size, 1234)[:side, :side])
+        n = sample.shape[0]
+        max_ep, max_sel = quality_to_clusters(args.quality, n)
         t0 = time.perf_counter()
         helpers.orc_encode_blocks(sample, args.level, True)
         dt = time.perf_counter() - t0
         kind, what = "port", "oracle per-block ETC1S fit only (reference build not present)"
     return {"value": round(side * side / 1e6 / dt, 4), "unit": "Mpixels/s", "cores": 1, "kind": kind,
-            "sample": f"{side}x{side} crop of the bench image, {n} blocks, {max_ep}/{max_sel} clusters, {what}, {dt:.2f} s",
+            "sample": f"{side}x{side} of the bench image, {n} blocks, {max_ep}/{max_sel} clusters, {what}, {dt:.2f} s",
             "host": f"{os.cpu_count()} logical CPUs on the GPU box"}
 
 
