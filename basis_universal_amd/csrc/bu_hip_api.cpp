@@ -57,6 +57,14 @@ struct bu_hip_context {
     // pinned staging ring for host -> device uploads of pageable caller memory (see h2d below)
     void* stage = nullptr; size_t stage_cap = 0, stage_used = 0;
     std::string error;
+    // bu_hip_malloc / bu_hip_free recycle blocks per context: an encoder frees and re-allocates the same dozen buffers for every
+    // image, and hipMalloc/hipFree cost 0.1-1 ms each (hipFree also synchronises the device). Reuse is stream-ordered: everything
+    // that touches these blocks is enqueued on the context's stream.
+    void* tsvq_pinned = nullptr; size_t tsvq_pinned_cap = 0;  // recycled by bu_tsvq objects (one alive at a time per stream in practice)
+    struct pooled { void* p; size_t cap; };
+    std::vector<pooled> pool_free;
+    std::vector<pooled> pool_live;
+    size_t pool_free_bytes = 0;
     // optional per-kernel timing with HIP events on the launch stream (bu_hip_profile_*)
     bool profiling = false;
     struct prof_rec { const char* name; hipEvent_t start, stop; };
@@ -204,6 +212,9 @@ void bu_hip_destroy_context(bu_hip_context* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     ctx->pixel_arena.release();
     for (auto& a : ctx->scratch) a.release();
+    if (ctx->tsvq_pinned) (void)hipHostFree(ctx->tsvq_pinned);
+    for (auto& b : ctx->pool_free) (void)hipFree(b.p);
+    for (auto& b : ctx->pool_live) (void)hipFree(b.p);  // leaked by the caller; the context owns all device memory it handed out
     if (ctx->stage) (void)hipHostFree(ctx->stage);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
@@ -230,13 +241,42 @@ int bu_hip_sync(bu_hip_context* ctx) {
 void* bu_hip_malloc(bu_hip_context* ctx, size_t bytes) {
     if (!ctx) return nullptr;
     device_guard g(ctx->device);
+    const size_t want = ((bytes ? bytes : 1) + 255) & ~(size_t)255;
+    // best fit among the cached blocks, but never more than twice (+1 MiB) what was asked for
+    int best = -1;
+    for (size_t i = 0; i < ctx->pool_free.size(); i++) {
+        const size_t cap = ctx->pool_free[i].cap;
+        if (cap >= want && cap <= want * 2 + ((size_t)1 << 20) && (best < 0 || cap < ctx->pool_free[(size_t)best].cap)) best = (int)i;
+    }
+    if (best >= 0) {
+        const bu_hip_context::pooled b = ctx->pool_free[(size_t)best];
+        ctx->pool_free.erase(ctx->pool_free.begin() + best);
+        ctx->pool_free_bytes -= b.cap;
+        ctx->pool_live.push_back(b);
+        return b.p;
+    }
     void* p = nullptr;
-    if (hipMalloc(&p, bytes ? bytes : 1) != hipSuccess) { set_error(ctx, "hipMalloc(%zu) failed", bytes); (void)hipGetLastError(); return nullptr; }
+    if (hipMalloc(&p, want) != hipSuccess) {
+        (void)hipGetLastError();
+        // out of memory: drop the cache and retry once
+        (void)hipStreamSynchronize(ctx->stream);
+        for (auto& b : ctx->pool_free) (void)hipFree(b.p);
+        ctx->pool_free.clear(); ctx->pool_free_bytes = 0;
+        if (hipMalloc(&p, want) != hipSuccess) { set_error(ctx, "hipMalloc(%zu) failed", bytes); (void)hipGetLastError(); return nullptr; }
+    }
+    ctx->pool_live.push_back({p, want});
     return p;
 }
 void bu_hip_free(bu_hip_context* ctx, void* p) {
     if (!ctx || !p) return;
     device_guard g(ctx->device);
+    for (size_t i = 0; i < ctx->pool_live.size(); i++)
+        if (ctx->pool_live[i].p == p) {
+            const bu_hip_context::pooled b = ctx->pool_live[i];
+            ctx->pool_live.erase(ctx->pool_live.begin() + (long)i);
+            if (ctx->pool_free_bytes + b.cap <= ((size_t)16 << 30)) { ctx->pool_free.push_back(b); ctx->pool_free_bytes += b.cap; return; }
+            break;
+        }
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipFree(p);
 }
@@ -438,9 +478,12 @@ void bu_hip_tsvq_destroy(bu_hip_context* ctx, bu_tsvq* q) {
     if (!ctx || !q) return;
     device_guard g(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    for (void* p : {q->rows, (void*)q->w64, (void*)q->perm[0], (void*)q->perm[1], (void*)q->side}) if (p) (void)hipFree(p);
-    q->nodes.release(); q->outs.release();
-    if (q->pinned) (void)hipHostFree(q->pinned);
+    for (void* p : {q->rows, (void*)q->w64, (void*)q->perm[0], (void*)q->perm[1], (void*)q->side, q->nodes.p, q->outs.p}) if (p) bu_hip_free(ctx, p);
+    q->nodes.p = nullptr; q->outs.p = nullptr;
+    if (q->pinned) {  // hand the pinned staging buffer back to the context (keep the larger one)
+        if (q->pinned_cap > ctx->tsvq_pinned_cap) { if (ctx->tsvq_pinned) (void)hipHostFree(ctx->tsvq_pinned); ctx->tsvq_pinned = q->pinned; ctx->tsvq_pinned_cap = q->pinned_cap; }
+        else (void)hipHostFree(q->pinned);
+    }
     delete q;
 }
 
@@ -453,11 +496,16 @@ static bu_tsvq* tsvq_create_common(bu_hip_context* ctx, uint32_t dim, bool packe
     q->force_chained = std::getenv("BU_TSVQ_CHAINED") != nullptr;
     const size_t row_bytes = packed ? 4 : (size_t)dim * 4;
     auto fail = [&](const char* what) -> bu_tsvq* { set_error(ctx, "tsvq_create: %s", what); bu_hip_tsvq_destroy(ctx, q); return nullptr; };
-    if (hipMalloc(&q->rows, (size_t)n * row_bytes) != hipSuccess || hipMalloc((void**)&q->w64, (size_t)n * 8) != hipSuccess ||
-        hipMalloc((void**)&q->perm[0], (size_t)n * 4) != hipSuccess || hipMalloc((void**)&q->perm[1], (size_t)n * 4) != hipSuccess ||
-        hipMalloc((void**)&q->side, (size_t)n) != hipSuccess)
-        return fail("allocation");
-    if (q->outs.reserve(sizeof(bu::tsvq_root_out)) != hipSuccess) return fail("allocation");
+    if (ctx->tsvq_pinned) { q->pinned = ctx->tsvq_pinned; q->pinned_cap = ctx->tsvq_pinned_cap; ctx->tsvq_pinned = nullptr; ctx->tsvq_pinned_cap = 0; }
+    // all device blocks come from (and return to) the context's pool; the node / result records are sized for the largest batch
+    // a codebook of cMaxSelectorClusters can ask for, so they never grow
+    const size_t rec_cap = (size_t)16384 * std::max(sizeof(bu_tsvq_node), sizeof(bu_tsvq_split));
+    q->rows = bu_hip_malloc(ctx, (size_t)n * row_bytes); q->w64 = (uint64_t*)bu_hip_malloc(ctx, (size_t)n * 8);
+    q->perm[0] = (uint32_t*)bu_hip_malloc(ctx, (size_t)n * 4); q->perm[1] = (uint32_t*)bu_hip_malloc(ctx, (size_t)n * 4);
+    q->side = (uint8_t*)bu_hip_malloc(ctx, n);
+    q->nodes.p = bu_hip_malloc(ctx, rec_cap); q->outs.p = bu_hip_malloc(ctx, rec_cap);
+    if (!q->rows || !q->w64 || !q->perm[0] || !q->perm[1] || !q->side || !q->nodes.p || !q->outs.p) return fail("allocation");
+    q->nodes.cap = q->outs.cap = rec_cap;
     // blocking copies (the sources are pageable, see bu_tsvq::pinned); the root kernel below needs both anyway
     if (hipStreamSynchronize(ctx->stream) != hipSuccess || hipMemcpy(q->rows, h_rows, (size_t)n * row_bytes, hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(q->w64, h_weights, (size_t)n * 8, hipMemcpyHostToDevice) != hipSuccess || hipDeviceSynchronize() != hipSuccess)
@@ -490,8 +538,7 @@ int bu_hip_tsvq_split(bu_hip_context* ctx, bu_tsvq* q, const bu_tsvq_node* h_nod
     if (!ctx || !q) return 0;
     if (!n_nodes) return 1;
     device_guard g(ctx->device);
-    BU_TRY(ctx, q->nodes.reserve((size_t)n_nodes * sizeof(bu_tsvq_node)));
-    BU_TRY(ctx, q->outs.reserve((size_t)n_nodes * sizeof(bu_tsvq_split)));
+    if ((size_t)n_nodes * sizeof(bu_tsvq_node) > q->nodes.cap || (size_t)n_nodes * sizeof(bu_tsvq_split) > q->outs.cap) { set_error(ctx, "tsvq_split: batch of %u nodes exceeds the record buffers", n_nodes); return 0; }
     const size_t in_bytes = (size_t)n_nodes * sizeof(bu_tsvq_node), out_bytes = (size_t)n_nodes * sizeof(bu_tsvq_split);
     BU_TRY(ctx, q->reserve_pinned(std::max(in_bytes, out_bytes)));
     std::memcpy(q->pinned, h_nodes, in_bytes);
