@@ -693,30 +693,107 @@ BU_FN_BIG void build_dual(uint32_t mode, uint32_t rot, const rgba8* px, const en
     }
 }
 
+// Interpolation weight of selector s for `bits` weight bits, computed instead of looked up: ASTC weight unquantisation (replicate
+// to 6 bits, +1 above 32) reproduces ku_weights for every set UASTC uses (checked against the table in tests/test_uastc_core_host.py).
+BU_FN uint32_t weight_of(uint32_t bits, uint32_t s) {
+    uint32_t w = bits == 1 ? s * 63 : (bits == 2 ? s * 21 : (bits == 3 ? s * 9 : (bits == 4 ? (s << 2) | (s >> 2) : (s << 1) | (s >> 4))));
+    return w + (w > 32 ? 1u : 0u);
+}
+
+// cell_estimate over the texels of a 4x4 block selected by `mask` (bit i = texel i), everything in registers: the texels are 16
+// packed dwords, the loops are fully unrolled and predicated on the mask. On the GPU the mask is wave-uniform when every lane
+// ranks the same pattern, so the predicates cost nothing. Thresholds are non-decreasing (the interpolants move monotonically from
+// the box's low corner to its high corner), so "last threshold not above d" is a count. The reference's early outs
+// (bc7enc.cpp:1880-1882 and the subset loop conditions) only ever stop once the running error exceeds the best total so far, which
+// cannot change which pattern wins, so the full error is computed here.
+template <int WBITS, int COMPS>
+BU_FN uint32_t estimate_masked(const uint32_t* px, uint32_t mask) {
+    constexpr int N = 1 << WBITS;
+    int lo[4] = { 255, 255, 255, 255 }, hi[4] = { 0, 0, 0, 0 };
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (int i = 0; i < 16; i++)
+        if ((mask >> i) & 1) {
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+            for (int c = 0; c < COMPS; c++) {
+                const int v = (int)((px[i] >> (8 * c)) & 255);
+                lo[c] = v < lo[c] ? v : lo[c];
+                hi[c] = v > hi[c] ? v : hi[c];
+            }
+        }
+    int axis[4], col[N][4], thresh[N - 1];
+    for (int c = 0; c < COMPS; c++) axis[c] = hi[c] - lo[c];
+    int prev_dot = 0;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (int k = 0; k < N; k++) {
+        int dot = 0;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+        for (int c = 0; c < COMPS; c++) {
+            col[k][c] = k == 0 ? lo[c] : (k == N - 1 ? hi[c] : (int)astc_lerp((uint32_t)lo[c], (uint32_t)hi[c], weight_of(WBITS, (uint32_t)k)));
+            dot += col[k][c] * axis[c];
+        }
+        if (k) thresh[k - 1] = (prev_dot + dot + 1) >> 1;
+        prev_dot = dot;
+    }
+    uint32_t total = 0;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (int i = 0; i < 16; i++)
+        if ((mask >> i) & 1) {
+            int v[4], d = 0;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+            for (int c = 0; c < COMPS; c++) { v[c] = (int)((px[i] >> (8 * c)) & 255); d += axis[c] * v[c]; }
+            int sel[4];
+            for (int c = 0; c < COMPS; c++) sel[c] = col[0][c];
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+            for (int k = 1; k < N; k++) {
+                const bool at_least = d >= thresh[k - 1];
+                for (int c = 0; c < COMPS; c++) sel[c] = at_least ? col[k][c] : sel[c];
+            }
+            for (int c = 0; c < COMPS; c++) { const int e = sel[c] - v[c]; total += (uint32_t)(e * e); }
+        }
+    return total;
+}
+
+BU_FN uint32_t estimate_masked_any(uint32_t wbits, uint32_t comps, const uint32_t* px, uint32_t mask) {
+    if (wbits == 3) return estimate_masked<3, 3>(px, mask);  // mode 2
+    return comps == 4 ? estimate_masked<2, 4>(px, mask) : estimate_masked<2, 3>(px, mask);
+}
+
 // estimate_partition2 / estimate_partition2_list and the inlined variants of modes 3 and 7 (uastc_enc.cpp:638-671, 828-860, 1362-1405,
-// 1542-1594): rank the common patterns by the cheap bounding-box estimate. Writes the `want` best patterns (ascending error).
+// 1542-1594): rank the common patterns by the cheap bounding-box estimate. Writes the `want` best patterns (ascending error,
+// earlier pattern first among equals).
 BU_FN void estimate_patterns(uint32_t mode, const rgba8* px_in, uint32_t want, uint32_t* out) {
     const uint32_t comps = ku_mode_comps[mode] == 3 ? 3 : 4, subsets = ku_mode_subsets[mode], wbits = ku_mode_weight_bits[mode];
     const uint32_t total = mode == 3 ? 11 : (mode == 7 ? 19 : 30);
-    rgba8 la[16];
-    const rgba8* px = px_in;
-    if (ku_mode_comps[mode] == 2) {
-        for (uint32_t i = 0; i < 16; i++) { la[i].c[0] = px_in[i].c[0]; la[i].c[1] = 0; la[i].c[2] = 0; la[i].c[3] = px_in[i].c[3]; }
-        px = la;
+    uint32_t px[16];
+    for (uint32_t i = 0; i < 16; i++) {
+        const uint8_t* c = px_in[i].c;
+        px[i] = ku_mode_comps[mode] == 2 ? ((uint32_t)c[0] | ((uint32_t)c[3] << 24)) : ((uint32_t)c[0] | ((uint32_t)c[1] << 8) | ((uint32_t)c[2] << 16) | ((uint32_t)c[3] << 24));
     }
     uint64_t best_err[8];
     for (uint32_t i = 0; i < 8; i++) { best_err[i] = UINT64_MAX; if (i < want) out[i] = 0; }
-    const bool list = want > 1;
     for (uint32_t pat = 0; pat < total; pat++) {
         const uint32_t bits = mode == 3 ? ku_bc7_part3[ku_cp3_bc7[pat]] : (mode == 7 ? ku_pat7[pat] : ku_bc7_part2[ku_cp2_bc7[pat]]);
-        uint64_t err = 0;
-        for (uint32_t s = 0; s < subsets && (list || err < best_err[0]); s++) {
-            rgba8 sub[16];
-            uint32_t n = 0;
-            for (uint32_t i = 0; i < 16; i++)
-                if (((bits >> (2 * i)) & 3) == s) sub[n++] = px[i];
-            err += cell_estimate(wbits, comps, sub, n, list ? UINT64_MAX : best_err[0]);
-        }
+        // per-subset texel masks from the 2-bit fields
+        const uint32_t lo_bits = bits & 0x55555555u, hi_bits = (bits >> 1) & 0x55555555u;
+        uint32_t m1 = 0, m2 = 0;
+        for (uint32_t i = 0; i < 16; i++) { m1 |= ((lo_bits >> (2 * i)) & 1u) << i; m2 |= ((hi_bits >> (2 * i)) & 1u) << i; }
+        const uint32_t m0 = 0xFFFFu & ~(m1 | m2);
+        uint64_t err = (uint64_t)estimate_masked_any(wbits, comps, px, m0) + estimate_masked_any(wbits, comps, px, m1);
+        if (subsets == 3) err += estimate_masked_any(wbits, comps, px, m2);
         for (uint32_t i = 0; i < want; i++)
             if (err < best_err[i]) {
                 for (uint32_t j = want - 1; j > i; --j) { out[j] = out[j - 1]; best_err[j] = best_err[j - 1]; }

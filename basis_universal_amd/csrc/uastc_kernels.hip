@@ -11,6 +11,8 @@
 // Slots are stored [slot][block] so a wave's 64 records are contiguous (coalesced 64 B per lane), pixels are read as 4 x 16 B per
 // lane. Between phases everything stays in HBM: at level 2 that is 27 x 64 B per block, i.e. ~1.8 GB for a 4096^2 image.
 #include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "uastc_core.h"
@@ -84,10 +86,10 @@ __global__ void __launch_bounds__(64) k_uastc_classify(const uint4* __restrict__
 }
 
 __global__ void __launch_bounds__(64) k_uastc_candidates(const uint4* __restrict__ px, uint32_t n, const uastc_plan* __restrict__ plan,
-                                                         const uint8_t* __restrict__ cls, cand* __restrict__ cands) {
+                                                         const uint8_t* __restrict__ cls, cand* __restrict__ cands, uint32_t first_job) {
     const uint32_t b = blockIdx.x * 64 + threadIdx.x;
     if (b >= n) return;
-    const uastc_job job = plan->jobs[blockIdx.y];
+    const uastc_job job = plan->jobs[first_job + blockIdx.y];
     const uint32_t c = cls[b];
     if ((c & CLS_SOLID) || !mode_applies(job.mode, c, plan->e)) return;
     alignas(16) rgba8 t[16];
@@ -179,7 +181,22 @@ hipError_t launch_uastc_phase(hipStream_t st, int phase, const void* d_px, uint3
         hipLaunchKernelGGL(k_uastc_classify, dim3(gx), dim3(64), 0, st, px, n, w.plan, w.cls, static_cast<uint4*>(d_out));
         break;
     case 1:
-        hipLaunchKernelGGL(k_uastc_candidates, dim3(gx, p.n_jobs), dim3(64), 0, st, px, n, w.plan, w.cls, w.cands);
+        if (std::getenv("BU_UASTC_JOB_TIMES")) {  // developer aid: one launch per job, timed with events, printed to stderr
+            for (uint32_t j = 0; j < p.n_jobs; j++) {
+                hipEvent_t a, b;
+                (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+                (void)hipEventRecord(a, st);
+                hipLaunchKernelGGL(k_uastc_candidates, dim3(gx, 1), dim3(64), 0, st, px, n, w.plan, w.cls, w.cands, j);
+                (void)hipEventRecord(b, st);
+                (void)hipEventSynchronize(b);
+                float ms = 0;
+                (void)hipEventElapsedTime(&ms, a, b);
+                std::fprintf(stderr, "[uastc job %2u] mode %2u variant %u x%u: %.3f ms\n", j, p.jobs[j].mode, p.jobs[j].first_variant, p.jobs[j].n_variants, ms);
+                (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+            }
+            break;
+        }
+        hipLaunchKernelGGL(k_uastc_candidates, dim3(gx, p.n_jobs), dim3(64), 0, st, px, n, w.plan, w.cls, w.cands, 0u);
         break;
     case 2:
         hipLaunchKernelGGL(k_uastc_score, dim3(gx, p.n_slots), dim3(64), 0, st, px, n, w.plan, w.cls, w.cands, w.overall, w.rms);
