@@ -1432,6 +1432,7 @@ BU_FN void eac_a8_hint(const rgba8* decoded, uint32_t mul_rad, uint32_t table_ma
 }
 
 struct etc1_hint { uint8_t flip, diff, inten0, inten1, bias; };
+BU_TAB unsigned char ku_etc1_bias_order[32] = { 13, 0, 22, 29, 27, 12, 26, 9, 30, 31, 8, 10, 25, 2, 23, 5, 15, 7, 3, 11, 6, 17, 28, 18, 1, 19, 20, 21, 24, 4, 14, 16 };
 
 BU_FN void ycbcr(const uint8_t* c, int* o) {  // rgb_to_y_cb_cr, uastc_enc.cpp:2638-2644
     const int y = c[0] * 54 + c[1] * 183 + c[2] * 19;
@@ -1507,11 +1508,152 @@ BU_FN bool etc1_estimate_flipped(const rgba8* p) {  // pack_etc1_estimate_flippe
     return ul < lr;
 }
 
-// compute_etc1_hints (uastc_enc.cpp:2714-3010) for non-solid blocks
+// ---- compute_etc1_hints (uastc_enc.cpp:2714-3010) for non-solid blocks.
+// The search is 2 flips x 2 colour modes x up to 32 biases, each trial fitting an intensity table per sub-block against the DECODED
+// texels and then scoring the trial against the SOURCE texels, all in a Y/Cb/Cr-like integer space. Everything below is laid out
+// so that a GPU lane keeps the 2 x 16 x 3 texel values in registers: flip and sub-block are template parameters (so every texel
+// index is a compile-time constant) and the squares are written so that they map to the 24-bit multiplier.
+// The reference's row-wise early outs (:2885, :2905, :2946, :2964) only stop once a running error has reached the best one, so
+// they cannot change a result and are dropped; the one early out that does (non-flipped: stop trying intensity tables at the
+// first one that is not better, :2906-2907) is kept.
+
+struct ycc { int y, cb, cr; };
+BU_FN ycc to_ycc(int r, int g, int b) { const int y = r * 54 + g * 183 + b * 19; ycc o = { y, (b << 8) - y, (r << 8) - y }; return o; }
+// d * d for |d| <= 130560 (differences of the 16.8 fixed-point luma / chroma values): the operand is masked to 18 bits so that the
+// compiler can prove it fits the 24-bit multiplier (v_mul_u32_u24 + v_mul_hi_u32_u24, full rate, instead of a 64-bit multiply).
+BU_FN uint64_t square_s18(int d) {
+    const uint32_t a = (uint32_t)(d < 0 ? -d : d) & 0x3FFFFu;
+    return (uint64_t)a * (uint64_t)a;
+}
+BU_FN uint64_t ycc_diff(const ycc& a, const ycc& b) {  // color_diff, uastc_enc.cpp:2646-2652
+    return (square_s18(a.y - b.y) << 2) + square_s18(a.cr - b.cr) + square_s18(a.cb - b.cb);
+}
+struct texels_ycc { ycc t[16]; };
+
+// raster index of texel j (0..7) of sub-block SUB; in the flipped layout j runs row by row (g_etc1_pixel_coords, etc.cpp:314-337)
+template <int FLIP, int SUB> constexpr int etc1_texel(int j) { return FLIP ? (SUB * 8 + j) : ((j & 3) * 4 + SUB * 2 + (j >> 2)); }
+
+struct etc1_subblock_stats { int mn[3], mx[3]; uint32_t sum[3]; };
+template <int FLIP, int SUB>
+BU_FN void etc1_stats(const rgba8* decoded, etc1_subblock_stats& s) {
+    for (int c = 0; c < 3; c++) { s.mn[c] = 255; s.mx[c] = 0; s.sum[c] = 0; }
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (int j = 0; j < 8; j++)
+        for (int c = 0; c < 3; c++) {
+            const int v = decoded[etc1_texel<FLIP, SUB>(j)].c[c];
+            s.sum[c] += (uint32_t)v; s.mn[c] = v < s.mn[c] ? v : s.mn[c]; s.mx[c] = v > s.mx[c] ? v : s.mx[c];
+        }
+}
+
+BU_FN void etc1_table_colours(const int* base, uint32_t table, ycc* out) {
+    for (uint32_t k = 0; k < 4; k++) {
+        const int d = ku_etc1_inten[table * 4 + k];
+        out[k] = to_ycc(clampi(base[0] + d, 0, 255), clampi(base[1] + d, 0, 255), clampi(base[2] + d, 0, 255));
+    }
+}
+
+// best intensity table of one sub-block for base colour `base` (uastc_enc.cpp:2858-2918)
+template <int FLIP, int SUB>
+BU_FN uint32_t etc1_pick_table(const texels_ycc& dec, const int* base, uint32_t limit) {
+    uint64_t best = UINT64_MAX;
+    uint32_t best_table = 0;
+    for (uint32_t table = 0; table < limit; table++) {
+        ycc col[4];
+        etc1_table_colours(base, table, col);
+        uint64_t total = 0;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+        for (int j = 0; j < 8; j++) {
+            const ycc& c = dec.t[etc1_texel<FLIP, SUB>(j)];
+            uint64_t m = ycc_diff(col[0], c);
+            for (int k = 1; k < 4; k++) { const uint64_t d = ycc_diff(col[k], c); m = d < m ? d : m; }
+            total += m;
+        }
+        if (!FLIP && total >= best) break;
+        if (total < best) { best = total; best_table = table; }
+    }
+    return best_table;
+}
+
+// error of one sub-block against the source texels when every texel takes the colour nearest to its decoded value (:2925-2973)
+template <int FLIP, int SUB>
+BU_FN uint64_t etc1_subblock_error(const texels_ycc& dec, const texels_ycc& src, const int* base, uint32_t table) {
+    ycc col[4];
+    etc1_table_colours(base, table, col);
+    uint64_t err = 0;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (int j = 0; j < 8; j++) {
+        const int t = etc1_texel<FLIP, SUB>(j);
+        uint64_t m = ycc_diff(col[0], dec.t[t]) << 2;
+        for (int k = 1; k < 4; k++) { const uint64_t d = (ycc_diff(col[k], dec.t[t]) << 2) + (uint64_t)k; m = d < m ? d : m; }
+        const uint32_t pick = (uint32_t)m & 3;
+        // the chosen colour by value: a dynamically indexed local array would live in scratch memory on the GPU
+        const ycc chosen = pick == 0 ? col[0] : (pick == 1 ? col[1] : (pick == 2 ? col[2] : col[3]));
+        err += ycc_diff(src.t[t], chosen);
+    }
+    return err;
+}
+
+struct etc1_search { uint64_t best_err; etc1_hint best; };
+
+template <int FLIP>
+BU_FN void etc1_trials(uint32_t mode, const rgba8* decoded, const texels_ycc& dec, const texels_ycc& src, const enc_cfg& e, uint32_t last_individ,
+                       uint32_t last_bias, bool sorted_table, etc1_search& out) {
+    const bool has_bias = ku_mode_has_etc1_bias[mode] != 0;
+    etc1_subblock_stats st[2];
+    etc1_stats<FLIP, 0>(decoded, st[0]);
+    etc1_stats<FLIP, 1>(decoded, st[1]);
+    for (uint32_t individ = 0; individ < last_individ; individ++) {
+        const uint32_t mul = individ ? 15 : 31;
+        uint32_t unbiased[2][3];
+        for (uint32_t sub = 0; sub < 2; sub++)
+            for (uint32_t c = 0; c < 3; c++) unbiased[sub][c] = (st[sub].sum[c] * mul + 1020) / (8 * 255);
+        for (uint32_t bi = 0; bi < last_bias; bi++) {
+            // 0 should come first, but 13 is the (0,0,0) bias (uastc_enc.cpp:2732-2733)
+            const uint32_t bias = sorted_table ? (uint32_t)ku_etc1_bias_order[bi] : bi;
+            int base[2][3];
+            for (uint32_t c = 0; c < 3; c++) {
+                const uint32_t c0 = has_bias ? etc1_bias_apply(unbiased[0][c], c, bias, mul, 0) : unbiased[0][c];
+                const uint32_t c1 = has_bias ? etc1_bias_apply(unbiased[1][c], c, bias, mul, 1) : unbiased[1][c];
+                if (individ) {
+                    base[0][c] = (int)((c0 << 4) | c0);
+                    base[1][c] = (int)((c1 << 4) | c1);
+                } else {
+                    const uint32_t c1d = (uint32_t)((int)c0 + clampi((int)c1 - (int)c0, -4, 3));  // set_block_color5_clamp, etc.h:674-690
+                    base[0][c] = (int)((c0 << 3) | (c0 >> 2));
+                    base[1][c] = (int)((c1d << 3) | (c1d >> 2));
+                }
+            }
+            uint32_t limit[2];
+            for (uint32_t sub = 0; sub < 2; sub++) {
+                int range = 0;
+                for (uint32_t c = 0; c < 3; c++) {
+                    const int pos = st[sub].mx[c] - base[sub][c], neg = base[sub][c] - st[sub].mn[c];
+                    const int ap = pos < 0 ? -pos : pos, an = neg < 0 ? -neg : neg;
+                    range = ap > range ? ap : range;
+                    range = an > range ? an : range;
+                }
+                limit[sub] = e.level == 4 ? 8 : (range > 51 ? 8 : (range >= 7 ? 4 : 2));
+            }
+            const uint32_t t0 = etc1_pick_table<FLIP, 0>(dec, base[0], limit[0]);
+            const uint32_t t1 = etc1_pick_table<FLIP, 1>(dec, base[1], limit[1]);
+            const uint64_t err = etc1_subblock_error<FLIP, 0>(dec, src, base[0], t0) + etc1_subblock_error<FLIP, 1>(dec, src, base[1], t1);
+            if (err < out.best_err) {
+                out.best_err = err;
+                out.best.flip = (uint8_t)FLIP; out.best.diff = (uint8_t)(individ == 0); out.best.inten0 = (uint8_t)t0; out.best.inten1 = (uint8_t)t1; out.best.bias = (uint8_t)bias;
+            }
+        }
+    }
+}
+
 BU_FN_BIG void etc1_hints(uint32_t mode, const rgba8* px, const rgba8* decoded, const enc_cfg& e, etc1_hint& best) {
     const bool faster = (e.flags & FLAG_ETC1_FASTER) != 0, fastest = (e.flags & FLAG_ETC1_FASTEST) != 0;
     const bool has_bias = ku_mode_has_etc1_bias[mode] != 0;
-    const uint8_t sorted_bias[32] = { 13, 0, 22, 29, 27, 12, 26, 9, 30, 31, 8, 10, 25, 2, 23, 5, 15, 7, 3, 11, 6, 17, 28, 18, 1, 19, 20, 21, 24, 4, 14, 16 };
     uint32_t last_bias = 1;
     bool sorted_table = false;
     const bool flip_estimate = e.level <= 1 || faster || fastest;
@@ -1525,116 +1667,23 @@ BU_FN_BIG void etc1_hints(uint32_t mode, const rgba8* px, const rgba8* decoded, 
         default: last_bias = 32; break;
         }
     }
-    best.flip = best.diff = best.inten0 = best.inten1 = best.bias = 0;
-    uint64_t best_err = UINT64_MAX;
-    int src_y[16][3], dec_y[16][3];
-    for (uint32_t i = 0; i < 16; i++) { ycbcr(px[i].c, src_y[i]); ycbcr(decoded[i].c, dec_y[i]); }
+    texels_ycc src, dec;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (int i = 0; i < 16; i++) {
+        src.t[i] = to_ycc(px[i].c[0], px[i].c[1], px[i].c[2]);
+        dec.t[i] = to_ycc(decoded[i].c[0], decoded[i].c[1], decoded[i].c[2]);
+    }
     uint32_t first_flip = 0, last_flip = 2, last_individ = 2;
     if (e.flags & FLAG_ETC1_NO_FLIP_INDIVIDUAL) { last_flip = 1; last_individ = 1; }
     else if (flip_estimate) { if (etc1_estimate_flipped(decoded)) first_flip = 1; last_flip = first_flip + 1; }
-
-    for (uint32_t flip = first_flip; flip < last_flip; flip++)
-        for (uint32_t individ = 0; individ < last_individ; individ++) {
-            const uint32_t mul = individ ? 15 : 31;
-            uint32_t unbiased[2][3];
-            int mn[2][3], mx[2][3];
-            uint8_t texel[2][8];  // raster index of the 8 texels of each sub-block
-            for (uint32_t sub = 0; sub < 2; sub++) {
-                uint32_t acc[3] = { 0, 0, 0 };
-                for (uint32_t c = 0; c < 3; c++) { mn[sub][c] = 255; mx[sub][c] = 0; }
-                for (uint32_t j = 0; j < 8; j++) {
-                    // g_etc1_pixel_coords (etc.cpp:314-337): unflipped = left/right halves scanned column-major, flipped = top/bottom halves row-major
-                    const uint32_t x = flip ? (j & 3) : (sub * 2 + (j >> 2)), y = flip ? (sub * 2 + (j >> 2)) : (j & 3);
-                    texel[sub][j] = (uint8_t)(x + y * 4);
-                    for (uint32_t c = 0; c < 3; c++) {
-                        const int v = decoded[x + y * 4].c[c];
-                        acc[c] += (uint32_t)v;
-                        mn[sub][c] = v < mn[sub][c] ? v : mn[sub][c];
-                        mx[sub][c] = v > mx[sub][c] ? v : mx[sub][c];
-                    }
-                }
-                for (uint32_t c = 0; c < 3; c++) unbiased[sub][c] = (acc[c] * mul + 1020) / (8 * 255);
-            }
-            for (uint32_t bi = 0; bi < last_bias; bi++) {
-                const uint32_t bias = sorted_table ? sorted_bias[bi] : bi;
-                int base[2][3];
-                {
-                    uint32_t col[2][3];
-                    for (uint32_t sub = 0; sub < 2; sub++)
-                        for (uint32_t c = 0; c < 3; c++) col[sub][c] = has_bias ? etc1_bias_apply(unbiased[sub][c], c, bias, mul, sub) : unbiased[sub][c];
-                    for (uint32_t c = 0; c < 3; c++) {
-                        if (individ) {
-                            base[0][c] = (int)((col[0][c] << 4) | col[0][c]);
-                            base[1][c] = (int)((col[1][c] << 4) | col[1][c]);
-                        } else {
-                            const int d = clampi((int)col[1][c] - (int)col[0][c], -4, 3);
-                            const uint32_t c1 = (uint32_t)((int)col[0][c] + d);
-                            base[0][c] = (int)((col[0][c] << 3) | (col[0][c] >> 2));
-                            base[1][c] = (int)((c1 << 3) | (c1 >> 2));
-                        }
-                    }
-                }
-                uint32_t inten[2] = { 0, 0 };
-                for (uint32_t sub = 0; sub < 2; sub++) {
-                    int range = 0;
-                    for (uint32_t c = 0; c < 3; c++) {
-                        const int pos = mx[sub][c] - base[sub][c], neg = base[sub][c] - mn[sub][c];
-                        const int ap = pos < 0 ? -pos : pos, an = neg < 0 ? -neg : neg;
-                        range = ap > range ? ap : range;
-                        range = an > range ? an : range;
-                    }
-                    const uint32_t limit = e.level == 4 ? 8 : (range > 51 ? 8 : (range >= 7 ? 4 : 2));
-                    uint64_t best_sub = UINT64_MAX;
-                    for (uint32_t table = 0; table < limit; table++) {
-                        int ty[4][3];
-                        for (uint32_t k = 0; k < 4; k++) {
-                            uint8_t col[3];
-                            for (uint32_t c = 0; c < 3; c++) col[c] = (uint8_t)clampi(base[sub][c] + ku_etc1_inten[table * 4 + k], 0, 255);
-                            ycbcr(col, ty[k]);
-                        }
-                        uint64_t total = 0;
-                        // the reference abandons a table after each row of 4 texels (flipped) or after all 8 (unflipped)
-                        for (uint32_t j = 0; j < 8; j++) {
-                            // texel order inside a sub-block does not change the sum; only the early-out granularity matters
-                            const uint32_t t = flip ? (uint32_t)(sub * 8 + j) : (uint32_t)((j >> 1) * 4 + sub * 2 + (j & 1));
-                            const int* c = dec_y[t];
-                            uint64_t m = ycbcr_diff(ty[0], c);
-                            for (uint32_t k = 1; k < 4; k++) { const uint64_t d = ycbcr_diff(ty[k], c); m = d < m ? d : m; }
-                            total += m;
-                            if (flip && (j & 3) == 3 && total >= best_sub) break;
-                        }
-                        if (!flip && total >= best_sub) break;
-                        if (total < best_sub) { best_sub = total; inten[sub] = table; }
-                    }
-                }
-                uint64_t err = 0;
-                for (uint32_t sub = 0; sub < 2; sub++) {
-                    int ty[4][3];
-                    for (uint32_t k = 0; k < 4; k++) {
-                        uint8_t col[3];
-                        for (uint32_t c = 0; c < 3; c++) col[c] = (uint8_t)clampi(base[sub][c] + ku_etc1_inten[inten[sub] * 4 + k], 0, 255);
-                        ycbcr(col, ty[k]);
-                    }
-                    // rows of 4 (flipped) or 2 (unflipped) texels, with the reference's per-row early out
-                    const uint32_t rows = flip ? 2 : 4, per_row = flip ? 4 : 2;
-                    for (uint32_t row = 0; row < rows; row++) {
-                        for (uint32_t k2 = 0; k2 < per_row; k2++) {
-                            const uint32_t t = flip ? ((sub * 2 + row) * 4 + k2) : (row * 4 + sub * 2 + k2);
-                            const int* c = dec_y[t];
-                            uint64_t m = ycbcr_diff(ty[0], c) << 2;
-                            for (uint32_t k = 1; k < 4; k++) { const uint64_t d = (ycbcr_diff(ty[k], c) << 2) + k; m = d < m ? d : m; }
-                            err += ycbcr_diff(src_y[t], ty[m & 3]);
-                        }
-                        if (err >= best_err) break;
-                    }
-                }
-                if (err < best_err) {
-                    best_err = err;
-                    best.flip = (uint8_t)flip; best.diff = (uint8_t)(individ == 0); best.inten0 = (uint8_t)inten[0]; best.inten1 = (uint8_t)inten[1]; best.bias = (uint8_t)bias;
-                }
-            }
-            (void)texel;
-        }
+    etc1_search s;
+    s.best_err = UINT64_MAX;
+    s.best.flip = s.best.diff = s.best.inten0 = s.best.inten1 = s.best.bias = 0;
+    if (first_flip == 0) etc1_trials<0>(mode, decoded, dec, src, e, last_individ, last_bias, sorted_table, s);
+    if (last_flip == 2 || first_flip == 1) etc1_trials<1>(mode, decoded, dec, src, e, last_individ, last_bias, sorted_table, s);
+    best = s.best;
 }
 
 // pack_etc1_block_solid_color (etc.cpp:181-257): diff, intensity table, selector and the packed base colour for a solid block
