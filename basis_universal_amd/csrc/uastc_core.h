@@ -38,6 +38,15 @@ namespace bu_uastc {
 
 struct rgba8 { uint8_t c[4]; };
 
+// 24-bit multiplies: every product below has operands far inside +-2^23, and the 24-bit multiplier is full rate where the 32-bit
+// one (v_mul_lo_u32) is quarter rate. On the host they are ordinary multiplies.
+#if defined(__HIPCC__)
+BU_FN int imul24(int a, int b) { return __mul24(a, b); }
+BU_FN uint32_t umul24(uint32_t a, uint32_t b) { return __umul24(a, b); }
+#else
+BU_FN int imul24(int a, int b) { return a * b; }
+BU_FN uint32_t umul24(uint32_t a, uint32_t b) { return a * b; }
+#endif
 BU_FN_HD int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 BU_FN float saturatef(float v) { return v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v); }
 BU_FN uint32_t astc_levels(uint32_t range) { return (1u + 2u * ku_bise[range * 3 + 1] + 4u * ku_bise[range * 3 + 2]) << ku_bise[range * 3]; }
@@ -45,13 +54,32 @@ BU_FN uint32_t astc_levels(uint32_t range) { return (1u + 2u * ku_bise[range * 3
 BU_FN uint32_t astc_lerp(uint32_t l, uint32_t h, uint32_t w) {
     l = (l << 8) | l;
     h = (h << 8) | h;
-    return ((l * (64 - w) + h * w + 32) >> 6) >> 8;
+    return ((umul24(l, 64 - w) + umul24(h, w) + 32) >> 6) >> 8;
 }
 BU_FN const uint8_t* weight_set(uint32_t bits) { return ku_weights + ((1u << bits) - 2u); }
 
 // ------------------------------------------------------------------------------------------------------------------
-// Colour-cell fit: color_cell_compression(mode = 255, ASTC range, weights 1/1/1/1, perceptual off)
+// Colour-cell fit: color_cell_compression(mode = 255, ASTC range, weights 1/1/1/1, perceptual off), bc7enc.cpp:1364-1762
+//
+// Register-resident formulation. A cell is "the texels of a 4x4 block selected by a 16-bit mask": the texels are 16 packed
+// RGBA dwords, every loop over them is fully unrolled and predicated on the mask, selectors are kept at their raster position
+// (byte-packed, 4 dwords) -- so nothing is gathered, nothing is dynamically indexed and a GPU lane needs no scratch memory.
+// Skipping non-members does not change the order in which the members are visited, which is all the reference's running float
+// sums depend on. The interpolated colours of a selector are computed (astc_lerp of the weight formula) instead of tabulated.
 // ------------------------------------------------------------------------------------------------------------------
+
+#if defined(__HIPCC__)
+#define BU_UNROLL _Pragma("unroll")
+#else
+#define BU_UNROLL
+#endif
+
+// Interpolation weight of selector s for `bits` weight bits, computed instead of looked up: ASTC weight unquantisation (replicate
+// to 6 bits, +1 above 32) reproduces ku_weights for every set UASTC uses (tests/test_uastc_core_host.py checks it against the table).
+BU_FN uint32_t weight_of(uint32_t bits, uint32_t s) {
+    uint32_t w = bits == 1 ? s * 63 : (bits == 2 ? s * 21 : (bits == 3 ? s * 9 : (bits == 4 ? (s << 2) | (s >> 2) : (s << 1) | (s >> 4))));
+    return w + (w > 32 ? 1u : 0u);
+}
 
 struct cell_cfg {
     uint8_t wbits;      // 1..5 weight bits -> 2..32 interpolants
@@ -59,160 +87,152 @@ struct cell_cfg {
     uint8_t alpha;      // fit 4 channels
     uint8_t uber;       // bc7enc_compress_block_params::m_uber_level
     uint8_t ls_passes;  // m_least_squares_passes
-    const uint8_t* force_sel;  // m_pForce_selectors (NULL normally)
 };
+
+struct sel16 { uint32_t w[4]; };  // 16 selectors, one byte each, texel i in byte i
+BU_FN uint32_t sel_get(const sel16& s, int i) { return (s.w[i >> 2] >> (8 * (i & 3))) & 255u; }
+BU_FN void sel_set(sel16& s, int i, uint32_t v) { const int sh = 8 * (i & 3); s.w[i >> 2] = (s.w[i >> 2] & ~(255u << sh)) | (v << sh); }
 
 struct cell_fit {
     uint64_t err;
     uint8_t lo[4], hi[4];            // endpoint RANKS (position in ascending unquantised order)
     uint8_t astc_lo[4], astc_hi[4];  // the same endpoints as ASTC endpoint indices
-    uint8_t sel[16];
+    sel16 sel;                       // selectors at raster positions (members only)
 };
 
 BU_FN uint32_t dist_rgb(const uint8_t* a, const uint8_t* b) {
     const int dr = (int)a[0] - (int)b[0], dg = (int)a[1] - (int)b[1], db = (int)a[2] - (int)b[2];
-    return (uint32_t)(dr * dr) + (uint32_t)(dg * dg) + (uint32_t)(db * db);
+    return (uint32_t)imul24(dr, dr) + (uint32_t)imul24(dg, dg) + (uint32_t)imul24(db, db);
 }
-BU_FN uint32_t dist_rgba(const uint8_t* a, const uint8_t* b) {
-    const int da = (int)a[3] - (int)b[3];
-    return dist_rgb(a, b) + (uint32_t)(da * da);
-}
+BU_FN int px_comp(uint32_t p, int c) { return (int)((p >> (8 * c)) & 255u); }
+BU_FN uint32_t pack_px(const uint8_t* c) { return (uint32_t)c[0] | ((uint32_t)c[1] << 8) | ((uint32_t)c[2] << 16) | ((uint32_t)c[3] << 24); }
 
-// evaluate_solution (bc7enc.cpp:822-1049), ASTC branch with the non-perceptual selector search
-BU_FN uint64_t cell_eval(const rgba8* px, uint32_t n, const cell_cfg& cfg, const uint8_t* lo, const uint8_t* hi, cell_fit& best) {
+// evaluate_solution (bc7enc.cpp:822-1049), ASTC branch with the non-perceptual selector search.
+// Interpolants are not tabulated: astc_lerp(L, H, w) = (64 * L257 + 32 + (H257 - L257) * w) >> 14 with X257 = X * 257, one multiply-add
+// per channel, and the weight of a selector comes from the set's (multiplier, shift) pair -- see weight_of.
+BU_FN uint64_t cell_eval(const uint32_t* px, uint32_t mask, const cell_cfg& cfg, const uint8_t* lo, const uint8_t* hi, cell_fit& best) {
     const uint32_t N = 1u << cfg.wbits;
-    const uint8_t* W = weight_set(cfg.wbits);
     const uint8_t* SU = ku_sorted_unquant + cfg.range * 256;
-    const uint32_t nc = cfg.alpha ? 4 : 3;
-    uint8_t wc[32][4];
-    for (uint32_t c = 0; c < 4; c++) {
-        wc[0][c] = SU[lo[c]];
-        wc[N - 1][c] = SU[hi[c]];
+    const int nc = cfg.alpha ? 4 : 3;
+    int L[4], base[4], slope[4];
+    for (int c = 0; c < 4; c++) {
+        L[c] = SU[lo[c]];
+        const int h = SU[hi[c]];
+        base[c] = L[c] * 257 * 64 + 32;
+        slope[c] = (h - L[c]) * 257;
     }
-    for (uint32_t i = 1; i + 1 < N; i++) {
-        for (uint32_t c = 0; c < nc; c++) wc[i][c] = (uint8_t)astc_lerp(wc[0][c], wc[N - 1][c], W[i]);
-        if (nc == 3) wc[i][3] = 0;
-    }
-    const int lr = wc[0][0], lg = wc[0][1], lb = wc[0][2], la = wc[0][3];
-    const int dr = wc[N - 1][0] - lr, dg = wc[N - 1][1] - lg, db = wc[N - 1][2] - lb, da = cfg.alpha ? (wc[N - 1][3] - la) : 0;
-
-    uint64_t total = 0;
-    uint8_t tmp[16];
-    if (cfg.force_sel) {
-        for (uint32_t i = 0; i < n; i++) {
-            const uint8_t s = cfg.force_sel[i];
-            total += cfg.alpha ? dist_rgba(wc[s], px[i].c) : dist_rgb(wc[s], px[i].c);
-            tmp[i] = s;
+    const int dr = slope[0] / 257, dg = slope[1] / 257, db = slope[2] / 257, da = cfg.alpha ? slope[3] / 257 : 0;
+    const float f = (float)N / ((float)(imul24(dr, dr) + imul24(dg, dg) + imul24(db, db) + imul24(da, da)) + .00000125f);
+    // weight(s) = s * wmul + (s >> wshift), +1 above 32: {63, 21, 9} x s for 1..3 bits, bit replication for 4 and 5 bits
+    const uint32_t wmul = cfg.wbits == 1 ? 63u : (cfg.wbits == 2 ? 21u : (cfg.wbits == 3 ? 9u : (cfg.wbits == 4 ? 4u : 2u)));
+    const uint32_t wshift = cfg.wbits == 4 ? 2u : (cfg.wbits == 5 ? 4u : 31u);
+    uint32_t total = 0;  // <= 16 * 4 * 255^2
+    sel16 tmp = { { 0, 0, 0, 0 } };
+    BU_UNROLL
+    for (int i = 0; i < 16; i++) {
+        if (!((mask >> i) & 1)) continue;
+        const uint32_t p = px[i];
+        int proj = imul24(px_comp(p, 0) - L[0], dr) + imul24(px_comp(p, 1) - L[1], dg) + imul24(px_comp(p, 2) - L[2], db);
+        if (cfg.alpha) proj += imul24(px_comp(p, 3) - L[3], da);
+        int s = (int)((float)proj * f + .5f);
+        s = clampi(s, 1, (int)N - 1);
+        uint32_t w1 = umul24((uint32_t)s, wmul) + ((uint32_t)s >> wshift), w0 = umul24((uint32_t)s - 1, wmul) + (((uint32_t)s - 1) >> wshift);
+        w1 += (w1 + 31) >> 6;
+        w0 += (w0 + 31) >> 6;
+        uint32_t e0 = 0, e1 = 0;
+        for (int c = 0; c < nc; c++) {
+            const int v = px_comp(p, c);
+            const int d0 = ((base[c] + imul24(slope[c], (int)w0)) >> 14) - v, d1 = ((base[c] + imul24(slope[c], (int)w1)) >> 14) - v;
+            e0 += (uint32_t)imul24(d0, d0); e1 += (uint32_t)imul24(d1, d1);
         }
-    } else {
-        const float f = (float)N / ((float)(dr * dr + dg * dg + db * db + da * da) + .00000125f);
-        for (uint32_t i = 0; i < n; i++) {
-            const uint8_t* p = px[i].c;
-            int proj = ((int)p[0] - lr) * dr + ((int)p[1] - lg) * dg + ((int)p[2] - lb) * db;
-            if (cfg.alpha) proj += ((int)p[3] - la) * da;
-            int s = (int)((float)proj * f + .5f);
-            s = clampi(s, 1, (int)N - 1);
-            const uint32_t e0 = cfg.alpha ? dist_rgba(wc[s - 1], p) : dist_rgb(wc[s - 1], p);
-            uint32_t e1 = cfg.alpha ? dist_rgba(wc[s], p) : dist_rgb(wc[s], p);
-            if (e0 == e1) {
-                if (s == 1) s = 0;  // prefer the non-interpolated endpoint
-            } else if (e0 < e1) {
-                e1 = e0;
-                --s;
-            }
-            total += e1;
-            tmp[i] = (uint8_t)s;
+        if (e0 == e1) {
+            if (s == 1) s = 0;  // prefer the non-interpolated endpoint
+        } else if (e0 < e1) {
+            e1 = e0;
+            --s;
         }
+        total += e1;
+        sel_set(tmp, i, (uint32_t)s);
     }
     if (total < best.err) {
         best.err = total;
-        for (uint32_t c = 0; c < 4; c++) { best.lo[c] = lo[c]; best.hi[c] = hi[c]; }
-        for (uint32_t i = 0; i < n; i++) best.sel[i] = tmp[i];
+        for (int c = 0; c < 4; c++) { best.lo[c] = lo[c]; best.hi[c] = hi[c]; }
+        best.sel = tmp;
     }
     return total;
 }
 
 // find_optimal_solution (bc7enc.cpp:1103-1282), ASTC branch, mode 255 degeneracy handling (:1051-1101)
-BU_FN uint64_t cell_try(const rgba8* px, uint32_t n, const cell_cfg& cfg, const float* xl_in, const float* xh_in, cell_fit& best) {
+BU_FN uint64_t cell_try(const uint32_t* px, uint32_t mask, const cell_cfg& cfg, const float* xl_in, const float* xh_in, cell_fit& best) {
     float xl[4], xh[4];
-    for (uint32_t c = 0; c < 4; c++) { xl[c] = saturatef(xl_in[c]); xh[c] = saturatef(xh_in[c]); }
+    for (int c = 0; c < 4; c++) { xl[c] = saturatef(xl_in[c]); xh[c] = saturatef(xh_in[c]); }
     const int top = (int)astc_levels(cfg.range) - 1;
     const uint8_t* NEAR = ku_nearest_rank + cfg.range * 256;
     uint8_t tmin[4], tmax[4];
-    for (uint32_t c = 0; c < 4; c++) {
+    for (int c = 0; c < 4; c++) {
         tmin[c] = NEAR[clampi((int)(xl[c] * 255.0f + .5f), 0, 255)];
         tmax[c] = NEAR[clampi((int)(xh[c] * 255.0f + .5f), 0, 255)];
     }
     bool degenerate = false;
-    for (uint32_t c = 0; c < 3; c++)
+    for (int c = 0; c < 3; c++)
         if (tmin[c] == tmax[c] && fabsf(xl[c] - xh[c]) > 0.0f) degenerate = true;
-
-    const uint32_t order[4] = { 1, 0, 2, 3 };
     const uint32_t trials = degenerate ? 4 : 1;
     for (uint32_t t = 0; t < trials; t++) {
         uint8_t a[4], b[4];
-        for (uint32_t c = 0; c < 4; c++) { a[c] = tmin[c]; b[c] = tmax[c]; }
+        for (int c = 0; c < 4; c++) { a[c] = tmin[c]; b[c] = tmax[c]; }
         if (degenerate) {
-            const uint32_t flags = order[t];
-            for (uint32_t c = 0; c < 3; c++)
+            const uint32_t flags = t == 0 ? 1u : (t == 1 ? 0u : t);  // the reference tries 1, 0, 2, 3
+            for (int c = 0; c < 3; c++)
                 if (a[c] == b[c] && fabsf(xl[c] - xh[c]) > 0.000125f) {
                     if ((flags & 1) && a[c] > 0) a[c]--;
                     if ((flags & 2) && (int)b[c] < top) b[c]++;
                 }
         }
         bool differs = best.err == UINT64_MAX;
-        for (uint32_t c = 0; c < 4; c++) differs = differs || a[c] != best.lo[c] || b[c] != best.hi[c];
-        if (differs) cell_eval(px, n, cfg, a, b, best);
+        for (int c = 0; c < 4; c++) differs = differs || a[c] != best.lo[c] || b[c] != best.hi[c];
+        if (differs) cell_eval(px, mask, cfg, a, b, best);
     }
     const uint8_t* SI = ku_sorted_index + cfg.range * 256;
-    for (uint32_t c = 0; c < 4; c++) { best.astc_lo[c] = SI[best.lo[c]]; best.astc_hi[c] = SI[best.hi[c]]; }
+    for (int c = 0; c < 4; c++) { best.astc_lo[c] = SI[best.lo[c]]; best.astc_hi[c] = SI[best.hi[c]]; }
     return best.err;
 }
 
-// compute_least_squares_endpoints_rgb / _rgba (bc7enc.cpp:394-518). Double accumulators of float products, as there.
-BU_FN void cell_least_squares(const rgba8* px, uint32_t n, const uint8_t* sel, const cell_cfg& cfg, float* xl, float* xh) {
+// compute_least_squares_endpoints_rgb / _rgba (bc7enc.cpp:394-518) followed by the 1/255 scaling of its callers
+BU_FN void cell_least_squares(const uint32_t* px, uint32_t mask, const sel16& sel, const cell_cfg& cfg, float* xl, float* xh) {
     const float* WX = ku_weights_ls + ((1u << cfg.wbits) - 2u) * 4;
-    const uint32_t nc = cfg.alpha ? 4 : 3;
+    const int nc = cfg.alpha ? 4 : 3;
     double z00 = 0.0, z10 = 0.0, z11 = 0.0;
     double q00[4] = { 0, 0, 0, 0 }, t[4] = { 0, 0, 0, 0 };
-    for (uint32_t i = 0; i < n; i++) {
-        const float* w4 = WX + sel[i] * 4;
+    int lo_v[4] = { 255, 255, 255, 255 }, hi_v[4] = { 0, 0, 0, 0 };
+    BU_UNROLL
+    for (int i = 0; i < 16; i++) {
+        if (!((mask >> i) & 1)) continue;
+        const float* w4 = WX + sel_get(sel, i) * 4;
         z00 += w4[0];
         z10 += w4[1];
         z11 += w4[2];
         const float w = w4[3];
-        for (uint32_t c = 0; c < nc; c++) {
-            q00[c] += w * px[i].c[c];
-            t[c] += px[i].c[c];
+        for (int c = 0; c < nc; c++) {
+            const int v = px_comp(px[i], c);
+            q00[c] += w * (float)v;
+            t[c] += (double)v;
+            lo_v[c] = v < lo_v[c] ? v : lo_v[c];
+            hi_v[c] = v > hi_v[c] ? v : hi_v[c];
         }
     }
     const double z01 = z10;
     double det = z00 * z11 - z01 * z10;
     if (det != 0.0) det = 1.0 / det;
     const double iz00 = z11 * det, iz01 = -z01 * det, iz10 = -z10 * det, iz11 = z00 * det;
-    for (uint32_t c = 0; c < nc; c++) {
+    for (int c = 0; c < nc; c++) {
         const double q10 = t[c] - q00[c];
         xl[c] = (float)(iz00 * q00[c] + iz01 * q10);
         xh[c] = (float)(iz10 * q00[c] + iz11 * q10);
     }
     if (nc == 3) { xl[3] = 255.0f; xh[3] = 255.0f; }
-    for (uint32_t c = 0; c < nc; c++)
-        if (xl[c] < 0.0f || xh[c] > 255.0f) {
-            uint32_t lo_v = 255, hi_v = 0;
-            for (uint32_t i = 0; i < n; i++) {
-                const uint32_t v = px[i].c[c];
-                lo_v = v < lo_v ? v : lo_v;
-                hi_v = v > hi_v ? v : hi_v;
-            }
-            if (lo_v == hi_v) { xl[c] = (float)lo_v; xh[c] = (float)hi_v; }
-        }
-}
-
-BU_FN bool cell_refit(const rgba8* px, uint32_t n, const uint8_t* sel, const cell_cfg& cfg, cell_fit& best) {
-    float xl[4], xh[4];
-    cell_least_squares(px, n, sel, cfg, xl, xh);
-    for (uint32_t c = 0; c < 4; c++) { xl[c] = xl[c] * (1.0f / 255.0f); xh[c] = xh[c] * (1.0f / 255.0f); }
-    return cell_try(px, n, cfg, xl, xh, best) != 0;
+    for (int c = 0; c < nc; c++)
+        if ((xl[c] < 0.0f || xh[c] > 255.0f) && lo_v[c] == hi_v[c]) { xl[c] = (float)lo_v[c]; xh[c] = (float)hi_v[c]; }
+    for (int c = 0; c < 4; c++) { xl[c] = xl[c] * (1.0f / 255.0f); xh[c] = xh[c] * (1.0f / 255.0f); }
 }
 
 // The optimal single-colour encodings (bc7enc.cpp:605-820); which one applies is a function of (range, weights, alpha).
@@ -226,12 +246,12 @@ BU_FN bool one_colour_lookup(const cell_cfg& cfg, one_colour_kind& k) {
     if (cfg.range == 11 && N == 32 && !cfg.alpha) { k.table = ku_opt_r11_5bit; k.widx = 13; k.alpha_rank = 31; k.rgba = 0; return true; }
     return false;
 }
-BU_FN uint64_t one_colour_fit(const rgba8* px, uint32_t n, const cell_cfg& cfg, const one_colour_kind& k, const uint32_t* col, cell_fit& out) {
+BU_FN uint64_t one_colour_fit(const uint32_t* px, uint32_t mask, const cell_cfg& cfg, const one_colour_kind& k, const uint32_t* col, cell_fit& out) {
     const uint8_t* SU = ku_sorted_unquant + cfg.range * 256;
     const uint8_t* SI = ku_sorted_index + cfg.range * 256;
-    const uint32_t w = weight_set(cfg.wbits)[k.widx];
-    uint8_t p[4] = { 0, 0, 0, 255 };
-    for (uint32_t c = 0; c < 4; c++) {
+    const uint32_t w = weight_of(cfg.wbits, k.widx);
+    int p[4] = { 0, 0, 0, 255 };
+    for (int c = 0; c < 4; c++) {
         if (c < 3 || k.rgba) {
             out.lo[c] = k.table[col[c] * 2];
             out.hi[c] = k.table[col[c] * 2 + 1];
@@ -241,41 +261,50 @@ BU_FN uint64_t one_colour_fit(const rgba8* px, uint32_t n, const cell_cfg& cfg, 
         }
         out.astc_lo[c] = SI[out.lo[c]];
         out.astc_hi[c] = SI[out.hi[c]];
-        if (c < 3 || k.rgba) p[c] = (uint8_t)astc_lerp(SU[out.lo[c]], SU[out.hi[c]], w);
+        if (c < 3 || k.rgba) p[c] = (int)astc_lerp(SU[out.lo[c]], SU[out.hi[c]], w);
     }
-    uint64_t total = 0;
-    for (uint32_t i = 0; i < n; i++) {
-        out.sel[i] = k.widx;
-        total += k.rgba ? dist_rgba(p, px[i].c) : dist_rgb(p, px[i].c);
+    uint32_t total = 0;
+    out.sel.w[0] = out.sel.w[1] = out.sel.w[2] = out.sel.w[3] = 0;
+    BU_UNROLL
+    for (int i = 0; i < 16; i++) {
+        if (!((mask >> i) & 1)) continue;
+        sel_set(out.sel, i, k.widx);
+        for (int c = 0; c < (k.rgba ? 4 : 3); c++) { const int d = p[c] - px_comp(px[i], c); total += (uint32_t)imul24(d, d); }
     }
     out.err = total;
     return total;
 }
 
-// color_cell_compression (bc7enc.cpp:1364-1762)
-BU_FN_BIG uint64_t cell_compress(const rgba8* px, uint32_t n, const cell_cfg& cfg, cell_fit& best) {
+// color_cell_compression (bc7enc.cpp:1364-1762). The endpoint proposals (principal axis, least squares on the current selectors,
+// the selector perturbations of the uber levels) are generated by one loop so that cell_try -- and with it the unrolled
+// cell_eval -- is instantiated once.
+BU_FN_BIG uint64_t cell_compress(const uint32_t* px, uint32_t mask, const cell_cfg& cfg, cell_fit& best) {
     best.err = UINT64_MAX;
+    best.sel.w[0] = best.sel.w[1] = best.sel.w[2] = best.sel.w[3] = 0;
+    const uint32_t n = (uint32_t)__builtin_popcount(mask);
     one_colour_kind kind;
-    const bool has_kind = !cfg.force_sel && one_colour_lookup(cfg, kind);
+    const bool has_kind = one_colour_lookup(cfg, kind);
 
-    if (has_kind) {
-        bool same = true;
-        for (uint32_t i = 1; i < n; i++)
-            for (uint32_t c = 0; c < (kind.rgba ? 4u : 3u); c++) same = same && px[i].c[c] == px[0].c[c];
-        if (same) {
-            const uint32_t col[4] = { px[0].c[0], px[0].c[1], px[0].c[2], px[0].c[3] };
-            return one_colour_fit(px, n, cfg, kind, col, best);
-        }
-    }
-
-    // mean and principal axis
+    // sums, "all texels equal", mean
     float sum[4] = { 0, 0, 0, 0 };
-    for (uint32_t i = 0; i < n; i++)
-        for (uint32_t c = 0; c < 4; c++) sum[c] = sum[c] + (float)px[i].c[c];
+    uint32_t first = 0;
+    bool have_first = false, same = true;
+    const uint32_t cmp_mask = (has_kind && kind.rgba) ? 0xFFFFFFFFu : 0x00FFFFFFu;
+    BU_UNROLL
+    for (int i = 0; i < 16; i++) {
+        if (!((mask >> i) & 1)) continue;
+        for (int c = 0; c < 4; c++) sum[c] = sum[c] + (float)px_comp(px[i], c);
+        if (!have_first) { first = px[i]; have_first = true; }
+        else same = same && (((px[i] ^ first) & cmp_mask) == 0);
+    }
+    if (has_kind && same) {
+        const uint32_t col[4] = { first & 255u, (first >> 8) & 255u, (first >> 16) & 255u, first >> 24 };
+        return one_colour_fit(px, mask, cfg, kind, col, best);
+    }
     const float inv_n = 1.0f / (float)n;
     const float inv_n255 = 1.0f / ((float)n * 255.0f);
     float mean_s[4], mean[4];
-    for (uint32_t c = 0; c < 4; c++) {
+    for (int c = 0; c < 4; c++) {
         mean_s[c] = sum[c] * inv_n;
         mean[c] = saturatef(sum[c] * inv_n255);
     }
@@ -284,17 +313,21 @@ BU_FN_BIG uint64_t cell_compress(const rgba8* px, uint32_t n, const cell_cfg& cf
     if (cfg.alpha) {
         // incremental 4-D PCA (bc7enc.cpp:1428-1448)
         axis[0] = axis[1] = axis[2] = axis[3] = 0.0f;
-        for (uint32_t i = 0; i < n; i++) {
+        bool started = false;
+        BU_UNROLL
+        for (int i = 0; i < 16; i++) {
+            if (!((mask >> i) & 1)) continue;
             float col[4];
-            for (uint32_t c = 0; c < 4; c++) col[c] = (float)px[i].c[c] - mean_s[c];
+            for (int c = 0; c < 4; c++) col[c] = (float)px_comp(px[i], c) - mean_s[c];
             float v[4];
-            for (uint32_t c = 0; c < 4; c++) v[c] = i ? axis[c] : col[c];
+            for (int c = 0; c < 4; c++) v[c] = started ? axis[c] : col[c];
+            started = true;
             float s = v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
             if (s != 0.0f) {
                 s = 1.0f / sqrtf(s);
                 v[0] *= s; v[1] *= s; v[2] *= s; v[3] *= s;
             }
-            for (uint32_t c = 0; c < 4; c++) {
+            for (int c = 0; c < 4; c++) {
                 const float k = col[c];
                 axis[c] += (col[0] * k) * v[0] + (col[1] * k) * v[1] + (col[2] * k) * v[2] + (col[3] * k) * v[3];
             }
@@ -307,10 +340,12 @@ BU_FN_BIG uint64_t cell_compress(const rgba8* px, uint32_t n, const cell_cfg& cf
     } else {
         // covariance + 3 power iterations (bc7enc.cpp:1450-1489)
         float cov[6] = { 0, 0, 0, 0, 0, 0 };
-        for (uint32_t i = 0; i < n; i++) {
-            const float r = (float)px[i].c[0] - mean_s[0];
-            const float g = (float)px[i].c[1] - mean_s[1];
-            const float b = (float)px[i].c[2] - mean_s[2];
+        BU_UNROLL
+        for (int i = 0; i < 16; i++) {
+            if (!((mask >> i) & 1)) continue;
+            const float r = (float)px_comp(px[i], 0) - mean_s[0];
+            const float g = (float)px_comp(px[i], 1) - mean_s[1];
+            const float b = (float)px_comp(px[i], 2) - mean_s[2];
             cov[0] += r * r; cov[1] += r * g; cov[2] += r * b; cov[3] += g * g; cov[4] += g * b; cov[5] += b * b;
         }
         float xr = .9f, xg = 1.0f, xb = .7f;
@@ -343,106 +378,143 @@ BU_FN_BIG uint64_t cell_compress(const rgba8* px, uint32_t n, const cell_cfg& cf
     }
 
     float l = 1e+9f, h = -1e+9f;
-    for (uint32_t i = 0; i < n; i++) {
+    BU_UNROLL
+    for (int i = 0; i < 16; i++) {
+        if (!((mask >> i) & 1)) continue;
         float q[4];
-        for (uint32_t c = 0; c < 4; c++) q[c] = (float)px[i].c[c] - mean_s[c];
+        for (int c = 0; c < 4; c++) q[c] = (float)px_comp(px[i], c) - mean_s[c];
         const float d = q[0] * axis[0] + q[1] * axis[1] + q[2] * axis[2] + q[3] * axis[3];
         l = l < d ? l : d;
         h = h > d ? h : d;
     }
     l *= (1.0f / 255.0f);
     h *= (1.0f / 255.0f);
-    float cmin[4], cmax[4];
-    for (uint32_t c = 0; c < 4; c++) {
-        cmin[c] = saturatef(mean[c] + axis[c] * l);
-        cmax[c] = saturatef(mean[c] + axis[c] * h);
+    float xl[4], xh[4];
+    for (int c = 0; c < 4; c++) {
+        xl[c] = saturatef(mean[c] + axis[c] * l);
+        xh[c] = saturatef(mean[c] + axis[c] * h);
     }
-    if (cmin[0] * 1.0f + cmin[1] * 1.0f + cmin[2] * 1.0f + cmin[3] * 1.0f > cmax[0] * 1.0f + cmax[1] * 1.0f + cmax[2] * 1.0f + cmax[3] * 1.0f)
-        for (uint32_t c = 0; c < 4; c++) { const float t = cmin[c]; cmin[c] = cmax[c]; cmax[c] = t; }
+    if (xl[0] * 1.0f + xl[1] * 1.0f + xl[2] * 1.0f + xl[3] * 1.0f > xh[0] * 1.0f + xh[1] * 1.0f + xh[2] * 1.0f + xh[3] * 1.0f)
+        for (int c = 0; c < 4; c++) { const float t = xl[c]; xl[c] = xh[c]; xh[c] = t; }
 
-    if (!cell_try(px, n, cfg, cmin, cmax, best)) return 0;
-
-    for (uint32_t pass = 0; pass < cfg.ls_passes; pass++)
-        if (!cell_refit(px, n, best.sel, cfg, best)) return 0;
-
-    if (!cfg.force_sel && cfg.uber > 0) {
-        // selector perturbations (bc7enc.cpp:1567-1677)
-        uint8_t base[16], trial[16];
-        const uint32_t top = (1u << cfg.wbits) - 1;
-        uint32_t smin = 256, smax = 0;
-        for (uint32_t i = 0; i < n; i++) {
-            base[i] = best.sel[i];
-            smin = base[i] < smin ? base[i] : smin;
-            smax = base[i] > smax ? base[i] : smax;
-        }
-        for (uint32_t variant = 0; variant < 3; variant++) {
-            for (uint32_t i = 0; i < n; i++) {
-                uint32_t s = base[i];
-                if (variant != 1 && s == smin && s < top) s++;
-                else if (variant != 0 && s == smax && s > 0) s--;
-                trial[i] = (uint8_t)s;
-            }
-            if (!cell_refit(px, n, trial, cfg, best)) return 0;
-        }
-        const uint32_t thresh = (n * 56) >> 4;
-        if (cfg.uber >= 2 && best.err > thresh) {
-            const int Q = cfg.uber >= 4 ? (int)cfg.uber - 2 : 1;
-            for (int ly = -Q; ly <= 1; ly++)
-                for (int hy = (int)top - 1; hy <= (int)top + Q; hy++) {
-                    if (ly == 0 && hy == (int)top) continue;
-                    for (uint32_t i = 0; i < n; i++) {
-                        float v = floorf((float)top * ((float)base[i] - (float)ly) / ((float)hy - (float)ly) + .5f);
-                        v = v < 0.0f ? 0.0f : (v > (float)top ? (float)top : v);
-                        trial[i] = (uint8_t)v;
-                    }
-                    if (!cell_refit(px, n, trial, cfg, best)) return 0;
+    // proposal schedule: 0 = principal axis; 1..ls = least squares on the best selectors so far; then (uber > 0) three perturbations
+    // of the selectors as they stood after the least-squares passes (raise the minimum, lower the maximum, both; :1567-1642), then
+    // (uber >= 2 and still a poor fit) rescalings of that selector set (:1644-1677)
+    const uint32_t top = (1u << cfg.wbits) - 1;
+    const uint32_t n_basic = 1 + cfg.ls_passes + (cfg.uber > 0 ? 3u : 0u);
+    const int Q = cfg.uber >= 4 ? (int)cfg.uber - 2 : 1;
+    const uint32_t n_scaled = cfg.uber >= 2 ? (uint32_t)((Q + 2) * (Q + 2) - 1) : 0;  // (ly, hy) pairs without (0, top)
+    sel16 base = { { 0, 0, 0, 0 } };
+    uint32_t smin = 256, smax = 0;
+    for (uint32_t step = 0; step < n_basic + n_scaled; step++) {
+        if (step >= 1) {
+            sel16 trial = best.sel;
+            if (step == 1u + cfg.ls_passes) {  // freeze the selector set the perturbations start from
+                base = best.sel;
+                BU_UNROLL
+                for (int i = 0; i < 16; i++) {
+                    if (!((mask >> i) & 1)) continue;
+                    const uint32_t sv = sel_get(base, i);
+                    smin = sv < smin ? sv : smin;
+                    smax = sv > smax ? sv : smax;
                 }
+            }
+            if (step > cfg.ls_passes && step < n_basic) {
+                const uint32_t variant = step - 1 - cfg.ls_passes;
+                BU_UNROLL
+                for (int i = 0; i < 16; i++) {
+                    if (!((mask >> i) & 1)) continue;
+                    uint32_t sv = sel_get(base, i);
+                    if (variant != 1 && sv == smin && sv < top) sv++;
+                    else if (variant != 0 && sv == smax && sv > 0) sv--;
+                    sel_set(trial, i, sv);
+                }
+            } else if (step >= n_basic) {
+                if (step == n_basic && !(best.err > ((n * 56) >> 4))) break;
+                // enumerate ly in [-Q, 1], hy in [top-1, top+Q], skipping (0, top), in the reference's order
+                uint32_t k = step - n_basic;
+                const uint32_t skip = (uint32_t)(Q * (Q + 2) + 1);  // index of (0, top) in the full grid
+                if (k >= skip) k++;
+                const int ly = -Q + (int)(k / (uint32_t)(Q + 2)), hy = (int)top - 1 + (int)(k % (uint32_t)(Q + 2));
+                BU_UNROLL
+                for (int i = 0; i < 16; i++) {
+                    if (!((mask >> i) & 1)) continue;
+                    float v = floorf((float)top * ((float)sel_get(base, i) - (float)ly) / ((float)hy - (float)ly) + .5f);
+                    v = v < 0.0f ? 0.0f : (v > (float)top ? (float)top : v);
+                    sel_set(trial, i, (uint32_t)v);
+                }
+            }
+            cell_least_squares(px, mask, trial, cfg, xl, xh);
         }
+        if (!cell_try(px, mask, cfg, xl, xh, best)) return 0;
     }
 
     if (has_kind) {
         // the whole cell as its mean colour (bc7enc.cpp:1679-1755)
         uint32_t col[4];
-        for (uint32_t c = 0; c < 4; c++) col[c] = (uint32_t)(int)(.5f + mean[c] * 255.0f);
+        for (int c = 0; c < 4; c++) col[c] = (uint32_t)(int)(.5f + mean[c] * 255.0f);
         cell_fit avg;
-        if (one_colour_fit(px, n, cfg, kind, col, avg) < best.err) best = avg;
+        if (one_colour_fit(px, mask, cfg, kind, col, avg) < best.err) best = avg;
     }
     return best.err;
 }
 
-// color_cell_compression_est_astc (bc7enc.cpp:1764-1984) with unit channel weights: bounding-box endpoints, threshold selectors
-BU_FN uint64_t cell_estimate(uint32_t wbits, uint32_t comps, const rgba8* px, uint32_t n, uint64_t best_so_far) {
-    const uint32_t N = 1u << wbits;
-    const uint8_t* W = weight_set(wbits);
+// color_cell_compression_est_astc (bc7enc.cpp:1764-1984) with unit channel weights over the texels selected by `mask`: bounding-box
+// endpoints, threshold selectors. On the GPU the mask is wave-uniform when every lane ranks the same pattern, so the predicates cost
+// nothing. Thresholds are non-decreasing (the interpolants move monotonically from the box's low corner to its high corner), so
+// "last threshold not above d" is a count. The reference's early outs (:1880-1882 and its callers' loop conditions) only ever stop
+// once the running error exceeds the best total so far, which cannot change which pattern wins, so the full error is computed.
+template <int WBITS, int COMPS>
+BU_FN uint32_t estimate_masked(const uint32_t* px, uint32_t mask) {
+    constexpr int N = 1 << WBITS;
     int lo[4] = { 255, 255, 255, 255 }, hi[4] = { 0, 0, 0, 0 };
-    for (uint32_t i = 0; i < n; i++)
-        for (uint32_t c = 0; c < comps; c++) {
-            const int v = px[i].c[c];
-            lo[c] = v < lo[c] ? v : lo[c];
-            hi[c] = v > hi[c] ? v : hi[c];
+    BU_UNROLL
+    for (int i = 0; i < 16; i++)
+        if ((mask >> i) & 1) {
+            BU_UNROLL
+            for (int c = 0; c < COMPS; c++) {
+                const int v = px_comp(px[i], c);
+                lo[c] = v < lo[c] ? v : lo[c];
+                hi[c] = v > hi[c] ? v : hi[c];
+            }
         }
-    if (comps == 3) { lo[3] = 255; hi[3] = 255; }
-    uint8_t wc[32][4];
-    int dots[32];
-    const int ar = hi[0] - lo[0], ag = hi[1] - lo[1], ab = hi[2] - lo[2], aa = hi[3] - lo[3];
-    for (uint32_t i = 0; i < N; i++) {
-        for (uint32_t c = 0; c < 4; c++)
-            wc[i][c] = (uint8_t)(i == 0 ? lo[c] : (i == N - 1 ? hi[c] : ((c < 3 || comps == 4) ? (int)astc_lerp(lo[c], hi[c], W[i]) : 255)));
-        dots[i] = wc[i][0] * ar + wc[i][1] * ag + wc[i][2] * ab + (comps == 4 ? wc[i][3] * aa : 0);
+    int axis[4], col[N][4], thresh[N - 1];
+    for (int c = 0; c < COMPS; c++) axis[c] = hi[c] - lo[c];
+    int prev_dot = 0;
+    BU_UNROLL
+    for (int k = 0; k < N; k++) {
+        int dot = 0;
+        BU_UNROLL
+        for (int c = 0; c < COMPS; c++) {
+            col[k][c] = k == 0 ? lo[c] : (k == N - 1 ? hi[c] : (int)astc_lerp((uint32_t)lo[c], (uint32_t)hi[c], weight_of(WBITS, (uint32_t)k)));
+            dot += imul24(col[k][c], axis[c]);
+        }
+        if (k) thresh[k - 1] = (prev_dot + dot + 1) >> 1;
+        prev_dot = dot;
     }
-    uint64_t total = 0;
-    for (uint32_t i = 0; i < n; i++) {
-        const uint8_t* p = px[i].c;
-        const int d = ar * p[0] + ag * p[1] + ab * p[2] + (comps == 4 ? aa * p[3] : 0);
-        uint32_t s = 0;
-        for (int j = (int)N - 2; j >= 0; j--)
-            if (d >= ((dots[j] + dots[j + 1] + 1) >> 1)) { s = (uint32_t)j + 1; break; }
-        total += comps == 4 ? dist_rgba(wc[s], p) : dist_rgb(wc[s], p);
-        if (total > best_so_far) break;
-    }
+    uint32_t total = 0;
+    BU_UNROLL
+    for (int i = 0; i < 16; i++)
+        if ((mask >> i) & 1) {
+            int v[4], d = 0;
+            BU_UNROLL
+            for (int c = 0; c < COMPS; c++) { v[c] = px_comp(px[i], c); d += imul24(axis[c], v[c]); }
+            int pick[4];
+            for (int c = 0; c < COMPS; c++) pick[c] = col[0][c];
+            BU_UNROLL
+            for (int k = 1; k < N; k++) {
+                const bool at_least = d >= thresh[k - 1];
+                for (int c = 0; c < COMPS; c++) pick[c] = at_least ? col[k][c] : pick[c];
+            }
+            for (int c = 0; c < COMPS; c++) { const int e = pick[c] - v[c]; total += (uint32_t)imul24(e, e); }
+        }
     return total;
 }
 
+BU_FN uint32_t estimate_masked_any(uint32_t wbits, uint32_t comps, const uint32_t* px, uint32_t mask) {
+    if (wbits == 3) return estimate_masked<3, 3>(px, mask);  // mode 2
+    return comps == 4 ? estimate_masked<2, 4>(px, mask) : estimate_masked<2, 3>(px, mask);
+}
 
 // ------------------------------------------------------------------------------------------------------------------
 // Candidates. One `cand` is one uastc_encode_results (uastc_enc.h:74-81) in a fixed 64-byte slot.
@@ -510,7 +582,6 @@ BU_FN cell_cfg mode_cell_cfg(uint32_t mode, bool alpha, const enc_cfg& e) {
     c.alpha = alpha ? 1 : 0;
     c.uber = e.uber;
     c.ls_passes = e.ls_passes;
-    c.force_sel = nullptr;
     return c;
 }
 
@@ -534,44 +605,50 @@ BU_FN void cand_begin(cand& r, uint32_t mode, uint32_t pattern) {
     r.pad[0] = r.pad[1] = 0;
 }
 
-// luminance/alpha error of a cell fitted on (l,0,0,a) pixels, measured the way the LA modes do (uastc_enc.cpp:1708-1728, 2480-2494)
-BU_FN uint64_t la_cell_error(const rgba8* px, uint32_t n, const cell_fit& f, uint32_t mode) {
+// the block's texels as packed dwords; luminance-alpha modes fit (l, 0, 0, a) so both channels weigh the same (uastc_enc.cpp:1611-1617, 2437-2440)
+BU_FN void pack_block_px(const rgba8* px, bool la, uint32_t* out) {
+    BU_UNROLL
+    for (int i = 0; i < 16; i++) out[i] = la ? ((uint32_t)px[i].c[0] | ((uint32_t)px[i].c[3] << 24)) : pack_px(px[i].c);
+}
+
+// luminance/alpha error of a cell fitted on (l,0,0,a) texels, measured the way the LA modes do (uastc_enc.cpp:1708-1728, 2480-2494)
+BU_FN uint64_t la_cell_error(const uint32_t* px, uint32_t mask, const cell_fit& f, uint32_t mode) {
     const uint8_t* UQ = ku_unquant + ku_mode_endpoint_ranges[mode] * 256;
-    const uint8_t* W = weight_set(ku_mode_weight_bits[mode]);
+    const uint32_t wbits = ku_mode_weight_bits[mode];
     const uint32_t ll = UQ[f.astc_lo[0]], lh = UQ[f.astc_hi[0]], al = UQ[f.astc_lo[3]], ah = UQ[f.astc_hi[3]];
-    const uint32_t top = (1u << ku_mode_weight_bits[mode]) - 1;
-    uint64_t total = 0;
-    for (uint32_t i = 0; i < n; i++) {
-        const uint32_t s = f.sel[i];
-        const int l = (int)(s == 0 ? ll : (s == top ? lh : astc_lerp(ll, lh, W[s])));
-        const int a = (int)(s == 0 ? al : (s == top ? ah : astc_lerp(al, ah, W[s])));
-        const int dl = (int)px[i].c[0] - l, da = (int)px[i].c[3] - a;
-        total += (uint32_t)(dl * dl + da * da);
+    uint32_t total = 0;
+    BU_UNROLL
+    for (int i = 0; i < 16; i++) {
+        if (!((mask >> i) & 1)) continue;
+        const uint32_t w = weight_of(wbits, sel_get(f.sel, i));
+        const int dl = px_comp(px[i], 0) - (int)astc_lerp(ll, lh, w), da = px_comp(px[i], 3) - (int)astc_lerp(al, ah, w);
+        total += (uint32_t)(imul24(dl, dl) + imul24(da, da));
     }
     return total;
 }
 
 // modes 0, 1, 5, 18 (RGB), 10, 12, 14 (RGBA), 15 (LA): one subset, one plane
-BU_FN_BIG void build_single(uint32_t mode, const rgba8* px, const enc_cfg& e, cand& r) {
+BU_FN_BIG void build_single(uint32_t mode, const rgba8* px_in, const enc_cfg& e, cand& r) {
     cand_begin(r, mode, 0);
     const uint32_t comps = ku_mode_comps[mode];
     const uint32_t top = (1u << ku_mode_weight_bits[mode]) - 1;
+    uint32_t px[16];
+    pack_block_px(px_in, comps == 2, px);
+    const cell_cfg cc = mode_cell_cfg(mode, comps != 3, e);
     cell_fit f;
+    const uint64_t err = cell_compress(px, 0xFFFFu, cc, f);
     if (comps == 2) {
-        rgba8 t[16];
-        for (uint32_t i = 0; i < 16; i++) { t[i].c[0] = px[i].c[0]; t[i].c[1] = 0; t[i].c[2] = 0; t[i].c[3] = px[i].c[3]; }
-        const cell_cfg cc = mode_cell_cfg(mode, true, e);
-        cell_compress(t, 16, cc, f);
         r.endpoints[0] = f.astc_lo[0]; r.endpoints[1] = f.astc_hi[0]; r.endpoints[2] = f.astc_lo[3]; r.endpoints[3] = f.astc_hi[3];
-        for (uint32_t i = 0; i < 16; i++) r.weights[i] = f.sel[i];
-        r.err = la_cell_error(t, 16, f, mode);
+        BU_UNROLL
+        for (int i = 0; i < 16; i++) r.weights[i] = (uint8_t)sel_get(f.sel, i);
+        r.err = la_cell_error(px, 0xFFFFu, f, mode);
         return;
     }
-    const cell_cfg cc = mode_cell_cfg(mode, comps == 4, e);
-    r.err = cell_compress(px, 16, cc, f);
+    r.err = err;
     for (uint32_t c = 0; c < comps; c++) { r.endpoints[c * 2] = f.astc_lo[c]; r.endpoints[c * 2 + 1] = f.astc_hi[c]; }
     const bool inv = order_endpoints(r.endpoints, comps, cc.range);
-    for (uint32_t i = 0; i < 16; i++) r.weights[i] = (uint8_t)(inv ? top - f.sel[i] : f.sel[i]);
+    BU_UNROLL
+    for (int i = 0; i < 16; i++) r.weights[i] = (uint8_t)(inv ? top - sel_get(f.sel, i) : sel_get(f.sel, i));
 }
 
 BU_FN uint32_t bc7_3_to_2(uint32_t p, uint32_t k) {  // bc7_convert_partition_index_3_to_2, transcoder.cpp:14303-14328
@@ -591,33 +668,26 @@ BU_FN uint32_t fit_partition_bits(uint32_t mode, uint32_t pattern) {
     }
     return ku_bc7_part2[ku_cp2_bc7[pattern]];
 }
+// 2-bit-per-texel partition -> the 16-bit texel masks of its subsets
+BU_FN void partition_masks(uint32_t bits, uint32_t* m) {
+    const uint32_t lo = bits & 0x55555555u, hi = (bits >> 1) & 0x55555555u;
+    uint32_t m1 = 0, m2 = 0;
+    BU_UNROLL
+    for (int i = 0; i < 16; i++) { m1 |= ((lo >> (2 * i)) & 1u) << i; m2 |= ((hi >> (2 * i)) & 1u) << i; }
+    m[0] = 0xFFFFu & ~(m1 | m2); m[1] = m1; m[2] = m2;
+}
 
 // modes 2, 4, 7 (RGB, 2 subsets), 3 (RGB, 3 subsets), 9 (RGBA, 2 subsets), 16 (LA, 2 subsets) for one common pattern
 BU_FN_BIG void build_multi(uint32_t mode, uint32_t pattern, const rgba8* px_in, const enc_cfg& e, cand& r) {
     cand_begin(r, mode, pattern);
     const uint32_t comps = ku_mode_comps[mode], subsets = ku_mode_subsets[mode];
     const uint32_t top = (1u << ku_mode_weight_bits[mode]) - 1;
-    rgba8 la[16];
-    const rgba8* px = px_in;
-    if (comps == 2) {
-        for (uint32_t i = 0; i < 16; i++) { la[i].c[0] = px_in[i].c[0]; la[i].c[1] = 0; la[i].c[2] = 0; la[i].c[3] = px_in[i].c[3]; }
-        px = la;
-    }
+    uint32_t px[16];
+    pack_block_px(px_in, comps == 2, px);
     const uint32_t part_bits = fit_partition_bits(mode, pattern);
+    uint32_t masks[3];
+    partition_masks(part_bits, masks);
     const cell_cfg cc = mode_cell_cfg(mode, comps != 3, e);
-
-    cell_fit fit[3];
-    uint8_t index_in_part[16];
-    uint64_t total = 0;
-    for (uint32_t s = 0; s < subsets; s++) {
-        rgba8 sub[16];
-        uint32_t n = 0;
-        for (uint32_t i = 0; i < 16; i++)
-            if (((part_bits >> (2 * i)) & 3) == s) { index_in_part[i] = (uint8_t)n; sub[n++] = px[i]; }
-        const uint64_t err = cell_compress(sub, n, cc, fit[s]);
-        total += comps == 2 ? la_cell_error(sub, n, fit[s], mode) : err;
-    }
-    r.err = total;
 
     // which fitted subset feeds ASTC subset a, and the inverse
     uint32_t src_of_astc[3] = { 0, 1, 2 }, astc_of_src[3] = { 0, 1, 2 };
@@ -629,48 +699,56 @@ BU_FN_BIG void build_multi(uint32_t mode, uint32_t pattern, const rgba8* px_in, 
         src_of_astc[0] = 1; src_of_astc[1] = 0;
         astc_of_src[0] = 1; astc_of_src[1] = 0;
     }
-    bool inv[3] = { false, false, false };
-    for (uint32_t a = 0; a < subsets; a++) {
-        const cell_fit& f = fit[src_of_astc[a]];
+    uint64_t total = 0;
+    for (uint32_t s = 0; s < subsets; s++) {  // one call site: the fit is large once unrolled
+        cell_fit f;
+        const uint64_t err = cell_compress(px, masks[s], cc, f);
+        total += comps == 2 ? la_cell_error(px, masks[s], f, mode) : err;
+        const uint32_t a = astc_of_src[s];
+        bool inv = false;
         if (comps == 2) {
             uint8_t* ep = r.endpoints + a * 4;
             ep[0] = f.astc_lo[0]; ep[1] = f.astc_hi[0]; ep[2] = f.astc_lo[3]; ep[3] = f.astc_hi[3];
         } else {
             uint8_t* ep = r.endpoints + a * comps * 2;
             for (uint32_t c = 0; c < comps; c++) { ep[c * 2] = f.astc_lo[c]; ep[c * 2 + 1] = f.astc_hi[c]; }
-            inv[a] = order_endpoints(ep, comps, cc.range);
+            inv = order_endpoints(ep, comps, cc.range);
         }
+        BU_UNROLL
+        for (int i = 0; i < 16; i++)
+            if ((masks[s] >> i) & 1) r.weights[i] = (uint8_t)(inv ? top - sel_get(f.sel, i) : sel_get(f.sel, i));
     }
-    for (uint32_t i = 0; i < 16; i++) {
-        const uint32_t s = (part_bits >> (2 * i)) & 3;
-        const uint32_t w = fit[s].sel[index_in_part[i]];
-        r.weights[i] = (uint8_t)(inv[astc_of_src[s]] ? top - w : w);
-    }
+    r.err = total;
 }
 
 // modes 6 (RGB), 11, 13 (RGBA), 17 (LA): one subset, two weight planes; `rot` is the channel on the second plane
 BU_FN_BIG void build_dual(uint32_t mode, uint32_t rot, const rgba8* px, const enc_cfg& e, cand& r) {
     cand_begin(r, mode, 0);
     const uint32_t top = (1u << ku_mode_weight_bits[mode]) - 1;
-    rgba8 main_px[16], second_px[16];
-    for (uint32_t i = 0; i < 16; i++) {
-        main_px[i] = px[i];
-        if (mode == 17) {
-            const uint8_t l = px[i].c[0], a = px[i].c[3];
-            second_px[i].c[0] = a; second_px[i].c[1] = a; second_px[i].c[2] = a; second_px[i].c[3] = 255;
-            main_px[i].c[1] = l; main_px[i].c[2] = l; main_px[i].c[3] = 255;
-        } else {
-            const uint8_t v = px[i].c[rot];
-            second_px[i].c[0] = v; second_px[i].c[1] = v; second_px[i].c[2] = v; second_px[i].c[3] = 255;
-            if (mode == 6) main_px[i].c[rot] = 255;
-            else { main_px[i].c[rot] = px[i].c[3]; main_px[i].c[3] = 255; }
-        }
-    }
     const cell_cfg cc = mode_cell_cfg(mode, false, e);
-    cell_fit fm, fs;
-    const uint64_t err_main = cell_compress(main_px, 16, cc, fm);
-    const uint64_t err_second = cell_compress(second_px, 16, cc, fs) / 3;
-    r.err = mode == 17 ? err_main / 3 + err_second : err_main + err_second;
+    cell_fit fit[2];  // [0] the three remaining channels, [1] the rotated channel replicated to grey
+    uint64_t err[2];
+    for (uint32_t plane = 0; plane < 2; plane++) {
+        uint32_t t[16];
+        BU_UNROLL
+        for (int i = 0; i < 16; i++) {
+            uint8_t c[4] = { px[i].c[0], px[i].c[1], px[i].c[2], px[i].c[3] };
+            if (plane == 1) {
+                const uint8_t v = mode == 17 ? c[3] : c[rot];
+                c[0] = c[1] = c[2] = v; c[3] = 255;
+            } else if (mode == 17) {
+                c[1] = c[0]; c[2] = c[0]; c[3] = 255;
+            } else if (mode == 6) {
+                c[rot] = 255;
+            } else {
+                c[rot] = c[3]; c[3] = 255;
+            }
+            t[i] = pack_px(c);
+        }
+        err[plane] = cell_compress(t, 0xFFFFu, cc, fit[plane]);
+    }
+    const cell_fit &fm = fit[0], &fs = fit[1];
+    r.err = mode == 17 ? err[0] / 3 + err[1] / 3 : err[0] + err[1] / 3;
     bool inv = false;
     if (mode == 17) {
         r.ccs = 3;
@@ -687,89 +765,11 @@ BU_FN_BIG void build_dual(uint32_t mode, uint32_t rot, const rgba8* px, const en
         }
         inv = order_endpoints(r.endpoints, mode == 6 ? 3 : 4, cc.range);
     }
-    for (uint32_t i = 0; i < 16; i++) {
-        r.weights[i * 2] = (uint8_t)(inv ? top - fm.sel[i] : fm.sel[i]);
-        r.weights[i * 2 + 1] = (uint8_t)(inv ? top - fs.sel[i] : fs.sel[i]);
+    BU_UNROLL
+    for (int i = 0; i < 16; i++) {
+        r.weights[i * 2] = (uint8_t)(inv ? top - sel_get(fm.sel, i) : sel_get(fm.sel, i));
+        r.weights[i * 2 + 1] = (uint8_t)(inv ? top - sel_get(fs.sel, i) : sel_get(fs.sel, i));
     }
-}
-
-// Interpolation weight of selector s for `bits` weight bits, computed instead of looked up: ASTC weight unquantisation (replicate
-// to 6 bits, +1 above 32) reproduces ku_weights for every set UASTC uses (checked against the table in tests/test_uastc_core_host.py).
-BU_FN uint32_t weight_of(uint32_t bits, uint32_t s) {
-    uint32_t w = bits == 1 ? s * 63 : (bits == 2 ? s * 21 : (bits == 3 ? s * 9 : (bits == 4 ? (s << 2) | (s >> 2) : (s << 1) | (s >> 4))));
-    return w + (w > 32 ? 1u : 0u);
-}
-
-// cell_estimate over the texels of a 4x4 block selected by `mask` (bit i = texel i), everything in registers: the texels are 16
-// packed dwords, the loops are fully unrolled and predicated on the mask. On the GPU the mask is wave-uniform when every lane
-// ranks the same pattern, so the predicates cost nothing. Thresholds are non-decreasing (the interpolants move monotonically from
-// the box's low corner to its high corner), so "last threshold not above d" is a count. The reference's early outs
-// (bc7enc.cpp:1880-1882 and the subset loop conditions) only ever stop once the running error exceeds the best total so far, which
-// cannot change which pattern wins, so the full error is computed here.
-template <int WBITS, int COMPS>
-BU_FN uint32_t estimate_masked(const uint32_t* px, uint32_t mask) {
-    constexpr int N = 1 << WBITS;
-    int lo[4] = { 255, 255, 255, 255 }, hi[4] = { 0, 0, 0, 0 };
-#if defined(__HIPCC__)
-#pragma unroll
-#endif
-    for (int i = 0; i < 16; i++)
-        if ((mask >> i) & 1) {
-#if defined(__HIPCC__)
-#pragma unroll
-#endif
-            for (int c = 0; c < COMPS; c++) {
-                const int v = (int)((px[i] >> (8 * c)) & 255);
-                lo[c] = v < lo[c] ? v : lo[c];
-                hi[c] = v > hi[c] ? v : hi[c];
-            }
-        }
-    int axis[4], col[N][4], thresh[N - 1];
-    for (int c = 0; c < COMPS; c++) axis[c] = hi[c] - lo[c];
-    int prev_dot = 0;
-#if defined(__HIPCC__)
-#pragma unroll
-#endif
-    for (int k = 0; k < N; k++) {
-        int dot = 0;
-#if defined(__HIPCC__)
-#pragma unroll
-#endif
-        for (int c = 0; c < COMPS; c++) {
-            col[k][c] = k == 0 ? lo[c] : (k == N - 1 ? hi[c] : (int)astc_lerp((uint32_t)lo[c], (uint32_t)hi[c], weight_of(WBITS, (uint32_t)k)));
-            dot += col[k][c] * axis[c];
-        }
-        if (k) thresh[k - 1] = (prev_dot + dot + 1) >> 1;
-        prev_dot = dot;
-    }
-    uint32_t total = 0;
-#if defined(__HIPCC__)
-#pragma unroll
-#endif
-    for (int i = 0; i < 16; i++)
-        if ((mask >> i) & 1) {
-            int v[4], d = 0;
-#if defined(__HIPCC__)
-#pragma unroll
-#endif
-            for (int c = 0; c < COMPS; c++) { v[c] = (int)((px[i] >> (8 * c)) & 255); d += axis[c] * v[c]; }
-            int sel[4];
-            for (int c = 0; c < COMPS; c++) sel[c] = col[0][c];
-#if defined(__HIPCC__)
-#pragma unroll
-#endif
-            for (int k = 1; k < N; k++) {
-                const bool at_least = d >= thresh[k - 1];
-                for (int c = 0; c < COMPS; c++) sel[c] = at_least ? col[k][c] : sel[c];
-            }
-            for (int c = 0; c < COMPS; c++) { const int e = sel[c] - v[c]; total += (uint32_t)(e * e); }
-        }
-    return total;
-}
-
-BU_FN uint32_t estimate_masked_any(uint32_t wbits, uint32_t comps, const uint32_t* px, uint32_t mask) {
-    if (wbits == 3) return estimate_masked<3, 3>(px, mask);  // mode 2
-    return comps == 4 ? estimate_masked<2, 4>(px, mask) : estimate_masked<2, 3>(px, mask);
 }
 
 // estimate_partition2 / estimate_partition2_list and the inlined variants of modes 3 and 7 (uastc_enc.cpp:638-671, 828-860, 1362-1405,
@@ -779,21 +779,15 @@ BU_FN void estimate_patterns(uint32_t mode, const rgba8* px_in, uint32_t want, u
     const uint32_t comps = ku_mode_comps[mode] == 3 ? 3 : 4, subsets = ku_mode_subsets[mode], wbits = ku_mode_weight_bits[mode];
     const uint32_t total = mode == 3 ? 11 : (mode == 7 ? 19 : 30);
     uint32_t px[16];
-    for (uint32_t i = 0; i < 16; i++) {
-        const uint8_t* c = px_in[i].c;
-        px[i] = ku_mode_comps[mode] == 2 ? ((uint32_t)c[0] | ((uint32_t)c[3] << 24)) : ((uint32_t)c[0] | ((uint32_t)c[1] << 8) | ((uint32_t)c[2] << 16) | ((uint32_t)c[3] << 24));
-    }
+    pack_block_px(px_in, ku_mode_comps[mode] == 2, px);
     uint64_t best_err[8];
     for (uint32_t i = 0; i < 8; i++) { best_err[i] = UINT64_MAX; if (i < want) out[i] = 0; }
     for (uint32_t pat = 0; pat < total; pat++) {
         const uint32_t bits = mode == 3 ? ku_bc7_part3[ku_cp3_bc7[pat]] : (mode == 7 ? ku_pat7[pat] : ku_bc7_part2[ku_cp2_bc7[pat]]);
-        // per-subset texel masks from the 2-bit fields
-        const uint32_t lo_bits = bits & 0x55555555u, hi_bits = (bits >> 1) & 0x55555555u;
-        uint32_t m1 = 0, m2 = 0;
-        for (uint32_t i = 0; i < 16; i++) { m1 |= ((lo_bits >> (2 * i)) & 1u) << i; m2 |= ((hi_bits >> (2 * i)) & 1u) << i; }
-        const uint32_t m0 = 0xFFFFu & ~(m1 | m2);
-        uint64_t err = (uint64_t)estimate_masked_any(wbits, comps, px, m0) + estimate_masked_any(wbits, comps, px, m1);
-        if (subsets == 3) err += estimate_masked_any(wbits, comps, px, m2);
+        uint32_t m[3];
+        partition_masks(bits, m);
+        uint64_t err = (uint64_t)estimate_masked_any(wbits, comps, px, m[0]) + estimate_masked_any(wbits, comps, px, m[1]);
+        if (subsets == 3) err += estimate_masked_any(wbits, comps, px, m[2]);
         for (uint32_t i = 0; i < want; i++)
             if (err < best_err[i]) {
                 for (uint32_t j = want - 1; j > i; --j) { out[j] = out[j - 1]; best_err[j] = best_err[j - 1]; }
@@ -946,7 +940,7 @@ BU_FN uint32_t bc7_dequant_p(uint32_t v, uint32_t pbit, uint32_t bits) {  // bc7
     return v | (v >> total);
 }
 BU_FN uint32_t bc7_dequant(uint32_t v, uint32_t bits) { v <<= (8 - bits); return v | (v >> bits); }
-BU_FN uint32_t bc7_lerp(uint32_t l, uint32_t h, uint32_t w) { return (l * (64 - w) + h * w + 32) >> 6; }
+BU_FN uint32_t bc7_lerp(uint32_t l, uint32_t h, uint32_t w) { return (umul24(l, 64 - w) + umul24(h, w) + 32) >> 6; }
 
 BU_FN_BIG void decode_bc7(const cand& r, rgba8* out) {
     const uint32_t mode = r.mode, comps = ku_mode_comps[mode], range = ku_mode_endpoint_ranges[mode];
@@ -1076,7 +1070,7 @@ struct block_err { uint64_t rgb, rgba, la; };
 BU_FN block_err block_error(const rgba8* a, const rgba8* b) {  // compute_block_error, uastc_enc.cpp:2510-2533
     uint64_t e[4] = { 0, 0, 0, 0 };
     for (uint32_t i = 0; i < 16; i++)
-        for (uint32_t c = 0; c < 4; c++) { const int d = (int)a[i].c[c] - (int)b[i].c[c]; e[c] += (uint32_t)(d * d); }
+        for (uint32_t c = 0; c < 4; c++) { const int d = (int)a[i].c[c] - (int)b[i].c[c]; e[c] += (uint32_t)imul24(d, d); }
     block_err r;
     r.la = e[0] + e[3]; r.rgb = e[0] + e[1] + e[2]; r.rgba = r.rgb + e[3];
     return r;
@@ -1170,11 +1164,11 @@ BU_FN void bc1_pick_selectors(const rgba8* px, const int* l, const int* h, uint8
     br[2] = (br[3] * 2 + br[0]) / 3; bg[2] = (bg[3] * 2 + bg[0]) / 3; bb[2] = (bb[3] * 2 + bb[0]) / 3;
     int ar = br[3] - br[0], ag = bg[3] - bg[0], ab = bb[3] - bb[0];
     int dots[4];
-    for (uint32_t i = 0; i < 4; i++) dots[i] = br[i] * ar + bg[i] * ag + bb[i] * ab;
+    for (uint32_t i = 0; i < 4; i++) dots[i] = imul24(br[i], ar) + imul24(bg[i], ag) + imul24(bb[i], ab);
     const int t0 = dots[0] + dots[1], t1 = dots[1] + dots[2], t2 = dots[2] + dots[3];
     ar *= 2; ag *= 2; ab *= 2;
     for (uint32_t i = 0; i < 16; i++) {
-        const int d = px[i].c[0] * ar + px[i].c[1] * ag + px[i].c[2] * ab;
+        const int d = imul24(px[i].c[0], ar) + imul24(px[i].c[1], ag) + imul24(px[i].c[2], ab);
         sels[i] = (uint8_t)(3 - ((d <= t0) + (d < t1) + (d < t2)));
     }
 }
@@ -1214,7 +1208,7 @@ BU_FN_BIG void bc1_encode(const rgba8* px, const uint8_t* given_sels, bc1_blk& o
         int icov[6] = { 0, 0, 0, 0, 0, 0 };
         for (uint32_t i = 0; i < 16; i++) {
             const int r = (int)px[i].c[0] - avg[0], g = (int)px[i].c[1] - avg[1], b = (int)px[i].c[2] - avg[2];
-            icov[0] += r * r; icov[1] += r * g; icov[2] += r * b; icov[3] += g * g; icov[4] += g * b; icov[5] += b * b;
+            icov[0] += imul24(r, r); icov[1] += imul24(r, g); icov[2] += imul24(r, b); icov[3] += imul24(g, g); icov[4] += imul24(g, b); icov[5] += imul24(b, b);
         }
         float cov[6];
         for (uint32_t i = 0; i < 6; i++) cov[i] = (float)icov[i] * (1.0f / 255.0f);
@@ -1235,7 +1229,7 @@ BU_FN_BIG void bc1_encode(const rgba8* px, const uint8_t* given_sels, bc1_blk& o
         int low_dot = INT32_MAX, high_dot = INT32_MIN;
         uint32_t low_c = 0, high_c = 0;
         for (uint32_t i = 0; i < 16; i++) {
-            const int dot = px[i].c[0] * sa[0] + px[i].c[1] * sa[1] + px[i].c[2] * sa[2];
+            const int dot = imul24(px[i].c[0], sa[0]) + imul24(px[i].c[1], sa[1]) + imul24(px[i].c[2], sa[2]);
             if (dot < low_dot) { low_dot = dot; low_c = i; }
             if (dot > high_dot) { high_dot = dot; high_c = i; }
         }
@@ -1518,7 +1512,7 @@ BU_FN bool etc1_estimate_flipped(const rgba8* p) {  // pack_etc1_estimate_flippe
 // first one that is not better, :2906-2907) is kept.
 
 struct ycc { int y, cb, cr; };
-BU_FN ycc to_ycc(int r, int g, int b) { const int y = r * 54 + g * 183 + b * 19; ycc o = { y, (b << 8) - y, (r << 8) - y }; return o; }
+BU_FN ycc to_ycc(int r, int g, int b) { const int y = imul24(r, 54) + imul24(g, 183) + imul24(b, 19); ycc o = { y, (b << 8) - y, (r << 8) - y }; return o; }
 // d * d for |d| <= 130560 (differences of the 16.8 fixed-point luma / chroma values): the operand is masked to 18 bits so that the
 // compiler can prove it fits the 24-bit multiplier (v_mul_u32_u24 + v_mul_hi_u32_u24, full rate, instead of a 64-bit multiply).
 BU_FN uint64_t square_s18(int d) {

@@ -280,9 +280,13 @@ def uastc_host():
         L = C.CDLL(str(so))
         L.hc_encode_uastc.argtypes = [u8p, C.c_uint32, C.c_uint32, u8p]
         L.hc_cell_compress.restype = C.c_uint64
-        L.hc_cell_compress.argtypes = [u8p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32, C.c_uint32, u8p, u8p]
+        L.hc_cell_compress.argtypes = [u8p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32, C.c_uint32, u8p]
         L.hc_cell_estimate.restype = C.c_uint64
-        L.hc_cell_estimate.argtypes = [C.c_uint32, C.c_uint32, u8p, C.c_uint32, C.c_uint64]
+        L.hc_cell_estimate.argtypes = [C.c_uint32, C.c_uint32, u8p, C.c_uint32]
+        L.hc_weight_of.restype = C.c_uint32
+        L.hc_weight_of.argtypes = [C.c_uint32, C.c_uint32]
+        L.hc_weight_table.restype = C.c_uint32
+        L.hc_weight_table.argtypes = [C.c_uint32, C.c_uint32]
         _uastc_host = L
     return _uastc_host
 

@@ -68,18 +68,30 @@ def test_colour_cell_fit_vs_reference():
 
     for _ in range(6000):
         wb, rg, al = combos[rng.integers(len(combos))]
-        n, kind = int(rng.integers(1, 17)), int(rng.integers(0, 5))
-        px = np.ascontiguousarray(gen(kind, n))
+        # the device code fits "the texels of a block selected by a mask"; the reference sees the same texels gathered in order
+        mask = int(rng.integers(1, 1 << 16)) if rng.random() < 0.7 else 0xFFFF
+        members = [i for i in range(16) if (mask >> i) & 1]
+        n, kind = len(members), int(rng.integers(0, 5))
+        px16 = np.ascontiguousarray(rng.integers(0, 256, (16, 4), dtype=np.uint8))
+        px16[members] = gen(kind, n)
         if not al and rng.random() < 0.7:
-            px[:, 3] = 255
+            px16[:, 3] = 255
+        px = np.ascontiguousarray(px16[members])
         uber, ls = int(rng.choice([0, 1, 1, 3, 6])), int(rng.choice([1, 1, 2]))
         o1, o2 = np.zeros(24, np.uint8), np.zeros(24, np.uint8)
         e1 = R.ref_color_cell_compression(ptr(px), n, wb, rg, al, uber, ls, None, ptr(o1))
-        e2 = H.hc_cell_compress(ptr(px), n, wb, rg, al, uber, ls, None, ptr(o2))
-        assert e1 == e2 and (o1[:8] == o2[:8]).all() and (o1[8:8 + n] == o2[8:8 + n]).all(), (wb, rg, al, n, kind, uber, ls, px.tolist())
-        limit = int(rng.choice([2 ** 64 - 1, 500, 5000]))
-        comps = 4 if al else 3
-        assert R.ref_ccell_est(wb, comps, ptr(px), n, limit) == H.hc_cell_estimate(wb, comps, ptr(px), n, limit)
+        e2 = H.hc_cell_compress(ptr(px16), mask, wb, rg, al, uber, ls, ptr(o2))
+        assert e1 == e2 and (o1[:8] == o2[:8]).all() and (o1[8:8 + n] == o2[8:][members]).all(), (wb, rg, al, mask, kind, uber, ls, px.tolist())
+        if wb in (2, 3) and not (wb == 3 and al):  # the (weights, channels) combinations the partition estimate is used with
+            comps = 4 if al else 3
+            assert R.ref_ccell_est(wb, comps, ptr(px), n, 2 ** 64 - 1) == H.hc_cell_estimate(wb, comps, ptr(px16), mask)
+
+
+def test_weight_formula_matches_tables():
+    H = helpers.uastc_host()
+    for bits in range(1, 6):
+        for s in range(1 << bits):
+            assert H.hc_weight_of(bits, s) == H.hc_weight_table(bits, s), (bits, s)
 
 
 @pytest.mark.ref
