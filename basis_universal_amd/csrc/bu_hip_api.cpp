@@ -390,6 +390,36 @@ int bu_hip_k_generate_endpoint_codebook(bu_hip_context* ctx, const void* d_px, u
     return 1;
 }
 
+int bu_hip_k_refit_endpoints_given_selectors(bu_hip_context* ctx, const void* d_px, const void* d_enc, uint32_t n_clusters, const uint32_t* h_offsets,
+                                             const uint32_t* d_offsets, const uint32_t* d_indices, int perceptual, uint8_t* d_params, uint64_t* d_err,
+                                             uint8_t* d_valid, uint64_t* d_cur_err) {
+    if (!ctx) return 0;
+    if (!n_clusters) return 1;
+    device_guard g(ctx->device);
+    std::vector<uint32_t> order(n_clusters);
+    std::iota(order.begin(), order.end(), 0u);
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return (h_offsets[a + 1] - h_offsets[a]) > (h_offsets[b + 1] - h_offsets[b]); });
+    arena& ord = ctx->scratch[5];
+    BU_TRY(ctx, ord.reserve(n_clusters * sizeof(uint32_t)));
+    BU_TRY(ctx, h2d(ctx, ord.p, order.data(), n_clusters * sizeof(uint32_t)));
+    {
+        prof_scope ps(ctx, "refit_endpoints_given_selectors");
+        BU_TRY(ctx, bu::launch_refit_endpoints_given_selectors(ctx->stream, d_px, d_enc, n_clusters, static_cast<const uint32_t*>(ord.p), d_offsets, d_indices,
+                                                               perceptual != 0, d_params, d_err, d_valid, d_cur_err));
+    }
+    BU_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return 1;
+}
+
+int bu_hip_k_subblock_errors(bu_hip_context* ctx, const void* d_px, uint32_t n_blocks, const uint32_t* d_block_cluster, const uint8_t* d_cluster_params,
+                             int perceptual, uint64_t* d_out) {
+    if (!ctx) return 0;
+    device_guard g(ctx->device);
+    prof_scope ps(ctx, "subblock_errors");
+    BU_TRY(ctx, bu::launch_subblock_errors(ctx->stream, d_px, n_blocks, d_block_cluster, d_cluster_params, perceptual != 0, d_out));
+    return 1;
+}
+
 int bu_hip_k_refine_endpoint_clusterization(bu_hip_context* ctx, const void* d_px, uint32_t n_blocks, const uint32_t* d_block_cluster,
                                             const uint8_t* d_cluster_params, uint32_t n_clusters, uint32_t n_parents, const uint32_t* d_cand_offsets,
                                             const uint32_t* d_cand_indices, const uint8_t* d_block_parent, int perceptual, uint32_t* d_out_best) {

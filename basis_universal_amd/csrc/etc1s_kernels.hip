@@ -393,10 +393,22 @@ __device__ __forceinline__ uint32_t cluster_pixel(const uint32_t* __restrict__ p
     return pixel_words[(size_t)tv * 8 + (j & 7u)];
 }
 
-template <bool PERCEPTUAL, int QUALITY>
+// forced selector of cluster pixel j (refine_block_endpoints_given_selectors, frontend.cpp:2766-2775): the selector the block's
+// current encoding gives that texel; sub-block texels are the flipped layout, i.e. rows {0,1} / {2,3} in raster order
+__device__ __forceinline__ uint32_t cluster_pixel_selector(const uint64_t* __restrict__ enc_blocks, const uint32_t* __restrict__ members, uint32_t j) {
+    const uint32_t tv = members[j >> 3], k = j & 7u;
+    const uint32_t lo32 = (uint32_t)bswap64(enc_blocks[tv >> 1]);
+    return selector_from_bits(lo32, k & 3u, (tv & 1u) * 2u + (k >> 2));
+}
+
+// FORCED = the etc1_optimizer with m_pForce_selectors (etc.cpp:1188-1193): every texel is scored against the colour its current
+// selector picks instead of the nearest one; the previous endpoints are never kept here, instead the cluster's CURRENT error
+// (each texel against its own block's current colours) is returned in cur_err_out for the caller's "only if better" test.
+template <bool PERCEPTUAL, int QUALITY, bool FORCED>
 __global__ __launch_bounds__(CB_THREADS) void k_generate_endpoint_codebook(
     const uint32_t* __restrict__ pixel_words, const uint32_t* __restrict__ order, const uint32_t* __restrict__ offsets,
-    const uint32_t* __restrict__ indices, uint32_t step, uint8_t* __restrict__ params, uint64_t* __restrict__ err_out, uint8_t* __restrict__ valid) {
+    const uint32_t* __restrict__ indices, uint32_t step, uint8_t* __restrict__ params, uint64_t* __restrict__ err_out, uint8_t* __restrict__ valid,
+    const uint64_t* __restrict__ enc_blocks, uint64_t* __restrict__ cur_err_out) {
     __shared__ uint64_t s_part[CB_WAVES][8];
     __shared__ uint64_t s_tot[8];
     __shared__ int s_mm[CB_WAVES][6];
@@ -482,9 +494,18 @@ __global__ __launch_bounds__(CB_THREADS) void k_generate_endpoint_codebook(
             for (int t = 0; t < 8; t++) tot[t] = 0;
             for (uint32_t j = tid; j < n; j += CB_THREADS) {
                 const cvec p = pixel_cvec<PERCEPTUAL>(cluster_pixel(pixel_words, members, j));
+                if (FORCED) {
+                    const uint32_t sel = cluster_pixel_selector(enc_blocks, members, j);
 #pragma unroll
-                for (int t = 0; t < 8; t++)
-                    if ((enable_mask >> t) & 1u) tot[t] += min_err4<PERCEPTUAL>(p, bc[t]);
+                    for (int t = 0; t < 8; t++) {
+                        const cvec c = sel == 0 ? bc[t][0] : (sel == 1 ? bc[t][1] : (sel == 2 ? bc[t][2] : bc[t][3]));
+                        tot[t] += cdist<PERCEPTUAL>(p, c);
+                    }
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 8; t++)
+                        if ((enable_mask >> t) & 1u) tot[t] += min_err4<PERCEPTUAL>(p, bc[t]);
+                }
             }
 #pragma unroll
             for (int t = 0; t < 8; t++) {
@@ -516,6 +537,33 @@ __global__ __launch_bounds__(CB_THREADS) void k_generate_endpoint_codebook(
         if (best_err == 0 || !best_valid) break; // etc.cpp:955-956, 993-994
     }
 
+    if (FORCED) {
+        // current error of the cluster's texels under their own blocks' present colours (frontend.cpp:2773)
+        uint64_t tot = 0;
+        for (uint32_t j = tid; j < n; j += CB_THREADS) {
+            const uint32_t tv = members[j >> 3];
+            uint32_t r5, g5, b5, inten;
+            unpack_etc1s_header(enc_blocks[tv >> 1], r5, g5, b5, inten);
+            cvec bc[4];
+            block_cvecs<PERCEPTUAL>(bc, scale5((int)r5), scale5((int)g5), scale5((int)b5), (int)inten);
+            const uint32_t sel = cluster_pixel_selector(enc_blocks, members, j);
+            const cvec c = sel == 0 ? bc[0] : (sel == 1 ? bc[1] : (sel == 2 ? bc[2] : bc[3]));
+            tot += cdist<PERCEPTUAL>(pixel_cvec<PERCEPTUAL>(cluster_pixel(pixel_words, members, j)), c);
+        }
+        tot = wave_sum_u64(tot);
+        __syncthreads();
+        if (lane == 0) s_part[wave][0] = tot;
+        __syncthreads();
+        if (tid == 0) {
+            uint64_t cur = 0;
+            for (int w = 0; w < CB_WAVES; w++) cur += s_part[w][0];
+            cur_err_out[ci] = cur;
+            params[ci * 4 + 0] = (uint8_t)best_r; params[ci * 4 + 1] = (uint8_t)best_g; params[ci * 4 + 2] = (uint8_t)best_b; params[ci * 4 + 3] = (uint8_t)best_inten;
+            err_out[ci] = best_err;
+            valid[ci] = best_valid ? 1 : 0;
+        }
+        return;
+    }
     // ---- keep the previous endpoints unless the error strictly drops (frontend.cpp:1554-1605)
     bool use_new = true;
     if (step != 0 && valid[ci]) {
@@ -835,13 +883,56 @@ hipError_t launch_generate_endpoint_codebook(hipStream_t st, const void* d_pixel
     const uint32_t* pw = static_cast<const uint32_t*>(d_pixel_blocks);
     // the etc1_optimizer never runs at "fast" quality for clusters (frontend.cpp:1530-1533)
     if (quality < BU_Q_MEDIUM) quality = BU_Q_MEDIUM;
-#define BU_CB(P, Q) hipLaunchKernelGGL((k_generate_endpoint_codebook<P, Q>), grid, blk, 0, st, pw, d_order, d_offsets, d_indices, step, d_params, d_err, d_valid)
+#define BU_CB(P, Q) hipLaunchKernelGGL((k_generate_endpoint_codebook<P, Q, false>), grid, blk, 0, st, pw, d_order, d_offsets, d_indices, step, d_params, d_err, d_valid, (const uint64_t*)nullptr, (uint64_t*)nullptr)
     if (perceptual) {
         if (quality == BU_Q_MEDIUM) BU_CB(true, BU_Q_MEDIUM); else if (quality == BU_Q_SLOW) BU_CB(true, BU_Q_SLOW); else BU_CB(true, BU_Q_UBER);
     } else {
         if (quality == BU_Q_MEDIUM) BU_CB(false, BU_Q_MEDIUM); else if (quality == BU_Q_SLOW) BU_CB(false, BU_Q_SLOW); else BU_CB(false, BU_Q_UBER);
     }
 #undef BU_CB
+    BU_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+// refine_block_endpoints_given_selectors (frontend.cpp:2718-2976): uber-quality cluster fit with the selectors held fixed
+hipError_t launch_refit_endpoints_given_selectors(hipStream_t st, const void* d_pixel_blocks, const void* d_enc_blocks, uint32_t n_clusters, const uint32_t* d_order,
+                                                  const uint32_t* d_offsets, const uint32_t* d_indices, bool perceptual, uint8_t* d_params, uint64_t* d_err,
+                                                  uint8_t* d_valid, uint64_t* d_cur_err) {
+    if (!n_clusters) return hipSuccess;
+    const dim3 grid(n_clusters), blk(CB_THREADS);
+    const uint32_t* pw = static_cast<const uint32_t*>(d_pixel_blocks);
+    const uint64_t* enc = static_cast<const uint64_t*>(d_enc_blocks);
+    if (perceptual) hipLaunchKernelGGL((k_generate_endpoint_codebook<true, BU_Q_UBER, true>), grid, blk, 0, st, pw, d_order, d_offsets, d_indices, 0u, d_params, d_err, d_valid, enc, d_cur_err);
+    else hipLaunchKernelGGL((k_generate_endpoint_codebook<false, BU_Q_UBER, true>), grid, blk, 0, st, pw, d_order, d_offsets, d_indices, 0u, d_params, d_err, d_valid, enc, d_cur_err);
+    BU_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
+// compute_endpoint_subblock_error_vec (frontend.cpp:1006-1091): error of every sub-block (training vector) under its cluster's endpoints
+template <bool PERCEPTUAL>
+__global__ __launch_bounds__(256) void k_subblock_errors(const uint32_t* __restrict__ pixel_words, uint32_t n_blocks, const uint32_t* __restrict__ block_cluster,
+                                                         const uint32_t* __restrict__ cluster_params, uint64_t* __restrict__ out) {
+    const uint32_t tv = blockIdx.x * 256u + threadIdx.x;
+    if (tv >= n_blocks * 2u) return;
+    const uint32_t prm = cluster_params[block_cluster[tv >> 1]];
+    cvec bc[4];
+    // NOT scale5(): the reference passes the 5-bit colour with scaled = true here (frontend.cpp:1043), so the sub-block errors that
+    // rank candidates for new clusters are measured against the unscaled values; reproduced as is
+    block_cvecs<PERCEPTUAL>(bc, (int)(prm & 255u), (int)((prm >> 8) & 255u), (int)((prm >> 16) & 255u), (int)(prm >> 24));
+    uint64_t tot = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) tot += min_err4<PERCEPTUAL>(pixel_cvec<PERCEPTUAL>(pixel_words[(size_t)tv * 8 + k]), bc);
+    out[tv] = tot;
+}
+
+hipError_t launch_subblock_errors(hipStream_t st, const void* d_pixel_blocks, uint32_t n_blocks, const uint32_t* d_block_cluster, const uint8_t* d_cluster_params,
+                                  bool perceptual, uint64_t* d_out) {
+    if (!n_blocks) return hipSuccess;
+    const dim3 grid((n_blocks * 2 + 255) / 256), blk(256);
+    const uint32_t* pw = static_cast<const uint32_t*>(d_pixel_blocks);
+    const uint32_t* prm = reinterpret_cast<const uint32_t*>(d_cluster_params);
+    if (perceptual) hipLaunchKernelGGL(k_subblock_errors<true>, grid, blk, 0, st, pw, n_blocks, d_block_cluster, prm, d_out);
+    else hipLaunchKernelGGL(k_subblock_errors<false>, grid, blk, 0, st, pw, n_blocks, d_block_cluster, prm, d_out);
     BU_LAUNCH_CHECK();
     return hipSuccess;
 }

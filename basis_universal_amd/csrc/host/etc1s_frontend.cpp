@@ -34,6 +34,7 @@ struct allocator_policy {
 const uint32_t kEndpointParentCodebookSize = 16;          // frontend.cpp:40
 const uint32_t kSelectorParentCodebookSizeLevel01 = 32;   // frontend.cpp:41
 const uint32_t kSelectorParentCodebookSizeDefault = 16;   // frontend.cpp:42
+const uint32_t kMaxEndpointRefinementSteps = 3;            // BASISU_MAX_ENDPOINT_REFINEMENT_STEPS, frontend.cpp:37
 const uint32_t kFoscJobSize = 2048;                        // frontend.cpp:2547
 
 const int kIntenB[8] = {8, 17, 29, 42, 60, 80, 106, 183}; // outer entries of g_etc1_inten_tables (etc.cpp:304-308)
@@ -187,7 +188,7 @@ bool etc1s_frontend::init(const params& p) {
     if (p.m_max_endpoint_clusters < 1 || p.m_max_endpoint_clusters > cMaxEndpointClusters) return fail("bad max_endpoint_clusters");
     if (p.m_max_selector_clusters < 1 || p.m_max_selector_clusters > cMaxSelectorClusters) return fail("bad max_selector_clusters");
     if (!p.m_num_source_blocks || (!p.m_pSource_blocks && !p.m_pDevice_blocks)) return fail("no source blocks");
-    if (p.m_compression_level > 3) return fail("ETC1S compression levels 4-6 (multi-pass codebook refinement) are not built yet");
+    if (p.m_compression_level > 6) return fail("bad compression level (0..6)");
     m_params = p;
     m_total_blocks = p.m_num_source_blocks;
 
@@ -209,7 +210,13 @@ bool etc1s_frontend::init(const params& p) {
     switch (p.m_compression_level) {  // frontend.cpp:87-148
     case 0: m_endpoint_refinement = false; m_use_hierarchical_endpoint_codebooks = true; m_use_hierarchical_selector_codebooks = true; break;
     case 1: case 2: m_endpoint_refinement = true; m_use_hierarchical_endpoint_codebooks = true; m_use_hierarchical_selector_codebooks = true; break;
-    default: m_endpoint_refinement = true; m_use_hierarchical_endpoint_codebooks = false; m_use_hierarchical_selector_codebooks = false; break;
+    case 3: m_endpoint_refinement = true; m_use_hierarchical_endpoint_codebooks = false; m_use_hierarchical_selector_codebooks = false; break;
+    case 4: m_endpoint_refinement = true; m_use_hierarchical_endpoint_codebooks = true; m_use_hierarchical_selector_codebooks = true;
+            m_num_endpoint_codebook_iterations = kMaxEndpointRefinementSteps; m_num_selector_codebook_iterations = kMaxEndpointRefinementSteps; break;
+    case 5: m_endpoint_refinement = true; m_use_hierarchical_endpoint_codebooks = false; m_use_hierarchical_selector_codebooks = false;
+            m_num_endpoint_codebook_iterations = kMaxEndpointRefinementSteps; m_num_selector_codebook_iterations = kMaxEndpointRefinementSteps; break;
+    default: m_endpoint_refinement = true; m_use_hierarchical_endpoint_codebooks = false; m_use_hierarchical_selector_codebooks = false;
+            m_num_endpoint_codebook_iterations = kMaxEndpointRefinementSteps * 2; m_num_selector_codebook_iterations = kMaxEndpointRefinementSteps * 2; break;
     }
     if (p.m_disable_hierarchical_endpoint_codebooks) m_use_hierarchical_endpoint_codebooks = false;
     return true;
@@ -224,21 +231,31 @@ bool etc1s_frontend::compress() {
     BU_STAGE("init_endpoint_training_vectors", init_endpoint_training_vectors());
     BU_STAGE("generate_endpoint_clusters", generate_endpoint_clusters());
     for (uint32_t step = 0; step < m_num_endpoint_codebook_iterations; step++) {
+        if (step) BU_STAGE("introduce_new_endpoint_clusters", introduce_new_endpoint_clusters());
         BU_STAGE("generate_endpoint_codebook", generate_endpoint_codebook(step));
+        bool early_out = false;
         if (m_endpoint_refinement) {
             uint32_t moved = 0;
             BU_STAGE("refine_endpoint_clusterization", refine_endpoint_clusterization(&moved));
+            if (!moved) early_out = true;  // frontend.cpp:215-216
         }
         BU_STAGE_V("eliminate_redundant_or_empty_endpoint_clusters", eliminate_redundant_or_empty_endpoint_clusters());
+        if (early_out) break;
     }
     BU_STAGE_V("generate_block_endpoint_clusters", generate_block_endpoint_clusters());
     BU_STAGE("create_initial_packed_texture", create_initial_packed_texture());
     BU_STAGE("generate_selector_clusters", generate_selector_clusters());
     if (m_use_hierarchical_selector_codebooks) BU_STAGE_V("compute_selector_clusters_within_each_parent_cluster", compute_selector_clusters_within_each_parent_cluster());
-    for (uint32_t it = 0; it < m_num_selector_codebook_iterations; it++) {
+    const uint32_t selector_steps = m_params.m_compression_level == 0 ? 1 : m_num_selector_codebook_iterations;
+    for (uint32_t it = 0; it < selector_steps; it++) {
         BU_STAGE("create_optimized_selector_codebook", create_optimized_selector_codebook(it));
         BU_STAGE("find_optimal_selector_clusters_for_each_block", find_optimal_selector_clusters_for_each_block());
         BU_STAGE("introduce_special_selector_clusters", introduce_special_selector_clusters());
+        if (m_params.m_compression_level >= 4) {
+            uint32_t refined = 0;
+            BU_STAGE("refine_block_endpoints_given_selectors", refine_block_endpoints_given_selectors(&refined));
+            if (!refined) break;  // frontend.cpp:283-286
+        }
     }
     BU_STAGE_V("optimize_selector_codebook", optimize_selector_codebook());
     BU_STAGE_V("finalize", finalize());
@@ -377,6 +394,123 @@ bool etc1s_frontend::generate_endpoint_codebook(uint32_t step) {
         endpoint_params& e = m_endpoint_cluster_etc_params[i];
         e.r = prm[i * 4]; e.g = prm[i * 4 + 1]; e.b = prm[i * 4 + 2]; e.inten = prm[i * 4 + 3]; e.valid = valid[i] != 0; e.color_error = err[i];
     }
+    return true;
+}
+
+// frontend.cpp:1093-1212 (+ compute_endpoint_subblock_error_vec :1006-1091 on the device). Between codebook iterations the sub-blocks
+// that their cluster represents worst are split off into new two-vector clusters until the codebook is full again.
+bool etc1s_frontend::introduce_new_endpoint_clusters() {
+    generate_block_endpoint_clusters();
+    int want = (int)m_params.m_max_endpoint_clusters - (int)m_endpoint_clusters.size();
+    if (want <= 0) return true;
+    const uint32_t n = m_total_blocks, k = (uint32_t)m_endpoint_clusters.size();
+    std::vector<uint8_t> prm(k * 4ull);
+    for (uint32_t i = 0; i < k; i++) {
+        const endpoint_params& e = m_endpoint_cluster_etc_params[i];
+        prm[i * 4] = e.r; prm[i * 4 + 1] = e.g; prm[i * 4 + 2] = e.b; prm[i * 4 + 3] = e.inten;
+    }
+    device_state& d = *m_dev;
+    if (!d.upload(d.block_cluster, m_block_endpoint_cluster.data(), n) || !d.upload(d.params, prm.data(), prm.size()) || !d.reserve(d.err, (size_t)n * 2 * 8)) return fail("upload");
+    if (!bu_hip_k_subblock_errors(d.ctx, d.d_pixels, n, (const uint32_t*)d.block_cluster.p, (const uint8_t*)d.params.p, m_params.m_perceptual, (uint64_t*)d.err.p))
+        return fail("bu_hip_k_subblock_errors");
+    std::vector<uint64_t> err((size_t)n * 2);
+    if (!d.download(err.data(), d.err, err.size())) return fail("download sub-block errors");
+    // The reference sorts (error, block, sub-block) ascending and takes candidates from the back (:1089, :1117-1119)
+    std::vector<uint32_t> order((size_t)n * 2);
+    std::iota(order.begin(), order.end(), 0u);
+    std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return err[a] < err[b] || (err[a] == err[b] && a < b); });
+    std::vector<uint32_t> cluster_sizes(k);
+    for (uint32_t i = 0; i < k; i++) cluster_sizes[i] = (uint32_t)m_endpoint_clusters[i].size();
+    std::vector<uint8_t> relocated((size_t)n * 2, 0), ignore_cluster(k, 0);
+    for (size_t pos = order.size(); pos-- > 0 && want > 0;) {
+        const uint32_t tv = order[pos];
+        const uint32_t ci = m_block_endpoint_cluster[tv >> 1];
+        if (ignore_cluster[ci]) continue;
+        if (cluster_sizes[ci] <= 2) continue;
+        if (relocated[tv] || relocated[tv ^ 1]) continue;
+        m_endpoint_clusters.push_back({tv, tv ^ 1});
+        m_endpoint_cluster_etc_params.emplace_back();
+        relocated[tv] = relocated[tv ^ 1] = 1;
+        cluster_sizes[ci] -= 2;
+        ignore_cluster[ci] = 1;
+        want--;
+    }
+    for (uint32_t i = 0; i < k; i++) {
+        std::vector<uint32_t>& l = m_endpoint_clusters[i];
+        l.erase(std::remove_if(l.begin(), l.end(), [&](uint32_t tv) { return relocated[tv] != 0; }), l.end());
+    }
+    generate_block_endpoint_clusters();
+    return true;
+}
+
+// frontend.cpp:2718-2976. ETC1S blocks always have the differential bit set, so only the "colour5" branch of the reference exists
+// here. The per-cluster sub-block lists are the reference's m_subblocks, which are appended to on every call and never cleared.
+bool etc1s_frontend::refine_block_endpoints_given_selectors(uint32_t* total_refined) {
+    const uint32_t n = m_total_blocks, k = (uint32_t)m_endpoint_cluster_etc_params.size();
+    m_endpoint_cluster_subblocks.resize(k);
+    for (uint32_t b = 0; b < n; b++) {
+        std::vector<uint32_t>& l = m_endpoint_cluster_subblocks[m_block_endpoint_cluster[b]];
+        l.push_back(b * 2); l.push_back(b * 2 + 1);
+    }
+    csr lists; lists.build(m_endpoint_cluster_subblocks);
+    device_state& d = *m_dev;
+    if (!d.upload(d.offsets, lists.offsets.data(), lists.offsets.size()) || !d.upload(d.indices, lists.indices.data(), lists.indices.size()) ||
+        !d.upload(d.enc, m_encoded_blocks.data(), n) || !d.reserve(d.params, (size_t)k * 4) || !d.reserve(d.err, (size_t)k * 8) || !d.reserve(d.valid, k) ||
+        !d.reserve(d.weights, (size_t)k * 8))
+        return fail("upload");
+    if (!bu_hip_k_refit_endpoints_given_selectors(d.ctx, d.d_pixels, d.enc.p, k, lists.offsets.data(), (const uint32_t*)d.offsets.p, (const uint32_t*)d.indices.p,
+                                                  m_params.m_perceptual, (uint8_t*)d.params.p, (uint64_t*)d.err.p, (uint8_t*)d.valid.p, (uint64_t*)d.weights.p))
+        return fail("bu_hip_k_refit_endpoints_given_selectors");
+    std::vector<uint8_t> prm(k * 4ull), valid(k);
+    std::vector<uint64_t> err(k), cur(k);
+    if (!d.download(prm.data(), d.params, prm.size()) || !d.download(err.data(), d.err, k) || !d.download(valid.data(), d.valid, k) || !d.download(cur.data(), d.weights, k))
+        return fail("download");
+    uint32_t refined = 0;
+    for (uint32_t ci = 0; ci < k; ci++) {
+        const std::vector<uint32_t>& subs = m_endpoint_cluster_subblocks[ci];
+        if (subs.empty() || !valid[ci] || !(err[ci] < cur[ci])) continue;
+        const int nr = prm[ci * 4], ng = prm[ci * 4 + 1], nb = prm[ci * 4 + 2];
+        const uint32_t ninten = prm[ci * 4 + 3];
+        // two passes (:2838-2921): first check that every (old, new) colour pair of every listed sub-block packs as colour5 + delta3,
+        // then apply. The check is made against the block as it stands at that moment, which only matters in the second pass.
+        bool all_passed = true;
+        for (uint32_t pass = 0; pass < 2 && all_passed; pass++) {
+            for (uint32_t tv : subs) {
+                bu_etc_block& blk = m_encoded_blocks[tv >> 1];
+                const uint32_t sub = tv & 1;
+                uint64_t v = load_be64(blk);
+                int c[2][3];
+                const int dl[3] = { (int)((v >> 56) & 7), (int)((v >> 48) & 7), (int)((v >> 40) & 7) };
+                const int base[3] = { (int)((v >> 59) & 31), (int)((v >> 51) & 31), (int)((v >> 43) & 31) };
+                for (int ch = 0; ch < 3; ch++) {
+                    c[0][ch] = base[ch];
+                    c[1][ch] = base[ch] + (dl[ch] >= 4 ? dl[ch] - 8 : dl[ch]);  // unpack_color5 with delta3 (etc.cpp:413-439); in range for ETC1S blocks
+                }
+                c[sub][0] = nr; c[sub][1] = ng; c[sub][2] = nb;
+                bool ok = true;
+                for (int ch = 0; ch < 3; ch++) { const int dd = c[1][ch] - c[0][ch]; ok = ok && dd >= -4 && dd <= 3; }  // try_pack_color5_delta3
+                if (!ok) { all_passed = false; break; }
+                if (pass == 1) {
+                    // set_block_color5 + set_inten_table(sub) (etc.h:633-646, 203-214)
+                    v &= ~((0xFFull << 56) | (0xFFull << 48) | (0xFFull << 40));
+                    for (int ch = 0; ch < 3; ch++) {
+                        const int dd = c[1][ch] - c[0][ch];
+                        v |= ((uint64_t)(((uint32_t)c[0][ch] << 3) | ((uint32_t)dd & 7u))) << (56 - 8 * ch);
+                    }
+                    const int shift = sub ? 34 : 37;
+                    v = (v & ~(7ull << shift)) | ((uint64_t)ninten << shift);
+                    store_be64(blk, v);
+                    refined++;
+                }
+            }
+        }
+        if (all_passed) {
+            endpoint_params& e = m_endpoint_cluster_etc_params[ci];
+            e.r = (uint8_t)nr; e.g = (uint8_t)ng; e.b = (uint8_t)nb; e.inten = (uint8_t)ninten; e.color_error = err[ci];
+        }
+    }
+    if (refined && !d.upload(d.enc, m_encoded_blocks.data(), n)) return fail("upload refined blocks");  // the next selector pass reads the device copy
+    if (total_refined) *total_refined = refined;
     return true;
 }
 

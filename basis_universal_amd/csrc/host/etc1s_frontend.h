@@ -81,6 +81,7 @@ public:
     bool init_etc1_images();
     bool init_endpoint_training_vectors();
     bool generate_endpoint_clusters();
+    bool introduce_new_endpoint_clusters();
     bool generate_endpoint_codebook(uint32_t step);
     bool refine_endpoint_clusterization(uint32_t* total_reassigned);
     void eliminate_redundant_or_empty_endpoint_clusters();
@@ -92,6 +93,7 @@ public:
     bool create_optimized_selector_codebook(uint32_t iter);
     bool find_optimal_selector_clusters_for_each_block();
     bool introduce_special_selector_clusters();
+    bool refine_block_endpoints_given_selectors(uint32_t* total_refined);
     void optimize_selector_codebook();
     void finalize();
 
@@ -121,6 +123,7 @@ private:
     std::vector<std::vector<uint32_t>> m_endpoint_clusters_within_each_parent_cluster;
     std::vector<endpoint_params> m_endpoint_cluster_etc_params;
     std::vector<uint32_t> m_block_endpoint_cluster;
+    std::vector<std::vector<uint32_t>> m_endpoint_cluster_subblocks;  // endpoint_cluster_etc_params::m_subblocks (never cleared, frontend.cpp:2727-2729)
 
     // selector side
     std::vector<std::vector<uint32_t>> m_selector_cluster_block_indices, m_selector_parent_cluster_block_indices;

@@ -119,6 +119,18 @@ BU_HIP_API int bu_hip_k_endpoint_training_vectors(bu_hip_context*, const void* d
 BU_HIP_API int bu_hip_k_generate_endpoint_codebook(bu_hip_context*, const void* d_pixel_blocks, uint32_t n_clusters,
     const uint32_t* h_offsets, const uint32_t* d_offsets, const uint32_t* d_indices, int quality, int perceptual, uint32_t step,
     uint8_t* d_params, uint64_t* d_err, uint8_t* d_valid);
+/* a15 refine_block_endpoints_given_selectors (frontend.cpp:2718-2976, ETC1S levels 4-6): per endpoint cluster, the uber-quality
+ *     etc1_optimizer with the selectors of d_encoded_blocks held fixed (m_pForce_selectors). Lists are CSR over training-vector indices
+ *     like a9 and MAY contain duplicates (the reference's m_subblocks lists grow from iteration to iteration). Outputs per cluster:
+ *     the refitted {r5,g5,b5,inten}, its error, a validity flag, and the CURRENT error of the listed sub-blocks under their blocks'
+ *     present colours -- the caller applies the refit only where new error < current error (:2822). */
+BU_HIP_API int bu_hip_k_refit_endpoints_given_selectors(bu_hip_context*, const void* d_pixel_blocks, const void* d_encoded_blocks, uint32_t n_clusters,
+    const uint32_t* h_offsets, const uint32_t* d_offsets, const uint32_t* d_indices, int perceptual,
+    uint8_t* d_params, uint64_t* d_err, uint8_t* d_valid, uint64_t* d_current_err);
+/* a15 compute_endpoint_subblock_error_vec (frontend.cpp:1006-1091): u64 error of every training vector (block*2+subblock) under the
+ *     endpoints of its block's cluster; feeds introduce_new_endpoint_clusters. d_out_err: 2*n_blocks entries. */
+BU_HIP_API int bu_hip_k_subblock_errors(bu_hip_context*, const void* d_pixel_blocks, uint32_t n_blocks, const uint32_t* d_block_cluster,
+    const uint8_t* d_cluster_params, int perceptual, uint64_t* d_out_err);
 /* a10 refine_endpoint_clusterization (frontend.cpp:1648-1917) for BOTH hierarchical (n_parents > 0: candidates are
  *     d_cand_indices[d_cand_offsets[p] .. d_cand_offsets[p+1]) for the block's parent p) and flat codebooks (n_parents == 0). */
 BU_HIP_API int bu_hip_k_refine_endpoint_clusterization(bu_hip_context*, const void* d_pixel_blocks, uint32_t n_blocks,

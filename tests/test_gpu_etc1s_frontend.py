@@ -25,6 +25,11 @@ CASES = {
     "noise_small_codebooks": (lambda: uniform_random(96, 64, 42), 64, 64, 1, True),
     "synth512_q128": (lambda: synth(512, 512, 99), None, None, 1, True),
     "ragged_edges": (lambda: synth(132, 68, 3)[:67, :130], 128, 128, 1, True),
+    # levels 4-6: several endpoint / selector iterations, new clusters introduced between them, endpoints refitted to the selectors (row a15)
+    "synth256_l4": (lambda: synth(256, 192, 21), 300, 300, 4, True),
+    "synth256_l5_linear": (lambda: synth(192, 128, 22), 200, 256, 5, False),
+    "synth128_l6": (lambda: synth(128, 128, 23), 128, 160, 6, True),
+    "noise_l4": (lambda: uniform_random(96, 64, 7), 100, 100, 4, True),
 }
 
 STATE = ["etc1_blocks", "endpoint_cluster_etc_params", "block_endpoint_clusters_indices", "orig_encoded_blocks", "encoded_blocks",
@@ -73,7 +78,7 @@ def test_frontend_matches_golden(hip_ctx, case):
 
 
 @pytest.mark.skipif(not have_ref(), reason="oracle/_ref not present")
-@pytest.mark.parametrize("case", ["synth256_l1", "synth256_l3_flat", "noise_small_codebooks"])
+@pytest.mark.parametrize("case", ["synth256_l1", "synth256_l3_flat", "noise_small_codebooks", "synth256_l4", "synth256_l5_linear", "synth128_l6", "noise_l4"])
 def test_frontend_matches_live_reference(hip_ctx, case):
     blocks, max_ep, max_sel, level, perceptual = _params(case)
     got = _run_hip(hip_ctx, blocks, max_ep, max_sel, level, perceptual)
