@@ -366,28 +366,39 @@ int bu_hip_k_endpoint_training_vectors(bu_hip_context* ctx, const void* d_etc, u
     return 1;
 }
 
-int bu_hip_k_generate_endpoint_codebook(bu_hip_context* ctx, const void* d_px, uint32_t n_clusters, const uint32_t* h_offsets,
-                                        const uint32_t* d_offsets, const uint32_t* d_indices, int quality, int perceptual, uint32_t step,
-                                        uint8_t* d_params, uint64_t* d_err, uint8_t* d_valid) {
+int bu_hip_k_generate_endpoint_codebook_part(bu_hip_context* ctx, const void* d_px, uint32_t n_clusters, const uint32_t* h_offsets,
+                                             const uint32_t* d_offsets, const uint32_t* d_indices, int quality, int perceptual, uint32_t step,
+                                             uint8_t* d_params, uint64_t* d_err, uint8_t* d_valid, uint32_t part, uint32_t parts) {
     if (!ctx) return 0;
     if (!n_clusters) return 1;
+    if (!parts || part >= parts) { set_error(ctx, "generate_endpoint_codebook: bad part %u of %u", part, parts); return 0; }
     device_guard g(ctx->device);
-    // largest clusters first: one workgroup per cluster, so the big ones must not start last
+    // largest clusters first: one workgroup per cluster, so the big ones must not start last. With parts > 1 this call handles the
+    // clusters at positions part, part + parts, ... of that order (the same order on every rank: the sort is stable and deterministic).
     std::vector<uint32_t> order(n_clusters);
     std::iota(order.begin(), order.end(), 0u);
     std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
         return (h_offsets[a + 1] - h_offsets[a]) > (h_offsets[b + 1] - h_offsets[b]);
     });
+    std::vector<uint32_t> mine;
+    for (uint32_t i = part; i < n_clusters; i += parts) mine.push_back(order[i]);
+    if (mine.empty()) return 1;
     arena& ord = ctx->scratch[5];
-    BU_TRY(ctx, ord.reserve(n_clusters * sizeof(uint32_t)));
-    BU_TRY(ctx, h2d(ctx, ord.p, order.data(), n_clusters * sizeof(uint32_t)));
+    BU_TRY(ctx, ord.reserve(mine.size() * sizeof(uint32_t)));
+    BU_TRY(ctx, h2d(ctx, ord.p, mine.data(), mine.size() * sizeof(uint32_t)));
     {
         prof_scope ps(ctx, "generate_endpoint_codebook");
-        BU_TRY(ctx, bu::launch_generate_endpoint_codebook(ctx->stream, d_px, n_clusters, static_cast<const uint32_t*>(ord.p), d_offsets, d_indices,
+        BU_TRY(ctx, bu::launch_generate_endpoint_codebook(ctx->stream, d_px, (uint32_t)mine.size(), static_cast<const uint32_t*>(ord.p), d_offsets, d_indices,
                                                           quality, perceptual != 0, step, d_params, d_err, d_valid));
     }
-    BU_TRY(ctx, hipStreamSynchronize(ctx->stream)); // `order` is pageable host memory owned by this call
+    BU_TRY(ctx, hipStreamSynchronize(ctx->stream)); // `mine` is pageable host memory owned by this call
     return 1;
+}
+
+int bu_hip_k_generate_endpoint_codebook(bu_hip_context* ctx, const void* d_px, uint32_t n_clusters, const uint32_t* h_offsets,
+                                        const uint32_t* d_offsets, const uint32_t* d_indices, int quality, int perceptual, uint32_t step,
+                                        uint8_t* d_params, uint64_t* d_err, uint8_t* d_valid) {
+    return bu_hip_k_generate_endpoint_codebook_part(ctx, d_px, n_clusters, h_offsets, d_offsets, d_indices, quality, perceptual, step, d_params, d_err, d_valid, 0, 1);
 }
 
 int bu_hip_k_refit_endpoints_given_selectors(bu_hip_context* ctx, const void* d_px, const void* d_enc, uint32_t n_clusters, const uint32_t* h_offsets,

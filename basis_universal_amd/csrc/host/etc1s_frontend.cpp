@@ -182,6 +182,30 @@ bool etc1s_frontend::fail(const char* what) {
     return false;
 }
 
+// ---- multi-GPU helpers (include/basisu_hip_frontend.h: bu_comm)
+uint32_t etc1s_frontend::slab_blocks() const {
+    const uint32_t w = comm_world();
+    const uint32_t per = (m_total_blocks + w - 1) / w;
+    return (per + kFoscJobSize - 1) / kFoscJobSize * kFoscJobSize;  // keeps find_optimal_selector_clusters' 2048-block jobs aligned
+}
+void etc1s_frontend::my_slab(uint32_t& first, uint32_t& count) const {
+    const uint32_t per = slab_blocks();
+    first = std::min<uint64_t>((uint64_t)comm_rank() * per, m_total_blocks);
+    count = std::min<uint32_t>(per, m_total_blocks - first);
+}
+bool etc1s_frontend::gather_blocks(void* d_buf, size_t bytes_per_block) {
+    if (!m_has_comm) return true;
+    if (!bu_hip_sync(m_dev->ctx)) return fail("sync before all_gather");
+    if (!m_comm.all_gather(m_comm.user, d_buf, (uint64_t)slab_blocks() * bytes_per_block)) return fail("all_gather failed");
+    return true;
+}
+bool etc1s_frontend::merge_disjoint(void* d_buf, size_t bytes) {
+    if (!m_has_comm) return true;
+    if (!bu_hip_sync(m_dev->ctx)) return fail("sync before all_reduce");
+    if (!m_comm.all_reduce_u64(m_comm.user, d_buf, (uint64_t)((bytes + 7) / 8))) return fail("all_reduce failed");
+    return true;
+}
+
 // basisu_frontend::init (frontend.cpp:51-157)
 bool etc1s_frontend::init(const params& p) {
     if (!p.m_pHIP_context) return fail("etc1s_frontend::init: a bu_hip_context is required (there is no CPU path)");
@@ -270,8 +294,12 @@ bool etc1s_frontend::init_etc1_images() {
     const int quality = m_params.m_compression_level == 0 ? BU_ETC_QUALITY_FAST : m_params.m_compression_level == 1 ? BU_ETC_QUALITY_MEDIUM
                       : m_params.m_compression_level == 6 ? BU_ETC_QUALITY_UBER : BU_ETC_QUALITY_SLOW; // frontend.cpp:783-788
     device_state& d = *m_dev;
-    if (!d.reserve(d.etc1, (size_t)n * 8)) return fail("alloc");
-    if (!bu_hip_k_encode_etc1s_blocks(d.ctx, d.d_pixels, n, quality, m_params.m_perceptual, d.etc1.p)) return fail("bu_hip_k_encode_etc1s_blocks");
+    uint32_t b0, nb;
+    my_slab(b0, nb);
+    if (!d.reserve(d.etc1, (size_t)comm_world() * slab_blocks() * 8)) return fail("alloc");
+    if (nb && !bu_hip_k_encode_etc1s_blocks(d.ctx, (const char*)d.d_pixels + (size_t)b0 * 64, nb, quality, m_params.m_perceptual, (char*)d.etc1.p + (size_t)b0 * 8))
+        return fail("bu_hip_k_encode_etc1s_blocks");
+    if (!gather_blocks(d.etc1.p, 8)) return false;
     m_etc1_blocks_etc1s.resize(n);
     if (!d.download(m_etc1_blocks_etc1s.data(), d.etc1, n)) return fail("download etc1 blocks");
     return true;
@@ -382,12 +410,28 @@ bool etc1s_frontend::generate_endpoint_codebook(uint32_t step) {
         prm[i * 4] = e.r; prm[i * 4 + 1] = e.g; prm[i * 4 + 2] = e.b; prm[i * 4 + 3] = e.inten; valid[i] = e.valid; err[i] = e.color_error;
     }
     device_state& d = *m_dev;
+    if (m_has_comm) {
+        // this rank fits the clusters at positions rank, rank + world, ... of the size-descending order (the order the device layer
+        // schedules them in); everything else is zeroed so that the sum-merge below puts the shares together
+        std::vector<uint32_t> order(k);
+        std::iota(order.begin(), order.end(), 0u);
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return (lists.offsets[a + 1] - lists.offsets[a]) > (lists.offsets[b + 1] - lists.offsets[b]); });
+        std::vector<uint8_t> own(k, 0);
+        for (uint32_t i = comm_rank(); i < k; i += comm_world()) own[order[i]] = 1;
+        for (uint32_t i = 0; i < k; i++)
+            if (!own[i]) { prm[i * 4] = prm[i * 4 + 1] = prm[i * 4 + 2] = prm[i * 4 + 3] = 0; valid[i] = 0; err[i] = 0; }
+    }
     if (!d.upload(d.offsets, lists.offsets.data(), lists.offsets.size()) || !d.upload(d.indices, lists.indices.data(), lists.indices.size()) ||
-        !d.upload(d.params, prm.data(), prm.size()) || !d.upload(d.err, err.data(), err.size()) || !d.upload(d.valid, valid.data(), valid.size()))
+        !d.reserve(d.params, (size_t)k * 4 + 8) || !d.upload(d.params, prm.data(), prm.size()) || !d.upload(d.err, err.data(), err.size()) ||
+        !d.reserve(d.valid, (size_t)k + 8) || !d.upload(d.valid, valid.data(), valid.size()))
         return fail("upload endpoint clusters");
-    if (!bu_hip_k_generate_endpoint_codebook(d.ctx, d.d_pixels, k, lists.offsets.data(), (const uint32_t*)d.offsets.p, (const uint32_t*)d.indices.p, quality,
-                                             m_params.m_perceptual, step, (uint8_t*)d.params.p, (uint64_t*)d.err.p, (uint8_t*)d.valid.p))
+    if (m_has_comm) {  // the u64 merge rounds the byte arrays up to whole words: clear the tail
+        if (!bu_hip_memset(d.ctx, (char*)d.params.p + (size_t)k * 4, 0, 8) || !bu_hip_memset(d.ctx, (char*)d.valid.p + k, 0, 8)) return fail("memset");
+    }
+    if (!bu_hip_k_generate_endpoint_codebook_part(d.ctx, d.d_pixels, k, lists.offsets.data(), (const uint32_t*)d.offsets.p, (const uint32_t*)d.indices.p, quality,
+                                                  m_params.m_perceptual, step, (uint8_t*)d.params.p, (uint64_t*)d.err.p, (uint8_t*)d.valid.p, comm_rank(), comm_world()))
         return fail("bu_hip_k_generate_endpoint_codebook");
+    if (!merge_disjoint(d.params.p, (size_t)k * 4) || !merge_disjoint(d.err.p, (size_t)k * 8) || !merge_disjoint(d.valid.p, k)) return false;
     if (!d.download(prm.data(), d.params, prm.size()) || !d.download(err.data(), d.err, err.size()) || !d.download(valid.data(), d.valid, valid.size()))
         return fail("download endpoint codebook");
     for (uint32_t i = 0; i < k; i++) {
@@ -535,11 +579,15 @@ bool etc1s_frontend::refine_endpoint_clusterization(uint32_t* total_reassigned) 
             !d.upload(d.block_parent, m_block_parent_endpoint_cluster.data(), n))
             return fail("upload parent lists");
     }
-    if (!d.upload(d.block_cluster, block_cluster.data(), n) || !d.upload(d.params, prm.data(), prm.size()) || !d.reserve(d.out_u32, (size_t)n * 4)) return fail("upload refine inputs");
-    if (!bu_hip_k_refine_endpoint_clusterization(d.ctx, d.d_pixels, n, (const uint32_t*)d.block_cluster.p, (const uint8_t*)d.params.p, k, n_parents,
-                                                 (const uint32_t*)d.cand_offsets.p, (const uint32_t*)d.cand_indices.p, (const uint8_t*)d.block_parent.p,
-                                                 m_params.m_perceptual, (uint32_t*)d.out_u32.p))
+    if (!d.upload(d.block_cluster, block_cluster.data(), n) || !d.upload(d.params, prm.data(), prm.size()) || !d.reserve(d.out_u32, (size_t)comm_world() * slab_blocks() * 4))
+        return fail("upload refine inputs");
+    uint32_t b0, nb;
+    my_slab(b0, nb);
+    if (nb && !bu_hip_k_refine_endpoint_clusterization(d.ctx, (const char*)d.d_pixels + (size_t)b0 * 64, nb, (const uint32_t*)d.block_cluster.p + b0, (const uint8_t*)d.params.p, k,
+                                                       n_parents, (const uint32_t*)d.cand_offsets.p, (const uint32_t*)d.cand_indices.p,
+                                                       n_parents ? (const uint8_t*)d.block_parent.p + b0 : nullptr, m_params.m_perceptual, (uint32_t*)d.out_u32.p + b0))
         return fail("bu_hip_k_refine_endpoint_clusterization");
+    if (!gather_blocks(d.out_u32.p, 4)) return false;
     std::vector<uint32_t> best(n);
     if (!d.download(best.data(), d.out_u32, n)) return fail("download refine result");
 
@@ -749,11 +797,25 @@ bool etc1s_frontend::create_optimized_selector_codebook(uint32_t /*iter*/) {
     m_optimized_cluster_selectors.resize(k, bu_etc_block{});
     csr lists; lists.build(m_selector_cluster_block_indices);
     device_state& d = *m_dev;
+    // multi-GPU: every rank takes a contiguous range of clusters holding about 1/world of the member blocks; entries it does not own
+    // are uploaded as zero, so that the sum-merge below reassembles the codebook exactly
+    uint32_t c0 = 0, c1 = k;
+    std::vector<bu_etc_block> mine(m_optimized_cluster_selectors);
+    if (m_has_comm) {
+        const uint64_t total = lists.offsets[k], w = comm_world(), r = comm_rank();
+        auto cut = [&](uint64_t part) { return (uint32_t)(std::lower_bound(lists.offsets.begin(), lists.offsets.end(), (uint32_t)(total * part / w)) - lists.offsets.begin()); };
+        c0 = r == 0 ? 0 : std::min(cut(r), k);
+        c1 = r + 1 == w ? k : std::min(cut(r + 1), k);
+        if (c1 < c0) c1 = c0;
+        for (uint32_t i = 0; i < k; i++) if (i < c0 || i >= c1) mine[i] = bu_etc_block{};
+    }
     if (!d.upload(d.offsets, lists.offsets.data(), lists.offsets.size()) || !d.upload(d.indices, lists.indices.data(), lists.indices.size()) ||
-        !d.upload(d.sel_blocks, m_optimized_cluster_selectors.data(), k))
+        !d.reserve(d.sel_blocks, (size_t)k * 8 + 8) || !d.upload(d.sel_blocks, mine.data(), k))
         return fail("upload selector clusters");
-    if (!bu_hip_k_create_optimized_selector_codebook(d.ctx, d.d_pixels, d.enc.p, k, (const uint32_t*)d.offsets.p, (const uint32_t*)d.indices.p, m_params.m_perceptual, d.sel_blocks.p))
+    if (c1 > c0 && !bu_hip_k_create_optimized_selector_codebook(d.ctx, d.d_pixels, d.enc.p, c1 - c0, (const uint32_t*)d.offsets.p + c0, (const uint32_t*)d.indices.p, m_params.m_perceptual,
+                                                               (char*)d.sel_blocks.p + (size_t)c0 * 8))
         return fail("bu_hip_k_create_optimized_selector_codebook");
+    if (!merge_disjoint(d.sel_blocks.p, (size_t)k * 8)) return false;
     if (!d.download(m_optimized_cluster_selectors.data(), d.sel_blocks, k)) return fail("download selector codebook");
     return true;
 }
@@ -782,10 +844,16 @@ bool etc1s_frontend::find_optimal_selector_clusters_for_each_block() {
             !d.upload(d.block_parent, m_block_parent_selector_cluster.data(), n))
             return fail("upload selector parent lists");
     }
-    if (!d.upload(d.sel_blocks, m_optimized_cluster_selectors.data(), k) || !d.upload(d.enc, m_encoded_blocks.data(), n) || !d.reserve(d.out_u32, (size_t)n * 4)) return fail("upload fosc inputs");
-    if (!bu_hip_k_find_optimal_selector_clusters(d.ctx, d.d_pixels, d.enc.p, n, d.sel_blocks.p, k, n_parents, (const uint32_t*)d.cand_offsets.p,
-                                                 (const uint32_t*)d.cand_indices.p, (const uint8_t*)d.block_parent.p, m_params.m_perceptual, kFoscJobSize, (uint32_t*)d.out_u32.p))
+    const size_t padded = (size_t)comm_world() * slab_blocks();
+    if (!d.upload(d.sel_blocks, m_optimized_cluster_selectors.data(), k) || !d.reserve(d.enc, padded * 8) || !d.upload(d.enc, m_encoded_blocks.data(), n) || !d.reserve(d.out_u32, padded * 4))
+        return fail("upload fosc inputs");
+    uint32_t b0, nb;
+    my_slab(b0, nb);  // slabs start on multiples of the reference's 2048-block jobs, so the "same tile as the previous block of this job" shortcut sees the same neighbours
+    if (nb && !bu_hip_k_find_optimal_selector_clusters(d.ctx, (const char*)d.d_pixels + (size_t)b0 * 64, (char*)d.enc.p + (size_t)b0 * 8, nb, d.sel_blocks.p, k, n_parents,
+                                                       (const uint32_t*)d.cand_offsets.p, (const uint32_t*)d.cand_indices.p, n_parents ? (const uint8_t*)d.block_parent.p + b0 : nullptr,
+                                                       m_params.m_perceptual, kFoscJobSize, (uint32_t*)d.out_u32.p + b0))
         return fail("bu_hip_k_find_optimal_selector_clusters");
+    if (!gather_blocks(d.enc.p, 8) || !gather_blocks(d.out_u32.p, 4)) return false;
     if (!d.download(m_block_selector_cluster_index.data(), d.out_u32, n) || !d.download(m_encoded_blocks.data(), d.enc, n)) return fail("download fosc result");
     // frontend.cpp:2696-2708
     std::vector<uint32_t> sizes(m_selector_cluster_block_indices.size(), 0);

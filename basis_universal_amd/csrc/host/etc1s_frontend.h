@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "../../../include/basisu_hip.h"
+#include "../../../include/basisu_hip_frontend.h"
 
 namespace bu {
 
@@ -44,6 +45,8 @@ public:
     etc1s_frontend(const etc1s_frontend&) = delete;
     etc1s_frontend& operator=(const etc1s_frontend&) = delete;
 
+    // multi-GPU: see include/basisu_hip_frontend.h (bu_comm). The struct is copied.
+    void set_comm(const bu_comm* c) { if (c) { m_comm = *c; m_has_comm = c->world > 1; } else m_has_comm = false; }
     bool init(const params& p);
     bool compress();
     const std::string& error() const { return m_error; }
@@ -102,6 +105,14 @@ private:
     bool fail(const char* what);
 
     params m_params;
+    bu_comm m_comm{};
+    bool m_has_comm = false;
+    uint32_t comm_world() const { return m_has_comm ? m_comm.world : 1; }
+    uint32_t comm_rank() const { return m_has_comm ? m_comm.rank : 0; }
+    uint32_t slab_blocks() const;                           // blocks per rank (multiple of the selector job size)
+    void my_slab(uint32_t& first, uint32_t& count) const;
+    bool gather_blocks(void* d_buf, size_t bytes_per_block); // all-gather of a per-block device array written slab-wise
+    bool merge_disjoint(void* d_buf, size_t bytes);          // sum-merge of per-rank partial results (zero where not owned)
     std::string m_error;
     device_state* m_dev = nullptr;
 

@@ -56,6 +56,12 @@ int bu_frontend_init(bu_frontend* f, bu_hip_context* ctx, const bu_pixel_block* 
     return f->fe.init(p) ? 1 : 0;
 }
 
+int bu_frontend_set_comm(bu_frontend* f, const bu_comm* comm) {
+    if (!f) return 0;
+    f->fe.set_comm(comm);
+    return 1;
+}
+
 int bu_frontend_compress(bu_frontend* f) { return (f && f->fe.compress()) ? 1 : 0; }
 
 int bu_frontend_call(bu_frontend* f, const char* stage, uint32_t arg) {

@@ -33,6 +33,8 @@ def load_frontend_library():
         L.bu_frontend_destroy.argtypes = [_vp]
         L.bu_frontend_init.restype = C.c_int
         L.bu_frontend_init.argtypes = [_vp, _vp, _vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int]
+        L.bu_frontend_set_comm.restype = C.c_int
+        L.bu_frontend_set_comm.argtypes = [_vp, _vp]
         L.bu_frontend_compress.restype = C.c_int
         L.bu_frontend_compress.argtypes = [_vp]
         L.bu_frontend_call.restype = C.c_int
@@ -59,12 +61,75 @@ def quality_to_clusters(quality_level, total_blocks):
     return ep.value, sel.value
 
 
+_GATHER_FN = C.CFUNCTYPE(C.c_int, _vp, _vp, C.c_uint64)
+_REDUCE_FN = C.CFUNCTYPE(C.c_int, _vp, _vp, C.c_uint64)
+
+
+class _BuComm(C.Structure):  # = bu_comm, include/basisu_hip_frontend.h
+    _fields_ = [("rank", C.c_uint32), ("world", C.c_uint32), ("user", _vp), ("all_gather", _GATHER_FN), ("all_reduce_u64", _REDUCE_FN)]
+
+
+class _DevicePtr:
+    """Zero-copy view of raw device memory for torch.as_tensor (CUDA array interface v2)."""
+
+    def __init__(self, ptr, nbytes, typestr="|u1", itemsize=1):
+        self.__cuda_array_interface__ = {"shape": (nbytes // itemsize,), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+
+
+class TorchComm:
+    """The two collectives the sharded frontend needs (bu_comm), on torch.distributed: backend "nccl" is RCCL over xGMI on ROCm;
+    "gloo" works too (tests). One instance per process group; keep it alive as long as frontends use it."""
+
+    def __init__(self, group=None, device=None):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist, self.group = torch, dist, group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self.calls = {"all_gather": 0, "all_reduce_u64": 0, "bytes": 0}
+
+        def gather(_user, d_buf, bytes_per_rank):
+            try:
+                n = int(bytes_per_rank)
+                t = torch.as_tensor(_DevicePtr(d_buf, n * self.world), device=self.device)
+                outs = [t[r * n:(r + 1) * n] for r in range(self.world)]
+                dist.all_gather(outs, outs[self.rank].clone(), group=self.group)
+                torch.cuda.synchronize(self.device)
+                self.calls["all_gather"] += 1
+                self.calls["bytes"] += n * self.world
+                return 1
+            except Exception as e:  # never let an exception cross the C boundary
+                self.error = repr(e)
+                return 0
+
+        def reduce(_user, d_buf, count):
+            try:
+                t = torch.as_tensor(_DevicePtr(d_buf, int(count) * 8, "<i8", 8), device=self.device)
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)  # two's complement: the i64 sum is the u64 sum
+                torch.cuda.synchronize(self.device)
+                self.calls["all_reduce_u64"] += 1
+                self.calls["bytes"] += int(count) * 8
+                return 1
+            except Exception as e:
+                self.error = repr(e)
+                return 0
+
+        self.error = ""
+        self._gather, self._reduce = _GATHER_FN(gather), _REDUCE_FN(reduce)
+        self.struct = _BuComm(self.rank, self.world, None, self._gather, self._reduce)
+
+
 class Etc1sFrontend:
-    def __init__(self, ctx):
+    def __init__(self, ctx, comm=None):
+        """comm: a TorchComm to shard the device stages over the ranks of its process group (every rank must drive an identical
+        frontend on identical tiles); None = single GPU."""
         self.ctx = ctx
         self.L = load_frontend_library()
         self.h = self.L.bu_frontend_create()
         self._keep = None
+        self.comm = comm
+        if comm is not None:
+            self._check(self.L.bu_frontend_set_comm(self.h, C.byref(comm.struct)), "bu_frontend_set_comm")
 
     def _check(self, ok, what):
         if not ok:

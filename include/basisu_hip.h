@@ -131,6 +131,11 @@ BU_HIP_API int bu_hip_k_refit_endpoints_given_selectors(bu_hip_context*, const v
  *     endpoints of its block's cluster; feeds introduce_new_endpoint_clusters. d_out_err: 2*n_blocks entries. */
 BU_HIP_API int bu_hip_k_subblock_errors(bu_hip_context*, const void* d_pixel_blocks, uint32_t n_blocks, const uint32_t* d_block_cluster,
     const uint8_t* d_cluster_params, int perceptual, uint64_t* d_out_err);
+/* a9 for one of `parts` equal shares of the clusters (multi-GPU): the clusters at positions part, part + parts, ... of the
+ *     size-descending order. Entries of clusters outside the share are neither read nor written. */
+BU_HIP_API int bu_hip_k_generate_endpoint_codebook_part(bu_hip_context*, const void* d_pixel_blocks, uint32_t n_clusters,
+    const uint32_t* h_offsets, const uint32_t* d_offsets, const uint32_t* d_indices, int quality, int perceptual, uint32_t step,
+    uint8_t* d_params, uint64_t* d_err, uint8_t* d_valid, uint32_t part, uint32_t parts);
 /* a10 refine_endpoint_clusterization (frontend.cpp:1648-1917) for BOTH hierarchical (n_parents > 0: candidates are
  *     d_cand_indices[d_cand_offsets[p] .. d_cand_offsets[p+1]) for the block's parent p) and flat codebooks (n_parents == 0). */
 BU_HIP_API int bu_hip_k_refine_endpoint_clusterization(bu_hip_context*, const void* d_pixel_blocks, uint32_t n_blocks,

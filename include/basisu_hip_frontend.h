@@ -18,6 +18,22 @@ BU_HIP_API void bu_frontend_destroy(bu_frontend*);
 /* basisu_frontend::init (frontend.cpp:51). Exactly one of h_blocks (host tiles, uploaded once) / d_blocks (tiles already in HBM). */
 BU_HIP_API int bu_frontend_init(bu_frontend*, bu_hip_context* ctx, const bu_pixel_block* h_blocks, const void* d_blocks, uint32_t n_blocks,
                                 uint32_t max_endpoint_clusters, uint32_t max_selector_clusters, uint32_t compression_level, int perceptual);
+/* Multi-GPU: one process per GPU, every rank runs the same frontend on the same (replicated) tiles. With a
+ * communicator set, the heavy device stages are SHARDED -- per-block stages by block-row slab (a6, a10, a14), per-cluster stages by
+ * cluster subsets (a9, a13) -- and their fixed-size results exchanged through the two collectives below; the order-dependent parts
+ * (TSVQ, cluster bookkeeping) run replicated, so every rank ends with the identical, single-GPU-identical state.
+ * The collectives are supplied by the host application (torch.distributed over RCCL in basis_universal_amd/etc1s.py). They are
+ * called with the context's stream idle and must return with the result complete:
+ *   all_gather    : in place over world * bytes_per_rank bytes; rank r owns segment r
+ *   all_reduce_u64: in place element-wise sum of `count` u64 (used to merge disjoint per-rank results and integer accumulators) */
+typedef struct bu_comm {
+    uint32_t rank, world;
+    void* user;
+    int (*all_gather)(void* user, void* d_buf, uint64_t bytes_per_rank);
+    int (*all_reduce_u64)(void* user, void* d_buf, uint64_t count);
+} bu_comm;
+BU_HIP_API int bu_frontend_set_comm(bu_frontend*, const bu_comm* comm); /* NULL = single GPU; call before bu_frontend_init */
+
 /* basisu_frontend::compress (frontend.cpp:159) */
 BU_HIP_API int bu_frontend_compress(bu_frontend*);
 /* Single-step one stage method by its reference name (tests); arg = step / iteration where the method takes one. */

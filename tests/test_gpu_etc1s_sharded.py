@@ -1,0 +1,59 @@
+"""-m gpu: the slab / cluster sharded ETC1S frontend (bu_comm) on real kernels. The GPU box has one GPU, so two
+ranks share cuda:0 and exchange through gloo; what is under test is the sharding itself: per-block stages by slab, per-cluster
+stages by cluster share, all-gather / sum-merge of the results. Every rank must end with exactly the single-GPU state, which in turn
+equals the reference's (golden digests)."""
+import json
+import os
+import socket
+
+import numpy as np
+import pytest
+
+import test_gpu_etc1s_frontend as T
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, case, out_dir):
+    import torch
+    import torch.distributed as dist
+    from basis_universal_amd import capi
+    from basis_universal_amd.etc1s import Etc1sFrontend, TorchComm
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ctx = capi.Context(0)
+        comm = TorchComm()
+        blocks, max_ep, max_sel, level, perceptual = T._params(case)
+        fe = Etc1sFrontend(ctx, comm)
+        fe.init(blocks, max_ep, max_sel, level, perceptual)
+        fe.compress()
+        digest = T._digest({k: fe.get(k) for k in T.STATE})
+        with open(os.path.join(out_dir, f"r{rank}.json"), "w") as f:
+            json.dump({"digest": digest, "calls": comm.calls, "error": comm.error}, f)
+        fe.close()
+        ctx.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case,world", [("synth256_l1", 2), ("synth256_l3_flat", 2), ("synth256_l4", 2), ("synth512_q128", 3)])
+def test_sharded_frontend_equals_single_gpu(tmp_path, case, world):
+    import torch.multiprocessing as mp
+    golden = json.loads(T.GOLDEN.read_text())[case]["digests"]
+    mp.spawn(_worker, args=(world, _free_port(), case, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        res = json.loads((tmp_path / f"r{r}.json").read_text())
+        assert res["error"] == ""
+        assert res["calls"]["all_gather"] > 0 and res["calls"]["all_reduce_u64"] > 0
+        assert res["digest"] == golden, (r, {k: v[:10] for k, v in res["digest"].items() if v != golden[k]})
