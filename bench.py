@@ -128,7 +128,13 @@ def main():
         if dom:
             name, (ms, launches) = dom
             avg_s = ms / 1e3 / launches
-            alg_bytes = KERNEL_BYTES_PER_BLOCK.get(name, 64) * n_blocks
+            if name.startswith("tsvq"):
+                # the selector TSVQ streams the distinct selector vectors (4 B packed key + 8 B weight) once per pass; a launch covers
+                # one tree level, i.e. every vector once: 12 B x distinct vectors is the floor for a launch
+                enc = last.get("orig_encoded_blocks", np.uint8).reshape(-1, 8)
+                alg_bytes = 12 * int(np.unique(np.ascontiguousarray(enc[:, 4:]).view(np.uint32)).size)
+            else:
+                alg_bytes = KERNEL_BYTES_PER_BLOCK.get(name, 64) * n_blocks
             achieved = alg_bytes / avg_s / 1e9
             roofline = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
