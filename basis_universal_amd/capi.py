@@ -61,6 +61,7 @@ _SIGNATURES = {
     "bu_hip_memset": (_int, [_vp, _vp, _int, C.c_size_t]),
     "bu_hip_set_pixel_blocks_device": (_int, [_vp, C.c_size_t, _vp]),
     "bu_hip_get_pixel_blocks_device": (_vp, [_vp, C.POINTER(C.c_size_t)]),
+    "bu_hip_k_extract_blocks": (_int, [_vp, _vp, _u32, _u32, _u32, _vp]),
     "bu_hip_k_encode_etc1s_blocks": (_int, [_vp, _vp, _u32, _int, _int, _vp]),
     "bu_hip_k_endpoint_training_vectors": (_int, [_vp, _vp, _u32, _vp]),
     "bu_hip_k_generate_endpoint_codebook": (_int, [_vp, _vp, _u32, _vp, _vp, _vp, _int, _int, _u32, _vp, _vp, _vp]),

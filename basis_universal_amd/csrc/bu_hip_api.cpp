@@ -442,6 +442,15 @@ int bu_hip_k_refine_endpoint_clusterization(bu_hip_context* ctx, const void* d_p
     return 1;
 }
 
+int bu_hip_k_extract_blocks(bu_hip_context* ctx, const void* d_rgba, uint32_t width, uint32_t height, uint32_t pitch_bytes, void* d_out) {
+    if (!ctx) return 0;
+    if (!d_rgba || !d_out || !width || !height || pitch_bytes < width * 4u) { set_error(ctx, "extract_blocks: bad arguments"); return 0; }
+    device_guard g(ctx->device);
+    prof_scope ps(ctx, "extract_blocks");
+    BU_TRY(ctx, bu::launch_extract_blocks(ctx->stream, d_rgba, width, height, pitch_bytes, d_out));
+    return 1;
+}
+
 int bu_hip_k_determine_selectors(bu_hip_context* ctx, const void* d_px, uint32_t n_blocks, const uint8_t* d_color5_inten,
                                  const uint32_t* d_block_cluster, int perceptual, void* d_out) {
     if (!ctx) return 0;

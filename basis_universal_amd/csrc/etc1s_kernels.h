@@ -32,4 +32,6 @@ hipError_t launch_find_optimal_selector_clusters(hipStream_t st, const void* d_p
                                                  const uint32_t* d_cand_indices, const uint8_t* d_block_parent, bool perceptual, uint32_t chunk,
                                                  uint32_t* d_scratch_idx, uint32_t* d_out_idx);
 
+hipError_t launch_extract_blocks(hipStream_t st, const void* d_rgba, uint32_t width, uint32_t height, uint32_t pitch_bytes, void* d_out_blocks);
+
 } // namespace bu

@@ -989,4 +989,42 @@ hipError_t launch_find_optimal_selector_clusters(hipStream_t st, const void* d_p
     return hipSuccess;
 }
 
+// -------------------------------------------------------------------------------------------------------------------
+// Input side: basis_compressor::extract_source_blocks (comp.cpp:3207-3268) = image::extract_block_clamped
+// per 4x4 block. One lane per block row: a 16-byte read of four texels (clamped at the right / bottom edges) and a 16-byte write,
+// so an RGBA raster can be uploaded once and tiled where it lives.
+// -------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_extract_blocks(const uint8_t* __restrict__ rgba, uint32_t width, uint32_t height, uint32_t pitch,
+                                                        uint32_t blocks_x, uint32_t n_blocks, uint4* __restrict__ out) {
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t block = t >> 2, row = t & 3u;
+    if (block >= n_blocks) return;
+    const uint32_t bx = block % blocks_x, by = block / blocks_x;
+    const uint32_t y = min(by * 4u + row, height - 1u);
+    const uint8_t* line = rgba + (size_t)y * pitch;
+    uint4 v;
+    if (bx * 4u + 3u < width && ((pitch | (uint32_t)(uintptr_t)rgba) & 15u) == 0) {
+        v = *reinterpret_cast<const uint4*>(line + (size_t)bx * 16u);
+    } else {
+        uint32_t p[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t x = min(bx * 4u + (uint32_t)k, width - 1u);
+            const uint8_t* q = line + (size_t)x * 4u;
+            p[k] = (uint32_t)q[0] | ((uint32_t)q[1] << 8) | ((uint32_t)q[2] << 16) | ((uint32_t)q[3] << 24);
+        }
+        v = make_uint4(p[0], p[1], p[2], p[3]);
+    }
+    out[(size_t)block * 4u + row] = v;
+}
+
+hipError_t launch_extract_blocks(hipStream_t st, const void* d_rgba, uint32_t width, uint32_t height, uint32_t pitch_bytes, void* d_out_blocks) {
+    if (!width || !height) return hipSuccess;
+    const uint32_t bx = (width + 3) / 4, by = (height + 3) / 4, n = bx * by;
+    hipLaunchKernelGGL(k_extract_blocks, dim3((n * 4 + 255) / 256), dim3(256), 0, st, static_cast<const uint8_t*>(d_rgba), width, height, pitch_bytes, bx, n,
+                       static_cast<uint4*>(d_out_blocks));
+    BU_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
 } // namespace bu

@@ -106,6 +106,11 @@ BU_HIP_API int   bu_hip_memset(bu_hip_context*, void* d_dst, int value, size_t b
 BU_HIP_API int   bu_hip_set_pixel_blocks_device(bu_hip_context*, size_t total_blocks, const void* d_pixel_blocks);
 BU_HIP_API const void* bu_hip_get_pixel_blocks_device(const bu_hip_context*, size_t* total_blocks);
 
+/* Input side: basis_compressor::extract_source_blocks (comp.cpp:3207-3268) on the device. d_rgba is a resident RGBA8 raster
+ * (row pitch in bytes >= 4*width); writes ceil(w/4)*ceil(h/4) tiles in block-raster order with the right/bottom edges clamped like
+ * image::extract_block_clamped. The result can be adopted with bu_hip_set_pixel_blocks_device. */
+BU_HIP_API int bu_hip_k_extract_blocks(bu_hip_context*, const void* d_rgba, uint32_t width, uint32_t height, uint32_t pitch_bytes, void* d_out_pixel_blocks);
+
 /* etc1_optimizer quality (basis_etc_quality, basisu_etc.h:794-801) */
 enum { BU_ETC_QUALITY_FAST = 0, BU_ETC_QUALITY_MEDIUM = 1, BU_ETC_QUALITY_SLOW = 2, BU_ETC_QUALITY_UBER = 3 };
 

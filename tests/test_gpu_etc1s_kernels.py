@@ -292,3 +292,63 @@ def test_find_optimal_selector_clusters(hip_ctx, blocks, hier, perceptual):
     assert (got_enc == exp_enc).all()
     for p in bufs + [d_out]:
         hip_ctx.free(p)
+
+
+@pytest.mark.parametrize("w,h,pad", [(64, 64, 0), (130, 67, 0), (5, 3, 0), (1, 1, 0), (257, 129, 12), (4096, 2048, 0)])
+def test_extract_blocks(hip_ctx, w, h, pad):
+    """extract_source_blocks on the device (comp.cpp:3207-3268): tiles of an RGBA raster, edges clamped, arbitrary row pitch."""
+    rng = np.random.default_rng(w * 1000 + h)
+    pitch = w * 4 + pad
+    raster = rng.integers(0, 256, (h, pitch), dtype=np.uint8)
+    img = np.ascontiguousarray(raster[:, :w * 4].reshape(h, w, 4))
+    want = to_pixel_blocks(img)
+    d_img = hip_ctx.upload(raster)
+    d_out = hip_ctx.alloc(want.size)
+    hip_ctx.check(hip_ctx.lib.k_extract_blocks(hip_ctx.h, d_img, w, h, pitch, d_out), "k_extract_blocks")
+    got = hip_ctx.download(d_out, want.shape, np.uint8)
+    hip_ctx.free(d_img); hip_ctx.free(d_out)
+    assert (got == want).all()
+    assert hip_ctx.lib.k_extract_blocks(hip_ctx.h, d_img, w, h, w * 4 - 1, d_out) == 0  # pitch smaller than a row: refused, not a crash
+
+
+def test_two_contexts_on_two_threads(hip_ctx):
+    """The reference's threading rule (basisu_opencl.h:28-31): one context per thread, different contexts may run concurrently."""
+    import threading
+    from basis_universal_amd import capi, uastc
+    from basis_universal_amd.etc1s import Etc1sFrontend
+    imgs = [to_pixel_blocks(synth(192, 128, 100 + i)) for i in range(2)]
+
+    def encode(ctx, blocks):
+        fe = Etc1sFrontend(ctx)
+        fe.init(blocks, 200, 200, 1, True)
+        fe.compress()
+        out = (fe.get("encoded_blocks").copy(), uastc.encode_uastc_blocks(ctx, blocks, 2))
+        fe.close()
+        return out
+
+    serial = [encode(hip_ctx, b) for b in imgs]
+    results, errors = [None, None], []
+
+    def worker(i):
+        try:
+            ctx = capi.Context(0)
+            for _ in range(3):
+                results[i] = encode(ctx, imgs[i])
+            ctx.close()
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    th = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errors, errors
+    for i in range(2):
+        assert (results[i][0] == serial[i][0]).all() and (results[i][1] == serial[i][1]).all()
+
+
+def test_error_convention(hip_ctx):
+    """Failures return 0 and leave a message; nothing throws or aborts (opencl.cpp:972-976 convention)."""
+    lib = hip_ctx.lib
+    assert lib.k_encode_uastc_blocks(hip_ctx.h, None, 16, 2, None) == 0 and b"null" in lib.dll.bu_hip_last_error(hip_ctx.h)
+    assert lib.encode_uastc_blocks(None, None, 2) == 0
+    assert lib.k_generate_endpoint_codebook_part(hip_ctx.h, None, 4, None, None, None, 1, 1, 0, None, None, None, 3, 2) == 0
