@@ -110,7 +110,9 @@ BU_FN uint32_t pack_px(const uint8_t* c) { return (uint32_t)c[0] | ((uint32_t)c[
 // evaluate_solution (bc7enc.cpp:822-1049), ASTC branch with the non-perceptual selector search.
 // Interpolants are not tabulated: astc_lerp(L, H, w) = (64 * L257 + 32 + (H257 - L257) * w) >> 14 with X257 = X * 257, one multiply-add
 // per channel, and the weight of a selector comes from the set's (multiplier, shift) pair -- see weight_of.
-BU_FN uint64_t cell_eval(const uint32_t* px, uint32_t mask, const cell_cfg& cfg, const uint8_t* lo, const uint8_t* hi, cell_fit& best) {
+// FORCED: the selectors are given (m_pForce_selectors, bc7enc.cpp:885-898) and only the error is measured.
+template <bool FORCED>
+BU_FN uint64_t cell_eval(const uint32_t* px, uint32_t mask, const cell_cfg& cfg, const uint8_t* lo, const uint8_t* hi, cell_fit& best, const sel16* forced) {
     const uint32_t N = 1u << cfg.wbits;
     const uint8_t* SU = ku_sorted_unquant + cfg.range * 256;
     const int nc = cfg.alpha ? 4 : 3;
@@ -132,6 +134,17 @@ BU_FN uint64_t cell_eval(const uint32_t* px, uint32_t mask, const cell_cfg& cfg,
     for (int i = 0; i < 16; i++) {
         if (!((mask >> i) & 1)) continue;
         const uint32_t p = px[i];
+        if (FORCED) {
+            const uint32_t sf = sel_get(*forced, i);
+            uint32_t wf = umul24(sf, wmul) + (sf >> wshift);
+            wf += (wf + 31) >> 6;
+            for (int c = 0; c < nc; c++) {
+                const int d = ((base[c] + imul24(slope[c], (int)wf)) >> 14) - px_comp(p, c);
+                total += (uint32_t)imul24(d, d);
+            }
+            sel_set(tmp, i, sf);
+            continue;
+        }
         int proj = imul24(px_comp(p, 0) - L[0], dr) + imul24(px_comp(p, 1) - L[1], dg) + imul24(px_comp(p, 2) - L[2], db);
         if (cfg.alpha) proj += imul24(px_comp(p, 3) - L[3], da);
         int s = (int)((float)proj * f + .5f);
@@ -163,7 +176,8 @@ BU_FN uint64_t cell_eval(const uint32_t* px, uint32_t mask, const cell_cfg& cfg,
 }
 
 // find_optimal_solution (bc7enc.cpp:1103-1282), ASTC branch, mode 255 degeneracy handling (:1051-1101)
-BU_FN uint64_t cell_try(const uint32_t* px, uint32_t mask, const cell_cfg& cfg, const float* xl_in, const float* xh_in, cell_fit& best) {
+template <bool FORCED>
+BU_FN uint64_t cell_try(const uint32_t* px, uint32_t mask, const cell_cfg& cfg, const float* xl_in, const float* xh_in, cell_fit& best, const sel16* forced) {
     float xl[4], xh[4];
     for (int c = 0; c < 4; c++) { xl[c] = saturatef(xl_in[c]); xh[c] = saturatef(xh_in[c]); }
     const int top = (int)astc_levels(cfg.range) - 1;
@@ -190,7 +204,7 @@ BU_FN uint64_t cell_try(const uint32_t* px, uint32_t mask, const cell_cfg& cfg, 
         }
         bool differs = best.err == UINT64_MAX;
         for (int c = 0; c < 4; c++) differs = differs || a[c] != best.lo[c] || b[c] != best.hi[c];
-        if (differs) cell_eval(px, mask, cfg, a, b, best);
+        if (differs) cell_eval<FORCED>(px, mask, cfg, a, b, best, forced);
     }
     const uint8_t* SI = ku_sorted_index + cfg.range * 256;
     for (int c = 0; c < 4; c++) { best.astc_lo[c] = SI[best.lo[c]]; best.astc_hi[c] = SI[best.hi[c]]; }
@@ -278,7 +292,10 @@ BU_FN uint64_t one_colour_fit(const uint32_t* px, uint32_t mask, const cell_cfg&
 // color_cell_compression (bc7enc.cpp:1364-1762). The endpoint proposals (principal axis, least squares on the current selectors,
 // the selector perturbations of the uber levels) are generated by one loop so that cell_try -- and with it the unrolled
 // cell_eval -- is instantiated once.
-BU_FN_BIG uint64_t cell_compress(const uint32_t* px, uint32_t mask, const cell_cfg& cfg, cell_fit& best) {
+// FORCED (m_pForce_selectors: uastc_rdo's mode-0 endpoint refit, uastc_enc.cpp:4046-4060): no single-colour shortcuts, the
+// selectors never change, every proposal is scored on them.
+template <bool FORCED>
+BU_FN uint64_t cell_compress_t(const uint32_t* px, uint32_t mask, const cell_cfg& cfg, cell_fit& best, const sel16* forced) {
     best.err = UINT64_MAX;
     best.sel.w[0] = best.sel.w[1] = best.sel.w[2] = best.sel.w[3] = 0;
     const uint32_t n = (uint32_t)__builtin_popcount(mask);
@@ -297,7 +314,7 @@ BU_FN_BIG uint64_t cell_compress(const uint32_t* px, uint32_t mask, const cell_c
         if (!have_first) { first = px[i]; have_first = true; }
         else same = same && (((px[i] ^ first) & cmp_mask) == 0);
     }
-    if (has_kind && same) {
+    if (!FORCED && has_kind && same) {
         const uint32_t col[4] = { first & 255u, (first >> 8) & 255u, (first >> 16) & 255u, first >> 24 };
         return one_colour_fit(px, mask, cfg, kind, col, best);
     }
@@ -446,10 +463,10 @@ BU_FN_BIG uint64_t cell_compress(const uint32_t* px, uint32_t mask, const cell_c
             }
             cell_least_squares(px, mask, trial, cfg, xl, xh);
         }
-        if (!cell_try(px, mask, cfg, xl, xh, best)) return 0;
+        if (!cell_try<FORCED>(px, mask, cfg, xl, xh, best, forced)) return 0;
     }
 
-    if (has_kind) {
+    if (!FORCED && has_kind) {
         // the whole cell as its mean colour (bc7enc.cpp:1679-1755)
         uint32_t col[4];
         for (int c = 0; c < 4; c++) col[c] = (uint32_t)(int)(.5f + mean[c] * 255.0f);
@@ -457,6 +474,9 @@ BU_FN_BIG uint64_t cell_compress(const uint32_t* px, uint32_t mask, const cell_c
         if (one_colour_fit(px, mask, cfg, kind, col, avg) < best.err) best = avg;
     }
     return best.err;
+}
+BU_FN_BIG uint64_t cell_compress(const uint32_t* px, uint32_t mask, const cell_cfg& cfg, cell_fit& best) {
+    return cell_compress_t<false>(px, mask, cfg, best, nullptr);
 }
 
 // color_cell_compression_est_astc (bc7enc.cpp:1764-1984) with unit channel weights over the texels selected by `mask`: bounding-box

@@ -311,6 +311,28 @@ REF_API void ref_encode_uastc(const uint8_t* pixel_blocks, uint32_t n_blocks, ui
 }
 
 
+// uastc_rdo (uastc_enc.h:139, uastc_enc.cpp:4095-4163) in place over packed blocks. params: lambda, max_allowed_rms_increase_ratio,
+// skip_block_rms_thresh, max_smooth_block_std_dev, smooth_block_max_error_scale; uparams: lz_dict_size, lz_literal_cost,
+// endpoint_refinement. total_jobs > 1 splits into strips exactly like the reference's multithreaded path (strips are independent, so the
+// thread schedule cannot change the result).
+REF_API int ref_uastc_rdo(uint8_t* blocks16, const uint8_t* pixel_blocks, uint32_t n_blocks, const float* params, const uint32_t* uparams,
+                          uint32_t flags, uint32_t total_jobs) {
+	uastc_rdo_params p;
+	p.m_lambda = params[0];
+	p.m_max_allowed_rms_increase_ratio = params[1];
+	p.m_skip_block_rms_thresh = params[2];
+	p.m_max_smooth_block_std_dev = params[3];
+	p.m_smooth_block_max_error_scale = params[4];
+	p.m_lz_dict_size = uparams[0];
+	p.m_lz_literal_cost = uparams[1];
+	p.m_endpoint_refinement = uparams[2] != 0;
+	if (total_jobs > 1) {
+		job_pool jp(total_jobs);
+		return uastc_rdo(n_blocks, (basist::uastc_block*)blocks16, (const color_rgba*)pixel_blocks, p, flags, &jp, total_jobs) ? 1 : 0;
+	}
+	return uastc_rdo(n_blocks, (basist::uastc_block*)blocks16, (const color_rgba*)pixel_blocks, p, flags, nullptr, 0) ? 1 : 0;
+}
+
 // ---------------------------------------------------------------- UASTC: tables and staged hooks
 
 // Raw bytes of the reference's extern data / run-time generated tables (after ref_init), for tools/gen_uastc_tables.py

@@ -152,6 +152,8 @@ def ref():
         L.ref_tsvq.restype = C.c_int
         L.ref_tsvq.argtypes = [C.c_uint32, f32p, u64p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, u32p, C.c_uint64, u32p, C.c_uint64]
         L.ref_encode_uastc.argtypes = [u8p, C.c_uint32, C.c_uint32, u8p]
+        L.ref_uastc_rdo.restype = C.c_int
+        L.ref_uastc_rdo.argtypes = [u8p, u8p, C.c_uint32, f32p, u32p, C.c_uint32, C.c_uint32]
         L.ref_color_cell_compression.restype = C.c_uint64
         L.ref_color_cell_compression.argtypes = [u8p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32, C.c_uint32, u8p, u8p]
         L.ref_ccell_est.restype = C.c_uint64
@@ -265,6 +267,33 @@ def ref_encode_uastc(blocks, flags):
     return out
 
 
+RDO_DEFAULTS = dict(lam=1.0, max_rms_ratio=10.0, skip_rms=8.0, smooth_std_dev=18.0, smooth_scale=10.0, dict_size=4096, literal_cost=100, refine=1)
+
+
+def rdo_param_arrays(**kw):
+    """uastc_rdo_params (uastc_enc.h:94-134) as the (float[5], uint32[3]) pair the harnesses take."""
+    p = dict(RDO_DEFAULTS)
+    p.update(kw)
+    return (np.array([p["lam"], p["max_rms_ratio"], p["skip_rms"], p["smooth_std_dev"], p["smooth_scale"]], np.float32),
+            np.array([p["dict_size"], p["literal_cost"], p["refine"]], np.uint32))
+
+
+def ref_uastc_rdo(packed, blocks, flags, total_jobs=0, **kw):
+    fp, up = rdo_param_arrays(**kw)
+    out = np.ascontiguousarray(packed).copy()
+    blocks = np.ascontiguousarray(blocks)
+    assert ref().ref_uastc_rdo(ptr(out), ptr(blocks), out.shape[0], ptr(fp, f32p), ptr(up, u32p), flags, total_jobs) == 1
+    return out
+
+
+def host_uastc_rdo(packed, blocks, flags, total_jobs=0, **kw):
+    fp, up = rdo_param_arrays(**kw)
+    out = np.ascontiguousarray(packed).copy()
+    blocks = np.ascontiguousarray(blocks)
+    assert uastc_host().hc_uastc_rdo(ptr(out), ptr(blocks), out.shape[0], ptr(fp, f32p), ptr(up, u32p), flags, total_jobs) == 1
+    return out
+
+
 _uastc_host = None
 
 
@@ -274,11 +303,14 @@ def uastc_host():
     if _uastc_host is None:
         d = ROOT / "tests" / "native"
         so, srcs = d / "libuastc_host.so", [d / "uastc_host.cpp", ROOT / "basis_universal_amd" / "csrc" / "uastc_core.h",
+                                            ROOT / "basis_universal_amd" / "csrc" / "uastc_rdo.h",
                                             ROOT / "basis_universal_amd" / "csrc" / "uastc_tables.inc"]
         if not so.exists() or so.stat().st_mtime < max(s.stat().st_mtime for s in srcs):
             subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-o", str(so), str(srcs[0])])
         L = C.CDLL(str(so))
         L.hc_encode_uastc.argtypes = [u8p, C.c_uint32, C.c_uint32, u8p]
+        L.hc_uastc_rdo.restype = C.c_int
+        L.hc_uastc_rdo.argtypes = [u8p, u8p, C.c_uint32, f32p, u32p, C.c_uint32, C.c_uint32]
         L.hc_cell_compress.restype = C.c_uint64
         L.hc_cell_compress.argtypes = [u8p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32, C.c_uint32, u8p]
         L.hc_cell_estimate.restype = C.c_uint64

@@ -2,7 +2,9 @@
 // for the host with g++, so that every stage can be diffed against the real reference (oracle/_ref) on the CPU, where there is
 // no GPU. The product never builds or loads this file; libbasisu_hip.so compiles the same header with hipcc.
 #include <cstring>
-#include "../../basis_universal_amd/csrc/uastc_core.h"
+#include <map>
+#include <utility>
+#include "../../basis_universal_amd/csrc/uastc_rdo.h"
 
 using namespace bu_uastc;
 #define HC_API extern "C" __attribute__((visibility("default")))
@@ -31,4 +33,74 @@ HC_API uint32_t hc_weight_table(uint32_t bits, uint32_t s) { return weight_set(b
 HC_API void hc_encode_uastc(const uint8_t* blocks, uint32_t n, uint32_t flags, uint8_t* out) {
     static cand scratch[MAX_SLOTS];
     for (uint32_t i = 0; i < n; i++) encode_block(blocks + (size_t)i * 64, flags, out + (size_t)i * 16, scratch);
+}
+
+// uastc_rdo (uastc_enc.cpp:3824-4163) as a scalar loop over the shared per-block pieces of uastc_rdo.h: the order-defining part of the
+// GPU strips kernel (history of selector fields, window scan newest-first, strict "<" on the cost) restated the plain way.
+static bool rdo_strip(uint32_t first, uint32_t last, uint8_t* blocks, const uint8_t* pixels, const rdo_params& p, uint32_t flags) {
+    enc_cfg e;
+    make_cfg(flags, e);
+    const int window = (int)(p.lz_dict_size / 16 > 1 ? p.lz_dict_size / 16 : 1);
+    std::map<std::pair<uint32_t, uint64_t>, uint32_t> history;
+    for (uint32_t i = first; i < last; i++) {
+        uint8_t* blk = blocks + (size_t)i * 16;
+        const rgba8* px = (const rgba8*)(pixels + (size_t)i * 64);
+        cand cur;
+        rdo_block_info info;
+        if (!rdo_prepare(blk, px, p, cur, info)) return false;
+        if (info.mode == 8) continue;
+        const uint32_t fsb = ku_sel_first[info.mode], len = ku_sel_len[info.mode], len_lo = len < 64 ? len : 64;
+        const uint64_t cur_lo = block_bits(blk, fsb, len_lo);
+        if (info.skip) { history[{ fsb, cur_lo }] = i; continue; }
+        int cur_bits;
+        auto it = history.find({ fsb, cur_lo });
+        if (it == history.end()) cur_bits = (int)((len * p.lz_literal_cost) / 100);
+        else cur_bits = (int)match_cost((i - it->second) * 16);
+        float best_t = info.ms_err * info.scale + (float)cur_bits * p.lambda;
+        int best_j = -1;
+        uint64_t best_lo = 0, best_hi = 0;
+        const int lo_j = (int)i - window > (int)first ? (int)i - window : (int)first;
+        for (int j = (int)i - 1; j >= lo_j; j--) {
+            const uint8_t* prev = blocks + (size_t)j * 16;
+            const uint64_t lo = block_bits(prev, fsb, len_lo), hi = len > 64 ? block_bits(prev, fsb + 64, len - 64) : 0;
+            int match = j;
+            auto f = history.find({ fsb, lo });
+            if (f != history.end()) match = (int)f->second;
+            if (match > j) continue;
+            cand tmp;
+            if (!unpack_block(prev, tmp)) return false;
+            float ms;
+            if (!rdo_trial(cur, lo, hi, px, info, p, ms)) continue;
+            const float t = ms * info.scale + (float)(int)match_cost((i - (uint32_t)match) * 16) * p.lambda;
+            if (t < best_t) { best_t = t; best_j = j; best_lo = lo; best_hi = hi; }
+        }
+        uint64_t final_lo = cur_lo;
+        if (best_j >= 0) {
+            bool refined;
+            rdo_write_back(cur, best_lo, best_hi, px, p, blk, refined);
+            if (!rdo_rehint(px, e, blk)) return false;
+            final_lo = block_bits(blk, fsb, len_lo);
+        }
+        history[{ fsb, final_lo }] = i;
+    }
+    return true;
+}
+
+HC_API int hc_uastc_rdo(uint8_t* blocks, const uint8_t* pixels, uint32_t n, const float* fp, const uint32_t* up, uint32_t flags, uint32_t total_jobs) {
+    rdo_params p;
+    p.lambda = fp[0]; p.max_allowed_rms_increase_ratio = fp[1]; p.skip_block_rms_thresh = fp[2]; p.max_smooth_block_std_dev = fp[3];
+    p.smooth_block_max_error_scale = fp[4];
+    p.lz_dict_size = up[0]; p.lz_literal_cost = up[1]; p.endpoint_refinement = up[2];
+    const uint32_t per_job = total_jobs ? n / total_jobs : 0;
+    if (total_jobs <= 1 || per_job <= 8) return rdo_strip(0, n, blocks, pixels, p, flags) ? 1 : 0;
+    for (uint32_t f = 0; f < n; f += per_job)
+        if (!rdo_strip(f, f + per_job < n ? f + per_job : n, blocks, pixels, p, flags)) return 0;
+    return 1;
+}
+
+HC_API int hc_unpack_block(const uint8_t* blk, uint8_t* out64) {
+    cand c;
+    const bool ok = unpack_block(blk, c);
+    memcpy(out64, &c, 64);
+    return ok ? 1 : 0;
 }
