@@ -663,6 +663,56 @@ int bu_hip_encode_uastc_blocks(bu_hip_context* ctx, bu_uastc_block* out, uint32_
     return 1;
 }
 
+void bu_hip_uastc_rdo_default_params(bu_uastc_rdo_params* p) {
+    if (!p) return;
+    p->m_lz_dict_size = 4096; p->m_lambda = 0.5f; p->m_max_allowed_rms_increase_ratio = 10.0f; p->m_skip_block_rms_thresh = 8.0f;
+    p->m_endpoint_refinement = 1; p->m_lz_literal_cost = 100; p->m_max_smooth_block_std_dev = 18.0f; p->m_smooth_block_max_error_scale = 10.0f;
+}
+
+int bu_hip_k_uastc_rdo(bu_hip_context* ctx, void* d_blocks, const void* d_px, uint32_t n_blocks, const bu_uastc_rdo_params* params, uint32_t flags,
+                       uint32_t total_jobs, uint32_t out_stats[4]) {
+    if (!ctx) return 0;
+    if (!d_blocks || !d_px || !params) { set_error(ctx, "uastc_rdo: null pointer"); return 0; }
+    // uastc_rdo's asserts (uastc_enc.cpp:4097-4099) as errors
+    if (!(params->m_max_allowed_rms_increase_ratio > 1.0f) || !params->m_lz_dict_size || !(params->m_lambda > 0.0f)) {
+        set_error(ctx, "uastc_rdo: need max_allowed_rms_increase_ratio > 1, lz_dict_size > 0, lambda > 0");
+        return 0;
+    }
+    device_guard g(ctx->device);
+    if (out_stats) out_stats[0] = out_stats[1] = out_stats[2] = 0, out_stats[3] = bu::uastc_rdo_strips(n_blocks, total_jobs);
+    if (!n_blocks) return 1;
+    const float fp[5] = { params->m_lambda, params->m_max_allowed_rms_increase_ratio, params->m_skip_block_rms_thresh, params->m_max_smooth_block_std_dev,
+                          params->m_smooth_block_max_error_scale };
+    const uint32_t up[3] = { params->m_lz_dict_size, params->m_lz_literal_cost, params->m_endpoint_refinement };
+    arena& ws = ctx->scratch[5];
+    BU_TRY(ctx, ws.reserve(bu::uastc_rdo_workspace_bytes(n_blocks, total_jobs)));
+    static const char* const names[3] = { "uastc_rdo_prepare", "uastc_rdo_strips", "uastc_rdo_rehint" };
+    for (int phase = 0; phase < 3; phase++) {
+        prof_scope ps(ctx, names[phase]);
+        BU_TRY(ctx, bu::launch_uastc_rdo_phase(ctx->stream, phase, d_blocks, d_px, n_blocks, fp, up, flags, total_jobs, ws.p));
+    }
+    uint32_t counters[4] = { 0, 0, 0, 0 };
+    BU_TRY(ctx, hipMemcpyAsync(counters, bu::uastc_rdo_counters(ws.p, n_blocks, total_jobs), sizeof(counters), hipMemcpyDeviceToHost, ctx->stream));
+    BU_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (counters[1]) { set_error(ctx, "uastc_rdo: a block does not unpack as UASTC"); return 0; }
+    if (out_stats) { out_stats[0] = counters[0]; out_stats[1] = counters[2]; out_stats[2] = counters[3]; }
+    return 1;
+}
+
+int bu_hip_uastc_rdo(bu_hip_context* ctx, bu_uastc_block* blocks, const bu_uastc_rdo_params* params, uint32_t flags, uint32_t total_jobs, uint32_t out_stats[4]) {
+    if (!ctx || !ctx->d_pixel_blocks) { if (ctx) set_error(ctx, "no pixel blocks set"); return 0; }
+    if (!blocks) { set_error(ctx, "uastc_rdo: null blocks"); return 0; }
+    device_guard g(ctx->device);
+    const uint32_t n = (uint32_t)ctx->total_blocks;
+    arena& o = ctx->scratch[0];
+    BU_TRY(ctx, o.reserve((size_t)n * 16));
+    BU_TRY(ctx, h2d(ctx, o.p, blocks, (size_t)n * 16));
+    if (!bu_hip_k_uastc_rdo(ctx, o.p, ctx->d_pixel_blocks, n, params, flags, total_jobs, out_stats)) return 0;
+    BU_TRY(ctx, hipMemcpyAsync(blocks, o.p, (size_t)n * 16, hipMemcpyDeviceToHost, ctx->stream));
+    BU_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return 1;
+}
+
 int bu_hip_encode_etc1s_blocks(bu_hip_context* ctx, bu_etc_block* out, int perceptual, uint32_t total_perms) {
     if (!ctx || !ctx->d_pixel_blocks) { if (ctx) set_error(ctx, "no pixel blocks set"); return 0; }
     device_guard g(ctx->device);

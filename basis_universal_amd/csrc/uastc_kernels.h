@@ -13,4 +13,15 @@ hipError_t launch_encode_uastc(hipStream_t st, const void* d_pixel_blocks, uint3
 // The four phases separately (profiling brackets in the C ABI layer).
 hipError_t launch_uastc_phase(hipStream_t st, int phase, const void* d_pixel_blocks, uint32_t n_blocks, uint32_t flags, void* d_workspace, void* d_out_blocks);
 
+// uastc_rdo (encoder/basisu_uastc_enc.h:139, uastc_enc.cpp:4095) in place over n_blocks resident UASTC blocks (uastc_rdo_kernels.hip).
+// fparams: lambda, max_allowed_rms_increase_ratio, skip_block_rms_thresh, max_smooth_block_std_dev, smooth_block_max_error_scale;
+// uparams: lz_dict_size, lz_literal_cost, endpoint_refinement. total_jobs splits into independent strips exactly as the reference does.
+// Phases: 0 prepare (parallel), 1 strips (serial per strip), 2 rehint (parallel over modified blocks). Stream-ordered.
+size_t uastc_rdo_workspace_bytes(uint32_t n_blocks, uint32_t total_jobs);
+uint32_t uastc_rdo_strips(uint32_t n_blocks, uint32_t total_jobs);
+hipError_t launch_uastc_rdo_phase(hipStream_t st, int phase, void* d_blocks, const void* d_pixel_blocks, uint32_t n_blocks, const float* fparams,
+                                  const uint32_t* uparams, uint32_t flags, uint32_t total_jobs, void* d_workspace);
+// device address of 4 x uint32 {modified, failed, refined, skipped} inside the workspace, valid after phase 1
+const void* uastc_rdo_counters(void* d_workspace, uint32_t n_blocks, uint32_t total_jobs);
+
 } // namespace bu

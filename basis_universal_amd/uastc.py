@@ -44,3 +44,60 @@ def encode_uastc_blocks(ctx, blocks, flags=LEVEL_DEFAULT, n_blocks=None, out_dev
             ctx.free(own)
         if out_device is None:
             ctx.free(d_out)
+
+
+class RdoParams(C.Structure):
+    """uastc_rdo_params (encoder/basisu_uastc_enc.h:94-134), same fields, same defaults (= bu_uastc_rdo_params in include/basisu_hip.h)."""
+    _fields_ = [("m_lambda", C.c_float), ("m_max_allowed_rms_increase_ratio", C.c_float), ("m_skip_block_rms_thresh", C.c_float),
+                ("m_max_smooth_block_std_dev", C.c_float), ("m_smooth_block_max_error_scale", C.c_float),
+                ("m_lz_dict_size", C.c_uint32), ("m_lz_literal_cost", C.c_uint32), ("m_endpoint_refinement", C.c_uint32)]
+
+    def __init__(self, **kw):
+        super().__init__()
+        self.m_lz_dict_size, self.m_lambda, self.m_max_allowed_rms_increase_ratio, self.m_skip_block_rms_thresh = 4096, 0.5, 10.0, 8.0
+        self.m_endpoint_refinement, self.m_lz_literal_cost = 1, 100
+        self.m_max_smooth_block_std_dev, self.m_smooth_block_max_error_scale = 18.0, 10.0
+        for k, v in kw.items():
+            if not hasattr(self, k):
+                raise AttributeError(k)
+            setattr(self, k, v)
+
+
+def uastc_rdo(ctx, uastc_blocks, pixel_blocks, params=None, flags=LEVEL_DEFAULT, total_jobs=0, n_blocks=None):
+    """basisu::uastc_rdo (uastc_enc.h:139) on the GPU. uastc_blocks / pixel_blocks: numpy arrays ((n,16) and (n,4,4,4) uint8; a modified copy
+    of the blocks is returned with the stats) or device pointers (ints; the blocks are modified in place, n_blocks required).
+    total_jobs as in the reference: 0/1 = one strip, k = strips of n // k blocks (comp.cpp:2078 uses min(4, threads)).
+    Returns (blocks or None, {"modified", "refined", "skipped", "strips"})."""
+    params = params or RdoParams()
+    host = isinstance(uastc_blocks, np.ndarray)
+    owned = []
+    try:
+        if host:
+            src = np.ascontiguousarray(uastc_blocks, np.uint8)
+            n = src.size // 16
+            d_blk = ctx.upload(src) if n else 0
+            if n:
+                owned.append(d_blk)
+        else:
+            if n_blocks is None:
+                raise ValueError("n_blocks is required with device pointers")
+            n, d_blk = int(n_blocks), uastc_blocks
+        if isinstance(pixel_blocks, np.ndarray):
+            px = np.ascontiguousarray(pixel_blocks, np.uint8)
+            if px.size != n * 64:
+                raise ValueError("pixel_blocks must hold 64 bytes per UASTC block")
+            d_px = ctx.upload(px) if n else 0
+            if n:
+                owned.append(d_px)
+        else:
+            d_px = pixel_blocks
+        stats = (C.c_uint32 * 4)()
+        if n:
+            ctx.check(ctx.lib.k_uastc_rdo(ctx.h, C.c_void_p(d_blk), C.c_void_p(d_px), n, C.byref(params), int(flags), int(total_jobs), stats), "uastc_rdo")
+        info = {"modified": stats[0], "refined": stats[1], "skipped": stats[2], "strips": stats[3]}
+        if host:
+            return (ctx.download(d_blk, (n, 16), np.uint8) if n else np.zeros((0, 16), np.uint8)), info
+        return None, info
+    finally:
+        for d in owned:
+            ctx.free(d)

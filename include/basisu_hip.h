@@ -168,6 +168,30 @@ BU_HIP_API int bu_hip_k_encode_uastc_blocks(bu_hip_context*, const void* d_pixel
 /* Bytes of context workspace that call needs (27 candidate slots x 76 B per block at level 2; 170 at level 4). */
 BU_HIP_API size_t bu_hip_uastc_workspace_bytes(uint32_t n_blocks, uint32_t flags);
 
+/* a20 (SURVEY.md 8a "next" row f1): basisu::uastc_rdo (encoder/basisu_uastc_enc.h:139, uastc_enc.cpp:4095-4163) in place over n_blocks
+ * resident UASTC blocks and the pixel blocks they were encoded from. `params` mirrors uastc_rdo_params (uastc_enc.h:94-134) field for
+ * field; `flags` are the pack flags the blocks were encoded with (the hints of modified blocks are recomputed with them);
+ * `total_jobs` has the reference's meaning: 0/1 = one strip, otherwise strips of n_blocks / total_jobs blocks that do not see each
+ * other (comp.cpp:2076-2078 passes min(4, threads)). Output is bit-identical to the reference called with the same total_jobs.
+ * Synchronises the context's stream; `out_stats` (optional) receives {modified, refined, skipped, strips}. Fails (0) like the reference
+ * when a block does not unpack. */
+typedef struct bu_uastc_rdo_params {
+    float m_lambda;
+    float m_max_allowed_rms_increase_ratio;
+    float m_skip_block_rms_thresh;
+    float m_max_smooth_block_std_dev;
+    float m_smooth_block_max_error_scale;
+    uint32_t m_lz_dict_size;
+    uint32_t m_lz_literal_cost;
+    uint32_t m_endpoint_refinement;
+} bu_uastc_rdo_params;
+BU_HIP_API void bu_hip_uastc_rdo_default_params(bu_uastc_rdo_params* out);   /* uastc_rdo_params::clear(), uastc_enc.h:101-112 */
+BU_HIP_API int bu_hip_k_uastc_rdo(bu_hip_context*, void* d_uastc_blocks, const void* d_pixel_blocks, uint32_t n_blocks, const bu_uastc_rdo_params* params,
+                                  uint32_t flags, uint32_t total_jobs, uint32_t out_stats[4]);
+/* host-buffer form over the context's resident pixel blocks (bu_hip_set_pixel_blocks): blocks in, blocks out */
+BU_HIP_API int bu_hip_uastc_rdo(bu_hip_context*, bu_uastc_block* blocks, const bu_uastc_rdo_params* params, uint32_t flags, uint32_t total_jobs,
+                                uint32_t out_stats[4]);
+
 /* a8  tree_vector_quant (encoder/basisu_enc.h:1546-2078): the order-dependent TSVQ tree build, split by split, bit-exact.
  *     The host keeps the tree, the variance priority queue and the split order (enc.h:1616-1660); the device executes batches of
  *     independent node splits (split_node, enc.h:1737-1800) on the resident training set. Rows must be the DISTINCT training

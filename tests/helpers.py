@@ -278,6 +278,25 @@ def rdo_param_arrays(**kw):
             np.array([p["dict_size"], p["literal_cost"], p["refine"]], np.uint32))
 
 
+def uastc_rdo_cases():
+    """(name, pack flags, total_jobs, uastc_rdo_params overrides) of the committed RDO known answers (tests/golden/uastc_rdo_vectors.npz)."""
+    return [("default_l2", 2, 0, dict(lam=1.0)),
+            ("jobs4_l2", 2, 4, dict(lam=1.0)),
+            ("strong_l2", 2, 0, dict(lam=4.0)),
+            ("norefine_l0", 0, 3, dict(lam=3.0, refine=0)),
+            ("bigdict_l1", 1, 0, dict(lam=2.0, dict_size=32768)),
+            ("tinydict_l2", 2, 5, dict(lam=10.0, dict_size=64, skip_rms=30.0)),
+            ("tuned_l3", 3, 2, dict(lam=1.5, max_rms_ratio=1.5, smooth_std_dev=40.0, smooth_scale=3.0, literal_cost=150))]
+
+
+def uastc_rdo_test_blocks():
+    """Source blocks of the RDO vectors: a smooth+noise image (neighbouring blocks resemble each other, which is what RDO feeds on), part
+    of it with a smooth alpha channel, followed by the every-class block set of the encoder vectors."""
+    b = to_pixel_blocks(synth(256, 96, 11)).copy()
+    b[1024:, :, :, 3] = b[1024:, :, :, 0] // 2 + 60
+    return np.ascontiguousarray(np.concatenate([b, uastc_test_blocks()[::3]]))
+
+
 def ref_uastc_rdo(packed, blocks, flags, total_jobs=0, **kw):
     fp, up = rdo_param_arrays(**kw)
     out = np.ascontiguousarray(packed).copy()
@@ -311,6 +330,8 @@ def uastc_host():
         L.hc_encode_uastc.argtypes = [u8p, C.c_uint32, C.c_uint32, u8p]
         L.hc_uastc_rdo.restype = C.c_int
         L.hc_uastc_rdo.argtypes = [u8p, u8p, C.c_uint32, f32p, u32p, C.c_uint32, C.c_uint32]
+        L.hc_rehint.argtypes = [u8p, C.c_uint32, C.c_uint32, u8p]
+        L.hc_unpack_block.argtypes = [u8p, u8p]
         L.hc_cell_compress.restype = C.c_uint64
         L.hc_cell_compress.argtypes = [u8p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32, C.c_uint32, u8p]
         L.hc_cell_estimate.restype = C.c_uint64

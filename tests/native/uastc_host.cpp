@@ -104,3 +104,11 @@ HC_API int hc_unpack_block(const uint8_t* blk, uint8_t* out64) {
     memcpy(out64, &c, 64);
     return ok ? 1 : 0;
 }
+
+HC_API int hc_rehint(const uint8_t* pixels, uint32_t n, uint32_t flags, uint8_t* blocks) {
+    enc_cfg e;
+    make_cfg(flags, e);
+    for (uint32_t i = 0; i < n; i++)
+        if (!rdo_rehint((const rgba8*)(pixels + (size_t)i * 64), e, blocks + (size_t)i * 16)) return 0;
+    return 1;
+}

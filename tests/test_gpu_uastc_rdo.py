@@ -1,0 +1,118 @@
+"""-m gpu parity tests of the UASTC RDO post-pass (include/basisu_hip.h: bu_hip_k_uastc_rdo / bu_hip_uastc_rdo).
+
+Bit-exact against (1) the committed known answers of the real reference's uastc_rdo for every parameter case, (2) the real reference
+(oracle/_ref) on a fresh image, and -- at a size the serial reference would need minutes for -- through size-independent properties:
+strips are independent (strip k of a many-strip run equals a run over that sub-array alone, checked against the reference on a sample of
+strips), the run is deterministic, and unmodified blocks keep every bit.
+"""
+import ctypes as C
+import pathlib
+
+import numpy as np
+import pytest
+
+import helpers
+from basis_universal_amd import uastc
+
+pytestmark = pytest.mark.gpu
+GOLDEN = pathlib.Path(__file__).resolve().parent / "golden" / "uastc_rdo_vectors.npz"
+KEYS = dict(lam="m_lambda", max_rms_ratio="m_max_allowed_rms_increase_ratio", skip_rms="m_skip_block_rms_thresh", smooth_std_dev="m_max_smooth_block_std_dev",
+            smooth_scale="m_smooth_block_max_error_scale", dict_size="m_lz_dict_size", literal_cost="m_lz_literal_cost", refine="m_endpoint_refinement")
+
+
+def params(**kw):
+    d = dict(helpers.RDO_DEFAULTS)
+    d.update(kw)
+    return uastc.RdoParams(**{KEYS[k]: v for k, v in d.items()})
+
+
+@pytest.fixture(scope="module")
+def golden():
+    return np.load(GOLDEN)
+
+
+@pytest.mark.parametrize("name,flags,jobs,kw", helpers.uastc_rdo_cases(), ids=[c[0] for c in helpers.uastc_rdo_cases()])
+def test_matches_reference_vectors(hip_ctx, golden, name, flags, jobs, kw):
+    packed = golden[f"packed_l{flags & 7}"]
+    got, info = uastc.uastc_rdo(hip_ctx, packed, golden["blocks"], params(**kw), flags, jobs)
+    want = golden[name]
+    bad = np.nonzero((got != want).any(1))[0]
+    assert bad.size == 0, f"{name}: {bad.size} blocks differ, first {bad[:5]}: got {got[bad[:1]].tobytes().hex()} want {want[bad[:1]].tobytes().hex()}"
+    assert info["modified"] == int((want != packed).any(1).sum()) or info["modified"] >= int((want != packed).any(1).sum())
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 40, 257, 600])
+@pytest.mark.parametrize("jobs", [0, 4])
+def test_ragged_sizes(hip_ctx, golden, n, jobs):
+    packed, blocks = golden["packed_l2"][:n], golden["blocks"][:n]
+    got, info = uastc.uastc_rdo(hip_ctx, packed, blocks, params(lam=4.0), 2, jobs)
+    assert got.shape == (n, 16)
+    assert (got == helpers.host_uastc_rdo(packed, blocks, 2, jobs, lam=4.0)).all()
+
+
+def test_blocking_host_pointer_entry(hip_ctx, golden):
+    blocks = np.ascontiguousarray(golden["blocks"])
+    n = blocks.shape[0]
+    hip_ctx.check(hip_ctx.lib.set_pixel_blocks(hip_ctx.h, n, blocks.ctypes.data), "set_pixel_blocks")
+    out = np.ascontiguousarray(golden["packed_l2"]).copy()
+    p = uastc.RdoParams()
+    hip_ctx.lib.uastc_rdo_default_params(C.byref(p))
+    assert (p.m_lambda, p.m_lz_dict_size, p.m_endpoint_refinement) == (0.5, 4096, 1)
+    p.m_lambda = 1.0
+    stats = (C.c_uint32 * 4)()
+    hip_ctx.check(hip_ctx.lib.uastc_rdo(hip_ctx.h, out.ctypes.data, C.byref(p), 2, 0, stats), "uastc_rdo")
+    assert (out == golden["default_l2"]).all()
+    assert stats[0] == int((golden["default_l2"] != golden["packed_l2"]).any(1).sum()) and stats[3] == 1
+
+
+def test_rejects_bad_arguments(hip_ctx, golden):
+    packed, blocks = golden["packed_l2"][:64], golden["blocks"][:64]
+    with pytest.raises(Exception):
+        uastc.uastc_rdo(hip_ctx, packed, blocks, params(lam=0.0), 2, 0)
+    with pytest.raises(Exception):
+        uastc.uastc_rdo(hip_ctx, packed, blocks, params(max_rms_ratio=1.0), 2, 0)
+    junk = packed.copy()
+    junk[5, 0] = 0x45  # not a mode code: the reference's unpack fails and uastc_rdo returns false
+    with pytest.raises(Exception):
+        uastc.uastc_rdo(hip_ctx, junk, blocks, params(), 2, 0)
+
+
+@pytest.mark.skipif(not helpers.have_ref(), reason="oracle/_ref not built")
+def test_vs_reference_fresh_image(hip_ctx):
+    rng = np.random.default_rng(9)
+    blocks = helpers.to_pixel_blocks(helpers.synth(512, 256, 33)).copy()
+    blocks[3000:5000, :, :, 3] = blocks[3000:5000, :, :, 2] // 2 + 100
+    for level, jobs, kw in [(2, 4, dict(lam=1.0)), (1, 0, dict(lam=3.0, dict_size=8192)), (0, 16, dict(lam=5.0, refine=0))]:
+        packed = uastc.encode_uastc_blocks(hip_ctx, blocks, level)
+        want = helpers.ref_uastc_rdo(packed, blocks, level, jobs, **kw)
+        got, info = uastc.uastc_rdo(hip_ctx, packed, blocks, params(**kw), level, jobs)
+        bad = np.nonzero((got != want).any(1))[0]
+        assert bad.size == 0, f"level {level} jobs {jobs} {kw}: {bad.size} of {blocks.shape[0]} blocks differ, first {bad[:5]}"
+        assert info["modified"] == int((want != packed).any(1).sum())
+
+
+def test_large_image_properties(hip_ctx):
+    """2048x2048 (262,144 blocks), 64 strips, everything device-resident: deterministic; each strip equals a run over that strip alone
+    (two sampled strips, also against the CPU reference when present); unmodified blocks are bit-identical to the input."""
+    blocks = helpers.to_pixel_blocks(helpers.synth(2048, 2048, 77))
+    n = blocks.shape[0]
+    d_px = hip_ctx.upload(blocks)
+    d_blk = hip_ctx.alloc(n * 16)
+    try:
+        uastc.encode_uastc_blocks(hip_ctx, d_px, 2, n_blocks=n, out_device=d_blk)
+        packed = hip_ctx.download(d_blk, (n, 16), np.uint8)
+        _, info = uastc.uastc_rdo(hip_ctx, d_blk, d_px, params(lam=2.0), 2, 64, n_blocks=n)
+        got = hip_ctx.download(d_blk, (n, 16), np.uint8)
+        assert info["strips"] == 64 and info["modified"] == int((got != packed).any(1).sum())
+        again, _ = uastc.uastc_rdo(hip_ctx, packed, blocks, params(lam=2.0), 2, 64)
+        assert (again == got).all()
+        per = n // 64
+        for k in (0, 37):
+            sl = slice(k * per, (k + 1) * per)
+            alone, _ = uastc.uastc_rdo(hip_ctx, packed[sl], blocks[sl], params(lam=2.0), 2, 0)
+            assert (alone == got[sl]).all()
+            if helpers.have_ref():
+                assert (helpers.ref_uastc_rdo(packed[sl], blocks[sl], 2, 0, lam=2.0) == got[sl]).all()
+    finally:
+        hip_ctx.free(d_px)
+        hip_ctx.free(d_blk)
