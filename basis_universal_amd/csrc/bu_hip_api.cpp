@@ -686,7 +686,7 @@ int bu_hip_k_uastc_rdo(bu_hip_context* ctx, void* d_blocks, const void* d_px, ui
     const uint32_t up[3] = { params->m_lz_dict_size, params->m_lz_literal_cost, params->m_endpoint_refinement };
     arena& ws = ctx->scratch[5];
     BU_TRY(ctx, ws.reserve(bu::uastc_rdo_workspace_bytes(n_blocks, total_jobs)));
-    static const char* const names[3] = { "uastc_rdo_prepare", "uastc_rdo_strips", "uastc_rdo_rehint" };
+    static const char* const names[3] = { "uastc_rdo_prepare", "uastc_rdo_strips", "uastc_rdo_finish" };
     for (int phase = 0; phase < 3; phase++) {
         prof_scope ps(ctx, names[phase]);
         BU_TRY(ctx, bu::launch_uastc_rdo_phase(ctx->stream, phase, d_blocks, d_px, n_blocks, fp, up, flags, total_jobs, ws.p));
@@ -694,6 +694,15 @@ int bu_hip_k_uastc_rdo(bu_hip_context* ctx, void* d_blocks, const void* d_px, ui
     uint32_t counters[4] = { 0, 0, 0, 0 };
     BU_TRY(ctx, hipMemcpyAsync(counters, bu::uastc_rdo_counters(ws.p, n_blocks, total_jobs), sizeof(counters), hipMemcpyDeviceToHost, ctx->stream));
     BU_TRY(ctx, hipStreamSynchronize(ctx->stream));
+#ifdef RDO_PROFILE
+    {
+        unsigned long long prof[16];
+        hipMemcpy(prof, static_cast<const char*>(bu::uastc_rdo_counters(ws.p, n_blocks, total_jobs)) + 64, sizeof(prof), hipMemcpyDeviceToHost);
+        fprintf(stderr, "rdo strip 0 cycles by phase:");
+        for (int k = 0; k < 16; k++) fprintf(stderr, " %llu", prof[k]);
+        fprintf(stderr, "\n");
+    }
+#endif
     if (counters[1]) { set_error(ctx, "uastc_rdo: a block does not unpack as UASTC"); return 0; }
     if (out_stats) { out_stats[0] = counters[0]; out_stats[1] = counters[2]; out_stats[2] = counters[3]; }
     return 1;

@@ -52,7 +52,7 @@ BU_FN void parse_weights(cand& r, uint64_t lo, uint64_t hi) {
         for (uint32_t s = 0; s < subsets; s++)
             if ((subsets >= 2 ? anchors[s] : 0u) == (i >> plane_shift)) { nb--; break; }
         r.weights[i] = (uint8_t)(lo & ((1u << nb) - 1));
-        lo = (lo >> nb) | (hi << (64 - nb));
+        lo = nb ? ((lo >> nb) | (hi << (64 - nb))) : lo;  // nb == 0: the anchors of 1-bit weights (mode 13)
         hi >>= nb;
     }
 }
@@ -119,14 +119,14 @@ BU_FN bool unpack_block(const uint8_t* blk, cand& r) {
 
 // compute_match_cost_estimate (uastc_enc.cpp:3773-3790). The two tdefl tables it indexes are "extra bits of the DEFLATE distance
 // code": floor(log2(d)) - 1 below 512 (0 under 4), floor(log2(d >> 8)) + 7 from there on.
-BU_FN uint32_t floor_log2(uint32_t v) { uint32_t l = 0; while (v > 1) { v >>= 1; l++; } return l; }
+BU_FN uint32_t floor_log2(uint32_t v) { return v ? 31u - (uint32_t)__builtin_clz(v) : 0u; }
 BU_FN uint32_t match_cost(uint32_t dist) {
     uint32_t cost = 7 + 5;
     if (dist < 512) cost += dist < 4 ? 0 : floor_log2(dist) - 1;
     else {
         const uint32_t idx = (dist < 32767 ? dist : 32767) >> 8;
         cost += idx < 2 ? 0 : floor_log2(idx) + 7;
-        while (dist >= 32768) { cost++; dist >>= 1; }
+        if (dist >= 32768) cost += floor_log2(dist) - 14;  // one more bit per halving it takes to get below 32768
     }
     return cost;
 }
@@ -177,6 +177,95 @@ BU_FN bool rdo_trial(const cand& base, uint64_t lo, uint64_t hi, const rgba8* px
     return !(sqrtf(ms_err) > info.rms_err * p.max_allowed_rms_increase_ratio);
 }
 
+// ---- Trials by table. A trial keeps the block's endpoints and replaces its weights, and both decoders are per texel: the UASTC colour of
+// texel i is astc_lerp(low_i, high_i, W[w]) and its BC7 transcode is bc7_lerp(low'_i, high'_i, W'[w]) with endpoints that do not depend on
+// the weights (decode_uastc / decode_bc7: the anchor-bit endpoint swaps of the real transcode cancel against the mirrored weights). So
+// for one block the error of "weight k takes value v" is a table E[k][v], and a trial's UASTC+BC7 error is the sum of 16 (32 for dual
+// plane) table entries -- same integers as decoding the trial twice. Dual-plane modes split by channel: the ccs channel reads plane 1.
+
+// BC7 interpolation weight (0..64) decode_bc7 applies for UASTC weight value w of `mode` (transcoder.cpp: the s_uastc*_to_bc7 conversions)
+BU_FN uint32_t bc7_weight_for(uint32_t mode, uint32_t w) {
+    switch (mode) {
+    case 0: case 10: case 15: return ku_bc7_weights4[w];
+    case 18: { const uint8_t five_to_four[32] = { 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 6, 7, 8, 9, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13, 14, 14, 15, 15 };
+               return ku_bc7_weights4[five_to_four[w]]; }
+    case 14: return ku_bc7_weights4[w * 5];
+    case 5: case 12: { const uint8_t three_to_four[8] = { 0, 2, 4, 6, 9, 11, 13, 15 }; return ku_bc7_weights4[three_to_four[w]]; }
+    case 2: return weight_set(3)[w];
+    case 13: return w ? 64u : 0u;
+    default: return weight_set(2)[w];  // 1, 4, 9, 16; 3, 7; 6, 11, 17
+    }
+}
+
+// per texel: the colours both decoders produce at weight 0 and at the top weight, RGBA packed
+struct texel_ends { uint32_t ul[16], uh[16], bl[16], bh[16]; };
+BU_FN void rdo_texel_ends(const cand& c, texel_ends& o) {
+    cand z = c;
+    rgba8 dec[16];
+    for (int i = 0; i < 32; i++) z.weights[i] = 0;
+    decode_uastc(z, dec);
+    for (int i = 0; i < 16; i++) o.ul[i] = pack_px(dec[i].c);
+    decode_bc7(z, dec);
+    for (int i = 0; i < 16; i++) o.bl[i] = pack_px(dec[i].c);
+    const uint8_t top = (uint8_t)((1u << ku_mode_weight_bits[c.mode]) - 1);
+    for (int i = 0; i < 32; i++) z.weights[i] = top;
+    decode_uastc(z, dec);
+    for (int i = 0; i < 16; i++) o.uh[i] = pack_px(dec[i].c);
+    decode_bc7(z, dec);
+    for (int i = 0; i < 16; i++) o.bh[i] = pack_px(dec[i].c);
+}
+
+constexpr uint32_t RDO_TABLE_WORDS = 512;
+// E[k][v]: weight slot k (texel k / planes, plane k % planes) at value v
+BU_FN uint32_t rdo_weight_error(uint32_t mode, uint32_t ccs, uint32_t k, uint32_t v, uint32_t ul, uint32_t uh, uint32_t bl, uint32_t bh, uint32_t px) {
+    const uint32_t planes = ku_mode_planes[mode], plane = planes == 2 ? (k & 1u) : 0u;
+    const uint32_t wu = weight_set(ku_mode_weight_bits[mode])[v], wb = bc7_weight_for(mode, v);
+    uint32_t e = 0;
+    for (uint32_t c = 0; c < 4; c++) {
+        if (planes == 2 && ((c == ccs) != (plane == 1))) continue;
+        const int t = px_comp(px, (int)c);
+        const int du = (int)astc_lerp((uint32_t)px_comp(ul, (int)c), (uint32_t)px_comp(uh, (int)c), wu) - t;
+        const int db = (int)bc7_lerp((uint32_t)px_comp(bl, (int)c), (uint32_t)px_comp(bh, (int)c), wb) - t;
+        e += (uint32_t)(imul24(du, du) + imul24(db, db));
+    }
+    return e;
+}
+
+// which weight slots are stored with one bit less (the anchors; pack_block / parse_weights)
+BU_FN uint32_t rdo_anchor_mask(uint32_t mode, uint32_t pattern) {
+    const uint32_t subsets = ku_mode_subsets[mode], planes = ku_mode_planes[mode];
+    if (planes == 2) return 3u;
+    if (subsets == 1) return 1u;
+    const uint8_t* anchors = subsets == 3 ? ku_anchor3 + pattern * 3 : (mode == 7 ? ku_anchor7 + pattern * 3 : ku_anchor2 + pattern * 3);
+    uint32_t m = 0;
+    for (uint32_t s = 0; s < subsets; s++) m |= 1u << anchors[s];
+    return m;
+}
+
+// a trial's (uastc_err + bc7_err) from the table, table[(k << weight_bits) + v] (at most 512 entries: 16 x 32 for mode 18, 32 x 4 dual plane)
+// Written as 16-slot groups with the indices extracted first, so the table reads of a group are independent (one wait per group on the GPU).
+template <class TABLE>
+BU_FN uint32_t rdo_trial_sum_n(const TABLE& table, uint32_t n_slots, uint32_t wbits, uint32_t anchor_mask, uint64_t lo, uint64_t hi) {
+    uint32_t total = 0;
+    for (uint32_t g = 0; g < n_slots; g += 16) {
+        uint32_t idx[16];
+        BU_UNROLL
+        for (uint32_t k = 0; k < 16; k++) {
+            const uint32_t nb = wbits - ((anchor_mask >> (g + k)) & 1u);
+            idx[k] = ((g + k) << wbits) + ((uint32_t)lo & ((1u << nb) - 1));
+            lo = nb ? ((lo >> nb) | (hi << (64 - nb))) : lo;  // nb == 0: the anchors of 1-bit weights (mode 13)
+            hi >>= nb;
+        }
+        BU_UNROLL
+        for (uint32_t k = 0; k < 16; k++) total += table[idx[k]];
+    }
+    return total;
+}
+template <class TABLE>
+BU_FN uint32_t rdo_trial_sum(const TABLE& table, uint32_t mode, uint32_t anchor_mask, uint64_t lo, uint64_t hi) {
+    return rdo_trial_sum_n(table, 16 * ku_mode_planes[mode], ku_mode_weight_bits[mode], anchor_mask, lo, hi);
+}
+
 // The accepted trial written back (:4012-4073): mode 0 gets its endpoints refitted to the new selectors when that lowers the UASTC
 // error. The hints are left zero -- nothing later in the strip reads them (every mode's selector field starts past bit 48, the hints end
 // before bit 30) -- and are recomputed for all modified blocks afterwards (uastc_recompute_hints, :3647-3726 == finish_block).
@@ -204,6 +293,37 @@ BU_FN void rdo_write_back(const cand& base, uint64_t lo, uint64_t hi, const rgba
     }
     const etc1_hint none = { 0, 0, 0, 0, 0 };
     pack_block(c, none, 0, 0, false, false, out16);
+}
+
+// set_block_bits (uastc_enc.cpp:3737-3754) for a whole selector field: the trial block is the current block with this field replaced
+BU_FN void put_field(uint8_t* b, uint32_t ofs, uint32_t n, uint64_t lo, uint64_t hi) {
+    for (uint32_t done = 0; done < n;) {
+        const uint32_t in_byte = ofs & 7, k = (n - done) < (8 - in_byte) ? (n - done) : (8 - in_byte);
+        const uint32_t m = ((1u << k) - 1) << in_byte;
+        b[ofs >> 3] = (uint8_t)((b[ofs >> 3] & ~m) | (((uint32_t)lo << in_byte) & m));
+        lo = (lo >> k) | (hi << (64 - k));
+        hi >>= k;
+        done += k;
+        ofs += k;
+    }
+}
+
+// Deferred form of the write-back. Only a mode-0 block's endpoint bits (up to bit 64) change in the refit, and only the selector fields of
+// modes 15, 17 and 18 start below bit 65 -- so as long as no block of those modes looks at a modified mode-0 block, the strip walk can
+// store the raw trial bits (put_field) and leave the refit to a parallel pass; a block of a "sensitive" mode first settles the pending
+// refits in its window. The refit of a block depends on nothing but that block, so when it runs does not matter.
+BU_FN bool rdo_mode_reads_endpoint_bits(uint32_t mode) { return mode == 15 || mode == 17 || mode == 18; }
+BU_FN bool rdo_refit_block(const rgba8* px, const rdo_params& p, uint8_t* blk16, bool& refined) {
+    cand c;
+    refined = false;
+    if (!unpack_block(blk16, c)) return false;
+    if (c.mode != 0 || !p.endpoint_refinement) return true;
+    const uint64_t lo = block_bits(blk16, ku_sel_first[0], 63);
+    uint8_t out[16];
+    rdo_write_back(c, lo, 0, px, p, out, refined);
+    if (refined)  // an unrefined block keeps its bytes (pack_block would zero the stale hints; harmless, but keep the bits stable)
+        for (int i = 0; i < 16; i++) blk16[i] = out[i];
+    return true;
 }
 
 // uastc_recompute_hints (:3647-3726) of a block whose weights (and maybe endpoints) changed

@@ -286,7 +286,32 @@ def uastc_rdo_cases():
             ("norefine_l0", 0, 3, dict(lam=3.0, refine=0)),
             ("bigdict_l1", 1, 0, dict(lam=2.0, dict_size=32768)),
             ("tinydict_l2", 2, 5, dict(lam=10.0, dict_size=64, skip_rms=30.0)),
+            ("settle_l0", 0, 0, dict(lam=20.0)),
             ("tuned_l3", 3, 2, dict(lam=1.5, max_rms_ratio=1.5, smooth_std_dev=40.0, smooth_scale=3.0, literal_cost=150))]
+
+
+def synth_smooth(w, h, seed):
+    """Low-noise RGBA image: blocks that UASTC encodes in mode 0 and that RDO modifies and refits a lot."""
+    rng = np.random.default_rng(seed)
+    y, x = np.mgrid[0:h, 0:w].astype(np.float32)
+    img = np.empty((h, w, 4), np.float32)
+    img[..., 0] = 128 + 100 * np.sin(x / 17) * np.cos(y / 23)
+    img[..., 1] = 128 + 90 * np.sin(x / 29 + 1) * np.cos(y / 13)
+    img[..., 2] = 128 + 80 * np.cos(x / 11) * np.sin(y / 19 + 2)
+    img[..., 3] = 255
+    img[..., :3] += rng.normal(0, 2.0, (h, w, 3))
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
+def smooth_with_la_blocks(w, h, seed):
+    """synth_smooth as blocks, every 4th block luminance+alpha: modes 15/17 next to modified mode-0 blocks, the one arrangement in which
+    the selector field of a block overlaps the (refitted) endpoint bits of its neighbours (uastc_rdo.h, deferred write-back)."""
+    b = to_pixel_blocks(synth_smooth(w, h, seed)).copy()
+    grey = b[::4, :, :, 1].copy()
+    b[::4, :, :, 0] = grey
+    b[::4, :, :, 2] = grey
+    b[::4, :, :, 3] = 255 - grey // 2
+    return b
 
 
 def uastc_rdo_test_blocks():
@@ -294,7 +319,7 @@ def uastc_rdo_test_blocks():
     of it with a smooth alpha channel, followed by the every-class block set of the encoder vectors."""
     b = to_pixel_blocks(synth(256, 96, 11)).copy()
     b[1024:, :, :, 3] = b[1024:, :, :, 0] // 2 + 60
-    return np.ascontiguousarray(np.concatenate([b, uastc_test_blocks()[::3]]))
+    return np.ascontiguousarray(np.concatenate([b, smooth_with_la_blocks(192, 64, 3), uastc_test_blocks()[::3]]))
 
 
 def ref_uastc_rdo(packed, blocks, flags, total_jobs=0, **kw):
@@ -305,8 +330,10 @@ def ref_uastc_rdo(packed, blocks, flags, total_jobs=0, **kw):
     return out
 
 
-def host_uastc_rdo(packed, blocks, flags, total_jobs=0, **kw):
+def host_uastc_rdo(packed, blocks, flags, total_jobs=0, table_trials=False, **kw):
+    """The host build of uastc_rdo.h under a scalar strip loop; table_trials scores trials from the per-block error table like the GPU kernel."""
     fp, up = rdo_param_arrays(**kw)
+    total_jobs |= 0x80000000 if table_trials else 0
     out = np.ascontiguousarray(packed).copy()
     blocks = np.ascontiguousarray(blocks)
     assert uastc_host().hc_uastc_rdo(ptr(out), ptr(blocks), out.shape[0], ptr(fp, f32p), ptr(up, u32p), flags, total_jobs) == 1

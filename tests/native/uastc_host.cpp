@@ -3,6 +3,7 @@
 // no GPU. The product never builds or loads this file; libbasisu_hip.so compiles the same header with hipcc.
 #include <cstring>
 #include <map>
+#include <vector>
 #include <utility>
 #include "../../basis_universal_amd/csrc/uastc_rdo.h"
 
@@ -37,11 +38,13 @@ HC_API void hc_encode_uastc(const uint8_t* blocks, uint32_t n, uint32_t flags, u
 
 // uastc_rdo (uastc_enc.cpp:3824-4163) as a scalar loop over the shared per-block pieces of uastc_rdo.h: the order-defining part of the
 // GPU strips kernel (history of selector fields, window scan newest-first, strict "<" on the cost) restated the plain way.
+static bool g_table_trials = false;  // score trials from the per-block error table (what the GPU strips kernel does) instead of decoding them
 static bool rdo_strip(uint32_t first, uint32_t last, uint8_t* blocks, const uint8_t* pixels, const rdo_params& p, uint32_t flags) {
     enc_cfg e;
     make_cfg(flags, e);
     const int window = (int)(p.lz_dict_size / 16 > 1 ? p.lz_dict_size / 16 : 1);
     std::map<std::pair<uint32_t, uint64_t>, uint32_t> history;
+    std::vector<uint8_t> state(last - first, 0);  // 1: modified, refit pending; 2: modified, only the hints are stale
     for (uint32_t i = first; i < last; i++) {
         uint8_t* blk = blocks + (size_t)i * 16;
         const rgba8* px = (const rgba8*)(pixels + (size_t)i * 64);
@@ -49,6 +52,15 @@ static bool rdo_strip(uint32_t first, uint32_t last, uint8_t* blocks, const uint
         rdo_block_info info;
         if (!rdo_prepare(blk, px, p, cur, info)) return false;
         if (info.mode == 8) continue;
+        if (g_table_trials && rdo_mode_reads_endpoint_bits(info.mode)) {
+            const int from = (int)i - window > (int)first ? (int)i - window : (int)first;
+            for (int j = from; j < (int)i; j++)
+                if (state[j - first] == 1) {
+                    bool refined;
+                    if (!rdo_refit_block((const rgba8*)(pixels + (size_t)j * 64), p, blocks + (size_t)j * 16, refined)) return false;
+                    state[j - first] = 2;
+                }
+        }
         const uint32_t fsb = ku_sel_first[info.mode], len = ku_sel_len[info.mode], len_lo = len < 64 ? len : 64;
         const uint64_t cur_lo = block_bits(blk, fsb, len_lo);
         if (info.skip) { history[{ fsb, cur_lo }] = i; continue; }
@@ -56,6 +68,18 @@ static bool rdo_strip(uint32_t first, uint32_t last, uint8_t* blocks, const uint
         auto it = history.find({ fsb, cur_lo });
         if (it == history.end()) cur_bits = (int)((len * p.lz_literal_cost) / 100);
         else cur_bits = (int)match_cost((i - it->second) * 16);
+        uint32_t table[RDO_TABLE_WORDS];
+        uint32_t amask = 0;
+        if (g_table_trials) {
+            texel_ends ends;
+            rdo_texel_ends(cur, ends);
+            amask = rdo_anchor_mask(cur.mode, cur.pattern);
+            const uint32_t planes = ku_mode_planes[cur.mode];
+            for (uint32_t k = 0; k < 16 * planes; k++)
+                for (uint32_t v = 0; v < (1u << ku_mode_weight_bits[cur.mode]); v++)
+                    table[(k << ku_mode_weight_bits[cur.mode]) + v] = rdo_weight_error(cur.mode, cur.ccs, k, v, ends.ul[k / planes], ends.uh[k / planes], ends.bl[k / planes], ends.bh[k / planes],
+                                                         pack_px(px[k / planes].c));
+        }
         float best_t = info.ms_err * info.scale + (float)cur_bits * p.lambda;
         int best_j = -1;
         uint64_t best_lo = 0, best_hi = 0;
@@ -70,23 +94,40 @@ static bool rdo_strip(uint32_t first, uint32_t last, uint8_t* blocks, const uint
             cand tmp;
             if (!unpack_block(prev, tmp)) return false;
             float ms;
-            if (!rdo_trial(cur, lo, hi, px, info, p, ms)) continue;
+            if (g_table_trials) {
+                ms = (float)(uint64_t)(rdo_trial_sum(table, cur.mode, amask, lo, hi) / 2) * (1.0f / 64.0f);
+                if (sqrtf(ms) > info.rms_err * p.max_allowed_rms_increase_ratio) continue;
+            } else if (!rdo_trial(cur, lo, hi, px, info, p, ms)) continue;
             const float t = ms * info.scale + (float)(int)match_cost((i - (uint32_t)match) * 16) * p.lambda;
             if (t < best_t) { best_t = t; best_j = j; best_lo = lo; best_hi = hi; }
         }
         uint64_t final_lo = cur_lo;
         if (best_j >= 0) {
-            bool refined;
-            rdo_write_back(cur, best_lo, best_hi, px, p, blk, refined);
-            if (!rdo_rehint(px, e, blk)) return false;
+            if (g_table_trials) {  // the GPU schedule: raw trial bits now, refit + hints later (uastc_rdo.h, "Deferred form")
+                put_field(blk, fsb, len, best_lo, best_hi);
+                state[i - first] = (p.endpoint_refinement && info.mode == 0) ? 1 : 2;
+            } else {
+                bool refined;
+                rdo_write_back(cur, best_lo, best_hi, px, p, blk, refined);
+                if (!rdo_rehint(px, e, blk)) return false;
+            }
             final_lo = block_bits(blk, fsb, len_lo);
         }
         history[{ fsb, final_lo }] = i;
+    }
+    for (uint32_t i = first; i < last; i++) {
+        if (!state[i - first]) continue;
+        const rgba8* px = (const rgba8*)(pixels + (size_t)i * 64);
+        bool refined;
+        if (state[i - first] == 1 && !rdo_refit_block(px, p, blocks + (size_t)i * 16, refined)) return false;
+        if (!rdo_rehint(px, e, blocks + (size_t)i * 16)) return false;
     }
     return true;
 }
 
 HC_API int hc_uastc_rdo(uint8_t* blocks, const uint8_t* pixels, uint32_t n, const float* fp, const uint32_t* up, uint32_t flags, uint32_t total_jobs) {
+    g_table_trials = (total_jobs >> 31) != 0;  // test switch in the top bit
+    total_jobs &= 0x7FFFFFFFu;
     rdo_params p;
     p.lambda = fp[0]; p.max_allowed_rms_increase_ratio = fp[1]; p.skip_block_rms_thresh = fp[2]; p.max_smooth_block_std_dev = fp[3];
     p.smooth_block_max_error_scale = fp[4];

@@ -23,9 +23,11 @@ def golden():
 
 
 @pytest.mark.parametrize("name,flags,jobs,kw", helpers.uastc_rdo_cases(), ids=[c[0] for c in helpers.uastc_rdo_cases()])
-def test_host_rdo_matches_reference_vectors(golden, name, flags, jobs, kw):
+@pytest.mark.parametrize("table", [False, True], ids=["decode", "table"])
+def test_host_rdo_matches_reference_vectors(golden, name, flags, jobs, kw, table):
+    """table: trials scored from the per-block weight-error table (uastc_rdo.h, what the GPU strips kernel does) instead of decoded."""
     packed = golden[f"packed_l{flags & 7}"]
-    got = helpers.host_uastc_rdo(packed, golden["blocks"], flags, jobs, **kw)
+    got = helpers.host_uastc_rdo(packed, golden["blocks"], flags, jobs, table, **kw)
     bad = np.nonzero((got != golden[name]).any(1))[0]
     assert bad.size == 0, f"{name}: {bad.size} blocks differ, first {bad[:5]}"
     assert (golden[name] != packed).any(), "the case must modify something"
@@ -69,14 +71,25 @@ def test_host_rdo_vs_reference_random_params():
     blocks = helpers.to_pixel_blocks(img).copy()
     blocks[700:1100, :, :, 3] = rng.integers(0, 256, size=(400, 4, 4), dtype=np.uint8)
     blocks[1100:, :, :, 3] = blocks[1100:, :, :, 1]
-    for trial in range(6):
-        level = int(rng.integers(0, 3))
+    # every 5th block luminance+alpha (modes 15/17, whose selector fields reach into the endpoint bits of their neighbours: the deferred
+    # refit of uastc_rdo.h has to settle those first)
+    grey = blocks[::5, :, :, 1].copy()
+    blocks[::5, :, :, 0] = grey
+    blocks[::5, :, :, 2] = grey
+    blocks[::5, :, :, 3] = 255 - grey // 2
+    for trial in range(7):
+        if trial == 6:
+            blocks = helpers.smooth_with_la_blocks(192, 128, 3)
+        level = int(rng.integers(0, 3)) if trial < 6 else 0
         packed = helpers.ref_encode_uastc(blocks, level)
         kw = dict(lam=float(rng.choice([0.25, 0.75, 2.0, 6.0])), dict_size=int(rng.choice([16, 256, 4096, 16384])), refine=int(rng.integers(0, 2)),
                   skip_rms=float(rng.choice([4.0, 8.0, 20.0])), max_rms_ratio=float(rng.choice([1.1, 3.0, 10.0])),
                   smooth_scale=float(rng.choice([1.0, 10.0, 20.0])), smooth_std_dev=float(rng.choice([9.0, 18.0])), literal_cost=int(rng.choice([80, 100, 130])))
         jobs = int(rng.choice([0, 2, 4, 7]))
+        if trial == 6:
+            kw, jobs = dict(lam=20.0), 0
         want = helpers.ref_uastc_rdo(packed, blocks, level, jobs, **kw)
-        got = helpers.host_uastc_rdo(packed, blocks, level, jobs, **kw)
-        bad = np.nonzero((got != want).any(1))[0]
-        assert bad.size == 0, f"trial {trial} level {level} jobs {jobs} {kw}: {bad.size} blocks differ, first {bad[:5]}"
+        for table in (False, True):
+            got = helpers.host_uastc_rdo(packed, blocks, level, jobs, table, **kw)
+            bad = np.nonzero((got != want).any(1))[0]
+            assert bad.size == 0, f"trial {trial} level {level} jobs {jobs} table {table} {kw}: {bad.size} blocks differ, first {bad[:5]}"
