@@ -220,6 +220,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(helpers, args)
         if not args.no_uastc:
             out["uastc"] = uastc_bench(ctx, d_blocks, n_blocks, w, h, helpers, args)
+            out["uastc_rdo"] = uastc_rdo_bench(ctx, helpers, args)
         print(json.dumps(out))
     if last is not None:
         last.close()
@@ -270,6 +271,52 @@ def uastc_bench(ctx, d_blocks, n_blocks, w, h, helpers, args):
         cdt = time.perf_counter() - t0
         res["cpu_baseline"] = {"value": round(sample.shape[0] * 16 / 1e6 / cdt, 4), "unit": "Mpixels/s", "cores": 1, "kind": "reference",
                                "sample": f"{sample.shape[0]} blocks strided over the bench image, reference encode_uastc level 2 (oracle/_ref), {cdt:.2f} s"}
+    return res
+
+
+def uastc_rdo_bench(ctx, helpers, args):
+    """BASELINE config #5 on one GPU: a batch of 24 Kodak-sized (768x512) images through encode_uastc level 2 and uastc_rdo (lambda 1.0,
+    4 strips per image = comp.cpp:2078's min(4, threads)). The batch is one resident array; 96 strips of 6144 blocks walk concurrently,
+    one workgroup each (row a20). One step = encode + RDO of the whole batch."""
+    import numpy as np
+    import torch
+    from basis_universal_amd import uastc
+    n_images, iw, ih = 24, 768, 512
+    blocks = np.concatenate([helpers.to_pixel_blocks(helpers.synth(iw, ih, 500 + k)) for k in range(n_images)])
+    n = blocks.shape[0]
+    d_px = torch.from_numpy(blocks.reshape(n, 64)).cuda()
+    d_out = torch.empty((n, 16), dtype=torch.uint8, device=d_px.device)
+    params = uastc.RdoParams(m_lambda=1.0)
+    flags, jobs = uastc.LEVEL_DEFAULT, 4 * n_images
+
+    def step():
+        uastc.encode_uastc_blocks(ctx, d_px.data_ptr(), flags, n_blocks=n, out_device=d_out.data_ptr())
+        return uastc.uastc_rdo(ctx, d_out.data_ptr(), d_px.data_ptr(), params, flags, jobs, n_blocks=n)[1]
+
+    step()
+    torch.cuda.synchronize()
+    ctx.profile_enable(True)
+    steps = max(args.steps, 3)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        info = step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    kern = ctx.profile_read()
+    ctx.profile_enable(False)
+    res = {"metric": "UASTC LDR 4x4 level 2 + RDO (lambda 1.0) Mpixels/s", "value": round(n * 16 / 1e6 / dt, 2), "unit": "Mpixels/s",
+           "ms_per_step": round(dt * 1e3, 2), "workload": f"{n_images} x {iw}x{ih} synthetic RGBA, {jobs} strips of {n // jobs} blocks",
+           "modified_blocks": int(info["modified"]), "kernels_ms_per_step": {k: round(v[0] / steps, 3) for k, v in kern.items()},
+           "serial_step_us": round(kern["uastc_rdo_strips"][0] / steps * 1e3 / (n // jobs), 3)}
+    if not args.no_cpu_baseline and helpers.have_ref():
+        one = blocks[: n // n_images]
+        t0 = time.perf_counter()
+        packed = helpers.ref_encode_uastc(one, flags)
+        t1 = time.perf_counter()
+        helpers.ref_uastc_rdo(packed, one, flags, 0, lam=1.0)
+        t2 = time.perf_counter()
+        res["cpu_baseline"] = {"value": round(one.shape[0] * 16 / 1e6 / (t2 - t0), 4), "unit": "Mpixels/s", "cores": 1, "kind": "reference",
+                               "sample": f"one {iw}x{ih} image of the batch: reference encode_uastc {t1 - t0:.2f} s + uastc_rdo {t2 - t1:.2f} s on one thread (oracle/_ref)"}
     return res
 
 
