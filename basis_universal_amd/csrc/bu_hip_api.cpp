@@ -686,10 +686,20 @@ int bu_hip_k_uastc_rdo(bu_hip_context* ctx, void* d_blocks, const void* d_px, ui
     const uint32_t up[3] = { params->m_lz_dict_size, params->m_lz_literal_cost, params->m_endpoint_refinement };
     arena& ws = ctx->scratch[5];
     BU_TRY(ctx, ws.reserve(bu::uastc_rdo_workspace_bytes(n_blocks, total_jobs)));
-    static const char* const names[3] = { "uastc_rdo_prepare", "uastc_rdo_strips", "uastc_rdo_finish" };
-    for (int phase = 0; phase < 3; phase++) {
+    static const char* const names[2] = { "uastc_rdo_prepare", "uastc_rdo_strips" };
+    for (int phase = 0; phase < 2; phase++) {
         prof_scope ps(ctx, names[phase]);
         BU_TRY(ctx, bu::launch_uastc_rdo_phase(ctx->stream, phase, d_blocks, d_px, n_blocks, fp, up, flags, total_jobs, ws.p));
+    }
+    // how many blocks each strip modified: sizes the finish launch (a 16-byte copy per 4 strips; the walk has to be over anyway)
+    std::vector<uint32_t> per_strip(bu::uastc_rdo_strips(n_blocks, total_jobs));
+    BU_TRY(ctx, hipMemcpyAsync(per_strip.data(), bu::uastc_rdo_strip_counts(ws.p, n_blocks, total_jobs), per_strip.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+    BU_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    uint32_t longest = 0;
+    for (uint32_t c : per_strip) longest = c > longest ? c : longest;
+    {
+        prof_scope ps(ctx, "uastc_rdo_finish");
+        BU_TRY(ctx, bu::launch_uastc_rdo_finish(ctx->stream, d_blocks, d_px, n_blocks, fp, up, flags, total_jobs, ws.p, longest));
     }
     uint32_t counters[4] = { 0, 0, 0, 0 };
     BU_TRY(ctx, hipMemcpyAsync(counters, bu::uastc_rdo_counters(ws.p, n_blocks, total_jobs), sizeof(counters), hipMemcpyDeviceToHost, ctx->stream));

@@ -89,8 +89,7 @@ struct csr {
 
 // Plain data-parallel loop over [0, n) on a few host threads (the per-block bookkeeping between device stages).
 template <class F> void parallel_for(uint32_t n, F fn) {
-    unsigned t = std::thread::hardware_concurrency();
-    t = t > 8 ? 8 : (t ? t : 1);
+    const unsigned t = host_threads();
     if (n < 65536 || t == 1) { fn(0u, n); return; }
     std::vector<std::thread> th;
     const uint32_t per = (n + t - 1) / t;
@@ -125,7 +124,7 @@ void lists_by_cluster(uint32_t n, uint32_t k, KeyFn cluster_of, std::vector<std:
     }
     lists.clear(); lists.resize(k);
     std::atomic<uint32_t> next{0};
-    parallel_for_chunks(n > 65536 ? 8 : 1, [&](unsigned) {
+    parallel_for_chunks(n > 65536 ? host_threads() : 1, [&](unsigned) {
         for (uint32_t c; (c = next.fetch_add(1)) < k;) lists[c].assign(flat.begin() + start[c], flat.begin() + start[c + 1]);
     });
 }
@@ -677,7 +676,7 @@ bool etc1s_frontend::generate_selector_clusters() {
     // Stable sort of (key, block) by key. One MSD pass on the top byte splits the blocks into 256 buckets (per-thread histograms, so
     // the scatter keeps block order inside a bucket); the buckets are then LSD-sorted on the remaining 24 bits independently.
     {
-        const unsigned T = 8;
+        const unsigned T = host_threads();
         const uint32_t per = (n + T - 1) / T;
         std::vector<uint32_t> hist((size_t)T * 256, 0);
         parallel_for_chunks(T, [&](unsigned t) {
@@ -726,9 +725,9 @@ bool etc1s_frontend::generate_selector_clusters() {
     // distinct keys with their summed weights; the members of distinct vector u are idx[goffs[u] .. goffs[u+1]) (ascending block index)
     std::vector<uint32_t> ukeys, goffs; std::vector<uint64_t> uw;
     {
-        const unsigned T = 8;
+        const unsigned T = host_threads();
         const uint32_t per = (n + T - 1) / T;
-        uint32_t starts[T + 1] = {0};
+        std::vector<uint32_t> starts(T + 1, 0);
         parallel_for_chunks(T, [&](unsigned t) {  // groups that START inside a chunk belong to it
             const uint32_t a = t * per, b = std::min(n, a + per);
             uint32_t c = 0;

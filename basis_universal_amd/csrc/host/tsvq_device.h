@@ -22,6 +22,18 @@
 
 namespace bu {
 
+// Host threads per parallel region of the bookkeeping between device stages: 8 unless BU_HOST_THREADS says otherwise (1..32).
+inline unsigned host_threads() {
+    static const unsigned t = [] {
+        const unsigned hw = std::thread::hardware_concurrency();
+        unsigned want = 8;
+        if (const char* e = std::getenv("BU_HOST_THREADS")) { const int v = std::atoi(e); if (v >= 1 && v <= 32) want = (unsigned)v; }
+        return hw ? (want < hw ? want : hw) : 1u;
+    }();
+    return t;
+}
+
+
 // The original training-vector indices behind every distinct vector: either one std::vector per distinct vector, or CSR
 // (offsets[u] .. offsets[u+1] into one index array), which is what a sort-based de-duplication yields for free.
 struct vec_groups {
@@ -216,7 +228,7 @@ private:
             std::atomic<size_t> next{0};
             auto work = [&] { for (size_t i; (i = next.fetch_add(1)) < leaf_members.size();) expand_one(leaf_members[i].p, leaf_members[i].n, codebook[i]); };
             std::vector<std::thread> th;
-            const unsigned T = n > 65536 ? 8 : 1;
+            const unsigned T = n > 65536 ? host_threads() : 1;
             for (unsigned t = 1; t < T; t++) th.emplace_back(work);
             work();
             for (auto& x : th) x.join();
@@ -260,7 +272,7 @@ private:
                 std::atomic<uint32_t> next{0};
                 auto work = [&] { for (uint32_t c; (c = next.fetch_add(1)) < cuts;) expand_one(sorted.data() + cut_ofs[c], cut_ofs[c + 1] - cut_ofs[c], parent_codebook[c]); };
                 std::vector<std::thread> th;
-                const unsigned T = n > 65536 ? 8 : 1;
+                const unsigned T = n > 65536 ? host_threads() : 1;
                 for (unsigned t = 1; t < T; t++) th.emplace_back(work);
                 work();
                 for (auto& x : th) x.join();

@@ -16,12 +16,17 @@ hipError_t launch_uastc_phase(hipStream_t st, int phase, const void* d_pixel_blo
 // uastc_rdo (encoder/basisu_uastc_enc.h:139, uastc_enc.cpp:4095) in place over n_blocks resident UASTC blocks (uastc_rdo_kernels.hip).
 // fparams: lambda, max_allowed_rms_increase_ratio, skip_block_rms_thresh, max_smooth_block_std_dev, smooth_block_max_error_scale;
 // uparams: lz_dict_size, lz_literal_cost, endpoint_refinement. total_jobs splits into independent strips exactly as the reference does.
-// Phases: 0 prepare (parallel), 1 strips (serial per strip), 2 rehint (parallel over modified blocks). Stream-ordered.
+// Phases: 0 prepare (parallel), 1 strips (serial per strip); then launch_uastc_rdo_finish (refit + hints of the modified blocks) with the
+// longest per-strip list length read back from uastc_rdo_strip_counts. Stream-ordered.
 size_t uastc_rdo_workspace_bytes(uint32_t n_blocks, uint32_t total_jobs);
 uint32_t uastc_rdo_strips(uint32_t n_blocks, uint32_t total_jobs);
 hipError_t launch_uastc_rdo_phase(hipStream_t st, int phase, void* d_blocks, const void* d_pixel_blocks, uint32_t n_blocks, const float* fparams,
                                   const uint32_t* uparams, uint32_t flags, uint32_t total_jobs, void* d_workspace);
-// device address of 4 x uint32 {modified, failed, refined, skipped} inside the workspace, valid after phase 1
+hipError_t launch_uastc_rdo_finish(hipStream_t st, void* d_blocks, const void* d_pixel_blocks, uint32_t n_blocks, const float* fparams, const uint32_t* uparams,
+                                   uint32_t flags, uint32_t total_jobs, void* d_workspace, uint32_t longest_list);
+// device address of uastc_rdo_strips() x uint32: modified blocks per strip, valid after phase 1
+const void* uastc_rdo_strip_counts(void* d_workspace, uint32_t n_blocks, uint32_t total_jobs);
+// device address of 4 x uint32 {modified, failed, refined, skipped} inside the workspace, valid after phase 1 (refined: after the finish)
 const void* uastc_rdo_counters(void* d_workspace, uint32_t n_blocks, uint32_t total_jobs);
 
 } // namespace bu

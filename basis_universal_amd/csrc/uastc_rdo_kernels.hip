@@ -426,11 +426,10 @@ __global__ void __launch_bounds__(RDO_THREADS) k_rdo_strips(uint4* blocks, const
 __global__ void __launch_bounds__(64) k_rdo_finish(uint4* blocks, const uint4* __restrict__ px, uint32_t n, uint32_t per_job, enc_cfg e, rdo_params p,
                                                    const uint32_t* __restrict__ mod_list, const uint32_t* __restrict__ strip_counts,
                                                    const uint8_t* __restrict__ state, uint32_t* counters) {
-    const uint32_t k = blockIdx.x * 64 + threadIdx.x;
-    if (k >= n) return;
-    const uint32_t strip = per_job ? k / per_job : 0;
-    if (k - strip * per_job >= strip_counts[strip]) return;
-    const uint32_t b = mod_list[k];
+    const uint32_t strip = blockIdx.y, k = blockIdx.x * 64 + threadIdx.x;  // grid.x covers the longest list
+    if (k >= strip_counts[strip]) return;
+    const uint32_t b = mod_list[(size_t)strip * per_job + k];
+    if (b >= n) return;
     alignas(16) uint8_t blk[16];
     *reinterpret_cast<uint4*>(blk) = blocks[b];
     alignas(16) rgba8 t[16];
@@ -497,15 +496,27 @@ hipError_t launch_uastc_rdo_phase(hipStream_t st, int phase, void* d_blocks, con
         break;
     }
     default: {
-        enc_cfg e;
-        make_cfg(flags, e);
-        hipLaunchKernelGGL(k_rdo_finish, dim3(gx), dim3(64), 0, st, blocks, px, n, per_job, e, p, w.mod_list, w.strip_counts, w.state, w.counters);
-        break;
+        // phase 2 takes the longest per-strip list length in `total_jobs`' place holder: see launch_uastc_rdo_finish
+        return hipErrorInvalidValue;
     }
     }
     return hipGetLastError();
 }
 
+hipError_t launch_uastc_rdo_finish(hipStream_t st, void* d_blocks, const void* d_px, uint32_t n, const float* fparams, const uint32_t* uparams, uint32_t flags,
+                                   uint32_t total_jobs, void* d_ws, uint32_t longest_list) {
+    if (!n || !longest_list) return hipSuccess;
+    const rdo_workspace w = carve(d_ws, n, total_jobs, nullptr);
+    uint32_t per_job, n_strips, cap;
+    strip_layout(n, total_jobs, per_job, n_strips, cap);
+    enc_cfg e;
+    make_cfg(flags, e);
+    hipLaunchKernelGGL(k_rdo_finish, dim3((longest_list + 63) / 64, n_strips), dim3(64), 0, st, static_cast<uint4*>(d_blocks), static_cast<const uint4*>(d_px), n,
+                       per_job, e, to_params(fparams, uparams), w.mod_list, w.strip_counts, w.state, w.counters);
+    return hipGetLastError();
+}
+
 const void* uastc_rdo_counters(void* d_ws, uint32_t n, uint32_t total_jobs) { return carve(d_ws, n, total_jobs, nullptr).counters; }
+const void* uastc_rdo_strip_counts(void* d_ws, uint32_t n, uint32_t total_jobs) { return carve(d_ws, n, total_jobs, nullptr).strip_counts; }
 
 } // namespace bu

@@ -300,6 +300,76 @@ REF_API int ref_tsvq(uint32_t dim, const float* vecs, const uint64_t* weights, u
 	return 1;
 }
 
+// ---------------------------------------------------------------- ETC1S backend, first stage
+// basisu_backend::create_encoder_blocks (encoder/basisu_backend.cpp:406-617) on a finished frontend: one 2D slice of num_blocks_x x
+// num_blocks_y blocks. Outputs per block (raster order): the endpoint index after the endpoint-prediction RDO remap (:441-586, BEFORE the
+// codebook re-sort: at levels > 1 this call applies reoptimize_remapped_endpoints to the frontend, exactly as the reference does), the
+// endpoint predictor, the selector index; and the two codebook remap tables the stage ends with.
+REF_API int ref_backend_create_encoder_blocks(void* hv, uint32_t num_blocks_x, uint32_t num_blocks_y, float endpoint_rdo_thresh, float selector_rdo_thresh,
+	int32_t* out_endpoint_index, uint32_t* out_predictor, int32_t* out_selector_index, uint32_t* out_endpoint_old_to_new, uint32_t* out_selector_new_to_old, double* seconds) {
+	frontend_handle* h = static_cast<frontend_handle*>(hv);
+	basisu_backend be;
+	basisu_backend_params bp;
+	bp.m_etc1s = true;
+	bp.m_compression_level = h->p.m_compression_level;
+	bp.m_endpoint_rdo_quality_thresh = endpoint_rdo_thresh;
+	bp.m_selector_rdo_quality_thresh = selector_rdo_thresh;
+	bp.m_used_global_codebooks = false;
+	basisu_backend_slice_desc_vec slices(1);
+	slices[0].m_first_block_index = 0;
+	slices[0].m_orig_width = slices[0].m_width = num_blocks_x * 4;
+	slices[0].m_orig_height = slices[0].m_height = num_blocks_y * 4;
+	slices[0].m_num_blocks_x = num_blocks_x;
+	slices[0].m_num_blocks_y = num_blocks_y;
+	slices[0].m_num_macroblocks_x = (num_blocks_x + 1) / 2;
+	slices[0].m_num_macroblocks_y = (num_blocks_y + 1) / 2;
+	slices[0].m_iframe = true;
+	if ((uint64_t)num_blocks_x * num_blocks_y != h->fe.m_total_blocks) return 0;
+	be.init(&h->fe, bp, slices);
+	be.create_endpoint_palette();
+	be.create_selector_palette();
+	interval_timer tm;
+	tm.start();
+	be.create_encoder_blocks();
+	if (seconds) *seconds = tm.get_elapsed_secs();
+	for (uint32_t y = 0; y < num_blocks_y; y++)
+		for (uint32_t x = 0; x < num_blocks_x; x++) {
+			const encoder_block& m = be.m_slice_encoder_blocks[0](x, y);
+			const size_t i = (size_t)y * num_blocks_x + x;
+			out_endpoint_index[i] = m.m_endpoint_index;
+			out_predictor[i] = m.m_endpoint_predictor;
+			out_selector_index[i] = m.m_selector_index;
+		}
+	if (out_endpoint_old_to_new) for (uint32_t i = 0; i < be.m_endpoint_remap_table_old_to_new.size(); i++) out_endpoint_old_to_new[i] = be.m_endpoint_remap_table_old_to_new[i];
+	if (out_selector_new_to_old) for (uint32_t i = 0; i < be.m_selector_remap_table_new_to_old.size(); i++) out_selector_new_to_old[i] = be.m_selector_remap_table_new_to_old[i];
+	return 1;
+}
+
+// basisu_backend::encode() (backend.cpp:1747) as a whole on a finished frontend, for timing the stages downstream of the hot path.
+REF_API uint32_t ref_backend_encode(void* hv, uint32_t num_blocks_x, uint32_t num_blocks_y, float endpoint_rdo_thresh, float selector_rdo_thresh, double* seconds) {
+	frontend_handle* h = static_cast<frontend_handle*>(hv);
+	basisu_backend be;
+	basisu_backend_params bp;
+	bp.m_etc1s = true;
+	bp.m_compression_level = h->p.m_compression_level;
+	bp.m_endpoint_rdo_quality_thresh = endpoint_rdo_thresh;
+	bp.m_selector_rdo_quality_thresh = selector_rdo_thresh;
+	basisu_backend_slice_desc_vec slices(1);
+	slices[0].m_orig_width = slices[0].m_width = num_blocks_x * 4;
+	slices[0].m_orig_height = slices[0].m_height = num_blocks_y * 4;
+	slices[0].m_num_blocks_x = num_blocks_x;
+	slices[0].m_num_blocks_y = num_blocks_y;
+	slices[0].m_num_macroblocks_x = (num_blocks_x + 1) / 2;
+	slices[0].m_num_macroblocks_y = (num_blocks_y + 1) / 2;
+	slices[0].m_iframe = true;
+	be.init(&h->fe, bp, slices);
+	interval_timer tm;
+	tm.start();
+	const uint32_t bytes = be.encode();
+	if (seconds) *seconds = tm.get_elapsed_secs();
+	return bytes;
+}
+
 // ---------------------------------------------------------------- UASTC
 
 REF_API void ref_encode_uastc(const uint8_t* pixel_blocks, uint32_t n_blocks, uint32_t flags, uint8_t* out_blocks16) {

@@ -191,6 +191,20 @@ class RefFrontend:
     def get_csr(self, name):
         return csr_blob_split(self.get(name, np.uint32))
 
+    def backend_encoder_blocks(self, nbx, nby, endpoint_thresh=1.5, selector_thresh=1.25):
+        """basisu_backend::create_encoder_blocks on the finished frontend (2D, one slice). Returns a dict of arrays + the CPU seconds."""
+        n = nbx * nby
+        ep, pred, sel = np.zeros(n, np.int32), np.zeros(n, np.uint32), np.zeros(n, np.int32)
+        k_ep = int(self.get("endpoint_cluster_etc_params").size // 1) if False else 65536
+        o2n, n2o = np.full(k_ep, 0xFFFFFFFF, np.uint32), np.full(k_ep, 0xFFFFFFFF, np.uint32)
+        secs = C.c_double(0)
+        f = self.L.ref_backend_create_encoder_blocks
+        f.restype = C.c_int
+        f.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]
+        assert f(self.h, nbx, nby, endpoint_thresh, selector_thresh, ep.ctypes.data, pred.ctypes.data, sel.ctypes.data, o2n.ctypes.data, n2o.ctypes.data, C.byref(secs)) == 1
+        return {"endpoint_index": ep, "predictor": pred, "selector_index": sel, "endpoint_old_to_new": o2n[o2n != 0xFFFFFFFF],
+                "selector_new_to_old": n2o[n2o != 0xFFFFFFFF], "seconds": secs.value}
+
     def close(self):
         if self.h:
             self.L.ref_frontend_destroy(self.h)
