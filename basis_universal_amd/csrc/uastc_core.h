@@ -1543,6 +1543,15 @@ BU_FN uint64_t ycc_diff(const ycc& a, const ycc& b) {  // color_diff, uastc_enc.
     return (square_s18(a.y - b.y) << 2) + square_s18(a.cr - b.cr) + square_s18(a.cb - b.cb);
 }
 struct texels_ycc { ycc t[16]; };
+// The same metric in double precision: every value is an integer far below 2^53, so the arithmetic is exact and orders like the u64 form --
+// but one v_fma_f64 (full rate on gfx950) replaces a 64-bit multiply-add (four 32-bit instructions), and one v_min_f64 a 64-bit
+// compare-and-select. The luma is kept doubled, so (2 dy)^2 is the reference's 4 dy^2.
+struct yccd { double y2, cb, cr; };
+BU_FN yccd to_yccd(const ycc& c) { yccd o = { (double)(2 * c.y), (double)c.cb, (double)c.cr }; return o; }
+BU_FN double ycc_diff_d(const yccd& a, const yccd& b) {
+    const double dy = a.y2 - b.y2, dcb = a.cb - b.cb, dcr = a.cr - b.cr;
+    return __builtin_fma(dy, dy, __builtin_fma(dcr, dcr, dcb * dcb));
+}
 
 // raster index of texel j (0..7) of sub-block SUB; in the flipped layout j runs row by row (g_etc1_pixel_coords, etc.cpp:314-337)
 template <int FLIP, int SUB> constexpr int etc1_texel(int j) { return FLIP ? (SUB * 8 + j) : ((j & 3) * 4 + SUB * 2 + (j >> 2)); }
@@ -1561,29 +1570,29 @@ BU_FN void etc1_stats(const rgba8* decoded, etc1_subblock_stats& s) {
         }
 }
 
-BU_FN void etc1_table_colours(const int* base, uint32_t table, ycc* out) {
+BU_FN void etc1_table_colours(const int* base, uint32_t table, yccd* out) {
     for (uint32_t k = 0; k < 4; k++) {
         const int d = ku_etc1_inten[table * 4 + k];
-        out[k] = to_ycc(clampi(base[0] + d, 0, 255), clampi(base[1] + d, 0, 255), clampi(base[2] + d, 0, 255));
+        out[k] = to_yccd(to_ycc(clampi(base[0] + d, 0, 255), clampi(base[1] + d, 0, 255), clampi(base[2] + d, 0, 255)));
     }
 }
 
 // best intensity table of one sub-block for base colour `base` (uastc_enc.cpp:2858-2918)
 template <int FLIP, int SUB>
 BU_FN uint32_t etc1_pick_table(const texels_ycc& dec, const int* base, uint32_t limit) {
-    uint64_t best = UINT64_MAX;
+    double best = 1e300;
     uint32_t best_table = 0;
     for (uint32_t table = 0; table < limit; table++) {
-        ycc col[4];
+        yccd col[4];
         etc1_table_colours(base, table, col);
-        uint64_t total = 0;
+        double total = 0.0;
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
         for (int j = 0; j < 8; j++) {
-            const ycc& c = dec.t[etc1_texel<FLIP, SUB>(j)];
-            uint64_t m = ycc_diff(col[0], c);
-            for (int k = 1; k < 4; k++) { const uint64_t d = ycc_diff(col[k], c); m = d < m ? d : m; }
+            const yccd c = to_yccd(dec.t[etc1_texel<FLIP, SUB>(j)]);
+            double m = ycc_diff_d(col[0], c);
+            for (int k = 1; k < 4; k++) { const double d = ycc_diff_d(col[k], c); m = d < m ? d : m; }
             total += m;
         }
         if (!FLIP && total >= best) break;
@@ -1594,29 +1603,34 @@ BU_FN uint32_t etc1_pick_table(const texels_ycc& dec, const int* base, uint32_t 
 
 // error of one sub-block against the source texels when every texel takes the colour nearest to its decoded value (:2925-2973)
 template <int FLIP, int SUB>
-BU_FN uint64_t etc1_subblock_error(const texels_ycc& dec, const texels_ycc& src, const int* base, uint32_t table) {
-    ycc col[4];
+BU_FN double etc1_subblock_error(const texels_ycc& dec, const rgba8* src, const int* base, uint32_t table) {
+    yccd col[4];
     etc1_table_colours(base, table, col);
-    uint64_t err = 0;
+    double err = 0.0;
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
     for (int j = 0; j < 8; j++) {
         const int t = etc1_texel<FLIP, SUB>(j);
-        uint64_t m = ycc_diff(col[0], dec.t[t]) << 2;
-        for (int k = 1; k < 4; k++) { const uint64_t d = (ycc_diff(col[k], dec.t[t]) << 2) + (uint64_t)k; m = d < m ? d : m; }
-        const uint32_t pick = (uint32_t)m & 3;
-        // the chosen colour by value: a dynamically indexed local array would live in scratch memory on the GPU
-        const ycc chosen = pick == 0 ? col[0] : (pick == 1 ? col[1] : (pick == 2 ? col[2] : col[3]));
-        err += ycc_diff(src.t[t], chosen);
+        const yccd c = to_yccd(dec.t[t]);
+        // first minimum: the chosen colour is carried by value (a dynamically indexed local array would live in scratch memory on the GPU)
+        double m = ycc_diff_d(col[0], c);
+        yccd chosen = col[0];
+        for (int k = 1; k < 4; k++) {
+            const double d = ycc_diff_d(col[k], c);
+            const bool better = d < m;
+            m = better ? d : m;
+            chosen.y2 = better ? col[k].y2 : chosen.y2; chosen.cb = better ? col[k].cb : chosen.cb; chosen.cr = better ? col[k].cr : chosen.cr;
+        }
+        err += ycc_diff_d(to_yccd(to_ycc(src[t].c[0], src[t].c[1], src[t].c[2])), chosen);  // converted here: 48 fewer live registers than a second texel table
     }
     return err;
 }
 
-struct etc1_search { uint64_t best_err; etc1_hint best; };
+struct etc1_search { double best_err; etc1_hint best; };
 
 template <int FLIP>
-BU_FN void etc1_trials(uint32_t mode, const rgba8* decoded, const texels_ycc& dec, const texels_ycc& src, const enc_cfg& e, uint32_t last_individ,
+BU_FN void etc1_trials(uint32_t mode, const rgba8* decoded, const texels_ycc& dec, const rgba8* src, const enc_cfg& e, uint32_t last_individ,
                        uint32_t last_bias, bool sorted_table, etc1_search& out) {
     const bool has_bias = ku_mode_has_etc1_bias[mode] != 0;
     etc1_subblock_stats st[2];
@@ -1656,7 +1670,7 @@ BU_FN void etc1_trials(uint32_t mode, const rgba8* decoded, const texels_ycc& de
             }
             const uint32_t t0 = etc1_pick_table<FLIP, 0>(dec, base[0], limit[0]);
             const uint32_t t1 = etc1_pick_table<FLIP, 1>(dec, base[1], limit[1]);
-            const uint64_t err = etc1_subblock_error<FLIP, 0>(dec, src, base[0], t0) + etc1_subblock_error<FLIP, 1>(dec, src, base[1], t1);
+            const double err = etc1_subblock_error<FLIP, 0>(dec, src, base[0], t0) + etc1_subblock_error<FLIP, 1>(dec, src, base[1], t1);
             if (err < out.best_err) {
                 out.best_err = err;
                 out.best.flip = (uint8_t)FLIP; out.best.diff = (uint8_t)(individ == 0); out.best.inten0 = (uint8_t)t0; out.best.inten1 = (uint8_t)t1; out.best.bias = (uint8_t)bias;
@@ -1681,22 +1695,19 @@ BU_FN_BIG void etc1_hints(uint32_t mode, const rgba8* px, const rgba8* decoded, 
         default: last_bias = 32; break;
         }
     }
-    texels_ycc src, dec;
+    texels_ycc dec;
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
-    for (int i = 0; i < 16; i++) {
-        src.t[i] = to_ycc(px[i].c[0], px[i].c[1], px[i].c[2]);
-        dec.t[i] = to_ycc(decoded[i].c[0], decoded[i].c[1], decoded[i].c[2]);
-    }
+    for (int i = 0; i < 16; i++) dec.t[i] = to_ycc(decoded[i].c[0], decoded[i].c[1], decoded[i].c[2]);
     uint32_t first_flip = 0, last_flip = 2, last_individ = 2;
     if (e.flags & FLAG_ETC1_NO_FLIP_INDIVIDUAL) { last_flip = 1; last_individ = 1; }
     else if (flip_estimate) { if (etc1_estimate_flipped(decoded)) first_flip = 1; last_flip = first_flip + 1; }
     etc1_search s;
-    s.best_err = UINT64_MAX;
+    s.best_err = 1e300;
     s.best.flip = s.best.diff = s.best.inten0 = s.best.inten1 = s.best.bias = 0;
-    if (first_flip == 0) etc1_trials<0>(mode, decoded, dec, src, e, last_individ, last_bias, sorted_table, s);
-    if (last_flip == 2 || first_flip == 1) etc1_trials<1>(mode, decoded, dec, src, e, last_individ, last_bias, sorted_table, s);
+    if (first_flip == 0) etc1_trials<0>(mode, decoded, dec, px, e, last_individ, last_bias, sorted_table, s);
+    if (last_flip == 2 || first_flip == 1) etc1_trials<1>(mode, decoded, dec, px, e, last_individ, last_bias, sorted_table, s);
     best = s.best;
 }
 

@@ -133,7 +133,7 @@ struct slot_view {
     __device__ inline uint32_t mode(uint32_t i) const { return plan->slot_mode[i]; }
 };
 
-__global__ void __launch_bounds__(64) k_uastc_finish(const uint4* __restrict__ px, uint32_t n, const uastc_plan* __restrict__ plan,
+__global__ void __launch_bounds__(64, 2) k_uastc_finish(const uint4* __restrict__ px, uint32_t n, const uastc_plan* __restrict__ plan,
                                                      const uint8_t* __restrict__ cls, const cand* __restrict__ cands,
                                                      const uint64_t* __restrict__ overall, const float* __restrict__ rms, uint4* __restrict__ out) {
     const uint32_t b = blockIdx.x * 64 + threadIdx.x;
