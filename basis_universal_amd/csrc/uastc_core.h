@@ -1629,10 +1629,24 @@ BU_FN double etc1_subblock_error(const texels_ycc& dec, const rgba8* src, const 
 
 struct etc1_search { double best_err; etc1_hint best; };
 
+// The ETC1 bias list repeats itself per sub-block: apply_etc1_bias (transcoder.cpp:16547-16612) moves sub-block `s` of bias b by a delta vector
+// that many biases share (most touch one sub-block only). ku_bias_slot[order][s][i] numbers the distinct vectors in list order (order 0 =
+// the sorted list, 1 = 0..31); bit i of ku_bias_first[order][s] is set where a vector occurs for the first time. (generated: see the note in
+// etc1_trials)
+BU_TAB unsigned char ku_bias_slot[2][2][32] = {
+    { { 0, 1, 2, 0, 1, 3, 4, 5, 0, 4, 0, 6, 7, 3, 8, 9, 2, 10, 11, 12, 13, 14, 4, 0, 15, 0, 0, 0, 0, 13, 10, 12 }, { 0, 1, 2, 3, 0, 4, 3, 5, 1, 0, 2, 6, 7, 0, 8, 0, 0, 0, 9, 0, 0, 10, 1, 4, 11, 12, 13, 14, 15, 13, 14, 15 } },
+    { { 0, 1, 2, 3, 4, 5, 4, 6, 7, 8, 9, 10, 2, 7, 6, 11, 10, 12, 7, 7, 7, 7, 11, 13, 7, 14, 15, 0, 15, 7, 7, 15 }, { 0, 1, 2, 3, 4, 2, 2, 2, 5, 6, 7, 2, 8, 2, 9, 2, 10, 11, 8, 12, 4, 9, 5, 13, 10, 14, 15, 2, 0, 15, 0, 2 } },
+};
+BU_TAB unsigned int ku_bias_first[2][2] = { { 0x013ED8E7u, 0x1F2458AFu }, { 0x06828FBFu, 0x068B571Fu } };
+// Per-block scratch for the repeats: 32 entries (16 per sub-block) of {error, table}; entry i of this block lives at [i * stride] (the GPU
+// keeps it in LDS, one column per lane). Optional: without it every trial is evaluated from scratch, with the same result.
+struct hint_cache { double* err; unsigned char* table; unsigned int stride; };
+
 template <int FLIP>
 BU_FN void etc1_trials(uint32_t mode, const rgba8* decoded, const texels_ycc& dec, const rgba8* src, const enc_cfg& e, uint32_t last_individ,
-                       uint32_t last_bias, bool sorted_table, etc1_search& out) {
+                       uint32_t last_bias, bool sorted_table, etc1_search& out, const hint_cache* cache) {
     const bool has_bias = ku_mode_has_etc1_bias[mode] != 0;
+    const uint32_t order = sorted_table ? 0u : 1u;
     etc1_subblock_stats st[2];
     etc1_stats<FLIP, 0>(decoded, st[0]);
     etc1_stats<FLIP, 1>(decoded, st[1]);
@@ -1668,9 +1682,27 @@ BU_FN void etc1_trials(uint32_t mode, const rgba8* decoded, const texels_ycc& de
                 }
                 limit[sub] = e.level == 4 ? 8 : (range > 51 ? 8 : (range >= 7 ? 4 : 2));
             }
-            const uint32_t t0 = etc1_pick_table<FLIP, 0>(dec, base[0], limit[0]);
-            const uint32_t t1 = etc1_pick_table<FLIP, 1>(dec, base[1], limit[1]);
-            const double err = etc1_subblock_error<FLIP, 0>(dec, src, base[0], t0) + etc1_subblock_error<FLIP, 1>(dec, src, base[1], t1);
+            // Sub-block 0's colour depends on its own delta vector only; sub-block 1's too in individual mode (in differential mode it is
+            // coded relative to sub-block 0). A vector seen before in this (flip, mode) pass gives the same table and error: reuse them.
+            uint32_t t0, t1;
+            double e0, e1;
+            const bool reuse = cache != nullptr && has_bias;
+            const uint32_t s0 = ku_bias_slot[order][0][bi], s1 = 16u + ku_bias_slot[order][1][bi];
+            if (reuse && !((ku_bias_first[order][0] >> bi) & 1u)) {
+                t0 = cache->table[s0 * cache->stride]; e0 = cache->err[s0 * cache->stride];
+            } else {
+                t0 = etc1_pick_table<FLIP, 0>(dec, base[0], limit[0]);
+                e0 = etc1_subblock_error<FLIP, 0>(dec, src, base[0], t0);
+                if (reuse) { cache->table[s0 * cache->stride] = (unsigned char)t0; cache->err[s0 * cache->stride] = e0; }
+            }
+            if (reuse && individ && !((ku_bias_first[order][1] >> bi) & 1u)) {
+                t1 = cache->table[s1 * cache->stride]; e1 = cache->err[s1 * cache->stride];
+            } else {
+                t1 = etc1_pick_table<FLIP, 1>(dec, base[1], limit[1]);
+                e1 = etc1_subblock_error<FLIP, 1>(dec, src, base[1], t1);
+                if (reuse && individ) { cache->table[s1 * cache->stride] = (unsigned char)t1; cache->err[s1 * cache->stride] = e1; }
+            }
+            const double err = e0 + e1;
             if (err < out.best_err) {
                 out.best_err = err;
                 out.best.flip = (uint8_t)FLIP; out.best.diff = (uint8_t)(individ == 0); out.best.inten0 = (uint8_t)t0; out.best.inten1 = (uint8_t)t1; out.best.bias = (uint8_t)bias;
@@ -1679,7 +1711,7 @@ BU_FN void etc1_trials(uint32_t mode, const rgba8* decoded, const texels_ycc& de
     }
 }
 
-BU_FN_BIG void etc1_hints(uint32_t mode, const rgba8* px, const rgba8* decoded, const enc_cfg& e, etc1_hint& best) {
+BU_FN_BIG void etc1_hints(uint32_t mode, const rgba8* px, const rgba8* decoded, const enc_cfg& e, etc1_hint& best, const hint_cache* cache = nullptr) {
     const bool faster = (e.flags & FLAG_ETC1_FASTER) != 0, fastest = (e.flags & FLAG_ETC1_FASTEST) != 0;
     const bool has_bias = ku_mode_has_etc1_bias[mode] != 0;
     uint32_t last_bias = 1;
@@ -1706,8 +1738,8 @@ BU_FN_BIG void etc1_hints(uint32_t mode, const rgba8* px, const rgba8* decoded, 
     etc1_search s;
     s.best_err = 1e300;
     s.best.flip = s.best.diff = s.best.inten0 = s.best.inten1 = s.best.bias = 0;
-    if (first_flip == 0) etc1_trials<0>(mode, decoded, dec, px, e, last_individ, last_bias, sorted_table, s);
-    if (last_flip == 2 || first_flip == 1) etc1_trials<1>(mode, decoded, dec, px, e, last_individ, last_bias, sorted_table, s);
+    if (first_flip == 0) etc1_trials<0>(mode, decoded, dec, px, e, last_individ, last_bias, sorted_table, s, cache);
+    if (last_flip == 2 || first_flip == 1) etc1_trials<1>(mode, decoded, dec, px, e, last_individ, last_bias, sorted_table, s, cache);
     best = s.best;
 }
 
@@ -1829,7 +1861,7 @@ BU_FN void pack_block(const cand& norm, const etc1_hint& etc1, uint32_t eac_tabl
 // ------------------------------------------------------------------------------------------------------------------
 
 // hints + packing of the chosen candidate (uastc_enc.cpp:3550-3644)
-BU_FN_BIG void finish_block(const rgba8* px, const enc_cfg& e, const cand& chosen, uint8_t* out16) {
+BU_FN_BIG void finish_block(const rgba8* px, const enc_cfg& e, const cand& chosen, uint8_t* out16, const hint_cache* cache = nullptr) {
     cand best = chosen;
     rgba8 decoded[16];
     decode_uastc(best, decoded);
@@ -1839,7 +1871,7 @@ BU_FN_BIG void finish_block(const rgba8* px, const enc_cfg& e, const cand& chose
     uint32_t eac_table = 0, eac_mul = 0;
     if (ku_mode_has_alpha[best.mode]) eac_a8_hint(decoded, e.eac_mul_rad, e.eac_table_mask, eac_table, eac_mul);
     etc1_hint eh;
-    etc1_hints(best.mode, px, decoded, e, eh);
+    etc1_hints(best.mode, px, decoded, e, eh, cache);
     pack_block(best, eh, eac_table, eac_mul, h0, h1, out16);
 }
 
@@ -1870,7 +1902,10 @@ BU_FN_BIG void encode_block(const uint8_t* rgba64, uint32_t flags, uint8_t* out1
         if (scratch[i].valid) score[i] = score_candidate(scratch[i], px, cls, e);
     }
     array_view v = { scratch, score };
-    finish_block(px, e, scratch[choose_candidate(v, n_slots, e)], out16);
+    double cache_err[32];
+    unsigned char cache_table[32];
+    const hint_cache hc = { cache_err, cache_table, 1 };
+    finish_block(px, e, scratch[choose_candidate(v, n_slots, e)], out16, &hc);
 }
 
 }  // namespace bu_uastc

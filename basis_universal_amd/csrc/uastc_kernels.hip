@@ -151,8 +151,12 @@ __global__ void __launch_bounds__(64, 2) k_uastc_finish(const uint4* __restrict_
 #pragma unroll
         for (int k = 0; k < 4; k++) d[k] = s[k];
     }
+    // repeats of the ETC1 bias list (uastc_core.h, hint_cache): one LDS column per lane
+    __shared__ double s_hint_err[32 * 64];
+    __shared__ unsigned char s_hint_table[32 * 64];
+    const hint_cache hc = { s_hint_err + threadIdx.x, s_hint_table + threadIdx.x, 64 };
     alignas(16) uint8_t o[16];
-    finish_block(t, plan->e, r, o);
+    finish_block(t, plan->e, r, o, &hc);
     out[b] = *reinterpret_cast<const uint4*>(o);
 }
 
