@@ -138,7 +138,9 @@ BU_FN uint64_t cell_eval(const uint32_t* px, uint32_t mask, const cell_cfg& cfg,
             const uint32_t sf = sel_get(*forced, i);
             uint32_t wf = umul24(sf, wmul) + (sf >> wshift);
             wf += (wf + 31) >> 6;
-            for (int c = 0; c < nc; c++) {
+            BU_UNROLL
+            for (int c = 0; c < 4; c++) {
+                if (c >= nc) continue;
                 const int d = ((base[c] + imul24(slope[c], (int)wf)) >> 14) - px_comp(p, c);
                 total += (uint32_t)imul24(d, d);
             }
@@ -153,7 +155,9 @@ BU_FN uint64_t cell_eval(const uint32_t* px, uint32_t mask, const cell_cfg& cfg,
         w1 += (w1 + 31) >> 6;
         w0 += (w0 + 31) >> 6;
         uint32_t e0 = 0, e1 = 0;
-        for (int c = 0; c < nc; c++) {
+        BU_UNROLL
+        for (int c = 0; c < 4; c++) {  // fixed trip count: a run-time bound turns base[] / slope[] into scratch arrays on the GPU
+            if (c >= nc) continue;
             const int v = px_comp(p, c);
             const int d0 = ((base[c] + imul24(slope[c], (int)w0)) >> 14) - v, d1 = ((base[c] + imul24(slope[c], (int)w1)) >> 14) - v;
             e0 += (uint32_t)imul24(d0, d0); e1 += (uint32_t)imul24(d1, d1);
@@ -226,7 +230,9 @@ BU_FN void cell_least_squares(const uint32_t* px, uint32_t mask, const sel16& se
         z10 += w4[1];
         z11 += w4[2];
         const float w = w4[3];
-        for (int c = 0; c < nc; c++) {
+        BU_UNROLL
+        for (int c = 0; c < 4; c++) {
+            if (c >= nc) continue;
             const int v = px_comp(px[i], c);
             q00[c] += w * (float)v;
             t[c] += (double)v;
@@ -238,14 +244,17 @@ BU_FN void cell_least_squares(const uint32_t* px, uint32_t mask, const sel16& se
     double det = z00 * z11 - z01 * z10;
     if (det != 0.0) det = 1.0 / det;
     const double iz00 = z11 * det, iz01 = -z01 * det, iz10 = -z10 * det, iz11 = z00 * det;
-    for (int c = 0; c < nc; c++) {
+    BU_UNROLL
+    for (int c = 0; c < 4; c++) {
+        if (c >= nc) continue;
         const double q10 = t[c] - q00[c];
         xl[c] = (float)(iz00 * q00[c] + iz01 * q10);
         xh[c] = (float)(iz10 * q00[c] + iz11 * q10);
     }
     if (nc == 3) { xl[3] = 255.0f; xh[3] = 255.0f; }
-    for (int c = 0; c < nc; c++)
-        if ((xl[c] < 0.0f || xh[c] > 255.0f) && lo_v[c] == hi_v[c]) { xl[c] = (float)lo_v[c]; xh[c] = (float)hi_v[c]; }
+    BU_UNROLL
+    for (int c = 0; c < 4; c++)
+        if (c < nc && (xl[c] < 0.0f || xh[c] > 255.0f) && lo_v[c] == hi_v[c]) { xl[c] = (float)lo_v[c]; xh[c] = (float)hi_v[c]; }
     for (int c = 0; c < 4; c++) { xl[c] = xl[c] * (1.0f / 255.0f); xh[c] = xh[c] * (1.0f / 255.0f); }
 }
 
@@ -283,7 +292,8 @@ BU_FN uint64_t one_colour_fit(const uint32_t* px, uint32_t mask, const cell_cfg&
     for (int i = 0; i < 16; i++) {
         if (!((mask >> i) & 1)) continue;
         sel_set(out.sel, i, k.widx);
-        for (int c = 0; c < (k.rgba ? 4 : 3); c++) { const int d = p[c] - px_comp(px[i], c); total += (uint32_t)imul24(d, d); }
+        BU_UNROLL
+        for (int c = 0; c < 4; c++) { if (c == 3 && !k.rgba) continue; const int d = p[c] - px_comp(px[i], c); total += (uint32_t)imul24(d, d); }
     }
     out.err = total;
     return total;
@@ -475,8 +485,20 @@ BU_FN uint64_t cell_compress_t(const uint32_t* px, uint32_t mask, const cell_cfg
     }
     return best.err;
 }
-BU_FN_BIG uint64_t cell_compress(const uint32_t* px, uint32_t mask, const cell_cfg& cfg, cell_fit& best) {
-    return cell_compress_t<false>(px, mask, cfg, best, nullptr);
+// The out-of-line instance takes the texels and the configuration and returns the fit BY VALUE: on the GPU they travel in registers, whereas
+// pointer / reference parameters of a real call live in scratch memory (and every load from them waits out a memory round trip).
+struct px16 { uint32_t v[16]; };
+BU_FN_BIG cell_fit cell_compress_rv(px16 px, uint32_t mask, cell_cfg cfg) {
+    cell_fit f;
+    cell_compress_t<false>(px.v, mask, cfg, f, nullptr);
+    return f;
+}
+BU_FN uint64_t cell_compress(const uint32_t* px, uint32_t mask, const cell_cfg& cfg, cell_fit& best) {
+    px16 p;
+    BU_UNROLL
+    for (int i = 0; i < 16; i++) p.v[i] = px[i];
+    best = cell_compress_rv(p, mask, cfg);
+    return best.err;
 }
 
 // color_cell_compression_est_astc (bc7enc.cpp:1764-1984) with unit channel weights over the texels selected by `mask`: bounding-box
