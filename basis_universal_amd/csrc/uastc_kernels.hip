@@ -85,7 +85,7 @@ __global__ void __launch_bounds__(64) k_uastc_classify(const uint4* __restrict__
     }
 }
 
-__global__ void __launch_bounds__(64) k_uastc_candidates(const uint4* __restrict__ px, uint32_t n, const uastc_plan* __restrict__ plan,
+__global__ void __launch_bounds__(64, 2) k_uastc_candidates(const uint4* __restrict__ px, uint32_t n, const uastc_plan* __restrict__ plan,
                                                          const uint8_t* __restrict__ cls, cand* __restrict__ cands, uint32_t first_job) {
     const uint32_t b = blockIdx.x * 64 + threadIdx.x;
     if (b >= n) return;
