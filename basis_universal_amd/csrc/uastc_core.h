@@ -488,7 +488,7 @@ BU_FN uint64_t cell_compress_t(const uint32_t* px, uint32_t mask, const cell_cfg
 // The out-of-line instance takes the texels and the configuration and returns the fit BY VALUE: on the GPU they travel in registers, whereas
 // pointer / reference parameters of a real call live in scratch memory (and every load from them waits out a memory round trip).
 struct px16 { uint32_t v[16]; };
-BU_FN_BIG cell_fit cell_compress_rv(px16 px, uint32_t mask, cell_cfg cfg) {
+BU_FN cell_fit cell_compress_rv(px16 px, uint32_t mask, cell_cfg cfg) {
     cell_fit f;
     cell_compress_t<false>(px.v, mask, cfg, f, nullptr);
     return f;
