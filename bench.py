@@ -38,6 +38,17 @@ KERNEL_BYTES_PER_BLOCK = {
 }
 
 
+def host_cpus():
+    """CPUs this process may really use: the cgroup quota if there is one, else the affinity mask."""
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            return max(1, int(int(quota) / int(period)))
+    except (OSError, ValueError):
+        pass
+    return len(os.sched_getaffinity(0))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -64,6 +75,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and "BU_HOST_THREADS" not in os.environ:
+        # the ranks of one node share its host cores: give each frontend its share (2..8 threads) instead of 8 each
+        os.environ["BU_HOST_THREADS"] = str(max(2, min(8, host_cpus() // int(os.environ.get("LOCAL_WORLD_SIZE", world)))))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
