@@ -253,6 +253,14 @@ __device__ inline uint4 with_field(const uint4& v, uint32_t fsb, uint32_t len, u
     return make_uint4((uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32));
 }
 
+// Workgroup barrier that orders LDS traffic only (s_waitcnt lgkmcnt(0) + s_barrier): unlike __syncthreads() it does not drain the
+// vector-memory loads in flight.
+__device__ inline void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 #ifdef RDO_PROFILE
 #define RDO_TICK(k) do { const long long now_ = clock64(); if (tid == 0) prof[k] += now_ - tick_; tick_ = now_; } while (0)
 #else
@@ -310,12 +318,6 @@ __global__ void __launch_bounds__(RDO_THREADS) k_rdo_strips(uint4* blocks, const
         inf.field = __builtin_amdgcn_readlane(pre, 4); inf.anchors = __builtin_amdgcn_readlane(pre, 5);
         const uint4 blkv = make_uint4(__builtin_amdgcn_readlane(pre, 8), __builtin_amdgcn_readlane(pre, 9), __builtin_amdgcn_readlane(pre, 10),
                                       __builtin_amdgcn_readlane(pre, 11));
-        uint32_t npre = 0, nt0 = 0, nt1 = 0;
-        if (has_next) {
-            npre = prefetch(i + 1);
-            nt0 = table[(size_t)(i + 1) * RDO_TABLE_WORDS + tid];
-            nt1 = table[(size_t)(i + 1) * RDO_TABLE_WORDS + RDO_THREADS + tid];
-        }
         const uint32_t mode = inf.meta & 255u, skip = (inf.meta >> 8) & 255u;
         const bool active = mode != 8 && !skip;
         const uint32_t fsb = inf.field & 255u, len = (inf.field >> 8) & 255u;
@@ -375,10 +377,18 @@ __global__ void __launch_bounds__(RDO_THREADS) k_rdo_strips(uint4* blocks, const
                 atomicMin(&s_min, my_key);
             }
         }
+        // The next block's info, bytes and table are requested HERE, as the youngest loads of the step: vector memory returns in order, so
+        // anything issued before the history lookups would have to land before they can be consumed. This way the HBM latency of the
+        // 2 KiB table row runs under the barrier and thread 0's write-back.
+        uint32_t npre = 0, nt0 = 0, nt1 = 0;
+        if (has_next) {
+            npre = prefetch(i + 1);
+            nt0 = table[(size_t)(i + 1) * RDO_TABLE_WORDS + tid];
+            nt1 = table[(size_t)(i + 1) * RDO_TABLE_WORDS + RDO_THREADS + tid];
+        }
         RDO_TICK(4);
-        __syncthreads();  // the winner is posted; nobody reads s_table any more
+        lds_barrier();  // the winner is posted; nobody reads s_table any more. LDS-only: the loads just issued stay in flight
         RDO_TICK(5);
-        if (has_next) { s_table[tid] = nt0; s_table[tid + RDO_THREADS] = nt1; }
         if (tid == 0) {
             uint4 final_blk = blkv;
             if (mode != 8) {
@@ -407,6 +417,7 @@ __global__ void __launch_bounds__(RDO_THREADS) k_rdo_strips(uint4* blocks, const
             }
             if (RING) s_ring_mem[i & ring_mask] = final_blk;
         }
+        if (has_next) { s_table[tid] = nt0; s_table[tid + RDO_THREADS] = nt1; }
         RDO_TICK(6);
         __syncthreads();
         RDO_TICK(7);
