@@ -565,7 +565,7 @@ static bu_tsvq* tsvq_create_common(bu_hip_context* ctx, uint32_t dim, bool packe
     for (int attempt = 0; attempt < 2; attempt++) {
         const bool exact = packed && attempt == 0 && !q->force_chained;
         {
-            prof_scope ps(ctx, "tsvq_root");
+            prof_scope ps(ctx, packed ? "tsvq_root_packed16" : "tsvq_root_float6");
             if (bu::launch_tsvq_root(ctx->stream, (int)dim, packed, exact, q->rows, q->w64, n, q->perm[0], static_cast<bu::tsvq_root_out*>(q->outs.p)) != hipSuccess) return fail("root launch");
         }
         if (hipMemcpyAsync(q->pinned, q->outs.p, sizeof(bu_tsvq_root), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess)
@@ -595,7 +595,7 @@ int bu_hip_tsvq_split(bu_hip_context* ctx, bu_tsvq* q, const bu_tsvq_node* h_nod
     BU_TRY(ctx, hipMemcpyAsync(q->nodes.p, q->pinned, in_bytes, hipMemcpyHostToDevice, ctx->stream));
     const bool exact = q->packed && !q->force_chained;
     {
-        prof_scope ps(ctx, "tsvq_split");
+        prof_scope ps(ctx, q->packed ? "tsvq_split_packed16" : "tsvq_split_float6");
         BU_TRY(ctx, bu::launch_tsvq_split(ctx->stream, (int)q->dim, q->packed, exact, q->rows, q->w64, q->perm[0], q->perm[1], q->side,
                                           static_cast<const bu::tsvq_node_in*>(q->nodes.p), n_nodes, static_cast<bu::tsvq_split_out*>(q->outs.p)));
     }
@@ -610,7 +610,7 @@ int bu_hip_tsvq_split(bu_hip_context* ctx, bu_tsvq* q, const bu_tsvq_node* h_nod
             for (size_t j = 0; j < redo.size(); j++) pn[j] = h_nodes[redo[j]];
             BU_TRY(ctx, hipMemcpyAsync(q->nodes.p, q->pinned, redo.size() * sizeof(bu_tsvq_node), hipMemcpyHostToDevice, ctx->stream));
             {
-                prof_scope ps(ctx, "tsvq_split");
+                prof_scope ps(ctx, q->packed ? "tsvq_split_packed16" : "tsvq_split_float6");
                 BU_TRY(ctx, bu::launch_tsvq_split(ctx->stream, (int)q->dim, q->packed, false, q->rows, q->w64, q->perm[0], q->perm[1], q->side,
                                                   static_cast<const bu::tsvq_node_in*>(q->nodes.p), (uint32_t)redo.size(), static_cast<bu::tsvq_split_out*>(q->outs.p)));
             }

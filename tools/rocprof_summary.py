@@ -42,6 +42,8 @@ def short(name):
     import re
     m = re.search(r"k_(\w+?)(?:<|\()", name)
     n = m.group(1) if m else name
+    if n in ("tsvq_split", "tsvq_root"):  # the two instantiations are timed separately (selector vectors packed in a dword / 6-float endpoint vectors)
+        n += "_packed16" if "packed16_rows" in name else "_float6"
     return {"refine_endpoint_clusterization": "refine_endpoint_clusterization", "fosc_resolve_and_stamp": "find_optimal_selector_clusters_stamp",
             "find_optimal_selector_clusters": "find_optimal_selector_clusters"}.get(n, n)
 
