@@ -18,6 +18,7 @@
 #include "etc1s_kernels.h"
 #include "tsvq_kernels.h"
 #include "uastc_kernels.h"
+#include "unique_kernels.h"
 
 namespace {
 
@@ -537,7 +538,8 @@ void bu_hip_tsvq_destroy(bu_hip_context* ctx, bu_tsvq* q) {
     delete q;
 }
 
-static bu_tsvq* tsvq_create_common(bu_hip_context* ctx, uint32_t dim, bool packed, const void* h_rows, const uint64_t* h_weights, uint32_t n, bu_tsvq_root* out_root) {
+static bu_tsvq* tsvq_create_common(bu_hip_context* ctx, uint32_t dim, bool packed, const void* h_rows, const uint64_t* h_weights, uint32_t n, bu_tsvq_root* out_root,
+                                   bool source_on_device = false) {
     if (!ctx || !n || !out_root || (dim != 6 && dim != 16) || (packed && dim != 16)) { if (ctx) set_error(ctx, "tsvq_create: bad arguments"); return nullptr; }
     device_guard g(ctx->device);
     bu_tsvq* q = new (std::nothrow) bu_tsvq();
@@ -556,10 +558,13 @@ static bu_tsvq* tsvq_create_common(bu_hip_context* ctx, uint32_t dim, bool packe
     q->nodes.p = bu_hip_malloc(ctx, rec_cap); q->outs.p = bu_hip_malloc(ctx, rec_cap);
     if (!q->rows || !q->w64 || !q->perm[0] || !q->perm[1] || !q->side || !q->nodes.p || !q->outs.p) return fail("allocation");
     q->nodes.cap = q->outs.cap = rec_cap;
-    // blocking copies (the sources are pageable, see bu_tsvq::pinned); the root kernel below needs both anyway
-    if (hipStreamSynchronize(ctx->stream) != hipSuccess || hipMemcpy(q->rows, h_rows, (size_t)n * row_bytes, hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(q->w64, h_weights, (size_t)n * 8, hipMemcpyHostToDevice) != hipSuccess || hipDeviceSynchronize() != hipSuccess)
-        return fail("upload");
+    if (source_on_device) {  // stream-ordered device copies: the vectors were produced on this context's stream
+        if (hipMemcpyAsync(q->rows, h_rows, (size_t)n * row_bytes, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess ||
+            hipMemcpyAsync(q->w64, h_weights, (size_t)n * 8, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess)
+            return fail("device copy");
+    } else if (hipStreamSynchronize(ctx->stream) != hipSuccess || hipMemcpy(q->rows, h_rows, (size_t)n * row_bytes, hipMemcpyHostToDevice) != hipSuccess ||
+               hipMemcpy(q->w64, h_weights, (size_t)n * 8, hipMemcpyHostToDevice) != hipSuccess || hipDeviceSynchronize() != hipSuccess)
+        return fail("upload");  // blocking copies (the sources are pageable, see bu_tsvq::pinned); the root kernel below needs both anyway
     if (q->reserve_pinned(sizeof(bu_tsvq_root)) != hipSuccess) return fail("pinned allocation");
     // exact (integer-reduced) variant first where it exists; a record flagged pad == 1 left the exact range -> chained variant
     for (int attempt = 0; attempt < 2; attempt++) {
@@ -582,6 +587,33 @@ bu_tsvq* bu_hip_tsvq_create(bu_hip_context* ctx, uint32_t dim, const float* h_ro
 
 bu_tsvq* bu_hip_tsvq_create_packed16(bu_hip_context* ctx, const uint32_t* h_keys, const uint64_t* h_weights, uint32_t n, bu_tsvq_root* out_root) {
     return tsvq_create_common(ctx, 16, true, h_keys, h_weights, n, out_root);
+}
+
+bu_tsvq* bu_hip_tsvq_create_packed16_device(bu_hip_context* ctx, const uint32_t* d_keys, const uint64_t* d_weights, uint32_t n, bu_tsvq_root* out_root) {
+    return tsvq_create_common(ctx, 16, true, d_keys, d_weights, n, out_root, true);
+}
+
+int bu_hip_k_unique_selector_vectors(bu_hip_context* ctx, const void* d_enc_blocks, const uint64_t* d_weights, uint32_t n_blocks, uint32_t* d_sorted_block_idx,
+                                     uint32_t* d_unique_keys, uint64_t* d_unique_weights, uint32_t* d_group_offsets, uint32_t* out_unique) {
+    if (!ctx) return 0;
+    if (!out_unique || (n_blocks && (!d_enc_blocks || !d_weights || !d_sorted_block_idx || !d_unique_keys || !d_unique_weights || !d_group_offsets))) {
+        set_error(ctx, "unique_selector_vectors: null pointer");
+        return 0;
+    }
+    *out_unique = 0;
+    if (!n_blocks) return 1;
+    device_guard g(ctx->device);
+    arena& ws = ctx->scratch[4];
+    BU_TRY(ctx, ws.reserve(bu::unique_selector_vectors_workspace_bytes(n_blocks)));
+    uint32_t* d_n = nullptr;
+    {
+        prof_scope ps(ctx, "unique_selector_vectors");
+        BU_TRY(ctx, bu::launch_unique_selector_vectors(ctx->stream, d_enc_blocks, d_weights, n_blocks, ws.p, d_sorted_block_idx, d_unique_keys, d_unique_weights,
+                                                        d_group_offsets, &d_n));
+    }
+    BU_TRY(ctx, hipMemcpyAsync(out_unique, d_n, 4, hipMemcpyDeviceToHost, ctx->stream));
+    BU_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return 1;
 }
 
 int bu_hip_tsvq_split(bu_hip_context* ctx, bu_tsvq* q, const bu_tsvq_node* h_nodes, uint32_t n_nodes, bu_tsvq_split* h_out) {

@@ -148,6 +148,7 @@ struct etc1s_frontend::device_state {
     const void* d_pixels = nullptr;
     bool owns_pixels = false;
     buf etc1, enc, block_cluster, params, err, valid, offsets, indices, cand_offsets, cand_indices, block_parent, out_u32, sel_blocks, weights;
+    buf sel_idx, sel_ukeys, sel_uw, sel_goffs;  // outputs of bu_hip_k_unique_selector_vectors
 
     bool reserve(buf& b, size_t bytes) {
         if (bytes <= b.cap) return true;
@@ -163,7 +164,8 @@ struct etc1s_frontend::device_state {
     }
     template <typename T> bool download(T* dst, const buf& b, size_t count) { return bu_hip_memcpy_d2h(ctx, dst, b.p, count * sizeof(T)) != 0; }
     void release() {
-        for (buf* b : {&etc1, &enc, &block_cluster, &params, &err, &valid, &offsets, &indices, &cand_offsets, &cand_indices, &block_parent, &out_u32, &sel_blocks, &weights})
+        for (buf* b : {&etc1, &enc, &block_cluster, &params, &err, &valid, &offsets, &indices, &cand_offsets, &cand_indices, &block_parent, &out_u32, &sel_blocks, &weights,
+                       &sel_idx, &sel_ukeys, &sel_uw, &sel_goffs})
             if (b->p) { bu_hip_free(ctx, b->p); b->p = nullptr; b->cap = 0; }
         if (owns_pixels && d_pixels) bu_hip_free(ctx, const_cast<void*>(d_pixels));
         d_pixels = nullptr;
@@ -659,104 +661,25 @@ bool etc1s_frontend::generate_selector_clusters() {
     auto lap = [&](const char* name) { m_stage_times.push_back(stage_time{name, sub.seconds()}); sub = timer(); };
     if (!d.reserve(d.weights, (size_t)n * 8)) return fail("alloc");
     if (!bu_hip_k_selector_training_vectors(d.ctx, d.enc.p, n, m_params.m_perceptual, nullptr, (uint64_t*)d.weights.p)) return fail("bu_hip_k_selector_training_vectors");
-    std::vector<uint64_t> weights(n);
-    if (!d.download(weights.data(), d.weights, n)) return fail("download selector weights");
     lap("~gsc/weights");
-
-    std::vector<uint32_t> keys(n), idx(n), keys2(n), idx2(n);
-    parallel_for(n, [&](uint32_t b0, uint32_t b1) {
-        for (uint32_t b = b0; b < b1; b++) {
-            const uint32_t lo = raw_selector_bits(m_encoded_blocks[b]);
-            uint32_t key = 0;
-            for (uint32_t i = 0; i < 16; i++) key = (key << 2) | selector_of(lo, i & 3, i >> 2);
-            keys[b] = key; idx[b] = b;
-        }
-    });
-    lap("~gsc/keys");
-    // Stable sort of (key, block) by key. One MSD pass on the top byte splits the blocks into 256 buckets (per-thread histograms, so
-    // the scatter keeps block order inside a bucket); the buckets are then LSD-sorted on the remaining 24 bits independently.
-    {
-        const unsigned T = host_threads();
-        const uint32_t per = (n + T - 1) / T;
-        std::vector<uint32_t> hist((size_t)T * 256, 0);
-        parallel_for_chunks(T, [&](unsigned t) {
-            uint32_t* h = &hist[(size_t)t * 256];
-            const uint32_t a = t * per, b = std::min(n, a + per);
-            for (uint32_t i = a; i < b; i++) h[keys[i] >> 24]++;
-        });
-        std::vector<uint32_t> bucket_start(257, 0);
-        {
-            uint32_t run = 0;
-            for (uint32_t v = 0; v < 256; v++) {
-                bucket_start[v] = run;
-                for (unsigned t = 0; t < T; t++) { const uint32_t c = hist[(size_t)t * 256 + v]; hist[(size_t)t * 256 + v] = run; run += c; }
-            }
-            bucket_start[256] = run;
-        }
-        parallel_for_chunks(T, [&](unsigned t) {
-            uint32_t* h = &hist[(size_t)t * 256];
-            const uint32_t a = t * per, b = std::min(n, a + per);
-            for (uint32_t i = a; i < b; i++) { const uint32_t p = h[keys[i] >> 24]++; keys2[p] = keys[i]; idx2[p] = idx[i]; }
-        });
-        keys.swap(keys2); idx.swap(idx2);
-        std::atomic<uint32_t> next{0};
-        parallel_for_chunks(T, [&](unsigned) {
-            for (;;) {
-                const uint32_t v = next.fetch_add(1);
-                if (v >= 256) break;
-                const uint32_t a = bucket_start[v], m = bucket_start[v + 1] - a;
-                if (m < 2) continue;
-                uint32_t *k0 = keys.data() + a, *i0 = idx.data() + a, *k1 = keys2.data() + a, *i1 = idx2.data() + a;
-                for (int pass = 0; pass < 3; pass++) {
-                    uint32_t h[257] = {0};
-                    const int sh = pass * 8;
-                    for (uint32_t i = 0; i < m; i++) h[((k0[i] >> sh) & 255) + 1]++;
-                    for (int i = 0; i < 256; i++) h[i + 1] += h[i];
-                    for (uint32_t i = 0; i < m; i++) { const uint32_t p = h[(k0[i] >> sh) & 255]++; k1[p] = k0[i]; i1[p] = i0[i]; }
-                    std::swap(k0, k1); std::swap(i0, i1);
-                }
-                // three passes: the sorted bucket sits in the "2" arrays; bring it home
-                std::memcpy(keys.data() + a, k0, (size_t)m * 4);
-                std::memcpy(idx.data() + a, i0, (size_t)m * 4);
-            }
-        });
-    }
-    lap("~gsc/sort");
-    // distinct keys with their summed weights; the members of distinct vector u are idx[goffs[u] .. goffs[u+1]) (ascending block index)
-    std::vector<uint32_t> ukeys, goffs; std::vector<uint64_t> uw;
-    {
-        const unsigned T = host_threads();
-        const uint32_t per = (n + T - 1) / T;
-        std::vector<uint32_t> starts(T + 1, 0);
-        parallel_for_chunks(T, [&](unsigned t) {  // groups that START inside a chunk belong to it
-            const uint32_t a = t * per, b = std::min(n, a + per);
-            uint32_t c = 0;
-            for (uint32_t i = a; i < b; i++) c += (i == 0 || keys[i] != keys[i - 1]);
-            starts[t + 1] = c;
-        });
-        for (unsigned t = 0; t < T; t++) starts[t + 1] += starts[t];
-        const uint32_t u_total = starts[T];
-        ukeys.resize(u_total); uw.resize(u_total); goffs.resize((size_t)u_total + 1);
-        goffs[u_total] = n;
-        parallel_for_chunks(T, [&](unsigned t) {
-            const uint32_t a = t * per, b = std::min(n, a + per);
-            uint32_t u = starts[t];
-            for (uint32_t i = a; i < b; i++) {
-                if (!(i == 0 || keys[i] != keys[i - 1])) continue;
-                uint32_t j = i; uint64_t w = 0;
-                const uint32_t key = keys[i];
-                while (j < n && keys[j] == key) { w += weights[idx[j]]; j++; }  // may run past b: the group still belongs to this chunk
-                ukeys[u] = key; uw[u] = w; goffs[u] = i; u++;
-            }
-        });
-    }
+    // De-duplication on the device (unique_kernels.hip): keys of the resident blocks, stable sort, run lengths, exact weight sums. The host
+    // only needs the grouping (which blocks share a vector) to turn TSVQ leaves back into block lists.
+    uint32_t u_total = 0;
+    if (!d.reserve(d.sel_idx, (size_t)n * 4) || !d.reserve(d.sel_ukeys, (size_t)n * 4) || !d.reserve(d.sel_uw, (size_t)n * 8) || !d.reserve(d.sel_goffs, ((size_t)n + 1) * 4))
+        return fail("alloc");
+    if (!bu_hip_k_unique_selector_vectors(d.ctx, d.enc.p, (const uint64_t*)d.weights.p, n, (uint32_t*)d.sel_idx.p, (uint32_t*)d.sel_ukeys.p, (uint64_t*)d.sel_uw.p,
+                                          (uint32_t*)d.sel_goffs.p, &u_total))
+        return fail("bu_hip_k_unique_selector_vectors");
+    std::vector<uint32_t> idx(n), goffs((size_t)u_total + 1);
+    if (!d.download(idx.data(), d.sel_idx, n) || !d.download(goffs.data(), d.sel_goffs, (size_t)u_total + 1)) return fail("download selector groups");
     const csr_groups groups{goffs.data(), idx.data()};
     lap("~gsc/unique");
     const uint32_t parent_default = (m_params.m_compression_level <= 1) ? kSelectorParentCodebookSizeLevel01 : kSelectorParentCodebookSizeDefault;
     const uint32_t parent_size = (m_params.m_max_selector_clusters >= 256) ? parent_default : 0;
     device_tsvq::stats ts;
-    if (!device_tsvq::hierarchical_codebook_packed16(d.ctx, ukeys, uw, groups, m_params.m_max_selector_clusters, m_use_hierarchical_selector_codebooks ? parent_size : 0,
-                                                     m_selector_cluster_block_indices, m_selector_parent_cluster_block_indices, &ts))
+    if (!device_tsvq::hierarchical_codebook_packed16_device(d.ctx, (const uint32_t*)d.sel_ukeys.p, (const uint64_t*)d.sel_uw.p, u_total, groups, m_params.m_max_selector_clusters,
+                                                            m_use_hierarchical_selector_codebooks ? parent_size : 0, m_selector_cluster_block_indices,
+                                                            m_selector_parent_cluster_block_indices, &ts))
         return fail("selector TSVQ failed");
     m_stage_times.push_back(stage_time{"~gsc/tsvq_create", ts.t_create});
     m_stage_times.push_back(stage_time{"~gsc/tsvq_device", ts.t_device});

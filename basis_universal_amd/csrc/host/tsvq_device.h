@@ -74,6 +74,18 @@ public:
         return q && build(ctx, q, root, (uint32_t)weights.size(), groups, max_codebook_size, max_parent_codebook_size, codebook, parent_codebook, st);
     }
 
+    // The same with the distinct vectors already resident (outputs of bu_hip_k_unique_selector_vectors): nothing is uploaded.
+    template <class Groups>
+    static bool hierarchical_codebook_packed16_device(bu_hip_context* ctx, const uint32_t* d_keys, const uint64_t* d_weights, uint32_t n_unique, const Groups& groups,
+                                                      uint32_t max_codebook_size, uint32_t max_parent_codebook_size, std::vector<std::vector<uint32_t>>& codebook,
+                                                      std::vector<std::vector<uint32_t>>& parent_codebook, stats* st = nullptr) {
+        bu_tsvq_root root;
+        const auto t0 = std::chrono::steady_clock::now();
+        bu_tsvq* q = n_unique ? bu_hip_tsvq_create_packed16_device(ctx, d_keys, d_weights, n_unique, &root) : nullptr;
+        if (st) st->t_create = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        return q && build(ctx, q, root, n_unique, groups, max_codebook_size, max_parent_codebook_size, codebook, parent_codebook, st);
+    }
+
 private:
     // Debug aid (BU_TSVQ_VERIFY=1): a split is a pure function of its node, so re-running every node of a batch on its own must
     // reproduce the batched result bit for bit, including the children's member lists. Reports the first differences to stderr.

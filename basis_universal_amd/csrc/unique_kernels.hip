@@ -1,0 +1,105 @@
+// unique_kernels.hip -- de-duplication of the selector training vectors on the device (row a12 + the std::map de-duplication that
+// generate_hierarchical_codebook_threaded performs before the TSVQ, encoder/basisu_frontend.cpp:2140-2189, encoder/basisu_enc.h:2218-2290).
+//
+// A selector training vector is the block's 16 two-bit selectors; the reference's std::map<vec16F, weight> orders the distinct vectors like
+// the 32-bit word that holds selector (0,0) in its top two bits ... (3,3) in its bottom two. So the de-duplication is: one key per block,
+// a STABLE radix sort of (key, block) pairs, run-length encoding of the sorted keys, and the sum of the u64 block weights of every run.
+// Everything is integer work, so the result does not depend on the order of evaluation: distinct keys ascending, the blocks of every
+// distinct vector ascending (stable sort), exact weight sums. The sort / run-length / scan primitives are hipCUB's (rocPRIM device-wide
+// algorithms); the key builder and the per-run weight sum are ours.
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+#include <stdint.h>
+
+#include "unique_kernels.h"
+
+namespace bu {
+
+namespace {
+
+// key of an ETC1S block: selector_of(x, y) for i = 0..15 with x = i & 3, y = i >> 2, first value in the top two bits. The block is stored
+// big-endian; its low 32 bits hold the selector LSB plane in bits 0..15 and the MSB plane in bits 16..31, pixel (x, y) at bit x*4+y
+// (etc.h:232-236); raw -> selector index is {2, 3, 1, 0}.
+__global__ void __launch_bounds__(256) k_selector_keys(const uint64_t* __restrict__ enc_blocks, uint32_t n, uint32_t* __restrict__ keys, uint32_t* __restrict__ idx) {
+    const uint32_t b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= n) return;
+    const uint32_t lo = (uint32_t)__builtin_bswap64(enc_blocks[b]);
+    uint32_t key = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < 16; i++) {
+        const uint32_t bit = (i & 3u) * 4u + (i >> 2);
+        const uint32_t raw = ((lo >> bit) & 1u) | (((lo >> (16u + bit)) & 1u) << 1);
+        key = (key << 2) | ((0x1Eu >> (raw * 2u)) & 3u);  // {2, 3, 1, 0}[raw]
+    }
+    keys[b] = key;
+    idx[b] = b;
+}
+
+__global__ void __launch_bounds__(256) k_run_weights(const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ n_runs, const uint32_t* __restrict__ idx,
+                                                     const uint64_t* __restrict__ weights, uint32_t n, uint32_t* __restrict__ offsets_end, uint64_t* __restrict__ out) {
+    const uint32_t u = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t runs = *n_runs;
+    if (u == 0) offsets_end[runs] = n;  // offsets[] comes from an exclusive scan: close it
+    if (u >= runs) return;
+    const uint32_t a = offsets[u], e = u + 1 < runs ? offsets[u + 1] : n;
+    uint64_t w = 0;
+    for (uint32_t j = a; j < e; j++) w += weights[idx[j]];
+    out[u] = w;
+}
+
+struct unique_temp { uint32_t *keys_in, *idx_in, *keys_sorted, *counts, *n_runs; void* cub; size_t cub_bytes; };
+size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
+
+size_t cub_bytes_for(uint32_t n) {
+    size_t a = 0, b = 0, c = 0;
+    uint32_t* p = nullptr;
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, a, p, p, p, p, (int)n);
+    (void)hipcub::DeviceRunLengthEncode::Encode(nullptr, b, p, p, p, p, (int)n);
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, c, p, p, (int)n);
+    return std::max(a, std::max(b, c));
+}
+
+unique_temp carve(void* base, uint32_t n, size_t* total) {
+    char* p = static_cast<char*>(base);
+    size_t o = 0;
+    unique_temp t;
+    t.keys_in = reinterpret_cast<uint32_t*>(p + o); o += align_up((size_t)n * 4);
+    t.idx_in = reinterpret_cast<uint32_t*>(p + o); o += align_up((size_t)n * 4);
+    t.keys_sorted = reinterpret_cast<uint32_t*>(p + o); o += align_up((size_t)n * 4);
+    t.counts = reinterpret_cast<uint32_t*>(p + o); o += align_up((size_t)n * 4);
+    t.n_runs = reinterpret_cast<uint32_t*>(p + o); o += 256;
+    t.cub_bytes = cub_bytes_for(n);
+    t.cub = p + o; o += align_up(t.cub_bytes);
+    if (total) *total = o;
+    return t;
+}
+
+} // namespace
+
+size_t unique_selector_vectors_workspace_bytes(uint32_t n_blocks) {
+    size_t total = 0;
+    carve(nullptr, n_blocks ? n_blocks : 1, &total);
+    return total;
+}
+
+hipError_t launch_unique_selector_vectors(hipStream_t st, const void* d_enc_blocks, const uint64_t* d_weights, uint32_t n, void* d_workspace, uint32_t* d_sorted_block_idx,
+                                          uint32_t* d_unique_keys, uint64_t* d_unique_weights, uint32_t* d_group_offsets, uint32_t** d_n_unique) {
+    const unique_temp t = carve(d_workspace, n, nullptr);
+    if (d_n_unique) *d_n_unique = t.n_runs;
+    if (!n) return hipMemsetAsync(t.n_runs, 0, 4, st);
+    hipLaunchKernelGGL(k_selector_keys, dim3((n + 255) / 256), dim3(256), 0, st, static_cast<const uint64_t*>(d_enc_blocks), n, t.keys_in, t.idx_in);
+    size_t bytes = t.cub_bytes;
+    hipError_t e = hipcub::DeviceRadixSort::SortPairs(t.cub, bytes, t.keys_in, t.keys_sorted, t.idx_in, d_sorted_block_idx, (int)n, 0, 32, st);
+    if (e != hipSuccess) return e;
+    bytes = t.cub_bytes;
+    e = hipcub::DeviceRunLengthEncode::Encode(t.cub, bytes, t.keys_sorted, d_unique_keys, t.counts, t.n_runs, (int)n, st);
+    if (e != hipSuccess) return e;
+    bytes = t.cub_bytes;
+    // scanning all n counts keeps the launch independent of the (device-side) run count; entries past the runs are never read
+    e = hipcub::DeviceScan::ExclusiveSum(t.cub, bytes, t.counts, d_group_offsets, (int)n, st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_run_weights, dim3((n + 255) / 256), dim3(256), 0, st, d_group_offsets, t.n_runs, d_sorted_block_idx, d_weights, n, d_group_offsets, d_unique_weights);
+    return hipGetLastError();
+}
+
+} // namespace bu

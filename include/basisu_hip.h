@@ -205,6 +205,15 @@ typedef struct { uint32_t ok, l_count, r_count, pad; uint64_t l_weight, r_weight
 BU_HIP_API bu_tsvq* bu_hip_tsvq_create(bu_hip_context*, uint32_t dim, const float* h_rows, const uint64_t* h_weights, uint32_t n, bu_tsvq_root* h_out_root);
 /* dim 16 with every component in {0,1,2,3} (ETC1S selector vectors): one dword per vector, component 0 in the top two bits. */
 BU_HIP_API bu_tsvq* bu_hip_tsvq_create_packed16(bu_hip_context*, const uint32_t* h_keys, const uint64_t* h_weights, uint32_t n, bu_tsvq_root* h_out_root);
+/* the same from device arrays (e.g. the outputs of bu_hip_k_unique_selector_vectors), copied on the context's stream */
+BU_HIP_API bu_tsvq* bu_hip_tsvq_create_packed16_device(bu_hip_context*, const uint32_t* d_keys, const uint64_t* d_weights, uint32_t n, bu_tsvq_root* h_out_root);
+/* a12 + the de-duplication in front of the selector TSVQ (frontend.cpp:2140-2189; std::map<vec16F, weight> of
+ * generate_hierarchical_codebook_threaded, enc.h:2218-2290) for n resident ETC1S blocks and their u64 training weights
+ * (bu_hip_k_selector_training_vectors): distinct selector vectors as packed keys in ascending order = the map's order, their summed
+ * weights, and the blocks of every distinct vector (ascending) as d_sorted_block_idx[d_group_offsets[u] .. d_group_offsets[u+1]).
+ * All outputs are device arrays of n_blocks entries (offsets: n_blocks + 1). Integer work: exact and order independent. Synchronises. */
+BU_HIP_API int bu_hip_k_unique_selector_vectors(bu_hip_context*, const void* d_enc_blocks, const uint64_t* d_weights, uint32_t n_blocks, uint32_t* d_sorted_block_idx,
+                                                uint32_t* d_unique_keys, uint64_t* d_unique_weights, uint32_t* d_group_offsets, uint32_t* out_unique);
 BU_HIP_API int  bu_hip_tsvq_split(bu_hip_context*, bu_tsvq*, const bu_tsvq_node* h_nodes, uint32_t n_nodes, bu_tsvq_split* h_out); /* synchronises */
 BU_HIP_API int  bu_hip_tsvq_read_members(bu_hip_context*, bu_tsvq*, uint32_t buf, uint32_t start, uint32_t count, uint32_t* h_out);
 BU_HIP_API void bu_hip_tsvq_destroy(bu_hip_context*, bu_tsvq*);
