@@ -76,6 +76,7 @@ _SIGNATURES = {
     "bu_hip_k_encode_uastc_blocks": (_int, [_vp, _vp, _u32, _u32, _vp]),
     "bu_hip_uastc_workspace_bytes": (C.c_size_t, [_u32, _u32]),
     "bu_hip_tsvq_create_packed16_device": (_vp, [_vp, _vp, _vp, _u32, _vp]),
+    "bu_hip_k_unique_endpoint_vectors": (_int, [_vp, _vp, _u32, _vp, _vp, _vp, _vp]),
     "bu_hip_k_unique_selector_vectors": (_int, [_vp, _vp, _vp, _u32, _vp, _vp, _vp, _vp, _vp]),
     "bu_hip_uastc_rdo_default_params": (None, [_vp]),
     "bu_hip_k_uastc_rdo": (_int, [_vp, _vp, _vp, _u32, _vp, _u32, _u32, _vp]),

@@ -593,6 +593,25 @@ bu_tsvq* bu_hip_tsvq_create_packed16_device(bu_hip_context* ctx, const uint32_t*
     return tsvq_create_common(ctx, 16, true, d_keys, d_weights, n, out_root, true);
 }
 
+int bu_hip_k_unique_endpoint_vectors(bu_hip_context* ctx, const void* d_etc1_blocks, uint32_t n_blocks, uint32_t* d_sorted_block_idx, uint64_t* d_unique_keys,
+                                     uint32_t* d_group_offsets, uint32_t* out_unique) {
+    if (!ctx) return 0;
+    if (!out_unique || (n_blocks && (!d_etc1_blocks || !d_sorted_block_idx || !d_unique_keys || !d_group_offsets))) { set_error(ctx, "unique_endpoint_vectors: null pointer"); return 0; }
+    *out_unique = 0;
+    if (!n_blocks) return 1;
+    device_guard g(ctx->device);
+    arena& ws = ctx->scratch[4];
+    BU_TRY(ctx, ws.reserve(bu::unique_endpoint_vectors_workspace_bytes(n_blocks)));
+    uint32_t* d_n = nullptr;
+    {
+        prof_scope ps(ctx, "unique_endpoint_vectors");
+        BU_TRY(ctx, bu::launch_unique_endpoint_vectors(ctx->stream, d_etc1_blocks, n_blocks, ws.p, d_sorted_block_idx, d_unique_keys, d_group_offsets, &d_n));
+    }
+    BU_TRY(ctx, hipMemcpyAsync(out_unique, d_n, 4, hipMemcpyDeviceToHost, ctx->stream));
+    BU_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return 1;
+}
+
 int bu_hip_k_unique_selector_vectors(bu_hip_context* ctx, const void* d_enc_blocks, const uint64_t* d_weights, uint32_t n_blocks, uint32_t* d_sorted_block_idx,
                                      uint32_t* d_unique_keys, uint64_t* d_unique_weights, uint32_t* d_group_offsets, uint32_t* out_unique) {
     if (!ctx) return 0;

@@ -149,6 +149,7 @@ struct etc1s_frontend::device_state {
     bool owns_pixels = false;
     buf etc1, enc, block_cluster, params, err, valid, offsets, indices, cand_offsets, cand_indices, block_parent, out_u32, sel_blocks, weights;
     buf sel_idx, sel_ukeys, sel_uw, sel_goffs;  // outputs of bu_hip_k_unique_selector_vectors
+    buf ep_idx, ep_ukeys, ep_goffs;             // outputs of bu_hip_k_unique_endpoint_vectors
 
     bool reserve(buf& b, size_t bytes) {
         if (bytes <= b.cap) return true;
@@ -165,7 +166,7 @@ struct etc1s_frontend::device_state {
     template <typename T> bool download(T* dst, const buf& b, size_t count) { return bu_hip_memcpy_d2h(ctx, dst, b.p, count * sizeof(T)) != 0; }
     void release() {
         for (buf* b : {&etc1, &enc, &block_cluster, &params, &err, &valid, &offsets, &indices, &cand_offsets, &cand_indices, &block_parent, &out_u32, &sel_blocks, &weights,
-                       &sel_idx, &sel_ukeys, &sel_uw, &sel_goffs})
+                       &sel_idx, &sel_ukeys, &sel_uw, &sel_goffs, &ep_idx, &ep_ukeys, &ep_goffs})
             if (b->p) { bu_hip_free(ctx, b->p); b->p = nullptr; b->cap = 0; }
         if (owns_pixels && d_pixels) bu_hip_free(ctx, const_cast<void*>(d_pixels));
         d_pixels = nullptr;
@@ -312,50 +313,21 @@ bool etc1s_frontend::init_etc1_images() {
 // so we sort integer keys instead and materialise only the distinct vectors.
 bool etc1s_frontend::init_endpoint_training_vectors() {
     const uint32_t n = m_total_blocks;
-    // counting sort of the blocks by their 18-bit (colour555, inten) code: stable, so every bucket lists its blocks ascending
-    std::vector<uint32_t> code(n), count((1u << 18) + 1, 0);
-    parallel_for(n, [&](uint32_t b0, uint32_t b1) {
-        for (uint32_t b = b0; b < b1; b++) {
-            const etc1s_header h = header_of(m_etc1_blocks_etc1s[b]);
-            code[b] = h.r | (h.g << 5) | (h.b << 10) | (h.inten << 15);
-        }
-    });
-    for (uint32_t b = 0; b < n; b++) count[code[b] + 1]++;
-    for (uint32_t c = 0; c < (1u << 18); c++) count[c + 1] += count[c];
-    std::vector<uint32_t> sorted_blocks(n), cursor(count.begin(), count.end() - 1);
-    for (uint32_t b = 0; b < n; b++) sorted_blocks[cursor[code[b]]++] = b;
-
-    struct distinct { uint64_t key; uint32_t code; };
-    std::vector<distinct> codes;
-    for (uint32_t c = 0; c < (1u << 18); c++) {
-        if (count[c + 1] == count[c]) continue;
-        const int r = scale5(c & 31), g = scale5((c >> 5) & 31), bl = scale5((c >> 10) & 31), d = kIntenB[c >> 15];
-        // etc_block::get_block_low_high_colors (etc.h:543-570): selector 0 and selector 3 colours
-        const uint64_t key = ((uint64_t)clamp255(r - d) << 40) | ((uint64_t)clamp255(g - d) << 32) | ((uint64_t)clamp255(bl - d) << 24) |
-                             ((uint64_t)clamp255(r + d) << 16) | ((uint64_t)clamp255(g + d) << 8) | (uint64_t)clamp255(bl + d);
-        codes.push_back(distinct{key, c});
-    }
-    std::sort(codes.begin(), codes.end(), [](const distinct& a, const distinct& b) { return a.key < b.key || (a.key == b.key && a.code < b.code); });
-
-    m_endpoint_unique_rows.clear(); m_endpoint_unique_weights.clear(); m_endpoint_unique_groups.clear();
-    for (size_t i = 0; i < codes.size();) {
-        size_t j = i + 1;
-        while (j < codes.size() && codes[j].key == codes[i].key) j++;
-        // blocks of all codes that decode to this vector, ascending block order
-        std::vector<uint32_t> blocks;
-        for (size_t k = i; k < j; k++) {
-            const uint32_t c = codes[k].code;
-            const size_t mid = blocks.size();
-            blocks.insert(blocks.end(), sorted_blocks.begin() + count[c], sorted_blocks.begin() + count[c + 1]);
-            if (mid) std::inplace_merge(blocks.begin(), blocks.begin() + mid, blocks.end());
-        }
-        std::vector<uint32_t> group(blocks.size() * 2);
-        for (size_t k = 0; k < blocks.size(); k++) { group[k * 2] = blocks[k] * 2; group[k * 2 + 1] = blocks[k] * 2 + 1; }
-        const uint64_t key = codes[i].key;
-        for (int k = 5; k >= 0; k--) m_endpoint_unique_rows.push_back((float)(int)((key >> (8 * k)) & 255) * (1.0f / 255.0f)); // frontend.cpp:846-851
-        m_endpoint_unique_weights.push_back((uint64_t)blocks.size() * 2);
-        m_endpoint_unique_groups.push_back(std::move(group));
-        i = j;
+    device_state& d = *m_dev;
+    // de-duplication on the device (unique_kernels.hip): 48-bit low/high colour keys of the resident blocks, stable sort, run lengths
+    uint32_t u_total = 0;
+    if (!d.reserve(d.ep_idx, (size_t)n * 4) || !d.reserve(d.ep_ukeys, (size_t)n * 8) || !d.reserve(d.ep_goffs, ((size_t)n + 1) * 4)) return fail("alloc");
+    if (!bu_hip_k_unique_endpoint_vectors(d.ctx, d.etc1.p, n, (uint32_t*)d.ep_idx.p, (uint64_t*)d.ep_ukeys.p, (uint32_t*)d.ep_goffs.p, &u_total))
+        return fail("bu_hip_k_unique_endpoint_vectors");
+    std::vector<uint64_t> ukeys(u_total);
+    m_endpoint_group_blocks.resize(n); m_endpoint_group_offsets.resize((size_t)u_total + 1);
+    if (!d.download(ukeys.data(), d.ep_ukeys, u_total) || !d.download(m_endpoint_group_offsets.data(), d.ep_goffs, (size_t)u_total + 1) ||
+        !d.download(m_endpoint_group_blocks.data(), d.ep_idx, n))
+        return fail("download endpoint groups");
+    m_endpoint_unique_rows.resize((size_t)u_total * 6); m_endpoint_unique_weights.resize(u_total);
+    for (uint32_t u = 0; u < u_total; u++) {
+        for (int k = 5; k >= 0; k--) m_endpoint_unique_rows[(size_t)u * 6 + (size_t)(5 - k)] = (float)(int)((ukeys[u] >> (8 * k)) & 255) * (1.0f / 255.0f);  // frontend.cpp:846-851
+        m_endpoint_unique_weights[u] = 2ull * (m_endpoint_group_offsets[u + 1] - m_endpoint_group_offsets[u]);  // both sub-blocks, weight 1 each
     }
     return true;
 }
@@ -363,7 +335,8 @@ bool etc1s_frontend::init_endpoint_training_vectors() {
 // frontend.cpp:868-944
 bool etc1s_frontend::generate_endpoint_clusters() {
     const uint32_t parent_size = (m_params.m_max_endpoint_clusters >= 256) ? kEndpointParentCodebookSize : 0;
-    if (!device_tsvq::hierarchical_codebook(m_dev->ctx, 6, m_endpoint_unique_rows, m_endpoint_unique_weights, m_endpoint_unique_groups, m_params.m_max_endpoint_clusters,
+    if (!device_tsvq::hierarchical_codebook(m_dev->ctx, 6, m_endpoint_unique_rows, m_endpoint_unique_weights,
+                                            csr_block_pair_groups{m_endpoint_group_offsets.data(), m_endpoint_group_blocks.data()}, m_params.m_max_endpoint_clusters,
                                             m_use_hierarchical_endpoint_codebooks ? parent_size : 0, m_endpoint_clusters, m_endpoint_parent_clusters))
         return fail("endpoint TSVQ failed");
     if (m_use_hierarchical_endpoint_codebooks) {
@@ -561,11 +534,10 @@ bool etc1s_frontend::refine_block_endpoints_given_selectors(uint32_t* total_refi
 
 // frontend.cpp:1648-1945
 bool etc1s_frontend::refine_endpoint_clusterization(uint32_t* total_reassigned) {
-    if (m_use_hierarchical_endpoint_codebooks) compute_endpoint_clusters_within_each_parent_cluster();
+    if (m_use_hierarchical_endpoint_codebooks) compute_endpoint_clusters_within_each_parent_cluster();  // refreshes m_block_endpoint_cluster
+    else generate_block_endpoint_clusters();
     const uint32_t n = m_total_blocks, k = (uint32_t)m_endpoint_clusters.size();
-    std::vector<uint32_t> block_cluster(n);
-    for (uint32_t ci = 0; ci < k; ci++)
-        for (uint32_t tv : m_endpoint_clusters[ci]) block_cluster[tv >> 1] = ci;
+    const std::vector<uint32_t>& block_cluster = m_block_endpoint_cluster;  // the block -> cluster map of the lists as they stand
     std::vector<uint8_t> prm(k * 4ull);
     for (uint32_t i = 0; i < k; i++) {
         const endpoint_params& e = m_endpoint_cluster_etc_params[i];
@@ -593,9 +565,8 @@ bool etc1s_frontend::refine_endpoint_clusterization(uint32_t* total_reassigned) 
     if (!d.download(best.data(), d.out_u32, n)) return fail("download refine result");
 
     // frontend.cpp:1921-1942: rebuild the cluster lists in block order (empty clusters stay, they are removed by eliminate_...)
-    std::vector<uint32_t> sizes(k, 0);
     uint32_t moved = 0;
-    for (uint32_t b = 0; b < n; b++) { sizes[best[b]] += 2; moved += best[b] != block_cluster[b]; }
+    for (uint32_t b = 0; b < n; b++) moved += best[b] != block_cluster[b];
     std::vector<std::vector<uint32_t>> fresh;
     lists_by_cluster<2>(n, k, [&](uint32_t b) { return best[b]; }, fresh);
     m_endpoint_clusters.swap(fresh);

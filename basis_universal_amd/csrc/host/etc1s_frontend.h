@@ -128,7 +128,7 @@ private:
     // endpoint side
     std::vector<float> m_endpoint_unique_rows;            // distinct (low rgb, high rgb)/255 vectors, ascending
     std::vector<uint64_t> m_endpoint_unique_weights;
-    std::vector<std::vector<uint32_t>> m_endpoint_unique_groups; // training-vector indices (block*2+s) per distinct vector
+    std::vector<uint32_t> m_endpoint_group_offsets, m_endpoint_group_blocks;  // CSR: the blocks behind every distinct vector, ascending
     std::vector<std::vector<uint32_t>> m_endpoint_clusters, m_endpoint_parent_clusters;
     std::vector<uint8_t> m_block_parent_endpoint_cluster;
     std::vector<std::vector<uint32_t>> m_endpoint_clusters_within_each_parent_cluster;

@@ -153,7 +153,7 @@ int bu_device_tsvq(bu_hip_context* ctx, uint32_t dim, const float* rows, const u
         std::vector<uint32_t> keys(n, 0);
         for (uint32_t i = 0; i < n; i++) for (uint32_t k = 0; k < 16; k++) keys[i] = (keys[i] << 2) | (uint32_t)r[(size_t)i * 16 + k];
         if (!bu::device_tsvq::hierarchical_codebook_packed16(ctx, keys, w, bu::vec_groups{&groups}, max_codebook_size, max_parent_codebook_size, codebook, parents, &st)) return 0;
-    } else if (!bu::device_tsvq::hierarchical_codebook(ctx, dim, r, w, groups, max_codebook_size, max_parent_codebook_size, codebook, parents, &st)) return 0;
+    } else if (!bu::device_tsvq::hierarchical_codebook(ctx, dim, r, w, bu::vec_groups{&groups}, max_codebook_size, max_parent_codebook_size, codebook, parents, &st)) return 0;
     if (stats3) { stats3[0] = st.rounds; stats3[1] = st.splits_computed; stats3[2] = st.splits_used; }
     const std::vector<uint32_t> a = csr_blob(codebook), b = csr_blob(parents);
     if (a.size() > cap_codebook_words || b.size() > cap_parent_words) return -1;

@@ -39,12 +39,20 @@ inline unsigned host_threads() {
 struct vec_groups {
     const std::vector<std::vector<uint32_t>>* g;
     size_t size(uint32_t u) const { return (*g)[u].size(); }
-    const uint32_t* begin(uint32_t u) const { return (*g)[u].data(); }
+    void copy(uint32_t u, uint32_t* dst) const { std::memcpy(dst, (*g)[u].data(), (*g)[u].size() * sizeof(uint32_t)); }
 };
 struct csr_groups {
     const uint32_t* offsets; const uint32_t* items;
     size_t size(uint32_t u) const { return offsets[u + 1] - offsets[u]; }
-    const uint32_t* begin(uint32_t u) const { return items + offsets[u]; }
+    void copy(uint32_t u, uint32_t* dst) const { std::memcpy(dst, items + offsets[u], size(u) * sizeof(uint32_t)); }
+};
+// groups of BLOCKS whose members are the blocks' two sub-block training vectors (ids 2b, 2b+1): the endpoint side
+struct csr_block_pair_groups {
+    const uint32_t* offsets; const uint32_t* blocks;
+    size_t size(uint32_t u) const { return 2 * (size_t)(offsets[u + 1] - offsets[u]); }
+    void copy(uint32_t u, uint32_t* dst) const {
+        for (uint32_t j = offsets[u]; j < offsets[u + 1]; j++) { *dst++ = blocks[j] * 2; *dst++ = blocks[j] * 2 + 1; }
+    }
 };
 
 class device_tsvq {
@@ -52,14 +60,15 @@ public:
     struct stats { uint32_t rounds = 0, splits_computed = 0, splits_used = 0; double t_create = 0, t_device = 0, t_replay = 0, t_expand = 0; };
 
     // rows: n distinct vectors of `dim` floats, ascending; groups[u]: original training-vector indices of unique vector u.
+    template <class Groups>
     static bool hierarchical_codebook(bu_hip_context* ctx, uint32_t dim, const std::vector<float>& rows, const std::vector<uint64_t>& weights,
-                                      const std::vector<std::vector<uint32_t>>& groups, uint32_t max_codebook_size, uint32_t max_parent_codebook_size,
+                                      const Groups& groups, uint32_t max_codebook_size, uint32_t max_parent_codebook_size,
                                       std::vector<std::vector<uint32_t>>& codebook, std::vector<std::vector<uint32_t>>& parent_codebook, stats* st = nullptr) {
         bu_tsvq_root root;
         const auto t0 = std::chrono::steady_clock::now();
         bu_tsvq* q = weights.empty() ? nullptr : bu_hip_tsvq_create(ctx, dim, rows.data(), weights.data(), (uint32_t)weights.size(), &root);
         if (st) st->t_create = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-        return q && build(ctx, q, root, (uint32_t)weights.size(), vec_groups{&groups}, max_codebook_size, max_parent_codebook_size, codebook, parent_codebook, st);
+        return q && build(ctx, q, root, (uint32_t)weights.size(), groups, max_codebook_size, max_parent_codebook_size, codebook, parent_codebook, st);
     }
 
     // Selector vectors: keys[u] packs the 16 selector values of distinct vector u (value 0 in the top two bits), ascending.
@@ -230,9 +239,8 @@ private:
             out.resize(total);
             uint32_t* dst = out.data();
             for (size_t i = 0; i < count; i++) {
-                const size_t k = groups.size(us[i]);
-                std::memcpy(dst, groups.begin(us[i]), k * sizeof(uint32_t));
-                dst += k;
+                groups.copy(us[i], dst);
+                dst += groups.size(us[i]);
             }
         };
         codebook.clear(); codebook.resize(leaf_members.size());

@@ -12,4 +12,10 @@ hipError_t launch_unique_selector_vectors(hipStream_t st, const void* d_enc_bloc
                                           uint32_t* d_sorted_block_idx, uint32_t* d_unique_keys, uint64_t* d_unique_weights, uint32_t* d_group_offsets,
                                           uint32_t** d_n_unique);
 
+// The same for the endpoint training vectors (frontend.cpp:825-866): one 48-bit key per ETC1S block (low / high block colour), distinct keys
+// ascending = the reference's vec6F order, blocks of every distinct vector ascending. The weight of a vector is twice its block count.
+size_t unique_endpoint_vectors_workspace_bytes(uint32_t n_blocks);
+hipError_t launch_unique_endpoint_vectors(hipStream_t st, const void* d_etc1_blocks, uint32_t n_blocks, void* d_workspace, uint32_t* d_sorted_block_idx,
+                                          uint64_t* d_unique_keys, uint32_t* d_group_offsets, uint32_t** d_n_unique);
+
 } // namespace bu

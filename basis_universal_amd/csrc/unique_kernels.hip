@@ -47,6 +47,26 @@ __global__ void __launch_bounds__(256) k_run_weights(const uint32_t* __restrict_
     out[u] = w;
 }
 
+// key of an ETC1S block for the endpoint training vectors (frontend.cpp:825-866): its low and high block colours (selector 0 and selector 3:
+// etc_block::get_block_low_high_colors, etc.h:543-570), low rgb in bits 47..24, high rgb in bits 23..0 -- the lexicographic order of the
+// reference's vec6F (the floats are monotone in these bytes).
+__global__ void __launch_bounds__(256) k_endpoint_keys(const uint64_t* __restrict__ etc1_blocks, uint32_t n, uint64_t* __restrict__ keys, uint32_t* __restrict__ idx) {
+    const uint32_t b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= n) return;
+    const uint64_t v = __builtin_bswap64(etc1_blocks[b]);
+    const int r5 = (int)((v >> 59) & 31), g5 = (int)((v >> 51) & 31), b5 = (int)((v >> 43) & 31), inten = (int)((v >> 37) & 7);
+    const int big[8] = { 8, 17, 29, 42, 60, 80, 106, 183 };  // the outer modifiers of g_etc1_inten_tables (etc.cpp:304-308)
+    const int d = big[inten];
+    const int r = (r5 << 3) | (r5 >> 2), g = (g5 << 3) | (g5 >> 2), bl = (b5 << 3) | (b5 >> 2);
+    auto c8 = [](int x) -> uint64_t { return (uint64_t)(x < 0 ? 0 : (x > 255 ? 255 : x)); };
+    keys[b] = (c8(r - d) << 40) | (c8(g - d) << 32) | (c8(bl - d) << 24) | (c8(r + d) << 16) | (c8(g + d) << 8) | c8(bl + d);
+    idx[b] = b;
+}
+
+__global__ void __launch_bounds__(256) k_close_offsets(const uint32_t* __restrict__ n_runs, uint32_t n, uint32_t* __restrict__ offsets) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) offsets[*n_runs] = n;
+}
+
 struct unique_temp { uint32_t *keys_in, *idx_in, *keys_sorted, *counts, *n_runs; void* cub; size_t cub_bytes; };
 size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 
@@ -74,7 +94,57 @@ unique_temp carve(void* base, uint32_t n, size_t* total) {
     return t;
 }
 
+struct unique64_temp { uint64_t *keys_in, *keys_sorted; uint32_t *idx_in, *counts, *n_runs; void* cub; size_t cub_bytes; };
+size_t cub_bytes_for64(uint32_t n) {
+    size_t a = 0, b = 0, c = 0;
+    uint64_t* k = nullptr;
+    uint32_t* p = nullptr;
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, a, k, k, p, p, (int)n);
+    (void)hipcub::DeviceRunLengthEncode::Encode(nullptr, b, k, k, p, p, (int)n);
+    (void)hipcub::DeviceScan::ExclusiveSum(nullptr, c, p, p, (int)n);
+    return std::max(a, std::max(b, c));
+}
+unique64_temp carve64(void* base, uint32_t n, size_t* total) {
+    char* p = static_cast<char*>(base);
+    size_t o = 0;
+    unique64_temp t;
+    t.keys_in = reinterpret_cast<uint64_t*>(p + o); o += align_up((size_t)n * 8);
+    t.keys_sorted = reinterpret_cast<uint64_t*>(p + o); o += align_up((size_t)n * 8);
+    t.idx_in = reinterpret_cast<uint32_t*>(p + o); o += align_up((size_t)n * 4);
+    t.counts = reinterpret_cast<uint32_t*>(p + o); o += align_up((size_t)n * 4);
+    t.n_runs = reinterpret_cast<uint32_t*>(p + o); o += 256;
+    t.cub_bytes = cub_bytes_for64(n);
+    t.cub = p + o; o += align_up(t.cub_bytes);
+    if (total) *total = o;
+    return t;
+}
+
 } // namespace
+
+size_t unique_endpoint_vectors_workspace_bytes(uint32_t n_blocks) {
+    size_t total = 0;
+    carve64(nullptr, n_blocks ? n_blocks : 1, &total);
+    return total;
+}
+
+hipError_t launch_unique_endpoint_vectors(hipStream_t st, const void* d_etc1_blocks, uint32_t n, void* d_workspace, uint32_t* d_sorted_block_idx, uint64_t* d_unique_keys,
+                                          uint32_t* d_group_offsets, uint32_t** d_n_unique) {
+    const unique64_temp t = carve64(d_workspace, n, nullptr);
+    if (d_n_unique) *d_n_unique = t.n_runs;
+    if (!n) return hipMemsetAsync(t.n_runs, 0, 4, st);
+    hipLaunchKernelGGL(k_endpoint_keys, dim3((n + 255) / 256), dim3(256), 0, st, static_cast<const uint64_t*>(d_etc1_blocks), n, t.keys_in, t.idx_in);
+    size_t bytes = t.cub_bytes;
+    hipError_t e = hipcub::DeviceRadixSort::SortPairs(t.cub, bytes, t.keys_in, t.keys_sorted, t.idx_in, d_sorted_block_idx, (int)n, 0, 48, st);
+    if (e != hipSuccess) return e;
+    bytes = t.cub_bytes;
+    e = hipcub::DeviceRunLengthEncode::Encode(t.cub, bytes, t.keys_sorted, d_unique_keys, t.counts, t.n_runs, (int)n, st);
+    if (e != hipSuccess) return e;
+    bytes = t.cub_bytes;
+    e = hipcub::DeviceScan::ExclusiveSum(t.cub, bytes, t.counts, d_group_offsets, (int)n, st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_close_offsets, dim3(1), dim3(64), 0, st, t.n_runs, n, d_group_offsets);
+    return hipGetLastError();
+}
 
 size_t unique_selector_vectors_workspace_bytes(uint32_t n_blocks) {
     size_t total = 0;

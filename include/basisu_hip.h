@@ -212,6 +212,12 @@ BU_HIP_API bu_tsvq* bu_hip_tsvq_create_packed16_device(bu_hip_context*, const ui
  * (bu_hip_k_selector_training_vectors): distinct selector vectors as packed keys in ascending order = the map's order, their summed
  * weights, and the blocks of every distinct vector (ascending) as d_sorted_block_idx[d_group_offsets[u] .. d_group_offsets[u+1]).
  * All outputs are device arrays of n_blocks entries (offsets: n_blocks + 1). Integer work: exact and order independent. Synchronises. */
+/* a7 + its de-duplication (frontend.cpp:825-866, enc.h:2218-2290) for n resident ETC1S blocks: distinct (low rgb, high rgb) block-colour vectors as
+ * 48-bit keys (low r,g,b in bits 47..24, high r,g,b in bits 23..0; divide the bytes by 255 for the reference's vec6F) in ascending order, and the
+ * blocks of every distinct vector (ascending) as d_sorted_block_idx[d_group_offsets[u] .. d_group_offsets[u+1]). Each block stands for its two
+ * sub-block training vectors (ids 2b and 2b+1, weight 1 each). Outputs: device arrays of n_blocks (offsets: n_blocks + 1) entries. Synchronises. */
+BU_HIP_API int bu_hip_k_unique_endpoint_vectors(bu_hip_context*, const void* d_etc1_blocks, uint32_t n_blocks, uint32_t* d_sorted_block_idx, uint64_t* d_unique_keys,
+                                                uint32_t* d_group_offsets, uint32_t* out_unique);
 BU_HIP_API int bu_hip_k_unique_selector_vectors(bu_hip_context*, const void* d_enc_blocks, const uint64_t* d_weights, uint32_t n_blocks, uint32_t* d_sorted_block_idx,
                                                 uint32_t* d_unique_keys, uint64_t* d_unique_weights, uint32_t* d_group_offsets, uint32_t* out_unique);
 BU_HIP_API int  bu_hip_tsvq_split(bu_hip_context*, bu_tsvq*, const bu_tsvq_node* h_nodes, uint32_t n_nodes, bu_tsvq_split* h_out); /* synchronises */
