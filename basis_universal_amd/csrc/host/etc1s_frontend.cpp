@@ -335,20 +335,37 @@ bool etc1s_frontend::init_endpoint_training_vectors() {
 // frontend.cpp:868-944
 bool etc1s_frontend::generate_endpoint_clusters() {
     const uint32_t parent_size = (m_params.m_max_endpoint_clusters >= 256) ? kEndpointParentCodebookSize : 0;
-    if (!device_tsvq::hierarchical_codebook(m_dev->ctx, 6, m_endpoint_unique_rows, m_endpoint_unique_weights,
-                                            csr_block_pair_groups{m_endpoint_group_offsets.data(), m_endpoint_group_blocks.data()}, m_params.m_max_endpoint_clusters,
-                                            m_use_hierarchical_endpoint_codebooks ? parent_size : 0, m_endpoint_clusters, m_endpoint_parent_clusters))
+    const csr_block_pair_groups groups{m_endpoint_group_offsets.data(), m_endpoint_group_blocks.data()};
+    m_endpoint_parent_clusters.clear();
+    if (!device_tsvq::hierarchical_codebook(m_dev->ctx, 6, m_endpoint_unique_rows, m_endpoint_unique_weights, groups, m_params.m_max_endpoint_clusters,
+                                            m_use_hierarchical_endpoint_codebooks ? parent_size : 0, m_endpoint_clusters, m_endpoint_parent_clusters, nullptr,
+                                            &m_endpoint_parent_of_unique, &m_endpoint_parent_count))
         return fail("endpoint TSVQ failed");
     if (m_use_hierarchical_endpoint_codebooks) {
-        if (m_endpoint_parent_clusters.empty()) {
-            m_endpoint_parent_clusters.resize(1);
-            for (uint32_t i = 0; i < m_total_blocks; i++) { m_endpoint_parent_clusters[0].push_back(i * 2); m_endpoint_parent_clusters[0].push_back(i * 2 + 1); }
-        }
-        m_block_parent_endpoint_cluster.assign(m_total_blocks, 0xFF);
-        for (size_t p = 0; p < m_endpoint_parent_clusters.size(); p++)
-            for (uint32_t tv : m_endpoint_parent_clusters[p]) m_block_parent_endpoint_cluster[tv >> 1] = (uint8_t)p;
+        // only the block -> parent map is needed from here on; the parent lists themselves are built when somebody asks (endpoint_parent_clusters())
+        m_block_parent_endpoint_cluster.assign(m_total_blocks, 0);
+        if (!m_endpoint_parent_count) m_endpoint_parent_count = 1;  // no parent level: one parent holding everything (frontend.cpp:905-911)
+        else
+            parallel_for((uint32_t)m_endpoint_parent_of_unique.size(), [&](uint32_t u0, uint32_t u1) {
+                for (uint32_t u = u0; u < u1; u++)
+                    for (uint32_t j = m_endpoint_group_offsets[u]; j < m_endpoint_group_offsets[u + 1]; j++)
+                        m_block_parent_endpoint_cluster[m_endpoint_group_blocks[j]] = (uint8_t)m_endpoint_parent_of_unique[u];
+            });
     }
     return true;
+}
+
+const std::vector<std::vector<uint32_t>>& etc1s_frontend::endpoint_parent_clusters() const {
+    if (m_endpoint_parent_clusters.empty() && m_use_hierarchical_endpoint_codebooks) {
+        if (m_endpoint_parent_of_unique.empty()) {
+            m_endpoint_parent_clusters.resize(1);
+            for (uint32_t i = 0; i < m_total_blocks; i++) { m_endpoint_parent_clusters[0].push_back(i * 2); m_endpoint_parent_clusters[0].push_back(i * 2 + 1); }
+        } else {
+            device_tsvq::expand_parents(m_endpoint_parent_of_unique, m_endpoint_parent_count,
+                                        csr_block_pair_groups{m_endpoint_group_offsets.data(), m_endpoint_group_blocks.data()}, m_endpoint_parent_clusters);
+        }
+    }
+    return m_endpoint_parent_clusters;
 }
 
 // frontend.cpp:947-968
@@ -362,7 +379,7 @@ void etc1s_frontend::generate_block_endpoint_clusters() {
 // "the ascending set of clusters that own at least one block of this parent", which a membership table gives in O(blocks).
 void etc1s_frontend::compute_endpoint_clusters_within_each_parent_cluster() {
     generate_block_endpoint_clusters();
-    const size_t parents = m_endpoint_parent_clusters.size(), clusters = m_endpoint_clusters.size();
+    const size_t parents = m_endpoint_parent_count, clusters = m_endpoint_clusters.size();
     std::vector<uint8_t> member(parents * clusters, 0);
     for (uint32_t b = 0; b < m_total_blocks; b++) member[(size_t)m_block_parent_endpoint_cluster[b] * clusters + m_block_endpoint_cluster[b]] = 1;
     m_endpoint_clusters_within_each_parent_cluster.assign(parents, {});
@@ -641,7 +658,8 @@ bool etc1s_frontend::generate_selector_clusters() {
     if (!bu_hip_k_unique_selector_vectors(d.ctx, d.enc.p, (const uint64_t*)d.weights.p, n, (uint32_t*)d.sel_idx.p, (uint32_t*)d.sel_ukeys.p, (uint64_t*)d.sel_uw.p,
                                           (uint32_t*)d.sel_goffs.p, &u_total))
         return fail("bu_hip_k_unique_selector_vectors");
-    std::vector<uint32_t> idx(n), goffs((size_t)u_total + 1);
+    std::vector<uint32_t>&idx = m_selector_group_blocks, &goffs = m_selector_group_offsets;
+    idx.resize(n); goffs.resize((size_t)u_total + 1);
     if (!d.download(idx.data(), d.sel_idx, n) || !d.download(goffs.data(), d.sel_goffs, (size_t)u_total + 1)) return fail("download selector groups");
     const csr_groups groups{goffs.data(), idx.data()};
     lap("~gsc/unique");
@@ -650,21 +668,23 @@ bool etc1s_frontend::generate_selector_clusters() {
     device_tsvq::stats ts;
     if (!device_tsvq::hierarchical_codebook_packed16_device(d.ctx, (const uint32_t*)d.sel_ukeys.p, (const uint64_t*)d.sel_uw.p, u_total, groups, m_params.m_max_selector_clusters,
                                                             m_use_hierarchical_selector_codebooks ? parent_size : 0, m_selector_cluster_block_indices,
-                                                            m_selector_parent_cluster_block_indices, &ts))
+                                                            m_selector_parent_cluster_block_indices, &ts, &m_selector_parent_of_unique, &m_selector_parent_count))
         return fail("selector TSVQ failed");
+    m_selector_parent_cluster_block_indices.clear();
     m_stage_times.push_back(stage_time{"~gsc/tsvq_create", ts.t_create});
     m_stage_times.push_back(stage_time{"~gsc/tsvq_device", ts.t_device});
     m_stage_times.push_back(stage_time{"~gsc/tsvq_replay", ts.t_replay});
     m_stage_times.push_back(stage_time{"~gsc/tsvq_expand", ts.t_expand});
     sub = timer();
     if (m_use_hierarchical_selector_codebooks) {
-        if (m_selector_parent_cluster_block_indices.empty()) {
-            m_selector_parent_cluster_block_indices.resize(1);
-            for (uint32_t i = 0; i < n; i++) m_selector_parent_cluster_block_indices[0].push_back(i);
-        }
-        m_block_parent_selector_cluster.assign(n, 0xFF);
-        for (size_t p = 0; p < m_selector_parent_cluster_block_indices.size(); p++)
-            for (uint32_t b : m_selector_parent_cluster_block_indices[p]) m_block_parent_selector_cluster[b] = (uint8_t)p;
+        // only the block -> parent map is needed from here on (the lists are not part of the frontend's interface)
+        m_block_parent_selector_cluster.assign(n, 0);
+        if (!m_selector_parent_count) m_selector_parent_count = 1;  // no parent level: one parent holding everything (frontend.cpp:2230-2236)
+        else
+            parallel_for(u_total, [&](uint32_t u0, uint32_t u1) {
+                for (uint32_t u = u0; u < u1; u++)
+                    for (uint32_t j = goffs[u]; j < goffs[u + 1]; j++) m_block_parent_selector_cluster[idx[j]] = (uint8_t)m_selector_parent_of_unique[u];
+            });
     }
     lap("~gsc/parents");
     return true;
@@ -672,7 +692,7 @@ bool etc1s_frontend::generate_selector_clusters() {
 
 // frontend.cpp:2098-2138
 void etc1s_frontend::compute_selector_clusters_within_each_parent_cluster() {
-    const size_t parents = m_selector_parent_cluster_block_indices.size(), clusters = m_selector_cluster_block_indices.size();
+    const size_t parents = m_selector_parent_count, clusters = m_selector_cluster_block_indices.size();
     std::vector<uint32_t> block_cluster(m_total_blocks, 0);
     for (size_t ci = 0; ci < clusters; ci++)
         for (uint32_t b : m_selector_cluster_block_indices[ci]) block_cluster[b] = (uint32_t)ci;

@@ -69,7 +69,7 @@ public:
     const std::vector<bu_etc_block>& etc1_blocks() const { return m_etc1_blocks_etc1s; }
     const std::vector<bu_etc_block>& orig_encoded_blocks() const { return m_orig_encoded_blocks; }
     const std::vector<std::vector<uint32_t>>& endpoint_clusters() const { return m_endpoint_clusters; }
-    const std::vector<std::vector<uint32_t>>& endpoint_parent_clusters() const { return m_endpoint_parent_clusters; }
+    const std::vector<std::vector<uint32_t>>& endpoint_parent_clusters() const;  // built on first use from the parent-of-vector map
     const std::vector<endpoint_params>& endpoint_cluster_params() const { return m_endpoint_cluster_etc_params; }
     const std::vector<uint32_t>& block_endpoint_clusters() const { return m_block_endpoint_cluster; }
     const std::vector<std::vector<uint32_t>>& selector_cluster_block_indices() const { return m_selector_cluster_block_indices; }
@@ -129,7 +129,11 @@ private:
     std::vector<float> m_endpoint_unique_rows;            // distinct (low rgb, high rgb)/255 vectors, ascending
     std::vector<uint64_t> m_endpoint_unique_weights;
     std::vector<uint32_t> m_endpoint_group_offsets, m_endpoint_group_blocks;  // CSR: the blocks behind every distinct vector, ascending
-    std::vector<std::vector<uint32_t>> m_endpoint_clusters, m_endpoint_parent_clusters;
+    std::vector<std::vector<uint32_t>> m_endpoint_clusters;
+    mutable std::vector<std::vector<uint32_t>> m_endpoint_parent_clusters;  // lazily materialised, see endpoint_parent_clusters()
+    std::vector<uint32_t> m_endpoint_parent_of_unique, m_selector_parent_of_unique;  // parent cluster of every distinct training vector
+    uint32_t m_endpoint_parent_count = 0, m_selector_parent_count = 0;
+    std::vector<uint32_t> m_selector_group_offsets, m_selector_group_blocks;  // CSR: the blocks behind every distinct selector vector
     std::vector<uint8_t> m_block_parent_endpoint_cluster;
     std::vector<std::vector<uint32_t>> m_endpoint_clusters_within_each_parent_cluster;
     std::vector<endpoint_params> m_endpoint_cluster_etc_params;

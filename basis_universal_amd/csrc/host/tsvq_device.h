@@ -63,12 +63,13 @@ public:
     template <class Groups>
     static bool hierarchical_codebook(bu_hip_context* ctx, uint32_t dim, const std::vector<float>& rows, const std::vector<uint64_t>& weights,
                                       const Groups& groups, uint32_t max_codebook_size, uint32_t max_parent_codebook_size,
-                                      std::vector<std::vector<uint32_t>>& codebook, std::vector<std::vector<uint32_t>>& parent_codebook, stats* st = nullptr) {
+                                      std::vector<std::vector<uint32_t>>& codebook, std::vector<std::vector<uint32_t>>& parent_codebook, stats* st = nullptr,
+                                      std::vector<uint32_t>* parent_of_unique = nullptr, uint32_t* parent_count = nullptr) {
         bu_tsvq_root root;
         const auto t0 = std::chrono::steady_clock::now();
         bu_tsvq* q = weights.empty() ? nullptr : bu_hip_tsvq_create(ctx, dim, rows.data(), weights.data(), (uint32_t)weights.size(), &root);
         if (st) st->t_create = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-        return q && build(ctx, q, root, (uint32_t)weights.size(), groups, max_codebook_size, max_parent_codebook_size, codebook, parent_codebook, st);
+        return q && build(ctx, q, root, (uint32_t)weights.size(), groups, max_codebook_size, max_parent_codebook_size, codebook, parent_codebook, st, parent_of_unique, parent_count);
     }
 
     // Selector vectors: keys[u] packs the 16 selector values of distinct vector u (value 0 in the top two bits), ascending.
@@ -87,12 +88,31 @@ public:
     template <class Groups>
     static bool hierarchical_codebook_packed16_device(bu_hip_context* ctx, const uint32_t* d_keys, const uint64_t* d_weights, uint32_t n_unique, const Groups& groups,
                                                       uint32_t max_codebook_size, uint32_t max_parent_codebook_size, std::vector<std::vector<uint32_t>>& codebook,
-                                                      std::vector<std::vector<uint32_t>>& parent_codebook, stats* st = nullptr) {
+                                                      std::vector<std::vector<uint32_t>>& parent_codebook, stats* st = nullptr,
+                                                      std::vector<uint32_t>* parent_of_unique = nullptr, uint32_t* parent_count = nullptr) {
         bu_tsvq_root root;
         const auto t0 = std::chrono::steady_clock::now();
         bu_tsvq* q = n_unique ? bu_hip_tsvq_create_packed16_device(ctx, d_keys, d_weights, n_unique, &root) : nullptr;
         if (st) st->t_create = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-        return q && build(ctx, q, root, n_unique, groups, max_codebook_size, max_parent_codebook_size, codebook, parent_codebook, st);
+        return q && build(ctx, q, root, n_unique, groups, max_codebook_size, max_parent_codebook_size, codebook, parent_codebook, st, parent_of_unique, parent_count);
+    }
+
+    // parent lists from a parent-of-unique map (what build() would have produced): vectors ascending inside a parent, members group by group
+    template <class Groups>
+    static void expand_parents(const std::vector<uint32_t>& parent_of_unique, uint32_t parents, const Groups& groups, std::vector<std::vector<uint32_t>>& lists) {
+        const uint32_t n = (uint32_t)parent_of_unique.size();
+        std::vector<uint32_t> ofs(parents + 1, 0), sorted(n);
+        for (uint32_t u = 0; u < n; u++) ofs[parent_of_unique[u] + 1]++;
+        for (uint32_t c = 0; c < parents; c++) ofs[c + 1] += ofs[c];
+        { std::vector<uint32_t> pos(ofs.begin(), ofs.end() - 1); for (uint32_t u = 0; u < n; u++) sorted[pos[parent_of_unique[u]]++] = u; }
+        lists.clear(); lists.resize(parents);
+        for (uint32_t c = 0; c < parents; c++) {
+            size_t total = 0;
+            for (uint32_t i = ofs[c]; i < ofs[c + 1]; i++) total += groups.size(sorted[i]);
+            lists[c].resize(total);
+            uint32_t* dst = lists[c].data();
+            for (uint32_t i = ofs[c]; i < ofs[c + 1]; i++) { groups.copy(sorted[i], dst); dst += groups.size(sorted[i]); }
+        }
     }
 
 private:
@@ -124,7 +144,10 @@ private:
     template <class Groups>
     static bool build(bu_hip_context* ctx, bu_tsvq* q, const bu_tsvq_root& root, uint32_t n, const Groups& groups,
                       uint32_t max_codebook_size, uint32_t max_parent_codebook_size, std::vector<std::vector<uint32_t>>& codebook,
-                      std::vector<std::vector<uint32_t>>& parent_codebook, stats* st) {
+                      std::vector<std::vector<uint32_t>>& parent_codebook, stats* st, std::vector<uint32_t>* parent_of_unique = nullptr,
+                      uint32_t* parent_count = nullptr) {
+        if (parent_of_unique) parent_of_unique->clear();
+        if (parent_count) *parent_count = 0;
         struct guard { bu_hip_context* c; bu_tsvq* q; ~guard() { bu_hip_tsvq_destroy(c, q); } } g{ctx, q};
 
         struct node {
@@ -282,6 +305,11 @@ private:
             std::vector<uint32_t> cut_of_vec(n);
             for (size_t l = 0; l < leaf_members.size(); l++)
                 for (uint32_t i = 0; i < leaf_members[l].n; i++) cut_of_vec[leaf_members[l].p[i]] = cut_of_leaf[l];
+            if (parent_of_unique) {  // the caller only wants "which parent does every distinct vector belong to": lists on demand (expand_parents)
+                parent_of_unique->swap(cut_of_vec);
+                if (parent_count) *parent_count = cuts;
+                return true;
+            }
             // counting sort of the distinct vectors by cut, ascending inside a cut
             std::vector<uint32_t> cut_ofs(cuts + 1, 0), sorted(n);
             for (uint32_t u = 0; u < n; u++) cut_ofs[cut_of_vec[u] + 1]++;
