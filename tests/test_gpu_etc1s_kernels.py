@@ -226,6 +226,63 @@ def test_selector_training_vectors(hip_ctx, blocks, perceptual):
         hip_ctx.free(p)
 
 
+def _check_groups(n, u, keys_np, got_keys, got_offsets, got_idx, weights=None, got_weights=None):
+    """distinct keys ascending; blocks of every distinct vector ascending and complete; summed weights"""
+    uniq, inverse = np.unique(keys_np, return_inverse=True)
+    assert u == uniq.size and (got_keys[:u] == uniq).all()
+    assert got_offsets[0] == 0 and got_offsets[u] == n and (np.diff(got_offsets[:u + 1].astype(np.int64)) > 0).all()
+    order = np.argsort(keys_np, kind="stable")        # stable: ascending block index inside a key
+    assert (got_idx == order).all()
+    if weights is not None:
+        assert (got_weights[:u] == np.array([weights[order[got_offsets[i]:got_offsets[i + 1]]].sum() for i in range(u)], np.uint64)).all()
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 257, 3072])
+def test_unique_selector_vectors(hip_ctx, blocks, n):
+    """bu_hip_k_unique_selector_vectors against the oracle's selector training vectors + numpy: the key is the vector's 16 values, first in the
+    top two bits (the reference's std::map<vec16F> order); all-equal and all-distinct inputs included through the block sample."""
+    enc_all = _encoded(blocks, 1)
+    enc = np.ascontiguousarray(np.concatenate([enc_all, enc_all[:64]])[:n])   # duplicates guaranteed
+    vec = np.zeros((n, 16), np.float32); w = np.zeros(n, np.uint64)
+    if n:
+        oracle().orc_selector_training_vectors(ptr(enc), n, 1, ptr(vec, f32p), ptr(w, u64p))
+    keys = (vec.astype(np.uint32) << (30 - 2 * np.arange(16, dtype=np.uint32))).sum(axis=1).astype(np.uint32) if n else np.zeros(0, np.uint32)
+    d_enc, d_w = hip_ctx.upload(enc), hip_ctx.upload(w)
+    d_idx, d_keys, d_uw, d_ofs = hip_ctx.alloc(n * 4 + 4), hip_ctx.alloc(n * 4 + 4), hip_ctx.alloc(n * 8 + 8), hip_ctx.alloc(n * 4 + 8)
+    u = C.c_uint32(12345)
+    hip_ctx.check(hip_ctx.lib.k_unique_selector_vectors(hip_ctx.h, d_enc, d_w, n, d_idx, d_keys, d_uw, d_ofs, C.byref(u)), "k_unique_selector_vectors")
+    if n:
+        _check_groups(n, u.value, keys, hip_ctx.download(d_keys, (n,), np.uint32), hip_ctx.download(d_ofs, (n + 1,), np.uint32),
+                      hip_ctx.download(d_idx, (n,), np.uint32), w, hip_ctx.download(d_uw, (n,), np.uint64))
+    else:
+        assert u.value == 0
+    for p_ in (d_enc, d_w, d_idx, d_keys, d_uw, d_ofs):
+        hip_ctx.free(p_)
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 257, 3072])
+def test_unique_endpoint_vectors(hip_ctx, blocks, n):
+    """bu_hip_k_unique_endpoint_vectors against the oracle's endpoint training vectors: key bytes / 255 are the vec6F, order is lexicographic."""
+    etc_all = _encode_ref(blocks)
+    etc = np.ascontiguousarray(np.concatenate([etc_all, etc_all[:64]])[:n])
+    vec = np.zeros((n, 6), np.float32)
+    if n:
+        oracle().orc_endpoint_training_vectors(ptr(etc), n, ptr(vec, f32p))
+    bytes_ = np.rint(vec.astype(np.float64) * 255.0).astype(np.uint64)
+    assert (bytes_.astype(np.float32) * np.float32(1.0 / 255.0) == vec).all()   # the float the reference stores is byte * (1/255)
+    keys = (bytes_ << (8 * (5 - np.arange(6, dtype=np.uint64)))).sum(axis=1).astype(np.uint64) if n else np.zeros(0, np.uint64)
+    d_etc = hip_ctx.upload(etc)
+    d_idx, d_keys, d_ofs = hip_ctx.alloc(n * 4 + 4), hip_ctx.alloc(n * 8 + 8), hip_ctx.alloc(n * 4 + 8)
+    u = C.c_uint32(12345)
+    hip_ctx.check(hip_ctx.lib.k_unique_endpoint_vectors(hip_ctx.h, d_etc, n, d_idx, d_keys, d_ofs, C.byref(u)), "k_unique_endpoint_vectors")
+    if n:
+        _check_groups(n, u.value, keys, hip_ctx.download(d_keys, (n,), np.uint64), hip_ctx.download(d_ofs, (n + 1,), np.uint32), hip_ctx.download(d_idx, (n,), np.uint32))
+    else:
+        assert u.value == 0
+    for p_ in (d_etc, d_idx, d_keys, d_ofs):
+        hip_ctx.free(p_)
+
+
 def _selector_clusters(enc, k, rng):
     n = enc.shape[0]
     key = enc[:, 4:].astype(np.uint32) @ np.array([1, 256, 65536, 16777216], np.uint32)
