@@ -151,6 +151,7 @@ def main():
     ctx.profile_enable(True)
     stage_acc = {}
     last = None
+    cpu0 = time.process_time()
     if args.streams <= 1:
         barrier()
         t0 = time.perf_counter()
@@ -170,6 +171,7 @@ def main():
         last = finished[-1]
         for fe in finished[:-1]:
             fe.close()
+    host_cpu_s = (time.process_time() - cpu0) / args.steps  # all host threads of this rank (spin-waits on the stream included)
     kernels = ctx.profile_read()
     ctx.profile_enable(False)
 
@@ -225,6 +227,7 @@ def main():
                                        if sharded else f"{world} x one image per GPU (no collective)")},
             "roofline": roofline,
             "pipelined": pipelined,
+            "host_cpu_s_per_step": round(host_cpu_s, 4),
             "stages_s_per_step": {k: round(v / args.steps, 4) for k, v in stage_acc.items()},
             "kernels_ms_per_step": {k: round(v[0] / args.steps, 3) for k, v in kernels.items()},
         }
