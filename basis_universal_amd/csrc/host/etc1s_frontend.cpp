@@ -292,7 +292,6 @@ bool etc1s_frontend::compress() {
 
 // frontend.cpp:733-823
 bool etc1s_frontend::init_etc1_images() {
-    const uint32_t n = m_total_blocks;
     const int quality = m_params.m_compression_level == 0 ? BU_ETC_QUALITY_FAST : m_params.m_compression_level == 1 ? BU_ETC_QUALITY_MEDIUM
                       : m_params.m_compression_level == 6 ? BU_ETC_QUALITY_UBER : BU_ETC_QUALITY_SLOW; // frontend.cpp:783-788
     device_state& d = *m_dev;
@@ -302,9 +301,19 @@ bool etc1s_frontend::init_etc1_images() {
     if (nb && !bu_hip_k_encode_etc1s_blocks(d.ctx, (const char*)d.d_pixels + (size_t)b0 * 64, nb, quality, m_params.m_perceptual, (char*)d.etc1.p + (size_t)b0 * 8))
         return fail("bu_hip_k_encode_etc1s_blocks");
     if (!gather_blocks(d.etc1.p, 8)) return false;
-    m_etc1_blocks_etc1s.resize(n);
-    if (!d.download(m_etc1_blocks_etc1s.data(), d.etc1, n)) return fail("download etc1 blocks");
+    // every consumer of these blocks runs on the device (the training-vector de-duplication); the host copy is fetched when somebody asks
+    m_etc1_blocks_etc1s.clear();
+    m_etc1_on_host = false;
     return true;
+}
+
+const std::vector<bu_etc_block>& etc1s_frontend::etc1_blocks() const {
+    if (!m_etc1_on_host && m_dev && m_dev->etc1.p) {
+        m_etc1_blocks_etc1s.resize(m_total_blocks);
+        if (!m_dev->download(m_etc1_blocks_etc1s.data(), m_dev->etc1, m_total_blocks)) m_etc1_blocks_etc1s.clear();
+        m_etc1_on_host = true;
+    }
+    return m_etc1_blocks_etc1s;
 }
 
 // frontend.cpp:825-866 + the de-duplication of generate_hierarchical_codebook_threaded (enc.h:2218-2290).
@@ -635,6 +644,7 @@ bool etc1s_frontend::create_initial_packed_texture() {
         return fail("bu_hip_k_determine_selectors");
     m_encoded_blocks.resize(n);
     if (!d.download(m_encoded_blocks.data(), d.enc, n)) return fail("download encoded blocks");
+    m_enc_device_current = true;
     m_orig_encoded_blocks = m_encoded_blocks;
     return true;
 }
@@ -746,6 +756,7 @@ bool etc1s_frontend::find_optimal_selector_clusters_for_each_block() {
                 store_be64(m_encoded_blocks[b], (load_be64(m_encoded_blocks[b]) & ~0xFFFFFFFFull) | bits);
             }
         }
+        m_enc_device_current = false;
         return true;
     }
     device_state& d = *m_dev;
@@ -758,7 +769,10 @@ bool etc1s_frontend::find_optimal_selector_clusters_for_each_block() {
             return fail("upload selector parent lists");
     }
     const size_t padded = (size_t)comm_world() * slab_blocks();
-    if (!d.upload(d.sel_blocks, m_optimized_cluster_selectors.data(), k) || !d.reserve(d.enc, padded * 8) || !d.upload(d.enc, m_encoded_blocks.data(), n) || !d.reserve(d.out_u32, padded * 4))
+    // the device copy of the encoded blocks is still the one create_initial_packed_texture produced unless the host touched them since
+    const bool enc_resident = m_enc_device_current && d.enc.cap >= padded * 8;
+    if (!d.upload(d.sel_blocks, m_optimized_cluster_selectors.data(), k) || (!enc_resident && (!d.reserve(d.enc, padded * 8) || !d.upload(d.enc, m_encoded_blocks.data(), n))) ||
+        !d.reserve(d.out_u32, padded * 4))
         return fail("upload fosc inputs");
     uint32_t b0, nb;
     my_slab(b0, nb);  // slabs start on multiples of the reference's 2048-block jobs, so the "same tile as the previous block of this job" shortcut sees the same neighbours
@@ -822,6 +836,7 @@ bool etc1s_frontend::introduce_special_selector_clusters() {
             relocated[b] = 1;
             total_relocated++;
             store_be64(m_encoded_blocks[b], (load_be64(m_encoded_blocks[b]) & ~0xFFFFFFFFull) | flat);
+            m_enc_device_current = false;
         }
     }
     if (total_relocated)

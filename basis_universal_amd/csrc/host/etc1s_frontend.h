@@ -56,7 +56,7 @@ public:
     uint32_t get_total_output_blocks() const { return (uint32_t)m_encoded_blocks.size(); }
     const bu_etc_block& get_output_block(uint32_t i) const { return m_encoded_blocks[i]; }
     const std::vector<bu_etc_block>& get_output_blocks() const { return m_encoded_blocks; }
-    const bu_etc_block& get_etc1s_block(uint32_t i) const { return m_etc1_blocks_etc1s[i]; }
+    const bu_etc_block& get_etc1s_block(uint32_t i) const { return etc1_blocks()[i]; }
     uint32_t get_total_endpoint_clusters() const { return (uint32_t)m_endpoint_clusters.size(); }
     uint32_t get_subblock_endpoint_cluster_index(uint32_t block, uint32_t) const { return m_block_endpoint_cluster[block]; }
     const endpoint_params& get_endpoint_cluster_params(uint32_t ci) const { return m_endpoint_cluster_etc_params[ci]; }
@@ -66,7 +66,7 @@ public:
     const std::vector<uint32_t>& get_selector_cluster_block_indices(uint32_t ci) const { return m_selector_cluster_block_indices[ci]; }
 
     // ---- stage state, exposed for stage-by-stage parity tests
-    const std::vector<bu_etc_block>& etc1_blocks() const { return m_etc1_blocks_etc1s; }
+    const std::vector<bu_etc_block>& etc1_blocks() const;  // fetched from the device on first use
     const std::vector<bu_etc_block>& orig_encoded_blocks() const { return m_orig_encoded_blocks; }
     const std::vector<std::vector<uint32_t>>& endpoint_clusters() const { return m_endpoint_clusters; }
     const std::vector<std::vector<uint32_t>>& endpoint_parent_clusters() const;  // built on first use from the parent-of-vector map
@@ -123,7 +123,10 @@ private:
     uint32_t m_num_endpoint_codebook_iterations = 1;
     uint32_t m_num_selector_codebook_iterations = 1;
 
-    std::vector<bu_etc_block> m_encoded_blocks, m_orig_encoded_blocks, m_etc1_blocks_etc1s;
+    std::vector<bu_etc_block> m_encoded_blocks, m_orig_encoded_blocks;
+    mutable std::vector<bu_etc_block> m_etc1_blocks_etc1s;  // host mirror of the device's a6 output, see etc1_blocks()
+    mutable bool m_etc1_on_host = false;
+    bool m_enc_device_current = false;  // the device copy of m_encoded_blocks is identical to the host's
 
     // endpoint side
     std::vector<float> m_endpoint_unique_rows;            // distinct (low rgb, high rgb)/255 vectors, ascending
