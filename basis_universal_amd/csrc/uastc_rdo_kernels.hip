@@ -434,7 +434,7 @@ __global__ void __launch_bounds__(RDO_THREADS) k_rdo_strips(uint4* blocks, const
 }
 
 // the modified blocks of strip s are listed in mod_list[s * per_job ...) (strip_counts[s] of them)
-__global__ void __launch_bounds__(64) k_rdo_finish(uint4* blocks, const uint4* __restrict__ px, uint32_t n, uint32_t per_job, enc_cfg e, rdo_params p,
+__global__ void __launch_bounds__(64, 2) k_rdo_finish(uint4* blocks, const uint4* __restrict__ px, uint32_t n, uint32_t per_job, enc_cfg e, rdo_params p,
                                                    const uint32_t* __restrict__ mod_list, const uint32_t* __restrict__ strip_counts,
                                                    const uint8_t* __restrict__ state, uint32_t* counters) {
     const uint32_t strip = blockIdx.y, k = blockIdx.x * 64 + threadIdx.x;  // grid.x covers the longest list
@@ -450,7 +450,10 @@ __global__ void __launch_bounds__(64) k_rdo_finish(uint4* blocks, const uint4* _
         rdo_refit_block(t, p, blk, refined);
         if (refined) atomicAdd(&counters[2], 1u);
     }
-    rdo_rehint(t, e, blk);
+    __shared__ double s_hint_err[32 * 64];       // repeats of the ETC1 bias list (uastc_core.h, hint_cache): one LDS column per lane
+    __shared__ unsigned char s_hint_table[32 * 64];
+    const hint_cache hc = { s_hint_err + threadIdx.x, s_hint_table + threadIdx.x, 64 };
+    rdo_rehint(t, e, blk, &hc);
     blocks[b] = *reinterpret_cast<const uint4*>(blk);
 }
 
