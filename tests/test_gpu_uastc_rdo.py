@@ -50,6 +50,17 @@ def test_ragged_sizes(hip_ctx, golden, n, jobs):
     assert (got == helpers.host_uastc_rdo(packed, blocks, 2, jobs, lam=4.0)).all()
 
 
+def test_window_larger_than_the_lds_ring(hip_ctx, golden):
+    """lz_dict_size 65536 -> a look-back of 4096 blocks: past the 2048-block LDS ring, the strips kernel reads its candidates back from HBM
+    (k_rdo_strips<false>); same bytes as the host build of the same core, and as the ring version where the window never fills."""
+    packed, blocks = golden["packed_l2"], golden["blocks"]
+    got, _ = uastc.uastc_rdo(hip_ctx, packed, blocks, params(lam=3.0, dict_size=65536), 2, 0)
+    assert (got == helpers.host_uastc_rdo(packed, blocks, 2, 0, lam=3.0, dict_size=65536)).all()
+    small, _ = uastc.uastc_rdo(hip_ctx, packed[:1500], blocks[:1500], params(lam=3.0, dict_size=65536), 2, 0)
+    ring, _ = uastc.uastc_rdo(hip_ctx, packed[:1500], blocks[:1500], params(lam=3.0, dict_size=32768), 2, 0)
+    assert (small == ring).all()   # 1500 blocks: both windows reach back to the strip's first block
+
+
 def test_blocking_host_pointer_entry(hip_ctx, golden):
     blocks = np.ascontiguousarray(golden["blocks"])
     n = blocks.shape[0]
