@@ -678,8 +678,17 @@ bool etc1s_frontend::generate_selector_clusters() {
     device_tsvq::stats ts;
     if (!device_tsvq::hierarchical_codebook_packed16_device(d.ctx, (const uint32_t*)d.sel_ukeys.p, (const uint64_t*)d.sel_uw.p, u_total, groups, m_params.m_max_selector_clusters,
                                                             m_use_hierarchical_selector_codebooks ? parent_size : 0, m_selector_cluster_block_indices,
-                                                            m_selector_parent_cluster_block_indices, &ts, &m_selector_parent_of_unique, &m_selector_parent_count))
+                                                            m_selector_parent_cluster_block_indices, &ts, &m_selector_parent_of_unique, &m_selector_parent_count,
+                                                            &m_selector_leaf_of_unique, &m_selector_cluster_count))
         return fail("selector TSVQ failed");
+    // the clustering is kept as a block -> cluster map; the lists are built when somebody asks (selector_cluster_block_indices())
+    m_selector_cluster_block_indices.clear();
+    m_selector_lists_valid = false;
+    m_block_selector_cluster_index.resize(n);
+    parallel_for(u_total, [&](uint32_t u0, uint32_t u1) {
+        for (uint32_t u = u0; u < u1; u++)
+            for (uint32_t j = goffs[u]; j < goffs[u + 1]; j++) m_block_selector_cluster_index[idx[j]] = m_selector_leaf_of_unique[u];
+    });
     m_selector_parent_cluster_block_indices.clear();
     m_stage_times.push_back(stage_time{"~gsc/tsvq_create", ts.t_create});
     m_stage_times.push_back(stage_time{"~gsc/tsvq_device", ts.t_device});
@@ -702,23 +711,57 @@ bool etc1s_frontend::generate_selector_clusters() {
 
 // frontend.cpp:2098-2138
 void etc1s_frontend::compute_selector_clusters_within_each_parent_cluster() {
-    const size_t parents = m_selector_parent_count, clusters = m_selector_cluster_block_indices.size();
-    std::vector<uint32_t> block_cluster(m_total_blocks, 0);
-    for (size_t ci = 0; ci < clusters; ci++)
-        for (uint32_t b : m_selector_cluster_block_indices[ci]) block_cluster[b] = (uint32_t)ci;
+    const size_t parents = m_selector_parent_count, clusters = m_selector_cluster_count;
     std::vector<uint8_t> member(parents * clusters, 0);
-    for (uint32_t b = 0; b < m_total_blocks; b++) member[(size_t)m_block_parent_selector_cluster[b] * clusters + block_cluster[b]] = 1;
+    for (uint32_t b = 0; b < m_total_blocks; b++) member[(size_t)m_block_parent_selector_cluster[b] * clusters + m_block_selector_cluster_index[b]] = 1;
     m_selector_clusters_within_each_parent_cluster.assign(parents, {});
     for (size_t p = 0; p < parents; p++)
         for (size_t c = 0; c < clusters; c++)
             if (member[p * clusters + c]) m_selector_clusters_within_each_parent_cluster[p].push_back((uint32_t)c);
 }
 
+// The blocks of every selector cluster, ascending, as one CSR array (what the per-cluster kernels read)
+void etc1s_frontend::selector_csr(std::vector<uint32_t>& offsets, std::vector<uint32_t>& indices) const {
+    const uint32_t n = m_total_blocks, k = m_selector_cluster_count;
+    const unsigned T = n > 65536 ? host_threads() : 1;
+    const uint32_t per = (n + T - 1) / T;
+    std::vector<uint32_t> hist((size_t)T * k, 0);
+    offsets.assign((size_t)k + 1, 0); indices.resize(n);
+    parallel_for_chunks(T, [&](unsigned t) {
+        uint32_t* h = &hist[(size_t)t * k];
+        const uint32_t a = t * per, b = std::min(n, a + per);
+        for (uint32_t i = a; i < b; i++) h[m_block_selector_cluster_index[i]]++;
+    });
+    uint32_t run = 0;
+    for (uint32_t c = 0; c < k; c++) {
+        offsets[c] = run;
+        for (unsigned t = 0; t < T; t++) { const uint32_t v = hist[(size_t)t * k + c]; hist[(size_t)t * k + c] = run; run += v; }
+    }
+    offsets[k] = run;
+    parallel_for_chunks(T, [&](unsigned t) {
+        uint32_t* cur = &hist[(size_t)t * k];
+        const uint32_t a = t * per, b = std::min(n, a + per);
+        for (uint32_t i = a; i < b; i++) indices[cur[m_block_selector_cluster_index[i]]++] = i;
+    });
+}
+
+const std::vector<std::vector<uint32_t>>& etc1s_frontend::selector_cluster_block_indices() const {
+    if (!m_selector_lists_valid) {
+        std::vector<uint32_t> offsets, indices;
+        selector_csr(offsets, indices);
+        m_selector_cluster_block_indices.assign(m_selector_cluster_count, {});
+        for (uint32_t c = 0; c < m_selector_cluster_count; c++) m_selector_cluster_block_indices[c].assign(indices.begin() + offsets[c], indices.begin() + offsets[c + 1]);
+        m_selector_lists_valid = true;
+    }
+    return m_selector_cluster_block_indices;
+}
+
 // frontend.cpp:2259-2354
 bool etc1s_frontend::create_optimized_selector_codebook(uint32_t /*iter*/) {
-    const uint32_t k = (uint32_t)m_selector_cluster_block_indices.size();
+    const uint32_t k = m_selector_cluster_count;
     m_optimized_cluster_selectors.resize(k, bu_etc_block{});
-    csr lists; lists.build(m_selector_cluster_block_indices);
+    csr lists;  // the accumulation is integer, so the order of a cluster's blocks does not matter: ascending
+    selector_csr(lists.offsets, lists.indices);
     device_state& d = *m_dev;
     // multi-GPU: every rank takes a contiguous range of clusters holding about 1/world of the member blocks; entries it does not own
     // are uploaded as zero, so that the sum-merge below reassembles the codebook exactly
@@ -749,12 +792,9 @@ bool etc1s_frontend::find_optimal_selector_clusters_for_each_block() {
     m_block_selector_cluster_index.resize(n);
     if (m_params.m_compression_level == 0) {
         // frontend.cpp:2420-2439: blocks stay in their TSVQ cluster and just take its optimised selectors
-        for (uint32_t ci = 0; ci < m_selector_cluster_block_indices.size(); ci++) {
-            const uint32_t bits = raw_selector_bits(m_optimized_cluster_selectors[ci]);
-            for (uint32_t b : m_selector_cluster_block_indices[ci]) {
-                m_block_selector_cluster_index[b] = ci;
-                store_be64(m_encoded_blocks[b], (load_be64(m_encoded_blocks[b]) & ~0xFFFFFFFFull) | bits);
-            }
+        for (uint32_t b = 0; b < n; b++) {
+            const uint32_t bits = raw_selector_bits(m_optimized_cluster_selectors[m_block_selector_cluster_index[b]]);
+            store_be64(m_encoded_blocks[b], (load_be64(m_encoded_blocks[b]) & ~0xFFFFFFFFull) | bits);
         }
         m_enc_device_current = false;
         return true;
@@ -782,9 +822,7 @@ bool etc1s_frontend::find_optimal_selector_clusters_for_each_block() {
         return fail("bu_hip_k_find_optimal_selector_clusters");
     if (!gather_blocks(d.enc.p, 8) || !gather_blocks(d.out_u32.p, 4)) return false;
     if (!d.download(m_block_selector_cluster_index.data(), d.out_u32, n) || !d.download(m_encoded_blocks.data(), d.enc, n)) return fail("download fosc result");
-    // frontend.cpp:2696-2708
-    std::vector<uint32_t> sizes(m_selector_cluster_block_indices.size(), 0);
-    lists_by_cluster<1>(n, (uint32_t)m_selector_cluster_block_indices.size(), [&](uint32_t b) { return m_block_selector_cluster_index[b]; }, m_selector_cluster_block_indices);
+    m_selector_lists_valid = false;  // frontend.cpp:2696-2708 rebuilds the lists in block order: that is what selector_cluster_block_indices() produces
     return true;
 }
 
@@ -793,8 +831,7 @@ bool etc1s_frontend::find_optimal_selector_clusters_for_each_block() {
 // candidate tiles (etc_block::evaluate_etc1_error, etc.cpp:640-700).
 bool etc1s_frontend::introduce_special_selector_clusters() {
     const uint32_t n = m_total_blocks;
-    const uint32_t initial_clusters = (uint32_t)m_selector_cluster_block_indices.size();
-    std::vector<uint8_t> relocated;
+    m_selector_cluster_count = (uint32_t)m_optimized_cluster_selectors.size();
     std::vector<bu_pixel_block> tiles; // fetched lazily, only when a candidate exists and the caller gave us no host copy
     auto tile = [&](uint32_t b) -> const bu_pixel_block* {
         if (m_params.m_pSource_blocks) return &m_params.m_pSource_blocks[b];
@@ -822,7 +859,8 @@ bool etc1s_frontend::introduce_special_selector_clusters() {
         const uint32_t new_index = (uint32_t)m_optimized_cluster_selectors.size();
         bu_etc_block nb{}; store_be64(nb, flat);
         m_optimized_cluster_selectors.push_back(nb);
-        if (m_selector_cluster_block_indices.size() <= new_index) m_selector_cluster_block_indices.resize(new_index + 1);
+        m_selector_cluster_count = new_index + 1;
+        m_selector_lists_valid = false;
         for (uint32_t b = 0; b < n; b++) {
             if (raw_selector_bits(m_orig_encoded_blocks[b]) != flat) continue;
             const bu_pixel_block* px = tile(b);
@@ -830,20 +868,13 @@ bool etc1s_frontend::introduce_special_selector_clusters() {
             const endpoint_params& e = m_endpoint_cluster_etc_params[m_block_endpoint_cluster[b]];
             const uint32_t cur_bits = raw_selector_bits(m_optimized_cluster_selectors[m_block_selector_cluster_index[b]]);
             if (block_error(*px, e, flat) >= block_error(*px, e, cur_bits)) continue;
-            m_block_selector_cluster_index[b] = new_index;
-            m_selector_cluster_block_indices[new_index].push_back(b);
-            if (relocated.empty()) relocated.assign(n, 0);
-            relocated[b] = 1;
+            m_block_selector_cluster_index[b] = new_index;  // the lists (block order) follow from the map
             total_relocated++;
             store_be64(m_encoded_blocks[b], (load_be64(m_encoded_blocks[b]) & ~0xFFFFFFFFull) | flat);
             m_enc_device_current = false;
         }
     }
-    if (total_relocated)
-        for (uint32_t ci = 0; ci < initial_clusters; ci++) {
-            std::vector<uint32_t>& v = m_selector_cluster_block_indices[ci];
-            v.erase(std::remove_if(v.begin(), v.end(), [&](uint32_t b) { return relocated[b] != 0; }), v.end());
-        }
+    (void)total_relocated;
     return true;
 }
 
@@ -867,10 +898,9 @@ void etc1s_frontend::optimize_selector_codebook() {
     for (uint32_t b = 0; b < m_total_blocks; b++) m_block_selector_cluster_index[b] = (uint32_t)old_to_new[m_block_selector_cluster_index[b]];
     std::vector<bu_etc_block> sels(new_to_old.size());
     for (size_t i = 0; i < new_to_old.size(); i++) sels[i] = m_optimized_cluster_selectors[new_to_old[i]];
-    std::vector<std::vector<uint32_t>> lists;
-    lists_by_cluster<1>(m_total_blocks, (uint32_t)new_to_old.size(), [&](uint32_t b) { return m_block_selector_cluster_index[b]; }, lists);
     m_optimized_cluster_selectors.swap(sels);
-    m_selector_cluster_block_indices.swap(lists);
+    m_selector_cluster_count = (uint32_t)new_to_old.size();
+    m_selector_lists_valid = false;
     for (auto& l : m_selector_clusters_within_each_parent_cluster)
         for (uint32_t& c : l) c = (uint32_t)old_to_new[c];
 }

@@ -60,10 +60,10 @@ public:
     uint32_t get_total_endpoint_clusters() const { return (uint32_t)m_endpoint_clusters.size(); }
     uint32_t get_subblock_endpoint_cluster_index(uint32_t block, uint32_t) const { return m_block_endpoint_cluster[block]; }
     const endpoint_params& get_endpoint_cluster_params(uint32_t ci) const { return m_endpoint_cluster_etc_params[ci]; }
-    uint32_t get_total_selector_clusters() const { return (uint32_t)m_selector_cluster_block_indices.size(); }
+    uint32_t get_total_selector_clusters() const { return m_selector_cluster_count; }
     uint32_t get_block_selector_cluster_index(uint32_t block) const { return m_block_selector_cluster_index[block]; }
     const bu_etc_block& get_selector_cluster_selector_bits(uint32_t ci) const { return m_optimized_cluster_selectors[ci]; }
-    const std::vector<uint32_t>& get_selector_cluster_block_indices(uint32_t ci) const { return m_selector_cluster_block_indices[ci]; }
+    const std::vector<uint32_t>& get_selector_cluster_block_indices(uint32_t ci) const { return selector_cluster_block_indices()[ci]; }
 
     // ---- stage state, exposed for stage-by-stage parity tests
     const std::vector<bu_etc_block>& etc1_blocks() const;  // fetched from the device on first use
@@ -72,7 +72,7 @@ public:
     const std::vector<std::vector<uint32_t>>& endpoint_parent_clusters() const;  // built on first use from the parent-of-vector map
     const std::vector<endpoint_params>& endpoint_cluster_params() const { return m_endpoint_cluster_etc_params; }
     const std::vector<uint32_t>& block_endpoint_clusters() const { return m_block_endpoint_cluster; }
-    const std::vector<std::vector<uint32_t>>& selector_cluster_block_indices() const { return m_selector_cluster_block_indices; }
+    const std::vector<std::vector<uint32_t>>& selector_cluster_block_indices() const;  // built on first use from the block -> cluster map (ascending blocks)
     const std::vector<bu_etc_block>& optimized_cluster_selectors() const { return m_optimized_cluster_selectors; }
     const std::vector<uint32_t>& block_selector_cluster_index() const { return m_block_selector_cluster_index; }
 
@@ -144,7 +144,12 @@ private:
     std::vector<std::vector<uint32_t>> m_endpoint_cluster_subblocks;  // endpoint_cluster_etc_params::m_subblocks (never cleared, frontend.cpp:2727-2729)
 
     // selector side
-    std::vector<std::vector<uint32_t>> m_selector_cluster_block_indices, m_selector_parent_cluster_block_indices;
+    mutable std::vector<std::vector<uint32_t>> m_selector_cluster_block_indices;  // lazily materialised from m_block_selector_cluster_index
+    mutable bool m_selector_lists_valid = false;
+    std::vector<std::vector<uint32_t>> m_selector_parent_cluster_block_indices;
+    std::vector<uint32_t> m_selector_leaf_of_unique;
+    uint32_t m_selector_cluster_count = 0;
+    void selector_csr(std::vector<uint32_t>& offsets, std::vector<uint32_t>& indices) const;
     std::vector<bu_etc_block> m_optimized_cluster_selectors;
     std::vector<uint8_t> m_block_parent_selector_cluster;
     std::vector<std::vector<uint32_t>> m_selector_clusters_within_each_parent_cluster;

@@ -89,12 +89,14 @@ public:
     static bool hierarchical_codebook_packed16_device(bu_hip_context* ctx, const uint32_t* d_keys, const uint64_t* d_weights, uint32_t n_unique, const Groups& groups,
                                                       uint32_t max_codebook_size, uint32_t max_parent_codebook_size, std::vector<std::vector<uint32_t>>& codebook,
                                                       std::vector<std::vector<uint32_t>>& parent_codebook, stats* st = nullptr,
-                                                      std::vector<uint32_t>* parent_of_unique = nullptr, uint32_t* parent_count = nullptr) {
+                                                      std::vector<uint32_t>* parent_of_unique = nullptr, uint32_t* parent_count = nullptr,
+                                                      std::vector<uint32_t>* leaf_of_unique = nullptr, uint32_t* leaf_count = nullptr) {
         bu_tsvq_root root;
         const auto t0 = std::chrono::steady_clock::now();
         bu_tsvq* q = n_unique ? bu_hip_tsvq_create_packed16_device(ctx, d_keys, d_weights, n_unique, &root) : nullptr;
         if (st) st->t_create = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-        return q && build(ctx, q, root, n_unique, groups, max_codebook_size, max_parent_codebook_size, codebook, parent_codebook, st, parent_of_unique, parent_count);
+        return q && build(ctx, q, root, n_unique, groups, max_codebook_size, max_parent_codebook_size, codebook, parent_codebook, st, parent_of_unique, parent_count,
+                          leaf_of_unique, leaf_count);
     }
 
     // parent lists from a parent-of-unique map (what build() would have produced): vectors ascending inside a parent, members group by group
@@ -145,9 +147,11 @@ private:
     static bool build(bu_hip_context* ctx, bu_tsvq* q, const bu_tsvq_root& root, uint32_t n, const Groups& groups,
                       uint32_t max_codebook_size, uint32_t max_parent_codebook_size, std::vector<std::vector<uint32_t>>& codebook,
                       std::vector<std::vector<uint32_t>>& parent_codebook, stats* st, std::vector<uint32_t>* parent_of_unique = nullptr,
-                      uint32_t* parent_count = nullptr) {
+                      uint32_t* parent_count = nullptr, std::vector<uint32_t>* leaf_of_unique = nullptr, uint32_t* leaf_count = nullptr) {
         if (parent_of_unique) parent_of_unique->clear();
         if (parent_count) *parent_count = 0;
+        if (leaf_of_unique) leaf_of_unique->clear();
+        if (leaf_count) *leaf_count = 0;
         struct guard { bu_hip_context* c; bu_tsvq* q; ~guard() { bu_hip_tsvq_destroy(c, q); } } g{ctx, q};
 
         struct node {
@@ -266,8 +270,14 @@ private:
                 dst += groups.size(us[i]);
             }
         };
-        codebook.clear(); codebook.resize(leaf_members.size());
-        {
+        codebook.clear();
+        if (leaf_count) *leaf_count = (uint32_t)leaf_members.size();
+        if (leaf_of_unique) {  // the caller keeps "which cluster does every distinct vector belong to" and builds lists only when asked
+            leaf_of_unique->resize(n);
+            for (size_t l = 0; l < leaf_members.size(); l++)
+                for (uint32_t i = 0; i < leaf_members[l].n; i++) (*leaf_of_unique)[leaf_members[l].p[i]] = (uint32_t)l;
+        } else {
+            codebook.resize(leaf_members.size());
             std::atomic<size_t> next{0};
             auto work = [&] { for (size_t i; (i = next.fetch_add(1)) < leaf_members.size();) expand_one(leaf_members[i].p, leaf_members[i].n, codebook[i]); };
             std::vector<std::thread> th;
