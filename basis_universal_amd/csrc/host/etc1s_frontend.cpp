@@ -346,23 +346,82 @@ bool etc1s_frontend::generate_endpoint_clusters() {
     const uint32_t parent_size = (m_params.m_max_endpoint_clusters >= 256) ? kEndpointParentCodebookSize : 0;
     const csr_block_pair_groups groups{m_endpoint_group_offsets.data(), m_endpoint_group_blocks.data()};
     m_endpoint_parent_clusters.clear();
+    std::vector<uint32_t> leaf_of_unique;
+    std::vector<std::vector<uint32_t>> unused;
     if (!device_tsvq::hierarchical_codebook(m_dev->ctx, 6, m_endpoint_unique_rows, m_endpoint_unique_weights, groups, m_params.m_max_endpoint_clusters,
-                                            m_use_hierarchical_endpoint_codebooks ? parent_size : 0, m_endpoint_clusters, m_endpoint_parent_clusters, nullptr,
-                                            &m_endpoint_parent_of_unique, &m_endpoint_parent_count))
+                                            m_use_hierarchical_endpoint_codebooks ? parent_size : 0, unused, m_endpoint_parent_clusters, nullptr,
+                                            &m_endpoint_parent_of_unique, &m_endpoint_parent_count, &leaf_of_unique, &m_endpoint_cluster_count))
         return fail("endpoint TSVQ failed");
+    // The clustering is kept as (cluster, position in the cluster's list) per block; the lists are built when somebody asks. A leaf lists its
+    // distinct vectors ascending and each vector's blocks ascending (enc.h:1573-1584 + the training-vector order of frontend.cpp:825-866).
+    const uint32_t n = m_total_blocks, u_total = (uint32_t)leaf_of_unique.size();
+    m_block_endpoint_cluster.resize(n); m_block_endpoint_pos.resize(n);
+    m_endpoint_cluster_sizes.assign(m_endpoint_cluster_count, 0);
     if (m_use_hierarchical_endpoint_codebooks) {
         // only the block -> parent map is needed from here on; the parent lists themselves are built when somebody asks (endpoint_parent_clusters())
-        m_block_parent_endpoint_cluster.assign(m_total_blocks, 0);
-        if (!m_endpoint_parent_count) m_endpoint_parent_count = 1;  // no parent level: one parent holding everything (frontend.cpp:905-911)
-        else
-            parallel_for((uint32_t)m_endpoint_parent_of_unique.size(), [&](uint32_t u0, uint32_t u1) {
-                for (uint32_t u = u0; u < u1; u++)
-                    for (uint32_t j = m_endpoint_group_offsets[u]; j < m_endpoint_group_offsets[u + 1]; j++)
-                        m_block_parent_endpoint_cluster[m_endpoint_group_blocks[j]] = (uint8_t)m_endpoint_parent_of_unique[u];
-            });
+        m_block_parent_endpoint_cluster.assign(n, 0);
+        if (!m_endpoint_parent_count) { m_endpoint_parent_count = 1; m_endpoint_parent_of_unique.clear(); }  // no parent level: one parent holding everything (frontend.cpp:905-911)
     }
+    std::vector<uint32_t> first_pos(u_total);  // where vector u's blocks start inside their cluster's list
+    for (uint32_t u = 0; u < u_total; u++) {
+        const uint32_t c = leaf_of_unique[u];
+        first_pos[u] = m_endpoint_cluster_sizes[c];
+        m_endpoint_cluster_sizes[c] += m_endpoint_group_offsets[u + 1] - m_endpoint_group_offsets[u];
+    }
+    parallel_for(u_total, [&](uint32_t u0, uint32_t u1) {
+        for (uint32_t u = u0; u < u1; u++) {
+            const uint32_t c = leaf_of_unique[u], a = m_endpoint_group_offsets[u];
+            for (uint32_t j = a; j < m_endpoint_group_offsets[u + 1]; j++) {
+                const uint32_t b = m_endpoint_group_blocks[j];
+                m_block_endpoint_cluster[b] = c; m_block_endpoint_pos[b] = first_pos[u] + (j - a);
+                if (m_use_hierarchical_endpoint_codebooks && !m_endpoint_parent_of_unique.empty()) m_block_parent_endpoint_cluster[b] = (uint8_t)m_endpoint_parent_of_unique[u];
+            }
+        }
+    });
+    m_endpoint_map_valid = true; m_endpoint_lists_valid = false; m_endpoint_clusters.clear();
     return true;
 }
+
+// ---- the endpoint clustering has two interchangeable forms: the reference's lists of training-vector ids (block * 2 + sub-block, both
+// sub-blocks of a block adjacent) and, per block, (cluster, position of the block in the cluster's list). The hot path works on the second
+// one; whoever needs lists (levels 4-6 bookkeeping, the getters) gets them built, and list surgery is folded back into the map.
+void etc1s_frontend::ensure_endpoint_map() const {
+    if (m_endpoint_map_valid) return;
+    const uint32_t k = (uint32_t)m_endpoint_clusters.size();
+    m_endpoint_cluster_count = k;
+    m_block_endpoint_cluster.resize(m_total_blocks); m_block_endpoint_pos.resize(m_total_blocks);
+    m_endpoint_cluster_sizes.assign(k, 0);
+    for (uint32_t ci = 0; ci < k; ci++) {
+        const std::vector<uint32_t>& l = m_endpoint_clusters[ci];
+        m_endpoint_cluster_sizes[ci] = (uint32_t)(l.size() / 2);
+        for (size_t i = 0; i < l.size(); i++) { m_block_endpoint_cluster[l[i] >> 1] = ci; m_block_endpoint_pos[l[i] >> 1] = (uint32_t)(i / 2); }
+    }
+    m_endpoint_map_valid = true;
+}
+void etc1s_frontend::endpoint_csr(std::vector<uint32_t>& offsets, std::vector<uint32_t>& indices) const {
+    ensure_endpoint_map();
+    const uint32_t k = m_endpoint_cluster_count, n = m_total_blocks;
+    offsets.resize((size_t)k + 1);
+    uint32_t run = 0;
+    for (uint32_t c = 0; c < k; c++) { offsets[c] = run; run += m_endpoint_cluster_sizes[c] * 2; }
+    offsets[k] = run;
+    indices.resize(run);
+    parallel_for(n, [&](uint32_t b0, uint32_t b1) {
+        for (uint32_t b = b0; b < b1; b++) {
+            const size_t at = (size_t)offsets[m_block_endpoint_cluster[b]] + 2ull * m_block_endpoint_pos[b];
+            indices[at] = b * 2; indices[at + 1] = b * 2 + 1;
+        }
+    });
+}
+void etc1s_frontend::ensure_endpoint_lists() const {
+    if (m_endpoint_lists_valid) return;
+    std::vector<uint32_t> offsets, indices;
+    endpoint_csr(offsets, indices);
+    m_endpoint_clusters.assign(m_endpoint_cluster_count, {});
+    for (uint32_t c = 0; c < m_endpoint_cluster_count; c++) m_endpoint_clusters[c].assign(indices.begin() + offsets[c], indices.begin() + offsets[c + 1]);
+    m_endpoint_lists_valid = true;
+}
+const std::vector<std::vector<uint32_t>>& etc1s_frontend::endpoint_clusters() const { ensure_endpoint_lists(); return m_endpoint_clusters; }
 
 const std::vector<std::vector<uint32_t>>& etc1s_frontend::endpoint_parent_clusters() const {
     if (m_endpoint_parent_clusters.empty() && m_use_hierarchical_endpoint_codebooks) {
@@ -378,17 +437,13 @@ const std::vector<std::vector<uint32_t>>& etc1s_frontend::endpoint_parent_cluste
 }
 
 // frontend.cpp:947-968
-void etc1s_frontend::generate_block_endpoint_clusters() {
-    m_block_endpoint_cluster.resize(m_total_blocks);
-    for (size_t ci = 0; ci < m_endpoint_clusters.size(); ci++)
-        for (uint32_t tv : m_endpoint_clusters[ci]) m_block_endpoint_cluster[tv >> 1] = (uint32_t)ci;
-}
+void etc1s_frontend::generate_block_endpoint_clusters() { ensure_endpoint_map(); }  // the map is the clustering (see ensure_endpoint_map)
 
 // frontend.cpp:971-1003. The reference collects one entry per block and then sorts + uniques each parent's list; the result is
 // "the ascending set of clusters that own at least one block of this parent", which a membership table gives in O(blocks).
 void etc1s_frontend::compute_endpoint_clusters_within_each_parent_cluster() {
     generate_block_endpoint_clusters();
-    const size_t parents = m_endpoint_parent_count, clusters = m_endpoint_clusters.size();
+    const size_t parents = m_endpoint_parent_count, clusters = m_endpoint_cluster_count;
     std::vector<uint8_t> member(parents * clusters, 0);
     for (uint32_t b = 0; b < m_total_blocks; b++) member[(size_t)m_block_parent_endpoint_cluster[b] * clusters + m_block_endpoint_cluster[b]] = 1;
     m_endpoint_clusters_within_each_parent_cluster.assign(parents, {});
@@ -399,10 +454,12 @@ void etc1s_frontend::compute_endpoint_clusters_within_each_parent_cluster() {
 
 // frontend.cpp:1214-1617 (CPU semantics; the kernel also handles step > 0)
 bool etc1s_frontend::generate_endpoint_codebook(uint32_t step) {
-    const uint32_t k = (uint32_t)m_endpoint_clusters.size();
+    csr lists;  // the members of every cluster in list order (it decides the float mean of clusters past 65k texels)
+    if (m_endpoint_lists_valid) lists.build(m_endpoint_clusters);
+    else endpoint_csr(lists.offsets, lists.indices);
+    const uint32_t k = (uint32_t)lists.offsets.size() - 1;
     m_endpoint_cluster_etc_params.resize(k);
     const int quality = m_params.m_compression_level <= 1 ? BU_ETC_QUALITY_MEDIUM : m_params.m_compression_level == 6 ? BU_ETC_QUALITY_UBER : BU_ETC_QUALITY_SLOW; // :1530-1533
-    csr lists; lists.build(m_endpoint_clusters);
     std::vector<uint8_t> prm(k * 4ull), valid(k);
     std::vector<uint64_t> err(k);
     for (uint32_t i = 0; i < k; i++) {
@@ -445,6 +502,7 @@ bool etc1s_frontend::generate_endpoint_codebook(uint32_t step) {
 // that their cluster represents worst are split off into new two-vector clusters until the codebook is full again.
 bool etc1s_frontend::introduce_new_endpoint_clusters() {
     generate_block_endpoint_clusters();
+    ensure_endpoint_lists();  // list surgery below; folded back into the map at the end
     int want = (int)m_params.m_max_endpoint_clusters - (int)m_endpoint_clusters.size();
     if (want <= 0) return true;
     const uint32_t n = m_total_blocks, k = (uint32_t)m_endpoint_clusters.size();
@@ -483,6 +541,7 @@ bool etc1s_frontend::introduce_new_endpoint_clusters() {
         std::vector<uint32_t>& l = m_endpoint_clusters[i];
         l.erase(std::remove_if(l.begin(), l.end(), [&](uint32_t tv) { return relocated[tv] != 0; }), l.end());
     }
+    m_endpoint_map_valid = false;
     generate_block_endpoint_clusters();
     return true;
 }
@@ -562,8 +621,8 @@ bool etc1s_frontend::refine_block_endpoints_given_selectors(uint32_t* total_refi
 bool etc1s_frontend::refine_endpoint_clusterization(uint32_t* total_reassigned) {
     if (m_use_hierarchical_endpoint_codebooks) compute_endpoint_clusters_within_each_parent_cluster();  // refreshes m_block_endpoint_cluster
     else generate_block_endpoint_clusters();
-    const uint32_t n = m_total_blocks, k = (uint32_t)m_endpoint_clusters.size();
-    const std::vector<uint32_t>& block_cluster = m_block_endpoint_cluster;  // the block -> cluster map of the lists as they stand
+    const uint32_t n = m_total_blocks, k = m_endpoint_cluster_count;
+    const std::vector<uint32_t>& block_cluster = m_block_endpoint_cluster;  // the block -> cluster map of the clustering as it stands
     std::vector<uint8_t> prm(k * 4ull);
     for (uint32_t i = 0; i < k; i++) {
         const endpoint_params& e = m_endpoint_cluster_etc_params[i];
@@ -590,12 +649,35 @@ bool etc1s_frontend::refine_endpoint_clusterization(uint32_t* total_reassigned) 
     std::vector<uint32_t> best(n);
     if (!d.download(best.data(), d.out_u32, n)) return fail("download refine result");
 
-    // frontend.cpp:1921-1942: rebuild the cluster lists in block order (empty clusters stay, they are removed by eliminate_...)
+    // frontend.cpp:1921-1942 rebuilds the cluster lists in block order (empty clusters stay, they are removed by eliminate_...): the new
+    // position of a block is its rank among its cluster's blocks. Per-thread counts over contiguous block ranges, then a second sweep.
     uint32_t moved = 0;
-    for (uint32_t b = 0; b < n; b++) moved += best[b] != block_cluster[b];
-    std::vector<std::vector<uint32_t>> fresh;
-    lists_by_cluster<2>(n, k, [&](uint32_t b) { return best[b]; }, fresh);
-    m_endpoint_clusters.swap(fresh);
+    {
+        const unsigned T = n > 65536 ? host_threads() : 1;
+        const uint32_t per = (n + T - 1) / T;
+        std::vector<uint32_t> hist((size_t)T * k, 0), moved_t(T, 0);
+        parallel_for_chunks(T, [&](unsigned t) {
+            uint32_t* h = &hist[(size_t)t * k];
+            const uint32_t a = t * per, b = std::min(n, a + per);
+            uint32_t m = 0;
+            for (uint32_t i = a; i < b; i++) { h[best[i]]++; m += best[i] != block_cluster[i]; }
+            moved_t[t] = m;
+        });
+        m_endpoint_cluster_sizes.assign(k, 0);
+        for (uint32_t c = 0; c < k; c++) {
+            uint32_t run = 0;
+            for (unsigned t = 0; t < T; t++) { const uint32_t v = hist[(size_t)t * k + c]; hist[(size_t)t * k + c] = run; run += v; }
+            m_endpoint_cluster_sizes[c] = run;
+        }
+        for (unsigned t = 0; t < T; t++) moved += moved_t[t];
+        parallel_for_chunks(T, [&](unsigned t) {
+            uint32_t* cur = &hist[(size_t)t * k];
+            const uint32_t a = t * per, b = std::min(n, a + per);
+            for (uint32_t i = a; i < b; i++) m_block_endpoint_pos[i] = cur[best[i]]++;
+        });
+    }
+    m_block_endpoint_cluster.swap(best);
+    m_endpoint_map_valid = true; m_endpoint_lists_valid = false; m_endpoint_clusters.clear();
     if (total_reassigned) *total_reassigned = moved;
     return true;
 }
@@ -604,30 +686,41 @@ bool etc1s_frontend::refine_endpoint_clusterization(uint32_t* total_reassigned) 
 // (frontend.h:248-267): (r, g, b, a=255) of the colour, then the (all-zero) second colour, then inten. std::sort is not stable,
 // so we call the very same algorithm with an equivalent comparator to get the same permutation among equal keys.
 void etc1s_frontend::eliminate_redundant_or_empty_endpoint_clusters() {
-    const uint32_t k = (uint32_t)m_endpoint_clusters.size();
+    ensure_endpoint_map();
+    const uint32_t k = m_endpoint_cluster_count, n = m_total_blocks;
     std::vector<uint32_t> order(k);
     std::iota(order.begin(), order.end(), 0u);
     const std::vector<endpoint_params>& P = m_endpoint_cluster_etc_params;
     auto key = [&](uint32_t i) { return ((uint32_t)P[i].r << 24) | ((uint32_t)P[i].g << 16) | ((uint32_t)P[i].b << 8) | P[i].inten; };
     std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return key(a) < key(b); });
 
-    std::vector<std::vector<uint32_t>> clusters;
+    // A run of equal parameters becomes one cluster: the first non-empty one followed by the members of the others, list after list. In map
+    // form: every old cluster gets its new index and the offset its list starts at inside the merged list.
+    std::vector<uint32_t> new_index(k, 0), base(k, 0), sizes;
     std::vector<endpoint_params> params;
     for (uint32_t i = 0; i < k;) {
         const uint32_t ci = order[i];
-        if (m_endpoint_clusters[ci].empty()) { i++; continue; }
+        if (!m_endpoint_cluster_sizes[ci]) { i++; continue; }
         uint32_t j = i + 1;
         while (j < k && key(order[j]) == key(ci)) j++;
-        clusters.push_back(std::move(m_endpoint_clusters[ci]));
+        const uint32_t ni = (uint32_t)params.size();
         params.push_back(P[ci]);
-        for (uint32_t t = i + 1; t < j; t++) {
-            const std::vector<uint32_t>& src = m_endpoint_clusters[order[t]];
-            clusters.back().insert(clusters.back().end(), src.begin(), src.end());
-        }
+        uint32_t run = 0;
+        for (uint32_t t = i; t < j; t++) { new_index[order[t]] = ni; base[order[t]] = run; run += m_endpoint_cluster_sizes[order[t]]; }
+        sizes.push_back(run);
         i = j;
     }
-    m_endpoint_clusters.swap(clusters);
+    parallel_for(n, [&](uint32_t b0, uint32_t b1) {
+        for (uint32_t b = b0; b < b1; b++) {
+            const uint32_t old = m_block_endpoint_cluster[b];
+            m_block_endpoint_pos[b] += base[old];
+            m_block_endpoint_cluster[b] = new_index[old];
+        }
+    });
+    m_endpoint_cluster_sizes.swap(sizes);
+    m_endpoint_cluster_count = (uint32_t)params.size();
     m_endpoint_cluster_etc_params.swap(params);
+    m_endpoint_lists_valid = false; m_endpoint_clusters.clear();
 }
 
 // frontend.cpp:2014-2096

@@ -57,8 +57,8 @@ public:
     const bu_etc_block& get_output_block(uint32_t i) const { return m_encoded_blocks[i]; }
     const std::vector<bu_etc_block>& get_output_blocks() const { return m_encoded_blocks; }
     const bu_etc_block& get_etc1s_block(uint32_t i) const { return etc1_blocks()[i]; }
-    uint32_t get_total_endpoint_clusters() const { return (uint32_t)m_endpoint_clusters.size(); }
-    uint32_t get_subblock_endpoint_cluster_index(uint32_t block, uint32_t) const { return m_block_endpoint_cluster[block]; }
+    uint32_t get_total_endpoint_clusters() const { ensure_endpoint_map(); return m_endpoint_cluster_count; }
+    uint32_t get_subblock_endpoint_cluster_index(uint32_t block, uint32_t) const { ensure_endpoint_map(); return m_block_endpoint_cluster[block]; }
     const endpoint_params& get_endpoint_cluster_params(uint32_t ci) const { return m_endpoint_cluster_etc_params[ci]; }
     uint32_t get_total_selector_clusters() const { return m_selector_cluster_count; }
     uint32_t get_block_selector_cluster_index(uint32_t block) const { return m_block_selector_cluster_index[block]; }
@@ -68,10 +68,10 @@ public:
     // ---- stage state, exposed for stage-by-stage parity tests
     const std::vector<bu_etc_block>& etc1_blocks() const;  // fetched from the device on first use
     const std::vector<bu_etc_block>& orig_encoded_blocks() const { return m_orig_encoded_blocks; }
-    const std::vector<std::vector<uint32_t>>& endpoint_clusters() const { return m_endpoint_clusters; }
+    const std::vector<std::vector<uint32_t>>& endpoint_clusters() const;  // built on first use from the (cluster, position) map
     const std::vector<std::vector<uint32_t>>& endpoint_parent_clusters() const;  // built on first use from the parent-of-vector map
     const std::vector<endpoint_params>& endpoint_cluster_params() const { return m_endpoint_cluster_etc_params; }
-    const std::vector<uint32_t>& block_endpoint_clusters() const { return m_block_endpoint_cluster; }
+    const std::vector<uint32_t>& block_endpoint_clusters() const { ensure_endpoint_map(); return m_block_endpoint_cluster; }
     const std::vector<std::vector<uint32_t>>& selector_cluster_block_indices() const;  // built on first use from the block -> cluster map (ascending blocks)
     const std::vector<bu_etc_block>& optimized_cluster_selectors() const { return m_optimized_cluster_selectors; }
     const std::vector<uint32_t>& block_selector_cluster_index() const { return m_block_selector_cluster_index; }
@@ -132,7 +132,14 @@ private:
     std::vector<float> m_endpoint_unique_rows;            // distinct (low rgb, high rgb)/255 vectors, ascending
     std::vector<uint64_t> m_endpoint_unique_weights;
     std::vector<uint32_t> m_endpoint_group_offsets, m_endpoint_group_blocks;  // CSR: the blocks behind every distinct vector, ascending
-    std::vector<std::vector<uint32_t>> m_endpoint_clusters;
+    // the endpoint clustering in its two forms (etc1s_frontend.cpp, ensure_endpoint_map / ensure_endpoint_lists)
+    mutable std::vector<std::vector<uint32_t>> m_endpoint_clusters;
+    mutable std::vector<uint32_t> m_block_endpoint_pos, m_endpoint_cluster_sizes;
+    mutable uint32_t m_endpoint_cluster_count = 0;
+    mutable bool m_endpoint_map_valid = false, m_endpoint_lists_valid = false;
+    void ensure_endpoint_map() const;
+    void ensure_endpoint_lists() const;
+    void endpoint_csr(std::vector<uint32_t>& offsets, std::vector<uint32_t>& indices) const;
     mutable std::vector<std::vector<uint32_t>> m_endpoint_parent_clusters;  // lazily materialised, see endpoint_parent_clusters()
     std::vector<uint32_t> m_endpoint_parent_of_unique, m_selector_parent_of_unique;  // parent cluster of every distinct training vector
     uint32_t m_endpoint_parent_count = 0, m_selector_parent_count = 0;
@@ -140,7 +147,7 @@ private:
     std::vector<uint8_t> m_block_parent_endpoint_cluster;
     std::vector<std::vector<uint32_t>> m_endpoint_clusters_within_each_parent_cluster;
     std::vector<endpoint_params> m_endpoint_cluster_etc_params;
-    std::vector<uint32_t> m_block_endpoint_cluster;
+    mutable std::vector<uint32_t> m_block_endpoint_cluster;  // mutable: part of the lazily synchronised clustering, see ensure_endpoint_map
     std::vector<std::vector<uint32_t>> m_endpoint_cluster_subblocks;  // endpoint_cluster_etc_params::m_subblocks (never cleared, frontend.cpp:2727-2729)
 
     // selector side

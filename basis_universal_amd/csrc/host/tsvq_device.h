@@ -64,12 +64,14 @@ public:
     static bool hierarchical_codebook(bu_hip_context* ctx, uint32_t dim, const std::vector<float>& rows, const std::vector<uint64_t>& weights,
                                       const Groups& groups, uint32_t max_codebook_size, uint32_t max_parent_codebook_size,
                                       std::vector<std::vector<uint32_t>>& codebook, std::vector<std::vector<uint32_t>>& parent_codebook, stats* st = nullptr,
-                                      std::vector<uint32_t>* parent_of_unique = nullptr, uint32_t* parent_count = nullptr) {
+                                      std::vector<uint32_t>* parent_of_unique = nullptr, uint32_t* parent_count = nullptr,
+                                      std::vector<uint32_t>* leaf_of_unique = nullptr, uint32_t* leaf_count = nullptr) {
         bu_tsvq_root root;
         const auto t0 = std::chrono::steady_clock::now();
         bu_tsvq* q = weights.empty() ? nullptr : bu_hip_tsvq_create(ctx, dim, rows.data(), weights.data(), (uint32_t)weights.size(), &root);
         if (st) st->t_create = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-        return q && build(ctx, q, root, (uint32_t)weights.size(), groups, max_codebook_size, max_parent_codebook_size, codebook, parent_codebook, st, parent_of_unique, parent_count);
+        return q && build(ctx, q, root, (uint32_t)weights.size(), groups, max_codebook_size, max_parent_codebook_size, codebook, parent_codebook, st, parent_of_unique, parent_count,
+                          leaf_of_unique, leaf_count);
     }
 
     // Selector vectors: keys[u] packs the 16 selector values of distinct vector u (value 0 in the top two bits), ascending.
