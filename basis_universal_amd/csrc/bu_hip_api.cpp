@@ -473,8 +473,18 @@ int bu_hip_k_create_optimized_selector_codebook(bu_hip_context* ctx, const void*
                                                 const uint32_t* d_offsets, const uint32_t* d_block_indices, int perceptual, void* d_selector_blocks) {
     if (!ctx) return 0;
     device_guard g(ctx->device);
+    if (!n_clusters) return 1;
+    // how many members the offsets span (two dwords back from the device; the launch is sized by member count, not by cluster)
+    uint32_t ends[2] = { 0, 0 };
+    BU_TRY(ctx, hipMemcpyAsync(&ends[0], d_offsets, 4, hipMemcpyDeviceToHost, ctx->stream));
+    BU_TRY(ctx, hipMemcpyAsync(&ends[1], d_offsets + n_clusters, 4, hipMemcpyDeviceToHost, ctx->stream));
+    BU_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (ends[1] < ends[0]) { set_error(ctx, "create_optimized_selector_codebook: offsets are not ascending"); return 0; }
+    arena& ws = ctx->scratch[4];
+    BU_TRY(ctx, ws.reserve(bu::create_optimized_selector_codebook_workspace_bytes(n_clusters)));
     prof_scope ps(ctx, "create_optimized_selector_codebook");
-    BU_TRY(ctx, bu::launch_create_optimized_selector_codebook(ctx->stream, d_px, d_enc, n_clusters, d_offsets, d_block_indices, perceptual != 0, d_selector_blocks));
+    BU_TRY(ctx, bu::launch_create_optimized_selector_codebook(ctx->stream, d_px, d_enc, n_clusters, d_offsets, d_block_indices, ends[1] - ends[0], perceptual != 0, ws.p,
+                                                              d_selector_blocks));
     return 1;
 }
 

@@ -698,31 +698,57 @@ __global__ __launch_bounds__(256) void k_determine_selectors(
 // -------------------------------------------------------------------------------------------------------------------
 // a13: create_optimized_selector_codebook (frontend.cpp:2259-2354)
 //
-// One wave per selector cluster; lane = (pixel p = lane>>2, selector s = lane&3) accumulates the u64 error of "pixel p of
-// every member block encoded with selector s" -- exactly the reference's total_err[y][x][s] -- then a 4-lane first-min.
+// lane = (pixel p = lane>>2, selector s = lane&3) accumulates the u64 error of "pixel p of every member block encoded with selector s" --
+// exactly the reference's total_err[y][x][s] -- then a 4-lane first-min picks the pixel's selector. Clusters are very uneven (a few hold tens
+// of thousands of blocks), so the accumulation is cut by POSITION in the CSR member array, not by cluster: every wave takes COSC_CHUNK
+// consecutive members, finds the cluster its first member belongs to (binary search in the offsets) and walks on, flushing its partial sums
+// into the cluster's 64 u64 counters with atomic adds whenever it crosses into the next cluster. Integer sums: exact in any order. A second
+// kernel (one wave per cluster) turns the counters into selectors.
 // -------------------------------------------------------------------------------------------------------------------
 
+constexpr uint32_t COSC_CHUNK = 128;
+
 template <bool PERCEPTUAL>
-__global__ __launch_bounds__(256) void k_create_optimized_selector_codebook(
+__global__ __launch_bounds__(256) void k_cosc_accumulate(
     const uint32_t* __restrict__ pixel_words, const uint64_t* __restrict__ enc_blocks, uint32_t n_clusters,
-    const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ block_indices, uint64_t* __restrict__ selector_blocks) {
+    const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ block_indices, unsigned long long* __restrict__ acc) {
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t ci = blockIdx.x * 4u + (threadIdx.x >> 6);
-    if (ci >= n_clusters) return;
-    const uint32_t first = offsets[ci], cnt = offsets[ci + 1] - first;
-    if (!cnt) return; // empty clusters keep their previous selectors (frontend.cpp:2282-2283)
+    const uint32_t wave = blockIdx.x * 4u + (threadIdx.x >> 6);
+    const uint32_t begin = offsets[0], end = offsets[n_clusters];
+    const uint64_t lo64 = (uint64_t)begin + (uint64_t)wave * COSC_CHUNK;
+    if (lo64 >= end) return;
+    const uint32_t lo = (uint32_t)lo64, hi = end - lo > COSC_CHUNK ? lo + COSC_CHUNK : end;
+    // cluster of member `lo`: the last cluster whose first member is <= lo (empty clusters in front of it share that offset and are skipped)
+    uint32_t a = 0, b = n_clusters;  // invariant: offsets[a] <= lo < offsets[b]
+    while (b - a > 1) { const uint32_t m = (a + b) >> 1; if (offsets[m] <= lo) a = m; else b = m; }
+    uint32_t ci = a, next = offsets[ci + 1];
     const uint32_t p = lane >> 2, s = lane & 3u;
-    uint64_t tot = 0;
-    for (uint32_t k = 0; k < cnt; k++) {
-        const uint32_t bi = block_indices[first + k];
+    unsigned long long tot = 0;
+    for (uint32_t k = lo; k < hi; k++) {
+        while (k >= next) {  // crossed into the next (non-empty) cluster
+            if (tot) atomicAdd(&acc[(size_t)ci * 64 + lane], tot);
+            tot = 0;
+            ci++; next = offsets[ci + 1];
+        }
+        const uint32_t bi = block_indices[k];
         uint32_t r5, g5, b5, inten;
         unpack_etc1s_header(enc_blocks[bi], r5, g5, b5, inten);
         const int yd = inten_delta((int)inten, (int)s);
         const cvec c = to_cvec<PERCEPTUAL>(clamp255(scale5((int)r5) + yd), clamp255(scale5((int)g5) + yd), clamp255(scale5((int)b5) + yd));
         tot += cdist<PERCEPTUAL>(c, pixel_cvec<PERCEPTUAL>(pixel_words[(size_t)bi * 16 + p]));
     }
+    if (tot) atomicAdd(&acc[(size_t)ci * 64 + lane], tot);
+}
+
+__global__ __launch_bounds__(256) void k_cosc_select(uint32_t n_clusters, const uint32_t* __restrict__ offsets, const unsigned long long* __restrict__ acc,
+                                                     uint64_t* __restrict__ selector_blocks) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t ci = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (ci >= n_clusters) return;
+    if (offsets[ci + 1] == offsets[ci]) return; // empty clusters keep their previous selectors (frontend.cpp:2282-2283)
+    const uint32_t p = lane >> 2, s = lane & 3u;
     // first-min over the 4 selectors of this pixel: compare (tot, s) lexicographically
-    uint64_t bt = tot; uint32_t bs = s;
+    uint64_t bt = acc[(size_t)ci * 64 + lane]; uint32_t bs = s;
 #pragma unroll
     for (int o = 1; o <= 2; o <<= 1) {
         const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)bt, o, 64);
@@ -962,13 +988,24 @@ hipError_t launch_determine_selectors(hipStream_t st, const void* d_pixel_blocks
     return hipSuccess;
 }
 
+size_t create_optimized_selector_codebook_workspace_bytes(uint32_t n_clusters) { return (size_t)n_clusters * 64 * 8; }
+
 hipError_t launch_create_optimized_selector_codebook(hipStream_t st, const void* d_pixel_blocks, const void* d_enc_blocks, uint32_t n_clusters,
-                                                     const uint32_t* d_offsets, const uint32_t* d_block_indices, bool perceptual, void* d_selector_blocks) {
+                                                     const uint32_t* d_offsets, const uint32_t* d_block_indices, uint32_t total_members, bool perceptual,
+                                                     void* d_workspace, void* d_selector_blocks) {
     if (!n_clusters) return hipSuccess;
-    const dim3 grid((n_clusters + 3) / 4), blk(256);
+    unsigned long long* acc = static_cast<unsigned long long*>(d_workspace);
+    hipError_t e = hipMemsetAsync(acc, 0, create_optimized_selector_codebook_workspace_bytes(n_clusters), st);
+    if (e != hipSuccess) return e;
     const uint32_t* pw = static_cast<const uint32_t*>(d_pixel_blocks);
-    if (perceptual) hipLaunchKernelGGL(k_create_optimized_selector_codebook<true>, grid, blk, 0, st, pw, static_cast<const uint64_t*>(d_enc_blocks), n_clusters, d_offsets, d_block_indices, static_cast<uint64_t*>(d_selector_blocks));
-    else hipLaunchKernelGGL(k_create_optimized_selector_codebook<false>, grid, blk, 0, st, pw, static_cast<const uint64_t*>(d_enc_blocks), n_clusters, d_offsets, d_block_indices, static_cast<uint64_t*>(d_selector_blocks));
+    if (total_members) {
+        const uint32_t waves = (total_members + COSC_CHUNK - 1) / COSC_CHUNK;
+        const dim3 grid((waves + 3) / 4), blk(256);
+        if (perceptual) hipLaunchKernelGGL(k_cosc_accumulate<true>, grid, blk, 0, st, pw, static_cast<const uint64_t*>(d_enc_blocks), n_clusters, d_offsets, d_block_indices, acc);
+        else hipLaunchKernelGGL(k_cosc_accumulate<false>, grid, blk, 0, st, pw, static_cast<const uint64_t*>(d_enc_blocks), n_clusters, d_offsets, d_block_indices, acc);
+        BU_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(k_cosc_select, dim3((n_clusters + 3) / 4), dim3(256), 0, st, n_clusters, d_offsets, acc, static_cast<uint64_t*>(d_selector_blocks));
     BU_LAUNCH_CHECK();
     return hipSuccess;
 }
