@@ -108,27 +108,6 @@ template <class F> void parallel_for_chunks(unsigned T, F fn) {
     for (auto& x : th) x.join();
 }
 
-// lists[c] = the items b in [0, n) with cluster_of(b) == c, ascending; every item contributes `emit(b, dst)` -> number of words
-// written (1 = block index, 2 = both training vectors of the block). Counting sort into one flat array, carved in parallel.
-template <int WORDS, class KeyFn>
-void lists_by_cluster(uint32_t n, uint32_t k, KeyFn cluster_of, std::vector<std::vector<uint32_t>>& lists) {
-    std::vector<uint32_t> start(k + 1, 0), flat((size_t)n * WORDS);
-    for (uint32_t b = 0; b < n; b++) start[cluster_of(b) + 1] += WORDS;
-    for (uint32_t c = 0; c < k; c++) start[c + 1] += start[c];
-    std::vector<uint32_t> cur(start.begin(), start.end() - 1);
-    for (uint32_t b = 0; b < n; b++) {
-        uint32_t& c = cur[cluster_of(b)];
-        if (WORDS == 1) flat[c] = b;
-        else { flat[c] = b * 2; flat[c + 1] = b * 2 + 1; }
-        c += WORDS;
-    }
-    lists.clear(); lists.resize(k);
-    std::atomic<uint32_t> next{0};
-    parallel_for_chunks(n > 65536 ? host_threads() : 1, [&](unsigned) {
-        for (uint32_t c; (c = next.fetch_add(1)) < k;) lists[c].assign(flat.begin() + start[c], flat.begin() + start[c + 1]);
-    });
-}
-
 class timer {
 public:
     timer() : t0_(std::chrono::steady_clock::now()) {}
