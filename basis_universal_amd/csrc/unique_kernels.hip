@@ -35,16 +35,14 @@ __global__ void __launch_bounds__(256) k_selector_keys(const uint64_t* __restric
     idx[b] = b;
 }
 
-__global__ void __launch_bounds__(256) k_run_weights(const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ n_runs, const uint32_t* __restrict__ idx,
-                                                     const uint64_t* __restrict__ weights, uint32_t n, uint32_t* __restrict__ offsets_end, uint64_t* __restrict__ out) {
-    const uint32_t u = blockIdx.x * 256 + threadIdx.x;
-    const uint32_t runs = *n_runs;
-    if (u == 0) offsets_end[runs] = n;  // offsets[] comes from an exclusive scan: close it
-    if (u >= runs) return;
-    const uint32_t a = offsets[u], e = u + 1 < runs ? offsets[u + 1] : n;
-    uint64_t w = 0;
-    for (uint32_t j = a; j < e; j++) w += weights[idx[j]];
-    out[u] = w;
+__global__ void __launch_bounds__(256) k_close_offsets(const uint32_t* __restrict__ n_runs, uint32_t n, uint32_t* __restrict__ offsets) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) offsets[*n_runs] = n;
+}
+
+// weight of block idx[j] at sorted position j: the input of the per-run sum
+__global__ void __launch_bounds__(256) k_gather_weights(const uint32_t* __restrict__ idx, const uint64_t* __restrict__ weights, uint32_t n, uint64_t* __restrict__ out) {
+    const uint32_t j = blockIdx.x * 256 + threadIdx.x;
+    if (j < n) out[j] = weights[idx[j]];
 }
 
 // key of an ETC1S block for the endpoint training vectors (frontend.cpp:825-866): its low and high block colours (selector 0 and selector 3:
@@ -63,20 +61,18 @@ __global__ void __launch_bounds__(256) k_endpoint_keys(const uint64_t* __restric
     idx[b] = b;
 }
 
-__global__ void __launch_bounds__(256) k_close_offsets(const uint32_t* __restrict__ n_runs, uint32_t n, uint32_t* __restrict__ offsets) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) offsets[*n_runs] = n;
-}
-
-struct unique_temp { uint32_t *keys_in, *idx_in, *keys_sorted, *counts, *n_runs; void* cub; size_t cub_bytes; };
+struct unique_temp { uint32_t *keys_in, *idx_in, *keys_sorted, *counts, *n_runs, *keys_again; uint64_t* w_sorted; void* cub; size_t cub_bytes; };
 size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
 
 size_t cub_bytes_for(uint32_t n) {
-    size_t a = 0, b = 0, c = 0;
+    size_t a = 0, b = 0, c = 0, d = 0;
     uint32_t* p = nullptr;
+    uint64_t* w = nullptr;
     (void)hipcub::DeviceRadixSort::SortPairs(nullptr, a, p, p, p, p, (int)n);
     (void)hipcub::DeviceRunLengthEncode::Encode(nullptr, b, p, p, p, p, (int)n);
     (void)hipcub::DeviceScan::ExclusiveSum(nullptr, c, p, p, (int)n);
-    return std::max(a, std::max(b, c));
+    (void)hipcub::DeviceReduce::ReduceByKey(nullptr, d, p, p, w, w, p, hipcub::Sum(), (int)n);
+    return std::max(std::max(a, b), std::max(c, d));
 }
 
 unique_temp carve(void* base, uint32_t n, size_t* total) {
@@ -88,6 +84,8 @@ unique_temp carve(void* base, uint32_t n, size_t* total) {
     t.keys_sorted = reinterpret_cast<uint32_t*>(p + o); o += align_up((size_t)n * 4);
     t.counts = reinterpret_cast<uint32_t*>(p + o); o += align_up((size_t)n * 4);
     t.n_runs = reinterpret_cast<uint32_t*>(p + o); o += 256;
+    t.keys_again = reinterpret_cast<uint32_t*>(p + o); o += align_up((size_t)n * 4);
+    t.w_sorted = reinterpret_cast<uint64_t*>(p + o); o += align_up((size_t)n * 8);
     t.cub_bytes = cub_bytes_for(n);
     t.cub = p + o; o += align_up(t.cub_bytes);
     if (total) *total = o;
@@ -168,7 +166,13 @@ hipError_t launch_unique_selector_vectors(hipStream_t st, const void* d_enc_bloc
     // scanning all n counts keeps the launch independent of the (device-side) run count; entries past the runs are never read
     e = hipcub::DeviceScan::ExclusiveSum(t.cub, bytes, t.counts, d_group_offsets, (int)n, st);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_run_weights, dim3((n + 255) / 256), dim3(256), 0, st, d_group_offsets, t.n_runs, d_sorted_block_idx, d_weights, n, d_group_offsets, d_unique_weights);
+    hipLaunchKernelGGL(k_close_offsets, dim3(1), dim3(64), 0, st, t.n_runs, n, d_group_offsets);
+    // weight of a distinct vector = sum over its run: a keyed reduction of the gathered weights (runs range from one block to a large part
+    // of the image, so one thread per run would leave a few threads with all the work)
+    hipLaunchKernelGGL(k_gather_weights, dim3((n + 255) / 256), dim3(256), 0, st, d_sorted_block_idx, d_weights, n, t.w_sorted);
+    bytes = t.cub_bytes;
+    e = hipcub::DeviceReduce::ReduceByKey(t.cub, bytes, t.keys_sorted, t.keys_again, t.w_sorted, d_unique_weights, t.n_runs + 1, hipcub::Sum(), (int)n, st);
+    if (e != hipSuccess) return e;
     return hipGetLastError();
 }
 
