@@ -233,9 +233,9 @@ def main():
         }
         if roofline:
             roofline["traffic"] = pmc_traffic(roofline["kernel"])
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # the CPU baseline and the secondary workloads are N=1 measurements
             out["cpu_baseline"] = cpu_baseline(helpers, args)
-        if not args.no_uastc:
+        if not args.no_uastc and world == 1:
             out["uastc"] = uastc_bench(ctx, d_blocks, n_blocks, w, h, helpers, args)
             out["uastc_rdo"] = uastc_rdo_bench(ctx, helpers, args)
         print(json.dumps(out))
