@@ -4,6 +4,7 @@ The binding mirrors the C ABI one-to-one; nothing here computes anything. `HipLi
 (so that CPU-only CI can check that the library loads and exports every declared symbol); creating a context without a GPU
 raises HipError.
 """
+import weakref
 import ctypes as C
 import os
 import pathlib
@@ -129,6 +130,12 @@ class Context:
         self.h = self.lib.create_context() if device is None else self.lib.create_context_on(int(device))
         if not self.h:
             raise HipError("bu_hip_create_context failed: " + self.lib.last_error(None))
+        self._dependants = weakref.WeakSet()
+
+    def adopt(self, obj):
+        """Registers an object that owns device memory of this context (it must have close()): closing the context closes it first,
+        so that a dependant collected later never frees through a dead context."""
+        self._dependants.add(obj)
 
     def check(self, ok, what=""):
         if not ok:
@@ -136,6 +143,8 @@ class Context:
 
     def close(self):
         if getattr(self, "h", None):
+            for d in list(getattr(self, "_dependants", ())):
+                d.close()
             self.lib.destroy_context(self.h)
             self.h = None
 

@@ -72,6 +72,7 @@ int bu_frontend_call(bu_frontend* f, const char* stage, uint32_t arg) {
     if (n == "init_etc1_images") return fe.init_etc1_images();
     if (n == "init_endpoint_training_vectors") return fe.init_endpoint_training_vectors();
     if (n == "generate_endpoint_clusters") return fe.generate_endpoint_clusters();
+    if (n == "introduce_new_endpoint_clusters") return fe.introduce_new_endpoint_clusters();
     if (n == "generate_endpoint_codebook") return fe.generate_endpoint_codebook(arg);
     if (n == "refine_endpoint_clusterization") { uint32_t moved = 0; return fe.refine_endpoint_clusterization(&moved); }
     if (n == "eliminate_redundant_or_empty_endpoint_clusters") { fe.eliminate_redundant_or_empty_endpoint_clusters(); return 1; }
@@ -82,6 +83,7 @@ int bu_frontend_call(bu_frontend* f, const char* stage, uint32_t arg) {
     if (n == "create_optimized_selector_codebook") return fe.create_optimized_selector_codebook(arg);
     if (n == "find_optimal_selector_clusters_for_each_block") return fe.find_optimal_selector_clusters_for_each_block();
     if (n == "introduce_special_selector_clusters") return fe.introduce_special_selector_clusters();
+    if (n == "refine_block_endpoints_given_selectors") { uint32_t refined = 0; return fe.refine_block_endpoints_given_selectors(&refined); }
     if (n == "optimize_selector_codebook") { fe.optimize_selector_codebook(); return 1; }
     if (n == "finalize") { fe.finalize(); return 1; }
     return 0;

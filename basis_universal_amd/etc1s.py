@@ -126,6 +126,7 @@ class Etc1sFrontend:
         self.ctx = ctx
         self.L = load_frontend_library()
         self.h = self.L.bu_frontend_create()
+        ctx.adopt(self)  # the frontend's device buffers belong to ctx: it must go first
         self._keep = None
         self.comm = comm
         if comm is not None:

@@ -14,7 +14,7 @@ extern "C" {
 typedef struct bu_frontend bu_frontend;
 
 BU_HIP_API bu_frontend* bu_frontend_create(void);
-BU_HIP_API void bu_frontend_destroy(bu_frontend*);
+BU_HIP_API void bu_frontend_destroy(bu_frontend*);  /* must precede bu_hip_destroy_context of the context it was initialised on (its device buffers are freed through it), like the reference frontend and its opencl context */
 /* basisu_frontend::init (frontend.cpp:51). Exactly one of h_blocks (host tiles, uploaded once) / d_blocks (tiles already in HBM). */
 BU_HIP_API int bu_frontend_init(bu_frontend*, bu_hip_context* ctx, const bu_pixel_block* h_blocks, const void* d_blocks, uint32_t n_blocks,
                                 uint32_t max_endpoint_clusters, uint32_t max_selector_clusters, uint32_t compression_level, int perceptual);

@@ -36,6 +36,16 @@ STATE = ["etc1_blocks", "endpoint_cluster_etc_params", "block_endpoint_clusters_
          "optimized_cluster_selectors", "block_selector_cluster_index", "endpoint_clusters", "selector_cluster_block_indices"]
 
 
+def _sorted_lists(blob):
+    """A CSR blob (count, offsets, indices) with every list sorted: the membership of the clusters without the order inside them."""
+    u = np.ascontiguousarray(blob).view(np.uint32).copy()
+    n = int(u[0])
+    offs, idx = u[1:n + 2], u[n + 2:]
+    for i in range(n):
+        idx[offs[i]:offs[i + 1]].sort()
+    return u
+
+
 def _canon(name, arr):
     a = np.asarray(arr)
     if name == "optimized_cluster_selectors":
@@ -102,3 +112,95 @@ def test_kodim03_q128_matches_live_reference(hip_ctx):
     fe.call("compress")
     for k in STATE:
         assert (_canon(k, got[k]) == _canon(k, fe.get(k))).all(), k
+
+
+# what each stage is expected to leave behind, in terms of the state both sides can serialise
+_STAGE_STATE = {
+    "init_etc1_images": ["etc1_blocks"],
+    "generate_endpoint_clusters": ["endpoint_clusters", "endpoint_parent_clusters"],
+    "introduce_new_endpoint_clusters": ["endpoint_clusters"],
+    "generate_endpoint_codebook": ["endpoint_cluster_etc_params"],
+    "refine_endpoint_clusterization": ["endpoint_clusters"],
+    "eliminate_redundant_or_empty_endpoint_clusters": ["endpoint_clusters", "endpoint_cluster_etc_params"],
+    "generate_block_endpoint_clusters": ["block_endpoint_clusters_indices"],
+    "create_initial_packed_texture": ["encoded_blocks", "orig_encoded_blocks"],
+    "generate_selector_clusters": ["selector_cluster_block_indices"],
+    "create_optimized_selector_codebook": ["optimized_cluster_selectors"],
+    "find_optimal_selector_clusters_for_each_block": ["block_selector_cluster_index", "encoded_blocks", "selector_cluster_block_indices"],
+    "introduce_special_selector_clusters": ["optimized_cluster_selectors", "block_selector_cluster_index", "encoded_blocks"],
+    "refine_block_endpoints_given_selectors": ["endpoint_cluster_etc_params", "encoded_blocks", "block_endpoint_clusters_indices", "endpoint_clusters"],
+    "optimize_selector_codebook": ["optimized_cluster_selectors", "block_selector_cluster_index"],
+    "finalize": STATE + ["endpoint_parent_clusters"],
+}
+
+
+@pytest.mark.skipif(not have_ref(), reason="oracle/_ref not present")
+@pytest.mark.parametrize("case", ["synth256_l1", "synth256_l4", "synth128_l6", "noise_l4"])
+def test_frontend_single_stepped_against_live_reference(hip_ctx, case):
+    """Both frontends driven one private stage at a time in the order of basisu_frontend::compress() (frontend.cpp:159-316), the state
+    compared after EVERY stage: a difference is pinned to the stage that introduced it, and the lazily materialised forms of our
+    clusterings (lists from the per-block maps, parents from the parent-of-vector map) are read in every intermediate state."""
+    from basis_universal_amd.etc1s import Etc1sFrontend
+    blocks, max_ep, max_sel, level, perceptual = _params(case)
+    ref = RefFrontend(blocks, max_ep, max_sel, level, perceptual)
+    fe = Etc1sFrontend(hip_ctx)
+    fe.init(blocks, max_ep, max_sel, level, perceptual)
+    trace = []
+
+    def step(stage, arg=0):
+        r = ref.call(stage, arg)
+        fe.call(stage, arg)
+        trace.append(stage)
+        for k in _STAGE_STATE.get(stage, []):
+            a, b = _canon(k, fe.get(k)), _canon(k, ref.get(k))
+            if stage == "generate_selector_clusters":
+                # the reference's lists are in TSVQ leaf order here and its next stages only sum over them (frontend.cpp:2267-2330)
+                # before find_optimal_selector_clusters_for_each_block rebuilds them ascending; ours are ascending throughout
+                a, b = _sorted_lists(a), _sorted_lists(b)
+            assert a.shape == b.shape and (a == b).all(), (stage, len(trace), k, a.shape, b.shape)
+        return r
+
+    step("init_etc1_images")
+    step("init_endpoint_training_vectors")
+    step("generate_endpoint_clusters")
+    for it in range(ref.call("num_endpoint_codebook_iterations")):
+        if it:
+            step("introduce_new_endpoint_clusters")
+        step("generate_endpoint_codebook", it)
+        early_out = False
+        if ref.call("endpoint_refinement"):
+            early_out = step("refine_endpoint_clusterization") == 0
+        step("eliminate_redundant_or_empty_endpoint_clusters")
+        if early_out:
+            break
+    step("generate_block_endpoint_clusters")
+    step("create_initial_packed_texture")
+    step("generate_selector_clusters")
+    if ref.call("use_hierarchical_selector_codebooks"):
+        step("compute_selector_clusters_within_each_parent_cluster")
+    for it in range(1 if level == 0 else ref.call("num_selector_codebook_iterations")):
+        step("create_optimized_selector_codebook", it)
+        step("find_optimal_selector_clusters_for_each_block")
+        step("introduce_special_selector_clusters")
+        if level >= 4 and not step("refine_block_endpoints_given_selectors"):
+            break
+    step("optimize_selector_codebook")
+    step("finalize")
+    assert "endpoint_parent_clusters" in _STAGE_STATE["finalize"] and len(trace) >= 12
+    fe.close()
+    ref.close()
+
+
+def test_context_close_takes_its_frontends_along():
+    """A frontend frees its device buffers through its context; closing the context first (a session fixture torn down before a
+    late garbage collection, say) must close the frontend rather than leave it to free through a dead context."""
+    from basis_universal_amd import capi
+    from basis_universal_amd.etc1s import Etc1sFrontend
+    ctx = capi.Context()
+    fe = Etc1sFrontend(ctx)
+    fe.init(to_pixel_blocks(synth(64, 64, 1)), 32, 32, 1, True)
+    fe.compress()
+    ctx.close()
+    assert fe.h is None and ctx.h is None
+    fe.close()
+    del fe
