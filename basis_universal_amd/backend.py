@@ -1,0 +1,128 @@
+"""ETC1S backend: Python view of bu::etc1s_backend through the C ABI of include/basisu_hip_backend.h.
+
+Mirrors basisu_backend (encoder/basisu_backend.h:278-408): a finished frontend in, the compressed payloads of a .basis / KTX2 file
+out. Host code in libbasisu_frontend.so; no GPU is needed when it is driven from plain arrays (`Etc1sBackend.from_arrays`), the
+frontend-driven form (`Etc1sBackend.from_frontend`) needs the frontend's device for compression levels above 1.
+"""
+import ctypes as C
+
+import numpy as np
+
+from .etc1s import load_frontend_library
+
+_vp = C.c_void_p
+
+
+class BackendParams(C.Structure):
+    _fields_ = [("endpoint_rdo_quality_thresh", C.c_float), ("selector_rdo_quality_thresh", C.c_float), ("compression_level", C.c_uint32)]
+
+
+class SliceDesc(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ("first_block_index", "orig_width", "orig_height", "width", "height", "num_blocks_x", "num_blocks_y")]
+
+
+class BackendArrays(C.Structure):
+    _fields_ = [("total_blocks", C.c_uint32), ("perceptual", C.c_int), ("source_blocks", _vp), ("output_blocks", _vp), ("block_endpoint_index", _vp),
+                ("block_selector_index", _vp), ("total_endpoints", C.c_uint32), ("endpoint_color5_inten", _vp), ("total_selectors", C.c_uint32),
+                ("selector_blocks", _vp)]
+
+
+class BackendError(RuntimeError):
+    pass
+
+
+def _lib():
+    L = load_frontend_library()
+    if not getattr(L, "_backend_bound", False):
+        L.bu_backend_create.restype = _vp
+        L.bu_backend_destroy.argtypes = [_vp]
+        L.bu_backend_init.argtypes = [_vp, _vp, C.POINTER(BackendParams), C.POINTER(SliceDesc), C.c_uint32]
+        L.bu_backend_init_arrays.argtypes = [_vp, C.POINTER(BackendArrays), C.POINTER(BackendParams), C.POINTER(SliceDesc), C.c_uint32]
+        L.bu_backend_encode.restype = C.c_uint32
+        L.bu_backend_encode.argtypes = [_vp]
+        L.bu_backend_get.restype = C.c_uint64
+        L.bu_backend_get.argtypes = [_vp, C.c_char_p, C.c_uint32, _vp, C.c_uint64]
+        L.bu_backend_error.restype = C.c_char_p
+        L.bu_backend_error.argtypes = [_vp]
+        L.bu_backend_stage_times.restype = C.c_uint32
+        L.bu_backend_stage_times.argtypes = [_vp, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.c_uint32]
+        L._backend_bound = True
+    return L
+
+
+def slice_descs(slices):
+    """[(first_block, num_blocks_x, num_blocks_y) or (first, nbx, nby, orig_width, orig_height)] -> SliceDesc array."""
+    arr = (SliceDesc * len(slices))()
+    for i, s in enumerate(slices):
+        first, nbx, nby = s[:3]
+        ow, oh = (s[3], s[4]) if len(s) >= 5 else (nbx * 4, nby * 4)
+        arr[i] = SliceDesc(first, ow, oh, nbx * 4, nby * 4, nbx, nby)
+    return arr
+
+
+class Etc1sBackend:
+    def __init__(self):
+        self.L = _lib()
+        self.h = self.L.bu_backend_create()
+        self._keep = []
+
+    @classmethod
+    def from_frontend(cls, frontend, slices, endpoint_rdo_thresh=1.5, selector_rdo_thresh=1.25, compression_level=1):
+        """frontend: a compressed basis_universal_amd.etc1s.Etc1sFrontend (kept alive by this object)."""
+        b = cls()
+        prm = BackendParams(endpoint_rdo_thresh, selector_rdo_thresh, compression_level)
+        sl = slice_descs(slices)
+        b._keep = [frontend]
+        if not b.L.bu_backend_init(b.h, frontend.h, C.byref(prm), sl, len(slices)):
+            raise BackendError("bu_backend_init failed")
+        return b
+
+    @classmethod
+    def from_arrays(cls, source_blocks, output_blocks, block_endpoint_index, block_selector_index, endpoint_color5_inten, selector_blocks, slices,
+                    perceptual=True, endpoint_rdo_thresh=1.5, selector_rdo_thresh=1.25, compression_level=1):
+        b = cls()
+        src = np.ascontiguousarray(source_blocks, np.uint8)
+        out = np.ascontiguousarray(output_blocks, np.uint8)
+        ei = np.ascontiguousarray(block_endpoint_index, np.uint32)
+        si = np.ascontiguousarray(block_selector_index, np.uint32)
+        ep = np.ascontiguousarray(endpoint_color5_inten, np.uint8).reshape(-1, 4)
+        sb = np.ascontiguousarray(selector_blocks, np.uint8).reshape(-1, 8)
+        b._keep = [src, out, ei, si, ep, sb]
+        p = lambda a: a.ctypes.data_as(_vp)
+        arrays = BackendArrays(ei.size, int(perceptual), p(src), p(out), p(ei), p(si), ep.shape[0], p(ep), sb.shape[0], p(sb))
+        prm = BackendParams(endpoint_rdo_thresh, selector_rdo_thresh, compression_level)
+        sl = slice_descs(slices)
+        if not b.L.bu_backend_init_arrays(b.h, C.byref(arrays), C.byref(prm), sl, len(slices)):
+            raise BackendError("bu_backend_init_arrays failed")
+        return b
+
+    def encode(self):
+        n = self.L.bu_backend_encode(self.h)
+        if not n:
+            raise BackendError("bu_backend_encode failed: " + self.L.bu_backend_error(self.h).decode())
+        return n
+
+    def get(self, name, slice_index=0, dtype=np.uint8):
+        need = self.L.bu_backend_get(self.h, name.encode(), slice_index, None, 0)
+        if need == 2 ** 64 - 1:
+            raise KeyError(name)
+        buf = np.zeros(need, np.uint8)
+        self.L.bu_backend_get(self.h, name.encode(), slice_index, buf.ctypes.data_as(_vp), need)
+        return buf.view(dtype)
+
+    def stage_times(self):
+        names = (C.c_char_p * 16)()
+        secs = (C.c_double * 16)()
+        n = min(self.L.bu_backend_stage_times(self.h, names, secs, 16), 16)
+        return [(names[i].decode(), secs[i]) for i in range(n)]
+
+    def close(self):
+        if self.h:
+            self.L.bu_backend_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -402,8 +402,8 @@ int bu_hip_k_generate_endpoint_codebook(bu_hip_context* ctx, const void* d_px, u
     return bu_hip_k_generate_endpoint_codebook_part(ctx, d_px, n_clusters, h_offsets, d_offsets, d_indices, quality, perceptual, step, d_params, d_err, d_valid, 0, 1);
 }
 
-int bu_hip_k_refit_endpoints_given_selectors(bu_hip_context* ctx, const void* d_px, const void* d_enc, uint32_t n_clusters, const uint32_t* h_offsets,
-                                             const uint32_t* d_offsets, const uint32_t* d_indices, int perceptual, uint8_t* d_params, uint64_t* d_err,
+int bu_hip_k_refit_endpoints_given_selectors_q(bu_hip_context* ctx, const void* d_px, const void* d_enc, uint32_t n_clusters, const uint32_t* h_offsets,
+                                               const uint32_t* d_offsets, const uint32_t* d_indices, int quality, int perceptual, uint8_t* d_params, uint64_t* d_err,
                                              uint8_t* d_valid, uint64_t* d_cur_err) {
     if (!ctx) return 0;
     if (!n_clusters) return 1;
@@ -417,10 +417,16 @@ int bu_hip_k_refit_endpoints_given_selectors(bu_hip_context* ctx, const void* d_
     {
         prof_scope ps(ctx, "refit_endpoints_given_selectors");
         BU_TRY(ctx, bu::launch_refit_endpoints_given_selectors(ctx->stream, d_px, d_enc, n_clusters, static_cast<const uint32_t*>(ord.p), d_offsets, d_indices,
-                                                               perceptual != 0, d_params, d_err, d_valid, d_cur_err));
+                                                               quality == BU_ETC_QUALITY_SLOW ? BU_ETC_QUALITY_SLOW : BU_ETC_QUALITY_UBER, perceptual != 0, d_params, d_err, d_valid, d_cur_err));
     }
     BU_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return 1;
+}
+
+int bu_hip_k_refit_endpoints_given_selectors(bu_hip_context* ctx, const void* d_px, const void* d_enc, uint32_t n_clusters, const uint32_t* h_offsets,
+                                             const uint32_t* d_offsets, const uint32_t* d_indices, int perceptual, uint8_t* d_params, uint64_t* d_err,
+                                             uint8_t* d_valid, uint64_t* d_cur_err) {
+    return bu_hip_k_refit_endpoints_given_selectors_q(ctx, d_px, d_enc, n_clusters, h_offsets, d_offsets, d_indices, BU_ETC_QUALITY_UBER, perceptual, d_params, d_err, d_valid, d_cur_err);
 }
 
 int bu_hip_k_subblock_errors(bu_hip_context* ctx, const void* d_px, uint32_t n_blocks, const uint32_t* d_block_cluster, const uint8_t* d_cluster_params,

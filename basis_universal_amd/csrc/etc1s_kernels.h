@@ -16,7 +16,7 @@ hipError_t launch_generate_endpoint_codebook(hipStream_t st, const void* d_pixel
                                              const uint32_t* d_offsets, const uint32_t* d_indices, int quality, bool perceptual, uint32_t step,
                                              uint8_t* d_params, uint64_t* d_err, uint8_t* d_valid);
 hipError_t launch_refit_endpoints_given_selectors(hipStream_t st, const void* d_pixel_blocks, const void* d_enc_blocks, uint32_t n_clusters, const uint32_t* d_order,
-                                                  const uint32_t* d_offsets, const uint32_t* d_indices, bool perceptual, uint8_t* d_params, uint64_t* d_err,
+                                                  const uint32_t* d_offsets, const uint32_t* d_indices, int quality, bool perceptual, uint8_t* d_params, uint64_t* d_err,
                                                   uint8_t* d_valid, uint64_t* d_cur_err);
 hipError_t launch_subblock_errors(hipStream_t st, const void* d_pixel_blocks, uint32_t n_blocks, const uint32_t* d_block_cluster, const uint8_t* d_cluster_params,
                                   bool perceptual, uint64_t* d_out);

@@ -920,16 +920,19 @@ hipError_t launch_generate_endpoint_codebook(hipStream_t st, const void* d_pixel
     return hipSuccess;
 }
 
-// refine_block_endpoints_given_selectors (frontend.cpp:2718-2976): uber-quality cluster fit with the selectors held fixed
+// refine_block_endpoints_given_selectors (frontend.cpp:2718-2976) / reoptimize_remapped_endpoints (:2996-3104): cluster fit with the selectors held fixed
 hipError_t launch_refit_endpoints_given_selectors(hipStream_t st, const void* d_pixel_blocks, const void* d_enc_blocks, uint32_t n_clusters, const uint32_t* d_order,
-                                                  const uint32_t* d_offsets, const uint32_t* d_indices, bool perceptual, uint8_t* d_params, uint64_t* d_err,
+                                                  const uint32_t* d_offsets, const uint32_t* d_indices, int quality, bool perceptual, uint8_t* d_params, uint64_t* d_err,
                                                   uint8_t* d_valid, uint64_t* d_cur_err) {
     if (!n_clusters) return hipSuccess;
     const dim3 grid(n_clusters), blk(CB_THREADS);
     const uint32_t* pw = static_cast<const uint32_t*>(d_pixel_blocks);
     const uint64_t* enc = static_cast<const uint64_t*>(d_enc_blocks);
-    if (perceptual) hipLaunchKernelGGL((k_generate_endpoint_codebook<true, BU_Q_UBER, true>), grid, blk, 0, st, pw, d_order, d_offsets, d_indices, 0u, d_params, d_err, d_valid, enc, d_cur_err);
-    else hipLaunchKernelGGL((k_generate_endpoint_codebook<false, BU_Q_UBER, true>), grid, blk, 0, st, pw, d_order, d_offsets, d_indices, 0u, d_params, d_err, d_valid, enc, d_cur_err);
+#define BU_RF(P, Q) hipLaunchKernelGGL((k_generate_endpoint_codebook<P, Q, true>), grid, blk, 0, st, pw, d_order, d_offsets, d_indices, 0u, d_params, d_err, d_valid, enc, d_cur_err)
+    // uber for refine_block_endpoints_given_selectors and level 6; slow for reoptimize_remapped_endpoints below level 6 (frontend.cpp:3073-3076)
+    if (perceptual) { if (quality == BU_Q_SLOW) BU_RF(true, BU_Q_SLOW); else BU_RF(true, BU_Q_UBER); }
+    else { if (quality == BU_Q_SLOW) BU_RF(false, BU_Q_SLOW); else BU_RF(false, BU_Q_UBER); }
+#undef BU_RF
     BU_LAUNCH_CHECK();
     return hipSuccess;
 }

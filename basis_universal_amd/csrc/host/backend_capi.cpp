@@ -1,0 +1,111 @@
+// backend_capi.cpp -- extern "C" wrapper of bu::etc1s_backend (include/basisu_hip_backend.h).
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../../include/basisu_hip_backend.h"
+#include "etc1s_backend.h"
+#include "etc1s_frontend.h"
+
+struct bu_frontend;
+bu::etc1s_frontend* bu_frontend_object(bu_frontend*);  // frontend_capi.cpp
+
+struct bu_backend {
+    bu::etc1s_backend be;
+};
+
+namespace {
+
+template <typename T> uint64_t emit(const std::vector<T>& v, void* buf, uint64_t cap) {
+    const uint64_t need = (uint64_t)v.size() * sizeof(T);
+    if (buf && cap >= need && need) std::memcpy(buf, v.data(), need);
+    return need;
+}
+
+void convert(const bu_backend_params* p, const bu_backend_slice_desc* s, uint32_t n, bu::backend_params& bp, std::vector<bu::backend_slice_desc>& slices) {
+    bp.m_etc1s = true;
+    bp.m_endpoint_rdo_quality_thresh = p->endpoint_rdo_quality_thresh;
+    bp.m_selector_rdo_quality_thresh = p->selector_rdo_quality_thresh;
+    bp.m_compression_level = p->compression_level;
+    slices.resize(n);
+    for (uint32_t i = 0; i < n; i++) {
+        bu::backend_slice_desc& d = slices[i];
+        d.m_first_block_index = s[i].first_block_index;
+        d.m_orig_width = s[i].orig_width; d.m_orig_height = s[i].orig_height;
+        d.m_width = s[i].width; d.m_height = s[i].height;
+        d.m_num_blocks_x = s[i].num_blocks_x; d.m_num_blocks_y = s[i].num_blocks_y;
+        d.m_num_macroblocks_x = (d.m_num_blocks_x + 1) / 2; d.m_num_macroblocks_y = (d.m_num_blocks_y + 1) / 2;
+        d.m_iframe = true;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+bu_backend* bu_backend_create(void) { return new (std::nothrow) bu_backend(); }
+void bu_backend_destroy(bu_backend* b) { delete b; }
+const char* bu_backend_error(const bu_backend* b) { return b ? b->be.error().c_str() : "null backend"; }
+
+int bu_backend_init(bu_backend* b, bu_frontend* frontend, const bu_backend_params* p, const bu_backend_slice_desc* s, uint32_t n) {
+    if (!b || !frontend || !p || (!s && n)) return 0;
+    bu::backend_params bp;
+    std::vector<bu::backend_slice_desc> slices;
+    convert(p, s, n, bp, slices);
+    b->be.init(bu_frontend_object(frontend), bp, slices);
+    return 1;
+}
+
+int bu_backend_init_arrays(bu_backend* b, const bu_backend_arrays* a, const bu_backend_params* p, const bu_backend_slice_desc* s, uint32_t n) {
+    if (!b || !a || !p || (!s && n)) return 0;
+    bu::backend_params bp;
+    std::vector<bu::backend_slice_desc> slices;
+    convert(p, s, n, bp, slices);
+    bu::backend_source src;
+    src.total_blocks = a->total_blocks;
+    src.perceptual = a->perceptual != 0;
+    src.source_blocks = a->source_blocks;
+    src.output_blocks = a->output_blocks;
+    src.block_endpoint_index = a->block_endpoint_index;
+    src.block_selector_index = a->block_selector_index;
+    src.total_endpoints = a->total_endpoints;
+    src.endpoint_color5_inten = a->endpoint_color5_inten;
+    src.total_selectors = a->total_selectors;
+    src.selector_blocks = a->selector_blocks;
+    b->be.init(src, bp, slices);
+    return 1;
+}
+
+uint32_t bu_backend_encode(bu_backend* b) { return b ? b->be.encode() : 0; }
+
+uint64_t bu_backend_get(bu_backend* b, const char* name, uint32_t slice, void* buf, uint64_t cap) {
+    if (!b) return ~0ull;
+    const std::string n(name);
+    const bu::backend_output& o = b->be.get_output();
+    if (n == "endpoint_palette") return emit(o.m_endpoint_palette, buf, cap);
+    if (n == "selector_palette") return emit(o.m_selector_palette, buf, cap);
+    if (n == "slice_image_tables") return emit(o.m_slice_image_tables, buf, cap);
+    if (n == "slice_image_data") return slice < o.m_slice_image_data.size() ? emit(o.m_slice_image_data[slice], buf, cap) : ~0ull;
+    if (n == "slice_image_crcs") return emit(o.m_slice_image_crcs, buf, cap);
+    if (n == "num_endpoints") return emit(std::vector<uint32_t>{o.m_num_endpoints}, buf, cap);
+    if (n == "num_selectors") return emit(std::vector<uint32_t>{o.m_num_selectors}, buf, cap);
+    if (n == "encoder_blocks") {
+        const auto& B = b->be.encoder_blocks();
+        std::vector<uint32_t> v(B.size() * 4);
+        for (size_t i = 0; i < B.size(); i++) { v[i * 4] = B[i].endpoint_index; v[i * 4 + 1] = B[i].endpoint_predictor; v[i * 4 + 2] = B[i].selector_index; v[i * 4 + 3] = (uint32_t)(B[i].selector_history_index + 1); }
+        return emit(v, buf, cap);
+    }
+    if (n == "endpoint_remap_old_to_new") return emit(b->be.endpoint_remap_old_to_new(), buf, cap);
+    if (n == "selector_remap_new_to_old") return emit(b->be.selector_remap_new_to_old(), buf, cap);
+    return ~0ull;
+}
+
+uint32_t bu_backend_stage_times(const bu_backend* b, const char** names, double* seconds, uint32_t cap) {
+    if (!b) return 0;
+    const auto& t = b->be.stage_times();
+    for (uint32_t i = 0; i < t.size() && i < cap; i++) { names[i] = t[i].name; seconds[i] = t[i].seconds; }
+    return (uint32_t)t.size();
+}
+
+}  // extern "C"

@@ -1,0 +1,748 @@
+// etc1s_backend.cpp -- see etc1s_backend.h. Reference: encoder/basisu_backend.cpp (cited per function).
+//
+// How the walk differs from the reference's while producing the same bytes:
+//  * one flat block array and one token stream per slice, written in bit-stream order (run tokens are placeholders patched when the
+//    run ends) instead of symbol vectors that a second walk over the blocks re-synchronises with;
+//  * the selector-history search looks a candidate's error up in a 16x4 table of the block's pixel-to-colour distances (64 distance
+//    evaluations per block instead of up to 16 per candidate and 64 candidates), and pre-filters candidates on packed selectors;
+//  * the palette reordering keeps the symbol adjacency counts as sparse lists instead of a dense num_syms^2 matrix (1 GB at 16128).
+#include "etc1s_backend.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <deque>
+
+#include "entropy.h"
+#include "etc1s_frontend.h"
+
+namespace bu {
+namespace {
+
+enum : uint32_t {  // transcoder/basisu_transcoder_internal.h:256-267
+    kEndpointPredSymbols = 4 * 4 * 4 * 4 + 1, kEndpointPredRepeatLast = kEndpointPredSymbols - 1, kEndpointPredMinRepeat = 3, kEndpointPredCountVlcBits = 4,
+    kNumEndpointPreds = 3, kNoEndpointPred = 3,
+    kSelectorHistorySize = 64, kSelectorRleThresh = 3, kSelectorRleCountBits = 6, kSelectorRleCountTotal = 1u << kSelectorRleCountBits
+};
+const int kColorDeltaThresh = 8, kSelDiffThreshold = 11;  // backend.cpp:719-720
+const int kPredDx[3] = {-1, 0, -1}, kPredDy[3] = {0, -1, -1};  // g_endpoint_preds, backend.cpp:120-128
+
+const int kInten[8][4] = {{-8, -2, 2, 8}, {-17, -5, 5, 17}, {-29, -9, 9, 29}, {-42, -13, 13, 42},
+                          {-60, -18, 18, 60}, {-80, -24, 24, 80}, {-106, -33, 33, 106}, {-183, -47, 47, 183}};  // g_etc1_inten_tables, etc.cpp:304-308
+
+inline int clamp255(int v) { return v < 0 ? 0 : (v > 255 ? 255 : v); }
+inline uint64_t load_be64(const bu_etc_block& b) { uint64_t v; std::memcpy(&v, b.m_bytes, 8); return __builtin_bswap64(v); }
+
+struct timer {
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    double seconds() const { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
+};
+
+// 16 selectors of an etc_block, pixel p = y*4+x in bits 2p (etc.h:232-236 for the bit positions, backend.cpp:104-117 for the order)
+inline uint32_t packed_selectors(const bu_etc_block& blk) {
+    static const uint8_t to_sel[4] = {2, 3, 1, 0};
+    const uint32_t lo32 = (uint32_t)load_be64(blk);
+    uint32_t out = 0;
+    for (uint32_t y = 0; y < 4; y++)
+        for (uint32_t x = 0; x < 4; x++) {
+            const uint32_t bit = x * 4 + y;
+            const uint32_t raw = ((lo32 >> bit) & 1u) | (((lo32 >> (16 + bit)) & 1u) << 1);
+            out |= (uint32_t)to_sel[raw] << (2 * (y * 4 + x));
+        }
+    return out;
+}
+
+struct color5 { uint8_t r, g, b, inten; };
+inline color5 header_of(const bu_etc_block& blk) {
+    const uint64_t v = load_be64(blk);
+    return color5{(uint8_t)((v >> 59) & 31), (uint8_t)((v >> 51) & 31), (uint8_t)((v >> 43) & 31), (uint8_t)((v >> 37) & 7)};
+}
+
+// The colour metric (enc.h:1141-1195) in the basis it is separable in: a colour becomes (l, cr, cb) once, a distance is three squares.
+struct cvec { int x, y, z; };
+template <bool P> inline cvec to_cvec(int r, int g, int b) {
+    if (P) { const int l = r * 14 + g * 45 + b * 5; return cvec{l, r * 64 - l, b * 64 - l}; }
+    return cvec{r, g, b};
+}
+template <bool P> inline uint32_t cdist(const cvec& a, const cvec& b) {
+    const int dx = a.x - b.x, dy = a.y - b.y, dz = a.z - b.z;
+    if (P) return ((uint32_t)(dx * dx) >> 5) + ((((uint32_t)(dy * dy) >> 5) * 26u) >> 7) + ((((uint32_t)(dz * dz) >> 5) * 3u) >> 7);
+    return (uint32_t)(dx * dx + dy * dy + dz * dz);
+}
+template <bool P> inline void block_colors(cvec out[4], color5 c) {  // etc.h:584-602
+    const int r = (c.r << 3) | (c.r >> 2), g = (c.g << 3) | (c.g >> 2), b = (c.b << 3) | (c.b >> 2);
+    for (int s = 0; s < 4; s++) { const int d = kInten[c.inten][s]; out[s] = to_cvec<P>(clamp255(r + d), clamp255(g + d), clamp255(b + d)); }
+}
+template <bool P> inline void pixel_cvecs(cvec out[16], const bu_pixel_block& px) {
+    for (int p = 0; p < 16; p++) out[p] = to_cvec<P>(px.m_pixels[p][0], px.m_pixels[p][1], px.m_pixels[p][2]);
+}
+// error of (colour, table) with the given selectors over the block = etc_block::evaluate_etc1_error for an ETC1S block
+template <bool P> inline uint64_t block_error(const cvec px[16], color5 c, uint32_t sels) {
+    cvec bc[4];
+    block_colors<P>(bc, c);
+    uint64_t e = 0;
+    for (int p = 0; p < 16; p++) e += cdist<P>(px[p], bc[(sels >> (2 * p)) & 3]);
+    return e;
+}
+
+// sum over the 16 pixels of |selector difference|, four selectors per byte
+struct sel_diff_table {
+    uint8_t v[256][256];
+    sel_diff_table() {
+        for (int a = 0; a < 256; a++)
+            for (int b = 0; b < 256; b++) {
+                int s = 0;
+                for (int k = 0; k < 4; k++) s += std::abs(((a >> (2 * k)) & 3) - ((b >> (2 * k)) & 3));
+                v[a][b] = (uint8_t)s;
+            }
+    }
+};
+inline int sel_diff(const sel_diff_table& t, uint32_t a, uint32_t b) {
+    return t.v[a & 255][b & 255] + t.v[(a >> 8) & 255][(b >> 8) & 255] + t.v[(a >> 16) & 255][(b >> 16) & 255] + t.v[a >> 24][b >> 24];
+}
+
+// basist::approx_move_to_front (transcoder_internal.h:863-929)
+struct history_buffer {
+    int v[kSelectorHistorySize];
+    uint32_t rover;
+    void reset() { std::memset(v, 0, sizeof(v)); rover = kSelectorHistorySize / 2; }
+    void add(int x) { v[rover++] = x; if (rover == kSelectorHistorySize) rover = kSelectorHistorySize / 2; }
+    void use(uint32_t i) { if (i) std::swap(v[i / 2], v[i]); }
+};
+
+enum token_kind : uint8_t { T_NONE, T_PRED, T_PRED_REPEAT, T_ENDPOINT_DELTA, T_SELECTOR, T_SELECTOR_RLE };
+struct token { uint32_t value; token_kind kind; };
+
+}  // namespace
+
+uint16_t crc16_ccitt(const void* data, size_t size, uint16_t crc) {
+    // CRC-16/CCITT (polynomial 0x1021, MSB first) on the inverted register, byte at a time from a table
+    static const struct table_t {
+        uint16_t t[256];
+        table_t() {
+            for (uint32_t i = 0; i < 256; i++) {
+                uint16_t c = (uint16_t)(i << 8);
+                for (int k = 0; k < 8; k++) c = (uint16_t)((c & 0x8000) ? (c << 1) ^ 0x1021 : (c << 1));
+                t[i] = c;
+            }
+        }
+    } T;
+    crc = (uint16_t)~crc;
+    const uint8_t* p = static_cast<const uint8_t*>(data);
+    for (size_t i = 0; i < size; i++) crc = (uint16_t)((crc << 8) ^ T.t[(crc >> 8) ^ p[i]]);
+    return (uint16_t)~crc;
+}
+
+std::vector<uint32_t> reorder_palette_by_adjacency(const uint32_t* indices, uint32_t num_indices, uint32_t n) {
+    std::vector<uint32_t> remap(n, 0);
+    if (num_indices <= 1 || !n) return remap;  // enc.cpp:1796-1797
+    // adjacency counts of unequal neighbours, one entry per unordered pair (enc.cpp:1832-1843)
+    std::vector<uint64_t> keys;
+    keys.reserve(num_indices);
+    for (uint32_t i = 0; i + 1 < num_indices; i++) {
+        const uint32_t a = indices[i], b = indices[i + 1];
+        if (a != b) keys.push_back((uint64_t)std::min(a, b) * n + std::max(a, b));
+    }
+    std::sort(keys.begin(), keys.end());
+    struct edge { uint32_t other, count; };
+    std::vector<uint32_t> degree(n + 1, 0);
+    std::vector<std::pair<uint64_t, uint32_t>> pairs;
+    for (size_t i = 0; i < keys.size();) {
+        size_t e = i + 1;
+        while (e < keys.size() && keys[e] == keys[i]) e++;
+        pairs.emplace_back(keys[i], (uint32_t)(e - i));
+        degree[keys[i] / n]++; degree[keys[i] % n]++;
+        i = e;
+    }
+    std::vector<uint32_t> first(n + 1, 0);
+    for (uint32_t s = 0; s < n; s++) first[s + 1] = first[s] + degree[s];
+    std::vector<edge> edges(first[n]);
+    std::vector<uint32_t> fill(first.begin(), first.end() - 1);
+    uint32_t max_count = 0; uint64_t max_key = 0;
+    for (const auto& p : pairs) {
+        const uint32_t a = (uint32_t)(p.first / n), b = (uint32_t)(p.first % n);
+        edges[fill[a]++] = edge{b, p.second};
+        edges[fill[b]++] = edge{a, p.second};
+        if (p.second > max_count) { max_count = p.second; max_key = p.first; }  // first maximum in row-major order (enc.cpp:1847-1852)
+    }
+    std::deque<uint32_t> picked;
+    std::vector<int32_t> coord(n, 0);     // position of a picked symbol on the line; the front's coordinate is `front`
+    std::vector<uint8_t> done(n, 0);
+    std::vector<uint32_t> to_picked(n, 0);
+    int32_t front = 0;
+    auto account = [&](uint32_t moved) { for (uint32_t k = first[moved]; k < first[moved + 1]; k++) if (!done[edges[k].other]) to_picked[edges[k].other] += edges[k].count; };
+    const uint32_t a0 = (uint32_t)(max_key / n), b0 = (uint32_t)(max_key % n);
+    picked.push_back(a0); picked.push_back(b0);
+    done[a0] = done[b0] = 1;
+    coord[a0] = 0; coord[b0] = 1;
+    account(a0);
+    if (b0 != a0) account(b0);
+    uint32_t remaining = 0;
+    for (uint32_t s = 0; s < n; s++) remaining += !done[s];
+    std::vector<std::pair<int32_t, uint32_t>> near;  // (position, count) of the picked neighbours of the symbol being placed
+    while (remaining) {
+        // the unplaced symbol most often adjacent to the placed ones; lowest number on ties, the lowest unplaced when all are 0 (enc.cpp:1868-1891)
+        uint32_t best = UINT32_MAX, best_count = 0;
+        for (uint32_t s = 0; s < n; s++) {
+            if (done[s]) continue;
+            if (best == UINT32_MAX) best = s;
+            if (to_picked[s] > best_count) { best = s; best_count = to_picked[s]; }
+        }
+        // which end: the float sum of count * (distance to the far end - distance to the near end), in line order (enc.cpp:1893-1915)
+        near.clear();
+        for (uint32_t k = first[best]; k < first[best + 1]; k++)
+            if (done[edges[k].other]) near.emplace_back(coord[edges[k].other] - front, edges[k].count);
+        std::sort(near.begin(), near.end());
+        float side = 0;
+        const int size = (int)picked.size();
+        for (const auto& pc : near) side += static_cast<float>((size + 1 - 2 * (pc.first + 1)) * (int)pc.second);
+        if (side <= 0) { coord[best] = front + size; picked.push_back(best); }
+        else { coord[best] = --front; picked.push_front(best); }
+        done[best] = 1;
+        remaining--;
+        account(best);
+    }
+    for (uint32_t i = 0; i < n; i++) remap[picked[i]] = i;
+    return remap;
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+
+void etc1s_backend::init(const backend_source& src, const backend_params& params, const std::vector<backend_slice_desc>& slices, reoptimize_fn reoptimize) {
+    m_frontend = nullptr;
+    m_src = src;
+    m_reoptimize = std::move(reoptimize);
+    m_params = params;
+    m_slices = slices;
+    m_output = backend_output();
+    m_error.clear();
+}
+
+// backend.cpp:52-75. The frontend's state is flattened into the arrays of backend_source; the one call back into it re-flattens.
+void etc1s_backend::init(etc1s_frontend* fe, const backend_params& params, const std::vector<backend_slice_desc>& slices) {
+    init(backend_source(), params, slices, nullptr);
+    m_frontend = fe;
+    auto flatten = [this](backend_source& src) {
+        etc1s_frontend& f = *m_frontend;
+        const auto& P = f.endpoint_cluster_params();
+        m_fe_endpoints.resize(P.size() * 4);
+        for (size_t i = 0; i < P.size(); i++) { m_fe_endpoints[i * 4] = P[i].r; m_fe_endpoints[i * 4 + 1] = P[i].g; m_fe_endpoints[i * 4 + 2] = P[i].b; m_fe_endpoints[i * 4 + 3] = P[i].inten; }
+        src.total_blocks = f.get_total_output_blocks();
+        src.perceptual = f.get_params().m_perceptual;
+        src.source_blocks = f.source_blocks_host();
+        src.output_blocks = f.get_output_blocks().data();
+        src.block_endpoint_index = f.block_endpoint_clusters().data();
+        src.block_selector_index = f.block_selector_cluster_index().data();
+        src.total_endpoints = (uint32_t)P.size();
+        src.endpoint_color5_inten = m_fe_endpoints.data();
+        src.total_selectors = f.get_total_selector_clusters();
+        src.selector_blocks = f.optimized_cluster_selectors().data();
+    };
+    flatten(m_src);
+    m_reoptimize = [this, flatten](const std::vector<uint32_t>& new_block_endpoints, std::vector<int>& old_to_new, bool final_codebook,
+                                   const std::vector<uint32_t>* block_selector_indices, backend_source& src) {
+        if (!m_frontend->reoptimize_remapped_endpoints(new_block_endpoints, old_to_new, final_codebook, block_selector_indices)) return false;
+        flatten(src);
+        return true;
+    };
+}
+
+void etc1s_backend::create_endpoint_palette() {  // backend.cpp:77-94
+    m_output.m_num_endpoints = m_src.total_endpoints;
+    m_endpoint_palette.resize(m_src.total_endpoints);
+    for (uint32_t i = 0; i < m_src.total_endpoints; i++) {
+        const uint8_t* e = m_src.endpoint_color5_inten + (size_t)i * 4;
+        m_endpoint_palette[i] = endpoint_entry{e[0], e[1], e[2], e[3]};
+    }
+}
+
+void etc1s_backend::create_selector_palette() {  // backend.cpp:96-118
+    m_output.m_num_selectors = m_src.total_selectors;
+    m_selector_palette.resize(m_src.total_selectors);
+    for (uint32_t i = 0; i < m_src.total_selectors; i++) m_selector_palette[i] = packed_selectors(m_src.selector_blocks[i]);
+}
+
+// backend.cpp:406-617: every block is predicted from its left, upper or upper-left neighbour when that one uses the same endpoints;
+// when none does, a neighbour's endpoints are adopted anyway if the block's error stays within the RDO threshold.
+bool etc1s_backend::create_encoder_blocks() {
+    const uint32_t total = m_src.total_blocks;
+    m_blocks.assign(total, encoder_block{0, 0, 0, 0});
+    uint32_t remapped = 0;
+    std::vector<uint32_t> all_endpoint_indices;
+    all_endpoint_indices.reserve(total);
+    const float thresh = m_params.m_endpoint_rdo_quality_thresh;
+    const bool perceptual = m_src.perceptual;
+    for (const backend_slice_desc& s : m_slices) {
+        const uint32_t nbx = s.m_num_blocks_x, nby = s.m_num_blocks_y;
+        if ((uint64_t)s.m_first_block_index + (uint64_t)nbx * nby > total) return fail("slice exceeds the frontend's blocks");
+        for (uint32_t by = 0; by < nby; by++)
+            for (uint32_t bx = 0; bx < nbx; bx++) {
+                const uint32_t b = s.m_first_block_index + bx + by * nbx;
+                encoder_block& m = m_blocks[b];
+                m.endpoint_index = m_src.block_endpoint_index[b];
+                m.selector_index = m_src.block_selector_index[b];
+                m.endpoint_predictor = kNoEndpointPred;
+                if (m.endpoint_index >= m_src.total_endpoints || m.selector_index >= m_src.total_selectors) return fail("block index out of range");
+                uint32_t neighbour[kNumEndpointPreds];
+                bool present[kNumEndpointPreds];
+                uint32_t best_pred = UINT32_MAX;
+                for (uint32_t p = 0; p < kNumEndpointPreds; p++) {
+                    const int px = (int)bx + kPredDx[p], py = (int)by + kPredDy[p];
+                    present[p] = px >= 0 && py >= 0;  // dx, dy <= 0: the far edges cannot be crossed
+                    if (!present[p]) continue;
+                    neighbour[p] = m_blocks[s.m_first_block_index + (uint32_t)px + (uint32_t)py * nbx].endpoint_index;
+                    if (neighbour[p] == m.endpoint_index && best_pred == UINT32_MAX) best_pred = p;
+                }
+                if (best_pred != UINT32_MAX) {
+                    m.endpoint_predictor = (uint8_t)best_pred;
+                } else if (thresh > 0.0f) {
+                    cvec px[16];
+                    if (perceptual) pixel_cvecs<true>(px, m_src.source_blocks[b]); else pixel_cvecs<false>(px, m_src.source_blocks[b]);
+                    const bu_etc_block& out = m_src.output_blocks[b];
+                    const uint32_t sels = packed_selectors(out);
+                    const uint64_t cur_err = perceptual ? block_error<true>(px, header_of(out), sels) : block_error<false>(px, header_of(out), sels);
+                    if (cur_err) {
+                        const uint64_t thresh_err = (uint64_t)(cur_err * std::max(1.0f, thresh));
+                        uint64_t best_err = UINT64_MAX;
+                        uint32_t best_index = 0;
+                        for (uint32_t p = 0; p < kNumEndpointPreds; p++) {
+                            if (!present[p]) continue;
+                            const endpoint_entry& e = m_endpoint_palette[neighbour[p]];
+                            const color5 c{e.r, e.g, e.b, e.inten};
+                            const uint64_t err = perceptual ? block_error<true>(px, c, sels) : block_error<false>(px, c, sels);
+                            if (err <= thresh_err && err < best_err) { best_err = err; best_pred = p; best_index = neighbour[p]; }  // ascending p: ties keep the lower predictor
+                        }
+                        if (best_pred != UINT32_MAX) {
+                            m.endpoint_index = best_index;
+                            m.endpoint_predictor = (uint8_t)best_pred;
+                            remapped++;
+                        }
+                    }
+                }
+                if (m.endpoint_predictor == kNoEndpointPred) all_endpoint_indices.push_back(m.endpoint_index);
+            }
+    }
+    if (!reoptimize_and_sort_endpoints_codebook(remapped, all_endpoint_indices)) return false;
+    sort_selector_codebook();
+    return true;
+}
+
+// backend.cpp:130-244
+bool etc1s_backend::reoptimize_and_sort_endpoints_codebook(uint32_t total_remapped, std::vector<uint32_t>& all_endpoint_indices) {
+    if (total_remapped && m_params.m_compression_level > 1) {
+        // the block -> endpoint assignment changed: let the frontend refit and compact its codebook (backend.cpp:145-191)
+        if (!m_reoptimize) return fail("compression levels above 1 need the frontend behind the backend (reoptimize_remapped_endpoints)");
+        std::vector<uint32_t> new_block_endpoints(m_src.total_blocks);
+        for (uint32_t b = 0; b < m_src.total_blocks; b++) new_block_endpoints[b] = m_blocks[b].endpoint_index;
+        std::vector<int> old_to_new;
+        if (!m_reoptimize(new_block_endpoints, old_to_new, true, nullptr, m_src)) return fail("reoptimize_remapped_endpoints failed");
+        create_endpoint_palette();
+        for (encoder_block& m : m_blocks) m.endpoint_index = (uint32_t)old_to_new[m.endpoint_index];
+        for (uint32_t& i : all_endpoint_indices) i = (uint32_t)old_to_new[i];
+    }
+    const uint32_t k = m_src.total_endpoints;
+    m_endpoint_old_to_new = reorder_palette_by_adjacency(all_endpoint_indices.data(), (uint32_t)all_endpoint_indices.size(), k);
+    // old -> new need not be onto: unused new slots point at the first used old entry (backend.cpp:199-243)
+    std::vector<uint8_t> old_used(k, 0);
+    uint32_t first_old = UINT32_MAX;
+    for (const backend_slice_desc& s : m_slices)
+        for (uint32_t i = 0, n = s.m_num_blocks_x * s.m_num_blocks_y; i < n; i++) {
+            const uint32_t e = m_blocks[s.m_first_block_index + i].endpoint_index;
+            old_used[e] = 1;
+            first_old = std::min(first_old, e);
+        }
+    m_new_endpoint_was_used.assign(k, 0);
+    m_endpoint_new_to_old.assign(k, first_old);
+    for (uint32_t o = 0; o < k; o++)
+        if (old_used[o]) { const uint32_t nw = m_endpoint_old_to_new[o]; m_new_endpoint_was_used[nw] = 1; m_endpoint_new_to_old[nw] = o; }
+    return true;
+}
+
+// backend.cpp:246-309: a greedy nearest-neighbour chain over the selector patterns by Hamming distance of the packed selectors
+void etc1s_backend::sort_selector_codebook() {
+    const uint32_t k = m_src.total_selectors;
+    m_selector_new_to_old.assign(k, 0);
+    if (m_params.m_compression_level == 0) {
+        for (uint32_t i = 0; i < k; i++) m_selector_new_to_old[i] = i;
+    } else if (k) {
+        std::vector<uint32_t> remaining(k - 1);
+        for (uint32_t i = 1; i < k; i++) remaining[i - 1] = i;
+        uint32_t prev = 0;
+        for (uint32_t i = 1; i < k; i++) {
+            const uint32_t prev_bits = m_selector_palette[prev];
+            uint32_t best_dist = 100, best_j = 0;
+            for (uint32_t j = 0; j < remaining.size(); j++) {
+                const uint32_t d = (uint32_t)__builtin_popcount(prev_bits ^ m_selector_palette[remaining[j]]);
+                if (d < best_dist) { best_dist = d; best_j = j; if (d <= 1) break; }
+            }
+            prev = remaining[best_j];
+            m_selector_new_to_old[i] = prev;
+            remaining[best_j] = remaining.back();
+            remaining.pop_back();
+        }
+    }
+    m_selector_old_to_new.assign(k, 0);
+    for (uint32_t i = 0; i < k; i++) m_selector_old_to_new[m_selector_new_to_old[i]] = i;
+}
+
+// backend.cpp:619-681: CRC-16 of the slice as plain ETC1 blocks (differential, not flipped), what a transcoder to ETC1 would produce
+void etc1s_backend::compute_slice_crcs() {
+    static const uint8_t to_raw[4] = {3, 2, 0, 1};  // g_selector_index_to_etc1
+    m_output.m_slice_image_crcs.assign(m_slices.size(), 0);
+    for (size_t si = 0; si < m_slices.size(); si++) {
+        const backend_slice_desc& s = m_slices[si];
+        const uint32_t gx = (s.m_width + 3) / 4, gy = (s.m_height + 3) / 4;
+        std::vector<uint8_t> img((size_t)gx * gy * 8, 0);
+        for (uint32_t by = 0; by < s.m_num_blocks_y && by < gy; by++)
+            for (uint32_t bx = 0; bx < s.m_num_blocks_x && bx < gx; bx++) {
+                const encoder_block& m = m_blocks[s.m_first_block_index + bx + by * s.m_num_blocks_x];
+                const endpoint_entry& e = m_endpoint_palette[m.endpoint_index];
+                const uint32_t sels = m_selector_palette[m.selector_index];
+                uint32_t lo32 = 0;
+                for (uint32_t y = 0; y < 4; y++)
+                    for (uint32_t x = 0; x < 4; x++) {
+                        const uint32_t raw = to_raw[(sels >> (2 * (y * 4 + x))) & 3], bit = x * 4 + y;
+                        lo32 |= (raw & 1u) << bit;
+                        lo32 |= (raw >> 1) << (16 + bit);
+                    }
+                const uint64_t v = ((uint64_t)e.r << 59) | ((uint64_t)e.g << 51) | ((uint64_t)e.b << 43) | ((uint64_t)e.inten << 37) | ((uint64_t)e.inten << 34) | (1ull << 33) | lo32;
+                const uint64_t be = __builtin_bswap64(v);
+                std::memcpy(&img[((size_t)by * gx + bx) * 8], &be, 8);
+            }
+        m_output.m_slice_image_crcs[si] = crc16_ccitt(img.data(), img.size(), 0);
+    }
+}
+
+// backend.cpp:687-1485
+bool etc1s_backend::encode_image() {
+    const uint32_t n_ep = m_src.total_endpoints, n_sel = m_src.total_selectors;
+    const bool perceptual = m_src.perceptual;
+    const uint32_t level = m_params.m_compression_level;
+    const uint32_t kHistFirstSym = n_sel, kHistRleSym = n_sel + kSelectorHistorySize;
+    std::vector<uint32_t> selector_hist(n_sel + kSelectorHistorySize + 1, 0), rle_hist(kSelectorRleCountTotal, 0), delta_hist(n_ep, 0), pred_hist(kEndpointPredSymbols, 0);
+    std::vector<std::vector<token>> slice_tokens(m_slices.size());
+    std::vector<uint32_t> block_endpoint_indices(m_src.total_blocks, 0), block_selector_indices(m_src.total_blocks, 0);
+    uint32_t endpoints_remapped = 0;
+    static const sel_diff_table diff_table;
+    const float selector_thresh = std::max(1.0f, m_params.m_selector_rdo_quality_thresh);
+    const float endpoint_thresh = std::max(1.0f, m_params.m_endpoint_rdo_quality_thresh);
+    const int max_search = level >= 2 ? 64 : 16;  // backend.cpp:852
+    history_buffer history;
+
+    for (size_t si = 0; si < m_slices.size(); si++) {
+        const backend_slice_desc& s = m_slices[si];
+        const uint32_t nbx = s.m_num_blocks_x, nby = s.m_num_blocks_y, base = s.m_first_block_index;
+        std::vector<token>& tokens = slice_tokens[si];
+        tokens.reserve((size_t)nbx * nby * 2 + 16);
+        history.reset();
+        // blocks whose endpoints a later block is predicted from must keep them (backend.cpp:740-766)
+        std::vector<uint8_t> referenced((size_t)nbx * nby, 0);
+        for (uint32_t by = 0; by < nby; by++)
+            for (uint32_t bx = 0; bx < nbx; bx++) {
+                const uint32_t p = m_blocks[base + bx + by * nbx].endpoint_predictor;
+                if (p < kNumEndpointPreds) referenced[(bx + kPredDx[p]) + (size_t)(by + kPredDy[p]) * nbx] = 1;
+            }
+        std::vector<size_t> pred_run, selector_run;   // placeholder tokens of the open runs
+        int prev_pred_sym = -1;
+        uint32_t prev_endpoint = 0;
+        auto close_pred_run = [&]() {
+            if (pred_run.empty()) return;
+            const uint32_t count = (uint32_t)pred_run.size();
+            if (count > kEndpointPredMinRepeat) {
+                pred_hist[kEndpointPredRepeatLast]++;
+                tokens[pred_run[0]] = token{count, T_PRED_REPEAT};
+            } else {
+                pred_hist[prev_pred_sym] += count;
+                for (size_t t : pred_run) tokens[t] = token{(uint32_t)prev_pred_sym, T_PRED};
+            }
+            pred_run.clear();
+        };
+        auto close_selector_run = [&]() {
+            if (selector_run.empty()) return;
+            const uint32_t count = (uint32_t)selector_run.size();
+            if (count >= kSelectorRleThresh) {
+                tokens[selector_run[0]] = token{count, T_SELECTOR_RLE};
+                rle_hist[std::min<uint32_t>(count - kSelectorRleThresh, kSelectorRleCountTotal - 1)]++;
+                selector_hist[kHistRleSym]++;
+            } else {
+                selector_hist[kHistFirstSym] += count;
+                for (size_t t : selector_run) tokens[t] = token{kHistFirstSym, T_SELECTOR};
+            }
+            selector_run.clear();
+        };
+
+        for (uint32_t by = 0; by < nby; by++)
+            for (uint32_t bx = 0; bx < nbx; bx++) {
+                const uint32_t b = base + bx + by * nbx;
+                encoder_block& m = m_blocks[b];
+                // ---- one endpoint-predictor symbol per 2x2 macroblock, runs of equal symbols collapsed (backend.cpp:776-827)
+                if (!(bx & 1) && !(by & 1)) {
+                    uint32_t sym = 0;
+                    for (uint32_t y = 0; y < 2; y++)
+                        for (uint32_t x = 0; x < 2; x++) {
+                            uint32_t pred = kNoEndpointPred;
+                            if (bx + x < nbx && by + y < nby) pred = m_blocks[base + (bx + x) + (by + y) * nbx].endpoint_predictor;
+                            sym |= pred << (x * 2 + y * 4);
+                        }
+                    if ((int)sym == prev_pred_sym) {
+                        pred_run.push_back(tokens.size());
+                        tokens.push_back(token{0, T_NONE});
+                    } else {
+                        close_pred_run();
+                        pred_hist[sym]++;
+                        tokens.push_back(token{sym, T_PRED});
+                        prev_pred_sym = (int)sym;
+                    }
+                }
+                // ---- endpoint index, as a delta to the previous block's in the sorted palette (backend.cpp:829-1009)
+                int new_endpoint = (int)m_endpoint_old_to_new[m.endpoint_index];
+                cvec px[16];
+                bool have_px = false;
+                auto need_px = [&]() { if (!have_px) { if (perceptual) pixel_cvecs<true>(px, m_src.source_blocks[b]); else pixel_cvecs<false>(px, m_src.source_blocks[b]); have_px = true; } };
+                if (m.endpoint_predictor == kNoEndpointPred) {
+                    int delta = new_endpoint - (int)prev_endpoint;
+                    if (m_params.m_endpoint_rdo_quality_thresh > 1.0f && std::abs(delta) > 1 && !referenced[bx + (size_t)by * nbx]) {
+                        // a palette entry closer to the previous index that keeps the error within the threshold is cheaper to code
+                        need_px();
+                        const bu_etc_block& out = m_src.output_blocks[b];
+                        const color5 cur_c = header_of(out);
+                        const uint32_t sels = packed_selectors(out);
+                        const uint64_t cur_err = perceptual ? block_error<true>(px, cur_c, sels) : block_error<false>(px, cur_c, sels);
+                        if (cur_err) {
+                            const endpoint_entry cur_e = m_endpoint_palette[m.endpoint_index];
+                            const uint64_t thresh_err = (uint64_t)(cur_err * endpoint_thresh);
+                            uint64_t best_err = UINT64_MAX;
+                            int best_idx = 0;
+                            const int dist = std::min(std::abs(delta) - 1, max_search);
+                            for (int d = -dist; d < dist; d++) {
+                                int trial = (int)prev_endpoint + d;
+                                if (trial < 0) trial += (int)n_ep; else if (trial >= (int)n_ep) trial -= (int)n_ep;
+                                if (trial == new_endpoint || !m_new_endpoint_was_used[trial]) continue;
+                                const endpoint_entry& p = m_endpoint_palette[m_endpoint_new_to_old[trial]];
+                                if (level <= 1) {
+                                    if (p.inten > cur_c.inten) continue;
+                                    if (std::abs((int)cur_e.r - p.r) + std::abs((int)cur_e.g - p.g) + std::abs((int)cur_e.b - p.b) > kColorDeltaThresh) continue;
+                                }
+                                const color5 c{p.r, p.g, p.b, p.inten};
+                                const uint64_t err = perceptual ? block_error<true>(px, c, sels) : block_error<false>(px, c, sels);
+                                if (err < best_err && err <= thresh_err) { best_err = err; best_idx = trial; }
+                            }
+                            if (best_err != UINT64_MAX) {
+                                m.endpoint_index = m_endpoint_new_to_old[best_idx];
+                                new_endpoint = best_idx;
+                                delta = new_endpoint - (int)prev_endpoint;
+                                endpoints_remapped++;
+                            }
+                        }
+                    }
+                    if (delta < 0) delta += (int)n_ep;
+                    delta_hist[delta]++;
+                    tokens.push_back(token{(uint32_t)delta, T_ENDPOINT_DELTA});
+                }
+                block_endpoint_indices[b] = m_endpoint_new_to_old[new_endpoint];
+                prev_endpoint = (uint32_t)new_endpoint;
+
+                // ---- selector index: a recently used pattern (history buffer) that is good enough, else the block's own (backend.cpp:1011-1205)
+                int new_selector = (int)m_selector_old_to_new[m.selector_index];
+                int history_index = -1;
+                if (level <= 1) {
+                    for (uint32_t j = 0; j < kSelectorHistorySize; j++)
+                        if (history.v[j] == new_selector) { history_index = (int)j; break; }
+                }
+                if (history_index == -1) {
+                    need_px();
+                    const endpoint_entry& q = m_endpoint_palette[m_endpoint_new_to_old[new_endpoint]];
+                    cvec bc[4];
+                    uint32_t dist[16][4];
+                    if (perceptual) { block_colors<true>(bc, color5{q.r, q.g, q.b, q.inten}); for (int p = 0; p < 16; p++) for (int k = 0; k < 4; k++) dist[p][k] = cdist<true>(px[p], bc[k]); }
+                    else { block_colors<false>(bc, color5{q.r, q.g, q.b, q.inten}); for (int p = 0; p < 16; p++) for (int k = 0; k < 4; k++) dist[p][k] = cdist<false>(px[p], bc[k]); }
+                    const uint32_t cur_sels = m_selector_palette[m.selector_index];
+                    uint64_t cur_err = 0;
+                    for (int p = 0; p < 16; p++) cur_err += dist[p][(cur_sels >> (2 * p)) & 3];
+                    const uint64_t limit_err = (uint64_t)ceilf(cur_err * selector_thresh);
+                    uint64_t best_err = UINT64_MAX;
+                    int best_idx = 0;
+                    uint32_t best_j = 0;
+                    for (uint32_t j = 0; j < kSelectorHistorySize; j++) {
+                        const int trial = history.v[j];
+                        const uint32_t sels = m_selector_palette[m_selector_new_to_old[trial]];
+                        if (level <= 1 && sel_diff(diff_table, cur_sels, sels) >= kSelDiffThreshold) continue;
+                        uint64_t err = 0;
+                        for (int p = 0; p < 16; p++) err += dist[p][(sels >> (2 * p)) & 3];
+                        if (err < best_err && err <= limit_err) { best_err = err; best_idx = trial; best_j = j; }
+                    }
+                    if (best_err != UINT64_MAX) { new_selector = best_idx; history_index = (int)best_j; }
+                }
+                m.selector_index = m_selector_new_to_old[new_selector];
+                if (history_index != 0) close_selector_run();
+                if (history_index == 0) {
+                    selector_run.push_back(tokens.size());
+                    tokens.push_back(token{0, T_NONE});
+                } else if (history_index > 0) {
+                    selector_hist[kHistFirstSym + history_index]++;
+                    tokens.push_back(token{kHistFirstSym + (uint32_t)history_index, T_SELECTOR});
+                } else {
+                    selector_hist[new_selector]++;
+                    tokens.push_back(token{(uint32_t)new_selector, T_SELECTOR});
+                }
+                m.selector_history_index = (int8_t)history_index;
+                if (history_index < 0) history.add(new_selector); else history.use((uint32_t)history_index);
+                block_selector_indices[b] = m.selector_index;
+            }
+        close_pred_run();
+        close_selector_run();
+    }
+
+    if (endpoints_remapped && level > 1) {  // backend.cpp:1281-1287: refit the palette entries in place (no renumbering)
+        if (!m_reoptimize) return fail("compression levels above 1 need the frontend behind the backend (reoptimize_remapped_endpoints)");
+        std::vector<int> unused;
+        if (!m_reoptimize(block_endpoint_indices, unused, false, &block_selector_indices, m_src)) return fail("reoptimize_remapped_endpoints failed");
+        create_endpoint_palette();
+    }
+    compute_slice_crcs();
+
+    // ---- the four models, then the slices (backend.cpp:1298-1472)
+    auto model = [](std::vector<uint32_t>& h, huffman_table& t) {
+        bool any = false;
+        for (uint32_t v : h) if (v) { any = true; break; }
+        if (!any) h[0]++;
+        return t.init(h, kHuffMaxCodeSize);
+    };
+    huffman_table pred_model, delta_model, selector_model, rle_model;
+    if (!model(pred_hist, pred_model) || !model(delta_hist, delta_model) || !model(selector_hist, selector_model) || !model(rle_hist, rle_model))
+        return fail("huffman model construction failed");
+    bit_writer w;
+    w.restart(4096);
+    if (!w.put_table(pred_model) || !w.put_table(delta_model) || !w.put_table(selector_model) || !w.put_table(rle_model)) return fail("huffman table serialisation failed");
+    w.put_bits(kSelectorHistorySize, 13);
+    w.flush();
+    m_output.m_slice_image_tables = w.bytes();
+    m_output.m_slice_image_data.assign(m_slices.size(), std::vector<uint8_t>());
+    for (size_t si = 0; si < m_slices.size(); si++) {
+        w.restart(slice_tokens[si].size() + 64);
+        for (const token& t : slice_tokens[si]) {
+            switch (t.kind) {
+            case T_NONE: break;
+            case T_PRED: w.put_code(t.value, pred_model); break;
+            case T_PRED_REPEAT: w.put_code(kEndpointPredRepeatLast, pred_model); w.put_vlc(t.value - kEndpointPredMinRepeat, kEndpointPredCountVlcBits); break;
+            case T_ENDPOINT_DELTA: w.put_code(t.value, delta_model); break;
+            case T_SELECTOR: w.put_code(t.value, selector_model); break;
+            case T_SELECTOR_RLE: {
+                w.put_code(kHistRleSym, selector_model);
+                const uint32_t run = t.value - kSelectorRleThresh;
+                if (run >= kSelectorRleCountTotal - 1) { w.put_code(kSelectorRleCountTotal - 1, rle_model); w.put_vlc(run, 7); }
+                else w.put_code(run, rle_model);
+                break;
+            }
+            }
+        }
+        w.flush();
+        m_output.m_slice_image_data[si] = w.bytes();
+    }
+    return true;
+}
+
+// backend.cpp:1487-1658: the palette in its final order, each entry as deltas to the previous one; three colour models picked by
+// the previous component value, one for the intensity table
+bool etc1s_backend::encode_endpoint_palette() {
+    const uint32_t k = m_src.total_endpoints;
+    std::vector<uint8_t> old_used(k, 0);
+    uint32_t first_old = UINT32_MAX;
+    for (const backend_slice_desc& s : m_slices)
+        for (uint32_t i = 0, n = s.m_num_blocks_x * s.m_num_blocks_y; i < n; i++) {
+            const uint32_t e = m_blocks[s.m_first_block_index + i].endpoint_index;
+            old_used[e] = 1;
+            first_old = std::min(first_old, e);
+        }
+    std::vector<uint32_t> new_to_old(k, first_old);
+    for (uint32_t o = 0; o < k; o++) if (old_used[o]) new_to_old[m_endpoint_old_to_new[o]] = o;
+    bool gray = true;
+    for (const endpoint_entry& e : m_endpoint_palette) if (e.r != e.g || e.r != e.b) { gray = false; break; }
+    const uint32_t comps = gray ? 1u : 3u;
+    std::vector<uint32_t> h0(32, 0), h1(32, 0), h2(32, 0), hi(8, 0);
+    auto walk = [&](auto&& on_inten, auto&& on_color) {
+        int prev[3] = {16, 16, 16}, prev_inten = 0;
+        for (uint32_t nw = 0; nw < k; nw++) {
+            const endpoint_entry& e = m_endpoint_palette[new_to_old[nw]];
+            on_inten((uint32_t)(((int)e.inten - prev_inten) & 7));
+            prev_inten = e.inten;
+            const int c[3] = {e.r, e.g, e.b};
+            for (uint32_t i = 0; i < comps; i++) {
+                on_color(prev[i] <= 9 ? 0 : (prev[i] <= 21 ? 1 : 2), (uint32_t)((c[i] - prev[i]) & 31));  // COLOR5_PAL0/1_PREV_HI
+                prev[i] = c[i];
+            }
+        }
+    };
+    walk([&](uint32_t d) { hi[d]++; }, [&](int which, uint32_t d) { (which == 0 ? h0 : which == 1 ? h1 : h2)[d]++; });
+    auto nonempty = [](std::vector<uint32_t>& h) { for (uint32_t v : h) if (v) return; h[0]++; };
+    nonempty(h0); nonempty(h1); nonempty(h2);
+    huffman_table m0, m1, m2, mi;
+    if (!m0.init(h0) || !m1.init(h1) || !m2.init(h2) || !mi.init(hi)) return fail("endpoint palette model construction failed");
+    bit_writer w;
+    w.restart(8192);
+    if (!w.put_table(m0) || !w.put_table(m1) || !w.put_table(m2) || !w.put_table(mi)) return fail("huffman table serialisation failed");
+    w.put_bits(gray ? 1 : 0, 1);
+    walk([&](uint32_t d) { w.put_code(d, mi); }, [&](int which, uint32_t d) { w.put_code(d, which == 0 ? m0 : which == 1 ? m1 : m2); });
+    w.flush();
+    m_output.m_endpoint_palette = w.bytes();
+    return true;
+}
+
+// backend.cpp:1660-1745: each pattern as four bytes XORed with the previous pattern's, Huffman coded; raw bytes when that is not smaller
+bool etc1s_backend::encode_selector_palette() {
+    const uint32_t k = m_src.total_selectors;
+    std::vector<uint32_t> h(256, 0);
+    for (uint32_t q = 1; q < k; q++) {
+        const uint32_t x = m_selector_palette[m_selector_new_to_old[q]] ^ m_selector_palette[m_selector_new_to_old[q - 1]];
+        for (int j = 0; j < 4; j++) h[(x >> (8 * j)) & 255]++;
+    }
+    if (k < 2) h[0]++;
+    huffman_table model;
+    if (!model.init(h)) return fail("selector palette model construction failed");
+    bit_writer w;
+    w.restart((size_t)k * 4 + 64);
+    w.put_bits(0, 1); w.put_bits(0, 1); w.put_bits(0, 1);  // global codebook, hybrid codebooks, raw bytes
+    if (!w.put_table(model)) return fail("huffman table serialisation failed");
+    for (uint32_t q = 0; q < k; q++) {
+        const uint32_t cur = m_selector_palette[m_selector_new_to_old[q]];
+        if (!q) { for (int j = 0; j < 4; j++) w.put_bits((cur >> (8 * j)) & 255, 8); continue; }
+        const uint32_t x = cur ^ m_selector_palette[m_selector_new_to_old[q - 1]];
+        for (int j = 0; j < 4; j++) w.put_code((x >> (8 * j)) & 255, model);
+    }
+    w.flush();
+    if (w.bytes().size() >= (size_t)k * 4) {
+        w.restart((size_t)k * 4 + 8);
+        w.put_bits(0, 1); w.put_bits(0, 1); w.put_bits(1, 1);
+        for (uint32_t q = 0; q < k; q++) {
+            const uint32_t cur = m_selector_palette[m_selector_new_to_old[q]];
+            for (int j = 0; j < 4; j++) w.put_bits((cur >> (8 * j)) & 255, 8);
+        }
+        w.flush();
+    }
+    m_output.m_selector_palette = w.bytes();
+    return true;
+}
+
+uint32_t etc1s_backend::encode() {  // backend.cpp:1747-1776
+    m_stage_times.clear();
+    m_error.clear();
+    if (m_params.m_used_global_codebooks) { fail("global codebooks are not supported"); return 0; }
+    if (!m_src.total_blocks || !m_src.total_endpoints || !m_src.total_selectors || !m_src.source_blocks || !m_src.output_blocks ||
+        !m_src.block_endpoint_index || !m_src.block_selector_index || !m_src.endpoint_color5_inten || !m_src.selector_blocks) { fail("incomplete backend source"); return 0; }
+    m_output = backend_output();
+    m_output.m_slice_desc = m_slices;
+    m_output.m_etc1s = m_params.m_etc1s;
+    m_output.m_uses_global_codebooks = false;
+    m_output.m_srgb = m_src.perceptual;
+#define BU_BSTAGE(name, call) do { timer t__; if (!(call)) return 0; m_stage_times.push_back(stage_time{name, t__.seconds()}); } while (0)
+    BU_BSTAGE("create_palettes", (create_endpoint_palette(), create_selector_palette(), true));
+    BU_BSTAGE("create_encoder_blocks", create_encoder_blocks());
+    BU_BSTAGE("encode_image", encode_image());
+    BU_BSTAGE("encode_endpoint_palette", encode_endpoint_palette());
+    BU_BSTAGE("encode_selector_palette", encode_selector_palette());
+#undef BU_BSTAGE
+    return m_output.get_output_size_estimate();
+}
+
+}  // namespace bu

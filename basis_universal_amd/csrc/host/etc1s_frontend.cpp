@@ -286,6 +286,20 @@ bool etc1s_frontend::init_etc1_images() {
     return true;
 }
 
+// get_source_pixel_block (frontend.h:155) for the backend: the host tiles the frontend was given, else one download of the resident ones
+const bu_pixel_block* etc1s_frontend::source_blocks_host() {
+    if (m_params.m_pSource_blocks) return m_params.m_pSource_blocks;
+    if (m_source_copy.size() != m_total_blocks) {
+        m_source_copy.resize(m_total_blocks);
+        if (!m_dev || !m_dev->d_pixels || !bu_hip_memcpy_d2h(m_dev->ctx, m_source_copy.data(), m_dev->d_pixels, (size_t)m_total_blocks * sizeof(bu_pixel_block))) {
+            m_source_copy.clear();
+            fail("download source blocks");
+            return nullptr;
+        }
+    }
+    return m_source_copy.data();
+}
+
 const std::vector<bu_etc_block>& etc1s_frontend::etc1_blocks() const {
     if (!m_etc1_on_host && m_dev && m_dev->etc1.p) {
         m_etc1_blocks_etc1s.resize(m_total_blocks);
@@ -593,6 +607,78 @@ bool etc1s_frontend::refine_block_endpoints_given_selectors(uint32_t* total_refi
     }
     if (refined && !d.upload(d.enc, m_encoded_blocks.data(), n)) return fail("upload refined blocks");  // the next selector pass reads the device copy
     if (total_refined) *total_refined = refined;
+    return true;
+}
+
+// frontend.cpp:2996-3220, called by the backend (etc1s_backend.cpp) after its rate-distortion passes moved blocks to other endpoint
+// clusters. Every cluster of the NEW assignment is refitted with its blocks' selectors held fixed (the device fit of row a15 at the
+// quality the reference uses here) and keeps the refit where it lowers the error. With optimize_final_codebook the codebook is then
+// compacted (unused clusters dropped, equal ones merged), the block map and the encoded blocks follow, and old_to_new says where
+// every old cluster went (-1: unused).
+bool etc1s_frontend::reoptimize_remapped_endpoints(const std::vector<uint32_t>& new_block_endpoints, std::vector<int>& old_to_new, bool optimize_final_codebook,
+                                                   const std::vector<uint32_t>* block_selector_indices) {
+    ensure_endpoint_map();
+    const uint32_t n = m_total_blocks, k = m_endpoint_cluster_count;
+    if (new_block_endpoints.size() != n || m_endpoint_cluster_etc_params.size() != k) return fail("reoptimize_remapped_endpoints: size mismatch");
+    // the blocks of every cluster under the new assignment, ascending, and the blocks as they would be coded with it
+    std::vector<uint32_t> offsets((size_t)k + 1, 0), indices((size_t)n * 2), fill;
+    for (uint32_t b = 0; b < n; b++) { if (new_block_endpoints[b] >= k) return fail("reoptimize_remapped_endpoints: bad index"); offsets[new_block_endpoints[b] + 1] += 2; }
+    for (uint32_t c = 0; c < k; c++) offsets[c + 1] += offsets[c];
+    fill.assign(offsets.begin(), offsets.end() - 1);
+    std::vector<bu_etc_block> trial(n);
+    for (uint32_t b = 0; b < n; b++) {
+        const uint32_t c = new_block_endpoints[b];
+        indices[fill[c]++] = b * 2; indices[fill[c]++] = b * 2 + 1;
+        const endpoint_params& e = m_endpoint_cluster_etc_params[c];
+        const uint32_t sc = block_selector_indices ? (*block_selector_indices)[b] : m_block_selector_cluster_index[b];
+        store_be64(trial[b], ((uint64_t)e.r << 59) | ((uint64_t)e.g << 51) | ((uint64_t)e.b << 43) | ((uint64_t)e.inten << 37) | ((uint64_t)e.inten << 34) | (3ull << 32) |
+                                 raw_selector_bits(m_optimized_cluster_selectors[sc]));
+    }
+    device_state& d = *m_dev;
+    const int quality = m_params.m_compression_level == 6 ? BU_ETC_QUALITY_UBER : BU_ETC_QUALITY_SLOW;  // frontend.cpp:3073-3076
+    if (!d.upload(d.offsets, offsets.data(), offsets.size()) || !d.upload(d.indices, indices.data(), indices.size()) || !d.upload(d.enc, trial.data(), n) ||
+        !d.reserve(d.params, (size_t)k * 4) || !d.reserve(d.err, (size_t)k * 8) || !d.reserve(d.valid, k) || !d.reserve(d.weights, (size_t)k * 8))
+        return fail("upload");
+    m_enc_device_current = false;
+    if (!bu_hip_k_refit_endpoints_given_selectors_q(d.ctx, d.d_pixels, d.enc.p, k, offsets.data(), (const uint32_t*)d.offsets.p, (const uint32_t*)d.indices.p, quality,
+                                                    m_params.m_perceptual, (uint8_t*)d.params.p, (uint64_t*)d.err.p, (uint8_t*)d.valid.p, (uint64_t*)d.weights.p))
+        return fail("bu_hip_k_refit_endpoints_given_selectors_q");
+    std::vector<uint8_t> prm(k * 4ull), valid(k);
+    std::vector<uint64_t> err(k), cur(k);
+    if (!d.download(prm.data(), d.params, prm.size()) || !d.download(err.data(), d.err, k) || !d.download(valid.data(), d.valid, k) || !d.download(cur.data(), d.weights, k))
+        return fail("download");
+    old_to_new.assign(k, -1);
+    uint32_t kept = 0;
+    for (uint32_t c = 0; c < k; c++) {
+        if (offsets[c + 1] == offsets[c]) continue;
+        old_to_new[c] = (int)kept++;
+        if (valid[c] && err[c] < cur[c]) {
+            endpoint_params& e = m_endpoint_cluster_etc_params[c];
+            e.r = prm[c * 4]; e.g = prm[c * 4 + 1]; e.b = prm[c * 4 + 2]; e.inten = prm[c * 4 + 3]; e.color_error = err[c]; e.valid = true; e.color_used = true;
+        }
+    }
+    if (!optimize_final_codebook) return true;
+
+    // compaction in old order, then the same sort-and-merge every codebook iteration ends with (frontend.cpp:3131-3199)
+    std::vector<endpoint_params> params(kept);
+    std::vector<uint32_t> sizes(kept);
+    for (uint32_t c = 0; c < k; c++)
+        if (old_to_new[c] >= 0) { params[old_to_new[c]] = m_endpoint_cluster_etc_params[c]; sizes[old_to_new[c]] = (offsets[c + 1] - offsets[c]) / 2; }
+    for (uint32_t c = 0; c < k; c++)
+        for (uint32_t i = offsets[c]; i < offsets[c + 1]; i += 2) { const uint32_t b = indices[i] >> 1; m_block_endpoint_cluster[b] = (uint32_t)old_to_new[c]; m_block_endpoint_pos[b] = (i - offsets[c]) / 2; }
+    m_endpoint_cluster_etc_params.swap(params);
+    m_endpoint_cluster_sizes.swap(sizes);
+    m_endpoint_cluster_count = kept;
+    m_endpoint_map_valid = true; m_endpoint_lists_valid = false; m_endpoint_clusters.clear();
+    m_endpoint_cluster_subblocks.clear();
+    eliminate_redundant_or_empty_endpoint_clusters();
+    for (uint32_t b = 0; b < n; b++) old_to_new[new_block_endpoints[b]] = (int)m_block_endpoint_cluster[b];
+    for (uint32_t b = 0; b < n; b++) {
+        const endpoint_params& e = m_endpoint_cluster_etc_params[m_block_endpoint_cluster[b]];
+        const uint64_t v = load_be64(m_encoded_blocks[b]);
+        const uint64_t keep = v & 0x3FFFFFFFFull;  // diff + flip bits and the selectors
+        store_be64(m_encoded_blocks[b], ((uint64_t)e.r << 59) | ((uint64_t)e.g << 51) | ((uint64_t)e.b << 43) | ((uint64_t)e.inten << 37) | ((uint64_t)e.inten << 34) | keep);
+    }
     return true;
 }
 

@@ -76,6 +76,12 @@ public:
     const std::vector<bu_etc_block>& optimized_cluster_selectors() const { return m_optimized_cluster_selectors; }
     const std::vector<uint32_t>& block_selector_cluster_index() const { return m_block_selector_cluster_index; }
 
+    // ---- what the backend needs beyond the getters (etc1s_backend.h)
+    const bu_pixel_block* source_blocks_host();  // get_source_pixel_block: the caller's host tiles, or a host copy of device-only tiles
+    // basisu_frontend::reoptimize_remapped_endpoints (frontend.cpp:2996-3220): the backend moved blocks to other endpoint clusters
+    bool reoptimize_remapped_endpoints(const std::vector<uint32_t>& new_block_endpoints, std::vector<int>& old_to_new, bool optimize_final_codebook,
+                                       const std::vector<uint32_t>* block_selector_indices);
+
     // wall time of each stage of the last compress(), in call order (name, seconds)
     struct stage_time { const char* name; double seconds; };
     const std::vector<stage_time>& stage_times() const { return m_stage_times; }
@@ -163,6 +169,7 @@ private:
     std::vector<uint32_t> m_block_selector_cluster_index;
 
     std::vector<stage_time> m_stage_times;
+    std::vector<bu_pixel_block> m_source_copy;  // see source_blocks_host()
 };
 
 } // namespace bu

@@ -35,6 +35,8 @@ template <typename T> T clampt(T v, T lo, T hi) { return v < lo ? lo : (v > hi ?
 
 } // namespace
 
+bu::etc1s_frontend* bu_frontend_object(bu_frontend* f) { return f ? &f->fe : nullptr; }  // for backend_capi.cpp
+
 extern "C" {
 
 bu_frontend* bu_frontend_create(void) { return new (std::nothrow) bu_frontend(); }

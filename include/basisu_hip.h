@@ -132,6 +132,11 @@ BU_HIP_API int bu_hip_k_generate_endpoint_codebook(bu_hip_context*, const void* 
 BU_HIP_API int bu_hip_k_refit_endpoints_given_selectors(bu_hip_context*, const void* d_pixel_blocks, const void* d_encoded_blocks, uint32_t n_clusters,
     const uint32_t* h_offsets, const uint32_t* d_offsets, const uint32_t* d_indices, int perceptual,
     uint8_t* d_params, uint64_t* d_err, uint8_t* d_valid, uint64_t* d_current_err);
+/* f2  the same fit at a chosen optimizer quality (BU_ETC_QUALITY_SLOW or _UBER), for basisu_frontend::reoptimize_remapped_endpoints
+ *     (frontend.cpp:2996-3104: slow below compression level 6), the backend's call back into the frontend. */
+BU_HIP_API int bu_hip_k_refit_endpoints_given_selectors_q(bu_hip_context*, const void* d_pixel_blocks, const void* d_encoded_blocks, uint32_t n_clusters,
+    const uint32_t* h_offsets, const uint32_t* d_offsets, const uint32_t* d_indices, int quality, int perceptual,
+    uint8_t* d_params, uint64_t* d_err, uint8_t* d_valid, uint64_t* d_current_err);
 /* a15 compute_endpoint_subblock_error_vec (frontend.cpp:1006-1091): u64 error of every training vector (block*2+subblock) under the
  *     endpoints of its block's cluster; feeds introduce_new_endpoint_clusters. d_out_err: 2*n_blocks entries. */
 BU_HIP_API int bu_hip_k_subblock_errors(bu_hip_context*, const void* d_pixel_blocks, uint32_t n_blocks, const uint32_t* d_block_cluster,

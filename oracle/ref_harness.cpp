@@ -53,6 +53,7 @@ struct frontend_handle {
 	job_pool jp;
 	std::vector<pixel_block> blocks;
 	basisu_frontend::params p;
+	std::unique_ptr<basisu_backend> be;  // see ref_backend_run
 	frontend_handle() : jp(1) {}
 };
 
@@ -368,6 +369,68 @@ REF_API uint32_t ref_backend_encode(void* hv, uint32_t num_blocks_x, uint32_t nu
 	const uint32_t bytes = be.encode();
 	if (seconds) *seconds = tm.get_elapsed_secs();
 	return bytes;
+}
+
+// basisu_backend::encode() on a finished frontend with any number of slices (slices = n x {first_block_index, num_blocks_x, num_blocks_y});
+// the backend stays alive in the handle so that ref_backend_get can serialise its output (basisu_backend_output, backend.h:218-276) and
+// its per-block state. At compression levels above 1 this MODIFIES the frontend (reoptimize_remapped_endpoints), as the reference does.
+REF_API uint32_t ref_backend_run(void* hv, const uint32_t* slices3, uint32_t n_slices, float endpoint_rdo_thresh, float selector_rdo_thresh, double* seconds) {
+	frontend_handle* h = static_cast<frontend_handle*>(hv);
+	h->be.reset(new basisu_backend());
+	basisu_backend_params bp;
+	bp.m_etc1s = true;
+	bp.m_compression_level = h->p.m_compression_level;
+	bp.m_endpoint_rdo_quality_thresh = endpoint_rdo_thresh;
+	bp.m_selector_rdo_quality_thresh = selector_rdo_thresh;
+	basisu_backend_slice_desc_vec slices(n_slices);
+	for (uint32_t i = 0; i < n_slices; i++) {
+		const uint32_t nbx = slices3[i * 3 + 1], nby = slices3[i * 3 + 2];
+		slices[i].m_first_block_index = slices3[i * 3];
+		slices[i].m_orig_width = slices[i].m_width = nbx * 4;
+		slices[i].m_orig_height = slices[i].m_height = nby * 4;
+		slices[i].m_num_blocks_x = nbx;
+		slices[i].m_num_blocks_y = nby;
+		slices[i].m_num_macroblocks_x = (nbx + 1) / 2;
+		slices[i].m_num_macroblocks_y = (nby + 1) / 2;
+		slices[i].m_source_file_index = i;
+		slices[i].m_iframe = true;
+	}
+	h->be->init(&h->fe, bp, slices);
+	interval_timer tm;
+	tm.start();
+	const uint32_t bytes = h->be->encode();
+	if (seconds) *seconds = tm.get_elapsed_secs();
+	return bytes;
+}
+
+REF_API uint64_t ref_backend_get(void* hv, const char* name, uint32_t slice, void* buf, uint64_t cap) {
+	frontend_handle* h = static_cast<frontend_handle*>(hv);
+	if (!h->be) return ~0ull;
+	const basisu_backend& be = *h->be;
+	const basisu_backend_output& o = be.get_output();
+	const std::string n(name);
+	auto bytes = [&](const uint8_vec& v) -> uint64_t { if (buf && cap >= v.size() && v.size()) memcpy(buf, v.data(), v.size()); return v.size(); };
+	if (n == "endpoint_palette") return bytes(o.m_endpoint_palette);
+	if (n == "selector_palette") return bytes(o.m_selector_palette);
+	if (n == "slice_image_tables") return bytes(o.m_slice_image_tables);
+	if (n == "slice_image_data") return slice < o.m_slice_image_data.size() ? bytes(o.m_slice_image_data[slice]) : ~0ull;
+	if (n == "slice_image_crcs") { std::vector<uint16_t> v(o.m_slice_image_crcs.begin(), o.m_slice_image_crcs.end()); return emit(v, buf, cap); }
+	if (n == "num_endpoints") return emit(std::vector<uint32_t>{o.m_num_endpoints}, buf, cap);
+	if (n == "num_selectors") return emit(std::vector<uint32_t>{o.m_num_selectors}, buf, cap);
+	if (n == "encoder_blocks") {  // u32 x 4 per block in block order: endpoint index, predictor, selector index, history index + 1
+		std::vector<uint32_t> v((size_t)h->fe.m_total_blocks * 4, 0);
+		for (uint32_t s = 0; s < be.m_slices.size(); s++)
+			for (uint32_t y = 0; y < be.m_slices[s].m_num_blocks_y; y++)
+				for (uint32_t x = 0; x < be.m_slices[s].m_num_blocks_x; x++) {
+					const encoder_block& m = be.m_slice_encoder_blocks[s](x, y);
+					const size_t i = (size_t)be.m_slices[s].m_first_block_index + x + (size_t)y * be.m_slices[s].m_num_blocks_x;
+					v[i * 4] = m.m_endpoint_index; v[i * 4 + 1] = m.m_endpoint_predictor; v[i * 4 + 2] = m.m_selector_index; v[i * 4 + 3] = (uint32_t)(m.m_selector_history_buf_index + 1);
+				}
+		return emit(v, buf, cap);
+	}
+	if (n == "endpoint_remap_old_to_new") { std::vector<uint32_t> v(be.m_endpoint_remap_table_old_to_new.begin(), be.m_endpoint_remap_table_old_to_new.end()); return emit(v, buf, cap); }
+	if (n == "selector_remap_new_to_old") { std::vector<uint32_t> v(be.m_selector_remap_table_new_to_old.begin(), be.m_selector_remap_table_new_to_old.end()); return emit(v, buf, cap); }
+	return ~0ull;
 }
 
 // ---------------------------------------------------------------- UASTC

@@ -205,6 +205,24 @@ class RefFrontend:
         return {"endpoint_index": ep, "predictor": pred, "selector_index": sel, "endpoint_old_to_new": o2n[o2n != 0xFFFFFFFF],
                 "selector_new_to_old": n2o[n2o != 0xFFFFFFFF], "seconds": secs.value}
 
+    def backend_run(self, slices, endpoint_thresh=1.5, selector_thresh=1.25):
+        """basisu_backend::encode on the finished frontend; slices = [(first_block, nbx, nby), ...]. Returns (bytes, seconds)."""
+        sl = np.ascontiguousarray(np.asarray(slices, np.uint32).reshape(-1, 3))
+        self.L.ref_backend_run.restype = C.c_uint32
+        self.L.ref_backend_run.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_float, C.c_float, C.c_void_p]
+        secs = C.c_double(0)
+        n = self.L.ref_backend_run(self.h, sl.ctypes.data_as(C.c_void_p), sl.shape[0], endpoint_thresh, selector_thresh, C.byref(secs))
+        return n, secs.value
+
+    def backend_get(self, name, slice_index=0, dtype=np.uint8):
+        self.L.ref_backend_get.restype = C.c_uint64
+        self.L.ref_backend_get.argtypes = [C.c_void_p, C.c_char_p, C.c_uint32, C.c_void_p, C.c_uint64]
+        need = self.L.ref_backend_get(self.h, name.encode(), slice_index, None, 0)
+        assert need != 2 ** 64 - 1, name
+        buf = np.zeros(need, np.uint8)
+        self.L.ref_backend_get(self.h, name.encode(), slice_index, buf.ctypes.data_as(C.c_void_p), need)
+        return buf.view(dtype)
+
     def close(self):
         if self.h:
             self.L.ref_frontend_destroy(self.h)
