@@ -1,0 +1,77 @@
+"""-m gpu: the whole ETC1S encoder path -- resident frontend (HIP kernels) followed by the host backend (bu::etc1s_backend) -- against the
+real reference frontend + basisu_backend::encode() (oracle/_ref): every output byte and the per-block state. At compression levels above 1
+the backend calls back into the frontend (reoptimize_remapped_endpoints -> the forced-selector cluster fit on the device), so the frontend
+state AFTER the backend is compared as well."""
+import numpy as np
+import pytest
+
+from helpers import have_ref, RefFrontend, synth, uniform_random, to_pixel_blocks
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not have_ref(), reason="oracle/_ref not present")]
+
+OUTPUTS = ["endpoint_palette", "selector_palette", "slice_image_tables", "slice_image_crcs", "num_endpoints", "num_selectors",
+           "encoder_blocks", "endpoint_remap_old_to_new", "selector_remap_new_to_old"]
+FRONTEND_AFTER = ["endpoint_cluster_etc_params", "block_endpoint_clusters_indices", "encoded_blocks"]
+
+CASES = {
+    # name: (image, max_ep, max_sel, level, perceptual, slices, endpoint thresh, selector thresh)
+    "l1": (lambda: synth(256, 192, 1234), 400, 500, 1, True, [(0, 64, 48)], 1.5, 1.25),
+    "l2": (lambda: synth(256, 192, 11), 300, 300, 2, True, [(0, 64, 48)], 1.5, 1.25),
+    "l2_linear_two_slices": (lambda: synth(256, 192, 12), 300, 400, 2, False, [(0, 64, 32), (2048, 64, 16)], 1.5, 1.25),
+    "l3_strong_rdo": (lambda: synth(192, 128, 13), 200, 256, 3, True, [(0, 48, 32)], 3.0, 2.0),
+    "l4": (lambda: synth(192, 128, 14), 200, 200, 4, True, [(0, 48, 32)], 1.5, 1.25),
+    "l6": (lambda: synth(128, 128, 15), 128, 160, 6, True, [(0, 32, 32)], 1.5, 1.25),
+    "noise_l2": (lambda: uniform_random(96, 64, 7), 100, 100, 2, True, [(0, 24, 16)], 2.0, 1.5),
+    "l2_no_rdo": (lambda: synth(128, 128, 16), 128, 128, 2, True, [(0, 32, 32)], 0.0, 0.0),
+}
+
+
+def _canon(name, a):
+    if name == "endpoint_cluster_etc_params":
+        a = a.reshape(-1, 16).copy(); a[:, 4:8] = 0
+    return a
+
+
+@pytest.mark.parametrize("case", sorted(CASES))
+def test_frontend_plus_backend_matches_reference(hip_ctx, case):
+    from basis_universal_amd.etc1s import Etc1sFrontend
+    from basis_universal_amd.backend import Etc1sBackend
+    img_fn, max_ep, max_sel, level, perceptual, slices, ept, selt = CASES[case]
+    blocks = to_pixel_blocks(img_fn())
+    fe = Etc1sFrontend(hip_ctx)
+    fe.init(blocks, max_ep, max_sel, level, perceptual)
+    fe.compress()
+    be = Etc1sBackend.from_frontend(fe, slices, ept, selt, level)
+    total = be.encode()
+    ref = RefFrontend(blocks, max_ep, max_sel, level, perceptual)
+    ref.call("compress")
+    ref_total, _ = ref.backend_run(slices, ept, selt)
+    assert total == ref_total
+    for k in OUTPUTS:
+        a, b = be.get(k), ref.backend_get(k)
+        assert a.shape == b.shape and (a == b).all(), k
+    for s in range(len(slices)):
+        a, b = be.get("slice_image_data", s), ref.backend_get("slice_image_data", s)
+        assert a.shape == b.shape and (a == b).all(), ("slice_image_data", s)
+    for k in FRONTEND_AFTER:
+        a, b = _canon(k, fe.get(k)), _canon(k, ref.get(k))
+        assert a.shape == b.shape and (a == b).all(), ("frontend after backend", k)
+    be.close(); fe.close(); ref.close()
+
+
+def test_backend_on_device_only_tiles(hip_ctx):
+    """The frontend was given tiles that live in HBM only: the backend fetches its host copy through the frontend."""
+    from basis_universal_amd.etc1s import Etc1sFrontend
+    from basis_universal_amd.backend import Etc1sBackend
+    blocks = to_pixel_blocks(synth(128, 96, 5))
+    d = hip_ctx.upload(blocks)
+    fe = Etc1sFrontend(hip_ctx)
+    fe.init(d, 100, 100, 1, True, n_blocks=blocks.shape[0])
+    fe.compress()
+    be = Etc1sBackend.from_frontend(fe, [(0, 32, 24)], 1.5, 1.25, 1)
+    total = be.encode()
+    ref = RefFrontend(blocks, 100, 100, 1, True)
+    ref.call("compress")
+    assert total == ref.backend_run([(0, 32, 24)])[0]
+    assert (be.get("slice_image_data") == ref.backend_get("slice_image_data")).all()
+    be.close(); fe.close(); hip_ctx.free(d); ref.close()
