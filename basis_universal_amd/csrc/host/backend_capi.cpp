@@ -5,6 +5,7 @@
 #include <vector>
 
 #include "../../../include/basisu_hip_backend.h"
+#include "entropy.h"
 #include "etc1s_backend.h"
 #include "etc1s_frontend.h"
 
@@ -106,6 +107,24 @@ uint32_t bu_backend_stage_times(const bu_backend* b, const char** names, double*
     const auto& t = b->be.stage_times();
     for (uint32_t i = 0; i < t.size() && i < cap; i++) { names[i] = t[i].name; seconds[i] = t[i].seconds; }
     return (uint32_t)t.size();
+}
+
+// ---- test hooks: the coding tools on their own (tests/test_backend_host.py diffs them against the reference's)
+uint64_t bu_backend_test_huffman(const uint32_t* freq, uint32_t n, uint32_t max_code_size, uint8_t* out_sizes, uint16_t* out_codes, uint8_t* out_bytes, uint64_t cap) {
+    bu::huffman_table t;
+    if (!t.init(freq, n, max_code_size)) return ~0ull;
+    for (uint32_t i = 0; i < n; i++) { out_sizes[i] = t.sizes()[i]; out_codes[i] = t.codes()[i]; }
+    bu::bit_writer w;
+    w.restart();
+    if (!w.put_table(t)) return ~0ull;
+    w.put_vlc(n, 4);
+    w.flush();
+    return emit(w.bytes(), out_bytes, cap);
+}
+uint32_t bu_backend_test_crc16(const uint8_t* data, uint64_t size, uint32_t crc) { return bu::crc16_ccitt(data, (size_t)size, (uint16_t)crc); }
+void bu_backend_test_reorder(const uint32_t* indices, uint32_t num_indices, uint32_t num_syms, uint32_t* out_old_to_new) {
+    const std::vector<uint32_t> r = bu::reorder_palette_by_adjacency(indices, num_indices, num_syms);
+    std::memcpy(out_old_to_new, r.data(), r.size() * sizeof(uint32_t));
 }
 
 }  // extern "C"

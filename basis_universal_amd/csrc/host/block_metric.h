@@ -1,0 +1,142 @@
+// block_metric.h -- the backend's inner loops: error of a 4x4 block against four ETC1S block colours under given selectors, in the
+// reference's integer colour metric (color_distance, encoder/basisu_enc.h:1141-1195; linear: sum of squared differences).
+//
+// The metric is separable once a colour is moved to (l, cr, cb) = (14r+45g+5b, 64r-l, 64b-l): a distance is three squares. Every
+// value below fits 32 bits (|dl| <= 16320, |dcr|,|dcb| <= 32640; one perceptual distance < 41e6, sixteen of them < 2^32), so the same
+// arithmetic runs in 32-bit SIMD lanes. There are two implementations of each loop, plain C++ and AVX2 (picked once at run time;
+// BU_BACKEND_NO_AVX2=1 forces the plain one); they are integer-exact and therefore interchangeable, which tests/test_backend_host.py
+// checks by running both.
+#pragma once
+#include <immintrin.h>
+
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+
+namespace bu {
+namespace metric {
+
+struct alignas(32) block_px { int32_t x[16], y[16], z[16]; };     // the 16 source pixels, pixel p = y*4+x
+struct alignas(16) pal_colors { int32_t x[4], y[4], z[4]; };      // the four block colours of one (colour5, intensity table)
+struct alignas(32) dist_table { uint32_t d[4][16]; };             // d[k][p]: pixel p against block colour k
+struct alignas(16) sel16 { uint8_t s[16]; };                      // 16 selectors, one per byte
+
+inline void to_metric(bool perceptual, int r, int g, int b, int32_t& x, int32_t& y, int32_t& z) {
+    if (perceptual) { const int l = r * 14 + g * 45 + b * 5; x = l; y = r * 64 - l; z = b * 64 - l; }
+    else { x = r; y = g; z = b; }
+}
+inline uint32_t dist1(bool perceptual, int dx, int dy, int dz) {
+    if (perceptual) return ((uint32_t)(dx * dx) >> 5) + ((((uint32_t)(dy * dy) >> 5) * 26u) >> 7) + ((((uint32_t)(dz * dz) >> 5) * 3u) >> 7);
+    return (uint32_t)(dx * dx + dy * dy + dz * dz);
+}
+inline sel16 unpack_selectors(uint32_t packed) {
+    sel16 o;
+    for (int p = 0; p < 16; p++) o.s[p] = (uint8_t)((packed >> (2 * p)) & 3);
+    return o;
+}
+
+// ---- plain C++
+inline uint64_t block_error_plain(bool perceptual, const block_px& px, const pal_colors& c, const sel16& sel) {
+    uint64_t e = 0;
+    for (int p = 0; p < 16; p++) { const int k = sel.s[p]; e += dist1(perceptual, px.x[p] - c.x[k], px.y[p] - c.y[k], px.z[p] - c.z[k]); }
+    return e;
+}
+inline void build_table_plain(bool perceptual, const block_px& px, const pal_colors& c, dist_table& t) {
+    for (int k = 0; k < 4; k++)
+        for (int p = 0; p < 16; p++) t.d[k][p] = dist1(perceptual, px.x[p] - c.x[k], px.y[p] - c.y[k], px.z[p] - c.z[k]);
+}
+// Sum over the pixels of d[selector][pixel]. `bound`: the caller only cares about results <= bound; once the first eight pixels alone
+// exceed it the partial sum is returned (any value > bound does).
+inline uint64_t table_error_plain(const dist_table& t, const sel16& sel, uint64_t bound) {
+    uint64_t e = 0;
+    for (int p = 0; p < 8; p++) e += t.d[sel.s[p]][p];
+    if (e > bound) return e;
+    for (int p = 8; p < 16; p++) e += t.d[sel.s[p]][p];
+    return e;
+}
+
+// ---- AVX2
+#define BU_AVX2 __attribute__((target("avx2")))
+BU_AVX2 inline __m256i dist8(bool perceptual, __m256i dx, __m256i dy, __m256i dz) {
+    const __m256i xx = _mm256_mullo_epi32(dx, dx), yy = _mm256_mullo_epi32(dy, dy), zz = _mm256_mullo_epi32(dz, dz);
+    if (!perceptual) return _mm256_add_epi32(_mm256_add_epi32(xx, yy), zz);
+    const __m256i l = _mm256_srli_epi32(xx, 5);
+    const __m256i cr = _mm256_srli_epi32(_mm256_mullo_epi32(_mm256_srli_epi32(yy, 5), _mm256_set1_epi32(26)), 7);
+    const __m256i cb = _mm256_srli_epi32(_mm256_mullo_epi32(_mm256_srli_epi32(zz, 5), _mm256_set1_epi32(3)), 7);
+    return _mm256_add_epi32(_mm256_add_epi32(l, cr), cb);
+}
+BU_AVX2 inline uint32_t hsum8(__m256i v) {
+    __m128i s = _mm_add_epi32(_mm256_castsi256_si128(v), _mm256_extracti128_si256(v, 1));
+    s = _mm_add_epi32(s, _mm_shuffle_epi32(s, 0x4E));
+    s = _mm_add_epi32(s, _mm_shuffle_epi32(s, 0xB1));
+    return (uint32_t)_mm_cvtsi128_si32(s);
+}
+BU_AVX2 inline uint64_t block_error_avx2(bool perceptual, const block_px& px, const pal_colors& c, const sel16& sel) {
+    const __m256i cx = _mm256_castsi128_si256(_mm_load_si128((const __m128i*)c.x)), cy = _mm256_castsi128_si256(_mm_load_si128((const __m128i*)c.y)),
+                  cz = _mm256_castsi128_si256(_mm_load_si128((const __m128i*)c.z));
+    const __m128i s = _mm_load_si128((const __m128i*)sel.s);
+    __m256i acc = _mm256_setzero_si256();
+    for (int h = 0; h < 2; h++) {
+        const __m256i idx = _mm256_cvtepu8_epi32(h ? _mm_srli_si128(s, 8) : s);
+        const __m256i dx = _mm256_sub_epi32(_mm256_load_si256((const __m256i*)(px.x + 8 * h)), _mm256_permutevar8x32_epi32(cx, idx));
+        const __m256i dy = _mm256_sub_epi32(_mm256_load_si256((const __m256i*)(px.y + 8 * h)), _mm256_permutevar8x32_epi32(cy, idx));
+        const __m256i dz = _mm256_sub_epi32(_mm256_load_si256((const __m256i*)(px.z + 8 * h)), _mm256_permutevar8x32_epi32(cz, idx));
+        acc = _mm256_add_epi32(acc, dist8(perceptual, dx, dy, dz));
+    }
+    return hsum8(acc);
+}
+BU_AVX2 inline void build_table_avx2(bool perceptual, const block_px& px, const pal_colors& c, dist_table& t) {
+    for (int k = 0; k < 4; k++) {
+        const __m256i cx = _mm256_set1_epi32(c.x[k]), cy = _mm256_set1_epi32(c.y[k]), cz = _mm256_set1_epi32(c.z[k]);
+        for (int h = 0; h < 2; h++) {
+            const __m256i dx = _mm256_sub_epi32(_mm256_load_si256((const __m256i*)(px.x + 8 * h)), cx);
+            const __m256i dy = _mm256_sub_epi32(_mm256_load_si256((const __m256i*)(px.y + 8 * h)), cy);
+            const __m256i dz = _mm256_sub_epi32(_mm256_load_si256((const __m256i*)(px.z + 8 * h)), cz);
+            _mm256_store_si256((__m256i*)(t.d[k] + 8 * h), dist8(perceptual, dx, dy, dz));
+        }
+    }
+}
+BU_AVX2 inline __m256i table_half_avx2(const dist_table& t, __m128i sel8, int h) {
+    const __m256i idx = _mm256_cvtepu8_epi32(sel8);
+    __m256i acc = _mm256_and_si256(_mm256_cmpeq_epi32(idx, _mm256_setzero_si256()), _mm256_load_si256((const __m256i*)(t.d[0] + 8 * h)));
+    for (int k = 1; k < 4; k++)
+        acc = _mm256_add_epi32(acc, _mm256_and_si256(_mm256_cmpeq_epi32(idx, _mm256_set1_epi32(k)), _mm256_load_si256((const __m256i*)(t.d[k] + 8 * h))));
+    return acc;
+}
+BU_AVX2 inline uint64_t table_error_avx2(const dist_table& t, const sel16& sel, uint64_t bound) {
+    const __m128i s = _mm_load_si128((const __m128i*)sel.s);
+    const __m256i lo = table_half_avx2(t, s, 0);
+    if (bound != UINT64_MAX) { const uint64_t e = hsum8(lo); if (e > bound) return e; }
+    return hsum8(_mm256_add_epi32(lo, table_half_avx2(t, _mm_srli_si128(s, 8), 1)));
+}
+#undef BU_AVX2
+
+// sum over the pixels of |selector difference| (SSE2: part of the x86-64 baseline)
+inline int selector_sad(const sel16& a, const sel16& b) {
+    const __m128i s = _mm_sad_epu8(_mm_load_si128((const __m128i*)a.s), _mm_load_si128((const __m128i*)b.s));
+    return _mm_cvtsi128_si32(s) + _mm_cvtsi128_si32(_mm_srli_si128(s, 8));
+}
+// first j in [0, 64) with v[j] == x, or -1
+inline int find_first_64(const int* v, int x) {
+    const __m128i key = _mm_set1_epi32(x);
+    for (int j = 0; j < 64; j += 4) {
+        const int m = _mm_movemask_ps(_mm_castsi128_ps(_mm_cmpeq_epi32(_mm_loadu_si128((const __m128i*)(v + j)), key)));
+        if (m) return j + __builtin_ctz((unsigned)m);
+    }
+    return -1;
+}
+
+struct kernels {
+    uint64_t (*block_error)(bool, const block_px&, const pal_colors&, const sel16&);
+    void (*build_table)(bool, const block_px&, const pal_colors&, dist_table&);
+    uint64_t (*table_error)(const dist_table&, const sel16&, uint64_t);
+    bool avx2;
+};
+inline kernels pick_kernels() {
+    const char* off = std::getenv("BU_BACKEND_NO_AVX2");
+    if (__builtin_cpu_supports("avx2") && !(off && off[0] == '1')) return kernels{block_error_avx2, build_table_avx2, table_error_avx2, true};
+    return kernels{block_error_plain, build_table_plain, table_error_plain, false};
+}
+
+}  // namespace metric
+}  // namespace bu

@@ -3,8 +3,10 @@
 // How the walk differs from the reference's while producing the same bytes:
 //  * one flat block array and one token stream per slice, written in bit-stream order (run tokens are placeholders patched when the
 //    run ends) instead of symbol vectors that a second walk over the blocks re-synchronises with;
-//  * the selector-history search looks a candidate's error up in a 16x4 table of the block's pixel-to-colour distances (64 distance
-//    evaluations per block instead of up to 16 per candidate and 64 candidates), and pre-filters candidates on packed selectors;
+//  * the selector-history search looks a candidate's error up in a 4x16 table of the block's pixel-to-colour distances (64 distance
+//    evaluations per block instead of up to 16 per candidate and 64 candidates), and pre-filters candidates with one SAD instruction;
+//  * the error loops run 8 pixels per instruction where the CPU has AVX2 (block_metric.h), the palette's block colours are converted to
+//    the metric's basis once per palette, not once per trial;
 //  * the palette reordering keeps the symbol adjacency counts as sparse lists instead of a dense num_syms^2 matrix (1 GB at 16128).
 #include "etc1s_backend.h"
 
@@ -14,6 +16,9 @@
 #include <cstring>
 #include <deque>
 
+#include <cstdio>
+#include <cstdlib>
+#include "block_metric.h"
 #include "entropy.h"
 #include "etc1s_frontend.h"
 
@@ -59,56 +64,26 @@ inline color5 header_of(const bu_etc_block& blk) {
     return color5{(uint8_t)((v >> 59) & 31), (uint8_t)((v >> 51) & 31), (uint8_t)((v >> 43) & 31), (uint8_t)((v >> 37) & 7)};
 }
 
-// The colour metric (enc.h:1141-1195) in the basis it is separable in: a colour becomes (l, cr, cb) once, a distance is three squares.
-struct cvec { int x, y, z; };
-template <bool P> inline cvec to_cvec(int r, int g, int b) {
-    if (P) { const int l = r * 14 + g * 45 + b * 5; return cvec{l, r * 64 - l, b * 64 - l}; }
-    return cvec{r, g, b};
-}
-template <bool P> inline uint32_t cdist(const cvec& a, const cvec& b) {
-    const int dx = a.x - b.x, dy = a.y - b.y, dz = a.z - b.z;
-    if (P) return ((uint32_t)(dx * dx) >> 5) + ((((uint32_t)(dy * dy) >> 5) * 26u) >> 7) + ((((uint32_t)(dz * dz) >> 5) * 3u) >> 7);
-    return (uint32_t)(dx * dx + dy * dy + dz * dz);
-}
-template <bool P> inline void block_colors(cvec out[4], color5 c) {  // etc.h:584-602
-    const int r = (c.r << 3) | (c.r >> 2), g = (c.g << 3) | (c.g >> 2), b = (c.b << 3) | (c.b >> 2);
-    for (int s = 0; s < 4; s++) { const int d = kInten[c.inten][s]; out[s] = to_cvec<P>(clamp255(r + d), clamp255(g + d), clamp255(b + d)); }
-}
-template <bool P> inline void pixel_cvecs(cvec out[16], const bu_pixel_block& px) {
-    for (int p = 0; p < 16; p++) out[p] = to_cvec<P>(px.m_pixels[p][0], px.m_pixels[p][1], px.m_pixels[p][2]);
-}
-// error of (colour, table) with the given selectors over the block = etc_block::evaluate_etc1_error for an ETC1S block
-template <bool P> inline uint64_t block_error(const cvec px[16], color5 c, uint32_t sels) {
-    cvec bc[4];
-    block_colors<P>(bc, c);
-    uint64_t e = 0;
-    for (int p = 0; p < 16; p++) e += cdist<P>(px[p], bc[(sels >> (2 * p)) & 3]);
-    return e;
-}
+using metric::block_px;
+using metric::pal_colors;
+using metric::sel16;
 
-// sum over the 16 pixels of |selector difference|, four selectors per byte
-struct sel_diff_table {
-    uint8_t v[256][256];
-    sel_diff_table() {
-        for (int a = 0; a < 256; a++)
-            for (int b = 0; b < 256; b++) {
-                int s = 0;
-                for (int k = 0; k < 4; k++) s += std::abs(((a >> (2 * k)) & 3) - ((b >> (2 * k)) & 3));
-                v[a][b] = (uint8_t)s;
-            }
-    }
-};
-inline int sel_diff(const sel_diff_table& t, uint32_t a, uint32_t b) {
-    return t.v[a & 255][b & 255] + t.v[(a >> 8) & 255][(b >> 8) & 255] + t.v[(a >> 16) & 255][(b >> 16) & 255] + t.v[a >> 24][b >> 24];
+inline void block_colors(bool perceptual, pal_colors& out, color5 c) {  // etc.h:584-602
+    const int r = (c.r << 3) | (c.r >> 2), g = (c.g << 3) | (c.g >> 2), b = (c.b << 3) | (c.b >> 2);
+    for (int k = 0; k < 4; k++) { const int d = kInten[c.inten][k]; metric::to_metric(perceptual, clamp255(r + d), clamp255(g + d), clamp255(b + d), out.x[k], out.y[k], out.z[k]); }
+}
+inline void load_pixels(bool perceptual, block_px& out, const bu_pixel_block& px) {
+    for (int p = 0; p < 16; p++) metric::to_metric(perceptual, px.m_pixels[p][0], px.m_pixels[p][1], px.m_pixels[p][2], out.x[p], out.y[p], out.z[p]);
 }
 
 // basist::approx_move_to_front (transcoder_internal.h:863-929)
 struct history_buffer {
     int v[kSelectorHistorySize];
+    sel16 sel[kSelectorHistorySize];   // the pattern behind every entry, kept in step
     uint32_t rover;
-    void reset() { std::memset(v, 0, sizeof(v)); rover = kSelectorHistorySize / 2; }
-    void add(int x) { v[rover++] = x; if (rover == kSelectorHistorySize) rover = kSelectorHistorySize / 2; }
-    void use(uint32_t i) { if (i) std::swap(v[i / 2], v[i]); }
+    void reset(const sel16& of_zero) { std::memset(v, 0, sizeof(v)); for (sel16& s : sel) s = of_zero; rover = kSelectorHistorySize / 2; }
+    void add(int x, const sel16& of_x) { v[rover] = x; sel[rover] = of_x; if (++rover == kSelectorHistorySize) rover = kSelectorHistorySize / 2; }
+    void use(uint32_t i) { if (i) { std::swap(v[i / 2], v[i]); std::swap(sel[i / 2], sel[i]); } }
 };
 
 enum token_kind : uint8_t { T_NONE, T_PRED, T_PRED_REPEAT, T_ENDPOINT_DELTA, T_SELECTOR, T_SELECTOR_RLE };
@@ -255,12 +230,21 @@ void etc1s_backend::create_endpoint_palette() {  // backend.cpp:77-94
         const uint8_t* e = m_src.endpoint_color5_inten + (size_t)i * 4;
         m_endpoint_palette[i] = endpoint_entry{e[0], e[1], e[2], e[3]};
     }
+    m_palette_colors.resize(m_src.total_endpoints);
+    for (uint32_t i = 0; i < m_src.total_endpoints; i++) {
+        const endpoint_entry& e = m_endpoint_palette[i];
+        block_colors(m_src.perceptual, m_palette_colors[i], color5{e.r, e.g, e.b, e.inten});
+    }
 }
 
 void etc1s_backend::create_selector_palette() {  // backend.cpp:96-118
     m_output.m_num_selectors = m_src.total_selectors;
     m_selector_palette.resize(m_src.total_selectors);
-    for (uint32_t i = 0; i < m_src.total_selectors; i++) m_selector_palette[i] = packed_selectors(m_src.selector_blocks[i]);
+    m_selector_bytes.resize(m_src.total_selectors);
+    for (uint32_t i = 0; i < m_src.total_selectors; i++) {
+        m_selector_palette[i] = packed_selectors(m_src.selector_blocks[i]);
+        m_selector_bytes[i] = metric::unpack_selectors(m_selector_palette[i]);
+    }
 }
 
 // backend.cpp:406-617: every block is predicted from its left, upper or upper-left neighbour when that one uses the same endpoints;
@@ -273,6 +257,7 @@ bool etc1s_backend::create_encoder_blocks() {
     all_endpoint_indices.reserve(total);
     const float thresh = m_params.m_endpoint_rdo_quality_thresh;
     const bool perceptual = m_src.perceptual;
+    const metric::kernels K = metric::pick_kernels();
     for (const backend_slice_desc& s : m_slices) {
         const uint32_t nbx = s.m_num_blocks_x, nby = s.m_num_blocks_y;
         if ((uint64_t)s.m_first_block_index + (uint64_t)nbx * nby > total) return fail("slice exceeds the frontend's blocks");
@@ -297,20 +282,20 @@ bool etc1s_backend::create_encoder_blocks() {
                 if (best_pred != UINT32_MAX) {
                     m.endpoint_predictor = (uint8_t)best_pred;
                 } else if (thresh > 0.0f) {
-                    cvec px[16];
-                    if (perceptual) pixel_cvecs<true>(px, m_src.source_blocks[b]); else pixel_cvecs<false>(px, m_src.source_blocks[b]);
+                    block_px px;
+                    load_pixels(perceptual, px, m_src.source_blocks[b]);
                     const bu_etc_block& out = m_src.output_blocks[b];
-                    const uint32_t sels = packed_selectors(out);
-                    const uint64_t cur_err = perceptual ? block_error<true>(px, header_of(out), sels) : block_error<false>(px, header_of(out), sels);
+                    const sel16 sels = metric::unpack_selectors(packed_selectors(out));
+                    pal_colors own;
+                    block_colors(perceptual, own, header_of(out));
+                    const uint64_t cur_err = K.block_error(perceptual, px, own, sels);
                     if (cur_err) {
                         const uint64_t thresh_err = (uint64_t)(cur_err * std::max(1.0f, thresh));
                         uint64_t best_err = UINT64_MAX;
                         uint32_t best_index = 0;
                         for (uint32_t p = 0; p < kNumEndpointPreds; p++) {
                             if (!present[p]) continue;
-                            const endpoint_entry& e = m_endpoint_palette[neighbour[p]];
-                            const color5 c{e.r, e.g, e.b, e.inten};
-                            const uint64_t err = perceptual ? block_error<true>(px, c, sels) : block_error<false>(px, c, sels);
+                            const uint64_t err = K.block_error(perceptual, px, m_palette_colors[neighbour[p]], sels);
                             if (err <= thresh_err && err < best_err) { best_err = err; best_pred = p; best_index = neighbour[p]; }  // ascending p: ties keep the lower predictor
                         }
                         if (best_pred != UINT32_MAX) {
@@ -424,18 +409,33 @@ bool etc1s_backend::encode_image() {
     std::vector<std::vector<token>> slice_tokens(m_slices.size());
     std::vector<uint32_t> block_endpoint_indices(m_src.total_blocks, 0), block_selector_indices(m_src.total_blocks, 0);
     uint32_t endpoints_remapped = 0;
-    static const sel_diff_table diff_table;
+    const metric::kernels K = metric::pick_kernels();
     const float selector_thresh = std::max(1.0f, m_params.m_selector_rdo_quality_thresh);
     const float endpoint_thresh = std::max(1.0f, m_params.m_endpoint_rdo_quality_thresh);
     const int max_search = level >= 2 ? 64 : 16;  // backend.cpp:852
+    // the endpoint search walks consecutive NEW indices: the palette in that order, unused slots flagged (backend.cpp:874-879)
+    struct sorted_entry { uint8_t r, g, b, inten, used; };
+    std::vector<sorted_entry> sorted_palette(n_ep);
+    std::vector<pal_colors> sorted_colors(n_ep);
+    for (uint32_t nw = 0; nw < n_ep; nw++) {
+        const endpoint_entry& e = m_endpoint_palette[m_endpoint_new_to_old[nw]];
+        sorted_palette[nw] = sorted_entry{e.r, e.g, e.b, e.inten, m_new_endpoint_was_used[nw]};
+        sorted_colors[nw] = m_palette_colors[m_endpoint_new_to_old[nw]];
+    }
     history_buffer history;
+#ifdef BU_BACKEND_TICKS
+    uint64_t tk[8] = {0}, tk0 = 0;
+#define TK(i) do { const uint64_t n__ = __rdtsc(); tk[i] += n__ - tk0; tk0 = n__; } while (0)
+#else
+#define TK(i) do {} while (0)
+#endif
 
     for (size_t si = 0; si < m_slices.size(); si++) {
         const backend_slice_desc& s = m_slices[si];
         const uint32_t nbx = s.m_num_blocks_x, nby = s.m_num_blocks_y, base = s.m_first_block_index;
         std::vector<token>& tokens = slice_tokens[si];
         tokens.reserve((size_t)nbx * nby * 2 + 16);
-        history.reset();
+        history.reset(m_selector_bytes[m_selector_new_to_old[0]]);
         // blocks whose endpoints a later block is predicted from must keep them (backend.cpp:740-766)
         std::vector<uint8_t> referenced((size_t)nbx * nby, 0);
         for (uint32_t by = 0; by < nby; by++)
@@ -476,6 +476,9 @@ bool etc1s_backend::encode_image() {
             for (uint32_t bx = 0; bx < nbx; bx++) {
                 const uint32_t b = base + bx + by * nbx;
                 encoder_block& m = m_blocks[b];
+#ifdef BU_BACKEND_TICKS
+                tk0 = __rdtsc();
+#endif
                 // ---- one endpoint-predictor symbol per 2x2 macroblock, runs of equal symbols collapsed (backend.cpp:776-827)
                 if (!(bx & 1) && !(by & 1)) {
                     uint32_t sym = 0;
@@ -495,11 +498,12 @@ bool etc1s_backend::encode_image() {
                         prev_pred_sym = (int)sym;
                     }
                 }
+                TK(0);
                 // ---- endpoint index, as a delta to the previous block's in the sorted palette (backend.cpp:829-1009)
                 int new_endpoint = (int)m_endpoint_old_to_new[m.endpoint_index];
-                cvec px[16];
+                block_px px;
                 bool have_px = false;
-                auto need_px = [&]() { if (!have_px) { if (perceptual) pixel_cvecs<true>(px, m_src.source_blocks[b]); else pixel_cvecs<false>(px, m_src.source_blocks[b]); have_px = true; } };
+                auto need_px = [&]() { if (!have_px) { load_pixels(perceptual, px, m_src.source_blocks[b]); have_px = true; } };
                 if (m.endpoint_predictor == kNoEndpointPred) {
                     int delta = new_endpoint - (int)prev_endpoint;
                     if (m_params.m_endpoint_rdo_quality_thresh > 1.0f && std::abs(delta) > 1 && !referenced[bx + (size_t)by * nbx]) {
@@ -507,8 +511,11 @@ bool etc1s_backend::encode_image() {
                         need_px();
                         const bu_etc_block& out = m_src.output_blocks[b];
                         const color5 cur_c = header_of(out);
-                        const uint32_t sels = packed_selectors(out);
-                        const uint64_t cur_err = perceptual ? block_error<true>(px, cur_c, sels) : block_error<false>(px, cur_c, sels);
+                        const sel16 sels = metric::unpack_selectors(packed_selectors(out));
+                        pal_colors own;
+                        block_colors(perceptual, own, cur_c);
+                        const uint64_t cur_err = K.block_error(perceptual, px, own, sels);
+                        TK(1);
                         if (cur_err) {
                             const endpoint_entry cur_e = m_endpoint_palette[m.endpoint_index];
                             const uint64_t thresh_err = (uint64_t)(cur_err * endpoint_thresh);
@@ -518,14 +525,13 @@ bool etc1s_backend::encode_image() {
                             for (int d = -dist; d < dist; d++) {
                                 int trial = (int)prev_endpoint + d;
                                 if (trial < 0) trial += (int)n_ep; else if (trial >= (int)n_ep) trial -= (int)n_ep;
-                                if (trial == new_endpoint || !m_new_endpoint_was_used[trial]) continue;
-                                const endpoint_entry& p = m_endpoint_palette[m_endpoint_new_to_old[trial]];
+                                const sorted_entry& p = sorted_palette[trial];
+                                if (trial == new_endpoint || !p.used) continue;
                                 if (level <= 1) {
                                     if (p.inten > cur_c.inten) continue;
                                     if (std::abs((int)cur_e.r - p.r) + std::abs((int)cur_e.g - p.g) + std::abs((int)cur_e.b - p.b) > kColorDeltaThresh) continue;
                                 }
-                                const color5 c{p.r, p.g, p.b, p.inten};
-                                const uint64_t err = perceptual ? block_error<true>(px, c, sels) : block_error<false>(px, c, sels);
+                                const uint64_t err = K.block_error(perceptual, px, sorted_colors[trial], sels);
                                 if (err < best_err && err <= thresh_err) { best_err = err; best_idx = trial; }
                             }
                             if (best_err != UINT64_MAX) {
@@ -543,37 +549,30 @@ bool etc1s_backend::encode_image() {
                 block_endpoint_indices[b] = m_endpoint_new_to_old[new_endpoint];
                 prev_endpoint = (uint32_t)new_endpoint;
 
+                TK(2);
                 // ---- selector index: a recently used pattern (history buffer) that is good enough, else the block's own (backend.cpp:1011-1205)
                 int new_selector = (int)m_selector_old_to_new[m.selector_index];
-                int history_index = -1;
-                if (level <= 1) {
-                    for (uint32_t j = 0; j < kSelectorHistorySize; j++)
-                        if (history.v[j] == new_selector) { history_index = (int)j; break; }
-                }
+                int history_index = level <= 1 ? metric::find_first_64(history.v, new_selector) : -1;
+                TK(3);
                 if (history_index == -1) {
                     need_px();
-                    const endpoint_entry& q = m_endpoint_palette[m_endpoint_new_to_old[new_endpoint]];
-                    cvec bc[4];
-                    uint32_t dist[16][4];
-                    if (perceptual) { block_colors<true>(bc, color5{q.r, q.g, q.b, q.inten}); for (int p = 0; p < 16; p++) for (int k = 0; k < 4; k++) dist[p][k] = cdist<true>(px[p], bc[k]); }
-                    else { block_colors<false>(bc, color5{q.r, q.g, q.b, q.inten}); for (int p = 0; p < 16; p++) for (int k = 0; k < 4; k++) dist[p][k] = cdist<false>(px[p], bc[k]); }
-                    const uint32_t cur_sels = m_selector_palette[m.selector_index];
-                    uint64_t cur_err = 0;
-                    for (int p = 0; p < 16; p++) cur_err += dist[p][(cur_sels >> (2 * p)) & 3];
+                    metric::dist_table table;
+                    K.build_table(perceptual, px, m_palette_colors[m_endpoint_new_to_old[new_endpoint]], table);
+                    const sel16& cur_sels = m_selector_bytes[m.selector_index];
+                    const uint64_t cur_err = K.table_error(table, cur_sels, UINT64_MAX);
+                    TK(4);
                     const uint64_t limit_err = (uint64_t)ceilf(cur_err * selector_thresh);
                     uint64_t best_err = UINT64_MAX;
                     int best_idx = 0;
                     uint32_t best_j = 0;
                     for (uint32_t j = 0; j < kSelectorHistorySize; j++) {
-                        const int trial = history.v[j];
-                        const uint32_t sels = m_selector_palette[m_selector_new_to_old[trial]];
-                        if (level <= 1 && sel_diff(diff_table, cur_sels, sels) >= kSelDiffThreshold) continue;
-                        uint64_t err = 0;
-                        for (int p = 0; p < 16; p++) err += dist[p][(sels >> (2 * p)) & 3];
-                        if (err < best_err && err <= limit_err) { best_err = err; best_idx = trial; best_j = j; }
+                        if (level <= 1 && metric::selector_sad(cur_sels, history.sel[j]) >= kSelDiffThreshold) continue;
+                        const uint64_t err = K.table_error(table, history.sel[j], std::min(limit_err, best_err));  // exact when <= the bound
+                        if (err < best_err && err <= limit_err) { best_err = err; best_idx = history.v[j]; best_j = j; }
                     }
                     if (best_err != UINT64_MAX) { new_selector = best_idx; history_index = (int)best_j; }
                 }
+                TK(5);
                 m.selector_index = m_selector_new_to_old[new_selector];
                 if (history_index != 0) close_selector_run();
                 if (history_index == 0) {
@@ -587,13 +586,18 @@ bool etc1s_backend::encode_image() {
                     tokens.push_back(token{(uint32_t)new_selector, T_SELECTOR});
                 }
                 m.selector_history_index = (int8_t)history_index;
-                if (history_index < 0) history.add(new_selector); else history.use((uint32_t)history_index);
+                if (history_index < 0) history.add(new_selector, m_selector_bytes[m.selector_index]); else history.use((uint32_t)history_index);
                 block_selector_indices[b] = m.selector_index;
+                TK(6);
             }
         close_pred_run();
         close_selector_run();
     }
 
+#ifdef BU_BACKEND_TICKS
+    fprintf(stderr, "Mclk: pred %.1f ep-prep %.1f ep-search %.1f exact %.1f table %.1f scan %.1f emit %.1f\n", tk[0]/1e6, tk[1]/1e6, tk[2]/1e6, tk[3]/1e6, tk[4]/1e6, tk[5]/1e6, tk[6]/1e6);
+#endif
+#undef TK
     if (endpoints_remapped && level > 1) {  // backend.cpp:1281-1287: refit the palette entries in place (no renumbering)
         if (!m_reoptimize) return fail("compression levels above 1 need the frontend behind the backend (reoptimize_remapped_endpoints)");
         std::vector<int> unused;

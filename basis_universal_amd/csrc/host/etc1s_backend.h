@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "../../../include/basisu_hip.h"
+#include "block_metric.h"
 
 namespace bu {
 
@@ -124,6 +125,8 @@ private:
     struct endpoint_entry { uint8_t r, g, b, inten; };
     std::vector<endpoint_entry> m_endpoint_palette;
     std::vector<uint32_t> m_selector_palette;      // 16 selectors, 2 bits each, pixel y*4+x at bits 2*(y*4+x) (= etc1_selector_palette_entry::get_uint32)
+    std::vector<metric::pal_colors> m_palette_colors;  // the block colours of every endpoint palette entry in the metric's basis
+    std::vector<metric::sel16> m_selector_bytes;       // every selector pattern, one selector per byte
     std::vector<encoder_block> m_blocks;
     std::vector<uint32_t> m_endpoint_old_to_new, m_endpoint_new_to_old;
     std::vector<uint8_t> m_new_endpoint_was_used;

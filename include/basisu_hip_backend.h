@@ -60,6 +60,12 @@ BU_HIP_API uint64_t bu_backend_get(bu_backend*, const char* name, uint32_t slice
 BU_HIP_API const char* bu_backend_error(const bu_backend*);
 BU_HIP_API uint32_t bu_backend_stage_times(const bu_backend*, const char** names, double* seconds, uint32_t cap);
 
+/* Test hooks: the coding tools on their own -- a length-limited Huffman table (code sizes, codes, and its serialised form followed by
+ * vlc(n, 4)) from a histogram; the slice CRC; the adjacency-driven palette ordering. */
+BU_HIP_API uint64_t bu_backend_test_huffman(const uint32_t* freq, uint32_t n, uint32_t max_code_size, uint8_t* out_sizes, uint16_t* out_codes, uint8_t* out_bytes, uint64_t cap);
+BU_HIP_API uint32_t bu_backend_test_crc16(const uint8_t* data, uint64_t size, uint32_t crc);
+BU_HIP_API void bu_backend_test_reorder(const uint32_t* indices, uint32_t num_indices, uint32_t num_syms, uint32_t* out_old_to_new);
+
 #ifdef __cplusplus
 }
 #endif

@@ -433,6 +433,29 @@ REF_API uint64_t ref_backend_get(void* hv, const char* name, uint32_t slice, voi
 	return ~0ull;
 }
 
+// The backend's coding tools on their own (known-answer style tests with synthetic inputs).
+REF_API uint64_t ref_huffman_table_bytes(const uint32_t* freq, uint32_t n, uint32_t max_code_size, uint8_t* out_sizes, uint16_t* out_codes, uint8_t* out_bytes, uint64_t cap) {
+	histogram h(n);
+	for (uint32_t i = 0; i < n; i++) h[i] = freq[i];
+	huffman_encoding_table t;
+	if (!t.init(h, max_code_size)) return ~0ull;
+	for (uint32_t i = 0; i < n; i++) { out_sizes[i] = t.get_code_sizes()[i]; out_codes[i] = t.get_codes()[i]; }
+	bitwise_coder c;
+	c.init(1024);
+	c.emit_huffman_table(t);
+	c.put_vlc(n, 4);
+	c.flush();
+	const uint8_vec& b = c.get_bytes();
+	if (out_bytes && cap >= b.size() && b.size()) memcpy(out_bytes, b.data(), b.size());
+	return b.size();
+}
+REF_API uint32_t ref_crc16(const uint8_t* data, uint64_t size, uint32_t crc) { return basist::crc16(data, (size_t)size, (uint16_t)crc); }
+REF_API void ref_palette_reorder(const uint32_t* indices, uint32_t num_indices, uint32_t num_syms, uint32_t* out_old_to_new) {
+	palette_index_reorderer r;
+	r.init(num_indices, indices, num_syms, nullptr, nullptr, 0);
+	for (uint32_t i = 0; i < num_syms; i++) out_old_to_new[i] = r.get_remap_table()[i];
+}
+
 // ---------------------------------------------------------------- UASTC
 
 REF_API void ref_encode_uastc(const uint8_t* pixel_blocks, uint32_t n_blocks, uint32_t flags, uint8_t* out_blocks16) {

@@ -74,10 +74,112 @@ def test_backend_above_level_1_needs_the_frontend():
     fe.close()
 
 
-def test_huffman_and_crc_known_answers():
-    """The entropy tools against reference outputs that do not need a frontend: a Fibonacci histogram forces the length limiter."""
+def _huffman(L, fn, freq, max_size):
+    import ctypes as C
+    f = np.ascontiguousarray(freq, np.uint32)
+    sizes, codes, out = np.zeros(f.size, np.uint8), np.zeros(f.size, np.uint16), np.zeros(f.size * 4 + 256, np.uint8)
+    g = getattr(L, fn)
+    g.restype = C.c_uint64
+    g.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
+    n = g(f.ctypes.data, f.size, max_size, sizes.ctypes.data, codes.ctypes.data, out.ctypes.data, out.size)
+    return (None, None, None) if n == 2 ** 64 - 1 else (sizes, codes, out[:n].copy())
+
+
+def _histograms():
+    rng = np.random.default_rng(5)
+    fib = [1, 1]
+    while len(fib) < 40:
+        fib.append(fib[-1] + fib[-2])
+    yield "fibonacci19", np.array(fib[:19]), 16       # the reference's own huffman_test (enc.cpp:1663-1672): forces the length limiter
+    yield "fibonacci40_scaled", np.array(fib[:40]), 16  # counts past 65535: rescaled to 16 bits first
+    yield "fibonacci19_max7", np.array(fib[:12]), 7
+    yield "single", np.array([0, 0, 7, 0]), 16
+    yield "two", np.array([3, 0, 0, 9]), 16
+    yield "flat256", np.full(256, 5), 16
+    yield "flat_ties", np.array([4] * 7 + [8] * 3 + [1] * 9), 16
+    yield "sparse_long_zero_runs", np.concatenate([np.zeros(300, np.int64), [5], np.zeros(139, np.int64), [2, 2, 2, 2, 2, 2, 2], np.zeros(11, np.int64), [1]]), 16
+    yield "long_repeats", np.concatenate([np.full(400, 3), [1000], np.full(135, 3)]), 16
+    for i in range(12):
+        n = int(rng.integers(2, 3000))
+        yield f"zipf{i}", (rng.zipf(1.3, n) * (rng.random(n) < 0.7)).clip(0, 10 ** 7), 16
+    yield "geometric_big", (2.0 ** np.arange(30, 0, -1)).astype(np.int64), 16
+    yield "wide16193", rng.integers(0, 50, 16193), 16
+
+
+def test_huffman_tables_match_reference():
+    """Code sizes, codes and the serialised table of bu::huffman_table / bit_writer against huffman_encoding_table / bitwise_coder."""
+    from helpers import ref
+    from basis_universal_amd.etc1s import load_frontend_library
+    R, L = ref(), load_frontend_library()
+    for name, freq, max_size in _histograms():
+        if not np.any(freq):
+            continue
+        a, b = _huffman(L, "bu_backend_test_huffman", freq, max_size), _huffman(R, "ref_huffman_table_bytes", freq, max_size)
+        assert (a[0] is None) == (b[0] is None), name
+        if a[0] is None:
+            continue
+        for x, y, what in zip(a, b, ("sizes", "codes", "bytes")):
+            assert x.shape == y.shape and (x == y).all(), (name, what)
+
+
+def test_crc16_matches_reference():
     import ctypes as C
     from helpers import ref
-    L = ref()
-    if not hasattr(L, "ref_huffman_table_bytes"):
-        pytest.skip("harness without ref_huffman_table_bytes")
+    from basis_universal_amd.etc1s import load_frontend_library
+    R, L = ref(), load_frontend_library()
+    rng = np.random.default_rng(1)
+    for n, crc in [(0, 0), (1, 0), (8, 0), (4097, 0), (100, 0x1234), (65536, 0xFFFF)]:
+        d = rng.integers(0, 256, max(n, 1), dtype=np.uint8)
+        for lib in (R, L):
+            for fn in ("ref_crc16", "bu_backend_test_crc16"):
+                if hasattr(lib, fn):
+                    getattr(lib, fn).restype = C.c_uint32
+                    getattr(lib, fn).argtypes = [C.c_void_p, C.c_uint64, C.c_uint32]
+        assert L.bu_backend_test_crc16(d.ctypes.data, n, crc) == R.ref_crc16(d.ctypes.data, n, crc), (n, crc)
+
+
+def test_palette_reordering_matches_reference():
+    """reorder_palette_by_adjacency (sparse adjacency) against palette_index_reorderer (dense matrix), degenerate inputs included."""
+    import ctypes as C
+    from helpers import ref
+    from basis_universal_amd.etc1s import load_frontend_library
+    R, L = ref(), load_frontend_library()
+    rng = np.random.default_rng(3)
+    cases = [("one_index", np.array([2]), 5), ("all_equal", np.full(50, 3), 6), ("two_syms", np.array([0, 1, 0, 1, 1, 0]), 2), ("unused_syms", np.array([7, 2, 7, 2, 9]), 12),
+             ("single_sym", np.array([0, 0, 0]), 1), ("pair_then_rest", np.array([4, 5, 4, 5, 4, 5, 1, 2, 3]), 8)]
+    for i in range(10):
+        k = int(rng.integers(2, 400))
+        idx = rng.integers(0, k, int(rng.integers(2, 5000)))
+        if i % 3 == 0:
+            idx = np.sort(idx)[::-1].copy()          # long monotone stretches: many ties
+        if i % 4 == 1:
+            idx = (rng.zipf(1.5, idx.size) % k)       # a few dominant symbols: large counts
+        cases.append((f"random{i}", idx, k))
+    for name, idx, k in cases:
+        idx = np.ascontiguousarray(idx, np.uint32)
+        a, b = np.zeros(k, np.uint32), np.zeros(k, np.uint32)
+        for lib, fn, out in ((L, "bu_backend_test_reorder", a), (R, "ref_palette_reorder", b)):
+            g = getattr(lib, fn)
+            g.restype = None
+            g.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
+            g(idx.ctypes.data, idx.size, k, out.ctypes.data)
+        assert (a == b).all(), name
+
+
+@pytest.mark.parametrize("case", ["synth_l1", "strong_rdo", "two_slices"])
+def test_backend_plain_and_avx2_paths_agree(case, monkeypatch):
+    """block_metric.h has a plain and an AVX2 form of every inner loop; both must give the reference's bytes."""
+    from basis_universal_amd.backend import Etc1sBackend
+    img_fn, max_ep, max_sel, level, perceptual, slices, ept, selt = CASES[case]
+    blocks = to_pixel_blocks(img_fn())
+    fe = RefFrontend(blocks, max_ep, max_sel, level, perceptual)
+    fe.call("compress")
+    arrays = _arrays(fe, blocks)
+    fe.backend_run(slices, ept, selt)
+    for no_avx2 in ("1", "0"):
+        monkeypatch.setenv("BU_BACKEND_NO_AVX2", no_avx2)
+        be = Etc1sBackend.from_arrays(slices=slices, perceptual=perceptual, endpoint_rdo_thresh=ept, selector_rdo_thresh=selt, compression_level=level, **arrays)
+        be.encode()
+        _compare(fe, be, len(slices))
+        be.close()
+    fe.close()
