@@ -16,8 +16,11 @@
 #include <cstring>
 #include <deque>
 
-#include <cstdio>
+#include <atomic>
 #include <cstdlib>
+#include <numeric>
+#include <thread>
+
 #include "block_metric.h"
 #include "entropy.h"
 #include "etc1s_frontend.h"
@@ -85,6 +88,26 @@ struct history_buffer {
     void add(int x, const sel16& of_x) { v[rover] = x; sel[rover] = of_x; if (++rover == kSelectorHistorySize) rover = kSelectorHistorySize / 2; }
     void use(uint32_t i) { if (i) { std::swap(v[i / 2], v[i]); std::swap(sel[i / 2], sel[i]); } }
 };
+
+// The slices of a file (mip levels, array layers / cube faces, the alpha slice) share the codebooks and the Huffman models but no
+// walking state: each is walked by its own host thread, largest first (BU_HOST_THREADS caps the count, default 8).
+template <class F> void for_each_slice(const std::vector<backend_slice_desc>& slices, F fn) {
+    const size_t n = slices.size();
+    unsigned want = 8;
+    if (const char* e = std::getenv("BU_HOST_THREADS")) { const int v = std::atoi(e); if (v >= 1 && v <= 64) want = (unsigned)v; }
+    const unsigned hw = std::thread::hardware_concurrency();
+    const size_t t = std::min<size_t>(std::min<unsigned>(want, hw ? hw : 1u), n);
+    if (t <= 1) { for (size_t i = 0; i < n; i++) fn(i); return; }
+    std::vector<size_t> order(n);
+    std::iota(order.begin(), order.end(), (size_t)0);
+    auto blocks = [&](size_t i) { return (uint64_t)slices[i].m_num_blocks_x * slices[i].m_num_blocks_y; };
+    std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return blocks(a) > blocks(b); });
+    std::atomic<size_t> next{0};
+    std::vector<std::thread> pool;
+    for (size_t w = 0; w < t; w++)
+        pool.emplace_back([&] { for (size_t k; (k = next.fetch_add(1)) < n;) fn(order[k]); });
+    for (std::thread& th : pool) th.join();
+}
 
 enum token_kind : uint8_t { T_NONE, T_PRED, T_PRED_REPEAT, T_ENDPOINT_DELTA, T_SELECTOR, T_SELECTOR_RLE };
 struct token { uint32_t value; token_kind kind; };
@@ -252,15 +275,25 @@ void etc1s_backend::create_selector_palette() {  // backend.cpp:96-118
 bool etc1s_backend::create_encoder_blocks() {
     const uint32_t total = m_src.total_blocks;
     m_blocks.assign(total, encoder_block{0, 0, 0, 0});
-    uint32_t remapped = 0;
-    std::vector<uint32_t> all_endpoint_indices;
-    all_endpoint_indices.reserve(total);
     const float thresh = m_params.m_endpoint_rdo_quality_thresh;
     const bool perceptual = m_src.perceptual;
     const metric::kernels K = metric::pick_kernels();
+    std::vector<std::pair<uint64_t, uint64_t>> extents;
     for (const backend_slice_desc& s : m_slices) {
+        if ((uint64_t)s.m_first_block_index + (uint64_t)s.m_num_blocks_x * s.m_num_blocks_y > total) return fail("slice exceeds the frontend's blocks");
+        extents.emplace_back(s.m_first_block_index, (uint64_t)s.m_first_block_index + (uint64_t)s.m_num_blocks_x * s.m_num_blocks_y);
+    }
+    std::sort(extents.begin(), extents.end());
+    for (size_t i = 1; i < extents.size(); i++)
+        if (extents[i].first < extents[i - 1].second) return fail("slices overlap");  // the per-block state is kept once per block, and slices are walked concurrently
+    struct slice_result { std::vector<uint32_t> unpredicted; uint32_t remapped = 0; const char* error = nullptr; };
+    std::vector<slice_result> results(m_slices.size());
+    for_each_slice(m_slices, [&](size_t si) {
+        const backend_slice_desc& s = m_slices[si];
         const uint32_t nbx = s.m_num_blocks_x, nby = s.m_num_blocks_y;
-        if ((uint64_t)s.m_first_block_index + (uint64_t)nbx * nby > total) return fail("slice exceeds the frontend's blocks");
+        std::vector<uint32_t>& all_endpoint_indices = results[si].unpredicted;
+        uint32_t& remapped = results[si].remapped;
+        all_endpoint_indices.reserve((size_t)nbx * nby);
         for (uint32_t by = 0; by < nby; by++)
             for (uint32_t bx = 0; bx < nbx; bx++) {
                 const uint32_t b = s.m_first_block_index + bx + by * nbx;
@@ -268,7 +301,7 @@ bool etc1s_backend::create_encoder_blocks() {
                 m.endpoint_index = m_src.block_endpoint_index[b];
                 m.selector_index = m_src.block_selector_index[b];
                 m.endpoint_predictor = kNoEndpointPred;
-                if (m.endpoint_index >= m_src.total_endpoints || m.selector_index >= m_src.total_selectors) return fail("block index out of range");
+                if (m.endpoint_index >= m_src.total_endpoints || m.selector_index >= m_src.total_selectors) { results[si].error = "block index out of range"; return; }
                 uint32_t neighbour[kNumEndpointPreds];
                 bool present[kNumEndpointPreds];
                 uint32_t best_pred = UINT32_MAX;
@@ -307,6 +340,14 @@ bool etc1s_backend::create_encoder_blocks() {
                 }
                 if (m.endpoint_predictor == kNoEndpointPred) all_endpoint_indices.push_back(m.endpoint_index);
             }
+    });
+    uint32_t remapped = 0;
+    std::vector<uint32_t> all_endpoint_indices;  // the unpredicted endpoint indices in coding order: what the palette ordering works from
+    all_endpoint_indices.reserve(total);
+    for (const slice_result& r : results) {
+        if (r.error) return fail(r.error);
+        remapped += r.remapped;
+        all_endpoint_indices.insert(all_endpoint_indices.end(), r.unpredicted.begin(), r.unpredicted.end());
     }
     if (!reoptimize_and_sort_endpoints_codebook(remapped, all_endpoint_indices)) return false;
     sort_selector_codebook();
@@ -405,10 +446,14 @@ bool etc1s_backend::encode_image() {
     const bool perceptual = m_src.perceptual;
     const uint32_t level = m_params.m_compression_level;
     const uint32_t kHistFirstSym = n_sel, kHistRleSym = n_sel + kSelectorHistorySize;
-    std::vector<uint32_t> selector_hist(n_sel + kSelectorHistorySize + 1, 0), rle_hist(kSelectorRleCountTotal, 0), delta_hist(n_ep, 0), pred_hist(kEndpointPredSymbols, 0);
+    struct slice_stats {
+        std::vector<uint32_t> selector_hist, rle_hist, delta_hist, pred_hist;
+        uint32_t endpoints_remapped = 0;
+        slice_stats(uint32_t n_sel_syms, uint32_t n_ep_syms) : selector_hist(n_sel_syms, 0), rle_hist(kSelectorRleCountTotal, 0), delta_hist(n_ep_syms, 0), pred_hist(kEndpointPredSymbols, 0) {}
+    };
+    std::vector<slice_stats> stats(m_slices.size(), slice_stats(n_sel + kSelectorHistorySize + 1, n_ep));
     std::vector<std::vector<token>> slice_tokens(m_slices.size());
     std::vector<uint32_t> block_endpoint_indices(m_src.total_blocks, 0), block_selector_indices(m_src.total_blocks, 0);
-    uint32_t endpoints_remapped = 0;
     const metric::kernels K = metric::pick_kernels();
     const float selector_thresh = std::max(1.0f, m_params.m_selector_rdo_quality_thresh);
     const float endpoint_thresh = std::max(1.0f, m_params.m_endpoint_rdo_quality_thresh);
@@ -422,16 +467,12 @@ bool etc1s_backend::encode_image() {
         sorted_palette[nw] = sorted_entry{e.r, e.g, e.b, e.inten, m_new_endpoint_was_used[nw]};
         sorted_colors[nw] = m_palette_colors[m_endpoint_new_to_old[nw]];
     }
-    history_buffer history;
-#ifdef BU_BACKEND_TICKS
-    uint64_t tk[8] = {0}, tk0 = 0;
-#define TK(i) do { const uint64_t n__ = __rdtsc(); tk[i] += n__ - tk0; tk0 = n__; } while (0)
-#else
-#define TK(i) do {} while (0)
-#endif
 
-    for (size_t si = 0; si < m_slices.size(); si++) {
+    for_each_slice(m_slices, [&](size_t si) {
         const backend_slice_desc& s = m_slices[si];
+        std::vector<uint32_t>&selector_hist = stats[si].selector_hist, &rle_hist = stats[si].rle_hist, &delta_hist = stats[si].delta_hist, &pred_hist = stats[si].pred_hist;
+        uint32_t& endpoints_remapped = stats[si].endpoints_remapped;
+        history_buffer history;
         const uint32_t nbx = s.m_num_blocks_x, nby = s.m_num_blocks_y, base = s.m_first_block_index;
         std::vector<token>& tokens = slice_tokens[si];
         tokens.reserve((size_t)nbx * nby * 2 + 16);
@@ -476,9 +517,6 @@ bool etc1s_backend::encode_image() {
             for (uint32_t bx = 0; bx < nbx; bx++) {
                 const uint32_t b = base + bx + by * nbx;
                 encoder_block& m = m_blocks[b];
-#ifdef BU_BACKEND_TICKS
-                tk0 = __rdtsc();
-#endif
                 // ---- one endpoint-predictor symbol per 2x2 macroblock, runs of equal symbols collapsed (backend.cpp:776-827)
                 if (!(bx & 1) && !(by & 1)) {
                     uint32_t sym = 0;
@@ -498,7 +536,6 @@ bool etc1s_backend::encode_image() {
                         prev_pred_sym = (int)sym;
                     }
                 }
-                TK(0);
                 // ---- endpoint index, as a delta to the previous block's in the sorted palette (backend.cpp:829-1009)
                 int new_endpoint = (int)m_endpoint_old_to_new[m.endpoint_index];
                 block_px px;
@@ -515,7 +552,6 @@ bool etc1s_backend::encode_image() {
                         pal_colors own;
                         block_colors(perceptual, own, cur_c);
                         const uint64_t cur_err = K.block_error(perceptual, px, own, sels);
-                        TK(1);
                         if (cur_err) {
                             const endpoint_entry cur_e = m_endpoint_palette[m.endpoint_index];
                             const uint64_t thresh_err = (uint64_t)(cur_err * endpoint_thresh);
@@ -548,19 +584,15 @@ bool etc1s_backend::encode_image() {
                 }
                 block_endpoint_indices[b] = m_endpoint_new_to_old[new_endpoint];
                 prev_endpoint = (uint32_t)new_endpoint;
-
-                TK(2);
                 // ---- selector index: a recently used pattern (history buffer) that is good enough, else the block's own (backend.cpp:1011-1205)
                 int new_selector = (int)m_selector_old_to_new[m.selector_index];
                 int history_index = level <= 1 ? metric::find_first_64(history.v, new_selector) : -1;
-                TK(3);
                 if (history_index == -1) {
                     need_px();
                     metric::dist_table table;
                     K.build_table(perceptual, px, m_palette_colors[m_endpoint_new_to_old[new_endpoint]], table);
                     const sel16& cur_sels = m_selector_bytes[m.selector_index];
                     const uint64_t cur_err = K.table_error(table, cur_sels, UINT64_MAX);
-                    TK(4);
                     const uint64_t limit_err = (uint64_t)ceilf(cur_err * selector_thresh);
                     uint64_t best_err = UINT64_MAX;
                     int best_idx = 0;
@@ -572,7 +604,6 @@ bool etc1s_backend::encode_image() {
                     }
                     if (best_err != UINT64_MAX) { new_selector = best_idx; history_index = (int)best_j; }
                 }
-                TK(5);
                 m.selector_index = m_selector_new_to_old[new_selector];
                 if (history_index != 0) close_selector_run();
                 if (history_index == 0) {
@@ -588,16 +619,20 @@ bool etc1s_backend::encode_image() {
                 m.selector_history_index = (int8_t)history_index;
                 if (history_index < 0) history.add(new_selector, m_selector_bytes[m.selector_index]); else history.use((uint32_t)history_index);
                 block_selector_indices[b] = m.selector_index;
-                TK(6);
             }
         close_pred_run();
         close_selector_run();
+    });
+    std::vector<uint32_t> selector_hist(n_sel + kSelectorHistorySize + 1, 0), rle_hist(kSelectorRleCountTotal, 0), delta_hist(n_ep, 0), pred_hist(kEndpointPredSymbols, 0);
+    uint32_t endpoints_remapped = 0;
+    for (const slice_stats& st : stats) {
+        for (size_t i = 0; i < selector_hist.size(); i++) selector_hist[i] += st.selector_hist[i];
+        for (size_t i = 0; i < rle_hist.size(); i++) rle_hist[i] += st.rle_hist[i];
+        for (size_t i = 0; i < delta_hist.size(); i++) delta_hist[i] += st.delta_hist[i];
+        for (size_t i = 0; i < pred_hist.size(); i++) pred_hist[i] += st.pred_hist[i];
+        endpoints_remapped += st.endpoints_remapped;
     }
 
-#ifdef BU_BACKEND_TICKS
-    fprintf(stderr, "Mclk: pred %.1f ep-prep %.1f ep-search %.1f exact %.1f table %.1f scan %.1f emit %.1f\n", tk[0]/1e6, tk[1]/1e6, tk[2]/1e6, tk[3]/1e6, tk[4]/1e6, tk[5]/1e6, tk[6]/1e6);
-#endif
-#undef TK
     if (endpoints_remapped && level > 1) {  // backend.cpp:1281-1287: refit the palette entries in place (no renumbering)
         if (!m_reoptimize) return fail("compression levels above 1 need the frontend behind the backend (reoptimize_remapped_endpoints)");
         std::vector<int> unused;

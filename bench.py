@@ -233,8 +233,17 @@ def main():
         }
         if roofline:
             roofline["traffic"] = pmc_traffic(roofline["kernel"])
+        if world == 1:  # what follows the hot path on the host: the ETC1S backend on the frontend just timed
+            out["backend"] = backend_bench(last, w, h, args, elapsed / args.steps)
         if not args.no_cpu_baseline and world == 1:  # the CPU baseline and the secondary workloads are N=1 measurements
             out["cpu_baseline"] = cpu_baseline(helpers, args)
+            ref_be = out["cpu_baseline"].pop("backend", None)
+            if ref_be and "backend" in out:
+                out["backend"]["reference_s"] = ref_be["seconds"]
+                out["backend"]["identical_to_reference"] = ref_be["sha256"] == out["backend"].pop("sha256")
+                out["backend"]["speedup_vs_reference"] = round(ref_be["seconds"] / (out["backend"]["ms_per_image"] / 1e3), 2)
+        if "backend" in out:
+            out["backend"].pop("sha256", None)
         if not args.no_uastc and world == 1:
             out["uastc"] = uastc_bench(ctx, d_blocks, n_blocks, w, h, helpers, args)
             out["uastc_rdo"] = uastc_rdo_bench(ctx, helpers, args)
@@ -339,6 +348,35 @@ def uastc_rdo_bench(ctx, helpers, args):
     return res
 
 
+def _payload_digest(get):
+    import hashlib
+    h = hashlib.sha256()
+    for k in ("endpoint_palette", "selector_palette", "slice_image_tables", "slice_image_data", "slice_image_crcs"):
+        h.update(np.ascontiguousarray(get(k)).tobytes())
+    return h.hexdigest()
+
+
+def backend_bench(fe, w, h, args, frontend_s):
+    """bu::etc1s_backend (host, one thread) on the finished frontend: endpoint prediction + RDO, selector history RDO, Huffman coding -> the
+    compressed payloads of the .basis file. Default basis_compressor thresholds (1.5 / 1.25)."""
+    from basis_universal_amd.backend import Etc1sBackend
+    best, n = None, 0
+    for _ in range(2):  # the first call also fetches the host copy of the resident tiles
+        be = Etc1sBackend.from_frontend(fe, [(0, w // 4, h // 4)], 1.5, 1.25, args.level)
+        t0 = time.perf_counter()
+        n = be.encode()
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+        digest = _payload_digest(be.get)
+        stages = {k: round(v, 4) for k, v in be.stage_times()}
+        be.close()
+        if args.level > 1:
+            break  # above level 1 the backend changes the frontend: once only
+    return {"what": "ETC1S backend on the host after the frontend (1 thread), endpoint/selector RDO thresholds 1.5/1.25", "ms_per_image": round(best * 1e3, 1),
+            "compressed_bytes": n, "bits_per_texel": round(n * 8 / (w * h), 3), "stages_s": stages,
+            "frontend_plus_backend_mpix_s": round(w * h / 1e6 / (frontend_s + best), 2), "sha256": digest}
+
+
 def cpu_baseline(helpers, args):
     """The same stage set (basisu_frontend init + compress) on one host core = the parity-pinned configuration of the reference.
     With oracle/_ref present the sample is the bench workload itself (the whole 4096x4096 image, ~20 s of CPU); without it, the C
@@ -353,6 +391,8 @@ def cpu_baseline(helpers, args):
         fe = helpers.RefFrontend(sample, max_ep, max_sel, args.level, True)
         fe.call("compress")
         dt = time.perf_counter() - t0
+        ref_total, ref_be_s = fe.backend_run([(0, side // 4, side // 4)], 1.5, 1.25)
+        ref_backend = {"seconds": round(ref_be_s, 3), "bytes": ref_total, "sha256": _payload_digest(fe.backend_get)}
         fe.close()
         kind, what = "reference", "reference basisu_frontend::init+compress (oracle/_ref, built from /root/reference, -O3, no SSE, single thread)"
     else:
@@ -364,9 +404,12 @@ def cpu_baseline(helpers, args):
         helpers.orc_encode_blocks(sample, args.level, True)
         dt = time.perf_counter() - t0
         kind, what = "port", "oracle per-block ETC1S fit only (reference build not present)"
-    return {"value": round(side * side / 1e6 / dt, 4), "unit": "Mpixels/s", "cores": 1, "kind": kind,
-            "sample": f"{side}x{side} of the bench image, {n} blocks, {max_ep}/{max_sel} clusters, {what}, {dt:.2f} s",
-            "host": f"{os.cpu_count()} logical CPUs on the GPU box"}
+    res = {"value": round(side * side / 1e6 / dt, 4), "unit": "Mpixels/s", "cores": 1, "kind": kind,
+           "sample": f"{side}x{side} of the bench image, {n} blocks, {max_ep}/{max_sel} clusters, {what}, {dt:.2f} s",
+           "host": f"{os.cpu_count()} logical CPUs on the GPU box"}
+    if kind == "reference":
+        res["backend"] = ref_backend
+    return res
 
 
 if __name__ == "__main__":

@@ -19,6 +19,10 @@ def _arrays(fe, blocks):
                 selector_blocks=fe.get("optimized_cluster_selectors"))
 
 
+def _blocks_of(img):
+    return np.concatenate([to_pixel_blocks(i) for i in img]) if isinstance(img, list) else to_pixel_blocks(img)
+
+
 def _compare(fe, be, n_slices):
     for k in OUTPUTS + STATE:
         a, b = be.get(k), fe.backend_get(k)
@@ -41,6 +45,11 @@ CASES = {
     "three_slices_ragged": (lambda: synth(160, 128, 31), 200, 256, 1, True, [(0, 40, 20), (800, 25, 16), (1200, 5, 16)], 1.5, 1.25),
     "flat": (lambda: np.full((64, 64, 4), 200, np.uint8), 32, 32, 1, True, [(0, 16, 16)], 1.5, 1.25),
     "tiny": (lambda: synth(8, 8, 1), 4, 4, 1, True, [(0, 2, 2)], 1.5, 1.25),
+    # a mip chain: six slices of one texture walked by concurrent host threads, sharing codebooks and Huffman models
+    "mip_chain": (lambda: [synth(256 >> i, 256 >> i, 40 + i) for i in range(6)], 400, 400, 1, True,
+                  [(0, 64, 64), (4096, 32, 32), (5120, 16, 16), (5376, 8, 8), (5440, 4, 4), (5456, 2, 2)], 1.5, 1.25),
+    # BASELINE-sized codebooks (quality 128 at 1024x1024): 16-bit count rescaling, long code lengths, every run-length token kind
+    "synth1024_q128": (lambda: synth(1024, 1024, 1234), None, None, 1, True, [(0, 256, 256)], 1.5, 1.25),
     "one_block": (lambda: synth(4, 4, 2), 1, 1, 1, True, [(0, 1, 1)], 1.5, 1.25),
 }
 
@@ -49,7 +58,10 @@ CASES = {
 def test_backend_matches_reference_bytes(case):
     from basis_universal_amd.backend import Etc1sBackend
     img_fn, max_ep, max_sel, level, perceptual, slices, ept, selt = CASES[case]
-    blocks = to_pixel_blocks(img_fn())
+    blocks = _blocks_of(img_fn())
+    if max_ep is None:
+        from basis_universal_amd.etc1s import quality_to_clusters
+        max_ep, max_sel = quality_to_clusters(128, blocks.shape[0])
     fe = RefFrontend(blocks, max_ep, max_sel, level, perceptual)
     fe.call("compress")
     arrays = _arrays(fe, blocks)  # before the reference backend runs (it does not touch the frontend at levels <= 1, but be safe)
@@ -59,6 +71,20 @@ def test_backend_matches_reference_bytes(case):
     assert total == ref_total
     _compare(fe, be, len(slices))
     be.close()
+    fe.close()
+
+
+def test_backend_rejects_overlapping_slices():
+    from basis_universal_amd.backend import Etc1sBackend, BackendError
+    blocks = to_pixel_blocks(synth(64, 64, 4))
+    fe = RefFrontend(blocks, 32, 32, 1, True)
+    fe.call("compress")
+    be = Etc1sBackend.from_arrays(slices=[(0, 16, 12), (128, 16, 8)], compression_level=1, **_arrays(fe, blocks))
+    with pytest.raises(BackendError, match="overlap"):
+        be.encode()
+    be = Etc1sBackend.from_arrays(slices=[(0, 16, 17)], compression_level=1, **_arrays(fe, blocks))
+    with pytest.raises(BackendError, match="exceeds"):
+        be.encode()
     fe.close()
 
 

@@ -25,6 +25,22 @@ def test_frontend_library_loads():
         assert hasattr(L, sym)
 
 
+def test_frontend_library_exports_every_declared_symbol():
+    """include/basisu_hip_frontend.h and include/basisu_hip_backend.h (both served by libbasisu_frontend.so)."""
+    import pathlib, re
+    from basis_universal_amd import etc1s
+    L = etc1s.load_frontend_library()
+    inc = pathlib.Path(__file__).resolve().parent.parent / "include"
+    total = 0
+    for header in ("basisu_hip_frontend.h", "basisu_hip_backend.h"):
+        names = re.findall(r"BU_HIP_API\s+[^;(]*?\b(\w+)\s*\(", (inc / header).read_text())
+        assert names, header
+        for sym in names:
+            assert hasattr(L, sym), (header, sym)
+        total += len(names)
+    assert total >= 20
+
+
 def test_no_silent_cpu_fallback():
     """Without a GPU, creating a context must raise -- never fall back to a host implementation."""
     import torch
