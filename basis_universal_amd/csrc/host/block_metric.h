@@ -3,9 +3,9 @@
 //
 // The metric is separable once a colour is moved to (l, cr, cb) = (14r+45g+5b, 64r-l, 64b-l): a distance is three squares. Every
 // value below fits 32 bits (|dl| <= 16320, |dcr|,|dcb| <= 32640; one perceptual distance < 41e6, sixteen of them < 2^32), so the same
-// arithmetic runs in 32-bit SIMD lanes. There are two implementations of each loop, plain C++ and AVX2 (picked once at run time;
-// BU_BACKEND_NO_AVX2=1 forces the plain one); they are integer-exact and therefore interchangeable, which tests/test_backend_host.py
-// checks by running both.
+// arithmetic runs in 32-bit SIMD lanes. There are three implementations of each loop -- plain C++, AVX2, AVX-512 -- picked once per
+// encode from what the CPU has (BU_BACKEND_ISA=plain|avx2 caps the choice); they are integer-exact and therefore interchangeable,
+// which tests/test_backend_host.py checks by running all of them.
 #pragma once
 #include <immintrin.h>
 
@@ -16,9 +16,9 @@
 namespace bu {
 namespace metric {
 
-struct alignas(32) block_px { int32_t x[16], y[16], z[16]; };     // the 16 source pixels, pixel p = y*4+x
+struct alignas(64) block_px { int32_t x[16], y[16], z[16]; };     // the 16 source pixels, pixel p = y*4+x
 struct alignas(16) pal_colors { int32_t x[4], y[4], z[4]; };      // the four block colours of one (colour5, intensity table)
-struct alignas(32) dist_table { uint32_t d[4][16]; };             // d[k][p]: pixel p against block colour k
+struct alignas(64) dist_table { uint32_t d[4][16]; };             // d[k][p]: pixel p against block colour k
 struct alignas(16) sel16 { uint8_t s[16]; };                      // 16 selectors, one per byte
 
 inline void to_metric(bool perceptual, int r, int g, int b, int32_t& x, int32_t& y, int32_t& z) {
@@ -53,6 +53,25 @@ inline uint64_t table_error_plain(const dist_table& t, const sel16& sel, uint64_
     if (e > bound) return e;
     for (int p = 8; p < 16; p++) e += t.d[sel.s[p]][p];
     return e;
+}
+
+// The two searches of the backend walk, batched so that each runs inside one ISA-specific function:
+//   scan_history : min over the 64 history patterns of the table error, first index on ties, only patterns within `limit` count; with
+//                  `sad_limit` > 0 patterns whose selectors differ from `cur` by that much or more (sum of absolute differences) are skipped
+//   block_errors : the block's error under each of n candidate colour sets
+struct scan_result { uint64_t err; int index; };  // index -1: nothing within the limit
+inline int selector_sad(const sel16& a, const sel16& b);
+inline scan_result scan_history_plain(const dist_table& t, const sel16& cur, const sel16* hist, int sad_limit, uint64_t limit) {
+    scan_result r{UINT64_MAX, -1};
+    for (int j = 0; j < 64; j++) {
+        if (sad_limit > 0 && selector_sad(cur, hist[j]) >= sad_limit) continue;
+        const uint64_t e = table_error_plain(t, hist[j], r.err < limit ? r.err : limit);
+        if (e < r.err && e <= limit) { r.err = e; r.index = j; }
+    }
+    return r;
+}
+inline void block_errors_plain(bool perceptual, const block_px& px, const sel16& sel, const pal_colors* colors, const int* which, int n, uint64_t* out) {
+    for (int i = 0; i < n; i++) out[i] = block_error_plain(perceptual, px, colors[which[i]], sel);
 }
 
 // ---- AVX2
@@ -109,7 +128,107 @@ BU_AVX2 inline uint64_t table_error_avx2(const dist_table& t, const sel16& sel, 
     if (bound != UINT64_MAX) { const uint64_t e = hsum8(lo); if (e > bound) return e; }
     return hsum8(_mm256_add_epi32(lo, table_half_avx2(t, _mm_srli_si128(s, 8), 1)));
 }
+BU_AVX2 inline scan_result scan_history_avx2(const dist_table& t, const sel16& cur, const sel16* hist, int sad_limit, uint64_t limit) {
+    scan_result r{UINT64_MAX, -1};
+    const __m128i c = _mm_load_si128((const __m128i*)cur.s);
+    for (int j = 0; j < 64; j++) {
+        const __m128i h = _mm_load_si128((const __m128i*)hist[j].s);
+        if (sad_limit > 0) {
+            const __m128i d = _mm_sad_epu8(c, h);
+            if (_mm_cvtsi128_si32(d) + _mm_extract_epi16(d, 4) >= sad_limit) continue;
+        }
+        const uint64_t bound = r.err < limit ? r.err : limit;
+        const __m256i lo = table_half_avx2(t, h, 0);
+        uint64_t e = hsum8(lo);
+        if (e > bound) continue;
+        e = hsum8(_mm256_add_epi32(lo, table_half_avx2(t, _mm_srli_si128(h, 8), 1)));
+        if (e < r.err && e <= limit) { r.err = e; r.index = j; }
+    }
+    return r;
+}
+BU_AVX2 inline void block_errors_avx2(bool perceptual, const block_px& px, const sel16& sel, const pal_colors* colors, const int* which, int n, uint64_t* out) {
+    const __m128i s = _mm_load_si128((const __m128i*)sel.s);
+    const __m256i i0 = _mm256_cvtepu8_epi32(s), i1 = _mm256_cvtepu8_epi32(_mm_srli_si128(s, 8));
+    const __m256i x0 = _mm256_load_si256((const __m256i*)px.x), x1 = _mm256_load_si256((const __m256i*)(px.x + 8)), y0 = _mm256_load_si256((const __m256i*)px.y),
+                  y1 = _mm256_load_si256((const __m256i*)(px.y + 8)), z0 = _mm256_load_si256((const __m256i*)px.z), z1 = _mm256_load_si256((const __m256i*)(px.z + 8));
+    for (int i = 0; i < n; i++) {
+        const pal_colors& c = colors[which[i]];
+        const __m256i cx = _mm256_castsi128_si256(_mm_load_si128((const __m128i*)c.x)), cy = _mm256_castsi128_si256(_mm_load_si128((const __m128i*)c.y)),
+                      cz = _mm256_castsi128_si256(_mm_load_si128((const __m128i*)c.z));
+        const __m256i a = dist8(perceptual, _mm256_sub_epi32(x0, _mm256_permutevar8x32_epi32(cx, i0)), _mm256_sub_epi32(y0, _mm256_permutevar8x32_epi32(cy, i0)),
+                                _mm256_sub_epi32(z0, _mm256_permutevar8x32_epi32(cz, i0)));
+        const __m256i b = dist8(perceptual, _mm256_sub_epi32(x1, _mm256_permutevar8x32_epi32(cx, i1)), _mm256_sub_epi32(y1, _mm256_permutevar8x32_epi32(cy, i1)),
+                                _mm256_sub_epi32(z1, _mm256_permutevar8x32_epi32(cz, i1)));
+        out[i] = hsum8(_mm256_add_epi32(a, b));
+    }
+}
 #undef BU_AVX2
+
+// ---- AVX-512 (F + BW + VL): all 16 pixels of a block in one register
+#define BU_AVX512 __attribute__((target("avx512f,avx512bw,avx512vl,avx2")))
+BU_AVX512 inline __m512i dist16(bool perceptual, __m512i dx, __m512i dy, __m512i dz) {
+    const __m512i xx = _mm512_mullo_epi32(dx, dx), yy = _mm512_mullo_epi32(dy, dy), zz = _mm512_mullo_epi32(dz, dz);
+    if (!perceptual) return _mm512_add_epi32(_mm512_add_epi32(xx, yy), zz);
+    const __m512i l = _mm512_srli_epi32(xx, 5);
+    const __m512i cr = _mm512_srli_epi32(_mm512_mullo_epi32(_mm512_srli_epi32(yy, 5), _mm512_set1_epi32(26)), 7);
+    const __m512i cb = _mm512_srli_epi32(_mm512_mullo_epi32(_mm512_srli_epi32(zz, 5), _mm512_set1_epi32(3)), 7);
+    return _mm512_add_epi32(_mm512_add_epi32(l, cr), cb);
+}
+BU_AVX512 inline uint64_t block_error_avx512(bool perceptual, const block_px& px, const pal_colors& c, const sel16& sel) {
+    const __m512i idx = _mm512_cvtepu8_epi32(_mm_load_si128((const __m128i*)sel.s));
+    const __m512i cx = _mm512_castsi128_si512(_mm_load_si128((const __m128i*)c.x)), cy = _mm512_castsi128_si512(_mm_load_si128((const __m128i*)c.y)),
+                  cz = _mm512_castsi128_si512(_mm_load_si128((const __m128i*)c.z));
+    const __m512i dx = _mm512_sub_epi32(_mm512_load_si512((const void*)px.x), _mm512_permutexvar_epi32(idx, cx));
+    const __m512i dy = _mm512_sub_epi32(_mm512_load_si512((const void*)px.y), _mm512_permutexvar_epi32(idx, cy));
+    const __m512i dz = _mm512_sub_epi32(_mm512_load_si512((const void*)px.z), _mm512_permutexvar_epi32(idx, cz));
+    return (uint32_t)_mm512_reduce_add_epi32(dist16(perceptual, dx, dy, dz));
+}
+BU_AVX512 inline void build_table_avx512(bool perceptual, const block_px& px, const pal_colors& c, dist_table& t) {
+    const __m512i x = _mm512_load_si512((const void*)px.x), y = _mm512_load_si512((const void*)px.y), z = _mm512_load_si512((const void*)px.z);
+    for (int k = 0; k < 4; k++)
+        _mm512_store_si512((void*)t.d[k], dist16(perceptual, _mm512_sub_epi32(x, _mm512_set1_epi32(c.x[k])), _mm512_sub_epi32(y, _mm512_set1_epi32(c.y[k])),
+                                                 _mm512_sub_epi32(z, _mm512_set1_epi32(c.z[k]))));
+}
+BU_AVX512 inline uint64_t table_error_avx512(const dist_table& t, const sel16& sel, uint64_t) {
+    const __m512i idx = _mm512_cvtepu8_epi32(_mm_load_si128((const __m128i*)sel.s));
+    __m512i acc = _mm512_maskz_mov_epi32(_mm512_cmpeq_epi32_mask(idx, _mm512_setzero_si512()), _mm512_load_si512((const void*)t.d[0]));
+    for (int k = 1; k < 4; k++) acc = _mm512_mask_add_epi32(acc, _mm512_cmpeq_epi32_mask(idx, _mm512_set1_epi32(k)), acc, _mm512_load_si512((const void*)t.d[k]));
+    return (uint32_t)_mm512_reduce_add_epi32(acc);
+}
+BU_AVX512 inline scan_result scan_history_avx512(const dist_table& t, const sel16& cur, const sel16* hist, int sad_limit, uint64_t limit) {
+    scan_result r{UINT64_MAX, -1};
+    const __m128i c = _mm_load_si128((const __m128i*)cur.s);
+    const __m512i d0 = _mm512_load_si512((const void*)t.d[0]), d1 = _mm512_load_si512((const void*)t.d[1]), d2 = _mm512_load_si512((const void*)t.d[2]),
+                  d3 = _mm512_load_si512((const void*)t.d[3]);
+    const __m512i k1 = _mm512_set1_epi32(1), k2 = _mm512_set1_epi32(2), k3 = _mm512_set1_epi32(3);
+    for (int j = 0; j < 64; j++) {
+        const __m128i h = _mm_load_si128((const __m128i*)hist[j].s);
+        if (sad_limit > 0) {
+            const __m128i d = _mm_sad_epu8(c, h);
+            if (_mm_cvtsi128_si32(d) + _mm_extract_epi16(d, 4) >= sad_limit) continue;
+        }
+        const __m512i idx = _mm512_cvtepu8_epi32(h);
+        __m512i acc = _mm512_maskz_mov_epi32(_mm512_testn_epi32_mask(idx, idx), d0);
+        acc = _mm512_mask_add_epi32(acc, _mm512_cmpeq_epi32_mask(idx, k1), acc, d1);
+        acc = _mm512_mask_add_epi32(acc, _mm512_cmpeq_epi32_mask(idx, k2), acc, d2);
+        acc = _mm512_mask_add_epi32(acc, _mm512_cmpeq_epi32_mask(idx, k3), acc, d3);
+        const uint64_t e = (uint32_t)_mm512_reduce_add_epi32(acc);
+        if (e < r.err && e <= limit) { r.err = e; r.index = j; }
+    }
+    return r;
+}
+BU_AVX512 inline void block_errors_avx512(bool perceptual, const block_px& px, const sel16& sel, const pal_colors* colors, const int* which, int n, uint64_t* out) {
+    const __m512i idx = _mm512_cvtepu8_epi32(_mm_load_si128((const __m128i*)sel.s));
+    const __m512i x = _mm512_load_si512((const void*)px.x), y = _mm512_load_si512((const void*)px.y), z = _mm512_load_si512((const void*)px.z);
+    for (int i = 0; i < n; i++) {
+        const pal_colors& c = colors[which[i]];
+        const __m512i cx = _mm512_castsi128_si512(_mm_load_si128((const __m128i*)c.x)), cy = _mm512_castsi128_si512(_mm_load_si128((const __m128i*)c.y)),
+                      cz = _mm512_castsi128_si512(_mm_load_si128((const __m128i*)c.z));
+        out[i] = (uint32_t)_mm512_reduce_add_epi32(dist16(perceptual, _mm512_sub_epi32(x, _mm512_permutexvar_epi32(idx, cx)), _mm512_sub_epi32(y, _mm512_permutexvar_epi32(idx, cy)),
+                                                          _mm512_sub_epi32(z, _mm512_permutexvar_epi32(idx, cz))));
+    }
+}
+#undef BU_AVX512
 
 // sum over the pixels of |selector difference| (SSE2: part of the x86-64 baseline)
 inline int selector_sad(const sel16& a, const sel16& b) {
@@ -130,12 +249,17 @@ struct kernels {
     uint64_t (*block_error)(bool, const block_px&, const pal_colors&, const sel16&);
     void (*build_table)(bool, const block_px&, const pal_colors&, dist_table&);
     uint64_t (*table_error)(const dist_table&, const sel16&, uint64_t);
-    bool avx2;
+    scan_result (*scan_history)(const dist_table&, const sel16&, const sel16*, int, uint64_t);
+    void (*block_errors)(bool, const block_px&, const sel16&, const pal_colors*, const int*, int, uint64_t*);
+    const char* isa;
 };
-inline kernels pick_kernels() {
-    const char* off = std::getenv("BU_BACKEND_NO_AVX2");
-    if (__builtin_cpu_supports("avx2") && !(off && off[0] == '1')) return kernels{block_error_avx2, build_table_avx2, table_error_avx2, true};
-    return kernels{block_error_plain, build_table_plain, table_error_plain, false};
+inline kernels pick_kernels() {  // BU_BACKEND_ISA = plain | avx2 | avx512 caps the choice (tests run all of them)
+    const char* cap = std::getenv("BU_BACKEND_ISA");
+    const int level = !cap ? 2 : (!std::strcmp(cap, "plain") ? 0 : (!std::strcmp(cap, "avx2") ? 1 : 2));
+    if (level >= 2 && __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512bw") && __builtin_cpu_supports("avx512vl"))
+        return kernels{block_error_avx512, build_table_avx512, table_error_avx512, scan_history_avx512, block_errors_avx512, "avx512"};
+    if (level >= 1 && __builtin_cpu_supports("avx2")) return kernels{block_error_avx2, build_table_avx2, table_error_avx2, scan_history_avx2, block_errors_avx2, "avx2"};
+    return kernels{block_error_plain, build_table_plain, table_error_plain, scan_history_plain, block_errors_plain, "plain"};
 }
 
 }  // namespace metric

@@ -558,6 +558,7 @@ bool etc1s_backend::encode_image() {
                             uint64_t best_err = UINT64_MAX;
                             int best_idx = 0;
                             const int dist = std::min(std::abs(delta) - 1, max_search);
+                            int cand[128], n_cand = 0;   // 2 * max_search at most
                             for (int d = -dist; d < dist; d++) {
                                 int trial = (int)prev_endpoint + d;
                                 if (trial < 0) trial += (int)n_ep; else if (trial >= (int)n_ep) trial -= (int)n_ep;
@@ -567,9 +568,12 @@ bool etc1s_backend::encode_image() {
                                     if (p.inten > cur_c.inten) continue;
                                     if (std::abs((int)cur_e.r - p.r) + std::abs((int)cur_e.g - p.g) + std::abs((int)cur_e.b - p.b) > kColorDeltaThresh) continue;
                                 }
-                                const uint64_t err = K.block_error(perceptual, px, sorted_colors[trial], sels);
-                                if (err < best_err && err <= thresh_err) { best_err = err; best_idx = trial; }
+                                cand[n_cand++] = trial;
                             }
+                            uint64_t cand_err[128];
+                            K.block_errors(perceptual, px, sels, sorted_colors.data(), cand, n_cand, cand_err);
+                            for (int i = 0; i < n_cand; i++)
+                                if (cand_err[i] < best_err && cand_err[i] <= thresh_err) { best_err = cand_err[i]; best_idx = cand[i]; }
                             if (best_err != UINT64_MAX) {
                                 m.endpoint_index = m_endpoint_new_to_old[best_idx];
                                 new_endpoint = best_idx;
@@ -594,15 +598,8 @@ bool etc1s_backend::encode_image() {
                     const sel16& cur_sels = m_selector_bytes[m.selector_index];
                     const uint64_t cur_err = K.table_error(table, cur_sels, UINT64_MAX);
                     const uint64_t limit_err = (uint64_t)ceilf(cur_err * selector_thresh);
-                    uint64_t best_err = UINT64_MAX;
-                    int best_idx = 0;
-                    uint32_t best_j = 0;
-                    for (uint32_t j = 0; j < kSelectorHistorySize; j++) {
-                        if (level <= 1 && metric::selector_sad(cur_sels, history.sel[j]) >= kSelDiffThreshold) continue;
-                        const uint64_t err = K.table_error(table, history.sel[j], std::min(limit_err, best_err));  // exact when <= the bound
-                        if (err < best_err && err <= limit_err) { best_err = err; best_idx = history.v[j]; best_j = j; }
-                    }
-                    if (best_err != UINT64_MAX) { new_selector = best_idx; history_index = (int)best_j; }
+                    const metric::scan_result best = K.scan_history(table, cur_sels, history.sel, level <= 1 ? kSelDiffThreshold : 0, limit_err);
+                    if (best.index >= 0) { new_selector = history.v[best.index]; history_index = best.index; }
                 }
                 m.selector_index = m_selector_new_to_old[new_selector];
                 if (history_index != 0) close_selector_run();

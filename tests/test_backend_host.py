@@ -193,8 +193,9 @@ def test_palette_reordering_matches_reference():
 
 
 @pytest.mark.parametrize("case", ["synth_l1", "strong_rdo", "two_slices"])
-def test_backend_plain_and_avx2_paths_agree(case, monkeypatch):
-    """block_metric.h has a plain and an AVX2 form of every inner loop; both must give the reference's bytes."""
+def test_backend_isa_paths_agree(case, monkeypatch):
+    """block_metric.h has a plain, an AVX2 and an AVX-512 form of every inner loop; each must give the reference's bytes (a form the
+    CPU lacks falls back to the next one down)."""
     from basis_universal_amd.backend import Etc1sBackend
     img_fn, max_ep, max_sel, level, perceptual, slices, ept, selt = CASES[case]
     blocks = to_pixel_blocks(img_fn())
@@ -202,8 +203,8 @@ def test_backend_plain_and_avx2_paths_agree(case, monkeypatch):
     fe.call("compress")
     arrays = _arrays(fe, blocks)
     fe.backend_run(slices, ept, selt)
-    for no_avx2 in ("1", "0"):
-        monkeypatch.setenv("BU_BACKEND_NO_AVX2", no_avx2)
+    for isa in ("plain", "avx2", "avx512"):
+        monkeypatch.setenv("BU_BACKEND_ISA", isa)
         be = Etc1sBackend.from_arrays(slices=slices, perceptual=perceptual, endpoint_rdo_thresh=ept, selector_rdo_thresh=selt, compression_level=level, **arrays)
         be.encode()
         _compare(fe, be, len(slices))

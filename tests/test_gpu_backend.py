@@ -7,7 +7,8 @@ import pytest
 
 from helpers import have_ref, RefFrontend, synth, uniform_random, to_pixel_blocks
 
-pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not have_ref(), reason="oracle/_ref not present")]
+pytestmark = pytest.mark.gpu
+needs_ref = pytest.mark.skipif(not have_ref(), reason="oracle/_ref not present")
 
 OUTPUTS = ["endpoint_palette", "selector_palette", "slice_image_tables", "slice_image_crcs", "num_endpoints", "num_selectors",
            "encoder_blocks", "endpoint_remap_old_to_new", "selector_remap_new_to_old"]
@@ -32,6 +33,7 @@ def _canon(name, a):
     return a
 
 
+@needs_ref
 @pytest.mark.parametrize("case", sorted(CASES))
 def test_frontend_plus_backend_matches_reference(hip_ctx, case):
     from basis_universal_amd.etc1s import Etc1sFrontend
@@ -59,6 +61,31 @@ def test_frontend_plus_backend_matches_reference(hip_ctx, case):
     be.close(); fe.close(); ref.close()
 
 
+def _golden_cases():
+    import json, pathlib
+    return json.loads((pathlib.Path(__file__).parent / "golden" / "etc1s_backend_digests.json").read_text())
+
+
+@pytest.mark.parametrize("case", sorted(_golden_cases()))
+def test_frontend_plus_backend_matches_golden(hip_ctx, case):
+    """The committed digests of the reference's payloads (tools/gen_golden_backend.py): needs no reference build at run time."""
+    import hashlib
+    import test_gpu_etc1s_frontend as T
+    from basis_universal_amd.etc1s import Etc1sFrontend
+    from basis_universal_amd.backend import Etc1sBackend
+    g = _golden_cases()[case]
+    blocks, max_ep, max_sel, level, perceptual = T._params(case)
+    fe = Etc1sFrontend(hip_ctx)
+    fe.init(blocks, max_ep, max_sel, level, perceptual)
+    fe.compress()
+    be = Etc1sBackend.from_frontend(fe, [tuple(s) for s in g["slices"]], 1.5, 1.25, level)
+    assert be.encode() == g["compressed_bytes"]
+    got = {k: hashlib.sha256(np.ascontiguousarray(be.get(k)).tobytes()).hexdigest() for k in g["digests"]}
+    assert got == g["digests"], [k for k in got if got[k] != g["digests"][k]]
+    be.close(); fe.close()
+
+
+@needs_ref
 def test_backend_on_device_only_tiles(hip_ctx):
     """The frontend was given tiles that live in HBM only: the backend fetches its host copy through the frontend."""
     from basis_universal_amd.etc1s import Etc1sFrontend
