@@ -29,10 +29,15 @@ inline uint32_t dist1(bool perceptual, int dx, int dy, int dz) {
     if (perceptual) return ((uint32_t)(dx * dx) >> 5) + ((((uint32_t)(dy * dy) >> 5) * 26u) >> 7) + ((((uint32_t)(dz * dz) >> 5) * 3u) >> 7);
     return (uint32_t)(dx * dx + dy * dy + dz * dz);
 }
-inline sel16 unpack_selectors(uint32_t packed) {
+inline sel16 unpack_selectors(uint32_t packed) {  // four selectors per byte -> one per byte
+    static const struct lut_t { uint32_t v[256]; lut_t() { for (uint32_t b = 0; b < 256; b++) v[b] = (b & 3) | (((b >> 2) & 3) << 8) | (((b >> 4) & 3) << 16) | ((b >> 6) << 24); } } lut;
     sel16 o;
-    for (int p = 0; p < 16; p++) o.s[p] = (uint8_t)((packed >> (2 * p)) & 3);
+    const uint32_t w[4] = {lut.v[packed & 255], lut.v[(packed >> 8) & 255], lut.v[(packed >> 16) & 255], lut.v[packed >> 24]};
+    std::memcpy(o.s, w, 16);
     return o;
+}
+inline void load_pixels_plain(bool perceptual, block_px& out, const uint8_t* rgba16) {
+    for (int p = 0; p < 16; p++) to_metric(perceptual, rgba16[p * 4], rgba16[p * 4 + 1], rgba16[p * 4 + 2], out.x[p], out.y[p], out.z[p]);
 }
 
 // ---- plain C++
@@ -74,8 +79,45 @@ inline void block_errors_plain(bool perceptual, const block_px& px, const sel16&
     for (int i = 0; i < n; i++) out[i] = block_error_plain(perceptual, px, colors[which[i]], sel);
 }
 
+// The endpoint search's pre-filter over a window of `count` (<= 128) consecutive palette entries given as byte arrays (colour5, intensity
+// table, used flag): bit i of the result says entry i is worth an error evaluation. With `strict` (compression levels 0 and 1) an entry
+// must not have a higher intensity table than the block's and must be within 8 in summed colour5 distance (backend.cpp:880-892).
+struct window_mask { uint64_t w[2]; };
+inline window_mask filter_window_plain(const uint8_t* r, const uint8_t* g, const uint8_t* b, const uint8_t* inten, const uint8_t* used, int count,
+                                       int cur_r, int cur_g, int cur_b, int cur_inten, bool strict) {
+    window_mask m{{0, 0}};
+    for (int i = 0; i < count; i++) {
+        if (!used[i]) continue;
+        if (strict && (inten[i] > cur_inten || std::abs(cur_r - r[i]) + std::abs(cur_g - g[i]) + std::abs(cur_b - b[i]) > 8)) continue;
+        m.w[i >> 6] |= 1ull << (i & 63);
+    }
+    return m;
+}
+
 // ---- AVX2
 #define BU_AVX2 __attribute__((target("avx2")))
+BU_AVX2 inline window_mask filter_window_avx2(const uint8_t* r, const uint8_t* g, const uint8_t* b, const uint8_t* inten, const uint8_t* used, int count,
+                                             int cur_r, int cur_g, int cur_b, int cur_inten, bool strict) {   // reads whole 32-byte chunks: arrays are padded
+    window_mask m{{0, 0}};
+    const __m256i cr = _mm256_set1_epi8((char)cur_r), cg = _mm256_set1_epi8((char)cur_g), cb = _mm256_set1_epi8((char)cur_b), ci = _mm256_set1_epi8((char)cur_inten);
+    const __m256i eight = _mm256_set1_epi8(8), zero = _mm256_setzero_si256();
+    for (int c = 0; c * 32 < count; c++) {
+        __m256i ok = _mm256_cmpeq_epi8(_mm256_cmpeq_epi8(_mm256_loadu_si256((const __m256i*)(used + 32 * c)), zero), zero);  // used != 0
+        if (strict) {
+            const __m256i R = _mm256_loadu_si256((const __m256i*)(r + 32 * c)), G = _mm256_loadu_si256((const __m256i*)(g + 32 * c)), B = _mm256_loadu_si256((const __m256i*)(b + 32 * c));
+            const __m256i dr = _mm256_or_si256(_mm256_subs_epu8(R, cr), _mm256_subs_epu8(cr, R)), dg = _mm256_or_si256(_mm256_subs_epu8(G, cg), _mm256_subs_epu8(cg, G)),
+                          db = _mm256_or_si256(_mm256_subs_epu8(B, cb), _mm256_subs_epu8(cb, B));
+            const __m256i sum = _mm256_adds_epu8(_mm256_adds_epu8(dr, dg), db);
+            ok = _mm256_and_si256(ok, _mm256_cmpeq_epi8(_mm256_max_epu8(sum, eight), eight));                                              // sum <= 8
+            ok = _mm256_and_si256(ok, _mm256_cmpeq_epi8(_mm256_max_epu8(_mm256_loadu_si256((const __m256i*)(inten + 32 * c)), ci), ci));  // inten <= cur
+        }
+        uint64_t bits = (uint32_t)_mm256_movemask_epi8(ok);
+        const int left = count - 32 * c;
+        if (left < 32) bits &= (1ull << left) - 1;
+        m.w[c >> 1] |= bits << (32 * (c & 1));
+    }
+    return m;
+}
 BU_AVX2 inline __m256i dist8(bool perceptual, __m256i dx, __m256i dy, __m256i dz) {
     const __m256i xx = _mm256_mullo_epi32(dx, dx), yy = _mm256_mullo_epi32(dy, dy), zz = _mm256_mullo_epi32(dz, dz);
     if (!perceptual) return _mm256_add_epi32(_mm256_add_epi32(xx, yy), zz);
@@ -128,21 +170,51 @@ BU_AVX2 inline uint64_t table_error_avx2(const dist_table& t, const sel16& sel, 
     if (bound != UINT64_MAX) { const uint64_t e = hsum8(lo); if (e > bound) return e; }
     return hsum8(_mm256_add_epi32(lo, table_half_avx2(t, _mm_srli_si128(s, 8), 1)));
 }
+BU_AVX2 inline void load_pixels_avx2(bool perceptual, block_px& out, const uint8_t* rgba16) {
+    const __m256i m = _mm256_set1_epi32(255);
+    for (int h = 0; h < 2; h++) {
+        const __m256i v = _mm256_loadu_si256((const __m256i*)(rgba16 + 32 * h));
+        const __m256i r = _mm256_and_si256(v, m), g = _mm256_and_si256(_mm256_srli_epi32(v, 8), m), b = _mm256_and_si256(_mm256_srli_epi32(v, 16), m);
+        if (perceptual) {
+            const __m256i l = _mm256_add_epi32(_mm256_add_epi32(_mm256_mullo_epi32(r, _mm256_set1_epi32(14)), _mm256_mullo_epi32(g, _mm256_set1_epi32(45))), _mm256_mullo_epi32(b, _mm256_set1_epi32(5)));
+            _mm256_store_si256((__m256i*)(out.x + 8 * h), l);
+            _mm256_store_si256((__m256i*)(out.y + 8 * h), _mm256_sub_epi32(_mm256_slli_epi32(r, 6), l));
+            _mm256_store_si256((__m256i*)(out.z + 8 * h), _mm256_sub_epi32(_mm256_slli_epi32(b, 6), l));
+        } else {
+            _mm256_store_si256((__m256i*)(out.x + 8 * h), r); _mm256_store_si256((__m256i*)(out.y + 8 * h), g); _mm256_store_si256((__m256i*)(out.z + 8 * h), b);
+        }
+    }
+}
 BU_AVX2 inline scan_result scan_history_avx2(const dist_table& t, const sel16& cur, const sel16* hist, int sad_limit, uint64_t limit) {
     scan_result r{UINT64_MAX, -1};
-    const __m128i c = _mm_load_si128((const __m128i*)cur.s);
-    for (int j = 0; j < 64; j++) {
-        const __m128i h = _mm_load_si128((const __m128i*)hist[j].s);
-        if (sad_limit > 0) {
-            const __m128i d = _mm_sad_epu8(c, h);
-            if (_mm_cvtsi128_si32(d) + _mm_extract_epi16(d, 4) >= sad_limit) continue;
+    uint64_t todo = ~0ull;
+    if (sad_limit > 0) {  // the pre-filter for all 64 patterns first, two per SAD instruction
+        todo = 0;
+        const __m256i c = _mm256_broadcastsi128_si256(_mm_load_si128((const __m128i*)cur.s)), lim = _mm256_set1_epi64x(sad_limit);
+        for (int q = 0; q < 32; q++) {
+            const __m256i d = _mm256_sad_epu8(c, _mm256_loadu_si256((const __m256i*)(hist + 2 * q)));
+            const __m256i sum = _mm256_add_epi64(d, _mm256_bsrli_epi128(d, 8));
+            const uint32_t m = (uint32_t)_mm256_movemask_pd(_mm256_castsi256_pd(_mm256_cmpgt_epi64(lim, sum)));  // bits 0 and 2
+            todo |= (uint64_t)((m & 1u) | ((m >> 1) & 2u)) << (2 * q);
         }
-        const uint64_t bound = r.err < limit ? r.err : limit;
-        const __m256i lo = table_half_avx2(t, h, 0);
-        uint64_t e = hsum8(lo);
-        if (e > bound) continue;
-        e = hsum8(_mm256_add_epi32(lo, table_half_avx2(t, _mm_srli_si128(h, 8), 1)));
-        if (e < r.err && e <= limit) { r.err = e; r.index = j; }
+    }
+    while (todo) {  // the survivors four at a time with one shared lane reduction
+        int j[4];
+        __m256i acc[4];
+        int n = 0;
+        for (; n < 4 && todo; n++) { j[n] = __builtin_ctzll(todo); todo &= todo - 1; }
+        for (int k = 0; k < 4; k++) {
+            const __m128i h = _mm_load_si128((const __m128i*)hist[j[k < n ? k : 0]].s);
+            acc[k] = _mm256_add_epi32(table_half_avx2(t, h, 0), table_half_avx2(t, _mm_srli_si128(h, 8), 1));
+        }
+        const __m256i t0 = _mm256_add_epi32(_mm256_unpacklo_epi32(acc[0], acc[1]), _mm256_unpackhi_epi32(acc[0], acc[1]));
+        const __m256i t1 = _mm256_add_epi32(_mm256_unpacklo_epi32(acc[2], acc[3]), _mm256_unpackhi_epi32(acc[2], acc[3]));
+        const __m256i u = _mm256_add_epi32(_mm256_unpacklo_epi64(t0, t1), _mm256_unpackhi_epi64(t0, t1));
+        const __m128i w = _mm_add_epi32(_mm256_castsi256_si128(u), _mm256_extracti128_si256(u, 1));
+        alignas(16) uint32_t e[4];
+        _mm_store_si128((__m128i*)e, w);
+        for (int k = 0; k < n; k++)
+            if (e[k] < r.err && e[k] <= limit) { r.err = e[k]; r.index = j[k]; }
     }
     return r;
 }
@@ -195,25 +267,58 @@ BU_AVX512 inline uint64_t table_error_avx512(const dist_table& t, const sel16& s
     for (int k = 1; k < 4; k++) acc = _mm512_mask_add_epi32(acc, _mm512_cmpeq_epi32_mask(idx, _mm512_set1_epi32(k)), acc, _mm512_load_si512((const void*)t.d[k]));
     return (uint32_t)_mm512_reduce_add_epi32(acc);
 }
+BU_AVX512 inline void load_pixels_avx512(bool perceptual, block_px& out, const uint8_t* rgba16) {
+    const __m512i m = _mm512_set1_epi32(255), v = _mm512_loadu_si512((const void*)rgba16);
+    const __m512i r = _mm512_and_si512(v, m), g = _mm512_and_si512(_mm512_srli_epi32(v, 8), m), b = _mm512_and_si512(_mm512_srli_epi32(v, 16), m);
+    if (perceptual) {
+        const __m512i l = _mm512_add_epi32(_mm512_add_epi32(_mm512_mullo_epi32(r, _mm512_set1_epi32(14)), _mm512_mullo_epi32(g, _mm512_set1_epi32(45))), _mm512_mullo_epi32(b, _mm512_set1_epi32(5)));
+        _mm512_store_si512((void*)out.x, l);
+        _mm512_store_si512((void*)out.y, _mm512_sub_epi32(_mm512_slli_epi32(r, 6), l));
+        _mm512_store_si512((void*)out.z, _mm512_sub_epi32(_mm512_slli_epi32(b, 6), l));
+    } else {
+        _mm512_store_si512((void*)out.x, r); _mm512_store_si512((void*)out.y, g); _mm512_store_si512((void*)out.z, b);
+    }
+}
+// The pre-filter for all 64 patterns first (four per SAD instruction -> a 64-bit candidate mask), then the survivors four at a time with
+// one shared lane reduction.
 BU_AVX512 inline scan_result scan_history_avx512(const dist_table& t, const sel16& cur, const sel16* hist, int sad_limit, uint64_t limit) {
     scan_result r{UINT64_MAX, -1};
-    const __m128i c = _mm_load_si128((const __m128i*)cur.s);
+    uint64_t todo = ~0ull;
+    if (sad_limit > 0) {
+        todo = 0;
+        const __m512i c = _mm512_broadcast_i32x4(_mm_load_si128((const __m128i*)cur.s)), lim = _mm512_set1_epi64(sad_limit);
+        for (int q = 0; q < 16; q++) {
+            const __m512i d = _mm512_sad_epu8(c, _mm512_loadu_si512((const void*)(hist + 4 * q)));   // per pattern: two 64-bit halves
+            const __m512i sum = _mm512_add_epi64(d, _mm512_bsrli_epi128(d, 8));                      // even 64-bit lanes: the pattern's SAD
+            const uint32_t m = _mm512_cmplt_epu64_mask(sum, lim);                                  // bits 0, 2, 4, 6
+            todo |= (uint64_t)((m & 1u) | ((m >> 1) & 2u) | ((m >> 2) & 4u) | ((m >> 3) & 8u)) << (4 * q);
+        }
+    }
     const __m512i d0 = _mm512_load_si512((const void*)t.d[0]), d1 = _mm512_load_si512((const void*)t.d[1]), d2 = _mm512_load_si512((const void*)t.d[2]),
                   d3 = _mm512_load_si512((const void*)t.d[3]);
     const __m512i k1 = _mm512_set1_epi32(1), k2 = _mm512_set1_epi32(2), k3 = _mm512_set1_epi32(3);
-    for (int j = 0; j < 64; j++) {
-        const __m128i h = _mm_load_si128((const __m128i*)hist[j].s);
-        if (sad_limit > 0) {
-            const __m128i d = _mm_sad_epu8(c, h);
-            if (_mm_cvtsi128_si32(d) + _mm_extract_epi16(d, 4) >= sad_limit) continue;
+    while (todo) {
+        int j[4];
+        __m512i acc[4];
+        int n = 0;
+        for (; n < 4 && todo; n++) { j[n] = __builtin_ctzll(todo); todo &= todo - 1; }
+        for (int k = 0; k < 4; k++) {
+            const __m512i idx = _mm512_cvtepu8_epi32(_mm_load_si128((const __m128i*)hist[j[k < n ? k : 0]].s));
+            __m512i a = _mm512_maskz_mov_epi32(_mm512_testn_epi32_mask(idx, idx), d0);
+            a = _mm512_mask_add_epi32(a, _mm512_cmpeq_epi32_mask(idx, k1), a, d1);
+            a = _mm512_mask_add_epi32(a, _mm512_cmpeq_epi32_mask(idx, k2), a, d2);
+            acc[k] = _mm512_mask_add_epi32(a, _mm512_cmpeq_epi32_mask(idx, k3), a, d3);
         }
-        const __m512i idx = _mm512_cvtepu8_epi32(h);
-        __m512i acc = _mm512_maskz_mov_epi32(_mm512_testn_epi32_mask(idx, idx), d0);
-        acc = _mm512_mask_add_epi32(acc, _mm512_cmpeq_epi32_mask(idx, k1), acc, d1);
-        acc = _mm512_mask_add_epi32(acc, _mm512_cmpeq_epi32_mask(idx, k2), acc, d2);
-        acc = _mm512_mask_add_epi32(acc, _mm512_cmpeq_epi32_mask(idx, k3), acc, d3);
-        const uint64_t e = (uint32_t)_mm512_reduce_add_epi32(acc);
-        if (e < r.err && e <= limit) { r.err = e; r.index = j; }
+        // lane sums of the four accumulators at once
+        const __m512i t0 = _mm512_add_epi32(_mm512_unpacklo_epi32(acc[0], acc[1]), _mm512_unpackhi_epi32(acc[0], acc[1]));
+        const __m512i t1 = _mm512_add_epi32(_mm512_unpacklo_epi32(acc[2], acc[3]), _mm512_unpackhi_epi32(acc[2], acc[3]));
+        const __m512i u = _mm512_add_epi32(_mm512_unpacklo_epi64(t0, t1), _mm512_unpackhi_epi64(t0, t1));  // per 128-bit lane: partial sums of a, b, c, d
+        const __m256i v = _mm256_add_epi32(_mm512_castsi512_si256(u), _mm512_extracti64x4_epi64(u, 1));
+        const __m128i w = _mm_add_epi32(_mm256_castsi256_si128(v), _mm256_extracti128_si256(v, 1));
+        alignas(16) uint32_t e[4];
+        _mm_store_si128((__m128i*)e, w);
+        for (int k = 0; k < n; k++)
+            if (e[k] < r.err && e[k] <= limit) { r.err = e[k]; r.index = j[k]; }
     }
     return r;
 }
@@ -251,15 +356,17 @@ struct kernels {
     uint64_t (*table_error)(const dist_table&, const sel16&, uint64_t);
     scan_result (*scan_history)(const dist_table&, const sel16&, const sel16*, int, uint64_t);
     void (*block_errors)(bool, const block_px&, const sel16&, const pal_colors*, const int*, int, uint64_t*);
+    void (*load_pixels)(bool, block_px&, const uint8_t*);
+    window_mask (*filter_window)(const uint8_t*, const uint8_t*, const uint8_t*, const uint8_t*, const uint8_t*, int, int, int, int, int, bool);
     const char* isa;
 };
 inline kernels pick_kernels() {  // BU_BACKEND_ISA = plain | avx2 | avx512 caps the choice (tests run all of them)
     const char* cap = std::getenv("BU_BACKEND_ISA");
     const int level = !cap ? 2 : (!std::strcmp(cap, "plain") ? 0 : (!std::strcmp(cap, "avx2") ? 1 : 2));
     if (level >= 2 && __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512bw") && __builtin_cpu_supports("avx512vl"))
-        return kernels{block_error_avx512, build_table_avx512, table_error_avx512, scan_history_avx512, block_errors_avx512, "avx512"};
-    if (level >= 1 && __builtin_cpu_supports("avx2")) return kernels{block_error_avx2, build_table_avx2, table_error_avx2, scan_history_avx2, block_errors_avx2, "avx2"};
-    return kernels{block_error_plain, build_table_plain, table_error_plain, scan_history_plain, block_errors_plain, "plain"};
+        return kernels{block_error_avx512, build_table_avx512, table_error_avx512, scan_history_avx512, block_errors_avx512, load_pixels_avx512, filter_window_avx2, "avx512"};
+    if (level >= 1 && __builtin_cpu_supports("avx2")) return kernels{block_error_avx2, build_table_avx2, table_error_avx2, scan_history_avx2, block_errors_avx2, load_pixels_avx2, filter_window_avx2, "avx2"};
+    return kernels{block_error_plain, build_table_plain, table_error_plain, scan_history_plain, block_errors_plain, load_pixels_plain, filter_window_plain, "plain"};
 }
 
 }  // namespace metric

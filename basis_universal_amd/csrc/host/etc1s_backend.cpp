@@ -1,8 +1,9 @@
 // etc1s_backend.cpp -- see etc1s_backend.h. Reference: encoder/basisu_backend.cpp (cited per function).
 //
 // How the walk differs from the reference's while producing the same bytes:
-//  * one flat block array and one token stream per slice, written in bit-stream order (run tokens are placeholders patched when the
-//    run ends) instead of symbol vectors that a second walk over the blocks re-synchronises with;
+//  * one flat block array; per slice three loops (endpoints, distance tables, selectors) that run as a three-thread pipeline, and one
+//    token stream in bit-stream order (run tokens are placeholders patched when the run ends) instead of symbol vectors that a second
+//    walk over the blocks re-synchronises with; slices run concurrently;
 //  * the selector-history search looks a candidate's error up in a 4x16 table of the block's pixel-to-colour distances (64 distance
 //    evaluations per block instead of up to 16 per candidate and 64 candidates), and pre-filters candidates with one SAD instruction;
 //  * the error loops run 8 pixels per instruction where the CPU has AVX2 (block_metric.h), the palette's block colours are converted to
@@ -49,16 +50,23 @@ struct timer {
 
 // 16 selectors of an etc_block, pixel p = y*4+x in bits 2p (etc.h:232-236 for the bit positions, backend.cpp:104-117 for the order)
 inline uint32_t packed_selectors(const bu_etc_block& blk) {
-    static const uint8_t to_sel[4] = {2, 3, 1, 0};
-    const uint32_t lo32 = (uint32_t)load_be64(blk);
-    uint32_t out = 0;
-    for (uint32_t y = 0; y < 4; y++)
-        for (uint32_t x = 0; x < 4; x++) {
-            const uint32_t bit = x * 4 + y;
-            const uint32_t raw = ((lo32 >> bit) & 1u) | (((lo32 >> (16 + bit)) & 1u) << 1);
-            out |= (uint32_t)to_sel[raw] << (2 * (y * 4 + x));
+    // each plane byte spreads to the even bits of its eight pixels' fields: plane bit x*4+y belongs to pixel y*4+x
+    static const struct spread_t {
+        uint32_t v[2][256];
+        spread_t() {
+            for (uint32_t half = 0; half < 2; half++)
+                for (uint32_t byte = 0; byte < 256; byte++) {
+                    uint32_t o = 0;
+                    for (uint32_t k = 0; k < 8; k++)
+                        if (byte & (1u << k)) { const uint32_t bit = half * 8 + k, x = bit >> 2, y = bit & 3; o |= 1u << (2 * (y * 4 + x)); }
+                    v[half][byte] = o;
+                }
         }
-    return out;
+    } S;
+    const uint32_t lo32 = (uint32_t)load_be64(blk);
+    const uint32_t lsb = S.v[0][lo32 & 255] | S.v[1][(lo32 >> 8) & 255], msb = S.v[0][(lo32 >> 16) & 255] | S.v[1][lo32 >> 24];
+    // raw (lsb | msb << 1) -> selector {2, 3, 1, 0}: high bit = !msb, low bit = lsb ^ msb
+    return ((msb ^ 0x55555555u) << 1) | (lsb ^ msb);
 }
 
 struct color5 { uint8_t r, g, b, inten; };
@@ -75,14 +83,10 @@ inline void block_colors(bool perceptual, pal_colors& out, color5 c) {  // etc.h
     const int r = (c.r << 3) | (c.r >> 2), g = (c.g << 3) | (c.g >> 2), b = (c.b << 3) | (c.b >> 2);
     for (int k = 0; k < 4; k++) { const int d = kInten[c.inten][k]; metric::to_metric(perceptual, clamp255(r + d), clamp255(g + d), clamp255(b + d), out.x[k], out.y[k], out.z[k]); }
 }
-inline void load_pixels(bool perceptual, block_px& out, const bu_pixel_block& px) {
-    for (int p = 0; p < 16; p++) metric::to_metric(perceptual, px.m_pixels[p][0], px.m_pixels[p][1], px.m_pixels[p][2], out.x[p], out.y[p], out.z[p]);
-}
-
 // basist::approx_move_to_front (transcoder_internal.h:863-929)
 struct history_buffer {
     int v[kSelectorHistorySize];
-    sel16 sel[kSelectorHistorySize];   // the pattern behind every entry, kept in step
+    alignas(64) sel16 sel[kSelectorHistorySize];   // the pattern behind every entry, kept in step
     uint32_t rover;
     void reset(const sel16& of_zero) { std::memset(v, 0, sizeof(v)); for (sel16& s : sel) s = of_zero; rover = kSelectorHistorySize / 2; }
     void add(int x, const sel16& of_x) { v[rover] = x; sel[rover] = of_x; if (++rover == kSelectorHistorySize) rover = kSelectorHistorySize / 2; }
@@ -316,7 +320,7 @@ bool etc1s_backend::create_encoder_blocks() {
                     m.endpoint_predictor = (uint8_t)best_pred;
                 } else if (thresh > 0.0f) {
                     block_px px;
-                    load_pixels(perceptual, px, m_src.source_blocks[b]);
+                    K.load_pixels(perceptual, px, &m_src.source_blocks[b].m_pixels[0][0]);
                     const bu_etc_block& out = m_src.output_blocks[b];
                     const sel16 sels = metric::unpack_selectors(packed_selectors(out));
                     pal_colors own;
@@ -415,8 +419,21 @@ void etc1s_backend::sort_selector_codebook() {
 // backend.cpp:619-681: CRC-16 of the slice as plain ETC1 blocks (differential, not flipped), what a transcoder to ETC1 would produce
 void etc1s_backend::compute_slice_crcs() {
     static const uint8_t to_raw[4] = {3, 2, 0, 1};  // g_selector_index_to_etc1
+    // the two selector bit planes of every palette pattern, once per pattern
+    std::vector<uint32_t> planes(m_selector_palette.size());
+    for (size_t k = 0; k < planes.size(); k++) {
+        const uint32_t sels = m_selector_palette[k];
+        uint32_t lo32 = 0;
+        for (uint32_t y = 0; y < 4; y++)
+            for (uint32_t x = 0; x < 4; x++) {
+                const uint32_t raw = to_raw[(sels >> (2 * (y * 4 + x))) & 3], bit = x * 4 + y;
+                lo32 |= (raw & 1u) << bit;
+                lo32 |= (raw >> 1) << (16 + bit);
+            }
+        planes[k] = lo32;
+    }
     m_output.m_slice_image_crcs.assign(m_slices.size(), 0);
-    for (size_t si = 0; si < m_slices.size(); si++) {
+    for_each_slice(m_slices, [&](size_t si) {
         const backend_slice_desc& s = m_slices[si];
         const uint32_t gx = (s.m_width + 3) / 4, gy = (s.m_height + 3) / 4;
         std::vector<uint8_t> img((size_t)gx * gy * 8, 0);
@@ -424,20 +441,13 @@ void etc1s_backend::compute_slice_crcs() {
             for (uint32_t bx = 0; bx < s.m_num_blocks_x && bx < gx; bx++) {
                 const encoder_block& m = m_blocks[s.m_first_block_index + bx + by * s.m_num_blocks_x];
                 const endpoint_entry& e = m_endpoint_palette[m.endpoint_index];
-                const uint32_t sels = m_selector_palette[m.selector_index];
-                uint32_t lo32 = 0;
-                for (uint32_t y = 0; y < 4; y++)
-                    for (uint32_t x = 0; x < 4; x++) {
-                        const uint32_t raw = to_raw[(sels >> (2 * (y * 4 + x))) & 3], bit = x * 4 + y;
-                        lo32 |= (raw & 1u) << bit;
-                        lo32 |= (raw >> 1) << (16 + bit);
-                    }
-                const uint64_t v = ((uint64_t)e.r << 59) | ((uint64_t)e.g << 51) | ((uint64_t)e.b << 43) | ((uint64_t)e.inten << 37) | ((uint64_t)e.inten << 34) | (1ull << 33) | lo32;
+                const uint64_t v = ((uint64_t)e.r << 59) | ((uint64_t)e.g << 51) | ((uint64_t)e.b << 43) | ((uint64_t)e.inten << 37) | ((uint64_t)e.inten << 34) | (1ull << 33) |
+                                   planes[m.selector_index];
                 const uint64_t be = __builtin_bswap64(v);
                 std::memcpy(&img[((size_t)by * gx + bx) * 8], &be, 8);
             }
         m_output.m_slice_image_crcs[si] = crc16_ccitt(img.data(), img.size(), 0);
-    }
+    });
 }
 
 // backend.cpp:687-1485
@@ -458,167 +468,234 @@ bool etc1s_backend::encode_image() {
     const float selector_thresh = std::max(1.0f, m_params.m_selector_rdo_quality_thresh);
     const float endpoint_thresh = std::max(1.0f, m_params.m_endpoint_rdo_quality_thresh);
     const int max_search = level >= 2 ? 64 : 16;  // backend.cpp:852
-    // the endpoint search walks consecutive NEW indices: the palette in that order, unused slots flagged (backend.cpp:874-879)
-    struct sorted_entry { uint8_t r, g, b, inten, used; };
-    std::vector<sorted_entry> sorted_palette(n_ep);
+    // the endpoint search walks a window of consecutive NEW indices (wrapping once at either end, backend.cpp:865-869): the palette in
+    // that order as byte arrays, extended by the largest half-window on both sides so that a window is one contiguous read
+    const uint32_t kPad = 64;
     std::vector<pal_colors> sorted_colors(n_ep);
-    for (uint32_t nw = 0; nw < n_ep; nw++) {
+    std::vector<uint8_t> win_r(n_ep + 2 * kPad + 32, 0), win_g(win_r.size(), 0), win_b(win_r.size(), 0), win_i(win_r.size(), 0), win_u(win_r.size(), 0);
+    for (uint32_t nw = 0; nw < n_ep; nw++) sorted_colors[nw] = m_palette_colors[m_endpoint_new_to_old[nw]];
+    for (uint32_t k = 0; k < n_ep + 2 * kPad; k++) {
+        const uint32_t nw = (uint32_t)(((int64_t)k - kPad) % (int64_t)n_ep + n_ep) % n_ep;
         const endpoint_entry& e = m_endpoint_palette[m_endpoint_new_to_old[nw]];
-        sorted_palette[nw] = sorted_entry{e.r, e.g, e.b, e.inten, m_new_endpoint_was_used[nw]};
-        sorted_colors[nw] = m_palette_colors[m_endpoint_new_to_old[nw]];
+        win_r[k] = e.r; win_g[k] = e.g; win_b[k] = e.b; win_i[k] = e.inten; win_u[k] = m_new_endpoint_was_used[nw];
     }
+
+    // A slice is walked by three loops over its blocks in raster order, each carrying its own state from block to block:
+    //   1. endpoints : predictor symbols per 2x2 macroblock, the endpoint search relative to the previous block's index  (state: previous index, runs)
+    //   2. tables    : the block's pixels against the four colours of its FINAL endpoints (stateless; needs loop 1's result)
+    //   3. selectors : the history-buffer search and the selector symbols                                              (state: history buffer, runs)
+    // Loop 2 only needs loop 1 to be ahead of it and loop 3 only loop 2, so for slices worth it the three run as a pipeline of three
+    // threads coupled by progress counters (the tables travel through a ring); small slices run them one after the other.
+    const uint32_t kPipelineMinBlocks = 16384, kRing = 4096, kPublishEvery = 64;
+    unsigned thread_cap = 8;
+    if (const char* e = std::getenv("BU_HOST_THREADS")) { const int v = std::atoi(e); if (v >= 1 && v <= 64) thread_cap = (unsigned)v; }
+    const bool may_pipeline = thread_cap >= 3 && std::thread::hardware_concurrency() >= 3;
+    struct table_slot { metric::dist_table table; uint64_t cur_err; };
 
     for_each_slice(m_slices, [&](size_t si) {
         const backend_slice_desc& s = m_slices[si];
         std::vector<uint32_t>&selector_hist = stats[si].selector_hist, &rle_hist = stats[si].rle_hist, &delta_hist = stats[si].delta_hist, &pred_hist = stats[si].pred_hist;
         uint32_t& endpoints_remapped = stats[si].endpoints_remapped;
-        history_buffer history;
-        const uint32_t nbx = s.m_num_blocks_x, nby = s.m_num_blocks_y, base = s.m_first_block_index;
-        std::vector<token>& tokens = slice_tokens[si];
-        tokens.reserve((size_t)nbx * nby * 2 + 16);
-        history.reset(m_selector_bytes[m_selector_new_to_old[0]]);
+        const uint32_t nbx = s.m_num_blocks_x, nby = s.m_num_blocks_y, base = s.m_first_block_index, n = nbx * nby;
+        if (!n) return;
         // blocks whose endpoints a later block is predicted from must keep them (backend.cpp:740-766)
-        std::vector<uint8_t> referenced((size_t)nbx * nby, 0);
+        std::vector<uint8_t> referenced(n, 0);
         for (uint32_t by = 0; by < nby; by++)
             for (uint32_t bx = 0; bx < nbx; bx++) {
                 const uint32_t p = m_blocks[base + bx + by * nbx].endpoint_predictor;
                 if (p < kNumEndpointPreds) referenced[(bx + kPredDx[p]) + (size_t)(by + kPredDy[p]) * nbx] = 1;
             }
-        std::vector<size_t> pred_run, selector_run;   // placeholder tokens of the open runs
-        int prev_pred_sym = -1;
-        uint32_t prev_endpoint = 0;
-        auto close_pred_run = [&]() {
-            if (pred_run.empty()) return;
-            const uint32_t count = (uint32_t)pred_run.size();
-            if (count > kEndpointPredMinRepeat) {
-                pred_hist[kEndpointPredRepeatLast]++;
-                tokens[pred_run[0]] = token{count, T_PRED_REPEAT};
-            } else {
-                pred_hist[prev_pred_sym] += count;
-                for (size_t t : pred_run) tokens[t] = token{(uint32_t)prev_pred_sym, T_PRED};
-            }
-            pred_run.clear();
-        };
-        auto close_selector_run = [&]() {
-            if (selector_run.empty()) return;
-            const uint32_t count = (uint32_t)selector_run.size();
-            if (count >= kSelectorRleThresh) {
-                tokens[selector_run[0]] = token{count, T_SELECTOR_RLE};
-                rle_hist[std::min<uint32_t>(count - kSelectorRleThresh, kSelectorRleCountTotal - 1)]++;
-                selector_hist[kHistRleSym]++;
-            } else {
-                selector_hist[kHistFirstSym] += count;
-                for (size_t t : selector_run) tokens[t] = token{kHistFirstSym, T_SELECTOR};
-            }
-            selector_run.clear();
+        // the symbols of a block, by producer; a run's symbol sits on the block that opens the run (placeholders patched when it closes)
+        std::vector<token> pred_tok(n, token{0, T_NONE}), delta_tok(n, token{0, T_NONE}), sel_tok(n, token{0, T_NONE});
+        std::vector<uint32_t> final_endpoint(n, 0);  // NEW palette index per block once loop 1 has passed it
+        const bool pipelined = may_pipeline && n >= kPipelineMinBlocks;
+        const uint32_t ring = pipelined ? kRing : n;
+        std::vector<table_slot> slots(ring);
+        std::atomic<uint32_t> done1{0}, done2{0}, done3{0};
+        auto wait_for = [](const std::atomic<uint32_t>& counter, uint32_t need) {  // until counter >= need
+            uint32_t v;
+            for (uint32_t spins = 0; (v = counter.load(std::memory_order_acquire)) < need; spins++)
+                if (spins > 64) std::this_thread::yield();
+            return v;
         };
 
-        for (uint32_t by = 0; by < nby; by++)
-            for (uint32_t bx = 0; bx < nbx; bx++) {
-                const uint32_t b = base + bx + by * nbx;
-                encoder_block& m = m_blocks[b];
-                // ---- one endpoint-predictor symbol per 2x2 macroblock, runs of equal symbols collapsed (backend.cpp:776-827)
-                if (!(bx & 1) && !(by & 1)) {
-                    uint32_t sym = 0;
-                    for (uint32_t y = 0; y < 2; y++)
-                        for (uint32_t x = 0; x < 2; x++) {
-                            uint32_t pred = kNoEndpointPred;
-                            if (bx + x < nbx && by + y < nby) pred = m_blocks[base + (bx + x) + (by + y) * nbx].endpoint_predictor;
-                            sym |= pred << (x * 2 + y * 4);
-                        }
-                    if ((int)sym == prev_pred_sym) {
-                        pred_run.push_back(tokens.size());
-                        tokens.push_back(token{0, T_NONE});
-                    } else {
-                        close_pred_run();
-                        pred_hist[sym]++;
-                        tokens.push_back(token{sym, T_PRED});
-                        prev_pred_sym = (int)sym;
-                    }
+        auto endpoints_loop = [&]() {
+            std::vector<uint32_t> pred_run;   // the blocks (macroblock corners) holding the placeholders of the open run
+            int prev_pred_sym = -1;
+            uint32_t prev_endpoint = 0;
+            auto close_pred_run = [&]() {
+                if (pred_run.empty()) return;
+                const uint32_t count = (uint32_t)pred_run.size();
+                if (count > kEndpointPredMinRepeat) {
+                    pred_hist[kEndpointPredRepeatLast]++;
+                    pred_tok[pred_run[0]] = token{count, T_PRED_REPEAT};
+                } else {
+                    pred_hist[prev_pred_sym] += count;
+                    for (uint32_t t : pred_run) pred_tok[t] = token{(uint32_t)prev_pred_sym, T_PRED};
                 }
-                // ---- endpoint index, as a delta to the previous block's in the sorted palette (backend.cpp:829-1009)
-                int new_endpoint = (int)m_endpoint_old_to_new[m.endpoint_index];
-                block_px px;
-                bool have_px = false;
-                auto need_px = [&]() { if (!have_px) { load_pixels(perceptual, px, m_src.source_blocks[b]); have_px = true; } };
-                if (m.endpoint_predictor == kNoEndpointPred) {
-                    int delta = new_endpoint - (int)prev_endpoint;
-                    if (m_params.m_endpoint_rdo_quality_thresh > 1.0f && std::abs(delta) > 1 && !referenced[bx + (size_t)by * nbx]) {
-                        // a palette entry closer to the previous index that keeps the error within the threshold is cheaper to code
-                        need_px();
-                        const bu_etc_block& out = m_src.output_blocks[b];
-                        const color5 cur_c = header_of(out);
-                        const sel16 sels = metric::unpack_selectors(packed_selectors(out));
-                        pal_colors own;
-                        block_colors(perceptual, own, cur_c);
-                        const uint64_t cur_err = K.block_error(perceptual, px, own, sels);
-                        if (cur_err) {
-                            const endpoint_entry cur_e = m_endpoint_palette[m.endpoint_index];
-                            const uint64_t thresh_err = (uint64_t)(cur_err * endpoint_thresh);
-                            uint64_t best_err = UINT64_MAX;
-                            int best_idx = 0;
-                            const int dist = std::min(std::abs(delta) - 1, max_search);
-                            int cand[128], n_cand = 0;   // 2 * max_search at most
-                            for (int d = -dist; d < dist; d++) {
-                                int trial = (int)prev_endpoint + d;
-                                if (trial < 0) trial += (int)n_ep; else if (trial >= (int)n_ep) trial -= (int)n_ep;
-                                const sorted_entry& p = sorted_palette[trial];
-                                if (trial == new_endpoint || !p.used) continue;
-                                if (level <= 1) {
-                                    if (p.inten > cur_c.inten) continue;
-                                    if (std::abs((int)cur_e.r - p.r) + std::abs((int)cur_e.g - p.g) + std::abs((int)cur_e.b - p.b) > kColorDeltaThresh) continue;
+                pred_run.clear();
+            };
+            for (uint32_t by = 0; by < nby; by++)
+                for (uint32_t bx = 0; bx < nbx; bx++) {
+                    const uint32_t i = bx + by * nbx, b = base + i;
+                    encoder_block& m = m_blocks[b];
+                    // ---- one endpoint-predictor symbol per 2x2 macroblock, runs of equal symbols collapsed (backend.cpp:776-827)
+                    if (!(bx & 1) && !(by & 1)) {
+                        uint32_t sym = 0;
+                        for (uint32_t y = 0; y < 2; y++)
+                            for (uint32_t x = 0; x < 2; x++) {
+                                uint32_t pred = kNoEndpointPred;
+                                if (bx + x < nbx && by + y < nby) pred = m_blocks[base + (bx + x) + (by + y) * nbx].endpoint_predictor;
+                                sym |= pred << (x * 2 + y * 4);
+                            }
+                        if ((int)sym == prev_pred_sym) {
+                            pred_run.push_back(i);
+                        } else {
+                            close_pred_run();
+                            pred_hist[sym]++;
+                            pred_tok[i] = token{sym, T_PRED};
+                            prev_pred_sym = (int)sym;
+                        }
+                    }
+                    // ---- endpoint index, as a delta to the previous block's in the sorted palette (backend.cpp:829-1009)
+                    int new_endpoint = (int)m_endpoint_old_to_new[m.endpoint_index];
+                    if (m.endpoint_predictor == kNoEndpointPred) {
+                        int delta = new_endpoint - (int)prev_endpoint;
+                        if (m_params.m_endpoint_rdo_quality_thresh > 1.0f && std::abs(delta) > 1 && !referenced[i]) {
+                            // a palette entry closer to the previous index that keeps the error within the threshold is cheaper to code
+                            block_px px;
+                            K.load_pixels(perceptual, px, &m_src.source_blocks[b].m_pixels[0][0]);
+                            const bu_etc_block& out = m_src.output_blocks[b];
+                            const color5 cur_c = header_of(out);
+                            const sel16 sels = metric::unpack_selectors(packed_selectors(out));
+                            pal_colors own;
+                            block_colors(perceptual, own, cur_c);
+                            const uint64_t cur_err = K.block_error(perceptual, px, own, sels);
+                            if (cur_err) {
+                                const endpoint_entry cur_e = m_endpoint_palette[m.endpoint_index];
+                                const uint64_t thresh_err = (uint64_t)(cur_err * endpoint_thresh);
+                                uint64_t best_err = UINT64_MAX;
+                                int best_idx = 0;
+                                const int dist = std::min(std::abs(delta) - 1, max_search);
+                                int cand[128], n_cand = 0;   // 2 * max_search at most
+                                const size_t w0 = (size_t)((int)prev_endpoint - dist + (int)kPad);
+                                metric::window_mask wm = K.filter_window(&win_r[w0], &win_g[w0], &win_b[w0], &win_i[w0], &win_u[w0], 2 * dist, cur_e.r, cur_e.g, cur_e.b, cur_c.inten, level <= 1);
+                                for (int half = 0; half < 2; half++)
+                                    for (uint64_t bits = wm.w[half]; bits; bits &= bits - 1) {
+                                        int trial = (int)prev_endpoint - dist + half * 64 + __builtin_ctzll(bits);
+                                        if (trial < 0) trial += (int)n_ep; else if (trial >= (int)n_ep) trial -= (int)n_ep;
+                                        if (trial != new_endpoint) cand[n_cand++] = trial;
+                                    }
+                                uint64_t cand_err[128];
+                                K.block_errors(perceptual, px, sels, sorted_colors.data(), cand, n_cand, cand_err);
+                                for (int k = 0; k < n_cand; k++)
+                                    if (cand_err[k] < best_err && cand_err[k] <= thresh_err) { best_err = cand_err[k]; best_idx = cand[k]; }
+                                if (best_err != UINT64_MAX) {
+                                    m.endpoint_index = m_endpoint_new_to_old[best_idx];
+                                    new_endpoint = best_idx;
+                                    delta = new_endpoint - (int)prev_endpoint;
+                                    endpoints_remapped++;
                                 }
-                                cand[n_cand++] = trial;
-                            }
-                            uint64_t cand_err[128];
-                            K.block_errors(perceptual, px, sels, sorted_colors.data(), cand, n_cand, cand_err);
-                            for (int i = 0; i < n_cand; i++)
-                                if (cand_err[i] < best_err && cand_err[i] <= thresh_err) { best_err = cand_err[i]; best_idx = cand[i]; }
-                            if (best_err != UINT64_MAX) {
-                                m.endpoint_index = m_endpoint_new_to_old[best_idx];
-                                new_endpoint = best_idx;
-                                delta = new_endpoint - (int)prev_endpoint;
-                                endpoints_remapped++;
                             }
                         }
+                        if (delta < 0) delta += (int)n_ep;
+                        delta_hist[delta]++;
+                        delta_tok[i] = token{(uint32_t)delta, T_ENDPOINT_DELTA};
                     }
-                    if (delta < 0) delta += (int)n_ep;
-                    delta_hist[delta]++;
-                    tokens.push_back(token{(uint32_t)delta, T_ENDPOINT_DELTA});
+                    block_endpoint_indices[b] = m_endpoint_new_to_old[new_endpoint];
+                    final_endpoint[i] = (uint32_t)new_endpoint;
+                    prev_endpoint = (uint32_t)new_endpoint;
+                    if (((i + 1) % kPublishEvery) == 0) done1.store(i + 1, std::memory_order_release);
                 }
-                block_endpoint_indices[b] = m_endpoint_new_to_old[new_endpoint];
-                prev_endpoint = (uint32_t)new_endpoint;
-                // ---- selector index: a recently used pattern (history buffer) that is good enough, else the block's own (backend.cpp:1011-1205)
+            close_pred_run();
+            done1.store(n, std::memory_order_release);
+        };
+
+        auto tables_loop = [&]() {
+            uint32_t ready = 0, consumed = 0;
+            for (uint32_t i = 0; i < n; i++) {
+                if (i >= ready) ready = wait_for(done1, i + 1);
+                if (i >= consumed + ring) consumed = wait_for(done3, i + 1 - ring);
+                const uint32_t b = base + i;
+                block_px px;
+                K.load_pixels(perceptual, px, &m_src.source_blocks[b].m_pixels[0][0]);
+                table_slot& slot = slots[i % ring];
+                K.build_table(perceptual, px, m_palette_colors[m_endpoint_new_to_old[final_endpoint[i]]], slot.table);
+                slot.cur_err = K.table_error(slot.table, m_selector_bytes[m_blocks[b].selector_index], UINT64_MAX);
+                if (((i + 1) % kPublishEvery) == 0) done2.store(i + 1, std::memory_order_release);
+            }
+            done2.store(n, std::memory_order_release);
+        };
+
+        auto selectors_loop = [&]() {
+            history_buffer history;
+            history.reset(m_selector_bytes[m_selector_new_to_old[0]]);
+            std::vector<uint32_t> selector_run;
+            auto close_selector_run = [&]() {
+                if (selector_run.empty()) return;
+                const uint32_t count = (uint32_t)selector_run.size();
+                if (count >= kSelectorRleThresh) {
+                    sel_tok[selector_run[0]] = token{count, T_SELECTOR_RLE};
+                    rle_hist[std::min<uint32_t>(count - kSelectorRleThresh, kSelectorRleCountTotal - 1)]++;
+                    selector_hist[kHistRleSym]++;
+                } else {
+                    selector_hist[kHistFirstSym] += count;
+                    for (uint32_t t : selector_run) sel_tok[t] = token{kHistFirstSym, T_SELECTOR};
+                }
+                selector_run.clear();
+            };
+            uint32_t ready = 0;
+            for (uint32_t i = 0; i < n; i++) {
+                if (i >= ready) ready = wait_for(done2, i + 1);
+                const uint32_t b = base + i;
+                encoder_block& m = m_blocks[b];
+                // ---- a recently used pattern (history buffer) that is good enough, else the block's own (backend.cpp:1011-1205)
                 int new_selector = (int)m_selector_old_to_new[m.selector_index];
                 int history_index = level <= 1 ? metric::find_first_64(history.v, new_selector) : -1;
                 if (history_index == -1) {
-                    need_px();
-                    metric::dist_table table;
-                    K.build_table(perceptual, px, m_palette_colors[m_endpoint_new_to_old[new_endpoint]], table);
-                    const sel16& cur_sels = m_selector_bytes[m.selector_index];
-                    const uint64_t cur_err = K.table_error(table, cur_sels, UINT64_MAX);
-                    const uint64_t limit_err = (uint64_t)ceilf(cur_err * selector_thresh);
-                    const metric::scan_result best = K.scan_history(table, cur_sels, history.sel, level <= 1 ? kSelDiffThreshold : 0, limit_err);
+                    const table_slot& slot = slots[i % ring];
+                    const uint64_t limit_err = (uint64_t)ceilf(slot.cur_err * selector_thresh);
+                    const metric::scan_result best = K.scan_history(slot.table, m_selector_bytes[m.selector_index], history.sel, level <= 1 ? kSelDiffThreshold : 0, limit_err);
                     if (best.index >= 0) { new_selector = history.v[best.index]; history_index = best.index; }
                 }
                 m.selector_index = m_selector_new_to_old[new_selector];
                 if (history_index != 0) close_selector_run();
                 if (history_index == 0) {
-                    selector_run.push_back(tokens.size());
-                    tokens.push_back(token{0, T_NONE});
+                    selector_run.push_back(i);
                 } else if (history_index > 0) {
                     selector_hist[kHistFirstSym + history_index]++;
-                    tokens.push_back(token{kHistFirstSym + (uint32_t)history_index, T_SELECTOR});
+                    sel_tok[i] = token{kHistFirstSym + (uint32_t)history_index, T_SELECTOR};
                 } else {
                     selector_hist[new_selector]++;
-                    tokens.push_back(token{(uint32_t)new_selector, T_SELECTOR});
+                    sel_tok[i] = token{(uint32_t)new_selector, T_SELECTOR};
                 }
                 m.selector_history_index = (int8_t)history_index;
                 if (history_index < 0) history.add(new_selector, m_selector_bytes[m.selector_index]); else history.use((uint32_t)history_index);
                 block_selector_indices[b] = m.selector_index;
+                if (((i + 1) % kPublishEvery) == 0) done3.store(i + 1, std::memory_order_release);
             }
-        close_pred_run();
-        close_selector_run();
+            close_selector_run();
+            done3.store(n, std::memory_order_release);
+        };
+
+        if (pipelined) {
+            std::thread t2(tables_loop), t3(selectors_loop);
+            endpoints_loop();
+            t2.join();
+            t3.join();
+        } else {
+            endpoints_loop();
+            tables_loop();
+            selectors_loop();
+        }
+        // the slice's symbols in bit-stream order: predictor, endpoint delta, selector of every block in turn
+        std::vector<token>& tokens = slice_tokens[si];
+        tokens.reserve((size_t)n * 2 + 16);
+        for (uint32_t i = 0; i < n; i++) {
+            if (pred_tok[i].kind != T_NONE) tokens.push_back(pred_tok[i]);
+            if (delta_tok[i].kind != T_NONE) tokens.push_back(delta_tok[i]);
+            if (sel_tok[i].kind != T_NONE) tokens.push_back(sel_tok[i]);
+        }
     });
     std::vector<uint32_t> selector_hist(n_sel + kSelectorHistorySize + 1, 0), rle_hist(kSelectorRleCountTotal, 0), delta_hist(n_ep, 0), pred_hist(kEndpointPredSymbols, 0);
     uint32_t endpoints_remapped = 0;
