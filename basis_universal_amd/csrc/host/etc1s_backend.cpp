@@ -140,16 +140,25 @@ std::vector<uint32_t> reorder_palette_by_adjacency(const uint32_t* indices, uint
     std::vector<uint32_t> remap(n, 0);
     if (num_indices <= 1 || !n) return remap;  // enc.cpp:1796-1797
     // adjacency counts of unequal neighbours, one entry per unordered pair (enc.cpp:1832-1843)
-    std::vector<uint64_t> keys;
+    std::vector<uint32_t> keys;   // min * n + max < 2^28 (n <= 16128)
     keys.reserve(num_indices);
     for (uint32_t i = 0; i + 1 < num_indices; i++) {
         const uint32_t a = indices[i], b = indices[i + 1];
-        if (a != b) keys.push_back((uint64_t)std::min(a, b) * n + std::max(a, b));
+        if (a != b) keys.push_back(std::min(a, b) * n + std::max(a, b));
     }
-    std::sort(keys.begin(), keys.end());
+    {   // LSD radix sort, three 11-bit digits (one key per coded block: a comparison sort here would cost more than the whole ordering)
+        std::vector<uint32_t> tmp(keys.size());
+        for (uint32_t shift = 0; shift < 33; shift += 11) {
+            uint32_t count[2049] = {0};
+            for (uint32_t k : keys) count[((k >> shift) & 2047u) + 1]++;
+            for (uint32_t d = 0; d < 2048; d++) count[d + 1] += count[d];
+            for (uint32_t k : keys) tmp[count[(k >> shift) & 2047u]++] = k;
+            keys.swap(tmp);
+        }
+    }
     struct edge { uint32_t other, count; };
     std::vector<uint32_t> degree(n + 1, 0);
-    std::vector<std::pair<uint64_t, uint32_t>> pairs;
+    std::vector<std::pair<uint32_t, uint32_t>> pairs;
     for (size_t i = 0; i < keys.size();) {
         size_t e = i + 1;
         while (e < keys.size() && keys[e] == keys[i]) e++;
@@ -161,7 +170,7 @@ std::vector<uint32_t> reorder_palette_by_adjacency(const uint32_t* indices, uint
     for (uint32_t s = 0; s < n; s++) first[s + 1] = first[s] + degree[s];
     std::vector<edge> edges(first[n]);
     std::vector<uint32_t> fill(first.begin(), first.end() - 1);
-    uint32_t max_count = 0; uint64_t max_key = 0;
+    uint32_t max_count = 0, max_key = 0;
     for (const auto& p : pairs) {
         const uint32_t a = (uint32_t)(p.first / n), b = (uint32_t)(p.first % n);
         edges[fill[a]++] = edge{b, p.second};
@@ -282,6 +291,11 @@ bool etc1s_backend::create_encoder_blocks() {
     const float thresh = m_params.m_endpoint_rdo_quality_thresh;
     const bool perceptual = m_src.perceptual;
     const metric::kernels K = metric::pick_kernels();
+    struct joined_thread {  // the selector codebook's order only depends on the codebook: sorted on the side while the blocks are walked
+        std::thread t;
+        void join() { if (t.joinable()) t.join(); }
+        ~joined_thread() { join(); }
+    } selector_sort{std::thread([this] { sort_selector_codebook(); })};
     std::vector<std::pair<uint64_t, uint64_t>> extents;
     for (const backend_slice_desc& s : m_slices) {
         if ((uint64_t)s.m_first_block_index + (uint64_t)s.m_num_blocks_x * s.m_num_blocks_y > total) return fail("slice exceeds the frontend's blocks");
@@ -353,9 +367,9 @@ bool etc1s_backend::create_encoder_blocks() {
         remapped += r.remapped;
         all_endpoint_indices.insert(all_endpoint_indices.end(), r.unpredicted.begin(), r.unpredicted.end());
     }
-    if (!reoptimize_and_sort_endpoints_codebook(remapped, all_endpoint_indices)) return false;
-    sort_selector_codebook();
-    return true;
+    const bool ok = reoptimize_and_sort_endpoints_codebook(remapped, all_endpoint_indices);
+    selector_sort.join();
+    return ok;
 }
 
 // backend.cpp:130-244
