@@ -210,3 +210,24 @@ def test_backend_isa_paths_agree(case, monkeypatch):
         _compare(fe, be, len(slices))
         be.close()
     fe.close()
+
+
+def test_backend_threading_modes_agree(monkeypatch):
+    """One thread, slices in parallel without the per-slice pipeline (2 threads), the three-thread pipeline per slice (slices of 32768
+    blocks each), repeated: the bytes never depend on the schedule."""
+    from basis_universal_amd.backend import Etc1sBackend
+    from basis_universal_amd.etc1s import quality_to_clusters
+    blocks = to_pixel_blocks(synth(1024, 1024, 77))
+    max_ep, max_sel = quality_to_clusters(128, blocks.shape[0])
+    fe = RefFrontend(blocks, max_ep, max_sel, 1, True)
+    fe.call("compress")
+    arrays = _arrays(fe, blocks)
+    slices = [(0, 256, 128), (32768, 256, 128)]
+    fe.backend_run(slices, 1.5, 1.25)
+    for threads in ("1", "2", "3", "8", "8"):
+        monkeypatch.setenv("BU_HOST_THREADS", threads)
+        be = Etc1sBackend.from_arrays(slices=slices, **arrays)
+        be.encode()
+        _compare(fe, be, len(slices))
+        be.close()
+    fe.close()
