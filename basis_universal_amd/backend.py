@@ -18,7 +18,12 @@ class BackendParams(C.Structure):
 
 
 class SliceDesc(C.Structure):
-    _fields_ = [(n, C.c_uint32) for n in ("first_block_index", "orig_width", "orig_height", "width", "height", "num_blocks_x", "num_blocks_y")]
+    _fields_ = [(n, C.c_uint32) for n in ("first_block_index", "orig_width", "orig_height", "width", "height", "num_blocks_x", "num_blocks_y",
+                                            "source_file_index", "mip_index")] + [("alpha", C.c_uint8), ("iframe", C.c_uint8), ("reserved", C.c_uint8 * 2)]
+
+
+class KeyValue(C.Structure):
+    _fields_ = [("key", C.c_char_p), ("value", _vp), ("value_size", C.c_uint32)]
 
 
 class BackendArrays(C.Structure):
@@ -34,6 +39,8 @@ class BackendError(RuntimeError):
 def _lib():
     L = load_frontend_library()
     if not getattr(L, "_backend_bound", False):
+        L.bu_backend_default_params.restype = None
+        L.bu_backend_default_params.argtypes = [C.c_int, C.c_uint32, C.POINTER(BackendParams)]
         L.bu_backend_create.restype = _vp
         L.bu_backend_destroy.argtypes = [_vp]
         L.bu_backend_init.argtypes = [_vp, _vp, C.POINTER(BackendParams), C.POINTER(SliceDesc), C.c_uint32]
@@ -42,6 +49,8 @@ def _lib():
         L.bu_backend_encode.argtypes = [_vp]
         L.bu_backend_get.restype = C.c_uint64
         L.bu_backend_get.argtypes = [_vp, C.c_char_p, C.c_uint32, _vp, C.c_uint64]
+        L.bu_backend_write_basis_file.restype = C.c_uint64
+        L.bu_backend_write_basis_file.argtypes = [_vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32, C.POINTER(KeyValue), C.c_uint32, _vp, C.c_uint64]
         L.bu_backend_error.restype = C.c_char_p
         L.bu_backend_error.argtypes = [_vp]
         L.bu_backend_stage_times.restype = C.c_uint32
@@ -50,13 +59,23 @@ def _lib():
     return L
 
 
+def default_params(quality_level=-1, compression_level=1):
+    """basis_compressor's backend thresholds for a quality level -> (endpoint_rdo_thresh, selector_rdo_thresh)."""
+    L = _lib()
+    p = BackendParams()
+    L.bu_backend_default_params(int(quality_level), int(compression_level), C.byref(p))
+    return p.endpoint_rdo_quality_thresh, p.selector_rdo_quality_thresh
+
+
 def slice_descs(slices):
-    """[(first_block, num_blocks_x, num_blocks_y) or (first, nbx, nby, orig_width, orig_height)] -> SliceDesc array."""
+    """[(first_block, num_blocks_x, num_blocks_y[, orig_width, orig_height[, image_index, mip_index, alpha]])] -> SliceDesc array.
+    Without the optional fields: unpadded size = padded size, slice i is mip 0 of image i (what the parity harness uses)."""
     arr = (SliceDesc * len(slices))()
     for i, s in enumerate(slices):
         first, nbx, nby = s[:3]
         ow, oh = (s[3], s[4]) if len(s) >= 5 else (nbx * 4, nby * 4)
-        arr[i] = SliceDesc(first, ow, oh, nbx * 4, nby * 4, nbx, nby)
+        image, mip, alpha = (s[5], s[6], s[7]) if len(s) >= 8 else (i, 0, 0)
+        arr[i] = SliceDesc(first, ow, oh, nbx * 4, nby * 4, nbx, nby, image, mip, int(alpha), 0)
     return arr
 
 
@@ -109,6 +128,22 @@ class Etc1sBackend:
         buf = np.zeros(need, np.uint8)
         self.L.bu_backend_get(self.h, name.encode(), slice_index, buf.ctypes.data_as(_vp), need)
         return buf.view(dtype)
+
+    def basis_file(self, tex_type=0, userdata0=0, userdata1=0, y_flipped=False, us_per_frame=0, key_values=()):
+        """The .basis container around the encoded output (basisu_file::init); key_values: [(str, bytes), ...]."""
+        kvs = (KeyValue * max(len(key_values), 1))()
+        keep = []
+        for i, (k, v) in enumerate(key_values):
+            vb = np.frombuffer(bytes(v), np.uint8) if len(v) else np.zeros(0, np.uint8)
+            keep.append(vb)
+            kvs[i] = KeyValue(k.encode(), vb.ctypes.data_as(_vp) if vb.size else None, vb.size)
+        args = (self.h, tex_type, userdata0, userdata1, int(y_flipped), us_per_frame, kvs, len(key_values))
+        need = self.L.bu_backend_write_basis_file(*args, None, 0)
+        if not need:
+            raise BackendError("bu_backend_write_basis_file failed")
+        buf = np.zeros(need, np.uint8)
+        self.L.bu_backend_write_basis_file(*args, buf.ctypes.data_as(_vp), need)
+        return buf
 
     def stage_times(self):
         names = (C.c_char_p * 16)()

@@ -37,13 +37,29 @@ void convert(const bu_backend_params* p, const bu_backend_slice_desc* s, uint32_
         d.m_width = s[i].width; d.m_height = s[i].height;
         d.m_num_blocks_x = s[i].num_blocks_x; d.m_num_blocks_y = s[i].num_blocks_y;
         d.m_num_macroblocks_x = (d.m_num_blocks_x + 1) / 2; d.m_num_macroblocks_y = (d.m_num_blocks_y + 1) / 2;
-        d.m_iframe = true;
+        d.m_source_file_index = s[i].source_file_index; d.m_mip_index = s[i].mip_index;
+        d.m_alpha = s[i].alpha != 0; d.m_iframe = s[i].iframe != 0;
     }
 }
 
 }  // namespace
 
 extern "C" {
+
+void bu_backend_default_params(int quality_level, uint32_t compression_level, bu_backend_params* out) {
+    if (!out) return;
+    float scale = 1.0f;
+    if (quality_level != -1) {
+        const float q = quality_level / 255.0f, quality = q < 0.0f ? 0.0f : (q > 1.0f ? 1.0f : q);
+        if (quality_level >= 223) scale = .25f;
+        else if (quality_level >= 192) scale = .5f;
+        else if (quality_level >= 160) scale = .75f;
+        else if (quality_level >= 129) { const float l = (quality - 129 / 255.0f) / ((160 - 129) / 255.0f); scale = 1.0f + (.75f - 1.0f) * l; }
+    }
+    out->endpoint_rdo_quality_thresh = 1.5f * scale;
+    out->selector_rdo_quality_thresh = 1.25f * scale;
+    out->compression_level = compression_level;
+}
 
 bu_backend* bu_backend_create(void) { return new (std::nothrow) bu_backend(); }
 void bu_backend_destroy(bu_backend* b) { delete b; }
@@ -79,6 +95,17 @@ int bu_backend_init_arrays(bu_backend* b, const bu_backend_arrays* a, const bu_b
 }
 
 uint32_t bu_backend_encode(bu_backend* b) { return b ? b->be.encode() : 0; }
+
+uint64_t bu_backend_write_basis_file(bu_backend* b, uint32_t tex_type, uint32_t userdata0, uint32_t userdata1, int y_flipped, uint32_t us_per_frame,
+                                     const bu_basis_key_value* kvs, uint32_t n_kvs, void* buf, uint64_t cap) {
+    if (!b || (!kvs && n_kvs)) return 0;
+    std::vector<bu::basis_key_value> kv(n_kvs);
+    for (uint32_t i = 0; i < n_kvs; i++) {
+        kv[i].key = kvs[i].key ? kvs[i].key : "";
+        if (kvs[i].value_size) kv[i].value.assign(kvs[i].value, kvs[i].value + kvs[i].value_size);
+    }
+    return emit(bu::write_basis_file(b->be.get_output(), tex_type, userdata0, userdata1, y_flipped != 0, us_per_frame, kv), buf, cap);
+}
 
 uint64_t bu_backend_get(bu_backend* b, const char* name, uint32_t slice, void* buf, uint64_t cap) {
     if (!b) return ~0ull;

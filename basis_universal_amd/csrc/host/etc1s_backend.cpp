@@ -136,6 +136,74 @@ uint16_t crc16_ccitt(const void* data, size_t size, uint16_t crc) {
     return (uint16_t)~crc;
 }
 
+std::vector<uint8_t> write_basis_file(const backend_output& out, uint32_t tex_type, uint32_t userdata0, uint32_t userdata1, bool y_flipped, uint32_t us_per_frame,
+                                      const std::vector<basis_key_value>& key_values) {
+    const uint32_t kHeaderSize = 77, kSliceDescSize = 23, kVersion = 0x13;  // sizeof(basis_file_header), sizeof(basis_slice_desc), BASIS_FILE_VERSION
+    std::vector<uint8_t> f;
+    auto put = [&f](uint64_t v, int bytes) { for (int i = 0; i < bytes; i++) f.push_back((uint8_t)(v >> (8 * i))); };
+    auto poke = [&f](size_t at, uint64_t v, int bytes) { for (int i = 0; i < bytes; i++) f[at + i] = (uint8_t)(v >> (8 * i)); };
+    // key-value block (basis_file.cpp:230-290): per pair the key's length (1-255, no terminator), the value's length (4 bytes), key, value
+    std::vector<uint8_t> kv;
+    if (!key_values.empty()) {
+        std::vector<uint8_t> body;
+        for (const basis_key_value& p : key_values) {
+            if (p.key.empty() || p.key.size() > 255 || p.key.find('\0') != std::string::npos || p.value.size() > UINT32_MAX) return {};
+            body.push_back((uint8_t)p.key.size());
+            for (int i = 0; i < 4; i++) body.push_back((uint8_t)(p.value.size() >> (8 * i)));
+            body.insert(body.end(), p.key.begin(), p.key.end());
+            body.insert(body.end(), p.value.begin(), p.value.end());
+        }
+        const uint16_t crc = crc16_ccitt(body.data(), body.size(), 0);
+        const uint32_t num = (uint32_t)key_values.size();
+        kv = {0x4B, 0x56, (uint8_t)num, (uint8_t)(num >> 8), (uint8_t)(num >> 16), (uint8_t)(num >> 24), (uint8_t)crc, (uint8_t)(crc >> 8)};  // cBASISKVDataSig, count, crc
+        kv.insert(kv.end(), body.begin(), body.end());
+    }
+    const size_t n_slices = out.m_slice_desc.size();
+    if (out.m_slice_image_data.size() != n_slices || out.m_slice_image_crcs.size() != n_slices) return {};
+    const uint64_t descs_ofs = kHeaderSize + kv.size(), endpoint_ofs = descs_ofs + (uint64_t)kSliceDescSize * n_slices, selector_ofs = endpoint_ofs + out.m_endpoint_palette.size(),
+                   tables_ofs = selector_ofs + out.m_selector_palette.size(), first_slice_ofs = tables_ofs + out.m_slice_image_tables.size();
+    uint64_t total = first_slice_ofs;
+    for (const auto& d : out.m_slice_image_data) total += d.size();
+    if (first_slice_ofs >= 0xFFFF0000ull || total >= 0xFFFF0000ull) return {};
+    uint32_t total_images = 0, flags = 1 /* cBASISHeaderFlagETC1S */;
+    for (const backend_slice_desc& s : out.m_slice_desc) { total_images = std::max(total_images, s.m_source_file_index + 1); if (s.m_alpha) flags |= 4; }
+    if (y_flipped) flags |= 2;
+    if (out.m_srgb) flags |= 16;
+    f.reserve((size_t)total);
+    // basis_file_header
+    put(0, 2); put(0, 2);                         // signature and version: written last
+    put(kHeaderSize, 2); put(0, 2);               // header size, header CRC (last)
+    put(total - kHeaderSize, 4); put(0, 2);       // data size, data CRC (last)
+    put(n_slices, 3); put(total_images, 3);
+    put(0, 1);                                    // tex format: cETC1S
+    put(flags, 2); put(tex_type, 1); put(std::min<uint32_t>(us_per_frame, 0xFFFFFFu), 3);
+    put(0, 4); put(userdata0, 4); put(userdata1, 4);
+    put(out.m_num_endpoints, 2); put(endpoint_ofs, 4); put(out.m_endpoint_palette.size(), 3);
+    put(out.m_num_selectors, 2); put(selector_ofs, 4); put(out.m_selector_palette.size(), 3);
+    put(tables_ofs, 4); put(out.m_slice_image_tables.size(), 4);
+    put(descs_ofs, 4);
+    put(kv.empty() ? 0 : kHeaderSize, 4); put(kv.size(), 4);
+    f.insert(f.end(), kv.begin(), kv.end());
+    uint64_t slice_ofs = first_slice_ofs;
+    for (size_t i = 0; i < n_slices; i++) {       // basis_slice_desc
+        const backend_slice_desc& s = out.m_slice_desc[i];
+        put(s.m_source_file_index, 3); put(s.m_mip_index, 1); put((s.m_alpha ? 1u : 0u) | (s.m_iframe ? 2u : 0u), 1);
+        put(s.m_orig_width, 2); put(s.m_orig_height, 2); put(s.m_num_blocks_x, 2); put(s.m_num_blocks_y, 2);
+        put(slice_ofs, 4); put(out.m_slice_image_data[i].size(), 4); put(out.m_slice_image_crcs[i], 2);
+        slice_ofs += out.m_slice_image_data[i].size();
+    }
+    f.insert(f.end(), out.m_endpoint_palette.begin(), out.m_endpoint_palette.end());
+    f.insert(f.end(), out.m_selector_palette.begin(), out.m_selector_palette.end());
+    f.insert(f.end(), out.m_slice_image_tables.begin(), out.m_slice_image_tables.end());
+    for (const auto& d : out.m_slice_image_data) f.insert(f.end(), d.begin(), d.end());
+    // CRCs: of everything after the header, then of the header from the data-size field on (basis_file.cpp:200-209)
+    poke(12, crc16_ccitt(f.data() + kHeaderSize, f.size() - kHeaderSize, 0), 2);
+    poke(6, crc16_ccitt(f.data() + 8, kHeaderSize - 8, 0), 2);
+    poke(0, ('B' << 8) | 's', 2);
+    poke(2, kVersion, 2);
+    return f;
+}
+
 std::vector<uint32_t> reorder_palette_by_adjacency(const uint32_t* indices, uint32_t num_indices, uint32_t n) {
     std::vector<uint32_t> remap(n, 0);
     if (num_indices <= 1 || !n) return remap;  // enc.cpp:1796-1797

@@ -135,6 +135,14 @@ private:
     std::vector<uint8_t> m_fe_endpoints;           // flattened endpoint codebook when driven by a frontend
 };
 
+// The .basis container around a backend's output = basisu_file::init + get_compressed_data (encoder/basisu_basis_file.cpp:25-388; the
+// layouts are basis_file_header / basis_slice_desc / basis_key_value_data_header of transcoder/basisu_file_headers.h:32-261): header,
+// optional key-value block, slice descriptors, the two palettes, the Huffman tables, the slices; little-endian packed fields, CRC-16 of
+// the data and of the header. Returns an empty vector when a 32-bit file field would overflow or a key is malformed.
+struct basis_key_value { std::string key; std::vector<uint8_t> value; };
+std::vector<uint8_t> write_basis_file(const backend_output& out, uint32_t tex_type, uint32_t userdata0, uint32_t userdata1, bool y_flipped, uint32_t us_per_frame,
+                                      const std::vector<basis_key_value>& key_values = {});
+
 // palette_index_reorderer (enc.cpp:1785-1915, without a distance function): orders the palette so that entries that follow each other
 // in `indices` get close numbers. Returns old -> new.
 std::vector<uint32_t> reorder_palette_by_adjacency(const uint32_t* indices, uint32_t num_indices, uint32_t num_syms);

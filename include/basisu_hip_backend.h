@@ -26,7 +26,16 @@ typedef struct bu_backend_slice_desc {      /* = basisu_backend_slice_desc, back
     uint32_t orig_width, orig_height;       /* texels before padding to whole blocks */
     uint32_t width, height;                 /* padded: multiples of 4 */
     uint32_t num_blocks_x, num_blocks_y;
+    uint32_t source_file_index;             /* = the basis image index; only the file writer reads these four */
+    uint32_t mip_index;
+    uint8_t alpha, iframe, reserved[2];     /* iframe: video only, 0 otherwise (comp.cpp:3016-3030) */
 } bu_backend_slice_desc;
+
+typedef struct bu_basis_key_value {         /* = basist::key_value: key = C string of 1..255 chars, value = opaque bytes */
+    const char* key;
+    const uint8_t* value;
+    uint32_t value_size;
+} bu_basis_key_value;
 
 /* A finished frontend as flat host arrays (the getters of basisu_frontend, frontend.h:119-156): what the backend reads when it is
  * not handed a bu_frontend. Arrays stay owned by the caller and must outlive bu_backend_encode. */
@@ -43,6 +52,9 @@ typedef struct bu_backend_arrays {
     const bu_etc_block* selector_blocks;        /* get_selector_cluster_selector_bits              */
 } bu_backend_arrays;
 
+/* basis_compressor's backend parameters for a quality level (comp.cpp:3381-3420, 3537-3538): the default thresholds 1.5 / 1.25, relaxed
+ * above quality 128 (x0.75 from 160, x0.5 from 192, x0.25 from 223, interpolated between 129 and 160); quality_level -1 = the defaults. */
+BU_HIP_API void bu_backend_default_params(int quality_level, uint32_t compression_level, bu_backend_params* out);
 BU_HIP_API bu_backend* bu_backend_create(void);
 BU_HIP_API void bu_backend_destroy(bu_backend*);
 /* basisu_backend::init (backend.cpp:52) on a compressed bu_frontend (which must outlive the backend) ... */
@@ -57,6 +69,11 @@ BU_HIP_API uint32_t bu_backend_encode(bu_backend*);
  * (u32 x 4 per block: endpoint index, endpoint predictor, selector index, selector history index + 1),
  * "endpoint_remap_old_to_new", "selector_remap_new_to_old" (u32 each). */
 BU_HIP_API uint64_t bu_backend_get(bu_backend*, const char* name, uint32_t slice, void* buf, uint64_t cap);
+/* The .basis file around the encoded output = basisu_file::init + get_compressed_data (encoder/basisu_basis_file.cpp:290-388): returns the
+ * file size, copies when cap suffices, 0 on failure. tex_type: basist::basis_texture_type (0 = 2D); basis_compressor passes its userdata,
+ * y-flip flag, microseconds per frame and key-values (comp.cpp:3563-3609). */
+BU_HIP_API uint64_t bu_backend_write_basis_file(bu_backend*, uint32_t tex_type, uint32_t userdata0, uint32_t userdata1, int y_flipped, uint32_t us_per_frame,
+                                                const bu_basis_key_value* key_values, uint32_t n_key_values, void* buf, uint64_t cap);
 BU_HIP_API const char* bu_backend_error(const bu_backend*);
 BU_HIP_API uint32_t bu_backend_stage_times(const bu_backend*, const char** names, double* seconds, uint32_t cap);
 

@@ -393,7 +393,7 @@ REF_API uint32_t ref_backend_run(void* hv, const uint32_t* slices3, uint32_t n_s
 		slices[i].m_num_macroblocks_x = (nbx + 1) / 2;
 		slices[i].m_num_macroblocks_y = (nby + 1) / 2;
 		slices[i].m_source_file_index = i;
-		slices[i].m_iframe = true;
+		slices[i].m_iframe = false;  // as basis_compressor sets it for everything but video (comp.cpp:3016-3030)
 	}
 	h->be->init(&h->fe, bp, slices);
 	interval_timer tm;
@@ -431,6 +431,26 @@ REF_API uint64_t ref_backend_get(void* hv, const char* name, uint32_t slice, voi
 	if (n == "endpoint_remap_old_to_new") { std::vector<uint32_t> v(be.m_endpoint_remap_table_old_to_new.begin(), be.m_endpoint_remap_table_old_to_new.end()); return emit(v, buf, cap); }
 	if (n == "selector_remap_new_to_old") { std::vector<uint32_t> v(be.m_selector_remap_table_new_to_old.begin(), be.m_selector_remap_table_new_to_old.end()); return emit(v, buf, cap); }
 	return ~0ull;
+}
+
+// basisu_file::init on the kept backend's output (encoder/basisu_basis_file.cpp:290): the .basis container, with optional key-values
+// given as n x (key C string, value bytes, value size).
+REF_API uint64_t ref_basis_file(void* hv, uint32_t tex_type, uint32_t userdata0, uint32_t userdata1, int y_flipped, uint32_t us_per_frame,
+	const char** keys, const uint8_t** values, const uint32_t* value_sizes, uint32_t n_kv, uint8_t* buf, uint64_t cap) {
+	frontend_handle* h = static_cast<frontend_handle*>(hv);
+	if (!h->be) return 0;
+	basist::key_value_vec kvs;
+	for (uint32_t i = 0; i < n_kv; i++) {
+		basist::key_value kv;
+		kv.m_key.append((const uint8_t*)keys[i], strlen(keys[i]) + 1);
+		if (value_sizes[i]) kv.m_value.append(values[i], value_sizes[i]);
+		kvs.push_back(kv);
+	}
+	basisu_file f;
+	if (!f.init(h->be->get_output(), (basist::basis_texture_type)tex_type, userdata0, userdata1, y_flipped != 0, us_per_frame, kvs)) return 0;
+	const uint8_vec& d = f.get_compressed_data();
+	if (buf && cap >= d.size() && d.size()) memcpy(buf, d.data(), d.size());
+	return d.size();
 }
 
 // The backend's coding tools on their own (known-answer style tests with synthetic inputs).

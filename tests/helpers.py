@@ -223,6 +223,23 @@ class RefFrontend:
         self.L.ref_backend_get(self.h, name.encode(), slice_index, buf.ctypes.data_as(C.c_void_p), need)
         return buf.view(dtype)
 
+    def basis_file(self, tex_type=0, userdata0=0, userdata1=0, y_flipped=False, us_per_frame=0, key_values=()):
+        """basisu_file::init on the last backend_run's output -> the .basis file bytes."""
+        f = self.L.ref_basis_file
+        f.restype = C.c_uint64
+        f.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64]
+        n = len(key_values)
+        keys = (C.c_char_p * max(n, 1))(*[k.encode() for k, _ in key_values])
+        bufs = [np.frombuffer(bytes(v), np.uint8) if len(v) else np.zeros(1, np.uint8) for _, v in key_values]
+        vals = (C.c_void_p * max(n, 1))(*[b.ctypes.data for b in bufs])
+        sizes = np.array([len(v) for _, v in key_values] + [0], np.uint32)
+        args = (self.h, tex_type, userdata0, userdata1, int(y_flipped), us_per_frame, keys, vals, sizes.ctypes.data, n)
+        need = f(*args, None, 0)
+        assert need, "ref_basis_file failed"
+        out = np.zeros(need, np.uint8)
+        f(*args, out.ctypes.data, need)
+        return out
+
     def close(self):
         if self.h:
             self.L.ref_frontend_destroy(self.h)
@@ -408,4 +425,46 @@ def host_encode_uastc(blocks, flags):
     n = blocks.shape[0]
     out = np.zeros((n, 16), np.uint8)
     uastc_host().hc_encode_uastc(ptr(blocks), n, flags, ptr(out))
+    return out
+
+
+def save_png(path, img):
+    """Minimal 8-bit RGBA PNG writer (test inputs for the reference CLI)."""
+    import struct, zlib
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w = img.shape[:2]
+    raw = b"".join(b"\x00" + img[y].tobytes() for y in range(h))
+
+    def chunk(tag, data):
+        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xFFFFFFFF)
+    pathlib.Path(path).write_bytes(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 6, 0, 0, 0)) + chunk(b"IDAT", zlib.compress(raw, 6)) + chunk(b"IEND", b""))
+
+
+def have_ref_cli():
+    return (ORACLE_DIR / "_ref" / "basisu").exists()
+
+
+def run_ref_cli(png_path, *args):
+    """The reference command line tool (oracle/_ref/basisu, built from /root/reference) on one PNG -> the bytes of the .basis it writes."""
+    import subprocess, tempfile, shutil
+    with tempfile.TemporaryDirectory() as d:
+        src = pathlib.Path(d) / "in.png"
+        shutil.copy(png_path, src)
+        r = subprocess.run([str(ORACLE_DIR / "_ref" / "basisu"), "-basis", "-no_multithreading", *args, "in.png"], cwd=d, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and (pathlib.Path(d) / "in.basis").exists(), r.stdout[-2000:] + r.stderr[-2000:]
+        return np.fromfile(pathlib.Path(d) / "in.basis", np.uint8)
+
+
+def basis_file_key_values(data):
+    """The key-value pairs stored in a .basis file (basis_file_header::m_extended_file_ofs/size)."""
+    import struct
+    raw = np.asarray(data, np.uint8).tobytes()
+    ofs, size = struct.unpack_from("<II", raw, 69)
+    if not size:
+        return []
+    kv, out, pos = raw[ofs:ofs + size], [], 8
+    for _ in range(struct.unpack_from("<I", kv, 2)[0]):
+        kl, vl = kv[pos], struct.unpack_from("<I", kv, pos + 1)[0]
+        out.append((kv[pos + 5:pos + 5 + kl].decode(), kv[pos + 5 + kl:pos + 5 + kl + vl]))
+        pos += 5 + kl + vl
     return out

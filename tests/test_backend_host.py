@@ -4,7 +4,7 @@ tables, every slice's bit stream, the CRCs -- has to be byte-identical, and so h
 import numpy as np
 import pytest
 
-from helpers import have_ref, RefFrontend, synth, uniform_random, to_pixel_blocks
+from helpers import have_ref, have_ref_cli, RefFrontend, synth, uniform_random, to_pixel_blocks, save_png, run_ref_cli, basis_file_key_values
 
 pytestmark = pytest.mark.skipif(not have_ref(), reason="oracle/_ref not present")
 
@@ -230,4 +230,50 @@ def test_backend_threading_modes_agree(monkeypatch):
         be.encode()
         _compare(fe, be, len(slices))
         be.close()
+    fe.close()
+
+
+@pytest.mark.parametrize("case", ["synth_l1", "two_slices", "mip_chain", "one_block"])
+def test_basis_file_matches_reference(case):
+    """write_basis_file against basisu_file::init on the reference backend's output: plain, with flags and user data, with key-values."""
+    from basis_universal_amd.backend import Etc1sBackend
+    img_fn, max_ep, max_sel, level, perceptual, slices, ept, selt = CASES[case]
+    blocks = _blocks_of(img_fn())
+    fe = RefFrontend(blocks, max_ep, max_sel, level, perceptual)
+    fe.call("compress")
+    be = Etc1sBackend.from_arrays(slices=slices, perceptual=perceptual, endpoint_rdo_thresh=ept, selector_rdo_thresh=selt, compression_level=level, **_arrays(fe, blocks))
+    be.encode()
+    fe.backend_run(slices, ept, selt)
+    variants = [dict(), dict(tex_type=1, userdata0=0xDEADBEEF, userdata1=7, y_flipped=True, us_per_frame=41666),
+                dict(key_values=[("BasisULibVersion", b"2.10"), ("empty", b""), ("k", bytes(range(256)) * 3)]),
+                dict(us_per_frame=0x7FFFFFFF, key_values=[("x" * 255, b"\x00\x01")])]
+    for v in variants:
+        a, b = be.basis_file(**v), fe.basis_file(**v)
+        assert a.shape == b.shape and (a == b).all(), v.keys()
+    assert bytes(be.basis_file()[:2]) == b"sB"
+    be.close()
+    fe.close()
+
+
+@pytest.mark.skipif(not have_ref_cli(), reason="oracle/_ref/basisu not present")
+@pytest.mark.parametrize("w,h,seed,quality", [(256, 192, 1234, 128), (130, 67, 3, 200), (128, 96, 9, 145), (96, 96, 11, 255), (160, 64, 12, 20)])
+def test_basis_file_matches_reference_command_line(tmp_path, w, h, seed, quality):
+    """End to end against the reference TOOL: `basisu -basis -etc1s -q N x.png` writes the same file as (reference frontend ->) our backend ->
+    our container writer, given the tool's own key-values (its library version string)."""
+    from basis_universal_amd.backend import Etc1sBackend, default_params
+    from basis_universal_amd.etc1s import quality_to_clusters
+    img = np.ascontiguousarray(synth((w + 3) // 4 * 4, (h + 3) // 4 * 4, seed)[:h, :w])  # ragged sizes: the tool pads by replicating the edge, like to_pixel_blocks
+    save_png(tmp_path / "x.png", img)
+    cli = run_ref_cli(tmp_path / "x.png", "-etc1s", "-q", str(quality))
+    blocks = to_pixel_blocks(img)
+    nbx, nby = (w + 3) // 4, (h + 3) // 4
+    max_ep, max_sel = quality_to_clusters(quality, blocks.shape[0])
+    fe = RefFrontend(blocks, max_ep, max_sel, 1, True)
+    fe.call("compress")
+    ept, selt = default_params(quality, 1)   # the tool relaxes the RDO thresholds above quality 128
+    be = Etc1sBackend.from_arrays(slices=[(0, nbx, nby, w, h, 0, 0, 0)], endpoint_rdo_thresh=ept, selector_rdo_thresh=selt, **_arrays(fe, blocks))
+    be.encode()
+    mine = be.basis_file(key_values=basis_file_key_values(cli))
+    assert mine.shape == cli.shape and (mine == cli).all()
+    be.close()
     fe.close()

@@ -102,3 +102,27 @@ def test_backend_on_device_only_tiles(hip_ctx):
     assert total == ref.backend_run([(0, 32, 24)])[0]
     assert (be.get("slice_image_data") == ref.backend_get("slice_image_data")).all()
     be.close(); fe.close(); hip_ctx.free(d); ref.close()
+
+
+@pytest.mark.skipif(not __import__("helpers").have_ref_cli(), reason="oracle/_ref/basisu not present")
+@pytest.mark.parametrize("w,h,seed,quality,level", [(256, 192, 1234, 128, 1), (130, 67, 3, 200, 1), (192, 128, 5, 128, 2), (128, 128, 6, 90, 4)])
+def test_whole_encoder_matches_reference_command_line(hip_ctx, tmp_path, w, h, seed, quality, level):
+    """Drop-in, end to end: the file the reference TOOL writes for a PNG (`basisu -basis -etc1s -q N -comp_level L`) against tiles ->
+    resident frontend (HIP) -> host backend -> container writer, byte for byte."""
+    from helpers import save_png, run_ref_cli, basis_file_key_values
+    from basis_universal_amd.etc1s import Etc1sFrontend, quality_to_clusters
+    from basis_universal_amd.backend import Etc1sBackend, default_params
+    img = np.ascontiguousarray(synth((w + 3) // 4 * 4, (h + 3) // 4 * 4, seed)[:h, :w])
+    save_png(tmp_path / "x.png", img)
+    cli = run_ref_cli(tmp_path / "x.png", "-etc1s", "-q", str(quality), "-comp_level", str(level))
+    blocks = to_pixel_blocks(img)
+    max_ep, max_sel = quality_to_clusters(quality, blocks.shape[0])
+    fe = Etc1sFrontend(hip_ctx)
+    fe.init(blocks, max_ep, max_sel, level, True)
+    fe.compress()
+    ept, selt = default_params(quality, level)
+    be = Etc1sBackend.from_frontend(fe, [(0, (w + 3) // 4, (h + 3) // 4, w, h, 0, 0, 0)], ept, selt, level)
+    be.encode()
+    mine = be.basis_file(key_values=basis_file_key_values(cli))
+    assert mine.shape == cli.shape and (mine == cli).all()
+    be.close(); fe.close()
