@@ -277,3 +277,32 @@ def test_basis_file_matches_reference_command_line(tmp_path, w, h, seed, quality
     assert mine.shape == cli.shape and (mine == cli).all()
     be.close()
     fe.close()
+
+
+@pytest.mark.skipif(not have_ref_cli(), reason="oracle/_ref/basisu not present")
+def test_basis_file_with_alpha_matches_reference_command_line(tmp_path):
+    """An RGBA source: the tool codes alpha as a second slice of (a, a, a) blocks behind the colour slice of the same image
+    (comp.cpp:2880-2910), sharing the codebooks; header and slice descriptors carry the alpha flags."""
+    from basis_universal_amd.backend import Etc1sBackend, default_params
+    from basis_universal_amd.etc1s import quality_to_clusters
+    w, h, quality = 192, 128, 128
+    img = synth(w, h, 21)
+    yy, xx = np.mgrid[0:h, 0:w]
+    img[..., 3] = np.clip(128 + 100 * np.sin(xx / 23.0) * np.cos(yy / 17.0) + (xx % 7) * 3, 0, 255).astype(np.uint8)
+    save_png(tmp_path / "x.png", img)
+    cli = run_ref_cli(tmp_path / "x.png", "-etc1s", "-q", str(quality))
+    rgb = img.copy(); rgb[..., 3] = 255
+    a = np.repeat(img[..., 3:4], 4, axis=2); a[..., 3] = 255
+    blocks = np.concatenate([to_pixel_blocks(rgb), to_pixel_blocks(a)])
+    n = blocks.shape[0] // 2
+    max_ep, max_sel = quality_to_clusters(quality, blocks.shape[0])
+    fe = RefFrontend(blocks, max_ep, max_sel, 1, True)
+    fe.call("compress")
+    ept, selt = default_params(quality, 1)
+    be = Etc1sBackend.from_arrays(slices=[(0, w // 4, h // 4, w, h, 0, 0, 0), (n, w // 4, h // 4, w, h, 0, 0, 1)], endpoint_rdo_thresh=ept, selector_rdo_thresh=selt,
+                                  **_arrays(fe, blocks))
+    be.encode()
+    mine = be.basis_file(key_values=basis_file_key_values(cli))
+    assert mine.shape == cli.shape and (mine == cli).all()
+    be.close()
+    fe.close()
