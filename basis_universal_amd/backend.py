@@ -51,6 +51,9 @@ def _lib():
         L.bu_backend_get.argtypes = [_vp, C.c_char_p, C.c_uint32, _vp, C.c_uint64]
         L.bu_backend_write_basis_file.restype = C.c_uint64
         L.bu_backend_write_basis_file.argtypes = [_vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32, C.POINTER(KeyValue), C.c_uint32, _vp, C.c_uint64]
+        L.bu_write_basis_file_uastc.restype = C.c_uint64
+        L.bu_write_basis_file_uastc.argtypes = [_vp, C.c_uint64, C.POINTER(SliceDesc), C.c_uint32, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32,
+                                                C.POINTER(KeyValue), C.c_uint32, _vp, C.c_uint64]
         L.bu_backend_error.restype = C.c_char_p
         L.bu_backend_error.argtypes = [_vp]
         L.bu_backend_stage_times.restype = C.c_uint32
@@ -77,6 +80,31 @@ def slice_descs(slices):
         image, mip, alpha = (s[5], s[6], s[7]) if len(s) >= 8 else (i, 0, 0)
         arr[i] = SliceDesc(first, ow, oh, nbx * 4, nby * 4, nbx, nby, image, mip, int(alpha), 0)
     return arr
+
+
+def _key_values(key_values):
+    kvs = (KeyValue * max(len(key_values), 1))()
+    keep = []
+    for i, (k, v) in enumerate(key_values):
+        vb = np.frombuffer(bytes(v), np.uint8) if len(v) else np.zeros(0, np.uint8)
+        keep.append(vb)
+        kvs[i] = KeyValue(k.encode(), vb.ctypes.data_as(_vp) if vb.size else None, vb.size)
+    return kvs, keep
+
+
+def uastc_basis_file(blocks16, slices, srgb=True, tex_type=0, userdata0=0, userdata1=0, y_flipped=False, us_per_frame=0, key_values=()):
+    """The .basis container around UASTC LDR 4x4 blocks ((n, 16) u8, e.g. uastc.encode_uastc_blocks / uastc.uastc_rdo output)."""
+    L = _lib()
+    b = np.ascontiguousarray(blocks16, np.uint8).reshape(-1, 16)
+    kvs, keep = _key_values(key_values)
+    sl = slice_descs(slices)
+    args = (b.ctypes.data_as(_vp), b.shape[0], sl, len(slices), int(srgb), tex_type, userdata0, userdata1, int(y_flipped), us_per_frame, kvs, len(key_values))
+    need = L.bu_write_basis_file_uastc(*args, None, 0)
+    if not need:
+        raise BackendError("bu_write_basis_file_uastc failed")
+    buf = np.zeros(need, np.uint8)
+    L.bu_write_basis_file_uastc(*args, buf.ctypes.data_as(_vp), need)
+    return buf
 
 
 class Etc1sBackend:

@@ -96,6 +96,24 @@ int bu_backend_init_arrays(bu_backend* b, const bu_backend_arrays* a, const bu_b
 
 uint32_t bu_backend_encode(bu_backend* b) { return b ? b->be.encode() : 0; }
 
+uint64_t bu_write_basis_file_uastc(const uint8_t* blocks16, uint64_t total_blocks, const bu_backend_slice_desc* s, uint32_t n, int srgb, uint32_t tex_type,
+                                   uint32_t userdata0, uint32_t userdata1, int y_flipped, uint32_t us_per_frame, const bu_basis_key_value* kvs, uint32_t n_kvs,
+                                   void* buf, uint64_t cap) {
+    if (!blocks16 || !s || !n || (!kvs && n_kvs)) return 0;
+    bu_backend_params unused = {0, 0, 0};
+    bu::backend_params bp;
+    std::vector<bu::backend_slice_desc> slices;
+    convert(&unused, s, n, bp, slices);
+    std::vector<bu::basis_key_value> kv(n_kvs);
+    for (uint32_t i = 0; i < n_kvs; i++) {
+        kv[i].key = kvs[i].key ? kvs[i].key : "";
+        if (kvs[i].value_size) kv[i].value.assign(kvs[i].value, kvs[i].value + kvs[i].value_size);
+    }
+    const bu::backend_output out = bu::uastc_backend_output(slices, blocks16, (size_t)total_blocks, srgb != 0);
+    if (out.m_slice_desc.empty()) return 0;
+    return emit(bu::write_basis_file(out, tex_type, userdata0, userdata1, y_flipped != 0, us_per_frame, kv), buf, cap);
+}
+
 uint64_t bu_backend_write_basis_file(bu_backend* b, uint32_t tex_type, uint32_t userdata0, uint32_t userdata1, int y_flipped, uint32_t us_per_frame,
                                      const bu_basis_key_value* kvs, uint32_t n_kvs, void* buf, uint64_t cap) {
     if (!b || (!kvs && n_kvs)) return 0;

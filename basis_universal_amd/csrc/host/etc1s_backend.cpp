@@ -160,12 +160,16 @@ std::vector<uint8_t> write_basis_file(const backend_output& out, uint32_t tex_ty
     }
     const size_t n_slices = out.m_slice_desc.size();
     if (out.m_slice_image_data.size() != n_slices || out.m_slice_image_crcs.size() != n_slices) return {};
-    const uint64_t descs_ofs = kHeaderSize + kv.size(), endpoint_ofs = descs_ofs + (uint64_t)kSliceDescSize * n_slices, selector_ofs = endpoint_ofs + out.m_endpoint_palette.size(),
-                   tables_ofs = selector_ofs + out.m_selector_palette.size(), first_slice_ofs = tables_ofs + out.m_slice_image_tables.size();
+    const bool etc1s = out.m_tex_format == 0;
+    if (etc1s != out.m_etc1s || (!etc1s && (!out.m_endpoint_palette.empty() || !out.m_selector_palette.empty() || !out.m_slice_image_tables.empty()))) return {};
+    // codebook and table offsets are 0 in files without them (basis_file.cpp:345-352)
+    const uint64_t descs_ofs = kHeaderSize + kv.size(), after_descs = descs_ofs + (uint64_t)kSliceDescSize * n_slices, endpoint_ofs = etc1s ? after_descs : 0,
+                   selector_ofs = etc1s ? endpoint_ofs + out.m_endpoint_palette.size() : 0, tables_ofs = etc1s ? selector_ofs + out.m_selector_palette.size() : 0,
+                   first_slice_ofs = etc1s ? tables_ofs + out.m_slice_image_tables.size() : after_descs;
     uint64_t total = first_slice_ofs;
     for (const auto& d : out.m_slice_image_data) total += d.size();
     if (first_slice_ofs >= 0xFFFF0000ull || total >= 0xFFFF0000ull) return {};
-    uint32_t total_images = 0, flags = 1 /* cBASISHeaderFlagETC1S */;
+    uint32_t total_images = 0, flags = etc1s ? 1u : 0u;  // cBASISHeaderFlagETC1S
     for (const backend_slice_desc& s : out.m_slice_desc) { total_images = std::max(total_images, s.m_source_file_index + 1); if (s.m_alpha) flags |= 4; }
     if (y_flipped) flags |= 2;
     if (out.m_srgb) flags |= 16;
@@ -175,7 +179,7 @@ std::vector<uint8_t> write_basis_file(const backend_output& out, uint32_t tex_ty
     put(kHeaderSize, 2); put(0, 2);               // header size, header CRC (last)
     put(total - kHeaderSize, 4); put(0, 2);       // data size, data CRC (last)
     put(n_slices, 3); put(total_images, 3);
-    put(0, 1);                                    // tex format: cETC1S
+    put(out.m_tex_format, 1);
     put(flags, 2); put(tex_type, 1); put(std::min<uint32_t>(us_per_frame, 0xFFFFFFu), 3);
     put(0, 4); put(userdata0, 4); put(userdata1, 4);
     put(out.m_num_endpoints, 2); put(endpoint_ofs, 4); put(out.m_endpoint_palette.size(), 3);
@@ -202,6 +206,22 @@ std::vector<uint8_t> write_basis_file(const backend_output& out, uint32_t tex_ty
     poke(0, ('B' << 8) | 's', 2);
     poke(2, kVersion, 2);
     return f;
+}
+
+backend_output uastc_backend_output(const std::vector<backend_slice_desc>& slices, const uint8_t* blocks16, size_t total_blocks, bool srgb) {
+    backend_output o;
+    o.m_tex_format = 1;  // cUASTC_LDR_4x4
+    o.m_etc1s = false;
+    o.m_srgb = srgb;
+    o.m_slice_desc = slices;
+    for (const backend_slice_desc& s : slices) {
+        const size_t n = (size_t)s.m_num_blocks_x * s.m_num_blocks_y;
+        if ((size_t)s.m_first_block_index + n > total_blocks) return backend_output();
+        const uint8_t* p = blocks16 + (size_t)s.m_first_block_index * 16;
+        o.m_slice_image_data.emplace_back(p, p + n * 16);
+        o.m_slice_image_crcs.push_back(crc16_ccitt(p, n * 16, 0));
+    }
+    return o;
 }
 
 std::vector<uint32_t> reorder_palette_by_adjacency(const uint32_t* indices, uint32_t num_indices, uint32_t n) {
@@ -927,7 +947,8 @@ uint32_t etc1s_backend::encode() {  // backend.cpp:1747-1776
         !m_src.block_endpoint_index || !m_src.block_selector_index || !m_src.endpoint_color5_inten || !m_src.selector_blocks) { fail("incomplete backend source"); return 0; }
     m_output = backend_output();
     m_output.m_slice_desc = m_slices;
-    m_output.m_etc1s = m_params.m_etc1s;
+    m_output.m_tex_format = 0;
+    m_output.m_etc1s = true;
     m_output.m_uses_global_codebooks = false;
     m_output.m_srgb = m_src.perceptual;
 #define BU_BSTAGE(name, call) do { timer t__; if (!(call)) return 0; m_stage_times.push_back(stage_time{name, t__.seconds()}); } while (0)

@@ -44,6 +44,7 @@ struct backend_slice_desc {                // = basisu_backend_slice_desc (backe
 };
 
 struct backend_output {                    // = basisu_backend_output (backend.h:218-276)
+    uint32_t m_tex_format = 0;             // basist::basis_tex_format: 0 = cETC1S, 1 = cUASTC_LDR_4x4
     bool m_etc1s = false;
     bool m_uses_global_codebooks = false;
     bool m_srgb = true;
@@ -142,6 +143,10 @@ private:
 struct basis_key_value { std::string key; std::vector<uint8_t> value; };
 std::vector<uint8_t> write_basis_file(const backend_output& out, uint32_t tex_type, uint32_t userdata0, uint32_t userdata1, bool y_flipped, uint32_t us_per_frame,
                                       const std::vector<basis_key_value>& key_values = {});
+
+// basis_compressor::encode_slices_to_uastc_4x4_ldr's output record (comp.cpp:1843-1850, 2086-2090): a UASTC file has no codebooks, a slice
+// is its blocks in raster order (16 bytes each, e.g. straight from bu_hip_encode_uastc_blocks / bu_hip_uastc_rdo) plus their CRC-16.
+backend_output uastc_backend_output(const std::vector<backend_slice_desc>& slices, const uint8_t* blocks16, size_t total_blocks, bool srgb);
 
 // palette_index_reorderer (enc.cpp:1785-1915, without a distance function): orders the palette so that entries that follow each other
 // in `indices` get close numbers. Returns old -> new.

@@ -306,3 +306,26 @@ def test_basis_file_with_alpha_matches_reference_command_line(tmp_path):
     assert mine.shape == cli.shape and (mine == cli).all()
     be.close()
     fe.close()
+
+
+@pytest.mark.skipif(not have_ref_cli(), reason="oracle/_ref/basisu not present")
+@pytest.mark.parametrize("level,rdo,alpha", [(2, None, False), (1, None, True), (2, 1.0, False), (0, 2.5, True)])
+def test_uastc_basis_file_matches_reference_command_line(tmp_path, level, rdo, alpha):
+    """UASTC LDR 4x4 side of the same container: `basisu -basis -uastc -uastc_level L [-uastc_rdo_l X]` against reference encode_uastc
+    (+ uastc_rdo) blocks wrapped by bu_write_basis_file_uastc -- pins the writer and the flag plumbing the GPU test relies on."""
+    from helpers import ref_encode_uastc, ref_uastc_rdo
+    from basis_universal_amd.backend import uastc_basis_file
+    w, h = 160, 96
+    img = synth(w, h, 50 + level)
+    if alpha:
+        yy, xx = np.mgrid[0:h, 0:w]
+        img[..., 3] = np.clip(140 + 110 * np.sin(xx / 19.0 + yy / 31.0), 0, 255).astype(np.uint8)
+    save_png(tmp_path / "x.png", img)
+    args = ["-uastc", "-uastc_level", str(level)] + (["-uastc_rdo_l", str(rdo)] if rdo else [])
+    cli = run_ref_cli(tmp_path / "x.png", *args)
+    blocks = to_pixel_blocks(img)
+    packed = ref_encode_uastc(blocks, level | (512 if rdo else 0))       # cPackUASTCFavorSimplerModes in RDO mode (comp.cpp:2016-2018)
+    if rdo:
+        packed = ref_uastc_rdo(packed, blocks, level, total_jobs=1, lam=rdo, dict_size=4096)
+    mine = uastc_basis_file(packed, [(0, w // 4, h // 4, w, h, 0, 0, int(alpha))], key_values=basis_file_key_values(cli))
+    assert mine.shape == cli.shape and (mine == cli).all()

@@ -126,3 +126,26 @@ def test_whole_encoder_matches_reference_command_line(hip_ctx, tmp_path, w, h, s
     mine = be.basis_file(key_values=basis_file_key_values(cli))
     assert mine.shape == cli.shape and (mine == cli).all()
     be.close(); fe.close()
+
+
+@pytest.mark.skipif(not __import__("helpers").have_ref_cli(), reason="oracle/_ref/basisu not present")
+@pytest.mark.parametrize("level,rdo,alpha", [(2, None, False), (1, None, True), (2, 1.0, False), (3, 2.0, True)])
+def test_uastc_whole_encoder_matches_reference_command_line(hip_ctx, tmp_path, level, rdo, alpha):
+    """`basisu -basis -uastc -uastc_level L [-uastc_rdo_l X]` for a PNG against tiles -> HIP encode_uastc (-> HIP uastc_rdo) -> container
+    writer, byte for byte."""
+    from helpers import save_png, run_ref_cli, basis_file_key_values
+    from basis_universal_amd import uastc
+    from basis_universal_amd.backend import uastc_basis_file
+    w, h = 192, 128
+    img = synth(w, h, 60 + level)
+    if alpha:
+        yy, xx = np.mgrid[0:h, 0:w]
+        img[..., 3] = np.clip(140 + 110 * np.sin(xx / 19.0 + yy / 31.0), 0, 255).astype(np.uint8)
+    save_png(tmp_path / "x.png", img)
+    cli = run_ref_cli(tmp_path / "x.png", "-uastc", "-uastc_level", str(level), *(["-uastc_rdo_l", str(rdo)] if rdo else []))
+    blocks = to_pixel_blocks(img)
+    packed = uastc.encode_uastc_blocks(hip_ctx, blocks, level | (uastc.FAVOR_SIMPLER_MODES if rdo else 0))
+    if rdo:
+        packed, _ = uastc.uastc_rdo(hip_ctx, packed, blocks, uastc.RdoParams(m_lambda=rdo), level, total_jobs=1)
+    mine = uastc_basis_file(packed, [(0, w // 4, h // 4, w, h, 0, 0, int(alpha))], key_values=basis_file_key_values(cli))
+    assert mine.shape == cli.shape and (mine == cli).all()
