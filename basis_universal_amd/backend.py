@@ -54,6 +54,10 @@ def _lib():
         L.bu_write_basis_file_uastc.restype = C.c_uint64
         L.bu_write_basis_file_uastc.argtypes = [_vp, C.c_uint64, C.POINTER(SliceDesc), C.c_uint32, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32,
                                                 C.POINTER(KeyValue), C.c_uint32, _vp, C.c_uint64]
+        L.bu_backend_write_ktx2_file.restype = C.c_uint64
+        L.bu_backend_write_ktx2_file.argtypes = [_vp, C.c_uint32, C.c_int, C.POINTER(KeyValue), C.c_uint32, _vp, C.c_uint64]
+        L.bu_write_ktx2_file_uastc.restype = C.c_uint64
+        L.bu_write_ktx2_file_uastc.argtypes = [_vp, C.c_uint64, C.POINTER(SliceDesc), C.c_uint32, C.c_int, C.c_uint32, C.c_int, C.POINTER(KeyValue), C.c_uint32, _vp, C.c_uint64]
         L.bu_backend_error.restype = C.c_char_p
         L.bu_backend_error.argtypes = [_vp]
         L.bu_backend_stage_times.restype = C.c_uint32
@@ -104,6 +108,21 @@ def uastc_basis_file(blocks16, slices, srgb=True, tex_type=0, userdata0=0, userd
         raise BackendError("bu_write_basis_file_uastc failed")
     buf = np.zeros(need, np.uint8)
     L.bu_write_basis_file_uastc(*args, buf.ctypes.data_as(_vp), need)
+    return buf
+
+
+def uastc_ktx2_file(blocks16, slices, srgb=True, tex_type=0, has_alpha=False, key_values=()):
+    """The KTX2 container (no supercompression) around UASTC LDR 4x4 blocks."""
+    L = _lib()
+    b = np.ascontiguousarray(blocks16, np.uint8).reshape(-1, 16)
+    kvs, keep = _key_values(key_values)
+    sl = slice_descs(slices)
+    args = (b.ctypes.data_as(_vp), b.shape[0], sl, len(slices), int(srgb), tex_type, int(has_alpha), kvs, len(key_values))
+    need = L.bu_write_ktx2_file_uastc(*args, None, 0)
+    if not need:
+        raise BackendError("bu_write_ktx2_file_uastc failed")
+    buf = np.zeros(need, np.uint8)
+    L.bu_write_ktx2_file_uastc(*args, buf.ctypes.data_as(_vp), need)
     return buf
 
 
@@ -171,6 +190,17 @@ class Etc1sBackend:
             raise BackendError("bu_backend_write_basis_file failed")
         buf = np.zeros(need, np.uint8)
         self.L.bu_backend_write_basis_file(*args, buf.ctypes.data_as(_vp), need)
+        return buf
+
+    def ktx2_file(self, tex_type=0, has_alpha=False, key_values=()):
+        """The KTX2 container (BasisLZ) around the encoded output (basis_compressor::create_ktx2_file); key_values: [(str, bytes), ...]."""
+        kvs, keep = _key_values(key_values)
+        args = (self.h, tex_type, int(has_alpha), kvs, len(key_values))
+        need = self.L.bu_backend_write_ktx2_file(*args, None, 0)
+        if not need:
+            raise BackendError("bu_backend_write_ktx2_file failed")
+        buf = np.zeros(need, np.uint8)
+        self.L.bu_backend_write_ktx2_file(*args, buf.ctypes.data_as(_vp), need)
         return buf
 
     def stage_times(self):

@@ -96,6 +96,34 @@ int bu_backend_init_arrays(bu_backend* b, const bu_backend_arrays* a, const bu_b
 
 uint32_t bu_backend_encode(bu_backend* b) { return b ? b->be.encode() : 0; }
 
+namespace {
+std::vector<bu::basis_key_value> to_kvs(const bu_basis_key_value* kvs, uint32_t n) {
+    std::vector<bu::basis_key_value> kv(n);
+    for (uint32_t i = 0; i < n; i++) {
+        kv[i].key = kvs[i].key ? kvs[i].key : "";
+        if (kvs[i].value_size) kv[i].value.assign(kvs[i].value, kvs[i].value + kvs[i].value_size);
+    }
+    return kv;
+}
+}  // namespace
+
+uint64_t bu_backend_write_ktx2_file(bu_backend* b, uint32_t tex_type, int has_alpha, const bu_basis_key_value* kvs, uint32_t n_kvs, void* buf, uint64_t cap) {
+    if (!b || (!kvs && n_kvs)) return 0;
+    return emit(bu::write_ktx2_file(b->be.get_output(), tex_type, has_alpha != 0, to_kvs(kvs, n_kvs)), buf, cap);
+}
+
+uint64_t bu_write_ktx2_file_uastc(const uint8_t* blocks16, uint64_t total_blocks, const bu_backend_slice_desc* s, uint32_t n, int srgb, uint32_t tex_type, int has_alpha,
+                                  const bu_basis_key_value* kvs, uint32_t n_kvs, void* buf, uint64_t cap) {
+    if (!blocks16 || !s || !n || (!kvs && n_kvs)) return 0;
+    bu_backend_params unused = {0, 0, 0};
+    bu::backend_params bp;
+    std::vector<bu::backend_slice_desc> slices;
+    convert(&unused, s, n, bp, slices);
+    const bu::backend_output out = bu::uastc_backend_output(slices, blocks16, (size_t)total_blocks, srgb != 0);
+    if (out.m_slice_desc.empty()) return 0;
+    return emit(bu::write_ktx2_file(out, tex_type, has_alpha != 0, to_kvs(kvs, n_kvs)), buf, cap);
+}
+
 uint64_t bu_write_basis_file_uastc(const uint8_t* blocks16, uint64_t total_blocks, const bu_backend_slice_desc* s, uint32_t n, int srgb, uint32_t tex_type,
                                    uint32_t userdata0, uint32_t userdata1, int y_flipped, uint32_t us_per_frame, const bu_basis_key_value* kvs, uint32_t n_kvs,
                                    void* buf, uint64_t cap) {

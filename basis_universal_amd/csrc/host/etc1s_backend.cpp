@@ -208,6 +208,113 @@ std::vector<uint8_t> write_basis_file(const backend_output& out, uint32_t tex_ty
     return f;
 }
 
+std::vector<uint8_t> write_ktx2_file(const backend_output& out, uint32_t tex_type, bool has_alpha, const std::vector<basis_key_value>& key_values_in) {
+    const bool etc1s = out.m_tex_format == 0;
+    if (!etc1s && out.m_tex_format != 1) return {};
+    const size_t n_slices = out.m_slice_desc.size();
+    if (!n_slices || out.m_slice_image_data.size() != n_slices) return {};
+    // dimensions of the texture from the slices (comp.cpp:4924-4945)
+    uint32_t width = 0, height = 0, layers = 0, levels = 0, faces = 1;
+    for (const backend_slice_desc& s : out.m_slice_desc) {
+        if (!s.m_mip_index && !width) { width = s.m_orig_width; height = s.m_orig_height; }
+        layers = std::max(layers, s.m_source_file_index + 1);
+        if (!s.m_source_file_index) levels = std::max(levels, s.m_mip_index + 1);
+    }
+    if (tex_type == 2) { if (layers % 6) return {}; layers /= 6; faces = 6; }  // cBASISTexTypeCubemapArray
+    for (const backend_slice_desc& s : out.m_slice_desc) if (s.m_mip_index >= levels) return {};
+    // every level's bytes: its slices in slice order
+    std::vector<std::vector<uint8_t>> level_bytes(levels);
+    std::vector<size_t> offset_in_level(n_slices);
+    for (size_t i = 0; i < n_slices; i++) {
+        std::vector<uint8_t>& l = level_bytes[out.m_slice_desc[i].m_mip_index];
+        offset_in_level[i] = l.size();
+        l.insert(l.end(), out.m_slice_image_data[i].begin(), out.m_slice_image_data[i].end());
+    }
+    std::vector<uint8_t> f, sgd;
+    auto put_to = [](std::vector<uint8_t>& v, uint64_t x, int bytes) { for (int i = 0; i < bytes; i++) v.push_back((uint8_t)(x >> (8 * i))); };
+    if (etc1s) {  // BasisLZ global data (comp.cpp:5104-5151)
+        put_to(sgd, out.m_num_endpoints, 2); put_to(sgd, out.m_num_selectors, 2);
+        put_to(sgd, out.m_endpoint_palette.size(), 4); put_to(sgd, out.m_selector_palette.size(), 4); put_to(sgd, out.m_slice_image_tables.size(), 4); put_to(sgd, 0, 4);
+        struct image_record { uint32_t flags = 0, rgb_ofs = 0, rgb_len = 0, alpha_ofs = 0, alpha_len = 0; };
+        std::vector<image_record> images((size_t)levels * layers * faces);
+        for (size_t i = 0; i < n_slices; i++) {
+            const backend_slice_desc& s = out.m_slice_desc[i];
+            uint32_t layer = s.m_source_file_index, face = 0;
+            if (tex_type == 2) { face = layer % 6; layer /= 6; }
+            const size_t at = (size_t)s.m_mip_index * layers * faces + (size_t)layer * faces + face;
+            if (at >= images.size()) return {};
+            if (s.m_alpha) { images[at].alpha_len = (uint32_t)out.m_slice_image_data[i].size(); images[at].alpha_ofs = (uint32_t)offset_in_level[i]; }
+            else { images[at].rgb_len = (uint32_t)out.m_slice_image_data[i].size(); images[at].rgb_ofs = (uint32_t)offset_in_level[i]; }
+        }
+        for (const image_record& r : images) { put_to(sgd, r.flags, 4); put_to(sgd, r.rgb_ofs, 4); put_to(sgd, r.rgb_len, 4); put_to(sgd, r.alpha_ofs, 4); put_to(sgd, r.alpha_len, 4); }
+        sgd.insert(sgd.end(), out.m_endpoint_palette.begin(), out.m_endpoint_palette.end());
+        sgd.insert(sgd.end(), out.m_selector_palette.begin(), out.m_selector_palette.end());
+        sgd.insert(sgd.end(), out.m_slice_image_tables.begin(), out.m_slice_image_tables.end());
+    }
+    // data format descriptor: one basic block, colour model ETC1S (163) / UASTC (166), BT.709 primaries, 4x4 texel block, one sample per
+    // plane (ETC1S: the colour slice, plus the alpha slice as a second 8-byte plane; UASTC: one 16-byte plane, channel id RGB 0 / RGBA 3)
+    std::vector<uint8_t> dfd;
+    const uint32_t samples = (etc1s && has_alpha) ? 2 : 1, block_size = 24 + 16 * samples;
+    put_to(dfd, 4 + block_size, 4);
+    put_to(dfd, 0, 4);                                   // vendor id 0 (Khronos), descriptor type 0 (basic)
+    put_to(dfd, 2, 2); put_to(dfd, block_size, 2);       // version 1.3, block size
+    put_to(dfd, etc1s ? 163 : 166, 1); put_to(dfd, 1, 1); put_to(dfd, out.m_srgb ? 2 : 1, 1); put_to(dfd, 0, 1);  // model, primaries, transfer, flags
+    put_to(dfd, 3, 1); put_to(dfd, 3, 1); put_to(dfd, 0, 2);                                                      // texel block 4x4x1x1, minus one
+    put_to(dfd, etc1s ? 8 : 16, 1); put_to(dfd, samples == 2 ? 8 : 0, 1); put_to(dfd, 0, 6);                      // bytes per plane
+    for (uint32_t k = 0; k < samples; k++) {
+        put_to(dfd, k * 64, 2); put_to(dfd, etc1s ? 63 : 127, 1);                                                 // bit offset, bit length - 1
+        put_to(dfd, etc1s ? (k ? 15 : 0) : (has_alpha ? 3 : 0), 1);                                               // channel: RGB / AAA; UASTC RGB / RGBA
+        put_to(dfd, 0, 4); put_to(dfd, 0, 4); put_to(dfd, 0xFFFFFFFFu, 4);                                        // position, lower, upper
+    }
+    // key-values, sorted by key (strcmp order); without supercompression a dummy key pads the block so that the levels start 16-byte aligned
+    std::vector<basis_key_value> kvs = key_values_in;
+    const uint32_t kvd_ofs = 80 + 24 * levels + (uint32_t)dfd.size();
+    std::vector<uint8_t> kvd;
+    for (int pass = 0; pass < 2; pass++) {
+        std::sort(kvs.begin(), kvs.end(), [](const basis_key_value& a, const basis_key_value& b) { return std::strcmp(a.key.c_str(), b.key.c_str()) < 0; });
+        kvd.clear();
+        for (const basis_key_value& p : kvs) {
+            if (p.key.empty() || p.key.find('\0') != std::string::npos) return {};
+            put_to(kvd, p.key.size() + 1 + p.value.size(), 4);
+            kvd.insert(kvd.end(), p.key.begin(), p.key.end());
+            kvd.push_back(0);
+            kvd.insert(kvd.end(), p.value.begin(), p.value.end());
+            while (kvd.size() & 3) kvd.push_back(0);
+        }
+        if (etc1s || pass) break;
+        uint32_t need = (16 - ((kvd_ofs + (uint32_t)kvd.size()) & 15)) & 15;
+        if (!need) break;
+        if (need < 6) need += 16;
+        kvs.push_back(basis_key_value{std::string(need - 6, (char)127), std::vector<uint8_t>{0}});  // 4 (length) + key + NUL + 1 value byte = need
+    }
+    // assemble
+    f.assign(80 + 24 * (size_t)levels, 0);
+    const size_t dfd_ofs = f.size();
+    f.insert(f.end(), dfd.begin(), dfd.end());
+    const size_t kvd_at = kvd.empty() ? 0 : f.size();
+    f.insert(f.end(), kvd.begin(), kvd.end());
+    size_t sgd_at = 0;
+    if (!sgd.empty()) { while (f.size() & 7) f.push_back(0); sgd_at = f.size(); f.insert(f.end(), sgd.begin(), sgd.end()); }
+    if (!etc1s) while (f.size() & 15) f.push_back(0);
+    std::vector<uint64_t> level_ofs(levels);
+    for (uint32_t l = levels; l-- > 0;) { level_ofs[l] = f.size(); f.insert(f.end(), level_bytes[l].begin(), level_bytes[l].end()); }
+    auto poke = [&f](size_t at, uint64_t v, int bytes) { for (int i = 0; i < bytes; i++) f[at + i] = (uint8_t)(v >> (8 * i)); };
+    static const uint8_t magic[12] = {0xAB, 0x4B, 0x54, 0x58, 0x20, 0x32, 0x30, 0xBB, 0x0D, 0x0A, 0x1A, 0x0A};
+    std::memcpy(f.data(), magic, 12);
+    poke(12, 0, 4); poke(16, 1, 4);                       // VK_FORMAT_UNDEFINED, type size 1
+    poke(20, width, 4); poke(24, height, 4); poke(28, 0, 4);
+    poke(32, layers > 1 ? layers : 0, 4); poke(36, faces, 4); poke(40, levels, 4);
+    poke(44, etc1s ? 1 : 0, 4);                           // supercompression scheme: BasisLZ / none
+    poke(48, dfd_ofs, 4); poke(52, dfd.size(), 4); poke(56, kvd_at, 4); poke(60, kvd.size(), 4);
+    poke(64, sgd_at, 8); poke(72, sgd.size(), 8);
+    for (uint32_t l = 0; l < levels; l++) {
+        poke(80 + 24 * (size_t)l, level_ofs[l], 8);
+        poke(88 + 24 * (size_t)l, level_bytes[l].size(), 8);
+        poke(96 + 24 * (size_t)l, etc1s ? 0 : level_bytes[l].size(), 8);  // uncompressed length: only where Zstandard could apply
+    }
+    return f;
+}
+
 backend_output uastc_backend_output(const std::vector<backend_slice_desc>& slices, const uint8_t* blocks16, size_t total_blocks, bool srgb) {
     backend_output o;
     o.m_tex_format = 1;  // cUASTC_LDR_4x4

@@ -144,6 +144,13 @@ struct basis_key_value { std::string key; std::vector<uint8_t> value; };
 std::vector<uint8_t> write_basis_file(const backend_output& out, uint32_t tex_type, uint32_t userdata0, uint32_t userdata1, bool y_flipped, uint32_t us_per_frame,
                                       const std::vector<basis_key_value>& key_values = {});
 
+// The KTX2 container around the same output = basis_compressor::create_ktx2_file + get_dfd (encoder/basisu_comp.cpp:4636-5445; structures
+// transcoder/basisu_transcoder.h:1028-1072): header, level index, data format descriptor, key-values (sorted by key, each padded to 4),
+// for ETC1S the BasisLZ global data (counts, one image record per level x layer x face, palettes, tables), then the levels, smallest
+// first, each the concatenation of its slices. UASTC is written without supercompression (the tool's -ktx2_no_zstandard), which needs
+// the key-value block padded with a dummy key so that the level data starts 16-byte aligned. has_alpha = any source image has alpha.
+std::vector<uint8_t> write_ktx2_file(const backend_output& out, uint32_t tex_type, bool has_alpha, const std::vector<basis_key_value>& key_values);
+
 // basis_compressor::encode_slices_to_uastc_4x4_ldr's output record (comp.cpp:1843-1850, 2086-2090): a UASTC file has no codebooks, a slice
 // is its blocks in raster order (16 bytes each, e.g. straight from bu_hip_encode_uastc_blocks / bu_hip_uastc_rdo) plus their CRC-16.
 backend_output uastc_backend_output(const std::vector<backend_slice_desc>& slices, const uint8_t* blocks16, size_t total_blocks, bool srgb);

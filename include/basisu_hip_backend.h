@@ -74,6 +74,13 @@ BU_HIP_API uint64_t bu_backend_get(bu_backend*, const char* name, uint32_t slice
  * y-flip flag, microseconds per frame and key-values (comp.cpp:3563-3609). */
 BU_HIP_API uint64_t bu_backend_write_basis_file(bu_backend*, uint32_t tex_type, uint32_t userdata0, uint32_t userdata1, int y_flipped, uint32_t us_per_frame,
                                                 const bu_basis_key_value* key_values, uint32_t n_key_values, void* buf, uint64_t cap);
+/* The KTX2 file around the encoded output = basis_compressor::create_ktx2_file (encoder/basisu_comp.cpp:4830-5445), BasisLZ supercompression
+ * scheme: header, level index, DFD, key-values, global data (codebooks + tables), levels. has_alpha: any source image has alpha. */
+BU_HIP_API uint64_t bu_backend_write_ktx2_file(bu_backend*, uint32_t tex_type, int has_alpha, const bu_basis_key_value* key_values, uint32_t n_key_values,
+                                               void* buf, uint64_t cap);
+/* ... and around UASTC LDR 4x4 blocks, without Zstandard supercompression (the tool's -ktx2_no_zstandard). */
+BU_HIP_API uint64_t bu_write_ktx2_file_uastc(const uint8_t* blocks16, uint64_t total_blocks, const bu_backend_slice_desc* slices, uint32_t n_slices, int srgb,
+                                             uint32_t tex_type, int has_alpha, const bu_basis_key_value* key_values, uint32_t n_key_values, void* buf, uint64_t cap);
 /* The same container around UASTC LDR 4x4 blocks (basis_compressor::encode_slices_to_uastc_4x4_ldr's output record, comp.cpp:1843-1850,
  * 2086-2090, then basisu_file::init): blocks16 = total_blocks x 16 bytes in the order the slices index them, e.g. the output of
  * bu_hip_encode_uastc_blocks / bu_hip_uastc_rdo. srgb = basis_compressor_params::m_ktx2_and_basis_srgb_transfer_function (default 1). */

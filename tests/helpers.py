@@ -444,15 +444,32 @@ def have_ref_cli():
     return (ORACLE_DIR / "_ref" / "basisu").exists()
 
 
-def run_ref_cli(png_path, *args):
-    """The reference command line tool (oracle/_ref/basisu, built from /root/reference) on one PNG -> the bytes of the .basis it writes."""
+def run_ref_cli(png_path, *args, ktx2=False):
+    """The reference command line tool (oracle/_ref/basisu, built from /root/reference) on one PNG -> the bytes of the .basis (or .ktx2) it writes."""
     import subprocess, tempfile, shutil
     with tempfile.TemporaryDirectory() as d:
         src = pathlib.Path(d) / "in.png"
         shutil.copy(png_path, src)
-        r = subprocess.run([str(ORACLE_DIR / "_ref" / "basisu"), "-basis", "-no_multithreading", *args, "in.png"], cwd=d, capture_output=True, text=True, timeout=600)
-        assert r.returncode == 0 and (pathlib.Path(d) / "in.basis").exists(), r.stdout[-2000:] + r.stderr[-2000:]
-        return np.fromfile(pathlib.Path(d) / "in.basis", np.uint8)
+        out = pathlib.Path(d) / ("in.ktx2" if ktx2 else "in.basis")
+        r = subprocess.run([str(ORACLE_DIR / "_ref" / "basisu"), "-ktx2" if ktx2 else "-basis", "-no_multithreading", *args, "in.png"], cwd=d, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and out.exists(), r.stdout[-2000:] + r.stderr[-2000:]
+        return np.fromfile(out, np.uint8)
+
+
+def ktx2_file_key_values(data):
+    """The key-value pairs of a KTX2 file (kvdByteOffset/Length of the header), without the alignment dummy key the writer adds itself."""
+    import struct
+    raw = np.asarray(data, np.uint8).tobytes()
+    ofs, size = struct.unpack_from("<II", raw, 56)
+    out, pos = [], ofs
+    while pos < ofs + size:
+        n = struct.unpack_from("<I", raw, pos)[0]
+        body = raw[pos + 4:pos + 4 + n]
+        k = body[:body.index(b"\0")]
+        if not (k and set(k) == {127}):
+            out.append((k.decode(), body[len(k) + 1:]))
+        pos = ofs + (pos + 4 + n - ofs + 3) // 4 * 4
+    return out
 
 
 def basis_file_key_values(data):

@@ -4,7 +4,7 @@ tables, every slice's bit stream, the CRCs -- has to be byte-identical, and so h
 import numpy as np
 import pytest
 
-from helpers import have_ref, have_ref_cli, RefFrontend, synth, uniform_random, to_pixel_blocks, save_png, run_ref_cli, basis_file_key_values
+from helpers import have_ref, have_ref_cli, RefFrontend, synth, uniform_random, to_pixel_blocks, save_png, run_ref_cli, basis_file_key_values, ktx2_file_key_values
 
 pytestmark = pytest.mark.skipif(not have_ref(), reason="oracle/_ref not present")
 
@@ -328,4 +328,54 @@ def test_uastc_basis_file_matches_reference_command_line(tmp_path, level, rdo, a
     if rdo:
         packed = ref_uastc_rdo(packed, blocks, level, total_jobs=1, lam=rdo, dict_size=4096)
     mine = uastc_basis_file(packed, [(0, w // 4, h // 4, w, h, 0, 0, int(alpha))], key_values=basis_file_key_values(cli))
+    assert mine.shape == cli.shape and (mine == cli).all()
+
+
+@pytest.mark.skipif(not have_ref_cli(), reason="oracle/_ref/basisu not present")
+@pytest.mark.parametrize("w,h,quality,alpha", [(256, 192, 128, False), (130, 67, 200, False), (192, 128, 128, True)])
+def test_ktx2_file_matches_reference_command_line(tmp_path, w, h, quality, alpha):
+    """`basisu -ktx2 -etc1s -q N x.png` (the tool's default container) against (reference frontend ->) our backend -> write_ktx2_file."""
+    from basis_universal_amd.backend import Etc1sBackend, default_params
+    from basis_universal_amd.etc1s import quality_to_clusters
+    img = np.ascontiguousarray(synth((w + 3) // 4 * 4, (h + 3) // 4 * 4, 31)[:h, :w])
+    if alpha:
+        yy, xx = np.mgrid[0:h, 0:w]
+        img[..., 3] = np.clip(128 + 100 * np.sin(xx / 23.0) * np.cos(yy / 17.0), 0, 255).astype(np.uint8)
+    save_png(tmp_path / "x.png", img)
+    cli = run_ref_cli(tmp_path / "x.png", "-etc1s", "-q", str(quality), ktx2=True)
+    nbx, nby = (w + 3) // 4, (h + 3) // 4
+    if alpha:
+        rgb = img.copy(); rgb[..., 3] = 255
+        a = np.repeat(img[..., 3:4], 4, axis=2); a[..., 3] = 255
+        blocks = np.concatenate([to_pixel_blocks(rgb), to_pixel_blocks(a)])
+        slices = [(0, nbx, nby, w, h, 0, 0, 0), (nbx * nby, nbx, nby, w, h, 0, 0, 1)]
+    else:
+        blocks = to_pixel_blocks(img)
+        slices = [(0, nbx, nby, w, h, 0, 0, 0)]
+    max_ep, max_sel = quality_to_clusters(quality, blocks.shape[0])
+    fe = RefFrontend(blocks, max_ep, max_sel, 1, True)
+    fe.call("compress")
+    ept, selt = default_params(quality, 1)
+    be = Etc1sBackend.from_arrays(slices=slices, endpoint_rdo_thresh=ept, selector_rdo_thresh=selt, **_arrays(fe, blocks))
+    be.encode()
+    mine = be.ktx2_file(has_alpha=alpha, key_values=ktx2_file_key_values(cli))
+    assert mine.shape == cli.shape and (mine == cli).all()
+    be.close()
+    fe.close()
+
+
+@pytest.mark.skipif(not have_ref_cli(), reason="oracle/_ref/basisu not present")
+@pytest.mark.parametrize("w,h,alpha", [(160, 96, False), (132, 68, True), (64, 64, False)])
+def test_uastc_ktx2_file_matches_reference_command_line(tmp_path, w, h, alpha):
+    """`basisu -ktx2 -uastc -ktx2_no_zstandard x.png` against reference encode_uastc blocks in write_ktx2_file (incl. the alignment dummy key)."""
+    from helpers import ref_encode_uastc
+    from basis_universal_amd.backend import uastc_ktx2_file
+    img = synth(w, h, 71)
+    if alpha:
+        yy, xx = np.mgrid[0:h, 0:w]
+        img[..., 3] = np.clip(140 + 110 * np.sin(xx / 19.0 + yy / 31.0), 0, 255).astype(np.uint8)
+    save_png(tmp_path / "x.png", img)
+    cli = run_ref_cli(tmp_path / "x.png", "-uastc", "-ktx2_no_zstandard", ktx2=True)
+    packed = ref_encode_uastc(to_pixel_blocks(img), 2)
+    mine = uastc_ktx2_file(packed, [(0, w // 4, h // 4, w, h, 0, 0, int(alpha))], has_alpha=alpha, key_values=ktx2_file_key_values(cli))
     assert mine.shape == cli.shape and (mine == cli).all()

@@ -125,6 +125,10 @@ def test_whole_encoder_matches_reference_command_line(hip_ctx, tmp_path, w, h, s
     be.encode()
     mine = be.basis_file(key_values=basis_file_key_values(cli))
     assert mine.shape == cli.shape and (mine == cli).all()
+    from helpers import ktx2_file_key_values
+    cli2 = run_ref_cli(tmp_path / "x.png", "-etc1s", "-q", str(quality), "-comp_level", str(level), ktx2=True)   # the tool's default container
+    mine2 = be.ktx2_file(key_values=ktx2_file_key_values(cli2))
+    assert mine2.shape == cli2.shape and (mine2 == cli2).all()
     be.close(); fe.close()
 
 
