@@ -68,6 +68,7 @@ _SIGNATURES = {
     "bu_hip_k_generate_endpoint_codebook": (_int, [_vp, _vp, _u32, _vp, _vp, _vp, _int, _int, _u32, _vp, _vp, _vp]),
     "bu_hip_k_generate_endpoint_codebook_part": (_int, [_vp, _vp, _u32, _vp, _vp, _vp, _int, _int, _u32, _vp, _vp, _vp, _u32, _u32]),
     "bu_hip_k_refit_endpoints_given_selectors": (_int, [_vp, _vp, _vp, _u32, _vp, _vp, _vp, _int, _vp, _vp, _vp, _vp]),
+    "bu_hip_k_resample_rgba8": (_int, [_vp, _vp, _u32, _u32, _vp, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _vp, _vp, _u32]),
     "bu_hip_k_refit_endpoints_given_selectors_q": (_int, [_vp, _vp, _vp, _u32, _vp, _vp, _vp, _int, _int, _vp, _vp, _vp, _vp]),
     "bu_hip_k_subblock_errors": (_int, [_vp, _vp, _u32, _vp, _vp, _int, _vp]),
     "bu_hip_k_refine_endpoint_clusterization": (_int, [_vp, _vp, _u32, _vp, _vp, _u32, _u32, _vp, _vp, _vp, _int, _vp]),

@@ -18,6 +18,7 @@
 #include "etc1s_kernels.h"
 #include "tsvq_kernels.h"
 #include "uastc_kernels.h"
+#include "mipmap_kernels.h"
 #include "unique_kernels.h"
 
 namespace {
@@ -455,6 +456,40 @@ int bu_hip_k_extract_blocks(bu_hip_context* ctx, const void* d_rgba, uint32_t wi
     device_guard g(ctx->device);
     prof_scope ps(ctx, "extract_blocks");
     BU_TRY(ctx, bu::launch_extract_blocks(ctx->stream, d_rgba, width, height, pitch_bytes, d_out));
+    return 1;
+}
+
+int bu_hip_k_resample_rgba8(bu_hip_context* ctx, const void* d_src, uint32_t src_w, uint32_t src_h, void* d_dst, uint32_t dst_w, uint32_t dst_h,
+                            const uint32_t* x_first, const uint16_t* x_pixel, const float* x_weight, const uint32_t* y_first, const uint16_t* y_pixel, const float* y_weight,
+                            int x_after_y, int srgb, const float* srgb_to_linear, const uint8_t* linear_to_srgb, uint32_t num_comps) {
+    if (!ctx) return 0;
+    if (!d_src || !d_dst || !src_w || !src_h || !dst_w || !dst_h || !x_first || !x_pixel || !x_weight || !y_first || !y_pixel || !y_weight || !srgb_to_linear ||
+        !linear_to_srgb || num_comps < 3 || num_comps > 4 || src_w > 16384 || src_h > 16384) { set_error(ctx, "resample_rgba8: bad arguments"); return 0; }
+    device_guard g(ctx->device);
+    // everything the kernels read besides the image, packed into one upload: lists of both axes, then the tables
+    const size_t nx = x_first[dst_w], ny = y_first[dst_h];
+    for (uint32_t i = 0; i < nx; i++) if (x_pixel[i] >= src_w) { set_error(ctx, "resample_rgba8: x contributor out of range"); return 0; }
+    for (uint32_t i = 0; i < ny; i++) if (y_pixel[i] >= src_h) { set_error(ctx, "resample_rgba8: y contributor out of range"); return 0; }
+    auto pad = [](size_t v) { return (v + 15) & ~(size_t)15; };
+    const size_t o_xf = 0, o_xw = pad(o_xf + (dst_w + 1) * 4), o_xp = pad(o_xw + nx * 4), o_yf = pad(o_xp + nx * 2), o_yw = pad(o_yf + (dst_h + 1) * 4), o_yp = pad(o_yw + ny * 4),
+                 o_t0 = pad(o_yp + ny * 2), o_t1 = o_t0 + 1024, total = o_t1 + 8192;
+    std::vector<uint8_t> pack(total, 0);
+    std::memcpy(&pack[o_xf], x_first, (dst_w + 1) * 4); std::memcpy(&pack[o_xw], x_weight, nx * 4); std::memcpy(&pack[o_xp], x_pixel, nx * 2);
+    std::memcpy(&pack[o_yf], y_first, (dst_h + 1) * 4); std::memcpy(&pack[o_yw], y_weight, ny * 4); std::memcpy(&pack[o_yp], y_pixel, ny * 2);
+    std::memcpy(&pack[o_t0], srgb_to_linear, 1024); std::memcpy(&pack[o_t1], linear_to_srgb, 8192);
+    arena &lists = ctx->scratch[4], &tmp = ctx->scratch[5];
+    const size_t tmp_px = std::max((size_t)dst_w * src_h, (size_t)src_w * dst_h);
+    BU_TRY(ctx, lists.reserve(total));
+    BU_TRY(ctx, tmp.reserve(tmp_px * 16));
+    BU_TRY(ctx, h2d(ctx, lists.p, pack.data(), total));
+    const char* b = static_cast<const char*>(lists.p);
+    {
+        prof_scope ps(ctx, "resample_rgba8");
+        BU_TRY(ctx, bu::launch_resample_rgba8(ctx->stream, d_src, src_w, src_h, d_dst, dst_w, dst_h, (const uint32_t*)(b + o_xf), (const uint16_t*)(b + o_xp), (const float*)(b + o_xw),
+                                              (const uint32_t*)(b + o_yf), (const uint16_t*)(b + o_yp), (const float*)(b + o_yw), x_after_y != 0, srgb != 0,
+                                              (const float*)(b + o_t0), (const uint8_t*)(b + o_t1), num_comps, tmp.p));
+    }
+    BU_TRY(ctx, hipStreamSynchronize(ctx->stream));  // the packed lists are reused by the next call
     return 1;
 }
 

@@ -6,6 +6,7 @@
 
 #include "../../../include/basisu_hip_frontend.h"
 #include "etc1s_frontend.h"
+#include "mipmap.h"
 #include "tsvq.h"
 #include "tsvq_device.h"
 
@@ -167,6 +168,32 @@ int bu_device_tsvq(bu_hip_context* ctx, uint32_t dim, const float* rows, const u
 }
 
 // comp.cpp:3310-3379, float arithmetic in the reference's order
+int bu_generate_mipmap_level(bu_hip_context* ctx, const void* d_src, uint32_t src_w, uint32_t src_h, void* d_dst, uint32_t dst_w, uint32_t dst_h, int srgb,
+                             const char* filter, float filter_scale, int wrapping, uint32_t num_comps) {
+    bu::mip::plan p;
+    if (!ctx || !filter || !bu::mip::make_plan(p, src_w, src_h, dst_w, dst_h, srgb != 0, filter, filter_scale, wrapping != 0)) return 0;
+    return bu_hip_k_resample_rgba8(ctx, d_src, src_w, src_h, d_dst, dst_w, dst_h, p.x.first.data(), p.x.pixel.data(), p.x.weight.data(), p.y.first.data(), p.y.pixel.data(),
+                                   p.y.weight.data(), p.x_after_y, srgb, p.srgb_to_linear, p.linear_to_srgb, num_comps);
+}
+
+uint32_t bu_mipmap_level_sizes(uint32_t w, uint32_t h, uint32_t smallest_dimension, uint32_t* out_wh, uint32_t cap) {
+    const auto sizes = bu::mip::level_sizes(w, h, smallest_dimension ? smallest_dimension : 1);
+    for (uint32_t i = 0; i < sizes.size() && i < cap; i++) { out_wh[i * 2] = sizes[i].first; out_wh[i * 2 + 1] = sizes[i].second; }
+    return (uint32_t)sizes.size();
+}
+
+int bu_mipmap_plan(uint32_t src_w, uint32_t src_h, uint32_t dst_w, uint32_t dst_h, int srgb, const char* filter, float filter_scale, int wrapping, uint32_t* out_counts,
+                   uint32_t* x_first, uint16_t* x_pixel, float* x_weight, uint32_t* y_first, uint16_t* y_pixel, float* y_weight, float* to_linear, uint8_t* to_srgb) {
+    bu::mip::plan p;
+    if (!filter || !out_counts || !bu::mip::make_plan(p, src_w, src_h, dst_w, dst_h, srgb != 0, filter, filter_scale, wrapping != 0)) return 0;
+    out_counts[0] = p.x.ops(); out_counts[1] = p.y.ops(); out_counts[2] = p.x_after_y; out_counts[3] = 0;
+    auto copy = [](auto* dst, const auto& v) { if (dst && !v.empty()) std::memcpy(dst, v.data(), v.size() * sizeof(v[0])); };
+    copy(x_first, p.x.first); copy(x_pixel, p.x.pixel); copy(x_weight, p.x.weight); copy(y_first, p.y.first); copy(y_pixel, p.y.pixel); copy(y_weight, p.y.weight);
+    if (to_linear) std::memcpy(to_linear, p.srgb_to_linear, sizeof(p.srgb_to_linear));
+    if (to_srgb) std::memcpy(to_srgb, p.linear_to_srgb, sizeof(p.linear_to_srgb));
+    return 1;
+}
+
 void bu_etc1s_quality_to_clusters(int quality_level, uint32_t total_blocks, uint32_t* out_ep, uint32_t* out_sel) {
     const double total_texels = total_blocks * 16.0f;
     const float quality = clampf(quality_level / 255.0f, 0.0f, 1.0f);

@@ -152,6 +152,15 @@ BU_HIP_API int bu_hip_k_refine_endpoint_clusterization(bu_hip_context*, const vo
     const uint32_t* d_block_cluster, const uint8_t* d_cluster_params, uint32_t n_clusters, uint32_t n_parents,
     const uint32_t* d_cand_offsets, const uint32_t* d_cand_indices, const uint8_t* d_block_parent, int perceptual, uint32_t* d_out_best_cluster);
 /* a11 create_initial_packed_texture (frontend.cpp:2014-2096): d_block_cluster may be NULL, then d_color5_inten is per block. */
+/* f4  One separable resampling step of mip generation on a resident RGBA8 raster (basis_compressor::generate_mipmaps -> image_resample ->
+ *     Resampler, comp.cpp:2146-2230, enc.cpp:1022-1180, resampler.cpp:343-435). The contributor lists of both axes (CSR: first[n+1],
+ *     pixel, weight), the pass order and the two value tables (256 floats, 8192 bytes) are HOST arrays computed by the caller
+ *     (libbasisu_frontend.so: bu_generate_mipmap_level does that exactly as the reference's host code); the device applies them with the
+ *     reference's float operations in the reference's order. d_src: src_w x src_h, d_dst: dst_w x dst_h, tightly packed. num_comps 3
+ *     or 4 (3: destination alpha = 255). */
+BU_HIP_API int bu_hip_k_resample_rgba8(bu_hip_context*, const void* d_src, uint32_t src_w, uint32_t src_h, void* d_dst, uint32_t dst_w, uint32_t dst_h,
+    const uint32_t* x_first, const uint16_t* x_pixel, const float* x_weight, const uint32_t* y_first, const uint16_t* y_pixel, const float* y_weight,
+    int x_after_y, int srgb, const float* srgb_to_linear_256, const uint8_t* linear_to_srgb_8192, uint32_t num_comps);
 BU_HIP_API int bu_hip_k_determine_selectors(bu_hip_context*, const void* d_pixel_blocks, uint32_t n_blocks,
     const uint8_t* d_color5_inten, const uint32_t* d_block_cluster, int perceptual, void* d_out_etc_blocks);
 /* a12 generate_selector_clusters training part (frontend.cpp:2155-2183): 16 floats + u64 weight per block (d_out_vec16 may be NULL). */

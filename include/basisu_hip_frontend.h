@@ -48,6 +48,20 @@ BU_HIP_API uint32_t bu_frontend_stage_times(const bu_frontend*, const char** nam
 /* basis_compressor::process_frontend's quality -> codebook size mapping (comp.cpp:3325-3379). */
 BU_HIP_API void bu_etc1s_quality_to_clusters(int quality_level, uint32_t total_blocks, uint32_t* max_endpoint_clusters, uint32_t* max_selector_clusters);
 
+/* f4  Mip generation (basis_compressor::generate_mipmaps, comp.cpp:2146-2230): one level = image_resample(src, dst, srgb, filter, scale,
+ *     wrapping, 0, num_comps) on a resident RGBA8 raster. The filter's contributor lists and tables are built here on the host exactly as
+ *     Resampler does (basis_universal_amd/csrc/host/mipmap.h), the pixels are resampled by bu_hip_k_resample_rgba8. filter: "kaiser" (the
+ *     compressor's default), "box", "tent", "bell", "mitchell", "catmullrom", "blackman", "lanczos3|4|6|12". The compressor's defaults:
+ *     srgb 1, scale 1, wrapping 1, and each level made from the previous one (m_mip_fast) down to 1x1. */
+BU_HIP_API int bu_generate_mipmap_level(bu_hip_context* ctx, const void* d_src, uint32_t src_w, uint32_t src_h, void* d_dst, uint32_t dst_w, uint32_t dst_h,
+                                        int srgb, const char* filter, float filter_scale, int wrapping, uint32_t num_comps);
+/* The sizes of the levels below w x h (comp.cpp:2153-2160): writes up to cap (w, h) pairs, returns the count. */
+BU_HIP_API uint32_t bu_mipmap_level_sizes(uint32_t w, uint32_t h, uint32_t smallest_dimension, uint32_t* out_wh, uint32_t cap);
+/* Test hook: the plan of one resampling step as flat arrays (counts via out_counts[4] = {x taps, y taps, x_after_y, 0}); buffers may be NULL. */
+BU_HIP_API int bu_mipmap_plan(uint32_t src_w, uint32_t src_h, uint32_t dst_w, uint32_t dst_h, int srgb, const char* filter, float filter_scale, int wrapping,
+                              uint32_t* out_counts, uint32_t* x_first, uint16_t* x_pixel, float* x_weight, uint32_t* y_first, uint16_t* y_pixel, float* y_weight,
+                              float* srgb_to_linear_256, uint8_t* linear_to_srgb_8192);
+
 /* Test hook: the host TSVQ (row a8) on n DISTINCT, ascending rows of `dim` (6 or 16) floats; CSR blobs out. */
 BU_HIP_API int bu_host_tsvq(uint32_t dim, const float* rows, const uint64_t* weights, uint32_t n, uint32_t max_codebook_size, uint32_t max_parent_codebook_size,
                             uint32_t* out_codebook, uint64_t cap_codebook_words, uint32_t* out_parent, uint64_t cap_parent_words);

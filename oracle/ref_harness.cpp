@@ -453,6 +453,15 @@ REF_API uint64_t ref_basis_file(void* hv, uint32_t tex_type, uint32_t userdata0,
 	return d.size();
 }
 
+// image_resample (encoder/basisu_enc.cpp:1022), the function behind basis_compressor::generate_mipmaps: RGBA8 in, RGBA8 out (tightly packed).
+REF_API int ref_image_resample(const uint8_t* src_rgba, uint32_t src_w, uint32_t src_h, uint8_t* dst_rgba, uint32_t dst_w, uint32_t dst_h, int srgb, const char* filter,
+	float filter_scale, int wrapping, uint32_t first_comp, uint32_t num_comps) {
+	image src(src_rgba, src_w, src_h, 4), dst(dst_w, dst_h);
+	if (!image_resample(src, dst, srgb != 0, filter, filter_scale, wrapping != 0, first_comp, num_comps)) return 0;
+	for (uint32_t y = 0; y < dst_h; y++) memcpy(dst_rgba + (size_t)y * dst_w * 4, &dst(0, y), (size_t)dst_w * 4);
+	return 1;
+}
+
 // The backend's coding tools on their own (known-answer style tests with synthetic inputs).
 REF_API uint64_t ref_huffman_table_bytes(const uint32_t* freq, uint32_t n, uint32_t max_code_size, uint8_t* out_sizes, uint16_t* out_codes, uint8_t* out_bytes, uint64_t cap) {
 	histogram h(n);

@@ -379,3 +379,58 @@ def test_uastc_ktx2_file_matches_reference_command_line(tmp_path, w, h, alpha):
     packed = ref_encode_uastc(to_pixel_blocks(img), 2)
     mine = uastc_ktx2_file(packed, [(0, w // 4, h // 4, w, h, 0, 0, int(alpha))], has_alpha=alpha, key_values=ktx2_file_key_values(cli))
     assert mine.shape == cli.shape and (mine == cli).all()
+
+
+def _ref_mip_chain(img, has_alpha):
+    """generate_mipmaps with the compressor's defaults, by the real image_resample (oracle/_ref): kaiser, sRGB, wrapping, each level from the
+    previous one."""
+    from test_mipmap_host import reference
+    levels, cur = [], img
+    w, h = img.shape[1], img.shape[0]
+    while max(w, h) > 1:
+        w, h = max(w >> 1, 1), max(h >> 1, 1)
+        cur = reference(cur, w, h, True, "kaiser", 1.0, True, 4 if has_alpha else 3)
+        levels.append(cur)
+    return levels
+
+
+@pytest.mark.skipif(not have_ref_cli(), reason="oracle/_ref/basisu not present")
+@pytest.mark.parametrize("w,h,alpha", [(64, 48, False), (52, 36, True)])
+def test_mipmapped_files_match_reference_command_line(tmp_path, w, h, alpha):
+    """`basisu -mipmap`: every level is a slice (colour, then alpha) of the one codebook pair; .basis and .ktx2 (levels smallest first)."""
+    from basis_universal_amd.backend import Etc1sBackend, default_params
+    from basis_universal_amd.etc1s import quality_to_clusters
+    img = np.ascontiguousarray(synth((w + 3) // 4 * 4, (h + 3) // 4 * 4, 91)[:h, :w])
+    if alpha:
+        yy, xx = np.mgrid[0:h, 0:w]
+        img[..., 3] = np.clip(128 + 100 * np.sin(xx / 13.0) * np.cos(yy / 11.0), 0, 255).astype(np.uint8)
+    save_png(tmp_path / "x.png", img)
+    levels = [img] + _ref_mip_chain(img, alpha)
+    blocks, slices, first = [], [], 0
+    for mip, lv in enumerate(levels):
+        lh, lw = lv.shape[:2]
+        nbx, nby = (lw + 3) // 4, (lh + 3) // 4
+        planes = [lv]
+        if alpha:
+            rgb = lv.copy(); rgb[..., 3] = 255
+            a = np.repeat(lv[..., 3:4], 4, axis=2); a[..., 3] = 255
+            planes = [rgb, a]
+        for k, pl in enumerate(planes):
+            blocks.append(to_pixel_blocks(pl))
+            slices.append((first, nbx, nby, lw, lh, 0, mip, k))
+            first += nbx * nby
+    blocks = np.concatenate(blocks)
+    max_ep, max_sel = quality_to_clusters(128, blocks.shape[0])
+    fe = RefFrontend(blocks, max_ep, max_sel, 1, True)
+    fe.call("compress")
+    ept, selt = default_params(128, 1)
+    be = Etc1sBackend.from_arrays(slices=slices, endpoint_rdo_thresh=ept, selector_rdo_thresh=selt, **_arrays(fe, blocks))
+    be.encode()
+    cli = run_ref_cli(tmp_path / "x.png", "-etc1s", "-q", "128", "-mipmap")
+    mine = be.basis_file(key_values=basis_file_key_values(cli))
+    assert mine.shape == cli.shape and (mine == cli).all()
+    cli2 = run_ref_cli(tmp_path / "x.png", "-etc1s", "-q", "128", "-mipmap", ktx2=True)
+    mine2 = be.ktx2_file(has_alpha=alpha, key_values=ktx2_file_key_values(cli2))
+    assert mine2.shape == cli2.shape and (mine2 == cli2).all()
+    be.close()
+    fe.close()
