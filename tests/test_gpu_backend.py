@@ -153,3 +153,26 @@ def test_uastc_whole_encoder_matches_reference_command_line(hip_ctx, tmp_path, l
         packed, _ = uastc.uastc_rdo(hip_ctx, packed, blocks, uastc.RdoParams(m_lambda=rdo), level, total_jobs=1)
     mine = uastc_basis_file(packed, [(0, w // 4, h // 4, w, h, 0, 0, int(alpha))], key_values=basis_file_key_values(cli))
     assert mine.shape == cli.shape and (mine == cli).all()
+
+
+@pytest.mark.skipif(not __import__("helpers").have_ref_cli(), reason="oracle/_ref/basisu not present")
+@pytest.mark.parametrize("name,kw,cli_args,alpha", [
+    ("etc1s_basis", dict(quality=128), ["-etc1s", "-q", "128"], False),
+    ("etc1s_alpha_mips_ktx2", dict(quality=160, comp_level=2, mipmaps=True, ktx2=True), ["-etc1s", "-q", "160", "-comp_level", "2", "-mipmap"], True),
+    ("uastc_rdo_mips_basis", dict(uastc=True, uastc_level=1, uastc_rdo_lambda=1.5, mipmaps=True), ["-uastc", "-uastc_level", "1", "-uastc_rdo_l", "1.5", "-mipmap"], False),
+    ("uastc_alpha_ktx2", dict(uastc=True, ktx2=True), ["-uastc", "-ktx2_no_zstandard"], True),
+])
+def test_compress_matches_reference_command_line(hip_ctx, tmp_path, name, kw, cli_args, alpha):
+    """compress(): one call from an RGBA image to the file, every stage on its MI355X path, against `basisu <options> x.png`."""
+    from helpers import save_png, run_ref_cli, basis_file_key_values, ktx2_file_key_values
+    from basis_universal_amd.compress import compress
+    w, h = 148, 100
+    img = np.ascontiguousarray(synth(148, 100, 17))
+    if alpha:
+        yy, xx = np.mgrid[0:h, 0:w]
+        img[..., 3] = np.clip(128 + 110 * np.sin(xx / 15.0) * np.cos(yy / 12.0), 0, 255).astype(np.uint8)
+    save_png(tmp_path / "x.png", img)
+    ktx2 = bool(kw.get("ktx2"))
+    cli = run_ref_cli(tmp_path / "x.png", *cli_args, ktx2=ktx2)
+    mine = compress(hip_ctx, img, key_values=(ktx2_file_key_values if ktx2 else basis_file_key_values)(cli), **kw)
+    assert mine.shape == cli.shape and (mine == cli).all(), name
