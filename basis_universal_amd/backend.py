@@ -58,6 +58,8 @@ def _lib():
         L.bu_backend_write_ktx2_file.argtypes = [_vp, C.c_uint32, C.c_int, C.POINTER(KeyValue), C.c_uint32, _vp, C.c_uint64]
         L.bu_write_ktx2_file_uastc.restype = C.c_uint64
         L.bu_write_ktx2_file_uastc.argtypes = [_vp, C.c_uint64, C.POINTER(SliceDesc), C.c_uint32, C.c_int, C.c_uint32, C.c_int, C.POINTER(KeyValue), C.c_uint32, _vp, C.c_uint64]
+        L.bu_backend_set_reoptimize_callback.restype = C.c_int
+        L.bu_backend_set_reoptimize_callback.argtypes = [_vp, _vp, _vp]
         L.bu_backend_error.restype = C.c_char_p
         L.bu_backend_error.argtypes = [_vp]
         L.bu_backend_stage_times.restype = C.c_uint32
@@ -161,6 +163,40 @@ class Etc1sBackend:
         if not b.L.bu_backend_init_arrays(b.h, C.byref(arrays), C.byref(prm), sl, len(slices)):
             raise BackendError("bu_backend_init_arrays failed")
         return b
+
+    REOPTIMIZE_FN = C.CFUNCTYPE(C.c_int, _vp, C.POINTER(C.c_uint32), C.c_uint32, C.POINTER(C.c_int32), C.c_int, C.POINTER(C.c_uint32), C.POINTER(BackendArrays))
+
+    def set_reoptimize(self, fn):
+        """fn(new_block_endpoints (u32 array), final_codebook (bool), block_selector_indices (u32 array or None)) -> (old_to_new int32 array,
+        dict of the arrays from_arrays takes, describing the frontend afterwards): the frontend call-back of compression levels above 1
+        for a backend driven from plain arrays."""
+        def thunk(user, nbe, n, o2n, final, bsi, refreshed):
+            try:
+                new_ep = np.ctypeslib.as_array(nbe, (n,)).copy()
+                sel = np.ctypeslib.as_array(bsi, (n,)).copy() if bsi else None
+                old_to_new, arrays = fn(new_ep, bool(final), sel)
+                old_to_new = np.asarray(old_to_new, np.int32)
+                C.memmove(o2n, old_to_new.ctypes.data, old_to_new.nbytes)
+                src = np.ascontiguousarray(arrays["source_blocks"], np.uint8)
+                out = np.ascontiguousarray(arrays["output_blocks"], np.uint8)
+                ei = np.ascontiguousarray(arrays["block_endpoint_index"], np.uint32)
+                si = np.ascontiguousarray(arrays["block_selector_index"], np.uint32)
+                ep = np.ascontiguousarray(arrays["endpoint_color5_inten"], np.uint8).reshape(-1, 4)
+                sb = np.ascontiguousarray(arrays["selector_blocks"], np.uint8).reshape(-1, 8)
+                self._keep_cb = [src, out, ei, si, ep, sb]
+                p = lambda a: a.ctypes.data
+                r = refreshed.contents
+                r.total_blocks, r.perceptual = ei.size, int(arrays.get("perceptual", True))
+                r.source_blocks, r.output_blocks, r.block_endpoint_index, r.block_selector_index = p(src), p(out), p(ei), p(si)
+                r.total_endpoints, r.endpoint_color5_inten, r.total_selectors, r.selector_blocks = ep.shape[0], p(ep), sb.shape[0], p(sb)
+                return 1
+            except Exception:
+                import traceback
+                traceback.print_exc()
+                return 0
+        self._cb = self.REOPTIMIZE_FN(thunk)
+        if not self.L.bu_backend_set_reoptimize_callback(self.h, C.cast(self._cb, _vp), None):
+            raise BackendError("bu_backend_set_reoptimize_callback failed")
 
     def encode(self):
         n = self.L.bu_backend_encode(self.h)

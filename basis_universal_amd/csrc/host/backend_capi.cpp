@@ -94,6 +94,44 @@ int bu_backend_init_arrays(bu_backend* b, const bu_backend_arrays* a, const bu_b
     return 1;
 }
 
+namespace {
+bu::backend_source to_source(const bu_backend_arrays* a) {
+    bu::backend_source src;
+    src.total_blocks = a->total_blocks;
+    src.perceptual = a->perceptual != 0;
+    src.source_blocks = a->source_blocks;
+    src.output_blocks = a->output_blocks;
+    src.block_endpoint_index = a->block_endpoint_index;
+    src.block_selector_index = a->block_selector_index;
+    src.total_endpoints = a->total_endpoints;
+    src.endpoint_color5_inten = a->endpoint_color5_inten;
+    src.total_selectors = a->total_selectors;
+    src.selector_blocks = a->selector_blocks;
+    return src;
+}
+}  // namespace
+
+int bu_backend_set_reoptimize_callback(bu_backend* b, bu_backend_reoptimize_fn fn, void* user) {
+    if (!b) return 0;
+    if (!fn) { b->be.set_reoptimize(nullptr); return 1; }
+    bu::etc1s_backend* be = &b->be;
+    b->be.set_reoptimize([fn, user, be](const std::vector<uint32_t>& new_block_endpoints, std::vector<int>& old_to_new, bool final_codebook,
+                                        const std::vector<uint32_t>* block_selector_indices, bu::backend_source& src) {
+        old_to_new.assign(be->total_endpoints(), -1);
+        bu_backend_arrays refreshed;
+        std::memset(&refreshed, 0, sizeof(refreshed));
+        if (!fn(user, new_block_endpoints.data(), (uint32_t)new_block_endpoints.size(), old_to_new.data(), final_codebook ? 1 : 0,
+                block_selector_indices ? block_selector_indices->data() : nullptr, &refreshed))
+            return false;
+        if (!refreshed.total_blocks || !refreshed.source_blocks || !refreshed.output_blocks || !refreshed.block_endpoint_index || !refreshed.block_selector_index ||
+            !refreshed.endpoint_color5_inten || !refreshed.selector_blocks)
+            return false;
+        src = to_source(&refreshed);
+        return true;
+    });
+    return 1;
+}
+
 uint32_t bu_backend_encode(bu_backend* b) { return b ? b->be.encode() : 0; }
 
 namespace {

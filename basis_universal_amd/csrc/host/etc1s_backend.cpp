@@ -113,6 +113,24 @@ template <class F> void for_each_slice(const std::vector<backend_slice_desc>& sl
     for (std::thread& th : pool) th.join();
 }
 
+// rows [0, n) of a slice over the host threads (stateless per-block work)
+template <class F> void parallel_rows(uint32_t n, uint64_t work_per_row, F fn) {
+    unsigned want = 8;
+    if (const char* e = std::getenv("BU_HOST_THREADS")) { const int v = std::atoi(e); if (v >= 1 && v <= 64) want = (unsigned)v; }
+    const unsigned hw = std::thread::hardware_concurrency();
+    unsigned t = std::min(want, hw ? hw : 1u);
+    if ((uint64_t)n * work_per_row < 32768) t = 1;
+    t = std::min<unsigned>(t, n ? n : 1);
+    if (t <= 1) { fn(0u, n); return; }
+    std::vector<std::thread> pool;
+    const uint32_t per = (n + t - 1) / t;
+    for (unsigned i = 0; i < t; i++) {
+        const uint32_t a = i * per, b = std::min(n, a + per);
+        if (a < b) pool.emplace_back([=] { fn(a, b); });
+    }
+    for (std::thread& th : pool) th.join();
+}
+
 enum token_kind : uint8_t { T_NONE, T_PRED, T_PRED_REPEAT, T_ENDPOINT_DELTA, T_SELECTOR, T_SELECTOR_RLE };
 struct token { uint32_t value; token_kind kind; };
 
@@ -478,6 +496,48 @@ void etc1s_backend::create_selector_palette() {  // backend.cpp:96-118
     }
 }
 
+// What both walks need of a block without knowing anything about the walk: the error of the frontend's block as it stands (the
+// reference's cur_err in backend.cpp:507 and :841), its selectors, and -- speculatively -- its error under the endpoints its three causal
+// neighbours had in the frontend (what backend.cpp:520-574 evaluates when those neighbours keep their endpoints, which most do). Stateless,
+// so it is spread over the host threads; the walks fall back to computing a value themselves where the speculation does not apply.
+void etc1s_backend::precompute_block_errors(bool with_neighbours) {
+    const bool perceptual = m_src.perceptual;
+    const metric::kernels K = metric::pick_kernels();
+    m_own_err.assign(m_src.total_blocks, 0);
+    m_own_sels.assign(m_src.total_blocks, 0);
+    if (with_neighbours) m_neighbour_err.assign((size_t)m_src.total_blocks * 3, UINT64_MAX);
+    for (const backend_slice_desc& s : m_slices) {
+        const uint32_t nbx = s.m_num_blocks_x, nby = s.m_num_blocks_y, base = s.m_first_block_index;
+        parallel_rows(nby, nbx, [&, nbx, base](uint32_t y0, uint32_t y1) {
+            for (uint32_t by = y0; by < y1; by++)
+                for (uint32_t bx = 0; bx < nbx; bx++) {
+                    const uint32_t b = base + bx + by * nbx;
+                    block_px px;
+                    K.load_pixels(perceptual, px, &m_src.source_blocks[b].m_pixels[0][0]);
+                    const bu_etc_block& out = m_src.output_blocks[b];
+                    const uint32_t packed = packed_selectors(out);
+                    const sel16 sels = metric::unpack_selectors(packed);
+                    pal_colors own;
+                    block_colors(perceptual, own, header_of(out));
+                    m_own_sels[b] = packed;
+                    m_own_err[b] = K.block_error(perceptual, px, own, sels);
+                    if (!with_neighbours || !m_own_err[b]) continue;
+                    const uint32_t mine = m_src.block_endpoint_index[b];
+                    uint32_t nb[kNumEndpointPreds];
+                    bool any_equal = false;
+                    for (uint32_t p = 0; p < kNumEndpointPreds; p++) {
+                        const int x = (int)bx + kPredDx[p], y = (int)by + kPredDy[p];
+                        nb[p] = (x >= 0 && y >= 0) ? m_src.block_endpoint_index[base + (uint32_t)x + (uint32_t)y * nbx] : UINT32_MAX;
+                        any_equal = any_equal || nb[p] == mine;
+                    }
+                    if (any_equal) continue;   // predicted unless a neighbour is remapped away: left to the walk
+                    for (uint32_t p = 0; p < kNumEndpointPreds; p++)
+                        if (nb[p] != UINT32_MAX && nb[p] < m_src.total_endpoints) m_neighbour_err[(size_t)b * 3 + p] = K.block_error(perceptual, px, m_palette_colors[nb[p]], sels);
+                }
+        });
+    }
+}
+
 // backend.cpp:406-617: every block is predicted from its left, upper or upper-left neighbour when that one uses the same endpoints;
 // when none does, a neighbour's endpoints are adopted anyway if the block's error stays within the RDO threshold.
 bool etc1s_backend::create_encoder_blocks() {
@@ -499,6 +559,7 @@ bool etc1s_backend::create_encoder_blocks() {
     std::sort(extents.begin(), extents.end());
     for (size_t i = 1; i < extents.size(); i++)
         if (extents[i].first < extents[i - 1].second) return fail("slices overlap");  // the per-block state is kept once per block, and slices are walked concurrently
+    if (thresh > 0.0f) precompute_block_errors(true);
     struct slice_result { std::vector<uint32_t> unpredicted; uint32_t remapped = 0; const char* error = nullptr; };
     std::vector<slice_result> results(m_slices.size());
     for_each_slice(m_slices, [&](size_t si) {
@@ -528,20 +589,22 @@ bool etc1s_backend::create_encoder_blocks() {
                 if (best_pred != UINT32_MAX) {
                     m.endpoint_predictor = (uint8_t)best_pred;
                 } else if (thresh > 0.0f) {
-                    block_px px;
-                    K.load_pixels(perceptual, px, &m_src.source_blocks[b].m_pixels[0][0]);
-                    const bu_etc_block& out = m_src.output_blocks[b];
-                    const sel16 sels = metric::unpack_selectors(packed_selectors(out));
-                    pal_colors own;
-                    block_colors(perceptual, own, header_of(out));
-                    const uint64_t cur_err = K.block_error(perceptual, px, own, sels);
+                    const uint64_t cur_err = m_own_err[b];
                     if (cur_err) {
                         const uint64_t thresh_err = (uint64_t)(cur_err * std::max(1.0f, thresh));
                         uint64_t best_err = UINT64_MAX;
                         uint32_t best_index = 0;
+                        block_px px;
+                        sel16 sels;
+                        bool have_px = false;
                         for (uint32_t p = 0; p < kNumEndpointPreds; p++) {
                             if (!present[p]) continue;
-                            const uint64_t err = K.block_error(perceptual, px, m_palette_colors[neighbour[p]], sels);
+                            const uint32_t nb_block = s.m_first_block_index + (uint32_t)((int)bx + kPredDx[p]) + (uint32_t)((int)by + kPredDy[p]) * nbx;
+                            uint64_t err = m_neighbour_err[(size_t)b * 3 + p];
+                            if (err == UINT64_MAX || neighbour[p] != m_src.block_endpoint_index[nb_block]) {   // not speculated, or the neighbour was remapped
+                                if (!have_px) { K.load_pixels(perceptual, px, &m_src.source_blocks[b].m_pixels[0][0]); sels = metric::unpack_selectors(m_own_sels[b]); have_px = true; }
+                                err = K.block_error(perceptual, px, m_palette_colors[neighbour[p]], sels);
+                            }
                             if (err <= thresh_err && err < best_err) { best_err = err; best_pred = p; best_index = neighbour[p]; }  // ascending p: ties keep the lower predictor
                         }
                         if (best_pred != UINT32_MAX) {
@@ -577,6 +640,7 @@ bool etc1s_backend::reoptimize_and_sort_endpoints_codebook(uint32_t total_remapp
         std::vector<int> old_to_new;
         if (!m_reoptimize(new_block_endpoints, old_to_new, true, nullptr, m_src)) return fail("reoptimize_remapped_endpoints failed");
         create_endpoint_palette();
+        precompute_block_errors(false);  // the frontend rewrote the colours of its output blocks
         for (encoder_block& m : m_blocks) m.endpoint_index = (uint32_t)old_to_new[m.endpoint_index];
         for (uint32_t& i : all_endpoint_indices) i = (uint32_t)old_to_new[i];
     }
@@ -772,19 +836,16 @@ bool etc1s_backend::encode_image() {
                         int delta = new_endpoint - (int)prev_endpoint;
                         if (m_params.m_endpoint_rdo_quality_thresh > 1.0f && std::abs(delta) > 1 && !referenced[i]) {
                             // a palette entry closer to the previous index that keeps the error within the threshold is cheaper to code
-                            block_px px;
-                            K.load_pixels(perceptual, px, &m_src.source_blocks[b].m_pixels[0][0]);
-                            const bu_etc_block& out = m_src.output_blocks[b];
-                            const color5 cur_c = header_of(out);
-                            const sel16 sels = metric::unpack_selectors(packed_selectors(out));
-                            pal_colors own;
-                            block_colors(perceptual, own, cur_c);
-                            const uint64_t cur_err = K.block_error(perceptual, px, own, sels);
+                            const color5 cur_c = header_of(m_src.output_blocks[b]);
+                            const uint64_t cur_err = m_own_err[b];
                             if (cur_err) {
                                 const endpoint_entry cur_e = m_endpoint_palette[m.endpoint_index];
                                 const uint64_t thresh_err = (uint64_t)(cur_err * endpoint_thresh);
                                 uint64_t best_err = UINT64_MAX;
                                 int best_idx = 0;
+                                block_px px;
+                                K.load_pixels(perceptual, px, &m_src.source_blocks[b].m_pixels[0][0]);
+                                const sel16 sels = metric::unpack_selectors(m_own_sels[b]);
                                 const int dist = std::min(std::abs(delta) - 1, max_search);
                                 int cand[128], n_cand = 0;   // 2 * max_search at most
                                 const size_t w0 = (size_t)((int)prev_endpoint - dist + (int)kPad);

@@ -87,6 +87,8 @@ public:
 
     void init(etc1s_frontend* frontend, const backend_params& params, const std::vector<backend_slice_desc>& slices);
     void init(const backend_source& src, const backend_params& params, const std::vector<backend_slice_desc>& slices, reoptimize_fn reoptimize = nullptr);
+    void set_reoptimize(reoptimize_fn fn) { m_reoptimize = std::move(fn); }
+    uint32_t total_endpoints() const { return m_src.total_endpoints; }
     uint32_t encode();                     // total compressed bytes, 0 on failure (error() says why)
     const backend_output& get_output() const { return m_output; }
     const backend_params& get_params() const { return m_params; }
@@ -114,6 +116,7 @@ private:
     bool reoptimize_and_sort_endpoints_codebook(uint32_t total_remapped, std::vector<uint32_t>& all_endpoint_indices);
     void sort_selector_codebook();
     void compute_slice_crcs();
+    void precompute_block_errors(bool with_neighbours);
 
     etc1s_frontend* m_frontend = nullptr;
     backend_source m_src;
@@ -129,6 +132,10 @@ private:
     std::vector<metric::pal_colors> m_palette_colors;  // the block colours of every endpoint palette entry in the metric's basis
     std::vector<metric::sel16> m_selector_bytes;       // every selector pattern, one selector per byte
     std::vector<encoder_block> m_blocks;
+    // stateless per-block quantities both walks need, computed by all host threads up front (precompute_block_errors)
+    std::vector<uint64_t> m_own_err;         // error of the frontend's output block under its own colours and selectors
+    std::vector<uint32_t> m_own_sels;        // its selectors, packed
+    std::vector<uint64_t> m_neighbour_err;   // 3 per block: error with the ORIGINAL endpoints of the left / upper / upper-left neighbour (UINT64_MAX: not computed)
     std::vector<uint32_t> m_endpoint_old_to_new, m_endpoint_new_to_old;
     std::vector<uint8_t> m_new_endpoint_was_used;
     std::vector<uint32_t> m_selector_old_to_new, m_selector_new_to_old;

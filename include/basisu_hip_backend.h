@@ -61,6 +61,13 @@ BU_HIP_API void bu_backend_destroy(bu_backend*);
 BU_HIP_API int bu_backend_init(bu_backend*, bu_frontend* frontend, const bu_backend_params*, const bu_backend_slice_desc* slices, uint32_t n_slices);
 /* ... or on plain arrays. Compression levels above 1 need the frontend (basisu_frontend::reoptimize_remapped_endpoints). */
 BU_HIP_API int bu_backend_init_arrays(bu_backend*, const bu_backend_arrays*, const bu_backend_params*, const bu_backend_slice_desc* slices, uint32_t n_slices);
+/* With bu_backend_init_arrays the frontend call-back of compression levels above 1 (basisu_frontend::reoptimize_remapped_endpoints,
+ * frontend.cpp:2996-3220) can be supplied by the host application: it receives the new endpoint cluster of every block, has to refit /
+ * (when final_codebook) renumber its codebook, fill old_to_new[total_endpoints before the call] (-1: unused) and describe its state afterwards
+ * in *refreshed (arrays it keeps alive until the next call or bu_backend_encode returns). Return 1 on success. */
+typedef int (*bu_backend_reoptimize_fn)(void* user, const uint32_t* new_block_endpoints, uint32_t total_blocks, int32_t* old_to_new, int final_codebook,
+                                        const uint32_t* block_selector_indices /* or NULL */, bu_backend_arrays* refreshed);
+BU_HIP_API int bu_backend_set_reoptimize_callback(bu_backend*, bu_backend_reoptimize_fn fn, void* user);  /* after bu_backend_init_arrays */
 /* basisu_backend::encode (backend.cpp:1747): total compressed bytes, 0 on failure. */
 BU_HIP_API uint32_t bu_backend_encode(bu_backend*);
 /* One piece of basisu_backend_output (backend.h:218-276) or of the per-block state; returns the bytes needed, copies when cap

@@ -433,6 +433,19 @@ REF_API uint64_t ref_backend_get(void* hv, const char* name, uint32_t slice, voi
 	return ~0ull;
 }
 
+// basisu_frontend::reoptimize_remapped_endpoints (frontend.cpp:2996) on the handle's frontend: what the reference backend calls at levels > 1.
+REF_API int ref_frontend_reoptimize(void* hv, const uint32_t* new_block_endpoints, uint32_t n, int32_t* old_to_new, int final_codebook, const uint32_t* block_selector_indices) {
+	basisu_frontend& fe = static_cast<frontend_handle*>(hv)->fe;
+	uint_vec nb(n);
+	for (uint32_t i = 0; i < n; i++) nb[i] = new_block_endpoints[i];
+	int_vec o2n;
+	uint_vec sel;
+	if (block_selector_indices) { sel.resize(n); for (uint32_t i = 0; i < n; i++) sel[i] = block_selector_indices[i]; }
+	fe.reoptimize_remapped_endpoints(nb, o2n, final_codebook != 0, block_selector_indices ? &sel : nullptr);
+	for (uint32_t i = 0; i < o2n.size(); i++) old_to_new[i] = o2n[i];
+	return 1;
+}
+
 // basisu_file::init on the kept backend's output (encoder/basisu_basis_file.cpp:290): the .basis container, with optional key-values
 // given as n x (key C string, value bytes, value size).
 REF_API uint64_t ref_basis_file(void* hv, uint32_t tex_type, uint32_t userdata0, uint32_t userdata1, int y_flipped, uint32_t us_per_frame,

@@ -223,6 +223,18 @@ class RefFrontend:
         self.L.ref_backend_get(self.h, name.encode(), slice_index, buf.ctypes.data_as(C.c_void_p), need)
         return buf.view(dtype)
 
+    def reoptimize(self, new_block_endpoints, final_codebook, block_selector_indices=None):
+        """basisu_frontend::reoptimize_remapped_endpoints on this frontend -> old_to_new (int32, one per endpoint cluster before the call)."""
+        f = self.L.ref_frontend_reoptimize
+        f.restype = C.c_int
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_int, C.c_void_p]
+        nb = np.ascontiguousarray(new_block_endpoints, np.uint32)
+        k = self.get("endpoint_cluster_etc_params").size // 16
+        o2n = np.full(max(k, 1), -1, np.int32)
+        sel = None if block_selector_indices is None else np.ascontiguousarray(block_selector_indices, np.uint32)
+        assert f(self.h, nb.ctypes.data, nb.size, o2n.ctypes.data, int(final_codebook), None if sel is None else sel.ctypes.data) == 1
+        return o2n
+
     def basis_file(self, tex_type=0, userdata0=0, userdata1=0, y_flipped=False, us_per_frame=0, key_values=()):
         """basisu_file::init on the last backend_run's output -> the .basis file bytes."""
         f = self.L.ref_basis_file

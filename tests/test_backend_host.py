@@ -434,3 +434,35 @@ def test_mipmapped_files_match_reference_command_line(tmp_path, w, h, alpha):
     assert mine2.shape == cli2.shape and (mine2 == cli2).all()
     be.close()
     fe.close()
+
+
+@pytest.mark.parametrize("case", [("l2", 2, 1.5, 1.25, True), ("l3_strong", 3, 3.0, 2.0, True), ("l4_linear", 4, 1.5, 1.25, False), ("l6", 6, 1.5, 1.25, True),
+                                   ("l2_two_slices", 2, 1.5, 1.25, True)], ids=lambda c: c[0])
+def test_backend_above_level_1_with_a_frontend_callback(case):
+    """Compression levels above 1 on the CPU: the backend's call-back into the frontend (reoptimize_remapped_endpoints, twice per encode) is
+    served by a SECOND copy of the reference frontend through bu_backend_set_reoptimize_callback, the bytes are compared with the reference
+    backend running on the first copy -- the same flow the GPU test runs with the resident frontend behind it."""
+    from basis_universal_amd.backend import Etc1sBackend
+    name, level, ept, selt, perceptual = case
+    w, h = 192, 128
+    blocks = to_pixel_blocks(synth(w, h, 40 + level))
+    slices = [(0, 48, 16), (768, 48, 16)] if "two" in name else [(0, 48, 32)]
+    fe_ref = RefFrontend(blocks, 200, 256, level, perceptual)
+    fe_ref.call("compress")
+    fe_cb = RefFrontend(blocks, 200, 256, level, perceptual)
+    fe_cb.call("compress")
+    be = Etc1sBackend.from_arrays(slices=slices, perceptual=perceptual, endpoint_rdo_thresh=ept, selector_rdo_thresh=selt, compression_level=level, **_arrays(fe_cb, blocks))
+    calls = []
+
+    def reoptimize(new_block_endpoints, final_codebook, block_selector_indices):
+        calls.append(final_codebook)
+        o2n = fe_cb.reoptimize(new_block_endpoints, final_codebook, block_selector_indices)
+        return o2n, dict(perceptual=perceptual, **_arrays(fe_cb, blocks))
+    be.set_reoptimize(reoptimize)
+    total = be.encode()
+    ref_total, _ = fe_ref.backend_run(slices, ept, selt)
+    assert total == ref_total and calls and calls[0] is True
+    _compare(fe_ref, be, len(slices))
+    for k in ("endpoint_cluster_etc_params", "block_endpoint_clusters_indices", "encoded_blocks"):   # both frontends went through the same call-backs
+        assert (fe_cb.get(k) == fe_ref.get(k)).all(), k
+    be.close(); fe_cb.close(); fe_ref.close()
