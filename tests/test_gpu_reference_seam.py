@@ -18,7 +18,7 @@ SHIM_TOOL = ORACLE_DIR / "_ref" / "basisu_hip"
 def _run(tool, png, *args):
     with tempfile.TemporaryDirectory() as d:
         save_png(pathlib.Path(d) / "in.png", png)
-        r = subprocess.run([str(tool), "-basis", "-no_multithreading", *args, "in.png"], cwd=d, capture_output=True, text=True, timeout=600)
+        r = subprocess.run([str(tool), "-basis", "-no_multithreading", *args, "in.png"], cwd=d, capture_output=True, text=True, timeout=120)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
         return np.fromfile(pathlib.Path(d) / "in.basis", np.uint8), r.stdout + r.stderr
 
