@@ -395,24 +395,39 @@ std::vector<uint32_t> reorder_palette_by_adjacency(const uint32_t* indices, uint
     std::vector<uint8_t> done(n, 0);
     std::vector<uint32_t> to_picked(n, 0);
     int32_t front = 0;
-    auto account = [&](uint32_t moved) { for (uint32_t k = first[moved]; k < first[moved + 1]; k++) if (!done[edges[k].other]) to_picked[edges[k].other] += edges[k].count; };
+    // the unplaced symbols by (adjacency to the placed ones, descending; number, ascending): a heap with lazy deletion -- an entry is
+    // current while its count still equals to_picked[symbol]; symbols nobody is adjacent to yet are not in it
+    struct cand { uint32_t count, sym; };
+    auto worse = [](const cand& a, const cand& b) { return a.count != b.count ? a.count < b.count : a.sym > b.sym; };
+    std::vector<cand> heap;
+    auto account = [&](uint32_t moved) {
+        for (uint32_t k = first[moved]; k < first[moved + 1]; k++) {
+            const uint32_t o = edges[k].other;
+            if (done[o]) continue;
+            to_picked[o] += edges[k].count;
+            heap.push_back(cand{to_picked[o], o});
+            std::push_heap(heap.begin(), heap.end(), worse);
+        }
+    };
     const uint32_t a0 = (uint32_t)(max_key / n), b0 = (uint32_t)(max_key % n);
     picked.push_back(a0); picked.push_back(b0);
     done[a0] = done[b0] = 1;
     coord[a0] = 0; coord[b0] = 1;
     account(a0);
     if (b0 != a0) account(b0);
-    uint32_t remaining = 0;
+    uint32_t remaining = 0, lowest = 0;
     for (uint32_t s = 0; s < n; s++) remaining += !done[s];
     std::vector<std::pair<int32_t, uint32_t>> near;  // (position, count) of the picked neighbours of the symbol being placed
     while (remaining) {
         // the unplaced symbol most often adjacent to the placed ones; lowest number on ties, the lowest unplaced when all are 0 (enc.cpp:1868-1891)
-        uint32_t best = UINT32_MAX, best_count = 0;
-        for (uint32_t s = 0; s < n; s++) {
-            if (done[s]) continue;
-            if (best == UINT32_MAX) best = s;
-            if (to_picked[s] > best_count) { best = s; best_count = to_picked[s]; }
+        uint32_t best = UINT32_MAX;
+        while (!heap.empty()) {
+            const cand top = heap.front();
+            if (!done[top.sym] && top.count == to_picked[top.sym]) { best = top.sym; break; }
+            std::pop_heap(heap.begin(), heap.end(), worse);
+            heap.pop_back();
         }
+        if (best == UINT32_MAX) { while (done[lowest]) lowest++; best = lowest; }
         // which end: the float sum of count * (distance to the far end - distance to the near end), in line order (enc.cpp:1893-1915)
         near.clear();
         for (uint32_t k = first[best]; k < first[best + 1]; k++)
