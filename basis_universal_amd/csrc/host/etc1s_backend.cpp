@@ -113,6 +113,18 @@ template <class F> void for_each_slice(const std::vector<backend_slice_desc>& sl
     for (std::thread& th : pool) th.join();
 }
 
+// first index of the smallest Hamming distance to `to` among n packed patterns, stopping at the first distance <= 1 (backend.cpp:274-296)
+#define BU_NEAREST_BODY(POPCOUNT) \
+    uint32_t best = 100, best_j = 0; \
+    for (uint32_t j = 0; j < n; j++) { \
+        const uint32_t d = (uint32_t)POPCOUNT(p[j] ^ to); \
+        if (d < best) { best = d; best_j = j; if (d <= 1) break; } \
+    } \
+    return best_j;
+inline uint32_t nearest_pattern_plain(const uint32_t* p, uint32_t n, uint32_t to) { BU_NEAREST_BODY(__builtin_popcount) }
+__attribute__((target("popcnt"))) inline uint32_t nearest_pattern_popcnt(const uint32_t* p, uint32_t n, uint32_t to) { BU_NEAREST_BODY(__builtin_popcount) }
+#undef BU_NEAREST_BODY
+
 // rows [0, n) of a slice over the host threads (stateless per-block work)
 template <class F> void parallel_rows(uint32_t n, uint64_t work_per_row, F fn) {
     unsigned want = 8;
@@ -684,20 +696,18 @@ void etc1s_backend::sort_selector_codebook() {
     if (m_params.m_compression_level == 0) {
         for (uint32_t i = 0; i < k; i++) m_selector_new_to_old[i] = i;
     } else if (k) {
-        std::vector<uint32_t> remaining(k - 1);
-        for (uint32_t i = 1; i < k; i++) remaining[i - 1] = i;
+        // `remaining` in the reference's order (swap-with-last removal), with the patterns alongside so that the scan reads memory linearly
+        std::vector<uint32_t> remaining(k - 1), bits(k - 1);
+        for (uint32_t i = 1; i < k; i++) { remaining[i - 1] = i; bits[i - 1] = m_selector_palette[i]; }
+        const bool hw_popcnt = __builtin_cpu_supports("popcnt");
         uint32_t prev = 0;
         for (uint32_t i = 1; i < k; i++) {
-            const uint32_t prev_bits = m_selector_palette[prev];
-            uint32_t best_dist = 100, best_j = 0;
-            for (uint32_t j = 0; j < remaining.size(); j++) {
-                const uint32_t d = (uint32_t)__builtin_popcount(prev_bits ^ m_selector_palette[remaining[j]]);
-                if (d < best_dist) { best_dist = d; best_j = j; if (d <= 1) break; }
-            }
+            const uint32_t left = (uint32_t)remaining.size();
+            const uint32_t best_j = hw_popcnt ? nearest_pattern_popcnt(bits.data(), left, m_selector_palette[prev]) : nearest_pattern_plain(bits.data(), left, m_selector_palette[prev]);
             prev = remaining[best_j];
             m_selector_new_to_old[i] = prev;
-            remaining[best_j] = remaining.back();
-            remaining.pop_back();
+            remaining[best_j] = remaining.back(); bits[best_j] = bits.back();
+            remaining.pop_back(); bits.pop_back();
         }
     }
     m_selector_old_to_new.assign(k, 0);
