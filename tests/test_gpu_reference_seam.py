@@ -24,8 +24,6 @@ def _run(tool, png, *args):
 
 
 @pytest.mark.skipif(not (have_ref_cli() and SHIM_TOOL.exists()), reason="oracle/_ref/basisu_hip not present")
-@pytest.mark.xfail(strict=False, reason="first run on hardware pending: every seam operation is parity-tested on its own (test_gpu_etc1s_kernels.py), "
-                                        "the tool-level binary was linked after round 1's GPU budget was spent")
 @pytest.mark.parametrize("level", [1, 2])
 def test_reference_tool_with_hip_seam_writes_the_cpu_tools_file(level):
     img = synth(256, 192, 77)
