@@ -433,6 +433,50 @@ REF_API uint64_t ref_backend_get(void* hv, const char* name, uint32_t slice, voi
 	return ~0ull;
 }
 
+// Overwrites the finished state of the handle's frontend with arbitrary codebooks and assignments (everything the backend reads through the
+// getters of frontend.h:119-156), so that the reference backend can be run on states no image would produce (backend fuzzing). The encoded
+// blocks are rebuilt from the codebooks: colour5 + table of the block's endpoint cluster, selectors of its selector cluster.
+REF_API int ref_frontend_set_state(void* hv, uint32_t n_endpoints, const uint8_t* color5_inten, uint32_t n_selectors, const uint8_t* selectors16,
+	const uint32_t* block_endpoint, const uint32_t* block_selector) {
+	frontend_handle* h = static_cast<frontend_handle*>(hv);
+	basisu_frontend& fe = h->fe;
+	const uint32_t n = fe.m_total_blocks;
+	fe.m_endpoint_clusters.clear(); fe.m_endpoint_clusters.resize(n_endpoints);
+	fe.m_endpoint_cluster_etc_params.clear(); fe.m_endpoint_cluster_etc_params.resize(n_endpoints);
+	for (uint32_t i = 0; i < n_endpoints; i++) {
+		auto& e = fe.m_endpoint_cluster_etc_params[i];
+		e.m_color_unscaled[0] = color_rgba(color5_inten[i * 4], color5_inten[i * 4 + 1], color5_inten[i * 4 + 2], 255);
+		e.m_inten_table[0] = color5_inten[i * 4 + 3];
+		e.m_color_used[0] = true;
+		e.m_valid = true;
+	}
+	fe.m_selector_cluster_block_indices.clear(); fe.m_selector_cluster_block_indices.resize(n_selectors);
+	fe.m_optimized_cluster_selectors.clear(); fe.m_optimized_cluster_selectors.resize(n_selectors);
+	for (uint32_t i = 0; i < n_selectors; i++) {
+		etc_block& b = fe.m_optimized_cluster_selectors[i];
+		memset(&b, 0, sizeof(b));
+		for (uint32_t y = 0; y < 4; y++) for (uint32_t x = 0; x < 4; x++) b.set_selector(x, y, selectors16[i * 16 + y * 4 + x] & 3);
+	}
+	fe.m_block_endpoint_clusters_indices.resize(n);
+	fe.m_block_selector_cluster_index.resize(n);
+	fe.m_encoded_blocks.resize(n);
+	for (uint32_t b = 0; b < n; b++) {
+		if (block_endpoint[b] >= n_endpoints || block_selector[b] >= n_selectors) return 0;
+		fe.m_block_endpoint_clusters_indices[b][0] = fe.m_block_endpoint_clusters_indices[b][1] = block_endpoint[b];
+		fe.m_block_selector_cluster_index[b] = block_selector[b];
+		fe.m_endpoint_clusters[block_endpoint[b]].push_back(b * 2); fe.m_endpoint_clusters[block_endpoint[b]].push_back(b * 2 + 1);
+		fe.m_selector_cluster_block_indices[block_selector[b]].push_back(b);
+		etc_block& blk = fe.m_encoded_blocks[b];
+		memset(&blk, 0, sizeof(blk));
+		blk.set_diff_bit(true);
+		blk.set_flip_bit(true);
+		blk.set_block_color5_etc1s(fe.m_endpoint_cluster_etc_params[block_endpoint[b]].m_color_unscaled[0]);
+		blk.set_inten_tables_etc1s(fe.m_endpoint_cluster_etc_params[block_endpoint[b]].m_inten_table[0]);
+		blk.set_raw_selector_bits(fe.m_optimized_cluster_selectors[block_selector[b]].get_raw_selector_bits());
+	}
+	return 1;
+}
+
 // basisu_frontend::reoptimize_remapped_endpoints (frontend.cpp:2996) on the handle's frontend: what the reference backend calls at levels > 1.
 REF_API int ref_frontend_reoptimize(void* hv, const uint32_t* new_block_endpoints, uint32_t n, int32_t* old_to_new, int final_codebook, const uint32_t* block_selector_indices) {
 	basisu_frontend& fe = static_cast<frontend_handle*>(hv)->fe;

@@ -223,6 +223,16 @@ class RefFrontend:
         self.L.ref_backend_get(self.h, name.encode(), slice_index, buf.ctypes.data_as(C.c_void_p), need)
         return buf.view(dtype)
 
+    def set_state(self, color5_inten, selectors16, block_endpoint, block_selector):
+        """Overwrite the finished frontend state with arbitrary codebooks / assignments (backend fuzzing)."""
+        f = self.L.ref_frontend_set_state
+        f.restype = C.c_int
+        f.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
+        ep = np.ascontiguousarray(color5_inten, np.uint8).reshape(-1, 4)
+        sel = np.ascontiguousarray(selectors16, np.uint8).reshape(-1, 16)
+        be, bs = np.ascontiguousarray(block_endpoint, np.uint32), np.ascontiguousarray(block_selector, np.uint32)
+        assert f(self.h, ep.shape[0], ep.ctypes.data, sel.shape[0], sel.ctypes.data, be.ctypes.data, bs.ctypes.data) == 1
+
     def reoptimize(self, new_block_endpoints, final_codebook, block_selector_indices=None):
         """basisu_frontend::reoptimize_remapped_endpoints on this frontend -> old_to_new (int32, one per endpoint cluster before the call)."""
         f = self.L.ref_frontend_reoptimize

@@ -466,3 +466,63 @@ def test_backend_above_level_1_with_a_frontend_callback(case):
     for k in ("endpoint_cluster_etc_params", "block_endpoint_clusters_indices", "encoded_blocks"):   # both frontends went through the same call-backs
         assert (fe_cb.get(k) == fe_ref.get(k)).all(), k
     be.close(); fe_cb.close(); fe_ref.close()
+
+
+def _fuzz_state(rng, nbx, nby, k_ep, k_sel, coherence):
+    """A frontend state no image would produce, but with the structure the backend's logic keys on: endpoint / selector indices that often
+    repeat between neighbours (predictors, runs), palettes with near-duplicates (RDO candidates), pixels near the coded colours (so that
+    remapping within the thresholds happens) or far from them."""
+    n = nbx * nby
+    ep = np.stack([rng.integers(0, 32, k_ep), rng.integers(0, 32, k_ep), rng.integers(0, 32, k_ep), rng.integers(0, 8, k_ep)], 1).astype(np.uint8)
+    if k_ep > 4:   # neighbours in the palette that are close in colour
+        dup = rng.integers(0, k_ep, k_ep // 3)
+        ep[dup] = np.clip(ep[(dup + 1) % k_ep].astype(int) + rng.integers(-1, 2, (dup.size, 4)), 0, [31, 31, 31, 7]).astype(np.uint8)
+    sel = rng.integers(0, 4, (k_sel, 16)).astype(np.uint8)
+    if k_sel > 4:
+        dup = rng.integers(0, k_sel, k_sel // 2)
+        sel[dup] = sel[(dup + 1) % k_sel]
+        flip = rng.integers(0, 16, dup.size)
+        sel[dup, flip] = rng.integers(0, 4, dup.size)
+    be, bs = np.zeros(n, np.uint32), np.zeros(n, np.uint32)
+    for i in range(n):
+        x, y = i % nbx, i // nbx
+        r = rng.random()
+        if r < coherence and x:
+            be[i] = be[i - 1]
+        elif r < 1.5 * coherence and y:
+            be[i] = be[i - nbx]
+        else:
+            be[i] = rng.integers(0, k_ep)
+        bs[i] = bs[i - 1] if (i and rng.random() < coherence) else rng.integers(0, k_sel)
+    inten = np.array([[-8, -2, 2, 8], [-17, -5, 5, 17], [-29, -9, 9, 29], [-42, -13, 13, 42], [-60, -18, 18, 60], [-80, -24, 24, 80], [-106, -33, 33, 106], [-183, -47, 47, 183]])
+    base = (ep[be, :3].astype(int) << 3) | (ep[be, :3].astype(int) >> 2)
+    px = np.clip(base[:, None, :] + inten[ep[be, 3]][np.arange(n)[:, None], sel[bs]][:, :, None] + rng.integers(-6, 7, (n, 16, 3)), 0, 255)
+    blocks = np.concatenate([px, np.full((n, 16, 1), 255)], 2).astype(np.uint8).reshape(n, 4, 4, 4)
+    return ep, sel, be, bs, blocks
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_backend_fuzzed_states_match_reference(seed):
+    """Random frontend states pushed into the REAL reference frontend object (ref_frontend_set_state) and through both backends: tiny and
+    large codebooks, one-entry codebooks, long runs, every threshold regime, levels 0 and 1, two slices."""
+    from basis_universal_amd.backend import Etc1sBackend
+    rng = np.random.default_rng(1000 + seed)
+    nbx, nby = int(rng.integers(1, 40)), int(rng.integers(1, 40))
+    k_ep = int(rng.choice([1, 2, 3, 17, 200, 1500]))
+    k_sel = int(rng.choice([1, 2, 5, 64, 300, 2000]))
+    coherence = float(rng.choice([0.0, 0.3, 0.6, 0.95]))
+    level = int(rng.integers(0, 2))
+    perceptual = bool(rng.integers(0, 2))
+    ept, selt = [(0.0, 0.0), (1.0, 1.0), (1.5, 1.25), (4.0, 3.0), (0.5, 2.0)][int(rng.integers(0, 5))]
+    ep, sel, be_idx, bs_idx, blocks = _fuzz_state(rng, nbx, nby, k_ep, k_sel, coherence)
+    fe = RefFrontend(blocks, max(k_ep, 1), max(k_sel, 1), level, perceptual)   # init only: the state is written directly
+    fe.set_state(ep, sel, be_idx, bs_idx)
+    arrays = _arrays(fe, blocks)
+    n = nbx * nby
+    slices = [(0, nbx, nby)] if (seed % 3 or nby < 2) else [(0, nbx, nby // 2), (nbx * (nby // 2), nbx, nby - nby // 2)]
+    be = Etc1sBackend.from_arrays(slices=slices, perceptual=perceptual, endpoint_rdo_thresh=ept, selector_rdo_thresh=selt, compression_level=level, **arrays)
+    total = be.encode()
+    ref_total, _ = fe.backend_run(slices, ept, selt)
+    assert total == ref_total, (nbx, nby, k_ep, k_sel, coherence, level, ept, selt)
+    _compare(fe, be, len(slices))
+    be.close(); fe.close()
