@@ -14,7 +14,7 @@ _vp = C.c_void_p
 
 
 class BackendParams(C.Structure):
-    _fields_ = [("endpoint_rdo_quality_thresh", C.c_float), ("selector_rdo_quality_thresh", C.c_float), ("compression_level", C.c_uint32)]
+    _fields_ = [("endpoint_rdo_quality_thresh", C.c_float), ("selector_rdo_quality_thresh", C.c_float), ("compression_level", C.c_uint32), ("video", C.c_uint32)]
 
 
 class SliceDesc(C.Structure):
@@ -84,7 +84,8 @@ def slice_descs(slices):
         first, nbx, nby = s[:3]
         ow, oh = (s[3], s[4]) if len(s) >= 5 else (nbx * 4, nby * 4)
         image, mip, alpha = (s[5], s[6], s[7]) if len(s) >= 8 else (i, 0, 0)
-        arr[i] = SliceDesc(first, ow, oh, nbx * 4, nby * 4, nbx, nby, image, mip, int(alpha), 0)
+        iframe = s[8] if len(s) >= 9 else 0
+        arr[i] = SliceDesc(first, ow, oh, nbx * 4, nby * 4, nbx, nby, image, mip, int(alpha), int(iframe))
     return arr
 
 
@@ -135,10 +136,10 @@ class Etc1sBackend:
         self._keep = []
 
     @classmethod
-    def from_frontend(cls, frontend, slices, endpoint_rdo_thresh=1.5, selector_rdo_thresh=1.25, compression_level=1):
+    def from_frontend(cls, frontend, slices, endpoint_rdo_thresh=1.5, selector_rdo_thresh=1.25, compression_level=1, video=False):
         """frontend: a compressed basis_universal_amd.etc1s.Etc1sFrontend (kept alive by this object)."""
         b = cls()
-        prm = BackendParams(endpoint_rdo_thresh, selector_rdo_thresh, compression_level)
+        prm = BackendParams(endpoint_rdo_thresh, selector_rdo_thresh, compression_level, int(video))
         sl = slice_descs(slices)
         b._keep = [frontend]
         if not b.L.bu_backend_init(b.h, frontend.h, C.byref(prm), sl, len(slices)):
@@ -147,7 +148,7 @@ class Etc1sBackend:
 
     @classmethod
     def from_arrays(cls, source_blocks, output_blocks, block_endpoint_index, block_selector_index, endpoint_color5_inten, selector_blocks, slices,
-                    perceptual=True, endpoint_rdo_thresh=1.5, selector_rdo_thresh=1.25, compression_level=1):
+                    perceptual=True, endpoint_rdo_thresh=1.5, selector_rdo_thresh=1.25, compression_level=1, video=False):
         b = cls()
         src = np.ascontiguousarray(source_blocks, np.uint8)
         out = np.ascontiguousarray(output_blocks, np.uint8)
@@ -158,7 +159,7 @@ class Etc1sBackend:
         b._keep = [src, out, ei, si, ep, sb]
         p = lambda a: a.ctypes.data_as(_vp)
         arrays = BackendArrays(ei.size, int(perceptual), p(src), p(out), p(ei), p(si), ep.shape[0], p(ep), sb.shape[0], p(sb))
-        prm = BackendParams(endpoint_rdo_thresh, selector_rdo_thresh, compression_level)
+        prm = BackendParams(endpoint_rdo_thresh, selector_rdo_thresh, compression_level, int(video))
         sl = slice_descs(slices)
         if not b.L.bu_backend_init_arrays(b.h, C.byref(arrays), C.byref(prm), sl, len(slices)):
             raise BackendError("bu_backend_init_arrays failed")

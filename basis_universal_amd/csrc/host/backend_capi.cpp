@@ -29,6 +29,7 @@ void convert(const bu_backend_params* p, const bu_backend_slice_desc* s, uint32_
     bp.m_endpoint_rdo_quality_thresh = p->endpoint_rdo_quality_thresh;
     bp.m_selector_rdo_quality_thresh = p->selector_rdo_quality_thresh;
     bp.m_compression_level = p->compression_level;
+    bp.m_video = p->video != 0;
     slices.resize(n);
     for (uint32_t i = 0; i < n; i++) {
         bu::backend_slice_desc& d = slices[i];
@@ -59,6 +60,7 @@ void bu_backend_default_params(int quality_level, uint32_t compression_level, bu
     out->endpoint_rdo_quality_thresh = 1.5f * scale;
     out->selector_rdo_quality_thresh = 1.25f * scale;
     out->compression_level = compression_level;
+    out->video = 0;
 }
 
 bu_backend* bu_backend_create(void) { return new (std::nothrow) bu_backend(); }
@@ -153,7 +155,7 @@ uint64_t bu_backend_write_ktx2_file(bu_backend* b, uint32_t tex_type, int has_al
 uint64_t bu_write_ktx2_file_uastc(const uint8_t* blocks16, uint64_t total_blocks, const bu_backend_slice_desc* s, uint32_t n, int srgb, uint32_t tex_type, int has_alpha,
                                   const bu_basis_key_value* kvs, uint32_t n_kvs, void* buf, uint64_t cap) {
     if (!blocks16 || !s || !n || (!kvs && n_kvs)) return 0;
-    bu_backend_params unused = {0, 0, 0};
+    bu_backend_params unused = {0, 0, 0, 0};
     bu::backend_params bp;
     std::vector<bu::backend_slice_desc> slices;
     convert(&unused, s, n, bp, slices);
@@ -166,7 +168,7 @@ uint64_t bu_write_basis_file_uastc(const uint8_t* blocks16, uint64_t total_block
                                    uint32_t userdata0, uint32_t userdata1, int y_flipped, uint32_t us_per_frame, const bu_basis_key_value* kvs, uint32_t n_kvs,
                                    void* buf, uint64_t cap) {
     if (!blocks16 || !s || !n || (!kvs && n_kvs)) return 0;
-    bu_backend_params unused = {0, 0, 0};
+    bu_backend_params unused = {0, 0, 0, 0};
     bu::backend_params bp;
     std::vector<bu::backend_slice_desc> slices;
     convert(&unused, s, n, bp, slices);

@@ -266,6 +266,7 @@ std::vector<uint8_t> write_ktx2_file(const backend_output& out, uint32_t tex_typ
         put_to(sgd, out.m_num_endpoints, 2); put_to(sgd, out.m_num_selectors, 2);
         put_to(sgd, out.m_endpoint_palette.size(), 4); put_to(sgd, out.m_selector_palette.size(), 4); put_to(sgd, out.m_slice_image_tables.size(), 4); put_to(sgd, 0, 4);
         struct image_record { uint32_t flags = 0, rgb_ofs = 0, rgb_len = 0, alpha_ofs = 0, alpha_len = 0; };
+        const bool video = tex_type == 3;  // cBASISTexTypeVideoFrames: frames that are not i-frames are flagged KTX2_IMAGE_IS_P_FRAME (comp.cpp:5144)
         std::vector<image_record> images((size_t)levels * layers * faces);
         for (size_t i = 0; i < n_slices; i++) {
             const backend_slice_desc& s = out.m_slice_desc[i];
@@ -274,7 +275,7 @@ std::vector<uint8_t> write_ktx2_file(const backend_output& out, uint32_t tex_typ
             const size_t at = (size_t)s.m_mip_index * layers * faces + (size_t)layer * faces + face;
             if (at >= images.size()) return {};
             if (s.m_alpha) { images[at].alpha_len = (uint32_t)out.m_slice_image_data[i].size(); images[at].alpha_ofs = (uint32_t)offset_in_level[i]; }
-            else { images[at].rgb_len = (uint32_t)out.m_slice_image_data[i].size(); images[at].rgb_ofs = (uint32_t)offset_in_level[i]; }
+            else { images[at].rgb_len = (uint32_t)out.m_slice_image_data[i].size(); images[at].rgb_ofs = (uint32_t)offset_in_level[i]; if (video && !s.m_iframe) images[at].flags = 2; }
         }
         for (const image_record& r : images) { put_to(sgd, r.flags, 4); put_to(sgd, r.rgb_ofs, 4); put_to(sgd, r.rgb_len, 4); put_to(sgd, r.alpha_ofs, 4); put_to(sgd, r.alpha_len, 4); }
         sgd.insert(sgd.end(), out.m_endpoint_palette.begin(), out.m_endpoint_palette.end());
@@ -523,6 +524,18 @@ void etc1s_backend::create_selector_palette() {  // backend.cpp:96-118
     }
 }
 
+// backend.cpp:310-330: the slice holding the same mip level of the frame `delta` away
+int etc1s_backend::find_video_frame(size_t slice, int delta) const {
+    const backend_slice_desc& c = m_slices[slice];
+    for (size_t s = 0; s < m_slices.size(); s++) {
+        const backend_slice_desc& o = m_slices[s];
+        if ((int)o.m_source_file_index == (int)c.m_source_file_index + delta && o.m_mip_index == c.m_mip_index && o.m_num_blocks_x == c.m_num_blocks_x &&
+            o.m_num_blocks_y == c.m_num_blocks_y && o.m_alpha == c.m_alpha)
+            return (int)s;
+    }
+    return -1;
+}
+
 // What both walks need of a block without knowing anything about the walk: the error of the frontend's block as it stands (the
 // reference's cur_err in backend.cpp:507 and :841), its selectors, and -- speculatively -- its error under the endpoints its three causal
 // neighbours had in the frontend (what backend.cpp:520-574 evaluates when those neighbours keep their endpoints, which most do). Stateless,
@@ -589,9 +602,13 @@ bool etc1s_backend::create_encoder_blocks() {
     if (thresh > 0.0f) precompute_block_errors(true);
     struct slice_result { std::vector<uint32_t> unpredicted; uint32_t remapped = 0; const char* error = nullptr; };
     std::vector<slice_result> results(m_slices.size());
-    for_each_slice(m_slices, [&](size_t si) {
+    const bool video = m_params.m_video;
+    const uint32_t spatial_preds = video ? 2u : 3u;   // in video files predictor 2 means "same as the previous frame", not the upper-left neighbour
+    m_cr_target.assign(video ? total : 0, 0);
+    auto walk_slice = [&](size_t si) {
         const backend_slice_desc& s = m_slices[si];
         const uint32_t nbx = s.m_num_blocks_x, nby = s.m_num_blocks_y;
+        const int prev_frame = video && !s.m_iframe ? find_video_frame(si, -1) : -1;
         std::vector<uint32_t>& all_endpoint_indices = results[si].unpredicted;
         uint32_t& remapped = results[si].remapped;
         all_endpoint_indices.reserve((size_t)nbx * nby);
@@ -608,10 +625,14 @@ bool etc1s_backend::create_encoder_blocks() {
                 uint32_t best_pred = UINT32_MAX;
                 for (uint32_t p = 0; p < kNumEndpointPreds; p++) {
                     const int px = (int)bx + kPredDx[p], py = (int)by + kPredDy[p];
-                    present[p] = px >= 0 && py >= 0;  // dx, dy <= 0: the far edges cannot be crossed
+                    present[p] = p < spatial_preds && px >= 0 && py >= 0;  // dx, dy <= 0: the far edges cannot be crossed
                     if (!present[p]) continue;
                     neighbour[p] = m_blocks[s.m_first_block_index + (uint32_t)px + (uint32_t)py * nbx].endpoint_index;
                     if (neighbour[p] == m.endpoint_index && best_pred == UINT32_MAX) best_pred = p;
+                }
+                if (prev_frame >= 0) {   // conditional replenishment wins over the spatial predictors (backend.cpp:457-471)
+                    const uint32_t pb = m_slices[prev_frame].m_first_block_index + bx + by * nbx;
+                    if (m_blocks[pb].endpoint_index == m.endpoint_index && m_blocks[pb].selector_index == m.selector_index) { best_pred = 2; m_cr_target[pb] = 1; }
                 }
                 if (best_pred != UINT32_MAX) {
                     m.endpoint_predictor = (uint8_t)best_pred;
@@ -643,7 +664,9 @@ bool etc1s_backend::create_encoder_blocks() {
                 }
                 if (m.endpoint_predictor == kNoEndpointPred) all_endpoint_indices.push_back(m.endpoint_index);
             }
-    });
+    };
+    if (video) { for (size_t si = 0; si < m_slices.size(); si++) walk_slice(si); }   // a frame reads the finished blocks of the frame before it
+    else for_each_slice(m_slices, walk_slice);
     uint32_t remapped = 0;
     std::vector<uint32_t> all_endpoint_indices;  // the unpredicted endpoint indices in coding order: what the palette ordering works from
     all_endpoint_indices.reserve(total);
@@ -766,6 +789,7 @@ bool etc1s_backend::encode_image() {
     const float selector_thresh = std::max(1.0f, m_params.m_selector_rdo_quality_thresh);
     const float endpoint_thresh = std::max(1.0f, m_params.m_endpoint_rdo_quality_thresh);
     const int max_search = level >= 2 ? 64 : 16;  // backend.cpp:852
+    const bool video = m_params.m_video;
     // the endpoint search walks a window of consecutive NEW indices (wrapping once at either end, backend.cpp:865-869): the palette in
     // that order as byte arrays, extended by the largest half-window on both sides so that a window is one contiguous read
     const uint32_t kPad = 64;
@@ -801,7 +825,8 @@ bool etc1s_backend::encode_image() {
         for (uint32_t by = 0; by < nby; by++)
             for (uint32_t bx = 0; bx < nbx; bx++) {
                 const uint32_t p = m_blocks[base + bx + by * nbx].endpoint_predictor;
-                if (p < kNumEndpointPreds) referenced[(bx + kPredDx[p]) + (size_t)(by + kPredDy[p]) * nbx] = 1;
+                if (p < (video ? 2u : 3u)) referenced[(bx + kPredDx[p]) + (size_t)(by + kPredDy[p]) * nbx] = 1;
+                if (video && m_cr_target[base + bx + by * nbx]) referenced[bx + (size_t)by * nbx] = 1;
             }
         // the symbols of a block, by producer; a run's symbol sits on the block that opens the run (placeholders patched when it closes)
         std::vector<token> pred_tok(n, token{0, T_NONE}), delta_tok(n, token{0, T_NONE}), sel_tok(n, token{0, T_NONE});
@@ -945,9 +970,15 @@ bool etc1s_backend::encode_image() {
                 const uint32_t b = base + i;
                 encoder_block& m = m_blocks[b];
                 // ---- a recently used pattern (history buffer) that is good enough, else the block's own (backend.cpp:1011-1205)
+                if (video && m.endpoint_predictor == 2) {   // repeats the previous frame's block: no selector symbol at all (backend.cpp:1011)
+                    block_selector_indices[b] = m.selector_index;
+                    if (((i + 1) % kPublishEvery) == 0) done3.store(i + 1, std::memory_order_release);
+                    continue;
+                }
+                const bool cr_target = video && m_cr_target[b];   // its selectors are what the next frame repeats: not to be traded (backend.cpp:1020, 1036)
                 int new_selector = (int)m_selector_old_to_new[m.selector_index];
-                int history_index = level <= 1 ? metric::find_first_64(history.v, new_selector) : -1;
-                if (history_index == -1) {
+                int history_index = (cr_target || level <= 1) ? metric::find_first_64(history.v, new_selector) : -1;
+                if (history_index == -1 && !cr_target) {
                     const table_slot& slot = slots[i % ring];
                     const uint64_t limit_err = (uint64_t)ceilf(slot.cur_err * selector_thresh);
                     const metric::scan_result best = K.scan_history(slot.table, m_selector_bytes[m.selector_index], history.sel, level <= 1 ? kSelDiffThreshold : 0, limit_err);

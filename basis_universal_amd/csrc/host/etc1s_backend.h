@@ -8,7 +8,8 @@
 // neighbours, the selector history buffer, run lengths), so it is host code like the reference's; what is different is how the
 // walk spends its time (etc1s_backend.cpp).
 //
-// Not supported: video textures (cBASISTexTypeVideoFrames: conditional-replenishment predictors) and global codebooks.
+// Not supported: global codebooks. Video textures (conditional replenishment: a block that repeats the block at its place in the previous
+// frame) are coded like the reference does; the frontend's video-specific iteration order (frontend.cpp:219-223, 291) is not built.
 #pragma once
 #include <cstdint>
 #include <functional>
@@ -28,6 +29,7 @@ struct backend_params {                    // = basisu_backend_params (backend.h
     float m_selector_rdo_quality_thresh = 0.0f;
     uint32_t m_compression_level = 0;
     bool m_used_global_codebooks = false;  // must stay false
+    bool m_video = false;                  // = frontend params' m_tex_type == cBASISTexTypeVideoFrames: slices are frames, blocks may repeat the previous frame's
     bool m_validate = true;
 };
 
@@ -117,6 +119,7 @@ private:
     void sort_selector_codebook();
     void compute_slice_crcs();
     void precompute_block_errors(bool with_neighbours);
+    int find_video_frame(size_t slice, int delta) const;
 
     etc1s_frontend* m_frontend = nullptr;
     backend_source m_src;
@@ -132,6 +135,7 @@ private:
     std::vector<metric::pal_colors> m_palette_colors;  // the block colours of every endpoint palette entry in the metric's basis
     std::vector<metric::sel16> m_selector_bytes;       // every selector pattern, one selector per byte
     std::vector<encoder_block> m_blocks;
+    std::vector<uint8_t> m_cr_target;        // video: the next frame repeats this block, so its indices must not change any more
     // stateless per-block quantities both walks need, computed by all host threads up front (precompute_block_errors)
     std::vector<uint64_t> m_own_err;         // error of the frontend's output block under its own colours and selectors
     std::vector<uint32_t> m_own_sels;        // its selectors, packed

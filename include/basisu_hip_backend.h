@@ -3,7 +3,7 @@
  * the compressed payloads of a .basis / KTX2 file out (endpoint palette, selector palette, slice Huffman tables, one bit stream
  * per slice, slice CRCs), byte-identical to basisu_backend::encode() (basisu_backend.cpp:1747-1776). Host code, lives in
  * libbasisu_frontend.so. All int-returning functions: 1 = success, 0 = failure (see bu_backend_error).
- * Not supported: video textures, global codebooks.
+ * Not supported: global codebooks.
  */
 #ifndef BASISU_HIP_BACKEND_H
 #define BASISU_HIP_BACKEND_H
@@ -19,6 +19,7 @@ typedef struct bu_backend_params {          /* = basisu_backend_params, backend.
     float endpoint_rdo_quality_thresh;      /* basis_compressor default 1.5 (comp.h: m_endpoint_rdo_thresh)  */
     float selector_rdo_quality_thresh;      /* basis_compressor default 1.25 (comp.h: m_selector_rdo_thresh) */
     uint32_t compression_level;             /* the frontend's compression level */
+    uint32_t video;                         /* 1: cBASISTexTypeVideoFrames -- slices are frames (iframe flag per slice), conditional replenishment is used */
 } bu_backend_params;
 
 typedef struct bu_backend_slice_desc {      /* = basisu_backend_slice_desc, backend.h:185-214 (the fields the ETC1S backend reads) */

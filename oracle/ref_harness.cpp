@@ -374,6 +374,13 @@ REF_API uint32_t ref_backend_encode(void* hv, uint32_t num_blocks_x, uint32_t nu
 // basisu_backend::encode() on a finished frontend with any number of slices (slices = n x {first_block_index, num_blocks_x, num_blocks_y});
 // the backend stays alive in the handle so that ref_backend_get can serialise its output (basisu_backend_output, backend.h:218-276) and
 // its per-block state. At compression levels above 1 this MODIFIES the frontend (reoptimize_remapped_endpoints), as the reference does.
+// The texture type the frontend (and through it the backend) works under; call before the stages run. 3 = cBASISTexTypeVideoFrames.
+REF_API void ref_frontend_set_tex_type(void* hv, uint32_t tex_type) {
+	frontend_handle* h = static_cast<frontend_handle*>(hv);
+	h->p.m_tex_type = (basist::basis_texture_type)tex_type;
+	h->fe.m_params.m_tex_type = (basist::basis_texture_type)tex_type;
+}
+
 REF_API uint32_t ref_backend_run(void* hv, const uint32_t* slices3, uint32_t n_slices, float endpoint_rdo_thresh, float selector_rdo_thresh, double* seconds) {
 	frontend_handle* h = static_cast<frontend_handle*>(hv);
 	h->be.reset(new basisu_backend());
@@ -393,7 +400,8 @@ REF_API uint32_t ref_backend_run(void* hv, const uint32_t* slices3, uint32_t n_s
 		slices[i].m_num_macroblocks_x = (nbx + 1) / 2;
 		slices[i].m_num_macroblocks_y = (nby + 1) / 2;
 		slices[i].m_source_file_index = i;
-		slices[i].m_iframe = false;  // as basis_compressor sets it for everything but video (comp.cpp:3016-3030)
+		// as basis_compressor sets it: only video has i-frames, and for ETC1S only the first frame is one (comp.cpp:3016-3030)
+		slices[i].m_iframe = (h->fe.m_params.m_tex_type == basist::cBASISTexTypeVideoFrames) && (i == 0);
 	}
 	h->be->init(&h->fe, bp, slices);
 	interval_timer tm;

@@ -223,6 +223,12 @@ class RefFrontend:
         self.L.ref_backend_get(self.h, name.encode(), slice_index, buf.ctypes.data_as(C.c_void_p), need)
         return buf.view(dtype)
 
+    def set_tex_type(self, tex_type):
+        """basist::basis_texture_type of the frontend params (3 = video frames); before compress."""
+        self.L.ref_frontend_set_tex_type.restype = None
+        self.L.ref_frontend_set_tex_type.argtypes = [C.c_void_p, C.c_uint32]
+        self.L.ref_frontend_set_tex_type(self.h, tex_type)
+
     def set_state(self, color5_inten, selectors16, block_endpoint, block_selector):
         """Overwrite the finished frontend state with arbitrary codebooks / assignments (backend fuzzing)."""
         f = self.L.ref_frontend_set_state

@@ -526,3 +526,36 @@ def test_backend_fuzzed_states_match_reference(seed):
     assert total == ref_total, (nbx, nby, k_ep, k_sel, coherence, level, ept, selt)
     _compare(fe, be, len(slices))
     be.close(); fe.close()
+
+
+@pytest.mark.parametrize("frames,level,ept,selt", [(3, 1, 1.5, 1.25), (4, 0, 1.5, 1.25), (2, 1, 0.0, 0.0), (3, 1, 3.0, 2.0)])
+def test_backend_video_frames_match_reference(frames, level, ept, selt):
+    """cBASISTexTypeVideoFrames: slices are frames of one clip; a block that has the endpoints and selectors of the block at its place in the
+    previous frame is coded as "repeat" (conditional replenishment), which also pins the repeated block's indices (backend.cpp:332-404,
+    457-471, 759-763, 1011-1036). The reference frontend runs in video mode, its final state feeds both backends."""
+    from basis_universal_amd.backend import Etc1sBackend
+    w, h = 128, 96
+    base = synth(w, h, 300)
+    clip = []
+    for f in range(frames):   # a static background with a patch that moves and changes
+        img = base.copy()
+        x0 = 8 + 12 * f
+        img[24:56, x0:x0 + 40] = synth(40, 32, 310 + f)
+        clip.append(img)
+    blocks = np.concatenate([to_pixel_blocks(i) for i in clip])
+    nbx, nby = w // 4, h // 4
+    slices = [(f * nbx * nby, nbx, nby, w, h, f, 0, 0, int(f == 0)) for f in range(frames)]
+    fe = RefFrontend(blocks, 300, 300, level, True)
+    fe.set_tex_type(3)
+    fe.call("compress")
+    be = Etc1sBackend.from_arrays(slices=slices, endpoint_rdo_thresh=ept, selector_rdo_thresh=selt, compression_level=level, video=True, **_arrays(fe, blocks))
+    total = be.encode()
+    ref_total, _ = fe.backend_run([s[:3] for s in slices], ept, selt)
+    assert total == ref_total
+    _compare(fe, be, frames)
+    preds = be.get("encoder_blocks", 0, np.uint32).reshape(-1, 4)[:, 1]
+    assert (preds[nbx * nby:] == 2).sum() > nbx * nby // 4, "the clip should make the backend repeat many blocks"
+    for v in (dict(tex_type=3, us_per_frame=33333), dict(tex_type=3, us_per_frame=33333, key_values=[("k", b"v")])):
+        a, b = be.basis_file(**v), fe.basis_file(**v)
+        assert a.shape == b.shape and (a == b).all()
+    be.close(); fe.close()
