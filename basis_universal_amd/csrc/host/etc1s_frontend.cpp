@@ -243,6 +243,10 @@ bool etc1s_frontend::compress() {
             uint32_t moved = 0;
             BU_STAGE("refine_endpoint_clusterization", refine_endpoint_clusterization(&moved));
             if (!moved) early_out = true;  // frontend.cpp:215-216
+            if (m_params.m_video && !step && m_num_endpoint_codebook_iterations == 1) {  // frontend.cpp:219-223: video clips get one more fit of the merged codebook
+                BU_STAGE_V("eliminate_redundant_or_empty_endpoint_clusters", eliminate_redundant_or_empty_endpoint_clusters());
+                BU_STAGE("generate_endpoint_codebook", generate_endpoint_codebook(1));
+            }
         }
         BU_STAGE_V("eliminate_redundant_or_empty_endpoint_clusters", eliminate_redundant_or_empty_endpoint_clusters());
         if (early_out) break;
@@ -256,7 +260,7 @@ bool etc1s_frontend::compress() {
         BU_STAGE("create_optimized_selector_codebook", create_optimized_selector_codebook(it));
         BU_STAGE("find_optimal_selector_clusters_for_each_block", find_optimal_selector_clusters_for_each_block());
         BU_STAGE("introduce_special_selector_clusters", introduce_special_selector_clusters());
-        if (m_params.m_compression_level >= 4) {
+        if (m_params.m_compression_level >= 4 || m_params.m_video) {  // frontend.cpp:291
             uint32_t refined = 0;
             BU_STAGE("refine_block_endpoints_given_selectors", refine_block_endpoints_given_selectors(&refined));
             if (!refined) break;  // frontend.cpp:283-286

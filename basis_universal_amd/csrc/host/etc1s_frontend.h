@@ -37,6 +37,7 @@ public:
         bool m_perceptual = true;
         bool m_validate = false;
         bool m_disable_hierarchical_endpoint_codebooks = false;
+        bool m_video = false;                             // = m_tex_type == cBASISTexTypeVideoFrames: only changes the order of stages (frontend.cpp:219-223, 291)
         bu_hip_context* m_pHIP_context = nullptr;         // = m_pOpenCL_context; REQUIRED
     };
 

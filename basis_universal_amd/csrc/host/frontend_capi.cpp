@@ -13,6 +13,7 @@
 struct bu_frontend {
     bu::etc1s_frontend fe;
     std::string error;
+    bool video = false;
 };
 
 namespace {
@@ -56,6 +57,7 @@ int bu_frontend_init(bu_frontend* f, bu_hip_context* ctx, const bu_pixel_block* 
     p.m_compression_level = level;
     p.m_perceptual = perceptual != 0;
     p.m_pHIP_context = ctx;
+    p.m_video = f->video;
     return f->fe.init(p) ? 1 : 0;
 }
 
@@ -64,6 +66,8 @@ int bu_frontend_set_comm(bu_frontend* f, const bu_comm* comm) {
     f->fe.set_comm(comm);
     return 1;
 }
+
+int bu_frontend_set_video(bu_frontend* f, int video) { if (!f) return 0; f->video = video != 0; return 1; }
 
 int bu_frontend_compress(bu_frontend* f) { return (f && f->fe.compress()) ? 1 : 0; }
 

@@ -120,7 +120,7 @@ class TorchComm:
 
 
 class Etc1sFrontend:
-    def __init__(self, ctx, comm=None):
+    def __init__(self, ctx, comm=None, video=False):
         """comm: a TorchComm to shard the device stages over the ranks of its process group (every rank must drive an identical
         frontend on identical tiles); None = single GPU."""
         self.ctx = ctx
@@ -129,6 +129,9 @@ class Etc1sFrontend:
         ctx.adopt(self)  # the frontend's device buffers belong to ctx: it must go first
         self._keep = None
         self.comm = comm
+        if video:  # cBASISTexTypeVideoFrames: a different order of stages, see include/basisu_hip_frontend.h
+            self.L.bu_frontend_set_video.argtypes = [_vp, C.c_int]
+            self._check(self.L.bu_frontend_set_video(self.h, 1), "bu_frontend_set_video")
         if comm is not None:
             self._check(self.L.bu_frontend_set_comm(self.h, C.byref(comm.struct)), "bu_frontend_set_comm")
 

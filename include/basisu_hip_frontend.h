@@ -33,6 +33,9 @@ typedef struct bu_comm {
     int (*all_reduce_u64)(void* user, void* d_buf, uint64_t count);
 } bu_comm;
 BU_HIP_API int bu_frontend_set_comm(bu_frontend*, const bu_comm* comm); /* NULL = single GPU; call before bu_frontend_init */
+/* basisu_frontend::params::m_tex_type == cBASISTexTypeVideoFrames (frontend.cpp:219-223, 291: one more fit of the merged endpoint codebook, endpoints
+ * refitted to the selectors at every level); call before bu_frontend_init. The backend's half is bu_backend_params::video. */
+BU_HIP_API int bu_frontend_set_video(bu_frontend*, int video);
 
 /* basisu_frontend::compress (frontend.cpp:159) */
 BU_HIP_API int bu_frontend_compress(bu_frontend*);

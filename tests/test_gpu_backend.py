@@ -176,3 +176,38 @@ def test_compress_matches_reference_command_line(hip_ctx, tmp_path, name, kw, cl
     cli = run_ref_cli(tmp_path / "x.png", *cli_args, ktx2=ktx2)
     mine = compress(hip_ctx, img, key_values=(ktx2_file_key_values if ktx2 else basis_file_key_values)(cli), **kw)
     assert mine.shape == cli.shape and (mine == cli).all(), name
+
+
+@needs_ref
+@pytest.mark.xfail(strict=False, reason="the frontend's video-mode stage order was added after round 1's GPU budget was spent (the stages themselves are covered "
+                                        "at levels 4-6); the backend's video coding is pinned on the CPU (tests/test_backend_host.py)")
+@pytest.mark.parametrize("level", [1, 2])
+def test_video_clip_matches_reference(hip_ctx, level):
+    """cBASISTexTypeVideoFrames end to end: resident frontend in video mode + backend with conditional replenishment vs the reference pair."""
+    from basis_universal_amd.etc1s import Etc1sFrontend
+    from basis_universal_amd.backend import Etc1sBackend
+    w, h, frames = 128, 96, 3
+    base = synth(w, h, 300)
+    clip = []
+    for f in range(frames):
+        img = base.copy()
+        img[24:56, 8 + 12 * f:48 + 12 * f] = synth(40, 32, 310 + f)
+        clip.append(img)
+    blocks = np.concatenate([to_pixel_blocks(i) for i in clip])
+    nbx, nby = w // 4, h // 4
+    slices = [(f * nbx * nby, nbx, nby, w, h, f, 0, 0, int(f == 0)) for f in range(frames)]
+    fe = Etc1sFrontend(hip_ctx, video=True)
+    fe.init(blocks, 300, 300, level, True)
+    fe.compress()
+    be = Etc1sBackend.from_frontend(fe, slices, 1.5, 1.25, level, video=True)
+    total = be.encode()
+    ref = RefFrontend(blocks, 300, 300, level, True)
+    ref.set_tex_type(3)
+    ref.call("compress")
+    assert total == ref.backend_run([s[:3] for s in slices], 1.5, 1.25)[0]
+    for k in OUTPUTS:
+        a, b = be.get(k), ref.backend_get(k)
+        assert a.shape == b.shape and (a == b).all(), k
+    for s in range(frames):
+        assert (be.get("slice_image_data", s) == ref.backend_get("slice_image_data", s)).all()
+    be.close(); fe.close(); ref.close()
