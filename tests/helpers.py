@@ -473,15 +473,19 @@ def have_ref_cli():
 
 
 def run_ref_cli(png_path, *args, ktx2=False):
-    """The reference command line tool (oracle/_ref/basisu, built from /root/reference) on one PNG -> the bytes of the .basis (or .ktx2) it writes."""
+    """The reference command line tool (oracle/_ref/basisu, built from /root/reference) on one PNG (or a list of PNGs: array layers, cubemap
+    faces, video frames of ONE output file) -> the bytes of the .basis (or .ktx2) it writes."""
     import subprocess, tempfile, shutil
+    paths = list(png_path) if isinstance(png_path, (list, tuple)) else [png_path]
     with tempfile.TemporaryDirectory() as d:
-        src = pathlib.Path(d) / "in.png"
-        shutil.copy(png_path, src)
-        out = pathlib.Path(d) / ("in.ktx2" if ktx2 else "in.basis")
-        r = subprocess.run([str(ORACLE_DIR / "_ref" / "basisu"), "-ktx2" if ktx2 else "-basis", "-no_multithreading", *args, "in.png"], cwd=d, capture_output=True, text=True, timeout=600)
-        assert r.returncode == 0 and out.exists(), r.stdout[-2000:] + r.stderr[-2000:]
-        return np.fromfile(out, np.uint8)
+        names = []
+        for i, p in enumerate(paths):
+            names.append("in.png" if len(paths) == 1 else f"in{i}.png")
+            shutil.copy(p, pathlib.Path(d) / names[-1])
+        r = subprocess.run([str(ORACLE_DIR / "_ref" / "basisu"), "-ktx2" if ktx2 else "-basis", "-no_multithreading", *args, *names], cwd=d, capture_output=True, text=True, timeout=600)
+        outs = sorted(pathlib.Path(d).glob("*.ktx2" if ktx2 else "*.basis"))
+        assert r.returncode == 0 and len(outs) == 1, r.stdout[-2000:] + r.stderr[-2000:]
+        return np.fromfile(outs[0], np.uint8)
 
 
 def ktx2_file_key_values(data):

@@ -559,3 +559,42 @@ def test_backend_video_frames_match_reference(frames, level, ept, selt):
         a, b = be.basis_file(**v), fe.basis_file(**v)
         assert a.shape == b.shape and (a == b).all()
     be.close(); fe.close()
+
+
+@pytest.mark.skipif(not have_ref_cli(), reason="oracle/_ref/basisu not present")
+@pytest.mark.parametrize("kind,count,tex_type", [("2darray", 3, 1), ("cubemap", 6, 2), ("video", 3, 3)])
+def test_multi_image_files_match_reference_command_line(tmp_path, kind, count, tex_type):
+    """Several source images in one file: array layers, cubemap faces (KTX2 face index), video frames (conditional replenishment, P-frame flags,
+    microseconds per frame) -- `basisu -tex_type <kind> a.png b.png ...` against (reference frontend ->) our backend -> both writers."""
+    import struct
+    from basis_universal_amd.backend import Etc1sBackend, default_params
+    from basis_universal_amd.etc1s import quality_to_clusters
+    w, h = 64, 64
+    base = synth(w, h, 500)
+    imgs = []
+    for i in range(count):
+        img = base.copy() if kind == "video" else synth(w, h, 500 + i)
+        if kind == "video":
+            img[16:40, 4 + 10 * i:36 + 10 * i] = synth(32, 24, 520 + i)
+        imgs.append(img)
+        save_png(tmp_path / f"f{i}.png", img)
+    files = [tmp_path / f"f{i}.png" for i in range(count)]
+    video = kind == "video"
+    blocks = np.concatenate([to_pixel_blocks(i) for i in imgs])
+    nbx, nby = w // 4, h // 4
+    slices = [(i * nbx * nby, nbx, nby, w, h, i, 0, 0, int(video and i == 0)) for i in range(count)]
+    max_ep, max_sel = quality_to_clusters(128, blocks.shape[0])
+    fe = RefFrontend(blocks, max_ep, max_sel, 1, True)
+    fe.set_tex_type(tex_type)
+    fe.call("compress")
+    ept, selt = default_params(128, 1)
+    be = Etc1sBackend.from_arrays(slices=slices, endpoint_rdo_thresh=ept, selector_rdo_thresh=selt, video=video, **_arrays(fe, blocks))
+    be.encode()
+    cli = run_ref_cli(files, "-etc1s", "-q", "128", "-tex_type", kind)
+    us_per_frame = struct.unpack_from("<I", cli[24:28].tobytes() + b"\0")[0] & 0xFFFFFF   # basis_file_header::m_us_per_frame (3 bytes at offset 24)
+    mine = be.basis_file(tex_type=tex_type, us_per_frame=us_per_frame, key_values=basis_file_key_values(cli))
+    assert mine.shape == cli.shape and (mine == cli).all()
+    cli2 = run_ref_cli(files, "-etc1s", "-q", "128", "-tex_type", kind, ktx2=True)
+    mine2 = be.ktx2_file(tex_type=tex_type, key_values=ktx2_file_key_values(cli2))
+    assert mine2.shape == cli2.shape and (mine2 == cli2).all()
+    be.close(); fe.close()
