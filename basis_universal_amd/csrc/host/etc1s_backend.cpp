@@ -124,6 +124,27 @@ template <class F> void for_each_slice(const std::vector<backend_slice_desc>& sl
 inline uint32_t nearest_pattern_plain(const uint32_t* p, uint32_t n, uint32_t to) { BU_NEAREST_BODY(__builtin_popcount) }
 __attribute__((target("popcnt"))) inline uint32_t nearest_pattern_popcnt(const uint32_t* p, uint32_t n, uint32_t to) { BU_NEAREST_BODY(__builtin_popcount) }
 #undef BU_NEAREST_BODY
+// eight patterns per step: bit counts from a nibble table, and the scalar rule re-run on a group only when one of its members can improve the best
+__attribute__((target("avx2"))) inline uint32_t nearest_pattern_avx2(const uint32_t* p, uint32_t n, uint32_t to) {
+    const __m256i nib = _mm256_setr_epi8(0, 1, 1, 2, 1, 2, 2, 3, 1, 2, 2, 3, 2, 3, 3, 4, 0, 1, 1, 2, 1, 2, 2, 3, 1, 2, 2, 3, 2, 3, 3, 4);
+    const __m256i low = _mm256_set1_epi8(15), key = _mm256_set1_epi32((int)to), ones8 = _mm256_set1_epi8(1), ones16 = _mm256_set1_epi16(1);
+    uint32_t best = 100, best_j = 0, j = 0;
+    for (; j + 8 <= n; j += 8) {
+        const __m256i x = _mm256_xor_si256(_mm256_loadu_si256((const __m256i*)(p + j)), key);
+        const __m256i cnt = _mm256_add_epi8(_mm256_shuffle_epi8(nib, _mm256_and_si256(x, low)), _mm256_shuffle_epi8(nib, _mm256_and_si256(_mm256_srli_epi16(x, 4), low)));
+        const __m256i d = _mm256_madd_epi16(_mm256_maddubs_epi16(cnt, ones8), ones16);   // per 32-bit lane
+        if (!_mm256_movemask_epi8(_mm256_cmpgt_epi32(_mm256_set1_epi32((int)best), d))) continue;
+        alignas(32) uint32_t dl[8];
+        _mm256_store_si256((__m256i*)dl, d);
+        for (uint32_t k = 0; k < 8; k++)
+            if (dl[k] < best) { best = dl[k]; best_j = j + k; if (best <= 1) return best_j; }
+    }
+    for (; j < n; j++) {
+        const uint32_t dd = (uint32_t)__builtin_popcount(p[j] ^ to);
+        if (dd < best) { best = dd; best_j = j; if (dd <= 1) break; }
+    }
+    return best_j;
+}
 
 // rows [0, n) of a slice over the host threads (stateless per-block work)
 template <class F> void parallel_rows(uint32_t n, uint64_t work_per_row, F fn) {
@@ -722,11 +743,11 @@ void etc1s_backend::sort_selector_codebook() {
         // `remaining` in the reference's order (swap-with-last removal), with the patterns alongside so that the scan reads memory linearly
         std::vector<uint32_t> remaining(k - 1), bits(k - 1);
         for (uint32_t i = 1; i < k; i++) { remaining[i - 1] = i; bits[i - 1] = m_selector_palette[i]; }
-        const bool hw_popcnt = __builtin_cpu_supports("popcnt");
+        const bool hw_popcnt = __builtin_cpu_supports("popcnt"), avx2 = metric::pick_kernels().isa[0] == 'a';
         uint32_t prev = 0;
         for (uint32_t i = 1; i < k; i++) {
             const uint32_t left = (uint32_t)remaining.size();
-            const uint32_t best_j = hw_popcnt ? nearest_pattern_popcnt(bits.data(), left, m_selector_palette[prev]) : nearest_pattern_plain(bits.data(), left, m_selector_palette[prev]);
+            const uint32_t best_j = avx2 ? nearest_pattern_avx2(bits.data(), left, m_selector_palette[prev]) : hw_popcnt ? nearest_pattern_popcnt(bits.data(), left, m_selector_palette[prev]) : nearest_pattern_plain(bits.data(), left, m_selector_palette[prev]);
             prev = remaining[best_j];
             m_selector_new_to_old[i] = prev;
             remaining[best_j] = remaining.back(); bits[best_j] = bits.back();
