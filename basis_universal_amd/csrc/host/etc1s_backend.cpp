@@ -1060,7 +1060,8 @@ bool etc1s_backend::encode_image() {
         if (!m_reoptimize(block_endpoint_indices, unused, false, &block_selector_indices, m_src)) return fail("reoptimize_remapped_endpoints failed");
         create_endpoint_palette();
     }
-    compute_slice_crcs();
+    // the slice CRCs only need the final indices: computed on the side while the symbols are coded
+    struct joined_thread { std::thread t; ~joined_thread() { if (t.joinable()) t.join(); } } crc_thread{std::thread([this] { compute_slice_crcs(); })};
 
     // ---- the four models, then the slices (backend.cpp:1298-1472)
     auto model = [](std::vector<uint32_t>& h, huffman_table& t) {
@@ -1079,7 +1080,8 @@ bool etc1s_backend::encode_image() {
     w.flush();
     m_output.m_slice_image_tables = w.bytes();
     m_output.m_slice_image_data.assign(m_slices.size(), std::vector<uint8_t>());
-    for (size_t si = 0; si < m_slices.size(); si++) {
+    for_each_slice(m_slices, [&](size_t si) {
+        bit_writer w;
         w.restart(slice_tokens[si].size() + 64);
         for (const token& t : slice_tokens[si]) {
             switch (t.kind) {
@@ -1099,7 +1101,7 @@ bool etc1s_backend::encode_image() {
         }
         w.flush();
         m_output.m_slice_image_data[si] = w.bytes();
-    }
+    });
     return true;
 }
 
