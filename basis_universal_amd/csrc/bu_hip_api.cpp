@@ -555,6 +555,11 @@ struct bu_tsvq {
     uint8_t* side = nullptr;
     arena nodes, outs;
     bool force_chained = false; // BU_TSVQ_CHAINED=1: never use the exact (integer-reduced) kernel variants (tests compare both)
+    // Nodes with at least wide_min members go through the many-workgroup path (tsvq_wide_kernels.hip; packed rows only).
+    // BU_TSVQ_WIDE_MIN overrides the threshold, BU_TSVQ_WIDE=0 switches the path off (tests compare both).
+    uint32_t wide_min = 0;      // 0: off
+    uint32_t wide_blocks_cap = 0, wide_nodes_cap = 0;
+    void* wide_ws = nullptr; void* wide_packed = nullptr; bu::tsvq_wide_node* wide_nodes = nullptr; bu::tsvq_wide_ctrl* wide_ctrl = nullptr;
     // Pinned staging for the per-round node / result records: hipMemcpyAsync on PAGEABLE host memory followed directly by a
     // kernel on the same stream was observed to let the kernel read the destination before the copy landed (MI355X, ROCm 7.2:
     // tools/tsvq_root_repeat.py, 2 of 10 runs), so nothing on this path hands pageable memory to an asynchronous copy.
@@ -580,7 +585,7 @@ void bu_hip_tsvq_destroy(bu_hip_context* ctx, bu_tsvq* q) {
     if (!ctx || !q) return;
     device_guard g(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    for (void* p : {q->rows, (void*)q->w64, (void*)q->perm[0], (void*)q->perm[1], (void*)q->side, q->nodes.p, q->outs.p}) if (p) bu_hip_free(ctx, p);
+    for (void* p : {q->rows, (void*)q->w64, (void*)q->perm[0], (void*)q->perm[1], (void*)q->side, q->nodes.p, q->outs.p, q->wide_ws, q->wide_packed, (void*)q->wide_nodes, (void*)q->wide_ctrl}) if (p) bu_hip_free(ctx, p);
     q->nodes.p = nullptr; q->outs.p = nullptr;
     if (q->pinned) {  // hand the pinned staging buffer back to the context (keep the larger one)
         if (q->pinned_cap > ctx->tsvq_pinned_cap) { if (ctx->tsvq_pinned) (void)hipHostFree(ctx->tsvq_pinned); ctx->tsvq_pinned = q->pinned; ctx->tsvq_pinned_cap = q->pinned_cap; }
@@ -609,6 +614,21 @@ static bu_tsvq* tsvq_create_common(bu_hip_context* ctx, uint32_t dim, bool packe
     q->nodes.p = bu_hip_malloc(ctx, rec_cap); q->outs.p = bu_hip_malloc(ctx, rec_cap);
     if (!q->rows || !q->w64 || !q->perm[0] || !q->perm[1] || !q->side || !q->nodes.p || !q->outs.p) return fail("allocation");
     q->nodes.cap = q->outs.cap = rec_cap;
+    if (packed && !q->force_chained) {
+        uint32_t wide_min = 4096;
+        if (const char* e = std::getenv("BU_TSVQ_WIDE_MIN")) { const long v = std::atol(e); if (v >= 512 && v <= (1l << 30)) wide_min = (uint32_t)v; }
+        if (const char* e = std::getenv("BU_TSVQ_WIDE")) if (std::atoi(e) == 0) wide_min = 0;
+        if (wide_min && n >= wide_min && n < (1u << 22)) {   // above 2^22 members the binade prediction loses its margin; the chained kernel takes those
+            q->wide_min = wide_min;
+            q->wide_nodes_cap = n / wide_min + 1;
+            q->wide_blocks_cap = (n + 255) / 256 + q->wide_nodes_cap;
+            q->wide_ws = bu_hip_malloc(ctx, bu::tsvq_wide_workspace_bytes(q->wide_blocks_cap));
+            q->wide_nodes = (bu::tsvq_wide_node*)bu_hip_malloc(ctx, (size_t)q->wide_nodes_cap * sizeof(bu::tsvq_wide_node));
+            q->wide_ctrl = (bu::tsvq_wide_ctrl*)bu_hip_malloc(ctx, (size_t)q->wide_nodes_cap * sizeof(bu::tsvq_wide_ctrl));
+            q->wide_packed = bu_hip_malloc(ctx, (size_t)n * 8);
+            if (!q->wide_ws || !q->wide_packed || !q->wide_nodes || !q->wide_ctrl) return fail("allocation");
+        }
+    }
     if (source_on_device) {  // stream-ordered device copies: the vectors were produced on this context's stream
         if (hipMemcpyAsync(q->rows, h_rows, (size_t)n * row_bytes, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess ||
             hipMemcpyAsync(q->w64, h_weights, (size_t)n * 8, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess)
@@ -616,17 +636,26 @@ static bu_tsvq* tsvq_create_common(bu_hip_context* ctx, uint32_t dim, bool packe
     } else if (hipStreamSynchronize(ctx->stream) != hipSuccess || hipMemcpy(q->rows, h_rows, (size_t)n * row_bytes, hipMemcpyHostToDevice) != hipSuccess ||
                hipMemcpy(q->w64, h_weights, (size_t)n * 8, hipMemcpyHostToDevice) != hipSuccess || hipDeviceSynchronize() != hipSuccess)
         return fail("upload");  // blocking copies (the sources are pageable, see bu_tsvq::pinned); the root kernel below needs both anyway
-    if (q->reserve_pinned(sizeof(bu_tsvq_root)) != hipSuccess) return fail("pinned allocation");
-    // exact (integer-reduced) variant first where it exists; a record flagged pad == 1 left the exact range -> chained variant
-    for (int attempt = 0; attempt < 2; attempt++) {
+    if (q->reserve_pinned(std::max(sizeof(bu_tsvq_root), sizeof(bu::tsvq_wide_node))) != hipSuccess) return fail("pinned allocation");
+    // many-workgroup variant first where it applies, then the exact (integer-reduced) one-workgroup variant; a record flagged
+    // pad == 1 left the exact range -> next variant, the chained one last
+    for (int attempt = q->wide_min ? -1 : 0; attempt < 2; attempt++) {
         const bool exact = packed && attempt == 0 && !q->force_chained;
-        {
+        if (attempt < 0) {
+            bu::tsvq_wide_node wn; std::memset(&wn, 0, sizeof(wn));
+            wn.count = n; wn.n_blocks = (n + 255) / 256;
+            std::memcpy(q->pinned, &wn, sizeof(wn));
+            if (hipMemcpyAsync(q->wide_nodes, q->pinned, sizeof(wn), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return fail("root upload");
+            prof_scope ps(ctx, "tsvq_root_packed16");
+            if (bu::launch_tsvq_wide_root(ctx->stream, static_cast<const uint32_t*>(q->rows), q->w64, n, q->perm[0], q->wide_nodes, q->wide_ctrl, q->wide_ws, wn.n_blocks,
+                                          static_cast<bu::tsvq_root_out*>(q->outs.p)) != hipSuccess) return fail("wide root launch");
+        } else {
             prof_scope ps(ctx, packed ? "tsvq_root_packed16" : "tsvq_root_float6");
             if (bu::launch_tsvq_root(ctx->stream, (int)dim, packed, exact, q->rows, q->w64, n, q->perm[0], static_cast<bu::tsvq_root_out*>(q->outs.p)) != hipSuccess) return fail("root launch");
         }
         if (hipMemcpyAsync(q->pinned, q->outs.p, sizeof(bu_tsvq_root), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess)
             return fail("root download");
-        if (!exact || static_cast<const bu_tsvq_root*>(q->pinned)->pad == 0) break;
+        if ((attempt >= 0 && !exact) || static_cast<const bu_tsvq_root*>(q->pinned)->pad == 0) break;
     }
     std::memcpy(out_root, q->pinned, sizeof(bu_tsvq_root));
     return q;
@@ -691,29 +720,68 @@ int bu_hip_tsvq_split(bu_hip_context* ctx, bu_tsvq* q, const bu_tsvq_node* h_nod
     if (!n_nodes) return 1;
     device_guard g(ctx->device);
     if ((size_t)n_nodes * sizeof(bu_tsvq_node) > q->nodes.cap || (size_t)n_nodes * sizeof(bu_tsvq_split) > q->outs.cap) { set_error(ctx, "tsvq_split: batch of %u nodes exceeds the record buffers", n_nodes); return 0; }
-    const size_t in_bytes = (size_t)n_nodes * sizeof(bu_tsvq_node), out_bytes = (size_t)n_nodes * sizeof(bu_tsvq_split);
-    BU_TRY(ctx, q->reserve_pinned(std::max(in_bytes, out_bytes)));
-    std::memcpy(q->pinned, h_nodes, in_bytes);
-    BU_TRY(ctx, hipMemcpyAsync(q->nodes.p, q->pinned, in_bytes, hipMemcpyHostToDevice, ctx->stream));
-    const bool exact = q->packed && !q->force_chained;
+    // Large nodes go through the many-workgroup path, the rest one workgroup each; both write one result array
+    // (narrow records first, in batch order, then the wide ones).
+    std::vector<uint32_t> order; order.reserve(n_nodes);
+    uint32_t n_wide = 0, wide_blocks = 0;
+    if (q->wide_min) {
+        std::vector<uint32_t> wide;
+        for (uint32_t i = 0; i < n_nodes; i++) {
+            const uint32_t nb = (h_nodes[i].count + 255) / 256;
+            if (h_nodes[i].count >= q->wide_min && wide.size() < q->wide_nodes_cap && wide_blocks + nb <= q->wide_blocks_cap) { wide.push_back(i); wide_blocks += nb; }
+            else order.push_back(i);
+        }
+        n_wide = (uint32_t)wide.size();
+        order.insert(order.end(), wide.begin(), wide.end());
+    } else for (uint32_t i = 0; i < n_nodes; i++) order.push_back(i);
+    const uint32_t n_narrow = n_nodes - n_wide;
+    const size_t in_bytes = (size_t)n_narrow * sizeof(bu_tsvq_node), wide_bytes = (size_t)n_wide * sizeof(bu::tsvq_wide_node), out_bytes = (size_t)n_nodes * sizeof(bu_tsvq_split);
+    const size_t wide_at = (in_bytes + 63) & ~(size_t)63;
+    BU_TRY(ctx, q->reserve_pinned(std::max(wide_at + wide_bytes, out_bytes)));
     {
+        bu_tsvq_node* pn = static_cast<bu_tsvq_node*>(q->pinned);
+        for (uint32_t i = 0; i < n_narrow; i++) pn[i] = h_nodes[order[i]];
+        bu::tsvq_wide_node* pw = reinterpret_cast<bu::tsvq_wide_node*>(static_cast<char*>(q->pinned) + wide_at);
+        uint32_t first = 0;
+        for (uint32_t i = 0; i < n_wide; i++) {
+            const bu_tsvq_node& s = h_nodes[order[n_narrow + i]];
+            bu::tsvq_wide_node w; std::memset(&w, 0, sizeof(w));
+            w.buf = s.buf; w.start = s.start; w.count = s.count; w.out_index = n_narrow + i; w.first_block = first; w.n_blocks = (s.count + 255) / 256; w.weight = s.weight;
+            std::memcpy(w.origin, s.origin, sizeof(w.origin));
+            first += w.n_blocks;
+            pw[i] = w;
+        }
+    }
+    if (n_narrow) BU_TRY(ctx, hipMemcpyAsync(q->nodes.p, q->pinned, in_bytes, hipMemcpyHostToDevice, ctx->stream));
+    if (n_wide) BU_TRY(ctx, hipMemcpyAsync(q->wide_nodes, static_cast<char*>(q->pinned) + wide_at, wide_bytes, hipMemcpyHostToDevice, ctx->stream));
+    const bool exact = q->packed && !q->force_chained;
+    if (n_wide) {
+        prof_scope ps(ctx, "tsvq_split_packed16_wide");
+        BU_TRY(ctx, bu::launch_tsvq_wide_split(ctx->stream, static_cast<const uint32_t*>(q->rows), q->w64, q->perm[0], q->perm[1], q->side, q->wide_packed, q->wide_nodes, n_wide, q->wide_ctrl,
+                                               q->wide_ws, wide_blocks, static_cast<bu::tsvq_split_out*>(q->outs.p)));
+    }
+    if (n_narrow) {
         prof_scope ps(ctx, q->packed ? "tsvq_split_packed16" : "tsvq_split_float6");
         BU_TRY(ctx, bu::launch_tsvq_split(ctx->stream, (int)q->dim, q->packed, exact, q->rows, q->w64, q->perm[0], q->perm[1], q->side,
-                                          static_cast<const bu::tsvq_node_in*>(q->nodes.p), n_nodes, static_cast<bu::tsvq_split_out*>(q->outs.p)));
+                                          static_cast<const bu::tsvq_node_in*>(q->nodes.p), n_narrow, static_cast<bu::tsvq_split_out*>(q->outs.p)));
     }
     BU_TRY(ctx, hipMemcpyAsync(q->pinned, q->outs.p, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
     BU_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    std::memcpy(h_out, q->pinned, out_bytes);
-    if (exact) { // nodes whose data left the exact range (ok == 2) go through the chained variant
-        std::vector<uint32_t> redo;
-        for (uint32_t i = 0; i < n_nodes; i++) if (h_out[i].ok == 2) redo.push_back(i);
-        if (!redo.empty()) {
+    {
+        const bu_tsvq_split* po = static_cast<const bu_tsvq_split*>(q->pinned);
+        for (uint32_t i = 0; i < n_nodes; i++) h_out[order[i]] = po[i];
+    }
+    if (exact) { // nodes whose data left the exact range, or that the wide path handed back (ok == 2), go through the one-workgroup kernel: wide ones through its exact variant first
+        for (int attempt = 0; attempt < 2; attempt++) {
+            std::vector<uint32_t> redo;
+            for (uint32_t i = 0; i < n_nodes; i++) if (h_out[i].ok == 2) redo.push_back(i);
+            if (redo.empty()) break;
             bu_tsvq_node* pn = static_cast<bu_tsvq_node*>(q->pinned);
             for (size_t j = 0; j < redo.size(); j++) pn[j] = h_nodes[redo[j]];
             BU_TRY(ctx, hipMemcpyAsync(q->nodes.p, q->pinned, redo.size() * sizeof(bu_tsvq_node), hipMemcpyHostToDevice, ctx->stream));
             {
                 prof_scope ps(ctx, q->packed ? "tsvq_split_packed16" : "tsvq_split_float6");
-                BU_TRY(ctx, bu::launch_tsvq_split(ctx->stream, (int)q->dim, q->packed, false, q->rows, q->w64, q->perm[0], q->perm[1], q->side,
+                BU_TRY(ctx, bu::launch_tsvq_split(ctx->stream, (int)q->dim, q->packed, attempt == 0 && n_wide != 0, q->rows, q->w64, q->perm[0], q->perm[1], q->side,
                                                   static_cast<const bu::tsvq_node_in*>(q->nodes.p), (uint32_t)redo.size(), static_cast<bu::tsvq_split_out*>(q->outs.p)));
             }
             BU_TRY(ctx, hipMemcpyAsync(q->pinned, q->outs.p, redo.size() * sizeof(bu_tsvq_split), hipMemcpyDeviceToHost, ctx->stream));

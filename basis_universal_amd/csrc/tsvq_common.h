@@ -1,0 +1,77 @@
+// tsvq_common.h -- device helpers shared by tsvq_kernels.hip (one workgroup per node, chained sums) and tsvq_wide_kernels.hip
+// (many workgroups per node, order-preserving sums through fsum_scan.h). Internal to libbasisu_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace bu {
+
+template <int N> __device__ __forceinline__ float dot_seq(const float* a, const float* b) {
+    float r = a[0] * b[0];
+#pragma unroll
+    for (int i = 1; i < N; i++) r += a[i] * b[i];
+    return r;
+}
+
+// compute_pca_from_covar (enc.h:605-648) on one thread: 8 power iterations, double row sums, float early-out.
+template <int N>
+__device__ __noinline__ void principal_axis(const float (*cov)[16], float* out_axis) {
+    float axis[N], prev[N];
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        const float t = (float)(uint32_t)i * (1.0f / (float)(N - 1 > 1 ? N - 1 : 1));
+        axis[i] = .75f + (1.25f - .75f) * t;
+        prev[i] = axis[i];
+    }
+    for (int iter = 0; iter < 8; iter++) {
+        float trial[N];
+        double max_sum = 0;
+        for (int i = 0; i < N; i++) {
+            double sum = 0;
+            for (int j = 0; j < N; j++) { const float p = cov[i][j] * axis[j]; sum += p; }
+            trial[i] = (float)sum;
+            const double a = fabs(sum);
+            if (a > max_sum) max_sum = a;
+        }
+        if (max_sum != 0.0) {
+            const float s = (float)(1.0 / max_sum);
+            for (int i = 0; i < N; i++) trial[i] *= s;
+        }
+        float delta[N];
+        for (int i = 0; i < N; i++) delta[i] = prev[i] - trial[i];
+        for (int i = 0; i < N; i++) { prev[i] = axis[i]; axis[i] = trial[i]; }
+        if (dot_seq<N>(delta, delta) < .0024f) break;
+    }
+    const float len = sqrtf(dot_seq<N>(axis, axis));
+    if (len != 0.0f) {
+        const float s = 1.0f / len;
+        for (int i = 0; i < N; i++) axis[i] *= s;
+    }
+    for (int i = 0; i < N; i++) out_axis[i] = axis[i];
+}
+
+// The reference's double accumulators (ttsum, l_weight / r_weight) only ever add floats. When every addend is a non-negative
+// INTEGER-valued float below 2^53 and the total stays below 2^53 (always the case for selector vectors with real weights), each
+// double add is exact, so the running sum equals the integer sum and its order does not matter: the "exact" kernel variants
+// replace those two chains by an integer reduction (low / high 32-bit halves summed separately so nothing overflows). When the
+// condition fails the kernel reports it and the caller re-runs the node with the chained variant.
+struct exact_acc {
+    uint64_t lo = 0, hi = 0;
+    __device__ __forceinline__ bool add(float t) { // returns false when t is outside the exact range
+        if (!(t < 9007199254740992.0f)) return false;
+        const uint64_t ti = (uint64_t)t;
+        lo += ti & 0xffffffffull; hi += ti >> 32;
+        return true;
+    }
+};
+__device__ __forceinline__ bool exact_total(uint64_t lo, uint64_t hi, double* out) {
+    const uint64_t h = hi + (lo >> 32);
+    if (h >= (1ull << 21)) return false;
+    *out = (double)((h << 32) | (lo & 0xffffffffull));
+    return true;
+}
+
+// value k (0..15) of a packed selector vector: element 0 in the top two bits (the order the frontend's de-duplication keys use)
+__device__ __forceinline__ uint32_t packed16_value(uint32_t key, int k) { return (key >> (30 - 2 * k)) & 3u; }
+
+} // namespace bu

@@ -18,4 +18,25 @@ hipError_t launch_tsvq_root(hipStream_t st, int dim, bool packed, bool exact, co
 hipError_t launch_tsvq_split(hipStream_t st, int dim, bool packed, bool exact, const void* d_rows, const uint64_t* d_w64, uint32_t* d_perm0, uint32_t* d_perm1, uint8_t* d_side,
                              const tsvq_node_in* d_nodes, uint32_t n_nodes, tsvq_split_out* d_outs);
 
+// ---- large nodes spread over many workgroups (tsvq_wide_kernels.hip; packed selector vectors only). Results are bit-identical to
+// launch_tsvq_root / launch_tsvq_split; a split record with ok == 2 (degenerate projection, empty child, data outside the exact
+// integer range) asks for that node to be run through launch_tsvq_split.
+constexpr int TSVQ_WIDE_MAX_CHAINS = 136;
+struct tsvq_wide_node { uint32_t buf, start, count, out_index, first_block, n_blocks, pad0, pad1; uint64_t weight; float origin[16]; };
+struct tsvq_wide_ctrl {   // device-side state of one node across the passes of its split
+    float l_c[16], r_c[16], axis[16];
+    float sums[TSVQ_WIDE_MAX_CHAINS];
+    uint64_t l_w, r_w;
+    double dsum[2];
+    uint32_t l_n, r_n;
+    float l_var, r_var, prev_total;
+    int32_t iter, done;
+    uint32_t ex_bad;
+};
+size_t tsvq_wide_workspace_bytes(uint32_t total_blocks);           // total_blocks = sum over the batch's nodes of ceil(count / 256)
+hipError_t launch_tsvq_wide_root(hipStream_t st, const uint32_t* d_keys, const uint64_t* d_w64, uint32_t n, uint32_t* d_perm0 /* out: 0..n-1 */,
+                                 const tsvq_wide_node* d_nodes /* one node: all n vectors */, tsvq_wide_ctrl* d_ctrl, void* d_ws, uint32_t total_blocks, tsvq_root_out* d_out);
+hipError_t launch_tsvq_wide_split(hipStream_t st, const uint32_t* d_keys, const uint64_t* d_w64, uint32_t* d_perm0, uint32_t* d_perm1, uint8_t* d_side, void* d_packed /* 8 bytes per vector */,
+                                  const tsvq_wide_node* d_nodes, uint32_t n_nodes, tsvq_wide_ctrl* d_ctrl, void* d_ws, uint32_t total_blocks, tsvq_split_out* d_outs);
+
 } // namespace bu

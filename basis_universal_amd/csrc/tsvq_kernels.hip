@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "tsvq_kernels.h"
+#include "tsvq_common.h"
 
 namespace bu {
 
@@ -38,12 +39,6 @@ struct tq_ctrl { // serial state of one split, written by thread 0 between passe
 
 enum { TQ_MODE_DIST = 0, TQ_MODE_PEEL_FIRST = 1, TQ_MODE_HALF = 2, TQ_MODE_PROJ = 3 };
 
-template <int N> __device__ __forceinline__ float dot_seq(const float* a, const float* b) {
-    float r = a[0] * b[0];
-#pragma unroll
-    for (int i = 1; i < N; i++) r += a[i] * b[i];
-    return r;
-}
 
 // ---- where a training vector comes from
 template <int N>
@@ -235,42 +230,6 @@ __device__ __forceinline__ void chain_add_prod_f32(float& acc, const float* dx, 
     for (; j < m; j++) { const float pp = dx[j] * wy[j]; acc = acc + pp; }
 }
 
-// compute_pca_from_covar (enc.h:605-648) on one thread: 8 power iterations, double row sums, float early-out.
-template <int N>
-__device__ __noinline__ void principal_axis(tq_ctrl& c) {
-    float axis[N], prev[N];
-#pragma unroll
-    for (int i = 0; i < N; i++) {
-        const float t = (float)(uint32_t)i * (1.0f / (float)(N - 1 > 1 ? N - 1 : 1));
-        axis[i] = .75f + (1.25f - .75f) * t;
-        prev[i] = axis[i];
-    }
-    for (int iter = 0; iter < 8; iter++) {
-        float trial[N];
-        double max_sum = 0;
-        for (int i = 0; i < N; i++) {
-            double sum = 0;
-            for (int j = 0; j < N; j++) { const float p = c.cov[i][j] * axis[j]; sum += p; }
-            trial[i] = (float)sum;
-            const double a = fabs(sum);
-            if (a > max_sum) max_sum = a;
-        }
-        if (max_sum != 0.0) {
-            const float s = (float)(1.0 / max_sum);
-            for (int i = 0; i < N; i++) trial[i] *= s;
-        }
-        float delta[N];
-        for (int i = 0; i < N; i++) delta[i] = prev[i] - trial[i];
-        for (int i = 0; i < N; i++) { prev[i] = axis[i]; axis[i] = trial[i]; }
-        if (dot_seq<N>(delta, delta) < .0024f) break;
-    }
-    const float len = sqrtf(dot_seq<N>(axis, axis));
-    if (len != 0.0f) {
-        const float s = 1.0f / len;
-        for (int i = 0; i < N; i++) axis[i] *= s;
-    }
-    for (int i = 0; i < N; i++) c.axis[i] = axis[i];
-}
 
 __device__ __forceinline__ uint64_t block_sum_u64(uint64_t v, uint64_t* scratch /* TQ_THREADS/64 */) {
 #pragma unroll
@@ -310,26 +269,6 @@ __device__ __forceinline__ void block_sum_u64xN(uint64_t (&v)[K], uint64_t* scra
     }
 }
 
-// The reference's double accumulators (ttsum, l_weight / r_weight) only ever add floats. When every addend is a non-negative
-// INTEGER-valued float below 2^53 and the total stays below 2^53 (always the case for selector vectors with real weights), each
-// double add is exact, so the running sum equals the integer sum and its order does not matter: the "exact" kernel variants
-// replace those two chains by an integer reduction (low / high 32-bit halves summed separately so nothing overflows). When the
-// condition fails the kernel reports it and the caller re-runs the node with the chained variant.
-struct exact_acc {
-    uint64_t lo = 0, hi = 0;
-    __device__ __forceinline__ bool add(float t) { // returns false when t is outside the exact range
-        if (!(t < 9007199254740992.0f)) return false;
-        const uint64_t ti = (uint64_t)t;
-        lo += ti & 0xffffffffull; hi += ti >> 32;
-        return true;
-    }
-};
-__device__ __forceinline__ bool exact_total(uint64_t lo, uint64_t hi, double* out) {
-    const uint64_t h = hi + (lo >> 32);
-    if (h >= (1ull << 21)) return false;
-    *out = (double)((h << 32) | (lo & 0xffffffffull));
-    return true;
-}
 
 __global__ __launch_bounds__(256) void k_tsvq_iota(uint32_t n, uint32_t* __restrict__ perm0) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -533,7 +472,7 @@ __global__ __launch_bounds__(TQ_THREADS) void k_tsvq_split(Src src, const uint64
             const float renorm = 1.0f / (float)nd.weight;
             for (int x = 0; x < N; x++) for (int y = x; y < N; y++) c.cov[x][y] *= renorm;
             for (int x = 0; x < N - 1; x++) for (int y = x + 1; y < N; y++) c.cov[y][x] = c.cov[x][y];
-            principal_axis<N>(c);
+            principal_axis<N>(c.cov, c.axis);
         }
         __syncthreads();
     }

@@ -1,0 +1,720 @@
+// tsvq_wide_kernels.hip -- the codebook builder's LARGE nodes (row a8): the same split as tsvq_kernels.hip, bit for bit, but spread
+// over the whole chip instead of one workgroup per node.
+//
+// tree_vector_quant<>::split_node (encoder/basisu_enc.h:1737-2077) is a handful of passes over the node's members; every pass
+// classifies each member (independent work) and adds its contribution to 16..136 RUNNING float sums in member order. The
+// one-workgroup kernel pays one dependent v_add_f32 per member per pass -- 18 ms for the root of the 4096^2 selector codebook
+// (674,691 members, ~9 passes), on 1 of 256 CUs. Here a pass is cut into blocks of 256 members:
+//
+//   k_wide_sums      per block: classify, store the side, exact block sums of every chain (double) + the integer totals
+//   k_wide_scan      per node:  prefix of the block sums -> the binade every chain's running sum will be in at every block start
+//                               (a PREDICTION: it steers work, it never decides a result), left-count prefix, exact totals
+//   k_wide_stretches per block: for each chain and two candidate binades, the block's addends folded into one parity map
+//                               (fsum_scan.h: inside a binade a float add is k -> k + d[k & 1] on the significand)
+//   k_wide_walk      per chain: one wave composes 64 blocks' maps at a time (prefix scan), applies the longest valid prefix to
+//                               the running sum, and adds the members of a block one by one only where a map does not apply
+//                               (binade crossings, a few dozen per chain)
+//   k_wide_finish    per node:  the serial tail of the pass (centroids, variances, convergence test; PCA after the covariance pass)
+//   k_wide_partition per block: the children's member lists (stable partition) + the result record
+//
+// The sums come out identical to the sequential ones because the walk applies a map only where fsum::applies() proves that
+// every single add of the stretch stayed inside the binade the map was built for; everything else is added for real, in order.
+// Selector vectors only (packed rows): that is where the large nodes are (the endpoint side has <= 2^18 distinct vectors).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "tsvq_kernels.h"
+#include "tsvq_common.h"
+#include "fsum_scan.h"
+
+namespace bu {
+
+namespace {
+
+constexpr int WB = 256;            // members per block = threads per workgroup of the per-block kernels
+constexpr int WROW = WB + 1;       // LDS row stride (floats)
+constexpr int NCH_MAX = TSVQ_WIDE_MAX_CHAINS;
+
+enum { WM_ROOT = 0, WM_COV = 1, WM_PROJ = 2, WM_DIST = 3 };
+
+template <int MODE> struct mode_traits;
+template <> struct mode_traits<WM_ROOT> { static constexpr int NCH = 16; };
+template <> struct mode_traits<WM_COV>  { static constexpr int NCH = 136; };
+template <> struct mode_traits<WM_PROJ> { static constexpr int NCH = 32; };
+template <> struct mode_traits<WM_DIST> { static constexpr int NCH = 32; };
+
+// covariance chain -> (x, y >= x), the enumeration of tsvq_kernels.hip (row-major upper triangle)
+__device__ __forceinline__ void cov_xy(int c, int& x, int& y) { x = 0; while (c >= 16 - x) { c -= 16 - x; x++; } y = x + c; }
+
+struct wide_ws {                   // views into the workspace; per-(chain, block) arrays are CHAIN-major: [chain][TB blocks]
+    double* bsum;                  // [NCH_MAX][TB]  sum of the block's addends per chain
+    uint8_t* bzero;                // [NCH_MAX][TB]  1: every addend of the block is +-0 for that chain
+    uint64_t* bex;                 // [TB][8]        lw, rw, ln, ex0.lo, ex0.hi, ex1.lo, ex1.hi, bad
+    uint16_t* epred;               // [NCH_MAX][TB]  predicted exponent | sign << 8 | single << 9; EP_NONE / EP_ZERO
+    uint32_t* lpre;                // [TB]           left members before the block (within its node)
+    int32_t* summ;                 // [NCH_MAX][TB][2][6]
+    uint32_t tb;
+    __host__ __device__ size_t at(int c, uint32_t blk) const { return (size_t)c * tb + blk; }
+};
+constexpr uint16_t EP_NONE = 0, EP_ZERO = 0xffff, EP_SINGLE = 0x200;
+
+__host__ __device__ inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+__host__ __device__ inline wide_ws carve(void* base, uint32_t tb) {
+    char* p = static_cast<char*>(base);
+    wide_ws w;
+    w.tb = tb;
+    w.bsum = reinterpret_cast<double*>(p);   p += align256((size_t)tb * NCH_MAX * sizeof(double));
+    w.bex = reinterpret_cast<uint64_t*>(p);  p += align256((size_t)tb * 8 * sizeof(uint64_t));
+    w.summ = reinterpret_cast<int32_t*>(p);  p += align256((size_t)tb * NCH_MAX * 2 * 6 * sizeof(int32_t));
+    w.lpre = reinterpret_cast<uint32_t*>(p); p += align256((size_t)tb * sizeof(uint32_t));
+    w.epred = reinterpret_cast<uint16_t*>(p); p += align256((size_t)tb * NCH_MAX * sizeof(uint16_t));
+    w.bzero = reinterpret_cast<uint8_t*>(p);
+    return w;
+}
+
+__device__ __forceinline__ uint32_t find_node(const tsvq_wide_node* __restrict__ nodes, uint32_t n_nodes, uint32_t blk) {
+    uint32_t lo = 0, hi = n_nodes;   // last node whose first_block <= blk
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (nodes[mid].first_block <= blk) lo = mid; else hi = mid; }
+    return lo;
+}
+
+struct member_info { uint32_t key; float wf; uint64_t w; bool valid; };
+
+__device__ __forceinline__ member_info fetch_member(const uint32_t* __restrict__ keys, const uint64_t* __restrict__ w64, const uint32_t* __restrict__ members,
+                                                    uint32_t pos, uint32_t count) {
+    member_info m;
+    m.valid = pos < count;
+    const uint32_t p = m.valid ? pos : count - 1;
+    const uint32_t mi = members ? members[p] : p;
+    m.key = keys[mi]; m.w = w64[mi]; m.wf = (float)m.w;
+    return m;
+}
+
+// which child does a member go to (enc.h:1870-1871 projection sign, enc.h:1991 distance comparison)
+template <int MODE>
+__device__ __forceinline__ bool classify(uint32_t key, const float* s_origin, const float* s_axis, const double2 (*s_tab)[4]) {
+    if (MODE == WM_DIST) {
+        double dl = 0, dr = 0;
+#pragma unroll
+        for (int k = 0; k < 16; k++) { const double2 t = s_tab[k][packed16_value(key, k)]; dl += t.x; dr += t.y; }
+        return dl >= dr;
+    } else if (MODE == WM_PROJ) {
+        float dd[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) dd[k] = (float)packed16_value(key, k) - s_origin[k];
+        return (double)dot_seq<16>(dd, s_axis) >= 0.0;
+    }
+    return false;
+}
+
+// ------------------------------------------------------------------------------------------------------------ per-block front end
+// The LDS tiles both per-block kernels work from. Side modes / root: fa[k][m] = v_k * w, sd[m] = side (2: no member).
+// Covariance: fa[k][m] = d_k, fb[k][m] = w * d_k.
+template <int MODE>
+struct tiles {
+    float fa[16][WROW];
+    float fb[MODE == WM_COV ? 16 : 1][WROW];
+    uint8_t sd[WB];
+};
+
+// ------------------------------------------------------------------------------------------------------------ k_wide_sums
+template <int MODE>
+__global__ __launch_bounds__(WB) void k_wide_sums(const uint32_t* __restrict__ keys, const uint64_t* __restrict__ w64, const uint32_t* __restrict__ perm0,
+                                                  const uint32_t* __restrict__ perm1, uint8_t* __restrict__ side, const tsvq_wide_node* __restrict__ nodes,
+                                                  uint32_t n_nodes, const tsvq_wide_ctrl* __restrict__ ctrl, void* ws_base, uint32_t tb, uint2* __restrict__ pk) {
+    constexpr int NCH = mode_traits<MODE>::NCH;
+    __shared__ tiles<MODE> T;
+    __shared__ float s_origin[16], s_axis[16];
+    __shared__ double2 s_tab[16][4];
+    __shared__ double s_part[8][32];
+    __shared__ double s_cpart[2][136];
+    __shared__ uint32_t s_cnz[2][136];
+    __shared__ uint64_t s_red[4][8];
+    const wide_ws ws = carve(ws_base, tb);
+    const int tid = threadIdx.x;
+    const uint32_t blk = blockIdx.x;
+    const uint32_t ni = find_node(nodes, n_nodes, blk);
+    const tsvq_wide_ctrl& ct = ctrl[ni];
+    if (ct.done) return;
+    const tsvq_wide_node& nd = nodes[ni];
+    if (tid < 16) { s_origin[tid] = nd.origin[tid]; s_axis[tid] = ct.axis[tid]; }
+    if (MODE == WM_DIST && tid < 64) {   // squared centroid differences per value (tsvq_kernels.hip, TQ_MODE_DIST)
+        const int k = tid >> 2, val = tid & 3;
+        const double a = (double)ct.l_c[k] - (double)(float)val, b = (double)ct.r_c[k] - (double)(float)val;
+        s_tab[k][val] = make_double2(a * a, b * b);
+    }
+    __syncthreads();
+    const uint32_t pos = (blk - nd.first_block) * WB + (uint32_t)tid;
+    const uint32_t* members = MODE == WM_ROOT ? nullptr : (nd.buf ? perm1 : perm0) + nd.start;
+    const member_info m = fetch_member(keys, w64, members, pos, nd.count);
+    bool right = false;
+    uint64_t red[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (MODE == WM_COV) {
+        // the first pass of a split also lays the members out in list order (key, float weight): the later passes and the walks
+        // read that instead of gathering through the member list
+        if (m.valid) pk[nd.start + pos] = make_uint2(m.key, __float_as_uint(m.wf));
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const float dk = (float)packed16_value(m.key, k) - s_origin[k];
+            T.fa[k][tid] = m.valid ? dk : 0.0f;
+            T.fb[k][tid] = m.valid ? m.wf * dk : 0.0f;
+        }
+    } else {
+        if (MODE != WM_ROOT) right = classify<MODE>(m.key, s_origin, s_axis, s_tab);
+        float vsq = 0.0f;
+        {
+            float v[16];
+#pragma unroll
+            for (int k = 0; k < 16; k++) { v[k] = (float)packed16_value(m.key, k); T.fa[k][tid] = m.valid ? v[k] * m.wf : 0.0f; }
+            vsq = dot_seq<16>(v, v);
+        }
+        T.sd[tid] = m.valid ? (right ? 1 : 0) : 2;
+        if (m.valid) {
+            if (MODE != WM_ROOT) side[nd.start + pos] = right ? 1 : 0;
+            // the reference's double accumulators: l_weight / r_weight in the projection pass (enc.h:1873-1881), ttsum otherwise
+            const float dvf = MODE == WM_PROJ ? m.wf : m.wf * vsq;
+            exact_acc ex;
+            const bool ok = ex.add(dvf);
+            if (right) { red[1] = m.w; red[5] = ex.lo; red[6] = ex.hi; } else { red[0] = m.w; red[2] = 1; red[3] = ex.lo; red[4] = ex.hi; }
+            red[7] = ok ? 0 : 1;
+        }
+    }
+    __syncthreads();
+    if (MODE == WM_COV) {
+        for (int item = tid; item < 2 * 136; item += WB) {
+            const int c = item % 136, h = item / 136;
+            int x, y; cov_xy(c, x, y);
+            double s = 0; uint32_t nz = 0;
+            for (int j = h * 128; j < h * 128 + 128; j++) {
+                const float p = T.fa[x][j] * T.fb[y][j];
+                s += (double)p;
+                nz |= __float_as_uint(p) << 1;
+            }
+            s_cpart[h][c] = s; s_cnz[h][c] = nz;
+        }
+        __syncthreads();
+        if (tid < 136) {
+            ws.bsum[ws.at(tid, blk)] = s_cpart[0][tid] + s_cpart[1][tid];
+            ws.bzero[ws.at(tid, blk)] = (s_cnz[0][tid] | s_cnz[1][tid]) ? 0 : 1;
+        }
+        return;
+    }
+    {   // 32 chains x 8 slices of 32 members
+        const int c = tid & 31, sl = tid >> 5;
+        const int k = c & 15; const uint8_t want = (uint8_t)(c >> 4);
+        double s = 0;
+        for (int j = sl * 32; j < sl * 32 + 32; j++) s += (T.sd[j] == want) ? (double)T.fa[k][j] : 0.0;
+        s_part[sl][c] = s;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        uint64_t v = red[i];
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, o, 64), hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), o, 64);
+            v += ((uint64_t)hi << 32) | lo;
+        }
+        if ((tid & 63) == 0) s_red[tid >> 6][i] = v;
+    }
+    __syncthreads();
+    if (tid < NCH) {
+        double s = 0;
+        for (int i = 0; i < 8; i++) s += s_part[i][tid];
+        ws.bsum[ws.at(tid, blk)] = s;
+        ws.bzero[ws.at(tid, blk)] = s == 0.0 ? 1 : 0;   // addends are >= 0 here
+    }
+    if (tid >= 64 && tid < 72) ws.bex[(size_t)blk * 8 + (tid - 64)] = s_red[0][tid - 64] + s_red[1][tid - 64] + s_red[2][tid - 64] + s_red[3][tid - 64];
+}
+
+// ------------------------------------------------------------------------------------------------------------ k_wide_scan
+// grid (node, y): y < ceil(NCH / 4): four chains, one wave each, 64 blocks per step (coalesced, wave prefix scan);
+//                 y == ceil(NCH / 4) (not for the covariance pass): the integer totals and the left-count prefix of the node.
+template <int MODE>
+__global__ __launch_bounds__(256) void k_wide_scan(const tsvq_wide_node* __restrict__ nodes, tsvq_wide_ctrl* __restrict__ ctrl, void* ws_base, uint32_t tb) {
+    constexpr int NCH = mode_traits<MODE>::NCH;
+    constexpr int NCW = (NCH + 3) / 4;
+    __shared__ uint64_t s_tot[4][8];
+    __shared__ uint32_t s_wl[4];
+    const wide_ws ws = carve(ws_base, tb);
+    const uint32_t ni = blockIdx.x;
+    if (ctrl[ni].done) return;
+    const tsvq_wide_node nd = nodes[ni];
+    const int tid = threadIdx.x, lane = tid & 63;
+    if ((int)blockIdx.y < NCW) {
+        const int c = (int)blockIdx.y * 4 + (tid >> 6);
+        if (c >= NCH) return;
+        double P = 0;   // sum of the blocks before the current 64
+        for (uint32_t b0 = 0; b0 < nd.n_blocks; b0 += 64) {
+            const uint32_t b = b0 + (uint32_t)lane;
+            const bool have = b < nd.n_blocks;
+            const size_t at = ws.at(c, nd.first_block + (have ? b : nd.n_blocks - 1));
+            const double v = have ? ws.bsum[at] : 0.0;
+            double incl = v;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const double t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+            const double Ps = P + (incl - v);
+            if (have) {
+                uint16_t ep;
+                if (ws.bzero[at]) ep = EP_ZERO;
+                else {
+                    // the running float sum at this block's start is within (members so far) half-ulps of Ps: the binade of the lower
+                    // end, and whether the upper end is in the same one (then only one map is needed)
+                    const double eps = (double)((uint64_t)b * WB + 1) * 5.9604644775390625e-08;
+                    const double lo = fabs(Ps) * (1.0 - eps), hi = fabs(Ps) * (1.0 + eps);
+                    float lf = (float)(lo > 0.0 ? lo : 0.0), hf = (float)hi;
+                    if ((double)lf > lo) lf = __uint_as_float(__float_as_uint(lf) - 1u);
+                    if ((double)hf < hi) hf = __uint_as_float(__float_as_uint(hf) + 1u);
+                    const uint32_t e = (__float_as_uint(lf) >> 23) & 0xffu, eh = (__float_as_uint(hf) >> 23) & 0xffu;
+                    ep = (e >= 1u && e <= 252u) ? (uint16_t)(e | (Ps < 0.0 ? 0x100u : 0u) | (eh == e ? EP_SINGLE : 0u)) : EP_NONE;
+                }
+                ws.epred[at] = ep;
+            }
+            P += __shfl(incl, 63, 64);
+        }
+        return;
+    }
+    // totals of the integer accumulators and the left-count prefix (block order)
+    uint64_t tot[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const uint32_t perb = (nd.n_blocks + 255) / 256;
+    const uint32_t q0 = min((uint32_t)tid * perb, nd.n_blocks), q1 = min(q0 + perb, nd.n_blocks);
+    for (uint32_t b = q0; b < q1; b++)
+#pragma unroll
+        for (int i = 0; i < 8; i++) tot[i] += ws.bex[(size_t)(nd.first_block + b) * 8 + i];
+    const uint32_t my_left = (uint32_t)tot[2];
+    uint32_t incl = my_left;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)incl, o, 64); if (lane >= o) incl += t; }
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        uint64_t v = tot[i];
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, o, 64), hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), o, 64);
+            v += ((uint64_t)hi << 32) | lo;
+        }
+        if (lane == 0) s_tot[tid >> 6][i] = v;
+    }
+    if (lane == 63) s_wl[tid >> 6] = incl;
+    __syncthreads();
+    uint32_t base = 0;
+    for (int w = 0; w < (tid >> 6); w++) base += s_wl[w];
+    uint32_t run = base + incl - my_left;
+    for (uint32_t b = q0; b < q1; b++) { ws.lpre[nd.first_block + b] = run; run += (uint32_t)ws.bex[(size_t)(nd.first_block + b) * 8 + 2]; }
+    if (tid == 0) {
+        uint64_t t[8];
+        for (int i = 0; i < 8; i++) { t[i] = 0; for (int w = 0; w < 4; w++) t[i] += s_tot[w][i]; }
+        tsvq_wide_ctrl& ct = ctrl[ni];
+        ct.l_w = t[0]; ct.r_w = t[1]; ct.l_n = (uint32_t)t[2]; ct.r_n = nd.count - (uint32_t)t[2];
+        double d0 = 0, d1 = 0;
+        const bool ok = t[7] == 0 && exact_total(t[3], t[4], &d0) && exact_total(t[5], t[6], &d1);
+        ct.dsum[0] = d0; ct.dsum[1] = d1;
+        ct.ex_bad = ok ? 0u : 1u;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------ k_wide_stretches
+// (key, float weight) of the member at list position pos: from the packed copy the covariance pass made, or -- root -- directly
+template <int MODE>
+__device__ __forceinline__ void fetch_packed(const uint32_t* __restrict__ keys, const uint64_t* __restrict__ w64, const uint2* __restrict__ pk, uint32_t node_start,
+                                             uint32_t pos, uint32_t count, uint32_t& key, float& wf, bool& valid) {
+    valid = pos < count;
+    const uint32_t p = valid ? pos : count - 1;
+    if (MODE == WM_ROOT) { key = keys[p]; wf = (float)w64[p]; }
+    else { const uint2 v = pk[node_start + p]; key = v.x; wf = __uint_as_float(v.y); }
+}
+
+__device__ __forceinline__ void st_store(int32_t* o, const fsum::stretch& a) { o[0] = a.d[0]; o[1] = a.d[1]; o[2] = a.lo[0]; o[3] = a.lo[1]; o[4] = a.hi[0]; o[5] = a.hi[1]; }
+__device__ __forceinline__ fsum::stretch st_load(const int32_t* o) { fsum::stretch a; a.d[0] = o[0]; a.d[1] = o[1]; a.lo[0] = o[2]; a.lo[1] = o[3]; a.hi[0] = o[4]; a.hi[1] = o[5]; return a; }
+
+template <int MODE>
+__global__ __launch_bounds__(WB) void k_wide_stretches(const uint32_t* __restrict__ keys, const uint64_t* __restrict__ w64, const uint2* __restrict__ pk,
+                                                       const uint8_t* __restrict__ side, const tsvq_wide_node* __restrict__ nodes,
+                                                       uint32_t n_nodes, const tsvq_wide_ctrl* __restrict__ ctrl, void* ws_base, uint32_t tb) {
+    constexpr int NCH = mode_traits<MODE>::NCH;
+    constexpr int Q = MODE == WM_COV ? 4 : (MODE == WM_ROOT ? 16 : 8);   // member slices per chain; an item = (chain, slice), both candidate binades
+    constexpr int ITEMS = NCH * Q;
+    constexpr int SL = WB / Q;
+    __shared__ tiles<MODE> T;
+    __shared__ float s_origin[16];
+    __shared__ int32_t s_st[ITEMS][2][6];
+    const wide_ws ws = carve(ws_base, tb);
+    const int tid = threadIdx.x;
+    const uint32_t blk = blockIdx.x;
+    const uint32_t ni = find_node(nodes, n_nodes, blk);
+    if (ctrl[ni].done) return;
+    const tsvq_wide_node& nd = nodes[ni];
+    if (tid < 16) s_origin[tid] = nd.origin[tid];
+    __syncthreads();
+    const uint32_t pos = (blk - nd.first_block) * WB + (uint32_t)tid;
+    uint32_t key; float wf; bool valid;
+    fetch_packed<MODE>(keys, w64, pk, nd.start, pos, nd.count, key, wf, valid);
+    if (MODE == WM_COV) {
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const float dk = (float)packed16_value(key, k) - s_origin[k];
+            T.fa[k][tid] = valid ? dk : 0.0f;
+            T.fb[k][tid] = valid ? wf * dk : 0.0f;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 16; k++) T.fa[k][tid] = valid ? (float)packed16_value(key, k) * wf : 0.0f;
+        T.sd[tid] = valid ? (MODE == WM_ROOT ? 0 : side[nd.start + pos]) : 2;
+    }
+    __syncthreads();
+    for (int item = tid; item < ITEMS; item += WB) {
+        const int c = item % NCH, q = item / NCH;
+        const uint16_t ep = ws.epred[ws.at(c, blk)];
+        fsum::stretch st0 = fsum::identity(), st1 = fsum::identity();
+        if (ep != EP_NONE && ep != EP_ZERO) {
+            const int E = (int)(ep & 0xffu);
+            const bool neg = (ep & 0x100u) != 0, two = (ep & EP_SINGLE) == 0;
+            int x = c & 15, y = 0;
+            if (MODE == WM_COV) cov_xy(c, x, y);
+            const uint8_t want = (uint8_t)(c >> 4);
+            for (int j = q * SL; j < q * SL + SL; j++) {
+                uint32_t bits;
+                if (MODE == WM_COV) bits = __float_as_uint(T.fa[x][j] * T.fb[y][j]);
+                else { if (T.sd[j] != want) continue; bits = __float_as_uint(T.fa[x][j]); }
+                if ((bits << 1) == 0) continue;
+                fsum::push(st0, fsum::decode(bits, E, neg));
+                if (two) fsum::push(st1, fsum::decode(bits, E + 1, neg));
+            }
+        }
+        st_store(s_st[item][0], st0); st_store(s_st[item][1], st1);
+    }
+    __syncthreads();
+    for (int item = tid; item < NCH * 2; item += WB) {   // slices in member order
+        const int c = item % NCH, cand = item / NCH;
+        fsum::stretch acc = st_load(s_st[c][cand]);
+#pragma unroll
+        for (int q = 1; q < Q; q++) acc = fsum::compose(acc, st_load(s_st[c + q * NCH][cand]));
+        st_store(ws.summ + (ws.at(c, blk) * 2 + (size_t)cand) * 6, acc);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------ k_wide_walk
+// One wave per (node, chain). A window of 64 blocks is resident in registers with the maps of BOTH candidate binades, so that
+// nothing has to be loaded again when the running sum changes binade inside the window; the following windows are loaded
+// while the current one is walked. A block whose map does not apply is added member by member out of LDS.
+struct walk_window { uint32_t ep; int32_t m[2][6]; };
+
+__device__ __forceinline__ void load_window(const wide_ws& ws, uint32_t first_block, uint32_t n_blocks, uint32_t b0, int lane, int c, walk_window& w) {
+    const uint32_t j = b0 + (uint32_t)lane;
+    w.ep = EP_ZERO;   // past the node's end: identity
+#pragma unroll
+    for (int k = 0; k < 2; k++)
+#pragma unroll
+        for (int i = 0; i < 6; i++) w.m[k][i] = 0;
+    if (j < n_blocks) {
+        const size_t at = ws.at(c, first_block + j);
+        w.ep = ws.epred[at];
+        const int4* p = reinterpret_cast<const int4*>(ws.summ + at * 12);   // 48-byte records, 16-byte aligned
+        const int4 a = p[0], b = p[1], d = p[2];
+        w.m[0][0] = a.x; w.m[0][1] = a.y; w.m[0][2] = a.z; w.m[0][3] = a.w; w.m[0][4] = b.x; w.m[0][5] = b.y;
+        w.m[1][0] = b.z; w.m[1][1] = b.w; w.m[1][2] = d.x; w.m[1][3] = d.y; w.m[1][4] = d.z; w.m[1][5] = d.w;
+    }
+}
+
+// wave64 inclusive scans by DPP (rows of 16 lanes: row_shr 1/2/4/8, then row_bcast15 into rows 1 and 3, row_bcast31 into rows 2 and 3).
+// Lanes without a source get `old`, which is the identity of the field, so every lane composes unconditionally.
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ int32_t dpp_mov(int32_t old, int32_t src) { return __builtin_amdgcn_update_dpp(old, src, CTRL, ROW_MASK, 0xf, false); }
+
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ void scan_step(fsum::stretch& st) {
+    fsum::stretch f;
+    f.d[0] = dpp_mov<CTRL, ROW_MASK>(0, st.d[0]); f.d[1] = dpp_mov<CTRL, ROW_MASK>(0, st.d[1]);
+    f.lo[0] = dpp_mov<CTRL, ROW_MASK>(fsum::D_SAT, st.lo[0]); f.lo[1] = dpp_mov<CTRL, ROW_MASK>(fsum::D_SAT, st.lo[1]);
+    f.hi[0] = dpp_mov<CTRL, ROW_MASK>(-fsum::D_SAT, st.hi[0]); f.hi[1] = dpp_mov<CTRL, ROW_MASK>(-fsum::D_SAT, st.hi[1]);
+    st = fsum::compose(f, st);
+}
+__device__ __forceinline__ void wave_scan(fsum::stretch& st) {
+    scan_step<0x111, 0xf>(st); scan_step<0x112, 0xf>(st); scan_step<0x114, 0xf>(st); scan_step<0x118, 0xf>(st);
+    scan_step<0x142, 0xa>(st); scan_step<0x143, 0xc>(st);
+}
+// monotone chains (addends >= 0 on a positive sum): the floor offsets never go below 0 and the greatest result offset is the last
+// one, so a map is its two result offsets and applies iff k + d[k & 1] < 2^24. A map that must not apply carries D_SAT.
+struct mono { int32_t d[2]; };
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ void scan_step(mono& st) {
+    const int32_t f0 = dpp_mov<CTRL, ROW_MASK>(0, st.d[0]), f1 = dpp_mov<CTRL, ROW_MASK>(0, st.d[1]);
+    const int32_t g0 = (f0 & 1) ? st.d[1] : st.d[0], g1 = (f1 & 1) ? st.d[0] : st.d[1];
+    st.d[0] = fsum::sat_add(f0, g0); st.d[1] = fsum::sat_add(f1, g1);
+}
+__device__ __forceinline__ void wave_scan(mono& st) {
+    scan_step<0x111, 0xf>(st); scan_step<0x112, 0xf>(st); scan_step<0x114, 0xf>(st); scan_step<0x118, 0xf>(st);
+    scan_step<0x142, 0xa>(st); scan_step<0x143, 0xc>(st);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(64) void k_wide_walk(const uint32_t* __restrict__ keys, const uint64_t* __restrict__ w64, const uint2* __restrict__ pk,
+                                                  const uint8_t* __restrict__ side, const tsvq_wide_node* __restrict__ nodes,
+                                                  tsvq_wide_ctrl* __restrict__ ctrl, void* ws_base, uint32_t tb) {
+    constexpr int NCH = mode_traits<MODE>::NCH;
+    constexpr bool MONO = MODE != WM_COV;
+    __shared__ __align__(16) float s_add[2][WB];
+    const wide_ws ws = carve(ws_base, tb);
+    const uint32_t ni = blockIdx.x / NCH;
+    const int c = (int)(blockIdx.x % NCH);
+    if (ctrl[ni].done) return;
+    const tsvq_wide_node& nd = nodes[ni];
+    const int lane = threadIdx.x;
+    // what the chain adds, per member: everything about the chain is uniform over the wave
+    int cx = 0, cy = 0;
+    if (MODE == WM_COV) cov_xy(c, cx, cy); else cx = c & 15;
+    const float ox = nd.origin[cx], oy = nd.origin[cy];
+    const bool chain_right = (c >> 4) != 0;
+    uint32_t s = 0;          // +0.0f
+    walk_window cur, n1, n2;
+
+    // this lane's block of the current window against the running sum s: 0 = identity (all addends zero / past the end),
+    // 1 = its map for s's binade exists (returned in st), 2 = no map for this state
+    auto pick = [&](fsum::stretch& st) -> int {
+        st = fsum::identity();
+        if (cur.ep == EP_ZERO) return 0;
+        const int cand = fsum::state_exp(s) - (int)(cur.ep & 0xffu);
+        const bool usable = cur.ep != EP_NONE && fsum::state_ok(s) && (cand == 0 || (cand == 1 && !(cur.ep & EP_SINGLE))) && (((cur.ep >> 8) & 1u) == (s >> 31));
+        if (!usable) return 2;
+        const int k = cand;
+        st.d[0] = cur.m[k][0]; st.d[1] = cur.m[k][1]; st.lo[0] = cur.m[k][2]; st.lo[1] = cur.m[k][3]; st.hi[0] = cur.m[k][4]; st.hi[1] = cur.m[k][5];
+        return 1;
+    };
+    // the addends of block `blk` (of the node) that this lane stages: members blk * 256 + r * 64 + lane
+    auto fetch_block = [&](uint32_t blk, float (&a)[4]) {
+        const uint32_t p0 = blk * WB;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const uint32_t pos = p0 + (uint32_t)(r * 64 + lane);
+            uint32_t key; float wf; bool valid;
+            fetch_packed<MODE>(keys, w64, pk, nd.start, pos, nd.count, key, wf, valid);
+            float v;
+            if (MODE == WM_COV) {
+                const float dx = (float)packed16_value(key, cx) - ox;
+                const float dy = (float)packed16_value(key, cy) - oy;
+                const float wdy = wf * dy;
+                v = dx * wdy;
+            } else {
+                v = (float)packed16_value(key, cx) * wf;
+                if (MODE == WM_PROJ || MODE == WM_DIST) { const bool right = side[nd.start + min(pos, nd.count - 1)] != 0; v = right == chain_right ? v : 0.0f; }
+            }
+            a[r] = valid ? v : 0.0f;
+        }
+    };
+
+    load_window(ws, nd.first_block, nd.n_blocks, 0, lane, c, cur);
+    load_window(ws, nd.first_block, nd.n_blocks, 64, lane, c, n1);
+    int lbuf = 0;
+    for (uint32_t b0 = 0; b0 < nd.n_blocks; b0 += 64) {
+        load_window(ws, nd.first_block, nd.n_blocks, b0 + 128, lane, c, n2);
+        int start = 0;       // lanes below are done
+        while (start < 64) {
+            fsum::stretch st;
+            int kind = pick(st);
+            if (lane < start) { kind = 0; st = fsum::identity(); }
+            const int32_t k0 = fsum::state_k(s);
+            const bool sok = fsum::state_ok(s);
+            bool ok; int32_t d_sel;
+            if (MONO) {
+                mono m;
+                m.d[0] = kind == 2 ? fsum::D_SAT : st.d[0]; m.d[1] = kind == 2 ? fsum::D_SAT : st.d[1];
+                wave_scan(m);
+                d_sel = (k0 & 1) ? m.d[1] : m.d[0];
+                // nothing added so far (zero blocks only): fine for any state, +0 included
+                ok = (m.d[0] == 0 && m.d[1] == 0) || (sok && k0 + d_sel < fsum::K_HI);
+            } else {
+                if (kind == 2) { st.lo[0] = st.lo[1] = -fsum::D_SAT; st.hi[0] = st.hi[1] = fsum::D_SAT; }
+                wave_scan(st);
+                d_sel = (k0 & 1) ? st.d[1] : st.d[0];
+                const bool ident = st.lo[0] == fsum::D_SAT && st.lo[1] == fsum::D_SAT && st.hi[0] == -fsum::D_SAT && st.hi[1] == -fsum::D_SAT;
+                if (ident) d_sel = 0;
+                ok = ident || (sok && fsum::applies(st, k0));
+            }
+            const uint64_t good = __ballot(ok);
+            const int first_fail = (~good == 0ull) ? 64 : __ffsll((long long)~good) - 1;
+            if (first_fail > 0) {
+                const int32_t d = __builtin_amdgcn_readlane(d_sel, first_fail - 1);
+                if (d != 0) s = (s & 0xff800000u) | ((uint32_t)(k0 + d) & 0x7fffffu);
+            }
+            start = first_fail;
+            if (first_fail == 64 || b0 + (uint32_t)first_fail >= nd.n_blocks) { start = 64; break; }
+            // ---- blocks added member by member, one after the other, until a block's own map applies to the sum again; the
+            //      next block's members are fetched while the current block is added
+            int j = first_fail;
+            float a[4], an[4];
+            fetch_block(b0 + (uint32_t)j, a);
+            for (;;) {
+                const bool more = j + 1 < 64 && b0 + (uint32_t)j + 1 < nd.n_blocks;
+                if (more) fetch_block(b0 + (uint32_t)j + 1, an);
+                float* buf = s_add[lbuf]; lbuf ^= 1;
+#pragma unroll
+                for (int r = 0; r < 4; r++) buf[r * 64 + lane] = a[r];
+                __syncthreads();
+                const uint32_t cnt = min((uint32_t)WB, nd.count - (b0 + (uint32_t)j) * WB);
+                float f = __uint_as_float(s);
+                const uint32_t full = cnt & ~3u;
+                for (uint32_t i = 0; i < full; i += 4) {
+                    const float4 v = *reinterpret_cast<const float4*>(&buf[i]);
+                    f = f + v.x; f = f + v.y; f = f + v.z; f = f + v.w;
+                }
+                for (uint32_t i = full; i < cnt; i++) f = f + buf[i];
+                s = __float_as_uint(f);
+                j++;
+                if (!more) break;
+                fsum::stretch t;
+                const int kd = pick(t);
+                const bool fits = kd == 0 || (kd == 1 && fsum::applies(t, fsum::state_k(s)));
+                if ((__ballot(fits) >> j) & 1ull) break;
+#pragma unroll
+                for (int r = 0; r < 4; r++) a[r] = an[r];
+            }
+            start = j;
+        }
+        cur = n1; n1 = n2;
+    }
+    if (lane == 0) ctrl[ni].sums[c] = __uint_as_float(s);
+}
+
+// ------------------------------------------------------------------------------------------------------------ k_wide_finish
+// The serial tail of a pass: what thread 0 of k_tsvq_split / k_tsvq_root does between passes.
+template <int MODE>
+__global__ __launch_bounds__(64) void k_wide_finish(const tsvq_wide_node* __restrict__ nodes, tsvq_wide_ctrl* __restrict__ ctrl, tsvq_root_out* __restrict__ root_out) {
+    if (threadIdx.x != 0) return;
+    const uint32_t ni = blockIdx.x;
+    tsvq_wide_ctrl& c = ctrl[ni];
+    if (c.done) return;
+    const tsvq_wide_node& nd = nodes[ni];
+    constexpr int N = 16;
+    if (MODE == WM_ROOT) {   // prepare_root (enc.h:1708-1735)
+        if (c.ex_bad) { root_out->pad = 1; c.done = 2; return; }
+        float o[N];
+        for (int k = 0; k < N; k++) o[k] = c.sums[k];
+        const float wfl = (float)c.l_w;
+        const float q = dot_seq<N>(o, o) / wfl;
+        root_out->var = (float)(c.dsum[0] - (double)q);
+        const float inv = 1.0f / wfl;
+        for (int k = 0; k < N; k++) root_out->origin[k] = o[k] * inv;
+        root_out->weight = c.l_w;
+        root_out->pad = 0;
+        c.done = 1;
+        return;
+    }
+    if (MODE == WM_COV) {    // compute_split_axis (enc.h:1802-1846)
+        float cov[16][16];
+        int ch = 0;
+        for (int x = 0; x < N; x++) for (int y = x; y < N; y++) cov[x][y] = c.sums[ch++];
+        const float renorm = 1.0f / (float)nd.weight;
+        for (int x = 0; x < N; x++) for (int y = x; y < N; y++) cov[x][y] *= renorm;
+        for (int x = 0; x < N - 1; x++) for (int y = x + 1; y < N; y++) cov[y][x] = cov[x][y];
+        principal_axis<N>(cov, c.axis);
+        return;
+    }
+    if (c.ex_bad) { c.done = 2; return; }
+    if (MODE == WM_PROJ) {   // prep_split (enc.h:1887-1891); the degenerate projection (:1893-1957) is left to the one-workgroup kernel
+        const double lw = c.dsum[0], rw = c.dsum[1];
+        if (!(lw > 0.0 && rw > 0.0)) { c.done = 2; return; }
+        const float ls = (float)(1.0 / lw), rs = (float)(1.0 / rw);
+        for (int k = 0; k < N; k++) { c.l_c[k] = c.sums[k] * ls; c.r_c[k] = c.sums[N + k] * rs; }
+        c.prev_total = 1e+10f; c.iter = 0;
+        return;
+    }
+    // refine_split (enc.h:2047-2073); an empty child (:2008) is left to the one-workgroup kernel
+    if (c.l_w == 0 || c.r_w == 0) { c.done = 2; return; }
+    float nl[N], nr[N];
+    for (int k = 0; k < N; k++) { nl[k] = c.sums[k]; nr[k] = c.sums[N + k]; }
+    const float lwf = (float)c.l_w, rwf = (float)c.r_w;
+    const float ql = dot_seq<N>(nl, nl) / lwf, qr = dot_seq<N>(nr, nr) / rwf;
+    c.l_var = (float)(c.dsum[0] - (double)ql);
+    c.r_var = (float)(c.dsum[1] - (double)qr);
+    const float li = 1.0f / lwf, ri = 1.0f / rwf;
+    for (int k = 0; k < N; k++) { c.l_c[k] = nl[k] * li; c.r_c[k] = nr[k] * ri; }
+    const float total = c.l_var + c.r_var;
+    bool stop = false;
+    if (total < .00001f) stop = true;
+    else {
+        const float rel = (c.prev_total - total) / total;
+        if (rel < .00125f) stop = true;
+        else c.prev_total = total;
+    }
+    c.iter++;
+    if (stop || c.iter == 6) c.done = 1;
+}
+
+// ------------------------------------------------------------------------------------------------------------ k_wide_partition
+__global__ __launch_bounds__(WB) void k_wide_partition(uint32_t* __restrict__ perm0, uint32_t* __restrict__ perm1, const uint8_t* __restrict__ side,
+                                                       const tsvq_wide_node* __restrict__ nodes, uint32_t n_nodes, const tsvq_wide_ctrl* __restrict__ ctrl,
+                                                       void* ws_base, uint32_t tb, tsvq_split_out* __restrict__ outs) {
+    __shared__ uint32_t s_wl[4];
+    const wide_ws ws = carve(ws_base, tb);
+    const int tid = threadIdx.x;
+    const uint32_t blk = blockIdx.x;
+    const uint32_t ni = find_node(nodes, n_nodes, blk);
+    const tsvq_wide_ctrl& c = ctrl[ni];
+    const tsvq_wide_node& nd = nodes[ni];
+    if (blk == nd.first_block && tid == 0) {
+        tsvq_split_out* out = outs + nd.out_index;
+        if (c.done == 1) {
+            out->ok = 1; out->l_count = c.l_n; out->r_count = c.r_n; out->l_weight = c.l_w; out->r_weight = c.r_w;
+            out->l_var = c.l_var; out->r_var = c.r_var;
+            for (int k = 0; k < 16; k++) { out->l_centroid[k] = c.l_c[k]; out->r_centroid[k] = c.r_c[k]; }
+        } else out->ok = 2;   // run this node through the one-workgroup kernel
+    }
+    if (c.done != 1) return;
+    const uint32_t* members = (nd.buf ? perm1 : perm0) + nd.start;
+    uint32_t* child = (nd.buf ? perm0 : perm1) + nd.start;
+    const uint32_t pos = (blk - nd.first_block) * WB + (uint32_t)tid;
+    const bool valid = pos < nd.count;
+    const bool right = valid && side[nd.start + pos] != 0;
+    const bool left = valid && !right;
+    const uint64_t mL = __ballot(left);
+    const int lane = tid & 63, wave = tid >> 6;
+    const uint64_t below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    if (lane == 0) s_wl[wave] = (uint32_t)__popcll(mL);
+    __syncthreads();
+    uint32_t lbefore = ws.lpre[blk] + (uint32_t)__popcll(mL & below);
+    for (int w = 0; w < wave; w++) lbefore += s_wl[w];
+    if (left) child[lbefore] = members[pos];
+    if (right) child[c.l_n + (pos - lbefore)] = members[pos];
+}
+
+__global__ __launch_bounds__(256) void k_wide_iota(uint32_t n, uint32_t* __restrict__ perm0) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) perm0[i] = i;
+}
+
+} // namespace
+
+size_t tsvq_wide_workspace_bytes(uint32_t total_blocks) {
+    const size_t tb = total_blocks;
+    return align256(tb * NCH_MAX * sizeof(double)) + align256(tb * 8 * sizeof(uint64_t)) + align256(tb * NCH_MAX * 2 * 6 * sizeof(int32_t)) +
+           align256(tb * sizeof(uint32_t)) + align256(tb * NCH_MAX * sizeof(uint16_t)) + align256(tb * NCH_MAX);
+}
+
+template <int MODE>
+static void launch_pass(hipStream_t st, const uint32_t* keys, const uint64_t* w64, uint32_t* perm0, uint32_t* perm1, uint8_t* side, uint2* pk, const tsvq_wide_node* nodes,
+                        uint32_t n_nodes, uint32_t tb, tsvq_wide_ctrl* ctrl, void* ws, tsvq_root_out* root_out) {
+    constexpr int NCH = mode_traits<MODE>::NCH;
+    hipLaunchKernelGGL((k_wide_sums<MODE>), dim3(tb), dim3(WB), 0, st, keys, w64, perm0, perm1, side, nodes, n_nodes, ctrl, ws, tb, pk);
+    hipLaunchKernelGGL((k_wide_scan<MODE>), dim3(n_nodes, (NCH + 3) / 4 + (MODE == WM_COV ? 0 : 1)), dim3(256), 0, st, nodes, ctrl, ws, tb);
+    hipLaunchKernelGGL((k_wide_stretches<MODE>), dim3(tb), dim3(WB), 0, st, keys, w64, pk, side, nodes, n_nodes, ctrl, ws, tb);
+    hipLaunchKernelGGL((k_wide_walk<MODE>), dim3(n_nodes * NCH), dim3(64), 0, st, keys, w64, pk, side, nodes, ctrl, ws, tb);
+    hipLaunchKernelGGL((k_wide_finish<MODE>), dim3(n_nodes), dim3(64), 0, st, nodes, ctrl, root_out);
+}
+
+hipError_t launch_tsvq_wide_root(hipStream_t st, const uint32_t* d_keys, const uint64_t* d_w64, uint32_t n, uint32_t* d_perm0, const tsvq_wide_node* d_nodes,
+                                 tsvq_wide_ctrl* d_ctrl, void* d_ws, uint32_t total_blocks, tsvq_root_out* d_out) {
+    hipError_t e = hipMemsetAsync(d_ctrl, 0, sizeof(tsvq_wide_ctrl), st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_wide_iota, dim3((n + 255) / 256), dim3(256), 0, st, n, d_perm0);
+    launch_pass<WM_ROOT>(st, d_keys, d_w64, nullptr, nullptr, nullptr, nullptr, d_nodes, 1, total_blocks, d_ctrl, d_ws, d_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_tsvq_wide_split(hipStream_t st, const uint32_t* d_keys, const uint64_t* d_w64, uint32_t* d_perm0, uint32_t* d_perm1, uint8_t* d_side, void* d_packed,
+                                  const tsvq_wide_node* d_nodes, uint32_t n_nodes, tsvq_wide_ctrl* d_ctrl, void* d_ws, uint32_t total_blocks, tsvq_split_out* d_outs) {
+    if (!n_nodes) return hipSuccess;
+    hipError_t e = hipMemsetAsync(d_ctrl, 0, (size_t)n_nodes * sizeof(tsvq_wide_ctrl), st);
+    if (e != hipSuccess) return e;
+    launch_pass<WM_COV>(st, d_keys, d_w64, d_perm0, d_perm1, d_side, static_cast<uint2*>(d_packed), d_nodes, n_nodes, total_blocks, d_ctrl, d_ws, nullptr);
+    launch_pass<WM_PROJ>(st, d_keys, d_w64, d_perm0, d_perm1, d_side, static_cast<uint2*>(d_packed), d_nodes, n_nodes, total_blocks, d_ctrl, d_ws, nullptr);
+    for (int it = 0; it < 6; it++) launch_pass<WM_DIST>(st, d_keys, d_w64, d_perm0, d_perm1, d_side, static_cast<uint2*>(d_packed), d_nodes, n_nodes, total_blocks, d_ctrl, d_ws, nullptr);
+    hipLaunchKernelGGL(k_wide_partition, dim3(total_blocks), dim3(WB), 0, st, d_perm0, d_perm1, d_side, d_nodes, n_nodes, d_ctrl, d_ws, total_blocks, d_outs);
+    return hipGetLastError();
+}
+
+} // namespace bu

@@ -448,6 +448,28 @@ def uastc_host():
     return _uastc_host
 
 
+_fsum_host = None
+
+
+def fsum_host():
+    """csrc/fsum_scan.h (the order-preserving float sum of the wide TSVQ kernels) compiled for the host: tests/native/fsum_host.cpp."""
+    global _fsum_host
+    if _fsum_host is None:
+        d = ROOT / "tests" / "native"
+        so, srcs = d / "libfsum_host.so", [d / "fsum_host.cpp", ROOT / "basis_universal_amd" / "csrc" / "fsum_scan.h"]
+        if not so.exists() or so.stat().st_mtime < max(s.stat().st_mtime for s in srcs):
+            subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-o", str(so), str(srcs[0])])
+        L = C.CDLL(str(so))
+        L.fsum_sequential.restype = C.c_float
+        L.fsum_sequential.argtypes = [f32p, C.c_uint64, C.c_float]
+        L.fsum_blocked.restype = C.c_float
+        L.fsum_blocked.argtypes = [f32p, C.c_uint64, C.c_float, C.c_uint32, u64p]
+        L.fsum_compose_check.restype = C.c_int
+        L.fsum_compose_check.argtypes = [f32p, C.c_uint64, C.c_int, C.c_int, C.c_uint32]
+        _fsum_host = L
+    return _fsum_host
+
+
 def host_encode_uastc(blocks, flags):
     blocks = np.ascontiguousarray(blocks)
     n = blocks.shape[0]

@@ -179,8 +179,6 @@ def test_compress_matches_reference_command_line(hip_ctx, tmp_path, name, kw, cl
 
 
 @needs_ref
-@pytest.mark.xfail(strict=False, reason="the frontend's video-mode stage order was added after round 1's GPU budget was spent (the stages themselves are covered "
-                                        "at levels 4-6); the backend's video coding is pinned on the CPU (tests/test_backend_host.py)")
 @pytest.mark.parametrize("level", [1, 2])
 def test_video_clip_matches_reference(hip_ctx, level):
     """cBASISTexTypeVideoFrames end to end: resident frontend in video mode + backend with conditional replenishment vs the reference pair."""

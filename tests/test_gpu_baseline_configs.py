@@ -1,0 +1,66 @@
+"""-m gpu: BASELINE.json's own configurations at FULL size against the reference, through committed goldens (tools/gen_golden_big.py ran
+the real reference -- oracle/_ref, single-threaded = the pinned configuration -- in the build container; the GPU box has no
+/root/reference and could not afford its minutes anyway):
+
+  configs[0]  kodim03.png 768x512 ETC1S -q128            pixels + the reference TOOL's .basis / .ktx2 bytes in tests/golden/kodim03.npz
+  configs[1]  4096x4096 synthetic RGBA (seed 1234) -q128  frontend state digests + backend payload digests
+  configs[3]  8192x8192 synthetic RGBA (seed 5678) -q255  the same, at the 8192 / 16128 cluster codebooks no smaller test reaches
+
+Everything compared is integer data; the comparison is exact."""
+import hashlib
+import json
+import pathlib
+
+import numpy as np
+import pytest
+
+from helpers import synth, to_pixel_blocks
+import test_gpu_etc1s_frontend as T
+
+pytestmark = pytest.mark.gpu
+GOLDEN = json.loads((pathlib.Path(__file__).parent / "golden" / "etc1s_big_digests.json").read_text())
+KODIM03 = pathlib.Path(__file__).parent / "golden" / "kodim03.npz"
+
+
+def _frontend_and_backend(hip_ctx, img, g):
+    from basis_universal_amd.etc1s import Etc1sFrontend, quality_to_clusters
+    from basis_universal_amd.backend import Etc1sBackend
+    blocks = to_pixel_blocks(img)
+    assert quality_to_clusters(g["quality"], blocks.shape[0]) == (g["max_endpoint_clusters"], g["max_selector_clusters"])
+    fe = Etc1sFrontend(hip_ctx)
+    fe.init(blocks, g["max_endpoint_clusters"], g["max_selector_clusters"], g["level"], g["perceptual"])
+    fe.compress()
+    got = T._digest({k: fe.get(k) for k in T.STATE})
+    assert got == g["frontend_digests"], {k: (got[k][:12], g["frontend_digests"][k][:12]) for k in got if got[k] != g["frontend_digests"][k]}
+    b = g["backend"]
+    be = Etc1sBackend.from_frontend(fe, [tuple(s) for s in b["slices"]], b["thresholds"][0], b["thresholds"][1], g["level"])
+    assert be.encode() == b["compressed_bytes"]
+    dg = {k: hashlib.sha256(np.ascontiguousarray(be.get(k)).tobytes()).hexdigest() for k in b["digests"]}
+    assert dg == b["digests"]
+    return fe, be
+
+
+def test_config1_synth4096_q128(hip_ctx):
+    fe, be = _frontend_and_backend(hip_ctx, synth(4096, 4096, 1234), GOLDEN["synth4096_q128"])
+    be.close(); fe.close()
+
+
+def test_config3_synth8192_q255(hip_ctx):
+    g = GOLDEN["synth8192_q255"]
+    assert (g["max_endpoint_clusters"], g["max_selector_clusters"]) == (8192, 16128)   # comp.cpp:3325-3379
+    fe, be = _frontend_and_backend(hip_ctx, synth(8192, 8192, 5678), g)
+    be.close(); fe.close()
+
+
+def test_config0_kodim03_q128_file_equals_the_reference_tools(hip_ctx):
+    """the row of the reference's own golden table (basisu_tool.cpp:6751), held to the bytes instead of its 4.5 % / 0.3 dB tolerance"""
+    from helpers import basis_file_key_values, ktx2_file_key_values
+    z = np.load(KODIM03)
+    img = np.ascontiguousarray(z["rgba"])
+    assert img.shape == (512, 768, 4)
+    fe, be = _frontend_and_backend(hip_ctx, img, GOLDEN["kodim03_q128"])
+    mine = be.basis_file(key_values=basis_file_key_values(z["tool_basis"]))
+    assert mine.shape == z["tool_basis"].shape and (mine == z["tool_basis"]).all()
+    mine2 = be.ktx2_file(key_values=ktx2_file_key_values(z["tool_ktx2"]))
+    assert mine2.shape == z["tool_ktx2"].shape and (mine2 == z["tool_ktx2"]).all()
+    be.close(); fe.close()

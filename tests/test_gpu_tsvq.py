@@ -97,3 +97,51 @@ def test_root_record_is_reproducible(hip_ctx, mode):
     # so only the weight is checked in closed form)
     rec = np.frombuffer(next(iter(seen)), np.uint32)
     assert int(rec[16]) | (int(rec[17]) << 32) == int(w.sum())
+
+
+WIDE_CASES = [(5000, 300, 32, "sel", 50, 512), (120000, 2731, 32, "sel", 4096, 512), (120000, 2731, 32, "sel", 4096, 16384), (30000, 900, 16, "sel_skewed", 4096, 512),
+              (700000, 2731, 32, "sel", 400, 16384), (60000, 500, 16, "sel", 1, 2048),
+              # weights around 2^50 / 2^44: the wide path must hand the nodes whose integer totals leave the exact range back to the chained kernel
+              (20000, 600, 16, "sel", 2 ** 50, 512), (3000, 200, 8, "sel", 2 ** 44, 512)]
+
+
+@pytest.mark.parametrize("n,k,p,kind,wmax,wide_min", WIDE_CASES)
+def test_wide_nodes_match_host_tsvq(hip_ctx, monkeypatch, n, k, p, kind, wmax, wide_min):
+    """Large nodes spread over many workgroups (tsvq_wide_kernels.hip: order-preserving float sums through per-block parity maps) must
+    give the tree of the sequential sums, member list for member list: against the host restatement tsvq.h (pinned to the reference in
+    tests/test_host_logic.py), against the one-workgroup kernels (BU_TSVQ_WIDE=0), and against the reference itself where present."""
+    from basis_universal_amd import etc1s
+    F = etc1s.load_frontend_library()
+    rng = np.random.default_rng(n * 3 + k + wide_min)
+    if kind == "sel" and n > 200000:   # dense sampling of 4^16 patterns around a few hundred centres, like a real selector training set
+        base = rng.integers(0, 4, (400, 16))
+        v = np.clip(base[rng.integers(0, 400, n)] + (rng.random((n, 16)) < 0.25) * rng.integers(-1, 2, (n, 16)), 0, 3).astype(np.float32)
+        v = np.ascontiguousarray(np.unique(v, axis=0))
+    else:
+        v = _data(kind, 16, n, rng)
+    n = v.shape[0]
+    w = rng.integers(1, wmax + 1, n).astype(np.uint64)
+    if kind == "sel_skewed":
+        w[rng.integers(0, n, 5)] = 3_000_000_000
+    cap = 4 * n + 4 * k + 100
+    outs = {}
+    for name, env in (("wide", {"BU_TSVQ_WIDE_MIN": str(wide_min)}), ("narrow", {"BU_TSVQ_WIDE": "0"})):
+        if name == "narrow" and n > 200000:
+            continue
+        for key in ("BU_TSVQ_WIDE_MIN", "BU_TSVQ_WIDE"):
+            monkeypatch.delenv(key, raising=False)
+        for key, val in env.items():
+            monkeypatch.setenv(key, val)
+        a = np.zeros(cap, np.uint32); b = np.zeros(cap, np.uint32); st = np.array([0xBACCED, 0, 0], np.uint32)
+        assert F.bu_device_tsvq(hip_ctx.h, 16, v.ctypes.data_as(VP), w.ctypes.data_as(VP), n, k, p, a.ctypes.data_as(VP), cap, b.ctypes.data_as(VP), cap,
+                                st.ctypes.data_as(VP)) == 1
+        outs[name] = (a, b)
+    a1 = np.zeros(cap, np.uint32); b1 = np.zeros(cap, np.uint32)
+    assert F.bu_host_tsvq(16, v.ctypes.data_as(VP), w.ctypes.data_as(VP), n, k, p, a1.ctypes.data_as(VP), cap, b1.ctypes.data_as(VP), cap) == 1
+    for name, (a, b) in outs.items():
+        assert (a1 == a).all(), f"{name}: codebook differs from the host tree (leaves host {a1[0]} device {a[0]})"
+        assert (b1 == b).all(), f"{name}: parent codebook differs"
+    if have_ref() and n <= 200000:
+        a3 = np.zeros(cap, np.uint32); b3 = np.zeros(cap, np.uint32)
+        assert ref().ref_tsvq(16, ptr(v, f32p), ptr(w, u64p), n, k, p, 0, ptr(a3, u32p), cap, ptr(b3, u32p), cap) == 1
+        assert (a3 == outs["wide"][0]).all() and (b3 == outs["wide"][1]).all()

@@ -1,0 +1,90 @@
+#!/usr/bin/env python3
+"""Golden digests of the REAL reference (oracle/_ref: basisu_frontend::compress + basisu_backend::encode, single-threaded = the pinned
+configuration, SURVEY hazard H1) for BASELINE.json's full-size configurations, which the reference needs minutes for and the GPU box
+cannot run (no /root/reference there, and its build of oracle/_ref would take the CPU baseline's time budget):
+
+  synth4096_q128   configs[1]: 4096x4096 synthetic RGBA, seed 1234, -q 128 (2416 / 2731 clusters), CLI level 1
+  synth8192_q255   configs[3]: 8192x8192 synthetic RGBA, seed 5678, -q 255 (8192 / 16128 clusters), CLI level 1
+  kodim03_q128     configs[0]: kodim03.png 768x512, -q 128, CLI level 1; the image itself is written to tests/golden/kodim03.npz so the
+                   GPU box has the pixels (a test fixture of the reference, basisu_tool.cpp:6751)
+
+-> tests/golden/etc1s_big_digests.json (frontend state digests as tests/test_gpu_etc1s_frontend.py computes them + the backend payload
+digests of tools/gen_golden_backend.py). Run in the build container; takes ~10-20 minutes for the 8192^2 case.
+usage: gen_golden_big.py [case ...]   (merges into the existing JSON)"""
+import hashlib
+import json
+import pathlib
+import sys
+import time
+
+import numpy as np
+
+ROOT = pathlib.Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT / "tests"))
+sys.path.insert(0, str(ROOT))
+import helpers  # noqa: E402
+import test_gpu_etc1s_frontend as T  # noqa: E402
+from basis_universal_amd.etc1s import quality_to_clusters  # noqa: E402
+
+OUT = ROOT / "tests" / "golden" / "etc1s_big_digests.json"
+PAYLOAD = ("endpoint_palette", "selector_palette", "slice_image_tables", "slice_image_data", "slice_image_crcs")
+
+
+def kodim03():
+    """the pixels + the file the reference TOOL writes for them (`basisu -etc1s -q 128 -comp_level 1`, single-threaded): the GPU box has neither"""
+    png = helpers.REF_DIR / "test_files" / "kodim03.png"
+    img = helpers.load_png(png)
+    basis = helpers.run_ref_cli(png, "-etc1s", "-q", "128", "-comp_level", "1")
+    ktx2 = helpers.run_ref_cli(png, "-etc1s", "-q", "128", "-comp_level", "1", ktx2=True)
+    np.savez_compressed(ROOT / "tests" / "golden" / "kodim03.npz", rgba=img, tool_basis=basis, tool_ktx2=ktx2)
+    return img
+
+
+CASES = {
+    "kodim03_q128": (kodim03, 128),
+    "synth4096_q128": (lambda: helpers.synth(4096, 4096, 1234), 128),
+    "synth8192_q255": (lambda: helpers.synth(8192, 8192, 5678), 255),
+}
+
+
+def main():
+    want = sys.argv[1:] or list(CASES)
+    out = json.loads(OUT.read_text()) if OUT.exists() else {}
+    for case in want:
+        img_fn, quality = CASES[case]
+        img = img_fn()
+        h, w = img.shape[:2]
+        blocks = helpers.to_pixel_blocks(img)
+        max_ep, max_sel = quality_to_clusters(quality, blocks.shape[0])
+        t0 = time.time()
+        fe = helpers.RefFrontend(blocks, max_ep, max_sel, 1, True)
+        fe.call("compress")
+        t1 = time.time()
+        st = {k: fe.get(k) for k in T.STATE}
+        nbx, nby = (w + 3) // 4, (h + 3) // 4
+        total, _ = fe.backend_run([(0, nbx, nby)], *helpers_backend_thresholds(quality))
+        t2 = time.time()
+        out[case] = {
+            "width": w, "height": h, "quality": quality, "level": 1, "perceptual": True, "n_blocks": int(blocks.shape[0]),
+            "max_endpoint_clusters": max_ep, "max_selector_clusters": max_sel,
+            "final_endpoint_clusters": int(st["endpoint_clusters"].view(np.uint32)[0]),
+            "final_selector_clusters": int(st["selector_cluster_block_indices"].view(np.uint32)[0]),
+            "frontend_digests": T._digest(st),
+            "backend": {"slices": [[0, nbx, nby]], "thresholds": list(helpers_backend_thresholds(quality)), "compressed_bytes": int(total),
+                        "digests": {k: hashlib.sha256(np.ascontiguousarray(fe.backend_get(k)).tobytes()).hexdigest() for k in PAYLOAD}},
+            "reference_seconds": {"frontend": round(t1 - t0, 2), "backend": round(t2 - t1, 2)},
+        }
+        fe.close()
+        print(case, out[case]["final_endpoint_clusters"], out[case]["final_selector_clusters"], total, out[case]["reference_seconds"], flush=True)
+        OUT.write_text(json.dumps(out, indent=1, sort_keys=True) + "\n")
+
+
+def helpers_backend_thresholds(quality):
+    """basis_compressor's quality-dependent RDO thresholds (comp.cpp:3381-3420), through our mirror (pinned to the reference in the CPU suite)."""
+    from basis_universal_amd.backend import default_params
+    p = default_params(quality)
+    return float(p[0]), float(p[1])
+
+
+if __name__ == "__main__":
+    main()
