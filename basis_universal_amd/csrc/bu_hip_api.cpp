@@ -558,6 +558,7 @@ struct bu_tsvq {
     // Nodes with at least wide_min members go through the many-workgroup path (tsvq_wide_kernels.hip; packed rows only).
     // BU_TSVQ_WIDE_MIN overrides the threshold, BU_TSVQ_WIDE=0 switches the path off (tests compare both).
     uint32_t wide_min = 0;      // 0: off
+    uint32_t wide_cov_min = 0;  // batches whose largest node is smaller run the covariance pass chained (BU_TSVQ_WIDE_COV_MIN)
     uint32_t wide_blocks_cap = 0, wide_nodes_cap = 0;
     void* wide_ws = nullptr; void* wide_packed = nullptr; bu::tsvq_wide_node* wide_nodes = nullptr; bu::tsvq_wide_ctrl* wide_ctrl = nullptr;
     // Pinned staging for the per-round node / result records: hipMemcpyAsync on PAGEABLE host memory followed directly by a
@@ -615,11 +616,13 @@ static bu_tsvq* tsvq_create_common(bu_hip_context* ctx, uint32_t dim, bool packe
     if (!q->rows || !q->w64 || !q->perm[0] || !q->perm[1] || !q->side || !q->nodes.p || !q->outs.p) return fail("allocation");
     q->nodes.cap = q->outs.cap = rec_cap;
     if (packed && !q->force_chained) {
-        uint32_t wide_min = 4096;
+        uint32_t wide_min = 16384;
         if (const char* e = std::getenv("BU_TSVQ_WIDE_MIN")) { const long v = std::atol(e); if (v >= 512 && v <= (1l << 30)) wide_min = (uint32_t)v; }
         if (const char* e = std::getenv("BU_TSVQ_WIDE")) if (std::atoi(e) == 0) wide_min = 0;
         if (wide_min && n >= wide_min && n < (1u << 22)) {   // above 2^22 members the binade prediction loses its margin; the chained kernel takes those
             q->wide_min = wide_min;
+            q->wide_cov_min = 98304;
+            if (const char* e = std::getenv("BU_TSVQ_WIDE_COV_MIN")) { const long v = std::atol(e); if (v >= 0 && v <= (1l << 30)) q->wide_cov_min = (uint32_t)v; }
             q->wide_nodes_cap = n / wide_min + 1;
             q->wide_blocks_cap = (n + 255) / 256 + q->wide_nodes_cap;
             q->wide_ws = bu_hip_malloc(ctx, bu::tsvq_wide_workspace_bytes(q->wide_blocks_cap));
@@ -723,12 +726,12 @@ int bu_hip_tsvq_split(bu_hip_context* ctx, bu_tsvq* q, const bu_tsvq_node* h_nod
     // Large nodes go through the many-workgroup path, the rest one workgroup each; both write one result array
     // (narrow records first, in batch order, then the wide ones).
     std::vector<uint32_t> order; order.reserve(n_nodes);
-    uint32_t n_wide = 0, wide_blocks = 0;
+    uint32_t n_wide = 0, wide_blocks = 0, wide_max_count = 0;
     if (q->wide_min) {
         std::vector<uint32_t> wide;
         for (uint32_t i = 0; i < n_nodes; i++) {
             const uint32_t nb = (h_nodes[i].count + 255) / 256;
-            if (h_nodes[i].count >= q->wide_min && wide.size() < q->wide_nodes_cap && wide_blocks + nb <= q->wide_blocks_cap) { wide.push_back(i); wide_blocks += nb; }
+            if (h_nodes[i].count >= q->wide_min && wide.size() < q->wide_nodes_cap && wide_blocks + nb <= q->wide_blocks_cap) { wide.push_back(i); wide_blocks += nb; wide_max_count = std::max(wide_max_count, h_nodes[i].count); }
             else order.push_back(i);
         }
         n_wide = (uint32_t)wide.size();
@@ -758,7 +761,7 @@ int bu_hip_tsvq_split(bu_hip_context* ctx, bu_tsvq* q, const bu_tsvq_node* h_nod
     if (n_wide) {
         prof_scope ps(ctx, "tsvq_split_packed16_wide");
         BU_TRY(ctx, bu::launch_tsvq_wide_split(ctx->stream, static_cast<const uint32_t*>(q->rows), q->w64, q->perm[0], q->perm[1], q->side, q->wide_packed, q->wide_nodes, n_wide, q->wide_ctrl,
-                                               q->wide_ws, wide_blocks, static_cast<bu::tsvq_split_out*>(q->outs.p)));
+                                               q->wide_ws, wide_blocks, static_cast<bu::tsvq_split_out*>(q->outs.p), wide_max_count < q->wide_cov_min));
     }
     if (n_narrow) {
         prof_scope ps(ctx, q->packed ? "tsvq_split_packed16" : "tsvq_split_float6");

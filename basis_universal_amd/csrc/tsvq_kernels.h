@@ -33,10 +33,14 @@ struct tsvq_wide_ctrl {   // device-side state of one node across the passes of 
     int32_t iter, done;
     uint32_t ex_bad;
 };
+// covariance + principal axis of every node (one workgroup each, chained sums) into d_ctrl[i].axis; fills d_packed for the nodes' members
+hipError_t launch_tsvq_cov_axis(hipStream_t st, const uint32_t* d_keys, const uint64_t* d_w64, const uint32_t* d_perm0, const uint32_t* d_perm1,
+                                const tsvq_wide_node* d_nodes, uint32_t n_nodes, tsvq_wide_ctrl* d_ctrl, void* d_packed);
 size_t tsvq_wide_workspace_bytes(uint32_t total_blocks);           // total_blocks = sum over the batch's nodes of ceil(count / 256)
 hipError_t launch_tsvq_wide_root(hipStream_t st, const uint32_t* d_keys, const uint64_t* d_w64, uint32_t n, uint32_t* d_perm0 /* out: 0..n-1 */,
                                  const tsvq_wide_node* d_nodes /* one node: all n vectors */, tsvq_wide_ctrl* d_ctrl, void* d_ws, uint32_t total_blocks, tsvq_root_out* d_out);
 hipError_t launch_tsvq_wide_split(hipStream_t st, const uint32_t* d_keys, const uint64_t* d_w64, uint32_t* d_perm0, uint32_t* d_perm1, uint8_t* d_side, void* d_packed /* 8 bytes per vector */,
-                                  const tsvq_wide_node* d_nodes, uint32_t n_nodes, tsvq_wide_ctrl* d_ctrl, void* d_ws, uint32_t total_blocks, tsvq_split_out* d_outs);
+                                  const tsvq_wide_node* d_nodes, uint32_t n_nodes, tsvq_wide_ctrl* d_ctrl, void* d_ws, uint32_t total_blocks, tsvq_split_out* d_outs,
+                                  bool chained_covariance /* the covariance pass through launch_tsvq_cov_axis instead of 136 walks per node */);
 
 } // namespace bu

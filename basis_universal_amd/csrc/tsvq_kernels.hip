@@ -608,6 +608,51 @@ __global__ __launch_bounds__(TQ_THREADS) void k_tsvq_split(Src src, const uint64
     }
 }
 
+// The covariance pass + principal axis of split_node on its own, one workgroup per node, chained sums: the many-workgroup path
+// (tsvq_wide_kernels.hip) uses it for nodes where 136 order-preserving walks cost more than one pass of dependent adds. Also lays
+// the members out in list order (key, float weight) for the passes that follow.
+__global__ __launch_bounds__(TQ_THREADS) void k_tsvq_cov_axis(packed16_rows src, const uint64_t* __restrict__ w64, const uint32_t* __restrict__ perm0,
+                                                             const uint32_t* __restrict__ perm1, const tsvq_wide_node* __restrict__ nodes,
+                                                             tsvq_wide_ctrl* __restrict__ ctrl, uint2* __restrict__ pk) {
+    constexpr int N = 16;
+    extern __shared__ __align__(16) char lds[];
+    __shared__ float s_origin[16];
+    __shared__ float s_cov[16][16];
+    const int tid = threadIdx.x;
+    const tsvq_wide_node nd = nodes[blockIdx.x];
+    const uint32_t* members = (nd.buf ? perm1 : perm0) + nd.start;
+    if (tid < 16) s_origin[tid] = nd.origin[tid];
+    __syncthreads();
+    constexpr int C = N * (N + 1) / 2;
+    constexpr int CW = (C + 63) / 64;
+    int cx = 0, cy = 0;
+    if (tid < C) { int cc = tid; while (cc >= N - cx) { cc -= N - cx; cx++; } cy = cx + cc; }
+    float cv = 0.0f;
+    pipeline_pass<2 * N, 0, CW>(lds, src, w64, members, nd.count,
+        [&](uint32_t pos, const packed16_rows::payload& p, float* f, double*) {
+            float v[N]; packed16_rows::decode(p, v);
+            const float w = (float)p.w;
+            pk[nd.start + pos] = make_uint2(p.key, __float_as_uint(w));
+#pragma unroll
+            for (int k = 0; k < N; k++) {
+                const float dk = v[k] - s_origin[k];
+                f[(size_t)k * TQ_STRIDE] = dk;
+                f[(size_t)(N + k) * TQ_STRIDE] = w * dk;
+            }
+        },
+        [&](const float* f, const double*, uint32_t m) {
+            if (tid < C) chain_add_prod_f32(cv, f + (size_t)cx * TQ_STRIDE, f + (size_t)(N + cy) * TQ_STRIDE, m);
+        });
+    if (tid < C) s_cov[cx][cy] = cv;
+    __syncthreads();
+    if (tid == 0) {
+        const float renorm = 1.0f / (float)nd.weight;
+        for (int x = 0; x < N; x++) for (int y = x; y < N; y++) s_cov[x][y] *= renorm;
+        for (int x = 0; x < N - 1; x++) for (int y = x + 1; y < N; y++) s_cov[y][x] = s_cov[x][y];
+        principal_axis<N>(s_cov, ctrl[blockIdx.x].axis);
+    }
+}
+
 // -------------------------------------------------------------------------------------------------------------------
 
 static size_t tsvq_lds_bytes(int n) {
@@ -619,6 +664,16 @@ static size_t tsvq_lds_bytes(int n) {
 
 template <typename K> static hipError_t set_lds(K kernel, size_t lds) {
     return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+}
+
+hipError_t launch_tsvq_cov_axis(hipStream_t st, const uint32_t* d_keys, const uint64_t* d_w64, const uint32_t* d_perm0, const uint32_t* d_perm1,
+                                const tsvq_wide_node* d_nodes, uint32_t n_nodes, tsvq_wide_ctrl* d_ctrl, void* d_packed) {
+    if (!n_nodes) return hipSuccess;
+    const size_t lds = tsvq_lds_bytes(16);
+    hipError_t e = set_lds(k_tsvq_cov_axis, lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_tsvq_cov_axis, dim3(n_nodes), dim3(TQ_THREADS), lds, st, packed16_rows{d_keys}, d_w64, d_perm0, d_perm1, d_nodes, d_ctrl, static_cast<uint2*>(d_packed));
+    return hipGetLastError();
 }
 
 hipError_t launch_tsvq_root(hipStream_t st, int dim, bool packed, bool exact, const void* d_rows, const uint64_t* d_w64, uint32_t n, uint32_t* d_perm0, tsvq_root_out* d_out) {

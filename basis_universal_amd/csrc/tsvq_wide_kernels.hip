@@ -706,11 +706,13 @@ hipError_t launch_tsvq_wide_root(hipStream_t st, const uint32_t* d_keys, const u
 }
 
 hipError_t launch_tsvq_wide_split(hipStream_t st, const uint32_t* d_keys, const uint64_t* d_w64, uint32_t* d_perm0, uint32_t* d_perm1, uint8_t* d_side, void* d_packed,
-                                  const tsvq_wide_node* d_nodes, uint32_t n_nodes, tsvq_wide_ctrl* d_ctrl, void* d_ws, uint32_t total_blocks, tsvq_split_out* d_outs) {
+                                  const tsvq_wide_node* d_nodes, uint32_t n_nodes, tsvq_wide_ctrl* d_ctrl, void* d_ws, uint32_t total_blocks, tsvq_split_out* d_outs,
+                                  bool chained_covariance) {
     if (!n_nodes) return hipSuccess;
     hipError_t e = hipMemsetAsync(d_ctrl, 0, (size_t)n_nodes * sizeof(tsvq_wide_ctrl), st);
     if (e != hipSuccess) return e;
-    launch_pass<WM_COV>(st, d_keys, d_w64, d_perm0, d_perm1, d_side, static_cast<uint2*>(d_packed), d_nodes, n_nodes, total_blocks, d_ctrl, d_ws, nullptr);
+    if (chained_covariance) { if ((e = launch_tsvq_cov_axis(st, d_keys, d_w64, d_perm0, d_perm1, d_nodes, n_nodes, d_ctrl, d_packed)) != hipSuccess) return e; }
+    else launch_pass<WM_COV>(st, d_keys, d_w64, d_perm0, d_perm1, d_side, static_cast<uint2*>(d_packed), d_nodes, n_nodes, total_blocks, d_ctrl, d_ws, nullptr);
     launch_pass<WM_PROJ>(st, d_keys, d_w64, d_perm0, d_perm1, d_side, static_cast<uint2*>(d_packed), d_nodes, n_nodes, total_blocks, d_ctrl, d_ws, nullptr);
     for (int it = 0; it < 6; it++) launch_pass<WM_DIST>(st, d_keys, d_w64, d_perm0, d_perm1, d_side, static_cast<uint2*>(d_packed), d_nodes, n_nodes, total_blocks, d_ctrl, d_ws, nullptr);
     hipLaunchKernelGGL(k_wide_partition, dim3(total_blocks), dim3(WB), 0, st, d_perm0, d_perm1, d_side, d_nodes, n_nodes, d_ctrl, d_ws, total_blocks, d_outs);

@@ -125,10 +125,12 @@ def test_wide_nodes_match_host_tsvq(hip_ctx, monkeypatch, n, k, p, kind, wmax, w
         w[rng.integers(0, n, 5)] = 3_000_000_000
     cap = 4 * n + 4 * k + 100
     outs = {}
-    for name, env in (("wide", {"BU_TSVQ_WIDE_MIN": str(wide_min)}), ("narrow", {"BU_TSVQ_WIDE": "0"})):
+    # wide: every pass through the parity maps; hybrid: the covariance pass of all but the largest nodes chained (the default)
+    for name, env in (("wide", {"BU_TSVQ_WIDE_MIN": str(wide_min), "BU_TSVQ_WIDE_COV_MIN": "0"}), ("hybrid", {"BU_TSVQ_WIDE_MIN": str(wide_min)}),
+                      ("narrow", {"BU_TSVQ_WIDE": "0"})):
         if name == "narrow" and n > 200000:
             continue
-        for key in ("BU_TSVQ_WIDE_MIN", "BU_TSVQ_WIDE"):
+        for key in ("BU_TSVQ_WIDE_MIN", "BU_TSVQ_WIDE", "BU_TSVQ_WIDE_COV_MIN"):
             monkeypatch.delenv(key, raising=False)
         for key, val in env.items():
             monkeypatch.setenv(key, val)
