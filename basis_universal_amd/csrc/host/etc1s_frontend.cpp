@@ -196,6 +196,7 @@ bool etc1s_frontend::init(const params& p) {
     if (p.m_compression_level > 6) return fail("bad compression level (0..6)");
     m_params = p;
     m_total_blocks = p.m_num_source_blocks;
+    m_source_copy.clear(); m_source_copy.shrink_to_fit();   // a host copy of device-only tiles belongs to the image it was made from
 
     if (m_dev) { m_dev->release(); delete m_dev; }
     m_dev = new device_state();

@@ -121,6 +121,21 @@ uint64_t bu_frontend_get(bu_frontend* f, const char* name, void* buf, uint64_t c
     return ~0ull;
 }
 
+int bu_frontend_reoptimize_remapped_endpoints(bu_frontend* f, const uint32_t* new_block_endpoints, uint32_t total_blocks, int32_t* old_to_new, uint32_t old_to_new_count,
+                                              int optimize_final_codebook, const uint32_t* block_selector_indices) {
+    if (!f || !new_block_endpoints || !old_to_new) return 0;
+    try {
+        const std::vector<uint32_t> nbe(new_block_endpoints, new_block_endpoints + total_blocks);
+        std::vector<uint32_t> bsi;
+        if (block_selector_indices) bsi.assign(block_selector_indices, block_selector_indices + total_blocks);
+        std::vector<int> o2n;
+        if (!f->fe.reoptimize_remapped_endpoints(nbe, o2n, optimize_final_codebook != 0, block_selector_indices ? &bsi : nullptr)) return 0;
+        if (o2n.size() != old_to_new_count) return 0;
+        for (size_t i = 0; i < o2n.size(); i++) old_to_new[i] = o2n[i];
+        return 1;
+    } catch (...) { return 0; }
+}
+
 uint32_t bu_frontend_stage_times(const bu_frontend* f, const char** names, double* seconds, uint32_t cap) {
     if (!f) return 0;
     const auto& t = f->fe.stage_times();

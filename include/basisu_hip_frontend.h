@@ -44,6 +44,10 @@ BU_HIP_API int bu_frontend_call(bu_frontend*, const char* stage, uint32_t arg);
 /* Serialise one piece of state into buf (returns bytes needed; copies only if cap suffices; ~0 = unknown name).
  * Names and formats match oracle/ref_harness.cpp::ref_frontend_get so both sides can be diffed directly. */
 BU_HIP_API uint64_t bu_frontend_get(bu_frontend*, const char* name, void* buf, uint64_t cap);
+/* basisu_frontend::reoptimize_remapped_endpoints (frontend.cpp:2996-3220), what a backend calls at compression levels above 1:
+ * new_block_endpoints[total blocks]; old_to_new[clusters before the call] is filled (-1: unused); block_selector_indices may be NULL. */
+BU_HIP_API int bu_frontend_reoptimize_remapped_endpoints(bu_frontend*, const uint32_t* new_block_endpoints, uint32_t total_blocks, int32_t* old_to_new,
+                                                         uint32_t old_to_new_count, int optimize_final_codebook, const uint32_t* block_selector_indices);
 BU_HIP_API const char* bu_frontend_error(const bu_frontend*);
 /* Wall seconds of each stage of the last compress(): writes up to cap entries, returns the count; names are static strings. */
 BU_HIP_API uint32_t bu_frontend_stage_times(const bu_frontend*, const char** names, double* seconds, uint32_t cap);

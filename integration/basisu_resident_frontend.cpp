@@ -1,0 +1,186 @@
+// integration/basisu_resident_frontend.cpp -- the translation unit a maintainer of the reference compiles INSTEAD OF
+// encoder/basisu_frontend.cpp to put the whole ETC1S frontend on the MI355X ("resident path"): the four member
+// functions of basisu::basisu_frontend that other translation units call (basis_compressor: init / compress / dump_debug_image,
+// comp.cpp:3441-3469; basisu_backend: reoptimize_remapped_endpoints, backend.cpp) implemented on libbasisu_frontend.so
+// (include/basisu_hip_frontend.h). After compress() the object holds exactly what the reference's own compress() leaves behind
+// for its getters (encoder/basisu_frontend.h:119-156), so basis_compressor and -- if it is kept -- the reference's basisu_backend
+// read it unchanged. This file is OURS and contains no reference code; it only includes the reference's headers.
+//
+// The tiles travel to the GPU once (bu_frontend_init uploads them); every stage of basisu_frontend::compress (frontend.cpp:159-316)
+// then runs device-resident. There is no CPU fallback behind this file: a failing device call fails compress().
+#include "encoder/basisu_frontend.h"
+
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <unordered_map>
+#include <vector>
+
+#include "basisu_resident.h"
+
+namespace {
+
+struct registry {
+    std::mutex lock;
+    std::unordered_map<const basisu::basisu_frontend*, bu_frontend*> map;
+    bu_hip_context* own_ctx = nullptr;   // used when the caller did not ask for the accelerator seam (no -opencl): the resident build always runs on the GPU
+    ~registry() {
+        for (auto& kv : map) bu_frontend_destroy(kv.second);
+        if (own_ctx) bu_hip_destroy_context(own_ctx);
+    }
+    bu_frontend* fresh(const basisu::basisu_frontend* key) {
+        std::lock_guard<std::mutex> g(lock);
+        bu_frontend*& slot = map[key];
+        if (slot) bu_frontend_destroy(slot);
+        slot = bu_frontend_create();
+        return slot;
+    }
+    bu_frontend* find(const basisu::basisu_frontend* key) {
+        std::lock_guard<std::mutex> g(lock);
+        auto it = map.find(key);
+        return it == map.end() ? nullptr : it->second;
+    }
+    bu_hip_context* context() {
+        std::lock_guard<std::mutex> g(lock);
+        if (!own_ctx) { bu_hip_init(0); own_ctx = bu_hip_create_context(); }
+        return own_ctx;
+    }
+};
+registry& reg() { static registry r; return r; }
+
+template <typename T> bool fetch(bu_frontend* f, const char* name, std::vector<T>& out) {
+    const uint64_t need = bu_frontend_get(f, name, nullptr, 0);
+    if (need == ~0ull || need % sizeof(T)) return false;
+    out.resize(need / sizeof(T));
+    return need == 0 || bu_frontend_get(f, name, out.data(), need) == need;
+}
+
+} // namespace
+
+bu_frontend* bu_resident_handle(const basisu::basisu_frontend* fe) { return reg().find(fe); }
+
+namespace basisu {
+
+// the accelerator context the reference hands around is the shim's wrapper (integration/basisu_hip_shim.cpp)
+struct opencl_context { bu_hip_context* h; };
+
+bool basisu_frontend::init(const params& p) {
+    if ((p.m_max_endpoint_clusters < 1) || (p.m_max_endpoint_clusters > cMaxEndpointClusters)) return false;
+    if ((p.m_max_selector_clusters < 1) || (p.m_max_selector_clusters > cMaxSelectorClusters)) return false;
+    if (p.m_pGlobal_codebooks) { error_printf("basisu_frontend (resident): global codebooks are not supported\n"); return false; }
+    m_params = p;
+    m_total_blocks = p.m_num_source_blocks;
+    m_total_pixels = p.m_num_source_blocks * 16;
+    m_opencl_failed = false;
+    // get_source_pixel_block (frontend.h:121) serves the backend from the frontend's own copy
+    m_source_blocks.resize(0);
+    append_vector(m_source_blocks, p.m_pSource_blocks, p.m_num_source_blocks);
+    m_encoded_blocks.resize(p.m_num_source_blocks);
+
+    bu_hip_context* ctx = p.m_pOpenCL_context ? p.m_pOpenCL_context->h : reg().context();
+    if (!ctx) { error_printf("basisu_frontend (resident): no HIP context\n"); return false; }
+    bu_frontend* f = reg().fresh(this);
+    if (!f) return false;
+    static_assert(sizeof(pixel_block) == sizeof(bu_pixel_block) && sizeof(etc_block) == sizeof(bu_etc_block), "layout");
+    bu_frontend_set_video(f, p.m_tex_type == basist::cBASISTexTypeVideoFrames);
+    if (!bu_frontend_init(f, ctx, reinterpret_cast<const bu_pixel_block*>(m_source_blocks.data()), nullptr, p.m_num_source_blocks, p.m_max_endpoint_clusters,
+                          p.m_max_selector_clusters, p.m_compression_level, p.m_perceptual)) {
+        error_printf("basisu_frontend (resident): init failed: %s\n", bu_frontend_error(f));
+        return false;
+    }
+    return true;
+}
+
+// Copies the resident frontend's state into the members the reference's getters read.
+static bool refresh_members(bu_frontend* f, uint32_t n, etc_block_vec& encoded, etc_block_vec* etc1s, basisu::vector<uint_vec>& endpoint_clusters,
+                            basisu::vector<vec2U>& block_endpoints, std::vector<uint8_t>& ep_params, basisu::vector<uint_vec>& selector_lists,
+                            basisu::vector<etc_block>& selector_blocks, basisu::vector<uint32_t>& block_selectors) {
+    std::vector<uint8_t> raw;
+    std::vector<uint32_t> u;
+    if (!fetch(f, "encoded_blocks", raw) || raw.size() != (size_t)n * 8) return false;
+    encoded.resize(n); std::memcpy(encoded.data(), raw.data(), raw.size());
+    if (etc1s) {
+        if (!fetch(f, "etc1_blocks", raw) || raw.size() != (size_t)n * 8) return false;
+        etc1s->resize(n); std::memcpy(etc1s->data(), raw.data(), raw.size());
+    }
+    if (!fetch(f, "block_endpoint_clusters_indices", u) || u.size() != n) return false;
+    block_endpoints.resize(n);
+    for (uint32_t i = 0; i < n; i++) { block_endpoints[i][0] = u[i]; block_endpoints[i][1] = u[i]; }
+    if (!fetch(f, "endpoint_cluster_etc_params", ep_params) || ep_params.size() % 16) return false;
+    // the lists themselves (training-vector ids 2b, 2b+1 in block order is all a consumer outside the frontend can rely on)
+    const uint32_t k = (uint32_t)(ep_params.size() / 16);
+    endpoint_clusters.resize(0); endpoint_clusters.resize(k);
+    for (uint32_t i = 0; i < n; i++) { if (u[i] >= k) return false; endpoint_clusters[u[i]].push_back(i * 2); endpoint_clusters[u[i]].push_back(i * 2 + 1); }
+    if (!fetch(f, "optimized_cluster_selectors", raw) || raw.size() % 8) return false;
+    selector_blocks.resize(raw.size() / 8); std::memcpy(selector_blocks.data(), raw.data(), raw.size());
+    if (!fetch(f, "block_selector_cluster_index", u) || u.size() != n) return false;
+    block_selectors.resize(n); std::memcpy(block_selectors.data(), u.data(), (size_t)n * 4);
+    selector_lists.resize(0); selector_lists.resize(selector_blocks.size());
+    for (uint32_t i = 0; i < n; i++) { if (u[i] >= selector_lists.size()) return false; selector_lists[u[i]].push_back(i); }
+    return true;
+}
+
+bool basisu_frontend::compress() {
+    bu_frontend* f = reg().find(this);
+    if (!f) return false;
+    if (!bu_frontend_compress(f)) {
+        error_printf("basisu_frontend (resident): compress failed: %s\n", bu_frontend_error(f));
+        m_opencl_failed = true;   // basis_compressor reports it (comp.cpp:3449); there is no CPU path to continue on
+        return false;
+    }
+    if (m_params.m_debug_stats) {
+        const char* names[64]; double secs[64];
+        const uint32_t cnt = bu_frontend_stage_times(f, names, secs, 64);
+        for (uint32_t i = 0; i < cnt && i < 64; i++) debug_printf("resident frontend: %-55s %8.3f ms\n", names[i], secs[i] * 1e3);
+    }
+    std::vector<uint8_t> prm;
+    if (!refresh_members(f, m_total_blocks, m_encoded_blocks, &m_etc1_blocks_etc1s, m_endpoint_clusters, m_block_endpoint_clusters_indices, prm,
+                         m_selector_cluster_block_indices, m_optimized_cluster_selectors, m_block_selector_cluster_index))
+        return false;
+    m_orig_encoded_blocks = m_encoded_blocks;
+    const uint32_t k = (uint32_t)(prm.size() / 16);
+    m_endpoint_cluster_etc_params.resize(0); m_endpoint_cluster_etc_params.resize(k);
+    for (uint32_t i = 0; i < k; i++) {
+        endpoint_cluster_etc_params& e = m_endpoint_cluster_etc_params[i];
+        const uint8_t* p = &prm[(size_t)i * 16];
+        e.m_color_unscaled[0].set(p[0], p[1], p[2], 255);          // what generate_endpoint_codebook stores (frontend.cpp:1586-1590)
+        e.m_inten_table[0] = p[3];
+        std::memcpy(&e.m_color_error[0], p + 8, 8);
+        e.m_valid = p[4] != 0;
+        e.m_color_used[0] = !m_endpoint_clusters[i].empty();        // finalize (frontend.cpp:2980-2992)
+    }
+    return true;
+}
+
+void basisu_frontend::reoptimize_remapped_endpoints(const uint_vec& new_block_endpoints, int_vec& old_to_new_endpoint_cluster_indices, bool optimize_final_codebook,
+                                                    uint_vec* pBlock_selector_indices) {
+    bu_frontend* f = reg().find(this);
+    const uint32_t k = (uint32_t)m_endpoint_cluster_etc_params.size();
+    old_to_new_endpoint_cluster_indices.resize(k);
+    if (!f || new_block_endpoints.size() != m_total_blocks ||
+        !bu_frontend_reoptimize_remapped_endpoints(f, new_block_endpoints.data(), m_total_blocks, old_to_new_endpoint_cluster_indices.data(), k, optimize_final_codebook,
+                                                   pBlock_selector_indices ? pBlock_selector_indices->data() : nullptr)) {
+        error_printf("basisu_frontend (resident): reoptimize_remapped_endpoints failed: %s\n", f ? bu_frontend_error(f) : "no frontend");
+        abort();   // the reference's own contract for internal failures (frontend.cpp:45-49)
+    }
+    std::vector<uint8_t> prm;
+    basisu::vector<uint_vec> sel_lists; basisu::vector<etc_block> sel_blocks; basisu::vector<uint32_t> block_sel;
+    if (!refresh_members(f, m_total_blocks, m_encoded_blocks, nullptr, m_endpoint_clusters, m_block_endpoint_clusters_indices, prm, sel_lists, sel_blocks, block_sel)) abort();
+    const uint32_t k2 = (uint32_t)(prm.size() / 16);
+    m_endpoint_cluster_etc_params.resize(0); m_endpoint_cluster_etc_params.resize(k2);
+    for (uint32_t i = 0; i < k2; i++) {
+        endpoint_cluster_etc_params& e = m_endpoint_cluster_etc_params[i];
+        const uint8_t* p = &prm[(size_t)i * 16];
+        e.m_color_unscaled[0].set(p[0], p[1], p[2], 255);
+        e.m_inten_table[0] = p[3];
+        std::memcpy(&e.m_color_error[0], p + 8, 8);
+        e.m_valid = p[4] != 0;
+        e.m_color_used[0] = !m_endpoint_clusters[i].empty();
+    }
+}
+
+void basisu_frontend::dump_debug_image(const char* pFilename, uint32_t, uint32_t, uint32_t, bool) {
+    debug_printf("basisu_frontend (resident): dump_debug_image(%s) is not provided by the resident build\n", pFilename ? pFilename : "");
+}
+
+} // namespace basisu

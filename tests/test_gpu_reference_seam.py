@@ -31,3 +31,38 @@ def test_reference_tool_with_hip_seam_writes_the_cpu_tools_file(level):
     hip, log = _run(SHIM_TOOL, img, "-etc1s", "-q", "128", "-comp_level", str(level), "-opencl")
     assert "Using CPU" not in log and "failed" not in log.lower(), log[-1500:]
     assert hip.shape == cpu.shape and (hip == cpu).all()
+
+
+RESIDENT_TOOL = ORACLE_DIR / "_ref" / "basisu_hip_resident"
+
+
+def _run_any(tool, png, out_ext, *args):
+    with tempfile.TemporaryDirectory() as d:
+        save_png(pathlib.Path(d) / "in.png", png)
+        r = subprocess.run([str(tool), "-no_multithreading", *args, "in.png"], cwd=d, capture_output=True, text=True, timeout=180)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        return np.fromfile(pathlib.Path(d) / ("in." + out_ext), np.uint8), r.stdout + r.stderr
+
+
+@pytest.mark.skipif(not (have_ref_cli() and RESIDENT_TOOL.exists()), reason="oracle/_ref/basisu_hip_resident not present")
+@pytest.mark.parametrize("args,ext,alpha", [
+    (("-basis", "-etc1s", "-q", "128"), "basis", False),
+    (("-etc1s", "-q", "128"), "ktx2", False),                                   # the tool's default container
+    (("-basis", "-etc1s", "-q", "200", "-comp_level", "2"), "basis", False),    # the backend calls back into the frontend
+    (("-basis", "-etc1s", "-q", "90", "-comp_level", "4"), "basis", False),
+    (("-basis", "-etc1s", "-q", "128", "-mipmap"), "basis", False),             # the reference's own mip generation, eight slices through one frontend
+    (("-basis", "-etc1s", "-q", "128"), "basis", True),                         # colour + alpha slices
+    (("-basis", "-etc1s", "-q", "128", "-linear"), "basis", False),
+])
+def test_reference_tool_with_resident_frontend_and_backend_writes_the_cpu_tools_file(args, ext, alpha):
+    """The reference's basis_compressor / containers / CLI (untouched objects) over integration/basisu_resident_frontend.cpp and
+    basisu_resident_backend.cpp: the whole ETC1S path of basis_compressor::process() resident on the MI355X behind the reference's own
+    classes. Same file as the stock tool, byte for byte."""
+    img = synth(256, 192, 78)
+    if alpha:
+        yy, xx = np.mgrid[0:192, 0:256]
+        img[..., 3] = np.clip(128 + 120 * np.sin(xx / 23.0 - yy / 17.0), 0, 255).astype(np.uint8)
+    cpu, _ = _run_any(ORACLE_DIR / "_ref" / "basisu", img, ext, *args)
+    res, log = _run_any(RESIDENT_TOOL, img, ext, *args)
+    assert "failed" not in log.lower(), log[-1500:]
+    assert res.shape == cpu.shape and (res == cpu).all()
