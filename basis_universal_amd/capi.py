@@ -48,6 +48,8 @@ _SIGNATURES = {
     "bu_hip_encode_uastc_blocks": (_int, [_vp, _vp, _u32]),
     # section 2
     "bu_hip_create_context_on": (_vp, [_int]),
+    "bu_hip_on_destroy": (_int, [_vp, _vp, _vp]),
+    "bu_hip_cancel_on_destroy": (None, [_vp, _vp, _vp]),
     "bu_hip_context_device": (_int, [_vp]),
     "bu_hip_set_stream": (_int, [_vp, _vp]),
     "bu_hip_get_stream": (_vp, [_vp]),

@@ -73,6 +73,9 @@ struct bu_hip_context {
     std::vector<prof_rec> prof_pending;
     struct prof_sum { const char* name; double ms; uint32_t launches; };
     std::vector<prof_sum> prof_totals;
+    // bu_hip_on_destroy registrations
+    std::mutex closing_lock;
+    std::vector<std::pair<bu_hip_destroy_fn, void*>> closing;
 };
 
 namespace {
@@ -208,9 +211,31 @@ bu_hip_context* bu_hip_create_context(void) {
     return bu_hip_create_context_on(dev);
 }
 
+int bu_hip_on_destroy(bu_hip_context* ctx, bu_hip_destroy_fn fn, void* user) {
+    if (!ctx || !fn) return 0;
+    std::lock_guard<std::mutex> g(ctx->closing_lock);
+    ctx->closing.emplace_back(fn, user);
+    return 1;
+}
+void bu_hip_cancel_on_destroy(bu_hip_context* ctx, bu_hip_destroy_fn fn, void* user) {
+    if (!ctx) return;
+    std::lock_guard<std::mutex> g(ctx->closing_lock);
+    for (size_t i = 0; i < ctx->closing.size(); i++)
+        if (ctx->closing[i].first == fn && ctx->closing[i].second == user) { ctx->closing.erase(ctx->closing.begin() + (long)i); break; }
+}
+
 void bu_hip_destroy_context(bu_hip_context* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
+    for (;;) {  // dependents first (a callback may cancel others; each runs once, outside the lock)
+        std::pair<bu_hip_destroy_fn, void*> cb;
+        {
+            std::lock_guard<std::mutex> g(ctx->closing_lock);
+            if (ctx->closing.empty()) break;
+            cb = ctx->closing.back(); ctx->closing.pop_back();
+        }
+        cb.first(cb.second);
+    }
     (void)hipStreamSynchronize(ctx->stream);
     ctx->pixel_arena.release();
     for (auto& a : ctx->scratch) a.release();

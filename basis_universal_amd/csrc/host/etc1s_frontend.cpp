@@ -153,8 +153,18 @@ struct etc1s_frontend::device_state {
 };
 
 etc1s_frontend::etc1s_frontend() {}
-etc1s_frontend::~etc1s_frontend() {
-    if (m_dev) { m_dev->release(); delete m_dev; }
+etc1s_frontend::~etc1s_frontend() { drop_device_state(); }
+
+// The device buffers are freed through the context they came from; if that context is destroyed first it tells us (bu_hip_on_destroy)
+// and the buffers are let go while it still works. The host-side results (getters) stay valid.
+static void frontend_context_closing(void* user) { static_cast<etc1s_frontend*>(user)->context_closing(); }
+void etc1s_frontend::context_closing() {
+    if (m_dev) { m_dev->release(); delete m_dev; m_dev = nullptr; }
+}
+void etc1s_frontend::drop_device_state() {
+    if (!m_dev) return;
+    bu_hip_cancel_on_destroy(m_dev->ctx, frontend_context_closing, this);
+    m_dev->release(); delete m_dev; m_dev = nullptr;
 }
 
 bool etc1s_frontend::fail(const char* what) {
@@ -198,9 +208,10 @@ bool etc1s_frontend::init(const params& p) {
     m_total_blocks = p.m_num_source_blocks;
     m_source_copy.clear(); m_source_copy.shrink_to_fit();   // a host copy of device-only tiles belongs to the image it was made from
 
-    if (m_dev) { m_dev->release(); delete m_dev; }
+    drop_device_state();
     m_dev = new device_state();
     m_dev->ctx = p.m_pHIP_context;
+    bu_hip_on_destroy(m_dev->ctx, frontend_context_closing, this);
     if (p.m_pDevice_blocks) {
         m_dev->d_pixels = p.m_pDevice_blocks;
     } else {
@@ -230,6 +241,7 @@ bool etc1s_frontend::init(const params& p) {
 
 // basisu_frontend::compress (frontend.cpp:159-316), single endpoint/selector iteration (levels 0-3)
 bool etc1s_frontend::compress() {
+    if (!m_dev) return fail("etc1s_frontend::compress: not initialised, or the context it was initialised on has been destroyed");
     m_stage_times.clear();
 #define BU_STAGE(name, call) do { timer t__; if (!(call)) return false; m_stage_times.push_back(stage_time{name, t__.seconds()}); } while (0)
 #define BU_STAGE_V(name, call) do { timer t__; call; m_stage_times.push_back(stage_time{name, t__.seconds()}); } while (0)
@@ -622,6 +634,7 @@ bool etc1s_frontend::refine_block_endpoints_given_selectors(uint32_t* total_refi
 // every old cluster went (-1: unused).
 bool etc1s_frontend::reoptimize_remapped_endpoints(const std::vector<uint32_t>& new_block_endpoints, std::vector<int>& old_to_new, bool optimize_final_codebook,
                                                    const std::vector<uint32_t>* block_selector_indices) {
+    if (!m_dev) return fail("reoptimize_remapped_endpoints: the context this frontend was initialised on has been destroyed");
     ensure_endpoint_map();
     const uint32_t n = m_total_blocks, k = m_endpoint_cluster_count;
     if (new_block_endpoints.size() != n || m_endpoint_cluster_etc_params.size() != k) return fail("reoptimize_remapped_endpoints: size mismatch");

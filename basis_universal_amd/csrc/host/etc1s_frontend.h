@@ -43,6 +43,7 @@ public:
 
     etc1s_frontend();
     ~etc1s_frontend();
+    void context_closing();   // called by the context while it is being destroyed (bu_hip_on_destroy): lets go of the device buffers
     etc1s_frontend(const etc1s_frontend&) = delete;
     etc1s_frontend& operator=(const etc1s_frontend&) = delete;
 
@@ -109,6 +110,7 @@ public:
 
 private:
     struct device_state;
+    void drop_device_state();
     bool fail(const char* what);
 
     params m_params;

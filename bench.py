@@ -245,12 +245,17 @@ def main():
             "stages_s_per_step": {k: round(v / args.steps, 4) for k, v in stage_acc.items()},
             "kernels_ms_per_step": {k: round(v[0] / args.steps, 3) for k, v in kernels.items()},
         }
+        # what is NOT device time inside a step: host bookkeeping, copies and synchronising calls between the kernels
+        out["host_gap_ms"] = round(elapsed / args.steps * 1e3 - sum(v[0] for v in kernels.values()) / args.steps, 2)
         if roofline:
             roofline["traffic"] = pmc_traffic(roofline["kernel"])
         if world == 1:  # what follows the hot path on the host: the ETC1S backend on the frontend just timed
             out["backend"] = backend_bench(last, w, h, args, elapsed / args.steps)
         if not args.no_cpu_baseline and world == 1:  # the CPU baseline and the secondary workloads are N=1 measurements
             out["cpu_baseline"] = cpu_baseline(helpers, args)
+            if helpers.have_ref():
+                out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(helpers, args)
+                out["end_to_end"] = end_to_end(helpers, args, img)
             ref_be = out["cpu_baseline"].pop("backend", None)
             if ref_be and "backend" in out:
                 out["backend"]["reference_s"] = ref_be["seconds"]
@@ -446,6 +451,65 @@ def cpu_baseline(helpers, args):
     if kind == "reference":
         res["backend"] = ref_backend
     return res
+
+
+def cpu_baseline_all_cores(helpers, args):
+    """The same stage set on ALL host cores: the reference frontend with its job pool sized like the tool sizes it by default (one thread per
+    hardware thread, basisu_tool.cpp:2331-2348). Not the parity configuration: above 262,144 distinct selector vectors the reference's
+    output depends on the thread count (SURVEY hazard H1)."""
+    from basis_universal_amd.etc1s import quality_to_clusters
+    threads = host_cpus()
+    sample = helpers.to_pixel_blocks(helpers.synth(args.size, args.size, 1234))
+    n = sample.shape[0]
+    max_ep, max_sel = quality_to_clusters(args.quality, n)
+    t0 = time.perf_counter()
+    fe = helpers.RefFrontend(sample, max_ep, max_sel, args.level, True, threads=threads)
+    fe.call("compress")
+    dt = time.perf_counter() - t0
+    fe.close()
+    return {"value": round(args.size * args.size / 1e6 / dt, 4), "unit": "Mpixels/s", "cores": threads, "kind": "reference",
+            "sample": f"{args.size}x{args.size} bench image, {n} blocks, {max_ep}/{max_sel} clusters, reference basisu_frontend::init+compress with a "
+                      f"{threads}-thread job pool (oracle/_ref), {dt:.2f} s"}
+
+
+def end_to_end(helpers, args, img):
+    """SURVEY 8d figure (ii): wall time of the reference's own driver, basis_compressor::init + process (raw RGBA in, .basis bytes out; PNG decode
+    and file writing outside), linked three ways from one source (integration/process_bench.cpp, oracle/Makefile): the stock reference (1 thread =
+    the parity configuration, and all host cores), the reference frontend calling the kernels through its accelerator seam, and the whole ETC1S
+    path resident on the GPU behind the reference's classes. `identical` compares the .basis bytes with the stock single-threaded run."""
+    import subprocess
+    import tempfile
+    ref_dir = ROOT / "oracle" / "_ref"
+    threads = host_cpus()
+    mpix = args.size * args.size / 1e6
+    runs = [("stock_1_thread", "process_bench", 1, 0, 1), ("stock_all_cores", "process_bench", threads, 0, 1), ("seam_1_thread", "process_bench_hip", 1, 1, 1),
+            ("seam_all_cores", "process_bench_hip", threads, 1, 1), ("resident", "process_bench_resident", min(threads, 8), 1, 3)]
+    out = {"what": "basis_compressor::init + process(), raw RGBA in, .basis bytes out, tool defaults (ETC1S comp level 1, sRGB metrics)", "host_cpus": threads}
+    with tempfile.TemporaryDirectory() as d:
+        raw = pathlib.Path(d) / "img.rgba"
+        np.ascontiguousarray(img).tofile(raw)
+        base_hash = None
+        for name, exe, thr, ocl, reps in runs:
+            tool = ref_dir / exe
+            if not tool.exists():
+                continue
+            try:
+                r = subprocess.run([str(tool), str(raw), str(args.size), str(args.size), str(args.quality), str(args.level), str(thr), str(ocl), str(reps)],
+                                   capture_output=True, text=True, timeout=600)
+                rec = json.loads(r.stdout.strip().splitlines()[-1])
+            except Exception as e:  # a failed variant is reported, not fatal
+                out[name] = {"error": str(e)[:200]}
+                continue
+            best = min(a + b for a, b in zip(rec["init_s"], rec["process_s"]))
+            if name == "stock_1_thread":
+                base_hash = rec["fnv1a64"]
+            out[name] = {"seconds": round(best, 4), "mpix_s": round(mpix / best, 3), "threads": thr, "bytes": rec["bytes"],
+                         "identical": (rec["fnv1a64"] == base_hash) if base_hash else None}
+    if "resident" in out and "stock_1_thread" in out and "seconds" in out["resident"] and "seconds" in out["stock_1_thread"]:
+        out["resident_vs_stock_1_thread"] = round(out["stock_1_thread"]["seconds"] / out["resident"]["seconds"], 1)
+        if "seconds" in out.get("stock_all_cores", {}):
+            out["resident_vs_stock_all_cores"] = round(out["stock_all_cores"]["seconds"] / out["resident"]["seconds"], 1)
+    return out
 
 
 if __name__ == "__main__":

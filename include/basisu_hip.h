@@ -84,6 +84,12 @@ BU_HIP_API int bu_hip_encode_uastc_blocks(bu_hip_context*, bu_uastc_block* outpu
  * ------------------------------------------------------------------------------------------------------------------ */
 
 BU_HIP_API bu_hip_context* bu_hip_create_context_on(int device);
+/* Objects that keep device memory of a context (a resident frontend, say) may ask to be told when it is being destroyed: fn(user) runs at the
+ * start of bu_hip_destroy_context, while the context still works, so that they can let go of their buffers instead of freeing them through a
+ * dead context later. bu_hip_cancel_on_destroy removes a registration (same fn and user). */
+typedef void (*bu_hip_destroy_fn)(void* user);
+BU_HIP_API int  bu_hip_on_destroy(bu_hip_context*, bu_hip_destroy_fn fn, void* user);
+BU_HIP_API void bu_hip_cancel_on_destroy(bu_hip_context*, bu_hip_destroy_fn fn, void* user);
 BU_HIP_API int   bu_hip_context_device(const bu_hip_context*);
 /* Use an externally owned hipStream_t (e.g. torch's current stream) instead of the context's own; NULL restores it. */
 BU_HIP_API int   bu_hip_set_stream(bu_hip_context*, void* hip_stream);

@@ -54,7 +54,7 @@ struct frontend_handle {
 	std::vector<pixel_block> blocks;
 	basisu_frontend::params p;
 	std::unique_ptr<basisu_backend> be;  // see ref_backend_run
-	frontend_handle() : jp(1) {}
+	explicit frontend_handle(uint32_t threads = 1) : jp(threads < 1 ? 1 : threads) {}
 };
 
 template <typename T>
@@ -165,9 +165,17 @@ REF_API uint32_t ref_color_distance(int perceptual, const uint8_t* a, const uint
 
 // ---------------------------------------------------------------- frontend, stage by stage
 
+// threads: total size of the job pool including the caller (1 = the pinned, single-threaded configuration; more = what the tool does by
+// default, basisu_tool.cpp:2331-2348 -- NOT bit-identical to 1 thread above 262,144 distinct selector vectors, SURVEY hazard H1)
+REF_API void* ref_frontend_create_mt(const uint8_t* pixel_blocks, uint32_t n_blocks, uint32_t max_endpoint_clusters,
+	uint32_t max_selector_clusters, int comp_level, int perceptual, uint32_t threads);
 REF_API void* ref_frontend_create(const uint8_t* pixel_blocks, uint32_t n_blocks, uint32_t max_endpoint_clusters,
 	uint32_t max_selector_clusters, int comp_level, int perceptual) {
-	frontend_handle* h = new frontend_handle();
+	return ref_frontend_create_mt(pixel_blocks, n_blocks, max_endpoint_clusters, max_selector_clusters, comp_level, perceptual, 1);
+}
+REF_API void* ref_frontend_create_mt(const uint8_t* pixel_blocks, uint32_t n_blocks, uint32_t max_endpoint_clusters,
+	uint32_t max_selector_clusters, int comp_level, int perceptual, uint32_t threads) {
+	frontend_handle* h = new frontend_handle(threads);
 	h->blocks.resize(n_blocks);
 	memcpy(h->blocks.data(), pixel_blocks, (size_t)n_blocks * sizeof(pixel_block));
 	basisu_frontend::params& p = h->p;
@@ -178,7 +186,7 @@ REF_API void* ref_frontend_create(const uint8_t* pixel_blocks, uint32_t n_blocks
 	p.m_perceptual = perceptual != 0;
 	p.m_compression_level = comp_level;
 	p.m_tex_type = basist::cBASISTexType2D;
-	p.m_multithreaded = false;
+	p.m_multithreaded = threads > 1;
 	p.m_validate = false;
 	p.m_pJob_pool = &h->jp;
 	p.m_pGlobal_codebooks = nullptr;

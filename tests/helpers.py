@@ -170,10 +170,16 @@ def ref():
 class RefFrontend:
     """The reference's basisu_frontend, driven one private stage at a time (oracle/ref_harness.cpp)."""
 
-    def __init__(self, blocks, max_ep, max_sel, level, perceptual=True):
+    def __init__(self, blocks, max_ep, max_sel, level, perceptual=True, threads=1):
+        """threads: the reference's job pool size including the caller; 1 is the pinned configuration every parity check uses"""
         self.L = ref()
         self.blocks = np.ascontiguousarray(blocks)
-        self.h = self.L.ref_frontend_create(ptr(self.blocks), self.blocks.shape[0], max_ep, max_sel, level, int(perceptual))
+        if threads == 1:
+            self.h = self.L.ref_frontend_create(ptr(self.blocks), self.blocks.shape[0], max_ep, max_sel, level, int(perceptual))
+        else:
+            self.L.ref_frontend_create_mt.restype = C.c_void_p
+            self.L.ref_frontend_create_mt.argtypes = [u8p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_uint32]
+            self.h = self.L.ref_frontend_create_mt(ptr(self.blocks), self.blocks.shape[0], max_ep, max_sel, level, int(perceptual), threads)
         assert self.h
 
     def call(self, name, arg=0):

@@ -204,3 +204,58 @@ def test_context_close_takes_its_frontends_along():
     assert fe.h is None and ctx.h is None
     fe.close()
     del fe
+
+
+def test_frontend_outlives_its_context_at_the_c_level():
+    """What the Python wrapper arranges for itself must also hold for a C / C++ host (the reference's basis_compressor destroys its accelerator
+    context before its frontend member): a context that is destroyed first tells its frontends (bu_hip_on_destroy), they let go of their
+    device buffers, their host-side results stay readable, and destroying them afterwards is harmless."""
+    import ctypes as C
+    from basis_universal_amd import capi, etc1s
+    lib = capi.load_library().dll
+    F = etc1s.load_frontend_library()
+    lib.bu_hip_create_context.restype = C.c_void_p
+    lib.bu_hip_destroy_context.argtypes = [C.c_void_p]
+    ctx = lib.bu_hip_create_context()
+    assert ctx
+    blocks = to_pixel_blocks(synth(64, 64, 1))
+    F.bu_frontend_create.restype = C.c_void_p
+    fe = F.bu_frontend_create()
+    assert F.bu_frontend_init(C.c_void_p(fe), C.c_void_p(ctx), blocks.ctypes.data_as(C.c_void_p), None, blocks.shape[0], 32, 32, 1, 1) == 1
+    assert F.bu_frontend_compress(C.c_void_p(fe)) == 1
+    lib.bu_hip_destroy_context(ctx)
+    F.bu_frontend_get.restype = C.c_uint64
+    F.bu_frontend_get.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_uint64]
+    assert F.bu_frontend_get(fe, b"encoded_blocks", None, 0) == blocks.shape[0] * 8
+    assert F.bu_frontend_compress(C.c_void_p(fe)) == 0          # fails cleanly, no device access through the dead context
+    F.bu_frontend_destroy.argtypes = [C.c_void_p]
+    F.bu_frontend_destroy(fe)
+
+
+def test_reinitialised_frontend_serves_the_new_images_tiles(hip_ctx):
+    """One frontend object, two device-only images of the same size one after the other: the host copy of the tiles the backend reads
+    (get_source_pixel_block) must be the second image's, i.e. the payload must equal a fresh frontend's for that image."""
+    from basis_universal_amd.etc1s import Etc1sFrontend
+    from basis_universal_amd.backend import Etc1sBackend
+    imgs = [synth(128, 96, 41), synth(128, 96, 42)]
+    outs = []
+    fe = Etc1sFrontend(hip_ctx)
+    for reuse in (True, False):
+        for i, img in enumerate(imgs):
+            if not reuse:
+                fe = Etc1sFrontend(hip_ctx)
+            blocks = to_pixel_blocks(img)
+            d = hip_ctx.upload(blocks)
+            fe.init(d, 200, 200, 1, True, n_blocks=blocks.shape[0])
+            fe.compress()
+            be = Etc1sBackend.from_frontend(fe, [(0, 32, 24)], 1.5, 1.25, 1)
+            be.encode()
+            outs.append((reuse, i, hashlib.sha256(np.ascontiguousarray(be.get("slice_image_data")).tobytes()).hexdigest()))
+            be.close()
+            hip_ctx.free(d)
+            if not reuse:
+                fe.close()
+        if reuse:
+            fe.close()
+    got = {(r, i): h for r, i, h in outs}
+    assert got[(True, 0)] == got[(False, 0)] and got[(True, 1)] == got[(False, 1)] and got[(True, 0)] != got[(True, 1)]
