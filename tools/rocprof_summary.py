@@ -66,7 +66,38 @@ def traffic(fetch_db, write_db):
     print(json.dumps(out, indent=1, sort_keys=True))
 
 
+def traffic_csv(fetch_csv, write_csv, commit):
+    """The same from two `pmc` CSVs (what a GPU-box run brings home when the databases are too large to). The many-workgroup TSVQ path is
+    one bench label ("tsvq_split_packed16_wide" = one batch of wide nodes = ~40 launches of the k_wide_* kernels + k_tsvq_cov_axis): its
+    entry is the traffic of all of them per BATCH (batches = launches of k_wide_partition)."""
+    import csv, json
+    out, wide, batches = {}, {"fetch_bytes_per_launch": 0.0, "write_bytes_per_launch": 0.0}, 0
+    for path, key, mul in ((fetch_csv, "fetch_bytes_per_launch", 2048.0), (write_csv, "write_bytes_per_launch", 1024.0)):
+        acc = {}
+        for r in csv.DictReader(open(path)):
+            n, k, tot = r["kernel"], int(r["dispatches"]), float(r["sum"]) * mul
+            if "k_wide_" in n or "k_tsvq_cov_axis" in n:
+                if "k_wide_iota" in n or "<0>" in n:
+                    continue  # the root record's pass belongs to tsvq_root_packed16
+                wide[key] += tot
+                if "k_wide_partition" in n:
+                    batches = k
+                continue
+            s_ = short(n)
+            a, c = acc.get(s_, (0.0, 0))
+            acc[s_] = (a + tot, c + k)
+        for s_, (tot, cnt) in acc.items():
+            out.setdefault(s_, {"fetch_bytes_per_launch": 0, "write_bytes_per_launch": 0})[key] = int(tot / cnt)
+    if batches:
+        out["tsvq_split_packed16_wide"] = {k: int(v / batches) for k, v in wide.items()}
+    out["_meta"] = {"commit": commit, "source": [fetch_csv, write_csv], "units": "bytes per launch; FETCH_SIZE x 2048 (KiB, doubled per the gfx950 note in MI355X_MICROARCH.md), WRITE_SIZE x 1024"}
+    print(json.dumps(out, indent=1, sort_keys=True))
+
+
 if __name__ == "__main__":
+    if sys.argv[1] == "traffic_csv":
+        traffic_csv(sys.argv[2], sys.argv[3], sys.argv[4] if len(sys.argv) > 4 else "")
+        sys.exit(0)
     if sys.argv[1] == "traffic":
         traffic(sys.argv[2], sys.argv[3])
         sys.exit(0)
