@@ -49,6 +49,15 @@ _SIGNATURES = {
     # section 2
     "bu_hip_create_context_on": (_vp, [_int]),
     "bu_hip_on_destroy": (_int, [_vp, _vp, _vp]),
+    "bu_hip_memcpy_d2d": (_int, [_vp, _vp, _vp, C.c_size_t]),
+    "bu_hip_k_map_blocks_from_groups": (_int, [_vp, _vp, _vp, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "bu_hip_k_map_rank_blocks": (_int, [_vp, _vp, _u32, _u32, _vp, _vp, _vp, _vp]),
+    "bu_hip_k_map_endpoint_csr": (_int, [_vp, _vp, _vp, _u32, _vp, _vp]),
+    "bu_hip_k_map_remap": (_int, [_vp, _vp, _vp, _u32, _vp, _vp]),
+    "bu_hip_k_map_count_differences": (_int, [_vp, _vp, _vp, _u32, _vp]),
+    "bu_hip_k_map_membership": (_int, [_vp, _vp, _vp, _u32, _u32, _u32, _vp]),
+    "bu_hip_k_map_gather": (_int, [_vp, _vp, _vp, _u32, _vp]),
+    "bu_hip_tsvq_scatter_spans": (_int, [_vp, _vp, _vp, _u32, _vp]),
     "bu_hip_cancel_on_destroy": (None, [_vp, _vp, _vp]),
     "bu_hip_context_device": (_int, [_vp]),
     "bu_hip_set_stream": (_int, [_vp, _vp]),

@@ -20,6 +20,7 @@
 #include "uastc_kernels.h"
 #include "mipmap_kernels.h"
 #include "unique_kernels.h"
+#include "bookkeeping_kernels.h"
 
 namespace {
 
@@ -322,6 +323,13 @@ int bu_hip_memcpy_d2h(bu_hip_context* ctx, void* h, const void* d, size_t bytes)
     BU_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return 1;
 }
+int bu_hip_memcpy_d2d(bu_hip_context* ctx, void* dst, const void* src, size_t bytes) {
+    if (!ctx) return 0;
+    if (!bytes) return 1;
+    device_guard g(ctx->device);
+    BU_TRY(ctx, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    return 1;
+}
 int bu_hip_memset(bu_hip_context* ctx, void* d, int value, size_t bytes) {
     if (!ctx) return 0;
     if (!bytes) return 1;
@@ -564,6 +572,66 @@ int bu_hip_k_find_optimal_selector_clusters(bu_hip_context* ctx, const void* d_p
     BU_TRY(ctx, tmp.reserve((size_t)n_blocks * sizeof(uint32_t)));
     BU_TRY(ctx, bu::launch_find_optimal_selector_clusters(ctx->stream, d_px, d_enc, n_blocks, d_selector_blocks, n_selectors, n_parents, d_cand_offsets,
                                                           d_cand_indices, d_block_parent, perceptual != 0, chunk, static_cast<uint32_t*>(tmp.p), d_out));
+    return 1;
+}
+
+// ---------------------------------------------------------------------------------------------------------------- cluster bookkeeping on the device
+
+int bu_hip_k_map_blocks_from_groups(bu_hip_context* ctx, const uint32_t* d_goffs, const uint32_t* d_idx, uint32_t n, uint32_t u_total, const uint32_t* d_leaf,
+                                    const uint32_t* d_first_pos, const uint32_t* d_parent_of_unique, uint32_t* d_cluster, uint32_t* d_pos, uint8_t* d_parent) {
+    if (!ctx) return 0;
+    if (n && (!d_goffs || !d_idx || !d_leaf || !d_cluster || (d_pos && !d_first_pos))) { set_error(ctx, "map_blocks_from_groups: null pointer"); return 0; }
+    device_guard g(ctx->device);
+    prof_scope ps(ctx, "map_blocks_from_groups");
+    BU_TRY(ctx, bu::launch_blocks_from_groups(ctx->stream, d_goffs, d_idx, n, u_total, d_leaf, d_first_pos, d_parent_of_unique, d_cluster, d_pos, d_parent));
+    return 1;
+}
+
+int bu_hip_k_map_rank_blocks(bu_hip_context* ctx, const uint32_t* d_cluster, uint32_t n, uint32_t k, uint32_t* d_sizes, uint32_t* d_offsets, uint32_t* d_sorted, uint32_t* d_pos) {
+    if (!ctx) return 0;
+    if (n && (!d_cluster || !d_sizes || !d_offsets || !d_sorted)) { set_error(ctx, "map_rank_blocks: null pointer"); return 0; }
+    device_guard g(ctx->device);
+    arena& ws = ctx->scratch[4];
+    BU_TRY(ctx, ws.reserve(bu::rank_blocks_workspace_bytes(n, k)));
+    prof_scope ps(ctx, "map_rank_blocks");
+    BU_TRY(ctx, bu::launch_rank_blocks(ctx->stream, d_cluster, n, k, ws.p, d_sizes, d_offsets, d_sorted, d_pos));
+    return 1;
+}
+
+int bu_hip_k_map_endpoint_csr(bu_hip_context* ctx, const uint32_t* d_cluster, const uint32_t* d_pos, uint32_t n, const uint32_t* d_offsets, uint32_t* d_indices) {
+    if (!ctx) return 0;
+    device_guard g(ctx->device);
+    prof_scope ps(ctx, "map_endpoint_csr");
+    BU_TRY(ctx, bu::launch_endpoint_csr_fill(ctx->stream, d_cluster, d_pos, n, d_offsets, d_indices));
+    return 1;
+}
+
+int bu_hip_k_map_remap(bu_hip_context* ctx, uint32_t* d_cluster, uint32_t* d_pos, uint32_t n, const uint32_t* d_new_index, const uint32_t* d_base) {
+    if (!ctx) return 0;
+    device_guard g(ctx->device);
+    prof_scope ps(ctx, "map_remap");
+    BU_TRY(ctx, bu::launch_remap_clusters(ctx->stream, d_cluster, d_pos, n, d_new_index, d_base));
+    return 1;
+}
+
+int bu_hip_k_map_count_differences(bu_hip_context* ctx, const uint32_t* d_a, const uint32_t* d_b, uint32_t n, uint32_t* d_count) {
+    if (!ctx) return 0;
+    device_guard g(ctx->device);
+    BU_TRY(ctx, bu::launch_count_differences(ctx->stream, d_a, d_b, n, d_count));
+    return 1;
+}
+
+int bu_hip_k_map_membership(bu_hip_context* ctx, const uint8_t* d_parent, const uint32_t* d_cluster, uint32_t n, uint32_t parents, uint32_t clusters, uint8_t* d_flags) {
+    if (!ctx) return 0;
+    device_guard g(ctx->device);
+    BU_TRY(ctx, bu::launch_membership(ctx->stream, d_parent, d_cluster, n, parents, clusters, d_flags));
+    return 1;
+}
+
+int bu_hip_k_map_gather(bu_hip_context* ctx, const uint32_t* d_table, const uint32_t* d_index, uint32_t n, uint32_t* d_out) {
+    if (!ctx) return 0;
+    device_guard g(ctx->device);
+    BU_TRY(ctx, bu::launch_gather_u32(ctx->stream, d_table, d_index, n, d_out));
     return 1;
 }
 
@@ -818,6 +886,22 @@ int bu_hip_tsvq_split(bu_hip_context* ctx, bu_tsvq* q, const bu_tsvq_node* h_nod
             for (size_t j = 0; j < redo.size(); j++) h_out[redo[j]] = po[j];
         }
     }
+    return 1;
+}
+
+static_assert(sizeof(bu_tsvq_span) == sizeof(bu::bk_span), "layout");
+int bu_hip_tsvq_scatter_spans(bu_hip_context* ctx, bu_tsvq* q, const bu_tsvq_span* h_spans, uint32_t n_spans, uint32_t* d_out) {
+    if (!ctx || !q || (n_spans && (!h_spans || !d_out))) return 0;
+    if (!n_spans) return 1;
+    device_guard g(ctx->device);
+    const size_t bytes = (size_t)n_spans * sizeof(bu_tsvq_span);
+    if (bytes > q->nodes.cap) { set_error(ctx, "tsvq_scatter_spans: %u spans exceed the record buffer", n_spans); return 0; }
+    BU_TRY(ctx, hipStreamSynchronize(ctx->stream));   // the pinned staging buffer may still feed an earlier copy
+    BU_TRY(ctx, q->reserve_pinned(bytes));
+    std::memcpy(q->pinned, h_spans, bytes);
+    BU_TRY(ctx, hipMemcpyAsync(q->nodes.p, q->pinned, bytes, hipMemcpyHostToDevice, ctx->stream));
+    BU_TRY(ctx, bu::launch_scatter_spans(ctx->stream, q->perm[0], q->perm[1], static_cast<const bu::bk_span*>(q->nodes.p), n_spans, d_out));
+    BU_TRY(ctx, hipStreamSynchronize(ctx->stream));   // q may be destroyed (and the pinned buffer recycled) right after
     return 1;
 }
 

@@ -129,6 +129,8 @@ struct etc1s_frontend::device_state {
     buf etc1, enc, block_cluster, params, err, valid, offsets, indices, cand_offsets, cand_indices, block_parent, out_u32, sel_blocks, weights;
     buf sel_idx, sel_ukeys, sel_uw, sel_goffs;  // outputs of bu_hip_k_unique_selector_vectors
     buf ep_idx, ep_ukeys, ep_goffs;             // outputs of bu_hip_k_unique_endpoint_vectors
+    // the clusterings as resident per-block maps (bookkeeping_kernels.hip) and the small arrays around them
+    buf ep_pos, ep_parent, sel_cluster, sel_parent, orig_enc, map_sizes, map_offs, map_sorted, map_word, tmp_a, tmp_b, tmp_c, flags;
 
     bool reserve(buf& b, size_t bytes) {
         if (bytes <= b.cap) return true;
@@ -145,7 +147,8 @@ struct etc1s_frontend::device_state {
     template <typename T> bool download(T* dst, const buf& b, size_t count) { return bu_hip_memcpy_d2h(ctx, dst, b.p, count * sizeof(T)) != 0; }
     void release() {
         for (buf* b : {&etc1, &enc, &block_cluster, &params, &err, &valid, &offsets, &indices, &cand_offsets, &cand_indices, &block_parent, &out_u32, &sel_blocks, &weights,
-                       &sel_idx, &sel_ukeys, &sel_uw, &sel_goffs, &ep_idx, &ep_ukeys, &ep_goffs})
+                       &sel_idx, &sel_ukeys, &sel_uw, &sel_goffs, &ep_idx, &ep_ukeys, &ep_goffs,
+                       &ep_pos, &ep_parent, &sel_cluster, &sel_parent, &orig_enc, &map_sizes, &map_offs, &map_sorted, &map_word, &tmp_a, &tmp_b, &tmp_c, &flags})
             if (b->p) { bu_hip_free(ctx, b->p); b->p = nullptr; b->cap = 0; }
         if (owns_pixels && d_pixels) bu_hip_free(ctx, const_cast<void*>(d_pixels));
         d_pixels = nullptr;
@@ -222,6 +225,10 @@ bool etc1s_frontend::init(const params& p) {
     }
 
     m_encoded_blocks.assign(m_total_blocks, bu_etc_block{});
+    m_orig_encoded_blocks.clear();
+    m_enc_host_valid = true; m_enc_dev_valid = false; m_orig_host_valid = true;
+    m_ep_dev_valid = false; m_endpoint_map_valid = false; m_endpoint_lists_valid = false;
+    m_endpoint_group_blocks.clear();
     m_num_endpoint_codebook_iterations = 1;
     m_num_selector_codebook_iterations = 1;
     switch (p.m_compression_level) {  // frontend.cpp:87-148
@@ -257,11 +264,11 @@ bool etc1s_frontend::compress() {
             BU_STAGE("refine_endpoint_clusterization", refine_endpoint_clusterization(&moved));
             if (!moved) early_out = true;  // frontend.cpp:215-216
             if (m_params.m_video && !step && m_num_endpoint_codebook_iterations == 1) {  // frontend.cpp:219-223: video clips get one more fit of the merged codebook
-                BU_STAGE_V("eliminate_redundant_or_empty_endpoint_clusters", eliminate_redundant_or_empty_endpoint_clusters());
+                BU_STAGE("eliminate_redundant_or_empty_endpoint_clusters", eliminate_redundant_or_empty_endpoint_clusters());
                 BU_STAGE("generate_endpoint_codebook", generate_endpoint_codebook(1));
             }
         }
-        BU_STAGE_V("eliminate_redundant_or_empty_endpoint_clusters", eliminate_redundant_or_empty_endpoint_clusters());
+        BU_STAGE("eliminate_redundant_or_empty_endpoint_clusters", eliminate_redundant_or_empty_endpoint_clusters());
         if (early_out) break;
     }
     BU_STAGE_V("generate_block_endpoint_clusters", generate_block_endpoint_clusters());
@@ -339,9 +346,8 @@ bool etc1s_frontend::init_endpoint_training_vectors() {
     if (!bu_hip_k_unique_endpoint_vectors(d.ctx, d.etc1.p, n, (uint32_t*)d.ep_idx.p, (uint64_t*)d.ep_ukeys.p, (uint32_t*)d.ep_goffs.p, &u_total))
         return fail("bu_hip_k_unique_endpoint_vectors");
     std::vector<uint64_t> ukeys(u_total);
-    m_endpoint_group_blocks.resize(n); m_endpoint_group_offsets.resize((size_t)u_total + 1);
-    if (!d.download(ukeys.data(), d.ep_ukeys, u_total) || !d.download(m_endpoint_group_offsets.data(), d.ep_goffs, (size_t)u_total + 1) ||
-        !d.download(m_endpoint_group_blocks.data(), d.ep_idx, n))
+    m_endpoint_group_blocks.clear(); m_endpoint_group_offsets.resize((size_t)u_total + 1);   // the blocks of the groups stay in HBM (endpoint_group_blocks_host())
+    if (!d.download(ukeys.data(), d.ep_ukeys, u_total) || !d.download(m_endpoint_group_offsets.data(), d.ep_goffs, (size_t)u_total + 1))
         return fail("download endpoint groups");
     m_endpoint_unique_rows.resize((size_t)u_total * 6); m_endpoint_unique_weights.resize(u_total);
     for (uint32_t u = 0; u < u_total; u++) {
@@ -354,7 +360,7 @@ bool etc1s_frontend::init_endpoint_training_vectors() {
 // frontend.cpp:868-944
 bool etc1s_frontend::generate_endpoint_clusters() {
     const uint32_t parent_size = (m_params.m_max_endpoint_clusters >= 256) ? kEndpointParentCodebookSize : 0;
-    const csr_block_pair_groups groups{m_endpoint_group_offsets.data(), m_endpoint_group_blocks.data()};
+    const csr_block_pair_groups groups{m_endpoint_group_offsets.data(), m_endpoint_group_blocks.data()};  // never dereferenced: only per-vector results are asked for
     m_endpoint_parent_clusters.clear();
     std::vector<uint32_t> leaf_of_unique;
     std::vector<std::vector<uint32_t>> unused;
@@ -362,34 +368,38 @@ bool etc1s_frontend::generate_endpoint_clusters() {
                                             m_use_hierarchical_endpoint_codebooks ? parent_size : 0, unused, m_endpoint_parent_clusters, nullptr,
                                             &m_endpoint_parent_of_unique, &m_endpoint_parent_count, &leaf_of_unique, &m_endpoint_cluster_count))
         return fail("endpoint TSVQ failed");
-    // The clustering is kept as (cluster, position in the cluster's list) per block; the lists are built when somebody asks. A leaf lists its
-    // distinct vectors ascending and each vector's blocks ascending (enc.h:1573-1584 + the training-vector order of frontend.cpp:825-866).
+    // The clustering is kept as (cluster, position in the cluster's list) per block, RESIDENT: the distinct vectors' leaves, parents and list
+    // offsets go up (a few thousand words), the per-block arrays are written by the device. A leaf lists its distinct vectors ascending and
+    // each vector's blocks ascending (enc.h:1573-1584 + the training-vector order of frontend.cpp:825-866).
     const uint32_t n = m_total_blocks, u_total = (uint32_t)leaf_of_unique.size();
-    m_block_endpoint_cluster.resize(n); m_block_endpoint_pos.resize(n);
     m_endpoint_cluster_sizes.assign(m_endpoint_cluster_count, 0);
-    if (m_use_hierarchical_endpoint_codebooks) {
-        // only the block -> parent map is needed from here on; the parent lists themselves are built when somebody asks (endpoint_parent_clusters())
-        m_block_parent_endpoint_cluster.assign(n, 0);
-        if (!m_endpoint_parent_count) { m_endpoint_parent_count = 1; m_endpoint_parent_of_unique.clear(); }  // no parent level: one parent holding everything (frontend.cpp:905-911)
-    }
+    if (m_use_hierarchical_endpoint_codebooks && !m_endpoint_parent_count) { m_endpoint_parent_count = 1; m_endpoint_parent_of_unique.clear(); }  // no parent level: one parent holding everything (frontend.cpp:905-911)
     std::vector<uint32_t> first_pos(u_total);  // where vector u's blocks start inside their cluster's list
     for (uint32_t u = 0; u < u_total; u++) {
         const uint32_t c = leaf_of_unique[u];
         first_pos[u] = m_endpoint_cluster_sizes[c];
         m_endpoint_cluster_sizes[c] += m_endpoint_group_offsets[u + 1] - m_endpoint_group_offsets[u];
     }
-    parallel_for(u_total, [&](uint32_t u0, uint32_t u1) {
-        for (uint32_t u = u0; u < u1; u++) {
-            const uint32_t c = leaf_of_unique[u], a = m_endpoint_group_offsets[u];
-            for (uint32_t j = a; j < m_endpoint_group_offsets[u + 1]; j++) {
-                const uint32_t b = m_endpoint_group_blocks[j];
-                m_block_endpoint_cluster[b] = c; m_block_endpoint_pos[b] = first_pos[u] + (j - a);
-                if (m_use_hierarchical_endpoint_codebooks && !m_endpoint_parent_of_unique.empty()) m_block_parent_endpoint_cluster[b] = (uint8_t)m_endpoint_parent_of_unique[u];
-            }
-        }
-    });
-    m_endpoint_map_valid = true; m_endpoint_lists_valid = false; m_endpoint_clusters.clear();
+    device_state& d = *m_dev;
+    const bool parents = m_use_hierarchical_endpoint_codebooks && !m_endpoint_parent_of_unique.empty();
+    if (!d.upload(d.tmp_a, leaf_of_unique.data(), u_total) || !d.upload(d.tmp_b, first_pos.data(), u_total) ||
+        (parents && !d.upload(d.tmp_c, m_endpoint_parent_of_unique.data(), u_total)) || !d.reserve(d.block_cluster, (size_t)n * 4) || !d.reserve(d.ep_pos, (size_t)n * 4) ||
+        !d.reserve(d.ep_parent, n))
+        return fail("upload endpoint leaves");
+    if (!bu_hip_k_map_blocks_from_groups(d.ctx, (const uint32_t*)d.ep_goffs.p, (const uint32_t*)d.ep_idx.p, n, u_total, (const uint32_t*)d.tmp_a.p, (const uint32_t*)d.tmp_b.p,
+                                         parents ? (const uint32_t*)d.tmp_c.p : nullptr, (uint32_t*)d.block_cluster.p, (uint32_t*)d.ep_pos.p, (uint8_t*)d.ep_parent.p))
+        return fail("bu_hip_k_map_blocks_from_groups");
+    m_ep_dev_valid = true; m_endpoint_map_valid = false; m_endpoint_lists_valid = false; m_endpoint_clusters.clear();
     return true;
+}
+
+// the blocks behind every distinct endpoint training vector (the device's stable sort order), fetched when a list form is asked for
+const std::vector<uint32_t>& etc1s_frontend::endpoint_group_blocks_host() const {
+    if (m_endpoint_group_blocks.size() != m_total_blocks && m_dev && m_dev->ep_idx.p) {
+        m_endpoint_group_blocks.resize(m_total_blocks);
+        if (!m_dev->download(m_endpoint_group_blocks.data(), m_dev->ep_idx, m_total_blocks)) m_endpoint_group_blocks.clear();
+    }
+    return m_endpoint_group_blocks;
 }
 
 // ---- the endpoint clustering has two interchangeable forms: the reference's lists of training-vector ids (block * 2 + sub-block, both
@@ -397,6 +407,12 @@ bool etc1s_frontend::generate_endpoint_clusters() {
 // one; whoever needs lists (levels 4-6 bookkeeping, the getters) gets them built, and list surgery is folded back into the map.
 void etc1s_frontend::ensure_endpoint_map() const {
     if (m_endpoint_map_valid) return;
+    if (m_ep_dev_valid && m_dev) {   // the resident map is the clustering: bring it over (sizes and count are kept on the host by every stage)
+        m_block_endpoint_cluster.resize(m_total_blocks); m_block_endpoint_pos.resize(m_total_blocks);
+        if (m_dev->download(m_block_endpoint_cluster.data(), m_dev->block_cluster, m_total_blocks) && m_dev->download(m_block_endpoint_pos.data(), m_dev->ep_pos, m_total_blocks))
+            m_endpoint_map_valid = true;
+        return;
+    }
     const uint32_t k = (uint32_t)m_endpoint_clusters.size();
     m_endpoint_cluster_count = k;
     m_block_endpoint_cluster.resize(m_total_blocks); m_block_endpoint_pos.resize(m_total_blocks);
@@ -408,6 +424,16 @@ void etc1s_frontend::ensure_endpoint_map() const {
     }
     m_endpoint_map_valid = true;
 }
+bool etc1s_frontend::ensure_endpoint_map_device() {
+    if (m_ep_dev_valid) return true;
+    ensure_endpoint_map();
+    device_state& d = *m_dev;
+    if (!m_endpoint_map_valid || !d.upload(d.block_cluster, m_block_endpoint_cluster.data(), m_total_blocks) || !d.upload(d.ep_pos, m_block_endpoint_pos.data(), m_total_blocks))
+        return fail("upload endpoint map");
+    m_ep_dev_valid = true;
+    return true;
+}
+
 void etc1s_frontend::endpoint_csr(std::vector<uint32_t>& offsets, std::vector<uint32_t>& indices) const {
     ensure_endpoint_map();
     const uint32_t k = m_endpoint_cluster_count, n = m_total_blocks;
@@ -440,7 +466,7 @@ const std::vector<std::vector<uint32_t>>& etc1s_frontend::endpoint_parent_cluste
             for (uint32_t i = 0; i < m_total_blocks; i++) { m_endpoint_parent_clusters[0].push_back(i * 2); m_endpoint_parent_clusters[0].push_back(i * 2 + 1); }
         } else {
             device_tsvq::expand_parents(m_endpoint_parent_of_unique, m_endpoint_parent_count,
-                                        csr_block_pair_groups{m_endpoint_group_offsets.data(), m_endpoint_group_blocks.data()}, m_endpoint_parent_clusters);
+                                        csr_block_pair_groups{m_endpoint_group_offsets.data(), endpoint_group_blocks_host().data()}, m_endpoint_parent_clusters);
         }
     }
     return m_endpoint_parent_clusters;
@@ -452,11 +478,16 @@ void etc1s_frontend::generate_block_endpoint_clusters() { ensure_endpoint_map();
 // frontend.cpp:971-1003. The reference collects one entry per block and then sorts + uniques each parent's list; the result is
 // "the ascending set of clusters that own at least one block of this parent", which a membership table gives in O(blocks).
 void etc1s_frontend::compute_endpoint_clusters_within_each_parent_cluster() {
-    generate_block_endpoint_clusters();
     const size_t parents = m_endpoint_parent_count, clusters = m_endpoint_cluster_count;
-    std::vector<uint8_t> member(parents * clusters, 0);
-    for (uint32_t b = 0; b < m_total_blocks; b++) member[(size_t)m_block_parent_endpoint_cluster[b] * clusters + m_block_endpoint_cluster[b]] = 1;
     m_endpoint_clusters_within_each_parent_cluster.assign(parents, {});
+    device_state& d = *m_dev;
+    std::vector<uint8_t> member(parents * clusters, 0);
+    if (!ensure_endpoint_map_device() || !d.reserve(d.flags, parents * clusters + 8) ||
+        !bu_hip_k_map_membership(d.ctx, (const uint8_t*)d.ep_parent.p, (const uint32_t*)d.block_cluster.p, m_total_blocks, (uint32_t)parents, (uint32_t)clusters, (uint8_t*)d.flags.p) ||
+        !d.download(member.data(), d.flags, member.size())) {
+        fail("compute_endpoint_clusters_within_each_parent_cluster");
+        return;
+    }
     for (size_t p = 0; p < parents; p++)
         for (size_t c = 0; c < clusters; c++)
             if (member[p * clusters + c]) m_endpoint_clusters_within_each_parent_cluster[p].push_back((uint32_t)c);
@@ -465,8 +496,15 @@ void etc1s_frontend::compute_endpoint_clusters_within_each_parent_cluster() {
 // frontend.cpp:1214-1617 (CPU semantics; the kernel also handles step > 0)
 bool etc1s_frontend::generate_endpoint_codebook(uint32_t step) {
     csr lists;  // the members of every cluster in list order (it decides the float mean of clusters past 65k texels)
-    if (m_endpoint_lists_valid) lists.build(m_endpoint_clusters);
-    else endpoint_csr(lists.offsets, lists.indices);
+    const bool resident = !m_endpoint_lists_valid;   // no host lists in play: the list array is written on the device from the resident map
+    if (!resident) lists.build(m_endpoint_clusters);
+    else {
+        if (!ensure_endpoint_map_device()) return false;
+        lists.offsets.resize((size_t)m_endpoint_cluster_count + 1);
+        uint32_t run = 0;
+        for (uint32_t c = 0; c < m_endpoint_cluster_count; c++) { lists.offsets[c] = run; run += m_endpoint_cluster_sizes[c] * 2; }
+        lists.offsets[m_endpoint_cluster_count] = run;
+    }
     const uint32_t k = (uint32_t)lists.offsets.size() - 1;
     m_endpoint_cluster_etc_params.resize(k);
     const int quality = m_params.m_compression_level <= 1 ? BU_ETC_QUALITY_MEDIUM : m_params.m_compression_level == 6 ? BU_ETC_QUALITY_UBER : BU_ETC_QUALITY_SLOW; // :1530-1533
@@ -488,7 +526,10 @@ bool etc1s_frontend::generate_endpoint_codebook(uint32_t step) {
         for (uint32_t i = 0; i < k; i++)
             if (!own[i]) { prm[i * 4] = prm[i * 4 + 1] = prm[i * 4 + 2] = prm[i * 4 + 3] = 0; valid[i] = 0; err[i] = 0; }
     }
-    if (!d.upload(d.offsets, lists.offsets.data(), lists.offsets.size()) || !d.upload(d.indices, lists.indices.data(), lists.indices.size()) ||
+    if (!d.upload(d.offsets, lists.offsets.data(), lists.offsets.size()) ||
+        (resident ? (!d.reserve(d.indices, (size_t)m_total_blocks * 8) ||
+                     !bu_hip_k_map_endpoint_csr(d.ctx, (const uint32_t*)d.block_cluster.p, (const uint32_t*)d.ep_pos.p, m_total_blocks, (const uint32_t*)d.offsets.p, (uint32_t*)d.indices.p))
+                  : !d.upload(d.indices, lists.indices.data(), lists.indices.size())) ||
         !d.reserve(d.params, (size_t)k * 4 + 8) || !d.upload(d.params, prm.data(), prm.size()) || !d.upload(d.err, err.data(), err.size()) ||
         !d.reserve(d.valid, (size_t)k + 8) || !d.upload(d.valid, valid.data(), valid.size()))
         return fail("upload endpoint clusters");
@@ -522,7 +563,7 @@ bool etc1s_frontend::introduce_new_endpoint_clusters() {
         prm[i * 4] = e.r; prm[i * 4 + 1] = e.g; prm[i * 4 + 2] = e.b; prm[i * 4 + 3] = e.inten;
     }
     device_state& d = *m_dev;
-    if (!d.upload(d.block_cluster, m_block_endpoint_cluster.data(), n) || !d.upload(d.params, prm.data(), prm.size()) || !d.reserve(d.err, (size_t)n * 2 * 8)) return fail("upload");
+    if (!ensure_endpoint_map_device() || !d.upload(d.params, prm.data(), prm.size()) || !d.reserve(d.err, (size_t)n * 2 * 8)) return fail("upload");
     if (!bu_hip_k_subblock_errors(d.ctx, d.d_pixels, n, (const uint32_t*)d.block_cluster.p, (const uint8_t*)d.params.p, m_params.m_perceptual, (uint64_t*)d.err.p))
         return fail("bu_hip_k_subblock_errors");
     std::vector<uint64_t> err((size_t)n * 2);
@@ -551,7 +592,7 @@ bool etc1s_frontend::introduce_new_endpoint_clusters() {
         std::vector<uint32_t>& l = m_endpoint_clusters[i];
         l.erase(std::remove_if(l.begin(), l.end(), [&](uint32_t tv) { return relocated[tv] != 0; }), l.end());
     }
-    m_endpoint_map_valid = false;
+    m_endpoint_map_valid = false; m_ep_dev_valid = false;
     generate_block_endpoint_clusters();
     return true;
 }
@@ -560,6 +601,7 @@ bool etc1s_frontend::introduce_new_endpoint_clusters() {
 // here. The per-cluster sub-block lists are the reference's m_subblocks, which are appended to on every call and never cleared.
 bool etc1s_frontend::refine_block_endpoints_given_selectors(uint32_t* total_refined) {
     const uint32_t n = m_total_blocks, k = (uint32_t)m_endpoint_cluster_etc_params.size();
+    ensure_endpoint_map(); ensure_encoded_host();
     m_endpoint_cluster_subblocks.resize(k);
     for (uint32_t b = 0; b < n; b++) {
         std::vector<uint32_t>& l = m_endpoint_cluster_subblocks[m_block_endpoint_cluster[b]];
@@ -568,7 +610,7 @@ bool etc1s_frontend::refine_block_endpoints_given_selectors(uint32_t* total_refi
     csr lists; lists.build(m_endpoint_cluster_subblocks);
     device_state& d = *m_dev;
     if (!d.upload(d.offsets, lists.offsets.data(), lists.offsets.size()) || !d.upload(d.indices, lists.indices.data(), lists.indices.size()) ||
-        !d.upload(d.enc, m_encoded_blocks.data(), n) || !d.reserve(d.params, (size_t)k * 4) || !d.reserve(d.err, (size_t)k * 8) || !d.reserve(d.valid, k) ||
+        !ensure_encoded_device() || !d.reserve(d.params, (size_t)k * 4) || !d.reserve(d.err, (size_t)k * 8) || !d.reserve(d.valid, k) ||
         !d.reserve(d.weights, (size_t)k * 8))
         return fail("upload");
     if (!bu_hip_k_refit_endpoints_given_selectors(d.ctx, d.d_pixels, d.enc.p, k, lists.offsets.data(), (const uint32_t*)d.offsets.p, (const uint32_t*)d.indices.p,
@@ -622,7 +664,7 @@ bool etc1s_frontend::refine_block_endpoints_given_selectors(uint32_t* total_refi
             e.r = (uint8_t)nr; e.g = (uint8_t)ng; e.b = (uint8_t)nb; e.inten = (uint8_t)ninten; e.color_error = err[ci];
         }
     }
-    if (refined && !d.upload(d.enc, m_encoded_blocks.data(), n)) return fail("upload refined blocks");  // the next selector pass reads the device copy
+    if (refined) m_enc_dev_valid = false;  // the host copy changed: the next selector pass uploads it (ensure_encoded_device)
     if (total_refined) *total_refined = refined;
     return true;
 }
@@ -635,7 +677,7 @@ bool etc1s_frontend::refine_block_endpoints_given_selectors(uint32_t* total_refi
 bool etc1s_frontend::reoptimize_remapped_endpoints(const std::vector<uint32_t>& new_block_endpoints, std::vector<int>& old_to_new, bool optimize_final_codebook,
                                                    const std::vector<uint32_t>* block_selector_indices) {
     if (!m_dev) return fail("reoptimize_remapped_endpoints: the context this frontend was initialised on has been destroyed");
-    ensure_endpoint_map();
+    ensure_endpoint_map(); ensure_encoded_host(); ensure_selector_map_host();
     const uint32_t n = m_total_blocks, k = m_endpoint_cluster_count;
     if (new_block_endpoints.size() != n || m_endpoint_cluster_etc_params.size() != k) return fail("reoptimize_remapped_endpoints: size mismatch");
     // the blocks of every cluster under the new assignment, ascending, and the blocks as they would be coded with it
@@ -657,7 +699,7 @@ bool etc1s_frontend::reoptimize_remapped_endpoints(const std::vector<uint32_t>& 
     if (!d.upload(d.offsets, offsets.data(), offsets.size()) || !d.upload(d.indices, indices.data(), indices.size()) || !d.upload(d.enc, trial.data(), n) ||
         !d.reserve(d.params, (size_t)k * 4) || !d.reserve(d.err, (size_t)k * 8) || !d.reserve(d.valid, k) || !d.reserve(d.weights, (size_t)k * 8))
         return fail("upload");
-    m_enc_device_current = false;
+    m_enc_dev_valid = false;   // d.enc now holds the trial blocks
     if (!bu_hip_k_refit_endpoints_given_selectors_q(d.ctx, d.d_pixels, d.enc.p, k, offsets.data(), (const uint32_t*)d.offsets.p, (const uint32_t*)d.indices.p, quality,
                                                     m_params.m_perceptual, (uint8_t*)d.params.p, (uint64_t*)d.err.p, (uint8_t*)d.valid.p, (uint64_t*)d.weights.p))
         return fail("bu_hip_k_refit_endpoints_given_selectors_q");
@@ -687,9 +729,9 @@ bool etc1s_frontend::reoptimize_remapped_endpoints(const std::vector<uint32_t>& 
     m_endpoint_cluster_etc_params.swap(params);
     m_endpoint_cluster_sizes.swap(sizes);
     m_endpoint_cluster_count = kept;
-    m_endpoint_map_valid = true; m_endpoint_lists_valid = false; m_endpoint_clusters.clear();
+    m_endpoint_map_valid = true; m_ep_dev_valid = false; m_endpoint_lists_valid = false; m_endpoint_clusters.clear();
     m_endpoint_cluster_subblocks.clear();
-    eliminate_redundant_or_empty_endpoint_clusters();
+    if (!eliminate_redundant_or_empty_endpoint_clusters()) return false;
     for (uint32_t b = 0; b < n; b++) old_to_new[new_block_endpoints[b]] = (int)m_block_endpoint_cluster[b];
     for (uint32_t b = 0; b < n; b++) {
         const endpoint_params& e = m_endpoint_cluster_etc_params[m_block_endpoint_cluster[b]];
@@ -702,10 +744,9 @@ bool etc1s_frontend::reoptimize_remapped_endpoints(const std::vector<uint32_t>& 
 
 // frontend.cpp:1648-1945
 bool etc1s_frontend::refine_endpoint_clusterization(uint32_t* total_reassigned) {
-    if (m_use_hierarchical_endpoint_codebooks) compute_endpoint_clusters_within_each_parent_cluster();  // refreshes m_block_endpoint_cluster
-    else generate_block_endpoint_clusters();
+    if (!ensure_endpoint_map_device()) return false;
+    if (m_use_hierarchical_endpoint_codebooks) compute_endpoint_clusters_within_each_parent_cluster();
     const uint32_t n = m_total_blocks, k = m_endpoint_cluster_count;
-    const std::vector<uint32_t>& block_cluster = m_block_endpoint_cluster;  // the block -> cluster map of the clustering as it stands
     std::vector<uint8_t> prm(k * 4ull);
     for (uint32_t i = 0; i < k; i++) {
         const endpoint_params& e = m_endpoint_cluster_etc_params[i];
@@ -714,53 +755,34 @@ bool etc1s_frontend::refine_endpoint_clusterization(uint32_t* total_reassigned) 
     device_state& d = *m_dev;
     uint32_t n_parents = 0;
     if (m_use_hierarchical_endpoint_codebooks) {
+        if (m_endpoint_clusters_within_each_parent_cluster.size() != m_endpoint_parent_count) return false;   // the membership pass failed (error already set)
         csr cand; cand.build(m_endpoint_clusters_within_each_parent_cluster);
         n_parents = (uint32_t)m_endpoint_clusters_within_each_parent_cluster.size();
-        if (!d.upload(d.cand_offsets, cand.offsets.data(), cand.offsets.size()) || !d.upload(d.cand_indices, cand.indices.data(), cand.indices.size()) ||
-            !d.upload(d.block_parent, m_block_parent_endpoint_cluster.data(), n))
+        if (!d.upload(d.cand_offsets, cand.offsets.data(), cand.offsets.size()) || !d.upload(d.cand_indices, cand.indices.data(), cand.indices.size()))
             return fail("upload parent lists");
     }
-    if (!d.upload(d.block_cluster, block_cluster.data(), n) || !d.upload(d.params, prm.data(), prm.size()) || !d.reserve(d.out_u32, (size_t)comm_world() * slab_blocks() * 4))
+    const size_t padded = (size_t)comm_world() * slab_blocks();
+    if (!d.upload(d.params, prm.data(), prm.size()) || !d.reserve(d.out_u32, padded * 4) || !d.reserve(d.map_sizes, ((size_t)k + 1) * 4) ||
+        !d.reserve(d.map_offs, ((size_t)k + 1) * 4) || !d.reserve(d.map_sorted, (size_t)n * 4) || !d.reserve(d.map_word, 64))
         return fail("upload refine inputs");
     uint32_t b0, nb;
     my_slab(b0, nb);
     if (nb && !bu_hip_k_refine_endpoint_clusterization(d.ctx, (const char*)d.d_pixels + (size_t)b0 * 64, nb, (const uint32_t*)d.block_cluster.p + b0, (const uint8_t*)d.params.p, k,
                                                        n_parents, (const uint32_t*)d.cand_offsets.p, (const uint32_t*)d.cand_indices.p,
-                                                       n_parents ? (const uint8_t*)d.block_parent.p + b0 : nullptr, m_params.m_perceptual, (uint32_t*)d.out_u32.p + b0))
+                                                       n_parents ? (const uint8_t*)d.ep_parent.p + b0 : nullptr, m_params.m_perceptual, (uint32_t*)d.out_u32.p + b0))
         return fail("bu_hip_k_refine_endpoint_clusterization");
     if (!gather_blocks(d.out_u32.p, 4)) return false;
-    std::vector<uint32_t> best(n);
-    if (!d.download(best.data(), d.out_u32, n)) return fail("download refine result");
-
     // frontend.cpp:1921-1942 rebuilds the cluster lists in block order (empty clusters stay, they are removed by eliminate_...): the new
-    // position of a block is its rank among its cluster's blocks. Per-thread counts over contiguous block ranges, then a second sweep.
+    // position of a block is its rank among its cluster's blocks -- a stable sort of the block ids by their new cluster, on the device.
+    if (!bu_hip_k_map_count_differences(d.ctx, (const uint32_t*)d.block_cluster.p, (const uint32_t*)d.out_u32.p, n, (uint32_t*)d.map_word.p) ||
+        !bu_hip_k_map_rank_blocks(d.ctx, (const uint32_t*)d.out_u32.p, n, k, (uint32_t*)d.map_sizes.p, (uint32_t*)d.map_offs.p, (uint32_t*)d.map_sorted.p, (uint32_t*)d.ep_pos.p))
+        return fail("bu_hip_k_map_rank_blocks");
     uint32_t moved = 0;
-    {
-        const unsigned T = n > 65536 ? host_threads() : 1;
-        const uint32_t per = (n + T - 1) / T;
-        std::vector<uint32_t> hist((size_t)T * k, 0), moved_t(T, 0);
-        parallel_for_chunks(T, [&](unsigned t) {
-            uint32_t* h = &hist[(size_t)t * k];
-            const uint32_t a = t * per, b = std::min(n, a + per);
-            uint32_t m = 0;
-            for (uint32_t i = a; i < b; i++) { h[best[i]]++; m += best[i] != block_cluster[i]; }
-            moved_t[t] = m;
-        });
-        m_endpoint_cluster_sizes.assign(k, 0);
-        for (uint32_t c = 0; c < k; c++) {
-            uint32_t run = 0;
-            for (unsigned t = 0; t < T; t++) { const uint32_t v = hist[(size_t)t * k + c]; hist[(size_t)t * k + c] = run; run += v; }
-            m_endpoint_cluster_sizes[c] = run;
-        }
-        for (unsigned t = 0; t < T; t++) moved += moved_t[t];
-        parallel_for_chunks(T, [&](unsigned t) {
-            uint32_t* cur = &hist[(size_t)t * k];
-            const uint32_t a = t * per, b = std::min(n, a + per);
-            for (uint32_t i = a; i < b; i++) m_block_endpoint_pos[i] = cur[best[i]]++;
-        });
-    }
-    m_block_endpoint_cluster.swap(best);
-    m_endpoint_map_valid = true; m_endpoint_lists_valid = false; m_endpoint_clusters.clear();
+    m_endpoint_cluster_sizes.assign(k, 0);
+    if (!d.download(m_endpoint_cluster_sizes.data(), d.map_sizes, k) || !d.download(&moved, d.map_word, 1)) return fail("download refine result");
+    std::swap(d.block_cluster, d.out_u32);   // the reassignment IS the clustering now
+    if (d.block_cluster.cap < (size_t)n * 4 || d.out_u32.cap < (size_t)n * 4) return fail("refine buffers");
+    m_ep_dev_valid = true; m_endpoint_map_valid = false; m_endpoint_lists_valid = false; m_endpoint_clusters.clear();
     if (total_reassigned) *total_reassigned = moved;
     return true;
 }
@@ -768,8 +790,8 @@ bool etc1s_frontend::refine_endpoint_clusterization(uint32_t* total_reassigned) 
 // frontend.cpp:1947-2012. The ordering comes from indirect_sort = std::sort over indices with operator< on the parameters
 // (frontend.h:248-267): (r, g, b, a=255) of the colour, then the (all-zero) second colour, then inten. std::sort is not stable,
 // so we call the very same algorithm with an equivalent comparator to get the same permutation among equal keys.
-void etc1s_frontend::eliminate_redundant_or_empty_endpoint_clusters() {
-    ensure_endpoint_map();
+bool etc1s_frontend::eliminate_redundant_or_empty_endpoint_clusters() {
+    if (!m_ep_dev_valid) ensure_endpoint_map();
     const uint32_t k = m_endpoint_cluster_count, n = m_total_blocks;
     std::vector<uint32_t> order(k);
     std::iota(order.begin(), order.end(), 0u);
@@ -793,17 +815,25 @@ void etc1s_frontend::eliminate_redundant_or_empty_endpoint_clusters() {
         sizes.push_back(run);
         i = j;
     }
-    parallel_for(n, [&](uint32_t b0, uint32_t b1) {
-        for (uint32_t b = b0; b < b1; b++) {
-            const uint32_t old = m_block_endpoint_cluster[b];
-            m_block_endpoint_pos[b] += base[old];
-            m_block_endpoint_cluster[b] = new_index[old];
-        }
-    });
+    if (m_endpoint_map_valid)
+        parallel_for(n, [&](uint32_t b0, uint32_t b1) {
+            for (uint32_t b = b0; b < b1; b++) {
+                const uint32_t old = m_block_endpoint_cluster[b];
+                m_block_endpoint_pos[b] += base[old];
+                m_block_endpoint_cluster[b] = new_index[old];
+            }
+        });
+    if (m_ep_dev_valid) {
+        device_state& d = *m_dev;
+        if (!d.upload(d.tmp_a, new_index.data(), k) || !d.upload(d.tmp_b, base.data(), k) ||
+            !bu_hip_k_map_remap(d.ctx, (uint32_t*)d.block_cluster.p, (uint32_t*)d.ep_pos.p, n, (const uint32_t*)d.tmp_a.p, (const uint32_t*)d.tmp_b.p))
+            return fail("bu_hip_k_map_remap");
+    }
     m_endpoint_cluster_sizes.swap(sizes);
     m_endpoint_cluster_count = (uint32_t)params.size();
     m_endpoint_cluster_etc_params.swap(params);
     m_endpoint_lists_valid = false; m_endpoint_clusters.clear();
+    return true;
 }
 
 // frontend.cpp:2014-2096
@@ -815,15 +845,37 @@ bool etc1s_frontend::create_initial_packed_texture() {
         prm[i * 4] = e.r; prm[i * 4 + 1] = e.g; prm[i * 4 + 2] = e.b; prm[i * 4 + 3] = e.inten;
     }
     device_state& d = *m_dev;
-    if (!d.upload(d.params, prm.data(), prm.size()) || !d.upload(d.block_cluster, m_block_endpoint_cluster.data(), n) || !d.reserve(d.enc, (size_t)n * 8)) return fail("upload");
+    const size_t padded = (size_t)comm_world() * slab_blocks();
+    if (!ensure_endpoint_map_device() || !d.upload(d.params, prm.data(), prm.size()) || !d.reserve(d.enc, padded * 8) || !d.reserve(d.orig_enc, (size_t)n * 8)) return fail("upload");
     if (!bu_hip_k_determine_selectors(d.ctx, d.d_pixels, n, (const uint8_t*)d.params.p, (const uint32_t*)d.block_cluster.p, m_params.m_perceptual, d.enc.p))
         return fail("bu_hip_k_determine_selectors");
-    m_encoded_blocks.resize(n);
-    if (!d.download(m_encoded_blocks.data(), d.enc, n)) return fail("download encoded blocks");
-    m_enc_device_current = true;
-    m_orig_encoded_blocks = m_encoded_blocks;
+    // m_orig_encoded_blocks = m_encoded_blocks (frontend.cpp:2093): both stay resident, the host copies are fetched when somebody asks
+    if (!bu_hip_memcpy_d2d(d.ctx, d.orig_enc.p, d.enc.p, (size_t)n * 8)) return fail("copy");
+    m_enc_dev_valid = true; m_enc_host_valid = false; m_orig_host_valid = false;
     return true;
 }
+
+// ---- the encoded blocks live where they were last written; the other side is brought up to date on demand
+void etc1s_frontend::ensure_encoded_host() const {
+    if (m_enc_host_valid) return;
+    m_encoded_blocks.resize(m_total_blocks);
+    if (m_dev && m_dev->enc.p && m_dev->download(m_encoded_blocks.data(), m_dev->enc, m_total_blocks)) m_enc_host_valid = true;
+}
+void etc1s_frontend::ensure_orig_encoded_host() const {
+    if (m_orig_host_valid) return;
+    m_orig_encoded_blocks.resize(m_total_blocks);
+    if (m_dev && m_dev->orig_enc.p && m_dev->download(m_orig_encoded_blocks.data(), m_dev->orig_enc, m_total_blocks)) m_orig_host_valid = true;
+}
+bool etc1s_frontend::ensure_encoded_device() {
+    if (m_enc_dev_valid) return true;
+    device_state& d = *m_dev;
+    const size_t padded = (size_t)comm_world() * slab_blocks();
+    ensure_encoded_host();
+    if (!m_enc_host_valid || !d.reserve(d.enc, padded * 8) || !d.upload(d.enc, m_encoded_blocks.data(), m_total_blocks)) return fail("upload encoded blocks");
+    m_enc_dev_valid = true;
+    return true;
+}
+void etc1s_frontend::ensure_selector_map_host() const {}   // the selector map is kept on the host (see find_optimal_selector_clusters_for_each_block)
 
 // frontend.cpp:2140-2257: selector training vectors (16 selector values as floats, weight from the endpoint colour spread) +
 // de-duplication + TSVQ. The std::map order of vec16F (enc.h:382) is the numeric order of the 32-bit word holding s(0,0) in
@@ -833,7 +885,7 @@ bool etc1s_frontend::generate_selector_clusters() {
     device_state& d = *m_dev;
     timer sub;
     auto lap = [&](const char* name) { m_stage_times.push_back(stage_time{name, sub.seconds()}); sub = timer(); };
-    if (!d.reserve(d.weights, (size_t)n * 8)) return fail("alloc");
+    if (!ensure_encoded_device() || !d.reserve(d.weights, (size_t)n * 8)) return fail("alloc");
     if (!bu_hip_k_selector_training_vectors(d.ctx, d.enc.p, n, m_params.m_perceptual, nullptr, (uint64_t*)d.weights.p)) return fail("bu_hip_k_selector_training_vectors");
     lap("~gsc/weights");
     // De-duplication on the device (unique_kernels.hip): keys of the resident blocks, stable sort, run lengths, exact weight sums. The host
@@ -951,7 +1003,7 @@ bool etc1s_frontend::create_optimized_selector_codebook(uint32_t /*iter*/) {
         if (c1 < c0) c1 = c0;
         for (uint32_t i = 0; i < k; i++) if (i < c0 || i >= c1) mine[i] = bu_etc_block{};
     }
-    if (!d.upload(d.offsets, lists.offsets.data(), lists.offsets.size()) || !d.upload(d.indices, lists.indices.data(), lists.indices.size()) ||
+    if (!ensure_encoded_device() || !d.upload(d.offsets, lists.offsets.data(), lists.offsets.size()) || !d.upload(d.indices, lists.indices.data(), lists.indices.size()) ||
         !d.reserve(d.sel_blocks, (size_t)k * 8 + 8) || !d.upload(d.sel_blocks, mine.data(), k))
         return fail("upload selector clusters");
     if (c1 > c0 && !bu_hip_k_create_optimized_selector_codebook(d.ctx, d.d_pixels, d.enc.p, c1 - c0, (const uint32_t*)d.offsets.p + c0, (const uint32_t*)d.indices.p, m_params.m_perceptual,
@@ -968,11 +1020,12 @@ bool etc1s_frontend::find_optimal_selector_clusters_for_each_block() {
     m_block_selector_cluster_index.resize(n);
     if (m_params.m_compression_level == 0) {
         // frontend.cpp:2420-2439: blocks stay in their TSVQ cluster and just take its optimised selectors
+        ensure_encoded_host();
         for (uint32_t b = 0; b < n; b++) {
             const uint32_t bits = raw_selector_bits(m_optimized_cluster_selectors[m_block_selector_cluster_index[b]]);
             store_be64(m_encoded_blocks[b], (load_be64(m_encoded_blocks[b]) & ~0xFFFFFFFFull) | bits);
         }
-        m_enc_device_current = false;
+        m_enc_dev_valid = false;
         return true;
     }
     device_state& d = *m_dev;
@@ -985,10 +1038,8 @@ bool etc1s_frontend::find_optimal_selector_clusters_for_each_block() {
             return fail("upload selector parent lists");
     }
     const size_t padded = (size_t)comm_world() * slab_blocks();
-    // the device copy of the encoded blocks is still the one create_initial_packed_texture produced unless the host touched them since
-    const bool enc_resident = m_enc_device_current && d.enc.cap >= padded * 8;
-    if (!d.upload(d.sel_blocks, m_optimized_cluster_selectors.data(), k) || (!enc_resident && (!d.reserve(d.enc, padded * 8) || !d.upload(d.enc, m_encoded_blocks.data(), n))) ||
-        !d.reserve(d.out_u32, padded * 4))
+    // the encoded blocks stay resident from create_initial_packed_texture on unless the host touched them since (ensure_encoded_device)
+    if (!ensure_encoded_device() || !d.upload(d.sel_blocks, m_optimized_cluster_selectors.data(), k) || !d.reserve(d.out_u32, padded * 4))
         return fail("upload fosc inputs");
     uint32_t b0, nb;
     my_slab(b0, nb);  // slabs start on multiples of the reference's 2048-block jobs, so the "same tile as the previous block of this job" shortcut sees the same neighbours
@@ -997,7 +1048,8 @@ bool etc1s_frontend::find_optimal_selector_clusters_for_each_block() {
                                                        m_params.m_perceptual, kFoscJobSize, (uint32_t*)d.out_u32.p + b0))
         return fail("bu_hip_k_find_optimal_selector_clusters");
     if (!gather_blocks(d.enc.p, 8) || !gather_blocks(d.out_u32.p, 4)) return false;
-    if (!d.download(m_block_selector_cluster_index.data(), d.out_u32, n) || !d.download(m_encoded_blocks.data(), d.enc, n)) return fail("download fosc result");
+    if (!d.download(m_block_selector_cluster_index.data(), d.out_u32, n)) return fail("download fosc result");
+    m_enc_host_valid = false;   // rewritten on the device; fetched when somebody asks (ensure_encoded_host)
     m_selector_lists_valid = false;  // frontend.cpp:2696-2708 rebuilds the lists in block order: that is what selector_cluster_block_indices() produces
     return true;
 }
@@ -1033,6 +1085,8 @@ bool etc1s_frontend::introduce_special_selector_clusters() {
         for (const bu_etc_block& s : m_optimized_cluster_selectors) if (raw_selector_bits(s) == flat) { present = true; break; }
         if (present) continue;
         const uint32_t new_index = (uint32_t)m_optimized_cluster_selectors.size();
+        ensure_orig_encoded_host(); ensure_encoded_host(); ensure_endpoint_map();
+        if (!m_orig_host_valid || !m_enc_host_valid || !m_endpoint_map_valid) return fail("download blocks");
         bu_etc_block nb{}; store_be64(nb, flat);
         m_optimized_cluster_selectors.push_back(nb);
         m_selector_cluster_count = new_index + 1;
@@ -1047,7 +1101,7 @@ bool etc1s_frontend::introduce_special_selector_clusters() {
             m_block_selector_cluster_index[b] = new_index;  // the lists (block order) follow from the map
             total_relocated++;
             store_be64(m_encoded_blocks[b], (load_be64(m_encoded_blocks[b]) & ~0xFFFFFFFFull) | flat);
-            m_enc_device_current = false;
+            m_enc_dev_valid = false;
         }
     }
     (void)total_relocated;
@@ -1083,7 +1137,15 @@ void etc1s_frontend::optimize_selector_codebook() {
 
 // frontend.cpp:2980-2992
 void etc1s_frontend::finalize() {
-    for (uint32_t b = 0; b < m_total_blocks; b++) m_endpoint_cluster_etc_params[m_block_endpoint_cluster[b]].color_used = true;
+    // "used" = owns at least one block; the sizes are kept current by every stage that changes the clustering
+    if (m_endpoint_cluster_sizes.size() == m_endpoint_cluster_etc_params.size() && (m_ep_dev_valid || m_endpoint_map_valid)) {
+        for (size_t c = 0; c < m_endpoint_cluster_sizes.size(); c++) if (m_endpoint_cluster_sizes[c]) m_endpoint_cluster_etc_params[c].color_used = true;
+    } else {
+        ensure_endpoint_map();
+        for (uint32_t b = 0; b < m_total_blocks; b++) m_endpoint_cluster_etc_params[m_block_endpoint_cluster[b]].color_used = true;
+    }
+    // the frontend's results as its consumers read them (frontend.h:119-156): encoded blocks and both per-block indices on the host
+    ensure_encoded_host(); ensure_endpoint_map(); ensure_selector_map_host();
 }
 
 } // namespace bu

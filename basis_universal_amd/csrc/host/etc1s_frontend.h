@@ -56,8 +56,8 @@ public:
     // ---- getters with the reference's names (frontend.h:119-156)
     const params& get_params() const { return m_params; }
     uint32_t get_total_output_blocks() const { return (uint32_t)m_encoded_blocks.size(); }
-    const bu_etc_block& get_output_block(uint32_t i) const { return m_encoded_blocks[i]; }
-    const std::vector<bu_etc_block>& get_output_blocks() const { return m_encoded_blocks; }
+    const bu_etc_block& get_output_block(uint32_t i) const { ensure_encoded_host(); return m_encoded_blocks[i]; }
+    const std::vector<bu_etc_block>& get_output_blocks() const { ensure_encoded_host(); return m_encoded_blocks; }
     const bu_etc_block& get_etc1s_block(uint32_t i) const { return etc1_blocks()[i]; }
     uint32_t get_total_endpoint_clusters() const { ensure_endpoint_map(); return m_endpoint_cluster_count; }
     uint32_t get_subblock_endpoint_cluster_index(uint32_t block, uint32_t) const { ensure_endpoint_map(); return m_block_endpoint_cluster[block]; }
@@ -69,7 +69,7 @@ public:
 
     // ---- stage state, exposed for stage-by-stage parity tests
     const std::vector<bu_etc_block>& etc1_blocks() const;  // fetched from the device on first use
-    const std::vector<bu_etc_block>& orig_encoded_blocks() const { return m_orig_encoded_blocks; }
+    const std::vector<bu_etc_block>& orig_encoded_blocks() const { ensure_orig_encoded_host(); return m_orig_encoded_blocks; }
     const std::vector<std::vector<uint32_t>>& endpoint_clusters() const;  // built on first use from the (cluster, position) map
     const std::vector<std::vector<uint32_t>>& endpoint_parent_clusters() const;  // built on first use from the parent-of-vector map
     const std::vector<endpoint_params>& endpoint_cluster_params() const { return m_endpoint_cluster_etc_params; }
@@ -95,7 +95,7 @@ public:
     bool introduce_new_endpoint_clusters();
     bool generate_endpoint_codebook(uint32_t step);
     bool refine_endpoint_clusterization(uint32_t* total_reassigned);
-    void eliminate_redundant_or_empty_endpoint_clusters();
+    bool eliminate_redundant_or_empty_endpoint_clusters();
     void generate_block_endpoint_clusters();
     void compute_endpoint_clusters_within_each_parent_cluster();
     bool create_initial_packed_texture();
@@ -132,21 +132,32 @@ private:
     uint32_t m_num_endpoint_codebook_iterations = 1;
     uint32_t m_num_selector_codebook_iterations = 1;
 
-    std::vector<bu_etc_block> m_encoded_blocks, m_orig_encoded_blocks;
+    // The encoded blocks (and their pre-selector-quantisation copy) live where they were last written -- normally HBM; the other side is
+    // brought up to date on demand (ensure_encoded_host / ensure_encoded_device).
+    mutable std::vector<bu_etc_block> m_encoded_blocks, m_orig_encoded_blocks;
+    mutable bool m_enc_host_valid = true, m_orig_host_valid = true;
+    bool m_enc_dev_valid = false;
+    void ensure_encoded_host() const;
+    void ensure_orig_encoded_host() const;
+    bool ensure_encoded_device();
+    void ensure_selector_map_host() const;
     mutable std::vector<bu_etc_block> m_etc1_blocks_etc1s;  // host mirror of the device's a6 output, see etc1_blocks()
     mutable bool m_etc1_on_host = false;
-    bool m_enc_device_current = false;  // the device copy of m_encoded_blocks is identical to the host's
 
     // endpoint side
     std::vector<float> m_endpoint_unique_rows;            // distinct (low rgb, high rgb)/255 vectors, ascending
     std::vector<uint64_t> m_endpoint_unique_weights;
-    std::vector<uint32_t> m_endpoint_group_offsets, m_endpoint_group_blocks;  // CSR: the blocks behind every distinct vector, ascending
+    std::vector<uint32_t> m_endpoint_group_offsets;            // CSR offsets: the blocks behind every distinct vector ...
+    mutable std::vector<uint32_t> m_endpoint_group_blocks;     // ... ascending; resident, fetched by endpoint_group_blocks_host() when a list form is asked for
+    const std::vector<uint32_t>& endpoint_group_blocks_host() const;
     // the endpoint clustering in its two forms (etc1s_frontend.cpp, ensure_endpoint_map / ensure_endpoint_lists)
     mutable std::vector<std::vector<uint32_t>> m_endpoint_clusters;
     mutable std::vector<uint32_t> m_block_endpoint_pos, m_endpoint_cluster_sizes;
     mutable uint32_t m_endpoint_cluster_count = 0;
-    mutable bool m_endpoint_map_valid = false, m_endpoint_lists_valid = false;
+    mutable bool m_endpoint_map_valid = false, m_endpoint_lists_valid = false;   // the HOST forms (per-block arrays / lists)
+    bool m_ep_dev_valid = false;                                                   // the RESIDENT per-block arrays (device_state::block_cluster, ep_pos) are current
     void ensure_endpoint_map() const;
+    bool ensure_endpoint_map_device();
     void ensure_endpoint_lists() const;
     void endpoint_csr(std::vector<uint32_t>& offsets, std::vector<uint32_t>& indices) const;
     mutable std::vector<std::vector<uint32_t>> m_endpoint_parent_clusters;  // lazily materialised, see endpoint_parent_clusters()

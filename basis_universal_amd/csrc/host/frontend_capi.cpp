@@ -82,7 +82,7 @@ int bu_frontend_call(bu_frontend* f, const char* stage, uint32_t arg) {
     if (n == "introduce_new_endpoint_clusters") return fe.introduce_new_endpoint_clusters();
     if (n == "generate_endpoint_codebook") return fe.generate_endpoint_codebook(arg);
     if (n == "refine_endpoint_clusterization") { uint32_t moved = 0; return fe.refine_endpoint_clusterization(&moved); }
-    if (n == "eliminate_redundant_or_empty_endpoint_clusters") { fe.eliminate_redundant_or_empty_endpoint_clusters(); return 1; }
+    if (n == "eliminate_redundant_or_empty_endpoint_clusters") return fe.eliminate_redundant_or_empty_endpoint_clusters();
     if (n == "generate_block_endpoint_clusters") { fe.generate_block_endpoint_clusters(); return 1; }
     if (n == "create_initial_packed_texture") return fe.create_initial_packed_texture();
     if (n == "generate_selector_clusters") return fe.generate_selector_clusters();

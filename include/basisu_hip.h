@@ -107,6 +107,7 @@ BU_HIP_API void  bu_hip_free(bu_hip_context*, void* d_ptr);
 BU_HIP_API int   bu_hip_memcpy_h2d(bu_hip_context*, void* d_dst, const void* h_src, size_t bytes); /* synchronises */
 BU_HIP_API int   bu_hip_memcpy_d2h(bu_hip_context*, void* h_dst, const void* d_src, size_t bytes); /* synchronises */
 BU_HIP_API int   bu_hip_memset(bu_hip_context*, void* d_dst, int value, size_t bytes);
+BU_HIP_API int   bu_hip_memcpy_d2d(bu_hip_context*, void* d_dst, const void* d_src, size_t bytes); /* stream-ordered */
 
 /* Adopt pixel blocks that are already resident (no copy, not owned). Counterpart of bu_hip_set_pixel_blocks. */
 BU_HIP_API int   bu_hip_set_pixel_blocks_device(bu_hip_context*, size_t total_blocks, const void* d_pixel_blocks);
@@ -212,6 +213,31 @@ BU_HIP_API int bu_hip_k_uastc_rdo(bu_hip_context*, void* d_uastc_blocks, const v
 BU_HIP_API int bu_hip_uastc_rdo(bu_hip_context*, bu_uastc_block* blocks, const bu_uastc_rdo_params* params, uint32_t flags, uint32_t total_jobs,
                                 uint32_t out_stats[4]);
 
+/* a15 + the list handling inside a9 / a10 / a13 / a14: cluster bookkeeping on the device (basis_universal_amd/csrc/bookkeeping_kernels.hip).
+ *     A clustering is two resident per-block arrays, cluster index and position inside the cluster's list; these calls turn distinct-vector level
+ *     results into them, rebuild them after a reassignment, apply codebook renumberings to them and produce the CSR lists the per-cluster
+ *     kernels read, so that no block-sized array crosses PCIe between the frontend's stages. Stream-ordered; nothing synchronises.
+ *   map_blocks_from_groups: groups = the output of bu_hip_k_unique_*_vectors (d_group_offsets[u_total + 1], d_sorted_block_idx[n]); every block of
+ *     distinct vector u gets cluster d_leaf_of_unique[u], position d_first_pos[u] + its rank inside the group, parent d_parent_of_unique[u]
+ *     (d_first_pos / d_out_pos and d_parent_of_unique / d_out_parent may be NULL).
+ *   map_rank_blocks (frontend.cpp:1921-1942, lists rebuilt in block order): d_out_sizes[k + 1] (last entry 0), d_out_offsets[k + 1] (exclusive
+ *     sum), d_out_sorted_blocks[n] = block ids grouped by cluster, ascending inside a cluster, d_out_pos[n] (may be NULL) = rank of every block. */
+BU_HIP_API int bu_hip_k_map_blocks_from_groups(bu_hip_context*, const uint32_t* d_group_offsets, const uint32_t* d_sorted_block_idx, uint32_t n_blocks, uint32_t u_total,
+    const uint32_t* d_leaf_of_unique, const uint32_t* d_first_pos, const uint32_t* d_parent_of_unique, uint32_t* d_out_cluster, uint32_t* d_out_pos, uint8_t* d_out_parent);
+BU_HIP_API int bu_hip_k_map_rank_blocks(bu_hip_context*, const uint32_t* d_block_cluster, uint32_t n_blocks, uint32_t n_clusters, uint32_t* d_out_sizes,
+    uint32_t* d_out_offsets, uint32_t* d_out_sorted_blocks, uint32_t* d_out_pos);
+/*   map_endpoint_csr: d_out_indices[d_offsets[cluster] + 2 * pos] = 2b, 2b + 1 (d_offsets in training-vector units: 2 per block). */
+BU_HIP_API int bu_hip_k_map_endpoint_csr(bu_hip_context*, const uint32_t* d_block_cluster, const uint32_t* d_block_pos, uint32_t n_blocks, const uint32_t* d_offsets,
+    uint32_t* d_out_indices);
+/*   map_remap: cluster[b] = d_new_index[old], pos[b] += d_base[old] (d_block_pos and d_base may be NULL). */
+BU_HIP_API int bu_hip_k_map_remap(bu_hip_context*, uint32_t* d_block_cluster, uint32_t* d_block_pos, uint32_t n_blocks, const uint32_t* d_new_index, const uint32_t* d_base);
+/*   map_count_differences: *d_out_count = |{ i : a[i] != b[i] }| (device word). map_membership: d_out_flags[parent * n_clusters + cluster] = 1 for
+ *     every (parent, cluster) pair that occurs (d_block_parent may be NULL = one parent). map_gather: out[i] = table[index[i]]. */
+BU_HIP_API int bu_hip_k_map_count_differences(bu_hip_context*, const uint32_t* d_a, const uint32_t* d_b, uint32_t n, uint32_t* d_out_count);
+BU_HIP_API int bu_hip_k_map_membership(bu_hip_context*, const uint8_t* d_block_parent, const uint32_t* d_block_cluster, uint32_t n_blocks, uint32_t n_parents,
+    uint32_t n_clusters, uint8_t* d_out_flags);
+BU_HIP_API int bu_hip_k_map_gather(bu_hip_context*, const uint32_t* d_table, const uint32_t* d_index, uint32_t n, uint32_t* d_out);
+
 /* a8  tree_vector_quant (encoder/basisu_enc.h:1546-2078): the order-dependent TSVQ tree build, split by split, bit-exact.
  *     The host keeps the tree, the variance priority queue and the split order (enc.h:1616-1660); the device executes batches of
  *     independent node splits (split_node, enc.h:1737-1800) on the resident training set. Rows must be the DISTINCT training
@@ -242,6 +268,10 @@ BU_HIP_API int bu_hip_k_unique_selector_vectors(bu_hip_context*, const void* d_e
                                                 uint32_t* d_unique_keys, uint64_t* d_unique_weights, uint32_t* d_group_offsets, uint32_t* out_unique);
 BU_HIP_API int  bu_hip_tsvq_split(bu_hip_context*, bu_tsvq*, const bu_tsvq_node* h_nodes, uint32_t n_nodes, bu_tsvq_split* h_out); /* synchronises */
 BU_HIP_API int  bu_hip_tsvq_read_members(bu_hip_context*, bu_tsvq*, uint32_t buf, uint32_t start, uint32_t count, uint32_t* h_out);
+/* Leaves (or cut nodes) as spans of the member buffers -> d_out[vector] = value for every member of every span: the leaf / parent index of
+ * every distinct vector without bringing the member lists to the host. h_spans: n_spans records. Stream-ordered after the splits. */
+typedef struct { uint32_t buf, start, count, value; } bu_tsvq_span;
+BU_HIP_API int  bu_hip_tsvq_scatter_spans(bu_hip_context*, bu_tsvq*, const bu_tsvq_span* h_spans, uint32_t n_spans, uint32_t* d_out);
 BU_HIP_API void bu_hip_tsvq_destroy(bu_hip_context*, bu_tsvq*);
 
 #ifdef __cplusplus
