@@ -228,6 +228,7 @@ bool etc1s_frontend::init(const params& p) {
     m_orig_encoded_blocks.clear();
     m_enc_host_valid = true; m_enc_dev_valid = false; m_orig_host_valid = true;
     m_ep_dev_valid = false; m_endpoint_map_valid = false; m_endpoint_lists_valid = false;
+    m_sel_dev_valid = false; m_sel_host_valid = true; m_selector_group_blocks.clear(); m_selector_group_offsets.clear();
     m_endpoint_group_blocks.clear();
     m_num_endpoint_codebook_iterations = 1;
     m_num_selector_codebook_iterations = 1;
@@ -875,7 +876,6 @@ bool etc1s_frontend::ensure_encoded_device() {
     m_enc_dev_valid = true;
     return true;
 }
-void etc1s_frontend::ensure_selector_map_host() const {}   // the selector map is kept on the host (see find_optimal_selector_clusters_for_each_block)
 
 // frontend.cpp:2140-2257: selector training vectors (16 selector values as floats, weight from the endpoint colour spread) +
 // de-duplication + TSVQ. The std::map order of vec16F (enc.h:382) is the numeric order of the 32-bit word holding s(0,0) in
@@ -896,43 +896,35 @@ bool etc1s_frontend::generate_selector_clusters() {
     if (!bu_hip_k_unique_selector_vectors(d.ctx, d.enc.p, (const uint64_t*)d.weights.p, n, (uint32_t*)d.sel_idx.p, (uint32_t*)d.sel_ukeys.p, (uint64_t*)d.sel_uw.p,
                                           (uint32_t*)d.sel_goffs.p, &u_total))
         return fail("bu_hip_k_unique_selector_vectors");
-    std::vector<uint32_t>&idx = m_selector_group_blocks, &goffs = m_selector_group_offsets;
-    idx.resize(n); goffs.resize((size_t)u_total + 1);
-    if (!d.download(idx.data(), d.sel_idx, n) || !d.download(goffs.data(), d.sel_goffs, (size_t)u_total + 1)) return fail("download selector groups");
-    const csr_groups groups{goffs.data(), idx.data()};
+    m_selector_group_blocks.clear(); m_selector_group_offsets.clear();   // the grouping stays resident (d.sel_idx / d.sel_goffs)
+    const csr_groups groups{nullptr, nullptr};                           // never dereferenced: only per-vector results are asked for
     lap("~gsc/unique");
     const uint32_t parent_default = (m_params.m_compression_level <= 1) ? kSelectorParentCodebookSizeLevel01 : kSelectorParentCodebookSizeDefault;
     const uint32_t parent_size = (m_params.m_max_selector_clusters >= 256) ? parent_default : 0;
+    const bool hier = m_use_hierarchical_selector_codebooks && parent_size;
     device_tsvq::stats ts;
+    // leaf and parent of every distinct vector are written on the device (tmp_a / tmp_b), then spread over the vectors' blocks
+    if (!d.reserve(d.tmp_a, (size_t)u_total * 4) || !d.reserve(d.tmp_b, (size_t)u_total * 4) || !d.reserve(d.sel_cluster, (size_t)comm_world() * slab_blocks() * 4) ||
+        !d.reserve(d.sel_parent, n))
+        return fail("alloc");
     if (!device_tsvq::hierarchical_codebook_packed16_device(d.ctx, (const uint32_t*)d.sel_ukeys.p, (const uint64_t*)d.sel_uw.p, u_total, groups, m_params.m_max_selector_clusters,
-                                                            m_use_hierarchical_selector_codebooks ? parent_size : 0, m_selector_cluster_block_indices,
-                                                            m_selector_parent_cluster_block_indices, &ts, &m_selector_parent_of_unique, &m_selector_parent_count,
-                                                            &m_selector_leaf_of_unique, &m_selector_cluster_count))
+                                                            hier ? parent_size : 0, m_selector_cluster_block_indices, m_selector_parent_cluster_block_indices, &ts, nullptr,
+                                                            &m_selector_parent_count, nullptr, &m_selector_cluster_count, (uint32_t*)d.tmp_a.p, (uint32_t*)d.tmp_b.p))
         return fail("selector TSVQ failed");
-    // the clustering is kept as a block -> cluster map; the lists are built when somebody asks (selector_cluster_block_indices())
-    m_selector_cluster_block_indices.clear();
-    m_selector_lists_valid = false;
-    m_block_selector_cluster_index.resize(n);
-    parallel_for(u_total, [&](uint32_t u0, uint32_t u1) {
-        for (uint32_t u = u0; u < u1; u++)
-            for (uint32_t j = goffs[u]; j < goffs[u + 1]; j++) m_block_selector_cluster_index[idx[j]] = m_selector_leaf_of_unique[u];
-    });
-    m_selector_parent_cluster_block_indices.clear();
     m_stage_times.push_back(stage_time{"~gsc/tsvq_create", ts.t_create});
     m_stage_times.push_back(stage_time{"~gsc/tsvq_device", ts.t_device});
     m_stage_times.push_back(stage_time{"~gsc/tsvq_replay", ts.t_replay});
     m_stage_times.push_back(stage_time{"~gsc/tsvq_expand", ts.t_expand});
     sub = timer();
-    if (m_use_hierarchical_selector_codebooks) {
-        // only the block -> parent map is needed from here on (the lists are not part of the frontend's interface)
-        m_block_parent_selector_cluster.assign(n, 0);
-        if (!m_selector_parent_count) m_selector_parent_count = 1;  // no parent level: one parent holding everything (frontend.cpp:2230-2236)
-        else
-            parallel_for(u_total, [&](uint32_t u0, uint32_t u1) {
-                for (uint32_t u = u0; u < u1; u++)
-                    for (uint32_t j = goffs[u]; j < goffs[u + 1]; j++) m_block_parent_selector_cluster[idx[j]] = (uint8_t)m_selector_parent_of_unique[u];
-            });
-    }
+    // the clustering is kept as a resident block -> cluster map (+ block -> parent); lists are built when somebody asks
+    const bool parents = hier && m_selector_parent_count;
+    if (!bu_hip_k_map_blocks_from_groups(d.ctx, (const uint32_t*)d.sel_goffs.p, (const uint32_t*)d.sel_idx.p, n, u_total, (const uint32_t*)d.tmp_a.p, nullptr,
+                                         parents ? (const uint32_t*)d.tmp_b.p : nullptr, (uint32_t*)d.sel_cluster.p, nullptr, (uint8_t*)d.sel_parent.p))
+        return fail("bu_hip_k_map_blocks_from_groups");
+    if (m_use_hierarchical_selector_codebooks && !m_selector_parent_count) m_selector_parent_count = 1;  // no parent level: one parent holding everything (frontend.cpp:2230-2236)
+    m_selector_cluster_block_indices.clear(); m_selector_parent_cluster_block_indices.clear();
+    m_selector_lists_valid = false;
+    m_sel_dev_valid = true; m_sel_host_valid = false;
     lap("~gsc/parents");
     return true;
 }
@@ -940,16 +932,39 @@ bool etc1s_frontend::generate_selector_clusters() {
 // frontend.cpp:2098-2138
 void etc1s_frontend::compute_selector_clusters_within_each_parent_cluster() {
     const size_t parents = m_selector_parent_count, clusters = m_selector_cluster_count;
-    std::vector<uint8_t> member(parents * clusters, 0);
-    for (uint32_t b = 0; b < m_total_blocks; b++) member[(size_t)m_block_parent_selector_cluster[b] * clusters + m_block_selector_cluster_index[b]] = 1;
     m_selector_clusters_within_each_parent_cluster.assign(parents, {});
+    device_state& d = *m_dev;
+    std::vector<uint8_t> member(parents * clusters, 0);
+    if (!ensure_selector_map_device() || !d.reserve(d.flags, parents * clusters + 8) ||
+        !bu_hip_k_map_membership(d.ctx, (const uint8_t*)d.sel_parent.p, (const uint32_t*)d.sel_cluster.p, m_total_blocks, (uint32_t)parents, (uint32_t)clusters, (uint8_t*)d.flags.p) ||
+        !d.download(member.data(), d.flags, member.size())) {
+        fail("compute_selector_clusters_within_each_parent_cluster");
+        return;
+    }
     for (size_t p = 0; p < parents; p++)
         for (size_t c = 0; c < clusters; c++)
             if (member[p * clusters + c]) m_selector_clusters_within_each_parent_cluster[p].push_back((uint32_t)c);
 }
 
+// ---- the selector clustering (block -> cluster) lives where it was last written; the other side is brought up to date on demand
+void etc1s_frontend::ensure_selector_map_host() const {
+    if (m_sel_host_valid) return;
+    m_block_selector_cluster_index.resize(m_total_blocks);
+    if (m_dev && m_dev->sel_cluster.p && m_dev->download(m_block_selector_cluster_index.data(), m_dev->sel_cluster, m_total_blocks)) m_sel_host_valid = true;
+}
+bool etc1s_frontend::ensure_selector_map_device() {
+    if (m_sel_dev_valid) return true;
+    device_state& d = *m_dev;
+    ensure_selector_map_host();
+    if (!m_sel_host_valid || !d.reserve(d.sel_cluster, (size_t)comm_world() * slab_blocks() * 4) || !d.upload(d.sel_cluster, m_block_selector_cluster_index.data(), m_total_blocks))
+        return fail("upload selector map");
+    m_sel_dev_valid = true;
+    return true;
+}
+
 // The blocks of every selector cluster, ascending, as one CSR array (what the per-cluster kernels read)
 void etc1s_frontend::selector_csr(std::vector<uint32_t>& offsets, std::vector<uint32_t>& indices) const {
+    ensure_selector_map_host();
     const uint32_t n = m_total_blocks, k = m_selector_cluster_count;
     const unsigned T = n > 65536 ? host_threads() : 1;
     const uint32_t per = (n + T - 1) / T;
@@ -986,27 +1001,31 @@ const std::vector<std::vector<uint32_t>>& etc1s_frontend::selector_cluster_block
 
 // frontend.cpp:2259-2354
 bool etc1s_frontend::create_optimized_selector_codebook(uint32_t /*iter*/) {
-    const uint32_t k = m_selector_cluster_count;
+    const uint32_t k = m_selector_cluster_count, n = m_total_blocks;
     m_optimized_cluster_selectors.resize(k, bu_etc_block{});
-    csr lists;  // the accumulation is integer, so the order of a cluster's blocks does not matter: ascending
-    selector_csr(lists.offsets, lists.indices);
     device_state& d = *m_dev;
+    // the blocks of every cluster (the accumulation is integer, so their order does not matter: ascending) = a stable sort of the block
+    // ids by cluster, on the device: offsets in map_offs, block ids in map_sorted
+    if (!ensure_selector_map_device() || !ensure_encoded_device() || !d.reserve(d.map_sizes, ((size_t)k + 1) * 4) || !d.reserve(d.map_offs, ((size_t)k + 1) * 4) ||
+        !d.reserve(d.map_sorted, (size_t)n * 4) ||
+        !bu_hip_k_map_rank_blocks(d.ctx, (const uint32_t*)d.sel_cluster.p, n, k, (uint32_t*)d.map_sizes.p, (uint32_t*)d.map_offs.p, (uint32_t*)d.map_sorted.p, nullptr))
+        return fail("bu_hip_k_map_rank_blocks");
     // multi-GPU: every rank takes a contiguous range of clusters holding about 1/world of the member blocks; entries it does not own
     // are uploaded as zero, so that the sum-merge below reassembles the codebook exactly
     uint32_t c0 = 0, c1 = k;
     std::vector<bu_etc_block> mine(m_optimized_cluster_selectors);
     if (m_has_comm) {
-        const uint64_t total = lists.offsets[k], w = comm_world(), r = comm_rank();
-        auto cut = [&](uint64_t part) { return (uint32_t)(std::lower_bound(lists.offsets.begin(), lists.offsets.end(), (uint32_t)(total * part / w)) - lists.offsets.begin()); };
+        std::vector<uint32_t> offsets((size_t)k + 1);
+        if (!d.download(offsets.data(), d.map_offs, (size_t)k + 1)) return fail("download offsets");
+        const uint64_t total = offsets[k], w = comm_world(), r = comm_rank();
+        auto cut = [&](uint64_t part) { return (uint32_t)(std::lower_bound(offsets.begin(), offsets.end(), (uint32_t)(total * part / w)) - offsets.begin()); };
         c0 = r == 0 ? 0 : std::min(cut(r), k);
         c1 = r + 1 == w ? k : std::min(cut(r + 1), k);
         if (c1 < c0) c1 = c0;
         for (uint32_t i = 0; i < k; i++) if (i < c0 || i >= c1) mine[i] = bu_etc_block{};
     }
-    if (!ensure_encoded_device() || !d.upload(d.offsets, lists.offsets.data(), lists.offsets.size()) || !d.upload(d.indices, lists.indices.data(), lists.indices.size()) ||
-        !d.reserve(d.sel_blocks, (size_t)k * 8 + 8) || !d.upload(d.sel_blocks, mine.data(), k))
-        return fail("upload selector clusters");
-    if (c1 > c0 && !bu_hip_k_create_optimized_selector_codebook(d.ctx, d.d_pixels, d.enc.p, c1 - c0, (const uint32_t*)d.offsets.p + c0, (const uint32_t*)d.indices.p, m_params.m_perceptual,
+    if (!d.reserve(d.sel_blocks, (size_t)k * 8 + 8) || !d.upload(d.sel_blocks, mine.data(), k)) return fail("upload selector clusters");
+    if (c1 > c0 && !bu_hip_k_create_optimized_selector_codebook(d.ctx, d.d_pixels, d.enc.p, c1 - c0, (const uint32_t*)d.map_offs.p + c0, (const uint32_t*)d.map_sorted.p, m_params.m_perceptual,
                                                                (char*)d.sel_blocks.p + (size_t)c0 * 8))
         return fail("bu_hip_k_create_optimized_selector_codebook");
     if (!merge_disjoint(d.sel_blocks.p, (size_t)k * 8)) return false;
@@ -1017,10 +1036,9 @@ bool etc1s_frontend::create_optimized_selector_codebook(uint32_t /*iter*/) {
 // frontend.cpp:2397-2715
 bool etc1s_frontend::find_optimal_selector_clusters_for_each_block() {
     const uint32_t n = m_total_blocks, k = (uint32_t)m_optimized_cluster_selectors.size();
-    m_block_selector_cluster_index.resize(n);
     if (m_params.m_compression_level == 0) {
         // frontend.cpp:2420-2439: blocks stay in their TSVQ cluster and just take its optimised selectors
-        ensure_encoded_host();
+        ensure_encoded_host(); ensure_selector_map_host();
         for (uint32_t b = 0; b < n; b++) {
             const uint32_t bits = raw_selector_bits(m_optimized_cluster_selectors[m_block_selector_cluster_index[b]]);
             store_be64(m_encoded_blocks[b], (load_be64(m_encoded_blocks[b]) & ~0xFFFFFFFFull) | bits);
@@ -1033,8 +1051,7 @@ bool etc1s_frontend::find_optimal_selector_clusters_for_each_block() {
     if (m_use_hierarchical_selector_codebooks) {
         csr cand; cand.build(m_selector_clusters_within_each_parent_cluster);
         n_parents = (uint32_t)m_selector_clusters_within_each_parent_cluster.size();
-        if (!d.upload(d.cand_offsets, cand.offsets.data(), cand.offsets.size()) || !d.upload(d.cand_indices, cand.indices.data(), cand.indices.size()) ||
-            !d.upload(d.block_parent, m_block_parent_selector_cluster.data(), n))
+        if (!d.upload(d.cand_offsets, cand.offsets.data(), cand.offsets.size()) || !d.upload(d.cand_indices, cand.indices.data(), cand.indices.size()))
             return fail("upload selector parent lists");
     }
     const size_t padded = (size_t)comm_world() * slab_blocks();
@@ -1044,12 +1061,13 @@ bool etc1s_frontend::find_optimal_selector_clusters_for_each_block() {
     uint32_t b0, nb;
     my_slab(b0, nb);  // slabs start on multiples of the reference's 2048-block jobs, so the "same tile as the previous block of this job" shortcut sees the same neighbours
     if (nb && !bu_hip_k_find_optimal_selector_clusters(d.ctx, (const char*)d.d_pixels + (size_t)b0 * 64, (char*)d.enc.p + (size_t)b0 * 8, nb, d.sel_blocks.p, k, n_parents,
-                                                       (const uint32_t*)d.cand_offsets.p, (const uint32_t*)d.cand_indices.p, n_parents ? (const uint8_t*)d.block_parent.p + b0 : nullptr,
+                                                       (const uint32_t*)d.cand_offsets.p, (const uint32_t*)d.cand_indices.p, n_parents ? (const uint8_t*)d.sel_parent.p + b0 : nullptr,
                                                        m_params.m_perceptual, kFoscJobSize, (uint32_t*)d.out_u32.p + b0))
         return fail("bu_hip_k_find_optimal_selector_clusters");
     if (!gather_blocks(d.enc.p, 8) || !gather_blocks(d.out_u32.p, 4)) return false;
-    if (!d.download(m_block_selector_cluster_index.data(), d.out_u32, n)) return fail("download fosc result");
-    m_enc_host_valid = false;   // rewritten on the device; fetched when somebody asks (ensure_encoded_host)
+    std::swap(d.sel_cluster, d.out_u32);   // the assignment IS the clustering now; both results stay resident, the host copies are fetched on demand
+    m_sel_dev_valid = true; m_sel_host_valid = false;
+    m_enc_host_valid = false;
     m_selector_lists_valid = false;  // frontend.cpp:2696-2708 rebuilds the lists in block order: that is what selector_cluster_block_indices() produces
     return true;
 }
@@ -1085,8 +1103,8 @@ bool etc1s_frontend::introduce_special_selector_clusters() {
         for (const bu_etc_block& s : m_optimized_cluster_selectors) if (raw_selector_bits(s) == flat) { present = true; break; }
         if (present) continue;
         const uint32_t new_index = (uint32_t)m_optimized_cluster_selectors.size();
-        ensure_orig_encoded_host(); ensure_encoded_host(); ensure_endpoint_map();
-        if (!m_orig_host_valid || !m_enc_host_valid || !m_endpoint_map_valid) return fail("download blocks");
+        ensure_orig_encoded_host(); ensure_encoded_host(); ensure_endpoint_map(); ensure_selector_map_host();
+        if (!m_orig_host_valid || !m_enc_host_valid || !m_endpoint_map_valid || !m_sel_host_valid) return fail("download blocks");
         bu_etc_block nb{}; store_be64(nb, flat);
         m_optimized_cluster_selectors.push_back(nb);
         m_selector_cluster_count = new_index + 1;
@@ -1099,6 +1117,7 @@ bool etc1s_frontend::introduce_special_selector_clusters() {
             const uint32_t cur_bits = raw_selector_bits(m_optimized_cluster_selectors[m_block_selector_cluster_index[b]]);
             if (block_error(*px, e, flat) >= block_error(*px, e, cur_bits)) continue;
             m_block_selector_cluster_index[b] = new_index;  // the lists (block order) follow from the map
+            m_sel_dev_valid = false;
             total_relocated++;
             store_be64(m_encoded_blocks[b], (load_be64(m_encoded_blocks[b]) & ~0xFFFFFFFFull) | flat);
             m_enc_dev_valid = false;
@@ -1110,9 +1129,22 @@ bool etc1s_frontend::introduce_special_selector_clusters() {
 
 // frontend.cpp:657-731: drop unused entries and merge entries with identical selector bits (first occurrence keeps its place)
 void etc1s_frontend::optimize_selector_codebook() {
-    const uint32_t k = (uint32_t)m_optimized_cluster_selectors.size();
+    const uint32_t k = (uint32_t)m_optimized_cluster_selectors.size(), n = m_total_blocks;
     std::vector<uint8_t> used(k, 0);
-    for (uint32_t b = 0; b < m_total_blocks; b++) used[m_block_selector_cluster_index[b]] = 1;
+    device_state& d = *m_dev;
+    bool on_device = m_sel_dev_valid;
+    if (on_device) {   // which entries own a block: the cluster sizes of the resident map
+        std::vector<uint32_t> sizes(k);
+        if (d.reserve(d.map_sizes, ((size_t)k + 1) * 4) && d.reserve(d.map_offs, ((size_t)k + 1) * 4) && d.reserve(d.map_sorted, (size_t)n * 4) &&
+            bu_hip_k_map_rank_blocks(d.ctx, (const uint32_t*)d.sel_cluster.p, n, k, (uint32_t*)d.map_sizes.p, (uint32_t*)d.map_offs.p, (uint32_t*)d.map_sorted.p, nullptr) &&
+            d.download(sizes.data(), d.map_sizes, k)) {
+            for (uint32_t i = 0; i < k; i++) used[i] = sizes[i] != 0;
+        } else on_device = false;
+    }
+    if (!on_device) {
+        ensure_selector_map_host();
+        for (uint32_t b = 0; b < n; b++) used[m_block_selector_cluster_index[b]] = 1;
+    }
     std::vector<int32_t> old_to_new(k, -1);
     std::vector<uint32_t> new_to_old;
     std::vector<std::pair<uint32_t, uint32_t>> seen; // (bits, new index), kept sorted
@@ -1125,7 +1157,17 @@ void etc1s_frontend::optimize_selector_codebook() {
         seen.insert(it, std::make_pair(bits, (uint32_t)new_to_old.size()));
         new_to_old.push_back(i);
     }
-    for (uint32_t b = 0; b < m_total_blocks; b++) m_block_selector_cluster_index[b] = (uint32_t)old_to_new[m_block_selector_cluster_index[b]];
+    if (m_sel_host_valid)
+        for (uint32_t b = 0; b < n; b++) m_block_selector_cluster_index[b] = (uint32_t)old_to_new[m_block_selector_cluster_index[b]];
+    if (m_sel_dev_valid) {
+        std::vector<uint32_t> remap(k);
+        for (uint32_t i = 0; i < k; i++) remap[i] = (uint32_t)old_to_new[i];
+        if (!d.upload(d.tmp_a, remap.data(), k) || !bu_hip_k_map_remap(d.ctx, (uint32_t*)d.sel_cluster.p, nullptr, n, (const uint32_t*)d.tmp_a.p, nullptr)) {
+            fail("bu_hip_k_map_remap");
+            ensure_selector_map_host();   // keep a consistent state on the host at least
+            m_sel_dev_valid = false;
+        }
+    }
     std::vector<bu_etc_block> sels(new_to_old.size());
     for (size_t i = 0; i < new_to_old.size(); i++) sels[i] = m_optimized_cluster_selectors[new_to_old[i]];
     m_optimized_cluster_selectors.swap(sels);

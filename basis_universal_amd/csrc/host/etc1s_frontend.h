@@ -63,7 +63,7 @@ public:
     uint32_t get_subblock_endpoint_cluster_index(uint32_t block, uint32_t) const { ensure_endpoint_map(); return m_block_endpoint_cluster[block]; }
     const endpoint_params& get_endpoint_cluster_params(uint32_t ci) const { return m_endpoint_cluster_etc_params[ci]; }
     uint32_t get_total_selector_clusters() const { return m_selector_cluster_count; }
-    uint32_t get_block_selector_cluster_index(uint32_t block) const { return m_block_selector_cluster_index[block]; }
+    uint32_t get_block_selector_cluster_index(uint32_t block) const { ensure_selector_map_host(); return m_block_selector_cluster_index[block]; }
     const bu_etc_block& get_selector_cluster_selector_bits(uint32_t ci) const { return m_optimized_cluster_selectors[ci]; }
     const std::vector<uint32_t>& get_selector_cluster_block_indices(uint32_t ci) const { return selector_cluster_block_indices()[ci]; }
 
@@ -76,7 +76,7 @@ public:
     const std::vector<uint32_t>& block_endpoint_clusters() const { ensure_endpoint_map(); return m_block_endpoint_cluster; }
     const std::vector<std::vector<uint32_t>>& selector_cluster_block_indices() const;  // built on first use from the block -> cluster map (ascending blocks)
     const std::vector<bu_etc_block>& optimized_cluster_selectors() const { return m_optimized_cluster_selectors; }
-    const std::vector<uint32_t>& block_selector_cluster_index() const { return m_block_selector_cluster_index; }
+    const std::vector<uint32_t>& block_selector_cluster_index() const { ensure_selector_map_host(); return m_block_selector_cluster_index; }
 
     // ---- what the backend needs beyond the getters (etc1s_backend.h)
     const bu_pixel_block* source_blocks_host();  // get_source_pixel_block: the caller's host tiles, or a host copy of device-only tiles
@@ -180,7 +180,10 @@ private:
     std::vector<bu_etc_block> m_optimized_cluster_selectors;
     std::vector<uint8_t> m_block_parent_selector_cluster;
     std::vector<std::vector<uint32_t>> m_selector_clusters_within_each_parent_cluster;
-    std::vector<uint32_t> m_block_selector_cluster_index;
+    mutable std::vector<uint32_t> m_block_selector_cluster_index;   // host form of the block -> selector cluster map ...
+    mutable bool m_sel_host_valid = true;
+    bool m_sel_dev_valid = false;                                    // ... and whether the resident form (device_state::sel_cluster) is current
+    bool ensure_selector_map_device();
 
     std::vector<stage_time> m_stage_times;
     std::vector<bu_pixel_block> m_source_copy;  // see source_blocks_host()

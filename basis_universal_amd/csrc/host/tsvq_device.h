@@ -92,13 +92,14 @@ public:
                                                       uint32_t max_codebook_size, uint32_t max_parent_codebook_size, std::vector<std::vector<uint32_t>>& codebook,
                                                       std::vector<std::vector<uint32_t>>& parent_codebook, stats* st = nullptr,
                                                       std::vector<uint32_t>* parent_of_unique = nullptr, uint32_t* parent_count = nullptr,
-                                                      std::vector<uint32_t>* leaf_of_unique = nullptr, uint32_t* leaf_count = nullptr) {
+                                                      std::vector<uint32_t>* leaf_of_unique = nullptr, uint32_t* leaf_count = nullptr,
+                                                      uint32_t* d_leaf_of_unique = nullptr, uint32_t* d_parent_of_unique = nullptr) {
         bu_tsvq_root root;
         const auto t0 = std::chrono::steady_clock::now();
         bu_tsvq* q = n_unique ? bu_hip_tsvq_create_packed16_device(ctx, d_keys, d_weights, n_unique, &root) : nullptr;
         if (st) st->t_create = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         return q && build(ctx, q, root, n_unique, groups, max_codebook_size, max_parent_codebook_size, codebook, parent_codebook, st, parent_of_unique, parent_count,
-                          leaf_of_unique, leaf_count);
+                          leaf_of_unique, leaf_count, d_leaf_of_unique, d_parent_of_unique);
     }
 
     // parent lists from a parent-of-unique map (what build() would have produced): vectors ascending inside a parent, members group by group
@@ -149,7 +150,8 @@ private:
     static bool build(bu_hip_context* ctx, bu_tsvq* q, const bu_tsvq_root& root, uint32_t n, const Groups& groups,
                       uint32_t max_codebook_size, uint32_t max_parent_codebook_size, std::vector<std::vector<uint32_t>>& codebook,
                       std::vector<std::vector<uint32_t>>& parent_codebook, stats* st, std::vector<uint32_t>* parent_of_unique = nullptr,
-                      uint32_t* parent_count = nullptr, std::vector<uint32_t>* leaf_of_unique = nullptr, uint32_t* leaf_count = nullptr) {
+                      uint32_t* parent_count = nullptr, std::vector<uint32_t>* leaf_of_unique = nullptr, uint32_t* leaf_count = nullptr,
+                      uint32_t* d_leaf_of_unique = nullptr, uint32_t* d_parent_of_unique = nullptr) {
         if (parent_of_unique) parent_of_unique->clear();
         if (parent_count) *parent_count = 0;
         if (leaf_of_unique) leaf_of_unique->clear();
@@ -248,6 +250,47 @@ private:
         const auto t_loop1 = now();
         local.t_replay = secs(t_loop0, t_loop1) - local.t_device;
         struct fin { stats* st; stats* local; std::chrono::steady_clock::time_point t; ~fin() { local->t_expand = std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count(); if (st) *st = *local; } } fin_{st, &local, t_loop1};
+
+        // ---- resident form: the leaf (and parent) of every distinct vector is written by the device from the leaves' spans of the member
+        //      buffers; no member list leaves HBM. Leaves in node order (enc.h:1573-1584), parents = retrieve(max_clusters) (enc.h:1598-1628).
+        if (d_leaf_of_unique) {
+            std::vector<bu_tsvq_span> spans;
+            std::vector<int32_t> leaf_id(nodes.size(), -1);
+            for (size_t ni = 0; ni < nodes.size(); ni++) {
+                if (nodes[ni].left >= 0) continue;
+                leaf_id[ni] = (int32_t)spans.size();
+                spans.push_back(bu_tsvq_span{nodes[ni].buf, nodes[ni].start, nodes[ni].count, (uint32_t)spans.size()});
+            }
+            if (leaf_count) *leaf_count = (uint32_t)spans.size();
+            if (!bu_hip_tsvq_scatter_spans(ctx, q, spans.data(), (uint32_t)spans.size(), d_leaf_of_unique)) return false;
+            if (parent_count) *parent_count = 0;
+            if (max_parent_codebook_size && d_parent_of_unique) {
+                uint32_t cuts = 0;
+                std::vector<uint32_t> stack, sub;
+                uint32_t ni = 0;
+                for (;;) {
+                    const node& cur = nodes[ni];
+                    if (cur.left < 0 || (2 + cur.codebook_index) > (int)max_parent_codebook_size) {
+                        sub.assign(1, ni);
+                        while (!sub.empty()) {
+                            const uint32_t x = sub.back(); sub.pop_back();
+                            if (nodes[x].left < 0) spans[(size_t)leaf_id[x]].value = cuts;
+                            else { sub.push_back((uint32_t)nodes[x].left); sub.push_back((uint32_t)nodes[x].right); }
+                        }
+                        cuts++;
+                        if (stack.empty()) break;
+                        ni = stack.back(); stack.pop_back();
+                        continue;
+                    }
+                    stack.push_back((uint32_t)cur.right);
+                    ni = (uint32_t)cur.left;
+                }
+                if (!bu_hip_tsvq_scatter_spans(ctx, q, spans.data(), (uint32_t)spans.size(), d_parent_of_unique)) return false;
+                if (parent_count) *parent_count = cuts;
+            }
+            codebook.clear(); parent_codebook.clear();
+            return true;
+        }
 
         // ---- leaves in node order (enc.h:1573-1584). Leaf segments are intact in their buffers and ascending.
         std::vector<uint32_t> perm[2];
