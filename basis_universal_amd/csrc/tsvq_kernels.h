@@ -26,6 +26,7 @@ struct tsvq_wide_node { uint32_t buf, start, count, out_index, first_block, n_bl
 struct tsvq_wide_ctrl {   // device-side state of one node across the passes of its split
     float l_c[16], r_c[16], axis[16];
     float sums[TSVQ_WIDE_MAX_CHAINS];
+    uint8_t exact[TSVQ_WIDE_MAX_CHAINS];   // this pass's chain total stayed below 2^24 with integer addends: the running sum is exact, no walk needed
     uint64_t l_w, r_w;
     double dsum[2];
     uint32_t l_n, r_n;

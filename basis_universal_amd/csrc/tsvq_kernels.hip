@@ -353,7 +353,91 @@ __global__ __launch_bounds__(TQ_THREADS) void k_tsvq_split(Src src, const uint64
     // One classification + accumulation pass. `mode` selects how a member picks its side; float chains 0..N-1 are the left sums,
     // N..2N-1 the right sums; the two double chains are the left/right "ttsum" (in the projection / half passes: the weights).
     // Returns true (uniformly) when the exact variant met data outside its range: the caller gives the node up with ok = 2.
+    // The same pass without any chain, for packed rows: the float addends are non-negative INTEGER-valued (value 0..3 times an integer weight),
+    // so when a chain's total is below 2^24 every partial sum of the sequential chain is an integer below 2^24, i.e. exact, and the chain's
+    // result is the plain integer total -- computed here by all 512 threads in any order. Returns 0 when every chain was exact (results
+    // stored like side_pass stores them), 1 when some total reached 2^24 (nothing stored: the caller runs the chained pass), 2 when the
+    // integer totals of the double accumulators left their exact range (the node is given up with ok = 2, as in side_pass).
+    auto side_pass_exact = [&](int mode, bool write_side) -> int {
+        if constexpr (!(Src::PACKED && EX && N == 16)) { return 1; } else {
+        uint32_t* s_part = reinterpret_cast<uint32_t*>(lds);          // [8 waves][32 chains]
+        uint32_t acc[32];
+#pragma unroll
+        for (int i = 0; i < 32; i++) acc[i] = 0;
+        uint64_t lw = 0, rw = 0; uint32_t ln = 0;
+        exact_acc ex[2];
+        bool bad = false, big = count > 512u * 64u;   // per-thread u32 partial sums stay below 2^32 for up to 64 members of < 2^24 each
+        if (mode == TQ_MODE_DIST && tid < 64) {
+            const int k = tid >> 2, val = tid & 3;
+            const double a = (double)c.l_c[k] - (double)(float)val, b = (double)c.r_c[k] - (double)(float)val;
+            s_tab[k][val] = make_double2(a * a, b * b);
+        }
+        __syncthreads();
+        for (uint32_t pos = (uint32_t)tid; pos < count; pos += TQ_THREADS) {
+            const payload p = src.fetch(w64, members[pos]);
+            const float w = (float)p.w;
+            bool right;
+            if (mode == TQ_MODE_DIST) {
+                double dl = 0, dr = 0;
+#pragma unroll
+                for (int k = 0; k < N; k++) { const double2 t = s_tab[k][(p.key >> (30 - 2 * k)) & 3u]; dl += t.x; dr += t.y; }
+                right = dl >= dr;
+            } else {
+                float dd[N];
+#pragma unroll
+                for (int k = 0; k < N; k++) dd[k] = (float)((p.key >> (30 - 2 * k)) & 3u) - s_origin[k];
+                right = (double)dot_seq<N>(dd, c.axis) >= 0.0;
+            }
+            if (write_side) node_side[pos] = right ? 1 : 0;
+            float vsq = 0.0f;
+#pragma unroll
+            for (int k = 0; k < N; k++) {
+                const float v = (float)((p.key >> (30 - 2 * k)) & 3u);
+                const float t = v * w;
+                big |= !(t < 16777216.0f);
+                const uint32_t ti = (uint32_t)t;
+                acc[k] += right ? 0u : ti;
+                acc[N + k] += right ? ti : 0u;
+                vsq = k == 0 ? v * v : vsq + v * v;   // dot_seq order
+            }
+            const float dvf = mode == TQ_MODE_PROJ ? w : w * vsq;
+            if (right) { bad |= !ex[1].add(dvf); rw += p.w; } else { bad |= !ex[0].add(dvf); lw += p.w; ln++; }
+        }
+        // wave totals of the 32 chains -> LDS -> block totals
+#pragma unroll
+        for (int i = 0; i < 32; i++) {
+            uint32_t v = acc[i];
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o, 64);
+            acc[i] = v;
+        }
+        if ((tid & 63) == 0)
+#pragma unroll
+            for (int i = 0; i < 32; i++) s_part[(tid >> 6) * 32 + i] = acc[i];
+        uint64_t sums[7] = {lw, rw, (uint64_t)ln, ex[0].lo, ex[0].hi, ex[1].lo, ex[1].hi};
+        block_sum_u64xN<7>(sums, s_red);    // two barriers: s_part is visible afterwards
+        const bool any_big = __syncthreads_or(big ? 1 : 0) != 0;
+        const bool any_bad = __syncthreads_or(bad ? 1 : 0) != 0;
+        uint64_t tot = 0;
+        if (tid < 32) for (int w8 = 0; w8 < TQ_THREADS / 64; w8++) tot += s_part[w8 * 32 + tid];
+        const bool inexact = __syncthreads_or((tid < 32 && tot >= 16777216ull) ? 1 : 0) != 0;
+        // no 32-bit wrap can have happened anywhere if four times the node's weight fits 32 bits (every chain total is at most 3 x that)
+        if (any_big || inexact || ((sums[0] + sums[1]) >> 30) != 0) return 1;
+        double t0 = 0.0, t1 = 0.0;
+        if (any_bad || !exact_total(sums[3], sums[4], &t0) || !exact_total(sums[5], sums[6], &t1)) return 2;
+        if (tid < 32) s_sum[tid / N][tid % N] = (float)(uint32_t)tot;
+        if (tid == 0) { s_dsum[0] = t0; s_dsum[1] = t1; c.l_w = sums[0]; c.r_w = sums[1]; c.l_n = (uint32_t)sums[2]; c.r_n = count - (uint32_t)sums[2]; }
+        __syncthreads();
+        return 0;
+        }
+    };
+
     auto side_pass = [&](int mode, bool write_side) -> bool {
+        if (mode == TQ_MODE_DIST || mode == TQ_MODE_PROJ) {
+            const int r = side_pass_exact(mode, write_side);
+            if (r == 0) return false;
+            if (r == 2) return true;
+        }
         float acc_f = 0.0f; double acc_d = 0.0;
         uint64_t lw = 0, rw = 0; uint32_t ln = 0;
         exact_acc ex[2];

@@ -243,6 +243,18 @@ __global__ __launch_bounds__(256) void k_wide_scan(const tsvq_wide_node* __restr
         const int c = (int)blockIdx.y * 4 + (tid >> 6);
         if (c >= NCH) return;
         double P = 0;   // sum of the blocks before the current 64
+        if (MODE != WM_COV) {
+            // Addends are non-negative INTEGER-valued floats here (value 0..3 times an integer weight). If the chain's total is below 2^24,
+            // every partial sum of the sequential float chain is an integer below 2^24, i.e. exact: the chain's result is the total, in any
+            // order. (Block sums are exact in double.) The other two kernels of the pass skip such chains.
+            double tot = 0;
+            for (uint32_t b = (uint32_t)lane; b < nd.n_blocks; b += 64) tot += ws.bsum[ws.at(c, nd.first_block + b)];
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) tot += __shfl_xor(tot, o, 64);
+            const bool exact = tot < 16777216.0;
+            if (lane == 0) { ctrl[ni].exact[c] = exact ? 1 : 0; if (exact) ctrl[ni].sums[c] = (float)tot; }
+            if (exact) return;
+        } else if (lane == 0) ctrl[ni].exact[c] = 0;
         for (uint32_t b0 = 0; b0 < nd.n_blocks; b0 += 64) {
             const uint32_t b = b0 + (uint32_t)lane;
             const bool have = b < nd.n_blocks;
@@ -362,7 +374,8 @@ __global__ __launch_bounds__(WB) void k_wide_stretches(const uint32_t* __restric
     __syncthreads();
     for (int item = tid; item < ITEMS; item += WB) {
         const int c = item % NCH, q = item / NCH;
-        const uint16_t ep = ws.epred[ws.at(c, blk)];
+        const bool skip = ctrl[ni].exact[c] != 0;
+        const uint16_t ep = skip ? EP_NONE : ws.epred[ws.at(c, blk)];
         fsum::stretch st0 = fsum::identity(), st1 = fsum::identity();
         if (ep != EP_NONE && ep != EP_ZERO) {
             const int E = (int)(ep & 0xffu);
@@ -384,6 +397,7 @@ __global__ __launch_bounds__(WB) void k_wide_stretches(const uint32_t* __restric
     __syncthreads();
     for (int item = tid; item < NCH * 2; item += WB) {   // slices in member order
         const int c = item % NCH, cand = item / NCH;
+        if (ctrl[ni].exact[c]) continue;
         fsum::stretch acc = st_load(s_st[c][cand]);
 #pragma unroll
         for (int q = 1; q < Q; q++) acc = fsum::compose(acc, st_load(s_st[c + q * NCH][cand]));
@@ -452,7 +466,7 @@ __global__ __launch_bounds__(64) void k_wide_walk(const uint32_t* __restrict__ k
     const wide_ws ws = carve(ws_base, tb);
     const uint32_t ni = blockIdx.x / NCH;
     const int c = (int)(blockIdx.x % NCH);
-    if (ctrl[ni].done) return;
+    if (ctrl[ni].done || ctrl[ni].exact[c]) return;
     const tsvq_wide_node& nd = nodes[ni];
     const int lane = threadIdx.x;
     // what the chain adds, per member: everything about the chain is uniform over the wave
