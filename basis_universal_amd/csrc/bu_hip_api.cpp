@@ -21,6 +21,7 @@
 #include "mipmap_kernels.h"
 #include "unique_kernels.h"
 #include "bookkeeping_kernels.h"
+#include "kmeans_kernels.h"
 
 namespace {
 
@@ -632,6 +633,83 @@ int bu_hip_k_map_gather(bu_hip_context* ctx, const uint32_t* d_table, const uint
     if (!ctx) return 0;
     device_guard g(ctx->device);
     BU_TRY(ctx, bu::launch_gather_u32(ctx->stream, d_table, d_index, n, d_out));
+    return 1;
+}
+
+// ---------------------------------------------------------------------------------------------------------------- f3: k-means codebooks (fast mode)
+
+int bu_hip_kmeans_codebook(bu_hip_context* ctx, int kind, const void* d_keys, const uint64_t* d_weights, const uint32_t* d_goffs, uint32_t n, uint32_t max_clusters,
+                           uint32_t n_parents, uint32_t iterations, uint32_t* d_cluster, uint32_t* d_parent, uint32_t* out_clusters, uint32_t* out_parents) {
+    if (!ctx) return 0;
+    if (!d_keys || !d_cluster || !out_clusters || !n || !max_clusters || (kind == 0 && !d_weights) || (kind != 0 && !d_goffs) || (n_parents && !d_parent)) {
+        set_error(ctx, "kmeans_codebook: bad arguments");
+        return 0;
+    }
+    device_guard g(ctx->device);
+    const uint32_t k = std::min(max_clusters, n);
+    if (const char* e = std::getenv("BU_FAST_ITERS")) { const int v = std::atoi(e); if (v >= 0 && v <= 64) iterations = (uint32_t)v; }
+    arena& ws = ctx->scratch[3];
+    BU_TRY(ctx, ws.reserve(bu::kmeans_workspace_bytes(n, k) + (size_t)k * 8 + 256));
+    const bu::kmeans_buffers b = bu::kmeans_carve(ws.p, n, k);
+    uint32_t* d_tab = reinterpret_cast<uint32_t*>(static_cast<char*>(ws.p) + bu::kmeans_workspace_bytes(n, k));
+    {
+        prof_scope ps(ctx, kind ? "kmeans_endpoints" : "kmeans_selectors");
+        BU_TRY(ctx, bu::launch_kmeans(ctx->stream, kind, d_keys, d_weights, d_goffs, n, k, iterations, b, d_cluster));
+    }
+    std::vector<uint64_t> sums((size_t)k * 17);
+    std::vector<float> cen((size_t)k * 16);
+    BU_TRY(ctx, hipMemcpyAsync(sums.data(), b.sums, sums.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+    BU_TRY(ctx, hipMemcpyAsync(cen.data(), b.cen, cen.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+    BU_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    // non-empty clusters, in index order
+    std::vector<uint32_t> old_to_new(k, 0), live;
+    for (uint32_t c = 0; c < k; c++) if (sums[(size_t)c * 17 + 16]) { old_to_new[c] = (uint32_t)live.size(); live.push_back(c); }
+    const uint32_t kl = (uint32_t)live.size();
+    *out_clusters = kl;
+    uint32_t parents = 0;
+    std::vector<uint32_t> parent_of_old(k, 0);
+    if (n_parents && kl) {
+        // the parent level: weighted k-means over the live clusters' final centres (the true means of their members), a few thousand points, on the host
+        const int D = 16;
+        std::vector<double> pts((size_t)kl * D), wts(kl);
+        for (uint32_t i = 0; i < kl; i++) {
+            const uint64_t w = sums[(size_t)live[i] * 17 + 16];
+            wts[i] = (double)w;
+            for (int d = 0; d < D; d++) pts[(size_t)i * D + d] = (double)sums[(size_t)live[i] * 17 + d] / (double)w;
+        }
+        const uint32_t P = std::min(n_parents, kl);
+        std::vector<double> pc((size_t)P * D);
+        for (uint32_t p = 0; p < P; p++) std::memcpy(&pc[(size_t)p * D], &pts[(size_t)(((uint64_t)p * 2 + 1) * kl / (2ull * P)) * D], D * sizeof(double));
+        std::vector<uint32_t> owner(kl, 0);
+        for (int it = 0; it < 12; it++) {
+            for (uint32_t i = 0; i < kl; i++) {
+                double bd = 1e300; uint32_t bp = 0;
+                for (uint32_t p = 0; p < P; p++) {
+                    double dd = 0;
+                    for (int d = 0; d < D; d++) { const double t = pts[(size_t)i * D + d] - pc[(size_t)p * D + d]; dd += t * t; }
+                    if (dd < bd) { bd = dd; bp = p; }
+                }
+                owner[i] = bp;
+            }
+            std::vector<double> acc((size_t)P * D, 0.0), aw(P, 0.0);
+            for (uint32_t i = 0; i < kl; i++) { aw[owner[i]] += wts[i]; for (int d = 0; d < D; d++) acc[(size_t)owner[i] * D + d] += wts[i] * pts[(size_t)i * D + d]; }
+            for (uint32_t p = 0; p < P; p++) if (aw[p] > 0) for (int d = 0; d < D; d++) pc[(size_t)p * D + d] = acc[(size_t)p * D + d] / aw[p];
+        }
+        std::vector<int32_t> renum(P, -1);   // parents that own something, in index order
+        for (uint32_t i = 0; i < kl; i++) if (renum[owner[i]] < 0) renum[owner[i]] = 0;
+        for (uint32_t p = 0; p < P; p++) if (renum[p] == 0) renum[p] = (int32_t)parents++;
+        for (uint32_t i = 0; i < kl; i++) parent_of_old[live[i]] = (uint32_t)renum[owner[i]];
+    }
+    if (out_parents) *out_parents = parents;
+    // per distinct vector: parent first (from the raw assignment), then the compacted cluster index in place
+    if (n_parents) {
+        BU_TRY(ctx, h2d(ctx, d_tab, parent_of_old.data(), (size_t)k * 4));
+        BU_TRY(ctx, bu::launch_gather_u32(ctx->stream, d_tab, d_cluster, n, d_parent));
+    }
+    BU_TRY(ctx, h2d(ctx, d_tab + k, old_to_new.data(), (size_t)k * 4));
+    BU_TRY(ctx, bu::launch_gather_u32(ctx->stream, d_tab + k, d_cluster, n, d_cluster));
+    BU_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    (void)cen;
     return 1;
 }
 

@@ -365,6 +365,18 @@ bool etc1s_frontend::generate_endpoint_clusters() {
     m_endpoint_parent_clusters.clear();
     std::vector<uint32_t> leaf_of_unique;
     std::vector<std::vector<uint32_t>> unused;
+    if (m_params.m_fast_codebooks && !std::getenv("BU_FAST_SELECTORS_ONLY")) {   // row f3: k-means on the matrix cores; the per-vector results come back (a few ten thousand words) for the list offsets below
+        device_state& dd = *m_dev;
+        const uint32_t u = (uint32_t)m_endpoint_unique_weights.size(), want_parents = m_use_hierarchical_endpoint_codebooks ? parent_size : 0;
+        if (!dd.reserve(dd.tmp_a, (size_t)u * 4) || !dd.reserve(dd.tmp_c, (size_t)u * 4)) return fail("alloc");
+        if (!bu_hip_kmeans_codebook(dd.ctx, 1, dd.ep_ukeys.p, nullptr, (const uint32_t*)dd.ep_goffs.p, u, m_params.m_max_endpoint_clusters, want_parents,
+                                    m_params.m_fast_codebook_iterations, (uint32_t*)dd.tmp_a.p, want_parents ? (uint32_t*)dd.tmp_c.p : nullptr, &m_endpoint_cluster_count,
+                                    &m_endpoint_parent_count))
+            return fail("bu_hip_kmeans_codebook (endpoints)");
+        leaf_of_unique.resize(u);
+        m_endpoint_parent_of_unique.assign(want_parents ? u : 0, 0);
+        if (!dd.download(leaf_of_unique.data(), dd.tmp_a, u) || (want_parents && !dd.download(m_endpoint_parent_of_unique.data(), dd.tmp_c, u))) return fail("download");
+    } else
     if (!device_tsvq::hierarchical_codebook(m_dev->ctx, 6, m_endpoint_unique_rows, m_endpoint_unique_weights, groups, m_params.m_max_endpoint_clusters,
                                             m_use_hierarchical_endpoint_codebooks ? parent_size : 0, unused, m_endpoint_parent_clusters, nullptr,
                                             &m_endpoint_parent_of_unique, &m_endpoint_parent_count, &leaf_of_unique, &m_endpoint_cluster_count))
@@ -907,6 +919,13 @@ bool etc1s_frontend::generate_selector_clusters() {
     if (!d.reserve(d.tmp_a, (size_t)u_total * 4) || !d.reserve(d.tmp_b, (size_t)u_total * 4) || !d.reserve(d.sel_cluster, (size_t)comm_world() * slab_blocks() * 4) ||
         !d.reserve(d.sel_parent, n))
         return fail("alloc");
+    if (m_params.m_fast_codebooks && !std::getenv("BU_FAST_ENDPOINTS_ONLY")) {   // row f3
+        if (!bu_hip_kmeans_codebook(d.ctx, 0, d.sel_ukeys.p, (const uint64_t*)d.sel_uw.p, nullptr, u_total, m_params.m_max_selector_clusters, hier ? parent_size : 0,
+                                    m_params.m_fast_codebook_iterations, (uint32_t*)d.tmp_a.p, hier ? (uint32_t*)d.tmp_b.p : nullptr, &m_selector_cluster_count,
+                                    &m_selector_parent_count))
+            return fail("bu_hip_kmeans_codebook (selectors)");
+        ts.t_device = sub.seconds();
+    } else
     if (!device_tsvq::hierarchical_codebook_packed16_device(d.ctx, (const uint32_t*)d.sel_ukeys.p, (const uint64_t*)d.sel_uw.p, u_total, groups, m_params.m_max_selector_clusters,
                                                             hier ? parent_size : 0, m_selector_cluster_block_indices, m_selector_parent_cluster_block_indices, &ts, nullptr,
                                                             &m_selector_parent_count, nullptr, &m_selector_cluster_count, (uint32_t*)d.tmp_a.p, (uint32_t*)d.tmp_b.p))

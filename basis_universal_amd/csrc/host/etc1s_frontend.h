@@ -38,6 +38,10 @@ public:
         bool m_validate = false;
         bool m_disable_hierarchical_endpoint_codebooks = false;
         bool m_video = false;                             // = m_tex_type == cBASISTexTypeVideoFrames: only changes the order of stages (frontend.cpp:219-223, 291)
+        // both codebooks from a k-means on the matrix cores (bu_hip_kmeans_codebook) instead of the order-dependent TSVQ. NOT
+        // bit-identical to the reference: different codebooks (deterministic), held to the reference's size / PSNR tolerances. Off by default.
+        bool m_fast_codebooks = false;
+        uint32_t m_fast_codebook_iterations = 4;
         bu_hip_context* m_pHIP_context = nullptr;         // = m_pOpenCL_context; REQUIRED
     };
 

@@ -14,6 +14,8 @@ struct bu_frontend {
     bu::etc1s_frontend fe;
     std::string error;
     bool video = false;
+    bool fast_codebooks = false;
+    uint32_t fast_iterations = 4;
 };
 
 namespace {
@@ -58,6 +60,8 @@ int bu_frontend_init(bu_frontend* f, bu_hip_context* ctx, const bu_pixel_block* 
     p.m_perceptual = perceptual != 0;
     p.m_pHIP_context = ctx;
     p.m_video = f->video;
+    p.m_fast_codebooks = f->fast_codebooks;
+    p.m_fast_codebook_iterations = f->fast_iterations;
     return f->fe.init(p) ? 1 : 0;
 }
 
@@ -68,6 +72,12 @@ int bu_frontend_set_comm(bu_frontend* f, const bu_comm* comm) {
 }
 
 int bu_frontend_set_video(bu_frontend* f, int video) { if (!f) return 0; f->video = video != 0; return 1; }
+int bu_frontend_set_fast_codebooks(bu_frontend* f, int on, uint32_t iterations) {
+    if (!f) return 0;
+    f->fast_codebooks = on != 0;
+    if (iterations) f->fast_iterations = iterations;
+    return 1;
+}
 
 int bu_frontend_compress(bu_frontend* f) { return (f && f->fe.compress()) ? 1 : 0; }
 

@@ -120,9 +120,10 @@ class TorchComm:
 
 
 class Etc1sFrontend:
-    def __init__(self, ctx, comm=None, video=False):
+    def __init__(self, ctx, comm=None, video=False, fast_codebooks=False, fast_iterations=0):
         """comm: a TorchComm to shard the device stages over the ranks of its process group (every rank must drive an identical
-        frontend on identical tiles); None = single GPU."""
+        frontend on identical tiles); None = single GPU. fast_codebooks: SURVEY 8f row f3 -- both codebooks from a k-means on the matrix
+        cores instead of the TSVQ: NOT bit-identical to the reference (see include/basisu_hip_frontend.h), off by default."""
         self.ctx = ctx
         self.L = load_frontend_library()
         self.h = self.L.bu_frontend_create()
@@ -132,6 +133,9 @@ class Etc1sFrontend:
         if video:  # cBASISTexTypeVideoFrames: a different order of stages, see include/basisu_hip_frontend.h
             self.L.bu_frontend_set_video.argtypes = [_vp, C.c_int]
             self._check(self.L.bu_frontend_set_video(self.h, 1), "bu_frontend_set_video")
+        if fast_codebooks:
+            self.L.bu_frontend_set_fast_codebooks.argtypes = [_vp, C.c_int, C.c_uint32]
+            self._check(self.L.bu_frontend_set_fast_codebooks(self.h, 1, int(fast_iterations)), "bu_frontend_set_fast_codebooks")
         if comm is not None:
             self._check(self.L.bu_frontend_set_comm(self.h, C.byref(comm.struct)), "bu_frontend_set_comm")
 

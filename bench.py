@@ -64,6 +64,7 @@ def main():
                     "basis_parallel_compress); the default 1 is what the headline number uses")
     ap.add_argument("--no-pipelined", action="store_true", help="skip the additional 3-images-in-flight throughput measurement")
     ap.add_argument("--no-uastc", action="store_true", help="skip the secondary UASTC level-2 measurement (BASELINE config #3)")
+    ap.add_argument("--no-fast", action="store_true", help="skip the secondary measurement of the codebook builders' fast mode (SURVEY 8f row f3, not bit-identical)")
     args = ap.parse_args()
 
     import torch
@@ -267,6 +268,8 @@ def main():
             out["mipmaps"] = mip_bench(ctx, img)
         if not args.no_uastc and world == 1:
             out["uastc"] = uastc_bench(ctx, d_blocks, n_blocks, w, h, helpers, args)
+        if not args.no_fast and world == 1:
+            out["fast_codebooks"] = fast_codebooks_bench(ctx, d_blocks, n_blocks, w, h, max_ep, max_sel, args)
             out["uastc_rdo"] = uastc_rdo_bench(ctx, helpers, args)
         print(json.dumps(out))
     if last is not None:
@@ -285,6 +288,58 @@ def pmc_traffic(kernel):
         return None
     rec = json.loads(f.read_text()).get(kernel)
     return None if not rec else int(rec["fetch_bytes_per_launch"] + rec["write_bytes_per_launch"])
+
+
+MFMA_F16_PEAK_TFLOPS = 2500.0  # dense, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def fast_codebooks_bench(ctx, d_blocks, n_blocks, w, h, max_ep, max_sel, args):
+    """the same step with both codebooks from the matrix-core k-means instead of the TSVQ. NOT bit-identical to the reference
+    (held to its size / PSNR tolerances by tests/test_gpu_fast_codebooks.py); reported beside the headline value, never as it. The roofline
+    of its dominant kernel is an MFMA one: flops of the assignment GEMMs (2 x vectors x padded centroids x 16 dims x 2 operand halves per round)."""
+    import torch
+    from basis_universal_amd.etc1s import Etc1sFrontend
+
+    def step():
+        fe = Etc1sFrontend(ctx, fast_codebooks=True)
+        fe.init(d_blocks.data_ptr(), max_ep, max_sel, args.level, True, n_blocks=n_blocks)
+        fe.compress()
+        return fe
+
+    step().close()
+    torch.cuda.synchronize()
+    ctx.profile_enable(True)
+    steps = max(args.steps, 3)
+    t0 = time.perf_counter()
+    last = None
+    for _ in range(steps):
+        if last is not None:
+            last.close()
+        last = step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    kernels = ctx.profile_read()
+    ctx.profile_enable(False)
+    enc = last.get("orig_encoded_blocks", np.uint8).reshape(-1, 8)
+    u_sel = int(np.unique(np.ascontiguousarray(enc[:, 4:]).view(np.uint32)).size)
+    final = (int(last.get("endpoint_clusters", np.uint32)[0]), int(last.get("selector_cluster_block_indices", np.uint32)[0]))
+    last.close()
+    out = {"what": "ETC1S frontend with both codebooks from k-means on the matrix cores (4 Lloyd rounds + the final assignment) instead of the TSVQ; "
+                   "NOT bit-identical to the reference, gated by its 4.5 % size / 0.3 dB tolerances (tests/test_gpu_fast_codebooks.py)",
+           "value": round(w * h / 1e6 / dt, 3), "unit": "Mpixels/s", "ms_per_step": round(dt * 1e3, 2), "final_clusters": final,
+           "kernels_ms_per_step": {k: round(v[0] / steps, 3) for k, v in kernels.items() if k.startswith("kmeans")}}
+    if "kmeans_selectors" in kernels:
+        ms, launches = kernels["kmeans_selectors"]
+        k_pad = (max_sel + 31) // 32 * 32
+        rounds = 5
+        flops = 2.0 * u_sel * k_pad * 16 * 2 * rounds
+        avg_s = ms / 1e3 / launches
+        out["roofline"] = {"bound": "mfma", "kernel": "kmeans_selectors", "achieved": round(flops / avg_s / 1e12, 2), "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                           "frac": round(flops / avg_s / 1e12 / MFMA_F16_PEAK_TFLOPS, 5), "traffic": None, "avg_launch_ms": round(avg_s * 1e3, 3),
+                           "flops_per_launch": flops, "distinct_vectors": u_sel,
+                           "note": "one launch = unpack + seeding + 5 assignment GEMMs with their argmin / integer accumulation epilogues + centroid updates; the "
+                                   "epilogue (16 compares per MFMA result register set) bounds it, not the matrix pipe"}
+    return out
 
 
 def uastc_bench(ctx, d_blocks, n_blocks, w, h, helpers, args):

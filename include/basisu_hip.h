@@ -238,6 +238,16 @@ BU_HIP_API int bu_hip_k_map_membership(bu_hip_context*, const uint8_t* d_block_p
     uint32_t n_clusters, uint8_t* d_out_flags);
 BU_HIP_API int bu_hip_k_map_gather(bu_hip_context*, const uint32_t* d_table, const uint32_t* d_index, uint32_t n, uint32_t* d_out);
 
+/* f3  Codebook builder FAST MODE (basis_universal_amd/csrc/kmeans_kernels.hip): weighted k-means over the distinct training
+ *     vectors with the assignment step on the matrix cores, instead of the TSVQ. NOT bit-identical to the reference (different, deterministic
+ *     codebooks); off unless asked for (bu_frontend_set_fast_codebooks), held to the reference's own size / PSNR tolerances by the tests.
+ *     kind 0: d_keys = uint32 packed selector vectors + d_weights; kind 1: d_keys = uint64 endpoint colour keys, weights = 2 x group sizes
+ *     (d_group_offsets[n + 1]). Writes, per distinct vector, its cluster (empty clusters removed, index order kept) and -- n_parents > 0 -- the
+ *     parent group of that cluster (k-means over the centroids); returns the counts. Synchronises. */
+BU_HIP_API int bu_hip_kmeans_codebook(bu_hip_context*, int kind, const void* d_keys, const uint64_t* d_weights, const uint32_t* d_group_offsets, uint32_t n_vectors,
+    uint32_t max_clusters, uint32_t n_parents, uint32_t iterations, uint32_t* d_out_cluster_of_vector, uint32_t* d_out_parent_of_vector, uint32_t* out_clusters,
+    uint32_t* out_parents);
+
 /* a8  tree_vector_quant (encoder/basisu_enc.h:1546-2078): the order-dependent TSVQ tree build, split by split, bit-exact.
  *     The host keeps the tree, the variance priority queue and the split order (enc.h:1616-1660); the device executes batches of
  *     independent node splits (split_node, enc.h:1737-1800) on the resident training set. Rows must be the DISTINCT training

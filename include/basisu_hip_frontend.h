@@ -36,6 +36,11 @@ BU_HIP_API int bu_frontend_set_comm(bu_frontend*, const bu_comm* comm); /* NULL 
 /* basisu_frontend::params::m_tex_type == cBASISTexTypeVideoFrames (frontend.cpp:219-223, 291: one more fit of the merged endpoint codebook, endpoints
  * refitted to the selectors at every level); call before bu_frontend_init. The backend's half is bu_backend_params::video. */
 BU_HIP_API int bu_frontend_set_video(bu_frontend*, int video);
+/* SURVEY 8f row f3, the codebook builders' fast mode: both codebooks (and their parent levels) from a weighted k-means whose assignment step runs
+ * on the matrix cores (bu_hip_kmeans_codebook) instead of the order-dependent TSVQ. The result is NOT bit-identical to the reference -- other,
+ * deterministic codebooks of the same sizes -- and is held to the reference's own tolerances (file size +-4.5 %, PSNR -0.3 dB, basisu_tool.cpp:
+ * 6786-6793) by tests/test_gpu_fast_codebooks.py. Off by default; iterations 0 keeps the default (4 Lloyd rounds + the final assignment; more rounds changed nothing measurable). Call before bu_frontend_init. */
+BU_HIP_API int bu_frontend_set_fast_codebooks(bu_frontend*, int on, uint32_t iterations);
 
 /* basisu_frontend::compress (frontend.cpp:159) */
 BU_HIP_API int bu_frontend_compress(bu_frontend*);

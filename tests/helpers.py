@@ -484,6 +484,38 @@ def host_encode_uastc(blocks, flags):
     return out
 
 
+def decode_etc1s_blocks(blocks, nbx, nby):
+    """ETC1S blocks (n, 8) u8 in block-raster order -> (nby * 4, nbx * 4, 3) u8: differential mode with zero deltas, both sub-blocks share
+    colour5 and the intensity table (etc_block::unpack_color5 / get_block_colors, etc.h:543-570), selector bit planes per etc.h:232-236."""
+    b = np.ascontiguousarray(blocks, np.uint8).reshape(-1, 8)
+    v = b.astype(np.uint64)
+    word = np.zeros(b.shape[0], np.uint64)
+    for i in range(8):
+        word = (word << np.uint64(8)) | v[:, i]
+    r5, g5, b5 = ((word >> np.uint64(s)) & np.uint64(31) for s in (59, 51, 43))
+    inten = ((word >> np.uint64(37)) & np.uint64(7)).astype(np.int64)
+    lo = (word & np.uint64(0xFFFFFFFF)).astype(np.uint64)
+    table = np.array([[-8, -2, 2, 8], [-17, -5, 5, 17], [-29, -9, 9, 29], [-42, -13, 13, 42], [-60, -18, 18, 60], [-80, -24, 24, 80], [-106, -33, 33, 106],
+                      [-183, -47, 47, 183]], np.int64)
+    base = np.stack([(c.astype(np.int64) << 3) | (c.astype(np.int64) >> 2) for c in (r5, g5, b5)], axis=1)      # (n, 3)
+    to_sel = np.array([2, 3, 1, 0], np.int64)
+    out = np.zeros((b.shape[0], 4, 4, 3), np.uint8)
+    for y in range(4):
+        for x in range(4):
+            bit = np.uint64(x * 4 + y)
+            raw = ((lo >> bit) & np.uint64(1)) | (((lo >> (np.uint64(16) + bit)) & np.uint64(1)) << np.uint64(1))
+            sel = to_sel[raw.astype(np.int64)]
+            out[:, y, x, :] = np.clip(base + table[inten, sel][:, None], 0, 255).astype(np.uint8)
+    return out.reshape(nby, nbx, 4, 4, 3).transpose(0, 2, 1, 3, 4).reshape(nby * 4, nbx * 4, 3)
+
+
+def psnr(a, b):
+    """image_metrics::calc's PSNR over the given channels (enc.cpp:2155-2226): 20 log10(255 / rms), clamped to 100"""
+    d = a.astype(np.float64) - b.astype(np.float64)
+    mse = float((d * d).mean())
+    return 100.0 if mse == 0 else min(100.0, 20.0 * np.log10(255.0 / np.sqrt(mse)))
+
+
 def save_png(path, img):
     """Minimal 8-bit RGBA PNG writer (test inputs for the reference CLI)."""
     import struct, zlib
