@@ -58,6 +58,8 @@ _SIGNATURES = {
     "bu_hip_k_map_membership": (_int, [_vp, _vp, _vp, _u32, _u32, _u32, _vp]),
     "bu_hip_k_map_gather": (_int, [_vp, _vp, _vp, _u32, _vp]),
     "bu_hip_tsvq_scatter_spans": (_int, [_vp, _vp, _vp, _u32, _vp]),
+    "bu_hip_tsvq_exchange_pack": (_int, [_vp, _vp, _vp, _vp, _vp, _u32, _vp, _vp]),
+    "bu_hip_tsvq_exchange_unpack": (_int, [_vp, _vp, _vp, _vp, _vp, _u32]),
     "bu_hip_kmeans_codebook": (_int, [_vp, _int, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _vp, _vp, _vp, _vp]),
     "bu_hip_cancel_on_destroy": (None, [_vp, _vp, _vp]),
     "bu_hip_context_device": (_int, [_vp]),

@@ -87,6 +87,21 @@ __global__ void __launch_bounds__(256) k_scatter_spans(const uint32_t* __restric
     for (uint32_t i = threadIdx.x; i < s.count; i += 256) out[p[i]] = s.value;
 }
 
+// multi-GPU TSVQ: the child member lists of a batch of split nodes, laid end to end in batch order (staging), to and from the member buffers.
+// A node's children live in the OTHER buffer than the node, at the node's own [start, start + count). dir 0: buffers -> staging for the nodes
+// flagged in `take` (zero for the others), dir 1: staging -> buffers for the flagged nodes.
+__global__ void __launch_bounds__(256) k_exchange_children(uint32_t* __restrict__ perm0, uint32_t* __restrict__ perm1, const bk_span* __restrict__ nodes /* value = offset in staging */,
+                                                           const uint8_t* __restrict__ take, uint32_t* __restrict__ staging, int dir) {
+    const bk_span nd = nodes[blockIdx.x];
+    uint32_t* child = (nd.buf ? perm0 : perm1) + nd.start;
+    uint32_t* st = staging + nd.value;
+    const bool mine = take[blockIdx.x] != 0;
+    for (uint32_t i = threadIdx.x; i < nd.count; i += 256) {
+        if (dir == 0) st[i] = mine ? child[i] : 0u;
+        else if (mine) child[i] = st[i];
+    }
+}
+
 __global__ void __launch_bounds__(256) k_gather_u32(const uint32_t* __restrict__ table, const uint32_t* __restrict__ index, uint32_t n, uint32_t* __restrict__ out) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i < n) out[i] = table[index[i]];
@@ -170,6 +185,12 @@ hipError_t launch_membership(hipStream_t st, const uint8_t* d_parent, const uint
 hipError_t launch_scatter_spans(hipStream_t st, const uint32_t* d_perm0, const uint32_t* d_perm1, const bk_span* d_spans, uint32_t n_spans, uint32_t* d_out) {
     if (!n_spans) return hipSuccess;
     hipLaunchKernelGGL(k_scatter_spans, dim3(n_spans), dim3(256), 0, st, d_perm0, d_perm1, d_spans, d_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_exchange_children(hipStream_t st, uint32_t* d_perm0, uint32_t* d_perm1, const bk_span* d_nodes, const uint8_t* d_take, uint32_t n_nodes, uint32_t* d_staging, int dir) {
+    if (!n_nodes) return hipSuccess;
+    hipLaunchKernelGGL(k_exchange_children, dim3(n_nodes), dim3(256), 0, st, d_perm0, d_perm1, d_nodes, d_take, d_staging, dir);
     return hipGetLastError();
 }
 

@@ -731,6 +731,7 @@ struct bu_tsvq {
     uint32_t wide_min = 0;      // 0: off
     uint32_t wide_cov_min = 0;  // batches whose largest node is smaller run the covariance pass chained (BU_TSVQ_WIDE_COV_MIN)
     uint32_t wide_blocks_cap = 0, wide_nodes_cap = 0;
+    void* xchg = nullptr; size_t xchg_cap = 0;   // staging of bu_hip_tsvq_exchange_* (multi-GPU)
     void* wide_ws = nullptr; void* wide_packed = nullptr; bu::tsvq_wide_node* wide_nodes = nullptr; bu::tsvq_wide_ctrl* wide_ctrl = nullptr;
     // Pinned staging for the per-round node / result records: hipMemcpyAsync on PAGEABLE host memory followed directly by a
     // kernel on the same stream was observed to let the kernel read the destination before the copy landed (MI355X, ROCm 7.2:
@@ -757,7 +758,7 @@ void bu_hip_tsvq_destroy(bu_hip_context* ctx, bu_tsvq* q) {
     if (!ctx || !q) return;
     device_guard g(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    for (void* p : {q->rows, (void*)q->w64, (void*)q->perm[0], (void*)q->perm[1], (void*)q->side, q->nodes.p, q->outs.p, q->wide_ws, q->wide_packed, (void*)q->wide_nodes, (void*)q->wide_ctrl}) if (p) bu_hip_free(ctx, p);
+    for (void* p : {q->rows, (void*)q->w64, (void*)q->perm[0], (void*)q->perm[1], (void*)q->side, q->nodes.p, q->outs.p, q->xchg, q->wide_ws, q->wide_packed, (void*)q->wide_nodes, (void*)q->wide_ctrl}) if (p) bu_hip_free(ctx, p);
     q->nodes.p = nullptr; q->outs.p = nullptr;
     if (q->pinned) {  // hand the pinned staging buffer back to the context (keep the larger one)
         if (q->pinned_cap > ctx->tsvq_pinned_cap) { if (ctx->tsvq_pinned) (void)hipHostFree(ctx->tsvq_pinned); ctx->tsvq_pinned = q->pinned; ctx->tsvq_pinned_cap = q->pinned_cap; }
@@ -980,6 +981,68 @@ int bu_hip_tsvq_scatter_spans(bu_hip_context* ctx, bu_tsvq* q, const bu_tsvq_spa
     BU_TRY(ctx, hipMemcpyAsync(q->nodes.p, q->pinned, bytes, hipMemcpyHostToDevice, ctx->stream));
     BU_TRY(ctx, bu::launch_scatter_spans(ctx->stream, q->perm[0], q->perm[1], static_cast<const bu::bk_span*>(q->nodes.p), n_spans, d_out));
     BU_TRY(ctx, hipStreamSynchronize(ctx->stream));   // q may be destroyed (and the pinned buffer recycled) right after
+    return 1;
+}
+
+// staging layout: [children of node 0 | children of node 1 | ... ] u32, padded to a u64 boundary, then n_nodes result records, then the node table + flags
+static int tsvq_exchange_layout(bu_hip_context* ctx, bu_tsvq* q, const bu_tsvq_node* h_nodes, uint32_t n_nodes, std::vector<bu::bk_span>& table, size_t& rec_at, size_t& tab_at, size_t& total) {
+    table.resize(n_nodes);
+    uint64_t run = 0;
+    for (uint32_t i = 0; i < n_nodes; i++) {
+        if ((uint64_t)h_nodes[i].start + h_nodes[i].count > q->n) { set_error(ctx, "tsvq_exchange: node outside the training set"); return 0; }
+        table[i] = bu::bk_span{h_nodes[i].buf, h_nodes[i].start, h_nodes[i].count, (uint32_t)run};
+        run += h_nodes[i].count;
+    }
+    if (run > q->n) { set_error(ctx, "tsvq_exchange: overlapping nodes"); return 0; }
+    rec_at = ((size_t)run * 4 + 7) & ~(size_t)7;
+    tab_at = rec_at + (size_t)n_nodes * sizeof(bu_tsvq_split);
+    total = tab_at + (size_t)n_nodes * sizeof(bu::bk_span) + ((size_t)n_nodes + 7 & ~(size_t)7);
+    if (total > q->xchg_cap) {
+        if (q->xchg) bu_hip_free(ctx, q->xchg);
+        q->xchg_cap = total + total / 4 + 4096;
+        q->xchg = bu_hip_malloc(ctx, q->xchg_cap);
+        if (!q->xchg) { q->xchg_cap = 0; set_error(ctx, "tsvq_exchange: allocation"); return 0; }
+    }
+    return 1;
+}
+
+int bu_hip_tsvq_exchange_pack(bu_hip_context* ctx, bu_tsvq* q, const bu_tsvq_node* h_nodes, const uint8_t* h_mine, const bu_tsvq_split* h_records, uint32_t n_nodes,
+                              void** d_staging, uint64_t* n_u64) {
+    if (!ctx || !q || !h_nodes || !h_mine || !h_records || !d_staging || !n_u64 || !n_nodes) return 0;
+    device_guard g(ctx->device);
+    std::vector<bu::bk_span> table;
+    size_t rec_at, tab_at, total;
+    if (!tsvq_exchange_layout(ctx, q, h_nodes, n_nodes, table, rec_at, tab_at, total)) return 0;
+    char* base = static_cast<char*>(q->xchg);
+    // host part of the staging buffer: records (zero where not mine), node table, flags -- one upload
+    std::vector<char> host(total - rec_at, 0);
+    for (uint32_t i = 0; i < n_nodes; i++) if (h_mine[i]) std::memcpy(&host[(size_t)i * sizeof(bu_tsvq_split)], &h_records[i], sizeof(bu_tsvq_split));
+    std::memcpy(&host[tab_at - rec_at], table.data(), (size_t)n_nodes * sizeof(bu::bk_span));
+    std::memcpy(&host[tab_at - rec_at + (size_t)n_nodes * sizeof(bu::bk_span)], h_mine, n_nodes);
+    BU_TRY(ctx, h2d(ctx, base + rec_at, host.data(), host.size()));
+    if (rec_at >= 8) BU_TRY(ctx, hipMemsetAsync(base + rec_at - 8, 0, 8, ctx->stream));   // the padding word of an odd child count
+    BU_TRY(ctx, bu::launch_exchange_children(ctx->stream, q->perm[0], q->perm[1], reinterpret_cast<const bu::bk_span*>(base + tab_at),
+                                             reinterpret_cast<const uint8_t*>(base + tab_at + (size_t)n_nodes * sizeof(bu::bk_span)), n_nodes, reinterpret_cast<uint32_t*>(base), 0));
+    BU_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    *d_staging = q->xchg;
+    *n_u64 = tab_at / 8;
+    return 1;
+}
+
+int bu_hip_tsvq_exchange_unpack(bu_hip_context* ctx, bu_tsvq* q, const bu_tsvq_node* h_nodes, const uint8_t* h_mine, bu_tsvq_split* h_records, uint32_t n_nodes) {
+    if (!ctx || !q || !h_nodes || !h_mine || !h_records || !n_nodes || !q->xchg) return 0;
+    device_guard g(ctx->device);
+    std::vector<bu::bk_span> table;
+    size_t rec_at, tab_at, total;
+    if (!tsvq_exchange_layout(ctx, q, h_nodes, n_nodes, table, rec_at, tab_at, total)) return 0;
+    char* base = static_cast<char*>(q->xchg);
+    std::vector<uint8_t> theirs(n_nodes);
+    for (uint32_t i = 0; i < n_nodes; i++) theirs[i] = h_mine[i] ? 0 : 1;
+    BU_TRY(ctx, h2d(ctx, base + tab_at + (size_t)n_nodes * sizeof(bu::bk_span), theirs.data(), n_nodes));
+    BU_TRY(ctx, bu::launch_exchange_children(ctx->stream, q->perm[0], q->perm[1], reinterpret_cast<const bu::bk_span*>(base + tab_at),
+                                             reinterpret_cast<const uint8_t*>(base + tab_at + (size_t)n_nodes * sizeof(bu::bk_span)), n_nodes, reinterpret_cast<uint32_t*>(base), 1));
+    BU_TRY(ctx, hipMemcpyAsync(h_records, base + rec_at, (size_t)n_nodes * sizeof(bu_tsvq_split), hipMemcpyDeviceToHost, ctx->stream));
+    BU_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return 1;
 }
 

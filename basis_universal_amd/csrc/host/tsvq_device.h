@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "../../../include/basisu_hip.h"
+#include "../../../include/basisu_hip_frontend.h"
 #include "tsvq.h"
 
 namespace bu {
@@ -65,13 +66,13 @@ public:
                                       const Groups& groups, uint32_t max_codebook_size, uint32_t max_parent_codebook_size,
                                       std::vector<std::vector<uint32_t>>& codebook, std::vector<std::vector<uint32_t>>& parent_codebook, stats* st = nullptr,
                                       std::vector<uint32_t>* parent_of_unique = nullptr, uint32_t* parent_count = nullptr,
-                                      std::vector<uint32_t>* leaf_of_unique = nullptr, uint32_t* leaf_count = nullptr) {
+                                      std::vector<uint32_t>* leaf_of_unique = nullptr, uint32_t* leaf_count = nullptr, const bu_comm* comm = nullptr) {
         bu_tsvq_root root;
         const auto t0 = std::chrono::steady_clock::now();
         bu_tsvq* q = weights.empty() ? nullptr : bu_hip_tsvq_create(ctx, dim, rows.data(), weights.data(), (uint32_t)weights.size(), &root);
         if (st) st->t_create = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         return q && build(ctx, q, root, (uint32_t)weights.size(), groups, max_codebook_size, max_parent_codebook_size, codebook, parent_codebook, st, parent_of_unique, parent_count,
-                          leaf_of_unique, leaf_count);
+                          leaf_of_unique, leaf_count, nullptr, nullptr, comm);
     }
 
     // Selector vectors: keys[u] packs the 16 selector values of distinct vector u (value 0 in the top two bits), ascending.
@@ -93,13 +94,13 @@ public:
                                                       std::vector<std::vector<uint32_t>>& parent_codebook, stats* st = nullptr,
                                                       std::vector<uint32_t>* parent_of_unique = nullptr, uint32_t* parent_count = nullptr,
                                                       std::vector<uint32_t>* leaf_of_unique = nullptr, uint32_t* leaf_count = nullptr,
-                                                      uint32_t* d_leaf_of_unique = nullptr, uint32_t* d_parent_of_unique = nullptr) {
+                                                      uint32_t* d_leaf_of_unique = nullptr, uint32_t* d_parent_of_unique = nullptr, const bu_comm* comm = nullptr) {
         bu_tsvq_root root;
         const auto t0 = std::chrono::steady_clock::now();
         bu_tsvq* q = n_unique ? bu_hip_tsvq_create_packed16_device(ctx, d_keys, d_weights, n_unique, &root) : nullptr;
         if (st) st->t_create = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         return q && build(ctx, q, root, n_unique, groups, max_codebook_size, max_parent_codebook_size, codebook, parent_codebook, st, parent_of_unique, parent_count,
-                          leaf_of_unique, leaf_count, d_leaf_of_unique, d_parent_of_unique);
+                          leaf_of_unique, leaf_count, d_leaf_of_unique, d_parent_of_unique, comm);
     }
 
     // parent lists from a parent-of-unique map (what build() would have produced): vectors ascending inside a parent, members group by group
@@ -151,7 +152,7 @@ private:
                       uint32_t max_codebook_size, uint32_t max_parent_codebook_size, std::vector<std::vector<uint32_t>>& codebook,
                       std::vector<std::vector<uint32_t>>& parent_codebook, stats* st, std::vector<uint32_t>* parent_of_unique = nullptr,
                       uint32_t* parent_count = nullptr, std::vector<uint32_t>* leaf_of_unique = nullptr, uint32_t* leaf_count = nullptr,
-                      uint32_t* d_leaf_of_unique = nullptr, uint32_t* d_parent_of_unique = nullptr) {
+                      uint32_t* d_leaf_of_unique = nullptr, uint32_t* d_parent_of_unique = nullptr, const bu_comm* comm = nullptr) {
         if (parent_of_unique) parent_of_unique->clear();
         if (parent_count) *parent_count = 0;
         if (leaf_of_unique) leaf_of_unique->clear();
@@ -235,7 +236,37 @@ private:
             }
             const size_t base = cache.size();
             cache.resize(base + batch.size());
-            if (std::getenv("BU_TSVQ_SERIAL")) { // debug: one node per launch
+            if (comm && comm->world > 1 && batch.size() > 1) {
+                // Multi-GPU: the nodes of a round are independent, so every rank splits a share of them (largest first onto the least loaded
+                // rank: the same assignment on every rank) and the child member lists + result records are merged by ONE exact sum all-reduce of
+                // a staging buffer in which everybody else's entries are zero. Afterwards every rank holds every result, bit for bit.
+                const auto td = now();
+                std::vector<uint32_t> order(batch.size());
+                for (uint32_t i = 0; i < order.size(); i++) order[i] = i;
+                std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return batch[a].count > batch[b].count; });
+                std::vector<uint64_t> load(comm->world, 0);
+                std::vector<uint8_t> mine(batch.size(), 0);
+                std::vector<uint32_t> my_idx;
+                for (uint32_t i : order) {
+                    uint32_t r = 0;
+                    for (uint32_t k = 1; k < comm->world; k++) if (load[k] < load[r]) r = k;
+                    load[r] += batch[i].count;
+                    if (r == comm->rank) { mine[i] = 1; my_idx.push_back(i); }
+                }
+                std::sort(my_idx.begin(), my_idx.end());
+                std::vector<bu_tsvq_node> my_nodes;
+                for (uint32_t i : my_idx) my_nodes.push_back(batch[i]);
+                std::vector<bu_tsvq_split> my_out(my_nodes.size());
+                if (!my_nodes.empty() && !bu_hip_tsvq_split(ctx, q, my_nodes.data(), (uint32_t)my_nodes.size(), my_out.data())) return false;
+                std::vector<bu_tsvq_split> rec(batch.size());
+                std::memset(rec.data(), 0, rec.size() * sizeof(bu_tsvq_split));
+                for (size_t j = 0; j < my_idx.size(); j++) { rec[my_idx[j]] = my_out[j]; rec[my_idx[j]].pad = 0; }
+                void* d_staging = nullptr; uint64_t n_u64 = 0;
+                if (!bu_hip_tsvq_exchange_pack(ctx, q, batch.data(), mine.data(), rec.data(), (uint32_t)batch.size(), &d_staging, &n_u64)) return false;
+                if (!comm->all_reduce_u64(comm->user, d_staging, n_u64)) return false;
+                if (!bu_hip_tsvq_exchange_unpack(ctx, q, batch.data(), mine.data(), cache.data() + base, (uint32_t)batch.size())) return false;
+                local.t_device += secs(td, now());
+            } else if (std::getenv("BU_TSVQ_SERIAL")) { // debug: one node per launch
                 for (size_t i = 0; i < batch.size(); i++)
                     if (!bu_hip_tsvq_split(ctx, q, &batch[i], 1, cache.data() + base + i)) return false;
             } else {

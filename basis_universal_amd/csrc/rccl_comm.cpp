@@ -1,0 +1,119 @@
+// rccl_comm.cpp -- libbasisu_rccl.so: bu_comm on RCCL (include/basisu_hip_comm.h). The reference has no communication layer at all
+// (single process, std::thread pool); this is the MI355X-native equivalent for the sharded frontend: in-place all-gather of
+// block-row slabs and in-place u64 sum all-reduce (exact: integer accumulators and disjoint per-rank results), enqueued on the
+// context's HIP stream behind the kernels that produced the data, over xGMI.
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/basisu_hip_comm.h"
+
+static_assert(BU_RCCL_UNIQUE_ID_BYTES == sizeof(ncclUniqueId), "unique id size");
+
+struct bu_rccl_comm {
+    ncclComm_t comm = nullptr;
+    bu_hip_context* ctx = nullptr;
+    uint32_t rank = 0, world = 1;
+};
+
+namespace {
+
+std::mutex g_lock;
+std::string g_error;
+
+int fail(const char* fmt, ...) {
+    char buf[512];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof(buf), fmt, ap); va_end(ap);
+    std::lock_guard<std::mutex> g(g_lock);
+    g_error = buf;
+    return 0;
+}
+
+int all_gather(void* user, void* d_buf, uint64_t bytes_per_rank) {
+    bu_rccl_comm* c = static_cast<bu_rccl_comm*>(user);
+    if (!c || !c->comm) return fail("all_gather: no communicator");
+    hipStream_t st = static_cast<hipStream_t>(bu_hip_get_stream(c->ctx));
+    if (hipSetDevice(bu_hip_context_device(c->ctx)) != hipSuccess) return fail("all_gather: hipSetDevice failed");
+    char* base = static_cast<char*>(d_buf);
+    const ncclResult_t r = ncclAllGather(base + (size_t)c->rank * bytes_per_rank, base, (size_t)bytes_per_rank, ncclUint8, c->comm, st);
+    if (r != ncclSuccess) return fail("ncclAllGather: %s", ncclGetErrorString(r));
+    if (hipStreamSynchronize(st) != hipSuccess) return fail("all_gather: stream synchronise failed");
+    return 1;
+}
+
+int all_reduce_u64(void* user, void* d_buf, uint64_t count) {
+    bu_rccl_comm* c = static_cast<bu_rccl_comm*>(user);
+    if (!c || !c->comm) return fail("all_reduce: no communicator");
+    hipStream_t st = static_cast<hipStream_t>(bu_hip_get_stream(c->ctx));
+    if (hipSetDevice(bu_hip_context_device(c->ctx)) != hipSuccess) return fail("all_reduce: hipSetDevice failed");
+    const ncclResult_t r = ncclAllReduce(d_buf, d_buf, (size_t)count, ncclUint64, ncclSum, c->comm, st);
+    if (r != ncclSuccess) return fail("ncclAllReduce: %s", ncclGetErrorString(r));
+    if (hipStreamSynchronize(st) != hipSuccess) return fail("all_reduce: stream synchronise failed");
+    return 1;
+}
+
+} // namespace
+
+extern "C" {
+
+const char* bu_rccl_last_error(void) { std::lock_guard<std::mutex> g(g_lock); static thread_local std::string copy; copy = g_error; return copy.c_str(); }
+
+int bu_rccl_get_unique_id(void* out_id) {
+    if (!out_id) return fail("get_unique_id: null pointer");
+    ncclUniqueId id;
+    const ncclResult_t r = ncclGetUniqueId(&id);
+    if (r != ncclSuccess) return fail("ncclGetUniqueId: %s", ncclGetErrorString(r));
+    std::memcpy(out_id, &id, sizeof(id));
+    return 1;
+}
+
+bu_rccl_comm* bu_rccl_comm_create(bu_hip_context* ctx, const void* id_bytes, uint32_t rank, uint32_t world) {
+    if (!ctx || !id_bytes || !world || rank >= world) { fail("comm_create: bad arguments"); return nullptr; }
+    if (hipSetDevice(bu_hip_context_device(ctx)) != hipSuccess) { fail("comm_create: hipSetDevice failed"); return nullptr; }
+    bu_rccl_comm* c = new (std::nothrow) bu_rccl_comm();
+    if (!c) return nullptr;
+    c->ctx = ctx; c->rank = rank; c->world = world;
+    ncclUniqueId id;
+    std::memcpy(&id, id_bytes, sizeof(id));
+    const ncclResult_t r = ncclCommInitRank(&c->comm, (int)world, id, (int)rank);
+    if (r != ncclSuccess) { fail("ncclCommInitRank: %s", ncclGetErrorString(r)); delete c; return nullptr; }
+    return c;
+}
+
+int bu_rccl_comm_init_all(bu_hip_context* const* ctxs, uint32_t n, bu_rccl_comm** out) {
+    if (!ctxs || !out || !n) return fail("comm_init_all: bad arguments");
+    std::vector<int> devs(n);
+    for (uint32_t i = 0; i < n; i++) { if (!ctxs[i]) return fail("comm_init_all: null context"); devs[i] = bu_hip_context_device(ctxs[i]); }
+    std::vector<ncclComm_t> comms(n, nullptr);
+    const ncclResult_t r = ncclCommInitAll(comms.data(), (int)n, devs.data());
+    if (r != ncclSuccess) return fail("ncclCommInitAll: %s", ncclGetErrorString(r));
+    for (uint32_t i = 0; i < n; i++) {
+        bu_rccl_comm* c = new (std::nothrow) bu_rccl_comm();
+        if (!c) { for (uint32_t j = 0; j < n; j++) { if (j < i) { delete out[j]; } (void)ncclCommDestroy(comms[j]); } return fail("comm_init_all: out of memory"); }
+        c->comm = comms[i]; c->ctx = ctxs[i]; c->rank = i; c->world = n;
+        out[i] = c;
+    }
+    return 1;
+}
+
+void bu_rccl_comm_destroy(bu_rccl_comm* c) {
+    if (!c) return;
+    if (c->comm) (void)ncclCommDestroy(c->comm);
+    delete c;
+}
+
+int bu_rccl_comm_fill(bu_rccl_comm* c, bu_comm* out) {
+    if (!c || !out) return fail("comm_fill: null pointer");
+    out->rank = c->rank; out->world = c->world; out->user = c;
+    out->all_gather = all_gather; out->all_reduce_u64 = all_reduce_u64;
+    return 1;
+}
+
+} // extern "C"

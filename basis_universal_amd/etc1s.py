@@ -119,6 +119,59 @@ class TorchComm:
         self.struct = _BuComm(self.rank, self.world, None, self._gather, self._reduce)
 
 
+_rccl_lib = None
+
+
+def load_rccl_library():
+    """libbasisu_rccl.so (include/basisu_hip_comm.h): bu_comm on RCCL, no Python in the collective path."""
+    global _rccl_lib
+    if _rccl_lib is None:
+        capi.load_library()   # libbasisu_hip.so first: the communicator library links against it
+        path = pathlib.Path(__file__).resolve().parent / "lib" / "libbasisu_rccl.so"
+        if not path.exists():
+            raise capi.HipError(f"{path} not found: build it (make -C basis_universal_amd/csrc)")
+        L = C.CDLL(str(path))
+        L.bu_rccl_get_unique_id.restype = C.c_int
+        L.bu_rccl_get_unique_id.argtypes = [_vp]
+        L.bu_rccl_comm_create.restype = _vp
+        L.bu_rccl_comm_create.argtypes = [_vp, _vp, C.c_uint32, C.c_uint32]
+        L.bu_rccl_comm_destroy.argtypes = [_vp]
+        L.bu_rccl_comm_fill.restype = C.c_int
+        L.bu_rccl_comm_fill.argtypes = [_vp, C.POINTER(_BuComm)]
+        L.bu_rccl_last_error.restype = C.c_char_p
+        _rccl_lib = L
+    return _rccl_lib
+
+
+class RcclComm:
+    """bu_comm on a NATIVE RCCL communicator (libbasisu_rccl.so): the collectives are enqueued by C++ on the context's HIP stream. Python only
+    hands the communicator's unique id from rank 0 to the other ranks once, through torch.distributed's object broadcast (any channel would do)."""
+
+    def __init__(self, ctx, group=None):
+        import torch.distributed as dist
+        self.L = load_rccl_library()
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        ident = C.create_string_buffer(128)
+        if self.rank == 0 and not self.L.bu_rccl_get_unique_id(ident):
+            raise capi.HipError("bu_rccl_get_unique_id: " + self.L.bu_rccl_last_error().decode())
+        box = [bytes(ident.raw)]
+        dist.broadcast_object_list(box, src=0, group=group)
+        self.h = self.L.bu_rccl_comm_create(ctx.h, box[0], self.rank, self.world)
+        if not self.h:
+            raise capi.HipError("bu_rccl_comm_create: " + self.L.bu_rccl_last_error().decode())
+        self.struct = _BuComm()
+        self.L.bu_rccl_comm_fill(self.h, C.byref(self.struct))
+        self.error = ""
+
+    def close(self):
+        if self.h:
+            self.L.bu_rccl_comm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+
 class Etc1sFrontend:
     def __init__(self, ctx, comm=None, video=False, fast_codebooks=False, fast_iterations=0):
         """comm: a TorchComm to shard the device stages over the ranks of its process group (every rank must drive an identical

@@ -100,8 +100,9 @@ def main():
 
     comm = None
     if sharded:
-        from basis_universal_amd.etc1s import TorchComm
-        comm = TorchComm()
+        # the native RCCL communicator (C++ collectives on the context's stream); BU_TORCH_COMM=1 goes through torch.distributed instead
+        from basis_universal_amd.etc1s import TorchComm, RcclComm
+        comm = TorchComm() if os.environ.get("BU_TORCH_COMM") else RcclComm(ctx)
 
     def step():
         fe = Etc1sFrontend(ctx, comm)

@@ -282,6 +282,14 @@ BU_HIP_API int  bu_hip_tsvq_read_members(bu_hip_context*, bu_tsvq*, uint32_t buf
  * every distinct vector without bringing the member lists to the host. h_spans: n_spans records. Stream-ordered after the splits. */
 typedef struct { uint32_t buf, start, count, value; } bu_tsvq_span;
 BU_HIP_API int  bu_hip_tsvq_scatter_spans(bu_hip_context*, bu_tsvq*, const bu_tsvq_span* h_spans, uint32_t n_spans, uint32_t* d_out);
+/* Multi-GPU (nodes of one round split by different ranks): the child member lists and result records of a batch laid end to end in a staging buffer the
+ * host application sum-reduces across ranks (all_reduce_u64 of bu_comm): entries of nodes a rank did not split are zero, so the sum is the union.
+ *   exchange_pack:   children of the nodes with h_mine[i] != 0 (from the member buffers) and their h_records into the staging buffer, zero elsewhere;
+ *                    returns the device pointer and its size in u64 words.   [host: all_reduce_u64(*d_staging, *n_u64)]
+ *   exchange_unpack: children of the nodes with h_mine[i] == 0 from the staging buffer into the member buffers, all records into h_records. Synchronises. */
+BU_HIP_API int  bu_hip_tsvq_exchange_pack(bu_hip_context*, bu_tsvq*, const bu_tsvq_node* h_nodes, const uint8_t* h_mine, const bu_tsvq_split* h_records, uint32_t n_nodes,
+                                          void** d_staging, uint64_t* n_u64);
+BU_HIP_API int  bu_hip_tsvq_exchange_unpack(bu_hip_context*, bu_tsvq*, const bu_tsvq_node* h_nodes, const uint8_t* h_mine, bu_tsvq_split* h_records, uint32_t n_nodes);
 BU_HIP_API void bu_hip_tsvq_destroy(bu_hip_context*, bu_tsvq*);
 
 #ifdef __cplusplus

@@ -22,7 +22,9 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, case, out_dir):
+def _worker(rank, world, port, case, out_dir, wide_min=0):
+    if wide_min:
+        os.environ["BU_TSVQ_WIDE_MIN"] = str(wide_min)   # large-node TSVQ path inside the rank-distributed splits
     import torch
     import torch.distributed as dist
     from basis_universal_amd import capi
@@ -47,13 +49,37 @@ def _worker(rank, world, port, case, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("case,world", [("synth256_l1", 2), ("synth256_l3_flat", 2), ("synth256_l4", 2), ("synth512_q128", 3)])
-def test_sharded_frontend_equals_single_gpu(tmp_path, case, world):
+@pytest.mark.parametrize("case,world,wide_min", [("synth256_l1", 2, 0), ("synth256_l3_flat", 2, 0), ("synth256_l4", 2, 0), ("synth512_q128", 3, 0), ("synth512_q128", 2, 512)])
+def test_sharded_frontend_equals_single_gpu(tmp_path, case, world, wide_min):
+    """per-block stages by slab, per-cluster stages by cluster share, and the TSVQ's node splits of every round shared out over the ranks (child
+    lists + result records merged by one exact sum all-reduce)"""
     import torch.multiprocessing as mp
     golden = json.loads(T.GOLDEN.read_text())[case]["digests"]
-    mp.spawn(_worker, args=(world, _free_port(), case, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), case, str(tmp_path), wide_min), nprocs=world, join=True)
     for r in range(world):
         res = json.loads((tmp_path / f"r{r}.json").read_text())
         assert res["error"] == ""
         assert res["calls"]["all_gather"] > 0 and res["calls"]["all_reduce_u64"] > 0
         assert res["digest"] == golden, (r, {k: v[:10] for k, v in res["digest"].items() if v != golden[k]})
+
+
+def test_native_rccl_communicator_single_rank(hip_ctx):
+    """include/basisu_hip_comm.h on the box's one GPU: a real RCCL communicator (world 1) behind bu_comm; the two collectives run on the
+    context's stream from C++ and leave a one-rank buffer as it is. (More ranks need more GPUs: RCCL refuses two ranks on one device.)"""
+    import ctypes as C
+    from basis_universal_amd import etc1s
+    L = etc1s.load_rccl_library()
+    ident = C.create_string_buffer(128)
+    assert L.bu_rccl_get_unique_id(ident) == 1, L.bu_rccl_last_error()
+    h = L.bu_rccl_comm_create(hip_ctx.h, ident.raw, 0, 1)
+    assert h, L.bu_rccl_last_error()
+    comm = etc1s._BuComm()
+    assert L.bu_rccl_comm_fill(h, C.byref(comm)) == 1 and comm.world == 1 and comm.rank == 0
+    data = np.arange(4096, dtype=np.uint64) * np.uint64(0x0101010101010101)
+    d = hip_ctx.upload(data)
+    assert comm.all_gather(comm.user, d, data.nbytes) == 1, L.bu_rccl_last_error()
+    assert comm.all_reduce_u64(comm.user, d, data.size) == 1, L.bu_rccl_last_error()
+    back = hip_ctx.download(d, data.shape, np.uint64)
+    assert (back == data).all()
+    hip_ctx.free(d)
+    L.bu_rccl_comm_destroy(h)

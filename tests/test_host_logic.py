@@ -1,6 +1,7 @@
 """CPU (-m "not gpu"): the C-ABI library loads and exports every declared symbol, fails loudly without a GPU, and the host-side
 logic above the C ABI (TSVQ, quality mapping) matches the real reference where oracle/_ref is available."""
 import ctypes as C
+import pathlib
 
 import numpy as np
 import pytest
@@ -109,3 +110,17 @@ def test_bench_contract_fields():
     for field in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
                   "config", "roofline", "cpu_baseline"):
         assert f'"{field}"' in txt, field
+
+
+def test_rccl_communicator_library_exports_its_header():
+    """include/basisu_hip_comm.h: every declared symbol is exported by libbasisu_rccl.so (loads without a GPU; no compute call here)"""
+    import re
+    import ctypes as C
+    from basis_universal_amd import capi
+    root = pathlib.Path(__file__).resolve().parent.parent
+    names = sorted(set(re.findall(r"BU_HIP_API[^;(]*?\b(bu_rccl_\w+)\s*\(", (root / "include" / "basisu_hip_comm.h").read_text())))
+    assert len(names) == 6
+    capi.load_library()
+    L = C.CDLL(str(root / "basis_universal_amd" / "lib" / "libbasisu_rccl.so"))
+    for n in names:
+        assert hasattr(L, n), n
