@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 #include <stdint.h>
+#include <algorithm>
 
 #include "bookkeeping_kernels.h"
 
@@ -40,9 +41,17 @@ __global__ void __launch_bounds__(256) k_iota_copy(const uint32_t* __restrict__ 
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i < n) { keys[i] = src[i]; vals[i] = i; }
 }
-__global__ void __launch_bounds__(256) k_count_clusters(const uint32_t* __restrict__ cluster, uint32_t n, uint32_t* __restrict__ sizes) {
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i < n) atomicAdd(&sizes[cluster[i]], 1u);
+// offsets[c] = first position of cluster c in the sorted key array (= number of keys below c), c = 0..k; sizes[c] = offsets[c + 1] - offsets[c]
+__global__ void __launch_bounds__(256) k_offsets_from_sorted(const uint32_t* __restrict__ keys_sorted, uint32_t n, uint32_t k, uint32_t* __restrict__ offsets) {
+    const uint32_t c = blockIdx.x * 256 + threadIdx.x;
+    if (c > k) return;
+    uint32_t lo = 0, hi = n;   // first i with keys_sorted[i] >= c
+    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (keys_sorted[mid] < c) lo = mid + 1; else hi = mid; }
+    offsets[c] = lo;
+}
+__global__ void __launch_bounds__(256) k_sizes_from_offsets(const uint32_t* __restrict__ offsets, uint32_t k, uint32_t* __restrict__ sizes) {
+    const uint32_t c = blockIdx.x * 256 + threadIdx.x;
+    if (c <= k) sizes[c] = c < k ? offsets[c + 1] - offsets[c] : 0u;
 }
 __global__ void __launch_bounds__(256) k_positions(const uint32_t* __restrict__ keys_sorted, const uint32_t* __restrict__ blocks_sorted, uint32_t n,
                                                    const uint32_t* __restrict__ offsets, uint32_t* __restrict__ pos) {
@@ -68,10 +77,14 @@ __global__ void __launch_bounds__(256) k_remap_clusters(uint32_t* __restrict__ c
 }
 
 __global__ void __launch_bounds__(256) k_count_differences(const uint32_t* __restrict__ a, const uint32_t* __restrict__ b, uint32_t n, uint32_t* __restrict__ out) {
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    const bool d = i < n && a[i] != b[i];
-    const uint32_t c = (uint32_t)__popcll(__ballot(d));
-    if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
+    __shared__ uint32_t s_c[4];
+    uint32_t c = 0;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) c += a[i] != b[i];
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) c += (uint32_t)__shfl_xor((int)c, o, 64);
+    if ((threadIdx.x & 63) == 0) s_c[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0 && (s_c[0] | s_c[1] | s_c[2] | s_c[3])) atomicAdd(out, s_c[0] + s_c[1] + s_c[2] + s_c[3]);
 }
 
 __global__ void __launch_bounds__(256) k_membership(const uint8_t* __restrict__ parent, const uint32_t* __restrict__ cluster, uint32_t n, uint32_t clusters,
@@ -141,17 +154,16 @@ hipError_t launch_rank_blocks(hipStream_t st, const uint32_t* d_cluster, uint32_
                               uint32_t* d_sorted_blocks, uint32_t* d_pos) {
     if (!n) return hipSuccess;
     const rank_temp t = carve_rank(d_ws, n, k, nullptr);
-    hipError_t e = hipMemsetAsync(d_sizes, 0, ((size_t)k + 1) * 4, st);
-    if (e != hipSuccess) return e;
-    const dim3 grid((n + 255) / 256), blk(256);
+    hipError_t e;
+    const dim3 grid((n + 255) / 256), blk(256), gk((k + 256) / 256);
     hipLaunchKernelGGL(k_iota_copy, grid, blk, 0, st, d_cluster, n, t.keys_in, t.vals_in);
-    hipLaunchKernelGGL(k_count_clusters, grid, blk, 0, st, d_cluster, n, d_sizes);
     int bits = 1;
     while (bits < 32 && (1u << bits) < k) bits++;
     size_t bytes = t.cub_bytes;
     if ((e = hipcub::DeviceRadixSort::SortPairs(t.cub, bytes, t.keys_in, t.keys_sorted, t.vals_in, d_sorted_blocks, (int)n, 0, bits, st)) != hipSuccess) return e;
-    bytes = t.cub_bytes;
-    if ((e = hipcub::DeviceScan::ExclusiveSum(t.cub, bytes, d_sizes, d_offsets, (int)k + 1, st)) != hipSuccess) return e;
+    // sizes and offsets from the sorted keys (a histogram by atomics on a few thousand skewed bins costs more than the sort)
+    hipLaunchKernelGGL(k_offsets_from_sorted, gk, blk, 0, st, t.keys_sorted, n, k, d_offsets);
+    hipLaunchKernelGGL(k_sizes_from_offsets, gk, blk, 0, st, d_offsets, k, d_sizes);
     if (d_pos) hipLaunchKernelGGL(k_positions, grid, blk, 0, st, t.keys_sorted, d_sorted_blocks, n, d_offsets, d_pos);
     return hipGetLastError();
 }
@@ -171,7 +183,7 @@ hipError_t launch_remap_clusters(hipStream_t st, uint32_t* d_cluster, uint32_t* 
 hipError_t launch_count_differences(hipStream_t st, const uint32_t* d_a, const uint32_t* d_b, uint32_t n, uint32_t* d_count) {
     hipError_t e = hipMemsetAsync(d_count, 0, 4, st);
     if (e != hipSuccess || !n) return e;
-    hipLaunchKernelGGL(k_count_differences, dim3((n + 255) / 256), dim3(256), 0, st, d_a, d_b, n, d_count);
+    hipLaunchKernelGGL(k_count_differences, dim3(std::min<uint32_t>((n + 255) / 256, 1024u)), dim3(256), 0, st, d_a, d_b, n, d_count);
     return hipGetLastError();
 }
 

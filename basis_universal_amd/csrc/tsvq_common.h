@@ -50,6 +50,53 @@ __device__ __noinline__ void principal_axis(const float (*cov)[16], float* out_a
     for (int i = 0; i < N; i++) out_axis[i] = axis[i];
 }
 
+// The same on ONE WAVE (all 64 lanes must call it): lane i < N owns row i of every matrix-vector product -- the same float products and the
+// same j = 0..N-1 double summation as the serial form -- the vector is kept replicated in every lane (gathered by shuffles), the order-dependent
+// float dot products are evaluated redundantly by every lane in the serial order. ~10x fewer dependent instructions than one thread doing all rows.
+template <int N>
+__device__ __forceinline__ void principal_axis_wave(const float (*cov)[16], float* out_axis) {
+    const int lane = threadIdx.x & 63;
+    const int row = lane < N ? lane : 0;
+    float crow[N];
+#pragma unroll
+    for (int j = 0; j < N; j++) crow[j] = cov[row][j];
+    float axis[N], prev[N];
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        const float t = (float)(uint32_t)i * (1.0f / (float)(N - 1 > 1 ? N - 1 : 1));
+        axis[i] = .75f + (1.25f - .75f) * t;
+        prev[i] = axis[i];
+    }
+    for (int iter = 0; iter < 8; iter++) {
+        double sum = 0;
+#pragma unroll
+        for (int j = 0; j < N; j++) { const float p = crow[j] * axis[j]; sum += p; }
+        double a = lane < N ? fabs(sum) : 0.0;
+        double max_sum = a;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) { const double t = __shfl_xor(max_sum, o, 64); max_sum = t > max_sum ? t : max_sum; }
+        float mine = (float)sum;
+        if (max_sum != 0.0) mine *= (float)(1.0 / max_sum);
+        float trial[N], delta[N];
+#pragma unroll
+        for (int i = 0; i < N; i++) trial[i] = __shfl(mine, i, 64);
+#pragma unroll
+        for (int i = 0; i < N; i++) delta[i] = prev[i] - trial[i];
+#pragma unroll
+        for (int i = 0; i < N; i++) { prev[i] = axis[i]; axis[i] = trial[i]; }
+        if (dot_seq<N>(delta, delta) < .0024f) break;
+    }
+    const float len = sqrtf(dot_seq<N>(axis, axis));
+    if (len != 0.0f) {
+        const float s = 1.0f / len;
+#pragma unroll
+        for (int i = 0; i < N; i++) axis[i] *= s;
+    }
+    if (lane == 0)
+#pragma unroll
+        for (int i = 0; i < N; i++) out_axis[i] = axis[i];
+}
+
 // The reference's double accumulators (ttsum, l_weight / r_weight) only ever add floats. When every addend is a non-negative
 // INTEGER-valued float below 2^53 and the total stays below 2^53 (always the case for selector vectors with real weights), each
 // double add is exact, so the running sum equals the integer sum and its order does not matter: the "exact" kernel variants

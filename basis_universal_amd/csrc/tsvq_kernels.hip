@@ -556,8 +556,9 @@ __global__ __launch_bounds__(TQ_THREADS) void k_tsvq_split(Src src, const uint64
             const float renorm = 1.0f / (float)nd.weight;
             for (int x = 0; x < N; x++) for (int y = x; y < N; y++) c.cov[x][y] *= renorm;
             for (int x = 0; x < N - 1; x++) for (int y = x + 1; y < N; y++) c.cov[y][x] = c.cov[x][y];
-            principal_axis<N>(c.cov, c.axis);
         }
+        __syncthreads();
+        if (tid < 64) principal_axis_wave<N>(c.cov, c.axis);
         __syncthreads();
     }
 
@@ -733,8 +734,9 @@ __global__ __launch_bounds__(TQ_THREADS) void k_tsvq_cov_axis(packed16_rows src,
         const float renorm = 1.0f / (float)nd.weight;
         for (int x = 0; x < N; x++) for (int y = x; y < N; y++) s_cov[x][y] *= renorm;
         for (int x = 0; x < N - 1; x++) for (int y = x + 1; y < N; y++) s_cov[y][x] = s_cov[x][y];
-        principal_axis<N>(s_cov, ctrl[blockIdx.x].axis);
     }
+    __syncthreads();
+    if (tid < 64) principal_axis_wave<N>(s_cov, ctrl[blockIdx.x].axis);
 }
 
 // -------------------------------------------------------------------------------------------------------------------

@@ -588,12 +588,25 @@ __global__ __launch_bounds__(64) void k_wide_walk(const uint32_t* __restrict__ k
 // The serial tail of a pass: what thread 0 of k_tsvq_split / k_tsvq_root does between passes.
 template <int MODE>
 __global__ __launch_bounds__(64) void k_wide_finish(const tsvq_wide_node* __restrict__ nodes, tsvq_wide_ctrl* __restrict__ ctrl, tsvq_root_out* __restrict__ root_out) {
-    if (threadIdx.x != 0) return;
     const uint32_t ni = blockIdx.x;
     tsvq_wide_ctrl& c = ctrl[ni];
     if (c.done) return;
     const tsvq_wide_node& nd = nodes[ni];
     constexpr int N = 16;
+    if (MODE == WM_COV) {    // compute_split_axis (enc.h:1802-1846): the whole wave
+        __shared__ float s_cov[16][16];
+        if (threadIdx.x == 0) {
+            int ch = 0;
+            for (int x = 0; x < N; x++) for (int y = x; y < N; y++) s_cov[x][y] = c.sums[ch++];
+            const float renorm = 1.0f / (float)nd.weight;
+            for (int x = 0; x < N; x++) for (int y = x; y < N; y++) s_cov[x][y] *= renorm;
+            for (int x = 0; x < N - 1; x++) for (int y = x + 1; y < N; y++) s_cov[y][x] = s_cov[x][y];
+        }
+        __syncthreads();
+        principal_axis_wave<N>(s_cov, c.axis);
+        return;
+    }
+    if (threadIdx.x != 0) return;
     if (MODE == WM_ROOT) {   // prepare_root (enc.h:1708-1735)
         if (c.ex_bad) { root_out->pad = 1; c.done = 2; return; }
         float o[N];
@@ -606,16 +619,6 @@ __global__ __launch_bounds__(64) void k_wide_finish(const tsvq_wide_node* __rest
         root_out->weight = c.l_w;
         root_out->pad = 0;
         c.done = 1;
-        return;
-    }
-    if (MODE == WM_COV) {    // compute_split_axis (enc.h:1802-1846)
-        float cov[16][16];
-        int ch = 0;
-        for (int x = 0; x < N; x++) for (int y = x; y < N; y++) cov[x][y] = c.sums[ch++];
-        const float renorm = 1.0f / (float)nd.weight;
-        for (int x = 0; x < N; x++) for (int y = x; y < N; y++) cov[x][y] *= renorm;
-        for (int x = 0; x < N - 1; x++) for (int y = x + 1; y < N; y++) cov[y][x] = cov[x][y];
-        principal_axis<N>(cov, c.axis);
         return;
     }
     if (c.ex_bad) { c.done = 2; return; }

@@ -63,23 +63,34 @@ def test_sharded_frontend_equals_single_gpu(tmp_path, case, world, wide_min):
         assert res["digest"] == golden, (r, {k: v[:10] for k, v in res["digest"].items() if v != golden[k]})
 
 
-def test_native_rccl_communicator_single_rank(hip_ctx):
-    """include/basisu_hip_comm.h on the box's one GPU: a real RCCL communicator (world 1) behind bu_comm; the two collectives run on the
-    context's stream from C++ and leave a one-rank buffer as it is. (More ranks need more GPUs: RCCL refuses two ranks on one device.)"""
+def _rccl_worker(rank, out_dir):
     import ctypes as C
-    from basis_universal_amd import etc1s
+    from basis_universal_amd import capi, etc1s
+    ctx = capi.Context(0)
     L = etc1s.load_rccl_library()
     ident = C.create_string_buffer(128)
     assert L.bu_rccl_get_unique_id(ident) == 1, L.bu_rccl_last_error()
-    h = L.bu_rccl_comm_create(hip_ctx.h, ident.raw, 0, 1)
+    h = L.bu_rccl_comm_create(ctx.h, ident.raw, 0, 1)
     assert h, L.bu_rccl_last_error()
     comm = etc1s._BuComm()
     assert L.bu_rccl_comm_fill(h, C.byref(comm)) == 1 and comm.world == 1 and comm.rank == 0
     data = np.arange(4096, dtype=np.uint64) * np.uint64(0x0101010101010101)
-    d = hip_ctx.upload(data)
+    d = ctx.upload(data)
     assert comm.all_gather(comm.user, d, data.nbytes) == 1, L.bu_rccl_last_error()
     assert comm.all_reduce_u64(comm.user, d, data.size) == 1, L.bu_rccl_last_error()
-    back = hip_ctx.download(d, data.shape, np.uint64)
+    back = ctx.download(d, data.shape, np.uint64)
     assert (back == data).all()
-    hip_ctx.free(d)
+    ctx.free(d)
     L.bu_rccl_comm_destroy(h)
+    ctx.close()
+    with open(os.path.join(out_dir, "rccl_ok"), "w") as f:
+        f.write("ok")
+
+
+def test_native_rccl_communicator_single_rank(tmp_path):
+    """include/basisu_hip_comm.h on the box's one GPU: a real RCCL communicator (world 1) behind bu_comm; the two collectives run on the
+    context's stream from C++ and leave a one-rank buffer as it is. (More ranks need more GPUs: RCCL refuses two ranks on one device.) In a
+    process of its own, like every rank of a real job: RCCL keeps helper threads and its own view of the HIP runtime alive in whoever creates it."""
+    import torch.multiprocessing as mp
+    mp.spawn(_rccl_worker, args=(str(tmp_path),), nprocs=1, join=True)
+    assert (tmp_path / "rccl_ok").read_text() == "ok"
