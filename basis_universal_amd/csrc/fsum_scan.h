@@ -101,6 +101,41 @@ FS_FN stretch compose(const stretch& f, const stretch& g) {
     return h;
 }
 
+// ---- the same two operations in the form the per-block kernels use: branch-light, no saturation. An addend whose |q| reaches 2^22 (it is within
+// a factor of four of the state, or above it) cannot be part of a valid 256-addend stretch anyway (offsets must stay within +-2^24); it raises
+// `bad` instead, and with |q| < 2^22 the int32 offsets of up to 512 addends cannot wrap. The caller turns a bad stretch into one that never applies.
+struct parts { int32_t SA; int32_t e; };   // a = SA * 2^(e - 150), SA sign-adjusted for the state's sign; e == 255: inf / nan
+FS_FN parts split(uint32_t a_bits, bool state_negative) {
+    const uint32_t ea = (a_bits >> 23) & 0xffu, ma = a_bits & 0x7fffffu;
+    const bool neg = ((a_bits >> 31) != 0) != state_negative;
+    const int32_t A = ea ? (int32_t)(ma | 0x800000u) : (int32_t)ma;
+    parts p; p.SA = neg ? -A : A; p.e = ea ? (int32_t)ea : 1;
+    if (ea == 0xffu) p.e = 255;
+    return p;
+}
+FS_FN addend decode_fast(parts p, int E, bool& bad) {
+    int d = E - p.e;
+    bad |= (d < 2) & (p.SA != 0);            // |a| >= u * 2^22 (d <= 1 with a 24-bit significand), or inf / nan (e = 255)
+    d = d < 1 ? 1 : (d > 25 ? 25 : d);       // beyond 25 the shift result and the rounding class no longer change
+    const int32_t rem = p.SA & ((1 << d) - 1), half = 1 << (d - 1);
+    addend r;
+    r.q = p.SA >> d;
+    r.c = rem > half ? 1u : (rem == half ? 2u : 0u);
+    return r;
+}
+FS_FN void push_fast(stretch& s, addend a) {
+#pragma unroll
+    for (int p = 0; p < 2; p++) {
+        const int32_t fl = s.d[p] + a.q;
+        const uint32_t odd = ((uint32_t)p + (uint32_t)fl) & 1u;
+        const int32_t t = fl + (int32_t)((a.c == 1u) | ((a.c == 2u) & odd));
+        s.d[p] = t;
+        s.lo[p] = fl < s.lo[p] ? fl : s.lo[p];
+        s.hi[p] = t > s.hi[p] ? t : s.hi[p];
+    }
+}
+FS_FN void poison(stretch& s) { s.d[0] = s.d[1] = D_SAT; s.lo[0] = s.lo[1] = -D_SAT; s.hi[0] = s.hi[1] = D_SAT; }   // never applies, whichever fields a consumer looks at
+
 // state helpers on float bits
 FS_FN bool state_ok(uint32_t s_bits) { const uint32_t e = (s_bits >> 23) & 0xffu; return e >= 1u && e <= 253u; } // normal, room above
 FS_FN int state_exp(uint32_t s_bits) { return (int)((s_bits >> 23) & 0xffu); }

@@ -383,14 +383,18 @@ __global__ __launch_bounds__(WB) void k_wide_stretches(const uint32_t* __restric
             int x = c & 15, y = 0;
             if (MODE == WM_COV) cov_xy(c, x, y);
             const uint8_t want = (uint8_t)(c >> 4);
+            bool bad0 = false, bad1 = false;
             for (int j = q * SL; j < q * SL + SL; j++) {
                 uint32_t bits;
                 if (MODE == WM_COV) bits = __float_as_uint(T.fa[x][j] * T.fb[y][j]);
                 else { if (T.sd[j] != want) continue; bits = __float_as_uint(T.fa[x][j]); }
                 if ((bits << 1) == 0) continue;
-                fsum::push(st0, fsum::decode(bits, E, neg));
-                if (two) fsum::push(st1, fsum::decode(bits, E + 1, neg));
+                const fsum::parts pr = fsum::split(bits, neg);
+                fsum::push_fast(st0, fsum::decode_fast(pr, E, bad0));
+                if (two) fsum::push_fast(st1, fsum::decode_fast(pr, E + 1, bad1));
             }
+            if (bad0) fsum::poison(st0);
+            if (bad1 || E + 1 > 253) fsum::poison(st1);
         }
         st_store(s_st[item][0], st0); st_store(s_st[item][1], st1);
     }

@@ -13,7 +13,11 @@ using namespace bu::fsum;
 static inline uint32_t f2u(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
 static inline float u2f(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
 
+static int g_fast = 0;
+
 extern "C" {
+
+void fsum_set_fast(int on) { g_fast = on; }
 
 // s <- RN(s + a[i]) for i = 0..n-1, from `start`
 float fsum_sequential(const float* a, uint64_t n, float start) {
@@ -40,7 +44,15 @@ float fsum_blocked(const float* a, uint64_t n, float start, uint32_t block, uint
         if (m.E > 0 && u2f(f2u(lof)) > lo) m.E = state_exp(f2u(std::nextafterf(lof, 0.0f))); // rounded up across a power of two
         for (int c = 0; c < 2; c++) {
             stretch s = identity();
-            for (uint64_t i = i0; i < i1; i++) push(s, decode(f2u(a[i]), m.E + c, m.neg));
+            if (g_fast && i1 - i0 <= 512) {   // the kernels' form: no saturation, a `bad` flag instead
+                bool bad = false;
+                for (uint64_t i = i0; i < i1; i++) {
+                    if ((f2u(a[i]) << 1) == 0) continue;
+                    push_fast(s, decode_fast(split(f2u(a[i]), m.neg), m.E + c, bad));
+                }
+                if (bad || m.E + c < 1 || m.E + c > 253) poison(s);
+            } else
+                for (uint64_t i = i0; i < i1; i++) push(s, decode(f2u(a[i]), m.E + c, m.neg));
             m.s[c] = s;
         }
         for (uint64_t i = i0; i < i1; i++) P += (double)a[i];
@@ -52,7 +64,9 @@ float fsum_blocked(const float* a, uint64_t n, float start, uint32_t block, uint
         const int c = state_exp(s) - m.E;
         const bool neg = (s >> 31) != 0;
         if (state_ok(s) && neg == m.neg && (c == 0 || c == 1)) {
-            if (applies(m.s[c], state_k(s))) { s = apply(m.s[c], s); if (stats) stats[0]++; continue; }
+            // g_fast == 2: the walk's rule for monotone chains (addends >= 0 on a positive sum): only the result offsets are looked at
+            const bool ok = g_fast == 2 ? (state_k(s) + m.s[c].d[state_k(s) & 1] < K_HI) : applies(m.s[c], state_k(s));
+            if (ok) { s = apply(m.s[c], s); if (stats) stats[0]++; continue; }
         } else if (stats) stats[2]++;
         const uint64_t i0 = b * block, i1 = i0 + block < n ? i0 + block : n;
         volatile float f = u2f(s);

@@ -8,11 +8,24 @@ from helpers import fsum_host, ptr, f32p, u64p
 
 
 def _both(a, start=0.0, block=256):
+    """the sequential sum, and the blocked form built BOTH ways (saturating reference form / the kernels' branch-light form): all three must agree"""
     a = np.ascontiguousarray(a, np.float32)
     L = fsum_host()
     stats = np.zeros(3, np.uint64)
     seq = np.float32(L.fsum_sequential(ptr(a, f32p), a.size, start))
+    L.fsum_set_fast(0)
     blk = np.float32(L.fsum_blocked(ptr(a, f32p), a.size, start, block, ptr(stats, u64p)))
+    L.fsum_set_fast(1)
+    stats2 = np.zeros(3, np.uint64)
+    fast = np.float32(L.fsum_blocked(ptr(a, f32p), a.size, start, block, ptr(stats2, u64p)))
+    if a.size and float(a.min()) >= 0.0 and start >= 0.0:   # monotone chain: the walk's two-integer rule must agree as well
+        L.fsum_set_fast(2)
+        mono = np.float32(L.fsum_blocked(ptr(a, f32p), a.size, start, block, None))
+        assert _same(blk, mono), ("monotone rule differs", blk, mono)
+    L.fsum_set_fast(0)
+    assert _same(blk, fast), ("kernel form differs", blk, fast)
+    if a.size >= 70000 and block <= 512:   # the kernels' form must not lose (many) stretches to its bad flag
+        assert stats2[0] >= 0.97 * stats[0], (stats, stats2)
     return seq, blk, stats
 
 
