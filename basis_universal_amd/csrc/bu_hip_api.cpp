@@ -935,6 +935,16 @@ int bu_hip_tsvq_split(bu_hip_context* ctx, bu_tsvq* q, const bu_tsvq_node* h_nod
         BU_TRY(ctx, bu::launch_tsvq_wide_split(ctx->stream, static_cast<const uint32_t*>(q->rows), q->w64, q->perm[0], q->perm[1], q->side, q->wide_packed, q->wide_nodes, n_wide, q->wide_ctrl,
                                                q->wide_ws, wide_blocks, static_cast<bu::tsvq_split_out*>(q->outs.p), wide_max_count < q->wide_cov_min));
     }
+    if (n_wide && std::getenv("BU_TSVQ_STATS")) {   // development aid: how the last pass's walks went, per wide node
+        std::vector<bu::tsvq_wide_ctrl> hc(n_wide);
+        if (hipMemcpyAsync(hc.data(), q->wide_ctrl, hc.size() * sizeof(bu::tsvq_wide_ctrl), hipMemcpyDeviceToHost, ctx->stream) == hipSuccess && hipStreamSynchronize(ctx->stream) == hipSuccess)
+            for (uint32_t i = 0; i < n_wide; i++) {
+                uint32_t ms = 0, mr = 0, ts = 0, tr = 0, ex = 0;
+                for (int c = 0; c < 32; c++) { ms = std::max<uint32_t>(ms, hc[i].stat_scans[c]); mr = std::max<uint32_t>(mr, hc[i].stat_raw[c]); ts += hc[i].stat_scans[c]; tr += hc[i].stat_raw[c]; ex += hc[i].exact[c]; }
+                std::fprintf(stderr, "[tsvq stats] wide node %u: count %u blocks %u iter %d | last pass, 32 side chains: scans max %u avg %.1f, raw blocks max %u avg %.1f, exact chains %u\n",
+                             i, h_nodes[order[n_narrow + i]].count, (h_nodes[order[n_narrow + i]].count + 255) / 256, hc[i].iter, ms, ts / 32.0, mr, tr / 32.0, ex);
+            }
+    }
     if (n_narrow) {
         prof_scope ps(ctx, q->packed ? "tsvq_split_packed16" : "tsvq_split_float6");
         BU_TRY(ctx, bu::launch_tsvq_split(ctx->stream, (int)q->dim, q->packed, exact, q->rows, q->w64, q->perm[0], q->perm[1], q->side,

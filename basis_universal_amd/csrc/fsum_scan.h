@@ -92,9 +92,9 @@ FS_FN stretch compose(const stretch& f, const stretch& g) {
     stretch h;
 #pragma unroll
     for (int p = 0; p < 2; p++) {
-        const int pg = (int)(((uint32_t)p + (uint32_t)f.d[p]) & 1u);
-        h.d[p] = sat_add(f.d[p], g.d[pg]);
-        const int32_t l = sat_add(f.d[p], g.lo[pg]), u = sat_add(f.d[p], g.hi[pg]);
+        const bool pg = (((uint32_t)p + (uint32_t)f.d[p]) & 1u) != 0;   // g's half for the parity f leaves (selects: no dynamic indexing of registers)
+        h.d[p] = sat_add(f.d[p], pg ? g.d[1] : g.d[0]);
+        const int32_t l = sat_add(f.d[p], pg ? g.lo[1] : g.lo[0]), u = sat_add(f.d[p], pg ? g.hi[1] : g.hi[0]);
         h.lo[p] = f.lo[p] < l ? f.lo[p] : l;
         h.hi[p] = f.hi[p] > u ? f.hi[p] : u;
     }
@@ -142,12 +142,12 @@ FS_FN int state_exp(uint32_t s_bits) { return (int)((s_bits >> 23) & 0xffu); }
 FS_FN int32_t state_k(uint32_t s_bits) { return (int32_t)((s_bits & 0x7fffffu) | 0x800000u); }
 // may the stretch be applied to this state? (every step stays inside the binade)
 FS_FN bool applies(const stretch& s, int32_t k) {
-    const int p = k & 1;
-    return k + s.lo[p] >= K_LO && k + s.hi[p] < K_HI;
+    const bool odd = (k & 1) != 0;   // selects: a dynamic index would send a register-resident stretch through scratch
+    return k + (odd ? s.lo[1] : s.lo[0]) >= K_LO && k + (odd ? s.hi[1] : s.hi[0]) < K_HI;
 }
 FS_FN uint32_t apply(const stretch& s, uint32_t s_bits) {
     const int32_t k = state_k(s_bits);
-    const int32_t K = k + s.d[k & 1];
+    const int32_t K = k + ((k & 1) ? s.d[1] : s.d[0]);
     return (s_bits & 0xff800000u) | ((uint32_t)K & 0x7fffffu);
 }
 

@@ -26,7 +26,12 @@ struct tsvq_wide_node { uint32_t buf, start, count, out_index, first_block, n_bl
 struct tsvq_wide_ctrl {   // device-side state of one node across the passes of its split
     float l_c[16], r_c[16], axis[16];
     float sums[TSVQ_WIDE_MAX_CHAINS];
-    uint8_t exact[TSVQ_WIDE_MAX_CHAINS];   // this pass's chain total stayed below 2^24 with integer addends: the running sum is exact, no walk needed
+    // this pass's chain total stayed below 2^24 with integer addends: the running sum is exact, no walk needed. (A dword per chain, not a
+    // byte: the chain index is wave-uniform, and hipcc 7.2 folds a uniform byte address into the base of the next scalar dword load, whose
+    // two low address bits the hardware then drops.)
+    uint32_t exact[TSVQ_WIDE_MAX_CHAINS];
+    uint32_t start_block[TSVQ_WIDE_MAX_CHAINS]; float start_sum[TSVQ_WIDE_MAX_CHAINS];   // where a chain's walk starts: everything before is exact (sum <= 2^24)
+    uint16_t stat_scans[TSVQ_WIDE_MAX_CHAINS], stat_raw[TSVQ_WIDE_MAX_CHAINS];   // of the LAST pass: wave scans and blocks added member by member, per chain (BU_TSVQ_STATS)
     uint64_t l_w, r_w;
     double dsum[2];
     uint32_t l_n, r_n;

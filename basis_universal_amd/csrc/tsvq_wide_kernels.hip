@@ -255,6 +255,7 @@ __global__ __launch_bounds__(256) void k_wide_scan(const tsvq_wide_node* __restr
             if (lane == 0) { ctrl[ni].exact[c] = exact ? 1 : 0; if (exact) ctrl[ni].sums[c] = (float)tot; }
             if (exact) return;
         } else if (lane == 0) ctrl[ni].exact[c] = 0;
+        uint32_t exact_blocks = 0; double exact_sum = 0.0;   // the leading blocks over which the (integer) running sum stays <= 2^24: no rounding there
         for (uint32_t b0 = 0; b0 < nd.n_blocks; b0 += 64) {
             const uint32_t b = b0 + (uint32_t)lane;
             const bool have = b < nd.n_blocks;
@@ -264,6 +265,11 @@ __global__ __launch_bounds__(256) void k_wide_scan(const tsvq_wide_node* __restr
 #pragma unroll
             for (int o = 1; o < 64; o <<= 1) { const double t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
             const double Ps = P + (incl - v);
+            if (MODE != WM_COV && exact_blocks == b0) {   // still inside the exact prefix at this chunk's start
+                const uint64_t inside = __ballot(have && P + incl <= 16777216.0);
+                const uint32_t cnt = (uint32_t)__popcll(inside);   // a prefix of the lanes: the sums are monotone
+                if (cnt) { exact_sum = P + __shfl(incl, (int)cnt - 1, 64); exact_blocks += cnt; }
+            }
             if (have) {
                 uint16_t ep;
                 if (ws.bzero[at]) ep = EP_ZERO;
@@ -282,6 +288,7 @@ __global__ __launch_bounds__(256) void k_wide_scan(const tsvq_wide_node* __restr
             }
             P += __shfl(incl, 63, 64);
         }
+        if (lane == 0) { ctrl[ni].start_block[c] = exact_blocks; ctrl[ni].start_sum[c] = (float)exact_sum; }
         return;
     }
     // totals of the integer accumulators and the left-count prefix (block order)
@@ -479,18 +486,20 @@ __global__ __launch_bounds__(64) void k_wide_walk(const uint32_t* __restrict__ k
     const float ox = nd.origin[cx], oy = nd.origin[cy];
     const bool chain_right = (c >> 4) != 0;
     uint32_t s = 0;          // +0.0f
-    walk_window cur, n1, n2;
 
     // this lane's block of the current window against the running sum s: 0 = identity (all addends zero / past the end),
     // 1 = its map for s's binade exists (returned in st), 2 = no map for this state
-    auto pick = [&](fsum::stretch& st) -> int {
+    auto pick = [&](const walk_window& cur, fsum::stretch& st) -> int {
         st = fsum::identity();
         if (cur.ep == EP_ZERO) return 0;
         const int cand = fsum::state_exp(s) - (int)(cur.ep & 0xffu);
         const bool usable = cur.ep != EP_NONE && fsum::state_ok(s) && (cand == 0 || (cand == 1 && !(cur.ep & EP_SINGLE))) && (((cur.ep >> 8) & 1u) == (s >> 31));
         if (!usable) return 2;
-        const int k = cand;
-        st.d[0] = cur.m[k][0]; st.d[1] = cur.m[k][1]; st.lo[0] = cur.m[k][2]; st.lo[1] = cur.m[k][3]; st.hi[0] = cur.m[k][4]; st.hi[1] = cur.m[k][5];
+        // selects, not cur.m[cand]: a dynamic index would put the windows into scratch
+        const bool up = cand != 0;
+        st.d[0] = up ? cur.m[1][0] : cur.m[0][0]; st.d[1] = up ? cur.m[1][1] : cur.m[0][1];
+        st.lo[0] = up ? cur.m[1][2] : cur.m[0][2]; st.lo[1] = up ? cur.m[1][3] : cur.m[0][3];
+        st.hi[0] = up ? cur.m[1][4] : cur.m[0][4]; st.hi[1] = up ? cur.m[1][5] : cur.m[0][5];
         return 1;
     };
     // the addends of block `blk` (of the node) that this lane stages: members blk * 256 + r * 64 + lane
@@ -515,15 +524,17 @@ __global__ __launch_bounds__(64) void k_wide_walk(const uint32_t* __restrict__ k
         }
     };
 
-    load_window(ws, nd.first_block, nd.n_blocks, 0, lane, c, cur);
-    load_window(ws, nd.first_block, nd.n_blocks, 64, lane, c, n1);
     int lbuf = 0;
-    for (uint32_t b0 = 0; b0 < nd.n_blocks; b0 += 64) {
-        load_window(ws, nd.first_block, nd.n_blocks, b0 + 128, lane, c, n2);
-        int start = 0;       // lanes below are done
+    uint32_t n_scans = 0, n_raw = 0;
+    // one window (64 blocks starting at b0) against the running sum
+    int first_start = 0;
+    auto process = [&](const walk_window& cur, uint32_t b0) {
+        int start = first_start;       // lanes below are done
+        first_start = 0;
         while (start < 64) {
             fsum::stretch st;
-            int kind = pick(st);
+            n_scans++;
+            int kind = pick(cur, st);
             if (lane < start) { kind = 0; st = fsum::identity(); }
             const int32_t k0 = fsum::state_k(s);
             const bool sok = fsum::state_ok(s);
@@ -572,10 +583,11 @@ __global__ __launch_bounds__(64) void k_wide_walk(const uint32_t* __restrict__ k
                 }
                 for (uint32_t i = full; i < cnt; i++) f = f + buf[i];
                 s = __float_as_uint(f);
+                n_raw++;
                 j++;
                 if (!more) break;
                 fsum::stretch t;
-                const int kd = pick(t);
+                const int kd = pick(cur, t);
                 const bool fits = kd == 0 || (kd == 1 && fsum::applies(t, fsum::state_k(s)));
                 if ((__ballot(fits) >> j) & 1ull) break;
 #pragma unroll
@@ -583,9 +595,33 @@ __global__ __launch_bounds__(64) void k_wide_walk(const uint32_t* __restrict__ k
             }
             start = j;
         }
-        cur = n1; n1 = n2;
+    };
+    // Four windows in flight: the maps of window w + 3 are requested before window w is walked, each buffer is only ever written by its own
+    // loads (no register copies between them), so a window's wait covers its own (oldest) loads only and ~3 windows' worth of work hides
+    // the trip to L2 / HBM.
+    // the leading blocks whose running sum is exact were summed by the scan: start behind them (window-aligned; their lanes are skipped)
+    const uint32_t skip = MONO ? min(ctrl[ni].start_block[c], nd.n_blocks) : 0u;
+    if (skip) s = __float_as_uint(ctrl[ni].start_sum[c]);
+    const uint32_t first_b0 = skip & ~63u;
+    first_start = (int)(skip - first_b0);
+    walk_window w0, w1, w2, w3;
+    load_window(ws, nd.first_block, nd.n_blocks, first_b0, lane, c, w0);
+    load_window(ws, nd.first_block, nd.n_blocks, first_b0 + 64, lane, c, w1);
+    load_window(ws, nd.first_block, nd.n_blocks, first_b0 + 128, lane, c, w2);
+    for (uint32_t b0 = first_b0; b0 < nd.n_blocks; b0 += 256) {
+        load_window(ws, nd.first_block, nd.n_blocks, b0 + 192, lane, c, w3);
+        process(w0, b0);
+        if (b0 + 64 >= nd.n_blocks) break;
+        load_window(ws, nd.first_block, nd.n_blocks, b0 + 256, lane, c, w0);
+        process(w1, b0 + 64);
+        if (b0 + 128 >= nd.n_blocks) break;
+        load_window(ws, nd.first_block, nd.n_blocks, b0 + 320, lane, c, w1);
+        process(w2, b0 + 128);
+        if (b0 + 192 >= nd.n_blocks) break;
+        load_window(ws, nd.first_block, nd.n_blocks, b0 + 384, lane, c, w2);
+        process(w3, b0 + 192);
     }
-    if (lane == 0) ctrl[ni].sums[c] = __uint_as_float(s);
+    if (lane == 0) { ctrl[ni].sums[c] = __uint_as_float(s); ctrl[ni].stat_scans[c] = (uint16_t)min(n_scans, 65535u); ctrl[ni].stat_raw[c] = (uint16_t)min(n_raw, 65535u); }
 }
 
 // ------------------------------------------------------------------------------------------------------------ k_wide_finish
