@@ -68,6 +68,19 @@ __device__ __forceinline__ void block_cvecs(cvec out[4], int br, int bg, int bb,
     out[3] = to_cvec<PERCEPTUAL>(clamp255(br + b), clamp255(bg + b), clamp255(bb + b));
 }
 
+// bc[s], s = 0..3, as selects on the components: a conditional expression on the whole struct makes clang copy from a selected POINTER,
+// which keeps the four colours in scratch memory instead of registers
+__device__ __forceinline__ cvec select_cvec(const cvec bc[4], uint32_t s) {
+    const int x0 = bc[0].x, x1 = bc[1].x, x2 = bc[2].x, x3 = bc[3].x, y0 = bc[0].y, y1 = bc[1].y, y2 = bc[2].y, y3 = bc[3].y;
+    const int z0 = bc[0].z, z1 = bc[1].z, z2 = bc[2].z, z3 = bc[3].z;
+    const bool odd = (s & 1u) != 0, up = (s & 2u) != 0;
+    cvec c;
+    c.x = up ? (odd ? x3 : x2) : (odd ? x1 : x0);
+    c.y = up ? (odd ? y3 : y2) : (odd ? y1 : y0);
+    c.z = up ? (odd ? z3 : z2) : (odd ? z1 : z0);
+    return c;
+}
+
 // min over the 4 selectors (error only)
 template <bool PERCEPTUAL>
 __device__ __forceinline__ uint32_t min_err4(const cvec& p, const cvec bc[4]) {

@@ -273,7 +273,7 @@ __global__ __launch_bounds__(256) void k_encode_etc1s_blocks_fast(const uint4* _
             for (int p = 0; p < 16; p++) {
                 const uint32_t s = (uint32_t)(luma2[p] >= m0) + (uint32_t)(luma2[p] >= m1) + (uint32_t)(luma2[p] >= m2);
                 // midpoints are non-decreasing, so the count equals the reference's walk (etc.cpp:1368-1376)
-                const cvec c = (s == 0) ? bc[0] : (s == 1) ? bc[1] : (s == 2) ? bc[2] : bc[3];
+                const cvec c = select_cvec(bc, s);
                 total += cdist<false>(pc[p], c);
             }
             uint32_t key = (total << 3) | (7u - table);
@@ -498,7 +498,7 @@ __global__ __launch_bounds__(CB_THREADS) void k_generate_endpoint_codebook(
                     const uint32_t sel = cluster_pixel_selector(enc_blocks, members, j);
 #pragma unroll
                     for (int t = 0; t < 8; t++) {
-                        const cvec c = sel == 0 ? bc[t][0] : (sel == 1 ? bc[t][1] : (sel == 2 ? bc[t][2] : bc[t][3]));
+                        const cvec c = select_cvec(bc[t], sel);
                         tot[t] += cdist<PERCEPTUAL>(p, c);
                     }
                 } else {
@@ -547,7 +547,7 @@ __global__ __launch_bounds__(CB_THREADS) void k_generate_endpoint_codebook(
             cvec bc[4];
             block_cvecs<PERCEPTUAL>(bc, scale5((int)r5), scale5((int)g5), scale5((int)b5), (int)inten);
             const uint32_t sel = cluster_pixel_selector(enc_blocks, members, j);
-            const cvec c = sel == 0 ? bc[0] : (sel == 1 ? bc[1] : (sel == 2 ? bc[2] : bc[3]));
+            const cvec c = select_cvec(bc, (uint32_t)sel);
             tot += cdist<PERCEPTUAL>(pixel_cvec<PERCEPTUAL>(cluster_pixel(pixel_words, members, j)), c);
         }
         tot = wave_sum_u64(tot);

@@ -110,6 +110,13 @@ struct exact_acc {
         lo += ti & 0xffffffffull; hi += ti >> 32;
         return true;
     }
+    // add(t) when `take`, nothing otherwise -- without a branch, so that two accumulators picked by a per-member flag stay in registers
+    __device__ __forceinline__ bool add_if(float t, bool take) {
+        const bool in_range = t < 9007199254740992.0f;
+        const uint64_t ti = (in_range && take) ? (uint64_t)t : 0ull;
+        lo += ti & 0xffffffffull; hi += ti >> 32;
+        return in_range || !take;
+    }
 };
 __device__ __forceinline__ bool exact_total(uint64_t lo, uint64_t hi, double* out) {
     const uint64_t h = hi + (lo >> 32);

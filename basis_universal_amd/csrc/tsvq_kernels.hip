@@ -347,7 +347,7 @@ __global__ __launch_bounds__(TQ_THREADS) void k_tsvq_split(Src src, const uint64
     const uint32_t* members = (nd.buf ? perm1 : perm0) + nd.start;
     uint32_t* child_members = (nd.buf ? perm0 : perm1) + nd.start;
     uint8_t* node_side = side + nd.start;
-    if (tid < 16) s_origin[tid] = nd.origin[tid];
+    if (tid < 16) s_origin[tid] = nodes[blockIdx.x].origin[tid];   // from memory: indexing the register copy by tid would put it in scratch
     __syncthreads();
 
     // One classification + accumulation pass. `mode` selects how a member picks its side; float chains 0..N-1 are the left sums,
@@ -401,7 +401,8 @@ __global__ __launch_bounds__(TQ_THREADS) void k_tsvq_split(Src src, const uint64
                 vsq = k == 0 ? v * v : vsq + v * v;   // dot_seq order
             }
             const float dvf = mode == TQ_MODE_PROJ ? w : w * vsq;
-            if (right) { bad |= !ex[1].add(dvf); rw += p.w; } else { bad |= !ex[0].add(dvf); lw += p.w; ln++; }
+            bad |= !ex[0].add_if(dvf, !right); bad |= !ex[1].add_if(dvf, right);
+            rw += right ? p.w : 0ull; lw += right ? 0ull : p.w; ln += right ? 0u : 1u;
         }
         // wave totals of the 32 chains -> LDS -> block totals
 #pragma unroll
@@ -492,7 +493,7 @@ __global__ __launch_bounds__(TQ_THREADS) void k_tsvq_split(Src src, const uint64
                 // l_weight / r_weight (projection and half passes) are doubles of the float weight; otherwise ttsum addends
                 const float dvf = (mode == TQ_MODE_PROJ || mode == TQ_MODE_HALF) ? w : w * dot_seq<N>(v, v);
                 if (EX) {
-                    if (right) bad |= !ex[1].add(dvf); else bad |= !ex[0].add(dvf);
+                    bad |= !ex[0].add_if(dvf, !right); bad |= !ex[1].add_if(dvf, right);
                 } else {
                     const double dv = (double)dvf;
                     d[0] = right ? 0.0 : dv;
@@ -706,7 +707,7 @@ __global__ __launch_bounds__(TQ_THREADS) void k_tsvq_cov_axis(packed16_rows src,
     const int tid = threadIdx.x;
     const tsvq_wide_node nd = nodes[blockIdx.x];
     const uint32_t* members = (nd.buf ? perm1 : perm0) + nd.start;
-    if (tid < 16) s_origin[tid] = nd.origin[tid];
+    if (tid < 16) s_origin[tid] = nodes[blockIdx.x].origin[tid];
     __syncthreads();
     constexpr int C = N * (N + 1) / 2;
     constexpr int CW = (C + 63) / 64;
