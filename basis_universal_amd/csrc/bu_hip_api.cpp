@@ -943,6 +943,13 @@ int bu_hip_tsvq_split(bu_hip_context* ctx, bu_tsvq* q, const bu_tsvq_node* h_nod
                 for (int c = 0; c < 32; c++) { ms = std::max<uint32_t>(ms, hc[i].stat_scans[c]); mr = std::max<uint32_t>(mr, hc[i].stat_raw[c]); ts += hc[i].stat_scans[c]; tr += hc[i].stat_raw[c]; ex += hc[i].exact[c]; }
                 std::fprintf(stderr, "[tsvq stats] wide node %u: count %u blocks %u iter %d | last pass, 32 side chains: scans max %u avg %.1f, raw blocks max %u avg %.1f, exact chains %u\n",
                              i, h_nodes[order[n_narrow + i]].count, (h_nodes[order[n_narrow + i]].count + 255) / 256, hc[i].iter, ms, ts / 32.0, mr, tr / 32.0, ex);
+                uint32_t cms = 0, cmr = 0, cts = 0, ctr = 0, diag_r = 0; int x = 0, y = 0;
+                for (int c = 0; c < 136; c++) {
+                    cms = std::max<uint32_t>(cms, hc[i].stat_cov_scans[c]); cmr = std::max<uint32_t>(cmr, hc[i].stat_cov_raw[c]); cts += hc[i].stat_cov_scans[c]; ctr += hc[i].stat_cov_raw[c];
+                    if (x == y) diag_r += hc[i].stat_cov_raw[c];
+                    if (++y == 16) { x++; y = x; }
+                }
+                if (cts) std::fprintf(stderr, "[tsvq stats]      covariance pass, 136 chains: scans max %u avg %.1f, raw blocks max %u avg %.1f (diagonal avg %.1f)\n", cms, cts / 136.0, cmr, ctr / 136.0, diag_r / 16.0);
             }
     }
     if (n_narrow) {

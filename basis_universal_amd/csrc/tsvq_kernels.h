@@ -31,7 +31,8 @@ struct tsvq_wide_ctrl {   // device-side state of one node across the passes of 
     // two low address bits the hardware then drops.)
     uint32_t exact[TSVQ_WIDE_MAX_CHAINS];
     uint32_t start_block[TSVQ_WIDE_MAX_CHAINS]; float start_sum[TSVQ_WIDE_MAX_CHAINS];   // where a chain's walk starts: everything before is exact (sum <= 2^24)
-    uint16_t stat_scans[TSVQ_WIDE_MAX_CHAINS], stat_raw[TSVQ_WIDE_MAX_CHAINS];   // of the LAST pass: wave scans and blocks added member by member, per chain (BU_TSVQ_STATS)
+    uint16_t stat_scans[TSVQ_WIDE_MAX_CHAINS], stat_raw[TSVQ_WIDE_MAX_CHAINS];   // of the LAST side pass: wave scans and blocks added member by member, per chain (BU_TSVQ_STATS)
+    uint16_t stat_cov_scans[TSVQ_WIDE_MAX_CHAINS], stat_cov_raw[TSVQ_WIDE_MAX_CHAINS];   // the same of the covariance pass
     uint64_t l_w, r_w;
     double dsum[2];
     uint32_t l_n, r_n;

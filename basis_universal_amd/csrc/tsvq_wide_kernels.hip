@@ -473,7 +473,7 @@ __global__ __launch_bounds__(64) void k_wide_walk(const uint32_t* __restrict__ k
                                                   tsvq_wide_ctrl* __restrict__ ctrl, void* ws_base, uint32_t tb) {
     constexpr int NCH = mode_traits<MODE>::NCH;
     constexpr bool MONO = MODE != WM_COV;
-    __shared__ __align__(16) float s_add[2][WB];
+    __shared__ __align__(16) float s_add[WB];
     const wide_ws ws = carve(ws_base, tb);
     const uint32_t ni = blockIdx.x / NCH;
     const int c = (int)(blockIdx.x % NCH);
@@ -502,14 +502,26 @@ __global__ __launch_bounds__(64) void k_wide_walk(const uint32_t* __restrict__ k
         st.hi[0] = up ? cur.m[1][4] : cur.m[0][4]; st.hi[1] = up ? cur.m[1][5] : cur.m[0][5];
         return 1;
     };
-    // the addends of block `blk` (of the node) that this lane stages: members blk * 256 + r * 64 + lane
-    auto fetch_block = [&](uint32_t blk, float (&a)[4]) {
+    // the members of block `blk` (of the node) that this lane stages: positions blk * 256 + r * 64 + lane. Loading and turning them into
+    // the chain's addends are separate steps so that the loads stay in flight until the addends are needed.
+    struct staged { uint32_t key[4]; uint64_t w[4]; uint8_t sd[4]; };
+    auto fetch_block = [&](uint32_t blk, staged& m) {
+        const uint32_t p0 = min(blk, nd.n_blocks - 1) * WB;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const uint32_t pos = min(p0 + (uint32_t)(r * 64 + lane), nd.count - 1);
+            if (MODE == WM_ROOT) { m.key[r] = keys[pos]; m.w[r] = w64[pos]; }
+            else { const uint2 v = pk[nd.start + pos]; m.key[r] = v.x; m.w[r] = v.y; }
+            m.sd[r] = (MODE == WM_PROJ || MODE == WM_DIST) ? side[nd.start + pos] : (uint8_t)0;
+        }
+    };
+    auto addends = [&](uint32_t blk, const staged& m, float (&a)[4]) {
         const uint32_t p0 = blk * WB;
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-            const uint32_t pos = p0 + (uint32_t)(r * 64 + lane);
-            uint32_t key; float wf; bool valid;
-            fetch_packed<MODE>(keys, w64, pk, nd.start, pos, nd.count, key, wf, valid);
+            const bool valid = p0 + (uint32_t)(r * 64 + lane) < nd.count;
+            const uint32_t key = m.key[r];
+            const float wf = MODE == WM_ROOT ? (float)m.w[r] : __uint_as_float((uint32_t)m.w[r]);
             float v;
             if (MODE == WM_COV) {
                 const float dx = (float)packed16_value(key, cx) - ox;
@@ -518,13 +530,12 @@ __global__ __launch_bounds__(64) void k_wide_walk(const uint32_t* __restrict__ k
                 v = dx * wdy;
             } else {
                 v = (float)packed16_value(key, cx) * wf;
-                if (MODE == WM_PROJ || MODE == WM_DIST) { const bool right = side[nd.start + min(pos, nd.count - 1)] != 0; v = right == chain_right ? v : 0.0f; }
+                if (MODE == WM_PROJ || MODE == WM_DIST) v = (m.sd[r] != 0) == chain_right ? v : 0.0f;
             }
-            a[r] = valid ? v : 0.0f;
+            a[r] = valid ? v : -0.0f;   // past the node's end: leaves every sum as it is
         }
     };
 
-    int lbuf = 0;
     uint32_t n_scans = 0, n_raw = 0;
     // one window (64 blocks starting at b0) against the running sum
     int first_start = 0;
@@ -562,37 +573,57 @@ __global__ __launch_bounds__(64) void k_wide_walk(const uint32_t* __restrict__ k
             }
             start = first_fail;
             if (first_fail == 64 || b0 + (uint32_t)first_fail >= nd.n_blocks) { start = 64; break; }
-            // ---- blocks added member by member, one after the other, until a block's own map applies to the sum again; the
-            //      next block's members are fetched while the current block is added
-            int j = first_fail;
-            float a[4], an[4];
-            fetch_block(b0 + (uint32_t)j, a);
-            for (;;) {
-                const bool more = j + 1 < 64 && b0 + (uint32_t)j + 1 < nd.n_blocks;
-                if (more) fetch_block(b0 + (uint32_t)j + 1, an);
-                float* buf = s_add[lbuf]; lbuf ^= 1;
-#pragma unroll
-                for (int r = 0; r < 4; r++) buf[r * 64 + lane] = a[r];
-                __syncthreads();
-                const uint32_t cnt = min((uint32_t)WB, nd.count - (b0 + (uint32_t)j) * WB);
-                float f = __uint_as_float(s);
-                const uint32_t full = cnt & ~3u;
-                for (uint32_t i = 0; i < full; i += 4) {
-                    const float4 v = *reinterpret_cast<const float4*>(&buf[i]);
-                    f = f + v.x; f = f + v.y; f = f + v.z; f = f + v.w;
-                }
-                for (uint32_t i = full; i < cnt; i++) f = f + buf[i];
-                s = __float_as_uint(f);
-                n_raw++;
-                j++;
-                if (!more) break;
+            // ---- a stretch of trouble (the sum changes binade inside blocks, or addends are as large as the sum): block by block, each
+            //      either through its own map or member by member, until six blocks in a row went through their maps. The members of
+            //      the next three blocks are always on their way (three rotating register sets), needed or not.
+            const int lim = (int)min(64u, nd.n_blocks - b0);
+            int j = first_fail, calm = 0;
+            staged a0, a1, a2;
+            // (unconditionally, past the end the last member again: with a fixed number of loads in flight the waits before a set's use
+            //  cover that set only)
+            fetch_block(b0 + (uint32_t)j, a0);
+            fetch_block(b0 + (uint32_t)j + 1, a1);
+            fetch_block(b0 + (uint32_t)j + 2, a2);
+            auto step = [&](staged& m) -> bool {   // block j against s; true = leave this mode
                 fsum::stretch t;
                 const int kd = pick(cur, t);
-                const bool fits = kd == 0 || (kd == 1 && fsum::applies(t, fsum::state_k(s)));
-                if ((__ballot(fits) >> j) & 1ull) break;
+                const int32_t k = fsum::state_k(s);
+                const bool fits = kd == 0 || (kd == 1 && fsum::applies(t, k));
+                const int32_t dsel = kd == 1 ? ((k & 1) ? t.d[1] : t.d[0]) : 0;
+                const int ju = __builtin_amdgcn_readfirstlane(j);
+                if ((__ballot(fits) >> ju) & 1ull) {
+                    const int32_t d = __builtin_amdgcn_readlane(dsel, ju);
+                    if (d != 0) s = (s & 0xff800000u) | ((uint32_t)(k + d) & 0x7fffffu);
+                    calm++;
+                } else {
+                    // the 256 addends go through LDS so that every lane can run the same chain on them; the reads are issued sixteen
+                    // (64 addends) ahead of the adds, which then follow each other at the VALU's own pace
+                    float a[4];
+                    addends(b0 + (uint32_t)j, m, a);
+                    __syncthreads();
 #pragma unroll
-                for (int r = 0; r < 4; r++) a[r] = an[r];
-            }
+                    for (int r = 0; r < 4; r++) s_add[r * 64 + lane] = a[r];
+                    __syncthreads();
+                    float f = __uint_as_float(s);
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        float4 v[16];
+#pragma unroll
+                        for (int q = 0; q < 16; q++) v[q] = *reinterpret_cast<const float4*>(&s_add[r * 64 + q * 4]);
+#pragma unroll
+                        for (int q = 0; q < 16; q++) { f = f + v[q].x; f = f + v[q].y; f = f + v[q].z; f = f + v[q].w; }
+                    }
+                    s = __float_as_uint(f);
+                    n_raw++;
+                    calm = 0;
+                }
+                j++;
+                const bool leave = j >= lim || calm >= 6;
+                fetch_block(b0 + (uint32_t)j + 2, m);
+                return leave;
+            };
+            for (;;) { if (step(a0)) break; if (step(a1)) break; if (step(a2)) break; }
+            if (j >= lim) j = 64;
             start = j;
         }
     };
@@ -621,7 +652,11 @@ __global__ __launch_bounds__(64) void k_wide_walk(const uint32_t* __restrict__ k
         load_window(ws, nd.first_block, nd.n_blocks, b0 + 384, lane, c, w2);
         process(w3, b0 + 192);
     }
-    if (lane == 0) { ctrl[ni].sums[c] = __uint_as_float(s); ctrl[ni].stat_scans[c] = (uint16_t)min(n_scans, 65535u); ctrl[ni].stat_raw[c] = (uint16_t)min(n_raw, 65535u); }
+    if (lane == 0) {
+        ctrl[ni].sums[c] = __uint_as_float(s);
+        if (MODE == WM_COV) { ctrl[ni].stat_cov_scans[c] = (uint16_t)min(n_scans, 65535u); ctrl[ni].stat_cov_raw[c] = (uint16_t)min(n_raw, 65535u); }
+        else { ctrl[ni].stat_scans[c] = (uint16_t)min(n_scans, 65535u); ctrl[ni].stat_raw[c] = (uint16_t)min(n_raw, 65535u); }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------ k_wide_finish
