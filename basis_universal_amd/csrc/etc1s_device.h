@@ -58,6 +58,31 @@ __device__ __forceinline__ uint32_t cdist(const cvec& a, const cvec& b) {
     }
 }
 
+// ---- block colours that need no clamping. The four colours of (base, table) are base + d * (1,1,1), d = -b, -a, +a, +b; when
+// 0 <= min(base) - b and max(base) + b <= 255 none of them is clamped, and in the basis of cvec a grey offset d moves x by 64 d
+// (14 + 45 + 5 = 64) and leaves y and z alone. The two chroma terms of the distance are then the same for all four colours (for
+// all eight tables, even), and because floor is monotone
+//     min_s [ (dx_s^2 >> 5) + C ] = (min_s dx_s^2 >> 5) + C :
+// one chroma term per pixel and candidate instead of four, bit for bit the same minimum. (Perceptual metric only.)
+__device__ __forceinline__ bool base_unclamped(int br, int bg, int bb, int table) {
+    const int b = k_inten_b[table];
+    return min(br, min(bg, bb)) - b >= 0 && max(br, max(bg, bb)) + b <= 255;
+}
+// perceptual only: the part of the distance the chroma differences contribute
+__device__ __forceinline__ uint32_t chroma_term(int dy, int dz) {
+    const uint32_t cr = (uint32_t)__mul24(dy, dy) >> 5;
+    const uint32_t cb = (uint32_t)__mul24(dz, dz) >> 5;
+    const uint32_t cr26 = (cr << 4) + (cr << 3) + (cr << 1);
+    const uint32_t cb3 = (cb << 1) + cb;
+    return (cr26 >> 7) + (cb3 >> 7);
+}
+// perceptual only: min over the four unclamped colours of the luma term, dx0 = pixel.x - base.x, a64 / b64 = 64 * the table's two deltas
+__device__ __forceinline__ uint32_t min_luma_term(int dx0, int a64, int b64) {
+    const int e0 = dx0 + b64, e1 = dx0 + a64, e2 = dx0 - a64, e3 = dx0 - b64;
+    const uint32_t q0 = (uint32_t)__mul24(e0, e0), q1 = (uint32_t)__mul24(e1, e1), q2 = (uint32_t)__mul24(e2, e2), q3 = (uint32_t)__mul24(e3, e3);
+    return min(min(q0, q1), min(q2, q3)) >> 5;
+}
+
 // The four block colours of (scaled base colour, intensity table), clamped per channel (etc.h:584-602).
 template <bool PERCEPTUAL>
 __device__ __forceinline__ void block_cvecs(cvec out[4], int br, int bg, int bb, int table) {

@@ -492,6 +492,11 @@ __global__ __launch_bounds__(CB_THREADS) void k_generate_endpoint_codebook(
             uint64_t tot[8];
 #pragma unroll
             for (int t = 0; t < 8; t++) tot[t] = 0;
+            uint32_t plain_mask = 0;   // workgroup-uniform
+#pragma unroll
+            for (int t = 0; t < 8; t++) plain_mask |= base_unclamped(scale5(tr), scale5(tg), scale5(tb), t) ? (1u << t) : 0u;
+            plain_mask &= enable_mask;
+            const cvec base_cv = to_cvec<PERCEPTUAL>(scale5(tr), scale5(tg), scale5(tb));
             for (uint32_t j = tid; j < n; j += CB_THREADS) {
                 const cvec p = pixel_cvec<PERCEPTUAL>(cluster_pixel(pixel_words, members, j));
                 if (FORCED) {
@@ -500,6 +505,16 @@ __global__ __launch_bounds__(CB_THREADS) void k_generate_endpoint_codebook(
                     for (int t = 0; t < 8; t++) {
                         const cvec c = select_cvec(bc[t], sel);
                         tot[t] += cdist<PERCEPTUAL>(p, c);
+                    }
+                } else if (PERCEPTUAL && plain_mask) {
+                    // tables whose four colours need no clamping share the pixel's chroma term (etc1s_device.h, base_unclamped)
+                    const uint32_t ch = chroma_term(p.y - base_cv.y, p.z - base_cv.z);
+                    const int dx0 = p.x - base_cv.x;
+#pragma unroll
+                    for (int t = 0; t < 8; t++) {
+                        if (!((enable_mask >> t) & 1u)) continue;
+                        if ((plain_mask >> t) & 1u) tot[t] += min_luma_term(dx0, k_inten_a[t] * 64, k_inten_b[t] * 64) + ch;
+                        else tot[t] += min_err4<PERCEPTUAL>(p, bc[t]);
                     }
                 } else {
 #pragma unroll
@@ -601,6 +616,8 @@ __global__ __launch_bounds__(256) void k_refine_endpoint_clusterization(
     const uint32_t* __restrict__ cluster_params, uint32_t n_clusters, uint32_t n_parents,
     const uint32_t* __restrict__ cand_offsets, const uint32_t* __restrict__ cand_indices, const uint8_t* __restrict__ block_parent,
     uint32_t* __restrict__ out_best) {
+    constexpr uint32_t RQ = 256;   // candidates per round
+    __shared__ uint2 s_q[4][2][RQ];   // per wave: {cluster parameters, position in the list | "is the block's current cluster" << 31}
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t block = blockIdx.x * 4u + (threadIdx.x >> 6);
     if (block >= n_blocks) return; // whole wave exits together
@@ -628,19 +645,57 @@ __global__ __launch_bounds__(256) void k_refine_endpoint_clusterization(
     // key = error << 32 | position in list; the skipped / out-of-range sentinel sorts last
     uint64_t best_key = ~0ull;
     uint32_t cur_err = 0xFFFFFFFFu;
-    for (uint32_t k = lane; k < total; k += 64) {
-        const uint32_t ci = n_parents ? cand_indices[first + k] : k;
-        const uint32_t prm = cluster_params[ci];
-        const uint32_t inten = (prm >> 24) & 255u;
-        if (inten > cur_inten) continue; // frontend.cpp:1811-1815
-        cvec bc[4];
-        block_cvecs<PERCEPTUAL>(bc, scale5((int)(prm & 255u)), scale5((int)((prm >> 8) & 255u)), scale5((int)((prm >> 16) & 255u)), (int)inten);
-        uint32_t tot = 0;
+    // The list is taken RQ candidates at a time. Each round first sorts its admissible candidates into two queues in LDS -- those whose
+    // four colours need no clamping and the others -- so that the lanes are full in both sweeps (the intensity filter of :1811-1815
+    // otherwise leaves holes) and the unclamped ones take the short form of the distance (etc1s_device.h, base_unclamped). The position
+    // in the list travels with the candidate: the winner does not depend on the order of evaluation.
+    uint2 (*q)[RQ] = s_q[threadIdx.x >> 6];
+    for (uint32_t base = 0; base < total; base += RQ) {
+        uint32_t n0 = 0, n1 = 0;
 #pragma unroll
-        for (int p = 0; p < 16; p++) tot += min_err4<PERCEPTUAL>(pc[p], bc);
-        const uint64_t key = ((uint64_t)tot << 32) | k;
-        best_key = min(best_key, key);
-        if (ci == cur) cur_err = tot;
+        for (int i = 0; i < (int)(RQ / 64); i++) {
+            const uint32_t k = base + (uint32_t)i * 64u + lane;
+            bool take = k < total;
+            uint32_t prm = 0, ci = 0;
+            if (take) {
+                ci = n_parents ? cand_indices[first + k] : k;
+                prm = cluster_params[ci];
+                take = ((prm >> 24) & 255u) <= cur_inten; // frontend.cpp:1811-1815
+            }
+            const bool plain = PERCEPTUAL && base_unclamped(scale5((int)(prm & 255u)), scale5((int)((prm >> 8) & 255u)), scale5((int)((prm >> 16) & 255u)), (int)((prm >> 24) & 7u));
+            const uint64_t m0 = __ballot(take && plain), m1 = __ballot(take && !plain);
+            const uint32_t r0 = __builtin_amdgcn_mbcnt_hi((uint32_t)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m0, 0u));
+            const uint32_t r1 = __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, 0u));
+            const uint2 e = make_uint2(prm, k | (ci == cur ? 0x80000000u : 0u));
+            if (take && plain) q[0][n0 + r0] = e;
+            if (take && !plain) q[1][n1 + r1] = e;
+            n0 += (uint32_t)__popcll(m0); n1 += (uint32_t)__popcll(m1);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (uint32_t j = lane; j < n0; j += 64) {   // unclamped: one chroma term per pixel, the luma term's minimum over the four offsets
+            const uint2 e = q[0][j];
+            const int inten = (int)((e.x >> 24) & 7u);
+            const cvec bcv = to_cvec<true>(scale5((int)(e.x & 255u)), scale5((int)((e.x >> 8) & 255u)), scale5((int)((e.x >> 16) & 255u)));
+            const int a64 = k_inten_a[inten] * 64, b64 = k_inten_b[inten] * 64;
+            uint32_t tot = 0;
+#pragma unroll
+            for (int p = 0; p < 16; p++) tot += min_luma_term(pc[p].x - bcv.x, a64, b64) + chroma_term(pc[p].y - bcv.y, pc[p].z - bcv.z);
+            best_key = min(best_key, ((uint64_t)tot << 32) | (e.y & 0x7fffffffu));
+            if (e.y >> 31) cur_err = tot;
+        }
+        for (uint32_t j = lane; j < n1; j += 64) {
+            const uint2 e = q[1][j];
+            cvec bc[4];
+            block_cvecs<PERCEPTUAL>(bc, scale5((int)(e.x & 255u)), scale5((int)((e.x >> 8) & 255u)), scale5((int)((e.x >> 16) & 255u)), (int)((e.x >> 24) & 7u));
+            uint32_t tot = 0;
+#pragma unroll
+            for (int p = 0; p < 16; p++) tot += min_err4<PERCEPTUAL>(pc[p], bc);
+            best_key = min(best_key, ((uint64_t)tot << 32) | (e.y & 0x7fffffffu));
+            if (e.y >> 31) cur_err = tot;
+        }
+        __builtin_amdgcn_wave_barrier();
     }
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) {
