@@ -211,6 +211,139 @@ __global__ __launch_bounds__(256) void k_encode_etc1s_blocks(const uint4* __rest
     }
 }
 
+// The same for the perceptual metric with the lanes turned by ninety degrees: the 8 lanes of a block each own TWO PIXELS and
+// walk all the enabled tables. A trial colour whose table needs no clamping then costs a lane one chroma term per pixel
+// (shared by all such tables) and one luma minimum per pixel and table (etc1s_device.h, base_unclamped) instead of four full
+// distances; clamped tables take the four-distance form as before. The per-table totals of the 8 lanes meet in a three-step
+// exchange that leaves lane l with the complete total of one table, and from there on the reduction is the one above.
+template <int QUALITY>
+__global__ __launch_bounds__(256) void k_encode_etc1s_blocks_by_pixel(const uint4* __restrict__ pixel_blocks, uint32_t n_blocks, uint2* __restrict__ out_blocks) {
+    __shared__ uint32_t s_bloom[32][32];
+
+    const uint32_t tid = threadIdx.x;
+    const uint32_t sub = tid & 7u;        // pixels 2 sub, 2 sub + 1
+    const uint32_t slot = tid >> 3;
+    const uint32_t block_raw = blockIdx.x * 32u + slot;
+    const bool in_range = block_raw < n_blocks;
+    const uint32_t block = in_range ? block_raw : (n_blocks - 1);
+#pragma unroll
+    for (int i = 0; i < 4; i++) s_bloom[slot][sub * 4 + i] = 0;
+
+    // etc1_optimizer::init (etc.cpp:998-1070): every lane over all 16 pixels (the float sums must run in pixel order)
+    float sum_r = 0.0f, sum_g = 0.0f, sum_b = 0.0f;
+    int mn_r = 255, mn_g = 255, mn_b = 255, mx_r = 0, mx_g = 0, mx_b = 0;
+    {
+        const uint4* src = pixel_blocks + (size_t)block * 4;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint4 v = src[i];
+            const uint32_t w4[4] = { v.x, v.y, v.z, v.w };
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int r = w4[k] & 255, g = (w4[k] >> 8) & 255, b = (w4[k] >> 16) & 255;
+                mn_r = min(mn_r, r); mn_g = min(mn_g, g); mn_b = min(mn_b, b);
+                mx_r = max(mx_r, r); mx_g = max(mx_g, g); mx_b = max(mx_b, b);
+                sum_r += (float)r; sum_g += (float)g; sum_b += (float)b;
+            }
+        }
+    }
+    const uint2 mine = reinterpret_cast<const uint2*>(pixel_blocks + (size_t)block * 4)[sub];
+    const cvec pc0 = pixel_cvec<true>(mine.x), pc1 = pixel_cvec<true>(mine.y);
+    const float avg_r = sum_r / 16.0f, avg_g = sum_g / 16.0f, avg_b = sum_b / 16.0f;
+    const int spread = max(max(mx_r - mn_r, mx_g - mn_g), mx_b - mn_b);
+    const uint32_t enable_mask = (QUALITY > BU_Q_MEDIUM) ? 0xFFu : (uint32_t)c_inten_enable_by_spread[spread]; // etc.cpp:1135-1140
+    // the table this lane ends up holding the total of (see the exchange below)
+    const uint32_t my_table = ((sub & 1u) << 2) | (sub & 2u) | ((sub >> 2) & 1u);
+
+    uint32_t best_err = 0xFFFFFFFFu; // every real total is < 2^28
+    int best_r = 0, best_g = 0, best_b = 0, best_inten = 0;
+    bool done = false;
+
+    __syncthreads(); // filters cleared
+
+    const int perms = (int)perms_for_quality(QUALITY);
+    for (int i = -1; i < perms; i++) {
+        if (__all(done)) break;
+        bool active = !done;
+        int tr = 0, tg = 0, tb = 0;
+        if (i < 0) {
+            tr = avg_to_color5(avg_r); tg = avg_to_color5(avg_g); tb = avg_to_color5(avg_b);
+        } else if (active) {
+            active = cluster_fit_trial(c_cluster_fit_order[i], best_r, best_g, best_b, best_inten, avg_r, avg_g, avg_b, tr, tg, tb);
+        }
+        if (active) active = bloom_test_and_set(&s_bloom[slot][0], tr, tg, tb);   // the 8 lanes read before any writes, and write the same
+        // evaluate_solution_slow (etc.cpp:1104-1278): this lane's two pixels against every enabled table
+        const int br = scale5(tr), bg = scale5(tg), bb = scale5(tb);
+        const cvec base_cv = to_cvec<true>(br, bg, bb);
+        const uint32_t todo = active ? enable_mask : 0u;
+        const uint32_t ch0 = chroma_term(pc0.y - base_cv.y, pc0.z - base_cv.z), ch1 = chroma_term(pc1.y - base_cv.y, pc1.z - base_cv.z);
+        const int dx0 = pc0.x - base_cv.x, dx1 = pc1.x - base_cv.x;
+        uint32_t tot[8];
+#pragma unroll
+        for (int t = 0; t < 8; t++) {
+            tot[t] = 0;
+            if (!((todo >> t) & 1u)) continue;
+            if (base_unclamped(br, bg, bb, t)) {
+                tot[t] = min_luma_term(dx0, k_inten_a[t] * 64, k_inten_b[t] * 64) + ch0 + min_luma_term(dx1, k_inten_a[t] * 64, k_inten_b[t] * 64) + ch1;
+            } else {
+                cvec bc[4];
+                block_cvecs<true>(bc, br, bg, bb, t);
+                tot[t] = min_err4<true>(pc0, bc) + min_err4<true>(pc1, bc);
+            }
+        }
+        // exchange: after the step with partner distance d the lane keeps the half of its tables selected by its bit d
+        uint32_t k4[4], k2[2], k1;
+        {
+            const bool up = (sub & 1u) != 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t give = up ? tot[k] : tot[4 + k];
+                k4[k] = (up ? tot[4 + k] : tot[k]) + (uint32_t)__shfl_xor((int)give, 1, 8);
+            }
+        }
+        {
+            const bool up = (sub & 2u) != 0;
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                const uint32_t give = up ? k4[k] : k4[2 + k];
+                k2[k] = (up ? k4[2 + k] : k4[k]) + (uint32_t)__shfl_xor((int)give, 2, 8);
+            }
+        }
+        {
+            const bool up = (sub & 4u) != 0;
+            const uint32_t give = up ? k2[0] : k2[1];
+            k1 = (up ? k2[1] : k2[0]) + (uint32_t)__shfl_xor((int)give, 4, 8);
+        }
+        if (active) {
+            const uint32_t total = ((enable_mask >> my_table) & 1u) ? k1 : 0x0FFFFFFFu;
+            uint32_t key = (total << 3) | my_table;
+            key = min(key, (uint32_t)__shfl_xor((int)key, 1, 8));
+            key = min(key, (uint32_t)__shfl_xor((int)key, 2, 8));
+            key = min(key, (uint32_t)__shfl_xor((int)key, 4, 8));
+            const uint32_t trial_err = key >> 3;
+            if (trial_err < best_err) {
+                best_err = trial_err; best_inten = (int)(key & 7u);
+                best_r = tr; best_g = tg; best_b = tb;
+            }
+        }
+        if (best_err == 0) done = true; // etc.cpp:955-956, 993-994
+    }
+
+    // Selectors of the winning (colour, table): first-min over s (etc.cpp:1188-1219), two pixels per lane
+    cvec bc[4];
+    block_cvecs<true>(bc, scale5(best_r), scale5(best_g), scale5(best_b), best_inten);
+    const uint32_t p0 = sub * 2u, p1 = p0 + 1u;
+    uint32_t bits = selector_bits(p0 & 3u, p0 >> 2, best_sel4<true>(pc0, bc)) | selector_bits(p1 & 3u, p1 >> 2, best_sel4<true>(pc1, bc));
+    bits |= (uint32_t)__shfl_xor((int)bits, 1, 8);
+    bits |= (uint32_t)__shfl_xor((int)bits, 2, 8);
+    bits |= (uint32_t)__shfl_xor((int)bits, 4, 8);
+    if (sub == 0 && in_range) {
+        const uint64_t v = etc1s_header_bits((uint32_t)best_r, (uint32_t)best_g, (uint32_t)best_b, (uint32_t)best_inten) | bits;
+        const uint64_t m = bswap64(v);
+        out_blocks[block] = make_uint2((uint32_t)m, (uint32_t)(m >> 32));
+    }
+}
+
 // Level-0 variant: evaluate_solution_fast (etc.cpp:1280-1506). Linear metric is forced (:1313); a pixel's selector is the
 // number of block-colour luma midpoints at or below twice its luma; tables are scanned 7..0 with strict <, so on equal error
 // the HIGHEST table wins -> reduction key uses (7 - table).
@@ -928,9 +1061,9 @@ hipError_t launch_encode_etc1s_blocks(hipStream_t st, const void* d_pixel_blocks
     if (quality == BU_Q_FAST) {
         hipLaunchKernelGGL(k_encode_etc1s_blocks_fast<false>, grid, blk, 0, st, in, n_blocks, out);
     } else if (perceptual) {
-        if (quality == BU_Q_MEDIUM) hipLaunchKernelGGL((k_encode_etc1s_blocks<true, BU_Q_MEDIUM>), grid, blk, 0, st, in, n_blocks, out);
-        else if (quality == BU_Q_SLOW) hipLaunchKernelGGL((k_encode_etc1s_blocks<true, BU_Q_SLOW>), grid, blk, 0, st, in, n_blocks, out);
-        else hipLaunchKernelGGL((k_encode_etc1s_blocks<true, BU_Q_UBER>), grid, blk, 0, st, in, n_blocks, out);
+        if (quality == BU_Q_MEDIUM) hipLaunchKernelGGL((k_encode_etc1s_blocks_by_pixel<BU_Q_MEDIUM>), grid, blk, 0, st, in, n_blocks, out);
+        else if (quality == BU_Q_SLOW) hipLaunchKernelGGL((k_encode_etc1s_blocks_by_pixel<BU_Q_SLOW>), grid, blk, 0, st, in, n_blocks, out);
+        else hipLaunchKernelGGL((k_encode_etc1s_blocks_by_pixel<BU_Q_UBER>), grid, blk, 0, st, in, n_blocks, out);
     } else {
         if (quality == BU_Q_MEDIUM) hipLaunchKernelGGL((k_encode_etc1s_blocks<false, BU_Q_MEDIUM>), grid, blk, 0, st, in, n_blocks, out);
         else if (quality == BU_Q_SLOW) hipLaunchKernelGGL((k_encode_etc1s_blocks<false, BU_Q_SLOW>), grid, blk, 0, st, in, n_blocks, out);
