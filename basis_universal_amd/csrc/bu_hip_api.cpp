@@ -54,6 +54,9 @@ struct bu_hip_context {
     int device = 0;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
+    // a second stream for work that is independent of what the main stream is doing (the one-workgroup TSVQ splits of a round next to
+    // its many-workgroup ones); joined back through the two events before anything reads the results
+    hipStream_t side_stream = nullptr; hipEvent_t side_fork = nullptr, side_join = nullptr;
     const void* d_pixel_blocks = nullptr; // resident tiles (a1): 64 B per block
     size_t total_blocks = 0;
     arena pixel_arena;                    // owns the tiles when they were uploaded through bu_hip_set_pixel_blocks
@@ -245,6 +248,9 @@ void bu_hip_destroy_context(bu_hip_context* ctx) {
     for (auto& b : ctx->pool_free) (void)hipFree(b.p);
     for (auto& b : ctx->pool_live) (void)hipFree(b.p);  // leaked by the caller; the context owns all device memory it handed out
     if (ctx->stage) (void)hipHostFree(ctx->stage);
+    if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
+    if (ctx->side_fork) (void)hipEventDestroy(ctx->side_fork);
+    if (ctx->side_join) (void)hipEventDestroy(ctx->side_join);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
@@ -930,6 +936,20 @@ int bu_hip_tsvq_split(bu_hip_context* ctx, bu_tsvq* q, const bu_tsvq_node* h_nod
     if (n_narrow) BU_TRY(ctx, hipMemcpyAsync(q->nodes.p, q->pinned, in_bytes, hipMemcpyHostToDevice, ctx->stream));
     if (n_wide) BU_TRY(ctx, hipMemcpyAsync(q->wide_nodes, static_cast<char*>(q->pinned) + wide_at, wide_bytes, hipMemcpyHostToDevice, ctx->stream));
     const bool exact = q->packed && !q->force_chained;
+    // The two kinds of node of a round do not touch each other's data: when both are present the one-workgroup kernel runs on the side
+    // stream, under the many small launches of the wide path. (Not while kernels are being timed one by one.)
+    bool narrow_on_side = n_wide && n_narrow && !ctx->profiling && !std::getenv("BU_TSVQ_SERIAL");
+    if (narrow_on_side && !ctx->side_stream) {
+        if (hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ctx->side_fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&ctx->side_join, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); narrow_on_side = false; }
+    }
+    if (narrow_on_side) {
+        BU_TRY(ctx, hipEventRecord(ctx->side_fork, ctx->stream));
+        BU_TRY(ctx, hipStreamWaitEvent(ctx->side_stream, ctx->side_fork, 0));
+        BU_TRY(ctx, bu::launch_tsvq_split(ctx->side_stream, (int)q->dim, q->packed, exact, q->rows, q->w64, q->perm[0], q->perm[1], q->side,
+                                          static_cast<const bu::tsvq_node_in*>(q->nodes.p), n_narrow, static_cast<bu::tsvq_split_out*>(q->outs.p)));
+        BU_TRY(ctx, hipEventRecord(ctx->side_join, ctx->side_stream));
+    }
     if (n_wide) {
         prof_scope ps(ctx, "tsvq_split_packed16_wide");
         BU_TRY(ctx, bu::launch_tsvq_wide_split(ctx->stream, static_cast<const uint32_t*>(q->rows), q->w64, q->perm[0], q->perm[1], q->side, q->wide_packed, q->wide_nodes, n_wide, q->wide_ctrl,
@@ -952,7 +972,8 @@ int bu_hip_tsvq_split(bu_hip_context* ctx, bu_tsvq* q, const bu_tsvq_node* h_nod
                 if (cts) std::fprintf(stderr, "[tsvq stats]      covariance pass, 136 chains: scans max %u avg %.1f, raw blocks max %u avg %.1f (diagonal avg %.1f)\n", cms, cts / 136.0, cmr, ctr / 136.0, diag_r / 16.0);
             }
     }
-    if (n_narrow) {
+    if (narrow_on_side) BU_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->side_join, 0));
+    else if (n_narrow) {
         prof_scope ps(ctx, q->packed ? "tsvq_split_packed16" : "tsvq_split_float6");
         BU_TRY(ctx, bu::launch_tsvq_split(ctx->stream, (int)q->dim, q->packed, exact, q->rows, q->w64, q->perm[0], q->perm[1], q->side,
                                           static_cast<const bu::tsvq_node_in*>(q->nodes.p), n_narrow, static_cast<bu::tsvq_split_out*>(q->outs.p)));
