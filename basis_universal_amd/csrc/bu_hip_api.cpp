@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstdarg>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -900,6 +901,8 @@ int bu_hip_tsvq_split(bu_hip_context* ctx, bu_tsvq* q, const bu_tsvq_node* h_nod
     if (!ctx || !q) return 0;
     if (!n_nodes) return 1;
     device_guard g(ctx->device);
+    const bool round_stats = std::getenv("BU_TSVQ_ROUNDS") != nullptr;   // development aid: one line per round on stderr
+    const auto round_t0 = std::chrono::steady_clock::now();
     if ((size_t)n_nodes * sizeof(bu_tsvq_node) > q->nodes.cap || (size_t)n_nodes * sizeof(bu_tsvq_split) > q->outs.cap) { set_error(ctx, "tsvq_split: batch of %u nodes exceeds the record buffers", n_nodes); return 0; }
     // Large nodes go through the many-workgroup path, the rest one workgroup each; both write one result array
     // (narrow records first, in batch order, then the wide ones).
@@ -980,6 +983,12 @@ int bu_hip_tsvq_split(bu_hip_context* ctx, bu_tsvq* q, const bu_tsvq_node* h_nod
     }
     BU_TRY(ctx, hipMemcpyAsync(q->pinned, q->outs.p, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
     BU_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (round_stats) {
+        uint32_t mx = 0; uint64_t tot = 0;
+        for (uint32_t i = 0; i < n_nodes; i++) { mx = std::max(mx, h_nodes[i].count); tot += h_nodes[i].count; }
+        std::fprintf(stderr, "[tsvq round] dim %u: %u nodes (%u wide), largest %u, members %llu: %.0f us\n", q->dim, n_nodes, n_wide, mx, (unsigned long long)tot,
+                     std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - round_t0).count());
+    }
     {
         const bu_tsvq_split* po = static_cast<const bu_tsvq_split*>(q->pinned);
         for (uint32_t i = 0; i < n_nodes; i++) h_out[order[i]] = po[i];
