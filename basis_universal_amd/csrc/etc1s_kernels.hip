@@ -751,6 +751,7 @@ __global__ __launch_bounds__(256) void k_refine_endpoint_clusterization(
     uint32_t* __restrict__ out_best) {
     constexpr uint32_t RQ = 256;   // candidates per round
     __shared__ uint2 s_q[4][2][RQ];   // per wave: {cluster parameters, position in the list | "is the block's current cluster" << 31}
+    __shared__ uint32_t s_qp[4][2][RQ];   // the partial error of a candidate that survived the first four pixels
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t block = blockIdx.x * 4u + (threadIdx.x >> 6);
     if (block >= n_blocks) return; // whole wave exits together
@@ -782,7 +783,40 @@ __global__ __launch_bounds__(256) void k_refine_endpoint_clusterization(
     // four colours need no clamping and the others -- so that the lanes are full in both sweeps (the intensity filter of :1811-1815
     // otherwise leaves holes) and the unclamped ones take the short form of the distance (etc1s_device.h, base_unclamped). The position
     // in the list travels with the candidate: the winner does not depend on the order of evaluation.
+    // Pruning (exact): a candidate whose error exceeds the error of ANY member of the list can neither win nor tie. The block's current
+    // cluster is a member of its own parent's list by construction, so its error -- computed here directly, one pixel per lane -- is the
+    // first threshold, tightened by the running minimum after every sweep. Each sweep first takes four of the sixteen pixels (a partial
+    // sum is a lower bound of the error), squeezes out the candidates that are already above the threshold, and finishes the others.
+    // Should the current cluster not turn up in the list after all, everything is done again without a threshold.
     uint2 (*q)[RQ] = s_q[threadIdx.x >> 6];
+    uint32_t (*qp)[RQ] = s_qp[threadIdx.x >> 6];
+    uint32_t thr;
+    {
+        const uint32_t prm = cluster_params[cur];
+        cvec bc[4];
+        block_cvecs<PERCEPTUAL>(bc, scale5((int)(prm & 255u)), scale5((int)((prm >> 8) & 255u)), scale5((int)((prm >> 16) & 255u)), (int)((prm >> 24) & 7u));
+        const uint32_t w = reinterpret_cast<const uint32_t*>(pixel_blocks + (size_t)block * 4)[lane & 15u];
+        uint32_t e = lane < 16 ? min_err4<PERCEPTUAL>(pixel_cvec<PERCEPTUAL>(w), bc) : 0u;
+#pragma unroll
+        for (int o = 8; o >= 1; o >>= 1) e += (uint32_t)__shfl_xor((int)e, o, 64);
+        thr = (uint32_t)__builtin_amdgcn_readfirstlane((int)e);
+    }
+    constexpr int FIRST_PX[4] = { 0, 5, 10, 15 };
+    constexpr uint64_t REST_PX = 0xEDCB98764321ull;   // the other twelve pixel indices, one per nibble
+    const uint32_t* block_words = reinterpret_cast<const uint32_t*>(pixel_blocks + (size_t)block * 4);
+    auto sync_queue = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    auto tighten = [&]() {
+        uint32_t m = (uint32_t)(best_key >> 32);
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) m = min(m, (uint32_t)__shfl_xor((int)m, o, 64));
+        thr = min(thr, m);
+    };
+    bool seen_cur = false;
+    for (int attempt = 0; attempt < 2; attempt++) {
     for (uint32_t base = 0; base < total; base += RQ) {
         uint32_t n0 = 0, n1 = 0;
 #pragma unroll
@@ -803,32 +837,96 @@ __global__ __launch_bounds__(256) void k_refine_endpoint_clusterization(
             if (take && plain) q[0][n0 + r0] = e;
             if (take && !plain) q[1][n1 + r1] = e;
             n0 += (uint32_t)__popcll(m0); n1 += (uint32_t)__popcll(m1);
+            seen_cur = seen_cur || __ballot(take && ci == cur) != 0ull;
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        for (uint32_t j = lane; j < n0; j += 64) {   // unclamped: one chroma term per pixel, the luma term's minimum over the four offsets
-            const uint2 e = q[0][j];
-            const int inten = (int)((e.x >> 24) & 7u);
-            const cvec bcv = to_cvec<true>(scale5((int)(e.x & 255u)), scale5((int)((e.x >> 8) & 255u)), scale5((int)((e.x >> 16) & 255u)));
-            const int a64 = k_inten_a[inten] * 64, b64 = k_inten_b[inten] * 64;
-            uint32_t tot = 0;
+        sync_queue();
+        // ---- unclamped: one chroma term per pixel, the luma term's minimum over the four offsets
+        {
+            uint32_t ns = 0;
+            for (uint32_t j0 = 0; j0 < n0; j0 += 64) {
+                const uint32_t j = j0 + lane;
+                const bool have = j < n0;
+                const uint2 e = q[0][have ? j : 0];
+                const int inten = (int)((e.x >> 24) & 7u);
+                const cvec bcv = to_cvec<true>(scale5((int)(e.x & 255u)), scale5((int)((e.x >> 8) & 255u)), scale5((int)((e.x >> 16) & 255u)));
+                const int a64 = k_inten_a[inten] * 64, b64 = k_inten_b[inten] * 64;
+                uint32_t part = 0;
 #pragma unroll
-            for (int p = 0; p < 16; p++) tot += min_luma_term(pc[p].x - bcv.x, a64, b64) + chroma_term(pc[p].y - bcv.y, pc[p].z - bcv.z);
-            best_key = min(best_key, ((uint64_t)tot << 32) | (e.y & 0x7fffffffu));
-            if (e.y >> 31) cur_err = tot;
-        }
-        for (uint32_t j = lane; j < n1; j += 64) {
-            const uint2 e = q[1][j];
-            cvec bc[4];
-            block_cvecs<PERCEPTUAL>(bc, scale5((int)(e.x & 255u)), scale5((int)((e.x >> 8) & 255u)), scale5((int)((e.x >> 16) & 255u)), (int)((e.x >> 24) & 7u));
-            uint32_t tot = 0;
+                for (int f = 0; f < 4; f++) { const int p = FIRST_PX[f]; part += min_luma_term(pc[p].x - bcv.x, a64, b64) + chroma_term(pc[p].y - bcv.y, pc[p].z - bcv.z); }
+                const bool keep = have && part <= thr;
+                const uint64_t m = __ballot(keep);
+                const uint32_t r = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                if (keep) { q[0][ns + r] = e; qp[0][ns + r] = part; }   // in place: everything up to j0 + 63 has been read
+                ns += (uint32_t)__popcll(m);
+            }
+            sync_queue();
+            // the twelve remaining pixels of a survivor are shared by four lanes (three pixels each, fetched by index: the wave-uniform
+            // copy in pc[] cannot be indexed per lane), so that a handful of survivors still fills the wave
+            for (uint32_t j4 = lane; j4 < ((ns * 4u + 63u) & ~63u); j4 += 64) {
+                const uint32_t j = j4 >> 2, part = j4 & 3u;
+                const bool have = j < ns;
+                const uint2 e = q[0][have ? j : 0];
+                const int inten = (int)((e.x >> 24) & 7u);
+                const cvec bcv = to_cvec<true>(scale5((int)(e.x & 255u)), scale5((int)((e.x >> 8) & 255u)), scale5((int)((e.x >> 16) & 255u)));
+                const int a64 = k_inten_a[inten] * 64, b64 = k_inten_b[inten] * 64;
+                uint32_t tot = 0;
 #pragma unroll
-            for (int p = 0; p < 16; p++) tot += min_err4<PERCEPTUAL>(pc[p], bc);
-            best_key = min(best_key, ((uint64_t)tot << 32) | (e.y & 0x7fffffffu));
-            if (e.y >> 31) cur_err = tot;
+                for (int i = 0; i < 3; i++) {
+                    const cvec p = pixel_cvec<true>(block_words[(REST_PX >> (4u * (part * 3u + (uint32_t)i))) & 15u]);
+                    tot += min_luma_term(p.x - bcv.x, a64, b64) + chroma_term(p.y - bcv.y, p.z - bcv.z);
+                }
+                tot += (uint32_t)__shfl_xor((int)tot, 1, 64);
+                tot += (uint32_t)__shfl_xor((int)tot, 2, 64);
+                if (have && part == 0) {
+                    tot += qp[0][j];
+                    best_key = min(best_key, ((uint64_t)tot << 32) | (e.y & 0x7fffffffu));
+                    if (e.y >> 31) cur_err = tot;
+                }
+            }
+            if (attempt == 0) tighten();
+        }
+        // ---- clamped colours: the four distances
+        {
+            uint32_t ns = 0;
+            for (uint32_t j0 = 0; j0 < n1; j0 += 64) {
+                const uint32_t j = j0 + lane;
+                const bool have = j < n1;
+                const uint2 e = q[1][have ? j : 0];
+                cvec bc[4];
+                block_cvecs<PERCEPTUAL>(bc, scale5((int)(e.x & 255u)), scale5((int)((e.x >> 8) & 255u)), scale5((int)((e.x >> 16) & 255u)), (int)((e.x >> 24) & 7u));
+                uint32_t part = 0;
+#pragma unroll
+                for (int f = 0; f < 4; f++) part += min_err4<PERCEPTUAL>(pc[FIRST_PX[f]], bc);
+                const bool keep = have && part <= thr;
+                const uint64_t m = __ballot(keep);
+                const uint32_t r = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                if (keep) { q[1][ns + r] = e; qp[1][ns + r] = part; }
+                ns += (uint32_t)__popcll(m);
+            }
+            sync_queue();
+            for (uint32_t j4 = lane; j4 < ((ns * 4u + 63u) & ~63u); j4 += 64) {
+                const uint32_t j = j4 >> 2, part = j4 & 3u;
+                const bool have = j < ns;
+                const uint2 e = q[1][have ? j : 0];
+                cvec bc[4];
+                block_cvecs<PERCEPTUAL>(bc, scale5((int)(e.x & 255u)), scale5((int)((e.x >> 8) & 255u)), scale5((int)((e.x >> 16) & 255u)), (int)((e.x >> 24) & 7u));
+                uint32_t tot = 0;
+#pragma unroll
+                for (int i = 0; i < 3; i++) tot += min_err4<PERCEPTUAL>(pixel_cvec<PERCEPTUAL>(block_words[(REST_PX >> (4u * (part * 3u + (uint32_t)i))) & 15u]), bc);
+                tot += (uint32_t)__shfl_xor((int)tot, 1, 64);
+                tot += (uint32_t)__shfl_xor((int)tot, 2, 64);
+                if (have && part == 0) {
+                    tot += qp[1][j];
+                    best_key = min(best_key, ((uint64_t)tot << 32) | (e.y & 0x7fffffffu));
+                    if (e.y >> 31) cur_err = tot;
+                }
+            }
+            if (attempt == 0) tighten();
         }
         __builtin_amdgcn_wave_barrier();
+    }
+    if (seen_cur || attempt == 1) break;
+    thr = 0xFFFFFFFFu; best_key = ~0ull; cur_err = 0xFFFFFFFFu;   // (not expected) the threshold was not a member's error: no pruning
     }
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) {
