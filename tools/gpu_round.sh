@@ -1,20 +1,30 @@
-# One GPU round trip: parity suite, smoke, bench, rocprof kernel stats, PMC passes. Every step has its own timeout.
-# usage: gpu_round.sh <tag> [prof] [pmc]
+# One GPU round trip: parity suite, smoke, bench, rocprof kernel stats, PMC passes. Every step has its own timeout. The rocpd
+# databases stay on the box (they exceed what gpurun merges back); what comes home are the CSV / JSON summaries under gpurun_out/.
+# usage: gpu_round.sh <tag> [tests] [bench] [prof] [pmc]
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 tag=${1:-x}
 R=$GRAFT_REPO_ROOT
-timeout 420 python -m pytest tests -m gpu -x -q 2>&1 | tail -4
-timeout 120 python __graft_entry__.py smoke 2>&1 | tail -2
-timeout 240 python bench.py --steps 3 --warmup 1 > gpurun_out/bench_$tag.json 2> gpurun_out/bench_$tag.err; tail -c 3000 gpurun_out/bench_$tag.json
+if [[ " $* " == *" tests "* ]]; then
+  timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -4
+  timeout 120 python __graft_entry__.py smoke 2>&1 | tail -2
+fi
+if [[ " $* " == *" bench "* ]]; then
+  timeout 600 python bench.py --steps 10 --warmup 2 > gpurun_out/bench_$tag.json 2> gpurun_out/bench_$tag.err; tail -c 1500 gpurun_out/bench_$tag.json
+fi
 cd /tmp && export TMPDIR=/tmp
+db() { ls /tmp/$1/*/*.db /tmp/$1/*.db 2>/dev/null | head -1; }
 if [[ " $* " == *" prof "* ]]; then
-  timeout 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_$tag -o bench -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $R/gpurun_out/prof_$tag.json 2> $R/gpurun_out/prof_$tag.err
-  ls $R/gpurun_out/prof_$tag | head
+  timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_$tag -o bench -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-pipelined > $R/gpurun_out/prof_$tag.json 2> $R/gpurun_out/prof_$tag.err
+  python $R/tools/rocprof_summary.py stats $(db prof_$tag) > $R/gpurun_out/${tag}_kernel_stats.csv; wc -l $R/gpurun_out/${tag}_kernel_stats.csv
 fi
 if [[ " $* " == *" pmc "* ]]; then
   # counters in their own passes (FETCH_SIZE and WRITE_SIZE do not fit one pass), no tracing domains besides kernel-trace
-  timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $R/gpurun_out/pmc_fetch_$tag -o bench -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > /dev/null 2> $R/gpurun_out/pmc_fetch_$tag.err
-  timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $R/gpurun_out/pmc_write_$tag -o bench -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > /dev/null 2> $R/gpurun_out/pmc_write_$tag.err
-  ls $R/gpurun_out/pmc_fetch_$tag $R/gpurun_out/pmc_write_$tag | head
+  for c in FETCH_SIZE WRITE_SIZE; do
+    l=$(echo $c | tr A-Z a-z)
+    timeout 300 rocprofv3 --kernel-trace --pmc $c -d /tmp/pmc_${l}_$tag -o bench -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-pipelined > /dev/null 2> $R/gpurun_out/pmc_${l}_$tag.err
+    python $R/tools/rocprof_summary.py pmc $(db pmc_${l}_$tag) > $R/gpurun_out/${tag}_pmc_${l}.csv; wc -l $R/gpurun_out/${tag}_pmc_${l}.csv
+  done
+  timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_INSTS_SALU SQ_WAIT_ANY SQ_ACTIVE_INST_ANY -d /tmp/pmc_sq_$tag -o bench -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-pipelined > /dev/null 2> $R/gpurun_out/pmc_sq_$tag.err
+  python $R/tools/rocprof_summary.py pmc $(db pmc_sq_$tag) > $R/gpurun_out/${tag}_pmc_sq.csv; wc -l $R/gpurun_out/${tag}_pmc_sq.csv
 fi

@@ -45,6 +45,7 @@ def short(name):
     if n in ("tsvq_split", "tsvq_root"):  # the two instantiations are timed separately (selector vectors packed in a dword / 6-float endpoint vectors)
         n += "_packed16" if "packed16_rows" in name else "_float6"
     return {"refine_endpoint_clusterization": "refine_endpoint_clusterization", "fosc_resolve_and_stamp": "find_optimal_selector_clusters_stamp",
+            "encode_etc1s_blocks_by_pixel": "encode_etc1s_blocks",
             "find_optimal_selector_clusters": "find_optimal_selector_clusters"}.get(n, n)
 
 
@@ -83,6 +84,8 @@ def traffic_csv(fetch_csv, write_csv, commit):
                 if "k_wide_partition" in n:
                     batches = k
                 continue
+            if "rocprim" in n or n.startswith("__amd_rocclr") or n.startswith("_Z"):
+                continue  # library kernels (sorts, scans, copies) and the k-means helpers of the fast mode: not part of the per-kernel table
             s_ = short(n)
             a, c = acc.get(s_, (0.0, 0))
             acc[s_] = (a + tot, c + k)
