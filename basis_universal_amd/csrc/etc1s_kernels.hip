@@ -497,7 +497,7 @@ __global__ __launch_bounds__(256) void k_selector_training_vectors(const uint64_
 // identical to the reference's running float sum; otherwise three lanes replay the float accumulation in pixel order.
 // -------------------------------------------------------------------------------------------------------------------
 
-constexpr int CB_THREADS = 1024;
+constexpr int CB_THREADS = 512;   // 1024 leaves the SIMDs 44 % idle on the bench image (barriers per trial, ~7 pixels per thread); 512: 1.14 ms against 1.80
 constexpr int CB_WAVES = CB_THREADS / 64;
 
 __device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
