@@ -163,6 +163,7 @@ class Etc1sBackend:
         sl = slice_descs(slices)
         if not b.L.bu_backend_init_arrays(b.h, C.byref(arrays), C.byref(prm), sl, len(slices)):
             raise BackendError("bu_backend_init_arrays failed")
+        b._total_endpoints = int(ep.shape[0])   # the length of the old_to_new array the C side hands to the reoptimize call-back
         return b
 
     REOPTIMIZE_FN = C.CFUNCTYPE(C.c_int, _vp, C.POINTER(C.c_uint32), C.c_uint32, C.POINTER(C.c_int32), C.c_int, C.POINTER(C.c_uint32), C.POINTER(BackendArrays))
@@ -176,7 +177,10 @@ class Etc1sBackend:
                 new_ep = np.ctypeslib.as_array(nbe, (n,)).copy()
                 sel = np.ctypeslib.as_array(bsi, (n,)).copy() if bsi else None
                 old_to_new, arrays = fn(new_ep, bool(final), sel)
-                old_to_new = np.asarray(old_to_new, np.int32)
+                old_to_new = np.ascontiguousarray(old_to_new, np.int32)
+                have = getattr(self, "_total_endpoints", None)
+                if have is not None and old_to_new.size != have:   # the C buffer holds exactly one entry per endpoint of the codebook being replaced
+                    raise BackendError(f"reoptimize call-back returned {old_to_new.size} old_to_new entries for a codebook of {have}")
                 C.memmove(o2n, old_to_new.ctypes.data, old_to_new.nbytes)
                 src = np.ascontiguousarray(arrays["source_blocks"], np.uint8)
                 out = np.ascontiguousarray(arrays["output_blocks"], np.uint8)
@@ -184,7 +188,10 @@ class Etc1sBackend:
                 si = np.ascontiguousarray(arrays["block_selector_index"], np.uint32)
                 ep = np.ascontiguousarray(arrays["endpoint_color5_inten"], np.uint8).reshape(-1, 4)
                 sb = np.ascontiguousarray(arrays["selector_blocks"], np.uint8).reshape(-1, 8)
+                if src.size != ei.size * 64 or out.size != ei.size * 8 or si.size != ei.size or n != ei.size:
+                    raise BackendError("reoptimize call-back returned arrays of inconsistent sizes")
                 self._keep_cb = [src, out, ei, si, ep, sb]
+                self._total_endpoints = int(ep.shape[0])
                 p = lambda a: a.ctypes.data
                 r = refreshed.contents
                 r.total_blocks, r.perceptual = ei.size, int(arrays.get("perceptual", True))

@@ -311,10 +311,13 @@ void bu_hip_free(bu_hip_context* ctx, void* p) {
             const bu_hip_context::pooled b = ctx->pool_live[i];
             ctx->pool_live.erase(ctx->pool_live.begin() + (long)i);
             if (ctx->pool_free_bytes + b.cap <= ((size_t)16 << 30)) { ctx->pool_free.push_back(b); ctx->pool_free_bytes += b.cap; return; }
-            break;
+            (void)hipStreamSynchronize(ctx->stream);
+            (void)hipFree(p);
+            return;
         }
-    (void)hipStreamSynchronize(ctx->stream);
-    (void)hipFree(p);
+    // not a live block of this context: a second free of a pooled block (it is in pool_free and will be handed out again -- hipFree here would
+    // turn that into a use after free) or a foreign pointer. Leave it alone and say so.
+    set_error(ctx, "bu_hip_free: %p is not a live allocation of this context (double free?)", p);
 }
 int bu_hip_memcpy_h2d(bu_hip_context* ctx, void* d, const void* h, size_t bytes) {
     if (!ctx) return 0;

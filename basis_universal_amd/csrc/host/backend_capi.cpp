@@ -8,6 +8,16 @@
 #include "entropy.h"
 #include "etc1s_backend.h"
 #include "etc1s_frontend.h"
+#include <exception>
+#include <string>
+
+// No exception may cross the C ABI (the callers are ctypes / cgo / JNI stubs): every entry point below is a function-try-block that turns a
+// std::bad_alloc, std::system_error (thread creation) or anything else into the function's failure value, with the text in bu_host_last_exception().
+extern thread_local std::string bu_last_exception_text;   // frontend_capi.cpp
+#define g_last_exception bu_last_exception_text
+#define BU_CATCH(fail_value) catch (const std::exception& e_) { g_last_exception = e_.what(); return fail_value; } catch (...) { g_last_exception = "unknown exception"; return fail_value; }
+#define BU_CATCH_VOID catch (const std::exception& e_) { g_last_exception = e_.what(); } catch (...) { g_last_exception = "unknown exception"; }
+
 
 struct bu_frontend;
 bu::etc1s_frontend* bu_frontend_object(bu_frontend*);  // frontend_capi.cpp
@@ -47,7 +57,7 @@ void convert(const bu_backend_params* p, const bu_backend_slice_desc* s, uint32_
 
 extern "C" {
 
-void bu_backend_default_params(int quality_level, uint32_t compression_level, bu_backend_params* out) {
+void bu_backend_default_params(int quality_level, uint32_t compression_level, bu_backend_params* out) try {
     if (!out) return;
     float scale = 1.0f;
     if (quality_level != -1) {
@@ -61,22 +71,22 @@ void bu_backend_default_params(int quality_level, uint32_t compression_level, bu
     out->selector_rdo_quality_thresh = 1.25f * scale;
     out->compression_level = compression_level;
     out->video = 0;
-}
+} BU_CATCH_VOID
 
-bu_backend* bu_backend_create(void) { return new (std::nothrow) bu_backend(); }
-void bu_backend_destroy(bu_backend* b) { delete b; }
+bu_backend* bu_backend_create(void) try { return new (std::nothrow) bu_backend(); } BU_CATCH(nullptr)
+void bu_backend_destroy(bu_backend* b) try { delete b; } BU_CATCH_VOID
 const char* bu_backend_error(const bu_backend* b) { return b ? b->be.error().c_str() : "null backend"; }
 
-int bu_backend_init(bu_backend* b, bu_frontend* frontend, const bu_backend_params* p, const bu_backend_slice_desc* s, uint32_t n) {
+int bu_backend_init(bu_backend* b, bu_frontend* frontend, const bu_backend_params* p, const bu_backend_slice_desc* s, uint32_t n) try {
     if (!b || !frontend || !p || (!s && n)) return 0;
     bu::backend_params bp;
     std::vector<bu::backend_slice_desc> slices;
     convert(p, s, n, bp, slices);
     b->be.init(bu_frontend_object(frontend), bp, slices);
     return 1;
-}
+} BU_CATCH(0)
 
-int bu_backend_init_arrays(bu_backend* b, const bu_backend_arrays* a, const bu_backend_params* p, const bu_backend_slice_desc* s, uint32_t n) {
+int bu_backend_init_arrays(bu_backend* b, const bu_backend_arrays* a, const bu_backend_params* p, const bu_backend_slice_desc* s, uint32_t n) try {
     if (!b || !a || !p || (!s && n)) return 0;
     bu::backend_params bp;
     std::vector<bu::backend_slice_desc> slices;
@@ -94,7 +104,7 @@ int bu_backend_init_arrays(bu_backend* b, const bu_backend_arrays* a, const bu_b
     src.selector_blocks = a->selector_blocks;
     b->be.init(src, bp, slices);
     return 1;
-}
+} BU_CATCH(0)
 
 namespace {
 bu::backend_source to_source(const bu_backend_arrays* a) {
@@ -113,7 +123,7 @@ bu::backend_source to_source(const bu_backend_arrays* a) {
 }
 }  // namespace
 
-int bu_backend_set_reoptimize_callback(bu_backend* b, bu_backend_reoptimize_fn fn, void* user) {
+int bu_backend_set_reoptimize_callback(bu_backend* b, bu_backend_reoptimize_fn fn, void* user) try {
     if (!b) return 0;
     if (!fn) { b->be.set_reoptimize(nullptr); return 1; }
     bu::etc1s_backend* be = &b->be;
@@ -132,9 +142,9 @@ int bu_backend_set_reoptimize_callback(bu_backend* b, bu_backend_reoptimize_fn f
         return true;
     });
     return 1;
-}
+} BU_CATCH(0)
 
-uint32_t bu_backend_encode(bu_backend* b) { return b ? b->be.encode() : 0; }
+uint32_t bu_backend_encode(bu_backend* b) try { return b ? b->be.encode() : 0; } BU_CATCH(0)
 
 namespace {
 std::vector<bu::basis_key_value> to_kvs(const bu_basis_key_value* kvs, uint32_t n) {
@@ -147,13 +157,13 @@ std::vector<bu::basis_key_value> to_kvs(const bu_basis_key_value* kvs, uint32_t 
 }
 }  // namespace
 
-uint64_t bu_backend_write_ktx2_file(bu_backend* b, uint32_t tex_type, int has_alpha, const bu_basis_key_value* kvs, uint32_t n_kvs, void* buf, uint64_t cap) {
+uint64_t bu_backend_write_ktx2_file(bu_backend* b, uint32_t tex_type, int has_alpha, const bu_basis_key_value* kvs, uint32_t n_kvs, void* buf, uint64_t cap) try {
     if (!b || (!kvs && n_kvs)) return 0;
     return emit(bu::write_ktx2_file(b->be.get_output(), tex_type, has_alpha != 0, to_kvs(kvs, n_kvs)), buf, cap);
-}
+} BU_CATCH(0)
 
 uint64_t bu_write_ktx2_file_uastc(const uint8_t* blocks16, uint64_t total_blocks, const bu_backend_slice_desc* s, uint32_t n, int srgb, uint32_t tex_type, int has_alpha,
-                                  const bu_basis_key_value* kvs, uint32_t n_kvs, void* buf, uint64_t cap) {
+                                  const bu_basis_key_value* kvs, uint32_t n_kvs, void* buf, uint64_t cap) try {
     if (!blocks16 || !s || !n || (!kvs && n_kvs)) return 0;
     bu_backend_params unused = {0, 0, 0, 0};
     bu::backend_params bp;
@@ -162,11 +172,11 @@ uint64_t bu_write_ktx2_file_uastc(const uint8_t* blocks16, uint64_t total_blocks
     const bu::backend_output out = bu::uastc_backend_output(slices, blocks16, (size_t)total_blocks, srgb != 0);
     if (out.m_slice_desc.empty()) return 0;
     return emit(bu::write_ktx2_file(out, tex_type, has_alpha != 0, to_kvs(kvs, n_kvs)), buf, cap);
-}
+} BU_CATCH(0)
 
 uint64_t bu_write_basis_file_uastc(const uint8_t* blocks16, uint64_t total_blocks, const bu_backend_slice_desc* s, uint32_t n, int srgb, uint32_t tex_type,
                                    uint32_t userdata0, uint32_t userdata1, int y_flipped, uint32_t us_per_frame, const bu_basis_key_value* kvs, uint32_t n_kvs,
-                                   void* buf, uint64_t cap) {
+                                   void* buf, uint64_t cap) try {
     if (!blocks16 || !s || !n || (!kvs && n_kvs)) return 0;
     bu_backend_params unused = {0, 0, 0, 0};
     bu::backend_params bp;
@@ -180,10 +190,10 @@ uint64_t bu_write_basis_file_uastc(const uint8_t* blocks16, uint64_t total_block
     const bu::backend_output out = bu::uastc_backend_output(slices, blocks16, (size_t)total_blocks, srgb != 0);
     if (out.m_slice_desc.empty()) return 0;
     return emit(bu::write_basis_file(out, tex_type, userdata0, userdata1, y_flipped != 0, us_per_frame, kv), buf, cap);
-}
+} BU_CATCH(0)
 
 uint64_t bu_backend_write_basis_file(bu_backend* b, uint32_t tex_type, uint32_t userdata0, uint32_t userdata1, int y_flipped, uint32_t us_per_frame,
-                                     const bu_basis_key_value* kvs, uint32_t n_kvs, void* buf, uint64_t cap) {
+                                     const bu_basis_key_value* kvs, uint32_t n_kvs, void* buf, uint64_t cap) try {
     if (!b || (!kvs && n_kvs)) return 0;
     std::vector<bu::basis_key_value> kv(n_kvs);
     for (uint32_t i = 0; i < n_kvs; i++) {
@@ -191,9 +201,9 @@ uint64_t bu_backend_write_basis_file(bu_backend* b, uint32_t tex_type, uint32_t 
         if (kvs[i].value_size) kv[i].value.assign(kvs[i].value, kvs[i].value + kvs[i].value_size);
     }
     return emit(bu::write_basis_file(b->be.get_output(), tex_type, userdata0, userdata1, y_flipped != 0, us_per_frame, kv), buf, cap);
-}
+} BU_CATCH(0)
 
-uint64_t bu_backend_get(bu_backend* b, const char* name, uint32_t slice, void* buf, uint64_t cap) {
+uint64_t bu_backend_get(bu_backend* b, const char* name, uint32_t slice, void* buf, uint64_t cap) try {
     if (!b) return ~0ull;
     const std::string n(name);
     const bu::backend_output& o = b->be.get_output();
@@ -213,17 +223,17 @@ uint64_t bu_backend_get(bu_backend* b, const char* name, uint32_t slice, void* b
     if (n == "endpoint_remap_old_to_new") return emit(b->be.endpoint_remap_old_to_new(), buf, cap);
     if (n == "selector_remap_new_to_old") return emit(b->be.selector_remap_new_to_old(), buf, cap);
     return ~0ull;
-}
+} BU_CATCH(0)
 
-uint32_t bu_backend_stage_times(const bu_backend* b, const char** names, double* seconds, uint32_t cap) {
+uint32_t bu_backend_stage_times(const bu_backend* b, const char** names, double* seconds, uint32_t cap) try {
     if (!b) return 0;
     const auto& t = b->be.stage_times();
     for (uint32_t i = 0; i < t.size() && i < cap; i++) { names[i] = t[i].name; seconds[i] = t[i].seconds; }
     return (uint32_t)t.size();
-}
+} BU_CATCH(0)
 
 // ---- test hooks: the coding tools on their own (tests/test_backend_host.py diffs them against the reference's)
-uint64_t bu_backend_test_huffman(const uint32_t* freq, uint32_t n, uint32_t max_code_size, uint8_t* out_sizes, uint16_t* out_codes, uint8_t* out_bytes, uint64_t cap) {
+uint64_t bu_backend_test_huffman(const uint32_t* freq, uint32_t n, uint32_t max_code_size, uint8_t* out_sizes, uint16_t* out_codes, uint8_t* out_bytes, uint64_t cap) try {
     bu::huffman_table t;
     if (!t.init(freq, n, max_code_size)) return ~0ull;
     for (uint32_t i = 0; i < n; i++) { out_sizes[i] = t.sizes()[i]; out_codes[i] = t.codes()[i]; }
@@ -233,11 +243,11 @@ uint64_t bu_backend_test_huffman(const uint32_t* freq, uint32_t n, uint32_t max_
     w.put_vlc(n, 4);
     w.flush();
     return emit(w.bytes(), out_bytes, cap);
-}
-uint32_t bu_backend_test_crc16(const uint8_t* data, uint64_t size, uint32_t crc) { return bu::crc16_ccitt(data, (size_t)size, (uint16_t)crc); }
-void bu_backend_test_reorder(const uint32_t* indices, uint32_t num_indices, uint32_t num_syms, uint32_t* out_old_to_new) {
+} BU_CATCH(0)
+uint32_t bu_backend_test_crc16(const uint8_t* data, uint64_t size, uint32_t crc) try { return bu::crc16_ccitt(data, (size_t)size, (uint16_t)crc); } BU_CATCH(0)
+void bu_backend_test_reorder(const uint32_t* indices, uint32_t num_indices, uint32_t num_syms, uint32_t* out_old_to_new) try {
     const std::vector<uint32_t> r = bu::reorder_palette_by_adjacency(indices, num_indices, num_syms);
     std::memcpy(out_old_to_new, r.data(), r.size() * sizeof(uint32_t));
-}
+} BU_CATCH_VOID
 
 }  // extern "C"

@@ -95,6 +95,11 @@ struct history_buffer {
 
 // The slices of a file (mip levels, array layers / cube faces, the alpha slice) share the codebooks and the Huffman models but no
 // walking state: each is walked by its own host thread, largest first (BU_HOST_THREADS caps the count, default 8).
+// BU_HOST_THREADS=1 means one thread altogether: the side jobs (selector codebook sort, slice CRCs) then run inline.
+static bool host_single_threaded() {
+    const char* e = std::getenv("BU_HOST_THREADS");
+    return e && std::atoi(e) == 1;
+}
 template <class F> void for_each_slice(const std::vector<backend_slice_desc>& slices, F fn) {
     const size_t n = slices.size();
     unsigned want = 8;
@@ -611,7 +616,9 @@ bool etc1s_backend::create_encoder_blocks() {
         std::thread t;
         void join() { if (t.joinable()) t.join(); }
         ~joined_thread() { join(); }
-    } selector_sort{std::thread([this] { sort_selector_codebook(); })};
+    } selector_sort;
+    if (host_single_threaded()) sort_selector_codebook();
+    else selector_sort.t = std::thread([this] { sort_selector_codebook(); });
     std::vector<std::pair<uint64_t, uint64_t>> extents;
     for (const backend_slice_desc& s : m_slices) {
         if ((uint64_t)s.m_first_block_index + (uint64_t)s.m_num_blocks_x * s.m_num_blocks_y > total) return fail("slice exceeds the frontend's blocks");
@@ -1061,7 +1068,9 @@ bool etc1s_backend::encode_image() {
         create_endpoint_palette();
     }
     // the slice CRCs only need the final indices: computed on the side while the symbols are coded
-    struct joined_thread { std::thread t; ~joined_thread() { if (t.joinable()) t.join(); } } crc_thread{std::thread([this] { compute_slice_crcs(); })};
+    struct joined_thread { std::thread t; ~joined_thread() { if (t.joinable()) t.join(); } } crc_thread;
+    if (host_single_threaded()) compute_slice_crcs();
+    else crc_thread.t = std::thread([this] { compute_slice_crcs(); });
 
     // ---- the four models, then the slices (backend.cpp:1298-1472)
     auto model = [](std::vector<uint32_t>& h, huffman_table& t) {

@@ -9,6 +9,17 @@
 #include "mipmap.h"
 #include "tsvq.h"
 #include "tsvq_device.h"
+#include <exception>
+#include <string>
+
+// No exception may cross the C ABI (the callers are ctypes / cgo / JNI stubs): every entry point below is a function-try-block that turns a
+// std::bad_alloc, std::system_error (thread creation) or anything else into the function's failure value, with the text in bu_host_last_exception().
+thread_local std::string bu_last_exception_text;   // shared with backend_capi.cpp
+#define g_last_exception bu_last_exception_text
+extern "C" __attribute__((visibility("default"))) const char* bu_host_last_exception() { return g_last_exception.c_str(); }
+#define BU_CATCH(fail_value) catch (const std::exception& e_) { g_last_exception = e_.what(); return fail_value; } catch (...) { g_last_exception = "unknown exception"; return fail_value; }
+#define BU_CATCH_VOID catch (const std::exception& e_) { g_last_exception = e_.what(); } catch (...) { g_last_exception = "unknown exception"; }
+
 
 struct bu_frontend {
     bu::etc1s_frontend fe;
@@ -43,12 +54,12 @@ bu::etc1s_frontend* bu_frontend_object(bu_frontend* f) { return f ? &f->fe : nul
 
 extern "C" {
 
-bu_frontend* bu_frontend_create(void) { return new (std::nothrow) bu_frontend(); }
-void bu_frontend_destroy(bu_frontend* f) { delete f; }
+bu_frontend* bu_frontend_create(void) try { return new (std::nothrow) bu_frontend(); } BU_CATCH(nullptr)
+void bu_frontend_destroy(bu_frontend* f) try { delete f; } BU_CATCH_VOID
 const char* bu_frontend_error(const bu_frontend* f) { return f ? f->fe.error().c_str() : "null frontend"; }
 
 int bu_frontend_init(bu_frontend* f, bu_hip_context* ctx, const bu_pixel_block* h_blocks, const void* d_blocks, uint32_t n_blocks,
-                     uint32_t max_ep, uint32_t max_sel, uint32_t level, int perceptual) {
+                     uint32_t max_ep, uint32_t max_sel, uint32_t level, int perceptual) try {
     if (!f) return 0;
     bu::etc1s_frontend::params p;
     p.m_num_source_blocks = n_blocks;
@@ -63,25 +74,25 @@ int bu_frontend_init(bu_frontend* f, bu_hip_context* ctx, const bu_pixel_block* 
     p.m_fast_codebooks = f->fast_codebooks;
     p.m_fast_codebook_iterations = f->fast_iterations;
     return f->fe.init(p) ? 1 : 0;
-}
+} BU_CATCH(0)
 
-int bu_frontend_set_comm(bu_frontend* f, const bu_comm* comm) {
+int bu_frontend_set_comm(bu_frontend* f, const bu_comm* comm) try {
     if (!f) return 0;
     f->fe.set_comm(comm);
     return 1;
-}
+} BU_CATCH(0)
 
-int bu_frontend_set_video(bu_frontend* f, int video) { if (!f) return 0; f->video = video != 0; return 1; }
-int bu_frontend_set_fast_codebooks(bu_frontend* f, int on, uint32_t iterations) {
+int bu_frontend_set_video(bu_frontend* f, int video) try { if (!f) return 0; f->video = video != 0; return 1; } BU_CATCH(0)
+int bu_frontend_set_fast_codebooks(bu_frontend* f, int on, uint32_t iterations) try {
     if (!f) return 0;
     f->fast_codebooks = on != 0;
     if (iterations) f->fast_iterations = iterations;
     return 1;
-}
+} BU_CATCH(0)
 
-int bu_frontend_compress(bu_frontend* f) { return (f && f->fe.compress()) ? 1 : 0; }
+int bu_frontend_compress(bu_frontend* f) try { return (f && f->fe.compress()) ? 1 : 0; } BU_CATCH(0)
 
-int bu_frontend_call(bu_frontend* f, const char* stage, uint32_t arg) {
+int bu_frontend_call(bu_frontend* f, const char* stage, uint32_t arg) try {
     if (!f) return 0;
     const std::string n(stage);
     bu::etc1s_frontend& fe = f->fe;
@@ -104,9 +115,9 @@ int bu_frontend_call(bu_frontend* f, const char* stage, uint32_t arg) {
     if (n == "optimize_selector_codebook") { fe.optimize_selector_codebook(); return 1; }
     if (n == "finalize") { fe.finalize(); return 1; }
     return 0;
-}
+} BU_CATCH(0)
 
-uint64_t bu_frontend_get(bu_frontend* f, const char* name, void* buf, uint64_t cap) {
+uint64_t bu_frontend_get(bu_frontend* f, const char* name, void* buf, uint64_t cap) try {
     if (!f) return ~0ull;
     const std::string n(name);
     const bu::etc1s_frontend& fe = f->fe;
@@ -129,10 +140,10 @@ uint64_t bu_frontend_get(bu_frontend* f, const char* name, void* buf, uint64_t c
         return emit(v, buf, cap);
     }
     return ~0ull;
-}
+} BU_CATCH(0)
 
 int bu_frontend_reoptimize_remapped_endpoints(bu_frontend* f, const uint32_t* new_block_endpoints, uint32_t total_blocks, int32_t* old_to_new, uint32_t old_to_new_count,
-                                              int optimize_final_codebook, const uint32_t* block_selector_indices) {
+                                              int optimize_final_codebook, const uint32_t* block_selector_indices) try {
     if (!f || !new_block_endpoints || !old_to_new) return 0;
     try {
         const std::vector<uint32_t> nbe(new_block_endpoints, new_block_endpoints + total_blocks);
@@ -144,20 +155,20 @@ int bu_frontend_reoptimize_remapped_endpoints(bu_frontend* f, const uint32_t* ne
         for (size_t i = 0; i < o2n.size(); i++) old_to_new[i] = o2n[i];
         return 1;
     } catch (...) { return 0; }
-}
+} BU_CATCH(0)
 
-uint32_t bu_frontend_stage_times(const bu_frontend* f, const char** names, double* seconds, uint32_t cap) {
+uint32_t bu_frontend_stage_times(const bu_frontend* f, const char** names, double* seconds, uint32_t cap) try {
     if (!f) return 0;
     const auto& t = f->fe.stage_times();
     const uint32_t n = (uint32_t)std::min<size_t>(t.size(), cap);
     for (uint32_t i = 0; i < n; i++) { names[i] = t[i].name; seconds[i] = t[i].seconds; }
     return (uint32_t)t.size();
-}
+} BU_CATCH(0)
 
 // Test hook for the host TSVQ (tsvq.h): rows must be DISTINCT and ascending (the order the reference's std::map yields).
 // Blobs are [n, off_0..off_n, idx...] u32, like bu_frontend_get's cluster lists. Returns 1, 0 on failure, -1 if a blob does not fit.
 int bu_host_tsvq(uint32_t dim, const float* rows, const uint64_t* weights, uint32_t n, uint32_t max_codebook_size, uint32_t max_parent_codebook_size,
-                 uint32_t* out_codebook, uint64_t cap_codebook_words, uint32_t* out_parent, uint64_t cap_parent_words) {
+                 uint32_t* out_codebook, uint64_t cap_codebook_words, uint32_t* out_parent, uint64_t cap_parent_words) try {
     std::vector<float> r(rows, rows + (size_t)n * dim);
     std::vector<uint64_t> w(weights, weights + n);
     std::vector<std::vector<uint32_t>> groups(n), codebook, parents;
@@ -171,11 +182,11 @@ int bu_host_tsvq(uint32_t dim, const float* rows, const uint64_t* weights, uint3
     std::memcpy(out_codebook, a.data(), a.size() * 4);
     std::memcpy(out_parent, b.data(), b.size() * 4);
     return 1;
-}
+} BU_CATCH(0)
 
 // The same through the device TSVQ (tsvq_device.h + bu_hip_tsvq_*): what the frontend actually uses. stats3 = {rounds, splits computed, splits used}.
 int bu_device_tsvq(bu_hip_context* ctx, uint32_t dim, const float* rows, const uint64_t* weights, uint32_t n, uint32_t max_codebook_size, uint32_t max_parent_codebook_size,
-                   uint32_t* out_codebook, uint64_t cap_codebook_words, uint32_t* out_parent, uint64_t cap_parent_words, uint32_t* stats3) {
+                   uint32_t* out_codebook, uint64_t cap_codebook_words, uint32_t* out_parent, uint64_t cap_parent_words, uint32_t* stats3) try {
     std::vector<float> r(rows, rows + (size_t)n * dim);
     std::vector<uint64_t> w(weights, weights + n);
     std::vector<std::vector<uint32_t>> groups(n), codebook, parents;
@@ -194,25 +205,25 @@ int bu_device_tsvq(bu_hip_context* ctx, uint32_t dim, const float* rows, const u
     std::memcpy(out_codebook, a.data(), a.size() * 4);
     std::memcpy(out_parent, b.data(), b.size() * 4);
     return 1;
-}
+} BU_CATCH(0)
 
 // comp.cpp:3310-3379, float arithmetic in the reference's order
 int bu_generate_mipmap_level(bu_hip_context* ctx, const void* d_src, uint32_t src_w, uint32_t src_h, void* d_dst, uint32_t dst_w, uint32_t dst_h, int srgb,
-                             const char* filter, float filter_scale, int wrapping, uint32_t num_comps) {
+                             const char* filter, float filter_scale, int wrapping, uint32_t num_comps) try {
     bu::mip::plan p;
     if (!ctx || !filter || !bu::mip::make_plan(p, src_w, src_h, dst_w, dst_h, srgb != 0, filter, filter_scale, wrapping != 0)) return 0;
     return bu_hip_k_resample_rgba8(ctx, d_src, src_w, src_h, d_dst, dst_w, dst_h, p.x.first.data(), p.x.pixel.data(), p.x.weight.data(), p.y.first.data(), p.y.pixel.data(),
                                    p.y.weight.data(), p.x_after_y, srgb, p.srgb_to_linear, p.linear_to_srgb, num_comps);
-}
+} BU_CATCH(0)
 
-uint32_t bu_mipmap_level_sizes(uint32_t w, uint32_t h, uint32_t smallest_dimension, uint32_t* out_wh, uint32_t cap) {
+uint32_t bu_mipmap_level_sizes(uint32_t w, uint32_t h, uint32_t smallest_dimension, uint32_t* out_wh, uint32_t cap) try {
     const auto sizes = bu::mip::level_sizes(w, h, smallest_dimension ? smallest_dimension : 1);
     for (uint32_t i = 0; i < sizes.size() && i < cap; i++) { out_wh[i * 2] = sizes[i].first; out_wh[i * 2 + 1] = sizes[i].second; }
     return (uint32_t)sizes.size();
-}
+} BU_CATCH(0)
 
 int bu_mipmap_plan(uint32_t src_w, uint32_t src_h, uint32_t dst_w, uint32_t dst_h, int srgb, const char* filter, float filter_scale, int wrapping, uint32_t* out_counts,
-                   uint32_t* x_first, uint16_t* x_pixel, float* x_weight, uint32_t* y_first, uint16_t* y_pixel, float* y_weight, float* to_linear, uint8_t* to_srgb) {
+                   uint32_t* x_first, uint16_t* x_pixel, float* x_weight, uint32_t* y_first, uint16_t* y_pixel, float* y_weight, float* to_linear, uint8_t* to_srgb) try {
     bu::mip::plan p;
     if (!filter || !out_counts || !bu::mip::make_plan(p, src_w, src_h, dst_w, dst_h, srgb != 0, filter, filter_scale, wrapping != 0)) return 0;
     out_counts[0] = p.x.ops(); out_counts[1] = p.y.ops(); out_counts[2] = p.x_after_y; out_counts[3] = 0;
@@ -221,9 +232,9 @@ int bu_mipmap_plan(uint32_t src_w, uint32_t src_h, uint32_t dst_w, uint32_t dst_
     if (to_linear) std::memcpy(to_linear, p.srgb_to_linear, sizeof(p.srgb_to_linear));
     if (to_srgb) std::memcpy(to_srgb, p.linear_to_srgb, sizeof(p.linear_to_srgb));
     return 1;
-}
+} BU_CATCH(0)
 
-void bu_etc1s_quality_to_clusters(int quality_level, uint32_t total_blocks, uint32_t* out_ep, uint32_t* out_sel) {
+void bu_etc1s_quality_to_clusters(int quality_level, uint32_t total_blocks, uint32_t* out_ep, uint32_t* out_sel) try {
     const double total_texels = total_blocks * 16.0f;
     const float quality = clampf(quality_level / 255.0f, 0.0f, 1.0f);
     const float bits_per_cluster = 14.0f;
@@ -252,6 +263,6 @@ void bu_etc1s_quality_to_clusters(int quality_level, uint32_t total_blocks, uint
     const uint32_t selector_clusters = clampt<uint32_t>((uint32_t)(.5f + (96.0f + (static_cast<float>(max_selectors) - 96.0f) * sq)), 8, 16128);
     *out_ep = endpoint_clusters;
     *out_sel = selector_clusters;
-}
+} BU_CATCH_VOID
 
 } // extern "C"

@@ -56,6 +56,9 @@ BU_HIP_API int bu_frontend_reoptimize_remapped_endpoints(bu_frontend*, const uin
 BU_HIP_API const char* bu_frontend_error(const bu_frontend*);
 /* Wall seconds of each stage of the last compress(): writes up to cap entries, returns the count; names are static strings. */
 BU_HIP_API uint32_t bu_frontend_stage_times(const bu_frontend*, const char** names, double* seconds, uint32_t cap);
+/* No exception leaves the library: an entry point of this header or of basisu_hip_backend.h that ran into one (std::bad_alloc, a failed thread
+   start) returns its failure value (0 / NULL) and leaves the exception's text here, per calling thread. */
+BU_HIP_API const char* bu_host_last_exception(void);
 
 /* basis_compressor::process_frontend's quality -> codebook size mapping (comp.cpp:3325-3379). */
 BU_HIP_API void bu_etc1s_quality_to_clusters(int quality_level, uint32_t total_blocks, uint32_t* max_endpoint_clusters, uint32_t* max_selector_clusters);
