@@ -344,8 +344,11 @@ __device__ __forceinline__ void fetch_packed(const uint32_t* __restrict__ keys, 
 __device__ __forceinline__ void st_store(int32_t* o, const fsum::stretch& a) { o[0] = a.d[0]; o[1] = a.d[1]; o[2] = a.lo[0]; o[3] = a.lo[1]; o[4] = a.hi[0]; o[5] = a.hi[1]; }
 __device__ __forceinline__ fsum::stretch st_load(const int32_t* o) { fsum::stretch a; a.d[0] = o[0]; a.d[1] = o[1]; a.lo[0] = o[2]; a.lo[1] = o[3]; a.hi[0] = o[4]; a.hi[1] = o[5]; return a; }
 
+// Launched with ST_THREADS = 320 threads: the first 256 stage the block's members, all of them take (chain, slice) items -- the 544 items of the
+// covariance pass are two rounds of 320 lanes instead of three of 256.
+constexpr int ST_THREADS = 320;
 template <int MODE>
-__global__ __launch_bounds__(WB) void k_wide_stretches(const uint32_t* __restrict__ keys, const uint64_t* __restrict__ w64, const uint2* __restrict__ pk,
+__global__ __launch_bounds__(ST_THREADS) void k_wide_stretches(const uint32_t* __restrict__ keys, const uint64_t* __restrict__ w64, const uint2* __restrict__ pk,
                                                        const uint8_t* __restrict__ side, const tsvq_wide_node* __restrict__ nodes,
                                                        uint32_t n_nodes, const tsvq_wide_ctrl* __restrict__ ctrl, void* ws_base, uint32_t tb) {
     constexpr int NCH = mode_traits<MODE>::NCH;
@@ -363,10 +366,12 @@ __global__ __launch_bounds__(WB) void k_wide_stretches(const uint32_t* __restric
     const tsvq_wide_node& nd = nodes[ni];
     if (tid < 16) s_origin[tid] = nd.origin[tid];
     __syncthreads();
-    const uint32_t pos = (blk - nd.first_block) * WB + (uint32_t)tid;
+    const uint32_t pos = (blk - nd.first_block) * WB + (uint32_t)min(tid, WB - 1);
     uint32_t key; float wf; bool valid;
     fetch_packed<MODE>(keys, w64, pk, nd.start, pos, nd.count, key, wf, valid);
-    if (MODE == WM_COV) {
+    if (tid >= WB) {
+        // not a staging thread
+    } else if (MODE == WM_COV) {
 #pragma unroll
         for (int k = 0; k < 16; k++) {
             const float dk = (float)packed16_value(key, k) - s_origin[k];
@@ -379,7 +384,7 @@ __global__ __launch_bounds__(WB) void k_wide_stretches(const uint32_t* __restric
         T.sd[tid] = valid ? (MODE == WM_ROOT ? 0 : side[nd.start + pos]) : 2;
     }
     __syncthreads();
-    for (int item = tid; item < ITEMS; item += WB) {
+    for (int item = tid; item < ITEMS; item += ST_THREADS) {
         const int c = item % NCH, q = item / NCH;
         const bool skip = ctrl[ni].exact[c] != 0;
         const uint16_t ep = skip ? EP_NONE : ws.epred[ws.at(c, blk)];
@@ -406,7 +411,7 @@ __global__ __launch_bounds__(WB) void k_wide_stretches(const uint32_t* __restric
         st_store(s_st[item][0], st0); st_store(s_st[item][1], st1);
     }
     __syncthreads();
-    for (int item = tid; item < NCH * 2; item += WB) {   // slices in member order
+    for (int item = tid; item < NCH * 2; item += ST_THREADS) {   // slices in member order
         const int c = item % NCH, cand = item / NCH;
         if (ctrl[ni].exact[c]) continue;
         fsum::stretch acc = st_load(s_st[c][cand]);
@@ -783,7 +788,7 @@ static void launch_pass(hipStream_t st, const uint32_t* keys, const uint64_t* w6
     constexpr int NCH = mode_traits<MODE>::NCH;
     hipLaunchKernelGGL((k_wide_sums<MODE>), dim3(tb), dim3(WB), 0, st, keys, w64, perm0, perm1, side, nodes, n_nodes, ctrl, ws, tb, pk);
     hipLaunchKernelGGL((k_wide_scan<MODE>), dim3(n_nodes, (NCH + 3) / 4 + (MODE == WM_COV ? 0 : 1)), dim3(256), 0, st, nodes, ctrl, ws, tb);
-    hipLaunchKernelGGL((k_wide_stretches<MODE>), dim3(tb), dim3(WB), 0, st, keys, w64, pk, side, nodes, n_nodes, ctrl, ws, tb);
+    hipLaunchKernelGGL((k_wide_stretches<MODE>), dim3(tb), dim3(ST_THREADS), 0, st, keys, w64, pk, side, nodes, n_nodes, ctrl, ws, tb);
     hipLaunchKernelGGL((k_wide_walk<MODE>), dim3(n_nodes * NCH), dim3(64), 0, st, keys, w64, pk, side, nodes, ctrl, ws, tb);
     hipLaunchKernelGGL((k_wide_finish<MODE>), dim3(n_nodes), dim3(64), 0, st, nodes, ctrl, root_out);
 }
