@@ -344,9 +344,8 @@ __device__ __forceinline__ void fetch_packed(const uint32_t* __restrict__ keys, 
 __device__ __forceinline__ void st_store(int32_t* o, const fsum::stretch& a) { o[0] = a.d[0]; o[1] = a.d[1]; o[2] = a.lo[0]; o[3] = a.lo[1]; o[4] = a.hi[0]; o[5] = a.hi[1]; }
 __device__ __forceinline__ fsum::stretch st_load(const int32_t* o) { fsum::stretch a; a.d[0] = o[0]; a.d[1] = o[1]; a.lo[0] = o[2]; a.lo[1] = o[3]; a.hi[0] = o[4]; a.hi[1] = o[5]; return a; }
 
-// Launched with ST_THREADS = 320 threads: the first 256 stage the block's members, all of them take (chain, slice) items -- the 544 items of the
-// covariance pass are two rounds of 320 lanes instead of three of 256.
-constexpr int ST_THREADS = 320;
+// (320 threads -- two rounds over the covariance pass's 544 items instead of three -- measured slower: 307 against 250 us for the root.)
+constexpr int ST_THREADS = WB;
 template <int MODE>
 __global__ __launch_bounds__(ST_THREADS) void k_wide_stretches(const uint32_t* __restrict__ keys, const uint64_t* __restrict__ w64, const uint2* __restrict__ pk,
                                                        const uint8_t* __restrict__ side, const tsvq_wide_node* __restrict__ nodes,
