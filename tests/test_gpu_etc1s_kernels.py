@@ -153,7 +153,7 @@ def _codebook(blocks, k, seed, level=1, perceptual=1):
 
 
 @pytest.mark.parametrize("perceptual", [1, 0])
-@pytest.mark.parametrize("hier", [True, False])
+@pytest.mark.parametrize("hier", [True, False, "foreign"])
 def test_refine_endpoint_clusterization(hip_ctx, blocks, d_blocks, hier, perceptual):
     n = blocks.shape[0]
     k = 300
@@ -166,6 +166,10 @@ def test_refine_endpoint_clusterization(hip_ctx, blocks, d_blocks, hier, percept
         # compute_endpoint_clusters_within_each_parent_cluster (frontend.cpp:971-996)
         cluster_parent = (np.arange(k) * n_parents // k).astype(np.uint8)
         block_parent = cluster_parent[block_cluster]
+        if hier == "foreign":
+            # blocks filed under a parent whose list does NOT hold their current cluster: never produced by the frontend, but the kernel's pruning
+            # threshold (the current cluster's error) is only valid for list members, so this exercises its fall-back
+            block_parent = np.random.default_rng(5).integers(0, n_parents, n).astype(np.uint8)
         cand = [np.nonzero(cluster_parent == p)[0].astype(np.uint32) for p in range(n_parents)]
         coffs, cidx = csr_from_lists(cand)
     else:
