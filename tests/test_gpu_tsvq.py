@@ -101,6 +101,9 @@ def test_root_record_is_reproducible(hip_ctx, mode):
 
 WIDE_CASES = [(5000, 300, 32, "sel", 50, 512), (120000, 2731, 32, "sel", 4096, 512), (120000, 2731, 32, "sel", 4096, 16384), (30000, 900, 16, "sel_skewed", 4096, 512),
               (700000, 2731, 32, "sel", 400, 16384), (60000, 500, 16, "sel", 1, 2048),
+              # weights that are powers of two over whole blocks of 256 members, then ones: chain sums land EXACTLY on 2^24 (the end of the prefix the walk
+              # skips) and on binade boundaries at block boundaries, and the ones that follow are exact ties of the rounding
+              (50000, 400, 16, "sel_pow2", 1, 512),
               # weights around 2^50 / 2^44: the wide path must hand the nodes whose integer totals leave the exact range back to the chained kernel
               (20000, 600, 16, "sel", 2 ** 50, 512), (3000, 200, 8, "sel", 2 ** 44, 512)]
 
@@ -118,11 +121,15 @@ def test_wide_nodes_match_host_tsvq(hip_ctx, monkeypatch, n, k, p, kind, wmax, w
         v = np.clip(base[rng.integers(0, 400, n)] + (rng.random((n, 16)) < 0.25) * rng.integers(-1, 2, (n, 16)), 0, 3).astype(np.float32)
         v = np.ascontiguousarray(np.unique(v, axis=0))
     else:
-        v = _data(kind, 16, n, rng)
+        v = _data("sel" if kind == "sel_pow2" else kind, 16, n, rng)
     n = v.shape[0]
     w = rng.integers(1, wmax + 1, n).astype(np.uint64)
     if kind == "sel_skewed":
         w[rng.integers(0, n, 5)] = 3_000_000_000
+    if kind == "sel_pow2":
+        w[:] = 1
+        w[: 256 * 40] = 65536
+        w[256 * 40: 256 * 44] = 1 << 20
     cap = 4 * n + 4 * k + 100
     outs = {}
     # wide: every pass through the parity maps; hybrid: the covariance pass of all but the largest nodes chained (the default)
