@@ -225,6 +225,19 @@ __global__ __launch_bounds__(WB) void k_wide_sums(const uint32_t* __restrict__ k
     if (tid >= 64 && tid < 72) ws.bex[(size_t)blk * 8 + (tid - 64)] = s_red[0][tid - 64] + s_red[1][tid - 64] + s_red[2][tid - 64] + s_red[3][tid - 64];
 }
 
+// inclusive prefix sum of a double over the wave by DPP (rows of 16: row_shr 1/2/4/8, then row_bcast15 into rows 1 and 3, row_bcast31 into rows 2 and 3);
+// lanes without a source add +0.0. A prediction aid (and exact for the integer-valued block sums): the association order does not matter.
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ double dpp_mov_f64(double src) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(src), CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(src), CTRL, ROW_MASK, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_prefix_f64(double v) {
+    v += dpp_mov_f64<0x111, 0xf>(v); v += dpp_mov_f64<0x112, 0xf>(v); v += dpp_mov_f64<0x114, 0xf>(v); v += dpp_mov_f64<0x118, 0xf>(v);
+    v += dpp_mov_f64<0x142, 0xa>(v); v += dpp_mov_f64<0x143, 0xc>(v);
+    return v;
+}
+
 // ------------------------------------------------------------------------------------------------------------ k_wide_scan
 // grid (node, y): y < ceil(NCH / 4): four chains, one wave each, 64 blocks per step (coalesced, wave prefix scan);
 //                 y == ceil(NCH / 4) (not for the covariance pass): the integer totals and the left-count prefix of the node.
@@ -243,27 +256,24 @@ __global__ __launch_bounds__(256) void k_wide_scan(const tsvq_wide_node* __restr
         const int c = (int)blockIdx.y * 4 + (tid >> 6);
         if (c >= NCH) return;
         double P = 0;   // sum of the blocks before the current 64
-        if (MODE != WM_COV) {
-            // Addends are non-negative INTEGER-valued floats here (value 0..3 times an integer weight). If the chain's total is below 2^24,
-            // every partial sum of the sequential float chain is an integer below 2^24, i.e. exact: the chain's result is the total, in any
-            // order. (Block sums are exact in double.) The other two kernels of the pass skip such chains.
-            double tot = 0;
-            for (uint32_t b = (uint32_t)lane; b < nd.n_blocks; b += 64) tot += ws.bsum[ws.at(c, nd.first_block + b)];
-#pragma unroll
-            for (int o = 32; o >= 1; o >>= 1) tot += __shfl_xor(tot, o, 64);
-            const bool exact = tot < 16777216.0;
-            if (lane == 0) { ctrl[ni].exact[c] = exact ? 1 : 0; if (exact) ctrl[ni].sums[c] = (float)tot; }
-            if (exact) return;
-        } else if (lane == 0) ctrl[ni].exact[c] = 0;
         uint32_t exact_blocks = 0; double exact_sum = 0.0;   // the leading blocks over which the (integer) running sum stays <= 2^24: no rounding there
-        for (uint32_t b0 = 0; b0 < nd.n_blocks; b0 += 64) {
+        // one sweep, the next chunk's block sums in flight while the current one is scanned (a chunk is one trip to L2)
+        auto fetch = [&](uint32_t b0, double& v, uint32_t& bz) {
             const uint32_t b = b0 + (uint32_t)lane;
             const bool have = b < nd.n_blocks;
             const size_t at = ws.at(c, nd.first_block + (have ? b : nd.n_blocks - 1));
-            const double v = have ? ws.bsum[at] : 0.0;
-            double incl = v;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) { const double t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+            v = have ? ws.bsum[at] : 0.0;
+            bz = have ? (uint32_t)ws.bzero[at] : 1u;
+        };
+        double v; uint32_t bz;
+        fetch(0, v, bz);
+        for (uint32_t b0 = 0; b0 < nd.n_blocks; b0 += 64) {
+            double vn; uint32_t bzn;
+            fetch(min(b0 + 64, nd.n_blocks - 1), vn, bzn);
+            const uint32_t b = b0 + (uint32_t)lane;
+            const bool have = b < nd.n_blocks;
+            const size_t at = ws.at(c, nd.first_block + (have ? b : nd.n_blocks - 1));
+            const double incl = wave_prefix_f64(v);
             const double Ps = P + (incl - v);
             if (MODE != WM_COV && exact_blocks == b0) {   // still inside the exact prefix at this chunk's start
                 const uint64_t inside = __ballot(have && P + incl <= 16777216.0);
@@ -272,7 +282,7 @@ __global__ __launch_bounds__(256) void k_wide_scan(const tsvq_wide_node* __restr
             }
             if (have) {
                 uint16_t ep;
-                if (ws.bzero[at]) ep = EP_ZERO;
+                if (bz) ep = EP_ZERO;
                 else {
                     // the running float sum at this block's start is within (members so far) half-ulps of Ps: the binade of the lower
                     // end, and whether the upper end is in the same one (then only one map is needed)
@@ -287,7 +297,13 @@ __global__ __launch_bounds__(256) void k_wide_scan(const tsvq_wide_node* __restr
                 ws.epred[at] = ep;
             }
             P += __shfl(incl, 63, 64);
+            v = vn; bz = bzn;
         }
+        // Side / root chains add non-negative INTEGER-valued floats (value 0..3 times an integer weight). If the chain's total is below 2^24, every
+        // partial sum of the sequential float chain is an integer below 2^24, i.e. exact: the chain's result is the total, in any order. (Block sums
+        // are exact in double.) The other kernels of the pass skip such chains; the predictions written above are then never looked at.
+        const bool exact = MODE != WM_COV && P < 16777216.0;
+        if (lane == 0) { ctrl[ni].exact[c] = exact ? 1u : 0u; if (exact) ctrl[ni].sums[c] = (float)P; }
         if (lane == 0) { ctrl[ni].start_block[c] = exact_blocks; ctrl[ni].start_sum[c] = (float)exact_sum; }
         return;
     }
@@ -362,6 +378,8 @@ __global__ __launch_bounds__(ST_THREADS) void k_wide_stretches(const uint32_t* _
     const uint32_t blk = blockIdx.x;
     const uint32_t ni = find_node(nodes, n_nodes, blk);
     if (ctrl[ni].done) return;
+    // every chain of this pass finished by the scan (integer totals below 2^24): nothing to fold
+    if (MODE != WM_COV && __syncthreads_and(tid < NCH ? (ctrl[ni].exact[tid] != 0 ? 1 : 0) : 1)) return;
     const tsvq_wide_node& nd = nodes[ni];
     if (tid < 16) s_origin[tid] = nd.origin[tid];
     __syncthreads();
