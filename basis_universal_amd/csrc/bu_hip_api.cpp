@@ -58,6 +58,7 @@ struct bu_hip_context {
     // a second stream for work that is independent of what the main stream is doing (the one-workgroup TSVQ splits of a round next to
     // its many-workgroup ones); joined back through the two events before anything reads the results
     hipStream_t side_stream = nullptr; hipEvent_t side_fork = nullptr, side_join = nullptr;
+    arena refine_lists;                   // the sorted candidate lists of refine_endpoint_clusterization (etc1s_kernels.hip, k_refine_sort_lists)
     const void* d_pixel_blocks = nullptr; // resident tiles (a1): 64 B per block
     size_t total_blocks = 0;
     arena pixel_arena;                    // owns the tiles when they were uploaded through bu_hip_set_pixel_blocks
@@ -245,6 +246,7 @@ void bu_hip_destroy_context(bu_hip_context* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     ctx->pixel_arena.release();
     for (auto& a : ctx->scratch) a.release();
+    ctx->refine_lists.release();
     if (ctx->tsvq_pinned) (void)hipHostFree(ctx->tsvq_pinned);
     for (auto& b : ctx->pool_free) (void)hipFree(b.p);
     for (auto& b : ctx->pool_live) (void)hipFree(b.p);  // leaked by the caller; the context owns all device memory it handed out
@@ -488,9 +490,11 @@ int bu_hip_k_refine_endpoint_clusterization(bu_hip_context* ctx, const void* d_p
                                             const uint32_t* d_cand_indices, const uint8_t* d_block_parent, int perceptual, uint32_t* d_out_best) {
     if (!ctx) return 0;
     device_guard g(ctx->device);
+    void* work = nullptr;
+    if (const size_t wb = std::getenv("BU_REFINE_UNSORTED") ? 0 : bu::refine_workspace_bytes(n_clusters, n_parents)) { BU_TRY(ctx, ctx->refine_lists.reserve(wb)); work = ctx->refine_lists.p; }
     prof_scope ps(ctx, "refine_endpoint_clusterization");
     BU_TRY(ctx, bu::launch_refine_endpoint_clusterization(ctx->stream, d_px, n_blocks, d_block_cluster, d_cluster_params, n_clusters, n_parents,
-                                                          d_cand_offsets, d_cand_indices, d_block_parent, perceptual != 0, d_out_best));
+                                                          d_cand_offsets, d_cand_indices, d_block_parent, perceptual != 0, d_out_best, work));
     return 1;
 }
 
@@ -1279,10 +1283,12 @@ int bu_hip_refine_endpoint_clusterization(bu_hip_context* ctx, const bu_block_in
     BU_TRY(ctx, h2d(ctx, a_off.p, cand_offsets.data(), cand_offsets.size() * 4ull));
     if (!cand_indices.empty()) BU_TRY(ctx, h2d(ctx, a_idx.p, cand_indices.data(), cand_indices.size() * 4ull));
     BU_TRY(ctx, h2d(ctx, a_bp.p, block_parent8.data(), n));
+    void* work = nullptr;
+    if (const size_t wb = bu::refine_workspace_bytes(total_clusters, (uint32_t)win_first.size())) { BU_TRY(ctx, ctx->refine_lists.reserve(wb)); work = ctx->refine_lists.p; }
     BU_TRY(ctx, bu::launch_refine_endpoint_clusterization(ctx->stream, ctx->d_pixel_blocks, n, static_cast<const uint32_t*>(a_cur.p),
                                                           static_cast<const uint8_t*>(a_par.p), total_clusters, (uint32_t)win_first.size(),
                                                           static_cast<const uint32_t*>(a_off.p), static_cast<const uint32_t*>(a_idx.p),
-                                                          static_cast<const uint8_t*>(a_bp.p), perceptual != 0, static_cast<uint32_t*>(a_out.p)));
+                                                          static_cast<const uint8_t*>(a_bp.p), perceptual != 0, static_cast<uint32_t*>(a_out.p), work));
     std::vector<uint32_t> pos(n);
     BU_TRY(ctx, hipMemcpyAsync(pos.data(), a_out.p, n * 4ull, hipMemcpyDeviceToHost, ctx->stream));
     BU_TRY(ctx, hipStreamSynchronize(ctx->stream));

@@ -22,7 +22,9 @@ hipError_t launch_subblock_errors(hipStream_t st, const void* d_pixel_blocks, ui
                                   bool perceptual, uint64_t* d_out);
 hipError_t launch_refine_endpoint_clusterization(hipStream_t st, const void* d_pixel_blocks, uint32_t n_blocks, const uint32_t* d_block_cluster,
                                                  const uint8_t* d_cluster_params, uint32_t n_clusters, uint32_t n_parents, const uint32_t* d_cand_offsets,
-                                                 const uint32_t* d_cand_indices, const uint8_t* d_block_parent, bool perceptual, uint32_t* d_out_best);
+                                                 const uint32_t* d_cand_indices, const uint8_t* d_block_parent, bool perceptual, uint32_t* d_out_best,
+                                                 void* d_work /* refine_workspace_bytes(), or null: unsorted lists */);
+size_t refine_workspace_bytes(uint32_t n_clusters, uint32_t n_parents);   // 0: lists too long for the sorted form
 hipError_t launch_determine_selectors(hipStream_t st, const void* d_pixel_blocks, uint32_t n_blocks, const uint8_t* d_color5_inten,
                                       const uint32_t* d_block_cluster, bool perceptual, void* d_out);
 // total_members = d_offsets[n_clusters] - d_offsets[0] (the caller knows it on the host); d_workspace: create_optimized_selector_codebook_workspace_bytes()

@@ -947,6 +947,223 @@ __global__ __launch_bounds__(256) void k_refine_endpoint_clusterization(
 }
 
 // -------------------------------------------------------------------------------------------------------------------
+// a10 with pre-sorted candidate lists. k_refine_endpoint_clusterization spends a third of its instructions on finding out which of a
+// list's entries a block may take at all (frontend.cpp:1811-1815: intensity table <= the block's) and which distance form they need.
+// Both are properties of the (list, entry) pair, not of the block: k_refine_sort_lists (one workgroup per list, a counting sort over
+// 2 classes x 8 tables in LDS) rewrites every list as [unclamped, by table][clamped, by table] with the entry's cluster parameters, its
+// position in the ORIGINAL list (the tie-break key: the order of evaluation does not matter) and its cluster id, plus the 2 x 8
+// cumulative counts. A block then sweeps two prefixes of that, straight from memory. Same pruning as above.
+// -------------------------------------------------------------------------------------------------------------------
+
+constexpr uint32_t RS_SEG = 18;   // per list: first entry, unclamped total, 8 cumulative unclamped counts (table <= t), 8 cumulative clamped counts
+
+template <bool PERCEPTUAL>
+__global__ __launch_bounds__(256) void k_refine_sort_lists(const uint32_t* __restrict__ cluster_params, uint32_t n_clusters, uint32_t n_parents,
+                                                           const uint32_t* __restrict__ cand_offsets, const uint32_t* __restrict__ cand_indices,
+                                                           uint2* __restrict__ items, uint32_t* __restrict__ seg) {
+    __shared__ uint32_t s_cnt[16], s_pos[16];
+    const uint32_t p = blockIdx.x, tid = threadIdx.x;
+    uint32_t first = 0, total = n_clusters;
+    if (n_parents) { first = cand_offsets[p]; total = cand_offsets[p + 1] - first; }
+    if (tid < 16) s_cnt[tid] = 0;
+    __syncthreads();
+    auto bucket_of = [&](uint32_t prm) -> uint32_t {
+        const uint32_t inten = (prm >> 24) & 7u;
+        const bool plain = PERCEPTUAL && base_unclamped(scale5((int)(prm & 255u)), scale5((int)((prm >> 8) & 255u)), scale5((int)((prm >> 16) & 255u)), (int)inten);
+        return (plain ? 0u : 8u) + inten;
+    };
+    for (uint32_t k = tid; k < total; k += 256) {
+        const uint32_t ci = n_parents ? cand_indices[first + k] : k;
+        atomicAdd(&s_cnt[bucket_of(cluster_params[ci])], 1u);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t run = 0;
+        uint32_t* sg = seg + (size_t)p * RS_SEG;
+        sg[0] = first;
+        for (int b = 0; b < 16; b++) {
+            s_pos[b] = run; run += s_cnt[b];
+            if (b < 8) sg[2 + b] = run;                 // unclamped entries with table <= b
+            else sg[10 + (b - 8)] = run - sg[9];       // clamped entries with table <= b - 8
+            if (b == 7) sg[1] = run;
+        }
+    }
+    __syncthreads();
+    for (uint32_t k = tid; k < total; k += 256) {
+        const uint32_t ci = n_parents ? cand_indices[first + k] : k;
+        const uint32_t prm = cluster_params[ci];
+        const uint32_t at = atomicAdd(&s_pos[bucket_of(prm)], 1u);
+        items[first + at] = make_uint2(prm, (k << 16) | ci);   // position above the cluster id: the key order is (error, position); both fit 16 bits (caller)
+    }
+}
+
+template <bool PERCEPTUAL>
+__global__ __launch_bounds__(256) void k_refine_sorted(const uint4* __restrict__ pixel_blocks, uint32_t n_blocks, const uint32_t* __restrict__ block_cluster,
+                                                       const uint32_t* __restrict__ cluster_params, uint32_t n_parents, const uint2* __restrict__ items,
+                                                       const uint32_t* __restrict__ seg, const uint8_t* __restrict__ block_parent, uint32_t* __restrict__ out_best) {
+    constexpr uint32_t RQ = 256;
+    __shared__ uint2 s_q[4][RQ];        // per wave: the survivors of a sweep's first four pixels
+    __shared__ uint32_t s_qp[4][RQ];    // and their partial errors
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t block = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (block >= n_blocks) return; // whole wave exits together
+
+    cvec pc[16];
+    {
+        const uint4* src = pixel_blocks + (size_t)block * 4;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint4 v = src[i];
+            pc[i * 4 + 0] = pixel_cvec<PERCEPTUAL>(v.x); pc[i * 4 + 1] = pixel_cvec<PERCEPTUAL>(v.y);
+            pc[i * 4 + 2] = pixel_cvec<PERCEPTUAL>(v.z); pc[i * 4 + 3] = pixel_cvec<PERCEPTUAL>(v.w);
+        }
+    }
+    const uint32_t cur = block_cluster[block];
+    const uint32_t cur_prm = cluster_params[cur];
+    const uint32_t cur_inten = (cur_prm >> 24) & 7u;
+    const uint32_t* sg = seg + (size_t)(n_parents ? block_parent[block] : 0u) * RS_SEG;
+    const uint32_t first = sg[0], plain_total = sg[1];
+    const uint32_t n_plain = sg[2 + cur_inten], n_clamped = sg[10 + cur_inten];
+    const uint2* plain_items = items + first;
+    const uint2* clamped_items = items + first + plain_total;
+
+    constexpr int FIRST_PX[4] = { 0, 5, 10, 15 };
+    constexpr uint64_t REST_PX = 0xEDCB98764321ull;   // the other twelve pixel indices, one per nibble
+    const uint32_t* block_words = reinterpret_cast<const uint32_t*>(pixel_blocks + (size_t)block * 4);
+    uint2* q = s_q[threadIdx.x >> 6];
+    uint32_t* qp = s_qp[threadIdx.x >> 6];
+    uint64_t best_key = ~0ull;
+    uint32_t cur_err = 0xFFFFFFFFu;
+    uint32_t thr;   // the error of the block's own cluster (a list member by construction), see k_refine_endpoint_clusterization
+    {
+        cvec bc[4];
+        block_cvecs<PERCEPTUAL>(bc, scale5((int)(cur_prm & 255u)), scale5((int)((cur_prm >> 8) & 255u)), scale5((int)((cur_prm >> 16) & 255u)), (int)cur_inten);
+        uint32_t e = lane < 16 ? min_err4<PERCEPTUAL>(pixel_cvec<PERCEPTUAL>(block_words[lane & 15u]), bc) : 0u;
+#pragma unroll
+        for (int o = 8; o >= 1; o >>= 1) e += (uint32_t)__shfl_xor((int)e, o, 64);
+        thr = (uint32_t)__builtin_amdgcn_readfirstlane((int)e);
+    }
+    auto sync_queue = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    auto tighten = [&]() {
+        uint32_t m = (uint32_t)(best_key >> 32);
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) m = min(m, (uint32_t)__shfl_xor((int)m, o, 64));
+        thr = min(thr, m);
+    };
+    bool seen_cur = false;
+    for (int attempt = 0; attempt < 2; attempt++) {
+        // ---- unclamped: one chroma term per pixel, the luma term's minimum over the four offsets
+        for (uint32_t base = 0; base < n_plain; base += RQ) {
+            const uint32_t n0 = min(RQ, n_plain - base);
+            uint32_t ns = 0;
+            for (uint32_t j0 = 0; j0 < n0; j0 += 64) {
+                const uint32_t j = j0 + lane;
+                const bool have = j < n0;
+                const uint2 e = plain_items[base + (have ? j : 0)];
+                const int inten = (int)((e.x >> 24) & 7u);
+                const cvec bcv = to_cvec<true>(scale5((int)(e.x & 255u)), scale5((int)((e.x >> 8) & 255u)), scale5((int)((e.x >> 16) & 255u)));
+                const int a64 = k_inten_a[inten] * 64, b64 = k_inten_b[inten] * 64;
+                uint32_t part = 0;
+#pragma unroll
+                for (int f = 0; f < 4; f++) { const int p = FIRST_PX[f]; part += min_luma_term(pc[p].x - bcv.x, a64, b64) + chroma_term(pc[p].y - bcv.y, pc[p].z - bcv.z); }
+                const bool keep = have && part <= thr;
+                const uint64_t m = __ballot(keep);
+                const uint32_t r = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                if (keep) { q[ns + r] = e; qp[ns + r] = part; }
+                ns += (uint32_t)__popcll(m);
+                seen_cur = seen_cur || __ballot(have && (e.y & 0xffffu) == cur) != 0ull;
+            }
+            sync_queue();
+            for (uint32_t j4 = lane; j4 < ((ns * 4u + 63u) & ~63u); j4 += 64) {   // four lanes per survivor, three pixels each
+                const uint32_t j = j4 >> 2, part = j4 & 3u;
+                const bool have = j < ns;
+                const uint2 e = q[have ? j : 0];
+                const int inten = (int)((e.x >> 24) & 7u);
+                const cvec bcv = to_cvec<true>(scale5((int)(e.x & 255u)), scale5((int)((e.x >> 8) & 255u)), scale5((int)((e.x >> 16) & 255u)));
+                const int a64 = k_inten_a[inten] * 64, b64 = k_inten_b[inten] * 64;
+                uint32_t tot = 0;
+#pragma unroll
+                for (int i = 0; i < 3; i++) {
+                    const cvec p = pixel_cvec<true>(block_words[(REST_PX >> (4u * (part * 3u + (uint32_t)i))) & 15u]);
+                    tot += min_luma_term(p.x - bcv.x, a64, b64) + chroma_term(p.y - bcv.y, p.z - bcv.z);
+                }
+                tot += (uint32_t)__shfl_xor((int)tot, 1, 64);
+                tot += (uint32_t)__shfl_xor((int)tot, 2, 64);
+                if (have && part == 0) {
+                    tot += qp[j];
+                    best_key = min(best_key, ((uint64_t)tot << 32) | e.y);
+                    if ((e.y & 0xffffu) == cur) cur_err = tot;
+                }
+            }
+            if (attempt == 0) tighten();
+            __builtin_amdgcn_wave_barrier();
+        }
+        // ---- clamped colours: the four distances
+        for (uint32_t base = 0; base < n_clamped; base += RQ) {
+            const uint32_t n1 = min(RQ, n_clamped - base);
+            uint32_t ns = 0;
+            for (uint32_t j0 = 0; j0 < n1; j0 += 64) {
+                const uint32_t j = j0 + lane;
+                const bool have = j < n1;
+                const uint2 e = clamped_items[base + (have ? j : 0)];
+                cvec bc[4];
+                block_cvecs<PERCEPTUAL>(bc, scale5((int)(e.x & 255u)), scale5((int)((e.x >> 8) & 255u)), scale5((int)((e.x >> 16) & 255u)), (int)((e.x >> 24) & 7u));
+                uint32_t part = 0;
+#pragma unroll
+                for (int f = 0; f < 4; f++) part += min_err4<PERCEPTUAL>(pc[FIRST_PX[f]], bc);
+                const bool keep = have && part <= thr;
+                const uint64_t m = __ballot(keep);
+                const uint32_t r = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                if (keep) { q[ns + r] = e; qp[ns + r] = part; }
+                ns += (uint32_t)__popcll(m);
+                seen_cur = seen_cur || __ballot(have && (e.y & 0xffffu) == cur) != 0ull;
+            }
+            sync_queue();
+            for (uint32_t j4 = lane; j4 < ((ns * 4u + 63u) & ~63u); j4 += 64) {
+                const uint32_t j = j4 >> 2, part = j4 & 3u;
+                const bool have = j < ns;
+                const uint2 e = q[have ? j : 0];
+                cvec bc[4];
+                block_cvecs<PERCEPTUAL>(bc, scale5((int)(e.x & 255u)), scale5((int)((e.x >> 8) & 255u)), scale5((int)((e.x >> 16) & 255u)), (int)((e.x >> 24) & 7u));
+                uint32_t tot = 0;
+#pragma unroll
+                for (int i = 0; i < 3; i++) tot += min_err4<PERCEPTUAL>(pixel_cvec<PERCEPTUAL>(block_words[(REST_PX >> (4u * (part * 3u + (uint32_t)i))) & 15u]), bc);
+                tot += (uint32_t)__shfl_xor((int)tot, 1, 64);
+                tot += (uint32_t)__shfl_xor((int)tot, 2, 64);
+                if (have && part == 0) {
+                    tot += qp[j];
+                    best_key = min(best_key, ((uint64_t)tot << 32) | e.y);
+                    if ((e.y & 0xffffu) == cur) cur_err = tot;
+                }
+            }
+            if (attempt == 0) tighten();
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (seen_cur || attempt == 1) break;
+        thr = 0xFFFFFFFFu; best_key = ~0ull; cur_err = 0xFFFFFFFFu;   // (not expected) the threshold was not a member's error: no pruning
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)best_key, o, 64);
+        const uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)(best_key >> 32), o, 64);
+        best_key = min(best_key, ((uint64_t)hi << 32) | lo);
+        cur_err = min(cur_err, (uint32_t)__shfl_xor((int)cur_err, o, 64));
+    }
+    if (lane == 0) {
+        const uint32_t min_err = (uint32_t)(best_key >> 32);
+        uint32_t winner;
+        if (best_key == ~0ull) winner = 0;                       // no admissible candidate: best_cluster_index stays 0 (:1787)
+        else if (min_err != 0 && cur_err == min_err) winner = cur; // tie goes to the current cluster
+        else winner = (uint32_t)best_key & 0xffffu;                // the winning entry's cluster id rides below its position
+        out_best[block] = winner;
+    }
+}
+
+// -------------------------------------------------------------------------------------------------------------------
 // a11: create_initial_packed_texture -> etc_block::determine_selectors (frontend.cpp:2058-2085, etc.h:374-436)
 //
 // 16 lanes per block, lane l owns pixel (x = l>>2, y = l&3) so that a wave ballot of "raw selector lsb/msb" IS the packed
@@ -1252,13 +1469,33 @@ hipError_t launch_subblock_errors(hipStream_t st, const void* d_pixel_blocks, ui
     return hipSuccess;
 }
 
+size_t refine_workspace_bytes(uint32_t n_clusters, uint32_t n_parents) {
+    if (n_clusters > 65535u) return 0;   // positions and cluster ids share a dword in the sorted lists
+    const size_t lists = n_parents ? n_parents : 1;
+    return ((lists * n_clusters * sizeof(uint2) + 255) & ~(size_t)255) + lists * RS_SEG * sizeof(uint32_t);   // a cluster is at most once in a list
+}
+
 hipError_t launch_refine_endpoint_clusterization(hipStream_t st, const void* d_pixel_blocks, uint32_t n_blocks, const uint32_t* d_block_cluster,
                                                  const uint8_t* d_cluster_params, uint32_t n_clusters, uint32_t n_parents, const uint32_t* d_cand_offsets,
-                                                 const uint32_t* d_cand_indices, const uint8_t* d_block_parent, bool perceptual, uint32_t* d_out_best) {
+                                                 const uint32_t* d_cand_indices, const uint8_t* d_block_parent, bool perceptual, uint32_t* d_out_best, void* d_work) {
     if (!n_blocks) return hipSuccess;
     const dim3 grid((n_blocks + 3) / 4), blk(256);
     const uint4* in = static_cast<const uint4*>(d_pixel_blocks);
     const uint32_t* prm = reinterpret_cast<const uint32_t*>(d_cluster_params);
+    if (d_work && refine_workspace_bytes(n_clusters, n_parents)) {
+        const size_t lists = n_parents ? n_parents : 1;
+        uint2* items = static_cast<uint2*>(d_work);
+        uint32_t* seg = reinterpret_cast<uint32_t*>(static_cast<char*>(d_work) + ((lists * n_clusters * sizeof(uint2) + 255) & ~(size_t)255));
+        if (perceptual) {
+            hipLaunchKernelGGL(k_refine_sort_lists<true>, dim3((uint32_t)lists), blk, 0, st, prm, n_clusters, n_parents, d_cand_offsets, d_cand_indices, items, seg);
+            hipLaunchKernelGGL(k_refine_sorted<true>, grid, blk, 0, st, in, n_blocks, d_block_cluster, prm, n_parents, items, seg, d_block_parent, d_out_best);
+        } else {
+            hipLaunchKernelGGL(k_refine_sort_lists<false>, dim3((uint32_t)lists), blk, 0, st, prm, n_clusters, n_parents, d_cand_offsets, d_cand_indices, items, seg);
+            hipLaunchKernelGGL(k_refine_sorted<false>, grid, blk, 0, st, in, n_blocks, d_block_cluster, prm, n_parents, items, seg, d_block_parent, d_out_best);
+        }
+        BU_LAUNCH_CHECK();
+        return hipSuccess;
+    }
     if (perceptual) hipLaunchKernelGGL(k_refine_endpoint_clusterization<true>, grid, blk, 0, st, in, n_blocks, d_block_cluster, prm, n_clusters, n_parents, d_cand_offsets, d_cand_indices, d_block_parent, d_out_best);
     else hipLaunchKernelGGL(k_refine_endpoint_clusterization<false>, grid, blk, 0, st, in, n_blocks, d_block_cluster, prm, n_clusters, n_parents, d_cand_offsets, d_cand_indices, d_block_parent, d_out_best);
     BU_LAUNCH_CHECK();
