@@ -10,21 +10,21 @@ if [[ " $* " == *" tests "* ]]; then
   timeout 120 python __graft_entry__.py smoke 2>&1 | tail -2
 fi
 if [[ " $* " == *" bench "* ]]; then
-  timeout 600 python bench.py --steps 10 --warmup 2 > gpurun_out/bench_$tag.json 2> gpurun_out/bench_$tag.err; tail -c 1500 gpurun_out/bench_$tag.json
+  timeout 240 python bench.py --steps 10 --warmup 2 > gpurun_out/bench_$tag.json 2> gpurun_out/bench_$tag.err; tail -c 1500 gpurun_out/bench_$tag.json
 fi
 cd /tmp && export TMPDIR=/tmp
 db() { ls /tmp/$1/*/*.db /tmp/$1/*.db 2>/dev/null | head -1; }
 if [[ " $* " == *" prof "* ]]; then
-  timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_$tag -o bench -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-pipelined > $R/gpurun_out/prof_$tag.json 2> $R/gpurun_out/prof_$tag.err
+  timeout 120 rocprofv3 --kernel-trace --stats -d /tmp/prof_$tag -o bench -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-pipelined > $R/gpurun_out/prof_$tag.json 2> $R/gpurun_out/prof_$tag.err
   python $R/tools/rocprof_summary.py stats $(db prof_$tag) > $R/gpurun_out/${tag}_kernel_stats.csv; wc -l $R/gpurun_out/${tag}_kernel_stats.csv
 fi
 if [[ " $* " == *" pmc "* ]]; then
   # counters in their own passes (FETCH_SIZE and WRITE_SIZE do not fit one pass), no tracing domains besides kernel-trace
   for c in FETCH_SIZE WRITE_SIZE; do
     l=$(echo $c | tr A-Z a-z)
-    timeout 300 rocprofv3 --kernel-trace --pmc $c -d /tmp/pmc_${l}_$tag -o bench -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-pipelined > /dev/null 2> $R/gpurun_out/pmc_${l}_$tag.err
+    timeout 120 rocprofv3 --kernel-trace --pmc $c -d /tmp/pmc_${l}_$tag -o bench -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-pipelined > /dev/null 2> $R/gpurun_out/pmc_${l}_$tag.err
     python $R/tools/rocprof_summary.py pmc $(db pmc_${l}_$tag) > $R/gpurun_out/${tag}_pmc_${l}.csv; wc -l $R/gpurun_out/${tag}_pmc_${l}.csv
   done
-  timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_INSTS_SALU SQ_WAIT_ANY SQ_ACTIVE_INST_ANY -d /tmp/pmc_sq_$tag -o bench -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-pipelined > /dev/null 2> $R/gpurun_out/pmc_sq_$tag.err
+  timeout 120 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_INSTS_SALU SQ_WAIT_ANY SQ_ACTIVE_INST_ANY -d /tmp/pmc_sq_$tag -o bench -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-pipelined > /dev/null 2> $R/gpurun_out/pmc_sq_$tag.err
   python $R/tools/rocprof_summary.py pmc $(db pmc_sq_$tag) > $R/gpurun_out/${tag}_pmc_sq.csv; wc -l $R/gpurun_out/${tag}_pmc_sq.csv
 fi

@@ -45,7 +45,7 @@ def short(name):
     if n in ("tsvq_split", "tsvq_root"):  # the two instantiations are timed separately (selector vectors packed in a dword / 6-float endpoint vectors)
         n += "_packed16" if "packed16_rows" in name else "_float6"
     return {"refine_endpoint_clusterization": "refine_endpoint_clusterization", "fosc_resolve_and_stamp": "find_optimal_selector_clusters_stamp",
-            "encode_etc1s_blocks_by_pixel": "encode_etc1s_blocks",
+            "encode_etc1s_blocks_by_pixel": "encode_etc1s_blocks", "refine_sorted": "refine_endpoint_clusterization",
             "find_optimal_selector_clusters": "find_optimal_selector_clusters"}.get(n, n)
 
 
