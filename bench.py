@@ -251,6 +251,9 @@ def main():
         out["host_gap_ms"] = round(elapsed / args.steps * 1e3 - sum(v[0] for v in kernels.values()) / args.steps, 2)
         if roofline:
             roofline["traffic"] = pmc_traffic(roofline["kernel"])
+        valu = valu_bound(out["kernels_ms_per_step"])
+        if valu:
+            out["valu_bound"] = valu
         if world == 1:  # what follows the hot path on the host: the ETC1S backend on the frontend just timed
             out["backend"] = backend_bench(last, w, h, args, elapsed / args.steps)
         if not args.no_cpu_baseline and world == 1:  # the CPU baseline and the secondary workloads are N=1 measurements
@@ -289,6 +292,19 @@ def pmc_traffic(kernel):
         return None
     rec = json.loads(f.read_text()).get(kernel)
     return None if not rec else int(rec["fetch_bytes_per_launch"] + rec["write_bytes_per_launch"])
+
+
+def valu_bound(kernels_ms):
+    """The per-block ETC1S kernels are bound by VALU instruction issue, not by HBM or the matrix cores: for the kernels of this
+    step that the committed SQ counter pass covers (profiles/valu_busy.json, written by tools/valu_table.py --json from a separate rocprofv3 --pmc run of this
+    same command), the share of all SIMD cycles in which a VALU instruction was executing, next to this run's own launch time."""
+    f = ROOT / "profiles" / "valu_busy.json"
+    if not f.exists():
+        return None
+    rec = json.loads(f.read_text())
+    rows = {k: {"ms_this_run": kernels_ms[k], "valu_busy_frac": v["valu_busy_frac"], "valu_instructions_per_launch": v["valu_instructions_per_launch"]}
+            for k, v in rec.items() if k in kernels_ms}
+    return {"kernels": rows, "ceiling": rec.get("_meta", {}).get("ceiling"), "source": "profiles/valu_busy.json"} if rows else None
 
 
 MFMA_F16_PEAK_TFLOPS = 2500.0  # dense, /opt/skills/guides/MI355X_MICROARCH.md
