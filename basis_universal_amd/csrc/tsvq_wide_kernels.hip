@@ -13,7 +13,8 @@
 //                               (fsum_scan.h: inside a binade a float add is k -> k + d[k & 1] on the significand)
 //   k_wide_walk      per chain: one wave composes 64 blocks' maps at a time (prefix scan), applies the longest valid prefix to
 //                               the running sum, and adds the members of a block one by one only where a map does not apply
-//                               (binade crossings, a few dozen per chain)
+//                               (binade crossings; stretches of those are taken block by block with the next blocks' members in
+//                               flight). Integer-valued chains start behind the blocks whose running sum is <= 2^24 (exact)
 //   k_wide_finish    per node:  the serial tail of the pass (centroids, variances, convergence test; PCA after the covariance pass)
 //   k_wide_partition per block: the children's member lists (stable partition) + the result record
 //
