@@ -915,11 +915,12 @@ int bu_hip_tsvq_split(bu_hip_context* ctx, bu_tsvq* q, const bu_tsvq_node* h_nod
     // (narrow records first, in batch order, then the wide ones).
     std::vector<uint32_t> order; order.reserve(n_nodes);
     uint32_t n_wide = 0, wide_blocks = 0, wide_max_count = 0;
+    uint64_t wide_max_weight = 0;   // chain addends are value (0..3) x weight: 3 x a node's weight bounds every side chain's total
     if (q->wide_min) {
         std::vector<uint32_t> wide;
         for (uint32_t i = 0; i < n_nodes; i++) {
             const uint32_t nb = (h_nodes[i].count + 255) / 256;
-            if (h_nodes[i].count >= q->wide_min && wide.size() < q->wide_nodes_cap && wide_blocks + nb <= q->wide_blocks_cap) { wide.push_back(i); wide_blocks += nb; wide_max_count = std::max(wide_max_count, h_nodes[i].count); }
+            if (h_nodes[i].count >= q->wide_min && wide.size() < q->wide_nodes_cap && wide_blocks + nb <= q->wide_blocks_cap) { wide.push_back(i); wide_blocks += nb; wide_max_count = std::max(wide_max_count, h_nodes[i].count); wide_max_weight = std::max<uint64_t>(wide_max_weight, h_nodes[i].weight); }
             else order.push_back(i);
         }
         n_wide = (uint32_t)wide.size();
@@ -963,7 +964,8 @@ int bu_hip_tsvq_split(bu_hip_context* ctx, bu_tsvq* q, const bu_tsvq_node* h_nod
     if (n_wide) {
         prof_scope ps(ctx, "tsvq_split_packed16_wide");
         BU_TRY(ctx, bu::launch_tsvq_wide_split(ctx->stream, static_cast<const uint32_t*>(q->rows), q->w64, q->perm[0], q->perm[1], q->side, q->wide_packed, q->wide_nodes, n_wide, q->wide_ctrl,
-                                               q->wide_ws, wide_blocks, static_cast<bu::tsvq_split_out*>(q->outs.p), wide_max_count < q->wide_cov_min));
+                                               q->wide_ws, wide_blocks, static_cast<bu::tsvq_split_out*>(q->outs.p), wide_max_count < q->wide_cov_min,
+                                               wide_max_weight * 3ull < (1ull << 24)));
     }
     if (n_wide && std::getenv("BU_TSVQ_STATS")) {   // development aid: how the last pass's walks went, per wide node
         std::vector<bu::tsvq_wide_ctrl> hc(n_wide);

@@ -48,6 +48,7 @@ hipError_t launch_tsvq_wide_root(hipStream_t st, const uint32_t* d_keys, const u
                                  const tsvq_wide_node* d_nodes /* one node: all n vectors */, tsvq_wide_ctrl* d_ctrl, void* d_ws, uint32_t total_blocks, tsvq_root_out* d_out);
 hipError_t launch_tsvq_wide_split(hipStream_t st, const uint32_t* d_keys, const uint64_t* d_w64, uint32_t* d_perm0, uint32_t* d_perm1, uint8_t* d_side, void* d_packed /* 8 bytes per vector */,
                                   const tsvq_wide_node* d_nodes, uint32_t n_nodes, tsvq_wide_ctrl* d_ctrl, void* d_ws, uint32_t total_blocks, tsvq_split_out* d_outs,
-                                  bool chained_covariance /* the covariance pass through launch_tsvq_cov_axis instead of 136 walks per node */);
+                                  bool chained_covariance /* the covariance pass through launch_tsvq_cov_axis instead of 136 walks per node */,
+                                  bool side_chains_exact /* 3 x the heaviest node's weight < 2^24: every projection / two-means chain total is exact, no maps needed */);
 
 } // namespace bu

@@ -802,12 +802,14 @@ size_t tsvq_wide_workspace_bytes(uint32_t total_blocks) {
 
 template <int MODE>
 static void launch_pass(hipStream_t st, const uint32_t* keys, const uint64_t* w64, uint32_t* perm0, uint32_t* perm1, uint8_t* side, uint2* pk, const tsvq_wide_node* nodes,
-                        uint32_t n_nodes, uint32_t tb, tsvq_wide_ctrl* ctrl, void* ws, tsvq_root_out* root_out) {
+                        uint32_t n_nodes, uint32_t tb, tsvq_wide_ctrl* ctrl, void* ws, tsvq_root_out* root_out, bool all_chains_exact = false) {
     constexpr int NCH = mode_traits<MODE>::NCH;
     hipLaunchKernelGGL((k_wide_sums<MODE>), dim3(tb), dim3(WB), 0, st, keys, w64, perm0, perm1, side, nodes, n_nodes, ctrl, ws, tb, pk);
     hipLaunchKernelGGL((k_wide_scan<MODE>), dim3(n_nodes, (NCH + 3) / 4 + (MODE == WM_COV ? 0 : 1)), dim3(256), 0, st, nodes, ctrl, ws, tb);
-    hipLaunchKernelGGL((k_wide_stretches<MODE>), dim3(tb), dim3(ST_THREADS), 0, st, keys, w64, pk, side, nodes, n_nodes, ctrl, ws, tb);
-    hipLaunchKernelGGL((k_wide_walk<MODE>), dim3(n_nodes * NCH), dim3(64), 0, st, keys, w64, pk, side, nodes, ctrl, ws, tb);
+    if (!(all_chains_exact && MODE != WM_COV)) {   // the caller knows that every chain total of the batch stays below 2^24: the scan finishes them all
+        hipLaunchKernelGGL((k_wide_stretches<MODE>), dim3(tb), dim3(ST_THREADS), 0, st, keys, w64, pk, side, nodes, n_nodes, ctrl, ws, tb);
+        hipLaunchKernelGGL((k_wide_walk<MODE>), dim3(n_nodes * NCH), dim3(64), 0, st, keys, w64, pk, side, nodes, ctrl, ws, tb);
+    }
     hipLaunchKernelGGL((k_wide_finish<MODE>), dim3(n_nodes), dim3(64), 0, st, nodes, ctrl, root_out);
 }
 
@@ -822,14 +824,14 @@ hipError_t launch_tsvq_wide_root(hipStream_t st, const uint32_t* d_keys, const u
 
 hipError_t launch_tsvq_wide_split(hipStream_t st, const uint32_t* d_keys, const uint64_t* d_w64, uint32_t* d_perm0, uint32_t* d_perm1, uint8_t* d_side, void* d_packed,
                                   const tsvq_wide_node* d_nodes, uint32_t n_nodes, tsvq_wide_ctrl* d_ctrl, void* d_ws, uint32_t total_blocks, tsvq_split_out* d_outs,
-                                  bool chained_covariance) {
+                                  bool chained_covariance, bool side_chains_exact) {
     if (!n_nodes) return hipSuccess;
     hipError_t e = hipMemsetAsync(d_ctrl, 0, (size_t)n_nodes * sizeof(tsvq_wide_ctrl), st);
     if (e != hipSuccess) return e;
     if (chained_covariance) { if ((e = launch_tsvq_cov_axis(st, d_keys, d_w64, d_perm0, d_perm1, d_nodes, n_nodes, d_ctrl, d_packed)) != hipSuccess) return e; }
     else launch_pass<WM_COV>(st, d_keys, d_w64, d_perm0, d_perm1, d_side, static_cast<uint2*>(d_packed), d_nodes, n_nodes, total_blocks, d_ctrl, d_ws, nullptr);
-    launch_pass<WM_PROJ>(st, d_keys, d_w64, d_perm0, d_perm1, d_side, static_cast<uint2*>(d_packed), d_nodes, n_nodes, total_blocks, d_ctrl, d_ws, nullptr);
-    for (int it = 0; it < 6; it++) launch_pass<WM_DIST>(st, d_keys, d_w64, d_perm0, d_perm1, d_side, static_cast<uint2*>(d_packed), d_nodes, n_nodes, total_blocks, d_ctrl, d_ws, nullptr);
+    launch_pass<WM_PROJ>(st, d_keys, d_w64, d_perm0, d_perm1, d_side, static_cast<uint2*>(d_packed), d_nodes, n_nodes, total_blocks, d_ctrl, d_ws, nullptr, side_chains_exact);
+    for (int it = 0; it < 6; it++) launch_pass<WM_DIST>(st, d_keys, d_w64, d_perm0, d_perm1, d_side, static_cast<uint2*>(d_packed), d_nodes, n_nodes, total_blocks, d_ctrl, d_ws, nullptr, side_chains_exact);
     hipLaunchKernelGGL(k_wide_partition, dim3(total_blocks), dim3(WB), 0, st, d_perm0, d_perm1, d_side, d_nodes, n_nodes, d_ctrl, d_ws, total_blocks, d_outs);
     return hipGetLastError();
 }
