@@ -115,7 +115,8 @@ __global__ void __launch_bounds__(256) k_exchange_children(uint32_t* __restrict_
     }
 }
 
-__global__ void __launch_bounds__(256) k_gather_u32(const uint32_t* __restrict__ table, const uint32_t* __restrict__ index, uint32_t n, uint32_t* __restrict__ out) {
+// `index` and `out` may be the same array (bu_hip_kmeans_codebook gathers in place): every thread reads and writes its own element only, so neither is __restrict__
+__global__ void __launch_bounds__(256) k_gather_u32(const uint32_t* __restrict__ table, const uint32_t* index, uint32_t n, uint32_t* out) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i < n) out[i] = table[index[i]];
 }

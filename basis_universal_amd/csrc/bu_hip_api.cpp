@@ -954,7 +954,11 @@ int bu_hip_tsvq_split(bu_hip_context* ctx, bu_tsvq* q, const bu_tsvq_node* h_nod
         if (hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ctx->side_fork, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&ctx->side_join, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); narrow_on_side = false; }
     }
+    // From the fork on, every early return must wait for the side stream first: the caller's guard destroys q (its buffers go back to the
+    // pool without a synchronisation) while the one-workgroup kernel may still be running on them.
+    struct side_joiner { hipStream_t s; bool armed; ~side_joiner() { if (armed) (void)hipStreamSynchronize(s); } } side_join_guard{ctx->side_stream, false};
     if (narrow_on_side) {
+        side_join_guard.s = ctx->side_stream; side_join_guard.armed = true;
         BU_TRY(ctx, hipEventRecord(ctx->side_fork, ctx->stream));
         BU_TRY(ctx, hipStreamWaitEvent(ctx->side_stream, ctx->side_fork, 0));
         BU_TRY(ctx, bu::launch_tsvq_split(ctx->side_stream, (int)q->dim, q->packed, exact, q->rows, q->w64, q->perm[0], q->perm[1], q->side,
@@ -984,7 +988,7 @@ int bu_hip_tsvq_split(bu_hip_context* ctx, bu_tsvq* q, const bu_tsvq_node* h_nod
                 if (cts) std::fprintf(stderr, "[tsvq stats]      covariance pass, 136 chains: scans max %u avg %.1f, raw blocks max %u avg %.1f (diagonal avg %.1f)\n", cms, cts / 136.0, cmr, ctr / 136.0, diag_r / 16.0);
             }
     }
-    if (narrow_on_side) BU_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->side_join, 0));
+    if (narrow_on_side) { BU_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->side_join, 0)); side_join_guard.armed = false; }
     else if (n_narrow) {
         prof_scope ps(ctx, q->packed ? "tsvq_split_packed16" : "tsvq_split_float6");
         BU_TRY(ctx, bu::launch_tsvq_split(ctx->stream, (int)q->dim, q->packed, exact, q->rows, q->w64, q->perm[0], q->perm[1], q->side,

@@ -223,7 +223,7 @@ uint64_t bu_backend_get(bu_backend* b, const char* name, uint32_t slice, void* b
     if (n == "endpoint_remap_old_to_new") return emit(b->be.endpoint_remap_old_to_new(), buf, cap);
     if (n == "selector_remap_new_to_old") return emit(b->be.selector_remap_new_to_old(), buf, cap);
     return ~0ull;
-} BU_CATCH(0)
+} BU_CATCH(~0ull)
 
 uint32_t bu_backend_stage_times(const bu_backend* b, const char** names, double* seconds, uint32_t cap) try {
     if (!b) return 0;

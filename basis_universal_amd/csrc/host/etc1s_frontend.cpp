@@ -287,7 +287,7 @@ bool etc1s_frontend::compress() {
             if (!refined) break;  // frontend.cpp:283-286
         }
     }
-    BU_STAGE_V("optimize_selector_codebook", optimize_selector_codebook());
+    BU_STAGE("optimize_selector_codebook", optimize_selector_codebook());
     BU_STAGE_V("finalize", finalize());
 #undef BU_STAGE
 #undef BU_STAGE_V
@@ -498,6 +498,7 @@ void etc1s_frontend::compute_endpoint_clusters_within_each_parent_cluster() {
     if (!ensure_endpoint_map_device() || !d.reserve(d.flags, parents * clusters + 8) ||
         !bu_hip_k_map_membership(d.ctx, (const uint8_t*)d.ep_parent.p, (const uint32_t*)d.block_cluster.p, m_total_blocks, (uint32_t)parents, (uint32_t)clusters, (uint8_t*)d.flags.p) ||
         !d.download(member.data(), d.flags, member.size())) {
+        m_endpoint_clusters_within_each_parent_cluster.clear();   // the size check of refine_endpoint_clusterization fires on this
         fail("compute_endpoint_clusters_within_each_parent_cluster");
         return;
     }
@@ -958,6 +959,7 @@ void etc1s_frontend::compute_selector_clusters_within_each_parent_cluster() {
     if (!ensure_selector_map_device() || !d.reserve(d.flags, parents * clusters + 8) ||
         !bu_hip_k_map_membership(d.ctx, (const uint8_t*)d.sel_parent.p, (const uint32_t*)d.sel_cluster.p, m_total_blocks, (uint32_t)parents, (uint32_t)clusters, (uint8_t*)d.flags.p) ||
         !d.download(member.data(), d.flags, member.size())) {
+        m_selector_clusters_within_each_parent_cluster.clear();   // find_optimal_selector_clusters_for_each_block checks the size
         fail("compute_selector_clusters_within_each_parent_cluster");
         return;
     }
@@ -1069,6 +1071,7 @@ bool etc1s_frontend::find_optimal_selector_clusters_for_each_block() {
     device_state& d = *m_dev;
     uint32_t n_parents = 0;
     if (m_use_hierarchical_selector_codebooks) {
+        if (m_selector_clusters_within_each_parent_cluster.size() != m_selector_parent_count) return fail("selector parent lists missing (the membership pass failed)");
         csr cand; cand.build(m_selector_clusters_within_each_parent_cluster);
         n_parents = (uint32_t)m_selector_clusters_within_each_parent_cluster.size();
         if (!d.upload(d.cand_offsets, cand.offsets.data(), cand.offsets.size()) || !d.upload(d.cand_indices, cand.indices.data(), cand.indices.size()))
@@ -1148,7 +1151,8 @@ bool etc1s_frontend::introduce_special_selector_clusters() {
 }
 
 // frontend.cpp:657-731: drop unused entries and merge entries with identical selector bits (first occurrence keeps its place)
-void etc1s_frontend::optimize_selector_codebook() {
+bool etc1s_frontend::optimize_selector_codebook() {
+    bool remap_failed = false;
     const uint32_t k = (uint32_t)m_optimized_cluster_selectors.size(), n = m_total_blocks;
     std::vector<uint8_t> used(k, 0);
     device_state& d = *m_dev;
@@ -1193,8 +1197,15 @@ void etc1s_frontend::optimize_selector_codebook() {
         for (uint32_t i = 0; i < k; i++) remap[i] = (uint32_t)old_to_new[i];
         if (!d.upload(d.tmp_a, remap.data(), k) || !bu_hip_k_map_remap(d.ctx, (uint32_t*)d.sel_cluster.p, nullptr, n, (const uint32_t*)d.tmp_a.p, nullptr)) {
             fail("bu_hip_k_map_remap");
-            ensure_selector_map_host();   // keep a consistent state on the host at least
+            // keep a consistent state on the host at least: a map downloaded now is still in the OLD numbering (a host copy that was
+            // valid before has been renumbered above)
+            if (!m_sel_host_valid) {
+                ensure_selector_map_host();
+                if (m_sel_host_valid)
+                    for (uint32_t b = 0; b < n; b++) m_block_selector_cluster_index[b] = (uint32_t)old_to_new[m_block_selector_cluster_index[b]];
+            }
             m_sel_dev_valid = false;
+            remap_failed = true;
         }
     }
     std::vector<bu_etc_block> sels(new_to_old.size());
@@ -1204,6 +1215,7 @@ void etc1s_frontend::optimize_selector_codebook() {
     m_selector_lists_valid = false;
     for (auto& l : m_selector_clusters_within_each_parent_cluster)
         for (uint32_t& c : l) c = (uint32_t)old_to_new[c];
+    return !remap_failed;
 }
 
 // frontend.cpp:2980-2992

@@ -109,7 +109,7 @@ public:
     bool find_optimal_selector_clusters_for_each_block();
     bool introduce_special_selector_clusters();
     bool refine_block_endpoints_given_selectors(uint32_t* total_refined);
-    void optimize_selector_codebook();
+    bool optimize_selector_codebook();
     void finalize();
 
 private:

@@ -112,7 +112,7 @@ int bu_frontend_call(bu_frontend* f, const char* stage, uint32_t arg) try {
     if (n == "find_optimal_selector_clusters_for_each_block") return fe.find_optimal_selector_clusters_for_each_block();
     if (n == "introduce_special_selector_clusters") return fe.introduce_special_selector_clusters();
     if (n == "refine_block_endpoints_given_selectors") { uint32_t refined = 0; return fe.refine_block_endpoints_given_selectors(&refined); }
-    if (n == "optimize_selector_codebook") { fe.optimize_selector_codebook(); return 1; }
+    if (n == "optimize_selector_codebook") return fe.optimize_selector_codebook();
     if (n == "finalize") { fe.finalize(); return 1; }
     return 0;
 } BU_CATCH(0)
@@ -140,7 +140,7 @@ uint64_t bu_frontend_get(bu_frontend* f, const char* name, void* buf, uint64_t c
         return emit(v, buf, cap);
     }
     return ~0ull;
-} BU_CATCH(0)
+} BU_CATCH(~0ull)
 
 int bu_frontend_reoptimize_remapped_endpoints(bu_frontend* f, const uint32_t* new_block_endpoints, uint32_t total_blocks, int32_t* old_to_new, uint32_t old_to_new_count,
                                               int optimize_final_codebook, const uint32_t* block_selector_indices) try {

@@ -149,6 +149,7 @@ class RcclComm:
 
     def __init__(self, ctx, group=None):
         import torch.distributed as dist
+        self.h = None   # close() / __del__ are safe however far __init__ got
         self.L = load_rccl_library()
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
         ident = C.create_string_buffer(128)
@@ -164,12 +165,15 @@ class RcclComm:
         self.error = ""
 
     def close(self):
-        if self.h:
+        if getattr(self, "h", None):
             self.L.bu_rccl_comm_destroy(self.h)
             self.h = None
 
     def __del__(self):
-        self.close()
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class Etc1sFrontend:

@@ -8,3 +8,8 @@ namespace basisu { class basisu_frontend; }
 // The bu_frontend that basisu_frontend::compress() ran on (nullptr: none). Owned by the registry: destroyed when the same
 // basisu_frontend object is initialised again, and at process exit.
 bu_frontend* bu_resident_handle(const basisu::basisu_frontend* fe);
+
+// Ends the resident state behind `fe` (device buffers back to the context's pool, registry entry erased). The reference's classes have no
+// destructor hook, so the host calls this when it is done: basisu_resident_backend.cpp does at the end of basisu_backend::encode(), after
+// which the basisu_frontend object still serves its getters from its own host members.
+void bu_resident_release(const basisu::basisu_frontend* fe);

@@ -79,6 +79,8 @@ uint32_t basisu_backend::encode() {
     if (!fetch("slice_image_crcs", 0, crcs) || crcs.size() != m_slices.size() * 2) return 0;
     m_output.m_slice_image_crcs.resize(m_slices.size());
     if (!crcs.empty()) memcpy(m_output.m_slice_image_crcs.data(), crcs.data(), crcs.size());
+    g.b = nullptr; bu_backend_destroy(be);   // the backend reads the frontend: it goes first
+    bu_resident_release(m_pFront_end);       // nothing after encode() needs the device state (the getters read the object's host members)
     return total;
 }
 

@@ -21,24 +21,38 @@
 namespace {
 
 struct registry {
+    // One entry per live basisu_frontend object. The reference class has no destructor hook, so an entry ends in one of three ways: the same
+    // object is init()ed again, init() fails (erased at once), or the backend is done with it (bu_resident_release at the end of
+    // basisu_backend::encode). `blocks` is the per-init token: a basisu_frontend constructed at a recycled address whose init() never ran or
+    // failed cannot resolve to the previous object's state, because find() is given the caller's own m_total_blocks.
+    struct entry { bu_frontend* f; uint32_t blocks; };
     std::mutex lock;
-    std::unordered_map<const basisu::basisu_frontend*, bu_frontend*> map;
+    std::unordered_map<const basisu::basisu_frontend*, entry> map;
     bu_hip_context* own_ctx = nullptr;   // used when the caller did not ask for the accelerator seam (no -opencl): the resident build always runs on the GPU
     ~registry() {
-        for (auto& kv : map) bu_frontend_destroy(kv.second);
+        for (auto& kv : map) bu_frontend_destroy(kv.second.f);
         if (own_ctx) bu_hip_destroy_context(own_ctx);
     }
-    bu_frontend* fresh(const basisu::basisu_frontend* key) {
+    bu_frontend* fresh(const basisu::basisu_frontend* key, uint32_t blocks) {
         std::lock_guard<std::mutex> g(lock);
-        bu_frontend*& slot = map[key];
-        if (slot) bu_frontend_destroy(slot);
-        slot = bu_frontend_create();
-        return slot;
+        entry& slot = map[key];
+        if (slot.f) bu_frontend_destroy(slot.f);
+        slot.f = bu_frontend_create();
+        slot.blocks = blocks;
+        if (!slot.f) { map.erase(key); return nullptr; }
+        return slot.f;
     }
-    bu_frontend* find(const basisu::basisu_frontend* key) {
+    bu_frontend* find(const basisu::basisu_frontend* key, uint32_t blocks) {
         std::lock_guard<std::mutex> g(lock);
         auto it = map.find(key);
-        return it == map.end() ? nullptr : it->second;
+        return (it == map.end() || it->second.blocks != blocks) ? nullptr : it->second.f;
+    }
+    void release(const basisu::basisu_frontend* key) {
+        std::lock_guard<std::mutex> g(lock);
+        auto it = map.find(key);
+        if (it == map.end()) return;
+        bu_frontend_destroy(it->second.f);   // gives the device buffers back
+        map.erase(it);
     }
     bu_hip_context* context() {
         std::lock_guard<std::mutex> g(lock);
@@ -57,7 +71,8 @@ template <typename T> bool fetch(bu_frontend* f, const char* name, std::vector<T
 
 } // namespace
 
-bu_frontend* bu_resident_handle(const basisu::basisu_frontend* fe) { return reg().find(fe); }
+bu_frontend* bu_resident_handle(const basisu::basisu_frontend* fe) { return fe ? reg().find(fe, fe->get_total_output_blocks()) : nullptr; }
+void bu_resident_release(const basisu::basisu_frontend* fe) { if (fe) reg().release(fe); }
 
 namespace basisu {
 
@@ -79,13 +94,14 @@ bool basisu_frontend::init(const params& p) {
 
     bu_hip_context* ctx = p.m_pOpenCL_context ? p.m_pOpenCL_context->h : reg().context();
     if (!ctx) { error_printf("basisu_frontend (resident): no HIP context\n"); return false; }
-    bu_frontend* f = reg().fresh(this);
+    bu_frontend* f = reg().fresh(this, m_total_blocks);
     if (!f) return false;
     static_assert(sizeof(pixel_block) == sizeof(bu_pixel_block) && sizeof(etc_block) == sizeof(bu_etc_block), "layout");
     bu_frontend_set_video(f, p.m_tex_type == basist::cBASISTexTypeVideoFrames);
     if (!bu_frontend_init(f, ctx, reinterpret_cast<const bu_pixel_block*>(m_source_blocks.data()), nullptr, p.m_num_source_blocks, p.m_max_endpoint_clusters,
                           p.m_max_selector_clusters, p.m_compression_level, p.m_perceptual)) {
         error_printf("basisu_frontend (resident): init failed: %s\n", bu_frontend_error(f));
+        reg().release(this);   // a later compress() / backend on this object finds nothing instead of a half-initialised frontend
         return false;
     }
     return true;
@@ -121,7 +137,7 @@ static bool refresh_members(bu_frontend* f, uint32_t n, etc_block_vec& encoded, 
 }
 
 bool basisu_frontend::compress() {
-    bu_frontend* f = reg().find(this);
+    bu_frontend* f = reg().find(this, m_total_blocks);
     if (!f) return false;
     if (!bu_frontend_compress(f)) {
         error_printf("basisu_frontend (resident): compress failed: %s\n", bu_frontend_error(f));
@@ -154,7 +170,7 @@ bool basisu_frontend::compress() {
 
 void basisu_frontend::reoptimize_remapped_endpoints(const uint_vec& new_block_endpoints, int_vec& old_to_new_endpoint_cluster_indices, bool optimize_final_codebook,
                                                     uint_vec* pBlock_selector_indices) {
-    bu_frontend* f = reg().find(this);
+    bu_frontend* f = reg().find(this, m_total_blocks);
     const uint32_t k = (uint32_t)m_endpoint_cluster_etc_params.size();
     old_to_new_endpoint_cluster_indices.resize(k);
     if (!f || new_block_endpoints.size() != m_total_blocks ||
