@@ -38,6 +38,19 @@ KERNEL_BYTES_PER_BLOCK = {
 }
 
 
+# profile label -> the one kernel it times (csrc/etc1s_kernels.hip); every other label of a step spans several launches
+KERNEL_SYMBOL = {
+    "encode_etc1s_blocks": "k_encode_etc1s_blocks_by_pixel",
+    "generate_endpoint_codebook": "k_generate_endpoint_codebook",
+    "refine_endpoint_clusterization": "k_refine_sort_lists + k_refine_sorted",
+    "determine_selectors": "k_determine_selectors",
+    "create_optimized_selector_codebook": "k_cosc_accumulate + k_cosc_select",
+    "find_optimal_selector_clusters": "k_find_optimal_selector_clusters",
+    "selector_training_vectors": "k_selector_training_vectors",
+    "endpoint_training_vectors": "k_endpoint_training_vectors",
+}
+
+
 def host_cpus():
     """CPUs this process may really use: the cgroup quota if there is one, else the affinity mask."""
     try:
@@ -64,6 +77,7 @@ def main():
                     "basis_parallel_compress); the default 1 is what the headline number uses")
     ap.add_argument("--no-pipelined", action="store_true", help="skip the additional 3-images-in-flight throughput measurement")
     ap.add_argument("--no-uastc", action="store_true", help="skip the secondary UASTC level-2 measurement (BASELINE config #3)")
+    ap.add_argument("--no-big", action="store_true", help="skip the secondary 8192x8192 -q255 measurement (BASELINE config #4's single-GPU form)")
     ap.add_argument("--no-fast", action="store_true", help="skip the secondary measurement of the codebook builders' fast mode (SURVEY 8f row f3, not bit-identical)")
     args = ap.parse_args()
 
@@ -209,24 +223,31 @@ def main():
     if rank == 0:
         mpix = (1 if sharded else world) * args.steps * (w * h) / 1e6
         value = mpix / elapsed
-        # ---- roofline of the dominant kernel
-        dom = max(kernels.items(), key=lambda kv: kv[1][0]) if kernels else None
+        # ---- roofline of the dominant KERNEL: the profile labels that are one kernel launch each (the tsvq_* / unique_* / map_* labels cover many launches
+        #      of several kernels -- a codebook build is reported as a stage below, not as a kernel)
+        single = {k: v for k, v in kernels.items() if k in KERNEL_SYMBOL}
+        dom = max(single.items(), key=lambda kv: kv[1][0]) if single else None
         roofline = None
         if dom:
             name, (ms, launches) = dom
             avg_s = ms / 1e3 / launches
-            if name.startswith("tsvq"):
-                # the selector TSVQ streams the distinct selector vectors (4 B packed key + 8 B weight) once per pass; a launch covers
-                # one tree level, i.e. every vector once: 12 B x distinct vectors is the floor for a launch
-                enc = last.get("orig_encoded_blocks", np.uint8).reshape(-1, 8)
-                alg_bytes = 12 * int(np.unique(np.ascontiguousarray(enc[:, 4:]).view(np.uint32)).size)
-            else:
-                alg_bytes = KERNEL_BYTES_PER_BLOCK.get(name, 64) * n_blocks
+            alg_bytes = KERNEL_BYTES_PER_BLOCK.get(name, 64) * n_blocks
             achieved = alg_bytes / avg_s / 1e9
-            roofline = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            roofline = {"bound": "hbm", "kernel": name, "kernel_symbol": KERNEL_SYMBOL[name], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
                         "avg_launch_ms": round(avg_s * 1e3, 4), "algorithmic_bytes_per_launch": alg_bytes,
-                        "note": "integer-ALU bound kernel: see DESIGN.md for the VALU-side analysis"}
+                        "note": "integer-ALU bound kernel (SURVEY 8d expected it): the bound that applies is VALU issue, see valu_bound and DESIGN.md section 4"}
+        # the whole step against SURVEY 8d's figure: 443 algorithmic bytes per block over the step's wall time
+        step_s = elapsed / args.steps
+        step_roofline = {"bound": "hbm", "algorithmic_bytes_per_step": 443 * n_blocks, "achieved": round(443 * n_blocks / step_s / 1e9 / (1 if sharded else 1), 2), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(443 * n_blocks / step_s / 1e9 / HBM_PEAK_GBS, 5)}
+        # the heaviest multi-launch stage (a TSVQ codebook build), by label
+        stages_multi = {k: v for k, v in kernels.items() if k not in KERNEL_SYMBOL}
+        dom_stage = None
+        if stages_multi:
+            k, (ms, launches) = max(stages_multi.items(), key=lambda kv: kv[1][0])
+            dom_stage = {"label": k, "ms_per_step": round(ms / args.steps, 3), "timed_regions_per_step": round(launches / args.steps, 1),
+                         "note": "a profile label over many kernel launches (not a kernel): device time between the HIP events around the region"}
         final_ep = int(last.get("endpoint_clusters", np.uint32)[0])
         final_sel = int(last.get("selector_cluster_block_indices", np.uint32)[0])
         out = {
@@ -241,6 +262,8 @@ def main():
                        "parallelism": (f"one image sharded over {world} GPUs: block-row slabs + cluster shares, RCCL all_gather / all_reduce between stages, TSVQ replicated"
                                        if sharded else f"{world} x one image per GPU (no collective)")},
             "roofline": roofline,
+            "step_roofline": step_roofline,
+            "dominant_stage": dom_stage,
             "pipelined": pipelined,
             "pipelined_with_backend": whole_encoder,
             "host_cpu_s_per_step": round(host_cpu_s, 4),
@@ -254,8 +277,11 @@ def main():
         valu = valu_bound(out["kernels_ms_per_step"])
         if valu:
             out["valu_bound"] = valu
+        # BASELINE's metric is "Mpixels/s + output PSNR": the texture the step's output decodes to against the source image
+        out["psnr"] = dict(frontend_psnr(last, img), of="the ETC1 texture the frontend's output blocks decode to; the file's (after the backend's RDO) is backend.psnr",
+                           semantics="image_metrics::calc, enc.cpp:2155-2226: RGB / RGBA average over channels, dB")
         if world == 1:  # what follows the hot path on the host: the ETC1S backend on the frontend just timed
-            out["backend"] = backend_bench(last, w, h, args, elapsed / args.steps)
+            out["backend"] = backend_bench(last, w, h, args, elapsed / args.steps, img)
         if not args.no_cpu_baseline and world == 1:  # the CPU baseline and the secondary workloads are N=1 measurements
             out["cpu_baseline"] = cpu_baseline(helpers, args)
             if helpers.have_ref():
@@ -269,18 +295,112 @@ def main():
         if "backend" in out:
             out["backend"].pop("sha256", None)
         if world == 1:
+            out["h2d_inclusive"] = h2d_inclusive_bench(ctx, blocks, n_blocks, w, h, max_ep, max_sel, args)
             out["mipmaps"] = mip_bench(ctx, img)
         if not args.no_uastc and world == 1:
             out["uastc"] = uastc_bench(ctx, d_blocks, n_blocks, w, h, helpers, args)
         if not args.no_fast and world == 1:
             out["fast_codebooks"] = fast_codebooks_bench(ctx, d_blocks, n_blocks, w, h, max_ep, max_sel, args)
             out["uastc_rdo"] = uastc_rdo_bench(ctx, helpers, args)
+        if not args.no_big and world == 1 and args.size == 4096:
+            out["etc1s_8192_q255"] = etc1s_8192_bench(ctx, helpers, args)
         print(json.dumps(out))
     if last is not None:
         last.close()
     ctx.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def psnr_pair(decoded_rgb, img):
+    """image_metrics::calc (encoder/basisu_enc.cpp:2155-2226) as basis_compressor calls it for its m_basis_rgb / rgba_avg_psnr stats (comp.cpp:4210-4221):
+    mean squared error over the 3 / 4 channels (the decoded ETC1 texture has alpha 255), 20 log10(255 / rms), clamped to 100 dB."""
+    import helpers
+    h, w = img.shape[:2]
+    rgba = np.concatenate([decoded_rgb, np.full((h, w, 1), 255, np.uint8)], axis=2)
+    return round(helpers.psnr(decoded_rgb, img[..., :3]), 4), round(helpers.psnr(rgba, img), 4)
+
+
+def frontend_psnr(fe, img):
+    """PSNR of the texture the frontend's output blocks decode to (its encoded_blocks: endpoint + selector codebook entry of every block)"""
+    import helpers
+    h, w = img.shape[:2]
+    rgb, rgba = psnr_pair(helpers.decode_etc1s_blocks(fe.get("encoded_blocks").reshape(-1, 8), w // 4, h // 4), img)
+    return {"rgb": rgb, "rgba": rgba}
+
+
+def etc1s_8192_bench(ctx, helpers, args):
+    """BASELINE configs[3] in its single-GPU form: 8192x8192 synthetic RGBA (seed 5678), ETC1S -q 255 (8192 / 16128 clusters), level 1, tiles resident.
+    The same full init + compress per step as the headline; the result is compared with the committed digest of the reference's output
+    (tests/golden/etc1s_big_digests.json, tools/gen_golden_big.py), whose single-core seconds are quoted beside it."""
+    import hashlib
+    import torch
+    from basis_universal_amd.etc1s import Etc1sFrontend, quality_to_clusters
+    img = helpers.synth(8192, 8192, 5678)
+    blocks = helpers.to_pixel_blocks(img)
+    n = blocks.shape[0]
+    d = torch.from_numpy(blocks.reshape(n, 64)).cuda()
+    max_ep, max_sel = quality_to_clusters(255, n)
+
+    def step():
+        fe = Etc1sFrontend(ctx)
+        fe.init(d.data_ptr(), max_ep, max_sel, 1, True, n_blocks=n)
+        fe.compress()
+        return fe
+
+    step().close()
+    torch.cuda.synchronize()
+    ctx.profile_enable(True)
+    steps, last = 3, None
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        if last is not None:
+            last.close()
+        last = step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    kern = ctx.profile_read()
+    ctx.profile_enable(False)
+    out = {"workload": "8192x8192 synthetic RGBA (SURVEY 8d recipe, seed 5678), ETC1S -q255 comp_level 1 (8192 / 16128 clusters), init+compress, tiles resident",
+           "value": round(8192 * 8192 / 1e6 / dt, 3), "unit": "Mpixels/s", "ms_per_step": round(dt * 1e3, 2), "steps": steps,
+           "kernels_ms_per_step": {k: round(v[0] / steps, 3) for k, v in kern.items()},
+           "host_gap_ms": round(dt * 1e3 - sum(v[0] for v in kern.values()) / steps, 2), "psnr": frontend_psnr(last, img)}
+    g = ROOT / "tests" / "golden" / "etc1s_big_digests.json"
+    if g.exists():
+        rec = json.loads(g.read_text()).get("synth8192_q255")
+        if rec:
+            out["identical_to_reference"] = hashlib.sha256(np.ascontiguousarray(last.get("encoded_blocks")).tobytes()).hexdigest() == rec["frontend_digests"]["encoded_blocks"]
+            out["reference_frontend_seconds_1_core"] = rec["reference_seconds"]["frontend"]
+            out["speedup_vs_reference_1_core"] = round(rec["reference_seconds"]["frontend"] / dt, 1)
+    last.close()
+    del d
+    torch.cuda.empty_cache()
+    return out
+
+
+def h2d_inclusive_bench(ctx, blocks, n_blocks, w, h, max_ep, max_sel, args):
+    """SURVEY 8d figure (i) as written there -- the hot path INCLUDING the host-to-device transfer of the tiles: every step hands bu_frontend_init a HOST pointer
+    (the boundary the reference's opencl_set_pixel_blocks has), once pageable (what a caller holding a std::vector gives) and once page-locked."""
+    import torch
+    from basis_universal_amd.etc1s import Etc1sFrontend
+    res = {"what": "init (64 B/block H2D inside the step) + compress; the headline `value` starts with the tiles resident", "bytes_per_step": int(n_blocks) * 64}
+    pinned = torch.from_numpy(blocks.reshape(n_blocks, 64)).pin_memory()
+    for name, host in (("pageable", np.ascontiguousarray(blocks).reshape(n_blocks, 64)), ("pinned", pinned.numpy())):
+        def step():
+            fe = Etc1sFrontend(ctx)
+            fe.init(host, max_ep, max_sel, args.level, True)
+            fe.compress()
+            return fe
+        step().close()
+        torch.cuda.synchronize()
+        steps = max(3, min(args.steps, 10))
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step().close()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        res[name] = {"value": round(w * h / 1e6 / dt, 3), "unit": "Mpixels/s", "ms_per_step": round(dt * 1e3, 2), "steps": steps}
+    return res
 
 
 def pmc_traffic(kernel):
@@ -383,6 +503,13 @@ def uastc_bench(ctx, d_blocks, n_blocks, w, h, helpers, args):
            "kernels_ms_per_step": {k: round(v[0] / steps, 3) for k, v in kern.items()},
            "roofline": {"bound": "hbm", "kernel": name, "achieved": round(alg / avg_s / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(alg / avg_s / 1e9 / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(name), "avg_launch_ms": round(avg_s * 1e3, 3)}}
+    # output PSNR over the whole image (the host build of the same core decodes the 1,048,576 blocks)
+    src = d_blocks.cpu().numpy().reshape(-1, 4, 4, 4)
+    res["psnr_rgba"] = round(helpers.psnr(helpers.host_decode_uastc(d_out.cpu().numpy()), src), 4)
+    g = ROOT / "tests" / "golden" / "uastc_big_digests.json"
+    if g.exists() and w == 4096 and h == 4096:
+        import hashlib
+        res["identical_to_reference"] = hashlib.sha256(d_out.cpu().numpy().tobytes()).hexdigest() == json.loads(g.read_text())["synth4096_l2"]["sha256"]
     if not args.no_cpu_baseline and helpers.have_ref():
         sample = d_blocks[:: max(1, n_blocks // 65536)][:65536].cpu().numpy().reshape(-1, 4, 4, 4)
         t0 = time.perf_counter()
@@ -394,16 +521,29 @@ def uastc_bench(ctx, d_blocks, n_blocks, w, h, helpers, args):
 
 
 def uastc_rdo_bench(ctx, helpers, args):
-    """BASELINE config #5 on one GPU: a batch of 24 Kodak-sized (768x512) images through encode_uastc level 2 and uastc_rdo (lambda 1.0,
-    4 strips per image = comp.cpp:2078's min(4, threads)). The batch is one resident array; 96 strips of 6144 blocks walk concurrently,
-    one workgroup each (row a20). One step = encode + RDO of the whole batch."""
+    """BASELINE config #5 on one GPU: the 24 Kodak images (tests/golden/kodak24.npz, the reference's own test_files/kodim01..24) as ONE resident batch through
+    encode_uastc level 2 and uastc_rdo (lambda 1.0, 4 strips per image = comp.cpp:2078's min(4, threads)): 96 strips of 6144 blocks walk
+    concurrently, one workgroup each (row a20). One step = encode + RDO of the whole batch. Every image's output is compared with the sha256 of the
+    reference's (tests/golden/kodak24_digests.json) and its RGBA PSNR is printed (BASELINE: "PSNR-gated vs. reference")."""
+    import hashlib
     import numpy as np
     import torch
     from basis_universal_amd import uastc
-    n_images, iw, ih = 24, 768, 512
-    # half the batch is the noisy SURVEY 8d recipe (RDO finds next to nothing to change at lambda 1), half a low-noise variant whose blocks RDO
-    # rewrites by the thousands -- photographs sit between the two
-    blocks = np.concatenate([helpers.to_pixel_blocks(helpers.synth(iw, ih, 500 + k) if k % 2 == 0 else helpers.synth_smooth(iw, ih, 500 + k)) for k in range(n_images)])
+    n_images = 24
+    npz, dig = ROOT / "tests" / "golden" / "kodak24.npz", ROOT / "tests" / "golden" / "kodak24_digests.json"
+    golden = json.loads(dig.read_text())["images"] if dig.exists() else None
+    if npz.exists():
+        z = np.load(npz)
+        names = sorted(z.files)
+        images = [np.concatenate([z[k], np.full(z[k].shape[:2] + (1,), 255, np.uint8)], axis=2) for k in names]
+        what = "the 24 Kodak images (kodim01..24, 768x512 / 512x768 RGB, alpha 255)"
+    else:   # fixture missing: synthetic stand-ins of the same size, said so in the line
+        names = [f"s{k:02d}" for k in range(n_images)]
+        images = [helpers.synth(768, 512, 500 + k) if k % 2 == 0 else helpers.synth_smooth(768, 512, 500 + k) for k in range(n_images)]
+        what = "24 x 768x512 synthetic RGBA (12 noisy + 12 smooth): tests/golden/kodak24.npz not found"
+    parts = [helpers.to_pixel_blocks(im) for im in images]
+    ofs = np.cumsum([0] + [p.shape[0] for p in parts])
+    blocks = np.concatenate(parts)
     n = blocks.shape[0]
     d_px = torch.from_numpy(blocks.reshape(n, 64)).cuda()
     d_out = torch.empty((n, 16), dtype=torch.uint8, device=d_px.device)
@@ -425,19 +565,32 @@ def uastc_rdo_bench(ctx, helpers, args):
     dt = (time.perf_counter() - t0) / steps
     kern = ctx.profile_read()
     ctx.profile_enable(False)
+    out_blocks = d_out.cpu().numpy()
+    psnrs, same = [], []
+    for i, (name, im) in enumerate(zip(names, images)):
+        mine = out_blocks[ofs[i]:ofs[i + 1]]
+        h, w = im.shape[:2]
+        psnrs.append(helpers.psnr(helpers.host_decode_uastc(mine, w // 4, h // 4), im))
+        if golden and name in golden:
+            same.append(hashlib.sha256(mine.tobytes()).hexdigest() == golden[name]["uastc_l2_rdo1_jobs4"])
     res = {"metric": "UASTC LDR 4x4 level 2 + RDO (lambda 1.0) Mpixels/s", "value": round(n * 16 / 1e6 / dt, 2), "unit": "Mpixels/s",
-           "ms_per_step": round(dt * 1e3, 2), "workload": f"{n_images} x {iw}x{ih} synthetic RGBA (12 noisy + 12 smooth), {jobs} strips of {n // jobs} blocks",
+           "ms_per_step": round(dt * 1e3, 2), "workload": f"{what}, {jobs} strips of {n // jobs} blocks",
            "modified_blocks": int(info["modified"]), "kernels_ms_per_step": {k: round(v[0] / steps, 3) for k, v in kern.items()},
-           "serial_step_us": round(kern["uastc_rdo_strips"][0] / steps * 1e3 / (n // jobs), 3)}
+           "serial_step_us": round(kern["uastc_rdo_strips"][0] / steps * 1e3 / (n // jobs), 3),
+           "psnr_rgba": {"mean": round(float(np.mean(psnrs)), 4), "min": round(float(np.min(psnrs)), 4), "max": round(float(np.max(psnrs)), 4)},
+           "images_identical_to_reference": (f"{sum(same)}/{len(same)}" if same else None)}
+    if golden and same:
+        ref_p = [golden[nm]["uastc_psnr_rgba_rdo1_jobs4"] for nm in names if nm in golden]
+        res["psnr_rgba"]["reference_mean"] = round(float(np.mean(ref_p)), 4)
     if not args.no_cpu_baseline and helpers.have_ref():
-        one = blocks[n // n_images: 2 * (n // n_images)]  # a smooth image: the one RDO works hardest on
+        one = parts[2]  # kodim03
         t0 = time.perf_counter()
         packed = helpers.ref_encode_uastc(one, flags)
         t1 = time.perf_counter()
         helpers.ref_uastc_rdo(packed, one, flags, 0, lam=1.0)
         t2 = time.perf_counter()
         res["cpu_baseline"] = {"value": round(one.shape[0] * 16 / 1e6 / (t2 - t0), 4), "unit": "Mpixels/s", "cores": 1, "kind": "reference",
-                               "sample": f"one {iw}x{ih} (smooth) image of the batch: reference encode_uastc {t1 - t0:.2f} s + uastc_rdo {t2 - t1:.2f} s on one thread (oracle/_ref)"}
+                               "sample": f"one image of the batch ({names[2]}): reference encode_uastc {t1 - t0:.2f} s + uastc_rdo {t2 - t1:.2f} s on one thread (oracle/_ref)"}
     return res
 
 
@@ -469,11 +622,11 @@ def _payload_digest(get):
     return h.hexdigest()
 
 
-def backend_bench(fe, w, h, args, frontend_s):
+def backend_bench(fe, w, h, args, frontend_s, img=None):
     """bu::etc1s_backend (host, one thread) on the finished frontend: endpoint prediction + RDO, selector history RDO, Huffman coding -> the
     compressed payloads of the .basis file. Default basis_compressor thresholds (1.5 / 1.25)."""
     from basis_universal_amd.backend import Etc1sBackend
-    best, n = None, 0
+    best, n, psnr = None, 0, None
     for _ in range(2):  # the first call also fetches the host copy of the resident tiles
         be = Etc1sBackend.from_frontend(fe, [(0, w // 4, h // 4)], 1.5, 1.25, args.level)
         t0 = time.perf_counter()
@@ -482,12 +635,16 @@ def backend_bench(fe, w, h, args, frontend_s):
         best = dt if best is None else min(best, dt)
         digest = _payload_digest(be.get)
         stages = {k: round(v, 4) for k, v in be.stage_times()}
+        if img is not None and psnr is None:
+            import helpers
+            rgb, rgba = psnr_pair(helpers.decode_backend_output(fe, be, w // 4, h // 4), img)
+            psnr = {"rgb": rgb, "rgba": rgba, "of": "the ETC1 texture the .basis file decodes to = basis_compressor's m_basis_rgb / rgba_avg_psnr"}
         be.close()
         if args.level > 1:
             break  # above level 1 the backend changes the frontend: once only
     return {"what": "ETC1S backend on the host after the frontend (1 thread), endpoint/selector RDO thresholds 1.5/1.25", "ms_per_image": round(best * 1e3, 1),
             "compressed_bytes": n, "bits_per_texel": round(n * 8 / (w * h), 3), "stages_s": stages,
-            "frontend_plus_backend_mpix_s": round(w * h / 1e6 / (frontend_s + best), 2), "sha256": digest}
+            "frontend_plus_backend_mpix_s": round(w * h / 1e6 / (frontend_s + best), 2), "psnr": psnr, "sha256": digest}
 
 
 def cpu_baseline(helpers, args):

@@ -442,6 +442,8 @@ def uastc_host():
         L.hc_uastc_rdo.argtypes = [u8p, u8p, C.c_uint32, f32p, u32p, C.c_uint32, C.c_uint32]
         L.hc_rehint.argtypes = [u8p, C.c_uint32, C.c_uint32, u8p]
         L.hc_unpack_block.argtypes = [u8p, u8p]
+        L.hc_decode_uastc.restype = C.c_int
+        L.hc_decode_uastc.argtypes = [u8p, C.c_uint32, u8p]
         L.hc_cell_compress.restype = C.c_uint64
         L.hc_cell_compress.argtypes = [u8p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32, C.c_uint32, u8p]
         L.hc_cell_estimate.restype = C.c_uint64
@@ -506,6 +508,33 @@ def host_encode_uastc(blocks, flags):
     return out
 
 
+def host_decode_uastc(packed, nbx=None, nby=None):
+    """UASTC LDR 4x4 blocks (n, 16) -> texels: (n, 4, 4, 4) u8, or the (nby * 4, nbx * 4, 4) raster when the block grid is given. The host build of the
+    product's own uastc_core.h (unpack + per-texel interpolation); pinned to the reference's unpack_uastc in tests/test_uastc_core_host.py."""
+    packed = np.ascontiguousarray(packed, np.uint8).reshape(-1, 16)
+    out = np.zeros((packed.shape[0], 4, 4, 4), np.uint8)
+    assert uastc_host().hc_decode_uastc(ptr(packed), packed.shape[0], ptr(out)) == 1
+    return out if nbx is None else blocks_to_raster(out, nbx, nby)
+
+
+def blocks_to_raster(texels, nbx, nby):
+    """(n, 4, 4, C) block-raster texels -> (nby * 4, nbx * 4, C)"""
+    c = texels.shape[-1]
+    return texels.reshape(nby, nbx, 4, 4, c).transpose(0, 2, 1, 3, 4).reshape(nby * 4, nbx * 4, c)
+
+
+def ref_decode_uastc(packed):
+    """the reference's unpack_uastc (transcoder/basisu_transcoder.cpp:15743) per block -> (n, 4, 4, 4) u8"""
+    L = ref()
+    L.ref_unpack_uastc.restype = C.c_int
+    L.ref_unpack_uastc.argtypes = [u8p, u8p]
+    packed = np.ascontiguousarray(packed, np.uint8).reshape(-1, 16)
+    out = np.zeros((packed.shape[0], 4, 4, 4), np.uint8)
+    for i in range(packed.shape[0]):
+        assert L.ref_unpack_uastc(ptr(packed[i]), ptr(out[i])) == 1
+    return out
+
+
 def decode_etc1s_blocks(blocks, nbx, nby):
     """ETC1S blocks (n, 8) u8 in block-raster order -> (nby * 4, nbx * 4, 3) u8: differential mode with zero deltas, both sub-blocks share
     colour5 and the intensity table (etc_block::unpack_color5 / get_block_colors, etc.h:543-570), selector bit planes per etc.h:232-236."""
@@ -529,6 +558,27 @@ def decode_etc1s_blocks(blocks, nbx, nby):
             sel = to_sel[raw.astype(np.int64)]
             out[:, y, x, :] = np.clip(base + table[inten, sel][:, None], 0, 255).astype(np.uint8)
     return out.reshape(nby, nbx, 4, 4, 3).transpose(0, 2, 1, 3, 4).reshape(nby * 4, nbx * 4, 3)
+
+
+def decode_backend_blocks(encoder_blocks, endpoint_color5_inten, selector_blocks, nbx, nby):
+    """What a transcoder to ETC1 decodes from the backend's output (the texture basis_compressor computes its m_basis_* stats on, comp.cpp:4194-4221):
+    per block the endpoint / selector codebook entries the backend finally coded (its RDO may have replaced the frontend's choice). encoder_blocks:
+    the (n, 4) u32 rows of Etc1sBackend.get("encoder_blocks") = (endpoint index, predictor, selector index, history index + 1), indices in the
+    frontend's numbering; endpoint_color5_inten (k, 4) u8; selector_blocks (m, 8) u8 (selector bit planes in bytes 4-7)."""
+    eb = np.ascontiguousarray(encoder_blocks).view(np.uint32).reshape(-1, 4)
+    ep = np.ascontiguousarray(endpoint_color5_inten, np.uint8).reshape(-1, 4)[eb[:, 0]]
+    sb = np.ascontiguousarray(selector_blocks, np.uint8).reshape(-1, 8)[eb[:, 2]]
+    blk = np.zeros((eb.shape[0], 8), np.uint8)
+    blk[:, 0:3] = ep[:, 0:3] << 3
+    blk[:, 3] = (ep[:, 3] << 5) | (ep[:, 3] << 2) | 3    # both intensity tables, differential + flip bits (etc_block::is_etc1s)
+    blk[:, 4:8] = sb[:, 4:8]
+    return decode_etc1s_blocks(blk, nbx, nby)
+
+
+def decode_backend_output(fe, be, nbx, nby):
+    """decode_backend_blocks for an Etc1sFrontend + Etc1sBackend pair (one slice covering all blocks)"""
+    prm = fe.get("endpoint_cluster_etc_params").reshape(-1, 16)[:, :4]
+    return decode_backend_blocks(be.get("encoder_blocks"), prm, fe.get("optimized_cluster_selectors"), nbx, nby)
 
 
 def psnr(a, b):

@@ -146,6 +146,18 @@ HC_API int hc_unpack_block(const uint8_t* blk, uint8_t* out64) {
     return ok ? 1 : 0;
 }
 
+// whole decoder: 16-byte UASTC blocks -> 4x4 RGBA texels (unpack_uastc + the per-texel interpolation of the core: what a transcoder to RGBA32 yields)
+HC_API int hc_decode_uastc(const uint8_t* blocks, uint32_t n, uint8_t* out_rgba64) {
+    for (uint32_t i = 0; i < n; i++) {
+        cand c;
+        if (!unpack_block(blocks + (size_t)i * 16, c)) return 0;
+        rgba8* o = reinterpret_cast<rgba8*>(out_rgba64 + (size_t)i * 64);
+        if (c.mode == 8) { for (int t = 0; t < 16; t++) for (int k = 0; k < 4; k++) o[t].c[k] = c.endpoints[k]; }   // solid colour: the four bytes are the texel
+        else decode_uastc(c, o);
+    }
+    return 1;
+}
+
 HC_API int hc_rehint(const uint8_t* pixels, uint32_t n, uint32_t flags, uint8_t* blocks) {
     enc_cfg e;
     make_cfg(flags, e);

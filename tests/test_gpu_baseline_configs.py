@@ -4,7 +4,9 @@ the real reference -- oracle/_ref, single-threaded = the pinned configuration --
 
   configs[0]  kodim03.png 768x512 ETC1S -q128            pixels + the reference TOOL's .basis / .ktx2 bytes in tests/golden/kodim03.npz
   configs[1]  4096x4096 synthetic RGBA (seed 1234) -q128  frontend state digests + backend payload digests
+  configs[2]  4096x4096 synthetic RGBA (seed 1234) UASTC   ALL 1,048,576 blocks at level 2: sha256 of the whole output + per 65,536-block chunk
   configs[3]  8192x8192 synthetic RGBA (seed 5678) -q255  the same, at the 8192 / 16128 cluster codebooks no smaller test reaches
+  configs[4]  the Kodak batch, UASTC + RDO                 tests/test_gpu_kodak24.py
 
 Everything compared is integer data; the comparison is exact."""
 import hashlib
@@ -64,3 +66,18 @@ def test_config0_kodim03_q128_file_equals_the_reference_tools(hip_ctx):
     mine2 = be.ktx2_file(key_values=ktx2_file_key_values(z["tool_ktx2"]))
     assert mine2.shape == z["tool_ktx2"].shape and (mine2 == z["tool_ktx2"]).all()
     be.close(); fe.close()
+
+
+def test_config2_synth4096_uastc_level2_every_block(hip_ctx):
+    """BASELINE configs[2] at full size against the reference's output for EVERY block (tools/gen_golden_uastc_big.py: ~80 s of oracle/_ref on one core):
+    a whole-output digest, with per-chunk digests so that a failure names its neighbourhood."""
+    from basis_universal_amd import uastc
+    g = json.loads((pathlib.Path(__file__).parent / "golden" / "uastc_big_digests.json").read_text())["synth4096_l2"]
+    blocks = to_pixel_blocks(synth(g["width"], g["height"], g["seed"]))
+    assert blocks.shape[0] == g["n_blocks"] == 1048576
+    got = uastc.encode_uastc_blocks(hip_ctx, blocks, g["flags"])
+    c = g["chunk_blocks"]
+    bad = [i for i, want in enumerate(g["chunk_sha256"]) if hashlib.sha256(got[i * c:(i + 1) * c].tobytes()).hexdigest() != want]
+    assert not bad, f"chunks {bad} of {len(g['chunk_sha256'])} differ from the reference"
+    assert hashlib.sha256(got.tobytes()).hexdigest() == g["sha256"]
+    assert np.bincount(got[:, 0] & 0x7F, minlength=128).tolist() == g["mode_histogram"]

@@ -106,3 +106,14 @@ def test_host_core_vs_reference_fresh_blocks(flags):
     if (flags & 7) == 3:
         blocks = blocks[:120]
     assert (helpers.host_encode_uastc(blocks, flags) == helpers.ref_encode_uastc(blocks, flags)).all()
+
+
+@pytest.mark.skipif(not helpers.have_ref(), reason="oracle/_ref not present")
+def test_host_decoder_matches_reference_unpack(golden):
+    """The decoder behind every PSNR this repository prints (helpers.host_decode_uastc = unpack + interpolation of the core) against the reference's
+    unpack_uastc, on the blocks of every level of the known answers (all modes incl. solid colour) and on RDO output."""
+    for name in ("level0", "level2", "level4"):
+        packed = golden[name]
+        assert (helpers.host_decode_uastc(packed) == helpers.ref_decode_uastc(packed)).all(), name
+    z = np.load(GOLDEN.parent / "uastc_rdo_vectors.npz")
+    assert (helpers.host_decode_uastc(z["strong_l2"]) == helpers.ref_decode_uastc(z["strong_l2"])).all()
