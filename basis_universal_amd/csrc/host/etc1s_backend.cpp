@@ -20,6 +20,7 @@
 #include <atomic>
 #include <cstdlib>
 #include <numeric>
+#include <mutex>
 #include <thread>
 
 #include "block_metric.h"
@@ -627,7 +628,8 @@ bool etc1s_backend::create_encoder_blocks() {
     std::sort(extents.begin(), extents.end());
     for (size_t i = 1; i < extents.size(); i++)
         if (extents[i].first < extents[i - 1].second) return fail("slices overlap");  // the per-block state is kept once per block, and slices are walked concurrently
-    if (thresh > 0.0f) precompute_block_errors(true);
+    { timer t__; if (thresh > 0.0f) precompute_block_errors(true); sub_time("~ceb/block_errors", t__.seconds()); }
+    timer walk_timer;
     struct slice_result { std::vector<uint32_t> unpredicted; uint32_t remapped = 0; const char* error = nullptr; };
     std::vector<slice_result> results(m_slices.size());
     const bool video = m_params.m_video;
@@ -703,8 +705,11 @@ bool etc1s_backend::create_encoder_blocks() {
         remapped += r.remapped;
         all_endpoint_indices.insert(all_endpoint_indices.end(), r.unpredicted.begin(), r.unpredicted.end());
     }
+    sub_time("~ceb/walk", walk_timer.seconds());
+    timer sort_timer;
     const bool ok = reoptimize_and_sort_endpoints_codebook(remapped, all_endpoint_indices);
     selector_sort.join();
+    sub_time("~ceb/palette_orders", sort_timer.seconds());
     return ok;
 }
 
@@ -842,6 +847,9 @@ bool etc1s_backend::encode_image() {
     const bool may_pipeline = thread_cap >= 3 && std::thread::hardware_concurrency() >= 3;
     struct table_slot { metric::dist_table table; uint64_t cur_err; };
 
+    std::mutex loop_time_lock;
+    double loop_times[4] = {0, 0, 0, 0};
+    timer walks_timer;
     for_each_slice(m_slices, [&](size_t si) {
         const backend_slice_desc& s = m_slices[si];
         std::vector<uint32_t>&selector_hist = stats[si].selector_hist, &rle_hist = stats[si].rle_hist, &delta_hist = stats[si].delta_hist, &pred_hist = stats[si].pred_hist;
@@ -1032,16 +1040,21 @@ bool etc1s_backend::encode_image() {
             done3.store(n, std::memory_order_release);
         };
 
+        // each loop's own duration (with the pipeline on they overlap: the slowest one is the walk's wall time)
+        double d1 = 0, d2 = 0, d3 = 0;
+        auto timed = [](auto& fn, double& out) { timer t__; fn(); out = t__.seconds(); };
         if (pipelined) {
-            std::thread t2(tables_loop), t3(selectors_loop);
-            endpoints_loop();
+            std::thread t2([&] { timed(tables_loop, d2); }), t3([&] { timed(selectors_loop, d3); });
+            timed(endpoints_loop, d1);
             t2.join();
             t3.join();
         } else {
-            endpoints_loop();
-            tables_loop();
-            selectors_loop();
+            timed(endpoints_loop, d1);
+            timed(tables_loop, d2);
+            timed(selectors_loop, d3);
         }
+        { std::lock_guard<std::mutex> g(loop_time_lock); loop_times[0] += d1; loop_times[1] += d2; loop_times[2] += d3; }
+        timer merge_timer;
         // the slice's symbols in bit-stream order: predictor, endpoint delta, selector of every block in turn
         std::vector<token>& tokens = slice_tokens[si];
         tokens.reserve((size_t)n * 2 + 16);
@@ -1050,7 +1063,11 @@ bool etc1s_backend::encode_image() {
             if (delta_tok[i].kind != T_NONE) tokens.push_back(delta_tok[i]);
             if (sel_tok[i].kind != T_NONE) tokens.push_back(sel_tok[i]);
         }
+        { std::lock_guard<std::mutex> g(loop_time_lock); loop_times[3] += merge_timer.seconds(); }
     });
+    sub_time("~ei/endpoints_loop", loop_times[0]); sub_time("~ei/tables_loop", loop_times[1]); sub_time("~ei/selectors_loop", loop_times[2]);
+    sub_time("~ei/token_merge", loop_times[3]); sub_time("~ei/walks_wall", walks_timer.seconds());
+    timer coding_timer;
     std::vector<uint32_t> selector_hist(n_sel + kSelectorHistorySize + 1, 0), rle_hist(kSelectorRleCountTotal, 0), delta_hist(n_ep, 0), pred_hist(kEndpointPredSymbols, 0);
     uint32_t endpoints_remapped = 0;
     for (const slice_stats& st : stats) {
@@ -1111,6 +1128,7 @@ bool etc1s_backend::encode_image() {
         w.flush();
         m_output.m_slice_image_data[si] = w.bytes();
     });
+    sub_time("~ei/huffman_coding", coding_timer.seconds());
     return true;
 }
 

@@ -115,6 +115,7 @@ public:
 
 private:
     bool fail(const char* what) { m_error = what; return false; }
+    void sub_time(const char* name, double seconds) { m_stage_times.push_back(stage_time{name, seconds}); }   // "~parent/part": inside the stage that follows it in the list
     bool reoptimize_and_sort_endpoints_codebook(uint32_t total_remapped, std::vector<uint32_t>& all_endpoint_indices);
     void sort_selector_codebook();
     void compute_slice_crcs();

@@ -189,13 +189,13 @@ void etc1s_frontend::my_slab(uint32_t& first, uint32_t& count) const {
 }
 bool etc1s_frontend::gather_blocks(void* d_buf, size_t bytes_per_block) {
     if (!m_has_comm) return true;
-    if (!bu_hip_sync(m_dev->ctx)) return fail("sync before all_gather");
+    if (!m_comm.stream_ordered && !bu_hip_sync(m_dev->ctx)) return fail("sync before all_gather");
     if (!m_comm.all_gather(m_comm.user, d_buf, (uint64_t)slab_blocks() * bytes_per_block)) return fail("all_gather failed");
     return true;
 }
 bool etc1s_frontend::merge_disjoint(void* d_buf, size_t bytes) {
     if (!m_has_comm) return true;
-    if (!bu_hip_sync(m_dev->ctx)) return fail("sync before all_reduce");
+    if (!m_comm.stream_ordered && !bu_hip_sync(m_dev->ctx)) return fail("sync before all_reduce");
     if (!m_comm.all_reduce_u64(m_comm.user, d_buf, (uint64_t)((bytes + 7) / 8))) return fail("all_reduce failed");
     return true;
 }

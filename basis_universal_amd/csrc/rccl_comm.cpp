@@ -44,8 +44,7 @@ int all_gather(void* user, void* d_buf, uint64_t bytes_per_rank) {
     char* base = static_cast<char*>(d_buf);
     const ncclResult_t r = ncclAllGather(base + (size_t)c->rank * bytes_per_rank, base, (size_t)bytes_per_rank, ncclUint8, c->comm, st);
     if (r != ncclSuccess) return fail("ncclAllGather: %s", ncclGetErrorString(r));
-    if (hipStreamSynchronize(st) != hipSuccess) return fail("all_gather: stream synchronise failed");
-    return 1;
+    return 1;   // stream-ordered (bu_comm::stream_ordered = 1): whoever reads the result on the host synchronises there
 }
 
 int all_reduce_u64(void* user, void* d_buf, uint64_t count) {
@@ -55,7 +54,6 @@ int all_reduce_u64(void* user, void* d_buf, uint64_t count) {
     if (hipSetDevice(bu_hip_context_device(c->ctx)) != hipSuccess) return fail("all_reduce: hipSetDevice failed");
     const ncclResult_t r = ncclAllReduce(d_buf, d_buf, (size_t)count, ncclUint64, ncclSum, c->comm, st);
     if (r != ncclSuccess) return fail("ncclAllReduce: %s", ncclGetErrorString(r));
-    if (hipStreamSynchronize(st) != hipSuccess) return fail("all_reduce: stream synchronise failed");
     return 1;
 }
 
@@ -113,6 +111,7 @@ int bu_rccl_comm_fill(bu_rccl_comm* c, bu_comm* out) {
     if (!c || !out) return fail("comm_fill: null pointer");
     out->rank = c->rank; out->world = c->world; out->user = c;
     out->all_gather = all_gather; out->all_reduce_u64 = all_reduce_u64;
+    out->stream_ordered = 1; out->reserved = 0;
     return 1;
 }
 

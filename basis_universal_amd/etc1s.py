@@ -66,7 +66,8 @@ _REDUCE_FN = C.CFUNCTYPE(C.c_int, _vp, _vp, C.c_uint64)
 
 
 class _BuComm(C.Structure):  # = bu_comm, include/basisu_hip_frontend.h
-    _fields_ = [("rank", C.c_uint32), ("world", C.c_uint32), ("user", _vp), ("all_gather", _GATHER_FN), ("all_reduce_u64", _REDUCE_FN)]
+    _fields_ = [("rank", C.c_uint32), ("world", C.c_uint32), ("user", _vp), ("all_gather", _GATHER_FN), ("all_reduce_u64", _REDUCE_FN),
+                ("stream_ordered", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class _DevicePtr:
@@ -116,7 +117,7 @@ class TorchComm:
 
         self.error = ""
         self._gather, self._reduce = _GATHER_FN(gather), _REDUCE_FN(reduce)
-        self.struct = _BuComm(self.rank, self.world, None, self._gather, self._reduce)
+        self.struct = _BuComm(self.rank, self.world, None, self._gather, self._reduce, 0, 0)   # blocking convention: torch owns its streams
 
 
 _rccl_lib = None

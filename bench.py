@@ -415,16 +415,18 @@ def pmc_traffic(kernel):
 
 
 def valu_bound(kernels_ms):
-    """The per-block ETC1S kernels are bound by VALU instruction issue, not by HBM or the matrix cores: for the kernels of this
-    step that the committed SQ counter pass covers (profiles/valu_busy.json, written by tools/valu_table.py --json from a separate rocprofv3 --pmc run of this
-    same command), the share of all SIMD cycles in which a VALU instruction was executing, next to this run's own launch time."""
+    """The per-block ETC1S kernels are bound by VALU instruction issue, not by HBM or the matrix cores. For the kernels of this step that
+    the committed SQ counter pass covers (profiles/valu_busy.json = tools/valu_table.py --json over a separate rocprofv3 --pmc run of this same command):
+    the share of all SIMD issue cycles their VALU instructions occupy -- instructions executed (SQ_INSTS_VALU) x the measured cost of their opcodes
+    (profiles/valu_calibration.json, tools/valu_calib.hip) over the launch's shader cycles (SQ_BUSY_CYCLES / 32) -- next to this run's own launch time."""
     f = ROOT / "profiles" / "valu_busy.json"
     if not f.exists():
         return None
     rec = json.loads(f.read_text())
-    rows = {k: {"ms_this_run": kernels_ms[k], "valu_busy_frac": v["valu_busy_frac"], "valu_instructions_per_launch": v["valu_instructions_per_launch"]}
-            for k, v in rec.items() if k in kernels_ms}
-    return {"kernels": rows, "ceiling": rec.get("_meta", {}).get("ceiling"), "source": "profiles/valu_busy.json"} if rows else None
+    keep = ("valu_busy_frac", "valu_instructions_per_launch", "mean_cycles_per_instruction", "static_mix", "waves_stalled_on_issue_frac")
+    rows = {k: dict({"ms_this_run": kernels_ms[k]}, **{kk: v[kk] for kk in keep if kk in v}) for k, v in rec.items() if k in kernels_ms}
+    meta = rec.get("_meta", {})
+    return {"kernels": rows, "ceiling": meta.get("ceiling"), "method": meta.get("busy"), "source": "profiles/valu_busy.json"} if rows else None
 
 
 MFMA_F16_PEAK_TFLOPS = 2500.0  # dense, /opt/skills/guides/MI355X_MICROARCH.md

@@ -24,7 +24,10 @@ BU_HIP_API bu_rccl_comm* bu_rccl_comm_create(bu_hip_context* ctx, const void* id
 BU_HIP_API int bu_rccl_comm_init_all(bu_hip_context* const* ctxs, uint32_t n, bu_rccl_comm** out_comms /* n entries */);
 BU_HIP_API void bu_rccl_comm_destroy(bu_rccl_comm*);
 /* The bu_comm view of a communicator: all_gather = ncclAllGather in place over world * bytes_per_rank bytes, all_reduce_u64 = ncclAllReduce
- * (sum, uint64) in place; both on the context's stream, returning with the result complete. `out->user` points at the communicator. */
+ * (sum, uint64) in place; both ENQUEUED on the context's stream (bu_comm::stream_ordered = 1: no host synchronisation inside, the result is
+ * ordered with everything enqueued on that stream afterwards). `out->user` points at the communicator.
+ * Threading: drive each communicator from its own host thread (one thread per GPU, as basis_parallel_compress does); the N communicators of
+ * bu_rccl_comm_init_all must not be driven in turn from ONE thread -- a collective only completes once every rank has enqueued its part. */
 BU_HIP_API int bu_rccl_comm_fill(bu_rccl_comm*, bu_comm* out);
 BU_HIP_API const char* bu_rccl_last_error(void);
 

@@ -22,15 +22,22 @@ BU_HIP_API int bu_frontend_init(bu_frontend*, bu_hip_context* ctx, const bu_pixe
  * communicator set, the heavy device stages are SHARDED -- per-block stages by block-row slab (a6, a10, a14), per-cluster stages by
  * cluster subsets (a9, a13) -- and their fixed-size results exchanged through the two collectives below; the order-dependent parts
  * (TSVQ, cluster bookkeeping) run replicated, so every rank ends with the identical, single-GPU-identical state.
- * The collectives are supplied by the host application (torch.distributed over RCCL in basis_universal_amd/etc1s.py). They are
- * called with the context's stream idle and must return with the result complete:
+ * The collectives are supplied by the host application (libbasisu_rccl.so: include/basisu_hip_comm.h; torch.distributed in
+ * basis_universal_amd/etc1s.py for tests):
  *   all_gather    : in place over world * bytes_per_rank bytes; rank r owns segment r
- *   all_reduce_u64: in place element-wise sum of `count` u64 (used to merge disjoint per-rank results and integer accumulators) */
+ *   all_reduce_u64: in place element-wise sum of `count` u64 (used to merge disjoint per-rank results and integer accumulators)
+ * Two calling conventions, told apart by `stream_ordered`:
+ *   0  blocking: the frontend synchronises the context's stream before the call, and the call returns with the result complete
+ *      (what a host framework that owns its own streams needs);
+ *   1  stream-ordered: the collective is ENQUEUED on the context's stream (bu_hip_get_stream) behind the kernels that produced its input and in
+ *      front of everything the frontend enqueues afterwards; nobody synchronises -- the host only waits where it reads a result, as in the
+ *      single-GPU path. This is what the RCCL communicator does. One host thread per communicator (RCCL's own rule for blocking-free use). */
 typedef struct bu_comm {
     uint32_t rank, world;
     void* user;
     int (*all_gather)(void* user, void* d_buf, uint64_t bytes_per_rank);
     int (*all_reduce_u64)(void* user, void* d_buf, uint64_t count);
+    uint32_t stream_ordered, reserved;
 } bu_comm;
 BU_HIP_API int bu_frontend_set_comm(bu_frontend*, const bu_comm* comm); /* NULL = single GPU; call before bu_frontend_init */
 /* basisu_frontend::params::m_tex_type == cBASISTexTypeVideoFrames (frontend.cpp:219-223, 291: one more fit of the merged endpoint codebook, endpoints

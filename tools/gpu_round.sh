@@ -40,3 +40,8 @@ if [[ " $* " == *" calib "* ]]; then
   timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_INSTS_SALU SQ_WAIT_ANY SQ_ACTIVE_INST_ANY -d /tmp/pmc_calib_$tag -o calib -- $R/tools/bin/valu_calib > /dev/null 2> $R/gpurun_out/pmc_calib_$tag.err
   python $R/tools/rocprof_summary.py pmc $(db pmc_calib_$tag) > $R/gpurun_out/${tag}_pmc_calib.csv; wc -l $R/gpurun_out/${tag}_pmc_calib.csv
 fi
+if [[ " $* " == *" rdoprof "* ]]; then
+  # where the serial RDO step goes (instrumented library, tools/build_rdo_profile.sh)
+  cd $R && timeout 300 python tools/rdo_step_profile.py > gpurun_out/rdo_step_$tag.txt 2> gpurun_out/rdo_step_$tag.err; cat gpurun_out/rdo_step_$tag.txt | tail -14
+  cd /tmp
+fi
