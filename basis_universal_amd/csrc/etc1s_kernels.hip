@@ -499,6 +499,10 @@ __global__ __launch_bounds__(256) void k_selector_training_vectors(const uint64_
 
 constexpr int CB_THREADS = 512;   // 1024 leaves the SIMDs 44 % idle on the bench image (barriers per trial, ~7 pixels per thread); 512: 1.14 ms against 1.80
 constexpr int CB_WAVES = CB_THREADS / 64;
+// The first CB_STAGE texels of a cluster are kept in LDS after the first pass over them: every trial (17 at the default quality, up to 166) re-reads the
+// cluster's texels, and from memory that is two dependent loads per texel (member list, then the tile) -- 7.7x the algorithmic bytes fetched per launch in
+// round 2's FETCH_SIZE pass. 8192 texels (32 KiB) hold the whole cluster for all but the largest few; the rest of a larger cluster still comes from L2.
+constexpr uint32_t CB_STAGE = 8192;
 
 __device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
 #pragma unroll
@@ -549,12 +553,14 @@ __global__ __launch_bounds__(CB_THREADS) void k_generate_endpoint_codebook(
     __shared__ float s_avg[3];
     __shared__ int s_spread;
     __shared__ int s_active;
+    __shared__ uint32_t s_px[CB_STAGE];
 
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t ci = order[blockIdx.x];
     const uint32_t first = offsets[ci];
     const uint32_t n = (offsets[ci + 1] - first) * 8u; // pixels
     const uint32_t* members = indices + first;
+    auto texel = [&](uint32_t j) -> uint32_t { return j < CB_STAGE ? s_px[j] : cluster_pixel(pixel_words, members, j); };   // valid after the init pass
 
     if (tid < 32) s_bloom[tid] = 0;
 
@@ -564,6 +570,7 @@ __global__ __launch_bounds__(CB_THREADS) void k_generate_endpoint_codebook(
         int mn_r = 255, mn_g = 255, mn_b = 255, mx_r = 0, mx_g = 0, mx_b = 0;
         for (uint32_t j = tid; j < n; j += CB_THREADS) {
             const uint32_t w = cluster_pixel(pixel_words, members, j);
+            if (j < CB_STAGE) s_px[j] = w;
             const int r = w & 255, g = (w >> 8) & 255, b = (w >> 16) & 255;
             sr += r; sg += g; sb += b;
             mn_r = min(mn_r, r); mn_g = min(mn_g, g); mn_b = min(mn_b, b);
@@ -587,7 +594,7 @@ __global__ __launch_bounds__(CB_THREADS) void k_generate_endpoint_codebook(
             fs = (float)s; // every partial sum of the reference's running float sum is an exactly representable integer
         } else {
             fs = 0.0f;     // replay the float accumulation in pixel order (etc.cpp:1034-1041)
-            for (uint32_t j = 0; j < n; j++) fs += (float)((cluster_pixel(pixel_words, members, j) >> (8 * tid)) & 255u);
+            for (uint32_t j = 0; j < n; j++) fs += (float)((texel(j) >> (8 * tid)) & 255u);
         }
         s_avg[tid] = fs / (float)n;
     }
@@ -631,7 +638,7 @@ __global__ __launch_bounds__(CB_THREADS) void k_generate_endpoint_codebook(
             plain_mask &= enable_mask;
             const cvec base_cv = to_cvec<PERCEPTUAL>(scale5(tr), scale5(tg), scale5(tb));
             for (uint32_t j = tid; j < n; j += CB_THREADS) {
-                const cvec p = pixel_cvec<PERCEPTUAL>(cluster_pixel(pixel_words, members, j));
+                const cvec p = pixel_cvec<PERCEPTUAL>(texel(j));
                 if (FORCED) {
                     const uint32_t sel = cluster_pixel_selector(enc_blocks, members, j);
 #pragma unroll
@@ -696,7 +703,7 @@ __global__ __launch_bounds__(CB_THREADS) void k_generate_endpoint_codebook(
             block_cvecs<PERCEPTUAL>(bc, scale5((int)r5), scale5((int)g5), scale5((int)b5), (int)inten);
             const uint32_t sel = cluster_pixel_selector(enc_blocks, members, j);
             const cvec c = select_cvec(bc, (uint32_t)sel);
-            tot += cdist<PERCEPTUAL>(pixel_cvec<PERCEPTUAL>(cluster_pixel(pixel_words, members, j)), c);
+            tot += cdist<PERCEPTUAL>(pixel_cvec<PERCEPTUAL>(texel(j)), c);
         }
         tot = wave_sum_u64(tot);
         __syncthreads();
@@ -719,7 +726,7 @@ __global__ __launch_bounds__(CB_THREADS) void k_generate_endpoint_codebook(
         cvec bc[4];
         block_cvecs<PERCEPTUAL>(bc, scale5(pr), scale5(pg), scale5(pb), pi);
         uint64_t tot = 0;
-        for (uint32_t j = tid; j < n; j += CB_THREADS) tot += min_err4<PERCEPTUAL>(pixel_cvec<PERCEPTUAL>(cluster_pixel(pixel_words, members, j)), bc);
+        for (uint32_t j = tid; j < n; j += CB_THREADS) tot += min_err4<PERCEPTUAL>(pixel_cvec<PERCEPTUAL>(texel(j)), bc);
         tot = wave_sum_u64(tot);
         if (lane == 0) s_part[wave][0] = tot;
         __syncthreads();
@@ -1106,16 +1113,18 @@ __global__ __launch_bounds__(256) void k_refine_sorted(const uint4* __restrict__
         for (uint32_t base = 0; base < n_clamped; base += RQ) {
             const uint32_t n1 = min(RQ, n_clamped - base);
             uint32_t ns = 0;
-            for (uint32_t j0 = 0; j0 < n1; j0 += 64) {
-                const uint32_t j = j0 + lane;
+            // the clamped entries are few (a tenth of a list on the bench image) and need the expensive four-distance form: FOUR lanes per entry
+            // take one of the four test pixels each (pixel 5 f), so that a handful of entries costs one pass of one distance instead of one of four
+            for (uint32_t j0 = 0; j0 < n1; j0 += 16) {
+                const uint32_t j = j0 + (lane >> 2), f = lane & 3u;
                 const bool have = j < n1;
                 const uint2 e = clamped_items[base + (have ? j : 0)];
                 cvec bc[4];
                 block_cvecs<PERCEPTUAL>(bc, scale5((int)(e.x & 255u)), scale5((int)((e.x >> 8) & 255u)), scale5((int)((e.x >> 16) & 255u)), (int)((e.x >> 24) & 7u));
-                uint32_t part = 0;
-#pragma unroll
-                for (int f = 0; f < 4; f++) part += min_err4<PERCEPTUAL>(pc[FIRST_PX[f]], bc);
-                const bool keep = have && part <= thr;
+                uint32_t part = min_err4<PERCEPTUAL>(pixel_cvec<PERCEPTUAL>(block_words[f * 5u]), bc);   // FIRST_PX[f] = 5 f
+                part += (uint32_t)__shfl_xor((int)part, 1, 64);
+                part += (uint32_t)__shfl_xor((int)part, 2, 64);
+                const bool keep = have && f == 0 && part <= thr;
                 const uint64_t m = __ballot(keep);
                 const uint32_t r = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
                 if (keep) { q[ns + r] = e; qp[ns + r] = part; }

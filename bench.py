@@ -77,6 +77,8 @@ def main():
                     "basis_parallel_compress); the default 1 is what the headline number uses")
     ap.add_argument("--no-pipelined", action="store_true", help="skip the additional 3-images-in-flight throughput measurement")
     ap.add_argument("--no-uastc", action="store_true", help="skip the secondary UASTC level-2 measurement (BASELINE config #3)")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend of the N > 1 launch: nccl (= RCCL over xGMI, one GPU per "
+                    "rank: what the driver runs) or gloo (ranks may share a GPU: the path tests/test_gpu_bench_distributed.py drives on a one-GPU box)")
     ap.add_argument("--no-big", action="store_true", help="skip the secondary 8192x8192 -q255 measurement (BASELINE config #4's single-GPU form)")
     ap.add_argument("--no-fast", action="store_true", help="skip the secondary measurement of the codebook builders' fast mode (SURVEY 8f row f3, not bit-identical)")
     args = ap.parse_args()
@@ -93,11 +95,18 @@ def main():
     if world > 1 and "BU_HOST_THREADS" not in os.environ:
         # the ranks of one node share its host cores: give each frontend its share (2..8 threads) instead of 8 each
         os.environ["BU_HOST_THREADS"] = str(max(2, min(8, host_cpus() // int(os.environ.get("LOCAL_WORLD_SIZE", world)))))
+    gloo = args.dist_backend == "gloo"
+    if gloo:
+        local_rank %= max(1, torch.cuda.device_count())   # ranks share the GPUs there are
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if gloo:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    red_dev = torch.device("cpu") if gloo else dev   # where the max-over-ranks of the timings is taken
 
     # ---- synthetic input (SURVEY 8d recipe), tiled on the host once, resident in HBM before the timed region
     w = h = args.size
@@ -116,7 +125,7 @@ def main():
     if sharded:
         # the native RCCL communicator (C++ collectives on the context's stream); BU_TORCH_COMM=1 goes through torch.distributed instead
         from basis_universal_amd.etc1s import TorchComm, RcclComm
-        comm = TorchComm() if os.environ.get("BU_TORCH_COMM") else RcclComm(ctx)
+        comm = TorchComm() if (gloo or os.environ.get("BU_TORCH_COMM")) else RcclComm(ctx)
 
     def step():
         fe = Etc1sFrontend(ctx, comm)
@@ -202,7 +211,7 @@ def main():
         for fe in fes:
             fe.close()
         if world > 1:
-            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            t = torch.tensor([dt], device=red_dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         pipelined = {"images_in_flight_per_gpu": 3, "images": 6 * world, "value": round(world * 6 * (w * h) / 1e6 / dt, 3), "unit": "Mpixels/s",
@@ -216,7 +225,7 @@ def main():
                          "note": "frontend (GPU) + backend (host) per image = everything between the tiled input and the file writer; six images in flight on six "
                                  "host threads / HIP streams, each backend using its own three-thread pipeline (throughput mode; not the headline value)"}
     if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], device=red_dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -469,15 +478,15 @@ def fast_codebooks_bench(ctx, d_blocks, n_blocks, w, h, max_ep, max_sel, args):
            "kernels_ms_per_step": {k: round(v[0] / steps, 3) for k, v in kernels.items() if k.startswith("kmeans")}}
     if "kmeans_selectors" in kernels:
         ms, launches = kernels["kmeans_selectors"]
-        k_pad = (max_sel + 31) // 32 * 32
+        k_pad = (max_sel + 63) // 64 * 64
         rounds = 5
         flops = 2.0 * u_sel * k_pad * 16 * 2 * rounds
         avg_s = ms / 1e3 / launches
         out["roofline"] = {"bound": "mfma", "kernel": "kmeans_selectors", "achieved": round(flops / avg_s / 1e12, 2), "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
                            "frac": round(flops / avg_s / 1e12 / MFMA_F16_PEAK_TFLOPS, 5), "traffic": None, "avg_launch_ms": round(avg_s * 1e3, 3),
                            "flops_per_launch": flops, "distinct_vectors": u_sel,
-                           "note": "one launch = unpack + seeding + 5 assignment GEMMs with their argmin / integer accumulation epilogues + centroid updates; the "
-                                   "epilogue (16 compares per MFMA result register set) bounds it, not the matrix pipe"}
+                           "note": "one timed region = unpack + seeding + 5 assignment GEMMs (k_km_assign: LDS-staged centroid tiles, 4 column tiles per wave, min-only epilogue of 17 VALU "
+                                   "instructions per MFMA pair, LDS accumulators for the centroid sums) + centroid updates + the reseeding of empty clusters"}
     return out
 
 

@@ -1,0 +1,70 @@
+"""-m gpu: bench.py's own N > 1 path, end to end, the way the driver launches it (`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`),
+on the one GPU the test box has: two ranks share cuda:0 and talk through gloo (--dist-backend gloo; with nccl = RCCL the driver gives every rank its own
+GPU). Both modes: independent images per rank (the default, weak scaling, no data-path collective) and one image sharded over the ranks (--shard-image:
+slabs / cluster shares / TSVQ node shares + all-gather / sum all-reduce). What is checked is the contract of the line rank 0 prints and that the sharded
+run ends with the single-GPU result (the codebook sizes of the line; the state itself is held to the reference by tests/test_gpu_etc1s_sharded.py)."""
+import json
+import os
+import pathlib
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = pathlib.Path(__file__).resolve().parent.parent
+COMMON = ["--steps", "2", "--warmup", "1", "--size", "512", "--no-cpu-baseline", "--no-pipelined", "--no-uastc", "--no-fast", "--no-big"]
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run(n, extra):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if n == 1:
+        cmd = [sys.executable, str(ROOT / "bench.py"), "--gpus", "1", *COMMON, *extra]
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+               str(ROOT / "bench.py"), "--gpus", str(n), "--dist-backend", "gloo", *COMMON, *extra]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=str(ROOT))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, "exactly one JSON line, from rank 0"
+    return json.loads(lines[0])
+
+
+@pytest.fixture(scope="module")
+def single():
+    return _run(1, [])
+
+
+def _contract(d, n):
+    assert d["n_gpus"] == n and d["steps"] == 2 and d["warmup"] == 1 and d["unit"] == "Mpixels/s" and d["higher_is_better"] is True
+    assert d["value"] > 0 and d["ms_per_step"] > 0 and d["data"] == "synthetic" and d["vs_baseline"] is None
+    assert d["roofline"]["bound"] == "hbm" and d["roofline"]["kernel_symbol"].startswith("k_")
+
+
+def test_weak_scaling_mode_two_ranks(single):
+    d = _run(2, [])
+    _contract(d, 2)
+    assert d["scaling"] == "weak" and "no collective" in d["config"]["parallelism"]
+    # value = the pixels of BOTH ranks' images over the slower rank's time
+    assert abs(d["value"] - 2 * 512 * 512 / 1e6 / (d["ms_per_step"] / 1e3)) / d["value"] < 0.01
+    assert d["config"]["final_endpoint_clusters"] > 0
+
+
+def test_sharded_image_mode_two_ranks(single):
+    d = _run(2, ["--shard-image"])
+    _contract(d, 2)
+    assert d["scaling"] == "strong" and "sharded" in d["config"]["parallelism"]
+    assert abs(d["value"] - 512 * 512 / 1e6 / (d["ms_per_step"] / 1e3)) / d["value"] < 0.01
+    # the same image as the single-GPU run (seed 1234): the sharded frontend must end with the same codebooks
+    for k in ("final_endpoint_clusters", "final_selector_clusters", "max_endpoint_clusters", "max_selector_clusters"):
+        assert d["config"][k] == single["config"][k], k
+    assert d["psnr"] == single["psnr"]
