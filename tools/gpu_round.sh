@@ -15,23 +15,23 @@ fi
 cd /tmp && export TMPDIR=/tmp
 db() { ls /tmp/$1/*/*.db /tmp/$1/*.db 2>/dev/null | head -1; }
 if [[ " $* " == *" prof "* ]]; then
-  timeout 120 rocprofv3 --kernel-trace --stats -d /tmp/prof_$tag -o bench -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-pipelined > $R/gpurun_out/prof_$tag.json 2> $R/gpurun_out/prof_$tag.err
+  timeout 120 rocprofv3 --kernel-trace --stats -d /tmp/prof_$tag -o bench -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-pipelined --no-big > $R/gpurun_out/prof_$tag.json 2> $R/gpurun_out/prof_$tag.err
   python $R/tools/rocprof_summary.py stats $(db prof_$tag) > $R/gpurun_out/${tag}_kernel_stats.csv; wc -l $R/gpurun_out/${tag}_kernel_stats.csv
 fi
 if [[ " $* " == *" pmc "* ]]; then
   # counters in their own passes (FETCH_SIZE and WRITE_SIZE do not fit one pass), no tracing domains besides kernel-trace
   for c in FETCH_SIZE WRITE_SIZE; do
     l=$(echo $c | tr A-Z a-z)
-    timeout 120 rocprofv3 --kernel-trace --pmc $c -d /tmp/pmc_${l}_$tag -o bench -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-pipelined > /dev/null 2> $R/gpurun_out/pmc_${l}_$tag.err
+    timeout 120 rocprofv3 --kernel-trace --pmc $c -d /tmp/pmc_${l}_$tag -o bench -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-pipelined --no-big > /dev/null 2> $R/gpurun_out/pmc_${l}_$tag.err
     python $R/tools/rocprof_summary.py pmc $(db pmc_${l}_$tag) > $R/gpurun_out/${tag}_pmc_${l}.csv; wc -l $R/gpurun_out/${tag}_pmc_${l}.csv
   done
-  timeout 120 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_INSTS_SALU SQ_WAIT_ANY SQ_ACTIVE_INST_ANY -d /tmp/pmc_sq_$tag -o bench -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-pipelined > /dev/null 2> $R/gpurun_out/pmc_sq_$tag.err
+  timeout 120 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_INSTS_SALU SQ_WAIT_ANY SQ_ACTIVE_INST_ANY -d /tmp/pmc_sq_$tag -o bench -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-pipelined --no-big > /dev/null 2> $R/gpurun_out/pmc_sq_$tag.err
   python $R/tools/rocprof_summary.py pmc $(db pmc_sq_$tag) > $R/gpurun_out/${tag}_pmc_sq.csv; wc -l $R/gpurun_out/${tag}_pmc_sq.csv
 fi
 
 if [[ " $* " == *" rounds "* ]]; then
   # one step with the TSVQ round time line on stderr (BU_TSVQ_ROUNDS)
-  cd $R && BU_TSVQ_ROUNDS=1 timeout 120 python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-pipelined --no-uastc --no-fast --no-big > /dev/null 2> gpurun_out/rounds_$tag.log; grep -c "tsvq round" gpurun_out/rounds_$tag.log
+  cd $R && BU_TSVQ_ROUNDS=1 timeout 120 python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-pipelined --no-big --no-uastc --no-fast --no-big > /dev/null 2> gpurun_out/rounds_$tag.log; grep -c "tsvq round" gpurun_out/rounds_$tag.log
   cd /tmp
 fi
 if [[ " $* " == *" calib "* ]]; then
