@@ -751,6 +751,12 @@ struct bu_tsvq {
     // kernel on the same stream was observed to let the kernel read the destination before the copy landed (MI355X, ROCm 7.2:
     // tools/tsvq_root_repeat.py, 2 of 10 runs), so nothing on this path hands pageable memory to an asynchronous copy.
     void* pinned = nullptr; size_t pinned_cap = 0;
+    // Zero-copy rounds (default; BU_TSVQ_ZEROCOPY=0 switches back to staged copies + hipStreamSynchronize): the one-workgroup kernel reads its node records
+    // from, and every split kernel writes its result records to, the page-locked buffer directly; a one-thread kernel behind them raises `round_flag`
+    // (system scope) and the host spins on it. That takes two copy launches and a blocking synchronisation out of every round of the tree build.
+    bool zero_copy = true;
+    uint32_t round_seq = 0;
+    bool dbg_rounds = false, dbg_serial = false, dbg_stats = false;   // BU_TSVQ_ROUNDS / _SERIAL / _STATS, read once per tree (getenv per round was 5-10 us of every round)
     hipError_t reserve_pinned(size_t bytes) {
         if (bytes <= pinned_cap) return hipSuccess;
         if (pinned) { (void)hipHostFree(pinned); pinned = nullptr; pinned_cap = 0; }
@@ -789,6 +795,8 @@ static bu_tsvq* tsvq_create_common(bu_hip_context* ctx, uint32_t dim, bool packe
     if (!q) return nullptr;
     q->dim = dim; q->n = n; q->packed = packed;
     q->force_chained = std::getenv("BU_TSVQ_CHAINED") != nullptr;
+    if (const char* e = std::getenv("BU_TSVQ_ZEROCOPY")) q->zero_copy = std::atoi(e) != 0;
+    q->dbg_rounds = std::getenv("BU_TSVQ_ROUNDS") != nullptr; q->dbg_serial = std::getenv("BU_TSVQ_SERIAL") != nullptr; q->dbg_stats = std::getenv("BU_TSVQ_STATS") != nullptr;
     const size_t row_bytes = packed ? 4 : (size_t)dim * 4;
     auto fail = [&](const char* what) -> bu_tsvq* { set_error(ctx, "tsvq_create: %s", what); bu_hip_tsvq_destroy(ctx, q); return nullptr; };
     if (ctx->tsvq_pinned) { q->pinned = ctx->tsvq_pinned; q->pinned_cap = ctx->tsvq_pinned_cap; ctx->tsvq_pinned = nullptr; ctx->tsvq_pinned_cap = 0; }
@@ -908,7 +916,7 @@ int bu_hip_tsvq_split(bu_hip_context* ctx, bu_tsvq* q, const bu_tsvq_node* h_nod
     if (!ctx || !q) return 0;
     if (!n_nodes) return 1;
     device_guard g(ctx->device);
-    const bool round_stats = std::getenv("BU_TSVQ_ROUNDS") != nullptr;   // development aid: one line per round on stderr
+    const bool round_stats = q->dbg_rounds;   // development aid: one line per round on stderr
     const auto round_t0 = std::chrono::steady_clock::now();
     if ((size_t)n_nodes * sizeof(bu_tsvq_node) > q->nodes.cap || (size_t)n_nodes * sizeof(bu_tsvq_split) > q->outs.cap) { set_error(ctx, "tsvq_split: batch of %u nodes exceeds the record buffers", n_nodes); return 0; }
     // Large nodes go through the many-workgroup path, the rest one workgroup each; both write one result array
@@ -929,7 +937,15 @@ int bu_hip_tsvq_split(bu_hip_context* ctx, bu_tsvq* q, const bu_tsvq_node* h_nod
     const uint32_t n_narrow = n_nodes - n_wide;
     const size_t in_bytes = (size_t)n_narrow * sizeof(bu_tsvq_node), wide_bytes = (size_t)n_wide * sizeof(bu::tsvq_wide_node), out_bytes = (size_t)n_nodes * sizeof(bu_tsvq_split);
     const size_t wide_at = (in_bytes + 63) & ~(size_t)63;
-    BU_TRY(ctx, q->reserve_pinned(std::max(wide_at + wide_bytes, out_bytes)));
+    const bool zero_copy = q->zero_copy;
+    // staged: the result records come back over the node records; zero-copy: the kernels write them while others still read their nodes, so they get their own place
+    const size_t out_at = zero_copy ? ((wide_at + wide_bytes + 63) & ~(size_t)63) : 0, flag_at = (out_at + out_bytes + 63) & ~(size_t)63;
+    BU_TRY(ctx, q->reserve_pinned(std::max(wide_at + wide_bytes, flag_at + 64)));
+    char* d_pinned = nullptr;   // the page-locked buffer as the device addresses it
+    if (zero_copy) BU_TRY(ctx, hipHostGetDevicePointer(reinterpret_cast<void**>(&d_pinned), q->pinned, 0));
+    volatile uint32_t* round_flag = reinterpret_cast<volatile uint32_t*>(static_cast<char*>(q->pinned) + flag_at);
+    const bu::tsvq_node_in* d_nodes_in = zero_copy ? reinterpret_cast<const bu::tsvq_node_in*>(d_pinned) : static_cast<const bu::tsvq_node_in*>(q->nodes.p);
+    bu::tsvq_split_out* d_outs = zero_copy ? reinterpret_cast<bu::tsvq_split_out*>(d_pinned + out_at) : static_cast<bu::tsvq_split_out*>(q->outs.p);
     {
         bu_tsvq_node* pn = static_cast<bu_tsvq_node*>(q->pinned);
         for (uint32_t i = 0; i < n_narrow; i++) pn[i] = h_nodes[order[i]];
@@ -944,12 +960,13 @@ int bu_hip_tsvq_split(bu_hip_context* ctx, bu_tsvq* q, const bu_tsvq_node* h_nod
             pw[i] = w;
         }
     }
-    if (n_narrow) BU_TRY(ctx, hipMemcpyAsync(q->nodes.p, q->pinned, in_bytes, hipMemcpyHostToDevice, ctx->stream));
+    if (zero_copy) { *round_flag = 0; __atomic_thread_fence(__ATOMIC_SEQ_CST); }
+    if (n_narrow && !zero_copy) BU_TRY(ctx, hipMemcpyAsync(q->nodes.p, q->pinned, in_bytes, hipMemcpyHostToDevice, ctx->stream));
     if (n_wide) BU_TRY(ctx, hipMemcpyAsync(q->wide_nodes, static_cast<char*>(q->pinned) + wide_at, wide_bytes, hipMemcpyHostToDevice, ctx->stream));
     const bool exact = q->packed && !q->force_chained;
     // The two kinds of node of a round do not touch each other's data: when both are present the one-workgroup kernel runs on the side
     // stream, under the many small launches of the wide path. (Not while kernels are being timed one by one.)
-    bool narrow_on_side = n_wide && n_narrow && !ctx->profiling && !std::getenv("BU_TSVQ_SERIAL");
+    bool narrow_on_side = n_wide && n_narrow && !ctx->profiling && !q->dbg_serial;
     if (narrow_on_side && !ctx->side_stream) {
         if (hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ctx->side_fork, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&ctx->side_join, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); narrow_on_side = false; }
@@ -961,17 +978,16 @@ int bu_hip_tsvq_split(bu_hip_context* ctx, bu_tsvq* q, const bu_tsvq_node* h_nod
         side_join_guard.s = ctx->side_stream; side_join_guard.armed = true;
         BU_TRY(ctx, hipEventRecord(ctx->side_fork, ctx->stream));
         BU_TRY(ctx, hipStreamWaitEvent(ctx->side_stream, ctx->side_fork, 0));
-        BU_TRY(ctx, bu::launch_tsvq_split(ctx->side_stream, (int)q->dim, q->packed, exact, q->rows, q->w64, q->perm[0], q->perm[1], q->side,
-                                          static_cast<const bu::tsvq_node_in*>(q->nodes.p), n_narrow, static_cast<bu::tsvq_split_out*>(q->outs.p)));
+        BU_TRY(ctx, bu::launch_tsvq_split(ctx->side_stream, (int)q->dim, q->packed, exact, q->rows, q->w64, q->perm[0], q->perm[1], q->side, d_nodes_in, n_narrow, d_outs));
         BU_TRY(ctx, hipEventRecord(ctx->side_join, ctx->side_stream));
     }
     if (n_wide) {
         prof_scope ps(ctx, "tsvq_split_packed16_wide");
         BU_TRY(ctx, bu::launch_tsvq_wide_split(ctx->stream, static_cast<const uint32_t*>(q->rows), q->w64, q->perm[0], q->perm[1], q->side, q->wide_packed, q->wide_nodes, n_wide, q->wide_ctrl,
-                                               q->wide_ws, wide_blocks, static_cast<bu::tsvq_split_out*>(q->outs.p), wide_max_count < q->wide_cov_min,
+                                               q->wide_ws, wide_blocks, d_outs, wide_max_count < q->wide_cov_min,
                                                wide_max_weight * 3ull < (1ull << 24)));
     }
-    if (n_wide && std::getenv("BU_TSVQ_STATS")) {   // development aid: how the last pass's walks went, per wide node
+    if (n_wide && q->dbg_stats) {   // development aid: how the last pass's walks went, per wide node
         std::vector<bu::tsvq_wide_ctrl> hc(n_wide);
         if (hipMemcpyAsync(hc.data(), q->wide_ctrl, hc.size() * sizeof(bu::tsvq_wide_ctrl), hipMemcpyDeviceToHost, ctx->stream) == hipSuccess && hipStreamSynchronize(ctx->stream) == hipSuccess)
             for (uint32_t i = 0; i < n_wide; i++) {
@@ -991,11 +1007,25 @@ int bu_hip_tsvq_split(bu_hip_context* ctx, bu_tsvq* q, const bu_tsvq_node* h_nod
     if (narrow_on_side) { BU_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->side_join, 0)); side_join_guard.armed = false; }
     else if (n_narrow) {
         prof_scope ps(ctx, q->packed ? "tsvq_split_packed16" : "tsvq_split_float6");
-        BU_TRY(ctx, bu::launch_tsvq_split(ctx->stream, (int)q->dim, q->packed, exact, q->rows, q->w64, q->perm[0], q->perm[1], q->side,
-                                          static_cast<const bu::tsvq_node_in*>(q->nodes.p), n_narrow, static_cast<bu::tsvq_split_out*>(q->outs.p)));
+        BU_TRY(ctx, bu::launch_tsvq_split(ctx->stream, (int)q->dim, q->packed, exact, q->rows, q->w64, q->perm[0], q->perm[1], q->side, d_nodes_in, n_narrow, d_outs));
     }
-    BU_TRY(ctx, hipMemcpyAsync(q->pinned, q->outs.p, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
-    BU_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (zero_copy) {
+        const uint32_t seq = ++q->round_seq ? q->round_seq : ++q->round_seq;   // never 0
+        BU_TRY(ctx, bu::launch_tsvq_signal(ctx->stream, reinterpret_cast<uint32_t*>(d_pinned + flag_at), seq));
+        for (uint32_t spins = 0;; spins++) {
+            if (*round_flag == seq) break;
+            if ((spins & 0x3fffu) == 0x3fffu) {   // now and then: did the stream die, or finish without the flag becoming visible?
+                const hipError_t e = hipStreamQuery(ctx->stream);
+                if (e == hipSuccess) { __atomic_thread_fence(__ATOMIC_SEQ_CST); if (*round_flag != seq) BU_TRY(ctx, hipStreamSynchronize(ctx->stream)); break; }
+                if (e != hipErrorNotReady) { set_error(ctx, "tsvq_split: %s", hipGetErrorString(e)); return 0; }
+            }
+            __builtin_ia32_pause();
+        }
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    } else {
+        BU_TRY(ctx, hipMemcpyAsync(q->pinned, q->outs.p, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+        BU_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
     if (round_stats) {
         uint32_t mx = 0; uint64_t tot = 0;
         for (uint32_t i = 0; i < n_nodes; i++) { mx = std::max(mx, h_nodes[i].count); tot += h_nodes[i].count; }
@@ -1003,7 +1033,7 @@ int bu_hip_tsvq_split(bu_hip_context* ctx, bu_tsvq* q, const bu_tsvq_node* h_nod
                      std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - round_t0).count());
     }
     {
-        const bu_tsvq_split* po = static_cast<const bu_tsvq_split*>(q->pinned);
+        const bu_tsvq_split* po = reinterpret_cast<const bu_tsvq_split*>(static_cast<const char*>(q->pinned) + out_at);
         for (uint32_t i = 0; i < n_nodes; i++) h_out[order[i]] = po[i];
     }
     if (exact) { // nodes whose data left the exact range, or that the wide path handed back (ok == 2), go through the one-workgroup kernel: wide ones through its exact variant first

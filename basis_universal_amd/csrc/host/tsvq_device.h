@@ -158,6 +158,7 @@ private:
         if (leaf_of_unique) leaf_of_unique->clear();
         if (leaf_count) *leaf_count = 0;
         struct guard { bu_hip_context* c; bu_tsvq* q; ~guard() { bu_hip_tsvq_destroy(c, q); } } g{ctx, q};
+        const bool dbg_serial = std::getenv("BU_TSVQ_SERIAL") != nullptr, dbg_verify = std::getenv("BU_TSVQ_VERIFY") != nullptr;   // once per tree, not per round
 
         struct node {
             float var; uint64_t weight; float origin[16];
@@ -266,7 +267,7 @@ private:
                 if (!comm->all_reduce_u64(comm->user, d_staging, n_u64)) return false;
                 if (!bu_hip_tsvq_exchange_unpack(ctx, q, batch.data(), mine.data(), cache.data() + base, (uint32_t)batch.size())) return false;
                 local.t_device += secs(td, now());
-            } else if (std::getenv("BU_TSVQ_SERIAL")) { // debug: one node per launch
+            } else if (dbg_serial) { // debug: one node per launch
                 for (size_t i = 0; i < batch.size(); i++)
                     if (!bu_hip_tsvq_split(ctx, q, &batch[i], 1, cache.data() + base + i)) return false;
             } else {
@@ -274,7 +275,7 @@ private:
                 if (!bu_hip_tsvq_split(ctx, q, batch.data(), (uint32_t)batch.size(), cache.data() + base)) return false;
                 local.t_device += secs(td, now());
             }
-            if (std::getenv("BU_TSVQ_VERIFY")) verify_batch(ctx, q, batch, cache.data() + base, local.rounds);
+            if (dbg_verify) verify_batch(ctx, q, batch, cache.data() + base, local.rounds);
             for (size_t i = 0; i < batch.size(); i++) nodes[batch_nodes[i]].cached = (int32_t)(base + i);
             local.rounds++; local.splits_computed += (uint32_t)batch.size();
         }

@@ -18,6 +18,9 @@ hipError_t launch_tsvq_root(hipStream_t st, int dim, bool packed, bool exact, co
 hipError_t launch_tsvq_split(hipStream_t st, int dim, bool packed, bool exact, const void* d_rows, const uint64_t* d_w64, uint32_t* d_perm0, uint32_t* d_perm1, uint8_t* d_side,
                              const tsvq_node_in* d_nodes, uint32_t n_nodes, tsvq_split_out* d_outs);
 
+// one-thread launch that stores `value` to *d_flag (page-locked host memory) with system scope once everything before it on the stream is done
+hipError_t launch_tsvq_signal(hipStream_t st, uint32_t* d_flag, uint32_t value);
+
 // ---- large nodes spread over many workgroups (tsvq_wide_kernels.hip; packed selector vectors only). Results are bit-identical to
 // launch_tsvq_root / launch_tsvq_split; a split record with ok == 2 (degenerate projection, empty child, data outside the exact
 // integer range) asks for that node to be run through launch_tsvq_split.

@@ -270,6 +270,16 @@ __device__ __forceinline__ void block_sum_u64xN(uint64_t (&v)[K], uint64_t* scra
 }
 
 
+// End-of-round signal for a host that polls (bu_hip_tsvq_split): everything enqueued before this launch on the stream has completed, so the result records
+// the split kernels wrote straight into page-locked host memory are in place; the flag is written with system scope behind them.
+__global__ void k_tsvq_signal(uint32_t* flag, uint32_t value) {
+    if (threadIdx.x == 0) __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+hipError_t launch_tsvq_signal(hipStream_t st, uint32_t* d_flag, uint32_t value) {
+    hipLaunchKernelGGL(k_tsvq_signal, dim3(1), dim3(64), 0, st, d_flag, value);
+    return hipGetLastError();
+}
+
 __global__ __launch_bounds__(256) void k_tsvq_iota(uint32_t n, uint32_t* __restrict__ perm0) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) perm0[i] = i;
