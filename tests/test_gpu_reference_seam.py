@@ -66,3 +66,29 @@ def test_reference_tool_with_resident_frontend_and_backend_writes_the_cpu_tools_
     res, log = _run_any(RESIDENT_TOOL, img, ext, *args)
     assert "failed" not in log.lower(), log[-1500:]
     assert res.shape == cpu.shape and (res == cpu).all()
+
+
+UASTC_TOOL = ORACLE_DIR / "_ref" / "basisu_hip_uastc"
+
+
+@pytest.mark.skipif(not (have_ref_cli() and UASTC_TOOL.exists()), reason="oracle/_ref/basisu_hip_uastc not present")
+@pytest.mark.parametrize("args,ext,alpha", [
+    (("-basis", "-uastc"), "basis", False),                                      # level 2 (the tool's default)
+    (("-basis", "-uastc", "-uastc_level", "1"), "basis", False),
+    (("-basis", "-uastc", "-uastc_level", "3"), "basis", True),                  # alpha: the modes with an alpha plane
+    (("-basis", "-uastc", "-uastc_rdo_l", "1.0"), "basis", False),               # BASELINE configs[4]'s settings: encode + uastc_rdo, one strip
+    (("-uastc", "-uastc_rdo_l", "2.0", "-mipmap"), "ktx2", False),               # the tool's default container (Zstandard over the RDO'd blocks), eight slices
+])
+def test_reference_tool_with_the_uastc_hot_path_on_the_gpu_writes_the_cpu_tools_file(args, ext, alpha):
+    """The reference's basis_compressor / containers / CLI (untouched objects; ONE symbol of basisu_comp.o weakened, oracle/Makefile) over
+    integration/basisu_resident_uastc.cpp: encode_slices_to_uastc_4x4_ldr = bu_hip_encode_uastc_blocks (+ bu_hip_uastc_rdo) per slice on the MI355X
+    instead of encode_uastc per block on the job pool. Same file as the stock tool, byte for byte."""
+    img = synth(256, 192, 79)
+    if alpha:
+        yy, xx = np.mgrid[0:192, 0:256]
+        img[..., 3] = np.clip(128 + 120 * np.sin(xx / 19.0 + yy / 29.0), 0, 255).astype(np.uint8)
+    cpu, _ = _run_any(ORACLE_DIR / "_ref" / "basisu", img, ext, *args)
+    gpu, log = _run_any(UASTC_TOOL, img, ext, *args, "-debug")
+    assert "encode_slices_to_uastc_4x4_ldr (MI355X)" in log, "the stock function ran, not integration/basisu_resident_uastc.cpp"
+    assert "failed" not in log.lower(), log[-1500:]
+    assert gpu.shape == cpu.shape and (gpu == cpu).all()
