@@ -1,13 +1,16 @@
 // tools/valu_calib.hip -- gfx950 micro-benchmark: how many SIMD cycles one wave64 VALU instruction of a given opcode occupies, as a
 // function of the instruction-level parallelism inside a wave (dependent chain vs 8 independent chains) and of the waves resident on a SIMD.
 // This is what prices the instruction-bound ETC1S / UASTC kernels: their bound is VALU issue, and the cost of an
-// instruction is not one number -- v_mul_lo_u32 and the 64-bit forms run at a fraction of the rate of v_add_u32.
+// instruction is not one number. What it measured (profiles/valu_calibration.json): two classes -- ~2.2 cycles for add / sub /
+// logic / right shifts / mov / f32 add, mul, fma and ~4.1 cycles for every other opcode timed (multiplies of any width INCLUDING the 24-bit forms,
+// left shifts, min / max, three-operand integer forms, compares, selects, converts, DPP, dot, packed 16-bit, f64 add) -- and ~8.2 for v_fma_f64 /
+// v_mad_u16. v_mul_lo_u32 is an ordinary member of the 4-cycle class, not an outlier.
 //
-// Method. One launch = (opcode, chains C, waves per SIMD W): 1024 SIMDs x W waves, each wave executes ITER x 32 x C instructions
-// `x[c] = op(x[c], a, b)` (C register chains, round robin: with C = 1 every instruction depends on the one before it, with C = 8 the
-// nearest dependency is 8 instructions away). Every wave brackets its loop with s_memtime and records HW_ID / XCC_ID, so the host can
-// (i) check that the waves really sat W to a SIMD and (ii) divide the median per-wave cycle count by W x instructions:
-//     cycles_per_instruction = median(t1 - t0) / (W x ITER x 32 x C)        [shader cycles a SIMD spends per wave-instruction]
+// Method. One launch = (opcode, chains C, waves per SIMD W): 256-thread workgroups, W per CU (= W waves per SIMD; LDS sized so that no more fit), each
+// wave executes ITER x 32 x C instructions `x[c] = op(x[c], a, b)` (C register chains, round robin: with C = 1 every instruction depends on the one
+// before it, with C = 8 the nearest dependency is 8 instructions away). Every wave records absolute s_memtime at both ends and HW_ID / XCC_ID, so the host can
+// (i) check how many waves really overlapped on a SIMD (the spans, not the launch geometry) and (ii) price an instruction from the launch's wall time:
+//     cycles_per_instruction = SIMD-busy shader cycles / (waves on the SIMD x ITER x 32 x C)        [shader cycles a SIMD spends per wave-instruction]
 // The kernel names carry (op, C, W) as template arguments, so a `rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES ...`
 // pass over this program gives the counters of every cell next to the measured cycles (tools/valu_table.py reads both).
 // Build: hipcc -O2 --offload-arch=gfx950 -o tools/bin/valu_calib tools/valu_calib.hip        Run: tools/bin/valu_calib > valu_calibration.json
