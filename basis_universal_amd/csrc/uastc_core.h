@@ -1548,33 +1548,14 @@ BU_FN bool etc1_estimate_flipped(const rgba8* p) {  // pack_etc1_estimate_flippe
 // The search is 2 flips x 2 colour modes x up to 32 biases, each trial fitting an intensity table per sub-block against the DECODED
 // texels and then scoring the trial against the SOURCE texels, all in a Y/Cb/Cr-like integer space. Everything below is laid out
 // so that a GPU lane keeps the 2 x 16 x 3 texel values in registers: flip and sub-block are template parameters (so every texel
-// index is a compile-time constant) and the squares are written so that they map to the 24-bit multiplier.
+// index is a compile-time constant) and the distances are written for the 32 x 32 + 64-bit multiply-add (etc1_fit_subblock).
 // The reference's row-wise early outs (:2885, :2905, :2946, :2964) only stop once a running error has reached the best one, so
 // they cannot change a result and are dropped; the one early out that does (non-flipped: stop trying intensity tables at the
 // first one that is not better, :2906-2907) is kept.
 
 struct ycc { int y, cb, cr; };
 BU_FN ycc to_ycc(int r, int g, int b) { const int y = imul24(r, 54) + imul24(g, 183) + imul24(b, 19); ycc o = { y, (b << 8) - y, (r << 8) - y }; return o; }
-// d * d for |d| <= 130560 (differences of the 16.8 fixed-point luma / chroma values): the operand is masked to 18 bits so that the
-// compiler can prove it fits the 24-bit multiplier (v_mul_u32_u24 + v_mul_hi_u32_u24, full rate, instead of a 64-bit multiply).
-BU_FN uint64_t square_s18(int d) {
-    const uint32_t a = (uint32_t)(d < 0 ? -d : d) & 0x3FFFFu;
-    return (uint64_t)a * (uint64_t)a;
-}
-BU_FN uint64_t ycc_diff(const ycc& a, const ycc& b) {  // color_diff, uastc_enc.cpp:2646-2652
-    return (square_s18(a.y - b.y) << 2) + square_s18(a.cr - b.cr) + square_s18(a.cb - b.cb);
-}
 struct texels_ycc { ycc t[16]; };
-// The same metric in double precision: every value is an integer far below 2^53, so the arithmetic is exact and orders like the u64 form --
-// but one v_fma_f64 (full rate on gfx950) replaces a 64-bit multiply-add (four 32-bit instructions), and one v_min_f64 a 64-bit
-// compare-and-select. The luma is kept doubled, so (2 dy)^2 is the reference's 4 dy^2.
-struct yccd { double y2, cb, cr; };
-BU_FN yccd to_yccd(const ycc& c) { yccd o = { (double)(2 * c.y), (double)c.cb, (double)c.cr }; return o; }
-BU_FN double ycc_diff_d(const yccd& a, const yccd& b) {
-    const double dy = a.y2 - b.y2, dcb = a.cb - b.cb, dcr = a.cr - b.cr;
-    return __builtin_fma(dy, dy, __builtin_fma(dcr, dcr, dcb * dcb));
-}
-
 // raster index of texel j (0..7) of sub-block SUB; in the flipped layout j runs row by row (g_etc1_pixel_coords, etc.cpp:314-337)
 template <int FLIP, int SUB> constexpr int etc1_texel(int j) { return FLIP ? (SUB * 8 + j) : ((j & 3) * 4 + SUB * 2 + (j >> 2)); }
 
@@ -1592,61 +1573,98 @@ BU_FN void etc1_stats(const rgba8* decoded, etc1_subblock_stats& s) {
         }
 }
 
-BU_FN void etc1_table_colours(const int* base, uint32_t table, yccd* out) {
+// ---- The two functions the search spends its time in, in 64-bit integer form. For a block colour c and a texel t
+//     D(c, t) = 4 (yc - yt)^2 + (cbc - cbt)^2 + (crc - crt)^2 = N(c) + N(t) - 2 (4 yc yt + cbc cbt + crc crt),        N(v) = 4 y^2 + cb^2 + cr^2,
+// so with the colour's -32 y, -8 cb, -8 cr and 4 N(c) prepared once per table, 4 (D - N(t)) is three v_mad_i64_i32 per texel and colour (4 issue
+// cycles each on gfx950, profiles/valu_calibration.json) where the double-precision form is three subtractions, a multiply and two v_fma_f64
+// (8 cycles each). The colour's index rides in the two low bits, so one minimum over the four keys gives the reference's FIRST minimum and
+// which colour it was; N(t) is the same for every colour and table and is added once per sub-block (its sum over the texels). The keys are kept as the
+// bit patterns of doubles in [2^52, 2^53) (offset 2^52 + 2^42 folded into the accumulator's start value): they order like the integers, so
+// the minimum is one v_min_f64, and subtracting the offset as doubles returns the exact integer. Every total is an integer below 2^53: the
+// doubles that come out are the ones the reference computes, bit for bit.
+struct etc1_colour { int a, b, c; long long n; };   // -32 y, -8 cb, -8 cr; 4 N(colour) + colour index + key offset
+BU_TAB long long ku_etc1_key_offset = 0x4330000000000000ll + (1ll << 42);   // bits of the double 2^52 + 2^42; 4 (D - N(t)) > -2^39 keeps every key above 2^52
+BU_FN double etc1_key_value(long long key) {   // 4 (D - N(t)) of a key, colour index dropped
+    return __builtin_bit_cast(double, key & ~3ll) - __builtin_bit_cast(double, ku_etc1_key_offset);
+}
+BU_FN long long etc1_key_min(long long x, long long y) {
+#if defined(__HIPCC__)
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(__builtin_bit_cast(double, x)), "v"(__builtin_bit_cast(double, y)));
+    return __builtin_bit_cast(long long, r);
+#else
+    return x < y ? x : y;
+#endif
+}
+BU_FN void etc1_colour_keys(const int* base, uint32_t table, etc1_colour* col) {
     for (uint32_t k = 0; k < 4; k++) {
         const int d = ku_etc1_inten[table * 4 + k];
-        out[k] = to_yccd(to_ycc(clampi(base[0] + d, 0, 255), clampi(base[1] + d, 0, 255), clampi(base[2] + d, 0, 255)));
+        const ycc c = to_ycc(clampi(base[0] + d, 0, 255), clampi(base[1] + d, 0, 255), clampi(base[2] + d, 0, 255));
+        col[k].a = imul24(c.y, -32); col[k].b = imul24(c.cb, -8); col[k].c = imul24(c.cr, -8);
+        const int y4 = 4 * c.y, cb2 = 2 * c.cb, cr2 = 2 * c.cr;
+        col[k].n = (long long)y4 * y4 + ((long long)cb2 * cb2 + ((long long)cr2 * cr2 + (ku_etc1_key_offset + (long long)k)));
     }
 }
+// x * y + z. Written out for the GPU: left to itself the compiler starts the chain of three from zero and adds the colour's constant with a
+// fourth instruction (v_lshl_add_u64) per key.
+BU_FN long long etc1_mad(int x, int y, long long z) {
+#if defined(__HIPCC__)
+    long long r;
+    asm("v_mad_i64_i32 %0, vcc, %1, %2, %3" : "=v"(r) : "v"(x), "v"(y), "v"(z) : "vcc");
+    return r;
+#else
+    return (long long)x * y + z;
+#endif
+}
+BU_FN long long etc1_key(const etc1_colour& c, const ycc& t) { return etc1_mad(c.a, t.y, etc1_mad(c.b, t.cb, etc1_mad(c.c, t.cr, c.n))); }
+BU_FN double etc1_norm(const ycc& c) {   // N(c)
+    const double y2 = (double)(2 * c.y), cb = (double)c.cb, cr = (double)c.cr;
+    return __builtin_fma(y2, y2, __builtin_fma(cb, cb, cr * cr));
+}
 
-// best intensity table of one sub-block for base colour `base` (uastc_enc.cpp:2858-2918)
+// Best intensity table of one sub-block for base colour `base` (uastc_enc.cpp:2858-2918: first minimum over the tables below `limit` of the texel sums of the
+// distance to the nearest block colour; the non-flipped search stops at the first table that is not better), then the sub-block's error against
+// the SOURCE texels when every texel takes the colour nearest to its DECODED value (:2925-2973). `sn_dec` / `sn_src`: sum of N(texel) over the sub-block.
 template <int FLIP, int SUB>
-BU_FN uint32_t etc1_pick_table(const texels_ycc& dec, const int* base, uint32_t limit) {
+BU_FN void etc1_fit_subblock(const texels_ycc& dec, const rgba8* src, double sn_dec, double sn_src, const int* base, uint32_t limit, uint32_t& table_out, double& err_out) {
     double best = 1e300;
     uint32_t best_table = 0;
+    etc1_colour col[4];
     for (uint32_t table = 0; table < limit; table++) {
-        yccd col[4];
-        etc1_table_colours(base, table, col);
-        double total = 0.0;
+        etc1_colour_keys(base, table, col);
+        double total4 = 0.0;
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
         for (int j = 0; j < 8; j++) {
-            const yccd c = to_yccd(dec.t[etc1_texel<FLIP, SUB>(j)]);
-            double m = ycc_diff_d(col[0], c);
-            for (int k = 1; k < 4; k++) { const double d = ycc_diff_d(col[k], c); m = d < m ? d : m; }
-            total += m;
+            const ycc& t = dec.t[etc1_texel<FLIP, SUB>(j)];
+            total4 += etc1_key_value(etc1_key_min(etc1_key_min(etc1_key(col[0], t), etc1_key(col[1], t)), etc1_key_min(etc1_key(col[2], t), etc1_key(col[3], t))));
         }
+        const double total = __builtin_fma(total4, 0.25, sn_dec);
         if (!FLIP && total >= best) break;
         if (total < best) { best = total; best_table = table; }
     }
-    return best_table;
-}
-
-// error of one sub-block against the source texels when every texel takes the colour nearest to its decoded value (:2925-2973)
-template <int FLIP, int SUB>
-BU_FN double etc1_subblock_error(const texels_ycc& dec, const rgba8* src, const int* base, uint32_t table) {
-    yccd col[4];
-    etc1_table_colours(base, table, col);
-    double err = 0.0;
+    table_out = best_table;
+    etc1_colour_keys(base, best_table, col);
+    double err4 = 0.0;
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
     for (int j = 0; j < 8; j++) {
-        const int t = etc1_texel<FLIP, SUB>(j);
-        const yccd c = to_yccd(dec.t[t]);
-        // first minimum: the chosen colour is carried by value (a dynamically indexed local array would live in scratch memory on the GPU)
-        double m = ycc_diff_d(col[0], c);
-        yccd chosen = col[0];
-        for (int k = 1; k < 4; k++) {
-            const double d = ycc_diff_d(col[k], c);
-            const bool better = d < m;
-            m = better ? d : m;
-            chosen.y2 = better ? col[k].y2 : chosen.y2; chosen.cb = better ? col[k].cb : chosen.cb; chosen.cr = better ? col[k].cr : chosen.cr;
-        }
-        err += ycc_diff_d(to_yccd(to_ycc(src[t].c[0], src[t].c[1], src[t].c[2])), chosen);  // converted here: 48 fewer live registers than a second texel table
+        const int ti = etc1_texel<FLIP, SUB>(j);
+        const ycc& t = dec.t[ti];
+        const long long m = etc1_key_min(etc1_key_min(etc1_key(col[0], t), etc1_key(col[1], t)), etc1_key_min(etc1_key(col[2], t), etc1_key(col[3], t)));
+        // the chosen colour is selected field by field (a dynamically indexed local array would live in scratch memory on the GPU, and
+        // conditional struct copies become branches)
+        const bool odd = ((int)m & 1) != 0, upper = ((int)m & 2) != 0;
+        etc1_colour ch;
+        ch.a = upper ? (odd ? col[3].a : col[2].a) : (odd ? col[1].a : col[0].a);
+        ch.b = upper ? (odd ? col[3].b : col[2].b) : (odd ? col[1].b : col[0].b);
+        ch.c = upper ? (odd ? col[3].c : col[2].c) : (odd ? col[1].c : col[0].c);
+        ch.n = upper ? (odd ? col[3].n : col[2].n) : (odd ? col[1].n : col[0].n);
+        err4 += etc1_key_value(etc1_key(ch, to_ycc(src[ti].c[0], src[ti].c[1], src[ti].c[2])));
     }
-    return err;
+    err_out = __builtin_fma(err4, 0.25, sn_src);
 }
 
 struct etc1_search { double best_err; etc1_hint best; };
@@ -1672,6 +1690,17 @@ BU_FN void etc1_trials(uint32_t mode, const rgba8* decoded, const texels_ycc& de
     etc1_subblock_stats st[2];
     etc1_stats<FLIP, 0>(decoded, st[0]);
     etc1_stats<FLIP, 1>(decoded, st[1]);
+    double sn_dec[2] = { 0.0, 0.0 }, sn_src[2] = { 0.0, 0.0 };
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+    for (int j = 0; j < 8; j++) {
+        sn_dec[0] += etc1_norm(dec.t[etc1_texel<FLIP, 0>(j)]);
+        sn_dec[1] += etc1_norm(dec.t[etc1_texel<FLIP, 1>(j)]);
+        const rgba8 &s0 = src[etc1_texel<FLIP, 0>(j)], &s1 = src[etc1_texel<FLIP, 1>(j)];
+        sn_src[0] += etc1_norm(to_ycc(s0.c[0], s0.c[1], s0.c[2]));
+        sn_src[1] += etc1_norm(to_ycc(s1.c[0], s1.c[1], s1.c[2]));
+    }
     for (uint32_t individ = 0; individ < last_individ; individ++) {
         const uint32_t mul = individ ? 15 : 31;
         uint32_t unbiased[2][3];
@@ -1713,15 +1742,13 @@ BU_FN void etc1_trials(uint32_t mode, const rgba8* decoded, const texels_ycc& de
             if (reuse && !((ku_bias_first[order][0] >> bi) & 1u)) {
                 t0 = cache->table[s0 * cache->stride]; e0 = cache->err[s0 * cache->stride];
             } else {
-                t0 = etc1_pick_table<FLIP, 0>(dec, base[0], limit[0]);
-                e0 = etc1_subblock_error<FLIP, 0>(dec, src, base[0], t0);
+                etc1_fit_subblock<FLIP, 0>(dec, src, sn_dec[0], sn_src[0], base[0], limit[0], t0, e0);
                 if (reuse) { cache->table[s0 * cache->stride] = (unsigned char)t0; cache->err[s0 * cache->stride] = e0; }
             }
             if (reuse && individ && !((ku_bias_first[order][1] >> bi) & 1u)) {
                 t1 = cache->table[s1 * cache->stride]; e1 = cache->err[s1 * cache->stride];
             } else {
-                t1 = etc1_pick_table<FLIP, 1>(dec, base[1], limit[1]);
-                e1 = etc1_subblock_error<FLIP, 1>(dec, src, base[1], t1);
+                etc1_fit_subblock<FLIP, 1>(dec, src, sn_dec[1], sn_src[1], base[1], limit[1], t1, e1);
                 if (reuse && individ) { cache->table[s1 * cache->stride] = (unsigned char)t1; cache->err[s1 * cache->stride] = e1; }
             }
             const double err = e0 + e1;

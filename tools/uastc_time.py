@@ -1,21 +1,30 @@
-"""Time the UASTC phases on the GPU (HIP events per phase): python tools/uastc_time.py [size] [flags]"""
-import sys, time, pathlib
-root = pathlib.Path(__file__).resolve().parent.parent
-sys.path.insert(0, str(root)); sys.path.insert(0, str(root / "tests"))
+#!/usr/bin/env python3
+"""Per-kernel time of the UASTC encoder for a few flag sets, on the bench image (synth 4096^2) and on the Kodak batch.   tools/uastc_time.py [steps]"""
+import sys, pathlib, json
 import numpy as np
+ROOT = pathlib.Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
+import torch
 import helpers
-from basis_universal_amd import capi, uastc
-size = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
-flags = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+from basis_universal_amd import uastc
+from basis_universal_amd import capi
+
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 ctx = capi.Context(0)
-blocks = helpers.to_pixel_blocks(helpers.synth(size, size, 1234))
-n = blocks.shape[0]
-d_px = ctx.upload(blocks); d_out = ctx.alloc(n * 16)
-for it in range(3):
-    ctx.profile_enable(True)
-    t0 = time.perf_counter()
-    uastc.encode_uastc_blocks(ctx, d_px, flags, n_blocks=n, out_device=d_out)
-    ctx.sync()
-    dt = time.perf_counter() - t0
-    k = ctx.profile_read()
-    print(f"run {it}: {dt*1e3:.1f} ms  {size*size/1e6/dt:.1f} Mpix/s ", {a: round(b[0], 2) for a, b in k.items()}, flush=True)
+z = np.load(ROOT / "tests" / "golden" / "kodak24.npz")
+kodak = np.concatenate([helpers.to_pixel_blocks(np.concatenate([z[k], np.full(z[k].shape[:2] + (1,), 255, np.uint8)], axis=2)) for k in sorted(z.files)])
+sets = {"synth4096": helpers.to_pixel_blocks(helpers.synth(4096, 4096, 1234)), "kodak24": kodak}
+for name, blocks in sets.items():
+    d = torch.from_numpy(np.ascontiguousarray(blocks)).cuda()
+    n = blocks.shape[0]
+    out = torch.empty((n, 16), dtype=torch.uint8, device="cuda")
+    for label, flags in [("level2", uastc.LEVEL_DEFAULT), ("level2+faster", uastc.LEVEL_DEFAULT | uastc.ETC1_FASTER_HINTS), ("level2+fastest", uastc.LEVEL_DEFAULT | uastc.ETC1_FASTEST_HINTS),
+                         ("level2+noflip", uastc.LEVEL_DEFAULT | uastc.ETC1_DISABLE_FLIP_AND_INDIVIDUAL), ("level1", uastc.LEVEL_FASTER), ("level3", uastc.LEVEL_SLOWER)]:
+        uastc.encode_uastc_blocks(ctx, d.data_ptr(), flags, n_blocks=n, out_device=out.data_ptr())
+        torch.cuda.synchronize()
+        ctx.profile_enable(True)
+        for _ in range(steps):
+            uastc.encode_uastc_blocks(ctx, d.data_ptr(), flags, n_blocks=n, out_device=out.data_ptr())
+        torch.cuda.synchronize()
+        k = ctx.profile_read(); ctx.profile_enable(False)
+        print(name, n, label, {a: round(v[0] / steps, 3) for a, v in k.items()}, flush=True)

@@ -31,7 +31,7 @@ enum op_id {
     OP_MUL_I32_I24, OP_MUL_U32_U24, OP_MAD_U32_U24, OP_MAD_I32_I24, OP_MUL_LO_U32, OP_MUL_HI_U32, OP_MAD_U64_U32, OP_BFE_U32, OP_PERM_B32, OP_SAD_U8,
     OP_DOT2_I32_I16, OP_DOT4_I32_I8, OP_PK_MUL_LO_U16, OP_PK_MAD_U16, OP_PK_ADD_U16, OP_PK_MAX_I16, OP_MAD_U16, OP_ADD_F32, OP_FMA_F32, OP_FMA_F64, OP_ADD_F64, OP_MOV_DPP,
     OP_ADD_DPP, OP_CVT_F32_U32, OP_MBCNT, OP_MOV_B32, OP_AND_B32, OP_OR_B32, OP_XOR_B32, OP_LSHLREV, OP_ASHRREV, OP_MIN_I32, OP_MUL_F32, OP_MIN_F32, OP_MAX_F32,
-    OP_CVT_U32_F32, OP_FMAC_F32, OP_ADD_CO_U32, OP_CMP_CNDMASK, OP_COUNT
+    OP_CVT_U32_F32, OP_FMAC_F32, OP_ADD_CO_U32, OP_CMP_CNDMASK, OP_MAD_I64_I32, OP_LSHL_ADD_U64, OP_MIN_F64, OP_MUL_F64, OP_FMA_F64_SQUARE, OP_CMP_LT_F64, OP_CVT_F64_I32, OP_COUNT
 };
 
 static const char* const OP_NAME[OP_COUNT] = {
@@ -39,7 +39,8 @@ static const char* const OP_NAME[OP_COUNT] = {
     "v_mul_i32_i24", "v_mul_u32_u24", "v_mad_u32_u24", "v_mad_i32_i24", "v_mul_lo_u32", "v_mul_hi_u32", "v_mad_u64_u32", "v_bfe_u32", "v_perm_b32", "v_sad_u8",
     "v_dot2_i32_i16", "v_dot4_i32_i8", "v_pk_mul_lo_u16", "v_pk_mad_u16", "v_pk_add_u16", "v_pk_max_i16", "v_mad_u16", "v_add_f32", "v_fma_f32", "v_fma_f64", "v_add_f64", "v_mov_b32_dpp",
     "v_add_u32_dpp", "v_cvt_f32_u32", "v_mbcnt_lo_u32_b32", "v_mov_b32", "v_and_b32", "v_or_b32", "v_xor_b32", "v_lshlrev_b32", "v_ashrrev_i32", "v_min_i32", "v_mul_f32", "v_min_f32",
-    "v_max_f32", "v_cvt_u32_f32", "v_fmac_f32", "v_add_co_u32", "v_cmp_lt_u32+v_cndmask_b32"};
+    "v_max_f32", "v_cvt_u32_f32", "v_fmac_f32", "v_add_co_u32", "v_cmp_lt_u32+v_cndmask_b32", "v_mad_i64_i32", "v_lshl_add_u64", "v_min_f64", "v_mul_f64", "v_fma_f64 (a, a, x)", "v_cmp_lt_f64",
+    "v_cvt_f64_i32"};
 
 template <int OP> __device__ __forceinline__ void step(uint32_t& x, uint64_t& x64, uint32_t a, uint32_t b, uint64_t mask) {
     if constexpr (OP == OP_ADD_U32) asm volatile("v_add_u32 %0, %0, %1" : "+v"(x) : "v"(a));
@@ -93,6 +94,13 @@ template <int OP> __device__ __forceinline__ void step(uint32_t& x, uint64_t& x6
     else if constexpr (OP == OP_ADD_DPP) asm volatile("v_add_u32_dpp %0, %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(x) : "v"(a));
     else if constexpr (OP == OP_CVT_F32_U32) asm volatile("v_cvt_f32_u32 %0, %0" : "+v"(x));
     else if constexpr (OP == OP_MBCNT) asm volatile("v_mbcnt_lo_u32_b32 %0, %1, %0" : "+v"(x) : "v"(a));
+    else if constexpr (OP == OP_MAD_I64_I32) asm volatile("v_mad_i64_i32 %0, vcc, %1, %2, %0" : "+v"(x64) : "v"(a), "v"(b) : "vcc");
+    else if constexpr (OP == OP_LSHL_ADD_U64) asm volatile("v_lshl_add_u64 %0, %0, 0, %1" : "+v"(x64) : "v"(x64 | 1));
+    else if constexpr (OP == OP_MIN_F64) asm volatile("v_min_f64 %0, %0, %1" : "+v"(x64) : "v"(x64 | 1));
+    else if constexpr (OP == OP_MUL_F64) asm volatile("v_mul_f64 %0, %0, %1" : "+v"(x64) : "v"(x64 | 1));
+    else if constexpr (OP == OP_FMA_F64_SQUARE) asm volatile("v_fma_f64 %0, %1, %1, %0" : "+v"(x64) : "v"(x64 | 1));
+    else if constexpr (OP == OP_CMP_LT_F64) asm volatile("v_cmp_lt_f64 vcc, %0, %1" : : "v"(x64), "v"(x64 | 1) : "vcc");
+    else if constexpr (OP == OP_CVT_F64_I32) asm volatile("v_cvt_f64_i32 %0, %1" : "=v"(x64) : "v"(x));
 }
 
 struct wave_rec { uint64_t t0, t1; uint32_t hw_id, xcc_id; };
@@ -136,7 +144,7 @@ template <int OP> constexpr int insts_per_step() { return OP == OP_CMP_CNDMASK ?
 
 template <int OP, int CH, int W> static result run_cell(uint32_t* d_out, wave_rec* d_rec, int n_cu) {
     const int threads = 256, blocks = n_cu * W, waves = blocks * threads / 64;   // a 256-thread workgroup = one wave per SIMD; W workgroups per CU
-    const int iters = (OP == OP_MUL_LO_U32 || OP == OP_MUL_HI_U32 || OP == OP_MAD_U64_U32 || OP == OP_FMA_F64 || OP == OP_ADD_F64) ? 64 : 128;
+    const int iters = (OP == OP_MUL_LO_U32 || OP == OP_MUL_HI_U32 || OP == OP_MAD_U64_U32 || OP == OP_FMA_F64 || OP == OP_ADD_F64 || OP >= OP_MAD_I64_I32) ? 64 : 128;
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     hipLaunchKernelGGL((k_calib<OP, CH, W>), dim3(blocks), dim3(threads), 0, 0, d_out, d_rec, 8, 1u);   // warm-up (clock ramp, code fetch)
@@ -184,11 +192,13 @@ template <int OP> static void run_op(uint32_t* d_out, wave_rec* d_rec, int n_cu,
     out.push_back(run_cell<OP, 8, 8>(d_out, d_rec, n_cu));
 }
 
+static int g_first_op = 0;   // argv[1]: skip the opcodes before this index (adding opcodes without re-timing the table)
 template <int OP> static void run_all(uint32_t* d_out, wave_rec* d_rec, int n_cu, std::vector<result>& out) {
-    if constexpr (OP < OP_COUNT) { run_op<OP>(d_out, d_rec, n_cu, out); run_all<OP + 1>(d_out, d_rec, n_cu, out); }
+    if constexpr (OP < OP_COUNT) { if (OP >= g_first_op) run_op<OP>(d_out, d_rec, n_cu, out); run_all<OP + 1>(d_out, d_rec, n_cu, out); }
 }
 
-int main() {
+int main(int argc, char** argv) {
+    if (argc > 1) g_first_op = std::atoi(argv[1]);
     hipDeviceProp_t p; CK(hipGetDeviceProperties(&p, 0));
     const int n_cu = p.multiProcessorCount;
     uint32_t* d_out; wave_rec* d_rec;
