@@ -3,8 +3,8 @@
 // This is what prices the instruction-bound ETC1S / UASTC kernels: their bound is VALU issue, and the cost of an
 // instruction is not one number. What it measured (profiles/valu_calibration.json): two classes -- ~2.2 cycles for add / sub /
 // logic / right shifts / mov / f32 add, mul, fma and ~4.1 cycles for every other opcode timed (multiplies of any width INCLUDING the 24-bit forms,
-// left shifts, min / max, three-operand integer forms, compares, selects, converts, DPP, dot, packed 16-bit, f64 add) -- and ~8.2 for v_fma_f64 /
-// v_mad_u16. v_mul_lo_u32 is an ordinary member of the 4-cycle class, not an outlier.
+// left shifts, min / max, three-operand integer forms, compares, selects, converts, DPP, dot, packed 16-bit, double-precision add / mul / fma / min,
+// v_mad_i64_i32) -- and ~8.1 for v_mad_u16. v_mul_lo_u32 is an ordinary member of the 4-cycle class, not an outlier.
 //
 // Method. One launch = (opcode, chains C, waves per SIMD W): 256-thread workgroups, W per CU (= W waves per SIMD; LDS sized so that no more fit), each
 // wave executes ITER x 32 x C instructions `x[c] = op(x[c], a, b)` (C register chains, round robin: with C = 1 every instruction depends on the one
@@ -42,7 +42,9 @@ static const char* const OP_NAME[OP_COUNT] = {
     "v_max_f32", "v_cvt_u32_f32", "v_fmac_f32", "v_add_co_u32", "v_cmp_lt_u32+v_cndmask_b32", "v_mad_i64_i32", "v_lshl_add_u64", "v_min_f64", "v_mul_f64", "v_fma_f64 (a, a, x)", "v_cmp_lt_f64",
     "v_cvt_f64_i32"};
 
-template <int OP> __device__ __forceinline__ void step(uint32_t& x, uint64_t& x64, uint32_t a, uint32_t b, uint64_t mask) {
+// c64: a loop-invariant 64-bit VGPR pair for the second operand of the 64-bit opcodes (the first version of this file built it inside the loop with a v_or +
+// v_mov per step, which it then timed along with v_fma_f64: 8.3 cycles reported for a 4.1-cycle instruction)
+template <int OP> __device__ __forceinline__ void step(uint32_t& x, uint64_t& x64, uint32_t a, uint32_t b, uint64_t mask, uint64_t c64) {
     if constexpr (OP == OP_ADD_U32) asm volatile("v_add_u32 %0, %0, %1" : "+v"(x) : "v"(a));
     else if constexpr (OP == OP_SUB_U32) asm volatile("v_sub_u32 %0, %0, %1" : "+v"(x) : "v"(a));
     else if constexpr (OP == OP_LSHRREV) asm volatile("v_lshrrev_b32 %0, 1, %0" : "+v"(x));
@@ -88,18 +90,18 @@ template <int OP> __device__ __forceinline__ void step(uint32_t& x, uint64_t& x6
     else if constexpr (OP == OP_MAD_U16) asm volatile("v_mad_u16 %0, %0, %1, %2" : "+v"(x) : "v"(a), "v"(b));
     else if constexpr (OP == OP_ADD_F32) asm volatile("v_add_f32 %0, %0, %1" : "+v"(x) : "v"(a));
     else if constexpr (OP == OP_FMA_F32) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(x) : "v"(a), "v"(b));
-    else if constexpr (OP == OP_FMA_F64) asm volatile("v_fma_f64 %0, %0, %1, %1" : "+v"(x64) : "v"(x64 | 1));
+    else if constexpr (OP == OP_FMA_F64) asm volatile("v_fma_f64 %0, %0, %1, %1" : "+v"(x64) : "v"(c64));
     else if constexpr (OP == OP_ADD_F64) asm volatile("v_add_f64 %0, %0, %0" : "+v"(x64));
     else if constexpr (OP == OP_MOV_DPP) asm volatile("v_mov_b32_dpp %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(x));
     else if constexpr (OP == OP_ADD_DPP) asm volatile("v_add_u32_dpp %0, %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(x) : "v"(a));
     else if constexpr (OP == OP_CVT_F32_U32) asm volatile("v_cvt_f32_u32 %0, %0" : "+v"(x));
     else if constexpr (OP == OP_MBCNT) asm volatile("v_mbcnt_lo_u32_b32 %0, %1, %0" : "+v"(x) : "v"(a));
     else if constexpr (OP == OP_MAD_I64_I32) asm volatile("v_mad_i64_i32 %0, vcc, %1, %2, %0" : "+v"(x64) : "v"(a), "v"(b) : "vcc");
-    else if constexpr (OP == OP_LSHL_ADD_U64) asm volatile("v_lshl_add_u64 %0, %0, 0, %1" : "+v"(x64) : "v"(x64 | 1));
-    else if constexpr (OP == OP_MIN_F64) asm volatile("v_min_f64 %0, %0, %1" : "+v"(x64) : "v"(x64 | 1));
-    else if constexpr (OP == OP_MUL_F64) asm volatile("v_mul_f64 %0, %0, %1" : "+v"(x64) : "v"(x64 | 1));
-    else if constexpr (OP == OP_FMA_F64_SQUARE) asm volatile("v_fma_f64 %0, %1, %1, %0" : "+v"(x64) : "v"(x64 | 1));
-    else if constexpr (OP == OP_CMP_LT_F64) asm volatile("v_cmp_lt_f64 vcc, %0, %1" : : "v"(x64), "v"(x64 | 1) : "vcc");
+    else if constexpr (OP == OP_LSHL_ADD_U64) asm volatile("v_lshl_add_u64 %0, %0, 0, %1" : "+v"(x64) : "v"(c64));
+    else if constexpr (OP == OP_MIN_F64) asm volatile("v_min_f64 %0, %0, %1" : "+v"(x64) : "v"(c64));
+    else if constexpr (OP == OP_MUL_F64) asm volatile("v_mul_f64 %0, %0, %1" : "+v"(x64) : "v"(c64));
+    else if constexpr (OP == OP_FMA_F64_SQUARE) asm volatile("v_fma_f64 %0, %1, %1, %0" : "+v"(x64) : "v"(c64));
+    else if constexpr (OP == OP_CMP_LT_F64) asm volatile("v_cmp_lt_f64 vcc, %0, %1" : : "v"(x64), "v"(c64) : "vcc");
     else if constexpr (OP == OP_CVT_F64_I32) asm volatile("v_cvt_f64_i32 %0, %1" : "=v"(x64) : "v"(x));
 }
 
@@ -114,6 +116,8 @@ __global__ void __launch_bounds__(256) k_calib(uint32_t* out, wave_rec* rec, int
 #pragma unroll
     for (int c = 0; c < CH; c++) { x[c] = tid + c * 977u + seed; x64[c] = (uint64_t)x[c] << 20 | 0x3ff0000000000000ull; }
     const uint64_t mask = __ballot((tid & 3u) != 0u);   // wave-uniform: lives in an SGPR pair
+    uint64_t c64 = 0x3ff0000000000001ull + tid;   // ~1.0 as a double
+    asm volatile("" : "+v"(c64));
     asm volatile("v_cmp_lt_u32 vcc, %0, %1" : : "v"(a), "v"(b) : "vcc");
     __syncthreads();
     uint64_t t0, t1;
@@ -122,7 +126,7 @@ __global__ void __launch_bounds__(256) k_calib(uint32_t* out, wave_rec* rec, int
 #pragma unroll
         for (int u = 0; u < 32; u++)
 #pragma unroll
-            for (int c = 0; c < CH; c++) step<OP>(x[c], x64[c], a, b, mask);
+            for (int c = 0; c < CH; c++) step<OP>(x[c], x64[c], a, b, mask, c64);
     }
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1));
     uint32_t acc = 0;

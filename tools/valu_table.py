@@ -7,7 +7,7 @@
                                 with the SIMD saturated (8 independent chains, 8 waves per SIMD). Two classes and a few outliers: ~2.2 cycles for
                                 add / sub / and / or / xor / right shifts / mov / f32 add, mul, fma -- ~4.1 cycles for everything else (multiplies of
                                 any width, min / max, left shifts, three-operand integer forms, compares, selects, converts, DPP, packed 16-bit,
-                                f64 add) -- ~8.2 for v_fma_f64 and v_mad_u16.
+                                double precision add / mul / fma / min, the 32 x 32 + 64-bit multiply-add) -- ~8.1 for v_mad_u16.
   * how many were executed      SQ_INSTS_VALU per launch of the kernel (one `rocprofv3 --pmc` pass over bench.py; SQ_ACTIVE_INST_VALU is the same
                                 number on gfx950: it counts instructions, not cycles -- the calibration pass shows it, profiles/r03b_pmc_calib.csv)
   * of which opcodes            the kernel's ISA (hipcc -S of the same source, same flags): STATIC opcode counts of the kernel's function. The dynamic
@@ -50,7 +50,7 @@ def load_calibration(path):
             cost[c["op"]] = c["cycles_per_inst"]
     # opcodes that are the same hardware operation as a measured one
     alias = {"v_subrev_u32": "v_sub_u32", "v_sub_f32": "v_add_f32", "v_subrev_f32": "v_add_f32", "v_mac_f32": "v_fmac_f32", "v_max_u32": "v_min_u32", "v_min_i32": "v_min_i32",
-             "v_max_f32": "v_max_f32", "v_not_b32": "v_xor_b32", "v_mov_b32_dpp": "v_mov_b32_dpp", "v_fma_f64": "v_fma_f64", "v_mul_f64": "v_fma_f64", "v_add_f64": "v_add_f64",
+             "v_max_f32": "v_max_f32", "v_not_b32": "v_xor_b32", "v_mov_b32_dpp": "v_mov_b32_dpp", "v_fma_f64": "v_fma_f64", "v_mul_f64": "v_mul_f64", "v_fmac_f64": "v_fma_f64", "v_max_f64": "v_min_f64", "v_mad_i64_i32": "v_mad_i64_i32", "v_cvt_f64_u32": "v_cvt_f64_i32", "v_mov_b64": "v_lshl_add_u64", "v_add_f64": "v_add_f64",
              "v_max3_u32": "v_min3_u32", "v_max3_i32": "v_min3_u32", "v_min3_i32": "v_min3_u32", "v_med3_u32": "v_med3_i32", "v_bfe_i32": "v_bfe_u32", "v_sub_co_u32": "v_add_co_u32",
              "v_addc_co_u32": "v_add_co_u32", "v_subb_co_u32": "v_add_co_u32", "v_subrev_co_u32": "v_add_co_u32", "v_lshlrev_b64": "v_lshlrev_b32", "v_lshrrev_b64": "v_lshlrev_b32",
              "v_mbcnt_hi_u32_b32": "v_mbcnt_lo_u32_b32", "v_cvt_f32_i32": "v_cvt_f32_u32", "v_cvt_i32_f32": "v_cvt_u32_f32"}
@@ -71,7 +71,7 @@ def opcode_cycles(op, cost):
 
 def isa_mix(isa_dir, cost):
     """kernel label (rocprof_summary.short of the demangled name is not available for .s symbols, so: mangled symbol) -> opcode histogram"""
-    out = {}
+    out, calls = {}, {}
     for s in sorted(pathlib.Path(isa_dir).glob("*.s")):
         cur, hist = None, None
         for line in s.read_text().splitlines():
@@ -79,6 +79,7 @@ def isa_mix(isa_dir, cost):
             if m:
                 cur, hist = m.group(1), collections.Counter()
                 out[cur] = hist
+                calls[cur] = set()
                 continue
             if cur is None:
                 continue
@@ -88,7 +89,24 @@ def isa_mix(isa_dir, cost):
             t = line.strip().split()
             if t and t[0].startswith("v_"):
                 hist[base_opcode(t[0])] += 1
-    return out
+            c = re.search(r"(_Z\w+)@rel32@lo", line)
+            if c:
+                calls[cur].add(c.group(1))
+    # a kernel's mix includes the functions it calls (the UASTC kernels keep their big stages out of line: the kernel's own body is a few hundred instructions,
+    # the work is in the callees)
+    def closure(sym, seen):
+        for c in calls.get(sym, ()):
+            if c in out and c not in seen:
+                seen.add(c)
+                closure(c, seen)
+        return seen
+    merged = {}
+    for sym, hist in out.items():
+        h = collections.Counter(hist)
+        for c in closure(sym, {sym}) - {sym}:
+            h.update(out[c])
+        merged[sym] = h
+    return merged
 
 
 def demangle(names):
@@ -182,7 +200,7 @@ def main():
                         "busy": "SQ_INSTS_VALU x static mean cycles per instruction / (1024 SIMDs x SQ_BUSY_CYCLES / 32); cycles per opcode measured by tools/valu_calib.hip "
                                 "(profiles/valu_calibration.json), opcode mix = static counts of the kernel's ISA; no clock frequency assumed",
                         "ceiling": "1.0 = every SIMD issue cycle taken by a VALU instruction. Per opcode class (MI355X, measured): ~2.2 cycles per wave64 instruction for add/sub/logic/right "
-                                   "shift/mov/f32 add-mul-fma, ~4.1 for every other integer, compare, select, convert and packed opcode, ~8.2 for v_fma_f64 / v_mad_u16"}
+                                   "shift/mov/f32 add-mul-fma, ~4.1 for every other integer, compare, select, convert, packed and double-precision opcode, ~8.1 for v_mad_u16"}
         print(json.dumps(out, indent=1, sort_keys=True))
     else:
         print("| kernel | VALU instructions / launch | static mix 2 / 4 / 8-cycle | mean cycles / instruction | launch, shader cycles | VALU-busy | waves stalled on issue |")
