@@ -165,8 +165,3 @@ HC_API int hc_rehint(const uint8_t* pixels, uint32_t n, uint32_t flags, uint8_t*
         if (!rdo_rehint((const rgba8*)(pixels + (size_t)i * 64), e, blocks + (size_t)i * 16)) return 0;
     return 1;
 }
-
-#if defined(BU_ETC1_STATS)
-// developer aid (tools/etc1_hint_stats.py): how many table / error evaluations of the ETC1 hint search took the integer form
-HC_API void hc_etc1_stats(unsigned long long* out4, int reset) { for (int i = 0; i < 4; i++) { out4[i] = g_etc1_stats[i]; if (reset) g_etc1_stats[i] = 0; } }
-#endif

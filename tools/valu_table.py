@@ -9,7 +9,7 @@
                                 any width, min / max, left shifts, three-operand integer forms, compares, selects, converts, DPP, packed 16-bit,
                                 double precision add / mul / fma / min, the 32 x 32 + 64-bit multiply-add) -- ~8.1 for v_mad_u16.
   * how many were executed      SQ_INSTS_VALU per launch of the kernel (one `rocprofv3 --pmc` pass over bench.py; SQ_ACTIVE_INST_VALU is the same
-                                number on gfx950: it counts instructions, not cycles -- the calibration pass shows it, profiles/r03b_pmc_calib.csv)
+                                number on gfx950: it counts instructions, not cycles -- the calibration pass shows it, profiles/r03h_pmc_calib.csv)
   * of which opcodes            the kernel's ISA (hipcc -S of the same source, same flags): STATIC opcode counts of the kernel's function. The dynamic
                                 mix is not observable with counters; the static one stands in for it (the hot loops are most of these kernels' code).
   * over how many cycles        SQ_BUSY_CYCLES / 32 = the launch's duration in shader cycles (32 = the counter's instances: 8 XCDs x 4 shader engines;
