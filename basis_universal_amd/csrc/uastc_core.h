@@ -1576,8 +1576,8 @@ BU_FN void etc1_stats(const rgba8* decoded, etc1_subblock_stats& s) {
 // ---- The two functions the search spends its time in, in 64-bit integer form. For a block colour c and a texel t
 //     D(c, t) = 4 (yc - yt)^2 + (cbc - cbt)^2 + (crc - crt)^2 = N(c) + N(t) - 2 (4 yc yt + cbc cbt + crc crt),        N(v) = 4 y^2 + cb^2 + cr^2,
 // so with the colour's -32 y, -8 cb, -8 cr and 4 N(c) prepared once per table, 4 (D - N(t)) is three v_mad_i64_i32 per texel and colour (4 issue
-// cycles each on gfx950, profiles/valu_calibration.json) where the double-precision form is three subtractions, a multiply and two v_fma_f64
-// (8 cycles each). The colour's index rides in the two low bits, so one minimum over the four keys gives the reference's FIRST minimum and
+// cycles each on gfx950, profiles/valu_calibration.json) where the double-precision form is three subtractions, a multiply, two v_fma_f64 and a
+// compare + two selects for the minimum. The colour's index rides in the two low bits, so one minimum over the four keys gives the reference's FIRST minimum and
 // which colour it was; N(t) is the same for every colour and table and is added once per sub-block (its sum over the texels). The keys are kept as the
 // bit patterns of doubles in [2^52, 2^53) (offset 2^52 + 2^42 folded into the accumulator's start value): they order like the integers, so
 // the minimum is one v_min_f64, and subtracting the offset as doubles returns the exact integer. Every total is an integer below 2^53: the
@@ -1617,34 +1617,113 @@ BU_FN long long etc1_mad(int x, int y, long long z) {
 #endif
 }
 BU_FN long long etc1_key(const etc1_colour& c, const ycc& t) { return etc1_mad(c.a, t.y, etc1_mad(c.b, t.cb, etc1_mad(c.c, t.cr, c.n))); }
-BU_FN double etc1_norm(const ycc& c) {   // N(c)
+// ---- The same sums when NO colour of the table clamps, i.e. when the four block colours are base + d (1, 1, 1) exactly. (1, 1, 1) is pure luma in this space
+// (54 + 183 + 19 = 256 and both chroma rows sum to zero), so with dy = y(base) - y(t)
+//     D(base + d, t) = 4 (dy + 256 d)^2 + dcb^2 + dcr^2 = D(base, t) + 2048 d (dy + 128 d),
+// and what depends on the table is a 32-bit integer. With the table's modifiers -b, -a, a, b (a < b) the minimum over the four colours is
+// min(a (128 a - |dy|), b (128 b - |dy|)), and the FIRST colour in table order that reaches it (the reference's strict "<") is -b or -a for dy >= 0 (-b on a tie),
+// +a or +b for dy < 0 (+a on a tie). The texel sums of D(base, t) are closed forms in the sub-block's moments. Exact integers throughout, so the totals are
+// the same doubles as the general form's. This form is only worth taking when EVERY lane of the wave can take it (a wave runs both sides of a branch
+// its lanes disagree on): the encoder therefore hands the finish kernel its blocks grouped by how much head room their colours have (uastc_kernels.hip,
+// etc1_order_key), and the test below is wave-wide. The host build decides per block; both forms give the same numbers, so it does not matter which ran.
+BU_TAB unsigned char ku_etc1_inten_small[8] = { 2, 5, 9, 13, 18, 24, 33, 47 };
+BU_TAB unsigned char ku_etc1_inten_large[8] = { 8, 17, 29, 42, 60, 80, 106, 183 };
+#if defined(__HIPCC__)
+#define BU_WAVE_ALL(cond) (__builtin_amdgcn_ballot_w64(!(cond)) == 0ull)
+#else
+#define BU_WAVE_ALL(cond) (cond)
+#endif
+struct etc1_moments { int sy, scb, scr; double sn; };   // sums over a sub-block's 8 texels of y, cb, cr and of N(texel)
+BU_FN void etc1_moments_add(etc1_moments& m, const ycc& c) {
+    m.sy += c.y; m.scb += c.cb; m.scr += c.cr;
     const double y2 = (double)(2 * c.y), cb = (double)c.cb, cr = (double)c.cr;
-    return __builtin_fma(y2, y2, __builtin_fma(cb, cb, cr * cr));
+    m.sn += __builtin_fma(y2, y2, __builtin_fma(cb, cb, cr * cr));
+}
+BU_FN double etc1_moment_distance(const etc1_moments& m, const ycc& c) {   // sum over the sub-block's texels t of D(c, t)
+    const double y2 = (double)(2 * c.y), cb = (double)c.cb, cr = (double)c.cr;
+    const double n = __builtin_fma(y2, y2, __builtin_fma(cb, cb, cr * cr));
+    const double dot = __builtin_fma(2.0 * y2, (double)m.sy, __builtin_fma(cb, (double)m.scb, cr * (double)m.scr));
+    return __builtin_fma(8.0, n, m.sn) - 2.0 * dot;
+}
+BU_FN uint32_t etc1_unclamped_tables(const int* base) {   // number of leading tables whose colours do not clamp for this base colour
+    int lo = base[0] < base[1] ? base[0] : base[1]; lo = base[2] < lo ? base[2] : lo;
+    int hi = base[0] > base[1] ? base[0] : base[1]; hi = base[2] > hi ? base[2] : hi;
+    const int room = lo < 255 - hi ? lo : 255 - hi;
+    uint32_t u = 0;
+    for (uint32_t t = 0; t < 8; t++) u += (int)ku_etc1_inten_large[t] <= room ? 1u : 0u;
+    return u;
 }
 
 // Best intensity table of one sub-block for base colour `base` (uastc_enc.cpp:2858-2918: first minimum over the tables below `limit` of the texel sums of the
 // distance to the nearest block colour; the non-flipped search stops at the first table that is not better), then the sub-block's error against
-// the SOURCE texels when every texel takes the colour nearest to its DECODED value (:2925-2973). `sn_dec` / `sn_src`: sum of N(texel) over the sub-block.
+// the SOURCE texels when every texel takes the colour nearest to its DECODED value (:2925-2973).
 template <int FLIP, int SUB>
-BU_FN void etc1_fit_subblock(const texels_ycc& dec, const rgba8* src, double sn_dec, double sn_src, const int* base, uint32_t limit, uint32_t& table_out, double& err_out) {
+BU_FN void etc1_fit_subblock(const texels_ycc& dec, const rgba8* src, const etc1_moments& mdec, const etc1_moments& msrc, const int* base, uint32_t limit,
+                             uint32_t& table_out, double& err_out) {
     double best = 1e300;
     uint32_t best_table = 0;
+    const uint32_t unclamped = etc1_unclamped_tables(base);
+    const ycc bc = to_ycc(base[0], base[1], base[2]);
     etc1_colour col[4];
-    for (uint32_t table = 0; table < limit; table++) {
-        etc1_colour_keys(base, table, col);
-        double total4 = 0.0;
+    int ady[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    double base_total = 0.0;   // the texel sum of D(base, t)
+    if (!BU_WAVE_ALL(unclamped == 0)) {   // some lane of the wave may get to use the short form
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
-        for (int j = 0; j < 8; j++) {
-            const ycc& t = dec.t[etc1_texel<FLIP, SUB>(j)];
-            total4 += etc1_key_value(etc1_key_min(etc1_key_min(etc1_key(col[0], t), etc1_key(col[1], t)), etc1_key_min(etc1_key(col[2], t), etc1_key(col[3], t))));
+        for (int j = 0; j < 8; j++) { const int d = bc.y - dec.t[etc1_texel<FLIP, SUB>(j)].y; ady[j] = d < 0 ? -d : d; }
+        base_total = etc1_moment_distance(mdec, bc);
+    }
+    for (uint32_t table = 0; table < limit; table++) {
+        double total;
+        if (BU_WAVE_ALL(table < unclamped)) {
+            const int a = ku_etc1_inten_small[table], b = ku_etc1_inten_large[table];
+            const int a2 = 128 * a * a, b2 = 128 * b * b;
+            int g = 0;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+            for (int j = 0; j < 8; j++) {
+                const int ga = a2 - imul24(a, ady[j]), gb = b2 - imul24(b, ady[j]);
+                g += ga < gb ? ga : gb;
+            }
+            total = __builtin_fma(2048.0, (double)g, base_total);
+        } else {
+            etc1_colour_keys(base, table, col);
+            double total4 = 0.0;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+            for (int j = 0; j < 8; j++) {
+                const ycc& t = dec.t[etc1_texel<FLIP, SUB>(j)];
+                total4 += etc1_key_value(etc1_key_min(etc1_key_min(etc1_key(col[0], t), etc1_key(col[1], t)), etc1_key_min(etc1_key(col[2], t), etc1_key(col[3], t))));
+            }
+            total = __builtin_fma(total4, 0.25, mdec.sn);
         }
-        const double total = __builtin_fma(total4, 0.25, sn_dec);
         if (!FLIP && total >= best) break;
         if (total < best) { best = total; best_table = table; }
     }
     table_out = best_table;
+    if (BU_WAVE_ALL(best_table < unclamped)) {
+        const int a = ku_etc1_inten_small[best_table], b = ku_etc1_inten_large[best_table];
+        const int a2 = 128 * a * a, b2 = 128 * b * b;
+        int s = 0;
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+        for (int j = 0; j < 8; j++) {
+            const int ti = etc1_texel<FLIP, SUB>(j);
+            const int dy = bc.y - dec.t[ti].y;
+            const int ga = a2 - imul24(a, ady[j]), gb = b2 - imul24(b, ady[j]);
+            const bool nonneg = dy >= 0;
+            const bool large = nonneg ? gb <= ga : gb < ga;
+            const int mag = large ? b : a, d = nonneg ? -mag : mag;
+            const int dys = bc.y - (imul24(src[ti].c[0], 54) + imul24(src[ti].c[1], 183) + imul24(src[ti].c[2], 19));
+            s += imul24(d, dys + 128 * d);
+        }
+        err_out = __builtin_fma(2048.0, (double)s, etc1_moment_distance(msrc, bc));
+        return;
+    }
     etc1_colour_keys(base, best_table, col);
     double err4 = 0.0;
 #if defined(__HIPCC__)
@@ -1664,7 +1743,7 @@ BU_FN void etc1_fit_subblock(const texels_ycc& dec, const rgba8* src, double sn_
         ch.n = upper ? (odd ? col[3].n : col[2].n) : (odd ? col[1].n : col[0].n);
         err4 += etc1_key_value(etc1_key(ch, to_ycc(src[ti].c[0], src[ti].c[1], src[ti].c[2])));
     }
-    err_out = __builtin_fma(err4, 0.25, sn_src);
+    err_out = __builtin_fma(err4, 0.25, msrc.sn);
 }
 
 struct etc1_search { double best_err; etc1_hint best; };
@@ -1690,16 +1769,17 @@ BU_FN void etc1_trials(uint32_t mode, const rgba8* decoded, const texels_ycc& de
     etc1_subblock_stats st[2];
     etc1_stats<FLIP, 0>(decoded, st[0]);
     etc1_stats<FLIP, 1>(decoded, st[1]);
-    double sn_dec[2] = { 0.0, 0.0 }, sn_src[2] = { 0.0, 0.0 };
+    etc1_moments mdec[2], msrc[2];
+    for (int sub = 0; sub < 2; sub++) { mdec[sub].sy = mdec[sub].scb = mdec[sub].scr = 0; mdec[sub].sn = 0.0; msrc[sub] = mdec[sub]; }
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
     for (int j = 0; j < 8; j++) {
-        sn_dec[0] += etc1_norm(dec.t[etc1_texel<FLIP, 0>(j)]);
-        sn_dec[1] += etc1_norm(dec.t[etc1_texel<FLIP, 1>(j)]);
+        etc1_moments_add(mdec[0], dec.t[etc1_texel<FLIP, 0>(j)]);
+        etc1_moments_add(mdec[1], dec.t[etc1_texel<FLIP, 1>(j)]);
         const rgba8 &s0 = src[etc1_texel<FLIP, 0>(j)], &s1 = src[etc1_texel<FLIP, 1>(j)];
-        sn_src[0] += etc1_norm(to_ycc(s0.c[0], s0.c[1], s0.c[2]));
-        sn_src[1] += etc1_norm(to_ycc(s1.c[0], s1.c[1], s1.c[2]));
+        etc1_moments_add(msrc[0], to_ycc(s0.c[0], s0.c[1], s0.c[2]));
+        etc1_moments_add(msrc[1], to_ycc(s1.c[0], s1.c[1], s1.c[2]));
     }
     for (uint32_t individ = 0; individ < last_individ; individ++) {
         const uint32_t mul = individ ? 15 : 31;
@@ -1742,13 +1822,13 @@ BU_FN void etc1_trials(uint32_t mode, const rgba8* decoded, const texels_ycc& de
             if (reuse && !((ku_bias_first[order][0] >> bi) & 1u)) {
                 t0 = cache->table[s0 * cache->stride]; e0 = cache->err[s0 * cache->stride];
             } else {
-                etc1_fit_subblock<FLIP, 0>(dec, src, sn_dec[0], sn_src[0], base[0], limit[0], t0, e0);
+                etc1_fit_subblock<FLIP, 0>(dec, src, mdec[0], msrc[0], base[0], limit[0], t0, e0);
                 if (reuse) { cache->table[s0 * cache->stride] = (unsigned char)t0; cache->err[s0 * cache->stride] = e0; }
             }
             if (reuse && individ && !((ku_bias_first[order][1] >> bi) & 1u)) {
                 t1 = cache->table[s1 * cache->stride]; e1 = cache->err[s1 * cache->stride];
             } else {
-                etc1_fit_subblock<FLIP, 1>(dec, src, sn_dec[1], sn_src[1], base[1], limit[1], t1, e1);
+                etc1_fit_subblock<FLIP, 1>(dec, src, mdec[1], msrc[1], base[1], limit[1], t1, e1);
                 if (reuse && individ) { cache->table[s1 * cache->stride] = (unsigned char)t1; cache->err[s1 * cache->stride] = e1; }
             }
             const double err = e0 + e1;
