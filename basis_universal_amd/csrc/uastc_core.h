@@ -210,9 +210,13 @@ BU_FN uint64_t cell_try(const uint32_t* px, uint32_t mask, const cell_cfg& cfg, 
         for (int c = 0; c < 4; c++) differs = differs || a[c] != best.lo[c] || b[c] != best.hi[c];
         if (differs) cell_eval<FORCED>(px, mask, cfg, a, b, best, forced);
     }
+    return best.err;
+}
+// the winner's endpoint ranks as ASTC endpoint indices: once per cell, not once per proposal (eight table loads and a wait each time; staging the three tables in
+// LDS, on the other hand, measured no gain: the fit is not waiting for them)
+BU_FN void cell_astc_indices(const cell_cfg& cfg, cell_fit& best) {
     const uint8_t* SI = ku_sorted_index + cfg.range * 256;
     for (int c = 0; c < 4; c++) { best.astc_lo[c] = SI[best.lo[c]]; best.astc_hi[c] = SI[best.hi[c]]; }
-    return best.err;
 }
 
 // compute_least_squares_endpoints_rgb / _rgba (bc7enc.cpp:394-518) followed by the 1/255 scaling of its callers
@@ -473,7 +477,7 @@ BU_FN uint64_t cell_compress_t(const uint32_t* px, uint32_t mask, const cell_cfg
             }
             cell_least_squares(px, mask, trial, cfg, xl, xh);
         }
-        if (!cell_try<FORCED>(px, mask, cfg, xl, xh, best, forced)) return 0;
+        if (!cell_try<FORCED>(px, mask, cfg, xl, xh, best, forced)) { cell_astc_indices(cfg, best); return 0; }
     }
 
     if (!FORCED && has_kind) {
@@ -481,8 +485,11 @@ BU_FN uint64_t cell_compress_t(const uint32_t* px, uint32_t mask, const cell_cfg
         uint32_t col[4];
         for (int c = 0; c < 4; c++) col[c] = (uint32_t)(int)(.5f + mean[c] * 255.0f);
         cell_fit avg;
+        cell_astc_indices(cfg, best);
         if (one_colour_fit(px, mask, cfg, kind, col, avg) < best.err) best = avg;
+        return best.err;
     }
+    cell_astc_indices(cfg, best);
     return best.err;
 }
 // The out-of-line instance takes the texels and the configuration and returns the fit BY VALUE: on the GPU they travel in registers, whereas
@@ -1556,6 +1563,11 @@ BU_FN bool etc1_estimate_flipped(const rgba8* p) {  // pack_etc1_estimate_flippe
 struct ycc { int y, cb, cr; };
 BU_FN ycc to_ycc(int r, int g, int b) { const int y = imul24(r, 54) + imul24(g, 183) + imul24(b, 19); ycc o = { y, (b << 8) - y, (r << 8) - y }; return o; }
 struct texels_ycc { ycc t[16]; };
+// The SOURCE texels in the same space, one register each: y | b << 16 | r << 24 (cb = 256 b - y, cr = 256 r - y). They are only read once per texel and fit, so
+// they are kept packed -- but kept: reading them through the caller's pointer is a scratch-memory load and a full wait per texel inside the innermost loop.
+struct texels_packed { uint32_t t[16]; };
+BU_FN uint32_t pack_ycc_source(const rgba8& p) { return (uint32_t)(imul24(p.c[0], 54) + imul24(p.c[1], 183) + imul24(p.c[2], 19)) | ((uint32_t)p.c[2] << 16) | ((uint32_t)p.c[0] << 24); }
+BU_FN ycc unpack_ycc_source(uint32_t v) { const int y = (int)(v & 0xFFFFu); ycc o = { y, (int)((v >> 8) & 0xFF00u) - y, (int)((v >> 16) & 0xFF00u) - y }; return o; }
 // raster index of texel j (0..7) of sub-block SUB; in the flipped layout j runs row by row (g_etc1_pixel_coords, etc.cpp:314-337)
 template <int FLIP, int SUB> constexpr int etc1_texel(int j) { return FLIP ? (SUB * 8 + j) : ((j & 3) * 4 + SUB * 2 + (j >> 2)); }
 
@@ -1582,6 +1594,10 @@ BU_FN void etc1_stats(const rgba8* decoded, etc1_subblock_stats& s) {
 // bit patterns of doubles in [2^52, 2^53) (offset 2^52 + 2^42 folded into the accumulator's start value): they order like the integers, so
 // the minimum is one v_min_f64, and subtracting the offset as doubles returns the exact integer. Every total is an integer below 2^53: the
 // doubles that come out are the ones the reference computes, bit for bit.
+// the eight intensity tables are -b, -a, a, b with these a (small) and b (large); a byte per table in a 64-bit literal, so a table's modifiers are two scalar shifts
+// and not a load from a constant array that the loop over the tables would wait for
+BU_FN int etc1_inten_small(uint32_t table) { return (int)((0x2F2118120D090502ull >> (8 * table)) & 255u); }   // 2, 5, 9, 13, 18, 24, 33, 47
+BU_FN int etc1_inten_large(uint32_t table) { return (int)((0xB76A503C2A1D1108ull >> (8 * table)) & 255u); }   // 8, 17, 29, 42, 60, 80, 106, 183
 struct etc1_colour { int a, b, c; long long n; };   // -32 y, -8 cb, -8 cr; 4 N(colour) + colour index + key offset
 BU_TAB long long ku_etc1_key_offset = 0x4330000000000000ll + (1ll << 42);   // bits of the double 2^52 + 2^42; 4 (D - N(t)) > -2^39 keeps every key above 2^52
 BU_FN double etc1_key_value(long long key) {   // 4 (D - N(t)) of a key, colour index dropped
@@ -1597,8 +1613,9 @@ BU_FN long long etc1_key_min(long long x, long long y) {
 #endif
 }
 BU_FN void etc1_colour_keys(const int* base, uint32_t table, etc1_colour* col) {
+    const int small = etc1_inten_small(table), large = etc1_inten_large(table);
     for (uint32_t k = 0; k < 4; k++) {
-        const int d = ku_etc1_inten[table * 4 + k];
+        const int d = k == 0 ? -large : (k == 1 ? -small : (k == 2 ? small : large));
         const ycc c = to_ycc(clampi(base[0] + d, 0, 255), clampi(base[1] + d, 0, 255), clampi(base[2] + d, 0, 255));
         col[k].a = imul24(c.y, -32); col[k].b = imul24(c.cb, -8); col[k].c = imul24(c.cr, -8);
         const int y4 = 4 * c.y, cb2 = 2 * c.cb, cr2 = 2 * c.cr;
@@ -1626,8 +1643,6 @@ BU_FN long long etc1_key(const etc1_colour& c, const ycc& t) { return etc1_mad(c
 // the same doubles as the general form's. This form is only worth taking when EVERY lane of the wave can take it (a wave runs both sides of a branch
 // its lanes disagree on): the encoder therefore hands the finish kernel its blocks grouped by how much head room their colours have (uastc_kernels.hip,
 // etc1_order_key), and the test below is wave-wide. The host build decides per block; both forms give the same numbers, so it does not matter which ran.
-BU_TAB unsigned char ku_etc1_inten_small[8] = { 2, 5, 9, 13, 18, 24, 33, 47 };
-BU_TAB unsigned char ku_etc1_inten_large[8] = { 8, 17, 29, 42, 60, 80, 106, 183 };
 #if defined(__HIPCC__)
 #define BU_WAVE_ALL(cond) (__builtin_amdgcn_ballot_w64(!(cond)) == 0ull)
 #else
@@ -1650,7 +1665,7 @@ BU_FN uint32_t etc1_unclamped_tables(const int* base) {   // number of leading t
     int hi = base[0] > base[1] ? base[0] : base[1]; hi = base[2] > hi ? base[2] : hi;
     const int room = lo < 255 - hi ? lo : 255 - hi;
     uint32_t u = 0;
-    for (uint32_t t = 0; t < 8; t++) u += (int)ku_etc1_inten_large[t] <= room ? 1u : 0u;
+    for (uint32_t t = 0; t < 8; t++) u += etc1_inten_large(t) <= room ? 1u : 0u;
     return u;
 }
 
@@ -1658,7 +1673,7 @@ BU_FN uint32_t etc1_unclamped_tables(const int* base) {   // number of leading t
 // distance to the nearest block colour; the non-flipped search stops at the first table that is not better), then the sub-block's error against
 // the SOURCE texels when every texel takes the colour nearest to its DECODED value (:2925-2973).
 template <int FLIP, int SUB>
-BU_FN void etc1_fit_subblock(const texels_ycc& dec, const rgba8* src, const etc1_moments& mdec, const etc1_moments& msrc, const int* base, uint32_t limit,
+BU_FN void etc1_fit_subblock(const texels_ycc& dec, const texels_packed& src, const etc1_moments& mdec, const etc1_moments& msrc, const int* base, uint32_t limit,
                              uint32_t& table_out, double& err_out) {
     double best = 1e300;
     uint32_t best_table = 0;
@@ -1677,7 +1692,7 @@ BU_FN void etc1_fit_subblock(const texels_ycc& dec, const rgba8* src, const etc1
     for (uint32_t table = 0; table < limit; table++) {
         double total;
         if (BU_WAVE_ALL(table < unclamped)) {
-            const int a = ku_etc1_inten_small[table], b = ku_etc1_inten_large[table];
+            const int a = etc1_inten_small(table), b = etc1_inten_large(table);
             const int a2 = 128 * a * a, b2 = 128 * b * b;
             int g = 0;
 #if defined(__HIPCC__)
@@ -1705,7 +1720,7 @@ BU_FN void etc1_fit_subblock(const texels_ycc& dec, const rgba8* src, const etc1
     }
     table_out = best_table;
     if (BU_WAVE_ALL(best_table < unclamped)) {
-        const int a = ku_etc1_inten_small[best_table], b = ku_etc1_inten_large[best_table];
+        const int a = etc1_inten_small(best_table), b = etc1_inten_large(best_table);
         const int a2 = 128 * a * a, b2 = 128 * b * b;
         int s = 0;
 #if defined(__HIPCC__)
@@ -1718,7 +1733,7 @@ BU_FN void etc1_fit_subblock(const texels_ycc& dec, const rgba8* src, const etc1
             const bool nonneg = dy >= 0;
             const bool large = nonneg ? gb <= ga : gb < ga;
             const int mag = large ? b : a, d = nonneg ? -mag : mag;
-            const int dys = bc.y - (imul24(src[ti].c[0], 54) + imul24(src[ti].c[1], 183) + imul24(src[ti].c[2], 19));
+            const int dys = bc.y - (int)(src.t[ti] & 0xFFFFu);
             s += imul24(d, dys + 128 * d);
         }
         err_out = __builtin_fma(2048.0, (double)s, etc1_moment_distance(msrc, bc));
@@ -1741,7 +1756,7 @@ BU_FN void etc1_fit_subblock(const texels_ycc& dec, const rgba8* src, const etc1
         ch.b = upper ? (odd ? col[3].b : col[2].b) : (odd ? col[1].b : col[0].b);
         ch.c = upper ? (odd ? col[3].c : col[2].c) : (odd ? col[1].c : col[0].c);
         ch.n = upper ? (odd ? col[3].n : col[2].n) : (odd ? col[1].n : col[0].n);
-        err4 += etc1_key_value(etc1_key(ch, to_ycc(src[ti].c[0], src[ti].c[1], src[ti].c[2])));
+        err4 += etc1_key_value(etc1_key(ch, unpack_ycc_source(src.t[ti])));
     }
     err_out = __builtin_fma(err4, 0.25, msrc.sn);
 }
@@ -1757,13 +1772,27 @@ BU_TAB unsigned char ku_bias_slot[2][2][32] = {
     { { 0, 1, 2, 3, 4, 5, 4, 6, 7, 8, 9, 10, 2, 7, 6, 11, 10, 12, 7, 7, 7, 7, 11, 13, 7, 14, 15, 0, 15, 7, 7, 15 }, { 0, 1, 2, 3, 4, 2, 2, 2, 5, 6, 7, 2, 8, 2, 9, 2, 10, 11, 8, 12, 4, 9, 5, 13, 10, 14, 15, 2, 0, 15, 0, 2 } },
 };
 BU_TAB unsigned int ku_bias_first[2][2] = { { 0x013ED8E7u, 0x1F2458AFu }, { 0x06828FBFu, 0x068B571Fu } };
+// The same lists as 64-bit literals (a byte / a nibble per entry): the search reads them once per bias, and a load from a constant array there is a memory wait in
+// front of every trial (the index is wave-uniform, so the literal form is a few scalar shifts).
+BU_FN uint32_t etc1_bias_in_order(uint32_t i) {
+    const uint64_t w = i < 8 ? 0x091a0c1b1d16000dull : (i < 16 ? 0x051702190a081f1eull : (i < 24 ? 0x121c11060b03070full : 0x100e041815141301ull));
+    return (uint32_t)(w >> (8 * (i & 7))) & 255u;
+}
+BU_FN uint32_t etc1_bias_slot(uint32_t order, uint32_t sub, uint32_t i) {
+    const uint64_t lo = order ? (sub ? 0x2928276522243210ull : 0xb672a98764543210ull) : (sub ? 0x0807620153403210ull : 0x9837604054310210ull);
+    const uint64_t hi = order ? (sub ? 0x20f02fead594c8baull : 0xf77f0fe7db7777caull) : (sub ? 0xfedfedcb41a00900ull : 0xcad0000f04edcba2ull);
+    return (uint32_t)((i < 16 ? lo : hi) >> (4 * (i & 15))) & 15u;
+}
 // Per-block scratch for the repeats: 32 entries (16 per sub-block) of {error, table}; entry i of this block lives at [i * stride] (the GPU
 // keeps it in LDS, one column per lane). Optional: without it every trial is evaluated from scratch, with the same result.
-struct hint_cache { double* err; unsigned char* table; unsigned int stride; };
+// The struct travels by value (a pointer to it would point into scratch memory on the GPU: one more dependent load per use). The pointers stay generic: declaring
+// them as LDS pointers (address_space(3), ds_read / ds_write instead of flat accesses) measured 10 % SLOWER for the finish kernel (tools/uastc_time.py, A/B on one box).
+struct hint_cache { double* err; unsigned char* table; unsigned int stride; };   // err == nullptr: no cache
+BU_FN hint_cache no_hint_cache() { hint_cache c = { nullptr, nullptr, 0 }; return c; }
 
 template <int FLIP>
-BU_FN void etc1_trials(uint32_t mode, const rgba8* decoded, const texels_ycc& dec, const rgba8* src, const enc_cfg& e, uint32_t last_individ,
-                       uint32_t last_bias, bool sorted_table, etc1_search& out, const hint_cache* cache) {
+BU_FN void etc1_trials(uint32_t mode, const rgba8* decoded, const texels_ycc& dec, const texels_packed& src, const enc_cfg& e, uint32_t last_individ,
+                       uint32_t last_bias, bool sorted_table, etc1_search& out, hint_cache cache) {
     const bool has_bias = ku_mode_has_etc1_bias[mode] != 0;
     const uint32_t order = sorted_table ? 0u : 1u;
     etc1_subblock_stats st[2];
@@ -1777,9 +1806,8 @@ BU_FN void etc1_trials(uint32_t mode, const rgba8* decoded, const texels_ycc& de
     for (int j = 0; j < 8; j++) {
         etc1_moments_add(mdec[0], dec.t[etc1_texel<FLIP, 0>(j)]);
         etc1_moments_add(mdec[1], dec.t[etc1_texel<FLIP, 1>(j)]);
-        const rgba8 &s0 = src[etc1_texel<FLIP, 0>(j)], &s1 = src[etc1_texel<FLIP, 1>(j)];
-        etc1_moments_add(msrc[0], to_ycc(s0.c[0], s0.c[1], s0.c[2]));
-        etc1_moments_add(msrc[1], to_ycc(s1.c[0], s1.c[1], s1.c[2]));
+        etc1_moments_add(msrc[0], unpack_ycc_source(src.t[etc1_texel<FLIP, 0>(j)]));
+        etc1_moments_add(msrc[1], unpack_ycc_source(src.t[etc1_texel<FLIP, 1>(j)]));
     }
     for (uint32_t individ = 0; individ < last_individ; individ++) {
         const uint32_t mul = individ ? 15 : 31;
@@ -1788,7 +1816,7 @@ BU_FN void etc1_trials(uint32_t mode, const rgba8* decoded, const texels_ycc& de
             for (uint32_t c = 0; c < 3; c++) unbiased[sub][c] = (st[sub].sum[c] * mul + 1020) / (8 * 255);
         for (uint32_t bi = 0; bi < last_bias; bi++) {
             // 0 should come first, but 13 is the (0,0,0) bias (uastc_enc.cpp:2732-2733)
-            const uint32_t bias = sorted_table ? (uint32_t)ku_etc1_bias_order[bi] : bi;
+            const uint32_t bias = sorted_table ? etc1_bias_in_order(bi) : bi;
             int base[2][3];
             for (uint32_t c = 0; c < 3; c++) {
                 const uint32_t c0 = has_bias ? etc1_bias_apply(unbiased[0][c], c, bias, mul, 0) : unbiased[0][c];
@@ -1817,19 +1845,19 @@ BU_FN void etc1_trials(uint32_t mode, const rgba8* decoded, const texels_ycc& de
             // coded relative to sub-block 0). A vector seen before in this (flip, mode) pass gives the same table and error: reuse them.
             uint32_t t0, t1;
             double e0, e1;
-            const bool reuse = cache != nullptr && has_bias;
-            const uint32_t s0 = ku_bias_slot[order][0][bi], s1 = 16u + ku_bias_slot[order][1][bi];
-            if (reuse && !((ku_bias_first[order][0] >> bi) & 1u)) {
-                t0 = cache->table[s0 * cache->stride]; e0 = cache->err[s0 * cache->stride];
+            const bool reuse = cache.err != nullptr && has_bias;
+            const uint32_t s0 = etc1_bias_slot(order, 0, bi), s1 = 16u + etc1_bias_slot(order, 1, bi);
+            if (reuse && !(((order ? 0x06828FBFu : 0x013ED8E7u) >> bi) & 1u)) {
+                t0 = cache.table[s0 * cache.stride]; e0 = cache.err[s0 * cache.stride];
             } else {
                 etc1_fit_subblock<FLIP, 0>(dec, src, mdec[0], msrc[0], base[0], limit[0], t0, e0);
-                if (reuse) { cache->table[s0 * cache->stride] = (unsigned char)t0; cache->err[s0 * cache->stride] = e0; }
+                if (reuse) { cache.table[s0 * cache.stride] = (unsigned char)t0; cache.err[s0 * cache.stride] = e0; }
             }
-            if (reuse && individ && !((ku_bias_first[order][1] >> bi) & 1u)) {
-                t1 = cache->table[s1 * cache->stride]; e1 = cache->err[s1 * cache->stride];
+            if (reuse && individ && !(((order ? 0x068B571Fu : 0x1F2458AFu) >> bi) & 1u)) {
+                t1 = cache.table[s1 * cache.stride]; e1 = cache.err[s1 * cache.stride];
             } else {
                 etc1_fit_subblock<FLIP, 1>(dec, src, mdec[1], msrc[1], base[1], limit[1], t1, e1);
-                if (reuse && individ) { cache->table[s1 * cache->stride] = (unsigned char)t1; cache->err[s1 * cache->stride] = e1; }
+                if (reuse && individ) { cache.table[s1 * cache.stride] = (unsigned char)t1; cache.err[s1 * cache.stride] = e1; }
             }
             const double err = e0 + e1;
             if (err < out.best_err) {
@@ -1840,7 +1868,7 @@ BU_FN void etc1_trials(uint32_t mode, const rgba8* decoded, const texels_ycc& de
     }
 }
 
-BU_FN_BIG void etc1_hints(uint32_t mode, const rgba8* px, const rgba8* decoded, const enc_cfg& e, etc1_hint& best, const hint_cache* cache = nullptr) {
+BU_FN_BIG void etc1_hints(uint32_t mode, const rgba8* px, const rgba8* decoded, const enc_cfg& e, etc1_hint& best, hint_cache cache = no_hint_cache()) {
     const bool faster = (e.flags & FLAG_ETC1_FASTER) != 0, fastest = (e.flags & FLAG_ETC1_FASTEST) != 0;
     const bool has_bias = ku_mode_has_etc1_bias[mode] != 0;
     uint32_t last_bias = 1;
@@ -1857,18 +1885,19 @@ BU_FN_BIG void etc1_hints(uint32_t mode, const rgba8* px, const rgba8* decoded, 
         }
     }
     texels_ycc dec;
+    texels_packed src;
 #if defined(__HIPCC__)
 #pragma unroll
 #endif
-    for (int i = 0; i < 16; i++) dec.t[i] = to_ycc(decoded[i].c[0], decoded[i].c[1], decoded[i].c[2]);
+    for (int i = 0; i < 16; i++) { dec.t[i] = to_ycc(decoded[i].c[0], decoded[i].c[1], decoded[i].c[2]); src.t[i] = pack_ycc_source(px[i]); }
     uint32_t first_flip = 0, last_flip = 2, last_individ = 2;
     if (e.flags & FLAG_ETC1_NO_FLIP_INDIVIDUAL) { last_flip = 1; last_individ = 1; }
     else if (flip_estimate) { if (etc1_estimate_flipped(decoded)) first_flip = 1; last_flip = first_flip + 1; }
     etc1_search s;
     s.best_err = 1e300;
     s.best.flip = s.best.diff = s.best.inten0 = s.best.inten1 = s.best.bias = 0;
-    if (first_flip == 0) etc1_trials<0>(mode, decoded, dec, px, e, last_individ, last_bias, sorted_table, s, cache);
-    if (last_flip == 2 || first_flip == 1) etc1_trials<1>(mode, decoded, dec, px, e, last_individ, last_bias, sorted_table, s, cache);
+    if (first_flip == 0) etc1_trials<0>(mode, decoded, dec, src, e, last_individ, last_bias, sorted_table, s, cache);
+    if (last_flip == 2 || first_flip == 1) etc1_trials<1>(mode, decoded, dec, src, e, last_individ, last_bias, sorted_table, s, cache);
     best = s.best;
 }
 
@@ -1990,7 +2019,7 @@ BU_FN void pack_block(const cand& norm, const etc1_hint& etc1, uint32_t eac_tabl
 // ------------------------------------------------------------------------------------------------------------------
 
 // hints + packing of the chosen candidate (uastc_enc.cpp:3550-3644)
-BU_FN_BIG void finish_block(const rgba8* px, const enc_cfg& e, const cand& chosen, uint8_t* out16, const hint_cache* cache = nullptr) {
+BU_FN_BIG void finish_block(const rgba8* px, const enc_cfg& e, const cand& chosen, uint8_t* out16, hint_cache cache = no_hint_cache()) {
     cand best = chosen;
     rgba8 decoded[16];
     decode_uastc(best, decoded);
@@ -2034,7 +2063,7 @@ BU_FN_BIG void encode_block(const uint8_t* rgba64, uint32_t flags, uint8_t* out1
     double cache_err[32];
     unsigned char cache_table[32];
     const hint_cache hc = { cache_err, cache_table, 1 };
-    finish_block(px, e, scratch[choose_candidate(v, n_slots, e)], out16, &hc);
+    finish_block(px, e, scratch[choose_candidate(v, n_slots, e)], out16, hc);
 }
 
 }  // namespace bu_uastc

@@ -103,7 +103,7 @@ __device__ inline uint32_t etc1_order_key(const rgba8* t) {
         spread_min = spread < spread_min ? spread : spread_min; spread_max = spread > spread_max ? spread : spread_max;
     }
     uint32_t lo = 0, hi = 0;
-    for (uint32_t k = 0; k < 8; k++) { lo += (int)ku_etc1_inten_large[k] + 12 <= room_min ? 1u : 0u; hi += (int)ku_etc1_inten_large[k] + 12 <= room_max ? 1u : 0u; }
+    for (uint32_t k = 0; k < 8; k++) { lo += etc1_inten_large(k) + 12 <= room_min ? 1u : 0u; hi += etc1_inten_large(k) + 12 <= room_max ? 1u : 0u; }
     const uint32_t tables_max = spread_max > 51 ? 2u : (spread_max >= 7 ? 1u : 0u), tables_min = spread_min > 51 ? 2u : (spread_min >= 7 ? 1u : 0u);
     return (tables_max << 9) | (lo << 5) | (tables_min << 3) | (hi < 7 ? hi : 7u);   // < 2048
 }
@@ -225,7 +225,7 @@ __global__ void __launch_bounds__(64, 2) k_uastc_finish(const uint4* __restrict_
     __shared__ unsigned char s_hint_table[32 * 64];
     const hint_cache hc = { s_hint_err + threadIdx.x, s_hint_table + threadIdx.x, 64 };
     alignas(16) uint8_t o[16];
-    finish_block(t, plan->e, r, o, &hc);
+    finish_block(t, plan->e, r, o, hc);
     out[b] = *reinterpret_cast<const uint4*>(o);
 }
 

@@ -327,7 +327,7 @@ BU_FN bool rdo_refit_block(const rgba8* px, const rdo_params& p, uint8_t* blk16,
 }
 
 // uastc_recompute_hints (:3647-3726) of a block whose weights (and maybe endpoints) changed
-BU_FN bool rdo_rehint(const rgba8* px, const enc_cfg& e, uint8_t* blk16, const hint_cache* cache = nullptr) {
+BU_FN bool rdo_rehint(const rgba8* px, const enc_cfg& e, uint8_t* blk16, hint_cache cache = no_hint_cache()) {
     cand c;
     if (!unpack_block(blk16, c)) return false;
     if (c.mode == 8) return true;

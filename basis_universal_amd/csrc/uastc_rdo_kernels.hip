@@ -453,7 +453,7 @@ __global__ void __launch_bounds__(64, 2) k_rdo_finish(uint4* blocks, const uint4
     __shared__ double s_hint_err[32 * 64];       // repeats of the ETC1 bias list (uastc_core.h, hint_cache): one LDS column per lane
     __shared__ unsigned char s_hint_table[32 * 64];
     const hint_cache hc = { s_hint_err + threadIdx.x, s_hint_table + threadIdx.x, 64 };
-    rdo_rehint(t, e, blk, &hc);
+    rdo_rehint(t, e, blk, hc);
     blocks[b] = *reinterpret_cast<const uint4*>(blk);
 }
 
