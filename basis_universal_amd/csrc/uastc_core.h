@@ -87,6 +87,7 @@ struct cell_cfg {
     uint8_t alpha;      // fit 4 channels
     uint8_t uber;       // bc7enc_compress_block_params::m_uber_level
     uint8_t ls_passes;  // m_least_squares_passes
+    const float* ls_weights;  // the weight set's {w*w, (1-w)*w, (1-w)*(1-w), w} rows (ku_weights_ls + ((1 << wbits) - 2) * 4), or a staged copy of them (LDS)
 };
 
 struct sel16 { uint32_t w[4]; };  // 16 selectors, one byte each, texel i in byte i
@@ -221,7 +222,7 @@ BU_FN void cell_astc_indices(const cell_cfg& cfg, cell_fit& best) {
 
 // compute_least_squares_endpoints_rgb / _rgba (bc7enc.cpp:394-518) followed by the 1/255 scaling of its callers
 BU_FN void cell_least_squares(const uint32_t* px, uint32_t mask, const sel16& sel, const cell_cfg& cfg, float* xl, float* xh) {
-    const float* WX = ku_weights_ls + ((1u << cfg.wbits) - 2u) * 4;
+    const float* WX = cfg.ls_weights;
     const int nc = cfg.alpha ? 4 : 3;
     double z00 = 0.0, z10 = 0.0, z11 = 0.0;
     double q00[4] = { 0, 0, 0, 0 }, t[4] = { 0, 0, 0, 0 };
@@ -624,13 +625,14 @@ BU_FN uint32_t classify(const rgba8* px, const enc_cfg& cfg) {
     return (alpha ? CLS_ALPHA : 0) | (la ? CLS_LA : 0);
 }
 
-BU_FN cell_cfg mode_cell_cfg(uint32_t mode, bool alpha, const enc_cfg& e) {
+BU_FN cell_cfg mode_cell_cfg(uint32_t mode, bool alpha, const enc_cfg& e, const float* staged_ls_weights = nullptr) {
     cell_cfg c;
     c.wbits = ku_mode_weight_bits[mode];
     c.range = ku_mode_endpoint_ranges[mode];
     c.alpha = alpha ? 1 : 0;
     c.uber = e.uber;
     c.ls_passes = e.ls_passes;
+    c.ls_weights = staged_ls_weights ? staged_ls_weights : ku_weights_ls + ((1u << c.wbits) - 2u) * 4;
     return c;
 }
 
@@ -677,13 +679,13 @@ BU_FN uint64_t la_cell_error(const uint32_t* px, uint32_t mask, const cell_fit& 
 }
 
 // modes 0, 1, 5, 18 (RGB), 10, 12, 14 (RGBA), 15 (LA): one subset, one plane
-BU_FN_BIG void build_single(uint32_t mode, const rgba8* px_in, const enc_cfg& e, cand& r) {
+BU_FN_BIG void build_single(uint32_t mode, const rgba8* px_in, const enc_cfg& e, cand& r, const float* staged = nullptr) {
     cand_begin(r, mode, 0);
     const uint32_t comps = ku_mode_comps[mode];
     const uint32_t top = (1u << ku_mode_weight_bits[mode]) - 1;
     uint32_t px[16];
     pack_block_px(px_in, comps == 2, px);
-    const cell_cfg cc = mode_cell_cfg(mode, comps != 3, e);
+    const cell_cfg cc = mode_cell_cfg(mode, comps != 3, e, staged);
     cell_fit f;
     const uint64_t err = cell_compress(px, 0xFFFFu, cc, f);
     if (comps == 2) {
@@ -727,7 +729,7 @@ BU_FN void partition_masks(uint32_t bits, uint32_t* m) {
 }
 
 // modes 2, 4, 7 (RGB, 2 subsets), 3 (RGB, 3 subsets), 9 (RGBA, 2 subsets), 16 (LA, 2 subsets) for one common pattern
-BU_FN_BIG void build_multi(uint32_t mode, uint32_t pattern, const rgba8* px_in, const enc_cfg& e, cand& r) {
+BU_FN_BIG void build_multi(uint32_t mode, uint32_t pattern, const rgba8* px_in, const enc_cfg& e, cand& r, const float* staged = nullptr) {
     cand_begin(r, mode, pattern);
     const uint32_t comps = ku_mode_comps[mode], subsets = ku_mode_subsets[mode];
     const uint32_t top = (1u << ku_mode_weight_bits[mode]) - 1;
@@ -736,7 +738,7 @@ BU_FN_BIG void build_multi(uint32_t mode, uint32_t pattern, const rgba8* px_in, 
     const uint32_t part_bits = fit_partition_bits(mode, pattern);
     uint32_t masks[3];
     partition_masks(part_bits, masks);
-    const cell_cfg cc = mode_cell_cfg(mode, comps != 3, e);
+    const cell_cfg cc = mode_cell_cfg(mode, comps != 3, e, staged);
 
     // which fitted subset feeds ASTC subset a, and the inverse
     uint32_t src_of_astc[3] = { 0, 1, 2 }, astc_of_src[3] = { 0, 1, 2 };
@@ -771,10 +773,10 @@ BU_FN_BIG void build_multi(uint32_t mode, uint32_t pattern, const rgba8* px_in, 
 }
 
 // modes 6 (RGB), 11, 13 (RGBA), 17 (LA): one subset, two weight planes; `rot` is the channel on the second plane
-BU_FN_BIG void build_dual(uint32_t mode, uint32_t rot, const rgba8* px, const enc_cfg& e, cand& r) {
+BU_FN_BIG void build_dual(uint32_t mode, uint32_t rot, const rgba8* px, const enc_cfg& e, cand& r, const float* staged = nullptr) {
     cand_begin(r, mode, 0);
     const uint32_t top = (1u << ku_mode_weight_bits[mode]) - 1;
-    const cell_cfg cc = mode_cell_cfg(mode, false, e);
+    const cell_cfg cc = mode_cell_cfg(mode, false, e, staged);
     cell_fit fit[2];  // [0] the three remaining channels, [1] the rotated channel replicated to grey
     uint64_t err[2];
     for (uint32_t plane = 0; plane < 2; plane++) {
@@ -894,19 +896,19 @@ BU_FN_HD uint32_t total_slots(const enc_cfg& e) {
 
 // Candidates `first_variant .. first_variant + n_variants` of one mode for one block -> out[0 .. n_variants).
 // The unit of GPU work is (block, mode, variant range).
-BU_FN void run_mode(uint32_t mode, const rgba8* px, const enc_cfg& e, cand* out, uint32_t first_variant, uint32_t n_variants) {
+BU_FN void run_mode(uint32_t mode, const rgba8* px, const enc_cfg& e, cand* out, uint32_t first_variant, uint32_t n_variants, const float* staged = nullptr) {
     const uint32_t subsets = ku_mode_subsets[mode], planes = ku_mode_planes[mode];
     if (planes == 2) {
-        for (uint32_t v = 0; v < n_variants; v++) build_dual(mode, first_variant + v, px, e, out[v]);
+        for (uint32_t v = 0; v < n_variants; v++) build_dual(mode, first_variant + v, px, e, out[v], staged);
     } else if (subsets == 1) {
-        build_single(mode, px, e, out[0]);
+        build_single(mode, px, e, out[0], staged);
     } else if (e.estimate_partition) {
         uint32_t pats[8];
         const uint32_t want = (mode == 9 || mode == 16) ? 4 : 1;
         estimate_patterns(mode, px, want, pats);
-        for (uint32_t v = 0; v < n_variants; v++) build_multi(mode, pats[first_variant + v], px, e, out[v]);
+        for (uint32_t v = 0; v < n_variants; v++) build_multi(mode, pats[first_variant + v], px, e, out[v], staged);
     } else {
-        for (uint32_t v = 0; v < n_variants; v++) build_multi(mode, first_variant + v, px, e, out[v]);
+        for (uint32_t v = 0; v < n_variants; v++) build_multi(mode, first_variant + v, px, e, out[v], staged);
     }
 }
 

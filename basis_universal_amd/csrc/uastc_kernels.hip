@@ -155,14 +155,21 @@ __global__ void __launch_bounds__(256) k_uastc_order_scatter(const uint16_t* __r
 __global__ void __launch_bounds__(64, 2) k_uastc_candidates(const uint4* __restrict__ px, uint32_t n, const uastc_plan* __restrict__ plan,
                                                          const uint8_t* __restrict__ cls, cand* __restrict__ cands, uint32_t first_job) {
     const uint32_t b = blockIdx.x * 64 + threadIdx.x;
-    if (b >= n) return;
     const uastc_job job = plan->jobs[first_job + blockIdx.y];
+    // the least-squares rows of this job's weight set, staged in LDS (the fit reads one 16-byte row per texel and pass, by a per-lane index)
+    __shared__ float s_ls[32 * 4];
+    {
+        const uint32_t wbits = ku_mode_weight_bits[job.mode], rows = 1u << wbits;
+        for (uint32_t i = threadIdx.x; i < rows * 4; i += 64) s_ls[i] = ku_weights_ls[(rows - 2u) * 4 + i];
+    }
+    __syncthreads();
+    if (b >= n) return;
     const uint32_t c = cls[b];
     if ((c & CLS_SOLID) || !mode_applies(job.mode, c, plan->e)) return;
     alignas(16) rgba8 t[16];
     load_tile(px, b, t);
     cand local[4];
-    run_mode(job.mode, t, plan->e, local, job.first_variant, job.n_variants);
+    run_mode(job.mode, t, plan->e, local, job.first_variant, job.n_variants, s_ls);
     for (uint32_t v = 0; v < job.n_variants; v++) {
         const uint4* s = reinterpret_cast<const uint4*>(&local[v]);
         uint4* d = reinterpret_cast<uint4*>(&cands[(size_t)(job.slot + v) * n + b]);

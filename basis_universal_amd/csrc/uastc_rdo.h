@@ -282,7 +282,7 @@ BU_FN void rdo_write_back(const cand& base, uint64_t lo, uint64_t hi, const rgba
         sel16 forced = { { 0, 0, 0, 0 } };
         for (int i = 0; i < 16; i++) sel_set(forced, i, c.weights[i]);
         cell_cfg cc;
-        cc.wbits = 4; cc.range = 19; cc.alpha = 0; cc.uber = 0; cc.ls_passes = 1;
+        cc.wbits = 4; cc.range = 19; cc.alpha = 0; cc.uber = 0; cc.ls_passes = 1; cc.ls_weights = ku_weights_ls + 14 * 4;
         cell_fit f;
         cell_compress_t<true>(packed, 0xFFFFu, cc, f, &forced);
         cand fitted = c;

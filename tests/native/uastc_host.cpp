@@ -13,7 +13,7 @@ using namespace bu_uastc;
 // `mask` selects the texels of the 16 given ones that form the cell (the reference sees them gathered, in the same order)
 HC_API uint64_t hc_cell_compress(const uint8_t* px16, uint32_t mask, uint32_t wbits, uint32_t range, int alpha, uint32_t uber, uint32_t ls_passes, uint8_t* out24) {
     cell_cfg cfg;
-    cfg.wbits = (uint8_t)wbits; cfg.range = (uint8_t)range; cfg.alpha = (uint8_t)alpha; cfg.uber = (uint8_t)uber; cfg.ls_passes = (uint8_t)ls_passes;
+    cfg.wbits = (uint8_t)wbits; cfg.range = (uint8_t)range; cfg.alpha = (uint8_t)alpha; cfg.uber = (uint8_t)uber; cfg.ls_passes = (uint8_t)ls_passes; cfg.ls_weights = ku_weights_ls + ((1u << wbits) - 2u) * 4;
     uint32_t px[16];
     for (int i = 0; i < 16; i++) px[i] = pack_px(px16 + i * 4);
     cell_fit f;
