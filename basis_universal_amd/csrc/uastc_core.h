@@ -1127,13 +1127,222 @@ BU_FN block_err block_error(const rgba8* a, const rgba8* b) {  // compute_block_
     return r;
 }
 
+// ---- The two decodes of a candidate and their errors against the source texels in one pass, without the decoded images: decode_uastc / decode_bc7 + block_error
+// fused per texel, every loop unrolled, every table of the candidate (endpoints per subset, p-bits) held as scalars and picked by compare-and-select. The general
+// decoders above write byte arrays that are indexed by run-time values -- on the GPU those live in scratch memory, and the scoring kernel spent its time waiting for
+// them (1.9 ms for ~600 arithmetic instructions per candidate). Same integers, same order of operations per texel and channel.
+struct chan_err { uint32_t e[4]; };   // per channel: sum over the texels of the squared difference (<= 16 * 255^2)
+BU_FN void chan_err_add(chan_err& a, uint32_t px, uint32_t r, uint32_t g, uint32_t b, uint32_t al) {
+    const int d0 = px_comp(px, 0) - (int)r, d1 = px_comp(px, 1) - (int)g, d2 = px_comp(px, 2) - (int)b, d3 = px_comp(px, 3) - (int)al;
+    a.e[0] += (uint32_t)imul24(d0, d0); a.e[1] += (uint32_t)imul24(d1, d1); a.e[2] += (uint32_t)imul24(d2, d2); a.e[3] += (uint32_t)imul24(d3, d3);
+}
+BU_FN block_err chan_err_totals(const chan_err& a) {
+    block_err r;
+    r.la = (uint64_t)a.e[0] + a.e[3]; r.rgb = (uint64_t)a.e[0] + a.e[1] + a.e[2]; r.rgba = r.rgb + a.e[3];
+    return r;
+}
+BU_FN uint32_t pick3(uint32_t s, uint32_t v0, uint32_t v1, uint32_t v2) { return s == 0 ? v0 : (s == 1 ? v1 : v2); }
+
+// decode_uastc + block_error
+template <int COMPS, int PLANES, int SUBSETS>
+BU_FN void uastc_errors_t(const cand& r, const uint32_t* px, chan_err& out) {
+    const uint32_t mode = r.mode, wbits = ku_mode_weight_bits[mode];
+    const uint8_t* UQ = ku_unquant + ku_mode_endpoint_ranges[mode] * 256;
+    const uint32_t pat = SUBSETS > 1 ? astc_pattern_bits(mode, r.pattern) : 0u;
+    uint32_t L[3][4], H[3][4];
+    BU_UNROLL
+    for (int s = 0; s < 3; s++)
+        BU_UNROLL
+        for (int c = 0; c < 4; c++) {
+            L[s][c] = 255; H[s][c] = 255;
+            if (s < SUBSETS) {
+                if (COMPS == 2) { const int k = c == 3 ? 2 : 0; L[s][c] = UQ[r.endpoints[s * 4 + k]]; H[s][c] = UQ[r.endpoints[s * 4 + k + 1]]; }
+                else if (c < COMPS) { L[s][c] = UQ[r.endpoints[s * COMPS * 2 + c * 2]]; H[s][c] = UQ[r.endpoints[s * COMPS * 2 + c * 2 + 1]]; }
+            }
+        }
+    out.e[0] = out.e[1] = out.e[2] = out.e[3] = 0;
+    BU_UNROLL
+    for (int i = 0; i < 16; i++) {
+        const uint32_t s = SUBSETS > 1 ? (pat >> (2 * i)) & 3u : 0u;
+        const uint32_t w0 = weight_of(wbits, r.weights[i * PLANES]), w1 = PLANES == 2 ? weight_of(wbits, r.weights[i * PLANES + (PLANES - 1)]) : w0;
+        uint32_t v[4];
+        BU_UNROLL
+        for (int c = 0; c < 4; c++) {
+            if (COMPS != 2 && c >= COMPS) { v[c] = 255; continue; }
+            const uint32_t l = SUBSETS == 1 ? L[0][c] : pick3(s, L[0][c], L[1][c], L[2][c]), h = SUBSETS == 1 ? H[0][c] : pick3(s, H[0][c], H[1][c], H[2][c]);
+            const uint32_t w = (PLANES == 2 && (uint32_t)c == r.ccs) ? w1 : w0;
+            v[c] = astc_lerp(l, h, w);
+        }
+        chan_err_add(out, px[i], v[0], v[1], v[2], v[3]);
+    }
+}
+BU_FN void uastc_errors(const cand& r, const uint32_t* px, chan_err& out) {
+    const uint32_t mode = r.mode, comps = ku_mode_comps[mode], planes = ku_mode_planes[mode], subsets = ku_mode_subsets[mode];
+    if (planes == 2) {
+        if (comps == 3) uastc_errors_t<3, 2, 1>(r, px, out); else if (comps == 4) uastc_errors_t<4, 2, 1>(r, px, out); else uastc_errors_t<2, 2, 1>(r, px, out);
+    } else if (comps == 3) {
+        if (subsets == 1) uastc_errors_t<3, 1, 1>(r, px, out); else if (subsets == 2) uastc_errors_t<3, 1, 2>(r, px, out); else uastc_errors_t<3, 1, 3>(r, px, out);
+    } else if (comps == 4) {
+        if (subsets == 1) uastc_errors_t<4, 1, 1>(r, px, out); else uastc_errors_t<4, 1, 2>(r, px, out);
+    } else {
+        if (subsets == 1) uastc_errors_t<2, 1, 1>(r, px, out); else uastc_errors_t<2, 1, 2>(r, px, out);
+    }
+}
+
+// decode_bc7 + block_error
+BU_FN void bc7_unquant_floats(const cand& r, uint32_t first, uint32_t comps, const uint8_t* UQ, float* xl, float* xh) {   // the float endpoints of the subset whose indices start at `first`
+    if (comps == 2) {
+        xl[0] = xl[1] = xl[2] = (float)UQ[r.endpoints[first]] / 255.0f; xh[0] = xh[1] = xh[2] = (float)UQ[r.endpoints[first + 1]] / 255.0f;
+        xl[3] = (float)UQ[r.endpoints[first + 2]] / 255.0f; xh[3] = (float)UQ[r.endpoints[first + 3]] / 255.0f;
+    } else {
+        BU_UNROLL
+        for (int c = 0; c < 4; c++) {
+            xl[c] = (uint32_t)c < comps ? (float)UQ[r.endpoints[first + c * 2]] / 255.0f : 1.0f;
+            xh[c] = (uint32_t)c < comps ? (float)UQ[r.endpoints[first + c * 2 + 1]] / 255.0f : 1.0f;
+        }
+    }
+}
+BU_FN void bc7_errors(const cand& r, const uint32_t* px, chan_err& out) {
+    const uint32_t mode = r.mode, comps = ku_mode_comps[mode];
+    const uint8_t* UQ = ku_unquant + ku_mode_endpoint_ranges[mode] * 256;
+    out.e[0] = out.e[1] = out.e[2] = out.e[3] = 0;
+    switch (mode) {
+    case 0: case 5: case 10: case 12: case 14: case 15: case 18: {  // -> BC7 mode 6
+        float xl[4], xh[4];
+        bc7_unquant_floats(r, 0, comps, UQ, xl, xh);
+        uint8_t lo[4] = { 0, 0, 0, 0 }, hi[4] = { 0, 0, 0, 0 };
+        uint32_t pb[2] = { 0, 0 };
+        bc7_pbit_quantise(false, comps == 2 ? 4 : comps, 7, xl, xh, lo, hi, pb);
+        if (comps == 3) { lo[3] = 127; hi[3] = 127; }
+        uint32_t l[4], h[4];
+        for (int c = 0; c < 4; c++) { l[c] = ((uint32_t)lo[c] << 1) | pb[0]; h[c] = ((uint32_t)hi[c] << 1) | pb[1]; }
+        BU_UNROLL
+        for (int i = 0; i < 16; i++) {
+            const uint32_t w = r.weights[i];
+            // five_to_four / three_to_four of decode_bc7 and the BC7 4-bit weights, as literals (a nibble / a byte per entry)
+            const uint32_t five = (uint32_t)((w < 16 ? 0x7666554433221100ull : 0xFFEEDDCCBBAA9998ull) >> (4 * (w & 15))) & 15u;
+            const uint32_t three = (0xFDB96420u >> (4 * (w & 7))) & 15u;
+            const uint32_t sx = mode == 18 ? five : (mode == 14 ? w * 5 : ((mode == 5 || mode == 12) ? three : w));
+            const uint32_t wt = (uint32_t)((sx < 8 ? 0x1E1A15110D090400ull : 0x403C37332F2B2622ull) >> (8 * (sx & 7))) & 255u;
+            chan_err_add(out, px[i], bc7_lerp(l[0], h[0], wt), bc7_lerp(l[1], h[1], wt), bc7_lerp(l[2], h[2], wt), bc7_lerp(l[3], h[3], wt));
+        }
+        break;
+    }
+    case 1: case 4: case 2: case 9: case 16: {  // -> BC7 mode 3 (1, 4), mode 1 (2), mode 7 (9, 16): two subsets with p-bits
+        const uint32_t ncomp = (mode == 9 || mode == 16) ? 4 : 3;
+        const uint32_t bits = mode == 2 ? 6 : (ncomp == 4 ? 5 : 7);
+        const uint32_t part = mode == 1 ? 0 : ku_bc7_part2[ku_cp2_bc7[r.pattern]];
+        const bool invert = mode != 1 && ku_cp2_invert[r.pattern];
+        uint32_t l[2][4], h[2][4];   // dequantised, by BC7 subset
+        BU_UNROLL
+        for (int s = 0; s < 2; s++) {
+            float xl[4], xh[4];
+            bc7_unquant_floats(r, mode == 1 ? 0u : (uint32_t)s * comps * 2, comps, UQ, xl, xh);
+            uint8_t lo[4] = { 0, 0, 0, 0 }, hi[4] = { 0, 0, 0, 0 };
+            uint32_t pb[2] = { 0, 0 };
+            bc7_pbit_quantise(mode == 2, ncomp, bits, xl, xh, lo, hi, pb);
+            uint32_t dl[4], dh[4];
+            for (int c = 0; c < 4; c++) { dl[c] = bc7_dequant_p(lo[c], pb[0], bits); dh[c] = bc7_dequant_p(hi[c], pb[mode == 2 ? 0 : 1], bits); }
+            // ASTC subset s is BC7 subset 1 - s when the pattern is inverted
+            for (int c = 0; c < 4; c++) {
+                if (s == 0) { l[0][c] = dl[c]; h[0][c] = dh[c]; l[1][c] = dl[c]; h[1][c] = dh[c]; }   // (both, so that every entry is defined; overwritten below)
+                else if (invert) { l[0][c] = dl[c]; h[0][c] = dh[c]; }
+                else { l[1][c] = dl[c]; h[1][c] = dh[c]; }
+            }
+            if (s == 0 && invert) { /* subset 0's values belong at index 1: they are there already (copied to both) */ }
+        }
+        const uint32_t wb = mode == 2 ? 3u : 2u;
+        BU_UNROLL
+        for (int i = 0; i < 16; i++) {
+            const uint32_t s = (part >> (2 * i)) & 3u, wt = weight_of(wb, r.weights[i]);
+            uint32_t v[4];
+            for (int c = 0; c < 4; c++) v[c] = (uint32_t)c < ncomp ? bc7_lerp(s ? l[1][c] : l[0][c], s ? h[1][c] : h[0][c], wt) : 255u;
+            chan_err_add(out, px[i], v[0], v[1], v[2], v[3]);
+        }
+        break;
+    }
+    case 3: case 7: {  // -> BC7 mode 2: three subsets, 5-bit endpoints, no p-bits
+        uint32_t l[3][3], h[3][3];
+        uint32_t part;
+        if (mode == 3) {
+            part = ku_bc7_part3[ku_cp3_bc7[r.pattern]];
+            const uint32_t perm = ku_cp3_perm[r.pattern];
+            BU_UNROLL
+            for (int d = 0; d < 3; d++) {
+                // the ASTC subset that lands in BC7 subset d
+                uint32_t sa = 0;
+                for (uint32_t s = 0; s < 3; s++) if (ku_astc_to_bc7_perm[perm * 3 + s] == (uint32_t)d) sa = s;
+                BU_UNROLL
+                for (int c = 0; c < 3; c++) {
+                    const uint32_t lv = pick3(sa, r.endpoints[c * 2], r.endpoints[c * 2 + 6], r.endpoints[c * 2 + 12]), hv = pick3(sa, r.endpoints[c * 2 + 1], r.endpoints[c * 2 + 7], r.endpoints[c * 2 + 13]);
+                    l[d][c] = bc7_dequant((UQ[lv] * 31 + 127) / 255, 5); h[d][c] = bc7_dequant((UQ[hv] * 31 + 127) / 255, 5);
+                }
+            }
+        } else {
+            part = ku_bc7_part3[ku_cp7_bc7[r.pattern]];
+            BU_UNROLL
+            for (int d = 0; d < 3; d++) {
+                const uint32_t sa = bc7_3_to_2((uint32_t)d, ku_cp7_k[r.pattern]);
+                BU_UNROLL
+                for (int c = 0; c < 3; c++) {
+                    const uint32_t lv = sa ? r.endpoints[c * 2 + 6] : r.endpoints[c * 2], hv = sa ? r.endpoints[c * 2 + 7] : r.endpoints[c * 2 + 1];
+                    l[d][c] = bc7_dequant((UQ[lv] * 31 + 127) / 255, 5); h[d][c] = bc7_dequant((UQ[hv] * 31 + 127) / 255, 5);
+                }
+            }
+        }
+        BU_UNROLL
+        for (int i = 0; i < 16; i++) {
+            const uint32_t s = (part >> (2 * i)) & 3u, wt = weight_of(2, r.weights[i]);
+            chan_err_add(out, px[i], bc7_lerp(pick3(s, l[0][0], l[1][0], l[2][0]), pick3(s, h[0][0], h[1][0], h[2][0]), wt),
+                         bc7_lerp(pick3(s, l[0][1], l[1][1], l[2][1]), pick3(s, h[0][1], h[1][1], h[2][1]), wt),
+                         bc7_lerp(pick3(s, l[0][2], l[1][2], l[2][2]), pick3(s, h[0][2], h[1][2], h[2][2]), wt), 255u);
+        }
+        break;
+    }
+    default: {  // 6, 11, 13, 17 -> BC7 mode 5: 7-bit colour + 8-bit alpha, separate index planes, channel rotation
+        uint32_t lo[4] = { 0, 0, 0, 0 }, hi[4] = { 0, 0, 0, 0 };   // by BC7 channel: 0..2 colour (7 bits), 3 the rotated-out channel (8 bits)
+        const uint32_t rot = (r.ccs + 1u) & 3u;
+        if (comps == 2) {
+            lo[0] = lo[1] = lo[2] = (UQ[r.endpoints[0]] * 127u + 127u) / 255u;
+            hi[0] = hi[1] = hi[2] = (UQ[r.endpoints[1]] * 127u + 127u) / 255u;
+            lo[3] = UQ[r.endpoints[2]]; hi[3] = UQ[r.endpoints[3]];
+        } else {
+            BU_UNROLL
+            for (int ac = 0; ac < 4; ac++) {
+                const uint32_t bc = (uint32_t)ac == r.ccs ? 3u : (ac == 3 ? r.ccs : (uint32_t)ac);
+                uint32_t lv = 255, hv = 255;
+                if ((uint32_t)ac < comps) { lv = UQ[r.endpoints[ac * 2]]; hv = UQ[r.endpoints[ac * 2 + 1]]; }
+                if (bc < 3) { lv = (lv * 127 + 127) / 255; hv = (hv * 127 + 127) / 255; }
+                BU_UNROLL
+                for (int k = 0; k < 4; k++) if (bc == (uint32_t)k) { lo[k] = lv; hi[k] = hv; }
+            }
+        }
+        uint32_t cl[3], ch[3];
+        for (int c = 0; c < 3; c++) { cl[c] = bc7_dequant(lo[c], 7); ch[c] = bc7_dequant(hi[c], 7); }
+        BU_UNROLL
+        for (int i = 0; i < 16; i++) {
+            uint32_t cs = r.weights[i * 2], as = r.weights[i * 2 + 1];
+            if (mode == 13) { cs = cs ? 3 : 0; as = as ? 3 : 0; }
+            const uint32_t wc = weight_of(2, cs), wa = weight_of(2, as);
+            const uint32_t v0 = bc7_lerp(cl[0], ch[0], wc), v1 = bc7_lerp(cl[1], ch[1], wc), v2 = bc7_lerp(cl[2], ch[2], wc), v3 = bc7_lerp(lo[3], hi[3], wa);
+            // undo the rotation: the alpha plane's value goes to channel rot - 1, that channel's to alpha
+            chan_err_add(out, px[i], rot == 1 ? v3 : v0, rot == 2 ? v3 : v1, rot == 3 ? v3 : v2, rot == 0 ? v3 : (rot == 1 ? v0 : (rot == 2 ? v1 : v2)));
+        }
+        break;
+    }
+    }
+}
+
 // Per-candidate scores used by the final choice (uastc_enc.cpp:3403-3488)
 struct cand_score { uint64_t overall; float uastc_rms; };
 BU_FN cand_score score_candidate(const cand& r, const rgba8* px, uint32_t cls, const enc_cfg& e) {
-    rgba8 du[16], db[16];
-    decode_uastc(r, du);
-    decode_bc7(r, db);
-    const block_err eu = block_error(px, du), eb = block_error(px, db);
+    uint32_t packed[16];
+    BU_UNROLL
+    for (int i = 0; i < 16; i++) packed[i] = pack_px(px[i].c);
+    chan_err cu, cb;
+    uastc_errors(r, packed, cu);
+    bc7_errors(r, packed, cb);
+    const block_err eu = chan_err_totals(cu), eb = chan_err_totals(cb);
     const bool favor_uastc = (e.flags & FLAG_FAVOR_UASTC) != 0, favor_bc7 = !favor_uastc && (e.flags & FLAG_FAVOR_BC7) != 0;
     const uint32_t bc7_w = favor_bc7 ? 100 : (favor_uastc ? 0 : 50), uastc_w = favor_bc7 ? 0 : 100;
     const uint64_t u = (cls & CLS_LA) ? eu.la : ((cls & CLS_ALPHA) ? eu.rgba : eu.rgb);

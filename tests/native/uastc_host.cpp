@@ -165,3 +165,42 @@ HC_API int hc_rehint(const uint8_t* pixels, uint32_t n, uint32_t flags, uint8_t*
         if (!rdo_rehint((const rgba8*)(pixels + (size_t)i * 64), e, blocks + (size_t)i * 16)) return 0;
     return 1;
 }
+
+// every candidate of every block: the fused decode + error (uastc_errors / bc7_errors, what score_candidate uses) against the general decoders + block_error
+HC_API uint32_t hc_score_selfcheck(const uint8_t* blocks, uint32_t n, uint32_t flags, uint32_t* checked) {
+    enc_cfg e;
+    make_cfg(flags, e);
+    uint32_t bad = 0, seen = 0;
+    static cand slots[MAX_SLOTS];
+    for (uint32_t i = 0; i < n; i++) {
+        const rgba8* px = (const rgba8*)(blocks + (size_t)i * 64);
+        const uint32_t cls = classify(px, e);
+        if (cls & CLS_SOLID) continue;
+        uint32_t packed[16];
+        for (int k = 0; k < 16; k++) packed[k] = pack_px(px[k].c);
+        for (uint32_t m = 0; m < 19; m++) {
+            const uint32_t nv = mode_variants(m, e);
+            if (!nv || !mode_applies(m, cls, e)) continue;
+            for (uint32_t v = 0; v < nv; v += (e.estimate_partition && (m == 9 || m == 16)) ? nv : 1) {
+                cand out[4];
+                const uint32_t cnt = (e.estimate_partition && (m == 9 || m == 16)) ? nv : 1;
+                run_mode(m, px, e, out, v, cnt);
+                for (uint32_t k = 0; k < cnt; k++) {
+                    rgba8 du[16], db[16];
+                    decode_uastc(out[k], du);
+                    decode_bc7(out[k], db);
+                    const block_err eu = block_error(px, du), eb = block_error(px, db);
+                    chan_err cu, cb;
+                    uastc_errors(out[k], packed, cu);
+                    bc7_errors(out[k], packed, cb);
+                    const block_err fu = chan_err_totals(cu), fb = chan_err_totals(cb);
+                    seen++;
+                    if (eu.rgb != fu.rgb || eu.rgba != fu.rgba || eu.la != fu.la || eb.rgb != fb.rgb || eb.rgba != fb.rgba || eb.la != fb.la) bad++;
+                }
+            }
+        }
+    }
+    (void)slots;
+    if (checked) *checked = seen;
+    return bad;
+}

@@ -117,3 +117,21 @@ def test_host_decoder_matches_reference_unpack(golden):
         assert (helpers.host_decode_uastc(packed) == helpers.ref_decode_uastc(packed)).all(), name
     z = np.load(GOLDEN.parent / "uastc_rdo_vectors.npz")
     assert (helpers.host_decode_uastc(z["strong_l2"]) == helpers.ref_decode_uastc(z["strong_l2"])).all()
+
+
+@pytest.mark.parametrize("flags", [0, 2, 3, 4])
+def test_fused_scoring_equals_the_general_decoders(flags):
+    """score_candidate's fused decode + error per texel (uastc_errors / bc7_errors: no decoded images, tables picked by select) against decode_uastc / decode_bc7 +
+    block_error, for every candidate of every mode: opaque, alpha and luminance-alpha blocks."""
+    import ctypes as C
+    from helpers import uastc_host, synth, to_pixel_blocks
+    rgb = to_pixel_blocks(synth(64, 48, 11))
+    rgba = rgb.copy(); rgba[..., 3] = (rgba[..., 0].astype(np.int32) * 3 + rgba[..., 1]) % 256
+    la = rgba.copy(); la[..., 1] = la[..., 0]; la[..., 2] = la[..., 0]
+    flat = rgb.copy(); flat[:, :, :, :3] = (flat[:, :, :, :3] // 64) * 64 + 7      # few distinct values per block: degenerate cells, two-level planes
+    blocks = np.ascontiguousarray(np.concatenate([rgb, rgba, la, flat]))
+    L = uastc_host()
+    L.hc_score_selfcheck.restype = C.c_uint32
+    checked = C.c_uint32(0)
+    bad = L.hc_score_selfcheck(blocks.ctypes.data_as(C.POINTER(C.c_uint8)), blocks.shape[0], flags, C.byref(checked))
+    assert checked.value > 2 * blocks.shape[0] and bad == 0, (bad, checked.value)
