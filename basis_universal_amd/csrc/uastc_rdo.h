@@ -133,11 +133,13 @@ BU_FN uint32_t match_cost(uint32_t dist) {
 
 // sum of the block's UASTC error and the error of its BC7 transcode, halved (uastc_enc.cpp:3872-3893, 3971-3991)
 BU_FN uint64_t rdo_block_error(const cand& r, const rgba8* px) {
-    rgba8 dec[16];
-    decode_uastc(r, dec);
-    const uint64_t a = block_error(px, dec).rgba;
-    decode_bc7(r, dec);
-    return (a + block_error(px, dec).rgba) / 2;
+    uint32_t packed[16];
+    BU_UNROLL
+    for (int i = 0; i < 16; i++) packed[i] = pack_px(px[i].c);
+    chan_err cu, cb;   // the fused decode + error of the scoring pass (uastc_core.h): no decoded images in scratch memory
+    uastc_errors(r, packed, cu);
+    bc7_errors(r, packed, cb);
+    return (chan_err_totals(cu).rgba + chan_err_totals(cb).rgba) / 2;
 }
 
 // What uastc_rdo_blocks derives from a block before looking at its neighbours (:3837-3915): the error it has now, the smooth-block scale,
