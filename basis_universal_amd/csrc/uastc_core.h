@@ -1393,30 +1393,40 @@ BU_FN uint32_t choose_candidate(const V& v, uint32_t n_slots, const enc_cfg& e) 
 
 struct bc1_blk { uint16_t c0, c1; uint32_t sel; };  // selectors: 2 bits per texel, texel 0 in the low bits
 
-BU_FN void bc1_decode(const bc1_blk& b, rgba8* out) {  // bcu::unpack_bc1, transcoder/basisu_dds_transcoder.inl:23-80
-    uint8_t col[4][4];
+// Everything below works on texels as packed dwords held in registers (r | g << 8 | b << 16 | a << 24), selector sets as 2 bits per texel in one dword, and blocks by
+// value: on the GPU an image that reaches a function through a pointer, or a byte array indexed by a run-time value, lives in scratch memory, and these functions used
+// to spend their time waiting for it (round 3; the same change as uastc_errors / bc7_errors).
+
+// bcu::unpack_bc1 (transcoder/basisu_dds_transcoder.inl:23-80) + the RGB error against `px` in one pass
+BU_FN uint32_t bc1_error(const bc1_blk& b, const uint32_t* px) {
+    int col[4][3];
     const uint32_t c[2] = { b.c0, b.c1 };
-    for (uint32_t k = 0; k < 2; k++) {
+    for (int k = 0; k < 2; k++) {
         const uint32_t r = (c[k] >> 11) & 31, g = (c[k] >> 5) & 63, bl = c[k] & 31;
-        col[k][0] = (uint8_t)((r << 3) | (r >> 2)); col[k][1] = (uint8_t)((g << 2) | (g >> 4)); col[k][2] = (uint8_t)((bl << 3) | (bl >> 2)); col[k][3] = 255;
+        col[k][0] = (int)((r << 3) | (r >> 2)); col[k][1] = (int)((g << 2) | (g >> 4)); col[k][2] = (int)((bl << 3) | (bl >> 2));
     }
-    for (uint32_t ch = 0; ch < 3; ch++) {
-        if (b.c0 > b.c1) {
-            col[2][ch] = (uint8_t)((col[0][ch] * 2 + col[1][ch]) / 3);
-            col[3][ch] = (uint8_t)((col[1][ch] * 2 + col[0][ch]) / 3);
-        } else {
-            col[2][ch] = (uint8_t)((col[0][ch] + col[1][ch]) / 2);
-            col[3][ch] = 0;
+    const bool four = b.c0 > b.c1;
+    for (int ch = 0; ch < 3; ch++) {
+        col[2][ch] = four ? (col[0][ch] * 2 + col[1][ch]) / 3 : (col[0][ch] + col[1][ch]) / 2;
+        col[3][ch] = four ? (col[1][ch] * 2 + col[0][ch]) / 3 : 0;
+    }
+    uint32_t total = 0;
+    BU_UNROLL
+    for (int i = 0; i < 16; i++) {
+        const uint32_t sl = (b.sel >> (2 * i)) & 3u;
+        const bool odd = (sl & 1u) != 0, upper = (sl & 2u) != 0;
+        BU_UNROLL
+        for (int ch = 0; ch < 3; ch++) {
+            const int v = upper ? (odd ? col[3][ch] : col[2][ch]) : (odd ? col[1][ch] : col[0][ch]);
+            const int d = px_comp(px[i], ch) - v;
+            total += (uint32_t)imul24(d, d);
         }
     }
-    col[2][3] = 255;
-    col[3][3] = b.c0 > b.c1 ? 255 : 0;
-    for (uint32_t i = 0; i < 16; i++)
-        for (uint32_t ch = 0; ch < 4; ch++) out[i].c[ch] = col[(b.sel >> (2 * i)) & 3][ch];
+    return total;
 }
 
-// bc1_find_sels (transcoder.cpp:17857-17885): linear selectors 0..3 along low->high for 5:6:5 endpoints
-BU_FN void bc1_pick_selectors(const rgba8* px, const int* l, const int* h, uint8_t* sels) {
+// bc1_find_sels (transcoder.cpp:17857-17885): linear selectors 0..3 along low->high for 5:6:5 endpoints; 2 bits per texel
+BU_FN uint32_t bc1_pick_selectors(const uint32_t* px, const int* l, const int* h) {
     int br[4], bg[4], bb[4];
     br[0] = (l[0] << 3) | (l[0] >> 2); bg[0] = (l[1] << 2) | (l[1] >> 4); bb[0] = (l[2] << 3) | (l[2] >> 2);
     br[3] = (h[0] << 3) | (h[0] >> 2); bg[3] = (h[1] << 2) | (h[1] >> 4); bb[3] = (h[2] << 3) | (h[2] >> 2);
@@ -1424,16 +1434,19 @@ BU_FN void bc1_pick_selectors(const rgba8* px, const int* l, const int* h, uint8
     br[2] = (br[3] * 2 + br[0]) / 3; bg[2] = (bg[3] * 2 + bg[0]) / 3; bb[2] = (bb[3] * 2 + bb[0]) / 3;
     int ar = br[3] - br[0], ag = bg[3] - bg[0], ab = bb[3] - bb[0];
     int dots[4];
-    for (uint32_t i = 0; i < 4; i++) dots[i] = imul24(br[i], ar) + imul24(bg[i], ag) + imul24(bb[i], ab);
+    for (int i = 0; i < 4; i++) dots[i] = imul24(br[i], ar) + imul24(bg[i], ag) + imul24(bb[i], ab);
     const int t0 = dots[0] + dots[1], t1 = dots[1] + dots[2], t2 = dots[2] + dots[3];
     ar *= 2; ag *= 2; ab *= 2;
-    for (uint32_t i = 0; i < 16; i++) {
-        const int d = imul24(px[i].c[0], ar) + imul24(px[i].c[1], ag) + imul24(px[i].c[2], ab);
-        sels[i] = (uint8_t)(3 - ((d <= t0) + (d < t1) + (d < t2)));
+    uint32_t sels = 0;
+    BU_UNROLL
+    for (int i = 0; i < 16; i++) {
+        const int d = imul24(px_comp(px[i], 0), ar) + imul24(px_comp(px[i], 1), ag) + imul24(px_comp(px[i], 2), ab);
+        sels |= (uint32_t)(3 - ((d <= t0) + (d < t1) + (d < t2))) << (2 * i);
     }
+    return sels;
 }
 
-BU_FN void bc1_solid(uint32_t r, uint32_t g, uint32_t b, bc1_blk& out) {  // encode_bc1_solid_block, transcoder.cpp:17999-18042
+BU_FN bc1_blk bc1_solid(uint32_t r, uint32_t g, uint32_t b) {  // encode_bc1_solid_block, transcoder.cpp:17999-18042
     uint32_t mask = 0xAA;
     uint32_t max16 = ((uint32_t)ku_bc1_match5[r * 2] << 11) | ((uint32_t)ku_bc1_match6[g * 2] << 5) | ku_bc1_match5[b * 2];
     uint32_t min16 = ((uint32_t)ku_bc1_match5[r * 2 + 1] << 11) | ((uint32_t)ku_bc1_match6[g * 2 + 1] << 5) | ku_bc1_match5[b * 2 + 1];
@@ -1443,37 +1456,38 @@ BU_FN void bc1_solid(uint32_t r, uint32_t g, uint32_t b, bc1_blk& out) {  // enc
         else { max16 = 1; min16 = 0; mask = 0x55; }
     }
     if (max16 < min16) { const uint32_t t = max16; max16 = min16; min16 = t; mask ^= 0x55; }
+    bc1_blk out;
     out.c0 = (uint16_t)max16; out.c1 = (uint16_t)min16;
     out.sel = mask * 0x01010101u;
+    return out;
 }
 
-// basist::encode_bc1 (transcoder.cpp:18047-18283) with flags 0 (given_sels == NULL) or cEncodeBC1UseSelectors
-BU_FN_BIG void bc1_encode(const rgba8* px, const uint8_t* given_sels, bc1_blk& out) {
+// basist::encode_bc1 (transcoder.cpp:18047-18283) with flags 0 (use_given false) or cEncodeBC1UseSelectors (the selectors in `given`, 2 bits per texel)
+BU_FN bc1_blk bc1_encode(const uint32_t* px, bool use_given, uint32_t given) {
     int avg[3] = { -1, 0, 0 };
     int l[3] = { 0, 0, 0 }, h[3] = { 0, 0, 0 };
-    uint8_t sels[16];
-    if (given_sels) {
-        for (uint32_t i = 0; i < 16; i++) sels[i] = given_sels[i];
-    } else {
-        bool same = true;
-        for (uint32_t i = 1; i < 16; i++) same = same && px[i].c[0] == px[0].c[0] && px[i].c[1] == px[0].c[1] && px[i].c[2] == px[0].c[2];
-        if (same) { bc1_solid(px[0].c[0], px[0].c[1], px[0].c[2], out); return; }
-        int tot[3] = { 0, 0, 0 }, mx[3] = { 0, 0, 0 }, mn[3] = { 255, 255, 255 };
-        for (uint32_t i = 0; i < 16; i++)
-            for (uint32_t c = 0; c < 3; c++) {
-                const int v = px[i].c[c];
-                tot[c] += v; mx[c] = v > mx[c] ? v : mx[c]; mn[c] = v < mn[c] ? v : mn[c];
-            }
-        for (uint32_t c = 0; c < 3; c++) avg[c] = (tot[c] + 8) >> 4;
+    uint32_t sels = given;
+    int tot[3] = { 0, 0, 0 }, mx[3] = { 0, 0, 0 }, mn[3] = { 255, 255, 255 };
+    BU_UNROLL
+    for (int i = 0; i < 16; i++)
+        BU_UNROLL
+        for (int c = 0; c < 3; c++) {
+            const int v = px_comp(px[i], c);
+            tot[c] += v; mx[c] = v > mx[c] ? v : mx[c]; mn[c] = v < mn[c] ? v : mn[c];
+        }
+    if (!use_given) {
+        if (mx[0] == mn[0] && mx[1] == mn[1] && mx[2] == mn[2]) return bc1_solid((uint32_t)mn[0], (uint32_t)mn[1], (uint32_t)mn[2]);
+        for (int c = 0; c < 3; c++) avg[c] = (tot[c] + 8) >> 4;
         int icov[6] = { 0, 0, 0, 0, 0, 0 };
-        for (uint32_t i = 0; i < 16; i++) {
-            const int r = (int)px[i].c[0] - avg[0], g = (int)px[i].c[1] - avg[1], b = (int)px[i].c[2] - avg[2];
+        BU_UNROLL
+        for (int i = 0; i < 16; i++) {
+            const int r = px_comp(px[i], 0) - avg[0], g = px_comp(px[i], 1) - avg[1], b = px_comp(px[i], 2) - avg[2];
             icov[0] += imul24(r, r); icov[1] += imul24(r, g); icov[2] += imul24(r, b); icov[3] += imul24(g, g); icov[4] += imul24(g, b); icov[5] += imul24(b, b);
         }
         float cov[6];
-        for (uint32_t i = 0; i < 6; i++) cov[i] = (float)icov[i] * (1.0f / 255.0f);
+        for (int i = 0; i < 6; i++) cov[i] = (float)icov[i] * (1.0f / 255.0f);
         float xr = (float)(mx[0] - mn[0]), xg = (float)(mx[1] - mn[1]), xb = (float)(mx[2] - mn[2]);
-        for (uint32_t it = 0; it < 4; it++) {
+        for (int it = 0; it < 4; it++) {
             const float r = xr * cov[0] + xg * cov[1] + xb * cov[2];
             const float g = xr * cov[1] + xg * cov[3] + xb * cov[4];
             const float b = xr * cov[2] + xg * cov[4] + xb * cov[5];
@@ -1487,62 +1501,57 @@ BU_FN_BIG void bc1_encode(const rgba8* px, const uint8_t* given_sels, bc1_blk& o
             sa[0] = (int)(xr * m); sa[1] = (int)(xg * m); sa[2] = (int)(xb * m);
         }
         int low_dot = INT32_MAX, high_dot = INT32_MIN;
-        uint32_t low_c = 0, high_c = 0;
-        for (uint32_t i = 0; i < 16; i++) {
-            const int dot = imul24(px[i].c[0], sa[0]) + imul24(px[i].c[1], sa[1]) + imul24(px[i].c[2], sa[2]);
-            if (dot < low_dot) { low_dot = dot; low_c = i; }
-            if (dot > high_dot) { high_dot = dot; high_c = i; }
+        uint32_t low_px = 0, high_px = 0;   // the first texel with the least / the greatest projection, itself rather than its index
+        BU_UNROLL
+        for (int i = 0; i < 16; i++) {
+            const int dot = imul24(px_comp(px[i], 0), sa[0]) + imul24(px_comp(px[i], 1), sa[1]) + imul24(px_comp(px[i], 2), sa[2]);
+            if (dot < low_dot) { low_dot = dot; low_px = px[i]; }
+            if (dot > high_dot) { high_dot = dot; high_px = px[i]; }
         }
-        for (uint32_t c = 0; c < 3; c++) {
+        for (int c = 0; c < 3; c++) {
             const uint32_t mul = c == 1 ? 63 : 31;
-            uint32_t v = px[low_c].c[c] * mul + 128;
+            uint32_t v = (uint32_t)px_comp(low_px, c) * mul + 128;
             l[c] = (int)((v + (v >> 8)) >> 8);
-            v = px[high_c].c[c] * mul + 128;
+            v = (uint32_t)px_comp(high_px, c) * mul + 128;
             h[c] = (int)((v + (v >> 8)) >> 8);
         }
-        bc1_pick_selectors(px, l, h, sels);
+        sels = bc1_pick_selectors(px, l, h);
     }
     {
         // one least-squares pass (compute_least_squares_endpoints_rgb, transcoder.cpp:17922-17997)
-        uint32_t q00[3] = { 0, 0, 0 }, t[3] = { 0, 0, 0 }, wacc = 0;
-        const uint32_t wvals[4] = { 0x000009, 0x010204, 0x040201, 0x090000 };
-        for (uint32_t i = 0; i < 16; i++) {
-            const uint32_t sel = sels[i];
-            wacc += wvals[sel];
-            for (uint32_t c = 0; c < 3; c++) { t[c] += px[i].c[c]; q00[c] += sel * px[i].c[c]; }
+        uint32_t q00[3] = { 0, 0, 0 }, wacc = 0;
+        BU_UNROLL
+        for (int i = 0; i < 16; i++) {
+            const uint32_t sel = (sels >> (2 * i)) & 3u;
+            wacc += sel == 0 ? 0x000009u : (sel == 1 ? 0x010204u : (sel == 2 ? 0x040201u : 0x090000u));
+            BU_UNROLL
+            for (int c = 0; c < 3; c++) q00[c] += sel * (uint32_t)px_comp(px[i], c);
         }
         const float z00 = (float)((wacc >> 16) & 0xFF), z10 = (float)((wacc >> 8) & 0xFF), z11 = (float)(wacc & 0xFF), z01 = z10;
         float det = z00 * z11 - z01 * z10;
         if (fabsf(det) < 1e-8f) {
-            if (avg[0] < 0) {
-                int tot[3] = { 0, 0, 0 };
-                for (uint32_t i = 0; i < 16; i++) for (uint32_t c = 0; c < 3; c++) tot[c] += px[i].c[c];
-                for (uint32_t c = 0; c < 3; c++) avg[c] = (tot[c] + 8) >> 4;
-            }
+            if (avg[0] < 0) for (int c = 0; c < 3; c++) avg[c] = (tot[c] + 8) >> 4;
             l[0] = ku_bc1_match5[avg[0] * 2]; l[1] = ku_bc1_match6[avg[1] * 2]; l[2] = ku_bc1_match5[avg[2] * 2];
             h[0] = ku_bc1_match5[avg[0] * 2 + 1]; h[1] = ku_bc1_match6[avg[1] * 2 + 1]; h[2] = ku_bc1_match5[avg[2] * 2 + 1];
         } else {
             det = 3.0f / det;
             const float iz00 = z11 * det, iz01 = -z01 * det, iz10 = -z10 * det, iz11 = z00 * det;
-            for (uint32_t c = 0; c < 3; c++) {
-                const float fq00 = (float)q00[c], ft = (float)t[c];
+            for (int c = 0; c < 3; c++) {
+                const float fq00 = (float)q00[c], ft = (float)tot[c];
                 const float fq10 = ft * 3.0f - fq00;
                 float xl = iz00 * fq00 + iz01 * fq10, xh = iz10 * fq00 + iz11 * fq10;
-                if (xl < 0.0f || xh > 255.0f) {
-                    uint32_t lo_v = 255, hi_v = 0;
-                    for (uint32_t i = 0; i < 16; i++) { const uint32_t v = px[i].c[c]; lo_v = v < lo_v ? v : lo_v; hi_v = v > hi_v ? v : hi_v; }
-                    if (lo_v == hi_v) { xl = (float)lo_v; xh = (float)hi_v; }
-                }
+                if ((xl < 0.0f || xh > 255.0f) && mn[c] == mx[c]) { xl = (float)mn[c]; xh = (float)mx[c]; }
                 const float scale = c == 1 ? (63.0f / 255.0f) : (31.0f / 255.0f);
                 const int top = c == 1 ? 63 : 31;
                 l[c] = clampi((int)(xl * scale + .5f), 0, top);
                 h[c] = clampi((int)(xh * scale + .5f), 0, top);
             }
         }
-        bc1_pick_selectors(px, l, h, sels);
+        sels = bc1_pick_selectors(px, l, h);
     }
     uint32_t lc16 = ((uint32_t)l[0] << 11) | ((uint32_t)l[1] << 5) | (uint32_t)l[2];
     uint32_t hc16 = ((uint32_t)h[0] << 11) | ((uint32_t)h[1] << 5) | (uint32_t)h[2];
+    bc1_blk out;
     if (lc16 == hc16) {
         uint32_t mask = 0;
         if (hc16 > 0) hc16--;
@@ -1551,11 +1560,11 @@ BU_FN_BIG void bc1_encode(const rgba8* px, const uint8_t* given_sels, bc1_blk& o
     } else {
         uint32_t invert = 0;
         if (lc16 < hc16) { const uint32_t t = lc16; lc16 = hc16; hc16 = t; invert = 0x55555555u; }
-        const uint8_t tr[4] = { 0, 2, 3, 1 };
-        uint32_t packed = 0;
-        for (uint32_t i = 0; i < 16; i++) packed |= (uint32_t)tr[sels[i]] << (i * 2);
-        out.c0 = (uint16_t)lc16; out.c1 = (uint16_t)hc16; out.sel = packed ^ invert;
+        // linear selector 0..3 -> BC1 code {0, 2, 3, 1}, all sixteen at once: code = (s >> 1) | ((s ^ (s >> 1)) & 1) << 1
+        const uint32_t hi = (sels >> 1) & 0x55555555u, lo = sels & 0x55555555u;
+        out.c0 = (uint16_t)lc16; out.c1 = (uint16_t)hc16; out.sel = (hi | ((hi ^ lo) << 1)) ^ invert;
     }
+    return out;
 }
 
 // The candidate as pack_uastc stores it: every subset/plane anchor weight has its top bit clear (weights mirrored and the
@@ -1582,12 +1591,8 @@ BU_FN void normalise_anchors(cand& r) {
         }
 }
 
-BU_FN uint32_t bc1_weight_translate(uint32_t wbits, uint32_t w) {  // s_uastc{1..5}_to_bc1, transcoder.cpp:17729-17735
-    const uint8_t t5[32] = { 0, 0, 0, 0, 0, 0, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 3, 3, 3, 3, 3, 3, 3, 3, 3, 3, 1, 1, 1, 1, 1, 1 };
-    const uint8_t t4[16] = { 0, 0, 0, 2, 2, 2, 2, 2, 3, 3, 3, 3, 3, 1, 1, 1 };
-    const uint8_t t3[8] = { 0, 0, 2, 2, 3, 3, 1, 1 };
-    const uint8_t t2[4] = { 0, 2, 3, 1 };
-    return wbits == 5 ? t5[w] : (wbits == 4 ? t4[w] : (wbits == 3 ? t3[w] : (wbits == 2 ? t2[w] : w)));
+BU_FN uint32_t bc1_weight_translate(uint32_t wbits, uint32_t w) {  // s_uastc{1..5}_to_bc1, transcoder.cpp:17729-17735 (2 bits per entry in a literal)
+    return wbits == 5 ? (uint32_t)(0x555fffffaaaaa000ull >> (2 * w)) & 3u : (wbits == 4 ? (0x57ffaa80u >> (2 * w)) & 3u : (wbits == 3 ? (0x5fa0u >> (2 * w)) & 3u : (wbits == 2 ? (0x78u >> (2 * w)) & 3u : w)));
 }
 
 BU_FN uint32_t pack565_scaled(uint32_t r, uint32_t g, uint32_t b) {  // dxt1_block::pack_color(scaled, bias 127), uastc_enc.cpp:69-80
@@ -1595,51 +1600,41 @@ BU_FN uint32_t pack565_scaled(uint32_t r, uint32_t g, uint32_t b) {  // dxt1_blo
     return (r << 11) | (g << 5) | b;
 }
 
-// compute_bc1_hints (uastc_enc.cpp:2535-2629); `norm` is the anchor-normalised winner, `decoded` its UASTC decode
-BU_FN_BIG void bc1_hints(const cand& norm, const rgba8* px, const rgba8* decoded, bool& hint0, bool& hint1) {
+// compute_bc1_hints (uastc_enc.cpp:2535-2629); `norm` is the anchor-normalised winner, `decoded` its UASTC decode, `px` the source texels (both packed dwords)
+BU_FN void bc1_hints(const cand& norm, const uint32_t* px, const uint32_t* decoded, bool& hint0, bool& hint1) {
     hint0 = hint1 = false;
     const uint32_t mode = norm.mode;
     const bool has0 = ku_mode_has_bc1_hint0[mode] != 0, has1 = ku_mode_has_bc1_hint1[mode] != 0;
     if (!has0 && !has1) return;
     const uint32_t wbits = ku_mode_weight_bits[mode], planes = ku_mode_planes[mode], comps = ku_mode_comps[mode];
-    rgba8 full[16], h0[16], h1[16];
-    bc1_blk b;
-    bc1_encode(decoded, nullptr, b);
-    bc1_decode(b, full);
-    for (uint32_t i = 0; i < 16; i++) for (uint32_t c = 0; c < 4; c++) { h0[i].c[c] = 0; h1[i].c[c] = 0; }
-    if (has1) {  // transcode_uastc_to_bc1_hint1, transcoder.cpp:18700-18728
-        uint8_t sels[16];
-        const uint8_t back[4] = { 0, 3, 1, 2 };
-        for (uint32_t i = 0; i < 16; i++) sels[i] = back[bc1_weight_translate(wbits, norm.weights[i * planes])];
-        bc1_encode(decoded, sels, b);
-        bc1_decode(b, h1);
+    // the first plane's weights translated to BC1's four levels, 2 bits per texel
+    uint32_t tw = 0;
+    BU_UNROLL
+    for (int i = 0; i < 16; i++) tw |= bc1_weight_translate(wbits, planes == 2 ? norm.weights[i * 2] : norm.weights[i]) << (2 * i);
+    const uint32_t et = bc1_error(bc1_encode(decoded, false, 0), px);
+    uint32_t e0 = 0, e1 = 0;
+    if (has1) {  // transcode_uastc_to_bc1_hint1, transcoder.cpp:18700-18728: BC1 code -> linear selector {0, 3, 1, 2}, all sixteen at once: (low bit, high ^ low)
+        const uint32_t hi = (tw >> 1) & 0x55555555u, lo = tw & 0x55555555u;
+        e1 = bc1_error(bc1_encode(decoded, true, (lo << 1) | (hi ^ lo)), px);
     }
     if (has0) {  // transcode_uastc_to_bc1_hint0, :18602-18697
         const uint8_t* UQ = ku_unquant + ku_mode_endpoint_ranges[mode] * 256;
-        const uint8_t* e = norm.endpoints;
         uint32_t lc, hc;
-        if (comps == 2) { lc = pack565_scaled(UQ[e[0]], UQ[e[0]], UQ[e[0]]); hc = pack565_scaled(UQ[e[1]], UQ[e[1]], UQ[e[1]]); }
-        else { lc = pack565_scaled(UQ[e[0]], UQ[e[2]], UQ[e[4]]); hc = pack565_scaled(UQ[e[1]], UQ[e[3]], UQ[e[5]]); }
+        if (comps == 2) { lc = pack565_scaled(UQ[norm.endpoints[0]], UQ[norm.endpoints[0]], UQ[norm.endpoints[0]]); hc = pack565_scaled(UQ[norm.endpoints[1]], UQ[norm.endpoints[1]], UQ[norm.endpoints[1]]); }
+        else { lc = pack565_scaled(UQ[norm.endpoints[0]], UQ[norm.endpoints[2]], UQ[norm.endpoints[4]]); hc = pack565_scaled(UQ[norm.endpoints[1]], UQ[norm.endpoints[3]], UQ[norm.endpoints[5]]); }
+        bc1_blk b;
         if (lc == hc) {
             uint32_t mask = 0;
             if (hc > 0) hc--;
             else { hc = 0; lc = 1; mask = 0x55; }
             b.c0 = (uint16_t)lc; b.c1 = (uint16_t)hc; b.sel = mask * 0x01010101u;
         } else {
-            bool inv = false;
-            if (lc < hc) { const uint32_t t = lc; lc = hc; hc = t; inv = true; }
-            uint32_t sels = 0;
-            for (int i = 15; i >= 0; --i) {
-                uint32_t s = bc1_weight_translate(wbits, norm.weights[(uint32_t)i * planes]);
-                if (inv) s ^= 1;
-                sels = (sels << 2) | s;
-            }
+            uint32_t sels = tw;
+            if (lc < hc) { const uint32_t t = lc; lc = hc; hc = t; sels ^= 0x55555555u; }
             b.c0 = (uint16_t)lc; b.c1 = (uint16_t)hc; b.sel = sels;
         }
-        bc1_decode(b, h0);
+        e0 = bc1_error(b, px);
     }
-    uint64_t et = 0, e0 = 0, e1 = 0;
-    for (uint32_t i = 0; i < 16; i++) { et += dist_rgb(px[i].c, full[i].c); e0 += dist_rgb(px[i].c, h0[i].c); e1 += dist_rgb(px[i].c, h1[i].c); }
     const float t_err = sqrtf((float)et), t0 = sqrtf((float)e0), t1 = sqrtf((float)e1);
     if (has0 && t0 <= t_err * 1.075f) hint0 = true;
     if (has1 && t1 <= t_err * 1.075f) hint1 = true;
@@ -2236,7 +2231,12 @@ BU_FN_BIG void finish_block(const rgba8* px, const enc_cfg& e, const cand& chose
     decode_uastc(best, decoded);
     normalise_anchors(best);
     bool h0 = false, h1 = false;
-    if (e.bc1_hints) bc1_hints(best, px, decoded, h0, h1);
+    if (e.bc1_hints) {
+        uint32_t spx[16], dpx[16];   // source and decoded texels as packed dwords, in registers for the whole hint computation
+        BU_UNROLL
+        for (int i = 0; i < 16; i++) { spx[i] = pack_px(px[i].c); dpx[i] = pack_px(decoded[i].c); }
+        bc1_hints(best, spx, dpx, h0, h1);
+    }
     uint32_t eac_table = 0, eac_mul = 0;
     if (ku_mode_has_alpha[best.mode]) eac_a8_hint(decoded, e.eac_mul_rad, e.eac_table_mask, eac_table, eac_mul);
     etc1_hint eh;
