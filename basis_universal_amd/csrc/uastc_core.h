@@ -16,6 +16,7 @@
 // reference on the CPU; the product only ever runs the hipcc build.
 #pragma once
 #include <stdint.h>
+#include <stdlib.h>
 #include <math.h>
 
 #if defined(__HIPCC__)
@@ -106,13 +107,14 @@ BU_FN uint32_t dist_rgb(const uint8_t* a, const uint8_t* b) {
     return (uint32_t)imul24(dr, dr) + (uint32_t)imul24(dg, dg) + (uint32_t)imul24(db, db);
 }
 BU_FN int px_comp(uint32_t p, int c) { return (int)((p >> (8 * c)) & 255u); }
+template <bool GREY> BU_FN int pxc(uint32_t p, int c) { return (GREY && c < 3) ? (int)(p & 255u) : px_comp(p, c); }   // GREY: r = g = b by construction (cell_compress_grey)
 BU_FN uint32_t pack_px(const uint8_t* c) { return (uint32_t)c[0] | ((uint32_t)c[1] << 8) | ((uint32_t)c[2] << 16) | ((uint32_t)c[3] << 24); }
 
 // evaluate_solution (bc7enc.cpp:822-1049), ASTC branch with the non-perceptual selector search.
 // Interpolants are not tabulated: astc_lerp(L, H, w) = (64 * L257 + 32 + (H257 - L257) * w) >> 14 with X257 = X * 257, one multiply-add
 // per channel, and the weight of a selector comes from the set's (multiplier, shift) pair -- see weight_of.
 // FORCED: the selectors are given (m_pForce_selectors, bc7enc.cpp:885-898) and only the error is measured.
-template <bool FORCED>
+template <bool FORCED, bool GREY>
 BU_FN uint64_t cell_eval(const uint32_t* px, uint32_t mask, const cell_cfg& cfg, const uint8_t* lo, const uint8_t* hi, cell_fit& best, const sel16* forced) {
     const uint32_t N = 1u << cfg.wbits;
     const uint8_t* SU = ku_sorted_unquant + cfg.range * 256;
@@ -125,6 +127,9 @@ BU_FN uint64_t cell_eval(const uint32_t* px, uint32_t mask, const cell_cfg& cfg,
         slope[c] = (h - L[c]) * 257;
     }
     const int dr = slope[0] / 257, dg = slope[1] / 257, db = slope[2] / 257, da = cfg.alpha ? slope[3] / 257 : 0;
+#if !defined(__HIPCC__)
+    if (GREY && (lo[0] != lo[1] || lo[1] != lo[2] || hi[0] != hi[1] || hi[1] != hi[2])) abort();   // (test builds) a grey cell's proposals are grey
+#endif
     const float f = (float)N / ((float)(imul24(dr, dr) + imul24(dg, dg) + imul24(db, db) + imul24(da, da)) + .00000125f);
     // weight(s) = s * wmul + (s >> wshift), +1 above 32: {63, 21, 9} x s for 1..3 bits, bit replication for 4 and 5 bits
     const uint32_t wmul = cfg.wbits == 1 ? 63u : (cfg.wbits == 2 ? 21u : (cfg.wbits == 3 ? 9u : (cfg.wbits == 4 ? 4u : 2u)));
@@ -142,14 +147,16 @@ BU_FN uint64_t cell_eval(const uint32_t* px, uint32_t mask, const cell_cfg& cfg,
             BU_UNROLL
             for (int c = 0; c < 4; c++) {
                 if (c >= nc) continue;
-                const int d = ((base[c] + imul24(slope[c], (int)wf)) >> 14) - px_comp(p, c);
+                const int d = ((base[c] + imul24(slope[c], (int)wf)) >> 14) - pxc<GREY>(p, c);
                 total += (uint32_t)imul24(d, d);
             }
             sel_set(tmp, i, sf);
             continue;
         }
-        int proj = imul24(px_comp(p, 0) - L[0], dr) + imul24(px_comp(p, 1) - L[1], dg) + imul24(px_comp(p, 2) - L[2], db);
-        if (cfg.alpha) proj += imul24(px_comp(p, 3) - L[3], da);
+        // GREY: the three colour channels carry one value and -- every endpoint proposal being built channel by channel from the same numbers -- one pair of
+        // endpoints (the host build checks it), so their three identical terms are one term times three
+        int proj = GREY ? 3 * imul24(pxc<GREY>(p, 0) - L[0], dr) : imul24(pxc<GREY>(p, 0) - L[0], dr) + imul24(pxc<GREY>(p, 1) - L[1], dg) + imul24(pxc<GREY>(p, 2) - L[2], db);
+        if (cfg.alpha) proj += imul24(pxc<GREY>(p, 3) - L[3], da);
         int s = (int)((float)proj * f + .5f);
         s = clampi(s, 1, (int)N - 1);
         uint32_t w1 = umul24((uint32_t)s, wmul) + ((uint32_t)s >> wshift), w0 = umul24((uint32_t)s - 1, wmul) + (((uint32_t)s - 1) >> wshift);
@@ -158,10 +165,11 @@ BU_FN uint64_t cell_eval(const uint32_t* px, uint32_t mask, const cell_cfg& cfg,
         uint32_t e0 = 0, e1 = 0;
         BU_UNROLL
         for (int c = 0; c < 4; c++) {  // fixed trip count: a run-time bound turns base[] / slope[] into scratch arrays on the GPU
-            if (c >= nc) continue;
-            const int v = px_comp(p, c);
+            if (c >= nc || (GREY && (c == 1 || c == 2))) continue;
+            const int v = pxc<GREY>(p, c);
             const int d0 = ((base[c] + imul24(slope[c], (int)w0)) >> 14) - v, d1 = ((base[c] + imul24(slope[c], (int)w1)) >> 14) - v;
-            e0 += (uint32_t)imul24(d0, d0); e1 += (uint32_t)imul24(d1, d1);
+            const uint32_t times = (GREY && c == 0) ? 3u : 1u;
+            e0 += times * (uint32_t)imul24(d0, d0); e1 += times * (uint32_t)imul24(d1, d1);
         }
         if (e0 == e1) {
             if (s == 1) s = 0;  // prefer the non-interpolated endpoint
@@ -181,7 +189,7 @@ BU_FN uint64_t cell_eval(const uint32_t* px, uint32_t mask, const cell_cfg& cfg,
 }
 
 // find_optimal_solution (bc7enc.cpp:1103-1282), ASTC branch, mode 255 degeneracy handling (:1051-1101)
-template <bool FORCED>
+template <bool FORCED, bool GREY>
 BU_FN uint64_t cell_try(const uint32_t* px, uint32_t mask, const cell_cfg& cfg, const float* xl_in, const float* xh_in, cell_fit& best, const sel16* forced) {
     float xl[4], xh[4];
     for (int c = 0; c < 4; c++) { xl[c] = saturatef(xl_in[c]); xh[c] = saturatef(xh_in[c]); }
@@ -209,7 +217,7 @@ BU_FN uint64_t cell_try(const uint32_t* px, uint32_t mask, const cell_cfg& cfg, 
         }
         bool differs = best.err == UINT64_MAX;
         for (int c = 0; c < 4; c++) differs = differs || a[c] != best.lo[c] || b[c] != best.hi[c];
-        if (differs) cell_eval<FORCED>(px, mask, cfg, a, b, best, forced);
+        if (differs) cell_eval<FORCED, GREY>(px, mask, cfg, a, b, best, forced);
     }
     return best.err;
 }
@@ -221,6 +229,7 @@ BU_FN void cell_astc_indices(const cell_cfg& cfg, cell_fit& best) {
 }
 
 // compute_least_squares_endpoints_rgb / _rgba (bc7enc.cpp:394-518) followed by the 1/255 scaling of its callers
+template <bool GREY>
 BU_FN void cell_least_squares(const uint32_t* px, uint32_t mask, const sel16& sel, const cell_cfg& cfg, float* xl, float* xh) {
     const float* WX = cfg.ls_weights;
     const int nc = cfg.alpha ? 4 : 3;
@@ -237,14 +246,15 @@ BU_FN void cell_least_squares(const uint32_t* px, uint32_t mask, const sel16& se
         const float w = w4[3];
         BU_UNROLL
         for (int c = 0; c < 4; c++) {
-            if (c >= nc) continue;
-            const int v = px_comp(px[i], c);
+            if (c >= nc || (GREY && (c == 1 || c == 2))) continue;   // GREY: green and blue are red's sums, copied below
+            const int v = pxc<GREY>(px[i], c);
             q00[c] += w * (float)v;
             t[c] += (double)v;
             lo_v[c] = v < lo_v[c] ? v : lo_v[c];
             hi_v[c] = v > hi_v[c] ? v : hi_v[c];
         }
     }
+    if (GREY) { q00[1] = q00[2] = q00[0]; t[1] = t[2] = t[0]; lo_v[1] = lo_v[2] = lo_v[0]; hi_v[1] = hi_v[2] = hi_v[0]; }
     const double z01 = z10;
     double det = z00 * z11 - z01 * z10;
     if (det != 0.0) det = 1.0 / det;
@@ -274,6 +284,7 @@ BU_FN bool one_colour_lookup(const cell_cfg& cfg, one_colour_kind& k) {
     if (cfg.range == 11 && N == 32 && !cfg.alpha) { k.table = ku_opt_r11_5bit; k.widx = 13; k.alpha_rank = 31; k.rgba = 0; return true; }
     return false;
 }
+template <bool GREY>
 BU_FN uint64_t one_colour_fit(const uint32_t* px, uint32_t mask, const cell_cfg& cfg, const one_colour_kind& k, const uint32_t* col, cell_fit& out) {
     const uint8_t* SU = ku_sorted_unquant + cfg.range * 256;
     const uint8_t* SI = ku_sorted_index + cfg.range * 256;
@@ -298,7 +309,7 @@ BU_FN uint64_t one_colour_fit(const uint32_t* px, uint32_t mask, const cell_cfg&
         if (!((mask >> i) & 1)) continue;
         sel_set(out.sel, i, k.widx);
         BU_UNROLL
-        for (int c = 0; c < 4; c++) { if (c == 3 && !k.rgba) continue; const int d = p[c] - px_comp(px[i], c); total += (uint32_t)imul24(d, d); }
+        for (int c = 0; c < 4; c++) { if (c == 3 && !k.rgba) continue; const int d = p[c] - pxc<GREY>(px[i], c); total += (uint32_t)imul24(d, d); }
     }
     out.err = total;
     return total;
@@ -309,7 +320,7 @@ BU_FN uint64_t one_colour_fit(const uint32_t* px, uint32_t mask, const cell_cfg&
 // cell_eval -- is instantiated once.
 // FORCED (m_pForce_selectors: uastc_rdo's mode-0 endpoint refit, uastc_enc.cpp:4046-4060): no single-colour shortcuts, the
 // selectors never change, every proposal is scored on them.
-template <bool FORCED>
+template <bool FORCED, bool GREY = false>
 BU_FN uint64_t cell_compress_t(const uint32_t* px, uint32_t mask, const cell_cfg& cfg, cell_fit& best, const sel16* forced) {
     best.err = UINT64_MAX;
     best.sel.w[0] = best.sel.w[1] = best.sel.w[2] = best.sel.w[3] = 0;
@@ -325,13 +336,13 @@ BU_FN uint64_t cell_compress_t(const uint32_t* px, uint32_t mask, const cell_cfg
     BU_UNROLL
     for (int i = 0; i < 16; i++) {
         if (!((mask >> i) & 1)) continue;
-        for (int c = 0; c < 4; c++) sum[c] = sum[c] + (float)px_comp(px[i], c);
+        for (int c = 0; c < 4; c++) sum[c] = sum[c] + (float)pxc<GREY>(px[i], c);
         if (!have_first) { first = px[i]; have_first = true; }
         else same = same && (((px[i] ^ first) & cmp_mask) == 0);
     }
     if (!FORCED && has_kind && same) {
         const uint32_t col[4] = { first & 255u, (first >> 8) & 255u, (first >> 16) & 255u, first >> 24 };
-        return one_colour_fit(px, mask, cfg, kind, col, best);
+        return one_colour_fit<GREY>(px, mask, cfg, kind, col, best);
     }
     const float inv_n = 1.0f / (float)n;
     const float inv_n255 = 1.0f / ((float)n * 255.0f);
@@ -350,7 +361,7 @@ BU_FN uint64_t cell_compress_t(const uint32_t* px, uint32_t mask, const cell_cfg
         for (int i = 0; i < 16; i++) {
             if (!((mask >> i) & 1)) continue;
             float col[4];
-            for (int c = 0; c < 4; c++) col[c] = (float)px_comp(px[i], c) - mean_s[c];
+            for (int c = 0; c < 4; c++) col[c] = (float)pxc<GREY>(px[i], c) - mean_s[c];
             float v[4];
             for (int c = 0; c < 4; c++) v[c] = started ? axis[c] : col[c];
             started = true;
@@ -375,9 +386,9 @@ BU_FN uint64_t cell_compress_t(const uint32_t* px, uint32_t mask, const cell_cfg
         BU_UNROLL
         for (int i = 0; i < 16; i++) {
             if (!((mask >> i) & 1)) continue;
-            const float r = (float)px_comp(px[i], 0) - mean_s[0];
-            const float g = (float)px_comp(px[i], 1) - mean_s[1];
-            const float b = (float)px_comp(px[i], 2) - mean_s[2];
+            const float r = (float)pxc<GREY>(px[i], 0) - mean_s[0];
+            const float g = (float)pxc<GREY>(px[i], 1) - mean_s[1];
+            const float b = (float)pxc<GREY>(px[i], 2) - mean_s[2];
             cov[0] += r * r; cov[1] += r * g; cov[2] += r * b; cov[3] += g * g; cov[4] += g * b; cov[5] += b * b;
         }
         float xr = .9f, xg = 1.0f, xb = .7f;
@@ -414,7 +425,7 @@ BU_FN uint64_t cell_compress_t(const uint32_t* px, uint32_t mask, const cell_cfg
     for (int i = 0; i < 16; i++) {
         if (!((mask >> i) & 1)) continue;
         float q[4];
-        for (int c = 0; c < 4; c++) q[c] = (float)px_comp(px[i], c) - mean_s[c];
+        for (int c = 0; c < 4; c++) q[c] = (float)pxc<GREY>(px[i], c) - mean_s[c];
         const float d = q[0] * axis[0] + q[1] * axis[1] + q[2] * axis[2] + q[3] * axis[3];
         l = l < d ? l : d;
         h = h > d ? h : d;
@@ -476,9 +487,9 @@ BU_FN uint64_t cell_compress_t(const uint32_t* px, uint32_t mask, const cell_cfg
                     sel_set(trial, i, (uint32_t)v);
                 }
             }
-            cell_least_squares(px, mask, trial, cfg, xl, xh);
+            cell_least_squares<GREY>(px, mask, trial, cfg, xl, xh);
         }
-        if (!cell_try<FORCED>(px, mask, cfg, xl, xh, best, forced)) { cell_astc_indices(cfg, best); return 0; }
+        if (!cell_try<FORCED, GREY>(px, mask, cfg, xl, xh, best, forced)) { cell_astc_indices(cfg, best); return 0; }
     }
 
     if (!FORCED && has_kind) {
@@ -487,7 +498,7 @@ BU_FN uint64_t cell_compress_t(const uint32_t* px, uint32_t mask, const cell_cfg
         for (int c = 0; c < 4; c++) col[c] = (uint32_t)(int)(.5f + mean[c] * 255.0f);
         cell_fit avg;
         cell_astc_indices(cfg, best);
-        if (one_colour_fit(px, mask, cfg, kind, col, avg) < best.err) best = avg;
+        if (one_colour_fit<GREY>(px, mask, cfg, kind, col, avg) < best.err) best = avg;
         return best.err;
     }
     cell_astc_indices(cfg, best);
@@ -496,16 +507,27 @@ BU_FN uint64_t cell_compress_t(const uint32_t* px, uint32_t mask, const cell_cfg
 // The out-of-line instance takes the texels and the configuration and returns the fit BY VALUE: on the GPU they travel in registers, whereas
 // pointer / reference parameters of a real call live in scratch memory (and every load from them waits out a memory round trip).
 struct px16 { uint32_t v[16]; };
+template <bool GREY>
 BU_FN cell_fit cell_compress_rv(px16 px, uint32_t mask, cell_cfg cfg) {
     cell_fit f;
-    cell_compress_t<false>(px.v, mask, cfg, f, nullptr);
+    cell_compress_t<false, GREY>(px.v, mask, cfg, f, nullptr);
     return f;
 }
 BU_FN uint64_t cell_compress(const uint32_t* px, uint32_t mask, const cell_cfg& cfg, cell_fit& best) {
     px16 p;
     BU_UNROLL
     for (int i = 0; i < 16; i++) p.v[i] = px[i];
-    best = cell_compress_rv(p, mask, cfg);
+    best = cell_compress_rv<false>(p, mask, cfg);
+    return best.err;
+}
+// The same fit for texels whose red, green and blue are one value (the second plane of the dual-plane modes: one channel replicated to grey, uastc_enc.cpp
+// e.g. :960-1010). Nothing is computed differently -- the channel accessor just returns the same register for the three colour channels, which lets the compiler
+// see that every per-channel expression of the fit is computed three times over and keep one (same operations on the same values: the same results).
+BU_FN uint64_t cell_compress_grey(const uint32_t* px, uint32_t mask, const cell_cfg& cfg, cell_fit& best) {
+    px16 p;
+    BU_UNROLL
+    for (int i = 0; i < 16; i++) p.v[i] = px[i];
+    best = cell_compress_rv<true>(p, mask, cfg);
     return best.err;
 }
 
@@ -796,7 +818,7 @@ BU_FN_BIG void build_dual(uint32_t mode, uint32_t rot, const rgba8* px, const en
             }
             t[i] = pack_px(c);
         }
-        err[plane] = cell_compress(t, 0xFFFFu, cc, fit[plane]);
+        err[plane] = (plane == 1 || mode == 17) ? cell_compress_grey(t, 0xFFFFu, cc, fit[plane]) : cell_compress(t, 0xFFFFu, cc, fit[plane]);   // (mode 17: both planes are one channel replicated)
     }
     const cell_fit &fm = fit[0], &fs = fit[1];
     r.err = mode == 17 ? err[0] / 3 + err[1] / 3 : err[0] + err[1] / 3;
