@@ -18,6 +18,7 @@
 #include <algorithm>
 
 #include "bookkeeping_kernels.h"
+#include "sort_pairs.h"
 
 namespace bu {
 
@@ -126,7 +127,7 @@ struct rank_temp { uint32_t *keys_in, *vals_in, *keys_sorted; void* cub; size_t 
 rank_temp carve_rank(void* ws, uint32_t n, uint32_t k, size_t* total) {
     auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
     size_t sort_bytes = 0, scan_bytes = 0;
-    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)n, 0, 32);
+    (void)sort_pairs<uint32_t, uint32_t>(nullptr, sort_bytes, nullptr, nullptr, nullptr, nullptr, n, 0, 32, nullptr);
     (void)hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)k + 1);
     rank_temp t;
     char* p = static_cast<char*>(ws);
@@ -161,7 +162,7 @@ hipError_t launch_rank_blocks(hipStream_t st, const uint32_t* d_cluster, uint32_
     int bits = 1;
     while (bits < 32 && (1u << bits) < k) bits++;
     size_t bytes = t.cub_bytes;
-    if ((e = hipcub::DeviceRadixSort::SortPairs(t.cub, bytes, t.keys_in, t.keys_sorted, t.vals_in, d_sorted_blocks, (int)n, 0, bits, st)) != hipSuccess) return e;
+    if ((e = sort_pairs<uint32_t, uint32_t>(t.cub, bytes, t.keys_in, t.keys_sorted, t.vals_in, d_sorted_blocks, n, 0, (unsigned)bits, st)) != hipSuccess) return e;
     // sizes and offsets from the sorted keys (a histogram by atomics on a few thousand skewed bins costs more than the sort)
     hipLaunchKernelGGL(k_offsets_from_sorted, gk, blk, 0, st, t.keys_sorted, n, k, d_offsets);
     hipLaunchKernelGGL(k_sizes_from_offsets, gk, blk, 0, st, d_offsets, k, d_sizes);

@@ -12,6 +12,7 @@
 #include <stdint.h>
 
 #include "unique_kernels.h"
+#include "sort_pairs.h"
 
 namespace bu {
 
@@ -68,7 +69,7 @@ size_t cub_bytes_for(uint32_t n) {
     size_t a = 0, b = 0, c = 0, d = 0;
     uint32_t* p = nullptr;
     uint64_t* w = nullptr;
-    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, a, p, p, p, p, (int)n);
+    (void)sort_pairs<uint32_t, uint32_t>(nullptr, a, p, p, p, p, n, 0, 32, nullptr);
     (void)hipcub::DeviceRunLengthEncode::Encode(nullptr, b, p, p, p, p, (int)n);
     (void)hipcub::DeviceScan::ExclusiveSum(nullptr, c, p, p, (int)n);
     (void)hipcub::DeviceReduce::ReduceByKey(nullptr, d, p, p, w, w, p, hipcub::Sum(), (int)n);
@@ -97,7 +98,7 @@ size_t cub_bytes_for64(uint32_t n) {
     size_t a = 0, b = 0, c = 0;
     uint64_t* k = nullptr;
     uint32_t* p = nullptr;
-    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, a, k, k, p, p, (int)n);
+    (void)sort_pairs<uint64_t, uint32_t>(nullptr, a, k, k, p, p, n, 0, 64, nullptr);
     (void)hipcub::DeviceRunLengthEncode::Encode(nullptr, b, k, k, p, p, (int)n);
     (void)hipcub::DeviceScan::ExclusiveSum(nullptr, c, p, p, (int)n);
     return std::max(a, std::max(b, c));
@@ -132,7 +133,7 @@ hipError_t launch_unique_endpoint_vectors(hipStream_t st, const void* d_etc1_blo
     if (!n) return hipMemsetAsync(t.n_runs, 0, 4, st);
     hipLaunchKernelGGL(k_endpoint_keys, dim3((n + 255) / 256), dim3(256), 0, st, static_cast<const uint64_t*>(d_etc1_blocks), n, t.keys_in, t.idx_in);
     size_t bytes = t.cub_bytes;
-    hipError_t e = hipcub::DeviceRadixSort::SortPairs(t.cub, bytes, t.keys_in, t.keys_sorted, t.idx_in, d_sorted_block_idx, (int)n, 0, 48, st);
+    hipError_t e = sort_pairs<uint64_t, uint32_t>(t.cub, bytes, t.keys_in, t.keys_sorted, t.idx_in, d_sorted_block_idx, n, 0, 48, st);
     if (e != hipSuccess) return e;
     bytes = t.cub_bytes;
     e = hipcub::DeviceRunLengthEncode::Encode(t.cub, bytes, t.keys_sorted, d_unique_keys, t.counts, t.n_runs, (int)n, st);
@@ -157,7 +158,7 @@ hipError_t launch_unique_selector_vectors(hipStream_t st, const void* d_enc_bloc
     if (!n) return hipMemsetAsync(t.n_runs, 0, 4, st);
     hipLaunchKernelGGL(k_selector_keys, dim3((n + 255) / 256), dim3(256), 0, st, static_cast<const uint64_t*>(d_enc_blocks), n, t.keys_in, t.idx_in);
     size_t bytes = t.cub_bytes;
-    hipError_t e = hipcub::DeviceRadixSort::SortPairs(t.cub, bytes, t.keys_in, t.keys_sorted, t.idx_in, d_sorted_block_idx, (int)n, 0, 32, st);
+    hipError_t e = sort_pairs<uint32_t, uint32_t>(t.cub, bytes, t.keys_in, t.keys_sorted, t.idx_in, d_sorted_block_idx, n, 0, 32, st);
     if (e != hipSuccess) return e;
     bytes = t.cub_bytes;
     e = hipcub::DeviceRunLengthEncode::Encode(t.cub, bytes, t.keys_sorted, d_unique_keys, t.counts, t.n_runs, (int)n, st);
