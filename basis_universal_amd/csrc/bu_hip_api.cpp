@@ -810,7 +810,7 @@ static bu_tsvq* tsvq_create_common(bu_hip_context* ctx, uint32_t dim, bool packe
     if (!q->rows || !q->w64 || !q->perm[0] || !q->perm[1] || !q->side || !q->nodes.p || !q->outs.p) return fail("allocation");
     q->nodes.cap = q->outs.cap = rec_cap;
     if (packed && !q->force_chained) {
-        uint32_t wide_min = 16384;
+        uint32_t wide_min = 8192;   // (16384 until round 3: the one-workgroup launches of the smaller nodes are the longer of the two concurrent streams)
         if (const char* e = std::getenv("BU_TSVQ_WIDE_MIN")) { const long v = std::atol(e); if (v >= 512 && v <= (1l << 30)) wide_min = (uint32_t)v; }
         if (const char* e = std::getenv("BU_TSVQ_WIDE")) if (std::atoi(e) == 0) wide_min = 0;
         if (wide_min && n >= wide_min && n < (1u << 22)) {   // above 2^22 members the binade prediction loses its margin; the chained kernel takes those
