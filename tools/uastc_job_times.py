@@ -1,6 +1,9 @@
+#!/usr/bin/env python3
+"""One launch per mode job of the UASTC candidates kernel, timed with events (the library prints them under BU_UASTC_JOB_TIMES=1):
+    gpurun -- 'BU_UASTC_JOB_TIMES=1 python tools/uastc_job_times.py 2>&1 | grep "uastc job"'"""
 import sys, pathlib
 import numpy as np
-ROOT = pathlib.Path("/root/repo")
+ROOT = pathlib.Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
 import torch, helpers
 from basis_universal_amd import uastc, capi
