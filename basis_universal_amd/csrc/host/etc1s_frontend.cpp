@@ -1157,13 +1157,10 @@ bool etc1s_frontend::optimize_selector_codebook() {
     std::vector<uint8_t> used(k, 0);
     device_state& d = *m_dev;
     bool on_device = m_sel_dev_valid;
-    if (on_device) {   // which entries own a block: the cluster sizes of the resident map
-        std::vector<uint32_t> sizes(k);
-        if (d.reserve(d.map_sizes, ((size_t)k + 1) * 4) && d.reserve(d.map_offs, ((size_t)k + 1) * 4) && d.reserve(d.map_sorted, (size_t)n * 4) &&
-            bu_hip_k_map_rank_blocks(d.ctx, (const uint32_t*)d.sel_cluster.p, n, k, (uint32_t*)d.map_sizes.p, (uint32_t*)d.map_offs.p, (uint32_t*)d.map_sorted.p, nullptr) &&
-            d.download(sizes.data(), d.map_sizes, k)) {
-            for (uint32_t i = 0; i < k; i++) used[i] = sizes[i] != 0;
-        } else on_device = false;
+    if (on_device) {   // which entries own a block: one flag per entry, set by every block of the resident map (a sort of the blocks by cluster was paid for the sizes here until round 3)
+        if (!(d.reserve(d.flags, k) && bu_hip_k_map_membership(d.ctx, nullptr, (const uint32_t*)d.sel_cluster.p, n, 1, k, (uint8_t*)d.flags.p) &&
+              bu_hip_memcpy_d2h(d.ctx, used.data(), d.flags.p, k)))
+            on_device = false;
     }
     if (!on_device) {
         ensure_selector_map_host();
