@@ -132,6 +132,23 @@ public:
     }
     void flush() { if (m_fill) { m_bytes.push_back((uint8_t)m_acc); m_acc = 0; m_fill = 0; } }
     const std::vector<uint8_t>& bytes() const { return m_bytes; }
+    // Everything `other` holds (whole bytes and its unflushed tail) behind what this writer holds, as if it had been put here bit by bit: lets one long symbol
+    // stream be coded in pieces on several threads and joined afterwards.
+    void append(const bit_writer& other) {
+        const std::vector<uint8_t>& ob = other.m_bytes;
+        if (!m_fill) {
+            m_bytes.insert(m_bytes.end(), ob.begin(), ob.end());
+        } else {
+            const size_t at = m_bytes.size(), n = ob.size();
+            m_bytes.resize(at + n);
+            uint8_t* dst = m_bytes.data() + at;
+            uint32_t carry = (uint32_t)m_acc;   // m_fill bits
+            const uint32_t sh = m_fill;
+            for (size_t i = 0; i < n; i++) { const uint32_t v = carry | ((uint32_t)ob[i] << sh); dst[i] = (uint8_t)v; carry = v >> 8; }
+            m_acc = carry;
+        }
+        if (other.m_fill) put_bits((uint32_t)other.m_acc, other.m_fill);
+    }
 
     // A table travels as its code lengths, run-length tokenised (literal 0..16, short/long zero runs, short/long repeats of the
     // previous length) and coded with a 21-symbol table of at most 7-bit codes whose own lengths go first in a fixed order.

@@ -635,65 +635,99 @@ bool etc1s_backend::create_encoder_blocks() {
     const bool video = m_params.m_video;
     const uint32_t spatial_preds = video ? 2u : 3u;   // in video files predictor 2 means "same as the previous frame", not the upper-left neighbour
     m_cr_target.assign(video ? total : 0, 0);
+    // One row of a slice. A block looks at its left, upper and upper-left neighbours AS THE WALK LEFT THEM, so row y can follow row y - 1 one block behind:
+    // large slices are walked as a wavefront, the rows dealt round robin to the host threads, each row waiting for the row above through a progress counter.
+    auto walk_row = [&](size_t si, uint32_t by, int prev_frame, std::vector<uint32_t>& unpredicted, uint32_t& remapped, const char*& error,
+                        const std::atomic<uint32_t>* above, std::atomic<uint32_t>* mine) {
+        const backend_slice_desc& s = m_slices[si];
+        const uint32_t nbx = s.m_num_blocks_x;
+        uint32_t ready = above ? 0u : nbx;   // blocks of the row above known to be finished
+        for (uint32_t bx = 0; bx < nbx; bx++) {
+            if (bx + 1 > ready && ready < nbx) {   // needs (bx, by - 1) and (bx - 1, by - 1)
+                for (uint32_t spins = 0; (ready = above->load(std::memory_order_acquire)) < std::min(nbx, bx + 1); spins++)
+                    if (spins > 64) std::this_thread::yield();
+            }
+            const uint32_t b = s.m_first_block_index + bx + by * nbx;
+            encoder_block& m = m_blocks[b];
+            m.endpoint_index = m_src.block_endpoint_index[b];
+            m.selector_index = m_src.block_selector_index[b];
+            m.endpoint_predictor = kNoEndpointPred;
+            if (m.endpoint_index >= m_src.total_endpoints || m.selector_index >= m_src.total_selectors) { error = "block index out of range"; if (mine) mine->store(nbx, std::memory_order_release); return; }
+            uint32_t neighbour[kNumEndpointPreds];
+            bool present[kNumEndpointPreds];
+            uint32_t best_pred = UINT32_MAX;
+            for (uint32_t p = 0; p < kNumEndpointPreds; p++) {
+                const int px = (int)bx + kPredDx[p], py = (int)by + kPredDy[p];
+                present[p] = p < spatial_preds && px >= 0 && py >= 0;  // dx, dy <= 0: the far edges cannot be crossed
+                if (!present[p]) continue;
+                neighbour[p] = m_blocks[s.m_first_block_index + (uint32_t)px + (uint32_t)py * nbx].endpoint_index;
+                if (neighbour[p] == m.endpoint_index && best_pred == UINT32_MAX) best_pred = p;
+            }
+            if (prev_frame >= 0) {   // conditional replenishment wins over the spatial predictors (backend.cpp:457-471)
+                const uint32_t pb = m_slices[prev_frame].m_first_block_index + bx + by * nbx;
+                if (m_blocks[pb].endpoint_index == m.endpoint_index && m_blocks[pb].selector_index == m.selector_index) { best_pred = 2; m_cr_target[pb] = 1; }
+            }
+            if (best_pred != UINT32_MAX) {
+                m.endpoint_predictor = (uint8_t)best_pred;
+            } else if (thresh > 0.0f) {
+                const uint64_t cur_err = m_own_err[b];
+                if (cur_err) {
+                    const uint64_t thresh_err = (uint64_t)(cur_err * std::max(1.0f, thresh));
+                    uint64_t best_err = UINT64_MAX;
+                    uint32_t best_index = 0;
+                    block_px px;
+                    sel16 sels;
+                    bool have_px = false;
+                    for (uint32_t p = 0; p < kNumEndpointPreds; p++) {
+                        if (!present[p]) continue;
+                        const uint32_t nb_block = s.m_first_block_index + (uint32_t)((int)bx + kPredDx[p]) + (uint32_t)((int)by + kPredDy[p]) * nbx;
+                        uint64_t err = m_neighbour_err[(size_t)b * 3 + p];
+                        if (err == UINT64_MAX || neighbour[p] != m_src.block_endpoint_index[nb_block]) {   // not speculated, or the neighbour was remapped
+                            if (!have_px) { K.load_pixels(perceptual, px, &m_src.source_blocks[b].m_pixels[0][0]); sels = metric::unpack_selectors(m_own_sels[b]); have_px = true; }
+                            err = K.block_error(perceptual, px, m_palette_colors[neighbour[p]], sels);
+                        }
+                        if (err <= thresh_err && err < best_err) { best_err = err; best_pred = p; best_index = neighbour[p]; }  // ascending p: ties keep the lower predictor
+                    }
+                    if (best_pred != UINT32_MAX) {
+                        m.endpoint_index = best_index;
+                        m.endpoint_predictor = (uint8_t)best_pred;
+                        remapped++;
+                    }
+                }
+            }
+            if (m.endpoint_predictor == kNoEndpointPred) unpredicted.push_back(m.endpoint_index);
+            if (mine && ((bx + 1) & 31u) == 0) mine->store(bx + 1, std::memory_order_release);
+        }
+        if (mine) mine->store(nbx, std::memory_order_release);
+    };
     auto walk_slice = [&](size_t si) {
         const backend_slice_desc& s = m_slices[si];
         const uint32_t nbx = s.m_num_blocks_x, nby = s.m_num_blocks_y;
         const int prev_frame = video && !s.m_iframe ? find_video_frame(si, -1) : -1;
         std::vector<uint32_t>& all_endpoint_indices = results[si].unpredicted;
-        uint32_t& remapped = results[si].remapped;
         all_endpoint_indices.reserve((size_t)nbx * nby);
-        for (uint32_t by = 0; by < nby; by++)
-            for (uint32_t bx = 0; bx < nbx; bx++) {
-                const uint32_t b = s.m_first_block_index + bx + by * nbx;
-                encoder_block& m = m_blocks[b];
-                m.endpoint_index = m_src.block_endpoint_index[b];
-                m.selector_index = m_src.block_selector_index[b];
-                m.endpoint_predictor = kNoEndpointPred;
-                if (m.endpoint_index >= m_src.total_endpoints || m.selector_index >= m_src.total_selectors) { results[si].error = "block index out of range"; return; }
-                uint32_t neighbour[kNumEndpointPreds];
-                bool present[kNumEndpointPreds];
-                uint32_t best_pred = UINT32_MAX;
-                for (uint32_t p = 0; p < kNumEndpointPreds; p++) {
-                    const int px = (int)bx + kPredDx[p], py = (int)by + kPredDy[p];
-                    present[p] = p < spatial_preds && px >= 0 && py >= 0;  // dx, dy <= 0: the far edges cannot be crossed
-                    if (!present[p]) continue;
-                    neighbour[p] = m_blocks[s.m_first_block_index + (uint32_t)px + (uint32_t)py * nbx].endpoint_index;
-                    if (neighbour[p] == m.endpoint_index && best_pred == UINT32_MAX) best_pred = p;
-                }
-                if (prev_frame >= 0) {   // conditional replenishment wins over the spatial predictors (backend.cpp:457-471)
-                    const uint32_t pb = m_slices[prev_frame].m_first_block_index + bx + by * nbx;
-                    if (m_blocks[pb].endpoint_index == m.endpoint_index && m_blocks[pb].selector_index == m.selector_index) { best_pred = 2; m_cr_target[pb] = 1; }
-                }
-                if (best_pred != UINT32_MAX) {
-                    m.endpoint_predictor = (uint8_t)best_pred;
-                } else if (thresh > 0.0f) {
-                    const uint64_t cur_err = m_own_err[b];
-                    if (cur_err) {
-                        const uint64_t thresh_err = (uint64_t)(cur_err * std::max(1.0f, thresh));
-                        uint64_t best_err = UINT64_MAX;
-                        uint32_t best_index = 0;
-                        block_px px;
-                        sel16 sels;
-                        bool have_px = false;
-                        for (uint32_t p = 0; p < kNumEndpointPreds; p++) {
-                            if (!present[p]) continue;
-                            const uint32_t nb_block = s.m_first_block_index + (uint32_t)((int)bx + kPredDx[p]) + (uint32_t)((int)by + kPredDy[p]) * nbx;
-                            uint64_t err = m_neighbour_err[(size_t)b * 3 + p];
-                            if (err == UINT64_MAX || neighbour[p] != m_src.block_endpoint_index[nb_block]) {   // not speculated, or the neighbour was remapped
-                                if (!have_px) { K.load_pixels(perceptual, px, &m_src.source_blocks[b].m_pixels[0][0]); sels = metric::unpack_selectors(m_own_sels[b]); have_px = true; }
-                                err = K.block_error(perceptual, px, m_palette_colors[neighbour[p]], sels);
-                            }
-                            if (err <= thresh_err && err < best_err) { best_err = err; best_pred = p; best_index = neighbour[p]; }  // ascending p: ties keep the lower predictor
-                        }
-                        if (best_pred != UINT32_MAX) {
-                            m.endpoint_index = best_index;
-                            m.endpoint_predictor = (uint8_t)best_pred;
-                            remapped++;
-                        }
-                    }
-                }
-                if (m.endpoint_predictor == kNoEndpointPred) all_endpoint_indices.push_back(m.endpoint_index);
-            }
+        unsigned threads = 8;
+        if (const char* e = std::getenv("BU_HOST_THREADS")) { const int v = std::atoi(e); if (v >= 1 && v <= 64) threads = (unsigned)v; }
+        threads = std::min<unsigned>(std::min<unsigned>(threads, std::max(1u, std::thread::hardware_concurrency())), nby);
+        if (video || threads <= 1 || (uint64_t)nbx * nby < 65536 || nbx < 64) {   // (video frames mark blocks of the previous frame: kept on one thread)
+            for (uint32_t by = 0; by < nby; by++) walk_row(si, by, prev_frame, all_endpoint_indices, results[si].remapped, results[si].error, nullptr, nullptr);
+            return;
+        }
+        std::vector<std::atomic<uint32_t>> done(nby);
+        for (auto& d : done) d.store(0, std::memory_order_relaxed);
+        struct row_out { std::vector<uint32_t> unpredicted; uint32_t remapped = 0; const char* error = nullptr; };
+        std::vector<row_out> rows(nby);
+        std::vector<std::thread> pool;
+        for (unsigned t = 0; t < threads; t++)
+            pool.emplace_back([&, t] {
+                for (uint32_t by = t; by < nby; by += threads) walk_row(si, by, -1, rows[by].unpredicted, rows[by].remapped, rows[by].error, by ? &done[by - 1] : nullptr, &done[by]);
+            });
+        for (std::thread& th : pool) th.join();
+        for (uint32_t by = 0; by < nby; by++) {
+            if (rows[by].error && !results[si].error) results[si].error = rows[by].error;
+            results[si].remapped += rows[by].remapped;
+            all_endpoint_indices.insert(all_endpoint_indices.end(), rows[by].unpredicted.begin(), rows[by].unpredicted.end());
+        }
     };
     if (video) { for (size_t si = 0; si < m_slices.size(); si++) walk_slice(si); }   // a frame reads the finished blocks of the frame before it
     else for_each_slice(m_slices, walk_slice);
@@ -835,17 +869,17 @@ bool etc1s_backend::encode_image() {
         win_r[k] = e.r; win_g[k] = e.g; win_b[k] = e.b; win_i[k] = e.inten; win_u[k] = m_new_endpoint_was_used[nw];
     }
 
-    // A slice is walked by three loops over its blocks in raster order, each carrying its own state from block to block:
+    // A slice is walked by two loops over its blocks in raster order, each carrying its own state from block to block:
     //   1. endpoints : predictor symbols per 2x2 macroblock, the endpoint search relative to the previous block's index  (state: previous index, runs)
-    //   2. tables    : the block's pixels against the four colours of its FINAL endpoints (stateless; needs loop 1's result)
-    //   3. selectors : the history-buffer search and the selector symbols                                              (state: history buffer, runs)
-    // Loop 2 only needs loop 1 to be ahead of it and loop 3 only loop 2, so for slices worth it the three run as a pipeline of three
-    // threads coupled by progress counters (the tables travel through a ring); small slices run them one after the other.
-    const uint32_t kPipelineMinBlocks = 16384, kRing = 4096, kPublishEvery = 64;
+    //   2. selectors : the history-buffer search and the selector symbols (state: history buffer, runs); where the search is needed it first builds the
+    //                  block's pixel-to-colour distance table against its FINAL endpoints, which is what it needs loop 1 for
+    // Loop 2 only needs loop 1 to be ahead of it, so for slices worth it they run as two threads coupled by a progress counter (four bytes per block cross
+    // between them). Until round 3 the tables were a third thread feeding a ring: every table (264 bytes) then crossed from one core's cache to another's,
+    // and the selector loop -- 105 ms on its own -- took 160 ms waiting for them; only the blocks that miss the history need a table at all.
+    const uint32_t kPipelineMinBlocks = 16384, kPublishEvery = 64;
     unsigned thread_cap = 8;
     if (const char* e = std::getenv("BU_HOST_THREADS")) { const int v = std::atoi(e); if (v >= 1 && v <= 64) thread_cap = (unsigned)v; }
-    const bool may_pipeline = thread_cap >= 3 && std::thread::hardware_concurrency() >= 3;
-    struct table_slot { metric::dist_table table; uint64_t cur_err; };
+    const bool may_pipeline = thread_cap >= 2 && std::thread::hardware_concurrency() >= 2;
 
     std::mutex loop_time_lock;
     double loop_times[4] = {0, 0, 0, 0};
@@ -868,9 +902,7 @@ bool etc1s_backend::encode_image() {
         std::vector<token> pred_tok(n, token{0, T_NONE}), delta_tok(n, token{0, T_NONE}), sel_tok(n, token{0, T_NONE});
         std::vector<uint32_t> final_endpoint(n, 0);  // NEW palette index per block once loop 1 has passed it
         const bool pipelined = may_pipeline && n >= kPipelineMinBlocks;
-        const uint32_t ring = pipelined ? kRing : n;
-        std::vector<table_slot> slots(ring);
-        std::atomic<uint32_t> done1{0}, done2{0}, done3{0};
+        std::atomic<uint32_t> done1{0};
         auto wait_for = [](const std::atomic<uint32_t>& counter, uint32_t need) {  // until counter >= need
             uint32_t v;
             for (uint32_t spins = 0; (v = counter.load(std::memory_order_acquire)) < need; spins++)
@@ -967,22 +999,6 @@ bool etc1s_backend::encode_image() {
             done1.store(n, std::memory_order_release);
         };
 
-        auto tables_loop = [&]() {
-            uint32_t ready = 0, consumed = 0;
-            for (uint32_t i = 0; i < n; i++) {
-                if (i >= ready) ready = wait_for(done1, i + 1);
-                if (i >= consumed + ring) consumed = wait_for(done3, i + 1 - ring);
-                const uint32_t b = base + i;
-                block_px px;
-                K.load_pixels(perceptual, px, &m_src.source_blocks[b].m_pixels[0][0]);
-                table_slot& slot = slots[i % ring];
-                K.build_table(perceptual, px, m_palette_colors[m_endpoint_new_to_old[final_endpoint[i]]], slot.table);
-                slot.cur_err = K.table_error(slot.table, m_selector_bytes[m_blocks[b].selector_index], UINT64_MAX);
-                if (((i + 1) % kPublishEvery) == 0) done2.store(i + 1, std::memory_order_release);
-            }
-            done2.store(n, std::memory_order_release);
-        };
-
         auto selectors_loop = [&]() {
             history_buffer history;
             history.reset(m_selector_bytes[m_selector_new_to_old[0]]);
@@ -1002,22 +1018,25 @@ bool etc1s_backend::encode_image() {
             };
             uint32_t ready = 0;
             for (uint32_t i = 0; i < n; i++) {
-                if (i >= ready) ready = wait_for(done2, i + 1);
+                if (i >= ready) ready = wait_for(done1, i + 1);
                 const uint32_t b = base + i;
                 encoder_block& m = m_blocks[b];
                 // ---- a recently used pattern (history buffer) that is good enough, else the block's own (backend.cpp:1011-1205)
                 if (video && m.endpoint_predictor == 2) {   // repeats the previous frame's block: no selector symbol at all (backend.cpp:1011)
                     block_selector_indices[b] = m.selector_index;
-                    if (((i + 1) % kPublishEvery) == 0) done3.store(i + 1, std::memory_order_release);
                     continue;
                 }
                 const bool cr_target = video && m_cr_target[b];   // its selectors are what the next frame repeats: not to be traded (backend.cpp:1020, 1036)
                 int new_selector = (int)m_selector_old_to_new[m.selector_index];
                 int history_index = (cr_target || level <= 1) ? metric::find_first_64(history.v, new_selector) : -1;
                 if (history_index == -1 && !cr_target) {
-                    const table_slot& slot = slots[i % ring];
-                    const uint64_t limit_err = (uint64_t)ceilf(slot.cur_err * selector_thresh);
-                    const metric::scan_result best = K.scan_history(slot.table, m_selector_bytes[m.selector_index], history.sel, level <= 1 ? kSelDiffThreshold : 0, limit_err);
+                    block_px px;
+                    K.load_pixels(perceptual, px, &m_src.source_blocks[b].m_pixels[0][0]);
+                    metric::dist_table table;   // the block's pixels against the four colours of its final endpoints
+                    K.build_table(perceptual, px, m_palette_colors[m_endpoint_new_to_old[final_endpoint[i]]], table);
+                    const uint64_t cur_err = K.table_error(table, m_selector_bytes[m.selector_index], UINT64_MAX);
+                    const uint64_t limit_err = (uint64_t)ceilf(cur_err * selector_thresh);
+                    const metric::scan_result best = K.scan_history(table, m_selector_bytes[m.selector_index], history.sel, level <= 1 ? kSelDiffThreshold : 0, limit_err);
                     if (best.index >= 0) { new_selector = history.v[best.index]; history_index = best.index; }
                 }
                 m.selector_index = m_selector_new_to_old[new_selector];
@@ -1034,26 +1053,22 @@ bool etc1s_backend::encode_image() {
                 m.selector_history_index = (int8_t)history_index;
                 if (history_index < 0) history.add(new_selector, m_selector_bytes[m.selector_index]); else history.use((uint32_t)history_index);
                 block_selector_indices[b] = m.selector_index;
-                if (((i + 1) % kPublishEvery) == 0) done3.store(i + 1, std::memory_order_release);
             }
             close_selector_run();
-            done3.store(n, std::memory_order_release);
         };
 
         // each loop's own duration (with the pipeline on they overlap: the slowest one is the walk's wall time)
-        double d1 = 0, d2 = 0, d3 = 0;
+        double d1 = 0, d3 = 0;
         auto timed = [](auto& fn, double& out) { timer t__; fn(); out = t__.seconds(); };
         if (pipelined) {
-            std::thread t2([&] { timed(tables_loop, d2); }), t3([&] { timed(selectors_loop, d3); });
+            std::thread t3([&] { timed(selectors_loop, d3); });
             timed(endpoints_loop, d1);
-            t2.join();
             t3.join();
         } else {
             timed(endpoints_loop, d1);
-            timed(tables_loop, d2);
             timed(selectors_loop, d3);
         }
-        { std::lock_guard<std::mutex> g(loop_time_lock); loop_times[0] += d1; loop_times[1] += d2; loop_times[2] += d3; }
+        { std::lock_guard<std::mutex> g(loop_time_lock); loop_times[0] += d1; loop_times[2] += d3; }
         timer merge_timer;
         // the slice's symbols in bit-stream order: predictor, endpoint delta, selector of every block in turn
         std::vector<token>& tokens = slice_tokens[si];
@@ -1065,7 +1080,7 @@ bool etc1s_backend::encode_image() {
         }
         { std::lock_guard<std::mutex> g(loop_time_lock); loop_times[3] += merge_timer.seconds(); }
     });
-    sub_time("~ei/endpoints_loop", loop_times[0]); sub_time("~ei/tables_loop", loop_times[1]); sub_time("~ei/selectors_loop", loop_times[2]);
+    sub_time("~ei/endpoints_loop", loop_times[0]); sub_time("~ei/selectors_loop", loop_times[2]);
     sub_time("~ei/token_merge", loop_times[3]); sub_time("~ei/walks_wall", walks_timer.seconds());
     timer coding_timer;
     std::vector<uint32_t> selector_hist(n_sel + kSelectorHistorySize + 1, 0), rle_hist(kSelectorRleCountTotal, 0), delta_hist(n_ep, 0), pred_hist(kEndpointPredSymbols, 0);
@@ -1106,24 +1121,47 @@ bool etc1s_backend::encode_image() {
     w.flush();
     m_output.m_slice_image_tables = w.bytes();
     m_output.m_slice_image_data.assign(m_slices.size(), std::vector<uint8_t>());
-    for_each_slice(m_slices, [&](size_t si) {
-        bit_writer w;
-        w.restart(slice_tokens[si].size() + 64);
-        for (const token& t : slice_tokens[si]) {
-            switch (t.kind) {
+    auto code_tokens = [&](const token* t, const token* end, bit_writer& w) {
+        for (; t != end; ++t) {
+            switch (t->kind) {
             case T_NONE: break;
-            case T_PRED: w.put_code(t.value, pred_model); break;
-            case T_PRED_REPEAT: w.put_code(kEndpointPredRepeatLast, pred_model); w.put_vlc(t.value - kEndpointPredMinRepeat, kEndpointPredCountVlcBits); break;
-            case T_ENDPOINT_DELTA: w.put_code(t.value, delta_model); break;
-            case T_SELECTOR: w.put_code(t.value, selector_model); break;
+            case T_PRED: w.put_code(t->value, pred_model); break;
+            case T_PRED_REPEAT: w.put_code(kEndpointPredRepeatLast, pred_model); w.put_vlc(t->value - kEndpointPredMinRepeat, kEndpointPredCountVlcBits); break;
+            case T_ENDPOINT_DELTA: w.put_code(t->value, delta_model); break;
+            case T_SELECTOR: w.put_code(t->value, selector_model); break;
             case T_SELECTOR_RLE: {
                 w.put_code(kHistRleSym, selector_model);
-                const uint32_t run = t.value - kSelectorRleThresh;
+                const uint32_t run = t->value - kSelectorRleThresh;
                 if (run >= kSelectorRleCountTotal - 1) { w.put_code(kSelectorRleCountTotal - 1, rle_model); w.put_vlc(run, 7); }
                 else w.put_code(run, rle_model);
                 break;
             }
             }
+        }
+    };
+    for_each_slice(m_slices, [&](size_t si) {
+        const std::vector<token>& toks = slice_tokens[si];
+        // a long slice is coded in pieces on the host threads and the pieces' bits are joined in order (the symbols are independent of each other once the models exist)
+        const unsigned pieces = host_single_threaded() ? 1u : (unsigned)std::min<size_t>(8, toks.size() / 131072);
+        bit_writer w;
+        if (pieces <= 1) {
+            w.restart(toks.size() + 64);
+            code_tokens(toks.data(), toks.data() + toks.size(), w);
+        } else {
+            std::vector<bit_writer> part(pieces);
+            std::vector<std::thread> pool;
+            const size_t per = (toks.size() + pieces - 1) / pieces;
+            for (unsigned k = 0; k < pieces; k++)
+                pool.emplace_back([&, k] {
+                    const size_t a = std::min(toks.size(), k * per), b = std::min(toks.size(), a + per);
+                    bit_writer local;   // on this thread's stack: the writers' accumulators are touched per symbol, and neighbours in one array would share cache lines
+                    local.restart(b - a + 64);
+                    code_tokens(toks.data() + a, toks.data() + b, local);
+                    part[k] = std::move(local);
+                });
+            for (std::thread& th : pool) th.join();
+            w.restart(toks.size() + 64);
+            for (unsigned k = 0; k < pieces; k++) w.append(part[k]);
         }
         w.flush();
         m_output.m_slice_image_data[si] = w.bytes();
