@@ -1142,7 +1142,7 @@ bool etc1s_backend::encode_image() {
     for_each_slice(m_slices, [&](size_t si) {
         const std::vector<token>& toks = slice_tokens[si];
         // a long slice is coded in pieces on the host threads and the pieces' bits are joined in order (the symbols are independent of each other once the models exist)
-        const unsigned pieces = host_single_threaded() ? 1u : (unsigned)std::min<size_t>(8, toks.size() / 131072);
+        const unsigned pieces = host_single_threaded() ? 1u : (unsigned)std::min<size_t>(8, toks.size() / 32768);
         bit_writer w;
         if (pieces <= 1) {
             w.restart(toks.size() + 64);
