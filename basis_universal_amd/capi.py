@@ -85,6 +85,7 @@ _SIGNATURES = {
     "bu_hip_k_resample_rgba8": (_int, [_vp, _vp, _u32, _u32, _vp, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _int, _int, _vp, _vp, _u32]),
     "bu_hip_k_refit_endpoints_given_selectors_q": (_int, [_vp, _vp, _vp, _u32, _vp, _vp, _vp, _int, _int, _vp, _vp, _vp, _vp]),
     "bu_hip_k_subblock_errors": (_int, [_vp, _vp, _u32, _vp, _vp, _int, _vp]),
+    "bu_hip_k_backend_block_errors": (_int, [_vp, _vp, _vp, _vp, _vp, _u32, _u32, _u32, _u32, _int, _int, _vp, _vp]),
     "bu_hip_k_refine_endpoint_clusterization": (_int, [_vp, _vp, _u32, _vp, _vp, _u32, _u32, _vp, _vp, _vp, _int, _vp]),
     "bu_hip_k_determine_selectors": (_int, [_vp, _vp, _u32, _vp, _vp, _int, _vp]),
     "bu_hip_k_selector_training_vectors": (_int, [_vp, _vp, _u32, _int, _vp, _vp]),

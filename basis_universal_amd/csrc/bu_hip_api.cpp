@@ -485,6 +485,18 @@ int bu_hip_k_subblock_errors(bu_hip_context* ctx, const void* d_px, uint32_t n_b
     return 1;
 }
 
+int bu_hip_k_backend_block_errors(bu_hip_context* ctx, const void* d_px, const void* d_etc_blocks, const uint32_t* d_block_cluster, const uint8_t* d_cluster_params,
+                                  uint32_t first_block, uint32_t num_blocks_x, uint32_t num_blocks_y, uint32_t n_clusters, int perceptual, int with_neighbours,
+                                  uint32_t* d_own_err, uint32_t* d_neighbour_err) {
+    if (!ctx) return 0;
+    if (!d_px || !d_etc_blocks || !d_block_cluster || !d_cluster_params || !d_own_err || (with_neighbours && !d_neighbour_err)) { set_error(ctx, "backend_block_errors: null argument"); return 0; }
+    device_guard g(ctx->device);
+    prof_scope ps(ctx, "backend_block_errors");
+    BU_TRY(ctx, bu::launch_backend_block_errors(ctx->stream, d_px, d_etc_blocks, d_block_cluster, d_cluster_params, first_block, num_blocks_x, num_blocks_y, n_clusters, perceptual != 0,
+                                                with_neighbours != 0, d_own_err, d_neighbour_err));
+    return 1;
+}
+
 int bu_hip_k_refine_endpoint_clusterization(bu_hip_context* ctx, const void* d_px, uint32_t n_blocks, const uint32_t* d_block_cluster,
                                             const uint8_t* d_cluster_params, uint32_t n_clusters, uint32_t n_parents, const uint32_t* d_cand_offsets,
                                             const uint32_t* d_cand_indices, const uint8_t* d_block_parent, int perceptual, uint32_t* d_out_best) {

@@ -20,6 +20,9 @@ hipError_t launch_refit_endpoints_given_selectors(hipStream_t st, const void* d_
                                                   uint8_t* d_valid, uint64_t* d_cur_err);
 hipError_t launch_subblock_errors(hipStream_t st, const void* d_pixel_blocks, uint32_t n_blocks, const uint32_t* d_block_cluster, const uint8_t* d_cluster_params,
                                   bool perceptual, uint64_t* d_out);
+hipError_t launch_backend_block_errors(hipStream_t st, const void* d_pixel_blocks, const void* d_etc_blocks, const uint32_t* d_block_cluster, const uint8_t* d_cluster_params,
+                                       uint32_t first_block, uint32_t nbx, uint32_t nby, uint32_t n_clusters, bool perceptual, bool with_neighbours, uint32_t* d_own,
+                                       uint32_t* d_neighbour);
 hipError_t launch_refine_endpoint_clusterization(hipStream_t st, const void* d_pixel_blocks, uint32_t n_blocks, const uint32_t* d_block_cluster,
                                                  const uint8_t* d_cluster_params, uint32_t n_clusters, uint32_t n_parents, const uint32_t* d_cand_offsets,
                                                  const uint32_t* d_cand_indices, const uint8_t* d_block_parent, bool perceptual, uint32_t* d_out_best,

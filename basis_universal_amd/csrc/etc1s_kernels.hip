@@ -1478,6 +1478,72 @@ hipError_t launch_subblock_errors(hipStream_t st, const void* d_pixel_blocks, ui
     return hipSuccess;
 }
 
+// The stateless part of basisu_backend::create_encoder_blocks (backend.cpp:406-617): for every block of a slice the error of the block as the
+// frontend left it (cur_err of :507 and :841) and -- where no causal neighbour already shares its endpoints -- its error under the endpoints of its left, upper and
+// upper-left neighbours with its own selectors (what :520-574 evaluates when those neighbours keep their endpoints). One thread per block, tiles and blocks resident;
+// the decisions that chain from block to block stay on the host. ~0u: not applicable (edge, shared endpoints, zero error, index out of range).
+template <bool PERCEPTUAL>
+__global__ __launch_bounds__(256) void k_backend_block_errors(const uint4* __restrict__ pixel_blocks, const uint64_t* __restrict__ etc_blocks, const uint32_t* __restrict__ block_cluster,
+                                                              const uint32_t* __restrict__ cluster_params, uint32_t first, uint32_t nbx, uint32_t nby, uint32_t n_clusters,
+                                                              int with_neighbours, uint32_t* __restrict__ own, uint32_t* __restrict__ neighbour) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= nbx * nby) return;
+    const uint32_t b = first + i, bx = i % nbx, by = i / nbx;
+    uint32_t px[16];
+#pragma unroll
+    for (int k = 0; k < 4; k++) { const uint4 v = pixel_blocks[(size_t)b * 4 + k]; px[k * 4] = v.x; px[k * 4 + 1] = v.y; px[k * 4 + 2] = v.z; px[k * 4 + 3] = v.w; }
+    const uint64_t mem = etc_blocks[b];
+    uint32_t r5, g5, b5, inten;
+    unpack_etc1s_header(mem, r5, g5, b5, inten);
+    const uint32_t lo32 = (uint32_t)bswap64(mem);
+    auto error_under = [&](uint32_t cr, uint32_t cg, uint32_t cb, uint32_t table) {
+        cvec bc[4];
+        block_cvecs<PERCEPTUAL>(bc, scale5((int)cr), scale5((int)cg), scale5((int)cb), (int)table);
+        uint32_t e = 0;
+#pragma unroll
+        for (uint32_t y = 0; y < 4; y++)
+#pragma unroll
+            for (uint32_t x = 0; x < 4; x++) e += cdist<PERCEPTUAL>(pixel_cvec<PERCEPTUAL>(px[y * 4 + x]), select_cvec(bc, selector_from_bits(lo32, x, y)));
+        return e;
+    };
+    const uint32_t mine_err = error_under(r5, g5, b5, inten);
+    own[b] = mine_err;
+    if (!with_neighbours) return;
+    const uint32_t mine = block_cluster[b];
+    const int dx[3] = { -1, 0, -1 }, dy[3] = { 0, -1, -1 };   // g_endpoint_preds (backend.cpp:120-128)
+    uint32_t nb[3];
+    bool any_equal = false;
+#pragma unroll
+    for (int p = 0; p < 3; p++) {
+        const int x = (int)bx + dx[p], y = (int)by + dy[p];
+        nb[p] = (x >= 0 && y >= 0) ? block_cluster[first + (uint32_t)x + (uint32_t)y * nbx] : ~0u;
+        any_equal = any_equal || nb[p] == mine;
+    }
+#pragma unroll
+    for (int p = 0; p < 3; p++) {
+        uint32_t e = ~0u;
+        if (mine_err && !any_equal && nb[p] != ~0u && nb[p] < n_clusters) {
+            const uint32_t prm = cluster_params[nb[p]];
+            e = error_under(prm & 255u, (prm >> 8) & 255u, (prm >> 16) & 255u, prm >> 24);
+        }
+        neighbour[(size_t)b * 3 + p] = e;
+    }
+}
+
+hipError_t launch_backend_block_errors(hipStream_t st, const void* d_pixel_blocks, const void* d_etc_blocks, const uint32_t* d_block_cluster, const uint8_t* d_cluster_params,
+                                       uint32_t first_block, uint32_t nbx, uint32_t nby, uint32_t n_clusters, bool perceptual, bool with_neighbours, uint32_t* d_own,
+                                       uint32_t* d_neighbour) {
+    if (!nbx || !nby) return hipSuccess;
+    const dim3 grid((nbx * nby + 255) / 256), blk(256);
+    const uint4* px = static_cast<const uint4*>(d_pixel_blocks);
+    const uint64_t* enc = static_cast<const uint64_t*>(d_etc_blocks);
+    const uint32_t* prm = reinterpret_cast<const uint32_t*>(d_cluster_params);
+    if (perceptual) hipLaunchKernelGGL(k_backend_block_errors<true>, grid, blk, 0, st, px, enc, d_block_cluster, prm, first_block, nbx, nby, n_clusters, with_neighbours ? 1 : 0, d_own, d_neighbour);
+    else hipLaunchKernelGGL(k_backend_block_errors<false>, grid, blk, 0, st, px, enc, d_block_cluster, prm, first_block, nbx, nby, n_clusters, with_neighbours ? 1 : 0, d_own, d_neighbour);
+    BU_LAUNCH_CHECK();
+    return hipSuccess;
+}
+
 size_t refine_workspace_bytes(uint32_t n_clusters, uint32_t n_parents) {
     if (n_clusters > 65535u) return 0;   // positions and cluster ids share a dword in the sorted lists
     const size_t lists = n_parents ? n_parents : 1;

@@ -502,6 +502,7 @@ void etc1s_backend::init(const backend_source& src, const backend_params& params
 void etc1s_backend::init(etc1s_frontend* fe, const backend_params& params, const std::vector<backend_slice_desc>& slices) {
     init(backend_source(), params, slices, nullptr);
     m_frontend = fe;
+    m_frontend_state_changed = false;
     auto flatten = [this](backend_source& src) {
         etc1s_frontend& f = *m_frontend;
         const auto& P = f.endpoint_cluster_params();
@@ -521,6 +522,7 @@ void etc1s_backend::init(etc1s_frontend* fe, const backend_params& params, const
     flatten(m_src);
     m_reoptimize = [this, flatten](const std::vector<uint32_t>& new_block_endpoints, std::vector<int>& old_to_new, bool final_codebook,
                                    const std::vector<uint32_t>* block_selector_indices, backend_source& src) {
+        m_frontend_state_changed = true;   // the resident blocks / clustering no longer describe what the backend walks
         if (!m_frontend->reoptimize_remapped_endpoints(new_block_endpoints, old_to_new, final_codebook, block_selector_indices)) return false;
         flatten(src);
         return true;
@@ -575,6 +577,22 @@ void etc1s_backend::precompute_block_errors(bool with_neighbours) {
     if (with_neighbours) m_neighbour_err.assign((size_t)m_src.total_blocks * 3, UINT64_MAX);
     for (const backend_slice_desc& s : m_slices) {
         const uint32_t nbx = s.m_num_blocks_x, nby = s.m_num_blocks_y, base = s.m_first_block_index;
+        // With a resident frontend behind the backend (and its state untouched since compress()) the errors come from the MI355X (k_backend_block_errors: tiles, blocks
+        // and clustering are still in HBM); only the selector unpacking stays here. The host loop below is the same arithmetic for the array-driven backend.
+        if (m_frontend && with_neighbours && !m_frontend_state_changed && (uint64_t)base + (uint64_t)nbx * nby <= m_src.total_blocks && nbx && nby) {
+            std::vector<uint32_t> own((size_t)nbx * nby), nb3((size_t)nbx * nby * 3);
+            if (m_frontend->backend_block_errors(base, nbx, nby, true, own.data(), nb3.data())) {
+                parallel_rows(nby, nbx, [&, nbx, base](uint32_t y0, uint32_t y1) {
+                    for (uint32_t i = y0 * nbx; i < y1 * nbx; i++) {
+                        const uint32_t b = base + i;
+                        m_own_sels[b] = packed_selectors(m_src.output_blocks[b]);
+                        m_own_err[b] = own[i];
+                        for (uint32_t p = 0; p < 3; p++) m_neighbour_err[(size_t)b * 3 + p] = nb3[(size_t)i * 3 + p] == UINT32_MAX ? UINT64_MAX : (uint64_t)nb3[(size_t)i * 3 + p];
+                    }
+                });
+                continue;
+            }
+        }
         parallel_rows(nby, nbx, [&, nbx, base](uint32_t y0, uint32_t y1) {
             for (uint32_t by = y0; by < y1; by++)
                 for (uint32_t bx = 0; bx < nbx; bx++) {

@@ -123,6 +123,8 @@ private:
     int find_video_frame(size_t slice, int delta) const;
 
     etc1s_frontend* m_frontend = nullptr;
+
+    bool m_frontend_state_changed = false;   // set once the backend has called back into the frontend (reoptimize_remapped_endpoints)
     backend_source m_src;
     reoptimize_fn m_reoptimize;
     backend_params m_params;

@@ -325,6 +325,28 @@ const bu_pixel_block* etc1s_frontend::source_blocks_host() {
     return m_source_copy.data();
 }
 
+bool etc1s_frontend::backend_block_errors(uint32_t first_block, uint32_t nbx, uint32_t nby, bool with_neighbours, uint32_t* own, uint32_t* neighbour) {
+    if (!m_dev || !m_dev->d_pixels || !m_enc_dev_valid || !m_ep_dev_valid || !m_dev->enc.p || !m_dev->block_cluster.p) return false;
+    const uint64_t n = (uint64_t)nbx * nby;
+    if (!n || first_block + n > m_total_blocks) return false;
+    device_state& d = *m_dev;
+    const uint32_t k = (uint32_t)m_endpoint_cluster_etc_params.size();
+    std::vector<uint8_t> prm((size_t)k * 4);
+    for (uint32_t i = 0; i < k; i++) {
+        const endpoint_params& e = m_endpoint_cluster_etc_params[i];
+        prm[i * 4] = e.r; prm[i * 4 + 1] = e.g; prm[i * 4 + 2] = e.b; prm[i * 4 + 3] = e.inten;
+    }
+    // results at slice-relative positions: the kernel indexes its outputs by absolute block, so the buffers cover blocks [0, first + n)
+    const size_t upto = (size_t)first_block + n;
+    if (!d.upload(d.params, prm.data(), prm.size()) || !d.reserve(d.tmp_a, upto * 4) || (with_neighbours && !d.reserve(d.tmp_c, upto * 12))) return false;
+    if (!bu_hip_k_backend_block_errors(d.ctx, d.d_pixels, d.enc.p, (const uint32_t*)d.block_cluster.p, (const uint8_t*)d.params.p, first_block, nbx, nby, k, m_params.m_perceptual ? 1 : 0,
+                                       with_neighbours ? 1 : 0, (uint32_t*)d.tmp_a.p, with_neighbours ? (uint32_t*)d.tmp_c.p : nullptr))
+        return false;
+    if (!bu_hip_memcpy_d2h(d.ctx, own, (const char*)d.tmp_a.p + (size_t)first_block * 4, n * 4)) return false;
+    if (with_neighbours && !bu_hip_memcpy_d2h(d.ctx, neighbour, (const char*)d.tmp_c.p + (size_t)first_block * 12, n * 12)) return false;
+    return true;
+}
+
 const std::vector<bu_etc_block>& etc1s_frontend::etc1_blocks() const {
     if (!m_etc1_on_host && m_dev && m_dev->etc1.p) {
         m_etc1_blocks_etc1s.resize(m_total_blocks);

@@ -84,6 +84,10 @@ public:
 
     // ---- what the backend needs beyond the getters (etc1s_backend.h)
     const bu_pixel_block* source_blocks_host();  // get_source_pixel_block: the caller's host tiles, or a host copy of device-only tiles
+    // For the backend's create_encoder_blocks (row f2): every block's error as encoded and, where asked, under its three causal neighbours' endpoints, computed on the
+    // device from the resident tiles, blocks and clustering (bu_hip_k_backend_block_errors). own: n words, neighbour: 3 n words (n = blocks of the slice). false: the
+    // resident state is not current (or the call failed) -- the backend then computes them on the host.
+    bool backend_block_errors(uint32_t first_block, uint32_t num_blocks_x, uint32_t num_blocks_y, bool with_neighbours, uint32_t* own, uint32_t* neighbour);
     // basisu_frontend::reoptimize_remapped_endpoints (frontend.cpp:2996-3220): the backend moved blocks to other endpoint clusters
     bool reoptimize_remapped_endpoints(const std::vector<uint32_t>& new_block_endpoints, std::vector<int>& old_to_new, bool optimize_final_codebook,
                                        const std::vector<uint32_t>* block_selector_indices);

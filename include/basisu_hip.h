@@ -148,6 +148,12 @@ BU_HIP_API int bu_hip_k_refit_endpoints_given_selectors_q(bu_hip_context*, const
  *     endpoints of its block's cluster; feeds introduce_new_endpoint_clusters. d_out_err: 2*n_blocks entries. */
 BU_HIP_API int bu_hip_k_subblock_errors(bu_hip_context*, const void* d_pixel_blocks, uint32_t n_blocks, const uint32_t* d_block_cluster,
     const uint8_t* d_cluster_params, int perceptual, uint64_t* d_out_err);
+/* The stateless part of basisu_backend::create_encoder_blocks (encoder/basisu_backend.cpp:406-617) for one slice of num_blocks_x x num_blocks_y blocks starting at first_block:
+ * d_own_err[b] = the block's error as encoded (cur_err of :507 / :841); with_neighbours: d_neighbour_err[b * 3 + p] = its error under the endpoints of its left / upper / upper-left
+ * neighbour (g_endpoint_preds order) with its own selectors, ~0u where the walk does not ask for it (edge, a neighbour already shares its endpoints, zero error). The decisions that chain
+ * from block to block stay on the host (include/basisu_hip_backend.h). d_cluster_params: r5, g5, b5, intensity table per endpoint cluster. */
+BU_HIP_API int bu_hip_k_backend_block_errors(bu_hip_context*, const void* d_pixel_blocks, const void* d_etc_blocks, const uint32_t* d_block_cluster, const uint8_t* d_cluster_params,
+    uint32_t first_block, uint32_t num_blocks_x, uint32_t num_blocks_y, uint32_t n_clusters, int perceptual, int with_neighbours, uint32_t* d_own_err, uint32_t* d_neighbour_err);
 /* a9 for one of `parts` equal shares of the clusters (multi-GPU): the clusters at positions part, part + parts, ... of the
  *     size-descending order. Entries of clusters outside the share are neither read nor written. */
 BU_HIP_API int bu_hip_k_generate_endpoint_codebook_part(bu_hip_context*, const void* d_pixel_blocks, uint32_t n_clusters,

@@ -209,3 +209,34 @@ def test_video_clip_matches_reference(hip_ctx, level):
     for s in range(frames):
         assert (be.get("slice_image_data", s) == ref.backend_get("slice_image_data", s)).all()
     be.close(); fe.close(); ref.close()
+
+
+@pytest.mark.parametrize("w,h,seed,perceptual", [(512, 384, 21, True), (260, 132, 22, False)])
+def test_device_block_errors_equal_the_host_ones(hip_ctx, w, h, seed, perceptual):
+    """create_encoder_blocks' stateless part (every block's error as encoded and under its causal neighbours' endpoints) comes from k_backend_block_errors when a resident
+    frontend is behind the backend, and from the host loop when the backend is driven from plain arrays: same state in, so same bytes and same per-block decisions out --
+    and the kernel must really have run."""
+    from basis_universal_amd.etc1s import Etc1sFrontend, quality_to_clusters
+    from basis_universal_amd.backend import Etc1sBackend
+    blocks = to_pixel_blocks(synth(w, h, seed))
+    nbx, nby = (w + 3) // 4, (h + 3) // 4
+    ep, sel = quality_to_clusters(128, blocks.shape[0])
+    fe = Etc1sFrontend(hip_ctx)
+    fe.init(blocks, ep, sel, 1, perceptual)
+    fe.compress()
+    prm = fe.get("endpoint_cluster_etc_params").reshape(-1, 16)[:, :4].copy()
+    arrays = dict(source_blocks=blocks, output_blocks=fe.get("encoded_blocks"), block_endpoint_index=fe.get("block_endpoint_clusters_indices", np.uint32),
+                  block_selector_index=fe.get("block_selector_cluster_index", np.uint32), endpoint_color5_inten=prm, selector_blocks=fe.get("optimized_cluster_selectors"))
+    host = Etc1sBackend.from_arrays(slices=[(0, nbx, nby)], perceptual=perceptual, endpoint_rdo_thresh=1.5, selector_rdo_thresh=1.25, compression_level=1, **arrays)
+    hip_ctx.profile_enable(True)
+    dev = Etc1sBackend.from_frontend(fe, [(0, nbx, nby)], 1.5, 1.25, 1)
+    assert dev.encode() == host.encode()
+    ran = hip_ctx.profile_read()
+    hip_ctx.profile_enable(False)
+    assert "backend_block_errors" in ran, sorted(ran)
+    for k in OUTPUTS + ["encoder_blocks", "endpoint_remap_old_to_new", "selector_remap_new_to_old"]:
+        a, b = dev.get(k), host.get(k)
+        assert a.shape == b.shape and (a == b).all(), k
+    a, b = dev.get("slice_image_data", 0), host.get("slice_image_data", 0)
+    assert a.shape == b.shape and (a == b).all()
+    dev.close(); host.close(); fe.close()
