@@ -1,9 +1,10 @@
 // etc1s_backend.cpp -- see etc1s_backend.h. Reference: encoder/basisu_backend.cpp (cited per function).
 //
 // How the walk differs from the reference's while producing the same bytes:
-//  * one flat block array; per slice three loops (endpoints, distance tables, selectors) that run as a three-thread pipeline, and one
-//    token stream in bit-stream order (run tokens are placeholders patched when the run ends) instead of symbol vectors that a second
-//    walk over the blocks re-synchronises with; slices run concurrently;
+//  * one flat block array; the predictor walk as a wavefront over the rows; per slice two loops (endpoints; selectors, which build a block's distance table
+//    where the history search needs one) that run as two threads, and one token stream in bit-stream order (run tokens are placeholders patched when the run ends) instead of symbol vectors that a second
+//    walk over the blocks re-synchronises with; slices run concurrently; long symbol streams are coded in pieces and joined bit-wise;
+//  * with a resident frontend behind it the per-block errors create_encoder_blocks starts from come from the device (k_backend_block_errors);
 //  * the selector-history search looks a candidate's error up in a 4x16 table of the block's pixel-to-colour distances (64 distance
 //    evaluations per block instead of up to 16 per candidate and 64 candidates), and pre-filters candidates with one SAD instruction;
 //  * the error loops run 8 pixels per instruction where the CPU has AVX2 (block_metric.h), the palette's block colours are converted to
