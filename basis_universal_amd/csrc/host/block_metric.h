@@ -3,9 +3,9 @@
 //
 // The metric is separable once a colour is moved to (l, cr, cb) = (14r+45g+5b, 64r-l, 64b-l): a distance is three squares. Every
 // value below fits 32 bits (|dl| <= 16320, |dcr|,|dcb| <= 32640; one perceptual distance < 41e6, sixteen of them < 2^32), so the same
-// arithmetic runs in 32-bit SIMD lanes. There are three implementations of each loop -- plain C++, AVX2, AVX-512 -- picked once per
-// encode from what the CPU has (BU_BACKEND_ISA=plain|avx2 caps the choice); they are integer-exact and therefore interchangeable,
-// which tests/test_backend_host.py checks by running all of them.
+// arithmetic runs in 32-bit SIMD lanes. There are three implementations of each loop -- plain C++, AVX2, AVX-512 -- and a fourth of the
+// history scan for CPUs with AVX-512 VBMI, picked once per encode from what the CPU has (BU_BACKEND_ISA=plain|avx2|avx512 caps the
+// choice); they are integer-exact and therefore interchangeable, which tests/test_backend_host.py checks by running all of them.
 #pragma once
 #include <immintrin.h>
 
@@ -279,31 +279,22 @@ BU_AVX512 inline void load_pixels_avx512(bool perceptual, block_px& out, const u
         _mm512_store_si512((void*)out.x, r); _mm512_store_si512((void*)out.y, g); _mm512_store_si512((void*)out.z, b);
     }
 }
-// The pre-filter for all 64 patterns first (four per SAD instruction -> a 64-bit candidate mask), then the survivors four at a time with
-// one shared lane reduction.
-BU_AVX512 inline scan_result scan_history_avx512(const dist_table& t, const sel16& cur, const sel16* hist, int sad_limit, uint64_t limit) {
-    scan_result r{UINT64_MAX, -1};
-    uint64_t todo = ~0ull;
-    if (sad_limit > 0) {
-        todo = 0;
-        const __m512i c = _mm512_broadcast_i32x4(_mm_load_si128((const __m128i*)cur.s)), lim = _mm512_set1_epi64(sad_limit);
-        for (int q = 0; q < 16; q++) {
-            const __m512i d = _mm512_sad_epu8(c, _mm512_loadu_si512((const void*)(hist + 4 * q)));   // per pattern: two 64-bit halves
-            const __m512i sum = _mm512_add_epi64(d, _mm512_bsrli_epi128(d, 8));                      // even 64-bit lanes: the pattern's SAD
-            const uint32_t m = _mm512_cmplt_epu64_mask(sum, lim);                                  // bits 0, 2, 4, 6
-            todo |= (uint64_t)((m & 1u) | ((m >> 1) & 2u) | ((m >> 2) & 4u) | ((m >> 3) & 8u)) << (4 * q);
-        }
-    }
+// The exact errors of the patterns whose bit is set in `todo`, four at a time with one shared lane reduction; the minimum within `limit`,
+// first index on ties.
+BU_AVX512 inline scan_result scan_survivors_avx512(const dist_table& t, const sel16* hist, uint64_t todo, uint64_t limit) {
     const __m512i d0 = _mm512_load_si512((const void*)t.d[0]), d1 = _mm512_load_si512((const void*)t.d[1]), d2 = _mm512_load_si512((const void*)t.d[2]),
                   d3 = _mm512_load_si512((const void*)t.d[3]);
     const __m512i k1 = _mm512_set1_epi32(1), k2 = _mm512_set1_epi32(2), k3 = _mm512_set1_epi32(3);
+    uint64_t best = UINT64_MAX;   // (error << 6) | index: the minimum is the smallest error at its first index (an error is below 2^32)
     while (todo) {
-        int j[4];
+        uint32_t j[4];
+        bool live[4];
         __m512i acc[4];
-        int n = 0;
-        for (; n < 4 && todo; n++) { j[n] = __builtin_ctzll(todo); todo &= todo - 1; }
-        for (int k = 0; k < 4; k++) {
-            const __m512i idx = _mm512_cvtepu8_epi32(_mm_load_si128((const __m128i*)hist[j[k < n ? k : 0]].s));
+        for (int k = 0; k < 4; k++) {   // no branches on the number of patterns left: a spent slot repeats pattern 0 and is not counted
+            live[k] = todo != 0;
+            j[k] = live[k] ? (uint32_t)__builtin_ctzll(todo) : 0u;
+            todo &= todo - (todo != 0);
+            const __m512i idx = _mm512_cvtepu8_epi32(_mm_load_si128((const __m128i*)hist[j[k]].s));
             __m512i a = _mm512_maskz_mov_epi32(_mm512_testn_epi32_mask(idx, idx), d0);
             a = _mm512_mask_add_epi32(a, _mm512_cmpeq_epi32_mask(idx, k1), a, d1);
             a = _mm512_mask_add_epi32(a, _mm512_cmpeq_epi32_mask(idx, k2), a, d2);
@@ -317,10 +308,28 @@ BU_AVX512 inline scan_result scan_history_avx512(const dist_table& t, const sel1
         const __m128i w = _mm_add_epi32(_mm256_castsi256_si128(v), _mm256_extracti128_si256(v, 1));
         alignas(16) uint32_t e[4];
         _mm_store_si128((__m128i*)e, w);
-        for (int k = 0; k < n; k++)
-            if (e[k] < r.err && e[k] <= limit) { r.err = e[k]; r.index = j[k]; }
+        for (int k = 0; k < 4; k++) {
+            const uint64_t key = ((uint64_t)e[k] << 6) | j[k];
+            best = (live[k] & (e[k] <= limit) & (key < best)) ? key : best;
+        }
     }
-    return r;
+    return best == UINT64_MAX ? scan_result{UINT64_MAX, -1} : scan_result{best >> 6, (int)(best & 63)};
+}
+// The pre-filter for all 64 patterns first (four per SAD instruction -> a 64-bit candidate mask), then the survivors four at a time with
+// one shared lane reduction.
+BU_AVX512 inline scan_result scan_history_avx512(const dist_table& t, const sel16& cur, const sel16* hist, int sad_limit, uint64_t limit) {
+    uint64_t todo = ~0ull;
+    if (sad_limit > 0) {
+        todo = 0;
+        const __m512i c = _mm512_broadcast_i32x4(_mm_load_si128((const __m128i*)cur.s)), lim = _mm512_set1_epi64(sad_limit);
+        for (int q = 0; q < 16; q++) {
+            const __m512i d = _mm512_sad_epu8(c, _mm512_loadu_si512((const void*)(hist + 4 * q)));   // per pattern: two 64-bit halves
+            const __m512i sum = _mm512_add_epi64(d, _mm512_bsrli_epi128(d, 8));                      // even 64-bit lanes: the pattern's SAD
+            const uint32_t m = _mm512_cmplt_epu64_mask(sum, lim);                                  // bits 0, 2, 4, 6
+            todo |= (uint64_t)((m & 1u) | ((m >> 1) & 2u) | ((m >> 2) & 4u) | ((m >> 3) & 8u)) << (4 * q);
+        }
+    }
+    return scan_survivors_avx512(t, hist, todo, limit);
 }
 BU_AVX512 inline void block_errors_avx512(bool perceptual, const block_px& px, const sel16& sel, const pal_colors* colors, const int* which, int n, uint64_t* out) {
     const __m512i idx = _mm512_cvtepu8_epi32(_mm_load_si128((const __m128i*)sel.s));
@@ -334,6 +343,43 @@ BU_AVX512 inline void block_errors_avx512(bool perceptual, const block_px& px, c
     }
 }
 #undef BU_AVX512
+
+// ---- AVX-512 VBMI: the history scan with a second pre-filter in front of the exact errors. The distance table is cut down to one byte per
+// entry, q[k][p] = min(255, d[k][p] >> shift), with the shift chosen so that limit >> shift stays below 1024: the sum of a pattern's q is
+// never above its error >> shift, so a pattern whose byte sum exceeds limit >> shift cannot be within the limit. All 64 byte sums cost one
+// VPERMB (the 64-entry table IS one register) and one VPSADBW per four patterns. On a 2048^2 photo-like image at level 1: 21.7 of the 64
+// patterns pass the selector-SAD test, 3.4 pass both, 2.9 are within the limit (a cap of 2048 lets 6.4 through, 512 3.6: a pixel whose
+// distance saturates the byte costs more than the rounding does).
+#define BU_VBMI __attribute__((target("avx512f,avx512bw,avx512vl,avx512vbmi,avx2,bmi2,lzcnt")))
+BU_VBMI inline scan_result scan_history_vbmi(const dist_table& t, const sel16& cur, const sel16* hist, int sad_limit, uint64_t limit) {
+    const int bits = 64 - (int)_lzcnt_u64(limit), shift = bits > 10 ? bits - 10 : 0;   // limit >> shift < 1024
+    const __m128i cnt = _mm_cvtsi32_si128(shift);
+    const __m512i cap = _mm512_set1_epi32(255);
+    __m512i plane = _mm512_castsi128_si512(_mm512_cvtepi32_epi8(_mm512_min_epu32(_mm512_srl_epi32(_mm512_load_si512((const void*)t.d[0]), cnt), cap)));
+    plane = _mm512_inserti32x4(plane, _mm512_cvtepi32_epi8(_mm512_min_epu32(_mm512_srl_epi32(_mm512_load_si512((const void*)t.d[1]), cnt), cap)), 1);
+    plane = _mm512_inserti32x4(plane, _mm512_cvtepi32_epi8(_mm512_min_epu32(_mm512_srl_epi32(_mm512_load_si512((const void*)t.d[2]), cnt), cap)), 2);
+    plane = _mm512_inserti32x4(plane, _mm512_cvtepi32_epi8(_mm512_min_epu32(_mm512_srl_epi32(_mm512_load_si512((const void*)t.d[3]), cnt), cap)), 3);
+    const __m512i pos = _mm512_broadcast_i32x4(_mm_setr_epi8(0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15));
+    const __m512i c = _mm512_broadcast_i32x4(_mm_load_si128((const __m128i*)cur.s)), zero = _mm512_setzero_si512();
+    // Per pattern a pair of 64-bit lanes, each (byte sum of eight pixels) | (selector SAD of eight pixels) << 32; two registers of four patterns are
+    // folded into one of eight sums, whose 32-bit lanes are compared against (limit >> shift) + 1 and sad_limit in one instruction.
+    const __m512i bound = _mm512_set1_epi64((long long)((limit >> shift) + 1) | ((long long)(sad_limit > 0 ? sad_limit : 1 << 20) << 32));
+    uint64_t pass[2] = {0, 0};   // 16 bits per eight patterns: bit 2l the byte-sum test, bit 2l+1 the SAD test of pattern (l & 1) * 4 + (l >> 1)
+    for (int q = 0; q < 8; q++) {
+        const __m512i ha = _mm512_load_si512((const void*)(hist + 8 * q)), hb = _mm512_load_si512((const void*)(hist + 8 * q + 4));
+        const __m512i va = _mm512_or_si512(_mm512_sad_epu8(_mm512_permutexvar_epi8(_mm512_or_si512(_mm512_slli_epi16(ha, 4), pos), plane), zero), _mm512_slli_epi64(_mm512_sad_epu8(c, ha), 32));
+        const __m512i vb = _mm512_or_si512(_mm512_sad_epu8(_mm512_permutexvar_epi8(_mm512_or_si512(_mm512_slli_epi16(hb, 4), pos), plane), zero), _mm512_slli_epi64(_mm512_sad_epu8(c, hb), 32));
+        const uint64_t m = _mm512_cmplt_epu32_mask(_mm512_add_epi64(_mm512_unpacklo_epi64(va, vb), _mm512_unpackhi_epi64(va, vb)), bound);
+        pass[q >> 2] |= m << (16 * (q & 3));
+    }
+    uint64_t todo = 0;
+    for (int w = 0; w < 2; w++) {
+        const uint64_t ok = _pext_u64(pass[w] & (pass[w] >> 1), 0x5555555555555555ull);   // per byte: a0 b0 a1 b1 a2 b2 a3 b3 (a: first four patterns, b: next four)
+        todo |= (_pdep_u64(_pext_u64(ok, 0x55555555ull), 0x0F0F0F0Full) | _pdep_u64(_pext_u64(ok, 0xAAAAAAAAull), 0xF0F0F0F0ull)) << (32 * w);
+    }
+    return scan_survivors_avx512(t, hist, todo, limit);
+}
+#undef BU_VBMI
 
 // sum over the pixels of |selector difference| (SSE2: part of the x86-64 baseline)
 inline int selector_sad(const sel16& a, const sel16& b) {
@@ -360,9 +406,12 @@ struct kernels {
     window_mask (*filter_window)(const uint8_t*, const uint8_t*, const uint8_t*, const uint8_t*, const uint8_t*, int, int, int, int, int, bool);
     const char* isa;
 };
-inline kernels pick_kernels() {  // BU_BACKEND_ISA = plain | avx2 | avx512 caps the choice (tests run all of them)
+inline kernels pick_kernels() {  // BU_BACKEND_ISA = plain | avx2 | avx512 | vbmi caps the choice (tests run all of them)
     const char* cap = std::getenv("BU_BACKEND_ISA");
-    const int level = !cap ? 2 : (!std::strcmp(cap, "plain") ? 0 : (!std::strcmp(cap, "avx2") ? 1 : 2));
+    const int level = !cap ? 3 : (!std::strcmp(cap, "plain") ? 0 : (!std::strcmp(cap, "avx2") ? 1 : (!std::strcmp(cap, "avx512") ? 2 : 3)));
+    if (level >= 3 && __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512bw") && __builtin_cpu_supports("avx512vl") && __builtin_cpu_supports("avx512vbmi") &&
+        __builtin_cpu_supports("bmi2"))
+        return kernels{block_error_avx512, build_table_avx512, table_error_avx512, scan_history_vbmi, block_errors_avx512, load_pixels_avx512, filter_window_avx2, "avx512+vbmi"};
     if (level >= 2 && __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512bw") && __builtin_cpu_supports("avx512vl"))
         return kernels{block_error_avx512, build_table_avx512, table_error_avx512, scan_history_avx512, block_errors_avx512, load_pixels_avx512, filter_window_avx2, "avx512"};
     if (level >= 1 && __builtin_cpu_supports("avx2")) return kernels{block_error_avx2, build_table_avx2, table_error_avx2, scan_history_avx2, block_errors_avx2, load_pixels_avx2, filter_window_avx2, "avx2"};

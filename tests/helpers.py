@@ -649,3 +649,22 @@ def basis_file_key_values(data):
         out.append((kv[pos + 5:pos + 5 + kl].decode(), kv[pos + 5 + kl:pos + 5 + kl + vl]))
         pos += 5 + kl + vl
     return out
+
+
+_block_metric_host = None
+
+
+def block_metric_host():
+    """csrc/host/block_metric.h (the backend's inner loops, one variant per instruction set) compiled for the host: tests/native/block_metric_host.cpp."""
+    global _block_metric_host
+    if _block_metric_host is None:
+        d = ROOT / "tests" / "native"
+        so, srcs = d / "libblock_metric_host.so", [d / "block_metric_host.cpp", ROOT / "basis_universal_amd" / "csrc" / "host" / "block_metric.h"]
+        if not so.exists() or so.stat().st_mtime < max(s.stat().st_mtime for s in srcs):
+            subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", str(so), str(srcs[0])])
+        L = C.CDLL(str(so))
+        L.bm_variants.restype = C.c_int
+        L.bm_scan_check.restype = C.c_int
+        L.bm_scan_check.argtypes = [C.c_uint64, C.c_int, C.c_int, C.c_int]
+        _block_metric_host = L
+    return _block_metric_host

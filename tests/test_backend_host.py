@@ -203,7 +203,7 @@ def test_backend_isa_paths_agree(case, monkeypatch):
     fe.call("compress")
     arrays = _arrays(fe, blocks)
     fe.backend_run(slices, ept, selt)
-    for isa in ("plain", "avx2", "avx512"):
+    for isa in ("plain", "avx2", "avx512", "vbmi"):
         monkeypatch.setenv("BU_BACKEND_ISA", isa)
         be = Etc1sBackend.from_arrays(slices=slices, perceptual=perceptual, endpoint_rdo_thresh=ept, selector_rdo_thresh=selt, compression_level=level, **arrays)
         be.encode()
