@@ -181,6 +181,10 @@ def test_palette_reordering_matches_reference():
         if i % 4 == 1:
             idx = (rng.zipf(1.5, idx.size) % k)       # a few dominant symbols: large counts
         cases.append((f"random{i}", idx, k))
+    # the size of a real slice: thousands of symbols, neighbours drawn near each other (a block's endpoint resembles the previous block's)
+    walk = np.cumsum(rng.integers(-40, 41, 300000)) % 2500
+    cases.append(("large_walk", walk, 2500))
+    cases.append(("large_sparse", rng.integers(0, 16000, 60000), 16128))
     for name, idx, k in cases:
         idx = np.ascontiguousarray(idx, np.uint32)
         a, b = np.zeros(k, np.uint32), np.zeros(k, np.uint32)
