@@ -177,20 +177,28 @@ struct token { uint32_t value; token_kind kind; };
 }  // namespace
 
 uint16_t crc16_ccitt(const void* data, size_t size, uint16_t crc) {
-    // CRC-16/CCITT (polynomial 0x1021, MSB first) on the inverted register, byte at a time from a table
+    // CRC-16/CCITT (polynomial 0x1021, MSB first) on the inverted register. t[0] is the usual byte table; t[k][i] is the register after byte i and
+    // k zero bytes, so eight input bytes are folded in with eight independent look-ups instead of a chain of eight dependent ones (a slice's
+    // ETC1 image is 8 MB at 4096^2: 13 ms a byte at a time, which the symbol coding next to it does not hide).
     static const struct table_t {
-        uint16_t t[256];
+        uint16_t t[8][256];
         table_t() {
             for (uint32_t i = 0; i < 256; i++) {
                 uint16_t c = (uint16_t)(i << 8);
                 for (int k = 0; k < 8; k++) c = (uint16_t)((c & 0x8000) ? (c << 1) ^ 0x1021 : (c << 1));
-                t[i] = c;
+                t[0][i] = c;
             }
+            for (int k = 1; k < 8; k++)
+                for (uint32_t i = 0; i < 256; i++) t[k][i] = (uint16_t)((t[k - 1][i] << 8) ^ t[0][t[k - 1][i] >> 8]);
         }
     } T;
     crc = (uint16_t)~crc;
     const uint8_t* p = static_cast<const uint8_t*>(data);
-    for (size_t i = 0; i < size; i++) crc = (uint16_t)((crc << 8) ^ T.t[(crc >> 8) ^ p[i]]);
+    size_t i = 0;
+    for (; i + 8 <= size; i += 8)
+        crc = (uint16_t)(T.t[7][p[i] ^ (crc >> 8)] ^ T.t[6][p[i + 1] ^ (crc & 255)] ^ T.t[5][p[i + 2]] ^ T.t[4][p[i + 3]] ^ T.t[3][p[i + 4]] ^ T.t[2][p[i + 5]] ^ T.t[1][p[i + 6]] ^
+                         T.t[0][p[i + 7]]);
+    for (; i < size; i++) crc = (uint16_t)((crc << 8) ^ T.t[0][(crc >> 8) ^ p[i]]);
     return (uint16_t)~crc;
 }
 

@@ -154,7 +154,7 @@ def test_crc16_matches_reference():
     from basis_universal_amd.etc1s import load_frontend_library
     R, L = ref(), load_frontend_library()
     rng = np.random.default_rng(1)
-    for n, crc in [(0, 0), (1, 0), (8, 0), (4097, 0), (100, 0x1234), (65536, 0xFFFF)]:
+    for n, crc in [(0, 0), (1, 0), (7, 0x8001), (8, 0), (9, 0xFFFF), (15, 1), (4097, 0), (100, 0x1234), (65536, 0xFFFF)]:
         d = rng.integers(0, 256, max(n, 1), dtype=np.uint8)
         for lib in (R, L):
             for fn in ("ref_crc16", "bu_backend_test_crc16"):
