@@ -9,6 +9,7 @@
 #pragma once
 #include <immintrin.h>
 
+#include <cmath>
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
@@ -379,6 +380,16 @@ BU_VBMI inline scan_result scan_history_vbmi(const dist_table& t, const sel16& c
     }
     return scan_survivors_avx512(t, hist, todo, limit);
 }
+// The whole search of one block in one function -- pixels to metric space, distance table, the block's own error, the limit, the scan -- so that
+// pixels and table stay in registers between the steps (the generic form below goes through memory and four indirect calls).
+BU_VBMI inline scan_result history_search_vbmi(bool perceptual, const uint8_t* rgba16, const pal_colors& colors, const sel16& cur, const sel16* hist, int sad_limit, float thresh) {
+    alignas(64) block_px px;
+    load_pixels_avx512(perceptual, px, rgba16);
+    alignas(64) dist_table t;
+    build_table_avx512(perceptual, px, colors, t);
+    const uint64_t own = table_error_avx512(t, cur, UINT64_MAX);
+    return scan_history_vbmi(t, cur, hist, sad_limit, (uint64_t)ceilf(own * thresh));
+}
 #undef BU_VBMI
 
 // sum over the pixels of |selector difference| (SSE2: part of the x86-64 baseline)
@@ -396,7 +407,24 @@ inline int find_first_64(const int* v, int x) {
     return -1;
 }
 
+// history_search: what the selector walk asks per block -- the best history pattern within own error * thresh (ceilf of the float product, as the
+// reference computes its limit, backend.cpp:1051).
+#define BU_HISTORY_SEARCH(NAME, TARGET, SUFFIX) \
+    TARGET inline scan_result NAME(bool perceptual, const uint8_t* rgba16, const pal_colors& colors, const sel16& cur, const sel16* hist, int sad_limit, float thresh) { \
+        block_px px; \
+        load_pixels_##SUFFIX(perceptual, px, rgba16); \
+        dist_table t; \
+        build_table_##SUFFIX(perceptual, px, colors, t); \
+        const uint64_t own = table_error_##SUFFIX(t, cur, UINT64_MAX); \
+        return scan_history_##SUFFIX(t, cur, hist, sad_limit, (uint64_t)ceilf(own * thresh)); \
+    }
+BU_HISTORY_SEARCH(history_search_plain, , plain)
+BU_HISTORY_SEARCH(history_search_avx2, __attribute__((target("avx2"))), avx2)
+BU_HISTORY_SEARCH(history_search_avx512, __attribute__((target("avx512f,avx512bw,avx512vl,avx2"))), avx512)
+#undef BU_HISTORY_SEARCH
+
 struct kernels {
+    scan_result (*history_search)(bool, const uint8_t*, const pal_colors&, const sel16&, const sel16*, int, float);
     uint64_t (*block_error)(bool, const block_px&, const pal_colors&, const sel16&);
     void (*build_table)(bool, const block_px&, const pal_colors&, dist_table&);
     uint64_t (*table_error)(const dist_table&, const sel16&, uint64_t);
@@ -411,11 +439,11 @@ inline kernels pick_kernels() {  // BU_BACKEND_ISA = plain | avx2 | avx512 | vbm
     const int level = !cap ? 3 : (!std::strcmp(cap, "plain") ? 0 : (!std::strcmp(cap, "avx2") ? 1 : (!std::strcmp(cap, "avx512") ? 2 : 3)));
     if (level >= 3 && __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512bw") && __builtin_cpu_supports("avx512vl") && __builtin_cpu_supports("avx512vbmi") &&
         __builtin_cpu_supports("bmi2"))
-        return kernels{block_error_avx512, build_table_avx512, table_error_avx512, scan_history_vbmi, block_errors_avx512, load_pixels_avx512, filter_window_avx2, "avx512+vbmi"};
+        return kernels{history_search_vbmi, block_error_avx512, build_table_avx512, table_error_avx512, scan_history_vbmi, block_errors_avx512, load_pixels_avx512, filter_window_avx2, "avx512+vbmi"};
     if (level >= 2 && __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512bw") && __builtin_cpu_supports("avx512vl"))
-        return kernels{block_error_avx512, build_table_avx512, table_error_avx512, scan_history_avx512, block_errors_avx512, load_pixels_avx512, filter_window_avx2, "avx512"};
-    if (level >= 1 && __builtin_cpu_supports("avx2")) return kernels{block_error_avx2, build_table_avx2, table_error_avx2, scan_history_avx2, block_errors_avx2, load_pixels_avx2, filter_window_avx2, "avx2"};
-    return kernels{block_error_plain, build_table_plain, table_error_plain, scan_history_plain, block_errors_plain, load_pixels_plain, filter_window_plain, "plain"};
+        return kernels{history_search_avx512, block_error_avx512, build_table_avx512, table_error_avx512, scan_history_avx512, block_errors_avx512, load_pixels_avx512, filter_window_avx2, "avx512"};
+    if (level >= 1 && __builtin_cpu_supports("avx2")) return kernels{history_search_avx2, block_error_avx2, build_table_avx2, table_error_avx2, scan_history_avx2, block_errors_avx2, load_pixels_avx2, filter_window_avx2, "avx2"};
+    return kernels{history_search_plain, block_error_plain, build_table_plain, table_error_plain, scan_history_plain, block_errors_plain, load_pixels_plain, filter_window_plain, "plain"};
 }
 
 }  // namespace metric

@@ -1087,13 +1087,9 @@ bool etc1s_backend::encode_image() {
                 int new_selector = (int)m_selector_old_to_new[m.selector_index];
                 int history_index = (cr_target || level <= 1) ? metric::find_first_64(history.v, new_selector) : -1;
                 if (history_index == -1 && !cr_target) {
-                    block_px px;
-                    K.load_pixels(perceptual, px, &m_src.source_blocks[b].m_pixels[0][0]);
-                    metric::dist_table table;   // the block's pixels against the four colours of its final endpoints
-                    K.build_table(perceptual, px, m_palette_colors[m_endpoint_new_to_old[final_endpoint[i]]], table);
-                    const uint64_t cur_err = K.table_error(table, m_selector_bytes[m.selector_index], UINT64_MAX);
-                    const uint64_t limit_err = (uint64_t)ceilf(cur_err * selector_thresh);
-                    const metric::scan_result best = K.scan_history(table, m_selector_bytes[m.selector_index], history.sel, level <= 1 ? kSelDiffThreshold : 0, limit_err);
+                    // the block's pixels against the four colours of its final endpoints: its own error, then the history patterns within thresh * that
+                    const metric::scan_result best = K.history_search(perceptual, &m_src.source_blocks[b].m_pixels[0][0], m_palette_colors[m_endpoint_new_to_old[final_endpoint[i]]],
+                                                                      m_selector_bytes[m.selector_index], history.sel, level <= 1 ? kSelDiffThreshold : 0, selector_thresh);
                     if (best.index >= 0) { new_selector = history.v[best.index]; history_index = best.index; }
                 }
                 m.selector_index = m_selector_new_to_old[new_selector];
