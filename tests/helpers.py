@@ -666,5 +666,7 @@ def block_metric_host():
         L.bm_variants.restype = C.c_int
         L.bm_scan_check.restype = C.c_int
         L.bm_scan_check.argtypes = [C.c_uint64, C.c_int, C.c_int, C.c_int]
+        L.bm_search_check.restype = C.c_int
+        L.bm_search_check.argtypes = [C.c_uint64, C.c_int, C.c_int]
         _block_metric_host = L
     return _block_metric_host

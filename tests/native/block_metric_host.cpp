@@ -68,4 +68,43 @@ int bm_scan_check(uint64_t seed, int cases, int magnitude, int variants) {
     return bad;
 }
 
+// the fused per-block search (pixels -> table -> own error -> limit -> scan) of every variant against the plain one, on random pixels and colours
+int bm_search_check(uint64_t seed, int cases, int variants) {
+    int bad = 0;
+    uint64_t s = seed * 0x9E3779B97F4A7C15ull + 7;
+    alignas(64) sel16 hist[64];
+    for (int c = 0; c < cases; c++) {
+        const bool perceptual = rng_next(s) & 1;
+        alignas(64) uint8_t rgba[64];
+        const int spread = 1 + (int)(rng_next(s) % 255);
+        const int base[3] = {(int)(rng_next(s) & 255), (int)(rng_next(s) & 255), (int)(rng_next(s) & 255)};
+        for (int p = 0; p < 16; p++) {
+            for (int ch = 0; ch < 3; ch++) { int v = base[ch] + (int)(rng_next(s) % (uint64_t)spread) - spread / 2; rgba[p * 4 + ch] = (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v); }
+            rgba[p * 4 + 3] = 255;
+        }
+        pal_colors col;
+        for (int k = 0; k < 4; k++) {
+            const int d = (k - 2) * (int)(rng_next(s) % 60);
+            int rgb[3];
+            for (int ch = 0; ch < 3; ch++) { int v = base[ch] + d; rgb[ch] = v < 0 ? 0 : v > 255 ? 255 : v; }
+            to_metric(perceptual, rgb[0], rgb[1], rgb[2], col.x[k], col.y[k], col.z[k]);
+        }
+        sel16 cur;
+        for (int p = 0; p < 16; p++) cur.s[p] = (uint8_t)(rng_next(s) & 3);
+        for (int j = 0; j < 64; j++)
+            for (int p = 0; p < 16; p++) hist[j].s[p] = (rng_next(s) % 5 == 0) ? (uint8_t)(rng_next(s) & 3) : cur.s[p];
+        const float thresh = 1.0f + (float)(rng_next(s) % 300) / 100.0f;
+        const int sad_limit = (rng_next(s) & 1) ? 0 : 11;
+        const scan_result want = history_search_plain(perceptual, rgba, col, cur, hist, sad_limit, thresh);
+        scan_result got[3];
+        int n = 0;
+        if (variants & 2) got[n++] = history_search_avx2(perceptual, rgba, col, cur, hist, sad_limit, thresh);
+        if (variants & 4) got[n++] = history_search_avx512(perceptual, rgba, col, cur, hist, sad_limit, thresh);
+        if (variants & 8) got[n++] = history_search_vbmi(perceptual, rgba, col, cur, hist, sad_limit, thresh);
+        for (int i = 0; i < n; i++)
+            if (got[i].index != want.index || (want.index >= 0 && got[i].err != want.err)) bad++;
+    }
+    return bad;
+}
+
 }  // extern "C"

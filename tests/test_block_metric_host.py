@@ -13,3 +13,12 @@ def test_history_scan_variants_agree(magnitude):
     if have == 1:
         pytest.skip("no SIMD variant on this CPU")
     assert L.bm_scan_check(1234 + magnitude, 20000, magnitude, have) == 0
+
+
+def test_fused_block_search_variants_agree():
+    """history_search (pixels -> distance table -> own error -> limit -> scan in one call; the AVX-512 VBMI form keeps everything in registers)."""
+    L = block_metric_host()
+    have = L.bm_variants()
+    if have == 1:
+        pytest.skip("no SIMD variant on this CPU")
+    assert L.bm_search_check(99, 40000, have) == 0
