@@ -76,6 +76,7 @@ def main():
     ap.add_argument("--streams", type=int, default=1, help="images in flight per GPU (one host thread + context + HIP stream each, like the reference's "
                     "basis_parallel_compress); the default 1 is what the headline number uses")
     ap.add_argument("--no-pipelined", action="store_true", help="skip the additional 3-images-in-flight throughput measurement")
+    ap.add_argument("--backend-in-flight", type=int, default=12, help="images in flight of the frontend + host backend throughput measurement (one host thread + context each)")
     ap.add_argument("--no-uastc", action="store_true", help="skip the secondary UASTC level-2 measurement (BASELINE config #3)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend of the N > 1 launch: nccl (= RCCL over xGMI, one GPU per "
                     "rank: what the driver runs) or gloo (ranks may share a GPU: the path tests/test_gpu_bench_distributed.py drives on a one-GPU box)")
@@ -218,12 +219,13 @@ def main():
                      "note": "same work per image, three images in flight per GPU on three host threads / HIP streams (throughput mode; not the headline value)"}
     whole_encoder = None
     if args.streams <= 1 and not sharded and not args.no_pipelined and world == 1:
-        fes, dt = run_in_flight(6, 12, with_backend=True)
+        nf = max(1, args.backend_in_flight)
+        fes, dt = run_in_flight(nf, 2 * nf, with_backend=True)
         for fe in fes:
             fe.close()
-        whole_encoder = {"images_in_flight_per_gpu": 6, "images": 12, "value": round(12 * (w * h) / 1e6 / dt, 3), "unit": "Mpixels/s",
-                         "note": "frontend (GPU) + backend (host) per image = everything between the tiled input and the file writer; six images in flight on six "
-                                 "host threads / HIP streams, each backend using its own three-thread pipeline (throughput mode; not the headline value)"}
+        whole_encoder = {"images_in_flight_per_gpu": nf, "images": 2 * nf, "value": round(2 * nf * (w * h) / 1e6 / dt, 3), "unit": "Mpixels/s",
+                         "note": "frontend (GPU) + backend (host) per image = everything between the tiled input and the file writer; that many images in flight, one "
+                                 "host thread / HIP stream each, each backend walking its image on two threads (throughput mode; not the headline value)"}
     if world > 1:
         t = torch.tensor([elapsed], device=red_dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
