@@ -427,15 +427,17 @@ std::vector<uint32_t> reorder_palette_by_adjacency(const uint32_t* indices, uint
     pairs.reserve(partner.size() / 4);
     for (uint32_t a = 0; a < n; a++) {
         if (row[a] == row[a + 1]) continue;
-        for (uint32_t k = row[a]; k < row[a + 1]; k++) { const uint32_t b = partner[k]; seen[b]++; touched[b >> 6] |= 1ull << (b & 63); }
-        for (uint32_t w = a >> 6; w < touched.size(); w++)   // partners are above a
+        uint32_t top = a;
+        for (uint32_t k = row[a]; k < row[a + 1]; k++) { const uint32_t b = partner[k]; seen[b]++; touched[b >> 6] |= 1ull << (b & 63); top = std::max(top, b); }
+        for (uint32_t w = a >> 6; w <= (top >> 6); w++) {   // partners are above a
             for (uint64_t bits = touched[w]; bits; bits &= bits - 1) {
                 const uint32_t b = w * 64 + (uint32_t)__builtin_ctzll(bits);
                 pairs.push_back(pair_count{a, b, seen[b]});
                 degree[a]++; degree[b]++;
                 seen[b] = 0;
             }
-        std::fill(touched.begin() + (a >> 6), touched.end(), 0ull);
+            touched[w] = 0;
+        }
     }
     std::vector<uint32_t> first(n + 1, 0);
     for (uint32_t s = 0; s < n; s++) first[s + 1] = first[s] + degree[s];
