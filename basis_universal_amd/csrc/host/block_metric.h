@@ -382,7 +382,14 @@ BU_VBMI inline scan_result scan_history_vbmi(const dist_table& t, const sel16& c
 }
 // The whole search of one block in one function -- pixels to metric space, distance table, the block's own error, the limit, the scan -- so that
 // pixels and table stay in registers between the steps (the generic form below goes through memory and four indirect calls).
-BU_VBMI inline scan_result history_search_vbmi(bool perceptual, const uint8_t* rgba16, const pal_colors& colors, const sel16& cur, const sel16* hist, int sad_limit, float thresh) {
+BU_VBMI inline scan_result history_search_vbmi(bool perceptual, const uint8_t* rgba16, const pal_colors& colors, const sel16& cur, const sel16* hist, int sad_limit, float thresh,
+                                               const int* hist_values, int own_value) {
+    if (own_value >= 0) {   // the block's own pattern is in the history: that entry, no search (backend.cpp:1024-1034)
+        const __m512i key = _mm512_set1_epi32(own_value);
+        const uint64_t m = (uint64_t)_mm512_cmpeq_epi32_mask(_mm512_loadu_si512((const void*)hist_values), key) | ((uint64_t)_mm512_cmpeq_epi32_mask(_mm512_loadu_si512((const void*)(hist_values + 16)), key) << 16) |
+                           ((uint64_t)_mm512_cmpeq_epi32_mask(_mm512_loadu_si512((const void*)(hist_values + 32)), key) << 32) | ((uint64_t)_mm512_cmpeq_epi32_mask(_mm512_loadu_si512((const void*)(hist_values + 48)), key) << 48);
+        if (m) return scan_result{0, (int)__builtin_ctzll(m)};
+    }
     alignas(64) block_px px;
     load_pixels_avx512(perceptual, px, rgba16);
     alignas(64) dist_table t;
@@ -407,10 +414,13 @@ inline int find_first_64(const int* v, int x) {
     return -1;
 }
 
-// history_search: what the selector walk asks per block -- the best history pattern within own error * thresh (ceilf of the float product, as the
-// reference computes its limit, backend.cpp:1051).
+// history_search: what the selector walk asks per block -- the history entry that holds the block's own pattern number (own_value >= 0: levels 0 and 1
+// look for it first), else the best history pattern within own error * thresh (ceilf of the float product, as the reference computes its limit,
+// backend.cpp:1051).
 #define BU_HISTORY_SEARCH(NAME, TARGET, SUFFIX) \
-    TARGET inline scan_result NAME(bool perceptual, const uint8_t* rgba16, const pal_colors& colors, const sel16& cur, const sel16* hist, int sad_limit, float thresh) { \
+    TARGET inline scan_result NAME(bool perceptual, const uint8_t* rgba16, const pal_colors& colors, const sel16& cur, const sel16* hist, int sad_limit, float thresh, \
+                                   const int* hist_values, int own_value) { \
+        if (own_value >= 0) { const int at = find_first_64(hist_values, own_value); if (at >= 0) return scan_result{0, at}; } \
         block_px px; \
         load_pixels_##SUFFIX(perceptual, px, rgba16); \
         dist_table t; \
@@ -424,7 +434,7 @@ BU_HISTORY_SEARCH(history_search_avx512, __attribute__((target("avx512f,avx512bw
 #undef BU_HISTORY_SEARCH
 
 struct kernels {
-    scan_result (*history_search)(bool, const uint8_t*, const pal_colors&, const sel16&, const sel16*, int, float);
+    scan_result (*history_search)(bool, const uint8_t*, const pal_colors&, const sel16&, const sel16*, int, float, const int*, int);
     uint64_t (*block_error)(bool, const block_px&, const pal_colors&, const sel16&);
     void (*build_table)(bool, const block_px&, const pal_colors&, dist_table&);
     uint64_t (*table_error)(const dist_table&, const sel16&, uint64_t);

@@ -1087,11 +1087,15 @@ bool etc1s_backend::encode_image() {
                 }
                 const bool cr_target = video && m_cr_target[b];   // its selectors are what the next frame repeats: not to be traded (backend.cpp:1020, 1036)
                 int new_selector = (int)m_selector_old_to_new[m.selector_index];
-                int history_index = (cr_target || level <= 1) ? metric::find_first_64(history.v, new_selector) : -1;
-                if (history_index == -1 && !cr_target) {
-                    // the block's pixels against the four colours of its final endpoints: its own error, then the history patterns within thresh * that
+                int history_index = -1;
+                if (cr_target) {
+                    history_index = metric::find_first_64(history.v, new_selector);
+                } else {
+                    // the entry that holds the block's own pattern (levels 0 and 1 look there first); else the block's pixels against the four colours of its final
+                    // endpoints: its own error, then the history patterns within thresh * that
                     const metric::scan_result best = K.history_search(perceptual, &m_src.source_blocks[b].m_pixels[0][0], m_palette_colors[m_endpoint_new_to_old[final_endpoint[i]]],
-                                                                      m_selector_bytes[m.selector_index], history.sel, level <= 1 ? kSelDiffThreshold : 0, selector_thresh);
+                                                                      m_selector_bytes[m.selector_index], history.sel, level <= 1 ? kSelDiffThreshold : 0, selector_thresh,
+                                                                      history.v, level <= 1 ? new_selector : -1);
                     if (best.index >= 0) { new_selector = history.v[best.index]; history_index = best.index; }
                 }
                 m.selector_index = m_selector_new_to_old[new_selector];

@@ -95,12 +95,15 @@ int bm_search_check(uint64_t seed, int cases, int variants) {
             for (int p = 0; p < 16; p++) hist[j].s[p] = (rng_next(s) % 5 == 0) ? (uint8_t)(rng_next(s) & 3) : cur.s[p];
         const float thresh = 1.0f + (float)(rng_next(s) % 300) / 100.0f;
         const int sad_limit = (rng_next(s) & 1) ? 0 : 11;
-        const scan_result want = history_search_plain(perceptual, rgba, col, cur, hist, sad_limit, thresh);
+        int values[64];
+        for (int j = 0; j < 64; j++) values[j] = (int)(rng_next(s) % 40);          // small range: repeats, so that "first index" matters
+        const int own = (rng_next(s) % 3 == 0) ? -1 : (int)(rng_next(s) % 60);       // -1: no look-up; 40..59: never present
+        const scan_result want = history_search_plain(perceptual, rgba, col, cur, hist, sad_limit, thresh, values, own);
         scan_result got[3];
         int n = 0;
-        if (variants & 2) got[n++] = history_search_avx2(perceptual, rgba, col, cur, hist, sad_limit, thresh);
-        if (variants & 4) got[n++] = history_search_avx512(perceptual, rgba, col, cur, hist, sad_limit, thresh);
-        if (variants & 8) got[n++] = history_search_vbmi(perceptual, rgba, col, cur, hist, sad_limit, thresh);
+        if (variants & 2) got[n++] = history_search_avx2(perceptual, rgba, col, cur, hist, sad_limit, thresh, values, own);
+        if (variants & 4) got[n++] = history_search_avx512(perceptual, rgba, col, cur, hist, sad_limit, thresh, values, own);
+        if (variants & 8) got[n++] = history_search_vbmi(perceptual, rgba, col, cur, hist, sad_limit, thresh, values, own);
         for (int i = 0; i < n; i++)
             if (got[i].index != want.index || (want.index >= 0 && got[i].err != want.err)) bad++;
     }
