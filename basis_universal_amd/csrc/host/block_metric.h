@@ -21,6 +21,15 @@ struct alignas(64) block_px { int32_t x[16], y[16], z[16]; };     // the 16 sour
 struct alignas(16) pal_colors { int32_t x[4], y[4], z[4]; };      // the four block colours of one (colour5, intensity table)
 struct alignas(64) dist_table { uint32_t d[4][16]; };             // d[k][p]: pixel p against block colour k
 struct alignas(16) sel16 { uint8_t s[16]; };                      // 16 selectors, one per byte
+// What the history search of one block needs that does not depend on the history: filled by search_prepare (for the NEXT block, while the
+// current one is being searched), read by search_history.
+struct alignas(64) search_prep {
+    dist_table t;            // the block's pixels against the four colours of its final endpoints
+    uint8_t bound[64];       // VBMI: min(255, d >> shift), entry [k * 16 + p]: the lower-bound filter's table
+    uint8_t exact[4][64];    // VBMI: the four byte planes of d, same layout: exact sums by table look-up
+    uint64_t limit;          // ceilf(own error * thresh)
+    uint32_t shift;
+};
 
 inline void to_metric(bool perceptual, int r, int g, int b, int32_t& x, int32_t& y, int32_t& z) {
     if (perceptual) { const int l = r * 14 + g * 45 + b * 5; x = l; y = r * 64 - l; z = b * 64 - l; }
@@ -380,22 +389,87 @@ BU_VBMI inline scan_result scan_history_vbmi(const dist_table& t, const sel16& c
     }
     return scan_survivors_avx512(t, hist, todo, limit);
 }
-// The whole search of one block in one function -- pixels to metric space, distance table, the block's own error, the limit, the scan -- so that
-// pixels and table stay in registers between the steps (the generic form below goes through memory and four indirect calls).
-BU_VBMI inline scan_result history_search_vbmi(bool perceptual, const uint8_t* rgba16, const pal_colors& colors, const sel16& cur, const sel16* hist, int sad_limit, float thresh,
-                                               const int* hist_values, int own_value) {
+// The search of one block in two calls: search_prepare_vbmi -- pixels to metric space, distance table, own error, limit, the byte tables -- has no input from the
+// history, so the selector walk issues it for block i + 1 BEFORE search_history_vbmi of block i: the walk is one chain of dependent steps per block (find, filter,
+// exact sums, update), 260 cycles long when the preparation was at its head, and the core overlaps the two calls on its own once they are independent.
+BU_VBMI inline void search_prepare_vbmi(bool perceptual, const uint8_t* rgba16, const pal_colors& colors, const sel16& cur, float thresh, search_prep& out) {
+    alignas(64) block_px px;
+    load_pixels_avx512(perceptual, px, rgba16);
+    build_table_avx512(perceptual, px, colors, out.t);
+    const uint64_t own = table_error_avx512(out.t, cur, UINT64_MAX);
+    const uint64_t limit = (uint64_t)ceilf(own * thresh);
+    const int bits = 64 - (int)_lzcnt_u64(limit), shift = bits > 10 ? bits - 10 : 0;   // limit >> shift < 1024
+    out.limit = limit;
+    out.shift = (uint32_t)shift;
+    const __m128i cnt = _mm_cvtsi32_si128(shift);
+    const __m512i cap = _mm512_set1_epi32(255);
+    for (int k = 0; k < 4; k++) {
+        const __m512i d = _mm512_load_si512((const void*)out.t.d[k]);
+        _mm_store_si128((__m128i*)(out.bound + 16 * k), _mm512_cvtepi32_epi8(_mm512_min_epu32(_mm512_srl_epi32(d, cnt), cap)));
+        _mm_store_si128((__m128i*)(out.exact[0] + 16 * k), _mm512_cvtepi32_epi8(d));
+        _mm_store_si128((__m128i*)(out.exact[1] + 16 * k), _mm512_cvtepi32_epi8(_mm512_srli_epi32(d, 8)));
+        _mm_store_si128((__m128i*)(out.exact[2] + 16 * k), _mm512_cvtepi32_epi8(_mm512_srli_epi32(d, 16)));
+        _mm_store_si128((__m128i*)(out.exact[3] + 16 * k), _mm512_cvtepi32_epi8(_mm512_srli_epi32(d, 24)));
+    }
+}
+BU_VBMI inline scan_result search_history_vbmi(const search_prep& pr, const sel16& cur, const sel16* hist, int sad_limit, const int* hist_values, int own_value) {
     if (own_value >= 0) {   // the block's own pattern is in the history: that entry, no search (backend.cpp:1024-1034)
         const __m512i key = _mm512_set1_epi32(own_value);
         const uint64_t m = (uint64_t)_mm512_cmpeq_epi32_mask(_mm512_loadu_si512((const void*)hist_values), key) | ((uint64_t)_mm512_cmpeq_epi32_mask(_mm512_loadu_si512((const void*)(hist_values + 16)), key) << 16) |
                            ((uint64_t)_mm512_cmpeq_epi32_mask(_mm512_loadu_si512((const void*)(hist_values + 32)), key) << 32) | ((uint64_t)_mm512_cmpeq_epi32_mask(_mm512_loadu_si512((const void*)(hist_values + 48)), key) << 48);
         if (m) return scan_result{0, (int)__builtin_ctzll(m)};
     }
-    alignas(64) block_px px;
-    load_pixels_avx512(perceptual, px, rgba16);
-    alignas(64) dist_table t;
-    build_table_avx512(perceptual, px, colors, t);
-    const uint64_t own = table_error_avx512(t, cur, UINT64_MAX);
-    return scan_history_vbmi(t, cur, hist, sad_limit, (uint64_t)ceilf(own * thresh));
+    const uint64_t limit = pr.limit;
+    const __m512i plane = _mm512_load_si512((const void*)pr.bound);
+    const __m512i pos = _mm512_broadcast_i32x4(_mm_setr_epi8(0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15));
+    const __m512i c = _mm512_broadcast_i32x4(_mm_load_si128((const __m128i*)cur.s)), zero = _mm512_setzero_si512();
+    const __m512i bound = _mm512_set1_epi64((long long)((limit >> pr.shift) + 1) | ((long long)(sad_limit > 0 ? sad_limit : 1 << 20) << 32));
+    uint64_t pass[2] = {0, 0};   // as in scan_history_vbmi
+    for (int q = 0; q < 8; q++) {
+        const __m512i ha = _mm512_load_si512((const void*)(hist + 8 * q)), hb = _mm512_load_si512((const void*)(hist + 8 * q + 4));
+        const __m512i va = _mm512_or_si512(_mm512_sad_epu8(_mm512_permutexvar_epi8(_mm512_or_si512(_mm512_slli_epi16(ha, 4), pos), plane), zero), _mm512_slli_epi64(_mm512_sad_epu8(c, ha), 32));
+        const __m512i vb = _mm512_or_si512(_mm512_sad_epu8(_mm512_permutexvar_epi8(_mm512_or_si512(_mm512_slli_epi16(hb, 4), pos), plane), zero), _mm512_slli_epi64(_mm512_sad_epu8(c, hb), 32));
+        const uint64_t m = _mm512_cmplt_epu32_mask(_mm512_add_epi64(_mm512_unpacklo_epi64(va, vb), _mm512_unpackhi_epi64(va, vb)), bound);
+        pass[q >> 2] |= m << (16 * (q & 3));
+    }
+    uint64_t todo = 0;
+    for (int w = 0; w < 2; w++) {
+        const uint64_t ok = _pext_u64(pass[w] & (pass[w] >> 1), 0x5555555555555555ull);
+        todo |= (_pdep_u64(_pext_u64(ok, 0x55555555ull), 0x0F0F0F0Full) | _pdep_u64(_pext_u64(ok, 0xAAAAAAAAull), 0xF0F0F0F0ull)) << (32 * w);
+    }
+    if (!todo) return scan_result{UINT64_MAX, -1};
+    // The exact errors of what is left, four patterns per round: their 64 selectors are one VPERMB index register, the table's four byte planes give four
+    // registers of bytes, VPSADBW sums eight of them at a time, and the sums are put back together with shifts -- a short chain (the masked adds plus lane
+    // reduction of scan_survivors_avx512 take three times as long from first load to result, and this loop waits for nothing else).
+    const __m512i e0 = _mm512_load_si512((const void*)pr.exact[0]), e1 = _mm512_load_si512((const void*)pr.exact[1]), e2 = _mm512_load_si512((const void*)pr.exact[2]),
+                  e3 = _mm512_load_si512((const void*)pr.exact[3]);
+    const __m256i lim4 = _mm256_set1_epi64x((long long)limit);
+    __m256i best = _mm256_set1_epi64x(-1);   // per lane (error << 6) | index; all ones: nothing
+    do {
+        uint64_t j[4];
+        uint32_t n = 0;
+        for (int k = 0; k < 4; k++) {   // no branches on the number of patterns left: a spent slot repeats pattern 0 and is masked out
+            const bool live = todo != 0;
+            j[k] = live ? (uint64_t)__builtin_ctzll(todo) : 0u;
+            n += live;
+            todo &= todo - (todo != 0);
+        }
+        __m512i h = _mm512_castsi128_si512(_mm_load_si128((const __m128i*)hist[j[0]].s));
+        h = _mm512_inserti32x4(h, _mm_load_si128((const __m128i*)hist[j[1]].s), 1);
+        h = _mm512_inserti32x4(h, _mm_load_si128((const __m128i*)hist[j[2]].s), 2);
+        h = _mm512_inserti32x4(h, _mm_load_si128((const __m128i*)hist[j[3]].s), 3);
+        const __m512i idx = _mm512_or_si512(_mm512_slli_epi16(h, 4), pos);
+        const __m512i s0 = _mm512_sad_epu8(_mm512_permutexvar_epi8(idx, e0), zero), s1 = _mm512_sad_epu8(_mm512_permutexvar_epi8(idx, e1), zero),
+                      s2 = _mm512_sad_epu8(_mm512_permutexvar_epi8(idx, e2), zero), s3 = _mm512_sad_epu8(_mm512_permutexvar_epi8(idx, e3), zero);
+        const __m512i half = _mm512_add_epi64(_mm512_add_epi64(s0, _mm512_slli_epi64(s1, 8)), _mm512_add_epi64(_mm512_slli_epi64(s2, 16), _mm512_slli_epi64(s3, 24)));
+        const __m256i err = _mm512_castsi512_si256(_mm512_maskz_compress_epi64(0x55, _mm512_add_epi64(half, _mm512_bsrli_epi128(half, 8))));   // four errors
+        const __m256i key = _mm256_or_si256(_mm256_slli_epi64(err, 6), _mm256_set_epi64x((long long)j[3], (long long)j[2], (long long)j[1], (long long)j[0]));
+        const __mmask8 ok = (__mmask8)(_mm256_cmple_epu64_mask(err, lim4) & ((1u << n) - 1u));
+        best = _mm256_mask_min_epu64(best, ok, best, key);
+    } while (todo);
+    const __m128i b2 = _mm_min_epu64(_mm256_castsi256_si128(best), _mm256_extracti128_si256(best, 1));
+    const uint64_t b = (uint64_t)_mm_cvtsi128_si64(_mm_min_epu64(b2, _mm_unpackhi_epi64(b2, b2)));
+    return b == UINT64_MAX ? scan_result{UINT64_MAX, -1} : scan_result{b >> 6, (int)(b & 63)};
 }
 #undef BU_VBMI
 
@@ -414,27 +488,28 @@ inline int find_first_64(const int* v, int x) {
     return -1;
 }
 
-// history_search: what the selector walk asks per block -- the history entry that holds the block's own pattern number (own_value >= 0: levels 0 and 1
-// look for it first), else the best history pattern within own error * thresh (ceilf of the float product, as the reference computes its limit,
-// backend.cpp:1051).
-#define BU_HISTORY_SEARCH(NAME, TARGET, SUFFIX) \
-    TARGET inline scan_result NAME(bool perceptual, const uint8_t* rgba16, const pal_colors& colors, const sel16& cur, const sel16* hist, int sad_limit, float thresh, \
-                                   const int* hist_values, int own_value) { \
-        if (own_value >= 0) { const int at = find_first_64(hist_values, own_value); if (at >= 0) return scan_result{0, at}; } \
+// search_prepare / search_history: what the selector walk asks per block, in two calls (see the VBMI pair above for why two) -- the history entry that holds the
+// block's own pattern number (own_value >= 0: levels 0 and 1 look for it first), else the best history pattern within own error * thresh (ceilf of the float
+// product, as the reference computes its limit, backend.cpp:1051).
+#define BU_HISTORY_SEARCH(TARGET, SUFFIX) \
+    TARGET inline void search_prepare_##SUFFIX(bool perceptual, const uint8_t* rgba16, const pal_colors& colors, const sel16& cur, float thresh, search_prep& out) { \
         block_px px; \
         load_pixels_##SUFFIX(perceptual, px, rgba16); \
-        dist_table t; \
-        build_table_##SUFFIX(perceptual, px, colors, t); \
-        const uint64_t own = table_error_##SUFFIX(t, cur, UINT64_MAX); \
-        return scan_history_##SUFFIX(t, cur, hist, sad_limit, (uint64_t)ceilf(own * thresh)); \
+        build_table_##SUFFIX(perceptual, px, colors, out.t); \
+        out.limit = (uint64_t)ceilf(table_error_##SUFFIX(out.t, cur, UINT64_MAX) * thresh); \
+    } \
+    TARGET inline scan_result search_history_##SUFFIX(const search_prep& pr, const sel16& cur, const sel16* hist, int sad_limit, const int* hist_values, int own_value) { \
+        if (own_value >= 0) { const int at = find_first_64(hist_values, own_value); if (at >= 0) return scan_result{0, at}; } \
+        return scan_history_##SUFFIX(pr.t, cur, hist, sad_limit, pr.limit); \
     }
-BU_HISTORY_SEARCH(history_search_plain, , plain)
-BU_HISTORY_SEARCH(history_search_avx2, __attribute__((target("avx2"))), avx2)
-BU_HISTORY_SEARCH(history_search_avx512, __attribute__((target("avx512f,avx512bw,avx512vl,avx2"))), avx512)
+BU_HISTORY_SEARCH(, plain)
+BU_HISTORY_SEARCH(__attribute__((target("avx2"))), avx2)
+BU_HISTORY_SEARCH(__attribute__((target("avx512f,avx512bw,avx512vl,avx2"))), avx512)
 #undef BU_HISTORY_SEARCH
 
 struct kernels {
-    scan_result (*history_search)(bool, const uint8_t*, const pal_colors&, const sel16&, const sel16*, int, float, const int*, int);
+    void (*search_prepare)(bool, const uint8_t*, const pal_colors&, const sel16&, float, search_prep&);
+    scan_result (*search_history)(const search_prep&, const sel16&, const sel16*, int, const int*, int);
     uint64_t (*block_error)(bool, const block_px&, const pal_colors&, const sel16&);
     void (*build_table)(bool, const block_px&, const pal_colors&, dist_table&);
     uint64_t (*table_error)(const dist_table&, const sel16&, uint64_t);
@@ -449,11 +524,11 @@ inline kernels pick_kernels() {  // BU_BACKEND_ISA = plain | avx2 | avx512 | vbm
     const int level = !cap ? 3 : (!std::strcmp(cap, "plain") ? 0 : (!std::strcmp(cap, "avx2") ? 1 : (!std::strcmp(cap, "avx512") ? 2 : 3)));
     if (level >= 3 && __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512bw") && __builtin_cpu_supports("avx512vl") && __builtin_cpu_supports("avx512vbmi") &&
         __builtin_cpu_supports("bmi2"))
-        return kernels{history_search_vbmi, block_error_avx512, build_table_avx512, table_error_avx512, scan_history_vbmi, block_errors_avx512, load_pixels_avx512, filter_window_avx2, "avx512+vbmi"};
+        return kernels{search_prepare_vbmi, search_history_vbmi, block_error_avx512, build_table_avx512, table_error_avx512, scan_history_vbmi, block_errors_avx512, load_pixels_avx512, filter_window_avx2, "avx512+vbmi"};
     if (level >= 2 && __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512bw") && __builtin_cpu_supports("avx512vl"))
-        return kernels{history_search_avx512, block_error_avx512, build_table_avx512, table_error_avx512, scan_history_avx512, block_errors_avx512, load_pixels_avx512, filter_window_avx2, "avx512"};
-    if (level >= 1 && __builtin_cpu_supports("avx2")) return kernels{history_search_avx2, block_error_avx2, build_table_avx2, table_error_avx2, scan_history_avx2, block_errors_avx2, load_pixels_avx2, filter_window_avx2, "avx2"};
-    return kernels{history_search_plain, block_error_plain, build_table_plain, table_error_plain, scan_history_plain, block_errors_plain, load_pixels_plain, filter_window_plain, "plain"};
+        return kernels{search_prepare_avx512, search_history_avx512, block_error_avx512, build_table_avx512, table_error_avx512, scan_history_avx512, block_errors_avx512, load_pixels_avx512, filter_window_avx2, "avx512"};
+    if (level >= 1 && __builtin_cpu_supports("avx2")) return kernels{search_prepare_avx2, search_history_avx2, block_error_avx2, build_table_avx2, table_error_avx2, scan_history_avx2, block_errors_avx2, load_pixels_avx2, filter_window_avx2, "avx2"};
+    return kernels{search_prepare_plain, search_history_plain, block_error_plain, build_table_plain, table_error_plain, scan_history_plain, block_errors_plain, load_pixels_plain, filter_window_plain, "plain"};
 }
 
 }  // namespace metric

@@ -1075,9 +1075,20 @@ bool etc1s_backend::encode_image() {
                 }
                 selector_run.clear();
             };
+            // The part of a block's search that does not depend on the history (distance table, own error, limit: metric::search_prep) is issued one block ahead
+            // of the search itself, so that the two overlap in the core; `prepared` is the block prep[prepared & 1] holds.
+            metric::search_prep prep[2];
+            uint32_t prepared = UINT32_MAX;
+            auto searched = [&](uint32_t i) { const uint32_t b = base + i; return !(video && (m_blocks[b].endpoint_predictor == 2 || m_cr_target[b])); };
+            auto prepare = [&](uint32_t i) {
+                const uint32_t b = base + i;
+                K.search_prepare(perceptual, &m_src.source_blocks[b].m_pixels[0][0], m_palette_colors[m_endpoint_new_to_old[final_endpoint[i]]], m_selector_bytes[m_blocks[b].selector_index],
+                                 selector_thresh, prep[i & 1]);
+                prepared = i;
+            };
             uint32_t ready = 0;
             for (uint32_t i = 0; i < n; i++) {
-                if (i >= ready) ready = wait_for(done1, i + 1);
+                if (std::min(i + 2, n) > ready) ready = wait_for(done1, std::min(i + 2, n));   // the next block's final endpoint is read one block early
                 const uint32_t b = base + i;
                 encoder_block& m = m_blocks[b];
                 // ---- a recently used pattern (history buffer) that is good enough, else the block's own (backend.cpp:1011-1205)
@@ -1093,9 +1104,10 @@ bool etc1s_backend::encode_image() {
                 } else {
                     // the entry that holds the block's own pattern (levels 0 and 1 look there first); else the block's pixels against the four colours of its final
                     // endpoints: its own error, then the history patterns within thresh * that
-                    const metric::scan_result best = K.history_search(perceptual, &m_src.source_blocks[b].m_pixels[0][0], m_palette_colors[m_endpoint_new_to_old[final_endpoint[i]]],
-                                                                      m_selector_bytes[m.selector_index], history.sel, level <= 1 ? kSelDiffThreshold : 0, selector_thresh,
-                                                                      history.v, level <= 1 ? new_selector : -1);
+                    if (prepared != i) prepare(i);
+                    const metric::search_prep& mine = prep[i & 1];
+                    if (i + 1 < n && searched(i + 1)) prepare(i + 1);
+                    const metric::scan_result best = K.search_history(mine, m_selector_bytes[m.selector_index], history.sel, level <= 1 ? kSelDiffThreshold : 0, history.v, level <= 1 ? new_selector : -1);
                     if (best.index >= 0) { new_selector = history.v[best.index]; history_index = best.index; }
                 }
                 m.selector_index = m_selector_new_to_old[new_selector];

@@ -68,7 +68,7 @@ int bm_scan_check(uint64_t seed, int cases, int magnitude, int variants) {
     return bad;
 }
 
-// the fused per-block search (pixels -> table -> own error -> limit -> scan) of every variant against the plain one, on random pixels and colours
+// the per-block search (search_prepare: pixels -> table -> own error -> limit; search_history: own pattern look-up, scan) of every variant against the plain one, on random pixels and colours
 int bm_search_check(uint64_t seed, int cases, int variants) {
     int bad = 0;
     uint64_t s = seed * 0x9E3779B97F4A7C15ull + 7;
@@ -98,12 +98,14 @@ int bm_search_check(uint64_t seed, int cases, int variants) {
         int values[64];
         for (int j = 0; j < 64; j++) values[j] = (int)(rng_next(s) % 40);          // small range: repeats, so that "first index" matters
         const int own = (rng_next(s) % 3 == 0) ? -1 : (int)(rng_next(s) % 60);       // -1: no look-up; 40..59: never present
-        const scan_result want = history_search_plain(perceptual, rgba, col, cur, hist, sad_limit, thresh, values, own);
+        search_prep pr;
+        search_prepare_plain(perceptual, rgba, col, cur, thresh, pr);
+        const scan_result want = search_history_plain(pr, cur, hist, sad_limit, values, own);
         scan_result got[3];
         int n = 0;
-        if (variants & 2) got[n++] = history_search_avx2(perceptual, rgba, col, cur, hist, sad_limit, thresh, values, own);
-        if (variants & 4) got[n++] = history_search_avx512(perceptual, rgba, col, cur, hist, sad_limit, thresh, values, own);
-        if (variants & 8) got[n++] = history_search_vbmi(perceptual, rgba, col, cur, hist, sad_limit, thresh, values, own);
+        if (variants & 2) { search_prep q; search_prepare_avx2(perceptual, rgba, col, cur, thresh, q); got[n++] = search_history_avx2(q, cur, hist, sad_limit, values, own); }
+        if (variants & 4) { search_prep q; search_prepare_avx512(perceptual, rgba, col, cur, thresh, q); got[n++] = search_history_avx512(q, cur, hist, sad_limit, values, own); }
+        if (variants & 8) { search_prep q; search_prepare_vbmi(perceptual, rgba, col, cur, thresh, q); got[n++] = search_history_vbmi(q, cur, hist, sad_limit, values, own); }
         for (int i = 0; i < n; i++)
             if (got[i].index != want.index || (want.index >= 0 && got[i].err != want.err)) bad++;
     }
