@@ -16,7 +16,7 @@ def test_history_scan_variants_agree(magnitude):
 
 
 def test_fused_block_search_variants_agree():
-    """history_search (pixels -> distance table -> own error -> limit -> scan in one call; the AVX-512 VBMI form keeps everything in registers)."""
+    """search_prepare + search_history (pixels -> distance table -> own error -> limit; own-pattern look-up -> filter -> exact sums): the two calls the selector walk makes per block."""
     L = block_metric_host()
     have = L.bm_variants()
     if have == 1:
