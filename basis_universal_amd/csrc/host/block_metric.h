@@ -341,16 +341,26 @@ BU_AVX512 inline scan_result scan_history_avx512(const dist_table& t, const sel1
     }
     return scan_survivors_avx512(t, hist, todo, limit);
 }
+// the 16 pixels against one candidate's colours under the block's selectors
+BU_AVX512 inline __m512i candidate_distances_avx512(bool perceptual, __m512i x, __m512i y, __m512i z, __m512i idx, const pal_colors& c) {
+    const __m512i cx = _mm512_castsi128_si512(_mm_load_si128((const __m128i*)c.x)), cy = _mm512_castsi128_si512(_mm_load_si128((const __m128i*)c.y)),
+                  cz = _mm512_castsi128_si512(_mm_load_si128((const __m128i*)c.z));
+    return dist16(perceptual, _mm512_sub_epi32(x, _mm512_permutexvar_epi32(idx, cx)), _mm512_sub_epi32(y, _mm512_permutexvar_epi32(idx, cy)), _mm512_sub_epi32(z, _mm512_permutexvar_epi32(idx, cz)));
+}
 BU_AVX512 inline void block_errors_avx512(bool perceptual, const block_px& px, const sel16& sel, const pal_colors* colors, const int* which, int n, uint64_t* out) {
     const __m512i idx = _mm512_cvtepu8_epi32(_mm_load_si128((const __m128i*)sel.s));
     const __m512i x = _mm512_load_si512((const void*)px.x), y = _mm512_load_si512((const void*)px.y), z = _mm512_load_si512((const void*)px.z);
-    for (int i = 0; i < n; i++) {
-        const pal_colors& c = colors[which[i]];
-        const __m512i cx = _mm512_castsi128_si512(_mm_load_si128((const __m128i*)c.x)), cy = _mm512_castsi128_si512(_mm_load_si128((const __m128i*)c.y)),
-                      cz = _mm512_castsi128_si512(_mm_load_si128((const __m128i*)c.z));
-        out[i] = (uint32_t)_mm512_reduce_add_epi32(dist16(perceptual, _mm512_sub_epi32(x, _mm512_permutexvar_epi32(idx, cx)), _mm512_sub_epi32(y, _mm512_permutexvar_epi32(idx, cy)),
-                                                          _mm512_sub_epi32(z, _mm512_permutexvar_epi32(idx, cz))));
+    int i = 0;
+    for (; i + 4 <= n; i += 4) {   // four candidates share one lane reduction (as in scan_survivors_avx512)
+        const __m512i a0 = candidate_distances_avx512(perceptual, x, y, z, idx, colors[which[i]]), a1 = candidate_distances_avx512(perceptual, x, y, z, idx, colors[which[i + 1]]),
+                      a2 = candidate_distances_avx512(perceptual, x, y, z, idx, colors[which[i + 2]]), a3 = candidate_distances_avx512(perceptual, x, y, z, idx, colors[which[i + 3]]);
+        const __m512i t0 = _mm512_add_epi32(_mm512_unpacklo_epi32(a0, a1), _mm512_unpackhi_epi32(a0, a1));
+        const __m512i t1 = _mm512_add_epi32(_mm512_unpacklo_epi32(a2, a3), _mm512_unpackhi_epi32(a2, a3));
+        const __m512i u = _mm512_add_epi32(_mm512_unpacklo_epi64(t0, t1), _mm512_unpackhi_epi64(t0, t1));
+        const __m256i v = _mm256_add_epi32(_mm512_castsi512_si256(u), _mm512_extracti64x4_epi64(u, 1));
+        _mm256_storeu_si256((__m256i*)(out + i), _mm256_cvtepu32_epi64(_mm_add_epi32(_mm256_castsi256_si128(v), _mm256_extracti128_si256(v, 1))));
     }
+    for (; i < n; i++) out[i] = (uint32_t)_mm512_reduce_add_epi32(candidate_distances_avx512(perceptual, x, y, z, idx, colors[which[i]]));
 }
 #undef BU_AVX512
 
