@@ -411,16 +411,22 @@ BU_VBMI inline void search_prepare_vbmi(bool perceptual, const uint8_t* rgba16, 
     const int bits = 64 - (int)_lzcnt_u64(limit), shift = bits > 10 ? bits - 10 : 0;   // limit >> shift < 1024
     out.limit = limit;
     out.shift = (uint32_t)shift;
-    const __m128i cnt = _mm_cvtsi32_si128(shift);
-    const __m512i cap = _mm512_set1_epi32(255);
-    for (int k = 0; k < 4; k++) {
-        const __m512i d = _mm512_load_si512((const void*)out.t.d[k]);
-        _mm_store_si128((__m128i*)(out.bound + 16 * k), _mm512_cvtepi32_epi8(_mm512_min_epu32(_mm512_srl_epi32(d, cnt), cap)));
-        _mm_store_si128((__m128i*)(out.exact[0] + 16 * k), _mm512_cvtepi32_epi8(d));
-        _mm_store_si128((__m128i*)(out.exact[1] + 16 * k), _mm512_cvtepi32_epi8(_mm512_srli_epi32(d, 8)));
-        _mm_store_si128((__m128i*)(out.exact[2] + 16 * k), _mm512_cvtepi32_epi8(_mm512_srli_epi32(d, 16)));
-        _mm_store_si128((__m128i*)(out.exact[3] + 16 * k), _mm512_cvtepi32_epi8(_mm512_srli_epi32(d, 24)));
+    // the table's byte planes: plane b = byte b of the 64 distances in table order, two two-source byte permutes (32 distances each) per plane
+    const __m512i d0 = _mm512_load_si512((const void*)out.t.d[0]), d1 = _mm512_load_si512((const void*)out.t.d[1]), d2 = _mm512_load_si512((const void*)out.t.d[2]),
+                  d3 = _mm512_load_si512((const void*)out.t.d[3]);
+    alignas(64) static const struct pick_t {
+        uint8_t at[4][64];   // at[b][i]: byte b of dword i of the 128-byte pair (i < 32); the upper half is not used
+        pick_t() { for (int b = 0; b < 4; b++) for (int i = 0; i < 64; i++) at[b][i] = (uint8_t)(((i & 31) * 4 + b) & 127); }
+    } pick;
+    for (int b = 0; b < 4; b++) {
+        const __m512i ix = _mm512_load_si512((const void*)pick.at[b]);
+        _mm512_store_si512((void*)out.exact[b], _mm512_inserti64x4(_mm512_permutex2var_epi8(d0, ix, d1), _mm512_castsi512_si256(_mm512_permutex2var_epi8(d2, ix, d3)), 1));
     }
+    const __m128i cnt = _mm_cvtsi32_si128(shift);
+    const __m512i cap = _mm512_set1_epi32(255), ix0 = _mm512_load_si512((const void*)pick.at[0]);
+    const __m512i q0 = _mm512_min_epu32(_mm512_srl_epi32(d0, cnt), cap), q1 = _mm512_min_epu32(_mm512_srl_epi32(d1, cnt), cap), q2 = _mm512_min_epu32(_mm512_srl_epi32(d2, cnt), cap),
+                  q3 = _mm512_min_epu32(_mm512_srl_epi32(d3, cnt), cap);
+    _mm512_store_si512((void*)out.bound, _mm512_inserti64x4(_mm512_permutex2var_epi8(q0, ix0, q1), _mm512_castsi512_si256(_mm512_permutex2var_epi8(q2, ix0, q3)), 1));
 }
 BU_VBMI inline scan_result search_history_vbmi(const search_prep& pr, const sel16& cur, const sel16* hist, int sad_limit, const int* hist_values, int own_value) {
     if (own_value >= 0) {   // the block's own pattern is in the history: that entry, no search (backend.cpp:1024-1034)
