@@ -909,7 +909,9 @@ bool etc1s_backend::encode_image() {
         slice_stats(uint32_t n_sel_syms, uint32_t n_ep_syms) : selector_hist(n_sel_syms, 0), rle_hist(kSelectorRleCountTotal, 0), delta_hist(n_ep_syms, 0), pred_hist(kEndpointPredSymbols, 0) {}
     };
     std::vector<slice_stats> stats(m_slices.size(), slice_stats(n_sel + kSelectorHistorySize + 1, n_ep));
-    std::vector<std::vector<token>> slice_tokens(m_slices.size());
+    // a slice's symbols stay where the two walks put them -- per block: predictor, endpoint delta, selector, each possibly absent -- and are coded from there in that order
+    struct slice_symbols { std::vector<token> pred, delta, sel; };
+    std::vector<slice_symbols> slice_tokens(m_slices.size());
     std::vector<uint32_t> block_endpoint_indices(m_src.total_blocks, 0), block_selector_indices(m_src.total_blocks, 0);
     const metric::kernels K = metric::pick_kernels();
     const float selector_thresh = std::max(1.0f, m_params.m_selector_rdo_quality_thresh);
@@ -958,7 +960,10 @@ bool etc1s_backend::encode_image() {
                 if (video && m_cr_target[base + bx + by * nbx]) referenced[bx + (size_t)by * nbx] = 1;
             }
         // the symbols of a block, by producer; a run's symbol sits on the block that opens the run (placeholders patched when it closes)
-        std::vector<token> pred_tok(n, token{0, T_NONE}), delta_tok(n, token{0, T_NONE}), sel_tok(n, token{0, T_NONE});
+        std::vector<token>& pred_tok = slice_tokens[si].pred;
+        std::vector<token>& delta_tok = slice_tokens[si].delta;
+        std::vector<token>& sel_tok = slice_tokens[si].sel;
+        pred_tok.assign(n, token{0, T_NONE}); delta_tok.assign(n, token{0, T_NONE}); sel_tok.assign(n, token{0, T_NONE});
         std::vector<uint32_t> final_endpoint(n, 0);  // NEW palette index per block once loop 1 has passed it
         const bool pipelined = may_pipeline && n >= kPipelineMinBlocks;
         std::atomic<uint32_t> done1{0};
@@ -1140,19 +1145,9 @@ bool etc1s_backend::encode_image() {
             timed(selectors_loop, d3);
         }
         { std::lock_guard<std::mutex> g(loop_time_lock); loop_times[0] += d1; loop_times[2] += d3; }
-        timer merge_timer;
-        // the slice's symbols in bit-stream order: predictor, endpoint delta, selector of every block in turn
-        std::vector<token>& tokens = slice_tokens[si];
-        tokens.reserve((size_t)n * 2 + 16);
-        for (uint32_t i = 0; i < n; i++) {
-            if (pred_tok[i].kind != T_NONE) tokens.push_back(pred_tok[i]);
-            if (delta_tok[i].kind != T_NONE) tokens.push_back(delta_tok[i]);
-            if (sel_tok[i].kind != T_NONE) tokens.push_back(sel_tok[i]);
-        }
-        { std::lock_guard<std::mutex> g(loop_time_lock); loop_times[3] += merge_timer.seconds(); }
     });
     sub_time("~ei/endpoints_loop", loop_times[0]); sub_time("~ei/selectors_loop", loop_times[2]);
-    sub_time("~ei/token_merge", loop_times[3]); sub_time("~ei/walks_wall", walks_timer.seconds());
+    sub_time("~ei/walks_wall", walks_timer.seconds());
     timer coding_timer;
     std::vector<uint32_t> selector_hist(n_sel + kSelectorHistorySize + 1, 0), rle_hist(kSelectorRleCountTotal, 0), delta_hist(n_ep, 0), pred_hist(kEndpointPredSymbols, 0);
     uint32_t endpoints_remapped = 0;
@@ -1192,46 +1187,48 @@ bool etc1s_backend::encode_image() {
     w.flush();
     m_output.m_slice_image_tables = w.bytes();
     m_output.m_slice_image_data.assign(m_slices.size(), std::vector<uint8_t>());
-    auto code_tokens = [&](const token* t, const token* end, bit_writer& w) {
-        for (; t != end; ++t) {
-            switch (t->kind) {
-            case T_NONE: break;
-            case T_PRED: w.put_code(t->value, pred_model); break;
-            case T_PRED_REPEAT: w.put_code(kEndpointPredRepeatLast, pred_model); w.put_vlc(t->value - kEndpointPredMinRepeat, kEndpointPredCountVlcBits); break;
-            case T_ENDPOINT_DELTA: w.put_code(t->value, delta_model); break;
-            case T_SELECTOR: w.put_code(t->value, selector_model); break;
-            case T_SELECTOR_RLE: {
-                w.put_code(kHistRleSym, selector_model);
-                const uint32_t run = t->value - kSelectorRleThresh;
-                if (run >= kSelectorRleCountTotal - 1) { w.put_code(kSelectorRleCountTotal - 1, rle_model); w.put_vlc(run, 7); }
-                else w.put_code(run, rle_model);
-                break;
-            }
-            }
+    auto code_token = [&](const token& t, bit_writer& w) {
+        switch (t.kind) {
+        case T_NONE: break;
+        case T_PRED: w.put_code(t.value, pred_model); break;
+        case T_PRED_REPEAT: w.put_code(kEndpointPredRepeatLast, pred_model); w.put_vlc(t.value - kEndpointPredMinRepeat, kEndpointPredCountVlcBits); break;
+        case T_ENDPOINT_DELTA: w.put_code(t.value, delta_model); break;
+        case T_SELECTOR: w.put_code(t.value, selector_model); break;
+        case T_SELECTOR_RLE: {
+            w.put_code(kHistRleSym, selector_model);
+            const uint32_t run = t.value - kSelectorRleThresh;
+            if (run >= kSelectorRleCountTotal - 1) { w.put_code(kSelectorRleCountTotal - 1, rle_model); w.put_vlc(run, 7); }
+            else w.put_code(run, rle_model);
+            break;
+        }
         }
     };
+    auto code_blocks = [&](const slice_symbols& s, size_t first, size_t end, bit_writer& w) {   // bit-stream order: predictor, endpoint delta, selector of every block in turn
+        for (size_t i = first; i < end; i++) { code_token(s.pred[i], w); code_token(s.delta[i], w); code_token(s.sel[i], w); }
+    };
     for_each_slice(m_slices, [&](size_t si) {
-        const std::vector<token>& toks = slice_tokens[si];
+        const slice_symbols& syms = slice_tokens[si];
+        const size_t blocks = syms.sel.size();
         // a long slice is coded in pieces on the host threads and the pieces' bits are joined in order (the symbols are independent of each other once the models exist)
-        const unsigned pieces = host_single_threaded() ? 1u : (unsigned)std::min<size_t>(8, toks.size() / 32768);
+        const unsigned pieces = host_single_threaded() ? 1u : (unsigned)std::min<size_t>(8, blocks / 16384);
         bit_writer w;
         if (pieces <= 1) {
-            w.restart(toks.size() + 64);
-            code_tokens(toks.data(), toks.data() + toks.size(), w);
+            w.restart(blocks * 3 + 64);
+            code_blocks(syms, 0, blocks, w);
         } else {
             std::vector<bit_writer> part(pieces);
             std::vector<std::thread> pool;
-            const size_t per = (toks.size() + pieces - 1) / pieces;
+            const size_t per = (blocks + pieces - 1) / pieces;
             for (unsigned k = 0; k < pieces; k++)
                 pool.emplace_back([&, k] {
-                    const size_t a = std::min(toks.size(), k * per), b = std::min(toks.size(), a + per);
+                    const size_t a = std::min(blocks, k * per), b = std::min(blocks, a + per);
                     bit_writer local;   // on this thread's stack: the writers' accumulators are touched per symbol, and neighbours in one array would share cache lines
-                    local.restart(b - a + 64);
-                    code_tokens(toks.data() + a, toks.data() + b, local);
+                    local.restart((b - a) * 3 + 64);
+                    code_blocks(syms, a, b, local);
                     part[k] = std::move(local);
                 });
             for (std::thread& th : pool) th.join();
-            w.restart(toks.size() + 64);
+            w.restart(blocks * 3 + 64);
             for (unsigned k = 0; k < pieces; k++) w.append(part[k]);
         }
         w.flush();
