@@ -102,6 +102,7 @@ _SIGNATURES = {
     "bu_hip_tsvq_create": (_vp, [_vp, _u32, _vp, _vp, _u32, _vp]),
     "bu_hip_tsvq_create_packed16": (_vp, [_vp, _vp, _vp, _u32, _vp]),
     "bu_hip_tsvq_split": (_int, [_vp, _vp, _vp, _u32, _vp]),
+    "bu_hip_tsvq_roots": (_int, [_vp, _vp, _vp, _u32, _vp]),
     "bu_hip_tsvq_read_members": (_int, [_vp, _vp, _u32, _u32, _u32, _vp]),
     "bu_hip_tsvq_destroy": (None, [_vp, _vp]),
 }

@@ -1070,6 +1070,42 @@ int bu_hip_tsvq_split(bu_hip_context* ctx, bu_tsvq* q, const bu_tsvq_node* h_nod
     return 1;
 }
 
+// prepare_root (enc.h:1708-1735) of member spans: what a tree_vector_quant whose training set is that span, in list order, starts from --
+// the roots of the T independent trees of generate_hierarchical_codebook_threaded_internal (enc.h:2137-2152).
+int bu_hip_tsvq_roots(bu_hip_context* ctx, bu_tsvq* q, const bu_tsvq_node* h_nodes, uint32_t n_nodes, bu_tsvq_root* h_out) {
+    if (!ctx || !q || (n_nodes && (!h_nodes || !h_out))) return 0;
+    if (!n_nodes) return 1;
+    device_guard g(ctx->device);
+    if ((size_t)n_nodes * sizeof(bu_tsvq_node) > q->nodes.cap) { set_error(ctx, "tsvq_roots: %u spans exceed the record buffer", n_nodes); return 0; }
+    for (uint32_t i = 0; i < n_nodes; i++)
+        if (h_nodes[i].buf > 1 || !h_nodes[i].count || (uint64_t)h_nodes[i].start + h_nodes[i].count > q->n) { set_error(ctx, "tsvq_roots: span outside the training set"); return 0; }
+    BU_TRY(ctx, hipStreamSynchronize(ctx->stream));   // the pinned staging buffer may still feed an earlier copy
+    BU_TRY(ctx, q->reserve_pinned((size_t)n_nodes * std::max(sizeof(bu_tsvq_node), sizeof(bu_tsvq_root))));
+    std::vector<uint32_t> todo(n_nodes);
+    for (uint32_t i = 0; i < n_nodes; i++) todo[i] = i;
+    // the exact (integer-reduced) variant first where it applies; a record flagged pad == 1 left the exact range -> the chained one
+    for (int attempt = (q->packed && !q->force_chained) ? 0 : 1; attempt < 2 && !todo.empty(); attempt++) {
+        bu_tsvq_node* pn = static_cast<bu_tsvq_node*>(q->pinned);
+        for (size_t j = 0; j < todo.size(); j++) pn[j] = h_nodes[todo[j]];
+        BU_TRY(ctx, hipMemcpyAsync(q->nodes.p, q->pinned, todo.size() * sizeof(bu_tsvq_node), hipMemcpyHostToDevice, ctx->stream));
+        {
+            prof_scope ps(ctx, q->packed ? "tsvq_root_packed16" : "tsvq_root_float6");
+            BU_TRY(ctx, bu::launch_tsvq_span_roots(ctx->stream, (int)q->dim, q->packed, attempt == 0, q->rows, q->w64, q->perm[0], q->perm[1],
+                                                   static_cast<const bu::tsvq_node_in*>(q->nodes.p), (uint32_t)todo.size(), static_cast<bu::tsvq_root_out*>(q->outs.p)));
+        }
+        BU_TRY(ctx, hipMemcpyAsync(q->pinned, q->outs.p, todo.size() * sizeof(bu_tsvq_root), hipMemcpyDeviceToHost, ctx->stream));
+        BU_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        const bu_tsvq_root* po = static_cast<const bu_tsvq_root*>(q->pinned);
+        std::vector<uint32_t> redo;
+        for (size_t j = 0; j < todo.size(); j++) {
+            if (attempt == 0 && po[j].pad) redo.push_back(todo[j]);
+            else h_out[todo[j]] = po[j];
+        }
+        todo.swap(redo);
+    }
+    return 1;
+}
+
 static_assert(sizeof(bu_tsvq_span) == sizeof(bu::bk_span), "layout");
 int bu_hip_tsvq_scatter_spans(bu_hip_context* ctx, bu_tsvq* q, const bu_tsvq_span* h_spans, uint32_t n_spans, uint32_t* d_out) {
     if (!ctx || !q || (n_spans && (!h_spans || !d_out))) return 0;

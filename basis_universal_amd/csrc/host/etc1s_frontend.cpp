@@ -401,7 +401,8 @@ bool etc1s_frontend::generate_endpoint_clusters() {
     } else
     if (!device_tsvq::hierarchical_codebook(m_dev->ctx, 6, m_endpoint_unique_rows, m_endpoint_unique_weights, groups, m_params.m_max_endpoint_clusters,
                                             m_use_hierarchical_endpoint_codebooks ? parent_size : 0, unused, m_endpoint_parent_clusters, nullptr,
-                                            &m_endpoint_parent_of_unique, &m_endpoint_parent_count, &leaf_of_unique, &m_endpoint_cluster_count, m_has_comm ? &m_comm : nullptr))
+                                            &m_endpoint_parent_of_unique, &m_endpoint_parent_count, &leaf_of_unique, &m_endpoint_cluster_count, m_has_comm ? &m_comm : nullptr,
+                                            m_params.m_codebook_threads))
         return fail("endpoint TSVQ failed");
     // The clustering is kept as (cluster, position in the cluster's list) per block, RESIDENT: the distinct vectors' leaves, parents and list
     // offsets go up (a few thousand words), the per-block arrays are written by the device. A leaf lists its distinct vectors ascending and
@@ -952,7 +953,7 @@ bool etc1s_frontend::generate_selector_clusters() {
     if (!device_tsvq::hierarchical_codebook_packed16_device(d.ctx, (const uint32_t*)d.sel_ukeys.p, (const uint64_t*)d.sel_uw.p, u_total, groups, m_params.m_max_selector_clusters,
                                                             hier ? parent_size : 0, m_selector_cluster_block_indices, m_selector_parent_cluster_block_indices, &ts, nullptr,
                                                             &m_selector_parent_count, nullptr, &m_selector_cluster_count, (uint32_t*)d.tmp_a.p, (uint32_t*)d.tmp_b.p,
-                                                            m_has_comm ? &m_comm : nullptr))
+                                                            m_has_comm ? &m_comm : nullptr, m_params.m_codebook_threads))
         return fail("selector TSVQ failed");
     m_stage_times.push_back(stage_time{"~gsc/tsvq_create", ts.t_create});
     m_stage_times.push_back(stage_time{"~gsc/tsvq_device", ts.t_device});

@@ -42,6 +42,10 @@ public:
         // bit-identical to the reference: different codebooks (deterministic), held to the reference's size / PSNR tolerances. Off by default.
         bool m_fast_codebooks = false;
         uint32_t m_fast_codebook_iterations = 4;
+        // What the reference computes from m_multithreaded and its job pool (frontend.cpp:873-876, 2195-2198): min(hardware threads, 8, pool size), or 0
+        // when not multithreaded. From 262,144 distinct training vectors up (enc.h:2316) a value T > 1 makes both codebook builders partition their
+        // tree T ways (enc.h:2086-2215) -- the tool's DEFAULT output on a machine with T threads; 0 / 1 = the tool under -no_multithreading.
+        uint32_t m_codebook_threads = 0;
         bu_hip_context* m_pHIP_context = nullptr;         // = m_pOpenCL_context; REQUIRED
     };
 

@@ -27,6 +27,7 @@ struct bu_frontend {
     bool video = false;
     bool fast_codebooks = false;
     uint32_t fast_iterations = 4;
+    uint32_t codebook_threads = 0;
 };
 
 namespace {
@@ -73,6 +74,7 @@ int bu_frontend_init(bu_frontend* f, bu_hip_context* ctx, const bu_pixel_block* 
     p.m_video = f->video;
     p.m_fast_codebooks = f->fast_codebooks;
     p.m_fast_codebook_iterations = f->fast_iterations;
+    p.m_codebook_threads = f->codebook_threads;
     return f->fe.init(p) ? 1 : 0;
 } BU_CATCH(0)
 
@@ -89,6 +91,15 @@ int bu_frontend_set_fast_codebooks(bu_frontend* f, int on, uint32_t iterations) 
     if (iterations) f->fast_iterations = iterations;
     return 1;
 } BU_CATCH(0)
+
+int bu_frontend_set_max_threads(bu_frontend* f, uint32_t max_threads) try { if (!f) return 0; f->codebook_threads = max_threads; return 1; } BU_CATCH(0)
+uint32_t bu_frontend_reference_max_threads(int multithreaded, uint32_t hardware_threads, uint32_t job_pool_threads) {
+    if (!multithreaded) return 0;
+    if (!hardware_threads) hardware_threads = std::max(1u, std::thread::hardware_concurrency());   // get_num_hardware_threads(), enc.h
+    uint32_t t = std::min<uint32_t>(hardware_threads, 8u);                                           // cMaxCodebookCreationThreads, frontend.cpp:35
+    if (job_pool_threads) t = std::min(t, job_pool_threads);
+    return t;
+}
 
 int bu_frontend_compress(bu_frontend* f) try { return (f && f->fe.compress()) ? 1 : 0; } BU_CATCH(0)
 
@@ -168,14 +179,19 @@ uint32_t bu_frontend_stage_times(const bu_frontend* f, const char** names, doubl
 // Test hook for the host TSVQ (tsvq.h): rows must be DISTINCT and ascending (the order the reference's std::map yields).
 // Blobs are [n, off_0..off_n, idx...] u32, like bu_frontend_get's cluster lists. Returns 1, 0 on failure, -1 if a blob does not fit.
 int bu_host_tsvq(uint32_t dim, const float* rows, const uint64_t* weights, uint32_t n, uint32_t max_codebook_size, uint32_t max_parent_codebook_size,
-                 uint32_t* out_codebook, uint64_t cap_codebook_words, uint32_t* out_parent, uint64_t cap_parent_words) try {
+                 uint32_t* out_codebook, uint64_t cap_codebook_words, uint32_t* out_parent, uint64_t cap_parent_words) {
+    return bu_host_tsvq_mt(dim, rows, weights, n, max_codebook_size, max_parent_codebook_size, 0, 0, out_codebook, cap_codebook_words, out_parent, cap_parent_words);
+}
+int bu_host_tsvq_mt(uint32_t dim, const float* rows, const uint64_t* weights, uint32_t n, uint32_t max_codebook_size, uint32_t max_parent_codebook_size,
+                    uint32_t max_threads, uint32_t min_unique_for_threads, uint32_t* out_codebook, uint64_t cap_codebook_words, uint32_t* out_parent, uint64_t cap_parent_words) try {
+    if (!min_unique_for_threads) min_unique_for_threads = bu::kThreadedCodebookMinUnique;
     std::vector<float> r(rows, rows + (size_t)n * dim);
     std::vector<uint64_t> w(weights, weights + n);
     std::vector<std::vector<uint32_t>> groups(n), codebook, parents;
     for (uint32_t i = 0; i < n; i++) groups[i].push_back(i);
     bool ok = false;
-    if (dim == 6) ok = bu::hierarchical_codebook<6>(r, w, groups, max_codebook_size, max_parent_codebook_size, codebook, parents);
-    else if (dim == 16) ok = bu::hierarchical_codebook<16>(r, w, groups, max_codebook_size, max_parent_codebook_size, codebook, parents);
+    if (dim == 6) ok = bu::hierarchical_codebook<6>(r, w, groups, max_codebook_size, max_parent_codebook_size, codebook, parents, max_threads, min_unique_for_threads);
+    else if (dim == 16) ok = bu::hierarchical_codebook<16>(r, w, groups, max_codebook_size, max_parent_codebook_size, codebook, parents, max_threads, min_unique_for_threads);
     if (!ok) return 0;
     const std::vector<uint32_t> a = csr_blob(codebook), b = csr_blob(parents);
     if (a.size() > cap_codebook_words || b.size() > cap_parent_words) return -1;
@@ -186,7 +202,13 @@ int bu_host_tsvq(uint32_t dim, const float* rows, const uint64_t* weights, uint3
 
 // The same through the device TSVQ (tsvq_device.h + bu_hip_tsvq_*): what the frontend actually uses. stats3 = {rounds, splits computed, splits used}.
 int bu_device_tsvq(bu_hip_context* ctx, uint32_t dim, const float* rows, const uint64_t* weights, uint32_t n, uint32_t max_codebook_size, uint32_t max_parent_codebook_size,
-                   uint32_t* out_codebook, uint64_t cap_codebook_words, uint32_t* out_parent, uint64_t cap_parent_words, uint32_t* stats3) try {
+                   uint32_t* out_codebook, uint64_t cap_codebook_words, uint32_t* out_parent, uint64_t cap_parent_words, uint32_t* stats3) {
+    return bu_device_tsvq_mt(ctx, dim, rows, weights, n, max_codebook_size, max_parent_codebook_size, 0, 0, out_codebook, cap_codebook_words, out_parent, cap_parent_words, stats3);
+}
+int bu_device_tsvq_mt(bu_hip_context* ctx, uint32_t dim, const float* rows, const uint64_t* weights, uint32_t n, uint32_t max_codebook_size, uint32_t max_parent_codebook_size,
+                      uint32_t max_threads, uint32_t min_unique_for_threads, uint32_t* out_codebook, uint64_t cap_codebook_words, uint32_t* out_parent, uint64_t cap_parent_words,
+                      uint32_t* stats3) try {
+    if (!min_unique_for_threads) min_unique_for_threads = bu::kThreadedCodebookMinUnique;
     std::vector<float> r(rows, rows + (size_t)n * dim);
     std::vector<uint64_t> w(weights, weights + n);
     std::vector<std::vector<uint32_t>> groups(n), codebook, parents;
@@ -197,8 +219,10 @@ int bu_device_tsvq(bu_hip_context* ctx, uint32_t dim, const float* rows, const u
     if (packable && (stats3 && stats3[0] == 0xBACCED)) { // caller asked for the packed selector path
         std::vector<uint32_t> keys(n, 0);
         for (uint32_t i = 0; i < n; i++) for (uint32_t k = 0; k < 16; k++) keys[i] = (keys[i] << 2) | (uint32_t)r[(size_t)i * 16 + k];
-        if (!bu::device_tsvq::hierarchical_codebook_packed16(ctx, keys, w, bu::vec_groups{&groups}, max_codebook_size, max_parent_codebook_size, codebook, parents, &st)) return 0;
-    } else if (!bu::device_tsvq::hierarchical_codebook(ctx, dim, r, w, bu::vec_groups{&groups}, max_codebook_size, max_parent_codebook_size, codebook, parents, &st)) return 0;
+        if (!bu::device_tsvq::hierarchical_codebook_packed16(ctx, keys, w, bu::vec_groups{&groups}, max_codebook_size, max_parent_codebook_size, codebook, parents, &st,
+                                                             max_threads, min_unique_for_threads)) return 0;
+    } else if (!bu::device_tsvq::hierarchical_codebook(ctx, dim, r, w, bu::vec_groups{&groups}, max_codebook_size, max_parent_codebook_size, codebook, parents, &st,
+                                                       nullptr, nullptr, nullptr, nullptr, nullptr, max_threads, min_unique_for_threads)) return 0;
     if (stats3) { stats3[0] = st.rounds; stats3[1] = st.splits_computed; stats3[2] = st.splits_used; }
     const std::vector<uint32_t> a = csr_blob(codebook), b = csr_blob(parents);
     if (a.size() > cap_codebook_words || b.size() > cap_parent_words) return -1;

@@ -352,19 +352,59 @@ private:
     uint32_t next_codebook_index_ = 0;
 };
 
-// generate_hierarchical_codebook_threaded (enc.h:2218-2354) in its single-threaded configuration (the parity-pinned one,
-// SURVEY hazard H1): `unique_rows` are the DISTINCT training vectors in ascending lexicographic order with their summed
-// weights; `groups[u]` lists the original training-vector indices that carry unique vector u, ascending.
+// The thread count generate_hierarchical_codebook_threaded hands to its _internal half (enc.h:2316): the T-way partition is only
+// taken from 262,144 distinct vectors up. `max_threads` is what the frontend computes (frontend.cpp:2195-2198): min(hardware threads,
+// 8, job pool size) when multithreaded, else 0.
+constexpr uint32_t kThreadedCodebookMinUnique = 65536 * 4;
+constexpr uint32_t kThreadedCodebookMaxThreads = 16;   // cMaxThreads, enc.h:2111
+inline uint32_t codebook_partitions(uint32_t n_unique, uint32_t max_codebook_size, uint32_t max_threads, uint32_t min_unique = kThreadedCodebookMinUnique) {
+    if (n_unique < min_unique) max_threads = 1;                                                          // enc.h:2316
+    if (max_threads <= 1 || n_unique < 256 || max_codebook_size < max_threads * 16) return 1;           // enc.h:2097
+    return std::min(max_threads, kThreadedCodebookMaxThreads);
+}
+
+// generate_hierarchical_codebook_threaded (enc.h:2218-2354): `unique_rows` are the DISTINCT training vectors in ascending
+// lexicographic order with their summed weights; `groups[u]` lists the original training-vector indices that carry unique vector u,
+// ascending. max_threads <= 1 is the single-threaded configuration. With T = codebook_partitions() > 1 the reference
+// (generate_hierarchical_codebook_threaded_internal, enc.h:2086-2215) first builds a T-leaf tree, then one INDEPENDENT tree per leaf
+// over that leaf's members in list order (own root, own variance queue, ceil(K / T) leaves and ceil(P / T) parents each) and
+// concatenates the results in leaf order: deterministic for a given T, whatever the threads' timing.
 template <int N>
 bool hierarchical_codebook(const std::vector<float>& unique_rows, const std::vector<uint64_t>& unique_weights,
                            const std::vector<std::vector<uint32_t>>& groups, uint32_t max_codebook_size, uint32_t max_parent_codebook_size,
-                           std::vector<std::vector<uint32_t>>& codebook, std::vector<std::vector<uint32_t>>& parent_codebook) {
+                           std::vector<std::vector<uint32_t>>& codebook, std::vector<std::vector<uint32_t>>& parent_codebook,
+                           uint32_t max_threads = 0, uint32_t min_unique_for_threads = kThreadedCodebookMinUnique) {
+    const uint32_t n = (uint32_t)unique_weights.size();
+    const uint32_t T = codebook_partitions(n, max_codebook_size, max_threads, min_unique_for_threads);
     tsvq<N> q;
-    q.set_training(unique_rows.data(), unique_weights.data(), (uint32_t)unique_weights.size());
-    if (!q.generate(max_codebook_size)) return false;
+    q.set_training(unique_rows.data(), unique_weights.data(), n);
+    if (!q.generate(T > 1 ? T : max_codebook_size)) return false;
     std::vector<std::vector<uint32_t>> group_codebook, group_parents;
     q.leaves(group_codebook);
-    if (max_parent_codebook_size) q.top_clusters(max_parent_codebook_size, group_parents);
+    if (T > 1 && group_codebook.size() >= T) {
+        const bool limit = n > max_codebook_size;   // limit_clusterizers, enc.h:2305-2307
+        std::vector<std::vector<uint32_t>> initial;
+        initial.swap(group_codebook);
+        for (uint32_t t = 0; t < T; t++) {
+            const std::vector<uint32_t>& members = initial[t];
+            std::vector<float> rows(members.size() * N);
+            std::vector<uint64_t> weights(members.size());
+            for (size_t i = 0; i < members.size(); i++) {
+                std::memcpy(&rows[i * N], &unique_rows[(size_t)members[i] * N], sizeof(float) * N);
+                weights[i] = unique_weights[members[i]];
+            }
+            tsvq<N> lq;
+            lq.set_training(rows.data(), weights.data(), (uint32_t)members.size());
+            if (!lq.generate(limit ? (max_codebook_size + T - 1) / T : (uint32_t)members.size())) return false;
+            std::vector<std::vector<uint32_t>> local, local_parents;
+            lq.leaves(local);
+            if (max_parent_codebook_size) lq.top_clusters((max_parent_codebook_size + T - 1) / T, local_parents);
+            for (auto* lists : {&local, &local_parents})
+                for (auto& l : *lists) for (uint32_t& m : l) m = members[m];
+            for (auto& l : local) group_codebook.emplace_back(std::move(l));
+            for (auto& l : local_parents) group_parents.emplace_back(std::move(l));
+        }
+    } else if (max_parent_codebook_size) q.top_clusters(max_parent_codebook_size, group_parents);
     auto expand = [&](const std::vector<std::vector<uint32_t>>& in, std::vector<std::vector<uint32_t>>& out) {
         out.clear();
         out.resize(in.size());

@@ -6,6 +6,9 @@
 // priority queue until it reaches a node whose split is not known yet, then asks the device to split every such candidate in
 // the queue at once (bounded by the number of splits still needed), and resumes the replay. Speculative results that the
 // replay never reaches are simply dropped, so the final tree is the reference's tree.
+//
+// The reference's multi-threaded configuration (generate_hierarchical_codebook_threaded_internal, enc.h:2086-2215; the tool's default) builds
+// a T-leaf tree and then T independent trees, one per leaf: here those T trees share every device round (run_trees), see build().
 #pragma once
 #include <algorithm>
 #include <atomic>
@@ -66,25 +69,29 @@ public:
                                       const Groups& groups, uint32_t max_codebook_size, uint32_t max_parent_codebook_size,
                                       std::vector<std::vector<uint32_t>>& codebook, std::vector<std::vector<uint32_t>>& parent_codebook, stats* st = nullptr,
                                       std::vector<uint32_t>* parent_of_unique = nullptr, uint32_t* parent_count = nullptr,
-                                      std::vector<uint32_t>* leaf_of_unique = nullptr, uint32_t* leaf_count = nullptr, const bu_comm* comm = nullptr) {
+                                      std::vector<uint32_t>* leaf_of_unique = nullptr, uint32_t* leaf_count = nullptr, const bu_comm* comm = nullptr,
+                                      uint32_t max_threads = 0, uint32_t min_unique_for_threads = kThreadedCodebookMinUnique) {
         bu_tsvq_root root;
         const auto t0 = std::chrono::steady_clock::now();
         bu_tsvq* q = weights.empty() ? nullptr : bu_hip_tsvq_create(ctx, dim, rows.data(), weights.data(), (uint32_t)weights.size(), &root);
         if (st) st->t_create = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         return q && build(ctx, q, root, (uint32_t)weights.size(), groups, max_codebook_size, max_parent_codebook_size, codebook, parent_codebook, st, parent_of_unique, parent_count,
-                          leaf_of_unique, leaf_count, nullptr, nullptr, comm);
+                          leaf_of_unique, leaf_count, nullptr, nullptr, comm,
+                          codebook_partitions((uint32_t)weights.size(), max_codebook_size, max_threads, min_unique_for_threads));
     }
 
     // Selector vectors: keys[u] packs the 16 selector values of distinct vector u (value 0 in the top two bits), ascending.
     template <class Groups>
     static bool hierarchical_codebook_packed16(bu_hip_context* ctx, const std::vector<uint32_t>& keys, const std::vector<uint64_t>& weights,
                                                const Groups& groups, uint32_t max_codebook_size, uint32_t max_parent_codebook_size,
-                                               std::vector<std::vector<uint32_t>>& codebook, std::vector<std::vector<uint32_t>>& parent_codebook, stats* st = nullptr) {
+                                               std::vector<std::vector<uint32_t>>& codebook, std::vector<std::vector<uint32_t>>& parent_codebook, stats* st = nullptr,
+                                               uint32_t max_threads = 0, uint32_t min_unique_for_threads = kThreadedCodebookMinUnique) {
         bu_tsvq_root root;
         const auto t0 = std::chrono::steady_clock::now();
         bu_tsvq* q = weights.empty() ? nullptr : bu_hip_tsvq_create_packed16(ctx, keys.data(), weights.data(), (uint32_t)weights.size(), &root);
         if (st) st->t_create = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-        return q && build(ctx, q, root, (uint32_t)weights.size(), groups, max_codebook_size, max_parent_codebook_size, codebook, parent_codebook, st);
+        return q && build(ctx, q, root, (uint32_t)weights.size(), groups, max_codebook_size, max_parent_codebook_size, codebook, parent_codebook, st, nullptr, nullptr, nullptr,
+                          nullptr, nullptr, nullptr, nullptr, codebook_partitions((uint32_t)weights.size(), max_codebook_size, max_threads, min_unique_for_threads));
     }
 
     // The same with the distinct vectors already resident (outputs of bu_hip_k_unique_selector_vectors): nothing is uploaded.
@@ -94,13 +101,15 @@ public:
                                                       std::vector<std::vector<uint32_t>>& parent_codebook, stats* st = nullptr,
                                                       std::vector<uint32_t>* parent_of_unique = nullptr, uint32_t* parent_count = nullptr,
                                                       std::vector<uint32_t>* leaf_of_unique = nullptr, uint32_t* leaf_count = nullptr,
-                                                      uint32_t* d_leaf_of_unique = nullptr, uint32_t* d_parent_of_unique = nullptr, const bu_comm* comm = nullptr) {
+                                                      uint32_t* d_leaf_of_unique = nullptr, uint32_t* d_parent_of_unique = nullptr, const bu_comm* comm = nullptr,
+                                                      uint32_t max_threads = 0, uint32_t min_unique_for_threads = kThreadedCodebookMinUnique) {
         bu_tsvq_root root;
         const auto t0 = std::chrono::steady_clock::now();
         bu_tsvq* q = n_unique ? bu_hip_tsvq_create_packed16_device(ctx, d_keys, d_weights, n_unique, &root) : nullptr;
         if (st) st->t_create = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         return q && build(ctx, q, root, n_unique, groups, max_codebook_size, max_parent_codebook_size, codebook, parent_codebook, st, parent_of_unique, parent_count,
-                          leaf_of_unique, leaf_count, d_leaf_of_unique, d_parent_of_unique, comm);
+                          leaf_of_unique, leaf_count, d_leaf_of_unique, d_parent_of_unique, comm,
+                          codebook_partitions(n_unique, max_codebook_size, max_threads, min_unique_for_threads));
     }
 
     // parent lists from a parent-of-unique map (what build() would have produced): vectors ascending inside a parent, members group by group
@@ -147,56 +156,35 @@ private:
         }
     }
 
-    template <class Groups>
-    static bool build(bu_hip_context* ctx, bu_tsvq* q, const bu_tsvq_root& root, uint32_t n, const Groups& groups,
-                      uint32_t max_codebook_size, uint32_t max_parent_codebook_size, std::vector<std::vector<uint32_t>>& codebook,
-                      std::vector<std::vector<uint32_t>>& parent_codebook, stats* st, std::vector<uint32_t>* parent_of_unique = nullptr,
-                      uint32_t* parent_count = nullptr, std::vector<uint32_t>* leaf_of_unique = nullptr, uint32_t* leaf_count = nullptr,
-                      uint32_t* d_leaf_of_unique = nullptr, uint32_t* d_parent_of_unique = nullptr, const bu_comm* comm = nullptr) {
-        if (parent_of_unique) parent_of_unique->clear();
-        if (parent_count) *parent_count = 0;
-        if (leaf_of_unique) leaf_of_unique->clear();
-        if (leaf_count) *leaf_count = 0;
-        struct guard { bu_hip_context* c; bu_tsvq* q; ~guard() { bu_hip_tsvq_destroy(c, q); } } g{ctx, q};
-        const bool dbg_serial = std::getenv("BU_TSVQ_SERIAL") != nullptr, dbg_verify = std::getenv("BU_TSVQ_VERIFY") != nullptr;   // once per tree, not per round
-
-        struct node {
-            float var; uint64_t weight; float origin[16];
-            int32_t left = -1, right = -1; int codebook_index = -1;
-            uint32_t buf, start, count;
-            int32_t cached = -1; // index into `cache`
-        };
+    // One tree of the build: the reference's node table + variance queue (enc.h:1616-1660), with the splits it has been handed so far.
+    struct node {
+        float var; uint64_t weight; float origin[16];
+        int32_t left = -1, right = -1; int codebook_index = -1;
+        uint32_t buf, start, count;
+        int32_t cached = -1; // index into the split cache
+    };
+    struct tree {
         std::vector<node> nodes;
-        std::vector<bu_tsvq_split> cache;
-        nodes.reserve((size_t)max_codebook_size * 2 + 1);
-        {
-            node r; r.var = root.var; r.weight = root.weight; std::memcpy(r.origin, root.origin, sizeof(r.origin));
-            r.buf = 0; r.start = 0; r.count = n;
-            nodes.push_back(r);
-        }
         variance_heap heap;
-        heap.reset(0, nodes[0].var);
-        uint32_t leaves = 1, next_codebook_index = 0;
-        stats local;
-        if (st) local.t_create = st->t_create;
-        auto now = [] { return std::chrono::steady_clock::now(); };
-        auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
-        const auto t_loop0 = now();
-        std::vector<bu_tsvq_node> batch;
-        std::vector<uint32_t> batch_nodes;
-        std::vector<std::pair<float, uint32_t>> pending;
-
-        while (heap.size() && leaves < max_codebook_size) {
-            // ---- replay generate()'s loop (enc.h:1636-1655) while the splits it needs are known
-            bool stalled = false;
-            while (heap.size() && leaves < max_codebook_size) {
+        uint32_t leaves = 1, next_codebook_index = 0, max_leaves = 0;
+        void reset(const bu_tsvq_root& root, uint32_t buf, uint32_t start, uint32_t count, uint32_t max_leaves_) {
+            nodes.clear(); nodes.reserve((size_t)std::min<uint64_t>(max_leaves_, count) * 2 + 1);
+            node r; r.var = root.var; r.weight = root.weight; std::memcpy(r.origin, root.origin, sizeof(r.origin));
+            r.buf = buf; r.start = start; r.count = count;
+            nodes.push_back(r);
+            heap.reset(0, r.var);
+            leaves = 1; next_codebook_index = 0; max_leaves = max_leaves_;
+        }
+        // generate()'s loop (enc.h:1636-1655) while the splits it needs are known; true = it stopped at a node whose split is not known yet
+        bool replay(const std::vector<bu_tsvq_split>& cache, uint32_t& splits_used) {
+            while (heap.size() && leaves < max_leaves) {
                 const uint32_t ni = heap.top_index();
-                if (nodes[ni].count > 1 && nodes[ni].cached < 0) { stalled = true; break; }
+                if (nodes[ni].count > 1 && nodes[ni].cached < 0) return true;
                 heap.pop();
                 if (nodes[ni].count <= 1) continue;
                 const bu_tsvq_split& s = cache[(size_t)nodes[ni].cached];
                 if (!s.ok) continue; // prep_split / refine_split returned false: the node stays a leaf
-                local.splits_used++;
+                splits_used++;
                 const uint32_t li = (uint32_t)nodes.size(), ri = li + 1;
                 nodes[ni].left = (int32_t)li; nodes[ni].right = (int32_t)ri;
                 nodes[ni].codebook_index = (int)next_codebook_index++;
@@ -214,27 +202,64 @@ private:
                 if (r.var > 0.0f && r.count > 1) heap.push(ri, r.var);
                 leaves++;
             }
-            if (!stalled) break;
-            // ---- one device round: every queued node whose split is unknown, largest variance first, at most as many as
-            //      there are splits left to do
+            return false;
+        }
+        // every queued node whose split is unknown, largest variance first, at most as many as there are splits left to do.
+        // The queue's top is among them (it is the maximum) -- otherwise the replay could not advance.
+        void pending_nodes(std::vector<std::pair<float, uint32_t>>& pending) const {
             pending.clear();
             for (uint32_t i = 1; i <= heap.size(); i++) {
                 const uint32_t ni = heap.entry_index(i);
                 if (nodes[ni].count > 1 && nodes[ni].cached < 0) pending.emplace_back(heap.entry_priority(i), ni);
             }
-            const size_t want = std::min<size_t>(pending.size(), (size_t)(max_codebook_size - leaves));
+            const size_t want = std::min<size_t>(pending.size(), (size_t)(max_leaves - leaves));
             if (want < pending.size()) {
                 std::nth_element(pending.begin(), pending.begin() + want, pending.end(), [](const std::pair<float, uint32_t>& a, const std::pair<float, uint32_t>& b) { return a.first > b.first || (a.first == b.first && a.second < b.second); });
                 pending.resize(want);
             }
-            // the queue's top must be among them (it is the maximum) -- otherwise the replay could not advance
-            batch.clear(); batch_nodes.clear();
-            for (const auto& p : pending) {
-                const node& nd = nodes[p.second];
-                bu_tsvq_node b; std::memset(&b, 0, sizeof(b));
-                b.buf = nd.buf; b.start = nd.start; b.count = nd.count; b.weight = nd.weight; std::memcpy(b.origin, nd.origin, sizeof(b.origin));
-                batch.push_back(b); batch_nodes.push_back(p.second);
+        }
+        // retrieve(max_clusters) (enc.h:1598-1628): cut the tree after its first max_clusters-1 splits, depth first, left before right;
+        // cut(ni) is called for every cut node in that order
+        template <class F> void cuts(uint32_t max_clusters, F&& cut) const {
+            std::vector<uint32_t> stack;
+            uint32_t ni = 0;
+            for (;;) {
+                const node& cur = nodes[ni];
+                if (cur.left < 0 || (2 + cur.codebook_index) > (int)max_clusters) {
+                    cut(ni);
+                    if (stack.empty()) break;
+                    ni = stack.back(); stack.pop_back();
+                    continue;
+                }
+                stack.push_back((uint32_t)cur.right);
+                ni = (uint32_t)cur.left;
             }
+        }
+    };
+
+    // Splits every tree of `trees` to its leaf budget: each device round takes the pending nodes of ALL trees (they are independent), so
+    // the T sub-trees of the partitioned build fill a round T times as well as one tree does.
+    static bool run_trees(bu_hip_context* ctx, bu_tsvq* q, std::vector<tree*>& trees, std::vector<bu_tsvq_split>& cache, stats& local, const bu_comm* comm,
+                          bool dbg_serial, bool dbg_verify) {
+        auto now = [] { return std::chrono::steady_clock::now(); };
+        auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+        std::vector<bu_tsvq_node> batch;
+        std::vector<std::pair<uint32_t, uint32_t>> batch_nodes;   // (tree, node)
+        std::vector<std::pair<float, uint32_t>> pending;
+        for (;;) {
+            batch.clear(); batch_nodes.clear();
+            for (uint32_t t = 0; t < trees.size(); t++) {
+                tree& tr = *trees[t];
+                if (!tr.replay(cache, local.splits_used)) continue;
+                tr.pending_nodes(pending);
+                for (const auto& p : pending) {
+                    const node& nd = tr.nodes[p.second];
+                    bu_tsvq_node b; std::memset(&b, 0, sizeof(b));
+                    b.buf = nd.buf; b.start = nd.start; b.count = nd.count; b.weight = nd.weight; std::memcpy(b.origin, nd.origin, sizeof(b.origin));
+                    batch.push_back(b); batch_nodes.emplace_back(t, p.second);
+                }
+            }
+            if (batch.empty()) return true;
             const size_t base = cache.size();
             cache.resize(base + batch.size());
             if (comm && comm->world > 1 && batch.size() > 1) {
@@ -276,66 +301,115 @@ private:
                 local.t_device += secs(td, now());
             }
             if (dbg_verify) verify_batch(ctx, q, batch, cache.data() + base, local.rounds);
-            for (size_t i = 0; i < batch.size(); i++) nodes[batch_nodes[i]].cached = (int32_t)(base + i);
+            for (size_t i = 0; i < batch.size(); i++) trees[batch_nodes[i].first]->nodes[batch_nodes[i].second].cached = (int32_t)(base + i);
             local.rounds++; local.splits_computed += (uint32_t)batch.size();
+        }
+    }
+
+    template <class Groups>
+    static bool build(bu_hip_context* ctx, bu_tsvq* q, const bu_tsvq_root& root, uint32_t n, const Groups& groups,
+                      uint32_t max_codebook_size, uint32_t max_parent_codebook_size, std::vector<std::vector<uint32_t>>& codebook,
+                      std::vector<std::vector<uint32_t>>& parent_codebook, stats* st, std::vector<uint32_t>* parent_of_unique = nullptr,
+                      uint32_t* parent_count = nullptr, std::vector<uint32_t>* leaf_of_unique = nullptr, uint32_t* leaf_count = nullptr,
+                      uint32_t* d_leaf_of_unique = nullptr, uint32_t* d_parent_of_unique = nullptr, const bu_comm* comm = nullptr,
+                      uint32_t partitions = 1) {
+        if (parent_of_unique) parent_of_unique->clear();
+        if (parent_count) *parent_count = 0;
+        if (leaf_of_unique) leaf_of_unique->clear();
+        if (leaf_count) *leaf_count = 0;
+        struct guard { bu_hip_context* c; bu_tsvq* q; ~guard() { bu_hip_tsvq_destroy(c, q); } } g{ctx, q};
+        const bool dbg_serial = std::getenv("BU_TSVQ_SERIAL") != nullptr, dbg_verify = std::getenv("BU_TSVQ_VERIFY") != nullptr;   // once per tree, not per round
+
+        stats local;
+        if (st) local.t_create = st->t_create;
+        auto now = [] { return std::chrono::steady_clock::now(); };
+        auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+        const auto t_loop0 = now();
+        std::vector<bu_tsvq_split> cache;
+
+        // ---- the tree, or -- partitions = T > 1, generate_hierarchical_codebook_threaded_internal (enc.h:2086-2215) -- a T-leaf tree first and then
+        //      one independent tree per leaf over that leaf's members: own root record (prepare_root over the span, bu_hip_tsvq_roots), own queue,
+        //      ceil(K / T) leaves (all of the span's vectors when the codebook is not limited, enc.h:2150) and ceil(P / T) parents each
+        const uint32_t T = partitions > 1 ? partitions : 1;
+        tree top;
+        top.reset(root, 0, 0, n, T > 1 ? T : max_codebook_size);
+        std::vector<tree> subs;
+        std::vector<tree*> active{&top};
+        if (!run_trees(ctx, q, active, cache, local, comm, dbg_serial, dbg_verify)) return false;
+        std::vector<const tree*> final_trees{&top};
+        std::vector<uint32_t> final_parents{max_parent_codebook_size};
+        if (T > 1) {
+            std::vector<bu_tsvq_node> spans;
+            for (const node& nd : top.nodes)
+                if (nd.left < 0) { bu_tsvq_node b; std::memset(&b, 0, sizeof(b)); b.buf = nd.buf; b.start = nd.start; b.count = nd.count; spans.push_back(b); }
+            if (spans.size() >= T) {   // enc.h:2122: fewer leaves than threads -> the T-leaf tree is the result
+                std::vector<bu_tsvq_root> roots(spans.size());
+                const auto td = now();
+                if (!bu_hip_tsvq_roots(ctx, q, spans.data(), (uint32_t)spans.size(), roots.data())) return false;
+                local.t_device += secs(td, now());
+                const bool limit = n > max_codebook_size;   // limit_clusterizers, enc.h:2305-2307
+                subs.resize(spans.size());
+                active.clear(); final_trees.clear(); final_parents.clear();
+                for (size_t t = 0; t < spans.size(); t++) {
+                    subs[t].reset(roots[t], spans[t].buf, spans[t].start, spans[t].count, limit ? (max_codebook_size + T - 1) / T : spans[t].count);
+                    active.push_back(&subs[t]); final_trees.push_back(&subs[t]);
+                    final_parents.push_back(max_parent_codebook_size ? (max_parent_codebook_size + T - 1) / T : 0);
+                }
+                if (!run_trees(ctx, q, active, cache, local, comm, dbg_serial, dbg_verify)) return false;
+            }
         }
         const auto t_loop1 = now();
         local.t_replay = secs(t_loop0, t_loop1) - local.t_device;
         struct fin { stats* st; stats* local; std::chrono::steady_clock::time_point t; ~fin() { local->t_expand = std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count(); if (st) *st = *local; } } fin_{st, &local, t_loop1};
 
-        // ---- resident form: the leaf (and parent) of every distinct vector is written by the device from the leaves' spans of the member
-        //      buffers; no member list leaves HBM. Leaves in node order (enc.h:1573-1584), parents = retrieve(max_clusters) (enc.h:1598-1628).
-        if (d_leaf_of_unique) {
-            std::vector<bu_tsvq_span> spans;
-            std::vector<int32_t> leaf_id(nodes.size(), -1);
-            for (size_t ni = 0; ni < nodes.size(); ni++) {
-                if (nodes[ni].left >= 0) continue;
-                leaf_id[ni] = (int32_t)spans.size();
-                spans.push_back(bu_tsvq_span{nodes[ni].buf, nodes[ni].start, nodes[ni].count, (uint32_t)spans.size()});
-            }
-            if (leaf_count) *leaf_count = (uint32_t)spans.size();
-            if (!bu_hip_tsvq_scatter_spans(ctx, q, spans.data(), (uint32_t)spans.size(), d_leaf_of_unique)) return false;
-            if (parent_count) *parent_count = 0;
-            if (max_parent_codebook_size && d_parent_of_unique) {
-                uint32_t cuts = 0;
-                std::vector<uint32_t> stack, sub;
-                uint32_t ni = 0;
-                for (;;) {
-                    const node& cur = nodes[ni];
-                    if (cur.left < 0 || (2 + cur.codebook_index) > (int)max_parent_codebook_size) {
-                        sub.assign(1, ni);
-                        while (!sub.empty()) {
-                            const uint32_t x = sub.back(); sub.pop_back();
-                            if (nodes[x].left < 0) spans[(size_t)leaf_id[x]].value = cuts;
-                            else { sub.push_back((uint32_t)nodes[x].left); sub.push_back((uint32_t)nodes[x].right); }
-                        }
-                        cuts++;
-                        if (stack.empty()) break;
-                        ni = stack.back(); stack.pop_back();
-                        continue;
-                    }
-                    stack.push_back((uint32_t)cur.right);
-                    ni = (uint32_t)cur.left;
+        // ---- leaves in node order (enc.h:1573-1584), tree after tree (enc.h:2196-2210); parents = retrieve(max_clusters) of every tree
+        //      (enc.h:1598-1628), likewise. Leaf segments are intact in their buffers and ascending.
+        std::vector<bu_tsvq_span> spans;      // value: the leaf's parent (cut) index
+        uint32_t cuts = 0;
+        {
+            std::vector<int32_t> leaf_id;
+            std::vector<uint32_t> sub;
+            for (size_t ti = 0; ti < final_trees.size(); ti++) {
+                const tree& tr = *final_trees[ti];
+                leaf_id.assign(tr.nodes.size(), -1);
+                for (size_t ni = 0; ni < tr.nodes.size(); ni++) {
+                    if (tr.nodes[ni].left >= 0) continue;
+                    leaf_id[ni] = (int32_t)spans.size();
+                    spans.push_back(bu_tsvq_span{tr.nodes[ni].buf, tr.nodes[ni].start, tr.nodes[ni].count, 0});
                 }
+                if (!final_parents[ti]) continue;
+                tr.cuts(final_parents[ti], [&](uint32_t ni) {
+                    sub.assign(1, ni);
+                    while (!sub.empty()) {   // all leaves below this cut node
+                        const uint32_t x = sub.back(); sub.pop_back();
+                        if (tr.nodes[x].left < 0) spans[(size_t)leaf_id[x]].value = cuts;
+                        else { sub.push_back((uint32_t)tr.nodes[x].left); sub.push_back((uint32_t)tr.nodes[x].right); }
+                    }
+                    cuts++;
+                });
+            }
+        }
+        if (leaf_count) *leaf_count = (uint32_t)spans.size();
+
+        // ---- resident form: the leaf (and parent) of every distinct vector is written by the device from the leaves' spans of the member
+        //      buffers; no member list leaves HBM.
+        if (d_leaf_of_unique) {
+            if (max_parent_codebook_size && d_parent_of_unique) {
                 if (!bu_hip_tsvq_scatter_spans(ctx, q, spans.data(), (uint32_t)spans.size(), d_parent_of_unique)) return false;
                 if (parent_count) *parent_count = cuts;
             }
+            for (size_t l = 0; l < spans.size(); l++) spans[l].value = (uint32_t)l;
+            if (!bu_hip_tsvq_scatter_spans(ctx, q, spans.data(), (uint32_t)spans.size(), d_leaf_of_unique)) return false;
             codebook.clear(); parent_codebook.clear();
             return true;
         }
 
-        // ---- leaves in node order (enc.h:1573-1584). Leaf segments are intact in their buffers and ascending.
         std::vector<uint32_t> perm[2];
         perm[0].resize(n); perm[1].resize(n);
         if (!bu_hip_tsvq_read_members(ctx, q, 0, 0, n, perm[0].data()) || !bu_hip_tsvq_read_members(ctx, q, 1, 0, n, perm[1].data())) return false;
-        std::vector<int32_t> leaf_of_node(nodes.size(), -1);
         struct span { const uint32_t* p; uint32_t n; };
         std::vector<span> leaf_members;
-        for (size_t ni = 0; ni < nodes.size(); ni++) {
-            if (nodes[ni].left >= 0) continue;
-            leaf_of_node[ni] = (int32_t)leaf_members.size();
-            leaf_members.push_back(span{perm[nodes[ni].buf].data() + nodes[ni].start, nodes[ni].count});
-        }
+        for (const bu_tsvq_span& s : spans) leaf_members.push_back(span{perm[s.buf].data() + s.start, s.count});
         // distinct vectors -> the training vectors behind them, list by list
         auto expand_one = [&](const uint32_t* us, size_t count, std::vector<uint32_t>& out) {
             size_t total = 0;
@@ -348,7 +422,6 @@ private:
             }
         };
         codebook.clear();
-        if (leaf_count) *leaf_count = (uint32_t)leaf_members.size();
         if (leaf_of_unique) {  // the caller keeps "which cluster does every distinct vector belong to" and builds lists only when asked
             leaf_of_unique->resize(n);
             for (size_t l = 0; l < leaf_members.size(); l++)
@@ -358,40 +431,18 @@ private:
             std::atomic<size_t> next{0};
             auto work = [&] { for (size_t i; (i = next.fetch_add(1)) < leaf_members.size();) expand_one(leaf_members[i].p, leaf_members[i].n, codebook[i]); };
             std::vector<std::thread> th;
-            const unsigned T = n > 65536 ? host_threads() : 1;
-            for (unsigned t = 1; t < T; t++) th.emplace_back(work);
+            const unsigned TH = n > 65536 ? host_threads() : 1;
+            for (unsigned t = 1; t < TH; t++) th.emplace_back(work);
             work();
             for (auto& x : th) x.join();
         }
 
         parent_codebook.clear();
         if (max_parent_codebook_size) {
-            // retrieve(max_clusters) (enc.h:1598-1628): cut the tree after its first max_clusters-1 splits, depth first, left before right.
-            // Every node's member list is the ascending union of its leaves, so assign each leaf to its cut node and sweep the vectors in order.
-            std::vector<uint32_t> cut_of_leaf(leaf_members.size(), 0);
-            uint32_t cuts = 0;
-            std::vector<uint32_t> stack, sub;
-            uint32_t ni = 0;
-            for (;;) {
-                const node& cur = nodes[ni];
-                if (cur.left < 0 || (2 + cur.codebook_index) > (int)max_parent_codebook_size) {
-                    sub.assign(1, ni);
-                    while (!sub.empty()) { // all leaves below this cut node
-                        const uint32_t x = sub.back(); sub.pop_back();
-                        if (nodes[x].left < 0) cut_of_leaf[(size_t)leaf_of_node[x]] = cuts;
-                        else { sub.push_back((uint32_t)nodes[x].left); sub.push_back((uint32_t)nodes[x].right); }
-                    }
-                    cuts++;
-                    if (stack.empty()) break;
-                    ni = stack.back(); stack.pop_back();
-                    continue;
-                }
-                stack.push_back((uint32_t)cur.right);
-                ni = (uint32_t)cur.left;
-            }
+            // Every cut node's member list is the ascending union of its leaves: sweep the vectors in order.
             std::vector<uint32_t> cut_of_vec(n);
             for (size_t l = 0; l < leaf_members.size(); l++)
-                for (uint32_t i = 0; i < leaf_members[l].n; i++) cut_of_vec[leaf_members[l].p[i]] = cut_of_leaf[l];
+                for (uint32_t i = 0; i < leaf_members[l].n; i++) cut_of_vec[leaf_members[l].p[i]] = spans[l].value;
             if (parent_of_unique) {  // the caller only wants "which parent does every distinct vector belong to": lists on demand (expand_parents)
                 parent_of_unique->swap(cut_of_vec);
                 if (parent_count) *parent_count = cuts;
@@ -407,8 +458,8 @@ private:
                 std::atomic<uint32_t> next{0};
                 auto work = [&] { for (uint32_t c; (c = next.fetch_add(1)) < cuts;) expand_one(sorted.data() + cut_ofs[c], cut_ofs[c + 1] - cut_ofs[c], parent_codebook[c]); };
                 std::vector<std::thread> th;
-                const unsigned T = n > 65536 ? host_threads() : 1;
-                for (unsigned t = 1; t < T; t++) th.emplace_back(work);
+                const unsigned TH = n > 65536 ? host_threads() : 1;
+                for (unsigned t = 1; t < TH; t++) th.emplace_back(work);
                 work();
                 for (auto& x : th) x.join();
             }

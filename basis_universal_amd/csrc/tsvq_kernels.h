@@ -15,6 +15,9 @@ struct tsvq_split_out { uint32_t ok, l_count, r_count, pad; uint64_t l_weight, r
 // exact: use the integer-reduction variants for the double accumulators (packed rows only; see exact_acc). A root record with pad == 1 /
 // a split record with ok == 2 means the data left the exact range: run that item again with exact == false.
 hipError_t launch_tsvq_root(hipStream_t st, int dim, bool packed, bool exact, const void* d_rows, const uint64_t* d_w64, uint32_t n, uint32_t* d_perm0, tsvq_root_out* d_out);
+// prepare_root of n_nodes member spans (buf / start / count of each record), one workgroup each: d_outs[i] for d_nodes[i]
+hipError_t launch_tsvq_span_roots(hipStream_t st, int dim, bool packed, bool exact, const void* d_rows, const uint64_t* d_w64, const uint32_t* d_perm0, const uint32_t* d_perm1,
+                                  const tsvq_node_in* d_nodes, uint32_t n_nodes, tsvq_root_out* d_outs);
 hipError_t launch_tsvq_split(hipStream_t st, int dim, bool packed, bool exact, const void* d_rows, const uint64_t* d_w64, uint32_t* d_perm0, uint32_t* d_perm1, uint8_t* d_side,
                              const tsvq_node_in* d_nodes, uint32_t n_nodes, tsvq_split_out* d_outs);
 

@@ -285,10 +285,20 @@ __global__ __launch_bounds__(256) void k_tsvq_iota(uint32_t n, uint32_t* __restr
     if (i < n) perm0[i] = i;
 }
 
-// prepare_root (enc.h:1708-1735): origin sums, weight, variance of the whole training set. EX: see exact_acc.
+// prepare_root (enc.h:1708-1735): origin sums, weight, variance of the whole training set -- or, with `nodes`, of one member span per
+// workgroup (the roots of the T independent trees of the partitioned build, enc.h:2137-2152: the sub-quantizer's training set is the
+// leaf's member list in list order). EX: see exact_acc.
 template <int N, typename Src, bool EX>
-__global__ __launch_bounds__(TQ_THREADS) void k_tsvq_root(Src src, const uint64_t* __restrict__ w64, uint32_t n, tsvq_root_out* __restrict__ out) {
+__global__ __launch_bounds__(TQ_THREADS) void k_tsvq_root(Src src, const uint64_t* __restrict__ w64, uint32_t n, tsvq_root_out* __restrict__ out,
+                                                         const uint32_t* __restrict__ perm0, const uint32_t* __restrict__ perm1, const tsvq_node_in* __restrict__ nodes) {
     extern __shared__ __align__(16) char lds[];
+    const uint32_t* members = nullptr;
+    if (nodes) {
+        const tsvq_node_in& nd = nodes[blockIdx.x];
+        members = (nd.buf ? perm1 : perm0) + nd.start;
+        n = nd.count;
+        out += blockIdx.x;
+    }
     __shared__ float s_origin[16];
     __shared__ double s_tt;
     __shared__ uint64_t s_red[TQ_THREADS / 64 * 3];
@@ -297,7 +307,7 @@ __global__ __launch_bounds__(TQ_THREADS) void k_tsvq_root(Src src, const uint64_
     uint64_t wsum = 0;
     exact_acc tt;
     bool bad = false;
-    pipeline_pass<N, EX ? 0 : 1, EX ? 1 : 2>(lds, src, w64, nullptr, n, // wave 0: the N float chains, wave 1: the double chain
+    pipeline_pass<N, EX ? 0 : 1, EX ? 1 : 2>(lds, src, w64, members, n, // wave 0: the N float chains, wave 1: the double chain
         [&](uint32_t, const typename Src::payload& p, float* f, double* d) {
             float v[N]; Src::decode(p, v);
             const float w = (float)p.w;
@@ -780,7 +790,7 @@ hipError_t launch_tsvq_root(hipStream_t st, int dim, bool packed, bool exact, co
     hipError_t e;
 #define TQ_LAUNCH_ROOT(NN, SRC, EXV, srcval) do { \
         if ((e = set_lds(k_tsvq_root<NN, SRC, EXV>, lds)) != hipSuccess) return e; \
-        hipLaunchKernelGGL((k_tsvq_root<NN, SRC, EXV>), dim3(1), dim3(TQ_THREADS), lds, st, srcval, d_w64, n, d_out); } while (0)
+        hipLaunchKernelGGL((k_tsvq_root<NN, SRC, EXV>), dim3(1), dim3(TQ_THREADS), lds, st, srcval, d_w64, n, d_out, nullptr, nullptr, nullptr); } while (0)
     if (dim == 16 && packed) {
         packed16_rows src{static_cast<const uint32_t*>(d_rows)};
         if (exact) TQ_LAUNCH_ROOT(16, packed16_rows, true, src); else TQ_LAUNCH_ROOT(16, packed16_rows, false, src);
@@ -792,6 +802,28 @@ hipError_t launch_tsvq_root(hipStream_t st, int dim, bool packed, bool exact, co
         TQ_LAUNCH_ROOT(6, float_rows<6>, false, src);
     } else return hipErrorInvalidValue;
 #undef TQ_LAUNCH_ROOT
+    return hipGetLastError();
+}
+
+hipError_t launch_tsvq_span_roots(hipStream_t st, int dim, bool packed, bool exact, const void* d_rows, const uint64_t* d_w64, const uint32_t* d_perm0, const uint32_t* d_perm1,
+                                  const tsvq_node_in* d_nodes, uint32_t n_nodes, tsvq_root_out* d_outs) {
+    if (!n_nodes) return hipSuccess;
+    const size_t lds = tsvq_lds_bytes(dim);
+    hipError_t e;
+#define TQ_LAUNCH_ROOTS(NN, SRC, EXV, srcval) do { \
+        if ((e = set_lds(k_tsvq_root<NN, SRC, EXV>, lds)) != hipSuccess) return e; \
+        hipLaunchKernelGGL((k_tsvq_root<NN, SRC, EXV>), dim3(n_nodes), dim3(TQ_THREADS), lds, st, srcval, d_w64, 0u, d_outs, d_perm0, d_perm1, d_nodes); } while (0)
+    if (dim == 16 && packed) {
+        packed16_rows src{static_cast<const uint32_t*>(d_rows)};
+        if (exact) TQ_LAUNCH_ROOTS(16, packed16_rows, true, src); else TQ_LAUNCH_ROOTS(16, packed16_rows, false, src);
+    } else if (dim == 16) {
+        float_rows<16> src{static_cast<const float*>(d_rows)};
+        TQ_LAUNCH_ROOTS(16, float_rows<16>, false, src);
+    } else if (dim == 6 && !packed) {
+        float_rows<6> src{static_cast<const float*>(d_rows)};
+        TQ_LAUNCH_ROOTS(6, float_rows<6>, false, src);
+    } else return hipErrorInvalidValue;
+#undef TQ_LAUNCH_ROOTS
     return hipGetLastError();
 }
 

@@ -50,8 +50,21 @@ def load_frontend_library():
         L.bu_host_tsvq.argtypes = [C.c_uint32, _vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32, _vp, C.c_uint64, _vp, C.c_uint64]
         L.bu_device_tsvq.restype = C.c_int
         L.bu_device_tsvq.argtypes = [_vp, C.c_uint32, _vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32, _vp, C.c_uint64, _vp, C.c_uint64, _vp]
+        L.bu_host_tsvq_mt.restype = C.c_int
+        L.bu_host_tsvq_mt.argtypes = [C.c_uint32, _vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _vp, C.c_uint64, _vp, C.c_uint64]
+        L.bu_device_tsvq_mt.restype = C.c_int
+        L.bu_device_tsvq_mt.argtypes = [_vp, C.c_uint32, _vp, _vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _vp, C.c_uint64, _vp, C.c_uint64, _vp]
+        L.bu_frontend_set_max_threads.restype = C.c_int
+        L.bu_frontend_set_max_threads.argtypes = [_vp, C.c_uint32]
+        L.bu_frontend_reference_max_threads.restype = C.c_uint32
+        L.bu_frontend_reference_max_threads.argtypes = [C.c_int, C.c_uint32, C.c_uint32]
         _lib = L
     return _lib
+
+
+def reference_max_threads(multithreaded=True, hardware_threads=0, job_pool_threads=0):
+    """frontend.cpp:873-876 / 2195-2198: the thread count the reference's codebook builders are handed (0 = single-threaded)."""
+    return int(load_frontend_library().bu_frontend_reference_max_threads(int(bool(multithreaded)), int(hardware_threads), int(job_pool_threads)))
 
 
 def quality_to_clusters(quality_level, total_blocks):
@@ -178,10 +191,12 @@ class RcclComm:
 
 
 class Etc1sFrontend:
-    def __init__(self, ctx, comm=None, video=False, fast_codebooks=False, fast_iterations=0):
+    def __init__(self, ctx, comm=None, video=False, fast_codebooks=False, fast_iterations=0, max_threads=0):
         """comm: a TorchComm to shard the device stages over the ranks of its process group (every rank must drive an identical
         frontend on identical tiles); None = single GPU. fast_codebooks: SURVEY 8f row f3 -- both codebooks from a k-means on the matrix
-        cores instead of the TSVQ: NOT bit-identical to the reference (see include/basisu_hip_frontend.h), off by default."""
+        cores instead of the TSVQ: NOT bit-identical to the reference (see include/basisu_hip_frontend.h), off by default.
+        max_threads: the reference's codebook-builder thread count (reference_max_threads()); > 1 reproduces the multi-threaded tool's output
+        (T-way partitioned codebooks from 262,144 distinct training vectors up), 0 / 1 the tool under -no_multithreading."""
         self.ctx = ctx
         self.L = load_frontend_library()
         self.h = self.L.bu_frontend_create()
@@ -194,6 +209,8 @@ class Etc1sFrontend:
         if fast_codebooks:
             self.L.bu_frontend_set_fast_codebooks.argtypes = [_vp, C.c_int, C.c_uint32]
             self._check(self.L.bu_frontend_set_fast_codebooks(self.h, 1, int(fast_iterations)), "bu_frontend_set_fast_codebooks")
+        if max_threads:
+            self._check(self.L.bu_frontend_set_max_threads(self.h, int(max_threads)), "bu_frontend_set_max_threads")
         if comm is not None:
             self._check(self.L.bu_frontend_set_comm(self.h, C.byref(comm.struct)), "bu_frontend_set_comm")
 

@@ -306,6 +306,7 @@ def main():
         if "backend" in out:
             out["backend"].pop("sha256", None)
         if world == 1:
+            out["reference_default_threads"] = multithreaded_config_bench(ctx, d_blocks, n_blocks, w, h, max_ep, max_sel, args)
             out["h2d_inclusive"] = h2d_inclusive_bench(ctx, blocks, n_blocks, w, h, max_ep, max_sel, args)
             out["mipmaps"] = mip_bench(ctx, img)
         if not args.no_uastc and world == 1:
@@ -386,6 +387,48 @@ def etc1s_8192_bench(ctx, helpers, args):
     last.close()
     del d
     torch.cuda.empty_cache()
+    return out
+
+
+def multithreaded_config_bench(ctx, d_blocks, n_blocks, w, h, max_ep, max_sel, args, threads=8):
+    """The headline workload under the reference's DEFAULT (multi-threaded) configuration: codebook builders handed `threads` threads (frontend.cpp:2195-2198), so
+    that the selector codebook (674,691 distinct vectors >= 262,144) comes from a T-way partitioned tree build (enc.h:2086-2215) whose T trees share every device
+    round. Same full init + compress per step; the output is compared with the committed digest of the reference run with a job pool of that many threads."""
+    import hashlib
+    import torch
+    from basis_universal_amd.etc1s import Etc1sFrontend
+
+    def step():
+        fe = Etc1sFrontend(ctx, max_threads=threads)
+        fe.init(d_blocks.data_ptr(), max_ep, max_sel, args.level, True, n_blocks=n_blocks)
+        fe.compress()
+        return fe
+
+    step().close()
+    torch.cuda.synchronize()
+    ctx.profile_enable(True)
+    steps, last = max(3, args.steps // 2), None
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        if last is not None:
+            last.close()
+        last = step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    kern = ctx.profile_read()
+    ctx.profile_enable(False)
+    out = {"workload": f"the headline workload with the reference's multi-threaded codebook builders, {threads} threads (the tool's default on a machine with >= {threads} hardware threads)",
+           "codebook_threads": threads, "value": round(w * h / 1e6 / dt, 3), "unit": "Mpixels/s", "ms_per_step": round(dt * 1e3, 2), "steps": steps,
+           "kernels_ms_per_step": {k: round(v[0] / steps, 3) for k, v in kern.items() if k.startswith("tsvq") or k.startswith("unique")},
+           "host_gap_ms": round(dt * 1e3 - sum(v[0] for v in kern.values()) / steps, 2),
+           "final_selector_clusters": int(last.get("selector_cluster_block_indices", np.uint32)[0])}
+    g = ROOT / "tests" / "golden" / "etc1s_big_digests.json"
+    if g.exists() and (w, h, args.quality, args.level) == (4096, 4096, 128, 1):
+        rec = json.loads(g.read_text()).get(f"synth4096_q128_t{threads}")
+        if rec:
+            out["identical_to_reference"] = hashlib.sha256(np.ascontiguousarray(last.get("encoded_blocks")).tobytes()).hexdigest() == rec["frontend_digests"]["encoded_blocks"]
+            out["reference_frontend_seconds"] = {"threads": threads, "seconds": rec["reference_seconds"]["frontend"], "where": "the build container (8 hardware threads), tools/gen_golden_big.py"}
+    last.close()
     return out
 
 
@@ -753,13 +796,16 @@ def end_to_end(helpers, args, img):
     ref_dir = ROOT / "oracle" / "_ref"
     threads = host_cpus()
     mpix = args.size * args.size / 1e6
+    pool = min(threads, 8)
     runs = [("stock_1_thread", "process_bench", 1, 0, 1), ("stock_all_cores", "process_bench", threads, 0, 1), ("seam_1_thread", "process_bench_hip", 1, 1, 1),
-            ("seam_all_cores", "process_bench_hip", threads, 1, 1), ("resident", "process_bench_resident", min(threads, 8), 1, 3)]
-    out = {"what": "basis_compressor::init + process(), raw RGBA in, .basis bytes out, tool defaults (ETC1S comp level 1, sRGB metrics)", "host_cpus": threads}
+            ("seam_all_cores", "process_bench_hip", threads, 1, 1), ("resident_1_thread", "process_bench_resident", 1, 1, 3), ("resident", "process_bench_resident", pool, 1, 3)]
+    out = {"what": "basis_compressor::init + process(), raw RGBA in, .basis bytes out, tool defaults (ETC1S comp level 1, sRGB metrics). `identical`: same .basis bytes as the "
+                   "STOCK reference in the same thread configuration (1 thread = the tool under -no_multithreading; more = the tool's default, whose codebook builders "
+                   "partition their trees min(hardware threads, 8, pool) ways, enc.h:2086-2215)", "host_cpus": threads}
     with tempfile.TemporaryDirectory() as d:
         raw = pathlib.Path(d) / "img.rgba"
         np.ascontiguousarray(img).tofile(raw)
-        base_hash = None
+        base_hash = {}
         for name, exe, thr, ocl, reps in runs:
             tool = ref_dir / exe
             if not tool.exists():
@@ -772,10 +818,14 @@ def end_to_end(helpers, args, img):
                 out[name] = {"error": str(e)[:200]}
                 continue
             best = min(a + b for a, b in zip(rec["init_s"], rec["process_s"]))
-            if name == "stock_1_thread":
-                base_hash = rec["fnv1a64"]
-            out[name] = {"seconds": round(best, 4), "mpix_s": round(mpix / best, 3), "threads": thr, "bytes": rec["bytes"],
-                         "identical": (rec["fnv1a64"] == base_hash) if base_hash else None}
+            # the reference's codebook-builder thread count for this run (frontend.cpp:2195-2198): the partition count of its selector codebook
+            t_codebook = 0 if thr <= 1 else min(os.cpu_count() or 1, 8, thr)
+            config = "stock_1_thread" if t_codebook <= 1 else "stock_all_cores"
+            if name.startswith("stock"):
+                base_hash[name] = (rec["fnv1a64"], t_codebook)
+            want = base_hash.get(config)
+            out[name] = {"seconds": round(best, 4), "mpix_s": round(mpix / best, 3), "threads": thr, "codebook_threads": t_codebook, "bytes": rec["bytes"],
+                         "identical_to": config, "identical": (rec["fnv1a64"] == want[0]) if want and want[1] == t_codebook else None}
     if "resident" in out and "stock_1_thread" in out and "seconds" in out["resident"] and "seconds" in out["stock_1_thread"]:
         out["resident_vs_stock_1_thread"] = round(out["stock_1_thread"]["seconds"] / out["resident"]["seconds"], 1)
         if "seconds" in out.get("stock_all_cores", {}):

@@ -283,6 +283,9 @@ BU_HIP_API int bu_hip_k_unique_endpoint_vectors(bu_hip_context*, const void* d_e
 BU_HIP_API int bu_hip_k_unique_selector_vectors(bu_hip_context*, const void* d_enc_blocks, const uint64_t* d_weights, uint32_t n_blocks, uint32_t* d_sorted_block_idx,
                                                 uint32_t* d_unique_keys, uint64_t* d_unique_weights, uint32_t* d_group_offsets, uint32_t* out_unique);
 BU_HIP_API int  bu_hip_tsvq_split(bu_hip_context*, bu_tsvq*, const bu_tsvq_node* h_nodes, uint32_t n_nodes, bu_tsvq_split* h_out); /* synchronises */
+/* prepare_root (enc.h:1708-1735) of n_nodes member spans (buf / start / count of each record; weight and origin are not read): the root records of the
+ * independent trees the reference's multi-threaded codebook build runs over the leaves of its first tree (enc.h:2137-2152). Synchronises. */
+BU_HIP_API int  bu_hip_tsvq_roots(bu_hip_context*, bu_tsvq*, const bu_tsvq_node* h_nodes, uint32_t n_nodes, bu_tsvq_root* h_out);
 BU_HIP_API int  bu_hip_tsvq_read_members(bu_hip_context*, bu_tsvq*, uint32_t buf, uint32_t start, uint32_t count, uint32_t* h_out);
 /* Leaves (or cut nodes) as spans of the member buffers -> d_out[vector] = value for every member of every span: the leaf / parent index of
  * every distinct vector without bringing the member lists to the host. h_spans: n_spans records. Stream-ordered after the splits. */

@@ -49,6 +49,15 @@ BU_HIP_API int bu_frontend_set_video(bu_frontend*, int video);
  * 6786-6793) by tests/test_gpu_fast_codebooks.py. Off by default; iterations 0 keeps the default (4 Lloyd rounds + the final assignment; more rounds changed nothing measurable). Call before bu_frontend_init. */
 BU_HIP_API int bu_frontend_set_fast_codebooks(bu_frontend*, int on, uint32_t iterations);
 
+/* The reference's multi-threaded configuration -- the tool's default. max_threads is what basisu_frontend computes from params::m_multithreaded and its job
+ * pool (frontend.cpp:873-876, 2195-2198; bu_frontend_reference_max_threads below restates it): from 262,144 distinct training vectors up (enc.h:2316) a value
+ * T > 1 makes generate_hierarchical_codebook_threaded_internal (enc.h:2086-2215) build a T-leaf tree and then T independent trees of ceil(K / T) leaves and
+ * ceil(P / T) parents over the leaves' members, concatenated in leaf order -- a different (deterministic) codebook than the single-threaded build. 0 / 1 (default)
+ * = the tool under -no_multithreading. On the device the T trees share every round of node splits. Call before bu_frontend_init. */
+BU_HIP_API int bu_frontend_set_max_threads(bu_frontend*, uint32_t max_threads);
+/* max_threads as the reference derives it: 0 when not multithreaded, else min(hardware threads (0 = this machine's), 8, job pool threads (0 = no pool)). */
+BU_HIP_API uint32_t bu_frontend_reference_max_threads(int multithreaded, uint32_t hardware_threads, uint32_t job_pool_threads);
+
 /* basisu_frontend::compress (frontend.cpp:159) */
 BU_HIP_API int bu_frontend_compress(bu_frontend*);
 /* Single-step one stage method by its reference name (tests); arg = step / iteration where the method takes one. */
@@ -88,10 +97,19 @@ BU_HIP_API int bu_mipmap_plan(uint32_t src_w, uint32_t src_h, uint32_t dst_w, ui
 BU_HIP_API int bu_host_tsvq(uint32_t dim, const float* rows, const uint64_t* weights, uint32_t n, uint32_t max_codebook_size, uint32_t max_parent_codebook_size,
                             uint32_t* out_codebook, uint64_t cap_codebook_words, uint32_t* out_parent, uint64_t cap_parent_words);
 
+/* ... with the reference's thread count (see bu_frontend_set_max_threads); min_unique_for_threads 0 = the reference's 262,144 gate, a smaller value
+ * exercises generate_hierarchical_codebook_threaded_internal (enc.h:2086-2215) on small inputs. */
+BU_HIP_API int bu_host_tsvq_mt(uint32_t dim, const float* rows, const uint64_t* weights, uint32_t n, uint32_t max_codebook_size, uint32_t max_parent_codebook_size,
+                               uint32_t max_threads, uint32_t min_unique_for_threads, uint32_t* out_codebook, uint64_t cap_codebook_words, uint32_t* out_parent,
+                               uint64_t cap_parent_words);
+
 /* The same input through the DEVICE TSVQ driver the frontend uses (basis_universal_amd/csrc/host/tsvq_device.h). */
 BU_HIP_API int bu_device_tsvq(bu_hip_context* ctx, uint32_t dim, const float* rows, const uint64_t* weights, uint32_t n, uint32_t max_codebook_size,
                               uint32_t max_parent_codebook_size, uint32_t* out_codebook, uint64_t cap_codebook_words, uint32_t* out_parent,
                               uint64_t cap_parent_words, uint32_t* stats3);
+BU_HIP_API int bu_device_tsvq_mt(bu_hip_context* ctx, uint32_t dim, const float* rows, const uint64_t* weights, uint32_t n, uint32_t max_codebook_size,
+                                 uint32_t max_parent_codebook_size, uint32_t max_threads, uint32_t min_unique_for_threads, uint32_t* out_codebook,
+                                 uint64_t cap_codebook_words, uint32_t* out_parent, uint64_t cap_parent_words, uint32_t* stats3);
 
 #ifdef __cplusplus
 }

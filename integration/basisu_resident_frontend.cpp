@@ -98,6 +98,8 @@ bool basisu_frontend::init(const params& p) {
     if (!f) return false;
     static_assert(sizeof(pixel_block) == sizeof(bu_pixel_block) && sizeof(etc_block) == sizeof(bu_etc_block), "layout");
     bu_frontend_set_video(f, p.m_tex_type == basist::cBASISTexTypeVideoFrames);
+    // the codebook builders' thread count exactly as frontend.cpp:873-876 / 2195-2198 derive it: the multi-threaded tool's files come out of T-way partitioned trees
+    bu_frontend_set_max_threads(f, bu_frontend_reference_max_threads(p.m_multithreaded, get_num_hardware_threads(), p.m_pJob_pool ? (uint32_t)p.m_pJob_pool->get_total_threads() : 0));
     if (!bu_frontend_init(f, ctx, reinterpret_cast<const bu_pixel_block*>(m_source_blocks.data()), nullptr, p.m_num_source_blocks, p.m_max_endpoint_clusters,
                           p.m_max_selector_clusters, p.m_compression_level, p.m_perceptual)) {
         error_printf("basisu_frontend (resident): init failed: %s\n", bu_frontend_error(f));

@@ -309,6 +309,35 @@ REF_API int ref_tsvq(uint32_t dim, const float* vecs, const uint64_t* weights, u
 	return 1;
 }
 
+// The same with the job pool and thread count the multi-threaded tool passes (frontend.cpp:2195-2204). `internal` != 0 calls
+// generate_hierarchical_codebook_threaded_internal (enc.h:2086-2215) directly on the rows as given (they must be distinct; limit_clusterizers
+// as the outer function derives it, enc.h:2305-2307), so that the T-way partition can be exercised below the outer function's 262,144 gate (enc.h:2316).
+REF_API int ref_tsvq_mt(uint32_t dim, const float* vecs, const uint64_t* weights, uint32_t n, uint32_t max_codebook_size,
+	uint32_t max_parent_codebook_size, uint32_t max_threads, int internal,
+	uint32_t* out_codebook, uint64_t cap_codebook_words, uint32_t* out_parent, uint64_t cap_parent_words) {
+	basisu::vector<uint_vec> codebook, parent;
+	job_pool jp(max_threads ? max_threads : 1);
+	bool ok = false;
+	const bool limit = n > max_codebook_size;
+	if (dim == 6) {
+		tree_vector_quant<vec<6, float>> q;
+		for (uint32_t i = 0; i < n; i++) { vec<6, float> v; for (uint32_t k = 0; k < 6; k++) v[k] = vecs[i * 6 + k]; q.add_training_vec(v, weights[i]); }
+		ok = internal ? generate_hierarchical_codebook_threaded_internal(q, max_codebook_size, max_parent_codebook_size, codebook, parent, max_threads, limit, &jp)
+		              : generate_hierarchical_codebook_threaded(q, max_codebook_size, max_parent_codebook_size, codebook, parent, max_threads, &jp, false);
+	} else if (dim == 16) {
+		tree_vector_quant<vec16F> q;
+		for (uint32_t i = 0; i < n; i++) { vec16F v; for (uint32_t k = 0; k < 16; k++) v[k] = vecs[i * 16 + k]; q.add_training_vec(v, weights[i]); }
+		ok = internal ? generate_hierarchical_codebook_threaded_internal(q, max_codebook_size, max_parent_codebook_size, codebook, parent, max_threads, limit, &jp)
+		              : generate_hierarchical_codebook_threaded(q, max_codebook_size, max_parent_codebook_size, codebook, parent, max_threads, &jp, false);
+	}
+	if (!ok) return 0;
+	std::vector<uint32_t> a = csr(codebook), b = csr(parent);
+	if (a.size() > cap_codebook_words || b.size() > cap_parent_words) return -1;
+	memcpy(out_codebook, a.data(), a.size() * 4);
+	memcpy(out_parent, b.data(), b.size() * 4);
+	return 1;
+}
+
 // ---------------------------------------------------------------- ETC1S backend, first stage
 // basisu_backend::create_encoder_blocks (encoder/basisu_backend.cpp:406-617) on a finished frontend: one 2D slice of num_blocks_x x
 // num_blocks_y blocks. Outputs per block (raster order): the endpoint index after the endpoint-prediction RDO remap (:441-586, BEFORE the

@@ -151,6 +151,8 @@ def ref():
         L.ref_frontend_get.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_uint64]
         L.ref_tsvq.restype = C.c_int
         L.ref_tsvq.argtypes = [C.c_uint32, f32p, u64p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, u32p, C.c_uint64, u32p, C.c_uint64]
+        L.ref_tsvq_mt.restype = C.c_int
+        L.ref_tsvq_mt.argtypes = [C.c_uint32, f32p, u64p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, u32p, C.c_uint64, u32p, C.c_uint64]
         L.ref_encode_uastc.argtypes = [u8p, C.c_uint32, C.c_uint32, u8p]
         L.ref_uastc_rdo.restype = C.c_int
         L.ref_uastc_rdo.argtypes = [u8p, u8p, C.c_uint32, f32p, u32p, C.c_uint32, C.c_uint32]

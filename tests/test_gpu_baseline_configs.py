@@ -1,5 +1,5 @@
 """-m gpu: BASELINE.json's own configurations at FULL size against the reference, through committed goldens (tools/gen_golden_big.py ran
-the real reference -- oracle/_ref, single-threaded = the pinned configuration -- in the build container; the GPU box has no
+the real reference -- oracle/_ref, single-threaded and with job pools of 2 / 4 / 8 threads (the tool's default configuration) -- in the build container; the GPU box has no
 /root/reference and could not afford its minutes anyway):
 
   configs[0]  kodim03.png 768x512 ETC1S -q128            pixels + the reference TOOL's .basis / .ktx2 bytes in tests/golden/kodim03.npz
@@ -29,7 +29,7 @@ def _frontend_and_backend(hip_ctx, img, g):
     from basis_universal_amd.backend import Etc1sBackend
     blocks = to_pixel_blocks(img)
     assert quality_to_clusters(g["quality"], blocks.shape[0]) == (g["max_endpoint_clusters"], g["max_selector_clusters"])
-    fe = Etc1sFrontend(hip_ctx)
+    fe = Etc1sFrontend(hip_ctx, max_threads=g.get("threads", 1))
     fe.init(blocks, g["max_endpoint_clusters"], g["max_selector_clusters"], g["level"], g["perceptual"])
     fe.compress()
     got = T._digest({k: fe.get(k) for k in T.STATE})
@@ -50,6 +50,24 @@ def test_config1_synth4096_q128(hip_ctx):
 def test_config3_synth8192_q255(hip_ctx):
     g = GOLDEN["synth8192_q255"]
     assert (g["max_endpoint_clusters"], g["max_selector_clusters"]) == (8192, 16128)   # comp.cpp:3325-3379
+    fe, be = _frontend_and_backend(hip_ctx, synth(8192, 8192, 5678), g)
+    be.close(); fe.close()
+
+
+@pytest.mark.parametrize("threads", [2, 4, 8])
+def test_config1_synth4096_q128_multithreaded_reference(hip_ctx, threads):
+    """The reference's DEFAULT configuration: a job pool of T threads -> T-way partitioned selector codebook (674,691 distinct selector vectors >= 262,144;
+    generate_hierarchical_codebook_threaded_internal, enc.h:2086-2215). Goldens: tools/gen_golden_big.py with RefFrontend(threads=T)."""
+    g = GOLDEN[f"synth4096_q128_t{threads}"]
+    assert g["threads"] == threads and g["frontend_digests"] != GOLDEN["synth4096_q128"]["frontend_digests"]
+    fe, be = _frontend_and_backend(hip_ctx, synth(4096, 4096, 1234), g)
+    be.close(); fe.close()
+
+
+@pytest.mark.parametrize("threads", [2, 4, 8])
+def test_config3_synth8192_q255_multithreaded_reference(hip_ctx, threads):
+    g = GOLDEN[f"synth8192_q255_t{threads}"]
+    assert g["threads"] == threads and g["frontend_digests"] != GOLDEN["synth8192_q255"]["frontend_digests"]
     fe, be = _frontend_and_backend(hip_ctx, synth(8192, 8192, 5678), g)
     be.close(); fe.close()
 

@@ -68,6 +68,31 @@ def test_reference_tool_with_resident_frontend_and_backend_writes_the_cpu_tools_
     assert res.shape == cpu.shape and (res == cpu).all()
 
 
+@pytest.mark.skipif(not (have_ref_cli() and RESIDENT_TOOL.exists()), reason="oracle/_ref/basisu_hip_resident not present")
+def test_reference_tool_default_threads_with_resident_frontend_writes_the_multithreaded_cpu_tools_file():
+    """The tool as users run it -- NO -no_multithreading: from 262,144 distinct selector vectors up the stock tool partitions its selector codebook build
+    T = min(hardware threads, 8) ways (frontend.cpp:2195-2204, enc.h:2086-2215) and writes a DIFFERENT file than under -no_multithreading. The resident
+    integration derives the same T from the same params and reproduces that file."""
+    import os
+    if (os.cpu_count() or 1) < 2:
+        pytest.skip("one hardware thread: the tool's default is the single-threaded configuration")
+    img = synth(3072, 3072, 80)   # 589,824 blocks, ~380k distinct selector vectors
+
+    def run(tool, *extra):
+        with tempfile.TemporaryDirectory() as d:
+            save_png(pathlib.Path(d) / "in.png", img)
+            r = subprocess.run([str(tool), "-basis", "-etc1s", "-q", "128", *extra, "in.png"], cwd=d, capture_output=True, text=True, timeout=600)
+            assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+            return np.fromfile(pathlib.Path(d) / "in.basis", np.uint8), r.stdout + r.stderr
+
+    cpu_mt, _ = run(ORACLE_DIR / "_ref" / "basisu")
+    cpu_st, _ = run(ORACLE_DIR / "_ref" / "basisu", "-no_multithreading")
+    assert cpu_mt.shape != cpu_st.shape or (cpu_mt != cpu_st).any(), "the image is too small to reach the reference's partitioned codebook build"
+    res, log = run(RESIDENT_TOOL)
+    assert "failed" not in log.lower(), log[-1500:]
+    assert res.shape == cpu_mt.shape and (res == cpu_mt).all()
+
+
 UASTC_TOOL = ORACLE_DIR / "_ref" / "basisu_hip_uastc"
 
 

@@ -154,3 +154,64 @@ def test_wide_nodes_match_host_tsvq(hip_ctx, monkeypatch, n, k, p, kind, wmax, w
         a3 = np.zeros(cap, np.uint32); b3 = np.zeros(cap, np.uint32)
         assert ref().ref_tsvq(16, ptr(v, f32p), ptr(w, u64p), n, k, p, 0, ptr(a3, u32p), cap, ptr(b3, u32p), cap) == 1
         assert (a3 == outs["wide"][0]).all() and (b3 == outs["wide"][1]).all()
+
+
+# The reference's multi-threaded configuration (generate_hierarchical_codebook_threaded_internal, enc.h:2086-2215; the tool's default from 262,144
+# distinct vectors up): a T-leaf tree, then T independent trees over the leaves' members whose device rounds are shared (tsvq_device.h run_trees).
+# min_unique_for_threads = 1 takes small inputs down the partitioned path; the 300k case goes through the reference's own gate.
+PARTITIONED = [(16, 20000, 500, 32, "sel", 50, 8), (16, 20000, 500, 32, "sel", 50, 2), (16, 120000, 2731, 32, "sel", 4096, 8), (16, 120000, 2731, 32, "sel", 4096, 3),
+               (6, 40000, 2416, 16, "ep", 3, 8), (6, 3000, 256, 16, "ep", 50, 4), (16, 4000, 300, 0, "gauss", 9, 5), (16, 300, 300, 32, "sel", 3, 8),
+               (16, 1000, 2000, 32, "sel", 7, 4), (6, 400, 64, 16, "line", 5, 4), (16, 5000, 256, 32, "sel", 2 ** 50, 16), (16, 30000, 900, 16, "sel_skewed", 4096, 8)]
+
+
+@pytest.mark.parametrize("dim,n,k,p,kind,wmax,threads", PARTITIONED)
+def test_partitioned_tsvq_matches_host_and_reference(hip_ctx, dim, n, k, p, kind, wmax, threads):
+    from basis_universal_amd import etc1s
+    F = etc1s.load_frontend_library()
+    rng = np.random.default_rng(n * 5 + k + threads)
+    v = _data(kind, dim, n, rng)
+    n = v.shape[0]
+    w = rng.integers(1, wmax + 1, n).astype(np.uint64)
+    if kind == "sel_skewed":
+        w[rng.integers(0, n, 5)] = 3_000_000_000
+    cap = 4 * n + 4 * k + 100
+    a1 = np.zeros(cap, np.uint32); b1 = np.zeros(cap, np.uint32)
+    assert F.bu_host_tsvq_mt(dim, v.ctypes.data_as(VP), w.ctypes.data_as(VP), n, k, p, threads, 1, a1.ctypes.data_as(VP), cap, b1.ctypes.data_as(VP), cap) == 1
+    for packed in ([False, True] if kind.startswith("sel") else [False]):
+        a2 = np.zeros(cap, np.uint32); b2 = np.zeros(cap, np.uint32); st = np.array([0xBACCED if packed else 0, 0, 0], np.uint32)
+        assert F.bu_device_tsvq_mt(hip_ctx.h, dim, v.ctypes.data_as(VP), w.ctypes.data_as(VP), n, k, p, threads, 1, a2.ctypes.data_as(VP), cap, b2.ctypes.data_as(VP), cap,
+                                   st.ctypes.data_as(VP)) == 1
+        assert (a1 == a2).all(), f"packed={packed}: codebook differs (leaves host {a1[0]} device {a2[0]}, rounds {st[0]}, splits {st[1]}/{st[2]})"
+        assert (b1 == b2).all(), f"packed={packed}: parent codebook differs"
+    if have_ref():
+        a3 = np.zeros(cap, np.uint32); b3 = np.zeros(cap, np.uint32)
+        assert ref().ref_tsvq_mt(dim, ptr(v, f32p), ptr(w, u64p), n, k, p, threads, 1, ptr(a3, u32p), cap, ptr(b3, u32p), cap) == 1
+        assert (a3 == a1).all() and (b3 == b1).all()
+
+
+@pytest.mark.parametrize("threads", [8, 2])
+def test_partitioned_tsvq_through_the_reference_gate(hip_ctx, threads):
+    """>= 262,144 distinct vectors: the outer function's own gate (enc.h:2316), the wide kernels for the first tree and the sub-trees' roots"""
+    from basis_universal_amd import etc1s
+    F = etc1s.load_frontend_library()
+    rng = np.random.default_rng(31 + threads)
+    base = rng.integers(0, 4, (400, 16))
+    n = 600000
+    v = np.clip(base[rng.integers(0, 400, n)] + (rng.random((n, 16)) < 0.25) * rng.integers(-1, 2, (n, 16)), 0, 3).astype(np.float32)
+    v = np.ascontiguousarray(np.unique(v, axis=0)); n = v.shape[0]
+    assert n >= 262144
+    w = rng.integers(1, 400, n).astype(np.uint64)
+    k, p = 2731, 32
+    cap = 4 * n + 4 * k + 100
+    a1 = np.zeros(cap, np.uint32); b1 = np.zeros(cap, np.uint32); a2 = np.zeros(cap, np.uint32); b2 = np.zeros(cap, np.uint32); st = np.array([0xBACCED, 0, 0], np.uint32)
+    assert F.bu_host_tsvq_mt(16, v.ctypes.data_as(VP), w.ctypes.data_as(VP), n, k, p, threads, 0, a1.ctypes.data_as(VP), cap, b1.ctypes.data_as(VP), cap) == 1
+    assert F.bu_device_tsvq_mt(hip_ctx.h, 16, v.ctypes.data_as(VP), w.ctypes.data_as(VP), n, k, p, threads, 0, a2.ctypes.data_as(VP), cap, b2.ctypes.data_as(VP), cap,
+                               st.ctypes.data_as(VP)) == 1
+    assert (a1 == a2).all() and (b1 == b2).all()
+    a0 = np.zeros(cap, np.uint32); b0 = np.zeros(cap, np.uint32); st0 = np.array([0xBACCED, 0, 0], np.uint32)
+    assert F.bu_device_tsvq(hip_ctx.h, 16, v.ctypes.data_as(VP), w.ctypes.data_as(VP), n, k, p, a0.ctypes.data_as(VP), cap, b0.ctypes.data_as(VP), cap, st0.ctypes.data_as(VP)) == 1
+    assert not (a0 == a2).all(), "the partitioned codebook must differ from the single-threaded one"
+    if have_ref():
+        a3 = np.zeros(cap, np.uint32); b3 = np.zeros(cap, np.uint32)
+        assert ref().ref_tsvq_mt(16, ptr(v, f32p), ptr(w, u64p), n, k, p, threads, 0, ptr(a3, u32p), cap, ptr(b3, u32p), cap) == 1
+        assert (a3 == a2).all() and (b3 == b2).all()

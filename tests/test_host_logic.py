@@ -93,6 +93,47 @@ def test_host_tsvq_matches_reference(dim, n, k, p, kind):
     assert (a1 == a2).all() and (b1 == b2).all()
 
 
+# The reference's multi-threaded configuration (generate_hierarchical_codebook_threaded_internal, enc.h:2086-2215): a T-leaf tree, then T independent
+# trees of ceil(K / T) leaves and ceil(P / T) parents. Driven through the reference's _internal half so that small inputs take the partitioned path
+# (the outer function only does above 262,144 distinct vectors, enc.h:2316 -- the last case goes through that gate with the real job pool).
+@pytest.mark.skipif(not have_ref(), reason="oracle/_ref not present")
+@pytest.mark.parametrize("dim,n,k,p,kind,threads", [(16, 20000, 500, 32, "sel", 8), (16, 20000, 500, 32, "sel", 2), (16, 6000, 512, 16, "sel", 4), (6, 20000, 1200, 16, "ep", 8),
+                                                    (6, 3000, 256, 16, "ep", 3), (16, 4000, 300, 0, "gauss", 5), (16, 300, 300, 32, "sel", 8), (16, 300, 100, 32, "sel", 8),
+                                                    (16, 1000, 2000, 32, "sel", 4), (6, 255, 64, 16, "ep", 4), (16, 5000, 256, 32, "sel", 16), (16, 5000, 256, 32, "sel", 24),
+                                                    (6, 400, 64, 16, "line", 4)])
+def test_host_tsvq_partitioned_matches_reference(dim, n, k, p, kind, threads):
+    from basis_universal_amd import etc1s
+    F = etc1s.load_frontend_library()
+    rng = np.random.default_rng(n + k + threads)
+    if kind == "sel":
+        v = rng.integers(0, 4, (n, dim)).astype(np.float32)
+    elif kind == "ep":
+        v = rng.integers(0, 256, (n, dim)).astype(np.float32) * np.float32(1.0 / 255.0)
+    elif kind == "line":   # degenerate covariance: the first tree may end with fewer leaves than threads (enc.h:2122)
+        v = np.tile(rng.integers(0, 3, n).astype(np.float32)[:, None], (1, dim))
+    else:
+        v = rng.normal(0, 1, (n, dim)).astype(np.float32)
+    v = np.ascontiguousarray(np.unique(v, axis=0))
+    n = v.shape[0]
+    w = rng.integers(1, 50, n).astype(np.uint64)
+    cap = 4 * n + 4 * k + 100
+    a1 = np.zeros(cap, np.uint32); b1 = np.zeros(cap, np.uint32); a2 = np.zeros(cap, np.uint32); b2 = np.zeros(cap, np.uint32)
+    assert ref().ref_tsvq_mt(dim, ptr(v, f32p), ptr(w, u64p), n, k, p, threads, 1, ptr(a1, u32p), cap, ptr(b1, u32p), cap) == 1
+    assert F.bu_host_tsvq_mt(dim, v.ctypes.data_as(C.c_void_p), w.ctypes.data_as(C.c_void_p), n, k, p, threads, 1, a2.ctypes.data_as(C.c_void_p), cap,
+                             b2.ctypes.data_as(C.c_void_p), cap) == 1
+    assert (a1 == a2).all() and (b1 == b2).all()
+    if threads > 1 and n >= 256 and k >= threads * 16 and kind != "line":   # the partition really is a different codebook
+        a0 = np.zeros(cap, np.uint32); b0 = np.zeros(cap, np.uint32)
+        assert F.bu_host_tsvq(dim, v.ctypes.data_as(C.c_void_p), w.ctypes.data_as(C.c_void_p), n, k, p, a0.ctypes.data_as(C.c_void_p), cap, b0.ctypes.data_as(C.c_void_p), cap) == 1
+        assert not ((a0 == a2).all() and (b0 == b2).all())
+
+
+def test_reference_max_threads():
+    """frontend.cpp:873-876 / 2195-2198"""
+    from basis_universal_amd.etc1s import reference_max_threads as t
+    assert t(False, 64, 64) == 0 and t(True, 64, 0) == 8 and t(True, 4, 0) == 4 and t(True, 64, 3) == 3 and t(True, 2, 16) == 2 and 1 <= t(True) <= 8
+
+
 @pytest.mark.skipif(not have_ref(), reason="oracle/_ref not present")
 @pytest.mark.parametrize("w,h,quality", [(64, 64, 128), (256, 192, 128), (512, 512, 128), (256, 256, 255), (256, 256, 1), (128, 128, 64), (768, 512, 192)])
 def test_quality_to_clusters_matches_reference(w, h, quality):

@@ -5,6 +5,7 @@ cannot run (no /root/reference there, and its build of oracle/_ref would take th
 
   synth4096_q128   configs[1]: 4096x4096 synthetic RGBA, seed 1234, -q 128 (2416 / 2731 clusters), CLI level 1
   synth8192_q255   configs[3]: 8192x8192 synthetic RGBA, seed 5678, -q 255 (8192 / 16128 clusters), CLI level 1
+  ..._t2 / _t4 / _t8  the same two images under the reference's MULTI-THREADED configuration with T codebook threads (the tool's default)
   kodim03_q128     configs[0]: kodim03.png 768x512, -q 128, CLI level 1; the image itself is written to tests/golden/kodim03.npz so the
                    GPU box has the pixels (a test fixture of the reference, basisu_tool.cpp:6751)
 
@@ -41,23 +42,28 @@ def kodim03():
 
 
 CASES = {
-    "kodim03_q128": (kodim03, 128),
-    "synth4096_q128": (lambda: helpers.synth(4096, 4096, 1234), 128),
-    "synth8192_q255": (lambda: helpers.synth(8192, 8192, 5678), 255),
+    "kodim03_q128": (kodim03, 128, 1),
+    "synth4096_q128": (lambda: helpers.synth(4096, 4096, 1234), 128, 1),
+    "synth8192_q255": (lambda: helpers.synth(8192, 8192, 5678), 255, 1),
 }
+# The reference's multi-threaded configuration (the tool's default): job pool of T threads -> max_threads = min(hardware threads, 8, T) = T on the 8-thread
+# build container (frontend.cpp:2195-2198) -> T-way partitioned selector codebook (674,691 / 2.3 M distinct selector vectors >= 262,144, enc.h:2316).
+for _t in (2, 4, 8):
+    CASES[f"synth4096_q128_t{_t}"] = (lambda: helpers.synth(4096, 4096, 1234), 128, _t)
+    CASES[f"synth8192_q255_t{_t}"] = (lambda: helpers.synth(8192, 8192, 5678), 255, _t)
 
 
 def main():
     want = sys.argv[1:] or list(CASES)
     out = json.loads(OUT.read_text()) if OUT.exists() else {}
     for case in want:
-        img_fn, quality = CASES[case]
+        img_fn, quality, threads = CASES[case]
         img = img_fn()
         h, w = img.shape[:2]
         blocks = helpers.to_pixel_blocks(img)
         max_ep, max_sel = quality_to_clusters(quality, blocks.shape[0])
         t0 = time.time()
-        fe = helpers.RefFrontend(blocks, max_ep, max_sel, 1, True)
+        fe = helpers.RefFrontend(blocks, max_ep, max_sel, 1, True, threads=threads)
         fe.call("compress")
         t1 = time.time()
         st = {k: fe.get(k) for k in T.STATE}
@@ -65,7 +71,7 @@ def main():
         total, _ = fe.backend_run([(0, nbx, nby)], *helpers_backend_thresholds(quality))
         t2 = time.time()
         out[case] = {
-            "width": w, "height": h, "quality": quality, "level": 1, "perceptual": True, "n_blocks": int(blocks.shape[0]),
+            "width": w, "height": h, "quality": quality, "level": 1, "perceptual": True, "n_blocks": int(blocks.shape[0]), "threads": threads,
             "max_endpoint_clusters": max_ep, "max_selector_clusters": max_sel,
             "final_endpoint_clusters": int(st["endpoint_clusters"].view(np.uint32)[0]),
             "final_selector_clusters": int(st["selector_cluster_block_indices"].view(np.uint32)[0]),
