@@ -72,7 +72,9 @@ def compress(ctx, image, *, uastc=False, quality=128, comp_level=1, uastc_level=
             packed = ctx.download(d_out, (total_blocks, 16), np.uint8)
             if ktx2:
                 return uastc_ktx2_file(packed, slices, srgb=srgb, has_alpha=has_alpha, key_values=key_values)
-            return uastc_basis_file(packed, slices, srgb=srgb, key_values=key_values)
+            # encode_slices_to_uastc_4x4_ldr (comp.cpp:1973-1985) never sets basisu_backend_output::m_srgb, which basisu_backend_output::clear() leaves true
+            # (backend.h:243): the reference's UASTC .basis files carry the sRGB header flag whatever -linear says (the .ktx2 DFD does follow the option)
+            return uastc_basis_file(packed, slices, srgb=True, key_values=key_values)
         max_ep, max_sel = quality_to_clusters(quality, total_blocks)
         fe = Etc1sFrontend(ctx)
         try:

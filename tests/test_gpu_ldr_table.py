@@ -1,0 +1,136 @@
+"""-m gpu: ALL 28 files and ALL three columns of the reference's own LDR golden table (g_etc1s_uastc_4x4_ldr_test_files, basisu_tool.cpp:6737-6776,
+`basisu -test`), and the ETC1S half of its codec grid (g_codec_test_cases, basisu_tool_test_codecs.inl:13-103, `basisu -test_codecs ETC1S`), through
+compress() -- image in, file out, every stage on the MI355X.
+
+tests/test_gpu_kodak24.py holds kodim01..24 to the quality-128 and UASTC columns; this file adds
+  * the quality-1 column (m_etc1s_size / m_etc1s_psnr) for all 28 files,
+  * the four non-Kodak files in every column: black_1x1, white_1x1 (one block), wikipedia (1845x894: both dimensions padded, text edges),
+    alpha0 (LA source: a colour and an alpha slice sharing the codebooks),
+  * the grid: kodim03 / 23 / 18, alpha0, wikipedia, black_1x1 x quality {10, 25, 50, 75, 100} x effort {0, 3, 6} -> .ktx2.
+Every case is held to the BYTES of the file the reference tool writes for the same settings first (tools/gen_golden_ldr_table.py ran oracle/_ref in the
+build container), then -- the reference's own acceptance rule (basisu_tool.cpp:6786-6793, 7855-7990) -- to the table's size within 4.5 % (50 % below
+2,000 bytes in the grid) and RGBA PSNR within 0.3 dB. The PSNR is the one the reference tool printed for these very bytes."""
+import hashlib
+import json
+import pathlib
+import re
+
+import numpy as np
+import pytest
+
+import helpers
+from basis_universal_amd import uastc
+from basis_universal_amd.compress import compress
+
+pytestmark = pytest.mark.gpu
+HERE = pathlib.Path(__file__).resolve().parent
+GOLDEN = json.loads((HERE / "golden" / "ldr_table_digests.json").read_text())
+KODAK = json.loads((HERE / "golden" / "kodak24_digests.json").read_text())
+EXTRA = ("black_1x1", "white_1x1", "wikipedia", "alpha0")
+NAMES = [f"kodim{k:02d}" for k in range(1, 25)] + list(EXTRA)
+FILESIZE_THRESHOLD, PSNR_THRESHOLD = 0.045, 0.3
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+@pytest.fixture(scope="module")
+def images():
+    zk, ze = np.load(HERE / "golden" / "kodak24.npz"), np.load(HERE / "golden" / "ldr_extra.npz")
+    out = {}
+    for name in NAMES:
+        if name in EXTRA:
+            img = np.ascontiguousarray(ze[name])
+        else:
+            rgb = zk["k" + name[5:]]
+            img = np.ascontiguousarray(np.concatenate([rgb, np.full(rgb.shape[:2] + (1,), 255, np.uint8)], axis=2))
+        assert sha(img) == GOLDEN["table"][name]["rgba_sha256"], name
+        out[name] = img
+    return out
+
+
+def table_row(name):
+    if name in EXTRA:
+        return GOLDEN["reference_table_extra"][name]
+    return KODAK["reference_table"]["k" + name[5:]]
+
+
+def _same_file(hip_ctx, img, g, ktx2=False, **kw):
+    kv = [(k, bytes.fromhex(v)) for k, v in g["key_values"]]
+    data = compress(hip_ctx, img, ktx2=ktx2, key_values=kv, **kw)
+    assert data.size == g["size"] and sha(data) == g["sha256"], (data.size, g["size"])
+    return data
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_reference_table_etc1s_quality_1_column(hip_ctx, images, name):
+    """basis_compress(cETC1S, no quality bits) = quality max(1, 0), comp level 2, linear metrics (comp.cpp:5704-5741)"""
+    g = GOLDEN["table"][name]["etc1s_q1_table"]
+    data = _same_file(hip_ctx, images[name], g, quality=1, comp_level=2, srgb=False)
+    row = table_row(name)
+    assert abs(data.size / row["etc1s_q1_size"] - 1.0) <= FILESIZE_THRESHOLD, (data.size, row["etc1s_q1_size"])
+    assert abs(g["tool_psnr_rgba_slice0"] - row["etc1s_q1_psnr"]) <= PSNR_THRESHOLD, (g["tool_psnr_rgba_slice0"], row["etc1s_q1_psnr"])
+
+
+@pytest.mark.parametrize("name", EXTRA)
+def test_reference_table_etc1s_quality_128_column_of_the_non_kodak_files(hip_ctx, images, name):
+    g = GOLDEN["table"][name]["etc1s_q128_table"]
+    data = _same_file(hip_ctx, images[name], g, quality=128, comp_level=2, srgb=False)
+    row = table_row(name)
+    assert abs(data.size / row["etc1s_q128_size"] - 1.0) <= FILESIZE_THRESHOLD, (data.size, row["etc1s_q128_size"])
+    assert abs(g["tool_psnr_rgba_slice0"] - row["etc1s_q128_psnr"]) <= PSNR_THRESHOLD
+    # and the command line's own defaults (comp level 1, sRGB metrics): BASELINE configs[0]'s settings on these files
+    _same_file(hip_ctx, images[name], GOLDEN["table"][name]["etc1s_q128"], quality=128, comp_level=1, srgb=True)
+
+
+@pytest.mark.parametrize("name", EXTRA)
+def test_reference_table_uastc_column_of_the_non_kodak_files(hip_ctx, images, name):
+    """basis_compress(cUASTC_LDR_4x4, no level bits) = pack level 0, linear; + the tool's default (level 2, sRGB) and the block-level digests incl. RDO"""
+    t = GOLDEN["table"][name]
+    _same_file(hip_ctx, images[name], t["uastc_l0_file"], uastc=True, uastc_level=0, srgb=False)
+    assert abs(t["uastc_l0_file"]["tool_psnr_rgba_slice0"] - table_row(name)["uastc_psnr"]) <= PSNR_THRESHOLD
+    _same_file(hip_ctx, images[name], t["uastc_l2_file"], uastc=True, uastc_level=2, srgb=True)
+    blocks = helpers.to_pixel_blocks(images[name])
+    assert blocks.shape[0] == t["n_blocks"]
+    packed = uastc.encode_uastc_blocks(hip_ctx, blocks, 2)
+    assert sha(packed) == t["uastc_l2"] and sha(uastc.encode_uastc_blocks(hip_ctx, blocks, 0)) == t["uastc_l0"]
+    for jobs in (1, 4):
+        if f"uastc_l2_rdo1_jobs{jobs}" in t:
+            got, _ = uastc.uastc_rdo(hip_ctx, packed, blocks, uastc.RdoParams(m_lambda=1.0), 2, 0 if jobs == 1 else jobs)
+            assert sha(got) == t[f"uastc_l2_rdo1_jobs{jobs}"], jobs
+
+
+def _codec_grid_rows():
+    """{file/quality/effort: ktx2 size} parsed from nothing on the GPU box: the sizes below are g_codec_test_cases' ETC1S rows (basisu_tool_test_codecs.inl:13-103)"""
+    rows = {}
+    sizes = {
+        "kodim03": [29403, 31195, 31148, 35402, 37598, 37752, 50025, 50708, 50888, 77208, 69650, 69920, 106817, 85220, 85193],
+        "kodim23": [32405, 33166, 33423, 39326, 40360, 40671, 54515, 55032, 55516, 86182, 78551, 78904, 119827, 97840, 97825],
+        "kodim18": [36817, 38266, 38503, 44202, 45220, 45484, 61749, 61946, 62305, 94102, 86860, 87232, 132900, 112250, 112531],
+        "alpha0": [887, 886, 886, 887, 887, 887, 887, 887, 887, 887, 887, 887, 887, 887, 887],
+        "wikipedia": [44660, 45772, 46228, 54243, 55226, 55415, 73344, 71150, 71324, 103597, 94349, 95310, 127265, 109006, 110043],
+        "black_1x1": [313] * 15,
+    }
+    for name, v in sizes.items():
+        i = 0
+        for q in (10, 25, 50, 75, 100):
+            for e in (0, 3, 6):
+                rows[f"{name}/q{q}/e{e}"] = v[i]
+                i += 1
+    return rows
+
+
+GRID = _codec_grid_rows()
+
+
+@pytest.mark.parametrize("case", sorted(GRID))
+def test_codec_grid_etc1s(hip_ctx, images, case):
+    """`basisu -test_codecs ETC1S`: quality [1,100] -> ETC1S quality round(2.55 q), effort [0,10] -> comp level round(0.6 e) (comp.cpp:76-92, 158-176), sRGB
+    metrics, .ktx2 out. Exact against the reference tool's file, then the grid's own size rule."""
+    g = GOLDEN["codec_grid_etc1s"][case]
+    name, q, e = re.match(r"(\w+)/q(\d+)/e(\d+)", case).groups()
+    assert (g["etc1s_quality"], g["comp_level"]) == (int(np.floor(255.0 * int(q) / 100.0 + 0.5)), int(np.floor(6.0 * int(e) / 10.0 + 0.5)))
+    data = _same_file(hip_ctx, images[name], g, ktx2=True, quality=g["etc1s_quality"], comp_level=g["comp_level"], srgb=True)
+    want = GRID[case]
+    assert abs(data.size / want - 1.0) <= (0.5 if want < 2000 else FILESIZE_THRESHOLD), (data.size, want)
