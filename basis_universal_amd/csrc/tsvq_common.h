@@ -71,15 +71,26 @@ __device__ __forceinline__ void principal_axis_wave(const float (*cov)[16], floa
         double sum = 0;
 #pragma unroll
         for (int j = 0; j < N; j++) { const float p = crow[j] * axis[j]; sum += p; }
-        double a = lane < N ? fabs(sum) : 0.0;
-        double max_sum = a;
+        // the largest |row sum|: a non-negative double orders like its bit pattern, so the maximum over lanes 0..N-1 is a DPP prefix maximum (rows of 16
+        // lanes; N <= 16) read from lane 15 -- no trip through the LDS crossbar per step
+        unsigned long long mb = lane < N ? (unsigned long long)__double_as_longlong(fabs(sum)) : 0ull;
 #pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) { const double t = __shfl_xor(max_sum, o, 64); max_sum = t > max_sum ? t : max_sum; }
+        for (int step = 0; step < 4; step++) {
+            uint32_t lo, hi;
+            if (step == 0) { lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)mb, 0x111, 0xf, 0xf, false); hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(mb >> 32), 0x111, 0xf, 0xf, false); }
+            else if (step == 1) { lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)mb, 0x112, 0xf, 0xf, false); hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(mb >> 32), 0x112, 0xf, 0xf, false); }
+            else if (step == 2) { lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)mb, 0x114, 0xf, 0xf, false); hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(mb >> 32), 0x114, 0xf, 0xf, false); }
+            else { lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)mb, 0x118, 0xf, 0xf, false); hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(mb >> 32), 0x118, 0xf, 0xf, false); }
+            const unsigned long long o = ((unsigned long long)hi << 32) | lo;
+            mb = o > mb ? o : mb;
+        }
+        const double max_sum = __longlong_as_double((long long)(((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mb >> 32), 15) << 32) |
+                                                                  (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mb, 15)));
         float mine = (float)sum;
         if (max_sum != 0.0) mine *= (float)(1.0 / max_sum);
         float trial[N], delta[N];
 #pragma unroll
-        for (int i = 0; i < N; i++) trial[i] = __shfl(mine, i, 64);
+        for (int i = 0; i < N; i++) trial[i] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(mine), i));
 #pragma unroll
         for (int i = 0; i < N; i++) delta[i] = prev[i] - trial[i];
 #pragma unroll

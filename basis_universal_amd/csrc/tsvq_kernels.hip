@@ -21,6 +21,17 @@
 
 namespace bu {
 
+// Development aid (tools/build_tsvq_profile.sh, -DTQ_PROFILE): clock64() ticks thread 0 of every split workgroup spends between the TQ_TICK marks, summed per
+// interval over all workgroups + the number of workgroups and of side passes; read and reset by tsvq_profile_read(). Never compiled into the product library.
+#ifdef TQ_PROFILE
+__device__ unsigned long long g_tq_prof[16];
+#define TQ_TICK(k) do { if (threadIdx.x == 0) { const long long now_ = clock64(); atomicAdd(&g_tq_prof[k], (unsigned long long)(now_ - tq_t_)); tq_t_ = now_; } } while (0)
+#define TQ_COUNT(k) do { if (threadIdx.x == 0) atomicAdd(&g_tq_prof[k], 1ull); } while (0)
+#else
+#define TQ_TICK(k) do { } while (0)
+#define TQ_COUNT(k) do { } while (0)
+#endif
+
 constexpr int TQ_THREADS = 512;
 constexpr int TQ_TILE = 256;           // members per LDS tile
 constexpr int TQ_STRIDE = TQ_TILE + 4; // float row stride: keeps 16-byte reads of different chains on different banks
@@ -112,17 +123,19 @@ __device__ __forceinline__ void pipeline_pass(char* lds, const Src& src, const u
         if (pos < count) emit(pos, p, fptr(t) + pid, dptr(t) + pid);
     };
     if (producer) { // wave-uniform roles: each role runs its own loop, the barriers pair up one to one
+        // (the run-ahead stops at the last tile: the tile count is uniform, so these are branches, not predicated loads -- a node of one or two tiles, which is
+        //  most nodes of a tree's lower levels, used to wait for two rounds of loads nobody needed before it could leave the pass)
         uint32_t idx = fetch_index(0);
         payload pay = src.fetch(w64, idx);   // tile 0
-        idx = fetch_index(1);
+        if (tiles > 1) idx = fetch_index(1);
         emit_tile(0, pay);
-        pay = src.fetch(w64, idx);           // tile 1
-        idx = fetch_index(2);                // index of tile 2
+        if (tiles > 1) pay = src.fetch(w64, idx);           // tile 1
+        if (tiles > 2) idx = fetch_index(2);                // index of tile 2
         __syncthreads();
         for (uint32_t t = 0; t < tiles; t++) {
             if (t + 1 < tiles) emit_tile(t + 1, pay);
-            pay = src.fetch(w64, idx);       // tile t + 2 (clamped past the end)
-            idx = fetch_index(t + 3);
+            if (t + 2 < tiles) pay = src.fetch(w64, idx);   // tile t + 2
+            if (t + 3 < tiles) idx = fetch_index(t + 3);
             __syncthreads();
         }
     } else if (consumer) {
@@ -231,14 +244,27 @@ __device__ __forceinline__ void chain_add_prod_f32(float& acc, const float* dx, 
 }
 
 
+// wave64 sums by DPP (rows of 16 lanes: row_shr 1/2/4/8, then row_bcast15 into rows 1 and 3, row_bcast31 into rows 2 and 3): an inclusive prefix whose LAST lane
+// holds the wave's total; lanes without a source add 0. No LDS traffic, six dependent adds.
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ uint32_t dpp_src_u32(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false); }
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {   // valid in lane 63
+    v += dpp_src_u32<0x111, 0xf>(v); v += dpp_src_u32<0x112, 0xf>(v); v += dpp_src_u32<0x114, 0xf>(v); v += dpp_src_u32<0x118, 0xf>(v);
+    v += dpp_src_u32<0x142, 0xa>(v); v += dpp_src_u32<0x143, 0xc>(v);
+    return v;
+}
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ uint64_t dpp_src_u64(uint64_t v) {
+    return ((uint64_t)dpp_src_u32<CTRL, ROW_MASK>((uint32_t)(v >> 32)) << 32) | dpp_src_u32<CTRL, ROW_MASK>((uint32_t)v);
+}
+__device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {   // valid in lane 63
+    v += dpp_src_u64<0x111, 0xf>(v); v += dpp_src_u64<0x112, 0xf>(v); v += dpp_src_u64<0x114, 0xf>(v); v += dpp_src_u64<0x118, 0xf>(v);
+    v += dpp_src_u64<0x142, 0xa>(v); v += dpp_src_u64<0x143, 0xc>(v);
+    return v;
+}
+
 __device__ __forceinline__ uint64_t block_sum_u64(uint64_t v, uint64_t* scratch /* TQ_THREADS/64 */) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) {
-        const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, o, 64), hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), o, 64);
-        v += ((uint64_t)hi << 32) | lo;
-    }
+    v = wave_sum_u64(v);
     __syncthreads();
-    if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
+    if ((threadIdx.x & 63) == 63) scratch[threadIdx.x >> 6] = v;
     __syncthreads();
     uint64_t s = 0;
     for (int w = 0; w < TQ_THREADS / 64; w++) s += scratch[w];
@@ -249,15 +275,9 @@ __device__ __forceinline__ uint64_t block_sum_u64(uint64_t v, uint64_t* scratch 
 template <int K>
 __device__ __forceinline__ void block_sum_u64xN(uint64_t (&v)[K], uint64_t* scratch) {
 #pragma unroll
-    for (int k = 0; k < K; k++) {
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) {
-            const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v[k], o, 64), hi = (uint32_t)__shfl_xor((int)(uint32_t)(v[k] >> 32), o, 64);
-            v[k] += ((uint64_t)hi << 32) | lo;
-        }
-    }
+    for (int k = 0; k < K; k++) v[k] = wave_sum_u64(v[k]);
     __syncthreads();
-    if ((threadIdx.x & 63) == 0)
+    if ((threadIdx.x & 63) == 63)
 #pragma unroll
         for (int k = 0; k < K; k++) scratch[(threadIdx.x >> 6) * K + k] = v[k];
     __syncthreads();
@@ -358,9 +378,14 @@ __global__ __launch_bounds__(TQ_THREADS) void k_tsvq_split(Src src, const uint64
     __shared__ uint32_t s_scan[TQ_THREADS / 64][2];
     __shared__ uint32_t s_base[2];
     __shared__ double2 s_tab[16][4]; // packed rows: {(l_c[k] - val)^2, (r_c[k] - val)^2} for val = 0..3 (see TQ_MODE_DIST)
+    __shared__ uint32_t s_tot[16];   // packed rows, exact side passes: sum over the node's members of value x weight, per component
     using payload = typename Src::payload;
 
     const int tid = threadIdx.x;
+#ifdef TQ_PROFILE
+    long long tq_t_ = clock64();
+    TQ_COUNT(15);
+#endif
     const tsvq_node_in nd = nodes[blockIdx.x];
     tsvq_split_out* out = outs + blockIdx.x;
     const uint32_t count = nd.count;
@@ -378,21 +403,29 @@ __global__ __launch_bounds__(TQ_THREADS) void k_tsvq_split(Src src, const uint64
     // result is the plain integer total -- computed here by all 512 threads in any order. Returns 0 when every chain was exact (results
     // stored like side_pass stores them), 1 when some total reached 2^24 (nothing stored: the caller runs the chained pass), 2 when the
     // integer totals of the double accumulators left their exact range (the node is given up with ok = 2, as in side_pass).
+    bool have_totals = false;   // s_tot holds the node's per-component totals (they do not depend on the classification)
     auto side_pass_exact = [&](int mode, bool write_side) -> int {
         if constexpr (!(Src::PACKED && EX && N == 16)) { return 1; } else {
-        uint32_t* s_part = reinterpret_cast<uint32_t*>(lds);          // [8 waves][32 chains]
-        uint32_t acc[32];
+        // scratch in the (otherwise idle) tile memory: per-wave partial sums, then the block's verdict
+        uint32_t* s_part = reinterpret_cast<uint32_t*>(lds);                     // [8 waves][32]: right sums 0..15, totals 16..31 (first pass only)
+        uint64_t* s_p64 = reinterpret_cast<uint64_t*>(lds + 1024);               // [8 waves][8]: lw, rw, ln, ex0.lo, ex0.hi, ex1.lo, ex1.hi, flags (bit 0 big, bit 1 bad)
+        uint32_t* s_status = reinterpret_cast<uint32_t*>(lds + 1024 + 512);
+        const bool first = !have_totals;
+        uint32_t acc_r[16], acc_t[16];
 #pragma unroll
-        for (int i = 0; i < 32; i++) acc[i] = 0;
+        for (int i = 0; i < 16; i++) { acc_r[i] = 0; acc_t[i] = 0; }
         uint64_t lw = 0, rw = 0; uint32_t ln = 0;
         exact_acc ex[2];
-        bool bad = false, big = count > 512u * 64u;   // per-thread u32 partial sums stay below 2^32 for up to 64 members of < 2^24 each
+        // per-thread u32 partial sums stay below 2^32 for up to 64 members of < 2^24 each; a member weighing 2^22 or more leaves the pass to the chained
+        // form (value x weight is then not known to stay below 2^24, where the float product and the integer one are the same number)
+        bool bad = false, big = count > 512u * 64u;
         if (mode == TQ_MODE_DIST && tid < 64) {
             const int k = tid >> 2, val = tid & 3;
             const double a = (double)c.l_c[k] - (double)(float)val, b = (double)c.r_c[k] - (double)(float)val;
             s_tab[k][val] = make_double2(a * a, b * b);
         }
         __syncthreads();
+        TQ_TICK(7);
         for (uint32_t pos = (uint32_t)tid; pos < count; pos += TQ_THREADS) {
             const payload p = src.fetch(w64, members[pos]);
             const float w = (float)p.w;
@@ -409,47 +442,75 @@ __global__ __launch_bounds__(TQ_THREADS) void k_tsvq_split(Src src, const uint64
                 right = (double)dot_seq<N>(dd, c.axis) >= 0.0;
             }
             if (write_side) node_side[pos] = right ? 1 : 0;
-            float vsq = 0.0f;
+            big |= (p.w >> 22) != 0;
+            const uint32_t w32 = (uint32_t)p.w & 0x3fffffu, rmask = right ? ~0u : 0u;
+            uint32_t vsq_i = 0;
 #pragma unroll
             for (int k = 0; k < N; k++) {
-                const float v = (float)((p.key >> (30 - 2 * k)) & 3u);
-                const float t = v * w;
-                big |= !(t < 16777216.0f);
-                const uint32_t ti = (uint32_t)t;
-                acc[k] += right ? 0u : ti;
-                acc[N + k] += right ? ti : 0u;
-                vsq = k == 0 ? v * v : vsq + v * v;   // dot_seq order
+                const uint32_t val = (p.key >> (30 - 2 * k)) & 3u;
+                const uint32_t ti = val * w32;          // = (uint32_t)((float)val * (float)weight): both exact below 2^24
+                acc_r[k] += ti & rmask;
+                if (first) acc_t[k] += ti;
+                vsq_i += val * val;                     // the float dot product of small integers, exact in any order
             }
-            const float dvf = mode == TQ_MODE_PROJ ? w : w * vsq;
+            const float dvf = mode == TQ_MODE_PROJ ? w : w * (float)vsq_i;
             bad |= !ex[0].add_if(dvf, !right); bad |= !ex[1].add_if(dvf, right);
             rw += right ? p.w : 0ull; lw += right ? 0ull : p.w; ln += right ? 0u : 1u;
         }
-        // wave totals of the 32 chains -> LDS -> block totals
+        TQ_TICK(8);
+        // wave totals (DPP prefix: the last lane holds the sum) -> LDS -> wave 0 adds the eight waves' parts and decides
+        const int lane = tid & 63, wave = tid >> 6;
 #pragma unroll
-        for (int i = 0; i < 32; i++) {
-            uint32_t v = acc[i];
+        for (int i = 0; i < 16; i++) acc_r[i] = wave_sum_u32(acc_r[i]);
+        if (first)
 #pragma unroll
-            for (int o = 32; o >= 1; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o, 64);
-            acc[i] = v;
+            for (int i = 0; i < 16; i++) acc_t[i] = wave_sum_u32(acc_t[i]);
+        uint64_t s7[7] = {lw, rw, (uint64_t)ln, ex[0].lo, ex[0].hi, ex[1].lo, ex[1].hi};
+#pragma unroll
+        for (int i = 0; i < 7; i++) s7[i] = wave_sum_u64(s7[i]);
+        const uint32_t wflags = (__ballot(big) != 0 ? 1u : 0u) | (__ballot(bad) != 0 ? 2u : 0u);
+        if (lane == 63) {
+#pragma unroll
+            for (int i = 0; i < 16; i++) s_part[wave * 32 + i] = acc_r[i];
+            if (first)
+#pragma unroll
+                for (int i = 0; i < 16; i++) s_part[wave * 32 + 16 + i] = acc_t[i];
+#pragma unroll
+            for (int i = 0; i < 7; i++) s_p64[wave * 8 + i] = s7[i];
+            s_p64[wave * 8 + 7] = wflags;
         }
-        if ((tid & 63) == 0)
-#pragma unroll
-            for (int i = 0; i < 32; i++) s_part[(tid >> 6) * 32 + i] = acc[i];
-        uint64_t sums[7] = {lw, rw, (uint64_t)ln, ex[0].lo, ex[0].hi, ex[1].lo, ex[1].hi};
-        block_sum_u64xN<7>(sums, s_red);    // two barriers: s_part is visible afterwards
-        const bool any_big = __syncthreads_or(big ? 1 : 0) != 0;
-        const bool any_bad = __syncthreads_or(bad ? 1 : 0) != 0;
-        uint64_t tot = 0;
-        if (tid < 32) for (int w8 = 0; w8 < TQ_THREADS / 64; w8++) tot += s_part[w8 * 32 + tid];
-        const bool inexact = __syncthreads_or((tid < 32 && tot >= 16777216ull) ? 1 : 0) != 0;
-        // no 32-bit wrap can have happened anywhere if four times the node's weight fits 32 bits (every chain total is at most 3 x that)
-        if (any_big || inexact || ((sums[0] + sums[1]) >> 30) != 0) return 1;
-        double t0 = 0.0, t1 = 0.0;
-        if (any_bad || !exact_total(sums[3], sums[4], &t0) || !exact_total(sums[5], sums[6], &t1)) return 2;
-        if (tid < 32) s_sum[tid / N][tid % N] = (float)(uint32_t)tot;
-        if (tid == 0) { s_dsum[0] = t0; s_dsum[1] = t1; c.l_w = sums[0]; c.r_w = sums[1]; c.l_n = (uint32_t)sums[2]; c.r_n = count - (uint32_t)sums[2]; }
+        TQ_TICK(9);
         __syncthreads();
-        return 0;
+        if (wave == 0) {
+            // lanes 0..15: right sum / total / left sum of component `lane`; lanes 32..39: the block's eight 64-bit sums
+            uint64_t r = 0, t = 0, v64 = 0;
+            if (lane < 16) {
+                for (int w8 = 0; w8 < TQ_THREADS / 64; w8++) { r += s_part[w8 * 32 + lane]; if (first) t += s_part[w8 * 32 + 16 + lane]; }
+                if (first) s_tot[lane] = (uint32_t)t; else t = s_tot[lane];
+            } else if (lane >= 32 && lane < 40) {
+                for (int w8 = 0; w8 < TQ_THREADS / 64; w8++) { const uint64_t x = s_p64[w8 * 8 + (lane - 32)]; v64 = (lane == 39) ? (v64 | x) : (v64 + x); }
+            }
+            const uint64_t l = t - r;   // (no 32-bit wrap can have happened if four times the node's weight fits 32 bits: checked below)
+            const bool inexact = __ballot(lane < 16 && (r >= 16777216ull || l >= 16777216ull)) != 0;
+            uint64_t sums[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) sums[i] = __shfl(v64, 32 + i, 64);
+            uint32_t status = 0;
+            double t0 = 0.0, t1 = 0.0;
+            if ((sums[7] & 1ull) || inexact || ((sums[0] + sums[1]) >> 30) != 0) status = 1;
+            else if ((sums[7] & 2ull) || !exact_total(sums[3], sums[4], &t0) || !exact_total(sums[5], sums[6], &t1)) status = 2;
+            if (status == 0) {
+                if (lane < 16) { s_sum[0][lane] = (float)(uint32_t)l; s_sum[1][lane] = (float)(uint32_t)r; }
+                if (lane == 0) { s_dsum[0] = t0; s_dsum[1] = t1; c.l_w = sums[0]; c.r_w = sums[1]; c.l_n = (uint32_t)sums[2]; c.r_n = count - (uint32_t)sums[2]; }
+            }
+            if (lane == 0) *s_status = status;
+        }
+        __syncthreads();
+        const uint32_t status = *s_status;
+        TQ_TICK(10);
+        // the totals are good once a pass got as far as adding them up without leaving the integer range (status 1 may be a wrap: do not trust them then)
+        if (first && status != 1) have_totals = true;
+        return (int)status;
         }
     };
 
@@ -542,6 +603,7 @@ __global__ __launch_bounds__(TQ_THREADS) void k_tsvq_split(Src src, const uint64
         return failed;
     };
 
+    TQ_TICK(0);
     // ---------------- prep_split
     if (count == 2) {
         if (tid == 0) {
@@ -571,16 +633,17 @@ __global__ __launch_bounds__(TQ_THREADS) void k_tsvq_split(Src src, const uint64
             [&](const float* f, const double*, uint32_t m) {
                 if (tid < C) chain_add_prod_f32(cv, f + (size_t)cx * TQ_STRIDE, f + (size_t)(N + cy) * TQ_STRIDE, m);
             });
-        if (tid < C) c.cov[cx][cy] = cv;
-        __syncthreads();
-        if (tid == 0) {
+        TQ_TICK(1);
+        if (tid < C) {   // enc.h:1825-1834: every entry times 1 / weight, mirrored -- by the thread that summed it
             const float renorm = 1.0f / (float)nd.weight;
-            for (int x = 0; x < N; x++) for (int y = x; y < N; y++) c.cov[x][y] *= renorm;
-            for (int x = 0; x < N - 1; x++) for (int y = x + 1; y < N; y++) c.cov[y][x] = c.cov[x][y];
+            const float e = cv * renorm;
+            c.cov[cx][cy] = e; c.cov[cy][cx] = e;
         }
         __syncthreads();
+        TQ_TICK(2);
         if (tid < 64) principal_axis_wave<N>(c.cov, c.axis);
         __syncthreads();
+        TQ_TICK(3);
     }
 
     // ---------------- the classification passes of prep_split and refine_split, driven from ONE call site (the pass body is
@@ -593,6 +656,7 @@ __global__ __launch_bounds__(TQ_THREADS) void k_tsvq_split(Src src, const uint64
     for (;;) {
         const int mode = phase == PH_PROJ ? TQ_MODE_PROJ : phase == PH_HALF ? TQ_MODE_HALF : phase == PH_REFINE ? TQ_MODE_DIST : TQ_MODE_PEEL_FIRST;
         if (side_pass(mode, phase == PH_REFINE || phase == PH_PEEL)) { if (tid == 0) out->ok = 2; return; }
+        TQ_TICK(4); TQ_COUNT(14);
         if (phase == PH_PROJ) {
             if (tid == 0) {
                 const double lw = s_dsum[0], rw = s_dsum[1];
@@ -677,6 +741,7 @@ __global__ __launch_bounds__(TQ_THREADS) void k_tsvq_split(Src src, const uint64
             }
         }
         __syncthreads();
+        TQ_TICK(5);
         if (c.state || ++iter == 6) break;
     }
 
@@ -707,6 +772,7 @@ __global__ __launch_bounds__(TQ_THREADS) void k_tsvq_split(Src src, const uint64
         }
         __syncthreads();
     }
+    TQ_TICK(6);
     if (tid == 0) {
         out->ok = 1; out->l_count = c.l_n; out->r_count = c.r_n; out->l_weight = c.l_w; out->r_weight = c.r_w;
         out->l_var = c.l_var; out->r_var = c.r_var;
@@ -749,12 +815,10 @@ __global__ __launch_bounds__(TQ_THREADS) void k_tsvq_cov_axis(packed16_rows src,
         [&](const float* f, const double*, uint32_t m) {
             if (tid < C) chain_add_prod_f32(cv, f + (size_t)cx * TQ_STRIDE, f + (size_t)(N + cy) * TQ_STRIDE, m);
         });
-    if (tid < C) s_cov[cx][cy] = cv;
-    __syncthreads();
-    if (tid == 0) {
+    if (tid < C) {
         const float renorm = 1.0f / (float)nd.weight;
-        for (int x = 0; x < N; x++) for (int y = x; y < N; y++) s_cov[x][y] *= renorm;
-        for (int x = 0; x < N - 1; x++) for (int y = x + 1; y < N; y++) s_cov[y][x] = s_cov[x][y];
+        const float e = cv * renorm;
+        s_cov[cx][cy] = e; s_cov[cy][cx] = e;
     }
     __syncthreads();
     if (tid < 64) principal_axis_wave<N>(s_cov, ctrl[blockIdx.x].axis);
@@ -804,6 +868,14 @@ hipError_t launch_tsvq_root(hipStream_t st, int dim, bool packed, bool exact, co
 #undef TQ_LAUNCH_ROOT
     return hipGetLastError();
 }
+
+#ifdef TQ_PROFILE
+extern "C" __attribute__((visibility("default"))) int tsvq_profile_read(unsigned long long* out16) {
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_tq_prof), sizeof(g_tq_prof)) != hipSuccess) return 0;
+    unsigned long long zero[16] = {};
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_tq_prof), zero, sizeof(zero)) == hipSuccess ? 1 : 0;
+}
+#endif
 
 hipError_t launch_tsvq_span_roots(hipStream_t st, int dim, bool packed, bool exact, const void* d_rows, const uint64_t* d_w64, const uint32_t* d_perm0, const uint32_t* d_perm1,
                                   const tsvq_node_in* d_nodes, uint32_t n_nodes, tsvq_root_out* d_outs) {
