@@ -46,7 +46,8 @@ struct tsvq_wide_ctrl {   // device-side state of one node across the passes of 
     int32_t iter, done;
     uint32_t ex_bad;
 };
-// covariance + principal axis of every node (one workgroup each, chained sums) into d_ctrl[i].axis; fills d_packed for the nodes' members
+// covariance chain sums of every node (chained sums, three workgroups per node, each a third of the chains) into d_ctrl[i].sums -- k_wide_finish<WM_COV> makes
+// the axis of them; fills d_packed for the nodes' members
 hipError_t launch_tsvq_cov_axis(hipStream_t st, const uint32_t* d_keys, const uint64_t* d_w64, const uint32_t* d_perm0, const uint32_t* d_perm1,
                                 const tsvq_wide_node* d_nodes, uint32_t n_nodes, tsvq_wide_ctrl* d_ctrl, void* d_packed);
 size_t tsvq_wide_workspace_bytes(uint32_t total_blocks);           // total_blocks = sum over the batch's nodes of ceil(count / 256)

@@ -16,6 +16,7 @@
 // Member lists of every node are ascending index lists (children are stable partitions of the parent).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <utility>
 #include "tsvq_kernels.h"
 #include "tsvq_common.h"
 
@@ -780,48 +781,62 @@ __global__ __launch_bounds__(TQ_THREADS) void k_tsvq_split(Src src, const uint64
     }
 }
 
-// The covariance pass + principal axis of split_node on its own, one workgroup per node, chained sums: the many-workgroup path
-// (tsvq_wide_kernels.hip) uses it for nodes where 136 order-preserving walks cost more than one pass of dependent adds. Also lays
-// the members out in list order (key, float weight) for the passes that follow.
+// The covariance pass of split_node on its own, chained sums, for the many-workgroup path (tsvq_wide_kernels.hip), which uses it for nodes where 136
+// order-preserving walks cost more than one pass of dependent adds. A chain lane is bound by instruction ISSUE, not by the dependent add: a wave64 instruction
+// takes four cycles to issue, and the one-workgroup kernel's lane issues a multiply, an add and half an LDS read per member (11 cycles). The batches that take
+// this path have few nodes, so every node is given COV_GROUPS workgroups, each streaming all members but owning a third of the chains: its four producer waves
+// lay out the chains' PRODUCTS (d[x] * (w * d[y]), the operands and the rounding of enc.h:1819) and its one consumer wave only adds, 16 bytes of LDS per
+// four members (5 cycles per member). The raw sums go to ctrl[].sums; k_wide_finish<WM_COV> turns them into the axis. Group 0 also lays the members out in
+// list order (key, float weight) for the passes that follow.
+constexpr int COV_GROUPS = 3, COV_GROUP_CHAINS = 46;
+constexpr int cov_chain_x(int c) { int x = 0; while (c >= 16 - x) { c -= 16 - x; x++; } return x; }
+constexpr int cov_chain_y(int c) { int x = 0; while (c >= 16 - x) { c -= 16 - x; x++; } return x + c; }
+
+template <int C> struct cov_chain { static constexpr int x = cov_chain_x(C), y = cov_chain_y(C); };
+// the products of chains FIRST + J...: the component indices are template constants, so d[] and wd[] stay in registers
+template <int FIRST, int... J>
+__device__ __forceinline__ void cov_products(float* f, const float (&d)[16], const float (&wd)[16], std::integer_sequence<int, J...>) {
+    ((f[(size_t)J * TQ_STRIDE] = d[cov_chain<FIRST + J>::x] * wd[cov_chain<FIRST + J>::y]), ...);
+}
+
+template <int GROUP>
+__device__ __forceinline__ void cov_axis_group(char* lds, const float* s_origin, packed16_rows src, const uint64_t* __restrict__ w64, const uint32_t* __restrict__ members,
+                                               const tsvq_wide_node& nd, tsvq_wide_ctrl* __restrict__ ct, uint2* __restrict__ pk) {
+    constexpr int N = 16, C = N * (N + 1) / 2;
+    constexpr int FIRST = GROUP * COV_GROUP_CHAINS, COUNT = (C - FIRST) < COV_GROUP_CHAINS ? (C - FIRST) : COV_GROUP_CHAINS;
+    const int tid = threadIdx.x;
+    float cv = 0.0f;
+    pipeline_pass<COV_GROUP_CHAINS, 0, 1>(lds, src, w64, members, nd.count,
+        [&](uint32_t pos, const packed16_rows::payload& p, float* f, double*) {
+            float v[N]; packed16_rows::decode(p, v);
+            const float w = (float)p.w;
+            if (GROUP == 0) pk[nd.start + pos] = make_uint2(p.key, __float_as_uint(w));
+            float d[N], wd[N];
+#pragma unroll
+            for (int k = 0; k < N; k++) { d[k] = v[k] - s_origin[k]; wd[k] = w * d[k]; }
+            cov_products<FIRST>(f, d, wd, std::make_integer_sequence<int, COUNT>{});
+        },
+        [&](const float* f, const double*, uint32_t m) {
+            if (tid < COUNT) chain_add_f32(cv, f + (size_t)tid * TQ_STRIDE, m);
+        });
+    if (tid < COUNT) ct->sums[FIRST + tid] = cv;
+}
+
 __global__ __launch_bounds__(TQ_THREADS) void k_tsvq_cov_axis(packed16_rows src, const uint64_t* __restrict__ w64, const uint32_t* __restrict__ perm0,
                                                              const uint32_t* __restrict__ perm1, const tsvq_wide_node* __restrict__ nodes,
                                                              tsvq_wide_ctrl* __restrict__ ctrl, uint2* __restrict__ pk) {
-    constexpr int N = 16;
+    static_assert(COV_GROUPS == 3 && COV_GROUPS * COV_GROUP_CHAINS >= 136 && COV_GROUP_CHAINS <= 64, "chain groups");
     extern __shared__ __align__(16) char lds[];
     __shared__ float s_origin[16];
-    __shared__ float s_cov[16][16];
     const int tid = threadIdx.x;
     const tsvq_wide_node nd = nodes[blockIdx.x];
     const uint32_t* members = (nd.buf ? perm1 : perm0) + nd.start;
     if (tid < 16) s_origin[tid] = nodes[blockIdx.x].origin[tid];
     __syncthreads();
-    constexpr int C = N * (N + 1) / 2;
-    constexpr int CW = (C + 63) / 64;
-    int cx = 0, cy = 0;
-    if (tid < C) { int cc = tid; while (cc >= N - cx) { cc -= N - cx; cx++; } cy = cx + cc; }
-    float cv = 0.0f;
-    pipeline_pass<2 * N, 0, CW>(lds, src, w64, members, nd.count,
-        [&](uint32_t pos, const packed16_rows::payload& p, float* f, double*) {
-            float v[N]; packed16_rows::decode(p, v);
-            const float w = (float)p.w;
-            pk[nd.start + pos] = make_uint2(p.key, __float_as_uint(w));
-#pragma unroll
-            for (int k = 0; k < N; k++) {
-                const float dk = v[k] - s_origin[k];
-                f[(size_t)k * TQ_STRIDE] = dk;
-                f[(size_t)(N + k) * TQ_STRIDE] = w * dk;
-            }
-        },
-        [&](const float* f, const double*, uint32_t m) {
-            if (tid < C) chain_add_prod_f32(cv, f + (size_t)cx * TQ_STRIDE, f + (size_t)(N + cy) * TQ_STRIDE, m);
-        });
-    if (tid < C) {
-        const float renorm = 1.0f / (float)nd.weight;
-        const float e = cv * renorm;
-        s_cov[cx][cy] = e; s_cov[cy][cx] = e;
-    }
-    __syncthreads();
-    if (tid < 64) principal_axis_wave<N>(s_cov, ctrl[blockIdx.x].axis);
+    // one instantiation per group: which components a chain multiplies must be known at compile time (run-time indices into v[] would put it in scratch)
+    if (blockIdx.y == 0) cov_axis_group<0>(lds, s_origin, src, w64, members, nd, ctrl + blockIdx.x, pk);
+    else if (blockIdx.y == 1) cov_axis_group<1>(lds, s_origin, src, w64, members, nd, ctrl + blockIdx.x, pk);
+    else cov_axis_group<2>(lds, s_origin, src, w64, members, nd, ctrl + blockIdx.x, pk);
 }
 
 // -------------------------------------------------------------------------------------------------------------------
@@ -840,10 +855,10 @@ template <typename K> static hipError_t set_lds(K kernel, size_t lds) {
 hipError_t launch_tsvq_cov_axis(hipStream_t st, const uint32_t* d_keys, const uint64_t* d_w64, const uint32_t* d_perm0, const uint32_t* d_perm1,
                                 const tsvq_wide_node* d_nodes, uint32_t n_nodes, tsvq_wide_ctrl* d_ctrl, void* d_packed) {
     if (!n_nodes) return hipSuccess;
-    const size_t lds = tsvq_lds_bytes(16);
+    const size_t lds = (size_t)2 * COV_GROUP_CHAINS * TQ_STRIDE * sizeof(float);   // two tiles of one float row per chain of the group
     hipError_t e = set_lds(k_tsvq_cov_axis, lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_tsvq_cov_axis, dim3(n_nodes), dim3(TQ_THREADS), lds, st, packed16_rows{d_keys}, d_w64, d_perm0, d_perm1, d_nodes, d_ctrl, static_cast<uint2*>(d_packed));
+    hipLaunchKernelGGL(k_tsvq_cov_axis, dim3(n_nodes, COV_GROUPS), dim3(TQ_THREADS), lds, st, packed16_rows{d_keys}, d_w64, d_perm0, d_perm1, d_nodes, d_ctrl, static_cast<uint2*>(d_packed));
     return hipGetLastError();
 }
 

@@ -828,7 +828,10 @@ hipError_t launch_tsvq_wide_split(hipStream_t st, const uint32_t* d_keys, const 
     if (!n_nodes) return hipSuccess;
     hipError_t e = hipMemsetAsync(d_ctrl, 0, (size_t)n_nodes * sizeof(tsvq_wide_ctrl), st);
     if (e != hipSuccess) return e;
-    if (chained_covariance) { if ((e = launch_tsvq_cov_axis(st, d_keys, d_w64, d_perm0, d_perm1, d_nodes, n_nodes, d_ctrl, d_packed)) != hipSuccess) return e; }
+    if (chained_covariance) {   // raw chain sums into ctrl[].sums (three workgroups per node), then the pass's own tail: renormalisation + principal axis
+        if ((e = launch_tsvq_cov_axis(st, d_keys, d_w64, d_perm0, d_perm1, d_nodes, n_nodes, d_ctrl, d_packed)) != hipSuccess) return e;
+        hipLaunchKernelGGL((k_wide_finish<WM_COV>), dim3(n_nodes), dim3(64), 0, st, d_nodes, d_ctrl, nullptr);
+    }
     else launch_pass<WM_COV>(st, d_keys, d_w64, d_perm0, d_perm1, d_side, static_cast<uint2*>(d_packed), d_nodes, n_nodes, total_blocks, d_ctrl, d_ws, nullptr);
     launch_pass<WM_PROJ>(st, d_keys, d_w64, d_perm0, d_perm1, d_side, static_cast<uint2*>(d_packed), d_nodes, n_nodes, total_blocks, d_ctrl, d_ws, nullptr, side_chains_exact);
     for (int it = 0; it < 6; it++) launch_pass<WM_DIST>(st, d_keys, d_w64, d_perm0, d_perm1, d_side, static_cast<uint2*>(d_packed), d_nodes, n_nodes, total_blocks, d_ctrl, d_ws, nullptr, side_chains_exact);
