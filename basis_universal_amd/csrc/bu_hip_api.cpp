@@ -1080,9 +1080,46 @@ int bu_hip_tsvq_roots(bu_hip_context* ctx, bu_tsvq* q, const bu_tsvq_node* h_nod
     for (uint32_t i = 0; i < n_nodes; i++)
         if (h_nodes[i].buf > 1 || !h_nodes[i].count || (uint64_t)h_nodes[i].start + h_nodes[i].count > q->n) { set_error(ctx, "tsvq_roots: span outside the training set"); return 0; }
     BU_TRY(ctx, hipStreamSynchronize(ctx->stream));   // the pinned staging buffer may still feed an earlier copy
-    BU_TRY(ctx, q->reserve_pinned((size_t)n_nodes * std::max(sizeof(bu_tsvq_node), sizeof(bu_tsvq_root))));
-    std::vector<uint32_t> todo(n_nodes);
-    for (uint32_t i = 0; i < n_nodes; i++) todo[i] = i;
+    BU_TRY(ctx, q->reserve_pinned((size_t)n_nodes * std::max(std::max(sizeof(bu_tsvq_node), sizeof(bu_tsvq_root)), sizeof(bu::tsvq_wide_node))));
+    std::vector<uint32_t> todo;
+    // large spans of packed rows: the many-workgroup root pass (one batch); a record flagged pad == 1 left its exact range -> the one-workgroup kernels below
+    if (q->wide_min) {
+        std::vector<uint32_t> wide;
+        uint32_t blocks = 0;
+        for (uint32_t i = 0; i < n_nodes; i++) {
+            const uint32_t nb = (h_nodes[i].count + 255) / 256;
+            if (h_nodes[i].count >= q->wide_min && wide.size() < q->wide_nodes_cap && blocks + nb <= q->wide_blocks_cap) { wide.push_back(i); blocks += nb; }
+            else todo.push_back(i);
+        }
+        if (!wide.empty()) {
+            bu::tsvq_wide_node* pw = static_cast<bu::tsvq_wide_node*>(q->pinned);
+            uint32_t first = 0;
+            for (size_t j = 0; j < wide.size(); j++) {
+                const bu_tsvq_node& sp = h_nodes[wide[j]];
+                bu::tsvq_wide_node w; std::memset(&w, 0, sizeof(w));
+                w.buf = sp.buf; w.start = sp.start; w.count = sp.count; w.out_index = (uint32_t)j; w.first_block = first; w.n_blocks = (sp.count + 255) / 256;
+                first += w.n_blocks;
+                pw[j] = w;
+            }
+            BU_TRY(ctx, hipMemcpyAsync(q->wide_nodes, q->pinned, wide.size() * sizeof(bu::tsvq_wide_node), hipMemcpyHostToDevice, ctx->stream));
+            {
+                prof_scope ps(ctx, "tsvq_root_packed16");
+                BU_TRY(ctx, bu::launch_tsvq_wide_span_roots(ctx->stream, static_cast<const uint32_t*>(q->rows), q->w64, q->perm[0], q->perm[1], q->wide_packed, q->wide_nodes,
+                                                            (uint32_t)wide.size(), q->wide_ctrl, q->wide_ws, blocks, static_cast<bu::tsvq_root_out*>(q->outs.p)));
+            }
+            BU_TRY(ctx, hipStreamSynchronize(ctx->stream));   // the node records were read from the pinned buffer the results come back to
+            BU_TRY(ctx, hipMemcpyAsync(q->pinned, q->outs.p, wide.size() * sizeof(bu_tsvq_root), hipMemcpyDeviceToHost, ctx->stream));
+            BU_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            const bu_tsvq_root* po = static_cast<const bu_tsvq_root*>(q->pinned);
+            for (size_t j = 0; j < wide.size(); j++) {
+                if (po[j].pad) todo.push_back(wide[j]); else h_out[wide[j]] = po[j];
+            }
+            std::sort(todo.begin(), todo.end());
+        }
+    } else {
+        todo.resize(n_nodes);
+        for (uint32_t i = 0; i < n_nodes; i++) todo[i] = i;
+    }
     // the exact (integer-reduced) variant first where it applies; a record flagged pad == 1 left the exact range -> the chained one
     for (int attempt = (q->packed && !q->force_chained) ? 0 : 1; attempt < 2 && !todo.empty(); attempt++) {
         bu_tsvq_node* pn = static_cast<bu_tsvq_node*>(q->pinned);
@@ -1093,6 +1130,7 @@ int bu_hip_tsvq_roots(bu_hip_context* ctx, bu_tsvq* q, const bu_tsvq_node* h_nod
             BU_TRY(ctx, bu::launch_tsvq_span_roots(ctx->stream, (int)q->dim, q->packed, attempt == 0, q->rows, q->w64, q->perm[0], q->perm[1],
                                                    static_cast<const bu::tsvq_node_in*>(q->nodes.p), (uint32_t)todo.size(), static_cast<bu::tsvq_root_out*>(q->outs.p)));
         }
+        BU_TRY(ctx, hipStreamSynchronize(ctx->stream));
         BU_TRY(ctx, hipMemcpyAsync(q->pinned, q->outs.p, todo.size() * sizeof(bu_tsvq_root), hipMemcpyDeviceToHost, ctx->stream));
         BU_TRY(ctx, hipStreamSynchronize(ctx->stream));
         const bu_tsvq_root* po = static_cast<const bu_tsvq_root*>(q->pinned);

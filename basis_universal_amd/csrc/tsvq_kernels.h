@@ -53,6 +53,10 @@ hipError_t launch_tsvq_cov_axis(hipStream_t st, const uint32_t* d_keys, const ui
 size_t tsvq_wide_workspace_bytes(uint32_t total_blocks);           // total_blocks = sum over the batch's nodes of ceil(count / 256)
 hipError_t launch_tsvq_wide_root(hipStream_t st, const uint32_t* d_keys, const uint64_t* d_w64, uint32_t n, uint32_t* d_perm0 /* out: 0..n-1 */,
                                  const tsvq_wide_node* d_nodes /* one node: all n vectors */, tsvq_wide_ctrl* d_ctrl, void* d_ws, uint32_t total_blocks, tsvq_root_out* d_out);
+// prepare_root of n_nodes member spans through the many-workgroup passes (nodes: buf / start / count / first_block / n_blocks / out_index); d_outs[out_index].pad == 1:
+// the span's integer totals left the exact range, run it through launch_tsvq_span_roots
+hipError_t launch_tsvq_wide_span_roots(hipStream_t st, const uint32_t* d_keys, const uint64_t* d_w64, const uint32_t* d_perm0, const uint32_t* d_perm1, void* d_packed,
+                                       const tsvq_wide_node* d_nodes, uint32_t n_nodes, tsvq_wide_ctrl* d_ctrl, void* d_ws, uint32_t total_blocks, tsvq_root_out* d_outs);
 hipError_t launch_tsvq_wide_split(hipStream_t st, const uint32_t* d_keys, const uint64_t* d_w64, uint32_t* d_perm0, uint32_t* d_perm1, uint8_t* d_side, void* d_packed /* 8 bytes per vector */,
                                   const tsvq_wide_node* d_nodes, uint32_t n_nodes, tsvq_wide_ctrl* d_ctrl, void* d_ws, uint32_t total_blocks, tsvq_split_out* d_outs,
                                   bool chained_covariance /* the covariance pass through launch_tsvq_cov_axis instead of 136 walks per node */,

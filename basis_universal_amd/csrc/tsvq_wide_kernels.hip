@@ -145,8 +145,11 @@ __global__ __launch_bounds__(WB) void k_wide_sums(const uint32_t* __restrict__ k
     }
     __syncthreads();
     const uint32_t pos = (blk - nd.first_block) * WB + (uint32_t)tid;
-    const uint32_t* members = MODE == WM_ROOT ? nullptr : (nd.buf ? perm1 : perm0) + nd.start;
+    // (the root pass of the whole training set has no member list: perm0 == nullptr; the roots of member SPANS -- the independent trees of the partitioned
+    //  build, enc.h:2137-2152 -- read their span and lay it out in list order like the covariance pass does)
+    const uint32_t* members = (MODE == WM_ROOT && !perm0) ? nullptr : (nd.buf ? perm1 : perm0) + nd.start;
     const member_info m = fetch_member(keys, w64, members, pos, nd.count);
+    if (MODE == WM_ROOT && pk && m.valid) pk[nd.start + pos] = make_uint2(m.key, __float_as_uint(m.wf));
     bool right = false;
     uint64_t red[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (MODE == WM_COV) {
@@ -354,7 +357,7 @@ __device__ __forceinline__ void fetch_packed(const uint32_t* __restrict__ keys, 
                                              uint32_t pos, uint32_t count, uint32_t& key, float& wf, bool& valid) {
     valid = pos < count;
     const uint32_t p = valid ? pos : count - 1;
-    if (MODE == WM_ROOT) { key = keys[p]; wf = (float)w64[p]; }
+    if (MODE == WM_ROOT && !pk) { key = keys[p]; wf = (float)w64[p]; }
     else { const uint2 v = pk[node_start + p]; key = v.x; wf = __uint_as_float(v.y); }
 }
 
@@ -533,7 +536,7 @@ __global__ __launch_bounds__(64) void k_wide_walk(const uint32_t* __restrict__ k
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             const uint32_t pos = min(p0 + (uint32_t)(r * 64 + lane), nd.count - 1);
-            if (MODE == WM_ROOT) { m.key[r] = keys[pos]; m.w[r] = w64[pos]; }
+            if (MODE == WM_ROOT && !pk) { m.key[r] = keys[pos]; m.w[r] = w64[pos]; }
             else { const uint2 v = pk[nd.start + pos]; m.key[r] = v.x; m.w[r] = v.y; }
             m.sd[r] = (MODE == WM_PROJ || MODE == WM_DIST) ? side[nd.start + pos] : (uint8_t)0;
         }
@@ -544,7 +547,7 @@ __global__ __launch_bounds__(64) void k_wide_walk(const uint32_t* __restrict__ k
         for (int r = 0; r < 4; r++) {
             const bool valid = p0 + (uint32_t)(r * 64 + lane) < nd.count;
             const uint32_t key = m.key[r];
-            const float wf = MODE == WM_ROOT ? (float)m.w[r] : __uint_as_float((uint32_t)m.w[r]);
+            const float wf = (MODE == WM_ROOT && !pk) ? (float)m.w[r] : __uint_as_float((uint32_t)m.w[r]);
             float v;
             if (MODE == WM_COV) {
                 const float dx = (float)packed16_value(key, cx) - ox;
@@ -706,6 +709,7 @@ __global__ __launch_bounds__(64) void k_wide_finish(const tsvq_wide_node* __rest
     }
     if (threadIdx.x != 0) return;
     if (MODE == WM_ROOT) {   // prepare_root (enc.h:1708-1735)
+        root_out += nd.out_index;
         if (c.ex_bad) { root_out->pad = 1; c.done = 2; return; }
         float o[N];
         for (int k = 0; k < N; k++) o[k] = c.sums[k];
@@ -714,6 +718,7 @@ __global__ __launch_bounds__(64) void k_wide_finish(const tsvq_wide_node* __rest
         root_out->var = (float)(c.dsum[0] - (double)q);
         const float inv = 1.0f / wfl;
         for (int k = 0; k < N; k++) root_out->origin[k] = o[k] * inv;
+        for (int k = N; k < 16; k++) root_out->origin[k] = 0.0f;
         root_out->weight = c.l_w;
         root_out->pad = 0;
         c.done = 1;
@@ -819,6 +824,15 @@ hipError_t launch_tsvq_wide_root(hipStream_t st, const uint32_t* d_keys, const u
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_wide_iota, dim3((n + 255) / 256), dim3(256), 0, st, n, d_perm0);
     launch_pass<WM_ROOT>(st, d_keys, d_w64, nullptr, nullptr, nullptr, nullptr, d_nodes, 1, total_blocks, d_ctrl, d_ws, d_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_tsvq_wide_span_roots(hipStream_t st, const uint32_t* d_keys, const uint64_t* d_w64, const uint32_t* d_perm0, const uint32_t* d_perm1, void* d_packed,
+                                       const tsvq_wide_node* d_nodes, uint32_t n_nodes, tsvq_wide_ctrl* d_ctrl, void* d_ws, uint32_t total_blocks, tsvq_root_out* d_outs) {
+    if (!n_nodes) return hipSuccess;
+    hipError_t e = hipMemsetAsync(d_ctrl, 0, (size_t)n_nodes * sizeof(tsvq_wide_ctrl), st);
+    if (e != hipSuccess) return e;
+    launch_pass<WM_ROOT>(st, d_keys, d_w64, const_cast<uint32_t*>(d_perm0), const_cast<uint32_t*>(d_perm1), nullptr, static_cast<uint2*>(d_packed), d_nodes, n_nodes, total_blocks, d_ctrl, d_ws, d_outs);
     return hipGetLastError();
 }
 
