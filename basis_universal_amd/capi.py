@@ -103,6 +103,10 @@ _SIGNATURES = {
     "bu_hip_tsvq_create_packed16": (_vp, [_vp, _vp, _vp, _u32, _vp]),
     "bu_hip_tsvq_split": (_int, [_vp, _vp, _vp, _u32, _vp]),
     "bu_hip_tsvq_roots": (_int, [_vp, _vp, _vp, _u32, _vp]),
+    "bu_hip_uastc_pipeline_create": (_vp, [_vp, _u32, _u32, _u32, _u32]),
+    "bu_hip_uastc_pipeline_submit": (_int, [_vp, _vp, _u32, _vp, _vp, _u32, _u32, _vp]),
+    "bu_hip_uastc_pipeline_wait": (_int, [_vp, C.c_uint64, _vp]),
+    "bu_hip_uastc_pipeline_destroy": (None, [_vp]),
     "bu_hip_tsvq_read_members": (_int, [_vp, _vp, _u32, _u32, _u32, _vp]),
     "bu_hip_tsvq_destroy": (None, [_vp, _vp]),
 }

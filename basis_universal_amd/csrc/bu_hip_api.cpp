@@ -176,6 +176,10 @@ extern "C" {
 // ---------------------------------------------------------------------------------------------------------------- init
 
 int bu_hip_init(int /*force_serialization*/) {
+    // Streams of a process share a few hardware queues (ROCm's default: 4) and two streams on one queue run their kernels one after the other; the lanes of the UASTC
+    // pipeline and contexts used side by side want queues of their own. Read by the runtime when it starts: effective when this library is the first to touch HIP in
+    // the process, a no-op otherwise (set GPU_MAX_HW_QUEUES=8 in the environment then). Never overrides the user's own setting.
+    (void)setenv("GPU_MAX_HW_QUEUES", "8", 0);
     std::lock_guard<std::mutex> lock(g_init_mutex);
     if (g_initialized) return 1;
     int n = 0;
@@ -1315,6 +1319,120 @@ int bu_hip_k_uastc_rdo(bu_hip_context* ctx, void* d_blocks, const void* d_px, ui
     if (counters[1]) { set_error(ctx, "uastc_rdo: a block does not unpack as UASTC"); return 0; }
     if (out_stats) { out_stats[0] = counters[0]; out_stats[1] = counters[2]; out_stats[2] = counters[3]; }
     return 1;
+}
+
+// ---------------------------------------------------------------- UASTC (+ RDO) over a stream of images: several in flight (BASELINE configs[4])
+//
+// uastc_rdo's walk is a serial chain per strip (uastc_enc.cpp:3824-4100): one workgroup per strip, ~3 us per block, so the strips of one batch of images occupy a
+// fraction of the chip for ~20 ms whatever the batch holds (96 strips of the Kodak batch: 96 of 256 CUs). Nothing in one batch can fill the rest -- the next batch can:
+// its encode / prepare kernels (and the previous batch's finish) run on the idle CUs while this batch's strips walk. The pipeline owns `lanes` private contexts (stream +
+// workspaces each); a submission is ENQUEUED on the next lane without any host synchronisation -- the finish kernel is launched for the longest list a strip can have
+// instead of waiting for the walk to learn the real one -- and completes behind an event. Results are those of bu_hip_k_encode_uastc_blocks + bu_hip_k_uastc_rdo.
+} // extern "C" (reopened below)
+struct bu_uastc_pipeline {
+    struct lane { bu_hip_context* ctx = nullptr; hipEvent_t done = nullptr, input = nullptr; uint32_t* stats = nullptr; bool busy = false, with_rdo = false; uint64_t ticket = 0; uint32_t strips = 0; };
+    bu_hip_context* parent = nullptr;
+    std::vector<lane> lanes;
+    uint64_t next_ticket = 1;
+};
+extern "C" {
+
+static int uastc_rdo_enqueue(bu_hip_context* ctx, void* d_blocks, const void* d_px, uint32_t n_blocks, const bu_uastc_rdo_params* params, uint32_t flags, uint32_t total_jobs,
+                             uint32_t* h_pinned_counters) {
+    if (!(params->m_max_allowed_rms_increase_ratio > 1.0f) || !params->m_lz_dict_size || !(params->m_lambda > 0.0f)) {
+        set_error(ctx, "uastc_rdo: need max_allowed_rms_increase_ratio > 1, lz_dict_size > 0, lambda > 0");
+        return 0;
+    }
+    const float fp[5] = { params->m_lambda, params->m_max_allowed_rms_increase_ratio, params->m_skip_block_rms_thresh, params->m_max_smooth_block_std_dev,
+                          params->m_smooth_block_max_error_scale };
+    const uint32_t up[3] = { params->m_lz_dict_size, params->m_lz_literal_cost, params->m_endpoint_refinement };
+    arena& ws = ctx->scratch[5];
+    BU_TRY(ctx, ws.reserve(bu::uastc_rdo_workspace_bytes(n_blocks, total_jobs)));
+    for (int phase = 0; phase < 2; phase++) BU_TRY(ctx, bu::launch_uastc_rdo_phase(ctx->stream, phase, d_blocks, d_px, n_blocks, fp, up, flags, total_jobs, ws.p));
+    // the longest list a strip can have (every block of it modified): the launch does not wait for the walk to know better, surplus workgroups leave at once
+    const uint32_t strips = bu::uastc_rdo_strips(n_blocks, total_jobs);
+    const uint32_t longest = strips > 1 ? (total_jobs ? n_blocks / total_jobs : n_blocks) : n_blocks;
+    BU_TRY(ctx, bu::launch_uastc_rdo_finish(ctx->stream, d_blocks, d_px, n_blocks, fp, up, flags, total_jobs, ws.p, longest));
+    BU_TRY(ctx, hipMemcpyAsync(h_pinned_counters, bu::uastc_rdo_counters(ws.p, n_blocks, total_jobs), 16, hipMemcpyDeviceToHost, ctx->stream));
+    return 1;
+}
+
+bu_uastc_pipeline* bu_hip_uastc_pipeline_create(bu_hip_context* ctx, uint32_t lanes, uint32_t max_blocks, uint32_t flags, uint32_t max_total_jobs) {
+    if (!ctx) return nullptr;
+    if (lanes < 1 || lanes > 8 || !max_blocks) { set_error(ctx, "uastc_pipeline_create: 1..8 lanes, max_blocks > 0"); return nullptr; }
+    device_guard g(ctx->device);
+    bu_uastc_pipeline* p = new (std::nothrow) bu_uastc_pipeline();
+    if (!p) return nullptr;
+    p->parent = ctx;
+    p->lanes.resize(lanes);
+    // every workspace at its final size now: growing one later would free it under the kernels of an earlier submission
+    const size_t ws_bytes = std::max(bu::uastc_workspace_bytes(max_blocks, flags), bu::uastc_rdo_workspace_bytes(max_blocks, max_total_jobs));
+    for (auto& l : p->lanes) {
+        l.ctx = bu_hip_create_context_on(ctx->device);
+        if (!l.ctx || hipEventCreateWithFlags(&l.done, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&l.input, hipEventDisableTiming) != hipSuccess ||
+            hipHostMalloc(reinterpret_cast<void**>(&l.stats), 64, hipHostMallocDefault) != hipSuccess || l.ctx->scratch[5].reserve(ws_bytes) != hipSuccess) {
+            set_error(ctx, "uastc_pipeline_create: lane set-up failed (%s)", l.ctx ? bu_hip_last_error(l.ctx) : "no context");
+            bu_hip_uastc_pipeline_destroy(p);
+            return nullptr;
+        }
+    }
+    return p;
+}
+
+static int uastc_pipeline_collect(bu_uastc_pipeline* p, bu_uastc_pipeline::lane& l, uint32_t out_stats[4]) {
+    if (!l.busy) return 1;
+    if (hipEventSynchronize(l.done) != hipSuccess) { set_error(p->parent, "uastc_pipeline: a submission failed on the device"); l.busy = false; return 0; }
+    l.busy = false;
+    if (out_stats) { out_stats[0] = l.with_rdo ? l.stats[0] : 0; out_stats[1] = l.with_rdo ? l.stats[2] : 0; out_stats[2] = l.with_rdo ? l.stats[3] : 0; out_stats[3] = l.strips; }
+    if (l.with_rdo && l.stats[1]) { set_error(p->parent, "uastc_rdo: a block does not unpack as UASTC"); return 0; }
+    return 1;
+}
+
+int bu_hip_uastc_pipeline_submit(bu_uastc_pipeline* p, const void* d_px, uint32_t n_blocks, void* d_out, const bu_uastc_rdo_params* rdo, uint32_t flags, uint32_t total_jobs,
+                                 uint64_t* out_ticket) {
+    if (!p) return 0;
+    bu_hip_context* ctx = p->parent;
+    if (!d_px || !d_out || !n_blocks) { set_error(ctx, "uastc_pipeline_submit: null pointer / no blocks"); return 0; }
+    device_guard g(ctx->device);
+    const uint64_t ticket = p->next_ticket;
+    bu_uastc_pipeline::lane& l = p->lanes[(size_t)(ticket % p->lanes.size())];
+    if (!uastc_pipeline_collect(p, l, nullptr)) return 0;   // the lane's previous submission (its results are complete from here on; nobody asked for its statistics)
+    const size_t need = std::max(bu::uastc_workspace_bytes(n_blocks, flags), rdo ? bu::uastc_rdo_workspace_bytes(n_blocks, total_jobs) : (size_t)0);
+    if (need > l.ctx->scratch[5].cap) { set_error(ctx, "uastc_pipeline_submit: %u blocks / %u jobs exceed what the pipeline was created for", n_blocks, total_jobs); return 0; }
+    // the input tiles may still be being produced on the caller's stream
+    BU_TRY(ctx, hipEventRecord(l.input, ctx->stream));
+    BU_TRY(ctx, hipStreamWaitEvent(l.ctx->stream, l.input, 0));
+    if (!bu_hip_k_encode_uastc_blocks(l.ctx, d_px, n_blocks, flags, d_out)) { set_error(ctx, "uastc_pipeline_submit: %s", bu_hip_last_error(l.ctx)); return 0; }
+    l.with_rdo = rdo != nullptr;
+    l.strips = rdo ? bu::uastc_rdo_strips(n_blocks, total_jobs) : 0;
+    if (rdo && !uastc_rdo_enqueue(l.ctx, d_out, d_px, n_blocks, rdo, flags, total_jobs, l.stats)) { set_error(ctx, "uastc_pipeline_submit: %s", bu_hip_last_error(l.ctx)); return 0; }
+    BU_TRY(ctx, hipEventRecord(l.done, l.ctx->stream));
+    l.busy = true; l.ticket = ticket;
+    p->next_ticket++;
+    if (out_ticket) *out_ticket = ticket;
+    return 1;
+}
+
+int bu_hip_uastc_pipeline_wait(bu_uastc_pipeline* p, uint64_t ticket, uint32_t out_stats[4]) {
+    if (!p) return 0;
+    if (out_stats) out_stats[0] = out_stats[1] = out_stats[2] = out_stats[3] = 0;
+    device_guard g(p->parent->device);
+    int ok = 1;
+    for (auto& l : p->lanes)
+        if (l.busy && (ticket == 0 || l.ticket == ticket)) ok &= uastc_pipeline_collect(p, l, ticket ? out_stats : nullptr);
+    return ok;
+}
+
+void bu_hip_uastc_pipeline_destroy(bu_uastc_pipeline* p) {
+    if (!p) return;
+    for (auto& l : p->lanes) {
+        if (l.ctx) { device_guard g(l.ctx->device); (void)hipStreamSynchronize(l.ctx->stream); }
+        if (l.done) (void)hipEventDestroy(l.done);
+        if (l.input) (void)hipEventDestroy(l.input);
+        if (l.stats) (void)hipHostFree(l.stats);
+        if (l.ctx) bu_hip_destroy_context(l.ctx);
+    }
+    delete p;
 }
 
 int bu_hip_uastc_rdo(bu_hip_context* ctx, bu_uastc_block* blocks, const bu_uastc_rdo_params* params, uint32_t flags, uint32_t total_jobs, uint32_t out_stats[4]) {

@@ -101,3 +101,40 @@ def uastc_rdo(ctx, uastc_blocks, pixel_blocks, params=None, flags=LEVEL_DEFAULT,
     finally:
         for d in owned:
             ctx.free(d)
+
+
+class UastcPipeline:
+    """encode_uastc (+ uastc_rdo) over a stream of images with several in flight on one GPU (bu_hip_uastc_pipeline_*, include/basisu_hip.h): every submission is
+    enqueued on one of `lanes` private streams without a host synchronisation, so one image's RDO walk (a serial chain per strip that leaves most of the chip idle)
+    runs beside the next image's encode kernels. Device pointers in, device pointers out; bytes as encode_uastc_blocks followed by uastc_rdo."""
+
+    def __init__(self, ctx, lanes, max_blocks, flags=LEVEL_DEFAULT, max_total_jobs=4):
+        self.ctx = ctx
+        self.h = ctx.lib.uastc_pipeline_create(ctx.h, int(lanes), int(max_blocks), int(flags), int(max_total_jobs))
+        if not self.h:
+            raise capi.HipError(f"uastc_pipeline_create failed: {ctx.lib.last_error(ctx.h)}")
+
+    def submit(self, d_px, n_blocks, d_out, rdo_params=None, flags=LEVEL_DEFAULT, total_jobs=0):
+        """-> ticket. rdo_params: an RdoParams to run the post-pass, None for the plain encode."""
+        ticket = C.c_uint64()
+        self._keep = rdo_params   # the structure is read during the call only; kept for symmetry with the other wrappers
+        self.ctx.check(self.ctx.lib.uastc_pipeline_submit(self.h, C.c_void_p(d_px), int(n_blocks), C.c_void_p(d_out), C.byref(rdo_params) if rdo_params is not None else None,
+                                                          int(flags), int(total_jobs), C.byref(ticket)), "uastc_pipeline_submit")
+        return ticket.value
+
+    def wait(self, ticket=0):
+        """ticket 0: everything submitted so far. Returns the ticket's RDO statistics (zeros for ticket 0)."""
+        stats = (C.c_uint32 * 4)()
+        self.ctx.check(self.ctx.lib.uastc_pipeline_wait(self.h, int(ticket), stats), "uastc_pipeline_wait")
+        return {"modified": stats[0], "refined": stats[1], "skipped": stats[2], "strips": stats[3]}
+
+    def close(self):
+        if self.h:
+            self.ctx.lib.uastc_pipeline_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -219,6 +219,22 @@ BU_HIP_API int bu_hip_k_uastc_rdo(bu_hip_context*, void* d_uastc_blocks, const v
 BU_HIP_API int bu_hip_uastc_rdo(bu_hip_context*, bu_uastc_block* blocks, const bu_uastc_rdo_params* params, uint32_t flags, uint32_t total_jobs,
                                 uint32_t out_stats[4]);
 
+/* encode_uastc (+ uastc_rdo) over a STREAM of images with several in flight on one GPU -- what basis_parallel_compress (comp.cpp:5466-5559) does with a job pool for
+ * BASELINE configs[4]'s batch. The RDO walk is one serial chain per strip and leaves most of the chip idle (96 strips of the Kodak batch: 96 of 256 CUs for ~20 ms);
+ * the pipeline owns `lanes` private streams + workspaces and ENQUEUES every submission without a host synchronisation, so the next submission's encode kernels and the
+ * previous one's hint refit run beside this one's walk. Bytes out = bu_hip_k_encode_uastc_blocks followed (rdo != NULL) by bu_hip_k_uastc_rdo; `flags` as there (callers
+ * add cPackUASTCFavorSimplerModes for RDO themselves, as comp.cpp:2016-2018 does).
+ *   create : lanes 1..8 (3 fills an MI355X with Kodak-sized batches); max_blocks / max_total_jobs size the workspaces once (they never grow afterwards)
+ *   submit : d_px (n_blocks x 64 B) must stay valid and d_out (n_blocks x 16 B) unread until the ticket is waited for; inputs may still be in flight on the context's
+ *            stream (the lane waits for them on the device). Blocks only when its lane's previous submission has not finished yet.
+ *   wait   : ticket 0 = everything submitted so far; out_stats (may be NULL) = {modified, refined, skipped, strips} of that ticket, as bu_hip_k_uastc_rdo reports them */
+typedef struct bu_uastc_pipeline bu_uastc_pipeline;
+BU_HIP_API bu_uastc_pipeline* bu_hip_uastc_pipeline_create(bu_hip_context*, uint32_t lanes, uint32_t max_blocks, uint32_t flags, uint32_t max_total_jobs);
+BU_HIP_API int  bu_hip_uastc_pipeline_submit(bu_uastc_pipeline*, const void* d_pixel_blocks, uint32_t n_blocks, void* d_out_uastc_blocks, const bu_uastc_rdo_params* rdo_or_null,
+                                             uint32_t flags, uint32_t total_jobs, uint64_t* out_ticket);
+BU_HIP_API int  bu_hip_uastc_pipeline_wait(bu_uastc_pipeline*, uint64_t ticket, uint32_t out_stats[4]);
+BU_HIP_API void bu_hip_uastc_pipeline_destroy(bu_uastc_pipeline*);
+
 /* a15 + the list handling inside a9 / a10 / a13 / a14: cluster bookkeeping on the device (basis_universal_amd/csrc/bookkeeping_kernels.hip).
  *     A clustering is two resident per-block arrays, cluster index and position inside the cluster's list; these calls turn distinct-vector level
  *     results into them, rebuild them after a reassignment, apply codebook renumberings to them and produce the CSR lists the per-cluster
