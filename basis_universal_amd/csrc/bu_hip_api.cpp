@@ -139,10 +139,14 @@ void prof_drain(bu_hip_context* ctx) {
 hipError_t h2d(bu_hip_context* ctx, void* d, const void* h, size_t bytes) {
     if (!bytes) return hipSuccess;
     hipError_t e;
-    if (bytes > ((size_t)8 << 20)) {
-        if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) return e;
-        if ((e = hipMemcpy(d, h, bytes, hipMemcpyHostToDevice)) != hipSuccess) return e;
-        return hipDeviceSynchronize();
+    if (bytes > ((size_t)4 << 20)) {
+        // large uploads (an image's tiles) go through the ring in 4 MiB pieces: a blocking hipMemcpy + hipDeviceSynchronize here made every image's upload wait for
+        // every OTHER context's kernels (basis_parallel_compress: one context per image in flight), which serialised the images
+        for (size_t at = 0; at < bytes; at += (size_t)4 << 20) {
+            const size_t piece = std::min(bytes - at, (size_t)4 << 20);
+            if ((e = h2d(ctx, static_cast<char*>(d) + at, static_cast<const char*>(h) + at, piece)) != hipSuccess) return e;
+        }
+        return hipSuccess;
     }
     const size_t need = (bytes + 255) & ~(size_t)255;
     if (need > ctx->stage_cap - ctx->stage_used) {
@@ -150,7 +154,7 @@ hipError_t h2d(bu_hip_context* ctx, void* d, const void* h, size_t bytes) {
         ctx->stage_used = 0;
         if (need > ctx->stage_cap) {
             if (ctx->stage) { (void)hipHostFree(ctx->stage); ctx->stage = nullptr; ctx->stage_cap = 0; }
-            const size_t want = std::max(need * 2, (size_t)4 << 20);
+            const size_t want = std::max(need * 2, (size_t)16 << 20);
             if ((e = hipHostMalloc(&ctx->stage, want, hipHostMallocDefault)) != hipSuccess) { ctx->stage = nullptr; return e; }
             ctx->stage_cap = want;
         }
@@ -194,7 +198,22 @@ int bu_hip_init(int /*force_serialization*/) {
     return 1;
 }
 
+// Contexts are PARKED, not torn down, when they are destroyed: the reference's throughput driver (basis_parallel_compress, comp.cpp:5466-5559) creates one accelerator
+// context per image and destroys it with the image, and a context's worth of device buffers costs ~20 hipMalloc calls to build and as many hipFree calls -- each one a
+// DEVICE-wide synchronisation that stalls every other image's stream -- to tear down. A parked context keeps its stream, its workspaces and its block pool; the next
+// bu_hip_create_context on that device gets it back, warm. At most BU_HIP_PARKED_CONTEXTS (default 16, 0 = off) are kept; bu_hip_deinit releases them.
+static std::mutex g_park_lock;
+static std::vector<bu_hip_context*> g_parked;
+static void context_release(bu_hip_context* ctx);   // the real teardown
+static size_t park_limit() {
+    static const size_t n = [] { const char* e = std::getenv("BU_HIP_PARKED_CONTEXTS"); const long v = e ? std::atol(e) : 16; return (size_t)(v < 0 ? 0 : (v > 64 ? 64 : v)); }();
+    return n;
+}
+
 void bu_hip_deinit(void) {
+    std::vector<bu_hip_context*> parked;
+    { std::lock_guard<std::mutex> g(g_park_lock); parked.swap(g_parked); }
+    for (bu_hip_context* c : parked) context_release(c);
     std::lock_guard<std::mutex> lock(g_init_mutex);
     g_initialized = false;
 }
@@ -205,6 +224,11 @@ bu_hip_context* bu_hip_create_context_on(int device) {
     if (!g_initialized) { set_error(nullptr, "bu_hip_create_context: bu_hip_init() has not succeeded"); return nullptr; }
     if (device < 0 || device >= g_device_count) { set_error(nullptr, "bu_hip_create_context: bad device %d", device); return nullptr; }
     if (hipSetDevice(device) != hipSuccess) { set_error(nullptr, "hipSetDevice(%d) failed", device); return nullptr; }
+    {
+        std::lock_guard<std::mutex> g(g_park_lock);
+        for (size_t i = 0; i < g_parked.size(); i++)
+            if (g_parked[i]->device == device) { bu_hip_context* c = g_parked[i]; g_parked.erase(g_parked.begin() + (long)i); return c; }
+    }
     bu_hip_context* ctx = new (std::nothrow) bu_hip_context();
     if (!ctx) return nullptr;
     ctx->device = device;
@@ -248,12 +272,32 @@ void bu_hip_destroy_context(bu_hip_context* ctx) {
         cb.first(cb.second);
     }
     (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->side_stream) (void)hipStreamSynchronize(ctx->side_stream);
+    if (ctx->own_stream != ctx->stream) (void)hipStreamSynchronize(ctx->own_stream);
+    prof_drain(ctx);
+    if (park_limit()) {
+        // back to the state bu_hip_create_context_on hands out, with the memory kept: blocks the caller leaked join the free list (the context owns all device memory it handed out)
+        for (auto& b : ctx->pool_live) { ctx->pool_free.push_back(b); ctx->pool_free_bytes += b.cap; }
+        ctx->pool_live.clear();
+        ctx->stream = ctx->own_stream;
+        ctx->d_pixel_blocks = nullptr; ctx->total_blocks = 0;
+        ctx->stage_used = 0;
+        ctx->error.clear();
+        ctx->profiling = false; ctx->prof_totals.clear();
+        std::lock_guard<std::mutex> g(g_park_lock);
+        if (g_parked.size() < park_limit()) { g_parked.push_back(ctx); return; }
+    }
+    context_release(ctx);
+}
+
+static void context_release(bu_hip_context* ctx) {
+    (void)hipSetDevice(ctx->device);
     ctx->pixel_arena.release();
     for (auto& a : ctx->scratch) a.release();
     ctx->refine_lists.release();
     if (ctx->tsvq_pinned) (void)hipHostFree(ctx->tsvq_pinned);
     for (auto& b : ctx->pool_free) (void)hipFree(b.p);
-    for (auto& b : ctx->pool_live) (void)hipFree(b.p);  // leaked by the caller; the context owns all device memory it handed out
+    for (auto& b : ctx->pool_live) (void)hipFree(b.p);
     if (ctx->stage) (void)hipHostFree(ctx->stage);
     if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
     if (ctx->side_fork) (void)hipEventDestroy(ctx->side_fork);

@@ -7,8 +7,11 @@
 //   _ref/process_bench_resident   + integration/basisu_resident_{frontend,backend}.cpp: the whole ETC1S path resident on the GPU
 // OURS; it only calls the reference's public API.
 //
-// usage: process_bench <raw rgba file> <width> <height> <quality 1..255> <comp level 0..6> <threads> <use_opencl 0|1> <repeats> [out.basis]
+// usage: process_bench <raw rgba file> <width> <height> <quality 1..255> <comp level 0..6> <threads> <use_opencl 0|1> <repeats> [out.basis | -] [parallel images]
 // prints one JSON line: seconds of init / process per repeat, the output size and an FNV-1a hash of the .basis bytes.
+// With `parallel images` = N > 0 the image is compressed N x `repeats` times through the reference's own throughput driver, basis_parallel_compress
+// (comp.cpp:5466-5559: a pool of `threads` workers, one basis_compressor -- and with use_opencl one accelerator context -- per image in flight): the JSON line
+// then carries the wall seconds of each call, and whether every image's bytes equal the others'.
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -34,6 +37,47 @@ int main(int argc, char** argv) {
         FILE* f = std::fopen(argv[1], "rb");
         if (!f || std::fread(img.get_ptr(), 4, (size_t)w * h, f) != (size_t)w * h) { std::fprintf(stderr, "cannot read %s\n", argv[1]); return 2; }
         std::fclose(f);
+    }
+    const int parallel = argc > 10 ? std::atoi(argv[10]) : 0;
+    if (parallel > 0) {
+        auto make = [&] {
+            basis_compressor_params p;
+            p.m_source_images.push_back(img);
+            p.m_use_opencl = use_opencl;
+            p.m_perceptual = true;
+            p.m_ktx2_and_basis_srgb_transfer_function = true;
+            p.m_quality_level = quality;
+            p.m_etc1s_compression_level = level;
+            p.m_write_output_basis_or_ktx2_files = false;
+            p.m_compute_stats = false;
+            p.m_status_output = false;
+            p.m_debug = false;
+            return p;
+        };
+        basisu::vector<basis_compressor_params> pv;
+        for (int i = 0; i < parallel; i++) pv.push_back(make());
+        std::vector<double> t_call;
+        uint64_t hash0 = 0; size_t bytes0 = 0; bool all_same = true, ok = true;
+        for (int r = 0; r < repeats; r++) {
+            basisu::vector<parallel_results> res;
+            const double t0 = now();
+            ok &= basis_parallel_compress(threads < 1 ? 1 : threads, pv, res);
+            t_call.push_back(now() - t0);
+            for (size_t i = 0; i < res.size(); i++) {
+                const uint8_vec& out = res[i].m_basis_file;
+                uint64_t h = 1469598103934665603ull;
+                for (size_t k = 0; k < out.size(); k++) { h ^= out[k]; h *= 1099511628211ull; }
+                if (r == 0 && i == 0) { hash0 = h; bytes0 = out.size(); }
+                all_same &= h == hash0 && out.size() == bytes0;
+            }
+        }
+        if (!ok) { std::fprintf(stderr, "basis_parallel_compress failed\n"); return 1; }
+        std::printf("{\"width\": %u, \"height\": %u, \"quality\": %d, \"level\": %d, \"threads\": %u, \"use_opencl\": %d, \"parallel_images\": %d, \"bytes\": %zu, \"fnv1a64\": \"%016llx\", "
+                    "\"all_images_identical\": %s, \"call_s\": [", w, h, quality, level, threads, use_opencl ? 1 : 0, parallel, bytes0, (unsigned long long)hash0, all_same ? "true" : "false");
+        for (size_t i = 0; i < t_call.size(); i++) std::printf("%s%.6f", i ? ", " : "", t_call[i]);
+        std::printf("]}\n");
+        basisu_encoder_deinit();
+        return 0;
     }
     job_pool jpool(threads < 1 ? 1 : threads);   // total pool size including the calling thread (basisu_tool.cpp:2345-2346)
     std::vector<double> t_init, t_process;
@@ -64,7 +108,7 @@ int main(int argc, char** argv) {
         bytes = out.size();
         hash = 1469598103934665603ull;
         for (size_t i = 0; i < out.size(); i++) { hash ^= out[i]; hash *= 1099511628211ull; }
-        if (argc > 9 && r == 0) { FILE* f = std::fopen(argv[9], "wb"); if (f) { std::fwrite(out.data(), 1, out.size(), f); std::fclose(f); } }
+        if (argc > 9 && r == 0 && std::strcmp(argv[9], "-") != 0) { FILE* f = std::fopen(argv[9], "wb"); if (f) { std::fwrite(out.data(), 1, out.size(), f); std::fclose(f); } }
     }
     std::printf("{\"width\": %u, \"height\": %u, \"quality\": %d, \"level\": %d, \"threads\": %u, \"use_opencl\": %d, \"bytes\": %zu, \"fnv1a64\": \"%016llx\", \"init_s\": [", w, h, quality,
                 level, threads, use_opencl ? 1 : 0, bytes, (unsigned long long)hash);
