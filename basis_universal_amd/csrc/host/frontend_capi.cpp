@@ -1,5 +1,6 @@
 // frontend_capi.cpp -- extern "C" wrapper of bu::etc1s_frontend (include/basisu_hip_frontend.h).
 #include <cmath>
+#include <cstddef>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -81,6 +82,18 @@ int bu_frontend_init(bu_frontend* f, bu_hip_context* ctx, const bu_pixel_block* 
 int bu_frontend_set_comm(bu_frontend* f, const bu_comm* comm) try {
     if (!f) return 0;
     f->fe.set_comm(comm);
+    return 1;
+} BU_CATCH(0)
+
+// A caller built against an older header passes a shorter bu_comm: what it does not carry is zero (stream_ordered = 0: the blocking convention of the first version)
+int bu_frontend_set_comm_sized(bu_frontend* f, const bu_comm* comm, uint32_t struct_bytes) try {
+    if (!f) return 0;
+    if (!comm) { f->fe.set_comm(nullptr); return 1; }
+    if (struct_bytes < offsetof(bu_comm, stream_ordered)) return 0;   // not even the first version's fields
+    bu_comm c;
+    std::memset(&c, 0, sizeof(c));
+    std::memcpy(&c, comm, std::min<size_t>(struct_bytes, sizeof(c)));
+    f->fe.set_comm(&c);
     return 1;
 } BU_CATCH(0)
 

@@ -11,16 +11,27 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/basisu_hip_comm.h"
 
 static_assert(BU_RCCL_UNIQUE_ID_BYTES == sizeof(ncclUniqueId), "unique id size");
 
+// The communicators one bu_rccl_comm_init_all call made live in ONE process. A collective only completes once every rank has enqueued its part, so a host thread
+// that drives two of them in turn waits inside the first call for the second it has not made yet: each communicator of a group is bound to the first thread that
+// issues a collective on it, and a thread that already drives another member of the group gets an error instead of a hang.
+struct comm_group {
+    std::mutex lock;
+    std::vector<std::thread::id> owner;
+    std::vector<uint8_t> owned;
+    uint32_t alive = 0;
+};
 struct bu_rccl_comm {
     ncclComm_t comm = nullptr;
     bu_hip_context* ctx = nullptr;
     uint32_t rank = 0, world = 1;
+    comm_group* group = nullptr;   // null for communicators made by bu_rccl_comm_create (one per process)
 };
 
 namespace {
@@ -36,9 +47,26 @@ int fail(const char* fmt, ...) {
     return 0;
 }
 
+// 1 = this thread may drive c; 0 = it already drives another communicator of the same bu_rccl_comm_init_all group
+int thread_rule(bu_rccl_comm* c, const char* what) {
+    if (!c->group) return 1;
+    comm_group& g = *c->group;
+    const std::thread::id me = std::this_thread::get_id();
+    std::lock_guard<std::mutex> lk(g.lock);
+    for (uint32_t j = 0; j < g.owner.size(); j++)
+        if (j != c->rank && g.owned[j] && g.owner[j] == me)
+            return fail("%s: this host thread already drives rank %u of the same bu_rccl_comm_init_all group; a collective completes only when every rank has enqueued "
+                        "its part, so every communicator of a group needs a thread of its own (include/basisu_hip_comm.h)", what, j);
+    if (g.owned[c->rank] && g.owner[c->rank] != me) return fail("%s: rank %u is driven by another host thread already", what, c->rank);
+    g.owned[c->rank] = 1; g.owner[c->rank] = me;
+    return 1;
+}
+
 int all_gather(void* user, void* d_buf, uint64_t bytes_per_rank) {
     bu_rccl_comm* c = static_cast<bu_rccl_comm*>(user);
-    if (!c || !c->comm) return fail("all_gather: no communicator");
+    if (!c) return fail("all_gather: no communicator");
+    if (!thread_rule(c, "all_gather")) return 0;
+    if (!c->comm) return fail("all_gather: no communicator");
     hipStream_t st = static_cast<hipStream_t>(bu_hip_get_stream(c->ctx));
     if (hipSetDevice(bu_hip_context_device(c->ctx)) != hipSuccess) return fail("all_gather: hipSetDevice failed");
     char* base = static_cast<char*>(d_buf);
@@ -49,7 +77,9 @@ int all_gather(void* user, void* d_buf, uint64_t bytes_per_rank) {
 
 int all_reduce_u64(void* user, void* d_buf, uint64_t count) {
     bu_rccl_comm* c = static_cast<bu_rccl_comm*>(user);
-    if (!c || !c->comm) return fail("all_reduce: no communicator");
+    if (!c) return fail("all_reduce: no communicator");
+    if (!thread_rule(c, "all_reduce")) return 0;
+    if (!c->comm) return fail("all_reduce: no communicator");
     hipStream_t st = static_cast<hipStream_t>(bu_hip_get_stream(c->ctx));
     if (hipSetDevice(bu_hip_context_device(c->ctx)) != hipSuccess) return fail("all_reduce: hipSetDevice failed");
     const ncclResult_t r = ncclAllReduce(d_buf, d_buf, (size_t)count, ncclUint64, ncclSum, c->comm, st);
@@ -92,10 +122,29 @@ int bu_rccl_comm_init_all(bu_hip_context* const* ctxs, uint32_t n, bu_rccl_comm*
     std::vector<ncclComm_t> comms(n, nullptr);
     const ncclResult_t r = ncclCommInitAll(comms.data(), (int)n, devs.data());
     if (r != ncclSuccess) return fail("ncclCommInitAll: %s", ncclGetErrorString(r));
+    comm_group* grp = new (std::nothrow) comm_group();
+    if (!grp) { for (uint32_t j = 0; j < n; j++) (void)ncclCommDestroy(comms[j]); return fail("comm_init_all: out of memory"); }
+    grp->owner.resize(n); grp->owned.assign(n, 0); grp->alive = n;
     for (uint32_t i = 0; i < n; i++) {
         bu_rccl_comm* c = new (std::nothrow) bu_rccl_comm();
-        if (!c) { for (uint32_t j = 0; j < n; j++) { if (j < i) { delete out[j]; } (void)ncclCommDestroy(comms[j]); } return fail("comm_init_all: out of memory"); }
-        c->comm = comms[i]; c->ctx = ctxs[i]; c->rank = i; c->world = n;
+        if (!c) { for (uint32_t j = 0; j < n; j++) { if (j < i) { delete out[j]; } (void)ncclCommDestroy(comms[j]); } delete grp; return fail("comm_init_all: out of memory"); }
+        c->comm = comms[i]; c->ctx = ctxs[i]; c->rank = i; c->world = n; c->group = grp;
+        out[i] = c;
+    }
+    return 1;
+}
+
+// Test hook (tests/test_host_logic.py, no GPU needed): a group of n communicators with NO RCCL communicator behind them -- a collective on one of them fails with
+// "no communicator" when the calling thread may drive it and with the thread rule's message when it may not, which is all the rule's test needs to tell apart.
+int bu_rccl_debug_unconnected_group(uint32_t n, bu_rccl_comm** out) {
+    if (!out || !n) return fail("debug_unconnected_group: bad arguments");
+    comm_group* grp = new (std::nothrow) comm_group();
+    if (!grp) return fail("debug_unconnected_group: out of memory");
+    grp->owner.resize(n); grp->owned.assign(n, 0); grp->alive = n;
+    for (uint32_t i = 0; i < n; i++) {
+        bu_rccl_comm* c = new (std::nothrow) bu_rccl_comm();
+        if (!c) return fail("debug_unconnected_group: out of memory");
+        c->rank = i; c->world = n; c->group = grp;
         out[i] = c;
     }
     return 1;
@@ -104,6 +153,11 @@ int bu_rccl_comm_init_all(bu_hip_context* const* ctxs, uint32_t n, bu_rccl_comm*
 void bu_rccl_comm_destroy(bu_rccl_comm* c) {
     if (!c) return;
     if (c->comm) (void)ncclCommDestroy(c->comm);
+    if (c->group) {
+        bool last;
+        { std::lock_guard<std::mutex> lk(c->group->lock); c->group->owned[c->rank] = 0; last = --c->group->alive == 0; }
+        if (last) delete c->group;
+    }
     delete c;
 }
 

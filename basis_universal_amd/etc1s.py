@@ -212,7 +212,8 @@ class Etc1sFrontend:
         if max_threads:
             self._check(self.L.bu_frontend_set_max_threads(self.h, int(max_threads)), "bu_frontend_set_max_threads")
         if comm is not None:
-            self._check(self.L.bu_frontend_set_comm(self.h, C.byref(comm.struct)), "bu_frontend_set_comm")
+            self.L.bu_frontend_set_comm_sized.argtypes = [_vp, _vp, C.c_uint32]
+            self._check(self.L.bu_frontend_set_comm_sized(self.h, C.byref(comm.struct), C.sizeof(comm.struct)), "bu_frontend_set_comm_sized")
 
     def _check(self, ok, what):
         if not ok:

@@ -273,7 +273,7 @@ def main():
                                    f"basisu_frontend init+compress with tiles resident in HBM",
                        "blocks": n_blocks, "max_endpoint_clusters": max_ep, "max_selector_clusters": max_sel,
                        "final_endpoint_clusters": final_ep, "final_selector_clusters": final_sel,
-                       "images_in_flight_per_gpu": args.streams,
+                       "images_in_flight_per_gpu": args.streams, "host_threads_per_rank": int(os.environ.get("BU_HOST_THREADS", "8")), "host_cpus": host_cpus(),
                        "parallelism": (f"one image sharded over {world} GPUs: block-row slabs + cluster shares, RCCL all_gather / all_reduce between stages, TSVQ replicated"
                                        if sharded else f"{world} x one image per GPU (no collective)")},
             "roofline": roofline,

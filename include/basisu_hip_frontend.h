@@ -40,6 +40,9 @@ typedef struct bu_comm {
     uint32_t stream_ordered, reserved;
 } bu_comm;
 BU_HIP_API int bu_frontend_set_comm(bu_frontend*, const bu_comm* comm); /* NULL = single GPU; call before bu_frontend_init */
+/* The same for a caller that says how large ITS bu_comm is (sizeof(bu_comm) of the header it was built against): the struct has grown at its end (stream_ordered) and may
+ * again; fields the caller's version does not have are taken as 0 (= the blocking convention). Prefer this entry point from bindings that outlive a header version. */
+BU_HIP_API int bu_frontend_set_comm_sized(bu_frontend*, const bu_comm* comm, uint32_t struct_bytes);
 /* basisu_frontend::params::m_tex_type == cBASISTexTypeVideoFrames (frontend.cpp:219-223, 291: one more fit of the merged endpoint codebook, endpoints
  * refitted to the selectors at every level); call before bu_frontend_init. The backend's half is bu_backend_params::video. */
 BU_HIP_API int bu_frontend_set_video(bu_frontend*, int video);

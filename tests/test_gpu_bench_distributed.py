@@ -68,3 +68,16 @@ def test_sharded_image_mode_two_ranks(single):
     for k in ("final_endpoint_clusters", "final_selector_clusters", "max_endpoint_clusters", "max_selector_clusters"):
         assert d["config"][k] == single["config"][k], k
     assert d["psnr"] == single["psnr"]
+
+
+def test_weak_scaling_mode_eight_ranks_share_the_gpu(single):
+    """The driver's 8-GPU launch in its default mode, on the one GPU there is: eight processes, eight contexts and eight resident frontends side by side, the node's host
+    cores divided between the ranks (bench.py sets BU_HOST_THREADS = cores / ranks, 2..8). No collective in the data path; rank 0's line carries all eight images."""
+    d = _run(8, [])
+    _contract(d, 8)
+    assert d["scaling"] == "weak" and "no collective" in d["config"]["parallelism"]
+    assert abs(d["value"] - 8 * 512 * 512 / 1e6 / (d["ms_per_step"] / 1e3)) / d["value"] < 0.01
+    cpus, per_rank = d["config"]["host_cpus"], d["config"]["host_threads_per_rank"]
+    assert per_rank == max(2, min(8, cpus // 8)), (cpus, per_rank)
+    for k in ("final_endpoint_clusters", "final_selector_clusters"):   # rank 0's image is the single-GPU run's image (seed 1234 + rank)
+        assert d["config"][k] == single["config"][k], k

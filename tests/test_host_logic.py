@@ -160,8 +160,50 @@ def test_rccl_communicator_library_exports_its_header():
     from basis_universal_amd import capi
     root = pathlib.Path(__file__).resolve().parent.parent
     names = sorted(set(re.findall(r"BU_HIP_API[^;(]*?\b(bu_rccl_\w+)\s*\(", (root / "include" / "basisu_hip_comm.h").read_text())))
-    assert len(names) == 6
+    assert len(names) == 7
     capi.load_library()
     L = C.CDLL(str(root / "basis_universal_amd" / "lib" / "libbasisu_rccl.so"))
     for n in names:
         assert hasattr(L, n), n
+
+
+def test_rccl_group_communicators_need_one_thread_each():
+    """bu_rccl_comm_init_all's communicators live in one process; a host thread that drives two of them in turn would wait inside the first collective for the second it
+    has not issued yet. The library binds every communicator of a group to the first thread that uses it and turns the second use into an error (no GPU needed: the
+    group here has no RCCL communicator behind it, so a collective the rule lets through fails with "no communicator")."""
+    import ctypes as C
+    import threading
+    from basis_universal_amd import capi
+    from basis_universal_amd.etc1s import _BuComm
+    capi.load_library()
+    root = pathlib.Path(__file__).resolve().parent.parent
+    L = C.CDLL(str(root / "basis_universal_amd" / "lib" / "libbasisu_rccl.so"))
+    L.bu_rccl_last_error.restype = C.c_char_p
+    L.bu_rccl_comm_destroy.argtypes = [C.c_void_p]
+    comms = (C.c_void_p * 3)()
+    assert L.bu_rccl_debug_unconnected_group(3, comms) == 1
+    views = []
+    for c in comms:
+        v = _BuComm()
+        assert L.bu_rccl_comm_fill(C.c_void_p(c), C.byref(v)) == 1
+        views.append(v)
+
+    def gather(i):
+        ok = views[i].all_gather(views[i].user, None, 16)
+        return ok, L.bu_rccl_last_error().decode()
+
+    ok, err = gather(0)                       # this thread takes rank 0: let through, then "no communicator"
+    assert ok == 0 and "no communicator" in err
+    ok, err = gather(1)                       # the same thread on rank 1: the rule
+    assert ok == 0 and "already drives rank 0" in err and "thread of its own" in err
+    ok, err = views[2].all_reduce_u64(views[2].user, None, 4), L.bu_rccl_last_error().decode()
+    assert ok == 0 and "already drives rank 0" in err
+    seen = {}
+    t = threading.Thread(target=lambda: seen.update(r=gather(1)))   # another thread may take rank 1 ...
+    t.start(); t.join()
+    assert seen["r"][0] == 0 and "no communicator" in seen["r"][1]
+    t = threading.Thread(target=lambda: seen.update(r0=gather(0)))  # ... but not rank 0, which has its thread
+    t.start(); t.join()
+    assert seen["r0"][0] == 0 and "driven by another host thread" in seen["r0"][1]
+    for c in comms:
+        L.bu_rccl_comm_destroy(C.c_void_p(c))
