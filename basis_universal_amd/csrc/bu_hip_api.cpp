@@ -821,7 +821,10 @@ struct bu_tsvq {
         if (bytes <= pinned_cap) return hipSuccess;
         if (pinned) { (void)hipHostFree(pinned); pinned = nullptr; pinned_cap = 0; }
         const size_t want = bytes + bytes / 4 + 4096;
-        hipError_t e = hipHostMalloc(&pinned, want, hipHostMallocDefault);
+        // coherent (fine-grained) host memory: the zero-copy rounds have kernels write result records and the completion word straight into this buffer while the host polls
+        // it; with a non-coherent mapping the word would only become visible when the kernel retires
+        hipError_t e = hipHostMalloc(&pinned, want, hipHostMallocCoherent);
+        if (e != hipSuccess) { (void)hipGetLastError(); e = hipHostMalloc(&pinned, want, hipHostMallocDefault); zero_copy = false; }
         if (e != hipSuccess) { pinned = nullptr; return e; }
         pinned_cap = want;
         return hipSuccess;
@@ -1072,9 +1075,12 @@ int bu_hip_tsvq_split(bu_hip_context* ctx, bu_tsvq* q, const bu_tsvq_node* h_nod
     if (zero_copy) {
         const uint32_t seq = ++q->round_seq ? q->round_seq : ++q->round_seq;   // never 0
         BU_TRY(ctx, bu::launch_tsvq_signal(ctx->stream, reinterpret_cast<uint32_t*>(d_pinned + flag_at), seq));
-        for (uint32_t spins = 0;; spins++) {
+        auto last_query = std::chrono::steady_clock::now();
+        for (;;) {
             if (*round_flag == seq) break;
-            if ((spins & 0x3fffu) == 0x3fffu) {   // now and then: did the stream die, or finish without the flag becoming visible?
+            const auto t_now = std::chrono::steady_clock::now();
+            if (t_now - last_query > std::chrono::microseconds(200)) {   // every 200 us: did the stream die, or finish without the flag becoming visible?
+                last_query = t_now;
                 const hipError_t e = hipStreamQuery(ctx->stream);
                 if (e == hipSuccess) { __atomic_thread_fence(__ATOMIC_SEQ_CST); if (*round_flag != seq) BU_TRY(ctx, hipStreamSynchronize(ctx->stream)); break; }
                 if (e != hipErrorNotReady) { set_error(ctx, "tsvq_split: %s", hipGetErrorString(e)); return 0; }

@@ -374,14 +374,22 @@ __global__ __launch_bounds__(256) void k_km_unpack_sums(uint64_t* __restrict__ s
 
 } // namespace
 
+// temporary storage of the two library calls launch_kmeans makes, sized from THOSE calls: the 64-bit key sort of one (error, index) key per assignment workgroup
+// and the inclusive weight scan of the seeding
+static size_t kmeans_cub_bytes(uint32_t n) {
+    size_t sort_bytes = 0, scan_bytes = 0;
+    const int groups = (int)((n + KM_WG_VECS - 1) / KM_WG_VECS);
+    (void)hipcub::DeviceRadixSort::SortKeysDescending(nullptr, sort_bytes, (const unsigned long long*)nullptr, (unsigned long long*)nullptr, groups > 0 ? groups : 1, 0, 64);
+    (void)hipcub::DeviceScan::InclusiveSum(nullptr, scan_bytes, (const uint64_t*)nullptr, (uint64_t*)nullptr, (int)n);
+    return sort_bytes > scan_bytes ? sort_bytes : scan_bytes;
+}
+
 size_t kmeans_workspace_bytes(uint32_t n, uint32_t k) {
     const size_t k_pad = ((size_t)k + 63) / 64 * 64;   // whole LDS stages of the assignment kernel (two centroid tiles)
     auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
-    size_t cub = 0, cub2 = 0;
-    (void)hipcub::DeviceRadixSort::SortPairsDescending(nullptr, cub, (const float*)nullptr, (float*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)n);
-    (void)hipcub::DeviceScan::InclusiveSum(nullptr, cub2, (const uint64_t*)nullptr, (uint64_t*)nullptr, (int)n);
+    const size_t cub = kmeans_cub_bytes(n);
     return up((size_t)n * KM_DIM * 2) + up((size_t)n * 8) + 2 * up(k_pad * KM_DIM * 2) + up(k_pad * 4) + up((size_t)k * KM_DIM * 4) + up((size_t)k * 17 * 8) +
-           4 * up((size_t)n * 4) + up((size_t)n * 8) + up((size_t)k * 4 + 4) + up((size_t)k * 4 + 8) + up(cub > cub2 ? cub : cub2);
+           4 * up((size_t)n * 4) + up((size_t)n * 8) + up((size_t)k * 4 + 4) + up((size_t)k * 4 + 8) + up(cub);
 }
 
 kmeans_buffers kmeans_carve(void* ws, uint32_t n, uint32_t k) {
@@ -405,10 +413,7 @@ kmeans_buffers kmeans_carve(void* ws, uint32_t n, uint32_t k) {
     b.pick = reinterpret_cast<uint32_t*>(p); p += up((size_t)k * 4 + 4);
     b.empty = reinterpret_cast<uint32_t*>(p); p += up((size_t)k * 4 + 8);   // behind the list: the count, then launch_kmeans' "packed sums" flag
     b.cub = p;
-    size_t cub = 0, cub2 = 0;
-    (void)hipcub::DeviceRadixSort::SortPairsDescending(nullptr, cub, (const float*)nullptr, (float*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr, (int)n);
-    (void)hipcub::DeviceScan::InclusiveSum(nullptr, cub2, (const uint64_t*)nullptr, (uint64_t*)nullptr, (int)n);
-    b.cub_bytes = cub > cub2 ? cub : cub2;
+    b.cub_bytes = kmeans_cub_bytes(n);
     return b;
 }
 

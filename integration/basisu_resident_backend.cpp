@@ -47,6 +47,9 @@ uint32_t basisu_backend::encode() {
     bp.selector_rdo_quality_thresh = m_params.m_selector_rdo_quality_thresh;
     bp.compression_level = m_params.m_compression_level;
     bp.video = video ? 1u : 0u;
+    // Whatever happens below, the resident frontend's device state is let go when this function returns -- after the backend, which reads it: `fg` is declared
+    // first, so `g` (the backend) is destroyed first. A long-lived host that carries on after a failed encode does not keep the frontend's buffers registered.
+    struct frontend_guard { const basisu_frontend* fe; ~frontend_guard() { bu_resident_release(fe); } } fg{m_pFront_end};
     bu_backend* be = bu_backend_create();
     if (!be) return 0;
     struct guard { bu_backend* b; ~guard() { bu_backend_destroy(b); } } g{be};
@@ -79,9 +82,7 @@ uint32_t basisu_backend::encode() {
     if (!fetch("slice_image_crcs", 0, crcs) || crcs.size() != m_slices.size() * 2) return 0;
     m_output.m_slice_image_crcs.resize(m_slices.size());
     if (!crcs.empty()) memcpy(m_output.m_slice_image_crcs.data(), crcs.data(), crcs.size());
-    g.b = nullptr; bu_backend_destroy(be);   // the backend reads the frontend: it goes first
-    bu_resident_release(m_pFront_end);       // nothing after encode() needs the device state (the getters read the object's host members)
-    return total;
+    return total;   // the guards: backend first, then the frontend's device state (nothing after encode() needs it: the getters read the object's host members)
 }
 
 } // namespace basisu
