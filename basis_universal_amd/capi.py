@@ -72,6 +72,7 @@ _SIGNATURES = {
     "bu_hip_malloc": (_vp, [_vp, C.c_size_t]),
     "bu_hip_free": (None, [_vp, _vp]),
     "bu_hip_memcpy_h2d": (_int, [_vp, _vp, _vp, C.c_size_t]),
+    "bu_hip_memcpy_h2d_async": (_int, [_vp, _vp, _vp, C.c_size_t]),
     "bu_hip_memcpy_d2h": (_int, [_vp, _vp, _vp, C.c_size_t]),
     "bu_hip_memset": (_int, [_vp, _vp, _int, C.c_size_t]),
     "bu_hip_set_pixel_blocks_device": (_int, [_vp, C.c_size_t, _vp]),
@@ -103,6 +104,8 @@ _SIGNATURES = {
     "bu_hip_tsvq_create_packed16": (_vp, [_vp, _vp, _vp, _u32, _vp]),
     "bu_hip_tsvq_split": (_int, [_vp, _vp, _vp, _u32, _vp]),
     "bu_hip_tsvq_roots": (_int, [_vp, _vp, _vp, _u32, _vp]),
+    "bu_hip_tsvq_finish_spans": (_int, [_vp, _vp, _vp, _u32, _vp, _vp, _vp, _vp, _vp]),
+    "bu_hip_tsvq_create_endpoint_device": (_vp, [_vp, _vp, _vp, _u32, _vp]),
     "bu_hip_uastc_pipeline_create": (_vp, [_vp, _u32, _u32, _u32, _u32]),
     "bu_hip_uastc_pipeline_submit": (_int, [_vp, _vp, _u32, _vp, _vp, _u32, _u32, _vp]),
     "bu_hip_uastc_pipeline_wait": (_int, [_vp, C.c_uint64, _vp]),

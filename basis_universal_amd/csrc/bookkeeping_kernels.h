@@ -18,6 +18,9 @@ hipError_t launch_remap_clusters(hipStream_t st, uint32_t* d_cluster, uint32_t* 
 hipError_t launch_count_differences(hipStream_t st, const uint32_t* d_a, const uint32_t* d_b, uint32_t n, uint32_t* d_count);
 hipError_t launch_membership(hipStream_t st, const uint8_t* d_parent, const uint32_t* d_cluster, uint32_t n, uint32_t parents, uint32_t clusters, uint8_t* d_flags);
 hipError_t launch_scatter_spans(hipStream_t st, const uint32_t* d_perm0, const uint32_t* d_perm1, const bk_span* d_spans, uint32_t n_spans, uint32_t* d_out);
+hipError_t launch_finish_spans(hipStream_t st, const uint32_t* d_perm0, const uint32_t* d_perm1, const bk_span* d_spans, uint32_t n_spans, uint32_t* d_leaf_of, uint32_t* d_parent_of /* may be null */,
+                               const uint32_t* d_goffs /* null: no positions / sizes */, uint32_t* d_first_pos, uint32_t* d_sizes);
+hipError_t launch_endpoint_rows(hipStream_t st, const uint64_t* d_keys, const uint32_t* d_goffs, uint32_t n, float* d_rows, uint64_t* d_weights);
 hipError_t launch_exchange_children(hipStream_t st, uint32_t* d_perm0, uint32_t* d_perm1, const bk_span* d_nodes, const uint8_t* d_take, uint32_t n_nodes, uint32_t* d_staging, int dir);
 hipError_t launch_gather_u32(hipStream_t st, const uint32_t* d_table, const uint32_t* d_index, uint32_t n, uint32_t* d_out);
 

@@ -101,6 +101,51 @@ __global__ void __launch_bounds__(256) k_scatter_spans(const uint32_t* __restric
     for (uint32_t i = threadIdx.x; i < s.count; i += 256) out[p[i]] = s.value;
 }
 
+// The same for a finished tree in one pass, with what the endpoint side needs on top: every span is a leaf (its index = blockIdx.x, its value = the parent cut it
+// lies under); per member (a distinct training vector) the leaf, the parent and -- when the vectors' group offsets are given -- the position of the vector's first block
+// inside its leaf's block list = the blocks of the members in front of it in the span (list order: enc.h:1573-1584 + the training-vector order of frontend.cpp:825-866);
+// per leaf the size of that list.
+__global__ void __launch_bounds__(256) k_finish_spans(const uint32_t* __restrict__ perm0, const uint32_t* __restrict__ perm1, const bk_span* __restrict__ spans,
+                                                      uint32_t* __restrict__ leaf_of, uint32_t* __restrict__ parent_of, const uint32_t* __restrict__ goffs,
+                                                      uint32_t* __restrict__ first_pos, uint32_t* __restrict__ sizes) {
+    __shared__ uint32_t s_wave[4];
+    const bk_span s = spans[blockIdx.x];
+    const uint32_t* p = (s.buf ? perm1 : perm0) + s.start;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t run = 0;
+    for (uint32_t base = 0; base < s.count; base += 256) {
+        const uint32_t i = base + threadIdx.x;
+        const bool have = i < s.count;
+        const uint32_t m = have ? p[i] : 0u;
+        if (have) { leaf_of[m] = blockIdx.x; if (parent_of) parent_of[m] = s.value; }
+        if (!goffs) continue;   // (uniform)
+        const uint32_t sz = have ? goffs[m + 1] - goffs[m] : 0u;
+        uint32_t incl = sz;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)incl, o, 64); if (lane >= o) incl += t; }
+        __syncthreads();
+        if (lane == 63) s_wave[wave] = incl;
+        __syncthreads();
+        uint32_t before = run;
+        for (int w = 0; w < wave; w++) before += s_wave[w];
+        if (have) first_pos[m] = before + incl - sz;
+        run += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+    }
+    if (goffs && threadIdx.x == 0) sizes[blockIdx.x] = run;
+}
+
+// distinct endpoint training vectors from their 48-bit keys (low r,g,b | high r,g,b): the six floats of frontend.cpp:846-851 (byte / 255 as byte * (1 / 255), the
+// reference's own expression) and the weight of the vector's group (both sub-blocks of every block, weight 1 each)
+__global__ void __launch_bounds__(256) k_endpoint_rows(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ goffs, uint32_t n, float* __restrict__ rows,
+                                                       uint64_t* __restrict__ weights) {
+    const uint32_t u = blockIdx.x * 256 + threadIdx.x;
+    if (u >= n) return;
+    const uint64_t k = keys[u];
+#pragma unroll
+    for (int c = 5; c >= 0; c--) rows[(size_t)u * 6 + (size_t)(5 - c)] = (float)(int)((k >> (8 * c)) & 255) * (1.0f / 255.0f);
+    weights[u] = 2ull * (goffs[u + 1] - goffs[u]);
+}
+
 // multi-GPU TSVQ: the child member lists of a batch of split nodes, laid end to end in batch order (staging), to and from the member buffers.
 // A node's children live in the OTHER buffer than the node, at the node's own [start, start + count). dir 0: buffers -> staging for the nodes
 // flagged in `take` (zero for the others), dir 1: staging -> buffers for the flagged nodes.
@@ -199,6 +244,19 @@ hipError_t launch_membership(hipStream_t st, const uint8_t* d_parent, const uint
 hipError_t launch_scatter_spans(hipStream_t st, const uint32_t* d_perm0, const uint32_t* d_perm1, const bk_span* d_spans, uint32_t n_spans, uint32_t* d_out) {
     if (!n_spans) return hipSuccess;
     hipLaunchKernelGGL(k_scatter_spans, dim3(n_spans), dim3(256), 0, st, d_perm0, d_perm1, d_spans, d_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_finish_spans(hipStream_t st, const uint32_t* d_perm0, const uint32_t* d_perm1, const bk_span* d_spans, uint32_t n_spans, uint32_t* d_leaf_of, uint32_t* d_parent_of,
+                               const uint32_t* d_goffs, uint32_t* d_first_pos, uint32_t* d_sizes) {
+    if (!n_spans) return hipSuccess;
+    hipLaunchKernelGGL(k_finish_spans, dim3(n_spans), dim3(256), 0, st, d_perm0, d_perm1, d_spans, d_leaf_of, d_parent_of, d_goffs, d_first_pos, d_sizes);
+    return hipGetLastError();
+}
+
+hipError_t launch_endpoint_rows(hipStream_t st, const uint64_t* d_keys, const uint32_t* d_goffs, uint32_t n, float* d_rows, uint64_t* d_weights) {
+    if (!n) return hipSuccess;
+    hipLaunchKernelGGL(k_endpoint_rows, dim3((n + 255) / 256), dim3(256), 0, st, d_keys, d_goffs, n, d_rows, d_weights);
     return hipGetLastError();
 }
 

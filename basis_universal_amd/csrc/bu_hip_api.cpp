@@ -377,6 +377,15 @@ int bu_hip_memcpy_h2d(bu_hip_context* ctx, void* d, const void* h, size_t bytes)
     BU_TRY(ctx, hipStreamSynchronize(ctx->stream)); // h may be pageable and released by the caller right after
     return 1;
 }
+// the same, stream-ordered: on return `h` has been copied out (into the context's pinned ring) and may be released; the device side is ordered with everything enqueued on
+// the context's stream before and after. No host synchronisation (the ring synchronises the stream only when it wraps).
+int bu_hip_memcpy_h2d_async(bu_hip_context* ctx, void* d, const void* h, size_t bytes) {
+    if (!ctx) return 0;
+    if (!bytes) return 1;
+    device_guard g(ctx->device);
+    BU_TRY(ctx, h2d(ctx, d, h, bytes));
+    return 1;
+}
 int bu_hip_memcpy_d2h(bu_hip_context* ctx, void* h, const void* d, size_t bytes) {
     if (!ctx) return 0;
     device_guard g(ctx->device);
@@ -851,7 +860,7 @@ void bu_hip_tsvq_destroy(bu_hip_context* ctx, bu_tsvq* q) {
 }
 
 static bu_tsvq* tsvq_create_common(bu_hip_context* ctx, uint32_t dim, bool packed, const void* h_rows, const uint64_t* h_weights, uint32_t n, bu_tsvq_root* out_root,
-                                   bool source_on_device = false) {
+                                   bool source_on_device = false, const uint64_t* d_endpoint_keys = nullptr, const uint32_t* d_endpoint_goffs = nullptr) {
     if (!ctx || !n || !out_root || (dim != 6 && dim != 16) || (packed && dim != 16)) { if (ctx) set_error(ctx, "tsvq_create: bad arguments"); return nullptr; }
     device_guard g(ctx->device);
     bu_tsvq* q = new (std::nothrow) bu_tsvq();
@@ -889,7 +898,9 @@ static bu_tsvq* tsvq_create_common(bu_hip_context* ctx, uint32_t dim, bool packe
             if (!q->wide_ws || !q->wide_packed || !q->wide_nodes || !q->wide_ctrl) return fail("allocation");
         }
     }
-    if (source_on_device) {  // stream-ordered device copies: the vectors were produced on this context's stream
+    if (d_endpoint_keys) {   // the rows are made on the device from the de-duplication's keys (bu_hip_k_unique_endpoint_vectors)
+        if (bu::launch_endpoint_rows(ctx->stream, d_endpoint_keys, d_endpoint_goffs, n, static_cast<float*>(q->rows), q->w64) != hipSuccess) return fail("endpoint rows");
+    } else if (source_on_device) {  // stream-ordered device copies: the vectors were produced on this context's stream
         if (hipMemcpyAsync(q->rows, h_rows, (size_t)n * row_bytes, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess ||
             hipMemcpyAsync(q->w64, h_weights, (size_t)n * 8, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess)
             return fail("device copy");
@@ -931,6 +942,11 @@ bu_tsvq* bu_hip_tsvq_create_packed16(bu_hip_context* ctx, const uint32_t* h_keys
 
 bu_tsvq* bu_hip_tsvq_create_packed16_device(bu_hip_context* ctx, const uint32_t* d_keys, const uint64_t* d_weights, uint32_t n, bu_tsvq_root* out_root) {
     return tsvq_create_common(ctx, 16, true, d_keys, d_weights, n, out_root, true);
+}
+
+bu_tsvq* bu_hip_tsvq_create_endpoint_device(bu_hip_context* ctx, const uint64_t* d_unique_keys, const uint32_t* d_group_offsets, uint32_t n, bu_tsvq_root* out_root) {
+    if (ctx && (!d_unique_keys || !d_group_offsets)) { set_error(ctx, "tsvq_create_endpoint_device: null pointer"); return nullptr; }
+    return tsvq_create_common(ctx, 6, false, nullptr, nullptr, n, out_root, true, d_unique_keys, d_group_offsets);
 }
 
 int bu_hip_k_unique_endpoint_vectors(bu_hip_context* ctx, const void* d_etc1_blocks, uint32_t n_blocks, uint32_t* d_sorted_block_idx, uint64_t* d_unique_keys,
@@ -1211,6 +1227,20 @@ int bu_hip_tsvq_scatter_spans(bu_hip_context* ctx, bu_tsvq* q, const bu_tsvq_spa
     BU_TRY(ctx, hipMemcpyAsync(q->nodes.p, q->pinned, bytes, hipMemcpyHostToDevice, ctx->stream));
     BU_TRY(ctx, bu::launch_scatter_spans(ctx->stream, q->perm[0], q->perm[1], static_cast<const bu::bk_span*>(q->nodes.p), n_spans, d_out));
     BU_TRY(ctx, hipStreamSynchronize(ctx->stream));   // q may be destroyed (and the pinned buffer recycled) right after
+    return 1;
+}
+
+int bu_hip_tsvq_finish_spans(bu_hip_context* ctx, bu_tsvq* q, const bu_tsvq_span* h_spans, uint32_t n_spans, uint32_t* d_leaf_of, uint32_t* d_parent_of, const uint32_t* d_group_offsets,
+                             uint32_t* d_first_pos, uint32_t* d_sizes) {
+    if (!ctx || !q || (n_spans && (!h_spans || !d_leaf_of)) || (d_group_offsets && (!d_first_pos || !d_sizes))) return 0;
+    if (!n_spans) return 1;
+    device_guard g(ctx->device);
+    const size_t bytes = (size_t)n_spans * sizeof(bu_tsvq_span);
+    if (bytes > q->nodes.cap) { set_error(ctx, "tsvq_finish_spans: %u spans exceed the record buffer", n_spans); return 0; }
+    BU_TRY(ctx, h2d(ctx, q->nodes.p, h_spans, bytes));   // through the context's pinned ring: the caller's array may go when this returns
+    BU_TRY(ctx, bu::launch_finish_spans(ctx->stream, q->perm[0], q->perm[1], static_cast<const bu::bk_span*>(q->nodes.p), n_spans, d_leaf_of, d_parent_of, d_group_offsets, d_first_pos,
+                                        d_sizes));
+    BU_TRY(ctx, hipStreamSynchronize(ctx->stream));   // q may be destroyed right after
     return 1;
 }
 

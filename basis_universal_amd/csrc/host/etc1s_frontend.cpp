@@ -130,7 +130,7 @@ struct etc1s_frontend::device_state {
     buf sel_idx, sel_ukeys, sel_uw, sel_goffs;  // outputs of bu_hip_k_unique_selector_vectors
     buf ep_idx, ep_ukeys, ep_goffs;             // outputs of bu_hip_k_unique_endpoint_vectors
     // the clusterings as resident per-block maps (bookkeeping_kernels.hip) and the small arrays around them
-    buf ep_pos, ep_parent, sel_cluster, sel_parent, orig_enc, map_sizes, map_offs, map_sorted, map_word, tmp_a, tmp_b, tmp_c, flags;
+    buf ep_pos, ep_parent, ep_parent_u, sel_cluster, sel_parent, orig_enc, map_sizes, map_offs, map_sorted, map_word, tmp_a, tmp_b, tmp_c, flags;
 
     bool reserve(buf& b, size_t bytes) {
         if (bytes <= b.cap) return true;
@@ -142,13 +142,14 @@ struct etc1s_frontend::device_state {
     }
     template <typename T> bool upload(buf& b, const T* src, size_t count) {
         if (!reserve(b, count * sizeof(T))) return false;
-        return count ? bu_hip_memcpy_h2d(ctx, b.p, src, count * sizeof(T)) != 0 : true;
+        // stream-ordered: the source has left for the context's pinned ring when this returns, every consumer is a kernel (or a copy) enqueued on the same stream afterwards
+        return count ? bu_hip_memcpy_h2d_async(ctx, b.p, src, count * sizeof(T)) != 0 : true;
     }
     template <typename T> bool download(T* dst, const buf& b, size_t count) { return bu_hip_memcpy_d2h(ctx, dst, b.p, count * sizeof(T)) != 0; }
     void release() {
         for (buf* b : {&etc1, &enc, &block_cluster, &params, &err, &valid, &offsets, &indices, &cand_offsets, &cand_indices, &block_parent, &out_u32, &sel_blocks, &weights,
                        &sel_idx, &sel_ukeys, &sel_uw, &sel_goffs, &ep_idx, &ep_ukeys, &ep_goffs,
-                       &ep_pos, &ep_parent, &sel_cluster, &sel_parent, &orig_enc, &map_sizes, &map_offs, &map_sorted, &map_word, &tmp_a, &tmp_b, &tmp_c, &flags})
+                       &ep_pos, &ep_parent, &ep_parent_u, &sel_cluster, &sel_parent, &orig_enc, &map_sizes, &map_offs, &map_sorted, &map_word, &tmp_a, &tmp_b, &tmp_c, &flags})
             if (b->p) { bu_hip_free(ctx, b->p); b->p = nullptr; b->cap = 0; }
         if (owns_pixels && d_pixels) bu_hip_free(ctx, const_cast<void*>(d_pixels));
         d_pixels = nullptr;
@@ -368,65 +369,77 @@ bool etc1s_frontend::init_endpoint_training_vectors() {
     if (!d.reserve(d.ep_idx, (size_t)n * 4) || !d.reserve(d.ep_ukeys, (size_t)n * 8) || !d.reserve(d.ep_goffs, ((size_t)n + 1) * 4)) return fail("alloc");
     if (!bu_hip_k_unique_endpoint_vectors(d.ctx, d.etc1.p, n, (uint32_t*)d.ep_idx.p, (uint64_t*)d.ep_ukeys.p, (uint32_t*)d.ep_goffs.p, &u_total))
         return fail("bu_hip_k_unique_endpoint_vectors");
-    std::vector<uint64_t> ukeys(u_total);
-    m_endpoint_group_blocks.clear(); m_endpoint_group_offsets.resize((size_t)u_total + 1);   // the blocks of the groups stay in HBM (endpoint_group_blocks_host())
-    if (!d.download(ukeys.data(), d.ep_ukeys, u_total) || !d.download(m_endpoint_group_offsets.data(), d.ep_goffs, (size_t)u_total + 1))
-        return fail("download endpoint groups");
-    m_endpoint_unique_rows.resize((size_t)u_total * 6); m_endpoint_unique_weights.resize(u_total);
-    for (uint32_t u = 0; u < u_total; u++) {
-        for (int k = 5; k >= 0; k--) m_endpoint_unique_rows[(size_t)u * 6 + (size_t)(5 - k)] = (float)(int)((ukeys[u] >> (8 * k)) & 255) * (1.0f / 255.0f);  // frontend.cpp:846-851
-        m_endpoint_unique_weights[u] = 2ull * (m_endpoint_group_offsets[u + 1] - m_endpoint_group_offsets[u]);  // both sub-blocks, weight 1 each
-    }
+    // the distinct vectors and their groups stay in HBM (ep_ukeys / ep_goffs / ep_idx): the codebook builder makes its float rows from the keys there
+    // (bu_hip_tsvq_create_endpoint_device); the host forms are fetched when a list getter asks (endpoint_group_offsets_host / endpoint_group_blocks_host)
+    m_endpoint_unique_count = u_total;
+    m_endpoint_group_blocks.clear(); m_endpoint_group_offsets.clear();
+    m_endpoint_unique_rows.clear(); m_endpoint_unique_weights.clear();
     return true;
 }
 
 // frontend.cpp:868-944
 bool etc1s_frontend::generate_endpoint_clusters() {
     const uint32_t parent_size = (m_params.m_max_endpoint_clusters >= 256) ? kEndpointParentCodebookSize : 0;
-    const csr_block_pair_groups groups{m_endpoint_group_offsets.data(), m_endpoint_group_blocks.data()};  // never dereferenced: only per-vector results are asked for
+    const uint32_t n = m_total_blocks, u_total = m_endpoint_unique_count;
+    const uint32_t want_parents = m_use_hierarchical_endpoint_codebooks ? parent_size : 0;
     m_endpoint_parent_clusters.clear();
-    std::vector<uint32_t> leaf_of_unique;
-    std::vector<std::vector<uint32_t>> unused;
+    m_endpoint_parent_of_unique.clear(); m_endpoint_parent_dev_valid = false;
+    device_state& d = *m_dev;
+    // Per distinct vector, resident: its leaf (tmp_a), the position of its first block in the leaf's list (tmp_b), its parent (tmp_c); per leaf the list length
+    // (out_u32). A leaf lists its distinct vectors ascending and each vector's blocks ascending (enc.h:1573-1584 + the training-vector order of frontend.cpp:825-866).
+    if (!d.reserve(d.tmp_a, (size_t)u_total * 4) || !d.reserve(d.tmp_b, (size_t)u_total * 4) || !d.reserve(d.tmp_c, (size_t)u_total * 4) ||
+        !d.reserve(d.out_u32, (size_t)cMaxEndpointClusters * 4) || !d.reserve(d.block_cluster, (size_t)n * 4) || !d.reserve(d.ep_pos, (size_t)n * 4) || !d.reserve(d.ep_parent, n))
+        return fail("alloc");
     if (m_params.m_fast_codebooks && !std::getenv("BU_FAST_SELECTORS_ONLY")) {   // row f3: k-means on the matrix cores; the per-vector results come back (a few ten thousand words) for the list offsets below
-        device_state& dd = *m_dev;
-        const uint32_t u = (uint32_t)m_endpoint_unique_weights.size(), want_parents = m_use_hierarchical_endpoint_codebooks ? parent_size : 0;
-        if (!dd.reserve(dd.tmp_a, (size_t)u * 4) || !dd.reserve(dd.tmp_c, (size_t)u * 4)) return fail("alloc");
-        if (!bu_hip_kmeans_codebook(dd.ctx, 1, dd.ep_ukeys.p, nullptr, (const uint32_t*)dd.ep_goffs.p, u, m_params.m_max_endpoint_clusters, want_parents,
-                                    m_params.m_fast_codebook_iterations, (uint32_t*)dd.tmp_a.p, want_parents ? (uint32_t*)dd.tmp_c.p : nullptr, &m_endpoint_cluster_count,
+        if (!bu_hip_kmeans_codebook(d.ctx, 1, d.ep_ukeys.p, nullptr, (const uint32_t*)d.ep_goffs.p, u_total, m_params.m_max_endpoint_clusters, want_parents,
+                                    m_params.m_fast_codebook_iterations, (uint32_t*)d.tmp_a.p, want_parents ? (uint32_t*)d.tmp_c.p : nullptr, &m_endpoint_cluster_count,
                                     &m_endpoint_parent_count))
             return fail("bu_hip_kmeans_codebook (endpoints)");
-        leaf_of_unique.resize(u);
-        m_endpoint_parent_of_unique.assign(want_parents ? u : 0, 0);
-        if (!dd.download(leaf_of_unique.data(), dd.tmp_a, u) || (want_parents && !dd.download(m_endpoint_parent_of_unique.data(), dd.tmp_c, u))) return fail("download");
-    } else
-    if (!device_tsvq::hierarchical_codebook(m_dev->ctx, 6, m_endpoint_unique_rows, m_endpoint_unique_weights, groups, m_params.m_max_endpoint_clusters,
-                                            m_use_hierarchical_endpoint_codebooks ? parent_size : 0, unused, m_endpoint_parent_clusters, nullptr,
-                                            &m_endpoint_parent_of_unique, &m_endpoint_parent_count, &leaf_of_unique, &m_endpoint_cluster_count, m_has_comm ? &m_comm : nullptr,
-                                            m_params.m_codebook_threads))
-        return fail("endpoint TSVQ failed");
-    // The clustering is kept as (cluster, position in the cluster's list) per block, RESIDENT: the distinct vectors' leaves, parents and list
-    // offsets go up (a few thousand words), the per-block arrays are written by the device. A leaf lists its distinct vectors ascending and
-    // each vector's blocks ascending (enc.h:1573-1584 + the training-vector order of frontend.cpp:825-866).
-    const uint32_t n = m_total_blocks, u_total = (uint32_t)leaf_of_unique.size();
-    m_endpoint_cluster_sizes.assign(m_endpoint_cluster_count, 0);
-    if (m_use_hierarchical_endpoint_codebooks && !m_endpoint_parent_count) { m_endpoint_parent_count = 1; m_endpoint_parent_of_unique.clear(); }  // no parent level: one parent holding everything (frontend.cpp:905-911)
-    std::vector<uint32_t> first_pos(u_total);  // where vector u's blocks start inside their cluster's list
-    for (uint32_t u = 0; u < u_total; u++) {
-        const uint32_t c = leaf_of_unique[u];
-        first_pos[u] = m_endpoint_cluster_sizes[c];
-        m_endpoint_cluster_sizes[c] += m_endpoint_group_offsets[u + 1] - m_endpoint_group_offsets[u];
+        std::vector<uint32_t> leaf_of_unique(u_total), first_pos(u_total);
+        const std::vector<uint32_t>& goffs = endpoint_group_offsets_host();
+        if (goffs.size() != (size_t)u_total + 1 || !d.download(leaf_of_unique.data(), d.tmp_a, u_total)) return fail("download");
+        m_endpoint_cluster_sizes.assign(m_endpoint_cluster_count, 0);
+        for (uint32_t u = 0; u < u_total; u++) {
+            const uint32_t c = leaf_of_unique[u];
+            first_pos[u] = m_endpoint_cluster_sizes[c];
+            m_endpoint_cluster_sizes[c] += goffs[u + 1] - goffs[u];
+        }
+        if (!d.upload(d.tmp_b, first_pos.data(), u_total)) return fail("upload");
+    } else {
+        if (!device_tsvq::hierarchical_codebook_endpoint_device(d.ctx, (const uint64_t*)d.ep_ukeys.p, (const uint32_t*)d.ep_goffs.p, u_total, m_params.m_max_endpoint_clusters,
+                                                                want_parents, &m_endpoint_cluster_count, &m_endpoint_parent_count, (uint32_t*)d.tmp_a.p, (uint32_t*)d.tmp_c.p,
+                                                                (uint32_t*)d.tmp_b.p, (uint32_t*)d.out_u32.p, nullptr, m_has_comm ? &m_comm : nullptr, m_params.m_codebook_threads))
+            return fail("endpoint TSVQ failed");
+        m_endpoint_cluster_sizes.resize(m_endpoint_cluster_count);
+        if (!d.download(m_endpoint_cluster_sizes.data(), d.out_u32, m_endpoint_cluster_count)) return fail("download cluster sizes");
     }
-    device_state& d = *m_dev;
-    const bool parents = m_use_hierarchical_endpoint_codebooks && !m_endpoint_parent_of_unique.empty();
-    if (!d.upload(d.tmp_a, leaf_of_unique.data(), u_total) || !d.upload(d.tmp_b, first_pos.data(), u_total) ||
-        (parents && !d.upload(d.tmp_c, m_endpoint_parent_of_unique.data(), u_total)) || !d.reserve(d.block_cluster, (size_t)n * 4) || !d.reserve(d.ep_pos, (size_t)n * 4) ||
-        !d.reserve(d.ep_parent, n))
-        return fail("upload endpoint leaves");
+    const bool parents = want_parents && m_endpoint_parent_count;
+    if (m_use_hierarchical_endpoint_codebooks && !m_endpoint_parent_count) m_endpoint_parent_count = 1;  // no parent level: one parent holding everything (frontend.cpp:905-911)
     if (!bu_hip_k_map_blocks_from_groups(d.ctx, (const uint32_t*)d.ep_goffs.p, (const uint32_t*)d.ep_idx.p, n, u_total, (const uint32_t*)d.tmp_a.p, (const uint32_t*)d.tmp_b.p,
                                          parents ? (const uint32_t*)d.tmp_c.p : nullptr, (uint32_t*)d.block_cluster.p, (uint32_t*)d.ep_pos.p, (uint8_t*)d.ep_parent.p))
         return fail("bu_hip_k_map_blocks_from_groups");
+    if (parents) {   // the parent of every distinct vector, kept for the parent-list getter (tmp_c is everybody's scratch)
+        if (!d.reserve(d.ep_parent_u, (size_t)u_total * 4) || !bu_hip_memcpy_d2d(d.ctx, d.ep_parent_u.p, d.tmp_c.p, (size_t)u_total * 4)) return fail("copy");
+        m_endpoint_parent_dev_valid = true;
+    }
     m_ep_dev_valid = true; m_endpoint_map_valid = false; m_endpoint_lists_valid = false; m_endpoint_clusters.clear();
     return true;
+}
+
+// the groups of the distinct endpoint training vectors (offsets into the sorted block array) and the parent of every distinct vector: resident, fetched when a list form is asked for
+const std::vector<uint32_t>& etc1s_frontend::endpoint_group_offsets_host() const {
+    if (m_endpoint_group_offsets.size() != (size_t)m_endpoint_unique_count + 1 && m_dev && m_dev->ep_goffs.p) {
+        m_endpoint_group_offsets.resize((size_t)m_endpoint_unique_count + 1);
+        if (!m_dev->download(m_endpoint_group_offsets.data(), m_dev->ep_goffs, (size_t)m_endpoint_unique_count + 1)) m_endpoint_group_offsets.clear();
+    }
+    return m_endpoint_group_offsets;
+}
+const std::vector<uint32_t>& etc1s_frontend::endpoint_parent_of_unique_host() const {
+    if (m_endpoint_parent_of_unique.empty() && m_endpoint_parent_dev_valid && m_dev && m_dev->ep_parent_u.p) {
+        m_endpoint_parent_of_unique.resize(m_endpoint_unique_count);
+        if (!m_dev->download(m_endpoint_parent_of_unique.data(), m_dev->ep_parent_u, m_endpoint_unique_count)) m_endpoint_parent_of_unique.clear();
+    }
+    return m_endpoint_parent_of_unique;
 }
 
 // the blocks behind every distinct endpoint training vector (the device's stable sort order), fetched when a list form is asked for
@@ -497,12 +510,13 @@ const std::vector<std::vector<uint32_t>>& etc1s_frontend::endpoint_clusters() co
 
 const std::vector<std::vector<uint32_t>>& etc1s_frontend::endpoint_parent_clusters() const {
     if (m_endpoint_parent_clusters.empty() && m_use_hierarchical_endpoint_codebooks) {
-        if (m_endpoint_parent_of_unique.empty()) {
+        const std::vector<uint32_t>& parent_of_unique = endpoint_parent_of_unique_host();
+        if (parent_of_unique.empty()) {
             m_endpoint_parent_clusters.resize(1);
             for (uint32_t i = 0; i < m_total_blocks; i++) { m_endpoint_parent_clusters[0].push_back(i * 2); m_endpoint_parent_clusters[0].push_back(i * 2 + 1); }
         } else {
-            device_tsvq::expand_parents(m_endpoint_parent_of_unique, m_endpoint_parent_count,
-                                        csr_block_pair_groups{m_endpoint_group_offsets.data(), endpoint_group_blocks_host().data()}, m_endpoint_parent_clusters);
+            device_tsvq::expand_parents(parent_of_unique, m_endpoint_parent_count,
+                                        csr_block_pair_groups{endpoint_group_offsets_host().data(), endpoint_group_blocks_host().data()}, m_endpoint_parent_clusters);
         }
     }
     return m_endpoint_parent_clusters;

@@ -159,9 +159,13 @@ private:
     // endpoint side
     std::vector<float> m_endpoint_unique_rows;            // distinct (low rgb, high rgb)/255 vectors, ascending
     std::vector<uint64_t> m_endpoint_unique_weights;
-    std::vector<uint32_t> m_endpoint_group_offsets;            // CSR offsets: the blocks behind every distinct vector ...
+    uint32_t m_endpoint_unique_count = 0;                     // distinct endpoint training vectors (resident: ep_ukeys / ep_goffs / ep_idx)
+    bool m_endpoint_parent_dev_valid = false;                 // ep_parent_u holds the parent of every distinct vector
+    mutable std::vector<uint32_t> m_endpoint_group_offsets;    // CSR offsets: the blocks behind every distinct vector ... (fetched on demand)
     mutable std::vector<uint32_t> m_endpoint_group_blocks;     // ... ascending; resident, fetched by endpoint_group_blocks_host() when a list form is asked for
     const std::vector<uint32_t>& endpoint_group_blocks_host() const;
+    const std::vector<uint32_t>& endpoint_group_offsets_host() const;
+    const std::vector<uint32_t>& endpoint_parent_of_unique_host() const;
     // the endpoint clustering in its two forms (etc1s_frontend.cpp, ensure_endpoint_map / ensure_endpoint_lists)
     mutable std::vector<std::vector<uint32_t>> m_endpoint_clusters;
     mutable std::vector<uint32_t> m_block_endpoint_pos, m_endpoint_cluster_sizes;
@@ -173,7 +177,8 @@ private:
     void ensure_endpoint_lists() const;
     void endpoint_csr(std::vector<uint32_t>& offsets, std::vector<uint32_t>& indices) const;
     mutable std::vector<std::vector<uint32_t>> m_endpoint_parent_clusters;  // lazily materialised, see endpoint_parent_clusters()
-    std::vector<uint32_t> m_endpoint_parent_of_unique, m_selector_parent_of_unique;  // parent cluster of every distinct training vector
+    mutable std::vector<uint32_t> m_endpoint_parent_of_unique;   // parent cluster of every distinct training vector (fetched on demand: endpoint_parent_of_unique_host)
+    std::vector<uint32_t> m_selector_parent_of_unique;
     uint32_t m_endpoint_parent_count = 0, m_selector_parent_count = 0;
     std::vector<uint32_t> m_selector_group_offsets, m_selector_group_blocks;  // CSR: the blocks behind every distinct selector vector
     std::vector<uint8_t> m_block_parent_endpoint_cluster;

@@ -112,6 +112,23 @@ public:
                           codebook_partitions(n_unique, max_codebook_size, max_threads, min_unique_for_threads));
     }
 
+    // The endpoint side with the distinct vectors resident as the de-duplication left them (48-bit keys + group offsets, bu_hip_k_unique_endpoint_vectors): the rows are
+    // made on the device, and the result stays there -- leaf, parent and first list position of every distinct vector, the block count of every leaf.
+    static bool hierarchical_codebook_endpoint_device(bu_hip_context* ctx, const uint64_t* d_unique_keys, const uint32_t* d_group_offsets, uint32_t n_unique,
+                                                      uint32_t max_codebook_size, uint32_t max_parent_codebook_size, uint32_t* leaf_count, uint32_t* parent_count,
+                                                      uint32_t* d_leaf_of_unique, uint32_t* d_parent_of_unique, uint32_t* d_first_pos, uint32_t* d_leaf_sizes, stats* st = nullptr,
+                                                      const bu_comm* comm = nullptr, uint32_t max_threads = 0, uint32_t min_unique_for_threads = kThreadedCodebookMinUnique) {
+        bu_tsvq_root root;
+        const auto t0 = std::chrono::steady_clock::now();
+        bu_tsvq* q = n_unique ? bu_hip_tsvq_create_endpoint_device(ctx, d_unique_keys, d_group_offsets, n_unique, &root) : nullptr;
+        if (st) st->t_create = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        std::vector<std::vector<uint32_t>> unused_a, unused_b;
+        const csr_groups no_groups{nullptr, nullptr};
+        finish_extra fx{d_group_offsets, d_first_pos, d_leaf_sizes};
+        return q && build(ctx, q, root, n_unique, no_groups, max_codebook_size, max_parent_codebook_size, unused_a, unused_b, st, nullptr, parent_count, nullptr, leaf_count,
+                          d_leaf_of_unique, d_parent_of_unique, comm, codebook_partitions(n_unique, max_codebook_size, max_threads, min_unique_for_threads), &fx);
+    }
+
     // parent lists from a parent-of-unique map (what build() would have produced): vectors ascending inside a parent, members group by group
     template <class Groups>
     static void expand_parents(const std::vector<uint32_t>& parent_of_unique, uint32_t parents, const Groups& groups, std::vector<std::vector<uint32_t>>& lists) {
@@ -131,6 +148,7 @@ public:
     }
 
 private:
+    struct finish_extra { const uint32_t* d_group_offsets; uint32_t* d_first_pos; uint32_t* d_leaf_sizes; };
     // Debug aid (BU_TSVQ_VERIFY=1): a split is a pure function of its node, so re-running every node of a batch on its own must
     // reproduce the batched result bit for bit, including the children's member lists. Reports the first differences to stderr.
     static void verify_batch(bu_hip_context* ctx, bu_tsvq* q, const std::vector<bu_tsvq_node>& batch, const bu_tsvq_split* batched, uint32_t round) {
@@ -312,7 +330,7 @@ private:
                       std::vector<std::vector<uint32_t>>& parent_codebook, stats* st, std::vector<uint32_t>* parent_of_unique = nullptr,
                       uint32_t* parent_count = nullptr, std::vector<uint32_t>* leaf_of_unique = nullptr, uint32_t* leaf_count = nullptr,
                       uint32_t* d_leaf_of_unique = nullptr, uint32_t* d_parent_of_unique = nullptr, const bu_comm* comm = nullptr,
-                      uint32_t partitions = 1) {
+                      uint32_t partitions = 1, const finish_extra* extra = nullptr) {
         if (parent_of_unique) parent_of_unique->clear();
         if (parent_count) *parent_count = 0;
         if (leaf_of_unique) leaf_of_unique->clear();
@@ -394,12 +412,12 @@ private:
         // ---- resident form: the leaf (and parent) of every distinct vector is written by the device from the leaves' spans of the member
         //      buffers; no member list leaves HBM.
         if (d_leaf_of_unique) {
-            if (max_parent_codebook_size && d_parent_of_unique) {
-                if (!bu_hip_tsvq_scatter_spans(ctx, q, spans.data(), (uint32_t)spans.size(), d_parent_of_unique)) return false;
-                if (parent_count) *parent_count = cuts;
-            }
-            for (size_t l = 0; l < spans.size(); l++) spans[l].value = (uint32_t)l;
-            if (!bu_hip_tsvq_scatter_spans(ctx, q, spans.data(), (uint32_t)spans.size(), d_leaf_of_unique)) return false;
+            const bool parents = max_parent_codebook_size && d_parent_of_unique;
+            if (parents && parent_count) *parent_count = cuts;
+            // one pass: span i is leaf i, its value the parent cut it lies under (+ list positions and leaf sizes where the vectors' groups are given)
+            if (!bu_hip_tsvq_finish_spans(ctx, q, spans.data(), (uint32_t)spans.size(), d_leaf_of_unique, parents ? d_parent_of_unique : nullptr,
+                                          extra ? extra->d_group_offsets : nullptr, extra ? extra->d_first_pos : nullptr, extra ? extra->d_leaf_sizes : nullptr))
+                return false;
             codebook.clear(); parent_codebook.clear();
             return true;
         }

@@ -105,6 +105,8 @@ BU_HIP_API uint32_t bu_hip_profile_read(bu_hip_context*, const char** names, dou
 BU_HIP_API void* bu_hip_malloc(bu_hip_context*, size_t bytes);
 BU_HIP_API void  bu_hip_free(bu_hip_context*, void* d_ptr);
 BU_HIP_API int   bu_hip_memcpy_h2d(bu_hip_context*, void* d_dst, const void* h_src, size_t bytes); /* synchronises */
+/* ... stream-ordered instead of blocking: the source has been copied out when the call returns (it may be released), the copy itself is ordered on the context's stream */
+BU_HIP_API int bu_hip_memcpy_h2d_async(bu_hip_context*, void* d_dst, const void* h_src, size_t bytes);
 BU_HIP_API int   bu_hip_memcpy_d2h(bu_hip_context*, void* h_dst, const void* d_src, size_t bytes); /* synchronises */
 BU_HIP_API int   bu_hip_memset(bu_hip_context*, void* d_dst, int value, size_t bytes);
 BU_HIP_API int   bu_hip_memcpy_d2d(bu_hip_context*, void* d_dst, const void* d_src, size_t bytes); /* stream-ordered */
@@ -285,6 +287,9 @@ BU_HIP_API bu_tsvq* bu_hip_tsvq_create(bu_hip_context*, uint32_t dim, const floa
 BU_HIP_API bu_tsvq* bu_hip_tsvq_create_packed16(bu_hip_context*, const uint32_t* h_keys, const uint64_t* h_weights, uint32_t n, bu_tsvq_root* h_out_root);
 /* the same from device arrays (e.g. the outputs of bu_hip_k_unique_selector_vectors), copied on the context's stream */
 BU_HIP_API bu_tsvq* bu_hip_tsvq_create_packed16_device(bu_hip_context*, const uint32_t* d_keys, const uint64_t* d_weights, uint32_t n, bu_tsvq_root* h_out_root);
+/* dim 6 from the outputs of bu_hip_k_unique_endpoint_vectors: the rows (six floats = key byte * (1 / 255), frontend.cpp:846-851) and the weights (2 per block of the
+ * vector's group) are made on the device; nothing is downloaded or uploaded */
+BU_HIP_API bu_tsvq* bu_hip_tsvq_create_endpoint_device(bu_hip_context*, const uint64_t* d_unique_keys, const uint32_t* d_group_offsets, uint32_t n, bu_tsvq_root* h_out_root);
 /* a12 + the de-duplication in front of the selector TSVQ (frontend.cpp:2140-2189; std::map<vec16F, weight> of
  * generate_hierarchical_codebook_threaded, enc.h:2218-2290) for n resident ETC1S blocks and their u64 training weights
  * (bu_hip_k_selector_training_vectors): distinct selector vectors as packed keys in ascending order = the map's order, their summed
@@ -307,6 +312,11 @@ BU_HIP_API int  bu_hip_tsvq_read_members(bu_hip_context*, bu_tsvq*, uint32_t buf
  * every distinct vector without bringing the member lists to the host. h_spans: n_spans records. Stream-ordered after the splits. */
 typedef struct { uint32_t buf, start, count, value; } bu_tsvq_span;
 BU_HIP_API int  bu_hip_tsvq_scatter_spans(bu_hip_context*, bu_tsvq*, const bu_tsvq_span* h_spans, uint32_t n_spans, uint32_t* d_out);
+/* A finished tree in one pass: span i is leaf i and `value` its parent (cut) index -> d_leaf_of[vector], d_parent_of[vector] (may be NULL); with d_group_offsets (the
+ * vectors' groups of blocks, bu_hip_k_unique_endpoint_vectors) also d_first_pos[vector] = where the vector's blocks start inside its leaf's block list (the blocks of the
+ * members in front of it, in list order) and d_sizes[leaf] = the length of that list. Synchronises. */
+BU_HIP_API int  bu_hip_tsvq_finish_spans(bu_hip_context*, bu_tsvq*, const bu_tsvq_span* h_spans, uint32_t n_spans, uint32_t* d_leaf_of, uint32_t* d_parent_of,
+                                         const uint32_t* d_group_offsets, uint32_t* d_first_pos, uint32_t* d_sizes);
 /* Multi-GPU (nodes of one round split by different ranks): the child member lists and result records of a batch laid end to end in a staging buffer the
  * host application sum-reduces across ranks (all_reduce_u64 of bu_comm): entries of nodes a rank did not split are zero, so the sum is the union.
  *   exchange_pack:   children of the nodes with h_mine[i] != 0 (from the member buffers) and their h_records into the staging buffer, zero elsewhere;
