@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <mutex>
 #include <numeric>
 #include <string>
@@ -800,6 +801,11 @@ int bu_hip_kmeans_codebook(bu_hip_context* ctx, int kind, const void* d_keys, co
 
 } // extern "C" (reopened below)
 
+// The fused side-pass kernel (tsvq_wide_kernels.hip, k_wide_side_passes) spins at device-wide barriers: one at a time per process (a second context takes the separate
+// kernels for that round instead of waiting), and never again in this process once one has given up (another process holding part of the chip: see the kernel's header).
+static std::mutex g_fused_lock;
+static std::atomic<bool> g_fused_gave_up{false};
+
 struct bu_tsvq {
     uint32_t dim = 0, n = 0;
     bool packed = false;
@@ -815,7 +821,8 @@ struct bu_tsvq {
     uint32_t wide_cov_min = 0;  // batches whose largest node is smaller run the covariance pass chained (BU_TSVQ_WIDE_COV_MIN)
     uint32_t wide_blocks_cap = 0, wide_nodes_cap = 0;
     void* xchg = nullptr; size_t xchg_cap = 0;   // staging of bu_hip_tsvq_exchange_* (multi-GPU)
-    void* wide_ws = nullptr; void* wide_packed = nullptr; bu::tsvq_wide_node* wide_nodes = nullptr; bu::tsvq_wide_ctrl* wide_ctrl = nullptr;
+    void* wide_ws = nullptr; void* wide_packed = nullptr; bu::tsvq_wide_node* wide_nodes = nullptr; bu::tsvq_wide_ctrl* wide_ctrl = nullptr; void* wide_ctrl_raw = nullptr;
+    uint32_t fused_workgroups = 0;   // > 0: a round's side passes as one persistent kernel of that many workgroups (the device's CU count); BU_TSVQ_FUSED=0 switches it off
     // Pinned staging for the per-round node / result records: hipMemcpyAsync on PAGEABLE host memory followed directly by a
     // kernel on the same stream was observed to let the kernel read the destination before the copy landed (MI355X, ROCm 7.2:
     // tools/tsvq_root_repeat.py, 2 of 10 runs), so nothing on this path hands pageable memory to an asynchronous copy.
@@ -850,7 +857,7 @@ void bu_hip_tsvq_destroy(bu_hip_context* ctx, bu_tsvq* q) {
     if (!ctx || !q) return;
     device_guard g(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    for (void* p : {q->rows, (void*)q->w64, (void*)q->perm[0], (void*)q->perm[1], (void*)q->side, q->nodes.p, q->outs.p, q->xchg, q->wide_ws, q->wide_packed, (void*)q->wide_nodes, (void*)q->wide_ctrl}) if (p) bu_hip_free(ctx, p);
+    for (void* p : {q->rows, (void*)q->w64, (void*)q->perm[0], (void*)q->perm[1], (void*)q->side, q->nodes.p, q->outs.p, q->xchg, q->wide_ws, q->wide_packed, (void*)q->wide_nodes, q->wide_ctrl_raw}) if (p) bu_hip_free(ctx, p);
     q->nodes.p = nullptr; q->outs.p = nullptr;
     if (q->pinned) {  // hand the pinned staging buffer back to the context (keep the larger one)
         if (q->pinned_cap > ctx->tsvq_pinned_cap) { if (ctx->tsvq_pinned) (void)hipHostFree(ctx->tsvq_pinned); ctx->tsvq_pinned = q->pinned; ctx->tsvq_pinned_cap = q->pinned_cap; }
@@ -893,10 +900,19 @@ static bu_tsvq* tsvq_create_common(bu_hip_context* ctx, uint32_t dim, bool packe
             q->wide_blocks_cap = (n + 255) / 256 + q->wide_nodes_cap;
             q->wide_ws = bu_hip_malloc(ctx, bu::tsvq_wide_workspace_bytes(q->wide_blocks_cap));
             q->wide_nodes = (bu::tsvq_wide_node*)bu_hip_malloc(ctx, (size_t)q->wide_nodes_cap * sizeof(bu::tsvq_wide_node));
-            q->wide_ctrl = (bu::tsvq_wide_ctrl*)bu_hip_malloc(ctx, (size_t)q->wide_nodes_cap * sizeof(bu::tsvq_wide_ctrl));
+            q->wide_ctrl_raw = bu_hip_malloc(ctx, bu::tsvq_wide_sync_bytes() + (size_t)q->wide_nodes_cap * sizeof(bu::tsvq_wide_ctrl));   // the fused kernel's barrier words in front
+            q->wide_ctrl = q->wide_ctrl_raw ? reinterpret_cast<bu::tsvq_wide_ctrl*>(static_cast<char*>(q->wide_ctrl_raw) + bu::tsvq_wide_sync_bytes()) : nullptr;
             q->wide_packed = bu_hip_malloc(ctx, (size_t)n * 8);
             if (!q->wide_ws || !q->wide_packed || !q->wide_nodes || !q->wide_ctrl) return fail("allocation");
-        }
+            {
+                // OFF unless BU_TSVQ_FUSED=1 (or 2: two workgroups per CU): built, bit-identical, and 2.5x SLOWER than the separate kernels on the bench image -- one
+                // workgroup per CU cannot hide the per-block latencies that ten co-resident workgroups of the separate launches hide, and the walk's 174 registers cap the kernel at two
+                const char* e = std::getenv("BU_TSVQ_FUSED");
+                const int per_cu = e ? std::atoi(e) : 0;
+                hipDeviceProp_t prop;
+                if (per_cu >= 1 && per_cu <= 2 && !g_fused_gave_up.load() && hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.multiProcessorCount > 0)
+                    q->fused_workgroups = (uint32_t)prop.multiProcessorCount * (uint32_t)per_cu;
+            }        }
     }
     if (d_endpoint_keys) {   // the rows are made on the device from the de-duplication's keys (bu_hip_k_unique_endpoint_vectors)
         if (bu::launch_endpoint_rows(ctx->stream, d_endpoint_keys, d_endpoint_goffs, n, static_cast<float*>(q->rows), q->w64) != hipSuccess) return fail("endpoint rows");
@@ -1019,7 +1035,7 @@ int bu_hip_tsvq_split(bu_hip_context* ctx, bu_tsvq* q, const bu_tsvq_node* h_nod
     const bool zero_copy = q->zero_copy;
     // staged: the result records come back over the node records; zero-copy: the kernels write them while others still read their nodes, so they get their own place
     const size_t out_at = zero_copy ? ((wide_at + wide_bytes + 63) & ~(size_t)63) : 0, flag_at = (out_at + out_bytes + 63) & ~(size_t)63;
-    BU_TRY(ctx, q->reserve_pinned(std::max(wide_at + wide_bytes, flag_at + 64)));
+    BU_TRY(ctx, q->reserve_pinned(std::max(wide_at + wide_bytes, flag_at + 128)));   // the round's flag, and 64 bytes on the fused kernel's verdict
     char* d_pinned = nullptr;   // the page-locked buffer as the device addresses it
     if (zero_copy) BU_TRY(ctx, hipHostGetDevicePointer(reinterpret_cast<void**>(&d_pinned), q->pinned, 0));
     volatile uint32_t* round_flag = reinterpret_cast<volatile uint32_t*>(static_cast<char*>(q->pinned) + flag_at);
@@ -1060,11 +1076,17 @@ int bu_hip_tsvq_split(bu_hip_context* ctx, bu_tsvq* q, const bu_tsvq_node* h_nod
         BU_TRY(ctx, bu::launch_tsvq_split(ctx->side_stream, (int)q->dim, q->packed, exact, q->rows, q->w64, q->perm[0], q->perm[1], q->side, d_nodes_in, n_narrow, d_outs));
         BU_TRY(ctx, hipEventRecord(ctx->side_join, ctx->side_stream));
     }
+    // the side passes of the wide batch as one persistent kernel when this context can have the chip's barrier to itself (see g_fused_lock)
+    volatile uint32_t* fused_verdict = reinterpret_cast<volatile uint32_t*>(static_cast<char*>(q->pinned) + flag_at + 64);
+    std::unique_lock<std::mutex> fused_turn(g_fused_lock, std::defer_lock);
+    const bool fused = n_wide && zero_copy && q->fused_workgroups && !q->dbg_serial && !g_fused_gave_up.load() && fused_turn.try_lock();
     if (n_wide) {
         prof_scope ps(ctx, "tsvq_split_packed16_wide");
+        if (fused) { *fused_verdict = 2; __atomic_thread_fence(__ATOMIC_SEQ_CST); }
         BU_TRY(ctx, bu::launch_tsvq_wide_split(ctx->stream, static_cast<const uint32_t*>(q->rows), q->w64, q->perm[0], q->perm[1], q->side, q->wide_packed, q->wide_nodes, n_wide, q->wide_ctrl,
                                                q->wide_ws, wide_blocks, d_outs, wide_max_count < q->wide_cov_min,
-                                               wide_max_weight * 3ull < (1ull << 24)));
+                                               wide_max_weight * 3ull < (1ull << 24), fused ? q->fused_workgroups : 0u,
+                                               fused ? reinterpret_cast<uint32_t*>(d_pinned + flag_at + 64) : nullptr));
     }
     if (n_wide && q->dbg_stats) {   // development aid: how the last pass's walks went, per wide node
         std::vector<bu::tsvq_wide_ctrl> hc(n_wide);
@@ -1111,12 +1133,20 @@ int bu_hip_tsvq_split(bu_hip_context* ctx, bu_tsvq* q, const bu_tsvq_node* h_nod
     if (round_stats) {
         uint32_t mx = 0; uint64_t tot = 0;
         for (uint32_t i = 0; i < n_nodes; i++) { mx = std::max(mx, h_nodes[i].count); tot += h_nodes[i].count; }
-        std::fprintf(stderr, "[tsvq round] dim %u: %u nodes (%u wide), largest %u, members %llu: %.0f us\n", q->dim, n_nodes, n_wide, mx, (unsigned long long)tot,
+        std::fprintf(stderr, "[tsvq round] dim %u: %u nodes (%u wide%s), largest %u, members %llu: %.0f us\n", q->dim, n_nodes, n_wide, fused ? (*fused_verdict == 1 ? ", fused" : ", fused GAVE UP") : "", mx, (unsigned long long)tot,
                      std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - round_t0).count());
     }
     {
         const bu_tsvq_split* po = reinterpret_cast<const bu_tsvq_split*>(static_cast<const char*>(q->pinned) + out_at);
         for (uint32_t i = 0; i < n_nodes; i++) h_out[order[i]] = po[i];
+    }
+    if (fused) {
+        fused_turn.unlock();
+        if (*fused_verdict != 1) {   // the persistent kernel gave up at a barrier (the chip was not its own): nothing it left behind is used, the nodes go the one-workgroup way,
+            g_fused_gave_up.store(true);   // and this process does not try again
+            q->fused_workgroups = 0;
+            for (uint32_t i = n_narrow; i < n_nodes; i++) { std::memset(&h_out[order[i]], 0, sizeof(bu_tsvq_split)); h_out[order[i]].ok = 2; }
+        }
     }
     if (exact) { // nodes whose data left the exact range, or that the wide path handed back (ok == 2), go through the one-workgroup kernel: wide ones through its exact variant first
         for (int attempt = 0; attempt < 2; attempt++) {

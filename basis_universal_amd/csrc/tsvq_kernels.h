@@ -60,6 +60,9 @@ hipError_t launch_tsvq_wide_span_roots(hipStream_t st, const uint32_t* d_keys, c
 hipError_t launch_tsvq_wide_split(hipStream_t st, const uint32_t* d_keys, const uint64_t* d_w64, uint32_t* d_perm0, uint32_t* d_perm1, uint8_t* d_side, void* d_packed /* 8 bytes per vector */,
                                   const tsvq_wide_node* d_nodes, uint32_t n_nodes, tsvq_wide_ctrl* d_ctrl, void* d_ws, uint32_t total_blocks, tsvq_split_out* d_outs,
                                   bool chained_covariance /* the covariance pass through launch_tsvq_cov_axis instead of 136 walks per node */,
-                                  bool side_chains_exact /* 3 x the heaviest node's weight < 2^24: every projection / two-means chain total is exact, no maps needed */);
+                                  bool side_chains_exact /* 3 x the heaviest node's weight < 2^24: every projection / two-means chain total is exact, no maps needed */,
+                                  uint32_t fused_workgroups /* > 0: the projection / two-means passes + the partition as ONE persistent kernel of that many workgroups (<= CUs) */,
+                                  uint32_t* d_fused_verdict /* host-visible word: 1 when the fused kernel ran to its end, 0 when it gave up (nothing of the round may be used) */);
+size_t tsvq_wide_sync_bytes();   // bytes the fused kernel's barrier words take IN FRONT OF d_ctrl (the ctrl allocation starts that many bytes earlier)
 
 } // namespace bu

@@ -35,13 +35,16 @@ constexpr int WB = 256;            // members per block = threads per workgroup 
 constexpr int WROW = WB + 1;       // LDS row stride (floats)
 constexpr int NCH_MAX = TSVQ_WIDE_MAX_CHAINS;
 
-enum { WM_ROOT = 0, WM_COV = 1, WM_PROJ = 2, WM_DIST = 3 };
+enum { WM_ROOT = 0, WM_COV = 1, WM_PROJ = 2, WM_DIST = 3, WM_SIDE = 4 };   // WM_SIDE: WM_PROJ or WM_DIST chosen at run time (`dist`): the passes of the fused kernel
+#define W_IS_DIST(MODE, dist) ((MODE) == WM_DIST || ((MODE) == WM_SIDE && (dist)))
+#define W_IS_PROJ(MODE, dist) ((MODE) == WM_PROJ || ((MODE) == WM_SIDE && !(dist)))
 
 template <int MODE> struct mode_traits;
 template <> struct mode_traits<WM_ROOT> { static constexpr int NCH = 16; };
 template <> struct mode_traits<WM_COV>  { static constexpr int NCH = 136; };
 template <> struct mode_traits<WM_PROJ> { static constexpr int NCH = 32; };
 template <> struct mode_traits<WM_DIST> { static constexpr int NCH = 32; };
+template <> struct mode_traits<WM_SIDE> { static constexpr int NCH = 32; };
 
 // covariance chain -> (x, y >= x), the enumeration of tsvq_kernels.hip (row-major upper triangle)
 __device__ __forceinline__ void cov_xy(int c, int& x, int& y) { x = 0; while (c >= 16 - x) { c -= 16 - x; x++; } y = x + c; }
@@ -92,13 +95,13 @@ __device__ __forceinline__ member_info fetch_member(const uint32_t* __restrict__
 
 // which child does a member go to (enc.h:1870-1871 projection sign, enc.h:1991 distance comparison)
 template <int MODE>
-__device__ __forceinline__ bool classify(uint32_t key, const float* s_origin, const float* s_axis, const double2 (*s_tab)[4]) {
-    if (MODE == WM_DIST) {
+__device__ __forceinline__ bool classify(uint32_t key, const float* s_origin, const float* s_axis, const double2 (*s_tab)[4], bool dist) {
+    if (W_IS_DIST(MODE, dist)) {
         double dl = 0, dr = 0;
 #pragma unroll
         for (int k = 0; k < 16; k++) { const double2 t = s_tab[k][packed16_value(key, k)]; dl += t.x; dr += t.y; }
         return dl >= dr;
-    } else if (MODE == WM_PROJ) {
+    } else if (W_IS_PROJ(MODE, dist)) {
         float dd[16];
 #pragma unroll
         for (int k = 0; k < 16; k++) dd[k] = (float)packed16_value(key, k) - s_origin[k];
@@ -118,10 +121,12 @@ struct tiles {
 };
 
 // ------------------------------------------------------------------------------------------------------------ k_wide_sums
+// (The per-phase bodies are device functions: the classic path wraps each in a kernel of its own, the fused kernel of the side passes calls them in turn with grid-wide
+//  barriers in between. What other workgroups write between phases -- ctrl, the workspace, side -- is reached through plain pointers: no __restrict__ promise there.)
 template <int MODE>
-__global__ __launch_bounds__(WB) void k_wide_sums(const uint32_t* __restrict__ keys, const uint64_t* __restrict__ w64, const uint32_t* __restrict__ perm0,
-                                                  const uint32_t* __restrict__ perm1, uint8_t* __restrict__ side, const tsvq_wide_node* __restrict__ nodes,
-                                                  uint32_t n_nodes, const tsvq_wide_ctrl* __restrict__ ctrl, void* ws_base, uint32_t tb, uint2* __restrict__ pk) {
+__device__ __forceinline__ void wide_sums_body(const uint32_t* __restrict__ keys, const uint64_t* __restrict__ w64, const uint32_t* perm0,
+                                               const uint32_t* perm1, uint8_t* side, const tsvq_wide_node* __restrict__ nodes,
+                                               uint32_t n_nodes, const tsvq_wide_ctrl* ctrl, void* ws_base, uint32_t tb, uint2* pk, const uint32_t blk, const bool dist) {
     constexpr int NCH = mode_traits<MODE>::NCH;
     __shared__ tiles<MODE> T;
     __shared__ float s_origin[16], s_axis[16];
@@ -132,13 +137,12 @@ __global__ __launch_bounds__(WB) void k_wide_sums(const uint32_t* __restrict__ k
     __shared__ uint64_t s_red[4][8];
     const wide_ws ws = carve(ws_base, tb);
     const int tid = threadIdx.x;
-    const uint32_t blk = blockIdx.x;
     const uint32_t ni = find_node(nodes, n_nodes, blk);
     const tsvq_wide_ctrl& ct = ctrl[ni];
     if (ct.done) return;
     const tsvq_wide_node& nd = nodes[ni];
     if (tid < 16) { s_origin[tid] = nd.origin[tid]; s_axis[tid] = ct.axis[tid]; }
-    if (MODE == WM_DIST && tid < 64) {   // squared centroid differences per value (tsvq_kernels.hip, TQ_MODE_DIST)
+    if (W_IS_DIST(MODE, dist) && tid < 64) {   // squared centroid differences per value (tsvq_kernels.hip, TQ_MODE_DIST)
         const int k = tid >> 2, val = tid & 3;
         const double a = (double)ct.l_c[k] - (double)(float)val, b = (double)ct.r_c[k] - (double)(float)val;
         s_tab[k][val] = make_double2(a * a, b * b);
@@ -163,7 +167,7 @@ __global__ __launch_bounds__(WB) void k_wide_sums(const uint32_t* __restrict__ k
             T.fb[k][tid] = m.valid ? m.wf * dk : 0.0f;
         }
     } else {
-        if (MODE != WM_ROOT) right = classify<MODE>(m.key, s_origin, s_axis, s_tab);
+        if (MODE != WM_ROOT) right = classify<MODE>(m.key, s_origin, s_axis, s_tab, dist);
         float vsq = 0.0f;
         {
             float v[16];
@@ -175,7 +179,7 @@ __global__ __launch_bounds__(WB) void k_wide_sums(const uint32_t* __restrict__ k
         if (m.valid) {
             if (MODE != WM_ROOT) side[nd.start + pos] = right ? 1 : 0;
             // the reference's double accumulators: l_weight / r_weight in the projection pass (enc.h:1873-1881), ttsum otherwise
-            const float dvf = MODE == WM_PROJ ? m.wf : m.wf * vsq;
+            const float dvf = W_IS_PROJ(MODE, dist) ? m.wf : m.wf * vsq;
             exact_acc ex;
             const bool ok = ex.add(dvf);
             if (right) { red[1] = m.w; red[5] = ex.lo; red[6] = ex.hi; } else { red[0] = m.w; red[2] = 1; red[3] = ex.lo; red[4] = ex.hi; }
@@ -228,6 +232,11 @@ __global__ __launch_bounds__(WB) void k_wide_sums(const uint32_t* __restrict__ k
     }
     if (tid >= 64 && tid < 72) ws.bex[(size_t)blk * 8 + (tid - 64)] = s_red[0][tid - 64] + s_red[1][tid - 64] + s_red[2][tid - 64] + s_red[3][tid - 64];
 }
+template <int MODE>
+__global__ __launch_bounds__(WB) void k_wide_sums(const uint32_t* __restrict__ keys, const uint64_t* __restrict__ w64, const uint32_t* perm0, const uint32_t* perm1, uint8_t* side,
+                                                  const tsvq_wide_node* __restrict__ nodes, uint32_t n_nodes, const tsvq_wide_ctrl* ctrl, void* ws_base, uint32_t tb, uint2* pk) {
+    wide_sums_body<MODE>(keys, w64, perm0, perm1, side, nodes, n_nodes, ctrl, ws_base, tb, pk, blockIdx.x, MODE == WM_DIST);
+}
 
 // inclusive prefix sum of a double over the wave by DPP (rows of 16: row_shr 1/2/4/8, then row_bcast15 into rows 1 and 3, row_bcast31 into rows 2 and 3);
 // lanes without a source add +0.0. A prediction aid (and exact for the integer-valued block sums): the association order does not matter.
@@ -246,18 +255,17 @@ __device__ __forceinline__ double wave_prefix_f64(double v) {
 // grid (node, y): y < ceil(NCH / 4): four chains, one wave each, 64 blocks per step (coalesced, wave prefix scan);
 //                 y == ceil(NCH / 4) (not for the covariance pass): the integer totals and the left-count prefix of the node.
 template <int MODE>
-__global__ __launch_bounds__(256) void k_wide_scan(const tsvq_wide_node* __restrict__ nodes, tsvq_wide_ctrl* __restrict__ ctrl, void* ws_base, uint32_t tb) {
+__device__ __forceinline__ void wide_scan_body(const tsvq_wide_node* __restrict__ nodes, tsvq_wide_ctrl* ctrl, void* ws_base, uint32_t tb, const uint32_t ni, const uint32_t y) {
     constexpr int NCH = mode_traits<MODE>::NCH;
     constexpr int NCW = (NCH + 3) / 4;
     __shared__ uint64_t s_tot[4][8];
     __shared__ uint32_t s_wl[4];
     const wide_ws ws = carve(ws_base, tb);
-    const uint32_t ni = blockIdx.x;
     if (ctrl[ni].done) return;
     const tsvq_wide_node nd = nodes[ni];
     const int tid = threadIdx.x, lane = tid & 63;
-    if ((int)blockIdx.y < NCW) {
-        const int c = (int)blockIdx.y * 4 + (tid >> 6);
+    if ((int)y < NCW) {
+        const int c = (int)y * 4 + (tid >> 6);
         if (c >= NCH) return;
         double P = 0;   // sum of the blocks before the current 64
         uint32_t exact_blocks = 0; double exact_sum = 0.0;   // the leading blocks over which the (integer) running sum stays <= 2^24: no rounding there
@@ -349,6 +357,10 @@ __global__ __launch_bounds__(256) void k_wide_scan(const tsvq_wide_node* __restr
         ct.ex_bad = ok ? 0u : 1u;
     }
 }
+template <int MODE>
+__global__ __launch_bounds__(256) void k_wide_scan(const tsvq_wide_node* __restrict__ nodes, tsvq_wide_ctrl* ctrl, void* ws_base, uint32_t tb) {
+    wide_scan_body<MODE>(nodes, ctrl, ws_base, tb, blockIdx.x, blockIdx.y);
+}
 
 // ------------------------------------------------------------------------------------------------------------ k_wide_stretches
 // (key, float weight) of the member at list position pos: from the packed copy the covariance pass made, or -- root -- directly
@@ -367,9 +379,9 @@ __device__ __forceinline__ fsum::stretch st_load(const int32_t* o) { fsum::stret
 // (320 threads -- two rounds over the covariance pass's 544 items instead of three -- measured slower: 307 against 250 us for the root.)
 constexpr int ST_THREADS = WB;
 template <int MODE>
-__global__ __launch_bounds__(ST_THREADS) void k_wide_stretches(const uint32_t* __restrict__ keys, const uint64_t* __restrict__ w64, const uint2* __restrict__ pk,
-                                                       const uint8_t* __restrict__ side, const tsvq_wide_node* __restrict__ nodes,
-                                                       uint32_t n_nodes, const tsvq_wide_ctrl* __restrict__ ctrl, void* ws_base, uint32_t tb) {
+__device__ __forceinline__ void wide_stretches_body(const uint32_t* __restrict__ keys, const uint64_t* __restrict__ w64, const uint2* pk,
+                                                    const uint8_t* side, const tsvq_wide_node* __restrict__ nodes,
+                                                    uint32_t n_nodes, const tsvq_wide_ctrl* ctrl, void* ws_base, uint32_t tb, const uint32_t blk) {
     constexpr int NCH = mode_traits<MODE>::NCH;
     constexpr int Q = MODE == WM_COV ? 4 : (MODE == WM_ROOT ? 16 : 8);   // member slices per chain; an item = (chain, slice), both candidate binades
     constexpr int ITEMS = NCH * Q;
@@ -379,7 +391,6 @@ __global__ __launch_bounds__(ST_THREADS) void k_wide_stretches(const uint32_t* _
     __shared__ int32_t s_st[ITEMS][2][6];
     const wide_ws ws = carve(ws_base, tb);
     const int tid = threadIdx.x;
-    const uint32_t blk = blockIdx.x;
     const uint32_t ni = find_node(nodes, n_nodes, blk);
     if (ctrl[ni].done) return;
     // every chain of this pass finished by the scan (integer totals below 2^24): nothing to fold
@@ -441,6 +452,11 @@ __global__ __launch_bounds__(ST_THREADS) void k_wide_stretches(const uint32_t* _
         st_store(ws.summ + (ws.at(c, blk) * 2 + (size_t)cand) * 6, acc);
     }
 }
+template <int MODE>
+__global__ __launch_bounds__(ST_THREADS) void k_wide_stretches(const uint32_t* __restrict__ keys, const uint64_t* __restrict__ w64, const uint2* pk, const uint8_t* side,
+                                                       const tsvq_wide_node* __restrict__ nodes, uint32_t n_nodes, const tsvq_wide_ctrl* ctrl, void* ws_base, uint32_t tb) {
+    wide_stretches_body<MODE>(keys, w64, pk, side, nodes, n_nodes, ctrl, ws_base, tb, blockIdx.x);
+}
 
 // ------------------------------------------------------------------------------------------------------------ k_wide_walk
 // One wave per (node, chain). A window of 64 blocks is resident in registers with the maps of BOTH candidate binades, so that
@@ -493,19 +509,19 @@ __device__ __forceinline__ void wave_scan(mono& st) {
     scan_step<0x142, 0xa>(st); scan_step<0x143, 0xc>(st);
 }
 
+// One WAVE per (node, chain) = `task`; s_add: 256 floats of LDS owned by that wave (the only synchronisation inside is between the lanes of the wave, whose LDS
+// accesses execute in program order: a scheduling fence is all the member-by-member blocks need).
 template <int MODE>
-__global__ __launch_bounds__(64) void k_wide_walk(const uint32_t* __restrict__ keys, const uint64_t* __restrict__ w64, const uint2* __restrict__ pk,
-                                                  const uint8_t* __restrict__ side, const tsvq_wide_node* __restrict__ nodes,
-                                                  tsvq_wide_ctrl* __restrict__ ctrl, void* ws_base, uint32_t tb) {
+__device__ __forceinline__ void wide_walk_body(const uint32_t* __restrict__ keys, const uint64_t* __restrict__ w64, const uint2* pk,
+                                               const uint8_t* side, const tsvq_wide_node* __restrict__ nodes,
+                                               tsvq_wide_ctrl* ctrl, void* ws_base, uint32_t tb, const uint32_t task, const int lane, float* s_add) {
     constexpr int NCH = mode_traits<MODE>::NCH;
     constexpr bool MONO = MODE != WM_COV;
-    __shared__ __align__(16) float s_add[WB];
     const wide_ws ws = carve(ws_base, tb);
-    const uint32_t ni = blockIdx.x / NCH;
-    const int c = (int)(blockIdx.x % NCH);
+    const uint32_t ni = task / NCH;
+    const int c = (int)(task % NCH);
     if (ctrl[ni].done || ctrl[ni].exact[c]) return;
     const tsvq_wide_node& nd = nodes[ni];
-    const int lane = threadIdx.x;
     // what the chain adds, per member: everything about the chain is uniform over the wave
     int cx = 0, cy = 0;
     if (MODE == WM_COV) cov_xy(c, cx, cy); else cx = c & 15;
@@ -538,7 +554,7 @@ __global__ __launch_bounds__(64) void k_wide_walk(const uint32_t* __restrict__ k
             const uint32_t pos = min(p0 + (uint32_t)(r * 64 + lane), nd.count - 1);
             if (MODE == WM_ROOT && !pk) { m.key[r] = keys[pos]; m.w[r] = w64[pos]; }
             else { const uint2 v = pk[nd.start + pos]; m.key[r] = v.x; m.w[r] = v.y; }
-            m.sd[r] = (MODE == WM_PROJ || MODE == WM_DIST) ? side[nd.start + pos] : (uint8_t)0;
+            m.sd[r] = (MODE == WM_PROJ || MODE == WM_DIST || MODE == WM_SIDE) ? side[nd.start + pos] : (uint8_t)0;
         }
     };
     auto addends = [&](uint32_t blk, const staged& m, float (&a)[4]) {
@@ -556,7 +572,7 @@ __global__ __launch_bounds__(64) void k_wide_walk(const uint32_t* __restrict__ k
                 v = dx * wdy;
             } else {
                 v = (float)packed16_value(key, cx) * wf;
-                if (MODE == WM_PROJ || MODE == WM_DIST) v = (m.sd[r] != 0) == chain_right ? v : 0.0f;
+                if (MODE == WM_PROJ || MODE == WM_DIST || MODE == WM_SIDE) v = (m.sd[r] != 0) == chain_right ? v : 0.0f;
             }
             a[r] = valid ? v : -0.0f;   // past the node's end: leaves every sum as it is
         }
@@ -626,10 +642,10 @@ __global__ __launch_bounds__(64) void k_wide_walk(const uint32_t* __restrict__ k
                     // (64 addends) ahead of the adds, which then follow each other at the VALU's own pace
                     float a[4];
                     addends(b0 + (uint32_t)j, m, a);
-                    __syncthreads();
+                    __builtin_amdgcn_wave_barrier();
 #pragma unroll
                     for (int r = 0; r < 4; r++) s_add[r * 64 + lane] = a[r];
-                    __syncthreads();
+                    __builtin_amdgcn_wave_barrier();
                     float f = __uint_as_float(s);
 #pragma unroll
                     for (int r = 0; r < 4; r++) {
@@ -684,19 +700,25 @@ __global__ __launch_bounds__(64) void k_wide_walk(const uint32_t* __restrict__ k
         else { ctrl[ni].stat_scans[c] = (uint16_t)min(n_scans, 65535u); ctrl[ni].stat_raw[c] = (uint16_t)min(n_raw, 65535u); }
     }
 }
+template <int MODE>
+__global__ __launch_bounds__(64) void k_wide_walk(const uint32_t* __restrict__ keys, const uint64_t* __restrict__ w64, const uint2* pk, const uint8_t* side,
+                                                  const tsvq_wide_node* __restrict__ nodes, tsvq_wide_ctrl* ctrl, void* ws_base, uint32_t tb) {
+    __shared__ __align__(16) float s_add[WB];
+    wide_walk_body<MODE>(keys, w64, pk, side, nodes, ctrl, ws_base, tb, blockIdx.x, (int)threadIdx.x, s_add);
+}
 
 // ------------------------------------------------------------------------------------------------------------ k_wide_finish
 // The serial tail of a pass: what thread 0 of k_tsvq_split / k_tsvq_root does between passes.
+// One WAVE per node (`lane` of it; the covariance tail, whole-wave work with a workgroup barrier inside, is only ever called from its own 64-thread kernel).
 template <int MODE>
-__global__ __launch_bounds__(64) void k_wide_finish(const tsvq_wide_node* __restrict__ nodes, tsvq_wide_ctrl* __restrict__ ctrl, tsvq_root_out* __restrict__ root_out) {
-    const uint32_t ni = blockIdx.x;
+__device__ __forceinline__ void wide_finish_body(const tsvq_wide_node* __restrict__ nodes, tsvq_wide_ctrl* ctrl, tsvq_root_out* root_out, const uint32_t ni, const int lane, const bool dist) {
     tsvq_wide_ctrl& c = ctrl[ni];
     if (c.done) return;
     const tsvq_wide_node& nd = nodes[ni];
     constexpr int N = 16;
     if (MODE == WM_COV) {    // compute_split_axis (enc.h:1802-1846): the whole wave
         __shared__ float s_cov[16][16];
-        if (threadIdx.x == 0) {
+        if (lane == 0) {
             int ch = 0;
             for (int x = 0; x < N; x++) for (int y = x; y < N; y++) s_cov[x][y] = c.sums[ch++];
             const float renorm = 1.0f / (float)nd.weight;
@@ -707,7 +729,7 @@ __global__ __launch_bounds__(64) void k_wide_finish(const tsvq_wide_node* __rest
         principal_axis_wave<N>(s_cov, c.axis);
         return;
     }
-    if (threadIdx.x != 0) return;
+    if (lane != 0) return;
     if (MODE == WM_ROOT) {   // prepare_root (enc.h:1708-1735)
         root_out += nd.out_index;
         if (c.ex_bad) { root_out->pad = 1; c.done = 2; return; }
@@ -725,7 +747,7 @@ __global__ __launch_bounds__(64) void k_wide_finish(const tsvq_wide_node* __rest
         return;
     }
     if (c.ex_bad) { c.done = 2; return; }
-    if (MODE == WM_PROJ) {   // prep_split (enc.h:1887-1891); the degenerate projection (:1893-1957) is left to the one-workgroup kernel
+    if (W_IS_PROJ(MODE, dist)) {   // prep_split (enc.h:1887-1891); the degenerate projection (:1893-1957) is left to the one-workgroup kernel
         const double lw = c.dsum[0], rw = c.dsum[1];
         if (!(lw > 0.0 && rw > 0.0)) { c.done = 2; return; }
         const float ls = (float)(1.0 / lw), rs = (float)(1.0 / rw);
@@ -754,15 +776,18 @@ __global__ __launch_bounds__(64) void k_wide_finish(const tsvq_wide_node* __rest
     c.iter++;
     if (stop || c.iter == 6) c.done = 1;
 }
+template <int MODE>
+__global__ __launch_bounds__(64) void k_wide_finish(const tsvq_wide_node* __restrict__ nodes, tsvq_wide_ctrl* ctrl, tsvq_root_out* root_out) {
+    wide_finish_body<MODE>(nodes, ctrl, root_out, blockIdx.x, (int)threadIdx.x, MODE == WM_DIST);
+}
 
 // ------------------------------------------------------------------------------------------------------------ k_wide_partition
-__global__ __launch_bounds__(WB) void k_wide_partition(uint32_t* __restrict__ perm0, uint32_t* __restrict__ perm1, const uint8_t* __restrict__ side,
-                                                       const tsvq_wide_node* __restrict__ nodes, uint32_t n_nodes, const tsvq_wide_ctrl* __restrict__ ctrl,
-                                                       void* ws_base, uint32_t tb, tsvq_split_out* __restrict__ outs) {
+__device__ __forceinline__ void wide_partition_body(uint32_t* perm0, uint32_t* perm1, const uint8_t* side,
+                                                    const tsvq_wide_node* __restrict__ nodes, uint32_t n_nodes, const tsvq_wide_ctrl* ctrl,
+                                                    void* ws_base, uint32_t tb, tsvq_split_out* outs, const uint32_t blk) {
     __shared__ uint32_t s_wl[4];
     const wide_ws ws = carve(ws_base, tb);
     const int tid = threadIdx.x;
-    const uint32_t blk = blockIdx.x;
     const uint32_t ni = find_node(nodes, n_nodes, blk);
     const tsvq_wide_ctrl& c = ctrl[ni];
     const tsvq_wide_node& nd = nodes[ni];
@@ -790,6 +815,94 @@ __global__ __launch_bounds__(WB) void k_wide_partition(uint32_t* __restrict__ pe
     for (int w = 0; w < wave; w++) lbefore += s_wl[w];
     if (left) child[lbefore] = members[pos];
     if (right) child[c.l_n + (pos - lbefore)] = members[pos];
+}
+__global__ __launch_bounds__(WB) void k_wide_partition(uint32_t* perm0, uint32_t* perm1, const uint8_t* side, const tsvq_wide_node* __restrict__ nodes, uint32_t n_nodes,
+                                                       const tsvq_wide_ctrl* ctrl, void* ws_base, uint32_t tb, tsvq_split_out* outs) {
+    wide_partition_body(perm0, perm1, side, nodes, n_nodes, ctrl, ws_base, tb, outs, blockIdx.x);
+}
+
+// ------------------------------------------------------------------------------------------------------------ the side passes of a round in ONE launch
+// The projection pass and the up to six two-means passes of a round are five dependent kernels each, 5 - 50 us apiece, and the host cannot know how many of the six the
+// nodes will need: a round paid ~35 launches (~4.6 us each even when every node had converged and the kernel had nothing to do) for ~0.3 ms of work. Here the same
+// per-phase bodies run inside one persistent kernel -- one workgroup per CU, a device-scope barrier where a kernel boundary used to be, the passes ending as soon as no
+// node is active -- followed by the partition. Results are those of the separate kernels (same bodies, same order).
+//
+// The barrier needs every workgroup resident at once. One workgroup per CU always is when the GPU is this kernel's alone; beside other kernels (the one-workgroup
+// splits on the side stream, other contexts) late workgroups get their slots as those kernels drain. What cannot be excluded is two such kernels of different
+// processes each holding part of the chip: a workgroup that waits longer than FUSED_SPIN_LIMIT polls raises `abort`, everybody leaves, no result record is written and
+// the host runs the round again through the separate kernels (bu_hip_tsvq_split).
+struct wide_sync { uint32_t arrived; uint32_t abort; uint32_t finished; uint32_t pad[61]; };   // 256 bytes, zeroed with the ctrl records in front of every round
+constexpr uint32_t FUSED_SPIN_LIMIT = 40000;   // ~20-40 ms
+
+__device__ __forceinline__ bool grid_sync(wide_sync* sy, uint32_t& epoch) {
+    __shared__ uint32_t s_ok;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        epoch++;
+        __threadfence();                                       // what this workgroup wrote is visible device-wide before it is counted
+        __hip_atomic_fetch_add(&sy->arrived, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t target = epoch * gridDim.x;
+        uint32_t ok = 1, spins = 0;
+        while (__hip_atomic_load(&sy->arrived, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            if (__hip_atomic_load(&sy->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 || ++spins > FUSED_SPIN_LIMIT) {
+                __hip_atomic_store(&sy->abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok = 0;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(4);
+        }
+        __threadfence();                                       // ... and what the others wrote is fetched anew from here on
+        s_ok = ok;
+    }
+    __syncthreads();
+    return s_ok != 0;
+}
+
+__global__ __launch_bounds__(WB) void k_wide_side_passes(const uint32_t* __restrict__ keys, const uint64_t* __restrict__ w64, uint32_t* perm0, uint32_t* perm1, uint8_t* side, uint2* pk,
+                                                         const tsvq_wide_node* __restrict__ nodes, uint32_t n_nodes, tsvq_wide_ctrl* ctrl, void* ws_base, uint32_t tb,
+                                                         tsvq_split_out* outs, wide_sync* sy, int all_chains_exact) {
+    constexpr int NCH = 32, NCW = 8;
+    __shared__ __align__(16) float s_add[4][WB];
+    __shared__ uint32_t s_active;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t G = gridDim.x, wg = blockIdx.x;
+    uint32_t epoch = 0;
+    for (int pass = 0; pass < 7; pass++) {
+        const bool dist = pass != 0;
+        if (pass > 1) {   // anybody still iterating? (the records were written before the barrier that ended the previous pass)
+            if (tid == 0) s_active = 0;
+            __syncthreads();
+            uint32_t mine = 0;
+            for (uint32_t i = (uint32_t)tid; i < n_nodes; i += WB) mine |= __hip_atomic_load(&ctrl[i].done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0 ? 1u : 0u;
+            if (mine) s_active = 1;   // (benign race: everybody writes 1)
+            __syncthreads();
+            const uint32_t active = s_active;
+            __syncthreads();
+            if (!active) break;
+        }
+        for (uint32_t blk = wg; blk < tb; blk += G) { wide_sums_body<WM_SIDE>(keys, w64, perm0, perm1, side, nodes, n_nodes, ctrl, ws_base, tb, pk, blk, dist); __syncthreads(); }
+        if (!grid_sync(sy, epoch)) return;
+        for (uint32_t t = wg; t < n_nodes * (uint32_t)(NCW + 1); t += G) { wide_scan_body<WM_SIDE>(nodes, ctrl, ws_base, tb, t / (NCW + 1), t % (NCW + 1)); __syncthreads(); }
+        if (!grid_sync(sy, epoch)) return;
+        if (!all_chains_exact) {
+            for (uint32_t blk = wg; blk < tb; blk += G) { wide_stretches_body<WM_SIDE>(keys, w64, pk, side, nodes, n_nodes, ctrl, ws_base, tb, blk); __syncthreads(); }
+            if (!grid_sync(sy, epoch)) return;
+            for (uint32_t t = wg * 4 + (uint32_t)wave; t < n_nodes * (uint32_t)NCH; t += G * 4) wide_walk_body<WM_SIDE>(keys, w64, pk, side, nodes, ctrl, ws_base, tb, t, lane, s_add[wave]);
+            if (!grid_sync(sy, epoch)) return;
+        }
+        if (wave == 0) for (uint32_t ni = wg; ni < n_nodes; ni += G) wide_finish_body<WM_SIDE>(nodes, ctrl, nullptr, ni, lane, dist);
+        if (!grid_sync(sy, epoch)) return;
+    }
+    for (uint32_t blk = wg; blk < tb; blk += G) { wide_partition_body(perm0, perm1, side, nodes, n_nodes, ctrl, ws_base, tb, outs, blk); __syncthreads(); }
+    if (tid == 0) __hip_atomic_fetch_add(&sy->finished, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);   // every workgroup got here: the round is whole
+}
+
+// behind the fused kernel on its stream: 1 when every one of its workgroups ran to the end (otherwise the round's records and member lists must not be used)
+__global__ void k_wide_fused_verdict(const wide_sync* sy, uint32_t workgroups, uint32_t* verdict) {
+    if (threadIdx.x == 0) {
+        const uint32_t ok = (__hip_atomic_load(&sy->finished, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == workgroups && __hip_atomic_load(&sy->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) ? 1u : 0u;
+        __hip_atomic_store(verdict, ok, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 __global__ __launch_bounds__(256) void k_wide_iota(uint32_t n, uint32_t* __restrict__ perm0) {
@@ -838,19 +951,28 @@ hipError_t launch_tsvq_wide_span_roots(hipStream_t st, const uint32_t* d_keys, c
 
 hipError_t launch_tsvq_wide_split(hipStream_t st, const uint32_t* d_keys, const uint64_t* d_w64, uint32_t* d_perm0, uint32_t* d_perm1, uint8_t* d_side, void* d_packed,
                                   const tsvq_wide_node* d_nodes, uint32_t n_nodes, tsvq_wide_ctrl* d_ctrl, void* d_ws, uint32_t total_blocks, tsvq_split_out* d_outs,
-                                  bool chained_covariance, bool side_chains_exact) {
+                                  bool chained_covariance, bool side_chains_exact, uint32_t fused_workgroups, uint32_t* d_fused_verdict) {
     if (!n_nodes) return hipSuccess;
-    hipError_t e = hipMemsetAsync(d_ctrl, 0, (size_t)n_nodes * sizeof(tsvq_wide_ctrl), st);
+    // the ctrl records of the batch and, in front of them, the fused kernel's barrier words (tsvq_wide_sync_bytes() in front of d_ctrl: one memset)
+    hipError_t e = hipMemsetAsync(reinterpret_cast<char*>(d_ctrl) - sizeof(wide_sync), 0, sizeof(wide_sync) + (size_t)n_nodes * sizeof(tsvq_wide_ctrl), st);
     if (e != hipSuccess) return e;
     if (chained_covariance) {   // raw chain sums into ctrl[].sums (three workgroups per node), then the pass's own tail: renormalisation + principal axis
         if ((e = launch_tsvq_cov_axis(st, d_keys, d_w64, d_perm0, d_perm1, d_nodes, n_nodes, d_ctrl, d_packed)) != hipSuccess) return e;
         hipLaunchKernelGGL((k_wide_finish<WM_COV>), dim3(n_nodes), dim3(64), 0, st, d_nodes, d_ctrl, nullptr);
     }
     else launch_pass<WM_COV>(st, d_keys, d_w64, d_perm0, d_perm1, d_side, static_cast<uint2*>(d_packed), d_nodes, n_nodes, total_blocks, d_ctrl, d_ws, nullptr);
+    if (fused_workgroups) {
+        hipLaunchKernelGGL(k_wide_side_passes, dim3(fused_workgroups), dim3(WB), 0, st, d_keys, d_w64, d_perm0, d_perm1, d_side, static_cast<uint2*>(d_packed), d_nodes, n_nodes, d_ctrl, d_ws,
+                           total_blocks, d_outs, reinterpret_cast<wide_sync*>(reinterpret_cast<char*>(d_ctrl) - sizeof(wide_sync)), side_chains_exact ? 1 : 0);
+        hipLaunchKernelGGL(k_wide_fused_verdict, dim3(1), dim3(64), 0, st, reinterpret_cast<const wide_sync*>(reinterpret_cast<char*>(d_ctrl) - sizeof(wide_sync)), fused_workgroups, d_fused_verdict);
+        return hipGetLastError();
+    }
     launch_pass<WM_PROJ>(st, d_keys, d_w64, d_perm0, d_perm1, d_side, static_cast<uint2*>(d_packed), d_nodes, n_nodes, total_blocks, d_ctrl, d_ws, nullptr, side_chains_exact);
     for (int it = 0; it < 6; it++) launch_pass<WM_DIST>(st, d_keys, d_w64, d_perm0, d_perm1, d_side, static_cast<uint2*>(d_packed), d_nodes, n_nodes, total_blocks, d_ctrl, d_ws, nullptr, side_chains_exact);
     hipLaunchKernelGGL(k_wide_partition, dim3(total_blocks), dim3(WB), 0, st, d_perm0, d_perm1, d_side, d_nodes, n_nodes, d_ctrl, d_ws, total_blocks, d_outs);
     return hipGetLastError();
 }
+
+size_t tsvq_wide_sync_bytes() { return sizeof(wide_sync); }
 
 } // namespace bu

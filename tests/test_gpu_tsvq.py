@@ -215,3 +215,26 @@ def test_partitioned_tsvq_through_the_reference_gate(hip_ctx, threads):
         a3 = np.zeros(cap, np.uint32); b3 = np.zeros(cap, np.uint32)
         assert ref().ref_tsvq_mt(16, ptr(v, f32p), ptr(w, u64p), n, k, p, threads, 0, ptr(a3, u32p), cap, ptr(b3, u32p), cap) == 1
         assert (a3 == a2).all() and (b3 == b2).all()
+
+
+@pytest.mark.parametrize("n,k,p,kind,wmax,wide_min", [(120000, 2731, 32, "sel", 4096, 512), (30000, 900, 16, "sel_skewed", 4096, 512), (20000, 600, 16, "sel", 2 ** 50, 512)])
+def test_fused_side_passes_match_host_tsvq(hip_ctx, monkeypatch, n, k, p, kind, wmax, wide_min):
+    """BU_TSVQ_FUSED=1: the projection / two-means passes and the partition of a round's large nodes as ONE persistent kernel with device-wide barriers between the phases
+    (tsvq_wide_kernels.hip, k_wide_side_passes) instead of ~35 launches. Off by default -- it measured 2.5x slower than the separate kernels -- but it is the same phase
+    bodies in the same order, so the tree must be the same tree; the heavy-weight case makes every node leave the exact range (records handed back: ok == 2)."""
+    from basis_universal_amd import etc1s
+    F = etc1s.load_frontend_library()
+    rng = np.random.default_rng(n * 3 + k + wide_min)
+    v = _data(kind, 16, n, rng)
+    n = v.shape[0]
+    w = rng.integers(1, wmax + 1, n).astype(np.uint64)
+    if kind == "sel_skewed":
+        w[rng.integers(0, n, 5)] = 3_000_000_000
+    cap = 4 * n + 4 * k + 100
+    a1 = np.zeros(cap, np.uint32); b1 = np.zeros(cap, np.uint32)
+    assert F.bu_host_tsvq(16, v.ctypes.data_as(VP), w.ctypes.data_as(VP), n, k, p, a1.ctypes.data_as(VP), cap, b1.ctypes.data_as(VP), cap) == 1
+    monkeypatch.setenv("BU_TSVQ_WIDE_MIN", str(wide_min))
+    monkeypatch.setenv("BU_TSVQ_FUSED", "1")
+    a = np.zeros(cap, np.uint32); b = np.zeros(cap, np.uint32); st = np.array([0xBACCED, 0, 0], np.uint32)
+    assert F.bu_device_tsvq(hip_ctx.h, 16, v.ctypes.data_as(VP), w.ctypes.data_as(VP), n, k, p, a.ctypes.data_as(VP), cap, b.ctypes.data_as(VP), cap, st.ctypes.data_as(VP)) == 1
+    assert (a1 == a).all() and (b1 == b).all()
