@@ -11,5 +11,5 @@ for f in kernel_stats pmc_fetch_size pmc_write_size pmc_sq pmc_calib; do [ -s gp
 python tools/rocprof_summary.py traffic_csv profiles/${tag}_pmc_fetch_size.csv profiles/${tag}_pmc_write_size.csv $commit > profiles/pmc_traffic.json
 python tools/valu_table.py --calib profiles/valu_calibration.json --pmc profiles/${tag}_pmc_sq.csv --build-isa --json --commit $commit > profiles/valu_busy.json
 python tools/valu_table.py --calib profiles/valu_calibration.json --pmc profiles/${tag}_pmc_sq.csv --build-isa > profiles/${tag}_valu_table.md
-tools/resource_usage.sh > profiles/r03_resource_usage.txt 2>/dev/null
+tools/resource_usage.sh > profiles/${tag}_resource_usage.txt 2>/dev/null
 ls -la profiles | grep "$tag\|pmc_traffic\|valu_busy\|valu_calibration"
