@@ -198,12 +198,19 @@ def test_rccl_group_communicators_need_one_thread_each():
     assert ok == 0 and "already drives rank 0" in err and "thread of its own" in err
     ok, err = views[2].all_reduce_u64(views[2].user, None, 4), L.bu_rccl_last_error().decode()
     assert ok == 0 and "already drives rank 0" in err
-    seen = {}
-    t = threading.Thread(target=lambda: seen.update(r=gather(1)))   # another thread may take rank 1 ...
-    t.start(); t.join()
+    seen, done, hold = {}, threading.Event(), threading.Event()
+
+    def rank1_owner():
+        seen.update(r=gather(1))
+        done.set()
+        hold.wait(30)     # stays alive: a finished thread's id may be handed to the next thread, which would then BE rank 1's owner
+
+    t1 = threading.Thread(target=rank1_owner)                       # another thread may take rank 1 ...
+    t1.start(); done.wait(30)
     assert seen["r"][0] == 0 and "no communicator" in seen["r"][1]
     t = threading.Thread(target=lambda: seen.update(r0=gather(0)))  # ... but not rank 0, which has its thread
     t.start(); t.join()
+    hold.set(); t1.join()
     assert seen["r0"][0] == 0 and "driven by another host thread" in seen["r0"][1]
     for c in comms:
         L.bu_rccl_comm_destroy(C.c_void_p(c))
