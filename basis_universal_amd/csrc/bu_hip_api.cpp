@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <atomic>
+#include <thread>
 #include <mutex>
 #include <numeric>
 #include <string>
@@ -205,6 +206,8 @@ int bu_hip_init(int /*force_serialization*/) {
 // bu_hip_create_context on that device gets it back, warm. At most BU_HIP_PARKED_CONTEXTS (default 16, 0 = off) are kept; bu_hip_deinit releases them.
 static std::mutex g_park_lock;
 static std::vector<bu_hip_context*> g_parked;
+// contexts handed out and not yet given back: with more than one, a host thread that waits for its device round shares the cores with the other contexts' host work
+static std::atomic<int> g_live_contexts{0};
 static void context_release(bu_hip_context* ctx);   // the real teardown
 static size_t park_limit() {
     static const size_t n = [] { const char* e = std::getenv("BU_HIP_PARKED_CONTEXTS"); const long v = e ? std::atol(e) : 16; return (size_t)(v < 0 ? 0 : (v > 64 ? 64 : v)); }();
@@ -228,7 +231,7 @@ bu_hip_context* bu_hip_create_context_on(int device) {
     {
         std::lock_guard<std::mutex> g(g_park_lock);
         for (size_t i = 0; i < g_parked.size(); i++)
-            if (g_parked[i]->device == device) { bu_hip_context* c = g_parked[i]; g_parked.erase(g_parked.begin() + (long)i); return c; }
+            if (g_parked[i]->device == device) { bu_hip_context* c = g_parked[i]; g_parked.erase(g_parked.begin() + (long)i); g_live_contexts.fetch_add(1); return c; }
     }
     bu_hip_context* ctx = new (std::nothrow) bu_hip_context();
     if (!ctx) return nullptr;
@@ -237,6 +240,7 @@ bu_hip_context* bu_hip_create_context_on(int device) {
     ctx->stream = ctx->own_stream;
     hipError_t e = bu::upload_etc1s_tables(device);
     if (e != hipSuccess) { set_error(nullptr, "constant table upload failed: %s", hipGetErrorString(e)); (void)hipStreamDestroy(ctx->own_stream); delete ctx; return nullptr; }
+    g_live_contexts.fetch_add(1);
     return ctx;
 }
 
@@ -262,6 +266,7 @@ void bu_hip_cancel_on_destroy(bu_hip_context* ctx, bu_hip_destroy_fn fn, void* u
 
 void bu_hip_destroy_context(bu_hip_context* ctx) {
     if (!ctx) return;
+    g_live_contexts.fetch_sub(1);
     (void)hipSetDevice(ctx->device);
     for (;;) {  // dependents first (a callback may cancel others; each runs once, outside the lock)
         std::pair<bu_hip_destroy_fn, void*> cb;
@@ -1113,10 +1118,20 @@ int bu_hip_tsvq_split(bu_hip_context* ctx, bu_tsvq* q, const bu_tsvq_node* h_nod
     if (zero_copy) {
         const uint32_t seq = ++q->round_seq ? q->round_seq : ++q->round_seq;   // never 0
         BU_TRY(ctx, bu::launch_tsvq_signal(ctx->stream, reinterpret_cast<uint32_t*>(d_pinned + flag_at), seq));
-        auto last_query = std::chrono::steady_clock::now();
+        // One context in the process: spin (the round trip is what the step waits for). Several (basis_parallel_compress, images in flight): the device is shared, a round
+        // can take milliseconds, and a spinning waiter takes a core from another image's host backend -- after 30 us the core is offered to whoever wants it, after
+        // 2 ms the thread sleeps between looks. BU_TSVQ_POLL=spin|yield overrides.
+        static const int poll_mode = [] { const char* e = std::getenv("BU_TSVQ_POLL"); return !e ? 0 : (e[0] == 's' ? 1 : 2); }();
+        const bool polite = poll_mode == 2 || (poll_mode == 0 && g_live_contexts.load(std::memory_order_relaxed) > 1);
+        const auto t_wait0 = std::chrono::steady_clock::now();
+        auto last_query = t_wait0;
         for (;;) {
             if (*round_flag == seq) break;
             const auto t_now = std::chrono::steady_clock::now();
+            if (polite && t_now - t_wait0 > std::chrono::microseconds(30)) {
+                if (t_now - t_wait0 > std::chrono::milliseconds(2)) std::this_thread::sleep_for(std::chrono::microseconds(50));
+                else std::this_thread::yield();
+            }
             if (t_now - last_query > std::chrono::microseconds(200)) {   // every 200 us: did the stream die, or finish without the flag becoming visible?
                 last_query = t_now;
                 const hipError_t e = hipStreamQuery(ctx->stream);

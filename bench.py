@@ -828,20 +828,28 @@ def end_to_end(helpers, args, img):
         # context per image in flight -- the host backend of image i runs while the GPU serves the frontends of the others
         tool = ref_dir / "process_bench_resident"
         if tool.exists():
-            n_par = max(2, min(16, threads))   # (a sweep on the 256-core GPU box: 8 / 16 / 24 images in flight -> 310 / 390 / 375 Mpix/s)
-            env = dict(os.environ)
-            env.setdefault("BU_HOST_THREADS", "2")   # host threads per frontend / backend: the images are the parallelism here
-            try:
-                r = subprocess.run([str(tool), str(raw), str(args.size), str(args.size), str(args.quality), str(args.level), str(n_par), "1", "3", "-", str(n_par)],
-                                   capture_output=True, text=True, timeout=600, env=env)
-                rec = json.loads(r.stdout.strip().splitlines()[-1])
-                best = min(rec["call_s"])
-                want = base_hash.get("stock_1_thread")   # every task of basis_parallel_compress owns a one-thread pool: the single-threaded codebooks
-                out["resident_parallel"] = {"driver": "basis_parallel_compress", "images_in_flight": n_par, "images_per_call": n_par, "seconds_per_call": round(best, 4),
-                                            "mpix_s": round(n_par * mpix / best, 3), "bytes": rec["bytes"], "host_threads_per_frontend": int(env["BU_HOST_THREADS"]),
-                                            "identical_to": "stock_1_thread", "identical": bool(rec["all_images_identical"]) and (rec["fnv1a64"] == want[0] if want else None)}
-            except Exception as e:
-                out["resident_parallel"] = {"error": str(e)[:200]}
+            n_par = max(2, min(16, threads))   # (a sweep on the GPU box's 16 cores: 12 / 16 / 24 images in flight -> 375 / 405 / 390 Mpix/s before the allocator setting below)
+            want = base_hash.get("stock_1_thread")   # every task of basis_parallel_compress owns a one-thread pool: the single-threaded codebooks
+            # Two runs. (1) As deployed: glibc's malloc backed by transparent huge pages (GLIBC_TUNABLES=glibc.malloc.hugetlb=1, glibc >= 2.35). Sixteen compressors allocate
+            # and release ~300 MB each per image (the reference's image copies and tile arrays above all); with 4 KiB pages that is ~75,000 page faults per image, all
+            # serialised on one address space's lock -- the faults, not the GPU or the backend, were what capped this mode at ~390 Mpix/s (tools/ab_parallel2.sh).
+            # (2) The same with the allocator's defaults.   One host thread per frontend / backend: the images are the parallelism here.
+            for key, tun in (("resident_parallel", "glibc.malloc.hugetlb=1"), ("resident_parallel_default_malloc", None)):
+                env = dict(os.environ)
+                env.setdefault("BU_HOST_THREADS", "1")
+                if tun:
+                    env.setdefault("GLIBC_TUNABLES", tun)
+                try:
+                    r = subprocess.run([str(tool), str(raw), str(args.size), str(args.size), str(args.quality), str(args.level), str(n_par), "1", "4", "-", str(n_par)],
+                                       capture_output=True, text=True, timeout=600, env=env)
+                    rec = json.loads(r.stdout.strip().splitlines()[-1])
+                    best = min(rec["call_s"])
+                    out[key] = {"driver": "basis_parallel_compress", "images_in_flight": n_par, "images_per_call": n_par, "seconds_per_call": round(best, 4),
+                                "mpix_s": round(n_par * mpix / best, 3), "bytes": rec["bytes"], "host_threads_per_frontend": int(env["BU_HOST_THREADS"]),
+                                "glibc_tunables": env.get("GLIBC_TUNABLES"),
+                                "identical_to": "stock_1_thread", "identical": bool(rec["all_images_identical"]) and (rec["fnv1a64"] == want[0] if want else None)}
+                except Exception as e:
+                    out[key] = {"error": str(e)[:200]}
     if "resident" in out and "stock_1_thread" in out and "seconds" in out["resident"] and "seconds" in out["stock_1_thread"]:
         out["resident_vs_stock_1_thread"] = round(out["stock_1_thread"]["seconds"] / out["resident"]["seconds"], 1)
         if "seconds" in out.get("stock_all_cores", {}):
