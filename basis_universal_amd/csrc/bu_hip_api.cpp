@@ -820,7 +820,7 @@ struct bu_tsvq {
     uint8_t* side = nullptr;
     arena nodes, outs;
     bool force_chained = false; // BU_TSVQ_CHAINED=1: never use the exact (integer-reduced) kernel variants (tests compare both)
-    // Nodes with at least wide_min members go through the many-workgroup path (tsvq_wide_kernels.hip; packed rows only).
+    // Nodes with at least wide_min members go through the many-workgroup path (tsvq_wide_kernels.hip for packed rows, tsvq_wide6_kernels.hip for 6-float rows).
     // BU_TSVQ_WIDE_MIN overrides the threshold, BU_TSVQ_WIDE=0 switches the path off (tests compare both).
     uint32_t wide_min = 0;      // 0: off
     uint32_t wide_cov_min = 0;  // batches whose largest node is smaller run the covariance pass chained (BU_TSVQ_WIDE_COV_MIN)
@@ -893,6 +893,25 @@ static bu_tsvq* tsvq_create_common(bu_hip_context* ctx, uint32_t dim, bool packe
     q->nodes.p = bu_hip_malloc(ctx, rec_cap); q->outs.p = bu_hip_malloc(ctx, rec_cap);
     if (!q->rows || !q->w64 || !q->perm[0] || !q->perm[1] || !q->side || !q->nodes.p || !q->outs.p) return fail("allocation");
     q->nodes.cap = q->outs.cap = rec_cap;
+    if (!packed && dim == 6 && !q->force_chained) {
+        // the endpoint tree's large nodes through the many-workgroup path for 6-float rows (tsvq_wide6_kernels.hip). BU_TSVQ_WIDE6_MIN sets the threshold, BU_TSVQ_WIDE6=0
+        // (or BU_TSVQ_WIDE=0) switches the path off (tests compare both).
+        uint32_t wide_min = 8192;   // (6,144 / 10,000 / 14,000 side by side on one box: 1.68 / 1.69 / 1.69 ms for the endpoint tree's splits, 2.15 without the path)
+        if (const char* e = std::getenv("BU_TSVQ_WIDE6_MIN")) { const long v = std::atol(e); if (v >= 512 && v <= (1l << 30)) wide_min = (uint32_t)v; }
+        if (const char* e = std::getenv("BU_TSVQ_WIDE6")) if (std::atoi(e) == 0) wide_min = 0;
+        if (const char* e = std::getenv("BU_TSVQ_WIDE")) if (std::atoi(e) == 0) wide_min = 0;
+        if (wide_min && n >= wide_min && n < (1u << 22)) {
+            q->wide_min = wide_min;
+            q->wide_nodes_cap = n / wide_min + 1;
+            q->wide_blocks_cap = (n + 255) / 256 + q->wide_nodes_cap;
+            q->wide_ws = bu_hip_malloc(ctx, bu::tsvq_wide_workspace_bytes(q->wide_blocks_cap));
+            q->wide_nodes = (bu::tsvq_wide_node*)bu_hip_malloc(ctx, (size_t)q->wide_nodes_cap * sizeof(bu::tsvq_wide_node));
+            q->wide_ctrl_raw = bu_hip_malloc(ctx, (size_t)q->wide_nodes_cap * sizeof(bu::tsvq_wide_ctrl));
+            q->wide_ctrl = static_cast<bu::tsvq_wide_ctrl*>(q->wide_ctrl_raw);
+            q->wide_packed = bu_hip_malloc(ctx, (size_t)n * 32);   // the list-order copies of the per-member addends: 6 n floats + n doubles
+            if (!q->wide_ws || !q->wide_nodes || !q->wide_ctrl || !q->wide_packed) return fail("allocation");
+        }
+    }
     if (packed && !q->force_chained) {
         uint32_t wide_min = 8192;   // (16384 until round 3: the one-workgroup launches of the smaller nodes are the longer of the two concurrent streams)
         if (const char* e = std::getenv("BU_TSVQ_WIDE_MIN")) { const long v = std::atol(e); if (v >= 512 && v <= (1l << 30)) wide_min = (uint32_t)v; }
@@ -931,7 +950,7 @@ static bu_tsvq* tsvq_create_common(bu_hip_context* ctx, uint32_t dim, bool packe
     if (q->reserve_pinned(std::max(sizeof(bu_tsvq_root), sizeof(bu::tsvq_wide_node))) != hipSuccess) return fail("pinned allocation");
     // many-workgroup variant first where it applies, then the exact (integer-reduced) one-workgroup variant; a record flagged
     // pad == 1 left the exact range -> next variant, the chained one last
-    for (int attempt = q->wide_min ? -1 : 0; attempt < 2; attempt++) {
+    for (int attempt = (q->wide_min && packed) ? -1 : 0; attempt < 2; attempt++) {
         const bool exact = packed && attempt == 0 && !q->force_chained;
         if (attempt < 0) {
             bu::tsvq_wide_node wn; std::memset(&wn, 0, sizeof(wn));
@@ -1028,7 +1047,7 @@ int bu_hip_tsvq_split(bu_hip_context* ctx, bu_tsvq* q, const bu_tsvq_node* h_nod
         std::vector<uint32_t> wide;
         for (uint32_t i = 0; i < n_nodes; i++) {
             const uint32_t nb = (h_nodes[i].count + 255) / 256;
-            if (h_nodes[i].count >= q->wide_min && wide.size() < q->wide_nodes_cap && wide_blocks + nb <= q->wide_blocks_cap) { wide.push_back(i); wide_blocks += nb; wide_max_count = std::max(wide_max_count, h_nodes[i].count); wide_max_weight = std::max<uint64_t>(wide_max_weight, h_nodes[i].weight); }
+            if (h_nodes[i].count >= q->wide_min && (q->packed || h_nodes[i].weight < (1ull << 52)) && wide.size() < q->wide_nodes_cap && wide_blocks + nb <= q->wide_blocks_cap) { wide.push_back(i); wide_blocks += nb; wide_max_count = std::max(wide_max_count, h_nodes[i].count); wide_max_weight = std::max<uint64_t>(wide_max_weight, h_nodes[i].weight); }
             else order.push_back(i);
         }
         n_wide = (uint32_t)wide.size();
@@ -1084,16 +1103,20 @@ int bu_hip_tsvq_split(bu_hip_context* ctx, bu_tsvq* q, const bu_tsvq_node* h_nod
     // the side passes of the wide batch as one persistent kernel when this context can have the chip's barrier to itself (see g_fused_lock)
     volatile uint32_t* fused_verdict = reinterpret_cast<volatile uint32_t*>(static_cast<char*>(q->pinned) + flag_at + 64);
     std::unique_lock<std::mutex> fused_turn(g_fused_lock, std::defer_lock);
-    const bool fused = n_wide && zero_copy && q->fused_workgroups && !q->dbg_serial && !g_fused_gave_up.load() && fused_turn.try_lock();
+    const bool fused = n_wide && q->packed && zero_copy && q->fused_workgroups && !q->dbg_serial && !g_fused_gave_up.load() && fused_turn.try_lock();
     if (n_wide) {
-        prof_scope ps(ctx, "tsvq_split_packed16_wide");
+        prof_scope ps(ctx, q->packed ? "tsvq_split_packed16_wide" : "tsvq_split_float6_wide");
         if (fused) { *fused_verdict = 2; __atomic_thread_fence(__ATOMIC_SEQ_CST); }
+        if (!q->packed)
+            BU_TRY(ctx, bu::launch_tsvq_wide6_split(ctx->stream, static_cast<const float*>(q->rows), q->w64, q->n, q->perm[0], q->perm[1], q->side, q->wide_nodes, n_wide, q->wide_ctrl, q->wide_ws,
+                                                    wide_blocks, d_outs, static_cast<float*>(q->wide_packed), reinterpret_cast<double*>(static_cast<char*>(q->wide_packed) + (size_t)q->n * 24)));
+        else
         BU_TRY(ctx, bu::launch_tsvq_wide_split(ctx->stream, static_cast<const uint32_t*>(q->rows), q->w64, q->perm[0], q->perm[1], q->side, q->wide_packed, q->wide_nodes, n_wide, q->wide_ctrl,
                                                q->wide_ws, wide_blocks, d_outs, wide_max_count < q->wide_cov_min,
                                                wide_max_weight * 3ull < (1ull << 24), fused ? q->fused_workgroups : 0u,
                                                fused ? reinterpret_cast<uint32_t*>(d_pinned + flag_at + 64) : nullptr));
     }
-    if (n_wide && q->dbg_stats) {   // development aid: how the last pass's walks went, per wide node
+    if (n_wide && q->dbg_stats && q->packed) {   // development aid: how the last pass's walks went, per wide node
         std::vector<bu::tsvq_wide_ctrl> hc(n_wide);
         if (hipMemcpyAsync(hc.data(), q->wide_ctrl, hc.size() * sizeof(bu::tsvq_wide_ctrl), hipMemcpyDeviceToHost, ctx->stream) == hipSuccess && hipStreamSynchronize(ctx->stream) == hipSuccess)
             for (uint32_t i = 0; i < n_wide; i++) {
@@ -1163,8 +1186,8 @@ int bu_hip_tsvq_split(bu_hip_context* ctx, bu_tsvq* q, const bu_tsvq_node* h_nod
             for (uint32_t i = n_narrow; i < n_nodes; i++) { std::memset(&h_out[order[i]], 0, sizeof(bu_tsvq_split)); h_out[order[i]].ok = 2; }
         }
     }
-    if (exact) { // nodes whose data left the exact range, or that the wide path handed back (ok == 2), go through the one-workgroup kernel: wide ones through its exact variant first
-        for (int attempt = 0; attempt < 2; attempt++) {
+    if (exact || n_wide) { // nodes whose data left the exact range, or that a wide path handed back (ok == 2), go through the one-workgroup kernel: packed wide ones through its exact variant first
+        for (int attempt = exact ? 0 : 1; attempt < 2; attempt++) {
             std::vector<uint32_t> redo;
             for (uint32_t i = 0; i < n_nodes; i++) if (h_out[i].ok == 2) redo.push_back(i);
             if (redo.empty()) break;
@@ -1173,7 +1196,7 @@ int bu_hip_tsvq_split(bu_hip_context* ctx, bu_tsvq* q, const bu_tsvq_node* h_nod
             BU_TRY(ctx, hipMemcpyAsync(q->nodes.p, q->pinned, redo.size() * sizeof(bu_tsvq_node), hipMemcpyHostToDevice, ctx->stream));
             {
                 prof_scope ps(ctx, q->packed ? "tsvq_split_packed16" : "tsvq_split_float6");
-                BU_TRY(ctx, bu::launch_tsvq_split(ctx->stream, (int)q->dim, q->packed, attempt == 0 && n_wide != 0, q->rows, q->w64, q->perm[0], q->perm[1], q->side,
+                BU_TRY(ctx, bu::launch_tsvq_split(ctx->stream, (int)q->dim, q->packed, exact && attempt == 0 && n_wide != 0, q->rows, q->w64, q->perm[0], q->perm[1], q->side,
                                                   static_cast<const bu::tsvq_node_in*>(q->nodes.p), (uint32_t)redo.size(), static_cast<bu::tsvq_split_out*>(q->outs.p)));
             }
             BU_TRY(ctx, hipMemcpyAsync(q->pinned, q->outs.p, redo.size() * sizeof(bu_tsvq_split), hipMemcpyDeviceToHost, ctx->stream));
@@ -1198,7 +1221,7 @@ int bu_hip_tsvq_roots(bu_hip_context* ctx, bu_tsvq* q, const bu_tsvq_node* h_nod
     BU_TRY(ctx, q->reserve_pinned((size_t)n_nodes * std::max(std::max(sizeof(bu_tsvq_node), sizeof(bu_tsvq_root)), sizeof(bu::tsvq_wide_node))));
     std::vector<uint32_t> todo;
     // large spans of packed rows: the many-workgroup root pass (one batch); a record flagged pad == 1 left its exact range -> the one-workgroup kernels below
-    if (q->wide_min) {
+    if (q->wide_min && q->packed) {
         std::vector<uint32_t> wide;
         uint32_t blocks = 0;
         for (uint32_t i = 0; i < n_nodes; i++) {

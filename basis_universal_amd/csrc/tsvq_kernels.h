@@ -63,6 +63,13 @@ hipError_t launch_tsvq_wide_split(hipStream_t st, const uint32_t* d_keys, const 
                                   bool side_chains_exact /* 3 x the heaviest node's weight < 2^24: every projection / two-means chain total is exact, no maps needed */,
                                   uint32_t fused_workgroups /* > 0: the projection / two-means passes + the partition as ONE persistent kernel of that many workgroups (<= CUs) */,
                                   uint32_t* d_fused_verdict /* host-visible word: 1 when the fused kernel ran to its end, 0 when it gave up (nothing of the round may be used) */);
+// the same split for 6-float rows (the endpoint tree's large nodes, tsvq_wide6_kernels.hip): workspace / node / ctrl records as above (no barrier words); d_va: 6 n floats,
+// d_tta: n doubles -- the list-order copies of the per-member addends the covariance pass lays out (launch_tsvq_cov_axis6: chained sums, one workgroup per node)
+hipError_t launch_tsvq_cov_axis6(hipStream_t st, const float* d_rows, const uint64_t* d_w64, const uint32_t* d_perm0, const uint32_t* d_perm1,
+                                 const tsvq_wide_node* d_nodes, uint32_t n_nodes, tsvq_wide_ctrl* d_ctrl, float* d_va, double* d_tta, uint32_t n);
+hipError_t launch_tsvq_wide6_split(hipStream_t st, const float* d_rows, const uint64_t* d_w64, uint32_t n, uint32_t* d_perm0, uint32_t* d_perm1, uint8_t* d_side,
+                                   const tsvq_wide_node* d_nodes, uint32_t n_nodes, tsvq_wide_ctrl* d_ctrl, void* d_ws, uint32_t total_blocks, tsvq_split_out* d_outs,
+                                   float* d_va, double* d_tta);
 size_t tsvq_wide_sync_bytes();   // bytes the fused kernel's barrier words take IN FRONT OF d_ctrl (the ctrl allocation starts that many bytes earlier)
 
 } // namespace bu

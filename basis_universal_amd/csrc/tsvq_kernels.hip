@@ -839,6 +839,48 @@ __global__ __launch_bounds__(TQ_THREADS) void k_tsvq_cov_axis(packed16_rows src,
     else cov_axis_group<2>(lds, s_origin, src, w64, members, nd, ctrl + blockIdx.x, pk);
 }
 
+// The same for the 6-float rows of the endpoint tree (tsvq_wide6_kernels.hip): 21 chains, one workgroup per node. Signed covariance chains of these rows change
+// binade too often for the parity maps to pay (305 us for a 35,000-member root against 135 us of dependent adds), so the covariance pass of that path stays chained.
+// The producers also lay out, in list order, what the passes that follow add per member: va[k][start + pos] = v_k * w (the side chains' addends) and
+// tta[start + pos] = (double)(w * |v|^2) (the ttsum addend) -- those passes then read coalesced arrays instead of gathering rows through the member list.
+constexpr int cov6_chain_x(int c) { int x = 0; while (c >= 6 - x) { c -= 6 - x; x++; } return x; }
+constexpr int cov6_chain_y(int c) { int x = 0; while (c >= 6 - x) { c -= 6 - x; x++; } return x + c; }
+template <int C> struct cov6_chain { static constexpr int x = cov6_chain_x(C), y = cov6_chain_y(C); };
+template <int... J>
+__device__ __forceinline__ void cov6_products(float* f, const float (&d)[6], const float (&wd)[6], std::integer_sequence<int, J...>) {
+    ((f[(size_t)J * TQ_STRIDE] = d[cov6_chain<J>::x] * wd[cov6_chain<J>::y]), ...);
+}
+
+__global__ __launch_bounds__(TQ_THREADS) void k_tsvq_cov_axis6(float_rows<6> src, const uint64_t* __restrict__ w64, const uint32_t* __restrict__ perm0,
+                                                              const uint32_t* __restrict__ perm1, const tsvq_wide_node* __restrict__ nodes,
+                                                              tsvq_wide_ctrl* __restrict__ ctrl, float* __restrict__ va, double* __restrict__ tta, uint32_t n) {
+    constexpr int N = 6, C = 21;
+    extern __shared__ __align__(16) char lds[];
+    __shared__ float s_origin[N];
+    const int tid = threadIdx.x;
+    const tsvq_wide_node nd = nodes[blockIdx.x];
+    const uint32_t* members = (nd.buf ? perm1 : perm0) + nd.start;
+    if (tid < N) s_origin[tid] = nodes[blockIdx.x].origin[tid];
+    __syncthreads();
+    float cv = 0.0f;
+    pipeline_pass<C, 0, 1>(lds, src, w64, members, nd.count,
+        [&](uint32_t pos, const float_rows<6>::payload& p, float* f, double*) {
+            float v[N]; float_rows<6>::decode(p, v);
+            const float w = (float)p.w;
+#pragma unroll
+            for (int k = 0; k < N; k++) va[(size_t)k * n + nd.start + pos] = v[k] * w;
+            tta[nd.start + pos] = (double)(w * dot_seq<N>(v, v));
+            float d[N], wd[N];
+#pragma unroll
+            for (int k = 0; k < N; k++) { d[k] = v[k] - s_origin[k]; wd[k] = w * d[k]; }
+            cov6_products(f, d, wd, std::make_integer_sequence<int, C>{});
+        },
+        [&](const float* f, const double*, uint32_t m) {
+            if (tid < C) chain_add_f32(cv, f + (size_t)tid * TQ_STRIDE, m);
+        });
+    if (tid < C) ctrl[blockIdx.x].sums[tid] = cv;
+}
+
 // -------------------------------------------------------------------------------------------------------------------
 
 static size_t tsvq_lds_bytes(int n) {
@@ -859,6 +901,16 @@ hipError_t launch_tsvq_cov_axis(hipStream_t st, const uint32_t* d_keys, const ui
     hipError_t e = set_lds(k_tsvq_cov_axis, lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_tsvq_cov_axis, dim3(n_nodes, COV_GROUPS), dim3(TQ_THREADS), lds, st, packed16_rows{d_keys}, d_w64, d_perm0, d_perm1, d_nodes, d_ctrl, static_cast<uint2*>(d_packed));
+    return hipGetLastError();
+}
+
+hipError_t launch_tsvq_cov_axis6(hipStream_t st, const float* d_rows, const uint64_t* d_w64, const uint32_t* d_perm0, const uint32_t* d_perm1,
+                                 const tsvq_wide_node* d_nodes, uint32_t n_nodes, tsvq_wide_ctrl* d_ctrl, float* d_va, double* d_tta, uint32_t n) {
+    if (!n_nodes) return hipSuccess;
+    const size_t lds = (size_t)2 * 21 * TQ_STRIDE * sizeof(float);
+    hipError_t e = set_lds(k_tsvq_cov_axis6, lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_tsvq_cov_axis6, dim3(n_nodes), dim3(TQ_THREADS), lds, st, float_rows<6>{d_rows}, d_w64, d_perm0, d_perm1, d_nodes, d_ctrl, d_va, d_tta, n);
     return hipGetLastError();
 }
 

@@ -156,6 +156,64 @@ def test_wide_nodes_match_host_tsvq(hip_ctx, monkeypatch, n, k, p, kind, wmax, w
         assert (a3 == outs["wide"][0]).all() and (b3 == outs["wide"][1]).all()
 
 
+def _endpoint_like(kind, n, rng):
+    """6-float training vectors the way the endpoint side makes them: 5-bit colours expanded to 8 bits, / 255 (frontend.cpp:825-866)"""
+    def expand(c5):
+        return ((c5 << 3) | (c5 >> 2)).astype(np.float32) * np.float32(1.0 / 255.0)
+    if kind == "ep5":       # low / high colours of photographic blocks: correlated, high >= low
+        lo = rng.integers(0, 32, (n, 3)); hi = np.minimum(31, lo + rng.integers(0, 12, (n, 3)))
+        v = np.concatenate([expand(lo), expand(hi)], axis=1)
+    elif kind == "ep5_dark":  # a dark image: most vectors within a few steps of black (tiny w * |v|^2), a few bright ones with heavy weights in between
+        lo = rng.integers(0, 3, (n, 3)); hi = np.minimum(31, lo + rng.integers(0, 3, (n, 3)))
+        bright = rng.random(n) < 0.1
+        lo[bright] = rng.integers(8, 32, (int(bright.sum()), 3)); hi[bright] = np.minimum(31, lo[bright] + rng.integers(0, 8, (int(bright.sum()), 3)))
+        v = np.concatenate([expand(lo), expand(hi)], axis=1)
+    else:
+        v = rng.integers(0, 256, (n, 6)).astype(np.float32) * np.float32(1.0 / 255.0)
+    return np.ascontiguousarray(np.unique(v, axis=0))
+
+
+WIDE6_CASES = [(40000, 2416, 16, "ep", 3, 512), (40000, 2416, 16, "ep", 3, 6144), (3000, 256, 16, "ep", 50, 512), (60000, 2416, 16, "ep5", 4096, 512),
+               (60000, 1200, 16, "ep5_dark", 1 << 20, 512), (20000, 700, 8, "ep5_dark", 1 << 34, 1024), (250000, 3000, 16, "ep", 40, 2048), (400, 64, 16, "line", 5, 512),
+               (20000, 600, 16, "ep", 2 ** 50, 512)]
+
+
+@pytest.mark.parametrize("n,k,p,kind,wmax,wide_min", WIDE6_CASES)
+def test_wide6_nodes_match_host_tsvq(hip_ctx, monkeypatch, n, k, p, kind, wmax, wide_min):
+    """The endpoint tree's large nodes through the many-workgroup path for 6-float rows (tsvq_wide6_kernels.hip): the tree of the sequential sums, member list for
+    member list -- against the host restatement, against the one-workgroup kernels (BU_TSVQ_WIDE6=0) and against the reference where present. The dark cases are built
+    for the double accumulators' block test (tiny addends under large sums, weights up to 2^34: blocks that must be added member by member), the 2^50 weights for the
+    guard that keeps nodes whose weight sums leave the exact range out of the path, the line for the degenerate projection that is handed back."""
+    from basis_universal_amd import etc1s
+    F = etc1s.load_frontend_library()
+    rng = np.random.default_rng(n * 5 + k + wide_min)
+    v = _data("line", 6, n, rng) if kind == "line" else _endpoint_like(kind, n, rng)
+    n = v.shape[0]
+    w = rng.integers(1, wmax + 1, n).astype(np.uint64)
+    if kind == "ep5_dark":
+        w[rng.random(n) < 0.7] = 1   # most weights small, a few enormous
+    cap = 4 * n + 4 * k + 100
+    outs = {}
+    for name, env in (("wide6", {"BU_TSVQ_WIDE6_MIN": str(wide_min)}), ("narrow", {"BU_TSVQ_WIDE6": "0"})):
+        for key in ("BU_TSVQ_WIDE6_MIN", "BU_TSVQ_WIDE6"):
+            monkeypatch.delenv(key, raising=False)
+        for key, val in env.items():
+            monkeypatch.setenv(key, val)
+        a = np.zeros(cap, np.uint32); b = np.zeros(cap, np.uint32); st = np.zeros(3, np.uint32)
+        assert F.bu_device_tsvq(hip_ctx.h, 6, v.ctypes.data_as(VP), w.ctypes.data_as(VP), n, k, p, a.ctypes.data_as(VP), cap, b.ctypes.data_as(VP), cap,
+                                st.ctypes.data_as(VP)) == 1
+        outs[name] = (a, b)
+    a1 = np.zeros(cap, np.uint32); b1 = np.zeros(cap, np.uint32)
+    assert F.bu_host_tsvq(6, v.ctypes.data_as(VP), w.ctypes.data_as(VP), n, k, p, a1.ctypes.data_as(VP), cap, b1.ctypes.data_as(VP), cap) == 1
+    for name, (a, b) in outs.items():
+        assert (a1 == a).all(), f"{name}: codebook differs from the host tree (leaves host {a1[0]} device {a[0]})"
+        assert (b1 == b).all(), f"{name}: parent codebook differs"
+    if have_ref() and n <= 100000:
+        a3 = np.zeros(cap, np.uint32); b3 = np.zeros(cap, np.uint32)
+        assert ref().ref_tsvq(6, ptr(v, f32p), ptr(w, u64p), n, k, p, 0, ptr(a3, u32p), cap, ptr(b3, u32p), cap) == 1
+        assert (a3 == outs["wide6"][0]).all() and (b3 == outs["wide6"][1]).all()
+
+
 # The reference's multi-threaded configuration (generate_hierarchical_codebook_threaded_internal, enc.h:2086-2215; the tool's default from 262,144
 # distinct vectors up): a T-leaf tree, then T independent trees over the leaves' members whose device rounds are shared (tsvq_device.h run_trees).
 # min_unique_for_threads = 1 takes small inputs down the partitioned path; the 300k case goes through the reference's own gate.
