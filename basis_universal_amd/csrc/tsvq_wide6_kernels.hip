@@ -25,6 +25,7 @@
 #include "tsvq_kernels.h"
 #include "tsvq_common.h"
 #include "fsum_scan.h"
+#include "tt_exact.h"
 
 namespace bu {
 
@@ -35,8 +36,6 @@ namespace {
 constexpr int D6 = 6;
 enum { W6_COV = 1, W6_PROJ = 2, W6_DIST = 3 };
 constexpr int NCH6 = 12;   // side passes: chain = side * 6 + component
-
-constexpr int L_FREE = 1 << 20;    // "no low bit to lose": exponent of the lowest set bit of an empty / zero sum
 
 struct member6 { float v[D6]; float wf; uint64_t w; bool valid; };
 __device__ __forceinline__ member6 fetch6(const float* __restrict__ rows, const uint64_t* __restrict__ w64, const uint32_t* __restrict__ members, uint32_t pos, uint32_t count) {
@@ -117,11 +116,8 @@ __global__ __launch_bounds__(WB) void k6_sums(const float* __restrict__ rows, co
         if (MODE == W6_DIST) {
             const float af = tt_addend(m);
             const uint32_t bits = __float_as_uint(af);
-            if ((bits << 1) != 0) {
-                const uint32_t e = (bits >> 23) & 0xffu;
-                tt[right ? 1 : 0] = (double)af;
-                em[right ? 1 : 0] = (e == 0xffu || (bits >> 31)) ? 0u : e;   // denormal (0) / non-finite / negative: never "safe"
-            }
+            tt[right ? 1 : 0] = (double)af;
+            em[right ? 1 : 0] = tt::addend_exp(bits);
         }
     }
     __syncthreads();
@@ -320,13 +316,8 @@ __device__ __forceinline__ void tt_walk(const double* __restrict__ tta, const ui
     double* s_a = sh.a; uint8_t* s_sd = sh.sd; double (*s_bs)[64] = sh.bs; uint64_t* s_em = sh.em;
     const int mine = lane == 1 ? 1 : 0;
     double s = 0.0;
-    int L = L_FREE;       // exponent (power of two) of the lowest bit that may be set in s
+    int L = tt::L_FREE;   // exponent (power of two) of the lowest bit that may be set in s
     bool bad = false;
-    auto low_bit = [](double x) -> int {   // exponent of the lowest set bit of a positive normal double
-        const uint64_t b = (uint64_t)__double_as_longlong(x);
-        const uint64_t sig = (b & 0xfffffffffffffull) | (1ull << 52);
-        return (int)((b >> 52) & 0x7ffu) - 1023 - 52 + (__ffsll((long long)sig) - 1);
-    };
     for (uint32_t b0 = 0; b0 < nd.n_blocks; b0 += 64) {
         // the records of the next 64 blocks, one per lane, into LDS: the loop below is a chain through s, and a trip to memory per block (0.3 us) was all of its time
         {
@@ -339,16 +330,10 @@ __device__ __forceinline__ void tt_walk(const double* __restrict__ tta, const ui
         const uint32_t lim = min(64u, nd.n_blocks - b0);
         for (uint32_t i = 0; i < lim; i++) {
             const uint32_t b = b0 + i;
-            const double bs = s_bs[mine][i];
-            const uint32_t emf = (uint32_t)(s_em[i] >> (mine ? 32 : 0));
-            const int Lb = emf == 0xffffu ? L_FREE : (emf == 0u ? -L_FREE : (int)emf - 150);
-            // Every partial sum of the block is a multiple of 2^min(L, Lb) and at most the sum after the block; with E the exponent of an UPPER BOUND u of that sum (the block sum
-            // this reads is a tree of double adds that may have rounded when the test is about to fail: a few parts in 2^53, covered by the factor) all of them fit into 53
-            // bits, i.e. every add of the block is exact in any order, iff min(L, Lb) >= E - 52.
-            const double s_end = s + bs, u = s_end * 1.0000000000009095;   // 1 + 2^-40
-            const uint32_t ef = (uint32_t)((uint64_t)__double_as_longlong(u) >> 52) & 0x7ffu;
-            const bool safe = emf == 0xffffu || (ef != 0x7ffu && ef != 0u && min(L, Lb) >= (int)ef - 1023 - 52);
-            if (__ballot(lane < 2 && !safe) == 0ull) { s = s_end; L = min(L, Lb); continue; }
+            const uint32_t summary = (uint32_t)(s_em[i] >> (mine ? 32 : 0));
+            double s_end;
+            const bool safe = tt::block_is_exact(s, s_bs[mine][i], L, summary, &s_end);   // tt_exact.h
+            if (__ballot(lane < 2 && !safe) == 0ull) { s = s_end; L = min(L, tt::block_low(summary)); continue; }
             // member by member, in list order, with the double adds the reference does (the addends were laid out by the covariance pass)
 #pragma unroll
             for (int r = 0; r < 4; r++) {
@@ -360,10 +345,8 @@ __device__ __forceinline__ void tt_walk(const double* __restrict__ tta, const ui
             __builtin_amdgcn_wave_barrier();
             for (int j = 0; j < WB; j++) s = s + ((int)s_sd[j] == mine ? s_a[j] : 0.0);   // + 0.0 leaves a non-negative sum as it is
             __builtin_amdgcn_wave_barrier();
-            const uint32_t sf = (uint32_t)((uint64_t)__double_as_longlong(s) >> 52) & 0x7ffu;
-            if (sf == 0x7ffu) bad = true;
-            L = (s == 0.0) ? L_FREE : (sf == 0u ? -L_FREE : low_bit(s));
-        
+            if (((uint32_t)((uint64_t)__double_as_longlong(s) >> 52) & 0x7ffu) == 0x7ffu) bad = true;
+            L = tt::low_bit(s);
         }
         __builtin_amdgcn_wave_barrier();
     }

@@ -480,26 +480,27 @@ def fsum_host():
     return _fsum_host
 
 
-_fsum64_host = None
+_tt_exact_host = None
 
 
-def fsum64_host():
-    """csrc/fsum_scan64.h (the order-preserving DOUBLE sum of float addends, not yet used by a kernel) compiled for the host: tests/native/fsum64_host.cpp."""
-    global _fsum64_host
-    if _fsum64_host is None:
+def tt_exact_host():
+    """csrc/tt_exact.h (when a block of the reference's double accumulators can be taken in one step: tsvq_wide6_kernels.hip, tt_walk) compiled for the host:
+    tests/native/tt_exact_host.cpp."""
+    global _tt_exact_host
+    if _tt_exact_host is None:
         d = ROOT / "tests" / "native"
-        so, srcs = d / "libfsum64_host.so", [d / "fsum64_host.cpp", ROOT / "basis_universal_amd" / "csrc" / "fsum_scan64.h"]
+        so, srcs = d / "libtt_exact_host.so", [d / "tt_exact_host.cpp", ROOT / "basis_universal_amd" / "csrc" / "tt_exact.h"]
         if not so.exists() or so.stat().st_mtime < max(s.stat().st_mtime for s in srcs):
             subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-o", str(so), str(srcs[0])])
         L = C.CDLL(str(so))
-        L.fsum64_sequential.restype = C.c_double
-        L.fsum64_sequential.argtypes = [f32p, C.c_uint64, C.c_double]
-        L.fsum64_blocked.restype = C.c_double
-        L.fsum64_blocked.argtypes = [f32p, C.c_uint64, C.c_double, C.c_uint32, u64p]
-        L.fsum64_compose_check.restype = C.c_int
-        L.fsum64_compose_check.argtypes = [f32p, C.c_uint64, C.c_int, C.c_int, C.c_uint32]
-        _fsum64_host = L
-    return _fsum64_host
+        L.tt_sequential.restype = C.c_double
+        L.tt_sequential.argtypes = [f32p, C.c_uint64]
+        L.tt_blocked.restype = C.c_double
+        L.tt_blocked.argtypes = [f32p, C.c_uint64, C.c_uint32, u64p]
+        L.tt_low_bit.restype = C.c_int
+        L.tt_low_bit.argtypes = [C.c_double]
+        _tt_exact_host = L
+    return _tt_exact_host
 
 
 def host_encode_uastc(blocks, flags):
