@@ -918,7 +918,7 @@ static bu_tsvq* tsvq_create_common(bu_hip_context* ctx, uint32_t dim, bool packe
         if (const char* e = std::getenv("BU_TSVQ_WIDE")) if (std::atoi(e) == 0) wide_min = 0;
         if (wide_min && n >= wide_min && n < (1u << 22)) {   // above 2^22 members the binade prediction loses its margin; the chained kernel takes those
             q->wide_min = wide_min;
-            q->wide_cov_min = 98304;
+            q->wide_cov_min = 131072;   // (98,304 until the end of round 4; side by side on one box: equal at 4096^2, 8192^2 q255 842 -> 857 Mpix/s)
             if (const char* e = std::getenv("BU_TSVQ_WIDE_COV_MIN")) { const long v = std::atol(e); if (v >= 0 && v <= (1l << 30)) q->wide_cov_min = (uint32_t)v; }
             q->wide_nodes_cap = n / wide_min + 1;
             q->wide_blocks_cap = (n + 255) / 256 + q->wide_nodes_cap;
@@ -950,14 +950,19 @@ static bu_tsvq* tsvq_create_common(bu_hip_context* ctx, uint32_t dim, bool packe
     if (q->reserve_pinned(std::max(sizeof(bu_tsvq_root), sizeof(bu::tsvq_wide_node))) != hipSuccess) return fail("pinned allocation");
     // many-workgroup variant first where it applies, then the exact (integer-reduced) one-workgroup variant; a record flagged
     // pad == 1 left the exact range -> next variant, the chained one last
-    for (int attempt = (q->wide_min && packed) ? -1 : 0; attempt < 2; attempt++) {
+    for (int attempt = q->wide_min ? -1 : 0; attempt < 2; attempt++) {
         const bool exact = packed && attempt == 0 && !q->force_chained;
         if (attempt < 0) {
             bu::tsvq_wide_node wn; std::memset(&wn, 0, sizeof(wn));
             wn.count = n; wn.n_blocks = (n + 255) / 256;
             std::memcpy(q->pinned, &wn, sizeof(wn));
             if (hipMemcpyAsync(q->wide_nodes, q->pinned, sizeof(wn), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return fail("root upload");
-            prof_scope ps(ctx, "tsvq_root_packed16");
+            prof_scope ps(ctx, packed ? "tsvq_root_packed16" : "tsvq_root_float6");
+            if (!packed) {
+                if (bu::launch_tsvq_wide6_root(ctx->stream, static_cast<const float*>(q->rows), q->w64, n, q->perm[0], q->side, q->wide_nodes, q->wide_ctrl, q->wide_ws, wn.n_blocks,
+                                               static_cast<bu::tsvq_root_out*>(q->outs.p), static_cast<float*>(q->wide_packed),
+                                               reinterpret_cast<double*>(static_cast<char*>(q->wide_packed) + (size_t)n * 24)) != hipSuccess) return fail("wide root launch");
+            } else
             if (bu::launch_tsvq_wide_root(ctx->stream, static_cast<const uint32_t*>(q->rows), q->w64, n, q->perm[0], q->wide_nodes, q->wide_ctrl, q->wide_ws, wn.n_blocks,
                                           static_cast<bu::tsvq_root_out*>(q->outs.p)) != hipSuccess) return fail("wide root launch");
         } else {

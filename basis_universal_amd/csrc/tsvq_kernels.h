@@ -67,6 +67,9 @@ hipError_t launch_tsvq_wide_split(hipStream_t st, const uint32_t* d_keys, const 
 // d_tta: n doubles -- the list-order copies of the per-member addends the covariance pass lays out (launch_tsvq_cov_axis6: chained sums, one workgroup per node)
 hipError_t launch_tsvq_cov_axis6(hipStream_t st, const float* d_rows, const uint64_t* d_w64, const uint32_t* d_perm0, const uint32_t* d_perm1,
                                  const tsvq_wide_node* d_nodes, uint32_t n_nodes, tsvq_wide_ctrl* d_ctrl, float* d_va, double* d_tta, uint32_t n);
+hipError_t launch_tsvq_wide6_root(hipStream_t st, const float* d_rows, const uint64_t* d_w64, uint32_t n, uint32_t* d_perm0 /* out: 0..n-1 */, uint8_t* d_side,
+                                  const tsvq_wide_node* d_nodes /* one node: all n vectors */, tsvq_wide_ctrl* d_ctrl, void* d_ws, uint32_t total_blocks, tsvq_root_out* d_out,
+                                  float* d_va, double* d_tta);
 hipError_t launch_tsvq_wide6_split(hipStream_t st, const float* d_rows, const uint64_t* d_w64, uint32_t n, uint32_t* d_perm0, uint32_t* d_perm1, uint8_t* d_side,
                                    const tsvq_wide_node* d_nodes, uint32_t n_nodes, tsvq_wide_ctrl* d_ctrl, void* d_ws, uint32_t total_blocks, tsvq_split_out* d_outs,
                                    float* d_va, double* d_tta);

@@ -34,14 +34,15 @@ namespace {
 #include "tsvq_wide_common.h"   // (inside the unnamed namespace: internal linkage in each of the two translation units that use it)
 
 constexpr int D6 = 6;
-enum { W6_COV = 1, W6_PROJ = 2, W6_DIST = 3 };
+enum { W6_ROOT = 0, W6_COV = 1, W6_PROJ = 2, W6_DIST = 3 };   // W6_ROOT: prepare_root of the whole training set (every vector "left", list order = index order)
 constexpr int NCH6 = 12;   // side passes: chain = side * 6 + component
 
 struct member6 { float v[D6]; float wf; uint64_t w; bool valid; };
 __device__ __forceinline__ member6 fetch6(const float* __restrict__ rows, const uint64_t* __restrict__ w64, const uint32_t* __restrict__ members, uint32_t pos, uint32_t count) {
     member6 m;
     m.valid = pos < count;
-    const uint32_t mi = members[m.valid ? pos : count - 1];
+    const uint32_t p = m.valid ? pos : count - 1;
+    const uint32_t mi = members ? members[p] : p;
     const float* r = rows + (size_t)mi * D6;
 #pragma unroll
     for (int k = 0; k < D6; k++) m.v[k] = r[k];
@@ -67,7 +68,8 @@ struct tiles6 {
 // ttsum block sums; projection pass: the integer sums of (float)w left / right, 5 the smallest addend's exponent field left | right << 32 (0xffff: no non-zero addend; 0: a denormal or non-finite one)
 template <int MODE>
 __global__ __launch_bounds__(WB) void k6_sums(const float* __restrict__ rows, const uint64_t* __restrict__ w64, const uint32_t* perm0, const uint32_t* perm1, uint8_t* side,
-                                              const tsvq_wide_node* __restrict__ nodes, uint32_t n_nodes, const tsvq_wide_ctrl* ctrl, void* ws_base, uint32_t tb) {
+                                              const tsvq_wide_node* __restrict__ nodes, uint32_t n_nodes, const tsvq_wide_ctrl* ctrl, void* ws_base, uint32_t tb,
+                                              float* va_out, double* tta_out, uint32_t n) {
     constexpr int NCH = NCH6;
     __shared__ tiles6 T;
     __shared__ float s_origin[D6], s_axis[D6], s_lc[D6], s_rc[D6];
@@ -85,11 +87,18 @@ __global__ __launch_bounds__(WB) void k6_sums(const float* __restrict__ rows, co
     if (tid < D6) { s_origin[tid] = nd.origin[tid]; s_axis[tid] = ct.axis[tid]; s_lc[tid] = ct.l_c[tid]; s_rc[tid] = ct.r_c[tid]; }
     __syncthreads();
     const uint32_t pos = (blk - nd.first_block) * WB + (uint32_t)tid;
-    const uint32_t* members = (nd.buf ? perm1 : perm0) + nd.start;
+    const uint32_t* members = MODE == W6_ROOT ? nullptr : (nd.buf ? perm1 : perm0) + nd.start;
     const member6 m = fetch6(rows, w64, members, pos, nd.count);
     // which child (enc.h:1870-1871 projection sign; enc.h:1991 distances in double, difference form)
     bool right;
-    if (MODE == W6_DIST) {
+    if (MODE == W6_ROOT) {   // what the covariance pass lays out for the splits, for the root's own passes
+        right = false;
+        if (m.valid) {
+#pragma unroll
+            for (int k = 0; k < D6; k++) va_out[(size_t)k * n + pos] = m.v[k] * m.wf;
+            tta_out[pos] = (double)tt_addend(m);
+        }
+    } else if (MODE == W6_DIST) {
         double dl = 0, dr = 0;
 #pragma unroll
         for (int k = 0; k < D6; k++) {
@@ -113,7 +122,7 @@ __global__ __launch_bounds__(WB) void k6_sums(const float* __restrict__ rows, co
     if (m.valid) {
         if (right) red[1] = m.w; else { red[0] = m.w; red[2] = 1; }
         if (MODE == W6_PROJ) red[right ? 4 : 3] = (uint64_t)m.wf;   // an integer-valued float below 2^64: exact
-        if (MODE == W6_DIST) {
+        if (MODE == W6_DIST || MODE == W6_ROOT) {
             const float af = tt_addend(m);
             const uint32_t bits = __float_as_uint(af);
             tt[right ? 1 : 0] = (double)af;
@@ -135,7 +144,7 @@ __global__ __launch_bounds__(WB) void k6_sums(const float* __restrict__ rows, co
             const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)red[i], o, 64), hi = (uint32_t)__shfl_xor((int)(uint32_t)(red[i] >> 32), o, 64);
             red[i] += ((uint64_t)hi << 32) | lo;
         }
-        if (MODE == W6_DIST) {
+        if (MODE == W6_DIST || MODE == W6_ROOT) {
 #pragma unroll
             for (int i = 0; i < 2; i++) {
                 tt[i] += shfl_xor_f64(tt[i], o);
@@ -155,12 +164,12 @@ __global__ __launch_bounds__(WB) void k6_sums(const float* __restrict__ rows, co
         ws.bzero[ws.at(tid, blk)] = s == 0.0 ? 1 : 0;   // addends are >= 0 here
     }
     if (tid >= 64 && tid < (MODE == W6_PROJ ? 69 : 67)) ws.bex[(size_t)blk * 8 + (tid - 64)] = s_red[0][tid - 64] + s_red[1][tid - 64] + s_red[2][tid - 64] + s_red[3][tid - 64];
-    if (MODE == W6_DIST && tid >= 128 && tid < 130) {
+    if ((MODE == W6_DIST || MODE == W6_ROOT) && tid >= 128 && tid < 130) {
         const int i = tid - 128;
         const double s = (s_tt[0][i] + s_tt[1][i]) + (s_tt[2][i] + s_tt[3][i]);
         ws.bex[(size_t)blk * 8 + 3 + i] = (uint64_t)__double_as_longlong(s);
     }
-    if (MODE == W6_DIST && tid == 192) {
+    if ((MODE == W6_DIST || MODE == W6_ROOT) && tid == 192) {
         const uint32_t e0 = min(min(s_em[0][0], s_em[1][0]), min(s_em[2][0], s_em[3][0])), e1 = min(min(s_em[0][1], s_em[1][1]), min(s_em[2][1], s_em[3][1]));
         ws.bex[(size_t)blk * 8 + 5] = (uint64_t)e0 | ((uint64_t)e1 << 32);
     }
@@ -510,7 +519,7 @@ __global__ __launch_bounds__(64) void k6_walk(const float* __restrict__ va, cons
 // ------------------------------------------------------------------------------------------------------------ finish
 // the serial tail of a pass; one wave per node
 template <int MODE>
-__global__ __launch_bounds__(64) void k6_finish(const tsvq_wide_node* __restrict__ nodes, tsvq_wide_ctrl* ctrl) {
+__global__ __launch_bounds__(64) void k6_finish(const tsvq_wide_node* __restrict__ nodes, tsvq_wide_ctrl* ctrl, tsvq_root_out* root_out) {
     const uint32_t ni = blockIdx.x;
     const int lane = (int)threadIdx.x;
     tsvq_wide_ctrl& c = ctrl[ni];
@@ -531,6 +540,21 @@ __global__ __launch_bounds__(64) void k6_finish(const tsvq_wide_node* __restrict
         return;
     }
     if (lane != 0) return;
+    if (MODE == W6_ROOT) {   // prepare_root (enc.h:1708-1735)
+        if (c.ex_bad) { root_out->pad = 1; c.done = 2; return; }
+        float o[N];
+        for (int k = 0; k < N; k++) o[k] = c.sums[k];
+        const float wfl = (float)c.l_w;
+        const float q = dot_seq<N>(o, o) / wfl;
+        root_out->var = (float)(c.dsum[0] - (double)q);
+        const float inv = 1.0f / wfl;
+        for (int k = 0; k < N; k++) root_out->origin[k] = o[k] * inv;
+        for (int k = N; k < 16; k++) root_out->origin[k] = 0.0f;
+        root_out->weight = c.l_w;
+        root_out->pad = 0;
+        c.done = 1;
+        return;
+    }
     if (c.ex_bad) { c.done = 2; return; }
     if (MODE == W6_PROJ) {   // prep_split (enc.h:1887-1891); the degenerate projection (:1893-1957) is left to the one-workgroup kernel
         const double lw = c.dsum[0], rw = c.dsum[1];   // sums of the integer-valued floats (float)w, below 2^53: what the reference's double accumulators hold
@@ -569,12 +593,18 @@ __global__ __launch_bounds__(WB) void k6_partition(uint32_t* perm0, uint32_t* pe
 
 template <int MODE>
 void launch_pass6(hipStream_t st, const float* rows, const uint64_t* w64, uint32_t n, uint32_t* perm0, uint32_t* perm1, uint8_t* side, const tsvq_wide_node* nodes, uint32_t n_nodes,
-                  uint32_t tb, tsvq_wide_ctrl* ctrl, void* ws, const float* va, const double* tta) {
-    hipLaunchKernelGGL((k6_sums<MODE>), dim3(tb), dim3(WB), 0, st, rows, w64, perm0, perm1, side, nodes, n_nodes, ctrl, ws, tb);
+                  uint32_t tb, tsvq_wide_ctrl* ctrl, void* ws, float* va, double* tta, tsvq_root_out* root_out = nullptr) {
+    constexpr bool TT = MODE == W6_DIST || MODE == W6_ROOT;
+    hipLaunchKernelGGL((k6_sums<MODE>), dim3(tb), dim3(WB), 0, st, rows, w64, perm0, perm1, side, nodes, n_nodes, ctrl, ws, tb, va, tta, n);
     hipLaunchKernelGGL((k6_scan<MODE>), dim3(n_nodes, (NCH6 + 3) / 4 + 1), dim3(256), 0, st, nodes, ctrl, ws, tb);
     hipLaunchKernelGGL(k6_stretches, dim3(tb), dim3(WB), 0, st, va, n, side, nodes, n_nodes, ctrl, ws, tb);
-    hipLaunchKernelGGL((k6_walk<MODE == W6_DIST>), dim3(n_nodes * (NCH6 + (MODE == W6_DIST ? 1 : 0))), dim3(64), 0, st, va, tta, n, side, nodes, n_nodes, ctrl, ws, tb);
-    hipLaunchKernelGGL((k6_finish<MODE>), dim3(n_nodes), dim3(64), 0, st, nodes, ctrl);
+    hipLaunchKernelGGL((k6_walk<TT>), dim3(n_nodes * (NCH6 + (TT ? 1 : 0))), dim3(64), 0, st, va, tta, n, side, nodes, n_nodes, ctrl, ws, tb);
+    hipLaunchKernelGGL((k6_finish<MODE>), dim3(n_nodes), dim3(64), 0, st, nodes, ctrl, root_out);
+}
+
+__global__ __launch_bounds__(256) void k6_iota(uint32_t n, uint32_t* __restrict__ perm0) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) perm0[i] = i;
 }
 
 } // namespace
@@ -587,10 +617,20 @@ hipError_t launch_tsvq_wide6_split(hipStream_t st, const float* d_rows, const ui
     if (e != hipSuccess) return e;
     // covariance: chained sums, one workgroup per node (+ the list-order copies of the per-member addends), then the principal axis
     if ((e = launch_tsvq_cov_axis6(st, d_rows, d_w64, d_perm0, d_perm1, d_nodes, n_nodes, d_ctrl, d_va, d_tta, n)) != hipSuccess) return e;
-    hipLaunchKernelGGL((k6_finish<W6_COV>), dim3(n_nodes), dim3(64), 0, st, d_nodes, d_ctrl);
+    hipLaunchKernelGGL((k6_finish<W6_COV>), dim3(n_nodes), dim3(64), 0, st, d_nodes, d_ctrl, static_cast<tsvq_root_out*>(nullptr));
     launch_pass6<W6_PROJ>(st, d_rows, d_w64, n, d_perm0, d_perm1, d_side, d_nodes, n_nodes, total_blocks, d_ctrl, d_ws, d_va, d_tta);
     for (int it = 0; it < 6; it++) launch_pass6<W6_DIST>(st, d_rows, d_w64, n, d_perm0, d_perm1, d_side, d_nodes, n_nodes, total_blocks, d_ctrl, d_ws, d_va, d_tta);
     hipLaunchKernelGGL(k6_partition, dim3(total_blocks), dim3(WB), 0, st, d_perm0, d_perm1, d_side, d_nodes, n_nodes, d_ctrl, d_ws, total_blocks, d_outs);
+    return hipGetLastError();
+}
+
+// prepare_root of the whole training set (one node: all n vectors, in index order) through the same passes; d_perm0 becomes 0..n-1
+hipError_t launch_tsvq_wide6_root(hipStream_t st, const float* d_rows, const uint64_t* d_w64, uint32_t n, uint32_t* d_perm0, uint8_t* d_side, const tsvq_wide_node* d_nodes,
+                                  tsvq_wide_ctrl* d_ctrl, void* d_ws, uint32_t total_blocks, tsvq_root_out* d_out, float* d_va, double* d_tta) {
+    hipError_t e = hipMemsetAsync(d_ctrl, 0, sizeof(tsvq_wide_ctrl), st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k6_iota, dim3((n + 255) / 256), dim3(256), 0, st, n, d_perm0);
+    launch_pass6<W6_ROOT>(st, d_rows, d_w64, n, d_perm0, nullptr, d_side, d_nodes, 1, total_blocks, d_ctrl, d_ws, d_va, d_tta, d_out);
     return hipGetLastError();
 }
 
