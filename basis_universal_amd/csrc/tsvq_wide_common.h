@@ -14,7 +14,8 @@ struct wide_ws {                   // views into the workspace; per-(chain, bloc
     uint16_t* epred;               // [NCH_MAX][TB]  predicted exponent | sign << 8 | single << 9; EP_NONE / EP_ZERO
     uint32_t* lpre;                // [TB]           left members before the block (within its node)
     int32_t* summ;                 // [NCH_MAX][TB][2][6]
-    uint32_t tb;
+    int32_t* win;                  // [NCH_MAX][TW][16]  the maps of 64 consecutive blocks of a node composed into one (k_wide_windows): meta, candidate 0, candidate 1
+    uint32_t tb, tw;               // tw = tb + tb / 64 + 1 >= the windows of any batch of tb blocks (window index: first_block / 64 + node index + window of the node)
     __host__ __device__ size_t at(int c, uint32_t blk) const { return (size_t)c * tb + blk; }
 };
 constexpr uint16_t EP_NONE = 0, EP_ZERO = 0xffff, EP_SINGLE = 0x200;
@@ -29,7 +30,9 @@ __host__ __device__ inline wide_ws carve(void* base, uint32_t tb) {
     w.summ = reinterpret_cast<int32_t*>(p);  p += align256((size_t)tb * NCH_MAX * 2 * 6 * sizeof(int32_t));
     w.lpre = reinterpret_cast<uint32_t*>(p); p += align256((size_t)tb * sizeof(uint32_t));
     w.epred = reinterpret_cast<uint16_t*>(p); p += align256((size_t)tb * NCH_MAX * sizeof(uint16_t));
-    w.bzero = reinterpret_cast<uint8_t*>(p);
+    w.bzero = reinterpret_cast<uint8_t*>(p); p += align256((size_t)tb * NCH_MAX);
+    w.win = reinterpret_cast<int32_t*>(p);
+    w.tw = tb + tb / 64 + 1;
     return w;
 }
 

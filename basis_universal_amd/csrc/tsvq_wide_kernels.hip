@@ -23,6 +23,7 @@
 // Selector vectors only (packed rows): that is where the large nodes are (the endpoint side has <= 2^18 distinct vectors).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <cstdlib>
 #include "tsvq_kernels.h"
 #include "tsvq_common.h"
 #include "fsum_scan.h"
@@ -412,13 +413,63 @@ __global__ __launch_bounds__(ST_THREADS) void k_wide_stretches(const uint32_t* _
     wide_stretches_body<MODE>(keys, w64, pk, side, nodes, n_nodes, ctrl, ws_base, tb, blockIdx.x);
 }
 
+// ------------------------------------------------------------------------------------------------------------ k_wide_windows
+// The walk below is serial in the running sum, but what it does per window of 64 blocks -- compose the blocks' maps -- is not: here every (chain, window) gets
+// a wave that composes the window's 64 maps for the two states the walk can arrive in (the binade the scan predicted for the window's first non-zero block, and the one
+// above), so that the walk takes a window it finds in one of them with ONE applies() test. A window whose blocks do not all have a map for the state (a binade change
+// predicted inside it, a block the stretches kernel gave up on) is recorded as never applying and walked block by block as before.
+// Record (16 dwords): [0] predicted exponent | sign << 8 | all-zero << 9, [2..7] the map for that exponent (d0 d1 lo0 lo1 hi0 hi1), [8..13] for the exponent above.
+__device__ __forceinline__ uint32_t window_index(const tsvq_wide_node& nd, uint32_t ni, uint32_t w) { return nd.first_block / 64 + ni + w; }
+
+template <int MODE>
+__global__ __launch_bounds__(64) void k_wide_windows(const tsvq_wide_node* __restrict__ nodes, uint32_t n_nodes, const tsvq_wide_ctrl* ctrl, void* ws_base, uint32_t tb) {
+    constexpr int NCH = mode_traits<MODE>::NCH;
+    const wide_ws ws = carve(ws_base, tb);
+    const int lane = (int)threadIdx.x;
+    const int c = (int)(blockIdx.x % NCH);
+    const uint32_t g = blockIdx.x / NCH;   // window index over the batch: first_block / 64 + node + window of the node (strictly increasing with the node)
+    uint32_t lo = 0, hi = n_nodes;         // last node whose first window index <= g
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (window_index(nodes[mid], mid, 0) <= g) lo = mid; else hi = mid; }
+    const uint32_t ni = lo;
+    const tsvq_wide_node& nd = nodes[ni];
+    const uint32_t w = g - window_index(nd, ni, 0);
+    if (w * 64 >= nd.n_blocks || ctrl[ni].done || (MODE != WM_COV && ctrl[ni].exact[c])) return;
+    walk_window cur;
+    load_window(ws, nd.first_block, nd.n_blocks, w * 64, lane, c, cur);
+    const uint64_t nonzero = __ballot(cur.ep != EP_ZERO);
+    int32_t* rec = ws.win + ((size_t)c * ws.tw + g) * 16;
+    if (nonzero == 0ull) { if (lane == 0) rec[0] = 1 << 9; return; }
+    const int first = __ffsll((long long)nonzero) - 1;
+    const uint32_t ep0 = (uint32_t)__builtin_amdgcn_readlane((int)cur.ep, first);
+    const int X0 = (int)(ep0 & 0xffu);
+    const uint32_t sign0 = (ep0 >> 8) & 1u;
+    if (lane == 0) rec[0] = (int32_t)((ep0 == EP_NONE ? 0u : (uint32_t)X0) | (sign0 << 8));   // exponent 0: no state has it -- never taken
+#pragma unroll
+    for (int cand = 0; cand < 2; cand++) {
+        fsum::stretch st = fsum::identity();
+        if (cur.ep != EP_ZERO) {
+            const int dE = X0 + cand - (int)(cur.ep & 0xffu);
+            const bool usable = cur.ep != EP_NONE && ep0 != EP_NONE && ((cur.ep >> 8) & 1u) == sign0 && (dE == 0 || (dE == 1 && !(cur.ep & EP_SINGLE)));
+            if (!usable) fsum::poison(st);
+            else {
+                const bool up = dE != 0;
+                st.d[0] = up ? cur.m[1][0] : cur.m[0][0]; st.d[1] = up ? cur.m[1][1] : cur.m[0][1];
+                st.lo[0] = up ? cur.m[1][2] : cur.m[0][2]; st.lo[1] = up ? cur.m[1][3] : cur.m[0][3];
+                st.hi[0] = up ? cur.m[1][4] : cur.m[0][4]; st.hi[1] = up ? cur.m[1][5] : cur.m[0][5];
+            }
+        }
+        wave_scan(st);
+        if (lane == 63) { int32_t* o = rec + 2 + cand * 6; o[0] = st.d[0]; o[1] = st.d[1]; o[2] = st.lo[0]; o[3] = st.lo[1]; o[4] = st.hi[0]; o[5] = st.hi[1]; }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------ k_wide_walk
 // One wave per (node, chain). A window of 64 blocks is resident in registers with the maps of BOTH candidate binades, so that
 // nothing has to be loaded again when the running sum changes binade inside the window; the following windows are loaded
 // while the current one is walked. A block whose map does not apply is added member by member out of LDS.
 // One WAVE per (node, chain) = `task`; s_add: 256 floats of LDS owned by that wave (the only synchronisation inside is between the lanes of the wave, whose LDS
 // accesses execute in program order: a scheduling fence is all the member-by-member blocks need).
-template <int MODE>
+template <int MODE, bool USE_WIN = false>
 __device__ __forceinline__ void wide_walk_body(const uint32_t* __restrict__ keys, const uint64_t* __restrict__ w64, const uint2* pk,
                                                const uint8_t* side, const tsvq_wide_node* __restrict__ nodes,
                                                tsvq_wide_ctrl* ctrl, void* ws_base, uint32_t tb, const uint32_t task, const int lane, float* s_add) {
@@ -584,22 +635,60 @@ __device__ __forceinline__ void wide_walk_body(const uint32_t* __restrict__ keys
     if (skip) s = __float_as_uint(ctrl[ni].start_sum[c]);
     const uint32_t first_b0 = skip & ~63u;
     first_start = (int)(skip - first_b0);
-    walk_window w0, w1, w2, w3;
-    load_window(ws, nd.first_block, nd.n_blocks, first_b0, lane, c, w0);
-    load_window(ws, nd.first_block, nd.n_blocks, first_b0 + 64, lane, c, w1);
-    load_window(ws, nd.first_block, nd.n_blocks, first_b0 + 128, lane, c, w2);
-    for (uint32_t b0 = first_b0; b0 < nd.n_blocks; b0 += 256) {
-        load_window(ws, nd.first_block, nd.n_blocks, b0 + 192, lane, c, w3);
-        process(w0, b0);
-        if (b0 + 64 >= nd.n_blocks) break;
-        load_window(ws, nd.first_block, nd.n_blocks, b0 + 256, lane, c, w0);
-        process(w1, b0 + 64);
-        if (b0 + 128 >= nd.n_blocks) break;
-        load_window(ws, nd.first_block, nd.n_blocks, b0 + 320, lane, c, w1);
-        process(w2, b0 + 128);
-        if (b0 + 192 >= nd.n_blocks) break;
-        load_window(ws, nd.first_block, nd.n_blocks, b0 + 384, lane, c, w2);
-        process(w3, b0 + 192);
+    // The pre-composed windows (k_wide_windows): lane L holds the record of window wb + L of the node; a window whose record has a map for the state the walk is in,
+    // and whose map applies, is taken in one step; everything else goes through process() as before.
+    uint32_t wb = 0;              // first window of the batch of records in registers
+    int32_t wrec[14];
+    auto load_records = [&](uint32_t first_window) {   // (unconditional, outside the window loop: a load the compiler cannot count would make every wait below a wait for everything)
+        wb = first_window;
+        const uint32_t nw = (nd.n_blocks + 63) / 64;
+        const int4* src = reinterpret_cast<const int4*>(ws.win + ((size_t)c * ws.tw + window_index(nd, ni, min(first_window + (uint32_t)lane, nw - 1))) * 16);
+        const int4 a = src[0], b = src[1], d = src[2], e = src[3];
+        wrec[0] = a.x; wrec[1] = a.y; wrec[2] = a.z; wrec[3] = a.w; wrec[4] = b.x; wrec[5] = b.y; wrec[6] = b.z; wrec[7] = b.w;
+        wrec[8] = d.x; wrec[9] = d.y; wrec[10] = d.z; wrec[11] = d.w; wrec[12] = e.x; wrec[13] = e.y;
+    };
+    auto take_window = [&](uint32_t b0) -> bool {
+        if (!USE_WIN || (b0 == first_b0 && first_start != 0)) return false;
+        const int i = (int)(b0 / 64 - wb);
+        const uint32_t meta = (uint32_t)__builtin_amdgcn_readlane(wrec[0], i);
+        if (meta & (1u << 9)) return true;                      // every block of the window adds +-0 only
+        const int cand = fsum::state_exp(s) - (int)(meta & 0xffu);
+        if (!fsum::state_ok(s) || (cand != 0 && cand != 1) || ((meta >> 8) & 1u) != (s >> 31)) return false;
+        fsum::stretch st;
+        const bool up = cand != 0;
+        const int32_t a0 = __builtin_amdgcn_readlane(wrec[2], i), a1 = __builtin_amdgcn_readlane(wrec[3], i), a2 = __builtin_amdgcn_readlane(wrec[4], i),
+                      a3 = __builtin_amdgcn_readlane(wrec[5], i), a4 = __builtin_amdgcn_readlane(wrec[6], i), a5 = __builtin_amdgcn_readlane(wrec[7], i);
+        const int32_t c0 = __builtin_amdgcn_readlane(wrec[8], i), c1 = __builtin_amdgcn_readlane(wrec[9], i), c2 = __builtin_amdgcn_readlane(wrec[10], i),
+                      c3 = __builtin_amdgcn_readlane(wrec[11], i), c4 = __builtin_amdgcn_readlane(wrec[12], i), c5 = __builtin_amdgcn_readlane(wrec[13], i);
+        st.d[0] = up ? c0 : a0; st.d[1] = up ? c1 : a1; st.lo[0] = up ? c2 : a2; st.lo[1] = up ? c3 : a3; st.hi[0] = up ? c4 : a4; st.hi[1] = up ? c5 : a5;
+        const int32_t k0 = fsum::state_k(s);
+        const bool ident = st.lo[0] == fsum::D_SAT && st.lo[1] == fsum::D_SAT && st.hi[0] == -fsum::D_SAT && st.hi[1] == -fsum::D_SAT;
+        if (!ident && !fsum::applies(st, k0)) return false;
+        const int32_t d = ident ? 0 : ((k0 & 1) ? st.d[1] : st.d[0]);
+        if (d != 0) s = (s & 0xff800000u) | ((uint32_t)(k0 + d) & 0x7fffffu);
+        n_scans++;
+        return true;
+    };
+    for (uint32_t batch0 = first_b0; batch0 < nd.n_blocks; batch0 += 64u * 64u) {   // 64 windows per batch of records
+        if (USE_WIN) load_records(batch0 / 64);
+        const uint32_t batch_end = min(batch0 + 64u * 64u, nd.n_blocks);
+        walk_window w0, w1, w2, w3;
+        load_window(ws, nd.first_block, nd.n_blocks, batch0, lane, c, w0);
+        load_window(ws, nd.first_block, nd.n_blocks, batch0 + 64, lane, c, w1);
+        load_window(ws, nd.first_block, nd.n_blocks, batch0 + 128, lane, c, w2);
+        for (uint32_t b0 = batch0; b0 < batch_end; b0 += 256) {
+            load_window(ws, nd.first_block, nd.n_blocks, b0 + 192, lane, c, w3);
+            if (!take_window(b0)) process(w0, b0);
+            if (b0 + 64 >= batch_end) break;
+            load_window(ws, nd.first_block, nd.n_blocks, b0 + 256, lane, c, w0);
+            if (!take_window(b0 + 64)) process(w1, b0 + 64);
+            if (b0 + 128 >= batch_end) break;
+            load_window(ws, nd.first_block, nd.n_blocks, b0 + 320, lane, c, w1);
+            if (!take_window(b0 + 128)) process(w2, b0 + 128);
+            if (b0 + 192 >= batch_end) break;
+            load_window(ws, nd.first_block, nd.n_blocks, b0 + 384, lane, c, w2);
+            if (!take_window(b0 + 192)) process(w3, b0 + 192);
+        }
     }
     if (lane == 0) {
         ctrl[ni].sums[c] = __uint_as_float(s);
@@ -607,11 +696,11 @@ __device__ __forceinline__ void wide_walk_body(const uint32_t* __restrict__ keys
         else { ctrl[ni].stat_scans[c] = (uint16_t)min(n_scans, 65535u); ctrl[ni].stat_raw[c] = (uint16_t)min(n_raw, 65535u); }
     }
 }
-template <int MODE>
+template <int MODE, bool WIN>
 __global__ __launch_bounds__(64) void k_wide_walk(const uint32_t* __restrict__ keys, const uint64_t* __restrict__ w64, const uint2* pk, const uint8_t* side,
                                                   const tsvq_wide_node* __restrict__ nodes, tsvq_wide_ctrl* ctrl, void* ws_base, uint32_t tb) {
     __shared__ __align__(16) float s_add[WB];
-    wide_walk_body<MODE>(keys, w64, pk, side, nodes, ctrl, ws_base, tb, blockIdx.x, (int)threadIdx.x, s_add);
+    wide_walk_body<MODE, WIN>(keys, w64, pk, side, nodes, ctrl, ws_base, tb, blockIdx.x, (int)threadIdx.x, s_add);
 }
 
 // ------------------------------------------------------------------------------------------------------------ k_wide_finish
@@ -788,7 +877,7 @@ __global__ __launch_bounds__(256) void k_wide_iota(uint32_t n, uint32_t* __restr
 size_t tsvq_wide_workspace_bytes(uint32_t total_blocks) {
     const size_t tb = total_blocks;
     return align256(tb * NCH_MAX * sizeof(double)) + align256(tb * 8 * sizeof(uint64_t)) + align256(tb * NCH_MAX * 2 * 6 * sizeof(int32_t)) +
-           align256(tb * sizeof(uint32_t)) + align256(tb * NCH_MAX * sizeof(uint16_t)) + align256(tb * NCH_MAX);
+           align256(tb * sizeof(uint32_t)) + align256(tb * NCH_MAX * sizeof(uint16_t)) + align256(tb * NCH_MAX) + align256((tb + tb / 64 + 1) * NCH_MAX * 16 * sizeof(int32_t));
 }
 
 template <int MODE>
@@ -799,7 +888,16 @@ static void launch_pass(hipStream_t st, const uint32_t* keys, const uint64_t* w6
     hipLaunchKernelGGL((k_wide_scan<MODE>), dim3(n_nodes, (NCH + 3) / 4 + (MODE == WM_COV ? 0 : 1)), dim3(256), 0, st, nodes, ctrl, ws, tb);
     if (!(all_chains_exact && MODE != WM_COV)) {   // the caller knows that every chain total of the batch stays below 2^24: the scan finishes them all
         hipLaunchKernelGGL((k_wide_stretches<MODE>), dim3(tb), dim3(ST_THREADS), 0, st, keys, w64, pk, side, nodes, n_nodes, ctrl, ws, tb);
-        hipLaunchKernelGGL((k_wide_walk<MODE>), dim3(n_nodes * NCH), dim3(64), 0, st, keys, w64, pk, side, nodes, ctrl, ws, tb);
+        // The pre-composed windows pay for nodes of millions of members (8192^2 q255, rounds 1-3: the covariance walk is 0.75 ms per round without them); for the
+        // 4096^2 image the extra launch costs more than the walk gains (root covariance walk 107 -> 53 us, many-workgroup rounds 5.50 -> 5.62 ms per step, one box):
+        // on from an average of 2,048 blocks per node of the batch. BU_TSVQ_WINDOWS=0 / 1 forces it (tests run both).
+        const char* we = std::getenv("BU_TSVQ_WINDOWS");
+        const bool windows = we ? we[0] != '0' : (tb / (n_nodes ? n_nodes : 1u) >= 2048u);
+        if (windows) {
+            hipLaunchKernelGGL((k_wide_windows<MODE>), dim3((tb / 64 + n_nodes) * NCH), dim3(64), 0, st, nodes, n_nodes, ctrl, ws, tb);
+            hipLaunchKernelGGL((k_wide_walk<MODE, true>), dim3(n_nodes * NCH), dim3(64), 0, st, keys, w64, pk, side, nodes, ctrl, ws, tb);
+        } else
+            hipLaunchKernelGGL((k_wide_walk<MODE, false>), dim3(n_nodes * NCH), dim3(64), 0, st, keys, w64, pk, side, nodes, ctrl, ws, tb);
     }
     hipLaunchKernelGGL((k_wide_finish<MODE>), dim3(n_nodes), dim3(64), 0, st, nodes, ctrl, root_out);
 }

@@ -133,11 +133,12 @@ def test_wide_nodes_match_host_tsvq(hip_ctx, monkeypatch, n, k, p, kind, wmax, w
     cap = 4 * n + 4 * k + 100
     outs = {}
     # wide: every pass through the parity maps; hybrid: the covariance pass of all but the largest nodes chained (the default)
-    for name, env in (("wide", {"BU_TSVQ_WIDE_MIN": str(wide_min), "BU_TSVQ_WIDE_COV_MIN": "0"}), ("hybrid", {"BU_TSVQ_WIDE_MIN": str(wide_min)}),
-                      ("narrow", {"BU_TSVQ_WIDE": "0"})):
+    # + windows: the walk takes 64 blocks at a time where their pre-composed map applies (k_wide_windows; on by itself only for nodes of millions of members)
+    for name, env in (("wide", {"BU_TSVQ_WIDE_MIN": str(wide_min), "BU_TSVQ_WIDE_COV_MIN": "0", "BU_TSVQ_WINDOWS": "0"}), ("hybrid", {"BU_TSVQ_WIDE_MIN": str(wide_min)}),
+                      ("windows", {"BU_TSVQ_WIDE_MIN": str(wide_min), "BU_TSVQ_WIDE_COV_MIN": "0", "BU_TSVQ_WINDOWS": "1"}), ("narrow", {"BU_TSVQ_WIDE": "0"})):
         if name == "narrow" and n > 200000:
             continue
-        for key in ("BU_TSVQ_WIDE_MIN", "BU_TSVQ_WIDE", "BU_TSVQ_WIDE_COV_MIN"):
+        for key in ("BU_TSVQ_WIDE_MIN", "BU_TSVQ_WIDE", "BU_TSVQ_WIDE_COV_MIN", "BU_TSVQ_WINDOWS"):
             monkeypatch.delenv(key, raising=False)
         for key, val in env.items():
             monkeypatch.setenv(key, val)
