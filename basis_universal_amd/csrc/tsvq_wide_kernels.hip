@@ -333,17 +333,46 @@ __device__ __forceinline__ void fetch_packed(const uint32_t* __restrict__ keys, 
 
 // (320 threads -- two rounds over the covariance pass's 544 items instead of three -- measured slower: 307 against 250 us for the root.)
 constexpr int ST_THREADS = WB;
+// One item = (chain, slice of the block's members), both candidate binades; the Q slices of a chain sit in Q neighbouring lanes and are composed in member order by
+// a segmented DPP scan (row_shr 1 / 2 / 4 / 8 inside aligned groups of Q lanes), so the folded maps never leave the registers -- the kernel's LDS is the tile alone
+// (37 KB for the covariance pass instead of 59 KB with a staging array for the maps: four workgroups per CU instead of two for a kernel that waits on LDS reads).
+// The tile's columns carry one float of padding per slice: the lanes of a group read the same rows at offsets 64 apart, which would be one bank.
+template <int CTRL, int SHIFT>
+__device__ __forceinline__ void seg_scan_step(fsum::stretch& st, const int q) {
+    fsum::stretch f;
+    f.d[0] = dpp_mov<CTRL, 0xf>(0, st.d[0]); f.d[1] = dpp_mov<CTRL, 0xf>(0, st.d[1]);
+    f.lo[0] = dpp_mov<CTRL, 0xf>(fsum::D_SAT, st.lo[0]); f.lo[1] = dpp_mov<CTRL, 0xf>(fsum::D_SAT, st.lo[1]);
+    f.hi[0] = dpp_mov<CTRL, 0xf>(-fsum::D_SAT, st.hi[0]); f.hi[1] = dpp_mov<CTRL, 0xf>(-fsum::D_SAT, st.hi[1]);
+    if (q < SHIFT) f = fsum::identity();   // the lane SHIFT below belongs to another chain
+    st = fsum::compose(f, st);
+}
+template <int Q>
+__device__ __forceinline__ void seg_scan(fsum::stretch& st, const int q) {
+    seg_scan_step<0x111, 1>(st, q);
+    if (Q > 2) seg_scan_step<0x112, 2>(st, q);
+    if (Q > 4) seg_scan_step<0x114, 4>(st, q);
+    if (Q > 8) seg_scan_step<0x118, 8>(st, q);
+}
+
+constexpr int ST_ROW = 289;   // 256 members + one float of padding per slice (<= 16), and = 1 mod 32
+template <int MODE>
+struct st_tiles {
+    float fa[16][ST_ROW];
+    float fb[MODE == WM_COV ? 16 : 1][ST_ROW];
+    uint8_t sd[WB];
+};
+
 template <int MODE>
 __device__ __forceinline__ void wide_stretches_body(const uint32_t* __restrict__ keys, const uint64_t* __restrict__ w64, const uint2* pk,
                                                     const uint8_t* side, const tsvq_wide_node* __restrict__ nodes,
                                                     uint32_t n_nodes, const tsvq_wide_ctrl* ctrl, void* ws_base, uint32_t tb, const uint32_t blk) {
     constexpr int NCH = mode_traits<MODE>::NCH;
-    constexpr int Q = MODE == WM_COV ? 4 : (MODE == WM_ROOT ? 16 : 8);   // member slices per chain; an item = (chain, slice), both candidate binades
+    constexpr int Q = MODE == WM_COV ? 4 : (MODE == WM_ROOT ? 16 : 8);   // member slices per chain
     constexpr int ITEMS = NCH * Q;
     constexpr int SL = WB / Q;
-    __shared__ tiles<MODE> T;
+    static_assert(ITEMS % Q == 0 && ST_THREADS % Q == 0 && 16 % Q == 0, "the slices of a chain are Q aligned lanes of one DPP row");
+    __shared__ st_tiles<MODE> T;
     __shared__ float s_origin[16];
-    __shared__ int32_t s_st[ITEMS][2][6];
     const wide_ws ws = carve(ws_base, tb);
     const int tid = threadIdx.x;
     const uint32_t ni = find_node(nodes, n_nodes, blk);
@@ -356,23 +385,24 @@ __device__ __forceinline__ void wide_stretches_body(const uint32_t* __restrict__
     const uint32_t pos = (blk - nd.first_block) * WB + (uint32_t)min(tid, WB - 1);
     uint32_t key; float wf; bool valid;
     fetch_packed<MODE>(keys, w64, pk, nd.start, pos, nd.count, key, wf, valid);
+    const int col = tid + tid / SL;   // member tid's column
     if (tid >= WB) {
         // not a staging thread
     } else if (MODE == WM_COV) {
 #pragma unroll
         for (int k = 0; k < 16; k++) {
             const float dk = (float)packed16_value(key, k) - s_origin[k];
-            T.fa[k][tid] = valid ? dk : 0.0f;
-            T.fb[k][tid] = valid ? wf * dk : 0.0f;
+            T.fa[k][col] = valid ? dk : 0.0f;
+            T.fb[k][col] = valid ? wf * dk : 0.0f;
         }
     } else {
 #pragma unroll
-        for (int k = 0; k < 16; k++) T.fa[k][tid] = valid ? (float)packed16_value(key, k) * wf : 0.0f;
+        for (int k = 0; k < 16; k++) T.fa[k][col] = valid ? (float)packed16_value(key, k) * wf : 0.0f;
         T.sd[tid] = valid ? (MODE == WM_ROOT ? 0 : side[nd.start + pos]) : 2;
     }
     __syncthreads();
     for (int item = tid; item < ITEMS; item += ST_THREADS) {
-        const int c = item % NCH, q = item / NCH;
+        const int c = item / Q, q = item % Q;
         const bool skip = ctrl[ni].exact[c] != 0;
         const uint16_t ep = skip ? EP_NONE : ws.epred[ws.at(c, blk)];
         fsum::stretch st0 = fsum::identity(), st1 = fsum::identity();
@@ -383,10 +413,12 @@ __device__ __forceinline__ void wide_stretches_body(const uint32_t* __restrict__
             if (MODE == WM_COV) cov_xy(c, x, y);
             const uint8_t want = (uint8_t)(c >> 4);
             bool bad0 = false, bad1 = false;
-            for (int j = q * SL; j < q * SL + SL; j++) {
+            const float* ra = &T.fa[x][q * SL + q];
+            const float* rb = &T.fb[MODE == WM_COV ? y : 0][q * SL + q];
+            for (int jj = 0; jj < SL; jj++) {
                 uint32_t bits;
-                if (MODE == WM_COV) bits = __float_as_uint(T.fa[x][j] * T.fb[y][j]);
-                else { if (T.sd[j] != want) continue; bits = __float_as_uint(T.fa[x][j]); }
+                if (MODE == WM_COV) bits = __float_as_uint(ra[jj] * rb[jj]);
+                else { if (T.sd[q * SL + jj] != want) continue; bits = __float_as_uint(ra[jj]); }
                 if ((bits << 1) == 0) continue;
                 const fsum::parts pr = fsum::split(bits, neg);
                 fsum::push_fast(st0, fsum::decode_fast(pr, E, bad0));
@@ -395,16 +427,13 @@ __device__ __forceinline__ void wide_stretches_body(const uint32_t* __restrict__
             if (bad0) fsum::poison(st0);
             if (bad1 || E + 1 > 253) fsum::poison(st1);
         }
-        st_store(s_st[item][0], st0); st_store(s_st[item][1], st1);
-    }
-    __syncthreads();
-    for (int item = tid; item < NCH * 2; item += ST_THREADS) {   // slices in member order
-        const int c = item % NCH, cand = item / NCH;
-        if (ctrl[ni].exact[c]) continue;
-        fsum::stretch acc = st_load(s_st[c][cand]);
-#pragma unroll
-        for (int q = 1; q < Q; q++) acc = fsum::compose(acc, st_load(s_st[c + q * NCH][cand]));
-        st_store(ws.summ + (ws.at(c, blk) * 2 + (size_t)cand) * 6, acc);
+        // slices in member order: an inclusive scan over the Q lanes of the chain, the last one has the block's map
+        seg_scan<Q>(st0, q);
+        seg_scan<Q>(st1, q);
+        if (q == Q - 1 && !skip) {
+            int32_t* o = ws.summ + ws.at(c, blk) * 2 * 6;
+            st_store(o, st0); st_store(o + 6, st1);
+        }
     }
 }
 template <int MODE>
