@@ -918,7 +918,7 @@ static bu_tsvq* tsvq_create_common(bu_hip_context* ctx, uint32_t dim, bool packe
         if (const char* e = std::getenv("BU_TSVQ_WIDE")) if (std::atoi(e) == 0) wide_min = 0;
         if (wide_min && n >= wide_min && n < (1u << 22)) {   // above 2^22 members the binade prediction loses its margin; the chained kernel takes those
             q->wide_min = wide_min;
-            q->wide_cov_min = 131072;   // (98,304 until the end of round 4; side by side on one box: equal at 4096^2, 8192^2 q255 842 -> 857 Mpix/s)
+            q->wide_cov_min = 98304;   // (side by side on one box with the register-composed stretches kernel: 131,072 / 98,304 / 65,536 / 49,152 -> 5.10 / 4.98 / 5.04 / 5.04 ms of many-workgroup rounds per 4096^2 step)
             if (const char* e = std::getenv("BU_TSVQ_WIDE_COV_MIN")) { const long v = std::atol(e); if (v >= 0 && v <= (1l << 30)) q->wide_cov_min = (uint32_t)v; }
             q->wide_nodes_cap = n / wide_min + 1;
             q->wide_blocks_cap = (n + 255) / 256 + q->wide_nodes_cap;
