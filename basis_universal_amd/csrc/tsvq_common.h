@@ -108,6 +108,23 @@ __device__ __forceinline__ void principal_axis_wave(const float (*cov)[16], floa
         for (int i = 0; i < N; i++) out_axis[i] = axis[i];
 }
 
+// wave64 sums by DPP (rows of 16 lanes: row_shr 1/2/4/8, then row_bcast15 into rows 1 and 3, row_bcast31 into rows 2 and 3): an inclusive prefix whose LAST lane
+// holds the wave's total; lanes without a source add 0. No LDS traffic, six dependent adds.
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ uint32_t dpp_src_u32(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false); }
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {   // valid in lane 63
+    v += dpp_src_u32<0x111, 0xf>(v); v += dpp_src_u32<0x112, 0xf>(v); v += dpp_src_u32<0x114, 0xf>(v); v += dpp_src_u32<0x118, 0xf>(v);
+    v += dpp_src_u32<0x142, 0xa>(v); v += dpp_src_u32<0x143, 0xc>(v);
+    return v;
+}
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ uint64_t dpp_src_u64(uint64_t v) {
+    return ((uint64_t)dpp_src_u32<CTRL, ROW_MASK>((uint32_t)(v >> 32)) << 32) | dpp_src_u32<CTRL, ROW_MASK>((uint32_t)v);
+}
+__device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {   // valid in lane 63
+    v += dpp_src_u64<0x111, 0xf>(v); v += dpp_src_u64<0x112, 0xf>(v); v += dpp_src_u64<0x114, 0xf>(v); v += dpp_src_u64<0x118, 0xf>(v);
+    v += dpp_src_u64<0x142, 0xa>(v); v += dpp_src_u64<0x143, 0xc>(v);
+    return v;
+}
+
 // The reference's double accumulators (ttsum, l_weight / r_weight) only ever add floats. When every addend is a non-negative
 // INTEGER-valued float below 2^53 and the total stays below 2^53 (always the case for selector vectors with real weights), each
 // double add is exact, so the running sum equals the integer sum and its order does not matter: the "exact" kernel variants

@@ -245,22 +245,6 @@ __device__ __forceinline__ void chain_add_prod_f32(float& acc, const float* dx, 
 }
 
 
-// wave64 sums by DPP (rows of 16 lanes: row_shr 1/2/4/8, then row_bcast15 into rows 1 and 3, row_bcast31 into rows 2 and 3): an inclusive prefix whose LAST lane
-// holds the wave's total; lanes without a source add 0. No LDS traffic, six dependent adds.
-template <int CTRL, int ROW_MASK> __device__ __forceinline__ uint32_t dpp_src_u32(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false); }
-__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {   // valid in lane 63
-    v += dpp_src_u32<0x111, 0xf>(v); v += dpp_src_u32<0x112, 0xf>(v); v += dpp_src_u32<0x114, 0xf>(v); v += dpp_src_u32<0x118, 0xf>(v);
-    v += dpp_src_u32<0x142, 0xa>(v); v += dpp_src_u32<0x143, 0xc>(v);
-    return v;
-}
-template <int CTRL, int ROW_MASK> __device__ __forceinline__ uint64_t dpp_src_u64(uint64_t v) {
-    return ((uint64_t)dpp_src_u32<CTRL, ROW_MASK>((uint32_t)(v >> 32)) << 32) | dpp_src_u32<CTRL, ROW_MASK>((uint32_t)v);
-}
-__device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {   // valid in lane 63
-    v += dpp_src_u64<0x111, 0xf>(v); v += dpp_src_u64<0x112, 0xf>(v); v += dpp_src_u64<0x114, 0xf>(v); v += dpp_src_u64<0x118, 0xf>(v);
-    v += dpp_src_u64<0x142, 0xa>(v); v += dpp_src_u64<0x143, 0xc>(v);
-    return v;
-}
 
 __device__ __forceinline__ uint64_t block_sum_u64(uint64_t v, uint64_t* scratch /* TQ_THREADS/64 */) {
     v = wave_sum_u64(v);

@@ -138,21 +138,16 @@ __global__ __launch_bounds__(WB) void k6_sums(const float* __restrict__ rows, co
         s_part[sl][c] = s;
     }
 #pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) {
+    for (int i = 0; i < (MODE == W6_PROJ ? 5 : 3); i++) red[i] = wave_sum_u64(red[i]);   // totals in lane 63
+    if (MODE == W6_DIST || MODE == W6_ROOT) {
 #pragma unroll
-        for (int i = 0; i < (MODE == W6_PROJ ? 5 : 3); i++) {
-            const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)red[i], o, 64), hi = (uint32_t)__shfl_xor((int)(uint32_t)(red[i] >> 32), o, 64);
-            red[i] += ((uint64_t)hi << 32) | lo;
-        }
-        if (MODE == W6_DIST || MODE == W6_ROOT) {
+        for (int i = 0; i < 2; i++) {
+            tt[i] = wave_prefix_f64(tt[i]);   // (a tree of double adds: exact whenever the block passes tt::block_is_exact, which is all that is asked of it)
 #pragma unroll
-            for (int i = 0; i < 2; i++) {
-                tt[i] += shfl_xor_f64(tt[i], o);
-                em[i] = min(em[i], (uint32_t)__shfl_xor((int)em[i], o, 64));
-            }
+            for (int o = 32; o >= 1; o >>= 1) em[i] = min(em[i], (uint32_t)__shfl_xor((int)em[i], o, 64));
         }
     }
-    if ((tid & 63) == 0) {
+    if ((tid & 63) == 63) {
         for (int i = 0; i < 5; i++) s_red[tid >> 6][i] = red[i];
         for (int i = 0; i < 2; i++) { s_tt[tid >> 6][i] = tt[i]; s_em[tid >> 6][i] = em[i]; }
     }
@@ -236,13 +231,8 @@ __global__ __launch_bounds__(256) void k6_scan(const tsvq_wide_node* __restrict_
         for (int o = 1; o < 64; o <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)incl, o, 64); if (lane >= o) incl += t; }
 #pragma unroll
         for (int i = 0; i < NT; i++) {
-            uint64_t v = tot[i];
-#pragma unroll
-            for (int o = 32; o >= 1; o >>= 1) {
-                const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, o, 64), hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), o, 64);
-                v += ((uint64_t)hi << 32) | lo;
-            }
-            if (lane == 0) s_tot[tid >> 6][i] = v;
+            const uint64_t v = wave_sum_u64(tot[i]);
+            if (lane == 63) s_tot[tid >> 6][i] = v;
         }
         if (lane == 63) s_wl[tid >> 6] = incl;
         __syncthreads();

@@ -183,14 +183,9 @@ __device__ __forceinline__ void wide_sums_body(const uint32_t* __restrict__ keys
         s_part[sl][c] = s;
     }
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-        uint64_t v = red[i];
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) {
-            const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, o, 64), hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), o, 64);
-            v += ((uint64_t)hi << 32) | lo;
-        }
-        if ((tid & 63) == 0) s_red[tid >> 6][i] = v;
+    for (int i = 0; i < 8; i++) {   // DPP wave sums (total in lane 63): the xor-shuffle tree this replaces was 96 trips through the LDS crossbar per thread
+        const uint64_t v = wave_sum_u64(red[i]);
+        if ((tid & 63) == 63) s_red[tid >> 6][i] = v;
     }
     __syncthreads();
     if (tid < NCH) {
@@ -289,13 +284,8 @@ __device__ __forceinline__ void wide_scan_body(const tsvq_wide_node* __restrict_
     for (int o = 1; o < 64; o <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)incl, o, 64); if (lane >= o) incl += t; }
 #pragma unroll
     for (int i = 0; i < 8; i++) {
-        uint64_t v = tot[i];
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) {
-            const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, o, 64), hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), o, 64);
-            v += ((uint64_t)hi << 32) | lo;
-        }
-        if (lane == 0) s_tot[tid >> 6][i] = v;
+        const uint64_t v = wave_sum_u64(tot[i]);
+        if (lane == 63) s_tot[tid >> 6][i] = v;
     }
     if (lane == 63) s_wl[tid >> 6] = incl;
     __syncthreads();
