@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <utility>
+#include <cstdlib>
 #include "tsvq_kernels.h"
 #include "tsvq_common.h"
 
@@ -352,8 +353,8 @@ __global__ __launch_bounds__(TQ_THREADS) void k_tsvq_root(Src src, const uint64_
 
 // split_node (enc.h:1737-1800) = prep_split (:1848-1960) + refine_split (:1962-2077) for one node per workgroup.
 template <int N, typename Src, bool EX>
-__global__ __launch_bounds__(TQ_THREADS) void k_tsvq_split(Src src, const uint64_t* __restrict__ w64, uint32_t* __restrict__ perm0, uint32_t* __restrict__ perm1,
-                                                          uint8_t* __restrict__ side, const tsvq_node_in* __restrict__ nodes, tsvq_split_out* __restrict__ outs) {
+__device__ __forceinline__ void tsvq_split_body(Src src, const uint64_t* __restrict__ w64, uint32_t* __restrict__ perm0, uint32_t* __restrict__ perm1,
+                                                uint8_t* __restrict__ side, const tsvq_node_in* __restrict__ nodes, tsvq_split_out* __restrict__ outs) {
     extern __shared__ __align__(16) char lds[];
     __shared__ tq_ctrl c;
     __shared__ float s_origin[16];
@@ -765,6 +766,19 @@ __global__ __launch_bounds__(TQ_THREADS) void k_tsvq_split(Src src, const uint64
     }
 }
 
+template <int N, typename Src, bool EX>
+__global__ __launch_bounds__(TQ_THREADS) void k_tsvq_split(Src src, const uint64_t* __restrict__ w64, uint32_t* __restrict__ perm0, uint32_t* __restrict__ perm1,
+                                                          uint8_t* __restrict__ side, const tsvq_node_in* __restrict__ nodes, tsvq_split_out* __restrict__ outs) {
+    tsvq_split_body<N, Src, EX>(src, w64, perm0, perm1, side, nodes, outs);
+}
+// The same, compiled for TWO workgroups per CU (four waves per SIMD: 128 registers, ~150 bytes of scratch per lane for the exact packed variant, which takes 173 on its
+// own): for the rounds of a tree's lower levels, which have more nodes than the chip has CUs -- there the second resident workgroup is worth more than the spills cost.
+template <int N, typename Src, bool EX>
+__global__ __launch_bounds__(TQ_THREADS, 4) void k_tsvq_split_dense(Src src, const uint64_t* __restrict__ w64, uint32_t* __restrict__ perm0, uint32_t* __restrict__ perm1,
+                                                                   uint8_t* __restrict__ side, const tsvq_node_in* __restrict__ nodes, tsvq_split_out* __restrict__ outs) {
+    tsvq_split_body<N, Src, EX>(src, w64, perm0, perm1, side, nodes, outs);
+}
+
 // The covariance pass of split_node on its own, chained sums, for the many-workgroup path (tsvq_wide_kernels.hip), which uses it for nodes where 136
 // order-preserving walks cost more than one pass of dependent adds. A chain lane is bound by instruction ISSUE, not by the dependent add: a wave64 instruction
 // takes four cycles to issue, and the one-workgroup kernel's lane issues a multiply, an add and half an LDS read per member (11 cycles). The batches that take
@@ -960,6 +974,12 @@ hipError_t launch_tsvq_split(hipStream_t st, int dim, bool packed, bool exact, c
         hipLaunchKernelGGL((k_tsvq_split<NN, SRC, EXV>), dim3(n_nodes), dim3(TQ_THREADS), lds, st, srcval, d_w64, d_perm0, d_perm1, d_side, d_nodes, d_outs); } while (0)
     if (dim == 16 && packed) {
         packed16_rows src{static_cast<const uint32_t*>(d_rows)};
+        const char* de = std::getenv("BU_TSVQ_DENSE_MIN");   // node count of a round from which the two-workgroups-per-CU build of the exact kernel is used (0: never)
+        const uint32_t dense_min = de ? (uint32_t)std::atoi(de) : 257u;
+        if (exact && dense_min && n_nodes >= dense_min) {
+            if ((e = set_lds(k_tsvq_split_dense<16, packed16_rows, true>, lds)) != hipSuccess) return e;
+            hipLaunchKernelGGL((k_tsvq_split_dense<16, packed16_rows, true>), dim3(n_nodes), dim3(TQ_THREADS), lds, st, src, d_w64, d_perm0, d_perm1, d_side, d_nodes, d_outs);
+        } else
         if (exact) TQ_LAUNCH_SPLIT(16, packed16_rows, true, src); else TQ_LAUNCH_SPLIT(16, packed16_rows, false, src);
     } else if (dim == 16) {
         float_rows<16> src{static_cast<const float*>(d_rows)};
