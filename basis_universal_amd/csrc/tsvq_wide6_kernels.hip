@@ -8,16 +8,17 @@
 //   * the addends v_k * w are not integers, so there is no "total below 2^24 = exact in any order" shortcut and no exact prefix: every chain is walked from block 0;
 //   * the reference's DOUBLE accumulators of the two-means passes (l_ttsum / r_ttsum += w * |v|^2, encoder/basisu_enc.h:1996-2006) add floats that are not integers either,
 //     so they cannot be integer reductions. A double has 29 bits more than the float it adds: the add is exact unless bits fall off the low end, which only happens when
-//     the running sum has outgrown the smallest addend so far by more than 2^29. The scan kernel therefore walks the blocks of a node in order with the block's sum
+//     the running sum has outgrown the smallest addend so far by more than 2^29. One wave per node (beside the chains' walks, in the walk kernel) therefore walks the blocks of the node in order with the block's sum
 //     (exact when the test below holds) and the exponent of its smallest addend: while [lowest set bit that can be in the sum] >= ulp(sum after the block) every add of
-//     the block is exact and the block is taken in one step; a block for which the test fails is added member by member, in order, with real double adds (tt_walk).
-//     The test errs on the safe side only (a failing block costs ~1 us, never a wrong bit);
+//     the block is exact and the block is taken in one step; a block for which the test fails is added member by member, in order, with real double adds (tt_walk; the test itself is csrc/tt_exact.h,
+//     shared with a host build the CPU tests run). It errs on the safe side only (a failing block costs ~1 us, never a wrong bit);
 //   * l_weight / r_weight of the projection pass add integer-valued floats far below 2^53: integer sums, as on the selector side;
 //   * the covariance pass stays CHAINED (k_tsvq_cov_axis6, tsvq_kernels.hip: one workgroup per node, 21 chains): its signed chains change binade in most blocks of
 //     nodes this size, and a block that has to be added member by member costs twice what the plain chain costs (measured: 305 us through the maps for the 35,502-member
 //     root of the bench image, 135 us chained). That kernel also lays out the addends of the passes that follow in list order (va = v_k * w, tta = w * |v|^2), so
 //     the per-block kernels here read coalesced arrays; only the classification gathers rows through the member list;
-//   * the side passes have 12 chains instead of 32.
+//   * the side passes have 12 chains instead of 32;
+//   * the root record of the tree (prepare_root) goes through the same passes with every vector on the "left" (W6_ROOT).
 // Anything out of the ordinary (an empty child, a degenerate projection, non-finite data) hands the node back (ok == 2) and the one-workgroup kernel splits it.
 // Parity: tests/test_gpu_tsvq.py runs trees through this path (BU_TSVQ_WIDE6_MIN lowered) against the host builder and the reference.
 #include <hip/hip_runtime.h>
@@ -52,10 +53,6 @@ __device__ __forceinline__ member6 fetch6(const float* __restrict__ rows, const 
 
 // the addend of the reference's ttsum for one member: (double)(w * |v|^2), the product in float (enc.h:1998: `l_ttsum += weight * v.dot(v)` with float operands)
 __device__ __forceinline__ float tt_addend(const member6& m) { return m.wf * dot_seq<D6>(m.v, m.v); }
-
-__device__ __forceinline__ double shfl_xor_f64(double v, int o) {
-    return __hiloint2double(__shfl_xor(__double2hiint(v), o, 64), __shfl_xor(__double2loint(v), o, 64));
-}
 
 struct tiles6 {
     float fa[D6][WROW];
