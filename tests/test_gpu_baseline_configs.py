@@ -72,6 +72,18 @@ def test_config3_synth8192_q255_multithreaded_reference(hip_ctx, threads):
     be.close(); fe.close()
 
 
+@pytest.mark.parametrize("case,single", [("synth3072_q200_l2_t8", "synth3072_q200_l2"), ("synth3072_q90_l4_t4", "synth3072_q90_l4")])
+def test_other_levels_in_both_thread_configurations(hip_ctx, case, single):
+    """The reference's two thread configurations at compression levels 2 (the library default: other parent codebook sizes, the backend's call back into the frontend)
+    and 4 (new-cluster insertion, endpoint refinement given selectors), 3072^2 (past the 262,144-vector gate of the partitioned codebook build): frontend state and
+    backend payloads of the reference run with a pool of 8 / 4 threads and of the single-threaded run (tools/gen_golden_big.py)."""
+    g, g1 = GOLDEN[case], GOLDEN[single]
+    assert g["threads"] > 1 and g1["threads"] == 1 and g["level"] == g1["level"] and g["frontend_digests"] != g1["frontend_digests"]
+    for gg in (g, g1):
+        fe, be = _frontend_and_backend(hip_ctx, synth(3072, 3072, 4321), gg)
+        be.close(); fe.close()
+
+
 def test_config0_kodim03_q128_file_equals_the_reference_tools(hip_ctx):
     """the row of the reference's own golden table (basisu_tool.cpp:6751), held to the bytes instead of its 4.5 % / 0.3 dB tolerance"""
     from helpers import basis_file_key_values, ktx2_file_key_values

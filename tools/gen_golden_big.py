@@ -51,19 +51,27 @@ CASES = {
 for _t in (2, 4, 8):
     CASES[f"synth4096_q128_t{_t}"] = (lambda: helpers.synth(4096, 4096, 1234), 128, _t)
     CASES[f"synth8192_q255_t{_t}"] = (lambda: helpers.synth(8192, 8192, 5678), 255, _t)
+# ... and at other compression levels (a fourth tuple entry; the cases above are level 1): 3072^2 (589,824 blocks, ~400,000 distinct selector vectors: past the gate) at
+# level 2 (the library's default: different parent codebook sizes, the backend's call back into the frontend) with 8 threads and at level 4 (new-cluster insertion,
+# endpoint refinement given selectors) with 4
+CASES["synth3072_q200_l2_t8"] = (lambda: helpers.synth(3072, 3072, 4321), 200, 8, 2)
+CASES["synth3072_q90_l4_t4"] = (lambda: helpers.synth(3072, 3072, 4321), 90, 4, 4)
+CASES["synth3072_q200_l2"] = (lambda: helpers.synth(3072, 3072, 4321), 200, 1, 2)   # (single-threaded: what the two above must differ from)
+CASES["synth3072_q90_l4"] = (lambda: helpers.synth(3072, 3072, 4321), 90, 1, 4)
 
 
 def main():
     want = sys.argv[1:] or list(CASES)
     out = json.loads(OUT.read_text()) if OUT.exists() else {}
     for case in want:
-        img_fn, quality, threads = CASES[case]
+        img_fn, quality, threads = CASES[case][:3]
+        level = CASES[case][3] if len(CASES[case]) > 3 else 1
         img = img_fn()
         h, w = img.shape[:2]
         blocks = helpers.to_pixel_blocks(img)
         max_ep, max_sel = quality_to_clusters(quality, blocks.shape[0])
         t0 = time.time()
-        fe = helpers.RefFrontend(blocks, max_ep, max_sel, 1, True, threads=threads)
+        fe = helpers.RefFrontend(blocks, max_ep, max_sel, level, True, threads=threads)
         fe.call("compress")
         t1 = time.time()
         st = {k: fe.get(k) for k in T.STATE}
@@ -71,7 +79,7 @@ def main():
         total, _ = fe.backend_run([(0, nbx, nby)], *helpers_backend_thresholds(quality))
         t2 = time.time()
         out[case] = {
-            "width": w, "height": h, "quality": quality, "level": 1, "perceptual": True, "n_blocks": int(blocks.shape[0]), "threads": threads,
+            "width": w, "height": h, "quality": quality, "level": level, "perceptual": True, "n_blocks": int(blocks.shape[0]), "threads": threads,
             "max_endpoint_clusters": max_ep, "max_selector_clusters": max_sel,
             "final_endpoint_clusters": int(st["endpoint_clusters"].view(np.uint32)[0]),
             "final_selector_clusters": int(st["selector_cluster_block_indices"].view(np.uint32)[0]),
