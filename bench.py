@@ -285,6 +285,9 @@ def main():
             "stages_s_per_step": {k: round(v / args.steps, 4) for k, v in stage_acc.items()},
             "kernels_ms_per_step": {k: round(v[0] / args.steps, 3) for k, v in kernels.items()},
         }
+        # the state the LAST timed step left (every per-block and per-cluster result the reference's getters serve) against the digests of the reference's
+        # own run on this image (tests/golden/: tools/gen_golden_big.py / gen_golden_etc1s.py ran oracle/_ref; nothing under oracle/ is touched here)
+        out["identical_to_reference"] = headline_identical(last, w, h, args)
         # what is NOT device time inside a step: host bookkeeping, copies and synchronising calls between the kernels
         out["host_gap_ms"] = round(elapsed / args.steps * 1e3 - sum(v[0] for v in kernels.values()) / args.steps, 2)
         if roofline:
@@ -343,6 +346,21 @@ def frontend_psnr(fe, img):
     h, w = img.shape[:2]
     rgb, rgba = psnr_pair(helpers.decode_etc1s_blocks(fe.get("encoded_blocks").reshape(-1, 8), w // 4, h // 4), img)
     return {"rgb": rgb, "rgba": rgba}
+
+
+def headline_identical(last, w, h, args):
+    """True / False: all eight frontend state digests of the step just timed = the committed digests of the reference's run on the same image and settings;
+    None when no golden exists for this size / quality / level (the 4096^2 -q128 level-1 headline has one; rank 0's image is the seed-1234 image in every mode)."""
+    if args.quality != 128 or args.level != 1 or (w, h) != (4096, 4096):
+        return None
+    g = ROOT / "tests" / "golden" / "etc1s_big_digests.json"
+    rec = json.loads(g.read_text()).get("synth4096_q128") if g.exists() else None
+    want = (rec or {}).get("frontend_digests")
+    if not want:
+        return None
+    import test_gpu_etc1s_frontend as T      # the canonical byte form of each state array (tests/: checker code, outside the timed region)
+    got = T._digest({k: last.get(k) for k in want})
+    return got == want
 
 
 def etc1s_8192_bench(ctx, helpers, args):

@@ -734,3 +734,16 @@ REF_API int ref_compress_etc1s(const uint8_t* rgba, uint32_t w, uint32_t h, int 
 	if (out_file && cap >= f.size()) memcpy(out_file, f.data(), f.size());
 	return 1;
 }
+
+// basis_compressor_params::set_format_mode_and_quality_effort (comp.cpp:76-205) for the two LDR formats of this package: what the unified
+// -quality / -effort pair turns into. out = { ETC1S quality level, ETC1S compression level, UASTC pack flags, UASTC RDO flag }, *lambda = the RDO scalar.
+REF_API int ref_quality_effort(int uastc, int quality, int effort, int32_t* out, float* lambda) {
+	basis_compressor_params params;
+	if (!params.set_format_mode_and_quality_effort(uastc ? basist::basis_tex_format::cUASTC_LDR_4x4 : basist::basis_tex_format::cETC1S, quality, effort, true)) return 0;
+	out[0] = params.m_quality_level;
+	out[1] = params.m_etc1s_compression_level;
+	out[2] = (int32_t)(uint32_t)params.m_pack_uastc_ldr_4x4_flags;
+	out[3] = params.m_rdo_uastc_ldr_4x4 ? 1 : 0;
+	*lambda = params.m_rdo_uastc_ldr_4x4_quality_scalar;
+	return 1;
+}

@@ -164,9 +164,18 @@ def ref():
         L.ref_table.argtypes = [C.c_char_p, C.c_void_p, C.c_uint64]
         L.ref_compress_etc1s.restype = C.c_int
         L.ref_compress_etc1s.argtypes = [u8p, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_int, u32p, u32p, u8p, C.c_uint64, u64p]
+        L.ref_quality_effort.restype = C.c_int
+        L.ref_quality_effort.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32), f32p]
         assert L.ref_init() == 1
         _ref = L
     return _ref
+
+
+def ref_quality_effort(uastc, quality, effort):
+    """basis_compressor_params::set_format_mode_and_quality_effort of the reference -> (etc1s quality, etc1s comp level, uastc pack flags, rdo flag, lambda as f32)"""
+    out, lam = np.zeros(4, np.int32), np.zeros(1, np.float32)
+    assert ref().ref_quality_effort(int(uastc), quality, effort, out.ctypes.data_as(C.POINTER(C.c_int32)), ptr(lam, f32p)) == 1
+    return int(out[0]), int(out[1]), int(out[2]), bool(out[3]), lam[0]
 
 
 class RefFrontend:

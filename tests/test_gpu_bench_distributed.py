@@ -81,3 +81,14 @@ def test_weak_scaling_mode_eight_ranks_share_the_gpu(single):
     assert per_rank == max(2, min(8, cpus // 8)), (cpus, per_rank)
     for k in ("final_endpoint_clusters", "final_selector_clusters"):   # rank 0's image is the single-GPU run's image (seed 1234 + rank)
         assert d["config"][k] == single["config"][k], k
+
+
+def test_sharded_image_mode_eight_ranks_share_the_gpu(single):
+    """`bench.py --gpus 8 --shard-image` as the driver would launch it: one image over eight ranks (slabs of 16 block rows each), strong scaling, the single-GPU result."""
+    d = _run(8, ["--shard-image"])
+    _contract(d, 8)
+    assert d["scaling"] == "strong" and "sharded" in d["config"]["parallelism"]
+    assert abs(d["value"] - 512 * 512 / 1e6 / (d["ms_per_step"] / 1e3)) / d["value"] < 0.01
+    for k in ("final_endpoint_clusters", "final_selector_clusters", "max_endpoint_clusters", "max_selector_clusters"):
+        assert d["config"][k] == single["config"][k], k
+    assert d["psnr"] == single["psnr"]

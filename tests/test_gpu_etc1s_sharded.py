@@ -63,6 +63,54 @@ def test_sharded_frontend_equals_single_gpu(tmp_path, case, world, wide_min):
         assert res["digest"] == golden, (r, {k: v[:10] for k, v in res["digest"].items() if v != golden[k]})
 
 
+def _big_worker(rank, world, port, tiles_path, g, out_dir):
+    import torch
+    import torch.distributed as dist
+    from basis_universal_amd import capi
+    from basis_universal_amd.etc1s import Etc1sFrontend, TorchComm
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["BU_HOST_THREADS"] = str(max(2, min(8, (os.cpu_count() or 8) // world)))     # the node's host cores divided over the ranks, as bench.py does
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ctx = capi.Context(0)
+        comm = TorchComm()
+        blocks = np.load(tiles_path, mmap_mode="r")
+        fe = Etc1sFrontend(ctx, comm, max_threads=g.get("threads", 1))
+        fe.init(np.ascontiguousarray(blocks), g["max_endpoint_clusters"], g["max_selector_clusters"], g["level"], g["perceptual"])
+        fe.compress()
+        digest = T._digest({k: fe.get(k) for k in T.STATE})
+        with open(os.path.join(out_dir, f"r{rank}.json"), "w") as f:
+            json.dump({"digest": digest, "calls": comm.calls, "error": comm.error}, f)
+        fe.close()
+        ctx.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case,world", [("synth4096_q128", 2), ("synth4096_q128", 8), ("synth4096_q128_t8", 8), ("synth8192_q255", 2), ("synth8192_q255_t8", 8)])
+def test_baseline_configs_sharded_over_ranks(tmp_path, case, world):
+    """BASELINE.json's configs[1] and configs[3] ("8192x8192 -q255, 8 x MI355X block-row shard + all-reduce for the global codebooks") in the form they are stated:
+    ONE image sharded over 2 and over 8 ranks (here: processes sharing the box's one GPU, gloo in the place of RCCL), single-tree and with the reference's default
+    8-thread codebook configuration (T = 8 independent trees whose rounds are shared out over the ranks). Every rank must end with the state the REFERENCE ends
+    with (tests/golden/etc1s_big_digests.json: tools/gen_golden_big.py ran oracle/_ref)."""
+    import pathlib
+    import torch.multiprocessing as mp
+    from helpers import synth, to_pixel_blocks
+    g = json.loads((pathlib.Path(__file__).parent / "golden" / "etc1s_big_digests.json").read_text())[case]
+    seed = {4096: 1234, 8192: 5678}[g["width"]]
+    tiles = tmp_path / "tiles.npy"
+    np.save(tiles, to_pixel_blocks(synth(g["width"], g["height"], seed)))
+    mp.spawn(_big_worker, args=(world, _free_port(), str(tiles), g, str(tmp_path)), nprocs=world, join=True)
+    tiles.unlink()
+    for r in range(world):
+        res = json.loads((tmp_path / f"r{r}.json").read_text())
+        assert res["error"] == ""
+        assert res["calls"]["all_gather"] > 0 and res["calls"]["all_reduce_u64"] > 0
+        assert res["digest"] == g["frontend_digests"], (r, {k: v[:10] for k, v in res["digest"].items() if v != g["frontend_digests"][k]})
+
+
 def _rccl_worker(rank, out_dir):
     import ctypes as C
     from basis_universal_amd import capi, etc1s

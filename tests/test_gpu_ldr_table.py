@@ -1,12 +1,14 @@
 """-m gpu: ALL 28 files and ALL three columns of the reference's own LDR golden table (g_etc1s_uastc_4x4_ldr_test_files, basisu_tool.cpp:6737-6776,
-`basisu -test`), and the ETC1S half of its codec grid (g_codec_test_cases, basisu_tool_test_codecs.inl:13-103, `basisu -test_codecs ETC1S`), through
-compress() -- image in, file out, every stage on the MI355X.
+`basisu -test`), and BOTH LDR halves of its codec grid (g_codec_test_cases, basisu_tool_test_codecs.inl:13-103 `basisu -test_codecs ETC1S` and :104-193
+`-test_codecs UASTC_LDR_4x4`), through compress() -- image in, file out, every stage on the MI355X.
 
 tests/test_gpu_kodak24.py holds kodim01..24 to the quality-128 and UASTC columns; this file adds
   * the quality-1 column (m_etc1s_size / m_etc1s_psnr) for all 28 files,
   * the four non-Kodak files in every column: black_1x1, white_1x1 (one block), wikipedia (1845x894: both dimensions padded, text edges),
     alpha0 (LA source: a colour and an alpha slice sharing the codebooks),
-  * the grid: kodim03 / 23 / 18, alpha0, wikipedia, black_1x1 x quality {10, 25, 50, 75, 100} x effort {0, 3, 6} -> .ktx2.
+  * the grid: kodim03 / 23 / 18, alpha0, wikipedia, black_1x1 x quality {10, 25, 50, 75, 100} x effort {0, 3, 6} -> .ktx2, for ETC1S and for UASTC LDR 4x4
+    (pack level 0 / 1 / 2 + the RDO post-pass at lambda 17.4 / 13.8 / 8.1 / 3.3 in four strips, none at quality 100; KTX2 without supercompression,
+    which is what run_codec_test_case writes: it never touches m_ktx2_uastc_supercompression, default KTX2_SS_NONE).
 Every case is held to the BYTES of the file the reference tool writes for the same settings first (tools/gen_golden_ldr_table.py ran oracle/_ref in the
 build container), then -- the reference's own acceptance rule (basisu_tool.cpp:6786-6793, 7855-7990) -- to the table's size within 4.5 % (50 % below
 2,000 bytes in the grid) and RGBA PSNR within 0.3 dB. The PSNR is the one the reference tool printed for these very bytes."""
@@ -134,3 +136,29 @@ def test_codec_grid_etc1s(hip_ctx, images, case):
     data = _same_file(hip_ctx, images[name], g, ktx2=True, quality=g["etc1s_quality"], comp_level=g["comp_level"], srgb=True)
     want = GRID[case]
     assert abs(data.size / want - 1.0) <= (0.5 if want < 2000 else FILESIZE_THRESHOLD), (data.size, want)
+
+
+UGRID = GOLDEN["reference_table_codec_grid_uastc"]
+
+
+@pytest.mark.parametrize("case", sorted(UGRID))
+def test_codec_grid_uastc(hip_ctx, images, case):
+    """`basisu -test_codecs UASTC_LDR_4x4` (basisu_tool.cpp:7704-7753, 7855-7990): quality -> RDO lambda, effort -> pack level
+    (set_format_mode_and_quality_effort, comp.cpp:76-205 = compress.unified_quality_effort), multithreaded (four RDO strips), sRGB metrics, .ktx2 without
+    supercompression. Exact against the file the reference tool writes for `-quality Q -effort E`, then the grid's own rule on size and the three PSNRs
+    (the PSNRs are the ones the reference tool printed for these very bytes; its tighter tolerance set, .125 dB, is used)."""
+    from basis_universal_amd.compress import unified_quality_effort
+    g = GOLDEN["codec_grid_uastc"][case]
+    name, q, e = re.match(r"(\w+)/q(\d+)/e(\d+)", case).groups()
+    kw = unified_quality_effort(True, int(q), int(e))
+    assert kw["uastc_level"] == g["uastc_level"] and (kw["uastc_rdo_lambda"] is not None) == g["rdo"]
+    if g["rdo"]:
+        assert np.float32(kw["uastc_rdo_lambda"]).tobytes().hex() == g["rdo_lambda_f32_hex"]
+    data = _same_file(hip_ctx, images[name], g, ktx2=True, srgb=True, uastc_rdo_jobs=g["rdo_jobs"], **kw)
+    row = UGRID[case]
+    assert abs(data.size / row["size"] - 1.0) <= (0.5 if row["size"] < 2048 else FILESIZE_THRESHOLD), (data.size, row["size"])
+    for want, got in ((row["rgb"], g["tool_psnr_rgb"]), (row["rgba"], g["tool_psnr_rgba_slice0"]), (row["bc7_rgba"], g["tool_psnr_bc7_rgba"])):
+        if want >= 99.0:          # LDR_SENTINEL_PSNR: lossless rows only need to stay very high
+            assert got >= 79.0, (want, got)
+        elif got < 55.0:
+            assert abs(got - want) <= 0.125, (want, got)

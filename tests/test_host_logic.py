@@ -214,3 +214,21 @@ def test_rccl_group_communicators_need_one_thread_each():
     assert seen["r0"][0] == 0 and "driven by another host thread" in seen["r0"][1]
     for c in comms:
         L.bu_rccl_comm_destroy(C.c_void_p(c))
+
+
+@pytest.mark.skipif(not have_ref(), reason="oracle/_ref not present")
+def test_unified_quality_effort_matches_the_reference():
+    """compress.unified_quality_effort = basis_compressor_params::set_format_mode_and_quality_effort (comp.cpp:76-205) for every quality 1..100 x effort 0..10
+    and the 'not given' value -1, both LDR formats; the RDO lambda bit for bit (binary32)."""
+    from helpers import ref_quality_effort
+    from basis_universal_amd.compress import unified_quality_effort
+    for q in [-1] + list(range(1, 101)):
+        for e in range(-1, 11):
+            rq, rl, _, _, _ = ref_quality_effort(False, q, e)
+            got = unified_quality_effort(False, q, e)
+            assert got.get("quality", -1) == rq and got["comp_level"] == rl, (q, e, got, rq, rl)
+            _, _, flags, rdo, lam = ref_quality_effort(True, q, e)
+            got = unified_quality_effort(True, q, e)
+            assert got["uastc_level"] == flags and (got["uastc_rdo_lambda"] is not None) == rdo, (q, e, got, flags, rdo)
+            if rdo:
+                assert np.float32(got["uastc_rdo_lambda"]).tobytes() == np.float32(lam).tobytes(), (q, got["uastc_rdo_lambda"], lam)

@@ -5,7 +5,12 @@
     (1845x894: neither dimension a multiple of 4, text edges), alpha0 (LA source -> colour + alpha slices) -- and THREE columns: ETC1S quality 1
     (m_etc1s_size / m_etc1s_psnr: basis_compress with no quality bits = max(1, 0), comp.cpp:5741), ETC1S quality 128, UASTC.
   * the ETC1S half of g_codec_test_cases (basisu_tool_test_codecs.inl:13-103, `basisu -test_codecs ETC1S`): kodim03 / 23 / 18, alpha0, wikipedia,
-    black_1x1 x quality {10, 25, 50, 75, 100} x effort {0, 3, 6} -> .ktx2 size (the UASTC half needs Zstandard, which is out of scope).
+    black_1x1 x quality {10, 25, 50, 75, 100} x effort {0, 3, 6} -> .ktx2 size.
+  * the UASTC LDR 4x4 half of the same grid (basisu_tool_test_codecs.inl:104-193, `basisu -test_codecs UASTC_LDR_4x4`): run_codec_test_case
+    (basisu_tool.cpp:7704-7753) leaves m_ktx2_uastc_supercompression at its default KTX2_SS_NONE (comp.h:323), so these are plain UASTC level
+    round(0.4 effort) + the RDO post-pass at lambda = 20 (1 - quality/100)^1.3 (quality 100: no post-pass), four strips, written without
+    Zstandard: `basisu -ktx2 -ktx2_no_zstandard -uastc -quality Q -effort E` in the tool's default (multi-threaded) configuration.
+    `python tools/gen_golden_ldr_table.py uastc_grid` makes only this section (~2 minutes).
 
 Writes
   tests/golden/ldr_extra.npz          the four non-Kodak images as RGBA u8 (fixtures of the reference, test_files/*.png; the GPU box has none)
@@ -52,14 +57,19 @@ def low_level(quality, effort):
     return int(math.floor(255.0 * quality / 100.0 + 0.5)), int(math.floor(6.0 * min(effort, 10) / 10.0 + 0.5))
 
 
-def run_tool(png, *args, ktx2=False, multithreaded=False):
-    """-> (file bytes, the RGBA Avg PSNR the tool prints for slice 0)"""
+def run_tool(png, *args, ktx2=False, multithreaded=False, all_psnrs=False):
+    """-> (file bytes, the RGBA Avg PSNR the tool prints for slice 0); all_psnrs: (file bytes, {rgb, rgba, bc7_rgba})"""
     with tempfile.TemporaryDirectory() as d:
         shutil.copy(png, pathlib.Path(d) / "in.png")
         cmd = [str(helpers.ORACLE_DIR / "_ref" / "basisu"), "-ktx2" if ktx2 else "-basis", *([] if multithreaded else ["-no_multithreading"]), "-stats", *args, "in.png"]
         r = subprocess.run(cmd, cwd=d, capture_output=True, text=True, timeout=900)
         outs = sorted(pathlib.Path(d).glob("*.ktx2" if ktx2 else "*.basis"))
         assert r.returncode == 0 and len(outs) == 1, r.stdout[-2000:] + r.stderr[-2000:]
+        if all_psnrs:
+            def grab(label):
+                mm = re.search(r"^" + label + r" Avg:\s+Max:\s*\S+\s+Mean:\s*\S+\s+RMS:\s*\S+\s+PSNR:\s*([0-9.]+)", r.stdout, re.M)
+                return float(mm.group(1)) if mm else None
+            return np.fromfile(outs[0], np.uint8), {"rgb": grab("RGB"), "rgba": grab("RGBA"), "bc7_rgba": grab("BC7 RGBA")}
         m = re.search(r"^RGBA Avg:\s+Max:\s*\S+\s+Mean:\s*\S+\s+RMS:\s*\S+\s+PSNR:\s*([0-9.]+)", r.stdout, re.M)
         return np.fromfile(outs[0], np.uint8), (float(m.group(1)) if m else None)
 
@@ -69,7 +79,40 @@ def file_record(data, psnr, ktx2):
     return {"size": int(data.size), "sha256": sha(data), "key_values": [[k, bytes(v).hex()] for k, v in kv], "tool_psnr_rgba_slice0": psnr}
 
 
+def uastc_grid(out):
+    """the 90 cUASTC_LDR_4x4 rows: the file the tool writes for -quality / -effort, the three PSNRs it prints, and the low-level settings the pair maps to
+    (from the reference's own set_format_mode_and_quality_effort through the harness)"""
+    tf = helpers.REF_DIR / "test_files"
+    grid = out.setdefault("codec_grid_uastc", {})
+    import os
+    # the table's own rows (file, quality, effort -> ktx2 size, RGB / RGBA / BC7 RGBA PSNR), read from the reference's generated header
+    rows = {}
+    for m in re.finditer(r'\{ "(\w+)\.png", basist::basis_tex_format::cUASTC_LDR_4x4, (\d+), (\d+), false, (\d+), ([0-9.]+)f, ([0-9.]+)f, ([0-9.]+)f \}',
+                         (helpers.REF_DIR / "basisu_tool_test_codecs.inl").read_text()):
+        rows[f"{m.group(1)}/q{m.group(2)}/e{m.group(3)}"] = {"size": int(m.group(4)), "rgb": float(m.group(5)), "rgba": float(m.group(6)), "bc7_rgba": float(m.group(7))}
+    assert len(rows) == 90, len(rows)
+    out["reference_table_codec_grid_uastc"] = rows
+    out["codec_grid_uastc_tool_threads"] = os.cpu_count()      # the post-pass takes min(4, pool threads) strips (comp.cpp:2078)
+    assert os.cpu_count() >= 4
+    for name in CODEC_FILES:
+        for q in QUALITIES:
+            for e in EFFORTS:
+                _, _, flags, rdo, lam = helpers.ref_quality_effort(True, q, e)
+                data, psnrs = run_tool(tf / f"{name}.png", "-ktx2_no_zstandard", "-uastc", "-quality", str(q), "-effort", str(e), ktx2=True, multithreaded=True, all_psnrs=True)
+                rec = file_record(data, psnrs["rgba"], True)
+                rec.update(tool_psnr_rgb=psnrs["rgb"], tool_psnr_bc7_rgba=psnrs["bc7_rgba"], uastc_level=flags, rdo=bool(rdo),
+                           rdo_lambda_f32_hex=np.float32(lam).tobytes().hex(), rdo_jobs=4)
+                grid[f"{name}/q{q}/e{e}"] = rec
+        print("uastc grid", name, flush=True)
+        OUT.write_text(json.dumps(out, indent=1, sort_keys=True) + "\n")
+
+
 def main():
+    if sys.argv[1:] == ["uastc_grid"]:
+        out = json.loads(OUT.read_text())
+        uastc_grid(out)
+        OUT.write_text(json.dumps(out, indent=1, sort_keys=True) + "\n")
+        return
     tf = helpers.REF_DIR / "test_files"
     extra = {n: helpers.load_png(tf / f"{n}.png") for n in EXTRA}
     np.savez_compressed(NPZ, **extra)
@@ -115,6 +158,7 @@ def main():
                 grid[f"{name}/q{q}/e{e}"] = dict(file_record(data, psnr, True), etc1s_quality=ql, comp_level=lvl)
         print("grid", name, flush=True)
         OUT.write_text(json.dumps(out, indent=1, sort_keys=True) + "\n")
+    uastc_grid(out)
     OUT.write_text(json.dumps(out, indent=1, sort_keys=True) + "\n")
 
 
