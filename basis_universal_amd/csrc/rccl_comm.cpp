@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -19,12 +20,14 @@
 static_assert(BU_RCCL_UNIQUE_ID_BYTES == sizeof(ncclUniqueId), "unique id size");
 
 // The communicators one bu_rccl_comm_init_all call made live in ONE process. A collective only completes once every rank has enqueued its part, so a host thread
-// that drives two of them in turn waits inside the first call for the second it has not made yet: each communicator of a group is bound to the first thread that
-// issues a collective on it, and a thread that already drives another member of the group gets an error instead of a hang.
+// that walks the ranks of ONE collective in turn waits (inside RCCL, or at its next stream synchronisation) for a part it has not issued yet. The ranks of a group
+// issue the same sequence of collectives, so the rule is stated on that sequence: a thread that has issued collective number e (or a later one) for rank j may not
+// issue number e for another rank i -- it gets an error instead of a hang. Nothing is bound for longer than that: any thread may issue a rank's NEXT collective
+// (executor pools), and threads are told apart by a token that is never handed out twice (std::thread::id values are reused once a thread has exited).
 struct comm_group {
     std::mutex lock;
-    std::vector<std::thread::id> owner;
-    std::vector<uint8_t> owned;
+    std::vector<uint64_t> seq;         // collectives let through so far, per rank
+    std::vector<uint64_t> last_token;  // who issued the last one (0 = nobody yet)
     uint32_t alive = 0;
 };
 struct bu_rccl_comm {
@@ -47,18 +50,22 @@ int fail(const char* fmt, ...) {
     return 0;
 }
 
-// 1 = this thread may drive c; 0 = it already drives another communicator of the same bu_rccl_comm_init_all group
+std::atomic<uint64_t> g_next_token{1};
+uint64_t thread_token() { static thread_local uint64_t t = g_next_token.fetch_add(1, std::memory_order_relaxed); return t; }
+
+// 1 = this thread may issue rank c->rank's next collective; 0 = it has already issued that collective (or a later one) for another rank of the group
 int thread_rule(bu_rccl_comm* c, const char* what) {
     if (!c->group) return 1;
     comm_group& g = *c->group;
-    const std::thread::id me = std::this_thread::get_id();
+    const uint64_t me = thread_token();
     std::lock_guard<std::mutex> lk(g.lock);
-    for (uint32_t j = 0; j < g.owner.size(); j++)
-        if (j != c->rank && g.owned[j] && g.owner[j] == me)
-            return fail("%s: this host thread already drives rank %u of the same bu_rccl_comm_init_all group; a collective completes only when every rank has enqueued "
-                        "its part, so every communicator of a group needs a thread of its own (include/basisu_hip_comm.h)", what, j);
-    if (g.owned[c->rank] && g.owner[c->rank] != me) return fail("%s: rank %u is driven by another host thread already", what, c->rank);
-    g.owned[c->rank] = 1; g.owner[c->rank] = me;
+    const uint64_t e = g.seq[c->rank];
+    for (uint32_t j = 0; j < g.seq.size(); j++)
+        if (j != c->rank && g.last_token[j] == me && g.seq[j] > e)
+            return fail("%s: this host thread has already issued collective #%llu for rank %u of the same bu_rccl_comm_init_all group and now issues #%llu for rank %u; a "
+                        "collective completes only when every rank has enqueued its part, so the ranks of one collective need a thread of their own each "
+                        "(include/basisu_hip_comm.h)", what, (unsigned long long)(g.seq[j] - 1), j, (unsigned long long)e, c->rank);
+    g.last_token[c->rank] = me; g.seq[c->rank] = e + 1;
     return 1;
 }
 
@@ -124,7 +131,7 @@ int bu_rccl_comm_init_all(bu_hip_context* const* ctxs, uint32_t n, bu_rccl_comm*
     if (r != ncclSuccess) return fail("ncclCommInitAll: %s", ncclGetErrorString(r));
     comm_group* grp = new (std::nothrow) comm_group();
     if (!grp) { for (uint32_t j = 0; j < n; j++) (void)ncclCommDestroy(comms[j]); return fail("comm_init_all: out of memory"); }
-    grp->owner.resize(n); grp->owned.assign(n, 0); grp->alive = n;
+    grp->seq.assign(n, 0); grp->last_token.assign(n, 0); grp->alive = n;
     for (uint32_t i = 0; i < n; i++) {
         bu_rccl_comm* c = new (std::nothrow) bu_rccl_comm();
         if (!c) { for (uint32_t j = 0; j < n; j++) { if (j < i) { delete out[j]; } (void)ncclCommDestroy(comms[j]); } delete grp; return fail("comm_init_all: out of memory"); }
@@ -140,7 +147,7 @@ int bu_rccl_debug_unconnected_group(uint32_t n, bu_rccl_comm** out) {
     if (!out || !n) return fail("debug_unconnected_group: bad arguments");
     comm_group* grp = new (std::nothrow) comm_group();
     if (!grp) return fail("debug_unconnected_group: out of memory");
-    grp->owner.resize(n); grp->owned.assign(n, 0); grp->alive = n;
+    grp->seq.assign(n, 0); grp->last_token.assign(n, 0); grp->alive = n;
     for (uint32_t i = 0; i < n; i++) {
         bu_rccl_comm* c = new (std::nothrow) bu_rccl_comm();
         if (!c) return fail("debug_unconnected_group: out of memory");
@@ -155,7 +162,7 @@ void bu_rccl_comm_destroy(bu_rccl_comm* c) {
     if (c->comm) (void)ncclCommDestroy(c->comm);
     if (c->group) {
         bool last;
-        { std::lock_guard<std::mutex> lk(c->group->lock); c->group->owned[c->rank] = 0; last = --c->group->alive == 0; }
+        { std::lock_guard<std::mutex> lk(c->group->lock); c->group->last_token[c->rank] = 0; last = --c->group->alive == 0; }
         if (last) delete c->group;
     }
     delete c;

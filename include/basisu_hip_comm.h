@@ -29,8 +29,10 @@ BU_HIP_API void bu_rccl_comm_destroy(bu_rccl_comm*);
  * Threading: drive each communicator from its own host thread (one thread per GPU, as basis_parallel_compress does); the N communicators of
  * bu_rccl_comm_init_all must not be driven in turn from ONE thread -- a collective only completes once every rank has enqueued its part. */
 BU_HIP_API int bu_rccl_comm_fill(bu_rccl_comm*, bu_comm* out);
-/* The threading rule above is ENFORCED for the communicators of one bu_rccl_comm_init_all call: each is bound to the first host thread that issues a collective on it,
- * and a collective from a thread that already drives another communicator of the group returns 0 (bu_rccl_last_error names both ranks) instead of waiting for ever.
+/* The threading rule above is ENFORCED for the communicators of one bu_rccl_comm_init_all call, on the sequence of collectives the ranks share: a host thread that has
+ * issued collective number e (or a later one) for one rank and then issues number e for ANOTHER rank of the group gets 0 (bu_rccl_last_error names both ranks and the
+ * number) instead of waiting for ever. Nothing else is bound: a rank's next collective may come from any thread (executor pools), and threads are told apart by tokens
+ * that are never reused, not by std::thread::id.
  * Test hook: n communicators of one group with no RCCL communicator behind them (their collectives fail with "no communicator" once the rule has let them through). */
 BU_HIP_API int bu_rccl_debug_unconnected_group(uint32_t n, bu_rccl_comm** out_comms);
 BU_HIP_API const char* bu_rccl_last_error(void);

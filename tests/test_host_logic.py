@@ -168,9 +168,10 @@ def test_rccl_communicator_library_exports_its_header():
 
 
 def test_rccl_group_communicators_need_one_thread_each():
-    """bu_rccl_comm_init_all's communicators live in one process; a host thread that drives two of them in turn would wait inside the first collective for the second it
-    has not issued yet. The library binds every communicator of a group to the first thread that uses it and turns the second use into an error (no GPU needed: the
-    group here has no RCCL communicator behind it, so a collective the rule lets through fails with "no communicator")."""
+    """bu_rccl_comm_init_all's communicators live in one process; a host thread that walks the ranks of ONE collective in turn would wait for a part it has not issued
+    yet. The library turns that into an error: a thread that has issued collective number e (or a later one) for rank j may not issue number e for rank i. Nothing is
+    bound beyond that -- a rank's NEXT collective may come from any thread (executor pools), and a new thread is never mistaken for a finished one whose id it
+    inherited. (No GPU needed: the group here has no RCCL communicator behind it, so a collective the rule lets through fails with "no communicator".)"""
     import ctypes as C
     import threading
     from basis_universal_amd import capi
@@ -192,26 +193,23 @@ def test_rccl_group_communicators_need_one_thread_each():
         ok = views[i].all_gather(views[i].user, None, 16)
         return ok, L.bu_rccl_last_error().decode()
 
-    ok, err = gather(0)                       # this thread takes rank 0: let through, then "no communicator"
+    ok, err = gather(0)                       # this thread issues collective #0 for rank 0: let through, then "no communicator"
     assert ok == 0 and "no communicator" in err
-    ok, err = gather(1)                       # the same thread on rank 1: the rule
-    assert ok == 0 and "already drives rank 0" in err and "thread of its own" in err
+    ok, err = gather(1)                       # the same thread with #0 for rank 1: the rule
+    assert ok == 0 and "already issued collective #0 for rank 0" in err and "thread of their own" in err
     ok, err = views[2].all_reduce_u64(views[2].user, None, 4), L.bu_rccl_last_error().decode()
-    assert ok == 0 and "already drives rank 0" in err
-    seen, done, hold = {}, threading.Event(), threading.Event()
-
-    def rank1_owner():
-        seen.update(r=gather(1))
-        done.set()
-        hold.wait(30)     # stays alive: a finished thread's id may be handed to the next thread, which would then BE rank 1's owner
-
-    t1 = threading.Thread(target=rank1_owner)                       # another thread may take rank 1 ...
-    t1.start(); done.wait(30)
-    assert seen["r"][0] == 0 and "no communicator" in seen["r"][1]
-    t = threading.Thread(target=lambda: seen.update(r0=gather(0)))  # ... but not rank 0, which has its thread
+    assert ok == 0 and "already issued collective #0 for rank 0" in err
+    seen = {}
+    for k in range(3):                        # short-lived threads one after the other (their ids get reused): #0 and #1 for rank 1, #0 for rank 2 -- all let through
+        t = threading.Thread(target=lambda k=k: seen.__setitem__(k, gather(1) if k < 2 else gather(2)))
+        t.start(); t.join()
+        assert seen[k][0] == 0 and "no communicator" in seen[k][1], seen[k]
+    t = threading.Thread(target=lambda: seen.update(r0=gather(0), r2=gather(2)))   # a pool thread takes rank 0's NEXT collective (#1) -- fine -- and then #1 of rank 2: the rule
     t.start(); t.join()
-    hold.set(); t1.join()
-    assert seen["r0"][0] == 0 and "driven by another host thread" in seen["r0"][1]
+    assert seen["r0"][0] == 0 and "no communicator" in seen["r0"][1]
+    assert seen["r2"][0] == 0 and "already issued collective #1 for rank 0" in seen["r2"][1]
+    ok, err = gather(1)                       # the first thread again: rank 1 is at #2 by now, ahead of everything this thread has issued: let through
+    assert ok == 0 and "no communicator" in err
     for c in comms:
         L.bu_rccl_comm_destroy(C.c_void_p(c))
 
