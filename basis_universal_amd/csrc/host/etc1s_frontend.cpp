@@ -388,7 +388,7 @@ bool etc1s_frontend::generate_endpoint_clusters() {
     // Per distinct vector, resident: its leaf (tmp_a), the position of its first block in the leaf's list (tmp_b), its parent (tmp_c); per leaf the list length
     // (out_u32). A leaf lists its distinct vectors ascending and each vector's blocks ascending (enc.h:1573-1584 + the training-vector order of frontend.cpp:825-866).
     if (!d.reserve(d.tmp_a, (size_t)u_total * 4) || !d.reserve(d.tmp_b, (size_t)u_total * 4) || !d.reserve(d.tmp_c, (size_t)u_total * 4) ||
-        !d.reserve(d.out_u32, (size_t)cMaxEndpointClusters * 4) || !d.reserve(d.block_cluster, (size_t)n * 4) || !d.reserve(d.ep_pos, (size_t)n * 4) || !d.reserve(d.ep_parent, n))
+        !d.reserve(d.out_u32, ((size_t)cMaxEndpointClusters + kThreadedCodebookMaxThreads) * 4) /* T trees of ceil(K/T) leaves: up to T - 1 more than K */ || !d.reserve(d.block_cluster, (size_t)n * 4) || !d.reserve(d.ep_pos, (size_t)n * 4) || !d.reserve(d.ep_parent, n))
         return fail("alloc");
     if (m_params.m_fast_codebooks && !std::getenv("BU_FAST_SELECTORS_ONLY")) {   // row f3: k-means on the matrix cores; the per-vector results come back (a few ten thousand words) for the list offsets below
         if (!bu_hip_kmeans_codebook(d.ctx, 1, d.ep_ukeys.p, nullptr, (const uint32_t*)d.ep_goffs.p, u_total, m_params.m_max_endpoint_clusters, want_parents,

@@ -71,6 +71,7 @@ __global__ __launch_bounds__(WB) void k6_sums(const float* __restrict__ rows, co
     __shared__ tiles6 T;
     __shared__ float s_origin[D6], s_axis[D6], s_lc[D6], s_rc[D6];
     __shared__ double s_part[8][12];
+    __shared__ uint8_t s_nz[8][12];   // some addend of the slice is not +-0
     __shared__ uint64_t s_red[4][5];
     __shared__ double s_tt[4][2];
     __shared__ uint32_t s_em[4][2];
@@ -131,8 +132,14 @@ __global__ __launch_bounds__(WB) void k6_sums(const float* __restrict__ rows, co
         const int c = item % NCH, sl = item / NCH;
         const int k = c % D6; const uint8_t want = (uint8_t)(c / D6);
         double s = 0;
-        for (int j = sl * 32; j < sl * 32 + 32; j++) s += (T.sd[j] == want) ? (double)T.fa[k][j] : 0.0;
+        uint32_t nz = 0;
+        for (int j = sl * 32; j < sl * 32 + 32; j++) {
+            const float a = (T.sd[j] == want) ? T.fa[k][j] : 0.0f;
+            s += (double)a;
+            nz |= __float_as_uint(a) << 1;   // anything but +-0
+        }
         s_part[sl][c] = s;
+        s_nz[sl][c] = nz ? 1 : 0;
     }
 #pragma unroll
     for (int i = 0; i < (MODE == W6_PROJ ? 5 : 3); i++) red[i] = wave_sum_u64(red[i]);   // totals in lane 63
@@ -151,9 +158,10 @@ __global__ __launch_bounds__(WB) void k6_sums(const float* __restrict__ rows, co
     __syncthreads();
     if (tid < NCH) {
         double s = 0;
-        for (int i = 0; i < 8; i++) s += s_part[i][tid];
+        uint32_t nz = 0;
+        for (int i = 0; i < 8; i++) { s += s_part[i][tid]; nz |= s_nz[i][tid]; }
         ws.bsum[ws.at(tid, blk)] = s;
-        ws.bzero[ws.at(tid, blk)] = s == 0.0 ? 1 : 0;   // addends are >= 0 here
+        ws.bzero[ws.at(tid, blk)] = nz ? 0 : 1;   // the block leaves the running sum alone only if EVERY addend is +-0 (signed rows can cancel to a zero sum)
     }
     if (tid >= 64 && tid < (MODE == W6_PROJ ? 69 : 67)) ws.bex[(size_t)blk * 8 + (tid - 64)] = s_red[0][tid - 64] + s_red[1][tid - 64] + s_red[2][tid - 64] + s_red[3][tid - 64];
     if ((MODE == W6_DIST || MODE == W6_ROOT) && tid >= 128 && tid < 130) {
