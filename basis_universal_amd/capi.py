@@ -66,6 +66,7 @@ _SIGNATURES = {
     "bu_hip_set_stream": (_int, [_vp, _vp]),
     "bu_hip_get_stream": (_vp, [_vp]),
     "bu_hip_sync": (_int, [_vp]),
+    "bu_hip_set_wait_hook": (_int, [_vp, _vp, _vp]),
     "bu_hip_last_error": (C.c_char_p, [_vp]),
     "bu_hip_profile_enable": (_int, [_vp, _int]),
     "bu_hip_profile_read": (_u32, [_vp, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(_u32), _u32]),

@@ -67,6 +67,7 @@ struct bu_hip_context {
     arena scratch[6];
     // pinned staging ring for host -> device uploads of pageable caller memory (see h2d below)
     void* stage = nullptr; size_t stage_cap = 0, stage_used = 0;
+    void* bounce = nullptr; size_t bounce_cap = 0;   // pinned bounce buffer of device -> host downloads under a wait hook (bu_hip_memcpy_d2h)
     std::string error;
     // bu_hip_malloc / bu_hip_free recycle blocks per context: an encoder frees and re-allocates the same dozen buffers for every
     // image, and hipMalloc/hipFree cost 0.1-1 ms each (hipFree also synchronises the device). Reuse is stream-ordered: everything
@@ -82,6 +83,8 @@ struct bu_hip_context {
     std::vector<prof_rec> prof_pending;
     struct prof_sum { const char* name; double ms; uint32_t launches; };
     std::vector<prof_sum> prof_totals;
+    // cooperative waiting (bu_hip_set_wait_hook): called between looks at the stream wherever a call on this context would block its host thread
+    bu_hip_wait_fn wait_hook = nullptr; void* wait_user = nullptr;
     // bu_hip_on_destroy registrations
     std::mutex closing_lock;
     std::vector<std::pair<bu_hip_destroy_fn, void*>> closing;
@@ -96,6 +99,25 @@ void set_error(bu_hip_context* ctx, const char* fmt, ...) {
 }
 
 #define BU_TRY(ctx, expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) { set_error(ctx, "%s: %s", #expr, hipGetErrorString(e__)); return 0; } } while (0)
+
+// Every wait of a call for its context's own stream. Default: block the host thread. With a wait hook (a host that runs several contexts as cooperative tasks
+// on one thread: bu_frontend_pipeline_*) the stream is only ever QUERIED and the hook runs between the looks -- it switches to another task and returns when it is
+// this one's turn again.
+hipError_t stream_wait(bu_hip_context* ctx, hipStream_t s) {
+    if (!ctx->wait_hook) return hipStreamSynchronize(s);
+    for (;;) {
+        const hipError_t e = hipStreamQuery(s);
+        if (e != hipErrorNotReady) return e;
+        ctx->wait_hook(ctx->wait_user);
+    }
+}
+
+// Device -> host copy into PAGEABLE caller memory, enqueued on the context's stream. The runtime blocks the calling thread inside such a copy until the stream has
+// drained; under a wait hook the draining is waited for cooperatively first, so that what blocks is only the (microseconds of a) copy from an idle stream.
+hipError_t d2h_pageable(bu_hip_context* ctx, void* h, const void* d, size_t bytes) {
+    if (ctx->wait_hook) { const hipError_t e = stream_wait(ctx, ctx->stream); if (e != hipSuccess) return e; }
+    return hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, ctx->stream);
+}
 
 struct device_guard {
     int prev = -1; bool ok = false;
@@ -152,7 +174,7 @@ hipError_t h2d(bu_hip_context* ctx, void* d, const void* h, size_t bytes) {
     }
     const size_t need = (bytes + 255) & ~(size_t)255;
     if (need > ctx->stage_cap - ctx->stage_used) {
-        if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) return e; // every copy out of the ring has completed
+        if ((e = stream_wait(ctx, ctx->stream)) != hipSuccess) return e; // every copy out of the ring has completed
         ctx->stage_used = 0;
         if (need > ctx->stage_cap) {
             if (ctx->stage) { (void)hipHostFree(ctx->stage); ctx->stage = nullptr; ctx->stage_cap = 0; }
@@ -277,7 +299,7 @@ void bu_hip_destroy_context(bu_hip_context* ctx) {
         }
         cb.first(cb.second);
     }
-    (void)hipStreamSynchronize(ctx->stream);
+    (void)stream_wait(ctx, ctx->stream);
     if (ctx->side_stream) (void)hipStreamSynchronize(ctx->side_stream);
     if (ctx->own_stream != ctx->stream) (void)hipStreamSynchronize(ctx->own_stream);
     prof_drain(ctx);
@@ -290,6 +312,7 @@ void bu_hip_destroy_context(bu_hip_context* ctx) {
         ctx->stage_used = 0;
         ctx->error.clear();
         ctx->profiling = false; ctx->prof_totals.clear();
+        ctx->wait_hook = nullptr; ctx->wait_user = nullptr;
         std::lock_guard<std::mutex> g(g_park_lock);
         if (g_parked.size() < park_limit()) { g_parked.push_back(ctx); return; }
     }
@@ -305,6 +328,7 @@ static void context_release(bu_hip_context* ctx) {
     for (auto& b : ctx->pool_free) (void)hipFree(b.p);
     for (auto& b : ctx->pool_live) (void)hipFree(b.p);
     if (ctx->stage) (void)hipHostFree(ctx->stage);
+    if (ctx->bounce) (void)hipHostFree(ctx->bounce);
     if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
     if (ctx->side_fork) (void)hipEventDestroy(ctx->side_fork);
     if (ctx->side_join) (void)hipEventDestroy(ctx->side_join);
@@ -315,7 +339,7 @@ static void context_release(bu_hip_context* ctx) {
 int bu_hip_context_device(const bu_hip_context* ctx) { return ctx ? ctx->device : -1; }
 int bu_hip_set_stream(bu_hip_context* ctx, void* s) {
     if (!ctx) return 0;
-    (void)hipStreamSynchronize(ctx->stream); // staged uploads still in flight belong to the old stream
+    (void)stream_wait(ctx, ctx->stream); // staged uploads still in flight belong to the old stream
     ctx->stage_used = 0;
     ctx->stream = s ? (hipStream_t)s : ctx->own_stream;
     return 1;
@@ -323,10 +347,16 @@ int bu_hip_set_stream(bu_hip_context* ctx, void* s) {
 void* bu_hip_get_stream(bu_hip_context* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
 const char* bu_hip_last_error(const bu_hip_context* ctx) { return ctx ? ctx->error.c_str() : g_global_error.c_str(); }
 
+int bu_hip_set_wait_hook(bu_hip_context* ctx, bu_hip_wait_fn fn, void* user) {
+    if (!ctx) return 0;
+    ctx->wait_hook = fn; ctx->wait_user = fn ? user : nullptr;
+    return 1;
+}
+
 int bu_hip_sync(bu_hip_context* ctx) {
     if (!ctx) return 0;
     device_guard g(ctx->device);
-    BU_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    BU_TRY(ctx, stream_wait(ctx, ctx->stream));
     return 1;
 }
 
@@ -351,7 +381,7 @@ void* bu_hip_malloc(bu_hip_context* ctx, size_t bytes) {
     if (hipMalloc(&p, want) != hipSuccess) {
         (void)hipGetLastError();
         // out of memory: drop the cache and retry once
-        (void)hipStreamSynchronize(ctx->stream);
+        (void)stream_wait(ctx, ctx->stream);
         for (auto& b : ctx->pool_free) (void)hipFree(b.p);
         ctx->pool_free.clear(); ctx->pool_free_bytes = 0;
         if (hipMalloc(&p, want) != hipSuccess) { set_error(ctx, "hipMalloc(%zu) failed", bytes); (void)hipGetLastError(); return nullptr; }
@@ -367,7 +397,7 @@ void bu_hip_free(bu_hip_context* ctx, void* p) {
             const bu_hip_context::pooled b = ctx->pool_live[i];
             ctx->pool_live.erase(ctx->pool_live.begin() + (long)i);
             if (ctx->pool_free_bytes + b.cap <= ((size_t)16 << 30)) { ctx->pool_free.push_back(b); ctx->pool_free_bytes += b.cap; return; }
-            (void)hipStreamSynchronize(ctx->stream);
+            (void)stream_wait(ctx, ctx->stream);
             (void)hipFree(p);
             return;
         }
@@ -380,7 +410,7 @@ int bu_hip_memcpy_h2d(bu_hip_context* ctx, void* d, const void* h, size_t bytes)
     if (!bytes) return 1;
     device_guard g(ctx->device);
     BU_TRY(ctx, h2d(ctx, d, h, bytes));
-    BU_TRY(ctx, hipStreamSynchronize(ctx->stream)); // h may be pageable and released by the caller right after
+    BU_TRY(ctx, stream_wait(ctx, ctx->stream)); // h may be pageable and released by the caller right after
     return 1;
 }
 // the same, stream-ordered: on return `h` has been copied out (into the context's pinned ring) and may be released; the device side is ordered with everything enqueued on
@@ -395,8 +425,26 @@ int bu_hip_memcpy_h2d_async(bu_hip_context* ctx, void* d, const void* h, size_t 
 int bu_hip_memcpy_d2h(bu_hip_context* ctx, void* h, const void* d, size_t bytes) {
     if (!ctx) return 0;
     device_guard g(ctx->device);
+    if (ctx->wait_hook && bytes > 4096) {
+        // cooperative host: hipMemcpyAsync into pageable memory would block this thread for the whole transfer (the runtime stages it synchronously). Through a pinned
+        // bounce buffer the transfer is a real stream-ordered DMA and the thread's other tasks run while it is in flight.
+        const size_t piece_max = (size_t)32 << 20;
+        const size_t want = std::min(bytes, piece_max);
+        if (want > ctx->bounce_cap) {
+            if (ctx->bounce) { (void)hipHostFree(ctx->bounce); ctx->bounce = nullptr; ctx->bounce_cap = 0; }
+            BU_TRY(ctx, hipHostMalloc(&ctx->bounce, want, hipHostMallocDefault));
+            ctx->bounce_cap = want;
+        }
+        for (size_t at = 0; at < bytes; at += piece_max) {
+            const size_t piece = std::min(bytes - at, piece_max);
+            BU_TRY(ctx, hipMemcpyAsync(ctx->bounce, static_cast<const char*>(d) + at, piece, hipMemcpyDeviceToHost, ctx->stream));
+            BU_TRY(ctx, stream_wait(ctx, ctx->stream));
+            std::memcpy(static_cast<char*>(h) + at, ctx->bounce, piece);
+        }
+        return 1;
+    }
     if (bytes) BU_TRY(ctx, hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, ctx->stream));
-    BU_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    BU_TRY(ctx, stream_wait(ctx, ctx->stream));
     return 1;
 }
 int bu_hip_memcpy_d2d(bu_hip_context* ctx, void* dst, const void* src, size_t bytes) {
@@ -440,7 +488,7 @@ int bu_hip_set_pixel_blocks(bu_hip_context* ctx, size_t total_blocks, const bu_p
     device_guard g(ctx->device);
     BU_TRY(ctx, ctx->pixel_arena.reserve(total_blocks * sizeof(bu_pixel_block)));
     if (total_blocks) BU_TRY(ctx, h2d(ctx, ctx->pixel_arena.p, blocks, total_blocks * sizeof(bu_pixel_block)));
-    BU_TRY(ctx, hipStreamSynchronize(ctx->stream)); // the caller may free its copy right after (frontend.cpp:67-79)
+    BU_TRY(ctx, stream_wait(ctx, ctx->stream)); // the caller may free its copy right after (frontend.cpp:67-79)
     ctx->d_pixel_blocks = ctx->pixel_arena.p;
     ctx->total_blocks = total_blocks;
     return 1;
@@ -502,7 +550,7 @@ int bu_hip_k_generate_endpoint_codebook_part(bu_hip_context* ctx, const void* d_
         BU_TRY(ctx, bu::launch_generate_endpoint_codebook(ctx->stream, d_px, (uint32_t)mine.size(), static_cast<const uint32_t*>(ord.p), d_offsets, d_indices,
                                                           quality, perceptual != 0, step, d_params, d_err, d_valid));
     }
-    BU_TRY(ctx, hipStreamSynchronize(ctx->stream)); // `mine` is pageable host memory owned by this call
+    BU_TRY(ctx, stream_wait(ctx, ctx->stream)); // `mine` is pageable host memory owned by this call
     return 1;
 }
 
@@ -529,7 +577,7 @@ int bu_hip_k_refit_endpoints_given_selectors_q(bu_hip_context* ctx, const void* 
         BU_TRY(ctx, bu::launch_refit_endpoints_given_selectors(ctx->stream, d_px, d_enc, n_clusters, static_cast<const uint32_t*>(ord.p), d_offsets, d_indices,
                                                                quality == BU_ETC_QUALITY_SLOW ? BU_ETC_QUALITY_SLOW : BU_ETC_QUALITY_UBER, perceptual != 0, d_params, d_err, d_valid, d_cur_err));
     }
-    BU_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    BU_TRY(ctx, stream_wait(ctx, ctx->stream));
     return 1;
 }
 
@@ -612,7 +660,7 @@ int bu_hip_k_resample_rgba8(bu_hip_context* ctx, const void* d_src, uint32_t src
                                               (const uint32_t*)(b + o_yf), (const uint16_t*)(b + o_yp), (const float*)(b + o_yw), x_after_y != 0, srgb != 0,
                                               (const float*)(b + o_t0), (const uint8_t*)(b + o_t1), num_comps, tmp.p));
     }
-    BU_TRY(ctx, hipStreamSynchronize(ctx->stream));  // the packed lists are reused by the next call
+    BU_TRY(ctx, stream_wait(ctx, ctx->stream));  // the packed lists are reused by the next call
     return 1;
 }
 
@@ -640,9 +688,9 @@ int bu_hip_k_create_optimized_selector_codebook(bu_hip_context* ctx, const void*
     if (!n_clusters) return 1;
     // how many members the offsets span (two dwords back from the device; the launch is sized by member count, not by cluster)
     uint32_t ends[2] = { 0, 0 };
-    BU_TRY(ctx, hipMemcpyAsync(&ends[0], d_offsets, 4, hipMemcpyDeviceToHost, ctx->stream));
-    BU_TRY(ctx, hipMemcpyAsync(&ends[1], d_offsets + n_clusters, 4, hipMemcpyDeviceToHost, ctx->stream));
-    BU_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    BU_TRY(ctx, d2h_pageable(ctx, &ends[0], d_offsets, 4));
+    BU_TRY(ctx, d2h_pageable(ctx, &ends[1], d_offsets + n_clusters, 4));
+    BU_TRY(ctx, stream_wait(ctx, ctx->stream));
     if (ends[1] < ends[0]) { set_error(ctx, "create_optimized_selector_codebook: offsets are not ascending"); return 0; }
     arena& ws = ctx->scratch[4];
     BU_TRY(ctx, ws.reserve(bu::create_optimized_selector_codebook_workspace_bytes(n_clusters)));
@@ -747,9 +795,9 @@ int bu_hip_kmeans_codebook(bu_hip_context* ctx, int kind, const void* d_keys, co
     }
     std::vector<uint64_t> sums((size_t)k * 17);
     std::vector<float> cen((size_t)k * 16);
-    BU_TRY(ctx, hipMemcpyAsync(sums.data(), b.sums, sums.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
-    BU_TRY(ctx, hipMemcpyAsync(cen.data(), b.cen, cen.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
-    BU_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    BU_TRY(ctx, d2h_pageable(ctx, sums.data(), b.sums, sums.size() * 8));
+    BU_TRY(ctx, d2h_pageable(ctx, cen.data(), b.cen, cen.size() * 4));
+    BU_TRY(ctx, stream_wait(ctx, ctx->stream));
     // non-empty clusters, in index order
     std::vector<uint32_t> old_to_new(k, 0), live;
     for (uint32_t c = 0; c < k; c++) if (sums[(size_t)c * 17 + 16]) { old_to_new[c] = (uint32_t)live.size(); live.push_back(c); }
@@ -797,7 +845,7 @@ int bu_hip_kmeans_codebook(bu_hip_context* ctx, int kind, const void* d_keys, co
     }
     BU_TRY(ctx, h2d(ctx, d_tab + k, old_to_new.data(), (size_t)k * 4));
     BU_TRY(ctx, bu::launch_gather_u32(ctx->stream, d_tab + k, d_cluster, n, d_cluster));
-    BU_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    BU_TRY(ctx, stream_wait(ctx, ctx->stream));
     (void)cen;
     return 1;
 }
@@ -861,7 +909,7 @@ extern "C" {
 void bu_hip_tsvq_destroy(bu_hip_context* ctx, bu_tsvq* q) {
     if (!ctx || !q) return;
     device_guard g(ctx->device);
-    (void)hipStreamSynchronize(ctx->stream);
+    (void)stream_wait(ctx, ctx->stream);
     for (void* p : {q->rows, (void*)q->w64, (void*)q->perm[0], (void*)q->perm[1], (void*)q->side, q->nodes.p, q->outs.p, q->xchg, q->wide_ws, q->wide_packed, (void*)q->wide_nodes, q->wide_ctrl_raw}) if (p) bu_hip_free(ctx, p);
     q->nodes.p = nullptr; q->outs.p = nullptr;
     if (q->pinned) {  // hand the pinned staging buffer back to the context (keep the larger one)
@@ -944,7 +992,7 @@ static bu_tsvq* tsvq_create_common(bu_hip_context* ctx, uint32_t dim, bool packe
         if (hipMemcpyAsync(q->rows, h_rows, (size_t)n * row_bytes, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess ||
             hipMemcpyAsync(q->w64, h_weights, (size_t)n * 8, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess)
             return fail("device copy");
-    } else if (hipStreamSynchronize(ctx->stream) != hipSuccess || hipMemcpy(q->rows, h_rows, (size_t)n * row_bytes, hipMemcpyHostToDevice) != hipSuccess ||
+    } else if (stream_wait(ctx, ctx->stream) != hipSuccess || hipMemcpy(q->rows, h_rows, (size_t)n * row_bytes, hipMemcpyHostToDevice) != hipSuccess ||
                hipMemcpy(q->w64, h_weights, (size_t)n * 8, hipMemcpyHostToDevice) != hipSuccess || hipDeviceSynchronize() != hipSuccess)
         return fail("upload");  // blocking copies (the sources are pageable, see bu_tsvq::pinned); the root kernel below needs both anyway
     if (q->reserve_pinned(std::max(sizeof(bu_tsvq_root), sizeof(bu::tsvq_wide_node))) != hipSuccess) return fail("pinned allocation");
@@ -969,7 +1017,7 @@ static bu_tsvq* tsvq_create_common(bu_hip_context* ctx, uint32_t dim, bool packe
             prof_scope ps(ctx, packed ? "tsvq_root_packed16" : "tsvq_root_float6");
             if (bu::launch_tsvq_root(ctx->stream, (int)dim, packed, exact, q->rows, q->w64, n, q->perm[0], static_cast<bu::tsvq_root_out*>(q->outs.p)) != hipSuccess) return fail("root launch");
         }
-        if (hipMemcpyAsync(q->pinned, q->outs.p, sizeof(bu_tsvq_root), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess)
+        if (hipMemcpyAsync(q->pinned, q->outs.p, sizeof(bu_tsvq_root), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || stream_wait(ctx, ctx->stream) != hipSuccess)
             return fail("root download");
         if ((attempt >= 0 && !exact) || static_cast<const bu_tsvq_root*>(q->pinned)->pad == 0) break;
     }
@@ -1008,8 +1056,8 @@ int bu_hip_k_unique_endpoint_vectors(bu_hip_context* ctx, const void* d_etc1_blo
         prof_scope ps(ctx, "unique_endpoint_vectors");
         BU_TRY(ctx, bu::launch_unique_endpoint_vectors(ctx->stream, d_etc1_blocks, n_blocks, ws.p, d_sorted_block_idx, d_unique_keys, d_group_offsets, &d_n));
     }
-    BU_TRY(ctx, hipMemcpyAsync(out_unique, d_n, 4, hipMemcpyDeviceToHost, ctx->stream));
-    BU_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    BU_TRY(ctx, d2h_pageable(ctx, out_unique, d_n, 4));
+    BU_TRY(ctx, stream_wait(ctx, ctx->stream));
     return 1;
 }
 
@@ -1031,8 +1079,8 @@ int bu_hip_k_unique_selector_vectors(bu_hip_context* ctx, const void* d_enc_bloc
         BU_TRY(ctx, bu::launch_unique_selector_vectors(ctx->stream, d_enc_blocks, d_weights, n_blocks, ws.p, d_sorted_block_idx, d_unique_keys, d_unique_weights,
                                                         d_group_offsets, &d_n));
     }
-    BU_TRY(ctx, hipMemcpyAsync(out_unique, d_n, 4, hipMemcpyDeviceToHost, ctx->stream));
-    BU_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    BU_TRY(ctx, d2h_pageable(ctx, out_unique, d_n, 4));
+    BU_TRY(ctx, stream_wait(ctx, ctx->stream));
     return 1;
 }
 
@@ -1123,7 +1171,7 @@ int bu_hip_tsvq_split(bu_hip_context* ctx, bu_tsvq* q, const bu_tsvq_node* h_nod
     }
     if (n_wide && q->dbg_stats && q->packed) {   // development aid: how the last pass's walks went, per wide node
         std::vector<bu::tsvq_wide_ctrl> hc(n_wide);
-        if (hipMemcpyAsync(hc.data(), q->wide_ctrl, hc.size() * sizeof(bu::tsvq_wide_ctrl), hipMemcpyDeviceToHost, ctx->stream) == hipSuccess && hipStreamSynchronize(ctx->stream) == hipSuccess)
+        if (d2h_pageable(ctx, hc.data(), q->wide_ctrl, hc.size() * sizeof(bu::tsvq_wide_ctrl)) == hipSuccess && stream_wait(ctx, ctx->stream) == hipSuccess)
             for (uint32_t i = 0; i < n_wide; i++) {
                 uint32_t ms = 0, mr = 0, ts = 0, tr = 0, ex = 0;
                 for (int c = 0; c < 32; c++) { ms = std::max<uint32_t>(ms, hc[i].stat_scans[c]); mr = std::max<uint32_t>(mr, hc[i].stat_raw[c]); ts += hc[i].stat_scans[c]; tr += hc[i].stat_raw[c]; ex += hc[i].exact[c]; }
@@ -1150,11 +1198,15 @@ int bu_hip_tsvq_split(bu_hip_context* ctx, bu_tsvq* q, const bu_tsvq_node* h_nod
         // can take milliseconds, and a spinning waiter takes a core from another image's host backend -- after 30 us the core is offered to whoever wants it, after
         // 2 ms the thread sleeps between looks. BU_TSVQ_POLL=spin|yield overrides.
         static const int poll_mode = [] { const char* e = std::getenv("BU_TSVQ_POLL"); return !e ? 0 : (e[0] == 's' ? 1 : 2); }();
-        const bool polite = poll_mode == 2 || (poll_mode == 0 && g_live_contexts.load(std::memory_order_relaxed) > 1);
+        const bool polite = !ctx->wait_hook && (poll_mode == 2 || (poll_mode == 0 && g_live_contexts.load(std::memory_order_relaxed) > 1));
         const auto t_wait0 = std::chrono::steady_clock::now();
         auto last_query = t_wait0;
         for (;;) {
             if (*round_flag == seq) break;
+            if (ctx->wait_hook) {   // cooperative: another task of this host thread runs while the round is on the device
+                ctx->wait_hook(ctx->wait_user);
+                if (*round_flag == seq) break;
+            }
             const auto t_now = std::chrono::steady_clock::now();
             if (polite && t_now - t_wait0 > std::chrono::microseconds(30)) {
                 if (t_now - t_wait0 > std::chrono::milliseconds(2)) std::this_thread::sleep_for(std::chrono::microseconds(50));
@@ -1163,7 +1215,7 @@ int bu_hip_tsvq_split(bu_hip_context* ctx, bu_tsvq* q, const bu_tsvq_node* h_nod
             if (t_now - last_query > std::chrono::microseconds(200)) {   // every 200 us: did the stream die, or finish without the flag becoming visible?
                 last_query = t_now;
                 const hipError_t e = hipStreamQuery(ctx->stream);
-                if (e == hipSuccess) { __atomic_thread_fence(__ATOMIC_SEQ_CST); if (*round_flag != seq) BU_TRY(ctx, hipStreamSynchronize(ctx->stream)); break; }
+                if (e == hipSuccess) { __atomic_thread_fence(__ATOMIC_SEQ_CST); if (*round_flag != seq) BU_TRY(ctx, stream_wait(ctx, ctx->stream)); break; }
                 if (e != hipErrorNotReady) { set_error(ctx, "tsvq_split: %s", hipGetErrorString(e)); return 0; }
             }
             __builtin_ia32_pause();
@@ -1171,7 +1223,7 @@ int bu_hip_tsvq_split(bu_hip_context* ctx, bu_tsvq* q, const bu_tsvq_node* h_nod
         __atomic_thread_fence(__ATOMIC_ACQUIRE);
     } else {
         BU_TRY(ctx, hipMemcpyAsync(q->pinned, q->outs.p, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
-        BU_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        BU_TRY(ctx, stream_wait(ctx, ctx->stream));
     }
     if (round_stats) {
         uint32_t mx = 0; uint64_t tot = 0;
@@ -1205,7 +1257,7 @@ int bu_hip_tsvq_split(bu_hip_context* ctx, bu_tsvq* q, const bu_tsvq_node* h_nod
                                                   static_cast<const bu::tsvq_node_in*>(q->nodes.p), (uint32_t)redo.size(), static_cast<bu::tsvq_split_out*>(q->outs.p)));
             }
             BU_TRY(ctx, hipMemcpyAsync(q->pinned, q->outs.p, redo.size() * sizeof(bu_tsvq_split), hipMemcpyDeviceToHost, ctx->stream));
-            BU_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            BU_TRY(ctx, stream_wait(ctx, ctx->stream));
             const bu_tsvq_split* po = static_cast<const bu_tsvq_split*>(q->pinned);
             for (size_t j = 0; j < redo.size(); j++) h_out[redo[j]] = po[j];
         }
@@ -1222,7 +1274,7 @@ int bu_hip_tsvq_roots(bu_hip_context* ctx, bu_tsvq* q, const bu_tsvq_node* h_nod
     if ((size_t)n_nodes * sizeof(bu_tsvq_node) > q->nodes.cap) { set_error(ctx, "tsvq_roots: %u spans exceed the record buffer", n_nodes); return 0; }
     for (uint32_t i = 0; i < n_nodes; i++)
         if (h_nodes[i].buf > 1 || !h_nodes[i].count || (uint64_t)h_nodes[i].start + h_nodes[i].count > q->n) { set_error(ctx, "tsvq_roots: span outside the training set"); return 0; }
-    BU_TRY(ctx, hipStreamSynchronize(ctx->stream));   // the pinned staging buffer may still feed an earlier copy
+    BU_TRY(ctx, stream_wait(ctx, ctx->stream));   // the pinned staging buffer may still feed an earlier copy
     BU_TRY(ctx, q->reserve_pinned((size_t)n_nodes * std::max(std::max(sizeof(bu_tsvq_node), sizeof(bu_tsvq_root)), sizeof(bu::tsvq_wide_node))));
     std::vector<uint32_t> todo;
     // large spans of packed rows: the many-workgroup root pass (one batch); a record flagged pad == 1 left its exact range -> the one-workgroup kernels below
@@ -1250,9 +1302,9 @@ int bu_hip_tsvq_roots(bu_hip_context* ctx, bu_tsvq* q, const bu_tsvq_node* h_nod
                 BU_TRY(ctx, bu::launch_tsvq_wide_span_roots(ctx->stream, static_cast<const uint32_t*>(q->rows), q->w64, q->perm[0], q->perm[1], q->wide_packed, q->wide_nodes,
                                                             (uint32_t)wide.size(), q->wide_ctrl, q->wide_ws, blocks, static_cast<bu::tsvq_root_out*>(q->outs.p)));
             }
-            BU_TRY(ctx, hipStreamSynchronize(ctx->stream));   // the node records were read from the pinned buffer the results come back to
+            BU_TRY(ctx, stream_wait(ctx, ctx->stream));   // the node records were read from the pinned buffer the results come back to
             BU_TRY(ctx, hipMemcpyAsync(q->pinned, q->outs.p, wide.size() * sizeof(bu_tsvq_root), hipMemcpyDeviceToHost, ctx->stream));
-            BU_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            BU_TRY(ctx, stream_wait(ctx, ctx->stream));
             const bu_tsvq_root* po = static_cast<const bu_tsvq_root*>(q->pinned);
             for (size_t j = 0; j < wide.size(); j++) {
                 if (po[j].pad) todo.push_back(wide[j]); else h_out[wide[j]] = po[j];
@@ -1273,9 +1325,9 @@ int bu_hip_tsvq_roots(bu_hip_context* ctx, bu_tsvq* q, const bu_tsvq_node* h_nod
             BU_TRY(ctx, bu::launch_tsvq_span_roots(ctx->stream, (int)q->dim, q->packed, attempt == 0, q->rows, q->w64, q->perm[0], q->perm[1],
                                                    static_cast<const bu::tsvq_node_in*>(q->nodes.p), (uint32_t)todo.size(), static_cast<bu::tsvq_root_out*>(q->outs.p)));
         }
-        BU_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        BU_TRY(ctx, stream_wait(ctx, ctx->stream));
         BU_TRY(ctx, hipMemcpyAsync(q->pinned, q->outs.p, todo.size() * sizeof(bu_tsvq_root), hipMemcpyDeviceToHost, ctx->stream));
-        BU_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        BU_TRY(ctx, stream_wait(ctx, ctx->stream));
         const bu_tsvq_root* po = static_cast<const bu_tsvq_root*>(q->pinned);
         std::vector<uint32_t> redo;
         for (size_t j = 0; j < todo.size(); j++) {
@@ -1294,12 +1346,12 @@ int bu_hip_tsvq_scatter_spans(bu_hip_context* ctx, bu_tsvq* q, const bu_tsvq_spa
     device_guard g(ctx->device);
     const size_t bytes = (size_t)n_spans * sizeof(bu_tsvq_span);
     if (bytes > q->nodes.cap) { set_error(ctx, "tsvq_scatter_spans: %u spans exceed the record buffer", n_spans); return 0; }
-    BU_TRY(ctx, hipStreamSynchronize(ctx->stream));   // the pinned staging buffer may still feed an earlier copy
+    BU_TRY(ctx, stream_wait(ctx, ctx->stream));   // the pinned staging buffer may still feed an earlier copy
     BU_TRY(ctx, q->reserve_pinned(bytes));
     std::memcpy(q->pinned, h_spans, bytes);
     BU_TRY(ctx, hipMemcpyAsync(q->nodes.p, q->pinned, bytes, hipMemcpyHostToDevice, ctx->stream));
     BU_TRY(ctx, bu::launch_scatter_spans(ctx->stream, q->perm[0], q->perm[1], static_cast<const bu::bk_span*>(q->nodes.p), n_spans, d_out));
-    BU_TRY(ctx, hipStreamSynchronize(ctx->stream));   // q may be destroyed (and the pinned buffer recycled) right after
+    BU_TRY(ctx, stream_wait(ctx, ctx->stream));   // q may be destroyed (and the pinned buffer recycled) right after
     return 1;
 }
 
@@ -1313,7 +1365,7 @@ int bu_hip_tsvq_finish_spans(bu_hip_context* ctx, bu_tsvq* q, const bu_tsvq_span
     BU_TRY(ctx, h2d(ctx, q->nodes.p, h_spans, bytes));   // through the context's pinned ring: the caller's array may go when this returns
     BU_TRY(ctx, bu::launch_finish_spans(ctx->stream, q->perm[0], q->perm[1], static_cast<const bu::bk_span*>(q->nodes.p), n_spans, d_leaf_of, d_parent_of, d_group_offsets, d_first_pos,
                                         d_sizes));
-    BU_TRY(ctx, hipStreamSynchronize(ctx->stream));   // q may be destroyed right after
+    BU_TRY(ctx, stream_wait(ctx, ctx->stream));   // q may be destroyed right after
     return 1;
 }
 
@@ -1356,7 +1408,7 @@ int bu_hip_tsvq_exchange_pack(bu_hip_context* ctx, bu_tsvq* q, const bu_tsvq_nod
     if (rec_at >= 8) BU_TRY(ctx, hipMemsetAsync(base + rec_at - 8, 0, 8, ctx->stream));   // the padding word of an odd child count
     BU_TRY(ctx, bu::launch_exchange_children(ctx->stream, q->perm[0], q->perm[1], reinterpret_cast<const bu::bk_span*>(base + tab_at),
                                              reinterpret_cast<const uint8_t*>(base + tab_at + (size_t)n_nodes * sizeof(bu::bk_span)), n_nodes, reinterpret_cast<uint32_t*>(base), 0));
-    BU_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    BU_TRY(ctx, stream_wait(ctx, ctx->stream));
     *d_staging = q->xchg;
     *n_u64 = tab_at / 8;
     return 1;
@@ -1374,16 +1426,16 @@ int bu_hip_tsvq_exchange_unpack(bu_hip_context* ctx, bu_tsvq* q, const bu_tsvq_n
     BU_TRY(ctx, h2d(ctx, base + tab_at + (size_t)n_nodes * sizeof(bu::bk_span), theirs.data(), n_nodes));
     BU_TRY(ctx, bu::launch_exchange_children(ctx->stream, q->perm[0], q->perm[1], reinterpret_cast<const bu::bk_span*>(base + tab_at),
                                              reinterpret_cast<const uint8_t*>(base + tab_at + (size_t)n_nodes * sizeof(bu::bk_span)), n_nodes, reinterpret_cast<uint32_t*>(base), 1));
-    BU_TRY(ctx, hipMemcpyAsync(h_records, base + rec_at, (size_t)n_nodes * sizeof(bu_tsvq_split), hipMemcpyDeviceToHost, ctx->stream));
-    BU_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    BU_TRY(ctx, d2h_pageable(ctx, h_records, base + rec_at, (size_t)n_nodes * sizeof(bu_tsvq_split)));
+    BU_TRY(ctx, stream_wait(ctx, ctx->stream));
     return 1;
 }
 
 int bu_hip_tsvq_read_members(bu_hip_context* ctx, bu_tsvq* q, uint32_t buf, uint32_t start, uint32_t count, uint32_t* h_out) {
     if (!ctx || !q || buf > 1 || (uint64_t)start + count > q->n) return 0;
     device_guard g(ctx->device);
-    if (count) BU_TRY(ctx, hipMemcpyAsync(h_out, q->perm[buf] + start, (size_t)count * 4, hipMemcpyDeviceToHost, ctx->stream));
-    BU_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (count) BU_TRY(ctx, d2h_pageable(ctx, h_out, q->perm[buf] + start, (size_t)count * 4));
+    BU_TRY(ctx, stream_wait(ctx, ctx->stream));
     return 1;
 }
 
@@ -1414,8 +1466,8 @@ int bu_hip_encode_uastc_blocks(bu_hip_context* ctx, bu_uastc_block* out, uint32_
     arena& o = ctx->scratch[0];
     BU_TRY(ctx, o.reserve((size_t)n * 16));
     if (!bu_hip_k_encode_uastc_blocks(ctx, ctx->d_pixel_blocks, n, flags, o.p)) return 0;
-    BU_TRY(ctx, hipMemcpyAsync(out, o.p, (size_t)n * 16, hipMemcpyDeviceToHost, ctx->stream));
-    BU_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    BU_TRY(ctx, d2h_pageable(ctx, out, o.p, (size_t)n * 16));
+    BU_TRY(ctx, stream_wait(ctx, ctx->stream));
     return 1;
 }
 
@@ -1449,8 +1501,8 @@ int bu_hip_k_uastc_rdo(bu_hip_context* ctx, void* d_blocks, const void* d_px, ui
     }
     // how many blocks each strip modified: sizes the finish launch (a 16-byte copy per 4 strips; the walk has to be over anyway)
     std::vector<uint32_t> per_strip(bu::uastc_rdo_strips(n_blocks, total_jobs));
-    BU_TRY(ctx, hipMemcpyAsync(per_strip.data(), bu::uastc_rdo_strip_counts(ws.p, n_blocks, total_jobs), per_strip.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
-    BU_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    BU_TRY(ctx, d2h_pageable(ctx, per_strip.data(), bu::uastc_rdo_strip_counts(ws.p, n_blocks, total_jobs), per_strip.size() * 4));
+    BU_TRY(ctx, stream_wait(ctx, ctx->stream));
     uint32_t longest = 0;
     for (uint32_t c : per_strip) longest = c > longest ? c : longest;
     {
@@ -1458,8 +1510,8 @@ int bu_hip_k_uastc_rdo(bu_hip_context* ctx, void* d_blocks, const void* d_px, ui
         BU_TRY(ctx, bu::launch_uastc_rdo_finish(ctx->stream, d_blocks, d_px, n_blocks, fp, up, flags, total_jobs, ws.p, longest));
     }
     uint32_t counters[4] = { 0, 0, 0, 0 };
-    BU_TRY(ctx, hipMemcpyAsync(counters, bu::uastc_rdo_counters(ws.p, n_blocks, total_jobs), sizeof(counters), hipMemcpyDeviceToHost, ctx->stream));
-    BU_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    BU_TRY(ctx, d2h_pageable(ctx, counters, bu::uastc_rdo_counters(ws.p, n_blocks, total_jobs), sizeof(counters)));
+    BU_TRY(ctx, stream_wait(ctx, ctx->stream));
 #ifdef RDO_PROFILE
     {
         unsigned long long prof[16];
@@ -1597,8 +1649,8 @@ int bu_hip_uastc_rdo(bu_hip_context* ctx, bu_uastc_block* blocks, const bu_uastc
     BU_TRY(ctx, o.reserve((size_t)n * 16));
     BU_TRY(ctx, h2d(ctx, o.p, blocks, (size_t)n * 16));
     if (!bu_hip_k_uastc_rdo(ctx, o.p, ctx->d_pixel_blocks, n, params, flags, total_jobs, out_stats)) return 0;
-    BU_TRY(ctx, hipMemcpyAsync(blocks, o.p, (size_t)n * 16, hipMemcpyDeviceToHost, ctx->stream));
-    BU_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    BU_TRY(ctx, d2h_pageable(ctx, blocks, o.p, (size_t)n * 16));
+    BU_TRY(ctx, stream_wait(ctx, ctx->stream));
     return 1;
 }
 
@@ -1609,8 +1661,8 @@ int bu_hip_encode_etc1s_blocks(bu_hip_context* ctx, bu_etc_block* out, int perce
     arena& o = ctx->scratch[0];
     BU_TRY(ctx, o.reserve((size_t)n * 8));
     BU_TRY(ctx, bu::launch_encode_etc1s_blocks(ctx->stream, ctx->d_pixel_blocks, n, quality_from_perms(total_perms), perceptual != 0, o.p));
-    BU_TRY(ctx, hipMemcpyAsync(out, o.p, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
-    BU_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    BU_TRY(ctx, d2h_pageable(ctx, out, o.p, (size_t)n * 8));
+    BU_TRY(ctx, stream_wait(ctx, ctx->stream));
     return 1;
 }
 
@@ -1623,8 +1675,8 @@ int bu_hip_determine_selectors(bu_hip_context* ctx, const bu_color_rgba* color5_
     BU_TRY(ctx, o.reserve((size_t)n * 8));
     BU_TRY(ctx, h2d(ctx, in.p, color5_inten, (size_t)n * 4));
     BU_TRY(ctx, bu::launch_determine_selectors(ctx->stream, ctx->d_pixel_blocks, n, static_cast<const uint8_t*>(in.p), nullptr, perceptual != 0, o.p));
-    BU_TRY(ctx, hipMemcpyAsync(out, o.p, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
-    BU_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    BU_TRY(ctx, d2h_pageable(ctx, out, o.p, (size_t)n * 8));
+    BU_TRY(ctx, stream_wait(ctx, ctx->stream));
     return 1;
 }
 
@@ -1683,8 +1735,8 @@ int bu_hip_refine_endpoint_clusterization(bu_hip_context* ctx, const bu_block_in
                                                           static_cast<const uint32_t*>(a_off.p), static_cast<const uint32_t*>(a_idx.p),
                                                           static_cast<const uint8_t*>(a_bp.p), perceptual != 0, static_cast<uint32_t*>(a_out.p), work));
     std::vector<uint32_t> pos(n);
-    BU_TRY(ctx, hipMemcpyAsync(pos.data(), a_out.p, n * 4ull, hipMemcpyDeviceToHost, ctx->stream));
-    BU_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    BU_TRY(ctx, d2h_pageable(ctx, pos.data(), a_out.p, n * 4ull));
+    BU_TRY(ctx, stream_wait(ctx, ctx->stream));
     for (uint32_t b = 0; b < n; b++) out[b] = clusters[pos[b]].m_cluster_index; // positions -> cluster indices (.cl:1150)
     return 1;
 }
@@ -1740,8 +1792,8 @@ int bu_hip_find_optimal_selector_clusters_for_each_block(bu_hip_context* ctx, co
                                                           static_cast<const uint32_t*>(a_off.p), static_cast<const uint32_t*>(a_idx.p), static_cast<const uint8_t*>(a_bp.p),
                                                           perceptual != 0, 0, static_cast<uint32_t*>(a_tmp.p), d_out));
     std::vector<uint32_t> pos(n);
-    BU_TRY(ctx, hipMemcpyAsync(pos.data(), d_out, n * 4ull, hipMemcpyDeviceToHost, ctx->stream));
-    BU_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    BU_TRY(ctx, d2h_pageable(ctx, pos.data(), d_out, n * 4ull));
+    BU_TRY(ctx, stream_wait(ctx, ctx->stream));
     for (uint32_t b = 0; b < n; b++) out[b] = selector_cluster_indices[pos[b]];
     return 1;
 }
@@ -1794,8 +1846,8 @@ int bu_hip_encode_etc1s_pixel_clusters(bu_hip_context* ctx, bu_etc_block* out, u
                                              std::max(quality_from_perms(total_perms), (int)bu::BU_Q_MEDIUM), perceptual, 0, d_params, d_err, d_valid))
         return 0;
     std::vector<uint8_t> params(total_clusters * 4ull);
-    BU_TRY(ctx, hipMemcpyAsync(params.data(), d_params, params.size(), hipMemcpyDeviceToHost, ctx->stream));
-    BU_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    BU_TRY(ctx, d2h_pageable(ctx, params.data(), d_params, params.size()));
+    BU_TRY(ctx, stream_wait(ctx, ctx->stream));
     for (uint32_t c = 0; c < total_clusters; c++) {
         const uint64_t v = ((uint64_t)params[c * 4] << 59) | ((uint64_t)params[c * 4 + 1] << 51) | ((uint64_t)params[c * 4 + 2] << 43) |
                            ((uint64_t)params[c * 4 + 3] << 37) | ((uint64_t)params[c * 4 + 3] << 34) | (3ull << 32);

@@ -58,6 +58,24 @@ def load_frontend_library():
         L.bu_frontend_set_max_threads.argtypes = [_vp, C.c_uint32]
         L.bu_frontend_reference_max_threads.restype = C.c_uint32
         L.bu_frontend_reference_max_threads.argtypes = [C.c_int, C.c_uint32, C.c_uint32]
+        L.bu_frontend_pipeline_create.restype = _vp
+        L.bu_frontend_pipeline_create.argtypes = [C.c_int, C.c_uint32]
+        L.bu_frontend_pipeline_submit.restype = C.c_uint64
+        L.bu_frontend_pipeline_submit.argtypes = [_vp, _vp, C.c_uint32]
+        L.bu_frontend_pipeline_wait.restype = _vp
+        L.bu_frontend_pipeline_wait.argtypes = [_vp, C.c_uint64]
+        L.bu_frontend_pipeline_poll.restype = C.c_int
+        L.bu_frontend_pipeline_poll.argtypes = [_vp, C.c_uint64]
+        L.bu_frontend_pipeline_context.restype = _vp
+        L.bu_frontend_pipeline_context.argtypes = [_vp, _vp]
+        L.bu_frontend_pipeline_release.restype = C.c_int
+        L.bu_frontend_pipeline_release.argtypes = [_vp, _vp]
+        L.bu_frontend_pipeline_destroy.argtypes = [_vp]
+        L.bu_frontend_pipeline_error.restype = C.c_char_p
+        L.bu_frontend_pipeline_error.argtypes = [_vp]
+        L.bu_frontend_pipeline_stats.restype = C.c_uint32
+        L.bu_frontend_pipeline_stats.argtypes = [_vp, C.POINTER(C.c_double), C.c_uint32]
+        L.bu_host_last_exception.restype = C.c_char_p
         _lib = L
     return _lib
 
@@ -259,6 +277,95 @@ class Etc1sFrontend:
     def close(self):
         if self.h:
             self.L.bu_frontend_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class _FrontendJob(C.Structure):  # = bu_frontend_job, include/basisu_hip_frontend.h
+    _fields_ = [("h_blocks", _vp), ("d_blocks", _vp), ("n_blocks", C.c_uint32), ("max_endpoint_clusters", C.c_uint32), ("max_selector_clusters", C.c_uint32),
+                ("compression_level", C.c_uint32), ("perceptual", C.c_int32), ("max_threads", C.c_uint32), ("flags", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+class PipelinedFrontend(Etc1sFrontend):
+    """A finished frontend handed out by FrontendPipeline.wait(): every getter of Etc1sFrontend (and Etc1sBackend.from_frontend) works on it;
+    close() gives it -- and the context it ran on -- back to the pipeline."""
+
+    def __init__(self, pipeline, handle, keep):
+        self.L = pipeline.L
+        self.pipeline = pipeline
+        self.h = handle
+        self.ctx = None
+        self._keep = keep
+        self.comm = None
+
+    def close(self):
+        if self.h:
+            if self.pipeline.h:
+                self.L.bu_frontend_pipeline_release(self.pipeline.h, self.h)
+            self.h = None
+
+
+class FrontendPipeline:
+    """bu_frontend_pipeline_*: `lanes` ETC1S frontends in flight on one GPU, all driven by the library's ONE driver thread (cooperative tasks; no host thread
+    per image as in the reference's basis_parallel_compress, comp.cpp:5466-5559). submit() never blocks; wait(ticket) returns the finished frontend.
+
+        pipe = FrontendPipeline(device=0, lanes=4)
+        tickets = [pipe.submit(d_ptr, max_ep, max_sel, n_blocks=n) for d_ptr in images]
+        for t in tickets:
+            fe = pipe.wait(t); ...fe.get("encoded_blocks")...; fe.close()
+        pipe.close()"""
+
+    def __init__(self, device=0, lanes=3):
+        lib = capi.load_library()
+        if not lib.init(0):
+            raise capi.HipError("bu_hip_init failed: " + lib.last_error(None))
+        self.L = load_frontend_library()
+        self.h = self.L.bu_frontend_pipeline_create(int(device), int(lanes))
+        if not self.h:
+            raise capi.HipError("bu_frontend_pipeline_create failed: " + (self.L.bu_host_last_exception() or b"").decode())
+        self.lanes = int(lanes)
+        self._keep = {}
+
+    def submit(self, blocks, max_endpoint_clusters, max_selector_clusters, compression_level=1, perceptual=True, n_blocks=None, max_threads=0, video=False):
+        """blocks: an (n, 4, 4, 4) uint8 array of tiles (uploaded by the job; kept alive until the frontend is closed) or a device pointer with n_blocks=."""
+        job = _FrontendJob()
+        keep = None
+        if isinstance(blocks, np.ndarray):
+            keep = np.ascontiguousarray(blocks, np.uint8)
+            job.h_blocks, job.n_blocks = keep.ctypes.data, keep.size // 64
+        else:
+            job.d_blocks, job.n_blocks = int(blocks), int(n_blocks)
+        job.max_endpoint_clusters, job.max_selector_clusters = int(max_endpoint_clusters), int(max_selector_clusters)
+        job.compression_level, job.perceptual, job.max_threads, job.flags = int(compression_level), int(bool(perceptual)), int(max_threads), 1 if video else 0
+        t = int(self.L.bu_frontend_pipeline_submit(self.h, C.byref(job), C.sizeof(job)))
+        if not t:
+            raise capi.HipError("bu_frontend_pipeline_submit refused the job: " + (self.L.bu_host_last_exception() or b"").decode())
+        self._keep[t] = keep
+        return t
+
+    def poll(self, ticket):
+        return self.L.bu_frontend_pipeline_poll(self.h, int(ticket)) == 1
+
+    def wait(self, ticket):
+        h = self.L.bu_frontend_pipeline_wait(self.h, int(ticket))
+        keep = self._keep.pop(int(ticket), None)
+        if not h:
+            raise capi.HipError("frontend pipeline: " + self.L.bu_frontend_pipeline_error(self.h).decode())
+        return PipelinedFrontend(self, h, keep)
+
+    def stats(self):
+        v = (C.c_double * 6)()
+        self.L.bu_frontend_pipeline_stats(self.h, v, 6)
+        return dict(zip(("jobs", "task_switches", "yields", "idle_naps", "driver_busy_s", "driver_idle_s"), [float(x) for x in v]))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.bu_frontend_pipeline_destroy(self.h)
             self.h = None
 
     def __del__(self):

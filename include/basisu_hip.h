@@ -95,6 +95,13 @@ BU_HIP_API int   bu_hip_context_device(const bu_hip_context*);
 BU_HIP_API int   bu_hip_set_stream(bu_hip_context*, void* hip_stream);
 BU_HIP_API void* bu_hip_get_stream(bu_hip_context*);
 BU_HIP_API int   bu_hip_sync(bu_hip_context*);
+/* Cooperative waiting. By default a call that needs a device result blocks its host thread (hipStreamSynchronize, or a look-loop on a zero-copy flag). A host that
+ * drives SEVERAL contexts from ONE thread -- bu_frontend_pipeline_* (basisu_hip_frontend.h): every image in flight is a task with a stack of its own on the pipeline's
+ * one driver thread -- installs a hook instead: wherever a call on this context would block, the stream is only queried, and fn(user) is called between the looks;
+ * fn switches to another task and returns when it is this one's turn again. fn NULL removes the hook (parking a context removes it too). The reference has no
+ * counterpart: its opencl_context calls all end in clFinish (opencl.cpp:972-976), one blocked host thread per image in flight (comp.cpp:5466-5559). */
+typedef void (*bu_hip_wait_fn)(void* user);
+BU_HIP_API int   bu_hip_set_wait_hook(bu_hip_context*, bu_hip_wait_fn fn, void* user);
 BU_HIP_API const char* bu_hip_last_error(const bu_hip_context*); /* NULL context -> last global (init) error */
 
 /* Per-kernel timing with HIP events recorded on the launch stream around every section-2 kernel. enable(1) resets the totals;

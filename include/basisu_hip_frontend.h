@@ -79,6 +79,47 @@ BU_HIP_API uint32_t bu_frontend_stage_times(const bu_frontend*, const char** nam
    start) returns its failure value (0 / NULL) and leaves the exception's text here, per calling thread. */
 BU_HIP_API const char* bu_host_last_exception(void);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * N images in flight on one GPU, as library behaviour: bu_frontend_pipeline_*.
+ * The reference's throughput driver is basis_parallel_compress (encoder/basisu_comp.cpp:5466-5559): one host thread + one accelerator context per image in flight,
+ * every thread blocked in its calls. Here the images in flight are cooperative tasks on ONE driver thread owned by the pipeline (a stack each; the frontend code is
+ * the same): wherever a task's context would block on the device it yields (bu_hip_set_wait_hook), and the thread launches another image's kernels meanwhile. Half
+ * of a frontend step is a chain of small dependent launches that leaves the chip mostly idle, the other half fills it: lanes interleave on the device, and the host
+ * pays one thread for all of them instead of one spinning thread per image.
+ *   p = bu_frontend_pipeline_create(device, lanes);                      lanes = images in flight (1..16; 3-4 fill an MI355X at 4096^2)
+ *   t = bu_frontend_pipeline_submit(p, &job, sizeof(job));               never blocks: jobs beyond `lanes` queue in submission order; 0 = refused
+ *   fe = bu_frontend_pipeline_wait(p, t);                                blocks the CALLER until that job's init + compress have finished; NULL = it failed
+ *   ... every getter of this header / a backend (basisu_hip_backend.h) on fe, from the caller's thread; bu_frontend_pipeline_context(p, fe) is the context it ran on ...
+ *   bu_frontend_pipeline_release(p, fe);                                 destroys the frontend, hands its context back (parked, warm, for a later job)
+ *   bu_frontend_pipeline_destroy(p);                                     finishes what is queued, releases what nobody collected
+ * Results are bit-identical to bu_frontend_init + bu_frontend_compress on a context of one's own, whatever the number of lanes (tests/test_gpu_frontend_pipeline.py).
+ * Thread safety: submit / wait / poll / release may be called from any threads. Host tiles (h_blocks) must stay valid until the job's wait has returned. */
+typedef struct bu_frontend_pipeline bu_frontend_pipeline;
+enum { BU_FRONTEND_JOB_VIDEO = 1 };   /* bu_frontend_set_video */
+typedef struct bu_frontend_job {
+    const bu_pixel_block* h_blocks;   /* exactly one of: host tiles (uploaded by the job), */
+    const void* d_blocks;             /*                 tiles resident on the pipeline's device */
+    uint32_t n_blocks, max_endpoint_clusters, max_selector_clusters, compression_level;
+    int32_t perceptual;
+    uint32_t max_threads;             /* bu_frontend_set_max_threads: the reference's codebook thread configuration, 0 / 1 = -no_multithreading */
+    uint32_t flags;                   /* BU_FRONTEND_JOB_* */
+    uint32_t reserved;
+} bu_frontend_job;
+BU_HIP_API bu_frontend_pipeline* bu_frontend_pipeline_create(int device, uint32_t lanes);
+BU_HIP_API uint64_t bu_frontend_pipeline_submit(bu_frontend_pipeline*, const bu_frontend_job* job, uint32_t struct_bytes /* sizeof(bu_frontend_job) of the caller's header */);
+BU_HIP_API bu_frontend* bu_frontend_pipeline_wait(bu_frontend_pipeline*, uint64_t ticket);
+BU_HIP_API int bu_frontend_pipeline_poll(bu_frontend_pipeline*, uint64_t ticket);   /* 1 finished (wait will not block), 0 not yet, -1 unknown ticket */
+BU_HIP_API bu_hip_context* bu_frontend_pipeline_context(bu_frontend_pipeline*, bu_frontend*);
+BU_HIP_API int bu_frontend_pipeline_release(bu_frontend_pipeline*, bu_frontend*);
+BU_HIP_API void bu_frontend_pipeline_destroy(bu_frontend_pipeline*);
+BU_HIP_API const char* bu_frontend_pipeline_error(const bu_frontend_pipeline*);
+/* {jobs finished, task switches, yields, idle naps, driver seconds spent in tasks, driver seconds spent looking at idle streams}; returns 6. The driver naps
+ * (BU_PIPELINE_SLEEP_US, default 30) between looks once no task has had anything to do for BU_PIPELINE_SPIN_US (default 200). */
+BU_HIP_API uint32_t bu_frontend_pipeline_stats(bu_frontend_pipeline*, double* out, uint32_t cap);
+/* Test hook, no GPU needed: `tasks` self-test tasks (a pattern kept on the task's own stack across `yields` yields, an exception thrown and caught inside every third
+ * one, the first `failing` of them ending in an exception) through a `lanes`-lane pipeline; 1 = every stack intact at every resume, failures reported as failures. */
+BU_HIP_API int bu_frontend_pipeline_selftest(uint32_t lanes, uint32_t tasks, uint32_t yields, uint32_t failing);
+
 /* basis_compressor::process_frontend's quality -> codebook size mapping (comp.cpp:3325-3379). */
 BU_HIP_API void bu_etc1s_quality_to_clusters(int quality_level, uint32_t total_blocks, uint32_t* max_endpoint_clusters, uint32_t* max_selector_clusters);
 

@@ -230,3 +230,16 @@ def test_unified_quality_effort_matches_the_reference():
             assert got["uastc_level"] == flags and (got["uastc_rdo_lambda"] is not None) == rdo, (q, e, got, flags, rdo)
             if rdo:
                 assert np.float32(got["uastc_rdo_lambda"]).tobytes() == np.float32(lam).tobytes(), (q, got["uastc_rdo_lambda"], lam)
+
+
+def test_frontend_pipeline_scheduler_selftest():
+    """bu_frontend_pipeline_* (include/basisu_hip_frontend.h): the cooperative-task scheduler without a GPU -- tasks keep a pattern on their own stacks across thousands
+    of yields on the one driver thread, exceptions thrown and caught inside a task stay inside it, a task that ends in an exception is reported as a failed job."""
+    import ctypes as C
+    from basis_universal_amd import etc1s
+    L = etc1s.load_frontend_library()
+    L.bu_frontend_pipeline_selftest.argtypes = [C.c_uint32] * 4
+    for lanes, tasks, yields, failing in [(1, 3, 10, 0), (4, 40, 1000, 3), (16, 200, 50, 10), (3, 7, 0, 1)]:
+        assert L.bu_frontend_pipeline_selftest(lanes, tasks, yields, failing) == 1, (lanes, tasks, yields, failing)
+    assert C.sizeof(etc1s._FrontendJob) == 48   # = sizeof(bu_frontend_job): two pointers + eight 32-bit fields
+    assert L.bu_frontend_pipeline_create(0, 0) is None and L.bu_frontend_pipeline_create(0, 17) is None   # 1..16 lanes
