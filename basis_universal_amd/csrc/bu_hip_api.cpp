@@ -204,10 +204,8 @@ extern "C" {
 // ---------------------------------------------------------------------------------------------------------------- init
 
 int bu_hip_init(int /*force_serialization*/) {
-    // Streams of a process share a few hardware queues (ROCm's default: 4) and two streams on one queue run their kernels one after the other; the lanes of the UASTC
-    // pipeline and contexts used side by side want queues of their own. Read by the runtime when it starts: effective when this library is the first to touch HIP in
-    // the process, a no-op otherwise (set GPU_MAX_HW_QUEUES=8 in the environment then). Never overrides the user's own setting.
-    (void)setenv("GPU_MAX_HW_QUEUES", "8", 0);
+    // (No environment is touched here. Streams of a process share a few hardware queues -- GPU_MAX_HW_QUEUES, ROCm's default: 4 -- and two streams that land on one
+    // queue run their kernels one after the other; a host that wants more than four lanes side by side sets that variable itself before its first HIP call: INTEGRATION.md.)
     std::lock_guard<std::mutex> lock(g_init_mutex);
     if (g_initialized) return 1;
     int n = 0;

@@ -13,23 +13,9 @@
 #include "tsvq.h"
 #include "tsvq_device.h"
 
-#include <malloc.h>
-
 namespace bu {
 
 namespace {
-
-// The frontend allocates and frees tens of multi-megabyte index arrays per image. With glibc's default policy each of them is a
-// fresh mmap whose pages fault in one by one (~0.2 ms per MB) and is unmapped again on free; keeping large blocks on the heap makes
-// the second and later images reuse warm pages. Process-wide, so it can be switched off: BU_KEEP_MALLOC_DEFAULTS=1.
-struct allocator_policy {
-    allocator_policy() {
-        if (std::getenv("BU_KEEP_MALLOC_DEFAULTS")) return;
-        mallopt(M_MMAP_THRESHOLD, 1 << 30);
-        mallopt(M_TRIM_THRESHOLD, 1 << 30);
-        mallopt(M_TOP_PAD, 64 << 20);
-    }
-} g_allocator_policy;
 
 const uint32_t kEndpointParentCodebookSize = 16;          // frontend.cpp:40
 const uint32_t kSelectorParentCodebookSizeLevel01 = 32;   // frontend.cpp:41

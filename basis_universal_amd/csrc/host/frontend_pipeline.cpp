@@ -8,6 +8,7 @@
 // driver, which resumes the next task. One thread launches the kernels of all lanes; nobody blocks in the runtime.
 #include <ucontext.h>
 #include <sys/mman.h>
+#include <time.h>
 
 #include <atomic>
 #include <chrono>
@@ -75,6 +76,7 @@ struct bu_frontend_pipeline {
     // counters (bu_frontend_pipeline_stats)
     uint64_t n_switches = 0, n_idle_sleeps = 0, n_done = 0;
     double driver_busy_s = 0, driver_idle_s = 0;
+    std::atomic<double> driver_cpu_s{0};   // CLOCK_THREAD_CPUTIME_ID of the driver thread, refreshed once per finished job
 };
 
 namespace {
@@ -174,6 +176,8 @@ void drive(bu_frontend_pipeline* p) {
                 job* j = l.j;
                 l.j = nullptr;
                 {
+                    timespec ts;
+                    if (clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts) == 0) p->driver_cpu_s.store((double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec, std::memory_order_relaxed);
                     std::lock_guard<std::mutex> g(p->m);
                     j->done = true; p->active--; p->n_done++;
                 }
@@ -356,9 +360,9 @@ uint32_t bu_frontend_pipeline_stats(bu_frontend_pipeline* p, double* out, uint32
     std::lock_guard<std::mutex> g(p->m);
     uint64_t yields = 0;
     for (auto& l : p->lanes) yields += l.yields;
-    const double v[6] = {(double)p->n_done, (double)p->n_switches, (double)yields, (double)p->n_idle_sleeps, p->driver_busy_s, p->driver_idle_s};
-    for (uint32_t i = 0; i < 6 && i < cap; i++) out[i] = v[i];
-    return 6;
+    const double v[7] = {(double)p->n_done, (double)p->n_switches, (double)yields, (double)p->n_idle_sleeps, p->driver_busy_s, p->driver_idle_s, p->driver_cpu_s.load()};
+    for (uint32_t i = 0; i < 7 && i < cap; i++) out[i] = v[i];
+    return 7;
 }
 
 } // extern "C"

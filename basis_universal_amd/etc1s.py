@@ -359,9 +359,9 @@ class FrontendPipeline:
         return PipelinedFrontend(self, h, keep)
 
     def stats(self):
-        v = (C.c_double * 6)()
-        self.L.bu_frontend_pipeline_stats(self.h, v, 6)
-        return dict(zip(("jobs", "task_switches", "yields", "idle_naps", "driver_busy_s", "driver_idle_s"), [float(x) for x in v]))
+        v = (C.c_double * 7)()
+        self.L.bu_frontend_pipeline_stats(self.h, v, 7)
+        return dict(zip(("jobs", "task_switches", "yields", "idle_naps", "driver_busy_s", "driver_idle_s", "driver_cpu_s"), [float(x) for x in v]))
 
     def close(self):
         if getattr(self, "h", None):

@@ -212,15 +212,19 @@ def main():
 
     pipelined = None
     if args.streams <= 1 and not sharded and not args.no_pipelined:
-        fes, dt = run_in_flight(3, 6)
+        pipelined = pipelined_bench(local_rank, d_blocks, n_blocks, w, h, max_ep, max_sel, args, barrier)
+        if world > 1:
+            t = torch.tensor([pipelined.pop("_seconds")], device=red_dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            pipelined["value"] = round(world * pipelined["images"] * (w * h) / 1e6 / float(t.item()), 3)
+            pipelined["images"] *= world
+        pipelined.pop("_seconds", None)
+        # the same images-in-flight count the round-4 way, one host thread + context per image (what the reference's basis_parallel_compress does): the host cost
+        # of the pipeline's one driver thread is to be read against this
+        fes, dt = run_in_flight(PIPELINE_LANES, 2 * PIPELINE_LANES)
         for fe in fes:
             fe.close()
-        if world > 1:
-            t = torch.tensor([dt], device=red_dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
-        pipelined = {"images_in_flight_per_gpu": 3, "images": 6 * world, "value": round(world * 6 * (w * h) / 1e6 / dt, 3), "unit": "Mpixels/s",
-                     "note": "same work per image, three images in flight per GPU on three host threads / HIP streams (throughput mode; not the headline value)"}
+        pipelined["thread_per_image"] = {"images_in_flight_per_gpu": PIPELINE_LANES, "value": round(2 * PIPELINE_LANES * (w * h) / 1e6 / dt, 3), "unit": "Mpixels/s (this rank)"}
     whole_encoder = None
     if args.streams <= 1 and not sharded and not args.no_pipelined and world == 1:
         nf = max(1, args.backend_in_flight)
@@ -329,6 +333,41 @@ def main():
     ctx.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+PIPELINE_LANES = 4
+
+
+def pipelined_bench(device, d_blocks, n_blocks, w, h, max_ep, max_sel, args, barrier):
+    """Throughput mode of ONE GPU as library behaviour: bu_frontend_pipeline_* (include/basisu_hip_frontend.h) -- PIPELINE_LANES images in flight as cooperative
+    tasks on the library's one driver thread; the caller only submits and collects. Every image's state is checked against the reference's digests (outside
+    the timed region); host CPU seconds per image cover ALL threads of this process while the images were in flight."""
+    from basis_universal_amd.etc1s import FrontendPipeline
+    import torch
+    images = 4 * PIPELINE_LANES
+    pipe = FrontendPipeline(device, PIPELINE_LANES)
+    submit = lambda: pipe.submit(d_blocks.data_ptr(), max_ep, max_sel, args.level, True, n_blocks=n_blocks)
+    for _ in range(2):   # as many warm contexts as results are held at once below
+        for fe in [pipe.wait(t) for t in [submit() for _ in range(images)]]:
+            fe.close()
+    s0 = pipe.stats()
+    barrier()
+    cpu0, t0 = time.process_time(), time.perf_counter()
+    done = [pipe.wait(t) for t in [submit() for _ in range(images)]]
+    barrier()
+    dt, cpu = time.perf_counter() - t0, time.process_time() - cpu0
+    s1 = pipe.stats()
+    same = [headline_identical(fe, w, h, args) for fe in done]
+    for fe in done:
+        fe.close()
+    pipe.close()
+    return {"api": "bu_frontend_pipeline_* (one driver thread, cooperative tasks)", "images_in_flight_per_gpu": PIPELINE_LANES, "images": images,
+            "value": round(images * (w * h) / 1e6 / dt, 3), "unit": "Mpixels/s", "ms_per_image": round(dt / images * 1e3, 3),
+            "host_cpu_s_per_image": round(cpu / images, 5), "driver_thread_cpu_s_per_image": round((s1["driver_cpu_s"] - s0["driver_cpu_s"]) / images, 5),
+            "driver_s_per_image": {"in_tasks": round((s1["driver_busy_s"] - s0["driver_busy_s"]) / images, 5), "idle": round((s1["driver_idle_s"] - s0["driver_idle_s"]) / images, 5),
+                                   "yields": round((s1["yields"] - s0["yields"]) / images), "naps": round((s1["idle_naps"] - s0["idle_naps"]) / images, 1)},
+            "identical_to_reference": (all(same) if all(x is not None for x in same) else None), "_seconds": dt,
+            "note": "same work per image as the headline step, tiles resident; throughput mode, not the headline value"}
 
 
 def psnr_pair(decoded_rgb, img):
@@ -848,11 +887,12 @@ def end_to_end(helpers, args, img):
         if tool.exists():
             n_par = max(2, min(16, threads))   # (a sweep on the GPU box's 16 cores: 12 / 16 / 24 images in flight -> 375 / 405 / 390 Mpix/s before the allocator setting below)
             want = base_hash.get("stock_1_thread")   # every task of basis_parallel_compress owns a one-thread pool: the single-threaded codebooks
-            # Two runs. (1) As deployed: glibc's malloc backed by transparent huge pages (GLIBC_TUNABLES=glibc.malloc.hugetlb=1, glibc >= 2.35). Sixteen compressors allocate
-            # and release ~300 MB each per image (the reference's image copies and tile arrays above all); with 4 KiB pages that is ~75,000 page faults per image, all
-            # serialised on one address space's lock -- the faults, not the GPU or the backend, were what capped this mode at ~390 Mpix/s (tools/ab_parallel2.sh).
-            # (2) The same with the allocator's defaults.   One host thread per frontend / backend: the images are the parallelism here.
-            for key, tun in (("resident_parallel", "glibc.malloc.hugetlb=1"), ("resident_parallel_default_malloc", None)):
+            # Sixteen compressors allocate and release ~300 MB each per image (the reference's image copies and tile arrays above all); with glibc's defaults that is ~75,000
+            # page faults per image, all serialised on one address space's lock -- the faults, not the GPU or the backend, capped this mode at ~390 Mpix/s in round 4
+            # (tools/ab_parallel2.sh). The benchmark APPLICATION therefore links a recycling operator new of its own (csrc/host/block_pool.cpp compiled into
+            # process_bench_resident; the library itself keeps the same pool private and never touches the process's malloc). Second run for comparison: glibc's malloc
+            # on transparent huge pages (GLIBC_TUNABLES=glibc.malloc.hugetlb=1), round 4's setting.   One host thread per frontend / backend: the images are the parallelism here.
+            for key, tun in (("resident_parallel", None), ("resident_parallel_glibc_hugetlb", "glibc.malloc.hugetlb=1")):
                 env = dict(os.environ)
                 env.setdefault("BU_HOST_THREADS", "1")
                 if tun:

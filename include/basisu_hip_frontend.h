@@ -113,12 +113,18 @@ BU_HIP_API bu_hip_context* bu_frontend_pipeline_context(bu_frontend_pipeline*, b
 BU_HIP_API int bu_frontend_pipeline_release(bu_frontend_pipeline*, bu_frontend*);
 BU_HIP_API void bu_frontend_pipeline_destroy(bu_frontend_pipeline*);
 BU_HIP_API const char* bu_frontend_pipeline_error(const bu_frontend_pipeline*);
-/* {jobs finished, task switches, yields, idle naps, driver seconds spent in tasks, driver seconds spent looking at idle streams}; returns 6. The driver naps
+/* {jobs finished, task switches, yields, idle naps, driver seconds spent in tasks, driver seconds spent looking at idle streams, CPU seconds of the driver thread};
+ * returns 7. The driver naps
  * (BU_PIPELINE_SLEEP_US, default 30) between looks once no task has had anything to do for BU_PIPELINE_SPIN_US (default 200). */
 BU_HIP_API uint32_t bu_frontend_pipeline_stats(bu_frontend_pipeline*, double* out, uint32_t cap);
 /* Test hook, no GPU needed: `tasks` self-test tasks (a pattern kept on the task's own stack across `yields` yields, an exception thrown and caught inside every third
  * one, the first `failing` of them ending in an exception) through a `lanes`-lane pipeline; 1 = every stack intact at every resume, failures reported as failures. */
 BU_HIP_API int bu_frontend_pipeline_selftest(uint32_t lanes, uint32_t tasks, uint32_t yields, uint32_t failing);
+
+/* The library's own host allocations of 1 MiB and more (the per-image index arrays of the frontend and the backend) come from a recycling pool of its own instead of
+ * being mapped and unmapped per image (csrc/host/block_pool.cpp): local to this library -- the process's malloc is left alone. BU_HOST_POOL_MB (read once) = most
+ * megabytes kept cached, default 6144, 0 = off. out = {mappings made, blocks reused, bytes cached now, cap in bytes}. */
+BU_HIP_API void bu_host_pool_stats(uint64_t out[4]);
 
 /* basis_compressor::process_frontend's quality -> codebook size mapping (comp.cpp:3325-3379). */
 BU_HIP_API void bu_etc1s_quality_to_clusters(int quality_level, uint32_t total_blocks, uint32_t* max_endpoint_clusters, uint32_t* max_selector_clusters);

@@ -8,10 +8,17 @@
 //
 // The tiles travel to the GPU once (bu_frontend_init uploads them); every stage of basisu_frontend::compress (frontend.cpp:159-316)
 // then runs device-resident. There is no CPU fallback behind this file: a failing device call fails compress().
+//
+// Images in flight. Under basis_parallel_compress (comp.cpp:5466-5559) N compressors run on N host threads, each with a frontend of its own. All of them go
+// through ONE bu_frontend_pipeline per GPU (include/basisu_hip_frontend.h): compress() submits its image and sleeps until the pipeline's single driver thread has
+// taken it through init + compress as one of BU_RESIDENT_LANES (default 4) cooperative tasks; the N host threads keep their cores for tiling and the backends
+// instead of waiting on the device. BU_RESIDENT_LANES=0 restores one blocking frontend per calling thread.
 #include "encoder/basisu_frontend.h"
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <unordered_map>
 #include <vector>
@@ -25,22 +32,58 @@ struct registry {
     // object is init()ed again, init() fails (erased at once), or the backend is done with it (bu_resident_release at the end of
     // basisu_backend::encode). `blocks` is the per-init token: a basisu_frontend constructed at a recycled address whose init() never ran or
     // failed cannot resolve to the previous object's state, because find() is given the caller's own m_total_blocks.
-    struct entry { bu_frontend* f; uint32_t blocks; };
+    struct entry { bu_frontend* f; uint32_t blocks; bu_frontend_pipeline* pipe; };   // pipe != null: f belongs to that pipeline (null until compress() has collected it)
     std::mutex lock;
     std::unordered_map<const basisu::basisu_frontend*, entry> map;
+    std::map<int, bu_frontend_pipeline*> pipes;   // one per device
     bu_hip_context* own_ctx = nullptr;   // used when the caller did not ask for the accelerator seam (no -opencl): the resident build always runs on the GPU
+    static void drop(entry& e) {
+        if (!e.f) return;
+        if (e.pipe) bu_frontend_pipeline_release(e.pipe, e.f); else bu_frontend_destroy(e.f);
+        e.f = nullptr;
+    }
     ~registry() {
-        for (auto& kv : map) bu_frontend_destroy(kv.second.f);
+        for (auto& kv : map) drop(kv.second);
+        for (auto& kv : pipes) bu_frontend_pipeline_destroy(kv.second);
         if (own_ctx) bu_hip_destroy_context(own_ctx);
+    }
+    static uint32_t lanes() {
+        static const uint32_t n = [] { const char* e = std::getenv("BU_RESIDENT_LANES"); const long v = e ? std::atol(e) : 4; return (uint32_t)(v < 0 ? 0 : (v > 16 ? 16 : v)); }();
+        return n;
+    }
+    bu_frontend_pipeline* pipeline(int device) {
+        std::lock_guard<std::mutex> g(lock);
+        auto it = pipes.find(device);
+        if (it != pipes.end()) return it->second;
+        bu_frontend_pipeline* p = bu_frontend_pipeline_create(device, lanes());
+        if (p) pipes[device] = p;
+        return p;
     }
     bu_frontend* fresh(const basisu::basisu_frontend* key, uint32_t blocks) {
         std::lock_guard<std::mutex> g(lock);
         entry& slot = map[key];
-        if (slot.f) bu_frontend_destroy(slot.f);
+        drop(slot);
         slot.f = bu_frontend_create();
-        slot.blocks = blocks;
+        slot.blocks = blocks; slot.pipe = nullptr;
         if (!slot.f) { map.erase(key); return nullptr; }
         return slot.f;
+    }
+    // pipeline mode: init() only books the object; compress() brings the frontend
+    void book(const basisu::basisu_frontend* key, uint32_t blocks, bu_frontend_pipeline* pipe) {
+        std::lock_guard<std::mutex> g(lock);
+        entry& slot = map[key];
+        drop(slot);
+        slot.blocks = blocks; slot.pipe = pipe;
+    }
+    bu_frontend_pipeline* booked(const basisu::basisu_frontend* key, uint32_t blocks) {
+        std::lock_guard<std::mutex> g(lock);
+        auto it = map.find(key);
+        return (it == map.end() || it->second.blocks != blocks || it->second.f) ? nullptr : it->second.pipe;
+    }
+    void collected(const basisu::basisu_frontend* key, bu_frontend* f) {
+        std::lock_guard<std::mutex> g(lock);
+        auto it = map.find(key);
+        if (it != map.end()) it->second.f = f;
     }
     bu_frontend* find(const basisu::basisu_frontend* key, uint32_t blocks) {
         std::lock_guard<std::mutex> g(lock);
@@ -51,7 +94,7 @@ struct registry {
         std::lock_guard<std::mutex> g(lock);
         auto it = map.find(key);
         if (it == map.end()) return;
-        bu_frontend_destroy(it->second.f);   // gives the device buffers back
+        drop(it->second);   // gives the device buffers (and, in pipeline mode, the context the image ran on) back
         map.erase(it);
     }
     bu_hip_context* context() {
@@ -94,6 +137,12 @@ bool basisu_frontend::init(const params& p) {
 
     bu_hip_context* ctx = p.m_pOpenCL_context ? p.m_pOpenCL_context->h : reg().context();
     if (!ctx) { error_printf("basisu_frontend (resident): no HIP context\n"); return false; }
+    if (registry::lanes()) {   // images in flight: the work happens in compress(), as one task of the device's pipeline
+        bu_frontend_pipeline* pipe = reg().pipeline(bu_hip_context_device(ctx));
+        if (!pipe) { error_printf("basisu_frontend (resident): no frontend pipeline: %s\n", bu_host_last_exception()); return false; }
+        reg().book(this, m_total_blocks, pipe);
+        return true;
+    }
     bu_frontend* f = reg().fresh(this, m_total_blocks);
     if (!f) return false;
     static_assert(sizeof(pixel_block) == sizeof(bu_pixel_block) && sizeof(etc_block) == sizeof(bu_etc_block), "layout");
@@ -139,12 +188,34 @@ static bool refresh_members(bu_frontend* f, uint32_t n, etc_block_vec& encoded, 
 }
 
 bool basisu_frontend::compress() {
-    bu_frontend* f = reg().find(this, m_total_blocks);
-    if (!f) return false;
-    if (!bu_frontend_compress(f)) {
-        error_printf("basisu_frontend (resident): compress failed: %s\n", bu_frontend_error(f));
-        m_opencl_failed = true;   // basis_compressor reports it (comp.cpp:3449); there is no CPU path to continue on
-        return false;
+    bu_frontend* f = nullptr;
+    if (bu_frontend_pipeline* pipe = reg().booked(this, m_total_blocks)) {
+        const params& p = m_params;
+        bu_frontend_job job;
+        std::memset(&job, 0, sizeof(job));
+        job.h_blocks = reinterpret_cast<const bu_pixel_block*>(m_source_blocks.data());
+        job.n_blocks = p.m_num_source_blocks;
+        job.max_endpoint_clusters = p.m_max_endpoint_clusters; job.max_selector_clusters = p.m_max_selector_clusters;
+        job.compression_level = p.m_compression_level; job.perceptual = p.m_perceptual;
+        job.max_threads = bu_frontend_reference_max_threads(p.m_multithreaded, get_num_hardware_threads(), p.m_pJob_pool ? (uint32_t)p.m_pJob_pool->get_total_threads() : 0);
+        job.flags = p.m_tex_type == basist::cBASISTexTypeVideoFrames ? BU_FRONTEND_JOB_VIDEO : 0;
+        const uint64_t ticket = bu_frontend_pipeline_submit(pipe, &job, sizeof(job));
+        f = ticket ? bu_frontend_pipeline_wait(pipe, ticket) : nullptr;   // this thread sleeps; the pipeline's driver thread runs init + compress among the other images
+        if (!f) {
+            error_printf("basisu_frontend (resident): pipelined compress failed: %s\n", ticket ? bu_frontend_pipeline_error(pipe) : bu_host_last_exception());
+            m_opencl_failed = true;
+            reg().release(this);
+            return false;
+        }
+        reg().collected(this, f);
+    } else {
+        f = reg().find(this, m_total_blocks);
+        if (!f) return false;
+        if (!bu_frontend_compress(f)) {
+            error_printf("basisu_frontend (resident): compress failed: %s\n", bu_frontend_error(f));
+            m_opencl_failed = true;   // basis_compressor reports it (comp.cpp:3449); there is no CPU path to continue on
+            return false;
+        }
     }
     if (m_params.m_debug_stats) {
         const char* names[64]; double secs[64];

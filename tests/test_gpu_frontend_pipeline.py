@@ -81,19 +81,18 @@ def test_a_failing_job_fails_alone():
     pipe.close()
 
 
-def test_headline_image_four_in_flight():
+def test_headline_image_four_in_flight(hip_ctx):
     """BASELINE configs[1] (4096^2 q128 level 1), eight images through four lanes, single-threaded and the reference's 8-thread codebook configuration mixed:
     every one = the reference's digests"""
-    import torch
     from helpers import synth, to_pixel_blocks
     from basis_universal_amd.etc1s import FrontendPipeline
     big = json.loads((pathlib.Path(__file__).parent / "golden" / "etc1s_big_digests.json").read_text())
     g1, g8 = big["synth4096_q128"], big["synth4096_q128_t8"]
     blocks = to_pixel_blocks(synth(4096, 4096, 1234))
     n = blocks.shape[0]
-    d = torch.from_numpy(blocks.reshape(n, 64)).to("cuda:0")
+    d = hip_ctx.upload(blocks)   # (not a torch tensor: torch brings a HIP runtime of its own, which cannot start once this process has initialised the system's)
     pipe = FrontendPipeline(0, 4)
-    ts = [(pipe.submit(d.data_ptr(), g1["max_endpoint_clusters"], g1["max_selector_clusters"], g1["level"], g1["perceptual"], n_blocks=n, max_threads=(8 if i % 4 == 3 else 0)),
+    ts = [(pipe.submit(d, g1["max_endpoint_clusters"], g1["max_selector_clusters"], g1["level"], g1["perceptual"], n_blocks=n, max_threads=(8 if i % 4 == 3 else 0)),
            g8 if i % 4 == 3 else g1) for i in range(8)]
     for t, g in ts:
         fe = pipe.wait(t)
@@ -101,3 +100,4 @@ def test_headline_image_four_in_flight():
         fe.close()
         assert got == g["frontend_digests"], [k for k in got if got[k] != g["frontend_digests"][k]]
     pipe.close()
+    hip_ctx.free(d)

@@ -243,3 +243,30 @@ def test_frontend_pipeline_scheduler_selftest():
         assert L.bu_frontend_pipeline_selftest(lanes, tasks, yields, failing) == 1, (lanes, tasks, yields, failing)
     assert C.sizeof(etc1s._FrontendJob) == 48   # = sizeof(bu_frontend_job): two pointers + eight 32-bit fields
     assert L.bu_frontend_pipeline_create(0, 0) is None and L.bu_frontend_pipeline_create(0, 17) is None   # 1..16 lanes
+
+
+def test_host_block_pool_recycles_large_blocks_and_leaves_the_process_alone():
+    """csrc/host/block_pool.cpp: the library's own allocations of 1 MiB and more are recycled (second run of the same work maps nothing new), and nothing of it is
+    visible outside the library: no operator new / delete among its dynamic symbols, no mallopt call left in its sources."""
+    import pathlib, subprocess
+    from basis_universal_amd import etc1s
+    F = etc1s.load_frontend_library()
+    F.bu_host_pool_stats.argtypes = [C.POINTER(C.c_uint64)]
+    rng = np.random.default_rng(5)
+    v = np.ascontiguousarray(np.unique(rng.integers(0, 4, (120000, 16)).astype(np.float32), axis=0))
+    n = v.shape[0]
+    w = np.ones(n, np.uint64)
+    cap = 4 * n + 1000
+    a = np.zeros(cap, np.uint32); b = np.zeros(cap, np.uint32)
+    st = [(C.c_uint64 * 4)() for _ in range(3)]
+    F.bu_host_pool_stats(st[0])
+    for i in (1, 2):
+        assert F.bu_host_tsvq(16, v.ctypes.data_as(C.c_void_p), w.ctypes.data_as(C.c_void_p), n, 8, 4, a.ctypes.data_as(C.c_void_p), cap, b.ctypes.data_as(C.c_void_p), cap) == 1
+        F.bu_host_pool_stats(st[i])
+    assert st[1][0] > st[0][0], "the first run maps its large blocks"
+    assert st[2][0] == st[1][0] and st[2][1] > st[1][1], "the second run reuses them"
+    assert st[2][2] <= st[2][3]
+    syms = subprocess.run(["nm", "-D", "--defined-only", str(etc1s.FRONTEND_LIB_PATH)], stdout=subprocess.PIPE, text=True, check=True).stdout.split("\n")
+    assert all(" bu_" in s for s in syms if s.strip()), [s for s in syms if s.strip() and " bu_" not in s][:5]
+    src = pathlib.Path(etc1s.__file__).parent / "csrc" / "host"
+    assert not any("mallopt(" in p.read_text() for p in src.glob("*.cpp"))
