@@ -67,6 +67,8 @@ _SIGNATURES = {
     "bu_hip_get_stream": (_vp, [_vp]),
     "bu_hip_sync": (_int, [_vp]),
     "bu_hip_set_wait_hook": (_int, [_vp, _vp, _vp]),
+    "bu_hip_get_tuning": (None, [_vp, _vp, _u32]),
+    "bu_hip_set_tuning": (_int, [_vp, _vp]),
     "bu_hip_last_error": (C.c_char_p, [_vp]),
     "bu_hip_profile_enable": (_int, [_vp, _int]),
     "bu_hip_profile_read": (_u32, [_vp, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(_u32), _u32]),
@@ -114,6 +116,11 @@ _SIGNATURES = {
     "bu_hip_tsvq_read_members": (_int, [_vp, _vp, _u32, _u32, _u32, _vp]),
     "bu_hip_tsvq_destroy": (None, [_vp, _vp]),
 }
+
+
+class Tuning(C.Structure):  # = bu_hip_tuning, include/basisu_hip.h
+    _fields_ = [(n, C.c_uint32) for n in ("struct_bytes", "tsvq_wide_min", "tsvq_wide6_min", "tsvq_wide_cov_min", "tsvq_windows", "tsvq_dense_min", "tsvq_zero_copy",
+                                          "tsvq_chained_only", "tsvq_poll", "refine_unsorted", "debug")]
 
 
 class HipLibrary:
@@ -166,6 +173,23 @@ class Context:
     def check(self, ok, what=""):
         if not ok:
             raise HipError(f"{what} failed: {self.lib.last_error(self.h)}")
+
+    def tuning(self):
+        """bu_hip_get_tuning: this context's path-selection knobs as a dict (all paths are bit-identical; see include/basisu_hip.h)."""
+        t = Tuning()
+        self.lib.get_tuning(self.h, C.byref(t), C.sizeof(t))
+        return {n: getattr(t, n) for n, _ in Tuning._fields_ if n != "struct_bytes"}
+
+    def set_tuning(self, **fields):
+        """bu_hip_set_tuning: the process defaults with `fields` replaced (no arguments = back to the defaults); codebook builds started on this context afterwards take them."""
+        t = Tuning()
+        self.lib.get_tuning(None, C.byref(t), C.sizeof(t))
+        for k, v in fields.items():
+            if k not in dict(Tuning._fields_) or k == "struct_bytes":
+                raise KeyError(k)
+            setattr(t, k, int(v))
+        t.struct_bytes = C.sizeof(t)
+        self.check(self.lib.set_tuning(self.h, C.byref(t)), "bu_hip_set_tuning")
 
     def close(self):
         if getattr(self, "h", None):

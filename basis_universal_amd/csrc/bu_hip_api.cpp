@@ -83,6 +83,7 @@ struct bu_hip_context {
     std::vector<prof_rec> prof_pending;
     struct prof_sum { const char* name; double ms; uint32_t launches; };
     std::vector<prof_sum> prof_totals;
+    bu_hip_tuning tuning{};               // bu_hip_set_tuning; starts as the process defaults (measured values, environment overrides read once)
     // cooperative waiting (bu_hip_set_wait_hook): called between looks at the stream wherever a call on this context would block its host thread
     bu_hip_wait_fn wait_hook = nullptr; void* wait_user = nullptr;
     // bu_hip_on_destroy registrations
@@ -229,6 +230,7 @@ static std::vector<bu_hip_context*> g_parked;
 // contexts handed out and not yet given back: with more than one, a host thread that waits for its device round shares the cores with the other contexts' host work
 static std::atomic<int> g_live_contexts{0};
 static void context_release(bu_hip_context* ctx);   // the real teardown
+static const bu_hip_tuning& default_tuning();
 static size_t park_limit() {
     static const size_t n = [] { const char* e = std::getenv("BU_HIP_PARKED_CONTEXTS"); const long v = e ? std::atol(e) : 16; return (size_t)(v < 0 ? 0 : (v > 64 ? 64 : v)); }();
     return n;
@@ -256,6 +258,7 @@ bu_hip_context* bu_hip_create_context_on(int device) {
     bu_hip_context* ctx = new (std::nothrow) bu_hip_context();
     if (!ctx) return nullptr;
     ctx->device = device;
+    ctx->tuning = default_tuning();
     if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) { set_error(nullptr, "hipStreamCreate failed"); delete ctx; return nullptr; }
     ctx->stream = ctx->own_stream;
     hipError_t e = bu::upload_etc1s_tables(device);
@@ -311,6 +314,7 @@ void bu_hip_destroy_context(bu_hip_context* ctx) {
         ctx->error.clear();
         ctx->profiling = false; ctx->prof_totals.clear();
         ctx->wait_hook = nullptr; ctx->wait_user = nullptr;
+        ctx->tuning = default_tuning();
         std::lock_guard<std::mutex> g(g_park_lock);
         if (g_parked.size() < park_limit()) { g_parked.push_back(ctx); return; }
     }
@@ -344,6 +348,52 @@ int bu_hip_set_stream(bu_hip_context* ctx, void* s) {
 }
 void* bu_hip_get_stream(bu_hip_context* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
 const char* bu_hip_last_error(const bu_hip_context* ctx) { return ctx ? ctx->error.c_str() : g_global_error.c_str(); }
+
+// The process defaults of bu_hip_tuning: measured values, each overridable ONCE per process by the environment variable named in basisu_hip.h.
+static const bu_hip_tuning& default_tuning() {
+    static const bu_hip_tuning t = [] {
+        bu_hip_tuning d;
+        std::memset(&d, 0, sizeof(d));
+        d.struct_bytes = (uint32_t)sizeof(d);
+        d.tsvq_wide_min = 8192; d.tsvq_wide6_min = 8192; d.tsvq_wide_cov_min = 98304; d.tsvq_windows = 0; d.tsvq_dense_min = 257; d.tsvq_zero_copy = 1;
+        auto num = [](const char* name, long lo, long hi, uint32_t* out) { if (const char* e = std::getenv(name)) { const long v = std::atol(e); if (v >= lo && v <= hi) *out = (uint32_t)v; } };
+        num("BU_TSVQ_WIDE_MIN", 512, 1l << 30, &d.tsvq_wide_min);
+        num("BU_TSVQ_WIDE6_MIN", 512, 1l << 30, &d.tsvq_wide6_min);
+        num("BU_TSVQ_WIDE_COV_MIN", 0, 1l << 30, &d.tsvq_wide_cov_min);
+        num("BU_TSVQ_DENSE_MIN", 0, 1l << 30, &d.tsvq_dense_min);
+        num("BU_TSVQ_ZEROCOPY", 0, 1, &d.tsvq_zero_copy);
+        if (const char* e = std::getenv("BU_TSVQ_WIDE")) if (std::atoi(e) == 0) d.tsvq_wide_min = d.tsvq_wide6_min = 0;
+        if (const char* e = std::getenv("BU_TSVQ_WIDE6")) if (std::atoi(e) == 0) d.tsvq_wide6_min = 0;
+        if (const char* e = std::getenv("BU_TSVQ_WINDOWS")) d.tsvq_windows = e[0] == '0' ? 2u : 1u;
+        if (std::getenv("BU_TSVQ_CHAINED")) d.tsvq_chained_only = 1;
+        if (const char* e = std::getenv("BU_TSVQ_POLL")) d.tsvq_poll = e[0] == 's' ? 1u : 2u;
+        d.debug = (std::getenv("BU_TSVQ_ROUNDS") ? 1u : 0u) | (std::getenv("BU_TSVQ_SERIAL") ? 2u : 0u) | (std::getenv("BU_TSVQ_STATS") ? 4u : 0u);
+        return d;
+    }();
+    return t;
+}
+
+void bu_hip_get_tuning(const bu_hip_context* ctx, bu_hip_tuning* out, uint32_t struct_bytes) {
+    if (!out || struct_bytes < 8) return;
+    const bu_hip_tuning& t = ctx ? ctx->tuning : default_tuning();
+    std::memcpy(out, &t, std::min<size_t>(struct_bytes, sizeof(t)));
+    out->struct_bytes = (uint32_t)std::min<size_t>(struct_bytes, sizeof(t));
+}
+
+int bu_hip_set_tuning(bu_hip_context* ctx, const bu_hip_tuning* t) {
+    if (!ctx) return 0;
+    if (!t) { ctx->tuning = default_tuning(); return 1; }
+    if (t->struct_bytes < 8 || t->struct_bytes > 4096) { set_error(ctx, "bu_hip_set_tuning: struct_bytes %u", t->struct_bytes); return 0; }
+    bu_hip_tuning n = default_tuning();   // fields a caller's older header does not have keep their defaults
+    std::memcpy(&n, t, std::min<size_t>(t->struct_bytes, sizeof(n)));
+    n.struct_bytes = (uint32_t)sizeof(n);
+    if ((n.tsvq_wide_min && n.tsvq_wide_min < 512) || (n.tsvq_wide6_min && n.tsvq_wide6_min < 512) || n.tsvq_windows > 2 || n.tsvq_poll > 2) {
+        set_error(ctx, "bu_hip_set_tuning: value out of range (many-workgroup thresholds are 0 or >= 512, windows / poll 0..2)");
+        return 0;
+    }
+    ctx->tuning = n;
+    return 1;
+}
 
 int bu_hip_set_wait_hook(bu_hip_context* ctx, bu_hip_wait_fn fn, void* user) {
     if (!ctx) return 0;
@@ -612,7 +662,7 @@ int bu_hip_k_refine_endpoint_clusterization(bu_hip_context* ctx, const void* d_p
     if (!ctx) return 0;
     device_guard g(ctx->device);
     void* work = nullptr;
-    if (const size_t wb = std::getenv("BU_REFINE_UNSORTED") ? 0 : bu::refine_workspace_bytes(n_clusters, n_parents)) { BU_TRY(ctx, ctx->refine_lists.reserve(wb)); work = ctx->refine_lists.p; }
+    if (const size_t wb = ctx->tuning.refine_unsorted ? 0 : bu::refine_workspace_bytes(n_clusters, n_parents)) { BU_TRY(ctx, ctx->refine_lists.reserve(wb)); work = ctx->refine_lists.p; }
     prof_scope ps(ctx, "refine_endpoint_clusterization");
     BU_TRY(ctx, bu::launch_refine_endpoint_clusterization(ctx->stream, d_px, n_blocks, d_block_cluster, d_cluster_params, n_clusters, n_parents,
                                                           d_cand_offsets, d_cand_indices, d_block_parent, perceptual != 0, d_out_best, work));
@@ -782,7 +832,6 @@ int bu_hip_kmeans_codebook(bu_hip_context* ctx, int kind, const void* d_keys, co
     }
     device_guard g(ctx->device);
     const uint32_t k = std::min(max_clusters, n);
-    if (const char* e = std::getenv("BU_FAST_ITERS")) { const int v = std::atoi(e); if (v >= 0 && v <= 64) iterations = (uint32_t)v; }
     arena& ws = ctx->scratch[3];
     BU_TRY(ctx, ws.reserve(bu::kmeans_workspace_bytes(n, k) + (size_t)k * 8 + 256));
     const bu::kmeans_buffers b = bu::kmeans_carve(ws.p, n, k);
@@ -852,11 +901,6 @@ int bu_hip_kmeans_codebook(bu_hip_context* ctx, int kind, const void* d_keys, co
 
 } // extern "C" (reopened below)
 
-// The fused side-pass kernel (tsvq_wide_kernels.hip, k_wide_side_passes) spins at device-wide barriers: one at a time per process (a second context takes the separate
-// kernels for that round instead of waiting), and never again in this process once one has given up (another process holding part of the chip: see the kernel's header).
-static std::mutex g_fused_lock;
-static std::atomic<bool> g_fused_gave_up{false};
-
 struct bu_tsvq {
     uint32_t dim = 0, n = 0;
     bool packed = false;
@@ -865,25 +909,25 @@ struct bu_tsvq {
     uint32_t* perm[2] = {nullptr, nullptr};
     uint8_t* side = nullptr;
     arena nodes, outs;
-    bool force_chained = false; // BU_TSVQ_CHAINED=1: never use the exact (integer-reduced) kernel variants (tests compare both)
+    // the knobs below are copies of the context's bu_hip_tuning at creation (basisu_hip.h): one tree never changes paths half way
+    bool force_chained = false; // tsvq_chained_only: never use the exact (integer-reduced) kernel variants (tests compare both)
     // Nodes with at least wide_min members go through the many-workgroup path (tsvq_wide_kernels.hip for packed rows, tsvq_wide6_kernels.hip for 6-float rows).
-    // BU_TSVQ_WIDE_MIN overrides the threshold, BU_TSVQ_WIDE=0 switches the path off (tests compare both).
     uint32_t wide_min = 0;      // 0: off
-    uint32_t wide_cov_min = 0;  // batches whose largest node is smaller run the covariance pass chained (BU_TSVQ_WIDE_COV_MIN)
+    uint32_t wide_cov_min = 0;  // batches whose largest node is smaller run the covariance pass chained (tsvq_wide_cov_min)
+    int windows = 0; uint32_t dense_min = 257; int poll = 0;
     uint32_t wide_blocks_cap = 0, wide_nodes_cap = 0;
     void* xchg = nullptr; size_t xchg_cap = 0;   // staging of bu_hip_tsvq_exchange_* (multi-GPU)
     void* wide_ws = nullptr; void* wide_packed = nullptr; bu::tsvq_wide_node* wide_nodes = nullptr; bu::tsvq_wide_ctrl* wide_ctrl = nullptr; void* wide_ctrl_raw = nullptr;
-    uint32_t fused_workgroups = 0;   // > 0: a round's side passes as one persistent kernel of that many workgroups (the device's CU count); BU_TSVQ_FUSED=0 switches it off
     // Pinned staging for the per-round node / result records: hipMemcpyAsync on PAGEABLE host memory followed directly by a
     // kernel on the same stream was observed to let the kernel read the destination before the copy landed (MI355X, ROCm 7.2:
     // tools/tsvq_root_repeat.py, 2 of 10 runs), so nothing on this path hands pageable memory to an asynchronous copy.
     void* pinned = nullptr; size_t pinned_cap = 0;
-    // Zero-copy rounds (default; BU_TSVQ_ZEROCOPY=0 switches back to staged copies + hipStreamSynchronize): the one-workgroup kernel reads its node records
+    // Zero-copy rounds (default; tsvq_zero_copy = 0 switches back to staged copies + hipStreamSynchronize): the one-workgroup kernel reads its node records
     // from, and every split kernel writes its result records to, the page-locked buffer directly; a one-thread kernel behind them raises `round_flag`
     // (system scope) and the host spins on it. That takes two copy launches and a blocking synchronisation out of every round of the tree build.
     bool zero_copy = true;
     uint32_t round_seq = 0;
-    bool dbg_rounds = false, dbg_serial = false, dbg_stats = false;   // BU_TSVQ_ROUNDS / _SERIAL / _STATS, read once per tree (getenv per round was 5-10 us of every round)
+    bool dbg_rounds = false, dbg_serial = false, dbg_stats = false;   // bu_hip_tuning::debug bits
     hipError_t reserve_pinned(size_t bytes) {
         if (bytes <= pinned_cap) return hipSuccess;
         if (pinned) { (void)hipHostFree(pinned); pinned = nullptr; pinned_cap = 0; }
@@ -924,9 +968,11 @@ static bu_tsvq* tsvq_create_common(bu_hip_context* ctx, uint32_t dim, bool packe
     bu_tsvq* q = new (std::nothrow) bu_tsvq();
     if (!q) return nullptr;
     q->dim = dim; q->n = n; q->packed = packed;
-    q->force_chained = std::getenv("BU_TSVQ_CHAINED") != nullptr;
-    if (const char* e = std::getenv("BU_TSVQ_ZEROCOPY")) q->zero_copy = std::atoi(e) != 0;
-    q->dbg_rounds = std::getenv("BU_TSVQ_ROUNDS") != nullptr; q->dbg_serial = std::getenv("BU_TSVQ_SERIAL") != nullptr; q->dbg_stats = std::getenv("BU_TSVQ_STATS") != nullptr;
+    const bu_hip_tuning& tune = ctx->tuning;
+    q->force_chained = tune.tsvq_chained_only != 0;
+    q->zero_copy = tune.tsvq_zero_copy != 0;
+    q->dbg_rounds = (tune.debug & 1) != 0; q->dbg_serial = (tune.debug & 2) != 0; q->dbg_stats = (tune.debug & 4) != 0;
+    q->windows = (int)tune.tsvq_windows; q->dense_min = tune.tsvq_dense_min; q->poll = (int)tune.tsvq_poll;
     const size_t row_bytes = packed ? 4 : (size_t)dim * 4;
     auto fail = [&](const char* what) -> bu_tsvq* { set_error(ctx, "tsvq_create: %s", what); bu_hip_tsvq_destroy(ctx, q); return nullptr; };
     if (ctx->tsvq_pinned) { q->pinned = ctx->tsvq_pinned; q->pinned_cap = ctx->tsvq_pinned_cap; ctx->tsvq_pinned = nullptr; ctx->tsvq_pinned_cap = 0; }
@@ -940,12 +986,9 @@ static bu_tsvq* tsvq_create_common(bu_hip_context* ctx, uint32_t dim, bool packe
     if (!q->rows || !q->w64 || !q->perm[0] || !q->perm[1] || !q->side || !q->nodes.p || !q->outs.p) return fail("allocation");
     q->nodes.cap = q->outs.cap = rec_cap;
     if (!packed && dim == 6 && !q->force_chained) {
-        // the endpoint tree's large nodes through the many-workgroup path for 6-float rows (tsvq_wide6_kernels.hip). BU_TSVQ_WIDE6_MIN sets the threshold, BU_TSVQ_WIDE6=0
-        // (or BU_TSVQ_WIDE=0) switches the path off (tests compare both).
-        uint32_t wide_min = 8192;   // (6,144 / 10,000 / 14,000 side by side on one box: 1.68 / 1.69 / 1.69 ms for the endpoint tree's splits, 2.15 without the path)
-        if (const char* e = std::getenv("BU_TSVQ_WIDE6_MIN")) { const long v = std::atol(e); if (v >= 512 && v <= (1l << 30)) wide_min = (uint32_t)v; }
-        if (const char* e = std::getenv("BU_TSVQ_WIDE6")) if (std::atoi(e) == 0) wide_min = 0;
-        if (const char* e = std::getenv("BU_TSVQ_WIDE")) if (std::atoi(e) == 0) wide_min = 0;
+        // the endpoint tree's large nodes through the many-workgroup path for 6-float rows (tsvq_wide6_kernels.hip): tsvq_wide6_min, default 8,192
+        // (6,144 / 10,000 / 14,000 side by side on one box: 1.68 / 1.69 / 1.69 ms for the endpoint tree's splits, 2.15 without the path); 0 = off (tests compare both)
+        const uint32_t wide_min = tune.tsvq_wide6_min;
         if (wide_min && n >= wide_min && n < (1u << 22)) {
             q->wide_min = wide_min;
             q->wide_nodes_cap = n / wide_min + 1;
@@ -959,30 +1002,19 @@ static bu_tsvq* tsvq_create_common(bu_hip_context* ctx, uint32_t dim, bool packe
         }
     }
     if (packed && !q->force_chained) {
-        uint32_t wide_min = 8192;   // (16384 until round 3: the one-workgroup launches of the smaller nodes are the longer of the two concurrent streams)
-        if (const char* e = std::getenv("BU_TSVQ_WIDE_MIN")) { const long v = std::atol(e); if (v >= 512 && v <= (1l << 30)) wide_min = (uint32_t)v; }
-        if (const char* e = std::getenv("BU_TSVQ_WIDE")) if (std::atoi(e) == 0) wide_min = 0;
+        const uint32_t wide_min = tune.tsvq_wide_min;   // default 8,192 (16,384 until round 3: the one-workgroup launches of the smaller nodes are the longer of the two concurrent streams)
         if (wide_min && n >= wide_min && n < (1u << 22)) {   // above 2^22 members the binade prediction loses its margin; the chained kernel takes those
             q->wide_min = wide_min;
-            q->wide_cov_min = 98304;   // (side by side on one box with the register-composed stretches kernel: 131,072 / 98,304 / 65,536 / 49,152 -> 5.10 / 4.98 / 5.04 / 5.04 ms of many-workgroup rounds per 4096^2 step)
-            if (const char* e = std::getenv("BU_TSVQ_WIDE_COV_MIN")) { const long v = std::atol(e); if (v >= 0 && v <= (1l << 30)) q->wide_cov_min = (uint32_t)v; }
+            q->wide_cov_min = tune.tsvq_wide_cov_min;   // default 98,304 (side by side on one box with the register-composed stretches kernel: 131,072 / 98,304 / 65,536 / 49,152 -> 5.10 / 4.98 / 5.04 / 5.04 ms of many-workgroup rounds per 4096^2 step)
             q->wide_nodes_cap = n / wide_min + 1;
             q->wide_blocks_cap = (n + 255) / 256 + q->wide_nodes_cap;
             q->wide_ws = bu_hip_malloc(ctx, bu::tsvq_wide_workspace_bytes(q->wide_blocks_cap));
             q->wide_nodes = (bu::tsvq_wide_node*)bu_hip_malloc(ctx, (size_t)q->wide_nodes_cap * sizeof(bu::tsvq_wide_node));
-            q->wide_ctrl_raw = bu_hip_malloc(ctx, bu::tsvq_wide_sync_bytes() + (size_t)q->wide_nodes_cap * sizeof(bu::tsvq_wide_ctrl));   // the fused kernel's barrier words in front
-            q->wide_ctrl = q->wide_ctrl_raw ? reinterpret_cast<bu::tsvq_wide_ctrl*>(static_cast<char*>(q->wide_ctrl_raw) + bu::tsvq_wide_sync_bytes()) : nullptr;
+            q->wide_ctrl_raw = bu_hip_malloc(ctx, (size_t)q->wide_nodes_cap * sizeof(bu::tsvq_wide_ctrl));
+            q->wide_ctrl = static_cast<bu::tsvq_wide_ctrl*>(q->wide_ctrl_raw);
             q->wide_packed = bu_hip_malloc(ctx, (size_t)n * 8);
             if (!q->wide_ws || !q->wide_packed || !q->wide_nodes || !q->wide_ctrl) return fail("allocation");
-            {
-                // OFF unless BU_TSVQ_FUSED=1 (or 2: two workgroups per CU): built, bit-identical, and 2.5x SLOWER than the separate kernels on the bench image -- one
-                // workgroup per CU cannot hide the per-block latencies that ten co-resident workgroups of the separate launches hide, and the walk's 174 registers cap the kernel at two
-                const char* e = std::getenv("BU_TSVQ_FUSED");
-                const int per_cu = e ? std::atoi(e) : 0;
-                hipDeviceProp_t prop;
-                if (per_cu >= 1 && per_cu <= 2 && !g_fused_gave_up.load() && hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.multiProcessorCount > 0)
-                    q->fused_workgroups = (uint32_t)prop.multiProcessorCount * (uint32_t)per_cu;
-            }        }
+        }
     }
     if (d_endpoint_keys) {   // the rows are made on the device from the de-duplication's keys (bu_hip_k_unique_endpoint_vectors)
         if (bu::launch_endpoint_rows(ctx->stream, d_endpoint_keys, d_endpoint_goffs, n, static_cast<float*>(q->rows), q->w64) != hipSuccess) return fail("endpoint rows");
@@ -1010,7 +1042,7 @@ static bu_tsvq* tsvq_create_common(bu_hip_context* ctx, uint32_t dim, bool packe
                                                reinterpret_cast<double*>(static_cast<char*>(q->wide_packed) + (size_t)n * 24)) != hipSuccess) return fail("wide root launch");
             } else
             if (bu::launch_tsvq_wide_root(ctx->stream, static_cast<const uint32_t*>(q->rows), q->w64, n, q->perm[0], q->wide_nodes, q->wide_ctrl, q->wide_ws, wn.n_blocks,
-                                          static_cast<bu::tsvq_root_out*>(q->outs.p)) != hipSuccess) return fail("wide root launch");
+                                          static_cast<bu::tsvq_root_out*>(q->outs.p), q->windows) != hipSuccess) return fail("wide root launch");
         } else {
             prof_scope ps(ctx, packed ? "tsvq_root_packed16" : "tsvq_root_float6");
             if (bu::launch_tsvq_root(ctx->stream, (int)dim, packed, exact, q->rows, q->w64, n, q->perm[0], static_cast<bu::tsvq_root_out*>(q->outs.p)) != hipSuccess) return fail("root launch");
@@ -1110,7 +1142,7 @@ int bu_hip_tsvq_split(bu_hip_context* ctx, bu_tsvq* q, const bu_tsvq_node* h_nod
     const bool zero_copy = q->zero_copy;
     // staged: the result records come back over the node records; zero-copy: the kernels write them while others still read their nodes, so they get their own place
     const size_t out_at = zero_copy ? ((wide_at + wide_bytes + 63) & ~(size_t)63) : 0, flag_at = (out_at + out_bytes + 63) & ~(size_t)63;
-    BU_TRY(ctx, q->reserve_pinned(std::max(wide_at + wide_bytes, flag_at + 128)));   // the round's flag, and 64 bytes on the fused kernel's verdict
+    BU_TRY(ctx, q->reserve_pinned(std::max(wide_at + wide_bytes, flag_at + 128)));   // the round's flag
     char* d_pinned = nullptr;   // the page-locked buffer as the device addresses it
     if (zero_copy) BU_TRY(ctx, hipHostGetDevicePointer(reinterpret_cast<void**>(&d_pinned), q->pinned, 0));
     volatile uint32_t* round_flag = reinterpret_cast<volatile uint32_t*>(static_cast<char*>(q->pinned) + flag_at);
@@ -1148,24 +1180,18 @@ int bu_hip_tsvq_split(bu_hip_context* ctx, bu_tsvq* q, const bu_tsvq_node* h_nod
         side_join_guard.s = ctx->side_stream; side_join_guard.armed = true;
         BU_TRY(ctx, hipEventRecord(ctx->side_fork, ctx->stream));
         BU_TRY(ctx, hipStreamWaitEvent(ctx->side_stream, ctx->side_fork, 0));
-        BU_TRY(ctx, bu::launch_tsvq_split(ctx->side_stream, (int)q->dim, q->packed, exact, q->rows, q->w64, q->perm[0], q->perm[1], q->side, d_nodes_in, n_narrow, d_outs));
+        BU_TRY(ctx, bu::launch_tsvq_split(ctx->side_stream, (int)q->dim, q->packed, exact, q->rows, q->w64, q->perm[0], q->perm[1], q->side, d_nodes_in, n_narrow, d_outs, q->dense_min));
         BU_TRY(ctx, hipEventRecord(ctx->side_join, ctx->side_stream));
     }
-    // the side passes of the wide batch as one persistent kernel when this context can have the chip's barrier to itself (see g_fused_lock)
-    volatile uint32_t* fused_verdict = reinterpret_cast<volatile uint32_t*>(static_cast<char*>(q->pinned) + flag_at + 64);
-    std::unique_lock<std::mutex> fused_turn(g_fused_lock, std::defer_lock);
-    const bool fused = n_wide && q->packed && zero_copy && q->fused_workgroups && !q->dbg_serial && !g_fused_gave_up.load() && fused_turn.try_lock();
     if (n_wide) {
         prof_scope ps(ctx, q->packed ? "tsvq_split_packed16_wide" : "tsvq_split_float6_wide");
-        if (fused) { *fused_verdict = 2; __atomic_thread_fence(__ATOMIC_SEQ_CST); }
         if (!q->packed)
             BU_TRY(ctx, bu::launch_tsvq_wide6_split(ctx->stream, static_cast<const float*>(q->rows), q->w64, q->n, q->perm[0], q->perm[1], q->side, q->wide_nodes, n_wide, q->wide_ctrl, q->wide_ws,
                                                     wide_blocks, d_outs, static_cast<float*>(q->wide_packed), reinterpret_cast<double*>(static_cast<char*>(q->wide_packed) + (size_t)q->n * 24)));
         else
         BU_TRY(ctx, bu::launch_tsvq_wide_split(ctx->stream, static_cast<const uint32_t*>(q->rows), q->w64, q->perm[0], q->perm[1], q->side, q->wide_packed, q->wide_nodes, n_wide, q->wide_ctrl,
                                                q->wide_ws, wide_blocks, d_outs, wide_max_count < q->wide_cov_min,
-                                               wide_max_weight * 3ull < (1ull << 24), fused ? q->fused_workgroups : 0u,
-                                               fused ? reinterpret_cast<uint32_t*>(d_pinned + flag_at + 64) : nullptr));
+                                               wide_max_weight * 3ull < (1ull << 24), q->windows));
     }
     if (n_wide && q->dbg_stats && q->packed) {   // development aid: how the last pass's walks went, per wide node
         std::vector<bu::tsvq_wide_ctrl> hc(n_wide);
@@ -1187,15 +1213,15 @@ int bu_hip_tsvq_split(bu_hip_context* ctx, bu_tsvq* q, const bu_tsvq_node* h_nod
     if (narrow_on_side) { BU_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->side_join, 0)); side_join_guard.armed = false; }
     else if (n_narrow) {
         prof_scope ps(ctx, q->packed ? "tsvq_split_packed16" : "tsvq_split_float6");
-        BU_TRY(ctx, bu::launch_tsvq_split(ctx->stream, (int)q->dim, q->packed, exact, q->rows, q->w64, q->perm[0], q->perm[1], q->side, d_nodes_in, n_narrow, d_outs));
+        BU_TRY(ctx, bu::launch_tsvq_split(ctx->stream, (int)q->dim, q->packed, exact, q->rows, q->w64, q->perm[0], q->perm[1], q->side, d_nodes_in, n_narrow, d_outs, q->dense_min));
     }
     if (zero_copy) {
         const uint32_t seq = ++q->round_seq ? q->round_seq : ++q->round_seq;   // never 0
         BU_TRY(ctx, bu::launch_tsvq_signal(ctx->stream, reinterpret_cast<uint32_t*>(d_pinned + flag_at), seq));
         // One context in the process: spin (the round trip is what the step waits for). Several (basis_parallel_compress, images in flight): the device is shared, a round
         // can take milliseconds, and a spinning waiter takes a core from another image's host backend -- after 30 us the core is offered to whoever wants it, after
-        // 2 ms the thread sleeps between looks. BU_TSVQ_POLL=spin|yield overrides.
-        static const int poll_mode = [] { const char* e = std::getenv("BU_TSVQ_POLL"); return !e ? 0 : (e[0] == 's' ? 1 : 2); }();
+        // 2 ms the thread sleeps between looks. bu_hip_tuning::tsvq_poll (BU_TSVQ_POLL=spin|yield) overrides.
+        const int poll_mode = q->poll;
         const bool polite = !ctx->wait_hook && (poll_mode == 2 || (poll_mode == 0 && g_live_contexts.load(std::memory_order_relaxed) > 1));
         const auto t_wait0 = std::chrono::steady_clock::now();
         auto last_query = t_wait0;
@@ -1226,20 +1252,12 @@ int bu_hip_tsvq_split(bu_hip_context* ctx, bu_tsvq* q, const bu_tsvq_node* h_nod
     if (round_stats) {
         uint32_t mx = 0; uint64_t tot = 0;
         for (uint32_t i = 0; i < n_nodes; i++) { mx = std::max(mx, h_nodes[i].count); tot += h_nodes[i].count; }
-        std::fprintf(stderr, "[tsvq round] dim %u: %u nodes (%u wide%s), largest %u, members %llu: %.0f us\n", q->dim, n_nodes, n_wide, fused ? (*fused_verdict == 1 ? ", fused" : ", fused GAVE UP") : "", mx, (unsigned long long)tot,
+        std::fprintf(stderr, "[tsvq round] dim %u: %u nodes (%u wide), largest %u, members %llu: %.0f us\n", q->dim, n_nodes, n_wide, mx, (unsigned long long)tot,
                      std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - round_t0).count());
     }
     {
         const bu_tsvq_split* po = reinterpret_cast<const bu_tsvq_split*>(static_cast<const char*>(q->pinned) + out_at);
         for (uint32_t i = 0; i < n_nodes; i++) h_out[order[i]] = po[i];
-    }
-    if (fused) {
-        fused_turn.unlock();
-        if (*fused_verdict != 1) {   // the persistent kernel gave up at a barrier (the chip was not its own): nothing it left behind is used, the nodes go the one-workgroup way,
-            g_fused_gave_up.store(true);   // and this process does not try again
-            q->fused_workgroups = 0;
-            for (uint32_t i = n_narrow; i < n_nodes; i++) { std::memset(&h_out[order[i]], 0, sizeof(bu_tsvq_split)); h_out[order[i]].ok = 2; }
-        }
     }
     if (exact || n_wide) { // nodes whose data left the exact range, or that a wide path handed back (ok == 2), go through the one-workgroup kernel: packed wide ones through its exact variant first
         for (int attempt = exact ? 0 : 1; attempt < 2; attempt++) {
@@ -1252,7 +1270,7 @@ int bu_hip_tsvq_split(bu_hip_context* ctx, bu_tsvq* q, const bu_tsvq_node* h_nod
             {
                 prof_scope ps(ctx, q->packed ? "tsvq_split_packed16" : "tsvq_split_float6");
                 BU_TRY(ctx, bu::launch_tsvq_split(ctx->stream, (int)q->dim, q->packed, exact && attempt == 0 && n_wide != 0, q->rows, q->w64, q->perm[0], q->perm[1], q->side,
-                                                  static_cast<const bu::tsvq_node_in*>(q->nodes.p), (uint32_t)redo.size(), static_cast<bu::tsvq_split_out*>(q->outs.p)));
+                                                  static_cast<const bu::tsvq_node_in*>(q->nodes.p), (uint32_t)redo.size(), static_cast<bu::tsvq_split_out*>(q->outs.p), q->dense_min));
             }
             BU_TRY(ctx, hipMemcpyAsync(q->pinned, q->outs.p, redo.size() * sizeof(bu_tsvq_split), hipMemcpyDeviceToHost, ctx->stream));
             BU_TRY(ctx, stream_wait(ctx, ctx->stream));
@@ -1298,7 +1316,7 @@ int bu_hip_tsvq_roots(bu_hip_context* ctx, bu_tsvq* q, const bu_tsvq_node* h_nod
             {
                 prof_scope ps(ctx, "tsvq_root_packed16");
                 BU_TRY(ctx, bu::launch_tsvq_wide_span_roots(ctx->stream, static_cast<const uint32_t*>(q->rows), q->w64, q->perm[0], q->perm[1], q->wide_packed, q->wide_nodes,
-                                                            (uint32_t)wide.size(), q->wide_ctrl, q->wide_ws, blocks, static_cast<bu::tsvq_root_out*>(q->outs.p)));
+                                                            (uint32_t)wide.size(), q->wide_ctrl, q->wide_ws, blocks, static_cast<bu::tsvq_root_out*>(q->outs.p), q->windows));
             }
             BU_TRY(ctx, stream_wait(ctx, ctx->stream));   // the node records were read from the pinned buffer the results come back to
             BU_TRY(ctx, hipMemcpyAsync(q->pinned, q->outs.p, wide.size() * sizeof(bu_tsvq_root), hipMemcpyDeviceToHost, ctx->stream));
@@ -1376,7 +1394,7 @@ static int tsvq_exchange_layout(bu_hip_context* ctx, bu_tsvq* q, const bu_tsvq_n
         table[i] = bu::bk_span{h_nodes[i].buf, h_nodes[i].start, h_nodes[i].count, (uint32_t)run};
         run += h_nodes[i].count;
     }
-    if (run > q->n) { set_error(ctx, "tsvq_exchange: overlapping nodes"); return 0; }
+    if (run > 2ull * q->n) { set_error(ctx, "tsvq_exchange: overlapping nodes"); return 0; }   // (both member buffers once over: the whole-tree exchange of the one-tree-per-rank build)
     rec_at = ((size_t)run * 4 + 7) & ~(size_t)7;
     tab_at = rec_at + (size_t)n_nodes * sizeof(bu_tsvq_split);
     total = tab_at + (size_t)n_nodes * sizeof(bu::bk_span) + ((size_t)n_nodes + 7 & ~(size_t)7);

@@ -7,8 +7,6 @@
 // come from a recycling pool of page-aligned mappings (advised to use huge pages), everything smaller goes to malloc untouched. The operators are LOCAL to
 // this library (the link hides them: csrc/host/exports.map + -Bsymbolic), so nobody else's allocations change; the library's C ABI never hands out or takes
 // ownership of C++ objects, so every block is freed by the operator delete that sits next to the operator new it came from.
-// The same file is compiled into the benchmark driver integration/process_bench.cpp, where -- as an APPLICATION's own choice of allocator -- it replaces the
-// global operators, so that the reference's compressor objects around the resident path recycle their blocks too (no GLIBC_TUNABLES needed).
 // Environment, read once: BU_HOST_POOL_MB = most megabytes kept cached (default 6144; 0 switches the pool off).
 #include <sys/mman.h>
 

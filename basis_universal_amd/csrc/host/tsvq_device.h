@@ -14,6 +14,7 @@
 #include <atomic>
 #include <chrono>
 #include <thread>
+#include <type_traits>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -324,6 +325,63 @@ private:
         }
     }
 
+    // The end of the one-tree-per-rank build: every rank contributes the trees it built -- both member buffers over each tree's span, and the tree's node table --
+    // to one staging buffer in which everybody else's entries are zero; ONE exact u64 sum all-reduce (bu_comm) makes it whole everywhere. The buffer is the one
+    // the per-round exchange uses (bu_hip_tsvq_exchange_pack / _unpack): per tree two pseudo-nodes over its span, {buf 1} for the list in buffer 0 and {buf 0}
+    // for the one in buffer 1 ("a node's children live in the other buffer"); the serialised node tables ride in the record slots of zero-member pseudo-nodes
+    // behind them (a table's region is a whole number of records, so a record has one owner).
+    static bool exchange_trees(bu_hip_context* ctx, bu_tsvq* q, const bu_comm* comm, std::vector<tree>& subs, const std::vector<bu_tsvq_node>& spans, const std::vector<uint32_t>& owner) {
+        static_assert(std::is_trivially_copyable<node>::value, "node tables are exchanged as bytes");
+        const size_t rec = sizeof(bu_tsvq_split), T = subs.size();
+        struct table_header { uint32_t n_nodes, leaves, next_codebook_index, pad; };
+        std::vector<size_t> rec_first(T + 1);
+        size_t n_rec = 0;
+        for (size_t t = 0; t < T; t++) {
+            rec_first[t] = n_rec;
+            const size_t cap_nodes = 2 * (size_t)std::min<uint64_t>(subs[t].max_leaves, spans[t].count) + 1;   // a tree of L leaves has 2 L - 1 nodes
+            n_rec += (sizeof(table_header) + cap_nodes * sizeof(node) + rec - 1) / rec;
+        }
+        rec_first[T] = n_rec;
+        std::vector<bu_tsvq_node> nodes(2 * T + n_rec);
+        std::memset(nodes.data(), 0, nodes.size() * sizeof(bu_tsvq_node));
+        std::vector<uint8_t> mine(nodes.size(), 0);
+        std::vector<bu_tsvq_split> recs(nodes.size());
+        std::memset(recs.data(), 0, recs.size() * sizeof(bu_tsvq_split));
+        char* blob = reinterpret_cast<char*>(recs.data() + 2 * T);
+        for (size_t t = 0; t < T; t++) {
+            const bool my = owner[t] == comm->rank;
+            nodes[2 * t].buf = 1; nodes[2 * t].start = spans[t].start; nodes[2 * t].count = spans[t].count;
+            nodes[2 * t + 1].buf = 0; nodes[2 * t + 1].start = spans[t].start; nodes[2 * t + 1].count = spans[t].count;
+            mine[2 * t] = mine[2 * t + 1] = my ? 1 : 0;
+            for (size_t r = rec_first[t]; r < rec_first[t + 1]; r++) mine[2 * T + r] = my ? 1 : 0;
+            if (!my) continue;
+            const tree& tr = subs[t];
+            if (sizeof(table_header) + tr.nodes.size() * sizeof(node) > (rec_first[t + 1] - rec_first[t]) * rec) return false;   // cannot happen: 2 L - 1 nodes
+            table_header h{(uint32_t)tr.nodes.size(), tr.leaves, tr.next_codebook_index, 0};
+            char* at = blob + rec_first[t] * rec;
+            std::memcpy(at, &h, sizeof(h));
+            std::memcpy(at + sizeof(h), tr.nodes.data(), tr.nodes.size() * sizeof(node));
+        }
+        void* d_staging = nullptr; uint64_t n_u64 = 0;
+        if (!bu_hip_tsvq_exchange_pack(ctx, q, nodes.data(), mine.data(), recs.data(), (uint32_t)nodes.size(), &d_staging, &n_u64)) return false;
+        if (!comm->stream_ordered && !bu_hip_sync(ctx)) return false;
+        if (!comm->all_reduce_u64(comm->user, d_staging, n_u64)) return false;
+        if (!bu_hip_tsvq_exchange_unpack(ctx, q, nodes.data(), mine.data(), recs.data(), (uint32_t)nodes.size())) return false;
+        blob = reinterpret_cast<char*>(recs.data() + 2 * T);
+        for (size_t t = 0; t < T; t++) {
+            if (owner[t] == comm->rank) continue;
+            table_header h;
+            const char* at = blob + rec_first[t] * rec;
+            std::memcpy(&h, at, sizeof(h));
+            if (!h.n_nodes || sizeof(h) + (size_t)h.n_nodes * sizeof(node) > (rec_first[t + 1] - rec_first[t]) * rec) return false;   // the owner never delivered
+            tree& tr = subs[t];
+            tr.nodes.resize(h.n_nodes);
+            std::memcpy(tr.nodes.data(), at + sizeof(h), (size_t)h.n_nodes * sizeof(node));
+            tr.leaves = h.leaves; tr.next_codebook_index = h.next_codebook_index;
+        }
+        return true;
+    }
+
     template <class Groups>
     static bool build(bu_hip_context* ctx, bu_tsvq* q, const bu_tsvq_root& root, uint32_t n, const Groups& groups,
                       uint32_t max_codebook_size, uint32_t max_parent_codebook_size, std::vector<std::vector<uint32_t>>& codebook,
@@ -373,7 +431,27 @@ private:
                     active.push_back(&subs[t]); final_trees.push_back(&subs[t]);
                     final_parents.push_back(max_parent_codebook_size ? (max_parent_codebook_size + T - 1) / T : 0);
                 }
-                if (!run_trees(ctx, q, active, cache, local, comm, dbg_serial, dbg_verify)) return false;
+                if (comm && comm->world > 1 && spans.size() >= 2 && !dbg_serial) {
+                    // Multi-GPU: ONE TREE PER RANK. The T trees are independent (own training sets, own queues: enc.h:2138-2215, where they are T host threads), so
+                    // instead of sharing out every round's nodes with an all-reduce per round, every rank builds whole trees -- largest span first onto the least
+                    // loaded rank, the same assignment everywhere -- without talking to anybody, and ONE exchange at the end hands every rank every tree: the member
+                    // buffers' spans and the node tables. A tree is a pure function of its span and root record, so it does not matter who built it.
+                    std::vector<uint32_t> order(spans.size()), owner(spans.size(), 0);
+                    for (uint32_t i = 0; i < order.size(); i++) order[i] = i;
+                    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return spans[a].count > spans[b].count; });
+                    std::vector<uint64_t> load(comm->world, 0);
+                    for (uint32_t t : order) {
+                        uint32_t r = 0;
+                        for (uint32_t k = 1; k < comm->world; k++) if (load[k] < load[r]) r = k;
+                        load[r] += spans[t].count; owner[t] = r;
+                    }
+                    std::vector<tree*> mine;
+                    for (size_t t = 0; t < subs.size(); t++) if (owner[t] == comm->rank) mine.push_back(&subs[t]);
+                    if (!mine.empty() && !run_trees(ctx, q, mine, cache, local, nullptr, dbg_serial, dbg_verify)) return false;
+                    const auto tx = now();
+                    if (!exchange_trees(ctx, q, comm, subs, spans, owner)) return false;
+                    local.t_device += secs(tx, now());
+                } else if (!run_trees(ctx, q, active, cache, local, comm, dbg_serial, dbg_verify)) return false;
             }
         }
         const auto t_loop1 = now();

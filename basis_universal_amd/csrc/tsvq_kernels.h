@@ -19,7 +19,7 @@ hipError_t launch_tsvq_root(hipStream_t st, int dim, bool packed, bool exact, co
 hipError_t launch_tsvq_span_roots(hipStream_t st, int dim, bool packed, bool exact, const void* d_rows, const uint64_t* d_w64, const uint32_t* d_perm0, const uint32_t* d_perm1,
                                   const tsvq_node_in* d_nodes, uint32_t n_nodes, tsvq_root_out* d_outs);
 hipError_t launch_tsvq_split(hipStream_t st, int dim, bool packed, bool exact, const void* d_rows, const uint64_t* d_w64, uint32_t* d_perm0, uint32_t* d_perm1, uint8_t* d_side,
-                             const tsvq_node_in* d_nodes, uint32_t n_nodes, tsvq_split_out* d_outs);
+                             const tsvq_node_in* d_nodes, uint32_t n_nodes, tsvq_split_out* d_outs, uint32_t dense_min);
 
 // one-thread launch that stores `value` to *d_flag (page-locked host memory) with system scope once everything before it on the stream is done
 hipError_t launch_tsvq_signal(hipStream_t st, uint32_t* d_flag, uint32_t value);
@@ -52,17 +52,17 @@ hipError_t launch_tsvq_cov_axis(hipStream_t st, const uint32_t* d_keys, const ui
                                 const tsvq_wide_node* d_nodes, uint32_t n_nodes, tsvq_wide_ctrl* d_ctrl, void* d_packed);
 size_t tsvq_wide_workspace_bytes(uint32_t total_blocks);           // total_blocks = sum over the batch's nodes of ceil(count / 256)
 hipError_t launch_tsvq_wide_root(hipStream_t st, const uint32_t* d_keys, const uint64_t* d_w64, uint32_t n, uint32_t* d_perm0 /* out: 0..n-1 */,
-                                 const tsvq_wide_node* d_nodes /* one node: all n vectors */, tsvq_wide_ctrl* d_ctrl, void* d_ws, uint32_t total_blocks, tsvq_root_out* d_out);
+                                 const tsvq_wide_node* d_nodes /* one node: all n vectors */, tsvq_wide_ctrl* d_ctrl, void* d_ws, uint32_t total_blocks, tsvq_root_out* d_out,
+                                 int windows /* bu_hip_tuning::tsvq_windows */);
 // prepare_root of n_nodes member spans through the many-workgroup passes (nodes: buf / start / count / first_block / n_blocks / out_index); d_outs[out_index].pad == 1:
 // the span's integer totals left the exact range, run it through launch_tsvq_span_roots
 hipError_t launch_tsvq_wide_span_roots(hipStream_t st, const uint32_t* d_keys, const uint64_t* d_w64, const uint32_t* d_perm0, const uint32_t* d_perm1, void* d_packed,
-                                       const tsvq_wide_node* d_nodes, uint32_t n_nodes, tsvq_wide_ctrl* d_ctrl, void* d_ws, uint32_t total_blocks, tsvq_root_out* d_outs);
+                                       const tsvq_wide_node* d_nodes, uint32_t n_nodes, tsvq_wide_ctrl* d_ctrl, void* d_ws, uint32_t total_blocks, tsvq_root_out* d_outs, int windows);
 hipError_t launch_tsvq_wide_split(hipStream_t st, const uint32_t* d_keys, const uint64_t* d_w64, uint32_t* d_perm0, uint32_t* d_perm1, uint8_t* d_side, void* d_packed /* 8 bytes per vector */,
                                   const tsvq_wide_node* d_nodes, uint32_t n_nodes, tsvq_wide_ctrl* d_ctrl, void* d_ws, uint32_t total_blocks, tsvq_split_out* d_outs,
                                   bool chained_covariance /* the covariance pass through launch_tsvq_cov_axis instead of 136 walks per node */,
                                   bool side_chains_exact /* 3 x the heaviest node's weight < 2^24: every projection / two-means chain total is exact, no maps needed */,
-                                  uint32_t fused_workgroups /* > 0: the projection / two-means passes + the partition as ONE persistent kernel of that many workgroups (<= CUs) */,
-                                  uint32_t* d_fused_verdict /* host-visible word: 1 when the fused kernel ran to its end, 0 when it gave up (nothing of the round may be used) */);
+                                  int windows /* bu_hip_tuning::tsvq_windows */);
 // the same split for 6-float rows (the endpoint tree's large nodes, tsvq_wide6_kernels.hip): workspace / node / ctrl records as above (no barrier words); d_va: 6 n floats,
 // d_tta: n doubles -- the list-order copies of the per-member addends the covariance pass lays out (launch_tsvq_cov_axis6: chained sums, one workgroup per node)
 hipError_t launch_tsvq_cov_axis6(hipStream_t st, const float* d_rows, const uint64_t* d_w64, const uint32_t* d_perm0, const uint32_t* d_perm1,
@@ -73,6 +73,5 @@ hipError_t launch_tsvq_wide6_root(hipStream_t st, const float* d_rows, const uin
 hipError_t launch_tsvq_wide6_split(hipStream_t st, const float* d_rows, const uint64_t* d_w64, uint32_t n, uint32_t* d_perm0, uint32_t* d_perm1, uint8_t* d_side,
                                    const tsvq_wide_node* d_nodes, uint32_t n_nodes, tsvq_wide_ctrl* d_ctrl, void* d_ws, uint32_t total_blocks, tsvq_split_out* d_outs,
                                    float* d_va, double* d_tta);
-size_t tsvq_wide_sync_bytes();   // bytes the fused kernel's barrier words take IN FRONT OF d_ctrl (the ctrl allocation starts that many bytes earlier)
 
 } // namespace bu

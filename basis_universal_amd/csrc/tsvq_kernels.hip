@@ -965,7 +965,7 @@ hipError_t launch_tsvq_span_roots(hipStream_t st, int dim, bool packed, bool exa
 }
 
 hipError_t launch_tsvq_split(hipStream_t st, int dim, bool packed, bool exact, const void* d_rows, const uint64_t* d_w64, uint32_t* d_perm0, uint32_t* d_perm1, uint8_t* d_side,
-                             const tsvq_node_in* d_nodes, uint32_t n_nodes, tsvq_split_out* d_outs) {
+                             const tsvq_node_in* d_nodes, uint32_t n_nodes, tsvq_split_out* d_outs, uint32_t dense_min) {
     if (!n_nodes) return hipSuccess;
     const size_t lds = tsvq_lds_bytes(dim);
     hipError_t e;
@@ -974,8 +974,7 @@ hipError_t launch_tsvq_split(hipStream_t st, int dim, bool packed, bool exact, c
         hipLaunchKernelGGL((k_tsvq_split<NN, SRC, EXV>), dim3(n_nodes), dim3(TQ_THREADS), lds, st, srcval, d_w64, d_perm0, d_perm1, d_side, d_nodes, d_outs); } while (0)
     if (dim == 16 && packed) {
         packed16_rows src{static_cast<const uint32_t*>(d_rows)};
-        const char* de = std::getenv("BU_TSVQ_DENSE_MIN");   // node count of a round from which the two-workgroups-per-CU build of the exact kernel is used (0: never)
-        const uint32_t dense_min = de ? (uint32_t)std::atoi(de) : 257u;
+        // dense_min (bu_hip_tuning::tsvq_dense_min, default 257): node count of a round from which the two-workgroups-per-CU build of the exact kernel is used (0: never)
         if (exact && dense_min && n_nodes >= dense_min) {
             if ((e = set_lds(k_tsvq_split_dense<16, packed16_rows, true>, lds)) != hipSuccess) return e;
             hipLaunchKernelGGL((k_tsvq_split_dense<16, packed16_rows, true>), dim3(n_nodes), dim3(TQ_THREADS), lds, st, src, d_w64, d_perm0, d_perm1, d_side, d_nodes, d_outs);

@@ -35,16 +35,15 @@ namespace {
 #include "tsvq_wide_common.h"   // (inside the unnamed namespace: internal linkage in each of the two translation units that use it)
 
 
-enum { WM_ROOT = 0, WM_COV = 1, WM_PROJ = 2, WM_DIST = 3, WM_SIDE = 4 };   // WM_SIDE: WM_PROJ or WM_DIST chosen at run time (`dist`): the passes of the fused kernel
-#define W_IS_DIST(MODE, dist) ((MODE) == WM_DIST || ((MODE) == WM_SIDE && (dist)))
-#define W_IS_PROJ(MODE, dist) ((MODE) == WM_PROJ || ((MODE) == WM_SIDE && !(dist)))
+enum { WM_ROOT = 0, WM_COV = 1, WM_PROJ = 2, WM_DIST = 3 };
+#define W_IS_DIST(MODE, dist) ((MODE) == WM_DIST)
+#define W_IS_PROJ(MODE, dist) ((MODE) == WM_PROJ)
 
 template <int MODE> struct mode_traits;
 template <> struct mode_traits<WM_ROOT> { static constexpr int NCH = 16; };
 template <> struct mode_traits<WM_COV>  { static constexpr int NCH = 136; };
 template <> struct mode_traits<WM_PROJ> { static constexpr int NCH = 32; };
 template <> struct mode_traits<WM_DIST> { static constexpr int NCH = 32; };
-template <> struct mode_traits<WM_SIDE> { static constexpr int NCH = 32; };
 
 // covariance chain -> (x, y >= x), the enumeration of tsvq_kernels.hip (row-major upper triangle)
 __device__ __forceinline__ void cov_xy(int c, int& x, int& y) { x = 0; while (c >= 16 - x) { c -= 16 - x; x++; } y = x + c; }
@@ -531,7 +530,7 @@ __device__ __forceinline__ void wide_walk_body(const uint32_t* __restrict__ keys
             const uint32_t pos = min(p0 + (uint32_t)(r * 64 + lane), nd.count - 1);
             if (MODE == WM_ROOT && !pk) { m.key[r] = keys[pos]; m.w[r] = w64[pos]; }
             else { const uint2 v = pk[nd.start + pos]; m.key[r] = v.x; m.w[r] = v.y; }
-            m.sd[r] = (MODE == WM_PROJ || MODE == WM_DIST || MODE == WM_SIDE) ? side[nd.start + pos] : (uint8_t)0;
+            m.sd[r] = (MODE == WM_PROJ || MODE == WM_DIST) ? side[nd.start + pos] : (uint8_t)0;
         }
     };
     auto addends = [&](uint32_t blk, const staged& m, float (&a)[4]) {
@@ -549,7 +548,7 @@ __device__ __forceinline__ void wide_walk_body(const uint32_t* __restrict__ keys
                 v = dx * wdy;
             } else {
                 v = (float)packed16_value(key, cx) * wf;
-                if (MODE == WM_PROJ || MODE == WM_DIST || MODE == WM_SIDE) v = (m.sd[r] != 0) == chain_right ? v : 0.0f;
+                if (MODE == WM_PROJ || MODE == WM_DIST) v = (m.sd[r] != 0) == chain_right ? v : 0.0f;
             }
             a[r] = valid ? v : -0.0f;   // past the node's end: leaves every sum as it is
         }
@@ -802,90 +801,6 @@ __global__ __launch_bounds__(WB) void k_wide_partition(uint32_t* perm0, uint32_t
     wide_partition_body(perm0, perm1, side, nodes, n_nodes, ctrl, ws_base, tb, outs, blockIdx.x);
 }
 
-// ------------------------------------------------------------------------------------------------------------ the side passes of a round in ONE launch
-// The projection pass and the up to six two-means passes of a round are five dependent kernels each, 5 - 50 us apiece, and the host cannot know how many of the six the
-// nodes will need: a round paid ~35 launches (~4.6 us each even when every node had converged and the kernel had nothing to do) for ~0.3 ms of work. Here the same
-// per-phase bodies run inside one persistent kernel -- one workgroup per CU, a device-scope barrier where a kernel boundary used to be, the passes ending as soon as no
-// node is active -- followed by the partition. Results are those of the separate kernels (same bodies, same order).
-//
-// The barrier needs every workgroup resident at once. One workgroup per CU always is when the GPU is this kernel's alone; beside other kernels (the one-workgroup
-// splits on the side stream, other contexts) late workgroups get their slots as those kernels drain. What cannot be excluded is two such kernels of different
-// processes each holding part of the chip: a workgroup that waits longer than FUSED_SPIN_LIMIT polls raises `abort`, everybody leaves, no result record is written and
-// the host runs the round again through the separate kernels (bu_hip_tsvq_split).
-struct wide_sync { uint32_t arrived; uint32_t abort; uint32_t finished; uint32_t pad[61]; };   // 256 bytes, zeroed with the ctrl records in front of every round
-constexpr uint32_t FUSED_SPIN_LIMIT = 40000;   // ~20-40 ms
-
-__device__ __forceinline__ bool grid_sync(wide_sync* sy, uint32_t& epoch) {
-    __shared__ uint32_t s_ok;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        epoch++;
-        __threadfence();                                       // what this workgroup wrote is visible device-wide before it is counted
-        __hip_atomic_fetch_add(&sy->arrived, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        const uint32_t target = epoch * gridDim.x;
-        uint32_t ok = 1, spins = 0;
-        while (__hip_atomic_load(&sy->arrived, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
-            if (__hip_atomic_load(&sy->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 || ++spins > FUSED_SPIN_LIMIT) {
-                __hip_atomic_store(&sy->abort, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                ok = 0;
-                break;
-            }
-            __builtin_amdgcn_s_sleep(4);
-        }
-        __threadfence();                                       // ... and what the others wrote is fetched anew from here on
-        s_ok = ok;
-    }
-    __syncthreads();
-    return s_ok != 0;
-}
-
-__global__ __launch_bounds__(WB) void k_wide_side_passes(const uint32_t* __restrict__ keys, const uint64_t* __restrict__ w64, uint32_t* perm0, uint32_t* perm1, uint8_t* side, uint2* pk,
-                                                         const tsvq_wide_node* __restrict__ nodes, uint32_t n_nodes, tsvq_wide_ctrl* ctrl, void* ws_base, uint32_t tb,
-                                                         tsvq_split_out* outs, wide_sync* sy, int all_chains_exact) {
-    constexpr int NCH = 32, NCW = 8;
-    __shared__ __align__(16) float s_add[4][WB];
-    __shared__ uint32_t s_active;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t G = gridDim.x, wg = blockIdx.x;
-    uint32_t epoch = 0;
-    for (int pass = 0; pass < 7; pass++) {
-        const bool dist = pass != 0;
-        if (pass > 1) {   // anybody still iterating? (the records were written before the barrier that ended the previous pass)
-            if (tid == 0) s_active = 0;
-            __syncthreads();
-            uint32_t mine = 0;
-            for (uint32_t i = (uint32_t)tid; i < n_nodes; i += WB) mine |= __hip_atomic_load(&ctrl[i].done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0 ? 1u : 0u;
-            if (mine) s_active = 1;   // (benign race: everybody writes 1)
-            __syncthreads();
-            const uint32_t active = s_active;
-            __syncthreads();
-            if (!active) break;
-        }
-        for (uint32_t blk = wg; blk < tb; blk += G) { wide_sums_body<WM_SIDE>(keys, w64, perm0, perm1, side, nodes, n_nodes, ctrl, ws_base, tb, pk, blk, dist); __syncthreads(); }
-        if (!grid_sync(sy, epoch)) return;
-        for (uint32_t t = wg; t < n_nodes * (uint32_t)(NCW + 1); t += G) { wide_scan_body<WM_SIDE>(nodes, ctrl, ws_base, tb, t / (NCW + 1), t % (NCW + 1)); __syncthreads(); }
-        if (!grid_sync(sy, epoch)) return;
-        if (!all_chains_exact) {
-            for (uint32_t blk = wg; blk < tb; blk += G) { wide_stretches_body<WM_SIDE>(keys, w64, pk, side, nodes, n_nodes, ctrl, ws_base, tb, blk); __syncthreads(); }
-            if (!grid_sync(sy, epoch)) return;
-            for (uint32_t t = wg * 4 + (uint32_t)wave; t < n_nodes * (uint32_t)NCH; t += G * 4) wide_walk_body<WM_SIDE>(keys, w64, pk, side, nodes, ctrl, ws_base, tb, t, lane, s_add[wave]);
-            if (!grid_sync(sy, epoch)) return;
-        }
-        if (wave == 0) for (uint32_t ni = wg; ni < n_nodes; ni += G) wide_finish_body<WM_SIDE>(nodes, ctrl, nullptr, ni, lane, dist);
-        if (!grid_sync(sy, epoch)) return;
-    }
-    for (uint32_t blk = wg; blk < tb; blk += G) { wide_partition_body(perm0, perm1, side, nodes, n_nodes, ctrl, ws_base, tb, outs, blk); __syncthreads(); }
-    if (tid == 0) __hip_atomic_fetch_add(&sy->finished, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);   // every workgroup got here: the round is whole
-}
-
-// behind the fused kernel on its stream: 1 when every one of its workgroups ran to the end (otherwise the round's records and member lists must not be used)
-__global__ void k_wide_fused_verdict(const wide_sync* sy, uint32_t workgroups, uint32_t* verdict) {
-    if (threadIdx.x == 0) {
-        const uint32_t ok = (__hip_atomic_load(&sy->finished, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == workgroups && __hip_atomic_load(&sy->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) ? 1u : 0u;
-        __hip_atomic_store(verdict, ok, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-}
-
 __global__ __launch_bounds__(256) void k_wide_iota(uint32_t n, uint32_t* __restrict__ perm0) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) perm0[i] = i;
@@ -901,7 +816,7 @@ size_t tsvq_wide_workspace_bytes(uint32_t total_blocks) {
 
 template <int MODE>
 static void launch_pass(hipStream_t st, const uint32_t* keys, const uint64_t* w64, uint32_t* perm0, uint32_t* perm1, uint8_t* side, uint2* pk, const tsvq_wide_node* nodes,
-                        uint32_t n_nodes, uint32_t tb, tsvq_wide_ctrl* ctrl, void* ws, tsvq_root_out* root_out, bool all_chains_exact = false) {
+                        uint32_t n_nodes, uint32_t tb, tsvq_wide_ctrl* ctrl, void* ws, tsvq_root_out* root_out, int windows_knob, bool all_chains_exact = false) {
     constexpr int NCH = mode_traits<MODE>::NCH;
     hipLaunchKernelGGL((k_wide_sums<MODE>), dim3(tb), dim3(WB), 0, st, keys, w64, perm0, perm1, side, nodes, n_nodes, ctrl, ws, tb, pk);
     hipLaunchKernelGGL((k_wide_scan<MODE>), dim3(n_nodes, (NCH + 3) / 4 + (MODE == WM_COV ? 0 : 1)), dim3(256), 0, st, nodes, ctrl, ws, tb);
@@ -909,9 +824,8 @@ static void launch_pass(hipStream_t st, const uint32_t* keys, const uint64_t* w6
         hipLaunchKernelGGL((k_wide_stretches<MODE>), dim3(tb), dim3(ST_THREADS), 0, st, keys, w64, pk, side, nodes, n_nodes, ctrl, ws, tb);
         // The pre-composed windows pay for nodes of millions of members (8192^2 q255, rounds 1-3: the covariance walk is 0.75 ms per round without them); for the
         // 4096^2 image the extra launch costs more than the walk gains (root covariance walk 107 -> 53 us, many-workgroup rounds 5.50 -> 5.62 ms per step, one box):
-        // on from an average of 2,048 blocks per node of the batch. BU_TSVQ_WINDOWS=0 / 1 forces it (tests run both).
-        const char* we = std::getenv("BU_TSVQ_WINDOWS");
-        const bool windows = we ? we[0] != '0' : (tb / (n_nodes ? n_nodes : 1u) >= 2048u);
+        // by default on from an average of 2,048 blocks per node of the batch (bu_hip_tuning::tsvq_windows: 0 = that rule, 1 = always, 2 = never; tests run both).
+        const bool windows = windows_knob == 1 || (windows_knob == 0 && tb / (n_nodes ? n_nodes : 1u) >= 2048u);
         if (windows) {
             hipLaunchKernelGGL((k_wide_windows<MODE>), dim3((tb / 64 + n_nodes) * NCH), dim3(64), 0, st, nodes, n_nodes, ctrl, ws, tb);
             hipLaunchKernelGGL((k_wide_walk<MODE, true>), dim3(n_nodes * NCH), dim3(64), 0, st, keys, w64, pk, side, nodes, ctrl, ws, tb);
@@ -922,47 +836,38 @@ static void launch_pass(hipStream_t st, const uint32_t* keys, const uint64_t* w6
 }
 
 hipError_t launch_tsvq_wide_root(hipStream_t st, const uint32_t* d_keys, const uint64_t* d_w64, uint32_t n, uint32_t* d_perm0, const tsvq_wide_node* d_nodes,
-                                 tsvq_wide_ctrl* d_ctrl, void* d_ws, uint32_t total_blocks, tsvq_root_out* d_out) {
+                                 tsvq_wide_ctrl* d_ctrl, void* d_ws, uint32_t total_blocks, tsvq_root_out* d_out, int windows) {
     hipError_t e = hipMemsetAsync(d_ctrl, 0, sizeof(tsvq_wide_ctrl), st);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_wide_iota, dim3((n + 255) / 256), dim3(256), 0, st, n, d_perm0);
-    launch_pass<WM_ROOT>(st, d_keys, d_w64, nullptr, nullptr, nullptr, nullptr, d_nodes, 1, total_blocks, d_ctrl, d_ws, d_out);
+    launch_pass<WM_ROOT>(st, d_keys, d_w64, nullptr, nullptr, nullptr, nullptr, d_nodes, 1, total_blocks, d_ctrl, d_ws, d_out, windows);
     return hipGetLastError();
 }
 
 hipError_t launch_tsvq_wide_span_roots(hipStream_t st, const uint32_t* d_keys, const uint64_t* d_w64, const uint32_t* d_perm0, const uint32_t* d_perm1, void* d_packed,
-                                       const tsvq_wide_node* d_nodes, uint32_t n_nodes, tsvq_wide_ctrl* d_ctrl, void* d_ws, uint32_t total_blocks, tsvq_root_out* d_outs) {
+                                       const tsvq_wide_node* d_nodes, uint32_t n_nodes, tsvq_wide_ctrl* d_ctrl, void* d_ws, uint32_t total_blocks, tsvq_root_out* d_outs, int windows) {
     if (!n_nodes) return hipSuccess;
     hipError_t e = hipMemsetAsync(d_ctrl, 0, (size_t)n_nodes * sizeof(tsvq_wide_ctrl), st);
     if (e != hipSuccess) return e;
-    launch_pass<WM_ROOT>(st, d_keys, d_w64, const_cast<uint32_t*>(d_perm0), const_cast<uint32_t*>(d_perm1), nullptr, static_cast<uint2*>(d_packed), d_nodes, n_nodes, total_blocks, d_ctrl, d_ws, d_outs);
+    launch_pass<WM_ROOT>(st, d_keys, d_w64, const_cast<uint32_t*>(d_perm0), const_cast<uint32_t*>(d_perm1), nullptr, static_cast<uint2*>(d_packed), d_nodes, n_nodes, total_blocks, d_ctrl, d_ws, d_outs, windows);
     return hipGetLastError();
 }
 
 hipError_t launch_tsvq_wide_split(hipStream_t st, const uint32_t* d_keys, const uint64_t* d_w64, uint32_t* d_perm0, uint32_t* d_perm1, uint8_t* d_side, void* d_packed,
                                   const tsvq_wide_node* d_nodes, uint32_t n_nodes, tsvq_wide_ctrl* d_ctrl, void* d_ws, uint32_t total_blocks, tsvq_split_out* d_outs,
-                                  bool chained_covariance, bool side_chains_exact, uint32_t fused_workgroups, uint32_t* d_fused_verdict) {
+                                  bool chained_covariance, bool side_chains_exact, int windows) {
     if (!n_nodes) return hipSuccess;
-    // the ctrl records of the batch and, in front of them, the fused kernel's barrier words (tsvq_wide_sync_bytes() in front of d_ctrl: one memset)
-    hipError_t e = hipMemsetAsync(reinterpret_cast<char*>(d_ctrl) - sizeof(wide_sync), 0, sizeof(wide_sync) + (size_t)n_nodes * sizeof(tsvq_wide_ctrl), st);
+    hipError_t e = hipMemsetAsync(d_ctrl, 0, (size_t)n_nodes * sizeof(tsvq_wide_ctrl), st);
     if (e != hipSuccess) return e;
     if (chained_covariance) {   // raw chain sums into ctrl[].sums (three workgroups per node), then the pass's own tail: renormalisation + principal axis
         if ((e = launch_tsvq_cov_axis(st, d_keys, d_w64, d_perm0, d_perm1, d_nodes, n_nodes, d_ctrl, d_packed)) != hipSuccess) return e;
         hipLaunchKernelGGL((k_wide_finish<WM_COV>), dim3(n_nodes), dim3(64), 0, st, d_nodes, d_ctrl, nullptr);
     }
-    else launch_pass<WM_COV>(st, d_keys, d_w64, d_perm0, d_perm1, d_side, static_cast<uint2*>(d_packed), d_nodes, n_nodes, total_blocks, d_ctrl, d_ws, nullptr);
-    if (fused_workgroups) {
-        hipLaunchKernelGGL(k_wide_side_passes, dim3(fused_workgroups), dim3(WB), 0, st, d_keys, d_w64, d_perm0, d_perm1, d_side, static_cast<uint2*>(d_packed), d_nodes, n_nodes, d_ctrl, d_ws,
-                           total_blocks, d_outs, reinterpret_cast<wide_sync*>(reinterpret_cast<char*>(d_ctrl) - sizeof(wide_sync)), side_chains_exact ? 1 : 0);
-        hipLaunchKernelGGL(k_wide_fused_verdict, dim3(1), dim3(64), 0, st, reinterpret_cast<const wide_sync*>(reinterpret_cast<char*>(d_ctrl) - sizeof(wide_sync)), fused_workgroups, d_fused_verdict);
-        return hipGetLastError();
-    }
-    launch_pass<WM_PROJ>(st, d_keys, d_w64, d_perm0, d_perm1, d_side, static_cast<uint2*>(d_packed), d_nodes, n_nodes, total_blocks, d_ctrl, d_ws, nullptr, side_chains_exact);
-    for (int it = 0; it < 6; it++) launch_pass<WM_DIST>(st, d_keys, d_w64, d_perm0, d_perm1, d_side, static_cast<uint2*>(d_packed), d_nodes, n_nodes, total_blocks, d_ctrl, d_ws, nullptr, side_chains_exact);
+    else launch_pass<WM_COV>(st, d_keys, d_w64, d_perm0, d_perm1, d_side, static_cast<uint2*>(d_packed), d_nodes, n_nodes, total_blocks, d_ctrl, d_ws, nullptr, windows);
+    launch_pass<WM_PROJ>(st, d_keys, d_w64, d_perm0, d_perm1, d_side, static_cast<uint2*>(d_packed), d_nodes, n_nodes, total_blocks, d_ctrl, d_ws, nullptr, windows, side_chains_exact);
+    for (int it = 0; it < 6; it++) launch_pass<WM_DIST>(st, d_keys, d_w64, d_perm0, d_perm1, d_side, static_cast<uint2*>(d_packed), d_nodes, n_nodes, total_blocks, d_ctrl, d_ws, nullptr, windows, side_chains_exact);
     hipLaunchKernelGGL(k_wide_partition, dim3(total_blocks), dim3(WB), 0, st, d_perm0, d_perm1, d_side, d_nodes, n_nodes, d_ctrl, d_ws, total_blocks, d_outs);
     return hipGetLastError();
 }
-
-size_t tsvq_wide_sync_bytes() { return sizeof(wide_sync); }
 
 } // namespace bu

@@ -889,9 +889,9 @@ def end_to_end(helpers, args, img):
             want = base_hash.get("stock_1_thread")   # every task of basis_parallel_compress owns a one-thread pool: the single-threaded codebooks
             # Sixteen compressors allocate and release ~300 MB each per image (the reference's image copies and tile arrays above all); with glibc's defaults that is ~75,000
             # page faults per image, all serialised on one address space's lock -- the faults, not the GPU or the backend, capped this mode at ~390 Mpix/s in round 4
-            # (tools/ab_parallel2.sh). The benchmark APPLICATION therefore links a recycling operator new of its own (csrc/host/block_pool.cpp compiled into
-            # process_bench_resident; the library itself keeps the same pool private and never touches the process's malloc). Second run for comparison: glibc's malloc
-            # on transparent huge pages (GLIBC_TUNABLES=glibc.malloc.hugetlb=1), round 4's setting.   One host thread per frontend / backend: the images are the parallelism here.
+            # (tools/ab_parallel2.sh). The benchmark APPLICATION sets its own malloc policy (mallopt in integration/process_bench.cpp's main, all link variants alike; the
+            # libraries never touch the process's allocator). Second run: the same on transparent huge pages (GLIBC_TUNABLES=glibc.malloc.hugetlb=1), round 4's setting.
+            # One host thread per frontend / backend: the images are the parallelism here.
             for key, tun in (("resident_parallel", None), ("resident_parallel_glibc_hugetlb", "glibc.malloc.hugetlb=1")):
                 env = dict(os.environ)
                 env.setdefault("BU_HOST_THREADS", "1")

@@ -95,6 +95,26 @@ BU_HIP_API int   bu_hip_context_device(const bu_hip_context*);
 BU_HIP_API int   bu_hip_set_stream(bu_hip_context*, void* hip_stream);
 BU_HIP_API void* bu_hip_get_stream(bu_hip_context*);
 BU_HIP_API int   bu_hip_sync(bu_hip_context*);
+/* Tuning of the device paths that have more than one (all bit-identical: tests run every one of them). Each field has a measured default; the
+ * environment variable named beside it overrides that default ONCE per process (read when the first context is created); bu_hip_set_tuning overrides both for one
+ * context (trees created on it afterwards take the values; NULL restores the process defaults; parking a context restores them too). Versioned by size:
+ * struct_bytes = sizeof(bu_hip_tuning) of the caller's header, fields a caller does not have keep their defaults. */
+typedef struct bu_hip_tuning {
+    uint32_t struct_bytes;
+    uint32_t tsvq_wide_min;       /* BU_TSVQ_WIDE_MIN      8192   selector (packed) nodes of this many members and more take the many-workgroup passes; 0 (BU_TSVQ_WIDE=0) = never */
+    uint32_t tsvq_wide6_min;      /* BU_TSVQ_WIDE6_MIN     8192   the same for endpoint (6-float) nodes; 0 (BU_TSVQ_WIDE6=0 or BU_TSVQ_WIDE=0) = never */
+    uint32_t tsvq_wide_cov_min;   /* BU_TSVQ_WIDE_COV_MIN  98304  batches whose largest node is smaller run the covariance pass chained instead of through the maps */
+    uint32_t tsvq_windows;        /* BU_TSVQ_WINDOWS       0      pre-composed 64-block windows in the walks: 0 = batches averaging >= 2048 blocks per node, 1 = always, 2 (env "0") = never */
+    uint32_t tsvq_dense_min;      /* BU_TSVQ_DENSE_MIN     257    rounds of this many nodes take the 128-register (two workgroups per CU) build of the exact split kernel; 0 = never */
+    uint32_t tsvq_zero_copy;      /* BU_TSVQ_ZEROCOPY      1      node / result records of a round in coherent pinned memory + a flag the host looks at; 0 = staged copies + synchronise */
+    uint32_t tsvq_chained_only;   /* BU_TSVQ_CHAINED       0      1 = every float sum member by member in one workgroup per node (the slowest path; what the others are tested against) */
+    uint32_t tsvq_poll;           /* BU_TSVQ_POLL          0      waiting for a round: 0 = spin when this is the process's only context, else yield / nap; 1 (spin) / 2 (yield) force it */
+    uint32_t refine_unsorted;     /*                       0      1 = refine_endpoint_clusterization through the unsorted kernel (the one lists beyond 65,535 entries take anyway) */
+    uint32_t debug;               /* BU_TSVQ_ROUNDS = 1 | BU_TSVQ_SERIAL = 2 | BU_TSVQ_STATS = 4: developer aids (round time line on stderr, one node per round, walk statistics) */
+} bu_hip_tuning;
+BU_HIP_API void bu_hip_get_tuning(const bu_hip_context* /* NULL: the process defaults */, bu_hip_tuning* out, uint32_t struct_bytes);
+BU_HIP_API int  bu_hip_set_tuning(bu_hip_context*, const bu_hip_tuning* /* NULL: back to the process defaults */);
+
 /* Cooperative waiting. By default a call that needs a device result blocks its host thread (hipStreamSynchronize, or a look-loop on a zero-copy flag). A host that
  * drives SEVERAL contexts from ONE thread -- bu_frontend_pipeline_* (basisu_hip_frontend.h): every image in flight is a task with a stack of its own on the pipeline's
  * one driver thread -- installs a hook instead: wherever a call on this context would block, the stream is only queried, and fn(user) is called between the looks;

@@ -12,6 +12,13 @@
 // With `parallel images` = N > 0 the image is compressed N x `repeats` times through the reference's own throughput driver, basis_parallel_compress
 // (comp.cpp:5466-5559: a pool of `threads` workers, one basis_compressor -- and with use_opencl one accelerator context -- per image in flight): the JSON line
 // then carries the wall seconds of each call, and whether every image's bytes equal the others'.
+//
+// Allocator policy of THIS application (all three link variants alike): a compressor allocates and frees ~300 MB of multi-megabyte arrays per image; with glibc's
+// defaults each of them is a fresh mapping whose pages fault in one by one and is unmapped again on free. main() keeps large blocks on the heap instead
+// (mallopt; BU_BENCH_KEEP_MALLOC_DEFAULTS=1 leaves glibc alone). Until round 4 the frontend LIBRARY did this to whatever process loaded it -- which only the
+// resident variant did; a library has no business there (it recycles its own blocks privately now: csrc/host/block_pool.cpp), an application does.
+#include <malloc.h>
+
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -31,6 +38,11 @@ int main(int argc, char** argv) {
     const uint32_t threads = (uint32_t)std::atoi(argv[6]);
     const bool use_opencl = std::atoi(argv[7]) != 0;
     const int repeats = std::atoi(argv[8]);
+    if (!std::getenv("BU_BENCH_KEEP_MALLOC_DEFAULTS")) {
+        mallopt(M_MMAP_THRESHOLD, 1 << 30);
+        mallopt(M_TRIM_THRESHOLD, 1 << 30);
+        mallopt(M_TOP_PAD, 64 << 20);
+    }
     basisu_encoder_init(use_opencl, false);
     image img(w, h);
     {

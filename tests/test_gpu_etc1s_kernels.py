@@ -155,11 +155,12 @@ def _codebook(blocks, k, seed, level=1, perceptual=1):
 @pytest.mark.parametrize("presorted", [True, False])
 @pytest.mark.parametrize("perceptual", [1, 0])
 @pytest.mark.parametrize("hier", [True, False, "foreign"])
-def test_refine_endpoint_clusterization(hip_ctx, blocks, d_blocks, hier, perceptual, presorted, monkeypatch):
+def test_refine_endpoint_clusterization(hip_ctx, blocks, d_blocks, hier, perceptual, presorted, request):
     # presorted: the candidate lists re-sorted on the device by (clamping class, intensity table) first (k_refine_sort_lists + k_refine_sorted, the
     # default); otherwise the kernel that filters and classifies the lists as it reads them (kept for codebooks beyond 65,535 entries)
     if not presorted:
-        monkeypatch.setenv("BU_REFINE_UNSORTED", "1")
+        hip_ctx.set_tuning(refine_unsorted=1)
+        request.addfinalizer(hip_ctx.set_tuning)   # back to the process defaults
     n = blocks.shape[0]
     k = 300
     params, block_cluster = _codebook(blocks, k, 11, perceptual=perceptual)

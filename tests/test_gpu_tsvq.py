@@ -112,7 +112,7 @@ WIDE_CASES = [(5000, 300, 32, "sel", 50, 512), (120000, 2731, 32, "sel", 4096, 5
 def test_wide_nodes_match_host_tsvq(hip_ctx, monkeypatch, n, k, p, kind, wmax, wide_min):
     """Large nodes spread over many workgroups (tsvq_wide_kernels.hip: order-preserving float sums through per-block parity maps) must
     give the tree of the sequential sums, member list for member list: against the host restatement tsvq.h (pinned to the reference in
-    tests/test_host_logic.py), against the one-workgroup kernels (BU_TSVQ_WIDE=0), and against the reference itself where present."""
+    tests/test_host_logic.py), against the one-workgroup kernels (tsvq_wide_min = 0), and against the reference itself where present."""
     from basis_universal_amd import etc1s
     F = etc1s.load_frontend_library()
     rng = np.random.default_rng(n * 3 + k + wide_min)
@@ -134,18 +134,16 @@ def test_wide_nodes_match_host_tsvq(hip_ctx, monkeypatch, n, k, p, kind, wmax, w
     outs = {}
     # wide: every pass through the parity maps; hybrid: the covariance pass of all but the largest nodes chained (the default)
     # + windows: the walk takes 64 blocks at a time where their pre-composed map applies (k_wide_windows; on by itself only for nodes of millions of members)
-    for name, env in (("wide", {"BU_TSVQ_WIDE_MIN": str(wide_min), "BU_TSVQ_WIDE_COV_MIN": "0", "BU_TSVQ_WINDOWS": "0"}), ("hybrid", {"BU_TSVQ_WIDE_MIN": str(wide_min)}),
-                      ("windows", {"BU_TSVQ_WIDE_MIN": str(wide_min), "BU_TSVQ_WIDE_COV_MIN": "0", "BU_TSVQ_WINDOWS": "1"}), ("narrow", {"BU_TSVQ_WIDE": "0"})):
+    for name, knobs in (("wide", dict(tsvq_wide_min=wide_min, tsvq_wide_cov_min=0, tsvq_windows=2)), ("hybrid", dict(tsvq_wide_min=wide_min)),
+                        ("windows", dict(tsvq_wide_min=wide_min, tsvq_wide_cov_min=0, tsvq_windows=1)), ("narrow", dict(tsvq_wide_min=0))):
         if name == "narrow" and n > 200000:
             continue
-        for key in ("BU_TSVQ_WIDE_MIN", "BU_TSVQ_WIDE", "BU_TSVQ_WIDE_COV_MIN", "BU_TSVQ_WINDOWS"):
-            monkeypatch.delenv(key, raising=False)
-        for key, val in env.items():
-            monkeypatch.setenv(key, val)
+        hip_ctx.set_tuning(**knobs)   # bu_hip_set_tuning (include/basisu_hip.h): which of the bit-identical paths the trees built on this context take
         a = np.zeros(cap, np.uint32); b = np.zeros(cap, np.uint32); st = np.array([0xBACCED, 0, 0], np.uint32)
         assert F.bu_device_tsvq(hip_ctx.h, 16, v.ctypes.data_as(VP), w.ctypes.data_as(VP), n, k, p, a.ctypes.data_as(VP), cap, b.ctypes.data_as(VP), cap,
                                 st.ctypes.data_as(VP)) == 1
         outs[name] = (a, b)
+    hip_ctx.set_tuning()   # the session's context back to the process defaults
     a1 = np.zeros(cap, np.uint32); b1 = np.zeros(cap, np.uint32)
     assert F.bu_host_tsvq(16, v.ctypes.data_as(VP), w.ctypes.data_as(VP), n, k, p, a1.ctypes.data_as(VP), cap, b1.ctypes.data_as(VP), cap) == 1
     for name, (a, b) in outs.items():
@@ -182,7 +180,7 @@ WIDE6_CASES = [(40000, 2416, 16, "ep", 3, 512), (40000, 2416, 16, "ep", 3, 6144)
 @pytest.mark.parametrize("n,k,p,kind,wmax,wide_min", WIDE6_CASES)
 def test_wide6_nodes_match_host_tsvq(hip_ctx, monkeypatch, n, k, p, kind, wmax, wide_min):
     """The endpoint tree's large nodes through the many-workgroup path for 6-float rows (tsvq_wide6_kernels.hip): the tree of the sequential sums, member list for
-    member list -- against the host restatement, against the one-workgroup kernels (BU_TSVQ_WIDE6=0) and against the reference where present. The dark cases are built
+    member list -- against the host restatement, against the one-workgroup kernels (tsvq_wide6_min = 0) and against the reference where present. The dark cases are built
     for the double accumulators' block test (tiny addends under large sums, weights up to 2^34: blocks that must be added member by member), the 2^50 weights for the
     guard that keeps nodes whose weight sums leave the exact range out of the path, the line for the degenerate projection that is handed back."""
     from basis_universal_amd import etc1s
@@ -195,15 +193,13 @@ def test_wide6_nodes_match_host_tsvq(hip_ctx, monkeypatch, n, k, p, kind, wmax, 
         w[rng.random(n) < 0.7] = 1   # most weights small, a few enormous
     cap = 4 * n + 4 * k + 100
     outs = {}
-    for name, env in (("wide6", {"BU_TSVQ_WIDE6_MIN": str(wide_min)}), ("narrow", {"BU_TSVQ_WIDE6": "0"})):
-        for key in ("BU_TSVQ_WIDE6_MIN", "BU_TSVQ_WIDE6"):
-            monkeypatch.delenv(key, raising=False)
-        for key, val in env.items():
-            monkeypatch.setenv(key, val)
+    for name, knobs in (("wide6", dict(tsvq_wide6_min=wide_min)), ("narrow", dict(tsvq_wide6_min=0))):
+        hip_ctx.set_tuning(**knobs)
         a = np.zeros(cap, np.uint32); b = np.zeros(cap, np.uint32); st = np.zeros(3, np.uint32)
         assert F.bu_device_tsvq(hip_ctx.h, 6, v.ctypes.data_as(VP), w.ctypes.data_as(VP), n, k, p, a.ctypes.data_as(VP), cap, b.ctypes.data_as(VP), cap,
                                 st.ctypes.data_as(VP)) == 1
         outs[name] = (a, b)
+    hip_ctx.set_tuning()
     a1 = np.zeros(cap, np.uint32); b1 = np.zeros(cap, np.uint32)
     assert F.bu_host_tsvq(6, v.ctypes.data_as(VP), w.ctypes.data_as(VP), n, k, p, a1.ctypes.data_as(VP), cap, b1.ctypes.data_as(VP), cap) == 1
     for name, (a, b) in outs.items():
@@ -276,24 +272,3 @@ def test_partitioned_tsvq_through_the_reference_gate(hip_ctx, threads):
         assert (a3 == a2).all() and (b3 == b2).all()
 
 
-@pytest.mark.parametrize("n,k,p,kind,wmax,wide_min", [(120000, 2731, 32, "sel", 4096, 512), (30000, 900, 16, "sel_skewed", 4096, 512), (20000, 600, 16, "sel", 2 ** 50, 512)])
-def test_fused_side_passes_match_host_tsvq(hip_ctx, monkeypatch, n, k, p, kind, wmax, wide_min):
-    """BU_TSVQ_FUSED=1: the projection / two-means passes and the partition of a round's large nodes as ONE persistent kernel with device-wide barriers between the phases
-    (tsvq_wide_kernels.hip, k_wide_side_passes) instead of ~35 launches. Off by default -- it measured 2.5x slower than the separate kernels -- but it is the same phase
-    bodies in the same order, so the tree must be the same tree; the heavy-weight case makes every node leave the exact range (records handed back: ok == 2)."""
-    from basis_universal_amd import etc1s
-    F = etc1s.load_frontend_library()
-    rng = np.random.default_rng(n * 3 + k + wide_min)
-    v = _data(kind, 16, n, rng)
-    n = v.shape[0]
-    w = rng.integers(1, wmax + 1, n).astype(np.uint64)
-    if kind == "sel_skewed":
-        w[rng.integers(0, n, 5)] = 3_000_000_000
-    cap = 4 * n + 4 * k + 100
-    a1 = np.zeros(cap, np.uint32); b1 = np.zeros(cap, np.uint32)
-    assert F.bu_host_tsvq(16, v.ctypes.data_as(VP), w.ctypes.data_as(VP), n, k, p, a1.ctypes.data_as(VP), cap, b1.ctypes.data_as(VP), cap) == 1
-    monkeypatch.setenv("BU_TSVQ_WIDE_MIN", str(wide_min))
-    monkeypatch.setenv("BU_TSVQ_FUSED", "1")
-    a = np.zeros(cap, np.uint32); b = np.zeros(cap, np.uint32); st = np.array([0xBACCED, 0, 0], np.uint32)
-    assert F.bu_device_tsvq(hip_ctx.h, 16, v.ctypes.data_as(VP), w.ctypes.data_as(VP), n, k, p, a.ctypes.data_as(VP), cap, b.ctypes.data_as(VP), cap, st.ctypes.data_as(VP)) == 1
-    assert (a1 == a).all() and (b1 == b).all()
