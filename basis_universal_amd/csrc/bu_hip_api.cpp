@@ -356,6 +356,7 @@ static const bu_hip_tuning& default_tuning() {
         std::memset(&d, 0, sizeof(d));
         d.struct_bytes = (uint32_t)sizeof(d);
         d.tsvq_wide_min = 8192; d.tsvq_wide6_min = 8192; d.tsvq_wide_cov_min = 98304; d.tsvq_windows = 0; d.tsvq_dense_min = 257; d.tsvq_zero_copy = 1;
+        d.uastc_rdo_settle_rounds = 3;
         auto num = [](const char* name, long lo, long hi, uint32_t* out) { if (const char* e = std::getenv(name)) { const long v = std::atol(e); if (v >= lo && v <= hi) *out = (uint32_t)v; } };
         num("BU_TSVQ_WIDE_MIN", 512, 1l << 30, &d.tsvq_wide_min);
         num("BU_TSVQ_WIDE6_MIN", 512, 1l << 30, &d.tsvq_wide6_min);
@@ -387,7 +388,7 @@ int bu_hip_set_tuning(bu_hip_context* ctx, const bu_hip_tuning* t) {
     bu_hip_tuning n = default_tuning();   // fields a caller's older header does not have keep their defaults
     std::memcpy(&n, t, std::min<size_t>(t->struct_bytes, sizeof(n)));
     n.struct_bytes = (uint32_t)sizeof(n);
-    if ((n.tsvq_wide_min && n.tsvq_wide_min < 512) || (n.tsvq_wide6_min && n.tsvq_wide6_min < 512) || n.tsvq_windows > 2 || n.tsvq_poll > 2) {
+    if ((n.tsvq_wide_min && n.tsvq_wide_min < 512) || (n.tsvq_wide6_min && n.tsvq_wide6_min < 512) || n.tsvq_windows > 2 || n.tsvq_poll > 2 || n.uastc_rdo_settle_rounds > 4096) {
         set_error(ctx, "bu_hip_set_tuning: value out of range (many-workgroup thresholds are 0 or >= 512, windows / poll 0..2)");
         return 0;
     }
@@ -1507,7 +1508,7 @@ int bu_hip_k_uastc_rdo(bu_hip_context* ctx, void* d_blocks, const void* d_px, ui
     if (!n_blocks) return 1;
     const float fp[5] = { params->m_lambda, params->m_max_allowed_rms_increase_ratio, params->m_skip_block_rms_thresh, params->m_max_smooth_block_std_dev,
                           params->m_smooth_block_max_error_scale };
-    const uint32_t up[3] = { params->m_lz_dict_size, params->m_lz_literal_cost, params->m_endpoint_refinement };
+    const uint32_t up[4] = { params->m_lz_dict_size, params->m_lz_literal_cost, params->m_endpoint_refinement, ctx->tuning.uastc_rdo_settle_rounds };
     arena& ws = ctx->scratch[5];
     BU_TRY(ctx, ws.reserve(bu::uastc_rdo_workspace_bytes(n_blocks, total_jobs)));
     static const char* const names[2] = { "uastc_rdo_prepare", "uastc_rdo_strips" };
@@ -1566,7 +1567,7 @@ static int uastc_rdo_enqueue(bu_hip_context* ctx, void* d_blocks, const void* d_
     }
     const float fp[5] = { params->m_lambda, params->m_max_allowed_rms_increase_ratio, params->m_skip_block_rms_thresh, params->m_max_smooth_block_std_dev,
                           params->m_smooth_block_max_error_scale };
-    const uint32_t up[3] = { params->m_lz_dict_size, params->m_lz_literal_cost, params->m_endpoint_refinement };
+    const uint32_t up[4] = { params->m_lz_dict_size, params->m_lz_literal_cost, params->m_endpoint_refinement, ctx->tuning.uastc_rdo_settle_rounds };
     arena& ws = ctx->scratch[5];
     BU_TRY(ctx, ws.reserve(bu::uastc_rdo_workspace_bytes(n_blocks, total_jobs)));
     for (int phase = 0; phase < 2; phase++) BU_TRY(ctx, bu::launch_uastc_rdo_phase(ctx->stream, phase, d_blocks, d_px, n_blocks, fp, up, flags, total_jobs, ws.p));
@@ -1590,6 +1591,7 @@ bu_uastc_pipeline* bu_hip_uastc_pipeline_create(bu_hip_context* ctx, uint32_t la
     const size_t ws_bytes = std::max(bu::uastc_workspace_bytes(max_blocks, flags), bu::uastc_rdo_workspace_bytes(max_blocks, max_total_jobs));
     for (auto& l : p->lanes) {
         l.ctx = bu_hip_create_context_on(ctx->device);
+        if (l.ctx) l.ctx->tuning = ctx->tuning;   // the lanes take the paths their parent context is set to
         if (!l.ctx || hipEventCreateWithFlags(&l.done, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&l.input, hipEventDisableTiming) != hipSuccess ||
             hipHostMalloc(reinterpret_cast<void**>(&l.stats), 64, hipHostMallocDefault) != hipSuccess || l.ctx->scratch[5].reserve(ws_bytes) != hipSuccess) {
             set_error(ctx, "uastc_pipeline_create: lane set-up failed (%s)", l.ctx ? bu_hip_last_error(l.ctx) : "no context");

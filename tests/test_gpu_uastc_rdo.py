@@ -41,6 +41,26 @@ def test_matches_reference_vectors(hip_ctx, golden, name, flags, jobs, kw):
     assert info["modified"] == int((want != packed).any(1).sum()) or info["modified"] >= int((want != packed).any(1).sum())
 
 
+@pytest.mark.parametrize("rounds", [0, 1, 500])
+def test_suspended_strips_resume_to_the_same_bytes(hip_ctx, golden, rounds, request):
+    """The walk is lean (no colour-cell refit in it): in front of a block of a sensitive mode with refits pending in its window the strip suspends, k_rdo_settle
+    refits the window in a launch of its own, the next walk launch resumes from the block array and the history in HBM; what is still suspended after
+    uastc_rdo_settle_rounds rounds goes to the walk that settles in place. The vectors hold hundreds of such blocks per strip (all alpha classes): 0 rounds =
+    everything after the first suspension in place, 500 = every suspension through settle + resume, 1 = a mixture. Same bytes as the reference's, always --
+    also with the window past the LDS ring (candidates and resume from HBM only) and with four strips."""
+    hip_ctx.set_tuning(uastc_rdo_settle_rounds=rounds)
+    request.addfinalizer(hip_ctx.set_tuning)
+    cases = {c[0]: c for c in helpers.uastc_rdo_cases()}
+    for name, flags, jobs, kw in cases.values():
+        packed = golden[f"packed_l{flags & 7}"]
+        got, _ = uastc.uastc_rdo(hip_ctx, packed, golden["blocks"], params(**kw), flags, jobs)
+        assert (got == golden[name]).all(), (name, rounds)
+    packed, blocks = golden["packed_l2"], golden["blocks"]
+    for jobs in (0, 4):
+        got, _ = uastc.uastc_rdo(hip_ctx, packed, blocks, params(lam=3.0, dict_size=65536), 2, jobs)
+        assert (got == helpers.host_uastc_rdo(packed, blocks, 2, jobs, lam=3.0, dict_size=65536)).all(), (jobs, rounds)
+
+
 @pytest.mark.parametrize("n", [0, 1, 2, 40, 257, 600])
 @pytest.mark.parametrize("jobs", [0, 4])
 def test_ragged_sizes(hip_ctx, golden, n, jobs):
