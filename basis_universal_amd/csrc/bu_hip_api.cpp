@@ -300,11 +300,12 @@ void bu_hip_destroy_context(bu_hip_context* ctx) {
         }
         cb.first(cb.second);
     }
-    (void)stream_wait(ctx, ctx->stream);
-    if (ctx->side_stream) (void)hipStreamSynchronize(ctx->side_stream);
-    if (ctx->own_stream != ctx->stream) (void)hipStreamSynchronize(ctx->own_stream);
+    bool healthy = stream_wait(ctx, ctx->stream) == hipSuccess;
+    if (ctx->side_stream) healthy = hipStreamSynchronize(ctx->side_stream) == hipSuccess && healthy;
+    if (ctx->own_stream != ctx->stream) healthy = hipStreamSynchronize(ctx->own_stream) == hipSuccess && healthy;
+    if (!healthy) (void)hipGetLastError();
     prof_drain(ctx);
-    if (park_limit()) {
+    if (park_limit() && healthy) {   // a context whose streams ended in an error is torn down, never handed to the next creator
         // back to the state bu_hip_create_context_on hands out, with the memory kept: blocks the caller leaked join the free list (the context owns all device memory it handed out)
         for (auto& b : ctx->pool_live) { ctx->pool_free.push_back(b); ctx->pool_free_bytes += b.cap; }
         ctx->pool_live.clear();

@@ -71,7 +71,7 @@ struct bu_frontend_pipeline {
     uint64_t next_ticket = 1;
     uint32_t active = 0;
     bool stop = false;
-    double idle_spin_s = 200e-6, idle_sleep_s = 30e-6;
+    double idle_spin_s = 50e-6, idle_sleep_s = 10e-6;
     std::string error;
     // counters (bu_frontend_pipeline_stats)
     uint64_t n_switches = 0, n_idle_sleeps = 0, n_done = 0;

@@ -83,6 +83,11 @@ BU_HIP_API int bu_hip_encode_uastc_blocks(bu_hip_context*, bu_uastc_block* outpu
  * enqueued on the context's stream and returns without synchronising unless stated. `h_` pointers are host pointers.
  * ------------------------------------------------------------------------------------------------------------------ */
 
+/* bu_hip_destroy_context PARKS a healthy context instead of tearing it down: its streams, workspaces and block pool (whatever it grew to -- up to 16 GiB of
+ * cached device blocks) stay allocated and the next bu_hip_create_context* on that device gets it back warm (the reference's basis_parallel_compress creates and
+ * destroys a context per image; a context's worth of hipMalloc / hipFree calls are device-wide synchronisations that stall every other image's stream). At most
+ * BU_HIP_PARKED_CONTEXTS (default 16; 0 = destroy means destroy) are kept; bu_hip_deinit releases them all. A context whose streams report an error is never parked.
+ * A process that shares the GPU with other allocators and wants the memory back at once sets BU_HIP_PARKED_CONTEXTS=0 or calls bu_hip_deinit. */
 BU_HIP_API bu_hip_context* bu_hip_create_context_on(int device);
 /* Objects that keep device memory of a context (a resident frontend, say) may ask to be told when it is being destroyed: fn(user) runs at the
  * start of bu_hip_destroy_context, while the context still works, so that they can let go of their buffers instead of freeing them through a

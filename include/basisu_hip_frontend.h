@@ -115,7 +115,7 @@ BU_HIP_API void bu_frontend_pipeline_destroy(bu_frontend_pipeline*);
 BU_HIP_API const char* bu_frontend_pipeline_error(const bu_frontend_pipeline*);
 /* {jobs finished, task switches, yields, idle naps, driver seconds spent in tasks, driver seconds spent looking at idle streams, CPU seconds of the driver thread};
  * returns 7. The driver naps
- * (BU_PIPELINE_SLEEP_US, default 30) between looks once no task has had anything to do for BU_PIPELINE_SPIN_US (default 200). */
+ * (BU_PIPELINE_SLEEP_US, default 10) between looks once no task has had anything to do for BU_PIPELINE_SPIN_US (default 50). */
 BU_HIP_API uint32_t bu_frontend_pipeline_stats(bu_frontend_pipeline*, double* out, uint32_t cap);
 /* Test hook, no GPU needed: `tasks` self-test tasks (a pattern kept on the task's own stack across `yields` yields, an exception thrown and caught inside every third
  * one, the first `failing` of them ending in an exception) through a `lanes`-lane pipeline; 1 = every stack intact at every resume, failures reported as failures. */
