@@ -81,6 +81,7 @@ struct bu_hip_context {
     bool profiling = false;
     struct prof_rec { const char* name; hipEvent_t start, stop; };
     std::vector<prof_rec> prof_pending;
+    std::vector<hipEvent_t> prof_events;   // recycled (creating and destroying two events per timed region cost more host time than recording them)
     struct prof_sum { const char* name; double ms; uint32_t launches; };
     std::vector<prof_sum> prof_totals;
     bu_hip_tuning tuning{};               // bu_hip_set_tuning; starts as the process defaults (measured values, environment overrides read once)
@@ -134,7 +135,27 @@ struct prof_scope {
     bu_hip_context* ctx; const char* name; hipEvent_t start = nullptr, stop = nullptr;
     prof_scope(bu_hip_context* c, const char* n) : ctx(c), name(n) {
         if (!ctx->profiling) return;
-        if (hipEventCreate(&start) != hipSuccess || hipEventCreate(&stop) != hipSuccess) { start = stop = nullptr; return; }
+        if (ctx->prof_events.size() < 2 && ctx->prof_pending.size() >= 64) {   // reap the oldest finished regions: their events are the next ones recorded
+            size_t done = 0;
+            while (done < ctx->prof_pending.size() && done < 8 && hipEventQuery(ctx->prof_pending[done].stop) == hipSuccess) {
+                const bu_hip_context::prof_rec& r = ctx->prof_pending[done++];
+                float ms = 0.0f;
+                if (hipEventElapsedTime(&ms, r.start, r.stop) == hipSuccess) {
+                    bool found = false;
+                    for (auto& t : ctx->prof_totals) if (t.name == r.name) { t.ms += ms; t.launches++; found = true; break; }
+                    if (!found) ctx->prof_totals.push_back({r.name, (double)ms, 1u});
+                }
+                ctx->prof_events.push_back(r.start); ctx->prof_events.push_back(r.stop);
+            }
+            if (done) ctx->prof_pending.erase(ctx->prof_pending.begin(), ctx->prof_pending.begin() + (long)done);
+            (void)hipGetLastError();   // a hipErrorNotReady of the last look must not be what the next launcher's hipGetLastError() finds
+        }
+        auto take = [&](hipEvent_t& e) {
+            if (!ctx->prof_events.empty()) { e = ctx->prof_events.back(); ctx->prof_events.pop_back(); return true; }
+            return hipEventCreate(&e) == hipSuccess;
+        };
+        if (!take(start)) { start = nullptr; return; }
+        if (!take(stop)) { ctx->prof_events.push_back(start); start = stop = nullptr; return; }
         (void)hipEventRecord(start, ctx->stream);
     }
     ~prof_scope() {
@@ -152,7 +173,7 @@ void prof_drain(bu_hip_context* ctx) {
             for (auto& t : ctx->prof_totals) if (t.name == r.name) { t.ms += ms; t.launches++; found = true; break; }
             if (!found) ctx->prof_totals.push_back({r.name, (double)ms, 1u});
         }
-        (void)hipEventDestroy(r.start); (void)hipEventDestroy(r.stop);
+        ctx->prof_events.push_back(r.start); ctx->prof_events.push_back(r.stop);
     }
     ctx->prof_pending.clear();
 }
@@ -332,6 +353,7 @@ static void context_release(bu_hip_context* ctx) {
     for (auto& b : ctx->pool_live) (void)hipFree(b.p);
     if (ctx->stage) (void)hipHostFree(ctx->stage);
     if (ctx->bounce) (void)hipHostFree(ctx->bounce);
+    for (hipEvent_t e : ctx->prof_events) (void)hipEventDestroy(e);
     if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
     if (ctx->side_fork) (void)hipEventDestroy(ctx->side_fork);
     if (ctx->side_join) (void)hipEventDestroy(ctx->side_join);
