@@ -252,6 +252,7 @@ static std::vector<bu_hip_context*> g_parked;
 static std::atomic<int> g_live_contexts{0};
 static void context_release(bu_hip_context* ctx);   // the real teardown
 static const bu_hip_tuning& default_tuning();
+static bool ensure_side_stream(bu_hip_context* ctx);
 static size_t park_limit() {
     static const size_t n = [] { const char* e = std::getenv("BU_HIP_PARKED_CONTEXTS"); const long v = e ? std::atol(e) : 16; return (size_t)(v < 0 ? 0 : (v > 64 ? 64 : v)); }();
     return n;
@@ -379,7 +380,6 @@ static const bu_hip_tuning& default_tuning() {
         std::memset(&d, 0, sizeof(d));
         d.struct_bytes = (uint32_t)sizeof(d);
         d.tsvq_wide_min = 8192; d.tsvq_wide6_min = 8192; d.tsvq_wide_cov_min = 98304; d.tsvq_windows = 0; d.tsvq_dense_min = 257; d.tsvq_zero_copy = 1;
-        d.uastc_rdo_settle_rounds = 3;
         auto num = [](const char* name, long lo, long hi, uint32_t* out) { if (const char* e = std::getenv(name)) { const long v = std::atol(e); if (v >= lo && v <= hi) *out = (uint32_t)v; } };
         num("BU_TSVQ_WIDE_MIN", 512, 1l << 30, &d.tsvq_wide_min);
         num("BU_TSVQ_WIDE6_MIN", 512, 1l << 30, &d.tsvq_wide6_min);
@@ -411,7 +411,7 @@ int bu_hip_set_tuning(bu_hip_context* ctx, const bu_hip_tuning* t) {
     bu_hip_tuning n = default_tuning();   // fields a caller's older header does not have keep their defaults
     std::memcpy(&n, t, std::min<size_t>(t->struct_bytes, sizeof(n)));
     n.struct_bytes = (uint32_t)sizeof(n);
-    if ((n.tsvq_wide_min && n.tsvq_wide_min < 512) || (n.tsvq_wide6_min && n.tsvq_wide6_min < 512) || n.tsvq_windows > 2 || n.tsvq_poll > 2 || n.uastc_rdo_settle_rounds > 4096) {
+    if ((n.tsvq_wide_min && n.tsvq_wide_min < 512) || (n.tsvq_wide6_min && n.tsvq_wide6_min < 512) || n.tsvq_windows > 2 || n.tsvq_poll > 2) {
         set_error(ctx, "bu_hip_set_tuning: value out of range (many-workgroup thresholds are 0 or >= 512, windows / poll 0..2)");
         return 0;
     }
@@ -1193,10 +1193,7 @@ int bu_hip_tsvq_split(bu_hip_context* ctx, bu_tsvq* q, const bu_tsvq_node* h_nod
     // The two kinds of node of a round do not touch each other's data: when both are present the one-workgroup kernel runs on the side
     // stream, under the many small launches of the wide path. (Not while kernels are being timed one by one.)
     bool narrow_on_side = n_wide && n_narrow && !ctx->profiling && !q->dbg_serial;
-    if (narrow_on_side && !ctx->side_stream) {
-        if (hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ctx->side_fork, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&ctx->side_join, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); narrow_on_side = false; }
-    }
+    if (narrow_on_side && !ensure_side_stream(ctx)) narrow_on_side = false;
     // From the fork on, every early return must wait for the side stream first: the caller's guard destroys q (its buffers go back to the
     // pool without a synchronisation) while the one-workgroup kernel may still be running on them.
     struct side_joiner { hipStream_t s; bool armed; ~side_joiner() { if (armed) (void)hipStreamSynchronize(s); } } side_join_guard{ctx->side_stream, false};
@@ -1517,6 +1514,38 @@ void bu_hip_uastc_rdo_default_params(bu_uastc_rdo_params* p) {
     p->m_endpoint_refinement = 1; p->m_lz_literal_cost = 100; p->m_max_smooth_block_std_dev = 18.0f; p->m_smooth_block_max_error_scale = 10.0f;
 }
 
+// The context's second stream (and the two events that fork it off the main stream and join it back), made on first use.
+static bool ensure_side_stream(bu_hip_context* ctx) {
+    if (ctx->side_stream) return true;
+    if (hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ctx->side_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->side_join, hipEventDisableTiming) != hipSuccess) {
+        (void)hipGetLastError();
+        if (ctx->side_stream) { (void)hipStreamDestroy(ctx->side_stream); ctx->side_stream = nullptr; }
+        if (ctx->side_fork) { (void)hipEventDestroy(ctx->side_fork); ctx->side_fork = nullptr; }
+        if (ctx->side_join) { (void)hipEventDestroy(ctx->side_join); ctx->side_join = nullptr; }
+        return false;
+    }
+    return true;
+}
+
+// The strip walks of uastc_rdo behind its prepare pass: the lean build (strips without a block of a sensitive mode: four waves per SIMD) on the context's stream and,
+// when endpoint refinement is on, the build with the refit in it (the flagged strips) on the side stream beside it -- forked and joined with events, nobody waits on
+// the host. Without a side stream the two launches simply follow each other.
+static int uastc_rdo_walks(bu_hip_context* ctx, void* d_blocks, const void* d_px, uint32_t n_blocks, const float* fp, const uint32_t* up, uint32_t flags, uint32_t total_jobs, void* ws) {
+    const bool refit = up[2] != 0;
+    const bool side = refit && ensure_side_stream(ctx);
+    if (side) {
+        BU_TRY(ctx, hipEventRecord(ctx->side_fork, ctx->stream));
+        BU_TRY(ctx, hipStreamWaitEvent(ctx->side_stream, ctx->side_fork, 0));
+        BU_TRY(ctx, bu::launch_uastc_rdo_phase(ctx->side_stream, 3, d_blocks, d_px, n_blocks, fp, up, flags, total_jobs, ws));
+        BU_TRY(ctx, hipEventRecord(ctx->side_join, ctx->side_stream));
+    }
+    BU_TRY(ctx, bu::launch_uastc_rdo_phase(ctx->stream, 1, d_blocks, d_px, n_blocks, fp, up, flags, total_jobs, ws));
+    if (side) BU_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->side_join, 0));
+    else if (refit) BU_TRY(ctx, bu::launch_uastc_rdo_phase(ctx->stream, 3, d_blocks, d_px, n_blocks, fp, up, flags, total_jobs, ws));
+    return 1;
+}
+
 int bu_hip_k_uastc_rdo(bu_hip_context* ctx, void* d_blocks, const void* d_px, uint32_t n_blocks, const bu_uastc_rdo_params* params, uint32_t flags,
                        uint32_t total_jobs, uint32_t out_stats[4]) {
     if (!ctx) return 0;
@@ -1531,13 +1560,16 @@ int bu_hip_k_uastc_rdo(bu_hip_context* ctx, void* d_blocks, const void* d_px, ui
     if (!n_blocks) return 1;
     const float fp[5] = { params->m_lambda, params->m_max_allowed_rms_increase_ratio, params->m_skip_block_rms_thresh, params->m_max_smooth_block_std_dev,
                           params->m_smooth_block_max_error_scale };
-    const uint32_t up[4] = { params->m_lz_dict_size, params->m_lz_literal_cost, params->m_endpoint_refinement, ctx->tuning.uastc_rdo_settle_rounds };
+    const uint32_t up[3] = { params->m_lz_dict_size, params->m_lz_literal_cost, params->m_endpoint_refinement };
     arena& ws = ctx->scratch[5];
     BU_TRY(ctx, ws.reserve(bu::uastc_rdo_workspace_bytes(n_blocks, total_jobs)));
-    static const char* const names[2] = { "uastc_rdo_prepare", "uastc_rdo_strips" };
-    for (int phase = 0; phase < 2; phase++) {
-        prof_scope ps(ctx, names[phase]);
-        BU_TRY(ctx, bu::launch_uastc_rdo_phase(ctx->stream, phase, d_blocks, d_px, n_blocks, fp, up, flags, total_jobs, ws.p));
+    {
+        prof_scope ps(ctx, "uastc_rdo_prepare");
+        BU_TRY(ctx, bu::launch_uastc_rdo_phase(ctx->stream, 0, d_blocks, d_px, n_blocks, fp, up, flags, total_jobs, ws.p));
+    }
+    {
+        prof_scope ps(ctx, "uastc_rdo_strips");   // both walks: the scope ends behind the join
+        if (!uastc_rdo_walks(ctx, d_blocks, d_px, n_blocks, fp, up, flags, total_jobs, ws.p)) return 0;
     }
     // how many blocks each strip modified: sizes the finish launch (a 16-byte copy per 4 strips; the walk has to be over anyway)
     std::vector<uint32_t> per_strip(bu::uastc_rdo_strips(n_blocks, total_jobs));
@@ -1590,10 +1622,11 @@ static int uastc_rdo_enqueue(bu_hip_context* ctx, void* d_blocks, const void* d_
     }
     const float fp[5] = { params->m_lambda, params->m_max_allowed_rms_increase_ratio, params->m_skip_block_rms_thresh, params->m_max_smooth_block_std_dev,
                           params->m_smooth_block_max_error_scale };
-    const uint32_t up[4] = { params->m_lz_dict_size, params->m_lz_literal_cost, params->m_endpoint_refinement, ctx->tuning.uastc_rdo_settle_rounds };
+    const uint32_t up[3] = { params->m_lz_dict_size, params->m_lz_literal_cost, params->m_endpoint_refinement };
     arena& ws = ctx->scratch[5];
     BU_TRY(ctx, ws.reserve(bu::uastc_rdo_workspace_bytes(n_blocks, total_jobs)));
-    for (int phase = 0; phase < 2; phase++) BU_TRY(ctx, bu::launch_uastc_rdo_phase(ctx->stream, phase, d_blocks, d_px, n_blocks, fp, up, flags, total_jobs, ws.p));
+    BU_TRY(ctx, bu::launch_uastc_rdo_phase(ctx->stream, 0, d_blocks, d_px, n_blocks, fp, up, flags, total_jobs, ws.p));
+    if (!uastc_rdo_walks(ctx, d_blocks, d_px, n_blocks, fp, up, flags, total_jobs, ws.p)) return 0;
     // the longest list a strip can have (every block of it modified): the launch does not wait for the walk to know better, surplus workgroups leave at once
     const uint32_t strips = bu::uastc_rdo_strips(n_blocks, total_jobs);
     const uint32_t longest = strips > 1 ? (total_jobs ? n_blocks / total_jobs : n_blocks) : n_blocks;

@@ -15,7 +15,7 @@ hipError_t launch_uastc_phase(hipStream_t st, int phase, const void* d_pixel_blo
 
 // uastc_rdo (encoder/basisu_uastc_enc.h:139, uastc_enc.cpp:4095) in place over n_blocks resident UASTC blocks (uastc_rdo_kernels.hip).
 // fparams: lambda, max_allowed_rms_increase_ratio, skip_block_rms_thresh, max_smooth_block_std_dev, smooth_block_max_error_scale;
-// uparams: lz_dict_size, lz_literal_cost, endpoint_refinement, settle rounds (bu_hip_tuning::uastc_rdo_settle_rounds). total_jobs splits into independent strips exactly as the reference does.
+// uparams: lz_dict_size, lz_literal_cost, endpoint_refinement. total_jobs splits into independent strips exactly as the reference does.
 // Phases: 0 prepare (parallel), 1 strips (serial per strip); then launch_uastc_rdo_finish (refit + hints of the modified blocks) with the
 // longest per-strip list length read back from uastc_rdo_strip_counts. Stream-ordered.
 size_t uastc_rdo_workspace_bytes(uint32_t n_blocks, uint32_t total_jobs);

@@ -38,7 +38,7 @@ constexpr uint32_t HIST_BUCKET = 4;  // entries per bucket = one 64-byte line, f
 struct rdo_workspace {
     rdo_info4* info; hist_entry* hist; uint32_t* mod_list; uint32_t* counters;  // counters: [0] modified, [1] failed, [2] refined, [3] skipped
     uint32_t* strip_counts;  // modified blocks per strip
-    uint4* strip_state;      // per strip {blocks walked so far, status: 0 walking / 1 suspended in front of a block whose window must be settled / 2 done, modified, skipped}
+    uint32_t* strip_flags;   // per strip: != 0 when it holds an active block of a sensitive mode (15 / 17 / 18) -- set by the prepare pass, decides which walk kernel takes the strip
     uint8_t* state;    // per block: 0 untouched, 1 modified + refit pending, 2 modified
     uint32_t* table;   // per block RDO_TABLE_WORDS
     size_t zero_bytes; // counters + hist + state, contiguous
@@ -62,7 +62,7 @@ rdo_workspace carve(void* base, uint32_t n, uint32_t total_jobs, size_t* total) 
     rdo_workspace w;
     w.counters = reinterpret_cast<uint32_t*>(p + o); o += 256;
     w.strip_counts = reinterpret_cast<uint32_t*>(p + o); o += align_up((size_t)n_strips * 4);
-    w.strip_state = reinterpret_cast<uint4*>(p + o); o += align_up((size_t)n_strips * 16);
+    w.strip_flags = reinterpret_cast<uint32_t*>(p + o); o += align_up((size_t)n_strips * 4);
     w.hist = reinterpret_cast<hist_entry*>(p + o); o += align_up((size_t)n_strips * cap * sizeof(hist_entry));
     w.state = reinterpret_cast<uint8_t*>(p + o); o += align_up(n);
     w.zero_bytes = o;
@@ -80,7 +80,8 @@ __device__ inline void load_tile(const uint4* px, uint32_t b, rgba8* out) {
 }
 
 __global__ void __launch_bounds__(64) k_rdo_prepare(const uint4* __restrict__ blocks, const uint4* __restrict__ px, uint32_t n, rdo_params p,
-                                                    rdo_info4* __restrict__ info, uint32_t* __restrict__ table, uint32_t* __restrict__ counters) {
+                                                    rdo_info4* __restrict__ info, uint32_t* __restrict__ table, uint32_t* __restrict__ counters,
+                                                    uint32_t* __restrict__ strip_flags, uint32_t per_job) {
     const uint32_t b = blockIdx.x * 64 + threadIdx.x;
     if (b >= n) return;
     alignas(16) uint8_t blk[16];
@@ -102,6 +103,7 @@ __global__ void __launch_bounds__(64) k_rdo_prepare(const uint4* __restrict__ bl
     }
     info[b] = o;
     if (bi.mode == 8 || bi.skip) return;
+    if (rdo_mode_reads_endpoint_bits(bi.mode) && p.endpoint_refinement) atomicOr(&strip_flags[per_job ? b / per_job : 0u], 1u);   // a handful per image
     texel_ends ends;
     rdo_texel_ends(c, ends);
     const uint32_t planes = ku_mode_planes[bi.mode], wbits = ku_mode_weight_bits[bi.mode];
@@ -273,17 +275,18 @@ struct cand_rec { uint64_t lo, hi; uint32_t slot, pad; };
 
 // RING: the look-back window fits the LDS ring (the normal case); otherwise candidates are read back from HBM. Two instantiations, so the
 // ring version has no global-load path whose wait would also drain the loads in flight.
-// FAT: what the walk does in front of a block of a sensitive mode (15 / 17 / 18: a handful per image) whose window still holds pending mode-0 refits. The refit is
-// the encoder's colour-cell fit -- 256 registers and scratch that the walk itself (110 registers) has no use for, and with it in the kernel a strip holds a whole
-// CU at one wave per SIMD for the 20 ms of its chain. So the LEAN walk does not settle: it SUSPENDS the strip there (position and counts to strip_state, the block
-// array and the history are in HBM anyway) and returns; k_rdo_settle refits the window in a launch of its own; the next walk launch resumes the strip (rebuilding
-// its LDS ring from the block array). The launcher enqueues lean, (settle, lean) x bu_hip_tuning::uastc_rdo_settle_rounds (3), and last one FAT walk that settles in place and finishes whatever is still
-// suspended; launches that find their strip done return at once. Same steps in the same order: the bytes are those of the one-kernel walk.
+// FAT: the walk of strips that hold a block of a sensitive mode (strip_flags, set by the prepare pass): in front of such a block the pending mode-0 refits of its
+// window are settled -- the encoder's colour-cell fit, 256 registers + 34 accumulation registers + scratch that the walk itself (110 registers) has no use for; with
+// it in the kernel a strip holds a whole CU at one wave per SIMD for the 20 ms of its chain. Sensitive blocks are a handful per image (alpha / luminance-alpha
+// content apart), so most strips take the LEAN build -- no refit in it, four waves per SIMD, a 256-register encode wave of the next batch fits beside it -- and
+// only the flagged ones the FAT one; both launches cover all strips and a workgroup whose strip belongs to the other returns at once. The launcher puts them on
+// two streams, so the chain of a batch is as long as before.
 template <bool RING, bool FAT>
 __global__ void __launch_bounds__(RDO_THREADS) k_rdo_strips(uint4* blocks, const uint4* __restrict__ px, uint32_t n, uint32_t per_job, rdo_params p,
                                                             const rdo_info4* info, const uint32_t* __restrict__ table, hist_entry* hist_all,
                                                             uint32_t hist_cap, uint8_t* state, uint32_t* mod_list, uint32_t* strip_counts, uint32_t* counters,
-                                                            uint32_t ring_slots, uint4* strip_state) {
+                                                            uint32_t ring_slots, const uint32_t* __restrict__ strip_flags) {
+    if ((strip_flags[blockIdx.x] != 0u) != FAT) return;
     extern __shared__ uint4 s_ring_mem[];
     __shared__ uint32_t s_table[RDO_TABLE_WORDS];
     __shared__ cand_rec s_cand[RDO_THREADS];
@@ -305,29 +308,19 @@ __global__ void __launch_bounds__(RDO_THREADS) k_rdo_strips(uint4* blocks, const
         const uint32_t* src = pre_lane < 8 ? info_words + (size_t)b * 8 + pre_lane : block_words + (size_t)b * 4 + (pre_lane & 3u);
         return pre_lane < 12 ? *src : 0u;
     };
-    const uint4 resume = strip_state[blockIdx.x];   // zero before the first launch
-    if (resume.y == 2u) return;                     // this strip is done
-    const uint32_t start = first + resume.x;
-    uint32_t n_modified = resume.z, n_skipped = resume.w;  // thread 0
+    uint32_t n_modified = 0, n_skipped = 0;  // thread 0
 #ifdef RDO_PROFILE
     long long prof[16] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
     long long tick_ = clock64();
 #endif
 
-    uint32_t pre = 0;
-    if (start < last) {
-        pre = prefetch(start);
-        s_table[tid] = table[(size_t)start * RDO_TABLE_WORDS + tid];
-        s_table[tid + RDO_THREADS] = table[(size_t)start * RDO_TABLE_WORDS + RDO_THREADS + tid];
-    }
-    if (RING && start > first) {   // resumed: the look-back window as the block array holds it now (the walk writes every block through, the settle pass its refits)
-        const uint32_t lo = start - first > ring_slots ? start - ring_slots : first;
-        for (uint32_t j = lo + tid; j < start; j += RDO_THREADS) s_ring_mem[j & ring_mask] = blocks[j];
-    }
+    uint32_t pre = prefetch(first);
+    s_table[tid] = table[(size_t)first * RDO_TABLE_WORDS + tid];
+    s_table[tid + RDO_THREADS] = table[(size_t)first * RDO_TABLE_WORDS + RDO_THREADS + tid];
     if (tid == 0) s_min = ~0ull;
     __syncthreads();
 
-    for (uint32_t i = start; i < last; i++) {
+    for (uint32_t i = first; i < last; i++) {
         // one step ahead: the next block is still the encoder's output, and its table / info never change
         const bool has_next = i + 1 < last;
         rdo_info4 inf;
@@ -345,18 +338,9 @@ __global__ void __launch_bounds__(RDO_THREADS) k_rdo_strips(uint4* blocks, const
         RDO_TICK(0);
         if (active) {
             const int lo_j = (int)i - window > (int)first ? (int)i - window : (int)first;
-            if (rdo_mode_reads_endpoint_bits(mode) && p.endpoint_refinement) {  // uniform branch
-                if (FAT) {
-                    settle_window(blocks, px, state, ring, ring_mask, lo_j, (int)i, p, counters);
-                    __syncthreads();
-                } else {
-                    int pending = 0;
-                    for (int j = (int)i - 1 - (int)tid; j >= lo_j; j -= (int)RDO_THREADS) pending |= state[j] == 1 ? 1 : 0;
-                    if (__syncthreads_or(pending)) {   // uniform: the strip waits here for k_rdo_settle
-                        if (tid == 0) strip_state[blockIdx.x] = make_uint4(i - first, 1u, n_modified, n_skipped);
-                        return;
-                    }
-                }
+            if (FAT && rdo_mode_reads_endpoint_bits(mode) && p.endpoint_refinement) {  // uniform branch; a strip with such a block is never given to the lean build
+                settle_window(blocks, px, state, ring, ring_mask, lo_j, (int)i, p, counters);
+                __syncthreads();
             }
             // first probes of the block's own key and of the candidate's key go out together; the table sum runs under their latency
             const uint32_t seen_home = hist_home(fsb, cur_lo, bucket_mask);
@@ -451,7 +435,6 @@ __global__ void __launch_bounds__(RDO_THREADS) k_rdo_strips(uint4* blocks, const
         pre = npre;
     }
     if (tid == 0) {
-        strip_state[blockIdx.x] = make_uint4(last - first, 2u, n_modified, n_skipped);
         strip_counts[blockIdx.x] = n_modified;
         atomicAdd(&counters[0], n_modified);
         atomicAdd(&counters[3], n_skipped);
@@ -459,18 +442,6 @@ __global__ void __launch_bounds__(RDO_THREADS) k_rdo_strips(uint4* blocks, const
         if (blockIdx.x == 0) for (int k = 0; k < 16; k++) reinterpret_cast<unsigned long long*>(counters + 16)[k] = (unsigned long long)prof[k];
 #endif
     }
-}
-
-// The pending refits in the window of the block a suspended strip waits in front of (see k_rdo_strips): one workgroup per strip, nothing to do for the others.
-__global__ void __launch_bounds__(RDO_THREADS) k_rdo_settle(uint4* blocks, const uint4* __restrict__ px, uint32_t n, uint32_t per_job, rdo_params p, uint8_t* state,
-                                                            uint32_t* counters, const uint4* __restrict__ strip_state) {
-    const uint4 st = strip_state[blockIdx.x];
-    if (st.y != 1u) return;
-    const uint32_t first = per_job ? blockIdx.x * per_job : 0;
-    const int i = (int)(first + st.x);
-    const int window = (int)(p.lz_dict_size / 16 > 1 ? p.lz_dict_size / 16 : 1);
-    const int lo_j = i - window > (int)first ? i - window : (int)first;
-    settle_window(blocks, px, state, nullptr, 0u, lo_j, i, p, counters);
 }
 
 // the modified blocks of strip s are listed in mod_list[s * per_job ...) (strip_counts[s] of them)
@@ -502,7 +473,7 @@ rdo_params to_params(const float* f, const uint32_t* u) {
     p.lambda = f[0]; p.max_allowed_rms_increase_ratio = f[1]; p.skip_block_rms_thresh = f[2]; p.max_smooth_block_std_dev = f[3];
     p.smooth_block_max_error_scale = f[4];
     p.lz_dict_size = u[0]; p.lz_literal_cost = u[1]; p.endpoint_refinement = u[2];
-    return p;   // (u[3]: bu_hip_tuning::uastc_rdo_settle_rounds, read by the launcher)
+    return p;
 }
 
 } // namespace
@@ -533,38 +504,28 @@ hipError_t launch_uastc_rdo_phase(hipStream_t st, int phase, void* d_blocks, con
     case 0: {
         const hipError_t e = hipMemsetAsync(w.counters, 0, w.zero_bytes, st);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(k_rdo_prepare, dim3(gx), dim3(64), 0, st, blocks, px, n, p, w.info, w.table, w.counters);
+        hipLaunchKernelGGL(k_rdo_prepare, dim3(gx), dim3(64), 0, st, blocks, px, n, p, w.info, w.table, w.counters, w.strip_flags, per_job);
         break;
     }
-    case 1: {
+    case 1:     // the lean walk: strips without a sensitive block
+    case 3: {   // the walk with the refit in it: the flagged strips (the caller runs it on a second stream beside phase 1)
         const uint32_t window = p.lz_dict_size / 16 > 1 ? p.lz_dict_size / 16 : 1;
         uint32_t ring = 1;
         while (ring < window) ring <<= 1;
         if (ring > RDO_RING_MAX) ring = 0;
-        // lean walk, (settle, lean walk) x settle_rounds, then the walk that settles in place for strips that are still suspended (see k_rdo_strips); launches whose strips are
-        // done return at once. Without endpoint refinement nothing ever suspends: one lean walk.
-        auto walk = [&](bool fat) {
-            if (ring && fat)
-                hipLaunchKernelGGL((k_rdo_strips<true, true>), dim3(n_strips), dim3(RDO_THREADS), (size_t)ring * 16, st, blocks, px, n, per_job, p, w.info, w.table, w.hist,
-                                   cap, w.state, w.mod_list, w.strip_counts, w.counters, ring, w.strip_state);
-            else if (ring)
-                hipLaunchKernelGGL((k_rdo_strips<true, false>), dim3(n_strips), dim3(RDO_THREADS), (size_t)ring * 16, st, blocks, px, n, per_job, p, w.info, w.table, w.hist,
-                                   cap, w.state, w.mod_list, w.strip_counts, w.counters, ring, w.strip_state);
-            else if (fat)
-                hipLaunchKernelGGL((k_rdo_strips<false, true>), dim3(n_strips), dim3(RDO_THREADS), 0, st, blocks, px, n, per_job, p, w.info, w.table, w.hist, cap, w.state,
-                                   w.mod_list, w.strip_counts, w.counters, 1u, w.strip_state);
-            else
-                hipLaunchKernelGGL((k_rdo_strips<false, false>), dim3(n_strips), dim3(RDO_THREADS), 0, st, blocks, px, n, per_job, p, w.info, w.table, w.hist, cap, w.state,
-                                   w.mod_list, w.strip_counts, w.counters, 1u, w.strip_state);
-        };
-        walk(false);
-        if (p.endpoint_refinement) {
-            for (uint32_t r = 0; r < uparams[3]; r++) {   // bu_hip_tuning::uastc_rdo_settle_rounds, default 3
-                hipLaunchKernelGGL(k_rdo_settle, dim3(n_strips), dim3(RDO_THREADS), 0, st, blocks, px, n, per_job, p, w.state, w.counters, w.strip_state);
-                walk(false);
-            }
-            walk(true);
-        }
+        const bool fat = phase == 3;
+        if (ring && fat)
+            hipLaunchKernelGGL((k_rdo_strips<true, true>), dim3(n_strips), dim3(RDO_THREADS), (size_t)ring * 16, st, blocks, px, n, per_job, p, w.info, w.table, w.hist,
+                               cap, w.state, w.mod_list, w.strip_counts, w.counters, ring, w.strip_flags);
+        else if (ring)
+            hipLaunchKernelGGL((k_rdo_strips<true, false>), dim3(n_strips), dim3(RDO_THREADS), (size_t)ring * 16, st, blocks, px, n, per_job, p, w.info, w.table, w.hist,
+                               cap, w.state, w.mod_list, w.strip_counts, w.counters, ring, w.strip_flags);
+        else if (fat)
+            hipLaunchKernelGGL((k_rdo_strips<false, true>), dim3(n_strips), dim3(RDO_THREADS), 0, st, blocks, px, n, per_job, p, w.info, w.table, w.hist, cap, w.state,
+                               w.mod_list, w.strip_counts, w.counters, 1u, w.strip_flags);
+        else
+            hipLaunchKernelGGL((k_rdo_strips<false, false>), dim3(n_strips), dim3(RDO_THREADS), 0, st, blocks, px, n, per_job, p, w.info, w.table, w.hist, cap, w.state,
+                               w.mod_list, w.strip_counts, w.counters, 1u, w.strip_flags);
         break;
     }
     default: {

@@ -115,7 +115,6 @@ typedef struct bu_hip_tuning {
     uint32_t tsvq_chained_only;   /* BU_TSVQ_CHAINED       0      1 = every float sum member by member in one workgroup per node (the slowest path; what the others are tested against) */
     uint32_t tsvq_poll;           /* BU_TSVQ_POLL          0      waiting for a round: 0 = spin when this is the process's only context, else yield / nap; 1 (spin) / 2 (yield) force it */
     uint32_t refine_unsorted;     /*                       0      1 = refine_endpoint_clusterization through the unsorted kernel (the one lists beyond 65,535 entries take anyway) */
-    uint32_t uastc_rdo_settle_rounds; /*                   3      UASTC RDO: (settle, lean walk) launch pairs behind the first lean walk before the walk that settles in place takes what is left (uastc_rdo_kernels.hip) */
     uint32_t debug;               /* BU_TSVQ_ROUNDS = 1 | BU_TSVQ_SERIAL = 2 | BU_TSVQ_STATS = 4: developer aids (round time line on stderr, one node per round, walk statistics) */
 } bu_hip_tuning;
 BU_HIP_API void bu_hip_get_tuning(const bu_hip_context* /* NULL: the process defaults */, bu_hip_tuning* out, uint32_t struct_bytes);

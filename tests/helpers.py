@@ -682,3 +682,9 @@ def block_metric_host():
         L.bm_search_check.argtypes = [C.c_uint64, C.c_int, C.c_int]
         _block_metric_host = L
     return _block_metric_host
+
+
+# g_uastc_huff_modes (transcoder/basisu_transcoder.cpp:14409-14413): the mode of a UASTC block from the low 7 bits of its first byte
+UASTC_HUFF_MODES = [11, 0, 10, 3, 11, 15, 12, 7, 11, 18, 10, 5, 11, 14, 12, 9, 11, 0, 10, 4, 11, 16, 12, 8, 11, 18, 10, 6, 11, 2, 12, 13, 11, 0, 10, 3, 11, 17, 12, 7, 11, 18, 10, 5, 11, 14, 12,
+                    9, 11, 0, 10, 4, 11, 1, 12, 8, 11, 18, 10, 6, 11, 2, 12, 13, 11, 0, 10, 3, 11, 19, 12, 7, 11, 18, 10, 5, 11, 14, 12, 9, 11, 0, 10, 4, 11, 16, 12, 8, 11, 18, 10, 6, 11, 2,
+                    12, 13, 11, 0, 10, 3, 11, 17, 12, 7, 11, 18, 10, 5, 11, 14, 12, 9, 11, 0, 10, 4, 11, 1, 12, 8, 11, 18, 10, 6, 11, 2, 12, 13]

@@ -41,24 +41,20 @@ def test_matches_reference_vectors(hip_ctx, golden, name, flags, jobs, kw):
     assert info["modified"] == int((want != packed).any(1).sum()) or info["modified"] >= int((want != packed).any(1).sum())
 
 
-@pytest.mark.parametrize("rounds", [0, 1, 500])
-def test_suspended_strips_resume_to_the_same_bytes(hip_ctx, golden, rounds, request):
-    """The walk is lean (no colour-cell refit in it): in front of a block of a sensitive mode with refits pending in its window the strip suspends, k_rdo_settle
-    refits the window in a launch of its own, the next walk launch resumes from the block array and the history in HBM; what is still suspended after
-    uastc_rdo_settle_rounds rounds goes to the walk that settles in place. The vectors hold hundreds of such blocks per strip (all alpha classes): 0 rounds =
-    everything after the first suspension in place, 500 = every suspension through settle + resume, 1 = a mixture. Same bytes as the reference's, always --
-    also with the window past the LDS ring (candidates and resume from HBM only) and with four strips."""
-    hip_ctx.set_tuning(uastc_rdo_settle_rounds=rounds)
-    request.addfinalizer(hip_ctx.set_tuning)
-    cases = {c[0]: c for c in helpers.uastc_rdo_cases()}
-    for name, flags, jobs, kw in cases.values():
-        packed = golden[f"packed_l{flags & 7}"]
-        got, _ = uastc.uastc_rdo(hip_ctx, packed, golden["blocks"], params(**kw), flags, jobs)
-        assert (got == golden[name]).all(), (name, rounds)
+def test_flagged_and_unflagged_strips_side_by_side(hip_ctx, golden):
+    """The walk comes in two builds: strips that hold a block of a sensitive mode (15 / 17 / 18: the prepare pass flags them) take the one with the colour-cell
+    refit in it, all others the lean one (no refit, four waves per SIMD), both launched over all strips on two streams. Pure RGB blocks in front of the vectors'
+    alpha classes give batches in which some strips are flagged and some are not, for several strip counts; with endpoint refinement off nothing is flagged.
+    Same bytes as the host build of the same core (pinned to the reference by tests/test_uastc_rdo_host.py) every time."""
     packed, blocks = golden["packed_l2"], golden["blocks"]
-    for jobs in (0, 4):
-        got, _ = uastc.uastc_rdo(hip_ctx, packed, blocks, params(lam=3.0, dict_size=65536), 2, jobs)
-        assert (got == helpers.host_uastc_rdo(packed, blocks, 2, jobs, lam=3.0, dict_size=65536)).all(), (jobs, rounds)
+    modes = np.array(helpers.UASTC_HUFF_MODES)[packed[:, 0] & 127]
+    plain = np.nonzero(~np.isin(modes, (8, 15, 16, 17)))[0]
+    order = np.concatenate([plain, np.setdiff1d(np.arange(packed.shape[0]), plain)])   # opaque modes first, the alpha / luminance-alpha classes last
+    pk, bl = np.ascontiguousarray(packed[order]), np.ascontiguousarray(blocks[order])
+    for jobs in (0, 2, 4, 7):
+        for refine in (1, 0):
+            got, _ = uastc.uastc_rdo(hip_ctx, pk, bl, params(lam=3.0, refine=refine), 2, jobs)
+            assert (got == helpers.host_uastc_rdo(pk, bl, 2, jobs, lam=3.0, refine=refine)).all(), (jobs, refine)
 
 
 @pytest.mark.parametrize("n", [0, 1, 2, 40, 257, 600])
