@@ -44,8 +44,10 @@ struct job {
     double t_submit = 0, t_start = 0, t_done = 0;
 };
 
+struct driver_state;
 struct lane {
     bu_frontend_pipeline* owner = nullptr;
+    driver_state* drv = nullptr;
     ucontext_t uc;
     void* stack = nullptr;
     size_t stack_bytes = 0;
@@ -56,27 +58,34 @@ struct lane {
 
 const size_t kStackBytes = (size_t)8 << 20;   // the frontend keeps its arrays on the heap; this is address space, touched pages only
 
+// One driver thread and the lanes it serves (a pipeline has one unless asked for more: bu_frontend_pipeline_create_n).
+struct driver_state {
+    bu_frontend_pipeline* p = nullptr;
+    ucontext_t sched;
+    std::thread th;
+    uint32_t first_lane = 0, n_lanes = 0, active = 0;
+    uint64_t n_switches = 0, n_idle_sleeps = 0;
+    double busy_s = 0, idle_s = 0;
+    std::atomic<double> cpu_s{0};   // CLOCK_THREAD_CPUTIME_ID of the thread, refreshed once per finished job
+};
+
 } // namespace
 
 struct bu_frontend_pipeline {
     int device = 0;
     std::vector<lane> lanes;
-    ucontext_t sched;
-    std::thread driver;
+    std::deque<driver_state> drivers;
     std::mutex m;
     std::condition_variable cv_work, cv_done;
     std::deque<job*> pending;
     std::map<uint64_t, job*> jobs;        // everything submitted and not yet released
     std::map<bu_frontend*, job*> by_frontend;
     uint64_t next_ticket = 1;
-    uint32_t active = 0;
     bool stop = false;
     double idle_spin_s = 50e-6, idle_sleep_s = 10e-6;
     std::string error;
     // counters (bu_frontend_pipeline_stats)
-    uint64_t n_switches = 0, n_idle_sleeps = 0, n_done = 0;
-    double driver_busy_s = 0, driver_idle_s = 0;
-    std::atomic<double> driver_cpu_s{0};   // CLOCK_THREAD_CPUTIME_ID of the driver thread, refreshed once per finished job
+    uint64_t n_done = 0;
 };
 
 namespace {
@@ -84,7 +93,7 @@ namespace {
 void lane_yield(void* user) {
     lane* l = static_cast<lane*>(user);
     l->yields++;
-    swapcontext(&l->uc, &l->owner->sched);
+    swapcontext(&l->uc, &l->drv->sched);
 }
 
 // Self-test task (bu_frontend_pipeline_selftest, no GPU): keeps a pattern on ITS stack across `n_blocks` yields, throws and catches an exception on the way when
@@ -144,21 +153,24 @@ void start_lane(lane& l, job* j) {
     getcontext(&l.uc);
     l.uc.uc_stack.ss_sp = l.stack;
     l.uc.uc_stack.ss_size = l.stack_bytes;
-    l.uc.uc_link = &l.owner->sched;
+    l.uc.uc_link = &l.drv->sched;
     const uintptr_t a = reinterpret_cast<uintptr_t>(&l);
     makecontext(&l.uc, reinterpret_cast<void (*)()>(lane_entry), 2, (unsigned)(a >> 32), (unsigned)(a & 0xFFFFFFFFu));
 }
 
-void drive(bu_frontend_pipeline* p) {
+void drive(driver_state* d) {
+    bu_frontend_pipeline* p = d->p;
     double idle_since = 0;
     for (;;) {
         {
             std::unique_lock<std::mutex> g(p->m);
             for (;;) {
-                for (auto& l : p->lanes)
-                    if (!l.j && !p->pending.empty()) { job* j = p->pending.front(); p->pending.pop_front(); start_lane(l, j); p->active++; }
-                if (p->active) break;
-                if (p->stop) return;
+                for (uint32_t k = 0; k < d->n_lanes; k++) {
+                    lane& l = p->lanes[d->first_lane + k];
+                    if (!l.j && !p->pending.empty()) { job* j = p->pending.front(); p->pending.pop_front(); start_lane(l, j); d->active++; }
+                }
+                if (d->active) break;
+                if (p->stop && p->pending.empty()) return;
                 p->cv_work.wait(g);
                 idle_since = 0;
             }
@@ -167,19 +179,20 @@ void drive(bu_frontend_pipeline* p) {
         const double t0 = now_s();
         bool finished_any = false;
         uint32_t ran = 0;
-        for (auto& l : p->lanes) {
+        for (uint32_t k = 0; k < d->n_lanes; k++) {
+            lane& l = p->lanes[d->first_lane + k];
             if (!l.j) continue;
             ran++;
-            p->n_switches++;
-            swapcontext(&p->sched, &l.uc);
+            d->n_switches++;
+            swapcontext(&d->sched, &l.uc);
             if (l.finished) {
                 job* j = l.j;
                 l.j = nullptr;
                 {
                     timespec ts;
-                    if (clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts) == 0) p->driver_cpu_s.store((double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec, std::memory_order_relaxed);
+                    if (clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts) == 0) d->cpu_s.store((double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec, std::memory_order_relaxed);
                     std::lock_guard<std::mutex> g(p->m);
-                    j->done = true; p->active--; p->n_done++;
+                    j->done = true; d->active--; p->n_done++;
                 }
                 p->cv_done.notify_all();
                 finished_any = true;
@@ -189,14 +202,14 @@ void drive(bu_frontend_pipeline* p) {
         // A round in which every task only looked at its stream and yielded again did no work: after idle_spin_s of such rounds the thread naps between looks
         // (the device is busy with launches already queued; the naps cost their length in latency at most once per wait).
         const bool worked = finished_any || (t1 - t0) > 4e-6 * ran;
-        if (worked) { idle_since = 0; p->driver_busy_s += t1 - t0; }
+        if (worked) { idle_since = 0; d->busy_s += t1 - t0; }
         else {
-            p->driver_idle_s += t1 - t0;
+            d->idle_s += t1 - t0;
             if (idle_since == 0) idle_since = t0;
             else if (p->idle_sleep_s > 0 && t1 - idle_since > p->idle_spin_s) {
-                p->n_idle_sleeps++;
+                d->n_idle_sleeps++;
                 std::this_thread::sleep_for(std::chrono::duration<double>(p->idle_sleep_s));
-                p->driver_idle_s += now_s() - t1;
+                d->idle_s += now_s() - t1;
             }
         }
     }
@@ -214,8 +227,9 @@ extern "C" {
 
 #define BU_PIPE_CATCH(fail_value) catch (const std::exception& e_) { bu_last_exception_text = e_.what(); return fail_value; } catch (...) { bu_last_exception_text = "unknown exception"; return fail_value; }
 
-static bu_frontend_pipeline* pipeline_new(int device, uint32_t lanes, bool need_device) {
+static bu_frontend_pipeline* pipeline_new(int device, uint32_t lanes, bool need_device, uint32_t n_drivers = 1) {
     if (lanes < 1 || lanes > 16) { bu_last_exception_text = "bu_frontend_pipeline_create: 1..16 lanes"; return nullptr; }
+    if (n_drivers < 1 || n_drivers > lanes) { bu_last_exception_text = "bu_frontend_pipeline_create: 1..lanes driver threads"; return nullptr; }
     if (need_device && !bu_hip_is_available() && !bu_hip_init(0)) { bu_last_exception_text = std::string("bu_frontend_pipeline_create: ") + bu_hip_last_error(nullptr); return nullptr; }
     bu_frontend_pipeline* p = new bu_frontend_pipeline();
     p->device = device;
@@ -235,16 +249,24 @@ static bu_frontend_pipeline* pipeline_new(int device, uint32_t lanes, bool need_
         mprotect(s, 4096, PROT_NONE);   // guard page below the stack
         l.stack = static_cast<char*>(s) + 4096;
     }
-    p->driver = std::thread(drive, p);
+    for (uint32_t k = 0, at = 0; k < n_drivers; k++) {   // the lanes dealt out evenly
+        p->drivers.emplace_back();
+        driver_state& d = p->drivers.back();
+        d.p = p; d.first_lane = at; d.n_lanes = lanes / n_drivers + (k < lanes % n_drivers ? 1u : 0u);
+        for (uint32_t i = 0; i < d.n_lanes; i++) p->lanes[at + i].drv = &d;
+        at += d.n_lanes;
+    }
+    for (auto& d : p->drivers) d.th = std::thread(drive, &d);
     return p;
 }
 
 bu_frontend_pipeline* bu_frontend_pipeline_create(int device, uint32_t lanes) try { return pipeline_new(device, lanes, true); } BU_PIPE_CATCH(nullptr)
+bu_frontend_pipeline* bu_frontend_pipeline_create_n(int device, uint32_t lanes, uint32_t driver_threads) try { return pipeline_new(device, lanes, true, driver_threads); } BU_PIPE_CATCH(nullptr)
 
 // Test hook (no GPU): `tasks` self-test tasks of `yields` yields each through a `lanes`-lane pipeline; every third one throws and catches inside, `failing` of them end in
 // an exception that must surface as a failed job. 1 = every task saw its own stack intact at every resume, failures were reported as failures, nothing else was.
 int bu_frontend_pipeline_selftest(uint32_t lanes, uint32_t tasks, uint32_t yields, uint32_t failing) try {
-    bu_frontend_pipeline* p = pipeline_new(0, lanes, false);
+    bu_frontend_pipeline* p = pipeline_new(0, lanes, false, lanes >= 4 ? 2u : 1u);   // two driver threads from four lanes up: both forms are exercised
     if (!p) return 0;
     p->idle_sleep_s = 0;
     std::vector<uint64_t> t;
@@ -256,7 +278,7 @@ int bu_frontend_pipeline_selftest(uint32_t lanes, uint32_t tasks, uint32_t yield
             std::lock_guard<std::mutex> g(p->m);
             j->ticket = p->next_ticket++; p->jobs[j->ticket] = j; p->pending.push_back(j);
         }
-        p->cv_work.notify_one();
+        p->cv_work.notify_all();
         t.push_back(j->ticket);
     }
     for (uint32_t i = 0; i < tasks; i++) {
@@ -287,7 +309,7 @@ uint64_t bu_frontend_pipeline_submit(bu_frontend_pipeline* p, const bu_frontend_
         p->jobs[j->ticket] = j;
         p->pending.push_back(j);
     }
-    p->cv_work.notify_one();
+    p->cv_work.notify_all();
     return j->ticket;
 } BU_PIPE_CATCH(0)
 
@@ -347,7 +369,7 @@ void bu_frontend_pipeline_destroy(bu_frontend_pipeline* p) try {
         p->stop = true;    // the driver finishes what is queued and in flight, then leaves
     }
     p->cv_work.notify_all();
-    if (p->driver.joinable()) p->driver.join();
+    for (auto& d : p->drivers) if (d.th.joinable()) d.th.join();
     for (auto& kv : p->jobs) free_job(kv.second);   // results nobody collected or released
     for (auto& l : p->lanes) if (l.stack) munmap(static_cast<char*>(l.stack) - 4096, l.stack_bytes + 4096);
     delete p;
@@ -360,7 +382,9 @@ uint32_t bu_frontend_pipeline_stats(bu_frontend_pipeline* p, double* out, uint32
     std::lock_guard<std::mutex> g(p->m);
     uint64_t yields = 0;
     for (auto& l : p->lanes) yields += l.yields;
-    const double v[7] = {(double)p->n_done, (double)p->n_switches, (double)yields, (double)p->n_idle_sleeps, p->driver_busy_s, p->driver_idle_s, p->driver_cpu_s.load()};
+    uint64_t switches = 0, naps = 0; double busy = 0, idle = 0, cpu = 0;
+    for (auto& d : p->drivers) { switches += d.n_switches; naps += d.n_idle_sleeps; busy += d.busy_s; idle += d.idle_s; cpu += d.cpu_s.load(); }
+    const double v[7] = {(double)p->n_done, (double)switches, (double)yields, (double)naps, busy, idle, cpu};
     for (uint32_t i = 0; i < 7 && i < cap; i++) out[i] = v[i];
     return 7;
 }

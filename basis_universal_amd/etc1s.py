@@ -60,6 +60,8 @@ def load_frontend_library():
         L.bu_frontend_reference_max_threads.argtypes = [C.c_int, C.c_uint32, C.c_uint32]
         L.bu_frontend_pipeline_create.restype = _vp
         L.bu_frontend_pipeline_create.argtypes = [C.c_int, C.c_uint32]
+        L.bu_frontend_pipeline_create_n.restype = _vp
+        L.bu_frontend_pipeline_create_n.argtypes = [C.c_int, C.c_uint32, C.c_uint32]
         L.bu_frontend_pipeline_submit.restype = C.c_uint64
         L.bu_frontend_pipeline_submit.argtypes = [_vp, _vp, C.c_uint32]
         L.bu_frontend_pipeline_wait.restype = _vp
@@ -320,12 +322,12 @@ class FrontendPipeline:
             fe = pipe.wait(t); ...fe.get("encoded_blocks")...; fe.close()
         pipe.close()"""
 
-    def __init__(self, device=0, lanes=3):
+    def __init__(self, device=0, lanes=3, drivers=1):
         lib = capi.load_library()
         if not lib.init(0):
             raise capi.HipError("bu_hip_init failed: " + lib.last_error(None))
         self.L = load_frontend_library()
-        self.h = self.L.bu_frontend_pipeline_create(int(device), int(lanes))
+        self.h = self.L.bu_frontend_pipeline_create_n(int(device), int(lanes), int(drivers))
         if not self.h:
             raise capi.HipError("bu_frontend_pipeline_create failed: " + (self.L.bu_host_last_exception() or b"").decode())
         self.lanes = int(lanes)

@@ -106,6 +106,9 @@ typedef struct bu_frontend_job {
     uint32_t reserved;
 } bu_frontend_job;
 BU_HIP_API bu_frontend_pipeline* bu_frontend_pipeline_create(int device, uint32_t lanes);
+/* ... with the lanes dealt out over `driver_threads` (1..lanes) driver threads instead of one: more host CPU, less waiting of a lane for the thread when the images'
+ * host work (host tiles to stage, results to hand back) is heavy. Results are the same. */
+BU_HIP_API bu_frontend_pipeline* bu_frontend_pipeline_create_n(int device, uint32_t lanes, uint32_t driver_threads);
 BU_HIP_API uint64_t bu_frontend_pipeline_submit(bu_frontend_pipeline*, const bu_frontend_job* job, uint32_t struct_bytes /* sizeof(bu_frontend_job) of the caller's header */);
 BU_HIP_API bu_frontend* bu_frontend_pipeline_wait(bu_frontend_pipeline*, uint64_t ticket);
 BU_HIP_API int bu_frontend_pipeline_poll(bu_frontend_pipeline*, uint64_t ticket);   /* 1 finished (wait will not block), 0 not yet, -1 unknown ticket */

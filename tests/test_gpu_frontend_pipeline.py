@@ -14,11 +14,11 @@ pytestmark = pytest.mark.gpu
 MIX = ["synth256_l1", "synth256_l3_flat", "synth256_l4", "synth512_q128", "noise_small_codebooks", "ragged_edges", "synth256_l0", "synth128_l6", "synth256_l2_linear"]
 
 
-@pytest.mark.parametrize("lanes", [1, 3, 8])
-def test_mixed_images_in_flight_equal_the_reference(lanes):
+@pytest.mark.parametrize("lanes,drivers", [(1, 1), (3, 1), (8, 1), (6, 2), (8, 4)])
+def test_mixed_images_in_flight_equal_the_reference(lanes, drivers):
     from basis_universal_amd.etc1s import FrontendPipeline
     golden = json.loads(T.GOLDEN.read_text())
-    pipe = FrontendPipeline(0, lanes)
+    pipe = FrontendPipeline(0, lanes, drivers)   # drivers > 1: the lanes dealt out over that many driver threads (bu_frontend_pipeline_create_n)
     tickets = []
     for rep in range(2):
         for case in MIX:

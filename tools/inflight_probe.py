@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--null-stream", action="store_true", help="context 0 on torch's current (null) stream as bench.py's headline context is")
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--pipeline", action="store_true", help="bu_frontend_pipeline_* (one driver thread, cooperative tasks) instead of one host thread per image in flight")
+    ap.add_argument("--drivers", type=int, default=1, help="driver threads of the pipeline (bu_frontend_pipeline_create_n)")
     ap.add_argument("--threads", type=int, default=0, help="the reference's codebook thread configuration (bu_frontend_set_max_threads)")
     args = ap.parse_args()
     os.environ.setdefault("BU_HIP_PARKED_CONTEXTS", "32")
@@ -52,7 +53,7 @@ def main():
         if args.threads:
             want = json.loads((ROOT / "tests" / "golden" / "etc1s_big_digests.json").read_text())[f"synth4096_q128_t{args.threads}"]["frontend_digests"] if want else None
         for n in counts:
-            pipe = FrontendPipeline(0, n)
+            pipe = FrontendPipeline(0, n, min(args.drivers, n))
             images = n * args.per_stream
             for rep in range(2):   # warm as many contexts as results will be held at once below (a job's context stays with its frontend until that is closed)
                 for fe in [pipe.wait(t) for t in [pipe.submit(d_blocks.data_ptr(), max_ep, max_sel, 1, True, n_blocks=n_blocks, max_threads=args.threads) for _ in range(images)]]:
@@ -69,7 +70,7 @@ def main():
             for fe in done:
                 fe.close()
             pipe.close()
-            print(json.dumps({"mode": "pipeline", "in_flight": n, "images": images, "value": round(images * w * h / 1e6 / dt, 1), "unit": "Mpixels/s", "ms_per_image": round(dt / images * 1e3, 2),
+            print(json.dumps({"mode": "pipeline", "drivers": min(args.drivers, n), "in_flight": n, "images": images, "value": round(images * w * h / 1e6 / dt, 1), "unit": "Mpixels/s", "ms_per_image": round(dt / images * 1e3, 2),
                               "host_cpu_s_per_image": round(cpu / images, 4), "identical_to_reference": same,
                               "driver": {k: round((s1[k] - s0[k]) / images, 5) for k in s1 if k != "jobs"},
                               "env": {k: os.environ[k] for k in ("GPU_MAX_HW_QUEUES", "BU_PIPELINE_SPIN_US", "BU_PIPELINE_SLEEP_US", "BU_HOST_THREADS") if k in os.environ}}), flush=True)
