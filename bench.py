@@ -219,12 +219,20 @@ def main():
             pipelined["value"] = round(world * pipelined["images"] * (w * h) / 1e6 / float(t.item()), 3)
             pipelined["images"] *= world
         pipelined.pop("_seconds", None)
-        # the same images-in-flight count the round-4 way, one host thread + context per image (what the reference's basis_parallel_compress does): the host cost
-        # of the pipeline's one driver thread is to be read against this
-        fes, dt = run_in_flight(PIPELINE_LANES, 2 * PIPELINE_LANES)
+        if world == 1:
+            # ... with ONE driver thread for all lanes (what bu_frontend_pipeline_create gives): the cheapest form on the host
+            one = pipelined_bench(local_rank, d_blocks, n_blocks, w, h, max_ep, max_sel, args, barrier, lanes=6, drivers=1)
+            one.pop("_seconds", None); one.pop("note", None)
+            pipelined["one_driver_thread"] = one
+        # the same images-in-flight idea the round-4 way, one host thread + context per image (what the reference's basis_parallel_compress does): the host cost
+        # of the pipeline's driver threads is to be read against this
+        cpu0 = time.process_time()
+        fes, dt = run_in_flight(6, 12)
+        cpu = time.process_time() - cpu0
         for fe in fes:
             fe.close()
-        pipelined["thread_per_image"] = {"images_in_flight_per_gpu": PIPELINE_LANES, "value": round(2 * PIPELINE_LANES * (w * h) / 1e6 / dt, 3), "unit": "Mpixels/s (this rank)"}
+        pipelined["thread_per_image"] = {"images_in_flight_per_gpu": 6, "value": round(12 * (w * h) / 1e6 / dt, 3), "unit": "Mpixels/s (this rank)",
+                                         "host_cpu_s_per_image": round(cpu / 12, 5)}
     whole_encoder = None
     if args.streams <= 1 and not sharded and not args.no_pipelined and world == 1:
         nf = max(1, args.backend_in_flight)
@@ -335,17 +343,19 @@ def main():
         dist.destroy_process_group()
 
 
-PIPELINE_LANES = 4
+PIPELINE_LANES = 8      # images in flight of the `pipelined` leg ...
+PIPELINE_DRIVERS = 2    # ... over this many driver threads (side by side on one box, 4096^2: 4 / 6 / 8 lanes on 1 / 1 / 2 threads = 1,402 / 1,564 / 1,801 Mpix/s; a host thread
+                        # per image, 4 / 6 in flight: 1,703 / 1,837 at three times the host CPU: docs/HISTORY.md R5.10)
 
 
-def pipelined_bench(device, d_blocks, n_blocks, w, h, max_ep, max_sel, args, barrier):
+def pipelined_bench(device, d_blocks, n_blocks, w, h, max_ep, max_sel, args, barrier, lanes=PIPELINE_LANES, drivers=PIPELINE_DRIVERS):
     """Throughput mode of ONE GPU as library behaviour: bu_frontend_pipeline_* (include/basisu_hip_frontend.h) -- PIPELINE_LANES images in flight as cooperative
     tasks on the library's one driver thread; the caller only submits and collects. Every image's state is checked against the reference's digests (outside
     the timed region); host CPU seconds per image cover ALL threads of this process while the images were in flight."""
     from basis_universal_amd.etc1s import FrontendPipeline
     import torch
-    images = 4 * PIPELINE_LANES
-    pipe = FrontendPipeline(device, PIPELINE_LANES)
+    images = 16   # results held at once below = contexts out at once (the library parks 16)
+    pipe = FrontendPipeline(device, lanes, drivers)
     submit = lambda: pipe.submit(d_blocks.data_ptr(), max_ep, max_sel, args.level, True, n_blocks=n_blocks)
     for _ in range(2):   # as many warm contexts as results are held at once below
         for fe in [pipe.wait(t) for t in [submit() for _ in range(images)]]:
@@ -361,9 +371,9 @@ def pipelined_bench(device, d_blocks, n_blocks, w, h, max_ep, max_sel, args, bar
     for fe in done:
         fe.close()
     pipe.close()
-    return {"api": "bu_frontend_pipeline_* (one driver thread, cooperative tasks)", "images_in_flight_per_gpu": PIPELINE_LANES, "images": images,
+    return {"api": f"bu_frontend_pipeline_* (cooperative tasks on {drivers} driver thread{'s' if drivers > 1 else ''})", "images_in_flight_per_gpu": lanes, "driver_threads": drivers, "images": images,
             "value": round(images * (w * h) / 1e6 / dt, 3), "unit": "Mpixels/s", "ms_per_image": round(dt / images * 1e3, 3),
-            "host_cpu_s_per_image": round(cpu / images, 5), "driver_thread_cpu_s_per_image": round((s1["driver_cpu_s"] - s0["driver_cpu_s"]) / images, 5),
+            "host_cpu_s_per_image": round(cpu / images, 5), "driver_threads_cpu_s_per_image": round((s1["driver_cpu_s"] - s0["driver_cpu_s"]) / images, 5),
             "driver_s_per_image": {"in_tasks": round((s1["driver_busy_s"] - s0["driver_busy_s"]) / images, 5), "idle": round((s1["driver_idle_s"] - s0["driver_idle_s"]) / images, 5),
                                    "yields": round((s1["yields"] - s0["yields"]) / images), "naps": round((s1["idle_naps"] - s0["idle_naps"]) / images, 1)},
             "identical_to_reference": (all(same) if all(x is not None for x in same) else None), "_seconds": dt,
