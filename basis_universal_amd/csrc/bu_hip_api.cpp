@@ -78,7 +78,7 @@ struct bu_hip_context {
     std::vector<pooled> pool_live;
     size_t pool_free_bytes = 0;
     // optional per-kernel timing with HIP events on the launch stream (bu_hip_profile_*)
-    bool profiling = false;
+    int profiling = 0;   // bu_hip_profile_enable: 0 off, 1 every region, 2 the regions that are one kernel launch each
     struct prof_rec { const char* name; hipEvent_t start, stop; };
     std::vector<prof_rec> prof_pending;
     std::vector<hipEvent_t> prof_events;   // recycled (creating and destroying two events per timed region cost more host time than recording them)
@@ -135,6 +135,9 @@ struct prof_scope {
     bu_hip_context* ctx; const char* name; hipEvent_t start = nullptr, stop = nullptr;
     prof_scope(bu_hip_context* c, const char* n) : ctx(c), name(n) {
         if (!ctx->profiling) return;
+        // level 2: only the regions that are ONE kernel launch; the many-launch regions (codebook builders' rounds, de-duplication sorts, list bookkeeping) go untimed,
+        // and with them the events that would sit between their kernels
+        if (ctx->profiling == 2 && (std::strncmp(n, "tsvq_", 5) == 0 || std::strncmp(n, "unique_", 7) == 0 || std::strncmp(n, "map_", 4) == 0 || std::strncmp(n, "kmeans_", 7) == 0)) return;
         if (ctx->prof_events.size() < 2 && ctx->prof_pending.size() >= 64) {   // reap the oldest finished regions: their events are the next ones recorded
             size_t done = 0;
             while (done < ctx->prof_pending.size() && done < 8 && hipEventQuery(ctx->prof_pending[done].stop) == hipSuccess) {
@@ -335,7 +338,7 @@ void bu_hip_destroy_context(bu_hip_context* ctx) {
         ctx->d_pixel_blocks = nullptr; ctx->total_blocks = 0;
         ctx->stage_used = 0;
         ctx->error.clear();
-        ctx->profiling = false; ctx->prof_totals.clear();
+        ctx->profiling = 0; ctx->prof_totals.clear();
         ctx->wait_hook = nullptr; ctx->wait_user = nullptr;
         ctx->tuning = default_tuning();
         std::lock_guard<std::mutex> g(g_park_lock);
@@ -539,7 +542,7 @@ int bu_hip_profile_enable(bu_hip_context* ctx, int on) {
     device_guard g(ctx->device);
     prof_drain(ctx);
     ctx->prof_totals.clear();
-    ctx->profiling = on != 0;
+    ctx->profiling = on == 2 ? 2 : (on != 0 ? 1 : 0);
     return 1;
 }
 
@@ -1192,7 +1195,7 @@ int bu_hip_tsvq_split(bu_hip_context* ctx, bu_tsvq* q, const bu_tsvq_node* h_nod
     const bool exact = q->packed && !q->force_chained;
     // The two kinds of node of a round do not touch each other's data: when both are present the one-workgroup kernel runs on the side
     // stream, under the many small launches of the wide path. (Not while kernels are being timed one by one.)
-    bool narrow_on_side = n_wide && n_narrow && !ctx->profiling && !q->dbg_serial;
+    bool narrow_on_side = n_wide && n_narrow && ctx->profiling != 1 && !q->dbg_serial;   // (not while the rounds' kernels are being timed one region after the other)
     if (narrow_on_side && !ensure_side_stream(ctx)) narrow_on_side = false;
     // From the fork on, every early return must wait for the side stream first: the caller's guard destroys q (its buffers go back to the
     // pool without a synchronisation) while the one-workgroup kernel may still be running on them.

@@ -129,7 +129,10 @@ typedef void (*bu_hip_wait_fn)(void* user);
 BU_HIP_API int   bu_hip_set_wait_hook(bu_hip_context*, bu_hip_wait_fn fn, void* user);
 BU_HIP_API const char* bu_hip_last_error(const bu_hip_context*); /* NULL context -> last global (init) error */
 
-/* Per-kernel timing with HIP events recorded on the launch stream around every section-2 kernel. enable(1) resets the totals;
+/* Per-kernel timing with HIP events recorded on the launch stream around every section-2 kernel. enable(1) resets the totals and times every region; enable(2) only
+ * the regions that are ONE kernel launch each (per-block and per-cluster kernels) -- the regions of many launches (codebook builders' rounds, de-duplication, list
+ * bookkeeping: names tsvq_*, unique_*, map_*, kmeans_*) go untimed, and the step runs as it does without instrumentation (an event between two kernels of a chain
+ * costs the chain ~3 us, and a round's two kinds of nodes only share the device when nobody times them apart: 0.5-0.7 ms of a 17 ms step, tools/headline_ab.py).
  * read() synchronises the pending events and returns the number of distinct kernels (names are static strings). */
 BU_HIP_API int      bu_hip_profile_enable(bu_hip_context*, int on);
 BU_HIP_API uint32_t bu_hip_profile_read(bu_hip_context*, const char** names, double* total_ms, uint32_t* launches, uint32_t cap);
