@@ -1520,8 +1520,8 @@ void bu_hip_uastc_rdo_default_params(bu_uastc_rdo_params* p) {
 // The context's second stream (and the two events that fork it off the main stream and join it back), made on first use.
 static bool ensure_side_stream(bu_hip_context* ctx) {
     if (ctx->side_stream) return true;
-    if (hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ctx->side_fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&ctx->side_join, hipEventDisableTiming) != hipSuccess) {
+    if (hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking) != hipSuccess || (!ctx->side_fork && hipEventCreateWithFlags(&ctx->side_fork, hipEventDisableTiming) != hipSuccess) ||
+        (!ctx->side_join && hipEventCreateWithFlags(&ctx->side_join, hipEventDisableTiming) != hipSuccess)) {
         (void)hipGetLastError();
         if (ctx->side_stream) { (void)hipStreamDestroy(ctx->side_stream); ctx->side_stream = nullptr; }
         if (ctx->side_fork) { (void)hipEventDestroy(ctx->side_fork); ctx->side_fork = nullptr; }
@@ -1650,7 +1650,21 @@ bu_uastc_pipeline* bu_hip_uastc_pipeline_create(bu_hip_context* ctx, uint32_t la
     const size_t ws_bytes = std::max(bu::uastc_workspace_bytes(max_blocks, flags), bu::uastc_rdo_workspace_bytes(max_blocks, max_total_jobs));
     for (auto& l : p->lanes) {
         l.ctx = bu_hip_create_context_on(ctx->device);
-        if (l.ctx) l.ctx->tuning = ctx->tuning;   // the lanes take the paths their parent context is set to
+        if (l.ctx) {
+            l.ctx->tuning = ctx->tuning;   // the lanes take the paths their parent context is set to
+            // A (parked) context's streams were made whenever it was first created, and the runtime maps streams onto its few hardware queues in creation order: two
+            // lanes whose streams share a queue run one after the other. The lanes get NEW streams, made here one after the other -- distinct queues as long as there
+            // are enough (GPU_MAX_HW_QUEUES >= 2 x lanes: the walks use a second stream per lane) -- the main ones first.
+            (void)hipStreamSynchronize(l.ctx->own_stream);
+            hipStream_t fresh = nullptr;
+            if (hipStreamCreateWithFlags(&fresh, hipStreamNonBlocking) == hipSuccess) {
+                const bool own = l.ctx->stream == l.ctx->own_stream;
+                (void)hipStreamDestroy(l.ctx->own_stream);
+                l.ctx->own_stream = fresh;
+                if (own) l.ctx->stream = fresh;
+            } else (void)hipGetLastError();
+            if (l.ctx->side_stream) { (void)hipStreamSynchronize(l.ctx->side_stream); (void)hipStreamDestroy(l.ctx->side_stream); l.ctx->side_stream = nullptr; }
+        }
         if (!l.ctx || hipEventCreateWithFlags(&l.done, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&l.input, hipEventDisableTiming) != hipSuccess ||
             hipHostMalloc(reinterpret_cast<void**>(&l.stats), 64, hipHostMallocDefault) != hipSuccess || l.ctx->scratch[5].reserve(ws_bytes) != hipSuccess) {
             set_error(ctx, "uastc_pipeline_create: lane set-up failed (%s)", l.ctx ? bu_hip_last_error(l.ctx) : "no context");
@@ -1658,6 +1672,7 @@ bu_uastc_pipeline* bu_hip_uastc_pipeline_create(bu_hip_context* ctx, uint32_t la
             return nullptr;
         }
     }
+    for (auto& l : p->lanes) (void)ensure_side_stream(l.ctx);   // the second streams, after all the first ones
     return p;
 }
 

@@ -17,9 +17,9 @@ print({k:(d.get(k) or {}).get("value") for k in ("uastc","uastc_rdo","etc1s_8192
 PY
 cd /tmp && export TMPDIR=/tmp
 db() { ls /tmp/$1/*/*.db /tmp/$1/*.db 2>/dev/null | head -1; }
-timeout 200 rocprofv3 --kernel-trace --stats -d /tmp/prof_$tag -o bench -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-pipelined --no-big > $R/gpurun_out/prof_$tag.json 2> $R/gpurun_out/prof_$tag.err
+timeout 200 rocprofv3 --kernel-trace --stats -d /tmp/prof_$tag -o bench -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-pipelined --no-big --no-fast --no-uastc > $R/gpurun_out/prof_$tag.json 2> $R/gpurun_out/prof_$tag.err
 python $R/tools/rocprof_summary.py stats $(db prof_$tag) > $R/gpurun_out/${tag}_kernel_stats.csv; wc -l $R/gpurun_out/${tag}_kernel_stats.csv
-python $R/tools/rocprof_timeline.py $(db prof_$tag) > $R/gpurun_out/${tag}_step_timeline_t0.txt 2>&1; tail -1 $R/gpurun_out/${tag}_step_timeline_t0.txt
+python $R/tools/rocprof_timeline.py $(db prof_$tag) 3 > $R/gpurun_out/${tag}_step_timeline_t0.txt 2>&1   # the 4th step of the run: a timed headline step; tail -1 $R/gpurun_out/${tag}_step_timeline_t0.txt
 for c in FETCH_SIZE WRITE_SIZE; do
   l=$(echo $c | tr A-Z a-z)
   timeout 150 rocprofv3 --kernel-trace --pmc $c -d /tmp/pmc_${l}_$tag -o bench -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-pipelined --no-big > /dev/null 2> $R/gpurun_out/pmc_${l}_$tag.err
@@ -29,4 +29,5 @@ timeout 150 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTI
 python $R/tools/rocprof_summary.py pmc $(db pmc_sq_$tag) > $R/gpurun_out/${tag}_pmc_sq.csv 2>/dev/null; wc -l $R/gpurun_out/${tag}_pmc_sq.csv
 timeout 200 rocprofv3 --kernel-trace -d /tmp/trp_$tag -o t -- python $R/tools/inflight_probe.py --pipeline --streams 4 --per-stream 4 --no-check > $R/gpurun_out/${tag}_pipelined_probe.txt 2>&1
 python $R/tools/rocprof_concurrency.py $(db trp_$tag) -150 -5 > $R/gpurun_out/${tag}_pipelined_concurrency.txt 2>&1; grep "executing at once" -A 7 $R/gpurun_out/${tag}_pipelined_concurrency.txt
-cd $R && BU_TSVQ_ROUNDS=1 timeout 120 python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-pipelined --no-big --no-uastc --no-fast > /dev/null 2> gpurun_out/${tag}_tsvq_rounds_t0.txt; grep -c "tsvq round" gpurun_out/${tag}_tsvq_rounds_t0.txt
+cd $R && BU_TSVQ_ROUNDS=1 timeout 120 python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-pipelined --no-big --no-uastc --no-fast > /dev/null 2> gpurun_out/rounds_$tag.log
+grep "tsvq round" gpurun_out/rounds_$tag.log | sed -n 30,58p > gpurun_out/${tag}_tsvq_rounds_t0.txt; wc -l gpurun_out/${tag}_tsvq_rounds_t0.txt   # the timed step (the warm-up step's 29 rounds come first)
