@@ -60,6 +60,7 @@ struct bu_hip_context {
     // a second stream for work that is independent of what the main stream is doing (the one-workgroup TSVQ splits of a round next to
     // its many-workgroup ones); joined back through the two events before anything reads the results
     hipStream_t side_stream = nullptr; hipEvent_t side_fork = nullptr, side_join = nullptr;
+    bool dedicated_queue = false;         // own_stream was made with a (full) CU mask: a hardware queue of its own instead of a share of the runtime's pool
     arena refine_lists;                   // the sorted candidate lists of refine_endpoint_clusterization (etc1s_kernels.hip, k_refine_sort_lists)
     const void* d_pixel_blocks = nullptr; // resident tiles (a1): 64 B per block
     size_t total_blocks = 0;
@@ -256,6 +257,7 @@ static std::atomic<int> g_live_contexts{0};
 static void context_release(bu_hip_context* ctx);   // the real teardown
 static const bu_hip_tuning& default_tuning();
 static bool ensure_side_stream(bu_hip_context* ctx);
+static hipStream_t make_dedicated_stream(int device);
 static size_t park_limit() {
     static const size_t n = [] { const char* e = std::getenv("BU_HIP_PARKED_CONTEXTS"); const long v = e ? std::atol(e) : 16; return (size_t)(v < 0 ? 0 : (v > 64 ? 64 : v)); }();
     return n;
@@ -284,7 +286,9 @@ bu_hip_context* bu_hip_create_context_on(int device) {
     if (!ctx) return nullptr;
     ctx->device = device;
     ctx->tuning = default_tuning();
-    if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) { set_error(nullptr, "hipStreamCreate failed"); delete ctx; return nullptr; }
+    static const bool all_dedicated = std::getenv("BU_HIP_DEDICATED_QUEUES") != nullptr;   // experiment switch: every context's stream on a hardware queue of its own
+    if (all_dedicated && (ctx->own_stream = make_dedicated_stream(device)) != nullptr) ctx->dedicated_queue = true;
+    else if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) { set_error(nullptr, "hipStreamCreate failed"); delete ctx; return nullptr; }
     ctx->stream = ctx->own_stream;
     hipError_t e = bu::upload_etc1s_tables(device);
     if (e != hipSuccess) { set_error(nullptr, "constant table upload failed: %s", hipGetErrorString(e)); (void)hipStreamDestroy(ctx->own_stream); delete ctx; return nullptr; }
@@ -1517,6 +1521,17 @@ void bu_hip_uastc_rdo_default_params(bu_uastc_rdo_params* p) {
     p->m_endpoint_refinement = 1; p->m_lz_literal_cost = 100; p->m_max_smooth_block_std_dev = 18.0f; p->m_smooth_block_max_error_scale = 10.0f;
 }
 
+// A stream with a hardware queue of its own: hipExtStreamCreateWithCUMask with every CU enabled (the runtime does not pool queues that carry a CU mask). nullptr on failure.
+static hipStream_t make_dedicated_stream(int device) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess || prop.multiProcessorCount <= 0) { (void)hipGetLastError(); return nullptr; }
+    std::vector<uint32_t> mask(((uint32_t)prop.multiProcessorCount + 31) / 32, 0xFFFFFFFFu);
+    if (prop.multiProcessorCount % 32) mask.back() = (1u << (prop.multiProcessorCount % 32)) - 1u;
+    hipStream_t s = nullptr;
+    if (hipExtStreamCreateWithCUMask(&s, (uint32_t)mask.size(), mask.data()) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return s;
+}
+
 // The context's second stream (and the two events that fork it off the main stream and join it back), made on first use.
 static bool ensure_side_stream(bu_hip_context* ctx) {
     if (ctx->side_stream) return true;
@@ -1652,18 +1667,19 @@ bu_uastc_pipeline* bu_hip_uastc_pipeline_create(bu_hip_context* ctx, uint32_t la
         l.ctx = bu_hip_create_context_on(ctx->device);
         if (l.ctx) {
             l.ctx->tuning = ctx->tuning;   // the lanes take the paths their parent context is set to
-            // A (parked) context's streams were made whenever it was first created, and the runtime maps streams onto its few hardware queues in creation order: two
-            // lanes whose streams share a queue run one after the other. The lanes get NEW streams, made here one after the other -- distinct queues as long as there
-            // are enough (GPU_MAX_HW_QUEUES >= 2 x lanes: the walks use a second stream per lane) -- the main ones first.
-            (void)hipStreamSynchronize(l.ctx->own_stream);
-            hipStream_t fresh = nullptr;
-            if (hipStreamCreateWithFlags(&fresh, hipStreamNonBlocking) == hipSuccess) {
-                const bool own = l.ctx->stream == l.ctx->own_stream;
-                (void)hipStreamDestroy(l.ctx->own_stream);
-                l.ctx->own_stream = fresh;
-                if (own) l.ctx->stream = fresh;
-            } else (void)hipGetLastError();
-            if (l.ctx->side_stream) { (void)hipStreamSynchronize(l.ctx->side_stream); (void)hipStreamDestroy(l.ctx->side_stream); l.ctx->side_stream = nullptr; }
+            // The runtime maps ordinary streams onto its few shared hardware queues (GPU_MAX_HW_QUEUES) by how many streams each queue already carries -- history, as far
+            // as a library can tell -- and two lanes whose streams share a queue run one after the other. A stream with a CU mask gets a hardware queue of its OWN: the
+            // lanes' streams are made with one that enables every CU.
+            if (!l.ctx->dedicated_queue) {
+                hipStream_t fresh = make_dedicated_stream(l.ctx->device);
+                if (fresh) {
+                    (void)hipStreamSynchronize(l.ctx->own_stream);
+                    const bool own = l.ctx->stream == l.ctx->own_stream;
+                    (void)hipStreamDestroy(l.ctx->own_stream);
+                    l.ctx->own_stream = fresh; l.ctx->dedicated_queue = true;
+                    if (own) l.ctx->stream = fresh;
+                }
+            }
         }
         if (!l.ctx || hipEventCreateWithFlags(&l.done, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&l.input, hipEventDisableTiming) != hipSuccess ||
             hipHostMalloc(reinterpret_cast<void**>(&l.stats), 64, hipHostMallocDefault) != hipSuccess || l.ctx->scratch[5].reserve(ws_bytes) != hipSuccess) {
@@ -1672,7 +1688,6 @@ bu_uastc_pipeline* bu_hip_uastc_pipeline_create(bu_hip_context* ctx, uint32_t la
             return nullptr;
         }
     }
-    for (auto& l : p->lanes) (void)ensure_side_stream(l.ctx);   // the second streams, after all the first ones
     return p;
 }
 
