@@ -286,9 +286,8 @@ bu_hip_context* bu_hip_create_context_on(int device) {
     if (!ctx) return nullptr;
     ctx->device = device;
     ctx->tuning = default_tuning();
-    static const bool all_dedicated = std::getenv("BU_HIP_DEDICATED_QUEUES") != nullptr;   // experiment switch: every context's stream on a hardware queue of its own
-    if (all_dedicated && (ctx->own_stream = make_dedicated_stream(device)) != nullptr) ctx->dedicated_queue = true;
-    else if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) { set_error(nullptr, "hipStreamCreate failed"); delete ctx; return nullptr; }
+    // (a pooled queue, not a dedicated one: with EVERY context on a queue of its own the frontend pipeline lost 15-20 %, measured)
+    if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) { set_error(nullptr, "hipStreamCreate failed"); delete ctx; return nullptr; }
     ctx->stream = ctx->own_stream;
     hipError_t e = bu::upload_etc1s_tables(device);
     if (e != hipSuccess) { set_error(nullptr, "constant table upload failed: %s", hipGetErrorString(e)); (void)hipStreamDestroy(ctx->own_stream); delete ctx; return nullptr; }
