@@ -63,6 +63,7 @@ struct driver_state {
     bu_frontend_pipeline* p = nullptr;
     ucontext_t sched;
     std::thread th;
+    std::thread::id tid;            // set by the thread itself before it runs its first task
     uint32_t first_lane = 0, n_lanes = 0, active = 0;
     uint64_t n_switches = 0, n_idle_sleeps = 0;
     double busy_s = 0, idle_s = 0;
@@ -92,6 +93,9 @@ namespace {
 
 void lane_yield(void* user) {
     lane* l = static_cast<lane*>(user);
+    // A task's stack can only be left from the thread that runs it. Should a helper thread of the frontend ever wait on the context (none does today: the host loops
+    // that fan out over BU_HOST_THREADS touch no device call), it simply gives up its time slice and looks again -- an ordinary polite wait.
+    if (std::this_thread::get_id() != l->drv->tid) { std::this_thread::yield(); return; }
     l->yields++;
     swapcontext(&l->uc, &l->drv->sched);
 }
@@ -160,6 +164,7 @@ void start_lane(lane& l, job* j) {
 
 void drive(driver_state* d) {
     bu_frontend_pipeline* p = d->p;
+    d->tid = std::this_thread::get_id();
     double idle_since = 0;
     for (;;) {
         {

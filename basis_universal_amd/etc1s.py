@@ -332,6 +332,8 @@ class FrontendPipeline:
             raise capi.HipError("bu_frontend_pipeline_create failed: " + (self.L.bu_host_last_exception() or b"").decode())
         self.lanes = int(lanes)
         self._keep = {}
+        import weakref
+        self._out = weakref.WeakSet()   # frontends handed out and not yet closed: destroying the pipeline takes them with it
 
     def submit(self, blocks, max_endpoint_clusters, max_selector_clusters, compression_level=1, perceptual=True, n_blocks=None, max_threads=0, video=False):
         """blocks: an (n, 4, 4, 4) uint8 array of tiles (uploaded by the job; kept alive until the frontend is closed) or a device pointer with n_blocks=."""
@@ -358,7 +360,9 @@ class FrontendPipeline:
         keep = self._keep.pop(int(ticket), None)
         if not h:
             raise capi.HipError("frontend pipeline: " + self.L.bu_frontend_pipeline_error(self.h).decode())
-        return PipelinedFrontend(self, h, keep)
+        fe = PipelinedFrontend(self, h, keep)
+        self._out.add(fe)
+        return fe
 
     def stats(self):
         v = (C.c_double * 7)()
@@ -367,6 +371,8 @@ class FrontendPipeline:
 
     def close(self):
         if getattr(self, "h", None):
+            for fe in list(self._out):   # bu_frontend_pipeline_destroy releases what nobody released: those handles are dead afterwards
+                fe.h = None
             self.L.bu_frontend_pipeline_destroy(self.h)
             self.h = None
 
