@@ -256,6 +256,37 @@ def main():
         whole_encoder = {"images_in_flight_per_gpu": nf, "images": 2 * nf, "value": round(2 * nf * (w * h) / 1e6 / dt, 3), "unit": "Mpixels/s",
                          "note": "frontend (GPU) + backend (host) per image = everything between the tiled input and the file writer; that many images in flight, one "
                                  "host thread / HIP stream each, each backend walking its image on two threads (throughput mode; not the headline value)"}
+        # the same through the frontend pipeline: the frontends of all images on its driver threads, `nf` host threads left to the backends alone
+        from basis_universal_amd.etc1s import FrontendPipeline
+        from basis_universal_amd.backend import Etc1sBackend
+        import threading
+        pipe = FrontendPipeline(local_rank, PIPELINE_LANES, PIPELINE_DRIVERS)
+        n_img = 2 * nf
+        lock, tickets = threading.Lock(), []
+
+        def backend_worker():
+            while True:
+                with lock:
+                    if not tickets:
+                        return
+                    t = tickets.pop(0)
+                fe = pipe.wait(t)
+                be = Etc1sBackend.from_frontend(fe, [(0, w // 4, h // 4)], 1.5, 1.25, args.level)
+                be.encode()
+                be.close()
+                fe.close()
+
+        barrier()
+        t0 = time.perf_counter()
+        tickets.extend(pipe.submit(d_blocks.data_ptr(), max_ep, max_sel, args.level, True, n_blocks=n_blocks) for _ in range(n_img))
+        th = [threading.Thread(target=backend_worker) for _ in range(nf)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        barrier()
+        dt = time.perf_counter() - t0
+        pipe.close()
+        whole_encoder["through_the_frontend_pipeline"] = {"lanes": PIPELINE_LANES, "driver_threads": PIPELINE_DRIVERS, "backend_threads": nf, "images": n_img,
+                                                          "value": round(n_img * (w * h) / 1e6 / dt, 3), "unit": "Mpixels/s"}
     if world > 1:
         t = torch.tensor([elapsed], device=red_dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
