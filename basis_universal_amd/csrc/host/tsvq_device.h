@@ -185,6 +185,9 @@ private:
     struct tree {
         std::vector<node> nodes;
         variance_heap heap;
+        // the queued nodes whose split has not been asked for yet, (variance, node) in creation order: what pending_nodes() offers the next round. (A scan of the whole
+        // queue per round found the same set; with 16,128 leaves that was ~1.5 ms of an 8192^2 step.)
+        std::vector<std::pair<float, uint32_t>> uncached;
         uint32_t leaves = 1, next_codebook_index = 0, max_leaves = 0;
         void reset(const bu_tsvq_root& root, uint32_t buf, uint32_t start, uint32_t count, uint32_t max_leaves_) {
             nodes.clear(); nodes.reserve((size_t)std::min<uint64_t>(max_leaves_, count) * 2 + 1);
@@ -192,6 +195,8 @@ private:
             r.buf = buf; r.start = start; r.count = count;
             nodes.push_back(r);
             heap.reset(0, r.var);
+            uncached.clear();
+            if (count > 1) uncached.emplace_back(r.var, 0u);
             leaves = 1; next_codebook_index = 0; max_leaves = max_leaves_;
         }
         // generate()'s loop (enc.h:1636-1655) while the splits it needs are known; true = it stopped at a node whose split is not known yet
@@ -217,20 +222,20 @@ private:
                 if (l.var <= 0.0f && l.count > 1) l.var = 1e-4f;
                 if (r.var <= 0.0f && r.count > 1) r.var = 1e-4f;
                 nodes.push_back(l); nodes.push_back(r);
-                if (l.var > 0.0f && l.count > 1) heap.push(li, l.var);
-                if (r.var > 0.0f && r.count > 1) heap.push(ri, r.var);
+                if (l.var > 0.0f && l.count > 1) { heap.push(li, l.var); uncached.emplace_back(l.var, li); }
+                if (r.var > 0.0f && r.count > 1) { heap.push(ri, r.var); uncached.emplace_back(r.var, ri); }
                 leaves++;
             }
             return false;
         }
         // every queued node whose split is unknown, largest variance first, at most as many as there are splits left to do.
         // The queue's top is among them (it is the maximum) -- otherwise the replay could not advance.
-        void pending_nodes(std::vector<std::pair<float, uint32_t>>& pending) const {
-            pending.clear();
-            for (uint32_t i = 1; i <= heap.size(); i++) {
-                const uint32_t ni = heap.entry_index(i);
-                if (nodes[ni].count > 1 && nodes[ni].cached < 0) pending.emplace_back(heap.entry_priority(i), ni);
-            }
+        void pending_nodes(std::vector<std::pair<float, uint32_t>>& pending) {
+            // (a node with an unknown split is never popped -- the replay stops at it -- so everything created and not yet handed to a round is still queued)
+            size_t keep = 0;
+            for (const auto& u : uncached) if (nodes[u.second].cached < 0) uncached[keep++] = u;
+            uncached.resize(keep);
+            pending = uncached;
             const size_t want = std::min<size_t>(pending.size(), (size_t)(max_leaves - leaves));
             if (want < pending.size()) {
                 std::nth_element(pending.begin(), pending.begin() + want, pending.end(), [](const std::pair<float, uint32_t>& a, const std::pair<float, uint32_t>& b) { return a.first > b.first || (a.first == b.first && a.second < b.second); });
