@@ -117,3 +117,30 @@ def test_reference_tool_with_the_uastc_hot_path_on_the_gpu_writes_the_cpu_tools_
     assert "encode_slices_to_uastc_4x4_ldr (MI355X)" in log, "the stock function ran, not integration/basisu_resident_uastc.cpp"
     assert "failed" not in log.lower(), log[-1500:]
     assert gpu.shape == cpu.shape and (gpu == cpu).all()
+
+
+@pytest.mark.skipif(not (have_ref_cli() and RESIDENT_TOOL.exists()), reason="oracle/_ref/basisu_hip_resident not present")
+@pytest.mark.parametrize("args,alpha", [(("-basis", "-etc1s", "-q", "128"), False), (("-basis", "-etc1s", "-q", "200", "-comp_level", "2"), False),
+                                        (("-basis", "-etc1s", "-q", "128", "-mipmap"), True)])
+def test_resident_frontend_through_the_frontend_pipeline_writes_the_same_file(args, alpha):
+    """BU_RESIDENT_LANES > 0: every basisu_frontend::compress() of the resident integration is submitted to one bu_frontend_pipeline per GPU and collected from it
+    (integration/basisu_resident_frontend.cpp) -- the backend, its call back into the frontend (level 2) and the slices of a mip chain then work on a frontend the
+    pipeline lent out. Same file as the direct form, which is the stock tool's."""
+    import os
+    img = synth(256, 192, 31)
+    if alpha:
+        img = img.copy(); img[..., 3] = (np.arange(256)[None, :] + np.arange(192)[:, None]).astype(np.uint8)
+    direct, _ = _run_any(RESIDENT_TOOL, img, "basis", *args)
+    old = os.environ.get("BU_RESIDENT_LANES")
+    os.environ["BU_RESIDENT_LANES"] = "3"
+    try:
+        piped, log = _run_any(RESIDENT_TOOL, img, "basis", *args)
+    finally:
+        if old is None:
+            os.environ.pop("BU_RESIDENT_LANES", None)
+        else:
+            os.environ["BU_RESIDENT_LANES"] = old
+    assert "failed" not in log.lower(), log[-1500:]
+    assert piped.shape == direct.shape and (piped == direct).all()
+    stock, _ = _run_any(ORACLE_DIR / "_ref" / "basisu", img, "basis", *args)
+    assert stock.shape == piped.shape and (stock == piped).all()
