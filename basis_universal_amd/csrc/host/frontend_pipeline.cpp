@@ -65,9 +65,11 @@ struct driver_state {
     std::thread th;
     std::thread::id tid;            // set by the thread itself before it runs its first task
     uint32_t first_lane = 0, n_lanes = 0, active = 0;
+    // counters of the thread itself (nobody else touches them) ...
     uint64_t n_switches = 0, n_idle_sleeps = 0;
     double busy_s = 0, idle_s = 0;
-    std::atomic<double> cpu_s{0};   // CLOCK_THREAD_CPUTIME_ID of the thread, refreshed once per finished job
+    // ... and the copy bu_frontend_pipeline_stats reads, refreshed under the pipeline's mutex whenever one of this thread's jobs finishes
+    struct snapshot { uint64_t switches = 0, naps = 0, yields = 0; double busy_s = 0, idle_s = 0, cpu_s = 0; } pub;
 };
 
 } // namespace
@@ -195,9 +197,12 @@ void drive(driver_state* d) {
                 l.j = nullptr;
                 {
                     timespec ts;
-                    if (clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts) == 0) d->cpu_s.store((double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec, std::memory_order_relaxed);
+                    const double cpu = clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts) == 0 ? (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec : 0.0;
+                    uint64_t yields = 0;
+                    for (uint32_t q = 0; q < d->n_lanes; q++) yields += p->lanes[d->first_lane + q].yields;
                     std::lock_guard<std::mutex> g(p->m);
                     j->done = true; d->active--; p->n_done++;
+                    d->pub = driver_state::snapshot{d->n_switches, d->n_idle_sleeps, yields, d->busy_s, d->idle_s, cpu};
                 }
                 p->cv_done.notify_all();
                 finished_any = true;
@@ -232,6 +237,8 @@ extern "C" {
 
 #define BU_PIPE_CATCH(fail_value) catch (const std::exception& e_) { bu_last_exception_text = e_.what(); return fail_value; } catch (...) { bu_last_exception_text = "unknown exception"; return fail_value; }
 
+void bu_frontend_pipeline_destroy(bu_frontend_pipeline* p);
+
 static bu_frontend_pipeline* pipeline_new(int device, uint32_t lanes, bool need_device, uint32_t n_drivers = 1) {
     if (lanes < 1 || lanes > 16) { bu_last_exception_text = "bu_frontend_pipeline_create: 1..16 lanes"; return nullptr; }
     if (n_drivers < 1 || n_drivers > lanes) { bu_last_exception_text = "bu_frontend_pipeline_create: 1..lanes driver threads"; return nullptr; }
@@ -261,7 +268,12 @@ static bu_frontend_pipeline* pipeline_new(int device, uint32_t lanes, bool need_
         for (uint32_t i = 0; i < d.n_lanes; i++) p->lanes[at + i].drv = &d;
         at += d.n_lanes;
     }
-    for (auto& d : p->drivers) d.th = std::thread(drive, &d);
+    try {
+        for (auto& d : p->drivers) d.th = std::thread(drive, &d);
+    } catch (...) {   // a thread could not be started: stop the ones that were, give everything back
+        bu_frontend_pipeline_destroy(p);
+        throw;
+    }
     return p;
 }
 
@@ -324,7 +336,8 @@ bu_frontend* bu_frontend_pipeline_wait(bu_frontend_pipeline* p, uint64_t ticket)
     auto it = p->jobs.find(ticket);
     if (it == p->jobs.end()) { p->error = "bu_frontend_pipeline_wait: unknown ticket"; return nullptr; }
     job* j = it->second;
-    if (j->handed_out) { p->error = "bu_frontend_pipeline_wait: this ticket's frontend has been handed out already"; return nullptr; }
+    if (j->handed_out) { p->error = "bu_frontend_pipeline_wait: this ticket has a waiter or has been collected already"; return nullptr; }
+    j->handed_out = true;   // the ticket is this caller's from here on (a second wait on it is refused instead of sharing -- or outliving -- the job)
     p->cv_done.wait(g, [&] { return j->done; });
     if (!j->ok) {
         p->error = "job " + std::to_string(ticket) + ": " + j->error;
@@ -333,7 +346,6 @@ bu_frontend* bu_frontend_pipeline_wait(bu_frontend_pipeline* p, uint64_t ticket)
         free_job(j);
         return nullptr;
     }
-    j->handed_out = true;
     p->by_frontend[j->fe] = j;
     return j->fe;
 } BU_PIPE_CATCH(nullptr)
@@ -380,15 +392,20 @@ void bu_frontend_pipeline_destroy(bu_frontend_pipeline* p) try {
     delete p;
 } catch (...) {}
 
-const char* bu_frontend_pipeline_error(const bu_frontend_pipeline* p) { return p ? p->error.c_str() : "null pipeline"; }
+const char* bu_frontend_pipeline_error(const bu_frontend_pipeline* cp) {   // a copy per calling thread: other threads' failures do not move it under the caller
+    if (!cp) return "null pipeline";
+    static thread_local std::string mine;
+    bu_frontend_pipeline* p = const_cast<bu_frontend_pipeline*>(cp);
+    std::lock_guard<std::mutex> g(p->m);
+    mine = p->error;
+    return mine.c_str();
+}
 
 uint32_t bu_frontend_pipeline_stats(bu_frontend_pipeline* p, double* out, uint32_t cap) {
     if (!p) return 0;
     std::lock_guard<std::mutex> g(p->m);
-    uint64_t yields = 0;
-    for (auto& l : p->lanes) yields += l.yields;
-    uint64_t switches = 0, naps = 0; double busy = 0, idle = 0, cpu = 0;
-    for (auto& d : p->drivers) { switches += d.n_switches; naps += d.n_idle_sleeps; busy += d.busy_s; idle += d.idle_s; cpu += d.cpu_s.load(); }
+    uint64_t yields = 0, switches = 0, naps = 0; double busy = 0, idle = 0, cpu = 0;
+    for (auto& d : p->drivers) { switches += d.pub.switches; naps += d.pub.naps; yields += d.pub.yields; busy += d.pub.busy_s; idle += d.pub.idle_s; cpu += d.pub.cpu_s; }
     const double v[7] = {(double)p->n_done, (double)switches, (double)yields, (double)naps, busy, idle, cpu};
     for (uint32_t i = 0; i < 7 && i < cap; i++) out[i] = v[i];
     return 7;
