@@ -57,17 +57,18 @@ struct pool {
         return c < kClasses ? c : -1;
     }
 
-    void table_put(uintptr_t p, size_t mapped, int cls) {
+    bool table_put(uintptr_t p, size_t mapped, int cls) {   // false: the table could not grow -- the caller must not hand the block out (delete would not know it)
         if ((table_used + 1) * 2 > table_cap) {
             const size_t ncap = table_cap ? table_cap * 2 : 1024;
             slot* nt = static_cast<slot*>(std::calloc(ncap, sizeof(slot)));
-            if (!nt) return;   // the block will be treated as foreign on delete and unmapped by size lookup failure -> leak rather than crash; practically unreachable
+            if (!nt) return false;
             for (size_t i = 0; i < table_cap; i++) if (table[i].p) { size_t h = (table[i].p >> 12) * 0x9E3779B97F4A7C15ull % ncap; while (nt[h].p) h = (h + 1) % ncap; nt[h] = table[i]; }
             std::free(table); table = nt; table_cap = ncap;
         }
         size_t h = (p >> 12) * 0x9E3779B97F4A7C15ull % table_cap;
         while (table[h].p) h = (h + 1) % table_cap;
         table[h] = slot{p, mapped, cls}; table_used++;
+        return true;
     }
     size_t table_take(uintptr_t p, int* cls) {   // removes p, returns its mapped size (0 = not ours)
         if (!table_cap) return 0;
@@ -97,8 +98,8 @@ struct pool {
         {
             std::lock_guard<std::mutex> g(m);
             if (free_block* b = free_list[c]) {
+                if (!table_put(reinterpret_cast<uintptr_t>(b), b->mapped, c)) return nullptr;   // (stays cached; the caller falls back to malloc)
                 free_list[c] = b->next; cached_bytes -= b->mapped; n_reuses++;
-                table_put(reinterpret_cast<uintptr_t>(b), b->mapped, c);
                 return b;
             }
         }
@@ -107,8 +108,8 @@ struct pool {
         if (p == MAP_FAILED) return nullptr;
         (void)madvise(p, mapped, MADV_HUGEPAGE);
         std::lock_guard<std::mutex> g(m);
+        if (!table_put(reinterpret_cast<uintptr_t>(p), mapped, c)) { munmap(p, mapped); return nullptr; }
         n_maps++;
-        table_put(reinterpret_cast<uintptr_t>(p), mapped, c);
         return p;
     }
 
