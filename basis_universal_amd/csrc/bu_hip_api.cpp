@@ -521,7 +521,7 @@ int bu_hip_memcpy_d2h(bu_hip_context* ctx, void* h, const void* d, size_t bytes)
         }
         return 1;
     }
-    if (bytes) BU_TRY(ctx, hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    if (bytes) BU_TRY(ctx, d2h_pageable(ctx, h, d, bytes));   // (under a wait hook the stream is drained cooperatively first: the runtime would block in the copy until it has)
     BU_TRY(ctx, stream_wait(ctx, ctx->stream));
     return 1;
 }
