@@ -51,6 +51,44 @@ def uniform_random(w, h, seed=42):
     return out
 
 
+def endpoint_cube(w, h, seed=7):
+    """The worst case for the ENDPOINT codebook builder: block b is drawn from the four colours of ETC1S endpoint (colour5, intensity table) number perm[b mod 2^18] with
+    random selectors, so the per-block fit finds (nearly) every one of the 32^3 x 8 endpoints and the builder gets as many distinct training vectors as an image can give it
+    (236,235 is the ceiling, tests/test_host_logic.py::test_endpoint_codebook_can_never_reach_the_threaded_gate; 14,177 for uniform noise, 35,502 for the synthetic image)."""
+    rng = np.random.default_rng(seed)
+    nb = (h // 4) * (w // 4)
+    code = rng.permutation(1 << 18)[np.arange(nb) % (1 << 18)]
+    table = np.array([[-8, -2, 2, 8], [-17, -5, 5, 17], [-29, -9, 9, 29], [-42, -13, 13, 42], [-60, -18, 18, 60], [-80, -24, 24, 80], [-106, -33, 33, 106], [-183, -47, 47, 183]], np.int32)
+    c5 = np.stack([(code >> 10) & 31, (code >> 5) & 31, code & 31], -1).astype(np.int32)
+    c8 = (c5 << 3) | (c5 >> 2)
+    sel = rng.integers(0, 4, (nb, 16))
+    d = table[(code >> 15) & 7][np.arange(nb)[:, None], sel]                       # (nb, 16)
+    px = np.clip(c8[:, None, :] + d[:, :, None], 0, 255).astype(np.uint8)          # (nb, 16, 3)
+    out = np.empty((h, w, 4), np.uint8)
+    out[..., 3] = 255
+    out[..., :3] = px.reshape(h // 4, w // 4, 4, 4, 3).transpose(0, 2, 1, 3, 4).reshape(h, w, 3)
+    return out
+
+
+def kodak_mosaic(w=4096, h=4096):
+    """The 24 Kodak images of the reference's own test set (tests/golden/kodak24.npz: the pixels of test_files/kodim01-24.png) tiled into one w x h RGBA image:
+    photographic statistics at BASELINE.json's full size. 768 x 512 slots, portrait images transposed; slot i holds image i mod 24, mirrored top to bottom from
+    the second time round (so no block repeats); cropped to w x h."""
+    z = np.load(pathlib.Path(__file__).parent / "golden" / "kodak24.npz")
+    imgs = [z[f"k{i:02d}"] for i in range(1, 25)]
+    imgs = [im if im.shape[0] == 512 else np.ascontiguousarray(im.transpose(1, 0, 2)) for im in imgs]
+    cols, rows = (w + 767) // 768, (h + 511) // 512
+    out = np.empty((rows * 512, cols * 768, 4), np.uint8)
+    out[..., 3] = 255
+    for i in range(rows * cols):
+        im = imgs[i % 24]
+        if (i // 24) & 1:
+            im = im[::-1]
+        r, c = divmod(i, cols)
+        out[r * 512:(r + 1) * 512, c * 768:(c + 1) * 768, :3] = im
+    return np.ascontiguousarray(out[:h, :w])
+
+
 def to_pixel_blocks(img):
     """(H, W, 4) u8 -> (n_blocks, 4, 4, 4) u8 in block-raster order, [y][x] inside the block (comp.cpp:3207-3268).
     Edges are clamped like image::extract_block_clamped."""

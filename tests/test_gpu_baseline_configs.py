@@ -16,7 +16,7 @@ import pathlib
 import numpy as np
 import pytest
 
-from helpers import synth, to_pixel_blocks
+from helpers import synth, to_pixel_blocks, uniform_random, kodak_mosaic, endpoint_cube
 import test_gpu_etc1s_frontend as T
 
 pytestmark = pytest.mark.gpu
@@ -82,6 +82,32 @@ def test_other_levels_in_both_thread_configurations(hip_ctx, case, single):
     for gg in (g, g1):
         fe, be = _frontend_and_backend(hip_ctx, synth(3072, 3072, 4321), gg)
         be.close(); fe.close()
+
+
+OTHER_DISTRIBUTIONS = {
+    # SURVEY 8d's second distribution at FULL size -- uniform-random RGB, seed 42: one distinct selector vector per block (1,048,431 / ~4.19 M: the largest trees, the
+    # largest T-way partitions and refine lists the builders can meet), photographic statistics at full size (the reference's 24 Kodak test images as one mosaic), and the
+    # worst case for the ENDPOINT builder (nearly every ETC1S endpoint occurs: ~2 x 10^5 distinct 6-float vectors in ONE tree -- the ceiling is 236,235, below the
+    # reference's 262,144 gate, tests/test_host_logic.py -- so the 6-float many-workgroup passes meet nodes of 10^5 members in a real run)
+    "noise4096_q128": lambda: uniform_random(4096, 4096, 42),
+    "kodak4096_q128": lambda: kodak_mosaic(4096, 4096),
+    "cube4096_q128": lambda: endpoint_cube(4096, 4096, 7),
+    "noise8192_q255": lambda: uniform_random(8192, 8192, 42),
+}
+
+
+@pytest.mark.parametrize("threads", [1, 8])
+@pytest.mark.parametrize("name", sorted(OTHER_DISTRIBUTIONS))
+def test_other_distributions_at_full_size_in_both_thread_configurations(hip_ctx, name, threads):
+    case = name if threads == 1 else f"{name}_t{threads}"
+    if case not in GOLDEN:
+        pytest.skip(f"no golden for {case} (tools/gen_golden_big.py {case})")
+    g = GOLDEN[case]
+    assert g.get("threads", 1) == threads
+    if threads > 1:
+        assert g["distinct_vectors"]["selector"] >= 262144 and g["frontend_digests"] != GOLDEN[name]["frontend_digests"]   # past the gate: a different codebook
+    fe, be = _frontend_and_backend(hip_ctx, OTHER_DISTRIBUTIONS[name](), g)
+    be.close(); fe.close()
 
 
 def test_config0_kodim03_q128_file_equals_the_reference_tools(hip_ctx):

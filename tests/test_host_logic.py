@@ -128,6 +128,26 @@ def test_host_tsvq_partitioned_matches_reference(dim, n, k, p, kind, threads):
         assert not ((a0 == a2).all() and (b0 == b2).all())
 
 
+def test_endpoint_codebook_can_never_reach_the_threaded_gate():
+    """The reference partitions a codebook build over its threads only from 262,144 DISTINCT training vectors up (enc.h:2316: `unique_vecs.size() < 65536*4 ? 1 : max_threads`).
+    An endpoint training vector is the low / high colour of an ETC1S block (frontend.cpp:825-866, etc.h:543-565) -- a function of (colour5, intensity table) alone, 32^3 x 8 =
+    262,144 combinations, and clamping at 0 / 255 makes many of them coincide: over ALL combinations the oracle's (reference-pinned) training vectors take 236,235 distinct
+    values. So whatever the image, the endpoint builder is single-tree in both of the reference's thread configurations; only the selector builder (up to one distinct
+    vector per block) ever takes the T-way path. 236,235 is also the largest node the 6-float many-workgroup passes can meet (tools/wide6_stress.py goes to 240,000)."""
+    from helpers import oracle, ptr, f32p
+    O = oracle()
+    c = np.arange(32, dtype=np.uint8)
+    r, g, b, t = np.meshgrid(c, c, c, np.arange(8, dtype=np.uint8), indexing="ij")
+    blk = np.zeros((r.size, 8), np.uint8)
+    blk[:, 0] = r.ravel() << 3; blk[:, 1] = g.ravel() << 3; blk[:, 2] = b.ravel() << 3          # base5, delta3 = 0
+    blk[:, 3] = (t.ravel() << 5) | (t.ravel() << 2) | 2                                             # both intensity tables, differential bit
+    v6 = np.zeros((blk.shape[0], 6), np.float32)
+    O.orc_endpoint_training_vectors(ptr(blk), blk.shape[0], ptr(v6, f32p))
+    distinct = np.unique(v6.view(np.uint32), axis=0).shape[0]
+    assert blk.shape[0] == 262144 and distinct == 236235
+    assert distinct < 65536 * 4      # = bu::kThreadedCodebookMinUnique (csrc/host/tsvq.h), the reference's gate
+
+
 def test_reference_max_threads():
     """frontend.cpp:873-876 / 2195-2198"""
     from basis_universal_amd.etc1s import reference_max_threads as t

@@ -58,6 +58,16 @@ CASES["synth3072_q200_l2_t8"] = (lambda: helpers.synth(3072, 3072, 4321), 200, 8
 CASES["synth3072_q90_l4_t4"] = (lambda: helpers.synth(3072, 3072, 4321), 90, 4, 4)
 CASES["synth3072_q200_l2"] = (lambda: helpers.synth(3072, 3072, 4321), 200, 1, 2)   # (single-threaded: what the two above must differ from)
 CASES["synth3072_q90_l4"] = (lambda: helpers.synth(3072, 3072, 4321), 90, 1, 4)
+# SURVEY 8d's second distribution at full size -- uniform-random RGB, seed 42: the worst case for every clustering stage (1,048,576 / 4,194,304 distinct selector vectors,
+# refine lists past 65,535 entries) -- and photographic statistics at full size (the reference's 24 Kodak test images as one 4096^2 mosaic), single-threaded and T = 8
+for _t in (1, 8):
+    _s = "" if _t == 1 else f"_t{_t}"
+    CASES[f"noise4096_q128{_s}"] = (lambda: helpers.uniform_random(4096, 4096, 42), 128, _t)
+    CASES[f"kodak4096_q128{_s}"] = (lambda: helpers.kodak_mosaic(4096, 4096), 128, _t)
+    CASES[f"noise8192_q255{_s}"] = (lambda: helpers.uniform_random(8192, 8192, 42), 255, _t)
+    # ... and the worst case for the ENDPOINT builder: (nearly) every ETC1S endpoint occurs, ~2 x 10^5 distinct 6-float vectors in one tree (the ceiling is 236,235 < the
+    # reference's 262,144 gate, so this tree is never partitioned: tests/test_host_logic.py)
+    CASES[f"cube4096_q128{_s}"] = (lambda: helpers.endpoint_cube(4096, 4096, 7), 128, _t)
 
 
 def main():
@@ -83,6 +93,7 @@ def main():
             "max_endpoint_clusters": max_ep, "max_selector_clusters": max_sel,
             "final_endpoint_clusters": int(st["endpoint_clusters"].view(np.uint32)[0]),
             "final_selector_clusters": int(st["selector_cluster_block_indices"].view(np.uint32)[0]),
+            "distinct_vectors": distinct_counts(st),
             "frontend_digests": T._digest(st),
             "backend": {"slices": [[0, nbx, nby]], "thresholds": list(helpers_backend_thresholds(quality)), "compressed_bytes": int(total),
                         "digests": {k: hashlib.sha256(np.ascontiguousarray(fe.backend_get(k)).tobytes()).hexdigest() for k in PAYLOAD}},
@@ -91,6 +102,14 @@ def main():
         fe.close()
         print(case, out[case]["final_endpoint_clusters"], out[case]["final_selector_clusters"], total, out[case]["reference_seconds"], flush=True)
         OUT.write_text(json.dumps(out, indent=1, sort_keys=True) + "\n")
+
+
+def distinct_counts(st):
+    """how many distinct training vectors each codebook builder saw (what decides the reference's T-way partition, enc.h:2316): endpoint side = distinct
+    (colour5, inten) of the per-block fit, selector side = distinct 16-selector patterns of the initial packed texture"""
+    e = np.ascontiguousarray(st["etc1_blocks"]).reshape(-1, 8)
+    o = np.ascontiguousarray(st["orig_encoded_blocks"]).reshape(-1, 8)
+    return {"endpoint": int(np.unique(e[:, :4].copy().view(np.uint32)).size), "selector": int(np.unique(o[:, 4:].copy().view(np.uint32)).size)}
 
 
 def helpers_backend_thresholds(quality):
