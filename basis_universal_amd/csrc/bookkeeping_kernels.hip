@@ -19,6 +19,7 @@
 
 #include "bookkeeping_kernels.h"
 #include "sort_pairs.h"
+#include "tsvq_bufs.h"
 
 namespace bu {
 
@@ -97,7 +98,7 @@ __global__ void __launch_bounds__(256) k_membership(const uint8_t* __restrict__ 
 __global__ void __launch_bounds__(256) k_scatter_spans(const uint32_t* __restrict__ perm0, const uint32_t* __restrict__ perm1, const bk_span* __restrict__ spans,
                                                        uint32_t* __restrict__ out) {
     const bk_span s = spans[blockIdx.x];
-    const uint32_t* p = (s.buf ? perm1 : perm0) + s.start;
+    const uint32_t* p = tsvq_list(perm0, perm1, s.buf) + s.start;
     for (uint32_t i = threadIdx.x; i < s.count; i += 256) out[p[i]] = s.value;
 }
 
@@ -110,7 +111,7 @@ __global__ void __launch_bounds__(256) k_finish_spans(const uint32_t* __restrict
                                                       uint32_t* __restrict__ first_pos, uint32_t* __restrict__ sizes) {
     __shared__ uint32_t s_wave[4];
     const bk_span s = spans[blockIdx.x];
-    const uint32_t* p = (s.buf ? perm1 : perm0) + s.start;
+    const uint32_t* p = tsvq_list(perm0, perm1, s.buf) + s.start;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t run = 0;
     for (uint32_t base = 0; base < s.count; base += 256) {
@@ -147,12 +148,12 @@ __global__ void __launch_bounds__(256) k_endpoint_rows(const uint64_t* __restric
 }
 
 // multi-GPU TSVQ: the child member lists of a batch of split nodes, laid end to end in batch order (staging), to and from the member buffers.
-// A node's children live in the OTHER buffer than the node, at the node's own [start, start + count). dir 0: buffers -> staging for the nodes
+// A node's children live in the NEXT buffer after the node's (tsvq_bufs.h), at the node's own [start, start + count). dir 0: buffers -> staging for the nodes
 // flagged in `take` (zero for the others), dir 1: staging -> buffers for the flagged nodes.
 __global__ void __launch_bounds__(256) k_exchange_children(uint32_t* __restrict__ perm0, uint32_t* __restrict__ perm1, const bk_span* __restrict__ nodes /* value = offset in staging */,
                                                            const uint8_t* __restrict__ take, uint32_t* __restrict__ staging, int dir) {
     const bk_span nd = nodes[blockIdx.x];
-    uint32_t* child = (nd.buf ? perm0 : perm1) + nd.start;
+    uint32_t* child = tsvq_child_list(perm0, perm1, nd.buf) + nd.start;
     uint32_t* st = staging + nd.value;
     const bool mine = take[blockIdx.x] != 0;
     for (uint32_t i = threadIdx.x; i < nd.count; i += 256) {

@@ -20,6 +20,7 @@
 #include "../../include/basisu_hip.h"
 #include "etc1s_kernels.h"
 #include "tsvq_kernels.h"
+#include "tsvq_bufs.h"
 #include "uastc_kernels.h"
 #include "mipmap_kernels.h"
 #include "unique_kernels.h"
@@ -385,13 +386,14 @@ static const bu_hip_tuning& default_tuning() {
         bu_hip_tuning d;
         std::memset(&d, 0, sizeof(d));
         d.struct_bytes = (uint32_t)sizeof(d);
-        d.tsvq_wide_min = 8192; d.tsvq_wide6_min = 8192; d.tsvq_wide_cov_min = 98304; d.tsvq_windows = 0; d.tsvq_dense_min = 257; d.tsvq_zero_copy = 1;
+        d.tsvq_wide_min = 8192; d.tsvq_wide6_min = 8192; d.tsvq_wide_cov_min = 98304; d.tsvq_windows = 0; d.tsvq_dense_min = 257; d.tsvq_zero_copy = 1; d.tsvq_deep_levels = 0;
         auto num = [](const char* name, long lo, long hi, uint32_t* out) { if (const char* e = std::getenv(name)) { const long v = std::atol(e); if (v >= lo && v <= hi) *out = (uint32_t)v; } };
         num("BU_TSVQ_WIDE_MIN", 512, 1l << 30, &d.tsvq_wide_min);
         num("BU_TSVQ_WIDE6_MIN", 512, 1l << 30, &d.tsvq_wide6_min);
         num("BU_TSVQ_WIDE_COV_MIN", 0, 1l << 30, &d.tsvq_wide_cov_min);
         num("BU_TSVQ_DENSE_MIN", 0, 1l << 30, &d.tsvq_dense_min);
         num("BU_TSVQ_ZEROCOPY", 0, 1, &d.tsvq_zero_copy);
+        num("BU_TSVQ_DEEP", 0, (long)bu::TSVQ_MAX_DEEP_LEVELS, &d.tsvq_deep_levels);
         if (const char* e = std::getenv("BU_TSVQ_WIDE")) if (std::atoi(e) == 0) d.tsvq_wide_min = d.tsvq_wide6_min = 0;
         if (const char* e = std::getenv("BU_TSVQ_WIDE6")) if (std::atoi(e) == 0) d.tsvq_wide6_min = 0;
         if (const char* e = std::getenv("BU_TSVQ_WINDOWS")) d.tsvq_windows = e[0] == '0' ? 2u : 1u;
@@ -417,8 +419,8 @@ int bu_hip_set_tuning(bu_hip_context* ctx, const bu_hip_tuning* t) {
     bu_hip_tuning n = default_tuning();   // fields a caller's older header does not have keep their defaults
     std::memcpy(&n, t, std::min<size_t>(t->struct_bytes, sizeof(n)));
     n.struct_bytes = (uint32_t)sizeof(n);
-    if ((n.tsvq_wide_min && n.tsvq_wide_min < 512) || (n.tsvq_wide6_min && n.tsvq_wide6_min < 512) || n.tsvq_windows > 2 || n.tsvq_poll > 2) {
-        set_error(ctx, "bu_hip_set_tuning: value out of range (many-workgroup thresholds are 0 or >= 512, windows / poll 0..2)");
+    if ((n.tsvq_wide_min && n.tsvq_wide_min < 512) || (n.tsvq_wide6_min && n.tsvq_wide6_min < 512) || n.tsvq_windows > 2 || n.tsvq_poll > 2 || n.tsvq_deep_levels > bu::TSVQ_MAX_DEEP_LEVELS) {
+        set_error(ctx, "bu_hip_set_tuning: value out of range (many-workgroup thresholds are 0 or >= 512, windows / poll 0..2, deep levels 0..2)");
         return 0;
     }
     ctx->tuning = n;
@@ -936,9 +938,10 @@ struct bu_tsvq {
     bool packed = false;
     void* rows = nullptr;       // float[n][dim], or uint32[n] when packed
     uint64_t* w64 = nullptr;
-    uint32_t* perm[2] = {nullptr, nullptr};
+    uint32_t* perm[2] = {nullptr, nullptr};   // perm[0]: ONE block of TSVQ_BUFS buffers of n indices each, perm[1] = perm[0] + n (tsvq_bufs.h: the pair gives every kernel base and stride)
     uint8_t* side = nullptr;
     arena nodes, outs;
+    arena deep_nodes;           // deep rounds: the node records of generations 1.. (made on the device by k_tsvq_children)
     // the knobs below are copies of the context's bu_hip_tuning at creation (basisu_hip.h): one tree never changes paths half way
     bool force_chained = false; // tsvq_chained_only: never use the exact (integer-reduced) kernel variants (tests compare both)
     // Nodes with at least wide_min members go through the many-workgroup path (tsvq_wide_kernels.hip for packed rows, tsvq_wide6_kernels.hip for 6-float rows).
@@ -982,8 +985,8 @@ void bu_hip_tsvq_destroy(bu_hip_context* ctx, bu_tsvq* q) {
     if (!ctx || !q) return;
     device_guard g(ctx->device);
     (void)stream_wait(ctx, ctx->stream);
-    for (void* p : {q->rows, (void*)q->w64, (void*)q->perm[0], (void*)q->perm[1], (void*)q->side, q->nodes.p, q->outs.p, q->xchg, q->wide_ws, q->wide_packed, (void*)q->wide_nodes, q->wide_ctrl_raw}) if (p) bu_hip_free(ctx, p);
-    q->nodes.p = nullptr; q->outs.p = nullptr;
+    for (void* p : {q->rows, (void*)q->w64, (void*)q->perm[0], (void*)q->side, q->nodes.p, q->outs.p, q->deep_nodes.p, q->xchg, q->wide_ws, q->wide_packed, (void*)q->wide_nodes, q->wide_ctrl_raw}) if (p) bu_hip_free(ctx, p);
+    q->nodes.p = nullptr; q->outs.p = nullptr; q->deep_nodes.p = nullptr;
     if (q->pinned) {  // hand the pinned staging buffer back to the context (keep the larger one)
         if (q->pinned_cap > ctx->tsvq_pinned_cap) { if (ctx->tsvq_pinned) (void)hipHostFree(ctx->tsvq_pinned); ctx->tsvq_pinned = q->pinned; ctx->tsvq_pinned_cap = q->pinned_cap; }
         else (void)hipHostFree(q->pinned);
@@ -1010,7 +1013,7 @@ static bu_tsvq* tsvq_create_common(bu_hip_context* ctx, uint32_t dim, bool packe
     // a codebook of cMaxSelectorClusters can ask for, so they never grow
     const size_t rec_cap = (size_t)16384 * std::max(sizeof(bu_tsvq_node), sizeof(bu_tsvq_split));
     q->rows = bu_hip_malloc(ctx, (size_t)n * row_bytes); q->w64 = (uint64_t*)bu_hip_malloc(ctx, (size_t)n * 8);
-    q->perm[0] = (uint32_t*)bu_hip_malloc(ctx, (size_t)n * 4); q->perm[1] = (uint32_t*)bu_hip_malloc(ctx, (size_t)n * 4);
+    q->perm[0] = (uint32_t*)bu_hip_malloc(ctx, (size_t)n * 4 * bu::TSVQ_BUFS); q->perm[1] = q->perm[0] ? q->perm[0] + n : nullptr;
     q->side = (uint8_t*)bu_hip_malloc(ctx, n);
     q->nodes.p = bu_hip_malloc(ctx, rec_cap); q->outs.p = bu_hip_malloc(ctx, rec_cap);
     if (!q->rows || !q->w64 || !q->perm[0] || !q->perm[1] || !q->side || !q->nodes.p || !q->outs.p) return fail("allocation");
@@ -1144,9 +1147,15 @@ int bu_hip_k_unique_selector_vectors(bu_hip_context* ctx, const void* d_enc_bloc
     return 1;
 }
 
-int bu_hip_tsvq_split(bu_hip_context* ctx, bu_tsvq* q, const bu_tsvq_node* h_nodes, uint32_t n_nodes, bu_tsvq_split* h_out) {
+// One round of splits. levels > 0 (deep round, zero-copy rounds only): the one-workgroup nodes' children, grandchildren, ... are split in the same round trip --
+// every generation's node records are made on the device from the results of the one before (k_tsvq_children), so `levels` more launches follow the batch's own
+// without the host. h_deep: generation g (1..levels) of batch node i, path p (the sides taken, first step in the top bit) at h_deep[n_nodes * (2^g - 2) + i * 2^g + p];
+// ok == 3 = not attempted (the parent's split failed or went through the many-workgroup passes, one member, variance below the floor in h_nodes[i].pad).
+static int tsvq_split_impl(bu_hip_context* ctx, bu_tsvq* q, const bu_tsvq_node* h_nodes, uint32_t n_nodes, bu_tsvq_split* h_out, uint32_t levels, bu_tsvq_split* h_deep) {
     if (!ctx || !q) return 0;
     if (!n_nodes) return 1;
+    if (levels > bu::TSVQ_MAX_DEEP_LEVELS) levels = bu::TSVQ_MAX_DEEP_LEVELS;   // tsvq_bufs.h: a write must not reach a list that may still become a leaf
+    const uint32_t h_deep_levels = h_deep ? levels : 0;   // what the caller's array is laid out for (the round may attempt fewer)
     device_guard g(ctx->device);
     const bool round_stats = q->dbg_rounds;   // development aid: one line per round on stderr
     const auto round_t0 = std::chrono::steady_clock::now();
@@ -1171,8 +1180,19 @@ int bu_hip_tsvq_split(bu_hip_context* ctx, bu_tsvq* q, const bu_tsvq_node* h_nod
     const size_t wide_at = (in_bytes + 63) & ~(size_t)63;
     const bool zero_copy = q->zero_copy;
     // staged: the result records come back over the node records; zero-copy: the kernels write them while others still read their nodes, so they get their own place
-    const size_t out_at = zero_copy ? ((wide_at + wide_bytes + 63) & ~(size_t)63) : 0, flag_at = (out_at + out_bytes + 63) & ~(size_t)63;
+    if (!zero_copy || !n_narrow || q->dbg_serial || !h_deep) levels = 0;
+    while (levels && (size_t)n_narrow * ((2u << levels) - 2u) * sizeof(bu_tsvq_split) > ((size_t)64 << 20)) levels--;   // (never in practice: 64 MiB of records)
+    const size_t deep_recs = (size_t)n_narrow * ((2u << levels) - 2u);   // 2 + 4 + ... + 2^levels per one-workgroup node
+    const size_t out_at = zero_copy ? ((wide_at + wide_bytes + 63) & ~(size_t)63) : 0, deep_at = out_at + out_bytes,
+                 flag_at = (deep_at + deep_recs * sizeof(bu_tsvq_split) + 63) & ~(size_t)63;
     BU_TRY(ctx, q->reserve_pinned(std::max(wide_at + wide_bytes, flag_at + 128)));   // the round's flag
+    if (deep_recs * sizeof(bu_tsvq_node) > q->deep_nodes.cap) {
+        if (q->deep_nodes.p) { BU_TRY(ctx, stream_wait(ctx, ctx->stream)); bu_hip_free(ctx, q->deep_nodes.p); q->deep_nodes.p = nullptr; q->deep_nodes.cap = 0; }
+        const size_t want = deep_recs * sizeof(bu_tsvq_node) * 2;
+        q->deep_nodes.p = bu_hip_malloc(ctx, want);
+        if (!q->deep_nodes.p) { set_error(ctx, "tsvq_split: allocation of %zu bytes of node records failed", want); return 0; }
+        q->deep_nodes.cap = want;
+    }
     char* d_pinned = nullptr;   // the page-locked buffer as the device addresses it
     if (zero_copy) BU_TRY(ctx, hipHostGetDevicePointer(reinterpret_cast<void**>(&d_pinned), q->pinned, 0));
     volatile uint32_t* round_flag = reinterpret_cast<volatile uint32_t*>(static_cast<char*>(q->pinned) + flag_at);
@@ -1200,6 +1220,25 @@ int bu_hip_tsvq_split(bu_hip_context* ctx, bu_tsvq* q, const bu_tsvq_node* h_nod
     // stream, under the many small launches of the wide path. (Not while kernels are being timed one by one.)
     bool narrow_on_side = n_wide && n_narrow && ctx->profiling != 1 && !q->dbg_serial;   // (not while the rounds' kernels are being timed one region after the other)
     if (narrow_on_side && !ensure_side_stream(ctx)) narrow_on_side = false;
+    // deep round: generation g's records from generation g - 1's results, then its splits, on the stream the batch's own one-workgroup launch went to
+    auto deep_generations = [&](hipStream_t st) -> bool {
+        const bu::tsvq_node_in* parents = d_nodes_in;
+        const bu::tsvq_split_out* parent_outs = d_outs;
+        bu::tsvq_node_in* children = static_cast<bu::tsvq_node_in*>(q->deep_nodes.p);
+        bu::tsvq_split_out* child_outs = reinterpret_cast<bu::tsvq_split_out*>(d_pinned + deep_at);
+        uint32_t n_parents = n_narrow;
+        for (uint32_t gen = 1; gen <= levels; gen++) {
+            if (bu::launch_tsvq_children(st, parents, parent_outs, n_parents, children, child_outs) != hipSuccess ||
+                bu::launch_tsvq_split(st, (int)q->dim, q->packed, exact, q->rows, q->w64, q->perm[0], q->perm[1], q->side, children, 2 * n_parents, child_outs, q->dense_min) != hipSuccess) {
+                set_error(ctx, "tsvq_split: deep generation %u: %s", gen, hipGetErrorString(hipGetLastError()));
+                return false;
+            }
+            parents = children; parent_outs = child_outs;
+            children += 2 * (size_t)n_parents; child_outs += 2 * (size_t)n_parents;
+            n_parents *= 2;
+        }
+        return true;
+    };
     // From the fork on, every early return must wait for the side stream first: the caller's guard destroys q (its buffers go back to the
     // pool without a synchronisation) while the one-workgroup kernel may still be running on them.
     struct side_joiner { hipStream_t s; bool armed; ~side_joiner() { if (armed) (void)hipStreamSynchronize(s); } } side_join_guard{ctx->side_stream, false};
@@ -1208,6 +1247,7 @@ int bu_hip_tsvq_split(bu_hip_context* ctx, bu_tsvq* q, const bu_tsvq_node* h_nod
         BU_TRY(ctx, hipEventRecord(ctx->side_fork, ctx->stream));
         BU_TRY(ctx, hipStreamWaitEvent(ctx->side_stream, ctx->side_fork, 0));
         BU_TRY(ctx, bu::launch_tsvq_split(ctx->side_stream, (int)q->dim, q->packed, exact, q->rows, q->w64, q->perm[0], q->perm[1], q->side, d_nodes_in, n_narrow, d_outs, q->dense_min));
+        if (levels && !deep_generations(ctx->side_stream)) return 0;
         BU_TRY(ctx, hipEventRecord(ctx->side_join, ctx->side_stream));
     }
     if (n_wide) {
@@ -1241,6 +1281,7 @@ int bu_hip_tsvq_split(bu_hip_context* ctx, bu_tsvq* q, const bu_tsvq_node* h_nod
     else if (n_narrow) {
         prof_scope ps(ctx, q->packed ? "tsvq_split_packed16" : "tsvq_split_float6");
         BU_TRY(ctx, bu::launch_tsvq_split(ctx->stream, (int)q->dim, q->packed, exact, q->rows, q->w64, q->perm[0], q->perm[1], q->side, d_nodes_in, n_narrow, d_outs, q->dense_min));
+        if (levels && !deep_generations(ctx->stream)) return 0;
     }
     if (zero_copy) {
         const uint32_t seq = ++q->round_seq ? q->round_seq : ++q->round_seq;   // never 0
@@ -1286,6 +1327,23 @@ int bu_hip_tsvq_split(bu_hip_context* ctx, bu_tsvq* q, const bu_tsvq_node* h_nod
         const bu_tsvq_split* po = reinterpret_cast<const bu_tsvq_split*>(static_cast<const char*>(q->pinned) + out_at);
         for (uint32_t i = 0; i < n_nodes; i++) h_out[order[i]] = po[i];
     }
+    if (h_deep) {   // generation g of batch node i, path p: h_deep[n_nodes * (2^g - 2) + i * 2^g + p]; here generation g of one-workgroup node j sits at pd[n_narrow * (2^g - 2) + j * 2^g + p]
+        const bu_tsvq_split* pd = reinterpret_cast<const bu_tsvq_split*>(static_cast<const char*>(q->pinned) + deep_at);
+        for (uint32_t gen = 1; gen <= h_deep_levels; gen++) {
+            bu_tsvq_split* dst = h_deep + (size_t)n_nodes * ((1u << gen) - 2u);
+            const uint32_t w = 1u << gen;
+            if (gen > levels) { for (size_t k = 0; k < (size_t)n_nodes * w; k++) dst[k].ok = 3; continue; }
+            const bu_tsvq_split* src = pd + (size_t)n_narrow * (w - 2u);
+            for (uint32_t j = 0; j < n_nodes; j++) {
+                bu_tsvq_split* d = dst + (size_t)order[j] * w;
+                if (j >= n_narrow) { for (uint32_t p2 = 0; p2 < w; p2++) d[p2].ok = 3; continue; }
+                for (uint32_t p2 = 0; p2 < w; p2++) {
+                    const bu_tsvq_split& r = src[(size_t)j * w + p2];
+                    if (r.ok == 1 || r.ok == 0) d[p2] = r; else d[p2].ok = 3;   // (ok == 2, data outside the exact kernel's range: left to a later round, which has the redo path)
+                }
+            }
+        }
+    }
     if (exact || n_wide) { // nodes whose data left the exact range, or that a wide path handed back (ok == 2), go through the one-workgroup kernel: packed wide ones through its exact variant first
         for (int attempt = exact ? 0 : 1; attempt < 2; attempt++) {
             std::vector<uint32_t> redo;
@@ -1308,6 +1366,16 @@ int bu_hip_tsvq_split(bu_hip_context* ctx, bu_tsvq* q, const bu_tsvq_node* h_nod
     return 1;
 }
 
+int bu_hip_tsvq_split(bu_hip_context* ctx, bu_tsvq* q, const bu_tsvq_node* h_nodes, uint32_t n_nodes, bu_tsvq_split* h_out) {
+    return tsvq_split_impl(ctx, q, h_nodes, n_nodes, h_out, 0, nullptr);
+}
+
+int bu_hip_tsvq_split_deep(bu_hip_context* ctx, bu_tsvq* q, const bu_tsvq_node* h_nodes, uint32_t n_nodes, bu_tsvq_split* h_out, uint32_t levels, bu_tsvq_split* h_deep) {
+    if (levels && !h_deep) { if (ctx) set_error(ctx, "tsvq_split_deep: no array for the deeper generations"); return 0; }
+    if (levels > bu::TSVQ_MAX_DEEP_LEVELS) { if (ctx) set_error(ctx, "tsvq_split_deep: %u levels (at most BU_TSVQ_BUFFERS - 2)", levels); return 0; }
+    return tsvq_split_impl(ctx, q, h_nodes, n_nodes, h_out, levels, h_deep);
+}
+
 // prepare_root (enc.h:1708-1735) of member spans: what a tree_vector_quant whose training set is that span, in list order, starts from --
 // the roots of the T independent trees of generate_hierarchical_codebook_threaded_internal (enc.h:2137-2152).
 int bu_hip_tsvq_roots(bu_hip_context* ctx, bu_tsvq* q, const bu_tsvq_node* h_nodes, uint32_t n_nodes, bu_tsvq_root* h_out) {
@@ -1316,7 +1384,7 @@ int bu_hip_tsvq_roots(bu_hip_context* ctx, bu_tsvq* q, const bu_tsvq_node* h_nod
     device_guard g(ctx->device);
     if ((size_t)n_nodes * sizeof(bu_tsvq_node) > q->nodes.cap) { set_error(ctx, "tsvq_roots: %u spans exceed the record buffer", n_nodes); return 0; }
     for (uint32_t i = 0; i < n_nodes; i++)
-        if (h_nodes[i].buf > 1 || !h_nodes[i].count || (uint64_t)h_nodes[i].start + h_nodes[i].count > q->n) { set_error(ctx, "tsvq_roots: span outside the training set"); return 0; }
+        if (h_nodes[i].buf >= bu::TSVQ_BUFS || !h_nodes[i].count || (uint64_t)h_nodes[i].start + h_nodes[i].count > q->n) { set_error(ctx, "tsvq_roots: span outside the training set"); return 0; }
     BU_TRY(ctx, stream_wait(ctx, ctx->stream));   // the pinned staging buffer may still feed an earlier copy
     BU_TRY(ctx, q->reserve_pinned((size_t)n_nodes * std::max(std::max(sizeof(bu_tsvq_node), sizeof(bu_tsvq_root)), sizeof(bu::tsvq_wide_node))));
     std::vector<uint32_t> todo;
@@ -1421,7 +1489,7 @@ static int tsvq_exchange_layout(bu_hip_context* ctx, bu_tsvq* q, const bu_tsvq_n
         table[i] = bu::bk_span{h_nodes[i].buf, h_nodes[i].start, h_nodes[i].count, (uint32_t)run};
         run += h_nodes[i].count;
     }
-    if (run > 2ull * q->n) { set_error(ctx, "tsvq_exchange: overlapping nodes"); return 0; }   // (both member buffers once over: the whole-tree exchange of the one-tree-per-rank build)
+    if (run > (uint64_t)bu::TSVQ_BUFS * q->n) { set_error(ctx, "tsvq_exchange: overlapping nodes"); return 0; }   // (every member buffer once over: the whole-tree exchange of the one-tree-per-rank build)
     rec_at = ((size_t)run * 4 + 7) & ~(size_t)7;
     tab_at = rec_at + (size_t)n_nodes * sizeof(bu_tsvq_split);
     total = tab_at + (size_t)n_nodes * sizeof(bu::bk_span) + ((size_t)n_nodes + 7 & ~(size_t)7);
@@ -1475,9 +1543,9 @@ int bu_hip_tsvq_exchange_unpack(bu_hip_context* ctx, bu_tsvq* q, const bu_tsvq_n
 }
 
 int bu_hip_tsvq_read_members(bu_hip_context* ctx, bu_tsvq* q, uint32_t buf, uint32_t start, uint32_t count, uint32_t* h_out) {
-    if (!ctx || !q || buf > 1 || (uint64_t)start + count > q->n) return 0;
+    if (!ctx || !q || buf >= bu::TSVQ_BUFS || (uint64_t)start + count > q->n) return 0;
     device_guard g(ctx->device);
-    if (count) BU_TRY(ctx, d2h_pageable(ctx, h_out, q->perm[buf] + start, (size_t)count * 4));
+    if (count) BU_TRY(ctx, d2h_pageable(ctx, h_out, q->perm[0] + (size_t)buf * q->n + start, (size_t)count * 4));
     BU_TRY(ctx, stream_wait(ctx, ctx->stream));
     return 1;
 }

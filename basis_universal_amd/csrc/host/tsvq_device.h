@@ -61,6 +61,8 @@ struct csr_block_pair_groups {
 };
 
 class device_tsvq {
+    // a node's children live over the node's span of the NEXT member buffer, cyclic (include/basisu_hip.h: BU_TSVQ_BUFFERS)
+    static uint32_t child_buf(uint32_t buf) { return (buf + 1u) % BU_TSVQ_BUFFERS; }
 public:
     struct stats { uint32_t rounds = 0, splits_computed = 0, splits_used = 0; double t_create = 0, t_device = 0, t_replay = 0, t_expand = 0; };
 
@@ -157,11 +159,11 @@ private:
         for (size_t i = 0; i < batch.size(); i++) {
             const bu_tsvq_node& b = batch[i];
             lists0.resize(b.count); lists1.resize(b.count);
-            if (!bu_hip_tsvq_read_members(ctx, q, b.buf ^ 1u, b.start, b.count, lists0.data())) return;
+            if (!bu_hip_tsvq_read_members(ctx, q, child_buf(b.buf), b.start, b.count, lists0.data())) return;
             for (int rep = 0; rep < 2; rep++) {
                 bu_tsvq_split s; std::memset(&s, 0, sizeof(s));
                 if (!bu_hip_tsvq_split(ctx, q, &b, 1, &s)) return;
-                if (!bu_hip_tsvq_read_members(ctx, q, b.buf ^ 1u, b.start, b.count, lists1.data())) return;
+                if (!bu_hip_tsvq_read_members(ctx, q, child_buf(b.buf), b.start, b.count, lists1.data())) return;
                 bu_tsvq_split ref = batched[i]; ref.pad = 0; s.pad = 0;
                 const bool same_out = s.ok == ref.ok && (!s.ok || std::memcmp(&s, &ref, sizeof(s)) == 0);
                 const bool same_list = !s.ok || lists0 == lists1;
@@ -200,13 +202,15 @@ private:
             leaves = 1; next_codebook_index = 0; max_leaves = max_leaves_;
         }
         // generate()'s loop (enc.h:1636-1655) while the splits it needs are known; true = it stopped at a node whose split is not known yet
-        bool replay(const std::vector<bu_tsvq_split>& cache, uint32_t& splits_used) {
+        // (kid[2 c + side]: the cache index of the split of that child of cache entry c, where a deep round has computed it already; -1 otherwise)
+        bool replay(const std::vector<bu_tsvq_split>& cache, const std::vector<int32_t>& kid, uint32_t& splits_used) {
             while (heap.size() && leaves < max_leaves) {
                 const uint32_t ni = heap.top_index();
                 if (nodes[ni].count > 1 && nodes[ni].cached < 0) return true;
                 heap.pop();
                 if (nodes[ni].count <= 1) continue;
-                const bu_tsvq_split& s = cache[(size_t)nodes[ni].cached];
+                const size_t ci = (size_t)nodes[ni].cached;
+                const bu_tsvq_split& s = cache[ci];
                 if (!s.ok) continue; // prep_split / refine_split returned false: the node stays a leaf
                 splits_used++;
                 const uint32_t li = (uint32_t)nodes.size(), ri = li + 1;
@@ -214,16 +218,17 @@ private:
                 nodes[ni].codebook_index = (int)next_codebook_index++;
                 node l, r;
                 l.var = s.l_var; l.weight = s.l_weight; std::memcpy(l.origin, s.l_centroid, sizeof(l.origin));
-                l.buf = nodes[ni].buf ^ 1u; l.start = nodes[ni].start; l.count = s.l_count;
+                l.buf = child_buf(nodes[ni].buf); l.start = nodes[ni].start; l.count = s.l_count;
                 r.var = s.r_var; r.weight = s.r_weight; std::memcpy(r.origin, s.r_centroid, sizeof(r.origin));
-                r.buf = nodes[ni].buf ^ 1u; r.start = nodes[ni].start + s.l_count; r.count = s.r_count;
+                r.buf = child_buf(nodes[ni].buf); r.start = nodes[ni].start + s.l_count; r.count = s.r_count;
                 // enc.h:1766-1792: a child with var <= 0 but differing members gets a tiny variance; rows are distinct, so any
                 // child with more than one member qualifies
                 if (l.var <= 0.0f && l.count > 1) l.var = 1e-4f;
                 if (r.var <= 0.0f && r.count > 1) r.var = 1e-4f;
+                l.cached = kid[2 * ci]; r.cached = kid[2 * ci + 1];
                 nodes.push_back(l); nodes.push_back(r);
-                if (l.var > 0.0f && l.count > 1) { heap.push(li, l.var); uncached.emplace_back(l.var, li); }
-                if (r.var > 0.0f && r.count > 1) { heap.push(ri, r.var); uncached.emplace_back(r.var, ri); }
+                if (l.var > 0.0f && l.count > 1) { heap.push(li, l.var); if (l.cached < 0) uncached.emplace_back(l.var, li); }
+                if (r.var > 0.0f && r.count > 1) { heap.push(ri, r.var); if (r.cached < 0) uncached.emplace_back(r.var, ri); }
                 leaves++;
             }
             return false;
@@ -241,6 +246,17 @@ private:
                 std::nth_element(pending.begin(), pending.begin() + want, pending.end(), [](const std::pair<float, uint32_t>& a, const std::pair<float, uint32_t>& b) { return a.first > b.first || (a.first == b.first && a.second < b.second); });
                 pending.resize(want);
             }
+        }
+        // A bound for the speculation of a deep round: with R splits left to do, a node whose variance is below the R-th largest variance in the queue will not be
+        // popped before the leaf budget is spent (popping is by descending variance; new nodes only push it further down), so its descendants are not worth a
+        // launch slot. 0 while the queue holds no more than R nodes. (Only a bound on wasted work: whatever the replay does need and does not find, the next round computes.)
+        float speculation_floor(std::vector<float>& scratch) const {
+            const size_t R = (size_t)(max_leaves - leaves);
+            if (!R || heap.size() <= R) return 0.0f;
+            scratch.resize(heap.size());
+            for (uint32_t i = 0; i < heap.size(); i++) scratch[i] = heap.entry_priority(i + 1);
+            std::nth_element(scratch.begin(), scratch.begin() + (R - 1), scratch.end(), [](float a, float b) { return a > b; });
+            return scratch[R - 1] > 0.0f ? scratch[R - 1] : 0.0f;
         }
         // retrieve(max_clusters) (enc.h:1598-1628): cut the tree after its first max_clusters-1 splits, depth first, left before right;
         // cut(ni) is called for every cut node in that order
@@ -263,22 +279,34 @@ private:
 
     // Splits every tree of `trees` to its leaf budget: each device round takes the pending nodes of ALL trees (they are independent), so
     // the T sub-trees of the partitioned build fill a round T times as well as one tree does.
-    static bool run_trees(bu_hip_context* ctx, bu_tsvq* q, std::vector<tree*>& trees, std::vector<bu_tsvq_split>& cache, stats& local, const bu_comm* comm,
-                          bool dbg_serial, bool dbg_verify) {
+    // Deep rounds (bu_hip_tsvq_split_deep, bu_hip_tuning::tsvq_deep_levels): with the batch, the device also splits the descendants of its one-workgroup nodes
+    // `deep_levels` generations down (bounded per tree by speculation_floor()), so the replay below runs through several generations before it needs the device again.
+    static bool run_trees(bu_hip_context* ctx, bu_tsvq* q, std::vector<tree*>& trees, std::vector<bu_tsvq_split>& cache, std::vector<int32_t>& kid, stats& local, const bu_comm* comm,
+                          bool dbg_serial, bool dbg_verify, uint32_t deep_levels) {
         auto now = [] { return std::chrono::steady_clock::now(); };
         auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
         std::vector<bu_tsvq_node> batch;
         std::vector<std::pair<uint32_t, uint32_t>> batch_nodes;   // (tree, node)
         std::vector<std::pair<float, uint32_t>> pending;
+        std::vector<float> floor_scratch;
+        std::vector<bu_tsvq_split> deep;
+        std::vector<int32_t> gen_idx[2];
+        const bool sharing = comm && comm->world > 1;
+        if (sharing || dbg_serial || dbg_verify) deep_levels = 0;   // (verify re-runs a node and compares the children's lists: they must not have been split further)
         for (;;) {
             batch.clear(); batch_nodes.clear();
+            uint64_t splits_left = 0;   // over the trees of this round
             for (uint32_t t = 0; t < trees.size(); t++) {
                 tree& tr = *trees[t];
-                if (!tr.replay(cache, local.splits_used)) continue;
+                if (!tr.replay(cache, kid, local.splits_used)) continue;
+                splits_left += tr.max_leaves - tr.leaves;
                 tr.pending_nodes(pending);
+                uint32_t floor_bits = 0;
+                if (deep_levels) { const float f = tr.speculation_floor(floor_scratch); std::memcpy(&floor_bits, &f, 4); }
                 for (const auto& p : pending) {
                     const node& nd = tr.nodes[p.second];
                     bu_tsvq_node b; std::memset(&b, 0, sizeof(b));
+                    b.pad = floor_bits;
                     b.buf = nd.buf; b.start = nd.start; b.count = nd.count; b.weight = nd.weight; std::memcpy(b.origin, nd.origin, sizeof(b.origin));
                     batch.push_back(b); batch_nodes.emplace_back(t, p.second);
                 }
@@ -286,7 +314,8 @@ private:
             if (batch.empty()) return true;
             const size_t base = cache.size();
             cache.resize(base + batch.size());
-            if (comm && comm->world > 1 && batch.size() > 1) {
+            kid.resize(2 * cache.size(), -1);
+            if (sharing && batch.size() > 1) {
                 // Multi-GPU: the nodes of a round are independent, so every rank splits a share of them (largest first onto the least loaded
                 // rank: the same assignment on every rank) and the child member lists + result records are merged by ONE exact sum all-reduce of
                 // a staging buffer in which everybody else's entries are zero. Afterwards every rank holds every result, bit for bit.
@@ -319,6 +348,35 @@ private:
             } else if (dbg_serial) { // debug: one node per launch
                 for (size_t i = 0; i < batch.size(); i++)
                     if (!bu_hip_tsvq_split(ctx, q, &batch[i], 1, cache.data() + base + i)) return false;
+            } else if (deep_levels) {
+                const auto td = now();
+                const size_t n = batch.size();
+                // As deep as the leaf budget can still use: every generation doubles the nodes, and in the rounds where the device is full (hundreds of nodes) a split
+                // nobody pops is paid for in device time -- two generations for every node of the batch measured SLOWER than none (4096^2 q128: 17.9 against 17.1 ms
+                // per step). While the batch with all its descendants fits the splits that are left, nothing attempted is likely to be wasted.
+                uint32_t levels = deep_levels;
+                while (levels && (uint64_t)n * ((2u << levels) - 1u) > splits_left) levels--;
+                deep.resize(n * ((2u << levels) - 2u) + 1);
+                if (!bu_hip_tsvq_split_deep(ctx, q, batch.data(), (uint32_t)n, cache.data() + base, levels, deep.data())) return false;
+                local.t_device += secs(td, now());
+                // the descendants that were attempted join the cache behind the batch; kid[] links every entry to its children's entries
+                gen_idx[0].resize(n);
+                for (size_t i = 0; i < n; i++) gen_idx[0][i] = (int32_t)(base + i);
+                for (uint32_t g = 1; g <= levels; g++) {
+                    const std::vector<int32_t>& up = gen_idx[(g - 1) & 1];
+                    std::vector<int32_t>& cur = gen_idx[g & 1];
+                    const size_t w = (size_t)1 << g;
+                    const bu_tsvq_split* src = deep.data() + n * (w - 2);
+                    cur.assign(n * w, -1);
+                    for (size_t k = 0; k < n * w; k++) {
+                        if (up[k >> 1] < 0 || src[k].ok == 3) continue;
+                        cur[k] = (int32_t)cache.size();
+                        kid[2 * (size_t)up[k >> 1] + (k & 1)] = cur[k];
+                        cache.push_back(src[k]);
+                        kid.push_back(-1); kid.push_back(-1);
+                        local.splits_computed++;
+                    }
+                }
             } else {
                 const auto td = now();
                 if (!bu_hip_tsvq_split(ctx, q, batch.data(), (uint32_t)batch.size(), cache.data() + base)) return false;
@@ -330,10 +388,10 @@ private:
         }
     }
 
-    // The end of the one-tree-per-rank build: every rank contributes the trees it built -- both member buffers over each tree's span, and the tree's node table --
+    // The end of the one-tree-per-rank build: every rank contributes the trees it built -- every member buffer over each tree's span, and the tree's node table --
     // to one staging buffer in which everybody else's entries are zero; ONE exact u64 sum all-reduce (bu_comm) makes it whole everywhere. The buffer is the one
-    // the per-round exchange uses (bu_hip_tsvq_exchange_pack / _unpack): per tree two pseudo-nodes over its span, {buf 1} for the list in buffer 0 and {buf 0}
-    // for the one in buffer 1 ("a node's children live in the other buffer"); the serialised node tables ride in the record slots of zero-member pseudo-nodes
+    // the per-round exchange uses (bu_hip_tsvq_exchange_pack / _unpack): per tree one pseudo-node per member buffer over its span, {buf b - 1} for the list in
+    // buffer b ("a node's children live in the next buffer"); the serialised node tables ride in the record slots of zero-member pseudo-nodes
     // behind them (a table's region is a whole number of records, so a record has one owner).
     static bool exchange_trees(bu_hip_context* ctx, bu_tsvq* q, const bu_comm* comm, std::vector<tree>& subs, const std::vector<bu_tsvq_node>& spans, const std::vector<uint32_t>& owner) {
         static_assert(std::is_trivially_copyable<node>::value, "node tables are exchanged as bytes");
@@ -347,18 +405,20 @@ private:
             n_rec += (sizeof(table_header) + cap_nodes * sizeof(node) + rec - 1) / rec;
         }
         rec_first[T] = n_rec;
-        std::vector<bu_tsvq_node> nodes(2 * T + n_rec);
+        constexpr size_t B = BU_TSVQ_BUFFERS;
+        std::vector<bu_tsvq_node> nodes(B * T + n_rec);
         std::memset(nodes.data(), 0, nodes.size() * sizeof(bu_tsvq_node));
         std::vector<uint8_t> mine(nodes.size(), 0);
         std::vector<bu_tsvq_split> recs(nodes.size());
         std::memset(recs.data(), 0, recs.size() * sizeof(bu_tsvq_split));
-        char* blob = reinterpret_cast<char*>(recs.data() + 2 * T);
+        char* blob = reinterpret_cast<char*>(recs.data() + B * T);
         for (size_t t = 0; t < T; t++) {
             const bool my = owner[t] == comm->rank;
-            nodes[2 * t].buf = 1; nodes[2 * t].start = spans[t].start; nodes[2 * t].count = spans[t].count;
-            nodes[2 * t + 1].buf = 0; nodes[2 * t + 1].start = spans[t].start; nodes[2 * t + 1].count = spans[t].count;
-            mine[2 * t] = mine[2 * t + 1] = my ? 1 : 0;
-            for (size_t r = rec_first[t]; r < rec_first[t + 1]; r++) mine[2 * T + r] = my ? 1 : 0;
+            for (size_t b = 0; b < B; b++) {   // pseudo-node b: "children" = the tree's span of buffer (b + 1) % B
+                nodes[B * t + b].buf = (uint32_t)b; nodes[B * t + b].start = spans[t].start; nodes[B * t + b].count = spans[t].count;
+                mine[B * t + b] = my ? 1 : 0;
+            }
+            for (size_t r = rec_first[t]; r < rec_first[t + 1]; r++) mine[B * T + r] = my ? 1 : 0;
             if (!my) continue;
             const tree& tr = subs[t];
             if (sizeof(table_header) + tr.nodes.size() * sizeof(node) > (rec_first[t + 1] - rec_first[t]) * rec) return false;   // cannot happen: 2 L - 1 nodes
@@ -372,7 +432,7 @@ private:
         if (!comm->stream_ordered && !bu_hip_sync(ctx)) return false;
         if (!comm->all_reduce_u64(comm->user, d_staging, n_u64)) return false;
         if (!bu_hip_tsvq_exchange_unpack(ctx, q, nodes.data(), mine.data(), recs.data(), (uint32_t)nodes.size())) return false;
-        blob = reinterpret_cast<char*>(recs.data() + 2 * T);
+        blob = reinterpret_cast<char*>(recs.data() + B * T);
         for (size_t t = 0; t < T; t++) {
             if (owner[t] == comm->rank) continue;
             table_header h;
@@ -399,7 +459,11 @@ private:
         if (leaf_of_unique) leaf_of_unique->clear();
         if (leaf_count) *leaf_count = 0;
         struct guard { bu_hip_context* c; bu_tsvq* q; ~guard() { bu_hip_tsvq_destroy(c, q); } } g{ctx, q};
-        const bool dbg_serial = std::getenv("BU_TSVQ_SERIAL") != nullptr, dbg_verify = std::getenv("BU_TSVQ_VERIFY") != nullptr;   // once per tree, not per round
+        // (the path choices are the context's tuning -- rank-agreed state under a communicator, not each process's environment; BU_TSVQ_VERIFY is a local debug aid)
+        bu_hip_tuning tune; std::memset(&tune, 0, sizeof(tune));
+        bu_hip_get_tuning(ctx, &tune, (uint32_t)sizeof(tune));
+        const bool dbg_serial = (tune.debug & 2u) != 0, dbg_verify = std::getenv("BU_TSVQ_VERIFY") != nullptr;
+        const uint32_t deep_levels = tune.tsvq_deep_levels;
 
         stats local;
         if (st) local.t_create = st->t_create;
@@ -407,6 +471,7 @@ private:
         auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double>(b - a).count(); };
         const auto t_loop0 = now();
         std::vector<bu_tsvq_split> cache;
+        std::vector<int32_t> kid;
 
         // ---- the tree, or -- partitions = T > 1, generate_hierarchical_codebook_threaded_internal (enc.h:2086-2215) -- a T-leaf tree first and then
         //      one independent tree per leaf over that leaf's members: own root record (prepare_root over the span, bu_hip_tsvq_roots), own queue,
@@ -416,7 +481,7 @@ private:
         top.reset(root, 0, 0, n, T > 1 ? T : max_codebook_size);
         std::vector<tree> subs;
         std::vector<tree*> active{&top};
-        if (!run_trees(ctx, q, active, cache, local, comm, dbg_serial, dbg_verify)) return false;
+        if (!run_trees(ctx, q, active, cache, kid, local, comm, dbg_serial, dbg_verify, deep_levels)) return false;
         std::vector<const tree*> final_trees{&top};
         std::vector<uint32_t> final_parents{max_parent_codebook_size};
         if (T > 1) {
@@ -452,11 +517,11 @@ private:
                     }
                     std::vector<tree*> mine;
                     for (size_t t = 0; t < subs.size(); t++) if (owner[t] == comm->rank) mine.push_back(&subs[t]);
-                    if (!mine.empty() && !run_trees(ctx, q, mine, cache, local, nullptr, dbg_serial, dbg_verify)) return false;
+                    if (!mine.empty() && !run_trees(ctx, q, mine, cache, kid, local, nullptr, dbg_serial, dbg_verify, deep_levels)) return false;
                     const auto tx = now();
                     if (!exchange_trees(ctx, q, comm, subs, spans, owner)) return false;
                     local.t_device += secs(tx, now());
-                } else if (!run_trees(ctx, q, active, cache, local, comm, dbg_serial, dbg_verify)) return false;
+                } else if (!run_trees(ctx, q, active, cache, kid, local, comm, dbg_serial, dbg_verify, deep_levels)) return false;
             }
         }
         const auto t_loop1 = now();
@@ -505,9 +570,16 @@ private:
             return true;
         }
 
-        std::vector<uint32_t> perm[2];
-        perm[0].resize(n); perm[1].resize(n);
-        if (!bu_hip_tsvq_read_members(ctx, q, 0, 0, n, perm[0].data()) || !bu_hip_tsvq_read_members(ctx, q, 1, 0, n, perm[1].data())) return false;
+        std::vector<uint32_t> perm[BU_TSVQ_BUFFERS];
+        {
+            bool used[BU_TSVQ_BUFFERS] = {};
+            for (const bu_tsvq_span& sp : spans) { if (sp.buf >= BU_TSVQ_BUFFERS) return false; used[sp.buf] = true; }
+            for (uint32_t b = 0; b < BU_TSVQ_BUFFERS; b++) {   // (a leaf's list lives in the buffer its depth put it in)
+                if (!used[b]) continue;
+                perm[b].resize(n);
+                if (!bu_hip_tsvq_read_members(ctx, q, b, 0, n, perm[b].data())) return false;
+            }
+        }
         struct span { const uint32_t* p; uint32_t n; };
         std::vector<span> leaf_members;
         for (const bu_tsvq_span& s : spans) leaf_members.push_back(span{perm[s.buf].data() + s.start, s.count});

@@ -21,6 +21,11 @@ hipError_t launch_tsvq_span_roots(hipStream_t st, int dim, bool packed, bool exa
 hipError_t launch_tsvq_split(hipStream_t st, int dim, bool packed, bool exact, const void* d_rows, const uint64_t* d_w64, uint32_t* d_perm0, uint32_t* d_perm1, uint8_t* d_side,
                              const tsvq_node_in* d_nodes, uint32_t n_nodes, tsvq_split_out* d_outs, uint32_t dense_min);
 
+// deep rounds: the 2 n_parents node records of the next generation from the parents' records and results (count = 0 and ok = 3 for what is not attempted; a parent's
+// `pad` holds the bits of the variance floor, inherited). d_parent_outs / d_child_outs may be page-locked host memory.
+hipError_t launch_tsvq_children(hipStream_t st, const tsvq_node_in* d_parents, const tsvq_split_out* d_parent_outs, uint32_t n_parents, tsvq_node_in* d_children,
+                                tsvq_split_out* d_child_outs);
+
 // one-thread launch that stores `value` to *d_flag (page-locked host memory) with system scope once everything before it on the stream is done
 hipError_t launch_tsvq_signal(hipStream_t st, uint32_t* d_flag, uint32_t value);
 

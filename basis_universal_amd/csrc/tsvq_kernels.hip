@@ -20,6 +20,7 @@
 #include <cstdlib>
 #include "tsvq_kernels.h"
 #include "tsvq_common.h"
+#include "tsvq_bufs.h"
 
 namespace bu {
 
@@ -286,6 +287,43 @@ hipError_t launch_tsvq_signal(hipStream_t st, uint32_t* d_flag, uint32_t value) 
     return hipGetLastError();
 }
 
+// Deep rounds (bu_hip_tsvq_split_deep): the node records of the NEXT generation, made on the device from the result records of the generation before it, so that the
+// children's splits follow their parents' on the stream without the host in between. Child t = side (t & 1) of parent t >> 1. A child is attempted when its parent's
+// split succeeded (ok == 1), it has more than one member, and its variance -- after the reference's substitution of 1e-4 for a non-positive variance of a node with
+// differing members (enc.h:1766-1792) -- is positive and not below the floor the host put into the FIRST generation's records (`pad`: the bits of a float; children
+// inherit it). The floor only bounds the speculation: a node below it cannot be popped from the caller's queue before the leaf budget is spent. What is not attempted
+// gets count = 0 (the split kernel returns at once) and ok = 3 in its result record.
+__global__ __launch_bounds__(256) void k_tsvq_children(const tsvq_node_in* __restrict__ parents, const tsvq_split_out* parent_outs, uint32_t n_parents,
+                                                       tsvq_node_in* __restrict__ children, tsvq_split_out* child_outs) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= 2 * n_parents) return;
+    const uint32_t j = t >> 1, s = t & 1u;
+    const tsvq_node_in pn = parents[j];
+    const tsvq_split_out* po = parent_outs + j;
+    tsvq_node_in ch;
+    ch.buf = tsvq_child_buf(pn.buf); ch.start = pn.start; ch.count = 0; ch.pad = pn.pad; ch.weight = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) ch.origin[k] = 0.0f;
+    if (pn.count != 0 && po->ok == 1u) {
+        const uint32_t cnt = s ? po->r_count : po->l_count;
+        float var = s ? po->r_var : po->l_var;
+        if (var <= 0.0f && cnt > 1) var = 1e-4f;
+        if (cnt > 1 && var > 0.0f && var >= __uint_as_float(pn.pad)) {
+            ch.start = pn.start + (s ? po->l_count : 0u); ch.count = cnt; ch.weight = s ? po->r_weight : po->l_weight;
+#pragma unroll
+            for (int k = 0; k < 16; k++) ch.origin[k] = s ? po->r_centroid[k] : po->l_centroid[k];
+        }
+    }
+    children[t] = ch;
+    if (ch.count == 0) child_outs[t].ok = 3u;
+}
+hipError_t launch_tsvq_children(hipStream_t st, const tsvq_node_in* d_parents, const tsvq_split_out* d_parent_outs, uint32_t n_parents, tsvq_node_in* d_children,
+                                tsvq_split_out* d_child_outs) {
+    if (!n_parents) return hipSuccess;
+    hipLaunchKernelGGL(k_tsvq_children, dim3((2 * n_parents + 255) / 256), dim3(256), 0, st, d_parents, d_parent_outs, n_parents, d_children, d_child_outs);
+    return hipGetLastError();
+}
+
 __global__ __launch_bounds__(256) void k_tsvq_iota(uint32_t n, uint32_t* __restrict__ perm0) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) perm0[i] = i;
@@ -301,7 +339,7 @@ __global__ __launch_bounds__(TQ_THREADS) void k_tsvq_root(Src src, const uint64_
     const uint32_t* members = nullptr;
     if (nodes) {
         const tsvq_node_in& nd = nodes[blockIdx.x];
-        members = (nd.buf ? perm1 : perm0) + nd.start;
+        members = tsvq_list(perm0, perm1, nd.buf) + nd.start;
         n = nd.count;
         out += blockIdx.x;
     }
@@ -375,8 +413,9 @@ __device__ __forceinline__ void tsvq_split_body(Src src, const uint64_t* __restr
     const tsvq_node_in nd = nodes[blockIdx.x];
     tsvq_split_out* out = outs + blockIdx.x;
     const uint32_t count = nd.count;
-    const uint32_t* members = (nd.buf ? perm1 : perm0) + nd.start;
-    uint32_t* child_members = (nd.buf ? perm0 : perm1) + nd.start;
+    if (count == 0) return;   // a child record k_tsvq_children decided not to attempt (its result record already says ok = 3); uniform, before any barrier
+    const uint32_t* members = tsvq_list(perm0, perm1, nd.buf) + nd.start;
+    uint32_t* child_members = tsvq_child_list(perm0, perm1, nd.buf) + nd.start;
     uint8_t* node_side = side + nd.start;
     if (tid < 16) s_origin[tid] = nodes[blockIdx.x].origin[tid];   // from memory: indexing the register copy by tid would put it in scratch
     __syncthreads();
@@ -828,7 +867,7 @@ __global__ __launch_bounds__(TQ_THREADS) void k_tsvq_cov_axis(packed16_rows src,
     __shared__ float s_origin[16];
     const int tid = threadIdx.x;
     const tsvq_wide_node nd = nodes[blockIdx.x];
-    const uint32_t* members = (nd.buf ? perm1 : perm0) + nd.start;
+    const uint32_t* members = tsvq_list(perm0, perm1, nd.buf) + nd.start;
     if (tid < 16) s_origin[tid] = nodes[blockIdx.x].origin[tid];
     __syncthreads();
     // one instantiation per group: which components a chain multiplies must be known at compile time (run-time indices into v[] would put it in scratch)
@@ -857,7 +896,7 @@ __global__ __launch_bounds__(TQ_THREADS) void k_tsvq_cov_axis6(float_rows<6> src
     __shared__ float s_origin[N];
     const int tid = threadIdx.x;
     const tsvq_wide_node nd = nodes[blockIdx.x];
-    const uint32_t* members = (nd.buf ? perm1 : perm0) + nd.start;
+    const uint32_t* members = tsvq_list(perm0, perm1, nd.buf) + nd.start;
     if (tid < N) s_origin[tid] = nodes[blockIdx.x].origin[tid];
     __syncthreads();
     float cv = 0.0f;

@@ -25,6 +25,7 @@
 #include <stdint.h>
 #include "tsvq_kernels.h"
 #include "tsvq_common.h"
+#include "tsvq_bufs.h"
 #include "fsum_scan.h"
 #include "tt_exact.h"
 
@@ -85,7 +86,7 @@ __global__ __launch_bounds__(WB) void k6_sums(const float* __restrict__ rows, co
     if (tid < D6) { s_origin[tid] = nd.origin[tid]; s_axis[tid] = ct.axis[tid]; s_lc[tid] = ct.l_c[tid]; s_rc[tid] = ct.r_c[tid]; }
     __syncthreads();
     const uint32_t pos = (blk - nd.first_block) * WB + (uint32_t)tid;
-    const uint32_t* members = MODE == W6_ROOT ? nullptr : (nd.buf ? perm1 : perm0) + nd.start;
+    const uint32_t* members = MODE == W6_ROOT ? nullptr : tsvq_list(perm0, perm1, nd.buf) + nd.start;
     const member6 m = fetch6(rows, w64, members, pos, nd.count);
     // which child (enc.h:1870-1871 projection sign; enc.h:1991 distances in double, difference form)
     bool right;

@@ -124,8 +124,8 @@ __device__ __forceinline__ void wide_partition_body(uint32_t* perm0, uint32_t* p
         } else out->ok = 2;   // run this node through the one-workgroup kernel
     }
     if (c.done != 1) return;
-    const uint32_t* members = (nd.buf ? perm1 : perm0) + nd.start;
-    uint32_t* child = (nd.buf ? perm0 : perm1) + nd.start;
+    const uint32_t* members = tsvq_list(perm0, perm1, nd.buf) + nd.start;
+    uint32_t* child = tsvq_child_list(perm0, perm1, nd.buf) + nd.start;
     const uint32_t pos = (blk - nd.first_block) * WB + (uint32_t)tid;
     const bool valid = pos < nd.count;
     const bool right = valid && side[nd.start + pos] != 0;

@@ -26,6 +26,7 @@
 #include <cstdlib>
 #include "tsvq_kernels.h"
 #include "tsvq_common.h"
+#include "tsvq_bufs.h"
 #include "fsum_scan.h"
 
 namespace bu {
@@ -119,7 +120,7 @@ __device__ __forceinline__ void wide_sums_body(const uint32_t* __restrict__ keys
     const uint32_t pos = (blk - nd.first_block) * WB + (uint32_t)tid;
     // (the root pass of the whole training set has no member list: perm0 == nullptr; the roots of member SPANS -- the independent trees of the partitioned
     //  build, enc.h:2137-2152 -- read their span and lay it out in list order like the covariance pass does)
-    const uint32_t* members = (MODE == WM_ROOT && !perm0) ? nullptr : (nd.buf ? perm1 : perm0) + nd.start;
+    const uint32_t* members = (MODE == WM_ROOT && !perm0) ? nullptr : tsvq_list(perm0, perm1, nd.buf) + nd.start;
     const member_info m = fetch_member(keys, w64, members, pos, nd.count);
     if (MODE == WM_ROOT && pk && m.valid) pk[nd.start + pos] = make_uint2(m.key, __float_as_uint(m.wf));
     bool right = false;
@@ -203,71 +204,74 @@ __global__ __launch_bounds__(WB) void k_wide_sums(const uint32_t* __restrict__ k
 
 
 // ------------------------------------------------------------------------------------------------------------ k_wide_scan
-// grid (node, y): y < ceil(NCH / 4): four chains, one wave each, 64 blocks per step (coalesced, wave prefix scan);
-//                 y == ceil(NCH / 4) (not for the covariance pass): the integer totals and the left-count prefix of the node.
+// grid (node, y): y < NCH: one chain per workgroup -- thread t takes ceil(n_blocks / 256) consecutive blocks, the workgroup scans the threads' totals, and every
+//                          thread walks its blocks again with the prefix in front of them (the sweep this replaces gave a chain ONE wave that took 64 blocks per
+//                          step: 42 dependent wave scans for the 2,636 blocks of the 4096^2 root, 17-31 us per pass; the block sums are 21 KB per chain, L2-resident);
+//                 y == NCH (not for the covariance pass): the integer totals and the left-count prefix of the node.
+// The prefix is a PREDICTION aid for the signed covariance chains (association order immaterial) and exact for the integer-valued side / root chains (doubles < 2^53).
 template <int MODE>
 __device__ __forceinline__ void wide_scan_body(const tsvq_wide_node* __restrict__ nodes, tsvq_wide_ctrl* ctrl, void* ws_base, uint32_t tb, const uint32_t ni, const uint32_t y) {
     constexpr int NCH = mode_traits<MODE>::NCH;
-    constexpr int NCW = (NCH + 3) / 4;
     __shared__ uint64_t s_tot[4][8];
     __shared__ uint32_t s_wl[4];
+    __shared__ double s_wsum[4], s_wmax[4];
+    __shared__ uint32_t s_wcnt[4];
     const wide_ws ws = carve(ws_base, tb);
     if (ctrl[ni].done) return;
     const tsvq_wide_node nd = nodes[ni];
-    const int tid = threadIdx.x, lane = tid & 63;
-    if ((int)y < NCW) {
-        const int c = (int)y * 4 + (tid >> 6);
-        if (c >= NCH) return;
-        double P = 0;   // sum of the blocks before the current 64
-        uint32_t exact_blocks = 0; double exact_sum = 0.0;   // the leading blocks over which the (integer) running sum stays <= 2^24: no rounding there
-        // one sweep, the next chunk's block sums in flight while the current one is scanned (a chunk is one trip to L2)
-        auto fetch = [&](uint32_t b0, double& v, uint32_t& bz) {
-            const uint32_t b = b0 + (uint32_t)lane;
-            const bool have = b < nd.n_blocks;
-            const size_t at = ws.at(c, nd.first_block + (have ? b : nd.n_blocks - 1));
-            v = have ? ws.bsum[at] : 0.0;
-            bz = have ? (uint32_t)ws.bzero[at] : 1u;
-        };
-        double v; uint32_t bz;
-        fetch(0, v, bz);
-        for (uint32_t b0 = 0; b0 < nd.n_blocks; b0 += 64) {
-            double vn; uint32_t bzn;
-            fetch(min(b0 + 64, nd.n_blocks - 1), vn, bzn);
-            const uint32_t b = b0 + (uint32_t)lane;
-            const bool have = b < nd.n_blocks;
-            const size_t at = ws.at(c, nd.first_block + (have ? b : nd.n_blocks - 1));
-            const double incl = wave_prefix_f64(v);
-            const double Ps = P + (incl - v);
-            if (MODE != WM_COV && exact_blocks == b0) {   // still inside the exact prefix at this chunk's start
-                const uint64_t inside = __ballot(have && P + incl <= 16777216.0);
-                const uint32_t cnt = (uint32_t)__popcll(inside);   // a prefix of the lanes: the sums are monotone
-                if (cnt) { exact_sum = P + __shfl(incl, (int)cnt - 1, 64); exact_blocks += cnt; }
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if ((int)y < NCH) {
+        const int c = (int)y;
+        const uint32_t perb = (nd.n_blocks + 255) / 256;
+        const uint32_t q0 = min((uint32_t)tid * perb, nd.n_blocks), q1 = min(q0 + perb, nd.n_blocks);
+        const size_t at0 = ws.at(c, nd.first_block);
+        double loc = 0;
+        for (uint32_t b = q0; b < q1; b++) loc += ws.bsum[at0 + b];
+        const double incl = wave_prefix_f64(loc);
+        if (lane == 63) s_wsum[wave] = incl;
+        __syncthreads();
+        double P = incl - loc;   // the sum of everything in front of this thread's first block
+        for (int w = 0; w < wave; w++) P += s_wsum[w];
+        const double total = ((s_wsum[0] + s_wsum[1]) + s_wsum[2]) + s_wsum[3];
+        // the leading blocks over which the (integer, non-decreasing) running sum stays <= 2^24: no rounding there, the walk starts behind them
+        uint32_t ex_n = 0; double ex_sum = 0.0;
+        for (uint32_t b = q0; b < q1; b++) {
+            const size_t at = at0 + b;
+            const double v = ws.bsum[at];
+            const double Ps = P;
+            P += v;
+            if (MODE != WM_COV && P <= 16777216.0) { ex_n++; ex_sum = P; }
+            uint16_t ep;
+            if (ws.bzero[at]) ep = EP_ZERO;
+            else {
+                // the running float sum at this block's start is within (members so far) half-ulps of Ps: the binade of the lower
+                // end, and whether the upper end is in the same one (then only one map is needed)
+                const double eps = (double)((uint64_t)b * WB + 1) * 5.9604644775390625e-08;
+                const double lo = fabs(Ps) * (1.0 - eps), hi = fabs(Ps) * (1.0 + eps);
+                float lf = (float)(lo > 0.0 ? lo : 0.0), hf = (float)hi;
+                if ((double)lf > lo) lf = __uint_as_float(__float_as_uint(lf) - 1u);
+                if ((double)hf < hi) hf = __uint_as_float(__float_as_uint(hf) + 1u);
+                const uint32_t e = (__float_as_uint(lf) >> 23) & 0xffu, eh = (__float_as_uint(hf) >> 23) & 0xffu;
+                ep = (e >= 1u && e <= 252u) ? (uint16_t)(e | (Ps < 0.0 ? 0x100u : 0u) | (eh == e ? EP_SINGLE : 0u)) : EP_NONE;
             }
-            if (have) {
-                uint16_t ep;
-                if (bz) ep = EP_ZERO;
-                else {
-                    // the running float sum at this block's start is within (members so far) half-ulps of Ps: the binade of the lower
-                    // end, and whether the upper end is in the same one (then only one map is needed)
-                    const double eps = (double)((uint64_t)b * WB + 1) * 5.9604644775390625e-08;
-                    const double lo = fabs(Ps) * (1.0 - eps), hi = fabs(Ps) * (1.0 + eps);
-                    float lf = (float)(lo > 0.0 ? lo : 0.0), hf = (float)hi;
-                    if ((double)lf > lo) lf = __uint_as_float(__float_as_uint(lf) - 1u);
-                    if ((double)hf < hi) hf = __uint_as_float(__float_as_uint(hf) + 1u);
-                    const uint32_t e = (__float_as_uint(lf) >> 23) & 0xffu, eh = (__float_as_uint(hf) >> 23) & 0xffu;
-                    ep = (e >= 1u && e <= 252u) ? (uint16_t)(e | (Ps < 0.0 ? 0x100u : 0u) | (eh == e ? EP_SINGLE : 0u)) : EP_NONE;
-                }
-                ws.epred[at] = ep;
-            }
-            P += __shfl(incl, 63, 64);
-            v = vn; bz = bzn;
+            ws.epred[at] = ep;
+        }
+        if (MODE != WM_COV) {   // (the sums are monotone: the blocks that qualify are a prefix of the list, the last of them carries the largest sum)
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) { ex_n += (uint32_t)__shfl_xor((int)ex_n, o, 64); ex_sum = fmax(ex_sum, __shfl_xor(ex_sum, o, 64)); }
+            if (lane == 0) { s_wcnt[wave] = ex_n; s_wmax[wave] = ex_sum; }
+            __syncthreads();
         }
         // Side / root chains add non-negative INTEGER-valued floats (value 0..3 times an integer weight). If the chain's total is below 2^24, every
         // partial sum of the sequential float chain is an integer below 2^24, i.e. exact: the chain's result is the total, in any order. (Block sums
         // are exact in double.) The other kernels of the pass skip such chains; the predictions written above are then never looked at.
-        const bool exact = MODE != WM_COV && P < 16777216.0;
-        if (lane == 0) { ctrl[ni].exact[c] = exact ? 1u : 0u; if (exact) ctrl[ni].sums[c] = (float)P; }
-        if (lane == 0) { ctrl[ni].start_block[c] = exact_blocks; ctrl[ni].start_sum[c] = (float)exact_sum; }
+        if (tid == 0) {
+            const bool exact = MODE != WM_COV && total < 16777216.0;
+            ctrl[ni].exact[c] = exact ? 1u : 0u; if (exact) ctrl[ni].sums[c] = (float)total;
+            const uint32_t exact_blocks = MODE != WM_COV ? s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3] : 0u;
+            const double exact_sum = MODE != WM_COV ? fmax(fmax(s_wmax[0], s_wmax[1]), fmax(s_wmax[2], s_wmax[3])) : 0.0;
+            ctrl[ni].start_block[c] = exact_blocks; ctrl[ni].start_sum[c] = (float)exact_sum;
+        }
         return;
     }
     // totals of the integer accumulators and the left-count prefix (block order)
@@ -819,7 +823,7 @@ static void launch_pass(hipStream_t st, const uint32_t* keys, const uint64_t* w6
                         uint32_t n_nodes, uint32_t tb, tsvq_wide_ctrl* ctrl, void* ws, tsvq_root_out* root_out, int windows_knob, bool all_chains_exact = false) {
     constexpr int NCH = mode_traits<MODE>::NCH;
     hipLaunchKernelGGL((k_wide_sums<MODE>), dim3(tb), dim3(WB), 0, st, keys, w64, perm0, perm1, side, nodes, n_nodes, ctrl, ws, tb, pk);
-    hipLaunchKernelGGL((k_wide_scan<MODE>), dim3(n_nodes, (NCH + 3) / 4 + (MODE == WM_COV ? 0 : 1)), dim3(256), 0, st, nodes, ctrl, ws, tb);
+    hipLaunchKernelGGL((k_wide_scan<MODE>), dim3(n_nodes, NCH + (MODE == WM_COV ? 0 : 1)), dim3(256), 0, st, nodes, ctrl, ws, tb);
     if (!(all_chains_exact && MODE != WM_COV)) {   // the caller knows that every chain total of the batch stays below 2^24: the scan finishes them all
         hipLaunchKernelGGL((k_wide_stretches<MODE>), dim3(tb), dim3(ST_THREADS), 0, st, keys, w64, pk, side, nodes, n_nodes, ctrl, ws, tb);
         // The pre-composed windows pay for nodes of millions of members (8192^2 q255, rounds 1-3: the covariance walk is 0.75 ms per round without them); for the

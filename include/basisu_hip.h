@@ -116,6 +116,7 @@ typedef struct bu_hip_tuning {
     uint32_t tsvq_poll;           /* BU_TSVQ_POLL          0      waiting for a round: 0 = spin when this is the process's only context, else yield / nap; 1 (spin) / 2 (yield) force it */
     uint32_t refine_unsorted;     /*                       0      1 = refine_endpoint_clusterization through the unsorted kernel (the one lists beyond 65,535 entries take anyway) */
     uint32_t debug;               /* BU_TSVQ_ROUNDS = 1 | BU_TSVQ_SERIAL = 2 | BU_TSVQ_STATS = 4: developer aids (round time line on stderr, one node per round, walk statistics) */
+    uint32_t tsvq_deep_levels;    /* BU_TSVQ_DEEP          0      deep rounds: generations of descendants of a round's one-workgroup nodes split in the same round trip (bu_hip_tsvq_split_deep); 0 = none, <= 2. Measured SLOWER at 4096^2 (17.4-18.0 against 16.8-17.6 ms per step: the rounds it saves cost ~50 us each, the splits nobody pops cost device time in rounds that fill the chip), hence off */
 } bu_hip_tuning;
 BU_HIP_API void bu_hip_get_tuning(const bu_hip_context* /* NULL: the process defaults */, bu_hip_tuning* out, uint32_t struct_bytes);
 BU_HIP_API int  bu_hip_set_tuning(bu_hip_context*, const bu_hip_tuning* /* NULL: back to the process defaults */);
@@ -314,6 +315,9 @@ BU_HIP_API int bu_hip_kmeans_codebook(bu_hip_context*, int kind, const void* d_k
  *     Node member lists live in two device index buffers: the root is {buf 0, start 0, count n}; a split of {buf, start, count}
  *     leaves its children at {buf^1, start, l_count} and {buf^1, start+l_count, r_count}. Member lists are ascending. */
 typedef struct bu_tsvq bu_tsvq;
+/* A node's member list is the span [start, start + count) of index buffer `buf` (0 .. BU_TSVQ_BUFFERS - 1); a split leaves the children's lists (left first) over the
+ * same span of buffer (buf + 1) % BU_TSVQ_BUFFERS. */
+#define BU_TSVQ_BUFFERS 4u
 typedef struct { float origin[16]; uint64_t weight; float var; uint32_t pad; } bu_tsvq_root;      /* prepare_root, enc.h:1708-1735 */
 typedef struct { uint32_t buf, start, count, pad; uint64_t weight; float origin[16]; } bu_tsvq_node;
 typedef struct { uint32_t ok, l_count, r_count, pad; uint64_t l_weight, r_weight; float l_var, r_var; float l_centroid[16], r_centroid[16]; } bu_tsvq_split;
@@ -339,6 +343,14 @@ BU_HIP_API int bu_hip_k_unique_endpoint_vectors(bu_hip_context*, const void* d_e
 BU_HIP_API int bu_hip_k_unique_selector_vectors(bu_hip_context*, const void* d_enc_blocks, const uint64_t* d_weights, uint32_t n_blocks, uint32_t* d_sorted_block_idx,
                                                 uint32_t* d_unique_keys, uint64_t* d_unique_weights, uint32_t* d_group_offsets, uint32_t* out_unique);
 BU_HIP_API int  bu_hip_tsvq_split(bu_hip_context*, bu_tsvq*, const bu_tsvq_node* h_nodes, uint32_t n_nodes, bu_tsvq_split* h_out); /* synchronises */
+/* A DEEP round: the same, and in the same round trip the splits of the children, grandchildren, ... (`levels` generations, <= BU_TSVQ_BUFFERS - 2) of every node of the batch that went
+ * through the one-workgroup kernel -- a split is a pure function of its node, so the caller's replay of the reference's variance queue (enc.h:1636-1655) finds them
+ * when it gets there instead of asking for another round; what it never reaches is dropped. Each generation's node records are made ON THE DEVICE from the results of
+ * the one before. A descendant is attempted when its parent's split succeeded, it has more than one member, and its variance (with the reference's 1e-4 for a
+ * non-positive variance, enc.h:1766-1792) is positive and not below the float whose bits the caller put into h_nodes[i].pad (0 = no floor): a bound on the
+ * speculation, never on the result. h_deep: (2^(levels+1) - 2) * n_nodes records; generation g = 1..levels of batch node i, path p (the sides taken, 0 = left, the
+ * first step in the top bit of g bits) at h_deep[n_nodes * (2^g - 2) + i * 2^g + p]; ok == 3 there = not attempted. Synchronises. */
+BU_HIP_API int  bu_hip_tsvq_split_deep(bu_hip_context*, bu_tsvq*, const bu_tsvq_node* h_nodes, uint32_t n_nodes, bu_tsvq_split* h_out, uint32_t levels, bu_tsvq_split* h_deep);
 /* prepare_root (enc.h:1708-1735) of n_nodes member spans (buf / start / count of each record; weight and origin are not read): the root records of the
  * independent trees the reference's multi-threaded codebook build runs over the leaves of its first tree (enc.h:2137-2152). Synchronises. */
 BU_HIP_API int  bu_hip_tsvq_roots(bu_hip_context*, bu_tsvq*, const bu_tsvq_node* h_nodes, uint32_t n_nodes, bu_tsvq_root* h_out);

@@ -109,7 +109,7 @@ WIDE_CASES = [(5000, 300, 32, "sel", 50, 512), (120000, 2731, 32, "sel", 4096, 5
 
 
 @pytest.mark.parametrize("n,k,p,kind,wmax,wide_min", WIDE_CASES)
-def test_wide_nodes_match_host_tsvq(hip_ctx, monkeypatch, n, k, p, kind, wmax, wide_min):
+def test_wide_nodes_match_host_tsvq(hip_ctx, request, n, k, p, kind, wmax, wide_min):
     """Large nodes spread over many workgroups (tsvq_wide_kernels.hip: order-preserving float sums through per-block parity maps) must
     give the tree of the sequential sums, member list for member list: against the host restatement tsvq.h (pinned to the reference in
     tests/test_host_logic.py), against the one-workgroup kernels (tsvq_wide_min = 0), and against the reference itself where present."""
@@ -131,11 +131,14 @@ def test_wide_nodes_match_host_tsvq(hip_ctx, monkeypatch, n, k, p, kind, wmax, w
         w[: 256 * 40] = 65536
         w[256 * 40: 256 * 44] = 1 << 20
     cap = 4 * n + 4 * k + 100
-    outs = {}
+    outs = {}; rounds = {}
     # wide: every pass through the parity maps; hybrid: the covariance pass of all but the largest nodes chained (the default)
     # + windows: the walk takes 64 blocks at a time where their pre-composed map applies (k_wide_windows; on by itself only for nodes of millions of members)
+    # deep1 / deep2: one / two generations of descendants split in the same round trip (bu_hip_tsvq_split_deep; off by default)
+    request.addfinalizer(hip_ctx.set_tuning)   # the session's context back to the process defaults, whatever happens below
     for name, knobs in (("wide", dict(tsvq_wide_min=wide_min, tsvq_wide_cov_min=0, tsvq_windows=2)), ("hybrid", dict(tsvq_wide_min=wide_min)),
-                        ("windows", dict(tsvq_wide_min=wide_min, tsvq_wide_cov_min=0, tsvq_windows=1)), ("narrow", dict(tsvq_wide_min=0))):
+                        ("windows", dict(tsvq_wide_min=wide_min, tsvq_wide_cov_min=0, tsvq_windows=1)), ("narrow", dict(tsvq_wide_min=0)),
+                        ("deep2", dict(tsvq_wide_min=wide_min, tsvq_deep_levels=2)), ("deep1", dict(tsvq_wide_min=wide_min, tsvq_deep_levels=1))):
         if name == "narrow" and n > 200000:
             continue
         hip_ctx.set_tuning(**knobs)   # bu_hip_set_tuning (include/basisu_hip.h): which of the bit-identical paths the trees built on this context take
@@ -143,7 +146,9 @@ def test_wide_nodes_match_host_tsvq(hip_ctx, monkeypatch, n, k, p, kind, wmax, w
         assert F.bu_device_tsvq(hip_ctx.h, 16, v.ctypes.data_as(VP), w.ctypes.data_as(VP), n, k, p, a.ctypes.data_as(VP), cap, b.ctypes.data_as(VP), cap,
                                 st.ctypes.data_as(VP)) == 1
         outs[name] = (a, b)
-    hip_ctx.set_tuning()   # the session's context back to the process defaults
+        rounds[name] = int(st[0])
+    hip_ctx.set_tuning()
+    assert rounds["deep2"] <= rounds["hybrid"] and (n < 2000 or rounds["deep2"] < rounds["hybrid"]), rounds   # deep rounds: fewer round trips
     a1 = np.zeros(cap, np.uint32); b1 = np.zeros(cap, np.uint32)
     assert F.bu_host_tsvq(16, v.ctypes.data_as(VP), w.ctypes.data_as(VP), n, k, p, a1.ctypes.data_as(VP), cap, b1.ctypes.data_as(VP), cap) == 1
     for name, (a, b) in outs.items():
@@ -178,7 +183,7 @@ WIDE6_CASES = [(40000, 2416, 16, "ep", 3, 512), (40000, 2416, 16, "ep", 3, 6144)
 
 
 @pytest.mark.parametrize("n,k,p,kind,wmax,wide_min", WIDE6_CASES)
-def test_wide6_nodes_match_host_tsvq(hip_ctx, monkeypatch, n, k, p, kind, wmax, wide_min):
+def test_wide6_nodes_match_host_tsvq(hip_ctx, request, n, k, p, kind, wmax, wide_min):
     """The endpoint tree's large nodes through the many-workgroup path for 6-float rows (tsvq_wide6_kernels.hip): the tree of the sequential sums, member list for
     member list -- against the host restatement, against the one-workgroup kernels (tsvq_wide6_min = 0) and against the reference where present. The dark cases are built
     for the double accumulators' block test (tiny addends under large sums, weights up to 2^34: blocks that must be added member by member), the 2^50 weights for the
@@ -193,7 +198,9 @@ def test_wide6_nodes_match_host_tsvq(hip_ctx, monkeypatch, n, k, p, kind, wmax, 
         w[rng.random(n) < 0.7] = 1   # most weights small, a few enormous
     cap = 4 * n + 4 * k + 100
     outs = {}
-    for name, knobs in (("wide6", dict(tsvq_wide6_min=wide_min)), ("narrow", dict(tsvq_wide6_min=0))):
+    request.addfinalizer(hip_ctx.set_tuning)
+    for name, knobs in (("wide6", dict(tsvq_wide6_min=wide_min)), ("narrow", dict(tsvq_wide6_min=0)), ("deep2", dict(tsvq_wide6_min=wide_min, tsvq_deep_levels=2)),
+                        ("narrow_deep1", dict(tsvq_wide6_min=0, tsvq_deep_levels=1))):
         hip_ctx.set_tuning(**knobs)
         a = np.zeros(cap, np.uint32); b = np.zeros(cap, np.uint32); st = np.zeros(3, np.uint32)
         assert F.bu_device_tsvq(hip_ctx.h, 6, v.ctypes.data_as(VP), w.ctypes.data_as(VP), n, k, p, a.ctypes.data_as(VP), cap, b.ctypes.data_as(VP), cap,
