@@ -274,14 +274,20 @@ void bu_hip_deinit(void) {
 
 int bu_hip_is_available(void) { return g_initialized ? 1 : 0; }
 
-bu_hip_context* bu_hip_create_context_on(int device) {
+// A parked context keeps its stream, and with it the KIND of queue the stream sits on: the lanes of a UASTC pipeline run on hardware queues of their own (dedicated_queue),
+// everybody else on the runtime's pooled ones -- ETC1S frontend jobs measured 15-20 % slower with every context on its own queue. So a caller gets a parked context of
+// the kind it asks for: the public create calls never a dedicated-queue one, the UASTC pipeline those first.
+static bu_hip_context* create_context_kind(int device, bool want_dedicated) {
     if (!g_initialized) { set_error(nullptr, "bu_hip_create_context: bu_hip_init() has not succeeded"); return nullptr; }
     if (device < 0 || device >= g_device_count) { set_error(nullptr, "bu_hip_create_context: bad device %d", device); return nullptr; }
     if (hipSetDevice(device) != hipSuccess) { set_error(nullptr, "hipSetDevice(%d) failed", device); return nullptr; }
     {
         std::lock_guard<std::mutex> g(g_park_lock);
-        for (size_t i = 0; i < g_parked.size(); i++)
-            if (g_parked[i]->device == device) { bu_hip_context* c = g_parked[i]; g_parked.erase(g_parked.begin() + (long)i); g_live_contexts.fetch_add(1); return c; }
+        for (int pass = 0; pass < (want_dedicated ? 2 : 1); pass++)   // (a lane that finds no parked context of its own kind takes a pooled one and moves it onto a queue of its own)
+            for (size_t i = 0; i < g_parked.size(); i++)
+                if (g_parked[i]->device == device && g_parked[i]->dedicated_queue == (want_dedicated && pass == 0)) {
+                    bu_hip_context* c = g_parked[i]; g_parked.erase(g_parked.begin() + (long)i); g_live_contexts.fetch_add(1); return c;
+                }
     }
     bu_hip_context* ctx = new (std::nothrow) bu_hip_context();
     if (!ctx) return nullptr;
@@ -295,6 +301,8 @@ bu_hip_context* bu_hip_create_context_on(int device) {
     g_live_contexts.fetch_add(1);
     return ctx;
 }
+
+bu_hip_context* bu_hip_create_context_on(int device) { return create_context_kind(device, false); }
 
 bu_hip_context* bu_hip_create_context(void) {
     int dev = 0;
@@ -1731,7 +1739,7 @@ bu_uastc_pipeline* bu_hip_uastc_pipeline_create(bu_hip_context* ctx, uint32_t la
     // every workspace at its final size now: growing one later would free it under the kernels of an earlier submission
     const size_t ws_bytes = std::max(bu::uastc_workspace_bytes(max_blocks, flags), bu::uastc_rdo_workspace_bytes(max_blocks, max_total_jobs));
     for (auto& l : p->lanes) {
-        l.ctx = bu_hip_create_context_on(ctx->device);
+        l.ctx = create_context_kind(ctx->device, true);
         if (l.ctx) {
             l.ctx->tuning = ctx->tuning;   // the lanes take the paths their parent context is set to
             // The runtime maps ordinary streams onto its few shared hardware queues (GPU_MAX_HW_QUEUES) by how many streams each queue already carries -- history, as far

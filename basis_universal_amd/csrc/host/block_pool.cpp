@@ -7,6 +7,12 @@
 // come from a recycling pool of page-aligned mappings (advised to use huge pages), everything smaller goes to malloc untouched. The operators are LOCAL to
 // this library (the link hides them: csrc/host/exports.map + -Bsymbolic), so nobody else's allocations change; the library's C ABI never hands out or takes
 // ownership of C++ objects, so every block is freed by the operator delete that sits next to the operator new it came from.
+// INVARIANT the local operators rest on: a block is freed by the module that allocated it. That holds for everything this library allocates large -- std::vector and
+// plain arrays are header-only code, instantiated here on both ends. It would NOT hold for a std::string (or stream buffer) of a megabyte and more: libstdc++ keeps
+// out-of-line instantiations of those (regrowing one there would free a pooled block with glibc's free). The library builds no such string -- its strings are error
+// texts and names -- and must not start to.
+// What the pool keeps is visible as resident memory of the host process until it is given back: bu_host_pool_trim() unmaps every cached block (a host that encodes in
+// bursts calls it between them); the cap bounds it at any time.
 // Environment, read once: BU_HOST_POOL_MB = most megabytes kept cached (default 6144; 0 switches the pool off).
 #include <sys/mman.h>
 
@@ -148,6 +154,23 @@ inline void pool_delete(void* p) {
 }
 
 } // namespace
+
+// Gives every cached block back to the kernel (blocks in use are not touched; later frees are cached again up to the cap). Returns the bytes released.
+extern "C" __attribute__((visibility("default"))) uint64_t bu_host_pool_trim(void) {
+    pool& P = the_pool();
+    free_block* chain = nullptr;
+    uint64_t bytes = 0;
+    {
+        std::lock_guard<std::mutex> g(P.m);
+        for (int c = 0; c < kClasses; c++) {
+            while (free_block* b = P.free_list[c]) { P.free_list[c] = b->next; b->next = chain; chain = b; }
+        }
+        bytes = P.cached_bytes;
+        P.cached_bytes = 0;
+    }
+    while (chain) { free_block* b = chain; chain = b->next; munmap(b, b->mapped); }   // (outside the lock: unmapping gigabytes takes a while)
+    return bytes;
+}
 
 extern "C" __attribute__((visibility("default"))) void bu_host_pool_stats(uint64_t out[4]) {
     pool& P = the_pool();

@@ -131,6 +131,9 @@ void run_job(lane& l) {
     j->ctx = bu_hip_create_context_on(p->device);   // a parked context comes back warm (its pools, arenas, pinned rings, streams)
     if (!j->ctx) { const char* e = bu_hip_last_error(nullptr); j->error = e ? e : "bu_hip_create_context_on failed"; return; }
     bu_hip_set_wait_hook(j->ctx, lane_yield, &l);
+    // However this task ends -- normally, or through an exception that lane_entry turns into a failed job -- the hook comes off the context: the lane goes on to another
+    // job, and whoever waits for the ticket (or frees the failed job) uses the context from a thread of its own with ordinary blocking calls.
+    struct unhook { bu_hip_context* c; ~unhook() { bu_hip_set_wait_hook(c, nullptr, nullptr); } } unhook_guard{j->ctx};
     j->fe = bu_frontend_create();
     bool ok = j->fe != nullptr;
     if (ok && (j->d.flags & BU_FRONTEND_JOB_VIDEO)) ok = bu_frontend_set_video(j->fe, 1) != 0;
@@ -142,8 +145,7 @@ void run_job(lane& l) {
         j->error = j->fe ? bu_frontend_error(j->fe) : "bu_frontend_create failed";
         if (j->error.empty()) j->error = bu_last_exception_text;
     }
-    bu_hip_set_wait_hook(j->ctx, nullptr, nullptr);   // from here on the frontend and its context belong to whoever waits for the ticket: ordinary blocking calls
-    j->ok = ok;
+    j->ok = ok;   // (from here on the frontend and its context belong to whoever waits for the ticket)
     j->t_done = now_s();
 }
 
@@ -318,6 +320,9 @@ uint64_t bu_frontend_pipeline_submit(bu_frontend_pipeline* p, const bu_frontend_
     job* j = new job();
     std::memcpy(&j->d, d, std::min<size_t>(struct_bytes, sizeof(j->d)));   // fields a caller's older header does not have stay 0
     if (!j->d.n_blocks || (!j->d.h_blocks == !j->d.d_blocks)) { delete j; bu_last_exception_text = "bu_frontend_pipeline_submit: exactly one of h_blocks / d_blocks, n_blocks > 0"; return 0; }
+    if (j->d.flags & ~(uint32_t)BU_FRONTEND_JOB_VIDEO) {   // unknown bits are refused, not ignored (the top one is the library's own self-test task: only bu_frontend_pipeline_selftest sets it)
+        delete j; bu_last_exception_text = "bu_frontend_pipeline_submit: unknown bits in bu_frontend_job::flags"; return 0;
+    }
     j->t_submit = now_s();
     {
         std::lock_guard<std::mutex> g(p->m);

@@ -336,14 +336,23 @@ private:
                 std::vector<bu_tsvq_node> my_nodes;
                 for (uint32_t i : my_idx) my_nodes.push_back(batch[i]);
                 std::vector<bu_tsvq_split> my_out(my_nodes.size());
-                if (!my_nodes.empty() && !bu_hip_tsvq_split(ctx, q, my_nodes.data(), (uint32_t)my_nodes.size(), my_out.data())) return false;
-                std::vector<bu_tsvq_split> rec(batch.size());
+                // A rank whose own share fails must still enter the collective -- the others are on their way into it -- and everybody must learn of the failure: one more
+                // (zero-member) entry behind the batch is everybody's, and its record carries an error word that the sum turns into "how many ranks failed".
+                const bool local_ok = my_nodes.empty() || bu_hip_tsvq_split(ctx, q, my_nodes.data(), (uint32_t)my_nodes.size(), my_out.data()) != 0;
+                const size_t nb = batch.size();
+                std::vector<bu_tsvq_split> rec(nb + 1);
                 std::memset(rec.data(), 0, rec.size() * sizeof(bu_tsvq_split));
-                for (size_t j = 0; j < my_idx.size(); j++) { rec[my_idx[j]] = my_out[j]; rec[my_idx[j]].pad = 0; }
+                if (local_ok) for (size_t j = 0; j < my_idx.size(); j++) { rec[my_idx[j]] = my_out[j]; rec[my_idx[j]].pad = 0; }
+                rec[nb].pad = local_ok ? 0u : 1u;
+                std::vector<bu_tsvq_node> xnodes(batch);
+                { bu_tsvq_node z; std::memset(&z, 0, sizeof(z)); xnodes.push_back(z); }
+                mine.push_back(1);
                 void* d_staging = nullptr; uint64_t n_u64 = 0;
-                if (!bu_hip_tsvq_exchange_pack(ctx, q, batch.data(), mine.data(), rec.data(), (uint32_t)batch.size(), &d_staging, &n_u64)) return false;
+                if (!bu_hip_tsvq_exchange_pack(ctx, q, xnodes.data(), mine.data(), rec.data(), (uint32_t)xnodes.size(), &d_staging, &n_u64)) return false;   // (the device itself is gone: nothing to enter the collective with)
                 if (!comm->all_reduce_u64(comm->user, d_staging, n_u64)) return false;
-                if (!bu_hip_tsvq_exchange_unpack(ctx, q, batch.data(), mine.data(), cache.data() + base, (uint32_t)batch.size())) return false;
+                if (!bu_hip_tsvq_exchange_unpack(ctx, q, xnodes.data(), mine.data(), rec.data(), (uint32_t)xnodes.size())) return false;
+                if (rec[nb].pad != 0) return false;   // some rank's share failed: every rank fails this round together
+                std::memcpy(cache.data() + base, rec.data(), nb * sizeof(bu_tsvq_split));
                 local.t_device += secs(td, now());
             } else if (dbg_serial) { // debug: one node per launch
                 for (size_t i = 0; i < batch.size(); i++)
@@ -393,7 +402,9 @@ private:
     // the per-round exchange uses (bu_hip_tsvq_exchange_pack / _unpack): per tree one pseudo-node per member buffer over its span, {buf b - 1} for the list in
     // buffer b ("a node's children live in the next buffer"); the serialised node tables ride in the record slots of zero-member pseudo-nodes
     // behind them (a table's region is a whole number of records, so a record has one owner).
-    static bool exchange_trees(bu_hip_context* ctx, bu_tsvq* q, const bu_comm* comm, std::vector<tree>& subs, const std::vector<bu_tsvq_node>& spans, const std::vector<uint32_t>& owner) {
+    // local_ok = false: this rank's own trees failed -- it still takes part (the others are waiting in the collective) and everybody returns false.
+    static bool exchange_trees(bu_hip_context* ctx, bu_tsvq* q, const bu_comm* comm, std::vector<tree>& subs, const std::vector<bu_tsvq_node>& spans, const std::vector<uint32_t>& owner,
+                               bool local_ok = true) {
         static_assert(std::is_trivially_copyable<node>::value, "node tables are exchanged as bytes");
         const size_t rec = sizeof(bu_tsvq_split), T = subs.size();
         struct table_header { uint32_t n_nodes, leaves, next_codebook_index, pad; };
@@ -406,7 +417,7 @@ private:
         }
         rec_first[T] = n_rec;
         constexpr size_t B = BU_TSVQ_BUFFERS;
-        std::vector<bu_tsvq_node> nodes(B * T + n_rec);
+        std::vector<bu_tsvq_node> nodes(B * T + n_rec + 1);   // + the error word's entry (everybody's)
         std::memset(nodes.data(), 0, nodes.size() * sizeof(bu_tsvq_node));
         std::vector<uint8_t> mine(nodes.size(), 0);
         std::vector<bu_tsvq_split> recs(nodes.size());
@@ -419,7 +430,7 @@ private:
                 mine[B * t + b] = my ? 1 : 0;
             }
             for (size_t r = rec_first[t]; r < rec_first[t + 1]; r++) mine[B * T + r] = my ? 1 : 0;
-            if (!my) continue;
+            if (!my || !local_ok) continue;
             const tree& tr = subs[t];
             if (sizeof(table_header) + tr.nodes.size() * sizeof(node) > (rec_first[t + 1] - rec_first[t]) * rec) return false;   // cannot happen: 2 L - 1 nodes
             table_header h{(uint32_t)tr.nodes.size(), tr.leaves, tr.next_codebook_index, 0};
@@ -427,11 +438,13 @@ private:
             std::memcpy(at, &h, sizeof(h));
             std::memcpy(at + sizeof(h), tr.nodes.data(), tr.nodes.size() * sizeof(node));
         }
+        mine[B * T + n_rec] = 1; recs[B * T + n_rec].pad = local_ok ? 0u : 1u;   // the last entry
         void* d_staging = nullptr; uint64_t n_u64 = 0;
         if (!bu_hip_tsvq_exchange_pack(ctx, q, nodes.data(), mine.data(), recs.data(), (uint32_t)nodes.size(), &d_staging, &n_u64)) return false;
         if (!comm->stream_ordered && !bu_hip_sync(ctx)) return false;
         if (!comm->all_reduce_u64(comm->user, d_staging, n_u64)) return false;
         if (!bu_hip_tsvq_exchange_unpack(ctx, q, nodes.data(), mine.data(), recs.data(), (uint32_t)nodes.size())) return false;
+        if (recs[B * T + n_rec].pad != 0) return false;   // a rank's trees failed: all ranks fail together
         blob = reinterpret_cast<char*>(recs.data() + B * T);
         for (size_t t = 0; t < T; t++) {
             if (owner[t] == comm->rank) continue;
@@ -517,9 +530,9 @@ private:
                     }
                     std::vector<tree*> mine;
                     for (size_t t = 0; t < subs.size(); t++) if (owner[t] == comm->rank) mine.push_back(&subs[t]);
-                    if (!mine.empty() && !run_trees(ctx, q, mine, cache, kid, local, nullptr, dbg_serial, dbg_verify, deep_levels)) return false;
+                    const bool mine_ok = mine.empty() || run_trees(ctx, q, mine, cache, kid, local, nullptr, dbg_serial, dbg_verify, deep_levels);
                     const auto tx = now();
-                    if (!exchange_trees(ctx, q, comm, subs, spans, owner)) return false;
+                    if (!exchange_trees(ctx, q, comm, subs, spans, owner, mine_ok)) return false;
                     local.t_device += secs(tx, now());
                 } else if (!run_trees(ctx, q, active, cache, kid, local, comm, dbg_serial, dbg_verify, deep_levels)) return false;
             }

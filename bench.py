@@ -112,6 +112,14 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     red_dev = torch.device("cpu") if gloo else dev   # where the max-over-ranks of the timings is taken
+    # The line is self-verifying for N > 1: how many ranks the process group really connected (one all-reduce of 1 per rank, over RCCL when the backend is nccl),
+    # and below the same through the communicator the sharded frontend uses (the native bu_comm of libbasisu_rccl.so, or torch's under gloo)
+    comm_check = None
+    if world > 1:
+        one = torch.ones(1, dtype=torch.int64, device=red_dev)
+        dist.all_reduce(one)
+        comm_check = {"process_group_backend": "gloo (ranks may share a GPU: the one-GPU test path)" if gloo else "nccl (= RCCL)", "world_size": world,
+                      "ranks_seen": int(one.item()), "devices": torch.cuda.device_count()}
 
     # ---- synthetic input (SURVEY 8d recipe), tiled on the host once, resident in HBM before the timed region
     w = h = args.size
@@ -126,11 +134,20 @@ def main():
     # run on torch's current stream so that torch.cuda.synchronize()/Events bracket our kernels
     ctx.check(ctx.lib.set_stream(ctx.h, torch.cuda.current_stream().cuda_stream), "set_stream")
 
+    def make_comm():
+        """the communicator of the sharded mode: native RCCL (C++ collectives on the context's stream); BU_TORCH_COMM=1 or gloo go through torch.distributed instead.
+        Returns it with the number of ranks ONE all_reduce_u64 of 1 through it saw."""
+        from basis_universal_amd.etc1s import TorchComm, RcclComm
+        c = TorchComm() if (gloo or os.environ.get("BU_TORCH_COMM")) else RcclComm(ctx)
+        t = torch.ones(1, dtype=torch.int64, device=dev)
+        ok = c.struct.all_reduce_u64(c.struct.user, t.data_ptr(), 1)
+        torch.cuda.synchronize()
+        return c, (int(t.item()) if ok else 0), ("torch.distributed" if isinstance(c, TorchComm) else "bu_rccl (libbasisu_rccl.so: ncclAllReduce on the context's stream)")
+
     comm = None
     if sharded:
-        # the native RCCL communicator (C++ collectives on the context's stream); BU_TORCH_COMM=1 goes through torch.distributed instead
-        from basis_universal_amd.etc1s import TorchComm, RcclComm
-        comm = TorchComm() if (gloo or os.environ.get("BU_TORCH_COMM")) else RcclComm(ctx)
+        comm, seen, kind = make_comm()
+        comm_check.update({"sharding_communicator": kind, "sharding_communicator_ranks_seen": seen})
 
     def step():
         fe = Etc1sFrontend(ctx, comm)
@@ -292,6 +309,61 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # ---- N > 1: BOTH modes in the same line. The headline is the mode asked for (default: one image per GPU, the throughput mode); the other one is measured
+    #      here with the same steps / barrier / max-over-ranks rule, the sharded one with its per-stage split, so that DESIGN.md section 7's estimates are checked by the
+    #      first run on a multi-GPU node.
+    both_modes = None
+    if world > 1 and args.streams <= 1:
+        def mode_leg(shard):
+            if shard:
+                c, seen, kind = (comm, comm_check.get("sharding_communicator_ranks_seen"), comm_check.get("sharding_communicator")) if comm is not None else make_comm()
+                blk = d_blocks if (sharded or rank == 0) else torch.from_numpy(helpers.to_pixel_blocks(helpers.synth(w, h, 1234)).reshape(n_blocks, 64)).to(dev)
+            else:
+                c, seen, kind = None, None, None
+                blk = d_blocks if (not sharded or rank == 0) else torch.from_numpy(helpers.to_pixel_blocks(helpers.synth(w, h, 1234 + rank)).reshape(n_blocks, 64)).to(dev)
+
+            def one():
+                fe = Etc1sFrontend(ctx, c)
+                fe.init(blk.data_ptr(), max_ep, max_sel, args.level, True, n_blocks=n_blocks)
+                fe.compress()
+                return fe
+            one().close()
+            calls0 = dict(getattr(c, "calls", {}) or {})
+            acc, fe = {}, None
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                if fe is not None:
+                    fe.close()
+                fe = one()
+                for name, sec in fe.stage_times():
+                    acc[name] = acc.get(name, 0.0) + sec
+            barrier()
+            tt = torch.tensor([time.perf_counter() - t0], device=red_dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+            leg = {"value": round((1 if shard else world) * args.steps * (w * h) / 1e6 / dt, 3), "unit": "Mpixels/s", "ms_per_step": round(dt / args.steps * 1e3, 2),
+                   "scaling": "strong" if shard else "weak"}
+            if shard:
+                leg.update({"communicator": kind, "communicator_ranks_seen": seen, "host_wall_s_per_step": stage_split(acc, args.steps),
+                            "identical_to_reference": headline_identical(fe, w, h, args) if rank == 0 else None})
+                if calls0 or getattr(c, "calls", None):
+                    leg["collectives_per_step"] = {k: round((c.calls[k] - calls0.get(k, 0)) / args.steps, 1) for k in c.calls}
+            fe.close()
+            if shard and comm is None and hasattr(c, "close"):
+                c.close()
+            return leg
+        other = mode_leg(not sharded)
+        mine = {"value": round((1 if sharded else world) * args.steps * (w * h) / 1e6 / elapsed, 3), "unit": "Mpixels/s", "ms_per_step": round(elapsed / args.steps * 1e3, 2),
+                "scaling": "strong" if sharded else "weak", "is_the_headline": True}
+        if sharded:
+            mine.update({"communicator": comm_check.get("sharding_communicator"), "communicator_ranks_seen": comm_check.get("sharding_communicator_ranks_seen"),
+                         "host_wall_s_per_step": stage_split(stage_acc, args.steps)})
+            if getattr(comm, "calls", None):
+                mine["collectives_total"] = dict(comm.calls)
+        both_modes = {"replicas (one image per GPU, no data-path collective)": other if sharded else mine,
+                      "one image sharded over the ranks (--shard-image)": mine if sharded else other}
+
     if rank == 0:
         mpix = (1 if sharded else world) * args.steps * (w * h) / 1e6
         value = mpix / elapsed
@@ -333,6 +405,8 @@ def main():
                        "images_in_flight_per_gpu": args.streams, "host_threads_per_rank": int(os.environ.get("BU_HOST_THREADS", "8")), "host_cpus": host_cpus(),
                        "parallelism": (f"one image sharded over {world} GPUs: block-row slabs + cluster shares, RCCL all_gather / all_reduce between stages, TSVQ replicated"
                                        if sharded else f"{world} x one image per GPU (no collective)")},
+            "comm": comm_check,
+            "both_modes": both_modes,
             "roofline": roofline,
             "step_roofline": step_roofline,
             "dominant_stage": dom_stage,
@@ -395,6 +469,17 @@ def main():
 PIPELINE_LANES = 8      # images in flight of the `pipelined` leg ...
 PIPELINE_DRIVERS = 2    # ... over this many driver threads (side by side on one box, 4096^2: 4 / 6 / 8 lanes on 1 / 1 / 2 threads = 1,402 / 1,564 / 1,801 Mpix/s; a host thread
                         # per image, 4 / 6 in flight: 1,703 / 1,837 at three times the host CPU: docs/HISTORY.md R5.10)
+
+
+def stage_split(acc, steps):
+    """The sharded step's host wall time by kind of stage (bu_frontend_stage_times: every stage ends with its results in place, collectives included): the codebook
+    builders (top tree / node shares per round or whole trees per rank + their exchanges: the part DESIGN.md section 7 calls serial) against the slab / cluster-share
+    stages. ('~gsc/...' entries are parts of generate_selector_clusters and are not counted twice.)"""
+    top = {k: v for k, v in acc.items() if not k.startswith("~")}
+    builders = ("generate_endpoint_clusters", "generate_selector_clusters")
+    return {"codebook_builders": round(sum(v for k, v in top.items() if k in builders) / steps, 5),
+            "slab_and_cluster_share_stages": round(sum(v for k, v in top.items() if k not in builders) / steps, 5),
+            "by_stage": {k: round(v / steps, 5) for k, v in acc.items()}}
 
 
 def pipelined_bench(device, d_blocks, n_blocks, w, h, max_ep, max_sel, args, barrier, lanes=PIPELINE_LANES, drivers=PIPELINE_DRIVERS):

@@ -128,6 +128,9 @@ BU_HIP_API int bu_frontend_pipeline_selftest(uint32_t lanes, uint32_t tasks, uin
  * being mapped and unmapped per image (csrc/host/block_pool.cpp): local to this library -- the process's malloc is left alone. BU_HOST_POOL_MB (read once) = most
  * megabytes kept cached, default 6144, 0 = off. out = {mappings made, blocks reused, bytes cached now, cap in bytes}. */
 BU_HIP_API void bu_host_pool_stats(uint64_t out[4]);
+/* Gives every block the pool has cached back to the kernel (what it keeps is resident memory of the host process: a host that encodes in bursts calls this between
+ * them). Blocks in use are not touched. Returns the bytes released. */
+BU_HIP_API uint64_t bu_host_pool_trim(void);
 
 /* basis_compressor::process_frontend's quality -> codebook size mapping (comp.cpp:3325-3379). */
 BU_HIP_API void bu_etc1s_quality_to_clusters(int quality_level, uint32_t total_blocks, uint32_t* max_endpoint_clusters, uint32_t* max_selector_clusters);

@@ -241,6 +241,41 @@ bool basisu_frontend::compress() {
         e.m_valid = p[4] != 0;
         e.m_color_used[0] = !m_endpoint_clusters[i].empty();        // finalize (frontend.cpp:2980-2992)
     }
+    if (m_params.m_validate && !validate_output()) {   // frontend.cpp:305-311 (there a failed check aborts; here compress() fails and the compressor reports it)
+        error_printf("basisu_frontend (resident): the state the device left does not pass validate_output\n");
+        return false;
+    }
+    return true;
+}
+
+// m_params.m_validate (frontend.h:103, frontend.cpp:3282-3338): the delivered state must be self-consistent -- every output block is the ETC1S block its endpoint cluster's
+// (colour5, table) and its selector cluster's selectors make, it is listed by that selector cluster, and the clusters it names exist and are in use. A restatement over the
+// members the getters serve; the mid-run checks of the reference's CPU stages (frontend.cpp:184-256) have no counterpart, the stages run on the device.
+bool basisu_frontend::validate_output() const {
+    const uint32_t n_ep = (uint32_t)m_endpoint_cluster_etc_params.size(), n_sel = (uint32_t)m_optimized_cluster_selectors.size();
+    if (m_encoded_blocks.size() != m_total_blocks || m_block_endpoint_clusters_indices.size() != m_total_blocks || m_block_selector_cluster_index.size() != m_total_blocks ||
+        m_selector_cluster_block_indices.size() != n_sel || m_endpoint_clusters.size() != n_ep)
+        return false;
+    std::vector<uint8_t> listed(m_total_blocks, 0);
+    for (uint32_t s = 0; s < n_sel; s++)
+        for (uint32_t b : m_selector_cluster_block_indices[s]) {
+            if (b >= m_total_blocks || m_block_selector_cluster_index[b] != s || listed[b]) return false;   // listed once, by the cluster the block names
+            listed[b] = 1;
+        }
+    for (uint32_t b = 0; b < m_total_blocks; b++) {
+        const etc_block& out = m_encoded_blocks[b];
+        const uint32_t e0 = m_block_endpoint_clusters_indices[b][0], e1 = m_block_endpoint_clusters_indices[b][1], sc = m_block_selector_cluster_index[b];
+        if (!listed[b] || e0 != e1 || e0 >= n_ep || sc >= n_sel || !out.get_flip_bit() || !out.get_diff_bit()) return false;
+        const endpoint_cluster_etc_params& ep = m_endpoint_cluster_etc_params[e0];
+        if (!ep.m_color_used[0]) return false;
+        etc_block want;
+        std::memset(&want, 0, sizeof(want));
+        want.set_flip_bit(true); want.set_diff_bit(true);
+        if (!want.set_block_color5_check(ep.m_color_unscaled[0], ep.m_color_unscaled[0])) return false;
+        want.set_inten_table(0, ep.m_inten_table[0]); want.set_inten_table(1, ep.m_inten_table[0]);
+        want.set_raw_selector_bits(m_optimized_cluster_selectors[sc].get_raw_selector_bits());
+        if (std::memcmp(&want, &out, sizeof(etc_block)) != 0) return false;
+    }
     return true;
 }
 
@@ -252,12 +287,21 @@ void basisu_frontend::reoptimize_remapped_endpoints(const uint_vec& new_block_en
     if (!f || new_block_endpoints.size() != m_total_blocks ||
         !bu_frontend_reoptimize_remapped_endpoints(f, new_block_endpoints.data(), m_total_blocks, old_to_new_endpoint_cluster_indices.data(), k, optimize_final_codebook,
                                                    pBlock_selector_indices ? pBlock_selector_indices->data() : nullptr)) {
-        error_printf("basisu_frontend (resident): reoptimize_remapped_endpoints failed: %s\n", f ? bu_frontend_error(f) : "no frontend");
-        abort();   // the reference's own contract for internal failures (frontend.cpp:45-49)
+        // A device error in the middle of the backend. The signature is the reference's (void): what can be done without taking the host process down (the reference aborts
+        // on internal invariants only, frontend.cpp:45-49) is to leave the frontend as it was, hand the caller the identity map -- the file it then writes is a valid one
+        // whose merged endpoint clusters were not re-fitted -- and raise the flag basis_compressor / basis_parallel_compress report (comp.cpp:3449, 5516).
+        error_printf("basisu_frontend (resident): reoptimize_remapped_endpoints failed: %s -- endpoints left as they were, get_opencl_failed() set\n", f ? bu_frontend_error(f) : "no frontend");
+        for (uint32_t i = 0; i < k; i++) old_to_new_endpoint_cluster_indices[i] = (int)i;
+        m_opencl_failed = true;
+        return;
     }
     std::vector<uint8_t> prm;
     basisu::vector<uint_vec> sel_lists; basisu::vector<etc_block> sel_blocks; basisu::vector<uint32_t> block_sel;
-    if (!refresh_members(f, m_total_blocks, m_encoded_blocks, nullptr, m_endpoint_clusters, m_block_endpoint_clusters_indices, prm, sel_lists, sel_blocks, block_sel)) abort();
+    if (!refresh_members(f, m_total_blocks, m_encoded_blocks, nullptr, m_endpoint_clusters, m_block_endpoint_clusters_indices, prm, sel_lists, sel_blocks, block_sel)) {
+        error_printf("basisu_frontend (resident): reoptimize_remapped_endpoints: the re-fitted state could not be read back: %s\n", bu_frontend_error(f));
+        m_opencl_failed = true;
+        return;
+    }
     const uint32_t k2 = (uint32_t)(prm.size() / 16);
     m_endpoint_cluster_etc_params.resize(0); m_endpoint_cluster_etc_params.resize(k2);
     for (uint32_t i = 0; i < k2; i++) {

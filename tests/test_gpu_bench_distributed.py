@@ -44,15 +44,53 @@ def single():
     return _run(1, [])
 
 
+def _both_modes(d, n, headline_sharded):
+    """N > 1: the line verifies itself -- how many ranks the process group and the sharding communicator really connected -- and carries BOTH modes, the sharded one with
+    its per-stage split (what DESIGN.md section 7's scaling estimate is made of)."""
+    assert d["comm"]["world_size"] == n and d["comm"]["ranks_seen"] == n
+    rep = d["both_modes"]["replicas (one image per GPU, no data-path collective)"]
+    sh = d["both_modes"]["one image sharded over the ranks (--shard-image)"]
+    assert rep["scaling"] == "weak" and sh["scaling"] == "strong" and rep["value"] > 0 and sh["value"] > 0
+    assert bool(sh.get("is_the_headline")) == headline_sharded and bool(rep.get("is_the_headline")) == (not headline_sharded)
+    head = sh if headline_sharded else rep
+    assert head["value"] == d["value"] and head["ms_per_step"] == d["ms_per_step"]
+    assert sh["communicator_ranks_seen"] == n and sh["communicator"]
+    split = sh["host_wall_s_per_step"]
+    assert split["codebook_builders"] > 0 and split["slab_and_cluster_share_stages"] > 0 and "refine_endpoint_clusterization" in split["by_stage"]
+    assert abs(rep["value"] - n * 512 * 512 / 1e6 / (rep["ms_per_step"] / 1e3)) / rep["value"] < 0.01
+    assert abs(sh["value"] - 512 * 512 / 1e6 / (sh["ms_per_step"] / 1e3)) / sh["value"] < 0.01
+
+
 def _contract(d, n):
     assert d["n_gpus"] == n and d["steps"] == 2 and d["warmup"] == 1 and d["unit"] == "Mpixels/s" and d["higher_is_better"] is True
     assert d["value"] > 0 and d["ms_per_step"] > 0 and d["data"] == "synthetic" and d["vs_baseline"] is None
     assert d["roofline"]["bound"] == "hbm" and d["roofline"]["kernel_symbol"].startswith("k_")
 
 
+def test_single_gpu_line_has_no_multi_gpu_objects(single):
+    assert single["comm"] is None and single["both_modes"] is None
+
+
+def test_native_rccl_communicator_two_processes():
+    """bu_rccl_comm_create over REAL RCCL between two processes with a GPU each: one all-reduce through the bu_comm view must see both ranks. Needs two devices: skips on
+    the one-GPU boxes of the test pool, runs on the first node that has them (bench.py --gpus N then reports the same figure as comm.sharding_communicator_ranks_seen)."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one GPU: RCCL cannot connect two ranks here (a communicator needs one device per rank)")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           str(ROOT / "bench.py"), "--gpus", "2", "--shard-image", *COMMON]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=str(ROOT))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert d["comm"]["ranks_seen"] == 2 and d["comm"]["sharding_communicator_ranks_seen"] == 2 and d["comm"]["sharding_communicator"].startswith("bu_rccl")
+    _both_modes(d, 2, True)
+
+
 def test_weak_scaling_mode_two_ranks(single):
     d = _run(2, [])
     _contract(d, 2)
+    _both_modes(d, 2, False)
     assert d["scaling"] == "weak" and "no collective" in d["config"]["parallelism"]
     # value = the pixels of BOTH ranks' images over the slower rank's time
     assert abs(d["value"] - 2 * 512 * 512 / 1e6 / (d["ms_per_step"] / 1e3)) / d["value"] < 0.01
@@ -62,6 +100,7 @@ def test_weak_scaling_mode_two_ranks(single):
 def test_sharded_image_mode_two_ranks(single):
     d = _run(2, ["--shard-image"])
     _contract(d, 2)
+    _both_modes(d, 2, True)
     assert d["scaling"] == "strong" and "sharded" in d["config"]["parallelism"]
     assert abs(d["value"] - 512 * 512 / 1e6 / (d["ms_per_step"] / 1e3)) / d["value"] < 0.01
     # the same image as the single-GPU run (seed 1234): the sharded frontend must end with the same codebooks
@@ -75,6 +114,7 @@ def test_weak_scaling_mode_eight_ranks_share_the_gpu(single):
     cores divided between the ranks (bench.py sets BU_HOST_THREADS = cores / ranks, 2..8). No collective in the data path; rank 0's line carries all eight images."""
     d = _run(8, [])
     _contract(d, 8)
+    _both_modes(d, 8, False)
     assert d["scaling"] == "weak" and "no collective" in d["config"]["parallelism"]
     assert abs(d["value"] - 8 * 512 * 512 / 1e6 / (d["ms_per_step"] / 1e3)) / d["value"] < 0.01
     cpus, per_rank = d["config"]["host_cpus"], d["config"]["host_threads_per_rank"]
@@ -87,6 +127,7 @@ def test_sharded_image_mode_eight_ranks_share_the_gpu(single):
     """`bench.py --gpus 8 --shard-image` as the driver would launch it: one image over eight ranks (slabs of 16 block rows each), strong scaling, the single-GPU result."""
     d = _run(8, ["--shard-image"])
     _contract(d, 8)
+    _both_modes(d, 8, True)
     assert d["scaling"] == "strong" and "sharded" in d["config"]["parallelism"]
     assert abs(d["value"] - 512 * 512 / 1e6 / (d["ms_per_step"] / 1e3)) / d["value"] < 0.01
     for k in ("final_endpoint_clusters", "final_selector_clusters", "max_endpoint_clusters", "max_selector_clusters"):

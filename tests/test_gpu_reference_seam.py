@@ -53,6 +53,8 @@ def _run_any(tool, png, out_ext, *args):
     (("-basis", "-etc1s", "-q", "128", "-mipmap"), "basis", False),             # the reference's own mip generation, eight slices through one frontend
     (("-basis", "-etc1s", "-q", "128"), "basis", True),                         # colour + alpha slices
     (("-basis", "-etc1s", "-q", "128", "-linear"), "basis", False),
+    # -validate_etc1s = basisu_frontend::params::m_validate (comp.cpp:3434): the resident frontend's own validate_output() over the state the device delivered
+    (("-basis", "-etc1s", "-q", "128", "-comp_level", "2", "-validate_etc1s"), "basis", True),
 ])
 def test_reference_tool_with_resident_frontend_and_backend_writes_the_cpu_tools_file(args, ext, alpha):
     """The reference's basis_compressor / containers / CLI (untouched objects) over integration/basisu_resident_frontend.cpp and

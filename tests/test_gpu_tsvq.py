@@ -148,7 +148,8 @@ def test_wide_nodes_match_host_tsvq(hip_ctx, request, n, k, p, kind, wmax, wide_
         outs[name] = (a, b)
         rounds[name] = int(st[0])
     hip_ctx.set_tuning()
-    assert rounds["deep2"] <= rounds["hybrid"] and (n < 2000 or rounds["deep2"] < rounds["hybrid"]), rounds   # deep rounds: fewer round trips
+    if wmax < 2 ** 40:   # (with weights beyond the exact kernels' range the descendants of a deep round are handed back to ordinary rounds: nothing is saved there)
+        assert rounds["deep2"] <= rounds["hybrid"] and (n < 2000 or rounds["deep2"] < rounds["hybrid"]), rounds   # deep rounds: fewer round trips
     a1 = np.zeros(cap, np.uint32); b1 = np.zeros(cap, np.uint32)
     assert F.bu_host_tsvq(16, v.ctypes.data_as(VP), w.ctypes.data_as(VP), n, k, p, a1.ctypes.data_as(VP), cap, b1.ctypes.data_as(VP), cap) == 1
     for name, (a, b) in outs.items():

@@ -286,6 +286,15 @@ def test_host_block_pool_recycles_large_blocks_and_leaves_the_process_alone():
     assert st[1][0] > st[0][0], "the first run maps its large blocks"
     assert st[2][0] == st[1][0] and st[2][1] > st[1][1], "the second run reuses them"
     assert st[2][2] <= st[2][3]
+    # bu_host_pool_trim: what the pool keeps goes back to the kernel on request, and the next run maps afresh
+    F.bu_host_pool_trim.restype = C.c_uint64
+    held = st[2][2]
+    assert held > 0 and F.bu_host_pool_trim() == held
+    F.bu_host_pool_stats(st[0])
+    assert st[0][2] == 0
+    assert F.bu_host_tsvq(16, v.ctypes.data_as(C.c_void_p), w.ctypes.data_as(C.c_void_p), n, 8, 4, a.ctypes.data_as(C.c_void_p), cap, b.ctypes.data_as(C.c_void_p), cap) == 1
+    F.bu_host_pool_stats(st[1])
+    assert st[1][0] > st[2][0], "after a trim the blocks are mapped again"
     syms = subprocess.run(["nm", "-D", "--defined-only", str(etc1s.FRONTEND_LIB_PATH)], stdout=subprocess.PIPE, text=True, check=True).stdout.split("\n")
     assert all(" bu_" in s for s in syms if s.strip()), [s for s in syms if s.strip() and " bu_" not in s][:5]
     src = pathlib.Path(etc1s.__file__).parent / "csrc" / "host"
