@@ -121,7 +121,7 @@ _SIGNATURES = {
 
 class Tuning(C.Structure):  # = bu_hip_tuning, include/basisu_hip.h
     _fields_ = [(n, C.c_uint32) for n in ("struct_bytes", "tsvq_wide_min", "tsvq_wide6_min", "tsvq_wide_cov_min", "tsvq_windows", "tsvq_dense_min", "tsvq_zero_copy",
-                                          "tsvq_chained_only", "tsvq_poll", "refine_unsorted", "debug", "tsvq_deep_levels")]
+                                          "tsvq_chained_only", "tsvq_poll", "refine_unsorted", "debug", "tsvq_deep_levels", "uastc_walk_cus")]
 
 
 class HipLibrary:

@@ -62,6 +62,9 @@ struct bu_hip_context {
     // its many-workgroup ones); joined back through the two events before anything reads the results
     hipStream_t side_stream = nullptr; hipEvent_t side_fork = nullptr, side_join = nullptr;
     bool dedicated_queue = false;         // own_stream was made with a (full) CU mask: a hardware queue of its own instead of a share of the runtime's pool
+    // UASTC pipeline lanes with reserved walk CUs (bu_hip_tuning::uastc_walk_cus): the lean strip walk of uastc_rdo goes to walk_stream, whose CU mask is the reserved
+    // set; own_stream (and with it everything that fills the chip) is masked to the OTHER CUs, side_stream (the walk with the refit in it) to the reserved ones
+    hipStream_t walk_stream = nullptr; hipEvent_t walk_join = nullptr; uint32_t walk_cus = 0;
     arena refine_lists;                   // the sorted candidate lists of refine_endpoint_clusterization (etc1s_kernels.hip, k_refine_sort_lists)
     const void* d_pixel_blocks = nullptr; // resident tiles (a1): 64 B per block
     size_t total_blocks = 0;
@@ -258,7 +261,7 @@ static std::atomic<int> g_live_contexts{0};
 static void context_release(bu_hip_context* ctx);   // the real teardown
 static const bu_hip_tuning& default_tuning();
 static bool ensure_side_stream(bu_hip_context* ctx);
-static hipStream_t make_dedicated_stream(int device);
+static hipStream_t make_dedicated_stream(int device, uint32_t reserve, bool reserved_side);
 static size_t park_limit() {
     static const size_t n = [] { const char* e = std::getenv("BU_HIP_PARKED_CONTEXTS"); const long v = e ? std::atol(e) : 16; return (size_t)(v < 0 ? 0 : (v > 64 ? 64 : v)); }();
     return n;
@@ -370,6 +373,8 @@ static void context_release(bu_hip_context* ctx) {
     if (ctx->stage) (void)hipHostFree(ctx->stage);
     if (ctx->bounce) (void)hipHostFree(ctx->bounce);
     for (hipEvent_t e : ctx->prof_events) (void)hipEventDestroy(e);
+    if (ctx->walk_stream) (void)hipStreamDestroy(ctx->walk_stream);
+    if (ctx->walk_join) (void)hipEventDestroy(ctx->walk_join);
     if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
     if (ctx->side_fork) (void)hipEventDestroy(ctx->side_fork);
     if (ctx->side_join) (void)hipEventDestroy(ctx->side_join);
@@ -394,7 +399,7 @@ static const bu_hip_tuning& default_tuning() {
         bu_hip_tuning d;
         std::memset(&d, 0, sizeof(d));
         d.struct_bytes = (uint32_t)sizeof(d);
-        d.tsvq_wide_min = 8192; d.tsvq_wide6_min = 8192; d.tsvq_wide_cov_min = 98304; d.tsvq_windows = 0; d.tsvq_dense_min = 257; d.tsvq_zero_copy = 1; d.tsvq_deep_levels = 0;
+        d.tsvq_wide_min = 8192; d.tsvq_wide6_min = 8192; d.tsvq_wide_cov_min = 98304; d.tsvq_windows = 0; d.tsvq_dense_min = 257; d.tsvq_zero_copy = 1; d.tsvq_deep_levels = 0; d.uastc_walk_cus = 0;
         auto num = [](const char* name, long lo, long hi, uint32_t* out) { if (const char* e = std::getenv(name)) { const long v = std::atol(e); if (v >= lo && v <= hi) *out = (uint32_t)v; } };
         num("BU_TSVQ_WIDE_MIN", 512, 1l << 30, &d.tsvq_wide_min);
         num("BU_TSVQ_WIDE6_MIN", 512, 1l << 30, &d.tsvq_wide6_min);
@@ -402,6 +407,7 @@ static const bu_hip_tuning& default_tuning() {
         num("BU_TSVQ_DENSE_MIN", 0, 1l << 30, &d.tsvq_dense_min);
         num("BU_TSVQ_ZEROCOPY", 0, 1, &d.tsvq_zero_copy);
         num("BU_TSVQ_DEEP", 0, (long)bu::TSVQ_MAX_DEEP_LEVELS, &d.tsvq_deep_levels);
+        num("BU_UASTC_WALK_CUS", 0, 128, &d.uastc_walk_cus);
         if (const char* e = std::getenv("BU_TSVQ_WIDE")) if (std::atoi(e) == 0) d.tsvq_wide_min = d.tsvq_wide6_min = 0;
         if (const char* e = std::getenv("BU_TSVQ_WIDE6")) if (std::atoi(e) == 0) d.tsvq_wide6_min = 0;
         if (const char* e = std::getenv("BU_TSVQ_WINDOWS")) d.tsvq_windows = e[0] == '0' ? 2u : 1u;
@@ -1597,11 +1603,21 @@ void bu_hip_uastc_rdo_default_params(bu_uastc_rdo_params* p) {
 }
 
 // A stream with a hardware queue of its own: hipExtStreamCreateWithCUMask with every CU enabled (the runtime does not pool queues that carry a CU mask). nullptr on failure.
-static hipStream_t make_dedicated_stream(int device) {
+// reserve = 0: every CU. Otherwise the device's CUs are split into a RESERVED set of about `reserve` CUs -- every (CUs / reserve)-th one, so that whatever order the
+// mask's bits have over XCDs and shader engines, every one of them gives its share -- and the rest; reserved_side picks which of the two the stream may use.
+static hipStream_t make_dedicated_stream(int device, uint32_t reserve = 0, bool reserved_side = false) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) != hipSuccess || prop.multiProcessorCount <= 0) { (void)hipGetLastError(); return nullptr; }
-    std::vector<uint32_t> mask(((uint32_t)prop.multiProcessorCount + 31) / 32, 0xFFFFFFFFu);
-    if (prop.multiProcessorCount % 32) mask.back() = (1u << (prop.multiProcessorCount % 32)) - 1u;
+    const uint32_t cus = (uint32_t)prop.multiProcessorCount;
+    std::vector<uint32_t> mask((cus + 31) / 32, 0xFFFFFFFFu);
+    if (cus % 32) mask.back() = (1u << (cus % 32)) - 1u;
+    if (reserve && reserve < cus) {
+        const uint32_t stride = cus / reserve;
+        for (uint32_t i = 0; i < cus; i++) {
+            const bool is_reserved = stride >= 2 ? (i % stride == stride - 1) : (i < reserve);
+            if (is_reserved != reserved_side) mask[i / 32] &= ~(1u << (i % 32));
+        }
+    }
     hipStream_t s = nullptr;
     if (hipExtStreamCreateWithCUMask(&s, (uint32_t)mask.size(), mask.data()) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
     return s;
@@ -1626,6 +1642,22 @@ static bool ensure_side_stream(bu_hip_context* ctx) {
 // the host. Without a side stream the two launches simply follow each other.
 static int uastc_rdo_walks(bu_hip_context* ctx, void* d_blocks, const void* d_px, uint32_t n_blocks, const float* fp, const uint32_t* up, uint32_t flags, uint32_t total_jobs, void* ws) {
     const bool refit = up[2] != 0;
+    if (ctx->walk_stream) {
+        // a pipeline lane with reserved walk CUs: both builds of the walk on streams of their own whose CU masks are the reserved set, forked off and joined back to the
+        // lane's stream (which may not use those CUs): the walks' waves never wait for a slot behind a chip-filling kernel, and never share a SIMD with one
+        BU_TRY(ctx, hipEventRecord(ctx->side_fork, ctx->stream));
+        BU_TRY(ctx, hipStreamWaitEvent(ctx->walk_stream, ctx->side_fork, 0));
+        BU_TRY(ctx, bu::launch_uastc_rdo_phase(ctx->walk_stream, 1, d_blocks, d_px, n_blocks, fp, up, flags, total_jobs, ws));
+        BU_TRY(ctx, hipEventRecord(ctx->walk_join, ctx->walk_stream));
+        if (refit) {
+            BU_TRY(ctx, hipStreamWaitEvent(ctx->side_stream, ctx->side_fork, 0));
+            BU_TRY(ctx, bu::launch_uastc_rdo_phase(ctx->side_stream, 3, d_blocks, d_px, n_blocks, fp, up, flags, total_jobs, ws));
+            BU_TRY(ctx, hipEventRecord(ctx->side_join, ctx->side_stream));
+            BU_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->side_join, 0));
+        }
+        BU_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->walk_join, 0));
+        return 1;
+    }
     const bool side = refit && ensure_side_stream(ctx);
     if (side) {
         BU_TRY(ctx, hipEventRecord(ctx->side_fork, ctx->stream));
@@ -1745,14 +1777,33 @@ bu_uastc_pipeline* bu_hip_uastc_pipeline_create(bu_hip_context* ctx, uint32_t la
             // The runtime maps ordinary streams onto its few shared hardware queues (GPU_MAX_HW_QUEUES) by how many streams each queue already carries -- history, as far
             // as a library can tell -- and two lanes whose streams share a queue run one after the other. A stream with a CU mask gets a hardware queue of its OWN: the
             // lanes' streams are made with one that enables every CU.
-            if (!l.ctx->dedicated_queue) {
-                hipStream_t fresh = make_dedicated_stream(l.ctx->device);
+            const uint32_t walk_cus = ctx->tuning.uastc_walk_cus;
+            if (!l.ctx->dedicated_queue || l.ctx->walk_cus != walk_cus) {
+                hipStream_t fresh = make_dedicated_stream(l.ctx->device, walk_cus, false);
                 if (fresh) {
                     (void)hipStreamSynchronize(l.ctx->own_stream);
                     const bool own = l.ctx->stream == l.ctx->own_stream;
                     (void)hipStreamDestroy(l.ctx->own_stream);
                     l.ctx->own_stream = fresh; l.ctx->dedicated_queue = true;
                     if (own) l.ctx->stream = fresh;
+                    // the walks' streams: on the reserved CUs (or gone, when nothing is reserved)
+                    if (l.ctx->walk_stream) { (void)hipStreamSynchronize(l.ctx->walk_stream); (void)hipStreamDestroy(l.ctx->walk_stream); l.ctx->walk_stream = nullptr; }
+                    if (l.ctx->side_stream) { (void)hipStreamSynchronize(l.ctx->side_stream); (void)hipStreamDestroy(l.ctx->side_stream); l.ctx->side_stream = nullptr; }
+                    l.ctx->walk_cus = 0;
+                    if (walk_cus) {
+                        l.ctx->walk_stream = make_dedicated_stream(l.ctx->device, walk_cus, true);
+                        l.ctx->side_stream = make_dedicated_stream(l.ctx->device, walk_cus, true);
+                        bool ok = l.ctx->walk_stream && l.ctx->side_stream;
+                        if (ok && !l.ctx->walk_join) ok = hipEventCreateWithFlags(&l.ctx->walk_join, hipEventDisableTiming) == hipSuccess;
+                        if (ok && !l.ctx->side_fork) ok = hipEventCreateWithFlags(&l.ctx->side_fork, hipEventDisableTiming) == hipSuccess;
+                        if (ok && !l.ctx->side_join) ok = hipEventCreateWithFlags(&l.ctx->side_join, hipEventDisableTiming) == hipSuccess;
+                        if (ok) l.ctx->walk_cus = walk_cus;
+                        else {   // fall back to the unreserved form rather than fail: the lane's own stream keeps its (restricted) mask, the walks share it
+                            (void)hipGetLastError();
+                            if (l.ctx->walk_stream) { (void)hipStreamDestroy(l.ctx->walk_stream); l.ctx->walk_stream = nullptr; }
+                            if (l.ctx->side_stream) { (void)hipStreamDestroy(l.ctx->side_stream); l.ctx->side_stream = nullptr; }
+                        }
+                    }
                 }
             }
         }

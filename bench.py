@@ -458,6 +458,11 @@ def main():
             out["uastc_rdo"] = uastc_rdo_bench(ctx, helpers, args)
         if not args.no_big and world == 1 and args.size == 4096:
             out["etc1s_8192_q255"] = etc1s_8192_bench(ctx, helpers, args)
+            # the other input distributions at the headline's size: beside the headline, never instead of it
+            out["etc1s_noise4096_q128"] = other_distribution_bench(ctx, helpers, "noise4096_q128", lambda: helpers.uniform_random(4096, 4096, 42), "uniform-random RGB (seed 42)")
+            out["etc1s_kodak4096_q128"] = other_distribution_bench(ctx, helpers, "kodak4096_q128", lambda: helpers.kodak_mosaic(4096, 4096), "mosaic of the 24 Kodak images")
+            out["etc1s_cube4096_q128"] = other_distribution_bench(ctx, helpers, "cube4096_q128", lambda: helpers.endpoint_cube(4096, 4096, 7),
+                                                                  "endpoint cube (nearly every ETC1S endpoint occurs: 228,656 distinct endpoint vectors)")
         print(json.dumps(out))
     if last is not None:
         last.close()
@@ -593,6 +598,60 @@ def etc1s_8192_bench(ctx, helpers, args):
             out["identical_to_reference"] = hashlib.sha256(np.ascontiguousarray(last.get("encoded_blocks")).tobytes()).hexdigest() == rec["frontend_digests"]["encoded_blocks"]
             out["reference_frontend_seconds_1_core"] = rec["reference_seconds"]["frontend"]
             out["speedup_vs_reference_1_core"] = round(rec["reference_seconds"]["frontend"] / dt, 1)
+    last.close()
+    del d
+    torch.cuda.empty_cache()
+    return out
+
+
+def other_distribution_bench(ctx, helpers, case, img_fn, what):
+    """The headline step on another input distribution at full size (uniform-random RGB seed 42 = the worst case for every clustering stage, the honest floor of
+    the Mpixels/s figure; the reference's Kodak images as one 4096^2 mosaic = photographic statistics; the endpoint cube = the most distinct endpoint vectors an image can
+    have). Same full init + compress per step, -q128 level 1, tiles resident, every state digest compared with the reference's run on the same image
+    (tests/golden/etc1s_big_digests.json: tools/gen_golden_big.py), which also recorded the distinct training vectors each codebook builder saw."""
+    import torch
+    from basis_universal_amd.etc1s import Etc1sFrontend
+    g = ROOT / "tests" / "golden" / "etc1s_big_digests.json"
+    rec = json.loads(g.read_text()).get(case) if g.exists() else None
+    if not rec:
+        return None
+    img = img_fn()
+    blocks = helpers.to_pixel_blocks(img)
+    n = blocks.shape[0]
+    d = torch.from_numpy(blocks.reshape(n, 64)).cuda()
+
+    def step():
+        fe = Etc1sFrontend(ctx)
+        fe.init(d.data_ptr(), rec["max_endpoint_clusters"], rec["max_selector_clusters"], rec["level"], True, n_blocks=n)
+        fe.compress()
+        return fe
+
+    step().close()
+    torch.cuda.synchronize()
+    steps, last = 5, None
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        if last is not None:
+            last.close()
+        last = step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    ctx.profile_enable(1)
+    t0 = time.perf_counter()
+    step().close()
+    torch.cuda.synchronize()
+    dt_instrumented = time.perf_counter() - t0
+    kern = ctx.profile_read()
+    ctx.profile_enable(False)
+    import test_gpu_etc1s_frontend as T
+    same = T._digest({k: last.get(k) for k in rec["frontend_digests"]}) == rec["frontend_digests"]
+    h, w = img.shape[:2]
+    out = {"workload": f"{w}x{h} {what}, ETC1S -q{rec['quality']} comp_level {rec['level']} ({rec['max_endpoint_clusters']} / {rec['max_selector_clusters']} clusters), init+compress, tiles resident",
+           "value": round(w * h / 1e6 / dt, 3), "unit": "Mpixels/s", "ms_per_step": round(dt * 1e3, 2), "steps": steps, "identical_to_reference": same,
+           "distinct_training_vectors": rec.get("distinct_vectors"), "final_clusters": [rec["final_endpoint_clusters"], rec["final_selector_clusters"]],
+           "kernels_ms_per_step": {k: round(v[0], 3) for k, v in kern.items()}, "instrumented_step_ms": round(dt_instrumented * 1e3, 2),
+           "psnr": frontend_psnr(last, img), "reference_frontend_seconds_1_core": rec["reference_seconds"]["frontend"],
+           "speedup_vs_reference_1_core": round(rec["reference_seconds"]["frontend"] / dt, 1)}
     last.close()
     del d
     torch.cuda.empty_cache()
@@ -1037,7 +1096,7 @@ def end_to_end(helpers, args, img):
             want = base_hash.get("stock_1_thread")   # every task of basis_parallel_compress owns a one-thread pool: the single-threaded codebooks
             # Sixteen compressors allocate and release ~300 MB each per image (the reference's image copies and tile arrays above all); with glibc's defaults that is ~75,000
             # page faults per image, all serialised on one address space's lock -- the faults, not the GPU or the backend, capped this mode at ~390 Mpix/s in round 4
-            # (tools/ab_parallel2.sh). The benchmark APPLICATION sets its own malloc policy (mallopt in integration/process_bench.cpp's main, all link variants alike; the
+            # (tools/scratch/ab_parallel2.sh). The benchmark APPLICATION sets its own malloc policy (mallopt in integration/process_bench.cpp's main, all link variants alike; the
             # libraries never touch the process's allocator). Second run: the same on transparent huge pages (GLIBC_TUNABLES=glibc.malloc.hugetlb=1), round 4's setting.
             # One host thread per frontend / backend: the images are the parallelism here.
             for key, tun in (("resident_parallel", None), ("resident_parallel_glibc_hugetlb", "glibc.malloc.hugetlb=1")):

@@ -117,6 +117,7 @@ typedef struct bu_hip_tuning {
     uint32_t refine_unsorted;     /*                       0      1 = refine_endpoint_clusterization through the unsorted kernel (the one lists beyond 65,535 entries take anyway) */
     uint32_t debug;               /* BU_TSVQ_ROUNDS = 1 | BU_TSVQ_SERIAL = 2 | BU_TSVQ_STATS = 4: developer aids (round time line on stderr, one node per round, walk statistics) */
     uint32_t tsvq_deep_levels;    /* BU_TSVQ_DEEP          0      deep rounds: generations of descendants of a round's one-workgroup nodes split in the same round trip (bu_hip_tsvq_split_deep); 0 = none, <= 2. Measured SLOWER at 4096^2 (17.4-18.0 against 16.8-17.6 ms per step: the rounds it saves cost ~50 us each, the splits nobody pops cost device time in rounds that fill the chip), hence off */
+    uint32_t uastc_walk_cus;      /* BU_UASTC_WALK_CUS     0      UASTC pipeline lanes: this many CUs (every (CUs / n)-th one) carry the strip walks of uastc_rdo and nothing else -- the lanes' other kernels are masked off them; 0 = no reservation */
 } bu_hip_tuning;
 BU_HIP_API void bu_hip_get_tuning(const bu_hip_context* /* NULL: the process defaults */, bu_hip_tuning* out, uint32_t struct_bytes);
 BU_HIP_API int  bu_hip_set_tuning(bu_hip_context*, const bu_hip_tuning* /* NULL: back to the process defaults */);

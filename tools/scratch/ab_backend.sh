@@ -1,5 +1,5 @@
 # Host backend, two builds of the libraries side by side on ONE box's host (gpurun_ab/A, gpurun_ab/B prepared beforehand): ms per image and the sub-stage timers.
-#   gpurun -- bash tools/ab_backend.sh
+#   gpurun -- bash tools/scratch/ab_backend.sh
 cd $GRAFT_REPO_ROOT
 for r in 1 2; do for v in A B; do
   cp gpurun_ab/$v/*.so basis_universal_amd/lib/

@@ -1,5 +1,5 @@
 # Host backend with 1 / 2 / 3 / 8 host threads on the GPU box's host: with one thread the walks run one after the other, so each loop's OWN cost shows
-# (that is how the three-thread pipeline of rounds 1-2 was found to cost more than it hid).   gpurun -- bash tools/ab_backend_threads.sh
+# (that is how the three-thread pipeline of rounds 1-2 was found to cost more than it hid).   gpurun -- bash tools/scratch/ab_backend_threads.sh
 cd $GRAFT_REPO_ROOT
 for t in 1 2 3 8; do
   echo -n "BU_HOST_THREADS=$t: "

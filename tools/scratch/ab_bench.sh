@@ -1,4 +1,4 @@
-# A/B of the ETC1S step between builds of the libraries on ONE box (the pool's boxes differ by a few per cent):  gpurun -- bash tools/ab_bench.sh "A B ..." [rounds]
+# A/B of the ETC1S step between builds of the libraries on ONE box (the pool's boxes differ by a few per cent):  gpurun -- bash tools/scratch/ab_bench.sh "A B ..." [rounds]
 # with gpurun_ab/<variant>/*.so prepared beforehand (cp basis_universal_amd/lib/*.so gpurun_ab/A/ ...). Prints value / ms_per_step / the TSVQ and sort labels per run.
 cd $GRAFT_REPO_ROOT
 for r in $(seq 1 ${2:-2}); do for v in $1; do

@@ -1,4 +1,4 @@
-# One box, several settings of an environment knob: ETC1S step (and the 8192^2 leg with `big`).   gpurun -- bash tools/ab_env.sh VAR "v1 v2 ..." [big]
+# One box, several settings of an environment knob: ETC1S step (and the 8192^2 leg with `big`).   gpurun -- bash tools/scratch/ab_env.sh VAR "v1 v2 ..." [big]
 cd $GRAFT_REPO_ROOT
 VAR=$1; VALS=$2; BIG=$3
 for r in 1 2; do for v in $VALS; do

@@ -1,4 +1,4 @@
-# basis_parallel_compress over the resident build (oracle/_ref/process_bench_resident), one box, several settings:  gpurun -- bash tools/ab_parallel.sh
+# basis_parallel_compress over the resident build (oracle/_ref/process_bench_resident), one box, several settings:  gpurun -- bash tools/scratch/ab_parallel.sh
 cd $GRAFT_REPO_ROOT
 python - <<PY
 import sys; sys.path.insert(0, "tests"); import helpers

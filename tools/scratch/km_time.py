@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Times bu_hip_kmeans_codebook on the selector training set of the bench image (4096x4096 synthetic, q128): the distinct packed selector vectors as the
 frontend would hand them over, HIP-event time of the whole call (label kmeans_selectors). BU_KM_DEBUG_SKIP=1/2/3 switches parts of k_km_assign off
-(timing experiments only).   usage: python tools/km_time.py [size]"""
+(timing experiments only).   usage: python tools/scratch/km_time.py [size]"""
 import ctypes as C, pathlib, sys
 root = pathlib.Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(root)); sys.path.insert(0, str(root / "tests"))

@@ -1,5 +1,5 @@
 # round 5: everything profiles/ needs at one commit -- parity suite, smoke, the bench line, rocprofv3 kernel stats + one step's time line, PMC passes, TSVQ round log,
-# and the concurrency of the pipelined leg.   usage (on the GPU box): bash tools/r05_final.sh [tag]
+# and the concurrency of the pipelined leg.   usage (on the GPU box): bash tools/scratch/r05_final.sh [tag]
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out; R=$GRAFT_REPO_ROOT; tag=${1:-r05}
 if [[ " $* " != *" notests "* ]]; then
   timeout 1500 python -m pytest tests -m gpu -x -q --durations=6 2>&1 | tail -12 > gpurun_out/${tag}_tests.txt; tail -2 gpurun_out/${tag}_tests.txt

@@ -1,6 +1,6 @@
 #!/bin/bash
-# After `gpurun -- bash tools/gpu_round.sh <tag> tests bench prof pmc [calib]`: copy the round's summaries from gpurun_out/ into profiles/ and regenerate the
-# derived tables (pmc_traffic.json, valu_busy.json, <tag>_valu_table.md, <tag>_resource_usage.txt) at the current commit.   usage: tools/refresh_profiles.sh <tag>
+# After `gpurun -- bash tools/scratch/gpu_round.sh <tag> tests bench prof pmc [calib]`: copy the round's summaries from gpurun_out/ into profiles/ and regenerate the
+# derived tables (pmc_traffic.json, valu_busy.json, <tag>_valu_table.md, <tag>_resource_usage.txt) at the current commit.   usage: tools/scratch/refresh_profiles.sh <tag>
 set -e
 cd "$(dirname "$0")/.."
 tag=$1

@@ -1,5 +1,5 @@
 # The rounds of both tree builds of one frontend step (BU_TSVQ_ROUNDS=1: one stderr line per device round) and the kernel time line of that step.
-# usage (on the GPU box): tools/tsvq_rounds.sh <tag> [codebook threads]
+# usage (on the GPU box): tools/scratch/tsvq_rounds.sh <tag> [codebook threads]
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
 tag=${1:-x}; thr=${2:-0}
 cat > /tmp/one_step.py <<PY

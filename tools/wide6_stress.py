@@ -1,5 +1,6 @@
 """GPU-box helper: randomized trees through the 6-float many-workgroup path (BU_TSVQ_WIDE6_MIN=512) against the host restatement -- endpoint-like vectors of random
-darkness, weight ranges from 1 to 2^40, random sizes and leaf budgets. Prints one line per mismatch and a summary; exit code 1 on any mismatch.
+darkness, weight ranges from 1 to 2^40, random sizes and leaf budgets; every fourth tree has 150,000-240,000 vectors: up to the CEILING of what the endpoint builder can
+ever be given (236,235 distinct vectors, tests/test_host_logic.py::test_endpoint_codebook_can_never_reach_the_threaded_gate). One line per mismatch and a summary; exit code 1 on any mismatch.
    usage: python tools/wide6_stress.py [seconds]"""
 import os, sys, time, ctypes as C, pathlib
 root = pathlib.Path(__file__).resolve().parent.parent
@@ -17,13 +18,13 @@ def expand(c5):
     return ((c5 << 3) | (c5 >> 2)).astype(np.float32) * np.float32(1.0 / 255.0)
 
 
-t_end, cases, bad, seed = time.time() + budget, 0, 0, 0
+t_end, cases, bad, seed, biggest = time.time() + budget, 0, 0, 0, 0
 while time.time() < t_end:
     seed += 1
     rng = np.random.default_rng(seed)
-    n = int(rng.integers(600, 90000))
+    n = int(rng.integers(150000, 240001)) if seed % 4 == 0 else int(rng.integers(600, 90000))
     dark = rng.random()                      # share of near-black vectors
-    span = int(rng.integers(1, 13))
+    span = int(rng.integers(1, 13)) if n < 100000 else int(rng.integers(6, 13))   # (enough distinct low / high pairs for the large trees)
     lo = rng.integers(0, 32, (n, 3)); hi = np.minimum(31, lo + rng.integers(0, span, (n, 3)))
     m = rng.random(n) < dark
     lo[m] = rng.integers(0, 3, (int(m.sum()), 3)); hi[m] = np.minimum(31, lo[m] + rng.integers(0, 3, (int(m.sum()), 3)))
@@ -44,5 +45,6 @@ while time.time() < t_end:
     if ok != 1 or not ((a1 == a2).all() and (b1 == b2).all()):
         bad += 1
         print(f"MISMATCH seed {seed}: n {n} k {k} p {p} wmax 2^{int(np.log2(wmax))} dark {dark:.2f} ok {ok} leaves {a1[0]} vs {a2[0]}", flush=True)
-print(f"{cases} trees, {bad} mismatches")
+    biggest = max(biggest, n)
+print(f"{cases} trees (largest {biggest} vectors), {bad} mismatches")
 sys.exit(1 if bad else 0)
