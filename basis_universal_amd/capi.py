@@ -105,6 +105,7 @@ _SIGNATURES = {
     "bu_hip_uastc_rdo": (_int, [_vp, _vp, _vp, _u32, _u32, _vp]),
     "bu_hip_tsvq_create": (_vp, [_vp, _u32, _vp, _vp, _u32, _vp]),
     "bu_hip_tsvq_create_packed16": (_vp, [_vp, _vp, _vp, _u32, _vp]),
+    "bu_hip_k_cluster_colour_means": (_int, [_vp, _vp, _u32, _vp, _vp, _vp]),
     "bu_hip_tsvq_split": (_int, [_vp, _vp, _vp, _u32, _vp]),
     "bu_hip_tsvq_split_deep": (_int, [_vp, _vp, _vp, _u32, _vp, _u32, _vp]),
     "bu_hip_tsvq_roots": (_int, [_vp, _vp, _vp, _u32, _vp]),
@@ -121,7 +122,7 @@ _SIGNATURES = {
 
 class Tuning(C.Structure):  # = bu_hip_tuning, include/basisu_hip.h
     _fields_ = [(n, C.c_uint32) for n in ("struct_bytes", "tsvq_wide_min", "tsvq_wide6_min", "tsvq_wide_cov_min", "tsvq_windows", "tsvq_dense_min", "tsvq_zero_copy",
-                                          "tsvq_chained_only", "tsvq_poll", "refine_unsorted", "debug", "tsvq_deep_levels", "uastc_walk_cus")]
+                                          "tsvq_chained_only", "tsvq_poll", "refine_unsorted", "debug", "tsvq_deep_levels", "uastc_walk_cus", "codebook_wide_min")]
 
 
 class HipLibrary:

@@ -399,7 +399,7 @@ static const bu_hip_tuning& default_tuning() {
         bu_hip_tuning d;
         std::memset(&d, 0, sizeof(d));
         d.struct_bytes = (uint32_t)sizeof(d);
-        d.tsvq_wide_min = 8192; d.tsvq_wide6_min = 8192; d.tsvq_wide_cov_min = 98304; d.tsvq_windows = 0; d.tsvq_dense_min = 257; d.tsvq_zero_copy = 1; d.tsvq_deep_levels = 0; d.uastc_walk_cus = 0;
+        d.tsvq_wide_min = 8192; d.tsvq_wide6_min = 8192; d.tsvq_wide_cov_min = 98304; d.tsvq_windows = 0; d.tsvq_dense_min = 257; d.tsvq_zero_copy = 1; d.tsvq_deep_levels = 0; d.uastc_walk_cus = 0; d.codebook_wide_min = 32768;
         auto num = [](const char* name, long lo, long hi, uint32_t* out) { if (const char* e = std::getenv(name)) { const long v = std::atol(e); if (v >= lo && v <= hi) *out = (uint32_t)v; } };
         num("BU_TSVQ_WIDE_MIN", 512, 1l << 30, &d.tsvq_wide_min);
         num("BU_TSVQ_WIDE6_MIN", 512, 1l << 30, &d.tsvq_wide6_min);
@@ -408,6 +408,7 @@ static const bu_hip_tuning& default_tuning() {
         num("BU_TSVQ_ZEROCOPY", 0, 1, &d.tsvq_zero_copy);
         num("BU_TSVQ_DEEP", 0, (long)bu::TSVQ_MAX_DEEP_LEVELS, &d.tsvq_deep_levels);
         num("BU_UASTC_WALK_CUS", 0, 128, &d.uastc_walk_cus);
+        num("BU_CODEBOOK_WIDE_MIN", 0, 1l << 30, &d.codebook_wide_min);
         if (const char* e = std::getenv("BU_TSVQ_WIDE")) if (std::atoi(e) == 0) d.tsvq_wide_min = d.tsvq_wide6_min = 0;
         if (const char* e = std::getenv("BU_TSVQ_WIDE6")) if (std::atoi(e) == 0) d.tsvq_wide6_min = 0;
         if (const char* e = std::getenv("BU_TSVQ_WINDOWS")) d.tsvq_windows = e[0] == '0' ? 2u : 1u;
@@ -619,6 +620,67 @@ int bu_hip_k_endpoint_training_vectors(bu_hip_context* ctx, const void* d_etc, u
     return 1;
 }
 
+// The clusters of a codebook fit, split by size: one workgroup per cluster for the many small ones (largest first, so the big ones do not start last), the
+// many-workgroup passes of etc1s_codebook_wide.inc for those of bu_hip_tuning::codebook_wide_min texels and more (a sky, a flat wall, a constant alpha plane: one
+// workgroup would walk 10^5-10^7 texels 17 times while the rest of the chip waits). `order`: the call's clusters, largest first.
+static int codebook_fit_split(bu_hip_context* ctx, const std::vector<uint32_t>& order, const uint32_t* h_offsets, const void* d_px, const void* d_enc, const uint32_t* d_offsets,
+                              const uint32_t* d_indices, int quality, bool perceptual, bool forced, uint32_t step, uint8_t* d_params, uint64_t* d_err, uint8_t* d_valid,
+                              uint64_t* d_cur_err, const char* label) {
+    const uint32_t wide_min = ctx->tuning.codebook_wide_min;
+    std::vector<uint32_t> small_ones, big_cluster, big_first, big_sub;
+    for (uint32_t c : order) {
+        const uint32_t sub = h_offsets[c + 1] - h_offsets[c];
+        if (wide_min && sub && (uint64_t)sub * 8u >= wide_min && sub < (1u << 28)) { big_cluster.push_back(c); big_first.push_back(h_offsets[c]); big_sub.push_back(sub); }
+        else small_ones.push_back(c);
+    }
+    std::vector<unsigned char> image;
+    bu::cb_wide_layout L{};
+    if (!big_cluster.empty()) L = bu::codebook_wide_prepare(big_cluster.data(), big_first.data(), big_sub.data(), (uint32_t)big_cluster.size(), image);
+    arena& ord = ctx->scratch[5];
+    const size_t ord_bytes = (small_ones.size() * sizeof(uint32_t) + 255) & ~(size_t)255;
+    BU_TRY(ctx, ord.reserve(ord_bytes + L.total));
+    char* work = static_cast<char*>(ord.p) + ord_bytes;
+    if (!small_ones.empty()) BU_TRY(ctx, h2d(ctx, ord.p, small_ones.data(), small_ones.size() * sizeof(uint32_t)));
+    if (!image.empty()) BU_TRY(ctx, h2d(ctx, work, image.data(), image.size()));
+    {
+        prof_scope ps(ctx, label);
+        if (!small_ones.empty()) {
+            if (forced) BU_TRY(ctx, bu::launch_refit_endpoints_given_selectors(ctx->stream, d_px, d_enc, (uint32_t)small_ones.size(), static_cast<const uint32_t*>(ord.p), d_offsets, d_indices,
+                                                                               quality, perceptual, d_params, d_err, d_valid, d_cur_err));
+            else BU_TRY(ctx, bu::launch_generate_endpoint_codebook(ctx->stream, d_px, (uint32_t)small_ones.size(), static_cast<const uint32_t*>(ord.p), d_offsets, d_indices,
+                                                                   quality, perceptual, step, d_params, d_err, d_valid));
+        }
+        if (L.n_big) BU_TRY(ctx, bu::launch_codebook_wide(ctx->stream, d_px, d_indices, work, L, quality, perceptual, forced, step, d_enc, d_params, d_err, d_valid, d_cur_err));
+    }
+    BU_TRY(ctx, stream_wait(ctx, ctx->stream)); // the uploads' sources are pageable host memory owned by this call
+    return 1;
+}
+
+// Test hook: the colour mean the cluster fit starts from (etc.cpp:1034-1041: a running float sum in texel order, divided by the count) of every cluster, through the
+// many-workgroup path's order-free evaluation of that sum (etc1s_codebook_wide.inc, cbw_ordered_sum) whatever the clusters' sizes. h_out: 3 floats per cluster.
+int bu_hip_k_cluster_colour_means(bu_hip_context* ctx, const void* d_px, uint32_t n_clusters, const uint32_t* h_offsets, const uint32_t* d_indices, float* h_out) {
+    if (!ctx) return 0;
+    if (!n_clusters) return 1;
+    if (!d_px || !h_offsets || !d_indices || !h_out) { set_error(ctx, "cluster_colour_means: null argument"); return 0; }
+    device_guard g(ctx->device);
+    std::vector<uint32_t> cl(n_clusters), first(n_clusters), sub(n_clusters);
+    for (uint32_t c = 0; c < n_clusters; c++) {
+        cl[c] = c; first[c] = h_offsets[c]; sub[c] = h_offsets[c + 1] - h_offsets[c];
+        if (!sub[c]) { set_error(ctx, "cluster_colour_means: empty cluster %u", c); return 0; }
+    }
+    std::vector<unsigned char> image;
+    const bu::cb_wide_layout L = bu::codebook_wide_prepare(cl.data(), first.data(), sub.data(), n_clusters, image);
+    arena& ws = ctx->scratch[5];
+    const size_t out_at = (L.total + 255) & ~(size_t)255;
+    BU_TRY(ctx, ws.reserve(out_at + (size_t)n_clusters * 12));
+    BU_TRY(ctx, h2d(ctx, ws.p, image.data(), image.size()));
+    float* d_out = reinterpret_cast<float*>(static_cast<char*>(ws.p) + out_at);
+    BU_TRY(ctx, bu::launch_codebook_wide_means(ctx->stream, d_px, d_indices, ws.p, L, d_out));
+    BU_TRY(ctx, d2h_pageable(ctx, h_out, d_out, (size_t)n_clusters * 12));
+    BU_TRY(ctx, stream_wait(ctx, ctx->stream));
+    return 1;
+}
+
 int bu_hip_k_generate_endpoint_codebook_part(bu_hip_context* ctx, const void* d_px, uint32_t n_clusters, const uint32_t* h_offsets,
                                              const uint32_t* d_offsets, const uint32_t* d_indices, int quality, int perceptual, uint32_t step,
                                              uint8_t* d_params, uint64_t* d_err, uint8_t* d_valid, uint32_t part, uint32_t parts) {
@@ -636,16 +698,7 @@ int bu_hip_k_generate_endpoint_codebook_part(bu_hip_context* ctx, const void* d_
     std::vector<uint32_t> mine;
     for (uint32_t i = part; i < n_clusters; i += parts) mine.push_back(order[i]);
     if (mine.empty()) return 1;
-    arena& ord = ctx->scratch[5];
-    BU_TRY(ctx, ord.reserve(mine.size() * sizeof(uint32_t)));
-    BU_TRY(ctx, h2d(ctx, ord.p, mine.data(), mine.size() * sizeof(uint32_t)));
-    {
-        prof_scope ps(ctx, "generate_endpoint_codebook");
-        BU_TRY(ctx, bu::launch_generate_endpoint_codebook(ctx->stream, d_px, (uint32_t)mine.size(), static_cast<const uint32_t*>(ord.p), d_offsets, d_indices,
-                                                          quality, perceptual != 0, step, d_params, d_err, d_valid));
-    }
-    BU_TRY(ctx, stream_wait(ctx, ctx->stream)); // `mine` is pageable host memory owned by this call
-    return 1;
+    return codebook_fit_split(ctx, mine, h_offsets, d_px, nullptr, d_offsets, d_indices, quality, perceptual != 0, false, step, d_params, d_err, d_valid, nullptr, "generate_endpoint_codebook");
 }
 
 int bu_hip_k_generate_endpoint_codebook(bu_hip_context* ctx, const void* d_px, uint32_t n_clusters, const uint32_t* h_offsets,
@@ -663,16 +716,8 @@ int bu_hip_k_refit_endpoints_given_selectors_q(bu_hip_context* ctx, const void* 
     std::vector<uint32_t> order(n_clusters);
     std::iota(order.begin(), order.end(), 0u);
     std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return (h_offsets[a + 1] - h_offsets[a]) > (h_offsets[b + 1] - h_offsets[b]); });
-    arena& ord = ctx->scratch[5];
-    BU_TRY(ctx, ord.reserve(n_clusters * sizeof(uint32_t)));
-    BU_TRY(ctx, h2d(ctx, ord.p, order.data(), n_clusters * sizeof(uint32_t)));
-    {
-        prof_scope ps(ctx, "refit_endpoints_given_selectors");
-        BU_TRY(ctx, bu::launch_refit_endpoints_given_selectors(ctx->stream, d_px, d_enc, n_clusters, static_cast<const uint32_t*>(ord.p), d_offsets, d_indices,
-                                                               quality == BU_ETC_QUALITY_SLOW ? BU_ETC_QUALITY_SLOW : BU_ETC_QUALITY_UBER, perceptual != 0, d_params, d_err, d_valid, d_cur_err));
-    }
-    BU_TRY(ctx, stream_wait(ctx, ctx->stream));
-    return 1;
+    return codebook_fit_split(ctx, order, h_offsets, d_px, d_enc, d_offsets, d_indices, quality == BU_ETC_QUALITY_SLOW ? BU_ETC_QUALITY_SLOW : BU_ETC_QUALITY_UBER, perceptual != 0, true, 0u,
+                              d_params, d_err, d_valid, d_cur_err, "refit_endpoints_given_selectors");
 }
 
 int bu_hip_k_refit_endpoints_given_selectors(bu_hip_context* ctx, const void* d_px, const void* d_enc, uint32_t n_clusters, const uint32_t* h_offsets,

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <vector>
 
 namespace bu {
 
@@ -15,6 +16,14 @@ hipError_t launch_selector_training_vectors(hipStream_t st, const void* d_enc_bl
 hipError_t launch_generate_endpoint_codebook(hipStream_t st, const void* d_pixel_blocks, uint32_t n_clusters, const uint32_t* d_order,
                                              const uint32_t* d_offsets, const uint32_t* d_indices, int quality, bool perceptual, uint32_t step,
                                              uint8_t* d_params, uint64_t* d_err, uint8_t* d_valid);
+// LARGE clusters (etc1s_codebook_wide.inc): many workgroups per cluster, a launch per pass over the texels of all large clusters of the call. h_cluster / h_first /
+// h_subblocks: per large cluster its index, the position of its first member in d_indices and its member (sub-block) count. prepare() lays out the workspace
+// [states | chunk table | scratch] and fills `image` with the bytes of its first two parts (the caller uploads them to d_work before launch_codebook_wide).
+struct cb_wide_layout { size_t states_at, chunks_at, sum_at, total, image_bytes; uint32_t n_big, n_chunks; };
+cb_wide_layout codebook_wide_prepare(const uint32_t* h_cluster, const uint32_t* h_first, const uint32_t* h_subblocks, uint32_t n_big, std::vector<unsigned char>& image);
+hipError_t launch_codebook_wide_means(hipStream_t st, const void* d_pixel_blocks, const uint32_t* d_indices, void* d_work, const cb_wide_layout& L, float* d_out /* 3 per large cluster */);
+hipError_t launch_codebook_wide(hipStream_t st, const void* d_pixel_blocks, const uint32_t* d_indices, void* d_work, const cb_wide_layout& L, int quality, bool perceptual, bool forced,
+                                uint32_t step, const void* d_enc_blocks, uint8_t* d_params, uint64_t* d_err, uint8_t* d_valid, uint64_t* d_cur_err);
 hipError_t launch_refit_endpoints_given_selectors(hipStream_t st, const void* d_pixel_blocks, const void* d_enc_blocks, uint32_t n_clusters, const uint32_t* d_order,
                                                   const uint32_t* d_offsets, const uint32_t* d_indices, int quality, bool perceptual, uint8_t* d_params, uint64_t* d_err,
                                                   uint8_t* d_valid, uint64_t* d_cur_err);

@@ -741,6 +741,8 @@ __global__ __launch_bounds__(CB_THREADS) void k_generate_endpoint_codebook(
     }
 }
 
+#include "etc1s_codebook_wide.inc"
+
 // -------------------------------------------------------------------------------------------------------------------
 // a10: refine_endpoint_clusterization (frontend.cpp:1772-1917)
 //

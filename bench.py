@@ -886,19 +886,22 @@ def uastc_rdo_bench(ctx, helpers, args):
     for _ in range(steps):
         info = step()
     torch.cuda.synchronize()
+    sync_steps = steps
     dt_one = (time.perf_counter() - t0) / steps   # one batch start to finish, the host waiting for each: the latency of a batch, and where the per-kernel times come from
     kern = ctx.profile_read()
     ctx.profile_enable(False)
     # The timed steps: every step SUBMITS the batch to the library's pipeline (bu_hip_uastc_pipeline_*: `lanes` private streams + workspaces, nothing between submissions
     # waits for the host), the timed region ends when the last one is complete. One batch's strips kernel is 96 serial chains on 96 of 256 CUs for ~20 ms; the next
     # submission's encode kernels and the previous one's hint refit run beside it. Same bytes per step as the synchronous form above (checked below on the last lanes).
-    lanes = int(os.environ.get("BU_UASTC_LANES", "3"))
+    lanes = int(os.environ.get("BU_UASTC_LANES", "4"))   # (3 / 4 lanes side by side, 12 steps each: 18.4 / 16.4 ms per batch -- profiles/r06_rdo_lanes.txt)
     pipe = uastc.UastcPipeline(ctx, lanes, n, flags, jobs)
     outs = [d_out] + [torch.empty_like(d_out) for _ in range(lanes - 1)]
     for k in range(lanes):
         pipe.submit(d_px.data_ptr(), n, outs[k].data_ptr(), params, flags, jobs)
     pipe.wait(0)
     torch.cuda.synchronize()
+    # (at least 12 submissions: with as many steps as lanes the figure is ONE wave of batches start to finish -- 17.9 and 24.3 ms per batch in two runs of the same build)
+    steps = max(steps, 12)
     t0 = time.perf_counter()
     for k in range(steps):
         last_ticket = pipe.submit(d_px.data_ptr(), n, outs[k % lanes].data_ptr(), params, flags, jobs)
@@ -922,8 +925,8 @@ def uastc_rdo_bench(ctx, helpers, args):
            "lanes": lanes, "lanes_identical": lanes_identical,
            "one_batch_start_to_finish": {"ms": round(dt_one * 1e3, 2), "value": round(n * 16 / 1e6 / dt_one, 2), "unit": "Mpixels/s",
                                          "note": "bu_hip_k_encode_uastc_blocks + bu_hip_k_uastc_rdo with the host waiting for each batch (round 3's `value`)"},
-           "modified_blocks": int(info["modified"]), "kernels_ms_per_step": {k: round(v[0] / steps, 3) for k, v in kern.items()},
-           "serial_step_us": round(kern["uastc_rdo_strips"][0] / steps * 1e3 / (n // jobs), 3),
+           "modified_blocks": int(info["modified"]), "kernels_ms_per_step": {k: round(v[0] / sync_steps, 3) for k, v in kern.items()},
+           "serial_step_us": round(kern["uastc_rdo_strips"][0] / sync_steps * 1e3 / (n // jobs), 3),
            "psnr_rgba": {"mean": round(float(np.mean(psnrs)), 4), "min": round(float(np.min(psnrs)), 4), "max": round(float(np.max(psnrs)), 4)},
            "images_identical_to_reference": (f"{sum(same)}/{len(same)}" if same else None)}
     if golden and same:

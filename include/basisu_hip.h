@@ -118,6 +118,7 @@ typedef struct bu_hip_tuning {
     uint32_t debug;               /* BU_TSVQ_ROUNDS = 1 | BU_TSVQ_SERIAL = 2 | BU_TSVQ_STATS = 4: developer aids (round time line on stderr, one node per round, walk statistics) */
     uint32_t tsvq_deep_levels;    /* BU_TSVQ_DEEP          0      deep rounds: generations of descendants of a round's one-workgroup nodes split in the same round trip (bu_hip_tsvq_split_deep); 0 = none, <= 2. Measured SLOWER at 4096^2 (17.4-18.0 against 16.8-17.6 ms per step: the rounds it saves cost ~50 us each, the splits nobody pops cost device time in rounds that fill the chip), hence off */
     uint32_t uastc_walk_cus;      /* BU_UASTC_WALK_CUS     0      UASTC pipeline lanes: this many CUs (every (CUs / n)-th one) carry the strip walks of uastc_rdo and nothing else -- the lanes' other kernels are masked off them; 0 = no reservation */
+    uint32_t codebook_wide_min;   /* BU_CODEBOOK_WIDE_MIN  32768  endpoint clusters of this many texels and more are fitted by many workgroups (a launch per pass over the texels of all of them) instead of one workgroup each; 0 = never */
 } bu_hip_tuning;
 BU_HIP_API void bu_hip_get_tuning(const bu_hip_context* /* NULL: the process defaults */, bu_hip_tuning* out, uint32_t struct_bytes);
 BU_HIP_API int  bu_hip_set_tuning(bu_hip_context*, const bu_hip_tuning* /* NULL: back to the process defaults */);
@@ -170,6 +171,10 @@ BU_HIP_API int bu_hip_k_endpoint_training_vectors(bu_hip_context*, const void* d
 BU_HIP_API int bu_hip_k_generate_endpoint_codebook(bu_hip_context*, const void* d_pixel_blocks, uint32_t n_clusters,
     const uint32_t* h_offsets, const uint32_t* d_offsets, const uint32_t* d_indices, int quality, int perceptual, uint32_t step,
     uint8_t* d_params, uint64_t* d_err, uint8_t* d_valid);
+/*     Clusters of bu_hip_tuning::codebook_wide_min texels and more (a sky, a flat wall, a constant alpha plane: 10^5-10^7 texels in ONE cluster) are fitted by many
+ *     workgroups each -- a launch per pass over the texels of all of them -- with the same results, the order-dependent float colour mean included (H4).
+ *     Test hook: that mean (etc.cpp:1034-1041: running float sum in texel order / count), evaluated the many-workgroup way for EVERY cluster given; h_out: 3 floats each. */
+BU_HIP_API int bu_hip_k_cluster_colour_means(bu_hip_context*, const void* d_pixel_blocks, uint32_t n_clusters, const uint32_t* h_offsets, const uint32_t* d_indices, float* h_out);
 /* a15 refine_block_endpoints_given_selectors (frontend.cpp:2718-2976, ETC1S levels 4-6): per endpoint cluster, the uber-quality
  *     etc1_optimizer with the selectors of d_encoded_blocks held fixed (m_pForce_selectors). Lists are CSR over training-vector indices
  *     like a9 and MAY contain duplicates (the reference's m_subblocks lists grow from iteration to iteration). Outputs per cluster:

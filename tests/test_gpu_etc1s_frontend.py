@@ -87,6 +87,18 @@ def test_frontend_matches_golden(hip_ctx, case):
     assert got == golden[case]["digests"], {k: (got[k][:12], golden[case]["digests"][k][:12]) for k in got if got[k] != golden[case]["digests"][k]}
 
 
+@pytest.mark.parametrize("case", ["synth256_l1", "synth256_l2_linear", "synth256_l4", "synth256_l5_linear", "synth128_l6", "noise_l4"])
+def test_frontend_with_every_codebook_fit_through_the_many_workgroup_passes(hip_ctx, case, request):
+    """bu_hip_tuning::codebook_wide_min = 8: EVERY endpoint cluster is fitted by etc1s_codebook_wide.inc -- generate_endpoint_codebook at step 0 and step > 0, and from
+    level 4 up the fit with forced selectors (refine_block_endpoints_given_selectors) -- instead of the large ones only. Same digests as the reference."""
+    request.addfinalizer(hip_ctx.set_tuning)
+    hip_ctx.set_tuning(codebook_wide_min=8)
+    golden = json.loads(GOLDEN.read_text())
+    blocks, max_ep, max_sel, level, perceptual = _params(case)
+    got = _digest(_run_hip(hip_ctx, blocks, max_ep, max_sel, level, perceptual))
+    assert got == golden[case]["digests"], {k: (got[k][:12], golden[case]["digests"][k][:12]) for k in got if got[k] != golden[case]["digests"][k]}
+
+
 @pytest.mark.skipif(not have_ref(), reason="oracle/_ref not present")
 @pytest.mark.parametrize("case", ["synth256_l1", "synth256_l3_flat", "noise_small_codebooks", "synth256_l4", "synth256_l5_linear", "synth128_l6", "noise_l4"])
 def test_frontend_matches_live_reference(hip_ctx, case):

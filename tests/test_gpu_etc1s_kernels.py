@@ -104,9 +104,15 @@ def _clusters_by_luma(blocks, k, rng):
     return lists, block_cluster
 
 
+# wide_min: bu_hip_tuning::codebook_wide_min -- None = the default (32,768 texels: only the giant cluster below takes the many-workgroup passes of
+# etc1s_codebook_wide.inc), 8 = every cluster does, 0 = none does (one workgroup per cluster throughout)
+@pytest.mark.parametrize("wide_min", [None, 8, 0])
 @pytest.mark.parametrize("perceptual", [1, 0])
 @pytest.mark.parametrize("quality,level", [(1, 1), (2, 2), (3, 6)])
-def test_generate_endpoint_codebook(hip_ctx, blocks, d_blocks, quality, level, perceptual):
+def test_generate_endpoint_codebook(hip_ctx, blocks, d_blocks, quality, level, perceptual, wide_min, request):
+    if wide_min is not None:
+        request.addfinalizer(hip_ctx.set_tuning)
+        hip_ctx.set_tuning(codebook_wide_min=wide_min)
     rng = np.random.default_rng(7)
     k = 97
     lists, _ = _clusters_by_luma(blocks, k, rng)
@@ -141,6 +147,89 @@ def test_generate_endpoint_codebook(hip_ctx, blocks, d_blocks, quality, level, p
     assert (got[0] == params2).all() and (got[1] == err2).all() and (got[2] == valid2).all()
     for p in (d_offs, d_idx, d_params, d_err, d_valid):
         hip_ctx.free(p)
+
+
+@pytest.mark.parametrize("kind", ["bright", "dark_then_bright", "solid"])
+def test_generate_endpoint_codebook_of_huge_clusters(hip_ctx, kind, request):
+    """Clusters of 10^5-10^6 texels (a sky, a constant alpha plane): their channel sums pass 2^24, where the reference's colour mean -- a RUNNING float sum in texel
+    order (etc.cpp:1034-1041, SURVEY hazard H4) -- depends on the order of the adds. The many-workgroup path evaluates that sum without its order
+    (etc1s_codebook_wide.inc, cbw_ordered_sum: parity maps per binade); the one-workgroup kernel replays it texel by texel; the oracle is the reference's loop.
+    All three must agree, for step 0 and for the keep-unless-better rule of step 1."""
+    rng = np.random.default_rng(len(kind))
+    n = 1024 * 1024 // 16
+    if kind == "bright":      # sums of ~2 x 10^8: four binade changes
+        px = rng.integers(120, 256, (n, 4, 4, 4), dtype=np.uint8)
+    elif kind == "dark_then_bright":   # a long exact prefix (the sum stays below 2^24 for most of the list), then large addends
+        px = rng.integers(0, 12, (n, 4, 4, 4), dtype=np.uint8)
+        px[n - n // 5:] = rng.integers(200, 256, (n // 5, 4, 4, 4), dtype=np.uint8)
+    else:                     # one colour: odd values make every add beyond 2^24 a tie of the rounding
+        px = np.full((n, 4, 4, 4), 255, np.uint8); px[..., 1] = 129; px[..., 2] = 1
+    px[..., 3] = 255
+    blocks = np.ascontiguousarray(px)
+    perm = rng.permutation(n).astype(np.uint32)
+    cuts = [0, n // 2 + 17, n // 2 + 17 + n // 3, n]    # ~524K, ~350K and ~175K texels
+    lists = [np.stack([perm[a:b] * 2, perm[a:b] * 2 + 1], axis=1).reshape(-1).astype(np.uint32) for a, b in zip(cuts[:-1], cuts[1:])]
+    k = len(lists)
+    offs, idx = csr_from_lists(lists)
+    d_blocks = hip_ctx.upload(blocks)
+    d_offs, d_idx = hip_ctx.upload(offs), hip_ctx.upload(idx)
+    params = np.zeros((k, 4), np.uint8); err = np.zeros(k, np.uint64); valid = np.zeros(k, np.uint8)
+    oracle().orc_generate_endpoint_codebook(ptr(blocks), k, ptr(offs, u32p), ptr(idx, u32p), 1, 1, 0, ptr(params), ptr(err, u64p), ptr(valid))
+    params1 = params.copy(); params1[0, 0] = min(int(params1[0, 0]) + 1, 31); params1[1, 3] = (int(params1[1, 3]) + 1) % 8
+    want1 = (params1.copy(), err.copy(), valid.copy())
+    oracle().orc_generate_endpoint_codebook(ptr(blocks), k, ptr(offs, u32p), ptr(idx, u32p), 1, 1, 1, ptr(want1[0]), ptr(want1[1], u64p), ptr(want1[2]))
+    L = hip_ctx.lib
+    request.addfinalizer(hip_ctx.set_tuning)
+    for wide_min in (32768, 0):   # the many-workgroup passes, then one workgroup per cluster
+        hip_ctx.set_tuning(codebook_wide_min=wide_min)
+        d_params, d_err, d_valid = hip_ctx.upload(np.zeros((k, 4), np.uint8)), hip_ctx.upload(np.zeros(k, np.uint64)), hip_ctx.upload(np.zeros(k, np.uint8))
+        hip_ctx.check(L.k_generate_endpoint_codebook(hip_ctx.h, d_blocks, k, offs.ctypes.data_as(VP), d_offs, d_idx, 1, 1, 0, d_params, d_err, d_valid), "k_gec")
+        got = hip_ctx.download(d_params, (k, 4), np.uint8), hip_ctx.download(d_err, (k,), np.uint64), hip_ctx.download(d_valid, (k,), np.uint8)
+        assert (got[0] == params).all() and (got[1] == err).all() and (got[2] == valid).all(), (kind, wide_min, got[0].tolist(), params.tolist())
+        hip_ctx.check(L.memcpy_h2d(hip_ctx.h, d_params, params1.ctypes.data_as(VP), params1.nbytes), "h2d")
+        hip_ctx.check(L.k_generate_endpoint_codebook(hip_ctx.h, d_blocks, k, offs.ctypes.data_as(VP), d_offs, d_idx, 1, 1, 1, d_params, d_err, d_valid), "k_gec")
+        got = hip_ctx.download(d_params, (k, 4), np.uint8), hip_ctx.download(d_err, (k,), np.uint64), hip_ctx.download(d_valid, (k,), np.uint8)
+        assert (got[0] == want1[0]).all() and (got[1] == want1[1]).all() and (got[2] == want1[2]).all(), (kind, wide_min, "step 1")
+        for q in (d_params, d_err, d_valid):
+            hip_ctx.free(q)
+    for q in (d_blocks, d_offs, d_idx):
+        hip_ctx.free(q)
+
+
+@pytest.mark.parametrize("kind", ["bright", "dark_then_bright", "solid", "ramp", "small"])
+def test_ordered_colour_mean_of_clusters(hip_ctx, kind):
+    """cbw_ordered_sum (etc1s_codebook_wide.inc) against the thing it replaces, the sequential float loop `fs += (float)value` over the cluster's texels in list order
+    (numpy float32 cumulative sums add in order): bit patterns of the three means, for sums that stay exact, that cross one binade, that cross many, whose every add is a tie."""
+    rng = np.random.default_rng(11)
+    n = {"small": 4096, "ramp": 200000}.get(kind, 65536)
+    if kind == "bright":
+        px = rng.integers(100, 256, (n, 4, 4, 4), dtype=np.uint8)
+    elif kind == "dark_then_bright":
+        px = rng.integers(0, 9, (n, 4, 4, 4), dtype=np.uint8); px[n - n // 4:] = rng.integers(180, 256, (n // 4, 4, 4, 4), dtype=np.uint8)
+    elif kind == "solid":
+        px = np.full((n, 4, 4, 4), 255, np.uint8); px[..., 1] = 129; px[..., 2] = 3
+    elif kind == "ramp":      # 3.2 M texels: sums near 4 x 10^8
+        px = rng.integers(0, 256, (n, 4, 4, 4), dtype=np.uint8); px[..., 0] |= 0x81
+    else:
+        px = rng.integers(0, 256, (n, 4, 4, 4), dtype=np.uint8)
+    blocks = np.ascontiguousarray(px)
+    perm = rng.permutation(n).astype(np.uint32)
+    cuts = [0, 3, 3 + n // 7, 3 + n // 7 + n // 3, n]
+    lists = [np.stack([perm[a:b] * 2, perm[a:b] * 2 + 1], axis=1).reshape(-1).astype(np.uint32) for a, b in zip(cuts[:-1], cuts[1:])]
+    if kind == "small":
+        lists[1] = lists[1][:1]   # a cluster of one sub-block
+    offs, idx = csr_from_lists(lists)
+    d_blocks, d_idx = hip_ctx.upload(blocks), hip_ctx.upload(idx)
+    got = np.zeros((len(lists), 3), np.float32)
+    hip_ctx.check(hip_ctx.lib.k_cluster_colour_means(hip_ctx.h, d_blocks, len(lists), offs.ctypes.data_as(VP), d_idx, got.ctypes.data_as(VP)), "k_cluster_colour_means")
+    for ci, tv in enumerate(lists):
+        # texels of training vector block * 2 + subblock: rows 2 * subblock, 2 * subblock + 1 of the block, in raster order (etc.cpp:352-361)
+        tex = blocks[tv >> 1].reshape(-1, 2, 8, 4)[np.arange(tv.size), tv & 1].reshape(-1, 4)
+        for c in range(3):
+            seq = np.cumsum(tex[:, c].astype(np.float32), dtype=np.float32)[-1]   # sequential float32 adds
+            want = np.float32(seq) / np.float32(tex.shape[0])
+            assert got[ci, c].view(np.uint32) == np.float32(want).view(np.uint32), (kind, ci, c, tex.shape[0], float(got[ci, c]), float(want))
+    hip_ctx.free(d_blocks); hip_ctx.free(d_idx)
 
 
 def _codebook(blocks, k, seed, level=1, perceptual=1):
