@@ -196,6 +196,7 @@ bool etc1s_frontend::init(const params& p) {
     if (p.m_compression_level > 6) return fail("bad compression level (0..6)");
     m_params = p;
     m_total_blocks = p.m_num_source_blocks;
+    m_etc1_made_by_init = false;
     m_source_copy.clear(); m_source_copy.shrink_to_fit();   // a host copy of device-only tiles belongs to the image it was made from
 
     drop_device_state();
@@ -208,7 +209,14 @@ bool etc1s_frontend::init(const params& p) {
         void* d = bu_hip_malloc(m_dev->ctx, (size_t)m_total_blocks * sizeof(bu_pixel_block));
         if (!d) return fail("device allocation of the source blocks failed");
         m_dev->d_pixels = d; m_dev->owns_pixels = true;
-        if (!bu_hip_memcpy_h2d(m_dev->ctx, d, p.m_pSource_blocks, (size_t)m_total_blocks * sizeof(bu_pixel_block))) return fail("upload of the source blocks failed");
+        if (!m_has_comm) {
+            // host tiles: the upload and the first stage (init_etc1_images, which needs nothing but the tiles and these parameters) as one pipeline -- piece i is encoded
+            // while piece i + 1 is on the link; compress() finds the ETC1 blocks made
+            if (!m_dev->reserve(m_dev->etc1, (size_t)slab_blocks() * 8)) return fail("alloc");
+            if (!bu_hip_k_upload_and_encode_etc1s_blocks(m_dev->ctx, d, p.m_pSource_blocks, m_total_blocks, etc1_images_quality(), p.m_perceptual, m_dev->etc1.p))
+                return fail("bu_hip_k_upload_and_encode_etc1s_blocks");
+            m_etc1_made_by_init = true;
+        } else if (!bu_hip_memcpy_h2d(m_dev->ctx, d, p.m_pSource_blocks, (size_t)m_total_blocks * sizeof(bu_pixel_block))) return fail("upload of the source blocks failed");
     }
 
     m_encoded_blocks.assign(m_total_blocks, bu_etc_block{});
@@ -282,10 +290,17 @@ bool etc1s_frontend::compress() {
 }
 
 // frontend.cpp:733-823
+int etc1s_frontend::etc1_images_quality() const {
+    return m_params.m_compression_level == 0 ? BU_ETC_QUALITY_FAST : m_params.m_compression_level == 1 ? BU_ETC_QUALITY_MEDIUM
+         : m_params.m_compression_level == 6 ? BU_ETC_QUALITY_UBER : BU_ETC_QUALITY_SLOW; // frontend.cpp:783-788
+}
 bool etc1s_frontend::init_etc1_images() {
-    const int quality = m_params.m_compression_level == 0 ? BU_ETC_QUALITY_FAST : m_params.m_compression_level == 1 ? BU_ETC_QUALITY_MEDIUM
-                      : m_params.m_compression_level == 6 ? BU_ETC_QUALITY_UBER : BU_ETC_QUALITY_SLOW; // frontend.cpp:783-788
+    const int quality = etc1_images_quality();
     device_state& d = *m_dev;
+    if (m_etc1_made_by_init) {   // init() encoded the tiles as they arrived (once: a second compress() of the same frontend does the stage again)
+        m_etc1_made_by_init = false;
+        if (!m_has_comm && d.etc1.p) { m_etc1_blocks_etc1s.clear(); m_etc1_on_host = false; return true; }
+    }
     uint32_t b0, nb;
     my_slab(b0, nb);
     if (!d.reserve(d.etc1, (size_t)comm_world() * slab_blocks() * 8)) return fail("alloc");

@@ -102,6 +102,7 @@ public:
 
     // ---- stage methods, same names and order as the reference (frontend.h:346-372); public so tests can single-step
     bool init_etc1_images();
+    int etc1_images_quality() const;
     bool init_endpoint_training_vectors();
     bool generate_endpoint_clusters();
     bool introduce_new_endpoint_clusters();
@@ -155,6 +156,7 @@ private:
     void ensure_selector_map_host() const;
     mutable std::vector<bu_etc_block> m_etc1_blocks_etc1s;  // host mirror of the device's a6 output, see etc1_blocks()
     mutable bool m_etc1_on_host = false;
+    bool m_etc1_made_by_init = false;   // init() uploaded host tiles and encoded them piece by piece (bu_hip_k_upload_and_encode_etc1s_blocks): init_etc1_images() has nothing left to do
 
     // endpoint side
     std::vector<float> m_endpoint_unique_rows;            // distinct (low rgb, high rgb)/255 vectors, ascending

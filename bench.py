@@ -705,7 +705,9 @@ def h2d_inclusive_bench(ctx, blocks, n_blocks, w, h, max_ep, max_sel, args):
     (the boundary the reference's opencl_set_pixel_blocks has), once pageable (what a caller holding a std::vector gives) and once page-locked."""
     import torch
     from basis_universal_amd.etc1s import Etc1sFrontend
-    res = {"what": "init (64 B/block H2D inside the step) + compress; the headline `value` starts with the tiles resident", "bytes_per_step": int(n_blocks) * 64}
+    res = {"what": "init (64 B/block H2D inside the step) + compress; the headline `value` starts with the tiles resident. The upload is pipelined with the first kernel "
+                   "(bu_hip_k_upload_and_encode_etc1s_blocks: 4 MiB pieces on the side stream, piece i encoded behind piece i's copy, pageable memory staged by helper threads)",
+           "bytes_per_step": int(n_blocks) * 64}
     pinned = torch.from_numpy(blocks.reshape(n_blocks, 64)).pin_memory()
     for name, host in (("pageable", np.ascontiguousarray(blocks).reshape(n_blocks, 64)), ("pinned", pinned.numpy())):
         def step():

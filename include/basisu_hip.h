@@ -163,6 +163,12 @@ enum { BU_ETC_QUALITY_FAST = 0, BU_ETC_QUALITY_MEDIUM = 1, BU_ETC_QUALITY_SLOW =
 
 /* a6  basisu_frontend::init_etc1_images (frontend.cpp:733-823): per block etc1_optimizer, n = 16. out: n_blocks x 8 B. */
 BU_HIP_API int bu_hip_k_encode_etc1s_blocks(bu_hip_context*, const void* d_pixel_blocks, uint32_t n_blocks, int quality, int perceptual, void* d_out_etc_blocks);
+/*     The same over tiles that are still in HOST memory, as one pipeline: the tiles go to d_pixel_blocks in 4 MiB pieces on the context's side stream (page-locked source
+ *     memory as it is, pageable memory through a pinned ring filled by BU_UPLOAD_THREADS (default 4) helper threads) and piece i's kernel starts behind piece i's copy, so
+ *     the transfer hides behind the kernel (SURVEY 8d figure (i): the hot path with the H2D inside). On return h_pixel_blocks may be released; the device side is ordered
+ *     on the context's stream. Replaces opencl_set_pixel_blocks + opencl_encode_etc1s_blocks (encoder/basisu_opencl.h:112-116) for a caller that wants both. */
+BU_HIP_API int bu_hip_k_upload_and_encode_etc1s_blocks(bu_hip_context*, void* d_pixel_blocks, const void* h_pixel_blocks, uint32_t n_blocks, int quality, int perceptual,
+    void* d_out_etc_blocks);
 /* a7  init_endpoint_training_vectors (frontend.cpp:825-866): per block 6 floats (low rgb, high rgb)/255. */
 BU_HIP_API int bu_hip_k_endpoint_training_vectors(bu_hip_context*, const void* d_etc_blocks, uint32_t n_blocks, float* d_out_vec6);
 /* a9  generate_endpoint_codebook (frontend.cpp:1214-1617), CPU semantics incl. step > 0. Clusters are CSR lists of

@@ -71,6 +71,43 @@ def test_encode_ragged_tail(hip_ctx, blocks):
         hip_ctx.free(d_in); hip_ctx.free(d_out)
 
 
+@pytest.mark.parametrize("kind", ["pageable", "pinned"])
+def test_upload_and_encode_pipeline(hip_ctx, blocks, kind):
+    """bu_hip_k_upload_and_encode_etc1s_blocks: host tiles in 65,536-block pieces on the side stream, piece i's kernel behind piece i's copy. 10 pieces and a ragged one
+    (more pieces than ring slots: the helper threads wait for slots), page-locked and pageable source: the tiles arrive intact and the ETC1S blocks are those of one launch
+    over resident tiles -- themselves held to the oracle on a sample."""
+    n = 10 * 65536 + 777
+    rng = np.random.default_rng(5)
+    src = np.ascontiguousarray(blocks[rng.integers(0, blocks.shape[0], n)]).reshape(n, 64)
+    src[:, 0] ^= (np.arange(n) & 255).astype(np.uint8)          # every piece differs from every other
+    hip, pinned = None, VP()
+    if kind == "pinned":   # page-locked memory from the runtime the library itself links
+        hip = C.CDLL("libamdhip64.so")
+        assert hip.hipHostMalloc(C.byref(pinned), C.c_size_t(n * 64), C.c_uint(0)) == 0
+        host = np.ctypeslib.as_array(C.cast(pinned, C.POINTER(C.c_uint8)), shape=(n * 64,)).reshape(n, 64)
+        host[:] = src
+    else:
+        host = src
+    d_px, d_out, d_ref = hip_ctx.alloc(n * 64), hip_ctx.alloc(n * 8), hip_ctx.alloc(n * 8)
+    hip_ctx.check(hip_ctx.lib.memset(hip_ctx.h, d_px, 0, n * 64), "memset")
+    for rep in range(2):   # the second call finds the ring and its events used
+        hip_ctx.check(hip_ctx.lib.k_upload_and_encode_etc1s_blocks(hip_ctx.h, d_px, host.ctypes.data_as(VP), n, 1, 1, d_out), "k_upload_and_encode")
+    assert (hip_ctx.download(d_px, (n, 64), np.uint8) == src).all(), "tiles damaged on the way"
+    hip_ctx.check(hip_ctx.lib.k_encode_etc1s_blocks(hip_ctx.h, d_px, n, 1, 1, d_ref), "k_encode")
+    got, ref = hip_ctx.download(d_out, (n, 8), np.uint8), hip_ctx.download(d_ref, (n, 8), np.uint8)
+    assert (got == ref).all(), np.nonzero((got != ref).any(axis=1))[0][:8]
+    pick = np.concatenate([np.arange(0, n, 997), np.arange(n - 64, n)])
+    sample = np.ascontiguousarray(src[pick])
+    exp = np.zeros((pick.size, 8), np.uint8)
+    oracle().orc_encode_etc1s_blocks(ptr(sample), pick.size, 1, 1, ptr(exp))
+    assert (got[pick] == exp).all()
+    for q in (d_px, d_out, d_ref):
+        hip_ctx.free(q)
+    if hip is not None:
+        del host
+        hip.hipHostFree(pinned)
+
+
 def _encode_ref(blocks, level=1, perceptual=1):
     n = blocks.shape[0]
     out = np.zeros((n, 8), np.uint8)
