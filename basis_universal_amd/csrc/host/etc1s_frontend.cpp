@@ -149,9 +149,11 @@ etc1s_frontend::~etc1s_frontend() { drop_device_state(); }
 // and the buffers are let go while it still works. The host-side results (getters) stay valid.
 static void frontend_context_closing(void* user) { static_cast<etc1s_frontend*>(user)->context_closing(); }
 void etc1s_frontend::context_closing() {
+    finish_prefetches();
     if (m_dev) { m_dev->release(); delete m_dev; m_dev = nullptr; }
 }
 void etc1s_frontend::drop_device_state() {
+    finish_prefetches();
     if (!m_dev) return;
     bu_hip_cancel_on_destroy(m_dev->ctx, frontend_context_closing, this);
     m_dev->release(); delete m_dev; m_dev = nullptr;
@@ -242,10 +244,40 @@ bool etc1s_frontend::init(const params& p) {
     return true;
 }
 
+// ---- results leave for the host as soon as they are final, behind the stages that follow (the device -> host copies of a 4096^2 image are 20 MB: 0.36 ms of link time
+// and as much again in round trips when they are fetched one after the other at the end)
+void etc1s_frontend::finish_prefetches(int which) const {   // 1 = the endpoint map, 2 = the encoded blocks, 3 = both
+    if ((which & 1) && (m_dl_ep_cluster || m_dl_ep_pos)) {
+        const bool a = !m_dl_ep_cluster || bu_hip_download_wait(m_dl_ep_cluster) != 0, b = !m_dl_ep_pos || bu_hip_download_wait(m_dl_ep_pos) != 0;
+        m_dl_ep_cluster = m_dl_ep_pos = nullptr;
+        if (a && b && m_ep_dev_valid) m_endpoint_map_valid = true;
+    }
+    if ((which & 2) && m_dl_enc) {
+        const bool ok = bu_hip_download_wait(m_dl_enc) != 0;
+        m_dl_enc = nullptr;
+        if (ok && m_enc_dev_valid) m_enc_host_valid = true;
+    }
+}
+void etc1s_frontend::prefetch_endpoint_map() {
+    if (!m_dev || !m_ep_dev_valid || m_endpoint_map_valid || m_dl_ep_cluster || m_dl_ep_pos) return;
+    m_block_endpoint_cluster.resize(m_total_blocks); m_block_endpoint_pos.resize(m_total_blocks);
+    m_dl_ep_cluster = bu_hip_download_begin(m_dev->ctx, m_block_endpoint_cluster.data(), m_dev->block_cluster.p, (size_t)m_total_blocks * 4);
+    if (m_dl_ep_cluster) m_dl_ep_pos = bu_hip_download_begin(m_dev->ctx, m_block_endpoint_pos.data(), m_dev->ep_pos.p, (size_t)m_total_blocks * 4);
+    if (m_dl_ep_cluster && !m_dl_ep_pos) { (void)bu_hip_download_wait(m_dl_ep_cluster); m_dl_ep_cluster = nullptr; }   // both or neither: ensure_endpoint_map fetches the pair
+}
+void etc1s_frontend::prefetch_encoded_blocks() {
+    if (!m_dev || !m_enc_dev_valid || m_enc_host_valid || m_dl_enc) return;
+    m_encoded_blocks.resize(m_total_blocks);
+    m_dl_enc = bu_hip_download_begin(m_dev->ctx, m_encoded_blocks.data(), m_dev->enc.p, (size_t)m_total_blocks * 8);
+}
+
 // basisu_frontend::compress (frontend.cpp:159-316), single endpoint/selector iteration (levels 0-3)
 bool etc1s_frontend::compress() {
     if (!m_dev) return fail("etc1s_frontend::compress: not initialised, or the context it was initialised on has been destroyed");
     m_stage_times.clear();
+    finish_prefetches();
+    // levels 4-6 and video clips go on changing the endpoint clustering and the encoded blocks (refine_block_endpoints_given_selectors): nothing is final early there
+    const bool early_results = m_params.m_compression_level <= 3 && !m_params.m_video;
 #define BU_STAGE(name, call) do { timer t__; if (!(call)) return false; m_stage_times.push_back(stage_time{name, t__.seconds()}); } while (0)
 #define BU_STAGE_V(name, call) do { timer t__; call; m_stage_times.push_back(stage_time{name, t__.seconds()}); } while (0)
     BU_STAGE("init_etc1_images", init_etc1_images());
@@ -267,6 +299,7 @@ bool etc1s_frontend::compress() {
         BU_STAGE("eliminate_redundant_or_empty_endpoint_clusters", eliminate_redundant_or_empty_endpoint_clusters());
         if (early_out) break;
     }
+    if (early_results) prefetch_endpoint_map();
     BU_STAGE_V("generate_block_endpoint_clusters", generate_block_endpoint_clusters());
     BU_STAGE("create_initial_packed_texture", create_initial_packed_texture());
     BU_STAGE("generate_selector_clusters", generate_selector_clusters());
@@ -275,6 +308,7 @@ bool etc1s_frontend::compress() {
     for (uint32_t it = 0; it < selector_steps; it++) {
         BU_STAGE("create_optimized_selector_codebook", create_optimized_selector_codebook(it));
         BU_STAGE("find_optimal_selector_clusters_for_each_block", find_optimal_selector_clusters_for_each_block());
+        if (early_results && it + 1 == selector_steps) prefetch_encoded_blocks();
         BU_STAGE("introduce_special_selector_clusters", introduce_special_selector_clusters());
         if (m_params.m_compression_level >= 4 || m_params.m_video) {  // frontend.cpp:291
             uint32_t refined = 0;
@@ -380,6 +414,7 @@ bool etc1s_frontend::init_endpoint_training_vectors() {
 
 // frontend.cpp:868-944
 bool etc1s_frontend::generate_endpoint_clusters() {
+    finish_prefetches(1);   // nothing rewrites what a pending download reads
     const uint32_t parent_size = (m_params.m_max_endpoint_clusters >= 256) ? kEndpointParentCodebookSize : 0;
     const uint32_t n = m_total_blocks, u_total = m_endpoint_unique_count;
     const uint32_t want_parents = m_use_hierarchical_endpoint_codebooks ? parent_size : 0;
@@ -456,6 +491,7 @@ const std::vector<uint32_t>& etc1s_frontend::endpoint_group_blocks_host() const 
 // sub-blocks of a block adjacent) and, per block, (cluster, position of the block in the cluster's list). The hot path works on the second
 // one; whoever needs lists (levels 4-6 bookkeeping, the getters) gets them built, and list surgery is folded back into the map.
 void etc1s_frontend::ensure_endpoint_map() const {
+    if (m_dl_ep_cluster || m_dl_ep_pos) finish_prefetches(1);
     if (m_endpoint_map_valid) return;
     if (m_ep_dev_valid && m_dev) {   // the resident map is the clustering: bring it over (sizes and count are kept on the host by every stage)
         m_block_endpoint_cluster.resize(m_total_blocks); m_block_endpoint_pos.resize(m_total_blocks);
@@ -475,6 +511,7 @@ void etc1s_frontend::ensure_endpoint_map() const {
     m_endpoint_map_valid = true;
 }
 bool etc1s_frontend::ensure_endpoint_map_device() {
+    finish_prefetches(1);   // nothing rewrites what a pending download reads
     if (m_ep_dev_valid) return true;
     ensure_endpoint_map();
     device_state& d = *m_dev;
@@ -524,7 +561,9 @@ const std::vector<std::vector<uint32_t>>& etc1s_frontend::endpoint_parent_cluste
 }
 
 // frontend.cpp:947-968
-void etc1s_frontend::generate_block_endpoint_clusters() { ensure_endpoint_map(); }  // the map is the clustering (see ensure_endpoint_map)
+void etc1s_frontend::generate_block_endpoint_clusters() {   // the map is the clustering (see ensure_endpoint_map); with a prefetch under way it is arriving
+    if (!(m_dl_ep_cluster || m_dl_ep_pos)) ensure_endpoint_map();
+}
 
 // frontend.cpp:971-1003. The reference collects one entry per block and then sorts + uniques each parent's list; the result is
 // "the ascending set of clusters that own at least one block of this parent", which a membership table gives in O(blocks).
@@ -604,6 +643,7 @@ bool etc1s_frontend::generate_endpoint_codebook(uint32_t step) {
 // frontend.cpp:1093-1212 (+ compute_endpoint_subblock_error_vec :1006-1091 on the device). Between codebook iterations the sub-blocks
 // that their cluster represents worst are split off into new two-vector clusters until the codebook is full again.
 bool etc1s_frontend::introduce_new_endpoint_clusters() {
+    finish_prefetches(1);   // nothing rewrites what a pending download reads
     generate_block_endpoint_clusters();
     ensure_endpoint_lists();  // list surgery below; folded back into the map at the end
     int want = (int)m_params.m_max_endpoint_clusters - (int)m_endpoint_clusters.size();
@@ -652,6 +692,7 @@ bool etc1s_frontend::introduce_new_endpoint_clusters() {
 // frontend.cpp:2718-2976. ETC1S blocks always have the differential bit set, so only the "colour5" branch of the reference exists
 // here. The per-cluster sub-block lists are the reference's m_subblocks, which are appended to on every call and never cleared.
 bool etc1s_frontend::refine_block_endpoints_given_selectors(uint32_t* total_refined) {
+    finish_prefetches();   // nothing rewrites what a pending download reads
     const uint32_t n = m_total_blocks, k = (uint32_t)m_endpoint_cluster_etc_params.size();
     ensure_endpoint_map(); ensure_encoded_host();
     m_endpoint_cluster_subblocks.resize(k);
@@ -728,6 +769,7 @@ bool etc1s_frontend::refine_block_endpoints_given_selectors(uint32_t* total_refi
 // every old cluster went (-1: unused).
 bool etc1s_frontend::reoptimize_remapped_endpoints(const std::vector<uint32_t>& new_block_endpoints, std::vector<int>& old_to_new, bool optimize_final_codebook,
                                                    const std::vector<uint32_t>* block_selector_indices) {
+    finish_prefetches();
     if (!m_dev) return fail("reoptimize_remapped_endpoints: the context this frontend was initialised on has been destroyed");
     ensure_endpoint_map(); ensure_encoded_host(); ensure_selector_map_host();
     const uint32_t n = m_total_blocks, k = m_endpoint_cluster_count;
@@ -796,6 +838,7 @@ bool etc1s_frontend::reoptimize_remapped_endpoints(const std::vector<uint32_t>& 
 
 // frontend.cpp:1648-1945
 bool etc1s_frontend::refine_endpoint_clusterization(uint32_t* total_reassigned) {
+    finish_prefetches(1);   // nothing rewrites what a pending download reads
     if (!ensure_endpoint_map_device()) return false;
     if (m_use_hierarchical_endpoint_codebooks) compute_endpoint_clusters_within_each_parent_cluster();
     const uint32_t n = m_total_blocks, k = m_endpoint_cluster_count;
@@ -843,6 +886,7 @@ bool etc1s_frontend::refine_endpoint_clusterization(uint32_t* total_reassigned) 
 // (frontend.h:248-267): (r, g, b, a=255) of the colour, then the (all-zero) second colour, then inten. std::sort is not stable,
 // so we call the very same algorithm with an equivalent comparator to get the same permutation among equal keys.
 bool etc1s_frontend::eliminate_redundant_or_empty_endpoint_clusters() {
+    finish_prefetches(1);   // nothing rewrites what a pending download reads
     if (!m_ep_dev_valid) ensure_endpoint_map();
     const uint32_t k = m_endpoint_cluster_count, n = m_total_blocks;
     std::vector<uint32_t> order(k);
@@ -890,6 +934,7 @@ bool etc1s_frontend::eliminate_redundant_or_empty_endpoint_clusters() {
 
 // frontend.cpp:2014-2096
 bool etc1s_frontend::create_initial_packed_texture() {
+    finish_prefetches(2);   // nothing rewrites what a pending download reads
     const uint32_t n = m_total_blocks, k = (uint32_t)m_endpoint_cluster_etc_params.size();
     std::vector<uint8_t> prm(k * 4ull);
     for (uint32_t i = 0; i < k; i++) {
@@ -909,6 +954,7 @@ bool etc1s_frontend::create_initial_packed_texture() {
 
 // ---- the encoded blocks live where they were last written; the other side is brought up to date on demand
 void etc1s_frontend::ensure_encoded_host() const {
+    if (m_dl_enc) finish_prefetches(2);
     if (m_enc_host_valid) return;
     m_encoded_blocks.resize(m_total_blocks);
     if (m_dev && m_dev->enc.p && m_dev->download(m_encoded_blocks.data(), m_dev->enc, m_total_blocks)) m_enc_host_valid = true;
@@ -919,6 +965,7 @@ void etc1s_frontend::ensure_orig_encoded_host() const {
     if (m_dev && m_dev->orig_enc.p && m_dev->download(m_orig_encoded_blocks.data(), m_dev->orig_enc, m_total_blocks)) m_orig_host_valid = true;
 }
 bool etc1s_frontend::ensure_encoded_device() {
+    finish_prefetches(2);   // nothing rewrites what a pending download reads
     if (m_enc_dev_valid) return true;
     device_state& d = *m_dev;
     const size_t padded = (size_t)comm_world() * slab_blocks();
@@ -1095,6 +1142,7 @@ bool etc1s_frontend::create_optimized_selector_codebook(uint32_t /*iter*/) {
 
 // frontend.cpp:2397-2715
 bool etc1s_frontend::find_optimal_selector_clusters_for_each_block() {
+    finish_prefetches(2);   // nothing rewrites what a pending download reads
     const uint32_t n = m_total_blocks, k = (uint32_t)m_optimized_cluster_selectors.size();
     if (m_params.m_compression_level == 0) {
         // frontend.cpp:2420-2439: blocks stay in their TSVQ cluster and just take its optimised selectors

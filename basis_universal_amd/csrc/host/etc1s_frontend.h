@@ -156,6 +156,13 @@ private:
     void ensure_selector_map_host() const;
     mutable std::vector<bu_etc_block> m_etc1_blocks_etc1s;  // host mirror of the device's a6 output, see etc1_blocks()
     mutable bool m_etc1_on_host = false;
+    // results on their way to the host while the later stages run (bu_hip_download_*): the endpoint map from the moment it is final (levels 0-3: after
+    // eliminate_redundant_or_empty_endpoint_clusters), the encoded blocks from find_optimal_selector_clusters_for_each_block on. Whoever needs the host form waits
+    // (ensure_endpoint_map / ensure_encoded_host); nothing writes the device form while one is pending.
+    mutable struct bu_hip_download *m_dl_ep_cluster = nullptr, *m_dl_ep_pos = nullptr, *m_dl_enc = nullptr;
+    void prefetch_endpoint_map();
+    void prefetch_encoded_blocks();
+    void finish_prefetches(int which = 3) const;
     bool m_etc1_made_by_init = false;   // init() uploaded host tiles and encoded them piece by piece (bu_hip_k_upload_and_encode_etc1s_blocks): init_etc1_images() has nothing left to do
 
     // endpoint side

@@ -152,8 +152,12 @@ __global__ void __launch_bounds__(256) k_uastc_order_scatter(const uint16_t* __r
     for (uint32_t b = first + threadIdx.x; b < last; b += 256) { const uint32_t k = key[b]; order[s_base[k] + atomicAdd(&s_h[k], 1u)] = b; }
 }
 
+// SCORE: the candidate is scored while it is still in registers (phase 2 folded in): the slots are written once and never read back by a scoring pass, which at level 2 was
+// 27 x 64 B per block fetched again plus a second read of the tiles.
+template <bool SCORE>
 __global__ void __launch_bounds__(64, 2) k_uastc_candidates(const uint4* __restrict__ px, uint32_t n, const uastc_plan* __restrict__ plan,
-                                                         const uint8_t* __restrict__ cls, cand* __restrict__ cands, uint32_t first_job) {
+                                                         const uint8_t* __restrict__ cls, cand* __restrict__ cands, uint32_t first_job,
+                                                         uint64_t* __restrict__ overall, float* __restrict__ rms) {
     const uint32_t b = blockIdx.x * 64 + threadIdx.x;
     const uastc_job job = plan->jobs[first_job + blockIdx.y];
     // the least-squares rows of this job's weight set, staged in LDS (the fit reads one 16-byte row per texel and pass, by a per-lane index)
@@ -175,6 +179,11 @@ __global__ void __launch_bounds__(64, 2) k_uastc_candidates(const uint4* __restr
         uint4* d = reinterpret_cast<uint4*>(&cands[(size_t)(job.slot + v) * n + b]);
 #pragma unroll
         for (int k = 0; k < 4; k++) d[k] = s[k];
+        if (SCORE) {
+            const cand_score sc = score_candidate(local[v], t, c, plan->e);
+            overall[(size_t)(job.slot + v) * n + b] = sc.overall;
+            rms[(size_t)(job.slot + v) * n + b] = sc.uastc_rms;
+        }
     }
 }
 
@@ -246,6 +255,8 @@ size_t uastc_workspace_bytes(uint32_t n_blocks, uint32_t flags) {
     return total;
 }
 
+static bool fused_score() { static const bool on = [] { const char* e = std::getenv("BU_UASTC_FUSED_SCORE"); return !e || e[0] != '0'; }(); return on; }
+
 hipError_t launch_uastc_phase(hipStream_t st, int phase, const void* d_px, uint32_t n, uint32_t flags, void* d_ws, void* d_out) {
     if (!n) return hipSuccess;
     uastc_plan p;
@@ -273,7 +284,7 @@ hipError_t launch_uastc_phase(hipStream_t st, int phase, const void* d_px, uint3
                 hipEvent_t a, b;
                 (void)hipEventCreate(&a); (void)hipEventCreate(&b);
                 (void)hipEventRecord(a, st);
-                hipLaunchKernelGGL(k_uastc_candidates, dim3(gx, 1), dim3(64), 0, st, px, n, w.plan, w.cls, w.cands, j);
+                hipLaunchKernelGGL(k_uastc_candidates<false>, dim3(gx, 1), dim3(64), 0, st, px, n, w.plan, w.cls, w.cands, j, w.overall, w.rms);
                 (void)hipEventRecord(b, st);
                 (void)hipEventSynchronize(b);
                 float ms = 0;
@@ -283,10 +294,12 @@ hipError_t launch_uastc_phase(hipStream_t st, int phase, const void* d_px, uint3
             }
             break;
         }
-        hipLaunchKernelGGL(k_uastc_candidates, dim3(gx, p.n_jobs), dim3(64), 0, st, px, n, w.plan, w.cls, w.cands, 0u);
+        if (fused_score()) hipLaunchKernelGGL(k_uastc_candidates<true>, dim3(gx, p.n_jobs), dim3(64), 0, st, px, n, w.plan, w.cls, w.cands, 0u, w.overall, w.rms);
+        else hipLaunchKernelGGL(k_uastc_candidates<false>, dim3(gx, p.n_jobs), dim3(64), 0, st, px, n, w.plan, w.cls, w.cands, 0u, w.overall, w.rms);
         break;
     case 2:
-        hipLaunchKernelGGL(k_uastc_score, dim3(gx, p.n_slots), dim3(64), 0, st, px, n, w.plan, w.cls, w.cands, w.overall, w.rms);
+        if (!fused_score() || std::getenv("BU_UASTC_JOB_TIMES"))
+            hipLaunchKernelGGL(k_uastc_score, dim3(gx, p.n_slots), dim3(64), 0, st, px, n, w.plan, w.cls, w.cands, w.overall, w.rms);
         break;
     default:
         hipLaunchKernelGGL(k_uastc_finish, dim3(gx), dim3(64), 0, st, px, n, w.plan, w.cls, w.cands, w.overall, w.rms, w.order, static_cast<uint4*>(d_out));

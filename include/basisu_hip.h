@@ -146,6 +146,13 @@ BU_HIP_API int   bu_hip_memcpy_h2d(bu_hip_context*, void* d_dst, const void* h_s
 /* ... stream-ordered instead of blocking: the source has been copied out when the call returns (it may be released), the copy itself is ordered on the context's stream */
 BU_HIP_API int bu_hip_memcpy_h2d_async(bu_hip_context*, void* d_dst, const void* h_src, size_t bytes);
 BU_HIP_API int   bu_hip_memcpy_d2h(bu_hip_context*, void* h_dst, const void* d_src, size_t bytes); /* synchronises */
+/* A download that nobody waits for yet: the bytes d_src holds once everything enqueued on the context's stream so far has run are brought to h_dst (pageable or pinned)
+ * by the copy engine on a stream of their own, driven by a helper thread, while the caller goes on enqueueing work. bu_hip_download_wait blocks until they are there
+ * (1 = arrived) and releases the handle; it must be called exactly once per handle, before h_dst is released and before anything overwrites d_src. NULL: not available
+ * on this context now (a wait hook is installed, or a resource could not be had) -- use bu_hip_memcpy_d2h. */
+typedef struct bu_hip_download bu_hip_download;
+BU_HIP_API bu_hip_download* bu_hip_download_begin(bu_hip_context*, void* h_dst, const void* d_src, size_t bytes);
+BU_HIP_API int   bu_hip_download_wait(bu_hip_download*);
 BU_HIP_API int   bu_hip_memset(bu_hip_context*, void* d_dst, int value, size_t bytes);
 BU_HIP_API int   bu_hip_memcpy_d2d(bu_hip_context*, void* d_dst, const void* d_src, size_t bytes); /* stream-ordered */
 
