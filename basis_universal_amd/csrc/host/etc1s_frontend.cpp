@@ -221,9 +221,10 @@ bool etc1s_frontend::init(const params& p) {
         } else if (!bu_hip_memcpy_h2d(m_dev->ctx, d, p.m_pSource_blocks, (size_t)m_total_blocks * sizeof(bu_pixel_block))) return fail("upload of the source blocks failed");
     }
 
-    m_encoded_blocks.assign(m_total_blocks, bu_etc_block{});
+    // (the encoded blocks are all-zero until create_initial_packed_texture makes them: the zeros are only written if somebody asks for them before, ensure_encoded_host)
+    m_encoded_blocks.clear();
     m_orig_encoded_blocks.clear();
-    m_enc_host_valid = true; m_enc_dev_valid = false; m_orig_host_valid = true;
+    m_enc_host_valid = false; m_enc_dev_valid = false; m_orig_host_valid = true;
     m_ep_dev_valid = false; m_endpoint_map_valid = false; m_endpoint_lists_valid = false;
     m_sel_dev_valid = false; m_sel_host_valid = true; m_selector_group_blocks.clear(); m_selector_group_offsets.clear();
     m_endpoint_group_blocks.clear();
@@ -956,6 +957,7 @@ bool etc1s_frontend::create_initial_packed_texture() {
 void etc1s_frontend::ensure_encoded_host() const {
     if (m_dl_enc) finish_prefetches(2);
     if (m_enc_host_valid) return;
+    if (!m_enc_dev_valid) { m_encoded_blocks.assign(m_total_blocks, bu_etc_block{}); m_enc_host_valid = true; return; }   // nothing made yet: init()'s zeros
     m_encoded_blocks.resize(m_total_blocks);
     if (m_dev && m_dev->enc.p && m_dev->download(m_encoded_blocks.data(), m_dev->enc, m_total_blocks)) m_enc_host_valid = true;
 }

@@ -8,7 +8,11 @@
 // call fails the frontend.
 #pragma once
 #include <cstdint>
+#include <memory>
+#include <new>
 #include <string>
+#include <type_traits>
+#include <utility>
 #include <vector>
 
 #include "../../../include/basisu_hip.h"
@@ -22,6 +26,17 @@ struct endpoint_params {   // = basisu_frontend::endpoint_cluster_etc_params red
     bool valid = false;
     bool color_used = false;
 };
+
+// The per-block result arrays (8 / 4 bytes x blocks) are filled by device -> host copies right after they are sized: a std::vector would zero them first -- 20 MB of
+// memset per 4096^2 image on the thread that drives the GPU, while the GPU waits for its next launch. resize() of these leaves new elements uninitialised.
+template <class T> struct default_init_allocator : std::allocator<T> {
+    template <class U> struct rebind { using other = default_init_allocator<U>; };
+    default_init_allocator() = default;
+    template <class U> default_init_allocator(const default_init_allocator<U>&) noexcept {}
+    template <class U> void construct(U* p) noexcept(std::is_nothrow_default_constructible<U>::value) { ::new (static_cast<void*>(p)) U; }
+    template <class U, class... A> void construct(U* p, A&&... a) { ::new (static_cast<void*>(p)) U(std::forward<A>(a)...); }
+};
+template <class T> using raw_vector = std::vector<T, default_init_allocator<T>>;
 
 class etc1s_frontend {
 public:
@@ -63,9 +78,9 @@ public:
 
     // ---- getters with the reference's names (frontend.h:119-156)
     const params& get_params() const { return m_params; }
-    uint32_t get_total_output_blocks() const { return (uint32_t)m_encoded_blocks.size(); }
+    uint32_t get_total_output_blocks() const { return m_total_blocks; }
     const bu_etc_block& get_output_block(uint32_t i) const { ensure_encoded_host(); return m_encoded_blocks[i]; }
-    const std::vector<bu_etc_block>& get_output_blocks() const { ensure_encoded_host(); return m_encoded_blocks; }
+    const raw_vector<bu_etc_block>& get_output_blocks() const { ensure_encoded_host(); return m_encoded_blocks; }
     const bu_etc_block& get_etc1s_block(uint32_t i) const { return etc1_blocks()[i]; }
     uint32_t get_total_endpoint_clusters() const { ensure_endpoint_map(); return m_endpoint_cluster_count; }
     uint32_t get_subblock_endpoint_cluster_index(uint32_t block, uint32_t) const { ensure_endpoint_map(); return m_block_endpoint_cluster[block]; }
@@ -77,14 +92,14 @@ public:
 
     // ---- stage state, exposed for stage-by-stage parity tests
     const std::vector<bu_etc_block>& etc1_blocks() const;  // fetched from the device on first use
-    const std::vector<bu_etc_block>& orig_encoded_blocks() const { ensure_orig_encoded_host(); return m_orig_encoded_blocks; }
+    const raw_vector<bu_etc_block>& orig_encoded_blocks() const { ensure_orig_encoded_host(); return m_orig_encoded_blocks; }
     const std::vector<std::vector<uint32_t>>& endpoint_clusters() const;  // built on first use from the (cluster, position) map
     const std::vector<std::vector<uint32_t>>& endpoint_parent_clusters() const;  // built on first use from the parent-of-vector map
     const std::vector<endpoint_params>& endpoint_cluster_params() const { return m_endpoint_cluster_etc_params; }
-    const std::vector<uint32_t>& block_endpoint_clusters() const { ensure_endpoint_map(); return m_block_endpoint_cluster; }
+    const raw_vector<uint32_t>& block_endpoint_clusters() const { ensure_endpoint_map(); return m_block_endpoint_cluster; }
     const std::vector<std::vector<uint32_t>>& selector_cluster_block_indices() const;  // built on first use from the block -> cluster map (ascending blocks)
     const std::vector<bu_etc_block>& optimized_cluster_selectors() const { return m_optimized_cluster_selectors; }
-    const std::vector<uint32_t>& block_selector_cluster_index() const { ensure_selector_map_host(); return m_block_selector_cluster_index; }
+    const raw_vector<uint32_t>& block_selector_cluster_index() const { ensure_selector_map_host(); return m_block_selector_cluster_index; }
 
     // ---- what the backend needs beyond the getters (etc1s_backend.h)
     const bu_pixel_block* source_blocks_host();  // get_source_pixel_block: the caller's host tiles, or a host copy of device-only tiles
@@ -147,7 +162,7 @@ private:
 
     // The encoded blocks (and their pre-selector-quantisation copy) live where they were last written -- normally HBM; the other side is
     // brought up to date on demand (ensure_encoded_host / ensure_encoded_device).
-    mutable std::vector<bu_etc_block> m_encoded_blocks, m_orig_encoded_blocks;
+    mutable raw_vector<bu_etc_block> m_encoded_blocks, m_orig_encoded_blocks;
     mutable bool m_enc_host_valid = true, m_orig_host_valid = true;
     bool m_enc_dev_valid = false;
     void ensure_encoded_host() const;
@@ -177,7 +192,8 @@ private:
     const std::vector<uint32_t>& endpoint_parent_of_unique_host() const;
     // the endpoint clustering in its two forms (etc1s_frontend.cpp, ensure_endpoint_map / ensure_endpoint_lists)
     mutable std::vector<std::vector<uint32_t>> m_endpoint_clusters;
-    mutable std::vector<uint32_t> m_block_endpoint_pos, m_endpoint_cluster_sizes;
+    mutable raw_vector<uint32_t> m_block_endpoint_pos;
+    mutable std::vector<uint32_t> m_endpoint_cluster_sizes;
     mutable uint32_t m_endpoint_cluster_count = 0;
     mutable bool m_endpoint_map_valid = false, m_endpoint_lists_valid = false;   // the HOST forms (per-block arrays / lists)
     bool m_ep_dev_valid = false;                                                   // the RESIDENT per-block arrays (device_state::block_cluster, ep_pos) are current
@@ -193,7 +209,7 @@ private:
     std::vector<uint8_t> m_block_parent_endpoint_cluster;
     std::vector<std::vector<uint32_t>> m_endpoint_clusters_within_each_parent_cluster;
     std::vector<endpoint_params> m_endpoint_cluster_etc_params;
-    mutable std::vector<uint32_t> m_block_endpoint_cluster;  // mutable: part of the lazily synchronised clustering, see ensure_endpoint_map
+    mutable raw_vector<uint32_t> m_block_endpoint_cluster;  // mutable: part of the lazily synchronised clustering, see ensure_endpoint_map
     std::vector<std::vector<uint32_t>> m_endpoint_cluster_subblocks;  // endpoint_cluster_etc_params::m_subblocks (never cleared, frontend.cpp:2727-2729)
 
     // selector side
@@ -206,7 +222,7 @@ private:
     std::vector<bu_etc_block> m_optimized_cluster_selectors;
     std::vector<uint8_t> m_block_parent_selector_cluster;
     std::vector<std::vector<uint32_t>> m_selector_clusters_within_each_parent_cluster;
-    mutable std::vector<uint32_t> m_block_selector_cluster_index;   // host form of the block -> selector cluster map ...
+    mutable raw_vector<uint32_t> m_block_selector_cluster_index;   // host form of the block -> selector cluster map ...
     mutable bool m_sel_host_valid = true;
     bool m_sel_dev_valid = false;                                    // ... and whether the resident form (device_state::sel_cluster) is current
     bool ensure_selector_map_device();

@@ -33,8 +33,8 @@ struct bu_frontend {
 
 namespace {
 
-template <typename T> uint64_t emit(const std::vector<T>& v, void* buf, uint64_t cap) {
-    const uint64_t need = (uint64_t)v.size() * sizeof(T);
+template <typename V> uint64_t emit(const V& v, void* buf, uint64_t cap) {   // any contiguous container of trivially copyable elements
+    const uint64_t need = (uint64_t)v.size() * sizeof(typename V::value_type);
     if (buf && cap >= need && need) std::memcpy(buf, v.data(), need);
     return need;
 }
