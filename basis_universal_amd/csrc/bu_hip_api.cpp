@@ -10,6 +10,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <deque>
 #include <atomic>
 #include <thread>
 #include <mutex>
@@ -77,7 +79,10 @@ struct bu_hip_context {
     // pipelined tile upload (bu_hip_k_upload_and_encode_etc1s_blocks): a pinned ring of UP_SLOTS pieces the helper threads fill, one event per piece in flight
     void* up_ring = nullptr; size_t up_ring_cap = 0; std::vector<hipEvent_t> up_events;
     // background downloads (bu_hip_download_*): their own stream, so that a copy never sits in front of the side stream's kernels; events recycled; handles not yet waited for
-    hipStream_t copy_stream = nullptr; std::vector<hipEvent_t> down_events; std::atomic<int> downloads_pending{0};
+    hipStream_t copy_stream = nullptr; std::vector<hipEvent_t> down_events;
+    // ... carried out by ONE helper thread per context, started with the first download and parked on a condition variable between them (starting a thread per
+    // download cost the calling thread 30-40 us each, on the step's critical path)
+    std::thread down_thread; std::mutex down_mu; std::condition_variable down_cv, down_done_cv; std::deque<struct bu_hip_download*> down_queue; bool down_stop = false;
     std::string error;
     // bu_hip_malloc / bu_hip_free recycle blocks per context: an encoder frees and re-allocates the same dozen buffers for every
     // image, and hipMalloc/hipFree cost 0.1-1 ms each (hipFree also synchronises the device). Reuse is stream-ordered: everything
@@ -378,6 +383,11 @@ static void context_release(bu_hip_context* ctx) {
     if (ctx->stage) (void)hipHostFree(ctx->stage);
     if (ctx->bounce) (void)hipHostFree(ctx->bounce);
     if (ctx->up_ring) (void)hipHostFree(ctx->up_ring);
+    if (ctx->down_thread.joinable()) {
+        { std::lock_guard<std::mutex> lk(ctx->down_mu); ctx->down_stop = true; }
+        ctx->down_cv.notify_all();
+        ctx->down_thread.join();
+    }
     if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
     for (hipEvent_t e : ctx->down_events) (void)hipEventDestroy(e);
     for (hipEvent_t e : ctx->up_events) (void)hipEventDestroy(e);
@@ -553,38 +563,48 @@ int bu_hip_memcpy_d2h(bu_hip_context* ctx, void* h, const void* d, size_t bytes)
 }
 // ---- background downloads
 struct bu_hip_download {
-    bu_hip_context* ctx; hipEvent_t ready; std::thread worker; hipError_t result = hipSuccess;
+    bu_hip_context* ctx; hipEvent_t ready; void* h; const void* d; size_t bytes; bool done; hipError_t result;
 };
+static void download_worker(bu_hip_context* c) {
+    (void)hipSetDevice(c->device);
+    for (;;) {
+        bu_hip_download* dl = nullptr;
+        {
+            std::unique_lock<std::mutex> lk(c->down_mu);
+            c->down_cv.wait(lk, [&] { return c->down_stop || !c->down_queue.empty(); });
+            if (c->down_queue.empty()) return;   // stop, and nothing left to do
+            dl = c->down_queue.front(); c->down_queue.pop_front();
+        }
+        // this thread is what blocks in the copy (into pageable memory the runtime holds the calling thread for the whole transfer); the copy waits for `ready` on the device
+        hipError_t e = hipStreamWaitEvent(c->copy_stream, dl->ready, 0);
+        if (e == hipSuccess) e = hipMemcpyAsync(dl->h, dl->d, dl->bytes, hipMemcpyDeviceToHost, c->copy_stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->copy_stream);
+        { std::lock_guard<std::mutex> lk(c->down_mu); dl->result = e; dl->done = true; }
+        c->down_done_cv.notify_all();
+    }
+}
 bu_hip_download* bu_hip_download_begin(bu_hip_context* ctx, void* h, const void* d, size_t bytes) {
     if (!ctx || !h || !d || !bytes || ctx->wait_hook) return nullptr;
     device_guard g(ctx->device);
     if (!ctx->copy_stream && hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); ctx->copy_stream = nullptr; return nullptr; }
+    if (!ctx->down_thread.joinable()) {
+        try { ctx->down_thread = std::thread(download_worker, ctx); } catch (...) { return nullptr; }
+    }
     hipEvent_t ev = nullptr;
     if (!ctx->down_events.empty()) { ev = ctx->down_events.back(); ctx->down_events.pop_back(); }
     else if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
     if (hipEventRecord(ev, ctx->stream) != hipSuccess) { (void)hipGetLastError(); ctx->down_events.push_back(ev); return nullptr; }
-    bu_hip_download* dl = new (std::nothrow) bu_hip_download{ctx, ev, {}, hipSuccess};
+    bu_hip_download* dl = new (std::nothrow) bu_hip_download{ctx, ev, h, d, bytes, false, hipSuccess};
     if (!dl) { ctx->down_events.push_back(ev); return nullptr; }
-    try {
-        // the helper thread is what blocks in the copy (into pageable memory the runtime holds the calling thread for the whole transfer); the copy waits for `ready` on the device
-        dl->worker = std::thread([dl, h, d, bytes] {
-            bu_hip_context* c = dl->ctx;
-            hipError_t e = hipSetDevice(c->device);
-            if (e == hipSuccess) e = hipStreamWaitEvent(c->copy_stream, dl->ready, 0);
-            if (e == hipSuccess) e = hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, c->copy_stream);
-            if (e == hipSuccess) e = hipStreamSynchronize(c->copy_stream);
-            dl->result = e;
-        });
-    } catch (...) { ctx->down_events.push_back(ev); delete dl; return nullptr; }
-    ctx->downloads_pending.fetch_add(1);
+    { std::lock_guard<std::mutex> lk(ctx->down_mu); ctx->down_queue.push_back(dl); }
+    ctx->down_cv.notify_one();
     return dl;
 }
 int bu_hip_download_wait(bu_hip_download* dl) {
     if (!dl) return 0;
-    if (dl->worker.joinable()) dl->worker.join();
     bu_hip_context* ctx = dl->ctx;
+    { std::unique_lock<std::mutex> lk(ctx->down_mu); ctx->down_done_cv.wait(lk, [&] { return dl->done; }); }
     ctx->down_events.push_back(dl->ready);
-    ctx->downloads_pending.fetch_sub(1);
     const hipError_t e = dl->result;
     delete dl;
     if (e != hipSuccess) { set_error(ctx, "bu_hip_download: %s", hipGetErrorString(e)); (void)hipGetLastError(); return 0; }
