@@ -107,6 +107,8 @@ _SIGNATURES = {
     "bu_hip_tsvq_create_packed16": (_vp, [_vp, _vp, _vp, _u32, _vp]),
     "bu_hip_k_cluster_colour_means": (_int, [_vp, _vp, _u32, _vp, _vp, _vp]),
     "bu_hip_k_upload_and_encode_etc1s_blocks": (_int, [_vp, _vp, _vp, _u32, _int, _int, _vp]),
+    "bu_hip_host_alloc": (_vp, [C.c_size_t]),
+    "bu_hip_host_free": (None, [_vp]),
     "bu_hip_download_begin": (_vp, [_vp, _vp, _vp, C.c_size_t]),
     "bu_hip_download_wait": (_int, [_vp]),
     "bu_hip_tsvq_split": (_int, [_vp, _vp, _vp, _u32, _vp]),

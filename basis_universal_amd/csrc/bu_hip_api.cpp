@@ -561,6 +561,13 @@ int bu_hip_memcpy_d2h(bu_hip_context* ctx, void* h, const void* d, size_t bytes)
     BU_TRY(ctx, stream_wait(ctx, ctx->stream));
     return 1;
 }
+void* bu_hip_host_alloc(size_t bytes) {
+    void* p = nullptr;
+    if (!bytes || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return p;
+}
+void bu_hip_host_free(void* p) { if (p) (void)hipHostFree(p); }
+
 // ---- background downloads
 struct bu_hip_download {
     bu_hip_context* ctx; hipEvent_t ready; void* h; const void* d; size_t bytes; bool done; hipError_t result;

@@ -150,6 +150,9 @@ BU_HIP_API int   bu_hip_memcpy_d2h(bu_hip_context*, void* h_dst, const void* d_s
  * by the copy engine on a stream of their own, driven by a helper thread, while the caller goes on enqueueing work. bu_hip_download_wait blocks until they are there
  * (1 = arrived) and releases the handle; it must be called exactly once per handle, before h_dst is released and before anything overwrites d_src. NULL: not available
  * on this context now (a wait hook is installed, or a resource could not be had) -- use bu_hip_memcpy_d2h. */
+/* Page-locked host memory (for callers that want their tiles taken by the copy engine as they are: bu_hip_k_upload_and_encode_etc1s_blocks, bu_frontend_init with host tiles). */
+BU_HIP_API void* bu_hip_host_alloc(size_t bytes);
+BU_HIP_API void  bu_hip_host_free(void* p);
 typedef struct bu_hip_download bu_hip_download;
 BU_HIP_API bu_hip_download* bu_hip_download_begin(bu_hip_context*, void* h_dst, const void* d_src, size_t bytes);
 BU_HIP_API int   bu_hip_download_wait(bu_hip_download*);

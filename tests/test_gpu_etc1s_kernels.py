@@ -80,10 +80,10 @@ def test_upload_and_encode_pipeline(hip_ctx, blocks, kind):
     rng = np.random.default_rng(5)
     src = np.ascontiguousarray(blocks[rng.integers(0, blocks.shape[0], n)]).reshape(n, 64)
     src[:, 0] ^= (np.arange(n) & 255).astype(np.uint8)          # every piece differs from every other
-    hip, pinned = None, VP()
-    if kind == "pinned":   # page-locked memory from the runtime the library itself links
-        hip = C.CDLL("libamdhip64.so")
-        assert hip.hipHostMalloc(C.byref(pinned), C.c_size_t(n * 64), C.c_uint(0)) == 0
+    pinned = None
+    if kind == "pinned":   # page-locked memory from the library (bu_hip_host_alloc)
+        pinned = hip_ctx.lib.host_alloc(n * 64)
+        assert pinned
         host = np.ctypeslib.as_array(C.cast(pinned, C.POINTER(C.c_uint8)), shape=(n * 64,)).reshape(n, 64)
         host[:] = src
     else:
@@ -103,9 +103,9 @@ def test_upload_and_encode_pipeline(hip_ctx, blocks, kind):
     assert (got[pick] == exp).all()
     for q in (d_px, d_out, d_ref):
         hip_ctx.free(q)
-    if hip is not None:
+    if pinned:
         del host
-        hip.hipHostFree(pinned)
+        hip_ctx.lib.host_free(pinned)
 
 
 def _encode_ref(blocks, level=1, perceptual=1):
