@@ -259,7 +259,9 @@ void etc1s_frontend::finish_prefetches(int which) const {   // 1 = the endpoint 
         if (ok && m_enc_dev_valid) m_enc_host_valid = true;
     }
 }
+static bool result_prefetch_on() { static const bool on = [] { const char* e = std::getenv("BU_RESULT_PREFETCH"); return !e || e[0] != '0'; }(); return on; }   // A/B switch
 void etc1s_frontend::prefetch_endpoint_map() {
+    if (!result_prefetch_on()) return;
     if (!m_dev || !m_ep_dev_valid || m_endpoint_map_valid || m_dl_ep_cluster || m_dl_ep_pos) return;
     m_block_endpoint_cluster.resize(m_total_blocks); m_block_endpoint_pos.resize(m_total_blocks);
     m_dl_ep_cluster = bu_hip_download_begin(m_dev->ctx, m_block_endpoint_cluster.data(), m_dev->block_cluster.p, (size_t)m_total_blocks * 4);
@@ -267,6 +269,7 @@ void etc1s_frontend::prefetch_endpoint_map() {
     if (m_dl_ep_cluster && !m_dl_ep_pos) { (void)bu_hip_download_wait(m_dl_ep_cluster); m_dl_ep_cluster = nullptr; }   // both or neither: ensure_endpoint_map fetches the pair
 }
 void etc1s_frontend::prefetch_encoded_blocks() {
+    if (!result_prefetch_on()) return;
     if (!m_dev || !m_enc_dev_valid || m_enc_host_valid || m_dl_enc) return;
     m_encoded_blocks.resize(m_total_blocks);
     m_dl_enc = bu_hip_download_begin(m_dev->ctx, m_encoded_blocks.data(), m_dev->enc.p, (size_t)m_total_blocks * 8);

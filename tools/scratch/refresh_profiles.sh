@@ -2,7 +2,7 @@
 # After `gpurun -- bash tools/scratch/gpu_round.sh <tag> tests bench prof pmc [calib]`: copy the round's summaries from gpurun_out/ into profiles/ and regenerate the
 # derived tables (pmc_traffic.json, valu_busy.json, <tag>_valu_table.md, <tag>_resource_usage.txt) at the current commit.   usage: tools/scratch/refresh_profiles.sh <tag>
 set -e
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 tag=$1
 commit=$(git rev-parse --short HEAD)
 for f in kernel_stats pmc_fetch_size pmc_write_size pmc_sq pmc_calib; do [ -s gpurun_out/${tag}_$f.csv ] && cp gpurun_out/${tag}_$f.csv profiles/; done
