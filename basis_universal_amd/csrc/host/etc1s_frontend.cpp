@@ -116,6 +116,7 @@ struct etc1s_frontend::device_state {
     buf sel_idx, sel_ukeys, sel_uw, sel_goffs;  // outputs of bu_hip_k_unique_selector_vectors
     buf ep_idx, ep_ukeys, ep_goffs;             // outputs of bu_hip_k_unique_endpoint_vectors
     // the clusterings as resident per-block maps (bookkeeping_kernels.hip) and the small arrays around them
+    buf cb_pack;   // one fit's results + the membership table behind them: one download (generate_endpoint_codebook)
     buf ep_pos, ep_parent, ep_parent_u, sel_cluster, sel_parent, orig_enc, map_sizes, map_offs, map_sorted, map_word, tmp_a, tmp_b, tmp_c, flags;
 
     bool reserve(buf& b, size_t bytes) {
@@ -134,7 +135,7 @@ struct etc1s_frontend::device_state {
     template <typename T> bool download(T* dst, const buf& b, size_t count) { return bu_hip_memcpy_d2h(ctx, dst, b.p, count * sizeof(T)) != 0; }
     void release() {
         for (buf* b : {&etc1, &enc, &block_cluster, &params, &err, &valid, &offsets, &indices, &cand_offsets, &cand_indices, &block_parent, &out_u32, &sel_blocks, &weights,
-                       &sel_idx, &sel_ukeys, &sel_uw, &sel_goffs, &ep_idx, &ep_ukeys, &ep_goffs,
+                       &sel_idx, &sel_ukeys, &sel_uw, &sel_goffs, &ep_idx, &ep_ukeys, &ep_goffs, &cb_pack,
                        &ep_pos, &ep_parent, &ep_parent_u, &sel_cluster, &sel_parent, &orig_enc, &map_sizes, &map_offs, &map_sorted, &map_word, &tmp_a, &tmp_b, &tmp_c, &flags})
             if (b->p) { bu_hip_free(ctx, b->p); b->p = nullptr; b->cap = 0; }
         if (owns_pixels && d_pixels) bu_hip_free(ctx, const_cast<void*>(d_pixels));
@@ -419,6 +420,7 @@ bool etc1s_frontend::init_endpoint_training_vectors() {
 // frontend.cpp:868-944
 bool etc1s_frontend::generate_endpoint_clusters() {
     finish_prefetches(1);   // nothing rewrites what a pending download reads
+    m_ep_member_valid = false;
     const uint32_t parent_size = (m_params.m_max_endpoint_clusters >= 256) ? kEndpointParentCodebookSize : 0;
     const uint32_t n = m_total_blocks, u_total = m_endpoint_unique_count;
     const uint32_t want_parents = m_use_hierarchical_endpoint_codebooks ? parent_size : 0;
@@ -515,8 +517,9 @@ void etc1s_frontend::ensure_endpoint_map() const {
     m_endpoint_map_valid = true;
 }
 bool etc1s_frontend::ensure_endpoint_map_device() {
-    finish_prefetches(1);   // nothing rewrites what a pending download reads
     if (m_ep_dev_valid) return true;
+    finish_prefetches(1);   // nothing rewrites what a pending download reads
+    m_ep_member_valid = false;
     ensure_endpoint_map();
     device_state& d = *m_dev;
     if (!m_endpoint_map_valid || !d.upload(d.block_cluster, m_block_endpoint_cluster.data(), m_total_blocks) || !d.upload(d.ep_pos, m_block_endpoint_pos.data(), m_total_blocks))
@@ -575,13 +578,19 @@ void etc1s_frontend::compute_endpoint_clusters_within_each_parent_cluster() {
     const size_t parents = m_endpoint_parent_count, clusters = m_endpoint_cluster_count;
     m_endpoint_clusters_within_each_parent_cluster.assign(parents, {});
     device_state& d = *m_dev;
-    std::vector<uint8_t> member(parents * clusters, 0);
+    std::vector<uint8_t> member;
+    if (m_ep_member_valid && m_ep_member_parents == parents && m_ep_member_clusters == clusters && m_ep_member.size() == parents * clusters) {
+        member.swap(m_ep_member);   // came back with the codebook fit's results (generate_endpoint_codebook): the clustering has not changed since
+        m_ep_member_valid = false;
+    } else {
+        member.assign(parents * clusters, 0);
     if (!ensure_endpoint_map_device() || !d.reserve(d.flags, parents * clusters + 8) ||
         !bu_hip_k_map_membership(d.ctx, (const uint8_t*)d.ep_parent.p, (const uint32_t*)d.block_cluster.p, m_total_blocks, (uint32_t)parents, (uint32_t)clusters, (uint8_t*)d.flags.p) ||
         !d.download(member.data(), d.flags, member.size())) {
         m_endpoint_clusters_within_each_parent_cluster.clear();   // the size check of refine_endpoint_clusterization fires on this
         fail("compute_endpoint_clusters_within_each_parent_cluster");
         return;
+    }
     }
     for (size_t p = 0; p < parents; p++)
         for (size_t c = 0; c < clusters; c++)
@@ -624,19 +633,43 @@ bool etc1s_frontend::generate_endpoint_codebook(uint32_t step) {
     if (!d.upload(d.offsets, lists.offsets.data(), lists.offsets.size()) ||
         (resident ? (!d.reserve(d.indices, (size_t)m_total_blocks * 8) ||
                      !bu_hip_k_map_endpoint_csr(d.ctx, (const uint32_t*)d.block_cluster.p, (const uint32_t*)d.ep_pos.p, m_total_blocks, (const uint32_t*)d.offsets.p, (uint32_t*)d.indices.p))
-                  : !d.upload(d.indices, lists.indices.data(), lists.indices.size())) ||
-        !d.reserve(d.params, (size_t)k * 4 + 8) || !d.upload(d.params, prm.data(), prm.size()) || !d.upload(d.err, err.data(), err.size()) ||
+                  : !d.upload(d.indices, lists.indices.data(), lists.indices.size())))
+        return fail("upload endpoint clusters");
+    m_ep_member_valid = false;
+    if (!m_has_comm) {
+        // One device buffer for the fit's three result arrays and -- when refine_endpoint_clusterization follows with parent lists -- the (parent, cluster) membership
+        // table it will ask for, whose kernel goes in front of the fit: everything comes back in ONE copy instead of four blocking ones (each a round trip with the device idle).
+        const size_t parents = m_endpoint_parent_count;
+        const bool with_members = resident && m_endpoint_refinement && m_use_hierarchical_endpoint_codebooks && parents && parents * (size_t)k <= ((size_t)64 << 20);
+        const size_t at_prm = (size_t)k * 8, at_valid = (size_t)k * 12, at_member = ((size_t)k * 13 + 15) & ~(size_t)15, total = at_member + (with_members ? parents * k : 0);
+        std::vector<uint8_t> pack(total, 0);
+        std::memcpy(pack.data(), err.data(), (size_t)k * 8); std::memcpy(pack.data() + at_prm, prm.data(), (size_t)k * 4); std::memcpy(pack.data() + at_valid, valid.data(), k);
+        if (!d.reserve(d.cb_pack, total + 16) || !bu_hip_memcpy_h2d_async(d.ctx, d.cb_pack.p, pack.data(), at_member)) return fail("upload endpoint clusters");
+        char* base = (char*)d.cb_pack.p;
+        if (with_members && !bu_hip_k_map_membership(d.ctx, (const uint8_t*)d.ep_parent.p, (const uint32_t*)d.block_cluster.p, m_total_blocks, (uint32_t)parents, k, (uint8_t*)(base + at_member)))
+            return fail("bu_hip_k_map_membership");
+        if (!bu_hip_k_generate_endpoint_codebook_part(d.ctx, d.d_pixels, k, lists.offsets.data(), (const uint32_t*)d.offsets.p, (const uint32_t*)d.indices.p, quality,
+                                                      m_params.m_perceptual, step, (uint8_t*)(base + at_prm), (uint64_t*)base, (uint8_t*)(base + at_valid), 0, 1))
+            return fail("bu_hip_k_generate_endpoint_codebook");
+        if (!bu_hip_memcpy_d2h(d.ctx, pack.data(), d.cb_pack.p, total)) return fail("download endpoint codebook");
+        std::memcpy(err.data(), pack.data(), (size_t)k * 8); std::memcpy(prm.data(), pack.data() + at_prm, (size_t)k * 4); std::memcpy(valid.data(), pack.data() + at_valid, k);
+        if (with_members) {
+            m_ep_member.assign(pack.begin() + (long)at_member, pack.end());
+            m_ep_member_parents = parents; m_ep_member_clusters = k; m_ep_member_valid = true;
+        }
+    } else {
+    if (!d.reserve(d.params, (size_t)k * 4 + 8) || !d.upload(d.params, prm.data(), prm.size()) || !d.upload(d.err, err.data(), err.size()) ||
         !d.reserve(d.valid, (size_t)k + 8) || !d.upload(d.valid, valid.data(), valid.size()))
         return fail("upload endpoint clusters");
-    if (m_has_comm) {  // the u64 merge rounds the byte arrays up to whole words: clear the tail
-        if (!bu_hip_memset(d.ctx, (char*)d.params.p + (size_t)k * 4, 0, 8) || !bu_hip_memset(d.ctx, (char*)d.valid.p + k, 0, 8)) return fail("memset");
-    }
+    // the u64 merge rounds the byte arrays up to whole words: clear the tail
+    if (!bu_hip_memset(d.ctx, (char*)d.params.p + (size_t)k * 4, 0, 8) || !bu_hip_memset(d.ctx, (char*)d.valid.p + k, 0, 8)) return fail("memset");
     if (!bu_hip_k_generate_endpoint_codebook_part(d.ctx, d.d_pixels, k, lists.offsets.data(), (const uint32_t*)d.offsets.p, (const uint32_t*)d.indices.p, quality,
                                                   m_params.m_perceptual, step, (uint8_t*)d.params.p, (uint64_t*)d.err.p, (uint8_t*)d.valid.p, comm_rank(), comm_world()))
         return fail("bu_hip_k_generate_endpoint_codebook");
     if (!merge_disjoint(d.params.p, (size_t)k * 4) || !merge_disjoint(d.err.p, (size_t)k * 8) || !merge_disjoint(d.valid.p, k)) return false;
     if (!d.download(prm.data(), d.params, prm.size()) || !d.download(err.data(), d.err, err.size()) || !d.download(valid.data(), d.valid, valid.size()))
         return fail("download endpoint codebook");
+    }
     for (uint32_t i = 0; i < k; i++) {
         endpoint_params& e = m_endpoint_cluster_etc_params[i];
         e.r = prm[i * 4]; e.g = prm[i * 4 + 1]; e.b = prm[i * 4 + 2]; e.inten = prm[i * 4 + 3]; e.valid = valid[i] != 0; e.color_error = err[i];
@@ -648,6 +681,7 @@ bool etc1s_frontend::generate_endpoint_codebook(uint32_t step) {
 // that their cluster represents worst are split off into new two-vector clusters until the codebook is full again.
 bool etc1s_frontend::introduce_new_endpoint_clusters() {
     finish_prefetches(1);   // nothing rewrites what a pending download reads
+    m_ep_member_valid = false;
     generate_block_endpoint_clusters();
     ensure_endpoint_lists();  // list surgery below; folded back into the map at the end
     int want = (int)m_params.m_max_endpoint_clusters - (int)m_endpoint_clusters.size();
@@ -697,6 +731,7 @@ bool etc1s_frontend::introduce_new_endpoint_clusters() {
 // here. The per-cluster sub-block lists are the reference's m_subblocks, which are appended to on every call and never cleared.
 bool etc1s_frontend::refine_block_endpoints_given_selectors(uint32_t* total_refined) {
     finish_prefetches();   // nothing rewrites what a pending download reads
+    m_ep_member_valid = false;
     const uint32_t n = m_total_blocks, k = (uint32_t)m_endpoint_cluster_etc_params.size();
     ensure_endpoint_map(); ensure_encoded_host();
     m_endpoint_cluster_subblocks.resize(k);
@@ -774,6 +809,7 @@ bool etc1s_frontend::refine_block_endpoints_given_selectors(uint32_t* total_refi
 bool etc1s_frontend::reoptimize_remapped_endpoints(const std::vector<uint32_t>& new_block_endpoints, std::vector<int>& old_to_new, bool optimize_final_codebook,
                                                    const std::vector<uint32_t>* block_selector_indices) {
     finish_prefetches();
+    m_ep_member_valid = false;
     if (!m_dev) return fail("reoptimize_remapped_endpoints: the context this frontend was initialised on has been destroyed");
     ensure_endpoint_map(); ensure_encoded_host(); ensure_selector_map_host();
     const uint32_t n = m_total_blocks, k = m_endpoint_cluster_count;
@@ -861,8 +897,8 @@ bool etc1s_frontend::refine_endpoint_clusterization(uint32_t* total_reassigned) 
             return fail("upload parent lists");
     }
     const size_t padded = (size_t)comm_world() * slab_blocks();
-    if (!d.upload(d.params, prm.data(), prm.size()) || !d.reserve(d.out_u32, padded * 4) || !d.reserve(d.map_sizes, ((size_t)k + 1) * 4) ||
-        !d.reserve(d.map_offs, ((size_t)k + 1) * 4) || !d.reserve(d.map_sorted, (size_t)n * 4) || !d.reserve(d.map_word, 64))
+    if (!d.upload(d.params, prm.data(), prm.size()) || !d.reserve(d.out_u32, padded * 4) || !d.reserve(d.map_sizes, ((size_t)k + 2) * 4) ||
+        !d.reserve(d.map_offs, ((size_t)k + 1) * 4) || !d.reserve(d.map_sorted, (size_t)n * 4))
         return fail("upload refine inputs");
     uint32_t b0, nb;
     my_slab(b0, nb);
@@ -873,12 +909,15 @@ bool etc1s_frontend::refine_endpoint_clusterization(uint32_t* total_reassigned) 
     if (!gather_blocks(d.out_u32.p, 4)) return false;
     // frontend.cpp:1921-1942 rebuilds the cluster lists in block order (empty clusters stay, they are removed by eliminate_...): the new
     // position of a block is its rank among its cluster's blocks -- a stable sort of the block ids by their new cluster, on the device.
-    if (!bu_hip_k_map_count_differences(d.ctx, (const uint32_t*)d.block_cluster.p, (const uint32_t*)d.out_u32.p, n, (uint32_t*)d.map_word.p) ||
+    // (the number of moved blocks lands behind the cluster sizes, word k + 1: both come back in one copy)
+    if (!bu_hip_k_map_count_differences(d.ctx, (const uint32_t*)d.block_cluster.p, (const uint32_t*)d.out_u32.p, n, (uint32_t*)d.map_sizes.p + k + 1) ||
         !bu_hip_k_map_rank_blocks(d.ctx, (const uint32_t*)d.out_u32.p, n, k, (uint32_t*)d.map_sizes.p, (uint32_t*)d.map_offs.p, (uint32_t*)d.map_sorted.p, (uint32_t*)d.ep_pos.p))
         return fail("bu_hip_k_map_rank_blocks");
     uint32_t moved = 0;
-    m_endpoint_cluster_sizes.assign(k, 0);
-    if (!d.download(m_endpoint_cluster_sizes.data(), d.map_sizes, k) || !d.download(&moved, d.map_word, 1)) return fail("download refine result");
+    m_endpoint_cluster_sizes.assign((size_t)k + 2, 0);
+    if (!d.download(m_endpoint_cluster_sizes.data(), d.map_sizes, (size_t)k + 2)) return fail("download refine result");
+    moved = m_endpoint_cluster_sizes[(size_t)k + 1];
+    m_endpoint_cluster_sizes.resize(k);
     std::swap(d.block_cluster, d.out_u32);   // the reassignment IS the clustering now
     if (d.block_cluster.cap < (size_t)n * 4 || d.out_u32.cap < (size_t)n * 4) return fail("refine buffers");
     m_ep_dev_valid = true; m_endpoint_map_valid = false; m_endpoint_lists_valid = false; m_endpoint_clusters.clear();
@@ -891,6 +930,7 @@ bool etc1s_frontend::refine_endpoint_clusterization(uint32_t* total_reassigned) 
 // so we call the very same algorithm with an equivalent comparator to get the same permutation among equal keys.
 bool etc1s_frontend::eliminate_redundant_or_empty_endpoint_clusters() {
     finish_prefetches(1);   // nothing rewrites what a pending download reads
+    m_ep_member_valid = false;
     if (!m_ep_dev_valid) ensure_endpoint_map();
     const uint32_t k = m_endpoint_cluster_count, n = m_total_blocks;
     std::vector<uint32_t> order(k);
@@ -970,8 +1010,8 @@ void etc1s_frontend::ensure_orig_encoded_host() const {
     if (m_dev && m_dev->orig_enc.p && m_dev->download(m_orig_encoded_blocks.data(), m_dev->orig_enc, m_total_blocks)) m_orig_host_valid = true;
 }
 bool etc1s_frontend::ensure_encoded_device() {
-    finish_prefetches(2);   // nothing rewrites what a pending download reads
     if (m_enc_dev_valid) return true;
+    finish_prefetches(2);   // nothing rewrites what a pending download reads
     device_state& d = *m_dev;
     const size_t padded = (size_t)comm_world() * slab_blocks();
     ensure_encoded_host();
