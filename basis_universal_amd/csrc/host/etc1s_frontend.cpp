@@ -308,7 +308,11 @@ bool etc1s_frontend::compress() {
     BU_STAGE_V("generate_block_endpoint_clusters", generate_block_endpoint_clusters());
     BU_STAGE("create_initial_packed_texture", create_initial_packed_texture());
     BU_STAGE("generate_selector_clusters", generate_selector_clusters());
-    if (m_use_hierarchical_selector_codebooks) BU_STAGE_V("compute_selector_clusters_within_each_parent_cluster", compute_selector_clusters_within_each_parent_cluster());
+    // (without a communicator the membership table of the selector parents comes back with the first codebook's download instead of in a round trip of its own:
+    //  create_optimized_selector_codebook; find_optimal_selector_clusters_for_each_block falls back on the pass below if the lists are missing)
+    m_selector_clusters_within_each_parent_cluster.clear();
+    if (m_use_hierarchical_selector_codebooks && (m_has_comm || m_params.m_compression_level == 0))
+        BU_STAGE_V("compute_selector_clusters_within_each_parent_cluster", compute_selector_clusters_within_each_parent_cluster());
     const uint32_t selector_steps = m_params.m_compression_level == 0 ? 1 : m_num_selector_codebook_iterations;
     for (uint32_t it = 0; it < selector_steps; it++) {
         BU_STAGE("create_optimized_selector_codebook", create_optimized_selector_codebook(it));
@@ -1176,6 +1180,29 @@ bool etc1s_frontend::create_optimized_selector_codebook(uint32_t /*iter*/) {
         if (c1 < c0) c1 = c0;
         for (uint32_t i = 0; i < k; i++) if (i < c0 || i >= c1) mine[i] = bu_etc_block{};
     }
+    if (!m_has_comm) {
+        // codebook (8 bytes per cluster) and, while the parent lists are still to be made, the (parent, cluster) membership table behind it: one buffer, one download
+        const size_t parents = m_selector_parent_count;
+        const bool with_members = m_use_hierarchical_selector_codebooks && m_params.m_compression_level != 0 && parents && m_selector_clusters_within_each_parent_cluster.size() != parents &&
+                                  parents * (size_t)k <= ((size_t)64 << 20);
+        const size_t at_member = ((size_t)k * 8 + 15) & ~(size_t)15, total = at_member + (with_members ? parents * k : 0);
+        if (!d.reserve(d.sel_blocks, total + 16) || !d.upload(d.sel_blocks, mine.data(), k)) return fail("upload selector clusters");
+        if (with_members && !bu_hip_k_map_membership(d.ctx, (const uint8_t*)d.sel_parent.p, (const uint32_t*)d.sel_cluster.p, n, (uint32_t)parents, k, (uint8_t*)d.sel_blocks.p + at_member))
+            return fail("bu_hip_k_map_membership");
+        if (k && !bu_hip_k_create_optimized_selector_codebook(d.ctx, d.d_pixels, d.enc.p, k, (const uint32_t*)d.map_offs.p, (const uint32_t*)d.map_sorted.p, m_params.m_perceptual, (char*)d.sel_blocks.p))
+            return fail("bu_hip_k_create_optimized_selector_codebook");
+        std::vector<uint8_t> pack(total);
+        if (total && !bu_hip_memcpy_d2h(d.ctx, pack.data(), d.sel_blocks.p, total)) return fail("download selector codebook");
+        std::memcpy(m_optimized_cluster_selectors.data(), pack.data(), (size_t)k * 8);
+        if (with_members) {
+            m_selector_clusters_within_each_parent_cluster.assign(parents, {});
+            for (size_t p = 0; p < parents; p++)
+                for (size_t c = 0; c < k; c++)
+                    if (pack[at_member + p * k + c]) m_selector_clusters_within_each_parent_cluster[p].push_back((uint32_t)c);
+        }
+        m_sel_blocks_dev_valid = true;   // d.sel_blocks holds what the host now holds: find_optimal_selector_clusters_for_each_block need not send it back
+        return true;
+    }
     if (!d.reserve(d.sel_blocks, (size_t)k * 8 + 8) || !d.upload(d.sel_blocks, mine.data(), k)) return fail("upload selector clusters");
     if (c1 > c0 && !bu_hip_k_create_optimized_selector_codebook(d.ctx, d.d_pixels, d.enc.p, c1 - c0, (const uint32_t*)d.map_offs.p + c0, (const uint32_t*)d.map_sorted.p, m_params.m_perceptual,
                                                                (char*)d.sel_blocks.p + (size_t)c0 * 8))
@@ -1202,6 +1229,7 @@ bool etc1s_frontend::find_optimal_selector_clusters_for_each_block() {
     device_state& d = *m_dev;
     uint32_t n_parents = 0;
     if (m_use_hierarchical_selector_codebooks) {
+        if (m_selector_clusters_within_each_parent_cluster.size() != m_selector_parent_count) compute_selector_clusters_within_each_parent_cluster();
         if (m_selector_clusters_within_each_parent_cluster.size() != m_selector_parent_count) return fail("selector parent lists missing (the membership pass failed)");
         csr cand; cand.build(m_selector_clusters_within_each_parent_cluster);
         n_parents = (uint32_t)m_selector_clusters_within_each_parent_cluster.size();
@@ -1210,7 +1238,9 @@ bool etc1s_frontend::find_optimal_selector_clusters_for_each_block() {
     }
     const size_t padded = (size_t)comm_world() * slab_blocks();
     // the encoded blocks stay resident from create_initial_packed_texture on unless the host touched them since (ensure_encoded_device)
-    if (!ensure_encoded_device() || !d.upload(d.sel_blocks, m_optimized_cluster_selectors.data(), k) || !d.reserve(d.out_u32, padded * 4))
+    const bool codebook_resident = m_sel_blocks_dev_valid && d.sel_blocks.p && d.sel_blocks.cap >= (size_t)k * 8;
+    m_sel_blocks_dev_valid = false;
+    if (!ensure_encoded_device() || (!codebook_resident && !d.upload(d.sel_blocks, m_optimized_cluster_selectors.data(), k)) || !d.reserve(d.out_u32, padded * 4))
         return fail("upload fosc inputs");
     uint32_t b0, nb;
     my_slab(b0, nb);  // slabs start on multiples of the reference's 2048-block jobs, so the "same tile as the previous block of this job" shortcut sees the same neighbours

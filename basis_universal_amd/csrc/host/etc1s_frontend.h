@@ -180,6 +180,7 @@ private:
     void finish_prefetches(int which = 3) const;
     // the (parent, cluster) membership table of refine_endpoint_clusterization, when it came back with the codebook fit's results (one copy instead of two round trips)
     std::vector<uint8_t> m_ep_member; size_t m_ep_member_parents = 0, m_ep_member_clusters = 0; bool m_ep_member_valid = false;
+    bool m_sel_blocks_dev_valid = false;   // the device copy of the selector codebook equals m_optimized_cluster_selectors (create_optimized_selector_codebook just made both)
     bool m_etc1_made_by_init = false;   // init() uploaded host tiles and encoded them piece by piece (bu_hip_k_upload_and_encode_etc1s_blocks): init_etc1_images() has nothing left to do
 
     // endpoint side
