@@ -108,6 +108,27 @@ def test_upload_and_encode_pipeline(hip_ctx, blocks, kind):
         hip_ctx.lib.host_free(pinned)
 
 
+def test_background_downloads(hip_ctx):
+    """bu_hip_download_begin / _wait: a copy on a stream of its own behind everything enqueued so far, carried out by the context's helper thread. Several at once, waited for in
+    the opposite order, each seeing the bytes its source held when it was begun (the source is rewritten only after the wait)."""
+    L = hip_ctx.lib
+    rng = np.random.default_rng(3)
+    n = 3 * 1024 * 1024 + 13
+    srcs = [rng.integers(0, 256, n, dtype=np.uint8) for _ in range(3)]
+    d = [hip_ctx.upload(a) for a in srcs]
+    outs = [np.zeros(n, np.uint8) for _ in range(3)]
+    for rep in range(2):   # the second round reuses the thread, the stream and the events
+        handles = [L.download_begin(hip_ctx.h, outs[i].ctypes.data_as(VP), d[i], n) for i in range(3)]
+        assert all(handles)
+        for i in (2, 1, 0):
+            assert L.download_wait(handles[i]) == 1
+            assert (outs[i] == srcs[i]).all()
+            outs[i][:] = 0
+    assert not L.download_begin(hip_ctx.h, None, d[0], n) and not L.download_begin(hip_ctx.h, outs[0].ctypes.data_as(VP), d[0], 0)   # refused, not crashed
+    for q in d:
+        hip_ctx.free(q)
+
+
 def _encode_ref(blocks, level=1, perceptual=1):
     n = blocks.shape[0]
     out = np.zeros((n, 8), np.uint8)
