@@ -1032,9 +1032,14 @@ int bu_hip_k_find_optimal_selector_clusters(bu_hip_context* ctx, const void* d_p
     device_guard g(ctx->device);
     prof_scope ps(ctx, "find_optimal_selector_clusters");
     arena& tmp = ctx->scratch[4];
-    BU_TRY(ctx, tmp.reserve((size_t)n_blocks * sizeof(uint32_t)));
+    // behind the per-block scratch: room for the candidates' selector words in list order (at most parents x selectors of them; left out beyond 64 MiB)
+    const size_t idx_bytes = ((size_t)n_blocks * sizeof(uint32_t) + 255) & ~(size_t)255;
+    size_t words = (size_t)(n_parents ? n_parents : 1u) * n_selectors;
+    if (words * 4 > ((size_t)64 << 20)) words = 0;
+    BU_TRY(ctx, tmp.reserve(idx_bytes + words * 4));
     BU_TRY(ctx, bu::launch_find_optimal_selector_clusters(ctx->stream, d_px, d_enc, n_blocks, d_selector_blocks, n_selectors, n_parents, d_cand_offsets,
-                                                          d_cand_indices, d_block_parent, perceptual != 0, chunk, static_cast<uint32_t*>(tmp.p), d_out));
+                                                          d_cand_indices, d_block_parent, perceptual != 0, chunk, static_cast<uint32_t*>(tmp.p), d_out,
+                                                          words ? reinterpret_cast<uint32_t*>(static_cast<char*>(tmp.p) + idx_bytes) : nullptr, words));
     return 1;
 }
 
@@ -2254,7 +2259,7 @@ int bu_hip_find_optimal_selector_clusters_for_each_block(bu_hip_context* ctx, co
     // chunk = 0: the OpenCL seam has no "same tile as previous block" shortcut (ocl_kernels.cl:1159-1225)
     BU_TRY(ctx, bu::launch_find_optimal_selector_clusters(ctx->stream, ctx->d_pixel_blocks, a_enc.p, n, a_sel.p, total_input_selectors, (uint32_t)win_first.size(),
                                                           static_cast<const uint32_t*>(a_off.p), static_cast<const uint32_t*>(a_idx.p), static_cast<const uint8_t*>(a_bp.p),
-                                                          perceptual != 0, 0, static_cast<uint32_t*>(a_tmp.p), d_out));
+                                                          perceptual != 0, 0, static_cast<uint32_t*>(a_tmp.p), d_out, nullptr, 0));
     std::vector<uint32_t> pos(n);
     BU_TRY(ctx, d2h_pageable(ctx, pos.data(), d_out, n * 4ull));
     BU_TRY(ctx, stream_wait(ctx, ctx->stream));

@@ -47,7 +47,7 @@ hipError_t launch_create_optimized_selector_codebook(hipStream_t st, const void*
 hipError_t launch_find_optimal_selector_clusters(hipStream_t st, const void* d_pixel_blocks, void* d_enc_blocks, uint32_t n_blocks,
                                                  const void* d_selector_blocks, uint32_t n_selectors, uint32_t n_parents, const uint32_t* d_cand_offsets,
                                                  const uint32_t* d_cand_indices, const uint8_t* d_block_parent, bool perceptual, uint32_t chunk,
-                                                 uint32_t* d_scratch_idx, uint32_t* d_out_idx);
+                                                 uint32_t* d_scratch_idx, uint32_t* d_out_idx, uint32_t* d_cand_words /* scratch for the candidates' selector words, or NULL */, size_t cand_words_capacity /* entries */);
 
 hipError_t launch_extract_blocks(hipStream_t st, const void* d_rgba, uint32_t width, uint32_t height, uint32_t pitch_bytes, void* d_out_blocks);
 

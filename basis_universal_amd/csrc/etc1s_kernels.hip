@@ -1291,13 +1291,29 @@ __global__ __launch_bounds__(256) void k_cosc_select(uint32_t n_clusters, const 
 // pass so that results stay identical even when equal tiles carry different endpoints.
 // -------------------------------------------------------------------------------------------------------------------
 
+// A candidate's error is a sum of 16 table entries err[selector of texel][texel]. The selector word keeps texel i's two bits at positions i and 16 + i (i = x * 4 + y), so two
+// neighbouring texels' selectors are a 4-bit code (two low-plane bits, two high-plane bits) and their two entries one entry of a 16-entry PAIR table: 8 look-ups per candidate
+// instead of 16, after 128 entries built once per block by the wave (integer sums: any grouping gives the same total). Blocks offered many candidates (q255: ~1,000 per block)
+// go one step further, four texels = an 8-bit code into four 256-entry tables made from the pair tables: 4 look-ups per candidate.
+// the low 32 bits (the selector bits) of every candidate in list order: words[j] = bits of selector_blocks[cand_indices[j]] (flat codebook: of selector_blocks[j])
+__global__ __launch_bounds__(256) void k_fosc_candidate_words(const uint64_t* __restrict__ selector_blocks, uint32_t n_selectors, uint32_t n_parents,
+                                                              const uint32_t* __restrict__ cand_offsets, const uint32_t* __restrict__ cand_indices, uint32_t* __restrict__ words) {
+    const uint32_t total = n_parents ? cand_offsets[n_parents] : n_selectors;
+    for (uint32_t j = blockIdx.x * 256u + threadIdx.x; j < total; j += gridDim.x * 256u)
+        words[j] = (uint32_t)bswap64(selector_blocks[n_parents ? cand_indices[j] : j]);
+}
+
+constexpr uint32_t FOSC_QUAD_MIN = 384;   // candidates per block from which the 1,024-entry tables pay for themselves (16 entries per lane to build)
+
 template <bool PERCEPTUAL>
 __global__ __launch_bounds__(256) void k_find_optimal_selector_clusters(
     const uint32_t* __restrict__ pixel_words, const uint64_t* __restrict__ enc_blocks, uint32_t n_blocks,
     const uint64_t* __restrict__ selector_blocks, uint32_t n_selectors, uint32_t n_parents,
     const uint32_t* __restrict__ cand_offsets, const uint32_t* __restrict__ cand_indices, const uint8_t* __restrict__ block_parent,
-    uint32_t* __restrict__ out_idx) {
-    __shared__ uint32_t s_err[4][64]; // [wave][s*16+p]
+    uint32_t* __restrict__ out_idx, const uint32_t* __restrict__ cand_words) {
+    __shared__ uint32_t s_err[4][64];     // [wave][s*16+p]
+    __shared__ uint32_t s_pair[4][128];   // [wave][g*16 + code4]: texels with selector bits 2g, 2g + 1
+    __shared__ uint32_t s_quad[4][1024];  // [wave][h*256 + code8]: texels with selector bits 4h .. 4h + 3
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t block = blockIdx.x * 4u + wave;
     if (block >= n_blocks) return;
@@ -1312,6 +1328,16 @@ __global__ __launch_bounds__(256) void k_find_optimal_selector_clusters(
     }
     // same-wave producer/consumer: LDS ops of one wave are ordered
     __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (uint32_t e = 0; e < 2; e++) {
+        const uint32_t idx = lane + e * 64u, g = idx >> 4, code = idx & 15u;
+        const uint32_t i0 = 2u * g, i1 = i0 + 1u;                               // selector bit positions = x * 4 + y
+        const uint32_t raw0 = (code & 1u) | ((code >> 1) & 2u), raw1 = ((code >> 1) & 1u) | ((code >> 2) & 2u);
+        const uint32_t s0 = (0x1Eu >> (raw0 * 2)) & 3u, s1 = (0x1Eu >> (raw1 * 2)) & 3u;   // g_etc1_to_selector_index (selector_from_bits)
+        const uint32_t p0 = (i0 & 3u) * 4u + (i0 >> 2), p1 = (i1 & 3u) * 4u + (i1 >> 2);   // raster texel y * 4 + x
+        s_pair[wave][idx] = s_err[wave][s0 * 16 + p0] + s_err[wave][s1 * 16 + p1];
+    }
+    __builtin_amdgcn_wave_barrier();
 
     uint32_t first = 0, total = n_selectors;
     if (n_parents) {
@@ -1320,16 +1346,35 @@ __global__ __launch_bounds__(256) void k_find_optimal_selector_clusters(
         total = cand_offsets[p + 1] - first;
     }
     uint64_t best_key = ~0ull;
-    for (uint32_t k = lane; k < total; k += 64) {
-        const uint32_t ci = n_parents ? cand_indices[first + k] : k;
-        const uint32_t lo = (uint32_t)bswap64(selector_blocks[ci]);
-        uint32_t e = 0;
+    if (total >= FOSC_QUAD_MIN) {   // wave-uniform
 #pragma unroll
-        for (uint32_t p = 0; p < 16; p++) {
-            const uint32_t s = selector_from_bits(lo, p & 3u, p >> 2);
-            e += s_err[wave][s * 16 + p];
+        for (uint32_t e = 0; e < 16; e++) {
+            const uint32_t idx = lane + e * 64u, h = idx >> 8, code = idx & 255u, a = code & 15u, b = code >> 4;
+            const uint32_t c_lo = (a & 3u) | ((b & 3u) << 2), c_hi = (a >> 2) | (b & 12u);
+            s_quad[wave][idx] = s_pair[wave][(2u * h) * 16u + c_lo] + s_pair[wave][(2u * h + 1u) * 16u + c_hi];
         }
-        best_key = min(best_key, ((uint64_t)e << 32) | k);
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t k = lane; k < total; k += 64) {
+            // cand_words (k_fosc_candidate_words): the candidates' selector words laid out in list order -- one coalesced load instead of list entry, then codebook entry
+            uint32_t lo;
+            if (cand_words) lo = cand_words[first + k];
+            else { const uint32_t ci = n_parents ? cand_indices[first + k] : k; lo = (uint32_t)bswap64(selector_blocks[ci]); }
+            uint32_t e = 0;
+#pragma unroll
+            for (uint32_t h = 0; h < 4; h++) e += s_quad[wave][h * 256u + (((lo >> (4u * h)) & 15u) | (((lo >> (16u + 4u * h)) & 15u) << 4))];
+            best_key = min(best_key, ((uint64_t)e << 32) | k);
+        }
+    } else {
+        for (uint32_t k = lane; k < total; k += 64) {
+            // cand_words (k_fosc_candidate_words): the candidates' selector words laid out in list order -- one coalesced load instead of list entry, then codebook entry
+            uint32_t lo;
+            if (cand_words) lo = cand_words[first + k];
+            else { const uint32_t ci = n_parents ? cand_indices[first + k] : k; lo = (uint32_t)bswap64(selector_blocks[ci]); }
+            uint32_t e = 0;
+#pragma unroll
+            for (uint32_t g = 0; g < 8; g++) e += s_pair[wave][g * 16u + (((lo >> (2u * g)) & 3u) | (((lo >> (16u + 2u * g)) & 3u) << 2))];
+            best_key = min(best_key, ((uint64_t)e << 32) | k);
+        }
     }
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) {
@@ -1616,12 +1661,19 @@ hipError_t launch_create_optimized_selector_codebook(hipStream_t st, const void*
 hipError_t launch_find_optimal_selector_clusters(hipStream_t st, const void* d_pixel_blocks, void* d_enc_blocks, uint32_t n_blocks,
                                                  const void* d_selector_blocks, uint32_t n_selectors, uint32_t n_parents, const uint32_t* d_cand_offsets,
                                                  const uint32_t* d_cand_indices, const uint8_t* d_block_parent, bool perceptual, uint32_t chunk,
-                                                 uint32_t* d_scratch_idx, uint32_t* d_out_idx) {
+                                                 uint32_t* d_scratch_idx, uint32_t* d_out_idx, uint32_t* d_cand_words, size_t cand_words_capacity) {
     if (!n_blocks) return hipSuccess;
     const dim3 grid((n_blocks + 3) / 4), blk(256);
     const uint32_t* pw = static_cast<const uint32_t*>(d_pixel_blocks);
-    if (perceptual) hipLaunchKernelGGL(k_find_optimal_selector_clusters<true>, grid, blk, 0, st, pw, static_cast<const uint64_t*>(d_enc_blocks), n_blocks, static_cast<const uint64_t*>(d_selector_blocks), n_selectors, n_parents, d_cand_offsets, d_cand_indices, d_block_parent, d_scratch_idx);
-    else hipLaunchKernelGGL(k_find_optimal_selector_clusters<false>, grid, blk, 0, st, pw, static_cast<const uint64_t*>(d_enc_blocks), n_blocks, static_cast<const uint64_t*>(d_selector_blocks), n_selectors, n_parents, d_cand_offsets, d_cand_indices, d_block_parent, d_scratch_idx);
+    // (a list holds every selector at most once: n_parents x n_selectors entries bound the lists' total, which only the device knows)
+    const size_t most = (size_t)(n_parents ? n_parents : 1u) * n_selectors;
+    if (d_cand_words && cand_words_capacity >= most && most) {
+        hipLaunchKernelGGL(k_fosc_candidate_words, dim3((uint32_t)std::min<size_t>((most + 255) / 256, 2048)), dim3(256), 0, st, static_cast<const uint64_t*>(d_selector_blocks), n_selectors, n_parents,
+                           d_cand_offsets, d_cand_indices, d_cand_words);
+        BU_LAUNCH_CHECK();
+    } else d_cand_words = nullptr;
+    if (perceptual) hipLaunchKernelGGL(k_find_optimal_selector_clusters<true>, grid, blk, 0, st, pw, static_cast<const uint64_t*>(d_enc_blocks), n_blocks, static_cast<const uint64_t*>(d_selector_blocks), n_selectors, n_parents, d_cand_offsets, d_cand_indices, d_block_parent, d_scratch_idx, d_cand_words);
+    else hipLaunchKernelGGL(k_find_optimal_selector_clusters<false>, grid, blk, 0, st, pw, static_cast<const uint64_t*>(d_enc_blocks), n_blocks, static_cast<const uint64_t*>(d_selector_blocks), n_selectors, n_parents, d_cand_offsets, d_cand_indices, d_block_parent, d_scratch_idx, d_cand_words);
     BU_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_fosc_resolve_and_stamp, dim3((n_blocks + 255) / 256), dim3(256), 0, st, static_cast<const uint4*>(d_pixel_blocks),
                        static_cast<uint64_t*>(d_enc_blocks), n_blocks, static_cast<const uint64_t*>(d_selector_blocks), chunk, d_scratch_idx, d_out_idx);
