@@ -187,10 +187,11 @@ class RcclComm:
         self.L = load_rccl_library()
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
         ident = C.create_string_buffer(128)
-        if self.rank == 0 and not self.L.bu_rccl_get_unique_id(ident):
-            raise capi.HipError("bu_rccl_get_unique_id: " + self.L.bu_rccl_last_error().decode())
-        box = [bytes(ident.raw)]
+        made = self.rank != 0 or bool(self.L.bu_rccl_get_unique_id(ident))
+        box = [bytes(ident.raw) if made else None]   # rank 0 broadcasts even when it has nothing: the other ranks must not wait for an id that never comes
         dist.broadcast_object_list(box, src=0, group=group)
+        if box[0] is None:
+            raise capi.HipError("bu_rccl_get_unique_id failed on rank 0" + (": " + self.L.bu_rccl_last_error().decode() if self.rank == 0 else ""))
         self.h = self.L.bu_rccl_comm_create(ctx.h, box[0], self.rank, self.world)
         if not self.h:
             raise capi.HipError("bu_rccl_comm_create: " + self.L.bu_rccl_last_error().decode())

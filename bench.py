@@ -353,7 +353,7 @@ def main():
             if shard and comm is None and hasattr(c, "close"):
                 c.close()
             return leg
-        other = mode_leg(not sharded)
+        other = None   # measured LAST, under a watchdog (below): the headline must not depend on a mode no hardware has run yet
         mine = {"value": round((1 if sharded else world) * args.steps * (w * h) / 1e6 / elapsed, 3), "unit": "Mpixels/s", "ms_per_step": round(elapsed / args.steps * 1e3, 2),
                 "scaling": "strong" if sharded else "weak", "is_the_headline": True}
         if sharded:
@@ -361,6 +361,7 @@ def main():
                          "host_wall_s_per_step": stage_split(stage_acc, args.steps)})
             if getattr(comm, "calls", None):
                 mine["collectives_total"] = dict(comm.calls)
+        OTHER_KEY = "replicas (one image per GPU, no data-path collective)" if sharded else "one image sharded over the ranks (--shard-image)"
         both_modes = {"replicas (one image per GPU, no data-path collective)": other if sharded else mine,
                       "one image sharded over the ranks (--shard-image)": mine if sharded else other}
 
@@ -463,6 +464,37 @@ def main():
             out["etc1s_kodak4096_q128"] = other_distribution_bench(ctx, helpers, "kodak4096_q128", lambda: helpers.kodak_mosaic(4096, 4096), "mosaic of the 24 Kodak images")
             out["etc1s_cube4096_q128"] = other_distribution_bench(ctx, helpers, "cube4096_q128", lambda: helpers.endpoint_cube(4096, 4096, 7),
                                                                   "endpoint cube (nearly every ETC1S endpoint occurs: 228,656 distinct endpoint vectors)")
+    # ---- N > 1: the OTHER mode's leg, after everything the line needs has been measured, and under a watchdog: if a rank fails in it or a collective never returns
+    #      (the native RCCL path has not met a multi-GPU node yet), rank 0 still prints the line -- with the leg marked -- and every rank leaves.
+    if both_modes is not None:
+        import threading
+        limit = float(os.environ.get("BU_BENCH_OTHER_MODE_TIMEOUT", "240"))
+        finished = threading.Event()
+
+        def bail():
+            if finished.is_set():
+                return
+            if rank == 0:
+                out["both_modes"][OTHER_KEY] = {"skipped": f"the leg did not finish within {limit:.0f} s; the headline and everything else in this line were measured before it"}
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+        timer = threading.Timer(limit, bail)
+        timer.daemon = True
+        timer.start()
+        failed = None
+        try:
+            other = mode_leg(not sharded)
+        except Exception as e:   # this rank failed: the others are (or will be) stuck in a collective and leave through their watchdogs
+            failed = f"{type(e).__name__}: {e}"[:400]
+            other = {"error": failed}
+        finished.set()
+        timer.cancel()
+        if rank == 0:
+            out["both_modes"][OTHER_KEY] = other
+            print(json.dumps(out), flush=True)
+        if failed is not None:
+            os._exit(0)
+    elif rank == 0:
         print(json.dumps(out))
     if last is not None:
         last.close()
