@@ -77,10 +77,12 @@ __device__ __forceinline__ uint32_t chroma_term(int dy, int dz) {
     return (cr26 >> 7) + (cb3 >> 7);
 }
 // perceptual only: min over the four unclamped colours of the luma term, dx0 = pixel.x - base.x, a64 / b64 = 64 * the table's two deltas
+// The four offsets are +-a, +-b: of each pair the one on dx0's side is the nearer, (|dx0| - a)^2 <= (|dx0| + a)^2, so two squares decide the minimum of four
+// (the same integers; |dx0| is shared by a pixel's eight tables). Until round 6 all four were squared: twice the multiplies and minimums of the kernels' innermost term.
 __device__ __forceinline__ uint32_t min_luma_term(int dx0, int a64, int b64) {
-    const int e0 = dx0 + b64, e1 = dx0 + a64, e2 = dx0 - a64, e3 = dx0 - b64;
-    const uint32_t q0 = (uint32_t)__mul24(e0, e0), q1 = (uint32_t)__mul24(e1, e1), q2 = (uint32_t)__mul24(e2, e2), q3 = (uint32_t)__mul24(e3, e3);
-    return min(min(q0, q1), min(q2, q3)) >> 5;
+    const int m = dx0 < 0 ? -dx0 : dx0;
+    const int ea = m - a64, eb = m - b64;
+    return min((uint32_t)__mul24(ea, ea), (uint32_t)__mul24(eb, eb)) >> 5;
 }
 
 // The four block colours of (scaled base colour, intensity table), clamped per channel (etc.h:584-602).
