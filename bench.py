@@ -928,7 +928,12 @@ def uastc_rdo_bench(ctx, helpers, args):
     # waits for the host), the timed region ends when the last one is complete. One batch's strips kernel is 96 serial chains on 96 of 256 CUs for ~20 ms; the next
     # submission's encode kernels and the previous one's hint refit run beside it. Same bytes per step as the synchronous form above (checked below on the last lanes).
     lanes = int(os.environ.get("BU_UASTC_LANES", "4"))   # (3 / 4 lanes side by side, 12 steps each: 18.4 / 16.4 ms per batch -- profiles/r06_rdo_lanes.txt)
+    # 64 of the 256 CUs carry the lanes' strip walks and nothing else (bu_hip_tuning::uastc_walk_cus, a setting of the pipeline's context, read when the lanes are made;
+    # off by default in the library: a pipeline that only encodes would lose those CUs). Three runs of tools/rdo_lanes.py, 4 lanes: 529 / 549 / 537 Mpix/s without, 557 / 572 / 569 with.
+    walk_cus = int(os.environ.get("BU_UASTC_WALK_CUS", "64"))
+    ctx.set_tuning(uastc_walk_cus=walk_cus)
     pipe = uastc.UastcPipeline(ctx, lanes, n, flags, jobs)
+    ctx.set_tuning()
     outs = [d_out] + [torch.empty_like(d_out) for _ in range(lanes - 1)]
     for k in range(lanes):
         pipe.submit(d_px.data_ptr(), n, outs[k].data_ptr(), params, flags, jobs)
@@ -956,7 +961,7 @@ def uastc_rdo_bench(ctx, helpers, args):
            "ms_per_step": round(dt * 1e3, 2), "steps": steps, "workload": f"{what}, {jobs} strips of {n // jobs} blocks per step",
            "submission": f"every step is one bu_hip_uastc_pipeline_submit of the batch ({lanes} lanes: that many steps in flight on the device, no host wait between them); "
                          "timed from the first submission to the completion of the last",
-           "lanes": lanes, "lanes_identical": lanes_identical,
+           "lanes": lanes, "reserved_walk_cus": walk_cus, "lanes_identical": lanes_identical,
            "one_batch_start_to_finish": {"ms": round(dt_one * 1e3, 2), "value": round(n * 16 / 1e6 / dt_one, 2), "unit": "Mpixels/s",
                                          "note": "bu_hip_k_encode_uastc_blocks + bu_hip_k_uastc_rdo with the host waiting for each batch (round 3's `value`)"},
            "modified_blocks": int(info["modified"]), "kernels_ms_per_step": {k: round(v[0] / sync_steps, 3) for k, v in kern.items()},
