@@ -762,7 +762,7 @@ __global__ __launch_bounds__(256) void k_refine_endpoint_clusterization(
     __shared__ uint2 s_q[4][2][RQ];   // per wave: {cluster parameters, position in the list | "is the block's current cluster" << 31}
     __shared__ uint32_t s_qp[4][2][RQ];   // the partial error of a candidate that survived the first four pixels
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t block = blockIdx.x * 4u + (threadIdx.x >> 6);
+    const uint32_t block = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4u + (threadIdx.x >> 6)));   // wave-uniform, and told so (see k_refine_sorted)
     if (block >= n_blocks) return; // whole wave exits together
 
     cvec pc[16];
@@ -1014,7 +1014,8 @@ __global__ __launch_bounds__(256) void k_refine_sorted(const uint4* __restrict__
     __shared__ uint2 s_q[4][RQ];        // per wave: the survivors of a sweep's first four pixels
     __shared__ uint32_t s_qp[4][RQ];    // and their partial errors
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t block = blockIdx.x * 4u + (threadIdx.x >> 6);
+    // (wave-uniform, and told so: the block's tile is then fetched with scalar loads and its sixteen colour vectors are made on the scalar unit, once per wave instead of per lane)
+    const uint32_t block = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4u + (threadIdx.x >> 6)));
     if (block >= n_blocks) return; // whole wave exits together
 
     cvec pc[16];
@@ -1227,7 +1228,7 @@ __global__ __launch_bounds__(256) void k_cosc_accumulate(
     const uint32_t* __restrict__ pixel_words, const uint64_t* __restrict__ enc_blocks, uint32_t n_clusters,
     const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ block_indices, unsigned long long* __restrict__ acc) {
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = blockIdx.x * 4u + (threadIdx.x >> 6);
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4u + (threadIdx.x >> 6)));   // wave-uniform, and told so: the search below runs on the scalar unit
     const uint32_t begin = offsets[0], end = offsets[n_clusters];
     const uint64_t lo64 = (uint64_t)begin + (uint64_t)wave * COSC_CHUNK;
     if (lo64 >= end) return;
@@ -1314,8 +1315,8 @@ __global__ __launch_bounds__(256) void k_find_optimal_selector_clusters(
     __shared__ uint32_t s_err[4][64];     // [wave][s*16+p]
     __shared__ uint32_t s_pair[4][128];   // [wave][g*16 + code4]: texels with selector bits 2g, 2g + 1
     __shared__ uint32_t s_quad[4][1024];  // [wave][h*256 + code8]: texels with selector bits 4h .. 4h + 3
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const uint32_t block = blockIdx.x * 4u + wave;
+    const uint32_t lane = threadIdx.x & 63u, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t block = blockIdx.x * 4u + wave;   // wave-uniform, and told so: the block's header, parent and list bounds come through scalar loads
     if (block >= n_blocks) return;
 
     {
