@@ -97,10 +97,10 @@ __device__ __forceinline__ void pipeline_pass(char* lds, const Src& src, const u
     constexpr size_t BUF_BYTES = ((F_BYTES + D_BYTES + 15) / 16) * 16;
     static_assert(TQ_THREADS == 512 && TQ_TILE == 256 && CW >= 1 && CW <= 3, "wave roles below assume 8 waves, 4 of them producing");
     const int tid = threadIdx.x;
-    const bool consumer = tid < CW * 64;
     // Producer waves are chosen so that they do not share a SIMD with a chain consumer where that is possible (waves are dealt to
     // the 4 SIMDs round robin): a dependent add chain issues one VALU op per ~4 cycles and every foreign op on its SIMD delays it.
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform, and told so: the roles below are scalar branches
+    const bool consumer = wave < CW;
     int pslot = -1;
     if (CW == 1) pslot = wave == 1 ? 0 : wave == 2 ? 1 : wave == 3 ? 2 : wave == 5 ? 3 : -1;        // SIMD 0 is the consumer's alone
     else if (CW == 2) pslot = wave == 2 ? 0 : wave == 3 ? 1 : wave == 6 ? 2 : wave == 7 ? 3 : -1;   // SIMD 0 / 1 reserved
@@ -484,7 +484,7 @@ __device__ __forceinline__ void tsvq_split_body(Src src, const uint64_t* __restr
         }
         TQ_TICK(8);
         // wave totals (DPP prefix: the last lane holds the sum) -> LDS -> wave 0 adds the eight waves' parts and decides
-        const int lane = tid & 63, wave = tid >> 6;
+        const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 #pragma unroll
         for (int i = 0; i < 16; i++) acc_r[i] = wave_sum_u32(acc_r[i]);
         if (first)
@@ -780,7 +780,7 @@ __device__ __forceinline__ void tsvq_split_body(Src src, const uint64_t* __restr
         const bool right = valid && node_side[pos] != 0;
         const bool left = valid && !right;
         const uint64_t mL = __ballot(left), mR = __ballot(right);
-        const uint32_t lane = tid & 63, wave = tid >> 6;
+        const uint32_t lane = tid & 63, wave = (uint32_t)__builtin_amdgcn_readfirstlane(tid >> 6);
         const uint64_t below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
         const uint32_t pl = __popcll(mL & below), pr = __popcll(mR & below);
         if (lane == 0) { s_scan[wave][0] = __popcll(mL); s_scan[wave][1] = __popcll(mR); }
