@@ -216,6 +216,15 @@ __global__ __launch_bounds__(256) void k_encode_etc1s_blocks(const uint4* __rest
 // (shared by all such tables) and one luma minimum per pixel and table (etc1s_device.h, base_unclamped) instead of four full
 // distances; clamped tables take the four-distance form as before. The per-table totals of the 8 lanes meet in a three-step
 // exchange that leaves lane l with the complete total of one table, and from there on the reduction is the one above.
+//
+// Trials. Most of a block's 1 + perms trial colours are ones it has seen (check_for_redundant_solution): 4.2 of 17 are
+// evaluated per block of the bench image, but WHICH ones differs from block to block, and a wave that steps its 8 blocks
+// through the trial indices together evaluates the union (10.4 of 17). Here every block moves at its own pace: its 8 lanes
+// make the next EIGHT trial colours from the current best solution at once (lane l: trial next + l), the first of them
+// the filter does not know is evaluated, and only an evaluation that improves the best solution -- the one thing later
+// trial colours depend on -- makes the lanes generate again. A trial the filter knew when it was looked at stays known
+// (the filter only grows), a trial is entered into the filter when it is evaluated and not before: the sequence of
+// (colour, filter state) pairs is the reference's. A wave evaluates max-over-blocks trials (5.2) instead of the union.
 template <int QUALITY>
 __global__ __launch_bounds__(256) void k_encode_etc1s_blocks_by_pixel(const uint4* __restrict__ pixel_blocks, uint32_t n_blocks, uint2* __restrict__ out_blocks) {
     __shared__ uint32_t s_bloom[32][32];
@@ -223,6 +232,7 @@ __global__ __launch_bounds__(256) void k_encode_etc1s_blocks_by_pixel(const uint
     const uint32_t tid = threadIdx.x;
     const uint32_t sub = tid & 7u;        // pixels 2 sub, 2 sub + 1
     const uint32_t slot = tid >> 3;
+    const uint32_t group_shift = tid & 56u; // where this block's 8 lanes sit in a wave-wide ballot
     const uint32_t block_raw = blockIdx.x * 32u + slot;
     const bool in_range = block_raw < n_blocks;
     const uint32_t block = in_range ? block_raw : (n_blocks - 1);
@@ -257,21 +267,64 @@ __global__ __launch_bounds__(256) void k_encode_etc1s_blocks_by_pixel(const uint
 
     uint32_t best_err = 0xFFFFFFFFu; // every real total is < 2^28
     int best_r = 0, best_g = 0, best_b = 0, best_inten = 0;
-    bool done = false;
 
     __syncthreads(); // filters cleared
 
     const int perms = (int)perms_for_quality(QUALITY);
-    for (int i = -1; i < perms; i++) {
-        if (__all(done)) break;
-        bool active = !done;
-        int tr = 0, tg = 0, tb = 0;
-        if (i < 0) {
-            tr = avg_to_color5(avg_r); tg = avg_to_color5(avg_g); tb = avg_to_color5(avg_b);
-        } else if (active) {
-            active = cluster_fit_trial(c_cluster_fit_order[i], best_r, best_g, best_b, best_inten, avg_r, avg_g, avg_b, tr, tg, tb);
+    // what this lane holds of the block's current batch of trials: trial batch_base + sub, made from the best solution as it was then
+    int batch_base = 0, mine_r = 0, mine_g = 0, mine_b = 0;
+    bool mine_ok = false, batch_fresh = false;
+    uint32_t mine_h0 = 0, mine_h1 = 0;
+    int next = -1;                    // the first trial index this block has not dealt with; -1 = the average colour (etc.cpp:1047-1049)
+    bool done = false;
+
+    for (;;) {
+        // ---- which trial does each block evaluate next? (blocks that find none are done)
+        int pick = -1;                // lane of the block's batch whose trial it is
+        if (next < 0) {
+            pick = 0; next = 0;
+            mine_r = avg_to_color5(avg_r); mine_g = avg_to_color5(avg_g); mine_b = avg_to_color5(avg_b);
+            const uint32_t kh = hash_hsieh3((uint32_t)mine_r, (uint32_t)mine_g, (uint32_t)mine_b);
+            mine_h0 = kh & 1023u; mine_h1 = (kh >> 10) & 1023u;
+        } else {
+            bool searching = !done;
+            while (__any(searching)) {
+                if (searching && !batch_fresh) {
+                    batch_base = next; batch_fresh = true;
+                    const int idx = batch_base + (int)sub;
+                    mine_ok = idx < perms &&
+                              cluster_fit_trial(c_cluster_fit_order[min(idx, perms - 1)], best_r, best_g, best_b, best_inten, avg_r, avg_g, avg_b, mine_r, mine_g, mine_b);
+                    const uint32_t kh = hash_hsieh3((uint32_t)mine_r, (uint32_t)mine_g, (uint32_t)mine_b);
+                    mine_h0 = kh & 1023u; mine_h1 = (kh >> 10) & 1023u;
+                }
+                bool fresh_colour = false;
+                if (searching && mine_ok && batch_base + (int)sub >= next) {
+                    const uint32_t w0 = s_bloom[slot][mine_h0 >> 5], w1 = s_bloom[slot][mine_h1 >> 5];
+                    fresh_colour = !(((w0 >> (mine_h0 & 31u)) & 1u) && ((w1 >> (mine_h1 & 31u)) & 1u));
+                }
+                const uint32_t m8 = (uint32_t)(__ballot(fresh_colour) >> group_shift) & 0xFFu;
+                if (searching) {
+                    if (m8) {
+                        pick = __ffs((int)m8) - 1;
+                        next = batch_base + pick + 1;
+                        searching = false;
+                    } else {
+                        next = batch_base + 8; batch_fresh = false;
+                        if (next >= perms) { done = true; searching = false; }
+                    }
+                }
+            }
         }
-        if (active) active = bloom_test_and_set(&s_bloom[slot][0], tr, tg, tb);   // the 8 lanes read before any writes, and write the same
+        if (__all(done)) break;
+        const bool active = pick >= 0;
+        const int src_lane = active ? pick : 0;
+        const int tr = __shfl(mine_r, src_lane, 8), tg = __shfl(mine_g, src_lane, 8), tb = __shfl(mine_b, src_lane, 8);
+        if (active) {
+            // check_for_redundant_solution's insertion (etc.cpp:1072-1089): the 8 lanes write the same values
+            const uint32_t h0 = (uint32_t)__shfl((int)mine_h0, src_lane, 8), h1 = (uint32_t)__shfl((int)mine_h1, src_lane, 8);
+            atomicOr(&s_bloom[slot][h0 >> 5], 1u << (h0 & 31u));
+            atomicOr(&s_bloom[slot][h1 >> 5], 1u << (h1 & 31u));
+        }
         // evaluate_solution_slow (etc.cpp:1104-1278): this lane's two pixels against every enabled table
         const int br = scale5(tr), bg = scale5(tg), bb = scale5(tb);
         const cvec base_cv = to_cvec<true>(br, bg, bb);
@@ -314,19 +367,20 @@ __global__ __launch_bounds__(256) void k_encode_etc1s_blocks_by_pixel(const uint
             const uint32_t give = up ? k2[0] : k2[1];
             k1 = (up ? k2[1] : k2[0]) + (uint32_t)__shfl_xor((int)give, 4, 8);
         }
-        if (active) {
+        {
             const uint32_t total = ((enable_mask >> my_table) & 1u) ? k1 : 0x0FFFFFFFu;
             uint32_t key = (total << 3) | my_table;
             key = min(key, (uint32_t)__shfl_xor((int)key, 1, 8));
             key = min(key, (uint32_t)__shfl_xor((int)key, 2, 8));
             key = min(key, (uint32_t)__shfl_xor((int)key, 4, 8));
             const uint32_t trial_err = key >> 3;
-            if (trial_err < best_err) {
+            if (active && trial_err < best_err) {
                 best_err = trial_err; best_inten = (int)(key & 7u);
                 best_r = tr; best_g = tg; best_b = tb;
+                batch_fresh = false;              // the trials after this one start from the new best solution
             }
         }
-        if (best_err == 0) done = true; // etc.cpp:955-956, 993-994
+        if (best_err == 0 || next >= perms) done = true; // etc.cpp:955-956, 993-994
     }
 
     // Selectors of the winning (colour, table): first-min over s (etc.cpp:1188-1219), two pixels per lane
