@@ -85,6 +85,11 @@ __device__ __forceinline__ uint32_t min_luma_term(int dx0, int a64, int b64) {
     return min((uint32_t)__mul24(ea, ea), (uint32_t)__mul24(eb, eb)) >> 5;
 }
 
+// perceptual only: min over the four block colours of the distance to ONE pixel when some of the colours are clamped. An offset d that clamps no channel
+// (mn + d >= 0 for the negative ones, mx + d <= 255 for the positive ones; mn / mx = the base colour's smallest / largest channel) still shares the base
+// colour's chroma, so it costs one square; only the offsets that do clamp take the full distance. The minimum of the same four integers as min_err4's.
+struct mixed_min { uint32_t luma_sq, full; };   // min squared luma difference over the unclamped offsets (not yet >> 5), min distance over the clamped ones
+__device__ __forceinline__ uint32_t mixed_min_total(const mixed_min& m, uint32_t chroma) { return min((m.luma_sq >> 5) + chroma, m.full); }
 // The four block colours of (scaled base colour, intensity table), clamped per channel (etc.h:584-602).
 template <bool PERCEPTUAL>
 __device__ __forceinline__ void block_cvecs(cvec out[4], int br, int bg, int bb, int table) {

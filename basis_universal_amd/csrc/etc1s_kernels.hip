@@ -331,6 +331,7 @@ __global__ __launch_bounds__(256) void k_encode_etc1s_blocks_by_pixel(const uint
         const uint32_t todo = active ? enable_mask : 0u;
         const uint32_t ch0 = chroma_term(pc0.y - base_cv.y, pc0.z - base_cv.z), ch1 = chroma_term(pc1.y - base_cv.y, pc1.z - base_cv.z);
         const int dx0 = pc0.x - base_cv.x, dx1 = pc1.x - base_cv.x;
+        const int base_mn = min(br, min(bg, bb)), base_mx = max(br, max(bg, bb));
         uint32_t tot[8];
 #pragma unroll
         for (int t = 0; t < 8; t++) {
@@ -339,9 +340,22 @@ __global__ __launch_bounds__(256) void k_encode_etc1s_blocks_by_pixel(const uint
             if (base_unclamped(br, bg, bb, t)) {
                 tot[t] = min_luma_term(dx0, k_inten_a[t] * 64, k_inten_b[t] * 64) + ch0 + min_luma_term(dx1, k_inten_a[t] * 64, k_inten_b[t] * 64) + ch1;
             } else {
-                cvec bc[4];
-                block_cvecs<true>(bc, br, bg, bb, t);
-                tot[t] = min_err4<true>(pc0, bc) + min_err4<true>(pc1, bc);
+                // some of the four colours clamp: the others keep the base colour's chroma (one square each), the clamped ones take the full distance
+                mixed_min m0 = { ~0u, ~0u }, m1 = { ~0u, ~0u };
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int d = k == 0 ? -k_inten_b[t] : k == 1 ? -k_inten_a[t] : k == 2 ? k_inten_a[t] : k_inten_b[t];
+                    const bool clamps = d < 0 ? base_mn + d < 0 : base_mx + d > 255;
+                    const int e0 = dx0 - 64 * d, e1 = dx1 - 64 * d;
+                    m0.luma_sq = min(m0.luma_sq, clamps ? ~0u : (uint32_t)__mul24(e0, e0));
+                    m1.luma_sq = min(m1.luma_sq, clamps ? ~0u : (uint32_t)__mul24(e1, e1));
+                    if (clamps) {
+                        const cvec c = to_cvec<true>(clamp255(br + d), clamp255(bg + d), clamp255(bb + d));
+                        m0.full = min(m0.full, cdist<true>(pc0, c));
+                        m1.full = min(m1.full, cdist<true>(pc1, c));
+                    }
+                }
+                tot[t] = mixed_min_total(m0, ch0) + mixed_min_total(m1, ch1);
             }
         }
         // exchange: after the step with partner distance d the lane keeps the half of its tables selected by its bit d
