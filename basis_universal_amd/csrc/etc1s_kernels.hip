@@ -705,6 +705,17 @@ __global__ __launch_bounds__(CB_THREADS) void k_generate_endpoint_codebook(
             for (int t = 0; t < 8; t++) plain_mask |= base_unclamped(scale5(tr), scale5(tg), scale5(tb), t) ? (1u << t) : 0u;
             plain_mask &= enable_mask;
             const cvec base_cv = to_cvec<PERCEPTUAL>(scale5(tr), scale5(tg), scale5(tb));
+            uint32_t clamp_bits = 0;   // bit 4 t + k: colour k of table t clamps a channel (workgroup-uniform)
+            {
+                const int base_mn = min(scale5(tr), min(scale5(tg), scale5(tb))), base_mx = max(scale5(tr), max(scale5(tg), scale5(tb)));
+#pragma unroll
+                for (int t = 0; t < 8; t++) {
+                    if (base_mn - k_inten_b[t] < 0) clamp_bits |= 1u << (t * 4);
+                    if (base_mn - k_inten_a[t] < 0) clamp_bits |= 2u << (t * 4);
+                    if (base_mx + k_inten_a[t] > 255) clamp_bits |= 4u << (t * 4);
+                    if (base_mx + k_inten_b[t] > 255) clamp_bits |= 8u << (t * 4);
+                }
+            }
             for (uint32_t j = tid; j < n; j += CB_THREADS) {
                 const cvec p = pixel_cvec<PERCEPTUAL>(texel(j));
                 if (FORCED) {
@@ -714,15 +725,30 @@ __global__ __launch_bounds__(CB_THREADS) void k_generate_endpoint_codebook(
                         const cvec c = select_cvec(bc[t], sel);
                         tot[t] += cdist<PERCEPTUAL>(p, c);
                     }
-                } else if (PERCEPTUAL && plain_mask) {
-                    // tables whose four colours need no clamping share the pixel's chroma term (etc1s_device.h, base_unclamped)
+                } else if (PERCEPTUAL) {
+                    // colours that need no clamping share the pixel's chroma term (etc1s_device.h, base_unclamped / mixed_min): a table none of whose colours clamp costs
+                    // two squares, in the others only the clamped colours take the full distance (which ones: workgroup-uniform, scalar branches)
                     const uint32_t ch = chroma_term(p.y - base_cv.y, p.z - base_cv.z);
                     const int dx0 = p.x - base_cv.x;
 #pragma unroll
                     for (int t = 0; t < 8; t++) {
                         if (!((enable_mask >> t) & 1u)) continue;
-                        if ((plain_mask >> t) & 1u) tot[t] += min_luma_term(dx0, k_inten_a[t] * 64, k_inten_b[t] * 64) + ch;
-                        else tot[t] += min_err4<PERCEPTUAL>(p, bc[t]);
+                        if ((plain_mask >> t) & 1u) {
+                            tot[t] += min_luma_term(dx0, k_inten_a[t] * 64, k_inten_b[t] * 64) + ch;
+                        } else {
+                            mixed_min m = { ~0u, ~0u };
+#pragma unroll
+                            for (int k = 0; k < 4; k++) {
+                                const int d = k == 0 ? -k_inten_b[t] : k == 1 ? -k_inten_a[t] : k == 2 ? k_inten_a[t] : k_inten_b[t];
+                                if ((clamp_bits >> (t * 4 + k)) & 1u) {
+                                    m.full = min(m.full, cdist<true>(p, bc[t][k]));
+                                } else {
+                                    const int e = dx0 - 64 * d;
+                                    m.luma_sq = min(m.luma_sq, (uint32_t)__mul24(e, e));
+                                }
+                            }
+                            tot[t] += mixed_min_total(m, ch);
+                        }
                     }
                 } else {
 #pragma unroll
@@ -1114,9 +1140,17 @@ __global__ __launch_bounds__(256) void k_refine_sorted(const uint4* __restrict__
     uint32_t cur_err = 0xFFFFFFFFu;
     uint32_t thr;   // the error of the block's own cluster (a list member by construction), see k_refine_endpoint_clusterization
     {
-        cvec bc[4];
-        block_cvecs<PERCEPTUAL>(bc, scale5((int)(cur_prm & 255u)), scale5((int)((cur_prm >> 8) & 255u)), scale5((int)((cur_prm >> 16) & 255u)), (int)cur_inten);
-        uint32_t e = lane < 16 ? min_err4<PERCEPTUAL>(pixel_cvec<PERCEPTUAL>(block_words[lane & 15u]), bc) : 0u;
+        const int cr = scale5((int)(cur_prm & 255u)), cg = scale5((int)((cur_prm >> 8) & 255u)), cb = scale5((int)((cur_prm >> 16) & 255u));
+        uint32_t e = 0;
+        if (PERCEPTUAL && base_unclamped(cr, cg, cb, (int)cur_inten)) {   // (wave-uniform) nine clusters in ten: one chroma term and two squares instead of four distances
+            const cvec bcv = to_cvec<true>(cr, cg, cb);
+            const cvec p = pixel_cvec<true>(block_words[lane & 15u]);
+            if (lane < 16) e = min_luma_term(p.x - bcv.x, k_inten_a[cur_inten] * 64, k_inten_b[cur_inten] * 64) + chroma_term(p.y - bcv.y, p.z - bcv.z);
+        } else {
+            cvec bc[4];
+            block_cvecs<PERCEPTUAL>(bc, cr, cg, cb, (int)cur_inten);
+            if (lane < 16) e = min_err4<PERCEPTUAL>(pixel_cvec<PERCEPTUAL>(block_words[lane & 15u]), bc);
+        }
 #pragma unroll
         for (int o = 8; o >= 1; o >>= 1) e += (uint32_t)__shfl_xor((int)e, o, 64);
         thr = (uint32_t)__builtin_amdgcn_readfirstlane((int)e);
