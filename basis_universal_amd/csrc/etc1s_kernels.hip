@@ -111,6 +111,7 @@ __global__ __launch_bounds__(256) void k_encode_etc1s_blocks(const uint4* __rest
     const uint32_t tid = threadIdx.x;
     const uint32_t table = tid & 7u;
     const uint32_t slot = tid >> 3;
+    const uint32_t group_shift = tid & 56u; // where this block's 8 lanes sit in a wave-wide ballot
     const uint32_t block_raw = blockIdx.x * 32u + slot;
     const bool in_range = block_raw < n_blocks;
     const uint32_t block = in_range ? block_raw : (n_blocks - 1);
@@ -148,29 +149,67 @@ __global__ __launch_bounds__(256) void k_encode_etc1s_blocks(const uint4* __rest
 
     uint32_t best_err = 0xFFFFFFFFu; // every real total is < 2^28
     int best_r = 0, best_g = 0, best_b = 0, best_inten = 0;
-    bool done = false;
 
     __syncthreads(); // filters cleared
 
+    // Trials: every block at its own pace, eight trial colours per generation (see k_encode_etc1s_blocks_by_pixel below, which explains the scheme)
     const int perms = (int)perms_for_quality(QUALITY);
-    for (int i = -1; i < perms; i++) {
+    int batch_base = 0, mine_r = 0, mine_g = 0, mine_b = 0;
+    bool mine_ok = false, batch_fresh = false;
+    uint32_t mine_h0 = 0, mine_h1 = 0;
+    int next = -1;                    // the first trial index this block has not dealt with; -1 = the average colour (etc.cpp:1047-1049)
+    bool done = false;
+
+    for (;;) {
+        int pick = -1;                // lane of the block's batch whose trial it evaluates now
+        if (next < 0) {
+            pick = 0; next = 0;
+            mine_r = avg_to_color5(avg_r); mine_g = avg_to_color5(avg_g); mine_b = avg_to_color5(avg_b);
+            const uint32_t kh = hash_hsieh3((uint32_t)mine_r, (uint32_t)mine_g, (uint32_t)mine_b);
+            mine_h0 = kh & 1023u; mine_h1 = (kh >> 10) & 1023u;
+        } else {
+            bool searching = !done;
+            while (__any(searching)) {
+                if (searching && !batch_fresh) {
+                    batch_base = next; batch_fresh = true;
+                    const int idx = batch_base + (int)table;
+                    mine_ok = idx < perms &&
+                              cluster_fit_trial(c_cluster_fit_order[min(idx, perms - 1)], best_r, best_g, best_b, best_inten, avg_r, avg_g, avg_b, mine_r, mine_g, mine_b);
+                    const uint32_t kh = hash_hsieh3((uint32_t)mine_r, (uint32_t)mine_g, (uint32_t)mine_b);
+                    mine_h0 = kh & 1023u; mine_h1 = (kh >> 10) & 1023u;
+                }
+                bool fresh_colour = false;
+                if (searching && mine_ok && batch_base + (int)table >= next) {
+                    const uint32_t w0 = s_bloom[slot][mine_h0 >> 5], w1 = s_bloom[slot][mine_h1 >> 5];
+                    fresh_colour = !(((w0 >> (mine_h0 & 31u)) & 1u) && ((w1 >> (mine_h1 & 31u)) & 1u));
+                }
+                const uint32_t m8 = (uint32_t)(__ballot(fresh_colour) >> group_shift) & 0xFFu;
+                if (searching) {
+                    if (m8) {
+                        pick = __ffs((int)m8) - 1;
+                        next = batch_base + pick + 1;
+                        searching = false;
+                    } else {
+                        next = batch_base + 8; batch_fresh = false;
+                        if (next >= perms) { done = true; searching = false; }
+                    }
+                }
+            }
+        }
         if (__all(done)) break;
-        bool active = !done;
-        int tr = 0, tg = 0, tb = 0;
-        if (i < 0) {
-            tr = avg_to_color5(avg_r); tg = avg_to_color5(avg_g); tb = avg_to_color5(avg_b);
-        } else if (active) {
-            active = cluster_fit_trial(c_cluster_fit_order[i], best_r, best_g, best_b, best_inten, avg_r, avg_g, avg_b, tr, tg, tb);
-        }
+        const bool active = pick >= 0;
+        const int src_lane = active ? pick : 0;
+        const int tr = __shfl(mine_r, src_lane, 8), tg = __shfl(mine_g, src_lane, 8), tb = __shfl(mine_b, src_lane, 8);
         if (active) {
-            // The 8 lanes of a block run in lockstep inside one wave: all of them read the filter words before any of them
-            // writes, and all write the same values.
-            active = bloom_test_and_set(&s_bloom[slot][0], tr, tg, tb);
+            // check_for_redundant_solution's insertion (etc.cpp:1072-1089): the 8 lanes write the same values
+            const uint32_t h0 = (uint32_t)__shfl((int)mine_h0, src_lane, 8), h1 = (uint32_t)__shfl((int)mine_h1, src_lane, 8);
+            atomicOr(&s_bloom[slot][h0 >> 5], 1u << (h0 & 31u));
+            atomicOr(&s_bloom[slot][h1 >> 5], 1u << (h1 & 31u));
         }
-        if (active) {
+        {
             // evaluate_solution_slow (etc.cpp:1104-1278): this lane's table only
             uint32_t total = 0x0FFFFFFFu;
-            if (table_enabled) {
+            if (active && table_enabled) {
                 cvec bc[4];
                 block_cvecs<PERCEPTUAL>(bc, scale5(tr), scale5(tg), scale5(tb), (int)table);
                 total = 0;
@@ -182,12 +221,13 @@ __global__ __launch_bounds__(256) void k_encode_etc1s_blocks(const uint4* __rest
             key = min(key, (uint32_t)__shfl_xor((int)key, 2, 8));
             key = min(key, (uint32_t)__shfl_xor((int)key, 4, 8));
             const uint32_t trial_err = key >> 3;
-            if (trial_err < best_err) {
+            if (active && trial_err < best_err) {
                 best_err = trial_err; best_inten = (int)(key & 7u);
                 best_r = tr; best_g = tg; best_b = tb;
+                batch_fresh = false;              // the trials after this one start from the new best solution
             }
         }
-        if (best_err == 0) done = true; // etc.cpp:955-956, 993-994
+        if (best_err == 0 || next >= perms) done = true; // etc.cpp:955-956, 993-994
     }
 
     // Selectors of the winning (colour, table): each of the 8 lanes classifies 2 pixels, first-min over s (etc.cpp:1188-1219).
