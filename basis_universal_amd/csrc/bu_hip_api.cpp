@@ -1464,7 +1464,10 @@ static int tsvq_split_impl(bu_hip_context* ctx, bu_tsvq* q, const bu_tsvq_node* 
     }
     if (zero_copy) { *round_flag = 0; __atomic_thread_fence(__ATOMIC_SEQ_CST); }
     if (n_narrow && !zero_copy) BU_TRY(ctx, hipMemcpyAsync(q->nodes.p, q->pinned, in_bytes, hipMemcpyHostToDevice, ctx->stream));
-    if (n_wide) BU_TRY(ctx, hipMemcpyAsync(q->wide_nodes, static_cast<char*>(q->pinned) + wide_at, wide_bytes, hipMemcpyHostToDevice, ctx->stream));
+    // the wide nodes' records + their cleared state: one kernel that reads the page-locked records, where the device can address them (otherwise a copy here and a fill in the launcher)
+    const bool wide_prologue = n_wide && zero_copy;
+    if (wide_prologue) BU_TRY(ctx, bu::launch_tsvq_wide_prologue(ctx->stream, reinterpret_cast<const bu::tsvq_wide_node*>(d_pinned + wide_at), q->wide_nodes, q->wide_ctrl, n_wide));
+    else if (n_wide) BU_TRY(ctx, hipMemcpyAsync(q->wide_nodes, static_cast<char*>(q->pinned) + wide_at, wide_bytes, hipMemcpyHostToDevice, ctx->stream));
     const bool exact = q->packed && !q->force_chained;
     // The two kinds of node of a round do not touch each other's data: when both are present the one-workgroup kernel runs on the side
     // stream, under the many small launches of the wide path. (Not while kernels are being timed one by one.)
@@ -1504,11 +1507,11 @@ static int tsvq_split_impl(bu_hip_context* ctx, bu_tsvq* q, const bu_tsvq_node* 
         prof_scope ps(ctx, q->packed ? "tsvq_split_packed16_wide" : "tsvq_split_float6_wide");
         if (!q->packed)
             BU_TRY(ctx, bu::launch_tsvq_wide6_split(ctx->stream, static_cast<const float*>(q->rows), q->w64, q->n, q->perm[0], q->perm[1], q->side, q->wide_nodes, n_wide, q->wide_ctrl, q->wide_ws,
-                                                    wide_blocks, d_outs, static_cast<float*>(q->wide_packed), reinterpret_cast<double*>(static_cast<char*>(q->wide_packed) + (size_t)q->n * 24)));
+                                                    wide_blocks, d_outs, static_cast<float*>(q->wide_packed), reinterpret_cast<double*>(static_cast<char*>(q->wide_packed) + (size_t)q->n * 24), wide_prologue));
         else
         BU_TRY(ctx, bu::launch_tsvq_wide_split(ctx->stream, static_cast<const uint32_t*>(q->rows), q->w64, q->perm[0], q->perm[1], q->side, q->wide_packed, q->wide_nodes, n_wide, q->wide_ctrl,
                                                q->wide_ws, wide_blocks, d_outs, wide_max_count < q->wide_cov_min,
-                                               wide_max_weight * 3ull < (1ull << 24), q->windows));
+                                               wide_max_weight * 3ull < (1ull << 24), q->windows, wide_prologue));
     }
     if (n_wide && q->dbg_stats && q->packed) {   // development aid: how the last pass's walks went, per wide node
         std::vector<bu::tsvq_wide_ctrl> hc(n_wide);

@@ -51,6 +51,9 @@ struct tsvq_wide_ctrl {   // device-side state of one node across the passes of 
     int32_t iter, done;
     uint32_t ex_bad;
 };
+// node records from device-visible host memory into d_nodes + cleared d_ctrl, one launch (instead of a copy and a fill in front of a round); a split launched after it
+// is told so (ctrl_cleared)
+hipError_t launch_tsvq_wide_prologue(hipStream_t st, const tsvq_wide_node* src, tsvq_wide_node* d_nodes, tsvq_wide_ctrl* d_ctrl, uint32_t n_nodes);
 // covariance chain sums of every node (chained sums, three workgroups per node, each a third of the chains) into d_ctrl[i].sums -- k_wide_finish<WM_COV> makes
 // the axis of them; fills d_packed for the nodes' members
 hipError_t launch_tsvq_cov_axis(hipStream_t st, const uint32_t* d_keys, const uint64_t* d_w64, const uint32_t* d_perm0, const uint32_t* d_perm1,
@@ -67,7 +70,7 @@ hipError_t launch_tsvq_wide_split(hipStream_t st, const uint32_t* d_keys, const 
                                   const tsvq_wide_node* d_nodes, uint32_t n_nodes, tsvq_wide_ctrl* d_ctrl, void* d_ws, uint32_t total_blocks, tsvq_split_out* d_outs,
                                   bool chained_covariance /* the covariance pass through launch_tsvq_cov_axis instead of 136 walks per node */,
                                   bool side_chains_exact /* 3 x the heaviest node's weight < 2^24: every projection / two-means chain total is exact, no maps needed */,
-                                  int windows /* bu_hip_tuning::tsvq_windows */);
+                                  int windows /* bu_hip_tuning::tsvq_windows */, bool ctrl_cleared = false /* launch_tsvq_wide_prologue went in front */);
 // the same split for 6-float rows (the endpoint tree's large nodes, tsvq_wide6_kernels.hip): workspace / node / ctrl records as above (no barrier words); d_va: 6 n floats,
 // d_tta: n doubles -- the list-order copies of the per-member addends the covariance pass lays out (launch_tsvq_cov_axis6: chained sums, one workgroup per node)
 hipError_t launch_tsvq_cov_axis6(hipStream_t st, const float* d_rows, const uint64_t* d_w64, const uint32_t* d_perm0, const uint32_t* d_perm1,
@@ -77,6 +80,6 @@ hipError_t launch_tsvq_wide6_root(hipStream_t st, const float* d_rows, const uin
                                   float* d_va, double* d_tta);
 hipError_t launch_tsvq_wide6_split(hipStream_t st, const float* d_rows, const uint64_t* d_w64, uint32_t n, uint32_t* d_perm0, uint32_t* d_perm1, uint8_t* d_side,
                                    const tsvq_wide_node* d_nodes, uint32_t n_nodes, tsvq_wide_ctrl* d_ctrl, void* d_ws, uint32_t total_blocks, tsvq_split_out* d_outs,
-                                   float* d_va, double* d_tta);
+                                   float* d_va, double* d_tta, bool ctrl_cleared = false);
 
 } // namespace bu

@@ -287,6 +287,25 @@ hipError_t launch_tsvq_signal(hipStream_t st, uint32_t* d_flag, uint32_t value) 
     return hipGetLastError();
 }
 
+// What a many-workgroup round starts with, as ONE launch instead of a host -> device copy and a fill (two runtime commands, each with its own ~10-20 us of
+// latency in front of the round's first kernel): workgroup i brings node record i over from the page-locked records the host has just written (device-visible
+// host memory, read once) and clears the node's state.
+__global__ __launch_bounds__(256) void k_tsvq_wide_prologue(const tsvq_wide_node* __restrict__ src, tsvq_wide_node* __restrict__ nodes, tsvq_wide_ctrl* __restrict__ ctrl) {
+    static_assert(sizeof(tsvq_wide_node) % 4 == 0 && sizeof(tsvq_wide_ctrl) % 4 == 0, "copied and cleared by dwords");
+    const uint32_t i = blockIdx.x;
+    const uint32_t* s = reinterpret_cast<const uint32_t*>(src + i);
+    uint32_t* d = reinterpret_cast<uint32_t*>(nodes + i);
+    if (threadIdx.x < sizeof(tsvq_wide_node) / 4) d[threadIdx.x] = __builtin_nontemporal_load(s + threadIdx.x);
+    uint32_t* c = reinterpret_cast<uint32_t*>(ctrl + i);
+    for (uint32_t k = threadIdx.x; k < sizeof(tsvq_wide_ctrl) / 4; k += 256) c[k] = 0;
+}
+hipError_t launch_tsvq_wide_prologue(hipStream_t st, const tsvq_wide_node* src, tsvq_wide_node* d_nodes, tsvq_wide_ctrl* d_ctrl, uint32_t n_nodes) {
+    static_assert(sizeof(tsvq_wide_node) / 4 <= 256, "one thread per dword of a node record");
+    if (!n_nodes) return hipSuccess;
+    hipLaunchKernelGGL(k_tsvq_wide_prologue, dim3(n_nodes), dim3(256), 0, st, src, d_nodes, d_ctrl);
+    return hipGetLastError();
+}
+
 // Deep rounds (bu_hip_tsvq_split_deep): the node records of the NEXT generation, made on the device from the result records of the generation before it, so that the
 // children's splits follow their parents' on the stream without the host in between. Child t = side (t & 1) of parent t >> 1. A child is attempted when its parent's
 // split succeeded (ok == 1), it has more than one member, and its variance -- after the reference's substitution of 1e-4 for a non-positive variance of a node with

@@ -607,9 +607,9 @@ __global__ __launch_bounds__(256) void k6_iota(uint32_t n, uint32_t* __restrict_
 
 hipError_t launch_tsvq_wide6_split(hipStream_t st, const float* d_rows, const uint64_t* d_w64, uint32_t n, uint32_t* d_perm0, uint32_t* d_perm1, uint8_t* d_side,
                                    const tsvq_wide_node* d_nodes, uint32_t n_nodes, tsvq_wide_ctrl* d_ctrl, void* d_ws, uint32_t total_blocks, tsvq_split_out* d_outs,
-                                   float* d_va, double* d_tta) {
+                                   float* d_va, double* d_tta, bool ctrl_cleared) {
     if (!n_nodes) return hipSuccess;
-    hipError_t e = hipMemsetAsync(d_ctrl, 0, (size_t)n_nodes * sizeof(tsvq_wide_ctrl), st);
+    hipError_t e = ctrl_cleared ? hipSuccess : hipMemsetAsync(d_ctrl, 0, (size_t)n_nodes * sizeof(tsvq_wide_ctrl), st);
     if (e != hipSuccess) return e;
     // covariance: chained sums, one workgroup per node (+ the list-order copies of the per-member addends), then the principal axis
     if ((e = launch_tsvq_cov_axis6(st, d_rows, d_w64, d_perm0, d_perm1, d_nodes, n_nodes, d_ctrl, d_va, d_tta, n)) != hipSuccess) return e;

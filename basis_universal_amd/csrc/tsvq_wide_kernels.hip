@@ -859,9 +859,9 @@ hipError_t launch_tsvq_wide_span_roots(hipStream_t st, const uint32_t* d_keys, c
 
 hipError_t launch_tsvq_wide_split(hipStream_t st, const uint32_t* d_keys, const uint64_t* d_w64, uint32_t* d_perm0, uint32_t* d_perm1, uint8_t* d_side, void* d_packed,
                                   const tsvq_wide_node* d_nodes, uint32_t n_nodes, tsvq_wide_ctrl* d_ctrl, void* d_ws, uint32_t total_blocks, tsvq_split_out* d_outs,
-                                  bool chained_covariance, bool side_chains_exact, int windows) {
+                                  bool chained_covariance, bool side_chains_exact, int windows, bool ctrl_cleared) {
     if (!n_nodes) return hipSuccess;
-    hipError_t e = hipMemsetAsync(d_ctrl, 0, (size_t)n_nodes * sizeof(tsvq_wide_ctrl), st);
+    hipError_t e = ctrl_cleared ? hipSuccess : hipMemsetAsync(d_ctrl, 0, (size_t)n_nodes * sizeof(tsvq_wide_ctrl), st);
     if (e != hipSuccess) return e;
     if (chained_covariance) {   // raw chain sums into ctrl[].sums (three workgroups per node), then the pass's own tail: renormalisation + principal axis
         if ((e = launch_tsvq_cov_axis(st, d_keys, d_w64, d_perm0, d_perm1, d_nodes, n_nodes, d_ctrl, d_packed)) != hipSuccess) return e;
