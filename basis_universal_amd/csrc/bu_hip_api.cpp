@@ -1228,6 +1228,7 @@ struct bu_tsvq {
 static_assert(sizeof(bu_tsvq_root) == sizeof(bu::tsvq_root_out), "layout");
 static_assert(sizeof(bu_tsvq_node) == sizeof(bu::tsvq_node_in), "layout");
 static_assert(sizeof(bu_tsvq_split) == sizeof(bu::tsvq_split_out), "layout");
+static int tsvq_wait_flag(bu_hip_context* ctx, bu_tsvq* q, volatile uint32_t* round_flag, uint32_t seq);
 
 extern "C" {
 
@@ -1308,33 +1309,51 @@ static bu_tsvq* tsvq_create_common(bu_hip_context* ctx, uint32_t dim, bool packe
     } else if (stream_wait(ctx, ctx->stream) != hipSuccess || hipMemcpy(q->rows, h_rows, (size_t)n * row_bytes, hipMemcpyHostToDevice) != hipSuccess ||
                hipMemcpy(q->w64, h_weights, (size_t)n * 8, hipMemcpyHostToDevice) != hipSuccess || hipDeviceSynchronize() != hipSuccess)
         return fail("upload");  // blocking copies (the sources are pageable, see bu_tsvq::pinned); the root kernel below needs both anyway
-    if (q->reserve_pinned(std::max(sizeof(bu_tsvq_root), sizeof(bu::tsvq_wide_node))) != hipSuccess) return fail("pinned allocation");
+    // the page-locked buffer here: [0] the root's node record (many-workgroup variant), [256] the root record the kernels produce, [768] the completion word
+    constexpr size_t ROOT_AT = 256, FLAG_AT = 768;
+    static_assert(sizeof(bu::tsvq_wide_node) <= ROOT_AT && ROOT_AT + sizeof(bu_tsvq_root) <= FLAG_AT, "layout of the root's page-locked records");
+    if (q->reserve_pinned(1024) != hipSuccess) return fail("pinned allocation");
+    // Zero-copy (as the rounds, tsvq_split_impl): the kernels read the node record from and write the root record into the page-locked buffer and a last one-thread kernel
+    // stores a word there that this thread looks at -- no copy commands, no hipStreamSynchronize between the root and the first round.
+    char* d_pinned = nullptr;
+    if (q->zero_copy && hipHostGetDevicePointer(reinterpret_cast<void**>(&d_pinned), q->pinned, 0) != hipSuccess) { (void)hipGetLastError(); d_pinned = nullptr; }
+    bu::tsvq_root_out* d_root = d_pinned ? reinterpret_cast<bu::tsvq_root_out*>(d_pinned + ROOT_AT) : static_cast<bu::tsvq_root_out*>(q->outs.p);
+    const bu_tsvq_root* h_root = reinterpret_cast<const bu_tsvq_root*>(static_cast<const char*>(q->pinned) + (d_pinned ? ROOT_AT : 0));
+    volatile uint32_t* flag = reinterpret_cast<volatile uint32_t*>(static_cast<char*>(q->pinned) + FLAG_AT);
     // many-workgroup variant first where it applies, then the exact (integer-reduced) one-workgroup variant; a record flagged
     // pad == 1 left the exact range -> next variant, the chained one last
     for (int attempt = q->wide_min ? -1 : 0; attempt < 2; attempt++) {
         const bool exact = packed && attempt == 0 && !q->force_chained;
+        if (d_pinned) { *flag = 0; }
         if (attempt < 0) {
             bu::tsvq_wide_node wn; std::memset(&wn, 0, sizeof(wn));
             wn.count = n; wn.n_blocks = (n + 255) / 256;
             std::memcpy(q->pinned, &wn, sizeof(wn));
-            if (hipMemcpyAsync(q->wide_nodes, q->pinned, sizeof(wn), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return fail("root upload");
+            if (d_pinned) {
+                __atomic_thread_fence(__ATOMIC_SEQ_CST);
+                if (bu::launch_tsvq_wide_prologue(ctx->stream, reinterpret_cast<const bu::tsvq_wide_node*>(d_pinned), q->wide_nodes, q->wide_ctrl, 1) != hipSuccess) return fail("root upload");
+            } else if (hipMemcpyAsync(q->wide_nodes, q->pinned, sizeof(wn), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return fail("root upload");
             prof_scope ps(ctx, packed ? "tsvq_root_packed16" : "tsvq_root_float6");
             if (!packed) {
                 if (bu::launch_tsvq_wide6_root(ctx->stream, static_cast<const float*>(q->rows), q->w64, n, q->perm[0], q->side, q->wide_nodes, q->wide_ctrl, q->wide_ws, wn.n_blocks,
-                                               static_cast<bu::tsvq_root_out*>(q->outs.p), static_cast<float*>(q->wide_packed),
-                                               reinterpret_cast<double*>(static_cast<char*>(q->wide_packed) + (size_t)n * 24)) != hipSuccess) return fail("wide root launch");
+                                               d_root, static_cast<float*>(q->wide_packed),
+                                               reinterpret_cast<double*>(static_cast<char*>(q->wide_packed) + (size_t)n * 24), d_pinned != nullptr) != hipSuccess) return fail("wide root launch");
             } else
             if (bu::launch_tsvq_wide_root(ctx->stream, static_cast<const uint32_t*>(q->rows), q->w64, n, q->perm[0], q->wide_nodes, q->wide_ctrl, q->wide_ws, wn.n_blocks,
-                                          static_cast<bu::tsvq_root_out*>(q->outs.p), q->windows) != hipSuccess) return fail("wide root launch");
+                                          d_root, q->windows, d_pinned != nullptr) != hipSuccess) return fail("wide root launch");
         } else {
+            if (d_pinned) __atomic_thread_fence(__ATOMIC_SEQ_CST);
             prof_scope ps(ctx, packed ? "tsvq_root_packed16" : "tsvq_root_float6");
-            if (bu::launch_tsvq_root(ctx->stream, (int)dim, packed, exact, q->rows, q->w64, n, q->perm[0], static_cast<bu::tsvq_root_out*>(q->outs.p)) != hipSuccess) return fail("root launch");
+            if (bu::launch_tsvq_root(ctx->stream, (int)dim, packed, exact, q->rows, q->w64, n, q->perm[0], d_root) != hipSuccess) return fail("root launch");
         }
-        if (hipMemcpyAsync(q->pinned, q->outs.p, sizeof(bu_tsvq_root), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || stream_wait(ctx, ctx->stream) != hipSuccess)
+        if (d_pinned) {
+            const uint32_t seq = ++q->round_seq ? q->round_seq : ++q->round_seq;   // never 0
+            if (bu::launch_tsvq_signal(ctx->stream, reinterpret_cast<uint32_t*>(d_pinned + FLAG_AT), seq) != hipSuccess || !tsvq_wait_flag(ctx, q, flag, seq)) return fail("root wait");
+        } else if (hipMemcpyAsync(q->pinned, q->outs.p, sizeof(bu_tsvq_root), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || stream_wait(ctx, ctx->stream) != hipSuccess)
             return fail("root download");
-        if ((attempt >= 0 && !exact) || static_cast<const bu_tsvq_root*>(q->pinned)->pad == 0) break;
+        if ((attempt >= 0 && !exact) || h_root->pad == 0) break;
     }
-    std::memcpy(out_root, q->pinned, sizeof(bu_tsvq_root));
+    std::memcpy(out_root, h_root, sizeof(bu_tsvq_root));
     return q;
 }
 
@@ -1394,6 +1413,38 @@ int bu_hip_k_unique_selector_vectors(bu_hip_context* ctx, const void* d_enc_bloc
     }
     BU_TRY(ctx, d2h_pageable(ctx, out_unique, d_n, 4));
     BU_TRY(ctx, stream_wait(ctx, ctx->stream));
+    return 1;
+}
+
+// Waits for the word a round's last kernel (k_tsvq_signal) stores into the coherent page-locked buffer. 1 = seen, 0 = the stream failed (error text set).
+static int tsvq_wait_flag(bu_hip_context* ctx, bu_tsvq* q, volatile uint32_t* round_flag, uint32_t seq) {
+    // One context in the process: spin (the round trip is what the step waits for). Several (basis_parallel_compress, images in flight): the device is shared, a round
+    // can take milliseconds, and a spinning waiter takes a core from another image's host backend -- after 30 us the core is offered to whoever wants it, after
+    // 2 ms the thread sleeps between looks. bu_hip_tuning::tsvq_poll (BU_TSVQ_POLL=spin|yield) overrides.
+    const int poll_mode = q->poll;
+    const bool polite = !ctx->wait_hook && (poll_mode == 2 || (poll_mode == 0 && g_live_contexts.load(std::memory_order_relaxed) > 1));
+    const auto t_wait0 = std::chrono::steady_clock::now();
+    auto last_query = t_wait0;
+    for (;;) {
+        if (*round_flag == seq) break;
+        if (ctx->wait_hook) {   // cooperative: another task of this host thread runs while the round is on the device
+            ctx->wait_hook(ctx->wait_user);
+            if (*round_flag == seq) break;
+        }
+        const auto t_now = std::chrono::steady_clock::now();
+        if (polite && t_now - t_wait0 > std::chrono::microseconds(30)) {
+            if (t_now - t_wait0 > std::chrono::milliseconds(2)) std::this_thread::sleep_for(std::chrono::microseconds(50));
+            else std::this_thread::yield();
+        }
+        if (t_now - last_query > std::chrono::microseconds(200)) {   // every 200 us: did the stream die, or finish without the flag becoming visible?
+            last_query = t_now;
+            const hipError_t e = hipStreamQuery(ctx->stream);
+            if (e == hipSuccess) { __atomic_thread_fence(__ATOMIC_SEQ_CST); if (*round_flag != seq) BU_TRY(ctx, stream_wait(ctx, ctx->stream)); break; }
+            if (e != hipErrorNotReady) { set_error(ctx, "tsvq_split: %s", hipGetErrorString(e)); return 0; }
+        }
+        __builtin_ia32_pause();
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
     return 1;
 }
 
@@ -1539,33 +1590,7 @@ static int tsvq_split_impl(bu_hip_context* ctx, bu_tsvq* q, const bu_tsvq_node* 
     if (zero_copy) {
         const uint32_t seq = ++q->round_seq ? q->round_seq : ++q->round_seq;   // never 0
         BU_TRY(ctx, bu::launch_tsvq_signal(ctx->stream, reinterpret_cast<uint32_t*>(d_pinned + flag_at), seq));
-        // One context in the process: spin (the round trip is what the step waits for). Several (basis_parallel_compress, images in flight): the device is shared, a round
-        // can take milliseconds, and a spinning waiter takes a core from another image's host backend -- after 30 us the core is offered to whoever wants it, after
-        // 2 ms the thread sleeps between looks. bu_hip_tuning::tsvq_poll (BU_TSVQ_POLL=spin|yield) overrides.
-        const int poll_mode = q->poll;
-        const bool polite = !ctx->wait_hook && (poll_mode == 2 || (poll_mode == 0 && g_live_contexts.load(std::memory_order_relaxed) > 1));
-        const auto t_wait0 = std::chrono::steady_clock::now();
-        auto last_query = t_wait0;
-        for (;;) {
-            if (*round_flag == seq) break;
-            if (ctx->wait_hook) {   // cooperative: another task of this host thread runs while the round is on the device
-                ctx->wait_hook(ctx->wait_user);
-                if (*round_flag == seq) break;
-            }
-            const auto t_now = std::chrono::steady_clock::now();
-            if (polite && t_now - t_wait0 > std::chrono::microseconds(30)) {
-                if (t_now - t_wait0 > std::chrono::milliseconds(2)) std::this_thread::sleep_for(std::chrono::microseconds(50));
-                else std::this_thread::yield();
-            }
-            if (t_now - last_query > std::chrono::microseconds(200)) {   // every 200 us: did the stream die, or finish without the flag becoming visible?
-                last_query = t_now;
-                const hipError_t e = hipStreamQuery(ctx->stream);
-                if (e == hipSuccess) { __atomic_thread_fence(__ATOMIC_SEQ_CST); if (*round_flag != seq) BU_TRY(ctx, stream_wait(ctx, ctx->stream)); break; }
-                if (e != hipErrorNotReady) { set_error(ctx, "tsvq_split: %s", hipGetErrorString(e)); return 0; }
-            }
-            __builtin_ia32_pause();
-        }
-        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        if (!tsvq_wait_flag(ctx, q, round_flag, seq)) return 0;
     } else {
         BU_TRY(ctx, hipMemcpyAsync(q->pinned, q->outs.p, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
         BU_TRY(ctx, stream_wait(ctx, ctx->stream));

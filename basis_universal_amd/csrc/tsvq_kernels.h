@@ -61,7 +61,7 @@ hipError_t launch_tsvq_cov_axis(hipStream_t st, const uint32_t* d_keys, const ui
 size_t tsvq_wide_workspace_bytes(uint32_t total_blocks);           // total_blocks = sum over the batch's nodes of ceil(count / 256)
 hipError_t launch_tsvq_wide_root(hipStream_t st, const uint32_t* d_keys, const uint64_t* d_w64, uint32_t n, uint32_t* d_perm0 /* out: 0..n-1 */,
                                  const tsvq_wide_node* d_nodes /* one node: all n vectors */, tsvq_wide_ctrl* d_ctrl, void* d_ws, uint32_t total_blocks, tsvq_root_out* d_out,
-                                 int windows /* bu_hip_tuning::tsvq_windows */);
+                                 int windows /* bu_hip_tuning::tsvq_windows */, bool ctrl_cleared = false);
 // prepare_root of n_nodes member spans through the many-workgroup passes (nodes: buf / start / count / first_block / n_blocks / out_index); d_outs[out_index].pad == 1:
 // the span's integer totals left the exact range, run it through launch_tsvq_span_roots
 hipError_t launch_tsvq_wide_span_roots(hipStream_t st, const uint32_t* d_keys, const uint64_t* d_w64, const uint32_t* d_perm0, const uint32_t* d_perm1, void* d_packed,
@@ -77,7 +77,7 @@ hipError_t launch_tsvq_cov_axis6(hipStream_t st, const float* d_rows, const uint
                                  const tsvq_wide_node* d_nodes, uint32_t n_nodes, tsvq_wide_ctrl* d_ctrl, float* d_va, double* d_tta, uint32_t n);
 hipError_t launch_tsvq_wide6_root(hipStream_t st, const float* d_rows, const uint64_t* d_w64, uint32_t n, uint32_t* d_perm0 /* out: 0..n-1 */, uint8_t* d_side,
                                   const tsvq_wide_node* d_nodes /* one node: all n vectors */, tsvq_wide_ctrl* d_ctrl, void* d_ws, uint32_t total_blocks, tsvq_root_out* d_out,
-                                  float* d_va, double* d_tta);
+                                  float* d_va, double* d_tta, bool ctrl_cleared = false);
 hipError_t launch_tsvq_wide6_split(hipStream_t st, const float* d_rows, const uint64_t* d_w64, uint32_t n, uint32_t* d_perm0, uint32_t* d_perm1, uint8_t* d_side,
                                    const tsvq_wide_node* d_nodes, uint32_t n_nodes, tsvq_wide_ctrl* d_ctrl, void* d_ws, uint32_t total_blocks, tsvq_split_out* d_outs,
                                    float* d_va, double* d_tta, bool ctrl_cleared = false);

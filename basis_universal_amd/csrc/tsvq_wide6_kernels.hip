@@ -622,8 +622,8 @@ hipError_t launch_tsvq_wide6_split(hipStream_t st, const float* d_rows, const ui
 
 // prepare_root of the whole training set (one node: all n vectors, in index order) through the same passes; d_perm0 becomes 0..n-1
 hipError_t launch_tsvq_wide6_root(hipStream_t st, const float* d_rows, const uint64_t* d_w64, uint32_t n, uint32_t* d_perm0, uint8_t* d_side, const tsvq_wide_node* d_nodes,
-                                  tsvq_wide_ctrl* d_ctrl, void* d_ws, uint32_t total_blocks, tsvq_root_out* d_out, float* d_va, double* d_tta) {
-    hipError_t e = hipMemsetAsync(d_ctrl, 0, sizeof(tsvq_wide_ctrl), st);
+                                  tsvq_wide_ctrl* d_ctrl, void* d_ws, uint32_t total_blocks, tsvq_root_out* d_out, float* d_va, double* d_tta, bool ctrl_cleared) {
+    hipError_t e = ctrl_cleared ? hipSuccess : hipMemsetAsync(d_ctrl, 0, sizeof(tsvq_wide_ctrl), st);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k6_iota, dim3((n + 255) / 256), dim3(256), 0, st, n, d_perm0);
     launch_pass6<W6_ROOT>(st, d_rows, d_w64, n, d_perm0, nullptr, d_side, d_nodes, 1, total_blocks, d_ctrl, d_ws, d_va, d_tta, d_out);

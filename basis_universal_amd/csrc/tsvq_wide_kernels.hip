@@ -840,8 +840,8 @@ static void launch_pass(hipStream_t st, const uint32_t* keys, const uint64_t* w6
 }
 
 hipError_t launch_tsvq_wide_root(hipStream_t st, const uint32_t* d_keys, const uint64_t* d_w64, uint32_t n, uint32_t* d_perm0, const tsvq_wide_node* d_nodes,
-                                 tsvq_wide_ctrl* d_ctrl, void* d_ws, uint32_t total_blocks, tsvq_root_out* d_out, int windows) {
-    hipError_t e = hipMemsetAsync(d_ctrl, 0, sizeof(tsvq_wide_ctrl), st);
+                                 tsvq_wide_ctrl* d_ctrl, void* d_ws, uint32_t total_blocks, tsvq_root_out* d_out, int windows, bool ctrl_cleared) {
+    hipError_t e = ctrl_cleared ? hipSuccess : hipMemsetAsync(d_ctrl, 0, sizeof(tsvq_wide_ctrl), st);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_wide_iota, dim3((n + 255) / 256), dim3(256), 0, st, n, d_perm0);
     launch_pass<WM_ROOT>(st, d_keys, d_w64, nullptr, nullptr, nullptr, nullptr, d_nodes, 1, total_blocks, d_ctrl, d_ws, d_out, windows);
