@@ -76,6 +76,8 @@ struct bu_hip_context {
     // pinned staging ring for host -> device uploads of pageable caller memory (see h2d below)
     void* stage = nullptr; size_t stage_cap = 0, stage_used = 0;
     void* bounce = nullptr; size_t bounce_cap = 0;   // pinned bounce buffer of device -> host downloads under a wait hook (bu_hip_memcpy_d2h)
+    // small results (mail_fetch): a coherent page-locked buffer a one-workgroup kernel copies them into, followed by a word the host looks at; -1 = not available
+    void* mail = nullptr; char* mail_dev = nullptr; int mail_state = 0; uint32_t mail_seq = 0;
     // pipelined tile upload (bu_hip_k_upload_and_encode_etc1s_blocks): a pinned ring of UP_SLOTS pieces the helper threads fill, one event per piece in flight
     void* up_ring = nullptr; size_t up_ring_cap = 0; std::vector<hipEvent_t> up_events;
     // background downloads (bu_hip_download_*): their own stream, so that a copy never sits in front of the side stream's kernels; events recycled; handles not yet waited for
@@ -107,6 +109,8 @@ struct bu_hip_context {
     std::vector<std::pair<bu_hip_destroy_fn, void*>> closing;
 };
 
+static std::atomic<int> g_live_contexts{0};   // contexts in use (not parked): decides how a waiting host thread waits
+
 namespace {
 
 void set_error(bu_hip_context* ctx, const char* fmt, ...) {
@@ -134,6 +138,92 @@ hipError_t stream_wait(bu_hip_context* ctx, hipStream_t s) {
 hipError_t d2h_pageable(bu_hip_context* ctx, void* h, const void* d, size_t bytes) {
     if (ctx->wait_hook) { const hipError_t e = stream_wait(ctx, ctx->stream); if (e != hipSuccess) return e; }
     return hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, ctx->stream);
+}
+
+
+// Waits for the word a one-thread kernel (k_tsvq_signal / the tail of k_mail_copy) stores into a coherent page-locked buffer. 1 = seen, 0 = the stream failed (error text set).
+int wait_flag(bu_hip_context* ctx, int poll_mode, volatile uint32_t* round_flag, uint32_t seq) {
+    // One context in the process: spin (the round trip is what the step waits for). Several (basis_parallel_compress, images in flight): the device is shared, a round
+    // can take milliseconds, and a spinning waiter takes a core from another image's host backend -- after 30 us the core is offered to whoever wants it, after
+    // 2 ms the thread sleeps between looks. bu_hip_tuning::tsvq_poll (BU_TSVQ_POLL=spin|yield) overrides.
+    const bool polite = !ctx->wait_hook && (poll_mode == 2 || (poll_mode == 0 && g_live_contexts.load(std::memory_order_relaxed) > 1));
+    const auto t_wait0 = std::chrono::steady_clock::now();
+    auto last_query = t_wait0;
+    for (;;) {
+        if (*round_flag == seq) break;
+        if (ctx->wait_hook) {   // cooperative: another task of this host thread runs while the round is on the device
+            ctx->wait_hook(ctx->wait_user);
+            if (*round_flag == seq) break;
+        }
+        const auto t_now = std::chrono::steady_clock::now();
+        if (polite && t_now - t_wait0 > std::chrono::microseconds(30)) {
+            if (t_now - t_wait0 > std::chrono::milliseconds(2)) std::this_thread::sleep_for(std::chrono::microseconds(50));
+            else std::this_thread::yield();
+        }
+        if (t_now - last_query > std::chrono::microseconds(200)) {   // every 200 us: did the stream die, or finish without the flag becoming visible?
+            last_query = t_now;
+            const hipError_t e = hipStreamQuery(ctx->stream);
+            if (e == hipSuccess) { __atomic_thread_fence(__ATOMIC_SEQ_CST); if (*round_flag != seq) BU_TRY(ctx, stream_wait(ctx, ctx->stream)); break; }
+            if (e != hipErrorNotReady) { set_error(ctx, "tsvq_split: %s", hipGetErrorString(e)); return 0; }
+        }
+        __builtin_ia32_pause();
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    return 1;
+}
+
+
+// Small device results for the host WITHOUT a copy command: a one-workgroup kernel copies them into a coherent page-locked buffer and stores a sequence number behind them,
+// the host looks at that word (wait_flag: spinning, yielding or running the wait hook) and copies them out. A hipMemcpyAsync into pageable memory + hipStreamSynchronize
+// costs a blit launch by the runtime, its completion signal and the wake-up: 25-40 us between the producing kernel and the host's next launch; this is ~10.
+// Up to four parts per wait (results that live in different arrays); what does not fit, or a context without the buffer, takes the copy.
+constexpr size_t MAIL_BYTES = (size_t)64 << 10, MAIL_FLAG_AT = MAIL_BYTES;
+struct mail_fetch {
+    bu_hip_context* ctx;
+    struct part { void* h; const void* d; size_t at, bytes; } parts[4];
+    int n = 0; size_t used = 0; bool copied = false;
+    explicit mail_fetch(bu_hip_context* c) : ctx(c) {}
+    bool usable() {
+        if (ctx->mail_state == 0) {
+            ctx->mail_state = -1;
+            static const bool on = [] { const char* e = std::getenv("BU_MAIL_FETCH"); return !e || e[0] != '0'; }();   // A/B switch
+            if (!on) return false;
+            void* p = nullptr;
+            if (hipHostMalloc(&p, MAIL_BYTES + 256, hipHostMallocCoherent) == hipSuccess) {
+                void* dp = nullptr;
+                if (hipHostGetDevicePointer(&dp, p, 0) == hipSuccess) { ctx->mail = p; ctx->mail_dev = static_cast<char*>(dp); ctx->mail_state = 1; *reinterpret_cast<volatile uint32_t*>(static_cast<char*>(p) + MAIL_FLAG_AT) = 0; }
+                else { (void)hipGetLastError(); (void)hipHostFree(p); }
+            } else (void)hipGetLastError();
+        }
+        return ctx->mail_state == 1;
+    }
+    hipError_t add(void* h, const void* d, size_t bytes) {
+        if (!bytes) return hipSuccess;
+        const size_t need = (bytes + 15) & ~(size_t)15;
+        if (n == 4 || used + need > MAIL_BYTES || !usable()) { copied = true; return d2h_pageable(ctx, h, d, bytes); }
+        parts[n++] = part{h, d, used, bytes};
+        used += need;
+        return hipSuccess;
+    }
+    // 1 = everything added is in the caller's memory
+    int wait() {
+        if (n) {
+            const uint32_t seq = ++ctx->mail_seq ? ctx->mail_seq : ++ctx->mail_seq;   // never 0
+            volatile uint32_t* flag = reinterpret_cast<volatile uint32_t*>(static_cast<char*>(ctx->mail) + MAIL_FLAG_AT);
+            for (int i = 0; i < n; i++)
+                BU_TRY(ctx, bu::launch_mail_copy(ctx->stream, ctx->mail_dev + parts[i].at, parts[i].d, parts[i].bytes, i + 1 == n ? reinterpret_cast<uint32_t*>(ctx->mail_dev + MAIL_FLAG_AT) : nullptr, seq));
+            if (!wait_flag(ctx, (int)ctx->tuning.tsvq_poll, flag, seq)) return 0;
+            for (int i = 0; i < n; i++) std::memcpy(parts[i].h, static_cast<const char*>(ctx->mail) + parts[i].at, parts[i].bytes);
+        }
+        if (copied || !n) BU_TRY(ctx, stream_wait(ctx, ctx->stream));
+        return 1;
+    }
+};
+// device -> host + wait, one result
+int fetch(bu_hip_context* ctx, void* h, const void* d, size_t bytes) {
+    mail_fetch f(ctx);
+    BU_TRY(ctx, f.add(h, d, bytes));
+    return f.wait();
 }
 
 struct device_guard {
@@ -267,7 +357,6 @@ int bu_hip_init(int /*force_serialization*/) {
 static std::mutex g_park_lock;
 static std::vector<bu_hip_context*> g_parked;
 // contexts handed out and not yet given back: with more than one, a host thread that waits for its device round shares the cores with the other contexts' host work
-static std::atomic<int> g_live_contexts{0};
 static void context_release(bu_hip_context* ctx);   // the real teardown
 static const bu_hip_tuning& default_tuning();
 static bool ensure_side_stream(bu_hip_context* ctx);
@@ -382,6 +471,7 @@ static void context_release(bu_hip_context* ctx) {
     for (auto& b : ctx->pool_live) (void)hipFree(b.p);
     if (ctx->stage) (void)hipHostFree(ctx->stage);
     if (ctx->bounce) (void)hipHostFree(ctx->bounce);
+    if (ctx->mail) (void)hipHostFree(ctx->mail);
     if (ctx->up_ring) (void)hipHostFree(ctx->up_ring);
     if (ctx->down_thread.joinable()) {
         { std::lock_guard<std::mutex> lk(ctx->down_mu); ctx->down_stop = true; }
@@ -557,9 +647,8 @@ int bu_hip_memcpy_d2h(bu_hip_context* ctx, void* h, const void* d, size_t bytes)
         }
         return 1;
     }
-    if (bytes) BU_TRY(ctx, d2h_pageable(ctx, h, d, bytes));   // (under a wait hook the stream is drained cooperatively first: the runtime would block in the copy until it has)
-    BU_TRY(ctx, stream_wait(ctx, ctx->stream));
-    return 1;
+    // small results travel without a copy command (mail_fetch); the rest: (under a wait hook the stream is drained cooperatively first: the runtime would block in the copy until it has)
+    return fetch(ctx, h, d, bytes);
 }
 void* bu_hip_host_alloc(size_t bytes) {
     void* p = nullptr;
@@ -862,8 +951,7 @@ int bu_hip_k_cluster_colour_means(bu_hip_context* ctx, const void* d_px, uint32_
     BU_TRY(ctx, h2d(ctx, ws.p, image.data(), image.size()));
     float* d_out = reinterpret_cast<float*>(static_cast<char*>(ws.p) + out_at);
     BU_TRY(ctx, bu::launch_codebook_wide_means(ctx->stream, d_px, d_indices, ws.p, L, d_out));
-    BU_TRY(ctx, d2h_pageable(ctx, h_out, d_out, (size_t)n_clusters * 12));
-    BU_TRY(ctx, stream_wait(ctx, ctx->stream));
+    if (!fetch(ctx, h_out, d_out, (size_t)n_clusters * 12)) return 0;
     return 1;
 }
 
@@ -1013,9 +1101,12 @@ int bu_hip_k_create_optimized_selector_codebook(bu_hip_context* ctx, const void*
     if (!n_clusters) return 1;
     // how many members the offsets span (two dwords back from the device; the launch is sized by member count, not by cluster)
     uint32_t ends[2] = { 0, 0 };
-    BU_TRY(ctx, d2h_pageable(ctx, &ends[0], d_offsets, 4));
-    BU_TRY(ctx, d2h_pageable(ctx, &ends[1], d_offsets + n_clusters, 4));
-    BU_TRY(ctx, stream_wait(ctx, ctx->stream));
+    {
+        mail_fetch f(ctx);
+        BU_TRY(ctx, f.add(&ends[0], d_offsets, 4));
+        BU_TRY(ctx, f.add(&ends[1], d_offsets + n_clusters, 4));
+        if (!f.wait()) return 0;
+    }
     if (ends[1] < ends[0]) { set_error(ctx, "create_optimized_selector_codebook: offsets are not ascending"); return 0; }
     arena& ws = ctx->scratch[4];
     BU_TRY(ctx, ws.reserve(bu::create_optimized_selector_codebook_workspace_bytes(n_clusters)));
@@ -1124,9 +1215,12 @@ int bu_hip_kmeans_codebook(bu_hip_context* ctx, int kind, const void* d_keys, co
     }
     std::vector<uint64_t> sums((size_t)k * 17);
     std::vector<float> cen((size_t)k * 16);
-    BU_TRY(ctx, d2h_pageable(ctx, sums.data(), b.sums, sums.size() * 8));
-    BU_TRY(ctx, d2h_pageable(ctx, cen.data(), b.cen, cen.size() * 4));
-    BU_TRY(ctx, stream_wait(ctx, ctx->stream));
+    {
+        mail_fetch f(ctx);
+        BU_TRY(ctx, f.add(sums.data(), b.sums, sums.size() * 8));
+        BU_TRY(ctx, f.add(cen.data(), b.cen, cen.size() * 4));
+        if (!f.wait()) return 0;
+    }
     // non-empty clusters, in index order
     std::vector<uint32_t> old_to_new(k, 0), live;
     for (uint32_t c = 0; c < k; c++) if (sums[(size_t)c * 17 + 16]) { old_to_new[c] = (uint32_t)live.size(); live.push_back(c); }
@@ -1228,7 +1322,7 @@ struct bu_tsvq {
 static_assert(sizeof(bu_tsvq_root) == sizeof(bu::tsvq_root_out), "layout");
 static_assert(sizeof(bu_tsvq_node) == sizeof(bu::tsvq_node_in), "layout");
 static_assert(sizeof(bu_tsvq_split) == sizeof(bu::tsvq_split_out), "layout");
-static int tsvq_wait_flag(bu_hip_context* ctx, bu_tsvq* q, volatile uint32_t* round_flag, uint32_t seq);
+
 
 extern "C" {
 
@@ -1348,7 +1442,7 @@ static bu_tsvq* tsvq_create_common(bu_hip_context* ctx, uint32_t dim, bool packe
         }
         if (d_pinned) {
             const uint32_t seq = ++q->round_seq ? q->round_seq : ++q->round_seq;   // never 0
-            if (bu::launch_tsvq_signal(ctx->stream, reinterpret_cast<uint32_t*>(d_pinned + FLAG_AT), seq) != hipSuccess || !tsvq_wait_flag(ctx, q, flag, seq)) return fail("root wait");
+            if (bu::launch_tsvq_signal(ctx->stream, reinterpret_cast<uint32_t*>(d_pinned + FLAG_AT), seq) != hipSuccess || !wait_flag(ctx, q->poll, flag, seq)) return fail("root wait");
         } else if (hipMemcpyAsync(q->pinned, q->outs.p, sizeof(bu_tsvq_root), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || stream_wait(ctx, ctx->stream) != hipSuccess)
             return fail("root download");
         if ((attempt >= 0 && !exact) || h_root->pad == 0) break;
@@ -1388,8 +1482,7 @@ int bu_hip_k_unique_endpoint_vectors(bu_hip_context* ctx, const void* d_etc1_blo
         prof_scope ps(ctx, "unique_endpoint_vectors");
         BU_TRY(ctx, bu::launch_unique_endpoint_vectors(ctx->stream, d_etc1_blocks, n_blocks, ws.p, d_sorted_block_idx, d_unique_keys, d_group_offsets, &d_n));
     }
-    BU_TRY(ctx, d2h_pageable(ctx, out_unique, d_n, 4));
-    BU_TRY(ctx, stream_wait(ctx, ctx->stream));
+    if (!fetch(ctx, out_unique, d_n, 4)) return 0;
     return 1;
 }
 
@@ -1411,40 +1504,7 @@ int bu_hip_k_unique_selector_vectors(bu_hip_context* ctx, const void* d_enc_bloc
         BU_TRY(ctx, bu::launch_unique_selector_vectors(ctx->stream, d_enc_blocks, d_weights, n_blocks, ws.p, d_sorted_block_idx, d_unique_keys, d_unique_weights,
                                                         d_group_offsets, &d_n));
     }
-    BU_TRY(ctx, d2h_pageable(ctx, out_unique, d_n, 4));
-    BU_TRY(ctx, stream_wait(ctx, ctx->stream));
-    return 1;
-}
-
-// Waits for the word a round's last kernel (k_tsvq_signal) stores into the coherent page-locked buffer. 1 = seen, 0 = the stream failed (error text set).
-static int tsvq_wait_flag(bu_hip_context* ctx, bu_tsvq* q, volatile uint32_t* round_flag, uint32_t seq) {
-    // One context in the process: spin (the round trip is what the step waits for). Several (basis_parallel_compress, images in flight): the device is shared, a round
-    // can take milliseconds, and a spinning waiter takes a core from another image's host backend -- after 30 us the core is offered to whoever wants it, after
-    // 2 ms the thread sleeps between looks. bu_hip_tuning::tsvq_poll (BU_TSVQ_POLL=spin|yield) overrides.
-    const int poll_mode = q->poll;
-    const bool polite = !ctx->wait_hook && (poll_mode == 2 || (poll_mode == 0 && g_live_contexts.load(std::memory_order_relaxed) > 1));
-    const auto t_wait0 = std::chrono::steady_clock::now();
-    auto last_query = t_wait0;
-    for (;;) {
-        if (*round_flag == seq) break;
-        if (ctx->wait_hook) {   // cooperative: another task of this host thread runs while the round is on the device
-            ctx->wait_hook(ctx->wait_user);
-            if (*round_flag == seq) break;
-        }
-        const auto t_now = std::chrono::steady_clock::now();
-        if (polite && t_now - t_wait0 > std::chrono::microseconds(30)) {
-            if (t_now - t_wait0 > std::chrono::milliseconds(2)) std::this_thread::sleep_for(std::chrono::microseconds(50));
-            else std::this_thread::yield();
-        }
-        if (t_now - last_query > std::chrono::microseconds(200)) {   // every 200 us: did the stream die, or finish without the flag becoming visible?
-            last_query = t_now;
-            const hipError_t e = hipStreamQuery(ctx->stream);
-            if (e == hipSuccess) { __atomic_thread_fence(__ATOMIC_SEQ_CST); if (*round_flag != seq) BU_TRY(ctx, stream_wait(ctx, ctx->stream)); break; }
-            if (e != hipErrorNotReady) { set_error(ctx, "tsvq_split: %s", hipGetErrorString(e)); return 0; }
-        }
-        __builtin_ia32_pause();
-    }
-    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    if (!fetch(ctx, out_unique, d_n, 4)) return 0;
     return 1;
 }
 
@@ -1590,7 +1650,7 @@ static int tsvq_split_impl(bu_hip_context* ctx, bu_tsvq* q, const bu_tsvq_node* 
     if (zero_copy) {
         const uint32_t seq = ++q->round_seq ? q->round_seq : ++q->round_seq;   // never 0
         BU_TRY(ctx, bu::launch_tsvq_signal(ctx->stream, reinterpret_cast<uint32_t*>(d_pinned + flag_at), seq));
-        if (!tsvq_wait_flag(ctx, q, round_flag, seq)) return 0;
+        if (!wait_flag(ctx, q->poll, round_flag, seq)) return 0;
     } else {
         BU_TRY(ctx, hipMemcpyAsync(q->pinned, q->outs.p, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
         BU_TRY(ctx, stream_wait(ctx, ctx->stream));
@@ -1815,8 +1875,7 @@ int bu_hip_tsvq_exchange_unpack(bu_hip_context* ctx, bu_tsvq* q, const bu_tsvq_n
     BU_TRY(ctx, h2d(ctx, base + tab_at + (size_t)n_nodes * sizeof(bu::bk_span), theirs.data(), n_nodes));
     BU_TRY(ctx, bu::launch_exchange_children(ctx->stream, q->perm[0], q->perm[1], reinterpret_cast<const bu::bk_span*>(base + tab_at),
                                              reinterpret_cast<const uint8_t*>(base + tab_at + (size_t)n_nodes * sizeof(bu::bk_span)), n_nodes, reinterpret_cast<uint32_t*>(base), 1));
-    BU_TRY(ctx, d2h_pageable(ctx, h_records, base + rec_at, (size_t)n_nodes * sizeof(bu_tsvq_split)));
-    BU_TRY(ctx, stream_wait(ctx, ctx->stream));
+    if (!fetch(ctx, h_records, base + rec_at, (size_t)n_nodes * sizeof(bu_tsvq_split))) return 0;
     return 1;
 }
 
@@ -1855,8 +1914,7 @@ int bu_hip_encode_uastc_blocks(bu_hip_context* ctx, bu_uastc_block* out, uint32_
     arena& o = ctx->scratch[0];
     BU_TRY(ctx, o.reserve((size_t)n * 16));
     if (!bu_hip_k_encode_uastc_blocks(ctx, ctx->d_pixel_blocks, n, flags, o.p)) return 0;
-    BU_TRY(ctx, d2h_pageable(ctx, out, o.p, (size_t)n * 16));
-    BU_TRY(ctx, stream_wait(ctx, ctx->stream));
+    if (!fetch(ctx, out, o.p, (size_t)n * 16)) return 0;
     return 1;
 }
 
@@ -1962,8 +2020,7 @@ int bu_hip_k_uastc_rdo(bu_hip_context* ctx, void* d_blocks, const void* d_px, ui
     }
     // how many blocks each strip modified: sizes the finish launch (a 16-byte copy per 4 strips; the walk has to be over anyway)
     std::vector<uint32_t> per_strip(bu::uastc_rdo_strips(n_blocks, total_jobs));
-    BU_TRY(ctx, d2h_pageable(ctx, per_strip.data(), bu::uastc_rdo_strip_counts(ws.p, n_blocks, total_jobs), per_strip.size() * 4));
-    BU_TRY(ctx, stream_wait(ctx, ctx->stream));
+    if (!fetch(ctx, per_strip.data(), bu::uastc_rdo_strip_counts(ws.p, n_blocks, total_jobs), per_strip.size() * 4)) return 0;
     uint32_t longest = 0;
     for (uint32_t c : per_strip) longest = c > longest ? c : longest;
     {
@@ -1971,8 +2028,7 @@ int bu_hip_k_uastc_rdo(bu_hip_context* ctx, void* d_blocks, const void* d_px, ui
         BU_TRY(ctx, bu::launch_uastc_rdo_finish(ctx->stream, d_blocks, d_px, n_blocks, fp, up, flags, total_jobs, ws.p, longest));
     }
     uint32_t counters[4] = { 0, 0, 0, 0 };
-    BU_TRY(ctx, d2h_pageable(ctx, counters, bu::uastc_rdo_counters(ws.p, n_blocks, total_jobs), sizeof(counters)));
-    BU_TRY(ctx, stream_wait(ctx, ctx->stream));
+    if (!fetch(ctx, counters, bu::uastc_rdo_counters(ws.p, n_blocks, total_jobs), sizeof(counters))) return 0;
 #ifdef RDO_PROFILE
     {
         unsigned long long prof[16];
@@ -2146,8 +2202,7 @@ int bu_hip_uastc_rdo(bu_hip_context* ctx, bu_uastc_block* blocks, const bu_uastc
     BU_TRY(ctx, o.reserve((size_t)n * 16));
     BU_TRY(ctx, h2d(ctx, o.p, blocks, (size_t)n * 16));
     if (!bu_hip_k_uastc_rdo(ctx, o.p, ctx->d_pixel_blocks, n, params, flags, total_jobs, out_stats)) return 0;
-    BU_TRY(ctx, d2h_pageable(ctx, blocks, o.p, (size_t)n * 16));
-    BU_TRY(ctx, stream_wait(ctx, ctx->stream));
+    if (!fetch(ctx, blocks, o.p, (size_t)n * 16)) return 0;
     return 1;
 }
 
@@ -2158,8 +2213,7 @@ int bu_hip_encode_etc1s_blocks(bu_hip_context* ctx, bu_etc_block* out, int perce
     arena& o = ctx->scratch[0];
     BU_TRY(ctx, o.reserve((size_t)n * 8));
     BU_TRY(ctx, bu::launch_encode_etc1s_blocks(ctx->stream, ctx->d_pixel_blocks, n, quality_from_perms(total_perms), perceptual != 0, o.p));
-    BU_TRY(ctx, d2h_pageable(ctx, out, o.p, (size_t)n * 8));
-    BU_TRY(ctx, stream_wait(ctx, ctx->stream));
+    if (!fetch(ctx, out, o.p, (size_t)n * 8)) return 0;
     return 1;
 }
 
@@ -2172,8 +2226,7 @@ int bu_hip_determine_selectors(bu_hip_context* ctx, const bu_color_rgba* color5_
     BU_TRY(ctx, o.reserve((size_t)n * 8));
     BU_TRY(ctx, h2d(ctx, in.p, color5_inten, (size_t)n * 4));
     BU_TRY(ctx, bu::launch_determine_selectors(ctx->stream, ctx->d_pixel_blocks, n, static_cast<const uint8_t*>(in.p), nullptr, perceptual != 0, o.p));
-    BU_TRY(ctx, d2h_pageable(ctx, out, o.p, (size_t)n * 8));
-    BU_TRY(ctx, stream_wait(ctx, ctx->stream));
+    if (!fetch(ctx, out, o.p, (size_t)n * 8)) return 0;
     return 1;
 }
 
@@ -2232,8 +2285,7 @@ int bu_hip_refine_endpoint_clusterization(bu_hip_context* ctx, const bu_block_in
                                                           static_cast<const uint32_t*>(a_off.p), static_cast<const uint32_t*>(a_idx.p),
                                                           static_cast<const uint8_t*>(a_bp.p), perceptual != 0, static_cast<uint32_t*>(a_out.p), work));
     std::vector<uint32_t> pos(n);
-    BU_TRY(ctx, d2h_pageable(ctx, pos.data(), a_out.p, n * 4ull));
-    BU_TRY(ctx, stream_wait(ctx, ctx->stream));
+    if (!fetch(ctx, pos.data(), a_out.p, n * 4ull)) return 0;
     for (uint32_t b = 0; b < n; b++) out[b] = clusters[pos[b]].m_cluster_index; // positions -> cluster indices (.cl:1150)
     return 1;
 }
@@ -2289,8 +2341,7 @@ int bu_hip_find_optimal_selector_clusters_for_each_block(bu_hip_context* ctx, co
                                                           static_cast<const uint32_t*>(a_off.p), static_cast<const uint32_t*>(a_idx.p), static_cast<const uint8_t*>(a_bp.p),
                                                           perceptual != 0, 0, static_cast<uint32_t*>(a_tmp.p), d_out, nullptr, 0));
     std::vector<uint32_t> pos(n);
-    BU_TRY(ctx, d2h_pageable(ctx, pos.data(), d_out, n * 4ull));
-    BU_TRY(ctx, stream_wait(ctx, ctx->stream));
+    if (!fetch(ctx, pos.data(), d_out, n * 4ull)) return 0;
     for (uint32_t b = 0; b < n; b++) out[b] = selector_cluster_indices[pos[b]];
     return 1;
 }
@@ -2343,8 +2394,7 @@ int bu_hip_encode_etc1s_pixel_clusters(bu_hip_context* ctx, bu_etc_block* out, u
                                              std::max(quality_from_perms(total_perms), (int)bu::BU_Q_MEDIUM), perceptual, 0, d_params, d_err, d_valid))
         return 0;
     std::vector<uint8_t> params(total_clusters * 4ull);
-    BU_TRY(ctx, d2h_pageable(ctx, params.data(), d_params, params.size()));
-    BU_TRY(ctx, stream_wait(ctx, ctx->stream));
+    if (!fetch(ctx, params.data(), d_params, params.size())) return 0;
     for (uint32_t c = 0; c < total_clusters; c++) {
         const uint64_t v = ((uint64_t)params[c * 4] << 59) | ((uint64_t)params[c * 4 + 1] << 51) | ((uint64_t)params[c * 4 + 2] << 43) |
                            ((uint64_t)params[c * 4 + 3] << 37) | ((uint64_t)params[c * 4 + 3] << 34) | (3ull << 32);

@@ -28,6 +28,8 @@ hipError_t launch_tsvq_children(hipStream_t st, const tsvq_node_in* d_parents, c
 
 // one-thread launch that stores `value` to *d_flag (page-locked host memory) with system scope once everything before it on the stream is done
 hipError_t launch_tsvq_signal(hipStream_t st, uint32_t* d_flag, uint32_t value);
+// one workgroup: bytes from device memory into (coherent, device-visible) host memory, then -- flag != nullptr -- `seq` stored to *flag with system-scope release
+hipError_t launch_mail_copy(hipStream_t st, void* dst, const void* src, size_t bytes, uint32_t* flag, uint32_t seq);
 
 // ---- large nodes spread over many workgroups (tsvq_wide_kernels.hip; packed selector vectors only). Results are bit-identical to
 // launch_tsvq_root / launch_tsvq_split; a split record with ok == 2 (degenerate projection, empty child, data outside the exact

@@ -287,6 +287,31 @@ hipError_t launch_tsvq_signal(hipStream_t st, uint32_t* d_flag, uint32_t value) 
     return hipGetLastError();
 }
 
+// Small results into coherent page-locked host memory + (flag != nullptr) a sequence number behind them for the host to look at (bu_hip_api.cpp, mail_fetch): one workgroup;
+// the data is fenced to system scope by every thread that wrote some of it before thread 0 releases the word.
+__global__ __launch_bounds__(256) void k_mail_copy(unsigned char* __restrict__ dst, const unsigned char* __restrict__ src, uint32_t bytes, uint32_t* flag, uint32_t seq) {
+    const uint32_t tid = threadIdx.x;
+    if (((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15u) == 0) {
+        const uint32_t n16 = bytes >> 4;
+        for (uint32_t i = tid; i < n16; i += 256) reinterpret_cast<uint4*>(dst)[i] = reinterpret_cast<const uint4*>(src)[i];
+        for (uint32_t i = (n16 << 4) + tid; i < bytes; i += 256) dst[i] = src[i];
+    } else if (((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 3u) == 0) {
+        const uint32_t n4 = bytes >> 2;
+        for (uint32_t i = tid; i < n4; i += 256) reinterpret_cast<uint32_t*>(dst)[i] = reinterpret_cast<const uint32_t*>(src)[i];
+        for (uint32_t i = (n4 << 2) + tid; i < bytes; i += 256) dst[i] = src[i];
+    } else {
+        for (uint32_t i = tid; i < bytes; i += 256) dst[i] = src[i];
+    }
+    if (!flag) return;
+    __threadfence_system();
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+hipError_t launch_mail_copy(hipStream_t st, void* dst, const void* src, size_t bytes, uint32_t* flag, uint32_t seq) {
+    hipLaunchKernelGGL(k_mail_copy, dim3(1), dim3(256), 0, st, static_cast<unsigned char*>(dst), static_cast<const unsigned char*>(src), (uint32_t)bytes, flag, seq);
+    return hipGetLastError();
+}
+
 // What a many-workgroup round starts with, as ONE launch instead of a host -> device copy and a fill (two runtime commands, each with its own ~10-20 us of
 // latency in front of the round's first kernel): workgroup i brings node record i over from the page-locked records the host has just written (device-visible
 // host memory, read once) and clears the node's state.
