@@ -927,7 +927,7 @@ static int codebook_fit_split(bu_hip_context* ctx, const std::vector<uint32_t>& 
         }
         if (L.n_big) BU_TRY(ctx, bu::launch_codebook_wide(ctx->stream, d_px, d_indices, work, L, quality, perceptual, forced, step, d_enc, d_params, d_err, d_valid, d_cur_err));
     }
-    BU_TRY(ctx, stream_wait(ctx, ctx->stream)); // the uploads' sources are pageable host memory owned by this call
+    // (no wait here: h2d has copied the uploads' sources into the context's page-locked ring before it returned, and whoever wants the results waits for them)
     return 1;
 }
 
@@ -955,6 +955,23 @@ int bu_hip_k_cluster_colour_means(bu_hip_context* ctx, const void* d_px, uint32_
     return 1;
 }
 
+// The clusters by descending size, ties in index order (= std::stable_sort with that comparator), as an LSD radix sort of the sizes: the device waits while this runs
+// (one workgroup per cluster, the big ones must not start last), and the comparison sort of a few thousand indirect keys was 50-80 us of that wait.
+static std::vector<uint32_t> size_descending_order(const uint32_t* h_offsets, uint32_t n) {
+    std::vector<uint32_t> order(n), tmp(n), key(n);
+    uint32_t largest = 0;
+    for (uint32_t i = 0; i < n; i++) largest = std::max(largest, h_offsets[i + 1] - h_offsets[i]);
+    for (uint32_t i = 0; i < n; i++) { order[i] = i; key[i] = largest - (h_offsets[i + 1] - h_offsets[i]); }   // ascending key = descending size
+    for (uint32_t shift = 0; shift < 32 && (largest >> shift); shift += 11) {
+        uint32_t count[2049] = {};
+        for (uint32_t i = 0; i < n; i++) count[((key[order[i]] >> shift) & 2047u) + 1]++;
+        for (uint32_t b = 0; b < 2048; b++) count[b + 1] += count[b];
+        for (uint32_t i = 0; i < n; i++) tmp[count[(key[order[i]] >> shift) & 2047u]++] = order[i];
+        order.swap(tmp);
+    }
+    return order;
+}
+
 int bu_hip_k_generate_endpoint_codebook_part(bu_hip_context* ctx, const void* d_px, uint32_t n_clusters, const uint32_t* h_offsets,
                                              const uint32_t* d_offsets, const uint32_t* d_indices, int quality, int perceptual, uint32_t step,
                                              uint8_t* d_params, uint64_t* d_err, uint8_t* d_valid, uint32_t part, uint32_t parts) {
@@ -964,11 +981,7 @@ int bu_hip_k_generate_endpoint_codebook_part(bu_hip_context* ctx, const void* d_
     device_guard g(ctx->device);
     // largest clusters first: one workgroup per cluster, so the big ones must not start last. With parts > 1 this call handles the
     // clusters at positions part, part + parts, ... of that order (the same order on every rank: the sort is stable and deterministic).
-    std::vector<uint32_t> order(n_clusters);
-    std::iota(order.begin(), order.end(), 0u);
-    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
-        return (h_offsets[a + 1] - h_offsets[a]) > (h_offsets[b + 1] - h_offsets[b]);
-    });
+    const std::vector<uint32_t> order = size_descending_order(h_offsets, n_clusters);
     std::vector<uint32_t> mine;
     for (uint32_t i = part; i < n_clusters; i += parts) mine.push_back(order[i]);
     if (mine.empty()) return 1;
@@ -987,9 +1000,7 @@ int bu_hip_k_refit_endpoints_given_selectors_q(bu_hip_context* ctx, const void* 
     if (!ctx) return 0;
     if (!n_clusters) return 1;
     device_guard g(ctx->device);
-    std::vector<uint32_t> order(n_clusters);
-    std::iota(order.begin(), order.end(), 0u);
-    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return (h_offsets[a + 1] - h_offsets[a]) > (h_offsets[b + 1] - h_offsets[b]); });
+    const std::vector<uint32_t> order = size_descending_order(h_offsets, n_clusters);
     return codebook_fit_split(ctx, order, h_offsets, d_px, d_enc, d_offsets, d_indices, quality == BU_ETC_QUALITY_SLOW ? BU_ETC_QUALITY_SLOW : BU_ETC_QUALITY_UBER, perceptual != 0, true, 0u,
                               d_params, d_err, d_valid, d_cur_err, "refit_endpoints_given_selectors");
 }
@@ -1099,19 +1110,11 @@ int bu_hip_k_create_optimized_selector_codebook(bu_hip_context* ctx, const void*
     if (!ctx) return 0;
     device_guard g(ctx->device);
     if (!n_clusters) return 1;
-    // how many members the offsets span (two dwords back from the device; the launch is sized by member count, not by cluster)
-    uint32_t ends[2] = { 0, 0 };
-    {
-        mail_fetch f(ctx);
-        BU_TRY(ctx, f.add(&ends[0], d_offsets, 4));
-        BU_TRY(ctx, f.add(&ends[1], d_offsets + n_clusters, 4));
-        if (!f.wait()) return 0;
-    }
-    if (ends[1] < ends[0]) { set_error(ctx, "create_optimized_selector_codebook: offsets are not ascending"); return 0; }
+    // (no look at the offsets from here: the accumulation kernel is a fixed number of waves that find the span on the device)
     arena& ws = ctx->scratch[4];
     BU_TRY(ctx, ws.reserve(bu::create_optimized_selector_codebook_workspace_bytes(n_clusters)));
     prof_scope ps(ctx, "create_optimized_selector_codebook");
-    BU_TRY(ctx, bu::launch_create_optimized_selector_codebook(ctx->stream, d_px, d_enc, n_clusters, d_offsets, d_block_indices, ends[1] - ends[0], perceptual != 0, ws.p,
+    BU_TRY(ctx, bu::launch_create_optimized_selector_codebook(ctx->stream, d_px, d_enc, n_clusters, d_offsets, d_block_indices, perceptual != 0, ws.p,
                                                               d_selector_blocks));
     return 1;
 }

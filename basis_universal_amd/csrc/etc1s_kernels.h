@@ -39,10 +39,10 @@ hipError_t launch_refine_endpoint_clusterization(hipStream_t st, const void* d_p
 size_t refine_workspace_bytes(uint32_t n_clusters, uint32_t n_parents);   // 0: lists too long for the sorted form
 hipError_t launch_determine_selectors(hipStream_t st, const void* d_pixel_blocks, uint32_t n_blocks, const uint8_t* d_color5_inten,
                                       const uint32_t* d_block_cluster, bool perceptual, void* d_out);
-// total_members = d_offsets[n_clusters] - d_offsets[0] (the caller knows it on the host); d_workspace: create_optimized_selector_codebook_workspace_bytes()
+// d_workspace: create_optimized_selector_codebook_workspace_bytes()
 size_t create_optimized_selector_codebook_workspace_bytes(uint32_t n_clusters);
 hipError_t launch_create_optimized_selector_codebook(hipStream_t st, const void* d_pixel_blocks, const void* d_enc_blocks, uint32_t n_clusters,
-                                                     const uint32_t* d_offsets, const uint32_t* d_block_indices, uint32_t total_members, bool perceptual,
+                                                     const uint32_t* d_offsets, const uint32_t* d_block_indices, bool perceptual,
                                                      void* d_workspace, void* d_selector_blocks);
 hipError_t launch_find_optimal_selector_clusters(hipStream_t st, const void* d_pixel_blocks, void* d_enc_blocks, uint32_t n_blocks,
                                                  const void* d_selector_blocks, uint32_t n_selectors, uint32_t n_parents, const uint32_t* d_cand_offsets,

@@ -1364,6 +1364,7 @@ __global__ __launch_bounds__(256) void k_determine_selectors(
 // -------------------------------------------------------------------------------------------------------------------
 
 constexpr uint32_t COSC_CHUNK = 128;
+constexpr uint32_t COSC_WORKGROUPS = 2048;   // of four waves: one chunk per wave for a 4096^2 image, the waves stride over the chunks of a larger one
 
 template <bool PERCEPTUAL>
 __global__ __launch_bounds__(256) void k_cosc_accumulate(
@@ -1371,9 +1372,9 @@ __global__ __launch_bounds__(256) void k_cosc_accumulate(
     const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ block_indices, unsigned long long* __restrict__ acc) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4u + (threadIdx.x >> 6)));   // wave-uniform, and told so: the search below runs on the scalar unit
+    // (the launch is a fixed number of waves that stride over the chunks: how many members the offsets span is on the device only, and asking for it was a round trip)
     const uint32_t begin = offsets[0], end = offsets[n_clusters];
-    const uint64_t lo64 = (uint64_t)begin + (uint64_t)wave * COSC_CHUNK;
-    if (lo64 >= end) return;
+    for (uint64_t lo64 = (uint64_t)begin + (uint64_t)wave * COSC_CHUNK; lo64 < end; lo64 += (uint64_t)gridDim.x * 4u * COSC_CHUNK) {
     const uint32_t lo = (uint32_t)lo64, hi = end - lo > COSC_CHUNK ? lo + COSC_CHUNK : end;
     // cluster of member `lo`: the last cluster whose first member is <= lo (empty clusters in front of it share that offset and are skipped)
     uint32_t a = 0, b = n_clusters;  // invariant: offsets[a] <= lo < offsets[b]
@@ -1395,6 +1396,7 @@ __global__ __launch_bounds__(256) void k_cosc_accumulate(
         tot += cdist<PERCEPTUAL>(c, pixel_cvec<PERCEPTUAL>(pixel_words[(size_t)bi * 16 + p]));
     }
     if (tot) atomicAdd(&acc[(size_t)ci * 64 + lane], tot);
+    }
 }
 
 __global__ __launch_bounds__(256) void k_cosc_select(uint32_t n_clusters, const uint32_t* __restrict__ offsets, const unsigned long long* __restrict__ acc,
@@ -1782,16 +1784,15 @@ hipError_t launch_determine_selectors(hipStream_t st, const void* d_pixel_blocks
 size_t create_optimized_selector_codebook_workspace_bytes(uint32_t n_clusters) { return (size_t)n_clusters * 64 * 8; }
 
 hipError_t launch_create_optimized_selector_codebook(hipStream_t st, const void* d_pixel_blocks, const void* d_enc_blocks, uint32_t n_clusters,
-                                                     const uint32_t* d_offsets, const uint32_t* d_block_indices, uint32_t total_members, bool perceptual,
+                                                     const uint32_t* d_offsets, const uint32_t* d_block_indices, bool perceptual,
                                                      void* d_workspace, void* d_selector_blocks) {
     if (!n_clusters) return hipSuccess;
     unsigned long long* acc = static_cast<unsigned long long*>(d_workspace);
     hipError_t e = hipMemsetAsync(acc, 0, create_optimized_selector_codebook_workspace_bytes(n_clusters), st);
     if (e != hipSuccess) return e;
     const uint32_t* pw = static_cast<const uint32_t*>(d_pixel_blocks);
-    if (total_members) {
-        const uint32_t waves = (total_members + COSC_CHUNK - 1) / COSC_CHUNK;
-        const dim3 grid((waves + 3) / 4), blk(256);
+    {
+        const dim3 grid(COSC_WORKGROUPS), blk(256);
         if (perceptual) hipLaunchKernelGGL(k_cosc_accumulate<true>, grid, blk, 0, st, pw, static_cast<const uint64_t*>(d_enc_blocks), n_clusters, d_offsets, d_block_indices, acc);
         else hipLaunchKernelGGL(k_cosc_accumulate<false>, grid, blk, 0, st, pw, static_cast<const uint64_t*>(d_enc_blocks), n_clusters, d_offsets, d_block_indices, acc);
         BU_LAUNCH_CHECK();

@@ -431,6 +431,7 @@ bool etc1s_frontend::generate_endpoint_clusters() {
     m_endpoint_parent_clusters.clear();
     m_endpoint_parent_of_unique.clear(); m_endpoint_parent_dev_valid = false;
     device_state& d = *m_dev;
+    bool sizes_pending = false;
     // Per distinct vector, resident: its leaf (tmp_a), the position of its first block in the leaf's list (tmp_b), its parent (tmp_c); per leaf the list length
     // (out_u32). A leaf lists its distinct vectors ascending and each vector's blocks ascending (enc.h:1573-1584 + the training-vector order of frontend.cpp:825-866).
     if (!d.reserve(d.tmp_a, (size_t)u_total * 4) || !d.reserve(d.tmp_b, (size_t)u_total * 4) || !d.reserve(d.tmp_c, (size_t)u_total * 4) ||
@@ -456,8 +457,7 @@ bool etc1s_frontend::generate_endpoint_clusters() {
                                                                 want_parents, &m_endpoint_cluster_count, &m_endpoint_parent_count, (uint32_t*)d.tmp_a.p, (uint32_t*)d.tmp_c.p,
                                                                 (uint32_t*)d.tmp_b.p, (uint32_t*)d.out_u32.p, nullptr, m_has_comm ? &m_comm : nullptr, m_params.m_codebook_threads))
             return fail("endpoint TSVQ failed");
-        m_endpoint_cluster_sizes.resize(m_endpoint_cluster_count);
-        if (!d.download(m_endpoint_cluster_sizes.data(), d.out_u32, m_endpoint_cluster_count)) return fail("download cluster sizes");
+        sizes_pending = true;
     }
     const bool parents = want_parents && m_endpoint_parent_count;
     if (m_use_hierarchical_endpoint_codebooks && !m_endpoint_parent_count) m_endpoint_parent_count = 1;  // no parent level: one parent holding everything (frontend.cpp:905-911)
@@ -467,6 +467,10 @@ bool etc1s_frontend::generate_endpoint_clusters() {
     if (parents) {   // the parent of every distinct vector, kept for the parent-list getter (tmp_c is everybody's scratch)
         if (!d.reserve(d.ep_parent_u, (size_t)u_total * 4) || !bu_hip_memcpy_d2d(d.ctx, d.ep_parent_u.p, d.tmp_c.p, (size_t)u_total * 4)) return fail("copy");
         m_endpoint_parent_dev_valid = true;
+    }
+    if (sizes_pending) {   // the leaves' list lengths: asked for behind the kernels above, which do not need them (the device works while the host waits)
+        m_endpoint_cluster_sizes.resize(m_endpoint_cluster_count);
+        if (!d.download(m_endpoint_cluster_sizes.data(), d.out_u32, m_endpoint_cluster_count)) return fail("download cluster sizes");
     }
     m_ep_dev_valid = true; m_endpoint_map_valid = false; m_endpoint_lists_valid = false; m_endpoint_clusters.clear();
     return true;
@@ -937,11 +941,15 @@ bool etc1s_frontend::eliminate_redundant_or_empty_endpoint_clusters() {
     m_ep_member_valid = false;
     if (!m_ep_dev_valid) ensure_endpoint_map();
     const uint32_t k = m_endpoint_cluster_count, n = m_total_blocks;
-    std::vector<uint32_t> order(k);
-    std::iota(order.begin(), order.end(), 0u);
     const std::vector<endpoint_params>& P = m_endpoint_cluster_etc_params;
     auto key = [&](uint32_t i) { return ((uint32_t)P[i].r << 24) | ((uint32_t)P[i].g << 16) | ((uint32_t)P[i].b << 8) | P[i].inten; };
-    std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return key(a) < key(b); });
+    // (the keys travel with the indices: what std::sort does to a sequence depends on the comparisons' outcomes only, so this is the permutation the sort of the bare
+    // indices through an indirect comparator gives -- without a look-up per comparison; the device is idle while this runs)
+    std::vector<std::pair<uint32_t, uint32_t>> keyed(k);
+    for (uint32_t i = 0; i < k; i++) keyed[i] = std::make_pair(key(i), i);
+    std::sort(keyed.begin(), keyed.end(), [](const std::pair<uint32_t, uint32_t>& a, const std::pair<uint32_t, uint32_t>& b) { return a.first < b.first; });
+    std::vector<uint32_t> order(k);
+    for (uint32_t i = 0; i < k; i++) order[i] = keyed[i].second;
 
     // A run of equal parameters becomes one cluster: the first non-empty one followed by the members of the others, list after list. In map
     // form: every old cluster gets its new index and the offset its list starts at inside the merged list.
