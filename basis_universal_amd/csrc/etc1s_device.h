@@ -76,6 +76,19 @@ __device__ __forceinline__ uint32_t chroma_term(int dy, int dz) {
     const uint32_t cb3 = (cb << 1) + cb;
     return (cr26 >> 7) + (cb3 >> 7);
 }
+// perceptual only: a LOWER BOUND of the sum over a tile's 16 pixels of chroma_term(y_p - cy, z_p - cz) from the tile's chroma moments -- what a sweep over
+// many candidate colours tests before it spends sixteen chroma terms on one (k_refine_sorted). With r_p = y_p - m (m = floor(mean y)), R1 = sum r_p (0..15),
+// e = m - cy:  sum (y_p - cy)^2 = sum r_p^2 + 2 e R1 + 16 e^2, so  A = (e^2 >> 6) + sum (r_p^2 >> 10) + ((e R1) >> 9)  <=  sum (y_p - cy)^2 / 1024  (floors only
+// take away), B the same for z. A pixel's term is floor(26 floor(dy^2 / 32) / 128) + floor(3 floor(dz^2 / 32) / 128) >= (26 dy^2 + 3 dz^2) / 4096 - 2.204
+// (each inner floor loses < 31/32 of its factor, each outer one < 127/128), over 16 pixels >= (26 A + 3 B) / 4 - 35.3. |y|, |z| <= 15045: everything fits 31 bits
+// (A, B < 2^24). struct: the tile's side of it (wave-uniform in the caller).
+struct chroma_moments { int my, mz, r1y, r1z, r2y, r2z; };   // floor means, sum r_p, sum (r_p^2 >> 10)
+__device__ __forceinline__ uint32_t chroma_lower_bound(const chroma_moments& t, int cy, int cz) {
+    const int ey = t.my - cy, ez = t.mz - cz;
+    const int A = (int)((uint32_t)__mul24(ey, ey) >> 6) + t.r2y + (__mul24(ey, t.r1y) >> 9);
+    const int B = (int)((uint32_t)__mul24(ez, ez) >> 6) + t.r2z + (__mul24(ez, t.r1z) >> 9);
+    return (uint32_t)max(((__mul24(A, 26) + __mul24(B, 3)) >> 2) - 36, 0);
+}
 // perceptual only: min over the four unclamped colours of the luma term, dx0 = pixel.x - base.x, a64 / b64 = 64 * the table's two deltas
 // The four offsets are +-a, +-b: of each pair the one on dx0's side is the nearer, (|dx0| - a)^2 <= (|dx0| + a)^2, so two squares decide the minimum of four
 // (the same integers; |dx0| is shared by a pixel's eight tables). Until round 6 all four were squared: twice the multiplies and minimums of the kernels' innermost term.
