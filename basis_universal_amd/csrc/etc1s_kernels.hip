@@ -1,7 +1,8 @@
 // etc1s_kernels.hip -- hand-written gfx950 kernels for the ETC1S frontend hot path.
 //
 // All kernels are integer-ALU bound (hundreds of integer ops per byte of pixel data), so the design rules are:
-//   * wave64 mappings that keep all 64 lanes on the SAME kind of work (no per-lane trial loops with different trip counts);
+//   * wave64 mappings that keep all 64 lanes on the SAME kind of work -- and where a wave's blocks need different NUMBERS of steps (the per-block fit's trials), the
+//     cheap part (finding the next step worth taking) loops per block while the expensive part (evaluating it) runs for all blocks at once;
 //   * the 64-byte pixel tile is read once per kernel with 16-byte loads and kept in registers in the metric's separable
 //     basis (etc1s_device.h: cvec), so a colour distance is 3 subtractions + 3 24-bit multiplies + shifts;
 //   * wavefront reductions (DPP/ds_swizzle via __shfl_xor) pick the best intensity table / candidate, with the

@@ -138,7 +138,10 @@ def test_wide_nodes_match_host_tsvq(hip_ctx, request, n, k, p, kind, wmax, wide_
     request.addfinalizer(hip_ctx.set_tuning)   # the session's context back to the process defaults, whatever happens below
     for name, knobs in (("wide", dict(tsvq_wide_min=wide_min, tsvq_wide_cov_min=0, tsvq_windows=2)), ("hybrid", dict(tsvq_wide_min=wide_min)),
                         ("windows", dict(tsvq_wide_min=wide_min, tsvq_wide_cov_min=0, tsvq_windows=1)), ("narrow", dict(tsvq_wide_min=0)),
-                        ("deep2", dict(tsvq_wide_min=wide_min, tsvq_deep_levels=2)), ("deep1", dict(tsvq_wide_min=wide_min, tsvq_deep_levels=1))):
+                        ("deep2", dict(tsvq_wide_min=wide_min, tsvq_deep_levels=2)), ("deep1", dict(tsvq_wide_min=wide_min, tsvq_deep_levels=1)),
+                        # staged: node / result records by copies + hipStreamSynchronize instead of the page-locked records the kernels address (the rounds' prologue kernel and
+                        # the roots' zero-copy records fall back to a copy and a fill)
+                        ("staged", dict(tsvq_wide_min=wide_min, tsvq_zero_copy=0))):
         if name == "narrow" and n > 200000:
             continue
         hip_ctx.set_tuning(**knobs)   # bu_hip_set_tuning (include/basisu_hip.h): which of the bit-identical paths the trees built on this context take
@@ -201,7 +204,7 @@ def test_wide6_nodes_match_host_tsvq(hip_ctx, request, n, k, p, kind, wmax, wide
     outs = {}
     request.addfinalizer(hip_ctx.set_tuning)
     for name, knobs in (("wide6", dict(tsvq_wide6_min=wide_min)), ("narrow", dict(tsvq_wide6_min=0)), ("deep2", dict(tsvq_wide6_min=wide_min, tsvq_deep_levels=2)),
-                        ("narrow_deep1", dict(tsvq_wide6_min=0, tsvq_deep_levels=1))):
+                        ("narrow_deep1", dict(tsvq_wide6_min=0, tsvq_deep_levels=1)), ("staged", dict(tsvq_wide6_min=wide_min, tsvq_zero_copy=0))):
         hip_ctx.set_tuning(**knobs)
         a = np.zeros(cap, np.uint32); b = np.zeros(cap, np.uint32); st = np.zeros(3, np.uint32)
         assert F.bu_device_tsvq(hip_ctx.h, 6, v.ctypes.data_as(VP), w.ctypes.data_as(VP), n, k, p, a.ctypes.data_as(VP), cap, b.ctypes.data_as(VP), cap,
