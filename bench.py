@@ -69,8 +69,8 @@ def host_cpus():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--size", type=int, default=4096)
     ap.add_argument("--quality", type=int, default=128)
     ap.add_argument("--level", type=int, default=1)
