@@ -1185,7 +1185,6 @@ __global__ __launch_bounds__(256) void k_refine_sorted(const uint4* __restrict__
     const uint2* plain_items = items + first;
     const uint2* clamped_items = items + first + plain_total;
 
-    constexpr int FIRST_PX[4] = { 0, 5, 10, 15 };
     constexpr uint64_t REST_PX = 0xEDCB98764321ull;   // the other twelve pixel indices, one per nibble
     const uint32_t* block_words = reinterpret_cast<const uint32_t*>(pixel_blocks + (size_t)block * 4);
     uint2* q = s_q[threadIdx.x >> 6];
@@ -1230,14 +1229,11 @@ __global__ __launch_bounds__(256) void k_refine_sorted(const uint4* __restrict__
                 const uint32_t j = j0 + lane;
                 const bool have = j < n0;
                 const uint2 e = plain_items[base + (have ? j : 0)];
-                const int inten = (int)((e.x >> 24) & 7u);
                 const cvec bcv = to_cvec<true>(scale5((int)(e.x & 255u)), scale5((int)((e.x >> 8) & 255u)), scale5((int)((e.x >> 16) & 255u)));
-                const int a64 = k_inten_a[inten] * 64, b64 = k_inten_b[inten] * 64;
-                // a lower bound of the candidate's error: the luma terms of four pixels + a bound of all sixteen chroma terms from the tile's moments (chroma_lower_bound:
-                // 20 instructions instead of the 40 of four chroma terms, and it sees the whole tile -- fewer survivors)
-                uint32_t part = chroma_lower_bound(cm, bcv.y, bcv.z);
-#pragma unroll
-                for (int f = 0; f < 4; f++) part += min_luma_term(pc[FIRST_PX[f]].x - bcv.x, a64, b64);
+                // a lower bound of the candidate's error: a bound of all sixteen chroma terms from the tile's moments (chroma_lower_bound: 20 instructions, and it sees the whole
+                // tile). Luma terms of a few pixels on top of it were measured and cost more than they prune: with 4 / 2 / 0 pixels' luma terms the kernel takes 1.64 / 1.59 / 1.52 ms
+                // (8192^2 q255: 9.2 / 8.4 / 7.8), and a bound from the tile's luma range 1.57 -- the chroma bound decides
+                const uint32_t part = chroma_lower_bound(cm, bcv.y, bcv.z);
                 const bool keep = have && part <= thr;
                 const uint64_t m = __ballot(keep);
                 const uint32_t r = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
