@@ -1,11 +1,8 @@
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
-timeout 1500 python -m pytest tests -m gpu -x -q -k "uastc or ldr_table or smoke" 2>&1 | tail -3
-for i in 1 2; do
-timeout 600 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-pipelined --no-fast --no-big > gpurun_out/r6u.json 2>gpurun_out/r6u.err
+timeout 900 python -m pytest tests/test_gpu_reference_seam.py -m gpu -x -q 2>&1 | tail -3
 python - <<P
-import json
-d=json.loads(open('gpurun_out/r6u.json').read().strip().splitlines()[-1])
-u=d['uastc']; r=d['uastc_rdo']
-print(u['value'], u['ms_per_step'], u['identical_to_reference'], u['kernels_ms_per_step'], '| rdo', r['value'], r['images_identical_to_reference'], r['kernels_ms_per_step'])
+import sys; sys.path.insert(0,'tests')
+import numpy as np, helpers
+helpers.synth(4096,4096,1234).tofile('/tmp/img.rgba')
 P
-done
+for t in 1 8; do oracle/_ref/process_bench_resident /tmp/img.rgba 4096 4096 128 1 $t 1 6 | tail -1; done
